@@ -1,0 +1,137 @@
+/*
+ * exl3_hip.h — C-ABI of the MI355X-native EXL3 quantized-linear hot path (libexl3_hip.so).
+ *
+ * This is the drop-in boundary for the path named by BASELINE.json `north_star`: every entry point
+ * replaces one op of the reference's native extension `exllamav3_ext` (pybind11 module,
+ * /root/reference/exllamav3/exllamav3_ext/bindings.cpp:69-226).  The reference binds at::Tensor
+ * arguments; here every argument is a plain device pointer / size / scalar so that any host language
+ * can bind it (the Python mirror of the reference op surface lives in exllamav3_amd/ext.py and is what
+ * INTEGRATION.md installs as the module `exllamav3_ext`).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer on `device`-current HBM unless marked host; the caller owns all
+ *     buffers (reference ownership contract: SURVEY.md 8b) and must keep them alive until the stream drains;
+ *   - `stream` is a hipStream_t (NULL = default stream); all calls are asynchronous w.r.t. the GPU;
+ *   - return 0 on success, <0 on error (EXL3_ERR_*); the message is available from exl3_last_error()
+ *     (thread-local).  The reference raises RuntimeError via TORCH_CHECK for the same argument violations
+ *     (exllamav3_ext/util.h:24-35); exllamav3_amd/ext.py converts a non-zero return into RuntimeError;
+ *   - fp16 = IEEE binary16 (`half`), trellis = int16 [k/16][n/16][16K] exactly as stored in EXL3 checkpoints;
+ *   - cb (codebook): 0 = 3INST, 1 = mcg, 2 = mul1  (reference passes two bools `mcg`, `mul1`;
+ *     reconstruct.cu:128-130 — mcg wins).
+ *   - all kernels are graph-capture safe after exl3_init(device) has run once outside capture.
+ */
+#ifndef EXL3_HIP_H
+#define EXL3_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXL3_OK        0
+#define EXL3_ERR_ARG  (-1)   /* shape / alignment / range violation (reference: TORCH_CHECK)      */
+#define EXL3_ERR_HIP  (-2)   /* HIP runtime error (reference: cuda_check, util.cuh:92-100)         */
+#define EXL3_ERR_INIT (-3)   /* per-device context missing while the stream is capturing           */
+
+#define EXL3_ABI_VERSION 1
+
+const char* exl3_last_error(void);
+int  exl3_abi_version(void);
+
+/* Per-device context: split-k workspace + zero-initialised ticket words (reference: DevCtx,
+ * quant/exl3_devctx.cuh:8-19, .cu:48-69).  Idempotent; must run once outside graph capture. */
+int  exl3_init(int device);
+/* bindings.cpp g_get_cc / g_get_num_sms equivalents: compute units and gfx arch number (950). */
+int  exl3_device_info(int device, int* num_cus, int* gfx_arch, int64_t* hbm_bytes);
+
+/* ---- format ops -------------------------------------------------------------------------------- */
+
+/* pack_trellis(packed, unpacked, K)       quant/pack.cu:68-95.   unpacked u16 [tk][tn][256], packed i16 [tk][tn][16K] */
+int exl3_pack_trellis(void* packed, const void* unpacked, int tiles_k, int tiles_n, int K, void* stream);
+/* unpack_trellis(unpacked, packed, K)     quant/pack.cu:148-175 */
+int exl3_unpack_trellis(void* unpacked, const void* packed, int tiles_k, int tiles_n, int K, void* stream);
+/* pack_signs(packed, unpacked)            quant/pack.cu:177-226.  signs fp16 [numel] (numel % 16 == 0) -> i16 [numel/16] */
+int exl3_pack_signs(void* packed, const void* signs, int64_t numel, void* stream);
+/* decode(idx, out, mcg, mul1)             quant/quantize.cu:89-168.  states u16 [numel] -> fp16 or fp32 [numel] */
+int exl3_decode(const void* states, void* out, int64_t numel, int out_fp32, int cb, void* stream);
+
+/* reconstruct / reconstruct_slice         quant/reconstruct.cu:98-144,375-386.
+ * out fp16 [16*tiles_k][n_size] (row stride n_size) = W_hat[:, n_offset : n_offset+n_size]; n_offset, n_size % 128 == 0 */
+int exl3_reconstruct(void* out, const void* trellis, int tiles_k, int tiles_n, int K, int cb,
+                     int64_t n_offset, int64_t n_size, void* stream);
+/* reconstruct_had_slice                   quant/reconstruct.cu:324-373.  Original-basis weights
+ * W = diag(suh) H W_hat H diag(svh); svh is pre-offset by the caller (points at element n_offset's scale). */
+int exl3_reconstruct_had(void* out, const void* trellis, const void* suh, const void* svh,
+                         int tiles_k, int tiles_n, int K, int cb, int64_t n_offset, int64_t n_size, void* stream);
+
+/* had_r_128(input, output, pre_scale, post_scale, scale)   quant/hadamard.cu:88-173.
+ * rows x cols, cols % 128 == 0; fp32 = 0: fp16 in/out, 1: fp32 in/out; scales fp16 [cols] or NULL; in-place allowed */
+int exl3_had_r_128(const void* in, void* out, const void* pre_scale, const void* post_scale, float scale,
+                   int rows, int cols, int fp32, void* stream);
+
+/* ---- quantized GEMM / GEMV --------------------------------------------------------------------- */
+
+/* exl3_gemm(A, B, C, suh, A_had, svh, force_shape_idx, mcg, mul1, force_num_sms)   quant/exl3_gemm.cuh:21-33
+ * + bias add of BC_LinearEXL3::run (libtorch/linear.cpp:34-71).
+ *   C[m][n] = ((A[m][k] * suh) H) @ dequant(B) H * svh (+ bias)
+ * A fp16 [m][k] contiguous; B int16 [k/16][n/16][16K]; C fp16 or fp32 [m][n]; suh [k], svh [n], bias [n] fp16 (bias may be NULL).
+ * k % 128 == 0, n % 128 == 0, 1 <= K <= 8.  Any m >= 1 (16-row passes; callers switch to reconstruct+hgemm above
+ * 144 rows as modules/quant/exl3.py:135 does).  force_split: 0 = heuristic, >0 = k-split count.
+ * Returns the kernel id (>= 1) on success like the reference, < 0 on error. */
+int exl3_gemm(const void* A, const void* B, void* C, const void* suh, const void* svh, const void* bias,
+              int m, int k, int n, int K, int cb, int c_fp32, int force_split, void* stream);
+
+/* exl3_mgemm (broadcast form)    quant/exl3_gemm.cuh:58-78 with indices == NULL, bszm matrices sharing one A:
+ * host arrays of `count` device pointers (B_i, C_i, suh_i, svh_i) and widths n_i; every matrix has the same k, K, cb.
+ * This is the fused q/k/v and gate/up launch (libtorch/mlp.cpp:40, attention.cpp:286-365). */
+int exl3_mgemm(const void* A, const void* const* Bs, void* const* Cs, const void* const* suhs, const void* const* svhs,
+               const int* ns, int count, int m, int k, int K, int cb, int c_fp32, int force_split, void* stream);
+
+/* hgemm(a, b, c)      hgemm.cu:19-102:  c[m][n] (row stride ldc elements, fp16 or fp32) = a[m][k] @ b[k][n], fp32 accumulate.
+ * m, k, n arbitrary multiples of 16/32/16. */
+int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, void* stream);
+
+/* ---- RMSNorm     norm.cuh:7-39, norm.cu:155-299 --------------------------------------------------- */
+/* mode 0: y = norm(x)*w ; 1: y += norm(x)*w (add_residual) ; 2: r += x; y = norm(r)*w (rms_norm_res_in).
+ * x_fp32 / y_fp32 / r_fp32 select fp16 or fp32 buffers; w fp16 (w_bf16 = 0) or bf16 (1) or NULL. dim % 4 == 0. */
+int exl3_rms_norm(const void* x, const void* w, void* y, void* r, float eps, float constant_bias, float constant_scale,
+                  int rows, int dim, int x_fp32, int y_fp32, int r_fp32, int w_bf16, int mode, void* stream);
+
+/* ---- RoPE        rope.cuh:51-72, rope.cu:16-296 -------------------------------------------------- */
+/* q [bsz][seq][heads_q][head_dim], k [bsz][seq][heads_k][head_dim] fp16 (k/out_k may be NULL); inv_freq fp32 [head_dim/2]
+ * (or [bsz*seq][head_dim/2] when inv_freq_per_token).  Position of (b,t) = position + t | positions[b] + t | position_ids[b][t]
+ * (int32 device arrays or NULL).  rope_mode 1 = GPTJ (interleaved), 2 = NEOX (half split).  q_norm/k_norm: optional fp16 [head_dim]
+ * per-head RMSNorm weights applied before the rotation (eps, constant_bias). */
+int exl3_rope(const void* q, void* out_q, const void* k, void* out_k, const float* inv_freq,
+              int bsz, int seq_len, int heads_q, int heads_k, int head_dim,
+              uint32_t position, const int32_t* positions, const int32_t* position_ids,
+              int rope_mode, float attn_factor, const void* q_norm, const void* k_norm, float norm_eps,
+              float norm_constant_bias, void* stream);
+
+/* ---- KV-cache quantization   cache/q_cache.cuh:48-62, q_cache_kernels.cuh:61-236 ------------------ */
+/* quant_cache_cont(in, out, out_scales): in fp16 [tokens][dim], out u32 [tokens][dim/32*bits], scales fp16 [tokens][dim/32] */
+int exl3_quant_cache_cont(const void* in, void* out, void* out_scales, int64_t tokens, int dim, int bits, void* stream);
+int exl3_dequant_cache_cont(const void* in, const void* in_scales, void* out, int64_t tokens, int dim, int bits, void* stream);
+/* quant_cache_paged: append seq_len new tokens per sequence to the paged quantized cache.
+ * k_in/v_in fp16 [bsz][seq_len][dim] (in_contiguous) ; caches u32 [pages][page_size][dim/32*bits], scales fp16 [pages][page_size][dim/32];
+ * cache_seqlens int32 [bsz] (tokens already in cache), block_table int32 [bsz][blocks_per_seq]. */
+int exl3_quant_cache_paged(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                           const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                           int page_size, int seq_len, int dim, int k_bits, int v_bits, void* stream);
+/* dequant_cache_paged: expand every page referenced by block_table up to cache_seqlens[b] (+ nothing beyond) into fp16 pages
+ * k_out/v_out fp16 [pages][page_size][dim]. */
+int exl3_dequant_cache_paged(const void* k_in, const void* k_scales, void* k_out, const void* v_in, const void* v_scales, void* v_out,
+                             const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                             int page_size, int dim, int k_bits, int v_bits, void* stream);
+
+/* ---- elementwise glue used by the decode step (activation.cu silu_mul, add.cu) -------------------- */
+/* y = silu(g) * u ; g, u fp16 or fp32 (in_fp32) [rows][dim]; y fp16 */
+int exl3_silu_mul(const void* g, const void* u, void* y, int64_t numel, int in_fp32, void* stream);
+/* x (fp16 or fp32) += y (fp16 or fp32) */
+int exl3_add(void* x, const void* y, int64_t numel, int x_fp32, int y_fp32, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

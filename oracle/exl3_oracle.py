@@ -1,0 +1,450 @@
+"""
+CPU ORACLE (test infrastructure, NOT product code) for the EXL3 quantized-linear hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product path (exllamav3_amd/) never imports it and fails loudly without the HIP library.
+
+Every function is a numpy restatement of the reference algorithm, citing the reference
+file:line it follows (paths relative to /root/reference/exllamav3/).  Integer / byte /
+index work is bit-exact by construction; floating-point rounding points follow the reference
+kernels.
+
+Parity pinning (see oracle/README.md and tests/test_oracle_pins.py):
+  * tensor_core_perm, Hadamard matrices, RMSNorm, RoPE, unpack_bf, and the constructive
+    tail-biting trellis generator are pinned against fixtures produced by IMPORTING the
+    reference's own Python (tests/golden/make_golden.py, run in the build container).
+  * trellis bit-window extraction + tile permutation + mul1 codebook + both Hadamards + suh/svh
+    are pinned against the reference's own CPU implementation (exllamav3_ext/cpu/moe_mul1.cpp,
+    compiled from where it lies into oracle/_ref/ by oracle/build_ref.sh).
+  * 3INST codebook: pinned by the reference constant codebook_scale = 1.24371088
+    (modules/quant/exl3_lib/quantize.py:16) = std of the codebook over all 65536 states.
+"""
+from __future__ import annotations
+import numpy as np
+
+# ------------------------------------------------------------------------------------------
+# Format constants
+# ------------------------------------------------------------------------------------------
+
+CB_3INST, CB_MCG, CB_MUL1 = 0, 1, 2
+MCG_MULT = 0xCBAC1FED      # modules/quant/exl3_lib/quantize.py:18
+MUL1_MULT = 0x83DCD12D     # modules/quant/exl3_lib/quantize.py:19
+HAD_SCALE_128 = np.float32(0.088388347648)  # exllamav3_ext/quant/hadamard.cu:103
+
+
+def cb_index(mcg: bool, mul1: bool) -> int:
+    """exllamav3_ext/quant/reconstruct.cu:128-130: mcg wins over mul1."""
+    return CB_MCG if mcg else (CB_MUL1 if mul1 else CB_3INST)
+
+
+def tensor_core_perm() -> np.ndarray:
+    """perm[t] = row*16 + col of stream index t in the 16x16 tile (row = k offset, col = n offset).
+    modules/quant/exl3_lib/quantize.py:21-44, exllamav3_ext/cpu/moe_mul1.cpp:97-111."""
+    t = np.arange(256)
+    l, j = t // 8, t % 8
+    row = 2 * (l % 4) + (j & 1) + 8 * ((j >> 1) & 1)
+    col = l // 4 + 8 * (j >> 2)
+    return (row * 16 + col).astype(np.int32)
+
+
+# ------------------------------------------------------------------------------------------
+# Bitstream pack / unpack     exllamav3_ext/quant/pack.cu:9-138, quant/exl3_dq.cuh:15-31
+# ------------------------------------------------------------------------------------------
+
+def _tile_words(trellis: np.ndarray) -> np.ndarray:
+    """(kt, nt, 16K) int16 -> (kt, nt, 8K) uint32 little-endian words (pack.cu:111-112)."""
+    t = np.ascontiguousarray(trellis).view(np.uint16)
+    return t.view(np.uint32)
+
+
+def unpack_trellis(trellis: np.ndarray, K: int) -> np.ndarray:
+    """Packed tiles (kt, nt, 16K) int16 -> 16-bit trellis states (kt, nt, 256) uint16 in STREAM order.
+    State of weight t = bits [(t+1)K-16, (t+1)K) of the circular MSB-first tile bitstream.
+    exllamav3_ext/quant/exl3_dq.cuh:15-31 (dq), quant/pack.cu:97-138 (unpack_trellis_kernel),
+    cpu/moe_mul1.cpp:162-172 (decode_state_scalar)."""
+    assert trellis.shape[-1] == 16 * K
+    w = _tile_words(trellis).astype(np.uint64)                       # (kt, nt, 8K)
+    nw = 8 * K
+    t = np.arange(256, dtype=np.int64)
+    b0 = t * K + K - 16 + 256 * K
+    b1 = b0 + 16
+    i0 = (b0 // 32) % nw
+    i1 = ((b1 - 1) // 32) % nw
+    sh = (((b1 - 1) // 32) + 1) * 32 - b1
+    merged = (w[..., i0] << np.uint64(32)) | w[..., i1]
+    return ((merged >> sh.astype(np.uint64)) & np.uint64(0xFFFF)).astype(np.uint16)
+
+
+def pack_trellis(states: np.ndarray, K: int) -> np.ndarray:
+    """States (kt, nt, 256) uint16 (only the low K bits of each are stored) -> packed (kt, nt, 16K) int16.
+    Symbols are concatenated MSB-first into 16-bit chunks; chunk c is stored at int16 index c^1 (SWAP16).
+    exllamav3_ext/quant/pack.cu:9-57."""
+    s = (states.astype(np.uint64) & np.uint64((1 << K) - 1))         # (kt, nt, 256)
+    kt, nt, _ = s.shape
+    # bit p of the tile stream (p = t*K + b, b = 0 is the symbol's MSB)
+    bits = ((s[..., :, None] >> np.arange(K - 1, -1, -1, dtype=np.uint64)) & np.uint64(1)).astype(np.uint8)
+    bits = bits.reshape(kt, nt, 256 * K)
+    chunks = bits.reshape(kt, nt, 16 * K, 16)
+    weights = (1 << np.arange(15, -1, -1)).astype(np.uint32)
+    vals = (chunks.astype(np.uint32) * weights).sum(-1).astype(np.uint16)   # (kt, nt, 16K) chunk order
+    out = np.empty_like(vals)
+    out[..., 0::2] = vals[..., 1::2]
+    out[..., 1::2] = vals[..., 0::2]
+    return out.view(np.int16)
+
+
+def random_tailbiting_states(rng: np.random.Generator, shape, K: int) -> np.ndarray:
+    """Constructive valid tail-biting state sequence: state_t = sym_t | sym_{t-1} << K | ... (16 bits).
+    Restates tests/test_quant_fn.py:100-113."""
+    sym = rng.integers(0, 1 << K, size=tuple(shape) + (256,), dtype=np.uint64)
+    st = np.zeros_like(sym)
+    n = (16 + K - 1) // K
+    for i in range(n):
+        st |= np.roll(sym, i, axis=-1) << np.uint64(i * K)
+    return (st & np.uint64(0xFFFF)).astype(np.uint16)
+
+
+def pack_signs(signs: np.ndarray) -> np.ndarray:
+    """fp16 vector (multiple of 16) -> int16 bitfield, bit b of word w = 1 iff element 16w+b is negative.
+    exllamav3_ext/quant/pack.cu:177-201; inverse = modules/quant/exl3.py:142-158 (unpack_bf)."""
+    neg = (np.asarray(signs).view(np.uint16) >> 15).astype(np.uint32).reshape(-1, 16)
+    return (neg << np.arange(16, dtype=np.uint32)).sum(-1).astype(np.uint16).view(np.int16)
+
+
+def unpack_bf(bitfield: np.ndarray) -> np.ndarray:
+    """modules/quant/exl3.py:142-158."""
+    b = np.asarray(bitfield).view(np.uint16).astype(np.uint32)
+    ex = ((b[:, None] >> np.arange(16, dtype=np.uint32)) & 1).reshape(-1)
+    return (1.0 - ex.astype(np.float16) * np.float16(2.0)).astype(np.float16)
+
+
+# ------------------------------------------------------------------------------------------
+# Codebooks      exllamav3_ext/quant/codebook.cuh:56-90
+# ------------------------------------------------------------------------------------------
+
+def decode(states: np.ndarray, cb: int) -> np.ndarray:
+    """16-bit state -> fp16 value.  All integer arithmetic mod 2^32; exactly ONE fp16 rounding per weight
+    (cb0/cb1: one RN fp16 add; cb2: one RN fp16 fma), evaluated here in float64 (exact) then rounded once."""
+    s = states.astype(np.uint64)
+    if cb == CB_3INST:
+        x = (s * np.uint64(89226354) + np.uint64(64248484)) & np.uint64(0xFFFFFFFF)
+    elif cb == CB_MCG:
+        x = (s * np.uint64(MCG_MULT)) & np.uint64(0xFFFFFFFF)
+    elif cb == CB_MUL1:
+        x = (s * np.uint64(MUL1_MULT)) & np.uint64(0xFFFFFFFF)
+        b = (x & np.uint64(0xFF)) + ((x >> np.uint64(8)) & np.uint64(0xFF)) + \
+            ((x >> np.uint64(16)) & np.uint64(0xFF)) + (x >> np.uint64(24))
+        h = (np.uint64(0x6400) + b).astype(np.uint16).view(np.float16).astype(np.float64)   # = 1024 + b exactly
+        k_inv = np.array([0x1EEE], dtype=np.uint16).view(np.float16).astype(np.float64)[0]
+        k_bias = np.array([0xC931], dtype=np.uint16).view(np.float16).astype(np.float64)[0]
+        return (h * k_inv + k_bias).astype(np.float16)            # exact in f64, single rounding = hfma
+    else:
+        raise ValueError(cb)
+    x = (x & np.uint64(0x8FFF8FFF)) ^ np.uint64(0x3B603B60)
+    lo = (x & np.uint64(0xFFFF)).astype(np.uint16).view(np.float16).astype(np.float64)
+    hi = (x >> np.uint64(16)).astype(np.uint16).view(np.float16).astype(np.float64)
+    return (lo + hi).astype(np.float16)                            # exact in f64, single rounding = hadd
+
+
+def decode_split(states: np.ndarray, cb: int):
+    """cb0/cb1 only: the two fp16 halves whose (unrounded) sum is the weight."""
+    s = states.astype(np.uint64)
+    if cb == CB_3INST:
+        x = (s * np.uint64(89226354) + np.uint64(64248484)) & np.uint64(0xFFFFFFFF)
+    else:
+        x = (s * np.uint64(MCG_MULT)) & np.uint64(0xFFFFFFFF)
+    x = (x & np.uint64(0x8FFF8FFF)) ^ np.uint64(0x3B603B60)
+    lo = (x & np.uint64(0xFFFF)).astype(np.uint16).view(np.float16)
+    hi = (x >> np.uint64(16)).astype(np.uint16).view(np.float16)
+    return lo, hi
+
+
+def reconstruct(trellis: np.ndarray, K: int, cb: int, n_offset: int = 0, n_size: int | None = None) -> np.ndarray:
+    """Packed (k/16, n/16, 16K) -> W_hat (k, n) fp16, rotated basis.  exllamav3_ext/quant/reconstruct.cu:13-84,98-144."""
+    if n_size is None:
+        n_size = trellis.shape[1] * 16 - n_offset
+    assert n_offset % 128 == 0 and n_size % 128 == 0
+    tr = trellis[:, n_offset // 16:(n_offset + n_size) // 16]
+    kt, nt, _ = tr.shape
+    vals = decode(unpack_trellis(tr, K), cb)                       # (kt, nt, 256) stream order
+    tile = np.empty_like(vals)
+    tile[..., tensor_core_perm()] = vals                          # tile[perm[t]] = v[t]  (moe_mul1.cpp:1103)
+    return tile.reshape(kt, nt, 16, 16).transpose(0, 2, 1, 3).reshape(kt * 16, nt * 16)
+
+
+# ------------------------------------------------------------------------------------------
+# 128-point Hadamard       exllamav3_ext/quant/hadamard_inner.cuh:17-279, quant/hadamard.cu:88-173
+# ------------------------------------------------------------------------------------------
+
+def _fwht128_f32(v: np.ndarray) -> np.ndarray:
+    """In-place-style fp32 FWHT over the last axis (length 128), Sylvester/natural order, stage order
+    bit0, bit1 (in-lane H4, hadamard_inner.cuh:117-129) then bits 2..6 (shuffle_had_f4x32 :17-45)."""
+    v = v.astype(np.float32).copy()
+    shp = v.shape
+    v = v.reshape(-1, 128)
+    idx = np.arange(128)
+    for bit in (1, 2, 4, 8, 16, 32, 64):
+        p = v[:, idx ^ bit]
+        sgn = np.where(idx & bit, np.float32(-1), np.float32(1)).astype(np.float32)
+        v = (v * sgn + p).astype(np.float32)
+    return v.reshape(shp)
+
+
+def had_r_128(x: np.ndarray, pre_scale=None, post_scale=None, scale: float = 1.0, out_dtype=None) -> np.ndarray:
+    """y = (x.view(-1,128) @ H128) * scale/sqrt(128), optional fp16 pre/post scale vectors.
+    fp16 input: pre-scale multiply in fp16, butterflies fp32, round to fp16, post-scale multiply in fp16
+    (hadamard_inner.cuh:93-147).  fp32 input: everything fp32 (:151-208); fp32->fp16 variant rounds before
+    the fp16 post-scale (:212-279)."""
+    rows, cols = x.shape
+    assert cols % 128 == 0
+    r_scale = np.float32(np.float32(scale) * HAD_SCALE_128)
+    if x.dtype == np.float16:
+        v = x
+        if pre_scale is not None:
+            v = (v * pre_scale.astype(np.float16)[None, :]).astype(np.float16)      # __hmul2
+        h = _fwht128_f32(v.astype(np.float32).reshape(rows, cols // 128, 128)).reshape(rows, cols)
+        o = (h * r_scale).astype(np.float32).astype(np.float16)
+        if post_scale is not None:
+            o = (o * post_scale.astype(np.float16)[None, :]).astype(np.float16)
+        return o
+    assert x.dtype == np.float32
+    v = x
+    if pre_scale is not None:
+        v = (v * pre_scale.astype(np.float32)[None, :]).astype(np.float32)
+    h = _fwht128_f32(v.reshape(rows, cols // 128, 128)).reshape(rows, cols)
+    h = (h * r_scale).astype(np.float32)
+    if out_dtype == np.float16:
+        h = h.astype(np.float16)
+        if post_scale is not None:
+            h = (h * post_scale.astype(np.float16)[None, :]).astype(np.float16)
+        return h
+    if post_scale is not None:
+        h = (h * post_scale.astype(np.float32)[None, :]).astype(np.float32)
+    return h
+
+
+def hadamard_matrix_128() -> np.ndarray:
+    """Sylvester H128 (+-1), symmetric.  util/hadamard.py:34-42."""
+    h = np.array([[1.0]], dtype=np.float32)
+    while h.shape[0] < 128:
+        h = np.block([[h, h], [h, -h]])
+    return h
+
+
+# ------------------------------------------------------------------------------------------
+# Quantized linear forward
+# ------------------------------------------------------------------------------------------
+
+def linear_forward(x: np.ndarray, trellis: np.ndarray, suh: np.ndarray, svh: np.ndarray, K: int, cb: int,
+                   bias: np.ndarray | None = None, out_fp32: bool = False, w_hat: np.ndarray | None = None) -> np.ndarray:
+    """y = ((x * suh) H) @ W_hat H * svh (+ bias) with the kernel path's rounding points
+    (quant/exl3_gemm_inner.cuh:456-480, hadamard_inner.cuh:93-147,191-208,256-275,
+    libtorch/linear.cpp:34-71): A_had rounded to fp16, fp32 accumulation, output Hadamard from fp32;
+    fp16 out = round_fp16(had * r) *_fp16 svh;  fp32 out = all fp32."""
+    m, k = x.shape
+    assert x.dtype == np.float16
+    if w_hat is None:
+        w_hat = reconstruct(trellis, K, cb)
+    xh = had_r_128(x, pre_scale=suh)                               # fp16
+    acc = xh.astype(np.float32) @ w_hat.astype(np.float32)         # fp32 accumulate (order-free within tol)
+    if out_fp32:
+        y = had_r_128(acc.astype(np.float32), post_scale=svh)
+        if bias is not None:
+            y = (y + bias.astype(np.float32)[None, :]).astype(np.float32)
+    else:
+        y = had_r_128(acc.astype(np.float32), post_scale=svh, out_dtype=np.float16)
+        if bias is not None:
+            y = (y + bias.astype(np.float16)[None, :]).astype(np.float16)
+    return y
+
+
+def weight_tensor(trellis: np.ndarray, suh: np.ndarray, svh: np.ndarray, K: int, cb: int) -> np.ndarray:
+    """Original-basis weights W = diag(suh) . H . W_hat . H . diag(svh), fp32 math (the parity target of
+    reconstruct_had_slice at 2e-3 rel-to-max: tests/test_reconstruct_had.py:25-33;
+    modules/quant/exl3.py:227-237 get_weight_tensor)."""
+    w = reconstruct(trellis, K, cb).astype(np.float32)
+    k, n = w.shape
+    H = hadamard_matrix_128() * np.float32(1.0 / np.sqrt(128.0))
+    w = np.einsum("ij,bjn->bin", H, w.reshape(k // 128, 128, n)).reshape(k, n)
+    w = w * suh.astype(np.float32)[:, None]
+    w = np.einsum("kbj,ji->kbi", w.reshape(k, n // 128, 128), H).reshape(k, n)
+    w = w * svh.astype(np.float32)[None, :]
+    return w.astype(np.float32)
+
+
+def tp_slice(trellis, suh, svh, bias, first: int, last: int, dim: str):
+    """TP shard of one quantized Linear.  modules/quant/exl3.py:284-330 (tp_import_split):
+    out-split ('n'): trellis[:, first/16:last/16], svh[first:last], bias[first:last], full suh;
+    in-split ('k'):  trellis[first/16:last/16], suh[first:last], full svh, bias only where first == 0."""
+    assert first % 128 == 0 and last % 128 == 0
+    if dim == "n":
+        return (np.ascontiguousarray(trellis[:, first // 16:last // 16]), suh, svh[first:last],
+                None if bias is None else bias[first:last])
+    return (np.ascontiguousarray(trellis[first // 16:last // 16]), suh[first:last], svh,
+            bias if (bias is not None and first == 0) else None)
+
+
+# ------------------------------------------------------------------------------------------
+# RMSNorm     exllamav3_ext/norm.cu:155-299 (kernel), modules/rmsnorm.py:65-79 (torch reference)
+# ------------------------------------------------------------------------------------------
+
+def rms_norm(x: np.ndarray, w: np.ndarray | None, eps: float, constant_bias: float = 0.0, constant_scale: float = 1.0,
+             out_dtype=np.float16, residual_in: np.ndarray | None = None, add_residual_to: np.ndarray | None = None):
+    """Kernel semantics: y = x * (w + bias) * rsqrt(mean(x^2) + eps) * scale, all fp32, one rounding to out dtype.
+    residual_in (RES_IN, norm.cu:193-218): r += x rounded to r's dtype first, then y = norm(r); returns (y, r).
+    add_residual_to (RES_POST, :257-266): y = existing + norm(x)."""
+    xf = x.astype(np.float32)
+    r_out = None
+    if residual_in is not None:
+        r_out = (residual_in.astype(np.float32) + xf).astype(residual_in.dtype)
+        xf = r_out.astype(np.float32)
+    dim = x.shape[-1]
+    ss = (xf.astype(np.float64) ** 2).sum(-1, keepdims=True).astype(np.float32)
+    rmf = (np.float32(1.0) / np.sqrt(ss / np.float32(dim) + np.float32(eps))).astype(np.float32) * np.float32(constant_scale)
+    if w is not None:
+        wf = w.astype(np.float32) + np.float32(constant_bias)
+        y = xf * wf[None, :] * rmf
+    else:
+        y = xf * rmf
+    if add_residual_to is not None:
+        y = y + add_residual_to.astype(np.float32)
+    y = y.astype(out_dtype)
+    return (y, r_out) if residual_in is not None else y
+
+
+# ------------------------------------------------------------------------------------------
+# RoPE      exllamav3_ext/rope.cu:16-296, util/rope.py:102-140,365-432
+# ------------------------------------------------------------------------------------------
+
+ROPE_GPTJ, ROPE_NEOX = 1, 2      # util/rope.py RopeStyle
+
+
+def rope(q: np.ndarray, k: np.ndarray | None, inv_freq: np.ndarray, position: int = 0, positions=None, position_ids=None,
+         rope_mode: int = ROPE_NEOX, attn_factor: float = 1.0, q_norm=None, k_norm=None, norm_eps: float = 1e-6,
+         norm_constant_bias: float = 0.0):
+    """q (b, s, hq, d), k (b, s, hk, d) fp16 -> rotated fp16.  Position of token (b, t) = position + t, or
+    positions[b] + t, or position_ids[b, t] (rope.cu:44-60).  Optional per-head RMSNorm before the rotation
+    (rope.cu:62-120).  NEOX pairs (i, i + d/2); GPTJ pairs (2i, 2i+1).  Math in fp32."""
+    def one(x, norm_w):
+        if x is None:
+            return None
+        b, s, h, d = x.shape
+        xf = x.astype(np.float32)
+        if norm_w is not None:
+            ss = (xf.astype(np.float64) ** 2).sum(-1, keepdims=True).astype(np.float32)
+            rmf = np.float32(1.0) / np.sqrt(ss / np.float32(d) + np.float32(norm_eps))
+            xf = xf * rmf * (norm_w.astype(np.float32) + np.float32(norm_constant_bias))
+        if position_ids is not None:
+            pos = np.asarray(position_ids).reshape(b, s).astype(np.float32)
+        elif positions is not None:
+            pos = (np.asarray(positions).reshape(b, 1) + np.arange(s)[None, :]).astype(np.float32)
+        else:
+            pos = np.broadcast_to((position + np.arange(s))[None, :], (b, s)).astype(np.float32)
+        ang = pos[:, :, None].astype(np.float32) * inv_freq.astype(np.float32)[None, None, :]      # (b, s, d/2)
+        sin = (np.sin(ang.astype(np.float64)) * attn_factor).astype(np.float32)[:, :, None, :]
+        cos = (np.cos(ang.astype(np.float64)) * attn_factor).astype(np.float32)[:, :, None, :]
+        out = np.empty_like(xf)
+        hd = d // 2
+        if rope_mode == ROPE_NEOX:
+            a, c = xf[..., :hd], xf[..., hd:]
+            out[..., :hd] = a * cos - c * sin
+            out[..., hd:] = c * cos + a * sin
+        else:
+            a, c = xf[..., 0::2], xf[..., 1::2]
+            out[..., 0::2] = a * cos - c * sin
+            out[..., 1::2] = c * cos + a * sin
+        return out.astype(np.float16)
+    return one(q, q_norm), one(k, k_norm)
+
+
+# ------------------------------------------------------------------------------------------
+# KV-cache quantization     exllamav3_ext/cache/q_cache_kernels.cuh:29-236
+# ------------------------------------------------------------------------------------------
+
+def _fwht32_f32(v: np.ndarray) -> np.ndarray:
+    v = v.astype(np.float32)
+    idx = np.arange(32)
+    for bit in (1, 2, 4, 8, 16):
+        p = v[..., idx ^ bit]
+        sgn = np.where(idx & bit, np.float32(-1), np.float32(1)).astype(np.float32)
+        v = (v * sgn + p).astype(np.float32)
+    return v
+
+
+def kv_planes(bits: int):
+    """Bit-plane widths, MSB plane first: set bits of `bits` among (8, 4, 2, 1).  q_cache_kernels.cuh:130-147."""
+    return [w for w in (8, 4, 2, 1) if bits & w]
+
+
+KV_RSQRT32 = np.float32(0.17677669529663689)
+
+
+def kv_quant(x: np.ndarray, bits: int):
+    """x (..., D) fp16, D % 32 == 0 -> (packed uint32 (..., D/32*bits), scales fp16 (..., D/32)).
+    Per 32-group: v = H32(x)/sqrt(32) (fp32); s = max|v| + 1e-10 (stored fp16);
+    q = clamp(floor(v / s * 2^(b-1) + 2^(b-1)), 0, 2^b - 1); bit-plane packing.
+    q_cache_kernels.cuh:61-156."""
+    shp = x.shape
+    g = x.astype(np.float32).reshape(-1, 32)
+    v = (_fwht32_f32(g) * KV_RSQRT32).astype(np.float32)
+    s = (np.abs(v).max(-1, keepdims=True) + np.float32(1e-10)).astype(np.float32)
+    sh = s.astype(np.float16)
+    half = np.float32(1 << (bits - 1))
+    qf = np.floor((v / sh.astype(np.float32)) * half + half)
+    q = np.clip(qf, 0, (1 << bits) - 1).astype(np.uint32)         # (G, 32)
+    words = []
+    rem = bits
+    for w in kv_planes(bits):
+        rem -= w
+        pv = (q >> np.uint32(rem)) & np.uint32((1 << w) - 1)       # (G, 32)
+        e = np.arange(32)
+        widx = (e * w) // 32
+        shift = ((e * w) % 32).astype(np.uint32)
+        plane = np.zeros((q.shape[0], w), dtype=np.uint32)
+        for wi in range(w):
+            sel = widx == wi
+            plane[:, wi] = (pv[:, sel] << shift[sel][None, :]).sum(-1, dtype=np.uint64).astype(np.uint32)
+        words.append(plane)
+    packed = np.concatenate(words, axis=-1)                        # (G, bits)
+    D = shp[-1]
+    return packed.reshape(shp[:-1] + (D // 32 * bits,)), sh.reshape(shp[:-1] + (D // 32,))
+
+
+def kv_dequant(packed: np.ndarray, scales: np.ndarray, bits: int) -> np.ndarray:
+    """Inverse of kv_quant: x = H32((q - (2^(b-1) - 0.5)) * s / 2^(b-1)) / sqrt(32) -> fp16.
+    q_cache_kernels.cuh:160-236."""
+    shp = scales.shape
+    pk = packed.reshape(-1, bits).astype(np.uint32)
+    q = np.zeros((pk.shape[0], 32), dtype=np.uint32)
+    off = 0
+    rem = bits
+    e = np.arange(32)
+    for w in kv_planes(bits):
+        rem -= w
+        widx = (e * w) // 32
+        shift = ((e * w) % 32).astype(np.uint32)
+        pv = (pk[:, off + widx] >> shift[None, :]) & np.uint32((1 << w) - 1)
+        q |= pv << np.uint32(rem)
+        off += w
+    s = scales.reshape(-1, 1).astype(np.float32)
+    half = np.float32(1 << (bits - 1))
+    v = ((q.astype(np.float32) - (half - np.float32(0.5))) * (s / half)).astype(np.float32)
+    x = (_fwht32_f32(v) * KV_RSQRT32).astype(np.float32)
+    return x.astype(np.float16).reshape(shp[:-1] + (shp[-1] * 32,))
+
+
+# ------------------------------------------------------------------------------------------
+# Synthetic tensors
+# ------------------------------------------------------------------------------------------
+
+def synth_linear(k: int, n: int, K: int, seed: int | None = None, realistic: bool = False):
+    """trellis = randint(0, 65536, (k/16, n/16, 16K)) -> int16 (tests/test_reconstruct_had.py:44-45);
+    suh/svh = sign(randn) fp16, or the log-normal 'realistic' variant of SURVEY 8(d)."""
+    rng = np.random.default_rng(k * 7 + n + K if seed is None else seed)
+    trellis = rng.integers(0, 65536, size=(k // 16, n // 16, 16 * K), dtype=np.uint16).view(np.int16)
+    su = np.where(rng.standard_normal(k) < 0, -1.0, 1.0)
+    sv = np.where(rng.standard_normal(n) < 0, -1.0, 1.0)
+    if realistic:
+        su = su * 0.02 * np.exp(0.2 * rng.standard_normal(k))
+        sv = sv * np.exp(0.2 * rng.standard_normal(n))
+    return trellis, su.astype(np.float16), sv.astype(np.float16)
