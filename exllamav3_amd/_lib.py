@@ -1,0 +1,104 @@
+"""
+ctypes binding of the C-ABI library libexl3_hip.so (include/exl3_hip.h).
+
+The product path has NO fallback: if the shared library is missing or fails to load, importing any op raises.
+"""
+from __future__ import annotations
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libexl3_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "exl3_hip.h")
+
+_lib = None
+
+
+def declared_symbols() -> list[str]:
+    """Every function name declared in include/exl3_hip.h."""
+    with open(HEADER_PATH) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    names = re.findall(r"\b(exl3_[a-z0-9_]+)\s*\(", src)
+    out = []
+    for n in names:
+        if n not in out:
+            out.append(n)
+    return out
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"exllamav3_amd: HIP library not built ({LIB_PATH}); run `python __graft_entry__.py` "
+                f"(there is no CPU fallback for the EXL3 hot path)")
+        _lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        _lib.exl3_last_error.restype = ctypes.c_char_p
+        ver = _lib.exl3_abi_version()
+        if ver != 1:
+            raise RuntimeError(f"exllamav3_amd: ABI version mismatch ({ver})")
+        _declare(_lib)
+    return _lib
+
+
+def check_symbols() -> list[str]:
+    """Load the library (no GPU needed) and verify it exports every symbol the header declares."""
+    l = lib()
+    missing = [s for s in declared_symbols() if not hasattr(l, s)]
+    if missing:
+        raise RuntimeError(f"libexl3_hip.so does not export: {missing}")
+    return declared_symbols()
+
+
+def last_error() -> str:
+    return lib().exl3_last_error().decode("utf-8", "replace")
+
+
+class Exl3Error(RuntimeError):
+    pass
+
+
+def check(rc: int) -> int:
+    """Reference behaviour: argument violations surface as RuntimeError (TORCH_CHECK, util.h:24-35)."""
+    if rc < 0:
+        raise Exl3Error(last_error())
+    return rc
+
+
+vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+u32 = ctypes.c_uint32
+
+
+def _declare(l):
+    def sig(name, *argtypes):
+        fn = getattr(l, name)
+        fn.argtypes = list(argtypes)
+        fn.restype = ctypes.c_int
+    sig("exl3_init", i32)
+    sig("exl3_device_info", i32, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i64))
+    sig("exl3_pack_trellis", vp, vp, i32, i32, i32, vp)
+    sig("exl3_unpack_trellis", vp, vp, i32, i32, i32, vp)
+    sig("exl3_pack_signs", vp, vp, i64, vp)
+    sig("exl3_decode", vp, vp, i64, i32, i32, vp)
+    sig("exl3_reconstruct", vp, vp, i32, i32, i32, i32, i64, i64, vp)
+    sig("exl3_reconstruct_had", vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, vp)
+    sig("exl3_had_r_128", vp, vp, vp, vp, f32, i32, i32, i32, vp)
+    sig("exl3_gemm", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp)
+    sig("exl3_mgemm", vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
+        ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, vp)
+    sig("exl3_hgemm", vp, vp, vp, i32, i32, i32, i64, i32, vp)
+    sig("exl3_rms_norm", vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i32, i32, i32, i32, vp)
+    sig("exl3_rope", vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, vp, vp, i32, f32, vp, vp, f32, f32, vp)
+    sig("exl3_quant_cache_cont", vp, vp, vp, i64, i32, i32, vp)
+    sig("exl3_dequant_cache_cont", vp, vp, vp, i64, i32, i32, vp)
+    sig("exl3_quant_cache_paged", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp)
+    sig("exl3_dequant_cache_paged", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp)
+    sig("exl3_silu_mul", vp, vp, vp, i64, i32, vp)
+    sig("exl3_add", vp, vp, i64, i32, i32, vp)
+    if hasattr(l, "exl3_set_gemv_variant"):
+        l.exl3_set_gemv_variant.argtypes = [i32]
+        l.exl3_set_gemv_variant.restype = ctypes.c_int

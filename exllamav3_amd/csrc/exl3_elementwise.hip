@@ -1,0 +1,152 @@
+// RMSNorm (+ fused residual modes), silu*mul, add.  HBM-bound elementwise/reduction kernels for gfx950:
+// 8-16 B per lane vector accesses, wave64 shuffle reductions.
+// reference: exllamav3_ext/norm.cu:155-299 (rms_norm_kernel), activation.cu (silu_mul), add.cu.
+#include "exl3_common.cuh"
+#include "exl3_api_internal.h"
+
+__device__ __forceinline__ float4_t load4(const void* p, int64_t idx4, bool fp32)
+{
+    if (fp32) return ((const float4_t*) p)[idx4];
+    half4_t h = ((const half4_t*) p)[idx4];
+    return float4_t{ (float) h.x, (float) h.y, (float) h.z, (float) h.w };
+}
+
+__device__ __forceinline__ void store4(void* p, int64_t idx4, float4_t v, bool fp32)
+{
+    if (fp32) ((float4_t*) p)[idx4] = v;
+    else ((half4_t*) p)[idx4] = half4_t{ (half_t) v.x, (half_t) v.y, (half_t) v.z, (half_t) v.w };
+}
+
+__device__ __forceinline__ float4_t load_w4(const void* w, int idx4, bool bf16)
+{
+    uint2_t raw = ((const uint2_t*) w)[idx4];
+    if (bf16)
+        return float4_t{ __uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u),
+                         __uint_as_float(raw.y << 16), __uint_as_float(raw.y & 0xffff0000u) };
+    half2_t a = u32_as_half2(raw.x), b = u32_as_half2(raw.y);
+    return float4_t{ (float) a.x, (float) a.y, (float) b.x, (float) b.y };
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red)
+{
+    #pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int nw = blockDim.x >> 6;
+    if (nw == 1) return v;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = lane < nw ? red[lane] : 0.0f;
+    #pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    return __shfl(t, 0, 64);
+}
+
+// MODE 0: y = norm(x) * w; 1: y += norm(x) * w; 2: r += x (rounded to r's dtype), y = norm(r) * w
+template <int MODE>
+__global__ __launch_bounds__(1024)
+void rms_norm_kernel(const void* __restrict__ x, const void* __restrict__ w, void* __restrict__ y, void* __restrict__ r,
+                     float eps, float constant_bias, float constant_scale, int dim,
+                     int x_fp32, int y_fp32, int r_fp32, int w_bf16)
+{
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    const int cols4 = dim >> 2;
+    const int64_t base4 = (int64_t) row * cols4;
+    float sum = 0.0f;
+    for (int c = threadIdx.x; c < cols4; c += blockDim.x)
+    {
+        float4_t v = load4(x, base4 + c, x_fp32);
+        if constexpr (MODE == 2)
+        {
+            float4_t rv = load4(r, base4 + c, r_fp32);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+            store4(r, base4 + c, v, r_fp32);
+            if (!r_fp32) { v.x = (float) (half_t) v.x; v.y = (float) (half_t) v.y; v.z = (float) (half_t) v.z; v.w = (float) (half_t) v.w; }  // norm sees r's rounding (norm.cu:206-213)
+        }
+        sum = __builtin_fmaf(v.x, v.x, sum); sum = __builtin_fmaf(v.y, v.y, sum);
+        sum = __builtin_fmaf(v.z, v.z, sum); sum = __builtin_fmaf(v.w, v.w, sum);
+    }
+    sum = block_sum(sum, red);
+    const float rmf = __frsqrt_rn(sum / (float) dim + eps) * constant_scale;
+    for (int c = threadIdx.x; c < cols4; c += blockDim.x)
+    {
+        float4_t v = (MODE == 2) ? load4(r, base4 + c, r_fp32) : load4(x, base4 + c, x_fp32);
+        if (w)
+        {
+            float4_t wv = load_w4(w, c, w_bf16);
+            if (constant_bias != 0.0f) { wv.x += constant_bias; wv.y += constant_bias; wv.z += constant_bias; wv.w += constant_bias; }
+            v.x = v.x * wv.x * rmf; v.y = v.y * wv.y * rmf; v.z = v.z * wv.z * rmf; v.w = v.w * wv.w * rmf;
+        }
+        else { v.x *= rmf; v.y *= rmf; v.z *= rmf; v.w *= rmf; }
+        if constexpr (MODE == 1)
+        {
+            float4_t o = load4(y, base4 + c, y_fp32);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        store4(y, base4 + c, v, y_fp32);
+    }
+}
+
+extern "C" int exl3_rms_norm(const void* x, const void* w, void* y, void* r, float eps, float constant_bias, float constant_scale,
+                             int rows, int dim, int x_fp32, int y_fp32, int r_fp32, int w_bf16, int mode, void* stream)
+{
+    EXL3_CHECK_ARG(x && y, "rms_norm: null pointer");
+    EXL3_CHECK_ARG(dim % 4 == 0 && dim > 0, "rms_norm: last dimension must be divisible by 4");
+    EXL3_CHECK_ARG(mode >= 0 && mode <= 2, "rms_norm: bad mode");
+    EXL3_CHECK_ARG(mode != 2 || r, "rms_norm: res_mode RES_IN requires residual tensor");
+    if (rows == 0) return EXL3_OK;
+    int threads = ((dim / 4 + 63) / 64) * 64;
+    if (threads > 1024) threads = 1024;
+    hipStream_t st = (hipStream_t) stream;
+    #define RN(M) rms_norm_kernel<M><<<dim3(rows), dim3(threads), 0, st>>>(x, w, y, r, eps, constant_bias, \
+                                     constant_scale, dim, x_fp32, y_fp32, r_fp32, w_bf16)
+    if (mode == 0) RN(0); else if (mode == 1) RN(1); else RN(2);
+    #undef RN
+    return exl3_check_launch("rms_norm");
+}
+
+// y = silu(g) * u      (activation.cu: _silu = x / (1 + exp(-x)), fast-math exp)
+__global__ __launch_bounds__(256)
+void silu_mul_kernel(const void* __restrict__ g, const void* __restrict__ u, half_t* __restrict__ y, int64_t n4, int in_fp32)
+{
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4_t gv = load4(g, i, in_fp32), uv = load4(u, i, in_fp32);
+    float4_t o;
+    o.x = gv.x / (1.0f + __expf(-gv.x)) * uv.x;
+    o.y = gv.y / (1.0f + __expf(-gv.y)) * uv.y;
+    o.z = gv.z / (1.0f + __expf(-gv.z)) * uv.z;
+    o.w = gv.w / (1.0f + __expf(-gv.w)) * uv.w;
+    store4(y, i, o, false);
+}
+
+extern "C" int exl3_silu_mul(const void* g, const void* u, void* y, int64_t numel, int in_fp32, void* stream)
+{
+    EXL3_CHECK_ARG(g && u && y, "silu_mul: null pointer");
+    EXL3_CHECK_ARG(numel % 4 == 0, "silu_mul: numel must be divisible by 4");
+    if (numel == 0) return EXL3_OK;
+    int64_t n4 = numel / 4;
+    silu_mul_kernel<<<dim3((unsigned) ((n4 + 255) / 256)), dim3(256), 0, (hipStream_t) stream>>>(g, u, (half_t*) y, n4, in_fp32);
+    return exl3_check_launch("silu_mul");
+}
+
+__global__ __launch_bounds__(256)
+void add_kernel(void* __restrict__ x, const void* __restrict__ y, int64_t n4, int x_fp32, int y_fp32)
+{
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4_t a = load4(x, i, x_fp32), b = load4(y, i, y_fp32);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    store4(x, i, a, x_fp32);
+}
+
+extern "C" int exl3_add(void* x, const void* y, int64_t numel, int x_fp32, int y_fp32, void* stream)
+{
+    EXL3_CHECK_ARG(x && y, "add: null pointer");
+    EXL3_CHECK_ARG(numel % 4 == 0, "add: numel must be divisible by 4");
+    if (numel == 0) return EXL3_OK;
+    int64_t n4 = numel / 4;
+    add_kernel<<<dim3((unsigned) ((n4 + 255) / 256)), dim3(256), 0, (hipStream_t) stream>>>(x, y, n4, x_fp32, y_fp32);
+    return exl3_check_launch("add");
+}

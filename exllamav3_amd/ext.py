@@ -1,0 +1,390 @@
+"""
+Host-side mirror of the reference's native op surface `exllamav3_ext` for the EXL3 quantized-linear hot path
+(/root/reference/exllamav3/exllamav3_ext/bindings.cpp:69-226).  Same names, argument order and meaning, same
+error behaviour (argument violations raise RuntimeError); every op forwards raw device pointers to the C-ABI
+library libexl3_hip.so (include/exl3_hip.h) on the caller's current HIP stream.  PyTorch is used only for device
+memory and streams.  There is no CPU or eager fallback: a missing library raises at first use.
+
+INTEGRATION.md shows how this module is installed under the name `exllamav3_ext` so that the reference's
+`exllamav3/ext.py:20-30` import seam picks it up unchanged.
+"""
+from __future__ import annotations
+import ctypes
+import torch
+from . import _lib
+from ._lib import check as _check
+
+_vp = ctypes.c_void_p
+
+
+def _p(t: torch.Tensor | None):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _cb(mcg: bool, mul1: bool) -> int:
+    # reconstruct.cu:128-130: mcg wins over mul1
+    return 1 if mcg else (2 if mul1 else 0)
+
+
+def _req(cond: bool, msg: str):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _dev(t: torch.Tensor):
+    _req(t.is_cuda, "tensor must be on a GPU device")
+    if t.device.index != torch.cuda.current_device():
+        torch.cuda.set_device(t.device)
+
+
+def init(device: int | torch.device | None = None):
+    """Create the per-device context (split-k workspace).  Must run once before graph capture."""
+    if device is None:
+        device = torch.cuda.current_device()
+    if isinstance(device, torch.device):
+        device = device.index if device.index is not None else torch.cuda.current_device()
+    torch.cuda.set_device(device)
+    _check(_lib.lib().exl3_init(int(device)))
+
+
+def g_get_num_sms(device: int) -> int:
+    n = ctypes.c_int(0)
+    _check(_lib.lib().exl3_device_info(int(device), ctypes.byref(n), None, None))
+    return n.value
+
+
+def g_get_cc(device: int) -> int:
+    a = ctypes.c_int(0)
+    _check(_lib.lib().exl3_device_info(int(device), None, ctypes.byref(a), None))
+    return a.value
+
+
+def set_gemv_variant(v: int):
+    """0 = EXACT (reference fp16 weights bit-for-bit in the MFMA), 1 = FAST (default)."""
+    _lib.lib().exl3_set_gemv_variant(int(v))
+
+
+# --------------------------------------------------------------------------------------------------
+# format ops
+# --------------------------------------------------------------------------------------------------
+
+def pack_trellis(packed: torch.Tensor, unpacked: torch.Tensor, K: int):
+    """quant/pack.cu:68-95"""
+    _dev(unpacked)
+    _req(packed.dim() == 3 and unpacked.dim() == 3, "pack_trellis: tensors must be 3-D")
+    _req(packed.shape[0] == unpacked.shape[0] and packed.shape[1] == unpacked.shape[1], "pack_trellis: shape mismatch")
+    _req(unpacked.shape[2] == 256, "pack_trellis: unpacked dim 2 must be 256")
+    _req(packed.shape[2] == 256 * K // 16, "pack_trellis: packed dim 2 must be 16*K")
+    _req(packed.is_contiguous() and unpacked.is_contiguous(), "pack_trellis: tensors must be contiguous")
+    _check(_lib.lib().exl3_pack_trellis(_p(packed), _p(unpacked), packed.shape[0], packed.shape[1], K, _stream(unpacked)))
+
+
+def unpack_trellis(unpacked: torch.Tensor, packed: torch.Tensor, K: int):
+    """quant/pack.cu:148-175"""
+    _dev(packed)
+    _req(packed.dim() == 3 and unpacked.dim() == 3, "unpack_trellis: tensors must be 3-D")
+    _req(packed.shape[0] == unpacked.shape[0] and packed.shape[1] == unpacked.shape[1], "unpack_trellis: shape mismatch")
+    _req(unpacked.shape[2] == 256, "unpack_trellis: unpacked dim 2 must be 256")
+    _req(packed.shape[2] == 256 * K // 16, "unpack_trellis: packed dim 2 must be 16*K")
+    _req(packed.is_contiguous() and unpacked.is_contiguous(), "unpack_trellis: tensors must be contiguous")
+    _check(_lib.lib().exl3_unpack_trellis(_p(unpacked), _p(packed), packed.shape[0], packed.shape[1], K, _stream(packed)))
+
+
+def pack_signs(packed: torch.Tensor, unpacked: torch.Tensor):
+    """quant/pack.cu:203-226"""
+    _dev(unpacked)
+    _req(unpacked.dtype == torch.half, "pack_signs: unpacked must be float16")
+    _req(packed.numel() * 16 == unpacked.numel(), "pack_signs: size mismatch")
+    _check(_lib.lib().exl3_pack_signs(_p(packed), _p(unpacked), unpacked.numel(), _stream(unpacked)))
+
+
+def decode(idx: torch.Tensor, out: torch.Tensor, mcg: bool, mul1: bool):
+    """quant/quantize.cu:118-168: 16-bit states -> codebook values (fp16 or fp32 out)"""
+    _dev(idx)
+    _req(idx.dtype in (torch.int16, torch.uint16), "decode: idx must be int16")
+    _req(out.dtype in (torch.half, torch.float), "decode: out must be float16 or float32")
+    _req(idx.numel() == out.numel(), "decode: size mismatch")
+    _check(_lib.lib().exl3_decode(_p(idx), _p(out), idx.numel(), int(out.dtype == torch.float), _cb(mcg, mul1), _stream(idx)))
+
+
+def _check_packed(unpacked, packed, K):
+    _req(packed.dim() == 3 and packed.dtype == torch.int16, "packed must be a 3-D int16 tensor")
+    _req(packed.shape[2] == 256 * K // 16, "packed dim 2 must be 16*K")
+    _req(unpacked.dtype == torch.half, "unpacked must be float16")
+    _req(unpacked.dim() == 2 and unpacked.shape[0] == packed.shape[0] * 16, "unpacked dim 0 must be 16 * packed dim 0")
+    _req(unpacked.is_contiguous() and packed.is_contiguous(), "tensors must be contiguous")
+
+
+def reconstruct_slice(unpacked: torch.Tensor, packed: torch.Tensor, K: int, mcg: bool, mul1: bool, n_offset: int):
+    """quant/reconstruct.cu:98-144"""
+    _dev(unpacked)
+    _check_packed(unpacked, packed, K)
+    _check(_lib.lib().exl3_reconstruct(_p(unpacked), _p(packed), packed.shape[0], packed.shape[1], K, _cb(mcg, mul1),
+                                       n_offset, unpacked.shape[1], _stream(unpacked)))
+
+
+def reconstruct(unpacked: torch.Tensor, packed: torch.Tensor, K: int, mcg: bool, mul1: bool):
+    """quant/reconstruct.cu:375-386"""
+    _req(unpacked.dim() == 2 and packed.dim() == 3 and unpacked.shape[1] == packed.shape[1] * 16,
+         "reconstruct: unpacked dim 1 must be 16 * packed dim 1")
+    reconstruct_slice(unpacked, packed, K, mcg, mul1, 0)
+
+
+def reconstruct_had_slice(unpacked: torch.Tensor, packed: torch.Tensor, suh: torch.Tensor, svh: torch.Tensor,
+                          K: int, mcg: bool, mul1: bool, n_offset: int):
+    """quant/reconstruct.cu:324-373 (svh pre-offset by the caller)"""
+    _dev(unpacked)
+    _check_packed(unpacked, packed, K)
+    _req(suh.dtype == torch.half and svh.dtype == torch.half, "suh/svh must be float16")
+    _req(unpacked.shape[0] % 128 == 0, "reconstruct_had_slice: K dimension must be divisible by 128")
+    _req(suh.numel() >= unpacked.shape[0] and svh.numel() >= unpacked.shape[1], "suh/svh too small")
+    _check(_lib.lib().exl3_reconstruct_had(_p(unpacked), _p(packed), _p(suh), _p(svh), packed.shape[0], packed.shape[1],
+                                           K, _cb(mcg, mul1), n_offset, unpacked.shape[1], _stream(unpacked)))
+
+
+def had_r_128(input: torch.Tensor, output: torch.Tensor, pre_scale: torch.Tensor | None, post_scale: torch.Tensor | None,
+              scale: float = 1.0):
+    """quant/hadamard.cu:88-173"""
+    _dev(input)
+    _req(input.shape == output.shape, "had_r_128: shape mismatch")
+    _req(input.dim() == 2, "had_r_128: input must be 2-D")
+    _req(input.shape[1] % 128 == 0, "had_r_128: dim 1 must be divisible by 128")
+    _req(input.dtype in (torch.half, torch.float), "unsupported datatype")
+    _req(output.dtype == input.dtype, "had_r_128: output dtype mismatch")
+    _req(input.is_contiguous() and output.is_contiguous(), "had_r_128: tensors must be contiguous")
+    for s in (pre_scale, post_scale):
+        _req(s is None or (s.dtype == torch.half and s.numel() >= input.shape[1]), "had_r_128: bad scale tensor")
+    _check(_lib.lib().exl3_had_r_128(_p(input), _p(output), _p(pre_scale), _p(post_scale), float(scale),
+                                     input.shape[0], input.shape[1], int(input.dtype == torch.float), _stream(input)))
+
+
+# --------------------------------------------------------------------------------------------------
+# quantized GEMM
+# --------------------------------------------------------------------------------------------------
+
+def exl3_gemm_num_kernel_shapes() -> int:
+    """quant/exl3_kernel_map.cuh:53-60 has 4 tile shapes; this implementation has one geometry."""
+    return 1
+
+
+def exl3_gemm_shape_compat(shape_idx: int, size_m: int, size_k: int, size_n: int, K: int) -> bool:
+    return size_k % 128 == 0 and size_n % 128 == 0 and 1 <= K <= 8
+
+
+def _gemm_checks(A, B, C, suh, svh):
+    _req(A.dtype == torch.half, "A must be float16")
+    _req(B.dtype == torch.int16 and B.dim() == 3, "B must be a 3-D int16 trellis tensor")
+    _req(C.dtype in (torch.half, torch.float), "C must be float16 or float32")
+    _req(A.is_contiguous() and B.is_contiguous() and C.is_contiguous(), "A, B and C must be contiguous")
+    k, n = B.shape[0] * 16, B.shape[1] * 16
+    _req(A.shape[-1] == k, "A dim -1 must match B")
+    _req(C.shape[-1] == n, "C dim -1 must match B")
+    m = A.numel() // k
+    _req(C.numel() // n == m, "A and C row counts differ")
+    _req(B.shape[2] % 16 == 0 and 1 <= B.shape[2] // 16 <= 8, "B dim 2 must be 16*K, K in [1, 8]")
+    _req(suh is not None and svh is not None, "suh and svh are required")
+    _req(suh.dtype == torch.half and svh.dtype == torch.half, "suh/svh must be float16")
+    _req(suh.numel() == k and svh.numel() == n, "suh/svh size mismatch")
+    return m, k, n, B.shape[2] // 16
+
+
+def exl3_gemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, suh: torch.Tensor | None, A_had: torch.Tensor | None,
+              svh: torch.Tensor | None, force_shape_idx: int = -1, mcg: bool = False, mul1: bool = False,
+              force_num_sms: int = 0, bias: torch.Tensor | None = None, force_split: int = 0) -> int:
+    """quant/exl3_gemm.cuh:21-33.  A_had (the reference's scratch for the rotated input) is accepted and ignored:
+    the input Hadamard is recomputed per workgroup in LDS.  Returns the kernel id (1)."""
+    _dev(A)
+    m, k, n, K = _gemm_checks(A, B, C, suh, svh)
+    if m == 0:
+        return 0
+    return _check(_lib.lib().exl3_gemm(_p(A), _p(B), _p(C), _p(suh), _p(svh), _p(bias), m, k, n, K, _cb(mcg, mul1),
+                                       int(C.dtype == torch.float), int(force_split), _stream(A)))
+
+
+def exl3_gemv(A, B, C, suh, A_had, svh, mcg: bool, mul1: bool):
+    """quant/exl3_gemv.cuh:30-40 (same kernel family here)"""
+    exl3_gemm(A, B, C, suh, A_had, svh, -1, mcg, mul1, 0)
+
+
+def exl3_mgemm_bcast(A: torch.Tensor, Bs: list[torch.Tensor], Cs: list[torch.Tensor], suhs: list[torch.Tensor],
+                     svhs: list[torch.Tensor], mcg: bool = False, mul1: bool = False, force_split: int = 0) -> int:
+    """Broadcast form of quant/exl3_gemm.cuh:58-78 (indices == None): one A against several matrices in ONE launch
+    (fused q/k/v, gate/up).  The reference passes int64 tensors of device pointers built from these same tensors
+    (modules/multilinear.py:30-32)."""
+    _dev(A)
+    cnt = len(Bs)
+    _req(cnt == len(Cs) == len(suhs) == len(svhs) and 1 <= cnt <= 4, "exl3_mgemm: between 1 and 4 matrices")
+    m = k = K = None
+    ns = []
+    for B, C, su, sv in zip(Bs, Cs, suhs, svhs):
+        mm, kk, nn, KK = _gemm_checks(A, B, C, su, sv)
+        _req(m is None or (mm == m and kk == k and KK == K), "exl3_mgemm: all matrices must share m, k and K")
+        _req(C.dtype == Cs[0].dtype, "exl3_mgemm: all outputs must share a dtype")
+        m, k, K = mm, kk, KK
+        ns.append(nn)
+    arr = lambda ts: (_vp * cnt)(*[t.data_ptr() for t in ts])
+    return _check(_lib.lib().exl3_mgemm(_p(A), arr(Bs), arr(Cs), arr(suhs), arr(svhs), (ctypes.c_int * cnt)(*ns), cnt,
+                                        m, k, K, _cb(mcg, mul1), int(Cs[0].dtype == torch.float), int(force_split), _stream(A)))
+
+
+def hgemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):
+    """hgemm.cu:19-102: c = a @ b, fp16 inputs, fp32 accumulate, c fp16/fp32 (may be a column slice)."""
+    _dev(a)
+    _req(a.dtype == torch.half and b.dtype == torch.half, "hgemm: a and b must be float16")
+    _req(c.dtype in (torch.half, torch.float), "hgemm: c must be float16 or float32")
+    _req(a.dim() == 2 and b.dim() == 2 and c.dim() == 2, "hgemm: tensors must be 2-D")
+    _req(a.shape[1] == b.shape[0] and a.shape[0] == c.shape[0] and b.shape[1] == c.shape[1], "hgemm: shape mismatch")
+    _req(a.is_contiguous() and b.is_contiguous() and c.stride(1) == 1, "hgemm: a, b contiguous; c unit column stride")
+    _check(_lib.lib().exl3_hgemm(_p(a), _p(b), _p(c), a.shape[0], a.shape[1], b.shape[1], c.stride(0),
+                                 int(c.dtype == torch.float), _stream(a)))
+
+
+class BC_LinearEXL3:
+    """libtorch/linear.h:29-64, linear.cpp:34-71: holder of {trellis, suh, svh, K, bias, mcg, mul1, xh}."""
+
+    def __init__(self, trellis, suh, svh, K, bias, mcg, mul1, xh):
+        self.trellis, self.suh, self.svh, self.K = trellis, suh, svh, int(K)
+        self.bias, self.mcg, self.mul1, self.xh = bias, bool(mcg), bool(mul1), xh
+
+    def run(self, x: torch.Tensor, y: torch.Tensor):
+        exl3_gemm(x, self.trellis, y, self.suh, self.xh, self.svh, -1, self.mcg, self.mul1, 0, bias=self.bias)
+
+    def run_alloc(self, x: torch.Tensor, out_features: int, output_fp32: bool) -> torch.Tensor:
+        y = torch.empty(x.shape[:-1] + (out_features,), dtype=torch.float if output_fp32 else torch.half, device=x.device)
+        self.run(x, y)
+        return y
+
+
+# --------------------------------------------------------------------------------------------------
+# norm / rope / cache / elementwise
+# --------------------------------------------------------------------------------------------------
+
+def _norm(x, w, y, r, eps, constant_bias, constant_scale, mode):
+    _dev(x)
+    _req(x.dtype in (torch.half, torch.float) and y.dtype in (torch.half, torch.float), "rms_norm: Invalid datatypes for input/output")
+    _req(x.shape == y.shape, "rms_norm: x and y shapes differ")
+    _req(x.shape[-1] % 4 == 0, "rms_norm: last dimension must be divisible by 4")
+    _req(x.is_contiguous() and y.is_contiguous(), "rms_norm: tensors must be contiguous")
+    w_bf16 = 0
+    if w is not None:
+        _req(w.dtype in (torch.half, torch.bfloat16) and w.numel() == x.shape[-1], "rms_norm: bad weight tensor")
+        w_bf16 = int(w.dtype == torch.bfloat16)
+    r_fp32 = 0
+    if r is not None:
+        _req(r.shape == x.shape and r.dtype in (torch.half, torch.float) and r.is_contiguous(), "rms_norm: bad residual tensor")
+        r_fp32 = int(r.dtype == torch.float)
+    dim = x.shape[-1]
+    rows = x.numel() // dim
+    _check(_lib.lib().exl3_rms_norm(_p(x), _p(w), _p(y), _p(r), float(eps), float(constant_bias), float(constant_scale),
+                                    rows, dim, int(x.dtype == torch.float), int(y.dtype == torch.float), r_fp32, w_bf16, mode, _stream(x)))
+
+
+def rms_norm(x, w, y, epsilon: float, constant_bias: float = 0.0, constant_scale: float = 1.0,
+             span_heads: bool = False, add_residual: bool = False):
+    """norm.cuh:7-17"""
+    if span_heads:
+        x = x.view(x.shape[:-2] + (-1,)) if x.dim() > 2 else x
+        y = y.view(x.shape)
+    _norm(x, w, y, None, epsilon, constant_bias, constant_scale, 1 if add_residual else 0)
+
+
+def rms_norm_res_in(x, w, y, r, epsilon: float, constant_bias: float = 0.0, constant_scale: float = 1.0):
+    """norm.cuh:29-39: r += x; y = norm(r)"""
+    _norm(x, w, y, r, epsilon, constant_bias, constant_scale, 2)
+
+
+def rope(q, out_q, k, out_k, inv_freq, position: int, positions, position_ids, rope_mode: int, attn_factor: float,
+         q_norm=None, k_norm=None, norm_eps: float = 1e-6, norm_constant_bias: float = 0.0, l4_beta: float = 0.0,
+         l4_orig: int = 1, post_rope_norm: bool = False, rotate_dims: int = 1, rotate_offset: int = 0):
+    """rope.cuh:51-72"""
+    _dev(q)
+    _req(q.dim() == 4 and q.dtype == torch.half and q.is_contiguous(), "rope: q must be contiguous float16 (b, s, h, d)")
+    _req(out_q.shape == q.shape and out_q.dtype == torch.half, "rope: out_q mismatch")
+    bsz, seq, hq, hd = q.shape
+    hk = 0
+    if k is not None:
+        _req(k.dim() == 4 and k.dtype == torch.half and k.is_contiguous() and k.shape[0] == bsz and k.shape[1] == seq and k.shape[3] == hd,
+             "rope: k must match q")
+        _req(out_k is not None and out_k.shape == k.shape, "rope: out_k mismatch")
+        hk = k.shape[2]
+    _req(l4_beta == 0.0 and not post_rope_norm and rotate_dims == 1 and rotate_offset == 0,
+         "rope: llama-4 scaling / post-rope norm / multi-dim rotation are outside the Llama/Mixtral path of this build")
+    _req(inv_freq.dtype == torch.float and inv_freq.dim() == 1 and inv_freq.numel() * 2 <= hd, "rope: inv_freq must be float32 [<= head_dim/2]")
+    _req(inv_freq.numel() * 2 == hd, "rope: partial rotary is outside this build")
+    for t in (positions, position_ids):
+        _req(t is None or t.dtype in (torch.int32, torch.int), "rope: positions / position_ids must be int32")
+    for t in (q_norm, k_norm):
+        _req(t is None or (t.dtype == torch.half and t.numel() == hd), "rope: norm weights must be float16 [head_dim]")
+    _check(_lib.lib().exl3_rope(_p(q), _p(out_q), _p(k), _p(out_k), _p(inv_freq), bsz, seq, hq, hk, hd, int(position),
+                                _p(positions), _p(position_ids), int(rope_mode), float(attn_factor), _p(q_norm), _p(k_norm),
+                                float(norm_eps), float(norm_constant_bias), _stream(q)))
+
+
+def _kv_bits(packed: torch.Tensor, scales: torch.Tensor) -> int:
+    return packed.shape[-1] // scales.shape[-1]
+
+
+def quant_cache_cont(inp, out, out_scales, compand_a: float = 0.0):
+    """cache/q_cache.cuh: contiguous quantization"""
+    _dev(inp)
+    _req(compand_a == 0.0, "quant_cache: compander is outside this build")
+    _req(inp.dtype == torch.half and inp.is_contiguous() and inp.shape[-1] % 32 == 0, "quant_cache_cont: bad input")
+    dim = inp.shape[-1]
+    bits = _kv_bits(out, out_scales)
+    _req(2 <= bits <= 8, "quant_cache_cont: bits must be in [2, 8]")
+    _check(_lib.lib().exl3_quant_cache_cont(_p(inp), _p(out), _p(out_scales), inp.numel() // dim, dim, bits, _stream(inp)))
+
+
+def dequant_cache_cont(inp, in_scales, out, compand_a: float = 0.0):
+    _dev(inp)
+    _req(compand_a == 0.0, "dequant_cache: compander is outside this build")
+    dim = out.shape[-1]
+    bits = _kv_bits(inp, in_scales)
+    _req(out.dtype == torch.half and out.is_contiguous() and dim % 32 == 0 and 2 <= bits <= 8, "dequant_cache_cont: bad arguments")
+    _check(_lib.lib().exl3_dequant_cache_cont(_p(inp), _p(in_scales), _p(out), out.numel() // dim, dim, bits, _stream(inp)))
+
+
+def quant_cache_paged(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, page_size: int, seq_len: int,
+                      compand_a: float = 0.0, in_contiguous: bool = True):
+    _dev(k_in)
+    _req(compand_a == 0.0, "quant_cache: compander is outside this build")
+    _req(in_contiguous, "quant_cache_paged: only in_contiguous inputs are supported by this build")
+    _req(page_size == 256, "quant_cache_paged: page size must be 256")
+    _req(cache_seqlens.dtype == torch.int32 and block_table.dtype == torch.int32, "cache_seqlens / block_table must be int32")
+    dim = k_out.shape[-1] // _kv_bits(k_out, k_scales) * 32
+    bsz = block_table.shape[0]
+    _check(_lib.lib().exl3_quant_cache_paged(_p(k_in), _p(k_out), _p(k_scales), _p(v_in), _p(v_out), _p(v_scales),
+                                             _p(cache_seqlens), _p(block_table), bsz, block_table.shape[1], page_size, seq_len, dim,
+                                             _kv_bits(k_out, k_scales), _kv_bits(v_out, v_scales), _stream(k_in)))
+
+
+def dequant_cache_paged(k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens, block_table, page_size: int,
+                        sliding_window: int = 0, compand_a: float = 0.0):
+    _dev(k_in)
+    _req(compand_a == 0.0 and sliding_window == 0, "dequant_cache_paged: compander / sliding window are outside this build")
+    _req(page_size == 256, "dequant_cache_paged: page size must be 256")
+    dim = k_out.shape[-1] * (k_out.shape[-2] if k_out.dim() == 4 else 1)
+    dim = k_in.shape[-1] // _kv_bits(k_in, k_scales) * 32
+    bsz = block_table.shape[0]
+    _check(_lib.lib().exl3_dequant_cache_paged(_p(k_in), _p(k_scales), _p(k_out), _p(v_in), _p(v_scales), _p(v_out),
+                                               _p(cache_seqlens), _p(block_table), bsz, block_table.shape[1], page_size, dim,
+                                               _kv_bits(k_in, k_scales), _kv_bits(v_in, v_scales), _stream(k_in)))
+
+
+def silu_mul(g, u, y):
+    """activation.cu silu_mul: y = silu(g) * u"""
+    _dev(g)
+    _req(g.shape == u.shape and g.dtype == u.dtype and g.dtype in (torch.half, torch.float), "silu_mul: bad inputs")
+    _req(y.dtype == torch.half and y.numel() == g.numel(), "silu_mul: y must be float16")
+    _check(_lib.lib().exl3_silu_mul(_p(g), _p(u), _p(y), g.numel(), int(g.dtype == torch.float), _stream(g)))
+
+
+def add(x, y):
+    """add.cu: x += y"""
+    _dev(x)
+    _req(x.numel() == y.numel(), "add: size mismatch")
+    _check(_lib.lib().exl3_add(_p(x), _p(y), x.numel(), int(x.dtype == torch.float), int(y.dtype == torch.float), _stream(x)))

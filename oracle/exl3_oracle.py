@@ -381,55 +381,59 @@ KV_RSQRT32 = np.float32(0.17677669529663689)
 
 def kv_quant(x: np.ndarray, bits: int):
     """x (..., D) fp16, D % 32 == 0 -> (packed uint32 (..., D/32*bits), scales fp16 (..., D/32)).
-    Per 32-group: v = H32(x)/sqrt(32) (fp32); s = max|v| + 1e-10 (stored fp16);
-    q = clamp(floor(v / s * 2^(b-1) + 2^(b-1)), 0, 2^b - 1); bit-plane packing.
-    q_cache_kernels.cuh:61-156."""
+    Per 32-group, in fp32 and in the reference's op order (q_cache_kernels.cuh:61-156):
+      v = H32(x) * (1/sqrt(32));  s = max|v| + 1e-10;  inv_s = 1/s;
+      q = clamp(floor(fma(v * inv_s, 2^(b-1), 2^(b-1))), 0, 2^b - 1);  stored scale = fp16(s);
+    bit planes (8,4,2,1 widths present in b, MSB plane first), value e of the group at bit e*w of the plane.
+    (The reference builds with --use_fast_math, so its 1/s is approximate; the oracle and the HIP kernel both use
+    the IEEE division, which is what 'bit-exact vs the oracle' refers to.)"""
     shp = x.shape
     g = x.astype(np.float32).reshape(-1, 32)
     v = (_fwht32_f32(g) * KV_RSQRT32).astype(np.float32)
     s = (np.abs(v).max(-1, keepdims=True) + np.float32(1e-10)).astype(np.float32)
-    sh = s.astype(np.float16)
+    inv_s = (np.float32(1.0) / s).astype(np.float32)
     half = np.float32(1 << (bits - 1))
-    qf = np.floor((v / sh.astype(np.float32)) * half + half)
+    t = (v * inv_s).astype(np.float32)
+    # fma(t, half, half): half is a power of two, so t*half is exact and the fma equals one rounded add
+    qf = np.floor((t.astype(np.float64) * np.float64(half) + np.float64(half)).astype(np.float32))
     q = np.clip(qf, 0, (1 << bits) - 1).astype(np.uint32)         # (G, 32)
     words = []
-    rem = bits
-    for w in kv_planes(bits):
-        rem -= w
-        pv = (q >> np.uint32(rem)) & np.uint32((1 << w) - 1)       # (G, 32)
-        e = np.arange(32)
-        widx = (e * w) // 32
-        shift = ((e * w) % 32).astype(np.uint32)
-        plane = np.zeros((q.shape[0], w), dtype=np.uint32)
-        for wi in range(w):
-            sel = widx == wi
-            plane[:, wi] = (pv[:, sel] << shift[sel][None, :]).sum(-1, dtype=np.uint64).astype(np.uint32)
-        words.append(plane)
-    packed = np.concatenate(words, axis=-1)                        # (G, bits)
-    D = shp[-1]
-    return packed.reshape(shp[:-1] + (D // 32 * bits,)), sh.reshape(shp[:-1] + (D // 32,))
-
-
-def kv_dequant(packed: np.ndarray, scales: np.ndarray, bits: int) -> np.ndarray:
-    """Inverse of kv_quant: x = H32((q - (2^(b-1) - 0.5)) * s / 2^(b-1)) / sqrt(32) -> fp16.
-    q_cache_kernels.cuh:160-236."""
-    shp = scales.shape
-    pk = packed.reshape(-1, bits).astype(np.uint32)
-    q = np.zeros((pk.shape[0], 32), dtype=np.uint32)
-    off = 0
     rem = bits
     e = np.arange(32)
     for w in kv_planes(bits):
         rem -= w
+        pv = (q >> np.uint32(rem)) & np.uint32((1 << w) - 1)       # (G, 32)
+        widx = (e * w) // 32
+        shift = ((e * w) % 32).astype(np.uint64)
+        plane = np.zeros((q.shape[0], w), dtype=np.uint32)
+        for wi in range(w):
+            sel = widx == wi
+            plane[:, wi] = (pv[:, sel].astype(np.uint64) << shift[sel][None, :]).sum(-1, dtype=np.uint64).astype(np.uint32)
+        words.append(plane)
+    packed = np.concatenate(words, axis=-1)                        # (G, bits)
+    D = shp[-1]
+    return packed.reshape(shp[:-1] + (D // 32 * bits,)), s.astype(np.float16).reshape(shp[:-1] + (D // 32,))
+
+
+def kv_dequant(packed: np.ndarray, scales: np.ndarray, bits: int) -> np.ndarray:
+    """Inverse of kv_quant (q_cache_kernels.cuh:160-236): s' = fp32(scale) * (1/sqrt(32)); sm = s' * 2^-(b-1);
+    v = (q - (2^(b-1) - 0.5)) * sm; x = H32(v) -> fp16."""
+    shp = scales.shape
+    pk = packed.reshape(-1, bits).astype(np.uint32)
+    q = np.zeros((pk.shape[0], 32), dtype=np.uint32)
+    off = 0
+    e = np.arange(32)
+    for w in kv_planes(bits):
         widx = (e * w) // 32
         shift = ((e * w) % 32).astype(np.uint32)
         pv = (pk[:, off + widx] >> shift[None, :]) & np.uint32((1 << w) - 1)
-        q |= pv << np.uint32(rem)
+        q = (q << np.uint32(w)) | pv
         off += w
-    s = scales.reshape(-1, 1).astype(np.float32)
+    s = (scales.reshape(-1, 1).astype(np.float32) * KV_RSQRT32).astype(np.float32)
     half = np.float32(1 << (bits - 1))
-    v = ((q.astype(np.float32) - (half - np.float32(0.5))) * (s / half)).astype(np.float32)
-    x = (_fwht32_f32(v) * KV_RSQRT32).astype(np.float32)
+    sm = (s * (np.float32(1.0) / half)).astype(np.float32)
+    v = ((q.astype(np.float32) - (half - np.float32(0.5))) * sm).astype(np.float32)
+    x = _fwht32_f32(v)
     return x.astype(np.float16).reshape(shp[:-1] + (shp[-1] * 32,))
 
 

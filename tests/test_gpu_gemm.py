@@ -1,0 +1,132 @@
+"""GPU parity of the fused EXL3 GEMV / small-m GEMM (decode path) against the oracle, through the C-ABI.
+
+Tolerance: max |y - y_ref| <= 1e-2 * rms(y_ref)   (rtol ~ 1e-2 on outputs of RMS ~ 1; the reference's
+own kernel-vs-reconstruct test uses rtol = atol = 0.05, tests/test_qgemm.py:31-58)."""
+import numpy as np
+import pytest
+import torch
+from oracle import exl3_oracle as o
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-2
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _run(dev, k, n, K, cb, m, variant, out_fp32=False, force_split=0, bias=False, realistic=False, seed=None):
+    from exllamav3_amd import ext
+    ext.set_gemv_variant(variant)
+    tr, suh, svh = o.synth_linear(k, n, K, seed=seed, realistic=realistic)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((m, k)).astype(np.float16)
+    b = (rng.standard_normal(n) * 0.5).astype(np.float16) if bias else None
+    ref = o.linear_forward(x, tr, suh, svh, K, cb, bias=b, out_fp32=out_fp32).astype(np.float32)
+    y = torch.full((m, n), float("nan"), dtype=torch.float if out_fp32 else torch.half, device=dev)
+    rc = ext.exl3_gemm(_t(x, dev), _t(tr, dev), y, _t(suh, dev), None, _t(svh, dev), -1, cb == 1, cb == 2, 0,
+                       bias=None if b is None else _t(b, dev), force_split=force_split)
+    assert rc >= 1
+    got = y.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max() / np.sqrt((ref ** 2).mean())
+    return err
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("cb", [0, 1, 2])
+@pytest.mark.parametrize("K", range(1, 9))
+def test_gemv_all_bitrates(dev, K, cb, variant):
+    assert _run(dev, 512, 256, K, cb, 1, variant) < TOL
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("m", [1, 2, 3, 8, 15, 16, 17, 31, 33])
+def test_gemm_batch_sizes(dev, m, variant):
+    # tests/test_qgemm.py bs list (those <= 33); m > 16 runs 16-row passes
+    for cb in (0, 2):
+        assert _run(dev, 1024, 384, 4, cb, m, variant) < TOL
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("split", [1, 2, 3, 4, 8])
+def test_split_k(dev, split, variant):
+    for cb in (0, 1, 2):
+        assert _run(dev, 2048, 256, 4, cb, 2, variant, force_split=split) < TOL
+        assert _run(dev, 2048, 256, 3, cb, 5, variant, out_fp32=True, force_split=split) < TOL
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_fp32_out_bias_realistic(dev, variant):
+    for cb in (0, 1, 2):
+        assert _run(dev, 512, 512, 4, cb, 4, variant, out_fp32=True, bias=True) < TOL
+        assert _run(dev, 512, 512, 5, cb, 1, variant, out_fp32=False, bias=True) < TOL
+        assert _run(dev, 4096, 1024, 4, cb, 1, variant, realistic=True) < TOL
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_llama_shapes(dev, variant):
+    # science/qgemm_benchmark.py shapes at 4 bpw (sizes the oracle finishes in seconds)
+    for (k, n) in [(4096, 4096), (4096, 1024), (14336, 4096)]:
+        assert _run(dev, k, n, 4, 2, 1, variant) < TOL
+    assert _run(dev, 4096, 14336, 4, 0, 16, variant) < TOL
+
+
+def test_exact_variant_matches_reconstruct_matmul_tightly(dev):
+    """EXACT variant feeds the reference's fp16 weights bit-for-bit to the MFMA: agreement with an fp64 matmul over the
+    reconstructed weights is limited only by the fp16 rounding of the output."""
+    assert _run(dev, 1024, 256, 4, 0, 4, 0, out_fp32=True) < 2e-4
+    assert _run(dev, 1024, 256, 4, 2, 4, 0, out_fp32=True) < 2e-4
+
+
+def test_mgemm_broadcast(dev):
+    from exllamav3_amd import ext
+    ext.set_gemv_variant(1)
+    k, K, cb, m = 1024, 4, 2, 2
+    ns = [512, 128, 128]
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((m, k)).astype(np.float16)
+    mats = [o.synth_linear(k, n, K, seed=50 + i) for i, n in enumerate(ns)]
+    Bs = [_t(t[0], dev) for t in mats]; su = [_t(t[1], dev) for t in mats]; sv = [_t(t[2], dev) for t in mats]
+    Cs = [torch.full((m, n), float("nan"), dtype=torch.half, device=dev) for n in ns]
+    for split in (0, 1, 4):
+        ext.exl3_mgemm_bcast(_t(x, dev), Bs, Cs, su, sv, False, True, force_split=split)
+        for (tr, suh, svh), C in zip(mats, Cs):
+            ref = o.linear_forward(x, tr, suh, svh, K, cb).astype(np.float32)
+            got = C.float().cpu().numpy()
+            assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < TOL
+
+
+def test_bc_linear_exl3(dev):
+    from exllamav3_amd import ext
+    k, n, K = 512, 256, 4
+    tr, suh, svh = o.synth_linear(k, n, K)
+    x = np.random.default_rng(0).standard_normal((1, 3, k)).astype(np.float16)
+    bc = ext.BC_LinearEXL3(_t(tr, dev), _t(suh, dev), _t(svh, dev), K, None, False, False, None)
+    y = bc.run_alloc(_t(x, dev), n, True)
+    assert y.shape == (1, 3, n) and y.dtype == torch.float
+    ref = o.linear_forward(x.reshape(3, k), tr, suh, svh, K, 0, out_fp32=True)
+    assert np.abs(y.cpu().numpy().reshape(3, n) - ref).max() / np.sqrt((ref ** 2).mean()) < TOL
+
+
+def test_graph_capture_replay(dev):
+    """Decode-step launches must be capturable into a hipGraph (reference: graph.cuh:100-137)."""
+    from exllamav3_amd import ext
+    k, n, K = 1024, 512, 4
+    tr, suh, svh = o.synth_linear(k, n, K)
+    x = _t(np.random.default_rng(0).standard_normal((1, k)).astype(np.float16), dev)
+    B, su, sv = _t(tr, dev), _t(suh, dev), _t(svh, dev)
+    y = torch.zeros((1, n), dtype=torch.half, device=dev)
+    ext.exl3_gemm(x, B, y, su, None, sv, -1, False, False, 0)
+    torch.cuda.synchronize()
+    expect = y.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y.zero_()
+        with torch.cuda.graph(g, stream=s):
+            ext.exl3_gemm(x, B, y, su, None, sv, -1, False, False, 0)
+    y.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y, expect)

@@ -1,0 +1,77 @@
+"""GPU parity of RMSNorm / silu_mul / add against the oracle and the reference-Python fixtures."""
+import numpy as np
+import pytest
+import torch
+from oracle import exl3_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("dim", [8, 128, 2048, 4096, 12288])
+@pytest.mark.parametrize("rows", [1, 3, 64])
+@pytest.mark.parametrize("dt_in,dt_out", [(np.float16, np.float16), (np.float32, np.float16), (np.float16, np.float32)])
+def test_rms_norm(dev, dim, rows, dt_in, dt_out):
+    # tests/test_ext_norm_.py:11-40: dims, rows, dtype combos, tolerance 1e-3
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(dim + rows)
+    x = (rng.standard_normal((rows, dim)) * 1.5).astype(dt_in)
+    w = (1 + 0.1 * rng.standard_normal(dim)).astype(np.float16)
+    ref = o.rms_norm(x, w, 1e-6, out_dtype=dt_out).astype(np.float32)
+    y = torch.empty((rows, dim), dtype=torch.float if dt_out == np.float32 else torch.half, device=dev)
+    ext.rms_norm(_t(x, dev), _t(w, dev), y, 1e-6)
+    assert np.allclose(y.float().cpu().numpy(), ref, rtol=1e-3, atol=1e-3)
+
+
+def test_rms_norm_golden_and_modes(dev, golden):
+    from exllamav3_amd import ext
+    for tag in "abc":
+        eps, cb, cs = golden[f"rms_{tag}_cfg"]
+        x, w = golden[f"rms_{tag}_x"], golden[f"rms_{tag}_w"]
+        y = torch.empty(x.shape, dtype=torch.half, device=dev)
+        ext.rms_norm(_t(x, dev), _t(w, dev), y, float(eps), float(cb), float(cs))
+        assert np.allclose(y.float().cpu().numpy(), golden[f"rms_{tag}_y"].astype(np.float32), rtol=2e-3, atol=2e-3)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((4, 4096)).astype(np.float16)
+    w = (1 + 0.1 * rng.standard_normal(4096)).astype(np.float16)
+    # RES_IN: r += x; y = norm(r), fp16 and fp32 residual streams
+    for rdt in (np.float16, np.float32):
+        r = rng.standard_normal((4, 4096)).astype(rdt)
+        y_ref, r_ref = o.rms_norm(x, w, 1e-5, residual_in=r)
+        rt = _t(r, dev)
+        y = torch.empty((4, 4096), dtype=torch.half, device=dev)
+        ext.rms_norm_res_in(_t(x, dev), _t(w, dev), y, rt, 1e-5)
+        assert np.allclose(rt.float().cpu().numpy(), r_ref.astype(np.float32), rtol=1e-3, atol=1e-3)
+        assert np.allclose(y.float().cpu().numpy(), y_ref.astype(np.float32), rtol=2e-3, atol=2e-3)
+    # RES_POST: y += norm(x)
+    base = rng.standard_normal((4, 4096)).astype(np.float16)
+    y_ref = o.rms_norm(x, w, 1e-5, add_residual_to=base)
+    y = _t(base, dev)
+    ext.rms_norm(_t(x, dev), _t(w, dev), y, 1e-5, 0.0, 1.0, False, True)
+    assert np.allclose(y.float().cpu().numpy(), y_ref.astype(np.float32), rtol=2e-3, atol=2e-3)
+    # bf16 weights, unweighted
+    wb = torch.from_numpy(w.astype(np.float32)).to(torch.bfloat16)
+    y = torch.empty((4, 4096), dtype=torch.half, device=dev)
+    ext.rms_norm(_t(x, dev), wb.to(dev), y, 1e-5)
+    ref = o.rms_norm(x, wb.float().numpy(), 1e-5)
+    assert np.allclose(y.float().cpu().numpy(), ref.astype(np.float32), rtol=2e-3, atol=2e-3)
+    ext.rms_norm(_t(x, dev), None, y, 1e-5)
+    assert np.allclose(y.float().cpu().numpy(), o.rms_norm(x, None, 1e-5).astype(np.float32), rtol=2e-3, atol=2e-3)
+
+
+def test_silu_mul_add(dev):
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(0)
+    g = rng.standard_normal((3, 1024)).astype(np.float32) * 3
+    u = rng.standard_normal((3, 1024)).astype(np.float32)
+    ref = g / (1 + np.exp(-g)) * u
+    for dt in (np.float16, np.float32):
+        y = torch.empty((3, 1024), dtype=torch.half, device=dev)
+        ext.silu_mul(_t(g.astype(dt), dev), _t(u.astype(dt), dev), y)
+        r = (g.astype(dt).astype(np.float32)); r = r / (1 + np.exp(-r)) * u.astype(dt).astype(np.float32)
+        assert np.allclose(y.float().cpu().numpy(), r, rtol=3e-3, atol=3e-3)
+    a = _t(g, dev); ext.add(a, _t(u.astype(np.float16), dev))
+    assert np.allclose(a.cpu().numpy(), g + u.astype(np.float16).astype(np.float32), rtol=1e-6, atol=1e-6)
