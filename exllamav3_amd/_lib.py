@@ -99,6 +99,5 @@ def _declare(l):
     sig("exl3_dequant_cache_paged", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_silu_mul", vp, vp, vp, i64, i32, vp)
     sig("exl3_add", vp, vp, i64, i32, i32, vp)
-    if hasattr(l, "exl3_set_gemv_variant"):
-        l.exl3_set_gemv_variant.argtypes = [i32]
-        l.exl3_set_gemv_variant.restype = ctypes.c_int
+    sig("exl3_set_gemv_variant", i32)
+    sig("exl3_set_gemv_gen", i32)

@@ -32,35 +32,8 @@
 #include <string.h>
 #include <stdlib.h>
 
-#define GEMV_THREADS 256
-#define GEMV_MAX_MATS 4
+#include "exl3_gemv_args.h"
 #define GEMV_PF 4
-
-struct GemvMat
-{
-    const uint32_t* B;
-    const half_t* suh;
-    const half_t* svh;
-    const half_t* bias;
-    void* C;
-    int n;
-    int cb_first;          // first column block of this matrix in the flattened grid
-    int ws_offset;         // float offset of this matrix's slabs in the workspace
-};
-
-struct GemvArgs
-{
-    GemvMat mat[GEMV_MAX_MATS];
-    const half_t* A;       // [m][k] (already offset to the first row of this pass)
-    float* workspace;
-    int num_mats;
-    int m;                 // rows in this pass (1..16)
-    int k;
-    int S;                 // k-slices
-    int kslice;            // elements per slice (multiple of 128)
-    int c_fp32;
-    int64_t c_row_offset;  // first output row of this pass
-};
 
 // ---- per-lane trellis words for one 8-weight group ------------------------------------------------
 
@@ -441,6 +414,21 @@ void exl3_gemv_reduce_kernel(const GemvArgs a, int total_colblocks)
 // ------------------------------------------------------------------------------------------------
 
 static int g_gemv_variant = -1;      // -1: read EXL3_HIP_GEMV_VARIANT (default 1 = FAST)
+static int g_gemv_gen = -1;          // -1: read EXL3_HIP_GEMV_GEN (default 2)
+
+static int gemv_gen()
+{
+    if (g_gemv_gen < 0)
+    {
+        const char* e = getenv("EXL3_HIP_GEMV_GEN");
+        g_gemv_gen = e ? atoi(e) : 2;
+        if (g_gemv_gen != 1) g_gemv_gen = 2;
+    }
+    return g_gemv_gen;
+}
+
+extern "C" int exl3_set_gemv_gen(int v) { g_gemv_gen = (v == 1) ? 1 : 2; return EXL3_OK; }
+
 
 static int gemv_variant()
 {
@@ -462,27 +450,31 @@ static void launch_gemv(int var, dim3 grid, size_t lds, hipStream_t st, const Ge
     else          exl3_gemv_kernel<K, CB, 1><<<grid, dim3(GEMV_THREADS), lds, st>>>(args);
 }
 
-static int choose_split(int total_colblocks, int k, int m, int num_cus, int force_split)
+static int choose_split(int gen, int total_colblocks, int k, int m, int num_cus, int force_split)
 {
     const int nb = k / 128;
     int S;
     if (force_split > 0) S = force_split;
     else
     {
-        // aim for >= 4 workgroups per CU in flight, but keep >= 2 Hadamard blocks (256 k) per slice
+        // aim for >= 4 workgroups per CU in flight
         int target = 4 * num_cus;
         S = (target + total_colblocks - 1) / total_colblocks;
-        int maxS = nb / 2; if (maxS < 1) maxS = 1;
+        // gen 1: >= 2 Hadamard blocks per slice; gen 2: >= 4 (one per wave)
+        int maxS = nb / (gen == 2 ? 4 : 2); if (maxS < 1) maxS = 1;
         if (S > maxS) S = maxS;
         if (S < 1) S = 1;
     }
     if (S > nb) S = nb;
-    // LDS limit for the activation fragments: kslice * m * 2 bytes <= 64 KB
     int blocks_per_slice = (nb + S - 1) / S;
-    while ((size_t) blocks_per_slice * 128 * m * 2 > 65536 && blocks_per_slice > 1)
+    if (gen == 1)
     {
-        S++;
-        blocks_per_slice = (nb + S - 1) / S;
+        // LDS limit for the activation fragments: kslice * m * 2 bytes <= 64 KB
+        while ((size_t) blocks_per_slice * 128 * m * 2 > 65536 && blocks_per_slice > 1)
+        {
+            S++;
+            blocks_per_slice = (nb + S - 1) / S;
+        }
     }
     // normalise S so that no slice is empty
     S = (nb + blocks_per_slice - 1) / blocks_per_slice;
@@ -515,7 +507,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         const int mp = (m - m0) < 16 ? (m - m0) : 16;
         GemvArgs args;
         memset((void*) &args, 0, sizeof(args));
-        const int S = choose_split(total_cb, k, mp, ctx->num_cus, force_split);
+        const int gen = gemv_gen();
+        const int S = choose_split(gen, total_cb, k, mp, ctx->num_cus, force_split);
         const int nb = k / 128;
         const int bps = (nb + S - 1) / S;
         int cbf = 0; int64_t wso = 0;
@@ -543,16 +536,35 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         args.c_fp32 = c_fp32;
         args.c_row_offset = m0;
 
-        size_t lds_frag = (size_t) bps * 128 * mp * 2 + 64 + 16;
-        size_t lds_part = (size_t) 16 * 128 * 4;
-        size_t lds = lds_frag > lds_part ? lds_frag : lds_part;
         dim3 grid((unsigned) (total_cb * S));
-        switch (K * 3 + cb)
+        if (gen == 2)
         {
-            #define GC(KK, CC) case KK * 3 + CC: launch_gemv<KK, CC>(var, grid, lds, st, args); break;
-            GC(1,0) GC(1,1) GC(1,2) GC(2,0) GC(2,1) GC(2,2) GC(3,0) GC(3,1) GC(3,2) GC(4,0) GC(4,1) GC(4,2)
-            GC(5,0) GC(5,1) GC(5,2) GC(6,0) GC(6,1) GC(6,2) GC(7,0) GC(7,1) GC(7,2) GC(8,0) GC(8,1) GC(8,2)
-            #undef GC
+            const int ng = mp <= 4 ? 1 : (mp <= 8 ? 2 : 4);
+            const size_t lds = exl3_gemv2_lds_bytes(ng, var, cb);
+            switch (K)
+            {
+                case 1: exl3_gemv2_launch_k1(cb, var, ng, grid, lds, st, args); break;
+                case 2: exl3_gemv2_launch_k2(cb, var, ng, grid, lds, st, args); break;
+                case 3: exl3_gemv2_launch_k3(cb, var, ng, grid, lds, st, args); break;
+                case 4: exl3_gemv2_launch_k4(cb, var, ng, grid, lds, st, args); break;
+                case 5: exl3_gemv2_launch_k5(cb, var, ng, grid, lds, st, args); break;
+                case 6: exl3_gemv2_launch_k6(cb, var, ng, grid, lds, st, args); break;
+                case 7: exl3_gemv2_launch_k7(cb, var, ng, grid, lds, st, args); break;
+                case 8: exl3_gemv2_launch_k8(cb, var, ng, grid, lds, st, args); break;
+            }
+        }
+        else
+        {
+            size_t lds_frag = (size_t) bps * 128 * mp * 2 + 64 + 16;
+            size_t lds_part = (size_t) 16 * 128 * 4;
+            size_t lds = lds_frag > lds_part ? lds_frag : lds_part;
+            switch (K * 3 + cb)
+            {
+                #define GC(KK, CC) case KK * 3 + CC: launch_gemv<KK, CC>(var, grid, lds, st, args); break;
+                GC(1,0) GC(1,1) GC(1,2) GC(2,0) GC(2,1) GC(2,2) GC(3,0) GC(3,1) GC(3,2) GC(4,0) GC(4,1) GC(4,2)
+                GC(5,0) GC(5,1) GC(5,2) GC(6,0) GC(6,1) GC(6,2) GC(7,0) GC(7,1) GC(7,2) GC(8,0) GC(8,1) GC(8,2)
+                #undef GC
+            }
         }
         int rc = exl3_check_launch("exl3_gemv");
         if (rc) return rc;

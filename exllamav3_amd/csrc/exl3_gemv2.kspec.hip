@@ -1,0 +1,410 @@
+// EXL3 quantized GEMV / small-m GEMM for gfx950, kernel generation 2 ("column-pair per lane").
+//
+//   C = ((A * suh) H) @ dequant(B) H * svh (+ bias)        reference: quant/exl3_gemv_kernel.cuh:138-402,
+//                                                          quant/exl3_gemm_kernel.cuh:8-80 (semantics only)
+//
+// Data-layout observation that drives the design: in the EXL3 tile bitstream the 32 weights with stream
+// indices [32c, 32c+32) are exactly columns c and c+8 of the 16x16 tile (all 16 rows of each), and they occupy
+// exactly K consecutive, word-aligned u32 words (words [cK, cK+K) of the tile).  So if lane (8T + c) of a wave
+// loads K consecutive words at word offset (8T + c) * K of a tile row, then
+//   * the wave's load is ONE fully contiguous 256*K-byte run (K = 4: a 1 KiB global_load_dwordx4),
+//   * the lane owns two complete output columns (16T + c, 16T + c + 8) of the 128-column block for 16 k-rows,
+//   * every bit-window shift is a compile-time constant for every K in 1..8 (one alignbit/bfe per weight),
+//   * the only cross-lane traffic is the previous lane's last word (16 - K carry-in bits of the trellis state).
+// A wave therefore owns a whole 128-column output block (= one output Hadamard block) and walks down k.
+//
+// MAC: v_mfma_f32_4x4x4_16B_f16 with A-broadcast (cbsz = 4): the instruction computes, for every lane j of the
+// wave, D[0..3][j] += sum_{k<4} A[0..3][k] * B[k][j] where B[.][j] is lane j's own 4 halves and A comes from
+// lanes 4*abid .. 4*abid+3.  That is a per-lane dot product against up to 4 activation rows -- exactly a GEMV with
+// per-lane columns, on the matrix pipe, with no cross-lane reduction at all.  Rows 4..15 use abid = 1..3.
+//
+// Workgroup = 4 waves = one column block x one k-slice; the waves split the slice, reduce through LDS, and the
+// output Hadamard runs in the epilogue (S == 1) or in the split-k reduce kernel (S > 1, exl3_gemv.hip).
+// The input Hadamard of each 128-block of x is computed by the wave that consumes it, just in time, into a
+// wave-private double-buffered LDS fragment store (no workgroup barrier in the main loop).
+#include "exl3_common.cuh"
+#include "exl3_api_internal.h"
+#include "exl3_gemv_args.h"
+
+#include <type_traits>
+#define G2_PF 4
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// ---- compile-time bit-window extraction ----------------------------------------------------------------
+// Wx[0] = previous lane's last word (carry-in), Wx[1..K] = the lane's K words.  Weight t (0..31): window of 16 bits
+// ending at extended-stream bit 32 + (t+1)K.
+template <int K, int T>
+__device__ __forceinline__ uint32_t lane_state(const uint32_t (&Wx)[K + 1])
+{
+    constexpr int e = 32 + (T + 1) * K;          // exclusive end, 33..288
+    constexpr int lo = (e - 1) >> 5;
+    constexpr int hi = (e - 16) >> 5;
+    constexpr int sh = 32 * (lo + 1) - e;        // 0..31
+    if constexpr (hi == lo)
+    {
+        if constexpr (sh == 0) return Wx[lo] & 0xffffu;
+        else if constexpr (sh == 16) return Wx[lo] >> 16;
+        else return __builtin_amdgcn_ubfe(Wx[lo], sh, 16);
+    }
+    else return __builtin_amdgcn_alignbit(Wx[hi], Wx[lo], sh) & 0xffffu;
+}
+
+__device__ __forceinline__ half4_t u2_as_half4(uint32_t a, uint32_t b)
+{
+    union { uint32_t u[2]; half4_t h; } c; c.u[0] = a; c.u[1] = b; return c.h;
+}
+
+// Decode the 4 weights T0..T0+3 into MFMA B operands.  out[0] (and out[1] for SPLIT) are half4 operands.
+template <int K, int CB, int VAR, int T0>
+__device__ __forceinline__ void decode_quad(const uint32_t (&Wx)[K + 1], half4_t (&out)[2])
+{
+    uint32_t x0 = cb_product<CB>(lane_state<K, T0 + 0>(Wx));
+    uint32_t x1 = cb_product<CB>(lane_state<K, T0 + 1>(Wx));
+    uint32_t x2 = cb_product<CB>(lane_state<K, T0 + 2>(Wx));
+    uint32_t x3 = cb_product<CB>(lane_state<K, T0 + 3>(Wx));
+    if constexpr (CB != EXL3_CB_MUL1)
+    {
+        x0 = cb_mask3inst(x0); x1 = cb_mask3inst(x1); x2 = cb_mask3inst(x2); x3 = cb_mask3inst(x3);
+        if constexpr (VAR == 1) { out[0] = u2_as_half4(x0, x1); out[1] = u2_as_half4(x2, x3); }
+        else
+        {
+            half2_t s01 = u32_as_half2(__builtin_amdgcn_perm(x1, x0, 0x05040100u)) + u32_as_half2(__builtin_amdgcn_perm(x1, x0, 0x07060302u));
+            half2_t s23 = u32_as_half2(__builtin_amdgcn_perm(x3, x2, 0x05040100u)) + u32_as_half2(__builtin_amdgcn_perm(x3, x2, 0x07060302u));
+            out[0] = u2_as_half4(half2_as_u32(s01), half2_as_u32(s23));
+        }
+    }
+    else
+    {
+        uint32_t h01 = __builtin_amdgcn_sad_hi_u8(x1, 0u, __builtin_amdgcn_sad_u8(x0, 0u, 0x64006400u));
+        uint32_t h23 = __builtin_amdgcn_sad_hi_u8(x3, 0u, __builtin_amdgcn_sad_u8(x2, 0u, 0x64006400u));
+        if constexpr (VAR == 1) out[0] = u2_as_half4(h01, h23);
+        else
+        {
+            const half2_t kinv = { u16_as_half(0x1eeeu), u16_as_half(0x1eeeu) };
+            const half2_t kbias = { u16_as_half(0xc931u), u16_as_half(0xc931u) };
+            half2_t ra, rb;
+            asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(ra) : "v"(u32_as_half2(h01)), "v"(kinv), "v"(kbias));
+            asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(rb) : "v"(u32_as_half2(h23)), "v"(kinv), "v"(kbias));
+            out[0] = u2_as_half4(half2_as_u32(ra), half2_as_u32(rb));
+        }
+    }
+}
+
+template <int K> struct LaneWords { uint32_t w[K]; };
+
+template <int K>
+__device__ __forceinline__ void load_lane_words(LaneWords<K>& d, const uint32_t* __restrict__ p)
+{
+    // p = this lane's first word of the tile row; K consecutive words (contiguous across the wave)
+    if constexpr (K == 4) { uint4_t v = __builtin_nontemporal_load((const uint4_t*) p); d.w[0] = v.x; d.w[1] = v.y; d.w[2] = v.z; d.w[3] = v.w; }
+    else if constexpr (K == 8)
+    {
+        uint4_t v = __builtin_nontemporal_load((const uint4_t*) p), u = __builtin_nontemporal_load((const uint4_t*) p + 1);
+        d.w[0] = v.x; d.w[1] = v.y; d.w[2] = v.z; d.w[3] = v.w; d.w[4] = u.x; d.w[5] = u.y; d.w[6] = u.z; d.w[7] = u.w;
+    }
+    else if constexpr (K == 2) { uint2_t v = __builtin_nontemporal_load((const uint2_t*) p); d.w[0] = v.x; d.w[1] = v.y; }
+    else
+    {
+        #pragma unroll
+        for (int i = 0; i < K; ++i) d.w[i] = __builtin_nontemporal_load(p + i);
+    }
+}
+
+template <int K, int CB, int VAR, int NG>
+__global__ __launch_bounds__(GEMV_THREADS)
+void exl3_gemv2_kernel(const GemvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool SPLIT = (VAR == 1) && (CB != EXL3_CB_MUL1);
+    constexpr bool RAW = (VAR == 1) && (CB == EXL3_CB_MUL1);
+    constexpr int MR = 4 * NG;                       // activation rows held by the A operand
+    constexpr int AH = SPLIT ? 32 : 16;              // halves per (tile row, activation row)
+    constexpr int NW = 8 * K;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int m = a.m;
+
+    const int s = blockIdx.x % a.S;
+    const int cbg = blockIdx.x / a.S;
+    int mi = 0;
+    #pragma unroll
+    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.num_mats && cbg >= a.mat[i].cb_first) mi = i;
+    const uint32_t* __restrict__ Bm = a.mat[mi].B;
+    const half_t* __restrict__ suh = a.mat[mi].suh;
+    const int n = a.mat[mi].n;
+    const int cbl = cbg - a.mat[mi].cb_first;
+    const int tiles_n = n >> 4;
+    const int k0s = s * a.kslice;
+    const int k1s = min(k0s + a.kslice, a.k);
+    const int nb = (k1s - k0s) >> 7;                 // 128-blocks in the workgroup's slice
+    const int b0 = (nb * wave) >> 2, b1 = (nb * (wave + 1)) >> 2;
+    const int nbw = b1 - b0;                         // blocks of this wave (may be 0)
+    const int k0 = k0s + 128 * b0;
+
+    // LDS carve: per-wave fragment double buffer | per-wave row sums | partials [4][MR][128]
+    constexpr int FRAG_HALVES = 2 * 8 * MR * AH;
+    half_t* xa = (half_t*) smem + (size_t) wave * FRAG_HALVES;
+    float* part = (float*) (smem + (size_t) 4 * FRAG_HALVES * 2);
+
+    // ---- just-in-time input Hadamard of one 128-block into fragment buffer `buf`
+    float rowsum[2 * NG];
+    #pragma unroll
+    for (int i = 0; i < 2 * NG; ++i) rowsum[i] = 0.0f;
+    const int l32 = lane & 31, hw = lane >> 5;
+    auto prep_block = [&] (int blk, int buf)
+    {
+        #pragma unroll
+        for (int p = 0; p < 2 * NG; ++p)
+        {
+            const int row = 2 * p + hw;
+            if (2 * p >= m) break;                                      // wave-uniform
+            const bool act = row < m;
+            const size_t off = (size_t) (act ? row : 0) * a.k + k0 + 128 * blk;
+            half4_t xv = ((const half4_t*) (a.A + off))[l32];
+            half4_t sv = ((const half4_t*) (suh + k0 + 128 * blk))[l32];
+            xv = xv * sv;
+            float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
+            had128_f32x4(h0, h1, h2, h3, l32);
+            half2_t o01 = { (half_t) (h0 * HAD_R_SCALE_128), (half_t) (h1 * HAD_R_SCALE_128) };
+            half2_t o23 = { (half_t) (h2 * HAD_R_SCALE_128), (half_t) (h3 * HAD_R_SCALE_128) };
+            if constexpr (RAW)
+            {
+                float t = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
+                #pragma unroll
+                for (int i = 1; i < 32; i <<= 1) t += __shfl_xor(t, i, 64);
+                if (act) rowsum[p] += t;
+            }
+            if (act)
+            {
+                // elements 4*l32 .. +3 of the block: tile row r8 = l32 >> 2, rows 4*(l32&3) .. +3 of the tile
+                const int r8 = l32 >> 2;
+                const int q0 = 2 * (l32 & 1);
+                const int sp = (l32 >> 1) & 1;                          // slot pair: rows {2q,2q+1} (0) or {2q+8,2q+9} (1)
+                half_t* base = xa + ((size_t) (buf * 8 + r8) * MR + row) * AH;
+                if constexpr (SPLIT)
+                {
+                    half4_t d01 = { o01.x, o01.x, o01.y, o01.y }, d23 = { o23.x, o23.x, o23.y, o23.y };
+                    *((half4_t*) (base + q0 * 8 + sp * 4)) = d01;
+                    *((half4_t*) (base + (q0 + 1) * 8 + sp * 4)) = d23;
+                }
+                else
+                {
+                    *((half2_t*) (base + q0 * 4 + sp * 2)) = o01;
+                    *((half2_t*) (base + (q0 + 1) * 4 + sp * 2)) = o23;
+                }
+            }
+        }
+    };
+
+    // ---- streaming state
+    const int T = lane >> 3, c = lane & 7;
+    const uint32_t* __restrict__ strip = Bm + ((size_t) (k0 >> 4) * tiles_n + (size_t) cbl * 8) * NW + (size_t) lane * K;
+    const size_t row_stride = (size_t) tiles_n * NW;
+    const int nrows = nbw * 8;
+    const int last_row = nrows > 0 ? nrows - 1 : 0;
+    const int prev_lane_addr = ((lane & ~7) | ((lane - 1) & 7)) << 2;   // ds_bpermute byte address
+    const half_t* arow = xa + (size_t) (lane & 15) * AH;                 // this lane's A row (rows >= m: garbage rows, ignored)
+
+    float4_t acc_c[NG], acc_d[NG];
+    #pragma unroll
+    for (int gq = 0; gq < NG; ++gq) { acc_c[gq] = float4_t{ 0.f, 0.f, 0.f, 0.f }; acc_d[gq] = float4_t{ 0.f, 0.f, 0.f, 0.f }; }
+
+    LaneWords<K> ring[G2_PF];
+    if (nbw > 0)
+    {
+        #pragma unroll
+        for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(u, last_row) * row_stride);
+    }
+
+    for (int blk = 0; blk < nbw; ++blk)
+    {
+        const int buf = blk & 1;
+        prep_block(blk, buf);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // wave-private LDS: in-order queue + drain
+        __builtin_amdgcn_wave_barrier();
+
+        #pragma unroll
+        for (int r = 0; r < 8; ++r)
+        {
+            const int u = r % G2_PF;
+            const int row = blk * 8 + r;
+
+            uint32_t Wx[K + 1];
+            #pragma unroll
+            for (int i = 0; i < K; ++i) Wx[i + 1] = ring[u].w[i];
+            Wx[0] = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) ring[u].w[K - 1]);
+
+            // refill the slot
+            load_lane_words<K>(ring[u], strip + (size_t) min(row + G2_PF, last_row) * row_stride);
+
+            // A fragments of this tile row for this lane's activation row
+            const half_t* ap = arow + (size_t) (buf * 8 + r) * MR * AH;
+            half8_t af[AH / 8];
+            #pragma unroll
+            for (int i = 0; i < AH / 8; ++i) af[i] = ((const half8_t*) ap)[i];
+
+            static_for<0, 4>([&] (auto qc)
+            {
+                constexpr int q = decltype(qc)::value;
+                half4_t bc[2], bd[2];
+                // weights 8q..8q+3 -> column c ; 8q+4..8q+7 -> column c + 8
+                decode_quad<K, CB, VAR, 8 * q>(Wx, bc);
+                decode_quad<K, CB, VAR, 8 * q + 4>(Wx, bd);
+                if constexpr (SPLIT)
+                {
+                    half8_t f = af[q];
+                    half4_t a0 = { f[0], f[1], f[2], f[3] }, a1 = { f[4], f[5], f[6], f[7] };
+                    static_for<0, NG>([&] (auto gc)
+                    {
+                        constexpr int gq = decltype(gc)::value;
+                        acc_c[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bc[0], acc_c[gq], 4, gq, 0);
+                        acc_c[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, bc[1], acc_c[gq], 4, gq, 0);
+                        acc_d[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bd[0], acc_d[gq], 4, gq, 0);
+                        acc_d[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, bd[1], acc_d[gq], 4, gq, 0);
+                    });
+                }
+                else
+                {
+                    half8_t f = af[q >> 1];
+                    half4_t a0 = (q & 1) ? half4_t{ f[4], f[5], f[6], f[7] } : half4_t{ f[0], f[1], f[2], f[3] };
+                    static_for<0, NG>([&] (auto gc)
+                    {
+                        constexpr int gq = decltype(gc)::value;
+                        acc_c[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bc[0], acc_c[gq], 4, gq, 0);
+                        acc_d[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bd[0], acc_d[gq], 4, gq, 0);
+                    });
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);      // keep the refill loads of different steps in program order
+        }
+    }
+
+    // ---- epilogue: per-wave partials -> LDS, cross-wave sum, output Hadamard
+    if constexpr (RAW)
+    {
+        // row sums live in lane 0 / lane 32 of the wave (rows 2p / 2p+1): publish through the partial area
+        float* sx = part + (size_t) 4 * MR * 128 + wave * MR;
+        #pragma unroll
+        for (int p = 0; p < 2 * NG; ++p) if (l32 == 0 && 2 * p + hw < MR) sx[2 * p + hw] = rowsum[p];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const float kinv = (float) u16_as_half(0x1eeeu), kbias = (float) u16_as_half(0xc931u);
+        #pragma unroll
+        for (int gq = 0; gq < NG; ++gq)
+        {
+            #pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                float sxv = sx[4 * gq + i];
+                acc_c[gq][i] = acc_c[gq][i] * kinv + kbias * sxv;
+                acc_d[gq][i] = acc_d[gq][i] * kinv + kbias * sxv;
+            }
+        }
+    }
+    {
+        float* pw = part + (size_t) wave * MR * 128;
+        const int col = 16 * T + c;
+        #pragma unroll
+        for (int gq = 0; gq < NG; ++gq)
+        {
+            #pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                const int row = 4 * gq + i;
+                if (row < m) { pw[row * 128 + col] = acc_c[gq][i]; pw[row * 128 + col + 8] = acc_d[gq][i]; }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int l = tid & 31, hw8 = tid >> 5;
+    const size_t wstride = (size_t) MR * 128;
+    if (a.S > 1)
+    {
+        float* slab = a.workspace + a.mat[mi].ws_offset + ((size_t) cbl * a.S + s) * (size_t) m * 128;
+        for (int row = hw8; row < m; row += 8)
+        {
+            const float* p0 = part + row * 128;
+            float4_t v0 = ((const float4_t*) p0)[l], v1 = ((const float4_t*) (p0 + wstride))[l];
+            float4_t v2 = ((const float4_t*) (p0 + 2 * wstride))[l], v3 = ((const float4_t*) (p0 + 3 * wstride))[l];
+            float4_t v = { (v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y), (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w) };
+            ((float4_t*) (slab + row * 128))[l] = v;
+        }
+        return;
+    }
+
+    const half_t* svh = a.mat[mi].svh + cbl * 128;
+    const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
+    for (int base = 0; base < m; base += 8)
+    {
+        int row = base + hw8;
+        bool act = row < m;
+        const float* p0 = part + (act ? row : 0) * 128;
+        float4_t v0 = ((const float4_t*) p0)[l], v1 = ((const float4_t*) (p0 + wstride))[l];
+        float4_t v2 = ((const float4_t*) (p0 + 2 * wstride))[l], v3 = ((const float4_t*) (p0 + 3 * wstride))[l];
+        float h0 = (v0.x + v1.x) + (v2.x + v3.x), h1 = (v0.y + v1.y) + (v2.y + v3.y);
+        float h2 = (v0.z + v1.z) + (v2.z + v3.z), h3 = (v0.w + v1.w) + (v2.w + v3.w);
+        had128_f32x4(h0, h1, h2, h3, l);
+        h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
+        if (!act) continue;
+        half4_t sc = ((const half4_t*) svh)[l];
+        size_t off = ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
+        if (a.c_fp32)
+        {
+            float4_t o = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
+            if (bias) { half4_t bv = ((const half4_t*) bias)[l]; o.x += (float) bv.x; o.y += (float) bv.y; o.z += (float) bv.z; o.w += (float) bv.w; }
+            *((float4_t*) ((float*) a.mat[mi].C + off)) = o;
+        }
+        else
+        {
+            half4_t o = { (half_t) h0, (half_t) h1, (half_t) h2, (half_t) h3 };
+            o = o * sc;
+            if (bias) o = o + ((const half4_t*) bias)[l];
+            *((half4_t*) ((half_t*) a.mat[mi].C + off)) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch (called from exl3_gemv.hip's dispatcher).  One translation unit per K: built with -DG2_K=1..8.
+// ------------------------------------------------------------------------------------------------
+#ifndef G2_K
+#error "compile with -DG2_K=<bits per weight>"
+#endif
+
+template <int CB>
+static void launch_cb(int var, int ng, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+{
+    #define L(V, N) exl3_gemv2_kernel<G2_K, CB, V, N><<<grid, dim3(GEMV_THREADS), lds, st>>>(args)
+    if (var == 0) { if (ng == 1) L(0, 1); else if (ng == 2) L(0, 2); else L(0, 4); }
+    else          { if (ng == 1) L(1, 1); else if (ng == 2) L(1, 2); else L(1, 4); }
+    #undef L
+}
+
+#define G2_CAT_(a, b) a##b
+#define G2_CAT(a, b) G2_CAT_(a, b)
+
+void G2_CAT(exl3_gemv2_launch_k, G2_K)(int cb, int var, int ng, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+{
+    if (cb == 0) launch_cb<0>(var, ng, grid, lds, st, args);
+    else if (cb == 1) launch_cb<1>(var, ng, grid, lds, st, args);
+    else launch_cb<2>(var, ng, grid, lds, st, args);
+}
+
+#if G2_K == 4
+size_t exl3_gemv2_lds_bytes(int ng, int var, int cb)
+{
+    const int MR = 4 * ng;
+    const int AH = (var == 1 && cb != 2) ? 32 : 16;
+    size_t frag = (size_t) 4 * (2 * 8 * MR * AH) * 2;
+    size_t part = (size_t) 4 * MR * 128 * 4 + (size_t) 4 * MR * 4;
+    return frag + part;
+}
+#endif

@@ -1,0 +1,38 @@
+// Kernel-argument block shared by the GEMV kernel generations.
+#pragma once
+#include "exl3_common.cuh"
+
+#define GEMV_THREADS 256
+#define GEMV_MAX_MATS 4
+
+struct GemvMat
+{
+    const uint32_t* B;
+    const half_t* suh;
+    const half_t* svh;
+    const half_t* bias;
+    void* C;
+    int n;
+    int cb_first;          // first column block of this matrix in the flattened grid
+    int ws_offset;         // float offset of this matrix's slabs in the workspace
+};
+
+struct GemvArgs
+{
+    GemvMat mat[GEMV_MAX_MATS];
+    const half_t* A;       // [m][k] (already offset to the first row of this pass)
+    float* workspace;
+    int num_mats;
+    int m;                 // rows in this pass (1..16)
+    int k;
+    int S;                 // k-slices
+    int kslice;            // elements per slice (multiple of 128)
+    int c_fp32;
+    int64_t c_row_offset;  // first output row of this pass
+};
+
+// generation-2 kernels: one translation unit per K (exl3_gemv2.kspec.hip compiled with -DG2_K=1..8)
+size_t exl3_gemv2_lds_bytes(int ng, int var, int cb);
+#define G2_DECL(KK) void exl3_gemv2_launch_k##KK(int cb, int var, int ng, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args);
+G2_DECL(1) G2_DECL(2) G2_DECL(3) G2_DECL(4) G2_DECL(5) G2_DECL(6) G2_DECL(7) G2_DECL(8)
+#undef G2_DECL

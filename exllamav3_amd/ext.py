@@ -68,6 +68,11 @@ def set_gemv_variant(v: int):
     _lib.lib().exl3_set_gemv_variant(int(v))
 
 
+def set_gemv_gen(g: int):
+    """1 = 16x16x32-MFMA kernel (exl3_gemv.hip), 2 = column-pair-per-lane kernel (exl3_gemv2.kspec.hip, default)."""
+    _lib.lib().exl3_set_gemv_gen(int(g))
+
+
 # --------------------------------------------------------------------------------------------------
 # format ops
 # --------------------------------------------------------------------------------------------------

@@ -88,6 +88,12 @@ int exl3_gemm(const void* A, const void* B, void* C, const void* suh, const void
 int exl3_mgemm(const void* A, const void* const* Bs, void* const* Cs, const void* const* suhs, const void* const* svhs,
                const int* ns, int count, int m, int k, int K, int cb, int c_fp32, int force_split, void* stream);
 
+/* Tuning hooks (no reference equivalent; the reference's knobs are env vars EXL3_GEMV / EXL3_GEMV_SMEM, doc/env_vars.md):
+ * variant 0 = EXACT (reference fp16 weights bit-for-bit into the MFMA), 1 = FAST (default; see exl3_gemv2.kspec.hip);
+ * gen 1 = 16x16x32-MFMA kernel, 2 = column-pair-per-lane kernel (default). */
+int exl3_set_gemv_variant(int variant);
+int exl3_set_gemv_gen(int gen);
+
 /* hgemm(a, b, c)      hgemm.cu:19-102:  c[m][n] (row stride ldc elements, fp16 or fp32) = a[m][k] @ b[k][n], fp32 accumulate.
  * m, k, n arbitrary multiples of 16/32/16. */
 int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, void* stream);

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--K", default="4")
     ap.add_argument("--splits", default="0")
     ap.add_argument("--shapes", default="")
+    ap.add_argument("--gens", default="2")
+    ap.add_argument("--eager", action="store_true", help="time eager launches (host-bound for small kernels) instead of a hipGraph")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     ext.init(0)
@@ -47,21 +49,33 @@ def main():
                 x = torch.randn((m, k), generator=gen).half().to(dev)
                 y = torch.empty((m, n), dtype=torch.half, device=dev)
                 for cb in [int(v) for v in args.cbs.split(",")]:
+                  for gen in [int(v) for v in args.gens.split(",")]:
                     for var in [int(v) for v in args.variants.split(",")]:
                         for split in [int(v) for v in args.splits.split(",")]:
                             ext.set_gemv_variant(var)
-                            for i in range(warm):
-                                ext.exl3_gemm(x, trs[i % copies], y, suh, None, svh, -1, cb == 1, cb == 2, 0, force_split=split)
+                            ext.set_gemv_gen(gen)
+
+                            def body(count):
+                                for i in range(count):
+                                    ext.exl3_gemm(x, trs[i % copies], y, suh, None, svh, -1, cb == 1, cb == 2, 0, force_split=split)
+                            body(warm)
                             torch.cuda.synchronize()
                             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                            for i in range(iters):
-                                ext.exl3_gemm(x, trs[i % copies], y, suh, None, svh, -1, cb == 1, cb == 2, 0, force_split=split)
-                            e1.record()
-                            torch.cuda.synchronize()
+                            if args.eager:
+                                e0.record(); body(iters); e1.record()
+                                torch.cuda.synchronize()
+                            else:
+                                st = torch.cuda.Stream()
+                                g = torch.cuda.CUDAGraph()
+                                with torch.cuda.stream(st):
+                                    with torch.cuda.graph(g, stream=st):
+                                        body(iters)
+                                g.replay(); torch.cuda.synchronize()
+                                e0.record(); g.replay(); e1.record()
+                                torch.cuda.synchronize()
                             us = e0.elapsed_time(e1) * 1e3 / iters
                             algo = wbytes + 2 * (k + n) + 2 * m * (k + n)
-                            print(json.dumps({"shape": name, "k": k, "n": n, "K": K, "m": m, "cb": cb, "variant": var, "split": split,
+                            print(json.dumps({"shape": name, "k": k, "n": n, "K": K, "m": m, "cb": cb, "gen": gen, "variant": var, "split": split,
                                               "us": round(us, 2), "GBps": round(algo / us / 1e3, 1),
                                               "frac_of_8TBps": round(algo / us / 1e3 / 8000, 3)}), flush=True)
             del trs
