@@ -66,9 +66,7 @@ __device__ __forceinline__ half_t decode_exact(uint32_t s)
         x = cb_mask3inst(x);
         half_t lo = u16_as_half(x & 0xffffu);
         half_t hi = u16_as_half(x >> 16);
-        half_t r;
-        asm volatile("v_add_f16 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-        return r;
+        return lo + hi;                                   // v_add_f16, one RN rounding
     }
     else
     {
@@ -76,9 +74,7 @@ __device__ __forceinline__ half_t decode_exact(uint32_t s)
         half_t h = u16_as_half(sum);
         half_t k_inv = u16_as_half(0x1eeeu);
         half_t k_bias = u16_as_half(0xc931u);
-        half_t r;
-        asm volatile("v_fma_f16 %0, %1, %2, %3" : "=v"(r) : "v"(h), "v"(k_inv), "v"(k_bias));
-        return r;
+        return __builtin_fmaf16(h, k_inv, k_bias);        // v_fma_f16, one RN rounding
     }
 }
 

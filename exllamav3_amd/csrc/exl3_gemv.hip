@@ -126,9 +126,8 @@ __device__ __forceinline__ void decode4(const uint32_t (&w)[3], int o, uint32_t 
             const half2_t kinv = { u16_as_half(0x1eeeu), u16_as_half(0x1eeeu) };
             const half2_t kbias = { u16_as_half(0xc931u), u16_as_half(0xc931u) };
             half2_t a = u32_as_half2(h01), b = u32_as_half2(h23);
-            half2_t ra, rb;
-            asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(ra) : "v"(a), "v"(kinv), "v"(kbias));
-            asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(rb) : "v"(b), "v"(kinv), "v"(kbias));
+            half2_t ra = __builtin_elementwise_fma(a, kinv, kbias);      // v_pk_fma_f16
+            half2_t rb = __builtin_elementwise_fma(b, kinv, kbias);
             out[0] = half2_as_u32(ra); out[1] = half2_as_u32(rb);
         }
         out[2] = 0; out[3] = 0;

@@ -87,9 +87,8 @@ __device__ __forceinline__ void decode_quad(const uint32_t (&Wx)[K + 1], half4_t
         {
             const half2_t kinv = { u16_as_half(0x1eeeu), u16_as_half(0x1eeeu) };
             const half2_t kbias = { u16_as_half(0xc931u), u16_as_half(0xc931u) };
-            half2_t ra, rb;
-            asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(ra) : "v"(u32_as_half2(h01)), "v"(kinv), "v"(kbias));
-            asm volatile("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(rb) : "v"(u32_as_half2(h23)), "v"(kinv), "v"(kbias));
+            half2_t ra = __builtin_elementwise_fma(u32_as_half2(h01), kinv, kbias);      // v_pk_fma_f16
+            half2_t rb = __builtin_elementwise_fma(u32_as_half2(h23), kinv, kbias);
             out[0] = u2_as_half4(half2_as_u32(ra), half2_as_u32(rb));
         }
     }

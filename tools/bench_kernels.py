@@ -49,11 +49,11 @@ def main():
                 x = torch.randn((m, k), generator=gen).half().to(dev)
                 y = torch.empty((m, n), dtype=torch.half, device=dev)
                 for cb in [int(v) for v in args.cbs.split(",")]:
-                  for gen in [int(v) for v in args.gens.split(",")]:
+                  for gg in [int(v) for v in args.gens.split(",")]:
                     for var in [int(v) for v in args.variants.split(",")]:
                         for split in [int(v) for v in args.splits.split(",")]:
                             ext.set_gemv_variant(var)
-                            ext.set_gemv_gen(gen)
+                            ext.set_gemv_gen(gg)
 
                             def body(count):
                                 for i in range(count):
@@ -75,7 +75,7 @@ def main():
                                 torch.cuda.synchronize()
                             us = e0.elapsed_time(e1) * 1e3 / iters
                             algo = wbytes + 2 * (k + n) + 2 * m * (k + n)
-                            print(json.dumps({"shape": name, "k": k, "n": n, "K": K, "m": m, "cb": cb, "gen": gen, "variant": var, "split": split,
+                            print(json.dumps({"shape": name, "k": k, "n": n, "K": K, "m": m, "cb": cb, "gen": gg, "variant": var, "split": split,
                                               "us": round(us, 2), "GBps": round(algo / us / 1e3, 1),
                                               "frac_of_8TBps": round(algo / us / 1e3 / 8000, 3)}), flush=True)
             del trs
