@@ -1,0 +1,81 @@
+// hgemm: c[m][n] = a[m][k] @ b[k][n], fp16 inputs, fp32 accumulate, fp16/fp32 output (optionally a column slice: ldc > n).
+// reference: exllamav3_ext/hgemm.cu:19-102 wraps cublasGemmEx; this is the same "plain library GEMM" role on ROCm, served
+// by hipBLASLt (MFMA kernels tuned for gfx950).  The fused dequant->LDS->MFMA prefill kernel replaces the
+// reconstruct + hgemm pair for EXL3 weights (exl3_gemm_prefill.hip); hgemm stays for the reference's op surface.
+#include "exl3_api_internal.h"
+#include <hipblaslt/hipblaslt.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#define HGEMM_WS_BYTES (64ll << 20)
+
+struct HgemmCtx
+{
+    bool ready = false;
+    hipblasLtHandle_t handle;
+    void* ws = nullptr;
+    std::map<std::tuple<int, int, int, int64_t, int>, hipblasLtMatmulAlgo_t> algos;
+};
+static HgemmCtx g_hctx[64];
+static std::mutex g_hmutex;
+
+#define CHECK_LT(expr, what) do { hipblasStatus_t s_ = (expr); if (s_ != HIPBLAS_STATUS_SUCCESS) { \
+    exl3_set_error("hgemm: %s failed (hipblasStatus %d)", what, (int) s_); return EXL3_ERR_HIP; } } while (0)
+
+extern "C" int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, void* stream)
+{
+    EXL3_CHECK_ARG(a && b && c, "hgemm: null pointer");
+    EXL3_CHECK_ARG(m >= 0 && k > 0 && n > 0 && ldc >= n, "hgemm: bad dimensions");
+    if (m == 0) return EXL3_OK;
+    int device = 0;
+    EXL3_CHECK_HIP(hipGetDevice(&device), "hipGetDevice");
+    std::lock_guard<std::mutex> lock(g_hmutex);
+    HgemmCtx& cx = g_hctx[device];
+    if (!cx.ready)
+    {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing((hipStream_t) stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+        {
+            exl3_set_error("hgemm: first call must happen outside graph capture");
+            return EXL3_ERR_INIT;
+        }
+        CHECK_LT(hipblasLtCreate(&cx.handle), "hipblasLtCreate");
+        EXL3_CHECK_HIP(hipMalloc(&cx.ws, HGEMM_WS_BYTES), "hipMalloc(hgemm workspace)");
+        cx.ready = true;
+    }
+
+    // row-major C[m,n] = A[m,k] B[k,n]   <=>   column-major C^T[n,m] = B^T[n,k] A^T[k,m]
+    hipblasLtMatmulDesc_t desc;
+    hipblasLtMatrixLayout_t la, lb, lc;
+    CHECK_LT(hipblasLtMatmulDescCreate(&desc, HIPBLAS_COMPUTE_32F, HIP_R_32F), "MatmulDescCreate");
+    hipblasOperation_t opn = HIPBLAS_OP_N;
+    CHECK_LT(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opn, sizeof(opn)), "set TRANSA");
+    CHECK_LT(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opn, sizeof(opn)), "set TRANSB");
+    CHECK_LT(hipblasLtMatrixLayoutCreate(&la, HIP_R_16F, n, k, n), "layout A");
+    CHECK_LT(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16F, k, m, k), "layout B");
+    CHECK_LT(hipblasLtMatrixLayoutCreate(&lc, c_fp32 ? HIP_R_32F : HIP_R_16F, n, m, ldc), "layout C");
+
+    auto key = std::make_tuple(m, k, n, ldc, c_fp32);
+    auto it = cx.algos.find(key);
+    if (it == cx.algos.end())
+    {
+        hipblasLtMatmulPreference_t pref;
+        CHECK_LT(hipblasLtMatmulPreferenceCreate(&pref), "PreferenceCreate");
+        size_t wsz = HGEMM_WS_BYTES;
+        CHECK_LT(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz)), "set workspace");
+        hipblasLtMatmulHeuristicResult_t res[1];
+        int found = 0;
+        CHECK_LT(hipblasLtMatmulAlgoGetHeuristic(cx.handle, desc, la, lb, lc, lc, pref, 1, res, &found), "AlgoGetHeuristic");
+        hipblasLtMatmulPreferenceDestroy(pref);
+        if (found < 1) { exl3_set_error("hgemm: no hipBLASLt algorithm for m=%d k=%d n=%d", m, k, n); return EXL3_ERR_HIP; }
+        it = cx.algos.emplace(key, res[0].algo).first;
+    }
+    const float alpha = 1.0f, beta = 0.0f;
+    hipblasStatus_t st = hipblasLtMatmul(cx.handle, desc, &alpha, b, la, a, lb, &beta, c, lc, c, lc, &it->second,
+                                         cx.ws, HGEMM_WS_BYTES, (hipStream_t) stream);
+    hipblasLtMatrixLayoutDestroy(la); hipblasLtMatrixLayoutDestroy(lb); hipblasLtMatrixLayoutDestroy(lc);
+    hipblasLtMatmulDescDestroy(desc);
+    if (st != HIPBLAS_STATUS_SUCCESS) { exl3_set_error("hgemm: hipblasLtMatmul failed (%d)", (int) st); return EXL3_ERR_HIP; }
+    return EXL3_OK;
+}

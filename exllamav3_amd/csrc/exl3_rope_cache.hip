@@ -1,0 +1,356 @@
+// RoPE (+ optional per-head RMSNorm) and KV-cache quantization for gfx950.
+// reference: exllamav3_ext/rope.cu:16-296 ; cache/q_cache_kernels.cuh:29-399, cache/q_cache.cu:19-434.
+// Both are tiny HBM-bound elementwise/pack kernels (a few KB per token): the design goal is few launches, wide
+// accesses and no LDS atomics, not FLOPs.
+#include "exl3_common.cuh"
+#include "exl3_api_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// RoPE.  One wave per (token, head); lane t owns rotation pair t (+ 64, + 128 ... for head_dim > 128).
+// NEOX pairs (t, t + d/2), GPTJ pairs (2t, 2t + 1).  Optional q/k head RMSNorm first, with the reference's
+// rounding points (normalised value rounded to fp16, multiplied by fp16 (w + bias) in fp16: rope.cu:199-233).
+// ------------------------------------------------------------------------------------------------
+#define ROPE_MAX_PAIRS_PER_LANE 4      // head_dim <= 512
+
+template <int MODE>     // 1 = GPTJ, 2 = NEOX
+__global__ __launch_bounds__(256)
+void rope_kernel(const half_t* __restrict__ q, half_t* __restrict__ out_q, const half_t* __restrict__ k, half_t* __restrict__ out_k,
+                 const float* __restrict__ inv_freq, int seq_len, int heads_q, int heads_k, int head_dim,
+                 uint32_t position, const int32_t* __restrict__ positions, const int32_t* __restrict__ position_ids,
+                 float attn_factor, const half_t* __restrict__ q_norm, const half_t* __restrict__ k_norm,
+                 float norm_eps, float norm_constant_bias)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int token = blockIdx.x, batch = blockIdx.y;
+    const int heads = heads_q + heads_k;
+    const int head = blockIdx.z * 4 + wave;
+    if (head >= heads) return;
+    const bool is_q = head < heads_q;
+    const int hi = is_q ? head : head - heads_q;
+    const int64_t tok = (int64_t) batch * seq_len + token;
+    const half_t* src = is_q ? q + (tok * heads_q + hi) * head_dim : k + (tok * heads_k + hi) * head_dim;
+    half_t* dst = is_q ? out_q + (tok * heads_q + hi) * head_dim : out_k + (tok * heads_k + hi) * head_dim;
+    const half_t* nw = is_q ? q_norm : k_norm;
+
+    int pos = token + (int) position;
+    if (positions) pos = token + positions[batch];
+    else if (position_ids) pos = position_ids[tok];
+    const float pf = (float) pos;
+
+    const int half_dim = head_dim >> 1;
+    float v1[ROPE_MAX_PAIRS_PER_LANE], v2[ROPE_MAX_PAIRS_PER_LANE];
+    float ss = 0.0f;
+    #pragma unroll
+    for (int i = 0; i < ROPE_MAX_PAIRS_PER_LANE; ++i)
+    {
+        int t = lane + 64 * i;
+        v1[i] = 0.f; v2[i] = 0.f;
+        if (t < half_dim)
+        {
+            int i1 = MODE == 2 ? t : 2 * t, i2 = MODE == 2 ? t + half_dim : 2 * t + 1;
+            v1[i] = (float) src[i1]; v2[i] = (float) src[i2];
+            ss += v1[i] * v1[i] + v2[i] * v2[i];
+        }
+    }
+    if (nw)
+    {
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float rmf = __frsqrt_rn(ss / (float) head_dim + norm_eps);
+        const half_t bias_h = (half_t) norm_constant_bias;
+        #pragma unroll
+        for (int i = 0; i < ROPE_MAX_PAIRS_PER_LANE; ++i)
+        {
+            int t = lane + 64 * i;
+            if (t < half_dim)
+            {
+                int i1 = MODE == 2 ? t : 2 * t, i2 = MODE == 2 ? t + half_dim : 2 * t + 1;
+                half_t w1 = nw[i1] + bias_h, w2 = nw[i2] + bias_h;
+                v1[i] = (float) (w1 * (half_t) (v1[i] * rmf));
+                v2[i] = (float) (w2 * (half_t) (v2[i] * rmf));
+            }
+        }
+    }
+    #pragma unroll
+    for (int i = 0; i < ROPE_MAX_PAIRS_PER_LANE; ++i)
+    {
+        int t = lane + 64 * i;
+        if (t < half_dim)
+        {
+            float sn, cs;
+            sincosf(inv_freq[t] * pf, &sn, &cs);
+            sn *= attn_factor; cs *= attn_factor;
+            int i1 = MODE == 2 ? t : 2 * t, i2 = MODE == 2 ? t + half_dim : 2 * t + 1;
+            dst[i1] = (half_t) (v1[i] * cs - v2[i] * sn);
+            dst[i2] = (half_t) (v2[i] * cs + v1[i] * sn);
+        }
+    }
+}
+
+extern "C" int exl3_rope(const void* q, void* out_q, const void* k, void* out_k, const float* inv_freq,
+                         int bsz, int seq_len, int heads_q, int heads_k, int head_dim,
+                         uint32_t position, const int32_t* positions, const int32_t* position_ids,
+                         int rope_mode, float attn_factor, const void* q_norm, const void* k_norm, float norm_eps,
+                         float norm_constant_bias, void* stream)
+{
+    EXL3_CHECK_ARG(q && out_q && inv_freq, "rope: null pointer");
+    EXL3_CHECK_ARG(heads_k == 0 || (k && out_k), "rope: k given without out_k");
+    EXL3_CHECK_ARG(head_dim % 2 == 0 && head_dim > 0 && head_dim <= 128 * ROPE_MAX_PAIRS_PER_LANE, "rope: head_dim must be even and <= 512");
+    EXL3_CHECK_ARG(rope_mode == 1 || rope_mode == 2, "rope: rope_mode must be 1 (GPTJ) or 2 (NEOX)");
+    if (bsz == 0 || seq_len == 0) return EXL3_OK;
+    dim3 grid(seq_len, bsz, (heads_q + heads_k + 3) / 4);
+    hipStream_t st = (hipStream_t) stream;
+    if (rope_mode == 2)
+        rope_kernel<2><<<grid, 256, 0, st>>>((const half_t*) q, (half_t*) out_q, (const half_t*) k, (half_t*) out_k, inv_freq, seq_len, heads_q, heads_k,
+                                             head_dim, position, positions, position_ids, attn_factor, (const half_t*) q_norm, (const half_t*) k_norm, norm_eps, norm_constant_bias);
+    else
+        rope_kernel<1><<<grid, 256, 0, st>>>((const half_t*) q, (half_t*) out_q, (const half_t*) k, (half_t*) out_k, inv_freq, seq_len, heads_q, heads_k,
+                                             head_dim, position, positions, position_ids, attn_factor, (const half_t*) q_norm, (const half_t*) k_norm, norm_eps, norm_constant_bias);
+    return exl3_check_launch("rope");
+}
+
+// ------------------------------------------------------------------------------------------------
+// KV-cache quantization: 32-value groups, H32 rotation, absmax scale, midpoint grid, power-of-two bit planes.
+// An 8-lane subgroup owns one group (4 consecutive values per lane), so a wave64 covers 8 groups (256 values).
+// H32 = in-register H4 x 3-round xor-shuffle H8 (same factorisation as q_cache_kernels.cuh:29-59).
+// Packing needs no LDS atomics: a plane of width w puts the lane's 4w-bit field at bit 4w*sl of the plane, the
+// 8/w lanes sharing a word OR-reduce with xor shuffles, and the first lane of each run stores the word.
+// ------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void kv_had32(float& v0, float& v1, float& v2, float& v3, int lane)
+{
+    float s0 = v0 + v1, d0 = v0 - v1, s1 = v2 + v3, d1 = v2 - v3;
+    v0 = s0 + s1; v1 = d0 + d1; v2 = s0 - s1; v3 = d0 - d1;
+    #pragma unroll
+    for (int i = 1; i < 8; i <<= 1)
+    {
+        float p0 = __shfl_xor(v0, i, 64), p1 = __shfl_xor(v1, i, 64), p2 = __shfl_xor(v2, i, 64), p3 = __shfl_xor(v3, i, 64);
+        bool neg = (lane & i) != 0;
+        v0 = (neg ? -v0 : v0) + p0; v1 = (neg ? -v1 : v1) + p1; v2 = (neg ? -v2 : v2) + p2; v3 = (neg ? -v3 : v3) + p3;
+    }
+}
+
+#define KV_R32 0.17677669529663688110f
+
+template <int W>
+__device__ __forceinline__ void kv_pack_plane(uint32_t* __restrict__ out, int word_base, int sl, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3, bool active)
+{
+    uint32_t field = f0 | (f1 << W) | (f2 << (2 * W)) | (f3 << (3 * W));
+    constexpr int LPW = 8 / W;                         // lanes per word
+    int off = sl * 4 * W;
+    uint32_t contrib = field << (off & 31);
+    #pragma unroll
+    for (int i = 1; i < LPW; i <<= 1) contrib |= (uint32_t) __shfl_xor((int) contrib, i, 64);
+    if (active && (sl % LPW) == 0) out[word_base + (off >> 5)] = contrib;
+}
+
+template <int BITS>
+__device__ __forceinline__ void kv_quant_group(const half_t* __restrict__ in, uint32_t* __restrict__ out, half_t* __restrict__ out_scale, bool active, int lane)
+{
+    constexpr float mf = (float) (1 << (BITS - 1));
+    constexpr int qmax = (1 << BITS) - 1;
+    const int sl = lane & 7;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (active)
+    {
+        half4_t x = ((const half4_t*) in)[sl];
+        v0 = (float) x.x; v1 = (float) x.y; v2 = (float) x.z; v3 = (float) x.w;
+    }
+    kv_had32(v0, v1, v2, v3, lane);
+    v0 *= KV_R32; v1 *= KV_R32; v2 *= KV_R32; v3 *= KV_R32;
+    float s = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) + 1e-10f;
+    #pragma unroll
+    for (int i = 1; i < 8; i <<= 1) s = fmaxf(s, __shfl_xor(s, i, 64));
+    const float inv_s = 1.0f / s;                      // IEEE division (the oracle's definition)
+    auto quant1 = [&] (float v) -> uint32_t
+    {
+        int qi = (int) floorf(__builtin_fmaf(v * inv_s, mf, mf));
+        return (uint32_t) max(min(qi, qmax), 0);
+    };
+    uint32_t q0 = quant1(v0), q1 = quant1(v1), q2 = quant1(v2), q3 = quant1(v3);
+    int rem = BITS, wb = 0;
+    if constexpr (BITS & 8) { rem -= 8; kv_pack_plane<8>(out, wb, sl, (q0 >> rem) & 255, (q1 >> rem) & 255, (q2 >> rem) & 255, (q3 >> rem) & 255, active); wb += 8; }
+    if constexpr (BITS & 4) { rem -= 4; kv_pack_plane<4>(out, wb, sl, (q0 >> rem) & 15, (q1 >> rem) & 15, (q2 >> rem) & 15, (q3 >> rem) & 15, active); wb += 4; }
+    if constexpr (BITS & 2) { rem -= 2; kv_pack_plane<2>(out, wb, sl, (q0 >> rem) & 3, (q1 >> rem) & 3, (q2 >> rem) & 3, (q3 >> rem) & 3, active); wb += 2; }
+    if constexpr (BITS & 1) { kv_pack_plane<1>(out, wb, sl, q0 & 1, q1 & 1, q2 & 1, q3 & 1, active); }
+    if (active && sl == 0) *out_scale = (half_t) s;
+}
+
+template <int BITS>
+__device__ __forceinline__ void kv_dequant_group(const uint32_t* __restrict__ in, const half_t* __restrict__ in_scale, half_t* __restrict__ out, bool active, int lane)
+{
+    constexpr int m = 1 << (BITS - 1);
+    constexpr float inv_mf = 1.0f / (float) m;
+    const int sl = lane & 7;
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    auto unpack_plane = [&] (int w, int word_base)
+    {
+        int off = sl * 4 * w;
+        uint32_t word = active ? (in[word_base + (off >> 5)] >> (off & 31)) : 0u;
+        uint32_t mask = (1u << w) - 1u;
+        q0 = (q0 << w) | (word & mask);
+        q1 = (q1 << w) | ((word >> w) & mask);
+        q2 = (q2 << w) | ((word >> (2 * w)) & mask);
+        q3 = (q3 << w) | ((word >> (3 * w)) & mask);
+    };
+    int wb = 0;
+    if constexpr (BITS & 8) { unpack_plane(8, wb); wb += 8; }
+    if constexpr (BITS & 4) { unpack_plane(4, wb); wb += 4; }
+    if constexpr (BITS & 2) { unpack_plane(2, wb); wb += 2; }
+    if constexpr (BITS & 1) { unpack_plane(1, wb); }
+    float s = active ? (float) *in_scale : 0.0f;
+    s *= KV_R32;
+    const float sm = s * inv_mf;
+    constexpr float mh = (float) m - 0.5f;
+    float v0 = ((float) (int) q0 - mh) * sm, v1 = ((float) (int) q1 - mh) * sm;
+    float v2 = ((float) (int) q2 - mh) * sm, v3 = ((float) (int) q3 - mh) * sm;
+    kv_had32(v0, v1, v2, v3, lane);
+    if (active) ((half4_t*) out)[sl] = half4_t{ (half_t) v0, (half_t) v1, (half_t) v2, (half_t) v3 };
+}
+
+// contiguous: group g of the flat tensor
+template <int BITS>
+__global__ __launch_bounds__(256)
+void kv_quant_cont_kernel(const half_t* __restrict__ in, uint32_t* __restrict__ out, half_t* __restrict__ scales, int64_t num_groups)
+{
+    int64_t g = (int64_t) blockIdx.x * 32 + (threadIdx.x >> 3);
+    bool active = g < num_groups;
+    int64_t gs = active ? g : 0;
+    kv_quant_group<BITS>(in + gs * 32, out + gs * BITS, scales + gs, active, threadIdx.x & 63);
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256)
+void kv_dequant_cont_kernel(const uint32_t* __restrict__ in, const half_t* __restrict__ scales, half_t* __restrict__ out, int64_t num_groups)
+{
+    int64_t g = (int64_t) blockIdx.x * 32 + (threadIdx.x >> 3);
+    bool active = g < num_groups;
+    int64_t gs = active ? g : 0;
+    kv_dequant_group<BITS>(in + gs * BITS, scales + gs, out + gs * 32, active, threadIdx.x & 63);
+}
+
+// paged append: grid (ceil(groups_per_token/32), seq_len, bsz); K and V in one launch (blockIdx.x parity split would
+// halve occupancy; instead each thread-group does K then V like the reference, q_cache_kernels.cuh:291-326)
+template <int KB, int VB>
+__global__ __launch_bounds__(256)
+void kv_quant_paged_kernel(const half_t* __restrict__ k_in, uint32_t* __restrict__ k_out, half_t* __restrict__ k_scales,
+                           const half_t* __restrict__ v_in, uint32_t* __restrict__ v_out, half_t* __restrict__ v_scales,
+                           const int32_t* __restrict__ cache_seqlens, const int32_t* __restrict__ block_table,
+                           int blocks_per_seq, int page_size, int groups_per_token)
+{
+    const int batch = blockIdx.z;
+    const int token_idx = blockIdx.y + cache_seqlens[batch];
+    const int page_idx = token_idx / page_size;
+    const int64_t token_pos = (int64_t) block_table[blocks_per_seq * batch + page_idx] * page_size + (token_idx % page_size);
+    const int64_t in_pos = (int64_t) batch * gridDim.y + blockIdx.y;
+    const int g = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool active = g < groups_per_token;
+    const int gs = active ? g : 0;
+    const int64_t base = token_pos * groups_per_token + gs;
+    const int64_t in_base = in_pos * groups_per_token + gs;
+    const int lane = threadIdx.x & 63;
+    kv_quant_group<KB>(k_in + in_base * 32, k_out + base * KB, k_scales + base, active, lane);
+    kv_quant_group<VB>(v_in + in_base * 32, v_out + base * VB, v_scales + base, active, lane);
+}
+
+// paged dequant of every cached token: grid (ceil(groups_per_token/32), max_tokens, bsz)
+template <int KB, int VB>
+__global__ __launch_bounds__(256)
+void kv_dequant_paged_kernel(const uint32_t* __restrict__ k_in, const half_t* __restrict__ k_scales, half_t* __restrict__ k_out,
+                             const uint32_t* __restrict__ v_in, const half_t* __restrict__ v_scales, half_t* __restrict__ v_out,
+                             const int32_t* __restrict__ cache_seqlens, const int32_t* __restrict__ block_table,
+                             int blocks_per_seq, int page_size, int groups_per_token)
+{
+    const int batch = blockIdx.z;
+    const int token_idx = blockIdx.y;
+    if (token_idx >= cache_seqlens[batch]) return;
+    const int page_idx = token_idx / page_size;
+    const int64_t token_pos = (int64_t) block_table[blocks_per_seq * batch + page_idx] * page_size + (token_idx % page_size);
+    const int g = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool active = g < groups_per_token;
+    const int gs = active ? g : 0;
+    const int64_t base = token_pos * groups_per_token + gs;
+    const int lane = threadIdx.x & 63;
+    kv_dequant_group<KB>(k_in + base * KB, k_scales + base, k_out + base * 32, active, lane);
+    kv_dequant_group<VB>(v_in + base * VB, v_scales + base, v_out + base * 32, active, lane);
+}
+
+#define BITS_SWITCH(b, CALL) switch (b) { \
+    case 2: { constexpr int BB = 2; CALL; } break; case 3: { constexpr int BB = 3; CALL; } break; case 4: { constexpr int BB = 4; CALL; } break; \
+    case 5: { constexpr int BB = 5; CALL; } break; case 6: { constexpr int BB = 6; CALL; } break; case 7: { constexpr int BB = 7; CALL; } break; \
+    case 8: { constexpr int BB = 8; CALL; } break; }
+
+extern "C" int exl3_quant_cache_cont(const void* in, void* out, void* out_scales, int64_t tokens, int dim, int bits, void* stream)
+{
+    EXL3_CHECK_ARG(in && out && out_scales, "quant_cache_cont: null pointer");
+    EXL3_CHECK_ARG(dim % 32 == 0, "quant_cache_cont: dim must be divisible by 32");
+    EXL3_CHECK_ARG(bits >= 2 && bits <= 8, "quant_cache_cont: bits must be in [2, 8]");
+    int64_t groups = tokens * (dim / 32);
+    if (groups == 0) return EXL3_OK;
+    dim3 grid((unsigned) ((groups + 31) / 32));
+    BITS_SWITCH(bits, (kv_quant_cont_kernel<BB><<<grid, 256, 0, (hipStream_t) stream>>>((const half_t*) in, (uint32_t*) out, (half_t*) out_scales, groups)));
+    return exl3_check_launch("quant_cache_cont");
+}
+
+extern "C" int exl3_dequant_cache_cont(const void* in, const void* in_scales, void* out, int64_t tokens, int dim, int bits, void* stream)
+{
+    EXL3_CHECK_ARG(in && out && in_scales, "dequant_cache_cont: null pointer");
+    EXL3_CHECK_ARG(dim % 32 == 0, "dequant_cache_cont: dim must be divisible by 32");
+    EXL3_CHECK_ARG(bits >= 2 && bits <= 8, "dequant_cache_cont: bits must be in [2, 8]");
+    int64_t groups = tokens * (dim / 32);
+    if (groups == 0) return EXL3_OK;
+    dim3 grid((unsigned) ((groups + 31) / 32));
+    BITS_SWITCH(bits, (kv_dequant_cont_kernel<BB><<<grid, 256, 0, (hipStream_t) stream>>>((const uint32_t*) in, (const half_t*) in_scales, (half_t*) out, groups)));
+    return exl3_check_launch("dequant_cache_cont");
+}
+
+template <int KB>
+static void launch_quant_paged(int vb, dim3 grid, hipStream_t st, const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                               const int32_t* sl, const int32_t* bt, int bps, int ps, int gpt)
+{
+    BITS_SWITCH(vb, (kv_quant_paged_kernel<KB, BB><<<grid, 256, 0, st>>>((const half_t*) k_in, (uint32_t*) k_out, (half_t*) k_scales, (const half_t*) v_in,
+                                                                         (uint32_t*) v_out, (half_t*) v_scales, sl, bt, bps, ps, gpt)));
+}
+
+template <int KB>
+static void launch_dequant_paged(int vb, dim3 grid, hipStream_t st, const void* k_in, const void* k_scales, void* k_out, const void* v_in, const void* v_scales, void* v_out,
+                                 const int32_t* sl, const int32_t* bt, int bps, int ps, int gpt)
+{
+    BITS_SWITCH(vb, (kv_dequant_paged_kernel<KB, BB><<<grid, 256, 0, st>>>((const uint32_t*) k_in, (const half_t*) k_scales, (half_t*) k_out, (const uint32_t*) v_in,
+                                                                           (const half_t*) v_scales, (half_t*) v_out, sl, bt, bps, ps, gpt)));
+}
+
+extern "C" int exl3_quant_cache_paged(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                                      const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                                      int page_size, int seq_len, int dim, int k_bits, int v_bits, void* stream)
+{
+    EXL3_CHECK_ARG(k_in && k_out && k_scales && v_in && v_out && v_scales && cache_seqlens && block_table, "quant_cache_paged: null pointer");
+    EXL3_CHECK_ARG(dim % 32 == 0 && page_size > 0, "quant_cache_paged: dim must be divisible by 32");
+    EXL3_CHECK_ARG(k_bits >= 2 && k_bits <= 8 && v_bits >= 2 && v_bits <= 8, "quant_cache_paged: bits must be in [2, 8]");
+    if (bsz == 0 || seq_len == 0) return EXL3_OK;
+    const int gpt = dim / 32;
+    dim3 grid((gpt + 31) / 32, seq_len, bsz);
+    hipStream_t st = (hipStream_t) stream;
+    #define QP(KBv) case KBv: launch_quant_paged<KBv>(v_bits, grid, st, k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, blocks_per_seq, page_size, gpt); break;
+    switch (k_bits) { QP(2) QP(3) QP(4) QP(5) QP(6) QP(7) QP(8) }
+    #undef QP
+    return exl3_check_launch("quant_cache_paged");
+}
+
+extern "C" int exl3_dequant_cache_paged(const void* k_in, const void* k_scales, void* k_out, const void* v_in, const void* v_scales, void* v_out,
+                                        const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                                        int page_size, int dim, int k_bits, int v_bits, void* stream)
+{
+    EXL3_CHECK_ARG(k_in && k_out && k_scales && v_in && v_out && v_scales && cache_seqlens && block_table, "dequant_cache_paged: null pointer");
+    EXL3_CHECK_ARG(dim % 32 == 0 && page_size > 0, "dequant_cache_paged: dim must be divisible by 32");
+    EXL3_CHECK_ARG(k_bits >= 2 && k_bits <= 8 && v_bits >= 2 && v_bits <= 8, "dequant_cache_paged: bits must be in [2, 8]");
+    if (bsz == 0 || blocks_per_seq == 0) return EXL3_OK;
+    const int gpt = dim / 32;
+    dim3 grid((gpt + 31) / 32, blocks_per_seq * page_size, bsz);
+    hipStream_t st = (hipStream_t) stream;
+    #define DP(KBv) case KBv: launch_dequant_paged<KBv>(v_bits, grid, st, k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens, block_table, blocks_per_seq, page_size, gpt); break;
+    switch (k_bits) { DP(2) DP(3) DP(4) DP(5) DP(6) DP(7) DP(8) }
+    #undef DP
+    return exl3_check_launch("dequant_cache_paged");
+}

@@ -372,7 +372,6 @@ def dequant_cache_paged(k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seql
     _dev(k_in)
     _req(compand_a == 0.0 and sliding_window == 0, "dequant_cache_paged: compander / sliding window are outside this build")
     _req(page_size == 256, "dequant_cache_paged: page size must be 256")
-    dim = k_out.shape[-1] * (k_out.shape[-2] if k_out.dim() == 4 else 1)
     dim = k_in.shape[-1] // _kv_bits(k_in, k_scales) * 32
     bsz = block_table.shape[0]
     _check(_lib.lib().exl3_dequant_cache_paged(_p(k_in), _p(k_scales), _p(k_out), _p(v_in), _p(v_scales), _p(v_out),

@@ -1,0 +1,116 @@
+"""
+Host-side mirror of the reference's inner quantized-linear op `LinearEXL3`
+(/root/reference/exllamav3/modules/quant/exl3.py:16-389): same path selection, slicing and TP-shard semantics, on top
+of the C-ABI ops in exllamav3_amd.ext.
+
+  forward(x, params, out_dtype):
+     rows <= AUTO_RECONSTRUCT_THRESHOLD (144)  -> fused HIP GEMV / small-m GEMM (exl3.py:133-137)
+     otherwise reconstruct_hgemm (exl3.py:161-218):
+        rows < 1024 : had_r_128(x, suh) -> reconstruct -> hgemm -> had_r_128(y, svh)
+        rows >= 1024: reconstruct_had_slice (original-basis W, both Hadamards on the matrix pipe) -> hgemm on raw x
+        out_features > MAX_RECONSTRUCT_SLICE_N: column slices
+"""
+from __future__ import annotations
+import torch
+from . import ext
+
+AUTO_RECONSTRUCT_THRESHOLD = 144          # exl3.py:10
+MAX_RECONSTRUCT_SLICE_N = 32768           # exl3.py:11
+FUSED_RECONSTRUCT_MIN_ROWS = 1024         # exl3.py:184
+
+
+class LinearEXL3:
+    quant_type = "exl3"
+
+    def __init__(self, in_features: int, out_features: int, trellis: torch.Tensor, suh: torch.Tensor, svh: torch.Tensor,
+                 mcg: bool = False, mul1: bool = False, bias: torch.Tensor | None = None, out_dtype: torch.dtype | None = None,
+                 key: str | None = None):
+        assert trellis.dtype == torch.int16 and trellis.dim() == 3, "trellis must be a 3-D int16 tensor"
+        assert suh.dtype == torch.half and svh.dtype == torch.half, "suh / svh must be float16"
+        assert trellis.shape[0] * 16 == in_features and trellis.shape[1] * 16 == out_features, "trellis shape mismatch"
+        if bias is not None and bias.dtype == torch.float:
+            bias = bias.to(torch.half)
+        self.in_features, self.out_features = in_features, out_features
+        self.trellis, self.suh, self.svh, self.bias = trellis.contiguous(), suh.contiguous(), svh.contiguous(), bias
+        self.K = trellis.shape[-1] // 16
+        self.mcg, self.mul1 = bool(mcg), bool(mul1)
+        self.out_dtype = out_dtype
+        self.default_out_dtype = out_dtype or torch.half
+        self.key = key
+        self.bc = ext.BC_LinearEXL3(self.trellis, self.suh, self.svh, self.K, self.bias, self.mcg, self.mul1, None)
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, params: dict | None = None, out_dtype: torch.dtype | None = None) -> torch.Tensor:
+        params = params or {}
+        assert x.is_contiguous(), f"LinearEXL3 {self.key}: non-contiguous input {tuple(x.shape)}"      # exl3.py:130
+        if not params.get("reconstruct"):
+            rows = x.numel() // x.shape[-1]
+            if rows <= AUTO_RECONSTRUCT_THRESHOLD or params.get("no_reconstruct"):
+                dtype = out_dtype or self.default_out_dtype
+                return self.bc.run_alloc(x, self.out_features, dtype == torch.float)
+        return self.reconstruct_hgemm(x, out_dtype)
+
+    def reconstruct_hgemm(self, x: torch.Tensor, out_dtype: torch.dtype | None) -> torch.Tensor:
+        shape = x.shape
+        rows = x.numel() // shape[-1]
+        y = torch.empty(shape[:-1] + (self.out_features,), dtype=out_dtype or self.default_out_dtype, device=x.device)
+        x2 = x.view(rows, self.in_features)
+        y2 = y.view(rows, self.out_features)
+        use_fused = self.in_features % 128 == 0 and self.out_features % 128 == 0 and rows >= FUSED_RECONSTRUCT_MIN_ROWS
+        if use_fused:
+            xh = x2
+        else:
+            xh = torch.empty_like(x2)
+            ext.had_r_128(x2, xh, self.suh, None, 1.0)
+        dev = self.trellis.device
+        if self.out_features <= MAX_RECONSTRUCT_SLICE_N:
+            w = torch.empty((self.in_features, self.out_features), dtype=torch.half, device=dev)
+            if use_fused:
+                ext.reconstruct_had_slice(w, self.trellis, self.suh, self.svh, self.K, self.mcg, self.mul1, 0)
+            else:
+                ext.reconstruct(w, self.trellis, self.K, self.mcg, self.mul1)
+            ext.hgemm(xh, w, y2)
+        else:
+            step = (MAX_RECONSTRUCT_SLICE_N // 128) * 128
+            w_ = torch.empty((self.in_features * step,), dtype=torch.half, device=dev)
+            for n0 in range(0, self.out_features, step):
+                n1 = min(n0 + step, self.out_features)
+                w = w_[: self.in_features * (n1 - n0)].view(self.in_features, n1 - n0)
+                if use_fused:
+                    ext.reconstruct_had_slice(w, self.trellis, self.suh, self.svh[n0:], self.K, self.mcg, self.mul1, n0)
+                else:
+                    ext.reconstruct_slice(w, self.trellis, self.K, self.mcg, self.mul1, n0)
+                ext.hgemm(xh, w, y2[:, n0:n1])
+        if not use_fused:
+            ext.had_r_128(y2, y2, None, self.svh, 1.0)
+        if self.bias is not None:
+            y += self.bias
+        return y
+
+    # ---- weights -----------------------------------------------------------------------------------
+    def get_inner_weight_tensor(self) -> torch.Tensor:
+        w = torch.empty((self.in_features, self.out_features), dtype=torch.half, device=self.trellis.device)
+        ext.reconstruct(w, self.trellis, self.K, self.mcg, self.mul1)
+        return w
+
+    def get_weight_tensor(self) -> torch.Tensor:
+        """exl3.py:227-237: original-basis weights."""
+        w = torch.empty((self.in_features, self.out_features), dtype=torch.half, device=self.trellis.device)
+        ext.reconstruct_had_slice(w, self.trellis, self.suh, self.svh, self.K, self.mcg, self.mul1, 0)
+        return w
+
+    # ---- tensor-parallel shards (exl3.py:284-330 tp_import_split) --------------------------------------
+    def tp_shard(self, first: int, last: int, split_dim: str) -> "LinearEXL3":
+        """Column ('n', out-features) or row ('k', in-features) shard [first, last); boundaries are multiples of 128
+        (Hadamard blocks).  Column shards slice trellis dim 1, svh and bias; row shards slice trellis dim 0 and suh, keep
+        the full svh and keep the bias only on the shard that starts at 0 (so that the all-reduce adds it once)."""
+        assert first % 128 == 0 and last % 128 == 0 and first < last
+        if split_dim == "n":
+            assert last <= self.out_features
+            return LinearEXL3(self.in_features, last - first, self.trellis[:, first // 16: last // 16].contiguous(),
+                              self.suh, self.svh[first:last].contiguous(), self.mcg, self.mul1,
+                              None if self.bias is None else self.bias[first:last].contiguous(), self.out_dtype, self.key)
+        assert split_dim == "k" and last <= self.in_features
+        return LinearEXL3(last - first, self.out_features, self.trellis[first // 16: last // 16].contiguous(),
+                          self.suh[first:last].contiguous(), self.svh, self.mcg, self.mul1,
+                          self.bias if first == 0 else None, self.out_dtype, self.key)

@@ -331,9 +331,12 @@ def rope(q: np.ndarray, k: np.ndarray | None, inv_freq: np.ndarray, position: in
         b, s, h, d = x.shape
         xf = x.astype(np.float32)
         if norm_w is not None:
+            # rope.cu:199-233: normalised value rounded to fp16, weight (w + bias) formed in fp16, product in fp16
             ss = (xf.astype(np.float64) ** 2).sum(-1, keepdims=True).astype(np.float32)
             rmf = np.float32(1.0) / np.sqrt(ss / np.float32(d) + np.float32(norm_eps))
-            xf = xf * rmf * (norm_w.astype(np.float32) + np.float32(norm_constant_bias))
+            vn = (xf * rmf).astype(np.float16)
+            wh = (norm_w.astype(np.float16) + np.float16(norm_constant_bias)).astype(np.float16)
+            xf = (vn * wh).astype(np.float16).astype(np.float32)
         if position_ids is not None:
             pos = np.asarray(position_ids).reshape(b, s).astype(np.float32)
         elif positions is not None:

@@ -1,0 +1,92 @@
+"""GPU parity of the prefill-side ops: reconstruct_had_slice, hgemm, and the LinearEXL3 host paths."""
+import numpy as np
+import pytest
+import torch
+from oracle import exl3_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("k,n,K,cb", [(256, 128, 3, 0), (512, 384, 2, 0), (1024, 512, 5, 0), (384, 256, 4, 1), (256, 512, 3, 2),
+                                      (4096, 1024, 3, 0), (128, 128, 1, 2), (256, 256, 8, 0), (128, 256, 6, 1), (256, 128, 7, 2)])
+def test_reconstruct_had_slice(dev, k, n, K, cb):
+    """tests/test_reconstruct_had.py:35-68 (shapes, seeds k*7+n+K, +-1 scales) + extra bitrates; max-abs/max < 2e-3."""
+    from exllamav3_amd import ext
+    tr, suh, svh = o.synth_linear(k, n, K)
+    ref = o.weight_tensor(tr, suh, svh, K, cb)
+    w = torch.empty((k, n), dtype=torch.half, device=dev)
+    ext.reconstruct_had_slice(w, _t(tr, dev), _t(suh, dev), _t(svh, dev), K, cb == 1, cb == 2, 0)
+    got = w.float().cpu().numpy()
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-3
+    if n >= 256:    # slice offset path (test_reconstruct_had.py:54-67)
+        ws = torch.empty((k, 128), dtype=torch.half, device=dev)
+        ext.reconstruct_had_slice(ws, _t(tr, dev), _t(suh, dev), _t(svh[128:], dev), K, cb == 1, cb == 2, 128)
+        assert np.abs(ws.float().cpu().numpy() - ref[:, 128:256]).max() / np.abs(ref).max() < 2e-3
+
+
+def test_reconstruct_had_real_valued_scales(dev):
+    from exllamav3_amd import ext
+    k, n, K, cb = 512, 256, 4, 2
+    tr, suh, svh = o.synth_linear(k, n, K, realistic=True)
+    ref = o.weight_tensor(tr, suh, svh, K, cb)
+    w = torch.empty((k, n), dtype=torch.half, device=dev)
+    ext.reconstruct_had_slice(w, _t(tr, dev), _t(suh, dev), _t(svh, dev), K, False, True, 0)
+    assert np.abs(w.float().cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-3
+
+
+@pytest.mark.parametrize("m,k,n", [(1, 128, 128), (17, 256, 384), (256, 1024, 512), (1000, 512, 640)])
+def test_hgemm(dev, m, k, n):
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(m + k)
+    a = rng.standard_normal((m, k)).astype(np.float16); b = (rng.standard_normal((k, n)) * 0.1).astype(np.float16)
+    ref = a.astype(np.float32) @ b.astype(np.float32)
+    for dt in (torch.half, torch.float):
+        c = torch.full((m, n), float("nan"), dtype=dt, device=dev)
+        ext.hgemm(_t(a, dev), _t(b, dev), c)
+        assert np.allclose(c.float().cpu().numpy(), ref, rtol=2e-2, atol=2e-2)
+    # column-slice output (hgemm.cu: c.stride(-2))
+    cbig = torch.zeros((m, n + 256), dtype=torch.half, device=dev)
+    ext.hgemm(_t(a, dev), _t(b, dev), cbig[:, 128:128 + n])
+    assert np.allclose(cbig[:, 128:128 + n].float().cpu().numpy(), ref, rtol=2e-2, atol=2e-2)
+    assert float(cbig[:, :128].abs().max()) == 0.0 and float(cbig[:, 128 + n:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows", [1, 16, 144, 145, 512, 1024, 1500])
+def test_linear_exl3_paths_agree(dev, rows):
+    """modules/quant/exl3.py:114-218: kernel path (rows <= 144), unfused reconstruct path (< 1024) and fused-W path
+    (>= 1024) against the oracle; tests/test_qgemm.py tolerance rtol = atol = 0.05."""
+    from exllamav3_amd.linear import LinearEXL3
+    k, n, K, cb = 512, 384, 4, 2
+    tr, suh, svh = o.synth_linear(k, n, K, realistic=True)
+    bias = (np.random.default_rng(1).standard_normal(n) * 0.1).astype(np.float16)
+    lin = LinearEXL3(k, n, _t(tr, dev), _t(suh, dev), _t(svh, dev), mul1=True, bias=_t(bias, dev))
+    x = np.random.default_rng(0).standard_normal((rows, k)).astype(np.float16)
+    ref = o.linear_forward(x, tr, suh, svh, K, cb, bias=bias).astype(np.float32)
+    y = lin.forward(_t(x, dev), {}).float().cpu().numpy()
+    assert np.allclose(y, ref, rtol=0.05, atol=0.05)
+    err = np.abs(y - ref).max() / np.sqrt((ref ** 2).mean())
+    assert err < 2e-2
+    y2 = lin.forward(_t(x, dev), {"reconstruct": True}).float().cpu().numpy()
+    assert np.allclose(y2, ref, rtol=0.05, atol=0.05)
+
+
+def test_linear_exl3_lm_head_slicing(dev):
+    """out_features > MAX_RECONSTRUCT_SLICE_N is processed in column slices (exl3.py:199-211)."""
+    from exllamav3_amd import linear
+    k, n, K, cb = 256, 1024, 3, 0
+    tr, suh, svh = o.synth_linear(k, n, K)
+    lin = linear.LinearEXL3(k, n, _t(tr, dev), _t(suh, dev), _t(svh, dev))
+    x = np.random.default_rng(0).standard_normal((1100, k)).astype(np.float16)
+    ref = o.linear_forward(x, tr, suh, svh, K, cb).astype(np.float32)
+    old = linear.MAX_RECONSTRUCT_SLICE_N
+    linear.MAX_RECONSTRUCT_SLICE_N = 384
+    try:
+        for rows in (200, 1100):
+            y = lin.forward(_t(x[:rows], dev), {}).float().cpu().numpy()
+            assert np.allclose(y, ref[:rows], rtol=0.05, atol=0.05)
+    finally:
+        linear.MAX_RECONSTRUCT_SLICE_N = old

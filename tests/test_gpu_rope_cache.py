@@ -1,0 +1,101 @@
+"""GPU parity of RoPE and the KV-cache quantization kernels (through the C-ABI)."""
+import numpy as np
+import pytest
+import torch
+from oracle import exl3_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("style,mode", [("neox", 2), ("gptj", 1)])
+def test_rope_vs_reference_python_fixtures(dev, golden, style, mode):
+    # fixtures produced by the reference's RoPE.apply_torch (tests/test_rope.py tolerance 3e-3)
+    from exllamav3_amd import ext
+    q, k, inv = golden[f"rope_{style}_q"], golden[f"rope_{style}_k"], golden[f"rope_{style}_inv_freq"]
+    cases = [("pos37", dict(position=37, positions=None, position_ids=None)),
+             ("posv", dict(position=0, positions=_t(golden[f"rope_{style}_positions"].astype(np.int32), dev), position_ids=None)),
+             ("pid", dict(position=0, positions=None, position_ids=_t(golden[f"rope_{style}_pid"].astype(np.int32), dev)))]
+    for tag, kw in cases:
+        qo = torch.empty(q.shape, dtype=torch.half, device=dev); ko = torch.empty(k.shape, dtype=torch.half, device=dev)
+        ext.rope(_t(q, dev), qo, _t(k, dev), ko, _t(inv, dev), kw["position"], kw["positions"], kw["position_ids"], mode, 1.0)
+        assert np.allclose(qo.float().cpu().numpy(), golden[f"rope_{style}_{tag}_q"].astype(np.float32), atol=3e-3, rtol=3e-3)
+        assert np.allclose(ko.float().cpu().numpy(), golden[f"rope_{style}_{tag}_k"].astype(np.float32), atol=3e-3, rtol=3e-3)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 32, 8, 128), (2, 7, 32, 8, 64), (1, 33, 4, 4, 256), (3, 5, 8, 2, 96)])
+def test_rope_shapes_norm_inplace(dev, shape):
+    # tests/test_rope.py:36-105 style sweep: (bsz, seq, heads_q, heads_k, head_dim), +- fused head norm, in place
+    from exllamav3_amd import ext
+    b, s, hq, hk, hd = shape
+    rng = np.random.default_rng(hd + s)
+    q = rng.standard_normal((b, s, hq, hd)).astype(np.float16)
+    k = rng.standard_normal((b, s, hk, hd)).astype(np.float16)
+    inv = (1.0 / (10000.0 ** (np.arange(0, hd, 2) / hd))).astype(np.float32)
+    for mode in (1, 2):
+        for with_norm in (False, True):
+            qn = (1 + 0.1 * rng.standard_normal(hd)).astype(np.float16) if with_norm else None
+            kn = (1 + 0.1 * rng.standard_normal(hd)).astype(np.float16) if with_norm else None
+            rq, rk = o.rope(q, k, inv, position=11, rope_mode=mode, attn_factor=1.1, q_norm=qn, k_norm=kn, norm_eps=1e-6, norm_constant_bias=0.0)
+            tq, tk = _t(q, dev), _t(k, dev)
+            ext.rope(tq, tq, tk, tk, _t(inv, dev), 11, None, None, mode, 1.1, None if qn is None else _t(qn, dev),
+                     None if kn is None else _t(kn, dev), 1e-6, 0.0)
+            tol = 6e-3 if with_norm else 3e-3
+            assert np.allclose(tq.float().cpu().numpy(), rq.astype(np.float32), atol=tol, rtol=tol)
+            assert np.allclose(tk.float().cpu().numpy(), rk.astype(np.float32), atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize("bits", range(2, 9))
+def test_kv_quant_cont_bit_exact(dev, bits):
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(bits)
+    x = (rng.standard_normal((37, 1024)) * rng.uniform(0.1, 4.0, size=(37, 1))).astype(np.float16)
+    x[3, :64] = 0                                              # an all-zero group pair
+    pk_ref, sc_ref = o.kv_quant(x, bits)
+    out = torch.zeros((37, 1024 // 32 * bits), dtype=torch.int32, device=dev)
+    sc = torch.zeros((37, 32), dtype=torch.half, device=dev)
+    ext.quant_cache_cont(_t(x, dev), out, sc)
+    assert np.array_equal(sc.cpu().numpy().view(np.uint16), sc_ref.view(np.uint16))
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), pk_ref)
+    y = torch.empty((37, 1024), dtype=torch.half, device=dev)
+    ext.dequant_cache_cont(out, sc, y)
+    y_ref = o.kv_dequant(pk_ref, sc_ref, bits)
+    assert np.array_equal(y.cpu().numpy().view(np.uint16), y_ref.view(np.uint16))
+    if bits == 8:       # tests/test_kv_quant.py tolerance
+        assert np.allclose(y.float().cpu().numpy(), x.astype(np.float32), atol=0.08, rtol=0.01)
+
+
+@pytest.mark.parametrize("kb,vb", [(8, 8), (4, 4), (6, 5), (2, 3)])
+def test_kv_quant_paged_roundtrip(dev, kb, vb):
+    """tests/test_kv_quant.py:21-143: paged quant -> dequant with a permuted page table and a 5-token append."""
+    from exllamav3_amd import ext
+    page, dim, bsz, pages_per_seq = 256, 1024, 2, 3
+    total_pages = bsz * pages_per_seq + 2
+    rng = np.random.default_rng(kb * 10 + vb)
+    perm = rng.permutation(total_pages)[: bsz * pages_per_seq].astype(np.int32).reshape(bsz, pages_per_seq)
+    bt = _t(perm, dev)
+    G = dim // 32
+    kq = torch.zeros((total_pages, page, G * kb), dtype=torch.int32, device=dev); ks = torch.zeros((total_pages, page, G), dtype=torch.half, device=dev)
+    vq = torch.zeros((total_pages, page, G * vb), dtype=torch.int32, device=dev); vs = torch.zeros((total_pages, page, G), dtype=torch.half, device=dev)
+    seqlens = np.array([0, 0], dtype=np.int32)
+    lens = [300, 5]                                               # a 300-token prefill then a 5-token append
+    full_k = [np.zeros((0, dim), np.float16) for _ in range(bsz)]; full_v = [np.zeros((0, dim), np.float16) for _ in range(bsz)]
+    for n_new in lens:
+        k_new = rng.standard_normal((bsz, n_new, dim)).astype(np.float16); v_new = rng.standard_normal((bsz, n_new, dim)).astype(np.float16)
+        ext.quant_cache_paged(_t(k_new, dev), kq, ks, _t(v_new, dev), vq, vs, _t(seqlens, dev), bt, page, n_new)
+        for b in range(bsz):
+            full_k[b] = np.concatenate([full_k[b], k_new[b]]); full_v[b] = np.concatenate([full_v[b], v_new[b]])
+        seqlens = seqlens + n_new
+    ko = torch.zeros((total_pages, page, dim), dtype=torch.half, device=dev); vo = torch.zeros_like(ko)
+    ext.dequant_cache_paged(kq, ks, ko, vq, vs, vo, _t(seqlens, dev), bt, page)
+    ko, vo = ko.cpu().numpy(), vo.cpu().numpy()
+    for b in range(bsz):
+        for t in range(int(seqlens[b])):
+            pg = perm[b, t // page]
+            for full, got, bits in ((full_k[b], ko, kb), (full_v[b], vo, vb)):
+                pk, sc = o.kv_quant(full[t:t + 1], bits)
+                ref = o.kv_dequant(pk, sc, bits)[0]
+                assert np.array_equal(got[pg, t % page].view(np.uint16), ref.view(np.uint16)), (b, t, bits)
