@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""
+bench.py — decode tok/s (+ prefill tok/s) of the EXL3 quantized-linear hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run)
+  * a "step" = one pass of the hot path over one batch of synthetic input = one decode step (bs tokens) through every
+    quantized Linear + RMSNorm + RoPE + KV-cache quantized append of Llama-3.1-8B @ 4.0 bpw (BASELINE.json metric /
+    configs[2]); random-init packed EXL3 tensors of that architecture, all resident in HBM before the timed region;
+  * W untimed warmup steps, then EXACTLY K timed steps bracketed by barrier + torch.cuda.synchronize() on both sides,
+    MAX over ranks; rank 0 prints ONE JSON line;
+  * N > 1 = tensor parallel (column/row shards + RCCL all-reduce over xGMI): total work is fixed -> "scaling": "strong".
+
+Extra objects on the JSON line (tier contract 4):
+  roofline     : the dominant kernel (the fused EXL3 GEMV, all of its launches in a decode step), bound "hbm":
+                 achieved = algorithmic bytes per launch / average launch duration, measured live with HIP events on
+                 the launch stream; peak = 8000 GB/s (HBM3E spec, MI355X_MICROARCH.md); traffic = PMC FETCH bytes per
+                 launch when profiles/traffic.json from a rocprofv3 --pmc pass is present, else null.
+  cpu_baseline : the numpy oracle (kind "port") timed on host cores on a bounded sample of the same workload.
+  prefill      : prefill tok/s of a 4096-token chunk through the same linears (reconstruct_had + MFMA GEMM), N = 1 only.
+"""
+from __future__ import annotations
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4-copy ceiling)
+MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--model", default="llama-3.1-8b")
+    ap.add_argument("--bits", type=int, default=4)
+    ap.add_argument("--codebook", default="mul1", choices=["3inst", "mcg", "mul1"],
+                    help="mul1 = default of new EXL3 conversions (conversion/convert_model.py:49)")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--kv-bits", type=int, default=4)
+    ap.add_argument("--layers", type=int, default=0, help="debug: fewer layers (invalidates the number)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--prefill-tokens", type=int, default=4096)
+    ap.add_argument("--variant", type=int, default=1)
+    ap.add_argument("--gen", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(shape, K, cb):
+    """Oracle (numpy port of the reference algorithm) on the host: reconstruct + forward of the attention linears of
+    ONE layer (q, k, v, o), m = 1; scaled to tokens/s by algorithmic bytes."""
+    import numpy as np
+    from oracle import exl3_oracle as orc
+    s = shape.linear_shapes()
+    sample = ["q", "k", "v", "o"]
+    t_total, bytes_sample = 0.0, 0
+    for name in sample:
+        k, n = s[name]
+        tr, suh, svh = orc.synth_linear(k, n, K, seed=7)
+        x = np.random.default_rng(0).standard_normal((1, k)).astype(np.float16)
+        t0 = time.perf_counter()
+        w = orc.reconstruct(tr, K, cb)
+        orc.linear_forward(x, tr, suh, svh, K, cb, w_hat=w)
+        t_total += time.perf_counter() - t0
+        bytes_sample += k * n * K // 8 + 2 * (k + n)
+    tok_s = 1.0 / (t_total * shape.decode_bytes_per_token(K) / bytes_sample)
+    return {"value": round(tok_s, 5), "unit": "tok/s", "cores": 1, "kind": "port",
+            "sample": f"numpy oracle reconstruct+GEMV of one layer's q,k,v,o linears ({bytes_sample / 1e6:.1f} MB of packed "
+                      f"weights, {t_total:.1f} s), scaled by bytes to the {shape.decode_bytes_per_token(K) / 1e9:.3f} GB/token model; "
+                      f"host has {os.cpu_count()} cores, the port is single-threaded"}
+
+
+def main():
+    args = parse()
+    import torch
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
+    from exllamav3_amd.tp import TPBackendRCCL
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    backend = TPBackendRCCL(rank, world, dev)
+    ext.init(local_rank)
+    ext.set_gemv_variant(args.variant)
+    ext.set_gemv_gen(args.gen)
+
+    shape = SHAPES[args.model]
+    cb = {"3inst": 0, "mcg": 1, "mul1": 2}[args.codebook]
+    model = SyntheticEXL3Llama(shape, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits,
+                               layers=args.layers or None)
+    model.alloc_state(args.batch)
+
+    # ---- decode: eager warm-up (also creates library contexts), graph capture, timed replays
+    model.decode_step()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        try:
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                model.decode_step()
+                st.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=st):
+                    model.decode_step()
+            torch.cuda.synchronize()
+        except Exception as e:          # e.g. a collective that cannot be captured: fall back to eager launches
+            if rank == 0:
+                print(f"bench.py: graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+        else:
+            model.decode_step()
+
+    for _ in range(args.warmup):
+        step()
+    backend.fwd_barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    backend.fwd_barrier()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    backend.all_reduce_max(el)
+    elapsed = float(el.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    tok_s = args.batch * args.steps / elapsed
+    assert torch.isfinite(model.logits.float()).all(), "non-finite logits"
+
+    # ---- roofline leg: every fused-GEMV launch of a decode step, bracketed by HIP events on the launch stream
+    roofline = None
+    if rank == 0 or world > 1:
+        import itertools
+        evs = []
+        L0 = model.layers
+        def timed(fn):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            evs.append((e0, e1))
+        bsz = args.batch
+        q2, k2, v2 = model.q.view(bsz, -1), model.k.view(bsz, -1), model.v.view(bsz, -1)
+        reps = 3
+        empty = []
+        for rep in range(reps):
+            for L in L0:
+                timed(lambda: ext.exl3_mgemm_bcast(model.xn, [L["q"].trellis, L["k"].trellis, L["v"].trellis], [q2, k2, v2],
+                                                   [L["q"].suh, L["k"].suh, L["v"].suh], [L["q"].svh, L["k"].svh, L["v"].svh], L["q"].mcg, L["q"].mul1))
+                timed(lambda: L["o"].bc.run(q2, model.o))
+                timed(lambda: ext.exl3_mgemm_bcast(model.xn, [L["gate"].trellis, L["up"].trellis], [model.g, model.u],
+                                                   [L["gate"].suh, L["up"].suh], [L["gate"].svh, L["up"].svh], L["gate"].mcg, L["gate"].mul1))
+                timed(lambda: L["down"].bc.run(model.a, model.d))
+            timed(lambda: model.lm_head.bc.run(model.xn, model.logits))
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); e1.record(); empty.append((e0, e1))
+        torch.cuda.synchronize()
+        per_rep = len(evs) // reps
+        durs = [a.elapsed_time(b) * 1e3 for a, b in evs[per_rep:]]          # us, first repetition discarded
+        ov = min(a.elapsed_time(b) * 1e3 for a, b in empty)
+        launches = len(durs)
+        total_us = sum(durs)
+        K = args.bits
+        bytes_step = sum((k * n * K // 8 + 2 * (k + n) + 2 * bsz * (k + n)) * cnt for (k, n, cnt) in model.gemv_launches_per_step())
+        launches_step = sum(cnt for (_, _, cnt) in model.gemv_launches_per_step())
+        avg_us = total_us / launches
+        bytes_per_launch = bytes_step / launches_step
+        achieved = bytes_per_launch / avg_us / 1e3                            # GB/s
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("fetch_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "exl3_gemv2_kernel (fused trellis decode + Hadamard + MFMA GEMV), all launches of a decode step",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "traffic": traffic, "avg_launch_us": round(avg_us, 2), "bytes_per_launch": int(bytes_per_launch),
+                    "launches_per_step": launches_step, "event_pair_overhead_us": round(ov, 2),
+                    "note": "event-bracketed eager launches (includes dispatch latency and the split-k reduce launch); "
+                            "compare profiles/ for rocprofv3 kernel-only durations"}
+
+    # ---- prefill leg (single GPU): one chunk through the same linears
+    prefill = None
+    if world == 1 and not args.no_prefill:
+        toks = args.prefill_tokens
+        model.prefill_chunk(toks)                       # warm-up (hipBLASLt heuristics, allocator)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            model.prefill_chunk(toks)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        flops = shape.prefill_flops_per_token() * toks * (model.n_layers / shape.layers)
+        prefill = {"metric": "prefill tok/s", "value": round(toks / dt, 1), "unit": "tok/s", "chunk_tokens": toks,
+                   "ms_per_chunk": round(dt * 1e3, 2),
+                   "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(flops / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                "note": "linears' 2*k*n flops over the whole chunk time (includes reconstruct_had, norms, rope, kv-quant)"}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(shape, args.bits, cb)
+
+    if rank == 0:
+        out = {
+            "metric": "decode tok/s, Llama-3.1-8B EXL3 4.0bpw hot path (all quantized linears + RMSNorm + RoPE + KV-quant), bs=%d" % args.batch,
+            "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{shape.name} EXL3 {args.bits}.0bpw {args.codebook} codebook, decode bs={args.batch}, "
+                                   f"{model.n_layers} layers, TP={world}, {args.kv_bits}-bit KV append, "
+                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}; attention core excluded (SURVEY.md 2.1)",
+                       "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
+                       "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),
+                       "parallelism": f"tp{world}", "gemv_variant": args.variant, "gemv_gen": args.gen},
+            "roofline": roofline, "cpu_baseline": cpu, "prefill": prefill,
+        }
+        print(json.dumps(out), flush=True)
+    backend.close()
+
+
+if __name__ == "__main__":
+    main()

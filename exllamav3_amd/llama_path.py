@@ -1,0 +1,228 @@
+"""
+The EXL3 hot path of a Llama-shaped decoder, driven op by op through exllamav3_amd.ext (i.e. through the C-ABI):
+every quantized Linear, RMSNorm, RoPE and the KV-cache quantized append of one decode step / one prefill chunk,
+on synthetic random EXL3 tensors (random trellis bits are legal inputs, decode is total over all
+2^16 states).  This is the workload bench.py times; it is also what tests/test_gpu_path.py checks against the
+oracle layer by layer.
+
+Mirrors the reference call stack of SURVEY.md 3.1 (TransformerBlock -> RMSNorm -> Attention(q,k,v,rope,kv-quant,o)
+-> RMSNorm(fused residual) -> GatedMLP(gate/up fused, silu*mul, down)) minus the attention core itself (flash-decoding
+over the cache), which SURVEY.md 2.1 marks out of scope: the attention output is taken to be q, so that o_proj has a
+correctly shaped, data-dependent input.
+
+Tensor parallelism (tp_size > 1): Megatron column/row shards, one all-reduce after o_proj and one after down_proj
+(reference: modules/attn.py:547, modules/mlp.py:770), lm_head column shards + gather.
+"""
+from __future__ import annotations
+from dataclasses import dataclass
+import math
+import torch
+from . import ext
+from .linear import LinearEXL3
+from .tp import TPBackendRCCL, split_points
+
+
+@dataclass(frozen=True)
+class LlamaShape:
+    name: str
+    hidden: int
+    inter: int
+    layers: int
+    heads_q: int
+    heads_kv: int
+    head_dim: int
+    vocab: int
+    rope_theta: float = 500000.0
+
+    def linear_shapes(self):
+        """(k, n) of every quantized linear of one layer + lm_head (science/qgemm_benchmark.py:15-34)."""
+        h, i = self.hidden, self.inter
+        return {"q": (h, self.heads_q * self.head_dim), "k": (h, self.heads_kv * self.head_dim),
+                "v": (h, self.heads_kv * self.head_dim), "o": (self.heads_q * self.head_dim, h),
+                "gate": (h, i), "up": (h, i), "down": (i, h), "lm_head": (h, self.vocab)}
+
+    def decode_bytes_per_token(self, K: int, head_K: int | None = None) -> int:
+        """Algorithmic bytes of the quantized linears per token at bs = 1: sum [k*n*K/8 + 2(k+n)]."""
+        s = self.linear_shapes()
+        per_layer = sum(k * n * K // 8 + 2 * (k + n) for name, (k, n) in s.items() if name != "lm_head")
+        k, n = s["lm_head"]
+        return per_layer * self.layers + k * n * (head_K or K) // 8 + 2 * (k + n)
+
+    def prefill_flops_per_token(self) -> int:
+        """2 * sum k*n over the layer linears (attention and lm_head excluded)."""
+        s = self.linear_shapes()
+        return 2 * sum(k * n for name, (k, n) in s.items() if name != "lm_head") * self.layers
+
+
+LLAMA_3_2_1B = LlamaShape("llama-3.2-1b", 2048, 8192, 16, 32, 8, 64, 128256)
+LLAMA_3_1_8B = LlamaShape("llama-3.1-8b", 4096, 14336, 32, 32, 8, 128, 128256)
+LLAMA_3_1_70B = LlamaShape("llama-3.1-70b", 8192, 28672, 80, 64, 8, 128, 128256)
+SHAPES = {s.name: s for s in (LLAMA_3_2_1B, LLAMA_3_1_8B, LLAMA_3_1_70B)}
+
+
+def _rand_linear(k: int, n: int, K: int, cb: int, device, gen: torch.Generator, out_dtype=None, out_scale: float = 0.5) -> LinearEXL3:
+    trellis = torch.randint(-32768, 32768, (k // 16, n // 16, 16 * K), dtype=torch.int16, device=device, generator=gen)
+    sgn_u = torch.where(torch.rand(k, device=device, generator=gen) < 0.5, -1.0, 1.0)
+    sgn_v = torch.where(torch.rand(n, device=device, generator=gen) < 0.5, -1.0, 1.0)
+    # magnitudes like real checkpoints: keep y at O(out_scale) for unit-RMS x
+    suh = (sgn_u * torch.exp(0.2 * torch.randn(k, device=device, generator=gen))).half()
+    svh = (sgn_v * (out_scale / math.sqrt(k)) * torch.exp(0.2 * torch.randn(n, device=device, generator=gen))).half()
+    return LinearEXL3(k, n, trellis, suh, svh, mcg=(cb == 1), mul1=(cb == 2), out_dtype=out_dtype)
+
+
+class SyntheticEXL3Llama:
+    def __init__(self, shape: LlamaShape, K: int = 4, cb: int = 2, device: torch.device | str = "cuda:0",
+                 backend: TPBackendRCCL | None = None, kv_bits: int = 4, seed: int = 0, head_K: int | None = None,
+                 max_ctx: int = 4096, layers: int | None = None):
+        self.shape, self.K, self.cb, self.kv_bits = shape, K, cb, kv_bits
+        self.device = torch.device(device)
+        self.backend = backend or TPBackendRCCL(0, 1, self.device)
+        self.tp, self.rank = self.backend.world_size, self.backend.rank
+        self.n_layers = layers or shape.layers
+        tp, rank = self.tp, self.rank
+        assert shape.heads_kv % tp == 0, "TP degree must divide the KV heads (attention splits whole KV-head groups)"
+        self.hq, self.hkv = shape.heads_q // tp, shape.heads_kv // tp
+        hd = shape.head_dim
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(seed * 1000 + rank)
+        ipts = split_points(shape.inter, tp)
+        self.inter_local = ipts[rank + 1] - ipts[rank]
+        vpts = split_points(shape.vocab, tp)
+        self.vocab_local = vpts[rank + 1] - vpts[rank]
+        self.vocab_ldims = [vpts[r + 1] - vpts[r] for r in range(tp)]
+        h = shape.hidden
+        self.layers = []
+        for _ in range(self.n_layers):
+            L = {
+                "q": _rand_linear(h, self.hq * hd, K, cb, self.device, gen),
+                "k": _rand_linear(h, self.hkv * hd, K, cb, self.device, gen),
+                "v": _rand_linear(h, self.hkv * hd, K, cb, self.device, gen),
+                # o / down: row shards, fp32 partial sums (architecture/llama.py:95,111 out_dtype = float)
+                "o": _rand_linear(self.hq * hd, h, K, cb, self.device, gen, out_dtype=torch.float),
+                "gate": _rand_linear(h, self.inter_local, K, cb, self.device, gen),
+                "up": _rand_linear(h, self.inter_local, K, cb, self.device, gen),
+                "down": _rand_linear(self.inter_local, h, K, cb, self.device, gen, out_dtype=torch.float),
+                "norm1": (1.0 + 0.05 * torch.randn(h, device=self.device, generator=gen)).half(),
+                "norm2": (1.0 + 0.05 * torch.randn(h, device=self.device, generator=gen)).half(),
+            }
+            self.layers.append(L)
+        self.final_norm = (1.0 + 0.05 * torch.randn(h, device=self.device, generator=gen)).half()
+        self.lm_head = _rand_linear(h, self.vocab_local, head_K or K, cb, self.device, gen)
+        self.inv_freq = (1.0 / (shape.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(self.device)
+        self.eps = 1e-5
+        # paged quantized KV cache (cache/quant.py:40-42): (pages, 256, kv_dim/32*bits) int32 + scales fp16
+        self.page = 256
+        self.max_ctx = max_ctx
+        self._state_bsz = None
+
+    # ---- state ---------------------------------------------------------------------------------------
+    def alloc_state(self, bsz: int, pos: int = 1000):
+        dev, s = self.device, self.shape
+        hd = s.head_dim
+        kv_dim = self.hkv * hd
+        G = kv_dim // 32
+        pages_per_seq = self.max_ctx // self.page
+        self.block_table = torch.arange(bsz * pages_per_seq, dtype=torch.int32, device=dev).view(bsz, pages_per_seq)
+        self.cache_seqlens = torch.full((bsz,), pos, dtype=torch.int32, device=dev)
+        self.positions = torch.full((bsz,), pos, dtype=torch.int32, device=dev)
+        n_pages = bsz * pages_per_seq
+        self.kcache = [(torch.zeros((n_pages, self.page, G * self.kv_bits), dtype=torch.int32, device=dev),
+                        torch.zeros((n_pages, self.page, G), dtype=torch.half, device=dev)) for _ in range(self.n_layers)]
+        self.vcache = [(torch.zeros((n_pages, self.page, G * self.kv_bits), dtype=torch.int32, device=dev),
+                        torch.zeros((n_pages, self.page, G), dtype=torch.half, device=dev)) for _ in range(self.n_layers)]
+        f16, f32 = torch.half, torch.float
+        self.x = torch.randn((bsz, s.hidden), device=dev).to(f16)            # residual stream (fp16)
+        self.x0 = self.x.clone()
+        self.xn = torch.empty((bsz, s.hidden), dtype=f16, device=dev)
+        self.q = torch.empty((bsz, 1, self.hq, hd), dtype=f16, device=dev)
+        self.k = torch.empty((bsz, 1, self.hkv, hd), dtype=f16, device=dev)
+        self.v = torch.empty((bsz, 1, self.hkv, hd), dtype=f16, device=dev)
+        self.o = torch.empty((bsz, s.hidden), dtype=f32, device=dev)
+        self.g = torch.empty((bsz, self.inter_local), dtype=f16, device=dev)
+        self.u = torch.empty((bsz, self.inter_local), dtype=f16, device=dev)
+        self.a = torch.empty((bsz, self.inter_local), dtype=f16, device=dev)
+        self.d = torch.empty((bsz, s.hidden), dtype=f32, device=dev)
+        self.logits = torch.empty((bsz, self.vocab_local), dtype=f16, device=dev)
+        self._state_bsz = bsz
+
+    # ---- one decode step (bsz tokens, one per sequence) -----------------------------------------------
+    def decode_step(self):
+        """Graph-capturable: only kernel launches on the current stream (+ RCCL all-reduces when tp > 1)."""
+        bsz = self._state_bsz
+        hd = self.shape.head_dim
+        be = self.backend
+        x = self.x
+        x.copy_(self.x0)                                   # keep the step idempotent across replays
+        pending = None                                     # fp32 sublayer output waiting for the fused residual add
+        for li, L in enumerate(self.layers):
+            if pending is None:
+                ext.rms_norm(x, L["norm1"], self.xn, self.eps)
+            else:
+                ext.rms_norm_res_in(pending, L["norm1"], self.xn, x, self.eps)          # x += pending ; xn = norm(x)
+            q2, k2, v2 = self.q.view(bsz, -1), self.k.view(bsz, -1), self.v.view(bsz, -1)
+            ext.exl3_mgemm_bcast(self.xn, [L["q"].trellis, L["k"].trellis, L["v"].trellis], [q2, k2, v2],
+                                 [L["q"].suh, L["k"].suh, L["v"].suh], [L["q"].svh, L["k"].svh, L["v"].svh],
+                                 L["q"].mcg, L["q"].mul1)
+            ext.rope(self.q, self.q, self.k, self.k, self.inv_freq, 0, self.positions, None, 2, 1.0)
+            kc, ks = self.kcache[li]
+            vc, vs = self.vcache[li]
+            ext.quant_cache_paged(self.k.view(bsz, 1, -1), kc, ks, self.v.view(bsz, 1, -1), vc, vs,
+                                  self.cache_seqlens, self.block_table, self.page, 1)
+            # [attention core out of scope: attention output := q]
+            L["o"].bc.run(q2, self.o)
+            be.all_reduce(self.o)
+            ext.rms_norm_res_in(self.o, L["norm2"], self.xn, x, self.eps)             # x += o ; xn = norm(x)
+            ext.exl3_mgemm_bcast(self.xn, [L["gate"].trellis, L["up"].trellis], [self.g, self.u],
+                                 [L["gate"].suh, L["up"].suh], [L["gate"].svh, L["up"].svh], L["gate"].mcg, L["gate"].mul1)
+            ext.silu_mul(self.g, self.u, self.a)
+            L["down"].bc.run(self.a, self.d)
+            be.all_reduce(self.d)
+            pending = self.d
+        ext.rms_norm_res_in(pending, self.final_norm, self.xn, x, self.eps)
+        self.lm_head.bc.run(self.xn, self.logits)
+        return self.logits
+
+    def gemv_launches_per_step(self):
+        """(k, n_total, count) of every quantized-GEMV launch of one decode step, for the roofline accounting."""
+        s, hd = self.shape, self.shape.head_dim
+        per_layer = [(s.hidden, (self.hq + 2 * self.hkv) * hd), (self.hq * hd, s.hidden),
+                     (s.hidden, 2 * self.inter_local), (self.inter_local, s.hidden)]
+        return [(k, n, self.n_layers) for (k, n) in per_layer] + [(s.hidden, self.vocab_local, 1)]
+
+    # ---- one prefill chunk -----------------------------------------------------------------------------
+    def prefill_chunk(self, tokens: int):
+        """All linears + norms + rope + KV-quant of a `tokens`-token chunk (bsz 1); attention core out of scope.
+        rows > 144 -> reconstruct_had_slice + hgemm (modules/quant/exl3.py:161-218)."""
+        s, hd, dev = self.shape, self.shape.head_dim, self.device
+        if getattr(self, "_pf_tokens", None) != tokens:
+            self.px0 = torch.randn((tokens, s.hidden), device=dev).half()
+            self._pf_tokens = tokens
+            G = self.hkv * hd // 32
+            pages = (tokens + self.page - 1) // self.page
+            self.pf_bt = torch.arange(pages, dtype=torch.int32, device=dev).view(1, pages)
+            self.pf_sl = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self.pf_cache = [torch.zeros((pages, self.page, G * self.kv_bits), dtype=torch.int32, device=dev) for _ in range(2)] + \
+                            [torch.zeros((pages, self.page, G), dtype=torch.half, device=dev) for _ in range(2)]
+        x = self.px0.clone()
+        be = self.backend
+        xn = torch.empty_like(x)
+        for L in self.layers:
+            ext.rms_norm(x, L["norm1"], xn, self.eps)
+            q = L["q"].forward(xn).view(1, tokens, self.hq, hd)
+            k = L["k"].forward(xn).view(1, tokens, self.hkv, hd)
+            v = L["v"].forward(xn).view(1, tokens, self.hkv, hd)
+            ext.rope(q, q, k, k, self.inv_freq, 0, None, None, 2, 1.0)
+            ext.quant_cache_paged(k.view(1, tokens, -1), self.pf_cache[0], self.pf_cache[2], v.view(1, tokens, -1), self.pf_cache[1],
+                                  self.pf_cache[3], self.pf_sl, self.pf_bt, self.page, tokens)
+            o = L["o"].forward(q.view(tokens, -1))
+            be.all_reduce(o)
+            ext.rms_norm_res_in(o, L["norm2"], xn, x, self.eps)
+            g = L["gate"].forward(xn)
+            u = L["up"].forward(xn)
+            a = torch.empty_like(g)
+            ext.silu_mul(g, u, a)
+            d = L["down"].forward(a)
+            be.all_reduce(d)
+            ext.add(x, d)
+        ext.rms_norm(x[-1:], self.final_norm, xn[-1:], self.eps)
+        return self.lm_head.forward(xn[-1:].contiguous())
