@@ -101,3 +101,4 @@ def _declare(l):
     sig("exl3_add", vp, vp, i64, i32, i32, vp)
     sig("exl3_set_gemv_variant", i32)
     sig("exl3_set_gemv_gen", i32)
+    sig("exl3_set_gemv_max_waves", i32)

@@ -427,6 +427,8 @@ static int gemv_gen()
 }
 
 extern "C" int exl3_set_gemv_gen(int v) { g_gemv_gen = (v == 1) ? 1 : 2; return EXL3_OK; }
+static int g_gemv_nwv = 0;           // 0 = heuristic; otherwise cap on waves per workgroup (tuning / tests)
+extern "C" int exl3_set_gemv_max_waves(int v) { g_gemv_nwv = v; return EXL3_OK; }
 
 
 static int gemv_variant()
@@ -454,16 +456,22 @@ static int choose_split(int gen, int total_colblocks, int k, int m, int num_cus,
     const int nb = k / 128;
     int S;
     if (force_split > 0) S = force_split;
+    else if (gen == 2)
+    {
+        // gen 2: a workgroup is up to 16 waves that split its k-slice, so one workgroup per CU already fills the CU.
+        // Split k across workgroups only until every CU has one (no reduce launch when the column blocks suffice).
+        if (4 * total_colblocks >= 3 * num_cus) S = 1;
+        else S = (num_cus + total_colblocks - 1) / total_colblocks;
+    }
     else
     {
-        // aim for >= 4 workgroups per CU in flight
+        // gen 1: aim for >= 4 workgroups per CU in flight, >= 2 Hadamard blocks per slice
         int target = 4 * num_cus;
         S = (target + total_colblocks - 1) / total_colblocks;
-        // gen 1: >= 2 Hadamard blocks per slice; gen 2: >= 4 (one per wave)
-        int maxS = nb / (gen == 2 ? 4 : 2); if (maxS < 1) maxS = 1;
+        int maxS = nb / 2; if (maxS < 1) maxS = 1;
         if (S > maxS) S = maxS;
-        if (S < 1) S = 1;
     }
+    if (S < 1) S = 1;
     if (S > nb) S = nb;
     int blocks_per_slice = (nb + S - 1) / S;
     if (gen == 1)
@@ -539,17 +547,21 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         if (gen == 2)
         {
             const int ng = mp <= 4 ? 1 : (mp <= 8 ? 2 : 4);
-            const size_t lds = exl3_gemv2_lds_bytes(ng, var, cb);
+            int nwv = 16 / ng;                                   // partial-sum LDS: nwv * 4*ng rows * 512 B <= 32 KB
+            if (nwv > bps) nwv = bps;                            // every wave gets at least one Hadamard block
+            if (g_gemv_nwv > 0 && nwv > g_gemv_nwv) nwv = g_gemv_nwv;
+            if (nwv < 1) nwv = 1;
+            const size_t lds = exl3_gemv2_lds_bytes(ng, var, cb, nwv);
             switch (K)
             {
-                case 1: exl3_gemv2_launch_k1(cb, var, ng, grid, lds, st, args); break;
-                case 2: exl3_gemv2_launch_k2(cb, var, ng, grid, lds, st, args); break;
-                case 3: exl3_gemv2_launch_k3(cb, var, ng, grid, lds, st, args); break;
-                case 4: exl3_gemv2_launch_k4(cb, var, ng, grid, lds, st, args); break;
-                case 5: exl3_gemv2_launch_k5(cb, var, ng, grid, lds, st, args); break;
-                case 6: exl3_gemv2_launch_k6(cb, var, ng, grid, lds, st, args); break;
-                case 7: exl3_gemv2_launch_k7(cb, var, ng, grid, lds, st, args); break;
-                case 8: exl3_gemv2_launch_k8(cb, var, ng, grid, lds, st, args); break;
+                case 1: exl3_gemv2_launch_k1(cb, var, ng, nwv, grid, lds, st, args); break;
+                case 2: exl3_gemv2_launch_k2(cb, var, ng, nwv, grid, lds, st, args); break;
+                case 3: exl3_gemv2_launch_k3(cb, var, ng, nwv, grid, lds, st, args); break;
+                case 4: exl3_gemv2_launch_k4(cb, var, ng, nwv, grid, lds, st, args); break;
+                case 5: exl3_gemv2_launch_k5(cb, var, ng, nwv, grid, lds, st, args); break;
+                case 6: exl3_gemv2_launch_k6(cb, var, ng, nwv, grid, lds, st, args); break;
+                case 7: exl3_gemv2_launch_k7(cb, var, ng, nwv, grid, lds, st, args); break;
+                case 8: exl3_gemv2_launch_k8(cb, var, ng, nwv, grid, lds, st, args); break;
             }
         }
         else

@@ -115,7 +115,7 @@ __device__ __forceinline__ void load_lane_words(LaneWords<K>& d, const uint32_t*
 }
 
 template <int K, int CB, int VAR, int NG>
-__global__ __launch_bounds__(GEMV_THREADS)
+__global__ __launch_bounds__(1024)
 void exl3_gemv2_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -143,14 +143,15 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const int k0s = s * a.kslice;
     const int k1s = min(k0s + a.kslice, a.k);
     const int nb = (k1s - k0s) >> 7;                 // 128-blocks in the workgroup's slice
-    const int b0 = (nb * wave) >> 2, b1 = (nb * (wave + 1)) >> 2;
+    const int nwv = blockDim.x >> 6;                 // waves per workgroup (4..16): they split the slice's blocks
+    const int b0 = (nb * wave) / nwv, b1 = (nb * (wave + 1)) / nwv;
     const int nbw = b1 - b0;                         // blocks of this wave (may be 0)
     const int k0 = k0s + 128 * b0;
 
     // LDS carve: per-wave fragment double buffer | per-wave row sums | partials [4][MR][128]
     constexpr int FRAG_HALVES = 2 * 8 * MR * AH;
     half_t* xa = (half_t*) smem + (size_t) wave * FRAG_HALVES;
-    float* part = (float*) (smem + (size_t) 4 * FRAG_HALVES * 2);
+    float* part = (float*) (smem + (size_t) nwv * FRAG_HALVES * 2);
 
     // ---- just-in-time input Hadamard of one 128-block into fragment buffer `buf`
     float rowsum[2 * NG];
@@ -289,7 +290,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
     if constexpr (RAW)
     {
         // row sums live in lane 0 / lane 32 of the wave (rows 2p / 2p+1): publish through the partial area
-        float* sx = part + (size_t) 4 * MR * 128 + wave * MR;
+        float* sx = part + (size_t) nwv * MR * 128 + wave * MR;
         #pragma unroll
         for (int p = 0; p < 2 * NG; ++p) if (l32 == 0 && 2 * p + hw < MR) sx[2 * p + hw] = rowsum[p];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -328,12 +329,15 @@ void exl3_gemv2_kernel(const GemvArgs a)
     if (a.S > 1)
     {
         float* slab = a.workspace + a.mat[mi].ws_offset + ((size_t) cbl * a.S + s) * (size_t) m * 128;
-        for (int row = hw8; row < m; row += 8)
+        for (int row = hw8; row < m; row += nwv * 2)
         {
             const float* p0 = part + row * 128;
-            float4_t v0 = ((const float4_t*) p0)[l], v1 = ((const float4_t*) (p0 + wstride))[l];
-            float4_t v2 = ((const float4_t*) (p0 + 2 * wstride))[l], v3 = ((const float4_t*) (p0 + 3 * wstride))[l];
-            float4_t v = { (v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y), (v0.z + v1.z) + (v2.z + v3.z), (v0.w + v1.w) + (v2.w + v3.w) };
+            float4_t v = ((const float4_t*) p0)[l];
+            for (int w = 1; w < nwv; ++w)
+            {
+                float4_t t = ((const float4_t*) (p0 + w * wstride))[l];
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
             ((float4_t*) (slab + row * 128))[l] = v;
         }
         return;
@@ -341,15 +345,18 @@ void exl3_gemv2_kernel(const GemvArgs a)
 
     const half_t* svh = a.mat[mi].svh + cbl * 128;
     const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
-    for (int base = 0; base < m; base += 8)
+    for (int base = 0; base < m; base += nwv * 2)
     {
         int row = base + hw8;
         bool act = row < m;
         const float* p0 = part + (act ? row : 0) * 128;
-        float4_t v0 = ((const float4_t*) p0)[l], v1 = ((const float4_t*) (p0 + wstride))[l];
-        float4_t v2 = ((const float4_t*) (p0 + 2 * wstride))[l], v3 = ((const float4_t*) (p0 + 3 * wstride))[l];
-        float h0 = (v0.x + v1.x) + (v2.x + v3.x), h1 = (v0.y + v1.y) + (v2.y + v3.y);
-        float h2 = (v0.z + v1.z) + (v2.z + v3.z), h3 = (v0.w + v1.w) + (v2.w + v3.w);
+        float4_t v = ((const float4_t*) p0)[l];
+        for (int w = 1; w < nwv; ++w)
+        {
+            float4_t t = ((const float4_t*) (p0 + w * wstride))[l];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
         had128_f32x4(h0, h1, h2, h3, l);
         h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
         if (!act) continue;
@@ -379,9 +386,9 @@ void exl3_gemv2_kernel(const GemvArgs a)
 #endif
 
 template <int CB>
-static void launch_cb(int var, int ng, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+static void launch_cb(int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
-    #define L(V, N) exl3_gemv2_kernel<G2_K, CB, V, N><<<grid, dim3(GEMV_THREADS), lds, st>>>(args)
+    #define L(V, N) exl3_gemv2_kernel<G2_K, CB, V, N><<<grid, dim3(64 * nwv), lds, st>>>(args)
     if (var == 0) { if (ng == 1) L(0, 1); else if (ng == 2) L(0, 2); else L(0, 4); }
     else          { if (ng == 1) L(1, 1); else if (ng == 2) L(1, 2); else L(1, 4); }
     #undef L
@@ -390,20 +397,20 @@ static void launch_cb(int var, int ng, dim3 grid, size_t lds, hipStream_t st, co
 #define G2_CAT_(a, b) a##b
 #define G2_CAT(a, b) G2_CAT_(a, b)
 
-void G2_CAT(exl3_gemv2_launch_k, G2_K)(int cb, int var, int ng, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+void G2_CAT(exl3_gemv2_launch_k, G2_K)(int cb, int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
-    if (cb == 0) launch_cb<0>(var, ng, grid, lds, st, args);
-    else if (cb == 1) launch_cb<1>(var, ng, grid, lds, st, args);
-    else launch_cb<2>(var, ng, grid, lds, st, args);
+    if (cb == 0) launch_cb<0>(var, ng, nwv, grid, lds, st, args);
+    else if (cb == 1) launch_cb<1>(var, ng, nwv, grid, lds, st, args);
+    else launch_cb<2>(var, ng, nwv, grid, lds, st, args);
 }
 
 #if G2_K == 4
-size_t exl3_gemv2_lds_bytes(int ng, int var, int cb)
+size_t exl3_gemv2_lds_bytes(int ng, int var, int cb, int nwv)
 {
     const int MR = 4 * ng;
     const int AH = (var == 1 && cb != 2) ? 32 : 16;
-    size_t frag = (size_t) 4 * (2 * 8 * MR * AH) * 2;
-    size_t part = (size_t) 4 * MR * 128 * 4 + (size_t) 4 * MR * 4;
+    size_t frag = (size_t) nwv * (2 * 8 * MR * AH) * 2;
+    size_t part = (size_t) nwv * MR * 128 * 4 + (size_t) nwv * MR * 4;
     return frag + part;
 }
 #endif

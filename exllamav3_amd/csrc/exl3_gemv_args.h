@@ -32,7 +32,7 @@ struct GemvArgs
 };
 
 // generation-2 kernels: one translation unit per K (exl3_gemv2.kspec.hip compiled with -DG2_K=1..8)
-size_t exl3_gemv2_lds_bytes(int ng, int var, int cb);
-#define G2_DECL(KK) void exl3_gemv2_launch_k##KK(int cb, int var, int ng, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args);
+size_t exl3_gemv2_lds_bytes(int ng, int var, int cb, int nwv);
+#define G2_DECL(KK) void exl3_gemv2_launch_k##KK(int cb, int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args);
 G2_DECL(1) G2_DECL(2) G2_DECL(3) G2_DECL(4) G2_DECL(5) G2_DECL(6) G2_DECL(7) G2_DECL(8)
 #undef G2_DECL

@@ -73,6 +73,11 @@ def set_gemv_gen(g: int):
     _lib.lib().exl3_set_gemv_gen(int(g))
 
 
+def set_gemv_max_waves(n: int):
+    """Cap on waves per workgroup of the gen-2 GEMV (0 = heuristic, up to 16)."""
+    _lib.lib().exl3_set_gemv_max_waves(int(n))
+
+
 # --------------------------------------------------------------------------------------------------
 # format ops
 # --------------------------------------------------------------------------------------------------

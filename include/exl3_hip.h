@@ -93,6 +93,7 @@ int exl3_mgemm(const void* A, const void* const* Bs, void* const* Cs, const void
  * gen 1 = 16x16x32-MFMA kernel, 2 = column-pair-per-lane kernel (default). */
 int exl3_set_gemv_variant(int variant);
 int exl3_set_gemv_gen(int gen);
+int exl3_set_gemv_max_waves(int max_waves_per_workgroup);   /* 0 = heuristic (up to 16) */
 
 /* hgemm(a, b, c)      hgemm.cu:19-102:  c[m][n] (row stride ldc elements, fp16 or fp32) = a[m][k] @ b[k][n], fp32 accumulate.
  * m, k, n arbitrary multiples of 16/32/16. */

@@ -144,3 +144,17 @@ def test_graph_capture_replay(dev):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(y, expect)
+
+
+@pytest.mark.parametrize("max_waves", [1, 3, 4, 7, 16])
+def test_gen2_waves_per_workgroup(dev, max_waves):
+    """gen 2 lets up to 16 waves split a workgroup's k-slice (uneven block counts, waves without work)."""
+    from exllamav3_amd import ext
+    ext.set_gemv_max_waves(max_waves)
+    try:
+        for (k, n, m, split) in [(4096, 256, 1, 1), (1664, 128, 2, 1), (14336, 128, 1, 0), (2048, 384, 16, 2), (1024, 128, 9, 1)]:
+            for cb in (0, 2):
+                assert _run(dev, k, n, 4, cb, m, 1, force_split=split, gen=2) < TOL
+        assert _run(dev, 4096, 256, 3, 1, 4, 0, force_split=1, gen=2) < TOL
+    finally:
+        ext.set_gemv_max_waves(0)
