@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--prefill-tokens", type=int, default=4096)
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--gen", type=int, default=2)
+    ap.add_argument("--unfused", action="store_true", help="one launch per reference op instead of the fused glue pipeline")
     return ap.parse_args()
 
 
@@ -104,7 +105,9 @@ def main():
     model.alloc_state(args.batch)
 
     # ---- decode: eager warm-up (also creates library contexts), graph capture, timed replays
-    model.decode_step()
+    fused = not args.unfused
+    run_step = model.decode_step_fused if fused else model.decode_step
+    run_step()
     torch.cuda.synchronize()
     graph = None
     if not args.no_graph:
@@ -112,11 +115,11 @@ def main():
             st = torch.cuda.Stream()
             st.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st):
-                model.decode_step()
+                run_step()
                 st.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=st):
-                    model.decode_step()
+                    run_step()
             torch.cuda.synchronize()
         except Exception as e:          # e.g. a collective that cannot be captured: fall back to eager launches
             if rank == 0:
@@ -128,7 +131,7 @@ def main():
         if graph is not None:
             graph.replay()
         else:
-            model.decode_step()
+            run_step()
 
     for _ in range(args.warmup):
         step()
@@ -150,26 +153,18 @@ def main():
     # ---- roofline leg: every fused-GEMV launch of a decode step, bracketed by HIP events on the launch stream
     roofline = None
     if rank == 0 or world > 1:
-        import itertools
         evs = []
-        L0 = model.layers
         def timed(fn):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record(); fn(); e1.record()
             evs.append((e0, e1))
         bsz = args.batch
-        q2, k2, v2 = model.q.view(bsz, -1), model.k.view(bsz, -1), model.v.view(bsz, -1)
+        calls = model.gemv_calls(fused)
         reps = 3
         empty = []
         for rep in range(reps):
-            for L in L0:
-                timed(lambda: ext.exl3_mgemm_bcast(model.xn, [L["q"].trellis, L["k"].trellis, L["v"].trellis], [q2, k2, v2],
-                                                   [L["q"].suh, L["k"].suh, L["v"].suh], [L["q"].svh, L["k"].svh, L["v"].svh], L["q"].mcg, L["q"].mul1))
-                timed(lambda: L["o"].bc.run(q2, model.o))
-                timed(lambda: ext.exl3_mgemm_bcast(model.xn, [L["gate"].trellis, L["up"].trellis], [model.g, model.u],
-                                                   [L["gate"].suh, L["up"].suh], [L["gate"].svh, L["up"].svh], L["gate"].mcg, L["gate"].mul1))
-                timed(lambda: L["down"].bc.run(model.a, model.d))
-            timed(lambda: model.lm_head.bc.run(model.xn, model.logits))
+            for c in calls:
+                timed(c)
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record(); e1.record(); empty.append((e0, e1))
         torch.cuda.synchronize()
@@ -195,7 +190,7 @@ def main():
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": traffic, "avg_launch_us": round(avg_us, 2), "bytes_per_launch": int(bytes_per_launch),
                     "launches_per_step": launches_step, "event_pair_overhead_us": round(ov, 2),
-                    "note": "event-bracketed eager launches (includes dispatch latency and the split-k reduce launch); "
+                    "note": "event-bracketed eager launches (includes dispatch latency" + ("" if fused else " and the split-k reduce launch") + "); "
                             "compare profiles/ for rocprofv3 kernel-only durations"}
 
     # ---- prefill leg (single GPU): one chunk through the same linears
@@ -229,7 +224,8 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{shape.name} EXL3 {args.bits}.0bpw {args.codebook} codebook, decode bs={args.batch}, "
                                    f"{model.n_layers} layers, TP={world}, {args.kv_bits}-bit KV append, "
-                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}; attention core excluded (SURVEY.md 2.1)",
+                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, {'fused glue pipeline (8 launches/layer)' if fused else 'one launch per reference op'}; "
+                                   f"attention core excluded (SURVEY.md 2.1)",
                        "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
                        "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),
                        "parallelism": f"tp{world}", "gemv_variant": args.variant, "gemv_gen": args.gen},

@@ -99,6 +99,12 @@ def _declare(l):
     sig("exl3_dequant_cache_paged", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_silu_mul", vp, vp, vp, i64, i32, vp)
     sig("exl3_add", vp, vp, i64, i32, i32, vp)
+    PP = ctypes.POINTER(vp)
+    sig("exl3_gemv_ex", vp, PP, PP, PP, PP, PP, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
+    sig("exl3_glue_norm", vp, i32, vp, vp, vp, vp, vp, f32, PP, PP, PP, i32, i32, i32, vp, vp)
+    sig("exl3_glue_qkv", vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp)
+    sig("exl3_glue_act", vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp)
     sig("exl3_set_gemv_variant", i32)
     sig("exl3_set_gemv_gen", i32)
     sig("exl3_set_gemv_max_waves", i32)
+    sig("exl3_set_gemv_defer_wg_per_cu", i32)

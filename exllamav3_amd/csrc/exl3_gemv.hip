@@ -428,6 +428,8 @@ static int gemv_gen()
 
 extern "C" int exl3_set_gemv_gen(int v) { g_gemv_gen = (v == 1) ? 1 : 2; return EXL3_OK; }
 static int g_gemv_nwv = 0;           // 0 = heuristic; otherwise cap on waves per workgroup (tuning / tests)
+static int g_gemv_defer_wg_per_cu = 0;
+extern "C" int exl3_set_gemv_defer_wg_per_cu(int v) { g_gemv_defer_wg_per_cu = v; return EXL3_OK; }
 extern "C" int exl3_set_gemv_max_waves(int v) { g_gemv_nwv = v; return EXL3_OK; }
 
 
@@ -490,19 +492,23 @@ static int choose_split(int gen, int total_colblocks, int k, int m, int num_cus,
 
 static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, const void* const* suhs, const void* const* svhs,
                      const void* const* biases, const int* ns, int count, int m, int k, int K, int cb, int c_fp32,
-                     int force_split, hipStream_t st)
+                     int force_split, hipStream_t st, int flags = 0, const void* const* xhs = nullptr, const float* const* xsums = nullptr,
+                     float** slabs_out = nullptr, int* S_out = nullptr)
 {
+    const bool deferred = (flags & GEMV_OUT_DEFERRED) != 0, rotated = (flags & GEMV_IN_ROTATED) != 0;
+    EXL3_CHECK_ARG(!(deferred || rotated) || m <= 16, "exl3_gemv_ex: at most 16 rows");
+    EXL3_CHECK_ARG(!rotated || xhs, "exl3_gemv_ex: rotated input requires xh pointers");
     EXL3_CHECK_ARG(count >= 1 && count <= GEMV_MAX_MATS, "exl3_mgemm: between 1 and %d matrices per launch", GEMV_MAX_MATS);
     EXL3_CHECK_ARG(K >= 1 && K <= 8, "exl3_gemm: K must be in [1, 8]");
     EXL3_CHECK_ARG(cb >= 0 && cb <= 2, "exl3_gemm: bad codebook");
     EXL3_CHECK_ARG(k % 128 == 0 && k > 0, "exl3_gemm: k must be divisible by 128");
     EXL3_CHECK_ARG(m >= 1, "exl3_gemm: m must be >= 1");
-    EXL3_CHECK_ARG(A, "exl3_gemm: null A");
+    EXL3_CHECK_ARG(A || rotated, "exl3_gemm: null A");
     int total_cb = 0;
     for (int i = 0; i < count; ++i)
     {
         EXL3_CHECK_ARG(ns[i] % 128 == 0 && ns[i] > 0, "exl3_gemm: n must be divisible by 128");
-        EXL3_CHECK_ARG(Bs[i] && Cs[i] && suhs[i] && svhs[i], "exl3_gemm: null pointer");
+        EXL3_CHECK_ARG(Bs[i] && (deferred || (Cs && Cs[i] && svhs && svhs[i])) && (rotated || (suhs && suhs[i])), "exl3_gemm: null pointer");
         total_cb += ns[i] / 128;
     }
     Exl3DevCtx* ctx = exl3_get_ctx(st);
@@ -514,25 +520,38 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         const int mp = (m - m0) < 16 ? (m - m0) : 16;
         GemvArgs args;
         memset((void*) &args, 0, sizeof(args));
-        const int gen = gemv_gen();
-        const int S = choose_split(gen, total_cb, k, mp, ctx->num_cus, force_split);
+        const int gen = (deferred || rotated) ? 2 : gemv_gen();
+        int fs = force_split;
+        if (deferred && fs == 0)
+        {
+            // deferred epilogue: the reduction is free (a glue kernel does it), so split k until ~2 workgroups per CU
+            fs = (2 * ctx->num_cus + total_cb - 1) / total_cb;
+            if (g_gemv_defer_wg_per_cu > 0) fs = (g_gemv_defer_wg_per_cu * ctx->num_cus + total_cb - 1) / total_cb;
+            if (fs < 1) fs = 1;
+        }
+        const int S = choose_split(gen, total_cb, k, mp, ctx->num_cus, fs);
         const int nb = k / 128;
         const int bps = (nb + S - 1) / S;
         int cbf = 0; int64_t wso = 0;
         for (int i = 0; i < count; ++i)
         {
             args.mat[i].B = (const uint32_t*) Bs[i];
-            args.mat[i].suh = (const half_t*) suhs[i];
-            args.mat[i].svh = (const half_t*) svhs[i];
+            args.mat[i].suh = suhs ? (const half_t*) suhs[i] : nullptr;
+            args.mat[i].svh = svhs ? (const half_t*) svhs[i] : nullptr;
             args.mat[i].bias = biases ? (const half_t*) biases[i] : nullptr;
-            args.mat[i].C = Cs[i];
+            args.mat[i].C = Cs ? Cs[i] : nullptr;
+            args.mat[i].xh = xhs ? (const half_t*) xhs[i] : nullptr;
+            args.mat[i].xsum = xsums ? xsums[i] : nullptr;
+            if (slabs_out) slabs_out[i] = ctx->workspace + wso;
             args.mat[i].n = ns[i];
             args.mat[i].cb_first = cbf;
             args.mat[i].ws_offset = (int) wso;
             cbf += ns[i] / 128;
             wso += (int64_t) (ns[i] / 128) * S * mp * 128;
         }
-        EXL3_CHECK_ARG(S == 1 || wso * 4 <= EXL3_WORKSPACE_BYTES, "exl3_gemm: split-k workspace too small");
+        EXL3_CHECK_ARG((S == 1 && !deferred) || wso * 4 <= EXL3_WORKSPACE_BYTES, "exl3_gemm: split-k workspace too small");
+        if (S_out) *S_out = S;
+        args.flags = flags;
         args.A = (const half_t*) A + (size_t) m0 * k;
         args.workspace = ctx->workspace;
         args.num_mats = count;
@@ -579,7 +598,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         }
         int rc = exl3_check_launch("exl3_gemv");
         if (rc) return rc;
-        if (S > 1)
+        if (S > 1 && !deferred)
         {
             int64_t items = (int64_t) total_cb * mp;
             exl3_gemv_reduce_kernel<<<dim3((unsigned) ((items + 7) / 8)), dim3(256), 0, st>>>(args, total_cb);
@@ -603,4 +622,15 @@ extern "C" int exl3_mgemm(const void* A, const void* const* Bs, void* const* Cs,
 {
     EXL3_CHECK_ARG(Bs && Cs && suhs && svhs && ns, "exl3_mgemm: null table");
     return run_mgemm(A, Bs, Cs, suhs, svhs, nullptr, ns, count, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream);
+}
+
+// Extended launch used by the fused decode pipeline (exl3_glue.hip): optional pre-rotated inputs per matrix and/or deferred
+// epilogue (raw fp32 partial slabs left in the per-device workspace for a glue kernel).  slabs_out[i] receives the device
+// pointer of matrix i's slabs [n_i/128][S][m][128]; *S_out the split count.
+extern "C" int exl3_gemv_ex(const void* A, const void* const* xhs, const float* const* xsums, const void* const* Bs, void* const* Cs,
+                            const void* const* suhs, const void* const* svhs, const void* const* biases, const int* ns, int count,
+                            int m, int k, int K, int cb, int c_fp32, int flags, int force_split, float** slabs_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(Bs && ns, "exl3_gemv_ex: null table");
+    return run_mgemm(A, Bs, Cs, suhs, svhs, biases, ns, count, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream, flags, xhs, xsums, slabs_out, S_out);
 }

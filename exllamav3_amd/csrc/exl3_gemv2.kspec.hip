@@ -158,6 +158,9 @@ void exl3_gemv2_kernel(const GemvArgs a)
     #pragma unroll
     for (int i = 0; i < 2 * NG; ++i) rowsum[i] = 0.0f;
     const int l32 = lane & 31, hw = lane >> 5;
+    const bool in_rotated = (a.flags & GEMV_IN_ROTATED) != 0;
+    const half_t* __restrict__ xh_in = a.mat[mi].xh;
+    const float* __restrict__ xsum_in = a.mat[mi].xsum;
     auto prep_block = [&] (int blk, int buf)
     {
         #pragma unroll
@@ -167,19 +170,30 @@ void exl3_gemv2_kernel(const GemvArgs a)
             if (2 * p >= m) break;                                      // wave-uniform
             const bool act = row < m;
             const size_t off = (size_t) (act ? row : 0) * a.k + k0 + 128 * blk;
-            half4_t xv = ((const half4_t*) (a.A + off))[l32];
-            half4_t sv = ((const half4_t*) (suh + k0 + 128 * blk))[l32];
-            xv = xv * sv;
-            float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
-            had128_f32x4(h0, h1, h2, h3, l32);
-            half2_t o01 = { (half_t) (h0 * HAD_R_SCALE_128), (half_t) (h1 * HAD_R_SCALE_128) };
-            half2_t o23 = { (half_t) (h2 * HAD_R_SCALE_128), (half_t) (h3 * HAD_R_SCALE_128) };
-            if constexpr (RAW)
+            half2_t o01, o23;
+            if (in_rotated)
             {
-                float t = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
-                #pragma unroll
-                for (int i = 1; i < 32; i <<= 1) t += __shfl_xor(t, i, 64);
-                if (act) rowsum[p] += t;
+                // producer already applied suh + Hadamard (and rounded to fp16): just fetch the 4 values of this lane
+                half4_t xv = ((const half4_t*) (xh_in + off))[l32];
+                o01 = half2_t{ xv.x, xv.y }; o23 = half2_t{ xv.z, xv.w };
+                if constexpr (RAW) { if (act) rowsum[p] += xsum_in[(size_t) row * (a.k >> 7) + (k0 >> 7) + blk]; }
+            }
+            else
+            {
+                half4_t xv = ((const half4_t*) (a.A + off))[l32];
+                half4_t sv = ((const half4_t*) (suh + k0 + 128 * blk))[l32];
+                xv = xv * sv;
+                float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
+                had128_f32x4(h0, h1, h2, h3, l32);
+                o01 = half2_t{ (half_t) (h0 * HAD_R_SCALE_128), (half_t) (h1 * HAD_R_SCALE_128) };
+                o23 = half2_t{ (half_t) (h2 * HAD_R_SCALE_128), (half_t) (h3 * HAD_R_SCALE_128) };
+                if constexpr (RAW)
+                {
+                    float t = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
+                    #pragma unroll
+                    for (int i = 1; i < 32; i <<= 1) t += __shfl_xor(t, i, 64);
+                    if (act) rowsum[p] += t;
+                }
             }
             if (act)
             {
@@ -326,7 +340,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
 
     const int l = tid & 31, hw8 = tid >> 5;
     const size_t wstride = (size_t) MR * 128;
-    if (a.S > 1)
+    if (a.S > 1 || (a.flags & GEMV_OUT_DEFERRED))
     {
         float* slab = a.workspace + a.mat[mi].ws_offset + ((size_t) cbl * a.S + s) * (size_t) m * 128;
         for (int row = hw8; row < m; row += nwv * 2)

@@ -3,6 +3,8 @@
 #include "exl3_common.cuh"
 
 #define GEMV_THREADS 256
+#define GEMV_IN_ROTATED   1   // the input Hadamard was applied by the producer (glue kernel): mat[i].xh / xsum
+#define GEMV_OUT_DEFERRED 2   // write raw rotated-basis partial slabs [colblock][S][m][128] fp32; a glue kernel finishes
 #define GEMV_MAX_MATS 4
 
 struct GemvMat
@@ -12,6 +14,8 @@ struct GemvMat
     const half_t* svh;
     const half_t* bias;
     void* C;
+    const half_t* xh;      // optional pre-rotated input [m][k] fp16 = had128(x * suh) (flags & GEMV_IN_ROTATED)
+    const float* xsum;     // optional per-128-block sums of xh [m][k/128] fp32 (needed by the cb2 FAST variant)
     int n;
     int cb_first;          // first column block of this matrix in the flattened grid
     int ws_offset;         // float offset of this matrix's slabs in the workspace
@@ -28,6 +32,7 @@ struct GemvArgs
     int S;                 // k-slices
     int kslice;            // elements per slice (multiple of 128)
     int c_fp32;
+    int flags;             // GEMV_IN_ROTATED | GEMV_OUT_DEFERRED
     int64_t c_row_offset;  // first output row of this pass
 };
 

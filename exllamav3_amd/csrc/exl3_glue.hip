@@ -1,0 +1,390 @@
+// "Glue" kernels of the fused decode step (m <= 16 rows): everything between two quantized GEMVs of a Llama layer in ONE
+// launch each.  The GEMVs run with a deferred epilogue (raw rotated-basis fp32 partial slabs [colblock][S][m][128] in the
+// per-device workspace) and pre-rotated inputs, so each glue kernel
+//     reduces the split-k slabs -> output Hadamard * svh (+bias) -> op-specific middle -> (x * suh) input Hadamard of the
+//     NEXT linear(s) + per-block sums
+// and replaces what the reference runs as separate graph nodes inside its BC_* runners: the split-k hand-off + output
+// Hadamard of exl3_gemm, rms_norm / rms_norm_res_in, rope, quant_cache_paged, silu_mul and the input Hadamard
+// (libtorch/attention.cpp:246-504, libtorch/mlp.cpp:14-91, quant/hadamard_inner.cuh:283-413 fuses the last two as well).
+// At batch 1 every one of those is a ~4.5 us latency-bound launch on MI355X (profiles/r01_bench_decode_kernel_stats.csv);
+// a 128-wide Hadamard block is handled by one 32-lane half-wave with 4 values per lane, so all of this is register work.
+//
+// Rounding points follow the unfused ops exactly (they are the same device functions), so fused and unfused pipelines agree
+// to fp32 summation order.
+#include "exl3_common.cuh"
+#include "exl3_api_internal.h"
+
+struct SlabRef { const float* base; int S; };       // slab(c, s, row) = base + ((c*S + s)*m + row)*128
+
+__device__ __forceinline__ float4_t slab_sum(const SlabRef& sr, int c, int row, int m, int l)
+{
+    const float* p = sr.base + ((size_t) c * sr.S * m + row) * 128;
+    float4_t v = ((const float4_t*) p)[l];
+    for (int s = 1; s < sr.S; ++s)
+    {
+        float4_t t = ((const float4_t*) (p + (size_t) s * m * 128))[l];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    return v;
+}
+
+// out-Hadamard of a reduced block -> fp32 (h *= 1/sqrt(128)); caller applies svh in the dtype of the logical output
+__device__ __forceinline__ void out_had(float4_t v, int l, float& h0, float& h1, float& h2, float& h3)
+{
+    h0 = v.x; h1 = v.y; h2 = v.z; h3 = v.w;
+    had128_f32x4(h0, h1, h2, h3, l);
+    h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
+}
+
+// input Hadamard of the next linear: xh = fp16(had(fp16 x * suh) / sqrt(128)); returns the block sum of the fp16 outputs
+__device__ __forceinline__ float in_had_store(half4_t x, const half_t* __restrict__ suh_blk, half_t* __restrict__ xh_blk, int l, bool act)
+{
+    half4_t sv = ((const half4_t*) suh_blk)[l];
+    half4_t t = x * sv;
+    float h0 = (float) t.x, h1 = (float) t.y, h2 = (float) t.z, h3 = (float) t.w;
+    had128_f32x4(h0, h1, h2, h3, l);
+    half4_t o = { (half_t) (h0 * HAD_R_SCALE_128), (half_t) (h1 * HAD_R_SCALE_128), (half_t) (h2 * HAD_R_SCALE_128), (half_t) (h3 * HAD_R_SCALE_128) };
+    float sum = ((float) o.x + (float) o.y) + ((float) o.z + (float) o.w);
+    #pragma unroll
+    for (int i = 1; i < 32; i <<= 1) sum += __shfl_xor(sum, i, 64);
+    if (act) ((half4_t*) xh_blk)[l] = o;
+    return sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// G1: [reduce + out-had + svh (+bias)] -> residual += y -> RMSNorm -> in-had for up to 3 next linears.  Single workgroup.
+//     y is the fp32 output of o_proj / down_proj (architecture/llama.py:95,111 out_dtype float); the residual stream is fp16.
+//     has_y == 0: first layer, no pending sublayer output (plain rms_norm of the residual).
+// ------------------------------------------------------------------------------------------------
+struct NormTargets { const half_t* suh[3]; half_t* xh[3]; float* xsum[3]; int count; };
+
+__global__ __launch_bounds__(1024)
+void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, const half_t* __restrict__ svh, const half_t* __restrict__ bias,
+                      half_t* __restrict__ resid, const half_t* __restrict__ w, float eps, NormTargets tg, int m, int hidden,
+                      half_t* __restrict__ xn_out)
+{
+    __shared__ float ss_part[16 * 128];          // [row][block] partial sums of squares (hidden <= 16384)
+    __shared__ float rmf_s[16];
+    const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5, nhw = blockDim.x >> 5;
+    const int nblk = hidden >> 7;
+    const int tasks = m * nblk;
+    // phase 1: residual update + sum of squares per (row, block)
+    for (int t0 = 0; t0 < tasks; t0 += nhw)
+    {
+        const int t = t0 + hw;
+        const bool act = t < tasks;
+        const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+        half4_t r = ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
+        float r0 = (float) r.x, r1 = (float) r.y, r2 = (float) r.z, r3 = (float) r.w;
+        if (has_y)
+        {
+            float h0, h1, h2, h3;
+            if (y_dense)
+            {
+                // finished fp32 sublayer output (e.g. after a tensor-parallel all-reduce)
+                float4_t yv = ((const float4_t*) (y_dense + (size_t) row * hidden + blk * 128))[l];
+                h0 = yv.x; h1 = yv.y; h2 = yv.z; h3 = yv.w;
+            }
+            else
+            {
+                out_had(slab_sum(y, blk, row, m, l), l, h0, h1, h2, h3);
+                half4_t sc = ((const half4_t*) (svh + blk * 128))[l];
+                h0 *= (float) sc.x; h1 *= (float) sc.y; h2 *= (float) sc.z; h3 *= (float) sc.w;
+                if (bias) { half4_t b = ((const half4_t*) (bias + blk * 128))[l]; h0 += (float) b.x; h1 += (float) b.y; h2 += (float) b.z; h3 += (float) b.w; }
+            }
+            // r += y, rounded to the residual dtype (norm.cu:193-218)
+            r = half4_t{ (half_t) (r0 + h0), (half_t) (r1 + h1), (half_t) (r2 + h2), (half_t) (r3 + h3) };
+            r0 = (float) r.x; r1 = (float) r.y; r2 = (float) r.z; r3 = (float) r.w;
+            if (act) ((half4_t*) (resid + (size_t) row * hidden + blk * 128))[l] = r;
+        }
+        float ss = r0 * r0;
+        ss = __builtin_fmaf(r1, r1, ss); ss = __builtin_fmaf(r2, r2, ss); ss = __builtin_fmaf(r3, r3, ss);
+        #pragma unroll
+        for (int i = 1; i < 32; i <<= 1) ss += __shfl_xor(ss, i, 64);
+        if (act && l == 0) ss_part[row * 128 + blk] = ss;
+    }
+    __syncthreads();
+    if (tid < m)
+    {
+        float s = 0.0f;
+        for (int b = 0; b < nblk; ++b) s += ss_part[tid * 128 + b];          // fixed order: deterministic
+        rmf_s[tid] = __frsqrt_rn(s / (float) hidden + eps);
+    }
+    __syncthreads();
+    // phase 2: normalise (fp32, one rounding to fp16 like rms_norm) and rotate for every consumer
+    for (int t0 = 0; t0 < tasks; t0 += nhw)
+    {
+        const int t = t0 + hw;
+        const bool act = t < tasks;
+        const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+        half4_t r = ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
+        half4_t wv = ((const half4_t*) (w + blk * 128))[l];
+        const float rmf = rmf_s[row];
+        half4_t xn = { (half_t) ((float) r.x * (float) wv.x * rmf), (half_t) ((float) r.y * (float) wv.y * rmf),
+                       (half_t) ((float) r.z * (float) wv.z * rmf), (half_t) ((float) r.w * (float) wv.w * rmf) };
+        if (xn_out && act) ((half4_t*) (xn_out + (size_t) row * hidden + blk * 128))[l] = xn;
+        #pragma unroll
+        for (int i = 0; i < 3; ++i)
+        {
+            if (i < tg.count)
+            {
+                float sum = in_had_store(xn, tg.suh[i] + blk * 128, tg.xh[i] + (size_t) row * hidden + blk * 128, l, act);
+                if (act && l == 0 && tg.xsum[i]) tg.xsum[i][(size_t) row * nblk + blk] = sum;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G2: q/k/v epilogue per (row, head), head_dim == 128 == one Hadamard block:
+//     reduce + out-had + fp16 svh -> RoPE (NEOX or GPTJ; sin/cos once per (row, frequency) in LDS) on q and k ->
+//     q fp16 out; k, v -> quantized paged cache append (and optional fp16 copies).
+// ------------------------------------------------------------------------------------------------
+template <int BITS>
+__device__ __forceinline__ void kv_quant_regs(float v0, float v1, float v2, float v3, uint32_t* __restrict__ out, half_t* __restrict__ out_scale, bool active, int lane);
+
+__device__ __forceinline__ void kvg_had32(float& v0, float& v1, float& v2, float& v3, int lane)
+{
+    float s0 = v0 + v1, d0 = v0 - v1, s1 = v2 + v3, d1 = v2 - v3;
+    v0 = s0 + s1; v1 = d0 + d1; v2 = s0 - s1; v3 = d0 - d1;
+    #pragma unroll
+    for (int i = 1; i < 8; i <<= 1)
+    {
+        float p0 = __shfl_xor(v0, i, 64), p1 = __shfl_xor(v1, i, 64), p2 = __shfl_xor(v2, i, 64), p3 = __shfl_xor(v3, i, 64);
+        bool neg = (lane & i) != 0;
+        v0 = (neg ? -v0 : v0) + p0; v1 = (neg ? -v1 : v1) + p1; v2 = (neg ? -v2 : v2) + p2; v3 = (neg ? -v3 : v3) + p3;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ void kvg_pack_plane(uint32_t* __restrict__ out, int word_base, int sl, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3, bool active)
+{
+    uint32_t field = f0 | (f1 << W) | (f2 << (2 * W)) | (f3 << (3 * W));
+    constexpr int LPW = 8 / W;
+    int off = sl * 4 * W;
+    uint32_t contrib = field << (off & 31);
+    #pragma unroll
+    for (int i = 1; i < LPW; i <<= 1) contrib |= (uint32_t) __shfl_xor((int) contrib, i, 64);
+    if (active && (sl % LPW) == 0) out[word_base + (off >> 5)] = contrib;
+}
+
+// same arithmetic as kv_quant_group in exl3_rope_cache.hip, input already in registers (fp16-rounded values)
+template <int BITS>
+__device__ __forceinline__ void kv_quant_regs(float v0, float v1, float v2, float v3, uint32_t* __restrict__ out, half_t* __restrict__ out_scale, bool active, int lane)
+{
+    constexpr float mf = (float) (1 << (BITS - 1));
+    constexpr int qmax = (1 << BITS) - 1;
+    const int sl = lane & 7;
+    kvg_had32(v0, v1, v2, v3, lane);
+    const float r32 = 0.17677669529663688110f;
+    v0 *= r32; v1 *= r32; v2 *= r32; v3 *= r32;
+    float s = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) + 1e-10f;
+    #pragma unroll
+    for (int i = 1; i < 8; i <<= 1) s = fmaxf(s, __shfl_xor(s, i, 64));
+    const float inv_s = 1.0f / s;
+    auto quant1 = [&] (float v) -> uint32_t { int qi = (int) floorf(__builtin_fmaf(v * inv_s, mf, mf)); return (uint32_t) max(min(qi, qmax), 0); };
+    uint32_t q0 = quant1(v0), q1 = quant1(v1), q2 = quant1(v2), q3 = quant1(v3);
+    int rem = BITS, wb = 0;
+    if constexpr (BITS & 8) { rem -= 8; kvg_pack_plane<8>(out, wb, sl, (q0 >> rem) & 255, (q1 >> rem) & 255, (q2 >> rem) & 255, (q3 >> rem) & 255, active); wb += 8; }
+    if constexpr (BITS & 4) { rem -= 4; kvg_pack_plane<4>(out, wb, sl, (q0 >> rem) & 15, (q1 >> rem) & 15, (q2 >> rem) & 15, (q3 >> rem) & 15, active); wb += 4; }
+    if constexpr (BITS & 2) { rem -= 2; kvg_pack_plane<2>(out, wb, sl, (q0 >> rem) & 3, (q1 >> rem) & 3, (q2 >> rem) & 3, (q3 >> rem) & 3, active); wb += 2; }
+    if constexpr (BITS & 1) { kvg_pack_plane<1>(out, wb, sl, q0 & 1, q1 & 1, q2 & 1, q3 & 1, active); }
+    if (active && sl == 0) *out_scale = (half_t) s;
+}
+
+struct QkvArgs
+{
+    SlabRef sq, sk, sv;
+    const half_t* svh_q; const half_t* svh_k; const half_t* svh_v;
+    half_t* q_out; half_t* k_out; half_t* v_out;          // [m][heads*128] fp16 (k_out / v_out optional)
+    const float* inv_freq;                                  // [64]
+    const int32_t* positions;                               // [m] absolute position of each row's token
+    uint32_t* k_cache; half_t* k_scales; uint32_t* v_cache; half_t* v_scales;      // paged quantized cache of this layer (optional)
+    const int32_t* block_table; int blocks_per_seq; int page_size;
+    int m, hq, hkv, rope_mode;
+    float attn_factor;
+};
+
+template <int KB, int VB>
+__global__ __launch_bounds__(256)
+void glue_qkv_kernel(QkvArgs a)
+{
+    __shared__ float sn_s[16 * 64], cs_s[16 * 64];
+    const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
+    for (int i = tid; i < a.m * 64; i += blockDim.x)
+    {
+        int row = i >> 6, f = i & 63;
+        float sn, cs;
+        sincosf(a.inv_freq[f] * (float) a.positions[row], &sn, &cs);
+        sn_s[i] = sn * a.attn_factor; cs_s[i] = cs * a.attn_factor;
+    }
+    __syncthreads();
+    const int heads = a.hq + 2 * a.hkv;
+    const int tasks = a.m * heads;
+    const int t = blockIdx.x * 8 + hw;
+    const bool act = t < tasks;
+    const int row = act ? t / heads : 0, head = act ? t % heads : 0;
+    const int kind = head < a.hq ? 0 : (head < a.hq + a.hkv ? 1 : 2);
+    const int hi = kind == 0 ? head : (kind == 1 ? head - a.hq : head - a.hq - a.hkv);
+    const SlabRef& sr = kind == 0 ? a.sq : (kind == 1 ? a.sk : a.sv);
+    const half_t* svh = (kind == 0 ? a.svh_q : (kind == 1 ? a.svh_k : a.svh_v)) + hi * 128;
+    float h0, h1, h2, h3;
+    out_had(slab_sum(sr, hi, row, a.m, l), l, h0, h1, h2, h3);
+    half4_t sc = ((const half4_t*) svh)[l];
+    half4_t y = half4_t{ (half_t) h0, (half_t) h1, (half_t) h2, (half_t) h3 } * sc;       // fp16 output semantics of exl3_gemm
+    if (kind != 2)
+    {
+        // RoPE on the fp16 head vector; lane l holds dims 4l..4l+3
+        float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
+        if (a.rope_mode == 2)
+        {
+            // NEOX: pairs (d, d+64): partner lane l ^ 16, frequency index d & 63
+            float p0 = __shfl_xor(v0, 16, 64), p1 = __shfl_xor(v1, 16, 64), p2 = __shfl_xor(v2, 16, 64), p3 = __shfl_xor(v3, 16, 64);
+            const int f = 4 * (l & 15);
+            const float* sn = sn_s + row * 64 + f; const float* cs = cs_s + row * 64 + f;
+            const bool upper = l >= 16;
+            // lower half: r1 = v1*cos - v2*sin ; upper half: r2 = v2*cos + v1*sin   (v1 = lower element, v2 = upper element)
+            float r0 = upper ? v0 * cs[0] + p0 * sn[0] : v0 * cs[0] - p0 * sn[0];
+            float r1 = upper ? v1 * cs[1] + p1 * sn[1] : v1 * cs[1] - p1 * sn[1];
+            float r2 = upper ? v2 * cs[2] + p2 * sn[2] : v2 * cs[2] - p2 * sn[2];
+            float r3 = upper ? v3 * cs[3] + p3 * sn[3] : v3 * cs[3] - p3 * sn[3];
+            y = half4_t{ (half_t) r0, (half_t) r1, (half_t) r2, (half_t) r3 };
+        }
+        else
+        {
+            // GPTJ: pairs (2i, 2i+1) both in this lane: frequencies 2l, 2l+1
+            const float* sn = sn_s + row * 64 + 2 * l; const float* cs = cs_s + row * 64 + 2 * l;
+            y = half4_t{ (half_t) (v0 * cs[0] - v1 * sn[0]), (half_t) (v1 * cs[0] + v0 * sn[0]),
+                         (half_t) (v2 * cs[1] - v3 * sn[1]), (half_t) (v3 * cs[1] + v2 * sn[1]) };
+        }
+    }
+    if (kind == 0 && act) ((half4_t*) (a.q_out + ((size_t) row * a.hq + hi) * 128))[l] = y;
+    half_t* dense = kind == 1 ? a.k_out : (kind == 2 ? a.v_out : nullptr);
+    if (dense && act && kind != 0) ((half4_t*) (dense + ((size_t) row * a.hkv + hi) * 128))[l] = y;
+    // quantized append (all lanes take part in the shuffles; stores are predicated)
+    const bool do_q = act && kind != 0 && a.k_cache != nullptr;
+    const int pos = a.positions[row];
+    const int page_idx = pos / a.page_size;
+    const int64_t token_pos = a.k_cache ? (int64_t) a.block_table[row * a.blocks_per_seq + page_idx] * a.page_size + (pos % a.page_size) : 0;
+    const int groups_per_token = a.hkv * 4;
+    const int64_t gbase = token_pos * groups_per_token + hi * 4 + (l >> 3);
+    {
+        float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
+        kv_quant_regs<KB>(v0, v1, v2, v3, a.k_cache ? a.k_cache + gbase * KB : nullptr, a.k_scales ? a.k_scales + gbase : nullptr, do_q && kind == 1, tid & 63);
+        kv_quant_regs<VB>(v0, v1, v2, v3, a.v_cache ? a.v_cache + gbase * VB : nullptr, a.v_scales ? a.v_scales + gbase : nullptr, do_q && kind == 2, tid & 63);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G3: gate/up epilogue per (row, 128-block of the intermediate dim): reduce + out-had + fp16 svh for g and u ->
+//     a = fp16(silu(g) * u) (activation.cu) -> in-had with suh_down -> xh_down + block sum.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void glue_act_kernel(SlabRef sg, SlabRef su, const half_t* __restrict__ svh_g, const half_t* __restrict__ svh_u,
+                     const half_t* __restrict__ suh_d, half_t* __restrict__ xh_d, float* __restrict__ xsum_d,
+                     half_t* __restrict__ a_out, int m, int inter)
+{
+    const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
+    const int nblk = inter >> 7;
+    const int tasks = m * nblk;
+    const int t = blockIdx.x * 8 + hw;
+    const bool act = t < tasks;
+    const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+    float g0, g1, g2, g3, u0, u1, u2, u3;
+    out_had(slab_sum(sg, blk, row, m, l), l, g0, g1, g2, g3);
+    out_had(slab_sum(su, blk, row, m, l), l, u0, u1, u2, u3);
+    half4_t gh = half4_t{ (half_t) g0, (half_t) g1, (half_t) g2, (half_t) g3 } * ((const half4_t*) (svh_g + blk * 128))[l];
+    half4_t uh = half4_t{ (half_t) u0, (half_t) u1, (half_t) u2, (half_t) u3 } * ((const half4_t*) (svh_u + blk * 128))[l];
+    auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return (half_t) (gf / (1.0f + __expf(-gf)) * (float) u); };
+    half4_t av = { silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
+    if (a_out && act) ((half4_t*) (a_out + (size_t) row * inter + blk * 128))[l] = av;
+    float sum = in_had_store(av, suh_d + blk * 128, xh_d + (size_t) row * inter + blk * 128, l, act);
+    if (act && l == 0 && xsum_d) xsum_d[(size_t) row * nblk + blk] = sum;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int exl3_glue_norm(const float* y_slabs, int y_S, const float* y_dense, const void* svh, const void* bias, void* resid, const void* w, float eps,
+                              const void* const* suhs, void* const* xhs, float* const* xsums, int count, int m, int hidden,
+                              void* xn_out, void* stream)
+{
+    EXL3_CHECK_ARG(resid && w, "glue_norm: null pointer");
+    EXL3_CHECK_ARG(m >= 1 && m <= 16, "glue_norm: 1 <= m <= 16");
+    EXL3_CHECK_ARG(hidden % 128 == 0 && hidden <= 16384, "glue_norm: hidden must be a multiple of 128, <= 16384");
+    EXL3_CHECK_ARG(count >= 0 && count <= 3, "glue_norm: at most 3 consumers");
+    EXL3_CHECK_ARG(!y_slabs || (svh && y_S >= 1), "glue_norm: pending output needs svh");
+    NormTargets tg; tg.count = count;
+    for (int i = 0; i < 3; ++i)
+    {
+        tg.suh[i] = i < count ? (const half_t*) suhs[i] : nullptr;
+        tg.xh[i] = i < count ? (half_t*) xhs[i] : nullptr;
+        tg.xsum[i] = (i < count && xsums) ? xsums[i] : nullptr;
+        EXL3_CHECK_ARG(i >= count || (tg.suh[i] && tg.xh[i]), "glue_norm: null consumer pointer");
+    }
+    SlabRef y = { y_slabs, y_S };
+    int tasks = m * (hidden / 128);
+    int threads = tasks * 32; if (threads > 1024) threads = 1024; if (threads < 64) threads = 64;
+    threads = (threads + 63) / 64 * 64;
+    glue_norm_kernel<<<1, threads, 0, (hipStream_t) stream>>>(y, (y_slabs || y_dense) ? 1 : 0, y_dense, (const half_t*) svh, (const half_t*) bias, (half_t*) resid,
+                                                             (const half_t*) w, eps, tg, m, hidden, (half_t*) xn_out);
+    return exl3_check_launch("glue_norm");
+}
+
+template <int KB>
+static void launch_qkv(int vb, dim3 grid, hipStream_t st, const QkvArgs& a)
+{
+    switch (vb)
+    {
+        case 2: glue_qkv_kernel<KB, 2><<<grid, 256, 0, st>>>(a); break; case 3: glue_qkv_kernel<KB, 3><<<grid, 256, 0, st>>>(a); break;
+        case 4: glue_qkv_kernel<KB, 4><<<grid, 256, 0, st>>>(a); break; case 5: glue_qkv_kernel<KB, 5><<<grid, 256, 0, st>>>(a); break;
+        case 6: glue_qkv_kernel<KB, 6><<<grid, 256, 0, st>>>(a); break; case 7: glue_qkv_kernel<KB, 7><<<grid, 256, 0, st>>>(a); break;
+        default: glue_qkv_kernel<KB, 8><<<grid, 256, 0, st>>>(a); break;
+    }
+}
+
+extern "C" int exl3_glue_qkv(const float* sq, const float* sk, const float* sv, int S, const void* svh_q, const void* svh_k, const void* svh_v,
+                             void* q_out, void* k_out, void* v_out, const float* inv_freq, const int32_t* positions,
+                             void* k_cache, void* k_scales, void* v_cache, void* v_scales, const int32_t* block_table, int blocks_per_seq,
+                             int page_size, int k_bits, int v_bits, int m, int heads_q, int heads_kv, int head_dim, int rope_mode,
+                             float attn_factor, void* stream)
+{
+    EXL3_CHECK_ARG(sq && sk && sv && svh_q && svh_k && svh_v && q_out && inv_freq && positions, "glue_qkv: null pointer");
+    EXL3_CHECK_ARG(head_dim == 128, "glue_qkv: head_dim must be 128 (one Hadamard block per head)");
+    EXL3_CHECK_ARG(m >= 1 && m <= 16, "glue_qkv: 1 <= m <= 16");
+    EXL3_CHECK_ARG(rope_mode == 1 || rope_mode == 2, "glue_qkv: rope_mode must be 1 (GPTJ) or 2 (NEOX)");
+    EXL3_CHECK_ARG(!k_cache || (k_scales && v_cache && v_scales && block_table && page_size > 0), "glue_qkv: incomplete cache arguments");
+    EXL3_CHECK_ARG(!k_cache || (k_bits >= 2 && k_bits <= 8 && v_bits >= 2 && v_bits <= 8), "glue_qkv: cache bits must be in [2, 8]");
+    QkvArgs a;
+    a.sq = { sq, S }; a.sk = { sk, S }; a.sv = { sv, S };
+    a.svh_q = (const half_t*) svh_q; a.svh_k = (const half_t*) svh_k; a.svh_v = (const half_t*) svh_v;
+    a.q_out = (half_t*) q_out; a.k_out = (half_t*) k_out; a.v_out = (half_t*) v_out;
+    a.inv_freq = inv_freq; a.positions = positions;
+    a.k_cache = (uint32_t*) k_cache; a.k_scales = (half_t*) k_scales; a.v_cache = (uint32_t*) v_cache; a.v_scales = (half_t*) v_scales;
+    a.block_table = block_table; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size > 0 ? page_size : 256;
+    a.m = m; a.hq = heads_q; a.hkv = heads_kv; a.rope_mode = rope_mode; a.attn_factor = attn_factor;
+    int tasks = m * (heads_q + 2 * heads_kv);
+    dim3 grid((tasks + 7) / 8);
+    hipStream_t st = (hipStream_t) stream;
+    int kb = k_cache ? k_bits : 8, vb = k_cache ? v_bits : 8;
+    switch (kb)
+    {
+        case 2: launch_qkv<2>(vb, grid, st, a); break; case 3: launch_qkv<3>(vb, grid, st, a); break; case 4: launch_qkv<4>(vb, grid, st, a); break;
+        case 5: launch_qkv<5>(vb, grid, st, a); break; case 6: launch_qkv<6>(vb, grid, st, a); break; case 7: launch_qkv<7>(vb, grid, st, a); break;
+        default: launch_qkv<8>(vb, grid, st, a); break;
+    }
+    return exl3_check_launch("glue_qkv");
+}
+
+extern "C" int exl3_glue_act(const float* sg, const float* su, int S, const void* svh_g, const void* svh_u, const void* suh_d,
+                             void* xh_d, float* xsum_d, void* a_out, int m, int inter, void* stream)
+{
+    EXL3_CHECK_ARG(sg && su && svh_g && svh_u && suh_d && xh_d, "glue_act: null pointer");
+    EXL3_CHECK_ARG(m >= 1 && m <= 16 && inter % 128 == 0, "glue_act: bad dimensions");
+    int tasks = m * (inter / 128);
+    SlabRef g = { sg, S }, u = { su, S };
+    glue_act_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>(g, u, (const half_t*) svh_g, (const half_t*) svh_u, (const half_t*) suh_d,
+                                                                       (half_t*) xh_d, xsum_d, (half_t*) a_out, m, inter);
+    return exl3_check_launch("glue_act");
+}

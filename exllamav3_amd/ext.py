@@ -397,3 +397,53 @@ def add(x, y):
     _dev(x)
     _req(x.numel() == y.numel(), "add: size mismatch")
     _check(_lib.lib().exl3_add(_p(x), _p(y), x.numel(), int(x.dtype == torch.float), int(y.dtype == torch.float), _stream(x)))
+
+
+# --------------------------------------------------------------------------------------------------
+# fused decode pipeline (deferred-epilogue GEMVs + glue kernels); see include/exl3_hip.h
+# --------------------------------------------------------------------------------------------------
+
+GEMV_IN_ROTATED, GEMV_OUT_DEFERRED = 1, 2
+
+
+def _parr(ptrs):
+    return (_vp * len(ptrs))(*[(p if isinstance(p, int) or p is None else p.data_ptr()) for p in ptrs])
+
+
+def exl3_gemv_ex(A, xhs, xsums, Bs, Cs, suhs, svhs, m: int, mcg: bool, mul1: bool, flags: int, force_split: int = 0, c_fp32: bool = False):
+    """Returns (slab_device_pointers, S).  A or xhs[i] is the input; Cs/svhs may be None with GEMV_OUT_DEFERRED."""
+    ref = A if A is not None else xhs[0]
+    _dev(ref)
+    cnt = len(Bs)
+    k, K = Bs[0].shape[0] * 16, Bs[0].shape[2] // 16
+    ns = (ctypes.c_int * cnt)(*[B.shape[1] * 16 for B in Bs])
+    slabs = (_vp * cnt)()
+    S = ctypes.c_int(0)
+    none = lambda: None
+    _check(_lib.lib().exl3_gemv_ex(_p(A), _parr(xhs) if xhs else None, _parr(xsums) if xsums else None, _parr(Bs),
+                                   _parr(Cs) if Cs else None, _parr(suhs) if suhs else None, _parr(svhs) if svhs else None, None,
+                                   ns, cnt, m, k, K, _cb(mcg, mul1), int(c_fp32), flags, force_split, slabs, ctypes.byref(S), _stream(ref)))
+    return [int(s) if s else 0 for s in slabs], S.value
+
+
+def glue_norm(y_slab: int | None, y_S: int, svh, bias, resid, w, eps: float, suhs, xhs, xsums, m: int, xn_out=None, y_dense=None):
+    _dev(resid)
+    hidden = resid.shape[-1]
+    _check(_lib.lib().exl3_glue_norm(y_slab, y_S, _p(y_dense), _p(svh), _p(bias), _p(resid), _p(w), float(eps), _parr(suhs), _parr(xhs), _parr(xsums),
+                                     len(suhs), m, hidden, _p(xn_out), _stream(resid)))
+
+
+def glue_qkv(slabs, S: int, svh_q, svh_k, svh_v, q_out, k_out, v_out, inv_freq, positions, k_cache, k_scales, v_cache, v_scales,
+             block_table, page_size: int, k_bits: int, v_bits: int, m: int, heads_q: int, heads_kv: int, head_dim: int,
+             rope_mode: int = 2, attn_factor: float = 1.0):
+    _dev(q_out)
+    _check(_lib.lib().exl3_glue_qkv(slabs[0], slabs[1], slabs[2], S, _p(svh_q), _p(svh_k), _p(svh_v), _p(q_out), _p(k_out), _p(v_out),
+                                    _p(inv_freq), _p(positions), _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table),
+                                    block_table.shape[1] if block_table is not None else 0, page_size, k_bits, v_bits, m, heads_q, heads_kv,
+                                    head_dim, rope_mode, float(attn_factor), _stream(q_out)))
+
+
+def glue_act(slabs, S: int, svh_g, svh_u, suh_d, xh_d, xsum_d, m: int, a_out=None):
+    _dev(xh_d)
+    _check(_lib.lib().exl3_glue_act(slabs[0], slabs[1], S, _p(svh_g), _p(svh_u), _p(suh_d), _p(xh_d), _p(xsum_d), _p(a_out), m,
+                                    xh_d.shape[-1], _stream(xh_d)))

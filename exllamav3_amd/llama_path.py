@@ -143,6 +143,12 @@ class SyntheticEXL3Llama:
         self.a = torch.empty((bsz, self.inter_local), dtype=f16, device=dev)
         self.d = torch.empty((bsz, s.hidden), dtype=f32, device=dev)
         self.logits = torch.empty((bsz, self.vocab_local), dtype=f16, device=dev)
+        # fused pipeline: pre-rotated inputs (+ per-128-block sums) of every linear
+        nb_h, nb_i, nb_a = s.hidden // 128, self.inter_local // 128, (self.hq * hd) // 128
+        self.xh3 = [torch.empty((bsz, s.hidden), dtype=f16, device=dev) for _ in range(3)]
+        self.xs3 = [torch.empty((bsz, nb_h), dtype=f32, device=dev) for _ in range(3)]
+        self.xh_d = torch.empty((bsz, self.inter_local), dtype=f16, device=dev)
+        self.xs_d = torch.empty((bsz, nb_i), dtype=f32, device=dev)
         self._state_bsz = bsz
 
     # ---- one decode step (bsz tokens, one per sequence) -----------------------------------------------
@@ -181,6 +187,83 @@ class SyntheticEXL3Llama:
         ext.rms_norm_res_in(pending, self.final_norm, self.xn, x, self.eps)
         self.lm_head.bc.run(self.xn, self.logits)
         return self.logits
+
+    # ---- the same step with the fused pipeline: deferred-epilogue GEMVs + glue kernels (8 launches per layer) ----------
+    def decode_step_fused(self):
+        bsz = self._state_bsz
+        hd = self.shape.head_dim
+        be = self.backend
+        x = self.x
+        x.copy_(self.x0)
+        ROT, DEF = ext.GEMV_IN_ROTATED, ext.GEMV_OUT_DEFERRED
+        q2 = self.q.view(bsz, -1)
+        pend = None                                            # (slab ptr, S, svh) of the pending down_proj, or a dense fp32 tensor
+        for li, L in enumerate(self.layers):
+            lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
+            tq = ([lq.suh, lk.suh, lv.suh], self.xh3, self.xs3)
+            if pend is None:
+                ext.glue_norm(None, 0, None, None, x, L["norm1"], self.eps, *tq, bsz)
+            elif isinstance(pend, torch.Tensor):
+                ext.glue_norm(None, 0, None, None, x, L["norm1"], self.eps, *tq, bsz, y_dense=pend)
+            else:
+                ext.glue_norm(pend[0], pend[1], pend[2], None, x, L["norm1"], self.eps, *tq, bsz)
+            slabs, S = ext.exl3_gemv_ex(None, self.xh3, self.xs3, [lq.trellis, lk.trellis, lv.trellis], None, None, None,
+                                        bsz, lq.mcg, lq.mul1, ROT | DEF)
+            kc, ks = self.kcache[li]
+            vc, vs = self.vcache[li]
+            ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                         self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd)
+            # [attention core out of scope: attention output := q]; o_proj takes the raw attention output (fused input Hadamard)
+            t2 = ([lg.suh, lu.suh], self.xh3[:2], self.xs3[:2])
+            if self.tp == 1:
+                so, So = ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF)
+                ext.glue_norm(so[0], So, lo.svh, None, x, L["norm2"], self.eps, *t2, bsz)
+            else:
+                lo.bc.run(q2, self.o)
+                be.all_reduce(self.o)
+                ext.glue_norm(None, 0, None, None, x, L["norm2"], self.eps, *t2, bsz, y_dense=self.o)
+            sgu, Sgu = ext.exl3_gemv_ex(None, self.xh3[:2], self.xs3[:2], [lg.trellis, lu.trellis], None, None, None,
+                                        bsz, lg.mcg, lg.mul1, ROT | DEF)
+            ext.glue_act(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz)
+            if self.tp == 1:
+                sd, Sd = ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF)
+                pend = (sd[0], Sd, ld.svh)
+            else:
+                ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.d], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT, c_fp32=True)
+                be.all_reduce(self.d)
+                pend = self.d
+        th = ([self.lm_head.suh], self.xh3[:1], self.xs3[:1])
+        if isinstance(pend, torch.Tensor):
+            ext.glue_norm(None, 0, None, None, x, self.final_norm, self.eps, *th, bsz, y_dense=pend)
+        else:
+            ext.glue_norm(pend[0], pend[1], pend[2], None, x, self.final_norm, self.eps, *th, bsz)
+        ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
+                         bsz, self.lm_head.mcg, self.lm_head.mul1, ROT)
+        return self.logits
+
+    def gemv_calls(self, fused: bool):
+        """Zero-argument callables, one per quantized-GEMV launch of a decode step (bench.py roofline leg)."""
+        bsz = self._state_bsz
+        q2, k2, v2 = self.q.view(bsz, -1), self.k.view(bsz, -1), self.v.view(bsz, -1)
+        ROT, DEF = ext.GEMV_IN_ROTATED, ext.GEMV_OUT_DEFERRED
+        calls = []
+        for L in self.layers:
+            lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
+            if fused and self.tp == 1:
+                calls.append(lambda lq=lq, lk=lk, lv=lv: ext.exl3_gemv_ex(None, self.xh3, self.xs3, [lq.trellis, lk.trellis, lv.trellis], None, None, None, bsz, lq.mcg, lq.mul1, ROT | DEF))
+                calls.append(lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF))
+                calls.append(lambda lg=lg, lu=lu: ext.exl3_gemv_ex(None, self.xh3[:2], self.xs3[:2], [lg.trellis, lu.trellis], None, None, None, bsz, lg.mcg, lg.mul1, ROT | DEF))
+                calls.append(lambda ld=ld: ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF))
+            else:
+                calls.append(lambda lq=lq, lk=lk, lv=lv: ext.exl3_mgemm_bcast(self.xn, [lq.trellis, lk.trellis, lv.trellis], [q2, k2, v2], [lq.suh, lk.suh, lv.suh], [lq.svh, lk.svh, lv.svh], lq.mcg, lq.mul1))
+                calls.append(lambda lo=lo: lo.bc.run(q2, self.o))
+                calls.append(lambda lg=lg, lu=lu: ext.exl3_mgemm_bcast(self.xn, [lg.trellis, lu.trellis], [self.g, self.u], [lg.suh, lu.suh], [lg.svh, lu.svh], lg.mcg, lg.mul1))
+                calls.append(lambda ld=ld: ld.bc.run(self.a, self.d))
+        if fused and self.tp == 1:
+            calls.append(lambda: ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, ROT))
+        else:
+            calls.append(lambda: self.lm_head.bc.run(self.xn, self.logits))
+        return calls
 
     def gemv_launches_per_step(self):
         """(k, n_total, count) of every quantized-GEMV launch of one decode step, for the roofline accounting."""

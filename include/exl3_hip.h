@@ -94,6 +94,38 @@ int exl3_mgemm(const void* A, const void* const* Bs, void* const* Cs, const void
 int exl3_set_gemv_variant(int variant);
 int exl3_set_gemv_gen(int gen);
 int exl3_set_gemv_max_waves(int max_waves_per_workgroup);   /* 0 = heuristic (up to 16) */
+int exl3_set_gemv_defer_wg_per_cu(int workgroups_per_cu);      /* deferred-epilogue k-split target, 0 = default (2) */
+
+/* ---- fused decode pipeline (m <= 16): the reference chains these steps as separate graph nodes inside its BC_* runners
+ * (libtorch/attention.cpp:246-504 BC_Attention::run_gr, libtorch/mlp.cpp:14-91 BC_GatedMLP::run_bszN_gr); on MI355X each
+ * node is a ~4.5 us latency-bound launch, so the GEMVs run with a deferred epilogue and three "glue" kernels do everything
+ * in between (exl3_glue.hip).
+ *
+ * exl3_gemv_ex: exl3_mgemm with flags: EXL3_GEMV_IN_ROTATED (1): per-matrix pre-rotated inputs xhs[i] = had128(x * suh_i) fp16 [m][k]
+ * and per-128-block sums xsums[i] fp32 [m][k/128] instead of A; EXL3_GEMV_OUT_DEFERRED (2): no output Hadamard, raw fp32 partial
+ * slabs [n_i/128][S][m][128] are left in the per-device workspace, slabs_out[i] (host array) receives their device address and
+ * *S_out the split count.  Arrays are host arrays of `count` (<= 4) entries. */
+#define EXL3_GEMV_IN_ROTATED   1
+#define EXL3_GEMV_OUT_DEFERRED 2
+int exl3_gemv_ex(const void* A, const void* const* xhs, const float* const* xsums, const void* const* Bs, void* const* Cs,
+                 const void* const* suhs, const void* const* svhs, const void* const* biases, const int* ns, int count,
+                 int m, int k, int K, int cb, int c_fp32, int flags, int force_split, float** slabs_out, int* S_out, void* stream);
+/* glue 1: [y = reduce slabs + out-Hadamard + svh (+bias), or y = y_dense fp32 [m][hidden] (e.g. after a TP all-reduce);
+ * residual(fp16) += y]  (skipped when both are NULL) -> RMSNorm(w, eps) (norm.cu rms_norm_res_in semantics) -> for each of `count`
+ * (<= 3) consumers: xh_i = had128(xn * suh_i), xsum_i.  xn_out optional. */
+int exl3_glue_norm(const float* y_slabs, int y_S, const float* y_dense, const void* svh, const void* bias, void* resid, const void* w, float eps,
+                   const void* const* suhs, void* const* xhs, float* const* xsums, int count, int m, int hidden,
+                   void* xn_out, void* stream);
+/* glue 2: q/k/v epilogue (head_dim 128): reduce + out-Hadamard + svh -> rope (rope.cu semantics, positions[m]) on q, k -> q_out fp16,
+ * k/v -> quantized paged-cache append at positions[m] (q_cache_kernels.cuh semantics; k_cache == NULL skips) and optional fp16 k_out/v_out. */
+int exl3_glue_qkv(const float* sq, const float* sk, const float* sv, int S, const void* svh_q, const void* svh_k, const void* svh_v,
+                  void* q_out, void* k_out, void* v_out, const float* inv_freq, const int32_t* positions,
+                  void* k_cache, void* k_scales, void* v_cache, void* v_scales, const int32_t* block_table, int blocks_per_seq,
+                  int page_size, int k_bits, int v_bits, int m, int heads_q, int heads_kv, int head_dim, int rope_mode,
+                  float attn_factor, void* stream);
+/* glue 3: gate/up epilogue: reduce + out-Hadamard + svh for g and u -> a = silu(g) * u (activation.cu) -> xh_d = had128(a * suh_down), xsum_d. */
+int exl3_glue_act(const float* sg, const float* su, int S, const void* svh_g, const void* svh_u, const void* suh_d,
+                  void* xh_d, float* xsum_d, void* a_out, int m, int inter, void* stream);
 
 /* hgemm(a, b, c)      hgemm.cu:19-102:  c[m][n] (row stride ldc elements, fp16 or fp32) = a[m][k] @ b[k][n], fp32 accumulate.
  * m, k, n arbitrary multiples of 16/32/16. */

@@ -96,3 +96,77 @@ def test_prefill_chunk_runs_and_matches_small_oracle(dev):
     ref = _lin(model.lm_head, xl).astype(np.float32)
     err = np.abs(logits - ref).max() / np.sqrt((ref ** 2).mean())
     assert err < 5e-2, err
+
+
+@pytest.mark.parametrize("cb", [0, 1, 2])
+@pytest.mark.parametrize("bsz", [1, 2, 5, 16])
+def test_fused_decode_pipeline_matches_unfused_and_oracle(dev, cb, bsz):
+    """Deferred-epilogue GEMVs + glue kernels (exl3_glue.hip) against the op-by-op pipeline and the oracle."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    shape = LlamaShape("tiny", 256, 512, 2, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(bsz, pos=700)
+    lu = model.decode_step().float().cpu().numpy().copy()
+    ku = [(kc.clone(), ks.clone()) for kc, ks in model.kcache]
+    vu = [(vc.clone(), vs.clone()) for vc, vs in model.vcache]
+    for kc, ks in model.kcache + model.vcache:
+        kc.zero_(); ks.zero_()
+    lf = model.decode_step_fused().float().cpu().numpy()
+    assert np.isfinite(lf).all()
+    rms = np.sqrt((lu ** 2).mean())
+    assert np.abs(lf - lu).max() / rms < 1e-2
+    if bsz <= 2:
+        ref = _oracle_decode(model, _np(model.x0))
+        assert np.abs(lf - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+    # quantized KV append: same slots, same values up to fp32 summation order
+    for (kc, ks), (kc0, ks0) in zip(model.kcache + model.vcache, ku + vu):
+        assert bool(((ks != 0) == (ks0 != 0)).all())
+        d1 = torch.empty((kc.shape[0] * kc.shape[1], kc.shape[2] // 4 * 32), dtype=torch.half, device=dev); d0 = torch.empty_like(d1)
+        ext.dequant_cache_cont(kc.view(d1.shape[0], -1), ks.view(d1.shape[0], -1), d1)
+        ext.dequant_cache_cont(kc0.view(d1.shape[0], -1), ks0.view(d1.shape[0], -1), d0)
+        assert float((d1.float() - d0.float()).abs().max()) < 0.35          # one 4-bit quantization step at most
+        assert float((d1.float() - d0.float()).abs().mean()) < 2e-3
+    # graph replay reproduces the eager bits
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            model.decode_step_fused()
+    model.logits.zero_(); g.replay(); torch.cuda.synchronize()
+    assert np.array_equal(model.logits.float().cpu().numpy(), lf)
+
+
+def test_fused_gptj_rope_and_gemv_ex_modes(dev):
+    """exl3_gemv_ex: rotated input + final output equals exl3_gemm on the unrotated input; glue_qkv GPTJ rope vs rope kernel."""
+    from exllamav3_amd import ext
+    k, n, K, m = 512, 256, 4, 3
+    tr, suh, svh = o.synth_linear(k, n, K, realistic=True)
+    x = np.random.default_rng(0).standard_normal((m, k)).astype(np.float16)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tx, ttr, tsu, tsv = T(x), T(tr), T(suh), T(svh)
+    for cb in (0, 2):
+        y0 = torch.empty((m, n), dtype=torch.half, device=dev)
+        ext.exl3_gemm(tx, ttr, y0, tsu, None, tsv, -1, False, cb == 2, 0)
+        xh = torch.empty_like(tx); ext.had_r_128(tx, xh, tsu, None, 1.0)
+        xs = xh.float().view(m, k // 128, 128).sum(-1).contiguous()
+        y1 = torch.full((m, n), float("nan"), dtype=torch.half, device=dev)
+        ext.exl3_gemv_ex(None, [xh], [xs], [ttr], [y1], None, [tsv], m, False, cb == 2, ext.GEMV_IN_ROTATED)
+        assert float((y1.float() - y0.float()).abs().max()) < 2e-3 * float(y0.float().abs().max()) + 1e-3
+    # glue_qkv with GPTJ rope against the standalone ops
+    hq, hkv = 2, 1
+    mats = [o.synth_linear(k, h * 128, K, seed=9 + i, realistic=True) for i, h in enumerate((hq, hkv, hkv))]
+    Bs = [T(t[0]) for t in mats]; su = [T(t[1]) for t in mats]; sv = [T(t[2]) for t in mats]
+    outs = [torch.empty((m, h * 128), dtype=torch.half, device=dev) for h in (hq, hkv, hkv)]
+    ext.exl3_mgemm_bcast(tx, Bs, outs, su, sv, False, True)
+    inv = T((1.0 / (10000.0 ** (np.arange(0, 128, 2) / 128))).astype(np.float32))
+    pos = T(np.array([5, 900, 31000], dtype=np.int32))
+    q4, k4 = outs[0].view(m, 1, hq, 128).clone(), outs[1].view(m, 1, hkv, 128).clone()
+    ext.rope(q4, q4, k4, k4, inv, 0, pos, None, 1, 1.0)
+    slabs, S = ext.exl3_gemv_ex(tx, None, None, Bs, None, su, None, m, False, True, ext.GEMV_OUT_DEFERRED)
+    qf = torch.empty((m, hq * 128), dtype=torch.half, device=dev); kf = torch.empty((m, hkv * 128), dtype=torch.half, device=dev)
+    vf = torch.empty((m, hkv * 128), dtype=torch.half, device=dev)
+    ext.glue_qkv(slabs, S, sv[0], sv[1], sv[2], qf, kf, vf, inv, pos, None, None, None, None, None, 256, 8, 8, m, hq, hkv, 128, rope_mode=1)
+    for a, b in ((qf, q4.view(m, -1)), (kf, k4.view(m, -1)), (vf, outs[2])):
+        assert float((a.float() - b.float()).abs().max()) < 4e-3 * float(b.float().abs().max()) + 2e-3
