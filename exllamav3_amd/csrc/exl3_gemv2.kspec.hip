@@ -27,7 +27,7 @@
 #include "exl3_gemv_args.h"
 
 #include <type_traits>
-#define G2_PF 8
+#define G2_PF 4
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f)
@@ -161,11 +161,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const bool in_rotated = (a.flags & GEMV_IN_ROTATED) != 0;
     const half_t* __restrict__ xh_in = a.mat[mi].xh;
     const float* __restrict__ xsum_in = a.mat[mi].xsum;
-    // The inputs of a block are fetched one block ahead (loads return in order: a load issued after the trellis ring
-    // refills could only be waited for with vmcnt(0), draining the ring once per block).
-    half4_t xin[2 * NG], sin_[2 * NG];
-    float xsin[2 * NG];
-    auto prefetch_block = [&] (int blk)
+    auto prep_block = [&] (int blk, int buf)
     {
         #pragma unroll
         for (int p = 0; p < 2 * NG; ++p)
@@ -174,36 +170,19 @@ void exl3_gemv2_kernel(const GemvArgs a)
             if (2 * p >= m) break;                                      // wave-uniform
             const bool act = row < m;
             const size_t off = (size_t) (act ? row : 0) * a.k + k0 + 128 * blk;
-            if (in_rotated)
-            {
-                xin[p] = ((const half4_t*) (xh_in + off))[l32];
-                if constexpr (RAW) xsin[p] = xsum_in[(size_t) (act ? row : 0) * (a.k >> 7) + (k0 >> 7) + blk];
-            }
-            else
-            {
-                xin[p] = ((const half4_t*) (a.A + off))[l32];
-                sin_[p] = ((const half4_t*) (suh + k0 + 128 * blk))[l32];
-            }
-        }
-    };
-    auto prep_block = [&] (int buf)
-    {
-        #pragma unroll
-        for (int p = 0; p < 2 * NG; ++p)
-        {
-            const int row = 2 * p + hw;
-            if (2 * p >= m) break;                                      // wave-uniform
-            const bool act = row < m;
             half2_t o01, o23;
             if (in_rotated)
             {
-                // producer already applied suh + Hadamard (and rounded to fp16)
-                o01 = half2_t{ xin[p].x, xin[p].y }; o23 = half2_t{ xin[p].z, xin[p].w };
-                if constexpr (RAW) { if (act) rowsum[p] += xsin[p]; }
+                // producer already applied suh + Hadamard (and rounded to fp16): just fetch the 4 values of this lane
+                half4_t xv = ((const half4_t*) (xh_in + off))[l32];
+                o01 = half2_t{ xv.x, xv.y }; o23 = half2_t{ xv.z, xv.w };
+                if constexpr (RAW) { if (act) rowsum[p] += xsum_in[(size_t) row * (a.k >> 7) + (k0 >> 7) + blk]; }
             }
             else
             {
-                half4_t xv = xin[p] * sin_[p];
+                half4_t xv = ((const half4_t*) (a.A + off))[l32];
+                half4_t sv = ((const half4_t*) (suh + k0 + 128 * blk))[l32];
+                xv = xv * sv;
                 float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
                 had128_f32x4(h0, h1, h2, h3, l32);
                 o01 = half2_t{ (half_t) (h0 * HAD_R_SCALE_128), (half_t) (h1 * HAD_R_SCALE_128) };
@@ -252,38 +231,31 @@ void exl3_gemv2_kernel(const GemvArgs a)
     for (int gq = 0; gq < NG; ++gq) { acc_c[gq] = float4_t{ 0.f, 0.f, 0.f, 0.f }; acc_d[gq] = float4_t{ 0.f, 0.f, 0.f, 0.f }; }
 
     LaneWords<K> ring[G2_PF];
-    uint32_t carry = 0;                                  // previous lane's last word for the CURRENT step (fetched one step early)
     if (nbw > 0)
     {
-        prefetch_block(0);
         #pragma unroll
         for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(u, last_row) * row_stride);
-        carry = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) ring[0].w[K - 1]);
     }
 
     for (int blk = 0; blk < nbw; ++blk)
     {
         const int buf = blk & 1;
-        prep_block(buf);
-        prefetch_block(min(blk + 1, nbw - 1));
+        prep_block(blk, buf);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // wave-private LDS: in-order queue + drain
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_sched_barrier(0);
 
         #pragma unroll
         for (int r = 0; r < 8; ++r)
         {
-            const int u = r % G2_PF, u1 = (r + 1) % G2_PF;
+            const int u = r % G2_PF;
             const int row = blk * 8 + r;
 
             uint32_t Wx[K + 1];
-            Wx[0] = carry;
             #pragma unroll
             for (int i = 0; i < K; ++i) Wx[i + 1] = ring[u].w[i];
+            Wx[0] = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) ring[u].w[K - 1]);
 
-            // software pipeline: the cross-lane carry-in of the NEXT step is requested now (its LDS-crossbar latency hides
-            // under this step's decode), then this slot is refilled G2_PF rows ahead
-            const uint32_t carry_next = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) ring[u1].w[K - 1]);
+            // refill the slot
             load_lane_words<K>(ring[u], strip + (size_t) min(row + G2_PF, last_row) * row_stride);
 
             // A fragments of this tile row for this lane's activation row
@@ -324,7 +296,6 @@ void exl3_gemv2_kernel(const GemvArgs a)
                     });
                 }
             });
-            carry = carry_next;
             __builtin_amdgcn_sched_barrier(0);      // keep the refill loads of different steps in program order
         }
     }
