@@ -125,8 +125,17 @@ def main():
             if rank == 0:
                 print(f"bench.py: graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
             graph = None
-            torch.cuda.synchronize()
-
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+        if world > 1:
+            # all ranks must agree on the mode (a rank replaying a graph while another launches eagerly would deadlock RCCL)
+            ok = torch.tensor([1.0 if graph is not None else 0.0], dtype=torch.float64, device=dev)
+            neg = -ok
+            backend.all_reduce_max(neg)                 # max(-ok) = -min(ok)
+            if float(neg.item()) != -1.0:
+                graph = None
     def step():
         if graph is not None:
             graph.replay()

@@ -27,7 +27,7 @@
 #include "exl3_gemv_args.h"
 
 #include <type_traits>
-#define G2_PF 4
+#define G2_PF 2
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f)

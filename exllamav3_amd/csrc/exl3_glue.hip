@@ -18,24 +18,19 @@ struct SlabRef { const float* base; int S; };       // slab(c, s, row) = base + 
 
 __device__ __forceinline__ float4_t slab_sum(const SlabRef& sr, int c, int row, int m, int l)
 {
-    // independent 16-byte loads in batches of 8 (a dependent load-add chain costs ~0.6 us of L2/HBM latency per slab)
+    // independent 16-byte loads in batches of 16 (a dependent load-add chain costs ~0.6 us of L2/HBM latency per slab);
+    // the summation order is fixed, so results are run-to-run deterministic
     const float* p = sr.base + ((size_t) c * sr.S * m + row) * 128;
     const size_t st = (size_t) m * 128;
     float4_t v = { 0.f, 0.f, 0.f, 0.f };
-    int s = 0;
-    for (; s + 8 <= sr.S; s += 8)
+    for (int s = 0; s < sr.S; s += 16)
     {
-        float4_t t[8];
+        float4_t t[16];
         #pragma unroll
-        for (int i = 0; i < 8; ++i) t[i] = ((const float4_t*) (p + (size_t) (s + i) * st))[l];
+        for (int i = 0; i < 16; ++i) t[i] = ((const float4_t*) (p + (size_t) min(s + i, sr.S - 1) * st))[l];
         #pragma unroll
-        for (int i = 0; i < 8; ++i) { v.x += t[i].x; v.y += t[i].y; v.z += t[i].z; v.w += t[i].w; }
+        for (int i = 0; i < 16; ++i) if (s + i < sr.S) { v.x += t[i].x; v.y += t[i].y; v.z += t[i].z; v.w += t[i].w; }
     }
-    float4_t t[8];
-    #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = ((const float4_t*) (p + (size_t) min(s + i, sr.S - 1) * st))[l];
-    #pragma unroll
-    for (int i = 0; i < 8; ++i) if (s + i < sr.S) { v.x += t[i].x; v.y += t[i].y; v.z += t[i].z; v.w += t[i].w; }
     return v;
 }
 
@@ -69,20 +64,24 @@ __device__ __forceinline__ float in_had_store(half4_t x, const half_t* __restric
 // ------------------------------------------------------------------------------------------------
 struct NormTargets { const half_t* suh[3]; half_t* xh[3]; float* xsum[3]; int count; };
 
+#define GN_MAXT 16       // tasks (row, block) per half-wave kept in registers: m * hidden/128 <= 32 * GN_MAXT
+
 __global__ __launch_bounds__(1024)
 void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, const half_t* __restrict__ svh, const half_t* __restrict__ bias,
                       half_t* __restrict__ resid, const half_t* __restrict__ w, float eps, NormTargets tg, int m, int hidden,
                       half_t* __restrict__ xn_out)
 {
     __shared__ float ss_part[16 * 128];          // [row][block] partial sums of squares (hidden <= 16384)
-    __shared__ float rmf_s[16];
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5, nhw = blockDim.x >> 5;
     const int nblk = hidden >> 7;
     const int tasks = m * nblk;
-    // phase 1: residual update + sum of squares per (row, block)
-    for (int t0 = 0; t0 < tasks; t0 += nhw)
+    // phase 1: residual update + sum of squares per (row, block); the updated residual stays in registers
+    half4_t rr[GN_MAXT];
+    #pragma unroll
+    for (int it = 0; it < GN_MAXT; ++it)
     {
-        const int t = t0 + hw;
+        const int t = it * nhw + hw;
+        if (it * nhw >= tasks) break;
         const bool act = t < tasks;
         const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
         half4_t r = ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
@@ -108,6 +107,7 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
             r0 = (float) r.x; r1 = (float) r.y; r2 = (float) r.z; r3 = (float) r.w;
             if (act) ((half4_t*) (resid + (size_t) row * hidden + blk * 128))[l] = r;
         }
+        rr[it] = r;
         float ss = r0 * r0;
         ss = __builtin_fmaf(r1, r1, ss); ss = __builtin_fmaf(r2, r2, ss); ss = __builtin_fmaf(r3, r3, ss);
         #pragma unroll
@@ -115,22 +115,26 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
         if (act && l == 0) ss_part[row * 128 + blk] = ss;
     }
     __syncthreads();
-    if (tid < m)
-    {
-        float s = 0.0f;
-        for (int b = 0; b < nblk; ++b) s += ss_part[tid * 128 + b];          // fixed order: deterministic
-        rmf_s[tid] = __frsqrt_rn(s / (float) hidden + eps);
-    }
-    __syncthreads();
     // phase 2: normalise (fp32, one rounding to fp16 like rms_norm) and rotate for every consumer
-    for (int t0 = 0; t0 < tasks; t0 += nhw)
+    #pragma unroll
+    for (int it = 0; it < GN_MAXT; ++it)
     {
-        const int t = t0 + hw;
+        const int t = it * nhw + hw;
+        if (it * nhw >= tasks) break;
         const bool act = t < tasks;
         const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
-        half4_t r = ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
+        // row sum of squares: fixed-order tree over the block partials (deterministic), redundantly per half-wave
+        float s2 = 0.0f;
+        for (int b0 = 0; b0 < nblk; b0 += 32)
+        {
+            float v = (b0 + l < nblk) ? ss_part[row * 128 + b0 + l] : 0.0f;
+            #pragma unroll
+            for (int i = 1; i < 32; i <<= 1) v += __shfl_xor(v, i, 64);
+            s2 += v;
+        }
+        const float rmf = __frsqrt_rn(s2 / (float) hidden + eps);
+        half4_t r = rr[it];
         half4_t wv = ((const half4_t*) (w + blk * 128))[l];
-        const float rmf = rmf_s[row];
         half4_t xn = { (half_t) ((float) r.x * (float) wv.x * rmf), (half_t) ((float) r.y * (float) wv.y * rmf),
                        (half_t) ((float) r.z * (float) wv.z * rmf), (half_t) ((float) r.w * (float) wv.w * rmf) };
         if (xn_out && act) ((half4_t*) (xn_out + (size_t) row * hidden + blk * 128))[l] = xn;
@@ -222,14 +226,6 @@ void glue_qkv_kernel(QkvArgs a)
 {
     __shared__ float sn_s[16 * 64], cs_s[16 * 64];
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
-    for (int i = tid; i < a.m * 64; i += blockDim.x)
-    {
-        int row = i >> 6, f = i & 63;
-        float sn, cs;
-        sincosf(a.inv_freq[f] * (float) a.positions[row], &sn, &cs);
-        sn_s[i] = sn * a.attn_factor; cs_s[i] = cs * a.attn_factor;
-    }
-    __syncthreads();
     const int heads = a.hq + 2 * a.hkv;
     const int tasks = a.m * heads;
     const int t = blockIdx.x * 8 + hw;
@@ -239,8 +235,17 @@ void glue_qkv_kernel(QkvArgs a)
     const int hi = kind == 0 ? head : (kind == 1 ? head - a.hq : head - a.hq - a.hkv);
     const SlabRef& sr = kind == 0 ? a.sq : (kind == 1 ? a.sk : a.sv);
     const half_t* svh = (kind == 0 ? a.svh_q : (kind == 1 ? a.svh_k : a.svh_v)) + hi * 128;
+    const float4_t ysum = slab_sum(sr, hi, row, a.m, l);            // slab loads in flight while the sin/cos table is built
+    for (int i = tid; i < a.m * 64; i += blockDim.x)
+    {
+        int rw = i >> 6, f = i & 63;
+        float sn, cs;
+        sincosf(a.inv_freq[f] * (float) a.positions[rw], &sn, &cs);
+        sn_s[i] = sn * a.attn_factor; cs_s[i] = cs * a.attn_factor;
+    }
+    __syncthreads();
     float h0, h1, h2, h3;
-    out_had(slab_sum(sr, hi, row, a.m, l), l, h0, h1, h2, h3);
+    out_had(ysum, l, h0, h1, h2, h3);
     half4_t sc = ((const half4_t*) svh)[l];
     half4_t y = half4_t{ (half_t) h0, (half_t) h1, (half_t) h2, (half_t) h3 } * sc;       // fp16 output semantics of exl3_gemm
     if (kind != 2)
@@ -324,6 +329,7 @@ extern "C" int exl3_glue_norm(const float* y_slabs, int y_S, const float* y_dens
     EXL3_CHECK_ARG(resid && w, "glue_norm: null pointer");
     EXL3_CHECK_ARG(m >= 1 && m <= 16, "glue_norm: 1 <= m <= 16");
     EXL3_CHECK_ARG(hidden % 128 == 0 && hidden <= 16384, "glue_norm: hidden must be a multiple of 128, <= 16384");
+    EXL3_CHECK_ARG(m * (hidden / 128) <= 32 * GN_MAXT, "glue_norm: m * hidden / 128 must be <= 512");
     EXL3_CHECK_ARG(count >= 0 && count <= 3, "glue_norm: at most 3 consumers");
     EXL3_CHECK_ARG(!y_slabs || (svh && y_S >= 1), "glue_norm: pending output needs svh");
     NormTargets tg; tg.count = count;
@@ -338,6 +344,7 @@ extern "C" int exl3_glue_norm(const float* y_slabs, int y_S, const float* y_dens
     int tasks = m * (hidden / 128);
     int threads = tasks * 32; if (threads > 1024) threads = 1024; if (threads < 64) threads = 64;
     threads = (threads + 63) / 64 * 64;
+    EXL3_CHECK_ARG((tasks + threads / 32 - 1) / (threads / 32) <= GN_MAXT, "glue_norm: too many (row, block) tasks");
     glue_norm_kernel<<<1, threads, 0, (hipStream_t) stream>>>(y, (y_slabs || y_dense) ? 1 : 0, y_dense, (const half_t*) svh, (const half_t*) bias, (half_t*) resid,
                                                              (const half_t*) w, eps, tg, m, hidden, (half_t*) xn_out);
     return exl3_check_launch("glue_norm");
