@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libexl3_hip.so")
+LIB_PATH = os.environ.get("EXL3_HIP_LIB") or os.path.join(_HERE, "libexl3_hip.so")      # override: diagnostics builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "exl3_hip.h")
 
 _lib = None

@@ -50,7 +50,7 @@ static int init_device(int device)
     EXL3_CHECK_HIP(hipMemset(c.tickets, 0, EXL3_NUM_TICKETS * sizeof(uint32_t)), "hipMemset(tickets)");
     EXL3_CHECK_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
     c.ready = true;
-    hipSetDevice(prev);
+    (void) hipSetDevice(prev);
     return EXL3_OK;
 }
 

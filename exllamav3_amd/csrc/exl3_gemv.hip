@@ -429,6 +429,7 @@ static int gemv_gen()
 extern "C" int exl3_set_gemv_gen(int v) { g_gemv_gen = (v == 1) ? 1 : 2; return EXL3_OK; }
 static int g_gemv_nwv = 0;           // 0 = heuristic; otherwise cap on waves per workgroup (tuning / tests)
 static int g_gemv_defer_wg_per_cu = 0;
+
 extern "C" int exl3_set_gemv_defer_wg_per_cu(int v) { g_gemv_defer_wg_per_cu = v; return EXL3_OK; }
 extern "C" int exl3_set_gemv_max_waves(int v) { g_gemv_nwv = v; return EXL3_OK; }
 
@@ -570,7 +571,14 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             if (nwv > bps) nwv = bps;                            // every wave gets at least one Hadamard block
             if (g_gemv_nwv > 0 && nwv > g_gemv_nwv) nwv = g_gemv_nwv;
             if (nwv < 1) nwv = 1;
-            const size_t lds = exl3_gemv2_lds_bytes(ng, var, cb, nwv);
+            // activation fragments: up to ~64 KB per workgroup, whole wave range when it fits (one prep, then a pure stream)
+            const int AHh = (var == 1 && cb != 2) ? 32 : 16;
+            const int blocks_per_wave = (bps + nwv - 1) / nwv;
+            int chunk = (int) ((size_t) 65536 / ((size_t) nwv * 8 * mp * AHh * 2));
+            if (chunk < 1) chunk = 1;
+            if (chunk > blocks_per_wave) chunk = blocks_per_wave;
+            args.chunk_blocks = chunk;
+            const size_t lds = exl3_gemv2_lds_bytes(ng, var, cb, nwv, mp, chunk);
             switch (K)
             {
                 case 1: exl3_gemv2_launch_k1(cb, var, ng, nwv, grid, lds, st, args); break;

@@ -148,12 +148,13 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const int nbw = b1 - b0;                         // blocks of this wave (may be 0)
     const int k0 = k0s + 128 * b0;
 
-    // LDS carve: per-wave fragment double buffer | per-wave row sums | partials [4][MR][128]
-    constexpr int FRAG_HALVES = 2 * 8 * MR * AH;
-    half_t* xa = (half_t*) smem + (size_t) wave * FRAG_HALVES;
-    float* part = (float*) (smem + (size_t) nwv * FRAG_HALVES * 2);
+    // LDS carve: per-wave activation fragments for a CHUNK of `chb` Hadamard blocks [blk][tile row 8][row m][AH halves]
+    //            | partials [nwv][MR][128] fp32 | per-wave row sums
+    const int chb = a.chunk_blocks;                  // blocks per chunk (host: LDS budget / waves)
+    const size_t frag_halves = (size_t) chb * 8 * m * AH;
+    half_t* xa = (half_t*) smem + (size_t) wave * frag_halves;
+    float* part = (float*) (smem + (((size_t) nwv * frag_halves * 2 + 15) & ~(size_t) 15));
 
-    // ---- just-in-time input Hadamard of one 128-block into fragment buffer `buf`
     float rowsum[2 * NG];
     #pragma unroll
     for (int i = 0; i < 2 * NG; ++i) rowsum[i] = 0.0f;
@@ -161,39 +162,66 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const bool in_rotated = (a.flags & GEMV_IN_ROTATED) != 0;
     const half_t* __restrict__ xh_in = a.mat[mi].xh;
     const float* __restrict__ xsum_in = a.mat[mi].xsum;
-    auto prep_block = [&] (int blk, int buf)
+    const int npass = (m + 1) >> 1;                  // passes of 2 rows (one per half-wave)
+
+    // ---- input Hadamard (or fetch of the pre-rotated input) of `cnt` blocks starting at wave-local block c0, written in
+    //      MFMA-A fragment order.  Software pipelined by one task so the global loads of task i+1 fly during task i.
+    auto prep_chunk = [&] (int c0, int cnt)
     {
-        #pragma unroll
-        for (int p = 0; p < 2 * NG; ++p)
+        const int ntask = cnt * npass;
+        half4_t xv_n = {}, sv_n = {}; float xs_n = 0.0f;
+        auto fetch = [&] (int t)
         {
+            const int blk = c0 + t / npass, p = t % npass;
             const int row = 2 * p + hw;
-            if (2 * p >= m) break;                                      // wave-uniform
             const bool act = row < m;
             const size_t off = (size_t) (act ? row : 0) * a.k + k0 + 128 * blk;
-            half2_t o01, o23;
             if (in_rotated)
             {
-                // producer already applied suh + Hadamard (and rounded to fp16): just fetch the 4 values of this lane
-                half4_t xv = ((const half4_t*) (xh_in + off))[l32];
-                o01 = half2_t{ xv.x, xv.y }; o23 = half2_t{ xv.z, xv.w };
-                if constexpr (RAW) { if (act) rowsum[p] += xsum_in[(size_t) row * (a.k >> 7) + (k0 >> 7) + blk]; }
+                xv_n = ((const half4_t*) (xh_in + off))[l32];
+                if constexpr (RAW) xs_n = xsum_in[(size_t) (act ? row : 0) * (a.k >> 7) + (k0 >> 7) + blk];
             }
             else
             {
-                half4_t xv = ((const half4_t*) (a.A + off))[l32];
-                half4_t sv = ((const half4_t*) (suh + k0 + 128 * blk))[l32];
-                xv = xv * sv;
+                xv_n = ((const half4_t*) (a.A + off))[l32];
+                sv_n = ((const half4_t*) (suh + k0 + 128 * blk))[l32];
+            }
+        };
+        fetch(0);
+        for (int t = 0; t < ntask; ++t)
+        {
+            const half4_t xv_c = xv_n, sv_c = sv_n; const float xs_c = xs_n;
+            if (t + 1 < ntask) fetch(t + 1);
+            const int blk_l = t / npass, p = t % npass;              // chunk-local block
+            const int row = 2 * p + hw;
+            const bool act = row < m;
+            half2_t o01, o23;
+            float bsum;
+            if (in_rotated)
+            {
+                o01 = half2_t{ xv_c.x, xv_c.y }; o23 = half2_t{ xv_c.z, xv_c.w };
+                bsum = xs_c;
+            }
+            else
+            {
+                half4_t xv = xv_c * sv_c;
                 float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
                 had128_f32x4(h0, h1, h2, h3, l32);
                 o01 = half2_t{ (half_t) (h0 * HAD_R_SCALE_128), (half_t) (h1 * HAD_R_SCALE_128) };
                 o23 = half2_t{ (half_t) (h2 * HAD_R_SCALE_128), (half_t) (h3 * HAD_R_SCALE_128) };
+                bsum = 0.0f;
                 if constexpr (RAW)
                 {
-                    float t = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
+                    bsum = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
                     #pragma unroll
-                    for (int i = 1; i < 32; i <<= 1) t += __shfl_xor(t, i, 64);
-                    if (act) rowsum[p] += t;
+                    for (int i = 1; i < 32; i <<= 1) bsum += __shfl_xor(bsum, i, 64);
                 }
+            }
+            if constexpr (RAW)
+            {
+                // rowsum[p] with a static index (p is runtime here): predicated adds
+                #pragma unroll
+                for (int pp = 0; pp < 2 * NG; ++pp) if (pp == p && act) rowsum[pp] += bsum;
             }
             if (act)
             {
@@ -201,7 +229,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 const int r8 = l32 >> 2;
                 const int q0 = 2 * (l32 & 1);
                 const int sp = (l32 >> 1) & 1;                          // slot pair: rows {2q,2q+1} (0) or {2q+8,2q+9} (1)
-                half_t* base = xa + ((size_t) (buf * 8 + r8) * MR + row) * AH;
+                half_t* base = xa + ((size_t) (blk_l * 8 + r8) * m + row) * AH;
                 if constexpr (SPLIT)
                 {
                     half4_t d01 = { o01.x, o01.x, o01.y, o01.y }, d23 = { o23.x, o23.x, o23.y, o23.y };
@@ -224,7 +252,9 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const int nrows = nbw * 8;
     const int last_row = nrows > 0 ? nrows - 1 : 0;
     const int prev_lane_addr = ((lane & ~7) | ((lane - 1) & 7)) << 2;   // ds_bpermute byte address
-    const half_t* arow = xa + (size_t) (lane & 15) * AH;                 // this lane's A row (rows >= m: garbage rows, ignored)
+    // this lane's A row; lanes whose row is >= m read row m-1 (their MFMA output rows are never stored)
+    const half_t* arow = xa + (size_t) min(lane & 15, m - 1) * AH;
+    const size_t astep = (size_t) m * AH;                               // halves per tile row
 
     float4_t acc_c[NG], acc_d[NG];
     #pragma unroll
@@ -237,67 +267,82 @@ void exl3_gemv2_kernel(const GemvArgs a)
         for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(u, last_row) * row_stride);
     }
 
-    for (int blk = 0; blk < nbw; ++blk)
+    for (int c0 = 0; c0 < nbw; c0 += chb)
     {
-        const int buf = blk & 1;
-        prep_block(blk, buf);
+        const int cnt = min(chb, nbw - c0);
+        prep_chunk(c0, cnt);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // wave-private LDS: in-order queue + drain
         __builtin_amdgcn_wave_barrier();
 
-        #pragma unroll
-        for (int r = 0; r < 8; ++r)
+        // pure streaming loop over the chunk's tile rows, G2_PF rows per iteration (8 * cnt is a multiple of G2_PF)
+        const int row_end = (c0 + cnt) * 8;
+        for (int row0 = c0 * 8; row0 < row_end; row0 += G2_PF)
         {
-            const int u = r % G2_PF;
-            const int row = blk * 8 + r;
-
-            uint32_t Wx[K + 1];
             #pragma unroll
-            for (int i = 0; i < K; ++i) Wx[i + 1] = ring[u].w[i];
-            Wx[0] = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) ring[u].w[K - 1]);
-
-            // refill the slot
-            load_lane_words<K>(ring[u], strip + (size_t) min(row + G2_PF, last_row) * row_stride);
-
-            // A fragments of this tile row for this lane's activation row
-            const half_t* ap = arow + (size_t) (buf * 8 + r) * MR * AH;
-            half8_t af[AH / 8];
-            #pragma unroll
-            for (int i = 0; i < AH / 8; ++i) af[i] = ((const half8_t*) ap)[i];
-
-            static_for<0, 4>([&] (auto qc)
+            for (int u = 0; u < G2_PF; ++u)
             {
-                constexpr int q = decltype(qc)::value;
-                half4_t bc[2], bd[2];
-                // weights 8q..8q+3 -> column c ; 8q+4..8q+7 -> column c + 8
-                decode_quad<K, CB, VAR, 8 * q>(Wx, bc);
-                decode_quad<K, CB, VAR, 8 * q + 4>(Wx, bd);
-                if constexpr (SPLIT)
+                const int row = row0 + u;
+                uint32_t Wx[K + 1];
+                #pragma unroll
+                for (int i = 0; i < K; ++i) Wx[i + 1] = ring[u].w[i];
+#ifdef G2_ABL_NOBPERM
+                Wx[0] = ring[u].w[K - 1] * 11u;                          // diagnostics build: no cross-lane carry
+#else
+                Wx[0] = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) ring[u].w[K - 1]);
+#endif
+
+                // refill the slot
+                load_lane_words<K>(ring[u], strip + (size_t) min(row + G2_PF, last_row) * row_stride);
+
+                // A fragments of this tile row for this lane's activation row
+                const half_t* ap = arow + (size_t) (row - c0 * 8) * astep;
+                half8_t af[AH / 8];
+#ifdef G2_ABL_NOAFRAG
+                #pragma unroll
+                for (int i = 0; i < AH / 8; ++i) af[i] = half8_t{ 1, 2, 3, 4, 5, 6, 7, 8 };   // diagnostics build: no LDS fragment reads
+                (void) ap;
+#else
+                #pragma unroll
+                for (int i = 0; i < AH / 8; ++i) af[i] = ((const half8_t*) ap)[i];
+#endif
+
+                static_for<0, 4>([&] (auto qc)
                 {
-                    half8_t f = af[q];
-                    half4_t a0 = { f[0], f[1], f[2], f[3] }, a1 = { f[4], f[5], f[6], f[7] };
-                    static_for<0, NG>([&] (auto gc)
+                    constexpr int q = decltype(qc)::value;
+                    half4_t bc[2], bd[2];
+                    // weights 8q..8q+3 -> column c ; 8q+4..8q+7 -> column c + 8
+                    decode_quad<K, CB, VAR, 8 * q>(Wx, bc);
+                    decode_quad<K, CB, VAR, 8 * q + 4>(Wx, bd);
+                    if constexpr (SPLIT)
                     {
-                        constexpr int gq = decltype(gc)::value;
-                        acc_c[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bc[0], acc_c[gq], 4, gq, 0);
-                        acc_c[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, bc[1], acc_c[gq], 4, gq, 0);
-                        acc_d[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bd[0], acc_d[gq], 4, gq, 0);
-                        acc_d[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, bd[1], acc_d[gq], 4, gq, 0);
-                    });
-                }
-                else
-                {
-                    half8_t f = af[q >> 1];
-                    half4_t a0 = (q & 1) ? half4_t{ f[4], f[5], f[6], f[7] } : half4_t{ f[0], f[1], f[2], f[3] };
-                    static_for<0, NG>([&] (auto gc)
+                        half8_t f = af[q];
+                        half4_t a0 = { f[0], f[1], f[2], f[3] }, a1 = { f[4], f[5], f[6], f[7] };
+                        static_for<0, NG>([&] (auto gc)
+                        {
+                            constexpr int gq = decltype(gc)::value;
+                            acc_c[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bc[0], acc_c[gq], 4, gq, 0);
+                            acc_d[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bd[0], acc_d[gq], 4, gq, 0);
+                            acc_c[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, bc[1], acc_c[gq], 4, gq, 0);
+                            acc_d[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a1, bd[1], acc_d[gq], 4, gq, 0);
+                        });
+                    }
+                    else
                     {
-                        constexpr int gq = decltype(gc)::value;
-                        acc_c[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bc[0], acc_c[gq], 4, gq, 0);
-                        acc_d[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bd[0], acc_d[gq], 4, gq, 0);
-                    });
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);      // keep the refill loads of different steps in program order
+                        half8_t f = af[q >> 1];
+                        half4_t a0 = (q & 1) ? half4_t{ f[4], f[5], f[6], f[7] } : half4_t{ f[0], f[1], f[2], f[3] };
+                        static_for<0, NG>([&] (auto gc)
+                        {
+                            constexpr int gq = decltype(gc)::value;
+                            acc_c[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bc[0], acc_c[gq], 4, gq, 0);
+                            acc_d[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bd[0], acc_d[gq], 4, gq, 0);
+                        });
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // bound live ranges: 8 weights in flight at a time (occupancy > ILP here)
+                });
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // fragment reads done before the next chunk overwrites them
+        __builtin_amdgcn_wave_barrier();
     }
 
     // ---- epilogue: per-wave partials -> LDS, cross-wave sum, output Hadamard
@@ -419,11 +464,11 @@ void G2_CAT(exl3_gemv2_launch_k, G2_K)(int cb, int var, int ng, int nwv, dim3 gr
 }
 
 #if G2_K == 4
-size_t exl3_gemv2_lds_bytes(int ng, int var, int cb, int nwv)
+size_t exl3_gemv2_lds_bytes(int ng, int var, int cb, int nwv, int m, int chunk_blocks)
 {
     const int MR = 4 * ng;
     const int AH = (var == 1 && cb != 2) ? 32 : 16;
-    size_t frag = (size_t) nwv * (2 * 8 * MR * AH) * 2;
+    size_t frag = ((size_t) nwv * chunk_blocks * 8 * m * AH * 2 + 15) & ~(size_t) 15;
     size_t part = (size_t) nwv * MR * 128 * 4 + (size_t) nwv * MR * 4;
     return frag + part;
 }

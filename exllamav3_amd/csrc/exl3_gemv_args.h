@@ -33,11 +33,12 @@ struct GemvArgs
     int kslice;            // elements per slice (multiple of 128)
     int c_fp32;
     int flags;             // GEMV_IN_ROTATED | GEMV_OUT_DEFERRED
+    int chunk_blocks;      // gen 2: Hadamard blocks of activation fragments a wave keeps in LDS at a time
     int64_t c_row_offset;  // first output row of this pass
 };
 
 // generation-2 kernels: one translation unit per K (exl3_gemv2.kspec.hip compiled with -DG2_K=1..8)
-size_t exl3_gemv2_lds_bytes(int ng, int var, int cb, int nwv);
+size_t exl3_gemv2_lds_bytes(int ng, int var, int cb, int nwv, int m, int chunk_blocks);
 #define G2_DECL(KK) void exl3_gemv2_launch_k##KK(int cb, int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args);
 G2_DECL(1) G2_DECL(2) G2_DECL(3) G2_DECL(4) G2_DECL(5) G2_DECL(6) G2_DECL(7) G2_DECL(8)
 #undef G2_DECL
