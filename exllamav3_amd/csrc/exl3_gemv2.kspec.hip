@@ -25,6 +25,7 @@
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
 #include "exl3_gemv_args.h"
+#include "exl3_lane_decode.cuh"
 
 #include <type_traits>
 #define G2_PF 2
@@ -33,25 +34,6 @@ template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f)
 {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-
-// ---- compile-time bit-window extraction ----------------------------------------------------------------
-// Wx[0] = previous lane's last word (carry-in), Wx[1..K] = the lane's K words.  Weight t (0..31): window of 16 bits
-// ending at extended-stream bit 32 + (t+1)K.
-template <int K, int T>
-__device__ __forceinline__ uint32_t lane_state(const uint32_t (&Wx)[K + 1])
-{
-    constexpr int e = 32 + (T + 1) * K;          // exclusive end, 33..288
-    constexpr int lo = (e - 1) >> 5;
-    constexpr int hi = (e - 16) >> 5;
-    constexpr int sh = 32 * (lo + 1) - e;        // 0..31
-    if constexpr (hi == lo)
-    {
-        if constexpr (sh == 0) return Wx[lo] & 0xffffu;
-        else if constexpr (sh == 16) return Wx[lo] >> 16;
-        else return __builtin_amdgcn_ubfe(Wx[lo], sh, 16);
-    }
-    else return __builtin_amdgcn_alignbit(Wx[hi], Wx[lo], sh) & 0xffffu;
 }
 
 __device__ __forceinline__ half4_t u2_as_half4(uint32_t a, uint32_t b)
@@ -91,26 +73,6 @@ __device__ __forceinline__ void decode_quad(const uint32_t (&Wx)[K + 1], half4_t
             half2_t rb = __builtin_elementwise_fma(u32_as_half2(h23), kinv, kbias);
             out[0] = u2_as_half4(half2_as_u32(ra), half2_as_u32(rb));
         }
-    }
-}
-
-template <int K> struct LaneWords { uint32_t w[K]; };
-
-template <int K>
-__device__ __forceinline__ void load_lane_words(LaneWords<K>& d, const uint32_t* __restrict__ p)
-{
-    // p = this lane's first word of the tile row; K consecutive words (contiguous across the wave)
-    if constexpr (K == 4) { uint4_t v = __builtin_nontemporal_load((const uint4_t*) p); d.w[0] = v.x; d.w[1] = v.y; d.w[2] = v.z; d.w[3] = v.w; }
-    else if constexpr (K == 8)
-    {
-        uint4_t v = __builtin_nontemporal_load((const uint4_t*) p), u = __builtin_nontemporal_load((const uint4_t*) p + 1);
-        d.w[0] = v.x; d.w[1] = v.y; d.w[2] = v.z; d.w[3] = v.w; d.w[4] = u.x; d.w[5] = u.y; d.w[6] = u.z; d.w[7] = u.w;
-    }
-    else if constexpr (K == 2) { uint2_t v = __builtin_nontemporal_load((const uint2_t*) p); d.w[0] = v.x; d.w[1] = v.y; }
-    else
-    {
-        #pragma unroll
-        for (int i = 0; i < K; ++i) d.w[i] = __builtin_nontemporal_load(p + i);
     }
 }
 

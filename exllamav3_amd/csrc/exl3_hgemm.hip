@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <stdlib.h>
 
 #define HGEMM_WS_BYTES (64ll << 20)
 
@@ -60,16 +61,50 @@ extern "C" int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, i
     auto it = cx.algos.find(key);
     if (it == cx.algos.end())
     {
+        // First use of a shape: ask hipBLASLt for its candidate list and, when not capturing, time them on the caller's
+        // buffers (the reference autotunes its own GEMM kernels the same way: quant/coop_autotune.cu).  EXL3_HIP_HGEMM_TUNE=0
+        // keeps the top heuristic.
         hipblasLtMatmulPreference_t pref;
         CHECK_LT(hipblasLtMatmulPreferenceCreate(&pref), "PreferenceCreate");
         size_t wsz = HGEMM_WS_BYTES;
         CHECK_LT(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz)), "set workspace");
-        hipblasLtMatmulHeuristicResult_t res[1];
+        constexpr int MAXA = 24;
+        hipblasLtMatmulHeuristicResult_t res[MAXA];
         int found = 0;
-        CHECK_LT(hipblasLtMatmulAlgoGetHeuristic(cx.handle, desc, la, lb, lc, lc, pref, 1, res, &found), "AlgoGetHeuristic");
+        CHECK_LT(hipblasLtMatmulAlgoGetHeuristic(cx.handle, desc, la, lb, lc, lc, pref, MAXA, res, &found), "AlgoGetHeuristic");
         hipblasLtMatmulPreferenceDestroy(pref);
         if (found < 1) { exl3_set_error("hgemm: no hipBLASLt algorithm for m=%d k=%d n=%d", m, k, n); return EXL3_ERR_HIP; }
-        it = cx.algos.emplace(key, res[0].algo).first;
+        int best = 0;
+        static int tune = -1;
+        if (tune < 0) { const char* e = getenv("EXL3_HIP_HGEMM_TUNE"); tune = e ? atoi(e) : 1; }
+        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+        bool capturing = stream && hipStreamIsCapturing((hipStream_t) stream, &cst) == hipSuccess && cst != hipStreamCaptureStatusNone;
+        if (tune && found > 1 && !capturing && (double) m * k * n > 1e9)
+        {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            const float al = 1.0f, be = 0.0f;
+            float best_ms = 1e30f;
+            for (int i = 0; i < found; ++i)
+            {
+                if (res[i].workspaceSize > HGEMM_WS_BYTES) continue;
+                bool ok = true;
+                float ms = 0.0f;
+                for (int rep = 0; rep < 3 && ok; ++rep)
+                {
+                    if (rep == 1) hipEventRecord(e0, (hipStream_t) stream);
+                    ok = hipblasLtMatmul(cx.handle, desc, &al, b, la, a, lb, &be, c, lc, c, lc, &res[i].algo, cx.ws, HGEMM_WS_BYTES,
+                                         (hipStream_t) stream) == HIPBLAS_STATUS_SUCCESS;
+                }
+                if (!ok) continue;
+                hipEventRecord(e1, (hipStream_t) stream);
+                hipEventSynchronize(e1);
+                hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best_ms) { best_ms = ms; best = i; }
+            }
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
+        it = cx.algos.emplace(key, res[best].algo).first;
     }
     const float alpha = 1.0f, beta = 0.0f;
     hipblasStatus_t st = hipblasLtMatmul(cx.handle, desc, &alpha, b, la, a, lb, &beta, c, lc, c, lc, &it->second,

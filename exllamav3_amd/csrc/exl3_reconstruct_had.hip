@@ -8,25 +8,35 @@
 // intermediate (after the k-side transform and suh) is rounded to fp16, the final result is rounded once.
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
+#include "exl3_lane_decode.cuh"
 
 #define RH_LD 136          // padded leading dimension (halves) of the 128x128 LDS images: 272 B rows -> conflict-free b128 reads
 
-// fp16 +-1 Hadamard fragment for v_mfma_f32_16x16x32_f16: 8 halves, element s = H[a][b0 + s], b0 % 8 == 0
-__device__ __forceinline__ half8_t had_frag(int a, int b0)
+// Sylvester structure: H128[a][b] = H8[a >> 4][b >> 4] * H16[a & 15][b & 15].  For an MFMA fragment whose k-slots are
+// b = 32 ks + 8 g + s (s = 0..7) and whose row/column index is a = 16 t + j, the 8 halves are
+//     H8[t][2 ks + (g >> 1)] * H16[j][8 (g & 1) + s]
+// i.e. ONE per-lane base fragment (depends on j, g & 1 only) times a +-1 scalar per (t, ks): 4 xors instead of 25 VALU ops.
+__device__ __forceinline__ void had_base_frag(int j, int g, uint32_t (&f)[4])
 {
-    const uint32_t p0 = __builtin_popcount(a & b0) & 1;
-    // parity((a & 7) & s) for s = 0..7 as a bit mask
-    const int a3 = a & 7;
-    uint32_t m8 = 0;
-    #pragma unroll
-    for (int s = 0; s < 8; ++s) m8 |= (uint32_t) (__builtin_popcount(a3 & s) & 1) << s;
-    m8 ^= p0 ? 0xffu : 0u;
-    union { uint32_t u[4]; half8_t h; } f;
+    const int b0 = 8 * (g & 1);
     #pragma unroll
     for (int r = 0; r < 4; ++r)
-        f.u[r] = 0x3C003C00u ^ (((m8 >> (2 * r)) & 1u) << 15) ^ (((m8 >> (2 * r + 1)) & 1u) << 31);
+    {
+        uint32_t s0 = __builtin_popcount(j & (b0 + 2 * r)) & 1, s1 = __builtin_popcount(j & (b0 + 2 * r + 1)) & 1;
+        f[r] = 0x3C003C00u ^ (s0 << 15) ^ (s1 << 31);
+    }
+}
+
+__device__ __forceinline__ half8_t had_frag_signed(const uint32_t (&base)[4], int t, int ks, int g)
+{
+    const uint32_t neg = (__builtin_popcount(t & (2 * ks + (g >> 1))) & 1) ? 0x80008000u : 0u;
+    union { uint32_t u[4]; half8_t h; } f;
+    f.u[0] = base[0] ^ neg; f.u[1] = base[1] ^ neg; f.u[2] = base[2] ^ neg; f.u[3] = base[3] ^ neg;
     return f.h;
 }
+
+// row r (0..15) of the lane's column c (HI = 0) or c + 8 (HI = 1) is weight t = 8q + j
+template <int R, int HI> struct RowToWeight { static constexpr int q = (R & 7) >> 1, j = (R & 1) + 2 * (R >> 3) + 4 * HI, t = 8 * q + j; };
 
 template <int K, int CB>
 __global__ __launch_bounds__(256)
@@ -37,36 +47,45 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* Wt = (half_t*) smem;                          // [n][RH_LD]  W_hat transposed; later the output staging [k'][RH_LD]
     half_t* T = Wt + 128 * RH_LD;                         // [k'][RH_LD] intermediate
-    uint32_t* words = (uint32_t*) (T + 128 * RH_LD);      // [8 tile rows][8 tiles][NW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kb = blockIdx.y, nb = blockIdx.x;
 
-    // ---- packed words of the 8x8 tiles
-    for (int i = tid; i < 8 * 8 * NW; i += 256)
+    // ---- decode: wave w handles tile rows 2w, 2w+1; lane (8T + c) owns columns c, c+8 of tile T (exl3_lane_decode.cuh):
+    //      one contiguous 256*K-byte load per wave and tile row, constant-shift windows, bit-exact fp16 values.
     {
-        int tr = i / (8 * NW), rest = i % (8 * NW);
-        words[i] = packed[((int64_t) (kb * 8 + tr) * tiles_n_total + tile_n_offset + nb * 8) * NW + rest];
-    }
-    __syncthreads();
-
-    // ---- decode: thread -> (tile, column, row half): 8 consecutive k of one n -> one 16-byte store into Wt[n][k]
-    #pragma unroll 2
-    for (int it = 0; it < 8; ++it)
-    {
-        int unit = tid + 256 * it;
-        int tile = unit >> 5, c = (unit & 31) >> 1, rh = unit & 1;
-        int tr = tile >> 3, tcn = tile & 7;
-        const uint32_t* w = words + (size_t) tile * NW;
-        half8_t v;
+        const int Tt = lane >> 3, c = lane & 7;
+        const int prev_lane_addr = ((lane & ~7) | ((lane - 1) & 7)) << 2;
         #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = decode_exact<CB>(tile_state<K>(w, tile_stream_index(8 * rh + r, c)));
-        *((half8_t*) (Wt + (size_t) (16 * tcn + c) * RH_LD + 16 * tr + 8 * rh)) = v;
+        for (int rr = 0; rr < 2; ++rr)
+        {
+            const int tr = 2 * wave + rr;
+            const uint32_t* src = packed + ((int64_t) (kb * 8 + tr) * tiles_n_total + tile_n_offset + nb * 8) * NW + (size_t) lane * K;
+            LaneWords<K> lw;
+            load_lane_words<K>(lw, src);
+            uint32_t Wx[K + 1];
+            #pragma unroll
+            for (int i = 0; i < K; ++i) Wx[i + 1] = lw.w[i];
+            Wx[0] = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) lw.w[K - 1]);
+            half8_t lo0, lo1, hi0, hi1;                   // column c rows 0-7 / 8-15 ; column c+8 rows 0-7 / 8-15
+            #define DEC(R, HI) decode_exact<CB>(lane_state<K, RowToWeight<R, HI>::t>(Wx))
+            lo0 = half8_t{ DEC(0, 0), DEC(1, 0), DEC(2, 0), DEC(3, 0), DEC(4, 0), DEC(5, 0), DEC(6, 0), DEC(7, 0) };
+            lo1 = half8_t{ DEC(8, 0), DEC(9, 0), DEC(10, 0), DEC(11, 0), DEC(12, 0), DEC(13, 0), DEC(14, 0), DEC(15, 0) };
+            hi0 = half8_t{ DEC(0, 1), DEC(1, 1), DEC(2, 1), DEC(3, 1), DEC(4, 1), DEC(5, 1), DEC(6, 1), DEC(7, 1) };
+            hi1 = half8_t{ DEC(8, 1), DEC(9, 1), DEC(10, 1), DEC(11, 1), DEC(12, 1), DEC(13, 1), DEC(14, 1), DEC(15, 1) };
+            #undef DEC
+            half_t* w0 = Wt + (size_t) (16 * Tt + c) * RH_LD + 16 * tr;
+            half_t* w1 = Wt + (size_t) (16 * Tt + c + 8) * RH_LD + 16 * tr;
+            *((half8_t*) w0) = lo0; *((half8_t*) (w0 + 8)) = lo1;
+            *((half8_t*) w1) = hi0; *((half8_t*) (w1 + 8)) = hi1;
+        }
     }
     __syncthreads();
 
     const int j = lane & 15, g = lane >> 4;
     const float r128 = HAD_R_SCALE_128;
+    uint32_t hbase[4];
+    had_base_frag(j, g, hbase);
 
     // ---- GEMM 1: D1[k'][n] = sum_k H[k'][k] * W_hat[k][n];   T = fp16(D1 * suh[k'] / sqrt(128))
     {
@@ -74,7 +93,14 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
         #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
             #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) ha[rt][ks] = had_frag(16 * (2 * wave + rt) + j, 32 * ks + 8 * g);
+            for (int ks = 0; ks < 4; ++ks) ha[rt][ks] = had_frag_signed(hbase, 2 * wave + rt, ks, g);
+        float sc0[4], sc1[4];
+        #pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            sc0[r] = (float) suh[kb * 128 + 16 * (2 * wave) + 4 * g + r] * r128;
+            sc1[r] = (float) suh[kb * 128 + 16 * (2 * wave + 1) + 4 * g + r] * r128;
+        }
         #pragma unroll 2
         for (int ct = 0; ct < 8; ++ct)
         {
@@ -90,9 +116,8 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
             for (int r = 0; r < 4; ++r)
             {
                 int k0r = 16 * (2 * wave) + 4 * g + r, k1r = k0r + 16;
-                float s0 = (float) suh[kb * 128 + k0r] * r128, s1 = (float) suh[kb * 128 + k1r] * r128;
-                T[(size_t) k0r * RH_LD + 16 * ct + j] = (half_t) (acc0[r] * s0);
-                T[(size_t) k1r * RH_LD + 16 * ct + j] = (half_t) (acc1[r] * s1);
+                T[(size_t) k0r * RH_LD + 16 * ct + j] = (half_t) (acc0[r] * sc0[r]);
+                T[(size_t) k1r * RH_LD + 16 * ct + j] = (half_t) (acc1[r] * sc1[r]);
             }
         }
     }
@@ -113,7 +138,7 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
             #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
             {
-                half8_t hb = had_frag(16 * ct + j, 32 * ks + 8 * g);
+                half8_t hb = had_frag_signed(hbase, ct, ks, g);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0][ks], hb, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[1][ks], hb, acc1, 0, 0, 0);
             }
@@ -151,7 +176,7 @@ extern "C" int exl3_reconstruct_had(void* out, const void* trellis, const void* 
     EXL3_CHECK_ARG(n_offset + n_size <= (int64_t) tiles_n * 16, "reconstruct slice exceeds packed tensor bounds");
     if (n_size == 0 || tiles_k == 0) return EXL3_OK;
     dim3 grid((unsigned) (n_size / 128), (unsigned) (tiles_k / 8));
-    size_t lds = (size_t) 2 * 128 * RH_LD * 2 + (size_t) 64 * 8 * K * 4;
+    size_t lds = (size_t) 2 * 128 * RH_LD * 2;
     hipStream_t st = (hipStream_t) stream;
     switch (K * 3 + cb)
     {
