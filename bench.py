@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--prefill-tokens", type=int, default=4096)
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--gen", type=int, default=2)
-    ap.add_argument("--unfused", action="store_true", help="one launch per reference op instead of the fused glue pipeline")
+    ap.add_argument("--unfused", action="store_true", help="one launch per reference op instead of the fused pipeline")
+    ap.add_argument("--pipeline", choices=["tail", "glue", "unfused"], default="tail",
+                    help="tail: sublayer boundaries run inside the GEMV launches (4 launches/layer); glue: separate glue kernels (8/layer)")
     return ap.parse_args()
 
 
@@ -105,8 +107,11 @@ def main():
     model.alloc_state(args.batch)
 
     # ---- decode: eager warm-up (also creates library contexts), graph capture, timed replays
-    fused = not args.unfused
-    run_step = model.decode_step_fused if fused else model.decode_step
+    pipeline = "unfused" if args.unfused else args.pipeline
+    if pipeline == "tail" and world > 1:
+        pipeline = "glue"                                  # TP ranks all-reduce between o/down and the norm
+    fused = pipeline != "unfused"
+    run_step = {"tail": model.decode_step_tail, "glue": model.decode_step_fused, "unfused": model.decode_step}[pipeline]
     run_step()
     torch.cuda.synchronize()
     graph = None
@@ -166,7 +171,7 @@ def main():
         # distinct cold weights) and the replay is bracketed by HIP events on the replay stream, so host/ctypes time
         # is excluded; the figure still contains the ~1-2 us inter-kernel gap of back-to-back graph nodes.
         bsz = args.batch
-        calls = model.gemv_calls(fused)
+        calls = model.gemv_calls(pipeline)
         per_layer = 4
         groups = [calls[i:len(calls) - 1:per_layer] for i in range(per_layer)] + [[calls[-1]] * 4]
         total_us, launches = 0.0, 0
@@ -248,7 +253,7 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{shape.name} EXL3 {args.bits}.0bpw {args.codebook} codebook, decode bs={args.batch}, "
                                    f"{model.n_layers} layers, TP={world}, {args.kv_bits}-bit KV append, "
-                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, {'fused glue pipeline (8 launches/layer)' if fused else 'one launch per reference op'}; "
+                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, { {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (8 launches/layer)', 'unfused': 'one launch per reference op'}[pipeline] }; "
                                    f"attention core excluded (SURVEY.md 2.1)",
                        "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
                        "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),

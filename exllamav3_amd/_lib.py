@@ -104,6 +104,10 @@ def _declare(l):
     sig("exl3_glue_norm", vp, i32, vp, vp, vp, vp, vp, f32, PP, PP, PP, i32, i32, i32, vp, vp)
     sig("exl3_glue_qkv", vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp)
     sig("exl3_glue_act", vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp)
+    sig("exl3_gemv_norm", vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, i32, vp, vp)
+    sig("exl3_gemv_act", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp)
+    sig("exl3_gemv_qkv", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp)
+    sig("exl3_rope_table", vp, vp, f32, i32, vp, vp, vp)
     sig("exl3_set_gemv_variant", i32)
     sig("exl3_set_gemv_gen", i32)
     sig("exl3_set_gemv_max_waves", i32)

@@ -101,6 +101,41 @@ __device__ __forceinline__ int tile_stream_index(int r, int c)
     return 8 * l + j;
 }
 
+// Butterfly exchange v[lane ^ I] for a compile-time I.  hipcc lowers __shfl_xor to ds_bpermute_b32 (LDS crossbar, ~100+ cycles of
+// dependent latency per stage); the latency-bound decode kernels are chains of these, so use the register-file paths instead:
+//   I = 1, 2 : one DPP quad_perm (folds into the consuming VALU op)
+//   I = 4    : row_half_mirror (i ^ 7) then quad reverse (i ^ 3)
+//   I = 8    : row_mirror (i ^ 15) then row_half_mirror (i ^ 7)
+//   I = 16/32: gfx950 v_permlane16_swap / v_permlane32_swap + one select
+__device__ __forceinline__ uint32_t xor_lane_u32(uint32_t v, const int i)
+{
+    #define EXL3_DPP(x, ctrl) ((uint32_t) __builtin_amdgcn_update_dpp(0, (int) (x), ctrl, 0xf, 0xf, true))
+    switch (i)
+    {
+        case 1: return EXL3_DPP(v, 0xB1);
+        case 2: return EXL3_DPP(v, 0x4E);
+        case 4: { uint32_t t = EXL3_DPP(v, 0x141); return EXL3_DPP(t, 0x1B); }
+        case 8: { uint32_t t = EXL3_DPP(v, 0x140); return EXL3_DPP(t, 0x141); }
+        case 16:
+        {
+            auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+            const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            return (lane & 16) ? r[0] : r[1];
+        }
+        case 32:
+        {
+            auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+            const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            return (lane & 32) ? r[0] : r[1];
+        }
+        default: return (uint32_t) __shfl_xor((int) v, i, 64);
+    }
+    #undef EXL3_DPP
+}
+__device__ __forceinline__ float xor_lane(float v, const int i) { return __uint_as_float(xor_lane_u32(__float_as_uint(v), i)); }
+__device__ __forceinline__ uint32_t xor_lane(uint32_t v, const int i) { return xor_lane_u32(v, i); }
+__device__ __forceinline__ int xor_lane(int v, const int i) { return (int) xor_lane_u32((uint32_t) v, i); }
+
 // 128-point Sylvester Hadamard over one 32-lane half-wave, 4 elements (4t..4t+3) per lane, fp32.
 // Stage order matches the reference (hadamard_inner.cuh:117-131: in-lane H4, then lane bits 0..4).
 __device__ __forceinline__ void had128_f32x4(float& h0, float& h1, float& h2, float& h3, int lane32)
@@ -110,10 +145,10 @@ __device__ __forceinline__ void had128_f32x4(float& h0, float& h1, float& h2, fl
     #pragma unroll
     for (int i = 1; i < 32; i <<= 1)
     {
-        float p0 = __shfl_xor(h0, i, 64);
-        float p1 = __shfl_xor(h1, i, 64);
-        float p2 = __shfl_xor(h2, i, 64);
-        float p3 = __shfl_xor(h3, i, 64);
+        float p0 = xor_lane(h0, i);
+        float p1 = xor_lane(h1, i);
+        float p2 = xor_lane(h2, i);
+        float p3 = xor_lane(h3, i);
         bool neg = (lane32 & i) != 0;
         h0 = (neg ? -h0 : h0) + p0;
         h1 = (neg ? -h1 : h1) + p1;

@@ -30,7 +30,7 @@ __device__ __forceinline__ float4_t load_w4(const void* w, int idx4, bool bf16)
 __device__ __forceinline__ float block_sum(float v, float* red)
 {
     #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = 32; o > 0; o >>= 1) v += xor_lane(v, o);
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int nw = blockDim.x >> 6;
     if (nw == 1) return v;
@@ -38,7 +38,7 @@ __device__ __forceinline__ float block_sum(float v, float* red)
     __syncthreads();
     float t = lane < nw ? red[lane] : 0.0f;
     #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    for (int o = 8; o > 0; o >>= 1) t += xor_lane(t, o);
     return __shfl(t, 0, 64);
 }
 

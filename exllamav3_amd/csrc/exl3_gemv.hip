@@ -198,7 +198,7 @@ void exl3_gemv_kernel(const GemvArgs a)
             {
                 float t = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
                 #pragma unroll
-                for (int i = 1; i < 32; i <<= 1) t += __shfl_xor(t, i, 64);
+                for (int i = 1; i < 32; i <<= 1) t += xor_lane(t, i);
                 if (act && l == 0) atomicAdd(&sumx[ii], t);
             }
             if (act)
@@ -494,10 +494,12 @@ static int choose_split(int gen, int total_colblocks, int k, int m, int num_cus,
 static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, const void* const* suhs, const void* const* svhs,
                      const void* const* biases, const int* ns, int count, int m, int k, int K, int cb, int c_fp32,
                      int force_split, hipStream_t st, int flags = 0, const void* const* xhs = nullptr, const float* const* xsums = nullptr,
-                     float** slabs_out = nullptr, int* S_out = nullptr)
+                     float** slabs_out = nullptr, int* S_out = nullptr, const GemvEpi* epi = nullptr)
 {
+    if (epi) flags |= GEMV_OUT_DEFERRED;
     const bool deferred = (flags & GEMV_OUT_DEFERRED) != 0, rotated = (flags & GEMV_IN_ROTATED) != 0;
     EXL3_CHECK_ARG(!(deferred || rotated) || m <= 16, "exl3_gemv_ex: at most 16 rows");
+    const int epi_sets = !epi ? 0 : (epi->mode == GEMV_EPI_ACT ? 2 : 1);
     EXL3_CHECK_ARG(!rotated || xhs, "exl3_gemv_ex: rotated input requires xh pointers");
     EXL3_CHECK_ARG(count >= 1 && count <= GEMV_MAX_MATS, "exl3_mgemm: between 1 and %d matrices per launch", GEMV_MAX_MATS);
     EXL3_CHECK_ARG(K >= 1 && K <= 8, "exl3_gemm: K must be in [1, 8]");
@@ -529,6 +531,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             fs = (2 * ctx->num_cus + total_cb - 1) / total_cb;
             if (g_gemv_defer_wg_per_cu > 0) fs = (g_gemv_defer_wg_per_cu * ctx->num_cus + total_cb - 1) / total_cb;
             if (fs < 1) fs = 1;
+            if (epi && fs > 64) fs = 64;                         // tail epilogue: one pass of slabs must fit the workgroup LDS
         }
         const int S = choose_split(gen, total_cb, k, mp, ctx->num_cus, fs);
         const int nb = k / 128;
@@ -550,6 +553,16 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             cbf += ns[i] / 128;
             wso += (int64_t) (ns[i] / 128) * S * mp * 128;
         }
+        if (epi)
+        {
+            args.epi = *epi;
+            args.epi.tickets = ctx->tickets;
+            args.epi.ticket_global = total_cb;
+            args.epi.ss_offset = (int) wso;
+            if (epi->mode == GEMV_EPI_NORM) wso += (int64_t) mp * (ns[0] / 128);
+            EXL3_CHECK_ARG(total_cb + 1 <= EXL3_NUM_TICKETS, "exl3_gemv: too many column blocks for the ticket table");
+            EXL3_CHECK_ARG(S <= 128, "exl3_gemv: split too deep for the tail epilogue");
+        }
         EXL3_CHECK_ARG((S == 1 && !deferred) || wso * 4 <= EXL3_WORKSPACE_BYTES, "exl3_gemm: split-k workspace too small");
         if (S_out) *S_out = S;
         args.flags = flags;
@@ -568,17 +581,36 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         {
             const int ng = mp <= 4 ? 1 : (mp <= 8 ? 2 : 4);
             int nwv = 16 / ng;                                   // partial-sum LDS: nwv * 4*ng rows * 512 B <= 32 KB
-            if (nwv > bps) nwv = bps;                            // every wave gets at least one Hadamard block
+            const int units = bps * 4;                           // the waves split the slice's tile rows in units of 2 (G2_PF)
+            // measured on MI355X (tools/prof_tail.py, batch 1): one wave per Hadamard block of the slice, but at least 4 waves --
+            // more waves than that do not help (the kernel is VALU / fixed-latency bound), fewer starve the short slices
+            if (nwv > (bps > 4 ? bps : 4)) nwv = bps > 4 ? bps : 4;
+            if (nwv > units) nwv = units;
             if (g_gemv_nwv > 0 && nwv > g_gemv_nwv) nwv = g_gemv_nwv;
             if (nwv < 1) nwv = 1;
             // activation fragments: up to ~64 KB per workgroup, whole wave range when it fits (one prep, then a pure stream)
             const int AHh = (var == 1 && cb != 2) ? 32 : 16;
-            const int blocks_per_wave = (bps + nwv - 1) / nwv;
+            int blocks_per_wave = 1;                             // most Hadamard blocks any wave touches
+            for (int w = 0; w < nwv; ++w)
+            {
+                const int r0 = (units * w) / nwv * 2, r1 = (units * (w + 1)) / nwv * 2;
+                if (r1 > r0 && ((r1 + 7) >> 3) - (r0 >> 3) > blocks_per_wave) blocks_per_wave = ((r1 + 7) >> 3) - (r0 >> 3);
+            }
             int chunk = (int) ((size_t) 65536 / ((size_t) nwv * 8 * mp * AHh * 2));
             if (chunk < 1) chunk = 1;
             if (chunk > blocks_per_wave) chunk = blocks_per_wave;
             args.chunk_blocks = chunk;
-            const size_t lds = exl3_gemv2_lds_bytes(ng, var, cb, nwv, mp, chunk);
+            size_t lds = exl3_gemv2_lds_bytes(ng, var, cb, nwv, mp, chunk);
+            if (epi)
+            {
+                // tail epilogue: the last workgroup of a column block stages rows_per_pass rows x sets x S slab lines (512 B) in LDS
+                const size_t line_bytes = (size_t) epi_sets * S * 512;
+                if (lds < line_bytes) lds = line_bytes;
+                int rpp = (int) (lds / line_bytes);
+                if (rpp > mp) rpp = mp;
+                if (rpp > 2 * nwv) rpp = 2 * nwv;
+                args.epi.rows_per_pass = rpp;
+            }
             switch (K)
             {
                 case 1: exl3_gemv2_launch_k1(cb, var, ng, nwv, grid, lds, st, args); break;
@@ -641,4 +673,67 @@ extern "C" int exl3_gemv_ex(const void* A, const void* const* xhs, const float* 
 {
     EXL3_CHECK_ARG(Bs && ns, "exl3_gemv_ex: null table");
     return run_mgemm(A, Bs, Cs, suhs, svhs, biases, ns, count, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream, flags, xhs, xsums, slabs_out, S_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMV launches with an in-kernel tail epilogue (exl3_gemv2_tail.cuh): a whole sublayer boundary of the decode step per launch.
+// Inputs are either pre-rotated (xhs / xsums from the producing tail or glue kernel) or raw (A + suhs: the kernel rotates).
+// ------------------------------------------------------------------------------------------------
+extern "C" int exl3_gemv_norm(const void* A, const void* xh, const float* xsum, const void* B, const void* suh, const void* svh, const void* bias,
+                              int m, int k, int n, int K, int cb, void* resid, const void* norm_w, float eps,
+                              const void* const* t_suhs, void* const* t_xhs, float* const* t_xsums, int t_count, void* xn_out, void* stream)
+{
+    EXL3_CHECK_ARG(B && svh && resid && norm_w, "exl3_gemv_norm: null pointer");
+    EXL3_CHECK_ARG(m >= 1 && m <= 16, "exl3_gemv_norm: 1 <= m <= 16");
+    EXL3_CHECK_ARG(t_count >= 0 && t_count <= 3, "exl3_gemv_norm: at most 3 consumers");
+    GemvEpi e; memset((void*) &e, 0, sizeof(e));
+    e.mode = GEMV_EPI_NORM;
+    e.resid = (half_t*) resid; e.norm_w = (const half_t*) norm_w; e.eps = eps; e.xn_out = (half_t*) xn_out; e.t_count = t_count;
+    for (int i = 0; i < t_count; ++i)
+    {
+        EXL3_CHECK_ARG(t_suhs && t_xhs && t_suhs[i] && t_xhs[i], "exl3_gemv_norm: null consumer pointer");
+        e.t_suh[i] = (const half_t*) t_suhs[i]; e.t_xh[i] = (half_t*) t_xhs[i]; e.t_xsum[i] = t_xsums ? t_xsums[i] : nullptr;
+    }
+    const void* Bs[1] = { B }; const void* su[1] = { suh }; const void* sv[1] = { svh }; const void* bi[1] = { bias };
+    const void* xhs[1] = { xh }; const float* xss[1] = { xsum }; int ns[1] = { n };
+    return run_mgemm(A, Bs, nullptr, su, sv, bi, ns, 1, m, k, K, cb, 1, 0, (hipStream_t) stream, xh ? GEMV_IN_ROTATED : 0,
+                     xh ? xhs : nullptr, xh ? xss : nullptr, nullptr, nullptr, &e);
+}
+
+extern "C" int exl3_gemv_act(const void* A, const void* const* xhs, const float* const* xsums, const void* const* Bs, const void* const* suhs,
+                             const void* const* svhs, int m, int k, int inter, int K, int cb,
+                             const void* suh_d, void* xh_d, float* xsum_d, void* a_out, void* stream)
+{
+    EXL3_CHECK_ARG(Bs && svhs && svhs[0] && svhs[1] && suh_d && xh_d, "exl3_gemv_act: null pointer");
+    EXL3_CHECK_ARG(m >= 1 && m <= 16, "exl3_gemv_act: 1 <= m <= 16");
+    GemvEpi e; memset((void*) &e, 0, sizeof(e));
+    e.mode = GEMV_EPI_ACT;
+    e.t_count = 1; e.t_suh[0] = (const half_t*) suh_d; e.t_xh[0] = (half_t*) xh_d; e.t_xsum[0] = xsum_d; e.a_out = (half_t*) a_out;
+    int ns[2] = { inter, inter };
+    return run_mgemm(A, Bs, nullptr, suhs, svhs, nullptr, ns, 2, m, k, K, cb, 0, 0, (hipStream_t) stream, xhs ? GEMV_IN_ROTATED : 0,
+                     xhs, xsums, nullptr, nullptr, &e);
+}
+
+extern "C" int exl3_gemv_qkv(const void* A, const void* const* xhs, const float* const* xsums, const void* const* Bs, const void* const* suhs,
+                             const void* const* svhs, int m, int k, int K, int cb, void* q_out, void* k_out, void* v_out,
+                             const float* rope_sin, const float* rope_cos, const int32_t* positions,
+                             void* k_cache, void* k_scales, void* v_cache, void* v_scales, const int32_t* block_table, int blocks_per_seq,
+                             int page_size, int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int rope_mode, void* stream)
+{
+    EXL3_CHECK_ARG(Bs && svhs && svhs[0] && svhs[1] && svhs[2] && q_out && rope_sin && rope_cos && positions, "exl3_gemv_qkv: null pointer");
+    EXL3_CHECK_ARG(head_dim == 128, "exl3_gemv_qkv: head_dim must be 128 (one Hadamard block per head)");
+    EXL3_CHECK_ARG(m >= 1 && m <= 16, "exl3_gemv_qkv: 1 <= m <= 16");
+    EXL3_CHECK_ARG(rope_mode == 1 || rope_mode == 2, "exl3_gemv_qkv: rope_mode must be 1 (GPTJ) or 2 (NEOX)");
+    EXL3_CHECK_ARG(!k_cache || (k_scales && v_cache && v_scales && block_table && page_size > 0), "exl3_gemv_qkv: incomplete cache arguments");
+    EXL3_CHECK_ARG(!k_cache || (k_bits >= 2 && k_bits <= 8 && v_bits >= 2 && v_bits <= 8), "exl3_gemv_qkv: cache bits must be in [2, 8]");
+    GemvEpi e; memset((void*) &e, 0, sizeof(e));
+    e.mode = GEMV_EPI_QKV;
+    e.q_out = (half_t*) q_out; e.k_out = (half_t*) k_out; e.v_out = (half_t*) v_out;
+    e.rope_sin = rope_sin; e.rope_cos = rope_cos; e.positions = positions;
+    e.k_cache = (uint32_t*) k_cache; e.k_scales = (half_t*) k_scales; e.v_cache = (uint32_t*) v_cache; e.v_scales = (half_t*) v_scales;
+    e.block_table = block_table; e.blocks_per_seq = blocks_per_seq; e.page_size = page_size > 0 ? page_size : 256;
+    e.k_bits = k_bits; e.v_bits = v_bits; e.hq = heads_q; e.hkv = heads_kv; e.rope_mode = rope_mode;
+    int ns[3] = { heads_q * 128, heads_kv * 128, heads_kv * 128 };
+    return run_mgemm(A, Bs, nullptr, suhs, svhs, nullptr, ns, 3, m, k, K, cb, 0, 0, (hipStream_t) stream, xhs ? GEMV_IN_ROTATED : 0,
+                     xhs, xsums, nullptr, nullptr, &e);
 }

@@ -26,6 +26,7 @@
 #include "exl3_api_internal.h"
 #include "exl3_gemv_args.h"
 #include "exl3_lane_decode.cuh"
+#include "exl3_gemv2_tail.cuh"
 
 #include <type_traits>
 #define G2_PF 2
@@ -77,10 +78,12 @@ __device__ __forceinline__ void decode_quad(const uint32_t (&Wx)[K + 1], half4_t
 }
 
 template <int K, int CB, int VAR, int NG>
-__global__ __launch_bounds__(1024)
+// m <= 4 (NG == 1): two 16-wave workgroups per CU need <= 64 VGPRs; the hot loop uses 62, the attribute keeps the tail epilogue from raising it
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NG == 1 ? 8 : 4)))
 void exl3_gemv2_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_tail_flag;
     constexpr bool SPLIT = (VAR == 1) && (CB != EXL3_CB_MUL1);
     constexpr bool RAW = (VAR == 1) && (CB == EXL3_CB_MUL1);
     constexpr int MR = 4 * NG;                       // activation rows held by the A operand
@@ -105,9 +108,15 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const int k0s = s * a.kslice;
     const int k1s = min(k0s + a.kslice, a.k);
     const int nb = (k1s - k0s) >> 7;                 // 128-blocks in the workgroup's slice
-    const int nwv = blockDim.x >> 6;                 // waves per workgroup (4..16): they split the slice's blocks
-    const int b0 = (nb * wave) / nwv, b1 = (nb * (wave + 1)) / nwv;
-    const int nbw = b1 - b0;                         // blocks of this wave (may be 0)
+    const int nwv = blockDim.x >> 6;                 // waves per workgroup (1..16)
+    // The waves split the slice's tile rows in units of G2_PF rows (not whole Hadamard blocks): a small matrix (o_proj at batch 1
+    // is 8192 tile rows for 1024 SIMDs) needs every SIMD to have several KB in flight to cover HBM latency, which only works if
+    // all 16 waves of a workgroup get rows.  A wave still rotates / fetches whole 128-blocks of x for the rows it touches.
+    const int units = nb * (8 / G2_PF);
+    const int R0 = ((units * wave) / nwv) * G2_PF, R1 = ((units * (wave + 1)) / nwv) * G2_PF;
+    const int b0 = R0 >> 3;                          // first block touched
+    const int nbw = R1 > R0 ? ((R1 + 7) >> 3) - b0 : 0;   // blocks touched by this wave (may be 0)
+    const int rbeg = R0 - 8 * b0, rend = R1 - 8 * b0;     // wave-local tile rows [rbeg, rend) relative to block b0
     const int k0 = k0s + 128 * b0;
 
     // LDS carve: per-wave activation fragments for a CHUNK of `chb` Hadamard blocks [blk][tile row 8][row m][AH halves]
@@ -159,10 +168,22 @@ void exl3_gemv2_kernel(const GemvArgs a)
             const bool act = row < m;
             half2_t o01, o23;
             float bsum;
+            const int blk_t = c0 + t / npass;                           // wave-local block of this task
+            const bool whole = 8 * blk_t >= rbeg && 8 * blk_t + 8 <= rend; // all 8 tile rows of the block belong to this wave
             if (in_rotated)
             {
                 o01 = half2_t{ xv_c.x, xv_c.y }; o23 = half2_t{ xv_c.z, xv_c.w };
                 bsum = xs_c;
+                if constexpr (RAW)
+                {
+                    if (!whole)
+                    {
+                        const int trow = 8 * blk_t + (l32 >> 2);
+                        bsum = (trow >= rbeg && trow < rend) ? ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y) : 0.0f;
+                        #pragma unroll
+                        for (int i = 1; i < 32; i <<= 1) bsum += xor_lane(bsum, i);
+                    }
+                }
             }
             else
             {
@@ -174,9 +195,10 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 bsum = 0.0f;
                 if constexpr (RAW)
                 {
-                    bsum = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
+                    const int trow = 8 * blk_t + (l32 >> 2);
+                    bsum = (trow >= rbeg && trow < rend) ? ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y) : 0.0f;
                     #pragma unroll
-                    for (int i = 1; i < 32; i <<= 1) bsum += __shfl_xor(bsum, i, 64);
+                    for (int i = 1; i < 32; i <<= 1) bsum += xor_lane(bsum, i);
                 }
             }
             if constexpr (RAW)
@@ -211,8 +233,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const int T = lane >> 3, c = lane & 7;
     const uint32_t* __restrict__ strip = Bm + ((size_t) (k0 >> 4) * tiles_n + (size_t) cbl * 8) * NW + (size_t) lane * K;
     const size_t row_stride = (size_t) tiles_n * NW;
-    const int nrows = nbw * 8;
-    const int last_row = nrows > 0 ? nrows - 1 : 0;
+    const int last_row = rend > rbeg ? rend - 1 : 0;
     const int prev_lane_addr = ((lane & ~7) | ((lane - 1) & 7)) << 2;   // ds_bpermute byte address
     // this lane's A row; lanes whose row is >= m read row m-1 (their MFMA output rows are never stored)
     const half_t* arow = xa + (size_t) min(lane & 15, m - 1) * AH;
@@ -226,7 +247,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
     if (nbw > 0)
     {
         #pragma unroll
-        for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(u, last_row) * row_stride);
+        for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(rbeg + u, last_row) * row_stride);
     }
 
     for (int c0 = 0; c0 < nbw; c0 += chb)
@@ -236,9 +257,10 @@ void exl3_gemv2_kernel(const GemvArgs a)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // wave-private LDS: in-order queue + drain
         __builtin_amdgcn_wave_barrier();
 
-        // pure streaming loop over the chunk's tile rows, G2_PF rows per iteration (8 * cnt is a multiple of G2_PF)
-        const int row_end = (c0 + cnt) * 8;
-        for (int row0 = c0 * 8; row0 < row_end; row0 += G2_PF)
+        // pure streaming loop over this wave's tile rows inside the chunk, G2_PF rows per iteration (rbeg, rend and the chunk
+        // bounds are multiples of G2_PF)
+        const int row_end = min((c0 + cnt) * 8, rend);
+        for (int row0 = max(c0 * 8, rbeg); row0 < row_end; row0 += G2_PF)
         {
             #pragma unroll
             for (int u = 0; u < G2_PF; ++u)
@@ -359,8 +381,10 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 float4_t t = ((const float4_t*) (p0 + w * wstride))[l];
                 v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
             }
-            ((float4_t*) (slab + row * 128))[l] = v;
+            if (a.epi.mode != GEMV_EPI_NONE) st_agent(slab + row * 128 + 4 * l, v);     // read by another workgroup of this launch
+            else ((float4_t*) (slab + row * 128))[l] = v;
         }
+        if (a.epi.mode != GEMV_EPI_NONE) gemv_tail(a, mi, cbl, cbg, tid, nwv, &s_tail_flag, (float4_t*) smem);
         return;
     }
 

@@ -21,6 +21,34 @@ struct GemvMat
     int ws_offset;         // float offset of this matrix's slabs in the workspace
 };
 
+// In-kernel tail epilogue of the gen-2 GEMV (deferred mode only): the LAST workgroup to finish a column block (arrival
+// ticket in device memory) reduces the split-k slabs of that block and runs what would otherwise be a separate glue launch.
+#define GEMV_EPI_NONE 0
+#define GEMV_EPI_NORM 1   // 1 matrix (o_proj / down_proj): out-had*svh(+bias) -> residual += y ; the last block overall: RMSNorm -> in-had
+#define GEMV_EPI_ACT  2   // 2 matrices (gate, up): out-had*svh -> silu(g)*u -> in-had of down_proj
+#define GEMV_EPI_QKV  3   // 3 matrices (q, k, v), head_dim 128: out-had*svh -> RoPE -> q out / quantized KV-cache append
+
+struct GemvEpi
+{
+    int mode;
+    int rows_per_pass;                       // rows whose slabs fit the workgroup LDS at once (host: lds >= rows * sets * S * 512 B)
+    int ticket_global;                       // index of the whole-launch ticket (NORM)
+    uint32_t* tickets;                       // zero on entry, zero on exit
+    // consumers of the produced activation (NORM: up to 3, ACT: 1): xh = fp16(had(x * suh)/sqrt(128)), per-block sums
+    const half_t* t_suh[3]; half_t* t_xh[3]; float* t_xsum[3]; int t_count;
+    // NORM
+    half_t* resid; const half_t* norm_w; float eps; int ss_offset /* workspace floats: [m][n/128] sums of squares */; half_t* xn_out;
+    // ACT
+    half_t* a_out;
+    // QKV
+    half_t* q_out; half_t* k_out; half_t* v_out;
+    const float* rope_sin; const float* rope_cos;   // [m][64] fp32, already scaled by attn_factor (exl3_rope_table)
+    const int32_t* positions;
+    uint32_t* k_cache; half_t* k_scales; uint32_t* v_cache; half_t* v_scales;
+    const int32_t* block_table; int blocks_per_seq; int page_size; int k_bits; int v_bits;
+    int hq, hkv, rope_mode;
+};
+
 struct GemvArgs
 {
     GemvMat mat[GEMV_MAX_MATS];
@@ -35,6 +63,7 @@ struct GemvArgs
     int flags;             // GEMV_IN_ROTATED | GEMV_OUT_DEFERRED
     int chunk_blocks;      // gen 2: Hadamard blocks of activation fragments a wave keeps in LDS at a time
     int64_t c_row_offset;  // first output row of this pass
+    GemvEpi epi;
 };
 
 // generation-2 kernels: one translation unit per K (exl3_gemv2.kspec.hip compiled with -DG2_K=1..8)

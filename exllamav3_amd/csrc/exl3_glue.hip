@@ -13,49 +13,8 @@
 // to fp32 summation order.
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
+#include "exl3_glue_device.cuh"
 
-struct SlabRef { const float* base; int S; };       // slab(c, s, row) = base + ((c*S + s)*m + row)*128
-
-__device__ __forceinline__ float4_t slab_sum(const SlabRef& sr, int c, int row, int m, int l)
-{
-    // independent 16-byte loads in batches of 16 (a dependent load-add chain costs ~0.6 us of L2/HBM latency per slab);
-    // the summation order is fixed, so results are run-to-run deterministic
-    const float* p = sr.base + ((size_t) c * sr.S * m + row) * 128;
-    const size_t st = (size_t) m * 128;
-    float4_t v = { 0.f, 0.f, 0.f, 0.f };
-    for (int s = 0; s < sr.S; s += 16)
-    {
-        float4_t t[16];
-        #pragma unroll
-        for (int i = 0; i < 16; ++i) t[i] = ((const float4_t*) (p + (size_t) min(s + i, sr.S - 1) * st))[l];
-        #pragma unroll
-        for (int i = 0; i < 16; ++i) if (s + i < sr.S) { v.x += t[i].x; v.y += t[i].y; v.z += t[i].z; v.w += t[i].w; }
-    }
-    return v;
-}
-
-// out-Hadamard of a reduced block -> fp32 (h *= 1/sqrt(128)); caller applies svh in the dtype of the logical output
-__device__ __forceinline__ void out_had(float4_t v, int l, float& h0, float& h1, float& h2, float& h3)
-{
-    h0 = v.x; h1 = v.y; h2 = v.z; h3 = v.w;
-    had128_f32x4(h0, h1, h2, h3, l);
-    h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
-}
-
-// input Hadamard of the next linear: xh = fp16(had(fp16 x * suh) / sqrt(128)); returns the block sum of the fp16 outputs
-__device__ __forceinline__ float in_had_store(half4_t x, const half_t* __restrict__ suh_blk, half_t* __restrict__ xh_blk, int l, bool act)
-{
-    half4_t sv = ((const half4_t*) suh_blk)[l];
-    half4_t t = x * sv;
-    float h0 = (float) t.x, h1 = (float) t.y, h2 = (float) t.z, h3 = (float) t.w;
-    had128_f32x4(h0, h1, h2, h3, l);
-    half4_t o = { (half_t) (h0 * HAD_R_SCALE_128), (half_t) (h1 * HAD_R_SCALE_128), (half_t) (h2 * HAD_R_SCALE_128), (half_t) (h3 * HAD_R_SCALE_128) };
-    float sum = ((float) o.x + (float) o.y) + ((float) o.z + (float) o.w);
-    #pragma unroll
-    for (int i = 1; i < 32; i <<= 1) sum += __shfl_xor(sum, i, 64);
-    if (act) ((half4_t*) xh_blk)[l] = o;
-    return sum;
-}
 
 // ------------------------------------------------------------------------------------------------
 // G1: [reduce + out-had + svh (+bias)] -> residual += y -> RMSNorm -> in-had for up to 3 next linears.  Single workgroup.
@@ -77,6 +36,16 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
     const int tasks = m * nblk;
     // phase 1: residual update + sum of squares per (row, block); the updated residual stays in registers
     half4_t rr[GN_MAXT];
+    // phase-2 operands of this half-wave's first task are fetched now, with the phase-1 loads (at batch 1 there is only one
+    // task per half-wave, and a load issued after the barrier would add a full memory latency to a ~5 us kernel)
+    half4_t w_first, suh_first[3];
+    {
+        const int t0 = hw < tasks ? hw : 0;
+        const int blk0 = t0 % nblk;
+        w_first = ((const half4_t*) (w + blk0 * 128))[l];
+        #pragma unroll
+        for (int i = 0; i < 3; ++i) suh_first[i] = i < tg.count ? ((const half4_t*) (tg.suh[i] + blk0 * 128))[l] : half4_t{ 0, 0, 0, 0 };
+    }
     #pragma unroll
     for (int it = 0; it < GN_MAXT; ++it)
     {
@@ -97,8 +66,8 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
             }
             else
             {
+                const half4_t sc = ((const half4_t*) (svh + blk * 128))[l];
                 out_had(slab_sum(y, blk, row, m, l), l, h0, h1, h2, h3);
-                half4_t sc = ((const half4_t*) (svh + blk * 128))[l];
                 h0 *= (float) sc.x; h1 *= (float) sc.y; h2 *= (float) sc.z; h3 *= (float) sc.w;
                 if (bias) { half4_t b = ((const half4_t*) (bias + blk * 128))[l]; h0 += (float) b.x; h1 += (float) b.y; h2 += (float) b.z; h3 += (float) b.w; }
             }
@@ -111,7 +80,7 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
         float ss = r0 * r0;
         ss = __builtin_fmaf(r1, r1, ss); ss = __builtin_fmaf(r2, r2, ss); ss = __builtin_fmaf(r3, r3, ss);
         #pragma unroll
-        for (int i = 1; i < 32; i <<= 1) ss += __shfl_xor(ss, i, 64);
+        for (int i = 1; i < 32; i <<= 1) ss += xor_lane(ss, i);
         if (act && l == 0) ss_part[row * 128 + blk] = ss;
     }
     __syncthreads();
@@ -129,12 +98,12 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
         {
             float v = (b0 + l < nblk) ? ss_part[row * 128 + b0 + l] : 0.0f;
             #pragma unroll
-            for (int i = 1; i < 32; i <<= 1) v += __shfl_xor(v, i, 64);
+            for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
             s2 += v;
         }
         const float rmf = __frsqrt_rn(s2 / (float) hidden + eps);
         half4_t r = rr[it];
-        half4_t wv = ((const half4_t*) (w + blk * 128))[l];
+        half4_t wv = it == 0 ? w_first : ((const half4_t*) (w + blk * 128))[l];
         half4_t xn = { (half_t) ((float) r.x * (float) wv.x * rmf), (half_t) ((float) r.y * (float) wv.y * rmf),
                        (half_t) ((float) r.z * (float) wv.z * rmf), (half_t) ((float) r.w * (float) wv.w * rmf) };
         if (xn_out && act) ((half4_t*) (xn_out + (size_t) row * hidden + blk * 128))[l] = xn;
@@ -143,7 +112,8 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
         {
             if (i < tg.count)
             {
-                float sum = in_had_store(xn, tg.suh[i] + blk * 128, tg.xh[i] + (size_t) row * hidden + blk * 128, l, act);
+                const half4_t sv = it == 0 ? suh_first[i] : ((const half4_t*) (tg.suh[i] + blk * 128))[l];
+                float sum = in_had_store_v(xn, sv, tg.xh[i] + (size_t) row * hidden + blk * 128, l, act);
                 if (act && l == 0 && tg.xsum[i]) tg.xsum[i][(size_t) row * nblk + blk] = sum;
             }
         }
@@ -155,57 +125,6 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
 //     reduce + out-had + fp16 svh -> RoPE (NEOX or GPTJ; sin/cos once per (row, frequency) in LDS) on q and k ->
 //     q fp16 out; k, v -> quantized paged cache append (and optional fp16 copies).
 // ------------------------------------------------------------------------------------------------
-template <int BITS>
-__device__ __forceinline__ void kv_quant_regs(float v0, float v1, float v2, float v3, uint32_t* __restrict__ out, half_t* __restrict__ out_scale, bool active, int lane);
-
-__device__ __forceinline__ void kvg_had32(float& v0, float& v1, float& v2, float& v3, int lane)
-{
-    float s0 = v0 + v1, d0 = v0 - v1, s1 = v2 + v3, d1 = v2 - v3;
-    v0 = s0 + s1; v1 = d0 + d1; v2 = s0 - s1; v3 = d0 - d1;
-    #pragma unroll
-    for (int i = 1; i < 8; i <<= 1)
-    {
-        float p0 = __shfl_xor(v0, i, 64), p1 = __shfl_xor(v1, i, 64), p2 = __shfl_xor(v2, i, 64), p3 = __shfl_xor(v3, i, 64);
-        bool neg = (lane & i) != 0;
-        v0 = (neg ? -v0 : v0) + p0; v1 = (neg ? -v1 : v1) + p1; v2 = (neg ? -v2 : v2) + p2; v3 = (neg ? -v3 : v3) + p3;
-    }
-}
-
-template <int W>
-__device__ __forceinline__ void kvg_pack_plane(uint32_t* __restrict__ out, int word_base, int sl, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3, bool active)
-{
-    uint32_t field = f0 | (f1 << W) | (f2 << (2 * W)) | (f3 << (3 * W));
-    constexpr int LPW = 8 / W;
-    int off = sl * 4 * W;
-    uint32_t contrib = field << (off & 31);
-    #pragma unroll
-    for (int i = 1; i < LPW; i <<= 1) contrib |= (uint32_t) __shfl_xor((int) contrib, i, 64);
-    if (active && (sl % LPW) == 0) out[word_base + (off >> 5)] = contrib;
-}
-
-// same arithmetic as kv_quant_group in exl3_rope_cache.hip, input already in registers (fp16-rounded values)
-template <int BITS>
-__device__ __forceinline__ void kv_quant_regs(float v0, float v1, float v2, float v3, uint32_t* __restrict__ out, half_t* __restrict__ out_scale, bool active, int lane)
-{
-    constexpr float mf = (float) (1 << (BITS - 1));
-    constexpr int qmax = (1 << BITS) - 1;
-    const int sl = lane & 7;
-    kvg_had32(v0, v1, v2, v3, lane);
-    const float r32 = 0.17677669529663688110f;
-    v0 *= r32; v1 *= r32; v2 *= r32; v3 *= r32;
-    float s = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) + 1e-10f;
-    #pragma unroll
-    for (int i = 1; i < 8; i <<= 1) s = fmaxf(s, __shfl_xor(s, i, 64));
-    const float inv_s = 1.0f / s;
-    auto quant1 = [&] (float v) -> uint32_t { int qi = (int) floorf(__builtin_fmaf(v * inv_s, mf, mf)); return (uint32_t) max(min(qi, qmax), 0); };
-    uint32_t q0 = quant1(v0), q1 = quant1(v1), q2 = quant1(v2), q3 = quant1(v3);
-    int rem = BITS, wb = 0;
-    if constexpr (BITS & 8) { rem -= 8; kvg_pack_plane<8>(out, wb, sl, (q0 >> rem) & 255, (q1 >> rem) & 255, (q2 >> rem) & 255, (q3 >> rem) & 255, active); wb += 8; }
-    if constexpr (BITS & 4) { rem -= 4; kvg_pack_plane<4>(out, wb, sl, (q0 >> rem) & 15, (q1 >> rem) & 15, (q2 >> rem) & 15, (q3 >> rem) & 15, active); wb += 4; }
-    if constexpr (BITS & 2) { rem -= 2; kvg_pack_plane<2>(out, wb, sl, (q0 >> rem) & 3, (q1 >> rem) & 3, (q2 >> rem) & 3, (q3 >> rem) & 3, active); wb += 2; }
-    if constexpr (BITS & 1) { kvg_pack_plane<1>(out, wb, sl, q0 & 1, q1 & 1, q2 & 1, q3 & 1, active); }
-    if (active && sl == 0) *out_scale = (half_t) s;
-}
 
 struct QkvArgs
 {
@@ -255,7 +174,7 @@ void glue_qkv_kernel(QkvArgs a)
         if (a.rope_mode == 2)
         {
             // NEOX: pairs (d, d+64): partner lane l ^ 16, frequency index d & 63
-            float p0 = __shfl_xor(v0, 16, 64), p1 = __shfl_xor(v1, 16, 64), p2 = __shfl_xor(v2, 16, 64), p3 = __shfl_xor(v3, 16, 64);
+            float p0 = xor_lane(v0, 16), p1 = xor_lane(v1, 16), p2 = xor_lane(v2, 16), p3 = xor_lane(v3, 16);
             const int f = 4 * (l & 15);
             const float* sn = sn_s + row * 64 + f; const float* cs = cs_s + row * 64 + f;
             const bool upper = l >= 16;
@@ -306,15 +225,20 @@ void glue_act_kernel(SlabRef sg, SlabRef su, const half_t* __restrict__ svh_g, c
     const int t = blockIdx.x * 8 + hw;
     const bool act = t < tasks;
     const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+    // all independent loads first (scales of this block), then the slabs
+    const half4_t svg = ((const half4_t*) (svh_g + blk * 128))[l], svu = ((const half4_t*) (svh_u + blk * 128))[l];
+    const half4_t sud = ((const half4_t*) (suh_d + blk * 128))[l];
     float g0, g1, g2, g3, u0, u1, u2, u3;
-    out_had(slab_sum(sg, blk, row, m, l), l, g0, g1, g2, g3);
-    out_had(slab_sum(su, blk, row, m, l), l, u0, u1, u2, u3);
-    half4_t gh = half4_t{ (half_t) g0, (half_t) g1, (half_t) g2, (half_t) g3 } * ((const half4_t*) (svh_g + blk * 128))[l];
-    half4_t uh = half4_t{ (half_t) u0, (half_t) u1, (half_t) u2, (half_t) u3 } * ((const half4_t*) (svh_u + blk * 128))[l];
+    float4_t vg, vu;
+    slab_sum2(sg, su, blk, row, m, l, vg, vu);
+    out_had(vg, l, g0, g1, g2, g3);
+    out_had(vu, l, u0, u1, u2, u3);
+    half4_t gh = half4_t{ (half_t) g0, (half_t) g1, (half_t) g2, (half_t) g3 } * svg;
+    half4_t uh = half4_t{ (half_t) u0, (half_t) u1, (half_t) u2, (half_t) u3 } * svu;
     auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return (half_t) (gf / (1.0f + __expf(-gf)) * (float) u); };
     half4_t av = { silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
     if (a_out && act) ((half4_t*) (a_out + (size_t) row * inter + blk * 128))[l] = av;
-    float sum = in_had_store(av, suh_d + blk * 128, xh_d + (size_t) row * inter + blk * 128, l, act);
+    float sum = in_had_store_v(av, sud, xh_d + (size_t) row * inter + blk * 128, l, act);
     if (act && l == 0 && xsum_d) xsum_d[(size_t) row * nblk + blk] = sum;
 }
 
@@ -405,4 +329,24 @@ extern "C" int exl3_glue_act(const float* sg, const float* su, int S, const void
     glue_act_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>(g, u, (const half_t*) svh_g, (const half_t*) svh_u, (const half_t*) suh_d,
                                                                        (half_t*) xh_d, xsum_d, (half_t*) a_out, m, inter);
     return exl3_check_launch("glue_act");
+}
+
+// sin / cos of (position x inverse frequency), scaled by attn_factor, for every row of a decode step: [m][64] fp32 each.
+// All layers of a step share the positions, so the fused pipeline builds this once per step (the reference recomputes it
+// inside every rope launch, rope.cu:60-120); values are the same sincosf() results the rope / glue_qkv kernels use.
+__global__ void rope_table_kernel(const float* __restrict__ inv_freq, const int32_t* __restrict__ positions, float attn_factor, int m,
+                                  float* __restrict__ sin_out, float* __restrict__ cos_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * 64) return;
+    float sn, cs;
+    sincosf(inv_freq[i & 63] * (float) positions[i >> 6], &sn, &cs);
+    sin_out[i] = sn * attn_factor; cos_out[i] = cs * attn_factor;
+}
+
+extern "C" int exl3_rope_table(const float* inv_freq, const int32_t* positions, float attn_factor, int m, float* sin_out, float* cos_out, void* stream)
+{
+    EXL3_CHECK_ARG(inv_freq && positions && sin_out && cos_out && m >= 1, "rope_table: bad arguments");
+    rope_table_kernel<<<(m * 64 + 255) / 256, 256, 0, (hipStream_t) stream>>>(inv_freq, positions, attn_factor, m, sin_out, cos_out);
+    return exl3_check_launch("rope_table");
 }

@@ -56,7 +56,7 @@ void rope_kernel(const half_t* __restrict__ q, half_t* __restrict__ out_q, const
     if (nw)
     {
         #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        for (int o = 32; o > 0; o >>= 1) ss += xor_lane(ss, o);
         const float rmf = __frsqrt_rn(ss / (float) head_dim + norm_eps);
         const half_t bias_h = (half_t) norm_constant_bias;
         #pragma unroll
@@ -125,7 +125,7 @@ __device__ __forceinline__ void kv_had32(float& v0, float& v1, float& v2, float&
     #pragma unroll
     for (int i = 1; i < 8; i <<= 1)
     {
-        float p0 = __shfl_xor(v0, i, 64), p1 = __shfl_xor(v1, i, 64), p2 = __shfl_xor(v2, i, 64), p3 = __shfl_xor(v3, i, 64);
+        float p0 = xor_lane(v0, i), p1 = xor_lane(v1, i), p2 = xor_lane(v2, i), p3 = xor_lane(v3, i);
         bool neg = (lane & i) != 0;
         v0 = (neg ? -v0 : v0) + p0; v1 = (neg ? -v1 : v1) + p1; v2 = (neg ? -v2 : v2) + p2; v3 = (neg ? -v3 : v3) + p3;
     }
@@ -141,7 +141,7 @@ __device__ __forceinline__ void kv_pack_plane(uint32_t* __restrict__ out, int wo
     int off = sl * 4 * W;
     uint32_t contrib = field << (off & 31);
     #pragma unroll
-    for (int i = 1; i < LPW; i <<= 1) contrib |= (uint32_t) __shfl_xor((int) contrib, i, 64);
+    for (int i = 1; i < LPW; i <<= 1) contrib |= (uint32_t) xor_lane((int) contrib, i);
     if (active && (sl % LPW) == 0) out[word_base + (off >> 5)] = contrib;
 }
 
@@ -161,7 +161,7 @@ __device__ __forceinline__ void kv_quant_group(const half_t* __restrict__ in, ui
     v0 *= KV_R32; v1 *= KV_R32; v2 *= KV_R32; v3 *= KV_R32;
     float s = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) + 1e-10f;
     #pragma unroll
-    for (int i = 1; i < 8; i <<= 1) s = fmaxf(s, __shfl_xor(s, i, 64));
+    for (int i = 1; i < 8; i <<= 1) s = fmaxf(s, xor_lane(s, i));
     const float inv_s = 1.0f / s;                      // IEEE division (the oracle's definition)
     auto quant1 = [&] (float v) -> uint32_t
     {

@@ -447,3 +447,45 @@ def glue_act(slabs, S: int, svh_g, svh_u, suh_d, xh_d, xsum_d, m: int, a_out=Non
     _dev(xh_d)
     _check(_lib.lib().exl3_glue_act(slabs[0], slabs[1], S, _p(svh_g), _p(svh_u), _p(suh_d), _p(xh_d), _p(xsum_d), _p(a_out), m,
                                     xh_d.shape[-1], _stream(xh_d)))
+
+
+# ---- GEMV launches with an in-kernel tail epilogue (one launch per sublayer boundary of a decode step) ----------------------
+
+def _kK(B):
+    return B.shape[0] * 16, B.shape[2] // 16
+
+
+def rope_table(inv_freq, positions, sin_out, cos_out, attn_factor: float = 1.0):
+    _dev(sin_out)
+    _check(_lib.lib().exl3_rope_table(_p(inv_freq), _p(positions), float(attn_factor), positions.shape[0], _p(sin_out), _p(cos_out), _stream(sin_out)))
+
+
+def exl3_gemv_norm(A, xh, xsum, B, suh, svh, bias, m: int, mcg: bool, mul1: bool, resid, norm_w, eps: float, t_suhs, t_xhs, t_xsums, xn_out=None):
+    """o_proj / down_proj + residual add + RMSNorm + input Hadamard of the next linears, one launch."""
+    _dev(resid)
+    k, K = _kK(B)
+    _check(_lib.lib().exl3_gemv_norm(_p(A), _p(xh), _p(xsum), _p(B), _p(suh), _p(svh), _p(bias), m, k, B.shape[1] * 16, K, _cb(mcg, mul1),
+                                     _p(resid), _p(norm_w), float(eps), _parr(t_suhs) if t_suhs else None, _parr(t_xhs) if t_xhs else None,
+                                     _parr(t_xsums) if t_xsums else None, len(t_suhs) if t_suhs else 0, _p(xn_out), _stream(resid)))
+
+
+def exl3_gemv_act(A, xhs, xsums, Bs, suhs, svhs, m: int, mcg: bool, mul1: bool, suh_d, xh_d, xsum_d, a_out=None):
+    """gate_proj + up_proj + silu(g) * u + input Hadamard of down_proj, one launch."""
+    _dev(xh_d)
+    k, K = _kK(Bs[0])
+    _check(_lib.lib().exl3_gemv_act(_p(A), _parr(xhs) if xhs else None, _parr(xsums) if xsums else None, _parr(Bs), _parr(suhs) if suhs else None,
+                                    _parr(svhs), m, k, Bs[0].shape[1] * 16, K, _cb(mcg, mul1), _p(suh_d), _p(xh_d), _p(xsum_d), _p(a_out),
+                                    _stream(xh_d)))
+
+
+def exl3_gemv_qkv(A, xhs, xsums, Bs, suhs, svhs, m: int, mcg: bool, mul1: bool, q_out, k_out, v_out, rope_sin, rope_cos, positions,
+                  k_cache, k_scales, v_cache, v_scales, block_table, page_size: int, k_bits: int, v_bits: int,
+                  heads_q: int, heads_kv: int, head_dim: int, rope_mode: int = 2):
+    """q/k/v projections + RoPE + quantized KV-cache append, one launch."""
+    _dev(q_out)
+    k, K = _kK(Bs[0])
+    _check(_lib.lib().exl3_gemv_qkv(_p(A), _parr(xhs) if xhs else None, _parr(xsums) if xsums else None, _parr(Bs), _parr(suhs) if suhs else None,
+                                    _parr(svhs), m, k, K, _cb(mcg, mul1), _p(q_out), _p(k_out), _p(v_out), _p(rope_sin), _p(rope_cos), _p(positions),
+                                    _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table),
+                                    block_table.shape[1] if block_table is not None else 0, page_size, k_bits, v_bits, heads_q, heads_kv,
+                                    head_dim, rope_mode, _stream(q_out)))

@@ -148,6 +148,8 @@ class SyntheticEXL3Llama:
         self.xh3 = [torch.empty((bsz, s.hidden), dtype=f16, device=dev) for _ in range(3)]
         self.xs3 = [torch.empty((bsz, nb_h), dtype=f32, device=dev) for _ in range(3)]
         self.xh_d = torch.empty((bsz, self.inter_local), dtype=f16, device=dev)
+        self.rope_sin = torch.empty((bsz, 64), dtype=f32, device=dev)
+        self.rope_cos = torch.empty((bsz, 64), dtype=f32, device=dev)
         self.xs_d = torch.empty((bsz, nb_i), dtype=f32, device=dev)
         self._state_bsz = bsz
 
@@ -189,7 +191,11 @@ class SyntheticEXL3Llama:
         return self.logits
 
     # ---- the same step with the fused pipeline: deferred-epilogue GEMVs + glue kernels (8 launches per layer) ----------
+    #: forced split-k factor per call type of the fused pipelines (0 = library heuristic); tools/sweep_split.py tunes these
+    split = {"qkv": 0, "o": 0, "gu": 0, "down": 0}
+
     def decode_step_fused(self):
+        sp = self.split
         bsz = self._state_bsz
         hd = self.shape.head_dim
         be = self.backend
@@ -208,7 +214,7 @@ class SyntheticEXL3Llama:
             else:
                 ext.glue_norm(pend[0], pend[1], pend[2], None, x, L["norm1"], self.eps, *tq, bsz)
             slabs, S = ext.exl3_gemv_ex(None, self.xh3, self.xs3, [lq.trellis, lk.trellis, lv.trellis], None, None, None,
-                                        bsz, lq.mcg, lq.mul1, ROT | DEF)
+                                        bsz, lq.mcg, lq.mul1, ROT | DEF, sp["qkv"])
             kc, ks = self.kcache[li]
             vc, vs = self.vcache[li]
             ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
@@ -216,17 +222,17 @@ class SyntheticEXL3Llama:
             # [attention core out of scope: attention output := q]; o_proj takes the raw attention output (fused input Hadamard)
             t2 = ([lg.suh, lu.suh], self.xh3[:2], self.xs3[:2])
             if self.tp == 1:
-                so, So = ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF)
+                so, So = ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"])
                 ext.glue_norm(so[0], So, lo.svh, None, x, L["norm2"], self.eps, *t2, bsz)
             else:
                 lo.bc.run(q2, self.o)
                 be.all_reduce(self.o)
                 ext.glue_norm(None, 0, None, None, x, L["norm2"], self.eps, *t2, bsz, y_dense=self.o)
             sgu, Sgu = ext.exl3_gemv_ex(None, self.xh3[:2], self.xs3[:2], [lg.trellis, lu.trellis], None, None, None,
-                                        bsz, lg.mcg, lg.mul1, ROT | DEF)
+                                        bsz, lg.mcg, lg.mul1, ROT | DEF, sp["gu"])
             ext.glue_act(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz)
             if self.tp == 1:
-                sd, Sd = ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF)
+                sd, Sd = ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF, sp["down"])
                 pend = (sd[0], Sd, ld.svh)
             else:
                 ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.d], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT, c_fp32=True)
@@ -241,15 +247,70 @@ class SyntheticEXL3Llama:
                          bsz, self.lm_head.mcg, self.lm_head.mul1, ROT)
         return self.logits
 
-    def gemv_calls(self, fused: bool):
-        """Zero-argument callables, one per quantized-GEMV launch of a decode step (bench.py roofline leg)."""
-        bsz = self._state_bsz
+    def decode_step_tail(self):
+        """Decode step with in-kernel tail epilogues: 4 launches per layer (qkv+rope+KV-append, o+add+norm, gate/up+act, down+add+norm).
+        Tensor-parallel ranks need the all-reduce between o/down and the norm, so TP > 1 uses decode_step_fused."""
+        if self.tp != 1:
+            return self.decode_step_fused()
+        bsz, hd = self._state_bsz, self.shape.head_dim
+        x = self.x
+        x.copy_(self.x0)
+        q2 = self.q.view(bsz, -1)
+        ext.rope_table(self.inv_freq, self.positions, self.rope_sin, self.rope_cos)
+        L0 = self.layers[0]
+        ext.glue_norm(None, 0, None, None, x, L0["norm1"], self.eps, [L0["q"].suh, L0["k"].suh, L0["v"].suh], self.xh3, self.xs3, bsz)
+        for li, L in enumerate(self.layers):
+            lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
+            kc, ks = self.kcache[li]
+            vc, vs = self.vcache[li]
+            ext.exl3_gemv_qkv(None, self.xh3, self.xs3, [lq.trellis, lk.trellis, lv.trellis], None, [lq.svh, lk.svh, lv.svh], bsz, lq.mcg, lq.mul1,
+                              self.q, None, None, self.rope_sin, self.rope_cos, self.positions, kc, ks, vc, vs, self.block_table, self.page,
+                              self.kv_bits, self.kv_bits, self.hq, self.hkv, hd)
+            # [attention core out of scope: attention output := q]
+            ext.exl3_gemv_norm(q2, None, None, lo.trellis, lo.suh, lo.svh, None, bsz, lo.mcg, lo.mul1, x, L["norm2"], self.eps,
+                               [lg.suh, lu.suh], self.xh3[:2], self.xs3[:2])
+            ext.exl3_gemv_act(None, self.xh3[:2], self.xs3[:2], [lg.trellis, lu.trellis], None, [lg.svh, lu.svh], bsz, lg.mcg, lg.mul1,
+                              ld.suh, self.xh_d, self.xs_d)
+            if li + 1 < len(self.layers):
+                N = self.layers[li + 1]
+                nw, tg, nx = N["norm1"], [N["q"].suh, N["k"].suh, N["v"].suh], 3
+            else:
+                nw, tg, nx = self.final_norm, [self.lm_head.suh], 1
+            ext.exl3_gemv_norm(None, self.xh_d, self.xs_d, ld.trellis, None, ld.svh, None, bsz, ld.mcg, ld.mul1, x, nw, self.eps,
+                               tg, self.xh3[:nx], self.xs3[:nx])
+        ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
+                         bsz, self.lm_head.mcg, self.lm_head.mul1, ext.GEMV_IN_ROTATED)
+        return self.logits
+
+    def gemv_calls(self, pipeline):
+        """Zero-argument callables, one per quantized-GEMV launch of a decode step (bench.py roofline leg).
+        pipeline: "tail" | "glue" | "unfused" (True / False are accepted for glue / unfused)."""
+        if pipeline is True: pipeline = "glue"
+        if pipeline is False: pipeline = "unfused"
+        if self.tp != 1 and pipeline == "tail": pipeline = "glue"
+        bsz, hd = self._state_bsz, self.shape.head_dim
         q2, k2, v2 = self.q.view(bsz, -1), self.k.view(bsz, -1), self.v.view(bsz, -1)
         ROT, DEF = ext.GEMV_IN_ROTATED, ext.GEMV_OUT_DEFERRED
         calls = []
-        for L in self.layers:
+        for li, L in enumerate(self.layers):
             lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
-            if fused and self.tp == 1:
+            if pipeline == "tail":
+                kc, ks = self.kcache[li]
+                vc, vs = self.vcache[li]
+                calls.append(lambda lq=lq, lk=lk, lv=lv, kc=kc, ks=ks, vc=vc, vs=vs: ext.exl3_gemv_qkv(
+                    None, self.xh3, self.xs3, [lq.trellis, lk.trellis, lv.trellis], None, [lq.svh, lk.svh, lv.svh], bsz, lq.mcg, lq.mul1,
+                    self.q, None, None, self.rope_sin, self.rope_cos, self.positions, kc, ks, vc, vs, self.block_table, self.page,
+                    self.kv_bits, self.kv_bits, self.hq, self.hkv, hd))
+                calls.append(lambda lo=lo, lg=lg, lu=lu, L=L: ext.exl3_gemv_norm(
+                    q2, None, None, lo.trellis, lo.suh, lo.svh, None, bsz, lo.mcg, lo.mul1, self.x, L["norm2"], self.eps,
+                    [lg.suh, lu.suh], self.xh3[:2], self.xs3[:2]))
+                calls.append(lambda lg=lg, lu=lu, ld=ld: ext.exl3_gemv_act(
+                    None, self.xh3[:2], self.xs3[:2], [lg.trellis, lu.trellis], None, [lg.svh, lu.svh], bsz, lg.mcg, lg.mul1,
+                    ld.suh, self.xh_d, self.xs_d))
+                calls.append(lambda ld=ld, lq=lq, lk=lk, lv=lv, L=L: ext.exl3_gemv_norm(
+                    None, self.xh_d, self.xs_d, ld.trellis, None, ld.svh, None, bsz, ld.mcg, ld.mul1, self.x, L["norm1"], self.eps,
+                    [lq.suh, lk.suh, lv.suh], self.xh3, self.xs3))
+            elif pipeline == "glue" and self.tp == 1:
                 calls.append(lambda lq=lq, lk=lk, lv=lv: ext.exl3_gemv_ex(None, self.xh3, self.xs3, [lq.trellis, lk.trellis, lv.trellis], None, None, None, bsz, lq.mcg, lq.mul1, ROT | DEF))
                 calls.append(lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF))
                 calls.append(lambda lg=lg, lu=lu: ext.exl3_gemv_ex(None, self.xh3[:2], self.xs3[:2], [lg.trellis, lu.trellis], None, None, None, bsz, lg.mcg, lg.mul1, ROT | DEF))
@@ -259,7 +320,7 @@ class SyntheticEXL3Llama:
                 calls.append(lambda lo=lo: lo.bc.run(q2, self.o))
                 calls.append(lambda lg=lg, lu=lu: ext.exl3_mgemm_bcast(self.xn, [lg.trellis, lu.trellis], [self.g, self.u], [lg.suh, lu.suh], [lg.svh, lu.svh], lg.mcg, lg.mul1))
                 calls.append(lambda ld=ld: ld.bc.run(self.a, self.d))
-        if fused and self.tp == 1:
+        if pipeline != "unfused" and self.tp == 1:
             calls.append(lambda: ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, ROT))
         else:
             calls.append(lambda: self.lm_head.bc.run(self.xn, self.logits))

@@ -127,6 +127,32 @@ int exl3_glue_qkv(const float* sq, const float* sk, const float* sv, int S, cons
 int exl3_glue_act(const float* sg, const float* su, int S, const void* svh_g, const void* svh_u, const void* suh_d,
                   void* xh_d, float* xsum_d, void* a_out, int m, int inter, void* stream);
 
+/* ---- GEMV launches with an in-kernel tail epilogue (decode, m <= 16) ------------------------------------------------------
+ * The workgroup that finishes a 128-column block last (device-memory arrival ticket) reduces the split-k partials of that
+ * block and runs the sublayer boundary the reference executes as separate graph nodes between two exl3_gemm calls
+ * (libtorch/attention.cpp:246-504, libtorch/mlp.cpp:14-91).  Inputs: pre-rotated (xh = had128(x * suh), xsum = per-block sums,
+ * as produced by these same epilogues / exl3_glue_norm) or raw (A + suh).  Results are bit-identical to the
+ * exl3_gemv_ex(GEMV_OUT_DEFERRED) + exl3_glue_* pair. */
+
+/* o_proj / down_proj:  y = linear(x) (fp32, + bias) ; resid += y (fp16, norm.cu:193-218 rms_norm_res_in semantics) ;
+ * xn = rms_norm(resid) * norm_w ; for each of t_count consumers: t_xhs[i] = had128(xn * t_suhs[i]), t_xsums[i] = block sums. */
+int exl3_gemv_norm(const void* A, const void* xh, const float* xsum, const void* B, const void* suh, const void* svh, const void* bias,
+                   int m, int k, int n, int K, int cb, void* resid, const void* norm_w, float eps,
+                   const void* const* t_suhs, void* const* t_xhs, float* const* t_xsums, int t_count, void* xn_out, void* stream);
+/* gate_proj + up_proj (Bs[0], Bs[1]): a = fp16(silu(g) * u) (activation.cu) ; xh_d = had128(a * suh_d), xsum_d ; a_out optional. */
+int exl3_gemv_act(const void* A, const void* const* xhs, const float* const* xsums, const void* const* Bs, const void* const* suhs,
+                  const void* const* svhs, int m, int k, int inter, int K, int cb,
+                  const void* suh_d, void* xh_d, float* xsum_d, void* a_out, void* stream);
+/* q/k/v projections (Bs[0..2]), head_dim 128: RoPE on q and k from the per-step table (exl3_rope_table), q_out fp16
+ * [m][heads_q*128]; k, v appended to the quantized paged cache (cache.cu quant_cache_paged semantics) and/or written to k_out/v_out. */
+int exl3_gemv_qkv(const void* A, const void* const* xhs, const float* const* xsums, const void* const* Bs, const void* const* suhs,
+                  const void* const* svhs, int m, int k, int K, int cb, void* q_out, void* k_out, void* v_out,
+                  const float* rope_sin, const float* rope_cos, const int32_t* positions,
+                  void* k_cache, void* k_scales, void* v_cache, void* v_scales, const int32_t* block_table, int blocks_per_seq,
+                  int page_size, int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int rope_mode, void* stream);
+/* sin_out/cos_out[m][64] = sincosf(inv_freq[f] * positions[row]) * attn_factor (rope.cu:60-120 evaluates the same per launch). */
+int exl3_rope_table(const float* inv_freq, const int32_t* positions, float attn_factor, int m, float* sin_out, float* cos_out, void* stream);
+
 /* hgemm(a, b, c)      hgemm.cu:19-102:  c[m][n] (row stride ldc elements, fp16 or fp32) = a[m][k] @ b[k][n], fp32 accumulate.
  * m, k, n arbitrary multiples of 16/32/16. */
 int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, void* stream);

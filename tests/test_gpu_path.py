@@ -170,3 +170,92 @@ def test_fused_gptj_rope_and_gemv_ex_modes(dev):
     ext.glue_qkv(slabs, S, sv[0], sv[1], sv[2], qf, kf, vf, inv, pos, None, None, None, None, None, 256, 8, 8, m, hq, hkv, 128, rope_mode=1)
     for a, b in ((qf, q4.view(m, -1)), (kf, k4.view(m, -1)), (vf, outs[2])):
         assert float((a.float() - b.float()).abs().max()) < 4e-3 * float(b.float().abs().max()) + 2e-3
+
+
+@pytest.mark.parametrize("cb", [0, 1, 2])
+@pytest.mark.parametrize("bsz", [1, 2, 5, 16])
+def test_tail_epilogue_pipeline_is_bit_identical_to_glue_pipeline(dev, cb, bsz):
+    """In-kernel tail epilogues (exl3_gemv2_tail.cuh, 4 launches/layer) run the glue kernels' arithmetic on the same slabs in the
+    same summation order: logits, residual stream, q and the quantized KV pages must match the glue pipeline bit for bit."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    shape = LlamaShape("tiny", 256, 512, 3, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(bsz, pos=1234)
+    lg = model.decode_step_fused().clone()
+    xg, qg = model.x.clone(), model.q.clone()
+    kvg = [(c.clone(), s.clone()) for c, s in model.kcache + model.vcache]
+    for c, s in model.kcache + model.vcache:
+        c.zero_(); s.zero_()
+    model.q.zero_(); model.logits.zero_()
+    for rep in range(3):                                   # tickets must be re-armed: repeated launches give the same bits
+        lt = model.decode_step_tail()
+        torch.cuda.synchronize()
+        assert torch.equal(lt, lg), f"logits differ (rep {rep})"
+        assert torch.equal(model.x, xg) and torch.equal(model.q, qg)
+        for (c, s), (c0, s0) in zip(model.kcache + model.vcache, kvg):
+            assert torch.equal(c, c0) and torch.equal(s, s0)
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            model.decode_step_tail()
+    model.logits.zero_(); g.replay(); g.replay(); torch.cuda.synchronize()
+    assert torch.equal(model.logits, lg)
+
+
+@pytest.mark.parametrize("K", [2, 3, 5, 8])
+def test_tail_epilogue_entry_points_raw_input_gptj_and_bits(dev, K):
+    """exl3_gemv_qkv / _act / _norm with un-rotated inputs (A + suh), GPTJ rope, 8-bit K / 3-bit V cache, bias, xn_out, a_out:
+    against deferred GEMV + glue kernels (bit-exact) for every bitrate."""
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(K)
+    k, m, hq, hkv, inter = 512, 3, 3, 1, 384
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x = T(rng.standard_normal((m, k)).astype(np.float16))
+    mats = [o.synth_linear(k, h * 128, K, seed=20 + i, realistic=True) for i, h in enumerate((hq, hkv, hkv))]
+    Bs = [T(t[0]) for t in mats]; su = [T(t[1]) for t in mats]; sv = [T(t[2]) for t in mats]
+    inv = T((1.0 / (10000.0 ** (np.arange(0, 128, 2) / 128))).astype(np.float32))
+    pos = T(np.array([7, 300, 1999], dtype=np.int32))
+    page, pages = 256, 8
+    bt = T(np.array([[3, 1, 0, 2, 7, 6, 5, 4], [0, 1, 2, 3, 4, 5, 6, 7], [7, 6, 5, 4, 3, 2, 1, 0]], dtype=np.int32))[:, :pages].contiguous()
+    def caches(bits):
+        return (torch.zeros((pages * 3, page, hkv * 128 // 32 * bits), dtype=torch.int32, device=dev),
+                torch.zeros((pages * 3, page, hkv * 128 // 32), dtype=torch.half, device=dev))
+    for mode in (1, 2):
+        kc0, ks0 = caches(8); vc0, vs0 = caches(3); kc1, ks1 = caches(8); vc1, vs1 = caches(3)
+        q0 = torch.empty((m, hq * 128), dtype=torch.half, device=dev); k0 = torch.empty((m, hkv * 128), dtype=torch.half, device=dev); v0 = torch.empty_like(k0)
+        q1, k1, v1 = torch.empty_like(q0), torch.empty_like(k0), torch.empty_like(v0)
+        slabs, S = ext.exl3_gemv_ex(x, None, None, Bs, None, su, None, m, False, False, ext.GEMV_OUT_DEFERRED)
+        ext.glue_qkv(slabs, S, sv[0], sv[1], sv[2], q0, k0, v0, inv, pos, kc0, ks0, vc0, vs0, bt, page, 8, 3, m, hq, hkv, 128, rope_mode=mode)
+        sn = torch.empty((m, 64), dtype=torch.float32, device=dev); cs = torch.empty_like(sn)
+        ext.rope_table(inv, pos, sn, cs)
+        ext.exl3_gemv_qkv(x, None, None, Bs, su, sv, m, False, False, q1, k1, v1, sn, cs, pos, kc1, ks1, vc1, vs1, bt, page, 8, 3, hq, hkv, 128, rope_mode=mode)
+        for a, b in ((q0, q1), (k0, k1), (v0, v1), (kc0, kc1), (ks0, ks1), (vc0, vc1), (vs0, vs1)):
+            assert torch.equal(a, b)
+        assert int((ks1 != 0).sum()) == m * hkv * 4
+    # gate/up + act
+    gu = [o.synth_linear(k, inter, K, seed=40 + i, realistic=True) for i in range(2)]
+    dn = o.synth_linear(inter, k, K, seed=50, realistic=True)
+    Bg = [T(t[0]) for t in gu]; sug = [T(t[1]) for t in gu]; svg = [T(t[2]) for t in gu]
+    Bd, sud, svd = T(dn[0]), T(dn[1]), T(dn[2])
+    xh0 = torch.empty((m, inter), dtype=torch.half, device=dev); xs0 = torch.empty((m, inter // 128), dtype=torch.float32, device=dev); a0 = torch.empty_like(xh0)
+    xh1, xs1, a1 = torch.empty_like(xh0), torch.empty_like(xs0), torch.empty_like(a0)
+    slabs, S = ext.exl3_gemv_ex(x, None, None, Bg, None, sug, None, m, False, False, ext.GEMV_OUT_DEFERRED)
+    ext.glue_act(slabs, S, svg[0], svg[1], sud, xh0, xs0, m, a_out=a0)
+    ext.exl3_gemv_act(x, None, None, Bg, sug, svg, m, False, False, sud, xh1, xs1, a_out=a1)
+    assert torch.equal(xh0, xh1) and torch.equal(xs0, xs1) and torch.equal(a0, a1)
+    # down + bias + residual + norm + 2 consumers + xn_out
+    bias = T((rng.standard_normal(k) * 0.1).astype(np.float16))
+    w = T((1 + 0.1 * rng.standard_normal(k)).astype(np.float16))
+    r0 = T(rng.standard_normal((m, k)).astype(np.float16)); r1 = r0.clone()
+    t0 = [torch.empty((m, k), dtype=torch.half, device=dev) for _ in range(2)]; s0 = [torch.empty((m, k // 128), dtype=torch.float32, device=dev) for _ in range(2)]
+    t1 = [torch.empty_like(t) for t in t0]; s1 = [torch.empty_like(t) for t in s0]
+    xn0 = torch.empty((m, k), dtype=torch.half, device=dev); xn1 = torch.empty_like(xn0)
+    slabs, S = ext.exl3_gemv_ex(None, [xh0], [xs0], [Bd], None, None, None, m, False, False, ext.GEMV_IN_ROTATED | ext.GEMV_OUT_DEFERRED)
+    ext.glue_norm(slabs[0], S, svd, bias, r0, w, 1e-5, su[:2], t0, s0, m, xn_out=xn0)
+    ext.exl3_gemv_norm(None, xh0, xs0, Bd, None, svd, bias, m, False, False, r1, w, 1e-5, su[:2], t1, s1, xn_out=xn1)
+    assert torch.equal(r0, r1) and torch.equal(xn0, xn1)
+    for a, b in zip(t0 + s0, t1 + s1):
+        assert torch.equal(a, b)

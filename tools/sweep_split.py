@@ -1,0 +1,35 @@
+"""Whole-step time of the glue pipeline (hipGraph replay) as a function of the split-k factor of each call type."""
+import sys, torch
+sys.path.insert(0, "/root/repo")
+from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
+
+dev = torch.device("cuda:0")
+layers = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+model = SyntheticEXL3Llama(SHAPES["llama-3.1-8b"], K=4, cb=2, device=dev, kv_bits=4, layers=layers)
+model.alloc_state(1)
+
+def step_us():
+    model.decode_step_fused(); torch.cuda.synchronize()
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            model.decode_step_fused()
+        g.replay(); st.synchronize()
+        best = 1e9
+        for _ in range(3):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(10): g.replay()
+            e1.record(st); st.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / 10)
+    return best / layers
+
+base = step_us()
+print(f"heuristic: {base:.2f} us/layer")
+cands = {"qkv": [3, 4, 6, 8, 11, 16], "o": [2, 4, 8, 16, 32], "gu": [1, 2, 3, 4], "down": [4, 7, 8, 14, 16, 28]}
+for key, vals in cands.items():
+    for v in vals:
+        model.split = dict(SyntheticEXL3Llama.split); model.split[key] = v
+        print(f"{key:5s} S={v:3d}: {step_us():7.2f} us/layer")
+    model.split = dict(SyntheticEXL3Llama.split)
