@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--gen", type=int, default=2)
     ap.add_argument("--unfused", action="store_true", help="one launch per reference op instead of the fused pipeline")
-    ap.add_argument("--pipeline", choices=["tail", "glue", "unfused"], default="tail",
-                    help="tail: sublayer boundaries run inside the GEMV launches (4 launches/layer); glue: separate glue kernels (8/layer)")
+    ap.add_argument("--pipeline", choices=["tail", "glue", "unfused"], default="glue",
+                    help="glue: deferred-epilogue GEMVs + glue kernels (8 launches/layer, fastest measured); tail: sublayer boundaries run "
+                         "inside the GEMV launches (4 launches/layer; the in-kernel cross-workgroup hand-off through memory costs more than a launch)")
     return ap.parse_args()
 
 

@@ -89,3 +89,14 @@ extern "C" int exl3_device_info(int device, int* num_cus, int* gfx_arch, int64_t
     if (hbm_bytes) *hbm_bytes = (int64_t) prop.totalGlobalMem;
     return EXL3_OK;
 }
+
+// Diagnostics: copy a range of the per-device split-k workspace into a caller buffer (device or host pointer).  Used by
+// tools/gemv_timeline.py with a -DG2_TIMING build, whose workgroups leave phase timestamps in the workspace tail.
+extern "C" int exl3_debug_copy_workspace(void* dst, int64_t byte_offset, int64_t nbytes, void* stream)
+{
+    Exl3DevCtx* ctx = exl3_get_ctx((hipStream_t) stream);
+    if (!ctx) return EXL3_ERR_INIT;
+    EXL3_CHECK_ARG(dst && byte_offset >= 0 && nbytes >= 0 && byte_offset + nbytes <= EXL3_WORKSPACE_BYTES, "debug_copy_workspace: bad range");
+    EXL3_CHECK_HIP(hipMemcpyAsync(dst, (const char*) ctx->workspace + byte_offset, (size_t) nbytes, hipMemcpyDefault, (hipStream_t) stream), "hipMemcpyAsync");
+    return EXL3_OK;
+}

@@ -527,8 +527,21 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         int fs = force_split;
         if (deferred && fs == 0)
         {
-            // deferred epilogue: the reduction is free (a glue kernel does it), so split k until ~2 workgroups per CU
-            fs = (2 * ctx->num_cus + total_cb - 1) / total_cb;
+            // deferred epilogue: the reduction is free (a glue kernel / tail epilogue does it), so pick the split that balances the
+            // chip.  All workgroups of these launches are resident at once and the kernel is VALU-bound per CU, so the launch
+            // takes as long as the busiest CU: ceil(workgroups / CUs) * blocks per workgroup.  Fewest slabs among the minima;
+            // a light preference for >= 2 workgroups per CU (tools/sweep_split.py: gate/up 3 -> 8 is -3 us per layer).
+            const int nbk = k / 128, cus = ctx->num_cus;
+            double best_cost = 1e30;
+            fs = 1;
+            for (int s = 1; s <= nbk && s <= 64; ++s)
+            {
+                const int b = (nbk + s - 1) / s;
+                if ((nbk + b - 1) / b != s) continue;              // not a normalised split
+                const long wg = (long) total_cb * s;
+                double cost = (double) ((wg + cus - 1) / cus) * b + (wg < 2l * cus ? 0.25 : 0.0) + 1e-3 * s;
+                if (cost < best_cost) { best_cost = cost; fs = s; }
+            }
             if (g_gemv_defer_wg_per_cu > 0) fs = (g_gemv_defer_wg_per_cu * ctx->num_cus + total_cb - 1) / total_cb;
             if (fs < 1) fs = 1;
             if (epi && fs > 64) fs = 64;                         // tail epilogue: one pass of slabs must fit the workgroup LDS

@@ -90,6 +90,14 @@ void exl3_gemv2_kernel(const GemvArgs a)
     constexpr int AH = SPLIT ? 32 : 16;              // halves per (tile row, activation row)
     constexpr int NW = 8 * K;
 
+#ifdef G2_TIMING
+    // diagnostics build: wave 0 of every workgroup leaves 100 MHz timestamps of its phases in the workspace tail (48 MiB offset)
+    uint64_t tstamp[6];
+    tstamp[0] = __builtin_amdgcn_s_memrealtime();
+    #define G2_T(i) tstamp[i] = __builtin_amdgcn_s_memrealtime()
+#else
+    #define G2_T(i)
+#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -250,12 +258,14 @@ void exl3_gemv2_kernel(const GemvArgs a)
         for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(rbeg + u, last_row) * row_stride);
     }
 
+    G2_T(1);
     for (int c0 = 0; c0 < nbw; c0 += chb)
     {
         const int cnt = min(chb, nbw - c0);
         prep_chunk(c0, cnt);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // wave-private LDS: in-order queue + drain
         __builtin_amdgcn_wave_barrier();
+        if (c0 == 0) { G2_T(2); }
 
         // pure streaming loop over this wave's tile rows inside the chunk, G2_PF rows per iteration (rbeg, rend and the chunk
         // bounds are multiples of G2_PF)
@@ -329,6 +339,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         __builtin_amdgcn_wave_barrier();
     }
 
+    G2_T(3);
     // ---- epilogue: per-wave partials -> LDS, cross-wave sum, output Hadamard
     if constexpr (RAW)
     {
@@ -366,6 +377,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         }
     }
     __syncthreads();
+    G2_T(4);
 
     const int l = tid & 31, hw8 = tid >> 5;
     const size_t wstride = (size_t) MR * 128;
@@ -384,6 +396,17 @@ void exl3_gemv2_kernel(const GemvArgs a)
             if (a.epi.mode != GEMV_EPI_NONE) st_agent(slab + row * 128 + 4 * l, v);     // read by another workgroup of this launch
             else ((float4_t*) (slab + row * 128))[l] = v;
         }
+#ifdef G2_TIMING
+        if (tid == 0)
+        {
+            tstamp[5] = __builtin_amdgcn_s_memrealtime();
+            uint64_t* dbg = (uint64_t*) ((char*) a.workspace + (48ll << 20)) + (size_t) blockIdx.x * 8;
+            for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
+            uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            uint32_t hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            dbg[6] = xcc; dbg[7] = hwid;
+        }
+#endif
         if (a.epi.mode != GEMV_EPI_NONE) gemv_tail(a, mi, cbl, cbg, tid, nwv, &s_tail_flag, (float4_t*) smem);
         return;
     }

@@ -153,6 +153,9 @@ int exl3_gemv_qkv(const void* A, const void* const* xhs, const float* const* xsu
 /* sin_out/cos_out[m][64] = sincosf(inv_freq[f] * positions[row]) * attn_factor (rope.cu:60-120 evaluates the same per launch). */
 int exl3_rope_table(const float* inv_freq, const int32_t* positions, float attn_factor, int m, float* sin_out, float* cos_out, void* stream);
 
+/* Diagnostics only: copy [byte_offset, byte_offset + nbytes) of the per-device split-k workspace to dst (tools/gemv_timeline.py). */
+int exl3_debug_copy_workspace(void* dst, int64_t byte_offset, int64_t nbytes, void* stream);
+
 /* hgemm(a, b, c)      hgemm.cu:19-102:  c[m][n] (row stride ldc elements, fp16 or fp32) = a[m][k] @ b[k][n], fp32 accumulate.
  * m, k, n arbitrary multiples of 16/32/16. */
 int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, void* stream);

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Phase timeline of the gen-2 GEMV workgroups (diagnostics build with -DG2_TIMING):
+   EXL3_HIP_LIB=build/libexl3_hip_timing.so python tools/gemv_timeline.py
+Every workgroup's wave 0 records 100 MHz timestamps: entry, ring loads issued, first prep done, stream done, partials in LDS,
+slab written.  Printed per call type of the Llama-3.1-8B decode step: percentiles relative to the earliest workgroup entry."""
+import ctypes, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from exllamav3_amd import ext, _lib
+from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
+
+dev = torch.device("cuda:0")
+model = SyntheticEXL3Llama(SHAPES["llama-3.1-8b"], K=4, cb=2, device=dev, kv_bits=4, layers=2)
+model.alloc_state(1)
+model.decode_step_fused(); torch.cuda.synchronize()
+calls = model.gemv_calls("glue")
+names = ["qkv", "o", "gate_up", "down", "lm_head"]
+grids = {"qkv": 48, "o": 32, "gate_up": 224, "down": 32, "lm_head": 1002}
+buf = torch.zeros(8 * 8192, dtype=torch.int64, device=dev)
+out = {}
+prev_newest = 0
+for i, nm in enumerate(names):
+    c = calls[4 + i] if i < 4 else calls[-1]          # second layer's instances
+    for rep in range(3):
+        c(); torch.cuda.synchronize()
+        if rep == 1:
+            _lib.lib().exl3_debug_copy_workspace(buf.data_ptr(), 48 << 20, buf.numel() * 8, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            prev_newest = int(buf[5::8].max().item())   # everything up to the second repetition is "old"
+    _lib.lib().exl3_debug_copy_workspace(buf.data_ptr(), 48 << 20, buf.numel() * 8, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    t = buf.cpu().numpy().reshape(-1, 8)
+    t = t[t[:, 0] > 0]
+    # the number of workgroups of this launch: rows whose entry stamp is within 1 ms of the newest
+    t = t[t[:, 0] > prev_newest]                        # stamps of this call type only (the workspace keeps older ones)
+    prev_newest = int(t[:, 5].max())
+    t0 = t[:, 0].min()
+    rel = (t[:, :6] - t0) * 0.01                        # us
+    row = {"workgroups": int(len(t))}
+    for j, ph in enumerate(["entry", "loads_issued", "first_prep", "stream_done", "partials", "slab_written"]):
+        v = rel[:, j]
+        row[ph] = [round(float(np.percentile(v, q)), 2) for q in (0, 50, 100)]
+    row["xcc_counts"] = np.bincount(t[:, 6].astype(int) & 15, minlength=8).tolist()
+    out[nm] = row
+    print(nm, json.dumps(row), flush=True)

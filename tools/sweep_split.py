@@ -27,7 +27,7 @@ def step_us():
 
 base = step_us()
 print(f"heuristic: {base:.2f} us/layer")
-cands = {"qkv": [3, 4, 6, 8, 11, 16], "o": [2, 4, 8, 16, 32], "gu": [1, 2, 3, 4], "down": [4, 7, 8, 14, 16, 28]}
+cands = {"qkv": [16, 32], "o": [16, 32], "gu": [2, 4, 8, 16, 32], "down": [16, 28, 56]}
 for key, vals in cands.items():
     for v in vals:
         model.split = dict(SyntheticEXL3Llama.split); model.split[key] = v
