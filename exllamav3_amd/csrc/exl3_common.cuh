@@ -101,6 +101,12 @@ __device__ __forceinline__ int tile_stream_index(int r, int c)
     return 8 * l + j;
 }
 
+// float -> half with the reference's rounding: the fp32 operation rounds to fp32 first, then RNE to fp16 (what __float2half_rn of
+// an fp32 expression does in the reference kernels and what numpy does in the oracle).  Without the barrier hipcc folds
+// fptrunc(fmul / fadd / fma) into v_fma_mixlo_f16, which rounds ONCE; the result differs from the two-step rounding in rare
+// cases and -- because the fold depends on the surrounding code -- two kernels computing the same expression disagree by 1 ulp.
+__device__ __forceinline__ half_t f2h(float v) { asm("" : "+v"(v)); return (half_t) v; }
+
 // Butterfly exchange v[lane ^ I] for a compile-time I.  hipcc lowers __shfl_xor to ds_bpermute_b32 (LDS crossbar, ~100+ cycles of
 // dependent latency per stage); the latency-bound decode kernels are chains of these, so use the register-file paths instead:
 //   I = 1, 2 : one DPP quad_perm (folds into the consuming VALU op)

@@ -14,7 +14,7 @@ __device__ __forceinline__ float4_t load4(const void* p, int64_t idx4, bool fp32
 __device__ __forceinline__ void store4(void* p, int64_t idx4, float4_t v, bool fp32)
 {
     if (fp32) ((float4_t*) p)[idx4] = v;
-    else ((half4_t*) p)[idx4] = half4_t{ (half_t) v.x, (half_t) v.y, (half_t) v.z, (half_t) v.w };
+    else ((half4_t*) p)[idx4] = half4_t{ f2h(v.x), f2h(v.y), f2h(v.z), f2h(v.w) };
 }
 
 __device__ __forceinline__ float4_t load_w4(const void* w, int idx4, bool bf16)
@@ -62,7 +62,7 @@ void rms_norm_kernel(const void* __restrict__ x, const void* __restrict__ w, voi
             float4_t rv = load4(r, base4 + c, r_fp32);
             v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
             store4(r, base4 + c, v, r_fp32);
-            if (!r_fp32) { v.x = (float) (half_t) v.x; v.y = (float) (half_t) v.y; v.z = (float) (half_t) v.z; v.w = (float) (half_t) v.w; }  // norm sees r's rounding (norm.cu:206-213)
+            if (!r_fp32) { v.x = (float) f2h(v.x); v.y = (float) f2h(v.y); v.z = (float) f2h(v.z); v.w = (float) f2h(v.w); }  // norm sees r's rounding (norm.cu:206-213)
         }
         sum = __builtin_fmaf(v.x, v.x, sum); sum = __builtin_fmaf(v.y, v.y, sum);
         sum = __builtin_fmaf(v.z, v.z, sum); sum = __builtin_fmaf(v.w, v.w, sum);

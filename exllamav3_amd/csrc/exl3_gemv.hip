@@ -192,8 +192,8 @@ void exl3_gemv_kernel(const GemvArgs a)
             xv = xv * sv;
             float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
             had128_f32x4(h0, h1, h2, h3, l);
-            half2_t o01 = { (half_t) (h0 * HAD_R_SCALE_128), (half_t) (h1 * HAD_R_SCALE_128) };
-            half2_t o23 = { (half_t) (h2 * HAD_R_SCALE_128), (half_t) (h3 * HAD_R_SCALE_128) };
+            half2_t o01 = { f2h(h0 * HAD_R_SCALE_128), f2h(h1 * HAD_R_SCALE_128) };
+            half2_t o23 = { f2h(h2 * HAD_R_SCALE_128), f2h(h3 * HAD_R_SCALE_128) };
             if (RAW)
             {
                 float t = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
@@ -355,7 +355,7 @@ void exl3_gemv_kernel(const GemvArgs a)
         }
         else
         {
-            half4_t o = { (half_t) h0, (half_t) h1, (half_t) h2, (half_t) h3 };
+            half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
             o = o * sc;
             if (bias) o = o + ((const half4_t*) bias)[l];
             *((half4_t*) ((half_t*) a.mat[mi].C + off)) = o;
@@ -401,7 +401,7 @@ void exl3_gemv_reduce_kernel(const GemvArgs a, int total_colblocks)
     }
     else
     {
-        half4_t o = { (half_t) h0, (half_t) h1, (half_t) h2, (half_t) h3 };
+        half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
         o = o * sc;
         if (bias) o = o + ((const half4_t*) bias)[l];
         *((half4_t*) ((half_t*) a.mat[mi].C + off)) = o;
@@ -494,13 +494,16 @@ static int choose_split(int gen, int total_colblocks, int k, int m, int num_cus,
 static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, const void* const* suhs, const void* const* svhs,
                      const void* const* biases, const int* ns, int count, int m, int k, int K, int cb, int c_fp32,
                      int force_split, hipStream_t st, int flags = 0, const void* const* xhs = nullptr, const float* const* xsums = nullptr,
-                     float** slabs_out = nullptr, int* S_out = nullptr, const GemvEpi* epi = nullptr)
+                     float** slabs_out = nullptr, int* S_out = nullptr, const GemvEpi* epi = nullptr,
+                     const void* norm_w = nullptr, const float* ss_part = nullptr, float eps = 0.0f)
 {
     if (epi) flags |= GEMV_OUT_DEFERRED;
     const bool deferred = (flags & GEMV_OUT_DEFERRED) != 0, rotated = (flags & GEMV_IN_ROTATED) != 0;
     EXL3_CHECK_ARG(!(deferred || rotated) || m <= 16, "exl3_gemv_ex: at most 16 rows");
     const int epi_sets = !epi ? 0 : (epi->mode == GEMV_EPI_ACT ? 2 : 1);
     EXL3_CHECK_ARG(!rotated || xhs, "exl3_gemv_ex: rotated input requires xh pointers");
+    const bool in_norm = (flags & GEMV_IN_NORM) != 0;
+    EXL3_CHECK_ARG(!in_norm || (norm_w && ss_part && !rotated && m <= 16), "exl3_gemv_ex: GEMV_IN_NORM needs norm_w, ss_part, raw input and m <= 16");
     EXL3_CHECK_ARG(count >= 1 && count <= GEMV_MAX_MATS, "exl3_mgemm: between 1 and %d matrices per launch", GEMV_MAX_MATS);
     EXL3_CHECK_ARG(K >= 1 && K <= 8, "exl3_gemm: K must be in [1, 8]");
     EXL3_CHECK_ARG(cb >= 0 && cb <= 2, "exl3_gemm: bad codebook");
@@ -523,7 +526,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         const int mp = (m - m0) < 16 ? (m - m0) : 16;
         GemvArgs args;
         memset((void*) &args, 0, sizeof(args));
-        const int gen = (deferred || rotated) ? 2 : gemv_gen();
+        const int gen = (deferred || rotated || in_norm) ? 2 : gemv_gen();
+        args.norm_w = (const half_t*) norm_w; args.ss_part = ss_part; args.eps = eps;
         int fs = force_split;
         if (deferred && fs == 0)
         {
@@ -598,6 +602,10 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             // measured on MI355X (tools/prof_tail.py, batch 1): one wave per Hadamard block of the slice, but at least 4 waves --
             // more waves than that do not help (the kernel is VALU / fixed-latency bound), fewer starve the short slices
             if (nwv > (bps > 4 ? bps : 4)) nwv = bps > 4 ? bps : 4;
+            // deferred launches keep every workgroup resident (balanced split above): 4 waves = one per SIMD per workgroup with equal
+            // rows each, so no SIMD ends up with an extra wave (tools/gemv_timeline.py: down_proj's 7-wave workgroups left a
+            // 4/4/3/3 SIMD load and a 1.8 us wait at the workgroup barrier)
+            if (deferred && nwv > 4 && bps <= 16) nwv = 4;
             if (nwv > units) nwv = units;
             if (g_gemv_nwv > 0 && nwv > g_gemv_nwv) nwv = g_gemv_nwv;
             if (nwv < 1) nwv = 1;
@@ -685,7 +693,19 @@ extern "C" int exl3_gemv_ex(const void* A, const void* const* xhs, const float* 
                             int m, int k, int K, int cb, int c_fp32, int flags, int force_split, float** slabs_out, int* S_out, void* stream)
 {
     EXL3_CHECK_ARG(Bs && ns, "exl3_gemv_ex: null table");
+    EXL3_CHECK_ARG(!(flags & GEMV_IN_NORM), "exl3_gemv_ex: use exl3_gemv_ex_norm for GEMV_IN_NORM");
     return run_mgemm(A, Bs, Cs, suhs, svhs, biases, ns, count, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream, flags, xhs, xsums, slabs_out, S_out);
+}
+
+// exl3_gemv_ex whose input A is the fp16 residual stream: RMSNorm (norm_w, eps; per-block sums of squares ss_part [m][k/128] from
+// exl3_glue_resid) is applied while the activation fragments are built.  flags: GEMV_OUT_DEFERRED optional.
+extern "C" int exl3_gemv_ex_norm(const void* resid, const void* norm_w, const float* ss_part, float eps, const void* const* Bs, void* const* Cs,
+                                 const void* const* suhs, const void* const* svhs, const void* const* biases, const int* ns, int count,
+                                 int m, int k, int K, int cb, int c_fp32, int flags, int force_split, float** slabs_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(Bs && ns && resid, "exl3_gemv_ex_norm: null table");
+    return run_mgemm(resid, Bs, Cs, suhs, svhs, biases, ns, count, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream,
+                     (flags & GEMV_OUT_DEFERRED) | GEMV_IN_NORM, nullptr, nullptr, slabs_out, S_out, nullptr, norm_w, ss_part, eps);
 }
 
 // ------------------------------------------------------------------------------------------------

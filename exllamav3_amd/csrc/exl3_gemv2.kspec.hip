@@ -77,9 +77,14 @@ __device__ __forceinline__ void decode_quad(const uint32_t (&Wx)[K + 1], half4_t
     }
 }
 
-template <int K, int CB, int VAR, int NG>
+#define G2_MODE_PLAIN 0     // rotated or raw input
+#define G2_MODE_NORM  1     // GEMV_IN_NORM: RMSNorm of the residual stream while building the activation fragments
+#define G2_MODE_TAIL  2     // in-kernel tail epilogue (exl3_gemv2_tail.cuh)
+// The modes are separate instantiations because the hot loop needs 62 of the 64 VGPRs that allow two 16-wave workgroups per CU: code
+// of a cold path that is merely present makes the allocator spill (scratch also slows every launch by ~1 us, measured).
+template <int K, int CB, int VAR, int NG, int MODE>
 // m <= 4 (NG == 1): two 16-wave workgroups per CU need <= 64 VGPRs; the hot loop uses 62, the attribute keeps the tail epilogue from raising it
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NG == 1 ? 8 : 4)))
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NG == 1 ? (MODE == G2_MODE_NORM ? 7 : 8) : 4)))
 void exl3_gemv2_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -143,34 +148,68 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const float* __restrict__ xsum_in = a.mat[mi].xsum;
     const int npass = (m + 1) >> 1;                  // passes of 2 rows (one per half-wave)
 
+    // GEMV_IN_NORM: A is the fp16 residual stream; x = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)) is formed in prep_chunk, per
+    // row from the per-block sums of squares a glue kernel left behind (same arithmetic and summation order as glue_norm_kernel /
+    // rms_norm: norm.cu:20-120), so the RMSNorm between two linears costs no launch and no single-workgroup pass.
+    constexpr bool in_norm = MODE == G2_MODE_NORM;
+
     // ---- input Hadamard (or fetch of the pre-rotated input) of `cnt` blocks starting at wave-local block c0, written in
     //      MFMA-A fragment order.  Software pipelined by one task so the global loads of task i+1 fly during task i.
     auto prep_chunk = [&] (int c0, int cnt)
     {
         const int ntask = cnt * npass;
-        half4_t xv_n = {}, sv_n = {}; float xs_n = 0.0f;
-        auto fetch = [&] (int t)
+        struct PrepIn { half4_t xv, sv, wv; float xs; };
+        auto fetch = [&] (int t) -> PrepIn
         {
+            PrepIn r; r.xv = half4_t{ 0, 0, 0, 0 }; r.sv = r.xv; r.wv = r.xv; r.xs = 0.0f;
             const int blk = c0 + t / npass, p = t % npass;
             const int row = 2 * p + hw;
             const bool act = row < m;
             const size_t off = (size_t) (act ? row : 0) * a.k + k0 + 128 * blk;
             if (in_rotated)
             {
-                xv_n = ((const half4_t*) (xh_in + off))[l32];
-                if constexpr (RAW) xs_n = xsum_in[(size_t) (act ? row : 0) * (a.k >> 7) + (k0 >> 7) + blk];
+                r.xv = ((const half4_t*) (xh_in + off))[l32];
+                if constexpr (RAW) r.xs = xsum_in[(size_t) (act ? row : 0) * (a.k >> 7) + (k0 >> 7) + blk];
             }
             else
             {
-                xv_n = ((const half4_t*) (a.A + off))[l32];
-                sv_n = ((const half4_t*) (suh + k0 + 128 * blk))[l32];
+                r.xv = ((const half4_t*) (a.A + off))[l32];
+                r.sv = ((const half4_t*) (suh + k0 + 128 * blk))[l32];
+                if constexpr (in_norm) r.wv = ((const half4_t*) (a.norm_w + k0 + 128 * blk))[l32];
             }
+            return r;
         };
-        fetch(0);
+        PrepIn nx = fetch(0);
+        // per-row 1/rms: computed here (after the weight ring loads and the first activation fetch were issued) and not kept live
+        // across the streaming loop
+        float rmf[2 * NG];
+        #pragma unroll
+        for (int p = 0; p < 2 * NG; ++p) rmf[p] = 1.0f;
+        if constexpr (in_norm)
+        {
+            const int nblk_k = a.k >> 7;
+            #pragma unroll
+            for (int p = 0; p < 2 * NG; ++p)
+            {
+                if (p < npass)
+                {
+                    const int row = min(2 * p + hw, m - 1);
+                    float s2 = 0.0f;
+                    for (int bb = 0; bb < nblk_k; bb += 32)
+                    {
+                        float v = (bb + l32 < nblk_k) ? a.ss_part[(size_t) row * nblk_k + bb + l32] : 0.0f;
+                        #pragma unroll
+                        for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
+                        s2 += v;
+                    }
+                    rmf[p] = __frsqrt_rn(s2 / (float) a.k + a.eps);
+                }
+            }
+        }
         for (int t = 0; t < ntask; ++t)
         {
-            const half4_t xv_c = xv_n, sv_c = sv_n; const float xs_c = xs_n;
-            if (t + 1 < ntask) fetch(t + 1);
+            const half4_t xv_c = nx.xv, sv_c = nx.sv, wv_c = nx.wv; const float xs_c = nx.xs;
+            if (t + 1 < ntask) nx = fetch(t + 1);
             const int blk_l = t / npass, p = t % npass;              // chunk-local block
             const int row = 2 * p + hw;
             const bool act = row < m;
@@ -195,11 +234,20 @@ void exl3_gemv2_kernel(const GemvArgs a)
             }
             else
             {
-                half4_t xv = xv_c * sv_c;
+                half4_t xv = xv_c;
+                if constexpr (in_norm)
+                {
+                    float r = 1.0f;
+                    #pragma unroll
+                    for (int pp = 0; pp < 2 * NG; ++pp) if (pp == p) r = rmf[pp];
+                    xv = half4_t{ f2h((float) xv_c.x * (float) wv_c.x * r), f2h((float) xv_c.y * (float) wv_c.y * r),
+                                  f2h((float) xv_c.z * (float) wv_c.z * r), f2h((float) xv_c.w * (float) wv_c.w * r) };
+                }
+                xv = xv * sv_c;
                 float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
                 had128_f32x4(h0, h1, h2, h3, l32);
-                o01 = half2_t{ (half_t) (h0 * HAD_R_SCALE_128), (half_t) (h1 * HAD_R_SCALE_128) };
-                o23 = half2_t{ (half_t) (h2 * HAD_R_SCALE_128), (half_t) (h3 * HAD_R_SCALE_128) };
+                o01 = half2_t{ f2h(h0 * HAD_R_SCALE_128), f2h(h1 * HAD_R_SCALE_128) };
+                o23 = half2_t{ f2h(h2 * HAD_R_SCALE_128), f2h(h3 * HAD_R_SCALE_128) };
                 bsum = 0.0f;
                 if constexpr (RAW)
                 {
@@ -209,6 +257,14 @@ void exl3_gemv2_kernel(const GemvArgs a)
                     for (int i = 1; i < 32; i <<= 1) bsum += xor_lane(bsum, i);
                 }
             }
+#ifdef G2_DEBUG_FRAG
+            // diagnostics build: workgroup 0 / wave 0 dumps the rotated activations it built (fp16 [blk][row][128]) at 40 MiB
+            if (blockIdx.x == 0 && wave == 0 && act)
+            {
+                half_t* dbg = (half_t*) ((char*) a.workspace + (40ll << 20)) + ((size_t) (k0 / 128 + c0 + t / npass) * m + row) * 128 + 4 * l32;
+                dbg[0] = o01.x; dbg[1] = o01.y; dbg[2] = o23.x; dbg[3] = o23.y;
+            }
+#endif
             if constexpr (RAW)
             {
                 // rowsum[p] with a static index (p is runtime here): predicated adds
@@ -393,7 +449,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 float4_t t = ((const float4_t*) (p0 + w * wstride))[l];
                 v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
             }
-            if (a.epi.mode != GEMV_EPI_NONE) st_agent(slab + row * 128 + 4 * l, v);     // read by another workgroup of this launch
+            if constexpr (MODE == G2_MODE_TAIL) st_agent(slab + row * 128 + 4 * l, v);     // read by another workgroup of this launch
             else ((float4_t*) (slab + row * 128))[l] = v;
         }
 #ifdef G2_TIMING
@@ -407,7 +463,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
             dbg[6] = xcc; dbg[7] = hwid;
         }
 #endif
-        if (a.epi.mode != GEMV_EPI_NONE) gemv_tail(a, mi, cbl, cbg, tid, nwv, &s_tail_flag, (float4_t*) smem);
+        if constexpr (MODE == G2_MODE_TAIL) gemv_tail(a, mi, cbl, cbg, tid, nwv, &s_tail_flag, (float4_t*) smem);
         return;
     }
 
@@ -438,7 +494,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         }
         else
         {
-            half4_t o = { (half_t) h0, (half_t) h1, (half_t) h2, (half_t) h3 };
+            half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
             o = o * sc;
             if (bias) o = o + ((const half4_t*) bias)[l];
             *((half4_t*) ((half_t*) a.mat[mi].C + off)) = o;
@@ -453,13 +509,21 @@ void exl3_gemv2_kernel(const GemvArgs a)
 #error "compile with -DG2_K=<bits per weight>"
 #endif
 
-template <int CB>
-static void launch_cb(int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+template <int CB, int MODE>
+static void launch_mode(int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
-    #define L(V, N) exl3_gemv2_kernel<G2_K, CB, V, N><<<grid, dim3(64 * nwv), lds, st>>>(args)
+    #define L(V, N) exl3_gemv2_kernel<G2_K, CB, V, N, MODE><<<grid, dim3(64 * nwv), lds, st>>>(args)
     if (var == 0) { if (ng == 1) L(0, 1); else if (ng == 2) L(0, 2); else L(0, 4); }
     else          { if (ng == 1) L(1, 1); else if (ng == 2) L(1, 2); else L(1, 4); }
     #undef L
+}
+
+template <int CB>
+static void launch_cb(int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+{
+    if (args.epi.mode != GEMV_EPI_NONE) launch_mode<CB, G2_MODE_TAIL>(var, ng, nwv, grid, lds, st, args);
+    else if (args.flags & GEMV_IN_NORM) launch_mode<CB, G2_MODE_NORM>(var, ng, nwv, grid, lds, st, args);
+    else                                launch_mode<CB, G2_MODE_PLAIN>(var, ng, nwv, grid, lds, st, args);
 }
 
 #define G2_CAT_(a, b) a##b

@@ -120,9 +120,9 @@ __device__ __forceinline__ void gemv_tail(const GemvArgs& a, const int mi, const
             float g0, g1, g2, g3, u0, u1, u2, u3;
             out_had(v[0], l, g0, g1, g2, g3);
             out_had(v[1], l, u0, u1, u2, u3);
-            half4_t gh = half4_t{ (half_t) g0, (half_t) g1, (half_t) g2, (half_t) g3 } * ((const half4_t*) (a.mat[0].svh + cbl * 128))[l];
-            half4_t uh = half4_t{ (half_t) u0, (half_t) u1, (half_t) u2, (half_t) u3 } * ((const half4_t*) (a.mat[1].svh + cbl * 128))[l];
-            auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return (half_t) (gf / (1.0f + __expf(-gf)) * (float) u); };
+            half4_t gh = half4_t{ f2h(g0), f2h(g1), f2h(g2), f2h(g3) } * ((const half4_t*) (a.mat[0].svh + cbl * 128))[l];
+            half4_t uh = half4_t{ f2h(u0), f2h(u1), f2h(u2), f2h(u3) } * ((const half4_t*) (a.mat[1].svh + cbl * 128))[l];
+            auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
             half4_t av = { silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
             if (e.a_out && act) ((half4_t*) (e.a_out + (size_t) row * inter + cbl * 128))[l] = av;
             float sum = in_had_store(av, e.t_suh[0] + cbl * 128, e.t_xh[0] + (size_t) row * inter + cbl * 128, l, act);
@@ -147,7 +147,7 @@ __device__ __forceinline__ void gemv_tail(const GemvArgs& a, const int mi, const
             tail_gather<1>(bases, S, hi, m, row0, rows, buf, hw8, nhw, l, rr, v);
             float h0, h1, h2, h3;
             out_had(v[0], l, h0, h1, h2, h3);
-            half4_t y = half4_t{ (half_t) h0, (half_t) h1, (half_t) h2, (half_t) h3 } * ((const half4_t*) svh)[l];
+            half4_t y = half4_t{ f2h(h0), f2h(h1), f2h(h2), f2h(h3) } * ((const half4_t*) svh)[l];
             const int pos = e.positions[row];
             if (kind != 2)
             {
@@ -165,14 +165,14 @@ __device__ __forceinline__ void gemv_tail(const GemvArgs& a, const int mi, const
                     float r1 = upper ? v1 * c4.y + p1 * s4.y : v1 * c4.y - p1 * s4.y;
                     float r2 = upper ? v2 * c4.z + p2 * s4.z : v2 * c4.z - p2 * s4.z;
                     float r3 = upper ? v3 * c4.w + p3 * s4.w : v3 * c4.w - p3 * s4.w;
-                    y = half4_t{ (half_t) r0, (half_t) r1, (half_t) r2, (half_t) r3 };
+                    y = half4_t{ f2h(r0), f2h(r1), f2h(r2), f2h(r3) };
                 }
                 else
                 {
                     // GPTJ pairs (2i, 2i+1), both in this lane: frequencies 2l, 2l+1
                     const float sa = sn[2 * l], sb = sn[2 * l + 1], ca = cs[2 * l], cb = cs[2 * l + 1];
-                    y = half4_t{ (half_t) (v0 * ca - v1 * sa), (half_t) (v1 * ca + v0 * sa),
-                                 (half_t) (v2 * cb - v3 * sb), (half_t) (v3 * cb + v2 * sb) };
+                    y = half4_t{ f2h(v0 * ca - v1 * sa), f2h(v1 * ca + v0 * sa),
+                                 f2h(v2 * cb - v3 * sb), f2h(v3 * cb + v2 * sb) };
                 }
             }
             if (kind == 0 && act) ((half4_t*) (e.q_out + ((size_t) row * e.hq + hi) * 128))[l] = y;
@@ -215,7 +215,7 @@ __device__ __forceinline__ void gemv_tail(const GemvArgs& a, const int mi, const
             half4_t sc = ((const half4_t*) svh)[l];
             h0 *= (float) sc.x; h1 *= (float) sc.y; h2 *= (float) sc.z; h3 *= (float) sc.w;
             if (bias) { half4_t b = ((const half4_t*) bias)[l]; h0 += (float) b.x; h1 += (float) b.y; h2 += (float) b.z; h3 += (float) b.w; }
-            r = half4_t{ (half_t) ((float) r.x + h0), (half_t) ((float) r.y + h1), (half_t) ((float) r.z + h2), (half_t) ((float) r.w + h3) };
+            r = half4_t{ f2h((float) r.x + h0), f2h((float) r.y + h1), f2h((float) r.z + h2), f2h((float) r.w + h3) };
             const float r0 = (float) r.x, r1 = (float) r.y, r2 = (float) r.z, r3 = (float) r.w;
             if (act) st_agent(rp + 4 * l, r);
             float ss = r0 * r0;
@@ -244,8 +244,8 @@ __device__ __forceinline__ void gemv_tail(const GemvArgs& a, const int mi, const
             const float rmf = __frsqrt_rn(s2 / (float) hidden + e.eps);
             half4_t r = ld_agent(e.resid + (size_t) row * hidden + blk * 128 + 4 * l);
             half4_t wv = ((const half4_t*) (e.norm_w + blk * 128))[l];
-            half4_t xn = { (half_t) ((float) r.x * (float) wv.x * rmf), (half_t) ((float) r.y * (float) wv.y * rmf),
-                           (half_t) ((float) r.z * (float) wv.z * rmf), (half_t) ((float) r.w * (float) wv.w * rmf) };
+            half4_t xn = { f2h((float) r.x * (float) wv.x * rmf), f2h((float) r.y * (float) wv.y * rmf),
+                           f2h((float) r.z * (float) wv.z * rmf), f2h((float) r.w * (float) wv.w * rmf) };
             if (e.xn_out && act) ((half4_t*) (e.xn_out + (size_t) row * hidden + blk * 128))[l] = xn;
             #pragma unroll
             for (int i = 0; i < 3; ++i)

@@ -5,6 +5,7 @@
 #define GEMV_THREADS 256
 #define GEMV_IN_ROTATED   1   // the input Hadamard was applied by the producer (glue kernel): mat[i].xh / xsum
 #define GEMV_OUT_DEFERRED 2   // write raw rotated-basis partial slabs [colblock][S][m][128] fp32; a glue kernel finishes
+#define GEMV_IN_NORM      4   // A is the residual stream: the kernel applies RMSNorm (norm_w, per-block sums of squares ss_part, eps) before the input Hadamard
 #define GEMV_MAX_MATS 4
 
 struct GemvMat
@@ -63,6 +64,9 @@ struct GemvArgs
     int flags;             // GEMV_IN_ROTATED | GEMV_OUT_DEFERRED
     int chunk_blocks;      // gen 2: Hadamard blocks of activation fragments a wave keeps in LDS at a time
     int64_t c_row_offset;  // first output row of this pass
+    const half_t* norm_w;  // GEMV_IN_NORM: RMSNorm weight [k]
+    const float* ss_part;  // GEMV_IN_NORM: [m][k/128] sums of squares of the residual blocks (exl3_glue_resid)
+    float eps;
     GemvEpi epi;
 };
 

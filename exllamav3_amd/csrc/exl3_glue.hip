@@ -72,7 +72,7 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
                 if (bias) { half4_t b = ((const half4_t*) (bias + blk * 128))[l]; h0 += (float) b.x; h1 += (float) b.y; h2 += (float) b.z; h3 += (float) b.w; }
             }
             // r += y, rounded to the residual dtype (norm.cu:193-218)
-            r = half4_t{ (half_t) (r0 + h0), (half_t) (r1 + h1), (half_t) (r2 + h2), (half_t) (r3 + h3) };
+            r = half4_t{ f2h(r0 + h0), f2h(r1 + h1), f2h(r2 + h2), f2h(r3 + h3) };
             r0 = (float) r.x; r1 = (float) r.y; r2 = (float) r.z; r3 = (float) r.w;
             if (act) ((half4_t*) (resid + (size_t) row * hidden + blk * 128))[l] = r;
         }
@@ -104,8 +104,8 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
         const float rmf = __frsqrt_rn(s2 / (float) hidden + eps);
         half4_t r = rr[it];
         half4_t wv = it == 0 ? w_first : ((const half4_t*) (w + blk * 128))[l];
-        half4_t xn = { (half_t) ((float) r.x * (float) wv.x * rmf), (half_t) ((float) r.y * (float) wv.y * rmf),
-                       (half_t) ((float) r.z * (float) wv.z * rmf), (half_t) ((float) r.w * (float) wv.w * rmf) };
+        half4_t xn = { f2h((float) r.x * (float) wv.x * rmf), f2h((float) r.y * (float) wv.y * rmf),
+                       f2h((float) r.z * (float) wv.z * rmf), f2h((float) r.w * (float) wv.w * rmf) };
         if (xn_out && act) ((half4_t*) (xn_out + (size_t) row * hidden + blk * 128))[l] = xn;
         #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -118,6 +118,52 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// G1a: the distributed half of G1: per (row, 128-block) half-wave: [reduce + out-had + svh (+bias)] -> residual += y (fp16) -> sum of
+//      squares of the block -> ss_part[row][block].  The consumer GEMVs (GEMV_IN_NORM) finish the RMSNorm while they build their
+//      activation fragments, so the norm needs neither a single-workgroup pass over all slabs nor its own launch.
+//      Same arithmetic as glue_norm_kernel phase 1 (bit-identical residual and partial sums).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void glue_resid_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, const half_t* __restrict__ svh, const half_t* __restrict__ bias,
+                       half_t* __restrict__ resid, float* __restrict__ ss_part, int m, int hidden)
+{
+    const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
+    const int nblk = hidden >> 7;
+    const int tasks = m * nblk;
+    const int t = blockIdx.x * 8 + hw;
+    const bool act = t < tasks;
+    const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+    half4_t r = ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
+    float r0 = (float) r.x, r1 = (float) r.y, r2 = (float) r.z, r3 = (float) r.w;
+    if (has_y)
+    {
+        float h0, h1, h2, h3;
+        if (y_dense)
+        {
+            float4_t yv = ((const float4_t*) (y_dense + (size_t) row * hidden + blk * 128))[l];
+            h0 = yv.x; h1 = yv.y; h2 = yv.z; h3 = yv.w;
+        }
+        else
+        {
+            const half4_t sc = ((const half4_t*) (svh + blk * 128))[l];
+            half4_t b = { 0, 0, 0, 0 };
+            if (bias) b = ((const half4_t*) (bias + blk * 128))[l];
+            out_had(slab_sum(y, blk, row, m, l), l, h0, h1, h2, h3);
+            h0 *= (float) sc.x; h1 *= (float) sc.y; h2 *= (float) sc.z; h3 *= (float) sc.w;
+            if (bias) { h0 += (float) b.x; h1 += (float) b.y; h2 += (float) b.z; h3 += (float) b.w; }
+        }
+        r = half4_t{ f2h(r0 + h0), f2h(r1 + h1), f2h(r2 + h2), f2h(r3 + h3) };
+        r0 = (float) r.x; r1 = (float) r.y; r2 = (float) r.z; r3 = (float) r.w;
+        if (act) ((half4_t*) (resid + (size_t) row * hidden + blk * 128))[l] = r;
+    }
+    float ss = r0 * r0;
+    ss = __builtin_fmaf(r1, r1, ss); ss = __builtin_fmaf(r2, r2, ss); ss = __builtin_fmaf(r3, r3, ss);
+    #pragma unroll
+    for (int i = 1; i < 32; i <<= 1) ss += xor_lane(ss, i);
+    if (act && l == 0) ss_part[(size_t) row * nblk + blk] = ss;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -166,7 +212,7 @@ void glue_qkv_kernel(QkvArgs a)
     float h0, h1, h2, h3;
     out_had(ysum, l, h0, h1, h2, h3);
     half4_t sc = ((const half4_t*) svh)[l];
-    half4_t y = half4_t{ (half_t) h0, (half_t) h1, (half_t) h2, (half_t) h3 } * sc;       // fp16 output semantics of exl3_gemm
+    half4_t y = half4_t{ f2h(h0), f2h(h1), f2h(h2), f2h(h3) } * sc;       // fp16 output semantics of exl3_gemm
     if (kind != 2)
     {
         // RoPE on the fp16 head vector; lane l holds dims 4l..4l+3
@@ -183,14 +229,14 @@ void glue_qkv_kernel(QkvArgs a)
             float r1 = upper ? v1 * cs[1] + p1 * sn[1] : v1 * cs[1] - p1 * sn[1];
             float r2 = upper ? v2 * cs[2] + p2 * sn[2] : v2 * cs[2] - p2 * sn[2];
             float r3 = upper ? v3 * cs[3] + p3 * sn[3] : v3 * cs[3] - p3 * sn[3];
-            y = half4_t{ (half_t) r0, (half_t) r1, (half_t) r2, (half_t) r3 };
+            y = half4_t{ f2h(r0), f2h(r1), f2h(r2), f2h(r3) };
         }
         else
         {
             // GPTJ: pairs (2i, 2i+1) both in this lane: frequencies 2l, 2l+1
             const float* sn = sn_s + row * 64 + 2 * l; const float* cs = cs_s + row * 64 + 2 * l;
-            y = half4_t{ (half_t) (v0 * cs[0] - v1 * sn[0]), (half_t) (v1 * cs[0] + v0 * sn[0]),
-                         (half_t) (v2 * cs[1] - v3 * sn[1]), (half_t) (v3 * cs[1] + v2 * sn[1]) };
+            y = half4_t{ f2h(v0 * cs[0] - v1 * sn[0]), f2h(v1 * cs[0] + v0 * sn[0]),
+                         f2h(v2 * cs[1] - v3 * sn[1]), f2h(v3 * cs[1] + v2 * sn[1]) };
         }
     }
     if (kind == 0 && act) ((half4_t*) (a.q_out + ((size_t) row * a.hq + hi) * 128))[l] = y;
@@ -233,9 +279,9 @@ void glue_act_kernel(SlabRef sg, SlabRef su, const half_t* __restrict__ svh_g, c
     slab_sum2(sg, su, blk, row, m, l, vg, vu);
     out_had(vg, l, g0, g1, g2, g3);
     out_had(vu, l, u0, u1, u2, u3);
-    half4_t gh = half4_t{ (half_t) g0, (half_t) g1, (half_t) g2, (half_t) g3 } * svg;
-    half4_t uh = half4_t{ (half_t) u0, (half_t) u1, (half_t) u2, (half_t) u3 } * svu;
-    auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return (half_t) (gf / (1.0f + __expf(-gf)) * (float) u); };
+    half4_t gh = half4_t{ f2h(g0), f2h(g1), f2h(g2), f2h(g3) } * svg;
+    half4_t uh = half4_t{ f2h(u0), f2h(u1), f2h(u2), f2h(u3) } * svu;
+    auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
     half4_t av = { silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
     if (a_out && act) ((half4_t*) (a_out + (size_t) row * inter + blk * 128))[l] = av;
     float sum = in_had_store_v(av, sud, xh_d + (size_t) row * inter + blk * 128, l, act);
@@ -349,4 +395,17 @@ extern "C" int exl3_rope_table(const float* inv_freq, const int32_t* positions, 
     EXL3_CHECK_ARG(inv_freq && positions && sin_out && cos_out && m >= 1, "rope_table: bad arguments");
     rope_table_kernel<<<(m * 64 + 255) / 256, 256, 0, (hipStream_t) stream>>>(inv_freq, positions, attn_factor, m, sin_out, cos_out);
     return exl3_check_launch("rope_table");
+}
+
+extern "C" int exl3_glue_resid(const float* y_slabs, int y_S, const float* y_dense, const void* svh, const void* bias, void* resid,
+                               float* ss_part, int m, int hidden, void* stream)
+{
+    EXL3_CHECK_ARG(resid && ss_part, "glue_resid: null pointer");
+    EXL3_CHECK_ARG(m >= 1 && m <= 16 && hidden % 128 == 0, "glue_resid: bad dimensions");
+    EXL3_CHECK_ARG(!y_slabs || (svh && y_S >= 1), "glue_resid: pending output needs svh");
+    SlabRef y = { y_slabs, y_S };
+    const int tasks = m * (hidden / 128);
+    glue_resid_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>(y, (y_slabs || y_dense) ? 1 : 0, y_dense, (const half_t*) svh, (const half_t*) bias,
+                                                                        (half_t*) resid, ss_part, m, hidden);
+    return exl3_check_launch("glue_resid");
 }

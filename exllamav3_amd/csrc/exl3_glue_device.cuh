@@ -62,7 +62,7 @@ __device__ __forceinline__ float in_had_store_v(half4_t x, half4_t sv, half_t* _
     half4_t t = x * sv;
     float h0 = (float) t.x, h1 = (float) t.y, h2 = (float) t.z, h3 = (float) t.w;
     had128_f32x4(h0, h1, h2, h3, l);
-    half4_t o = { (half_t) (h0 * HAD_R_SCALE_128), (half_t) (h1 * HAD_R_SCALE_128), (half_t) (h2 * HAD_R_SCALE_128), (half_t) (h3 * HAD_R_SCALE_128) };
+    half4_t o = { f2h(h0 * HAD_R_SCALE_128), f2h(h1 * HAD_R_SCALE_128), f2h(h2 * HAD_R_SCALE_128), f2h(h3 * HAD_R_SCALE_128) };
     float sum = ((float) o.x + (float) o.y) + ((float) o.z + (float) o.w);
     #pragma unroll
     for (int i = 1; i < 32; i <<= 1) sum += xor_lane(sum, i);
@@ -122,7 +122,7 @@ __device__ __forceinline__ void kv_quant_regs_rt(const int bits, float v0, float
     if (bits & 4) { rem -= 4; kvg_pack_plane<4>(out, wb, sl, (q0 >> rem) & 15, (q1 >> rem) & 15, (q2 >> rem) & 15, (q3 >> rem) & 15, active); wb += 4; }
     if (bits & 2) { rem -= 2; kvg_pack_plane<2>(out, wb, sl, (q0 >> rem) & 3, (q1 >> rem) & 3, (q2 >> rem) & 3, (q3 >> rem) & 3, active); wb += 2; }
     if (bits & 1) { kvg_pack_plane<1>(out, wb, sl, q0 & 1, q1 & 1, q2 & 1, q3 & 1, active); }
-    if (active && sl == 0) *out_scale = (half_t) s;
+    if (active && sl == 0) *out_scale = f2h(s);
 }
 
 template <int BITS>

@@ -165,7 +165,7 @@ void had_r_128_kernel(const void* __restrict__ in, void* __restrict__ out, const
     }
     else
     {
-        half4_t o = { (half_t) h0, (half_t) h1, (half_t) h2, (half_t) h3 };
+        half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
         if constexpr (SCALE_MODE == 2) o = o * sc;
         ((half4_t*) ((half_t*) out + vec * 128))[l] = o;
     }

@@ -58,7 +58,7 @@ void rope_kernel(const half_t* __restrict__ q, half_t* __restrict__ out_q, const
         #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += xor_lane(ss, o);
         const float rmf = __frsqrt_rn(ss / (float) head_dim + norm_eps);
-        const half_t bias_h = (half_t) norm_constant_bias;
+        const half_t bias_h = f2h(norm_constant_bias);
         #pragma unroll
         for (int i = 0; i < ROPE_MAX_PAIRS_PER_LANE; ++i)
         {
@@ -67,8 +67,8 @@ void rope_kernel(const half_t* __restrict__ q, half_t* __restrict__ out_q, const
             {
                 int i1 = MODE == 2 ? t : 2 * t, i2 = MODE == 2 ? t + half_dim : 2 * t + 1;
                 half_t w1 = nw[i1] + bias_h, w2 = nw[i2] + bias_h;
-                v1[i] = (float) (w1 * (half_t) (v1[i] * rmf));
-                v2[i] = (float) (w2 * (half_t) (v2[i] * rmf));
+                v1[i] = (float) (w1 * f2h(v1[i] * rmf));
+                v2[i] = (float) (w2 * f2h(v2[i] * rmf));
             }
         }
     }
@@ -82,8 +82,8 @@ void rope_kernel(const half_t* __restrict__ q, half_t* __restrict__ out_q, const
             sincosf(inv_freq[t] * pf, &sn, &cs);
             sn *= attn_factor; cs *= attn_factor;
             int i1 = MODE == 2 ? t : 2 * t, i2 = MODE == 2 ? t + half_dim : 2 * t + 1;
-            dst[i1] = (half_t) (v1[i] * cs - v2[i] * sn);
-            dst[i2] = (half_t) (v2[i] * cs + v1[i] * sn);
+            dst[i1] = f2h(v1[i] * cs - v2[i] * sn);
+            dst[i2] = f2h(v2[i] * cs + v1[i] * sn);
         }
     }
 }
@@ -174,7 +174,7 @@ __device__ __forceinline__ void kv_quant_group(const half_t* __restrict__ in, ui
     if constexpr (BITS & 4) { rem -= 4; kv_pack_plane<4>(out, wb, sl, (q0 >> rem) & 15, (q1 >> rem) & 15, (q2 >> rem) & 15, (q3 >> rem) & 15, active); wb += 4; }
     if constexpr (BITS & 2) { rem -= 2; kv_pack_plane<2>(out, wb, sl, (q0 >> rem) & 3, (q1 >> rem) & 3, (q2 >> rem) & 3, (q3 >> rem) & 3, active); wb += 2; }
     if constexpr (BITS & 1) { kv_pack_plane<1>(out, wb, sl, q0 & 1, q1 & 1, q2 & 1, q3 & 1, active); }
-    if (active && sl == 0) *out_scale = (half_t) s;
+    if (active && sl == 0) *out_scale = f2h(s);
 }
 
 template <int BITS>
@@ -206,7 +206,7 @@ __device__ __forceinline__ void kv_dequant_group(const uint32_t* __restrict__ in
     float v0 = ((float) (int) q0 - mh) * sm, v1 = ((float) (int) q1 - mh) * sm;
     float v2 = ((float) (int) q2 - mh) * sm, v3 = ((float) (int) q3 - mh) * sm;
     kv_had32(v0, v1, v2, v3, lane);
-    if (active) ((half4_t*) out)[sl] = half4_t{ (half_t) v0, (half_t) v1, (half_t) v2, (half_t) v3 };
+    if (active) ((half4_t*) out)[sl] = half4_t{ f2h(v0), f2h(v1), f2h(v2), f2h(v3) };
 }
 
 // contiguous: group g of the flat tensor

@@ -403,7 +403,7 @@ def add(x, y):
 # fused decode pipeline (deferred-epilogue GEMVs + glue kernels); see include/exl3_hip.h
 # --------------------------------------------------------------------------------------------------
 
-GEMV_IN_ROTATED, GEMV_OUT_DEFERRED = 1, 2
+GEMV_IN_ROTATED, GEMV_OUT_DEFERRED, GEMV_IN_NORM = 1, 2, 4
 
 
 def _parr(ptrs):
@@ -489,3 +489,23 @@ def exl3_gemv_qkv(A, xhs, xsums, Bs, suhs, svhs, m: int, mcg: bool, mul1: bool, 
                                     _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table),
                                     block_table.shape[1] if block_table is not None else 0, page_size, k_bits, v_bits, heads_q, heads_kv,
                                     head_dim, rope_mode, _stream(q_out)))
+
+
+def exl3_gemv_ex_norm(resid, norm_w, ss_part, eps: float, Bs, Cs, suhs, svhs, m: int, mcg: bool, mul1: bool, flags: int = 0,
+                      force_split: int = 0, c_fp32: bool = False):
+    """exl3_gemv_ex on rms_norm(resid) * norm_w, the norm applied inside the GEMV (ss_part from glue_resid).  Returns (slabs, S)."""
+    _dev(resid)
+    cnt = len(Bs)
+    k, K = _kK(Bs[0])
+    ns = (ctypes.c_int * cnt)(*[B.shape[1] * 16 for B in Bs])
+    slabs = (_vp * cnt)()
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_gemv_ex_norm(_p(resid), _p(norm_w), _p(ss_part), float(eps), _parr(Bs), _parr(Cs) if Cs else None, _parr(suhs),
+                                        _parr(svhs) if svhs else None, None, ns, cnt, m, k, K, _cb(mcg, mul1), int(c_fp32), flags, force_split,
+                                        slabs, ctypes.byref(S), _stream(resid)))
+    return [int(s) if s else 0 for s in slabs], S.value
+
+
+def glue_resid(y_slab, y_S: int, svh, bias, resid, ss_part, m: int, y_dense=None):
+    _dev(resid)
+    _check(_lib.lib().exl3_glue_resid(y_slab, y_S, _p(y_dense), _p(svh), _p(bias), _p(resid), _p(ss_part), m, resid.shape[-1], _stream(resid)))

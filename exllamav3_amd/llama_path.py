@@ -148,6 +148,7 @@ class SyntheticEXL3Llama:
         self.xh3 = [torch.empty((bsz, s.hidden), dtype=f16, device=dev) for _ in range(3)]
         self.xs3 = [torch.empty((bsz, nb_h), dtype=f32, device=dev) for _ in range(3)]
         self.xh_d = torch.empty((bsz, self.inter_local), dtype=f16, device=dev)
+        self.ss = torch.empty((bsz, nb_h), dtype=f32, device=dev)
         self.rope_sin = torch.empty((bsz, 64), dtype=f32, device=dev)
         self.rope_cos = torch.empty((bsz, 64), dtype=f32, device=dev)
         self.xs_d = torch.empty((bsz, nb_i), dtype=f32, device=dev)
@@ -195,6 +196,52 @@ class SyntheticEXL3Llama:
     split = {"qkv": 0, "o": 0, "gu": 0, "down": 0}
 
     def decode_step_fused(self):
+        """Fused decode step, 8 launches per layer: deferred-epilogue GEMVs + glue kernels.  The RMSNorm between two linears is
+        split: glue_resid (distributed: split-k reduce + out-Hadamard + residual add + per-block sums of squares) and the consumer
+        GEMV itself (GEMV_IN_NORM: normalise + input Hadamard while building its activation fragments)."""
+        sp = self.split
+        bsz = self._state_bsz
+        hd = self.shape.head_dim
+        be = self.backend
+        x = self.x
+        x.copy_(self.x0)
+        ROT, DEF = ext.GEMV_IN_ROTATED, ext.GEMV_OUT_DEFERRED
+        q2 = self.q.view(bsz, -1)
+        ss = self.ss
+        ext.glue_resid(None, 0, None, None, x, ss, bsz)
+        for li, L in enumerate(self.layers):
+            lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
+            slabs, S = ext.exl3_gemv_ex_norm(x, L["norm1"], ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh],
+                                             None, bsz, lq.mcg, lq.mul1, DEF, sp["qkv"])
+            kc, ks = self.kcache[li]
+            vc, vs = self.vcache[li]
+            ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                         self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd)
+            # [attention core out of scope: attention output := q]; o_proj takes the raw attention output (fused input Hadamard)
+            if self.tp == 1:
+                so, So = ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"])
+                ext.glue_resid(so[0], So, lo.svh, None, x, ss, bsz)
+            else:
+                lo.bc.run(q2, self.o)
+                be.all_reduce(self.o)
+                ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=self.o)
+            sgu, Sgu = ext.exl3_gemv_ex_norm(x, L["norm2"], ss, self.eps, [lg.trellis, lu.trellis], None, [lg.suh, lu.suh], None,
+                                             bsz, lg.mcg, lg.mul1, DEF, sp["gu"])
+            ext.glue_act(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz)
+            if self.tp == 1:
+                sd, Sd = ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF, sp["down"])
+                ext.glue_resid(sd[0], Sd, ld.svh, None, x, ss, bsz)
+            else:
+                ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.d], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT, c_fp32=True)
+                be.all_reduce(self.d)
+                ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=self.d)
+        ext.exl3_gemv_ex_norm(x, self.final_norm, ss, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
+                              bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
+        return self.logits
+
+    def decode_step_fused_v1(self):
+        """First-generation glue pipeline: RMSNorm + input Hadamards in a single-workgroup glue_norm launch (kept as the
+        comparison baseline for decode_step_fused; same bits)."""
         sp = self.split
         bsz = self._state_bsz
         hd = self.shape.head_dim
@@ -311,16 +358,18 @@ class SyntheticEXL3Llama:
                     None, self.xh_d, self.xs_d, ld.trellis, None, ld.svh, None, bsz, ld.mcg, ld.mul1, self.x, L["norm1"], self.eps,
                     [lq.suh, lk.suh, lv.suh], self.xh3, self.xs3))
             elif pipeline == "glue" and self.tp == 1:
-                calls.append(lambda lq=lq, lk=lk, lv=lv: ext.exl3_gemv_ex(None, self.xh3, self.xs3, [lq.trellis, lk.trellis, lv.trellis], None, None, None, bsz, lq.mcg, lq.mul1, ROT | DEF))
+                calls.append(lambda lq=lq, lk=lk, lv=lv, L=L: ext.exl3_gemv_ex_norm(self.x, L["norm1"], self.ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh], None, bsz, lq.mcg, lq.mul1, DEF))
                 calls.append(lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF))
-                calls.append(lambda lg=lg, lu=lu: ext.exl3_gemv_ex(None, self.xh3[:2], self.xs3[:2], [lg.trellis, lu.trellis], None, None, None, bsz, lg.mcg, lg.mul1, ROT | DEF))
+                calls.append(lambda lg=lg, lu=lu, L=L: ext.exl3_gemv_ex_norm(self.x, L["norm2"], self.ss, self.eps, [lg.trellis, lu.trellis], None, [lg.suh, lu.suh], None, bsz, lg.mcg, lg.mul1, DEF))
                 calls.append(lambda ld=ld: ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF))
             else:
                 calls.append(lambda lq=lq, lk=lk, lv=lv: ext.exl3_mgemm_bcast(self.xn, [lq.trellis, lk.trellis, lv.trellis], [q2, k2, v2], [lq.suh, lk.suh, lv.suh], [lq.svh, lk.svh, lv.svh], lq.mcg, lq.mul1))
                 calls.append(lambda lo=lo: lo.bc.run(q2, self.o))
                 calls.append(lambda lg=lg, lu=lu: ext.exl3_mgemm_bcast(self.xn, [lg.trellis, lu.trellis], [self.g, self.u], [lg.suh, lu.suh], [lg.svh, lu.svh], lg.mcg, lg.mul1))
                 calls.append(lambda ld=ld: ld.bc.run(self.a, self.d))
-        if pipeline != "unfused" and self.tp == 1:
+        if pipeline == "glue" and self.tp == 1:
+            calls.append(lambda: ext.exl3_gemv_ex_norm(self.x, self.final_norm, self.ss, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, 0))
+        elif pipeline == "tail" and self.tp == 1:
             calls.append(lambda: ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, ROT))
         else:
             calls.append(lambda: self.lm_head.bc.run(self.xn, self.logits))

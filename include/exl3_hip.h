@@ -153,6 +153,16 @@ int exl3_gemv_qkv(const void* A, const void* const* xhs, const float* const* xsu
 /* sin_out/cos_out[m][64] = sincosf(inv_freq[f] * positions[row]) * attn_factor (rope.cu:60-120 evaluates the same per launch). */
 int exl3_rope_table(const float* inv_freq, const int32_t* positions, float attn_factor, int m, float* sin_out, float* cos_out, void* stream);
 
+/* exl3_gemv_ex whose input is the fp16 residual stream: x = rms_norm(resid) * norm_w (norm.cu:20-120) is formed inside the GEMV from
+ * the per-block sums of squares ss_part [m][k/128] (exl3_glue_resid), then (x * suh) H as usual.  flags: EXL3_GEMV_OUT_DEFERRED optional. */
+int exl3_gemv_ex_norm(const void* resid, const void* norm_w, const float* ss_part, float eps, const void* const* Bs, void* const* Cs,
+                      const void* const* suhs, const void* const* svhs, const void* const* biases, const int* ns, int count,
+                      int m, int k, int K, int cb, int c_fp32, int flags, int force_split, float** slabs_out, int* S_out, void* stream);
+/* glue 1a: [reduce y_slabs + out-Hadamard + svh (+bias) | y_dense] -> resid += y (fp16, norm.cu:193-218) -> ss_part[row][block] =
+ * sum of squares of each 128-block of the updated residual.  y_slabs == y_dense == NULL: sums of squares only. */
+int exl3_glue_resid(const float* y_slabs, int y_S, const float* y_dense, const void* svh, const void* bias, void* resid,
+                    float* ss_part, int m, int hidden, void* stream);
+
 /* Diagnostics only: copy [byte_offset, byte_offset + nbytes) of the per-device split-k workspace to dst (tools/gemv_timeline.py). */
 int exl3_debug_copy_workspace(void* dst, int64_t byte_offset, int64_t nbytes, void* stream);
 

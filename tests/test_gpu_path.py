@@ -183,7 +183,7 @@ def test_tail_epilogue_pipeline_is_bit_identical_to_glue_pipeline(dev, cb, bsz):
     shape = LlamaShape("tiny", 256, 512, 3, 4, 2, 128, 384)
     model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
     model.alloc_state(bsz, pos=1234)
-    lg = model.decode_step_fused().clone()
+    lg = model.decode_step_fused_v1().clone()
     xg, qg = model.x.clone(), model.q.clone()
     kvg = [(c.clone(), s.clone()) for c, s in model.kcache + model.vcache]
     for c, s in model.kcache + model.vcache:
@@ -259,3 +259,28 @@ def test_tail_epilogue_entry_points_raw_input_gptj_and_bits(dev, K):
     assert torch.equal(r0, r1) and torch.equal(xn0, xn1)
     for a, b in zip(t0 + s0, t1 + s1):
         assert torch.equal(a, b)
+
+
+
+@pytest.mark.parametrize("cb", [0, 1, 2])
+@pytest.mark.parametrize("bsz", [1, 3, 16])
+def test_in_gemv_rmsnorm_pipeline_is_bit_identical_to_single_workgroup_norm(dev, cb, bsz):
+    """glue_resid + GEMV_IN_NORM (RMSNorm finished inside the consumer GEMV) against glue_norm (one workgroup normalises the row and
+    rotates it for every consumer): same arithmetic and summation order, so logits, residual, q and KV pages match bit for bit."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    shape = LlamaShape("tiny", 384, 512, 3, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=5, max_ctx=2048)
+    model.alloc_state(bsz, pos=99)
+    l1 = model.decode_step_fused_v1().clone()
+    x1, q1 = model.x.clone(), model.q.clone()
+    kv1 = [(c.clone(), s.clone()) for c, s in model.kcache + model.vcache]
+    for c, s in model.kcache + model.vcache:
+        c.zero_(); s.zero_()
+    model.q.zero_(); model.logits.zero_()
+    l2 = model.decode_step_fused()
+    torch.cuda.synchronize()
+    assert torch.equal(l2, l1) and torch.equal(model.x, x1) and torch.equal(model.q, q1)
+    for (c, s), (c0, s0) in zip(model.kcache + model.vcache, kv1):
+        assert torch.equal(c, c0) and torch.equal(s, s0)

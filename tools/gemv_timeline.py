@@ -14,7 +14,7 @@ model = SyntheticEXL3Llama(SHAPES["llama-3.1-8b"], K=4, cb=2, device=dev, kv_bit
 model.alloc_state(1)
 model.decode_step_fused(); torch.cuda.synchronize()
 calls = model.gemv_calls("glue")
-names = ["qkv", "o", "gate_up", "down", "lm_head"]
+names = ["qkv", "o", "gate_up", "down"]
 grids = {"qkv": 48, "o": 32, "gate_up": 224, "down": 32, "lm_head": 1002}
 buf = torch.zeros(8 * 8192, dtype=torch.int64, device=dev)
 out = {}
@@ -26,17 +26,25 @@ for i, nm in enumerate(names):
         if rep == 1:
             _lib.lib().exl3_debug_copy_workspace(buf.data_ptr(), 48 << 20, buf.numel() * 8, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            prev_newest = int(buf[5::8].max().item())   # everything up to the second repetition is "old"
+            tt = buf.cpu().numpy().reshape(-1, 8)
+            tt = tt[(tt[:, 0] > 0) & (tt[:, 5] >= tt[:, 0]) & (tt[:, 5] - tt[:, 0] < 1000000)]   # uninitialised rows are garbage
+            prev_newest = int(tt[:, 5].max())           # everything up to the second repetition is "old"
     _lib.lib().exl3_debug_copy_workspace(buf.data_ptr(), 48 << 20, buf.numel() * 8, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     t = buf.cpu().numpy().reshape(-1, 8)
-    t = t[t[:, 0] > 0]
+    t = t[(t[:, 0] > 0) & (t[:, 5] >= t[:, 0]) & (t[:, 5] - t[:, 0] < 1000000)]
     # the number of workgroups of this launch: rows whose entry stamp is within 1 ms of the newest
     t = t[t[:, 0] > prev_newest]                        # stamps of this call type only (the workspace keeps older ones)
     prev_newest = int(t[:, 5].max())
-    t0 = t[:, 0].min()
-    rel = (t[:, :6] - t0) * 0.01                        # us
-    row = {"workgroups": int(len(t))}
+    # s_memrealtime is per XCD (offsets of a few us between XCDs were observed), so phases are taken relative to the earliest
+    # workgroup entry on the SAME XCD
+    xcc = t[:, 6].astype(int) & 15
+    rel = np.zeros((len(t), 6))
+    for x in range(16):
+        sel = xcc == x
+        if sel.any(): rel[sel] = (t[sel, :6] - t[sel, 0].min()) * 0.01
+    row_off = [round(float((t[xcc == x, 0].min() - t[:, 0].min()) * 0.01), 2) for x in range(8) if (xcc == x).any()]
+    row = {"workgroups": int(len(t)), "xcd_first_entry_offsets_us": row_off}
     for j, ph in enumerate(["entry", "loads_issued", "first_prep", "stream_done", "partials", "slab_written"]):
         v = rel[:, j]
         row[ph] = [round(float(np.percentile(v, q)), 2) for q in (0, 50, 100)]

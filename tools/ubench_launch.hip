@@ -10,6 +10,13 @@ struct Big { uint64_t v[60]; };
 __global__ void k_empty(float* p) { if (p && threadIdx.x == 4096) p[0] = 1.0f; }
 __global__ void k_big(Big b, float* p) { if (p && b.v[3] == 77 && threadIdx.x == 4096) p[0] = 1.0f; }
 __global__ void k_lds(float* p) { extern __shared__ float sm[]; if (p && threadIdx.x == 4096) p[0] = sm[5]; }
+// scratch: a dynamically indexed private array forces a scratch (private segment) allocation for every wave
+__global__ void k_scratch(float* p, int idx)
+{
+    volatile float priv[8];
+    for (int i = 0; i < 8; ++i) priv[i] = (float) (i + threadIdx.x);
+    if (p && priv[idx & 7] == -5.0f) p[0] = 1.0f;
+}
 // touch: every workgroup reads 16 B per thread from a buffer and (never) writes: adds one global-load latency
 __global__ void k_touch(const float4* src, float* p) { float4 v = src[blockIdx.x * blockDim.x + threadIdx.x]; if (v.x == 123.456f) p[0] = v.y; }
 
@@ -49,8 +56,9 @@ int main()
         float a = time_graph(st, n, [&] { k_empty<<<G, T, 0, st>>>(d); });
         float c = time_graph(st, n, [&] { k_big<<<G, T, 0, st>>>(b, d); });
         float l = time_graph(st, n, [&] { k_lds<<<G, T, 65536, st>>>(d); });
+        float sc = time_graph(st, n, [&] { k_scratch<<<G, T, 0, st>>>(d, gi); });
         float t = (size_t) G * T * 16 <= (1u << 26) ? time_graph(st, n, [&] { k_touch<<<G, T, 0, st>>>((const float4*) d, d); }) : -1.f;
-        printf("  {\"grid\": %d, \"threads\": %d, \"empty_us\": %.2f, \"kernarg480B_us\": %.2f, \"lds64k_us\": %.2f, \"one_load_us\": %.2f},\n", G, T, a, c, l, t);
+        printf("  {\"grid\": %d, \"threads\": %d, \"empty_us\": %.2f, \"kernarg480B_us\": %.2f, \"lds64k_us\": %.2f, \"one_load_us\": %.2f, \"scratch_us\": %.2f},\n", G, T, a, c, l, t, sc);
     }
     printf("  {}]}\n");
     return 0;
