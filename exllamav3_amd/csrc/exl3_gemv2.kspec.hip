@@ -83,8 +83,10 @@ __device__ __forceinline__ void decode_quad(const uint32_t (&Wx)[K + 1], half4_t
 // The modes are separate instantiations because the hot loop needs 62 of the 64 VGPRs that allow two 16-wave workgroups per CU: code
 // of a cold path that is merely present makes the allocator spill (scratch also slows every launch by ~1 us, measured).
 template <int K, int CB, int VAR, int NG, int MODE>
-// m <= 4 (NG == 1): two 16-wave workgroups per CU need <= 64 VGPRs; the hot loop uses 62, the attribute keeps the tail epilogue from raising it
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NG == 1 ? (MODE == G2_MODE_NORM ? 7 : 8) : 4)))
+// m <= 4 (NG == 1): two 16-wave workgroups per CU need <= 64 VGPRs (K <= 4, MUL1: the hot loop uses 59..62).  Variants that do not fit
+// (3INST/MCG, NORM prep, K >= 5 rings) get the next budget instead of spilling: any scratch use costs every launch ~1-2 us
+// (profiles/r01_launch_chain_microbench.json)
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NG != 1 ? 4 : (K >= 5 ? 6 : ((MODE == G2_MODE_NORM || CB != EXL3_CB_MUL1) ? 7 : 8)))))
 void exl3_gemv2_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -209,7 +211,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         for (int t = 0; t < ntask; ++t)
         {
             const half4_t xv_c = nx.xv, sv_c = nx.sv, wv_c = nx.wv; const float xs_c = nx.xs;
-            if (t + 1 < ntask) nx = fetch(t + 1);
+            if constexpr (!in_norm) { if (t + 1 < ntask) nx = fetch(t + 1); }   // NORM mode fetches after the task (register budget)
             const int blk_l = t / npass, p = t % npass;              // chunk-local block
             const int row = 2 * p + hw;
             const bool act = row < m;
@@ -290,6 +292,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
                     *((half2_t*) (base + (q0 + 1) * 4 + sp * 2)) = o23;
                 }
             }
+            if constexpr (in_norm) { if (t + 1 < ntask) nx = fetch(t + 1); }
         }
     };
 
