@@ -91,6 +91,7 @@ def _declare(l):
     sig("exl3_mgemm", vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp),
         ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_hgemm", vp, vp, vp, i32, i32, i32, i64, i32, vp)
+    sig("exl3_hgemm_acc", vp, vp, vp, i32, i32, i32, i64, vp)
     sig("exl3_rms_norm", vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_rope", vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, vp, vp, i32, f32, vp, vp, f32, f32, vp)
     sig("exl3_quant_cache_cont", vp, vp, vp, i64, i32, i32, vp)

@@ -86,7 +86,11 @@ template <int K, int CB, int VAR, int NG, int MODE>
 // m <= 4 (NG == 1): two 16-wave workgroups per CU need <= 64 VGPRs (K <= 4, MUL1: the hot loop uses 59..62).  Variants that do not fit
 // (3INST/MCG, NORM prep, K >= 5 rings) get the next budget instead of spilling: any scratch use costs every launch ~1-2 us
 // (profiles/r01_launch_chain_microbench.json)
+#ifdef G2_ABL_ILP
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
+#else
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NG != 1 ? 4 : (K >= 5 ? 6 : ((MODE == G2_MODE_NORM || CB != EXL3_CB_MUL1) ? 7 : 8)))))
+#endif
 void exl3_gemv2_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -390,7 +394,9 @@ void exl3_gemv2_kernel(const GemvArgs a)
                             acc_d[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bd[0], acc_d[gq], 4, gq, 0);
                         });
                     }
+#ifndef G2_ABL_ILP
                     __builtin_amdgcn_sched_barrier(0);  // bound live ranges: 8 weights in flight at a time (occupancy > ILP here)
+#endif
                 });
             }
         }
@@ -452,8 +458,12 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 float4_t t = ((const float4_t*) (p0 + w * wstride))[l];
                 v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
             }
+#ifdef G2_SLAB_SC1
+            st_agent(slab + row * 128 + 4 * l, v);                                         // experiment: write-through slabs in every mode
+#else
             if constexpr (MODE == G2_MODE_TAIL) st_agent(slab + row * 128 + 4 * l, v);     // read by another workgroup of this launch
             else ((float4_t*) (slab + row * 128))[l] = v;
+#endif
         }
 #ifdef G2_TIMING
         if (tid == 0)

@@ -16,7 +16,7 @@ struct HgemmCtx
     bool ready = false;
     hipblasLtHandle_t handle;
     void* ws = nullptr;
-    std::map<std::tuple<int, int, int, int64_t, int>, hipblasLtMatmulAlgo_t> algos;
+    std::map<std::tuple<int, int, int, int64_t, int, int>, hipblasLtMatmulAlgo_t> algos;
 };
 static HgemmCtx g_hctx[64];
 static std::mutex g_hmutex;
@@ -24,7 +24,7 @@ static std::mutex g_hmutex;
 #define CHECK_LT(expr, what) do { hipblasStatus_t s_ = (expr); if (s_ != HIPBLAS_STATUS_SUCCESS) { \
     exl3_set_error("hgemm: %s failed (hipblasStatus %d)", what, (int) s_); return EXL3_ERR_HIP; } } while (0)
 
-extern "C" int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, void* stream)
+static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, int accumulate, void* stream)
 {
     EXL3_CHECK_ARG(a && b && c, "hgemm: null pointer");
     EXL3_CHECK_ARG(m >= 0 && k > 0 && n > 0 && ldc >= n, "hgemm: bad dimensions");
@@ -57,7 +57,7 @@ extern "C" int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, i
     CHECK_LT(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16F, k, m, k), "layout B");
     CHECK_LT(hipblasLtMatrixLayoutCreate(&lc, c_fp32 ? HIP_R_32F : HIP_R_16F, n, m, ldc), "layout C");
 
-    auto key = std::make_tuple(m, k, n, ldc, c_fp32);
+    auto key = std::make_tuple(m, k, n, ldc, c_fp32, accumulate);
     auto it = cx.algos.find(key);
     if (it == cx.algos.end())
     {
@@ -83,7 +83,10 @@ extern "C" int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, i
         {
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
-            const float al = 1.0f, be = 0.0f;
+            const float al = 1.0f, be = accumulate ? 1.0f : 0.0f;
+            // accumulate mode reads c: time the candidates into a scratch D so the caller's c is not summed into repeatedly
+            void* dtune = c;
+            if (accumulate && hipMalloc(&dtune, (size_t) m * ldc * (c_fp32 ? 4 : 2)) != hipSuccess) dtune = nullptr;
             float best_ms = 1e30f;
             for (int i = 0; i < found; ++i)
             {
@@ -93,8 +96,8 @@ extern "C" int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, i
                 for (int rep = 0; rep < 3 && ok; ++rep)
                 {
                     if (rep == 1) hipEventRecord(e0, (hipStream_t) stream);
-                    ok = hipblasLtMatmul(cx.handle, desc, &al, b, la, a, lb, &be, c, lc, c, lc, &res[i].algo, cx.ws, HGEMM_WS_BYTES,
-                                         (hipStream_t) stream) == HIPBLAS_STATUS_SUCCESS;
+                    ok = dtune && hipblasLtMatmul(cx.handle, desc, &al, b, la, a, lb, &be, c, lc, dtune, lc, &res[i].algo, cx.ws, HGEMM_WS_BYTES,
+                                                  (hipStream_t) stream) == HIPBLAS_STATUS_SUCCESS;
                 }
                 if (!ok) continue;
                 hipEventRecord(e1, (hipStream_t) stream);
@@ -103,14 +106,27 @@ extern "C" int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, i
                 if (ms < best_ms) { best_ms = ms; best = i; }
             }
             hipEventDestroy(e0); hipEventDestroy(e1);
+            if (accumulate && dtune) { hipStreamSynchronize((hipStream_t) stream); hipFree(dtune); }
         }
         it = cx.algos.emplace(key, res[best].algo).first;
     }
-    const float alpha = 1.0f, beta = 0.0f;
+    const float alpha = 1.0f, beta = accumulate ? 1.0f : 0.0f;
     hipblasStatus_t st = hipblasLtMatmul(cx.handle, desc, &alpha, b, la, a, lb, &beta, c, lc, c, lc, &it->second,
                                          cx.ws, HGEMM_WS_BYTES, (hipStream_t) stream);
     hipblasLtMatrixLayoutDestroy(la); hipblasLtMatrixLayoutDestroy(lb); hipblasLtMatrixLayoutDestroy(lc);
     hipblasLtMatmulDescDestroy(desc);
     if (st != HIPBLAS_STATUS_SUCCESS) { exl3_set_error("hgemm: hipblasLtMatmul failed (%d)", (int) st); return EXL3_ERR_HIP; }
     return EXL3_OK;
+}
+
+extern "C" int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, void* stream)
+{
+    return hgemm_impl(a, b, c, m, k, n, ldc, c_fp32, 0, stream);
+}
+
+// c[m][n] (fp16, in place) = fp16(a @ b + c): the residual add of the reference's o_proj / down_proj boundary (fp32 GEMM output, then
+// `x += y` rounded to fp16: norm.cu:193-218 / add.cu) folded into the GEMM epilogue -- one rounding, the same value.
+extern "C" int exl3_hgemm_acc(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, void* stream)
+{
+    return hgemm_impl(a, b, c, m, k, n, ldc, 0, 1, stream);
 }

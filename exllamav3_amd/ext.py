@@ -253,6 +253,16 @@ def hgemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):
                                  int(c.dtype == torch.float), _stream(a)))
 
 
+def hgemm_acc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):
+    """c (fp16, in place) = fp16(a @ b + c): hgemm + residual add in the GEMM epilogue (one rounding, as fp32 output + `x += y`)."""
+    _dev(a)
+    _req(a.dtype == torch.half and b.dtype == torch.half and c.dtype == torch.half, "hgemm_acc: tensors must be float16")
+    _req(a.dim() == 2 and b.dim() == 2 and c.dim() == 2, "hgemm_acc: tensors must be 2-D")
+    _req(a.shape[1] == b.shape[0] and a.shape[0] == c.shape[0] and b.shape[1] == c.shape[1], "hgemm_acc: shape mismatch")
+    _req(a.is_contiguous() and b.is_contiguous() and c.stride(1) == 1, "hgemm_acc: a, b contiguous; c unit column stride")
+    _check(_lib.lib().exl3_hgemm_acc(_p(a), _p(b), _p(c), a.shape[0], a.shape[1], b.shape[1], c.stride(0), _stream(a)))
+
+
 class BC_LinearEXL3:
     """libtorch/linear.h:29-64, linear.cpp:34-71: holder of {trellis, suh, svh, K, bias, mcg, mul1, xh}."""
 
@@ -509,3 +519,57 @@ def exl3_gemv_ex_norm(resid, norm_w, ss_part, eps: float, Bs, Cs, suhs, svhs, m:
 def glue_resid(y_slab, y_S: int, svh, bias, resid, ss_part, m: int, y_dense=None):
     _dev(resid)
     _check(_lib.lib().exl3_glue_resid(y_slab, y_S, _p(y_dense), _p(svh), _p(bias), _p(resid), _p(ss_part), m, resid.shape[-1], _stream(resid)))
+
+
+# --------------------------------------------------------------------------------------------------
+# BC_GatedMLP (libtorch/mlp.h:20-118, mlp.cpp:14-130): d = down(act(gate(x)) * up(x)) for 1..MAX_BSZN tokens
+# --------------------------------------------------------------------------------------------------
+
+MAX_BSZN = 8        # libtorch/mlp.h:11 (this build accepts up to 16 rows, the GEMV pass size)
+
+
+class BC_GatedMLP:
+    """Mirror of the reference's decode-time gated-MLP runner.  Constructor arguments follow libtorch/mlp.h:53-72.  The reference
+    runs exl3_mgemm -> silu_mul -> exl3_gemm (+ bias adds) as separate graph nodes; here the SiLU path without biases is three
+    launches with no intermediate round trip of g/u: gate/up GEMV with deferred epilogue -> glue_act (split-k reduce, output
+    Hadamards, silu(g)*u, input Hadamard of down) -> down GEMV on the pre-rotated input.  `a` still receives silu(g)*u (the
+    reference's observable intermediate).  GELU / relu2 / act_limit are outside this build."""
+
+    def __init__(self, guh, gu, a, down_xh, gu_ptrs_trellis, gu_ptrs_suh, gu_ptrs_svh, gu_K, gu_mcg, gu_mul1,
+                 act_silu, act_gelu, act_relu2, gate, up, down, act_limit):
+        _req(gu_ptrs_trellis is not None or (gate is not None and up is not None),
+             "BC_GatedMLP: need fused mgemm tensors or gate/up handles")
+        _req(gate is not None and up is not None and down is not None, "BC_GatedMLP: this build needs the gate/up/down handles")
+        _req(bool(act_silu) and not act_gelu and not act_relu2, "BC_GatedMLP: only the SiLU activation is provided by this build")
+        _req(float(act_limit) == 0.0, "BC_GatedMLP: act_limit is outside this build")
+        self.guh, self.gu, self.a, self.down_xh = guh, gu, a, down_xh
+        self.gate, self.up, self.down = gate, up, down
+        self._xs = None
+
+    def run_bszN(self, x: torch.Tensor, d: torch.Tensor):
+        _dev(x)
+        hidden = x.shape[-1]
+        m = x.numel() // hidden
+        _req(1 <= m <= 16, "run_bszN: bsz out of supported range")
+        g, u, dn = self.gate, self.up, self.down
+        inter = g.trellis.shape[1] * 16
+        x2 = x.view(m, hidden)
+        a_n = self.a.view(-1, inter)[:m]
+        xh_n = self.down_xh.view(-1, inter)[:m]
+        _req(a_n.shape[0] == m and xh_n.shape[0] == m, "run_bszN: scratch buffers too small for this bsz")
+        if g.bias is not None or u.bias is not None or g.K != u.K or g.mcg != u.mcg or g.mul1 != u.mul1:
+            # op-by-op route (reference's non-mgemm branch, mlp.cpp:62-77)
+            gu_n = self.gu.view(2, -1, inter)[:, :m].contiguous() if self.gu.numel() >= 2 * m * inter else torch.empty((2, m, inter), dtype=torch.half, device=x.device)
+            g.run(x2, gu_n[0]); u.run(x2, gu_n[1])
+            silu_mul(gu_n[0], gu_n[1], a_n)
+            dn.run(a_n, d.view(m, -1))
+            return
+        if self._xs is None or self._xs.shape[0] < m:
+            self._xs = torch.empty((16, inter // 128), dtype=torch.float, device=x.device)
+        xs = self._xs[:m]
+        slabs, S = exl3_gemv_ex(x2, None, None, [g.trellis, u.trellis], None, [g.suh, u.suh], None, m, g.mcg, g.mul1, GEMV_OUT_DEFERRED)
+        glue_act(slabs, S, g.svh, u.svh, dn.suh, xh_n, xs, m, a_out=a_n)
+        d2 = d.view(m, -1)
+        exl3_gemv_ex(None, [xh_n], [xs], [dn.trellis], [d2], None, [dn.svh], m, dn.mcg, dn.mul1, GEMV_IN_ROTATED, c_fp32=(d.dtype == torch.float))
+        if dn.bias is not None:
+            add(d2, dn.bias.view(1, -1).expand(m, -1).contiguous() if m > 1 else dn.bias)

@@ -87,6 +87,21 @@ class LinearEXL3:
             y += self.bias
         return y
 
+    def forward_add_residual(self, x: torch.Tensor, resid: torch.Tensor) -> None:
+        """resid (fp16, in place) += linear(x) for the prefill route: reconstruct_had_slice + hgemm whose epilogue adds the residual
+        (the reference runs the GEMM with fp32 output and adds afterwards, modules/quant/exl3.py:161-218 + rms_norm_res_in / add;
+        the sum is rounded to fp16 once either way).  Saves the fp32 (tokens, hidden) round trip and the add launch."""
+        rows = x.numel() // x.shape[-1]
+        fused = (self.in_features % 128 == 0 and self.out_features % 128 == 0 and rows >= FUSED_RECONSTRUCT_MIN_ROWS
+                 and self.out_features <= MAX_RECONSTRUCT_SLICE_N and self.bias is None and rows > AUTO_RECONSTRUCT_THRESHOLD)
+        if not fused:
+            y = self.forward(x, out_dtype=torch.float)
+            ext.add(resid, y.view(resid.shape))
+            return
+        w = torch.empty((self.in_features, self.out_features), dtype=torch.half, device=self.trellis.device)
+        ext.reconstruct_had_slice(w, self.trellis, self.suh, self.svh, self.K, self.mcg, self.mul1, 0)
+        ext.hgemm_acc(x.view(rows, self.in_features), w, resid.view(rows, self.out_features))
+
     # ---- weights -----------------------------------------------------------------------------------
     def get_inner_weight_tensor(self) -> torch.Tensor:
         w = torch.empty((self.in_features, self.out_features), dtype=torch.half, device=self.trellis.device)

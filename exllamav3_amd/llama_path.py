@@ -407,15 +407,22 @@ class SyntheticEXL3Llama:
             ext.rope(q, q, k, k, self.inv_freq, 0, None, None, 2, 1.0)
             ext.quant_cache_paged(k.view(1, tokens, -1), self.pf_cache[0], self.pf_cache[2], v.view(1, tokens, -1), self.pf_cache[1],
                                   self.pf_cache[3], self.pf_sl, self.pf_bt, self.page, tokens)
-            o = L["o"].forward(q.view(tokens, -1))
-            be.all_reduce(o)
-            ext.rms_norm_res_in(o, L["norm2"], xn, x, self.eps)
+            if self.tp == 1:
+                L["o"].forward_add_residual(q.view(tokens, -1), x)          # residual add in the GEMM epilogue
+                ext.rms_norm(x, L["norm2"], xn, self.eps)
+            else:
+                o = L["o"].forward(q.view(tokens, -1))
+                be.all_reduce(o)
+                ext.rms_norm_res_in(o, L["norm2"], xn, x, self.eps)
             g = L["gate"].forward(xn)
             u = L["up"].forward(xn)
             a = torch.empty_like(g)
             ext.silu_mul(g, u, a)
-            d = L["down"].forward(a)
-            be.all_reduce(d)
-            ext.add(x, d)
+            if self.tp == 1:
+                L["down"].forward_add_residual(a, x)
+            else:
+                d = L["down"].forward(a)
+                be.all_reduce(d)
+                ext.add(x, d)
         ext.rms_norm(x[-1:], self.final_norm, xn[-1:], self.eps)
         return self.lm_head.forward(xn[-1:].contiguous())

@@ -169,6 +169,9 @@ int exl3_debug_copy_workspace(void* dst, int64_t byte_offset, int64_t nbytes, vo
 /* hgemm(a, b, c)      hgemm.cu:19-102:  c[m][n] (row stride ldc elements, fp16 or fp32) = a[m][k] @ b[k][n], fp32 accumulate.
  * m, k, n arbitrary multiples of 16/32/16. */
 int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, void* stream);
+/* c (fp16, in place) = fp16(a @ b + c): hgemm with the residual add of the o_proj / down_proj boundary (norm.cu:193-218, add.cu) in the
+ * GEMM epilogue; same single rounding as fp32 output + add. */
+int exl3_hgemm_acc(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, void* stream);
 
 /* ---- RMSNorm     norm.cuh:7-39, norm.cu:155-299 --------------------------------------------------- */
 /* mode 0: y = norm(x)*w ; 1: y += norm(x)*w (add_residual) ; 2: r += x; y = norm(r)*w (rms_norm_res_in).

@@ -284,3 +284,38 @@ def test_in_gemv_rmsnorm_pipeline_is_bit_identical_to_single_workgroup_norm(dev,
     assert torch.equal(l2, l1) and torch.equal(model.x, x1) and torch.equal(model.q, q1)
     for (c, s), (c0, s0) in zip(model.kcache + model.vcache, kv1):
         assert torch.equal(c, c0) and torch.equal(s, s0)
+
+
+@pytest.mark.parametrize("cb", [0, 2])
+@pytest.mark.parametrize("m", [1, 3, 8])
+def test_bc_gated_mlp_matches_oracle_and_op_by_op(dev, cb, m):
+    """BC_GatedMLP.run_bszN (libtorch/mlp.cpp:14-91 semantics) against the oracle composition and the op-by-op ops."""
+    from exllamav3_amd import ext
+    hidden, inter, K = 512, 768, 4
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mats = [o.synth_linear(hidden, inter, K, seed=61, realistic=True), o.synth_linear(hidden, inter, K, seed=62, realistic=True),
+            o.synth_linear(inter, hidden, K, seed=63, realistic=True)]
+    bcs = [ext.BC_LinearEXL3(T(t[0]), T(t[1]), T(t[2]), K, None, cb == 1, cb == 2, None) for t in mats]
+    x = np.random.default_rng(m).standard_normal((1, m, hidden)).astype(np.float16)
+    a = torch.empty((1, 8, inter), dtype=torch.half, device=dev); dxh = torch.empty_like(a)
+    gu = torch.empty((2, 8, inter), dtype=torch.half, device=dev); guh = torch.empty((2, 8, hidden), dtype=torch.half, device=dev)
+    mlp = ext.BC_GatedMLP(guh, gu, a, dxh, None, None, None, K, cb == 1, cb == 2, True, False, False, bcs[0], bcs[1], bcs[2], 0.0)
+    for out_dtype in (torch.half, torch.float):
+        d = torch.full((1, m, hidden), float("nan"), dtype=out_dtype, device=dev)
+        mlp.run_bszN(T(x), d)
+        x2 = x.reshape(m, hidden)
+        g = o.linear_forward(x2, mats[0][0], mats[0][1], mats[0][2], K, cb).astype(np.float32)
+        u = o.linear_forward(x2, mats[1][0], mats[1][1], mats[1][2], K, cb).astype(np.float32)
+        av = (g / (1 + np.exp(-g)) * u).astype(np.float16)
+        ref = o.linear_forward(av, mats[2][0], mats[2][1], mats[2][2], K, cb, out_fp32=(out_dtype == torch.float)).astype(np.float32)
+        got = d.float().cpu().numpy().reshape(m, hidden)
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
+        assert np.abs(a[0, :m].float().cpu().numpy() - av.astype(np.float32)).max() < 2e-2 * max(1.0, float(np.abs(av).max()))
+        # op-by-op ops of the reference surface
+        g2 = torch.empty((m, inter), dtype=torch.half, device=dev); u2 = torch.empty_like(g2); a2 = torch.empty_like(g2)
+        bcs[0].run(T(x2), g2); bcs[1].run(T(x2), u2); ext.silu_mul(g2, u2, a2)
+        d2 = torch.empty((m, hidden), dtype=out_dtype, device=dev); bcs[2].run(a2, d2)
+        assert float((d2.float() - d.float().view(m, hidden)).abs().max()) < 1e-2 * float(d2.float().abs().max()) + 1e-3
+    with pytest.raises(RuntimeError):
+        ext.BC_GatedMLP(guh, gu, a, dxh, None, None, None, K, False, False, False, True, False, bcs[0], bcs[1], bcs[2], 0.0)

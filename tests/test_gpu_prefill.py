@@ -90,3 +90,32 @@ def test_linear_exl3_lm_head_slicing(dev):
             assert np.allclose(y, ref[:rows], rtol=0.05, atol=0.05)
     finally:
         linear.MAX_RECONSTRUCT_SLICE_N = old
+
+
+@pytest.mark.parametrize("m,k,n", [(1024, 512, 384), (2048, 256, 1024)])
+def test_hgemm_acc_and_forward_add_residual(dev, m, k, n):
+    """hgemm_acc: c = fp16(a @ b + c) equals fp32-output hgemm followed by the fp16 residual add (same single rounding up to the
+    GEMM's fp32 summation order); LinearEXL3.forward_add_residual against forward(out fp32) + add, and the oracle."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.linear import LinearEXL3
+    rng = np.random.default_rng(m + n)
+    a = _t(rng.standard_normal((m, k)).astype(np.float16), dev)
+    b = _t((rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float16), dev)
+    r0 = _t(rng.standard_normal((m, n)).astype(np.float16), dev)
+    y = torch.empty((m, n), dtype=torch.float, device=dev)
+    ext.hgemm(a, b, y)
+    ref = (r0.float() + y).half()
+    r1 = r0.clone()
+    ext.hgemm_acc(a, b, r1)
+    d = (r1.float() - ref.float()).abs()
+    assert float(d.max()) <= 2e-3 * float(ref.float().abs().max())          # at most an fp16 ulp where the fp32 sums differ in order
+    assert float((d > 0).float().mean()) < 0.02
+    tr, suh, svh = o.synth_linear(k, n, 4, realistic=True)
+    lin = LinearEXL3(k, n, _t(tr, dev), _t(suh, dev), _t(svh, dev), mul1=True)
+    x = _t(rng.standard_normal((m, k)).astype(np.float16), dev)
+    ra = r0.clone(); rb = r0.clone()
+    lin.forward_add_residual(x, ra)
+    ext.add(rb, lin.forward(x, out_dtype=torch.float))
+    assert float((ra.float() - rb.float()).abs().max()) <= 4e-3 * float(rb.float().abs().max())
+    ref2 = (r0.float().cpu().numpy() + o.linear_forward(x.cpu().numpy(), tr, suh, svh, 4, 2, out_fp32=True)).astype(np.float16).astype(np.float32)
+    assert np.abs(ra.float().cpu().numpy() - ref2).max() / np.sqrt((ref2 ** 2).mean()) < 2e-2
