@@ -75,10 +75,57 @@ def cpu_baseline(shape, K, cb):
         t_total += time.perf_counter() - t0
         bytes_sample += k * n * K // 8 + 2 * (k + n)
     tok_s = 1.0 / (t_total * shape.decode_bytes_per_token(K) / bytes_sample)
+    ref = cpu_baseline_reference(shape, K) if cb == 2 else None
+    if ref is not None:
+        ref["port_value"] = round(tok_s, 5)
+        ref["port_sample"] = f"numpy oracle, 1 core, q,k,v,o of one layer ({t_total:.1f} s)"
+        return ref
     return {"value": round(tok_s, 5), "unit": "tok/s", "cores": 1, "kind": "port",
             "sample": f"numpy oracle reconstruct+GEMV of one layer's q,k,v,o linears ({bytes_sample / 1e6:.1f} MB of packed "
                       f"weights, {t_total:.1f} s), scaled by bytes to the {shape.decode_bytes_per_token(K) / 1e9:.3f} GB/token model; "
                       f"host has {os.cpu_count()} cores, the port is single-threaded"}
+
+
+def cpu_baseline_reference(shape, K):
+    """The reference's OWN CPU implementation of the EXL3 tile format (exllamav3_ext/cpu/moe_mul1.cpp, mul1 codebook), compiled from
+    /root/reference into oracle/_ref/ by oracle/build_ref.sh (travels to the GPU box as a prebuilt .so).  One gateless expert =
+    up (hidden -> inter) + down (inter -> hidden) of the benchmark model, m = 1, its own thread pool on all host cores, its default
+    (fastest available) ISA tier; ~10 s sample, scaled to tokens/s by packed-weight bytes.  None if the library is not present."""
+    import ctypes
+    import numpy as np
+    from oracle import exl3_oracle as orc
+    path = os.path.join(ROOT, "oracle", "_ref", "libexl3_ref_mul1.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError:
+        return None
+    s = shape.linear_shapes()
+    H, I = s["up"]
+    I = min(I, 8192)                     # the reference CPU path asserts k <= 8192 (cpu/moe_mul1.cpp:1895); throughput is scaled by bytes
+    ut, us, uv = orc.synth_linear(H, I, K, seed=11)
+    dt, ds, dv = orc.synth_linear(I, H, K, seed=12)
+    x = np.random.default_rng(0).standard_normal((1, H)).astype(np.float16)
+    out = np.zeros((1, H), dtype=np.float32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    threads = os.cpu_count() or 1
+    call = lambda: lib.ref_mul1_mlp_relu2(P(ut), P(us), P(uv), P(dt), P(ds), P(dv), H, I, K, K, P(x), 1, P(out), threads)
+    if call() != 0:
+        return None
+    n, t0 = 0, time.perf_counter()
+    while True:
+        call(); n += 1
+        dt_s = time.perf_counter() - t0
+        if dt_s > 10.0 or n >= 100000:
+            break
+    per_call = dt_s / n
+    bytes_call = 2 * (H * I * K // 8) + 2 * 2 * (H + I)
+    tok_s = 1.0 / (per_call * shape.decode_bytes_per_token(K) / bytes_call)
+    return {"value": round(tok_s, 4), "unit": "tok/s", "cores": threads, "kind": "reference",
+            "sample": f"reference cpu/moe_mul1.cpp (oracle/_ref, default ISA tier, {threads} threads): up+down linears of one layer "
+                      f"({bytes_call / 1e6:.1f} MB packed weights) x {n} calls in {dt_s:.1f} s, includes its per-call layer setup; scaled by "
+                      f"bytes to the {shape.decode_bytes_per_token(K) / 1e9:.3f} GB/token model"}
 
 
 def main():
@@ -241,6 +288,24 @@ def main():
                    "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(flops / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                 "note": "linears' 2*k*n flops over the whole chunk time (includes reconstruct_had, norms, rope, kv-quant)"}}
+
+        # MI355X option: reconstructed fp16 W kept resident across chunks (LinearEXL3.cache_reconstructed; 0.5 GB per 8B layer).
+        # Reported separately: the chunk above reconstructs every matrix per forward exactly like the reference.
+        from exllamav3_amd.linear import LinearEXL3
+        LinearEXL3.cache_reconstructed = True
+        model.prefill_chunk(toks); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model.prefill_chunk(toks)
+        torch.cuda.synchronize()
+        dtc = (time.perf_counter() - t0) / reps
+        LinearEXL3.cache_reconstructed = False
+        for L in model.layers:
+            for lin in L.values():
+                if hasattr(lin, "_w_cache"): del lin._w_cache
+        prefill["resident_w_option"] = {"value": round(toks / dtc, 1), "unit": "tok/s", "ms_per_chunk": round(dtc * 1e3, 2),
+                                        "tflops": round(flops / dtc / 1e12, 1),
+                                        "note": "later chunks with the reconstructed fp16 weights left resident in HBM (not the reference's per-forward reconstruct)"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -64,10 +64,10 @@ class LinearEXL3:
             ext.had_r_128(x2, xh, self.suh, None, 1.0)
         dev = self.trellis.device
         if self.out_features <= MAX_RECONSTRUCT_SLICE_N:
-            w = torch.empty((self.in_features, self.out_features), dtype=torch.half, device=dev)
             if use_fused:
-                ext.reconstruct_had_slice(w, self.trellis, self.suh, self.svh, self.K, self.mcg, self.mul1, 0)
+                w = self._reconstructed_w()
             else:
+                w = torch.empty((self.in_features, self.out_features), dtype=torch.half, device=dev)
                 ext.reconstruct(w, self.trellis, self.K, self.mcg, self.mul1)
             ext.hgemm(xh, w, y2)
         else:
@@ -98,9 +98,22 @@ class LinearEXL3:
             y = self.forward(x, out_dtype=torch.float)
             ext.add(resid, y.view(resid.shape))
             return
+        ext.hgemm_acc(x.view(rows, self.in_features), self._reconstructed_w(), resid.view(rows, self.out_features))
+
+    #: MI355X option (not in the reference): keep the reconstructed original-basis fp16 W of every Linear resident after its first
+    #: prefill use -- 16 GB for an 8B model, 141 GB for 70B, both fit the 288 GB of one MI355X next to the packed weights -- so later
+    #: prefill chunks are pure MFMA GEMMs.  Off by default: the reference reconstructs per forward (exl3.py:161-218).
+    cache_reconstructed = False
+
+    def _reconstructed_w(self) -> torch.Tensor:
+        w = getattr(self, "_w_cache", None)
+        if w is not None:
+            return w
         w = torch.empty((self.in_features, self.out_features), dtype=torch.half, device=self.trellis.device)
         ext.reconstruct_had_slice(w, self.trellis, self.suh, self.svh, self.K, self.mcg, self.mul1, 0)
-        ext.hgemm_acc(x.view(rows, self.in_features), w, resid.view(rows, self.out_features))
+        if self.cache_reconstructed:
+            self._w_cache = w
+        return w
 
     # ---- weights -----------------------------------------------------------------------------------
     def get_inner_weight_tensor(self) -> torch.Tensor:
