@@ -373,12 +373,29 @@ void exl3_gemv_reduce_kernel(const GemvArgs a, int total_colblocks)
     const bool act = item < (int64_t) total_colblocks * m;
     const int cbg = act ? (int) (item / m) : 0;
     const int row = act ? (int) (item % m) : 0;
-    int mi = 0;
-    #pragma unroll
-    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.num_mats && cbg >= a.mat[i].cb_first) mi = i;
-    const int cbl = cbg - a.mat[mi].cb_first;
-    const int n = a.mat[mi].n;
-    const float* slab = a.workspace + a.mat[mi].ws_offset + ((size_t) cbl * a.S) * (size_t) m * 128 + (size_t) row * 128;
+    int mi = 0, cbl, n, ws_off;
+    const half_t* svh_m; const half_t* bias_m = nullptr; void* C_m;
+    float out_scale = HAD_R_SCALE_128;
+    bool skip = false;
+    if (a.tbl.B)
+    {
+        const int slot = cbg / a.tbl.cbs_per_mat;
+        const SlotRef_t sr = resolve_slot(a.tbl, slot);
+        skip = sr.mat_index < 0;
+        cbl = cbg - slot * a.tbl.cbs_per_mat; n = a.tbl.n;
+        ws_off = slot * a.tbl.cbs_per_mat * a.S * a.m * 128;
+        svh_m = skip ? nullptr : (const half_t*) a.tbl.svh[sr.mat_index];
+        C_m = a.c_fp32 ? (void*) ((float*) a.tbl.C + (size_t) slot * a.tbl.c_slot_stride) : (void*) ((half_t*) a.tbl.C + (size_t) slot * a.tbl.c_slot_stride);
+        out_scale = HAD_R_SCALE_128 * sr.weight;
+    }
+    else
+    {
+        #pragma unroll
+        for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.num_mats && cbg >= a.mat[i].cb_first) mi = i;
+        cbl = cbg - a.mat[mi].cb_first; n = a.mat[mi].n; ws_off = a.mat[mi].ws_offset;
+        svh_m = a.mat[mi].svh; bias_m = a.mat[mi].bias; C_m = a.mat[mi].C;
+    }
+    const float* slab = a.workspace + ws_off + ((size_t) cbl * a.S) * (size_t) m * 128 + (size_t) row * 128;
     float4_t v = { 0.f, 0.f, 0.f, 0.f };
     for (int s = 0; s < a.S; ++s)
     {
@@ -387,24 +404,50 @@ void exl3_gemv_reduce_kernel(const GemvArgs a, int total_colblocks)
     }
     float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
     had128_f32x4(h0, h1, h2, h3, l);
-    h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
-    if (!act) return;
-    const half_t* svh = a.mat[mi].svh + cbl * 128;
-    const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
+    h0 *= out_scale; h1 *= out_scale; h2 *= out_scale; h3 *= out_scale;
+    if (!act || skip) return;
+    const half_t* svh = svh_m + cbl * 128;
+    const half_t* bias = bias_m ? bias_m + cbl * 128 : nullptr;
     half4_t sc = ((const half4_t*) svh)[l];
     size_t off = ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
     if (a.c_fp32)
     {
         float4_t o = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
         if (bias) { half4_t bv = ((const half4_t*) bias)[l]; o.x += (float) bv.x; o.y += (float) bv.y; o.z += (float) bv.z; o.w += (float) bv.w; }
-        *((float4_t*) ((float*) a.mat[mi].C + off)) = o;
+        *((float4_t*) ((float*) C_m + off)) = o;
     }
     else
     {
         half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
         o = o * sc;
         if (bias) o = o + ((const half4_t*) bias)[l];
-        *((half4_t*) ((half_t*) a.mat[mi].C + off)) = o;
+        *((half4_t*) ((half_t*) C_m + off)) = o;
+    }
+}
+
+// Final step of the weighted (MoE) mgemm: every group of `stride` consecutive slots is summed into output row-block t, in slot order
+// (fp16: sequential __hadd from zero, fp32: sequential adds -- quant/exl3_gemm_kernel.cuh:241-290).  Filtered-out slots were never written
+// by this launch; like the reference, the caller zero-fills C when it uses an expert range together with weights.
+__global__ void mgemm_slot_reduce_kernel(void* C, int c_fp32, int num_tokens, int stride, int64_t mn)
+{
+    const int64_t col = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= mn) return;
+    for (int t = 0; t < num_tokens; ++t)
+    {
+        if (c_fp32)
+        {
+            const float* p = (const float*) C + (int64_t) t * stride * mn + col;
+            float sum = 0.0f;
+            for (int j = 0; j < stride; ++j) sum += p[(int64_t) j * mn];
+            ((float*) C)[(int64_t) t * mn + col] = sum;
+        }
+        else
+        {
+            const half_t* p = (const half_t*) C + (int64_t) t * stride * mn + col;
+            half_t sum = (half_t) 0.0f;
+            for (int j = 0; j < stride; ++j) sum = sum + p[(int64_t) j * mn];
+            ((half_t*) C)[(int64_t) t * mn + col] = sum;
+        }
     }
 }
 
@@ -495,7 +538,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                      const void* const* biases, const int* ns, int count, int m, int k, int K, int cb, int c_fp32,
                      int force_split, hipStream_t st, int flags = 0, const void* const* xhs = nullptr, const float* const* xsums = nullptr,
                      float** slabs_out = nullptr, int* S_out = nullptr, const GemvEpi* epi = nullptr,
-                     const void* norm_w = nullptr, const float* ss_part = nullptr, float eps = 0.0f)
+                     const void* norm_w = nullptr, const float* ss_part = nullptr, float eps = 0.0f, const GemvTable* tbl = nullptr)
 {
     if (epi) flags |= GEMV_OUT_DEFERRED;
     const bool deferred = (flags & GEMV_OUT_DEFERRED) != 0, rotated = (flags & GEMV_IN_ROTATED) != 0;
@@ -504,14 +547,20 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     EXL3_CHECK_ARG(!rotated || xhs, "exl3_gemv_ex: rotated input requires xh pointers");
     const bool in_norm = (flags & GEMV_IN_NORM) != 0;
     EXL3_CHECK_ARG(!in_norm || (norm_w && ss_part && !rotated && m <= 16), "exl3_gemv_ex: GEMV_IN_NORM needs norm_w, ss_part, raw input and m <= 16");
-    EXL3_CHECK_ARG(count >= 1 && count <= GEMV_MAX_MATS, "exl3_mgemm: between 1 and %d matrices per launch", GEMV_MAX_MATS);
+    EXL3_CHECK_ARG(count >= 1 && (tbl || count <= GEMV_MAX_MATS), "exl3_mgemm: between 1 and %d matrices per launch", GEMV_MAX_MATS);
+    EXL3_CHECK_ARG(!tbl || (m <= 16 && !deferred && !rotated && !epi), "exl3_mgemm (indexed): at most 16 rows per slot");
     EXL3_CHECK_ARG(K >= 1 && K <= 8, "exl3_gemm: K must be in [1, 8]");
     EXL3_CHECK_ARG(cb >= 0 && cb <= 2, "exl3_gemm: bad codebook");
     EXL3_CHECK_ARG(k % 128 == 0 && k > 0, "exl3_gemm: k must be divisible by 128");
     EXL3_CHECK_ARG(m >= 1, "exl3_gemm: m must be >= 1");
     EXL3_CHECK_ARG(A || rotated, "exl3_gemm: null A");
     int total_cb = 0;
-    for (int i = 0; i < count; ++i)
+    if (tbl)
+    {
+        EXL3_CHECK_ARG(ns[0] % 128 == 0 && ns[0] > 0, "exl3_gemm: n must be divisible by 128");
+        total_cb = count * (ns[0] / 128);
+    }
+    for (int i = 0; i < (tbl ? 0 : count); ++i)
     {
         EXL3_CHECK_ARG(ns[i] % 128 == 0 && ns[i] > 0, "exl3_gemm: n must be divisible by 128");
         EXL3_CHECK_ARG(Bs[i] && (deferred || (Cs && Cs[i] && svhs && svhs[i])) && (rotated || (suhs && suhs[i])), "exl3_gemm: null pointer");
@@ -526,7 +575,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         const int mp = (m - m0) < 16 ? (m - m0) : 16;
         GemvArgs args;
         memset((void*) &args, 0, sizeof(args));
-        const int gen = (deferred || rotated || in_norm) ? 2 : gemv_gen();
+        const int gen = (deferred || rotated || in_norm || tbl) ? 2 : gemv_gen();
         args.norm_w = (const half_t*) norm_w; args.ss_part = ss_part; args.eps = eps;
         int fs = force_split;
         if (deferred && fs == 0)
@@ -554,7 +603,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         const int nb = k / 128;
         const int bps = (nb + S - 1) / S;
         int cbf = 0; int64_t wso = 0;
-        for (int i = 0; i < count; ++i)
+        if (tbl) { args.tbl = *tbl; wso = (int64_t) total_cb * S * mp * 128; }
+        for (int i = 0; i < (tbl ? 0 : count); ++i)
         {
             args.mat[i].B = (const uint32_t*) Bs[i];
             args.mat[i].suh = suhs ? (const half_t*) suhs[i] : nullptr;
@@ -585,7 +635,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         args.flags = flags;
         args.A = (const half_t*) A + (size_t) m0 * k;
         args.workspace = ctx->workspace;
-        args.num_mats = count;
+        args.num_mats = tbl ? 1 : count;
         args.m = mp;
         args.k = k;
         args.S = S;
@@ -608,7 +658,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             if (deferred && nwv > 4 && bps <= 16) nwv = 4;
             // variants above 64 VGPRs (3INST/MCG decode, NORM prep, K >= 5 rings) fit 7 or 6 waves per SIMD: three 8-wave workgroups per
             // CU instead of one 16-wave workgroup (tools/bench_lmhead.py: lm_head 3INST 105 -> 87 us, NORM 92 -> 81 us)
-            if (!deferred && ng == 1 && (cb != 2 || in_norm || K >= 5) && nwv > 8) nwv = 8;
+            if (!deferred && ng == 1 && (cb != 2 || in_norm || tbl || K >= 5) && nwv > 8) nwv = 8;
             if (nwv > units) nwv = units;
             if (g_gemv_nwv > 0 && nwv > g_gemv_nwv) nwv = g_gemv_nwv;
             if (nwv < 1) nwv = 1;
@@ -772,4 +822,38 @@ extern "C" int exl3_gemv_qkv(const void* A, const void* const* xhs, const float*
     int ns[3] = { heads_q * 128, heads_kv * 128, heads_kv * 128 };
     return run_mgemm(A, Bs, nullptr, suhs, svhs, nullptr, ns, 3, m, k, K, cb, 0, 0, (hipStream_t) stream, xhs ? GEMV_IN_ROTATED : 0,
                      xhs, xsums, nullptr, nullptr, &e);
+}
+
+// Indexed / weighted multi-matrix launch (MoE): exl3_mgemm with pointer tables (quant/exl3_gemm.cuh:58-78, kernel exl3_gemm_kernel.cuh:88-292).
+//   slot j of bszm: matrix = indices ? indices[j] : j (device int64); with an expert range, in-range entries are compacted to the front and
+//   re-based to min_index, the remaining slots are skipped; A [bszm_in][m][k] (bszm_in == 1: shared), C [bszm][m][n];
+//   weights (fp16 [bszm]): each slot's output is scaled by its weight inside the output Hadamard scale, then every group of
+//   bszm / num_tokens slots is summed into C[t].
+extern "C" int exl3_mgemm_indexed(const void* A, int bszm_in, const void* tbl_B, const void* tbl_suh, const void* tbl_svh,
+                                  const int64_t* indices, const void* weights, int bszm, void* C, int m, int k, int n, int K, int cb, int c_fp32,
+                                  int min_index, int max_index, int num_tokens, void* stream)
+{
+    EXL3_CHECK_ARG(A && tbl_B && tbl_suh && tbl_svh && C, "exl3_mgemm: null pointer");
+    EXL3_CHECK_ARG(bszm >= 1 && (bszm_in == 1 || bszm_in == bszm), "exl3_mgemm: A must have 1 or bszm slots");
+    EXL3_CHECK_ARG(num_tokens >= 1 && bszm % num_tokens == 0, "exl3_mgemm: bszm must be divisible by num_tokens");
+    EXL3_CHECK_ARG(num_tokens == 1 || min_index < 0, "exl3_mgemm: multi-token reduction (num_tokens > 1) is not compatible with expert-range filtering (min_index >= 0); TP-sharded experts must use num_tokens == 1");
+    EXL3_CHECK_ARG(min_index < 0 || indices, "exl3_mgemm: an expert range needs indices");
+    GemvTable t; memset((void*) &t, 0, sizeof(t));
+    t.B = (const uint64_t*) tbl_B; t.suh = (const uint64_t*) tbl_suh; t.svh = (const uint64_t*) tbl_svh;
+    t.indices = indices; t.weights = (const half_t*) weights; t.C = C;
+    t.bszm = bszm; t.min_index = min_index; t.max_index = max_index; t.n = n; t.cbs_per_mat = n / 128;
+    t.a_slot_stride = bszm_in == 1 ? 0 : (int64_t) m * k;
+    t.c_slot_stride = (int64_t) m * n;
+    const void* Bs[1] = { tbl_B }; int ns[1] = { n };
+    const void* su[1] = { tbl_suh }; const void* sv[1] = { tbl_svh }; void* Cs[1] = { C };
+    int rc = run_mgemm(A, Bs, Cs, su, sv, nullptr, ns, bszm, m, k, K, cb, c_fp32, 0, (hipStream_t) stream, 0, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, 0.0f, &t);
+    if (rc < 0) return rc;
+    if (weights)
+    {
+        const int64_t mn = (int64_t) m * n;
+        mgemm_slot_reduce_kernel<<<dim3((unsigned) ((mn + 255) / 256)), dim3(256), 0, (hipStream_t) stream>>>(C, c_fp32, num_tokens, bszm / num_tokens, mn);
+        return exl3_check_launch("exl3_mgemm slot reduce") < 0 ? EXL3_ERR_HIP : rc;
+    }
+    return rc;
 }

@@ -80,6 +80,7 @@ __device__ __forceinline__ void decode_quad(const uint32_t (&Wx)[K + 1], half4_t
 #define G2_MODE_PLAIN 0     // rotated or raw input
 #define G2_MODE_NORM  1     // GEMV_IN_NORM: RMSNorm of the residual stream while building the activation fragments
 #define G2_MODE_TAIL  2     // in-kernel tail epilogue (exl3_gemv2_tail.cuh)
+#define G2_MODE_TABLE 3     // device-side pointer tables + indices + routing weights (MoE exl3_mgemm)
 // The modes are separate instantiations because the hot loop needs 62 of the 64 VGPRs that allow two 16-wave workgroups per CU: code
 // of a cold path that is merely present makes the allocator spill (scratch also slows every launch by ~1 us, measured).
 template <int K, int CB, int VAR, int NG, int MODE>
@@ -89,7 +90,7 @@ template <int K, int CB, int VAR, int NG, int MODE>
 #ifdef G2_ABL_ILP
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 #else
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NG != 1 ? 4 : (K >= 5 ? 6 : ((MODE == G2_MODE_NORM || CB != EXL3_CB_MUL1) ? 7 : 8)))))
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NG != 1 ? 4 : (K >= 5 ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || CB != EXL3_CB_MUL1) ? 7 : 8)))))
 #endif
 void exl3_gemv2_kernel(const GemvArgs a)
 {
@@ -117,12 +118,28 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const int s = blockIdx.x % a.S;
     const int cbg = blockIdx.x / a.S;
     int mi = 0;
-    #pragma unroll
-    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.num_mats && cbg >= a.mat[i].cb_first) mi = i;
-    const uint32_t* __restrict__ Bm = a.mat[mi].B;
-    const half_t* __restrict__ suh = a.mat[mi].suh;
-    const int n = a.mat[mi].n;
-    const int cbl = cbg - a.mat[mi].cb_first;
+    const uint32_t* __restrict__ Bm;
+    const half_t* __restrict__ suh;
+    const half_t* A_in = a.A;
+    int n, cbl, ws_off;
+    if constexpr (MODE == G2_MODE_TABLE)
+    {
+        const int slot = cbg / a.tbl.cbs_per_mat;
+        const SlotRef_t sr = resolve_slot(a.tbl, slot);
+        if (sr.mat_index < 0) return;                                  // filtered-out slot: nothing is written (as the reference)
+        Bm = (const uint32_t*) a.tbl.B[sr.mat_index];
+        suh = (const half_t*) a.tbl.suh[sr.mat_index];
+        n = a.tbl.n; cbl = cbg - slot * a.tbl.cbs_per_mat;
+        A_in = a.A + (size_t) slot * a.tbl.a_slot_stride;
+        ws_off = slot * a.tbl.cbs_per_mat * a.S * a.m * 128;
+    }
+    else
+    {
+        #pragma unroll
+        for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.num_mats && cbg >= a.mat[i].cb_first) mi = i;
+        Bm = a.mat[mi].B; suh = a.mat[mi].suh;
+        n = a.mat[mi].n; cbl = cbg - a.mat[mi].cb_first; ws_off = a.mat[mi].ws_offset;
+    }
     const int tiles_n = n >> 4;
     const int k0s = s * a.kslice;
     const int k1s = min(k0s + a.kslice, a.k);
@@ -150,8 +167,9 @@ void exl3_gemv2_kernel(const GemvArgs a)
     for (int i = 0; i < 2 * NG; ++i) rowsum[i] = 0.0f;
     const int l32 = lane & 31, hw = lane >> 5;
     const bool in_rotated = (a.flags & GEMV_IN_ROTATED) != 0;
-    const half_t* __restrict__ xh_in = a.mat[mi].xh;
-    const float* __restrict__ xsum_in = a.mat[mi].xsum;
+    const half_t* __restrict__ xh_in = MODE == G2_MODE_TABLE ? nullptr : a.mat[mi].xh;
+    const float* __restrict__ xsum_in = MODE == G2_MODE_TABLE ? nullptr : a.mat[mi].xsum;
+    const half_t* __restrict__ x_src = in_rotated ? xh_in : A_in;          // one scalar select (two pointers picked per load became a stack table)
     const int npass = (m + 1) >> 1;                  // passes of 2 rows (one per half-wave)
 
     // GEMV_IN_NORM: A is the fp16 residual stream; x = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)) is formed in prep_chunk, per
@@ -172,14 +190,13 @@ void exl3_gemv2_kernel(const GemvArgs a)
             const int row = 2 * p + hw;
             const bool act = row < m;
             const size_t off = (size_t) (act ? row : 0) * a.k + k0 + 128 * blk;
+            r.xv = ((const half4_t*) (x_src + off))[l32];
             if (in_rotated)
             {
-                r.xv = ((const half4_t*) (xh_in + off))[l32];
                 if constexpr (RAW) r.xs = xsum_in[(size_t) (act ? row : 0) * (a.k >> 7) + (k0 >> 7) + blk];
             }
             else
             {
-                r.xv = ((const half4_t*) (a.A + off))[l32];
                 r.sv = ((const half4_t*) (suh + k0 + 128 * blk))[l32];
                 if constexpr (in_norm) r.wv = ((const half4_t*) (a.norm_w + k0 + 128 * blk))[l32];
             }
@@ -448,7 +465,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const size_t wstride = (size_t) MR * 128;
     if (a.S > 1 || (a.flags & GEMV_OUT_DEFERRED))
     {
-        float* slab = a.workspace + a.mat[mi].ws_offset + ((size_t) cbl * a.S + s) * (size_t) m * 128;
+        float* slab = a.workspace + ws_off + ((size_t) cbl * a.S + s) * (size_t) m * 128;
         for (int row = hw8; row < m; row += nwv * 2)
         {
             const float* p0 = part + row * 128;
@@ -480,8 +497,23 @@ void exl3_gemv2_kernel(const GemvArgs a)
         return;
     }
 
-    const half_t* svh = a.mat[mi].svh + cbl * 128;
-    const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
+    // output side resolved here (not kept live across the streaming loop: 64-VGPR budget)
+    const half_t* svh; const half_t* bias = nullptr; void* C_m;
+    float out_scale = HAD_R_SCALE_128;
+    if constexpr (MODE == G2_MODE_TABLE)
+    {
+        const int slot = cbg / a.tbl.cbs_per_mat;
+        const SlotRef_t sr = resolve_slot(a.tbl, slot);
+        svh = (const half_t*) a.tbl.svh[sr.mat_index] + cbl * 128;
+        C_m = a.c_fp32 ? (void*) ((float*) a.tbl.C + (size_t) slot * a.tbl.c_slot_stride) : (void*) ((half_t*) a.tbl.C + (size_t) slot * a.tbl.c_slot_stride);
+        out_scale = HAD_R_SCALE_128 * sr.weight;                       // reference: scale *= weight, then one multiply (kernel.cuh:216-217)
+    }
+    else
+    {
+        svh = a.mat[mi].svh + cbl * 128;
+        if (a.mat[mi].bias) bias = a.mat[mi].bias + cbl * 128;
+        C_m = a.mat[mi].C;
+    }
     for (int base = 0; base < m; base += nwv * 2)
     {
         int row = base + hw8;
@@ -495,7 +527,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         }
         float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
         had128_f32x4(h0, h1, h2, h3, l);
-        h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
+        h0 *= out_scale; h1 *= out_scale; h2 *= out_scale; h3 *= out_scale;
         if (!act) continue;
         half4_t sc = ((const half4_t*) svh)[l];
         size_t off = ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
@@ -503,14 +535,14 @@ void exl3_gemv2_kernel(const GemvArgs a)
         {
             float4_t o = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
             if (bias) { half4_t bv = ((const half4_t*) bias)[l]; o.x += (float) bv.x; o.y += (float) bv.y; o.z += (float) bv.z; o.w += (float) bv.w; }
-            *((float4_t*) ((float*) a.mat[mi].C + off)) = o;
+            *((float4_t*) ((float*) C_m + off)) = o;
         }
         else
         {
             half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
             o = o * sc;
             if (bias) o = o + ((const half4_t*) bias)[l];
-            *((half4_t*) ((half_t*) a.mat[mi].C + off)) = o;
+            *((half4_t*) ((half_t*) C_m + off)) = o;
         }
     }
 }
@@ -534,7 +566,8 @@ static void launch_mode(int var, int ng, int nwv, dim3 grid, size_t lds, hipStre
 template <int CB>
 static void launch_cb(int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
-    if (args.epi.mode != GEMV_EPI_NONE) launch_mode<CB, G2_MODE_TAIL>(var, ng, nwv, grid, lds, st, args);
+    if (args.tbl.B) launch_mode<CB, G2_MODE_TABLE>(var, ng, nwv, grid, lds, st, args);
+    else if (args.epi.mode != GEMV_EPI_NONE) launch_mode<CB, G2_MODE_TAIL>(var, ng, nwv, grid, lds, st, args);
     else if (args.flags & GEMV_IN_NORM) launch_mode<CB, G2_MODE_NORM>(var, ng, nwv, grid, lds, st, args);
     else                                launch_mode<CB, G2_MODE_PLAIN>(var, ng, nwv, grid, lds, st, args);
 }

@@ -50,6 +50,47 @@ struct GemvEpi
     int hq, hkv, rope_mode;
 };
 
+// Table mode (MoE / indexed exl3_mgemm, quant/exl3_gemm_kernel.cuh:88-292): the matrices are device-side pointer tables and the
+// slot -> matrix mapping (`indices`, optional expert-range filter, optional routing weights) is resolved on the device.
+struct GemvTable
+{
+    const uint64_t* B; const uint64_t* suh; const uint64_t* svh;   // [num matrices] device addresses
+    const int64_t* indices;                                         // [bszm] or null (slot j -> matrix j)
+    const half_t* weights;                                          // [bszm] or null
+    void* C;                                                        // [bszm][m][n]
+    int bszm, min_index, max_index, n, cbs_per_mat;
+    int64_t a_slot_stride;                                          // elements between the inputs of two slots (0: one shared input)
+    int64_t c_slot_stride;                                          // elements between the outputs of two slots
+};
+
+struct SlotRef_t { int mat_index; float weight; };
+
+// slot -> (matrix, routing weight).  With an expert range [min_index, max_index) the in-range entries are compacted to the front in
+// order (reference: single-thread pre-pass + grid sync, exl3_gemm_kernel.cuh:101-127); every workgroup recomputes it from <= bszm entries.
+__device__ __forceinline__ SlotRef_t resolve_slot(const GemvTable& t, int slot)
+{
+    SlotRef_t r; r.mat_index = slot; r.weight = 1.0f;
+    if (!t.indices) { if (t.weights) r.weight = (float) t.weights[slot]; return r; }
+    if (t.min_index < 0)
+    {
+        r.mat_index = (int) t.indices[slot];
+        if (t.weights) r.weight = (float) t.weights[slot];
+        return r;
+    }
+    r.mat_index = -1;
+    int cnt = 0;
+    for (int i = 0; i < t.bszm; ++i)
+    {
+        const int idx = (int) t.indices[i];
+        if (idx >= t.min_index && idx < t.max_index)
+        {
+            if (cnt == slot) { r.mat_index = idx - t.min_index; if (t.weights) r.weight = (float) t.weights[i]; }
+            ++cnt;
+        }
+    }
+    return r;
+}
+
 struct GemvArgs
 {
     GemvMat mat[GEMV_MAX_MATS];
@@ -67,6 +108,7 @@ struct GemvArgs
     const half_t* norm_w;  // GEMV_IN_NORM: RMSNorm weight [k]
     const float* ss_part;  // GEMV_IN_NORM: [m][k/128] sums of squares of the residual blocks (exl3_glue_resid)
     float eps;
+    GemvTable tbl;         // table mode when tbl.B != nullptr
     GemvEpi epi;
 };
 

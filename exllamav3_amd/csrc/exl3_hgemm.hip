@@ -82,7 +82,7 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
         if (tune && found > 1 && !capturing && (double) m * k * n > 1e9)
         {
             hipEvent_t e0, e1;
-            hipEventCreate(&e0); hipEventCreate(&e1);
+            (void) hipEventCreate(&e0); (void) hipEventCreate(&e1);
             const float al = 1.0f, be = accumulate ? 1.0f : 0.0f;
             // accumulate mode reads c: time the candidates into a scratch D so the caller's c is not summed into repeatedly
             void* dtune = c;
@@ -95,18 +95,18 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
                 float ms = 0.0f;
                 for (int rep = 0; rep < 3 && ok; ++rep)
                 {
-                    if (rep == 1) hipEventRecord(e0, (hipStream_t) stream);
+                    if (rep == 1) (void) hipEventRecord(e0, (hipStream_t) stream);
                     ok = dtune && hipblasLtMatmul(cx.handle, desc, &al, b, la, a, lb, &be, c, lc, dtune, lc, &res[i].algo, cx.ws, HGEMM_WS_BYTES,
                                                   (hipStream_t) stream) == HIPBLAS_STATUS_SUCCESS;
                 }
                 if (!ok) continue;
-                hipEventRecord(e1, (hipStream_t) stream);
-                hipEventSynchronize(e1);
-                hipEventElapsedTime(&ms, e0, e1);
+                (void) hipEventRecord(e1, (hipStream_t) stream);
+                (void) hipEventSynchronize(e1);
+                (void) hipEventElapsedTime(&ms, e0, e1);
                 if (ms < best_ms) { best_ms = ms; best = i; }
             }
-            hipEventDestroy(e0); hipEventDestroy(e1);
-            if (accumulate && dtune) { hipStreamSynchronize((hipStream_t) stream); hipFree(dtune); }
+            (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+            if (accumulate && dtune) { (void) hipStreamSynchronize((hipStream_t) stream); (void) hipFree(dtune); }
         }
         it = cx.algos.emplace(key, res[best].algo).first;
     }

@@ -220,6 +220,38 @@ def exl3_gemv(A, B, C, suh, A_had, svh, mcg: bool, mul1: bool):
     exl3_gemm(A, B, C, suh, A_had, svh, -1, mcg, mul1, 0)
 
 
+def exl3_mgemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, suh: torch.Tensor, A_had, svh: torch.Tensor, indices, weights,
+               K: int, force_shape_idx: int, mcg: int, mul1: int, min_index: int, max_index: int, force_num_sms: int = 0,
+               num_tokens: int = 1, size_n_list=None, c_ptrs=None) -> int:
+    """quant/exl3_gemm.cuh:58-78 (verbatim argument order).  A [bA, m, k] fp16; B / suh / svh: int64 device tensors of device pointers
+    (modules/multilinear.py:30-32, block_sparse_mlp.py); C [bC, m, n] fp16/fp32; indices int64 [*, top] or None; weights fp16 or None.
+    A_had (scratch) is not needed here.  Per-matrix widths (size_n_list / c_ptrs) are outside this build."""
+    _dev(A)
+    _req(size_n_list is None and c_ptrs is None, "exl3_mgemm: per-matrix widths (size_n_list / c_ptrs) are outside this build")
+    _req(A.dtype == torch.half, "exl3_mgemm: A must be float16")
+    _req(B.dtype == torch.long and suh.dtype == torch.long and svh.dtype == torch.long, "exl3_mgemm: B, suh, svh must be int64 pointer tensors")
+    _req(C.dtype in (torch.half, torch.float), "exl3_mgemm: C must be float16 or float32")
+    _req(A.dim() == 3 and C.dim() == 3 and B.dim() == 1 and suh.dim() == 1 and svh.dim() == 1, "exl3_mgemm: bad tensor ranks")
+    _req(A.shape[1] == C.shape[1], "exl3_mgemm: A and C must share m")
+    _req(B.shape[0] == suh.shape[0] == svh.shape[0], "exl3_mgemm: pointer tables must share a length")
+    _req(A.is_contiguous() and C.is_contiguous(), "exl3_mgemm: A and C must be contiguous")
+    _req(num_tokens == 1 or min_index < 0, "exl3_mgemm: multi-token reduction (num_tokens > 1) is not compatible with expert-range "
+                                           "filtering (min_index >= 0); TP-sharded experts must use num_tokens == 1")
+    bA, m, k = A.shape
+    bC, _, n = C.shape
+    bszm = max(bA, bC)
+    _req(bA in (1, bszm) and bC == bszm, "exl3_mgemm: A must hold 1 or bszm slots, C bszm slots")
+    _req(k % 128 == 0 and n % 128 == 0, "exl3_mgemm: k and n must be divisible by 128")
+    if indices is not None:
+        _req(indices.dtype == torch.long and indices.numel() >= bszm and indices.is_contiguous(), "exl3_mgemm: indices must be int64 with >= bszm entries")
+    if weights is not None:
+        _req(weights.dtype == torch.half and weights.numel() >= bszm and weights.is_contiguous(), "exl3_mgemm: weights must be float16 with >= bszm entries")
+    _check(_lib.lib().exl3_mgemm_indexed(_p(A), bA, _p(B), _p(suh), _p(svh), _p(indices), _p(weights), bszm, _p(C), m, k, n, int(K),
+                                         _cb(bool(mcg), bool(mul1)), int(C.dtype == torch.float), int(min_index), int(max_index),
+                                         int(num_tokens), _stream(A)))
+    return 90
+
+
 def exl3_mgemm_bcast(A: torch.Tensor, Bs: list[torch.Tensor], Cs: list[torch.Tensor], suhs: list[torch.Tensor],
                      svhs: list[torch.Tensor], mcg: bool = False, mul1: bool = False, force_split: int = 0) -> int:
     """Broadcast form of quant/exl3_gemm.cuh:58-78 (indices == None): one A against several matrices in ONE launch

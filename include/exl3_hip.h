@@ -127,6 +127,17 @@ int exl3_glue_qkv(const float* sq, const float* sk, const float* sv, int S, cons
 int exl3_glue_act(const float* sg, const float* su, int S, const void* svh_g, const void* svh_u, const void* suh_d,
                   void* xh_d, float* xsum_d, void* a_out, int m, int inter, void* stream);
 
+/* exl3_mgemm with pointer tables, indices and routing weights (MoE form)   quant/exl3_gemm.cuh:58-78, exl3_gemm_kernel.cuh:88-292
+ * tbl_B / tbl_suh / tbl_svh: device arrays of device addresses (int64), one entry per matrix (all k x n, same K and codebook).
+ * Slot j of bszm uses matrix indices[j] (device int64; NULL: matrix j).  min_index >= 0: only indices in [min_index, max_index) run,
+ * compacted to the front in order and re-based to min_index (expert-parallel ranks); the other slots are left unwritten.
+ * A [bszm_in][m][k] fp16 with bszm_in == 1 (shared input) or bszm; C [bszm][m][n] fp16/fp32.
+ * weights (fp16 [bszm], NULL: none): slot output scaled by its weight inside the output-Hadamard scale, then every group of
+ * bszm / num_tokens consecutive slots is summed into C[t] (fp16: sequential half adds, fp32: float adds).  m <= 16. */
+int exl3_mgemm_indexed(const void* A, int bszm_in, const void* tbl_B, const void* tbl_suh, const void* tbl_svh,
+                       const int64_t* indices, const void* weights, int bszm, void* C, int m, int k, int n, int K, int cb, int c_fp32,
+                       int min_index, int max_index, int num_tokens, void* stream);
+
 /* ---- GEMV launches with an in-kernel tail epilogue (decode, m <= 16) ------------------------------------------------------
  * The workgroup that finishes a 128-column block last (device-memory arrival ticket) reduces the split-k partials of that
  * block and runs the sublayer boundary the reference executes as separate graph nodes between two exl3_gemm calls

@@ -158,3 +158,57 @@ def test_gen2_waves_per_workgroup(dev, max_waves):
         assert _run(dev, 4096, 256, 3, 1, 4, 0, force_split=1, gen=2) < TOL
     finally:
         ext.set_gemv_max_waves(0)
+
+
+@pytest.mark.parametrize("cb", [0, 2])
+@pytest.mark.parametrize("k,n,K", [(512, 256, 4), (1024, 384, 3)])
+def test_mgemm_indexed_moe_forms(dev, cb, k, n, K):
+    """exl3_mgemm with pointer tables (quant/exl3_gemm.cuh:58-78): (1) shared input, indices -> per-slot outputs (gate/up of selected
+    experts); (2) per-slot inputs + routing weights -> weighted sum into C[0] (down); (3) expert-range filter (compaction, re-basing,
+    untouched slots); (4) num_tokens > 1 grouped reduction.  Against the oracle linear per slot."""
+    from exllamav3_amd import ext
+    E, top, m = 6, 3, 2
+    rng = np.random.default_rng(k + n + K + cb)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mats = [o.synth_linear(k, n, K, seed=100 + e, realistic=True) for e in range(E)]
+    tB = [T(t[0]) for t in mats]; tsu = [T(t[1]) for t in mats]; tsv = [T(t[2]) for t in mats]
+    ptr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.long, device=dev)
+    pB, psu, psv = ptr(tB), ptr(tsu), ptr(tsv)
+    lin = lambda x, e, fp32=False: o.linear_forward(x, mats[e][0], mats[e][1], mats[e][2], K, cb, out_fp32=fp32).astype(np.float32)
+    tol = lambda ref: 1e-2 * np.sqrt((ref ** 2).mean()) + 1e-3
+    # (1) shared input
+    x = rng.standard_normal((1, m, k)).astype(np.float16)
+    sel = np.array([4, 0, 3], dtype=np.int64)
+    C = torch.full((top, m, n), float("nan"), dtype=torch.half, device=dev)
+    ext.exl3_mgemm(T(x), pB, C, psu, None, psv, T(sel), None, K, -1, cb == 1, cb == 2, -1, -1, 0)
+    for j, e in enumerate(sel):
+        ref = lin(x[0], int(e))
+        assert np.abs(C[j].float().cpu().numpy() - ref).max() < tol(ref)
+    # (2) per-slot inputs + weights, fp32 and fp16 outputs
+    xs = rng.standard_normal((top, m, k)).astype(np.float16)
+    w = np.array([0.5, 0.3, 0.2], dtype=np.float16)
+    for dt in (torch.float, torch.half):
+        C = torch.zeros((top, m, n), dtype=dt, device=dev)
+        ext.exl3_mgemm(T(xs), pB, C, psu, None, psv, T(sel), T(w), K, -1, cb == 1, cb == 2, -1, -1, 0)
+        ref = sum(float(w[j]) * lin(xs[j], int(e), fp32=True) for j, e in enumerate(sel))
+        assert np.abs(C[0].float().cpu().numpy() - ref).max() < 2 * tol(ref)
+    # (3) expert range [3, 6): slots with experts 4 and 3 run (compacted to slots 0, 1 and re-based to a local table), slot 2 untouched
+    lo, hi = 3, 6
+    pBl, psul, psvl = ptr(tB[lo:hi]), ptr(tsu[lo:hi]), ptr(tsv[lo:hi])
+    C = torch.full((top, m, n), 7.0, dtype=torch.half, device=dev)
+    ext.exl3_mgemm(T(x), pBl, C, psul, None, psvl, T(sel), None, K, -1, cb == 1, cb == 2, lo, hi, 0)
+    kept = [int(e) for e in sel if lo <= e < hi]
+    for j, e in enumerate(kept):
+        ref = lin(x[0], e)
+        assert np.abs(C[j].float().cpu().numpy() - ref).max() < tol(ref)
+    assert bool((C[len(kept):] == 7.0).all())
+    # (4) two tokens x two experts each, grouped reduction into rows 0 and 1
+    sel2 = np.array([1, 5, 2, 0], dtype=np.int64); w2 = np.array([0.6, 0.4, 0.7, 0.3], dtype=np.float16)
+    xs2 = rng.standard_normal((4, 1, k)).astype(np.float16)
+    C = torch.zeros((4, 1, n), dtype=torch.float, device=dev)
+    ext.exl3_mgemm(T(xs2), pB, C, psu, None, psv, T(sel2), T(w2), K, -1, cb == 1, cb == 2, -1, -1, 0, num_tokens=2)
+    for t in range(2):
+        ref = sum(float(w2[2 * t + j]) * lin(xs2[2 * t + j], int(sel2[2 * t + j]), fp32=True) for j in range(2))
+        assert np.abs(C[t].float().cpu().numpy() - ref).max() < 2 * tol(ref)
+    with pytest.raises(RuntimeError):
+        ext.exl3_mgemm(T(xs2), pB, C, psu, None, psv, T(sel2), T(w2), K, -1, cb == 1, cb == 2, 0, 4, 0, num_tokens=2)
