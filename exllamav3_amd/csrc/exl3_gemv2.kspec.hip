@@ -90,7 +90,7 @@ template <int K, int CB, int VAR, int NG, int MODE>
 #ifdef G2_ABL_ILP
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 #else
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NG != 1 ? 4 : (K >= 5 ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || CB != EXL3_CB_MUL1) ? 7 : 8)))))
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NG != 1 ? 4 : ((K >= 5 || (MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || CB != EXL3_CB_MUL1) ? 7 : 8)))))
 #endif
 void exl3_gemv2_kernel(const GemvArgs a)
 {
