@@ -6,6 +6,8 @@
 // (sign = parity(popcount(i & j))) -- no Hadamard matrix in memory, no 7-stage butterfly with LDS round trips,
 // and exact fp32 accumulation of exactly representable products.  Rounding points follow the reference: the
 // intermediate (after the k-side transform and suh) is rounded to fp16, the final result is rounded once.
+// The first GEMM is computed transposed so that its accumulators ARE the second GEMM's A operand (no LDS round trip for
+// the intermediate, one 34.8 KB LDS image per workgroup).
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
 #include "exl3_lane_decode.cuh"
@@ -46,7 +48,6 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
     constexpr int NW = 8 * K;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* Wt = (half_t*) smem;                          // [n][RH_LD]  W_hat transposed; later the output staging [k'][RH_LD]
-    half_t* T = Wt + 128 * RH_LD;                         // [k'][RH_LD] intermediate
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kb = blockIdx.y, nb = blockIdx.x;
@@ -87,60 +88,68 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
     uint32_t hbase[4];
     had_base_frag(j, g, hbase);
 
-    // ---- GEMM 1: D1[k'][n] = sum_k H[k'][k] * W_hat[k][n];   T = fp16(D1 * suh[k'] / sqrt(128))
+    // ---- GEMM 1 (transposed): D1t[n][k'] = sum_k W_hat^T[n][k] * H[k][k'];  Tt = fp16(D1t * suh[k'] / sqrt(128))
+    //      A = rows of Wt (LDS), B = Hadamard fragment.  The accumulator layout (lane: k' = j, four consecutive n = 4g..4g+3 per n-tile)
+    //      is exactly what GEMM 2 needs for its A operand (row k' = j, n along the k-slots), so the intermediate never leaves registers:
+    //      k-slot (g, s) of GEMM-2 step u holds n = 16(2u) + 4g + s for s < 4 and n = 16(2u+1) + 4g + s - 4 for s >= 4 -- a permutation of
+    //      n that the generated Hadamard B fragments of GEMM 2 simply follow.
+    half8_t ta[2][4];                                     // [k' tile of this wave][step u]
     {
-        half8_t ha[2][4];
+        half8_t hb[2][4];
         #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
             #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) ha[rt][ks] = had_frag_signed(hbase, 2 * wave + rt, ks, g);
-        float sc0[4], sc1[4];
+            for (int ks = 0; ks < 4; ++ks) hb[rt][ks] = had_frag_signed(hbase, 2 * wave + rt, ks, g);
+        const float sc0 = (float) suh[kb * 128 + 16 * (2 * wave) + j] * r128;
+        const float sc1 = (float) suh[kb * 128 + 16 * (2 * wave + 1) + j] * r128;
         #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int u = 0; u < 4; ++u)
         {
-            sc0[r] = (float) suh[kb * 128 + 16 * (2 * wave) + 4 * g + r] * r128;
-            sc1[r] = (float) suh[kb * 128 + 16 * (2 * wave + 1) + 4 * g + r] * r128;
-        }
-        #pragma unroll 2
-        for (int ct = 0; ct < 8; ++ct)
-        {
-            float4_t acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
+            float4_t acc[2][2];                           // [n-tile parity][k' tile]
             #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int e = 0; e < 2; ++e)
             {
-                half8_t bf = *((const half8_t*) (Wt + (size_t) (16 * ct + j) * RH_LD + 32 * ks + 8 * g));
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha[0][ks], bf, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ha[1][ks], bf, acc1, 0, 0, 0);
+                acc[e][0] = float4_t{ 0.f, 0.f, 0.f, 0.f }; acc[e][1] = acc[e][0];
+                #pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                {
+                    half8_t af = *((const half8_t*) (Wt + (size_t) (16 * (2 * u + e) + j) * RH_LD + 32 * ks + 8 * g));
+                    acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, hb[0][ks], acc[e][0], 0, 0, 0);
+                    acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, hb[1][ks], acc[e][1], 0, 0, 0);
+                }
             }
-            #pragma unroll
-            for (int r = 0; r < 4; ++r)
-            {
-                int k0r = 16 * (2 * wave) + 4 * g + r, k1r = k0r + 16;
-                T[(size_t) k0r * RH_LD + 16 * ct + j] = (half_t) (acc0[r] * sc0[r]);
-                T[(size_t) k1r * RH_LD + 16 * ct + j] = (half_t) (acc1[r] * sc1[r]);
-            }
+            ta[0][u] = half8_t{ (half_t) (acc[0][0][0] * sc0), (half_t) (acc[0][0][1] * sc0), (half_t) (acc[0][0][2] * sc0), (half_t) (acc[0][0][3] * sc0),
+                                (half_t) (acc[1][0][0] * sc0), (half_t) (acc[1][0][1] * sc0), (half_t) (acc[1][0][2] * sc0), (half_t) (acc[1][0][3] * sc0) };
+            ta[1][u] = half8_t{ (half_t) (acc[0][1][0] * sc1), (half_t) (acc[0][1][1] * sc1), (half_t) (acc[0][1][2] * sc1), (half_t) (acc[0][1][3] * sc1),
+                                (half_t) (acc[1][1][0] * sc1), (half_t) (acc[1][1][1] * sc1), (half_t) (acc[1][1][2] * sc1), (half_t) (acc[1][1][3] * sc1) };
         }
     }
-    __syncthreads();
+    __syncthreads();                                      // every wave is done reading Wt: it becomes the output staging buffer
 
-    // ---- GEMM 2: Out[k'][n'] = sum_n T[k'][n] * H[n][n'];   out = fp16(Out * svh[n'] / sqrt(128))   (staged in Wt)
+    // ---- GEMM 2: Out[k'][n'] = sum_n T[k'][n] * H[n][n'];   out = fp16(Out * svh[n'] / sqrt(128))
     {
-        half8_t ta[2][4];
+        // H16[4g + s][j] for s = 0..3: the per-lane base of the permuted-n Hadamard fragment
+        uint32_t h16[2];
         #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-            #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                ta[rt][ks] = *((const half8_t*) (T + (size_t) (16 * (2 * wave + rt) + j) * RH_LD + 32 * ks + 8 * g));
+        for (int r = 0; r < 2; ++r)
+        {
+            uint32_t s0 = __builtin_popcount(j & (4 * g + 2 * r)) & 1, s1 = __builtin_popcount(j & (4 * g + 2 * r + 1)) & 1;
+            h16[r] = 0x3C003C00u ^ (s0 << 15) ^ (s1 << 31);
+        }
         #pragma unroll 2
         for (int ct = 0; ct < 8; ++ct)
         {
             float4_t acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
             #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int u = 0; u < 4; ++u)
             {
-                half8_t hb = had_frag_signed(hbase, ct, ks, g);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0][ks], hb, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[1][ks], hb, acc1, 0, 0, 0);
+                // signs H8[2u][ct] and H8[2u+1][ct]
+                const uint32_t na = (__builtin_popcount((2 * u) & ct) & 1) ? 0x80008000u : 0u;
+                const uint32_t nb2 = (__builtin_popcount((2 * u + 1) & ct) & 1) ? 0x80008000u : 0u;
+                union { uint32_t w[4]; half8_t h; } f;
+                f.w[0] = h16[0] ^ na; f.w[1] = h16[1] ^ na; f.w[2] = h16[0] ^ nb2; f.w[3] = h16[1] ^ nb2;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0][u], f.h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[1][u], f.h, acc1, 0, 0, 0);
             }
             const float sv = (float) svh[nb * 128 + 16 * ct + j] * r128;
             #pragma unroll
@@ -176,7 +185,7 @@ extern "C" int exl3_reconstruct_had(void* out, const void* trellis, const void* 
     EXL3_CHECK_ARG(n_offset + n_size <= (int64_t) tiles_n * 16, "reconstruct slice exceeds packed tensor bounds");
     if (n_size == 0 || tiles_k == 0) return EXL3_OK;
     dim3 grid((unsigned) (n_size / 128), (unsigned) (tiles_k / 8));
-    size_t lds = (size_t) 2 * 128 * RH_LD * 2;
+    size_t lds = (size_t) 128 * RH_LD * 2;                 // 34.8 KB: four workgroups per CU
     hipStream_t st = (hipStream_t) stream;
     switch (K * 3 + cb)
     {
