@@ -70,6 +70,8 @@ class LinearEXL3:
                 w = torch.empty((self.in_features, self.out_features), dtype=torch.half, device=dev)
                 ext.reconstruct(w, self.trellis, self.K, self.mcg, self.mul1)
             ext.hgemm(xh, w, y2)
+            if use_fused:
+                self._release_w()
         else:
             step = (MAX_RECONSTRUCT_SLICE_N // 128) * 128
             w_ = torch.empty((self.in_features * step,), dtype=torch.half, device=dev)
@@ -99,13 +101,25 @@ class LinearEXL3:
             ext.add(resid, y.view(resid.shape))
             return
         ext.hgemm_acc(x.view(rows, self.in_features), self._reconstructed_w(), resid.view(rows, self.out_features))
+        self._release_w()
 
     #: MI355X option (not in the reference): keep the reconstructed original-basis fp16 W of every Linear resident after its first
     #: prefill use -- 16 GB for an 8B model, 141 GB for 70B, both fit the 288 GB of one MI355X next to the packed weights -- so later
     #: prefill chunks are pure MFMA GEMMs.  Off by default: the reference reconstructs per forward (exl3.py:161-218).
     cache_reconstructed = False
 
+    #: optional ReconstructAhead (below) that rebuilds W on a side stream ahead of use
+    ahead = None
+
+    def _release_w(self) -> None:
+        if LinearEXL3.ahead is not None:
+            LinearEXL3.ahead.release(self)
+
     def _reconstructed_w(self) -> torch.Tensor:
+        if LinearEXL3.ahead is not None:
+            w = LinearEXL3.ahead.acquire(self)
+            if w is not None:
+                return w
         w = getattr(self, "_w_cache", None)
         if w is not None:
             return w
@@ -142,3 +156,60 @@ class LinearEXL3:
         return LinearEXL3(last - first, self.out_features, self.trellis[first // 16: last // 16].contiguous(),
                           self.suh[first:last].contiguous(), self.svh, self.mcg, self.mul1,
                           self.bias if first == 0 else None, self.out_dtype, self.key)
+
+
+class ReconstructAhead:
+    """Prefill scheduler piece (no counterpart in the reference, which reconstructs inline on one stream): the reconstructed fp16 W of
+    the next `depth` Linears of a known sequence is rebuilt on a second HIP stream while the GEMM of the current one runs on the main
+    stream.  The GEMM is MFMA-bound, reconstruct_had_slice is VALU / latency-bound: the two share the chip well.  W never depends on the
+    activations, so the only ordering is buffer reuse (ring of depth + 1 buffers) -- expressed with HIP events, no host synchronisation.
+
+        ahead = ReconstructAhead(sequence_of_linears); LinearEXL3.ahead = ahead; ahead.begin(); ...forward calls in that order...;
+        ahead.end(); LinearEXL3.ahead = None
+    """
+
+    def __init__(self, linears, depth: int = 2):
+        self.seq = list(linears)
+        self.nbuf = depth + 1
+        dev = self.seq[0].trellis.device
+        cap = max(l.in_features * l.out_features for l in self.seq)
+        self.bufs = [torch.empty((cap,), dtype=torch.half, device=dev) for _ in range(self.nbuf)]
+        self.side = torch.cuda.Stream(device=dev)
+        self.ready, self.released, self.w = {}, {}, {}
+        self.pos = 0
+
+    def _issue(self, i: int):
+        if i >= len(self.seq):
+            return
+        lin = self.seq[i]
+        with torch.cuda.stream(self.side):
+            if i - self.nbuf in self.released:
+                self.side.wait_event(self.released.pop(i - self.nbuf))       # the GEMM that read this buffer last has finished
+            w = self.bufs[i % self.nbuf][: lin.in_features * lin.out_features].view(lin.in_features, lin.out_features)
+            ext.reconstruct_had_slice(w, lin.trellis, lin.suh, lin.svh, lin.K, lin.mcg, lin.mul1, 0)
+            ev = torch.cuda.Event(); ev.record(self.side)
+        self.ready[i], self.w[i] = ev, w
+
+    def begin(self):
+        self.pos = 0
+        self.side.wait_stream(torch.cuda.current_stream())
+        for i in range(self.nbuf):
+            self._issue(i)
+
+    def acquire(self, lin):
+        if self.pos >= len(self.seq) or self.seq[self.pos] is not lin:
+            return None                                                       # not part of the announced sequence: caller reconstructs inline
+        torch.cuda.current_stream().wait_event(self.ready.pop(self.pos))
+        return self.w.pop(self.pos)
+
+    def release(self, lin):
+        if self.pos >= len(self.seq) or self.seq[self.pos] is not lin:
+            return
+        ev = torch.cuda.Event(); ev.record(torch.cuda.current_stream())
+        self.released[self.pos] = ev
+        i = self.pos
+        self.pos += 1
+        self._issue(i + self.nbuf)
+
+    def end(self):
+        torch.cuda.current_stream().wait_stream(self.side)

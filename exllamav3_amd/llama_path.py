@@ -192,6 +192,11 @@ class SyntheticEXL3Llama:
         return self.logits
 
     # ---- the same step with the fused pipeline: deferred-epilogue GEMVs + glue kernels (8 launches per layer) ----------
+    #: prefill: rebuild the next Linears' fp16 W on a side stream while the current GEMM runs (linear.ReconstructAhead).  Measured on
+    #: MI355X: 68.3k tok/s with it vs 70.6k inline -- the concurrent kernel slows the hipBLASLt GEMM and W is no longer Infinity-Cache-warm
+    #: when the GEMM reads it -- so it stays off; kept as a tested option.
+    reconstruct_ahead = False
+
     #: forced split-k factor per call type of the fused pipelines (0 = library heuristic); tools/sweep_split.py tunes these
     split = {"qkv": 0, "o": 0, "gu": 0, "down": 0}
 
@@ -399,6 +404,15 @@ class SyntheticEXL3Llama:
         x = self.px0.clone()
         be = self.backend
         xn = torch.empty_like(x)
+        ahead = None
+        if self.reconstruct_ahead and tokens >= 1024:
+            from .linear import LinearEXL3, ReconstructAhead
+            ahead = getattr(self, "_ahead", None)
+            if ahead is None:
+                seq = [L[nm] for L in self.layers for nm in ("q", "k", "v", "o", "gate", "up", "down")]
+                ahead = self._ahead = ReconstructAhead(seq, depth=2)
+            LinearEXL3.ahead = ahead
+            ahead.begin()
         for L in self.layers:
             ext.rms_norm(x, L["norm1"], xn, self.eps)
             q = L["q"].forward(xn).view(1, tokens, self.hq, hd)
@@ -424,5 +438,9 @@ class SyntheticEXL3Llama:
                 d = L["down"].forward(a)
                 be.all_reduce(d)
                 ext.add(x, d)
+        if ahead is not None:
+            from .linear import LinearEXL3
+            ahead.end()
+            LinearEXL3.ahead = None
         ext.rms_norm(x[-1:], self.final_norm, xn[-1:], self.eps)
         return self.lm_head.forward(xn[-1:].contiguous())

@@ -319,3 +319,22 @@ def test_bc_gated_mlp_matches_oracle_and_op_by_op(dev, cb, m):
         assert float((d2.float() - d.float().view(m, hidden)).abs().max()) < 1e-2 * float(d2.float().abs().max()) + 1e-3
     with pytest.raises(RuntimeError):
         ext.BC_GatedMLP(guh, gu, a, dxh, None, None, None, K, False, False, False, True, False, bcs[0], bcs[1], bcs[2], 0.0)
+
+
+def test_prefill_reconstruct_ahead_is_bit_identical_to_inline(dev):
+    """ReconstructAhead (W of the next Linears rebuilt on a side stream, ring of 3 buffers, event-ordered) must not change a bit:
+    3 layers x 7 linears cycle the ring several times; repeated chunks reuse the scheduler object."""
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 256, 512, 3, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4)
+    model.reconstruct_ahead = False
+    ref = model.prefill_chunk(1024).clone()
+    kv_ref = [c.clone() for c in model.pf_cache]
+    model.reconstruct_ahead = True
+    for rep in range(3):
+        for c in model.pf_cache: c.zero_()
+        got = model.prefill_chunk(1024)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref), f"rep {rep}"
+        for a, b in zip(model.pf_cache, kv_ref):
+            assert torch.equal(a, b)
