@@ -1,11 +1,11 @@
 """Per-call-type GPU time of the decode GEMV launches (graph replays bracketed by events), for the three pipelines."""
-import sys, torch
+import os, sys, torch
 sys.path.insert(0, "/root/repo")
 from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
 
 dev = torch.device("cuda:0")
 model = SyntheticEXL3Llama(SHAPES["llama-3.1-8b"], K=4, cb=2, device=dev, kv_bits=4, layers=int(sys.argv[1]) if len(sys.argv) > 1 else 8)
-model.alloc_state(1)
+model.alloc_state(int(os.environ.get("BSZ", "1")))
 import os
 from exllamav3_amd import ext
 if os.environ.get("MAXW"): ext.set_gemv_max_waves(int(os.environ["MAXW"]))
