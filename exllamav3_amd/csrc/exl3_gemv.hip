@@ -662,17 +662,11 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             if (nwv > units) nwv = units;
             if (g_gemv_nwv > 0 && nwv > g_gemv_nwv) nwv = g_gemv_nwv;
             if (nwv < 1) nwv = 1;
-            // activation fragments: up to ~64 KB per workgroup, whole wave range when it fits (one prep, then a pure stream)
+            // activation fragments of one chunk of Hadamard blocks, built once per workgroup: up to ~48 KB, the whole slice when it fits
             const int AHh = (var == 1 && cb != 2) ? 32 : 16;
-            int blocks_per_wave = 1;                             // most Hadamard blocks any wave touches
-            for (int w = 0; w < nwv; ++w)
-            {
-                const int r0 = (units * w) / nwv * 2, r1 = (units * (w + 1)) / nwv * 2;
-                if (r1 > r0 && ((r1 + 7) >> 3) - (r0 >> 3) > blocks_per_wave) blocks_per_wave = ((r1 + 7) >> 3) - (r0 >> 3);
-            }
-            int chunk = (int) ((size_t) 65536 / ((size_t) nwv * 8 * mp * AHh * 2));
+            int chunk = (int) ((size_t) 49152 / ((size_t) 8 * mp * AHh * 2));
             if (chunk < 1) chunk = 1;
-            if (chunk > blocks_per_wave) chunk = blocks_per_wave;
+            if (chunk > bps) chunk = bps;
             args.chunk_blocks = chunk;
             size_t lds = exl3_gemv2_lds_bytes(ng, var, cb, nwv, mp, chunk);
             if (epi)

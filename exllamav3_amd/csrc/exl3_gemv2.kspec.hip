@@ -90,7 +90,7 @@ template <int K, int CB, int VAR, int NG, int MODE>
 #ifdef G2_ABL_ILP
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 #else
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(NG != 1 ? 4 : ((K >= 5 || (MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || CB != EXL3_CB_MUL1) ? 7 : 8)))))
+__global__ __launch_bounds__(1024 / NG) __attribute__((amdgpu_waves_per_eu(NG == 4 ? 3 : NG == 2 ? 4 : (K >= 5 && MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1) ? 5 : ((K >= 5 || (MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || CB != EXL3_CB_MUL1) ? 7 : 8)))))
 #endif
 void exl3_gemv2_kernel(const GemvArgs a)
 {
@@ -145,22 +145,21 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const int k1s = min(k0s + a.kslice, a.k);
     const int nb = (k1s - k0s) >> 7;                 // 128-blocks in the workgroup's slice
     const int nwv = blockDim.x >> 6;                 // waves per workgroup (1..16)
-    // The waves split the slice's tile rows in units of G2_PF rows (not whole Hadamard blocks): a small matrix (o_proj at batch 1
-    // is 8192 tile rows for 1024 SIMDs) needs every SIMD to have several KB in flight to cover HBM latency, which only works if
-    // all 16 waves of a workgroup get rows.  A wave still rotates / fetches whole 128-blocks of x for the rows it touches.
+    // Work split inside the workgroup: the slice is walked in units of G2_PF (= 2) tile rows, unit u belongs to wave u % nwv.  All waves
+    // therefore advance down k together, which lets the workgroup build the activation fragments of a CHUNK of Hadamard blocks ONCE,
+    // cooperatively (one (block, row) task per 32-lane half-wave), instead of every wave rotating every block it touches: at batch 16 the
+    // per-wave version spent 6x more VALU time on input Hadamards than on decoding weights (tools/gemv_timeline.py).
     const int units = nb * (8 / G2_PF);
-    const int R0 = ((units * wave) / nwv) * G2_PF, R1 = ((units * (wave + 1)) / nwv) * G2_PF;
-    const int b0 = R0 >> 3;                          // first block touched
-    const int nbw = R1 > R0 ? ((R1 + 7) >> 3) - b0 : 0;   // blocks touched by this wave (may be 0)
-    const int rbeg = R0 - 8 * b0, rend = R1 - 8 * b0;     // wave-local tile rows [rbeg, rend) relative to block b0
-    const int k0 = k0s + 128 * b0;
+    const int nunits_w = wave < units ? (units - wave + nwv - 1) / nwv : 0;     // units of this wave
 
-    // LDS carve: per-wave activation fragments for a CHUNK of `chb` Hadamard blocks [blk][tile row 8][row m][AH halves]
-    //            | partials [nwv][MR][128] fp32 | per-wave row sums
-    const int chb = a.chunk_blocks;                  // blocks per chunk (host: LDS budget / waves)
+    // LDS carve: fragments of one chunk [blk][tile row 8][row m][AH halves] | partials [nwv][MR][128] fp32 + per-wave row sums |
+    //            tile-row sums [blk * 8][m] fp32 (RAW) | 1/rms per row [16] fp32 (NORM)
+    const int chb = a.chunk_blocks;                  // blocks per chunk (host: LDS budget)
     const size_t frag_halves = (size_t) chb * 8 * m * AH;
-    half_t* xa = (half_t*) smem + (size_t) wave * frag_halves;
-    float* part = (float*) (smem + (((size_t) nwv * frag_halves * 2 + 15) & ~(size_t) 15));
+    half_t* xa = (half_t*) smem;
+    float* part = (float*) (smem + ((frag_halves * 2 + 15) & ~(size_t) 15));
+    float* tsum = part + (size_t) nwv * MR * 128 + (size_t) nwv * MR;
+    float* rmf_s = tsum + (size_t) chb * 8 * m;
 
     float rowsum[2 * NG];
     #pragma unroll
@@ -168,190 +167,203 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const int l32 = lane & 31, hw = lane >> 5;
     const bool in_rotated = (a.flags & GEMV_IN_ROTATED) != 0;
     const half_t* __restrict__ xh_in = MODE == G2_MODE_TABLE ? nullptr : a.mat[mi].xh;
-    const float* __restrict__ xsum_in = MODE == G2_MODE_TABLE ? nullptr : a.mat[mi].xsum;
     const half_t* __restrict__ x_src = in_rotated ? xh_in : A_in;          // one scalar select (two pointers picked per load became a stack table)
-    const int npass = (m + 1) >> 1;                  // passes of 2 rows (one per half-wave)
+    const int npass = (m + 1) >> 1;                  // row pairs (2p, 2p + 1) held by the two half-waves of the streaming loop
+    const int hwid = tid >> 5, nhw = nwv * 2;        // half-wave id in the workgroup: the prep task owner
 
-    // GEMV_IN_NORM: A is the fp16 residual stream; x = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)) is formed in prep_chunk, per
+    // GEMV_IN_NORM: A is the fp16 residual stream; x = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)) is formed in the prep tasks, per
     // row from the per-block sums of squares a glue kernel left behind (same arithmetic and summation order as glue_norm_kernel /
     // rms_norm: norm.cu:20-120), so the RMSNorm between two linears costs no launch and no single-workgroup pass.
     constexpr bool in_norm = MODE == G2_MODE_NORM;
 
-    // ---- input Hadamard (or fetch of the pre-rotated input) of `cnt` blocks starting at wave-local block c0, written in
-    //      MFMA-A fragment order.  Software pipelined by one task so the global loads of task i+1 fly during task i.
-    auto prep_chunk = [&] (int c0, int cnt)
-    {
-        const int ntask = cnt * npass;
-        struct PrepIn { half4_t xv, sv, wv; float xs; };
-        auto fetch = [&] (int t) -> PrepIn
-        {
-            PrepIn r; r.xv = half4_t{ 0, 0, 0, 0 }; r.sv = r.xv; r.wv = r.xv; r.xs = 0.0f;
-            const int blk = c0 + t / npass, p = t % npass;
-            const int row = 2 * p + hw;
-            const bool act = row < m;
-            const size_t off = (size_t) (act ? row : 0) * a.k + k0 + 128 * blk;
-            r.xv = ((const half4_t*) (x_src + off))[l32];
-            if (in_rotated)
-            {
-                if constexpr (RAW) r.xs = xsum_in[(size_t) (act ? row : 0) * (a.k >> 7) + (k0 >> 7) + blk];
-            }
-            else
-            {
-                r.sv = ((const half4_t*) (suh + k0 + 128 * blk))[l32];
-                if constexpr (in_norm) r.wv = ((const half4_t*) (a.norm_w + k0 + 128 * blk))[l32];
-            }
-            return r;
-        };
-        PrepIn nx = fetch(0);
-        // per-row 1/rms: computed here (after the weight ring loads and the first activation fetch were issued) and not kept live
-        // across the streaming loop
-        float rmf[2 * NG];
-        #pragma unroll
-        for (int p = 0; p < 2 * NG; ++p) rmf[p] = 1.0f;
-        if constexpr (in_norm)
-        {
-            const int nblk_k = a.k >> 7;
-            #pragma unroll
-            for (int p = 0; p < 2 * NG; ++p)
-            {
-                if (p < npass)
-                {
-                    const int row = min(2 * p + hw, m - 1);
-                    float s2 = 0.0f;
-                    for (int bb = 0; bb < nblk_k; bb += 32)
-                    {
-                        float v = (bb + l32 < nblk_k) ? a.ss_part[(size_t) row * nblk_k + bb + l32] : 0.0f;
-                        #pragma unroll
-                        for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
-                        s2 += v;
-                    }
-                    rmf[p] = __frsqrt_rn(s2 / (float) a.k + a.eps);
-                }
-            }
-        }
-        for (int t = 0; t < ntask; ++t)
-        {
-            const half4_t xv_c = nx.xv, sv_c = nx.sv, wv_c = nx.wv; const float xs_c = nx.xs;
-            if constexpr (!in_norm) { if (t + 1 < ntask) nx = fetch(t + 1); }   // NORM mode fetches after the task (register budget)
-            const int blk_l = t / npass, p = t % npass;              // chunk-local block
-            const int row = 2 * p + hw;
-            const bool act = row < m;
-            half2_t o01, o23;
-            float bsum;
-            const int blk_t = c0 + t / npass;                           // wave-local block of this task
-            const bool whole = 8 * blk_t >= rbeg && 8 * blk_t + 8 <= rend; // all 8 tile rows of the block belong to this wave
-            if (in_rotated)
-            {
-                o01 = half2_t{ xv_c.x, xv_c.y }; o23 = half2_t{ xv_c.z, xv_c.w };
-                bsum = xs_c;
-                if constexpr (RAW)
-                {
-                    if (!whole)
-                    {
-                        const int trow = 8 * blk_t + (l32 >> 2);
-                        bsum = (trow >= rbeg && trow < rend) ? ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y) : 0.0f;
-                        #pragma unroll
-                        for (int i = 1; i < 32; i <<= 1) bsum += xor_lane(bsum, i);
-                    }
-                }
-            }
-            else
-            {
-                half4_t xv = xv_c;
-                if constexpr (in_norm)
-                {
-                    float r = 1.0f;
-                    #pragma unroll
-                    for (int pp = 0; pp < 2 * NG; ++pp) if (pp == p) r = rmf[pp];
-                    xv = half4_t{ f2h((float) xv_c.x * (float) wv_c.x * r), f2h((float) xv_c.y * (float) wv_c.y * r),
-                                  f2h((float) xv_c.z * (float) wv_c.z * r), f2h((float) xv_c.w * (float) wv_c.w * r) };
-                }
-                xv = xv * sv_c;
-                float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
-                had128_f32x4(h0, h1, h2, h3, l32);
-                o01 = half2_t{ f2h(h0 * HAD_R_SCALE_128), f2h(h1 * HAD_R_SCALE_128) };
-                o23 = half2_t{ f2h(h2 * HAD_R_SCALE_128), f2h(h3 * HAD_R_SCALE_128) };
-                bsum = 0.0f;
-                if constexpr (RAW)
-                {
-                    const int trow = 8 * blk_t + (l32 >> 2);
-                    bsum = (trow >= rbeg && trow < rend) ? ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y) : 0.0f;
-                    #pragma unroll
-                    for (int i = 1; i < 32; i <<= 1) bsum += xor_lane(bsum, i);
-                }
-            }
-#ifdef G2_DEBUG_FRAG
-            // diagnostics build: workgroup 0 / wave 0 dumps the rotated activations it built (fp16 [blk][row][128]) at 40 MiB
-            if (blockIdx.x == 0 && wave == 0 && act)
-            {
-                half_t* dbg = (half_t*) ((char*) a.workspace + (40ll << 20)) + ((size_t) (k0 / 128 + c0 + t / npass) * m + row) * 128 + 4 * l32;
-                dbg[0] = o01.x; dbg[1] = o01.y; dbg[2] = o23.x; dbg[3] = o23.y;
-            }
-#endif
-            if constexpr (RAW)
-            {
-                // rowsum[p] with a static index (p is runtime here): predicated adds
-                #pragma unroll
-                for (int pp = 0; pp < 2 * NG; ++pp) if (pp == p && act) rowsum[pp] += bsum;
-            }
-            if (act)
-            {
-                // elements 4*l32 .. +3 of the block: tile row r8 = l32 >> 2, rows 4*(l32&3) .. +3 of the tile
-                const int r8 = l32 >> 2;
-                const int q0 = 2 * (l32 & 1);
-                const int sp = (l32 >> 1) & 1;                          // slot pair: rows {2q,2q+1} (0) or {2q+8,2q+9} (1)
-                half_t* base = xa + ((size_t) (blk_l * 8 + r8) * m + row) * AH;
-                if constexpr (SPLIT)
-                {
-                    half4_t d01 = { o01.x, o01.x, o01.y, o01.y }, d23 = { o23.x, o23.x, o23.y, o23.y };
-                    *((half4_t*) (base + q0 * 8 + sp * 4)) = d01;
-                    *((half4_t*) (base + (q0 + 1) * 8 + sp * 4)) = d23;
-                }
-                else
-                {
-                    *((half2_t*) (base + q0 * 4 + sp * 2)) = o01;
-                    *((half2_t*) (base + (q0 + 1) * 4 + sp * 2)) = o23;
-                }
-            }
-            if constexpr (in_norm) { if (t + 1 < ntask) nx = fetch(t + 1); }
-        }
-    };
-
-    // ---- streaming state
+    // ---- streaming state: issue the first weight rows before anything else
     const int T = lane >> 3, c = lane & 7;
-    const uint32_t* __restrict__ strip = Bm + ((size_t) (k0 >> 4) * tiles_n + (size_t) cbl * 8) * NW + (size_t) lane * K;
+    const uint32_t* __restrict__ strip = Bm + ((size_t) (k0s >> 4) * tiles_n + (size_t) cbl * 8) * NW + (size_t) lane * K;
     const size_t row_stride = (size_t) tiles_n * NW;
-    const int last_row = rend > rbeg ? rend - 1 : 0;
     const int prev_lane_addr = ((lane & ~7) | ((lane - 1) & 7)) << 2;   // ds_bpermute byte address
-    // this lane's A row; lanes whose row is >= m read row m-1 (their MFMA output rows are never stored)
-    const half_t* arow = xa + (size_t) min(lane & 15, m - 1) * AH;
-    const size_t astep = (size_t) m * AH;                               // halves per tile row
+    const int last_unit = nunits_w > 0 ? wave + (nunits_w - 1) * nwv : 0;
 
     float4_t acc_c[NG], acc_d[NG];
     #pragma unroll
     for (int gq = 0; gq < NG; ++gq) { acc_c[gq] = float4_t{ 0.f, 0.f, 0.f, 0.f }; acc_d[gq] = float4_t{ 0.f, 0.f, 0.f, 0.f }; }
 
     LaneWords<K> ring[G2_PF];
-    if (nbw > 0)
+    if (nunits_w > 0)
     {
         #pragma unroll
-        for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(rbeg + u, last_row) * row_stride);
+        for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) (G2_PF * wave + u) * row_stride);
+    }
+    G2_T(1);
+
+    // prep task fetch: task t = it * nhw + hwid of chunk (c0, cnt) -> (block c0 + t / m, row t % m); loads only
+    // NORM at m <= 4 and hidden <= 4096: the task owner reduces its row's 32 partial sums of squares itself (loaded with the task's
+    // operands: one memory latency, no extra workgroup barrier); otherwise 1/rms per row goes through LDS (rmf_s) once per launch.
+    const bool norm_in_task = in_norm && NG == 1 && (a.k >> 7) <= 32;
+    struct PrepIn { half4_t xv, sv, wv; float ss; };
+    auto fetch = [&] (int c0, int cnt, int it) -> PrepIn
+    {
+        PrepIn r; r.xv = half4_t{ 0, 0, 0, 0 }; r.sv = r.xv; r.wv = r.xv; r.ss = 0.0f;
+        const int t = min(it * nhw + hwid, cnt * m - 1);
+        const int blk = c0 + t / m, row = t % m;
+        const size_t kofs = (size_t) k0s + 128 * blk;
+        r.xv = ((const half4_t*) (x_src + (size_t) row * a.k + kofs))[l32];
+        if (!in_rotated)
+        {
+            r.sv = ((const half4_t*) (suh + kofs))[l32];
+            if constexpr (in_norm)
+            {
+                r.wv = ((const half4_t*) (a.norm_w + kofs))[l32];
+                if (norm_in_task && l32 < (a.k >> 7)) r.ss = a.ss_part[(size_t) row * (a.k >> 7) + l32];
+            }
+        }
+        return r;
+    };
+    // the first task's operands are requested now, together with the weight rows (and before the 1/rms loads of NORM mode)
+    PrepIn nx = fetch(0, min(chb, nb), 0);
+
+    if (in_norm && !norm_in_task)
+    {
+        // 1/rms of row h by half-wave h (m <= 16 <= half-waves of any launch with >= 8 waves; fewer waves loop)
+        const int nblk_k = a.k >> 7;
+        for (int base = 0; base < m; base += nhw)                       // uniform trip count: the butterflies need whole waves
+        {
+            const int row = min(base + hwid, m - 1);
+            float s2 = 0.0f;
+            for (int bb = 0; bb < nblk_k; bb += 32)
+            {
+                float v = (bb + l32 < nblk_k) ? a.ss_part[(size_t) row * nblk_k + bb + l32] : 0.0f;
+                #pragma unroll
+                for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
+                s2 += v;
+            }
+            if (l32 == 0 && base + hwid < m) rmf_s[row] = __frsqrt_rn(s2 / (float) a.k + a.eps);
+        }
+        __syncthreads();
     }
 
-    G2_T(1);
-    for (int c0 = 0; c0 < nbw; c0 += chb)
+    // this lane's A row in the streaming loop; lanes whose row is >= m read row m-1 (their MFMA output rows are never stored)
+    const half_t* arow = xa + (size_t) min(lane & 15, m - 1) * AH;
+    const size_t astep = (size_t) m * AH;                               // halves per tile row
+    int ui = 0;                                                         // index of this wave's next unit
+
+    for (int c0 = 0; c0 < nb; c0 += chb)
     {
-        const int cnt = min(chb, nbw - c0);
-        prep_chunk(c0, cnt);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // wave-private LDS: in-order queue + drain
-        __builtin_amdgcn_wave_barrier();
+        const int cnt = min(chb, nb - c0);
+        if (c0 > 0) __syncthreads();                                    // the previous chunk's fragments are no longer read
+
+        // ---- cooperative prep of blocks [c0, c0 + cnt): task t = (block t / m, row t % m), one per half-wave, software pipelined by one
+        {
+            const int ntask = cnt * m;
+            const int trips = (ntask + nhw - 1) / nhw;
+            if (c0 > 0) nx = fetch(c0, cnt, 0);
+            for (int it = 0; it < trips; ++it)
+            {
+                const PrepIn cur = nx;
+                if (it + 1 < trips) nx = fetch(c0, cnt, it + 1);
+                const int t = it * nhw + hwid;
+                const bool act = t < ntask;
+                const int tc = min(t, ntask - 1);
+                const int blk_l = tc / m, row = tc % m;                 // chunk-local block
+                half2_t o01, o23;
+                if (in_rotated)
+                {
+                    o01 = half2_t{ cur.xv.x, cur.xv.y }; o23 = half2_t{ cur.xv.z, cur.xv.w };
+                }
+                else
+                {
+                    half4_t xv = cur.xv;
+                    if constexpr (in_norm)
+                    {
+                        float r;
+                        if (norm_in_task)
+                        {
+                            float s2 = cur.ss;
+                            #pragma unroll
+                            for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
+                            r = __frsqrt_rn((0.0f + s2) / (float) a.k + a.eps);
+                        }
+                        else r = rmf_s[row];
+                        xv = half4_t{ f2h((float) cur.xv.x * (float) cur.wv.x * r), f2h((float) cur.xv.y * (float) cur.wv.y * r),
+                                      f2h((float) cur.xv.z * (float) cur.wv.z * r), f2h((float) cur.xv.w * (float) cur.wv.w * r) };
+                    }
+                    xv = xv * cur.sv;
+                    float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
+                    had128_f32x4(h0, h1, h2, h3, l32);
+                    o01 = half2_t{ f2h(h0 * HAD_R_SCALE_128), f2h(h1 * HAD_R_SCALE_128) };
+                    o23 = half2_t{ f2h(h2 * HAD_R_SCALE_128), f2h(h3 * HAD_R_SCALE_128) };
+                }
+#ifdef G2_DEBUG_FRAG
+                // diagnostics build: workgroup 0 dumps the rotated activations it built (fp16 [blk][row][128]) at 40 MiB
+                if (blockIdx.x == 0 && act)
+                {
+                    half_t* dbg = (half_t*) ((char*) a.workspace + (40ll << 20)) + ((size_t) (k0s / 128 + c0 + blk_l) * m + row) * 128 + 4 * l32;
+                    dbg[0] = o01.x; dbg[1] = o01.y; dbg[2] = o23.x; dbg[3] = o23.y;
+                }
+#endif
+                // elements 4*l32 .. +3 of the block: tile row r8 = l32 >> 2, rows 4*(l32&3) .. +3 of the tile
+                const int r8 = l32 >> 2;
+                if constexpr (RAW)
+                {
+                    // sum of the fp16 fragment values per (tile row, activation row): the FAST mul1 variant's bias term
+                    float ts = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
+                    ts += xor_lane(ts, 1);
+                    ts += xor_lane(ts, 2);
+                    if (act && (l32 & 3) == 0) tsum[(size_t) (blk_l * 8 + r8) * m + row] = ts;
+                }
+                if (act)
+                {
+                    const int q0 = 2 * (l32 & 1);
+                    const int sp = (l32 >> 1) & 1;                          // slot pair: rows {2q,2q+1} (0) or {2q+8,2q+9} (1)
+                    half_t* base = xa + ((size_t) (blk_l * 8 + r8) * m + row) * AH;
+                    if constexpr (SPLIT)
+                    {
+                        half4_t d01 = { o01.x, o01.x, o01.y, o01.y }, d23 = { o23.x, o23.x, o23.y, o23.y };
+                        *((half4_t*) (base + q0 * 8 + sp * 4)) = d01;
+                        *((half4_t*) (base + (q0 + 1) * 8 + sp * 4)) = d23;
+                    }
+                    else
+                    {
+                        *((half2_t*) (base + q0 * 4 + sp * 2)) = o01;
+                        *((half2_t*) (base + (q0 + 1) * 4 + sp * 2)) = o23;
+                    }
+                }
+            }
+        }
+        __syncthreads();
         if (c0 == 0) { G2_T(2); }
 
-        // pure streaming loop over this wave's tile rows inside the chunk, G2_PF rows per iteration (rbeg, rend and the chunk
-        // bounds are multiples of G2_PF)
-        const int row_end = min((c0 + cnt) * 8, rend);
-        for (int row0 = max(c0 * 8, rbeg); row0 < row_end; row0 += G2_PF)
+        const int row_end = (c0 + cnt) * 8;                             // slice-local tile row bound of the chunk
+        if constexpr (RAW)
         {
+            // sum(x) over the tile rows this wave streams in this chunk, per activation row of the half-wave: lane i takes the wave's
+            // i-th unit of the chunk, then a 32-lane butterfly (outside the streaming loop: no LDS wait on its critical path)
+            const int u_end = min(nunits_w, (G2_PF * wave < row_end) ? ((row_end / G2_PF - 1 - wave) / nwv + 1) : 0);   // first unit index beyond the chunk
+            #pragma unroll
+            for (int p = 0; p < 2 * NG; ++p)
+            {
+                if (p < npass)
+                {
+                    const int rowp = min(2 * p + hw, m - 1);
+                    float v = 0.0f;
+                    for (int i = ui + l32; i < u_end; i += 32)
+                    {
+                        const float* tsr = tsum + (size_t) (G2_PF * (wave + i * nwv) - c0 * 8) * m + rowp;
+                        v += tsr[0] + tsr[m];
+                    }
+                    #pragma unroll
+                    for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
+                    rowsum[p] += v;
+                }
+            }
+        }
+
+        // ---- pure streaming loop over this wave's units inside the chunk
+        for (; ui < nunits_w; ++ui)
+        {
+            const int unit = wave + ui * nwv;
+            const int row0 = G2_PF * unit;
+            if (row0 >= row_end) break;
+            const int nxt = min(unit + nwv, last_unit);                // next unit of this wave (clamped: a harmless reload at the end)
             #pragma unroll
             for (int u = 0; u < G2_PF; ++u)
             {
@@ -366,7 +378,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
 #endif
 
                 // refill the slot
-                load_lane_words<K>(ring[u], strip + (size_t) min(row + G2_PF, last_row) * row_stride);
+                load_lane_words<K>(ring[u], strip + (size_t) (G2_PF * nxt + u) * row_stride);
 
                 // A fragments of this tile row for this lane's activation row
                 const half_t* ap = arow + (size_t) (row - c0 * 8) * astep;
@@ -379,7 +391,6 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 #pragma unroll
                 for (int i = 0; i < AH / 8; ++i) af[i] = ((const half8_t*) ap)[i];
 #endif
-
                 static_for<0, 4>([&] (auto qc)
                 {
                     constexpr int q = decltype(qc)::value;
@@ -417,8 +428,6 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 });
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // fragment reads done before the next chunk overwrites them
-        __builtin_amdgcn_wave_barrier();
     }
 
     G2_T(3);
@@ -587,8 +596,9 @@ size_t exl3_gemv2_lds_bytes(int ng, int var, int cb, int nwv, int m, int chunk_b
 {
     const int MR = 4 * ng;
     const int AH = (var == 1 && cb != 2) ? 32 : 16;
-    size_t frag = ((size_t) nwv * chunk_blocks * 8 * m * AH * 2 + 15) & ~(size_t) 15;
+    size_t frag = ((size_t) chunk_blocks * 8 * m * AH * 2 + 15) & ~(size_t) 15;
     size_t part = (size_t) nwv * MR * 128 * 4 + (size_t) nwv * MR * 4;
-    return frag + part;
+    size_t tsum = (size_t) chunk_blocks * 8 * m * 4 + 64;          // tile-row sums + 1/rms per row
+    return frag + part + tsum;
 }
 #endif

@@ -167,6 +167,49 @@ void glue_resid_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// G1b: the other half of the norm boundary for batches above 4 rows: per (row, 128-block) half-wave: 1/rms of the row from the per-block
+//      sums of squares (same fixed-order sum as everywhere else) -> x = fp16(resid * w / rms) -> (x * suh_i) input Hadamard for up to 3
+//      consumers.  At m <= 4 the consumer GEMVs do this themselves (GEMV_IN_NORM); at m = 16 that would repeat 16 Hadamards per block
+//      in every one of the 48..224 column-block workgroups, 6x the VALU time of the weight decode (tools/gemv_timeline.py).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void glue_rotate_kernel(const half_t* __restrict__ resid, const float* __restrict__ ss_part, const half_t* __restrict__ w, float eps,
+                        NormTargets tg, int m, int hidden)
+{
+    const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
+    const int nblk = hidden >> 7;
+    const int tasks = m * nblk;
+    const int t = blockIdx.x * 8 + hw;
+    const bool act = t < tasks;
+    const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+    const half4_t r = ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
+    const half4_t wv = ((const half4_t*) (w + blk * 128))[l];
+    half4_t sv[3];
+    #pragma unroll
+    for (int i = 0; i < 3; ++i) sv[i] = i < tg.count ? ((const half4_t*) (tg.suh[i] + blk * 128))[l] : half4_t{ 0, 0, 0, 0 };
+    float s2 = 0.0f;
+    for (int b0 = 0; b0 < nblk; b0 += 32)
+    {
+        float v = (b0 + l < nblk) ? ss_part[(size_t) row * nblk + b0 + l] : 0.0f;
+        #pragma unroll
+        for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
+        s2 += v;
+    }
+    const float rmf = __frsqrt_rn(s2 / (float) hidden + eps);
+    half4_t xn = { f2h((float) r.x * (float) wv.x * rmf), f2h((float) r.y * (float) wv.y * rmf),
+                   f2h((float) r.z * (float) wv.z * rmf), f2h((float) r.w * (float) wv.w * rmf) };
+    #pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+        if (i < tg.count)
+        {
+            float sum = in_had_store_v(xn, sv[i], tg.xh[i] + (size_t) row * hidden + blk * 128, l, act);
+            if (act && l == 0 && tg.xsum[i]) tg.xsum[i][(size_t) row * nblk + blk] = sum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // G2: q/k/v epilogue per (row, head), head_dim == 128 == one Hadamard block:
 //     reduce + out-had + fp16 svh -> RoPE (NEOX or GPTJ; sin/cos once per (row, frequency) in LDS) on q and k ->
 //     q fp16 out; k, v -> quantized paged cache append (and optional fp16 copies).
@@ -408,4 +451,23 @@ extern "C" int exl3_glue_resid(const float* y_slabs, int y_S, const float* y_den
     glue_resid_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>(y, (y_slabs || y_dense) ? 1 : 0, y_dense, (const half_t*) svh, (const half_t*) bias,
                                                                         (half_t*) resid, ss_part, m, hidden);
     return exl3_check_launch("glue_resid");
+}
+
+extern "C" int exl3_glue_rotate(const void* resid, const float* ss_part, const void* w, float eps, const void* const* suhs, void* const* xhs,
+                                float* const* xsums, int count, int m, int hidden, void* stream)
+{
+    EXL3_CHECK_ARG(resid && ss_part && w && suhs && xhs, "glue_rotate: null pointer");
+    EXL3_CHECK_ARG(m >= 1 && m <= 16 && hidden % 128 == 0, "glue_rotate: bad dimensions");
+    EXL3_CHECK_ARG(count >= 1 && count <= 3, "glue_rotate: between 1 and 3 consumers");
+    NormTargets tg; tg.count = count;
+    for (int i = 0; i < 3; ++i)
+    {
+        tg.suh[i] = i < count ? (const half_t*) suhs[i] : nullptr;
+        tg.xh[i] = i < count ? (half_t*) xhs[i] : nullptr;
+        tg.xsum[i] = (i < count && xsums) ? xsums[i] : nullptr;
+        EXL3_CHECK_ARG(i >= count || (tg.suh[i] && tg.xh[i]), "glue_rotate: null consumer pointer");
+    }
+    const int tasks = m * (hidden / 128);
+    glue_rotate_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>((const half_t*) resid, ss_part, (const half_t*) w, eps, tg, m, hidden);
+    return exl3_check_launch("glue_rotate");
 }

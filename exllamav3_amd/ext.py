@@ -548,6 +548,13 @@ def exl3_gemv_ex_norm(resid, norm_w, ss_part, eps: float, Bs, Cs, suhs, svhs, m:
     return [int(s) if s else 0 for s in slabs], S.value
 
 
+def glue_rotate(resid, ss_part, w, eps: float, suhs, xhs, m: int, xsums=None):
+    """xh_i = had128(rms_norm(resid) * w * suh_i) for up to 3 consumers (batches above 4 rows; see exl3_glue.hip G1b)."""
+    _dev(resid)
+    _check(_lib.lib().exl3_glue_rotate(_p(resid), _p(ss_part), _p(w), float(eps), _parr(suhs), _parr(xhs), _parr(xsums) if xsums else None,
+                                       len(suhs), m, resid.shape[-1], _stream(resid)))
+
+
 def glue_resid(y_slab, y_S: int, svh, bias, resid, ss_part, m: int, y_dense=None):
     _dev(resid)
     _check(_lib.lib().exl3_glue_resid(y_slab, y_S, _p(y_dense), _p(svh), _p(bias), _p(resid), _p(ss_part), m, resid.shape[-1], _stream(resid)))

@@ -213,11 +213,18 @@ class SyntheticEXL3Llama:
         ROT, DEF = ext.GEMV_IN_ROTATED, ext.GEMV_OUT_DEFERRED
         q2 = self.q.view(bsz, -1)
         ss = self.ss
+        # batches above 4 rows: the norm + input Hadamards run once in glue_rotate instead of in every column-block workgroup
+        rot = bsz > 4
         ext.glue_resid(None, 0, None, None, x, ss, bsz)
         for li, L in enumerate(self.layers):
             lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
-            slabs, S = ext.exl3_gemv_ex_norm(x, L["norm1"], ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh],
-                                             None, bsz, lq.mcg, lq.mul1, DEF, sp["qkv"])
+            if rot:
+                ext.glue_rotate(x, ss, L["norm1"], self.eps, [lq.suh, lk.suh, lv.suh], self.xh3, bsz)
+                slabs, S = ext.exl3_gemv_ex(None, self.xh3, None, [lq.trellis, lk.trellis, lv.trellis], None, None, None,
+                                            bsz, lq.mcg, lq.mul1, ROT | DEF, sp["qkv"])
+            else:
+                slabs, S = ext.exl3_gemv_ex_norm(x, L["norm1"], ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh],
+                                                 None, bsz, lq.mcg, lq.mul1, DEF, sp["qkv"])
             kc, ks = self.kcache[li]
             vc, vs = self.vcache[li]
             ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
@@ -230,8 +237,13 @@ class SyntheticEXL3Llama:
                 lo.bc.run(q2, self.o)
                 be.all_reduce(self.o)
                 ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=self.o)
-            sgu, Sgu = ext.exl3_gemv_ex_norm(x, L["norm2"], ss, self.eps, [lg.trellis, lu.trellis], None, [lg.suh, lu.suh], None,
-                                             bsz, lg.mcg, lg.mul1, DEF, sp["gu"])
+            if rot:
+                ext.glue_rotate(x, ss, L["norm2"], self.eps, [lg.suh, lu.suh], self.xh3[:2], bsz)
+                sgu, Sgu = ext.exl3_gemv_ex(None, self.xh3[:2], None, [lg.trellis, lu.trellis], None, None, None,
+                                            bsz, lg.mcg, lg.mul1, ROT | DEF, sp["gu"])
+            else:
+                sgu, Sgu = ext.exl3_gemv_ex_norm(x, L["norm2"], ss, self.eps, [lg.trellis, lu.trellis], None, [lg.suh, lu.suh], None,
+                                                 bsz, lg.mcg, lg.mul1, DEF, sp["gu"])
             ext.glue_act(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz)
             if self.tp == 1:
                 sd, Sd = ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF, sp["down"])

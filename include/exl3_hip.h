@@ -174,6 +174,11 @@ int exl3_gemv_ex_norm(const void* resid, const void* norm_w, const float* ss_par
 int exl3_glue_resid(const float* y_slabs, int y_S, const float* y_dense, const void* svh, const void* bias, void* resid,
                     float* ss_part, int m, int hidden, void* stream);
 
+/* glue 1b (batches above 4 rows): xh_i = had128(rms_norm(resid) * w * suh_i) for up to 3 consumers from resid + ss_part (exl3_glue_resid);
+ * distributed over (row, block); the consumer GEMVs then run with EXL3_GEMV_IN_ROTATED.  xsums optional. */
+int exl3_glue_rotate(const void* resid, const float* ss_part, const void* w, float eps, const void* const* suhs, void* const* xhs,
+                     float* const* xsums, int count, int m, int hidden, void* stream);
+
 /* Diagnostics only: copy [byte_offset, byte_offset + nbytes) of the per-device split-k workspace to dst (tools/gemv_timeline.py). */
 int exl3_debug_copy_workspace(void* dst, int64_t byte_offset, int64_t nbytes, void* stream);
 

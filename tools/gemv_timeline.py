@@ -11,7 +11,7 @@ from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
 
 dev = torch.device("cuda:0")
 model = SyntheticEXL3Llama(SHAPES["llama-3.1-8b"], K=4, cb=2, device=dev, kv_bits=4, layers=2)
-model.alloc_state(1)
+model.alloc_state(int(os.environ.get("BSZ", "1")))
 model.decode_step_fused(); torch.cuda.synchronize()
 calls = model.gemv_calls("glue")
 names = ["qkv", "o", "gate_up", "down"]
