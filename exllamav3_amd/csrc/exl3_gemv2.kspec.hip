@@ -150,7 +150,13 @@ void exl3_gemv2_kernel(const GemvArgs a)
     // cooperatively (one (block, row) task per 32-lane half-wave), instead of every wave rotating every block it touches: at batch 16 the
     // per-wave version spent 6x more VALU time on input Hadamards than on decoding weights (tools/gemv_timeline.py).
     const int units = nb * (8 / G2_PF);
-    const int nunits_w = wave < units ? (units - wave + nwv - 1) / nwv : 0;     // units of this wave
+    // unit i of this wave = ubase + i * ustride.  One chunk (the usual case: the whole slice's fragments fit the LDS budget): contiguous
+    // ranges per wave, [units*w/nwv, units*(w+1)/nwv); several chunks: unit u belongs to wave u % nwv so that every wave has rows in
+    // every chunk.
+    const bool one_chunk = a.chunk_blocks >= nb;
+    const int ubase = one_chunk ? (units * wave) / nwv : wave;
+    const int ustride = one_chunk ? 1 : nwv;
+    const int nunits_w = one_chunk ? (units * (wave + 1)) / nwv - ubase : (wave < units ? (units - wave + nwv - 1) / nwv : 0);
 
     // LDS carve: fragments of one chunk [blk][tile row 8][row m][AH halves] | partials [nwv][MR][128] fp32 + per-wave row sums |
     //            tile-row sums [blk * 8][m] fp32 (RAW) | 1/rms per row [16] fp32 (NORM)
@@ -181,7 +187,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const uint32_t* __restrict__ strip = Bm + ((size_t) (k0s >> 4) * tiles_n + (size_t) cbl * 8) * NW + (size_t) lane * K;
     const size_t row_stride = (size_t) tiles_n * NW;
     const int prev_lane_addr = ((lane & ~7) | ((lane - 1) & 7)) << 2;   // ds_bpermute byte address
-    const int last_unit = nunits_w > 0 ? wave + (nunits_w - 1) * nwv : 0;
+    const int last_unit = nunits_w > 0 ? ubase + (nunits_w - 1) * ustride : 0;
 
     float4_t acc_c[NG], acc_d[NG];
     #pragma unroll
@@ -191,7 +197,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
     if (nunits_w > 0)
     {
         #pragma unroll
-        for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) (G2_PF * wave + u) * row_stride);
+        for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) (G2_PF * ubase + u) * row_stride);
     }
     G2_T(1);
 
@@ -333,11 +339,11 @@ void exl3_gemv2_kernel(const GemvArgs a)
         if (c0 == 0) { G2_T(2); }
 
         const int row_end = (c0 + cnt) * 8;                             // slice-local tile row bound of the chunk
+        const int u_end = min(nunits_w, (G2_PF * ubase < row_end) ? ((row_end / G2_PF - 1 - ubase) / ustride + 1) : 0);   // this wave's first unit index beyond the chunk
         if constexpr (RAW)
         {
             // sum(x) over the tile rows this wave streams in this chunk, per activation row of the half-wave: lane i takes the wave's
             // i-th unit of the chunk, then a 32-lane butterfly (outside the streaming loop: no LDS wait on its critical path)
-            const int u_end = min(nunits_w, (G2_PF * wave < row_end) ? ((row_end / G2_PF - 1 - wave) / nwv + 1) : 0);   // first unit index beyond the chunk
             #pragma unroll
             for (int p = 0; p < 2 * NG; ++p)
             {
@@ -347,7 +353,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
                     float v = 0.0f;
                     for (int i = ui + l32; i < u_end; i += 32)
                     {
-                        const float* tsr = tsum + (size_t) (G2_PF * (wave + i * nwv) - c0 * 8) * m + rowp;
+                        const float* tsr = tsum + (size_t) (G2_PF * (ubase + i * ustride) - c0 * 8) * m + rowp;
                         v += tsr[0] + tsr[m];
                     }
                     #pragma unroll
@@ -358,12 +364,11 @@ void exl3_gemv2_kernel(const GemvArgs a)
         }
 
         // ---- pure streaming loop over this wave's units inside the chunk
-        for (; ui < nunits_w; ++ui)
+        for (; ui < u_end; ++ui)                                       // plain counted loop: an early exit made the compiler drain vmcnt every iteration
         {
-            const int unit = wave + ui * nwv;
+            const int unit = ubase + ui * ustride;
             const int row0 = G2_PF * unit;
-            if (row0 >= row_end) break;
-            const int nxt = min(unit + nwv, last_unit);                // next unit of this wave (clamped: a harmless reload at the end)
+            const int nxt = min(unit + ustride, last_unit);                // next unit of this wave (clamped: a harmless reload at the end)
             #pragma unroll
             for (int u = 0; u < G2_PF; ++u)
             {
