@@ -648,7 +648,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         {
             const int ng = mp <= 4 ? 1 : (mp <= 8 ? 2 : 4);
             int nwv = 16 / ng;                                   // partial-sum LDS: nwv * 4*ng rows * 512 B <= 32 KB
-            const int units = bps * 4;                           // the waves split the slice's tile rows in units of 2 (G2_PF)
+            const int units = bps * (8 / G2_PF);                 // the waves split the slice's tile rows in units of G2_PF
             // measured on MI355X (tools/prof_tail.py, batch 1): one wave per Hadamard block of the slice, but at least 4 waves --
             // more waves than that do not help (the kernel is VALU / fixed-latency bound), fewer starve the short slices
             if (nwv > (bps > 4 ? bps : 4)) nwv = bps > 4 ? bps : 4;

@@ -29,7 +29,6 @@
 #include "exl3_gemv2_tail.cuh"
 
 #include <type_traits>
-#define G2_PF 2
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f)
