@@ -313,7 +313,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "decode tok/s, Llama-3.1-8B EXL3 4.0bpw hot path (all quantized linears + RMSNorm + RoPE + KV-quant), bs=%d" % args.batch,
+            "metric": "decode tok/s, %s EXL3 %d.0bpw hot path (all quantized linears + RMSNorm + RoPE + KV-quant), bs=%d" % (
+                {"llama-3.1-8b": "Llama-3.1-8B", "llama-3.2-1b": "Llama-3.2-1B", "llama-3.1-70b": "Llama-3.1-70B"}.get(shape.name, shape.name), args.bits, args.batch),
             "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",

@@ -224,7 +224,8 @@ struct QkvArgs
     const int32_t* positions;                               // [m] absolute position of each row's token
     uint32_t* k_cache; half_t* k_scales; uint32_t* v_cache; half_t* v_scales;      // paged quantized cache of this layer (optional)
     const int32_t* block_table; int blocks_per_seq; int page_size;
-    int m, hq, hkv, rope_mode;
+    int m, hq, hkv, rope_mode;                              // hq / hkv count 128-wide blocks (= heads at head_dim 128, head pairs at 64)
+    int hd;
     float attn_factor;
 };
 
@@ -244,12 +245,13 @@ void glue_qkv_kernel(QkvArgs a)
     const SlabRef& sr = kind == 0 ? a.sq : (kind == 1 ? a.sk : a.sv);
     const half_t* svh = (kind == 0 ? a.svh_q : (kind == 1 ? a.svh_k : a.svh_v)) + hi * 128;
     const float4_t ysum = slab_sum(sr, hi, row, a.m, l);            // slab loads in flight while the sin/cos table is built
-    for (int i = tid; i < a.m * 64; i += blockDim.x)
+    const int nfreq = a.hd >> 1;                                        // 64 (head_dim 128) or 32 (head_dim 64: two heads per block)
+    for (int i = tid; i < a.m * nfreq; i += blockDim.x)
     {
-        int rw = i >> 6, f = i & 63;
+        int rw = i / nfreq, f = i % nfreq;
         float sn, cs;
         sincosf(a.inv_freq[f] * (float) a.positions[rw], &sn, &cs);
-        sn_s[i] = sn * a.attn_factor; cs_s[i] = cs * a.attn_factor;
+        sn_s[rw * 64 + f] = sn * a.attn_factor; cs_s[rw * 64 + f] = cs * a.attn_factor;
     }
     __syncthreads();
     float h0, h1, h2, h3;
@@ -262,11 +264,14 @@ void glue_qkv_kernel(QkvArgs a)
         float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
         if (a.rope_mode == 2)
         {
-            // NEOX: pairs (d, d+64): partner lane l ^ 16, frequency index d & 63
-            float p0 = xor_lane(v0, 16), p1 = xor_lane(v1, 16), p2 = xor_lane(v2, 16), p3 = xor_lane(v3, 16);
-            const int f = 4 * (l & 15);
+            // NEOX: pairs (d, d + hd/2) inside a head: partner lane l ^ (hd/8), frequency index d mod hd/2
+            const int ph = a.hd >> 3;                                   // 16 or 8 lanes
+            float p0, p1, p2, p3;
+            if (ph == 16) { p0 = xor_lane(v0, 16); p1 = xor_lane(v1, 16); p2 = xor_lane(v2, 16); p3 = xor_lane(v3, 16); }
+            else          { p0 = xor_lane(v0, 8);  p1 = xor_lane(v1, 8);  p2 = xor_lane(v2, 8);  p3 = xor_lane(v3, 8); }
+            const int f = 4 * (l & (ph - 1));
             const float* sn = sn_s + row * 64 + f; const float* cs = cs_s + row * 64 + f;
-            const bool upper = l >= 16;
+            const bool upper = (l & ph) != 0;
             // lower half: r1 = v1*cos - v2*sin ; upper half: r2 = v2*cos + v1*sin   (v1 = lower element, v2 = upper element)
             float r0 = upper ? v0 * cs[0] + p0 * sn[0] : v0 * cs[0] - p0 * sn[0];
             float r1 = upper ? v1 * cs[1] + p1 * sn[1] : v1 * cs[1] - p1 * sn[1];
@@ -276,8 +281,9 @@ void glue_qkv_kernel(QkvArgs a)
         }
         else
         {
-            // GPTJ: pairs (2i, 2i+1) both in this lane: frequencies 2l, 2l+1
-            const float* sn = sn_s + row * 64 + 2 * l; const float* cs = cs_s + row * 64 + 2 * l;
+            // GPTJ: pairs (2i, 2i+1) both in this lane: frequencies 2l', 2l'+1 with l' the lane inside the head
+            const int lf = 2 * (l & ((a.hd >> 2) - 1));
+            const float* sn = sn_s + row * 64 + lf; const float* cs = cs_s + row * 64 + lf;
             y = half4_t{ f2h(v0 * cs[0] - v1 * sn[0]), f2h(v1 * cs[0] + v0 * sn[0]),
                          f2h(v2 * cs[1] - v3 * sn[1]), f2h(v3 * cs[1] + v2 * sn[1]) };
         }
@@ -382,7 +388,8 @@ extern "C" int exl3_glue_qkv(const float* sq, const float* sk, const float* sv, 
                              float attn_factor, void* stream)
 {
     EXL3_CHECK_ARG(sq && sk && sv && svh_q && svh_k && svh_v && q_out && inv_freq && positions, "glue_qkv: null pointer");
-    EXL3_CHECK_ARG(head_dim == 128, "glue_qkv: head_dim must be 128 (one Hadamard block per head)");
+    EXL3_CHECK_ARG(head_dim == 128 || head_dim == 64, "glue_qkv: head_dim must be 128 or 64 (one or two heads per Hadamard block)");
+    EXL3_CHECK_ARG((heads_q * head_dim) % 128 == 0 && (heads_kv * head_dim) % 128 == 0, "glue_qkv: heads * head_dim must be a multiple of 128");
     EXL3_CHECK_ARG(m >= 1 && m <= 16, "glue_qkv: 1 <= m <= 16");
     EXL3_CHECK_ARG(rope_mode == 1 || rope_mode == 2, "glue_qkv: rope_mode must be 1 (GPTJ) or 2 (NEOX)");
     EXL3_CHECK_ARG(!k_cache || (k_scales && v_cache && v_scales && block_table && page_size > 0), "glue_qkv: incomplete cache arguments");
@@ -394,8 +401,8 @@ extern "C" int exl3_glue_qkv(const float* sq, const float* sk, const float* sv, 
     a.inv_freq = inv_freq; a.positions = positions;
     a.k_cache = (uint32_t*) k_cache; a.k_scales = (half_t*) k_scales; a.v_cache = (uint32_t*) v_cache; a.v_scales = (half_t*) v_scales;
     a.block_table = block_table; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size > 0 ? page_size : 256;
-    a.m = m; a.hq = heads_q; a.hkv = heads_kv; a.rope_mode = rope_mode; a.attn_factor = attn_factor;
-    int tasks = m * (heads_q + 2 * heads_kv);
+    a.m = m; a.hq = heads_q * head_dim / 128; a.hkv = heads_kv * head_dim / 128; a.hd = head_dim; a.rope_mode = rope_mode; a.attn_factor = attn_factor;
+    int tasks = m * (a.hq + 2 * a.hkv);
     dim3 grid((tasks + 7) / 8);
     hipStream_t st = (hipStream_t) stream;
     int kb = k_cache ? k_bits : 8, vb = k_cache ? v_bits : 8;

@@ -338,3 +338,32 @@ def test_prefill_reconstruct_ahead_is_bit_identical_to_inline(dev):
         assert torch.equal(got, ref), f"rep {rep}"
         for a, b in zip(model.pf_cache, kv_ref):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("bsz", [1, 3, 9])
+def test_fused_pipeline_head_dim_64(dev, bsz):
+    """Llama-3.2-1B geometry (head_dim 64: two heads per Hadamard block) through the fused pipeline: glue_qkv's RoPE pairs (d, d + 32) and
+    the KV groups must land exactly where the op-by-op pipeline puts them; logits against the oracle."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    shape = LlamaShape("tiny64", 256, 512, 2, 8, 4, 64, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(bsz, pos=777)
+    lu = model.decode_step().float().cpu().numpy().copy()
+    qu = model.q.clone()
+    ku = [(c.clone(), s.clone()) for c, s in model.kcache + model.vcache]
+    for c, s in model.kcache + model.vcache:
+        c.zero_(); s.zero_()
+    lf = model.decode_step_fused().float().cpu().numpy()
+    rms = np.sqrt((lu ** 2).mean())
+    assert np.abs(lf - lu).max() / rms < 1e-2
+    for (c, s), (c0, s0) in zip(model.kcache + model.vcache, ku):
+        assert bool(((s != 0) == (s0 != 0)).all())                        # same slots written
+        d1 = torch.empty((c.shape[0] * c.shape[1], c.shape[2] // 4 * 32), dtype=torch.half, device=dev); d0 = torch.empty_like(d1)
+        ext.dequant_cache_cont(c.view(d1.shape[0], -1), s.view(d1.shape[0], -1), d1)
+        ext.dequant_cache_cont(c0.view(d1.shape[0], -1), s0.view(d1.shape[0], -1), d0)
+        assert float((d1.float() - d0.float()).abs().max()) < 0.35
+    if bsz <= 3:
+        ref = _oracle_decode(model, _np(model.x0))
+        assert np.abs(lf - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
