@@ -367,3 +367,33 @@ def test_fused_pipeline_head_dim_64(dev, bsz):
     if bsz <= 3:
         ref = _oracle_decode(model, _np(model.x0))
         assert np.abs(lf - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+
+
+@pytest.mark.parametrize("m", [1, 5, 8])
+def test_in_gemv_rmsnorm_hidden_8192(dev, m):
+    """Llama-70B width (64 Hadamard blocks per row: more than one 32-lane pass over the per-block sums of squares): glue_resid +
+    GEMV_IN_NORM and glue_resid + glue_rotate + rotated GEMV against glue_norm + rotated GEMV, bit for bit."""
+    from exllamav3_amd import ext
+    k, n, K = 8192, 256, 3
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rng = np.random.default_rng(m)
+    tr, suh, svh = o.synth_linear(k, n, K, realistic=True)
+    ttr, tsu, tsv = T(tr), T(suh), T(svh)
+    w = T((1 + 0.1 * rng.standard_normal(k)).astype(np.float16))
+    r0 = T((rng.standard_normal((m, k)) * 2.5).astype(np.float16))
+    xh = torch.empty((m, k), dtype=torch.half, device=dev); xs = torch.empty((m, k // 128), dtype=torch.float32, device=dev)
+    ext.glue_norm(None, 0, None, None, r0, w, 1e-5, [tsu], [xh], [xs], m)
+    y0 = torch.empty((m, n), dtype=torch.half, device=dev)
+    ext.exl3_gemv_ex(None, [xh], [xs], [ttr], [y0], None, [tsv], m, False, False, ext.GEMV_IN_ROTATED)
+    ss = torch.empty((m, k // 128), dtype=torch.float32, device=dev)
+    ext.glue_resid(None, 0, None, None, r0, ss, m)
+    y1 = torch.empty_like(y0)
+    ext.exl3_gemv_ex_norm(r0, w, ss, 1e-5, [ttr], [y1], [tsu], [tsv], m, False, False, 0)
+    xh2 = torch.empty_like(xh)
+    ext.glue_rotate(r0, ss, w, 1e-5, [tsu], [xh2], m)
+    y2 = torch.empty_like(y0)
+    ext.exl3_gemv_ex(None, [xh2], None, [ttr], [y2], None, [tsv], m, False, False, ext.GEMV_IN_ROTATED)
+    assert torch.equal(xh, xh2)
+    assert torch.equal(y0, y1) and torch.equal(y0, y2)
+    ref = o.linear_forward(o.rms_norm(r0.cpu().numpy(), w.cpu().numpy(), 1e-5), tr, suh, svh, K, 0).astype(np.float32)
+    assert np.abs(y1.float().cpu().numpy() - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
