@@ -1,0 +1,85 @@
+// routing_std: MoE router for one token step.  scores = hidden @ gate (fp32 accumulate, fp16 out), top-K experts by logit
+// (descending, ties to the lower index), weights = softmax over the K selected logits (fp16), optional bias on the logits.
+// reference: exllamav3_ext/routing.cu:457-590 (routing_std_topk_kernel) + routing_gemv :955-1010; python seam modules/block_sparse_mlp.py:51-93.
+// One workgroup per row; E <= 512, K <= 16.  This is the caller of the indexed exl3_mgemm.
+#include "exl3_common.cuh"
+#include "exl3_api_internal.h"
+
+#define ROUTING_MAX_EXPERTS 512
+#define ROUTING_MAX_K 16
+
+__global__ __launch_bounds__(256)
+void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restrict__ gate, const half_t* __restrict__ bias,
+                        half_t* __restrict__ scores, int64_t* __restrict__ topk_indices, half_t* __restrict__ topk_weights,
+                        int H, int E, int K)
+{
+    __shared__ float logit_s[ROUTING_MAX_EXPERTS];
+    __shared__ float sel_logit[ROUTING_MAX_K];
+    __shared__ int sel_idx[ROUTING_MAX_K];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const half_t* x = hidden + (size_t) row * H;
+
+    // scores: one wave per expert (round robin), lanes stride over the hidden dimension; gate is [H][E] row-major
+    for (int e = wave; e < E; e += 4)
+    {
+        float acc = 0.0f;
+        for (int h = lane; h < H; h += 64) acc = __builtin_fmaf((float) x[h], (float) gate[(size_t) h * E + e], acc);
+        #pragma unroll
+        for (int i = 1; i < 64; i <<= 1) acc += xor_lane(acc, i);
+        if (lane == 0)
+        {
+            const half_t s = f2h(acc);                     // the reference materialises fp16 scores and routes on them
+            scores[(size_t) row * E + e] = s;
+            logit_s[e] = (float) s + (bias ? (float) bias[e] : 0.0f);
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+
+    // top-K by repeated arg-max over the wave (candidates e = lane + 64 j); ties go to the lower expert index
+    uint64_t taken_lo = 0;                                 // bit j: candidate j of this lane already selected (E <= 512 -> j < 8)
+    float max_logit = -1.0e30f;
+    for (int k = 0; k < K; ++k)
+    {
+        float best = -1.0e30f; int best_e = 0x7fffffff;
+        for (int j = 0; lane + 64 * j < E; ++j)
+        {
+            const int e = lane + 64 * j;
+            const float v = logit_s[e];
+            if (!((taken_lo >> j) & 1) && (v > best || (v == best && e < best_e))) { best = v; best_e = e; }
+        }
+        #pragma unroll
+        for (int i = 1; i < 64; i <<= 1)
+        {
+            const float ov = xor_lane(best, i); const int oe = xor_lane(best_e, i);
+            if (ov > best || (ov == best && oe < best_e)) { best = ov; best_e = oe; }
+        }
+        if (k == 0) max_logit = best;
+        if ((best_e & 63) == lane) taken_lo |= 1ull << (best_e >> 6);
+        if (lane == 0) { sel_logit[k] = best; sel_idx[k] = best_e; }
+    }
+    // softmax over the selected logits
+    float ev = lane < K ? expf(sel_logit[lane] - max_logit) : 0.0f;
+    float sum = ev;
+    #pragma unroll
+    for (int i = 1; i < 64; i <<= 1) sum += xor_lane(sum, i);
+    ev /= (sum + 1e-20f);
+    if (lane < K)
+    {
+        topk_indices[(size_t) row * K + lane] = (int64_t) sel_idx[lane];
+        topk_weights[(size_t) row * K + lane] = f2h(ev);
+    }
+}
+
+extern "C" int exl3_routing_std(const void* hidden, const void* gate, const void* bias, void* scores, int64_t* topk_indices, void* topk_weights,
+                                int bsz, int hidden_size, int num_experts, int K, void* stream)
+{
+    EXL3_CHECK_ARG(hidden && gate && scores && topk_indices && topk_weights, "routing_std: null pointer");
+    EXL3_CHECK_ARG(num_experts >= 1 && num_experts <= ROUTING_MAX_EXPERTS, "Too many experts");
+    EXL3_CHECK_ARG(K >= 1 && K <= ROUTING_MAX_K, "Too many experts per token");
+    EXL3_CHECK_ARG(K <= num_experts, "K cannot exceed number of experts");
+    if (bsz == 0) return EXL3_OK;
+    routing_std_kernel<<<bsz, 256, 0, (hipStream_t) stream>>>((const half_t*) hidden, (const half_t*) gate, (const half_t*) bias, (half_t*) scores,
+                                                             topk_indices, (half_t*) topk_weights, hidden_size, num_experts, K);
+    return exl3_check_launch("routing_std");
+}

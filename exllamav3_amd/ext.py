@@ -612,3 +612,17 @@ class BC_GatedMLP:
         exl3_gemv_ex(None, [xh_n], [xs], [dn.trellis], [d2], None, [dn.svh], m, dn.mcg, dn.mul1, GEMV_IN_ROTATED, c_fp32=(d.dtype == torch.float))
         if dn.bias is not None:
             add(d2, dn.bias.view(1, -1).expand(m, -1).contiguous() if m > 1 else dn.bias)
+
+
+def routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_scale=None, gate_t=None, bias=None):
+    """routing.cu:955-1010 (same argument order): scores = hidden @ gate, top-K by logit, softmax over the selected logits."""
+    _dev(hidden)
+    _req(per_expert_scale is None, "routing_std: per_expert_scale is outside this build")
+    _req(hidden.dtype == torch.half and gate.dtype == torch.half and scores.dtype == torch.half, "routing_std: hidden, gate, scores must be float16")
+    _req(topk_indices.dtype == torch.long and topk_weights.dtype == torch.half, "routing_std: topk_indices int64, topk_weights float16")
+    _req(gate.dim() == 2 and gate.shape[0] == hidden.shape[-1] and gate.shape[1] == scores.shape[-1], "routing_std: gate must be (hidden, experts)")
+    _req(topk_indices.shape == topk_weights.shape and scores.shape[0] == topk_indices.shape[0], "routing_std: shape mismatch")
+    _req(hidden.is_contiguous() and gate.is_contiguous() and scores.is_contiguous(), "routing_std: tensors must be contiguous")
+    bsz = scores.shape[0]
+    _check(_lib.lib().exl3_routing_std(_p(hidden), _p(gate), _p(bias), _p(scores), _p(topk_indices), _p(topk_weights), bsz, hidden.shape[-1],
+                                       scores.shape[1], topk_indices.shape[1], _stream(hidden)))

@@ -138,6 +138,12 @@ int exl3_mgemm_indexed(const void* A, int bszm_in, const void* tbl_B, const void
                        const int64_t* indices, const void* weights, int bszm, void* C, int m, int k, int n, int K, int cb, int c_fp32,
                        int min_index, int max_index, int num_tokens, void* stream);
 
+/* routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_scale, gate_t, bias)   routing.cu:955-1010, kernel :457-590
+ * scores[bsz][E] fp16 = hidden[bsz][H] @ gate[H][E]; top-K logits (descending, ties to the lower index) -> topk_indices int64 [bsz][K],
+ * topk_weights fp16 [bsz][K] = softmax over the K selected logits.  bias (fp16 [E], optional) is added to the logits before selection. */
+int exl3_routing_std(const void* hidden, const void* gate, const void* bias, void* scores, int64_t* topk_indices, void* topk_weights,
+                     int bsz, int hidden_size, int num_experts, int K, void* stream);
+
 /* ---- GEMV launches with an in-kernel tail epilogue (decode, m <= 16) ------------------------------------------------------
  * The workgroup that finishes a 128-column block last (device-memory arrival ticket) reduces the split-k partials of that
  * block and runs the sublayer boundary the reference executes as separate graph nodes between two exl3_gemm calls

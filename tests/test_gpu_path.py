@@ -397,3 +397,27 @@ def test_in_gemv_rmsnorm_hidden_8192(dev, m):
     assert torch.equal(y0, y1) and torch.equal(y0, y2)
     ref = o.linear_forward(o.rms_norm(r0.cpu().numpy(), w.cpu().numpy(), 1e-5), tr, suh, svh, K, 0).astype(np.float32)
     assert np.abs(y1.float().cpu().numpy() - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
+
+
+@pytest.mark.parametrize("cb", [0, 2])
+@pytest.mark.parametrize("tokens", [1, 3])
+def test_moe_block_matches_oracle(dev, cb, tokens):
+    """Router (routing_std) + indexed / weighted exl3_mgemm composition (moe_path.SyntheticEXL3MoE) against the oracle: same experts
+    selected, weights within fp16, output within 2e-2 RMS."""
+    from exllamav3_amd.moe_path import SyntheticEXL3MoE
+    moe = SyntheticEXL3MoE(256, 384, experts=6, top_k=2, K=4, cb=cb, device=dev, seed=5)
+    x = torch.randn((tokens, 256), device=dev, generator=torch.Generator(device=dev).manual_seed(tokens)).half()
+    y = moe.forward(x).float().cpu().numpy()
+    xs = x.cpu().numpy()
+    scores, sel, w = o.routing_std(xs, moe.router.cpu().numpy(), 2)
+    assert np.abs(moe.scores.float().cpu().numpy() - scores.astype(np.float32)).max() < 2e-3 * max(1.0, float(np.abs(scores).max()))
+    assert np.array_equal(moe.sel.cpu().numpy(), sel)
+    assert np.abs(moe.w.float().cpu().numpy() - w.astype(np.float32)).max() < 2e-3
+    ref = np.zeros((tokens, 256), dtype=np.float32)
+    for t in range(tokens):
+        for j in range(2):
+            e = int(sel[t, j])
+            g = _lin(moe.gate[e], xs[t:t + 1]).astype(np.float32); u = _lin(moe.up[e], xs[t:t + 1]).astype(np.float32)
+            a = (g / (1 + np.exp(-g)) * u).astype(np.float16)
+            ref[t] += float(w[t, j]) * _lin(moe.down[e], a, out_fp32=True)[0]
+    assert np.abs(y - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
