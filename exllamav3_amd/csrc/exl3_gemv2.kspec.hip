@@ -89,7 +89,7 @@ template <int K, int CB, int VAR, int NG, int MODE>
 #ifdef G2_ABL_ILP
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 #else
-__global__ __launch_bounds__(1024 / NG) __attribute__((amdgpu_waves_per_eu(NG == 4 ? 3 : NG == 2 ? 4 : (K >= 5 && MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1) ? 5 : ((K >= 5 || (MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || CB != EXL3_CB_MUL1) ? 7 : 8)))))
+__global__ __launch_bounds__(1024 / NG) __attribute__((amdgpu_waves_per_eu(NG == 4 ? 3 : NG == 2 ? 4 : G2_PF > 2 ? 6 : (K >= 5 && MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1) ? 5 : ((K >= 5 || (MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || CB != EXL3_CB_MUL1) ? 7 : 8)))))
 #endif
 void exl3_gemv2_kernel(const GemvArgs a)
 {
@@ -353,7 +353,8 @@ void exl3_gemv2_kernel(const GemvArgs a)
                     for (int i = ui + l32; i < u_end; i += 32)
                     {
                         const float* tsr = tsum + (size_t) (G2_PF * (ubase + i * ustride) - c0 * 8) * m + rowp;
-                        v += tsr[0] + tsr[m];
+                        #pragma unroll
+                        for (int rr = 0; rr < G2_PF; ++rr) v += tsr[rr * m];
                     }
                     #pragma unroll
                     for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);

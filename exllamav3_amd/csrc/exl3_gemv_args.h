@@ -3,7 +3,9 @@
 #include "exl3_common.cuh"
 
 #define GEMV_THREADS 256
-#define G2_PF 2             // gen 2: tile rows per work unit = depth of the per-wave weight-row register ring (the kernel assumes 2)
+#ifndef G2_PF
+#define G2_PF 2             // gen 2: tile rows per work unit = depth of the per-wave weight-row register ring (2 or 4)
+#endif
 #define GEMV_IN_ROTATED   1   // the input Hadamard was applied by the producer (glue kernel): mat[i].xh / xsum
 #define GEMV_OUT_DEFERRED 2   // write raw rotated-basis partial slabs [colblock][S][m][128] fp32; a glue kernel finishes
 #define GEMV_IN_NORM      4   // A is the residual stream: the kernel applies RMSNorm (norm_w, per-block sums of squares ss_part, eps) before the input Hadamard
