@@ -110,6 +110,7 @@ def _declare(l):
     sig("exl3_gemv_qkv", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_rope_table", vp, vp, f32, i32, vp, vp, vp)
     sig("exl3_debug_copy_workspace", vp, i64, i64, vp)
+    sig("exl3_gemv_ex_act", vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
     sig("exl3_routing_std", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
     sig("exl3_glue_rotate", vp, vp, vp, f32, PP, PP, PP, i32, i32, i32, vp)
     sig("exl3_mgemm_indexed", vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp)

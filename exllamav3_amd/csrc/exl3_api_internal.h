@@ -20,9 +20,12 @@ struct Exl3DevCtx
     int    num_cus;
     float* workspace;          // EXL3_WORKSPACE_BYTES
     uint32_t* tickets;         // zero-initialised, every kernel leaves it zeroed
+    int    ws_toggle;          // slab-writing launches alternate between two workspace regions: a launch may read its predecessor's slabs
+                               // (GEMV ACT mode) while its own workgroups already write theirs
 };
 #define EXL3_WORKSPACE_BYTES (64ll << 20)
 #define EXL3_NUM_TICKETS 65536
+#define EXL3_WS_REGION_BYTES (24ll << 20)     // two slab regions [0, 24) and [24, 48) MiB; diagnostics builds use the tail
 
 // Returns nullptr (and sets the error) if the context cannot be created (e.g. stream capturing before exl3_init).
 Exl3DevCtx* exl3_get_ctx(hipStream_t stream);

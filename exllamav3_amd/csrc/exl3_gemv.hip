@@ -538,8 +538,11 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                      const void* const* biases, const int* ns, int count, int m, int k, int K, int cb, int c_fp32,
                      int force_split, hipStream_t st, int flags = 0, const void* const* xhs = nullptr, const float* const* xsums = nullptr,
                      float** slabs_out = nullptr, int* S_out = nullptr, const GemvEpi* epi = nullptr,
-                     const void* norm_w = nullptr, const float* ss_part = nullptr, float eps = 0.0f, const GemvTable* tbl = nullptr)
+                     const void* norm_w = nullptr, const float* ss_part = nullptr, float eps = 0.0f, const GemvTable* tbl = nullptr,
+                     const float* act_g = nullptr, const float* act_u = nullptr, int act_S = 0, const void* act_svh_g = nullptr,
+                     const void* act_svh_u = nullptr)
 {
+    if (act_g) flags |= GEMV_IN_ACT;
     if (epi) flags |= GEMV_OUT_DEFERRED;
     const bool deferred = (flags & GEMV_OUT_DEFERRED) != 0, rotated = (flags & GEMV_IN_ROTATED) != 0;
     EXL3_CHECK_ARG(!(deferred || rotated) || m <= 16, "exl3_gemv_ex: at most 16 rows");
@@ -553,7 +556,10 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     EXL3_CHECK_ARG(cb >= 0 && cb <= 2, "exl3_gemm: bad codebook");
     EXL3_CHECK_ARG(k % 128 == 0 && k > 0, "exl3_gemm: k must be divisible by 128");
     EXL3_CHECK_ARG(m >= 1, "exl3_gemm: m must be >= 1");
-    EXL3_CHECK_ARG(A || rotated, "exl3_gemm: null A");
+    const bool in_act = (flags & GEMV_IN_ACT) != 0;
+    EXL3_CHECK_ARG(!in_act || (act_g && act_u && act_svh_g && act_svh_u && act_S >= 1 && !rotated && count == 1 && m <= 4),
+                   "exl3_gemv_ex_act: needs gate / up slabs + svh, one matrix, m <= 4");
+    EXL3_CHECK_ARG(A || rotated || in_act, "exl3_gemm: null A");
     int total_cb = 0;
     if (tbl)
     {
@@ -575,7 +581,9 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         const int mp = (m - m0) < 16 ? (m - m0) : 16;
         GemvArgs args;
         memset((void*) &args, 0, sizeof(args));
-        const int gen = (deferred || rotated || in_norm || tbl) ? 2 : gemv_gen();
+        const int gen = (deferred || rotated || in_norm || tbl || in_act) ? 2 : gemv_gen();
+        args.act_g = act_g; args.act_u = act_u; args.act_S = act_S;
+        args.act_svh_g = (const half_t*) act_svh_g; args.act_svh_u = (const half_t*) act_svh_u;
         args.norm_w = (const half_t*) norm_w; args.ss_part = ss_part; args.eps = eps;
         int fs = force_split;
         if (deferred && fs == 0)
@@ -613,7 +621,6 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             args.mat[i].C = Cs ? Cs[i] : nullptr;
             args.mat[i].xh = xhs ? (const half_t*) xhs[i] : nullptr;
             args.mat[i].xsum = xsums ? xsums[i] : nullptr;
-            if (slabs_out) slabs_out[i] = ctx->workspace + wso;
             args.mat[i].n = ns[i];
             args.mat[i].cb_first = cbf;
             args.mat[i].ws_offset = (int) wso;
@@ -630,11 +637,19 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             EXL3_CHECK_ARG(total_cb + 1 <= EXL3_NUM_TICKETS, "exl3_gemv: too many column blocks for the ticket table");
             EXL3_CHECK_ARG(S <= 128, "exl3_gemv: split too deep for the tail epilogue");
         }
-        EXL3_CHECK_ARG((S == 1 && !deferred) || wso * 4 <= EXL3_WORKSPACE_BYTES, "exl3_gemm: split-k workspace too small");
+        EXL3_CHECK_ARG((S == 1 && !deferred) || wso * 4 <= EXL3_WS_REGION_BYTES, "exl3_gemm: split-k workspace too small");
+        float* ws_region = ctx->workspace;
+        if (S > 1 || deferred)
+        {
+            ws_region += ctx->ws_toggle ? EXL3_WS_REGION_BYTES / 4 : 0;
+            ctx->ws_toggle ^= 1;
+            if (slabs_out) for (int i = 0; i < (tbl ? 0 : count); ++i) slabs_out[i] = ws_region + args.mat[i].ws_offset;
+        }
         if (S_out) *S_out = S;
         args.flags = flags;
         args.A = (const half_t*) A + (size_t) m0 * k;
-        args.workspace = ctx->workspace;
+        args.workspace = ws_region;
+        args.ws_debug = ctx->workspace + (48ll << 20) / 4;
         args.num_mats = tbl ? 1 : count;
         args.m = mp;
         args.k = k;
@@ -851,4 +866,19 @@ extern "C" int exl3_mgemm_indexed(const void* A, int bszm_in, const void* tbl_B,
         return exl3_check_launch("exl3_mgemm slot reduce") < 0 ? EXL3_ERR_HIP : rc;
     }
     return rc;
+}
+
+// down_proj whose input a = fp16(silu(g) * u) is finished from the gate / up launch's deferred slabs while the activation fragments are
+// built (m <= 4): replaces exl3_glue_act + exl3_gemv_ex(IN_ROTATED).  g_slabs / u_slabs / act_S: as returned by the gate / up exl3_gemv_ex
+// call (they live in the other workspace region than this launch's own slabs).  flags: EXL3_GEMV_OUT_DEFERRED optional.
+extern "C" int exl3_gemv_ex_act(const float* g_slabs, const float* u_slabs, int act_S, const void* svh_g, const void* svh_u,
+                                const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
+                                int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(B && suh, "exl3_gemv_ex_act: null pointer");
+    const void* Bs[1] = { B }; void* Cs[1] = { C }; const void* su[1] = { suh }; const void* sv[1] = { svh }; const void* bi[1] = { bias };
+    int ns[1] = { n };
+    return run_mgemm(nullptr, Bs, C ? Cs : nullptr, su, svh ? sv : nullptr, bi, ns, 1, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream,
+                     (flags & GEMV_OUT_DEFERRED), nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
+                     g_slabs, u_slabs, act_S, svh_g, svh_u);
 }

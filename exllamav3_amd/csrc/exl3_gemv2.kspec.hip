@@ -27,6 +27,7 @@
 #include "exl3_gemv_args.h"
 #include "exl3_lane_decode.cuh"
 #include "exl3_gemv2_tail.cuh"
+#include "exl3_glue_device.cuh"
 
 #include <type_traits>
 
@@ -80,6 +81,7 @@ __device__ __forceinline__ void decode_quad(const uint32_t (&Wx)[K + 1], half4_t
 #define G2_MODE_NORM  1     // GEMV_IN_NORM: RMSNorm of the residual stream while building the activation fragments
 #define G2_MODE_TAIL  2     // in-kernel tail epilogue (exl3_gemv2_tail.cuh)
 #define G2_MODE_TABLE 3     // device-side pointer tables + indices + routing weights (MoE exl3_mgemm)
+#define G2_MODE_ACT   4     // GEMV_IN_ACT: down_proj whose input is finished from the gate / up slabs (replaces the glue_act launch at m <= 4)
 // The modes are separate instantiations because the hot loop needs 62 of the 64 VGPRs that allow two 16-wave workgroups per CU: code
 // of a cold path that is merely present makes the allocator spill (scratch also slows every launch by ~1 us, measured).
 template <int K, int CB, int VAR, int NG, int MODE>
@@ -89,7 +91,7 @@ template <int K, int CB, int VAR, int NG, int MODE>
 #ifdef G2_ABL_ILP
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 #else
-__global__ __launch_bounds__(1024 / NG) __attribute__((amdgpu_waves_per_eu(NG == 4 ? 3 : NG == 2 ? 4 : G2_PF > 2 ? 6 : (K >= 5 && MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1) ? 5 : ((K >= 5 || (MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || CB != EXL3_CB_MUL1) ? 7 : 8)))))
+__global__ __launch_bounds__(1024 / NG) __attribute__((amdgpu_waves_per_eu(NG == 4 ? 3 : NG == 2 ? 4 : (G2_PF > 2 || MODE == G2_MODE_ACT) ? (MODE == G2_MODE_ACT ? 4 : 6) : (K >= 5 && MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1) ? 5 : ((K >= 5 || (MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || MODE == G2_MODE_ACT || CB != EXL3_CB_MUL1) ? 7 : 8)))))
 #endif
 void exl3_gemv2_kernel(const GemvArgs a)
 {
@@ -211,7 +213,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         const int t = min(it * nhw + hwid, cnt * m - 1);
         const int blk = c0 + t / m, row = t % m;
         const size_t kofs = (size_t) k0s + 128 * blk;
-        r.xv = ((const half4_t*) (x_src + (size_t) row * a.k + kofs))[l32];
+        if constexpr (MODE != G2_MODE_ACT) r.xv = ((const half4_t*) (x_src + (size_t) row * a.k + kofs))[l32];
         if (!in_rotated)
         {
             r.sv = ((const half4_t*) (suh + kofs))[l32];
@@ -277,6 +279,23 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 else
                 {
                     half4_t xv = cur.xv;
+                    if constexpr (MODE == G2_MODE_ACT)
+                    {
+                        // a = fp16(silu(g) * u) of this (row, block): split-k reduce of the gate / up slabs, output Hadamards, svh -- the arithmetic of
+                        // glue_act_kernel (same device functions), done by the half-wave that needs the block
+                        const int blk_abs = (k0s >> 7) + c0 + blk_l;
+                        const SlabRef sg = { a.act_g, a.act_S }, su = { a.act_u, a.act_S };
+                        const half4_t svg = ((const half4_t*) (a.act_svh_g + blk_abs * 128))[l32], svu = ((const half4_t*) (a.act_svh_u + blk_abs * 128))[l32];
+                        float4_t vg, vu;
+                        slab_sum2<8>(sg, su, blk_abs, row, m, l32, vg, vu);
+                        float g0, g1, g2, g3, u0, u1, u2, u3;
+                        out_had(vg, l32, g0, g1, g2, g3);
+                        out_had(vu, l32, u0, u1, u2, u3);
+                        const half4_t gh = half4_t{ f2h(g0), f2h(g1), f2h(g2), f2h(g3) } * svg;
+                        const half4_t uh = half4_t{ f2h(u0), f2h(u1), f2h(u2), f2h(u3) } * svu;
+                        auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
+                        xv = half4_t{ silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
+                    }
                     if constexpr (in_norm)
                     {
                         float r;
@@ -301,7 +320,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 // diagnostics build: workgroup 0 dumps the rotated activations it built (fp16 [blk][row][128]) at 40 MiB
                 if (blockIdx.x == 0 && act)
                 {
-                    half_t* dbg = (half_t*) ((char*) a.workspace + (40ll << 20)) + ((size_t) (k0s / 128 + c0 + blk_l) * m + row) * 128 + 4 * l32;
+                    half_t* dbg = (half_t*) ((char*) a.ws_debug + (4ll << 20)) + ((size_t) (k0s / 128 + c0 + blk_l) * m + row) * 128 + 4 * l32;
                     dbg[0] = o01.x; dbg[1] = o01.y; dbg[2] = o23.x; dbg[3] = o23.y;
                 }
 #endif
@@ -500,7 +519,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         if (tid == 0)
         {
             tstamp[5] = __builtin_amdgcn_s_memrealtime();
-            uint64_t* dbg = (uint64_t*) ((char*) a.workspace + (48ll << 20)) + (size_t) blockIdx.x * 8;
+            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) blockIdx.x * 8;
             for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
             uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             uint32_t hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -581,6 +600,7 @@ template <int CB>
 static void launch_cb(int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
     if (args.tbl.B) launch_mode<CB, G2_MODE_TABLE>(var, ng, nwv, grid, lds, st, args);
+    else if (args.flags & GEMV_IN_ACT) launch_mode<CB, G2_MODE_ACT>(var, ng, nwv, grid, lds, st, args);
     else if (args.epi.mode != GEMV_EPI_NONE) launch_mode<CB, G2_MODE_TAIL>(var, ng, nwv, grid, lds, st, args);
     else if (args.flags & GEMV_IN_NORM) launch_mode<CB, G2_MODE_NORM>(var, ng, nwv, grid, lds, st, args);
     else                                launch_mode<CB, G2_MODE_PLAIN>(var, ng, nwv, grid, lds, st, args);

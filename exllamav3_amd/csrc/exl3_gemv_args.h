@@ -9,6 +9,7 @@
 #define GEMV_IN_ROTATED   1   // the input Hadamard was applied by the producer (glue kernel): mat[i].xh / xsum
 #define GEMV_OUT_DEFERRED 2   // write raw rotated-basis partial slabs [colblock][S][m][128] fp32; a glue kernel finishes
 #define GEMV_IN_NORM      4   // A is the residual stream: the kernel applies RMSNorm (norm_w, per-block sums of squares ss_part, eps) before the input Hadamard
+#define GEMV_IN_ACT       8   // input = silu(g) * u formed from the previous launch's gate / up slabs while the activation fragments are built
 #define GEMV_MAX_MATS 4
 
 struct GemvMat
@@ -98,7 +99,8 @@ struct GemvArgs
 {
     GemvMat mat[GEMV_MAX_MATS];
     const half_t* A;       // [m][k] (already offset to the first row of this pass)
-    float* workspace;
+    float* workspace;      // slab region of this launch
+    float* ws_debug;       // diagnostics builds: fixed area at 48 MiB of the per-device workspace
     int num_mats;
     int m;                 // rows in this pass (1..16)
     int k;
@@ -112,6 +114,10 @@ struct GemvArgs
     const float* ss_part;  // GEMV_IN_NORM: [m][k/128] sums of squares of the residual blocks (exl3_glue_resid)
     float eps;
     GemvTable tbl;         // table mode when tbl.B != nullptr
+    // ACT mode (GEMV_IN_ACT): the input is silu(g) * u of the PREVIOUS launch's deferred gate / up slabs, finished here per Hadamard block
+    const float* act_g; const float* act_u;      // slab bases [inter/128][act_S][m][128] fp32 (the other workspace region)
+    const half_t* act_svh_g; const half_t* act_svh_u;
+    int act_S;
     GemvEpi epi;
 };
 

@@ -24,7 +24,9 @@ __device__ __forceinline__ float4_t slab_sum(const SlabRef& sr, int c, int row, 
     return v;
 }
 
-// two slab sets at once (gate & up): both sets' loads are in flight before the first add
+// two slab sets at once (gate & up): both sets' loads are in flight before the first add; NB lines per set per round (register budget:
+// 2 * NB float4).  The summation order is slice order for every NB, so all callers agree bit for bit.
+template <int NB = 8>
 __device__ __forceinline__ void slab_sum2(const SlabRef& sa, const SlabRef& sb, int c, int row, int m, int l, float4_t& va, float4_t& vb)
 {
     const float* pa = sa.base + ((size_t) c * sa.S * m + row) * 128;
@@ -32,13 +34,13 @@ __device__ __forceinline__ void slab_sum2(const SlabRef& sa, const SlabRef& sb, 
     const size_t st = (size_t) m * 128;
     va = float4_t{ 0.f, 0.f, 0.f, 0.f }; vb = va;
     const int S = sa.S;                                   // both sets come from one launch: same split
-    for (int s = 0; s < S; s += 8)
+    for (int s = 0; s < S; s += NB)
     {
-        float4_t ta[8], tb[8];
+        float4_t ta[NB], tb[NB];
         #pragma unroll
-        for (int i = 0; i < 8; ++i) { ta[i] = ((const float4_t*) (pa + (size_t) min(s + i, S - 1) * st))[l]; tb[i] = ((const float4_t*) (pb + (size_t) min(s + i, S - 1) * st))[l]; }
+        for (int i = 0; i < NB; ++i) { ta[i] = ((const float4_t*) (pa + (size_t) min(s + i, S - 1) * st))[l]; tb[i] = ((const float4_t*) (pb + (size_t) min(s + i, S - 1) * st))[l]; }
         #pragma unroll
-        for (int i = 0; i < 8; ++i) if (s + i < S)
+        for (int i = 0; i < NB; ++i) if (s + i < S)
         {
             va.x += ta[i].x; va.y += ta[i].y; va.z += ta[i].z; va.w += ta[i].w;
             vb.x += tb[i].x; vb.y += tb[i].y; vb.z += tb[i].z; vb.w += tb[i].w;

@@ -626,3 +626,16 @@ def routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_sca
     bsz = scores.shape[0]
     _check(_lib.lib().exl3_routing_std(_p(hidden), _p(gate), _p(bias), _p(scores), _p(topk_indices), _p(topk_weights), bsz, hidden.shape[-1],
                                        scores.shape[1], topk_indices.shape[1], _stream(hidden)))
+
+
+def exl3_gemv_ex_act(gu_slabs, gu_S: int, svh_g, svh_u, B, C, suh, svh, m: int, mcg: bool, mul1: bool, flags: int = 0, force_split: int = 0,
+                     c_fp32: bool = False):
+    """down_proj fed by the gate / up launch's deferred slabs (gu_slabs = [gate ptr, up ptr] as returned by exl3_gemv_ex*): silu(g) * u and the
+    input Hadamard happen inside this GEMV (m <= 4).  Returns (slab pointer list, S) like exl3_gemv_ex."""
+    _dev(B)
+    k, K = _kK(B)
+    slab = (_vp * 1)()
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_gemv_ex_act(gu_slabs[0], gu_slabs[1], gu_S, _p(svh_g), _p(svh_u), _p(B), _p(C), _p(suh), _p(svh), None, m, k,
+                                       B.shape[1] * 16, K, _cb(mcg, mul1), int(c_fp32), flags, force_split, slab, ctypes.byref(S), _stream(B)))
+    return [int(slab[0]) if slab[0] else 0], S.value

@@ -16,6 +16,7 @@ Tensor parallelism (tp_size > 1): Megatron column/row shards, one all-reduce aft
 from __future__ import annotations
 from dataclasses import dataclass
 import math
+import os
 import torch
 from . import ext
 from .linear import LinearEXL3
@@ -197,6 +198,9 @@ class SyntheticEXL3Llama:
     #: when the GEMM reads it -- so it stays off; kept as a tested option.
     reconstruct_ahead = False
 
+    #: m <= 4: finish silu(g) * u inside the down GEMV instead of a glue_act launch
+    act_in_gemv = os.environ.get("EXL3_HIP_ACT_IN_GEMV", "1") != "0"
+
     #: forced split-k factor per call type of the fused pipelines (0 = library heuristic); tools/sweep_split.py tunes these
     split = {"qkv": 0, "o": 0, "gu": 0, "down": 0}
 
@@ -244,6 +248,11 @@ class SyntheticEXL3Llama:
             else:
                 sgu, Sgu = ext.exl3_gemv_ex_norm(x, L["norm2"], ss, self.eps, [lg.trellis, lu.trellis], None, [lg.suh, lu.suh], None,
                                                  bsz, lg.mcg, lg.mul1, DEF, sp["gu"])
+            if self.tp == 1 and bsz == 1 and self.act_in_gemv:
+                # silu(g) * u + input Hadamard inside the down GEMV (reads the gate / up slabs of the other workspace region): 7 launches / layer
+                sd, Sd = ext.exl3_gemv_ex_act(sgu, Sgu, lg.svh, lu.svh, ld.trellis, None, ld.suh, None, bsz, ld.mcg, ld.mul1, DEF, sp["down"])
+                ext.glue_resid(sd[0], Sd, ld.svh, None, x, ss, bsz)
+                continue
             ext.glue_act(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz)
             if self.tp == 1:
                 sd, Sd = ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF, sp["down"])
@@ -378,7 +387,12 @@ class SyntheticEXL3Llama:
                 calls.append(lambda lq=lq, lk=lk, lv=lv, L=L: ext.exl3_gemv_ex_norm(self.x, L["norm1"], self.ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh], None, bsz, lq.mcg, lq.mul1, DEF))
                 calls.append(lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF))
                 calls.append(lambda lg=lg, lu=lu, L=L: ext.exl3_gemv_ex_norm(self.x, L["norm2"], self.ss, self.eps, [lg.trellis, lu.trellis], None, [lg.suh, lu.suh], None, bsz, lg.mcg, lg.mul1, DEF))
-                calls.append(lambda ld=ld: ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF))
+                if bsz == 1 and self.act_in_gemv:
+                    if li == 0:
+                        gu0 = ext.exl3_gemv_ex_norm(self.x, L["norm2"], self.ss, self.eps, [lg.trellis, lu.trellis], None, [lg.suh, lu.suh], None, bsz, lg.mcg, lg.mul1, DEF)
+                    calls.append(lambda ld=ld, lg=lg, lu=lu, gu0=gu0: ext.exl3_gemv_ex_act(gu0[0], gu0[1], lg.svh, lu.svh, ld.trellis, None, ld.suh, None, bsz, ld.mcg, ld.mul1, DEF))
+                else:
+                    calls.append(lambda ld=ld: ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF))
             else:
                 calls.append(lambda lq=lq, lk=lk, lv=lv: ext.exl3_mgemm_bcast(self.xn, [lq.trellis, lk.trellis, lv.trellis], [q2, k2, v2], [lq.suh, lk.suh, lv.suh], [lq.svh, lk.svh, lv.svh], lq.mcg, lq.mul1))
                 calls.append(lambda lo=lo: lo.bc.run(q2, self.o))

@@ -185,6 +185,12 @@ int exl3_glue_resid(const float* y_slabs, int y_S, const float* y_dense, const v
 int exl3_glue_rotate(const void* resid, const float* ss_part, const void* w, float eps, const void* const* suhs, void* const* xhs,
                      float* const* xsums, int count, int m, int hidden, void* stream);
 
+/* down_proj on a = fp16(silu(g) * u) taken straight from the gate / up launch's deferred slabs (m <= 4): the reduce + output Hadamards +
+ * svh + silu*mul (activation.cu) + input Hadamard of exl3_glue_act happen while this GEMV builds its activation fragments. */
+int exl3_gemv_ex_act(const float* g_slabs, const float* u_slabs, int act_S, const void* svh_g, const void* svh_u,
+                     const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
+                     int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream);
+
 /* Diagnostics only: copy [byte_offset, byte_offset + nbytes) of the per-device split-k workspace to dst (tools/gemv_timeline.py). */
 int exl3_debug_copy_workspace(void* dst, int64_t byte_offset, int64_t nbytes, void* stream);
 
