@@ -92,6 +92,8 @@ def _declare(l):
         ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_hgemm", vp, vp, vp, i32, i32, i32, i64, i32, vp)
     sig("exl3_hgemm_acc", vp, vp, vp, i32, i32, i32, i64, vp)
+    sig("exl3_hgemm_nt", vp, vp, vp, i32, i32, i32, i64, i64, i32, i32, vp)
+    sig("exl3_reconstruct_had_t", vp, i64, vp, vp, vp, i32, i32, i32, i32, i64, i64, vp)
     sig("exl3_rms_norm", vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_rope", vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, vp, vp, i32, f32, vp, vp, f32, f32, vp)
     sig("exl3_quant_cache_cont", vp, vp, vp, i64, i32, i32, vp)

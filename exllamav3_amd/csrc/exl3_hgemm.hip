@@ -16,7 +16,7 @@ struct HgemmCtx
     bool ready = false;
     hipblasLtHandle_t handle;
     void* ws = nullptr;
-    std::map<std::tuple<int, int, int, int64_t, int, int>, hipblasLtMatmulAlgo_t> algos;
+    std::map<std::tuple<int, int, int, int64_t, int, int, int64_t>, hipblasLtMatmulAlgo_t> algos;
 };
 static HgemmCtx g_hctx[64];
 static std::mutex g_hmutex;
@@ -24,7 +24,8 @@ static std::mutex g_hmutex;
 #define CHECK_LT(expr, what) do { hipblasStatus_t s_ = (expr); if (s_ != HIPBLAS_STATUS_SUCCESS) { \
     exl3_set_error("hgemm: %s failed (hipblasStatus %d)", what, (int) s_); return EXL3_ERR_HIP; } } while (0)
 
-static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, int accumulate, void* stream)
+// b_t_ld == 0: b is [k][n] row-major.  b_t_ld > 0: b holds B^T, [n][b_t_ld] row-major with k contiguous (b_t_ld >= k).
+static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, int accumulate, int64_t b_t_ld, void* stream)
 {
     EXL3_CHECK_ARG(a && b && c, "hgemm: null pointer");
     EXL3_CHECK_ARG(m >= 0 && k > 0 && n > 0 && ldc >= n, "hgemm: bad dimensions");
@@ -50,14 +51,17 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
     hipblasLtMatmulDesc_t desc;
     hipblasLtMatrixLayout_t la, lb, lc;
     CHECK_LT(hipblasLtMatmulDescCreate(&desc, HIPBLAS_COMPUTE_32F, HIP_R_32F), "MatmulDescCreate");
-    hipblasOperation_t opn = HIPBLAS_OP_N;
-    CHECK_LT(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opn, sizeof(opn)), "set TRANSA");
+    hipblasOperation_t opn = HIPBLAS_OP_N, opt = HIPBLAS_OP_T;
+    CHECK_LT(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSA, b_t_ld ? &opt : &opn, sizeof(opn)), "set TRANSA");
     CHECK_LT(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opn, sizeof(opn)), "set TRANSB");
-    CHECK_LT(hipblasLtMatrixLayoutCreate(&la, HIP_R_16F, n, k, n), "layout A");
+    // first operand of the column-major product: B^T (n x k).  [k][n] row-major memory IS that matrix (ld n); [n][k] row-major memory is
+    // its transpose (k x n, ld b_t_ld) and is used with op = T -- both GEMM operands are then K-major
+    if (b_t_ld) { CHECK_LT(hipblasLtMatrixLayoutCreate(&la, HIP_R_16F, k, n, b_t_ld), "layout A^T"); }
+    else        CHECK_LT(hipblasLtMatrixLayoutCreate(&la, HIP_R_16F, n, k, n), "layout A");
     CHECK_LT(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16F, k, m, k), "layout B");
     CHECK_LT(hipblasLtMatrixLayoutCreate(&lc, c_fp32 ? HIP_R_32F : HIP_R_16F, n, m, ldc), "layout C");
 
-    auto key = std::make_tuple(m, k, n, ldc, c_fp32, accumulate);
+    auto key = std::make_tuple(m, k, n, ldc, c_fp32, accumulate, b_t_ld);
     auto it = cx.algos.find(key);
     if (it == cx.algos.end())
     {
@@ -68,7 +72,7 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
         CHECK_LT(hipblasLtMatmulPreferenceCreate(&pref), "PreferenceCreate");
         size_t wsz = HGEMM_WS_BYTES;
         CHECK_LT(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsz, sizeof(wsz)), "set workspace");
-        constexpr int MAXA = 24;
+        constexpr int MAXA = 64;
         hipblasLtMatmulHeuristicResult_t res[MAXA];
         int found = 0;
         CHECK_LT(hipblasLtMatmulAlgoGetHeuristic(cx.handle, desc, la, lb, lc, lc, pref, MAXA, res, &found), "AlgoGetHeuristic");
@@ -93,9 +97,9 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
                 if (res[i].workspaceSize > HGEMM_WS_BYTES) continue;
                 bool ok = true;
                 float ms = 0.0f;
-                for (int rep = 0; rep < 3 && ok; ++rep)
+                for (int rep = 0; rep < 7 && ok; ++rep)
                 {
-                    if (rep == 1) (void) hipEventRecord(e0, (hipStream_t) stream);
+                    if (rep == 2) (void) hipEventRecord(e0, (hipStream_t) stream);     // 2 warm-up runs, 5 timed
                     ok = dtune && hipblasLtMatmul(cx.handle, desc, &al, b, la, a, lb, &be, c, lc, dtune, lc, &res[i].algo, cx.ws, HGEMM_WS_BYTES,
                                                   (hipStream_t) stream) == HIPBLAS_STATUS_SUCCESS;
                 }
@@ -121,12 +125,21 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
 
 extern "C" int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, void* stream)
 {
-    return hgemm_impl(a, b, c, m, k, n, ldc, c_fp32, 0, stream);
+    return hgemm_impl(a, b, c, m, k, n, ldc, c_fp32, 0, 0, stream);
+}
+
+// c[m][n] = a[m][k] @ bt[n][k]^T with bt = B^T stored row-major, row stride ldb >= k (what exl3_reconstruct_had_t writes); accumulate != 0:
+// c (fp16) += product (the exl3_hgemm_acc epilogue).
+extern "C" int exl3_hgemm_nt(const void* a, const void* bt, void* c, int m, int k, int n, int64_t ldb, int64_t ldc, int c_fp32, int accumulate, void* stream)
+{
+    EXL3_CHECK_ARG(ldb >= k, "hgemm_nt: ldb must be >= k");
+    EXL3_CHECK_ARG(!accumulate || !c_fp32, "hgemm_nt: accumulate mode needs an fp16 c");
+    return hgemm_impl(a, bt, c, m, k, n, ldc, c_fp32, accumulate ? 1 : 0, ldb, stream);
 }
 
 // c[m][n] (fp16, in place) = fp16(a @ b + c): the residual add of the reference's o_proj / down_proj boundary (fp32 GEMM output, then
 // `x += y` rounded to fp16: norm.cu:193-218 / add.cu) folded into the GEMM epilogue -- one rounding, the same value.
 extern "C" int exl3_hgemm_acc(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, void* stream)
 {
-    return hgemm_impl(a, b, c, m, k, n, ldc, 0, 1, stream);
+    return hgemm_impl(a, b, c, m, k, n, ldc, 0, 1, 0, stream);
 }

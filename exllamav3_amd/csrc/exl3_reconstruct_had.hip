@@ -4,7 +4,9 @@
 // MI355X design: the two 128-point Hadamard transforms are done on the MATRIX pipe as two 128x128x128 fp16 GEMMs
 // against the +-1 Sylvester matrix, whose MFMA operand fragments are generated in registers from lane indices
 // (sign = parity(popcount(i & j))) -- no Hadamard matrix in memory, no 7-stage butterfly with LDS round trips,
-// and exact fp32 accumulation of exactly representable products.  Rounding points follow the reference: the
+// and exact fp32 accumulation of exactly representable products.  (The float -> half conversions here are left to the compiler, which
+// folds scale-multiply + convert into v_fma_mixlo_f16: one rounding instead of the reference's two, half the VALU work of the kernel's
+// hottest non-MFMA part, and inside the op's 2e-3 tolerance; the decode-path kernels use f2h() because pipelines are compared bit for bit.)  Rounding points follow the reference: the
 // intermediate (after the k-side transform and suh) is rounded to fp16, the final result is rounded once.
 // The first GEMM is computed transposed so that its accumulators ARE the second GEMM's A operand (no LDS round trip for
 // the intermediate, one 34.8 KB LDS image per workgroup).
@@ -40,7 +42,7 @@ __device__ __forceinline__ half8_t had_frag_signed(const uint32_t (&base)[4], in
 // row r (0..15) of the lane's column c (HI = 0) or c + 8 (HI = 1) is weight t = 8q + j
 template <int R, int HI> struct RowToWeight { static constexpr int q = (R & 7) >> 1, j = (R & 1) + 2 * (R >> 3) + 4 * HI, t = 8 * q + j; };
 
-template <int K, int CB>
+template <int K, int CB, bool TR>
 __global__ __launch_bounds__(256)
 void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict__ packed, const half_t* __restrict__ suh,
                             const half_t* __restrict__ svh, int tiles_n_total, int tile_n_offset, int64_t out_stride)
@@ -156,8 +158,17 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
             for (int r = 0; r < 4; ++r)
             {
                 int k0r = 16 * (2 * wave) + 4 * g + r, k1r = k0r + 16;
-                Wt[(size_t) k0r * RH_LD + 16 * ct + j] = (half_t) (acc0[r] * sv);
-                Wt[(size_t) k1r * RH_LD + 16 * ct + j] = (half_t) (acc1[r] * sv);
+                if constexpr (TR)
+                {
+                    // transposed output W^T[n'][k'] (k contiguous): the layout the MFMA GEMM library is fastest on (both operands K-major)
+                    Wt[(size_t) (16 * ct + j) * RH_LD + k0r] = (half_t) (acc0[r] * sv);
+                    Wt[(size_t) (16 * ct + j) * RH_LD + k1r] = (half_t) (acc1[r] * sv);
+                }
+                else
+                {
+                    Wt[(size_t) k0r * RH_LD + 16 * ct + j] = (half_t) (acc0[r] * sv);
+                    Wt[(size_t) k1r * RH_LD + 16 * ct + j] = (half_t) (acc1[r] * sv);
+                }
             }
         }
     }
@@ -169,12 +180,14 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
     {
         int row = (tid >> 4) + 16 * it, seg = tid & 15;
         half8_t v = *((const half8_t*) (Wt + (size_t) row * RH_LD + 8 * seg));
-        *((half8_t*) (out + ((int64_t) kb * 128 + row) * out_stride + (int64_t) nb * 128 + 8 * seg)) = v;
+        if constexpr (TR) *((half8_t*) (out + ((int64_t) nb * 128 + row) * out_stride + (int64_t) kb * 128 + 8 * seg)) = v;     // row = n'
+        else              *((half8_t*) (out + ((int64_t) kb * 128 + row) * out_stride + (int64_t) nb * 128 + 8 * seg)) = v;     // row = k'
+
     }
 }
 
-extern "C" int exl3_reconstruct_had(void* out, const void* trellis, const void* suh, const void* svh,
-                                    int tiles_k, int tiles_n, int K, int cb, int64_t n_offset, int64_t n_size, void* stream)
+static int reconstruct_had_impl(void* out, int64_t ld_out, int transposed, const void* trellis, const void* suh, const void* svh,
+                                int tiles_k, int tiles_n, int K, int cb, int64_t n_offset, int64_t n_size, void* stream)
 {
     EXL3_CHECK_ARG(out && trellis && suh && svh, "reconstruct_had_slice: null pointer");
     EXL3_CHECK_ARG(K >= 1 && K <= 8, "reconstruct_had_slice: K must be in [1, 8]");
@@ -183,17 +196,36 @@ extern "C" int exl3_reconstruct_had(void* out, const void* trellis, const void* 
     EXL3_CHECK_ARG(n_size % 128 == 0, "unpacked N dimension must be divisible by 128");
     EXL3_CHECK_ARG(n_offset % 128 == 0 && n_offset >= 0, "n_offset must be a non-negative multiple of 128");
     EXL3_CHECK_ARG(n_offset + n_size <= (int64_t) tiles_n * 16, "reconstruct slice exceeds packed tensor bounds");
+    EXL3_CHECK_ARG(ld_out >= (transposed ? (int64_t) tiles_k * 16 : n_size) && ld_out % 8 == 0, "reconstruct_had_slice: bad output row stride");
     if (n_size == 0 || tiles_k == 0) return EXL3_OK;
     dim3 grid((unsigned) (n_size / 128), (unsigned) (tiles_k / 8));
     size_t lds = (size_t) 128 * RH_LD * 2;                 // 34.8 KB: four workgroups per CU
     hipStream_t st = (hipStream_t) stream;
+    #define RC(KK, CC) case KK * 3 + CC: \
+        if (transposed) reconstruct_had_kernel<KK, CC, true><<<grid, 256, lds, st>>>((half_t*) out, (const uint32_t*) trellis, \
+            (const half_t*) suh, (const half_t*) svh, tiles_n, (int) (n_offset / 16), ld_out); \
+        else reconstruct_had_kernel<KK, CC, false><<<grid, 256, lds, st>>>((half_t*) out, (const uint32_t*) trellis, \
+            (const half_t*) suh, (const half_t*) svh, tiles_n, (int) (n_offset / 16), ld_out); break;
     switch (K * 3 + cb)
     {
-        #define RC(KK, CC) case KK * 3 + CC: reconstruct_had_kernel<KK, CC><<<grid, 256, lds, st>>>((half_t*) out, (const uint32_t*) trellis, \
-            (const half_t*) suh, (const half_t*) svh, tiles_n, (int) (n_offset / 16), n_size); break;
         RC(1,0) RC(1,1) RC(1,2) RC(2,0) RC(2,1) RC(2,2) RC(3,0) RC(3,1) RC(3,2) RC(4,0) RC(4,1) RC(4,2)
         RC(5,0) RC(5,1) RC(5,2) RC(6,0) RC(6,1) RC(6,2) RC(7,0) RC(7,1) RC(7,2) RC(8,0) RC(8,1) RC(8,2)
-        #undef RC
     }
+    #undef RC
     return exl3_check_launch("reconstruct_had_slice");
+}
+
+extern "C" int exl3_reconstruct_had(void* out, const void* trellis, const void* suh, const void* svh,
+                                    int tiles_k, int tiles_n, int K, int cb, int64_t n_offset, int64_t n_size, void* stream)
+{
+    return reconstruct_had_impl(out, n_size, 0, trellis, suh, svh, tiles_k, tiles_n, K, cb, n_offset, n_size, stream);
+}
+
+// Same reconstruction, written TRANSPOSED: out[n_size][ld_out] holds W^T (row = output feature, k contiguous; ld_out >= k, so several
+// matrices can share one buffer row-wise).  The prefill GEMM then has both operands K-major ("NT"), the layout hipBLASLt's MFMA kernels
+// are 15-28 % faster on (tools/bench_gemm_layouts.py).
+extern "C" int exl3_reconstruct_had_t(void* out, int64_t ld_out, const void* trellis, const void* suh, const void* svh,
+                                      int tiles_k, int tiles_n, int K, int cb, int64_t n_offset, int64_t n_size, void* stream)
+{
+    return reconstruct_had_impl(out, ld_out, 1, trellis, suh, svh, tiles_k, tiles_n, K, cb, n_offset, n_size, stream);
 }

@@ -285,6 +285,31 @@ def hgemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):
                                  int(c.dtype == torch.float), _stream(a)))
 
 
+def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: bool = False):
+    """c = a @ bt.T (+ c if accumulate): bt is B^T, (n, k) with unit column stride (row stride >= k) -- both operands K-major."""
+    _dev(a)
+    _req(a.dtype == torch.half and bt.dtype == torch.half and c.dtype in (torch.half, torch.float), "hgemm_nt: bad dtypes")
+    _req(a.dim() == 2 and bt.dim() == 2 and c.dim() == 2, "hgemm_nt: tensors must be 2-D")
+    _req(a.shape[1] == bt.shape[1] and a.shape[0] == c.shape[0] and bt.shape[0] == c.shape[1], "hgemm_nt: shape mismatch")
+    _req(a.is_contiguous() and bt.stride(1) == 1 and c.stride(1) == 1, "hgemm_nt: a contiguous; bt, c unit column stride")
+    _req(not accumulate or c.dtype == torch.half, "hgemm_nt: accumulate needs a float16 c")
+    _check(_lib.lib().exl3_hgemm_nt(_p(a), _p(bt), _p(c), a.shape[0], a.shape[1], bt.shape[0], bt.stride(0), c.stride(0),
+                                    int(c.dtype == torch.float), int(accumulate), _stream(a)))
+
+
+def reconstruct_had_slice_t(unpacked_t: torch.Tensor, packed: torch.Tensor, suh: torch.Tensor, svh: torch.Tensor,
+                            K: int, mcg: bool, mul1: bool, n_offset: int):
+    """reconstruct_had_slice written transposed: unpacked_t is (n_size, k) with unit column stride (row stride >= k) and receives W^T."""
+    _dev(unpacked_t)
+    _req(packed.dim() == 3 and packed.dtype == torch.int16 and packed.shape[2] == 16 * K, "packed must be a 3-D int16 tensor with dim 2 = 16*K")
+    _req(unpacked_t.dtype == torch.half and unpacked_t.dim() == 2 and unpacked_t.shape[1] == packed.shape[0] * 16, "unpacked_t must be (n, k) float16")
+    _req(unpacked_t.stride(1) == 1 and packed.is_contiguous(), "unpacked_t needs a unit column stride; packed contiguous")
+    _req(suh.dtype == torch.half and svh.dtype == torch.half, "suh/svh must be float16")
+    _req(suh.numel() >= unpacked_t.shape[1] and svh.numel() >= unpacked_t.shape[0], "suh/svh too small")
+    _check(_lib.lib().exl3_reconstruct_had_t(_p(unpacked_t), unpacked_t.stride(0), _p(packed), _p(suh), _p(svh), packed.shape[0], packed.shape[1],
+                                             K, _cb(mcg, mul1), n_offset, unpacked_t.shape[0], _stream(unpacked_t)))
+
+
 def hgemm_acc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):
     """c (fp16, in place) = fp16(a @ b + c): hgemm + residual add in the GEMM epilogue (one rounding, as fp32 output + `x += y`)."""
     _dev(a)

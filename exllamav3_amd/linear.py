@@ -65,13 +65,12 @@ class LinearEXL3:
         dev = self.trellis.device
         if self.out_features <= MAX_RECONSTRUCT_SLICE_N:
             if use_fused:
-                w = self._reconstructed_w()
+                ext.hgemm_nt(xh, self._reconstructed_w(), y2)           # W^T, k contiguous: both GEMM operands K-major
+                self._release_w()
             else:
                 w = torch.empty((self.in_features, self.out_features), dtype=torch.half, device=dev)
                 ext.reconstruct(w, self.trellis, self.K, self.mcg, self.mul1)
-            ext.hgemm(xh, w, y2)
-            if use_fused:
-                self._release_w()
+                ext.hgemm(xh, w, y2)
         else:
             step = (MAX_RECONSTRUCT_SLICE_N // 128) * 128
             w_ = torch.empty((self.in_features * step,), dtype=torch.half, device=dev)
@@ -100,7 +99,7 @@ class LinearEXL3:
             y = self.forward(x, out_dtype=torch.float)
             ext.add(resid, y.view(resid.shape))
             return
-        ext.hgemm_acc(x.view(rows, self.in_features), self._reconstructed_w(), resid.view(rows, self.out_features))
+        ext.hgemm_nt(x.view(rows, self.in_features), self._reconstructed_w(), resid.view(rows, self.out_features), accumulate=True)
         self._release_w()
 
     #: MI355X option (not in the reference): keep the reconstructed original-basis fp16 W of every Linear resident after its first
@@ -123,8 +122,8 @@ class LinearEXL3:
         w = getattr(self, "_w_cache", None)
         if w is not None:
             return w
-        w = torch.empty((self.in_features, self.out_features), dtype=torch.half, device=self.trellis.device)
-        ext.reconstruct_had_slice(w, self.trellis, self.suh, self.svh, self.K, self.mcg, self.mul1, 0)
+        w = torch.empty((self.out_features, self.in_features), dtype=torch.half, device=self.trellis.device)     # W^T
+        ext.reconstruct_had_slice_t(w, self.trellis, self.suh, self.svh, self.K, self.mcg, self.mul1, 0)
         if self.cache_reconstructed:
             self._w_cache = w
         return w
@@ -185,8 +184,8 @@ class ReconstructAhead:
         with torch.cuda.stream(self.side):
             if i - self.nbuf in self.released:
                 self.side.wait_event(self.released.pop(i - self.nbuf))       # the GEMM that read this buffer last has finished
-            w = self.bufs[i % self.nbuf][: lin.in_features * lin.out_features].view(lin.in_features, lin.out_features)
-            ext.reconstruct_had_slice(w, lin.trellis, lin.suh, lin.svh, lin.K, lin.mcg, lin.mul1, 0)
+            w = self.bufs[i % self.nbuf][: lin.in_features * lin.out_features].view(lin.out_features, lin.in_features)     # W^T
+            ext.reconstruct_had_slice_t(w, lin.trellis, lin.suh, lin.svh, lin.K, lin.mcg, lin.mul1, 0)
             ev = torch.cuda.Event(); ev.record(self.side)
         self.ready[i], self.w[i] = ev, w
 

@@ -64,6 +64,9 @@ int exl3_reconstruct(void* out, const void* trellis, int tiles_k, int tiles_n, i
  * W = diag(suh) H W_hat H diag(svh); svh is pre-offset by the caller (points at element n_offset's scale). */
 int exl3_reconstruct_had(void* out, const void* trellis, const void* suh, const void* svh,
                          int tiles_k, int tiles_n, int K, int cb, int64_t n_offset, int64_t n_size, void* stream);
+/* reconstruct_had_slice written transposed: out[n_size][ld_out] = W^T (row = output feature, k contiguous, ld_out >= k). */
+int exl3_reconstruct_had_t(void* out, int64_t ld_out, const void* trellis, const void* suh, const void* svh,
+                           int tiles_k, int tiles_n, int K, int cb, int64_t n_offset, int64_t n_size, void* stream);
 
 /* had_r_128(input, output, pre_scale, post_scale, scale)   quant/hadamard.cu:88-173.
  * rows x cols, cols % 128 == 0; fp32 = 0: fp16 in/out, 1: fp32 in/out; scales fp16 [cols] or NULL; in-place allowed */
@@ -200,6 +203,9 @@ int exl3_hgemm(const void* a, const void* b, void* c, int m, int k, int n, int64
 /* c (fp16, in place) = fp16(a @ b + c): hgemm with the residual add of the o_proj / down_proj boundary (norm.cu:193-218, add.cu) in the
  * GEMM epilogue; same single rounding as fp32 output + add. */
 int exl3_hgemm_acc(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, void* stream);
+/* c[m][n] = a[m][k] @ bt[n][k]^T: bt is B^T row-major with row stride ldb >= k (both operands K-major, the layout the library's MFMA kernels
+ * run 15-28 % faster on MI355X); accumulate != 0: c (fp16) += product. */
+int exl3_hgemm_nt(const void* a, const void* bt, void* c, int m, int k, int n, int64_t ldb, int64_t ldc, int c_fp32, int accumulate, void* stream);
 
 /* ---- RMSNorm     norm.cuh:7-39, norm.cu:155-299 --------------------------------------------------- */
 /* mode 0: y = norm(x)*w ; 1: y += norm(x)*w (add_residual) ; 2: r += x; y = norm(r)*w (rms_norm_res_in).

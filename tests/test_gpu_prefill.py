@@ -119,3 +119,46 @@ def test_hgemm_acc_and_forward_add_residual(dev, m, k, n):
     assert float((ra.float() - rb.float()).abs().max()) <= 4e-3 * float(rb.float().abs().max())
     ref2 = (r0.float().cpu().numpy() + o.linear_forward(x.cpu().numpy(), tr, suh, svh, 4, 2, out_fp32=True)).astype(np.float16).astype(np.float32)
     assert np.abs(ra.float().cpu().numpy() - ref2).max() / np.sqrt((ref2 ** 2).mean()) < 2e-2
+
+
+@pytest.mark.parametrize("k,n,K,cb", [(256, 384, 4, 2), (512, 256, 3, 0), (1024, 128, 6, 1)])
+def test_reconstruct_had_slice_transposed(dev, k, n, K, cb):
+    """reconstruct_had_slice_t writes W^T (row stride >= k): bit-identical to the transpose of reconstruct_had_slice, whole matrix, a column
+    slice, and into a wider row-strided buffer shared by two matrices."""
+    from exllamav3_amd import ext
+    tr, suh, svh = o.synth_linear(k, n, K, realistic=True)
+    ttr, tsu, tsv = _t(tr, dev), _t(suh, dev), _t(svh, dev)
+    w = torch.empty((k, n), dtype=torch.half, device=dev)
+    ext.reconstruct_had_slice(w, ttr, tsu, tsv, K, cb == 1, cb == 2, 0)
+    wt = torch.empty((n, k), dtype=torch.half, device=dev)
+    ext.reconstruct_had_slice_t(wt, ttr, tsu, tsv, K, cb == 1, cb == 2, 0)
+    ref = o.weight_tensor(tr, suh, svh, K, cb)
+    # same arithmetic up to the compiler's choice of single- vs double-rounded float -> half conversions: at most one fp16 ulp apart
+    ulp = 2.0 ** -10 * float(np.abs(ref).max())
+    assert float((wt.float() - w.t().float()).abs().max()) <= ulp
+    assert np.abs(wt.t().float().cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-3
+    if n >= 256:
+        ws = torch.empty((128, k), dtype=torch.half, device=dev)
+        ext.reconstruct_had_slice_t(ws, ttr, tsu, tsv[128:], K, cb == 1, cb == 2, 128)
+        assert float((ws.float() - w[:, 128:256].t().float()).abs().max()) <= ulp
+    wide = torch.zeros((n, k + 64), dtype=torch.half, device=dev)
+    ext.reconstruct_had_slice_t(wide[:, :k], ttr, tsu, tsv, K, cb == 1, cb == 2, 0)
+    assert torch.equal(wide[:, :k], wt) and float(wide[:, k:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("m,k,n", [(1024, 512, 384), (2048, 1024, 256)])
+def test_hgemm_nt(dev, m, k, n):
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(m + k + n)
+    a = _t(rng.standard_normal((m, k)).astype(np.float16), dev)
+    b = _t((rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float16), dev)
+    bt = b.t().contiguous()
+    ref = a.float() @ b.float()
+    for dt in (torch.half, torch.float):
+        c = torch.empty((m, n), dtype=dt, device=dev)
+        ext.hgemm_nt(a, bt, c)
+        assert float((c.float() - ref).abs().max()) < 2e-2
+    r0 = _t(rng.standard_normal((m, n)).astype(np.float16), dev)
+    r1 = r0.clone()
+    ext.hgemm_nt(a, bt, r1, accumulate=True)
+    assert float((r1.float() - (r0.float() + ref)).abs().max()) < 3e-2
