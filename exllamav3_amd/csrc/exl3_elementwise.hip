@@ -131,6 +131,33 @@ extern "C" int exl3_silu_mul(const void* g, const void* u, void* y, int64_t nume
     return exl3_check_launch("silu_mul");
 }
 
+// row-strided variant (fp16): g and u are column ranges of wider matrices (the fused gate|up prefill GEMM writes one [rows][2*cols] output);
+// 8 halves per thread (16-byte accesses)
+__global__ __launch_bounds__(256)
+void silu_mul_2d_kernel(const half_t* __restrict__ g, const half_t* __restrict__ u, half_t* __restrict__ y, int64_t rows, int cols8,
+                        int64_t ld_g, int64_t ld_u)
+{
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols8) return;
+    const int64_t r = i / cols8; const int c = (int) (i % cols8);
+    const half8_t gv = ((const half8_t*) (g + r * ld_g))[c], uv = ((const half8_t*) (u + r * ld_u))[c];
+    half8_t o;
+    #pragma unroll
+    for (int j = 0; j < 8; ++j) { const float gf = (float) gv[j]; o[j] = f2h(gf / (1.0f + __expf(-gf)) * (float) uv[j]); }
+    ((half8_t*) (y + r * (int64_t) cols8 * 8))[c] = o;
+}
+
+extern "C" int exl3_silu_mul_2d(const void* g, const void* u, void* y, int64_t rows, int64_t cols, int64_t ld_g, int64_t ld_u, void* stream)
+{
+    EXL3_CHECK_ARG(g && u && y, "silu_mul_2d: null pointer");
+    EXL3_CHECK_ARG(cols % 8 == 0 && ld_g % 8 == 0 && ld_u % 8 == 0 && ld_g >= cols && ld_u >= cols, "silu_mul_2d: columns and row strides must be multiples of 8");
+    if (rows == 0 || cols == 0) return EXL3_OK;
+    const int64_t n = rows * (cols / 8);
+    silu_mul_2d_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream>>>((const half_t*) g, (const half_t*) u, (half_t*) y,
+                                                                                                 rows, (int) (cols / 8), ld_g, ld_u);
+    return exl3_check_launch("silu_mul_2d");
+}
+
 __global__ __launch_bounds__(256)
 void add_kernel(void* __restrict__ x, const void* __restrict__ y, int64_t n4, int x_fp32, int y_fp32)
 {

@@ -459,6 +459,14 @@ def silu_mul(g, u, y):
     _check(_lib.lib().exl3_silu_mul(_p(g), _p(u), _p(y), g.numel(), int(g.dtype == torch.float), _stream(g)))
 
 
+def silu_mul_2d(g, u, y):
+    """y = silu(g) * u for fp16 2-D views with unit column stride (g, u may be column ranges of one wider matrix)."""
+    _dev(g)
+    _req(g.dtype == torch.half and u.dtype == torch.half and y.dtype == torch.half, "silu_mul_2d: tensors must be float16")
+    _req(g.dim() == 2 and g.shape == u.shape == y.shape and g.stride(1) == 1 and u.stride(1) == 1 and y.is_contiguous(), "silu_mul_2d: bad shapes / strides")
+    _check(_lib.lib().exl3_silu_mul_2d(_p(g), _p(u), _p(y), g.shape[0], g.shape[1], g.stride(0), u.stride(0), _stream(g)))
+
+
 def add(x, y):
     """add.cu: x += y"""
     _dev(x)

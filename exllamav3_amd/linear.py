@@ -102,6 +102,29 @@ class LinearEXL3:
         ext.hgemm_nt(x.view(rows, self.in_features), self._reconstructed_w(), resid.view(rows, self.out_features), accumulate=True)
         self._release_w()
 
+    @staticmethod
+    def forward_gate_up_silu(gate: "LinearEXL3", up: "LinearEXL3", x: torch.Tensor) -> torch.Tensor:
+        """a = silu(gate(x)) * up(x) for the prefill route with ONE GEMM: both W^T are reconstructed into one (2n, k) buffer (rows of W^T
+        stack along n for free), hgemm_nt writes (rows, 2n), silu_mul_2d reads the two column halves.  Same values as two forwards + silu_mul
+        (the library may pick another tile for the wider GEMM: fp32 summation order only)."""
+        rows = x.numel() // x.shape[-1]
+        k, n = gate.in_features, gate.out_features
+        ok = (up.in_features == k and up.out_features == n and k % 128 == 0 and n % 128 == 0 and rows >= FUSED_RECONSTRUCT_MIN_ROWS
+              and 2 * n <= 2 * MAX_RECONSTRUCT_SLICE_N and gate.bias is None and up.bias is None and LinearEXL3.ahead is None
+              and not LinearEXL3.cache_reconstructed)
+        dev = x.device
+        a = torch.empty(x.shape[:-1] + (n,), dtype=torch.half, device=dev)
+        if not ok:
+            ext.silu_mul(gate.forward(x), up.forward(x), a)
+            return a
+        wt = torch.empty((2 * n, k), dtype=torch.half, device=dev)
+        ext.reconstruct_had_slice_t(wt[:n], gate.trellis, gate.suh, gate.svh, gate.K, gate.mcg, gate.mul1, 0)
+        ext.reconstruct_had_slice_t(wt[n:], up.trellis, up.suh, up.svh, up.K, up.mcg, up.mul1, 0)
+        y = torch.empty((rows, 2 * n), dtype=torch.half, device=dev)
+        ext.hgemm_nt(x.view(rows, k), wt, y)
+        ext.silu_mul_2d(y[:, :n], y[:, n:], a.view(rows, n))
+        return a
+
     #: MI355X option (not in the reference): keep the reconstructed original-basis fp16 W of every Linear resident after its first
     #: prefill use -- 16 GB for an 8B model, 141 GB for 70B, both fit the 288 GB of one MI355X next to the packed weights -- so later
     #: prefill chunks are pure MFMA GEMMs.  Off by default: the reference reconstructs per forward (exl3.py:161-218).

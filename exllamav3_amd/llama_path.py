@@ -454,10 +454,7 @@ class SyntheticEXL3Llama:
                 o = L["o"].forward(q.view(tokens, -1))
                 be.all_reduce(o)
                 ext.rms_norm_res_in(o, L["norm2"], xn, x, self.eps)
-            g = L["gate"].forward(xn)
-            u = L["up"].forward(xn)
-            a = torch.empty_like(g)
-            ext.silu_mul(g, u, a)
+            a = type(L["gate"]).forward_gate_up_silu(L["gate"], L["up"], xn)      # one GEMM for gate|up when the rows allow it
             if self.tp == 1:
                 L["down"].forward_add_residual(a, x)
             else:

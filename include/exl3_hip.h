@@ -194,6 +194,9 @@ int exl3_gemv_ex_act(const float* g_slabs, const float* u_slabs, int act_S, cons
                      const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
                      int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream);
 
+/* y[rows][cols] = silu(g) * u (activation.cu) where g and u are fp16 column ranges of wider matrices (row strides ld_g, ld_u). */
+int exl3_silu_mul_2d(const void* g, const void* u, void* y, int64_t rows, int64_t cols, int64_t ld_g, int64_t ld_u, void* stream);
+
 /* Diagnostics only: copy [byte_offset, byte_offset + nbytes) of the per-device split-k workspace to dst (tools/gemv_timeline.py). */
 int exl3_debug_copy_workspace(void* dst, int64_t byte_offset, int64_t nbytes, void* stream);
 

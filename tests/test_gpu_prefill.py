@@ -162,3 +162,21 @@ def test_hgemm_nt(dev, m, k, n):
     r1 = r0.clone()
     ext.hgemm_nt(a, bt, r1, accumulate=True)
     assert float((r1.float() - (r0.float() + ref)).abs().max()) < 3e-2
+
+
+def test_forward_gate_up_silu_fused_gemm(dev):
+    """One NT GEMM for gate|up + silu_mul_2d against two forwards + silu_mul and the oracle."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.linear import LinearEXL3
+    k, n, K, rows = 256, 384, 4, 1024
+    g = o.synth_linear(k, n, K, seed=1, realistic=True); u = o.synth_linear(k, n, K, seed=2, realistic=True)
+    lg = LinearEXL3(k, n, _t(g[0], dev), _t(g[1], dev), _t(g[2], dev), mul1=True)
+    lu = LinearEXL3(k, n, _t(u[0], dev), _t(u[1], dev), _t(u[2], dev), mul1=True)
+    x = np.random.default_rng(0).standard_normal((rows, k)).astype(np.float16)
+    a = LinearEXL3.forward_gate_up_silu(lg, lu, _t(x, dev))
+    a2 = torch.empty_like(a)
+    ext.silu_mul(lg.forward(_t(x, dev)), lu.forward(_t(x, dev)), a2)
+    assert float((a.float() - a2.float()).abs().max()) <= 4e-3 * float(a2.float().abs().max()) + 1e-3
+    gf = o.linear_forward(x, g[0], g[1], g[2], K, 2).astype(np.float32); uf = o.linear_forward(x, u[0], u[1], u[2], K, 2).astype(np.float32)
+    ref = (gf / (1 + np.exp(-gf)) * uf)
+    assert np.abs(a.float().cpu().numpy() - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
