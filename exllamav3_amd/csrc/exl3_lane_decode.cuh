@@ -44,3 +44,42 @@ __device__ __forceinline__ void load_lane_words(LaneWords<K>& d, const uint32_t*
     }
 }
 
+__device__ __forceinline__ half4_t u2_as_half4(uint32_t a, uint32_t b)
+{
+    union { uint32_t u[2]; half4_t h; } c; c.u[0] = a; c.u[1] = b; return c.h;
+}
+
+// Decode the 4 weights T0..T0+3 into MFMA B operands.  out[0] (and out[1] for SPLIT) are half4 operands.
+template <int K, int CB, int VAR, int T0>
+__device__ __forceinline__ void decode_quad(const uint32_t (&Wx)[K + 1], half4_t (&out)[2])
+{
+    uint32_t x0 = cb_product<CB>(lane_state<K, T0 + 0>(Wx));
+    uint32_t x1 = cb_product<CB>(lane_state<K, T0 + 1>(Wx));
+    uint32_t x2 = cb_product<CB>(lane_state<K, T0 + 2>(Wx));
+    uint32_t x3 = cb_product<CB>(lane_state<K, T0 + 3>(Wx));
+    if constexpr (CB != EXL3_CB_MUL1)
+    {
+        x0 = cb_mask3inst(x0); x1 = cb_mask3inst(x1); x2 = cb_mask3inst(x2); x3 = cb_mask3inst(x3);
+        if constexpr (VAR == 1) { out[0] = u2_as_half4(x0, x1); out[1] = u2_as_half4(x2, x3); }
+        else
+        {
+            half2_t s01 = u32_as_half2(__builtin_amdgcn_perm(x1, x0, 0x05040100u)) + u32_as_half2(__builtin_amdgcn_perm(x1, x0, 0x07060302u));
+            half2_t s23 = u32_as_half2(__builtin_amdgcn_perm(x3, x2, 0x05040100u)) + u32_as_half2(__builtin_amdgcn_perm(x3, x2, 0x07060302u));
+            out[0] = u2_as_half4(half2_as_u32(s01), half2_as_u32(s23));
+        }
+    }
+    else
+    {
+        uint32_t h01 = __builtin_amdgcn_sad_hi_u8(x1, 0u, __builtin_amdgcn_sad_u8(x0, 0u, 0x64006400u));
+        uint32_t h23 = __builtin_amdgcn_sad_hi_u8(x3, 0u, __builtin_amdgcn_sad_u8(x2, 0u, 0x64006400u));
+        if constexpr (VAR == 1) out[0] = u2_as_half4(h01, h23);
+        else
+        {
+            const half2_t kinv = { u16_as_half(0x1eeeu), u16_as_half(0x1eeeu) };
+            const half2_t kbias = { u16_as_half(0xc931u), u16_as_half(0xc931u) };
+            half2_t ra = __builtin_elementwise_fma(u32_as_half2(h01), kinv, kbias);      // v_pk_fma_f16
+            half2_t rb = __builtin_elementwise_fma(u32_as_half2(h23), kinv, kbias);
+            out[0] = u2_as_half4(half2_as_u32(ra), half2_as_u32(rb));
+        }
+    }
+}

@@ -70,13 +70,16 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
             #pragma unroll
             for (int i = 0; i < K; ++i) Wx[i + 1] = lw.w[i];
             Wx[0] = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) lw.w[K - 1]);
-            half8_t lo0, lo1, hi0, hi1;                   // column c rows 0-7 / 8-15 ; column c+8 rows 0-7 / 8-15
-            #define DEC(R, HI) decode_exact<CB>(lane_state<K, RowToWeight<R, HI>::t>(Wx))
-            lo0 = half8_t{ DEC(0, 0), DEC(1, 0), DEC(2, 0), DEC(3, 0), DEC(4, 0), DEC(5, 0), DEC(6, 0), DEC(7, 0) };
-            lo1 = half8_t{ DEC(8, 0), DEC(9, 0), DEC(10, 0), DEC(11, 0), DEC(12, 0), DEC(13, 0), DEC(14, 0), DEC(15, 0) };
-            hi0 = half8_t{ DEC(0, 1), DEC(1, 1), DEC(2, 1), DEC(3, 1), DEC(4, 1), DEC(5, 1), DEC(6, 1), DEC(7, 1) };
-            hi1 = half8_t{ DEC(8, 1), DEC(9, 1), DEC(10, 1), DEC(11, 1), DEC(12, 1), DEC(13, 1), DEC(14, 1), DEC(15, 1) };
-            #undef DEC
+            // Exact fp16 weights four at a time (exl3_lane_decode.cuh decode_quad, EXACT variant: the reference's values bit for bit with
+            // packed ops: 2.5 VALU per weight instead of ~5).  Quad t = 8q .. 8q+3 is rows (2q, 2q+1, 2q+8, 2q+9) of column c, quad
+            // 8q+4 .. 8q+7 the same rows of column c + 8: the low dword of quad q is dword q of rows 0-7, the high dword that of rows 8-15.
+            union { uint32_t u[4]; half8_t h; } lo0u, lo1u, hi0u, hi1u;
+            #define DQ(Q) { half4_t qa[2], qb[2]; decode_quad<K, CB, 0, 8 * Q>(Wx, qa); decode_quad<K, CB, 0, 8 * Q + 4>(Wx, qb); \
+                            union { half4_t h; uint32_t u[2]; } ca, cb2; ca.h = qa[0]; cb2.h = qb[0]; \
+                            lo0u.u[Q] = ca.u[0]; lo1u.u[Q] = ca.u[1]; hi0u.u[Q] = cb2.u[0]; hi1u.u[Q] = cb2.u[1]; }
+            DQ(0) DQ(1) DQ(2) DQ(3)
+            #undef DQ
+            const half8_t lo0 = lo0u.h, lo1 = lo1u.h, hi0 = hi0u.h, hi1 = hi1u.h;   // column c rows 0-7 / 8-15 ; column c+8 rows 0-7 / 8-15
             half_t* w0 = Wt + (size_t) (16 * Tt + c) * RH_LD + 16 * tr;
             half_t* w1 = Wt + (size_t) (16 * Tt + c + 8) * RH_LD + 16 * tr;
             *((half8_t*) w0) = lo0; *((half8_t*) (w0 + 8)) = lo1;
