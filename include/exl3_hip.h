@@ -105,7 +105,7 @@ int exl3_set_gemv_defer_wg_per_cu(int workgroups_per_cu);      /* deferred-epilo
  * in between (exl3_glue.hip).
  *
  * exl3_gemv_ex: exl3_mgemm with flags: EXL3_GEMV_IN_ROTATED (1): per-matrix pre-rotated inputs xhs[i] = had128(x * suh_i) fp16 [m][k]
- * and per-128-block sums xsums[i] fp32 [m][k/128] instead of A; EXL3_GEMV_OUT_DEFERRED (2): no output Hadamard, raw fp32 partial
+ * (xsums[i], per-128-block sums fp32 [m][k/128], are accepted for compatibility and no longer read: the kernel sums the fragments it builds) instead of A; EXL3_GEMV_OUT_DEFERRED (2): no output Hadamard, raw fp32 partial
  * slabs [n_i/128][S][m][128] are left in the per-device workspace, slabs_out[i] (host array) receives their device address and
  * *S_out the split count.  Arrays are host arrays of `count` (<= 4) entries. */
 #define EXL3_GEMV_IN_ROTATED   1
