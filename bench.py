@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--prefill-tokens", type=int, default=4096)
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--gen", type=int, default=2)
+    ap.add_argument("--attention", action="store_true", help="include decode attention over the quantized KV cache (context = 1000 tokens) in the timed step")
     ap.add_argument("--unfused", action="store_true", help="one launch per reference op instead of the fused pipeline")
     ap.add_argument("--pipeline", choices=["tail", "glue", "unfused"], default="glue",
                     help="glue: deferred-epilogue GEMVs + glue kernels (8 launches/layer, fastest measured); tail: sublayer boundaries run "
@@ -153,6 +154,7 @@ def main():
     model = SyntheticEXL3Llama(shape, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits,
                                layers=args.layers or None)
     model.alloc_state(args.batch)
+    model.with_attention = bool(args.attention)
 
     # ---- decode: eager warm-up (also creates library contexts), graph capture, timed replays
     pipeline = "unfused" if args.unfused else args.pipeline
@@ -321,7 +323,7 @@ def main():
             "config": {"workload": f"{shape.name} EXL3 {args.bits}.0bpw {args.codebook} codebook, decode bs={args.batch}, "
                                    f"{model.n_layers} layers, TP={world}, {args.kv_bits}-bit KV append, "
                                    f"{'hipGraph replay' if graph is not None else 'eager launches'}, { {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (%d launches/layer)' % (7 if (args.batch == 1 and model.act_in_gemv and world == 1) else (10 if args.batch > 4 else 8)), 'unfused': 'one launch per reference op'}[pipeline] }; "
-                                   f"attention core excluded (SURVEY.md 2.1)",
+                                   f"{'attention core INCLUDED: quant-cache-direct decode attention over a 1000-token context' if args.attention else 'attention core excluded (SURVEY.md 2.1)'}",
                        "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
                        "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),
                        "parallelism": f"tp{world}", "gemv_variant": args.variant, "gemv_gen": args.gen},

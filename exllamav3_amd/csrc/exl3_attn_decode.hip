@@ -1,0 +1,237 @@
+// Decode attention straight from the quantized paged KV cache ("quant-cache-direct flash decoding").
+//
+//   out[b][hq][:] = softmax(q[b][hq] . K[b][:len][kvh]^T * scale) @ V[b][:len][kvh]         one new token per sequence, GQA
+//
+// reference: libtorch/attention.cpp:246-504 decodes through dequant_cache_paged (cache/q_cache.cu) + an fp16 attention kernel.  Here K and V are
+// never materialised: a cached 32-group is x' = H u with H = H32/sqrt(32) orthonormal and symmetric and u the rotated-domain levels*scale, so
+//   q . x' = (H q) . u            -> q is rotated once per head, scores are dot products with the raw dequantized levels
+//   sum_t p_t x'_t = H (sum_t p_t u_t)   -> the output is accumulated in the rotated domain and rotated back once at the end.
+// The only deviation from the reference's arithmetic is that it rounds x' to fp16 before use (2^-11 relative): inside the 1e-2 tolerance.
+//
+// Mapping: a 32-lane half-wave per cached token (lane = 4 consecutive head dims = one 8-lane quantization subgroup position), the 8 half-waves
+// of a workgroup stride over the tokens of one (sequence, kv head, context split); online softmax per half-wave, merged through LDS; context
+// splits are merged by a second small kernel (flash decoding).  The work is tiny (144 B per token and kv head at 4 bits): the design goal is
+// two short launches, not throughput.
+#include "exl3_common.cuh"
+#include "exl3_api_internal.h"
+#include "exl3_glue_device.cuh"
+
+#define ATT_MAX_GQ 8
+#define ATT_R32 0.17677669529663688110f
+
+struct AttnArgs
+{
+    const half_t* q; half_t* out;                               // [bsz][hq][128]
+    const uint32_t* k_cache; const half_t* k_scales; const uint32_t* v_cache; const half_t* v_scales;
+    const int32_t* block_table; const int32_t* cache_seqlens;   // [bsz][blocks_per_seq], [bsz] (length INCLUDING the new token)
+    float* part;                                                // [bsz][hq][nsplit][132] partial (m, l, o[128]) when nsplit > 1
+    int blocks_per_seq, page_size, k_bits, v_bits, hq, hkv, nsplit, split_tokens;
+    float scale;
+};
+
+template <int GQ>
+__global__ __launch_bounds__(256)
+void attn_decode_kernel(const AttnArgs a)
+{
+    __shared__ float ml_s[8][GQ][2];
+    __shared__ float o_s[8][GQ][128];
+    const int tid = threadIdx.x, l = tid & 31, hwid = tid >> 5, lane = tid & 63;
+    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = a.cache_seqlens[b];
+    const int t0 = split * a.split_tokens, t1 = min(len, t0 + a.split_tokens);
+    const int G = a.hkv * 4;                                    // quantization groups per token
+    const int g = l >> 3;
+
+    // rotated, pre-scaled queries of the GQ heads sharing this kv head: qh = H32(q) / sqrt(32) * softmax scale
+    float qh[GQ][4];
+    #pragma unroll
+    for (int i = 0; i < GQ; ++i)
+    {
+        const half4_t qv = ((const half4_t*) (a.q + ((size_t) b * a.hq + h * GQ + i) * 128))[l];
+        float v0 = (float) qv.x, v1 = (float) qv.y, v2 = (float) qv.z, v3 = (float) qv.w;
+        kvg_had32(v0, v1, v2, v3, lane);
+        const float f = ATT_R32 * a.scale;
+        qh[i][0] = v0 * f; qh[i][1] = v1 * f; qh[i][2] = v2 * f; qh[i][3] = v3 * f;
+    }
+    float mx[GQ], ls[GQ], oa[GQ][4];
+    #pragma unroll
+    for (int i = 0; i < GQ; ++i) { mx[i] = -1.0e30f; ls[i] = 0.0f; oa[i][0] = oa[i][1] = oa[i][2] = oa[i][3] = 0.0f; }
+
+    // the split's page: one block-table read per workgroup when the split lies inside one page (always, for the host's 32 / 64-token splits)
+    // (neither depends on the sequence length: the block-table read is issued together with the q and length loads, and tokens beyond the
+    // length inside the page are fetched speculatively -- the page is allocated memory -- and masked afterwards)
+    const int t1_max = t0 + a.split_tokens;
+    const bool one_page = (t0 / a.page_size) == ((t1_max - 1) / a.page_size) && t0 / a.page_size < a.blocks_per_seq;
+    const int64_t page_phys = a.block_table[(size_t) b * a.blocks_per_seq + min(t0 / a.page_size, a.blocks_per_seq - 1)];
+    const int ntok = max(t1 - t0, 0);
+    const int trips = one_page ? a.split_tokens / 8 : (ntok + 7) / 8;   // uniform trip count (the butterflies need whole waves), length-independent when possible
+    // a split never straddles a page when split_tokens divides the page size (the host guarantees that or single-page splits are not assumed):
+    // the page lookup is still per token, but batches of ATT_UNROLL tokens are fetched and dequantized before any softmax update so that the
+    // cache loads of a batch are in flight together (this loop is a chain of ~1 us memory latencies otherwise)
+    constexpr int ATT_UNROLL = 4;
+    for (int it0 = 0; it0 < trips; it0 += ATT_UNROLL)
+    {
+        float kv[ATT_UNROLL][8];
+        bool actv[ATT_UNROLL];
+        #pragma unroll
+        for (int u = 0; u < ATT_UNROLL; ++u)
+        {
+            const int t = t0 + (it0 + u) * 8 + hwid;
+            actv[u] = (it0 + u) < trips && t < t1;
+            const int tc = (actv[u] || one_page) ? t : max(t1 - 1, 0);
+            const int64_t pg = one_page ? page_phys : (int64_t) a.block_table[(size_t) b * a.blocks_per_seq + tc / a.page_size];
+            const int64_t token_pos = pg * a.page_size + (tc % a.page_size);
+            const int64_t gb = token_pos * G + h * 4 + g;
+            kv_dequant_vals_rt(a.k_bits, a.k_cache + gb * a.k_bits, a.k_scales + gb, lane, kv[u][0], kv[u][1], kv[u][2], kv[u][3]);
+            kv_dequant_vals_rt(a.v_bits, a.v_cache + gb * a.v_bits, a.v_scales + gb, lane, kv[u][4], kv[u][5], kv[u][6], kv[u][7]);
+        }
+        #pragma unroll
+        for (int u = 0; u < ATT_UNROLL; ++u)
+        {
+            #pragma unroll
+            for (int i = 0; i < GQ; ++i)
+            {
+                float s = qh[i][0] * kv[u][0] + qh[i][1] * kv[u][1] + qh[i][2] * kv[u][2] + qh[i][3] * kv[u][3];
+                #pragma unroll
+                for (int j = 1; j < 32; j <<= 1) s += xor_lane(s, j);
+                if (actv[u])
+                {
+                    const float mn = fmaxf(mx[i], s);
+                    const float corr = __expf(mx[i] - mn), p = __expf(s - mn);
+                    ls[i] = ls[i] * corr + p;
+                    oa[i][0] = oa[i][0] * corr + p * kv[u][4]; oa[i][1] = oa[i][1] * corr + p * kv[u][5];
+                    oa[i][2] = oa[i][2] * corr + p * kv[u][6]; oa[i][3] = oa[i][3] * corr + p * kv[u][7];
+                    mx[i] = mn;
+                }
+            }
+        }
+    }
+    // merge the 8 half-waves
+    #pragma unroll
+    for (int i = 0; i < GQ; ++i)
+    {
+        if (l == 0) { ml_s[hwid][i][0] = mx[i]; ml_s[hwid][i][1] = ls[i]; }
+        *((float4_t*) &o_s[hwid][i][4 * l]) = float4_t{ oa[i][0], oa[i][1], oa[i][2], oa[i][3] };
+    }
+    __syncthreads();
+    for (int i = hwid; i < GQ; i += 8)
+    {
+        float M = -1.0e30f;
+        #pragma unroll
+        for (int k = 0; k < 8; ++k) M = fmaxf(M, ml_s[k][i][0]);
+        float L = 0.0f; float4_t O = { 0.f, 0.f, 0.f, 0.f };
+        #pragma unroll
+        for (int k = 0; k < 8; ++k)
+        {
+            const float e = __expf(ml_s[k][i][0] - M);
+            L += ml_s[k][i][1] * e;
+            const float4_t ov = *((const float4_t*) &o_s[k][i][4 * l]);
+            O.x += ov.x * e; O.y += ov.y * e; O.z += ov.z * e; O.w += ov.w * e;
+        }
+        const int head = h * GQ + i;
+        if (a.nsplit == 1)
+        {
+            const float inv = L > 0.0f ? 1.0f / L : 0.0f;
+            float v0 = O.x * inv, v1 = O.y * inv, v2 = O.z * inv, v3 = O.w * inv;
+            kvg_had32(v0, v1, v2, v3, lane);
+            ((half4_t*) (a.out + ((size_t) b * a.hq + head) * 128))[l] = half4_t{ f2h(v0 * ATT_R32), f2h(v1 * ATT_R32), f2h(v2 * ATT_R32), f2h(v3 * ATT_R32) };
+        }
+        else
+        {
+            float* p = a.part + (((size_t) b * a.hq + head) * a.nsplit + split) * 132;
+            if (l == 0) { p[0] = M; p[1] = L; }
+            *((float4_t*) (p + 4 + 4 * l)) = O;                 // record = {m, l, pad, pad, o[128]}
+        }
+    }
+}
+
+// merge of the context splits: one half-wave per (sequence, head).  Lane s fetches split s's (max, sum) so the statistics of up to 32 splits
+// arrive in one memory round trip; the weighted accumulation then streams the split outputs 8 at a time (independent loads).
+__global__ __launch_bounds__(256)
+void attn_merge_kernel(const float* __restrict__ part, half_t* __restrict__ out, int heads_total, int nsplit)
+{
+    const int tid = threadIdx.x, l = tid & 31, lane = tid & 63;
+    const int item = blockIdx.x * 8 + (tid >> 5);
+    const bool act = item < heads_total;
+    const float* p = part + (size_t) (act ? item : 0) * nsplit * 132;
+    float M = -1.0e30f;
+    for (int s0 = 0; s0 < nsplit; s0 += 32)
+    {
+        float m = (s0 + l < nsplit) ? p[(size_t) (s0 + l) * 132] : -1.0e30f;
+        #pragma unroll
+        for (int j = 1; j < 32; j <<= 1) m = fmaxf(m, xor_lane(m, j));
+        M = fmaxf(M, m);
+    }
+    float L = 0.0f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    for (int s0 = 0; s0 < nsplit; s0 += 32)
+    {
+        const bool has = s0 + l < nsplit;
+        const float2 ml = has ? *((const float2*) (p + (size_t) (s0 + l) * 132)) : float2{ -1.0e30f, 0.0f };
+        const float e_mine = has ? __expf(ml.x - M) : 0.0f;
+        float lsum = ml.y * e_mine;
+        #pragma unroll
+        for (int j = 1; j < 32; j <<= 1) lsum += xor_lane(lsum, j);
+        L += lsum;
+        const int cnt = min(32, nsplit - s0);
+        for (int c0 = 0; c0 < cnt; c0 += 8)
+        {
+            float4_t ov[8]; float ev[8];
+            #pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                const int sidx = min(c0 + u, cnt - 1);
+                ov[u] = *((const float4_t*) (p + (size_t) (s0 + sidx) * 132 + 4 + 4 * l));
+                ev[u] = __shfl(e_mine, (lane & 32) + sidx, 64);                      // split sidx's weight lives in lane sidx of this half-wave
+            }
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) if (c0 + u < cnt) { o0 += ov[u].x * ev[u]; o1 += ov[u].y * ev[u]; o2 += ov[u].z * ev[u]; o3 += ov[u].w * ev[u]; }
+        }
+    }
+    const float inv = L > 0.0f ? 1.0f / L : 0.0f;
+    float v0 = o0 * inv, v1 = o1 * inv, v2 = o2 * inv, v3 = o3 * inv;
+    kvg_had32(v0, v1, v2, v3, lane);
+    if (act) ((half4_t*) (out + (size_t) item * 128))[l] = half4_t{ f2h(v0 * ATT_R32), f2h(v1 * ATT_R32), f2h(v2 * ATT_R32), f2h(v3 * ATT_R32) };
+}
+
+extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
+                                       const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
+                                       int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
+                                       float* workspace, int64_t workspace_floats, void* stream)
+{
+    EXL3_CHECK_ARG(q && out && k_cache && k_scales && v_cache && v_scales && block_table && cache_seqlens, "attn_decode: null pointer");
+    EXL3_CHECK_ARG(head_dim == 128, "attn_decode: head_dim must be 128");
+    EXL3_CHECK_ARG(heads_kv >= 1 && heads_q % heads_kv == 0 && heads_q / heads_kv <= ATT_MAX_GQ, "attn_decode: heads_q must be a multiple (<= 8x) of heads_kv");
+    EXL3_CHECK_ARG(k_bits >= 2 && k_bits <= 8 && v_bits >= 2 && v_bits <= 8, "attn_decode: cache bits must be in [2, 8]");
+    EXL3_CHECK_ARG(page_size > 0 && max_len >= 1, "attn_decode: bad page size / length bound");
+    if (bsz == 0) return EXL3_OK;
+    // context splits: enough workgroups to cover the chip, at least 64 tokens (8 per half-wave) each
+    int split_tokens = ((max_len + 31) / 32) * bsz * heads_kv <= 1024 ? 32 : 64;   // 4 or 8 tokens per half-wave
+    int nsplit = (max_len + split_tokens - 1) / split_tokens;
+    const int cap = 1024 / (bsz * heads_kv) > 1 ? 1024 / (bsz * heads_kv) : 1;
+    if (nsplit > cap) { nsplit = cap; split_tokens = ((max_len + nsplit - 1) / nsplit + 7) / 8 * 8; nsplit = (max_len + split_tokens - 1) / split_tokens; }
+    EXL3_CHECK_ARG(nsplit == 1 || (workspace && workspace_floats >= (int64_t) bsz * heads_q * nsplit * 132), "attn_decode: workspace too small for the context splits");
+    AttnArgs a;
+    a.q = (const half_t*) q; a.out = (half_t*) out;
+    a.k_cache = (const uint32_t*) k_cache; a.k_scales = (const half_t*) k_scales; a.v_cache = (const uint32_t*) v_cache; a.v_scales = (const half_t*) v_scales;
+    a.block_table = block_table; a.cache_seqlens = cache_seqlens; a.part = workspace;
+    a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.k_bits = k_bits; a.v_bits = v_bits; a.hq = heads_q; a.hkv = heads_kv;
+    a.nsplit = nsplit; a.split_tokens = split_tokens; a.scale = scale;
+    dim3 grid(nsplit, heads_kv, bsz);
+    hipStream_t st = (hipStream_t) stream;
+    switch (heads_q / heads_kv)
+    {
+        case 1: attn_decode_kernel<1><<<grid, 256, 0, st>>>(a); break; case 2: attn_decode_kernel<2><<<grid, 256, 0, st>>>(a); break;
+        case 3: attn_decode_kernel<3><<<grid, 256, 0, st>>>(a); break; case 4: attn_decode_kernel<4><<<grid, 256, 0, st>>>(a); break;
+        case 5: attn_decode_kernel<5><<<grid, 256, 0, st>>>(a); break; case 6: attn_decode_kernel<6><<<grid, 256, 0, st>>>(a); break;
+        case 7: attn_decode_kernel<7><<<grid, 256, 0, st>>>(a); break; default: attn_decode_kernel<8><<<grid, 256, 0, st>>>(a); break;
+    }
+    int rc = exl3_check_launch("attn_decode");
+    if (rc) return rc;
+    if (nsplit > 1)
+    {
+        const int items = bsz * heads_q;
+        attn_merge_kernel<<<(items + 7) / 8, 256, 0, st>>>(workspace, (half_t*) out, items, nsplit);
+        rc = exl3_check_launch("attn_merge");
+    }
+    return rc;
+}

@@ -132,3 +132,45 @@ __device__ __forceinline__ void kv_quant_regs(float v0, float v1, float v2, floa
 {
     kv_quant_regs_rt(BITS, v0, v1, v2, v3, out, out_scale, active, lane);
 }
+
+// Rotated-domain values of one quantized 32-group (8 lanes x 4 values): u = (level - (2^(b-1) - 0.5)) * scale / 2^(b-1).  The dequantized
+// K / V the reference materialises is x' = H32(u) / sqrt(32) (cache/q_cache_kernels.cuh:150-236, exl3_rope_cache.hip kv_dequant_group); attention
+// can stay in the rotated domain because H32/sqrt(32) is orthonormal and symmetric.  `bits` may be a runtime value.
+__device__ __forceinline__ void kv_dequant_vals_rt(const int bits, const uint32_t* __restrict__ in, const half_t* __restrict__ in_scale, int lane,
+                                                   float& v0, float& v1, float& v2, float& v3)
+{
+    // branch-free: the (up to 4) plane words and the scale are loaded unconditionally (absent planes re-read word 0) so that a caller that
+    // unrolls over several tokens gets all of their loads in flight at once; absent planes are masked out with selects
+    const int sl = lane & 7;
+    uint32_t word[4];
+    int wb = 0;
+    #pragma unroll
+    for (int pi = 0; pi < 4; ++pi)
+    {
+        const int w = 8 >> pi;
+        const bool has = (bits & w) != 0;
+        const int off = sl * 4 * w;
+        word[pi] = in[has ? wb + (off >> 5) : 0];
+        wb += has ? w : 0;
+    }
+    const float scale = (float) *in_scale;
+    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    #pragma unroll
+    for (int pi = 0; pi < 4; ++pi)
+    {
+        const int w = 8 >> pi;
+        const bool has = (bits & w) != 0;
+        const int off = sl * 4 * w;
+        const uint32_t x = word[pi] >> (off & 31);
+        const uint32_t mask = (1u << w) - 1u;
+        q0 = has ? ((q0 << w) | (x & mask)) : q0;
+        q1 = has ? ((q1 << w) | ((x >> w) & mask)) : q1;
+        q2 = has ? ((q2 << w) | ((x >> (2 * w)) & mask)) : q2;
+        q3 = has ? ((q3 << w) | ((x >> (3 * w)) & mask)) : q3;
+    }
+    const int m = 1 << (bits - 1);
+    const float sm = scale * (1.0f / (float) m);
+    const float mh = (float) m - 0.5f;
+    v0 = ((float) (int) q0 - mh) * sm; v1 = ((float) (int) q1 - mh) * sm;
+    v2 = ((float) (int) q2 - mh) * sm; v3 = ((float) (int) q3 - mh) * sm;
+}

@@ -672,3 +672,25 @@ def exl3_gemv_ex_act(gu_slabs, gu_S: int, svh_g, svh_u, B, C, suh, svh, m: int, 
     _check(_lib.lib().exl3_gemv_ex_act(gu_slabs[0], gu_slabs[1], gu_S, _p(svh_g), _p(svh_u), _p(B), _p(C), _p(suh), _p(svh), None, m, k,
                                        B.shape[1] * 16, K, _cb(mcg, mul1), int(c_fp32), flags, force_split, slab, ctypes.byref(S), _stream(B)))
     return [int(slab[0]) if slab[0] else 0], S.value
+
+
+def attn_decode_qcache(q, out, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, max_len: int, scale: float | None = None,
+                       workspace: torch.Tensor | None = None):
+    """Decode attention straight from the quantized paged cache.  q / out: (bsz, heads_q, 128) fp16; caches (pages, page, G * bits) int32 +
+    scales (pages, page, G) fp16 as written by quant_cache_paged / glue_qkv; cache_seqlens int32 (bsz) INCLUDING the new token."""
+    _dev(q)
+    _req(q.dtype == torch.half and out.dtype == torch.half and q.shape == out.shape and q.dim() == 3 and q.shape[-1] == 128, "attn_decode: q/out must be (bsz, heads, 128) float16")
+    _req(q.is_contiguous() and out.is_contiguous(), "attn_decode: q/out must be contiguous")
+    _req(block_table.dtype == torch.int32 and cache_seqlens.dtype == torch.int32, "attn_decode: block_table / cache_seqlens must be int32")
+    bsz, hq, hd = q.shape
+    G = k_scales.shape[-1]
+    hkv = G * 32 // hd
+    kb, vb = _kv_bits(k_cache, k_scales), _kv_bits(v_cache, v_scales)
+    nsplit_max = (max_len + 31) // 32
+    need = bsz * hq * nsplit_max * 132
+    if workspace is None and nsplit_max > 1:
+        workspace = torch.empty((need,), dtype=torch.float, device=q.device)
+    _check(_lib.lib().exl3_attn_decode_qcache(_p(q), _p(out), _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table), _p(cache_seqlens),
+                                              bsz, block_table.shape[1], k_cache.shape[1], kb, vb, hq, hkv, hd, int(max_len),
+                                              float(scale if scale is not None else hd ** -0.5), _p(workspace),
+                                              workspace.numel() if workspace is not None else 0, _stream(q)))

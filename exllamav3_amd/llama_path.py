@@ -150,6 +150,11 @@ class SyntheticEXL3Llama:
         self.xs3 = [torch.empty((bsz, nb_h), dtype=f32, device=dev) for _ in range(3)]
         self.xh_d = torch.empty((bsz, self.inter_local), dtype=f16, device=dev)
         self.ss = torch.empty((bsz, nb_h), dtype=f32, device=dev)
+        # decode attention straight from the quantized cache (optional, head_dim 128): output, lengths incl. the new token, split partials
+        self.attn_pos = pos
+        self.attn_out = torch.empty((bsz, self.hq, hd), dtype=f16, device=dev)
+        self.attn_lens = torch.full((bsz,), pos + 1, dtype=torch.int32, device=dev)
+        self.attn_ws = torch.empty((bsz * self.hq * ((pos + 32) // 32) * 132,), dtype=f32, device=dev)
         self.rope_sin = torch.empty((bsz, 64), dtype=f32, device=dev)
         self.rope_cos = torch.empty((bsz, 64), dtype=f32, device=dev)
         self.xs_d = torch.empty((bsz, nb_i), dtype=f32, device=dev)
@@ -198,6 +203,9 @@ class SyntheticEXL3Llama:
     #: when the GEMM reads it -- so it stays off; kept as a tested option.
     reconstruct_ahead = False
 
+    #: include the decode attention over the quantized cache in decode_step_fused (bench.py --attention)
+    with_attention = False
+
     #: m <= 4: finish silu(g) * u inside the down GEMV instead of a glue_act launch
     act_in_gemv = os.environ.get("EXL3_HIP_ACT_IN_GEMV", "1") != "0"
 
@@ -233,12 +241,19 @@ class SyntheticEXL3Llama:
             vc, vs = self.vcache[li]
             ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
                          self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd)
-            # [attention core out of scope: attention output := q]; o_proj takes the raw attention output (fused input Hadamard)
+            # attention core: out of the benchmark's scope by default (attention output := q); with_attention runs the
+            # quant-cache-direct decode attention over the cached context (the K/V pages hold whatever the cache holds: zeros here except the
+            # appended token, which is enough for timing and for the parity test that fills the cache first)
+            o_in = q2
+            if self.with_attention and hd == 128:
+                ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
+                                       self.attn_pos + 1, workspace=self.attn_ws)
+                o_in = self.attn_out.view(bsz, -1)
             if self.tp == 1:
-                so, So = ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"])
+                so, So = ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"])
                 ext.glue_resid(so[0], So, lo.svh, None, x, ss, bsz)
             else:
-                lo.bc.run(q2, self.o)
+                lo.bc.run(o_in, self.o)
                 be.all_reduce(self.o)
                 ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=self.o)
             if rot:

@@ -197,6 +197,17 @@ int exl3_gemv_ex_act(const float* g_slabs, const float* u_slabs, int act_S, cons
 /* y[rows][cols] = silu(g) * u (activation.cu) where g and u are fp16 column ranges of wider matrices (row strides ld_g, ld_u). */
 int exl3_silu_mul_2d(const void* g, const void* u, void* y, int64_t rows, int64_t cols, int64_t ld_g, int64_t ld_u, void* stream);
 
+/* Decode attention straight from the quantized paged cache (one new token per sequence, GQA, head_dim 128):
+ *   out[b][h] = softmax(q[b][h] . K[b][:len]^T * scale) @ V[b][:len]     with K, V the dequantized cache (cache/q_cache_kernels.cuh semantics)
+ * reference: libtorch/attention.cpp:246-504 (dequant_cache_paged + fp16 attention).  K / V are never materialised: scores and the output are
+ * computed in the cache's rotated (H32) domain.  cache_seqlens[b] = length INCLUDING the new token (append it first).  max_len bounds the
+ * lengths (host value: no sync).  workspace: >= bsz * heads_q * ceil(max_len / 32) * 132 floats for the flash-decoding partials (may be NULL
+ * when max_len <= 32). */
+int exl3_attn_decode_qcache(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
+                            const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
+                            int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
+                            float* workspace, int64_t workspace_floats, void* stream);
+
 /* Diagnostics only: copy [byte_offset, byte_offset + nbytes) of the per-device split-k workspace to dst (tools/gemv_timeline.py). */
 int exl3_debug_copy_workspace(void* dst, int64_t byte_offset, int64_t nbytes, void* stream);
 

@@ -467,3 +467,22 @@ def routing_std(hidden: np.ndarray, gate: np.ndarray, k: int, bias: np.ndarray |
     e = np.exp(sel - sel[:, :1])
     w = (e / (e.sum(-1, keepdims=True) + 1e-20)).astype(np.float16)
     return scores, order.astype(np.int64), w
+
+
+def attn_decode_qcache(q: np.ndarray, k_deq: np.ndarray, v_deq: np.ndarray, lens, scale: float | None = None) -> np.ndarray:
+    """Decode attention of one new token per sequence over the DEQUANTIZED cache (what the reference attends to after dequant_cache_paged,
+    libtorch/attention.cpp:246-504): q (b, hq, d) fp16; k_deq / v_deq (b, T, hkv, d) fp16 = kv_dequant of the cache; lens[b] tokens valid.
+    GQA: q head h uses kv head h // (hq / hkv).  fp32 softmax / accumulation, fp16 result."""
+    b, hq, d = q.shape
+    hkv = k_deq.shape[2]
+    gq = hq // hkv
+    sc = np.float32(scale if scale is not None else d ** -0.5)
+    out = np.zeros((b, hq, d), dtype=np.float32)
+    for bi in range(b):
+        L = int(lens[bi])
+        for h in range(hq):
+            kk = k_deq[bi, :L, h // gq].astype(np.float32); vv = v_deq[bi, :L, h // gq].astype(np.float32)
+            s = (kk @ q[bi, h].astype(np.float32)) * sc
+            p = np.exp(s - s.max()); p /= p.sum()
+            out[bi, h] = p @ vv
+    return out.astype(np.float16)

@@ -421,3 +421,41 @@ def test_moe_block_matches_oracle(dev, cb, tokens):
             a = (g / (1 + np.exp(-g)) * u).astype(np.float16)
             ref[t] += float(w[t, j]) * _lin(moe.down[e], a, out_fp32=True)[0]
     assert np.abs(y - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
+
+
+def test_fused_step_with_attention_matches_oracle(dev):
+    """decode_step_fused(with_attention): q/k/v -> RoPE -> quantized append -> attention over the (pre-filled) quantized cache -> o_proj ...
+    against the oracle composition (attention over the dequantized cache)."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 256, 512, 1, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=1024)
+    bsz, pos = 2, 300
+    model.alloc_state(bsz, pos=pos)
+    model.with_attention = True
+    # pre-fill the cache of layer 0 with random context (contiguous pages per sequence in this model)
+    rng = np.random.default_rng(3)
+    ctx_k = rng.standard_normal((bsz, 1024, model.hkv * 128)).astype(np.float16); ctx_v = rng.standard_normal((bsz, 1024, model.hkv * 128)).astype(np.float16)
+    kq, ks = o.kv_quant(ctx_k, 4); vq, vs = o.kv_quant(ctx_v, 4)
+    kc, ksc = model.kcache[0]; vc, vsc = model.vcache[0]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    kc.copy_(T(kq.view(np.int32)).view(kc.shape)); ksc.copy_(T(ks).view(ksc.shape)); vc.copy_(T(vq.view(np.int32)).view(vc.shape)); vsc.copy_(T(vs).view(vsc.shape))
+    logits = model.decode_step_fused().float().cpu().numpy()
+    # oracle
+    x = _np(model.x0); L = model.layers[0]
+    xn = o.rms_norm(x, _np(L["norm1"]), model.eps)
+    q, k, v = _lin(L["q"], xn), _lin(L["k"], xn), _lin(L["v"], xn)
+    posv = _np(model.positions)
+    q4, k4 = o.rope(q.reshape(bsz, 1, model.hq, 128), k.reshape(bsz, 1, model.hkv, 128), _np(model.inv_freq), positions=posv, rope_mode=o.ROPE_NEOX)
+    knq, kns = o.kv_quant(k4.reshape(bsz, 1, -1), 4); vnq, vns = o.kv_quant(v.reshape(bsz, 1, -1), 4)
+    kq[:, pos:pos + 1] = knq; ks[:, pos:pos + 1] = kns; vq[:, pos:pos + 1] = vnq; vs[:, pos:pos + 1] = vns
+    kd = o.kv_dequant(kq, ks, 4).reshape(bsz, 1024, model.hkv, 128); vd = o.kv_dequant(vq, vs, 4).reshape(bsz, 1024, model.hkv, 128)
+    att = o.attn_decode_qcache(q4.reshape(bsz, model.hq, 128), kd, vd, [pos + 1] * bsz)
+    ov = _lin(L["o"], att.reshape(bsz, -1), out_fp32=True)
+    xn, x = o.rms_norm(ov, _np(L["norm2"]), model.eps, residual_in=x)
+    gf, uf = _lin(L["gate"], xn).astype(np.float32), _lin(L["up"], xn).astype(np.float32)
+    a = (gf / (1 + np.exp(-gf)) * uf).astype(np.float16)
+    d = _lin(L["down"], a, out_fp32=True)
+    xn, x = o.rms_norm(d, _np(model.final_norm), model.eps, residual_in=x)
+    ref = _lin(model.lm_head, xn).astype(np.float32)
+    assert np.abs(logits - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2

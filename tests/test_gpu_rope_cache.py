@@ -103,3 +103,36 @@ def test_kv_quant_paged_roundtrip(dev, kb, vb):
                 pk, sc = o.kv_quant(full[t:t + 1], bits)
                 ref = o.kv_dequant(pk, sc, bits)[0]
                 assert np.array_equal(got[pg, t % page].view(np.uint16), ref.view(np.uint16)), (b, t, bits)
+
+
+@pytest.mark.parametrize("kb,vb", [(4, 4), (8, 3), (2, 6)])
+@pytest.mark.parametrize("lens", [[1], [63, 64], [300, 1000, 77]])
+def test_attn_decode_qcache(dev, kb, vb, lens):
+    """Decode attention straight from the quantized paged cache (rotated-domain scores / accumulation, flash-decoding splits) against the
+    oracle attention over the dequantized cache; scattered pages, ragged lengths, GQA 4."""
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(kb * 10 + vb + len(lens))
+    bsz, hq, hkv, hd, page = len(lens), 8, 2, 128, 256
+    maxlen = max(lens)
+    pps = (maxlen + page - 1) // page
+    npages = bsz * pps + 3
+    perm = rng.permutation(npages)[: bsz * pps].reshape(bsz, pps).astype(np.int32)          # scattered physical pages
+    G = hkv * hd // 32
+    k = (rng.standard_normal((bsz, pps * page, hkv * hd)) * 1.5).astype(np.float16)
+    v = rng.standard_normal((bsz, pps * page, hkv * hd)).astype(np.float16)
+    kq, ks = o.kv_quant(k, kb); vq, vs = o.kv_quant(v, vb)
+    kc = np.zeros((npages, page, G * kb), dtype=np.uint32); ksc = np.zeros((npages, page, G), dtype=np.float16)
+    vc = np.zeros((npages, page, G * vb), dtype=np.uint32); vsc = np.zeros((npages, page, G), dtype=np.float16)
+    for b in range(bsz):
+        for p in range(pps):
+            kc[perm[b, p]] = kq[b, p * page:(p + 1) * page]; ksc[perm[b, p]] = ks[b, p * page:(p + 1) * page]
+            vc[perm[b, p]] = vq[b, p * page:(p + 1) * page]; vsc[perm[b, p]] = vs[b, p * page:(p + 1) * page]
+    q = rng.standard_normal((bsz, hq, hd)).astype(np.float16)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out = torch.full((bsz, hq, hd), float("nan"), dtype=torch.half, device=dev)
+    ext.attn_decode_qcache(T(q), out, T(kc.view(np.int32)), T(ksc), T(vc.view(np.int32)), T(vsc), T(perm), T(np.array(lens, dtype=np.int32)), maxlen)
+    kd = o.kv_dequant(kq, ks, kb).reshape(bsz, -1, hkv, hd); vd = o.kv_dequant(vq, vs, vb).reshape(bsz, -1, hkv, hd)
+    ref = o.attn_decode_qcache(q, kd, vd, lens).astype(np.float32)
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
