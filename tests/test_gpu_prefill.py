@@ -180,3 +180,19 @@ def test_forward_gate_up_silu_fused_gemm(dev):
     gf = o.linear_forward(x, g[0], g[1], g[2], K, 2).astype(np.float32); uf = o.linear_forward(x, u[0], u[1], u[2], K, 2).astype(np.float32)
     ref = (gf / (1 + np.exp(-gf)) * uf)
     assert np.abs(a.float().cpu().numpy() - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+
+
+def test_loaded_checkpoint_linear_runs_on_gpu(dev, tmp_path):
+    """safetensors file -> loader.load_linear_exl3 (tensors land on the GPU as stored) -> forward, against the oracle."""
+    from safetensors.torch import save_file
+    from exllamav3_amd import loader
+    k, n, K = 256, 384, 4
+    tr, suh, svh = o.synth_linear(k, n, K, seed=8, realistic=True)
+    save_file({"m.q_proj.trellis": torch.from_numpy(tr), "m.q_proj.suh": torch.from_numpy(suh), "m.q_proj.svh": torch.from_numpy(svh),
+               "m.q_proj.mcg": torch.zeros(1, dtype=torch.int32)}, str(tmp_path / "model.safetensors"))
+    lin = loader.load_linear_exl3(loader.SafetensorsCollection(str(tmp_path)), "m.q_proj", dev)
+    assert lin.mcg and not lin.mul1 and lin.trellis.device.type == "cuda"
+    x = np.random.default_rng(0).standard_normal((3, k)).astype(np.float16)
+    y = lin.forward(_t(x, dev)).float().cpu().numpy()
+    ref = o.linear_forward(x, tr, suh, svh, K, 1).astype(np.float32)
+    assert np.abs(y - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
