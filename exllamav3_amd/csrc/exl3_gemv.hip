@@ -674,7 +674,9 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             // variants above 64 VGPRs (3INST/MCG decode, NORM prep, K >= 5 rings) fit 7 or 6 waves per SIMD: three 8-wave workgroups per
             // CU instead of one 16-wave workgroup (tools/bench_lmhead.py: lm_head 3INST 105 -> 87 us, NORM 92 -> 81 us)
             if (!deferred && ng == 1 && (cb != 2 || tbl || K >= 5) && nwv > 8) nwv = 8;
+            if (in_act && nwv > 4) nwv = 4;                      // ACT-mode kernels are built for 4-wave workgroups (256 VGPRs available)
             if (g_gemv_nwv < 0) nwv = (-g_gemv_nwv < 16 / ng) ? -g_gemv_nwv : 16 / ng;      // tuning: forced wave count
+            if (in_act && nwv > 4) nwv = 4;
             if (nwv > units) nwv = units;
             if (g_gemv_nwv > 0 && nwv > g_gemv_nwv) nwv = g_gemv_nwv;
             if (nwv < 1) nwv = 1;

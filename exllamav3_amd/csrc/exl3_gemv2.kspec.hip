@@ -51,7 +51,7 @@ template <int K, int CB, int VAR, int NG, int MODE>
 #ifdef G2_ABL_ILP
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 #else
-__global__ __launch_bounds__(1024 / NG) __attribute__((amdgpu_waves_per_eu(NG == 4 ? 3 : NG == 2 ? 4 : (G2_PF > 2 || MODE == G2_MODE_ACT) ? (MODE == G2_MODE_ACT ? 4 : 6) : (K >= 5 && MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1) ? 5 : ((K >= 5 || (MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || MODE == G2_MODE_ACT || CB != EXL3_CB_MUL1) ? 7 : 8)))))
+__global__ __launch_bounds__(MODE == G2_MODE_ACT ? 256 : 1024 / NG) __attribute__((amdgpu_waves_per_eu(MODE == G2_MODE_ACT ? 2 : NG == 4 ? 3 : NG == 2 ? 4 : G2_PF > 2 ? 6 : (K >= 5 && MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1) ? 5 : ((K >= 5 || (MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || MODE == G2_MODE_ACT || CB != EXL3_CB_MUL1) ? 7 : 8)))))
 #endif
 void exl3_gemv2_kernel(const GemvArgs a)
 {
@@ -154,19 +154,14 @@ void exl3_gemv2_kernel(const GemvArgs a)
     #pragma unroll
     for (int gq = 0; gq < NG; ++gq) { acc_c[gq] = float4_t{ 0.f, 0.f, 0.f, 0.f }; acc_d[gq] = float4_t{ 0.f, 0.f, 0.f, 0.f }; }
 
-    LaneWords<K> ring[G2_PF];
-    if (nunits_w > 0)
-    {
-        #pragma unroll
-        for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) (G2_PF * ubase + u) * row_stride);
-    }
-    G2_T(1);
 
     // prep task fetch: task t = it * nhw + hwid of chunk (c0, cnt) -> (block c0 + t / m, row t % m); loads only
     // NORM at m <= 4 and hidden <= 4096: the task owner reduces its row's 32 partial sums of squares itself (loaded with the task's
     // operands: one memory latency, no extra workgroup barrier); otherwise 1/rms per row goes through LDS (rmf_s) once per launch.
     const bool norm_in_task = in_norm && NG == 1 && (a.k >> 7) <= 32;
-    struct PrepIn { half4_t xv, sv, wv; float ss; };
+    // ACT mode: the first 8 gate and 8 up slab lines of the task's block travel with the task operands (issued before the weight rows)
+    constexpr int ACT_PRE = MODE == G2_MODE_ACT ? 8 : 1;
+    struct PrepIn { half4_t xv, sv, wv; float ss; float4_t sg[ACT_PRE], su[ACT_PRE]; half4_t svg, svu; };
     auto fetch = [&] (int c0, int cnt, int it) -> PrepIn
     {
         PrepIn r; r.xv = half4_t{ 0, 0, 0, 0 }; r.sv = r.xv; r.wv = r.xv; r.ss = 0.0f;
@@ -174,6 +169,21 @@ void exl3_gemv2_kernel(const GemvArgs a)
         const int blk = c0 + t / m, row = t % m;
         const size_t kofs = (size_t) k0s + 128 * blk;
         if constexpr (MODE != G2_MODE_ACT) r.xv = ((const half4_t*) (x_src + (size_t) row * a.k + kofs))[l32];
+        else
+        {
+            const int blk_abs = (k0s >> 7) + blk;
+            const float* pg = a.act_g + ((size_t) blk_abs * a.act_S * m + row) * 128;
+            const float* pu = a.act_u + ((size_t) blk_abs * a.act_S * m + row) * 128;
+            const size_t st = (size_t) m * 128;
+            #pragma unroll
+            for (int i = 0; i < ACT_PRE; ++i)
+            {
+                r.sg[i] = ((const float4_t*) (pg + (size_t) min(i, a.act_S - 1) * st))[l32];
+                r.su[i] = ((const float4_t*) (pu + (size_t) min(i, a.act_S - 1) * st))[l32];
+            }
+            r.svg = ((const half4_t*) (a.act_svh_g + blk_abs * 128))[l32];
+            r.svu = ((const half4_t*) (a.act_svh_u + blk_abs * 128))[l32];
+        }
         if (!in_rotated)
         {
             r.sv = ((const half4_t*) (suh + kofs))[l32];
@@ -185,8 +195,19 @@ void exl3_gemv2_kernel(const GemvArgs a)
         }
         return r;
     };
-    // the first task's operands are requested now, together with the weight rows (and before the 1/rms loads of NORM mode)
+    // the first task's operands are requested first (before the 1/rms loads of NORM mode) ...
     PrepIn nx = fetch(0, min(chb, nb), 0);
+
+    // ... and only then the first weight rows: loads return in issue order per wave, so with the weights first the (small, L2-resident)
+    // activation operands could not be consumed -- and the input Hadamards could not start -- before the first weight rows had arrived from
+    // HBM; this way the prep computes underneath the weight latency
+    LaneWords<K> ring[G2_PF];
+    if (nunits_w > 0)
+    {
+        #pragma unroll
+        for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) (G2_PF * ubase + u) * row_stride);
+    }
+    G2_T(1);
 
     if (in_norm && !norm_in_task)
     {
@@ -226,7 +247,8 @@ void exl3_gemv2_kernel(const GemvArgs a)
             for (int it = 0; it < trips; ++it)
             {
                 const PrepIn cur = nx;
-                if (it + 1 < trips) nx = fetch(c0, cnt, it + 1);
+                // software pipelining by one task, except in ACT mode where a task's operands are 64 VGPRs of slab lines (fetched after the task)
+                if constexpr (MODE != G2_MODE_ACT) { if (it + 1 < trips) nx = fetch(c0, cnt, it + 1); }
                 const int t = it * nhw + hwid;
                 const bool act = t < ntask;
                 const int tc = min(t, ntask - 1);
@@ -244,10 +266,21 @@ void exl3_gemv2_kernel(const GemvArgs a)
                         // a = fp16(silu(g) * u) of this (row, block): split-k reduce of the gate / up slabs, output Hadamards, svh -- the arithmetic of
                         // glue_act_kernel (same device functions), done by the half-wave that needs the block
                         const int blk_abs = (k0s >> 7) + c0 + blk_l;
-                        const SlabRef sg = { a.act_g, a.act_S }, su = { a.act_u, a.act_S };
-                        const half4_t svg = ((const half4_t*) (a.act_svh_g + blk_abs * 128))[l32], svu = ((const half4_t*) (a.act_svh_u + blk_abs * 128))[l32];
-                        float4_t vg, vu;
-                        slab_sum2<8>(sg, su, blk_abs, row, m, l32, vg, vu);
+                        const half4_t svg = cur.svg, svu = cur.svu;
+                        // slice-order sums (the order of slab_sum2 / glue_act_kernel): the prefetched lines first, any further slices from memory
+                        float4_t vg = { 0.f, 0.f, 0.f, 0.f }, vu = vg;
+                        #pragma unroll
+                        for (int i = 0; i < ACT_PRE; ++i) if (i < a.act_S)
+                        {
+                            vg.x += cur.sg[i].x; vg.y += cur.sg[i].y; vg.z += cur.sg[i].z; vg.w += cur.sg[i].w;
+                            vu.x += cur.su[i].x; vu.y += cur.su[i].y; vu.z += cur.su[i].z; vu.w += cur.su[i].w;
+                        }
+                        for (int sl = ACT_PRE; sl < a.act_S; ++sl)
+                        {
+                            const float4_t tg = ((const float4_t*) (a.act_g + (((size_t) blk_abs * a.act_S + sl) * m + row) * 128))[l32];
+                            const float4_t tu = ((const float4_t*) (a.act_u + (((size_t) blk_abs * a.act_S + sl) * m + row) * 128))[l32];
+                            vg.x += tg.x; vg.y += tg.y; vg.z += tg.z; vg.w += tg.w; vu.x += tu.x; vu.y += tu.y; vu.z += tu.z; vu.w += tu.w;
+                        }
                         float g0, g1, g2, g3, u0, u1, u2, u3;
                         out_had(vg, l32, g0, g1, g2, g3);
                         out_had(vu, l32, u0, u1, u2, u3);
@@ -311,6 +344,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
                         *((half2_t*) (base + (q0 + 1) * 4 + sp * 2)) = o23;
                     }
                 }
+                if constexpr (MODE == G2_MODE_ACT) { if (it + 1 < trips) nx = fetch(c0, cnt, it + 1); }
             }
         }
         __syncthreads();
