@@ -276,8 +276,13 @@ class SyntheticEXL3Llama:
                 ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.d], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT, c_fp32=True)
                 be.all_reduce(self.d)
                 ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=self.d)
-        ext.exl3_gemv_ex_norm(x, self.final_norm, ss, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
-                              bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
+        if rot:
+            ext.glue_rotate(x, ss, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz)
+            ext.exl3_gemv_ex(None, self.xh3[:1], None, [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
+                             bsz, self.lm_head.mcg, self.lm_head.mul1, ROT)
+        else:
+            ext.exl3_gemv_ex_norm(x, self.final_norm, ss, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
+                                  bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
         return self.logits
 
     def decode_step_fused_v1(self):
@@ -398,6 +403,12 @@ class SyntheticEXL3Llama:
                 calls.append(lambda ld=ld, lq=lq, lk=lk, lv=lv, L=L: ext.exl3_gemv_norm(
                     None, self.xh_d, self.xs_d, ld.trellis, None, ld.svh, None, bsz, ld.mcg, ld.mul1, self.x, L["norm1"], self.eps,
                     [lq.suh, lk.suh, lv.suh], self.xh3, self.xs3))
+            elif pipeline == "glue" and self.tp == 1 and bsz > 4:
+                # batches above 4 rows: the step rotates once (glue_rotate) and the GEMVs read pre-rotated inputs
+                calls.append(lambda lq=lq, lk=lk, lv=lv: ext.exl3_gemv_ex(None, self.xh3, None, [lq.trellis, lk.trellis, lv.trellis], None, None, None, bsz, lq.mcg, lq.mul1, ROT | DEF))
+                calls.append(lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF))
+                calls.append(lambda lg=lg, lu=lu: ext.exl3_gemv_ex(None, self.xh3[:2], None, [lg.trellis, lu.trellis], None, None, None, bsz, lg.mcg, lg.mul1, ROT | DEF))
+                calls.append(lambda ld=ld: ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF))
             elif pipeline == "glue" and self.tp == 1:
                 calls.append(lambda lq=lq, lk=lk, lv=lv, L=L: ext.exl3_gemv_ex_norm(self.x, L["norm1"], self.ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh], None, bsz, lq.mcg, lq.mul1, DEF))
                 calls.append(lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF))
@@ -413,7 +424,9 @@ class SyntheticEXL3Llama:
                 calls.append(lambda lo=lo: lo.bc.run(q2, self.o))
                 calls.append(lambda lg=lg, lu=lu: ext.exl3_mgemm_bcast(self.xn, [lg.trellis, lu.trellis], [self.g, self.u], [lg.suh, lu.suh], [lg.svh, lu.svh], lg.mcg, lg.mul1))
                 calls.append(lambda ld=ld: ld.bc.run(self.a, self.d))
-        if pipeline == "glue" and self.tp == 1:
+        if pipeline == "glue" and self.tp == 1 and bsz > 4:
+            calls.append(lambda: ext.exl3_gemv_ex(None, self.xh3[:1], None, [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, ROT))
+        elif pipeline == "glue" and self.tp == 1:
             calls.append(lambda: ext.exl3_gemv_ex_norm(self.x, self.final_norm, self.ss, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, 0))
         elif pipeline == "tail" and self.tp == 1:
             calls.append(lambda: ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, ROT))
