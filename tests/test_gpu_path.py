@@ -459,3 +459,19 @@ def test_fused_step_with_attention_matches_oracle(dev):
     xn, x = o.rms_norm(d, _np(model.final_norm), model.eps, residual_in=x)
     ref = _lin(model.lm_head, xn).astype(np.float32)
     assert np.abs(logits - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+
+
+@pytest.mark.parametrize("bsz", [1, 16])
+def test_fused_pipeline_on_70b_tp8_rank_shapes(dev, bsz):
+    """The per-rank shapes of Llama-3.1-70B under TP = 8 (hidden 8192, q 8 heads, ONE kv head -> 128-column k / v matrices, inter 3584,
+    vocab shard 16128): fused pipeline against the op-by-op pipeline (single process; the collectives are exercised by test_tp_gloo.py)."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    shape = LlamaShape("70b-rank", 8192, 3584, 1, 8, 1, 128, 16128)
+    model = SyntheticEXL3Llama(shape, K=3, cb=2, device=dev, kv_bits=4, max_ctx=1024)
+    model.alloc_state(bsz, pos=500)
+    lu = model.decode_step().float().cpu().numpy().copy()
+    lf = model.decode_step_fused().float().cpu().numpy()
+    assert np.isfinite(lf).all()
+    assert np.abs(lf - lu).max() / np.sqrt((lu ** 2).mean()) < 1e-2
