@@ -472,6 +472,8 @@ static int gemv_gen()
 extern "C" int exl3_set_gemv_gen(int v) { g_gemv_gen = (v == 1) ? 1 : 2; return EXL3_OK; }
 static int g_gemv_nwv = 0;           // 0 = heuristic; otherwise cap on waves per workgroup (tuning / tests)
 static int g_gemv_defer_wg_per_cu = 0;
+static int g_gemm3_min_rows = 9;     // passes with at least this many rows take generation 3 (0 = never)
+extern "C" int exl3_set_gemm3_min_rows(int v) { g_gemm3_min_rows = v; return EXL3_OK; }
 
 extern "C" int exl3_set_gemv_defer_wg_per_cu(int v) { g_gemv_defer_wg_per_cu = v; return EXL3_OK; }
 extern "C" int exl3_set_gemv_max_waves(int v) { g_gemv_nwv = v; return EXL3_OK; }
@@ -576,12 +578,16 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     if (!ctx) return EXL3_ERR_INIT;
 
     const int var = gemv_variant();
-    for (int m0 = 0; m0 < m; m0 += 16)
+    // generation 3 streams the weights once per 32 rows (exl3_gemm3.kspec.hip); the special input / output modes stay on generation 2
+    const bool g3_ok = g_gemm3_min_rows > 0 && !in_norm && !tbl && !in_act && !epi && (deferred || rotated || gemv_gen() == 2);
+    const int pass_rows = (g3_ok && !deferred && !rotated && m > 16) ? 32 : 16;
+    for (int m0 = 0; m0 < m; m0 += pass_rows)
     {
-        const int mp = (m - m0) < 16 ? (m - m0) : 16;
+        const int mp = (m - m0) < pass_rows ? (m - m0) : pass_rows;
         GemvArgs args;
         memset((void*) &args, 0, sizeof(args));
-        const int gen = (deferred || rotated || in_norm || tbl || in_act) ? 2 : gemv_gen();
+        const bool g3 = g3_ok && mp >= g_gemm3_min_rows;
+        const int gen = g3 ? 3 : (deferred || rotated || in_norm || tbl || in_act) ? 2 : gemv_gen();
         args.act_g = act_g; args.act_u = act_u; args.act_S = act_S;
         args.act_svh_g = (const half_t*) act_svh_g; args.act_svh_u = (const half_t*) act_svh_u;
         args.norm_w = (const half_t*) norm_w; args.ss_part = ss_part; args.eps = eps;
@@ -607,7 +613,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             if (fs < 1) fs = 1;
             if (epi && fs > 64) fs = 64;                         // tail epilogue: one pass of slabs must fit the workgroup LDS
         }
-        const int S = choose_split(gen, total_cb, k, mp, ctx->num_cus, fs);
+        const int S = choose_split(gen == 3 ? 2 : gen, total_cb, k, mp, ctx->num_cus, fs);
         const int nb = k / 128;
         const int bps = (nb + S - 1) / S;
         int cbf = 0; int64_t wso = 0;
@@ -659,7 +665,31 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         args.c_row_offset = m0;
 
         dim3 grid((unsigned) (total_cb * S));
-        if (gen == 2)
+        if (gen == 3)
+        {
+            const int mt = mp > 16 ? 2 : 1;
+            int nwv = 4;
+            if (g_gemv_nwv < 0) nwv = -g_gemv_nwv < 8 ? -g_gemv_nwv : 8;
+            if (nwv > bps * 2) nwv = bps * 2;                    // units of >= 4 tile rows
+            // three workgroups per CU: 36 KB of transpose buffers + <= 17 KB of activations each
+            int chunk = (17408 / (mp * 2) - 16) / 128;
+            if (chunk < 1) chunk = 1;
+            if (chunk > bps) chunk = bps;
+            args.chunk_blocks = chunk;
+            const size_t lds = exl3_gemm3_lds_bytes(mt, nwv, mp, chunk);
+            switch (K)
+            {
+                case 1: exl3_gemm3_launch_k1(cb, mt, nwv, grid, lds, st, args); break;
+                case 2: exl3_gemm3_launch_k2(cb, mt, nwv, grid, lds, st, args); break;
+                case 3: exl3_gemm3_launch_k3(cb, mt, nwv, grid, lds, st, args); break;
+                case 4: exl3_gemm3_launch_k4(cb, mt, nwv, grid, lds, st, args); break;
+                case 5: exl3_gemm3_launch_k5(cb, mt, nwv, grid, lds, st, args); break;
+                case 6: exl3_gemm3_launch_k6(cb, mt, nwv, grid, lds, st, args); break;
+                case 7: exl3_gemm3_launch_k7(cb, mt, nwv, grid, lds, st, args); break;
+                case 8: exl3_gemm3_launch_k8(cb, mt, nwv, grid, lds, st, args); break;
+            }
+        }
+        else if (gen == 2)
         {
             const int ng = mp <= 4 ? 1 : (mp <= 8 ? 2 : 4);
             int nwv = 16 / ng;                                   // partial-sum LDS: nwv * 4*ng rows * 512 B <= 32 KB

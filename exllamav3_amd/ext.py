@@ -78,6 +78,11 @@ def set_gemv_max_waves(n: int):
     _lib.lib().exl3_set_gemv_max_waves(int(n))
 
 
+def set_gemm3_min_rows(n: int):
+    """Passes with at least n rows use the generation-3 small-m GEMM (exl3_gemm3.kspec.hip); default 9, 0 = never."""
+    _lib.lib().exl3_set_gemm3_min_rows(int(n))
+
+
 # --------------------------------------------------------------------------------------------------
 # format ops
 # --------------------------------------------------------------------------------------------------

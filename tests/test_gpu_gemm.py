@@ -212,3 +212,42 @@ def test_mgemm_indexed_moe_forms(dev, cb, k, n, K):
         assert np.abs(C[t].float().cpu().numpy() - ref).max() < 2 * tol(ref)
     with pytest.raises(RuntimeError):
         ext.exl3_mgemm(T(xs2), pB, C, psu, None, psv, T(sel2), T(w2), K, -1, cb == 1, cb == 2, 0, 4, 0, num_tokens=2)
+
+
+# ---- generation 3 (exl3_gemm3.kspec.hip): 9..32 rows per pass through the LDS transpose into 16x16x32 MFMAs ----------------------------
+
+@pytest.mark.parametrize("cb", [0, 1, 2])
+@pytest.mark.parametrize("K", range(1, 9))
+def test_gemm3_all_bitrates(dev, K, cb):
+    from exllamav3_amd import ext
+    ext.set_gemm3_min_rows(9)
+    assert _run(dev, 512, 256, K, cb, 12, 1) < TOL
+    assert _run(dev, 1024, 128, K, cb, 32, 1) < TOL
+
+
+@pytest.mark.parametrize("m", [9, 16, 17, 24, 32, 33, 47, 64, 65, 144])
+@pytest.mark.parametrize("split", [0, 1, 3, 8])
+def test_gemm3_rows_and_splits(dev, m, split):
+    # uneven slices, several activation chunks per slice (k = 2816 at split 1: 22 Hadamard blocks against a 2..4 block LDS budget),
+    # tails of 1 row (33, 65) that fall back to generation 2 inside the same call
+    from exllamav3_amd import ext
+    ext.set_gemm3_min_rows(9)
+    for cb in (0, 2):
+        assert _run(dev, 2816, 256, 4, cb, m, 1, force_split=split) < TOL
+        assert _run(dev, 1024, 384, 3, cb, m, 1, out_fp32=True, bias=True, force_split=split, realistic=True, seed=5) < TOL
+
+
+def test_gemm3_agrees_with_generation_2(dev):
+    # same products, fp32 accumulation in a different order: the two kernels agree far inside the oracle tolerance
+    from exllamav3_amd import ext
+    tr, suh, svh = o.synth_linear(4096, 512, 4, seed=11, realistic=True)
+    x = torch.randn((16, 4096), device=dev).half()
+    ys = []
+    for mr in (0, 9):
+        ext.set_gemm3_min_rows(mr)
+        y = torch.empty((16, 512), dtype=torch.float, device=dev)
+        ext.exl3_gemm(x, _t(tr, dev), y, _t(suh, dev), None, _t(svh, dev), -1, False, True, 0)
+        ys.append(y)
+    ext.set_gemm3_min_rows(9)
+    err = (ys[0] - ys[1]).abs().max() / ys[0].pow(2).mean().sqrt()
+    assert err < 2e-3, err

@@ -9,6 +9,7 @@ model.alloc_state(int(os.environ.get("BSZ", "1")))
 import os
 from exllamav3_amd import ext
 if os.environ.get("MAXW"): ext.set_gemv_max_waves(int(os.environ["MAXW"]))
+if os.environ.get("G3MIN"): ext.set_gemm3_min_rows(int(os.environ["G3MIN"]))
 for pipe in os.environ.get("PIPES", "glue,tail").split(","):
     {"glue": model.decode_step_fused, "tail": model.decode_step_tail}[pipe]()
     torch.cuda.synchronize()

@@ -1,12 +1,14 @@
-"""Whole-step time of the glue pipeline (hipGraph replay) as a function of the split-k factor of each call type."""
-import sys, torch
+"""Whole-step time of the glue pipeline (hipGraph replay) as a function of the split-k factor of each call type.  env: BSZ, G3MIN, CANDS (json)."""
+import json, os, sys, torch
 sys.path.insert(0, "/root/repo")
 from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
 
 dev = torch.device("cuda:0")
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 model = SyntheticEXL3Llama(SHAPES["llama-3.1-8b"], K=4, cb=2, device=dev, kv_bits=4, layers=layers)
-model.alloc_state(1)
+model.alloc_state(int(os.environ.get('BSZ', '1')))
+from exllamav3_amd import ext
+if os.environ.get('G3MIN'): ext.set_gemm3_min_rows(int(os.environ['G3MIN']))
 
 def step_us():
     model.decode_step_fused(); torch.cuda.synchronize()
@@ -28,6 +30,7 @@ def step_us():
 base = step_us()
 print(f"heuristic: {base:.2f} us/layer")
 cands = {"qkv": [16, 32], "o": [16, 32], "gu": [2, 4, 8, 16, 32], "down": [16, 28, 56]}
+if os.environ.get("CANDS"): cands = json.loads(os.environ["CANDS"])
 for key, vals in cands.items():
     for v in vals:
         model.split = dict(SyntheticEXL3Llama.split); model.split[key] = v
