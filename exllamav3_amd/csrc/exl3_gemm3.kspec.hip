@@ -1,22 +1,28 @@
-// EXL3 quantized small-m GEMM for gfx950, kernel generation 3 ("decode -> LDS transpose -> 16x16x32 MFMA"), 9..32 rows per pass.
+// EXL3 quantized small-m GEMM for gfx950, kernel generation 3 ("decode -> LDS transpose -> 16x16x32 MFMA"), 9..64 rows per pass.
 //
 //   C = ((A * suh) H) @ dequant(B) H * svh (+ bias)        reference: quant/exl3_gemm_kernel.cuh:8-80, quant/exl3_gemm_inner.cuh
 //                                                          (semantics only; the reference streams 16 rows per pass)
 //
 // Why a third kernel: generation 2 (exl3_gemv2.kspec.hip) multiplies straight out of the decoding lane's registers with
 // v_mfma_f32_4x4x4_16B_f16, which does a quarter of the matrix pipe's work per cycle.  That is free at m <= 4 (the decode VALU work
-// dominates) but at 16 rows the kernel is MFMA-bound: 1024 MFMA cycles against ~800 decode cycles per 2 tile rows.  Here the decoding
-// lane still reads one contiguous run of the bitstream (lane 8T + c owns columns c, c + 8 of tile T: exl3_lane_decode.cuh), but the fp16
-// weights go through a wave-private LDS buffer into the B-operand layout of v_mfma_f32_16x16x32_f16: 8 MFMAs (128 cycles) per 16 rows
-// per 2 tile rows.  The weight pass is decode-bound again up to 32 rows, so a 32-row pass costs about what a 4-row pass does.
+// dominates) but at 16 rows the kernel is MFMA-bound: 1024 MFMA cycles against ~660 decode cycles per tile row.  Here the fp16 weights
+// go through a wave-private 4.5 KB LDS buffer into the B-operand layout of v_mfma_f32_16x16x32_f16: 64 MFMA cycles per 16 rows per
+// decode step, so the weight pass is decode-bound again and a 32-row pass costs about what a 4-row pass does.
 //
-// LDS transpose.  Unit = 2 tile rows = 32 k x 128 columns = 512 chunks of 8 halves (16 B); chunk (h, kq, T, c) = rows 8 kq .. 8 kq + 7
-// of the unit, column 16 T + 8 h + c.  The decoding lane (T, c) writes its 8 chunks with ds_write_b128 at
-//     (4 h + kq) * 1152 + (8 T + c) * 16          -- 1 KiB contiguous per instruction, conflict-free
-// and MFMA lane (j, kg) reads, for column tile T, the chunk (h = j >> 3, kq = kg, T, c = j & 7): the 1152-byte row pitch puts the four
-// 64-byte runs of every 16-lane ds_read_b128 group on disjoint banks.
-// The k order inside the unit is natural (k = 8 kq + i), so the A operand is read straight from a row-major fp16 copy of the rotated
-// activations (row pitch padded by 32 B: conflict-free ds_read_b128 across the 16 rows).
+// Work split: a workgroup = 4 waves = one 128-column block x one k-slice, as in generation 2, but the waves split the COLUMNS (32 each),
+// not k: every wave walks the whole slice.  Nothing is reduced across waves -- no partial sums through LDS, no barrier after the
+// streaming loop, 8 accumulator VGPRs per 16 rows -- and all waves have exactly the same amount of work.
+//
+// Lane geometry of a decode step (4 tile rows x the wave's 2 tiles): lane = 16 g + 8 t2 + c owns, as in exl3_lane_decode.cuh, the K
+// words [cK, cK + K) of tile (2 wave + t2) of tile row 4 step + g = columns c, c + 8 of that tile, 16 k each: one 16-byte load per lane
+// (K = 4), 256 contiguous bytes per 16-lane group.
+//
+// LDS transpose.  The decoded step is 4 chunk rows r = 2 h + half (h: column c or c + 8, half: k 0..7 or 8..15 of the tile row), each
+// 64 lanes x 16 B, row pitch 1152 B; written with ds_write_b128 at r * 1152 + lane * 16 (contiguous).  MFMA (p, t) -- tile rows 2p, 2p + 1
+// of the step x tile t -- reads for lane (j, kg) the chunk of writer lane 16 (2p + (kg >> 1)) + 8 t + (j & 7) in row 2 (j >> 3) + (kg & 1):
+// the 128-byte pitch offset puts the four 64-byte runs of every 16-lane ds_read_b128 group on disjoint banks.
+// k inside an MFMA is natural (k = 8 kg + i over the two tile rows), so the A operand comes straight from a row-major fp16 copy of the
+// rotated activations (row pitch padded by 32 B: conflict-free ds_read_b128 across the 16 rows).
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
 #include "exl3_gemv_args.h"
@@ -31,19 +37,19 @@ __device__ __forceinline__ void g3_static_for(F&& f)
 }
 
 #define G3_STG_ROW 1152
-#define G3_STG_BYTES (8 * G3_STG_ROW)
+#define G3_STG_BYTES (4 * G3_STG_ROW)
 #define G3_XPAD 16
-#ifndef G3_ROWS
-#define G3_ROWS 4           // tile rows per unit = weight rows in flight per wave (2 per MFMA k-step)
-#endif
+#define G3_WAVES 4
 
-template <int K, int CB, int MT>
-__global__ __launch_bounds__(256)
+template <int K, int CB, int MT, bool ROT>
+// ROT: the input is already rotated (fused decode pipeline) -- a separate instantiation so that neither prologue's registers burden the other.
+// five 4-wave workgroups per CU (LDS: 5 x 31 KB) need <= 96 VGPRs; the 64-row passes and the ROT prologue (16 registers of activation
+// copy in flight next to the weight ring) take four workgroups per CU instead of spilling (any scratch use slows every launch)
+__global__ __launch_bounds__(64 * G3_WAVES) __attribute__((amdgpu_waves_per_eu(((MT == 4 && (ROT || K >= 5)) || K >= 7) ? 3 : ((MT == 4 || ROT || K >= 5) ? 4 : 5))))
 void exl3_gemm3_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = 8 * K;
-    constexpr int MR = 16 * MT;
 
 #ifdef G2_TIMING
     // diagnostics build: the stamps of exl3_gemv2.kspec.hip (tools/gemv_timeline.py reads both)
@@ -68,95 +74,134 @@ void exl3_gemm3_kernel(const GemvArgs a)
     const int tiles_n = n >> 4;
     const int k0s = s * a.kslice;
     const int k1s = min(k0s + a.kslice, a.k);
-    const int nb = (k1s - k0s) >> 7;
-    const int nwv = blockDim.x >> 6;
-    // the same unit distribution as generation 2, in units of G3_ROWS tile rows; one chunk: contiguous ranges per wave, several: round robin
-    const int units = nb * (8 / G3_ROWS);
+    const int nb = (k1s - k0s) >> 7;                 // Hadamard blocks in the slice; every wave streams all of them
     const int chb = a.chunk_blocks;
-    const bool one_chunk = chb >= nb;
-    const int ubase = one_chunk ? (units * wave) / nwv : wave;
-    const int ustride = one_chunk ? 1 : nwv;
-    const int nunits_w = one_chunk ? (units * (wave + 1)) / nwv - ubase : (wave < units ? (units - wave + nwv - 1) / nwv : 0);
 
-    // LDS carve: [wave-private transpose buffers] [activations of one chunk, row-major fp16] ; the partial sums alias both after the loop
+    // LDS carve: [wave-private transpose buffers] [activations of one chunk, row-major fp16]; the S == 1 epilogue reuses it for [m][128] fp32
     const int ldx = chb * 128 + G3_XPAD;
     char* stg = smem + (size_t) wave * G3_STG_BYTES;
-    half_t* xa = (half_t*) (smem + (size_t) nwv * G3_STG_BYTES);
-    float* part = (float*) smem;
+    half_t* xa = (half_t*) (smem + (size_t) G3_WAVES * G3_STG_BYTES);
 
     const int l32 = lane & 31;
-    const bool in_rotated = (a.flags & GEMV_IN_ROTATED) != 0;
+    constexpr bool in_rotated = ROT;
     const half_t* __restrict__ x_src = in_rotated ? a.mat[mi].xh : a.A;
-    const int hwid = tid >> 5, nhw = nwv * 2;
+    const int hwid = tid >> 5, nhw = G3_WAVES * 2;
 
-    const int T = lane >> 3, c = lane & 7;
-    const uint32_t* __restrict__ strip = Bm + ((size_t) (k0s >> 4) * tiles_n + (size_t) cbl * 8) * NW + (size_t) lane * K;
+    // decode geometry
+    const int g = lane >> 4, t2 = (lane >> 3) & 1, c = lane & 7;
     const size_t row_stride = (size_t) tiles_n * NW;
+    const uint32_t* __restrict__ strip = Bm + ((size_t) (k0s >> 4) + g) * row_stride + (size_t) (cbl * 8 + 2 * wave + t2) * NW + (size_t) c * K;
     const int prev_lane_addr = ((lane & ~7) | ((lane - 1) & 7)) << 2;
-    const int last_unit = nunits_w > 0 ? ubase + (nunits_w - 1) * ustride : 0;
 
-    float4_t acc[MT][8];
+    float4_t acc[MT][2];
     #pragma unroll
-    for (int i = 0; i < MT; ++i)
-    {
-        #pragma unroll
-        for (int t = 0; t < 8; ++t) acc[i][t] = float4_t{ 0.f, 0.f, 0.f, 0.f };
-    }
+    for (int i = 0; i < MT; ++i) { acc[i][0] = float4_t{ 0.f, 0.f, 0.f, 0.f }; acc[i][1] = acc[i][0]; }
 
+    // ---- activation fetch helpers
     struct PrepIn { half4_t xv, sv; };
     auto fetch = [&] (int c0, int cnt, int it) -> PrepIn
     {
-        PrepIn r; r.sv = half4_t{ 0, 0, 0, 0 };
+        PrepIn r;
         const int t = min(it * nhw + hwid, cnt * m - 1);
         const int blk = c0 + t / m, row = t % m;
         const size_t kofs = (size_t) k0s + 128 * blk;
         r.xv = ((const half4_t*) (x_src + (size_t) row * a.k + kofs))[l32];
-        if (!in_rotated) r.sv = ((const half4_t*) (suh + kofs))[l32];
+        r.sv = ((const half4_t*) (suh + kofs))[l32];
         return r;
     };
-    // activation operands first, weight rows second: loads return in issue order per wave (see exl3_gemv2.kspec.hip)
-    // already rotated input (glue_rotate / glue_act): a straight copy in 16-byte pieces, four loads in flight per thread
+    // already rotated input (glue_rotate / glue_act): a straight copy in 16-byte pieces; thread = (row parity tid >> 7, piece tid & 127 of the
+    // row's cnt * 16), four row pairs in flight per thread
+    const int cp_piece = tid & 127, cp_rsub = tid >> 7;
     auto copy_load = [&] (int c0, int cnt, int base, uint4_t (&v)[4])
     {
-        const int per_row = cnt * 16, total = m * per_row;
-        const half_t* src0 = x_src + (size_t) k0s + 128 * c0;
+        const half_t* src0 = x_src + (size_t) k0s + 128 * c0 + 8 * min(cp_piece, cnt * 16 - 1);
         #pragma unroll
-        for (int j = 0; j < 4; ++j)
-        {
-            const int idx = min(base + j * (int) blockDim.x + tid, total - 1);
-            v[j] = *((const uint4_t*) (src0 + (size_t) (idx / per_row) * a.k + (idx % per_row) * 8));
-        }
+        for (int j = 0; j < 4; ++j) v[j] = *((const uint4_t*) (src0 + (size_t) min(base + 2 * j + cp_rsub, m - 1) * a.k));
     };
     auto copy_store = [&] (int cnt, int base, const uint4_t (&v)[4])
     {
-        const int per_row = cnt * 16, total = m * per_row;
         #pragma unroll
         for (int j = 0; j < 4; ++j)
         {
-            const int idx = base + j * (int) blockDim.x + tid;
-            if (idx < total) *((uint4_t*) (xa + (size_t) (idx / per_row) * ldx + (idx % per_row) * 8)) = v[j];
+            const int row = base + 2 * j + cp_rsub;
+            if (row < m && cp_piece < cnt * 16) *((uint4_t*) (xa + (size_t) row * ldx + 8 * cp_piece)) = v[j];
         }
     };
+    // activation operands first, weight rows second: loads return in issue order per wave (see exl3_gemv2.kspec.hip)
     PrepIn nx = { half4_t{ 0, 0, 0, 0 }, half4_t{ 0, 0, 0, 0 } };
     uint4_t cv[4];
-    if (in_rotated) copy_load(0, min(chb, nb), 0, cv); else nx = fetch(0, min(chb, nb), 0);
-    LaneWords<K> ring[G3_ROWS];
-    if (nunits_w > 0)
-    {
-        #pragma unroll
-        for (int u = 0; u < G3_ROWS; ++u) load_lane_words<K>(ring[u], strip + (size_t) (G3_ROWS * ubase + u) * row_stride);
-    }
+    if constexpr (in_rotated) copy_load(0, min(chb, nb), 0, cv); else nx = fetch(0, min(chb, nb), 0);
 
+    // weight ring: two slots of one Hadamard block (8 tile rows = 2 decode steps) each
+    LaneWords<K> ring[2][2];
+    auto load_block = [&] (LaneWords<K> (&slot)[2], int blk)
+    {
+        const uint32_t* p = strip + (size_t) (8 * min(blk, nb - 1)) * row_stride;
+        load_lane_words<K>(slot[0], p);
+        load_lane_words<K>(slot[1], p + 4 * row_stride);
+    };
+    load_block(ring[0], 0);
+    load_block(ring[1], 1);
     G3_T(1);
 
     // MFMA operand geometry
     const int mj = lane & 15, kg = lane >> 4;
-    const char* bsrc = stg + (4 * (mj >> 3) + kg) * G3_STG_ROW + (mj & 7) * 16;            // + T * 128 per column tile
-    char* bdst = stg + lane * 16;                                                        // + (4 h + kq) * G3_STG_ROW per chunk
+    const char* bsrc = stg + (2 * (mj >> 3) + (kg & 1)) * G3_STG_ROW + ((kg >> 1) * 16 + (mj & 7)) * 16;   // + (32 p + 8 t) * 16
+    char* bdst = stg + lane * 16;                                                                        // + r * G3_STG_ROW
     const half_t* arow[MT];
     #pragma unroll
     for (int i = 0; i < MT; ++i) arow[i] = xa + (size_t) min(16 * i + mj, m - 1) * ldx + 8 * kg;
-    int ui = 0;
+
+    // one Hadamard block (2 decode steps) from a ring slot; kloc = chunk-local k of the block
+    auto do_block = [&] (LaneWords<K> (&slot)[2], int kloc, int refill_blk)
+    {
+        #pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+        {
+            uint32_t Wx[K + 1];
+            #pragma unroll
+            for (int i = 0; i < K; ++i) Wx[i + 1] = slot[sub].w[i];
+            Wx[0] = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) slot[sub].w[K - 1]);
+            // refill the slot half that was just consumed
+            load_lane_words<K>(slot[sub], strip + (size_t) (8 * refill_blk + 4 * sub) * row_stride);
+
+            // exact fp16 weights: quad q of column c / c + 8 = rows {2q, 2q+1 | 2q+8, 2q+9}: low words -> rows 0..7, high words -> rows 8..15
+            uint32_t clo[4], chi[4], dlo[4], dhi[4];
+            g3_static_for<0, 4>([&] (auto qc)
+            {
+                constexpr int q = decltype(qc)::value;
+                half4_t bc[2], bd[2];
+                decode_quad<K, CB, 0, 8 * q>(Wx, bc);
+                decode_quad<K, CB, 0, 8 * q + 4>(Wx, bd);
+                union { half4_t h; uint32_t w[2]; } uc, ud; uc.h = bc[0]; ud.h = bd[0];
+                clo[q] = uc.w[0]; chi[q] = uc.w[1]; dlo[q] = ud.w[0]; dhi[q] = ud.w[1];
+                __builtin_amdgcn_sched_barrier(0);      // bound live ranges: 8 weights in flight at a time (occupancy > ILP here)
+            });
+            *((uint4_t*) (bdst + 0 * G3_STG_ROW)) = uint4_t{ clo[0], clo[1], clo[2], clo[3] };
+            *((uint4_t*) (bdst + 1 * G3_STG_ROW)) = uint4_t{ chi[0], chi[1], chi[2], chi[3] };
+            *((uint4_t*) (bdst + 2 * G3_STG_ROW)) = uint4_t{ dlo[0], dlo[1], dlo[2], dlo[3] };
+            *((uint4_t*) (bdst + 3 * G3_STG_ROW)) = uint4_t{ dhi[0], dhi[1], dhi[2], dhi[3] };
+            // the wave's own LDS operations complete in order: no wait between its stores and the loads below, only compiler ordering
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            #pragma unroll
+            for (int p = 0; p < 2; ++p)
+            {
+                half8_t af[MT];
+                #pragma unroll
+                for (int i = 0; i < MT; ++i) af[i] = *((const half8_t*) (arow[i] + kloc + 64 * sub + 32 * p));
+                #pragma unroll
+                for (int t = 0; t < 2; ++t)
+                {
+                    const half8_t bf = *((const half8_t*) (bsrc + (32 * p + 8 * t) * 16));
+                    #pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf, acc[i][t], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
 
     for (int c0 = 0; c0 < nb; c0 += chb)
     {
@@ -164,10 +209,9 @@ void exl3_gemm3_kernel(const GemvArgs a)
         if (c0 > 0) __syncthreads();
 
         // ---- activations of blocks [c0, c0 + cnt) -> LDS, row-major
-        if (in_rotated)
+        if constexpr (in_rotated)
         {
-            const int total = m * cnt * 16;
-            for (int base = 0; base < total; base += 4 * (int) blockDim.x)
+            for (int base = 0; base < m; base += 8)
             {
                 if (c0 > 0 || base > 0) copy_load(c0, cnt, base, cv);
                 copy_store(cnt, base, cv);
@@ -197,122 +241,45 @@ void exl3_gemm3_kernel(const GemvArgs a)
         __syncthreads();
         if (c0 == 0) { G3_T(2); }
 
-        const int row_end = (c0 + cnt) * 8;
-        const int u_end = min(nunits_w, (G3_ROWS * ubase < row_end) ? ((row_end / G3_ROWS - 1 - ubase) / ustride + 1) : 0);
-
-        for (; ui < u_end; ++ui)
+        // ---- streaming: blocks c0 .. c0 + cnt - 1, two per trip (one per ring slot); an odd tail swaps the slots
+        int b = c0;
+        for (; b + 1 < c0 + cnt; b += 2)
         {
-            const int unit = ubase + ui * ustride;
-            const int nxt = min(unit + ustride, last_unit);
+            do_block(ring[0], 128 * (b - c0), min(b + 2, nb - 1));
+            do_block(ring[1], 128 * (b + 1 - c0), min(b + 3, nb - 1));
+        }
+        if (b < c0 + cnt)
+        {
+            do_block(ring[0], 128 * (b - c0), min(b + 2, nb - 1));
             #pragma unroll
-            for (int hh = 0; hh < G3_ROWS / 2; ++hh)
-            {
-            #pragma unroll
-            for (int u = 0; u < 2; ++u)
-            {
-                uint32_t Wx[K + 1];
-                #pragma unroll
-                for (int i = 0; i < K; ++i) Wx[i + 1] = ring[2 * hh + u].w[i];
-                Wx[0] = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) ring[2 * hh + u].w[K - 1]);
-                load_lane_words<K>(ring[2 * hh + u], strip + (size_t) (G3_ROWS * nxt + 2 * hh + u) * row_stride);
-
-                // exact fp16 weights: quad q of column c / c + 8 = rows {2q, 2q+1 | 2q+8, 2q+9}: low words -> rows 0..7, high words -> rows 8..15
-                uint32_t clo[4], chi[4], dlo[4], dhi[4];
-#ifdef G3_ABL_NODECODE
-                #pragma unroll
-                for (int q = 0; q < 4; ++q) { clo[q] = Wx[q + 1]; chi[q] = Wx[q]; dlo[q] = Wx[q + 1] * 3u; dhi[q] = Wx[q] * 5u; }
-#else
-                g3_static_for<0, 4>([&] (auto qc)
-                {
-                    constexpr int q = decltype(qc)::value;
-                    half4_t bc[2], bd[2];
-                    decode_quad<K, CB, 0, 8 * q>(Wx, bc);
-                    decode_quad<K, CB, 0, 8 * q + 4>(Wx, bd);
-                    union { half4_t h; uint32_t w[2]; } uc, ud; uc.h = bc[0]; ud.h = bd[0];
-                    clo[q] = uc.w[0]; chi[q] = uc.w[1]; dlo[q] = ud.w[0]; dhi[q] = ud.w[1];
-                });
-#endif
-#ifdef G3_ABL_NOLDS
-                asm volatile("" :: "v"(clo[0] ^ clo[1] ^ clo[2] ^ clo[3] ^ chi[0] ^ chi[1] ^ chi[2] ^ chi[3] ^ dlo[0] ^ dlo[1] ^ dlo[2] ^ dlo[3] ^ dhi[0] ^ dhi[1] ^ dhi[2] ^ dhi[3]));
-#else
-                *((uint4_t*) (bdst + (0 + 2 * u + 0) * G3_STG_ROW)) = uint4_t{ clo[0], clo[1], clo[2], clo[3] };
-                *((uint4_t*) (bdst + (0 + 2 * u + 1) * G3_STG_ROW)) = uint4_t{ chi[0], chi[1], chi[2], chi[3] };
-                *((uint4_t*) (bdst + (4 + 2 * u + 0) * G3_STG_ROW)) = uint4_t{ dlo[0], dlo[1], dlo[2], dlo[3] };
-                *((uint4_t*) (bdst + (4 + 2 * u + 1) * G3_STG_ROW)) = uint4_t{ dhi[0], dhi[1], dhi[2], dhi[3] };
-#endif
-            }
-            // the wave's own LDS operations complete in order: no wait between its stores and the loads below, only compiler ordering
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-
-            half8_t af[MT];
-            const int kloc = 16 * G3_ROWS * unit + 32 * hh - 128 * c0;
-            #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *((const half8_t*) (arow[i] + kloc));
-            #pragma unroll
-            for (int t = 0; t < 8; ++t)
-            {
-#ifdef G3_ABL_NOLDS
-                const half8_t bf = af[0];
-#else
-                const half8_t bf = *((const half8_t*) (bsrc + t * 128));
-#endif
-#ifdef G3_ABL_NOMFMA
-                #pragma unroll
-                for (int i = 0; i < MT; ++i) { acc[i][t][0] += (float) bf[0] * (float) af[i][0]; }
-#else
-                #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf, acc[i][t], 0, 0, 0);
-#endif
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            }
+            for (int sub = 0; sub < 2; ++sub) { LaneWords<K> t = ring[0][sub]; ring[0][sub] = ring[1][sub]; ring[1][sub] = t; }
         }
     }
-
-    // ---- epilogue: per-wave partials -> LDS (aliases the transpose buffers and the activations), cross-wave sum, output Hadamard
     G3_T(3);
-    __syncthreads();
+
+    // ---- epilogue.  D layout of acc[i][t]: rows 16 i + 4 kg + r, column 32 wave + 16 t + mj
+    // (lane index laundered through an empty asm: the output addresses are computed here, not hoisted above the streaming loop where they
+    // would cost registers -- the prologue spilled to scratch otherwise, and any scratch use slows every launch)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int mj_e = lane_e & 15, kg_e = lane_e >> 4;
+    if (a.S > 1 || (a.flags & GEMV_OUT_DEFERRED))
     {
-        float* pw = part + (size_t) wave * MR * 128;
+        float* slab = a.workspace + ws_off + ((size_t) cbl * a.S + s) * (size_t) m * 128 + 32 * wave + mj_e;
         #pragma unroll
         for (int i = 0; i < MT; ++i)
         {
             #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int r = 0; r < 4; ++r)
             {
-                #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                {
-                    const int row = 16 * i + 4 * kg + r;
-                    if (row < m) pw[row * 128 + 16 * t + mj] = acc[i][t][r];
-                }
+                const int row = 16 * i + 4 * kg_e + r;
+                if (row < m) { slab[row * 128] = acc[i][0][r]; slab[row * 128 + 16] = acc[i][1][r]; }
             }
-        }
-    }
-    __syncthreads();
-    G3_T(4);
-
-    const int l = tid & 31, hw8 = tid >> 5;
-    const size_t wstride = (size_t) MR * 128;
-    if (a.S > 1 || (a.flags & GEMV_OUT_DEFERRED))
-    {
-        float* slab = a.workspace + ws_off + ((size_t) cbl * a.S + s) * (size_t) m * 128;
-        for (int row = hw8; row < m; row += nwv * 2)
-        {
-            const float* p0 = part + row * 128;
-            float4_t v = ((const float4_t*) p0)[l];
-            for (int w = 1; w < nwv; ++w)
-            {
-                float4_t t = ((const float4_t*) (p0 + w * wstride))[l];
-                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
-            ((float4_t*) (slab + row * 128))[l] = v;
         }
 #ifdef G2_TIMING
         if (tid == 0)
         {
+            tstamp[4] = tstamp[3];
             tstamp[5] = __builtin_amdgcn_s_memrealtime();
             uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) blockIdx.x * 8;
             for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
@@ -324,20 +291,30 @@ void exl3_gemm3_kernel(const GemvArgs a)
         return;
     }
 
+    // S == 1: the output Hadamard needs whole 128-column rows -> through LDS (over the transpose buffers / activations)
+    __syncthreads();
+    float* part = (float*) smem;
+    #pragma unroll
+    for (int i = 0; i < MT; ++i)
+    {
+        #pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            const int row = 16 * i + 4 * kg_e + r;
+            if (row < m) { part[row * 128 + 32 * wave + mj_e] = acc[i][0][r]; part[row * 128 + 32 * wave + 16 + mj_e] = acc[i][1][r]; }
+        }
+    }
+    __syncthreads();
+
+    const int l = lane_e & 31, hw8 = 2 * wave + (lane_e >> 5);
     const half_t* svh = a.mat[mi].svh + cbl * 128;
     const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
     void* C_m = a.mat[mi].C;
-    for (int base = 0; base < m; base += nwv * 2)
+    for (int base = 0; base < m; base += G3_WAVES * 2)
     {
         int row = base + hw8;
         bool act = row < m;
-        const float* p0 = part + (act ? row : 0) * 128;
-        float4_t v = ((const float4_t*) p0)[l];
-        for (int w = 1; w < nwv; ++w)
-        {
-            float4_t t = ((const float4_t*) (p0 + w * wstride))[l];
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
+        float4_t v = ((const float4_t*) (part + (act ? row : 0) * 128))[l];
         float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
         had128_f32x4(h0, h1, h2, h3, l);
         h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
@@ -366,28 +343,33 @@ void exl3_gemm3_kernel(const GemvArgs a)
 #endif
 
 template <int CB>
-static void g3_launch_cb(int mt, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+static void g3_launch_cb(int mt, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
-    if (mt == 1) exl3_gemm3_kernel<G2_K, CB, 1><<<grid, dim3(64 * nwv), lds, st>>>(args);
-    else         exl3_gemm3_kernel<G2_K, CB, 2><<<grid, dim3(64 * nwv), lds, st>>>(args);
+    const bool rot = (args.flags & GEMV_IN_ROTATED) != 0;
+    #define L(M, R) exl3_gemm3_kernel<G2_K, CB, M, R><<<grid, dim3(64 * G3_WAVES), lds, st>>>(args)
+    if (mt == 1)      { if (rot) L(1, true); else L(1, false); }
+    else if (mt == 2) { if (rot) L(2, true); else L(2, false); }
+    else              { if (rot) L(4, true); else L(4, false); }
+    #undef L
 }
 
 #define G3_CAT_(a, b) a##b
 #define G3_CAT(a, b) G3_CAT_(a, b)
 
-void G3_CAT(exl3_gemm3_launch_k, G2_K)(int cb, int mt, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+// mt = row tiles of 16 per pass: 1, 2 or 4
+void G3_CAT(exl3_gemm3_launch_k, G2_K)(int cb, int mt, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
-    if (cb == 0) g3_launch_cb<0>(mt, nwv, grid, lds, st, args);
-    else if (cb == 1) g3_launch_cb<1>(mt, nwv, grid, lds, st, args);
-    else g3_launch_cb<2>(mt, nwv, grid, lds, st, args);
+    if (cb == 0) g3_launch_cb<0>(mt, grid, lds, st, args);
+    else if (cb == 1) g3_launch_cb<1>(mt, grid, lds, st, args);
+    else g3_launch_cb<2>(mt, grid, lds, st, args);
 }
 
 #if G2_K == 4
-// LDS bytes of a launch: max(transpose buffers + activations of one chunk, partial sums)
-size_t exl3_gemm3_lds_bytes(int mt, int nwv, int m, int chunk_blocks)
+// LDS bytes of a launch: transpose buffers + activations of one chunk; the S == 1 epilogue's [m][128] fp32 overlays them
+size_t exl3_gemm3_lds_bytes(int m, int chunk_blocks)
 {
-    const size_t stream = (size_t) nwv * G3_STG_BYTES + (size_t) m * (chunk_blocks * 128 + G3_XPAD) * 2;
-    const size_t part = (size_t) nwv * 16 * mt * 128 * 4;
+    const size_t stream = (size_t) G3_WAVES * G3_STG_BYTES + (size_t) m * (chunk_blocks * 128 + G3_XPAD) * 2;
+    const size_t part = (size_t) m * 128 * 4;
     return stream > part ? stream : part;
 }
 #endif

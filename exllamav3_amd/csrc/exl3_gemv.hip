@@ -578,9 +578,9 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     if (!ctx) return EXL3_ERR_INIT;
 
     const int var = gemv_variant();
-    // generation 3 streams the weights once per 32 rows (exl3_gemm3.kspec.hip); the special input / output modes stay on generation 2
+    // generation 3 streams the weights once per up to 64 rows (exl3_gemm3.kspec.hip); the special input / output modes stay on generation 2
     const bool g3_ok = g_gemm3_min_rows > 0 && !in_norm && !tbl && !in_act && !epi && (deferred || rotated || gemv_gen() == 2);
-    const int pass_rows = (g3_ok && !deferred && !rotated && m > 16) ? 32 : 16;
+    const int pass_rows = (g3_ok && !deferred && !rotated && m > 16) ? (m > 32 ? 64 : 32) : 16;
     for (int m0 = 0; m0 < m; m0 += pass_rows)
     {
         const int mp = (m - m0) < pass_rows ? (m - m0) : pass_rows;
@@ -667,26 +667,23 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         dim3 grid((unsigned) (total_cb * S));
         if (gen == 3)
         {
-            const int mt = mp > 16 ? 2 : 1;
-            int nwv = 4;
-            if (g_gemv_nwv < 0) nwv = -g_gemv_nwv < 8 ? -g_gemv_nwv : 8;
-            if (nwv > bps * 2) nwv = bps * 2;                    // units of >= 4 tile rows
-            // three workgroups per CU: 36 KB of transpose buffers + <= 17 KB of activations each
-            int chunk = (17408 / (mp * 2) - 16) / 128;
+            const int mt = mp > 32 ? 4 : (mp > 16 ? 2 : 1);
+            // five workgroups per CU: 18 KB of transpose buffers + <= 14 KB of activations each
+            int chunk = (14336 / (mp * 2) - 16) / 128;
             if (chunk < 1) chunk = 1;
             if (chunk > bps) chunk = bps;
             args.chunk_blocks = chunk;
-            const size_t lds = exl3_gemm3_lds_bytes(mt, nwv, mp, chunk);
+            const size_t lds = exl3_gemm3_lds_bytes(mp, chunk);
             switch (K)
             {
-                case 1: exl3_gemm3_launch_k1(cb, mt, nwv, grid, lds, st, args); break;
-                case 2: exl3_gemm3_launch_k2(cb, mt, nwv, grid, lds, st, args); break;
-                case 3: exl3_gemm3_launch_k3(cb, mt, nwv, grid, lds, st, args); break;
-                case 4: exl3_gemm3_launch_k4(cb, mt, nwv, grid, lds, st, args); break;
-                case 5: exl3_gemm3_launch_k5(cb, mt, nwv, grid, lds, st, args); break;
-                case 6: exl3_gemm3_launch_k6(cb, mt, nwv, grid, lds, st, args); break;
-                case 7: exl3_gemm3_launch_k7(cb, mt, nwv, grid, lds, st, args); break;
-                case 8: exl3_gemm3_launch_k8(cb, mt, nwv, grid, lds, st, args); break;
+                case 1: exl3_gemm3_launch_k1(cb, mt, grid, lds, st, args); break;
+                case 2: exl3_gemm3_launch_k2(cb, mt, grid, lds, st, args); break;
+                case 3: exl3_gemm3_launch_k3(cb, mt, grid, lds, st, args); break;
+                case 4: exl3_gemm3_launch_k4(cb, mt, grid, lds, st, args); break;
+                case 5: exl3_gemm3_launch_k5(cb, mt, grid, lds, st, args); break;
+                case 6: exl3_gemm3_launch_k6(cb, mt, grid, lds, st, args); break;
+                case 7: exl3_gemm3_launch_k7(cb, mt, grid, lds, st, args); break;
+                case 8: exl3_gemm3_launch_k8(cb, mt, grid, lds, st, args); break;
             }
         }
         else if (gen == 2)

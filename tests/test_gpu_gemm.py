@@ -214,7 +214,7 @@ def test_mgemm_indexed_moe_forms(dev, cb, k, n, K):
         ext.exl3_mgemm(T(xs2), pB, C, psu, None, psv, T(sel2), T(w2), K, -1, cb == 1, cb == 2, 0, 4, 0, num_tokens=2)
 
 
-# ---- generation 3 (exl3_gemm3.kspec.hip): 9..32 rows per pass through the LDS transpose into 16x16x32 MFMAs ----------------------------
+# ---- generation 3 (exl3_gemm3.kspec.hip): 9..64 rows per pass through the LDS transpose into 16x16x32 MFMAs ----------------------------
 
 @pytest.mark.parametrize("cb", [0, 1, 2])
 @pytest.mark.parametrize("K", range(1, 9))
@@ -223,6 +223,7 @@ def test_gemm3_all_bitrates(dev, K, cb):
     ext.set_gemm3_min_rows(9)
     assert _run(dev, 512, 256, K, cb, 12, 1) < TOL
     assert _run(dev, 1024, 128, K, cb, 32, 1) < TOL
+    assert _run(dev, 640, 128, K, cb, 50, 1) < TOL            # 5 Hadamard blocks (odd: ring slot swap), 64-row pass
 
 
 @pytest.mark.parametrize("m", [9, 16, 17, 24, 32, 33, 47, 64, 65, 144])
