@@ -25,6 +25,8 @@ struct Exl3DevCtx
 };
 #define EXL3_WORKSPACE_BYTES (64ll << 20)
 #define EXL3_NUM_TICKETS 65536
+#define EXL3_WS_XH_OFFSET (50ll << 20)         // rotated activations of one generation-3 pass (exl3_gemv.hip), up to the end of the workspace
+#define EXL3_WS_XH_BYTES (14ll << 20)
 #define EXL3_WS_REGION_BYTES (24ll << 20)     // two slab regions [0, 24) and [24, 48) MiB; diagnostics builds use the tail
 
 // Returns nullptr (and sets the error) if the context cannot be created (e.g. stream capturing before exl3_init).

@@ -55,6 +55,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
     // diagnostics build: the stamps of exl3_gemv2.kspec.hip (tools/gemv_timeline.py reads both)
     uint64_t tstamp[6];
     tstamp[0] = __builtin_amdgcn_s_memrealtime();
+    const uint64_t cyc0 = __builtin_amdgcn_s_memtime();          // shader-clock counter: cycles / realtime = the clock the launch ran at
     #define G3_T(i) tstamp[i] = __builtin_amdgcn_s_memrealtime()
 #else
     #define G3_T(i)
@@ -109,21 +110,23 @@ void exl3_gemm3_kernel(const GemvArgs a)
         r.sv = ((const half4_t*) (suh + kofs))[l32];
         return r;
     };
-    // already rotated input (glue_rotate / glue_act): a straight copy in 16-byte pieces; thread = (row parity tid >> 7, piece tid & 127 of the
-    // row's cnt * 16), four row pairs in flight per thread
-    const int cp_piece = tid & 127, cp_rsub = tid >> 7;
+    // already rotated input (glue_rotate / glue_act): a straight copy in 16-byte pieces.  A row of the chunk is <= 2^cp_sl pieces; thread =
+    // (row tid >> cp_sl of the instruction's 256 >> cp_sl rows, piece tid & (2^cp_sl - 1)); four instructions in flight per thread, so one batch
+    // covers 16 rows at up to 4 blocks per chunk (the decode shapes), 32 rows at 2, 64 rows at 1
+    const int cp_sl = chb <= 1 ? 4 : (chb <= 2 ? 5 : (chb <= 4 ? 6 : 7));
+    const int cp_piece = tid & ((1 << cp_sl) - 1), cp_rsub = tid >> cp_sl, cp_rows = (64 * G3_WAVES) >> cp_sl;
     auto copy_load = [&] (int c0, int cnt, int base, uint4_t (&v)[4])
     {
         const half_t* src0 = x_src + (size_t) k0s + 128 * c0 + 8 * min(cp_piece, cnt * 16 - 1);
         #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = *((const uint4_t*) (src0 + (size_t) min(base + 2 * j + cp_rsub, m - 1) * a.k));
+        for (int j = 0; j < 4; ++j) v[j] = *((const uint4_t*) (src0 + (size_t) min(base + cp_rows * j + cp_rsub, m - 1) * a.k));
     };
     auto copy_store = [&] (int cnt, int base, const uint4_t (&v)[4])
     {
         #pragma unroll
         for (int j = 0; j < 4; ++j)
         {
-            const int row = base + 2 * j + cp_rsub;
+            const int row = base + cp_rows * j + cp_rsub;
             if (row < m && cp_piece < cnt * 16) *((uint4_t*) (xa + (size_t) row * ldx + 8 * cp_piece)) = v[j];
         }
     };
@@ -211,9 +214,10 @@ void exl3_gemm3_kernel(const GemvArgs a)
         // ---- activations of blocks [c0, c0 + cnt) -> LDS, row-major
         if constexpr (in_rotated)
         {
-            for (int base = 0; base < m; base += 8)
+            // the first batch of rows is already in registers (requested before the weight ring, or during the previous chunk's streaming)
+            for (int base = 0; base < m; base += 4 * cp_rows)
             {
-                if (c0 > 0 || base > 0) copy_load(c0, cnt, base, cv);
+                if (base > 0) copy_load(c0, cnt, base, cv);
                 copy_store(cnt, base, cv);
             }
         }
@@ -240,6 +244,8 @@ void exl3_gemm3_kernel(const GemvArgs a)
         }
         __syncthreads();
         if (c0 == 0) { G3_T(2); }
+        // next chunk's first rows: in flight underneath this chunk's streaming
+        if constexpr (in_rotated) { if (c0 + chb < nb) copy_load(c0 + chb, min(chb, nb - c0 - chb), 0, cv); }
 
         // ---- streaming: blocks c0 .. c0 + cnt - 1, two per trip (one per ring slot); an odd tail swaps the slots
         int b = c0;
@@ -284,8 +290,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
             uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) blockIdx.x * 8;
             for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
             uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            uint32_t hwreg; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwreg));
-            dbg[6] = xcc; dbg[7] = hwreg;
+            dbg[6] = xcc; dbg[7] = __builtin_amdgcn_s_memtime() - cyc0;
         }
 #endif
         return;

@@ -472,7 +472,7 @@ static int gemv_gen()
 extern "C" int exl3_set_gemv_gen(int v) { g_gemv_gen = (v == 1) ? 1 : 2; return EXL3_OK; }
 static int g_gemv_nwv = 0;           // 0 = heuristic; otherwise cap on waves per workgroup (tuning / tests)
 static int g_gemv_defer_wg_per_cu = 0;
-static int g_gemm3_min_rows = 9;     // passes with at least this many rows take generation 3 (0 = never)
+static int g_gemm3_min_rows = 5;     // passes with at least this many rows take generation 3 (0 = never); raw (unrotated) input: >= 9
 extern "C" int exl3_set_gemm3_min_rows(int v) { g_gemm3_min_rows = v; return EXL3_OK; }
 
 extern "C" int exl3_set_gemv_defer_wg_per_cu(int v) { g_gemv_defer_wg_per_cu = v; return EXL3_OK; }
@@ -586,8 +586,30 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         const int mp = (m - m0) < pass_rows ? (m - m0) : pass_rows;
         GemvArgs args;
         memset((void*) &args, 0, sizeof(args));
-        const bool g3 = g3_ok && mp >= g_gemm3_min_rows;
+        // measured in the fused pipeline (tools/prof_tail.py, Llama-3.1-8B shapes): generation 3 is ahead from 5 rows with rotated input; with raw
+        // input its 8 half-waves per workgroup would spend longer on the input Hadamards than generation 2's 16..32, so it starts at 9 rows
+        // and, for wide launches, rotates the activations ONCE first (the role of the reference's A_had temporary, "storage for input transform": quant/exl3_gemm.cu:30, 139-145)
+        const bool g3 = g3_ok && mp >= (rotated ? g_gemm3_min_rows : (g_gemm3_min_rows > 9 ? g_gemm3_min_rows : 9));
         const int gen = g3 ? 3 : (deferred || rotated || in_norm || tbl || in_act) ? 2 : gemv_gen();
+        int pass_flags = flags;
+        const void* pre_xh[GEMV_MAX_MATS] = { nullptr };
+        const size_t xh_bytes = (size_t) mp * k * 2;
+        if (g3 && !rotated && (long) total_cb * mp >= 1024 && xh_bytes * count <= (size_t) EXL3_WS_XH_BYTES)
+        {
+            char* xh0 = (char*) ctx->workspace + EXL3_WS_XH_OFFSET;
+            for (int i = 0; i < count; ++i)
+            {
+                // identical suh -> one rotation serves both (gate / up of some checkpoints share it; cheap pointer test)
+                int same = -1;
+                for (int j = 0; j < i; ++j) if (suhs[j] == suhs[i]) { same = j; break; }
+                if (same >= 0) { pre_xh[i] = pre_xh[same]; continue; }
+                void* dst = xh0 + (size_t) i * xh_bytes;
+                int rc = exl3_had_r_128((const half_t*) A + (size_t) m0 * k, dst, suhs[i], nullptr, 1.0f, mp, k, 0, st);
+                if (rc != EXL3_OK) return rc;
+                pre_xh[i] = dst;
+            }
+            pass_flags |= GEMV_IN_ROTATED;
+        }
         args.act_g = act_g; args.act_u = act_u; args.act_S = act_S;
         args.act_svh_g = (const half_t*) act_svh_g; args.act_svh_u = (const half_t*) act_svh_u;
         args.norm_w = (const half_t*) norm_w; args.ss_part = ss_part; args.eps = eps;
@@ -625,7 +647,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             args.mat[i].svh = svhs ? (const half_t*) svhs[i] : nullptr;
             args.mat[i].bias = biases ? (const half_t*) biases[i] : nullptr;
             args.mat[i].C = Cs ? Cs[i] : nullptr;
-            args.mat[i].xh = xhs ? (const half_t*) xhs[i] : nullptr;
+            args.mat[i].xh = pre_xh[i] ? (const half_t*) pre_xh[i] : (xhs ? (const half_t*) xhs[i] : nullptr);
             args.mat[i].xsum = xsums ? xsums[i] : nullptr;
             args.mat[i].n = ns[i];
             args.mat[i].cb_first = cbf;
@@ -652,7 +674,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             if (slabs_out) for (int i = 0; i < (tbl ? 0 : count); ++i) slabs_out[i] = ws_region + args.mat[i].ws_offset;
         }
         if (S_out) *S_out = S;
-        args.flags = flags;
+        args.flags = pass_flags;
         args.A = (const half_t*) A + (size_t) m0 * k;
         args.workspace = ws_region;
         args.ws_debug = ctx->workspace + (48ll << 20) / 4;
@@ -668,8 +690,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         if (gen == 3)
         {
             const int mt = mp > 32 ? 4 : (mp > 16 ? 2 : 1);
-            // five workgroups per CU: 18 KB of transpose buffers + <= 14 KB of activations each
-            int chunk = (14336 / (mp * 2) - 16) / 128;
+            // four workgroups per CU (the register budget of the rotated-input variants): 18 KB of transpose buffers + <= 22 KB of activations
+            int chunk = (22528 / (mp * 2) - 16) / 128;
             if (chunk < 1) chunk = 1;
             if (chunk > bps) chunk = bps;
             args.chunk_blocks = chunk;

@@ -433,12 +433,16 @@ void exl3_gemv2_kernel(const GemvArgs a)
                     {
                         half8_t f = af[q >> 1];
                         half4_t a0 = (q & 1) ? half4_t{ f[4], f[5], f[6], f[7] } : half4_t{ f[0], f[1], f[2], f[3] };
+#ifdef G2_ABL_NOMFMA
+                        asm volatile("" :: "v"(bc[0]), "v"(bd[0]), "v"(a0));     // diagnostics build: decode only, no MAC
+#else
                         static_for<0, NG>([&] (auto gc)
                         {
                             constexpr int gq = decltype(gc)::value;
                             acc_c[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bc[0], acc_c[gq], 4, gq, 0);
                             acc_d[gq] = __builtin_amdgcn_mfma_f32_4x4x4f16(a0, bd[0], acc_d[gq], 4, gq, 0);
                         });
+#endif
                     }
 #ifndef G2_ABL_ILP
                     __builtin_amdgcn_sched_barrier(0);  // bound live ranges: 8 weights in flight at a time (occupancy > ILP here)

@@ -25,3 +25,16 @@ def dev():
     from exllamav3_amd import ext
     ext.init(0)
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _default_kernel_selection(request):
+    """GPU tests start from the library's default kernel selection (tests that pin a generation / variant do so explicitly)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+    if torch.cuda.is_available():
+        from exllamav3_amd import ext
+        ext.set_gemm3_min_rows(5)
+    yield

@@ -220,7 +220,7 @@ def test_mgemm_indexed_moe_forms(dev, cb, k, n, K):
 @pytest.mark.parametrize("K", range(1, 9))
 def test_gemm3_all_bitrates(dev, K, cb):
     from exllamav3_amd import ext
-    ext.set_gemm3_min_rows(9)
+    ext.set_gemm3_min_rows(5)
     assert _run(dev, 512, 256, K, cb, 12, 1) < TOL
     assert _run(dev, 1024, 128, K, cb, 32, 1) < TOL
     assert _run(dev, 640, 128, K, cb, 50, 1) < TOL            # 5 Hadamard blocks (odd: ring slot swap), 64-row pass
@@ -232,7 +232,7 @@ def test_gemm3_rows_and_splits(dev, m, split):
     # uneven slices, several activation chunks per slice (k = 2816 at split 1: 22 Hadamard blocks against a 2..4 block LDS budget),
     # tails of 1 row (33, 65) that fall back to generation 2 inside the same call
     from exllamav3_amd import ext
-    ext.set_gemm3_min_rows(9)
+    ext.set_gemm3_min_rows(5)
     for cb in (0, 2):
         assert _run(dev, 2816, 256, 4, cb, m, 1, force_split=split) < TOL
         assert _run(dev, 1024, 384, 3, cb, m, 1, out_fp32=True, bias=True, force_split=split, realistic=True, seed=5) < TOL
@@ -244,11 +244,11 @@ def test_gemm3_agrees_with_generation_2(dev):
     tr, suh, svh = o.synth_linear(4096, 512, 4, seed=11, realistic=True)
     x = torch.randn((16, 4096), device=dev).half()
     ys = []
-    for mr in (0, 9):
+    for mr in (0, 5):
         ext.set_gemm3_min_rows(mr)
         y = torch.empty((16, 512), dtype=torch.float, device=dev)
         ext.exl3_gemm(x, _t(tr, dev), y, _t(suh, dev), None, _t(svh, dev), -1, False, True, 0)
         ys.append(y)
-    ext.set_gemm3_min_rows(9)
+    ext.set_gemm3_min_rows(5)
     err = (ys[0] - ys[1]).abs().max() / ys[0].pow(2).mean().sqrt()
     assert err < 2e-3, err

@@ -180,6 +180,8 @@ def test_tail_epilogue_pipeline_is_bit_identical_to_glue_pipeline(dev, cb, bsz):
     from exllamav3_amd import ext
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
     ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    # the tail epilogues live in the generation-2 kernel: the glue side is pinned to it too (generation 3 sums k in a different order)
+    ext.set_gemm3_min_rows(0)
     shape = LlamaShape("tiny", 256, 512, 3, 4, 2, 128, 384)
     model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
     model.alloc_state(bsz, pos=1234)
@@ -374,6 +376,7 @@ def test_in_gemv_rmsnorm_hidden_8192(dev, m):
     """Llama-70B width (64 Hadamard blocks per row: more than one 32-lane pass over the per-block sums of squares): glue_resid +
     GEMV_IN_NORM and glue_resid + glue_rotate + rotated GEMV against glue_norm + rotated GEMV, bit for bit."""
     from exllamav3_amd import ext
+    ext.set_gemm3_min_rows(0)          # bit-for-bit needs one kernel generation on all three routes (GEMV_IN_NORM exists in generation 2 only)
     k, n, K = 8192, 256, 3
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rng = np.random.default_rng(m)

@@ -48,6 +48,9 @@ for i, nm in enumerate(names):
     for j, ph in enumerate(["entry", "loads_issued", "first_prep", "stream_done", "partials", "slab_written"]):
         v = rel[:, j]
         row[ph] = [round(float(np.percentile(v, q)), 2) for q in (0, 50, 100)]
+    life = (t[:, 5] - t[:, 0]).astype(float) * 0.01
+    if os.environ.get("BSZ", "1") not in ("1", "2", "3", "4"):   # generation 3 stores shader cycles of the workgroup in column 7
+        row["shader_clock_GHz_median"] = round(float(np.median(t[:, 7][life > 0] / life[life > 0])) * 1e-3, 3)
     row["xcc_counts"] = np.bincount(t[:, 6].astype(int) & 15, minlength=8).tolist()
     out[nm] = row
     print(nm, json.dumps(row), flush=True)
