@@ -692,6 +692,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             const int mt = mp > 32 ? 4 : (mp > 16 ? 2 : 1);
             // four workgroups per CU (the register budget of the rotated-input variants): 18 KB of transpose buffers + <= 22 KB of activations
             int chunk = (22528 / (mp * 2) - 16) / 128;
+            if (chunk > 8) chunk = 8;                            // the rotated-input copy maps a chunk row onto <= 128 16-byte pieces
             if (chunk < 1) chunk = 1;
             if (chunk > bps) chunk = bps;
             args.chunk_blocks = chunk;

@@ -6,8 +6,9 @@ of the C-ABI ops in exllamav3_amd.ext.
   forward(x, params, out_dtype):
      rows <= AUTO_RECONSTRUCT_THRESHOLD (144)  -> fused HIP GEMV / small-m GEMM (exl3.py:133-137)
      otherwise reconstruct_hgemm (exl3.py:161-218):
-        rows < 1024 : had_r_128(x, suh) -> reconstruct -> hgemm -> had_r_128(y, svh)
-        rows >= 1024: reconstruct_had_slice (original-basis W, both Hadamards on the matrix pipe) -> hgemm on raw x
+        rows <  FUSED_RECONSTRUCT_MIN_ROWS: had_r_128(x, suh) -> reconstruct -> hgemm -> had_r_128(y, svh)
+        rows >= FUSED_RECONSTRUCT_MIN_ROWS: reconstruct_had_slice (original-basis W, both Hadamards on the matrix pipe) -> hgemm on raw x
+        (the reference switches at 1024 rows; on MI355X the fused route is ahead from the first row above the small-m threshold)
         out_features > MAX_RECONSTRUCT_SLICE_N: column slices
 """
 from __future__ import annotations
@@ -16,7 +17,9 @@ from . import ext
 
 AUTO_RECONSTRUCT_THRESHOLD = 144          # exl3.py:10
 MAX_RECONSTRUCT_SLICE_N = 32768           # exl3.py:11
-FUSED_RECONSTRUCT_MIN_ROWS = 1024         # exl3.py:184
+# exl3.py:184 switches to the fused route at 1024 rows.  Measured on MI355X (tools/bench_mid_rows.py, Llama-3.1-8B shapes, 144..512 rows) the fused
+# route is 20-35 % faster than had_r_128 + reconstruct + hgemm + had_r_128 at every row count, so it starts right above the small-m threshold.
+FUSED_RECONSTRUCT_MIN_ROWS = AUTO_RECONSTRUCT_THRESHOLD + 1
 
 
 class LinearEXL3:

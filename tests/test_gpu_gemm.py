@@ -252,3 +252,23 @@ def test_gemm3_agrees_with_generation_2(dev):
     ext.set_gemm3_min_rows(5)
     err = (ys[0] - ys[1]).abs().max() / ys[0].pow(2).mean().sqrt()
     assert err < 2e-3, err
+
+
+@pytest.mark.parametrize("m", [5, 8, 9, 16])
+@pytest.mark.parametrize("split", [1, 2, 5])
+def test_gemm3_rotated_input_long_slices(dev, m, split):
+    """Pre-rotated activations (the fused pipeline's route) over slices much longer than one LDS chunk: 32 Hadamard blocks at split 1
+    against a chunk of <= 8, with the next chunk's rows prefetched underneath the streaming loop; against the raw-input route."""
+    from exllamav3_amd import ext
+    k, n, K = 4096, 256, 4
+    tr, suh, svh = o.synth_linear(k, n, K, seed=21, realistic=True)
+    ttr, tsu, tsv = _t(tr, dev), _t(suh, dev), _t(svh, dev)
+    x = torch.randn((m, k), device=dev, generator=torch.Generator(device=dev).manual_seed(m)).half()
+    xh = torch.empty_like(x)
+    ext.had_r_128(x, xh, tsu, None, 1.0)
+    y_rot = torch.full((m, n), float("nan"), dtype=torch.half, device=dev)
+    ext.exl3_gemv_ex(None, [xh], None, [ttr], [y_rot], None, [tsv], m, False, True, ext.GEMV_IN_ROTATED, force_split=split)
+    ref = o.linear_forward(x.cpu().numpy(), tr, suh, svh, K, 2).astype(np.float32)
+    got = y_rot.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < TOL

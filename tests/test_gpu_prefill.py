@@ -57,8 +57,9 @@ def test_hgemm(dev, m, k, n):
 
 @pytest.mark.parametrize("rows", [1, 16, 144, 145, 512, 1024, 1500])
 def test_linear_exl3_paths_agree(dev, rows):
-    """modules/quant/exl3.py:114-218: kernel path (rows <= 144), unfused reconstruct path (< 1024) and fused-W path
-    (>= 1024) against the oracle; tests/test_qgemm.py tolerance rtol = atol = 0.05."""
+    """modules/quant/exl3.py:114-218: kernel path (rows <= 144), unfused reconstruct path and fused-W path against the oracle, with this
+    library's switch point (fused from 145 rows) and the reference's (1024 rows); tests/test_qgemm.py tolerance rtol = atol = 0.05."""
+    from exllamav3_amd import linear
     from exllamav3_amd.linear import LinearEXL3
     k, n, K, cb = 512, 384, 4, 2
     tr, suh, svh = o.synth_linear(k, n, K, realistic=True)
@@ -72,6 +73,13 @@ def test_linear_exl3_paths_agree(dev, rows):
     assert err < 2e-2
     y2 = lin.forward(_t(x, dev), {"reconstruct": True}).float().cpu().numpy()
     assert np.allclose(y2, ref, rtol=0.05, atol=0.05)
+    old = linear.FUSED_RECONSTRUCT_MIN_ROWS
+    linear.FUSED_RECONSTRUCT_MIN_ROWS = 1024                     # exl3.py:184
+    try:
+        y3 = lin.forward(_t(x, dev), {"reconstruct": True}).float().cpu().numpy()
+    finally:
+        linear.FUSED_RECONSTRUCT_MIN_ROWS = old
+    assert np.allclose(y3, ref, rtol=0.05, atol=0.05)
 
 
 def test_linear_exl3_lm_head_slicing(dev):
@@ -88,6 +96,13 @@ def test_linear_exl3_lm_head_slicing(dev):
         for rows in (200, 1100):
             y = lin.forward(_t(x[:rows], dev), {}).float().cpu().numpy()
             assert np.allclose(y, ref[:rows], rtol=0.05, atol=0.05)
+        old_f = linear.FUSED_RECONSTRUCT_MIN_ROWS
+        linear.FUSED_RECONSTRUCT_MIN_ROWS = 1024                 # the unfused slices (reference switch point)
+        try:
+            y = lin.forward(_t(x[:200], dev), {}).float().cpu().numpy()
+        finally:
+            linear.FUSED_RECONSTRUCT_MIN_ROWS = old_f
+        assert np.allclose(y, ref[:200], rtol=0.05, atol=0.05)
     finally:
         linear.MAX_RECONSTRUCT_SLICE_N = old
 
