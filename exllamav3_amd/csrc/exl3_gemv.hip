@@ -504,6 +504,17 @@ static int choose_split(int gen, int total_colblocks, int k, int m, int num_cus,
     const int nb = k / 128;
     int S;
     if (force_split > 0) S = force_split;
+    else if (gen == 3)
+    {
+        // gen 3: 4-wave workgroups, four resident per CU (LDS / registers); fill those slots, slices of at least 4 Hadamard blocks (shorter
+        // slices lose more to the reduce launch and the per-workgroup prologue than they gain: tools/bench_gemm3.py, 4096 x 4096)
+        // (PMC on gate|up at 16 rows with S = 1: 224 workgroups = one wave per SIMD, VALU active 29 % of the kernel)
+        S = (4 * num_cus + total_colblocks / 2) / total_colblocks;
+        int maxS = nb / 4; if (maxS < 1) maxS = 1;
+        if (S > maxS) S = maxS;
+        const long ws_cap = (long) (EXL3_WS_REGION_BYTES / ((long) total_colblocks * m * 512));      // the slabs must fit one workspace region
+        if (S > ws_cap) S = ws_cap < 1 ? 1 : (int) ws_cap;
+    }
     else if (gen == 2)
     {
         // gen 2: a workgroup is up to 16 waves that split its k-slice, so one workgroup per CU already fills the CU.
@@ -635,7 +646,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             if (fs < 1) fs = 1;
             if (epi && fs > 64) fs = 64;                         // tail epilogue: one pass of slabs must fit the workgroup LDS
         }
-        const int S = choose_split(gen == 3 ? 2 : gen, total_cb, k, mp, ctx->num_cus, fs);
+        const int S = choose_split(gen, total_cb, k, mp, ctx->num_cus, fs);
         const int nb = k / 128;
         const int bps = (nb + S - 1) / S;
         int cbf = 0; int64_t wso = 0;

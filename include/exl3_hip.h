@@ -97,7 +97,7 @@ int exl3_mgemm(const void* A, const void* const* Bs, void* const* Cs, const void
 int exl3_set_gemv_variant(int variant);
 int exl3_set_gemv_gen(int gen);
 int exl3_set_gemv_max_waves(int max_waves_per_workgroup);   /* 0 = heuristic (up to 16) */
-int exl3_set_gemm3_min_rows(int min_rows);                   /* passes with >= min_rows rows use the LDS-transpose kernel (exl3_gemm3.kspec.hip); default 9, 0 = never */
+int exl3_set_gemm3_min_rows(int min_rows);                   /* passes with >= min_rows rows use the LDS-transpose kernel (exl3_gemm3.kspec.hip); default 5 (9 for raw input), 0 = never */
 int exl3_set_gemv_defer_wg_per_cu(int workgroups_per_cu);      /* deferred-epilogue k-split target, 0 = default (2) */
 
 /* ---- fused decode pipeline (m <= 16): the reference chains these steps as separate graph nodes inside its BC_* runners
