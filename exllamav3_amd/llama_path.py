@@ -116,6 +116,106 @@ class SyntheticEXL3Llama:
         self.max_ctx = max_ctx
         self._state_bsz = None
 
+    # ---- checkpoints ----------------------------------------------------------------
+    _HF = {"q": "self_attn.q_proj", "k": "self_attn.k_proj", "v": "self_attn.v_proj", "o": "self_attn.o_proj",
+           "gate": "mlp.gate_proj", "up": "mlp.up_proj", "down": "mlp.down_proj"}
+
+    def save_checkpoint(self, directory: str) -> None:
+        """Write this (TP = 1) model as an EXL3 checkpoint directory with the reference's tensor naming for Llama (HF module names +
+        .trellis/.suh/.svh/.mul1|.mcg, modules/linear.py:389-425) and a config.json with the fields from_checkpoint reads."""
+        import json
+        from safetensors.torch import save_file
+        assert self.tp == 1, "save_checkpoint writes whole tensors: build the model with TP = 1"
+        os.makedirs(directory, exist_ok=True)
+        t = {}
+
+        def put(key, lin):
+            t[key + ".trellis"] = lin.trellis.cpu(); t[key + ".suh"] = lin.suh.cpu(); t[key + ".svh"] = lin.svh.cpu()
+            if lin.mul1: t[key + ".mul1"] = torch.tensor([0xCAF6A435 - (1 << 32)], dtype=torch.int32)     # quantize.py:1414-1424 (value never read)
+            if lin.mcg: t[key + ".mcg"] = torch.tensor([0xCBAC1FED - (1 << 32)], dtype=torch.int32)
+            if lin.bias is not None: t[key + ".bias"] = lin.bias.cpu()
+
+        for i, L in enumerate(self.layers):
+            for nm, hf in self._HF.items():
+                put(f"model.layers.{i}.{hf}", L[nm])
+            t[f"model.layers.{i}.input_layernorm.weight"] = L["norm1"].cpu()
+            t[f"model.layers.{i}.post_attention_layernorm.weight"] = L["norm2"].cpu()
+        t["model.norm.weight"] = self.final_norm.cpu()
+        put("lm_head", self.lm_head)
+        save_file({k: v.contiguous() for k, v in t.items()}, os.path.join(directory, "model.safetensors"))
+        s = self.shape
+        cfg = {"architectures": ["LlamaForCausalLM"], "hidden_size": s.hidden, "intermediate_size": s.inter, "num_hidden_layers": self.n_layers,
+               "num_attention_heads": s.heads_q, "num_key_value_heads": s.heads_kv, "head_dim": s.head_dim, "vocab_size": s.vocab,
+               "rope_theta": s.rope_theta, "rms_norm_eps": self.eps, "quantization_config": {"quant_method": "exl3"}}
+        json.dump(cfg, open(os.path.join(directory, "config.json"), "w"), indent=1)
+
+    @classmethod
+    def from_checkpoint(cls, directory: str, device: torch.device | str = "cuda:0", backend: TPBackendRCCL | None = None,
+                        kv_bits: int = 4, max_ctx: int = 4096, layers: int | None = None) -> "SyntheticEXL3Llama":
+        """The same hot path over a real EXL3 Llama checkpoint directory (config.json + *.safetensors).  Every tensor-parallel rank reads
+        its own shards straight from the files (loader.load_linear_exl3 tp_slice): q/k/v/gate/up/lm_head column shards, o/down row shards
+        (architecture/llama.py + modules/quant/exl3.py:284-330 split the same way).  The fused launches take q|k|v and gate|up in one
+        kernel each, so those groups must share bits-per-weight and codebook (the reference fuses under the same condition: modules/mlp.py:635,
+        modules/attn.py:439 compare `inner.K`, and falls back to separate GEMVs otherwise); anything else is free to differ (o, down, lm_head, layer to layer)."""
+        import json
+        from . import loader
+        cfg = json.load(open(os.path.join(directory, "config.json")))
+        hq, hkv = cfg["num_attention_heads"], cfg.get("num_key_value_heads", cfg["num_attention_heads"])
+        hd = cfg.get("head_dim") or cfg["hidden_size"] // hq
+        shape = LlamaShape(os.path.basename(os.path.normpath(directory)), cfg["hidden_size"], cfg["intermediate_size"], cfg["num_hidden_layers"],
+                           hq, hkv, hd, cfg["vocab_size"], float(cfg.get("rope_theta", 10000.0)))
+        stc = loader.SafetensorsCollection(directory)
+        self = cls.__new__(cls)
+        self.shape, self.kv_bits = shape, kv_bits
+        self.device = torch.device(device)
+        self.backend = backend or TPBackendRCCL(0, 1, self.device)
+        self.tp, self.rank = self.backend.world_size, self.backend.rank
+        tp, rank = self.tp, self.rank
+        self.n_layers = layers or shape.layers
+        assert shape.heads_kv % tp == 0, "TP degree must divide the KV heads (attention splits whole KV-head groups)"
+        self.hq, self.hkv = shape.heads_q // tp, shape.heads_kv // tp
+        ipts = split_points(shape.inter, tp)
+        self.inter_local = ipts[rank + 1] - ipts[rank]
+        vocab_pad = (shape.vocab + 127) // 128 * 128                        # stored padded to the Hadamard block (modules/linear.py:69-72)
+        vpts = split_points(vocab_pad, tp)
+        self.vocab_local = vpts[rank + 1] - vpts[rank]
+        self.vocab_ldims = [vpts[r + 1] - vpts[r] for r in range(tp)]
+        q0, q1 = rank * self.hq * hd, (rank + 1) * self.hq * hd
+        kv0, kv1 = rank * self.hkv * hd, (rank + 1) * self.hkv * hd
+        assert q0 % 128 == 0 and kv0 % 128 == 0 and (q1 - q0) % 128 == 0 and (kv1 - kv0) % 128 == 0, "head shards must be whole Hadamard blocks"
+        whole = tp == 1
+
+        def lin(key, sl, out_dtype=None):
+            return loader.load_linear_exl3(stc, key, self.device, out_dtype, None if whole else sl)
+
+        self.layers = []
+        for i in range(self.n_layers):
+            p = f"model.layers.{i}."
+            L = {
+                "q": lin(p + "self_attn.q_proj", (q0, q1, "n")), "k": lin(p + "self_attn.k_proj", (kv0, kv1, "n")),
+                "v": lin(p + "self_attn.v_proj", (kv0, kv1, "n")), "o": lin(p + "self_attn.o_proj", (q0, q1, "k"), torch.float),
+                "gate": lin(p + "mlp.gate_proj", (ipts[rank], ipts[rank + 1], "n")), "up": lin(p + "mlp.up_proj", (ipts[rank], ipts[rank + 1], "n")),
+                "down": lin(p + "mlp.down_proj", (ipts[rank], ipts[rank + 1], "k"), torch.float),
+                "norm1": stc.get_tensor(p + "input_layernorm.weight", self.device).half(),
+                "norm2": stc.get_tensor(p + "post_attention_layernorm.weight", self.device).half(),
+            }
+            for grp in (("q", "k", "v"), ("gate", "up")):
+                kinds = {(L[n].K, L[n].mcg, L[n].mul1) for n in grp}
+                if len(kinds) != 1:
+                    raise NotImplementedError(f"layer {i}: {'|'.join(grp)} mix bits-per-weight / codebooks {sorted(kinds)}; the fused launches need one kind per group")
+            self.layers.append(L)
+        self.final_norm = stc.get_tensor("model.norm.weight", self.device).half()
+        head_key = "lm_head" if loader.is_exl3_storage(stc, "lm_head") else None
+        if head_key is None:
+            raise NotImplementedError("unquantized / tied lm_head: only EXL3 heads are on this path")
+        self.lm_head = lin(head_key, (vpts[rank], vpts[rank + 1], "n"))
+        l0 = self.layers[0]["q"]
+        self.K, self.cb = l0.K, (2 if l0.mul1 else (1 if l0.mcg else 0))
+        self.inv_freq = (1.0 / (shape.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(self.device)
+        self.eps = float(cfg.get("rms_norm_eps", 1e-5))
+        self.page, self.max_ctx, self._state_bsz = 256, max_ctx, None
+        return self
+
     # ---- state ---------------------------------------------------------------------------------------
     def alloc_state(self, bsz: int, pos: int = 1000):
         dev, s = self.device, self.shape

@@ -478,3 +478,34 @@ def test_fused_pipeline_on_70b_tp8_rank_shapes(dev, bsz):
     lf = model.decode_step_fused().float().cpu().numpy()
     assert np.isfinite(lf).all()
     assert np.abs(lf - lu).max() / np.sqrt((lu ** 2).mean()) < 1e-2
+
+
+def test_checkpoint_round_trip_reproduces_logits(dev, tmp_path):
+    """save_checkpoint -> from_checkpoint (safetensors + config.json, HF Llama naming): the loaded model owns bit-identical tensors and the
+    fused decode step gives bit-identical logits; per-group bitrates may differ (o / down / lm_head at other K than q|k|v and gate|up)."""
+    from exllamav3_amd import linear
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama, _rand_linear
+    shape = LlamaShape("tiny", 256, 512, 2, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048, head_K=6)
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    for L in model.layers:                                                    # mixed bitrates across groups
+        L["o"] = _rand_linear(256, 256, 3, 0, dev, g, out_dtype=torch.float)
+        L["down"] = _rand_linear(512, 256, 5, 1, dev, g, out_dtype=torch.float)
+    model.save_checkpoint(str(tmp_path))
+    loaded = SyntheticEXL3Llama.from_checkpoint(str(tmp_path), device=dev, max_ctx=2048)
+    assert (loaded.K, loaded.cb, loaded.lm_head.K, loaded.layers[0]["o"].K, loaded.layers[1]["down"].mcg) == (4, 2, 6, 3, True)
+    for La, Lb in zip(model.layers, loaded.layers):
+        for nm in ("q", "k", "v", "o", "gate", "up", "down"):
+            assert torch.equal(La[nm].trellis, Lb[nm].trellis) and torch.equal(La[nm].suh, Lb[nm].suh) and torch.equal(La[nm].svh, Lb[nm].svh)
+        assert torch.equal(La["norm1"], Lb["norm1"]) and torch.equal(La["norm2"], Lb["norm2"])
+    for bsz in (1, 6):
+        model.alloc_state(bsz, pos=77); loaded.alloc_state(bsz, pos=77)
+        loaded.x0.copy_(model.x0)
+        la = model.decode_step_fused().clone()
+        lb = loaded.decode_step_fused()
+        assert torch.equal(la, lb)
+    # a group that mixes bitrates is refused with a clear error
+    model.layers[0]["k"] = _rand_linear(256, 256, 5, 2, dev, g)
+    model.save_checkpoint(str(tmp_path / "mixed"))
+    with pytest.raises(NotImplementedError):
+        SyntheticEXL3Llama.from_checkpoint(str(tmp_path / "mixed"), device=dev)
