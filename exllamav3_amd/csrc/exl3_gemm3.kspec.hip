@@ -43,9 +43,10 @@ __device__ __forceinline__ void g3_static_for(F&& f)
 
 template <int K, int CB, int MT, bool ROT>
 // ROT: the input is already rotated (fused decode pipeline) -- a separate instantiation so that neither prologue's registers burden the other.
-// five 4-wave workgroups per CU (LDS: 5 x 31 KB) need <= 96 VGPRs; the 64-row passes and the ROT prologue (16 registers of activation
-// copy in flight next to the weight ring) take four workgroups per CU instead of spilling (any scratch use slows every launch)
-__global__ __launch_bounds__(64 * G3_WAVES) __attribute__((amdgpu_waves_per_eu(((MT == 4 && (ROT || K >= 5)) || K >= 7) ? 3 : ((MT == 4 || ROT || K >= 5) ? 4 : 5))))
+// five 4-wave workgroups per CU (LDS: 5 x 31 KB) need <= 96 VGPRs; the 64-row passes, the ROT prologue (16 registers of activation copy in
+// flight next to the weight ring) and the wide rings of K >= 5 take the next register budgets instead of spilling (any scratch use slows
+// every launch); the table below is what hipcc 7.2 needs for zero scratch in every (K, codebook, MT, ROT) instantiation
+__global__ __launch_bounds__(64 * G3_WAVES) __attribute__((amdgpu_waves_per_eu(MT == 4 ? (ROT ? (K >= 5 ? 2 : 3) : ((K == 4 || K <= 2) ? 4 : 3)) : ((K >= 7 || (ROT && K >= 5)) ? 3 : ((ROT || K >= 5) ? 4 : 5)))))
 void exl3_gemm3_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
