@@ -496,10 +496,11 @@ def exl3_gemv_ex(A, xhs, xsums, Bs, Cs, suhs, svhs, m: int, mcg: bool, mul1: boo
     _dev(ref)
     cnt = len(Bs)
     k, K = Bs[0].shape[0] * 16, Bs[0].shape[2] // 16
+    _req(ref.shape[-1] == k and ref.numel() >= m * k, "exl3_gemv_ex: input width must match B (k)")
+    _req(all(B.shape[0] * 16 == k and B.shape[2] // 16 == K for B in Bs), "exl3_gemv_ex: the matrices of one launch share k and bits per weight")
     ns = (ctypes.c_int * cnt)(*[B.shape[1] * 16 for B in Bs])
     slabs = (_vp * cnt)()
     S = ctypes.c_int(0)
-    none = lambda: None
     _check(_lib.lib().exl3_gemv_ex(_p(A), _parr(xhs) if xhs else None, _parr(xsums) if xsums else None, _parr(Bs),
                                    _parr(Cs) if Cs else None, _parr(suhs) if suhs else None, _parr(svhs) if svhs else None, None,
                                    ns, cnt, m, k, K, _cb(mcg, mul1), int(c_fp32), flags, force_split, slabs, ctypes.byref(S), _stream(ref)))

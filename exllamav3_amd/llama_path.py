@@ -71,6 +71,14 @@ def _rand_linear(k: int, n: int, K: int, cb: int, device, gen: torch.Generator, 
     return LinearEXL3(k, n, trellis, suh, svh, mcg=(cb == 1), mul1=(cb == 2), out_dtype=out_dtype)
 
 
+def _same_kind(*lins: LinearEXL3) -> bool:
+    """One fused launch takes matrices of one bits-per-weight and codebook (the kernels are compiled per K); the reference fuses q|k|v and
+    gate|up under the same test (modules/attn.py:439, modules/mlp.py:635) and otherwise runs one GEMV per matrix.  Its bit allocation moves
+    q, k, v together (qgroup key.qkv, modules/attn.py:244-280) but gate and up separately, so a fractional-bpw checkpoint can have one
+    layer whose gate and up differ by a bit (conversion/allocation.py:131-141)."""
+    return len({(l.K, l.mcg, l.mul1) for l in lins}) == 1
+
+
 class SyntheticEXL3Llama:
     def __init__(self, shape: LlamaShape, K: int = 4, cb: int = 2, device: torch.device | str = "cuda:0",
                  backend: TPBackendRCCL | None = None, kv_bits: int = 4, seed: int = 0, head_K: int | None = None,
@@ -154,9 +162,8 @@ class SyntheticEXL3Llama:
                         kv_bits: int = 4, max_ctx: int = 4096, layers: int | None = None) -> "SyntheticEXL3Llama":
         """The same hot path over a real EXL3 Llama checkpoint directory (config.json + *.safetensors).  Every tensor-parallel rank reads
         its own shards straight from the files (loader.load_linear_exl3 tp_slice): q/k/v/gate/up/lm_head column shards, o/down row shards
-        (architecture/llama.py + modules/quant/exl3.py:284-330 split the same way).  The fused launches take q|k|v and gate|up in one
-        kernel each, so those groups must share bits-per-weight and codebook (the reference fuses under the same condition: modules/mlp.py:635,
-        modules/attn.py:439 compare `inner.K`, and falls back to separate GEMVs otherwise); anything else is free to differ (o, down, lm_head, layer to layer)."""
+        (architecture/llama.py + modules/quant/exl3.py:284-330 split the same way).  Bitrates and codebooks may differ per tensor: a q|k|v or gate|up
+        group of one kind runs as one fused launch, a mixed group as one GEMV per matrix (_same_kind)."""
         import json
         from . import loader
         cfg = json.load(open(os.path.join(directory, "config.json")))
@@ -199,10 +206,6 @@ class SyntheticEXL3Llama:
                 "norm1": stc.get_tensor(p + "input_layernorm.weight", self.device).half(),
                 "norm2": stc.get_tensor(p + "post_attention_layernorm.weight", self.device).half(),
             }
-            for grp in (("q", "k", "v"), ("gate", "up")):
-                kinds = {(L[n].K, L[n].mcg, L[n].mul1) for n in grp}
-                if len(kinds) != 1:
-                    raise NotImplementedError(f"layer {i}: {'|'.join(grp)} mix bits-per-weight / codebooks {sorted(kinds)}; the fused launches need one kind per group")
             self.layers.append(L)
         self.final_norm = stc.get_tensor("model.norm.weight", self.device).half()
         head_key = "lm_head" if loader.is_exl3_storage(stc, "lm_head") else None
@@ -275,9 +278,12 @@ class SyntheticEXL3Llama:
             else:
                 ext.rms_norm_res_in(pending, L["norm1"], self.xn, x, self.eps)          # x += pending ; xn = norm(x)
             q2, k2, v2 = self.q.view(bsz, -1), self.k.view(bsz, -1), self.v.view(bsz, -1)
-            ext.exl3_mgemm_bcast(self.xn, [L["q"].trellis, L["k"].trellis, L["v"].trellis], [q2, k2, v2],
-                                 [L["q"].suh, L["k"].suh, L["v"].suh], [L["q"].svh, L["k"].svh, L["v"].svh],
-                                 L["q"].mcg, L["q"].mul1)
+            if _same_kind(L["q"], L["k"], L["v"]):
+                ext.exl3_mgemm_bcast(self.xn, [L["q"].trellis, L["k"].trellis, L["v"].trellis], [q2, k2, v2],
+                                     [L["q"].suh, L["k"].suh, L["v"].suh], [L["q"].svh, L["k"].svh, L["v"].svh],
+                                     L["q"].mcg, L["q"].mul1)
+            else:
+                L["q"].bc.run(self.xn, q2); L["k"].bc.run(self.xn, k2); L["v"].bc.run(self.xn, v2)
             ext.rope(self.q, self.q, self.k, self.k, self.inv_freq, 0, self.positions, None, 2, 1.0)
             kc, ks = self.kcache[li]
             vc, vs = self.vcache[li]
@@ -287,8 +293,11 @@ class SyntheticEXL3Llama:
             L["o"].bc.run(q2, self.o)
             be.all_reduce(self.o)
             ext.rms_norm_res_in(self.o, L["norm2"], self.xn, x, self.eps)             # x += o ; xn = norm(x)
-            ext.exl3_mgemm_bcast(self.xn, [L["gate"].trellis, L["up"].trellis], [self.g, self.u],
-                                 [L["gate"].suh, L["up"].suh], [L["gate"].svh, L["up"].svh], L["gate"].mcg, L["gate"].mul1)
+            if _same_kind(L["gate"], L["up"]):
+                ext.exl3_mgemm_bcast(self.xn, [L["gate"].trellis, L["up"].trellis], [self.g, self.u],
+                                     [L["gate"].suh, L["up"].suh], [L["gate"].svh, L["up"].svh], L["gate"].mcg, L["gate"].mul1)
+            else:
+                L["gate"].bc.run(self.xn, self.g); L["up"].bc.run(self.xn, self.u)
             ext.silu_mul(self.g, self.u, self.a)
             L["down"].bc.run(self.a, self.d)
             be.all_reduce(self.d)
@@ -330,17 +339,24 @@ class SyntheticEXL3Llama:
         ext.glue_resid(None, 0, None, None, x, ss, bsz)
         for li, L in enumerate(self.layers):
             lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
-            if rot:
-                ext.glue_rotate(x, ss, L["norm1"], self.eps, [lq.suh, lk.suh, lv.suh], self.xh3, bsz)
-                slabs, S = ext.exl3_gemv_ex(None, self.xh3, None, [lq.trellis, lk.trellis, lv.trellis], None, None, None,
-                                            bsz, lq.mcg, lq.mul1, ROT | DEF, sp["qkv"])
-            else:
-                slabs, S = ext.exl3_gemv_ex_norm(x, L["norm1"], ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh],
-                                                 None, bsz, lq.mcg, lq.mul1, DEF, sp["qkv"])
             kc, ks = self.kcache[li]
             vc, vs = self.vcache[li]
-            ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
-                         self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd)
+            if not _same_kind(lq, lk, lv):
+                # q, k, v of different bitrates / codebooks: one GEMV each and the reference's standalone ops for this boundary
+                ext.rms_norm(x, L["norm1"], self.xn, self.eps)
+                lq.bc.run(self.xn, q2); lk.bc.run(self.xn, self.k.view(bsz, -1)); lv.bc.run(self.xn, self.v.view(bsz, -1))
+                ext.rope(self.q, self.q, self.k, self.k, self.inv_freq, 0, self.positions, None, 2, 1.0)
+                ext.quant_cache_paged(self.k.view(bsz, 1, -1), kc, ks, self.v.view(bsz, 1, -1), vc, vs, self.cache_seqlens, self.block_table, self.page, 1)
+            else:
+                if rot:
+                    ext.glue_rotate(x, ss, L["norm1"], self.eps, [lq.suh, lk.suh, lv.suh], self.xh3, bsz)
+                    slabs, S = ext.exl3_gemv_ex(None, self.xh3, None, [lq.trellis, lk.trellis, lv.trellis], None, None, None,
+                                                bsz, lq.mcg, lq.mul1, ROT | DEF, sp["qkv"])
+                else:
+                    slabs, S = ext.exl3_gemv_ex_norm(x, L["norm1"], ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh],
+                                                     None, bsz, lq.mcg, lq.mul1, DEF, sp["qkv"])
+                ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                             self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd)
             # attention core: out of the benchmark's scope by default (attention output := q); with_attention runs the
             # quant-cache-direct decode attention over the cached context (the K/V pages hold whatever the cache holds: zeros here except the
             # appended token, which is enough for timing and for the parity test that fills the cache first)
@@ -356,6 +372,20 @@ class SyntheticEXL3Llama:
                 lo.bc.run(o_in, self.o)
                 be.all_reduce(self.o)
                 ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=self.o)
+            if not _same_kind(lg, lu):
+                # gate and up of different bitrates (at most one layer of a fractional-bpw checkpoint): one GEMV each + silu_mul, then the
+                # down projection from the unrotated activation like o_proj
+                ext.rms_norm(x, L["norm2"], self.xn, self.eps)
+                lg.bc.run(self.xn, self.g); lu.bc.run(self.xn, self.u)
+                ext.silu_mul(self.g, self.u, self.a)
+                if self.tp == 1:
+                    sd, Sd = ext.exl3_gemv_ex(self.a, None, None, [ld.trellis], None, [ld.suh], None, bsz, ld.mcg, ld.mul1, DEF, sp["down"])
+                    ext.glue_resid(sd[0], Sd, ld.svh, None, x, ss, bsz)
+                else:
+                    ld.bc.run(self.a, self.d)
+                    be.all_reduce(self.d)
+                    ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=self.d)
+                continue
             if rot:
                 ext.glue_rotate(x, ss, L["norm2"], self.eps, [lg.suh, lu.suh], self.xh3[:2], bsz)
                 sgu, Sgu = ext.exl3_gemv_ex(None, self.xh3[:2], None, [lg.trellis, lu.trellis], None, None, None,

@@ -489,11 +489,12 @@ def test_checkpoint_round_trip_reproduces_logits(dev, tmp_path):
     model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048, head_K=6)
     g = torch.Generator(device=dev); g.manual_seed(7)
     for L in model.layers:                                                    # mixed bitrates across groups
-        L["o"] = _rand_linear(256, 256, 3, 0, dev, g, out_dtype=torch.float)
+        L["o"] = _rand_linear(512, 256, 3, 0, dev, g, out_dtype=torch.float)
         L["down"] = _rand_linear(512, 256, 5, 1, dev, g, out_dtype=torch.float)
     model.save_checkpoint(str(tmp_path))
     loaded = SyntheticEXL3Llama.from_checkpoint(str(tmp_path), device=dev, max_ctx=2048)
     assert (loaded.K, loaded.cb, loaded.lm_head.K, loaded.layers[0]["o"].K, loaded.layers[1]["down"].mcg) == (4, 2, 6, 3, True)
+    assert loaded.layers[0]["o"].in_features == 512
     for La, Lb in zip(model.layers, loaded.layers):
         for nm in ("q", "k", "v", "o", "gate", "up", "down"):
             assert torch.equal(La[nm].trellis, Lb[nm].trellis) and torch.equal(La[nm].suh, Lb[nm].suh) and torch.equal(La[nm].svh, Lb[nm].svh)
@@ -504,8 +505,20 @@ def test_checkpoint_round_trip_reproduces_logits(dev, tmp_path):
         la = model.decode_step_fused().clone()
         lb = loaded.decode_step_fused()
         assert torch.equal(la, lb)
-    # a group that mixes bitrates is refused with a clear error
+    # a q|k|v or gate|up group that mixes bitrates / codebooks runs as one GEMV per matrix (the reference's fallback, modules/attn.py:439,
+    # modules/mlp.py:635): same logits as the op-by-op pipeline up to fp32 summation order, at m <= 4 and above
     model.layers[0]["k"] = _rand_linear(256, 256, 5, 2, dev, g)
+    model.layers[1]["up"] = _rand_linear(256, 512, 3, 0, dev, g)
     model.save_checkpoint(str(tmp_path / "mixed"))
-    with pytest.raises(NotImplementedError):
-        SyntheticEXL3Llama.from_checkpoint(str(tmp_path / "mixed"), device=dev)
+    mixed = SyntheticEXL3Llama.from_checkpoint(str(tmp_path / "mixed"), device=dev, max_ctx=2048)
+    assert (mixed.layers[0]["k"].K, mixed.layers[0]["q"].K, mixed.layers[1]["up"].K, mixed.layers[1]["gate"].K) == (5, 4, 3, 4)
+    for bsz in (1, 3, 6):
+        mixed.alloc_state(bsz, pos=90)
+        lu = mixed.decode_step().float().cpu().numpy().copy()
+        for c, s in mixed.kcache + mixed.vcache:
+            c.zero_(); s.zero_()
+        lf = mixed.decode_step_fused().float().cpu().numpy()
+        assert np.isfinite(lf).all()
+        assert np.abs(lf - lu).max() / np.sqrt((lu ** 2).mean()) < 1e-2
+    mixed.prefill_chunk(160)                                                  # the prefill route reconstructs every matrix with its own K
+    torch.cuda.synchronize()
