@@ -4,6 +4,9 @@
 // reconstruct + hgemm pair for EXL3 weights (exl3_gemm_prefill.hip); hgemm stays for the reference's op surface.
 #include "exl3_api_internal.h"
 #include <hipblaslt/hipblaslt.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
+#include <vector>
+#include <stdio.h>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -109,10 +112,48 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
                 (void) hipEventElapsedTime(&ms, e0, e1);
                 if (ms < best_ms) { best_ms = ms; best = i; }
             }
+            hipblasLtMatmulAlgo_t best_algo = res[best].algo;
+            int extra_better = 0, extra_tried = 0;
+            if (tune >= 2 && dtune)
+            {
+                // EXL3_HIP_HGEMM_TUNE=2: beyond the heuristic's candidates, time EVERY solution the library holds for this type
+                // combination that supports the problem (hipblaslt_ext::getAllAlgos + matmulIsAlgoSupported).  Seconds per shape, once.
+                std::vector<hipblasLtMatmulHeuristicResult_t> all;
+                if (hipblaslt_ext::getAllAlgos(cx.handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, b_t_ld ? HIPBLAS_OP_T : HIPBLAS_OP_N, HIPBLAS_OP_N,
+                                               HIP_R_16F, HIP_R_16F, c_fp32 ? HIP_R_32F : HIP_R_16F, c_fp32 ? HIP_R_32F : HIP_R_16F,
+                                               HIPBLAS_COMPUTE_32F, all) == HIPBLAS_STATUS_SUCCESS)
+                {
+                    for (auto& cand : all)
+                    {
+                        size_t need = 0;
+                        if (hipblaslt_ext::matmulIsAlgoSupported(cx.handle, desc, &al, la, lb, &be, lc, lc, cand.algo, need) != HIPBLAS_STATUS_SUCCESS) continue;
+                        if (need > (size_t) HGEMM_WS_BYTES) continue;
+                        ++extra_tried;
+                        bool ok = true;
+                        float ms = 0.0f;
+                        for (int rep = 0; rep < 4 && ok; ++rep)
+                        {
+                            if (rep == 1) (void) hipEventRecord(e0, (hipStream_t) stream);     // 1 warm-up run, 3 timed
+                            ok = hipblasLtMatmul(cx.handle, desc, &al, b, la, a, lb, &be, c, lc, dtune, lc, &cand.algo, cx.ws, HGEMM_WS_BYTES,
+                                                 (hipStream_t) stream) == HIPBLAS_STATUS_SUCCESS;
+                        }
+                        if (!ok) continue;
+                        (void) hipEventRecord(e1, (hipStream_t) stream);
+                        (void) hipEventSynchronize(e1);
+                        (void) hipEventElapsedTime(&ms, e0, e1);
+                        ms *= 5.0f / 3.0f;                                                  // same scale as the 5-run figures above
+                        if (ms < best_ms) { best_ms = ms; best_algo = cand.algo; ++extra_better; }
+                    }
+                }
+                if (getenv("EXL3_HIP_HGEMM_TUNE_VERBOSE"))
+                    fprintf(stderr, "hgemm tune: m=%d k=%d n=%d acc=%d nt=%d: %d heuristic + %d further candidates, %d improvements, best %.1f us (solution index %d)\n",
+                            m, k, n, accumulate, b_t_ld ? 1 : 0, found, extra_tried, extra_better, best_ms * 200.0f, hipblaslt_ext::getIndexFromAlgo(best_algo));
+            }
             (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
             if (accumulate && dtune) { (void) hipStreamSynchronize((hipStream_t) stream); (void) hipFree(dtune); }
+            it = cx.algos.emplace(key, best_algo).first;
         }
-        it = cx.algos.emplace(key, res[best].algo).first;
+        else it = cx.algos.emplace(key, res[best].algo).first;
     }
     const float alpha = 1.0f, beta = accumulate ? 1.0f : 0.0f;
     hipblasStatus_t st = hipblasLtMatmul(cx.handle, desc, &alpha, b, la, a, lb, &beta, c, lc, c, lc, &it->second,
