@@ -88,6 +88,68 @@ void rms_norm_kernel(const void* __restrict__ x, const void* __restrict__ w, voi
     }
 }
 
+// Many-row variant (prefill: thousands of rows of 2048 / 4096 / 8192 halves): one WAVE per row.  The row lives in registers (NV 16-byte
+// pieces per lane), so x is read once, the sum of squares is a DPP butterfly, and there is no workgroup barrier; 4 rows per 256-thread
+// workgroup.  The block-per-row kernel above spends a 4096-wide row on 1024 threads x 8 bytes, two barriers and a second pass over x:
+// 25.6 us for 4096 x 4096 fp16 (2.6 TB/s, profiles/r01_prefill_chunk_kernel_stats.csv).  Same per-element arithmetic (v * w * rmf in
+// fp32, one rounding); the sum of squares is accumulated in another order (fp32), inside the op's 1e-3 tolerance.
+template <int MODE, int NV>
+__global__ __launch_bounds__(256)
+void rms_norm_rows_kernel(const half_t* __restrict__ x, const void* __restrict__ w, half_t* __restrict__ y, half_t* __restrict__ r,
+                          float eps, float constant_bias, float constant_scale, int rows, int w_bf16)
+{
+    constexpr int DIM = NV * 512;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4)
+    {
+        half8_t v[NV];
+        const half8_t* xr = (const half8_t*) (x + (size_t) row * DIM);
+        #pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = xr[i * 64 + lane];
+        if constexpr (MODE == 2)
+        {
+            half8_t* rr = (half8_t*) (r + (size_t) row * DIM);
+            #pragma unroll
+            for (int i = 0; i < NV; ++i)
+            {
+                const half8_t rv = rr[i * 64 + lane];
+                #pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = f2h((float) v[i][j] + (float) rv[j]);      // r += x rounded to r's dtype; the norm sees that value
+                rr[i * 64 + lane] = v[i];
+            }
+        }
+        float sum = 0.0f;
+        #pragma unroll
+        for (int i = 0; i < NV; ++i)
+        {
+            #pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float) v[i][j]; sum = __builtin_fmaf(f, f, sum); }
+        }
+        #pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += xor_lane(sum, o);
+        const float rmf = __frsqrt_rn(sum / (float) DIM + eps) * constant_scale;
+        half8_t* yr = (half8_t*) (y + (size_t) row * DIM);
+        #pragma unroll
+        for (int i = 0; i < NV; ++i)
+        {
+            half8_t o8;
+            if (w)
+            {
+                const float4_t w0 = load_w4(w, 2 * (i * 64 + lane), w_bf16), w1 = load_w4(w, 2 * (i * 64 + lane) + 1, w_bf16);
+                const float wf[8] = { w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w };
+                #pragma unroll
+                for (int j = 0; j < 8; ++j) o8[j] = f2h((float) v[i][j] * (wf[j] + constant_bias) * rmf);
+            }
+            else
+            {
+                #pragma unroll
+                for (int j = 0; j < 8; ++j) o8[j] = f2h((float) v[i][j] * rmf);
+            }
+            yr[i * 64 + lane] = o8;
+        }
+    }
+}
+
 extern "C" int exl3_rms_norm(const void* x, const void* w, void* y, void* r, float eps, float constant_bias, float constant_scale,
                              int rows, int dim, int x_fp32, int y_fp32, int r_fp32, int w_bf16, int mode, void* stream)
 {
@@ -96,9 +158,19 @@ extern "C" int exl3_rms_norm(const void* x, const void* w, void* y, void* r, flo
     EXL3_CHECK_ARG(mode >= 0 && mode <= 2, "rms_norm: bad mode");
     EXL3_CHECK_ARG(mode != 2 || r, "rms_norm: res_mode RES_IN requires residual tensor");
     if (rows == 0) return EXL3_OK;
+    hipStream_t st = (hipStream_t) stream;
+    if (rows >= 64 && !x_fp32 && !y_fp32 && (mode != 2 || !r_fp32) && mode != 1 && (dim == 2048 || dim == 4096 || dim == 8192))
+    {
+        const unsigned grid = (unsigned) ((rows + 3) / 4);
+        #define RR(M, NV) rms_norm_rows_kernel<M, NV><<<dim3(grid), dim3(256), 0, st>>>((const half_t*) x, w, (half_t*) y, (half_t*) r, eps, \
+                                                                                     constant_bias, constant_scale, rows, w_bf16)
+        if (mode == 0) { if (dim == 2048) RR(0, 4); else if (dim == 4096) RR(0, 8); else RR(0, 16); }
+        else           { if (dim == 2048) RR(2, 4); else if (dim == 4096) RR(2, 8); else RR(2, 16); }
+        #undef RR
+        return exl3_check_launch("rms_norm");
+    }
     int threads = ((dim / 4 + 63) / 64) * 64;
     if (threads > 1024) threads = 1024;
-    hipStream_t st = (hipStream_t) stream;
     #define RN(M) rms_norm_kernel<M><<<dim3(rows), dim3(threads), 0, st>>>(x, w, y, r, eps, constant_bias, \
                                      constant_scale, dim, x_fp32, y_fp32, r_fp32, w_bf16)
     if (mode == 0) RN(0); else if (mode == 1) RN(1); else RN(2);
@@ -137,14 +209,28 @@ __global__ __launch_bounds__(256)
 void silu_mul_2d_kernel(const half_t* __restrict__ g, const half_t* __restrict__ u, half_t* __restrict__ y, int64_t rows, int cols8,
                         int64_t ld_g, int64_t ld_u)
 {
-    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cols8) return;
-    const int64_t r = i / cols8; const int c = (int) (i % cols8);
-    const half8_t gv = ((const half8_t*) (g + r * ld_g))[c], uv = ((const half8_t*) (u + r * ld_u))[c];
-    half8_t o;
-    #pragma unroll
-    for (int j = 0; j < 8; ++j) { const float gf = (float) gv[j]; o[j] = f2h(gf / (1.0f + __expf(-gf)) * (float) uv[j]); }
-    ((half8_t*) (y + r * (int64_t) cols8 * 8))[c] = o;
+    // grid = (column chunks of 256 x 8 halves, row groups); a workgroup walks its rows with a stride of gridDim.y: no per-thread division,
+    // two rows in flight per thread
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols8) return;
+    for (int64_t r = blockIdx.y; r < rows; r += 2 * (int64_t) gridDim.y)
+    {
+        const int64_t r1 = r + gridDim.y;
+        const bool two = r1 < rows;
+        const half8_t g0 = ((const half8_t*) (g + r * ld_g))[c], u0 = ((const half8_t*) (u + r * ld_u))[c];
+        half8_t g1 = g0, u1 = u0;
+        if (two) { g1 = ((const half8_t*) (g + r1 * ld_g))[c]; u1 = ((const half8_t*) (u + r1 * ld_u))[c]; }
+        half8_t o0, o1;
+        #pragma unroll
+        for (int j = 0; j < 8; ++j)
+        {
+            const float a = (float) g0[j], b = (float) g1[j];
+            o0[j] = f2h(a / (1.0f + __expf(-a)) * (float) u0[j]);
+            o1[j] = f2h(b / (1.0f + __expf(-b)) * (float) u1[j]);
+        }
+        ((half8_t*) (y + r * (int64_t) cols8 * 8))[c] = o0;
+        if (two) ((half8_t*) (y + r1 * (int64_t) cols8 * 8))[c] = o1;
+    }
 }
 
 extern "C" int exl3_silu_mul_2d(const void* g, const void* u, void* y, int64_t rows, int64_t cols, int64_t ld_g, int64_t ld_u, void* stream)
@@ -152,9 +238,10 @@ extern "C" int exl3_silu_mul_2d(const void* g, const void* u, void* y, int64_t r
     EXL3_CHECK_ARG(g && u && y, "silu_mul_2d: null pointer");
     EXL3_CHECK_ARG(cols % 8 == 0 && ld_g % 8 == 0 && ld_u % 8 == 0 && ld_g >= cols && ld_u >= cols, "silu_mul_2d: columns and row strides must be multiples of 8");
     if (rows == 0 || cols == 0) return EXL3_OK;
-    const int64_t n = rows * (cols / 8);
-    silu_mul_2d_kernel<<<dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream>>>((const half_t*) g, (const half_t*) u, (half_t*) y,
-                                                                                                 rows, (int) (cols / 8), ld_g, ld_u);
+    const int cols8 = (int) (cols / 8);
+    const unsigned gx = (unsigned) ((cols8 + 255) / 256);
+    unsigned gy = (unsigned) (rows < 2048 ? rows : 2048);                  // >= 8 workgroups per CU in flight for wide matrices
+    silu_mul_2d_kernel<<<dim3(gx, gy), dim3(256), 0, (hipStream_t) stream>>>((const half_t*) g, (const half_t*) u, (half_t*) y, rows, cols8, ld_g, ld_u);
     return exl3_check_launch("silu_mul_2d");
 }
 

@@ -97,6 +97,68 @@ void rope_kernel(const half_t* __restrict__ q, half_t* __restrict__ out_q, const
     }
 }
 
+// NEOX, head_dim 128, no head norm (Llama / Mixtral prefill): 8 lanes per head, 16-byte accesses -- lane l of a head holds elements
+// 8l .. 8l+7 and their partners 64 + 8l .. 64 + 8l + 7.  The general kernel above moves 2 bytes per lane per access (128 B per wave
+// instruction): 31.5 us for a 4096-token q + k (2.7 TB/s, profiles/r01_prefill_chunk_kernel_stats.csv).  Same arithmetic per element.
+__global__ __launch_bounds__(256)
+void rope_neox128_kernel(const half_t* __restrict__ q, half_t* __restrict__ out_q, const half_t* __restrict__ k, half_t* __restrict__ out_k,
+                         const float* __restrict__ inv_freq, int seq_len, int heads_q, int heads_k,
+                         uint32_t position, const int32_t* __restrict__ positions, const int32_t* __restrict__ position_ids, float attn_factor)
+{
+    __shared__ __attribute__((aligned(16))) float sn_s[64], cs_s[64];
+    const int token = blockIdx.x, batch = blockIdx.y;
+    {
+        int pos0 = token + (int) position;
+        if (positions) pos0 = token + positions[batch];
+        else if (position_ids) pos0 = position_ids[(int64_t) batch * seq_len + token];
+        if (threadIdx.x < 64)
+        {
+            float sn, cs;
+            sincosf(inv_freq[threadIdx.x] * (float) pos0, &sn, &cs);
+            sn_s[threadIdx.x] = sn * attn_factor; cs_s[threadIdx.x] = cs * attn_factor;
+        }
+    }
+    // the first unit's data is requested before the barrier
+    const int heads = heads_q + heads_k;
+    const int64_t tok = (int64_t) batch * seq_len + token;
+    const int l = threadIdx.x & 7;
+    auto ptrs = [&] (int head, const half_t*& src, half_t*& dst)
+    {
+        const bool is_q = head < heads_q;
+        const int hi = is_q ? head : head - heads_q;
+        src = is_q ? q + (tok * heads_q + hi) * 128 : k + (tok * heads_k + hi) * 128;
+        dst = is_q ? out_q + (tok * heads_q + hi) * 128 : out_k + (tok * heads_k + hi) * 128;
+    };
+    int head = threadIdx.x >> 3;
+    half8_t a = {}, b = {};
+    const half_t* src; half_t* dst = nullptr;
+    if (head < heads) { ptrs(head, src, dst); a = ((const half8_t*) src)[l]; b = ((const half8_t*) (src + 64))[l]; }
+    __syncthreads();
+    float sn[8], cs[8];
+    {
+        const float4_t s0 = ((const float4_t*) sn_s)[2 * l], s1 = ((const float4_t*) sn_s)[2 * l + 1];
+        const float4_t c0 = ((const float4_t*) cs_s)[2 * l], c1 = ((const float4_t*) cs_s)[2 * l + 1];
+        sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+        cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+    }
+    for (; head < heads; head += 32)
+    {
+        half8_t na = a, nb = b;
+        const half_t* nsrc; half_t* ndst = nullptr;
+        if (head + 32 < heads) { ptrs(head + 32, nsrc, ndst); na = ((const half8_t*) nsrc)[l]; nb = ((const half8_t*) (nsrc + 64))[l]; }
+        half8_t oa, ob;
+        #pragma unroll
+        for (int j = 0; j < 8; ++j)
+        {
+            const float v1 = (float) a[j], v2 = (float) b[j];
+            oa[j] = f2h(v1 * cs[j] - v2 * sn[j]);
+            ob[j] = f2h(v2 * cs[j] + v1 * sn[j]);
+        }
+        ((half8_t*) dst)[l] = oa; ((half8_t*) (dst + 64))[l] = ob;
+        a = na; b = nb; dst = ndst;
+    }
+}
+
 extern "C" int exl3_rope(const void* q, void* out_q, const void* k, void* out_k, const float* inv_freq,
                          int bsz, int seq_len, int heads_q, int heads_k, int head_dim,
                          uint32_t position, const int32_t* positions, const int32_t* position_ids,
@@ -110,6 +172,12 @@ extern "C" int exl3_rope(const void* q, void* out_q, const void* k, void* out_k,
     if (bsz == 0 || seq_len == 0) return EXL3_OK;
     dim3 grid(seq_len, bsz, 1);
     hipStream_t st = (hipStream_t) stream;
+    if (rope_mode == 2 && head_dim == 128 && !q_norm && !k_norm && seq_len >= 16)
+    {
+        rope_neox128_kernel<<<grid, 256, 0, st>>>((const half_t*) q, (half_t*) out_q, (const half_t*) k, (half_t*) out_k, inv_freq, seq_len, heads_q, heads_k,
+                                                  position, positions, position_ids, attn_factor);
+        return exl3_check_launch("rope");
+    }
     if (rope_mode == 2)
         rope_kernel<2><<<grid, 256, 0, st>>>((const half_t*) q, (half_t*) out_q, (const half_t*) k, (half_t*) out_k, inv_freq, seq_len, heads_q, heads_k,
                                              head_dim, position, positions, position_ids, attn_factor, (const half_t*) q_norm, (const half_t*) k_norm, norm_eps, norm_constant_bias);

@@ -75,3 +75,28 @@ def test_silu_mul_add(dev):
         assert np.allclose(y.float().cpu().numpy(), r, rtol=3e-3, atol=3e-3)
     a = _t(g, dev); ext.add(a, _t(u.astype(np.float16), dev))
     assert np.allclose(a.cpu().numpy(), g + u.astype(np.float16).astype(np.float32), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dim", [2048, 4096, 8192])
+@pytest.mark.parametrize("rows", [64, 257, 4096])
+def test_rms_norm_many_rows_fast_path(dev, dim, rows):
+    """>= 64 fp16 rows of 2048 / 4096 / 8192: the one-wave-per-row kernel (prefill), plain and RES_IN, fp16 and bf16 weights, with the
+    constant bias / scale arguments; same tolerance as the block-per-row kernel."""
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(dim + rows)
+    x = (rng.standard_normal((rows, dim)) * 1.5).astype(np.float16)
+    w = (1 + 0.1 * rng.standard_normal(dim)).astype(np.float16)
+    y = torch.empty((rows, dim), dtype=torch.half, device=dev)
+    ext.rms_norm(_t(x, dev), _t(w, dev), y, 1e-6)
+    assert np.allclose(y.float().cpu().numpy(), o.rms_norm(x, w, 1e-6).astype(np.float32), rtol=1e-3, atol=1e-3)
+    ext.rms_norm(_t(x, dev), _t(w, dev), y, 1e-5, 1.0, 0.5)
+    assert np.allclose(y.float().cpu().numpy(), o.rms_norm(x, w, 1e-5, constant_bias=1.0, constant_scale=0.5).astype(np.float32), rtol=2e-3, atol=2e-3)
+    wb = torch.from_numpy(w.astype(np.float32)).to(torch.bfloat16)
+    ext.rms_norm(_t(x, dev), wb.to(dev), y, 1e-5)
+    assert np.allclose(y.float().cpu().numpy(), o.rms_norm(x, wb.float().numpy(), 1e-5).astype(np.float32), rtol=2e-3, atol=2e-3)
+    r = rng.standard_normal((rows, dim)).astype(np.float16)
+    y_ref, r_ref = o.rms_norm(x, w, 1e-5, residual_in=r)
+    rt = _t(r, dev)
+    ext.rms_norm_res_in(_t(x, dev), _t(w, dev), y, rt, 1e-5)
+    assert np.allclose(rt.float().cpu().numpy(), r_ref.astype(np.float32), rtol=1e-3, atol=1e-3)
+    assert np.allclose(y.float().cpu().numpy(), y_ref.astype(np.float32), rtol=2e-3, atol=2e-3)

@@ -136,3 +136,31 @@ def test_attn_decode_qcache(dev, kb, vb, lens):
     got = out.float().cpu().numpy()
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
+
+
+@pytest.mark.parametrize("shape", [(1, 300, 32, 8, 128), (2, 17, 5, 3, 128), (1, 64, 40, 40, 128), (1, 16, 1, 0, 128)])
+def test_rope_neox_head_dim_128_prefill_kernel(dev, shape):
+    """>= 16 tokens, NEOX, head_dim 128, no head norm: the 16-byte-per-lane kernel (8 lanes per head); scalar position, per-sequence
+    positions and position ids, in place and out of place, q only (heads_k = 0)."""
+    from exllamav3_amd import ext
+    b, s, hq, hk, hd = shape
+    rng = np.random.default_rng(s + hq)
+    q = rng.standard_normal((b, s, hq, hd)).astype(np.float16)
+    k = rng.standard_normal((b, s, hk, hd)).astype(np.float16) if hk else None
+    inv = (1.0 / (500000.0 ** (np.arange(0, hd, 2) / hd))).astype(np.float32)
+    positions = rng.integers(0, 5000, size=b).astype(np.int32)
+    pid = rng.integers(0, 100000, size=(b, s)).astype(np.int32)
+    for kw in (dict(position=1234), dict(positions=positions), dict(position_ids=pid)):
+        rq, rk = o.rope(q, k, inv, rope_mode=2, attn_factor=0.9, **kw)
+        qo = torch.empty(q.shape, dtype=torch.half, device=dev)
+        ko = torch.empty(k.shape, dtype=torch.half, device=dev) if hk else None
+        ext.rope(_t(q, dev), qo, _t(k, dev) if hk else None, ko, _t(inv, dev), kw.get("position", 0),
+                 _t(kw["positions"], dev) if "positions" in kw else None, _t(kw["position_ids"], dev) if "position_ids" in kw else None, 2, 0.9)
+        assert np.allclose(qo.float().cpu().numpy(), rq.astype(np.float32), atol=3e-3, rtol=3e-3)
+        if hk:
+            assert np.allclose(ko.float().cpu().numpy(), rk.astype(np.float32), atol=3e-3, rtol=3e-3)
+    tq = _t(q, dev)
+    tk = _t(k, dev) if hk else None
+    rq, rk = o.rope(q, k, inv, position=7, rope_mode=2)
+    ext.rope(tq, tq, tk, tk, _t(inv, dev), 7, None, None, 2, 1.0)
+    assert np.allclose(tq.float().cpu().numpy(), rq.astype(np.float32), atol=3e-3, rtol=3e-3)
