@@ -93,12 +93,15 @@ def _declare(l):
     sig("exl3_hgemm", vp, vp, vp, i32, i32, i32, i64, i32, vp)
     sig("exl3_hgemm_acc", vp, vp, vp, i32, i32, i32, i64, vp)
     sig("exl3_hgemm_nt", vp, vp, vp, i32, i32, i32, i64, i64, i32, i32, vp)
+    sig("exl3_hgemm_nt_lda", vp, i64, vp, vp, i32, i32, i32, i64, i64, i32, i32, vp)
     sig("exl3_reconstruct_had_t", vp, i64, vp, vp, vp, i32, i32, i32, i32, i64, i64, vp)
     sig("exl3_rms_norm", vp, vp, vp, vp, f32, f32, f32, i32, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_rope", vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, u32, vp, vp, i32, f32, vp, vp, f32, f32, vp)
     sig("exl3_quant_cache_cont", vp, vp, vp, i64, i32, i32, vp)
     sig("exl3_dequant_cache_cont", vp, vp, vp, i64, i32, i32, vp)
     sig("exl3_quant_cache_paged", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp)
+    sig("exl3_quant_cache_paged_strided", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, vp)
+    sig("exl3_rope_strided", vp, vp, vp, i32, i32, i32, i32, i64, i64, u32, vp, vp, f32, vp)
     sig("exl3_dequant_cache_paged", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_silu_mul", vp, vp, vp, i64, i32, vp)
     sig("exl3_add", vp, vp, i64, i32, i32, vp)

@@ -6,6 +6,7 @@
 #include <hipblaslt/hipblaslt.h>
 #include <hipblaslt/hipblaslt-ext.hpp>
 #include <vector>
+#include <algorithm>
 #include <stdio.h>
 #include <map>
 #include <mutex>
@@ -19,7 +20,7 @@ struct HgemmCtx
     bool ready = false;
     hipblasLtHandle_t handle;
     void* ws = nullptr;
-    std::map<std::tuple<int, int, int, int64_t, int, int, int64_t>, hipblasLtMatmulAlgo_t> algos;
+    std::map<std::tuple<int, int, int, int64_t, int, int, int64_t, int64_t>, hipblasLtMatmulAlgo_t> algos;
 };
 static HgemmCtx g_hctx[64];
 static std::mutex g_hmutex;
@@ -28,8 +29,10 @@ static std::mutex g_hmutex;
     exl3_set_error("hgemm: %s failed (hipblasStatus %d)", what, (int) s_); return EXL3_ERR_HIP; } } while (0)
 
 // b_t_ld == 0: b is [k][n] row-major.  b_t_ld > 0: b holds B^T, [n][b_t_ld] row-major with k contiguous (b_t_ld >= k).
-static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, int accumulate, int64_t b_t_ld, void* stream)
+static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n, int64_t ldc, int c_fp32, int accumulate, int64_t b_t_ld, void* stream,
+                      int64_t lda = 0)
 {
+    if (lda == 0) lda = k;                                // a: [m][lda] row-major, lda >= k (a column range of a wider matrix)
     EXL3_CHECK_ARG(a && b && c, "hgemm: null pointer");
     EXL3_CHECK_ARG(m >= 0 && k > 0 && n > 0 && ldc >= n, "hgemm: bad dimensions");
     if (m == 0) return EXL3_OK;
@@ -61,10 +64,10 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
     // its transpose (k x n, ld b_t_ld) and is used with op = T -- both GEMM operands are then K-major
     if (b_t_ld) { CHECK_LT(hipblasLtMatrixLayoutCreate(&la, HIP_R_16F, k, n, b_t_ld), "layout A^T"); }
     else        CHECK_LT(hipblasLtMatrixLayoutCreate(&la, HIP_R_16F, n, k, n), "layout A");
-    CHECK_LT(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16F, k, m, k), "layout B");
+    CHECK_LT(hipblasLtMatrixLayoutCreate(&lb, HIP_R_16F, k, m, lda), "layout B");
     CHECK_LT(hipblasLtMatrixLayoutCreate(&lc, c_fp32 ? HIP_R_32F : HIP_R_16F, n, m, ldc), "layout C");
 
-    auto key = std::make_tuple(m, k, n, ldc, c_fp32, accumulate, b_t_ld);
+    auto key = std::make_tuple(m, k, n, ldc, c_fp32, accumulate, b_t_ld, lda);
     auto it = cx.algos.find(key);
     if (it == cx.algos.end())
     {
@@ -95,6 +98,7 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
             void* dtune = c;
             if (accumulate && hipMalloc(&dtune, (size_t) m * ldc * (c_fp32 ? 4 : 2)) != hipSuccess) dtune = nullptr;
             float best_ms = 1e30f;
+            std::vector<std::pair<float, int>> timed;
             for (int i = 0; i < found; ++i)
             {
                 if (res[i].workspaceSize > HGEMM_WS_BYTES) continue;
@@ -110,7 +114,30 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
                 (void) hipEventRecord(e1, (hipStream_t) stream);
                 (void) hipEventSynchronize(e1);
                 (void) hipEventElapsedTime(&ms, e0, e1);
+                timed.push_back({ ms, i });
                 if (ms < best_ms) { best_ms = ms; best = i; }
+            }
+            // second pass: the four fastest again, 20 runs each -- the first pass's 5-run figures of neighbouring candidates differ by less than
+            // their run-to-run noise, and a chunk-level 3 % swing between processes came from that coin toss (rocprofv3 traces of two runs)
+            std::sort(timed.begin(), timed.end());
+            if (timed.size() > 1)
+            {
+                float best2 = 1e30f;
+                for (size_t t = 0; t < timed.size() && t < 4; ++t)
+                {
+                    const int i = timed[t].second;
+                    bool ok = true;
+                    float ms = 0.0f;
+                    (void) hipEventRecord(e0, (hipStream_t) stream);
+                    for (int rep = 0; rep < 20 && ok; ++rep)
+                        ok = hipblasLtMatmul(cx.handle, desc, &al, b, la, a, lb, &be, c, lc, dtune, lc, &res[i].algo, cx.ws, HGEMM_WS_BYTES,
+                                             (hipStream_t) stream) == HIPBLAS_STATUS_SUCCESS;
+                    (void) hipEventRecord(e1, (hipStream_t) stream);
+                    (void) hipEventSynchronize(e1);
+                    (void) hipEventElapsedTime(&ms, e0, e1);
+                    if (ok && ms < best2) { best2 = ms; best = i; }
+                }
+                best_ms = best2 / 4.0f;                                                 // back on the 5-run scale
             }
             hipblasLtMatmulAlgo_t best_algo = res[best].algo;
             int extra_better = 0, extra_tried = 0;
@@ -176,6 +203,15 @@ extern "C" int exl3_hgemm_nt(const void* a, const void* bt, void* c, int m, int 
     EXL3_CHECK_ARG(ldb >= k, "hgemm_nt: ldb must be >= k");
     EXL3_CHECK_ARG(!accumulate || !c_fp32, "hgemm_nt: accumulate mode needs an fp16 c");
     return hgemm_impl(a, bt, c, m, k, n, ldc, c_fp32, accumulate ? 1 : 0, ldb, stream);
+}
+
+// exl3_hgemm_nt with a row stride for a as well (lda >= k): a is a column range of a wider row-major matrix, e.g. the q columns of the prefill
+// route's fused q|k|v GEMM output feeding o_proj
+extern "C" int exl3_hgemm_nt_lda(const void* a, int64_t lda, const void* bt, void* c, int m, int k, int n, int64_t ldb, int64_t ldc, int c_fp32, int accumulate, void* stream)
+{
+    EXL3_CHECK_ARG(ldb >= k && lda >= k && lda % 8 == 0, "hgemm_nt_lda: lda, ldb must be >= k (lda a multiple of 8)");
+    EXL3_CHECK_ARG(!accumulate || !c_fp32, "hgemm_nt: accumulate mode needs an fp16 c");
+    return hgemm_impl(a, bt, c, m, k, n, ldc, c_fp32, accumulate ? 1 : 0, ldb, stream, lda);
 }
 
 // c[m][n] (fp16, in place) = fp16(a @ b + c): the residual add of the reference's o_proj / down_proj boundary (fp32 GEMM output, then

@@ -103,8 +103,11 @@ void rope_kernel(const half_t* __restrict__ q, half_t* __restrict__ out_q, const
 __global__ __launch_bounds__(256)
 void rope_neox128_kernel(const half_t* __restrict__ q, half_t* __restrict__ out_q, const half_t* __restrict__ k, half_t* __restrict__ out_k,
                          const float* __restrict__ inv_freq, int seq_len, int heads_q, int heads_k,
-                         uint32_t position, const int32_t* __restrict__ positions, const int32_t* __restrict__ position_ids, float attn_factor)
+                         uint32_t position, const int32_t* __restrict__ positions, const int32_t* __restrict__ position_ids, float attn_factor,
+                         int64_t ld_q, int64_t ld_k)
 {
+    // ld_q / ld_k: halves between consecutive tokens (heads * 128 when contiguous; larger when q / k are column ranges of one fused
+    // q|k|v GEMM output)
     __shared__ __attribute__((aligned(16))) float sn_s[64], cs_s[64];
     const int token = blockIdx.x, batch = blockIdx.y;
     {
@@ -126,8 +129,8 @@ void rope_neox128_kernel(const half_t* __restrict__ q, half_t* __restrict__ out_
     {
         const bool is_q = head < heads_q;
         const int hi = is_q ? head : head - heads_q;
-        src = is_q ? q + (tok * heads_q + hi) * 128 : k + (tok * heads_k + hi) * 128;
-        dst = is_q ? out_q + (tok * heads_q + hi) * 128 : out_k + (tok * heads_k + hi) * 128;
+        src = is_q ? q + tok * ld_q + hi * 128 : k + tok * ld_k + hi * 128;
+        dst = is_q ? out_q + tok * ld_q + hi * 128 : out_k + tok * ld_k + hi * 128;
     };
     int head = threadIdx.x >> 3;
     half8_t a = {}, b = {};
@@ -175,7 +178,7 @@ extern "C" int exl3_rope(const void* q, void* out_q, const void* k, void* out_k,
     if (rope_mode == 2 && head_dim == 128 && !q_norm && !k_norm && seq_len >= 16)
     {
         rope_neox128_kernel<<<grid, 256, 0, st>>>((const half_t*) q, (half_t*) out_q, (const half_t*) k, (half_t*) out_k, inv_freq, seq_len, heads_q, heads_k,
-                                                  position, positions, position_ids, attn_factor);
+                                                  position, positions, position_ids, attn_factor, (int64_t) heads_q * 128, (int64_t) heads_k * 128);
         return exl3_check_launch("rope");
     }
     if (rope_mode == 2)
@@ -185,6 +188,19 @@ extern "C" int exl3_rope(const void* q, void* out_q, const void* k, void* out_k,
         rope_kernel<1><<<grid, 256, 0, st>>>((const half_t*) q, (half_t*) out_q, (const half_t*) k, (half_t*) out_k, inv_freq, seq_len, heads_q, heads_k,
                                              head_dim, position, positions, position_ids, attn_factor, (const half_t*) q_norm, (const half_t*) k_norm, norm_eps, norm_constant_bias);
     return exl3_check_launch("rope");
+}
+
+// In-place NEOX rope (head_dim 128, no head norm) on q / k that are column ranges of a wider row-major matrix: ld_q, ld_k = halves per token.
+// Used by the prefill route's fused q|k|v GEMM (linear.LinearEXL3.forward_multi); same kernel as exl3_rope's fast path.
+extern "C" int exl3_rope_strided(void* q, void* k, const float* inv_freq, int bsz, int seq_len, int heads_q, int heads_k, int64_t ld_q, int64_t ld_k,
+                                 uint32_t position, const int32_t* positions, const int32_t* position_ids, float attn_factor, void* stream)
+{
+    EXL3_CHECK_ARG(q && inv_freq && (heads_k == 0 || k), "rope_strided: null pointer");
+    EXL3_CHECK_ARG(ld_q >= (int64_t) heads_q * 128 && ld_k >= (int64_t) heads_k * 128 && ld_q % 8 == 0 && ld_k % 8 == 0, "rope_strided: bad row strides");
+    if (bsz == 0 || seq_len == 0) return EXL3_OK;
+    rope_neox128_kernel<<<dim3(seq_len, bsz, 1), 256, 0, (hipStream_t) stream>>>((const half_t*) q, (half_t*) q, (const half_t*) k, (half_t*) k, inv_freq, seq_len,
+                                                                                 heads_q, heads_k, position, positions, position_ids, attn_factor, ld_q, ld_k);
+    return exl3_check_launch("rope_strided");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -314,8 +330,9 @@ __global__ __launch_bounds__(256)
 void kv_quant_paged_kernel(const half_t* __restrict__ k_in, uint32_t* __restrict__ k_out, half_t* __restrict__ k_scales,
                            const half_t* __restrict__ v_in, uint32_t* __restrict__ v_out, half_t* __restrict__ v_scales,
                            const int32_t* __restrict__ cache_seqlens, const int32_t* __restrict__ block_table,
-                           int blocks_per_seq, int page_size, int groups_per_token)
+                           int blocks_per_seq, int page_size, int groups_per_token, int64_t ld_k, int64_t ld_v)
 {
+    // ld_k / ld_v: halves between consecutive input tokens (groups_per_token * 32 when contiguous)
     const int batch = blockIdx.z;
     const int token_idx = blockIdx.y + cache_seqlens[batch];
     const int page_idx = token_idx / page_size;
@@ -325,10 +342,9 @@ void kv_quant_paged_kernel(const half_t* __restrict__ k_in, uint32_t* __restrict
     const bool active = g < groups_per_token;
     const int gs = active ? g : 0;
     const int64_t base = token_pos * groups_per_token + gs;
-    const int64_t in_base = in_pos * groups_per_token + gs;
     const int lane = threadIdx.x & 63;
-    kv_quant_group<KB>(k_in + in_base * 32, k_out + base * KB, k_scales + base, active, lane);
-    kv_quant_group<VB>(v_in + in_base * 32, v_out + base * VB, v_scales + base, active, lane);
+    kv_quant_group<KB>(k_in + in_pos * ld_k + gs * 32, k_out + base * KB, k_scales + base, active, lane);
+    kv_quant_group<VB>(v_in + in_pos * ld_v + gs * 32, v_out + base * VB, v_scales + base, active, lane);
 }
 
 // paged dequant of every cached token: grid (ceil(groups_per_token/32), max_tokens, bsz)
@@ -384,10 +400,10 @@ extern "C" int exl3_dequant_cache_cont(const void* in, const void* in_scales, vo
 
 template <int KB>
 static void launch_quant_paged(int vb, dim3 grid, hipStream_t st, const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
-                               const int32_t* sl, const int32_t* bt, int bps, int ps, int gpt)
+                               const int32_t* sl, const int32_t* bt, int bps, int ps, int gpt, int64_t ld_k, int64_t ld_v)
 {
     BITS_SWITCH(vb, (kv_quant_paged_kernel<KB, BB><<<grid, 256, 0, st>>>((const half_t*) k_in, (uint32_t*) k_out, (half_t*) k_scales, (const half_t*) v_in,
-                                                                         (uint32_t*) v_out, (half_t*) v_scales, sl, bt, bps, ps, gpt)));
+                                                                         (uint32_t*) v_out, (half_t*) v_scales, sl, bt, bps, ps, gpt, ld_k, ld_v)));
 }
 
 template <int KB>
@@ -398,21 +414,39 @@ static void launch_dequant_paged(int vb, dim3 grid, hipStream_t st, const void* 
                                                                            (const half_t*) v_scales, (half_t*) v_out, sl, bt, bps, ps, gpt)));
 }
 
-extern "C" int exl3_quant_cache_paged(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
-                                      const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
-                                      int page_size, int seq_len, int dim, int k_bits, int v_bits, void* stream)
+static int quant_cache_paged_impl(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                                  const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                                  int page_size, int seq_len, int dim, int k_bits, int v_bits, int64_t ld_k, int64_t ld_v, void* stream)
 {
     EXL3_CHECK_ARG(k_in && k_out && k_scales && v_in && v_out && v_scales && cache_seqlens && block_table, "quant_cache_paged: null pointer");
     EXL3_CHECK_ARG(dim % 32 == 0 && page_size > 0, "quant_cache_paged: dim must be divisible by 32");
     EXL3_CHECK_ARG(k_bits >= 2 && k_bits <= 8 && v_bits >= 2 && v_bits <= 8, "quant_cache_paged: bits must be in [2, 8]");
+    EXL3_CHECK_ARG(ld_k >= dim && ld_v >= dim && ld_k % 4 == 0 && ld_v % 4 == 0, "quant_cache_paged: bad token strides");
     if (bsz == 0 || seq_len == 0) return EXL3_OK;
     const int gpt = dim / 32;
     dim3 grid((gpt + 31) / 32, seq_len, bsz);
     hipStream_t st = (hipStream_t) stream;
-    #define QP(KBv) case KBv: launch_quant_paged<KBv>(v_bits, grid, st, k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, blocks_per_seq, page_size, gpt); break;
+    #define QP(KBv) case KBv: launch_quant_paged<KBv>(v_bits, grid, st, k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, blocks_per_seq, page_size, gpt, ld_k, ld_v); break;
     switch (k_bits) { QP(2) QP(3) QP(4) QP(5) QP(6) QP(7) QP(8) }
     #undef QP
     return exl3_check_launch("quant_cache_paged");
+}
+
+extern "C" int exl3_quant_cache_paged(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                                      const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                                      int page_size, int seq_len, int dim, int k_bits, int v_bits, void* stream)
+{
+    return quant_cache_paged_impl(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, bsz, blocks_per_seq, page_size, seq_len, dim,
+                                  k_bits, v_bits, dim, dim, stream);
+}
+
+// k_in / v_in are column ranges of a wider row-major matrix: ld_k, ld_v = halves per token (the prefill route's fused q|k|v GEMM output)
+extern "C" int exl3_quant_cache_paged_strided(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                                              const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                                              int page_size, int seq_len, int dim, int k_bits, int v_bits, int64_t ld_k, int64_t ld_v, void* stream)
+{
+    return quant_cache_paged_impl(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, bsz, blocks_per_seq, page_size, seq_len, dim,
+                                  k_bits, v_bits, ld_k, ld_v, stream);
 }
 
 extern "C" int exl3_dequant_cache_paged(const void* k_in, const void* k_scales, void* k_out, const void* v_in, const void* v_scales, void* v_out,

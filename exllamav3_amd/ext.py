@@ -296,10 +296,15 @@ def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: boo
     _req(a.dtype == torch.half and bt.dtype == torch.half and c.dtype in (torch.half, torch.float), "hgemm_nt: bad dtypes")
     _req(a.dim() == 2 and bt.dim() == 2 and c.dim() == 2, "hgemm_nt: tensors must be 2-D")
     _req(a.shape[1] == bt.shape[1] and a.shape[0] == c.shape[0] and bt.shape[0] == c.shape[1], "hgemm_nt: shape mismatch")
-    _req(a.is_contiguous() and bt.stride(1) == 1 and c.stride(1) == 1, "hgemm_nt: a contiguous; bt, c unit column stride")
+    _req(a.stride(1) == 1 and bt.stride(1) == 1 and c.stride(1) == 1, "hgemm_nt: a, bt, c need unit column stride")
     _req(not accumulate or c.dtype == torch.half, "hgemm_nt: accumulate needs a float16 c")
-    _check(_lib.lib().exl3_hgemm_nt(_p(a), _p(bt), _p(c), a.shape[0], a.shape[1], bt.shape[0], bt.stride(0), c.stride(0),
-                                    int(c.dtype == torch.float), int(accumulate), _stream(a)))
+    if a.is_contiguous():
+        _check(_lib.lib().exl3_hgemm_nt(_p(a), _p(bt), _p(c), a.shape[0], a.shape[1], bt.shape[0], bt.stride(0), c.stride(0),
+                                        int(c.dtype == torch.float), int(accumulate), _stream(a)))
+    else:
+        # a is a column range of a wider row-major matrix
+        _check(_lib.lib().exl3_hgemm_nt_lda(_p(a), a.stride(0), _p(bt), _p(c), a.shape[0], a.shape[1], bt.shape[0], bt.stride(0), c.stride(0),
+                                            int(c.dtype == torch.float), int(accumulate), _stream(a)))
 
 
 def reconstruct_had_slice_t(unpacked_t: torch.Tensor, packed: torch.Tensor, suh: torch.Tensor, svh: torch.Tensor,
@@ -442,6 +447,36 @@ def quant_cache_paged(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlen
     _check(_lib.lib().exl3_quant_cache_paged(_p(k_in), _p(k_out), _p(k_scales), _p(v_in), _p(v_out), _p(v_scales),
                                              _p(cache_seqlens), _p(block_table), bsz, block_table.shape[1], page_size, seq_len, dim,
                                              _kv_bits(k_out, k_scales), _kv_bits(v_out, v_scales), _stream(k_in)))
+
+
+def quant_cache_paged_strided(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, page_size: int, seq_len: int):
+    """quant_cache_paged on k_in / v_in that are column ranges (bsz * seq_len, dim) of a wider row-major fp16 matrix (unit column stride):
+    the fused q|k|v prefill GEMM output, consumed without a split copy."""
+    _dev(k_in)
+    _req(page_size == 256, "quant_cache_paged: page size must be 256")
+    _req(k_in.dim() == 2 and v_in.dim() == 2 and k_in.stride(1) == 1 and v_in.stride(1) == 1 and k_in.dtype == torch.half and v_in.dtype == torch.half,
+         "quant_cache_paged_strided: k_in / v_in must be 2-D fp16 views with unit column stride")
+    dim = k_out.shape[-1] // _kv_bits(k_out, k_scales) * 32
+    _req(k_in.shape[1] == dim and v_in.shape[1] == dim, "quant_cache_paged_strided: width must match the cache")
+    bsz = block_table.shape[0]
+    _req(k_in.shape[0] == bsz * seq_len and v_in.shape[0] == bsz * seq_len, "quant_cache_paged_strided: rows must be bsz * seq_len")
+    _check(_lib.lib().exl3_quant_cache_paged_strided(_p(k_in), _p(k_out), _p(k_scales), _p(v_in), _p(v_out), _p(v_scales),
+                                                     _p(cache_seqlens), _p(block_table), bsz, block_table.shape[1], page_size, seq_len, dim,
+                                                     _kv_bits(k_out, k_scales), _kv_bits(v_out, v_scales), k_in.stride(0), v_in.stride(0), _stream(k_in)))
+
+
+def rope_strided(q, k, inv_freq, position: int, positions, position_ids, attn_factor: float, bsz: int, seq_len: int):
+    """In-place NEOX rope (head_dim 128, no head norm) on q (bsz * seq_len, heads_q * 128) and k (.., heads_k * 128), column ranges of a wider
+    row-major fp16 matrix; rope.cu semantics otherwise."""
+    _dev(q)
+    _req(q.dim() == 2 and q.dtype == torch.half and q.stride(1) == 1 and q.shape[0] == bsz * seq_len and q.shape[1] % 128 == 0, "rope_strided: bad q")
+    hk, ldk = 0, 0
+    if k is not None:
+        _req(k.dim() == 2 and k.dtype == torch.half and k.stride(1) == 1 and k.shape[0] == bsz * seq_len and k.shape[1] % 128 == 0, "rope_strided: bad k")
+        hk, ldk = k.shape[1] // 128, k.stride(0)
+    _req(inv_freq.numel() == 64 and inv_freq.dtype == torch.float, "rope_strided: inv_freq must be 64 floats")
+    _check(_lib.lib().exl3_rope_strided(_p(q), _p(k), _p(inv_freq), bsz, seq_len, q.shape[1] // 128, hk, q.stride(0), ldk, int(position),
+                                        _p(positions), _p(position_ids), float(attn_factor), _stream(q)))
 
 
 def dequant_cache_paged(k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens, block_table, page_size: int,

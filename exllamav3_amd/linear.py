@@ -102,7 +102,8 @@ class LinearEXL3:
             y = self.forward(x, out_dtype=torch.float)
             ext.add(resid, y.view(resid.shape))
             return
-        ext.hgemm_nt(x.view(rows, self.in_features), self._reconstructed_w(), resid.view(rows, self.out_features), accumulate=True)
+        x2 = x if (x.dim() == 2 and x.stride(1) == 1) else x.view(rows, self.in_features)     # a strided 2-D column range is taken as it is
+        ext.hgemm_nt(x2, self._reconstructed_w(), resid.view(rows, self.out_features), accumulate=True)
         self._release_w()
 
     @staticmethod
@@ -127,6 +128,34 @@ class LinearEXL3:
         ext.hgemm_nt(x.view(rows, k), wt, y)
         ext.silu_mul_2d(y[:, :n], y[:, n:], a.view(rows, n))
         return a
+
+    @staticmethod
+    def forward_multi(lins: list["LinearEXL3"], x: torch.Tensor) -> list[torch.Tensor] | None:
+        """[lin(x) for lin in lins] for the prefill route with ONE GEMM: the W^T of all matrices are reconstructed into one (sum n, k) buffer
+        and hgemm_nt writes one (rows, sum n) output; the results are its column ranges (row stride sum n: consumers take strided views --
+        ext.rope_strided, ext.quant_cache_paged_strided, hgemm_nt's A operand).  q|k|v of Llama-3.1-8B: 96 + 38 + 38 us -> one GEMM at the wide
+        shape's efficiency (k / v alone run at 0.9 PFLOP/s).  Returns None when the route does not apply (caller falls back to separate forwards)."""
+        rows = x.numel() // x.shape[-1]
+        k = lins[0].in_features
+        ok = (all(l.in_features == k and l.out_features % 128 == 0 and l.bias is None for l in lins) and k % 128 == 0
+              and rows >= FUSED_RECONSTRUCT_MIN_ROWS and sum(l.out_features for l in lins) <= MAX_RECONSTRUCT_SLICE_N
+              and LinearEXL3.ahead is None and not LinearEXL3.cache_reconstructed)
+        if not ok:
+            return None
+        dev = x.device
+        ntot = sum(l.out_features for l in lins)
+        wt = torch.empty((ntot, k), dtype=torch.half, device=dev)
+        n0 = 0
+        for l in lins:
+            ext.reconstruct_had_slice_t(wt[n0: n0 + l.out_features], l.trellis, l.suh, l.svh, l.K, l.mcg, l.mul1, 0)
+            n0 += l.out_features
+        y = torch.empty((rows, ntot), dtype=torch.half, device=dev)
+        ext.hgemm_nt(x.view(rows, k), wt, y)
+        outs, n0 = [], 0
+        for l in lins:
+            outs.append(y[:, n0: n0 + l.out_features])
+            n0 += l.out_features
+        return outs
 
     #: MI355X option (not in the reference): keep the reconstructed original-basis fp16 W of every Linear resident after its first
     #: prefill use -- 16 GB for an 8B model, 141 GB for 70B, both fit the 288 GB of one MI355X next to the packed weights -- so later

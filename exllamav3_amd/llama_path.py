@@ -599,17 +599,26 @@ class SyntheticEXL3Llama:
             ahead.begin()
         for L in self.layers:
             ext.rms_norm(x, L["norm1"], xn, self.eps)
-            q = L["q"].forward(xn).view(1, tokens, self.hq, hd)
-            k = L["k"].forward(xn).view(1, tokens, self.hkv, hd)
-            v = L["v"].forward(xn).view(1, tokens, self.hkv, hd)
-            ext.rope(q, q, k, k, self.inv_freq, 0, None, None, 2, 1.0)
-            ext.quant_cache_paged(k.view(1, tokens, -1), self.pf_cache[0], self.pf_cache[2], v.view(1, tokens, -1), self.pf_cache[1],
-                                  self.pf_cache[3], self.pf_sl, self.pf_bt, self.page, tokens)
+            qkv = type(L["q"]).forward_multi([L["q"], L["k"], L["v"]], xn) if hd == 128 else None
+            if qkv is not None:
+                # one GEMM for q|k|v; rope and the KV-cache append read its column ranges in place
+                q, k, v = qkv
+                ext.rope_strided(q, k, self.inv_freq, 0, None, None, 1.0, 1, tokens)
+                ext.quant_cache_paged_strided(k, self.pf_cache[0], self.pf_cache[2], v, self.pf_cache[1], self.pf_cache[3], self.pf_sl, self.pf_bt,
+                                              self.page, tokens)
+            else:
+                q = L["q"].forward(xn).view(1, tokens, self.hq, hd)
+                k = L["k"].forward(xn).view(1, tokens, self.hkv, hd)
+                v = L["v"].forward(xn).view(1, tokens, self.hkv, hd)
+                ext.rope(q, q, k, k, self.inv_freq, 0, None, None, 2, 1.0)
+                ext.quant_cache_paged(k.view(1, tokens, -1), self.pf_cache[0], self.pf_cache[2], v.view(1, tokens, -1), self.pf_cache[1],
+                                      self.pf_cache[3], self.pf_sl, self.pf_bt, self.page, tokens)
+                q = q.view(tokens, -1)
             if self.tp == 1:
-                L["o"].forward_add_residual(q.view(tokens, -1), x)          # residual add in the GEMM epilogue
+                L["o"].forward_add_residual(q, x)                           # residual add in the GEMM epilogue (q: attention output stand-in)
                 ext.rms_norm(x, L["norm2"], xn, self.eps)
             else:
-                o = L["o"].forward(q.view(tokens, -1))
+                o = L["o"].forward(q.contiguous().view(tokens, -1))
                 be.all_reduce(o)
                 ext.rms_norm_res_in(o, L["norm2"], xn, x, self.eps)
             a = type(L["gate"]).forward_gate_up_silu(L["gate"], L["up"], xn)      # one GEMM for gate|up when the rows allow it

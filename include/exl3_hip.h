@@ -221,6 +221,8 @@ int exl3_hgemm_acc(const void* a, const void* b, void* c, int m, int k, int n, i
 /* c[m][n] = a[m][k] @ bt[n][k]^T: bt is B^T row-major with row stride ldb >= k (both operands K-major, the layout the library's MFMA kernels
  * run 15-28 % faster on MI355X); accumulate != 0: c (fp16) += product. */
 int exl3_hgemm_nt(const void* a, const void* bt, void* c, int m, int k, int n, int64_t ldb, int64_t ldc, int c_fp32, int accumulate, void* stream);
+/* the same with a row stride for a (lda >= k): a is a column range of a wider row-major matrix */
+int exl3_hgemm_nt_lda(const void* a, int64_t lda, const void* bt, void* c, int m, int k, int n, int64_t ldb, int64_t ldc, int c_fp32, int accumulate, void* stream);
 
 /* ---- RMSNorm     norm.cuh:7-39, norm.cu:155-299 --------------------------------------------------- */
 /* mode 0: y = norm(x)*w ; 1: y += norm(x)*w (add_residual) ; 2: r += x; y = norm(r)*w (rms_norm_res_in).
@@ -249,6 +251,14 @@ int exl3_dequant_cache_cont(const void* in, const void* in_scales, void* out, in
 int exl3_quant_cache_paged(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
                            const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
                            int page_size, int seq_len, int dim, int k_bits, int v_bits, void* stream);
+/* the same append with k_in / v_in as column ranges of a wider row-major matrix (ld_k, ld_v = halves per token): consumes the prefill
+ * route's fused q|k|v GEMM output without a split copy */
+int exl3_quant_cache_paged_strided(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                                   const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                                   int page_size, int seq_len, int dim, int k_bits, int v_bits, int64_t ld_k, int64_t ld_v, void* stream);
+/* in-place NEOX rope, head_dim 128, no head norm, on q / k column ranges of a wider matrix (rope.cu semantics otherwise) */
+int exl3_rope_strided(void* q, void* k, const float* inv_freq, int bsz, int seq_len, int heads_q, int heads_k, int64_t ld_q, int64_t ld_k,
+                      uint32_t position, const int32_t* positions, const int32_t* position_ids, float attn_factor, void* stream);
 /* dequant_cache_paged: expand every page referenced by block_table up to cache_seqlens[b] (+ nothing beyond) into fp16 pages
  * k_out/v_out fp16 [pages][page_size][dim]. */
 int exl3_dequant_cache_paged(const void* k_in, const void* k_scales, void* k_out, const void* v_in, const void* v_scales, void* v_out,

@@ -211,3 +211,46 @@ def test_loaded_checkpoint_linear_runs_on_gpu(dev, tmp_path):
     y = lin.forward(_t(x, dev)).float().cpu().numpy()
     ref = o.linear_forward(x, tr, suh, svh, K, 1).astype(np.float32)
     assert np.abs(y - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
+
+
+def test_fused_qkv_route_strided_consumers(dev):
+    """LinearEXL3.forward_multi (one GEMM for q|k|v) and its strided consumers against the separate-forward route: column ranges equal the
+    separate GEMMs up to fp32 summation order, rope_strided == rope and quant_cache_paged_strided == quant_cache_paged bit for bit on the
+    same values, hgemm_nt with a strided A operand == the contiguous call."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.linear import LinearEXL3
+    tokens, h, hq, hkv, hd = 300, 512, 4, 2, 128
+    rng = np.random.default_rng(3)
+    lins = []
+    for n, K, cb in ((hq * hd, 4, 2), (hkv * hd, 3, 0), (hkv * hd, 5, 2)):               # per-matrix bitrates / codebooks are free on this route
+        tr, suh, svh = o.synth_linear(h, n, K, seed=n + K, realistic=True)
+        lins.append(LinearEXL3(h, n, _t(tr, dev), _t(suh, dev), _t(svh, dev), mcg=(cb == 1), mul1=(cb == 2)))
+    x = _t(rng.standard_normal((tokens, h)).astype(np.float16), dev)
+    outs = LinearEXL3.forward_multi(lins, x)
+    assert outs is not None and [tuple(t.shape) for t in outs] == [(tokens, 512), (tokens, 256), (tokens, 256)] and outs[0].stride(0) == 1024
+    sep = [l.forward(x) for l in lins]
+    for a, b in zip(outs, sep):
+        assert float((a.float() - b.float()).abs().max()) < 2e-2 * float(b.float().abs().max()) + 1e-3
+    assert LinearEXL3.forward_multi(lins, x[:100]) is None                              # below the reconstruct threshold: caller falls back
+    # rope in place on the column ranges == rope on contiguous copies
+    inv = (1.0 / (500000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(dev)
+    qc, kc = outs[0].contiguous().view(1, tokens, hq, hd), outs[1].contiguous().view(1, tokens, hkv, hd)
+    ext.rope(qc, qc, kc, kc, inv, 5, None, None, 2, 1.0)
+    ext.rope_strided(outs[0], outs[1], inv, 5, None, None, 1.0, 1, tokens)
+    assert torch.equal(outs[0], qc.view(tokens, -1)) and torch.equal(outs[1], kc.view(tokens, -1))
+    # paged KV append from the column ranges == from contiguous copies
+    G, pages, bits = hkv * hd // 32, 2, 4
+    bt = torch.arange(pages, dtype=torch.int32, device=dev).view(1, pages); sl = torch.zeros((1,), dtype=torch.int32, device=dev)
+    mk = lambda: [torch.zeros((pages, 256, G * bits), dtype=torch.int32, device=dev) for _ in range(2)] + [torch.zeros((pages, 256, G), dtype=torch.half, device=dev) for _ in range(2)]
+    c0, c1 = mk(), mk()
+    ext.quant_cache_paged(outs[1].contiguous().view(1, tokens, -1), c0[0], c0[2], outs[2].contiguous().view(1, tokens, -1), c0[1], c0[3], sl, bt, 256, tokens)
+    ext.quant_cache_paged_strided(outs[1], c1[0], c1[2], outs[2], c1[1], c1[3], sl, bt, 256, tokens)
+    for a, b in zip(c0, c1):
+        assert torch.equal(a, b)
+    # o_proj from the strided q columns
+    tr, suh, svh = o.synth_linear(hq * hd, h, 4, seed=9, realistic=True)
+    lo = LinearEXL3(hq * hd, h, _t(tr, dev), _t(suh, dev), _t(svh, dev), mul1=True)
+    r0 = _t(rng.standard_normal((tokens, h)).astype(np.float16), dev); r1 = r0.clone()
+    lo.forward_add_residual(outs[0], r0)
+    lo.forward_add_residual(outs[0].contiguous(), r1)
+    assert float((r0.float() - r1.float()).abs().max()) < 2e-2 * float(r1.float().abs().max())
