@@ -27,11 +27,62 @@ class SyntheticEXL3MoE:
         self.up = [_rand_linear(hidden, inter, K, cb, self.device, gen) for _ in range(experts)]
         self.down = [_rand_linear(inter, hidden, K, cb, self.device, gen, out_dtype=torch.float) for _ in range(experts)]
         self.router = (torch.randn((hidden, experts), device=self.device, generator=gen) / math.sqrt(hidden)).half()
+        self.first, self.last = 0, experts
+        self._build_tables()
+
+    def _build_tables(self):
+        """Device pointer tables of the LOCAL experts [first, last) (all of them without expert parallelism)."""
         ptr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.long, device=self.device)
         gu = self.gate + self.up
         self.gu_B, self.gu_suh, self.gu_svh = ptr([l.trellis for l in gu]), ptr([l.suh for l in gu]), ptr([l.svh for l in gu])
+        self.g_B, self.g_suh, self.g_svh = ptr([l.trellis for l in self.gate]), ptr([l.suh for l in self.gate]), ptr([l.svh for l in self.gate])
+        self.u_B, self.u_suh, self.u_svh = ptr([l.trellis for l in self.up]), ptr([l.suh for l in self.up]), ptr([l.svh for l in self.up])
         self.d_B, self.d_suh, self.d_svh = ptr([l.trellis for l in self.down]), ptr([l.suh for l in self.down]), ptr([l.svh for l in self.down])
         self._state = None
+
+    # ---- checkpoints + expert parallelism (SURVEY.md 8e: each rank holds experts [first, last), the kernel filters the routed indices to
+    #      that range -- modules/block_sparse_mlp.py:1556-1590, quant/exl3_gemm_kernel.cuh:99-127 -- and the partial sums are all-reduced)
+    def save_checkpoint(self, directory: str, prefix: str = "model.layers.0.block_sparse_moe") -> None:
+        """Mixtral tensor names: prefix.gate.weight (router, (experts, hidden)), prefix.experts.{e}.w1 / w3 / w2 = gate / up / down."""
+        import os
+        from safetensors.torch import save_file
+        assert (self.first, self.last) == (0, self.E), "save the whole block"
+        os.makedirs(directory, exist_ok=True)
+        t = {prefix + ".gate.weight": self.router.t().contiguous().cpu()}
+        for e in range(self.E):
+            for nm, lin in (("w1", self.gate[e]), ("w3", self.up[e]), ("w2", self.down[e])):
+                key = f"{prefix}.experts.{e}.{nm}"
+                t[key + ".trellis"] = lin.trellis.cpu(); t[key + ".suh"] = lin.suh.cpu(); t[key + ".svh"] = lin.svh.cpu()
+                if lin.mul1: t[key + ".mul1"] = torch.zeros(1, dtype=torch.int32)
+                if lin.mcg: t[key + ".mcg"] = torch.zeros(1, dtype=torch.int32)
+        save_file(t, os.path.join(directory, "moe.safetensors"))
+
+    @classmethod
+    def from_checkpoint(cls, directory: str, top_k: int, prefix: str = "model.layers.0.block_sparse_moe", device="cuda:0",
+                        first_expert: int = 0, last_expert: int | None = None) -> "SyntheticEXL3MoE":
+        """One sparse-MoE block from an EXL3 checkpoint directory.  first_expert / last_expert: this rank's expert range (expert
+        parallelism): only those experts' tensors are read; forward() then returns the PARTIAL sum over the local experts among the routed
+        ones (all-reduce it across ranks; the router is replicated)."""
+        from . import loader
+        stc = loader.SafetensorsCollection(directory)
+        self = cls.__new__(cls)
+        self.device = torch.device(device)
+        self.router = stc.get_tensor(prefix + ".gate.weight", self.device).half().t().contiguous()          # (hidden, experts)
+        self.hidden, self.E = self.router.shape
+        self.top_k = top_k
+        self.first, self.last = first_expert, self.E if last_expert is None else last_expert
+        assert 0 <= self.first < self.last <= self.E
+        load = lambda e, nm, dt=None: loader.load_linear_exl3(stc, f"{prefix}.experts.{e}.{nm}", self.device, dt)
+        self.gate = [load(e, "w1") for e in range(self.first, self.last)]
+        self.up = [load(e, "w3") for e in range(self.first, self.last)]
+        self.down = [load(e, "w2", torch.float) for e in range(self.first, self.last)]
+        kinds = {(l.K, l.mcg, l.mul1) for l in self.gate + self.up + self.down}
+        if len(kinds) != 1:
+            raise NotImplementedError(f"{prefix}: experts mix bits-per-weight / codebooks {sorted(kinds)}; one indexed launch needs one kind")
+        l0 = self.gate[0]
+        self.inter, self.K, self.cb = l0.out_features, l0.K, (2 if l0.mul1 else (1 if l0.mcg else 0))
+        self._build_tables()
+        return self
 
     def alloc_state(self, tokens: int = 1):
         dev, f16 = self.device, torch.half
@@ -52,6 +103,8 @@ class SyntheticEXL3MoE:
             self.alloc_state(t)
         ext.routing_std(x, self.router, self.scores, self.sel, self.w)
         mcg, mul1 = self.cb == 1, self.cb == 2
+        if (self.first, self.last) != (0, self.E):
+            return self._forward_expert_parallel(x)
         if t == 1:
             # one shared input row: gate and up of the k selected experts in one launch (slots = 2k)
             torch.stack((self.sel.view(-1), self.sel.view(-1) + self.E), out=self.sel2)
@@ -68,6 +121,23 @@ class SyntheticEXL3MoE:
         ext.exl3_mgemm(self.a, self.d_B, self.d, self.d_suh, None, self.d_svh, self.sel.view(-1), self.w.view(-1), self.K, -1, mcg, mul1,
                        -1, -1, 0, num_tokens=t)
         return self.d[:t, 0]
+
+    def _forward_expert_parallel(self, x: torch.Tensor) -> torch.Tensor:
+        """Local experts [first, last) only: the launches filter the routed indices to the range (in-range slots are compacted to the front,
+        the same order in the gate, up and down launches), C is zero-filled because filtered slots are never written, and the weighted down
+        launch sums the slots.  One token per set of launches (the range filter works on one token's slots, as in the reference)."""
+        t, k = x.shape[0], self.top_k
+        mcg, mul1 = self.cb == 1, self.cb == 2
+        self.d.zero_()
+        for i in range(t):
+            xi = x[i].view(1, 1, -1)
+            sel, w = self.sel[i].contiguous(), self.w[i].contiguous()
+            g, u, a, d = self.gu[i * k: (i + 1) * k], self.gu[(t + i) * k: (t + i + 1) * k], self.a[i * k: (i + 1) * k], self.d[i * k: (i + 1) * k]
+            ext.exl3_mgemm(xi, self.g_B, g, self.g_suh, None, self.g_svh, sel, None, self.K, -1, mcg, mul1, self.first, self.last, 0)
+            ext.exl3_mgemm(xi, self.u_B, u, self.u_suh, None, self.u_svh, sel, None, self.K, -1, mcg, mul1, self.first, self.last, 0)
+            ext.silu_mul(g, u, a)
+            ext.exl3_mgemm(a, self.d_B, d, self.d_suh, None, self.d_svh, sel, w, self.K, -1, mcg, mul1, self.first, self.last, 0)
+        return self.d.view(t, k, 1, self.hidden)[:, 0, 0]
 
     def packed_bytes_per_token(self) -> int:
         """Algorithmic weight bytes one token touches: top_k experts x (gate + up + down)."""

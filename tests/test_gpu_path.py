@@ -522,3 +522,31 @@ def test_checkpoint_round_trip_reproduces_logits(dev, tmp_path):
         assert np.abs(lf - lu).max() / np.sqrt((lu ** 2).mean()) < 1e-2
     mixed.prefill_chunk(160)                                                  # the prefill route reconstructs every matrix with its own K
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("tokens", [1, 3])
+def test_moe_expert_parallel_partials_sum_to_the_whole_block(dev, tokens, tmp_path):
+    """Expert parallelism (BASELINE config 5, TP = 2): two blocks loaded from the same checkpoint with expert ranges [0, 3) and [3, 6) return
+    partial sums over their local experts (range-filtered indexed launches, quant/exl3_gemm_kernel.cuh:99-127); their sum -- what the
+    all-reduce produces -- equals the whole block's output, and the whole block loaded from files equals the original bit for bit."""
+    from exllamav3_amd.moe_path import SyntheticEXL3MoE
+    moe = SyntheticEXL3MoE(256, 384, experts=6, top_k=2, K=4, cb=2, device=dev, seed=11)
+    moe.save_checkpoint(str(tmp_path))
+    x = torch.randn((tokens, 256), device=dev, generator=torch.Generator(device=dev).manual_seed(tokens)).half()
+    y = moe.forward(x).float().clone()
+    whole = SyntheticEXL3MoE.from_checkpoint(str(tmp_path), top_k=2, device=dev)
+    assert (whole.hidden, whole.inter, whole.E, whole.K, whole.cb) == (256, 384, 6, 4, 2)
+    assert torch.equal(whole.forward(x).float(), y)
+    parts = []
+    for first, last in ((0, 3), (3, 6)):
+        part = SyntheticEXL3MoE.from_checkpoint(str(tmp_path), top_k=2, device=dev, first_expert=first, last_expert=last)
+        assert len(part.gate) == 3
+        parts.append(part.forward(x).float().clone())
+        assert torch.equal(part.sel, moe.sel)                                   # the router is replicated
+    s = parts[0] + parts[1]
+    assert float((s - y).abs().max()) < 2e-3 * float(y.abs().max()) + 1e-4
+    # every token has at least one rank with work; a rank whose range holds none of a token's experts returns zeros for it
+    for i in range(tokens):
+        local0 = int(((moe.sel[i] >= 0) & (moe.sel[i] < 3)).sum())
+        if local0 == 0:
+            assert float(parts[0][i].abs().max()) == 0.0
