@@ -136,6 +136,13 @@ def test_fused_decode_pipeline_matches_unfused_and_oracle(dev, cb, bsz):
             model.decode_step_fused()
     model.logits.zero_(); g.replay(); torch.cuda.synchronize()
     assert np.array_equal(model.logits.float().cpu().numpy(), lf)
+    # the bench's roofline leg launches every GEMV of the step on its own (bench.py): they must run with the rank's shapes too
+    calls = model.gemv_calls("glue")
+    assert len(calls) == 4 * model.n_layers + 1
+    for c in calls:
+        c()
+    torch.cuda.synchronize()
+    assert sum(cnt for (_, _, cnt) in model.gemv_launches_per_step()) == len(calls)
 
 
 def test_fused_gptj_rope_and_gemv_ex_modes(dev):
@@ -550,3 +557,39 @@ def test_moe_expert_parallel_partials_sum_to_the_whole_block(dev, tokens, tmp_pa
         local0 = int(((moe.sel[i] >= 0) & (moe.sel[i] < 3)).sum())
         if local0 == 0:
             assert float(parts[0][i].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("model_name,tp", [("llama-3.1-8b", 2), ("llama-3.1-8b", 4), ("llama-3.1-8b", 8), ("llama-3.1-70b", 8)])
+@pytest.mark.parametrize("bsz", [1, 16])
+def test_tp_rank_code_path_on_one_gpu(dev, model_name, tp, bsz):
+    """The tensor-parallel branches of the pipelines (non-deferred o / down with fp32 partial outputs, all-reduce hook, glue_resid on the dense
+    tensor, sharded lm_head) with the real per-rank shapes of the multi-GPU bench, run as rank 0 of a world of `tp` on ONE GPU: the backend's
+    all-reduce is replaced by a no-op (the collective itself is covered by test_tp_gloo.py), so fused and op-by-op pipelines both work on
+    this rank's partial sums and must agree; one layer, finite logits of the rank's vocabulary shard."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
+
+    class OneRankOfMany:
+        def __init__(self, world): self.rank, self.world_size, self.calls = 0, world, 0
+        def all_reduce(self, tensor, contribution=True): self.calls += 1
+        def fwd_barrier(self): pass
+
+    be = OneRankOfMany(tp)
+    model = SyntheticEXL3Llama(SHAPES[model_name], K=4, cb=2, device=dev, backend=be, kv_bits=4, max_ctx=1024, layers=1)
+    s = SHAPES[model_name]
+    assert (model.hq, model.hkv) == (s.heads_q // tp, s.heads_kv // tp) and model.layers[0]["down"].in_features == model.inter_local
+    model.alloc_state(bsz, pos=300)
+    lu = model.decode_step().float().cpu().numpy().copy()
+    n_unfused = be.calls
+    lf = model.decode_step_fused().float().cpu().numpy()
+    assert be.calls == 2 * n_unfused and n_unfused == 2                       # o and down of the one layer, in both pipelines
+    assert lf.shape == (bsz, model.vocab_local) and np.isfinite(lf).all()
+    assert np.abs(lf - lu).max() / np.sqrt((lu ** 2).mean()) < 1e-2
+    # graph capture of the rank's step (the bench replays it)
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            model.decode_step_fused()
+        g.replay(); st.synchronize()
+    assert np.array_equal(model.logits.float().cpu().numpy(), lf)
