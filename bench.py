@@ -142,10 +142,13 @@ def main():
     if args.gpus > 1 and world == 1:
         print("bench.py: --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr)
         sys.exit(2)
-    dev = torch.device(f"cuda:{local_rank}")
+    # one rank per GPU; EXL3_HIP_TP_BACKEND=gloo (test hook) lets several ranks share a device so that the multi-rank control flow of this
+    # script can be exercised on a single-GPU box (RCCL refuses two ranks on one device)
+    tp_backend = os.environ.get("EXL3_HIP_TP_BACKEND") or None
+    dev = torch.device(f"cuda:{local_rank % torch.cuda.device_count() if tp_backend == 'gloo' else local_rank}")
     torch.cuda.set_device(dev)
-    backend = TPBackendRCCL(rank, world, dev)
-    ext.init(local_rank)
+    backend = TPBackendRCCL(rank, world, dev, backend=tp_backend)
+    ext.init(dev.index)
     ext.set_gemv_variant(args.variant)
     ext.set_gemv_gen(args.gen)
 

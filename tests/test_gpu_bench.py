@@ -1,0 +1,42 @@
+"""bench.py's contract on the GPU box: one JSON line with the required keys, single process and as two torch.distributed ranks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+        "config", "roofline", "cpu_baseline"}
+
+
+def _line(out: str) -> dict:
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_process_line(dev):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--layers", "2", "--steps", "3", "--warmup", "1", "--no-prefill", "--no-cpu"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "workload" in d["config"]
+
+
+def test_bench_two_ranks_control_flow(dev):
+    """`--gpus 2` as launched by the driver (torch.distributed.run, one rank per process).  This box has one GPU, so the test hook
+    EXL3_HIP_TP_BACKEND=gloo lets both ranks share it (RCCL refuses that) -- the collectives are gloo's, everything else is the
+    multi-rank path of bench.py: per-rank shards, barriers, max-over-ranks timing, rank 0 printing the one line."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, EXL3_HIP_TP_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "2", "--warmup", "1",
+                        "--no-graph"], capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _line(r.stdout)
+    assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "tp2" and d["cpu_baseline"] is None
