@@ -315,6 +315,10 @@ class SyntheticEXL3Llama:
     #: include the decode attention over the quantized cache in decode_step_fused (bench.py --attention)
     with_attention = False
 
+    #: lm_head at m <= 4: glue_rotate + pre-rotated GEMV instead of the in-GEMV RMSNorm (the 1002-column-block launch repeats the 32 input
+    #: Hadamards in every workgroup in NORM mode)
+    rotate_for_head = os.environ.get("EXL3_HIP_ROTATE_FOR_HEAD", "1") != "0"       # measured +0.5 % at bs 1 (508.1 -> 510.5 tok/s)
+
     #: m <= 4: finish silu(g) * u inside the down GEMV instead of a glue_act launch
     act_in_gemv = os.environ.get("EXL3_HIP_ACT_IN_GEMV", "1") != "0"
 
@@ -406,7 +410,7 @@ class SyntheticEXL3Llama:
                 ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.d], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT, c_fp32=True)
                 be.all_reduce(self.d)
                 ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=self.d)
-        if rot:
+        if rot or self.rotate_for_head:
             ext.glue_rotate(x, ss, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz)
             ext.exl3_gemv_ex(None, self.xh3[:1], None, [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
                              bsz, self.lm_head.mcg, self.lm_head.mul1, ROT)
