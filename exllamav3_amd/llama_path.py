@@ -339,7 +339,7 @@ class SyntheticEXL3Llama:
         q2 = self.q.view(bsz, -1)
         ss = self.ss
         # batches above 4 rows: the norm + input Hadamards run once in glue_rotate instead of in every column-block workgroup
-        rot = bsz > 4
+        rot = bsz > int(os.environ.get("EXL3_HIP_ROTATE_ABOVE", "4"))
         ext.glue_resid(None, 0, None, None, x, ss, bsz)
         for li, L in enumerate(self.layers):
             lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
