@@ -176,7 +176,9 @@ def main():
                 run_step()
                 st.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph, stream=st):
+                # multi-rank: the process group's watchdog thread issues event queries of its own; thread-local capture mode keeps those from
+                # invalidating this thread's capture
+                with torch.cuda.graph(graph, stream=st, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
                     run_step()
             torch.cuda.synchronize()
         except Exception as e:          # e.g. a collective that cannot be captured: fall back to eager launches
