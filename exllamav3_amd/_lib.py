@@ -111,6 +111,8 @@ def _declare(l):
     sig("exl3_glue_qkv", vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp)
     sig("exl3_glue_act", vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp)
     sig("exl3_gemv_norm", vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, i32, vp, vp)
+    sig("exl3_gemv_resid", vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp)
+    sig("exl3_set_tail_xcd_local", i32)
     sig("exl3_gemv_act", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp)
     sig("exl3_gemv_qkv", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_rope_table", vp, vp, f32, i32, vp, vp, vp)

@@ -472,6 +472,8 @@ static int gemv_gen()
 extern "C" int exl3_set_gemv_gen(int v) { g_gemv_gen = (v == 1) ? 1 : 2; return EXL3_OK; }
 static int g_gemv_nwv = 0;           // 0 = heuristic; otherwise cap on waves per workgroup (tuning / tests)
 static int g_gemv_defer_wg_per_cu = 0;
+static int g_tail_xcd_local = 1;     // tail epilogues that can keep a column block on one XCD do (0: agent-scope hand-off everywhere)
+extern "C" int exl3_set_tail_xcd_local(int v) { g_tail_xcd_local = v ? 1 : 0; return EXL3_OK; }
 static int g_gemm3_min_rows = 5;     // passes with at least this many rows take generation 3 (0 = never); raw (unrotated) input: >= 9
 extern "C" int exl3_set_gemm3_min_rows(int v) { g_gemm3_min_rows = v; return EXL3_OK; }
 
@@ -673,6 +675,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             args.epi.ticket_global = total_cb;
             args.epi.ss_offset = (int) wso;
             if (epi->mode == GEMV_EPI_NORM) wso += (int64_t) mp * (ns[0] / 128);
+            // one XCD per column block needs (column blocks x S) / 8 consecutive logical workgroups to hold whole column blocks
+            args.epi.xcd_local = (epi->mode == GEMV_EPI_RESID && g_tail_xcd_local && total_cb % 8 == 0) ? 1 : 0;
             EXL3_CHECK_ARG(total_cb + 1 <= EXL3_NUM_TICKETS, "exl3_gemv: too many column blocks for the ticket table");
             EXL3_CHECK_ARG(S <= 128, "exl3_gemv: split too deep for the tail epilogue");
         }
@@ -856,6 +860,23 @@ extern "C" int exl3_gemv_norm(const void* A, const void* xh, const float* xsum, 
     const void* Bs[1] = { B }; const void* su[1] = { suh }; const void* sv[1] = { svh }; const void* bi[1] = { bias };
     const void* xhs[1] = { xh }; const float* xss[1] = { xsum }; int ns[1] = { n };
     return run_mgemm(A, Bs, nullptr, su, sv, bi, ns, 1, m, k, K, cb, 1, 0, (hipStream_t) stream, xh ? GEMV_IN_ROTATED : 0,
+                     xh ? xhs : nullptr, xh ? xss : nullptr, nullptr, nullptr, &e);
+}
+
+// o_proj / down_proj with glue_resid inside the launch: resid (fp16, in place) += linear(x), ss_out[m][n/128] = per-block sums of squares of the
+// new residual (what the consumer's GEMV_IN_NORM needs).  The workgroup that finishes a column block last does it; with n/128 % 8 == 0 all
+// slices of a column block are placed on one XCD and the hand-off stays in its L2.
+extern "C" int exl3_gemv_resid(const void* A, const void* xh, const float* xsum, const void* B, const void* suh, const void* svh, const void* bias,
+                               int m, int k, int n, int K, int cb, void* resid, float* ss_out, int force_split, void* stream)
+{
+    EXL3_CHECK_ARG(B && svh && resid && ss_out, "exl3_gemv_resid: null pointer");
+    EXL3_CHECK_ARG(m >= 1 && m <= 16, "exl3_gemv_resid: 1 <= m <= 16");
+    GemvEpi e; memset((void*) &e, 0, sizeof(e));
+    e.mode = GEMV_EPI_RESID;
+    e.resid = (half_t*) resid; e.ss_out = ss_out;
+    const void* Bs[1] = { B }; const void* su[1] = { suh }; const void* sv[1] = { svh }; const void* bi[1] = { bias };
+    const void* xhs[1] = { xh }; const float* xss[1] = { xsum }; int ns[1] = { n };
+    return run_mgemm(A, Bs, nullptr, su, sv, bi, ns, 1, m, k, K, cb, 1, force_split, (hipStream_t) stream, xh ? GEMV_IN_ROTATED : 0,
                      xh ? xhs : nullptr, xh ? xss : nullptr, nullptr, nullptr, &e);
 }
 

@@ -76,8 +76,12 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const int lane = tid & 63;
     const int m = a.m;
 
-    const int s = blockIdx.x % a.S;
-    const int cbg = blockIdx.x / a.S;
+    // xcd_local tail epilogues: workgroup i runs on XCD i % 8 (tools/ubench_xcc.hip), so logical workgroup (i % 8) * (grid / 8) + i / 8 puts each
+    // run of grid / 8 consecutive logical ids -- hence all S slices of a column block -- on one XCD (host: column blocks % 8 == 0)
+    int bid = blockIdx.x;
+    if constexpr (MODE == G2_MODE_TAIL) { if (a.epi.xcd_local) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+    const int s = bid % a.S;
+    const int cbg = bid / a.S;
     int mi = 0;
     const uint32_t* __restrict__ Bm;
     const half_t* __restrict__ suh;
@@ -509,7 +513,11 @@ void exl3_gemv2_kernel(const GemvArgs a)
 #ifdef G2_SLAB_SC1
             st_agent(slab + row * 128 + 4 * l, v);                                         // experiment: write-through slabs in every mode
 #else
-            if constexpr (MODE == G2_MODE_TAIL) st_agent(slab + row * 128 + 4 * l, v);     // read by another workgroup of this launch
+            if constexpr (MODE == G2_MODE_TAIL)
+            {
+                if (a.epi.xcd_local) ((float4_t*) (slab + row * 128))[l] = v;              // reader is on this XCD: the L2 copy is enough
+                else st_agent(slab + row * 128 + 4 * l, v);                                // read by another workgroup of this launch
+            }
             else ((float4_t*) (slab + row * 128))[l] = v;
 #endif
         }

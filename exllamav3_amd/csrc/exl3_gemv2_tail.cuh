@@ -49,18 +49,26 @@ __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store
 __device__ __forceinline__ float ld_agent1(const float* p) { return __hip_atomic_load((float*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // returns true for the workgroup that arrived last at `ticket` (and re-arms the ticket)
-__device__ __forceinline__ bool tail_arrive(uint32_t* ticket, uint32_t expected, int tid, int* s_flag)
+// local: every participant runs on the same XCD (GemvEpi::xcd_local).  Stores are acknowledged by that XCD's L2 and atomics execute there, so a
+// plain store -> s_waitcnt -> L2 atomic -> plain load chain is ordered without any memory-side (sc1) round trip: the hand-off costs an L2
+// latency instead of the ~2 us per hop of the agent-scope version.
+__device__ __forceinline__ bool tail_arrive(uint32_t* ticket, uint32_t expected, int tid, int* s_flag, bool local = false)
 {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores are acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are acknowledged (by L2; write-through ones by memory)
     __syncthreads();
     if (tid == 0)
     {
         bool last = true;
         if (expected > 1)
         {
-            uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t old = local ? __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                 : __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             last = old == expected - 1;
-            if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (last)
+            {
+                if (local) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         *s_flag = last ? 1 : 0;
     }
@@ -73,7 +81,7 @@ __device__ __forceinline__ bool tail_arrive(uint32_t* ticket, uint32_t expected,
 // half-wave j sums row j's S lines in slice order -- the same order as slab_sum(), so glue and tail pipelines agree bit for bit.
 template <int NS>
 __device__ __forceinline__ void tail_gather(const float* const (&bases)[NS], const int S, const int c, const int m, const int row0, const int rows,
-                                            float4_t* buf, const int hw8, const int nhw, const int l, const int rr, float4_t (&v)[NS])
+                                            float4_t* buf, const int hw8, const int nhw, const int l, const int rr, float4_t (&v)[NS], const bool local = false)
 {
     const int items = rows * NS * S;
     for (int it = hw8; it < items; it += nhw)
@@ -82,7 +90,8 @@ __device__ __forceinline__ void tail_gather(const float* const (&bases)[NS], con
         const float* base = bases[0];
         #pragma unroll
         for (int i = 1; i < NS; ++i) if (set == i) base = bases[i];
-        buf[it * 32 + l] = ld_agent(base + ((size_t) (c * S + sl) * m + row0 + r) * 128 + 4 * l);
+        const float* src = base + ((size_t) (c * S + sl) * m + row0 + r) * 128 + 4 * l;
+        buf[it * 32 + l] = local ? *((const float4_t*) src) : ld_agent(src);
     }
     __syncthreads();
     #pragma unroll
@@ -103,7 +112,8 @@ __device__ __forceinline__ void gemv_tail(const GemvArgs& a, const int mi, const
     const int l = tid & 31, hw8 = tid >> 5, nhw = nwv * 2;
     const int group = e.mode == GEMV_EPI_ACT ? cbl : cbg;
     const uint32_t expected = e.mode == GEMV_EPI_ACT ? 2u * S : (uint32_t) S;
-    if (!tail_arrive(e.tickets + group, expected, tid, s_flag)) return;
+    const bool local = e.xcd_local != 0;
+    if (!tail_arrive(e.tickets + group, expected, tid, s_flag, local)) return;
 
     if (e.mode == GEMV_EPI_ACT)
     {
@@ -197,7 +207,7 @@ __device__ __forceinline__ void gemv_tail(const GemvArgs& a, const int mi, const
     {
         const int hidden = a.mat[0].n, nblk = hidden >> 7;
         const SlabRef sr = { a.workspace + a.mat[0].ws_offset, S };
-        float* ss_part = a.workspace + e.ss_offset;                         // [m][nblk]
+        float* ss_part = e.mode == GEMV_EPI_RESID ? e.ss_out : a.workspace + e.ss_offset;   // [m][nblk]
         const half_t* svh = a.mat[0].svh + cbl * 128;
         const half_t* bias = a.mat[0].bias ? a.mat[0].bias + cbl * 128 : nullptr;
         const float* const bases[1] = { sr.base };
@@ -209,7 +219,7 @@ __device__ __forceinline__ void gemv_tail(const GemvArgs& a, const int mi, const
             half_t* rp = e.resid + (size_t) row * hidden + cbl * 128;
             half4_t r = ((const half4_t*) rp)[l];
             float4_t v[1];
-            tail_gather<1>(bases, S, cbl, m, row0, rows, buf, hw8, nhw, l, rr, v);
+            tail_gather<1>(bases, S, cbl, m, row0, rows, buf, hw8, nhw, l, rr, v, local);
             float h0, h1, h2, h3;
             out_had(v[0], l, h0, h1, h2, h3);
             half4_t sc = ((const half4_t*) svh)[l];
@@ -217,14 +227,15 @@ __device__ __forceinline__ void gemv_tail(const GemvArgs& a, const int mi, const
             if (bias) { half4_t b = ((const half4_t*) bias)[l]; h0 += (float) b.x; h1 += (float) b.y; h2 += (float) b.z; h3 += (float) b.w; }
             r = half4_t{ f2h((float) r.x + h0), f2h((float) r.y + h1), f2h((float) r.z + h2), f2h((float) r.w + h3) };
             const float r0 = (float) r.x, r1 = (float) r.y, r2 = (float) r.z, r3 = (float) r.w;
-            if (act) st_agent(rp + 4 * l, r);
+            if (act) { if (e.mode == GEMV_EPI_RESID) ((half4_t*) rp)[l] = r; else st_agent(rp + 4 * l, r); }    // RESID: read by the NEXT launch only
             float ss = r0 * r0;
             ss = __builtin_fmaf(r1, r1, ss); ss = __builtin_fmaf(r2, r2, ss); ss = __builtin_fmaf(r3, r3, ss);
             #pragma unroll
             for (int i = 1; i < 32; i <<= 1) ss += xor_lane(ss, i);
-            if (act && l == 0) st_agent(ss_part + row * nblk + cbl, ss);
+            if (act && l == 0) { if (e.mode == GEMV_EPI_RESID) ss_part[row * nblk + cbl] = ss; else st_agent(ss_part + row * nblk + cbl, ss); }
             __syncthreads();
         }
+        if (e.mode == GEMV_EPI_RESID) return;                               // the row-wide RMSNorm happens in the consumer (GEMV_IN_NORM)
         if (!tail_arrive(e.tickets + e.ticket_global, (uint32_t) nblk, tid, s_flag)) return;
 
         const int tasks = m * nblk;

@@ -31,6 +31,7 @@ struct GemvMat
 #define GEMV_EPI_NONE 0
 #define GEMV_EPI_NORM 1   // 1 matrix (o_proj / down_proj): out-had*svh(+bias) -> residual += y ; the last block overall: RMSNorm -> in-had
 #define GEMV_EPI_ACT  2   // 2 matrices (gate, up): out-had*svh -> silu(g)*u -> in-had of down_proj
+#define GEMV_EPI_RESID 4  // 1 matrix (o_proj / down_proj): out-had*svh(+bias) -> residual += y -> per-block sums of squares (glue_resid inside the launch)
 #define GEMV_EPI_QKV  3   // 3 matrices (q, k, v), head_dim 128: out-had*svh -> RoPE -> q out / quantized KV-cache append
 
 struct GemvEpi
@@ -38,6 +39,8 @@ struct GemvEpi
     int mode;
     int rows_per_pass;                       // rows whose slabs fit the workgroup LDS at once (host: lds >= rows * sets * S * 512 B)
     int ticket_global;                       // index of the whole-launch ticket (NORM)
+    int xcd_local;                           // all slices of a column block run on ONE XCD (host-arranged): the hand-off stays in that XCD's L2
+    float* ss_out;                           // RESID: [m][n/128] per-block sums of squares for the consumer's GEMV_IN_NORM
     uint32_t* tickets;                       // zero on entry, zero on exit
     // consumers of the produced activation (NORM: up to 3, ACT: 1): xh = fp16(had(x * suh)/sqrt(128)), per-block sums
     const half_t* t_suh[3]; half_t* t_xh[3]; float* t_xsum[3]; int t_count;

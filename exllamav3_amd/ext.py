@@ -78,6 +78,24 @@ def set_gemv_max_waves(n: int):
     _lib.lib().exl3_set_gemv_max_waves(int(n))
 
 
+def set_tail_xcd_local(on: bool):
+    """Tail epilogues keep a column block on one XCD when they can (default); False: agent-scope hand-off everywhere."""
+    _lib.lib().exl3_set_tail_xcd_local(int(bool(on)))
+
+
+def exl3_gemv_resid(A, xh, xsum, B, suh, svh, bias, m: int, mcg: bool, mul1: bool, resid, ss_out, force_split: int = 0):
+    """o_proj / down_proj whose launch also does glue_resid: resid += linear(x) (fp16, in place), ss_out[m][n/128] = per-block sums of squares.
+    Input: raw A (+ suh) or pre-rotated xh."""
+    ref = A if A is not None else xh
+    _dev(ref)
+    k, K = _kK(B)
+    n = B.shape[1] * 16
+    _req(ref.shape[-1] == k, "exl3_gemv_resid: input width must match B (k)")
+    _req(resid.dtype == torch.half and resid.shape[-1] == n and ss_out.dtype == torch.float and ss_out.numel() >= m * (n // 128), "exl3_gemv_resid: bad resid / ss_out")
+    _check(_lib.lib().exl3_gemv_resid(_p(A), _p(xh), _p(xsum), _p(B), _p(suh), _p(svh), _p(bias), m, k, n, K, _cb(mcg, mul1), _p(resid), _p(ss_out),
+                                      int(force_split), _stream(ref)))
+
+
 def set_gemm3_min_rows(n: int):
     """Passes with at least n rows use the generation-3 small-m GEMM (exl3_gemm3.kspec.hip); default 9, 0 = never."""
     _lib.lib().exl3_set_gemm3_min_rows(int(n))

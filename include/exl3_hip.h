@@ -157,6 +157,11 @@ int exl3_routing_std(const void* hidden, const void* gate, const void* bias, voi
 
 /* o_proj / down_proj:  y = linear(x) (fp32, + bias) ; resid += y (fp16, norm.cu:193-218 rms_norm_res_in semantics) ;
  * xn = rms_norm(resid) * norm_w ; for each of t_count consumers: t_xhs[i] = had128(xn * t_suhs[i]), t_xsums[i] = block sums. */
+/* o_proj / down_proj with the glue_resid step inside the launch (tail epilogue kept on one XCD when n/128 % 8 == 0):
+ * resid (fp16 [m][n], in place) += linear(x); ss_out [m][n/128] = per-block sums of squares of the new residual. */
+int exl3_gemv_resid(const void* A, const void* xh, const float* xsum, const void* B, const void* suh, const void* svh, const void* bias,
+                    int m, int k, int n, int K, int cb, void* resid, float* ss_out, int force_split, void* stream);
+int exl3_set_tail_xcd_local(int enable);    /* 0: agent-scope (memory-side) hand-off in every tail epilogue */
 int exl3_gemv_norm(const void* A, const void* xh, const float* xsum, const void* B, const void* suh, const void* svh, const void* bias,
                    int m, int k, int n, int K, int cb, void* resid, const void* norm_w, float eps,
                    const void* const* t_suhs, void* const* t_xhs, float* const* t_xsums, int t_count, void* xn_out, void* stream);

@@ -593,3 +593,39 @@ def test_tp_rank_code_path_on_one_gpu(dev, model_name, tp, bsz):
             model.decode_step_fused()
         g.replay(); st.synchronize()
     assert np.array_equal(model.logits.float().cpu().numpy(), lf)
+
+
+@pytest.mark.parametrize("k,n", [(512, 4096), (1792, 4096), (512, 384), (512, 2048)])
+@pytest.mark.parametrize("m", [1, 4, 7])
+def test_gemv_resid_tail_equals_gemv_plus_glue_resid(dev, k, n, m):
+    """exl3_gemv_resid (o_proj / down_proj with glue_resid inside the launch) against the two-launch route, bit for bit: the residual stream and
+    the per-block sums of squares.  n/128 % 8 == 0 takes the XCD-local hand-off (all slices of a column block on one XCD, plain stores + an
+    L2 atomic), otherwise -- and with the switch off -- the agent-scope one; 30 repetitions on the same workspace catch stale reads."""
+    from exllamav3_amd import ext
+    ext.set_gemm3_min_rows(0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rng = np.random.default_rng(k + n + m)
+    tr, suh, svh = o.synth_linear(k, n, 4, seed=3, realistic=True)
+    ttr, tsu, tsv = T(tr), T(suh), T(svh)
+    for rotated in (False, True):
+        for rep in range(30 if n == 4096 else 6):
+            x = T(rng.standard_normal((m, k)).astype(np.float16))
+            r0 = T((rng.standard_normal((m, n)) * 2).astype(np.float16))
+            xh = torch.empty_like(x)
+            if rotated:
+                ext.had_r_128(x, xh, tsu, None, 1.0)
+            # reference route: deferred GEMV + glue_resid
+            r_ref = r0.clone(); ss_ref = torch.zeros((m, n // 128), dtype=torch.float32, device=dev)
+            if rotated:
+                slabs, S = ext.exl3_gemv_ex(None, [xh], None, [ttr], None, None, None, m, False, True, ext.GEMV_IN_ROTATED | ext.GEMV_OUT_DEFERRED)
+            else:
+                slabs, S = ext.exl3_gemv_ex(x, None, None, [ttr], None, [tsu], None, m, False, True, ext.GEMV_OUT_DEFERRED)
+            ext.glue_resid(slabs[0], S, tsv, None, r_ref, ss_ref, m)
+            for local in (True, False):
+                ext.set_tail_xcd_local(local)
+                r1 = r0.clone(); ss1 = torch.full((m, n // 128), float("nan"), dtype=torch.float32, device=dev)
+                ext.exl3_gemv_resid(None if rotated else x, xh if rotated else None, None, ttr, None if rotated else tsu, tsv, None, m, False, True, r1, ss1,
+                                    force_split=S)
+                assert torch.equal(r1, r_ref), f"residual differs (rotated={rotated}, local={local}, rep={rep})"
+                assert torch.equal(ss1, ss_ref), f"sums of squares differ (rotated={rotated}, local={local}, rep={rep})"
+    ext.set_tail_xcd_local(True)
