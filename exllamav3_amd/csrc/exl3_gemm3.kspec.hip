@@ -1,4 +1,4 @@
-// EXL3 quantized small-m GEMM for gfx950, kernel generation 3 ("decode -> LDS transpose -> 16x16x32 MFMA"), 9..64 rows per pass.
+// EXL3 quantized small-m GEMM for gfx950, kernel generation 3 ("decode -> LDS transpose -> 16x16x32 MFMA"), 5..64 rows per pass.
 //
 //   C = ((A * suh) H) @ dequant(B) H * svh (+ bias)        reference: quant/exl3_gemm_kernel.cuh:8-80, quant/exl3_gemm_inner.cuh
 //                                                          (semantics only; the reference streams 16 rows per pass)
