@@ -51,7 +51,7 @@ template <int K, int CB, int VAR, int NG, int MODE>
 #ifdef G2_ABL_ILP
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 #else
-__global__ __launch_bounds__(MODE == G2_MODE_ACT ? 256 : 1024 / NG) __attribute__((amdgpu_waves_per_eu(MODE == G2_MODE_ACT ? 2 : NG == 4 ? 3 : NG == 2 ? 4 : G2_PF > 2 ? 6 : (K >= 5 && MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1) ? 5 : ((K >= 5 || (MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || MODE == G2_MODE_ACT || CB != EXL3_CB_MUL1) ? 7 : 8)))))
+__global__ __launch_bounds__(MODE == G2_MODE_ACT ? 256 : 1024 / NG) __attribute__((amdgpu_waves_per_eu(MODE == G2_MODE_ACT ? 2 : NG == 4 ? 3 : NG == 2 ? 4 : G2_PF > 2 ? 6 : (K >= 5 && MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1) ? 5 : ((K >= 5 || ((MODE == G2_MODE_NORM || MODE == G2_MODE_TAIL) && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || MODE == G2_MODE_ACT || MODE == G2_MODE_TAIL || CB != EXL3_CB_MUL1) ? 7 : 8)))))
 #endif
 void exl3_gemv2_kernel(const GemvArgs a)
 {
