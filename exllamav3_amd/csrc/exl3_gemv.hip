@@ -472,8 +472,43 @@ static int gemv_gen()
 extern "C" int exl3_set_gemv_gen(int v) { g_gemv_gen = (v == 1) ? 1 : 2; return EXL3_OK; }
 static int g_gemv_nwv = 0;           // 0 = heuristic; otherwise cap on waves per workgroup (tuning / tests)
 static int g_gemv_defer_wg_per_cu = 0;
-static int g_tail_xcd_local = 1;     // tail epilogues that can keep a column block on one XCD do (0: agent-scope hand-off everywhere)
-extern "C" int exl3_set_tail_xcd_local(int v) { g_tail_xcd_local = v ? 1 : 0; return EXL3_OK; }
+// XCD-local tail hand-off (exl3_gemv_resid): OPT-IN.  It is only correct if workgroup i of a 1-D grid runs on XCD i % 8, which HIP does not
+// promise (CU masking, harvested XCDs, other firmware): enabling it runs a probe over the grid sizes the mode is used with and refuses
+// (EXL3_ERR_ARG, mode stays off) unless every workgroup reported XCC_ID == blockIdx % 8 on several launches.  Default: agent-scope hand-off.
+static int g_tail_xcd_local = 0;
+__global__ void exl3_xcc_probe_kernel(uint32_t* bad)
+{
+    if (threadIdx.x == 0)
+    {
+        uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        if ((x & 15u) != (blockIdx.x & 7u)) atomicAdd(bad, 1u);
+    }
+}
+extern "C" int exl3_set_tail_xcd_local(int v)
+{
+    if (!v) { g_tail_xcd_local = 0; return EXL3_OK; }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(0, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+    { exl3_set_error("exl3_set_tail_xcd_local: cannot probe the workgroup -> XCD mapping during graph capture"); return EXL3_ERR_ARG; }
+    uint32_t* bad = nullptr;
+    EXL3_CHECK_HIP(hipMalloc(&bad, 4), "exl3_set_tail_xcd_local");
+    uint32_t h = 0;
+    hipError_t e = hipMemset(bad, 0, 4);
+    const int grids[] = { 64, 256, 512, 1024, 2048 };
+    for (int rep = 0; rep < 3 && e == hipSuccess; ++rep)
+        for (int g : grids) exl3_xcc_probe_kernel<<<g, 256>>>(bad);
+    if (e == hipSuccess) e = hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
+    (void) hipFree(bad);
+    EXL3_CHECK_HIP(e, "exl3_set_tail_xcd_local");
+    if (h != 0)
+    {
+        g_tail_xcd_local = 0;
+        exl3_set_error("exl3_set_tail_xcd_local: %u probe workgroups did not run on XCD blockIdx %% 8 on this device; the XCD-local hand-off stays off", h);
+        return EXL3_ERR_ARG;
+    }
+    g_tail_xcd_local = 1;
+    return EXL3_OK;
+}
 static int g_gemm3_min_rows = 5;     // passes with at least this many rows take generation 3 (0 = never); raw (unrotated) input: >= 9
 extern "C" int exl3_set_gemm3_min_rows(int v) { g_gemm3_min_rows = v; return EXL3_OK; }
 

@@ -23,7 +23,21 @@ struct HgemmCtx
     std::map<std::tuple<int, int, int, int64_t, int, int, int64_t, int64_t>, hipblasLtMatmulAlgo_t> algos;
 };
 static HgemmCtx g_hctx[64];
-static std::mutex g_hmutex;
+static std::mutex g_hmutex[64];        // one per device: a first-use autotune on one device (it synchronises) does not block hgemm on the others
+
+// the descriptor + three layouts of one call: released on every return path
+struct LtObjs
+{
+    hipblasLtMatmulDesc_t desc = nullptr;
+    hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
+    ~LtObjs()
+    {
+        if (la) hipblasLtMatrixLayoutDestroy(la);
+        if (lb) hipblasLtMatrixLayoutDestroy(lb);
+        if (lc) hipblasLtMatrixLayoutDestroy(lc);
+        if (desc) hipblasLtMatmulDescDestroy(desc);
+    }
+};
 
 #define CHECK_LT(expr, what) do { hipblasStatus_t s_ = (expr); if (s_ != HIPBLAS_STATUS_SUCCESS) { \
     exl3_set_error("hgemm: %s failed (hipblasStatus %d)", what, (int) s_); return EXL3_ERR_HIP; } } while (0)
@@ -38,7 +52,8 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
     if (m == 0) return EXL3_OK;
     int device = 0;
     EXL3_CHECK_HIP(hipGetDevice(&device), "hipGetDevice");
-    std::lock_guard<std::mutex> lock(g_hmutex);
+    EXL3_CHECK_ARG(device >= 0 && device < 64, "hgemm: device index out of range");
+    std::lock_guard<std::mutex> lock(g_hmutex[device]);
     HgemmCtx& cx = g_hctx[device];
     if (!cx.ready)
     {
@@ -54,8 +69,9 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
     }
 
     // row-major C[m,n] = A[m,k] B[k,n]   <=>   column-major C^T[n,m] = B^T[n,k] A^T[k,m]
-    hipblasLtMatmulDesc_t desc;
-    hipblasLtMatrixLayout_t la, lb, lc;
+    LtObjs lt;
+    hipblasLtMatmulDesc_t& desc = lt.desc;
+    hipblasLtMatrixLayout_t &la = lt.la, &lb = lt.lb, &lc = lt.lc;
     CHECK_LT(hipblasLtMatmulDescCreate(&desc, HIPBLAS_COMPUTE_32F, HIP_R_32F), "MatmulDescCreate");
     hipblasOperation_t opn = HIPBLAS_OP_N, opt = HIPBLAS_OP_T;
     CHECK_LT(hipblasLtMatmulDescSetAttribute(desc, HIPBLASLT_MATMUL_DESC_TRANSA, b_t_ld ? &opt : &opn, sizeof(opn)), "set TRANSA");
@@ -69,7 +85,9 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
 
     auto key = std::make_tuple(m, k, n, ldc, c_fp32, accumulate, b_t_ld, lda);
     auto it = cx.algos.find(key);
-    if (it == cx.algos.end())
+    hipblasLtMatmulAlgo_t algo_now;
+    if (it != cx.algos.end()) algo_now = it->second;
+    else
     {
         // First use of a shape: ask hipBLASLt for its candidate list and, when not capturing, time them on the caller's
         // buffers (the reference autotunes its own GEMM kernels the same way: quant/coop_autotune.cu).  EXL3_HIP_HGEMM_TUNE=0
@@ -81,8 +99,9 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
         constexpr int MAXA = 64;
         hipblasLtMatmulHeuristicResult_t res[MAXA];
         int found = 0;
-        CHECK_LT(hipblasLtMatmulAlgoGetHeuristic(cx.handle, desc, la, lb, lc, lc, pref, MAXA, res, &found), "AlgoGetHeuristic");
+        hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(cx.handle, desc, la, lb, lc, lc, pref, MAXA, res, &found);
         hipblasLtMatmulPreferenceDestroy(pref);
+        CHECK_LT(hs, "AlgoGetHeuristic");
         if (found < 1) { exl3_set_error("hgemm: no hipBLASLt algorithm for m=%d k=%d n=%d", m, k, n); return EXL3_ERR_HIP; }
         int best = 0;
         static int tune = -1;
@@ -178,15 +197,20 @@ static int hgemm_impl(const void* a, const void* b, void* c, int m, int k, int n
             }
             (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
             if (accumulate && dtune) { (void) hipStreamSynchronize((hipStream_t) stream); (void) hipFree(dtune); }
-            it = cx.algos.emplace(key, best_algo).first;
+            algo_now = best_algo;
+            cx.algos.emplace(key, best_algo);
         }
-        else it = cx.algos.emplace(key, res[best].algo).first;
+        else
+        {
+            // not timed (tuning off, one candidate, a small problem, or a shape first seen during graph capture): the top heuristic.  A choice made
+            // while capturing is NOT cached, so the first eager call of the shape still gets its autotune.
+            algo_now = res[best].algo;
+            if (!capturing) cx.algos.emplace(key, algo_now);
+        }
     }
     const float alpha = 1.0f, beta = accumulate ? 1.0f : 0.0f;
-    hipblasStatus_t st = hipblasLtMatmul(cx.handle, desc, &alpha, b, la, a, lb, &beta, c, lc, c, lc, &it->second,
+    hipblasStatus_t st = hipblasLtMatmul(cx.handle, desc, &alpha, b, la, a, lb, &beta, c, lc, c, lc, &algo_now,
                                          cx.ws, HGEMM_WS_BYTES, (hipStream_t) stream);
-    hipblasLtMatrixLayoutDestroy(la); hipblasLtMatrixLayoutDestroy(lb); hipblasLtMatrixLayoutDestroy(lc);
-    hipblasLtMatmulDescDestroy(desc);
     if (st != HIPBLAS_STATUS_SUCCESS) { exl3_set_error("hgemm: hipblasLtMatmul failed (%d)", (int) st); return EXL3_ERR_HIP; }
     return EXL3_OK;
 }

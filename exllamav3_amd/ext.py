@@ -79,8 +79,9 @@ def set_gemv_max_waves(n: int):
 
 
 def set_tail_xcd_local(on: bool):
-    """Tail epilogues keep a column block on one XCD when they can (default); False: agent-scope hand-off everywhere."""
-    _lib.lib().exl3_set_tail_xcd_local(int(bool(on)))
+    """Opt in to the XCD-local tail hand-off of exl3_gemv_resid (default off: agent-scope hand-off, placement-independent).  Enabling probes the
+    workgroup -> XCD mapping the mode relies on and raises RuntimeError (mode stays off) if the device does not dispatch block i to XCD i % 8."""
+    _check(_lib.lib().exl3_set_tail_xcd_local(int(bool(on))))
 
 
 def exl3_gemv_resid(A, xh, xsum, B, suh, svh, bias, m: int, mcg: bool, mul1: bool, resid, ss_out, force_split: int = 0):

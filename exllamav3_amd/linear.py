@@ -99,7 +99,8 @@ class LinearEXL3:
         fused = (self.in_features % 128 == 0 and self.out_features % 128 == 0 and rows >= FUSED_RECONSTRUCT_MIN_ROWS
                  and self.out_features <= MAX_RECONSTRUCT_SLICE_N and self.bias is None and rows > AUTO_RECONSTRUCT_THRESHOLD)
         if not fused:
-            y = self.forward(x, out_dtype=torch.float)
+            # forward() wants a contiguous x; prefill_chunk hands over strided column ranges of the fused q|k|v output
+            y = self.forward(x if x.is_contiguous() else x.contiguous(), out_dtype=torch.float)
             ext.add(resid, y.view(resid.shape))
             return
         x2 = x if (x.dim() == 2 and x.stride(1) == 1) else x.view(rows, self.in_features)     # a strided 2-D column range is taken as it is

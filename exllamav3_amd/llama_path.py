@@ -61,6 +61,30 @@ LLAMA_3_1_70B = LlamaShape("llama-3.1-70b", 8192, 28672, 80, 64, 8, 128, 128256)
 SHAPES = {s.name: s for s in (LLAMA_3_2_1B, LLAMA_3_1_8B, LLAMA_3_1_70B)}
 
 
+def rope_inv_freq(head_dim: int, rope_theta: float, rope_scaling: dict | None = None) -> torch.Tensor:
+    """Per-pair rotation frequencies fp32 [head_dim / 2] from a config.json, with the `rope_scaling` transform the reference applies on the
+    host (util/rope.py:187-228): none / "default", "linear" (divide by factor) and "llama3" (Llama-3.1+: wavelengths beyond
+    original_max_position_embeddings / low_freq_factor are slowed by `factor`, those below .../high_freq_factor kept, the band between
+    interpolated).  Other kinds (yarn, longrope, proportional, mrope) are not on this path: NotImplementedError, never a silent default."""
+    inv = 1.0 / (rope_theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    kind = None if not rope_scaling else rope_scaling.get("rope_type", rope_scaling.get("type"))
+    if kind in (None, "default"):
+        return inv
+    if kind == "linear":
+        return inv / float(rope_scaling.get("factor", 1.0))
+    if kind == "llama3":
+        factor = float(rope_scaling.get("factor", 8.0))
+        lo_f, hi_f = float(rope_scaling.get("low_freq_factor", 1.0)), float(rope_scaling.get("high_freq_factor", 4.0))
+        ctx = float(rope_scaling.get("original_max_position_embeddings", 8192))
+        wavelen = 2.0 * math.pi / inv
+        slowed = torch.where(wavelen > ctx / lo_f, inv / factor, inv)
+        t = (ctx / wavelen - lo_f) / (hi_f - lo_f)                      # 0 at the low-frequency edge of the band, 1 at the high one
+        blended = (1.0 - t) * slowed / factor + t * slowed
+        band = (wavelen >= ctx / hi_f) & (wavelen <= ctx / lo_f)
+        return torch.where(band, blended, slowed)
+    raise NotImplementedError(f"rope_scaling type {kind!r} is not supported by this path")
+
+
 def _rand_linear(k: int, n: int, K: int, cb: int, device, gen: torch.Generator, out_dtype=None, out_scale: float = 0.5) -> LinearEXL3:
     trellis = torch.randint(-32768, 32768, (k // 16, n // 16, 16 * K), dtype=torch.int16, device=device, generator=gen)
     sgn_u = torch.where(torch.rand(k, device=device, generator=gen) < 0.5, -1.0, 1.0)
@@ -214,7 +238,7 @@ class SyntheticEXL3Llama:
         self.lm_head = lin(head_key, (vpts[rank], vpts[rank + 1], "n"))
         l0 = self.layers[0]["q"]
         self.K, self.cb = l0.K, (2 if l0.mul1 else (1 if l0.mcg else 0))
-        self.inv_freq = (1.0 / (shape.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(self.device)
+        self.inv_freq = rope_inv_freq(hd, shape.rope_theta, cfg.get("rope_scaling")).to(self.device)
         self.eps = float(cfg.get("rms_norm_eps", 1e-5))
         self.page, self.max_ctx, self._state_bsz = 256, max_ctx, None
         return self

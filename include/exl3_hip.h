@@ -19,6 +19,13 @@
  *   - cb (codebook): 0 = 3INST, 1 = mcg, 2 = mul1  (reference passes two bools `mcg`, `mul1`;
  *     reconstruct.cu:128-130 — mcg wins).
  *   - all kernels are graph-capture safe after exl3_init(device) has run once outside capture.
+ *   - ONE STREAM PER DEVICE AT A TIME.  The split-k partial slabs, the arrival tickets, the generation-3 rotated-activation scratch and the
+ *     hgemm workspace are one per device (like the reference's DevCtx lock buffer + workspace, quant/exl3_devctx.cuh:8-19), and slab-writing
+ *     GEMV launches alternate between two workspace regions in issue order (a launch may read its predecessor's slabs: exl3_gemv_ex_act,
+ *     exl3_glue_*).  Calls on one device must therefore be issued from one host thread at a time onto one stream (or onto streams that are
+ *     ordered with respect to each other); two streams / threads issuing GEMVs concurrently on the same device overwrite each other's
+ *     partial sums.  The reference has the same contract (its A_had scratch and lock buffer are shared by every Linear of a device,
+ *     SURVEY.md 8b Ownership).  Different devices are independent.
  */
 #ifndef EXL3_HIP_H
 #define EXL3_HIP_H
@@ -157,11 +164,13 @@ int exl3_routing_std(const void* hidden, const void* gate, const void* bias, voi
 
 /* o_proj / down_proj:  y = linear(x) (fp32, + bias) ; resid += y (fp16, norm.cu:193-218 rms_norm_res_in semantics) ;
  * xn = rms_norm(resid) * norm_w ; for each of t_count consumers: t_xhs[i] = had128(xn * t_suhs[i]), t_xsums[i] = block sums. */
-/* o_proj / down_proj with the glue_resid step inside the launch (tail epilogue kept on one XCD when n/128 % 8 == 0):
+/* o_proj / down_proj with the glue_resid step inside the launch (agent-scope tail hand-off; kept on one XCD only after exl3_set_tail_xcd_local(1) and when n/128 % 8 == 0):
  * resid (fp16 [m][n], in place) += linear(x); ss_out [m][n/128] = per-block sums of squares of the new residual. */
 int exl3_gemv_resid(const void* A, const void* xh, const float* xsum, const void* B, const void* suh, const void* svh, const void* bias,
                     int m, int k, int n, int K, int cb, void* resid, float* ss_out, int force_split, void* stream);
-int exl3_set_tail_xcd_local(int enable);    /* 0: agent-scope (memory-side) hand-off in every tail epilogue */
+/* XCD-local tail hand-off of exl3_gemv_resid: OFF by default (agent-scope, placement-independent hand-off).  enable != 0 first probes that
+ * workgroup i runs on XCD i % 8 on this device (not a HIP guarantee) and returns EXL3_ERR_ARG, leaving the mode off, if any probe workgroup did not. */
+int exl3_set_tail_xcd_local(int enable);
 int exl3_gemv_norm(const void* A, const void* xh, const float* xsum, const void* B, const void* suh, const void* svh, const void* bias,
                    int m, int k, int n, int K, int cb, void* resid, const void* norm_w, float eps,
                    const void* const* t_suhs, void* const* t_xhs, float* const* t_xsums, int t_count, void* xn_out, void* stream);

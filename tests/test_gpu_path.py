@@ -628,4 +628,4 @@ def test_gemv_resid_tail_equals_gemv_plus_glue_resid(dev, k, n, m):
                                     force_split=S)
                 assert torch.equal(r1, r_ref), f"residual differs (rotated={rotated}, local={local}, rep={rep})"
                 assert torch.equal(ss1, ss_ref), f"sums of squares differ (rotated={rotated}, local={local}, rep={rep})"
-    ext.set_tail_xcd_local(True)
+    ext.set_tail_xcd_local(False)

@@ -107,3 +107,17 @@ def test_binding_argument_checks_raise_before_any_launch():
     with pytest.raises(RuntimeError):
         ext.quant_cache_paged_strided(h(4, 64), torch.zeros((1, 256, 8), dtype=torch.int32), h(1, 256, 2), h(4, 32), torch.zeros((1, 256, 8), dtype=torch.int32),
                                       h(1, 256, 2), torch.zeros(1, dtype=torch.int32), torch.zeros((1, 1), dtype=torch.int32), 256, 4)
+
+
+def test_rope_inv_freq_matches_reference_llama3_and_default(golden):
+    """config.json rope_scaling -> inv_freq: llama3 and default agree with the reference's RoPE object (fixtures from util/rope.py)."""
+    import torch
+    from exllamav3_amd.llama_path import rope_inv_freq
+    rs = {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0, "original_max_position_embeddings": 8192}
+    got = rope_inv_freq(128, 500000.0, rs).numpy()
+    np.testing.assert_allclose(got, golden["rope_neox_inv_freq"], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(rope_inv_freq(64, 10000.0, None).numpy(), golden["rope_default64_inv_freq"], rtol=1e-6, atol=0)
+    lin = rope_inv_freq(64, 10000.0, {"type": "linear", "factor": 4.0}).numpy()
+    np.testing.assert_allclose(lin * 4.0, golden["rope_default64_inv_freq"], rtol=1e-6, atol=0)
+    with pytest.raises(NotImplementedError):
+        rope_inv_freq(64, 10000.0, {"rope_type": "yarn", "factor": 4.0})

@@ -35,5 +35,5 @@ for (k, n, rot) in ((4096, 4096, False), (14336, 4096, True)):
     for local in (True, False):
         ext.set_tail_xcd_local(local)
         row["gemv_resid_" + ("xcd_local" if local else "agent_scope") + "_us"] = round(graph_us(one), 2)
-    ext.set_tail_xcd_local(True)
+    ext.set_tail_xcd_local(False)
     print(json.dumps(row), flush=True)
