@@ -1,7 +1,10 @@
 #!/bin/bash
-# ORACLE / TEST INFRASTRUCTURE.  Builds oracle/_ref/libexl3_ref_mul1.so from the reference's own
-# host-only C++ (exllamav3_ext/cpu/moe_mul1.cpp) compiled FROM WHERE IT LIES under /root/reference,
-# plus our extern "C" harness.  No reference source is copied into the repo; outputs only into oracle/_ref/.
+# ORACLE / TEST INFRASTRUCTURE.  Builds, FROM WHERE THE SOURCES LIE under /root/reference (no reference source is copied into the
+# repo; outputs only into oracle/_ref/):
+#   oracle/_ref/libexl3_ref_cuda.so  the reference's DEVICE headers for the codebooks, the trellis window readers and the KV-cache
+#                                    quantizer (quant/codebook.cuh, quant/exl3_dq.cuh, cache/lmq.cuh, cache/q_cache_kernels.cuh) compiled for
+#                                    the host on top of oracle/cuda_host_shim.h, behind the extern "C" harness oracle/ref_cuda_harness.cpp;
+#   oracle/_ref/libexl3_ref_mul1.so  the reference's own host-only C++ (exllamav3_ext/cpu/moe_mul1.cpp) + oracle/ref_harness.cpp.
 # Skips quietly when /root/reference is absent (GPU box: the prebuilt .so travels with the snapshot).
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
@@ -11,6 +14,13 @@ if [ ! -f "$REF/cpu/moe_mul1.cpp" ]; then
     echo "build_ref: $REF not present, skipping"; exit 0
 fi
 mkdir -p "$OUT"
+if [ "$OUT/libexl3_ref_cuda.so" -nt "$HERE/ref_cuda_harness.cpp" ] && [ "$OUT/libexl3_ref_cuda.so" -nt "$HERE/cuda_host_shim.h" ] \
+   && [ "$OUT/libexl3_ref_cuda.so" -nt "$REF/quant/codebook.cuh" ] && [ "$OUT/libexl3_ref_cuda.so" -nt "$REF/cache/q_cache_kernels.cuh" ]; then
+    echo "build_ref: libexl3_ref_cuda.so up to date"
+else
+    g++ -O1 -std=c++17 -fPIC -shared -Wno-attributes -I"$REF" -I"$HERE" "$HERE/ref_cuda_harness.cpp" -lpthread -o "$OUT/libexl3_ref_cuda.so"
+    echo "build_ref: built $OUT/libexl3_ref_cuda.so"
+fi
 if [ "$OUT/libexl3_ref_mul1.so" -nt "$HERE/ref_harness.cpp" ] && [ "$OUT/libexl3_ref_mul1.so" -nt "$REF/cpu/moe_mul1.cpp" ]; then
     echo "build_ref: up to date"; exit 0
 fi

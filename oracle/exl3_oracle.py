@@ -16,7 +16,13 @@ Parity pinning (see oracle/README.md and tests/test_oracle_pins.py):
   * trellis bit-window extraction + tile permutation + mul1 codebook + both Hadamards + suh/svh
     are pinned against the reference's own CPU implementation (exllamav3_ext/cpu/moe_mul1.cpp,
     compiled from where it lies into oracle/_ref/ by oracle/build_ref.sh).
-  * 3INST codebook: pinned by the reference constant codebook_scale = 1.24371088
+  * all three codebooks for all 65536 states incl. the single fp16 rounding (decode_3inst / decode_3inst_2, quant/codebook.cuh:56-123),
+    the trellis window readers for K = 1..8 incl. every dq_dispatch fast path (quant/exl3_dq.cuh:15-293), and the KV-cache quantizer
+    (words, scales, dequantized values for 2..8 bits, ragged groups, paged addressing: cache/q_cache_kernels.cuh:61-399) are pinned BIT
+    FOR BIT against the reference's own device headers compiled for the host from where they lie (oracle/cuda_host_shim.h +
+    oracle/ref_cuda_harness.cpp -> oracle/_ref/libexl3_ref_cuda.so).
+  * the MoE router is pinned against the reference's torch routing (modules/block_sparse_mlp.py:95-127, fixture).
+  * 3INST codebook, additionally: the reference constant codebook_scale = 1.24371088
     (modules/quant/exl3_lib/quantize.py:16) = std of the codebook over all 65536 states.
 """
 from __future__ import annotations
@@ -438,6 +444,45 @@ def kv_dequant(packed: np.ndarray, scales: np.ndarray, bits: int) -> np.ndarray:
     v = ((q.astype(np.float32) - (half - np.float32(0.5))) * sm).astype(np.float32)
     x = _fwht32_f32(v)
     return x.astype(np.float16).reshape(shp[:-1] + (shp[-1] * 32,))
+
+
+def kv_quant_paged(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, k_bits: int, v_bits: int,
+                   page_size: int = 256, in_contiguous: bool = True, seq_len: int | None = None):
+    """quant_cache_paged_kernel's addressing (cache/q_cache_kernels.cuh:289-325): new token j of sequence b lands at logical position
+    cache_seqlens[b] + j, i.e. physical row block_table[b][pos // page] * page + pos % page of the flat (pages * page) cache.
+    k_in / v_in: (bsz, seq_len, D) fp16 when in_contiguous, else the flat (pages * page, D) staging cache read at the same physical row.
+    k_out / v_out: uint32 (pages, page, D/32*bits), scales fp16 (pages, page, D/32): updated in place."""
+    bsz = block_table.shape[0]
+    if in_contiguous: seq_len = k_in.shape[1]
+    D = k_in.shape[-1]
+    ko, ks = k_out.reshape(-1, D // 32 * k_bits), k_scales.reshape(-1, D // 32)
+    vo, vs = v_out.reshape(-1, D // 32 * v_bits), v_scales.reshape(-1, D // 32)
+    kf, vf = (k_in, v_in) if in_contiguous else (k_in.reshape(-1, D), v_in.reshape(-1, D))
+    for b in range(bsz):
+        for j in range(seq_len):
+            pos = int(cache_seqlens[b]) + j
+            row = int(block_table[b, pos // page_size]) * page_size + pos % page_size
+            kx = kf[b, j] if in_contiguous else kf[row]
+            vx = vf[b, j] if in_contiguous else vf[row]
+            pk, sc = kv_quant(kx[None, :], k_bits); ko[row] = pk[0]; ks[row] = sc[0]
+            pk, sc = kv_quant(vx[None, :], v_bits); vo[row] = pk[0]; vs[row] = sc[0]
+
+
+def kv_dequant_paged(k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens, block_table, k_bits: int, v_bits: int,
+                     page_size: int = 256, bonus_len: int = 0):
+    """dequant_cache_paged_kernel's addressing without a sliding window (cache/q_cache_kernels.cuh:342-399): logical positions
+    [0, cache_seqlens[b] + bonus_len) of every sequence are dequantized into the same physical rows of k_out / v_out (fp16 (pages, page, D));
+    other rows are left untouched.  (With sliding_window > 0 the reference additionally SKIPS whole thread blocks that end before
+    max_len - window: which rows that covers depends on its launch geometry; rows inside the window are always written.)"""
+    D = k_out.shape[-1]
+    ki, ks = k_in.reshape(-1, D // 32 * k_bits), k_scales.reshape(-1, D // 32)
+    vi, vs = v_in.reshape(-1, D // 32 * v_bits), v_scales.reshape(-1, D // 32)
+    ko, vo = k_out.reshape(-1, D), v_out.reshape(-1, D)
+    for b in range(block_table.shape[0]):
+        for pos in range(int(cache_seqlens[b]) + bonus_len):
+            row = int(block_table[b, pos // page_size]) * page_size + pos % page_size
+            ko[row] = kv_dequant(ki[row][None, :], ks[row][None, :], k_bits)[0]
+            vo[row] = kv_dequant(vi[row][None, :], vs[row][None, :], v_bits)[0]
 
 
 # ------------------------------------------------------------------------------------------

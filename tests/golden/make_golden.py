@@ -158,6 +158,25 @@ def main():
         print("RMSNorm reference import failed:", repr(e))
         raise
 
+    # --- MoE router, torch path of the reference (modules/block_sparse_mlp.py:95-127 routing_std_bias with bsz > 1: logits = y @ gate (+ bias),
+    # top-k of the logits, weights = softmax over the selected logits in fp32 -> fp16; with no bias this is routing_std's contract, which the
+    # reference itself only implements natively (routing.cu:457-590)).  The function is compiled from the reference file's own source text.
+    import ast
+    src = open(REF + "/modules/block_sparse_mlp.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "routing_std_bias"][0]
+    ns = {"torch": torch, "ext": stub}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), REF + "/modules/block_sparse_mlp.py", "exec"), ns)
+    for tag, E, topk, with_bias in (("mixtral", 8, 2, False), ("wide", 64, 6, True)):
+        y = torch.randn(5, 256, generator=g).half()
+        gate = (torch.randn(256, E, generator=g) * 0.1).half()
+        bias = (torch.randn(E, generator=g) * 0.5).half() if with_bias else None
+        cfg = types.SimpleNamespace(gate_tensor=gate, gate_tensor_t=None, router_bias=bias, num_experts=E, num_experts_per_tok=topk,
+                                    per_expert_scale=None)
+        sel, wts = ns["routing_std_bias"](5, cfg, y, {})
+        out[f"route_{tag}_y"] = y.numpy(); out[f"route_{tag}_gate"] = gate.numpy()
+        out[f"route_{tag}_bias"] = bias.numpy() if with_bias else np.zeros(0, np.float16)
+        out[f"route_{tag}_sel"] = sel.numpy(); out[f"route_{tag}_w"] = wts.numpy()
+
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: getattr(v, "shape", None) for k, v in out.items()})
 
