@@ -660,5 +660,6 @@ class SyntheticEXL3Llama:
             from .linear import LinearEXL3
             ahead.end()
             LinearEXL3.ahead = None
+        self.px_out = x                                                     # residual stream after the last layer (parity tests read sampled rows)
         ext.rms_norm(x[-1:], self.final_norm, xn[-1:], self.eps)
         return self.lm_head.forward(xn[-1:].contiguous())

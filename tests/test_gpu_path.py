@@ -117,9 +117,8 @@ def test_fused_decode_pipeline_matches_unfused_and_oracle(dev, cb, bsz):
     assert np.isfinite(lf).all()
     rms = np.sqrt((lu ** 2).mean())
     assert np.abs(lf - lu).max() / rms < 1e-2
-    if bsz <= 2:
-        ref = _oracle_decode(model, _np(model.x0))
-        assert np.abs(lf - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+    ref = _oracle_decode(model, _np(model.x0))                                  # every batch size, incl. the generation-3 route at 5 and 16
+    assert np.abs(lf - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
     # quantized KV append: same slots, same values up to fp32 summation order
     for (kc, ks), (kc0, ks0) in zip(model.kcache + model.vcache, ku + vu):
         assert bool(((ks != 0) == (ks0 != 0)).all())
@@ -622,7 +621,11 @@ def test_gemv_resid_tail_equals_gemv_plus_glue_resid(dev, k, n, m):
                 slabs, S = ext.exl3_gemv_ex(x, None, None, [ttr], None, [tsu], None, m, False, True, ext.GEMV_OUT_DEFERRED)
             ext.glue_resid(slabs[0], S, tsv, None, r_ref, ss_ref, m)
             for local in (True, False):
-                ext.set_tail_xcd_local(local)
+                try:
+                    ext.set_tail_xcd_local(local)      # opt-in: enabling probes the workgroup -> XCD mapping and refuses if it is not i % 8
+                except RuntimeError:
+                    assert local
+                    continue
                 r1 = r0.clone(); ss1 = torch.full((m, n // 128), float("nan"), dtype=torch.float32, device=dev)
                 ext.exl3_gemv_resid(None if rotated else x, xh if rotated else None, None, ttr, None if rotated else tsu, tsv, None, m, False, True, r1, ss1,
                                     force_split=S)
