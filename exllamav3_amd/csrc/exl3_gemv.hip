@@ -584,14 +584,23 @@ static int choose_split(int gen, int total_colblocks, int k, int m, int num_cus,
     return S;
 }
 
+// GEMV_IN_RESID operands: the producer linear's deferred slabs + svh, and where the workgroups of column block 0 publish the new residual
+struct GemvResidIn { const float* slab; int S; const void* svh; void* resid_out; float* ss_out; };
+
 static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, const void* const* suhs, const void* const* svhs,
                      const void* const* biases, const int* ns, int count, int m, int k, int K, int cb, int c_fp32,
                      int force_split, hipStream_t st, int flags = 0, const void* const* xhs = nullptr, const float* const* xsums = nullptr,
                      float** slabs_out = nullptr, int* S_out = nullptr, const GemvEpi* epi = nullptr,
                      const void* norm_w = nullptr, const float* ss_part = nullptr, float eps = 0.0f, const GemvTable* tbl = nullptr,
                      const float* act_g = nullptr, const float* act_u = nullptr, int act_S = 0, const void* act_svh_g = nullptr,
-                     const void* act_svh_u = nullptr)
+                     const void* act_svh_u = nullptr, const GemvResidIn* rsd = nullptr, const GemvRescale* act_rs = nullptr, int cpw = 0)
 {
+    if (rsd) flags |= GEMV_IN_RESID;
+    // cpw > 0: wave-per-column-block layout (exl3_gemv2.kspec.hip): cpw column blocks of one matrix per workgroup, one wave each
+    EXL3_CHECK_ARG(cpw >= 0 && cpw <= 16, "exl3_gemv_ex: column blocks per workgroup must be in [0, 16]");
+    EXL3_CHECK_ARG(!rsd || cpw > 0, "exl3_gemv_ex_resid: needs the wave-per-column-block layout (cpw >= 1)");
+    EXL3_CHECK_ARG(cpw == 0 || ((flags & GEMV_OUT_DEFERRED) && m <= 4 && !tbl && !epi && !(flags & GEMV_IN_ROTATED)),
+                   "exl3_gemv_ex (cpw): wave-per-column-block launches are deferred, m <= 4, raw / resid / act input");
     if (act_g) flags |= GEMV_IN_ACT;
     if (epi) flags |= GEMV_OUT_DEFERRED;
     const bool deferred = (flags & GEMV_OUT_DEFERRED) != 0, rotated = (flags & GEMV_IN_ROTATED) != 0;
@@ -610,6 +619,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     EXL3_CHECK_ARG(!in_act || (act_g && act_u && act_svh_g && act_svh_u && act_S >= 1 && !rotated && count == 1 && m <= 4),
                    "exl3_gemv_ex_act: needs gate / up slabs + svh, one matrix, m <= 4");
     EXL3_CHECK_ARG(A || rotated || in_act, "exl3_gemm: null A");
+    EXL3_CHECK_ARG(!rsd || (in_norm && deferred && m <= 4 && rsd->slab && rsd->S >= 1 && rsd->svh && rsd->resid_out && rsd->ss_out && rsd->resid_out != A),
+                   "exl3_gemv_ex_resid: needs GEMV_IN_NORM, deferred output, m <= 4, producer slabs + svh and a resid_out buffer other than resid_in");
     int total_cb = 0;
     if (tbl)
     {
@@ -637,8 +648,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         // measured in the fused pipeline (tools/prof_tail.py, Llama-3.1-8B shapes): generation 3 is ahead from 5 rows with rotated input; with raw
         // input its 8 half-waves per workgroup would spend longer on the input Hadamards than generation 2's 16..32, so it starts at 9 rows
         // and, for wide launches, rotates the activations ONCE first (the role of the reference's A_had temporary, "storage for input transform": quant/exl3_gemm.cu:30, 139-145)
-        const bool g3 = g3_ok && mp >= (rotated ? g_gemm3_min_rows : (g_gemm3_min_rows > 9 ? g_gemm3_min_rows : 9));
-        const int gen = g3 ? 3 : (deferred || rotated || in_norm || tbl || in_act) ? 2 : gemv_gen();
+        const bool g3 = cpw == 0 && g3_ok && mp >= (rotated ? g_gemm3_min_rows : (g_gemm3_min_rows > 9 ? g_gemm3_min_rows : 9));
+        const int gen = cpw > 0 ? 2 : g3 ? 3 : (deferred || rotated || in_norm || tbl || in_act) ? 2 : gemv_gen();
         int pass_flags = flags;
         const void* pre_xh[GEMV_MAX_MATS] = { nullptr };
         const size_t xh_bytes = (size_t) mp * k * 2;
@@ -661,6 +672,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         args.act_g = act_g; args.act_u = act_u; args.act_S = act_S;
         args.act_svh_g = (const half_t*) act_svh_g; args.act_svh_u = (const half_t*) act_svh_u;
         args.norm_w = (const half_t*) norm_w; args.ss_part = ss_part; args.eps = eps;
+        if (rsd) { args.rs_slab = rsd->slab; args.rs_S = rsd->S; args.rs_svh = (const half_t*) rsd->svh; args.rs_resid_out = (half_t*) rsd->resid_out; args.rs_ss_out = rsd->ss_out; }
+        if (act_rs) args.act_rs = *act_rs;
         int fs = force_split;
         if (deferred && fs == 0)
         {
@@ -683,6 +696,21 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             if (fs < 1) fs = 1;
             if (epi && fs > 64) fs = 64;                         // tail epilogue: one pass of slabs must fit the workgroup LDS
         }
+        int total_groups = 0;
+        if (cpw > 0)
+        {
+            for (int i = 0; i < count; ++i) total_groups += (ns[i] / 128 + cpw - 1) / cpw;
+            if (force_split == 0)
+            {
+                // default: about 16 waves per CU in all (4 per SIMD at this layout's 128 VGPRs); tuned values come from the caller
+                const int nbk = k / 128;
+                long want = ((long) ctx->num_cus * 16 + (long) total_groups * cpw - 1) / ((long) total_groups * cpw);
+                if (want < 1) want = 1;
+                if (want > nbk) want = nbk;
+                fs = (int) want;
+            }
+            else fs = force_split;
+        }
         const int S = choose_split(gen, total_cb, k, mp, ctx->num_cus, fs);
         const int nb = k / 128;
         const int bps = (nb + S - 1) / S;
@@ -700,7 +728,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             args.mat[i].n = ns[i];
             args.mat[i].cb_first = cbf;
             args.mat[i].ws_offset = (int) wso;
-            cbf += ns[i] / 128;
+            cbf += cpw > 0 ? (ns[i] / 128 + cpw - 1) / cpw : ns[i] / 128;
             wso += (int64_t) (ns[i] / 128) * S * mp * 128;
         }
         if (epi)
@@ -736,7 +764,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         args.c_fp32 = c_fp32;
         args.c_row_offset = m0;
 
-        dim3 grid((unsigned) (total_cb * S));
+        args.cpw = cpw;
+        dim3 grid((unsigned) ((cpw > 0 ? total_groups : total_cb) * S));
         if (gen == 3)
         {
             const int mt = mp > 32 ? 4 : (mp > 16 ? 2 : 1);
@@ -774,17 +803,19 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             // variants above 64 VGPRs (3INST/MCG decode, NORM prep, K >= 5 rings) fit 7 or 6 waves per SIMD: three 8-wave workgroups per
             // CU instead of one 16-wave workgroup (tools/bench_lmhead.py: lm_head 3INST 105 -> 87 us, NORM 92 -> 81 us)
             if (!deferred && ng == 1 && (cb != 2 || tbl || K >= 5) && nwv > 8) nwv = 8;
-            if (in_act && nwv > 4) nwv = 4;                      // ACT-mode kernels are built for 4-wave workgroups (256 VGPRs available)
+            if (in_act && nwv > 4) nwv = 4;                      // (classic layout) ACT-mode kernels are built for 4-wave workgroups (256 VGPRs available)
             if (g_gemv_nwv < 0) nwv = (-g_gemv_nwv < 16 / ng) ? -g_gemv_nwv : 16 / ng;      // tuning: forced wave count
             if (in_act && nwv > 4) nwv = 4;
             if (nwv > units) nwv = units;
             if (g_gemv_nwv > 0 && nwv > g_gemv_nwv) nwv = g_gemv_nwv;
             if (nwv < 1) nwv = 1;
+            if (cpw > 0) nwv = cpw;                              // one wave per column block of the group
             // activation fragments of one chunk of Hadamard blocks, built once per workgroup: up to ~48 KB, the whole slice when it fits
             const int AHh = (var == 1 && cb != 2) ? 32 : 16;
             int chunk = (int) ((size_t) 49152 / ((size_t) 8 * mp * AHh * 2));
             if (chunk < 1) chunk = 1;
             if (chunk > bps) chunk = bps;
+            EXL3_CHECK_ARG(cpw == 0 || chunk >= bps, "exl3_gemv_ex (cpw): the slice's activation fragments must fit one LDS chunk (use a deeper split)");
             args.chunk_blocks = chunk;
             size_t lds = exl3_gemv2_lds_bytes(ng, var, cb, nwv, mp, chunk);
             if (epi)
@@ -990,6 +1021,50 @@ extern "C" int exl3_mgemm_indexed(const void* A, int bszm_in, const void* tbl_B,
 // down_proj whose input a = fp16(silu(g) * u) is finished from the gate / up launch's deferred slabs while the activation fragments are
 // built (m <= 4): replaces exl3_glue_act + exl3_gemv_ex(IN_ROTATED).  g_slabs / u_slabs / act_S: as returned by the gate / up exl3_gemv_ex
 // call (they live in the other workspace region than this launch's own slabs).  flags: EXL3_GEMV_OUT_DEFERRED optional.
+// exl3_gemv_ex_norm that also finishes the PRODUCER linear's residual add (replaces the exl3_glue_resid launch between o_proj / down_proj and the
+// next q|k|v / gate|up launch at m <= 4).  resid_in: fp16 [m][k] residual BEFORE the producer's output is added (read only); prod_slabs / prod_S /
+// prod_svh: the producer's deferred slabs (exl3_gemv_ex*, GEMV_OUT_DEFERRED; they live in the other workspace region); every workgroup rebuilds
+// resid_new = resid_in + linear_out for the Hadamard blocks of its k-slice, the column-block-0 workgroups write resid_out (a different buffer)
+// and ss_out [m][k/128].  The RMSNorm row scale comes from ss_prev (sums of squares of resid_in): consumers of THIS launch's deferred slabs apply
+// rsqrt(mean(resid_new^2) + eps) / rsqrt(mean(resid_in^2) + eps) (exl3_glue_qkv_rs, exl3_gemv_ex_act_rs).  Output: always deferred slabs.
+extern "C" int exl3_gemv_ex_resid(const void* resid_in, const void* norm_w, const float* ss_prev, float eps, const float* prod_slabs, int prod_S,
+                                  const void* prod_svh, void* resid_out, float* ss_out, const void* const* Bs, const void* const* suhs, const int* ns,
+                                  int count, int m, int k, int K, int cb, int cpw, int force_split, float** slabs_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(Bs && ns && resid_in && suhs, "exl3_gemv_ex_resid: null table");
+    GemvResidIn rsd = { prod_slabs, prod_S, prod_svh, resid_out, ss_out };
+    return run_mgemm(resid_in, Bs, nullptr, suhs, nullptr, nullptr, ns, count, m, k, K, cb, 0, force_split, (hipStream_t) stream,
+                     GEMV_OUT_DEFERRED | GEMV_IN_NORM, nullptr, nullptr, slabs_out, S_out, nullptr, norm_w, ss_prev, eps, nullptr,
+                     nullptr, nullptr, 0, nullptr, nullptr, &rsd, nullptr, cpw > 0 ? cpw : 4);
+}
+
+// exl3_gemv_ex (raw input A + suhs, deferred output, m <= 4) in the wave-per-column-block layout: cpw column blocks of one matrix per workgroup,
+// every wave streams the whole k-slice of its column block and writes its own slab (no cross-wave reduction).  cpw in [1, 16].
+extern "C" int exl3_gemv_ex_wpc(const void* A, const void* const* Bs, const void* const* suhs, const int* ns, int count, int m, int k, int K, int cb,
+                                int cpw, int force_split, float** slabs_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(Bs && ns && A && suhs && cpw >= 1, "exl3_gemv_ex_wpc: null table / cpw");
+    return run_mgemm(A, Bs, nullptr, suhs, nullptr, nullptr, ns, count, m, k, K, cb, 0, force_split, (hipStream_t) stream, GEMV_OUT_DEFERRED,
+                     nullptr, nullptr, slabs_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr, nullptr, 0, nullptr, nullptr,
+                     nullptr, nullptr, cpw);
+}
+
+// exl3_gemv_ex_act whose gate / up slabs come from an exl3_gemv_ex_resid launch: g and u are multiplied by the exact-over-estimated RMSNorm
+// scale of their row (ss_prev / ss_new [m][hidden/128], eps) before svh and silu.
+extern "C" int exl3_gemv_ex_act_rs(const float* g_slabs, const float* u_slabs, int act_S, const void* svh_g, const void* svh_u,
+                                   const float* ss_prev, const float* ss_new, int hidden, float eps,
+                                   const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
+                                   int c_fp32, int flags, int cpw, int force_split, float** slab_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(B && suh && ss_prev && ss_new && hidden % 128 == 0, "exl3_gemv_ex_act_rs: null pointer");
+    const void* Bs[1] = { B }; void* Cs[1] = { C }; const void* su[1] = { suh }; const void* sv[1] = { svh }; const void* bi[1] = { bias };
+    int ns[1] = { n };
+    GemvRescale rs = { ss_prev, ss_new, hidden, eps };
+    return run_mgemm(nullptr, Bs, C ? Cs : nullptr, su, svh ? sv : nullptr, bi, ns, 1, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream,
+                     (flags & GEMV_OUT_DEFERRED), nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
+                     g_slabs, u_slabs, act_S, svh_g, svh_u, nullptr, &rs, cpw);
+}
+
 extern "C" int exl3_gemv_ex_act(const float* g_slabs, const float* u_slabs, int act_S, const void* svh_g, const void* svh_u,
                                 const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
                                 int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream)

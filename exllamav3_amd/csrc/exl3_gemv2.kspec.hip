@@ -42,8 +42,33 @@ __device__ __forceinline__ void static_for(F&& f)
 #define G2_MODE_TAIL  2     // in-kernel tail epilogue (exl3_gemv2_tail.cuh)
 #define G2_MODE_TABLE 3     // device-side pointer tables + indices + routing weights (MoE exl3_mgemm)
 #define G2_MODE_ACT   4     // GEMV_IN_ACT: down_proj whose input is finished from the gate / up slabs (replaces the glue_act launch at m <= 4)
+#define G2_MODE_RNORM 5     // GEMV_IN_NORM | GEMV_IN_RESID: the residual add of the PREVIOUS linear (its split-k slabs) + RMSNorm while the fragments are built
+#define G2_MODE_WPLAIN 6    // PLAIN in the wave-per-column-block layout
+#define G2_MODE_WACT   7    // ACT in the wave-per-column-block layout
+// Wave-per-column-block layout (RNORM, WPLAIN, WACT; deferred output, m <= 4): a workgroup = `cpw` column blocks of ONE matrix x one k-slice, wave w
+// streams ALL tile rows of the slice for column block (group * cpw + w) and writes its own slab -- no cross-wave reduction, no barrier after the
+// streaming loop -- while the activation fragments of the slice are still built once per workgroup.  What it buys: the fused prologues (RESID,
+// ACT) re-read the producer's slabs once per workgroup, i.e. per cpw column blocks instead of per column block (29 MB -> 2-4 MB per launch for
+// Llama-3.1-8B's gate|up and down), which is what makes folding the glue launches into the consumer GEMVs pay.
+#define G2_IS_WPC(M) ((M) == G2_MODE_RNORM || (M) == G2_MODE_WPLAIN || (M) == G2_MODE_WACT)
+#define G2_IS_ACT(M) ((M) == G2_MODE_ACT || (M) == G2_MODE_WACT)
 // The modes are separate instantiations because the hot loop needs 62 of the 64 VGPRs that allow two 16-wave workgroups per CU: code
 // of a cold path that is merely present makes the allocator spill (scratch also slows every launch by ~1 us, measured).
+// register budget (waves per SIMD) of an instantiation: chosen so that NO variant spills (tests/test_no_scratch.py)
+constexpr int g2_waves_per_eu(int K, int CB, int NG, int MODE)
+{
+    if (MODE == G2_MODE_ACT) return 2;
+    if (G2_IS_WPC(MODE)) return 4;                // up to 16 waves per workgroup, 128 VGPRs: 8 prefetched slab lines (32 VGPRs) on top of the prep
+    if (NG == 4) return 3;
+    if (NG == 2) return 4;
+    if (G2_PF > 2) return 6;
+    const bool normish = MODE == G2_MODE_NORM || MODE == G2_MODE_RNORM;
+    int w = (K >= 5 && normish && CB != EXL3_CB_MUL1) ? 5
+          : ((K >= 5 || ((normish || MODE == G2_MODE_TAIL) && CB != EXL3_CB_MUL1)) ? 6
+          : ((normish || MODE == G2_MODE_TABLE || MODE == G2_MODE_TAIL || CB != EXL3_CB_MUL1) ? 7 : 8));
+    return w;
+}
+
 template <int K, int CB, int VAR, int NG, int MODE>
 // m <= 4 (NG == 1): two 16-wave workgroups per CU need <= 64 VGPRs (K <= 4, MUL1: the hot loop uses 59..62).  Variants that do not fit
 // (3INST/MCG, NORM prep, K >= 5 rings) get the next budget instead of spilling: any scratch use costs every launch ~1-2 us
@@ -51,7 +76,7 @@ template <int K, int CB, int VAR, int NG, int MODE>
 #ifdef G2_ABL_ILP
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
 #else
-__global__ __launch_bounds__(MODE == G2_MODE_ACT ? 256 : 1024 / NG) __attribute__((amdgpu_waves_per_eu(MODE == G2_MODE_ACT ? 2 : NG == 4 ? 3 : NG == 2 ? 4 : G2_PF > 2 ? 6 : (K >= 5 && MODE == G2_MODE_NORM && CB != EXL3_CB_MUL1) ? 5 : ((K >= 5 || ((MODE == G2_MODE_NORM || MODE == G2_MODE_TAIL) && CB != EXL3_CB_MUL1)) ? 6 : ((MODE == G2_MODE_NORM || MODE == G2_MODE_TABLE || MODE == G2_MODE_ACT || MODE == G2_MODE_TAIL || CB != EXL3_CB_MUL1) ? 7 : 8)))))
+__global__ __launch_bounds__(MODE == G2_MODE_ACT ? 256 : 1024 / NG) __attribute__((amdgpu_waves_per_eu(g2_waves_per_eu(K, CB, NG, MODE))))
 #endif
 void exl3_gemv2_kernel(const GemvArgs a)
 {
@@ -62,6 +87,12 @@ void exl3_gemv2_kernel(const GemvArgs a)
     constexpr int MR = 4 * NG;                       // activation rows held by the A operand
     constexpr int AH = SPLIT ? 32 : 16;              // halves per (tile row, activation row)
     constexpr int NW = 8 * K;
+#ifndef G2_WPC_PF
+#define G2_WPC_PF 4
+#endif
+    // tile rows per work unit = depth of the per-wave weight-row register ring.  The wave-per-column-block layouts run 4 waves per SIMD (128 VGPRs)
+    // and every wave walks its slice alone: a 2-row ring left them waiting on HBM (o_proj 9.9 vs 5.5 us), so they keep 4 rows in flight
+    constexpr int PF = G2_IS_WPC(MODE) ? G2_WPC_PF : G2_PF;
 
 #ifdef G2_TIMING
     // diagnostics build: wave 0 of every workgroup leaves 100 MHz timestamps of its phases in the workspace tail (48 MiB offset)
@@ -80,13 +111,15 @@ void exl3_gemv2_kernel(const GemvArgs a)
     // run of grid / 8 consecutive logical ids -- hence all S slices of a column block -- on one XCD (host: column blocks % 8 == 0)
     int bid = blockIdx.x;
     if constexpr (MODE == G2_MODE_TAIL) { if (a.epi.xcd_local) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+    constexpr bool WPC = G2_IS_WPC(MODE);
     const int s = bid % a.S;
-    const int cbg = bid / a.S;
+    int cbg = bid / a.S;                             // classic: global column block of the workgroup; WPC: column-block GROUP of the workgroup
     int mi = 0;
     const uint32_t* __restrict__ Bm;
     const half_t* __restrict__ suh;
     const half_t* A_in = a.A;
     int n, cbl, ws_off;
+    bool wave_live = true;                           // WPC: this wave has a column block (the last group of a matrix may be partial)
     if constexpr (MODE == G2_MODE_TABLE)
     {
         const int slot = cbg / a.tbl.cbs_per_mat;
@@ -97,6 +130,17 @@ void exl3_gemv2_kernel(const GemvArgs a)
         n = a.tbl.n; cbl = cbg - slot * a.tbl.cbs_per_mat;
         A_in = a.A + (size_t) slot * a.tbl.a_slot_stride;
         ws_off = slot * a.tbl.cbs_per_mat * a.S * a.m * 128;
+    }
+    else if constexpr (WPC)
+    {
+        // groups never straddle matrices (q|k|v, gate|up have different suh): mat[i].cb_first holds the first GROUP of matrix i
+        #pragma unroll
+        for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.num_mats && cbg >= a.mat[i].cb_first) mi = i;
+        Bm = a.mat[mi].B; suh = a.mat[mi].suh;
+        n = a.mat[mi].n; ws_off = a.mat[mi].ws_offset;
+        cbl = (cbg - a.mat[mi].cb_first) * a.cpw + wave;
+        wave_live = cbl < (n >> 7);
+        if (!wave_live) cbl = (n >> 7) - 1;
     }
     else
     {
@@ -110,18 +154,20 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const int k1s = min(k0s + a.kslice, a.k);
     const int nb = (k1s - k0s) >> 7;                 // 128-blocks in the workgroup's slice
     const int nwv = blockDim.x >> 6;                 // waves per workgroup (1..16)
-    // Work split inside the workgroup: the slice is walked in units of G2_PF (= 2) tile rows, unit u belongs to wave u % nwv.  All waves
+    // Work split inside the workgroup: the slice is walked in units of PF (= 2) tile rows, unit u belongs to wave u % nwv.  All waves
     // therefore advance down k together, which lets the workgroup build the activation fragments of a CHUNK of Hadamard blocks ONCE,
     // cooperatively (one (block, row) task per 32-lane half-wave), instead of every wave rotating every block it touches: at batch 16 the
     // per-wave version spent 6x more VALU time on input Hadamards than on decoding weights (tools/gemv_timeline.py).
-    const int units = nb * (8 / G2_PF);
+    const int units = nb * (8 / PF);
     // unit i of this wave = ubase + i * ustride.  One chunk (the usual case: the whole slice's fragments fit the LDS budget): contiguous
     // ranges per wave, [units*w/nwv, units*(w+1)/nwv); several chunks: unit u belongs to wave u % nwv so that every wave has rows in
     // every chunk.
     const bool one_chunk = a.chunk_blocks >= nb;
-    const int ubase = one_chunk ? (units * wave) / nwv : wave;
-    const int ustride = one_chunk ? 1 : nwv;
-    const int nunits_w = one_chunk ? (units * (wave + 1)) / nwv - ubase : (wave < units ? (units - wave + nwv - 1) / nwv : 0);
+    // WPC: every live wave walks ALL units of the slice (its own column block); the host guarantees one chunk
+    const int ubase = WPC ? 0 : (one_chunk ? (units * wave) / nwv : wave);
+    const int ustride = (WPC || one_chunk) ? 1 : nwv;
+    const int nunits_w = WPC ? (wave_live ? units : 0)
+                             : (one_chunk ? (units * (wave + 1)) / nwv - ubase : (wave < units ? (units - wave + nwv - 1) / nwv : 0));
 
     // LDS carve: fragments of one chunk [blk][tile row 8][row m][AH halves] | partials [nwv][MR][128] fp32 + per-wave row sums |
     //            tile-row sums [blk * 8][m] fp32 (RAW) | 1/rms per row [16] fp32 (NORM)
@@ -145,7 +191,12 @@ void exl3_gemv2_kernel(const GemvArgs a)
     // GEMV_IN_NORM: A is the fp16 residual stream; x = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)) is formed in the prep tasks, per
     // row from the per-block sums of squares a glue kernel left behind (same arithmetic and summation order as glue_norm_kernel /
     // rms_norm: norm.cu:20-120), so the RMSNorm between two linears costs no launch and no single-workgroup pass.
-    constexpr bool in_norm = MODE == G2_MODE_NORM;
+    constexpr bool in_norm = MODE == G2_MODE_NORM || MODE == G2_MODE_RNORM;
+    // RNORM: this launch also finishes the producer linear's output for the blocks it needs: resid_new = resid_in + out-had(slab sum) * svh.  The
+    // workgroups of column block 0 of matrix 0 (one per k-slice) publish resid_new and the per-block sums of squares; the row scale used here
+    // is the PREVIOUS residual's 1/rms (ss_part), corrected by whoever finishes this launch's outputs (GemvRescale)
+    constexpr bool RES = MODE == G2_MODE_RNORM;
+    const bool res_writer = RES && cbg == 0;                 // WPC: group 0 (= the first column blocks of matrix 0), one workgroup per k-slice
 
     // ---- streaming state: issue the first weight rows before anything else
     const int T = lane >> 3, c = lane & 7;
@@ -164,15 +215,16 @@ void exl3_gemv2_kernel(const GemvArgs a)
     // operands: one memory latency, no extra workgroup barrier); otherwise 1/rms per row goes through LDS (rmf_s) once per launch.
     const bool norm_in_task = in_norm && NG == 1 && (a.k >> 7) <= 32;
     // ACT mode: the first 8 gate and 8 up slab lines of the task's block travel with the task operands (issued before the weight rows)
-    constexpr int ACT_PRE = MODE == G2_MODE_ACT ? 8 : 1;
-    struct PrepIn { half4_t xv, sv, wv; float ss; float4_t sg[ACT_PRE], su[ACT_PRE]; half4_t svg, svu; };
+    constexpr int ACT_PRE = MODE == G2_MODE_ACT ? 8 : (MODE == G2_MODE_WACT ? 2 : 1);   // WPC layouts: 128-VGPR budget
+    constexpr int SLAB_PRE = MODE == G2_MODE_ACT ? 8 : (MODE == G2_MODE_WACT ? 2 : (RES ? 4 : 1));                // slab lines of the first set that travel with the task operands
+    struct PrepIn { half4_t xv, sv, wv; float ss, ssn; float4_t sg[SLAB_PRE], su[ACT_PRE]; half4_t svg, svu; };
     auto fetch = [&] (int c0, int cnt, int it) -> PrepIn
     {
-        PrepIn r; r.xv = half4_t{ 0, 0, 0, 0 }; r.sv = r.xv; r.wv = r.xv; r.ss = 0.0f;
+        PrepIn r; r.xv = half4_t{ 0, 0, 0, 0 }; r.sv = r.xv; r.wv = r.xv; r.ss = 0.0f; r.ssn = 0.0f;
         const int t = min(it * nhw + hwid, cnt * m - 1);
         const int blk = c0 + t / m, row = t % m;
         const size_t kofs = (size_t) k0s + 128 * blk;
-        if constexpr (MODE != G2_MODE_ACT) r.xv = ((const half4_t*) (x_src + (size_t) row * a.k + kofs))[l32];
+        if constexpr (!G2_IS_ACT(MODE)) r.xv = ((const half4_t*) (x_src + (size_t) row * a.k + kofs))[l32];
         else
         {
             const int blk_abs = (k0s >> 7) + blk;
@@ -187,6 +239,20 @@ void exl3_gemv2_kernel(const GemvArgs a)
             }
             r.svg = ((const half4_t*) (a.act_svh_g + blk_abs * 128))[l32];
             r.svu = ((const half4_t*) (a.act_svh_u + blk_abs * 128))[l32];
+            if (a.act_rs.ss_new)
+            {
+                const int nbh = a.act_rs.k >> 7;
+                if (l32 < nbh) { r.ss = a.act_rs.ss_prev[(size_t) row * nbh + l32]; r.ssn = a.act_rs.ss_new[(size_t) row * nbh + l32]; }
+            }
+        }
+        if constexpr (RES)
+        {
+            const int blk_abs = (k0s >> 7) + blk;
+            const float* pg = a.rs_slab + ((size_t) blk_abs * a.rs_S * m + row) * 128;
+            const size_t st = (size_t) m * 128;
+            #pragma unroll
+            for (int i = 0; i < SLAB_PRE; ++i) r.sg[i] = ((const float4_t*) (pg + (size_t) min(i, a.rs_S - 1) * st))[l32];
+            r.svg = ((const half4_t*) (a.rs_svh + blk_abs * 128))[l32];
         }
         if (!in_rotated)
         {
@@ -205,11 +271,11 @@ void exl3_gemv2_kernel(const GemvArgs a)
     // ... and only then the first weight rows: loads return in issue order per wave, so with the weights first the (small, L2-resident)
     // activation operands could not be consumed -- and the input Hadamards could not start -- before the first weight rows had arrived from
     // HBM; this way the prep computes underneath the weight latency
-    LaneWords<K> ring[G2_PF];
+    LaneWords<K> ring[PF];
     if (nunits_w > 0)
     {
         #pragma unroll
-        for (int u = 0; u < G2_PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) (G2_PF * ubase + u) * row_stride);
+        for (int u = 0; u < PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) (PF * ubase + u) * row_stride);
     }
     G2_T(1);
 
@@ -252,7 +318,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
             {
                 const PrepIn cur = nx;
                 // software pipelining by one task, except in ACT mode where a task's operands are 64 VGPRs of slab lines (fetched after the task)
-                if constexpr (MODE != G2_MODE_ACT) { if (it + 1 < trips) nx = fetch(c0, cnt, it + 1); }
+                if constexpr (!G2_IS_ACT(MODE) && !RES) { if (it + 1 < trips) nx = fetch(c0, cnt, it + 1); }
                 const int t = it * nhw + hwid;
                 const bool act = t < ntask;
                 const int tc = min(t, ntask - 1);
@@ -265,7 +331,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 else
                 {
                     half4_t xv = cur.xv;
-                    if constexpr (MODE == G2_MODE_ACT)
+                    if constexpr (G2_IS_ACT(MODE))
                     {
                         // a = fp16(silu(g) * u) of this (row, block): split-k reduce of the gate / up slabs, output Hadamards, svh -- the arithmetic of
                         // glue_act_kernel (same device functions), done by the half-wave that needs the block
@@ -279,19 +345,73 @@ void exl3_gemv2_kernel(const GemvArgs a)
                             vg.x += cur.sg[i].x; vg.y += cur.sg[i].y; vg.z += cur.sg[i].z; vg.w += cur.sg[i].w;
                             vu.x += cur.su[i].x; vu.y += cur.su[i].y; vu.z += cur.su[i].z; vu.w += cur.su[i].w;
                         }
-                        for (int sl = ACT_PRE; sl < a.act_S; ++sl)
+                        for (int sl = ACT_PRE; sl < a.act_S; sl += 4)        // further slices: 4 + 4 independent loads per round, slice-order sums
                         {
-                            const float4_t tg = ((const float4_t*) (a.act_g + (((size_t) blk_abs * a.act_S + sl) * m + row) * 128))[l32];
-                            const float4_t tu = ((const float4_t*) (a.act_u + (((size_t) blk_abs * a.act_S + sl) * m + row) * 128))[l32];
-                            vg.x += tg.x; vg.y += tg.y; vg.z += tg.z; vg.w += tg.w; vu.x += tu.x; vu.y += tu.y; vu.z += tu.z; vu.w += tu.w;
+                            float4_t tg[4], tu[4];
+                            const float* pg = a.act_g + ((size_t) blk_abs * a.act_S * m + row) * 128;
+                            const float* pu = a.act_u + ((size_t) blk_abs * a.act_S * m + row) * 128;
+                            #pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                            {
+                                tg[i] = ((const float4_t*) (pg + (size_t) min(sl + i, a.act_S - 1) * m * 128))[l32];
+                                tu[i] = ((const float4_t*) (pu + (size_t) min(sl + i, a.act_S - 1) * m * 128))[l32];
+                            }
+                            #pragma unroll
+                            for (int i = 0; i < 4; ++i) if (sl + i < a.act_S)
+                            {
+                                vg.x += tg[i].x; vg.y += tg[i].y; vg.z += tg[i].z; vg.w += tg[i].w;
+                                vu.x += tu[i].x; vu.y += tu[i].y; vu.z += tu[i].z; vu.w += tu[i].w;
+                            }
                         }
                         float g0, g1, g2, g3, u0, u1, u2, u3;
                         out_had(vg, l32, g0, g1, g2, g3);
                         out_had(vu, l32, u0, u1, u2, u3);
+                        if (a.act_rs.ss_new)
+                        {
+                            // gate / up were computed from fp16(x * w * r_prev): apply r_new / r_prev (exact sums of squares of the new residual)
+                            const float rsc = gemv_rescale(a.act_rs, row, l32, cur.ss, cur.ssn);
+                            g0 *= rsc; g1 *= rsc; g2 *= rsc; g3 *= rsc; u0 *= rsc; u1 *= rsc; u2 *= rsc; u3 *= rsc;
+                        }
                         const half4_t gh = half4_t{ f2h(g0), f2h(g1), f2h(g2), f2h(g3) } * svg;
                         const half4_t uh = half4_t{ f2h(u0), f2h(u1), f2h(u2), f2h(u3) } * svu;
                         auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
                         xv = half4_t{ silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
+                    }
+                    if constexpr (RES)
+                    {
+                        // resid_new of this (row, block): the arithmetic of glue_resid_kernel (same device functions, slice-order slab sum)
+                        const int blk_abs = (k0s >> 7) + c0 + blk_l;
+                        float4_t vy = { 0.f, 0.f, 0.f, 0.f };
+                        #pragma unroll
+                        for (int i = 0; i < SLAB_PRE; ++i) if (i < a.rs_S) { vy.x += cur.sg[i].x; vy.y += cur.sg[i].y; vy.z += cur.sg[i].z; vy.w += cur.sg[i].w; }
+                        // further slices: independent loads in batches of 8 (a load-add chain costs a memory latency per slab line: 5 us at 16 slices)
+                        for (int sl = SLAB_PRE; sl < a.rs_S; sl += 8)
+                        {
+                            float4_t ty[8];
+                            const float* pl = a.rs_slab + ((size_t) blk_abs * a.rs_S * m + row) * 128;
+                            #pragma unroll
+                            for (int i = 0; i < 8; ++i) ty[i] = ((const float4_t*) (pl + (size_t) min(sl + i, a.rs_S - 1) * m * 128))[l32];
+                            #pragma unroll
+                            for (int i = 0; i < 8; ++i) if (sl + i < a.rs_S) { vy.x += ty[i].x; vy.y += ty[i].y; vy.z += ty[i].z; vy.w += ty[i].w; }
+                        }
+                        float h0, h1, h2, h3;
+                        out_had(vy, l32, h0, h1, h2, h3);
+                        const half4_t sc = cur.svg;
+                        h0 *= (float) sc.x; h1 *= (float) sc.y; h2 *= (float) sc.z; h3 *= (float) sc.w;
+                        xv = half4_t{ f2h((float) xv.x + h0), f2h((float) xv.y + h1), f2h((float) xv.z + h2), f2h((float) xv.w + h3) };
+                        if (res_writer)
+                        {
+                            const float r0 = (float) xv.x, r1 = (float) xv.y, r2 = (float) xv.z, r3 = (float) xv.w;
+                            float ssq = r0 * r0;
+                            ssq = __builtin_fmaf(r1, r1, ssq); ssq = __builtin_fmaf(r2, r2, ssq); ssq = __builtin_fmaf(r3, r3, ssq);
+                            #pragma unroll
+                            for (int i = 1; i < 32; i <<= 1) ssq += xor_lane(ssq, i);
+                            if (act)
+                            {
+                                ((half4_t*) (a.rs_resid_out + (size_t) row * a.k + (size_t) blk_abs * 128))[l32] = xv;
+                                if (l32 == 0) a.rs_ss_out[(size_t) row * (a.k >> 7) + blk_abs] = ssq;
+                            }
+                        }
                     }
                     if constexpr (in_norm)
                     {
@@ -304,8 +424,8 @@ void exl3_gemv2_kernel(const GemvArgs a)
                             r = __frsqrt_rn((0.0f + s2) / (float) a.k + a.eps);
                         }
                         else r = rmf_s[row];
-                        xv = half4_t{ f2h((float) cur.xv.x * (float) cur.wv.x * r), f2h((float) cur.xv.y * (float) cur.wv.y * r),
-                                      f2h((float) cur.xv.z * (float) cur.wv.z * r), f2h((float) cur.xv.w * (float) cur.wv.w * r) };
+                        xv = half4_t{ f2h((float) xv.x * (float) cur.wv.x * r), f2h((float) xv.y * (float) cur.wv.y * r),
+                                      f2h((float) xv.z * (float) cur.wv.z * r), f2h((float) xv.w * (float) cur.wv.w * r) };
                     }
                     xv = xv * cur.sv;
                     float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
@@ -348,14 +468,14 @@ void exl3_gemv2_kernel(const GemvArgs a)
                         *((half2_t*) (base + (q0 + 1) * 4 + sp * 2)) = o23;
                     }
                 }
-                if constexpr (MODE == G2_MODE_ACT) { if (it + 1 < trips) nx = fetch(c0, cnt, it + 1); }
+                if constexpr (G2_IS_ACT(MODE) || RES) { if (it + 1 < trips) nx = fetch(c0, cnt, it + 1); }
             }
         }
         __syncthreads();
         if (c0 == 0) { G2_T(2); }
 
         const int row_end = (c0 + cnt) * 8;                             // slice-local tile row bound of the chunk
-        const int u_end = min(nunits_w, (G2_PF * ubase < row_end) ? ((row_end / G2_PF - 1 - ubase) / ustride + 1) : 0);   // this wave's first unit index beyond the chunk
+        const int u_end = min(nunits_w, (PF * ubase < row_end) ? ((row_end / PF - 1 - ubase) / ustride + 1) : 0);   // this wave's first unit index beyond the chunk
         if constexpr (RAW)
         {
             // sum(x) over the tile rows this wave streams in this chunk, per activation row of the half-wave: lane i takes the wave's
@@ -369,9 +489,9 @@ void exl3_gemv2_kernel(const GemvArgs a)
                     float v = 0.0f;
                     for (int i = ui + l32; i < u_end; i += 32)
                     {
-                        const float* tsr = tsum + (size_t) (G2_PF * (ubase + i * ustride) - c0 * 8) * m + rowp;
+                        const float* tsr = tsum + (size_t) (PF * (ubase + i * ustride) - c0 * 8) * m + rowp;
                         #pragma unroll
-                        for (int rr = 0; rr < G2_PF; ++rr) v += tsr[rr * m];
+                        for (int rr = 0; rr < PF; ++rr) v += tsr[rr * m];
                     }
                     #pragma unroll
                     for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
@@ -384,10 +504,10 @@ void exl3_gemv2_kernel(const GemvArgs a)
         for (; ui < u_end; ++ui)                                       // plain counted loop: an early exit made the compiler drain vmcnt every iteration
         {
             const int unit = ubase + ui * ustride;
-            const int row0 = G2_PF * unit;
+            const int row0 = PF * unit;
             const int nxt = min(unit + ustride, last_unit);                // next unit of this wave (clamped: a harmless reload at the end)
             #pragma unroll
-            for (int u = 0; u < G2_PF; ++u)
+            for (int u = 0; u < PF; ++u)
             {
                 const int row = row0 + u;
                 uint32_t Wx[K + 1];
@@ -400,7 +520,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
 #endif
 
                 // refill the slot
-                load_lane_words<K>(ring[u], strip + (size_t) (G2_PF * nxt + u) * row_stride);
+                load_lane_words<K>(ring[u], strip + (size_t) (PF * nxt + u) * row_stride);
 
                 // A fragments of this tile row for this lane's activation row
                 const half_t* ap = arow + (size_t) (row - c0 * 8) * astep;
@@ -449,7 +569,9 @@ void exl3_gemv2_kernel(const GemvArgs a)
 #endif
                     }
 #ifndef G2_ABL_ILP
-                    __builtin_amdgcn_sched_barrier(0);  // bound live ranges: 8 weights in flight at a time (occupancy > ILP here)
+                    // bound live ranges: 8 weights in flight at a time (occupancy > ILP; letting the compiler overlap the quads in the 128-VGPR
+                    // wave-per-column-block layouts changed nothing: 81.9 vs 82.2 us per layer)
+                    __builtin_amdgcn_sched_barrier(0);
 #endif
                 });
             }
@@ -492,6 +614,31 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 if (row < m) { pw[row * 128 + col] = acc_c[gq][i]; pw[row * 128 + col + 8] = acc_d[gq][i]; }
             }
         }
+    }
+    if constexpr (WPC)
+    {
+        // the wave owns its column block for the whole slice: its partials ARE the slab lines.  Through the wave's own LDS rows for 16-byte
+        // coalesced stores (row r by half-wave r & 1); wave-level ordering only, no workgroup barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (wave_live)
+        {
+            const float* pw = part + (size_t) wave * MR * 128;
+            float* slab = a.workspace + ws_off + ((size_t) cbl * a.S + s) * (size_t) m * 128;
+            for (int row = hw; row < m; row += 2)
+                ((float4_t*) (slab + row * 128))[l32] = ((const float4_t*) (pw + row * 128))[l32];
+        }
+#ifdef G2_TIMING
+        if (tid == 0)
+        {
+            tstamp[4] = tstamp[5] = __builtin_amdgcn_s_memrealtime();
+            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) blockIdx.x * 8;
+            for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
+            uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            dbg[6] = xcc; dbg[7] = 0;
+        }
+#endif
+        return;
     }
     __syncthreads();
     G2_T(4);
@@ -597,8 +744,16 @@ template <int CB, int MODE>
 static void launch_mode(int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
     #define L(V, N) exl3_gemv2_kernel<G2_K, CB, V, N, MODE><<<grid, dim3(64 * nwv), lds, st>>>(args)
-    if (var == 0) { if (ng == 1) L(0, 1); else if (ng == 2) L(0, 2); else L(0, 4); }
-    else          { if (ng == 1) L(1, 1); else if (ng == 2) L(1, 2); else L(1, 4); }
+    if constexpr (G2_IS_ACT(MODE) || G2_IS_WPC(MODE))
+    {
+        // m <= 4 only (host-checked): one instantiation per variant
+        if (var == 0) L(0, 1); else L(1, 1);
+    }
+    else
+    {
+        if (var == 0) { if (ng == 1) L(0, 1); else if (ng == 2) L(0, 2); else L(0, 4); }
+        else          { if (ng == 1) L(1, 1); else if (ng == 2) L(1, 2); else L(1, 4); }
+    }
     #undef L
 }
 
@@ -606,6 +761,13 @@ template <int CB>
 static void launch_cb(int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
     if (args.tbl.B) launch_mode<CB, G2_MODE_TABLE>(var, ng, nwv, grid, lds, st, args);
+    else if (args.cpw > 0)
+    {
+        // wave-per-column-block layout (host: deferred output, m <= 4, one chunk)
+        if (args.flags & GEMV_IN_ACT) launch_mode<CB, G2_MODE_WACT>(var, ng, nwv, grid, lds, st, args);
+        else if (args.flags & GEMV_IN_RESID) launch_mode<CB, G2_MODE_RNORM>(var, ng, nwv, grid, lds, st, args);
+        else launch_mode<CB, G2_MODE_WPLAIN>(var, ng, nwv, grid, lds, st, args);
+    }
     else if (args.flags & GEMV_IN_ACT) launch_mode<CB, G2_MODE_ACT>(var, ng, nwv, grid, lds, st, args);
     else if (args.epi.mode != GEMV_EPI_NONE) launch_mode<CB, G2_MODE_TAIL>(var, ng, nwv, grid, lds, st, args);
     else if (args.flags & GEMV_IN_NORM) launch_mode<CB, G2_MODE_NORM>(var, ng, nwv, grid, lds, st, args);

@@ -10,7 +10,14 @@
 #define GEMV_OUT_DEFERRED 2   // write raw rotated-basis partial slabs [colblock][S][m][128] fp32; a glue kernel finishes
 #define GEMV_IN_NORM      4   // A is the residual stream: the kernel applies RMSNorm (norm_w, per-block sums of squares ss_part, eps) before the input Hadamard
 #define GEMV_IN_ACT       8   // input = silu(g) * u formed from the previous launch's gate / up slabs while the activation fragments are built
+#define GEMV_IN_RESID     16  // (with GEMV_IN_NORM) the residual stream is finished HERE: resid_new = resid_in + out-had(sum of the producer's split-k slabs) * svh,
+                              // per Hadamard block while the activation fragments are built (replaces the glue_resid launch).  The row scale of the
+                              // RMSNorm is taken from the PREVIOUS residual's sums of squares (ss_part); consumers of this launch's outputs
+                              // multiply by rsqrt(ms_new + eps) / rsqrt(ms_prev + eps) (GemvRescale) -- the linear map commutes with the scalar
 #define GEMV_MAX_MATS 4
+
+// r = rsqrt(sum(ss_new[row]) / k + eps) / rsqrt(sum(ss_prev[row]) / k + eps): the exact RMSNorm scale over the estimate a GEMV_IN_RESID launch used.
+struct GemvRescale { const float* ss_prev; const float* ss_new; int k; float eps; };
 
 struct GemvMat
 {
@@ -112,6 +119,8 @@ struct GemvArgs
     int c_fp32;
     int flags;             // GEMV_IN_ROTATED | GEMV_OUT_DEFERRED
     int chunk_blocks;      // gen 2: Hadamard blocks of activation fragments a wave keeps in LDS at a time
+    int cpw;               // > 0: wave-per-column-block layout (exl3_gemv2.kspec.hip G2_IS_WPC): column blocks per workgroup = waves per workgroup;
+                           // mat[i].cb_first then counts GROUPS of cpw column blocks (groups never straddle matrices)
     int64_t c_row_offset;  // first output row of this pass
     const half_t* norm_w;  // GEMV_IN_NORM: RMSNorm weight [k]
     const float* ss_part;  // GEMV_IN_NORM: [m][k/128] sums of squares of the residual blocks (exl3_glue_resid)
@@ -121,6 +130,10 @@ struct GemvArgs
     const float* act_g; const float* act_u;      // slab bases [inter/128][act_S][m][128] fp32 (the other workspace region)
     const half_t* act_svh_g; const half_t* act_svh_u;
     int act_S;
+    GemvRescale act_rs;                          // ACT mode: g, u came from a GEMV_IN_RESID launch (ss_new == nullptr: no rescale)
+    // RESID mode (GEMV_IN_NORM | GEMV_IN_RESID): A = resid_in (fp16 [m][k], read only); producer slabs [k/128][rs_S][m][128] + its svh; the
+    // workgroups of column block 0 of matrix 0 write resid_out (fp16 [m][k], a DIFFERENT buffer) and ss_out [m][k/128]
+    const float* rs_slab; const half_t* rs_svh; half_t* rs_resid_out; float* rs_ss_out; int rs_S;
     GemvEpi epi;
 };
 

@@ -230,6 +230,7 @@ struct QkvArgs
     int m, hq, hkv, rope_mode;                              // hq / hkv count 128-wide blocks (= heads at head_dim 128, head pairs at 64)
     int hd;
     float attn_factor;
+    GemvRescale rs;                                         // ss_new != nullptr: q, k, v came from an exl3_gemv_ex_resid launch (row scale correction)
 };
 
 template <int KB, int VB>
@@ -247,6 +248,8 @@ void glue_qkv_kernel(QkvArgs a)
     const int hi = kind == 0 ? head : (kind == 1 ? head - a.hq : head - a.hq - a.hkv);
     const SlabRef& sr = kind == 0 ? a.sq : (kind == 1 ? a.sk : a.sv);
     const half_t* svh = (kind == 0 ? a.svh_q : (kind == 1 ? a.svh_k : a.svh_v)) + hi * 128;
+    float rs_p = 0.0f, rs_n = 0.0f;
+    if (a.rs.ss_new && l < (a.rs.k >> 7)) { rs_p = a.rs.ss_prev[(size_t) row * (a.rs.k >> 7) + l]; rs_n = a.rs.ss_new[(size_t) row * (a.rs.k >> 7) + l]; }
     const float4_t ysum = slab_sum(sr, hi, row, a.m, l);            // slab loads in flight while the sin/cos table is built
     const int nfreq = a.hd >> 1;                                        // 64 (head_dim 128) or 32 (head_dim 64: two heads per block)
     for (int i = tid; i < a.m * nfreq; i += blockDim.x)
@@ -259,6 +262,7 @@ void glue_qkv_kernel(QkvArgs a)
     __syncthreads();
     float h0, h1, h2, h3;
     out_had(ysum, l, h0, h1, h2, h3);
+    if (a.rs.ss_new) { const float rsc = gemv_rescale(a.rs, row, l, rs_p, rs_n); h0 *= rsc; h1 *= rsc; h2 *= rsc; h3 *= rsc; }
     half4_t sc = ((const half4_t*) svh)[l];
     half4_t y = half4_t{ f2h(h0), f2h(h1), f2h(h2), f2h(h3) } * sc;       // fp16 output semantics of exl3_gemm
     if (kind != 2)
@@ -390,6 +394,19 @@ extern "C" int exl3_glue_qkv(const float* sq, const float* sk, const float* sv, 
                              int page_size, int k_bits, int v_bits, int m, int heads_q, int heads_kv, int head_dim, int rope_mode,
                              float attn_factor, void* stream)
 {
+    return exl3_glue_qkv_rs(sq, sk, sv, S, svh_q, svh_k, svh_v, q_out, k_out, v_out, inv_freq, positions, k_cache, k_scales, v_cache, v_scales,
+                            block_table, blocks_per_seq, page_size, k_bits, v_bits, m, heads_q, heads_kv, head_dim, rope_mode, attn_factor,
+                            nullptr, nullptr, 0, 0.0f, stream);
+}
+
+// exl3_glue_qkv for slabs produced by exl3_gemv_ex_resid: ss_prev / ss_new [m][hidden/128] + eps give the row scale correction (null: none)
+extern "C" int exl3_glue_qkv_rs(const float* sq, const float* sk, const float* sv, int S, const void* svh_q, const void* svh_k, const void* svh_v,
+                                void* q_out, void* k_out, void* v_out, const float* inv_freq, const int32_t* positions,
+                                void* k_cache, void* k_scales, void* v_cache, void* v_scales, const int32_t* block_table, int blocks_per_seq,
+                                int page_size, int k_bits, int v_bits, int m, int heads_q, int heads_kv, int head_dim, int rope_mode,
+                                float attn_factor, const float* ss_prev, const float* ss_new, int hidden, float eps, void* stream)
+{
+    EXL3_CHECK_ARG(!ss_new || (ss_prev && hidden > 0 && hidden % 128 == 0), "glue_qkv_rs: rescale needs ss_prev and hidden");
     EXL3_CHECK_ARG(sq && sk && sv && svh_q && svh_k && svh_v && q_out && inv_freq && positions, "glue_qkv: null pointer");
     EXL3_CHECK_ARG(head_dim == 128 || head_dim == 64, "glue_qkv: head_dim must be 128 or 64 (one or two heads per Hadamard block)");
     EXL3_CHECK_ARG((heads_q * head_dim) % 128 == 0 && (heads_kv * head_dim) % 128 == 0, "glue_qkv: heads * head_dim must be a multiple of 128");
@@ -405,6 +422,7 @@ extern "C" int exl3_glue_qkv(const float* sq, const float* sk, const float* sv, 
     a.k_cache = (uint32_t*) k_cache; a.k_scales = (half_t*) k_scales; a.v_cache = (uint32_t*) v_cache; a.v_scales = (half_t*) v_scales;
     a.block_table = block_table; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size > 0 ? page_size : 256;
     a.m = m; a.hq = heads_q * head_dim / 128; a.hkv = heads_kv * head_dim / 128; a.hd = head_dim; a.rope_mode = rope_mode; a.attn_factor = attn_factor;
+    a.rs = GemvRescale{ ss_prev, ss_new, hidden, eps };
     int tasks = m * (a.hq + 2 * a.hkv);
     dim3 grid((tasks + 7) / 8);
     hipStream_t st = (hipStream_t) stream;

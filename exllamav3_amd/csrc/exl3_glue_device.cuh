@@ -4,6 +4,30 @@
 #pragma once
 #include "exl3_common.cuh"
 
+#include "exl3_gemv_args.h"
+
+// r_new / r_prev of one row (GemvRescale): both sums in the fixed order every consumer of ss_part uses (32-lane tree per 32 blocks, then the
+// partial trees in sequence).  p0 / n0: the lane's first-32 values, loaded by the caller with its other operands (0 for lanes >= k/128).
+__device__ __forceinline__ float gemv_rescale(const GemvRescale& rs, int row, int l32, float p0, float n0)
+{
+    const int nb = rs.k >> 7;
+    float sp = 0.0f, sn = 0.0f;
+    for (int b0 = 0; b0 < nb; b0 += 32)
+    {
+        float vp = p0, vn = n0;
+        if (b0 > 0)
+        {
+            vp = (b0 + l32 < nb) ? rs.ss_prev[(size_t) row * nb + b0 + l32] : 0.0f;
+            vn = (b0 + l32 < nb) ? rs.ss_new[(size_t) row * nb + b0 + l32] : 0.0f;
+        }
+        #pragma unroll
+        for (int i = 1; i < 32; i <<= 1) { vp += xor_lane(vp, i); vn += xor_lane(vn, i); }
+        sp += vp; sn += vn;
+    }
+    const float rp = __frsqrt_rn(sp / (float) rs.k + rs.eps), rn = __frsqrt_rn(sn / (float) rs.k + rs.eps);
+    return rn / rp;
+}
+
 struct SlabRef { const float* base; int S; };       // slab(c, s, row) = base + ((c*S + s)*m + row)*128
 
 __device__ __forceinline__ float4_t slab_sum(const SlabRef& sr, int c, int row, int m, int l)

@@ -578,6 +578,17 @@ def glue_qkv(slabs, S: int, svh_q, svh_k, svh_v, q_out, k_out, v_out, inv_freq, 
                                     head_dim, rope_mode, float(attn_factor), _stream(q_out)))
 
 
+def glue_qkv_rs(slabs, S: int, svh_q, svh_k, svh_v, q_out, k_out, v_out, inv_freq, positions, k_cache, k_scales, v_cache, v_scales,
+                block_table, page_size: int, k_bits: int, v_bits: int, m: int, heads_q: int, heads_kv: int, head_dim: int,
+                ss_prev, ss_new, hidden: int, eps: float, rope_mode: int = 2, attn_factor: float = 1.0):
+    """glue_qkv for slabs written by exl3_gemv_ex_resid: q, k, v are multiplied by rsqrt(ms_new + eps) / rsqrt(ms_prev + eps) of their row."""
+    _dev(q_out)
+    _check(_lib.lib().exl3_glue_qkv_rs(slabs[0], slabs[1], slabs[2], S, _p(svh_q), _p(svh_k), _p(svh_v), _p(q_out), _p(k_out), _p(v_out),
+                                       _p(inv_freq), _p(positions), _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table),
+                                       block_table.shape[1] if block_table is not None else 0, page_size, k_bits, v_bits, m, heads_q, heads_kv,
+                                       head_dim, rope_mode, float(attn_factor), _p(ss_prev), _p(ss_new), int(hidden), float(eps), _stream(q_out)))
+
+
 def glue_act(slabs, S: int, svh_g, svh_u, suh_d, xh_d, xsum_d, m: int, a_out=None):
     _dev(xh_d)
     _check(_lib.lib().exl3_glue_act(slabs[0], slabs[1], S, _p(svh_g), _p(svh_u), _p(suh_d), _p(xh_d), _p(xsum_d), _p(a_out), m,
@@ -731,6 +742,49 @@ def exl3_gemv_ex_act(gu_slabs, gu_S: int, svh_g, svh_u, B, C, suh, svh, m: int, 
     S = ctypes.c_int(0)
     _check(_lib.lib().exl3_gemv_ex_act(gu_slabs[0], gu_slabs[1], gu_S, _p(svh_g), _p(svh_u), _p(B), _p(C), _p(suh), _p(svh), None, m, k,
                                        B.shape[1] * 16, K, _cb(mcg, mul1), int(c_fp32), flags, force_split, slab, ctypes.byref(S), _stream(B)))
+    return [int(slab[0]) if slab[0] else 0], S.value
+
+
+def exl3_gemv_ex_wpc(A, Bs, suhs, m: int, mcg: bool, mul1: bool, cpw: int, force_split: int = 0):
+    """exl3_gemv_ex(raw A, deferred) in the wave-per-column-block layout (cpw column blocks of one matrix per workgroup).  Returns (slabs, S)."""
+    _dev(A)
+    cnt = len(Bs)
+    k, K = _kK(Bs[0])
+    ns = (ctypes.c_int * cnt)(*[B.shape[1] * 16 for B in Bs])
+    slabs = (_vp * cnt)()
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_gemv_ex_wpc(_p(A), _parr(Bs), _parr(suhs), ns, cnt, m, k, K, _cb(mcg, mul1), int(cpw), force_split, slabs, ctypes.byref(S),
+                                       _stream(A)))
+    return [int(s) if s else 0 for s in slabs], S.value
+
+
+def exl3_gemv_ex_resid(resid_in, norm_w, ss_prev, eps: float, prod_slab: int, prod_S: int, prod_svh, resid_out, ss_out, Bs, suhs, m: int,
+                       mcg: bool, mul1: bool, force_split: int = 0, cpw: int = 4):
+    """glue_resid + exl3_gemv_ex_norm in one launch (m <= 4): the residual add of the producer linear (its deferred slabs prod_slab / prod_S +
+    prod_svh) is finished inside this GEMV; column-block-0 workgroups write resid_out (a different buffer than resid_in) and ss_out.  The RMSNorm
+    scale applied here is resid_in's (ss_prev); finish this launch's slabs with glue_qkv_rs / exl3_gemv_ex_act_rs.  Returns (slabs, S)."""
+    _dev(resid_in)
+    cnt = len(Bs)
+    k, K = _kK(Bs[0])
+    ns = (ctypes.c_int * cnt)(*[B.shape[1] * 16 for B in Bs])
+    slabs = (_vp * cnt)()
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_gemv_ex_resid(_p(resid_in), _p(norm_w), _p(ss_prev), float(eps), prod_slab, prod_S, _p(prod_svh), _p(resid_out), _p(ss_out),
+                                         _parr(Bs), _parr(suhs), ns, cnt, m, k, K, _cb(mcg, mul1), int(cpw), force_split, slabs, ctypes.byref(S),
+                                         _stream(resid_in)))
+    return [int(s) if s else 0 for s in slabs], S.value
+
+
+def exl3_gemv_ex_act_rs(gu_slabs, gu_S: int, svh_g, svh_u, ss_prev, ss_new, hidden: int, eps: float, B, C, suh, svh, m: int, mcg: bool, mul1: bool,
+                        flags: int = 0, force_split: int = 0, c_fp32: bool = False, cpw: int = 0):
+    """exl3_gemv_ex_act for gate / up slabs written by exl3_gemv_ex_resid (row scale correction from ss_prev / ss_new)."""
+    _dev(B)
+    k, K = _kK(B)
+    slab = (_vp * 1)()
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_gemv_ex_act_rs(gu_slabs[0], gu_slabs[1], gu_S, _p(svh_g), _p(svh_u), _p(ss_prev), _p(ss_new), int(hidden), float(eps),
+                                          _p(B), _p(C), _p(suh), _p(svh), None, m, k, B.shape[1] * 16, K, _cb(mcg, mul1), int(c_fp32), flags,
+                                          int(cpw), force_split, slab, ctypes.byref(S), _stream(B)))
     return [int(slab[0]) if slab[0] else 0], S.value
 
 

@@ -277,6 +277,9 @@ class SyntheticEXL3Llama:
         self.xs3 = [torch.empty((bsz, nb_h), dtype=f32, device=dev) for _ in range(3)]
         self.xh_d = torch.empty((bsz, self.inter_local), dtype=f16, device=dev)
         self.ss = torch.empty((bsz, nb_h), dtype=f32, device=dev)
+        # decode_step_resid ping-pongs the residual stream and its per-block sums of squares between two buffers
+        self.x2 = torch.empty((bsz, s.hidden), dtype=f16, device=dev)
+        self.ss2 = torch.empty((bsz, nb_h), dtype=f32, device=dev)
         # decode attention straight from the quantized cache (optional, head_dim 128): output, lengths incl. the new token, split partials
         self.attn_pos = pos
         self.attn_out = torch.empty((bsz, self.hq, hd), dtype=f16, device=dev)
@@ -443,6 +446,67 @@ class SyntheticEXL3Llama:
                                   bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
         return self.logits
 
+    def decode_step_resid(self):
+        """Decode step with the residual adds folded into the consumer GEMVs: 5 launches per layer at batch <= 4, TP = 1
+        (q|k|v [resid-in + norm], glue_qkv, o, gate|up [resid-in + norm], down [act-in]).  A GEMV_IN_RESID launch rebuilds
+        resid += linear_out of the PREVIOUS linear from its split-k slabs for the Hadamard blocks of its own k-slice, normalises with the previous
+        residual's 1/rms and lets the consumers of its outputs apply r_new / r_prev (the quantized linear commutes with the row scalar).  Other
+        configurations (TP, batch > 4, mixed-kind groups) take decode_step_fused."""
+        bsz = self._state_bsz
+        same = all(_same_kind(L["q"], L["k"], L["v"]) and _same_kind(L["gate"], L["up"]) for L in self.layers)
+        if self.tp != 1 or bsz > 4 or not same:
+            return self.decode_step_fused()
+        sp, hd, hidden = self.split, self.shape.head_dim, self.shape.hidden
+        DEF = ext.GEMV_OUT_DEFERRED
+        xc, xa, sc, sa = self.x, self.x2, self.ss, self.ss2               # current / alternate residual + sums of squares
+        xc.copy_(self.x0)
+        q2 = self.q.view(bsz, -1)
+        ext.glue_resid(None, 0, None, None, xc, sc, bsz)                  # sums of squares of the embedding row(s)
+        pend = None                                                        # (slab, S, svh) of the down_proj whose output is not yet in the residual
+        # (column blocks per workgroup, k-slices) of the wave-per-column-block launches; tools/sweep_resid.py tunes these
+        # o_proj / down_proj (32 column blocks) stay in the classic layout (cpw 0: the waves of a workgroup split the k-slice)
+        wq, wo, wg, wd = sp.get("qkv_resid", (4, 16)), sp.get("o_resid", (0, 0)), sp.get("gu_resid", (14, 16)), sp.get("down_resid", (0, 0))
+        for li, L in enumerate(self.layers):
+            lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
+            kc, ks = self.kcache[li]
+            vc, vs = self.vcache[li]
+            if pend is None:
+                slabs, S = ext.exl3_gemv_ex_norm(xc, L["norm1"], sc, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh],
+                                                 None, bsz, lq.mcg, lq.mul1, DEF, sp["qkv"])
+                ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                             self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd)
+            else:
+                slabs, S = ext.exl3_gemv_ex_resid(xc, L["norm1"], sc, self.eps, pend[0], pend[1], pend[2], xa, sa,
+                                                  [lq.trellis, lk.trellis, lv.trellis], [lq.suh, lk.suh, lv.suh], bsz, lq.mcg, lq.mul1, wq[1], wq[0])
+                ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                                self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, sa, hidden, self.eps)
+                xc, xa, sc, sa = xa, xc, sa, sc
+            o_in = q2
+            if self.with_attention and hd == 128:
+                ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
+                                       self.attn_pos + 1, workspace=self.attn_ws)
+                o_in = self.attn_out.view(bsz, -1)
+            if wo[0] > 0:
+                so, So = ext.exl3_gemv_ex_wpc(o_in, [lo.trellis], [lo.suh], bsz, lo.mcg, lo.mul1, wo[0], wo[1])
+            else:
+                so, So = ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, wo[1])
+            sgu, Sgu = ext.exl3_gemv_ex_resid(xc, L["norm2"], sc, self.eps, so[0], So, lo.svh, xa, sa, [lg.trellis, lu.trellis], [lg.suh, lu.suh],
+                                              bsz, lg.mcg, lg.mul1, wg[1], wg[0])
+            sd, Sd = ext.exl3_gemv_ex_act_rs(sgu, Sgu, lg.svh, lu.svh, sc, sa, hidden, self.eps, ld.trellis, None, ld.suh, None, bsz, ld.mcg, ld.mul1,
+                                             DEF, wd[1], cpw=wd[0])
+            xc, xa, sc, sa = xa, xc, sa, sc
+            pend = (sd[0], Sd, ld.svh)
+        ext.glue_resid(pend[0], pend[1], pend[2], None, xc, sc, bsz)
+        self.x_final = xc
+        if self.rotate_for_head:
+            ext.glue_rotate(xc, sc, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz)
+            ext.exl3_gemv_ex(None, self.xh3[:1], None, [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
+                             bsz, self.lm_head.mcg, self.lm_head.mul1, ext.GEMV_IN_ROTATED)
+        else:
+            ext.exl3_gemv_ex_norm(xc, self.final_norm, sc, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
+                                  bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
+        return self.logits
+
     def decode_step_fused_v1(self):
         """First-generation glue pipeline: RMSNorm + input Hadamards in a single-workgroup glue_norm launch (kept as the
         comparison baseline for decode_step_fused; same bits)."""
@@ -539,6 +603,7 @@ class SyntheticEXL3Llama:
         if pipeline is True: pipeline = "glue"
         if pipeline is False: pipeline = "unfused"
         if self.tp != 1 and pipeline == "tail": pipeline = "glue"
+        if pipeline == "resid" and (self.tp != 1 or self._state_bsz > 4): pipeline = "glue"
         bsz, hd = self._state_bsz, self.shape.head_dim
         q2, k2, v2 = self.q.view(bsz, -1), self.k.view(bsz, -1), self.v.view(bsz, -1)
         ROT, DEF = ext.GEMV_IN_ROTATED, ext.GEMV_OUT_DEFERRED
@@ -561,6 +626,30 @@ class SyntheticEXL3Llama:
                 calls.append(lambda ld=ld, lq=lq, lk=lk, lv=lv, L=L: ext.exl3_gemv_norm(
                     None, self.xh_d, self.xs_d, ld.trellis, None, ld.svh, None, bsz, ld.mcg, ld.mul1, self.x, L["norm1"], self.eps,
                     [lq.suh, lk.suh, lv.suh], self.xh3, self.xs3))
+            elif pipeline == "resid" and self.tp == 1 and bsz <= 4:
+                # decode_step_resid's four GEMV launches per layer; producer slabs of one sample launch each stand in for the chain (timing only)
+                sp, hidden = self.split, self.shape.hidden
+                wq, wo, wg, wd = sp.get("qkv_resid", (4, 16)), sp.get("o_resid", (0, 0)), sp.get("gu_resid", (14, 16)), sp.get("down_resid", (0, 0))
+                if wo[0] > 0:
+                    o_call = lambda lo=lo: ext.exl3_gemv_ex_wpc(q2, [lo.trellis], [lo.suh], bsz, lo.mcg, lo.mul1, wo[0], wo[1])
+                else:
+                    o_call = lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, wo[1])
+                if li == 0:
+                    so0 = o_call()
+                    gu0 = ext.exl3_gemv_ex_resid(self.x, L["norm2"], self.ss, self.eps, so0[0][0], so0[1], lo.svh, self.x2, self.ss2,
+                                                 [lg.trellis, lu.trellis], [lg.suh, lu.suh], bsz, lg.mcg, lg.mul1, wg[1], wg[0])
+                    sd0 = ext.exl3_gemv_ex_act_rs(gu0[0], gu0[1], lg.svh, lu.svh, self.ss, self.ss2, hidden, self.eps, ld.trellis, None, ld.suh, None,
+                                                  bsz, ld.mcg, ld.mul1, DEF, wd[1], cpw=wd[0])
+                calls.append(lambda lq=lq, lk=lk, lv=lv, L=L, ld=ld: ext.exl3_gemv_ex_resid(
+                    self.x, L["norm1"], self.ss, self.eps, sd0[0][0], sd0[1], ld.svh, self.x2, self.ss2, [lq.trellis, lk.trellis, lv.trellis],
+                    [lq.suh, lk.suh, lv.suh], bsz, lq.mcg, lq.mul1, wq[1], wq[0]))
+                calls.append(o_call)
+                calls.append(lambda lg=lg, lu=lu, L=L, lo=lo: ext.exl3_gemv_ex_resid(
+                    self.x, L["norm2"], self.ss, self.eps, so0[0][0], so0[1], lo.svh, self.x2, self.ss2, [lg.trellis, lu.trellis], [lg.suh, lu.suh],
+                    bsz, lg.mcg, lg.mul1, wg[1], wg[0]))
+                calls.append(lambda ld=ld, lg=lg, lu=lu: ext.exl3_gemv_ex_act_rs(
+                    gu0[0], gu0[1], lg.svh, lu.svh, self.ss, self.ss2, hidden, self.eps, ld.trellis, None, ld.suh, None, bsz, ld.mcg, ld.mul1, DEF,
+                    wd[1], cpw=wd[0]))
             elif pipeline == "glue" and self.tp == 1 and bsz > 4:
                 # batches above 4 rows: the step rotates once (glue_rotate) and the GEMVs read pre-rotated inputs
                 calls.append(lambda lq=lq, lk=lk, lv=lv: ext.exl3_gemv_ex(None, self.xh3, None, [lq.trellis, lk.trellis, lv.trellis], None, None, None, bsz, lq.mcg, lq.mul1, ROT | DEF))

@@ -205,6 +205,30 @@ int exl3_glue_rotate(const void* resid, const float* ss_part, const void* w, flo
 
 /* down_proj on a = fp16(silu(g) * u) taken straight from the gate / up launch's deferred slabs (m <= 4): the reduce + output Hadamards +
  * svh + silu*mul (activation.cu) + input Hadamard of exl3_glue_act happen while this GEMV builds its activation fragments. */
+/* ---- residual add folded into the consumer GEMV (decode, m <= 4): 5 launches per Llama layer instead of 7 ------------------------------------
+ * exl3_gemv_ex_resid = exl3_glue_resid + exl3_gemv_ex_norm in one launch: every workgroup finishes the PRODUCER linear's output (its deferred split-k
+ * slabs: out-Hadamard, svh, + resid_in) for the Hadamard blocks of its own k-slice; the workgroups of column block 0 write resid_out (must differ
+ * from resid_in) and ss_out [m][k/128].  The RMSNorm scale applied to the activations is the one of resid_in (ss_prev); because the quantized
+ * linear is linear, whoever finishes this launch's slabs multiplies by r_new / r_prev (exl3_glue_qkv_rs, exl3_gemv_ex_act_rs) -- same value as
+ * rms_norm_res_in (norm.cu:193-299) + exl3_mgemm up to the rounding point of the normalised activation (fp16 at scale r_prev instead of r_new).
+ * Replaces the same reference graph nodes as exl3_glue_resid + exl3_gemv_ex_norm (libtorch/mlp.cpp:14-91, libtorch/attention.cpp:246-330). */
+int exl3_gemv_ex_resid(const void* resid_in, const void* norm_w, const float* ss_prev, float eps, const float* prod_slabs, int prod_S,
+                       const void* prod_svh, void* resid_out, float* ss_out, const void* const* Bs, const void* const* suhs, const int* ns,
+                       int count, int m, int k, int K, int cb, int cpw, int force_split, float** slabs_out, int* S_out, void* stream);
+/* exl3_gemv_ex (raw input, deferred output, m <= 4) in the wave-per-column-block layout used by the three launches above and below: `cpw` (1..16)
+ * column blocks of ONE matrix per workgroup, each wave streams the whole k-slice of its column block and writes its own slab.  The fused
+ * prologues then re-read the producer's slabs once per cpw column blocks instead of once per column block. */
+int exl3_gemv_ex_wpc(const void* A, const void* const* Bs, const void* const* suhs, const int* ns, int count, int m, int k, int K, int cb,
+                     int cpw, int force_split, float** slabs_out, int* S_out, void* stream);
+int exl3_gemv_ex_act_rs(const float* g_slabs, const float* u_slabs, int act_S, const void* svh_g, const void* svh_u,
+                        const float* ss_prev, const float* ss_new, int hidden, float eps,
+                        const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
+                        int c_fp32, int flags, int cpw /* 0: classic layout */, int force_split, float** slab_out, int* S_out, void* stream);
+int exl3_glue_qkv_rs(const float* sq, const float* sk, const float* sv, int S, const void* svh_q, const void* svh_k, const void* svh_v,
+                     void* q_out, void* k_out, void* v_out, const float* inv_freq, const int32_t* positions,
+                     void* k_cache, void* k_scales, void* v_cache, void* v_scales, const int32_t* block_table, int blocks_per_seq,
+                     int page_size, int k_bits, int v_bits, int m, int heads_q, int heads_kv, int head_dim, int rope_mode,
+                     float attn_factor, const float* ss_prev, const float* ss_new, int hidden, float eps, void* stream);
 int exl3_gemv_ex_act(const float* g_slabs, const float* u_slabs, int act_S, const void* svh_g, const void* svh_u,
                      const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
                      int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream);

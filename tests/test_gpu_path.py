@@ -632,3 +632,58 @@ def test_gemv_resid_tail_equals_gemv_plus_glue_resid(dev, k, n, m):
                 assert torch.equal(r1, r_ref), f"residual differs (rotated={rotated}, local={local}, rep={rep})"
                 assert torch.equal(ss1, ss_ref), f"sums of squares differ (rotated={rotated}, local={local}, rep={rep})"
     ext.set_tail_xcd_local(False)
+
+
+@pytest.mark.parametrize("cb", [0, 2])
+@pytest.mark.parametrize("bsz", [1, 3, 4])
+@pytest.mark.parametrize("K", [4, 3])
+def test_resid_in_gemv_pipeline_matches_oracle_and_glue_pipeline(dev, cb, bsz, K):
+    """decode_step_resid (5 launches per layer: the residual add of o_proj / down_proj is finished inside the next q|k|v / gate|up GEMV, RMSNorm
+    scale corrected downstream) against the oracle and the glue pipeline; graph replay reproduces the eager bits; the residual stream it
+    publishes equals the glue pipeline's to fp16 rounding."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    shape = LlamaShape("tiny", 512, 1024, 3, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=K, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(bsz, pos=700)
+    lf = model.decode_step_fused().float().cpu().numpy().copy()
+    xf = model.x.float().cpu().numpy().copy()
+    kf = [(kc.clone(), ks.clone()) for kc, ks in model.kcache]
+    for kc, ks in model.kcache + model.vcache:
+        kc.zero_(); ks.zero_()
+    lr = model.decode_step_resid().float().cpu().numpy().copy()
+    assert np.isfinite(lr).all()
+    ref = _oracle_decode(model, _np(model.x0))
+    rms = np.sqrt((ref ** 2).mean())
+    assert np.abs(lr - ref).max() / rms < 3e-2
+    assert np.abs(lr - lf).max() / rms < 1.5e-2
+    xr = model.x_final.float().cpu().numpy()
+    assert np.abs(xr - xf).max() / np.sqrt((xf ** 2).mean()) < 1e-2
+    # the quantized K append of every layer landed in the same slots with (nearly) the same scales
+    for (kc, ks), (kc0, ks0) in zip(model.kcache, kf):
+        assert bool(((ks != 0) == (ks0 != 0)).all())
+        assert float((ks.float() - ks0.float()).abs().max()) <= 0.02 * float(ks0.float().abs().max()) + 1e-3
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            model.decode_step_resid()
+    for _ in range(3):
+        model.logits.zero_(); g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(model.logits.float().cpu().numpy(), lr)
+
+
+def test_resid_in_gemv_pipeline_with_large_residual_scale_change(dev):
+    """The estimate r_prev may be far from r_new (a layer whose output dwarfs the residual): the correction r_new / r_prev keeps the result
+    within tolerance as long as fp16(x * w * r_prev) neither overflows nor flushes -- checked with a residual 50x smaller than the sublayer output."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 512, 1024, 2, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(1, pos=100)
+    model.x0.mul_(0.02)
+    lr = model.decode_step_resid().float().cpu().numpy().copy()
+    ref = _oracle_decode(model, _np(model.x0))
+    assert np.abs(lr - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
