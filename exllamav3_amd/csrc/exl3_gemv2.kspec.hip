@@ -272,6 +272,9 @@ void exl3_gemv2_kernel(const GemvArgs a)
     // activation operands could not be consumed -- and the input Hadamards could not start -- before the first weight rows had arrived from
     // HBM; this way the prep computes underneath the weight latency
     LaneWords<K> ring[PF];
+#ifdef G2_ABL_LATE_RING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // diagnostics build: the first weight rows are requested only after the task operands arrived
+#endif
     if (nunits_w > 0)
     {
         #pragma unroll

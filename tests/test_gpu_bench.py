@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-        "config", "roofline", "cpu_baseline"}
+        "config", "roofline", "cpu_baseline", "repeat_ms_per_step", "other_configs"}
 
 
 def _line(out: str) -> dict:
