@@ -105,6 +105,7 @@ def _declare(l):
     sig("exl3_dequant_cache_paged", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_silu_mul", vp, vp, vp, i64, i32, vp)
     sig("exl3_add", vp, vp, i64, i32, i32, vp)
+    sig("exl3_softcap", vp, vp, i64, f32, i32, vp)
     PP = ctypes.POINTER(vp)
     sig("exl3_gemv_ex", vp, PP, PP, PP, PP, PP, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
     sig("exl3_glue_norm", vp, i32, vp, vp, vp, vp, vp, f32, PP, PP, PP, i32, i32, i32, vp, vp)

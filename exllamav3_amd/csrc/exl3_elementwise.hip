@@ -264,3 +264,57 @@ extern "C" int exl3_add(void* x, const void* y, int64_t numel, int x_fp32, int y
     add_kernel<<<dim3((unsigned) ((n4 + 255) / 256)), dim3(256), 0, (hipStream_t) stream>>>(x, y, n4, x_fp32, y_fp32);
     return exl3_check_launch("add");
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// softcap(x, y, scale): y = scale * tanh(x / scale), fp32 math, fp16 or fp32 tensors, in place allowed (softcap.cu:11-100; applied by
+// Linear.forward after the quantized linear for models with logit / attention soft-capping, modules/linear.py:598-599).
+// HBM-bound element-wise pass: 16 bytes per lane.
+// ------------------------------------------------------------------------------------------------
+template <bool FP32>
+__global__ __launch_bounds__(256)
+void softcap_kernel(const void* __restrict__ x, void* __restrict__ y, int64_t numel, float scale)
+{
+    constexpr int V = FP32 ? 4 : 8;
+    const int64_t i0 = ((int64_t) blockIdx.x * 256 + threadIdx.x) * V;
+    if (i0 >= numel) return;
+    const float inv = 1.0f / scale;
+    if (i0 + V <= numel)
+    {
+        if constexpr (FP32)
+        {
+            float4_t v = *((const float4_t*) ((const float*) x + i0));
+            v = float4_t{ tanhf(v.x / scale) * scale, tanhf(v.y / scale) * scale, tanhf(v.z / scale) * scale, tanhf(v.w / scale) * scale };
+            *((float4_t*) ((float*) y + i0)) = v;
+        }
+        else
+        {
+            half8_t v = *((const half8_t*) ((const half_t*) x + i0));
+            half8_t o;
+            #pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = f2h(tanhf((float) v[i] / scale) * scale);
+            *((half8_t*) ((half_t*) y + i0)) = o;
+        }
+    }
+    else
+    {
+        for (int64_t i = i0; i < numel; ++i)
+        {
+            if constexpr (FP32) ((float*) y)[i] = tanhf(((const float*) x)[i] / scale) * scale;
+            else ((half_t*) y)[i] = f2h(tanhf((float) ((const half_t*) x)[i] / scale) * scale);
+        }
+    }
+    (void) inv;
+}
+
+extern "C" int exl3_softcap(const void* x, void* y, int64_t numel, float scale, int is_fp32, void* stream)
+{
+    EXL3_CHECK_ARG(x && y && numel >= 0, "softcap: null pointer");
+    EXL3_CHECK_ARG(scale != 0.0f, "softcap: scale must be non-zero");
+    if (numel == 0) return EXL3_OK;
+    const int V = is_fp32 ? 4 : 8;
+    const unsigned blocks = (unsigned) ((numel + (int64_t) 256 * V - 1) / ((int64_t) 256 * V));
+    if (is_fp32) softcap_kernel<true><<<blocks, 256, 0, (hipStream_t) stream>>>(x, y, numel, scale);
+    else softcap_kernel<false><<<blocks, 256, 0, (hipStream_t) stream>>>(x, y, numel, scale);
+    return exl3_check_launch("softcap");
+}

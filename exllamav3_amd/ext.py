@@ -365,6 +365,26 @@ class BC_LinearEXL3:
         return y
 
 
+class BC_LinearFP16:
+    """libtorch/linear.h:10-27, linear.cpp:11-25: unquantized fp16 Linear holder {weight (k, n), bias}: y = x @ weight (+ bias) through hgemm.
+    (The reference takes at::matmul_out when dtypes match and hgemm otherwise; both are the library GEMM.)"""
+
+    def __init__(self, weight, bias=None):
+        self.weight, self.bias = weight, bias
+
+    def run(self, x: torch.Tensor, y: torch.Tensor):
+        x2 = x.view(-1, x.shape[-1])
+        hgemm(x2, self.weight, y.view(x2.shape[0], -1))
+        if self.bias is not None:
+            y2 = y.view(x2.shape[0], -1)
+            add(y2, self.bias.view(1, -1).expand(x2.shape[0], -1).contiguous() if x2.shape[0] > 1 else self.bias)
+
+
+def __getattr__(name: str):
+    # PEP 562: anything the wider reference stack looks up that is not part of the EXL3 quantized-linear hot path (SURVEY.md 8)
+    raise AttributeError(f"exllamav3_ext (exllamav3_amd build): op '{name}' is outside the EXL3 quantized-linear hot path and is not provided")
+
+
 # --------------------------------------------------------------------------------------------------
 # norm / rope / cache / elementwise
 # --------------------------------------------------------------------------------------------------
@@ -531,6 +551,14 @@ def add(x, y):
     _dev(x)
     _req(x.numel() == y.numel(), "add: size mismatch")
     _check(_lib.lib().exl3_add(_p(x), _p(y), x.numel(), int(x.dtype == torch.float), int(y.dtype == torch.float), _stream(x)))
+
+
+def softcap(x, y, scale: float):
+    """softcap.cu:59-100 (same argument order): y = scale * tanh(x / scale); fp16 or fp32, in place when y is x."""
+    _dev(x)
+    _req(x.dtype == y.dtype and x.dtype in (torch.half, torch.float), "softcap: x, y must both be float16 or float32")
+    _req(x.numel() == y.numel() and x.is_contiguous() and y.is_contiguous(), "softcap: contiguous tensors of equal size")
+    _check(_lib.lib().exl3_softcap(_p(x), _p(y), x.numel(), float(scale), int(x.dtype == torch.float), _stream(x)))
 
 
 # --------------------------------------------------------------------------------------------------

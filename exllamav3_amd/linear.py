@@ -268,3 +268,38 @@ class ReconstructAhead:
 
     def end(self):
         torch.cuda.current_stream().wait_stream(self.side)
+
+
+
+class Linear:
+    """The module-level wrapper of the reference (modules/linear.py:32-120,561-602) around a quantized inner op, host logic only:
+      * in / out features are padded up to a multiple of `pad_to` (128 = the Hadamard block; modules/linear.py:69-72) -- the stored tensors
+        already have the padded shape;
+      * an input narrower than the padded weight is zero-extended (exact: the padded weight rows are zeros, :575-576);
+      * padded output columns are trimmed (contiguous copy) when `trim_padded_out` (:589-590);
+      * softcap (ext.softcap) and post_scale are applied after the inner op (:598-601).
+    LoRA, H capture and the unquantized / fp16 inner types are outside this path."""
+
+    def __init__(self, inner: LinearEXL3, in_features: int, out_features: int, pad_to: int = 128, trim_padded_out: bool = True,
+                 softcap: float = 0.0, post_scale: float = 1.0, out_dtype: torch.dtype | None = None):
+        self.in_features_unpadded, self.out_features_unpadded = in_features, out_features
+        self.in_features = (in_features + pad_to - 1) // pad_to * pad_to
+        self.out_features = (out_features + pad_to - 1) // pad_to * pad_to
+        if (inner.in_features, inner.out_features) != (self.in_features, self.out_features):
+            raise RuntimeError(f"Linear: inner op is {inner.in_features} x {inner.out_features}, expected the padded "
+                               f"{self.in_features} x {self.out_features}")
+        self.inner, self.trim_padded_out, self.softcap, self.post_scale, self.out_dtype = inner, trim_padded_out, softcap, post_scale, out_dtype
+
+    def forward(self, x: torch.Tensor, out_dtype: torch.dtype | None = None) -> torch.Tensor:
+        if self.out_features == 0:
+            return x.new_empty((*x.shape[:-1], 0), dtype=out_dtype or self.out_dtype or torch.half)
+        if x.shape[-1] < self.in_features:
+            x = torch.nn.functional.pad(x, (0, self.in_features - x.shape[-1]))
+        y = self.inner.forward(x.contiguous(), out_dtype=out_dtype or self.out_dtype)
+        if self.trim_padded_out and self.out_features != self.out_features_unpadded:
+            y = y[..., :self.out_features_unpadded].contiguous()
+        if self.softcap != 0.0:
+            ext.softcap(y, y, self.softcap)
+        if self.post_scale != 1.0:
+            y *= self.post_scale
+        return y

@@ -308,6 +308,9 @@ int exl3_dequant_cache_paged(const void* k_in, const void* k_scales, void* k_out
 int exl3_silu_mul(const void* g, const void* u, void* y, int64_t numel, int in_fp32, void* stream);
 /* x (fp16 or fp32) += y (fp16 or fp32) */
 int exl3_add(void* x, const void* y, int64_t numel, int x_fp32, int y_fp32, void* stream);
+/* softcap(x, y, scale)   softcap.cu:59-100: y = scale * tanh(x / scale) (fp32 math; fp16 or fp32 tensors; y == x allowed); Linear.forward's
+ * post-op for soft-capped logits (modules/linear.py:598-599) */
+int exl3_softcap(const void* x, void* y, int64_t numel, float scale, int is_fp32, void* stream);
 
 #ifdef __cplusplus
 }

@@ -485,6 +485,29 @@ def kv_dequant_paged(k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens
             vo[row] = kv_dequant(vi[row][None, :], vs[row][None, :], v_bits)[0]
 
 
+def softcap(x: np.ndarray, scale: float) -> np.ndarray:
+    """y = scale * tanh(x / scale) in fp32, rounded to x's dtype (exllamav3_ext/softcap.cu:11-52)."""
+    v = x.astype(np.float32) / np.float32(scale)
+    return (np.tanh(v).astype(np.float32) * np.float32(scale)).astype(x.dtype)
+
+
+def linear_wrapper_forward(x: np.ndarray, trellis, suh, svh, K: int, cb: int, out_features_unpadded: int, trim: bool = True,
+                           softcap_scale: float = 0.0, post_scale: float = 1.0, out_fp32: bool = False) -> np.ndarray:
+    """Linear.forward around the quantized inner op (modules/linear.py:561-602): zero-extend x to the padded in_features, inner forward, trim the
+    padded output columns, softcap, post_scale."""
+    k = suh.shape[0]
+    if x.shape[-1] < k:
+        x = np.concatenate([x, np.zeros(x.shape[:-1] + (k - x.shape[-1],), x.dtype)], axis=-1)
+    y = linear_forward(x, trellis, suh, svh, K, cb, out_fp32=out_fp32)
+    if trim and out_features_unpadded != y.shape[-1]:
+        y = np.ascontiguousarray(y[..., :out_features_unpadded])
+    if softcap_scale != 0.0:
+        y = softcap(y, softcap_scale)
+    if post_scale != 1.0:
+        y = (y.astype(np.float32) * np.float32(post_scale)).astype(y.dtype) if y.dtype == np.float16 else (y * np.float32(post_scale)).astype(np.float32)
+    return y
+
+
 # ------------------------------------------------------------------------------------------
 # Synthetic tensors (SURVEY 8d)
 # ------------------------------------------------------------------------------------------

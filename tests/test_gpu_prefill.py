@@ -254,3 +254,56 @@ def test_fused_qkv_route_strided_consumers(dev):
     lo.forward_add_residual(outs[0], r0)
     lo.forward_add_residual(outs[0].contiguous(), r1)
     assert float((r0.float() - r1.float()).abs().max()) < 2e-2 * float(r1.float().abs().max())
+
+
+@pytest.mark.parametrize("dt", [torch.half, torch.float])
+def test_softcap_matches_oracle(dev, dt):
+    """ext.softcap (softcap.cu): y = scale * tanh(x / scale), fp16 / fp32, in place and out of place, ragged tail."""
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(5)
+    for numel, scale in ((8 * 257 + 3, 30.0), (4096, 50.0), (5, 2.5)):
+        x = (rng.standard_normal(numel) * 40).astype(np.float16 if dt == torch.half else np.float32)
+        ref = o.softcap(x, scale).astype(np.float32)
+        tx = torch.from_numpy(x).to(dev)
+        ty = torch.empty_like(tx)
+        ext.softcap(tx, ty, scale)
+        assert np.allclose(ty.float().cpu().numpy(), ref, rtol=2e-3, atol=2e-3)
+        ext.softcap(tx, tx, scale)
+        assert torch.equal(tx, ty)
+
+
+@pytest.mark.parametrize("rows", [1, 7, 160])
+def test_linear_wrapper_pad_trim_softcap_post_scale(dev, rows):
+    """exllamav3_amd.linear.Linear (modules/linear.py:69-72,561-602): features not multiples of 128 -- input zero-extended to the padded width,
+    padded output columns trimmed, softcap and post_scale applied -- against the oracle composition, on the GEMV (rows <= 144) and the
+    reconstruct + GEMM (rows > 144) routes."""
+    from exllamav3_amd.linear import Linear, LinearEXL3
+    k_u, n_u, K, cb = 300, 200, 4, 2                    # padded: 384 x 256
+    tr, su, sv = o.synth_linear(384, 256, K, seed=21)
+    su[k_u:] = 0                                         # padded input channels carry no weight (modules/linear.py: "the padded weight rows are zeros")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    inner = LinearEXL3(384, 256, T(tr), T(su), T(sv), mcg=False, mul1=True)
+    lin = Linear(inner, k_u, n_u, softcap=30.0, post_scale=0.5)
+    assert (lin.in_features, lin.out_features) == (384, 256)
+    x = np.random.default_rng(rows).standard_normal((rows, k_u)).astype(np.float16)
+    y = lin.forward(T(x))
+    assert tuple(y.shape) == (rows, n_u) and y.is_contiguous()
+    ref = o.linear_wrapper_forward(x, tr, su, sv, K, cb, n_u, softcap_scale=30.0, post_scale=0.5).astype(np.float32)
+    err = np.abs(y.float().cpu().numpy() - ref).max() / np.sqrt((ref ** 2).mean())
+    assert err < 2e-2, err
+    with pytest.raises(RuntimeError):
+        Linear(inner, 300, 300)                          # inner op does not have the padded shape
+
+
+def test_bc_linear_fp16(dev):
+    """BC_LinearFP16 (libtorch/linear.h:10-27): y = x @ weight + bias through hgemm."""
+    from exllamav3_amd import ext
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    w = (torch.randn((256, 384), device=dev, generator=g) * 0.1).half()
+    b = torch.randn(384, device=dev, generator=g).half()
+    for rows in (1, 5):
+        x = torch.randn((rows, 256), device=dev, generator=g).half()
+        y = torch.empty((rows, 384), dtype=torch.half, device=dev)
+        ext.BC_LinearFP16(w, b).run(x, y)
+        ref = (x.float() @ w.float() + b.float())
+        assert float((y.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
