@@ -195,37 +195,57 @@ def main():
         pipeline = "glue"                                  # TP ranks all-reduce between o/down and the norm
     fused = pipeline != "unfused"
     run_step = {"tail": model.decode_step_tail, "glue": model.decode_step_fused, "resid": model.decode_step_resid, "unfused": model.decode_step}[pipeline]
-    run_step()
-    torch.cuda.synchronize()
-    graph = None
-    if not args.no_graph:
+    # tensor-parallel decode: the o_proj / down_proj all-reduces go through the one-shot IPC push (exl3_allreduce.hip, fused with the residual
+    # add) unless EXL3_HIP_TP_ALLREDUCE=rccl; the set-up self-tests against the collective library and every rank falls back together
+    ipc_on = False
+    if world > 1 and os.environ.get("EXL3_HIP_TP_ALLREDUCE", "ipc") == "ipc":
+        ipc_on = backend.enable_ipc_allreduce(max(args.batch, 1) * shape.hidden)
+
+    def capture():
+        run_step()
+        torch.cuda.synchronize()
+        g_ = None
+        if args.no_graph:
+            return None
         try:
             st = torch.cuda.Stream()
             st.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st):
                 run_step()
                 st.synchronize()
-                graph = torch.cuda.CUDAGraph()
+                g_ = torch.cuda.CUDAGraph()
                 # multi-rank: the process group's watchdog thread issues event queries of its own; thread-local capture mode keeps those from
                 # invalidating this thread's capture
-                with torch.cuda.graph(graph, stream=st, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
+                with torch.cuda.graph(g_, stream=st, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
                     run_step()
             torch.cuda.synchronize()
         except Exception as e:          # e.g. a collective that cannot be captured: fall back to eager launches
             if rank == 0:
                 print(f"bench.py: graph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-            graph = None
+            g_ = None
             try:
                 torch.cuda.synchronize()
             except Exception:
                 pass
         if world > 1:
             # all ranks must agree on the mode (a rank replaying a graph while another launches eagerly would deadlock RCCL)
-            ok = torch.tensor([1.0 if graph is not None else 0.0], dtype=torch.float64, device=dev)
+            ok = torch.tensor([1.0 if g_ is not None else 0.0], dtype=torch.float64, device=dev)
             neg = -ok
             backend.all_reduce_max(neg)                 # max(-ok) = -min(ok)
             if float(neg.item()) != -1.0:
-                graph = None
+                g_ = None
+        return g_
+
+    graph = capture()
+    if ipc_on:
+        # a peer that never arrived leaves the error word set (bounded spins): then every rank drops to RCCL and captures again
+        err = torch.tensor([float(backend.ipc.error())], dtype=torch.float64, device=dev)
+        backend.all_reduce_max(err)
+        if float(err.item()) != 0.0:
+            if rank == 0:
+                print("bench.py: IPC all-reduce reported a timed-out peer; falling back to RCCL all-reduce", file=sys.stderr)
+            backend.ipc.close(); backend.ipc = None; ipc_on = False
+            graph = capture()
     def step():
         if graph is not None:
             graph.replay()
@@ -259,6 +279,30 @@ def main():
         eb = torch.tensor([time.perf_counter() - ta], dtype=torch.float64, device=dev)
         backend.all_reduce_max(eb)
         repeat_ms.append(round(float(eb.item()) * 1e3 / args.steps, 4))
+
+    # ---- N > 1: latency of one decode all-reduce (batch x hidden fp32 + residual add), IPC push and the collective library, 64 back-to-back calls
+    allreduce = None
+    if world > 1:
+        def time_calls(fn, n=64):
+            fn(); torch.cuda.synchronize(); backend.fwd_barrier()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) * 1e3 / n], dtype=torch.float64, device=dev)
+            backend.all_reduce_max(t)
+            return round(float(t.item()), 2)
+        yb = torch.randn((args.batch, shape.hidden), device=dev)
+        rb = torch.zeros((args.batch, shape.hidden), dtype=torch.half, device=dev)
+        sb = torch.zeros((args.batch, shape.hidden // 128), device=dev)
+        allreduce = {"message_bytes": args.batch * shape.hidden * 4, "per_step": 2 * model.n_layers,
+                     "path": "ipc one-shot push + fused residual add (exl3_allreduce.hip)" if ipc_on else "collective library all_reduce + glue_resid"}
+        if ipc_on:
+            allreduce["ipc_us"] = time_calls(lambda: backend.ipc.reduce(yb, resid=rb, ss_part=sb, m=args.batch))
+        saved_ipc, backend.ipc = backend.ipc, None
+        allreduce["library_us"] = time_calls(lambda: backend.all_reduce_resid(yb, rb, sb, args.batch))
+        backend.ipc = saved_ipc
 
     # ---- roofline leg: every fused-GEMV launch of a decode step, bracketed by HIP events on the launch stream
     roofline = None
@@ -413,7 +457,7 @@ def main():
                        "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
                        "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),
                        "parallelism": f"tp{world}", "gemv_variant": args.variant, "gemv_gen": args.gen},
-            "repeat_ms_per_step": repeat_ms,
+            "repeat_ms_per_step": repeat_ms, "allreduce": allreduce,
             "roofline": roofline, "cpu_baseline": cpu, "prefill": prefill, "other_configs": extra,
         }
         print(json.dumps(out), flush=True)

@@ -401,8 +401,7 @@ class SyntheticEXL3Llama:
                 ext.glue_resid(so[0], So, lo.svh, None, x, ss, bsz)
             else:
                 lo.bc.run(o_in, self.o)
-                be.all_reduce(self.o)
-                ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=self.o)
+                be.all_reduce_resid(self.o, x, ss, bsz)                    # one-shot IPC push + residual add, or RCCL all-reduce + glue_resid
             if not _same_kind(lg, lu):
                 # gate and up of different bitrates (at most one layer of a fractional-bpw checkpoint): one GEMV each + silu_mul, then the
                 # down projection from the unrotated activation like o_proj
@@ -414,8 +413,7 @@ class SyntheticEXL3Llama:
                     ext.glue_resid(sd[0], Sd, ld.svh, None, x, ss, bsz)
                 else:
                     ld.bc.run(self.a, self.d)
-                    be.all_reduce(self.d)
-                    ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=self.d)
+                    be.all_reduce_resid(self.d, x, ss, bsz)
                 continue
             if rot:
                 ext.glue_rotate(x, ss, L["norm2"], self.eps, [lg.suh, lu.suh], self.xh3[:2], bsz)
@@ -435,8 +433,7 @@ class SyntheticEXL3Llama:
                 ext.glue_resid(sd[0], Sd, ld.svh, None, x, ss, bsz)
             else:
                 ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.d], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT, c_fp32=True)
-                be.all_reduce(self.d)
-                ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=self.d)
+                be.all_reduce_resid(self.d, x, ss, bsz)
         if rot or self.rotate_for_head:
             ext.glue_rotate(x, ss, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz)
             ext.exl3_gemv_ex(None, self.xh3[:1], None, [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],

@@ -14,6 +14,7 @@ Partitioning (reference modules/quant/exl3.py:284-330, modules/mlp
 Split points are multiples of 128 (Hadamard blocks); attention splits whole KV-head groups.
 """
 from __future__ import annotations
+import ctypes
 import os
 import torch
 import torch.distributed as dist
@@ -41,6 +42,7 @@ class TPBackendRCCL:
         # The reference halves the wire by casting fp32 -> bf16 -> fp32 (model_tp_backend.py:120-124); that changes
         # numerics, so it is opt-in here.
         self.bf16_wire = bf16_wire
+        self.ipc = None
         if self.world_size > 1 and not dist.is_initialized():
             if backend is None:
                 backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
@@ -52,9 +54,54 @@ class TPBackendRCCL:
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size, **kw)
 
     def close(self):
+        if self.ipc is not None:
+            self.ipc.close()
+            self.ipc = None
         if self.world_size > 1 and dist.is_initialized():
             dist.barrier()
             dist.destroy_process_group()
+
+    # ---- decode all-reduce over IPC-mapped peer buffers (exl3_allreduce.hip): one hop over xGMI, fused with the residual add ----------
+    def enable_ipc_allreduce(self, max_elems: int, self_test: bool = True) -> bool:
+        """Set up the one-shot push all-reduce for messages of up to max_elems fp32 values (tokens x hidden of a decode step).  The 64-byte IPC
+        handles travel through the process group; with self_test the first reduction is checked against the collective library and the path
+        stays off (returns False, RCCL keeps doing the decode all-reduces) if a peer cannot be mapped or the sums differ."""
+        if self.world_size == 1 or self.device is None or self.device.type != "cuda":
+            return False
+        try:
+            ipc = IpcAllReduce(self.rank, self.world_size, self.device, max_elems)
+            ok = True
+            if self_test:
+                g = torch.Generator(device=self.device); g.manual_seed(1234 + self.rank)
+                y = torch.randn((1, 256), device=self.device, generator=g)
+                ref = y.clone(); dist.all_reduce(ref)
+                out = torch.empty_like(y)
+                ipc.reduce(y, y_out=out)
+                ok = ipc.error() == 0 and bool(torch.allclose(out, ref, rtol=1e-5, atol=1e-5))
+            flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)                   # every rank takes the same decision
+            if float(flag.item()) != 1.0:
+                ipc.close()
+                return False
+            self.ipc = ipc
+            return True
+        except Exception:
+            flag = torch.tensor([0.0], device=self.device)
+            try:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            except Exception:
+                pass
+            return False
+
+    def all_reduce_resid(self, y: torch.Tensor, resid: torch.Tensor, ss_part: torch.Tensor, m: int):
+        """resid (fp16) += sum over ranks of y (fp32 [m][hidden]); ss_part = per-block sums of squares of the new residual: the o_proj / down_proj
+        boundary of a tensor-parallel decode step.  One kernel on the IPC path; all_reduce + glue_resid otherwise."""
+        if self.ipc is not None and y.numel() <= self.ipc.max_elems:
+            self.ipc.reduce(y, resid=resid, ss_part=ss_part, m=m)
+            return
+        from . import ext
+        self.all_reduce(y)
+        ext.glue_resid(None, 0, None, None, resid, ss_part, m, y_dense=y)
 
     def fwd_barrier(self):
         if self.world_size > 1:
@@ -101,3 +148,44 @@ class TPBackendRCCL:
             for p, ld in zip(parts, ldims):
                 out_tensor[..., od: od + ld] = p[..., :ld]
                 od += ld
+
+
+
+class IpcAllReduce:
+    """Host side of exl3_allreduce.hip: this rank's receive buffer + the peers' buffers mapped through hipIpc handles exchanged over the process
+    group.  Every rank must issue the same sequence of reduce() calls (a captured hipGraph replays them identically)."""
+
+    def __init__(self, rank: int, world: int, device: torch.device, max_elems: int):
+        from . import _lib
+        self._lib = _lib.lib()
+        self.rank, self.world, self.device, self.max_elems = rank, world, device, int(max_elems)
+        torch.cuda.set_device(device)
+        ctx = ctypes.c_void_p()
+        handle = ctypes.create_string_buffer(64)
+        _lib.check(self._lib.exl3_ar_create(world, rank, self.max_elems, ctypes.byref(ctx), handle))
+        self.ctx = ctx
+        handles = [None] * world
+        dist.all_gather_object(handles, bytes(handle.raw))
+        for r in range(world):
+            if r != rank:
+                _lib.check(self._lib.exl3_ar_open_peer(self.ctx, r, ctypes.create_string_buffer(handles[r], 64)))
+        dist.barrier()
+
+    def reduce(self, y: torch.Tensor, y_out: torch.Tensor | None = None, resid: torch.Tensor | None = None, ss_part: torch.Tensor | None = None,
+               m: int | None = None):
+        from . import _lib
+        assert y.dtype == torch.float and y.is_contiguous() and y.is_cuda
+        hidden = y.shape[-1]
+        rows = m if m is not None else y.numel() // hidden
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self._lib.exl3_ar_reduce(self.ctx, p(y), p(y_out), p(resid), p(ss_part), rows, hidden, torch.cuda.current_stream(y.device).cuda_stream))
+
+    def error(self) -> int:
+        from . import _lib
+        return _lib.check(self._lib.exl3_ar_error(self.ctx, torch.cuda.current_stream(self.device).cuda_stream))
+
+    def close(self):
+        if self.ctx is not None:
+            torch.cuda.synchronize(self.device)
+            self._lib.exl3_ar_destroy(self.ctx)
+            self.ctx = None

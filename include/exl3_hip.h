@@ -312,6 +312,24 @@ int exl3_add(void* x, const void* y, int64_t numel, int x_fp32, int y_fp32, void
  * post-op for soft-capped logits (modules/linear.py:598-599) */
 int exl3_softcap(const void* x, void* y, int64_t numel, float scale, int is_fp32, void* stream);
 
+/* ---- tensor-parallel decode all-reduce: one-shot push over IPC-mapped peer buffers (xGMI), fused with the residual add -------------------------
+ * Replaces TPBackendNCCL.all_reduce (model/model_tp_backend.py:119-126) / the native small-message all-reduce (exllamav3_ext/parallel/all_reduce.cu:18-232)
+ * for the (tokens x hidden) fp32 partial sums after o_proj / down_proj at decode.  One process per GPU:
+ *   exl3_ar_create(world, rank, max_elems, &ctx, handle64)   allocates this rank's fine-grained receive buffer, returns its 64-byte IPC handle;
+ *   [exchange the handles between the ranks with any host-side channel]
+ *   exl3_ar_open_peer(ctx, r, handle_of_rank_r)              maps rank r's buffer (hipIpcOpenMemHandle);
+ *   exl3_ar_reduce(ctx, y, y_out, resid, ss_part, m, hidden, stream)
+ *        every rank pushes its partial y [m][hidden] fp32 to all ranks as 8-byte {value, epoch} granules and sums the W partials it received in
+ *        rank order (same bits on every rank).  y_out (optional) = the sum; resid (optional, fp16 [m][hidden]) += sum with the rounding of
+ *        rms_norm_res_in (norm.cu:193-218); ss_part (optional) = per-128-block sums of squares of the new residual (exl3_glue_resid's output).
+ *        Graph-capturable (epochs live in device memory).  Every rank must issue the same sequence of calls.
+ *   exl3_ar_error(ctx, stream)  1 if a bounded spin gave up since the last query (a peer never arrived), else 0; synchronises the stream. */
+int exl3_ar_create(int world, int rank, int64_t max_elems, void** ctx_out, void* handle_out);
+int exl3_ar_open_peer(void* ctx, int peer_rank, const void* handle);
+int exl3_ar_destroy(void* ctx);
+int exl3_ar_error(void* ctx, void* stream);
+int exl3_ar_reduce(void* ctx, const float* y, float* y_out, void* resid, float* ss_part, int m, int hidden, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

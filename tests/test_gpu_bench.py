@@ -40,3 +40,6 @@ def test_bench_two_ranks_control_flow(dev):
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _line(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "tp2" and d["cpu_baseline"] is None
+    # the decode all-reduces ran through the IPC push (two processes mapping each other's buffers on the shared GPU) and were timed
+    ar = d["allreduce"]
+    assert ar["path"].startswith("ipc") and ar["ipc_us"] > 0 and ar["library_us"] > 0 and ar["per_step"] == 4

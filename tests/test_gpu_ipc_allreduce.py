@@ -1,0 +1,90 @@
+"""The one-shot IPC all-reduce of the tensor-parallel decode path (exl3_allreduce.hip) with TWO processes sharing the one GPU of the test box:
+each rank allocates its fine-grained receive buffer, the 64-byte hipIpc handles travel over a gloo process group, every rank maps its peer and
+the push/poll kernels of the two processes run concurrently.  Checked: plain sums (bit-exact: rank-order fp32 adds), the fused residual add +
+per-block sums of squares against exl3_glue_resid on the summed tensor, many back-to-back calls (slot-set alternation), hipGraph replay, and
+TPBackendRCCL.enable_ipc_allreduce's self-test.  (xGMI between 8 GPUs is first exercised by the driver's scaling run.)"""
+import os
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from exllamav3_amd import ext
+    from exllamav3_amd.tp import TPBackendRCCL
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    ext.init(0)
+    be = TPBackendRCCL(rank, world, dev, backend="gloo")
+    ok = {}
+    try:
+        ok["enabled"] = be.enable_ipc_allreduce(4 * 8192)
+        ipc = be.ipc
+        g = torch.Generator(device=dev); g.manual_seed(100 + rank)
+        # ---- plain sums, several shapes, 40 back-to-back calls (slot sets alternate; a rank may run one call ahead of its peer)
+        exact = True
+        for it in range(40):
+            m, hidden = [(1, 4096), (4, 8192), (2, 2048), (3, 128)][it % 4]
+            y = torch.randn((m, hidden), device=dev, generator=g)
+            ref = y.clone(); dist.all_reduce(ref)                      # gloo: the sum of the two ranks' tensors
+            out = torch.empty_like(y)
+            ipc.reduce(y, y_out=out)
+            exact = exact and bool(torch.equal(out, ref))
+        ok["sums_exact"] = exact and ipc.error() == 0
+        # ---- fused residual add + sums of squares == all_reduce + glue_resid
+        m, hidden = 2, 4096
+        y = torch.randn((m, hidden), device=dev, generator=g)
+        r0 = (torch.randn((m, hidden), device=dev, generator=torch.Generator(device=dev).manual_seed(7)) * 2).half()   # same on both ranks
+        ysum = y.clone(); dist.all_reduce(ysum)
+        r_ref = r0.clone(); ss_ref = torch.zeros((m, hidden // 128), device=dev)
+        ext.glue_resid(None, 0, None, None, r_ref, ss_ref, m, y_dense=ysum)
+        r1 = r0.clone(); ss1 = torch.full_like(ss_ref, float("nan"))
+        be.all_reduce_resid(y, r1, ss1, m)
+        ok["resid_equal"] = bool(torch.equal(r1, r_ref)) and bool(torch.equal(ss1, ss_ref))
+        # ---- hipGraph: three reductions captured once, replayed five times with fresh inputs
+        ys = [torch.zeros((1, 4096), device=dev) for _ in range(3)]
+        outs = [torch.empty_like(t) for t in ys]
+        st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+        dist.barrier()
+        with torch.cuda.stream(st):
+            for a, b in zip(ys, outs): ipc.reduce(a, y_out=b)          # warm-up outside capture (both ranks: same call sequence)
+            st.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=st):
+                for a, b in zip(ys, outs): ipc.reduce(a, y_out=b)
+        torch.cuda.synchronize()
+        gok = True
+        for rep in range(5):
+            for t in ys: t.copy_(torch.randn(t.shape, device=dev, generator=g))
+            refs = []
+            for t in ys:
+                r = t.clone(); dist.all_reduce(r); refs.append(r)
+            graph.replay(); torch.cuda.synchronize()
+            gok = gok and all(bool(torch.equal(o_, r_)) for o_, r_ in zip(outs, refs))
+        ok["graph_replay"] = gok and ipc.error() == 0
+    except Exception as e:           # report instead of hanging the peer
+        ok["exception"] = repr(e)
+    ret[rank] = ok
+    try:
+        be.close()
+    except Exception:
+        pass
+
+
+def test_ipc_allreduce_two_processes_one_gpu(dev):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29800 + (os.getpid() % 150)
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        res = ret.get(r)
+        assert res and "exception" not in res, res
+        assert res == {"enabled": True, "sums_exact": True, "resid_equal": True, "graph_replay": True}, (r, res)
