@@ -12,6 +12,8 @@
 // of a workgroup stride over the tokens of one (sequence, kv head, context split); online softmax per half-wave, merged through LDS; context
 // splits are merged by a second small kernel (flash decoding).  The work is tiny (144 B per token and kv head at 4 bits): the design goal is
 // two short launches, not throughput.
+// head_dim 64 (Llama-3.2-1B): a 128-value block of the token vector holds TWO kv heads; the half-wave then carries two independent 16-lane
+// attention problems (score reductions over 16 lanes, per-half statistics), everything else is unchanged.
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
 #include "exl3_glue_device.cuh"
@@ -28,18 +30,23 @@ struct AttnArgs
     int blocks_per_seq, page_size, k_bits, v_bits, hq, hkv, nsplit, split_tokens;
     float scale;
 };
+// hq / hkv in AttnArgs count HEADS; a workgroup handles one 128-value block of the kv vector = 128 / HD kv heads
 
-template <int GQ>
+template <int GQ, int HD>
 __global__ __launch_bounds__(256)
 void attn_decode_kernel(const AttnArgs a)
 {
-    __shared__ float ml_s[8][GQ][2];
+    constexpr int NSUB = 128 / HD;                              // kv heads per 128-value block (1 or 2)
+    constexpr int RW = HD / 4;                                  // lanes per head (32 or 16)
+    __shared__ float ml_s[8][GQ][NSUB][2];
     __shared__ float o_s[8][GQ][128];
     const int tid = threadIdx.x, l = tid & 31, hwid = tid >> 5, lane = tid & 63;
-    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;          // h: 128-value block of the kv vector
+    const int sub = l / RW;                                     // which kv head of the block this lane belongs to
+    const int kvh = h * NSUB + sub;
     const int len = a.cache_seqlens[b];
     const int t0 = split * a.split_tokens, t1 = min(len, t0 + a.split_tokens);
-    const int G = a.hkv * 4;                                    // quantization groups per token
+    const int G = a.hkv * HD / 32;                              // quantization groups per token
     const int g = l >> 3;
 
     // rotated, pre-scaled queries of the GQ heads sharing this kv head: qh = H32(q) / sqrt(32) * softmax scale
@@ -47,7 +54,7 @@ void attn_decode_kernel(const AttnArgs a)
     #pragma unroll
     for (int i = 0; i < GQ; ++i)
     {
-        const half4_t qv = ((const half4_t*) (a.q + ((size_t) b * a.hq + h * GQ + i) * 128))[l];
+        const half4_t qv = ((const half4_t*) (a.q + ((size_t) b * a.hq + kvh * GQ + i) * HD))[l % RW];
         float v0 = (float) qv.x, v1 = (float) qv.y, v2 = (float) qv.z, v3 = (float) qv.w;
         kvg_had32(v0, v1, v2, v3, lane);
         const float f = ATT_R32 * a.scale;
@@ -93,7 +100,7 @@ void attn_decode_kernel(const AttnArgs a)
             {
                 float s = qh[i][0] * kv[u][0] + qh[i][1] * kv[u][1] + qh[i][2] * kv[u][2] + qh[i][3] * kv[u][3];
                 #pragma unroll
-                for (int j = 1; j < 32; j <<= 1) s += xor_lane(s, j);
+                for (int j = 1; j < RW; j <<= 1) s += xor_lane(s, j);     // over the lanes of THIS head
                 if (actv[u])
                 {
                     const float mn = fmaxf(mx[i], s);
@@ -110,7 +117,7 @@ void attn_decode_kernel(const AttnArgs a)
     #pragma unroll
     for (int i = 0; i < GQ; ++i)
     {
-        if (l == 0) { ml_s[hwid][i][0] = mx[i]; ml_s[hwid][i][1] = ls[i]; }
+        if (l % RW == 0) { ml_s[hwid][i][sub][0] = mx[i]; ml_s[hwid][i][sub][1] = ls[i]; }
         *((float4_t*) &o_s[hwid][i][4 * l]) = float4_t{ oa[i][0], oa[i][1], oa[i][2], oa[i][3] };
     }
     __syncthreads();
@@ -118,29 +125,30 @@ void attn_decode_kernel(const AttnArgs a)
     {
         float M = -1.0e30f;
         #pragma unroll
-        for (int k = 0; k < 8; ++k) M = fmaxf(M, ml_s[k][i][0]);
+        for (int k = 0; k < 8; ++k) M = fmaxf(M, ml_s[k][i][sub][0]);
         float L = 0.0f; float4_t O = { 0.f, 0.f, 0.f, 0.f };
         #pragma unroll
         for (int k = 0; k < 8; ++k)
         {
-            const float e = __expf(ml_s[k][i][0] - M);
-            L += ml_s[k][i][1] * e;
+            const float e = __expf(ml_s[k][i][sub][0] - M);
+            L += ml_s[k][i][sub][1] * e;
             const float4_t ov = *((const float4_t*) &o_s[k][i][4 * l]);
             O.x += ov.x * e; O.y += ov.y * e; O.z += ov.z * e; O.w += ov.w * e;
         }
-        const int head = h * GQ + i;
+        const int head = kvh * GQ + i;                          // query head of this lane
         if (a.nsplit == 1)
         {
             const float inv = L > 0.0f ? 1.0f / L : 0.0f;
             float v0 = O.x * inv, v1 = O.y * inv, v2 = O.z * inv, v3 = O.w * inv;
             kvg_had32(v0, v1, v2, v3, lane);
-            ((half4_t*) (a.out + ((size_t) b * a.hq + head) * 128))[l] = half4_t{ f2h(v0 * ATT_R32), f2h(v1 * ATT_R32), f2h(v2 * ATT_R32), f2h(v3 * ATT_R32) };
+            ((half4_t*) (a.out + ((size_t) b * a.hq + head) * HD))[l % RW] = half4_t{ f2h(v0 * ATT_R32), f2h(v1 * ATT_R32), f2h(v2 * ATT_R32), f2h(v3 * ATT_R32) };
         }
         else
         {
-            float* p = a.part + (((size_t) b * a.hq + head) * a.nsplit + split) * 132;
-            if (l == 0) { p[0] = M; p[1] = L; }
-            *((float4_t*) (p + 4 + 4 * l)) = O;                 // record = {m, l, pad, pad, o[128]}
+            // one record per (sequence, 128-value block, query index i): {m, l} of each kv head of the block, then the 128 accumulators
+            float* p = a.part + ((((size_t) b * gridDim.y + h) * GQ + i) * a.nsplit + split) * 132;
+            if (l % RW == 0) { p[2 * sub] = M; p[2 * sub + 1] = L; }
+            *((float4_t*) (p + 4 + 4 * l)) = O;                 // record = {m0, l0, m1, l1, o[128]}
         }
     }
 }
@@ -148,49 +156,45 @@ void attn_decode_kernel(const AttnArgs a)
 // merge of the context splits: one half-wave per (sequence, head).  Lane s fetches split s's (max, sum) so the statistics of up to 32 splits
 // arrive in one memory round trip; the weighted accumulation then streams the split outputs 8 at a time (independent loads).
 __global__ __launch_bounds__(256)
-void attn_merge_kernel(const float* __restrict__ part, half_t* __restrict__ out, int heads_total, int nsplit)
+void attn_merge_kernel(const float* __restrict__ part, half_t* __restrict__ out, int items_total, int nsplit, int hd, int gq, int blocks, int hq)
 {
+    // item = (sequence b, 128-value block h, query index i); at head_dim 64 lanes 0-15 / 16-31 belong to the block's two kv heads
     const int tid = threadIdx.x, l = tid & 31, lane = tid & 63;
     const int item = blockIdx.x * 8 + (tid >> 5);
-    const bool act = item < heads_total;
+    const bool act = item < items_total;
+    const int rw = hd >> 2, sub = l / rw, nsub = 128 / hd;
     const float* p = part + (size_t) (act ? item : 0) * nsplit * 132;
+    // statistics of split s: every lane reads its own head's (m, l) -- 8 splits per round, independent loads
     float M = -1.0e30f;
-    for (int s0 = 0; s0 < nsplit; s0 += 32)
-    {
-        float m = (s0 + l < nsplit) ? p[(size_t) (s0 + l) * 132] : -1.0e30f;
-        #pragma unroll
-        for (int j = 1; j < 32; j <<= 1) m = fmaxf(m, xor_lane(m, j));
-        M = fmaxf(M, m);
-    }
+    for (int s0 = 0; s0 < nsplit; ++s0) M = fmaxf(M, p[(size_t) s0 * 132 + 2 * sub]);
     float L = 0.0f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    for (int s0 = 0; s0 < nsplit; s0 += 32)
+    for (int c0 = 0; c0 < nsplit; c0 += 8)
     {
-        const bool has = s0 + l < nsplit;
-        const float2 ml = has ? *((const float2*) (p + (size_t) (s0 + l) * 132)) : float2{ -1.0e30f, 0.0f };
-        const float e_mine = has ? __expf(ml.x - M) : 0.0f;
-        float lsum = ml.y * e_mine;
+        float4_t ov[8]; float ev[8], lv[8];
         #pragma unroll
-        for (int j = 1; j < 32; j <<= 1) lsum += xor_lane(lsum, j);
-        L += lsum;
-        const int cnt = min(32, nsplit - s0);
-        for (int c0 = 0; c0 < cnt; c0 += 8)
+        for (int u = 0; u < 8; ++u)
         {
-            float4_t ov[8]; float ev[8];
-            #pragma unroll
-            for (int u = 0; u < 8; ++u)
-            {
-                const int sidx = min(c0 + u, cnt - 1);
-                ov[u] = *((const float4_t*) (p + (size_t) (s0 + sidx) * 132 + 4 + 4 * l));
-                ev[u] = __shfl(e_mine, (lane & 32) + sidx, 64);                      // split sidx's weight lives in lane sidx of this half-wave
-            }
-            #pragma unroll
-            for (int u = 0; u < 8; ++u) if (c0 + u < cnt) { o0 += ov[u].x * ev[u]; o1 += ov[u].y * ev[u]; o2 += ov[u].z * ev[u]; o3 += ov[u].w * ev[u]; }
+            const int sidx = min(c0 + u, nsplit - 1);
+            ov[u] = *((const float4_t*) (p + (size_t) sidx * 132 + 4 + 4 * l));
+            ev[u] = p[(size_t) sidx * 132 + 2 * sub];
+            lv[u] = p[(size_t) sidx * 132 + 2 * sub + 1];
+        }
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) if (c0 + u < nsplit)
+        {
+            const float e = __expf(ev[u] - M);
+            L += lv[u] * e;
+            o0 += ov[u].x * e; o1 += ov[u].y * e; o2 += ov[u].z * e; o3 += ov[u].w * e;
         }
     }
     const float inv = L > 0.0f ? 1.0f / L : 0.0f;
     float v0 = o0 * inv, v1 = o1 * inv, v2 = o2 * inv, v3 = o3 * inv;
     kvg_had32(v0, v1, v2, v3, lane);
-    if (act) ((half4_t*) (out + (size_t) item * 128))[l] = half4_t{ f2h(v0 * ATT_R32), f2h(v1 * ATT_R32), f2h(v2 * ATT_R32), f2h(v3 * ATT_R32) };
+    // item -> query head: b = item / (blocks * gq), h = (item / gq) % blocks, i = item % gq; head = (h * nsub + sub) * gq + i
+    const int it = act ? item : 0;
+    const int b = it / (blocks * gq), h = (it / gq) % blocks, i = it % gq;
+    const int head = (h * nsub + sub) * gq + i;
+    if (act) ((half4_t*) (out + ((size_t) b * hq + head) * hd))[l % rw] = half4_t{ f2h(v0 * ATT_R32), f2h(v1 * ATT_R32), f2h(v2 * ATT_R32), f2h(v3 * ATT_R32) };
 }
 
 extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
@@ -199,38 +203,37 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
                                        float* workspace, int64_t workspace_floats, void* stream)
 {
     EXL3_CHECK_ARG(q && out && k_cache && k_scales && v_cache && v_scales && block_table && cache_seqlens, "attn_decode: null pointer");
-    EXL3_CHECK_ARG(head_dim == 128, "attn_decode: head_dim must be 128");
+    EXL3_CHECK_ARG(head_dim == 128 || head_dim == 64, "attn_decode: head_dim must be 128 or 64");
+    EXL3_CHECK_ARG((heads_kv * head_dim) % 128 == 0, "attn_decode: heads_kv * head_dim must be a multiple of 128 (whole Hadamard blocks)");
     EXL3_CHECK_ARG(heads_kv >= 1 && heads_q % heads_kv == 0 && heads_q / heads_kv <= ATT_MAX_GQ, "attn_decode: heads_q must be a multiple (<= 8x) of heads_kv");
     EXL3_CHECK_ARG(k_bits >= 2 && k_bits <= 8 && v_bits >= 2 && v_bits <= 8, "attn_decode: cache bits must be in [2, 8]");
     EXL3_CHECK_ARG(page_size > 0 && max_len >= 1, "attn_decode: bad page size / length bound");
     if (bsz == 0) return EXL3_OK;
     // context splits: enough workgroups to cover the chip, at least 64 tokens (8 per half-wave) each
-    int split_tokens = ((max_len + 31) / 32) * bsz * heads_kv <= 1024 ? 32 : 64;   // 4 or 8 tokens per half-wave
+    const int blocks = heads_kv * head_dim / 128;                                    // 128-value blocks of the kv vector = workgroups per (split, sequence)
+    const int gq = heads_q / heads_kv;
+    int split_tokens = ((max_len + 31) / 32) * bsz * blocks <= 1024 ? 32 : 64;      // 4 or 8 tokens per half-wave
     int nsplit = (max_len + split_tokens - 1) / split_tokens;
-    const int cap = 1024 / (bsz * heads_kv) > 1 ? 1024 / (bsz * heads_kv) : 1;
+    const int cap = 1024 / (bsz * blocks) > 1 ? 1024 / (bsz * blocks) : 1;
     if (nsplit > cap) { nsplit = cap; split_tokens = ((max_len + nsplit - 1) / nsplit + 7) / 8 * 8; nsplit = (max_len + split_tokens - 1) / split_tokens; }
-    EXL3_CHECK_ARG(nsplit == 1 || (workspace && workspace_floats >= (int64_t) bsz * heads_q * nsplit * 132), "attn_decode: workspace too small for the context splits");
+    EXL3_CHECK_ARG(nsplit == 1 || (workspace && workspace_floats >= (int64_t) bsz * blocks * gq * nsplit * 132), "attn_decode: workspace too small for the context splits");
     AttnArgs a;
     a.q = (const half_t*) q; a.out = (half_t*) out;
     a.k_cache = (const uint32_t*) k_cache; a.k_scales = (const half_t*) k_scales; a.v_cache = (const uint32_t*) v_cache; a.v_scales = (const half_t*) v_scales;
     a.block_table = block_table; a.cache_seqlens = cache_seqlens; a.part = workspace;
     a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.k_bits = k_bits; a.v_bits = v_bits; a.hq = heads_q; a.hkv = heads_kv;
     a.nsplit = nsplit; a.split_tokens = split_tokens; a.scale = scale;
-    dim3 grid(nsplit, heads_kv, bsz);
+    dim3 grid(nsplit, blocks, bsz);
     hipStream_t st = (hipStream_t) stream;
-    switch (heads_q / heads_kv)
-    {
-        case 1: attn_decode_kernel<1><<<grid, 256, 0, st>>>(a); break; case 2: attn_decode_kernel<2><<<grid, 256, 0, st>>>(a); break;
-        case 3: attn_decode_kernel<3><<<grid, 256, 0, st>>>(a); break; case 4: attn_decode_kernel<4><<<grid, 256, 0, st>>>(a); break;
-        case 5: attn_decode_kernel<5><<<grid, 256, 0, st>>>(a); break; case 6: attn_decode_kernel<6><<<grid, 256, 0, st>>>(a); break;
-        case 7: attn_decode_kernel<7><<<grid, 256, 0, st>>>(a); break; default: attn_decode_kernel<8><<<grid, 256, 0, st>>>(a); break;
-    }
+    #define ATT_L(GQv) case GQv: if (head_dim == 128) attn_decode_kernel<GQv, 128><<<grid, 256, 0, st>>>(a); else attn_decode_kernel<GQv, 64><<<grid, 256, 0, st>>>(a); break;
+    switch (gq) { ATT_L(1) ATT_L(2) ATT_L(3) ATT_L(4) ATT_L(5) ATT_L(6) ATT_L(7) default: if (head_dim == 128) attn_decode_kernel<8, 128><<<grid, 256, 0, st>>>(a); else attn_decode_kernel<8, 64><<<grid, 256, 0, st>>>(a); break; }
+    #undef ATT_L
     int rc = exl3_check_launch("attn_decode");
     if (rc) return rc;
     if (nsplit > 1)
     {
-        const int items = bsz * heads_q;
-        attn_merge_kernel<<<(items + 7) / 8, 256, 0, st>>>(workspace, (half_t*) out, items, nsplit);
+        const int items = bsz * blocks * gq;
+        attn_merge_kernel<<<(items + 7) / 8, 256, 0, st>>>(workspace, (half_t*) out, items, nsplit, head_dim, gq, blocks, heads_q);
         rc = exl3_check_launch("attn_merge");
     }
     return rc;

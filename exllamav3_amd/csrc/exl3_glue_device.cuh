@@ -5,6 +5,7 @@
 #include "exl3_common.cuh"
 
 #include "exl3_gemv_args.h"
+#include "exl3_kvq.cuh"
 
 // r_new / r_prev of one row (GemvRescale): both sums in the fixed order every consumer of ss_part uses (32-lane tree per 32 blocks, then the
 // partial trees in sequence).  p0 / n0: the lane's first-32 values, loaded by the caller with its other operands (0 for lanes >= k/128).
@@ -101,54 +102,21 @@ __device__ __forceinline__ float in_had_store(half4_t x, const half_t* __restric
     return in_had_store_v(x, ((const half4_t*) suh_blk)[l], xh_blk, l, act);
 }
 
+// ---- KV-cache quantization on register values, 4 values per lane (the layout the 128-point output Hadamard leaves a head in): thin views of
+// the generic group code in exl3_kvq.cuh (KvGroup<4>: 8 lanes per 32-group)
 __device__ __forceinline__ void kvg_had32(float& v0, float& v1, float& v2, float& v3, int lane)
 {
-    float s0 = v0 + v1, d0 = v0 - v1, s1 = v2 + v3, d1 = v2 - v3;
-    v0 = s0 + s1; v1 = d0 + d1; v2 = s0 - s1; v3 = d0 - d1;
-    #pragma unroll
-    for (int i = 1; i < 8; i <<= 1)
-    {
-        float p0 = xor_lane(v0, i), p1 = xor_lane(v1, i), p2 = xor_lane(v2, i), p3 = xor_lane(v3, i);
-        bool neg = (lane & i) != 0;
-        v0 = (neg ? -v0 : v0) + p0; v1 = (neg ? -v1 : v1) + p1; v2 = (neg ? -v2 : v2) + p2; v3 = (neg ? -v3 : v3) + p3;
-    }
+    float v[4] = { v0, v1, v2, v3 };
+    KvGroup<4>::hadamard(v, lane);
+    v0 = v[0]; v1 = v[1]; v2 = v[2]; v3 = v[3];
 }
 
-template <int W>
-__device__ __forceinline__ void kvg_pack_plane(uint32_t* __restrict__ out, int word_base, int sl, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3, bool active)
-{
-    uint32_t field = f0 | (f1 << W) | (f2 << (2 * W)) | (f3 << (3 * W));
-    constexpr int LPW = 8 / W;
-    int off = sl * 4 * W;
-    uint32_t contrib = field << (off & 31);
-    #pragma unroll
-    for (int i = 1; i < LPW; i <<= 1) contrib |= (uint32_t) xor_lane((int) contrib, i);
-    if (active && (sl % LPW) == 0) out[word_base + (off >> 5)] = contrib;
-}
-
-// same arithmetic as kv_quant_group in exl3_rope_cache.hip, input already in registers (fp16-rounded values); `bits` may be a
-// runtime value (GEMV tail epilogue) or a compile-time constant (glue_qkv_kernel) -- the arithmetic is identical.
+// `bits` may be a runtime value (GEMV tail epilogue) or a compile-time constant (glue_qkv_kernel) -- the arithmetic is identical
 __device__ __forceinline__ void kv_quant_regs_rt(const int bits, float v0, float v1, float v2, float v3, uint32_t* __restrict__ out,
                                                  half_t* __restrict__ out_scale, bool active, int lane)
 {
-    const float mf = (float) (1 << (bits - 1));
-    const int qmax = (1 << bits) - 1;
-    const int sl = lane & 7;
-    kvg_had32(v0, v1, v2, v3, lane);
-    const float r32 = 0.17677669529663688110f;
-    v0 *= r32; v1 *= r32; v2 *= r32; v3 *= r32;
-    float s = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) + 1e-10f;
-    #pragma unroll
-    for (int i = 1; i < 8; i <<= 1) s = fmaxf(s, xor_lane(s, i));
-    const float inv_s = 1.0f / s;
-    auto quant1 = [&] (float v) -> uint32_t { int qi = (int) floorf(__builtin_fmaf(v * inv_s, mf, mf)); return (uint32_t) max(min(qi, qmax), 0); };
-    uint32_t q0 = quant1(v0), q1 = quant1(v1), q2 = quant1(v2), q3 = quant1(v3);
-    int rem = bits, wb = 0;
-    if (bits & 8) { rem -= 8; kvg_pack_plane<8>(out, wb, sl, (q0 >> rem) & 255, (q1 >> rem) & 255, (q2 >> rem) & 255, (q3 >> rem) & 255, active); wb += 8; }
-    if (bits & 4) { rem -= 4; kvg_pack_plane<4>(out, wb, sl, (q0 >> rem) & 15, (q1 >> rem) & 15, (q2 >> rem) & 15, (q3 >> rem) & 15, active); wb += 4; }
-    if (bits & 2) { rem -= 2; kvg_pack_plane<2>(out, wb, sl, (q0 >> rem) & 3, (q1 >> rem) & 3, (q2 >> rem) & 3, (q3 >> rem) & 3, active); wb += 2; }
-    if (bits & 1) { kvg_pack_plane<1>(out, wb, sl, q0 & 1, q1 & 1, q2 & 1, q3 & 1, active); }
-    if (active && sl == 0) *out_scale = f2h(s);
+    float v[4] = { v0, v1, v2, v3 };
+    KvGroup<4>::quantize(bits, v, out, out_scale, active, lane);
 }
 
 template <int BITS>
@@ -158,43 +126,12 @@ __device__ __forceinline__ void kv_quant_regs(float v0, float v1, float v2, floa
 }
 
 // Rotated-domain values of one quantized 32-group (8 lanes x 4 values): u = (level - (2^(b-1) - 0.5)) * scale / 2^(b-1).  The dequantized
-// K / V the reference materialises is x' = H32(u) / sqrt(32) (cache/q_cache_kernels.cuh:150-236, exl3_rope_cache.hip kv_dequant_group); attention
-// can stay in the rotated domain because H32/sqrt(32) is orthonormal and symmetric.  `bits` may be a runtime value.
+// K / V the reference materialises is x' = H32(u) / sqrt(32) (cache/q_cache_kernels.cuh:150-236); attention can stay in the rotated domain
+// because H32 / sqrt(32) is orthonormal and symmetric.
 __device__ __forceinline__ void kv_dequant_vals_rt(const int bits, const uint32_t* __restrict__ in, const half_t* __restrict__ in_scale, int lane,
                                                    float& v0, float& v1, float& v2, float& v3)
 {
-    // branch-free: the (up to 4) plane words and the scale are loaded unconditionally (absent planes re-read word 0) so that a caller that
-    // unrolls over several tokens gets all of their loads in flight at once; absent planes are masked out with selects
-    const int sl = lane & 7;
-    uint32_t word[4];
-    int wb = 0;
-    #pragma unroll
-    for (int pi = 0; pi < 4; ++pi)
-    {
-        const int w = 8 >> pi;
-        const bool has = (bits & w) != 0;
-        const int off = sl * 4 * w;
-        word[pi] = in[has ? wb + (off >> 5) : 0];
-        wb += has ? w : 0;
-    }
-    const float scale = (float) *in_scale;
-    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    #pragma unroll
-    for (int pi = 0; pi < 4; ++pi)
-    {
-        const int w = 8 >> pi;
-        const bool has = (bits & w) != 0;
-        const int off = sl * 4 * w;
-        const uint32_t x = word[pi] >> (off & 31);
-        const uint32_t mask = (1u << w) - 1u;
-        q0 = has ? ((q0 << w) | (x & mask)) : q0;
-        q1 = has ? ((q1 << w) | ((x >> w) & mask)) : q1;
-        q2 = has ? ((q2 << w) | ((x >> (2 * w)) & mask)) : q2;
-        q3 = has ? ((q3 << w) | ((x >> (3 * w)) & mask)) : q3;
-    }
-    const int m = 1 << (bits - 1);
-    const float sm = scale * (1.0f / (float) m);
-    const float mh = (float) m - 0.5f;
-    v0 = ((float) (int) q0 - mh) * sm; v1 = ((float) (int) q1 - mh) * sm;
-    v2 = ((float) (int) q2 - mh) * sm; v3 = ((float) (int) q3 - mh) * sm;
+    float u[4];
+    KvGroup<4>::levels<false>(bits, in, in_scale, lane, u);
+    v0 = u[0]; v1 = u[1]; v2 = u[2]; v3 = u[3];
 }

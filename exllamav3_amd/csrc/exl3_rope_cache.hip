@@ -4,6 +4,7 @@
 // accesses and no LDS atomics, not FLOPs.
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
+#include "exl3_kvq.cuh"
 
 // ------------------------------------------------------------------------------------------------
 // RoPE.  One wave per (token, head); lane t owns rotation pair t (+ 64, + 128 ... for head_dim > 128).
@@ -204,102 +205,28 @@ extern "C" int exl3_rope_strided(void* q, void* k, const float* inv_freq, int bs
 }
 
 // ------------------------------------------------------------------------------------------------
-// KV-cache quantization: 32-value groups, H32 rotation, absmax scale, midpoint grid, power-of-two bit planes.
-// An 8-lane subgroup owns one group (4 consecutive values per lane), so a wave64 covers 8 groups (256 values).
-// H32 = in-register H4 x 3-round xor-shuffle H8 (same factorisation as q_cache_kernels.cuh:29-59).
-// Packing needs no LDS atomics: a plane of width w puts the lane's 4w-bit field at bit 4w*sl of the plane, the
-// 8/w lanes sharing a word OR-reduce with xor shuffles, and the first lane of each run stores the word.
+// KV-cache quantization (quant_cache_cont / _paged, dequant_cache_cont / _paged): 32-value groups, H32 rotation, absmax scale, midpoint grid,
+// power-of-two bit planes.  Group code: exl3_kvq.cuh.  These kernels map ONE GROUP TO ONE 16-LANE DPP ROW (2 consecutive values per lane), so
+// a wave64 holds four groups = one 128-wide head, the butterflies / max / plane OR-reductions are DPP row operations, a group's fp16 values
+// are one 64-byte row access and its scale + plane words are written by that row alone.
 // ------------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ void kv_had32(float& v0, float& v1, float& v2, float& v3, int lane)
-{
-    float s0 = v0 + v1, d0 = v0 - v1, s1 = v2 + v3, d1 = v2 - v3;
-    v0 = s0 + s1; v1 = d0 + d1; v2 = s0 - s1; v3 = d0 - d1;
-    #pragma unroll
-    for (int i = 1; i < 8; i <<= 1)
-    {
-        float p0 = xor_lane(v0, i), p1 = xor_lane(v1, i), p2 = xor_lane(v2, i), p3 = xor_lane(v3, i);
-        bool neg = (lane & i) != 0;
-        v0 = (neg ? -v0 : v0) + p0; v1 = (neg ? -v1 : v1) + p1; v2 = (neg ? -v2 : v2) + p2; v3 = (neg ? -v3 : v3) + p3;
-    }
-}
-
-#define KV_R32 0.17677669529663688110f
-
-template <int W>
-__device__ __forceinline__ void kv_pack_plane(uint32_t* __restrict__ out, int word_base, int sl, uint32_t f0, uint32_t f1, uint32_t f2, uint32_t f3, bool active)
-{
-    uint32_t field = f0 | (f1 << W) | (f2 << (2 * W)) | (f3 << (3 * W));
-    constexpr int LPW = 8 / W;                         // lanes per word
-    int off = sl * 4 * W;
-    uint32_t contrib = field << (off & 31);
-    #pragma unroll
-    for (int i = 1; i < LPW; i <<= 1) contrib |= (uint32_t) xor_lane((int) contrib, i);
-    if (active && (sl % LPW) == 0) out[word_base + (off >> 5)] = contrib;
-}
-
+// One 32-group per 16-lane DPP row, two consecutive values per lane, four groups (128 values) per wave: exl3_kvq.cuh KvGroup<2>.
 template <int BITS>
 __device__ __forceinline__ void kv_quant_group(const half_t* __restrict__ in, uint32_t* __restrict__ out, half_t* __restrict__ out_scale, bool active, int lane)
 {
-    constexpr float mf = (float) (1 << (BITS - 1));
-    constexpr int qmax = (1 << BITS) - 1;
-    const int sl = lane & 7;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-    if (active)
-    {
-        half4_t x = ((const half4_t*) in)[sl];
-        v0 = (float) x.x; v1 = (float) x.y; v2 = (float) x.z; v3 = (float) x.w;
-    }
-    kv_had32(v0, v1, v2, v3, lane);
-    v0 *= KV_R32; v1 *= KV_R32; v2 *= KV_R32; v3 *= KV_R32;
-    float s = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))) + 1e-10f;
-    #pragma unroll
-    for (int i = 1; i < 8; i <<= 1) s = fmaxf(s, xor_lane(s, i));
-    const float inv_s = 1.0f / s;                      // IEEE division (the oracle's definition)
-    auto quant1 = [&] (float v) -> uint32_t
-    {
-        int qi = (int) floorf(__builtin_fmaf(v * inv_s, mf, mf));
-        return (uint32_t) max(min(qi, qmax), 0);
-    };
-    uint32_t q0 = quant1(v0), q1 = quant1(v1), q2 = quant1(v2), q3 = quant1(v3);
-    int rem = BITS, wb = 0;
-    if constexpr (BITS & 8) { rem -= 8; kv_pack_plane<8>(out, wb, sl, (q0 >> rem) & 255, (q1 >> rem) & 255, (q2 >> rem) & 255, (q3 >> rem) & 255, active); wb += 8; }
-    if constexpr (BITS & 4) { rem -= 4; kv_pack_plane<4>(out, wb, sl, (q0 >> rem) & 15, (q1 >> rem) & 15, (q2 >> rem) & 15, (q3 >> rem) & 15, active); wb += 4; }
-    if constexpr (BITS & 2) { rem -= 2; kv_pack_plane<2>(out, wb, sl, (q0 >> rem) & 3, (q1 >> rem) & 3, (q2 >> rem) & 3, (q3 >> rem) & 3, active); wb += 2; }
-    if constexpr (BITS & 1) { kv_pack_plane<1>(out, wb, sl, q0 & 1, q1 & 1, q2 & 1, q3 & 1, active); }
-    if (active && sl == 0) *out_scale = f2h(s);
+    float v[2] = { 0.0f, 0.0f };
+    if (active) { const half2_t x = ((const half2_t*) in)[lane & 15]; v[0] = (float) x.x; v[1] = (float) x.y; }
+    KvGroup<2>::quantize(BITS, v, out, out_scale, active, lane);
 }
 
 template <int BITS>
 __device__ __forceinline__ void kv_dequant_group(const uint32_t* __restrict__ in, const half_t* __restrict__ in_scale, half_t* __restrict__ out, bool active, int lane)
 {
-    constexpr int m = 1 << (BITS - 1);
-    constexpr float inv_mf = 1.0f / (float) m;
-    const int sl = lane & 7;
-    uint32_t q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-    auto unpack_plane = [&] (int w, int word_base)
-    {
-        int off = sl * 4 * w;
-        uint32_t word = active ? (in[word_base + (off >> 5)] >> (off & 31)) : 0u;
-        uint32_t mask = (1u << w) - 1u;
-        q0 = (q0 << w) | (word & mask);
-        q1 = (q1 << w) | ((word >> w) & mask);
-        q2 = (q2 << w) | ((word >> (2 * w)) & mask);
-        q3 = (q3 << w) | ((word >> (3 * w)) & mask);
-    };
-    int wb = 0;
-    if constexpr (BITS & 8) { unpack_plane(8, wb); wb += 8; }
-    if constexpr (BITS & 4) { unpack_plane(4, wb); wb += 4; }
-    if constexpr (BITS & 2) { unpack_plane(2, wb); wb += 2; }
-    if constexpr (BITS & 1) { unpack_plane(1, wb); }
-    float s = active ? (float) *in_scale : 0.0f;
-    s *= KV_R32;
-    const float sm = s * inv_mf;
-    constexpr float mh = (float) m - 0.5f;
-    float v0 = ((float) (int) q0 - mh) * sm, v1 = ((float) (int) q1 - mh) * sm;
-    float v2 = ((float) (int) q2 - mh) * sm, v3 = ((float) (int) q3 - mh) * sm;
-    kv_had32(v0, v1, v2, v3, lane);
-    if (active) ((half4_t*) out)[sl] = half4_t{ f2h(v0), f2h(v1), f2h(v2), f2h(v3) };
+    float u[2];
+    KvGroup<2>::levels<true>(BITS, in, in_scale, lane, u);                 // inactive lanes read group 0 (valid memory), results discarded
+    KvGroup<2>::hadamard(u, lane);
+    if (active) ((half2_t*) out)[lane & 15] = half2_t{ f2h(u[0]), f2h(u[1]) };
 }
 
 // contiguous: group g of the flat tensor
@@ -307,7 +234,7 @@ template <int BITS>
 __global__ __launch_bounds__(256)
 void kv_quant_cont_kernel(const half_t* __restrict__ in, uint32_t* __restrict__ out, half_t* __restrict__ scales, int64_t num_groups)
 {
-    int64_t g = (int64_t) blockIdx.x * 32 + (threadIdx.x >> 3);
+    int64_t g = (int64_t) blockIdx.x * 16 + (threadIdx.x >> 4);
     bool active = g < num_groups;
     int64_t gs = active ? g : 0;
     kv_quant_group<BITS>(in + gs * 32, out + gs * BITS, scales + gs, active, threadIdx.x & 63);
@@ -317,13 +244,13 @@ template <int BITS>
 __global__ __launch_bounds__(256)
 void kv_dequant_cont_kernel(const uint32_t* __restrict__ in, const half_t* __restrict__ scales, half_t* __restrict__ out, int64_t num_groups)
 {
-    int64_t g = (int64_t) blockIdx.x * 32 + (threadIdx.x >> 3);
+    int64_t g = (int64_t) blockIdx.x * 16 + (threadIdx.x >> 4);
     bool active = g < num_groups;
     int64_t gs = active ? g : 0;
     kv_dequant_group<BITS>(in + gs * BITS, scales + gs, out + gs * 32, active, threadIdx.x & 63);
 }
 
-// paged append: grid (ceil(groups_per_token/32), seq_len, bsz); K and V in one launch (blockIdx.x parity split would
+// paged append: grid (ceil(groups_per_token/16), seq_len, bsz); K and V in one launch (blockIdx.x parity split would
 // halve occupancy; instead each thread-group does K then V like the reference, q_cache_kernels.cuh:291-326)
 template <int KB, int VB>
 __global__ __launch_bounds__(256)
@@ -338,7 +265,7 @@ void kv_quant_paged_kernel(const half_t* __restrict__ k_in, uint32_t* __restrict
     const int page_idx = token_idx / page_size;
     const int64_t token_pos = (int64_t) block_table[blocks_per_seq * batch + page_idx] * page_size + (token_idx % page_size);
     const int64_t in_pos = (int64_t) batch * gridDim.y + blockIdx.y;
-    const int g = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int g = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool active = g < groups_per_token;
     const int gs = active ? g : 0;
     const int64_t base = token_pos * groups_per_token + gs;
@@ -347,7 +274,7 @@ void kv_quant_paged_kernel(const half_t* __restrict__ k_in, uint32_t* __restrict
     kv_quant_group<VB>(v_in + in_pos * ld_v + gs * 32, v_out + base * VB, v_scales + base, active, lane);
 }
 
-// paged dequant of every cached token: grid (ceil(groups_per_token/32), max_tokens, bsz)
+// paged dequant of every cached token: grid (ceil(groups_per_token/16), max_tokens, bsz)
 template <int KB, int VB>
 __global__ __launch_bounds__(256)
 void kv_dequant_paged_kernel(const uint32_t* __restrict__ k_in, const half_t* __restrict__ k_scales, half_t* __restrict__ k_out,
@@ -360,7 +287,7 @@ void kv_dequant_paged_kernel(const uint32_t* __restrict__ k_in, const half_t* __
     if (token_idx >= cache_seqlens[batch]) return;
     const int page_idx = token_idx / page_size;
     const int64_t token_pos = (int64_t) block_table[blocks_per_seq * batch + page_idx] * page_size + (token_idx % page_size);
-    const int g = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int g = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool active = g < groups_per_token;
     const int gs = active ? g : 0;
     const int64_t base = token_pos * groups_per_token + gs;
@@ -381,7 +308,7 @@ extern "C" int exl3_quant_cache_cont(const void* in, void* out, void* out_scales
     EXL3_CHECK_ARG(bits >= 2 && bits <= 8, "quant_cache_cont: bits must be in [2, 8]");
     int64_t groups = tokens * (dim / 32);
     if (groups == 0) return EXL3_OK;
-    dim3 grid((unsigned) ((groups + 31) / 32));
+    dim3 grid((unsigned) ((groups + 15) / 16));
     BITS_SWITCH(bits, (kv_quant_cont_kernel<BB><<<grid, 256, 0, (hipStream_t) stream>>>((const half_t*) in, (uint32_t*) out, (half_t*) out_scales, groups)));
     return exl3_check_launch("quant_cache_cont");
 }
@@ -393,7 +320,7 @@ extern "C" int exl3_dequant_cache_cont(const void* in, const void* in_scales, vo
     EXL3_CHECK_ARG(bits >= 2 && bits <= 8, "dequant_cache_cont: bits must be in [2, 8]");
     int64_t groups = tokens * (dim / 32);
     if (groups == 0) return EXL3_OK;
-    dim3 grid((unsigned) ((groups + 31) / 32));
+    dim3 grid((unsigned) ((groups + 15) / 16));
     BITS_SWITCH(bits, (kv_dequant_cont_kernel<BB><<<grid, 256, 0, (hipStream_t) stream>>>((const uint32_t*) in, (const half_t*) in_scales, (half_t*) out, groups)));
     return exl3_check_launch("dequant_cache_cont");
 }
@@ -424,7 +351,7 @@ static int quant_cache_paged_impl(const void* k_in, void* k_out, void* k_scales,
     EXL3_CHECK_ARG(ld_k >= dim && ld_v >= dim && ld_k % 4 == 0 && ld_v % 4 == 0, "quant_cache_paged: bad token strides");
     if (bsz == 0 || seq_len == 0) return EXL3_OK;
     const int gpt = dim / 32;
-    dim3 grid((gpt + 31) / 32, seq_len, bsz);
+    dim3 grid((gpt + 15) / 16, seq_len, bsz);
     hipStream_t st = (hipStream_t) stream;
     #define QP(KBv) case KBv: launch_quant_paged<KBv>(v_bits, grid, st, k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, blocks_per_seq, page_size, gpt, ld_k, ld_v); break;
     switch (k_bits) { QP(2) QP(3) QP(4) QP(5) QP(6) QP(7) QP(8) }
@@ -458,7 +385,7 @@ extern "C" int exl3_dequant_cache_paged(const void* k_in, const void* k_scales, 
     EXL3_CHECK_ARG(k_bits >= 2 && k_bits <= 8 && v_bits >= 2 && v_bits <= 8, "dequant_cache_paged: bits must be in [2, 8]");
     if (bsz == 0 || blocks_per_seq == 0) return EXL3_OK;
     const int gpt = dim / 32;
-    dim3 grid((gpt + 31) / 32, blocks_per_seq * page_size, bsz);
+    dim3 grid((gpt + 15) / 16, blocks_per_seq * page_size, bsz);
     hipStream_t st = (hipStream_t) stream;
     #define DP(KBv) case KBv: launch_dequant_paged<KBv>(v_bits, grid, st, k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens, block_table, blocks_per_seq, page_size, gpt); break;
     switch (k_bits) { DP(2) DP(3) DP(4) DP(5) DP(6) DP(7) DP(8) }

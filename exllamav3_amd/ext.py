@@ -821,7 +821,8 @@ def attn_decode_qcache(q, out, k_cache, k_scales, v_cache, v_scales, block_table
     """Decode attention straight from the quantized paged cache.  q / out: (bsz, heads_q, 128) fp16; caches (pages, page, G * bits) int32 +
     scales (pages, page, G) fp16 as written by quant_cache_paged / glue_qkv; cache_seqlens int32 (bsz) INCLUDING the new token."""
     _dev(q)
-    _req(q.dtype == torch.half and out.dtype == torch.half and q.shape == out.shape and q.dim() == 3 and q.shape[-1] == 128, "attn_decode: q/out must be (bsz, heads, 128) float16")
+    _req(q.dtype == torch.half and out.dtype == torch.half and q.shape == out.shape and q.dim() == 3 and q.shape[-1] in (64, 128),
+         "attn_decode: q/out must be (bsz, heads, 64 | 128) float16")
     _req(q.is_contiguous() and out.is_contiguous(), "attn_decode: q/out must be contiguous")
     _req(block_table.dtype == torch.int32 and cache_seqlens.dtype == torch.int32, "attn_decode: block_table / cache_seqlens must be int32")
     bsz, hq, hd = q.shape
@@ -829,7 +830,7 @@ def attn_decode_qcache(q, out, k_cache, k_scales, v_cache, v_scales, block_table
     hkv = G * 32 // hd
     kb, vb = _kv_bits(k_cache, k_scales), _kv_bits(v_cache, v_scales)
     nsplit_max = (max_len + 31) // 32
-    need = bsz * hq * nsplit_max * 132
+    need = bsz * (hq * hd // 128) * nsplit_max * 132              # one record per (sequence, 128-value block, query index) and split
     if workspace is None and nsplit_max > 1:
         workspace = torch.empty((need,), dtype=torch.float, device=q.device)
     _check(_lib.lib().exl3_attn_decode_qcache(_p(q), _p(out), _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table), _p(cache_seqlens),

@@ -392,7 +392,7 @@ class SyntheticEXL3Llama:
             # quant-cache-direct decode attention over the cached context (the K/V pages hold whatever the cache holds: zeros here except the
             # appended token, which is enough for timing and for the parity test that fills the cache first)
             o_in = q2
-            if self.with_attention and hd == 128:
+            if self.with_attention and hd in (64, 128):
                 ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
                                        self.attn_pos + 1, workspace=self.attn_ws)
                 o_in = self.attn_out.view(bsz, -1)
@@ -479,7 +479,7 @@ class SyntheticEXL3Llama:
                                 self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, sa, hidden, self.eps)
                 xc, xa, sc, sa = xa, xc, sa, sc
             o_in = q2
-            if self.with_attention and hd == 128:
+            if self.with_attention and hd in (64, 128):
                 ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
                                        self.attn_pos + 1, workspace=self.attn_ws)
                 o_in = self.attn_out.view(bsz, -1)

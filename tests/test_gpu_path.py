@@ -572,6 +572,9 @@ def test_tp_rank_code_path_on_one_gpu(dev, model_name, tp, bsz):
         def __init__(self, world): self.rank, self.world_size, self.calls = 0, world, 0
         def all_reduce(self, tensor, contribution=True): self.calls += 1
         def fwd_barrier(self): pass
+        def all_reduce_resid(self, y, resid, ss_part, m):            # TPBackendRCCL.all_reduce_resid's fallback route: all_reduce + glue_resid
+            self.all_reduce(y)
+            ext.glue_resid(None, 0, None, None, resid, ss_part, m, y_dense=y)
 
     be = OneRankOfMany(tp)
     model = SyntheticEXL3Llama(SHAPES[model_name], K=4, cb=2, device=dev, backend=be, kv_bits=4, max_ctx=1024, layers=1)

@@ -107,12 +107,14 @@ def test_kv_quant_paged_roundtrip(dev, kb, vb):
 
 @pytest.mark.parametrize("kb,vb", [(4, 4), (8, 3), (2, 6)])
 @pytest.mark.parametrize("lens", [[1], [63, 64], [300, 1000, 77]])
-def test_attn_decode_qcache(dev, kb, vb, lens):
+@pytest.mark.parametrize("hd,hq,hkv", [(128, 8, 2), (64, 8, 2), (64, 32, 8)])
+def test_attn_decode_qcache(dev, kb, vb, lens, hd, hq, hkv):
     """Decode attention straight from the quantized paged cache (rotated-domain scores / accumulation, flash-decoding splits) against the
-    oracle attention over the dequantized cache; scattered pages, ragged lengths, GQA 4."""
+    oracle attention over the dequantized cache; scattered pages, ragged lengths, GQA 4; head_dim 128 and 64 (two kv heads per 128-value
+    block: Llama-3.2-1B's 32 q / 8 kv heads x 64)."""
     from exllamav3_amd import ext
     rng = np.random.default_rng(kb * 10 + vb + len(lens))
-    bsz, hq, hkv, hd, page = len(lens), 8, 2, 128, 256
+    bsz, page = len(lens), 256
     maxlen = max(lens)
     pps = (maxlen + page - 1) // page
     npages = bsz * pps + 3
