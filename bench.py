@@ -182,10 +182,18 @@ def main():
     ext.set_gemv_variant(args.variant)
     ext.set_gemv_gen(args.gen)
 
-    shape = SHAPES[args.model]
+    from exllamav3_amd.mixtral_path import MIXTRAL_SHAPES, SyntheticEXL3Mixtral
     cb = {"3inst": 0, "mcg": 1, "mul1": 2}[args.codebook]
-    model = SyntheticEXL3Llama(shape, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits,
-                               layers=args.layers or None)
+    is_moe = args.model in MIXTRAL_SHAPES
+    if is_moe:
+        # BASELINE config 5: Mixtral layer = attention (tensor-parallel) + sparse-MoE block (expert-parallel over the ranks), 4-bit KV
+        shape = MIXTRAL_SHAPES[args.model]
+        model = SyntheticEXL3Mixtral(shape, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits, layers=args.layers or None)
+        args.no_prefill = True
+    else:
+        shape = SHAPES[args.model]
+        model = SyntheticEXL3Llama(shape, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits,
+                                   layers=args.layers or None)
     model.alloc_state(args.batch)
     model.with_attention = bool(args.attention)
 
@@ -194,7 +202,8 @@ def main():
     if pipeline == "tail" and world > 1:
         pipeline = "glue"                                  # TP ranks all-reduce between o/down and the norm
     fused = pipeline != "unfused"
-    run_step = {"tail": model.decode_step_tail, "glue": model.decode_step_fused, "resid": model.decode_step_resid, "unfused": model.decode_step}[pipeline]
+    run_step = model.decode_step if is_moe else \
+        {"tail": model.decode_step_tail, "glue": model.decode_step_fused, "resid": model.decode_step_resid, "unfused": model.decode_step}[pipeline]
     # tensor-parallel decode: the o_proj / down_proj all-reduces go through the one-shot IPC push (exl3_allreduce.hip, fused with the residual
     # add) unless EXL3_HIP_TP_ALLREDUCE=rccl; the set-up self-tests against the collective library and every rank falls back together
     ipc_on = False
@@ -306,7 +315,15 @@ def main():
 
     # ---- roofline leg: every fused-GEMV launch of a decode step, bracketed by HIP events on the launch stream
     roofline = None
-    if rank == 0 or world > 1:
+    if is_moe:
+        # whole-step figure: the step streams the attention linears + the routed experts' packed weights once (bytes_per_token); per-launch
+        # event timing of the indexed exl3_mgemm launches is in tools/bench_moe.py
+        bpt = shape.decode_bytes_per_token(args.bits)
+        ach = bpt / (ms_per_step * 1e-3) / 1e9 / max(world, 1)
+        roofline = {"bound": "hbm", "kernel": "whole decode step (quantized GEMV / indexed exl3_mgemm launches + glue)", "achieved": round(ach, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "note": "algorithmic bytes per token per GPU / step time (not a single kernel)"}
+    elif rank == 0 or world > 1:
         # GPU-side timing only: the launches are captured into a hipGraph per call type (all layers' instances, i.e.
         # distinct cold weights) and the replay is bracketed by HIP events on the replay stream, so host/ctypes time
         # is excluded; the figure still contains the ~1-2 us inter-kernel gap of back-to-back graph nodes.
@@ -438,6 +455,13 @@ def main():
         extra["llama-3.2-1b_bs1"] = timed_decode(m1, m1.decode_step_fused, 1)
         del m1
         torch.cuda.empty_cache()
+        # config 5 on one GPU: Mixtral 8x7B (23 GB of packed weights), bs 1, 4-bit KV; `--gpus 2 --model mixtral-8x7b` runs it TP = 2 / EP = 2
+        from exllamav3_amd.mixtral_path import MIXTRAL_8X7B
+        mm = SyntheticEXL3Mixtral(MIXTRAL_8X7B, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits)
+        mm.alloc_state(1)
+        extra["mixtral-8x7b_bs1"] = timed_decode(mm, mm.decode_step, 1)
+        del mm
+        torch.cuda.empty_cache()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -445,14 +469,14 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "decode tok/s, %s EXL3 %d.0bpw hot path (all quantized linears + RMSNorm + RoPE + KV-quant), bs=%d" % (
+            "metric": ("decode tok/s, Mixtral-8x7B EXL3 %d.0bpw hot path (attention linears + top-2 of 8 experts per layer + RMSNorm + RoPE + KV-quant), bs=%d" % (args.bits, args.batch)) if is_moe else "decode tok/s, %s EXL3 %d.0bpw hot path (all quantized linears + RMSNorm + RoPE + KV-quant), bs=%d" % (
                 {"llama-3.1-8b": "Llama-3.1-8B", "llama-3.2-1b": "Llama-3.2-1B", "llama-3.1-70b": "Llama-3.1-70B"}.get(shape.name, shape.name), args.bits, args.batch),
             "value": round(tok_s, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{shape.name} EXL3 {args.bits}.0bpw {args.codebook} codebook, decode bs={args.batch}, "
-                                   f"{model.n_layers} layers, TP={world}, {args.kv_bits}-bit KV append, "
-                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, { {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (%d launches/layer)' % (7 if (args.batch == 1 and model.act_in_gemv and world == 1) else (10 if args.batch > 4 else 8)), 'resid': 'resid-in-GEMV pipeline (5 launches/layer: residual add + RMSNorm finished inside the consumer GEMV)' if (args.batch <= 4 and world == 1) else 'fused glue pipeline', 'unfused': 'one launch per reference op'}[pipeline] }; "
+                                   f"{model.n_layers} layers, {'attention TP=%d + expert-parallel MoE over %d rank(s)' % (world, world) if is_moe else 'TP=%d' % world}, {args.kv_bits}-bit KV append, "
+                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, { 'glue pipeline + indexed exl3_mgemm MoE block' if is_moe else {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (%d launches/layer)' % (7 if (args.batch == 1 and model.act_in_gemv and world == 1) else (10 if args.batch > 4 else 8)), 'resid': 'resid-in-GEMV pipeline (5 launches/layer: residual add + RMSNorm finished inside the consumer GEMV)' if (args.batch <= 4 and world == 1) else 'fused glue pipeline', 'unfused': 'one launch per reference op'}[pipeline] }; "
                                    f"{'attention core INCLUDED: quant-cache-direct decode attention over a 1000-token context' if args.attention else 'attention core excluded (SURVEY.md 2.1)'}",
                        "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
                        "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),

@@ -164,27 +164,38 @@ void attn_merge_kernel(const float* __restrict__ part, half_t* __restrict__ out,
     const bool act = item < items_total;
     const int rw = hd >> 2, sub = l / rw, nsub = 128 / hd;
     const float* p = part + (size_t) (act ? item : 0) * nsplit * 132;
-    // statistics of split s: every lane reads its own head's (m, l) -- 8 splits per round, independent loads
+    // lane lr of a head's rw lanes fetches split (s0 + lr)'s (max, sum) so the statistics of up to rw splits arrive in one memory round trip;
+    // the weighted accumulation then streams the split outputs 8 at a time (independent loads)
+    const int lr = l % rw, lbase = lane - lr;
     float M = -1.0e30f;
-    for (int s0 = 0; s0 < nsplit; ++s0) M = fmaxf(M, p[(size_t) s0 * 132 + 2 * sub]);
-    float L = 0.0f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    for (int c0 = 0; c0 < nsplit; c0 += 8)
+    for (int s0 = 0; s0 < nsplit; s0 += rw)
     {
-        float4_t ov[8]; float ev[8], lv[8];
-        #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        float m = (s0 + lr < nsplit) ? p[(size_t) (s0 + lr) * 132 + 2 * sub] : -1.0e30f;
+        for (int j = 1; j < rw; j <<= 1) m = fmaxf(m, __shfl_xor(m, j, 64));
+        M = fmaxf(M, m);
+    }
+    float L = 0.0f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    for (int s0 = 0; s0 < nsplit; s0 += rw)
+    {
+        const bool has = s0 + lr < nsplit;
+        const float2 ml = has ? *((const float2*) (p + (size_t) (s0 + lr) * 132 + 2 * sub)) : float2{ -1.0e30f, 0.0f };
+        const float e_mine = has ? __expf(ml.x - M) : 0.0f;
+        float lsum = ml.y * e_mine;
+        for (int j = 1; j < rw; j <<= 1) lsum += __shfl_xor(lsum, j, 64);
+        L += lsum;
+        const int cnt = min(rw, nsplit - s0);
+        for (int c0 = 0; c0 < cnt; c0 += 8)
         {
-            const int sidx = min(c0 + u, nsplit - 1);
-            ov[u] = *((const float4_t*) (p + (size_t) sidx * 132 + 4 + 4 * l));
-            ev[u] = p[(size_t) sidx * 132 + 2 * sub];
-            lv[u] = p[(size_t) sidx * 132 + 2 * sub + 1];
-        }
-        #pragma unroll
-        for (int u = 0; u < 8; ++u) if (c0 + u < nsplit)
-        {
-            const float e = __expf(ev[u] - M);
-            L += lv[u] * e;
-            o0 += ov[u].x * e; o1 += ov[u].y * e; o2 += ov[u].z * e; o3 += ov[u].w * e;
+            float4_t ov[8]; float ev[8];
+            #pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                const int sidx = min(c0 + u, cnt - 1);
+                ov[u] = *((const float4_t*) (p + (size_t) (s0 + sidx) * 132 + 4 + 4 * l));
+                ev[u] = __shfl(e_mine, lbase + sidx, 64);                            // split sidx's weight lives in lane sidx of this head's lanes
+            }
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) if (c0 + u < cnt) { o0 += ov[u].x * ev[u]; o1 += ov[u].y * ev[u]; o2 += ov[u].z * ev[u]; o3 += ov[u].w * ev[u]; }
         }
     }
     const float inv = L > 0.0f ? 1.0f / L : 0.0f;

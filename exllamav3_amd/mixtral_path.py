@@ -1,0 +1,151 @@
+"""
+The EXL3 hot path of a Mixtral-shaped decoder (BASELINE.json config 5: Mixtral 8x7B, 4.0 bpw, 4-bit KV cache, TP = 2), decode form:
+every layer = attention sublayer (q|k|v GEMV with the RMSNorm inside, RoPE + quantized KV append, optional decode attention straight from
+the quantized cache, o_proj) + sparse-MoE sublayer (RMSNorm, router, indexed gate|up exl3_mgemm of the routed experts, silu * mul, weighted
+down exl3_mgemm) -- reference: TransformerBlock -> Attention (modules/attn.py) + BlockSparseMLP.forward (modules/block_sparse_mlp.py:1099-1478).
+
+Parallelism over N ranks as the reference does it for this model: attention is tensor-parallel (column shards of q/k/v by whole
+KV-head groups, row shard of o_proj + one all-reduce), the MoE block is expert-parallel (each rank holds experts [first, last), the routed
+indices outside the range are filtered inside the launches, the partial sums are all-reduced).  Both all-reduces go through
+TPBackendRCCL.all_reduce_resid: the one-shot IPC push fused with the residual add where it is enabled, RCCL + glue_resid otherwise.
+"""
+from __future__ import annotations
+from dataclasses import dataclass
+import torch
+from . import ext
+from .llama_path import _rand_linear
+from .moe_path import SyntheticEXL3MoE
+from .tp import TPBackendRCCL
+
+
+@dataclass(frozen=True)
+class MixtralShape:
+    name: str
+    hidden: int
+    inter: int
+    layers: int
+    heads_q: int
+    heads_kv: int
+    head_dim: int
+    vocab: int
+    experts: int
+    top_k: int
+    rope_theta: float = 1000000.0
+
+    def decode_bytes_per_token(self, K: int) -> int:
+        """Algorithmic bytes of the quantized linears one token touches at bs = 1: attention linears + top_k experts x (gate, up, down) per layer
+        (k * n * K / 8 + 2 (k + n) each) + the fp16 router + lm_head."""
+        h, i, hd = self.hidden, self.inter, self.head_dim
+        lin = lambda k, n: k * n * K // 8 + 2 * (k + n)
+        attn = lin(h, self.heads_q * hd) + 2 * lin(h, self.heads_kv * hd) + lin(self.heads_q * hd, h)
+        moe = self.top_k * (2 * lin(h, i) + lin(i, h)) + 2 * h * self.experts
+        return (attn + moe) * self.layers + lin(h, self.vocab)
+
+
+MIXTRAL_8X7B = MixtralShape("mixtral-8x7b", 4096, 14336, 32, 32, 8, 128, 32000, 8, 2)
+MIXTRAL_SHAPES = {MIXTRAL_8X7B.name: MIXTRAL_8X7B}
+
+
+class SyntheticEXL3Mixtral:
+    def __init__(self, shape: MixtralShape, K: int = 4, cb: int = 2, device="cuda:0", backend: TPBackendRCCL | None = None, kv_bits: int = 4,
+                 seed: int = 0, max_ctx: int = 4096, layers: int | None = None):
+        self.shape, self.K, self.cb, self.kv_bits = shape, K, cb, kv_bits
+        self.device = torch.device(device)
+        self.backend = backend or TPBackendRCCL(0, 1, self.device)
+        self.tp, self.rank = self.backend.world_size, self.backend.rank
+        self.n_layers = layers or shape.layers
+        tp, rank, hd, h = self.tp, self.rank, shape.head_dim, shape.hidden
+        assert shape.heads_kv % tp == 0 and shape.experts % tp == 0, "TP degree must divide the KV heads and the experts"
+        self.hq, self.hkv = shape.heads_q // tp, shape.heads_kv // tp
+        self.first_expert, self.last_expert = rank * shape.experts // tp, (rank + 1) * shape.experts // tp
+        gen = torch.Generator(device=self.device); gen.manual_seed(seed * 1000 + rank)
+        self.layers = []
+        for li in range(self.n_layers):
+            moe = SyntheticEXL3MoE(h, shape.inter, shape.experts, shape.top_k, K, cb, self.device, seed=seed * 100 + li)   # same experts / router on every rank
+            if tp > 1:
+                # expert parallelism: keep this rank's experts only (the others' tensors are freed), launches filter the routed indices to the range
+                moe.gate, moe.up, moe.down = (l[self.first_expert:self.last_expert] for l in (moe.gate, moe.up, moe.down))
+                moe.first, moe.last = self.first_expert, self.last_expert
+                moe._build_tables()
+            self.layers.append({
+                "q": _rand_linear(h, self.hq * hd, K, cb, self.device, gen), "k": _rand_linear(h, self.hkv * hd, K, cb, self.device, gen),
+                "v": _rand_linear(h, self.hkv * hd, K, cb, self.device, gen),
+                "o": _rand_linear(self.hq * hd, h, K, cb, self.device, gen, out_dtype=torch.float),
+                "norm1": (1.0 + 0.05 * torch.randn(h, device=self.device, generator=gen)).half(),
+                "norm2": (1.0 + 0.05 * torch.randn(h, device=self.device, generator=gen)).half(),
+                "moe": moe,
+            })
+            torch.cuda.empty_cache() if tp > 1 else None
+        self.final_norm = (1.0 + 0.05 * torch.randn(h, device=self.device, generator=gen)).half()
+        vloc = shape.vocab // tp // 128 * 128 if tp > 1 else shape.vocab
+        self.vocab_local = vloc
+        self.lm_head = _rand_linear(h, vloc, K, cb, self.device, gen)
+        self.inv_freq = (1.0 / (shape.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(self.device)
+        self.eps, self.page, self.max_ctx = 1e-5, 256, max_ctx
+        self.with_attention = False
+        self._state_bsz = None
+
+    def alloc_state(self, bsz: int, pos: int = 1000):
+        dev, s, hd = self.device, self.shape, self.shape.head_dim
+        G = self.hkv * hd // 32
+        pps = self.max_ctx // self.page
+        self.block_table = torch.arange(bsz * pps, dtype=torch.int32, device=dev).view(bsz, pps)
+        self.positions = torch.full((bsz,), pos, dtype=torch.int32, device=dev)
+        n_pages = bsz * pps
+        mk = lambda: (torch.zeros((n_pages, self.page, G * self.kv_bits), dtype=torch.int32, device=dev), torch.zeros((n_pages, self.page, G), dtype=torch.half, device=dev))
+        self.kcache = [mk() for _ in range(self.n_layers)]
+        self.vcache = [mk() for _ in range(self.n_layers)]
+        f16, f32 = torch.half, torch.float
+        self.x = torch.randn((bsz, s.hidden), device=dev).to(f16)
+        self.x0 = self.x.clone()
+        self.xn = torch.empty_like(self.x)
+        self.q = torch.empty((bsz, 1, self.hq, hd), dtype=f16, device=dev)
+        self.o = torch.empty((bsz, s.hidden), dtype=f32, device=dev)
+        self.ss = torch.empty((bsz, s.hidden // 128), dtype=f32, device=dev)
+        self.logits = torch.empty((bsz, self.vocab_local), dtype=f16, device=dev)
+        self.attn_pos = pos
+        self.attn_out = torch.empty((bsz, self.hq, hd), dtype=f16, device=dev)
+        self.attn_lens = torch.full((bsz,), pos + 1, dtype=torch.int32, device=dev)
+        self.attn_ws = torch.empty((bsz * self.hq * ((pos + 32) // 32) * 132,), dtype=f32, device=dev)
+        for L in self.layers:
+            L["moe"].alloc_state(bsz)
+        self._state_bsz = bsz
+
+    def decode_step(self):
+        """One decode step (bsz tokens, one per sequence), graph-capturable.  Per layer: 4 launches for the attention sublayer (+2 with the
+        attention core), rms_norm + router + 3-5 launches for the MoE block, glue_resid (or the fused IPC all-reduce) after each sublayer."""
+        bsz, hd, be = self._state_bsz, self.shape.head_dim, self.backend
+        x, ss = self.x, self.ss
+        x.copy_(self.x0)
+        DEF = ext.GEMV_OUT_DEFERRED
+        q2 = self.q.view(bsz, -1)
+        ext.glue_resid(None, 0, None, None, x, ss, bsz)
+        for li, L in enumerate(self.layers):
+            lq, lk, lv, lo, moe = L["q"], L["k"], L["v"], L["o"], L["moe"]
+            kc, ks = self.kcache[li]
+            vc, vs = self.vcache[li]
+            slabs, S = ext.exl3_gemv_ex_norm(x, L["norm1"], ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh], None,
+                                             bsz, lq.mcg, lq.mul1, DEF)
+            ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                         self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd)
+            o_in = q2                                                  # attention core out of the default scope, as in llama_path
+            if self.with_attention:
+                ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
+                                       self.attn_pos + 1, workspace=self.attn_ws)
+                o_in = self.attn_out.view(bsz, -1)
+            if self.tp == 1:
+                so, So = ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF)
+                ext.glue_resid(so[0], So, lo.svh, None, x, ss, bsz)
+            else:
+                lo.bc.run(o_in, self.o)
+                be.all_reduce_resid(self.o, x, ss, bsz)
+            # sparse-MoE sublayer: xn = rms_norm(x) ; y = sum_k w_k expert_k(xn) (this rank's experts) ; x += all_reduce(y)
+            ext.rms_norm(x, L["norm2"], self.xn, self.eps)
+            y = moe.forward(self.xn)                                   # (bsz, hidden) fp32 view of the block's output buffer
+            if self.tp == 1:
+                ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=y.contiguous() if not y.is_contiguous() else y)
+            else:
+                be.all_reduce_resid(y.contiguous() if not y.is_contiguous() else y, x, ss, bsz)
+        ext.exl3_gemv_ex_norm(x, self.final_norm, ss, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
+                              bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
+        return self.logits

@@ -690,3 +690,65 @@ def test_resid_in_gemv_pipeline_with_large_residual_scale_change(dev):
     lr = model.decode_step_resid().float().cpu().numpy().copy()
     ref = _oracle_decode(model, _np(model.x0))
     assert np.abs(lr - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+
+
+@pytest.mark.parametrize("bsz", [1, 3])
+@pytest.mark.parametrize("with_attention", [False, True])
+def test_mixtral_layer_path_matches_oracle(dev, bsz, with_attention):
+    """mixtral_path.SyntheticEXL3Mixtral (config 5's layer: attention sublayer + sparse-MoE sublayer with top-2 routing, 4-bit KV) against the
+    oracle composition, with and without the decode attention over the quantized cache; graph replay reproduces the eager bits."""
+    from exllamav3_amd.mixtral_path import MixtralShape, SyntheticEXL3Mixtral
+    shape = MixtralShape("tiny-moe", 256, 384, 2, 4, 2, 128, 384, 6, 2)
+    model = SyntheticEXL3Mixtral(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=1024)
+    pos = 300
+    model.alloc_state(bsz, pos=pos)
+    model.with_attention = with_attention
+    rng = np.random.default_rng(9)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ctx = []
+    if with_attention:
+        for li in range(shape.layers):      # random context in every layer's cache (contiguous pages per sequence in this model)
+            ck = rng.standard_normal((bsz, 1024, model.hkv * 128)).astype(np.float16); cv = rng.standard_normal((bsz, 1024, model.hkv * 128)).astype(np.float16)
+            kq, ks = o.kv_quant(ck, 4); vq, vs = o.kv_quant(cv, 4)
+            kc, ksc = model.kcache[li]; vc, vsc = model.vcache[li]
+            kc.copy_(T(kq.view(np.int32)).view(kc.shape)); ksc.copy_(T(ks).view(ksc.shape)); vc.copy_(T(vq.view(np.int32)).view(vc.shape)); vsc.copy_(T(vs).view(vsc.shape))
+            ctx.append((kq, ks, vq, vs))
+    logits = model.decode_step().float().cpu().numpy().copy()
+    assert np.isfinite(logits).all()
+    # ---- oracle
+    x = _np(model.x0)
+    pend = None
+    for li, L in enumerate(model.layers):
+        if pend is None: xn = o.rms_norm(x, _np(L["norm1"]), model.eps)
+        else: xn, x = o.rms_norm(pend, _np(L["norm1"]), model.eps, residual_in=x)
+        q, k, v = _lin(L["q"], xn), _lin(L["k"], xn), _lin(L["v"], xn)
+        q4, k4 = o.rope(q.reshape(bsz, 1, model.hq, 128), k.reshape(bsz, 1, model.hkv, 128), _np(model.inv_freq), positions=_np(model.positions), rope_mode=o.ROPE_NEOX)
+        att = q4.reshape(bsz, -1)
+        if with_attention:
+            kq, ks, vq, vs = ctx[li]
+            knq, kns = o.kv_quant(k4.reshape(bsz, 1, -1), 4); vnq, vns = o.kv_quant(v.reshape(bsz, 1, -1), 4)
+            kq[:, pos:pos + 1] = knq; ks[:, pos:pos + 1] = kns; vq[:, pos:pos + 1] = vnq; vs[:, pos:pos + 1] = vns
+            kd = o.kv_dequant(kq, ks, 4).reshape(bsz, 1024, model.hkv, 128); vd = o.kv_dequant(vq, vs, 4).reshape(bsz, 1024, model.hkv, 128)
+            att = o.attn_decode_qcache(q4.reshape(bsz, model.hq, 128), kd, vd, [pos + 1] * bsz).reshape(bsz, -1)
+        ov = _lin(L["o"], att, out_fp32=True)
+        xn, x = o.rms_norm(ov, _np(L["norm2"]), model.eps, residual_in=x)
+        moe = L["moe"]
+        _, sel, w = o.routing_std(xn, _np(moe.router), 2)
+        y = np.zeros((bsz, 256), dtype=np.float32)
+        for t in range(bsz):
+            for j in range(2):
+                e = int(sel[t, j])
+                g = _lin(moe.gate[e], xn[t:t + 1]).astype(np.float32); u = _lin(moe.up[e], xn[t:t + 1]).astype(np.float32)
+                a = (g / (1 + np.exp(-g)) * u).astype(np.float16)
+                y[t] += float(w[t, j]) * _lin(moe.down[e], a, out_fp32=True)[0]
+        pend = y
+    xn, x = o.rms_norm(pend, _np(model.final_norm), model.eps, residual_in=x)
+    ref = _lin(model.lm_head, xn).astype(np.float32)
+    assert np.abs(logits - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_, stream=st):
+            model.decode_step()
+    model.logits.zero_(); g_.replay(); torch.cuda.synchronize()
+    assert np.array_equal(model.logits.float().cpu().numpy(), logits)
