@@ -989,9 +989,32 @@ extern "C" int exl3_gemv_qkv(const void* A, const void* const* xhs, const float*
 //   re-based to min_index, the remaining slots are skipped; A [bszm_in][m][k] (bszm_in == 1: shared), C [bszm][m][n];
 //   weights (fp16 [bszm]): each slot's output is scaled by its weight inside the output Hadamard scale, then every group of
 //   bszm / num_tokens slots is summed into C[t].
+static int mgemm_indexed_impl(const void* A, const void* act_u, int bszm_in, const void* tbl_B, const void* tbl_suh, const void* tbl_svh,
+                              const int64_t* indices, const void* weights, int bszm, void* C, int m, int k, int n, int K, int cb, int c_fp32,
+                              int min_index, int max_index, int num_tokens, void* stream);
+
 extern "C" int exl3_mgemm_indexed(const void* A, int bszm_in, const void* tbl_B, const void* tbl_suh, const void* tbl_svh,
                                   const int64_t* indices, const void* weights, int bszm, void* C, int m, int k, int n, int K, int cb, int c_fp32,
                                   int min_index, int max_index, int num_tokens, void* stream)
+{
+    return mgemm_indexed_impl(A, nullptr, bszm_in, tbl_B, tbl_suh, tbl_svh, indices, weights, bszm, C, m, k, n, K, cb, c_fp32, min_index, max_index,
+                              num_tokens, stream);
+}
+
+// exl3_mgemm_indexed whose input is fp16(silu(G_j) * U_j) per slot (G, U: [bszm][m][k] fp16, the gate / up outputs of the routed experts): the
+// silu_mul launch between the gate|up and the down exl3_mgemm of a MoE block (block_sparse_mlp.py / activation.cu) folded into the down launch.
+extern "C" int exl3_mgemm_indexed_act(const void* G, const void* U, const void* tbl_B, const void* tbl_suh, const void* tbl_svh,
+                                      const int64_t* indices, const void* weights, int bszm, void* C, int m, int k, int n, int K, int cb, int c_fp32,
+                                      int min_index, int max_index, int num_tokens, void* stream)
+{
+    EXL3_CHECK_ARG(U, "exl3_mgemm_indexed_act: null up tensor");
+    return mgemm_indexed_impl(G, U, bszm, tbl_B, tbl_suh, tbl_svh, indices, weights, bszm, C, m, k, n, K, cb, c_fp32, min_index, max_index,
+                              num_tokens, stream);
+}
+
+static int mgemm_indexed_impl(const void* A, const void* act_u, int bszm_in, const void* tbl_B, const void* tbl_suh, const void* tbl_svh,
+                              const int64_t* indices, const void* weights, int bszm, void* C, int m, int k, int n, int K, int cb, int c_fp32,
+                              int min_index, int max_index, int num_tokens, void* stream)
 {
     EXL3_CHECK_ARG(A && tbl_B && tbl_suh && tbl_svh && C, "exl3_mgemm: null pointer");
     EXL3_CHECK_ARG(bszm >= 1 && (bszm_in == 1 || bszm_in == bszm), "exl3_mgemm: A must have 1 or bszm slots");
@@ -1004,6 +1027,7 @@ extern "C" int exl3_mgemm_indexed(const void* A, int bszm_in, const void* tbl_B,
     t.bszm = bszm; t.min_index = min_index; t.max_index = max_index; t.n = n; t.cbs_per_mat = n / 128;
     t.a_slot_stride = bszm_in == 1 ? 0 : (int64_t) m * k;
     t.c_slot_stride = (int64_t) m * n;
+    t.act_u = (const half_t*) act_u;
     const void* Bs[1] = { tbl_B }; int ns[1] = { n };
     const void* su[1] = { tbl_suh }; const void* sv[1] = { tbl_svh }; void* Cs[1] = { C };
     int rc = run_mgemm(A, Bs, Cs, su, sv, nullptr, ns, bszm, m, k, K, cb, c_fp32, 0, (hipStream_t) stream, 0, nullptr, nullptr, nullptr, nullptr,

@@ -254,6 +254,10 @@ void exl3_gemv2_kernel(const GemvArgs a)
             for (int i = 0; i < SLAB_PRE; ++i) r.sg[i] = ((const float4_t*) (pg + (size_t) min(i, a.rs_S - 1) * st))[l32];
             r.svg = ((const half4_t*) (a.rs_svh + blk_abs * 128))[l32];
         }
+        if constexpr (MODE == G2_MODE_TABLE)
+        {
+            if (a.tbl.act_u) r.wv = ((const half4_t*) (a.tbl.act_u + (A_in - a.A) + (size_t) row * a.k + kofs))[l32];   // the slot's `up` row
+        }
         if (!in_rotated)
         {
             r.sv = ((const half4_t*) (suh + kofs))[l32];
@@ -334,6 +338,15 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 else
                 {
                     half4_t xv = cur.xv;
+                    if constexpr (MODE == G2_MODE_TABLE)
+                    {
+                        if (a.tbl.act_u)
+                        {
+                            // x = fp16(silu(g) * u): the arithmetic of silu_mul (exl3_elementwise.hip / activation.cu), per element
+                            auto silu_mul1 = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
+                            xv = half4_t{ silu_mul1(xv.x, cur.wv.x), silu_mul1(xv.y, cur.wv.y), silu_mul1(xv.z, cur.wv.z), silu_mul1(xv.w, cur.wv.w) };
+                        }
+                    }
                     if constexpr (G2_IS_ACT(MODE))
                     {
                         // a = fp16(silu(g) * u) of this (row, block): split-k reduce of the gate / up slabs, output Hadamards, svh -- the arithmetic of

@@ -75,6 +75,8 @@ struct GemvTable
     int bszm, min_index, max_index, n, cbs_per_mat;
     int64_t a_slot_stride;                                          // elements between the inputs of two slots (0: one shared input)
     int64_t c_slot_stride;                                          // elements between the outputs of two slots
+    const half_t* act_u;                                            // non-null: the input of slot j is fp16(silu(A_j) * act_u_j) (A = gate, act_u = up outputs,
+                                                                    // same slot stride): activation.cu silu_mul folded into the down launch of a MoE block
 };
 
 struct SlotRef_t { int mat_index; float weight; };

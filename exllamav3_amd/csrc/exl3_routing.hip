@@ -11,7 +11,7 @@
 __global__ __launch_bounds__(256)
 void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restrict__ gate, const half_t* __restrict__ bias,
                         half_t* __restrict__ scores, int64_t* __restrict__ topk_indices, half_t* __restrict__ topk_weights,
-                        int H, int E, int K)
+                        int H, int E, int K, int64_t* __restrict__ gu_slots, int rows)
 {
     __shared__ float logit_s[ROUTING_MAX_EXPERTS];
     __shared__ float sel_logit[ROUTING_MAX_K];
@@ -68,11 +68,25 @@ void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restr
     {
         topk_indices[(size_t) row * K + lane] = (int64_t) sel_idx[lane];
         topk_weights[(size_t) row * K + lane] = f2h(ev);
+        if (gu_slots)
+        {
+            // slot lists of the indexed gate | up launch over the pointer tables [gate_0..gate_E-1, up_0..up_E-1]: [rows * K gate slots | rows * K up slots]
+            gu_slots[(size_t) row * K + lane] = (int64_t) sel_idx[lane];
+            gu_slots[(size_t) rows * K + (size_t) row * K + lane] = (int64_t) sel_idx[lane] + E;
+        }
     }
 }
 
 extern "C" int exl3_routing_std(const void* hidden, const void* gate, const void* bias, void* scores, int64_t* topk_indices, void* topk_weights,
                                 int bsz, int hidden_size, int num_experts, int K, void* stream)
+{
+    return exl3_routing_std_slots(hidden, gate, bias, scores, topk_indices, topk_weights, nullptr, bsz, hidden_size, num_experts, K, stream);
+}
+
+// routing_std that also writes gu_slots int64 [2][bsz * K] = [selected experts | selected experts + num_experts]: the slot list of ONE indexed
+// exl3_mgemm over the concatenated gate | up pointer tables (saves the two torch index kernels between the router and the launch)
+extern "C" int exl3_routing_std_slots(const void* hidden, const void* gate, const void* bias, void* scores, int64_t* topk_indices, void* topk_weights,
+                                      int64_t* gu_slots, int bsz, int hidden_size, int num_experts, int K, void* stream)
 {
     EXL3_CHECK_ARG(hidden && gate && scores && topk_indices && topk_weights, "routing_std: null pointer");
     EXL3_CHECK_ARG(num_experts >= 1 && num_experts <= ROUTING_MAX_EXPERTS, "Too many experts");
@@ -80,6 +94,6 @@ extern "C" int exl3_routing_std(const void* hidden, const void* gate, const void
     EXL3_CHECK_ARG(K <= num_experts, "K cannot exceed number of experts");
     if (bsz == 0) return EXL3_OK;
     routing_std_kernel<<<bsz, 256, 0, (hipStream_t) stream>>>((const half_t*) hidden, (const half_t*) gate, (const half_t*) bias, (half_t*) scores,
-                                                             topk_indices, (half_t*) topk_weights, hidden_size, num_experts, K);
+                                                             topk_indices, (half_t*) topk_weights, hidden_size, num_experts, K, gu_slots, bsz);
     return exl3_check_launch("routing_std");
 }

@@ -276,6 +276,25 @@ def exl3_mgemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, suh: torch.Ten
     return 90
 
 
+def exl3_mgemm_act(G: torch.Tensor, U: torch.Tensor, B: torch.Tensor, C: torch.Tensor, suh: torch.Tensor, svh: torch.Tensor, indices, weights,
+                   K: int, mcg: int, mul1: int, min_index: int = -1, max_index: int = -1, num_tokens: int = 1) -> int:
+    """exl3_mgemm (indexed) whose per-slot input is fp16(silu(G_j) * U_j): G, U [bszm, m, k] fp16 = the gate / up outputs of the routed experts
+    (the silu_mul launch of the MoE block folded into the down launch).  Other arguments as exl3_mgemm."""
+    _dev(G)
+    _req(G.dtype == torch.half and U.dtype == torch.half and G.shape == U.shape and G.dim() == 3 and G.is_contiguous() and U.is_contiguous(),
+         "exl3_mgemm_act: G, U must be contiguous float16 [bszm, m, k]")
+    _req(B.dtype == torch.long and suh.dtype == torch.long and svh.dtype == torch.long, "exl3_mgemm_act: B, suh, svh must be int64 pointer tensors")
+    _req(C.dim() == 3 and C.is_contiguous() and C.shape[0] == G.shape[0] and C.shape[1] == G.shape[1] and C.dtype in (torch.half, torch.float), "exl3_mgemm_act: bad C")
+    bszm, m, k = G.shape
+    n = C.shape[2]
+    _req(k % 128 == 0 and n % 128 == 0, "exl3_mgemm_act: k and n must be divisible by 128")
+    _req(num_tokens == 1 or min_index < 0, "exl3_mgemm_act: num_tokens > 1 is not compatible with an expert range")
+    _check(_lib.lib().exl3_mgemm_indexed_act(_p(G), _p(U), _p(B), _p(suh), _p(svh), _p(indices), _p(weights), bszm, _p(C), m, k, n, int(K),
+                                             _cb(bool(mcg), bool(mul1)), int(C.dtype == torch.float), int(min_index), int(max_index),
+                                             int(num_tokens), _stream(G)))
+    return 90
+
+
 def exl3_mgemm_bcast(A: torch.Tensor, Bs: list[torch.Tensor], Cs: list[torch.Tensor], suhs: list[torch.Tensor],
                      svhs: list[torch.Tensor], mcg: bool = False, mul1: bool = False, force_split: int = 0) -> int:
     """Broadcast form of quant/exl3_gemm.cuh:58-78 (indices == None): one A against several matrices in ONE launch
@@ -746,8 +765,10 @@ class BC_GatedMLP:
             add(d2, dn.bias.view(1, -1).expand(m, -1).contiguous() if m > 1 else dn.bias)
 
 
-def routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_scale=None, gate_t=None, bias=None):
-    """routing.cu:955-1010 (same argument order): scores = hidden @ gate, top-K by logit, softmax over the selected logits."""
+def routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_scale=None, gate_t=None, bias=None, gu_slots=None):
+    """routing.cu:955-1010 (same argument order): scores = hidden @ gate, top-K by logit, softmax over the selected logits.
+    gu_slots (this build, optional): int64 [2][bsz * K] receiving [selected | selected + experts], the slot list of one indexed exl3_mgemm over
+    concatenated gate | up pointer tables."""
     _dev(hidden)
     _req(per_expert_scale is None, "routing_std: per_expert_scale is outside this build")
     _req(hidden.dtype == torch.half and gate.dtype == torch.half and scores.dtype == torch.half, "routing_std: hidden, gate, scores must be float16")
@@ -756,8 +777,10 @@ def routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_sca
     _req(topk_indices.shape == topk_weights.shape and scores.shape[0] == topk_indices.shape[0], "routing_std: shape mismatch")
     _req(hidden.is_contiguous() and gate.is_contiguous() and scores.is_contiguous(), "routing_std: tensors must be contiguous")
     bsz = scores.shape[0]
-    _check(_lib.lib().exl3_routing_std(_p(hidden), _p(gate), _p(bias), _p(scores), _p(topk_indices), _p(topk_weights), bsz, hidden.shape[-1],
-                                       scores.shape[1], topk_indices.shape[1], _stream(hidden)))
+    if gu_slots is not None:
+        _req(gu_slots.dtype == torch.long and gu_slots.is_contiguous() and gu_slots.numel() == 2 * topk_indices.numel(), "routing_std: gu_slots must be int64 [2][bsz * K]")
+    _check(_lib.lib().exl3_routing_std_slots(_p(hidden), _p(gate), _p(bias), _p(scores), _p(topk_indices), _p(topk_weights), _p(gu_slots), bsz,
+                                             hidden.shape[-1], scores.shape[1], topk_indices.shape[1], _stream(hidden)))
 
 
 def exl3_gemv_ex_act(gu_slabs, gu_S: int, svh_g, svh_u, B, C, suh, svh, m: int, mcg: bool, mul1: bool, flags: int = 0, force_split: int = 0,

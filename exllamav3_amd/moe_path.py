@@ -101,25 +101,23 @@ class SyntheticEXL3MoE:
         t, k = x.shape[0], self.top_k
         if self._state != t:
             self.alloc_state(t)
-        ext.routing_std(x, self.router, self.scores, self.sel, self.w)
+        # the router also leaves the [gate slots | up slots] index list of the one-launch gate|up mgemm (no torch index kernels in between)
+        ext.routing_std(x, self.router, self.scores, self.sel, self.w, gu_slots=self.sel2)
         mcg, mul1 = self.cb == 1, self.cb == 2
         if (self.first, self.last) != (0, self.E):
             return self._forward_expert_parallel(x)
         if t == 1:
             # one shared input row: gate and up of the k selected experts in one launch (slots = 2k)
-            torch.stack((self.sel.view(-1), self.sel.view(-1) + self.E), out=self.sel2)
             ext.exl3_mgemm(x.view(1, 1, -1), self.gu_B, self.gu, self.gu_suh, None, self.gu_svh, self.sel2.view(-1), None,
                            self.K, -1, mcg, mul1, -1, -1, 0)
         else:
             # several tokens: every (token, expert) slot has its own input row
             xs = x.repeat_interleave(k, dim=0).view(t * k, 1, -1).contiguous()
-            sel = self.sel.view(-1)
-            ext.exl3_mgemm(xs, self.gu_B, self.gu[: t * k], self.gu_suh, None, self.gu_svh, sel, None, self.K, -1, mcg, mul1, -1, -1, 0)
-            ext.exl3_mgemm(xs, self.gu_B, self.gu[t * k:], self.gu_suh, None, self.gu_svh, (sel + self.E).contiguous(), None,
-                           self.K, -1, mcg, mul1, -1, -1, 0)
-        ext.silu_mul(self.gu[: t * k], self.gu[t * k:], self.a)
-        ext.exl3_mgemm(self.a, self.d_B, self.d, self.d_suh, None, self.d_svh, self.sel.view(-1), self.w.view(-1), self.K, -1, mcg, mul1,
-                       -1, -1, 0, num_tokens=t)
+            ext.exl3_mgemm(xs, self.gu_B, self.gu[: t * k], self.gu_suh, None, self.gu_svh, self.sel2[0], None, self.K, -1, mcg, mul1, -1, -1, 0)
+            ext.exl3_mgemm(xs, self.gu_B, self.gu[t * k:], self.gu_suh, None, self.gu_svh, self.sel2[1], None, self.K, -1, mcg, mul1, -1, -1, 0)
+        # down of the routed experts on a = silu(g) * u, formed while the launch builds its activation fragments (no silu_mul launch)
+        ext.exl3_mgemm_act(self.gu[: t * k], self.gu[t * k:], self.d_B, self.d, self.d_suh, self.d_svh, self.sel.view(-1), self.w.view(-1), self.K,
+                           mcg, mul1, -1, -1, num_tokens=t)
         return self.d[:t, 0]
 
     def _forward_expert_parallel(self, x: torch.Tensor) -> torch.Tensor:
@@ -135,8 +133,7 @@ class SyntheticEXL3MoE:
             g, u, a, d = self.gu[i * k: (i + 1) * k], self.gu[(t + i) * k: (t + i + 1) * k], self.a[i * k: (i + 1) * k], self.d[i * k: (i + 1) * k]
             ext.exl3_mgemm(xi, self.g_B, g, self.g_suh, None, self.g_svh, sel, None, self.K, -1, mcg, mul1, self.first, self.last, 0)
             ext.exl3_mgemm(xi, self.u_B, u, self.u_suh, None, self.u_svh, sel, None, self.K, -1, mcg, mul1, self.first, self.last, 0)
-            ext.silu_mul(g, u, a)
-            ext.exl3_mgemm(a, self.d_B, d, self.d_suh, None, self.d_svh, sel, w, self.K, -1, mcg, mul1, self.first, self.last, 0)
+            ext.exl3_mgemm_act(g, u, self.d_B, d, self.d_suh, self.d_svh, sel, w, self.K, mcg, mul1, self.first, self.last)
         return self.d.view(t, k, 1, self.hidden)[:, 0, 0]
 
     def packed_bytes_per_token(self) -> int:

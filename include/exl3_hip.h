@@ -312,6 +312,15 @@ int exl3_add(void* x, const void* y, int64_t numel, int x_fp32, int y_fp32, void
  * post-op for soft-capped logits (modules/linear.py:598-599) */
 int exl3_softcap(const void* x, void* y, int64_t numel, float scale, int is_fp32, void* stream);
 
+/* ---- MoE block fusions (block_sparse_mlp.py:1099-1478 at decode): fewer launches around the indexed exl3_mgemm ------------------------------
+ * exl3_routing_std_slots: routing_std (routing.cu:955-1010) that also writes the [gate slots | up slots] index list of one indexed launch over the
+ * concatenated gate | up pointer tables.  exl3_mgemm_indexed_act: the down launch whose per-slot input is fp16(silu(G_j) * U_j) (silu_mul folded in). */
+int exl3_routing_std_slots(const void* hidden, const void* gate, const void* bias, void* scores, int64_t* topk_indices, void* topk_weights,
+                           int64_t* gu_slots, int bsz, int hidden_size, int num_experts, int K, void* stream);
+int exl3_mgemm_indexed_act(const void* G, const void* U, const void* tbl_B, const void* tbl_suh, const void* tbl_svh,
+                           const int64_t* indices, const void* weights, int bszm, void* C, int m, int k, int n, int K, int cb, int c_fp32,
+                           int min_index, int max_index, int num_tokens, void* stream);
+
 /* ---- tensor-parallel decode all-reduce: one-shot push over IPC-mapped peer buffers (xGMI), fused with the residual add -------------------------
  * Replaces TPBackendNCCL.all_reduce (model/model_tp_backend.py:119-126) / the native small-message all-reduce (exllamav3_ext/parallel/all_reduce.cu:18-232)
  * for the (tokens x hidden) fp32 partial sums after o_proj / down_proj at decode.  One process per GPU:
