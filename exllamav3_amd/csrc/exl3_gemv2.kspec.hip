@@ -532,11 +532,27 @@ void exl3_gemv2_kernel(const GemvArgs a)
 #ifdef G2_ABL_NOBPERM
                 Wx[0] = ring[u].w[K - 1] * 11u;                          // diagnostics build: no cross-lane carry
 #else
+#ifdef G2_CARRY_BPERMUTE
                 Wx[0] = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) ring[u].w[K - 1]);
+#else
+                // carry-in = last word of the previous lane of the 8-lane tile group (lane c = 0 wraps to c = 7: the tile stream is circular).
+                // Two DPP row rotates + a select (register file only) instead of ds_bpermute (LDS crossbar: -6 % on lm_head when ablated):
+                // row_ror:1 gives lane i <- i - 1 within the 16-lane row, row_ror:9 gives i <- i - 9 = i + 7 (mod 16), i.e. the wrap for c = 0
+                {
+                    const uint32_t wl = ring[u].w[K - 1];
+                    const uint32_t r1 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x121, 0xf, 0xf, true);
+                    const uint32_t r9 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x129, 0xf, 0xf, true);
+                    Wx[0] = (lane & 7) ? r1 : r9;
+                }
+#endif
 #endif
 
                 // refill the slot
+#ifdef G2_ABL_HOT
+                load_lane_words<K>(ring[u], strip + (size_t) ((PF * nxt + u) & 1) * row_stride);     // diagnostics build: the same two (cache-hot) rows every step
+#else
                 load_lane_words<K>(ring[u], strip + (size_t) (PF * nxt + u) * row_stride);
+#endif
 
                 // A fragments of this tile row for this lane's activation row
                 const half_t* ap = arow + (size_t) (row - c0 * 8) * astep;
