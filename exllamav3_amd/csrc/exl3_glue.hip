@@ -136,7 +136,7 @@ void glue_resid_kernel(const float* __restrict__ y_base, int y_S, int has_y, con
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
     const int nblk = hidden >> 7;
     const int tasks = m * nblk;
-    const int t = blockIdx.x * 8 + hw;
+    const int t = blockIdx.x * (blockDim.x >> 5) + hw;                 // half-wave tasks per workgroup = blockDim / 32
     const bool act = t < tasks;
     const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
     half4_t r = ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
@@ -182,7 +182,7 @@ void glue_rotate_kernel(const half_t* __restrict__ resid, const float* __restric
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
     const int nblk = hidden >> 7;
     const int tasks = m * nblk;
-    const int t = blockIdx.x * 8 + hw;
+    const int t = blockIdx.x * (blockDim.x >> 5) + hw;                 // half-wave tasks per workgroup = blockDim / 32
     const bool act = t < tasks;
     const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
     const half4_t r = ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
@@ -241,7 +241,7 @@ void glue_qkv_kernel(QkvArgs a)
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
     const int heads = a.hq + 2 * a.hkv;
     const int tasks = a.m * heads;
-    const int t = blockIdx.x * 8 + hw;
+    const int t = blockIdx.x * (blockDim.x >> 5) + hw;                 // half-wave tasks per workgroup = blockDim / 32
     const bool act = t < tasks;
     const int row = act ? t / heads : 0, head = act ? t % heads : 0;
     const int kind = head < a.hq ? 0 : (head < a.hq + a.hkv ? 1 : 2);
@@ -324,7 +324,7 @@ void glue_act_kernel(SlabRef sg, SlabRef su, const half_t* __restrict__ svh_g, c
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
     const int nblk = inter >> 7;
     const int tasks = m * nblk;
-    const int t = blockIdx.x * 8 + hw;
+    const int t = blockIdx.x * (blockDim.x >> 5) + hw;                 // half-wave tasks per workgroup = blockDim / 32
     const bool act = t < tasks;
     const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
     // all independent loads first (scales of this block), then the slabs
@@ -377,15 +377,26 @@ extern "C" int exl3_glue_norm(const float* y_slabs, int y_S, const float* y_dens
 }
 
 template <int KB>
-static void launch_qkv(int vb, dim3 grid, hipStream_t st, const QkvArgs& a)
+static void launch_qkv(int vb, dim3 grid, int threads, hipStream_t st, const QkvArgs& a)
 {
     switch (vb)
     {
-        case 2: glue_qkv_kernel<KB, 2><<<grid, 256, 0, st>>>(a); break; case 3: glue_qkv_kernel<KB, 3><<<grid, 256, 0, st>>>(a); break;
-        case 4: glue_qkv_kernel<KB, 4><<<grid, 256, 0, st>>>(a); break; case 5: glue_qkv_kernel<KB, 5><<<grid, 256, 0, st>>>(a); break;
-        case 6: glue_qkv_kernel<KB, 6><<<grid, 256, 0, st>>>(a); break; case 7: glue_qkv_kernel<KB, 7><<<grid, 256, 0, st>>>(a); break;
-        default: glue_qkv_kernel<KB, 8><<<grid, 256, 0, st>>>(a); break;
+        case 2: glue_qkv_kernel<KB, 2><<<grid, threads, 0, st>>>(a); break; case 3: glue_qkv_kernel<KB, 3><<<grid, threads, 0, st>>>(a); break;
+        case 4: glue_qkv_kernel<KB, 4><<<grid, threads, 0, st>>>(a); break; case 5: glue_qkv_kernel<KB, 5><<<grid, threads, 0, st>>>(a); break;
+        case 6: glue_qkv_kernel<KB, 6><<<grid, threads, 0, st>>>(a); break; case 7: glue_qkv_kernel<KB, 7><<<grid, threads, 0, st>>>(a); break;
+        default: glue_qkv_kernel<KB, 8><<<grid, threads, 0, st>>>(a); break;
     }
+}
+
+// half-wave tasks of the glue kernels are spread over as many CUs as possible: a task's slab lines (S x 512 B) come in at the per-CU load rate, so
+// few fat workgroups are slower than many thin ones (a one-workgroup-per-row fusion of glue_resid + glue_rotate measured 2.2 us SLOWER per
+// boundary than the two launches).  64-thread workgroups (2 tasks) up to 512 tasks, 256-thread ones above.
+static int g_glue_threads = 0;
+extern "C" int exl3_set_glue_threads(int t) { g_glue_threads = t; return EXL3_OK; }
+static int glue_threads(int tasks)
+{
+    if (g_glue_threads > 0) return g_glue_threads;
+    return tasks <= 512 ? 64 : 256;
 }
 
 extern "C" int exl3_glue_qkv(const float* sq, const float* sk, const float* sv, int S, const void* svh_q, const void* svh_k, const void* svh_v,
@@ -424,14 +435,15 @@ extern "C" int exl3_glue_qkv_rs(const float* sq, const float* sk, const float* s
     a.m = m; a.hq = heads_q * head_dim / 128; a.hkv = heads_kv * head_dim / 128; a.hd = head_dim; a.rope_mode = rope_mode; a.attn_factor = attn_factor;
     a.rs = GemvRescale{ ss_prev, ss_new, hidden, eps };
     int tasks = m * (a.hq + 2 * a.hkv);
-    dim3 grid((tasks + 7) / 8);
+    const int th = glue_threads(tasks), tpw = th / 32;
+    dim3 grid((tasks + tpw - 1) / tpw);
     hipStream_t st = (hipStream_t) stream;
     int kb = k_cache ? k_bits : 8, vb = k_cache ? v_bits : 8;
     switch (kb)
     {
-        case 2: launch_qkv<2>(vb, grid, st, a); break; case 3: launch_qkv<3>(vb, grid, st, a); break; case 4: launch_qkv<4>(vb, grid, st, a); break;
-        case 5: launch_qkv<5>(vb, grid, st, a); break; case 6: launch_qkv<6>(vb, grid, st, a); break; case 7: launch_qkv<7>(vb, grid, st, a); break;
-        default: launch_qkv<8>(vb, grid, st, a); break;
+        case 2: launch_qkv<2>(vb, grid, th, st, a); break; case 3: launch_qkv<3>(vb, grid, th, st, a); break; case 4: launch_qkv<4>(vb, grid, th, st, a); break;
+        case 5: launch_qkv<5>(vb, grid, th, st, a); break; case 6: launch_qkv<6>(vb, grid, th, st, a); break; case 7: launch_qkv<7>(vb, grid, th, st, a); break;
+        default: launch_qkv<8>(vb, grid, th, st, a); break;
     }
     return exl3_check_launch("glue_qkv");
 }
@@ -443,7 +455,8 @@ extern "C" int exl3_glue_act(const float* sg, const float* su, int S, const void
     EXL3_CHECK_ARG(m >= 1 && m <= 16 && inter % 128 == 0, "glue_act: bad dimensions");
     int tasks = m * (inter / 128);
     SlabRef g = { sg, S }, u = { su, S };
-    glue_act_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>(g, u, (const half_t*) svh_g, (const half_t*) svh_u, (const half_t*) suh_d,
+    const int th = glue_threads(tasks), tpw = th / 32;
+    glue_act_kernel<<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(g, u, (const half_t*) svh_g, (const half_t*) svh_u, (const half_t*) suh_d,
                                                                        (half_t*) xh_d, xsum_d, (half_t*) a_out, m, inter);
     return exl3_check_launch("glue_act");
 }
@@ -476,7 +489,8 @@ extern "C" int exl3_glue_resid(const float* y_slabs, int y_S, const float* y_den
     EXL3_CHECK_ARG(!y_slabs || (svh && y_S >= 1), "glue_resid: pending output needs svh");
     SlabRef y = { y_slabs, y_S };
     const int tasks = m * (hidden / 128);
-    glue_resid_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>(y.base, y.S, (y_slabs || y_dense) ? 1 : 0, y_dense, (const half_t*) svh,
+    const int th = glue_threads(tasks), tpw = th / 32;
+    glue_resid_kernel<<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(y.base, y.S, (y_slabs || y_dense) ? 1 : 0, y_dense, (const half_t*) svh,
                                                                         (const half_t*) bias, (half_t*) resid, ss_part, m, hidden);
     return exl3_check_launch("glue_resid");
 }
@@ -496,6 +510,7 @@ extern "C" int exl3_glue_rotate(const void* resid, const float* ss_part, const v
         EXL3_CHECK_ARG(i >= count || (tg.suh[i] && tg.xh[i]), "glue_rotate: null consumer pointer");
     }
     const int tasks = m * (hidden / 128);
-    glue_rotate_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>((const half_t*) resid, ss_part, (const half_t*) w, eps, tg, m, hidden);
+    const int th = glue_threads(tasks), tpw = th / 32;
+    glue_rotate_kernel<<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>((const half_t*) resid, ss_part, (const half_t*) w, eps, tg, m, hidden);
     return exl3_check_launch("glue_rotate");
 }

@@ -200,6 +200,7 @@ int exl3_glue_resid(const float* y_slabs, int y_S, const float* y_dense, const v
 
 /* glue 1b (batches above 4 rows): xh_i = had128(rms_norm(resid) * w * suh_i) for up to 3 consumers from resid + ss_part (exl3_glue_resid);
  * distributed over (row, block); the consumer GEMVs then run with EXL3_GEMV_IN_ROTATED.  xsums optional. */
+int exl3_set_glue_threads(int threads);   /* tuning: threads per workgroup of the glue kernels (0 = heuristic: 64 up to 512 half-wave tasks, else 256) */
 int exl3_glue_rotate(const void* resid, const float* ss_part, const void* w, float eps, const void* const* suhs, void* const* xhs,
                      float* const* xsums, int count, int m, int hidden, void* stream);
 
