@@ -19,18 +19,57 @@ void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restr
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const half_t* x = hidden + (size_t) row * H;
 
-    // scores: one wave per expert (round robin), lanes stride over the hidden dimension; gate is [H][E] row-major
-    for (int e = wave; e < E; e += 4)
+    // scores: gate is [H][E] row-major, so a thread reads 8 consecutive experts of one hidden row as ONE 16-byte load.  E a multiple of 8 with
+    // E / 8 dividing 256 (8, 16, 32, 64 ... 512 experts): thread t owns expert chunk t % (E / 8) and the hidden rows t / (E / 8) + j * (256 / (E / 8));
+    // 16-byte loads, 8 independent FMA chains per thread, then a fixed-order sum of the per-thread partials through LDS (deterministic).
+    // (The first version -- one wave per expert striding over H with 2-byte loads at stride 2E -- took 25.6 us per call at E = 8, H = 4096:
+    // 13 % of the Mixtral decode step, profiles/r02_bench_mixtral_kernel_stats.csv.)  Other E: the per-expert loop.
+    const int nch = E >> 3;
+    if ((E & 7) == 0 && nch <= 64 && (256 % nch) == 0)
     {
-        float acc = 0.0f;
-        for (int h = lane; h < H; h += 64) acc = __builtin_fmaf((float) x[h], (float) gate[(size_t) h * E + e], acc);
-        #pragma unroll
-        for (int i = 1; i < 64; i <<= 1) acc += xor_lane(acc, i);
-        if (lane == 0)
+        __shared__ float part_s[256][8];
+        const int ch = tid % nch, rows_per_pass = 256 / nch;
+        float acc[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        for (int h = tid / nch; h < H; h += rows_per_pass)
         {
-            const half_t s = f2h(acc);                     // the reference materialises fp16 scores and routes on them
-            scores[(size_t) row * E + e] = s;
-            logit_s[e] = (float) s + (bias ? (float) bias[e] : 0.0f);
+            const half8_t g = *((const half8_t*) (gate + (size_t) h * E + ch * 8));
+            const float xv = (float) x[h];
+            #pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(xv, (float) g[i], acc[i]);
+        }
+        #pragma unroll
+        for (int i = 0; i < 8; ++i) part_s[tid][i] = acc[i];
+        __syncthreads();
+        for (int e = tid; e < E; e += 256)
+        {
+            const int c = e >> 3, i = e & 7;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;                    // four interleaved chains, fixed order
+            for (int t = c; t < 256; t += 4 * nch)
+            {
+                a0 += part_s[t][i];
+                if (t + nch < 256) a1 += part_s[t + nch][i];
+                if (t + 2 * nch < 256) a2 += part_s[t + 2 * nch][i];
+                if (t + 3 * nch < 256) a3 += part_s[t + 3 * nch][i];
+            }
+            const half_t sc = f2h((a0 + a1) + (a2 + a3));                    // the reference materialises fp16 scores and routes on them
+            scores[(size_t) row * E + e] = sc;
+            logit_s[e] = (float) sc + (bias ? (float) bias[e] : 0.0f);
+        }
+    }
+    else
+    {
+        for (int e = wave; e < E; e += 4)
+        {
+            float acc = 0.0f;
+            for (int h = lane; h < H; h += 64) acc = __builtin_fmaf((float) x[h], (float) gate[(size_t) h * E + e], acc);
+            #pragma unroll
+            for (int i = 1; i < 64; i <<= 1) acc += xor_lane(acc, i);
+            if (lane == 0)
+            {
+                const half_t s = f2h(acc);
+                scores[(size_t) row * E + e] = s;
+                logit_s[e] = (float) s + (bias ? (float) bias[e] : 0.0f);
+            }
         }
     }
     __syncthreads();
