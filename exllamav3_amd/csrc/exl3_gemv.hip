@@ -476,14 +476,6 @@ static int g_gemv_defer_wg_per_cu = 0;
 // promise (CU masking, harvested XCDs, other firmware): enabling it runs a probe over the grid sizes the mode is used with and refuses
 // (EXL3_ERR_ARG, mode stays off) unless every workgroup reported XCC_ID == blockIdx % 8 on several launches.  Default: agent-scope hand-off.
 static int g_tail_xcd_local = 0;
-// one-shot: the NEXT exl3_gemv_ex / exl3_gemv_ex_norm launch of this thread overlaps with its producer (GemvArgs::wait_flag)
-static thread_local struct { const int* flag; int count; int* err; } g_wait_next = { nullptr, 0, nullptr };
-extern "C" int exl3_gemv_wait_on(const int* flag, int count, int* err)
-{
-    EXL3_CHECK_ARG((flag && err && count >= 1) || (!flag && !err), "exl3_gemv_wait_on: flag, error word and a count >= 1 (or all null to clear)");
-    g_wait_next = { flag, count, err };
-    return EXL3_OK;
-}
 __global__ void exl3_xcc_probe_kernel(uint32_t* bad)
 {
     if (threadIdx.x == 0)
@@ -697,7 +689,6 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                 const int b = (nbk + s - 1) / s;
                 if ((nbk + b - 1) / b != s) continue;              // not a normalised split
                 const long wg = (long) total_cb * s;
-                if (g_wait_next.flag && wg * 4 > 7l * cus) continue;     // overlapped launch: must leave its producer room (below)
                 double cost = (double) ((wg + cus - 1) / cus) * b + (wg < 2l * cus ? 0.25 : 0.0) + 1e-3 * s;
                 if (cost < best_cost) { best_cost = cost; fs = s; }
             }
@@ -775,18 +766,6 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
 
         args.cpw = cpw;
         dim3 grid((unsigned) ((cpw > 0 ? total_groups : total_cb) * S));
-        if (g_wait_next.flag)
-        {
-            // overlapped launch: the resident workgroups spin until the producer signals, so they must leave its (one-wave) workgroups room.  At
-            // <= 64 VGPRs two 16-wave workgroups fill a CU: at most 7/8 of those 2 x CUs slots may be taken; above 64 VGPRs one workgroup per CU is
-            // resident and 1..3 wave slots per SIMD stay free whatever the grid.  Only the plain / norm deferred forms at m <= 4 have the variant
-            const auto w = g_wait_next;
-            g_wait_next = { nullptr, 0, nullptr };
-            EXL3_CHECK_ARG(gen == 2 && cpw == 0 && deferred && !rotated && !tbl && !epi && !in_act && mp <= 4 && m <= 4,
-                           "exl3_gemv_wait_on: only deferred raw-input launches with m <= 4 can overlap with their producer");
-            EXL3_CHECK_ARG((long) grid.x * 4 <= (long) ctx->num_cus * 7, "exl3_gemv_wait_on: the launch is too wide to run beside its producer");
-            args.wait_flag = w.flag; args.wait_count = w.count; args.wait_err = w.err;
-        }
         if (gen == 3)
         {
             const int mt = mp > 32 ? 4 : (mp > 16 ? 2 : 1);

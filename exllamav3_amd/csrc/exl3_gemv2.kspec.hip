@@ -69,20 +69,19 @@ constexpr int g2_waves_per_eu(int K, int CB, int NG, int MODE)
     return w;
 }
 
-// Register budgets (g2_waves_per_eu above): m <= 4 (NG == 1): two 16-wave workgroups per CU need <= 64 VGPRs (K <= 4, MUL1: the hot loop uses
-// 59..62).  Variants that do not fit (3INST/MCG, NORM prep, K >= 5 rings) get the next budget instead of spilling: any scratch use costs every
-// launch ~1-2 us (profiles/r01_launch_chain_microbench.json)
-// Cross-workgroup ordering hook of the persistent chain kernel (exl3_chain_kernel below): the tile's FIRST producer-dependent load must come
-// after wait(); everything that does not depend on the previous stage (addresses, the first weight rows) is issued before it.
-struct ChainNoWait { __device__ __forceinline__ void operator()() const {} };
-
-// The kernel body as a device function: `a` is either the by-value kernel argument (classic launches) or a reference into the stage table of the
-// chain kernel in the constant address space (scalar loads, as for kernargs); bid_in / nblocks replace blockIdx.x / gridDim.x.  CHAIN: the data
-// another workgroup of the SAME launch produced (residual stream, sums of squares, activation rows) is read with agent-scope loads and the slabs
-// are written through (agent-scope stores), see exl3_gemv2_tail.cuh.
-template <int K, int CB, int VAR, int NG, int MODE, bool CHAIN, typename A, typename W>
-__device__ __forceinline__ void gemv2_body(const A& a, const int bid_in, const int nblocks, char* smem, int* s_tail_flag_p, const W& chain_wait)
+template <int K, int CB, int VAR, int NG, int MODE>
+// m <= 4 (NG == 1): two 16-wave workgroups per CU need <= 64 VGPRs (K <= 4, MUL1: the hot loop uses 59..62).  Variants that do not fit
+// (3INST/MCG, NORM prep, K >= 5 rings) get the next budget instead of spilling: any scratch use costs every launch ~1-2 us
+// (profiles/r01_launch_chain_microbench.json)
+#ifdef G2_ABL_ILP
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
+#else
+__global__ __launch_bounds__(MODE == G2_MODE_ACT ? 256 : 1024 / NG) __attribute__((amdgpu_waves_per_eu(g2_waves_per_eu(K, CB, NG, MODE))))
+#endif
+void exl3_gemv2_kernel(const GemvArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_tail_flag;
     constexpr bool SPLIT = (VAR == 1) && (CB != EXL3_CB_MUL1);
     constexpr bool RAW = (VAR == 1) && (CB == EXL3_CB_MUL1);
     constexpr int MR = 4 * NG;                       // activation rows held by the A operand
@@ -110,8 +109,8 @@ __device__ __forceinline__ void gemv2_body(const A& a, const int bid_in, const i
 
     // xcd_local tail epilogues: workgroup i runs on XCD i % 8 (tools/ubench_xcc.hip), so logical workgroup (i % 8) * (grid / 8) + i / 8 puts each
     // run of grid / 8 consecutive logical ids -- hence all S slices of a column block -- on one XCD (host: column blocks % 8 == 0)
-    int bid = bid_in;
-    if constexpr (MODE == G2_MODE_TAIL) { if (a.epi.xcd_local) bid = (bid_in & 7) * (nblocks >> 3) + (bid_in >> 3); }
+    int bid = blockIdx.x;
+    if constexpr (MODE == G2_MODE_TAIL) { if (a.epi.xcd_local) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
     constexpr bool WPC = G2_IS_WPC(MODE);
     const int s = bid % a.S;
     int cbg = bid / a.S;                             // classic: global column block of the workgroup; WPC: column-block GROUP of the workgroup
@@ -225,11 +224,7 @@ __device__ __forceinline__ void gemv2_body(const A& a, const int bid_in, const i
         const int t = min(it * nhw + hwid, cnt * m - 1);
         const int blk = c0 + t / m, row = t % m;
         const size_t kofs = (size_t) k0s + 128 * blk;
-        if constexpr (!G2_IS_ACT(MODE))
-        {
-            if constexpr (CHAIN) r.xv = ld_agent(x_src + (size_t) row * a.k + kofs + 4 * l32);
-            else r.xv = ((const half4_t*) (x_src + (size_t) row * a.k + kofs))[l32];
-        }
+        if constexpr (!G2_IS_ACT(MODE)) r.xv = ((const half4_t*) (x_src + (size_t) row * a.k + kofs))[l32];
         else
         {
             const int blk_abs = (k0s >> 7) + blk;
@@ -269,39 +264,25 @@ __device__ __forceinline__ void gemv2_body(const A& a, const int bid_in, const i
             if constexpr (in_norm)
             {
                 r.wv = ((const half4_t*) (a.norm_w + kofs))[l32];
-                if (norm_in_task && l32 < (a.k >> 7)) r.ss = CHAIN ? ld_agent1(a.ss_part + (size_t) row * (a.k >> 7) + l32) : a.ss_part[(size_t) row * (a.k >> 7) + l32];
+                if (norm_in_task && l32 < (a.k >> 7)) r.ss = a.ss_part[(size_t) row * (a.k >> 7) + l32];
             }
         }
         return r;
     };
-    PrepIn nx;
+    // the first task's operands are requested first (before the 1/rms loads of NORM mode) ...
+    PrepIn nx = fetch(0, min(chb, nb), 0);
+
+    // ... and only then the first weight rows: loads return in issue order per wave, so with the weights first the (small, L2-resident)
+    // activation operands could not be consumed -- and the input Hadamards could not start -- before the first weight rows had arrived from
+    // HBM; this way the prep computes underneath the weight latency
     LaneWords<K> ring[PF];
-    if constexpr (CHAIN)
-    {
-        // chain kernel: the weights do not depend on the previous stage -- request the first rows, THEN wait for the producers, then fetch
-        if (nunits_w > 0)
-        {
-            #pragma unroll
-            for (int u = 0; u < PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) (PF * ubase + u) * row_stride);
-        }
-        chain_wait();
-        nx = fetch(0, min(chb, nb), 0);
-    }
-    else
-    {
-        // the first task's operands are requested first (before the 1/rms loads of NORM mode) ...
-        nx = fetch(0, min(chb, nb), 0);
-        // ... and only then the first weight rows: loads return in issue order per wave, so with the weights first the (small, L2-resident)
-        // activation operands could not be consumed -- and the input Hadamards could not start -- before the first weight rows had arrived from
-        // HBM; this way the prep computes underneath the weight latency
 #ifdef G2_ABL_LATE_RING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // diagnostics build: the first weight rows are requested only after the task operands arrived
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // diagnostics build: the first weight rows are requested only after the task operands arrived
 #endif
-        if (nunits_w > 0)
-        {
-            #pragma unroll
-            for (int u = 0; u < PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) (PF * ubase + u) * row_stride);
-        }
+    if (nunits_w > 0)
+    {
+        #pragma unroll
+        for (int u = 0; u < PF; ++u) load_lane_words<K>(ring[u], strip + (size_t) (PF * ubase + u) * row_stride);
     }
     G2_T(1);
 
@@ -315,7 +296,7 @@ __device__ __forceinline__ void gemv2_body(const A& a, const int bid_in, const i
             float s2 = 0.0f;
             for (int bb = 0; bb < nblk_k; bb += 32)
             {
-                float v = (bb + l32 < nblk_k) ? (CHAIN ? ld_agent1(a.ss_part + (size_t) row * nblk_k + bb + l32) : a.ss_part[(size_t) row * nblk_k + bb + l32]) : 0.0f;
+                float v = (bb + l32 < nblk_k) ? a.ss_part[(size_t) row * nblk_k + bb + l32] : 0.0f;
                 #pragma unroll
                 for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
                 s2 += v;
@@ -683,7 +664,7 @@ __device__ __forceinline__ void gemv2_body(const A& a, const int bid_in, const i
         if (tid == 0)
         {
             tstamp[4] = tstamp[5] = __builtin_amdgcn_s_memrealtime();
-            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) bid_in * 8;
+            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) blockIdx.x * 8;
             for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
             uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             dbg[6] = xcc; dbg[7] = 0;
@@ -716,7 +697,6 @@ __device__ __forceinline__ void gemv2_body(const A& a, const int bid_in, const i
                 if (a.epi.xcd_local) ((float4_t*) (slab + row * 128))[l] = v;              // reader is on this XCD: the L2 copy is enough
                 else st_agent(slab + row * 128 + 4 * l, v);                                // read by another workgroup of this launch
             }
-            else if constexpr (CHAIN) st_agent(slab + row * 128 + 4 * l, v);               // read by a later stage of this launch
             else ((float4_t*) (slab + row * 128))[l] = v;
 #endif
         }
@@ -724,14 +704,14 @@ __device__ __forceinline__ void gemv2_body(const A& a, const int bid_in, const i
         if (tid == 0)
         {
             tstamp[5] = __builtin_amdgcn_s_memrealtime();
-            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) bid_in * 8;
+            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) blockIdx.x * 8;
             for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
             uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             uint32_t hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             dbg[6] = xcc; dbg[7] = hwid;
         }
 #endif
-        if constexpr (MODE == G2_MODE_TAIL) gemv_tail(a, mi, cbl, cbg, tid, nwv, s_tail_flag_p, (float4_t*) smem);
+        if constexpr (MODE == G2_MODE_TAIL) gemv_tail(a, mi, cbl, cbg, tid, nwv, &s_tail_flag, (float4_t*) smem);
         return;
     }
 
@@ -785,47 +765,6 @@ __device__ __forceinline__ void gemv2_body(const A& a, const int bid_in, const i
     }
 }
 
-#ifdef G2_ABL_ILP
-template <int K, int CB, int VAR, int NG, int MODE>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4)))
-#else
-template <int K, int CB, int VAR, int NG, int MODE>
-__global__ __launch_bounds__(MODE == G2_MODE_ACT ? 256 : 1024 / NG) __attribute__((amdgpu_waves_per_eu(g2_waves_per_eu(K, CB, NG, MODE))))
-#endif
-void exl3_gemv2_kernel(const GemvArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_tail_flag;
-    gemv2_body<K, CB, VAR, NG, MODE, false>(a, (int) blockIdx.x, (int) gridDim.x, smem, &s_tail_flag, ChainNoWait());
-}
-
-// Overlapped variant (m <= 4, PLAIN / NORM): launched beside the glue kernel that produces its activations.  Wave 0 polls the producer's
-// completion counter (one lane, agent-scope load + s_sleep, bounded), the workgroup barrier releases the other waves; by then every wave has
-// its first weight rows in flight.  The activations are read with agent-scope loads (this XCD's L2 may hold last layer's lines).
-struct ChainFlagWait
-{
-    const int* flag; int count; int* err;
-    __device__ __forceinline__ void operator()() const
-    {
-        if (threadIdx.x < 64)
-        {
-            int spins = 0, v;
-            while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < count && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(4);
-            if (v < count && threadIdx.x == 0) __hip_atomic_fetch_or(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-    }
-};
-
-template <int K, int CB, int VAR, int MODE>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(g2_waves_per_eu(K, CB, 1, MODE) - (K == 8 && MODE == G2_MODE_NORM ? 1 : 0))))   // K = 8 NORM: 8 B spill at the plain budget
-void exl3_gemv2_ovl_kernel(const GemvArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int s_tail_flag;
-    gemv2_body<K, CB, VAR, 1, MODE, true>(a, (int) blockIdx.x, (int) gridDim.x, smem, &s_tail_flag, ChainFlagWait{ a.wait_flag, a.wait_count, a.wait_err });
-}
-
 // ------------------------------------------------------------------------------------------------
 // launch (called from exl3_gemv.hip's dispatcher).  One translation unit per K: built with -DG2_K=1..8.
 // ------------------------------------------------------------------------------------------------
@@ -837,16 +776,6 @@ template <int CB, int MODE>
 static void launch_mode(int var, int ng, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
     #define L(V, N) exl3_gemv2_kernel<G2_K, CB, V, N, MODE><<<grid, dim3(64 * nwv), lds, st>>>(args)
-    if constexpr (MODE == G2_MODE_PLAIN || MODE == G2_MODE_NORM)
-    {
-        if (args.wait_flag)
-        {
-            // host-checked: m <= 4 (ng == 1), deferred output, grid small enough to leave the producer room on the chip
-            if (var == 0) exl3_gemv2_ovl_kernel<G2_K, CB, 0, MODE><<<grid, dim3(64 * nwv), lds, st>>>(args);
-            else          exl3_gemv2_ovl_kernel<G2_K, CB, 1, MODE><<<grid, dim3(64 * nwv), lds, st>>>(args);
-            return;
-        }
-    }
     if constexpr (G2_IS_ACT(MODE) || G2_IS_WPC(MODE))
     {
         // m <= 4 only (host-checked): one instantiation per variant

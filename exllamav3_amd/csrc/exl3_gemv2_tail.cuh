@@ -16,7 +16,37 @@
 #include "exl3_gemv_args.h"
 #include "exl3_glue_device.cuh"
 
-// (st_agent / ld_agent: exl3_glue_device.cuh)
+// Cross-workgroup hand-off inside one launch.  The 8 XCD L2s are not coherent with each other for plain accesses, and an
+// agent-scope release/acquire FENCE costs an L2 write-back / invalidate per wave (measured: ~115 us per launch with 8192 waves).
+// So every datum that crosses workgroups (split-k slabs, NORM residual block + sum of squares) is written and read with
+// agent-scope relaxed ATOMIC accesses instead -- write-through / L2-bypassing (sc1) loads and stores -- and the only
+// ordering needed is "my stores have been acknowledged before my ticket is taken": s_waitcnt vmcnt(0) + workgroup barrier.
+__device__ __forceinline__ void st_agent(float* p, float4_t v)
+{
+    union { float4_t f; uint64_t u[2]; } c; c.f = v;
+    __hip_atomic_store((uint64_t*) p, c.u[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((uint64_t*) p + 1, c.u[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4_t ld_agent(const float* p)
+{
+    union { float4_t f; uint64_t u[2]; } c;
+    c.u[0] = __hip_atomic_load((uint64_t*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.u[1] = __hip_atomic_load((uint64_t*) p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return c.f;
+}
+__device__ __forceinline__ void st_agent(half_t* p, half4_t v)
+{
+    union { half4_t h; uint64_t u; } c; c.h = v;
+    __hip_atomic_store((uint64_t*) p, c.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ half4_t ld_agent(const half_t* p)
+{
+    union { half4_t h; uint64_t u; } c;
+    c.u = __hip_atomic_load((uint64_t*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return c.h;
+}
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent1(const float* p) { return __hip_atomic_load((float*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // returns true for the workgroup that arrived last at `ticket` (and re-arms the ticket)
 // local: every participant runs on the same XCD (GemvEpi::xcd_local).  Stores are acknowledged by that XCD's L2 and atomics execute there, so a

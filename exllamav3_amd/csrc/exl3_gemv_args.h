@@ -137,10 +137,6 @@ struct GemvArgs
     // workgroups of column block 0 of matrix 0 write resid_out (fp16 [m][k], a DIFFERENT buffer) and ss_out [m][k/128]
     const float* rs_slab; const half_t* rs_svh; half_t* rs_resid_out; float* rs_ss_out; int rs_S;
     GemvEpi epi;
-    // overlapped launch (exl3_gemv_wait_on): the launch runs CONCURRENTLY with its producer (another stream / graph branch), requests its first
-    // weight rows, then waits until *wait_flag >= wait_count (agent-scope loads, bounded) before it touches the activations; a give-up is
-    // recorded in *wait_err and the launch finishes with whatever it reads
-    const int* wait_flag; int wait_count; int* wait_err;
 };
 
 // generation-2 kernels: one translation unit per K (exl3_gemv2.kspec.hip compiled with -DG2_K=1..8)

@@ -120,16 +120,6 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
     }
 }
 
-// Producer side of an overlapped consumer launch (exl3_gemv_wait_on): the outputs above were written through (st_agent); once every wave's
-// stores are acknowledged the workgroup adds 1 to the consumer's counter.  done_flag == nullptr: plain launch, nothing to do.
-__device__ __forceinline__ void glue_signal(int* done_flag)
-{
-    if (!done_flag) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(done_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // ------------------------------------------------------------------------------------------------
 // G1a: the distributed half of G1: per (row, 128-block) half-wave: [reduce + out-had + svh (+bias)] -> residual += y (fp16) -> sum of
 //      squares of the block -> ss_part[row][block].  The consumer GEMVs (GEMV_IN_NORM) finish the RMSNorm while they build their
@@ -138,7 +128,7 @@ __device__ __forceinline__ void glue_signal(int* done_flag)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void glue_resid_kernel(const float* __restrict__ y_base, int y_S, int has_y, const float* __restrict__ y_dense, const half_t* __restrict__ svh,
-                       const half_t* __restrict__ bias, half_t* __restrict__ resid, float* __restrict__ ss_part, int m, int hidden, int* done_flag)
+                       const half_t* __restrict__ bias, half_t* __restrict__ resid, float* __restrict__ ss_part, int m, int hidden)
 {
     // flat scalar / pointer arguments (16 dwords): eligible for kernarg preloading (-mllvm -amdgpu-kernarg-preload-count=16); measured on
     // MI355X / ROCm 7.2: no gain (4.73 vs 4.60 us), so the build does not enable it
@@ -170,18 +160,13 @@ void glue_resid_kernel(const float* __restrict__ y_base, int y_S, int has_y, con
         }
         r = half4_t{ f2h(r0 + h0), f2h(r1 + h1), f2h(r2 + h2), f2h(r3 + h3) };
         r0 = (float) r.x; r1 = (float) r.y; r2 = (float) r.z; r3 = (float) r.w;
-        if (act)
-        {
-            if (done_flag) st_agent(resid + (size_t) row * hidden + blk * 128 + 4 * l, r);     // read by a launch that is already running
-            else ((half4_t*) (resid + (size_t) row * hidden + blk * 128))[l] = r;
-        }
+        if (act) ((half4_t*) (resid + (size_t) row * hidden + blk * 128))[l] = r;
     }
     float ss = r0 * r0;
     ss = __builtin_fmaf(r1, r1, ss); ss = __builtin_fmaf(r2, r2, ss); ss = __builtin_fmaf(r3, r3, ss);
     #pragma unroll
     for (int i = 1; i < 32; i <<= 1) ss += xor_lane(ss, i);
-    if (act && l == 0) { if (done_flag) st_agent(ss_part + (size_t) row * nblk + blk, ss); else ss_part[(size_t) row * nblk + blk] = ss; }
-    glue_signal(done_flag);
+    if (act && l == 0) ss_part[(size_t) row * nblk + blk] = ss;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -246,7 +231,6 @@ struct QkvArgs
     int hd;
     float attn_factor;
     GemvRescale rs;                                         // ss_new != nullptr: q, k, v came from an exl3_gemv_ex_resid launch (row scale correction)
-    int* done_flag;                                         // exl3_glue_signal: q_out is read by a launch that is already running
 };
 
 template <int KB, int VB>
@@ -311,11 +295,7 @@ void glue_qkv_kernel(QkvArgs a)
                          f2h(v2 * cs[1] - v3 * sn[1]), f2h(v3 * cs[1] + v2 * sn[1]) };
         }
     }
-    if (kind == 0 && act)
-    {
-        if (a.done_flag) st_agent(a.q_out + ((size_t) row * a.hq + hi) * 128 + 4 * l, y);
-        else ((half4_t*) (a.q_out + ((size_t) row * a.hq + hi) * 128))[l] = y;
-    }
+    if (kind == 0 && act) ((half4_t*) (a.q_out + ((size_t) row * a.hq + hi) * 128))[l] = y;
     half_t* dense = kind == 1 ? a.k_out : (kind == 2 ? a.v_out : nullptr);
     if (dense && act && kind != 0) ((half4_t*) (dense + ((size_t) row * a.hkv + hi) * 128))[l] = y;
     // quantized append (all lanes take part in the shuffles; stores are predicated)
@@ -330,7 +310,6 @@ void glue_qkv_kernel(QkvArgs a)
         kv_quant_regs<KB>(v0, v1, v2, v3, a.k_cache ? a.k_cache + gbase * KB : nullptr, a.k_scales ? a.k_scales + gbase : nullptr, do_q && kind == 1, tid & 63);
         kv_quant_regs<VB>(v0, v1, v2, v3, a.v_cache ? a.v_cache + gbase * VB : nullptr, a.v_scales ? a.v_scales + gbase : nullptr, do_q && kind == 2, tid & 63);
     }
-    glue_signal(a.done_flag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,23 +391,6 @@ static void launch_qkv(int vb, dim3 grid, int threads, hipStream_t st, const Qkv
 // half-wave tasks of the glue kernels are spread over as many CUs as possible: a task's slab lines (S x 512 B) come in at the per-CU load rate, so
 // few fat workgroups are slower than many thin ones (a one-workgroup-per-row fusion of glue_resid + glue_rotate measured 2.2 us SLOWER per
 // boundary than the two launches).  64-thread workgroups (2 tasks) up to 512 tasks, 256-thread ones above.
-// one-shot: the NEXT exl3_glue_resid / exl3_glue_qkv launch of this thread signals `flag` (+1 per workgroup, outputs written through) for a
-// consumer launched with exl3_gemv_wait_on; *count_out receives the number of workgroups = the value the consumer waits for
-static thread_local struct { int* flag; int* count_out; } g_signal_next = { nullptr, nullptr };
-extern "C" int exl3_glue_signal(int* flag, int* count_out)
-{
-    EXL3_CHECK_ARG((flag && count_out) || (!flag && !count_out), "exl3_glue_signal: flag and count_out (or both null to clear)");
-    g_signal_next = { flag, count_out };
-    return EXL3_OK;
-}
-static int* take_signal(int grid)
-{
-    int* f = g_signal_next.flag;
-    if (f) *g_signal_next.count_out = grid;
-    g_signal_next = { nullptr, nullptr };
-    return f;
-}
-
 static int g_glue_threads = 0;
 extern "C" int exl3_set_glue_threads(int t) { g_glue_threads = t; return EXL3_OK; }
 static int glue_threads(int tasks)
@@ -475,7 +437,6 @@ extern "C" int exl3_glue_qkv_rs(const float* sq, const float* sk, const float* s
     int tasks = m * (a.hq + 2 * a.hkv);
     const int th = glue_threads(tasks), tpw = th / 32;
     dim3 grid((tasks + tpw - 1) / tpw);
-    a.done_flag = take_signal((int) grid.x);
     hipStream_t st = (hipStream_t) stream;
     int kb = k_cache ? k_bits : 8, vb = k_cache ? v_bits : 8;
     switch (kb)
@@ -529,9 +490,8 @@ extern "C" int exl3_glue_resid(const float* y_slabs, int y_S, const float* y_den
     SlabRef y = { y_slabs, y_S };
     const int tasks = m * (hidden / 128);
     const int th = glue_threads(tasks), tpw = th / 32;
-    const int grid = (tasks + tpw - 1) / tpw;
-    glue_resid_kernel<<<grid, th, 0, (hipStream_t) stream>>>(y.base, y.S, (y_slabs || y_dense) ? 1 : 0, y_dense, (const half_t*) svh,
-                                                             (const half_t*) bias, (half_t*) resid, ss_part, m, hidden, take_signal(grid));
+    glue_resid_kernel<<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(y.base, y.S, (y_slabs || y_dense) ? 1 : 0, y_dense, (const half_t*) svh,
+                                                                        (const half_t*) bias, (half_t*) resid, ss_part, m, hidden);
     return exl3_check_launch("glue_resid");
 }
 

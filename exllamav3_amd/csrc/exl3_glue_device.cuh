@@ -135,35 +135,3 @@ __device__ __forceinline__ void kv_dequant_vals_rt(const int bits, const uint32_
     KvGroup<4>::levels<false>(bits, in, in_scale, lane, u);
     v0 = u[0]; v1 = u[1]; v2 = u[2]; v3 = u[3];
 }
-
-// Cross-workgroup hand-off inside one launch.  The 8 XCD L2s are not coherent with each other for plain accesses, and an
-// agent-scope release/acquire FENCE costs an L2 write-back / invalidate per wave (measured: ~115 us per launch with 8192 waves).
-// So every datum that crosses workgroups (split-k slabs, NORM residual block + sum of squares) is written and read with
-// agent-scope relaxed ATOMIC accesses instead -- write-through / L2-bypassing (sc1) loads and stores -- and the only
-// ordering needed is "my stores have been acknowledged before my ticket is taken": s_waitcnt vmcnt(0) + workgroup barrier.
-__device__ __forceinline__ void st_agent(float* p, float4_t v)
-{
-    union { float4_t f; uint64_t u[2]; } c; c.f = v;
-    __hip_atomic_store((uint64_t*) p, c.u[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store((uint64_t*) p + 1, c.u[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float4_t ld_agent(const float* p)
-{
-    union { float4_t f; uint64_t u[2]; } c;
-    c.u[0] = __hip_atomic_load((uint64_t*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    c.u[1] = __hip_atomic_load((uint64_t*) p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return c.f;
-}
-__device__ __forceinline__ void st_agent(half_t* p, half4_t v)
-{
-    union { half4_t h; uint64_t u; } c; c.h = v;
-    __hip_atomic_store((uint64_t*) p, c.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ half4_t ld_agent(const half_t* p)
-{
-    union { half4_t h; uint64_t u; } c;
-    c.u = __hip_atomic_load((uint64_t*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return c.h;
-}
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent1(const float* p) { return __hip_atomic_load((float*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -706,34 +706,6 @@ def glue_rotate(resid, ss_part, w, eps: float, suhs, xhs, m: int, xsums=None):
                                        len(suhs), m, resid.shape[-1], _stream(resid)))
 
 
-class _SignalCount:
-    """Filled by the next glue launch with its workgroup count (= the value its consumer waits for)."""
-    def __init__(self):
-        self.c = ctypes.c_int32(0)
-    @property
-    def value(self) -> int:
-        return int(self.c.value)
-
-
-def glue_signal(flag: torch.Tensor, index: int) -> _SignalCount:
-    """One-shot: the NEXT glue_resid / glue_qkv launch of this thread writes its outputs through and adds 1 per workgroup to flag[index]
-    (int32, zeroed by the caller before each step).  Returns a holder whose .value is that launch's workgroup count once it has been issued;
-    pass it to gemv_wait_on for the consumer, which may then be launched on ANOTHER stream without waiting for the glue kernel."""
-    _req(flag.dtype == torch.int32 and flag.is_cuda and 0 <= index < flag.numel(), "glue_signal: flag must be a device int32 tensor")
-    h = _SignalCount()
-    _check(_lib.lib().exl3_glue_signal(flag.data_ptr() + 4 * index, ctypes.byref(h.c)))
-    return h
-
-
-def gemv_wait_on(flag: torch.Tensor, index: int, count, err: torch.Tensor):
-    """One-shot: the NEXT exl3_gemv_ex / exl3_gemv_ex_norm launch (deferred, m <= 4) requests its first weight rows, then waits until
-    flag[index] >= count before it reads its activations (agent-scope loads); a give-up after ~2^22 polls sets err[0] |= 1."""
-    c = count.value if isinstance(count, _SignalCount) else int(count)
-    _req(c >= 1, "gemv_wait_on: the producer has not been launched yet")
-    _req(err.dtype == torch.int32 and err.is_cuda, "gemv_wait_on: err must be a device int32 tensor")
-    _check(_lib.lib().exl3_gemv_wait_on(flag.data_ptr() + 4 * index, c, err.data_ptr()))
-
-
 def glue_resid(y_slab, y_S: int, svh, bias, resid, ss_part, m: int, y_dense=None):
     _dev(resid)
     _check(_lib.lib().exl3_glue_resid(y_slab, y_S, _p(y_dense), _p(svh), _p(bias), _p(resid), _p(ss_part), m, resid.shape[-1], _stream(resid)))

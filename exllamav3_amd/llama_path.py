@@ -443,79 +443,6 @@ class SyntheticEXL3Llama:
                                   bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
         return self.logits
 
-    def decode_step_overlap(self):
-        """decode_step_fused with the glue kernels on a SECOND stream (a second branch of the captured graph) and their consumer GEMVs launched
-        beside them on the main stream (ext.gemv_wait_on / ext.glue_signal): the consumer requests its first weight rows and sets up while the
-        glue kernel runs, then waits on the glue kernel's completion counter instead of on a kernel boundary.  Overlapped per layer: o_proj
-        (behind glue_qkv, unless the attention core runs in between), gate|up (behind glue_resid) and the next layer's q|k|v (behind glue_resid).
-        Same kernels' arithmetic, same bits as decode_step_fused; batch <= 4, TP = 1.  self.ovl_err[0] != 0 after a step = a consumer gave up
-        waiting (its producer was not scheduled beside it): the step's output is invalid and the caller must fall back to decode_step_fused."""
-        bsz = self._state_bsz
-        same = all(_same_kind(L["q"], L["k"], L["v"]) and _same_kind(L["gate"], L["up"]) for L in self.layers)
-        if self.tp != 1 or bsz > 4 or not same:
-            return self.decode_step_fused()
-        sp, hd = self.split, self.shape.head_dim
-        DEF, ROT = ext.GEMV_OUT_DEFERRED, ext.GEMV_IN_ROTATED
-        x, ss = self.x, self.ss
-        main = torch.cuda.current_stream(self.device)
-        if getattr(self, "_ovl_side", None) is None:
-            self._ovl_side = torch.cuda.Stream(self.device)
-            self.ovl_flags = torch.zeros((3 * self.n_layers + 1,), dtype=torch.int32, device=self.device)
-            self.ovl_err = torch.zeros((1,), dtype=torch.int32, device=self.device)
-        side, flags, err = self._ovl_side, self.ovl_flags, self.ovl_err
-        if os.environ.get("EXL3_HIP_OVERLAP_SAME_STREAM", "0") == "1":
-            side = main                                                     # diagnostics: price the waiting variant without the second branch
-        flags.zero_()
-        x.copy_(self.x0)
-        q2 = self.q.view(bsz, -1)
-        ext.glue_resid(None, 0, None, None, x, ss, bsz)
-        attn = self.with_attention and hd in (64, 128)
-        pend = None                                                        # (flag index, count) the next q|k|v launch waits for
-        for li, L in enumerate(self.layers):
-            lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
-            kc, ks = self.kcache[li]
-            vc, vs = self.vcache[li]
-            if pend: ext.gemv_wait_on(flags, pend[0], pend[1], err)
-            slabs, S = ext.exl3_gemv_ex_norm(x, L["norm1"], ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh],
-                                             None, bsz, lq.mcg, lq.mul1, DEF, sp["qkv"])
-            qkv_args = (slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
-                        self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd)
-            if attn:
-                ext.glue_qkv(*qkv_args)
-                ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
-                                       self.attn_pos + 1, workspace=self.attn_ws)
-                so, So = ext.exl3_gemv_ex(self.attn_out.view(bsz, -1), None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"])
-            else:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    h = ext.glue_signal(flags, 3 * li)
-                    ext.glue_qkv(*qkv_args)
-                ext.gemv_wait_on(flags, 3 * li, h, err)
-                so, So = ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"])
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                h = ext.glue_signal(flags, 3 * li + 1)
-                ext.glue_resid(so[0], So, lo.svh, None, x, ss, bsz)
-            ext.gemv_wait_on(flags, 3 * li + 1, h, err)
-            sgu, Sgu = ext.exl3_gemv_ex_norm(x, L["norm2"], ss, self.eps, [lg.trellis, lu.trellis], None, [lg.suh, lu.suh], None,
-                                             bsz, lg.mcg, lg.mul1, DEF, sp["gu"])
-            if bsz == 1 and self.act_in_gemv:
-                sd, Sd = ext.exl3_gemv_ex_act(sgu, Sgu, lg.svh, lu.svh, ld.trellis, None, ld.suh, None, bsz, ld.mcg, ld.mul1, DEF, sp["down"])
-            else:
-                ext.glue_act(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz)
-                sd, Sd = ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF, sp["down"])
-            last = li == self.n_layers - 1
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                h = None if last else ext.glue_signal(flags, 3 * li + 2)
-                ext.glue_resid(sd[0], Sd, ld.svh, None, x, ss, bsz)
-            pend = None if last else (3 * li + 2, h)
-        main.wait_stream(side)
-        # lm_head: wider than the chip's resident workgroups, so it waits on the kernel boundary like everything else
-        ext.exl3_gemv_ex_norm(x, self.final_norm, ss, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
-                              bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
-        return self.logits
-
     def decode_step_resid(self):
         """Decode step with the residual adds folded into the consumer GEMVs: 5 launches per layer at batch <= 4, TP = 1
         (q|k|v [resid-in + norm], glue_qkv, o, gate|up [resid-in + norm], down [act-in]).  A GEMV_IN_RESID launch rebuilds
