@@ -54,7 +54,6 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs (1B bs 1, 8B bs 16, 8B bs 1 with attention) on the JSON line")
     ap.add_argument("--prefill-tokens", type=int, default=4096)
     ap.add_argument("--variant", type=int, default=1)
-    ap.add_argument("--gen", type=int, default=2)
     ap.add_argument("--attention", action="store_true", help="include decode attention over the quantized KV cache (context = 1000 tokens) in the timed step")
     ap.add_argument("--unfused", action="store_true", help="one launch per reference op instead of the fused pipeline")
     ap.add_argument("--pipeline", choices=["tail", "glue", "resid", "unfused"], default="glue",
@@ -180,7 +179,6 @@ def main():
     backend = TPBackendRCCL(rank, world, dev, backend=tp_backend)
     ext.init(dev.index)
     ext.set_gemv_variant(args.variant)
-    ext.set_gemv_gen(args.gen)
 
     from exllamav3_amd.mixtral_path import MIXTRAL_SHAPES, SyntheticEXL3Mixtral
     cb = {"3inst": 0, "mcg": 1, "mul1": 2}[args.codebook]
@@ -480,7 +478,7 @@ def main():
                                    f"{'attention core INCLUDED: quant-cache-direct decode attention over a 1000-token context' if args.attention else 'attention core excluded (SURVEY.md 2.1)'}",
                        "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
                        "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),
-                       "parallelism": f"tp{world}", "gemv_variant": args.variant, "gemv_gen": args.gen},
+                       "parallelism": f"tp{world}", "gemv_variant": args.variant},
             "repeat_ms_per_step": repeat_ms, "allreduce": allreduce,
             "roofline": roofline, "cpu_baseline": cpu, "prefill": prefill, "other_configs": extra,
         }

@@ -139,7 +139,6 @@ def _declare(l):
     sig("exl3_gemv_ex_norm", vp, vp, vp, f32, PP, PP, PP, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
     sig("exl3_glue_resid", vp, i32, vp, vp, vp, vp, vp, i32, i32, vp)
     sig("exl3_set_gemv_variant", i32)
-    sig("exl3_set_gemv_gen", i32)
     sig("exl3_set_gemv_max_waves", i32)
     sig("exl3_set_gemm3_min_rows", i32)
     sig("exl3_set_gemv_defer_wg_per_cu", i32)

@@ -1,24 +1,14 @@
 // EXL3 quantized GEMV / small-m GEMM for gfx950 (decode path):   C = ((A * suh) H) @ dequant(B) H * svh (+ bias)
 //
-// Replaces the reference's cooperative stream-K kernels (quant/exl3_gemv_kernel.cuh:138-402,
-// quant/exl3_gemm_kernel.cuh:8-80) with a design that needs no grid sync (a grid sync costs 26 us on
-// MI355X, MI355X_MICROARCH.md "barrier-cg"):
-//
-//   * grid = (n/128 column blocks) x S k-slices.  A workgroup (4 waves) owns 128 output columns = one output
-//     Hadamard block and a k-slice that is a whole number of 128-wide input Hadamard blocks, so BOTH
-//     rotations are workgroup-local: the input Hadamard is recomputed per workgroup in the prologue from
-//     x (L2-resident, <= 458 KB) and the output Hadamard runs in the epilogue (S == 1) or in the tiny
-//     split-k reduce kernel (S > 1).
-//   * each wave owns 2 tile columns (32 output columns) and streams its strip of the trellis straight from
-//     HBM into registers (the trellis is read exactly once; nothing is shared between waves, so an LDS round
-//     trip would be pure overhead) with a PF-step software prefetch.
-//   * MAC on the matrix pipe: v_mfma_f32_16x16x32_f16 with the m <= 16 activation rows as the A operand.
-//     The VALU only decodes.  The EXL3 tile order (NVIDIA mma.m16n8k16 B-fragment order) is made native to
-//     CDNA4 without any weight permutation: lane (j, g) of the wave decodes word 4*(j&7)+g of tiles
-//     (2*step, tc + (j>>3)) and (2*step+1, tc + (j>>3)); its 8 weights of column (j&7) form the B operand of
-//     one MFMA and the 8 weights of column 8+(j&7) the B operand of a second one.  The k order inside an MFMA
-//     is free as long as A agrees, so the activation fragment is stored in LDS pre-permuted to
-//     rows {2g, 2g+1, 2g+8, 2g+9} of both tiles (one ds_read_b128 per step).
+// Host dispatcher + the split-k reduce kernels.  Replaces the reference's cooperative stream-K kernels (quant/exl3_gemv_kernel.cuh:138-402,
+// quant/exl3_gemm_kernel.cuh:8-80) with a design that needs no grid sync (a grid sync costs 26 us on MI355X, MI355X_MICROARCH.md
+// "barrier-cg"): grid = (n/128 column blocks) x S k-slices; a workgroup owns 128 output columns = one output Hadamard block and a k-slice
+// that is a whole number of 128-wide input Hadamard blocks, so BOTH rotations are workgroup-local: the input Hadamard is recomputed per
+// workgroup in the prologue from x (L2-resident) and the output Hadamard runs in the epilogue (S == 1), in the split-k reduce kernel below
+// (S > 1) or in the consumer of a deferred launch (exl3_glue.hip).  The kernels themselves: exl3_gemv2.kspec.hip (1..16 rows per weight
+// pass, column-pair-per-lane decode into v_mfma_f32_4x4x4_16B_f16) and exl3_gemm3.kspec.hip (5..64 rows, LDS transpose into 16x16x32 MFMAs).
+// (The first-generation kernel of round 1 -- 4-wave workgroups, 16x16x32 MFMA on B-fragment-ordered lanes -- was an A/B baseline only and
+// has been removed; git history has it.)
 //
 // Variants (VAR):
 //   0 EXACT : B operand = the reference's fp16 weights bit-for-bit (one fp16 add / fma per weight).
@@ -33,335 +23,6 @@
 #include <stdlib.h>
 
 #include "exl3_gemv_args.h"
-#define GEMV_PF 4
-
-// ---- per-lane trellis words for one 8-weight group ------------------------------------------------
-
-template <int K> struct GroupWords { static constexpr int N = (K == 4 || K == 2 || K == 1) ? 2 : 3; };
-
-template <int K>
-struct LaneGeom
-{
-    int i0, i1, i2;     // word indices inside the tile (already wrapped)
-    int o;              // bit offset of state 0's window start inside word i0 (MSB-first)
-    __device__ __forceinline__ void init(int l)
-    {
-        constexpr int NW = 8 * K;
-        int start = 8 * l * K + K - 16;
-        if (start < 0) start += 256 * K;
-        i0 = start >> 5;
-        o = start & 31;
-        i1 = i0 + 1; if (i1 >= NW) i1 -= NW;
-        i2 = i1 + 1; if (i2 >= NW) i2 -= NW;
-    }
-};
-
-template <int K>
-__device__ __forceinline__ void load_group(uint32_t (&w)[3], const uint32_t* __restrict__ tile, const LaneGeom<K>& geo)
-{
-    w[0] = __builtin_nontemporal_load(tile + geo.i0);
-    w[1] = __builtin_nontemporal_load(tile + geo.i1);
-    if constexpr (GroupWords<K>::N == 3) w[2] = __builtin_nontemporal_load(tile + geo.i2);
-    else w[2] = 0;
-}
-
-// 16-bit state j (0..7) of the group.  Window = stream bits [o + jK, o + jK + 16) of w0:w1:w2 (MSB-first).
-template <int K, int J>
-__device__ __forceinline__ uint32_t group_state(const uint32_t (&w)[3], int o)
-{
-    if constexpr (K == 4)
-    {
-        // o == 20 for every lane: window end e = 36 + 4j <= 64
-        constexpr int sh = 28 - 4 * J;                         // (w0:w1) >> sh
-        if constexpr (sh == 0) return w[1] & 0xffffu;
-        else if constexpr (sh <= 16) return __builtin_amdgcn_ubfe(w[1], sh, 16);
-        else return __builtin_amdgcn_alignbit(w[0], w[1], sh) & 0xffffu;
-    }
-    else
-    {
-        int e = o + 16 + J * K;                                 // window end (exclusive), 17..96
-        uint64_t v01 = ((uint64_t) w[0] << 32) | w[1];
-        if constexpr (GroupWords<K>::N == 2)
-            return (uint32_t) (v01 >> (64 - e)) & 0xffffu;
-        else
-        {
-            uint64_t v12 = ((uint64_t) w[1] << 32) | w[2];
-            uint32_t a = (uint32_t) (v01 >> ((64 - e) & 63));
-            uint32_t b = (uint32_t) (v12 >> ((96 - e) & 63));
-            return (e <= 64 ? a : b) & 0xffffu;
-        }
-    }
-}
-
-__device__ __forceinline__ uint32_t perm_lo_lo(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }  // (a.lo, b.lo)
-__device__ __forceinline__ uint32_t perm_hi_hi(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }  // (a.hi, b.hi)
-
-// Decode 4 consecutive states (J0..J0+3) of a group into two packed-fp16 registers (EXACT / cb2 RAW) or
-// four registers of (lo, hi) halves (cb0/cb1 SPLIT).
-template <int K, int CB, int VAR, int J0>
-__device__ __forceinline__ void decode4(const uint32_t (&w)[3], int o, uint32_t (&out)[4])
-{
-    uint32_t x0 = cb_product<CB>(group_state<K, J0 + 0>(w, o));
-    uint32_t x1 = cb_product<CB>(group_state<K, J0 + 1>(w, o));
-    uint32_t x2 = cb_product<CB>(group_state<K, J0 + 2>(w, o));
-    uint32_t x3 = cb_product<CB>(group_state<K, J0 + 3>(w, o));
-    if constexpr (CB != EXL3_CB_MUL1)
-    {
-        x0 = cb_mask3inst(x0); x1 = cb_mask3inst(x1); x2 = cb_mask3inst(x2); x3 = cb_mask3inst(x3);
-        if constexpr (VAR == 1) { out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3; }
-        else
-        {
-            half2_t s01 = u32_as_half2(perm_lo_lo(x0, x1)) + u32_as_half2(perm_hi_hi(x0, x1));   // v_pk_add_f16 (RN)
-            half2_t s23 = u32_as_half2(perm_lo_lo(x2, x3)) + u32_as_half2(perm_hi_hi(x2, x3));
-            out[0] = half2_as_u32(s01); out[1] = half2_as_u32(s23); out[2] = 0; out[3] = 0;
-        }
-    }
-    else
-    {
-        uint32_t h01 = __builtin_amdgcn_sad_hi_u8(x1, 0u, __builtin_amdgcn_sad_u8(x0, 0u, 0x64006400u));
-        uint32_t h23 = __builtin_amdgcn_sad_hi_u8(x3, 0u, __builtin_amdgcn_sad_u8(x2, 0u, 0x64006400u));
-        if constexpr (VAR == 1) { out[0] = h01; out[1] = h23; }
-        else
-        {
-            const half2_t kinv = { u16_as_half(0x1eeeu), u16_as_half(0x1eeeu) };
-            const half2_t kbias = { u16_as_half(0xc931u), u16_as_half(0xc931u) };
-            half2_t a = u32_as_half2(h01), b = u32_as_half2(h23);
-            half2_t ra = __builtin_elementwise_fma(a, kinv, kbias);      // v_pk_fma_f16
-            half2_t rb = __builtin_elementwise_fma(b, kinv, kbias);
-            out[0] = half2_as_u32(ra); out[1] = half2_as_u32(rb);
-        }
-        out[2] = 0; out[3] = 0;
-    }
-}
-
-__device__ __forceinline__ half8_t make_frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
-{
-    union { uint32_t u[4]; half8_t h; } f; f.u[0] = a; f.u[1] = b; f.u[2] = c; f.u[3] = d; return f.h;
-}
-
-template <int K, int CB, int VAR>
-__global__ __launch_bounds__(GEMV_THREADS)
-void exl3_gemv_kernel(const GemvArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool SPLIT = (VAR == 1) && (CB != EXL3_CB_MUL1);
-    constexpr bool RAW = (VAR == 1) && (CB == EXL3_CB_MUL1);
-    constexpr int NW = 8 * K;
-
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6;
-    const int lane = tid & 63;
-    const int m = a.m;
-
-    // ---- which (matrix, column block, k-slice) is this workgroup
-    const int s = blockIdx.x % a.S;
-    const int cbg = blockIdx.x / a.S;
-    int mi = 0;
-    #pragma unroll
-    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.num_mats && cbg >= a.mat[i].cb_first) mi = i;
-    const uint32_t* __restrict__ Bm = a.mat[mi].B;
-    const half_t* __restrict__ suh = a.mat[mi].suh;
-    const int n = a.mat[mi].n;
-    const int cbl = cbg - a.mat[mi].cb_first;
-    const int tiles_n = n >> 4;
-    const int k0 = s * a.kslice;
-    const int k1 = min(k0 + a.kslice, a.k);
-    const int nblocks = (k1 - k0) >> 7;         // 128-blocks in this slice
-    const int nsteps = nblocks * 4;             // 32 k per step
-
-    // LDS: activation fragments [step][g][row][8 halves]; then (after the main loop) partial sums [16][128] fp32
-    half_t* xfrag = (half_t*) smem;
-    float* sumx = (float*) (smem + (size_t) nsteps * 4 * m * 16);       // [16] (RAW only)
-    if (tid < 16) sumx[tid] = 0.0f;                  // RAW row sums
-    if (tid >= 16 && tid < 20) sumx[tid] = 0.0f;     // 16-byte zero A fragment for lanes whose row is >= m
-    if (RAW) __syncthreads();
-
-    // ---- prologue: xh = fp16( had128( fp16(x * suh) ) / sqrt(128) ), written in MFMA A-fragment order
-    {
-        const int l = tid & 31;
-        const int hw = tid >> 5;                                        // half-wave 0..7
-        const int count = m * nblocks;
-        for (int base = 0; base < count; base += 8)
-        {
-            int idx = base + hw;
-            bool act = idx < count;
-            int ii = act ? idx / nblocks : 0;
-            int b = act ? idx % nblocks : 0;
-            half4_t xv = ((const half4_t*) (a.A + (size_t) ii * a.k + k0 + 128 * b))[l];
-            half4_t sv = ((const half4_t*) (suh + k0 + 128 * b))[l];
-            xv = xv * sv;
-            float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
-            had128_f32x4(h0, h1, h2, h3, l);
-            half2_t o01 = { f2h(h0 * HAD_R_SCALE_128), f2h(h1 * HAD_R_SCALE_128) };
-            half2_t o23 = { f2h(h2 * HAD_R_SCALE_128), f2h(h3 * HAD_R_SCALE_128) };
-            if (RAW)
-            {
-                float t = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
-                #pragma unroll
-                for (int i = 1; i < 32; i <<= 1) t += xor_lane(t, i);
-                if (act && l == 0) atomicAdd(&sumx[ii], t);
-            }
-            if (act)
-            {
-                // element e = 4l + {0,1,2,3} of block b: tile row kr = 8b + l/4, r = 4(l&3) + {0..3}
-                int kr = 8 * b + (l >> 2);
-                int sp = kr >> 1, T = kr & 1;
-                int g0 = 2 * (l & 1);
-                int slot = 2 * ((l >> 1) & 1) + 4 * T;
-                half_t* f0 = xfrag + (((size_t) sp * 4 + g0) * m + ii) * 8 + slot;
-                half_t* f1 = xfrag + (((size_t) sp * 4 + g0 + 1) * m + ii) * 8 + slot;
-                *((half2_t*) f0) = o01;
-                *((half2_t*) f1) = o23;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- main loop
-    const int j = lane & 15, g = lane >> 4;
-    LaneGeom<K> geo; geo.init(4 * (j & 7) + g);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    // uniform base of this wave's strip (tile row k0/16, tile col 8*cbl + 2*wave); per-lane 32-bit word offsets
-    const uint32_t* __restrict__ strip = Bm + ((size_t) (k0 >> 4) * tiles_n + (size_t) cbl * 8 + wave_u * 2) * NW;
-    const uint32_t lo0 = (uint32_t) ((j >> 3) * NW + geo.i0);
-    const uint32_t lo1 = (uint32_t) ((j >> 3) * NW + geo.i1);
-    const uint32_t lo2 = (uint32_t) ((j >> 3) * NW + geo.i2);
-    const size_t row_stride = (size_t) tiles_n * NW;                                // words per tile row
-    const int last_row = 2 * nsteps - 1;
-    const bool a_row_valid = j < m;
-    // lanes whose A row is >= m read a zero fragment (stride 0) placed after the real fragments
-    const half_t* zfrag = xfrag + (size_t) nsteps * 4 * m * 8 + 32;                 // 16 B aligned, after sumx (zeroed in the prologue)
-    const half_t* afrag_ptr = a_row_valid ? xfrag + ((size_t) g * m + j) * 8 : zfrag;
-    const size_t afrag_step = a_row_valid ? (size_t) 4 * m * 8 : 0;
-
-    float4_t acc_a = { 0.f, 0.f, 0.f, 0.f };
-    float4_t acc_b = { 0.f, 0.f, 0.f, 0.f };
-
-    #define LOAD_ROW(dst, row) do { \
-        const uint32_t* rp_ = strip + (size_t) min((row), last_row) * row_stride; \
-        dst[0] = __builtin_nontemporal_load(rp_ + lo0); \
-        dst[1] = __builtin_nontemporal_load(rp_ + lo1); \
-        if constexpr (GroupWords<K>::N == 3) dst[2] = __builtin_nontemporal_load(rp_ + lo2); else dst[2] = 0; } while (0)
-
-    uint32_t buf[GEMV_PF][2][3];
-    #pragma unroll
-    for (int u = 0; u < GEMV_PF; ++u)
-    {
-        LOAD_ROW(buf[u][0], 2 * u);
-        LOAD_ROW(buf[u][1], 2 * u + 1);
-    }
-
-    for (int sp0 = 0; sp0 < nsteps; sp0 += GEMV_PF)
-    {
-        #pragma unroll
-        for (int u = 0; u < GEMV_PF; ++u)
-        {
-            const int sp = sp0 + u;
-            half8_t af = *((const half8_t*) (afrag_ptr + (size_t) sp * afrag_step));
-
-            uint32_t t0a[4], t0b[4], t1a[4], t1b[4];
-            decode4<K, CB, VAR, 0>(buf[u][0], geo.o, t0a);
-            decode4<K, CB, VAR, 4>(buf[u][0], geo.o, t0b);
-            decode4<K, CB, VAR, 0>(buf[u][1], geo.o, t1a);
-            decode4<K, CB, VAR, 4>(buf[u][1], geo.o, t1b);
-
-            // refill this ring slot (rows clamped at the tail: harmless re-read, keeps the load count static)
-            LOAD_ROW(buf[u][0], 2 * (sp + GEMV_PF));
-            LOAD_ROW(buf[u][1], 2 * (sp + GEMV_PF) + 1);
-
-            if constexpr (SPLIT)
-            {
-                union { half8_t h; uint32_t u[4]; } au; au.h = af;
-                half8_t a0 = make_frag(__builtin_amdgcn_perm(au.u[0], au.u[0], 0x01000100u), __builtin_amdgcn_perm(au.u[0], au.u[0], 0x03020302u),
-                                       __builtin_amdgcn_perm(au.u[1], au.u[1], 0x01000100u), __builtin_amdgcn_perm(au.u[1], au.u[1], 0x03020302u));
-                half8_t a1 = make_frag(__builtin_amdgcn_perm(au.u[2], au.u[2], 0x01000100u), __builtin_amdgcn_perm(au.u[2], au.u[2], 0x03020302u),
-                                       __builtin_amdgcn_perm(au.u[3], au.u[3], 0x01000100u), __builtin_amdgcn_perm(au.u[3], au.u[3], 0x03020302u));
-                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, make_frag(t0a[0], t0a[1], t0a[2], t0a[3]), acc_a, 0, 0, 0);
-                acc_b = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, make_frag(t0b[0], t0b[1], t0b[2], t0b[3]), acc_b, 0, 0, 0);
-                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, make_frag(t1a[0], t1a[1], t1a[2], t1a[3]), acc_a, 0, 0, 0);
-                acc_b = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, make_frag(t1b[0], t1b[1], t1b[2], t1b[3]), acc_b, 0, 0, 0);
-            }
-            else
-            {
-                acc_a = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, make_frag(t0a[0], t0a[1], t1a[0], t1a[1]), acc_a, 0, 0, 0);
-                acc_b = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, make_frag(t0b[0], t0b[1], t1b[0], t1b[1]), acc_b, 0, 0, 0);
-            }
-        }
-    }
-    #undef LOAD_ROW
-    float sx[4] = { 0.f, 0.f, 0.f, 0.f };
-    if constexpr (RAW)
-    {
-        #pragma unroll
-        for (int r = 0; r < 4; ++r) { int row = 4 * (lane >> 4) + r; sx[r] = row < m ? sumx[row] : 0.f; }
-    }
-    __syncthreads();       // everyone is done reading xfrag / sumx
-
-    // ---- epilogue: accumulators -> LDS partial [row][128]
-    float* part = (float*) smem;
-    {
-        // MFMA C/D layout: lane l holds column l&15, rows 4*(l>>4) + r
-        int jj = lane & 15;
-        int col_a = wave * 32 + 16 * (jj >> 3) + (jj & 7);
-        #pragma unroll
-        for (int r = 0; r < 4; ++r)
-        {
-            int row = 4 * (lane >> 4) + r;
-            if (row < m)
-            {
-                float va = acc_a[r], vb = acc_b[r];
-                if constexpr (RAW)
-                {
-                    const float kinv = (float) u16_as_half(0x1eeeu), kbias = (float) u16_as_half(0xc931u);
-                    va = va * kinv + kbias * sx[r];
-                    vb = vb * kinv + kbias * sx[r];
-                }
-                part[row * 128 + col_a] = va;
-                part[row * 128 + col_a + 8] = vb;
-            }
-        }
-    }
-    __syncthreads();
-
-    const int l = tid & 31, hw = tid >> 5;
-    if (a.S > 1)
-    {
-        // slab [cbl][s][row][128] in this matrix's workspace region
-        float* slab = a.workspace + a.mat[mi].ws_offset + ((size_t) cbl * a.S + s) * (size_t) m * 128;
-        for (int row = hw; row < m; row += 8)
-            ((float4_t*) (slab + row * 128))[l] = ((const float4_t*) (part + row * 128))[l];
-        return;
-    }
-
-    // S == 1: output Hadamard + svh (+ bias) right here
-    const half_t* svh = a.mat[mi].svh + cbl * 128;
-    const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
-    for (int base = 0; base < m; base += 8)
-    {
-        int row = base + hw;
-        bool act = row < m;
-        float4_t v = ((const float4_t*) (part + (act ? row : 0) * 128))[l];
-        float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
-        had128_f32x4(h0, h1, h2, h3, l);
-        h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
-        if (!act) continue;
-        half4_t sc = ((const half4_t*) svh)[l];
-        size_t off = ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
-        if (a.c_fp32)
-        {
-            float4_t o = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
-            if (bias) { half4_t bv = ((const half4_t*) bias)[l]; o.x += (float) bv.x; o.y += (float) bv.y; o.z += (float) bv.z; o.w += (float) bv.w; }
-            *((float4_t*) ((float*) a.mat[mi].C + off)) = o;
-        }
-        else
-        {
-            half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
-            o = o * sc;
-            if (bias) o = o + ((const half4_t*) bias)[l];
-            *((half4_t*) ((half_t*) a.mat[mi].C + off)) = o;
-        }
-    }
-}
 
 // Split-k reduce + output Hadamard + svh (+ bias).  One half-wave per (row, column block).
 __global__ __launch_bounds__(256)
@@ -456,20 +117,6 @@ __global__ void mgemm_slot_reduce_kernel(void* C, int c_fp32, int num_tokens, in
 // ------------------------------------------------------------------------------------------------
 
 static int g_gemv_variant = -1;      // -1: read EXL3_HIP_GEMV_VARIANT (default 1 = FAST)
-static int g_gemv_gen = -1;          // -1: read EXL3_HIP_GEMV_GEN (default 2)
-
-static int gemv_gen()
-{
-    if (g_gemv_gen < 0)
-    {
-        const char* e = getenv("EXL3_HIP_GEMV_GEN");
-        g_gemv_gen = e ? atoi(e) : 2;
-        if (g_gemv_gen != 1) g_gemv_gen = 2;
-    }
-    return g_gemv_gen;
-}
-
-extern "C" int exl3_set_gemv_gen(int v) { g_gemv_gen = (v == 1) ? 1 : 2; return EXL3_OK; }
 static int g_gemv_nwv = 0;           // 0 = heuristic; otherwise cap on waves per workgroup (tuning / tests)
 static int g_gemv_defer_wg_per_cu = 0;
 // XCD-local tail hand-off (exl3_gemv_resid): OPT-IN.  It is only correct if workgroup i of a 1-D grid runs on XCD i % 8, which HIP does not
@@ -529,13 +176,6 @@ static int gemv_variant()
 
 extern "C" int exl3_set_gemv_variant(int v) { g_gemv_variant = v ? 1 : 0; return EXL3_OK; }
 
-template <int K, int CB>
-static void launch_gemv(int var, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
-{
-    if (var == 0) exl3_gemv_kernel<K, CB, 0><<<grid, dim3(GEMV_THREADS), lds, st>>>(args);
-    else          exl3_gemv_kernel<K, CB, 1><<<grid, dim3(GEMV_THREADS), lds, st>>>(args);
-}
-
 static int choose_split(int gen, int total_colblocks, int k, int m, int num_cus, int force_split)
 {
     const int nb = k / 128;
@@ -552,33 +192,16 @@ static int choose_split(int gen, int total_colblocks, int k, int m, int num_cus,
         const long ws_cap = (long) (EXL3_WS_REGION_BYTES / ((long) total_colblocks * m * 512));      // the slabs must fit one workspace region
         if (S > ws_cap) S = ws_cap < 1 ? 1 : (int) ws_cap;
     }
-    else if (gen == 2)
+    else
     {
         // gen 2: a workgroup is up to 16 waves that split its k-slice, so one workgroup per CU already fills the CU.
         // Split k across workgroups only until every CU has one (no reduce launch when the column blocks suffice).
         if (4 * total_colblocks >= 3 * num_cus) S = 1;
         else S = (num_cus + total_colblocks - 1) / total_colblocks;
     }
-    else
-    {
-        // gen 1: aim for >= 4 workgroups per CU in flight, >= 2 Hadamard blocks per slice
-        int target = 4 * num_cus;
-        S = (target + total_colblocks - 1) / total_colblocks;
-        int maxS = nb / 2; if (maxS < 1) maxS = 1;
-        if (S > maxS) S = maxS;
-    }
     if (S < 1) S = 1;
     if (S > nb) S = nb;
     int blocks_per_slice = (nb + S - 1) / S;
-    if (gen == 1)
-    {
-        // LDS limit for the activation fragments: kslice * m * 2 bytes <= 64 KB
-        while ((size_t) blocks_per_slice * 128 * m * 2 > 65536 && blocks_per_slice > 1)
-        {
-            S++;
-            blocks_per_slice = (nb + S - 1) / S;
-        }
-    }
     // normalise S so that no slice is empty
     S = (nb + blocks_per_slice - 1) / blocks_per_slice;
     return S;
@@ -638,7 +261,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
 
     const int var = gemv_variant();
     // generation 3 streams the weights once per up to 64 rows (exl3_gemm3.kspec.hip); the special input / output modes stay on generation 2
-    const bool g3_ok = g_gemm3_min_rows > 0 && !in_norm && !tbl && !in_act && !epi && (deferred || rotated || gemv_gen() == 2);
+    const bool g3_ok = g_gemm3_min_rows > 0 && !in_norm && !tbl && !in_act && !epi && true;
     const int pass_rows = (g3_ok && !deferred && !rotated && m > 16) ? (m > 32 ? 64 : 32) : 16;
     for (int m0 = 0; m0 < m; m0 += pass_rows)
     {
@@ -649,7 +272,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         // input its 8 half-waves per workgroup would spend longer on the input Hadamards than generation 2's 16..32, so it starts at 9 rows
         // and, for wide launches, rotates the activations ONCE first (the role of the reference's A_had temporary, "storage for input transform": quant/exl3_gemm.cu:30, 139-145)
         const bool g3 = cpw == 0 && g3_ok && mp >= (rotated ? g_gemm3_min_rows : (g_gemm3_min_rows > 9 ? g_gemm3_min_rows : 9));
-        const int gen = cpw > 0 ? 2 : g3 ? 3 : (deferred || rotated || in_norm || tbl || in_act) ? 2 : gemv_gen();
+        const int gen = (cpw == 0 && g3) ? 3 : 2;
         int pass_flags = flags;
         const void* pre_xh[GEMV_MAX_MATS] = { nullptr };
         const size_t xh_bytes = (size_t) mp * k * 2;
@@ -788,7 +411,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                 case 8: exl3_gemm3_launch_k8(cb, mt, grid, lds, st, args); break;
             }
         }
-        else if (gen == 2)
+        else
         {
             const int ng = mp <= 4 ? 1 : (mp <= 8 ? 2 : 4);
             int nwv = 16 / ng;                                   // partial-sum LDS: nwv * 4*ng rows * 512 B <= 32 KB
@@ -838,19 +461,6 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                 case 6: exl3_gemv2_launch_k6(cb, var, ng, nwv, grid, lds, st, args); break;
                 case 7: exl3_gemv2_launch_k7(cb, var, ng, nwv, grid, lds, st, args); break;
                 case 8: exl3_gemv2_launch_k8(cb, var, ng, nwv, grid, lds, st, args); break;
-            }
-        }
-        else
-        {
-            size_t lds_frag = (size_t) bps * 128 * mp * 2 + 64 + 16;
-            size_t lds_part = (size_t) 16 * 128 * 4;
-            size_t lds = lds_frag > lds_part ? lds_frag : lds_part;
-            switch (K * 3 + cb)
-            {
-                #define GC(KK, CC) case KK * 3 + CC: launch_gemv<KK, CC>(var, grid, lds, st, args); break;
-                GC(1,0) GC(1,1) GC(1,2) GC(2,0) GC(2,1) GC(2,2) GC(3,0) GC(3,1) GC(3,2) GC(4,0) GC(4,1) GC(4,2)
-                GC(5,0) GC(5,1) GC(5,2) GC(6,0) GC(6,1) GC(6,2) GC(7,0) GC(7,1) GC(7,2) GC(8,0) GC(8,1) GC(8,2)
-                #undef GC
             }
         }
         int rc = exl3_check_launch("exl3_gemv");

@@ -2,7 +2,6 @@
 #pragma once
 #include "exl3_common.cuh"
 
-#define GEMV_THREADS 256
 #ifndef G2_PF
 #define G2_PF 2             // gen 2: tile rows per work unit = depth of the per-wave weight-row register ring (2 or 4)
 #endif

@@ -68,11 +68,6 @@ def set_gemv_variant(v: int):
     _lib.lib().exl3_set_gemv_variant(int(v))
 
 
-def set_gemv_gen(g: int):
-    """1 = 16x16x32-MFMA kernel (exl3_gemv.hip), 2 = column-pair-per-lane kernel (exl3_gemv2.kspec.hip, default)."""
-    _lib.lib().exl3_set_gemv_gen(int(g))
-
-
 def set_gemv_max_waves(n: int):
     """Cap on waves per workgroup of the gen-2 GEMV (0 = heuristic, up to 16)."""
     _lib.lib().exl3_set_gemv_max_waves(int(n))

@@ -99,10 +99,8 @@ int exl3_mgemm(const void* A, const void* const* Bs, void* const* Cs, const void
                const int* ns, int count, int m, int k, int K, int cb, int c_fp32, int force_split, void* stream);
 
 /* Tuning hooks (no reference equivalent; the reference's knobs are env vars EXL3_GEMV / EXL3_GEMV_SMEM, doc/env_vars.md):
- * variant 0 = EXACT (reference fp16 weights bit-for-bit into the MFMA), 1 = FAST (default; see exl3_gemv2.kspec.hip);
- * gen 1 = 16x16x32-MFMA kernel, 2 = column-pair-per-lane kernel (default). */
+ * variant 0 = EXACT (reference fp16 weights bit-for-bit into the MFMA), 1 = FAST (default; see exl3_gemv2.kspec.hip). */
 int exl3_set_gemv_variant(int variant);
-int exl3_set_gemv_gen(int gen);
 int exl3_set_gemv_max_waves(int max_waves_per_workgroup);   /* 0 = heuristic (up to 16) */
 int exl3_set_gemm3_min_rows(int min_rows);                   /* passes with >= min_rows rows use the LDS-transpose kernel (exl3_gemm3.kspec.hip); default 5 (9 for raw input), 0 = never */
 int exl3_set_gemv_defer_wg_per_cu(int workgroups_per_cu);      /* deferred-epilogue k-split target, 0 = default (2) */

@@ -74,7 +74,7 @@ def test_fused_decode_layer_at_70b_tp8_rank_shapes_vs_oracle(dev):
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
     from test_gpu_path import _oracle_decode
     import test_gpu_path
-    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    ext.set_gemv_variant(1)
     shape = LlamaShape("70b-tp8-rank", 8192, 3584, 1, 8, 1, 128, 1024)
     model = SyntheticEXL3Llama(shape, K=3, cb=2, device=dev, kv_bits=4, max_ctx=1024)
     model.alloc_state(1, pos=300)

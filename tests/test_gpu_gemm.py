@@ -15,10 +15,9 @@ def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-def _run(dev, k, n, K, cb, m, variant, out_fp32=False, force_split=0, bias=False, realistic=False, seed=None, gen=2):
+def _run(dev, k, n, K, cb, m, variant, out_fp32=False, force_split=0, bias=False, realistic=False, seed=None):
     from exllamav3_amd import ext
     ext.set_gemv_variant(variant)
-    ext.set_gemv_gen(gen)
     tr, suh, svh = o.synth_linear(k, n, K, seed=seed, realistic=realistic)
     rng = np.random.default_rng(0)
     x = rng.standard_normal((m, k)).astype(np.float16)
@@ -34,66 +33,58 @@ def _run(dev, k, n, K, cb, m, variant, out_fp32=False, force_split=0, bias=False
     return err
 
 
-@pytest.mark.parametrize("gen", [1, 2])
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("cb", [0, 1, 2])
 @pytest.mark.parametrize("K", range(1, 9))
-def test_gemv_all_bitrates(dev, K, cb, variant, gen):
-    assert _run(dev, 512, 256, K, cb, 1, variant, gen=gen) < TOL
-    assert _run(dev, 1024, 128, K, cb, 3, variant, gen=gen) < TOL
+def test_gemv_all_bitrates(dev, K, cb, variant):
+    assert _run(dev, 512, 256, K, cb, 1, variant) < TOL
+    assert _run(dev, 1024, 128, K, cb, 3, variant) < TOL
 
 
-@pytest.mark.parametrize("gen", [1, 2])
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 8, 9, 15, 16, 17, 31, 33])
-def test_gemm_batch_sizes(dev, m, variant, gen):
+def test_gemm_batch_sizes(dev, m, variant):
     # tests/test_qgemm.py bs list (those <= 33); m > 16 runs 16-row passes
     for cb in (0, 2):
-        assert _run(dev, 1024, 384, 4, cb, m, variant, gen=gen) < TOL
+        assert _run(dev, 1024, 384, 4, cb, m, variant) < TOL
 
 
-@pytest.mark.parametrize("gen", [1, 2])
 @pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("split", [1, 2, 3, 4, 8, 16])
-def test_split_k(dev, split, variant, gen):
+def test_split_k(dev, split, variant):
     # includes uneven slices and slices shorter than 4 Hadamard blocks (some waves of a workgroup get no work)
     for cb in (0, 1, 2):
-        assert _run(dev, 2048, 256, 4, cb, 2, variant, force_split=split, gen=gen) < TOL
-        assert _run(dev, 2048, 256, 3, cb, 5, variant, out_fp32=True, force_split=split, gen=gen) < TOL
-        assert _run(dev, 1664, 128, 4, cb, 1, variant, force_split=split, gen=gen) < TOL       # 13 blocks
+        assert _run(dev, 2048, 256, 4, cb, 2, variant, force_split=split) < TOL
+        assert _run(dev, 2048, 256, 3, cb, 5, variant, out_fp32=True, force_split=split) < TOL
+        assert _run(dev, 1664, 128, 4, cb, 1, variant, force_split=split) < TOL       # 13 blocks
 
 
-@pytest.mark.parametrize("gen", [1, 2])
 @pytest.mark.parametrize("variant", [0, 1])
-def test_fp32_out_bias_realistic(dev, variant, gen):
+def test_fp32_out_bias_realistic(dev, variant):
     for cb in (0, 1, 2):
-        assert _run(dev, 512, 512, 4, cb, 4, variant, out_fp32=True, bias=True, gen=gen) < TOL
-        assert _run(dev, 512, 512, 5, cb, 1, variant, out_fp32=False, bias=True, gen=gen) < TOL
-        assert _run(dev, 4096, 1024, 4, cb, 1, variant, realistic=True, gen=gen) < TOL
+        assert _run(dev, 512, 512, 4, cb, 4, variant, out_fp32=True, bias=True) < TOL
+        assert _run(dev, 512, 512, 5, cb, 1, variant, out_fp32=False, bias=True) < TOL
+        assert _run(dev, 4096, 1024, 4, cb, 1, variant, realistic=True) < TOL
 
 
-@pytest.mark.parametrize("gen", [1, 2])
 @pytest.mark.parametrize("variant", [0, 1])
-def test_llama_shapes(dev, variant, gen):
+def test_llama_shapes(dev, variant):
     # science/qgemm_benchmark.py shapes at 4 bpw (sizes the oracle finishes in seconds)
     for (k, n) in [(4096, 4096), (4096, 1024), (14336, 4096)]:
-        assert _run(dev, k, n, 4, 2, 1, variant, gen=gen) < TOL
-    assert _run(dev, 4096, 14336, 4, 0, 16, variant, gen=gen) < TOL
+        assert _run(dev, k, n, 4, 2, 1, variant) < TOL
+    assert _run(dev, 4096, 14336, 4, 0, 16, variant) < TOL
 
 
 def test_exact_variant_matches_reconstruct_matmul_tightly(dev):
     """EXACT variant feeds the reference's fp16 weights bit-for-bit to the MFMA: agreement with an fp64 matmul over the
     reconstructed weights is limited only by the fp16 rounding of the output."""
-    for gen in (1, 2):
-        assert _run(dev, 1024, 256, 4, 0, 4, 0, out_fp32=True, gen=gen) < 2e-4
-        assert _run(dev, 1024, 256, 4, 2, 4, 0, out_fp32=True, gen=gen) < 2e-4
+    assert _run(dev, 1024, 256, 4, 0, 4, 0, out_fp32=True) < 2e-4
+    assert _run(dev, 1024, 256, 4, 2, 4, 0, out_fp32=True) < 2e-4
 
 
-@pytest.mark.parametrize("gen", [1, 2])
-def test_mgemm_broadcast(dev, gen):
+def test_mgemm_broadcast(dev):
     from exllamav3_amd import ext
     ext.set_gemv_variant(1)
-    ext.set_gemv_gen(gen)
     k, K, cb, m = 1024, 4, 2, 2
     ns = [512, 128, 128]
     rng = np.random.default_rng(0)
@@ -111,7 +102,6 @@ def test_mgemm_broadcast(dev, gen):
 
 def test_bc_linear_exl3(dev):
     from exllamav3_amd import ext
-    ext.set_gemv_gen(2)
     k, n, K = 512, 256, 4
     tr, suh, svh = o.synth_linear(k, n, K)
     x = np.random.default_rng(0).standard_normal((1, 3, k)).astype(np.float16)
@@ -125,7 +115,6 @@ def test_bc_linear_exl3(dev):
 def test_graph_capture_replay(dev):
     """Decode-step launches must be capturable into a hipGraph (reference: graph.cuh:100-137)."""
     from exllamav3_amd import ext
-    ext.set_gemv_gen(2)
     k, n, K = 1024, 512, 4
     tr, suh, svh = o.synth_linear(k, n, K)
     x = _t(np.random.default_rng(0).standard_normal((1, k)).astype(np.float16), dev)
@@ -154,8 +143,8 @@ def test_gen2_waves_per_workgroup(dev, max_waves):
     try:
         for (k, n, m, split) in [(4096, 256, 1, 1), (1664, 128, 2, 1), (14336, 128, 1, 0), (2048, 384, 16, 2), (1024, 128, 9, 1)]:
             for cb in (0, 2):
-                assert _run(dev, k, n, 4, cb, m, 1, force_split=split, gen=2) < TOL
-        assert _run(dev, 4096, 256, 3, 1, 4, 0, force_split=1, gen=2) < TOL
+                assert _run(dev, k, n, 4, cb, m, 1, force_split=split) < TOL
+        assert _run(dev, 4096, 256, 3, 1, 4, 0, force_split=1) < TOL
     finally:
         ext.set_gemv_max_waves(0)
 

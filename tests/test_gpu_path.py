@@ -46,7 +46,7 @@ def _oracle_decode(model, x0):
 def test_decode_step_matches_oracle(dev, cb, bsz):
     from exllamav3_amd import ext
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
-    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    ext.set_gemv_variant(1)
     shape = LlamaShape("tiny", 256, 512, 2, 4, 2, 128, 384)
     model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
     model.alloc_state(bsz, pos=700)
@@ -104,7 +104,7 @@ def test_fused_decode_pipeline_matches_unfused_and_oracle(dev, cb, bsz):
     """Deferred-epilogue GEMVs + glue kernels (exl3_glue.hip) against the op-by-op pipeline and the oracle."""
     from exllamav3_amd import ext
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
-    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    ext.set_gemv_variant(1)
     shape = LlamaShape("tiny", 256, 512, 2, 4, 2, 128, 384)
     model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
     model.alloc_state(bsz, pos=700)
@@ -185,7 +185,7 @@ def test_tail_epilogue_pipeline_is_bit_identical_to_glue_pipeline(dev, cb, bsz):
     same summation order: logits, residual stream, q and the quantized KV pages must match the glue pipeline bit for bit."""
     from exllamav3_amd import ext
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
-    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    ext.set_gemv_variant(1)
     # the tail epilogues live in the generation-2 kernel: the glue side is pinned to it too (generation 3 sums k in a different order)
     ext.set_gemm3_min_rows(0)
     shape = LlamaShape("tiny", 256, 512, 3, 4, 2, 128, 384)
@@ -277,7 +277,7 @@ def test_in_gemv_rmsnorm_pipeline_is_bit_identical_to_single_workgroup_norm(dev,
     rotates it for every consumer): same arithmetic and summation order, so logits, residual, q and KV pages match bit for bit."""
     from exllamav3_amd import ext
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
-    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    ext.set_gemv_variant(1)
     shape = LlamaShape("tiny", 384, 512, 3, 4, 2, 128, 384)
     model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=5, max_ctx=2048)
     model.alloc_state(bsz, pos=99)
@@ -354,7 +354,7 @@ def test_fused_pipeline_head_dim_64(dev, bsz):
     the KV groups must land exactly where the op-by-op pipeline puts them; logits against the oracle."""
     from exllamav3_amd import ext
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
-    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    ext.set_gemv_variant(1)
     shape = LlamaShape("tiny64", 256, 512, 2, 8, 4, 64, 384)
     model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
     model.alloc_state(bsz, pos=777)
@@ -476,7 +476,7 @@ def test_fused_pipeline_on_70b_tp8_rank_shapes(dev, bsz):
     vocab shard 16128): fused pipeline against the op-by-op pipeline (single process; the collectives are exercised by test_tp_gloo.py)."""
     from exllamav3_amd import ext
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
-    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    ext.set_gemv_variant(1)
     shape = LlamaShape("70b-rank", 8192, 3584, 1, 8, 1, 128, 16128)
     model = SyntheticEXL3Llama(shape, K=3, cb=2, device=dev, kv_bits=4, max_ctx=1024)
     model.alloc_state(bsz, pos=500)
@@ -646,7 +646,7 @@ def test_resid_in_gemv_pipeline_matches_oracle_and_glue_pipeline(dev, cb, bsz, K
     publishes equals the glue pipeline's to fp16 rounding."""
     from exllamav3_amd import ext
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
-    ext.set_gemv_gen(2); ext.set_gemv_variant(1)
+    ext.set_gemv_variant(1)
     shape = LlamaShape("tiny", 512, 1024, 3, 4, 2, 128, 384)
     model = SyntheticEXL3Llama(shape, K=K, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
     model.alloc_state(bsz, pos=700)

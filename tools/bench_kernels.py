@@ -53,7 +53,6 @@ def main():
                     for var in [int(v) for v in args.variants.split(",")]:
                         for split in [int(v) for v in args.splits.split(",")]:
                             ext.set_gemv_variant(var)
-                            ext.set_gemv_gen(gg)
 
                             def body(count):
                                 for i in range(count):
