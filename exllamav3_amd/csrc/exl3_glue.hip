@@ -126,9 +126,16 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
 //      activation fragments, so the norm needs neither a single-workgroup pass over all slabs nor its own launch.
 //      Same arithmetic as glue_norm_kernel phase 1 (bit-identical residual and partial sums).
 // ------------------------------------------------------------------------------------------------
+// ROT (batches above 4 rows, one rank): the task also does glue_rotate's work for the consumers of the NEW residual -- normalised with the
+// PREVIOUS residual's 1/rms (rot.ss_prev, complete before this launch; the new row sum does not exist until every block of the row is done),
+// so x = fp16(resid_new * w * r_prev) and whoever finishes the consumers' outputs multiplies by r_new / r_prev (GemvRescale: exl3_glue_qkv_rs,
+// exl3_glue_act_rs; the quantized linear commutes with the row scalar).  ss_part must then be a different buffer than rot.ss_prev.
+struct ResidRotate { const float* ss_prev; const half_t* w; float eps; NormTargets tg; };
+
+template <bool ROT>
 __global__ __launch_bounds__(256)
 void glue_resid_kernel(const float* __restrict__ y_base, int y_S, int has_y, const float* __restrict__ y_dense, const half_t* __restrict__ svh,
-                       const half_t* __restrict__ bias, half_t* __restrict__ resid, float* __restrict__ ss_part, int m, int hidden)
+                       const half_t* __restrict__ bias, half_t* __restrict__ resid, float* __restrict__ ss_part, int m, int hidden, ResidRotate rot)
 {
     // flat scalar / pointer arguments (16 dwords): eligible for kernarg preloading (-mllvm -amdgpu-kernarg-preload-count=16); measured on
     // MI355X / ROCm 7.2: no gain (4.73 vs 4.60 us), so the build does not enable it
@@ -141,6 +148,16 @@ void glue_resid_kernel(const float* __restrict__ y_base, int y_S, int has_y, con
     const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
     half4_t r = ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
     float r0 = (float) r.x, r1 = (float) r.y, r2 = (float) r.z, r3 = (float) r.w;
+    half4_t wv = { 0, 0, 0, 0 }, sv[3];
+    float ssp0 = 0.0f;
+    if constexpr (ROT)
+    {
+        // everything the rotation needs that does not depend on the slabs: in flight together with them
+        wv = ((const half4_t*) (rot.w + blk * 128))[l];
+        #pragma unroll
+        for (int i = 0; i < 3; ++i) sv[i] = i < rot.tg.count ? ((const half4_t*) (rot.tg.suh[i] + blk * 128))[l] : half4_t{ 0, 0, 0, 0 };
+        ssp0 = l < nblk ? rot.ss_prev[(size_t) row * nblk + l] : 0.0f;
+    }
     if (has_y)
     {
         float h0, h1, h2, h3;
@@ -167,6 +184,29 @@ void glue_resid_kernel(const float* __restrict__ y_base, int y_S, int has_y, con
     #pragma unroll
     for (int i = 1; i < 32; i <<= 1) ss += xor_lane(ss, i);
     if (act && l == 0) ss_part[(size_t) row * nblk + blk] = ss;
+    if constexpr (ROT)
+    {
+        // 1/rms of the previous residual: the same fixed-order sum as glue_rotate / GEMV_IN_NORM
+        float s2 = 0.0f;
+        for (int b0 = 0; b0 < nblk; b0 += 32)
+        {
+            float v = b0 == 0 ? ssp0 : ((b0 + l < nblk) ? rot.ss_prev[(size_t) row * nblk + b0 + l] : 0.0f);
+            #pragma unroll
+            for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
+            s2 += v;
+        }
+        const float rmf = __frsqrt_rn(s2 / (float) hidden + rot.eps);
+        const half4_t xn = { f2h(r0 * (float) wv.x * rmf), f2h(r1 * (float) wv.y * rmf), f2h(r2 * (float) wv.z * rmf), f2h(r3 * (float) wv.w * rmf) };
+        #pragma unroll
+        for (int i = 0; i < 3; ++i)
+        {
+            if (i < rot.tg.count)
+            {
+                float sum = in_had_store_v(xn, sv[i], rot.tg.xh[i] + (size_t) row * hidden + blk * 128, l, act);
+                if (act && l == 0 && rot.tg.xsum[i]) rot.tg.xsum[i][(size_t) row * nblk + blk] = sum;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -319,7 +359,7 @@ void glue_qkv_kernel(QkvArgs a)
 __global__ __launch_bounds__(256)
 void glue_act_kernel(SlabRef sg, SlabRef su, const half_t* __restrict__ svh_g, const half_t* __restrict__ svh_u,
                      const half_t* __restrict__ suh_d, half_t* __restrict__ xh_d, float* __restrict__ xsum_d,
-                     half_t* __restrict__ a_out, int m, int inter)
+                     half_t* __restrict__ a_out, int m, int inter, GemvRescale rs)
 {
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
     const int nblk = inter >> 7;
@@ -332,9 +372,17 @@ void glue_act_kernel(SlabRef sg, SlabRef su, const half_t* __restrict__ svh_g, c
     const half4_t sud = ((const half4_t*) (suh_d + blk * 128))[l];
     float g0, g1, g2, g3, u0, u1, u2, u3;
     float4_t vg, vu;
+    float rs_p = 0.0f, rs_n = 0.0f;
+    if (rs.ss_new && l < (rs.k >> 7)) { rs_p = rs.ss_prev[(size_t) row * (rs.k >> 7) + l]; rs_n = rs.ss_new[(size_t) row * (rs.k >> 7) + l]; }
     slab_sum2(sg, su, blk, row, m, l, vg, vu);
     out_had(vg, l, g0, g1, g2, g3);
     out_had(vu, l, u0, u1, u2, u3);
+    if (rs.ss_new)
+    {
+        // gate / up were computed from a row normalised with the previous residual's 1/rms (glue_resid ROT): r_new / r_prev on both
+        const float rsc = gemv_rescale(rs, row, l, rs_p, rs_n);
+        g0 *= rsc; g1 *= rsc; g2 *= rsc; g3 *= rsc; u0 *= rsc; u1 *= rsc; u2 *= rsc; u3 *= rsc;
+    }
     half4_t gh = half4_t{ f2h(g0), f2h(g1), f2h(g2), f2h(g3) } * svg;
     half4_t uh = half4_t{ f2h(u0), f2h(u1), f2h(u2), f2h(u3) } * svu;
     auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
@@ -451,13 +499,24 @@ extern "C" int exl3_glue_qkv_rs(const float* sq, const float* sk, const float* s
 extern "C" int exl3_glue_act(const float* sg, const float* su, int S, const void* svh_g, const void* svh_u, const void* suh_d,
                              void* xh_d, float* xsum_d, void* a_out, int m, int inter, void* stream)
 {
+    return exl3_glue_act_rs(sg, su, S, svh_g, svh_u, suh_d, xh_d, xsum_d, a_out, m, inter, nullptr, nullptr, 0, 0.0f, stream);
+}
+
+// exl3_glue_act for gate / up slabs computed from a row that exl3_glue_resid_rotate normalised with the previous residual's 1/rms:
+// ss_prev / ss_new [m][hidden/128] + eps give r_new / r_prev (null: none)
+extern "C" int exl3_glue_act_rs(const float* sg, const float* su, int S, const void* svh_g, const void* svh_u, const void* suh_d,
+                                void* xh_d, float* xsum_d, void* a_out, int m, int inter, const float* ss_prev, const float* ss_new, int hidden,
+                                float eps, void* stream)
+{
+    EXL3_CHECK_ARG(!ss_new || (ss_prev && hidden > 0 && hidden % 128 == 0), "glue_act_rs: rescale needs ss_prev and hidden");
     EXL3_CHECK_ARG(sg && su && svh_g && svh_u && suh_d && xh_d, "glue_act: null pointer");
     EXL3_CHECK_ARG(m >= 1 && m <= 16 && inter % 128 == 0, "glue_act: bad dimensions");
     int tasks = m * (inter / 128);
     SlabRef g = { sg, S }, u = { su, S };
     const int th = glue_threads(tasks), tpw = th / 32;
     glue_act_kernel<<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(g, u, (const half_t*) svh_g, (const half_t*) svh_u, (const half_t*) suh_d,
-                                                                       (half_t*) xh_d, xsum_d, (half_t*) a_out, m, inter);
+                                                                       (half_t*) xh_d, xsum_d, (half_t*) a_out, m, inter,
+                                                                       GemvRescale{ ss_prev, ss_new, hidden, eps });
     return exl3_check_launch("glue_act");
 }
 
@@ -490,9 +549,38 @@ extern "C" int exl3_glue_resid(const float* y_slabs, int y_S, const float* y_den
     SlabRef y = { y_slabs, y_S };
     const int tasks = m * (hidden / 128);
     const int th = glue_threads(tasks), tpw = th / 32;
-    glue_resid_kernel<<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(y.base, y.S, (y_slabs || y_dense) ? 1 : 0, y_dense, (const half_t*) svh,
-                                                                        (const half_t*) bias, (half_t*) resid, ss_part, m, hidden);
+    glue_resid_kernel<false><<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(y.base, y.S, (y_slabs || y_dense) ? 1 : 0, y_dense, (const half_t*) svh,
+                                                                               (const half_t*) bias, (half_t*) resid, ss_part, m, hidden, ResidRotate{});
     return exl3_check_launch("glue_resid");
+}
+
+// glue_resid + glue_rotate in one launch (see glue_resid_kernel ROT): resid += y; ss_new = block sums of squares of the new residual;
+// xh_i = had128(fp16(resid_new * w * r_prev) * suh_i) with r_prev from ss_prev (a different buffer than ss_new).  The consumers of xh_i
+// must be finished with exl3_glue_qkv_rs / exl3_glue_act_rs (ss_prev, ss_new).
+extern "C" int exl3_glue_resid_rotate(const float* y_slabs, int y_S, const float* y_dense, const void* svh, const void* bias, void* resid,
+                                      const float* ss_prev, float* ss_new, const void* w, float eps, const void* const* suhs, void* const* xhs,
+                                      float* const* xsums, int count, int m, int hidden, void* stream)
+{
+    EXL3_CHECK_ARG(resid && ss_prev && ss_new && ss_prev != ss_new && w && suhs && xhs, "glue_resid_rotate: null pointer / ss_prev == ss_new");
+    EXL3_CHECK_ARG(m >= 1 && m <= 16 && hidden % 128 == 0, "glue_resid_rotate: bad dimensions");
+    EXL3_CHECK_ARG(count >= 1 && count <= 3, "glue_resid_rotate: 1..3 consumers");
+    EXL3_CHECK_ARG((y_slabs && svh && y_S >= 1) || y_dense, "glue_resid_rotate: needs a pending output (slabs + svh, or a dense tensor)");
+    ResidRotate rot;
+    rot.ss_prev = ss_prev; rot.w = (const half_t*) w; rot.eps = eps;
+    rot.tg.count = count;
+    for (int i = 0; i < 3; ++i)
+    {
+        rot.tg.suh[i] = i < count ? (const half_t*) suhs[i] : nullptr;
+        rot.tg.xh[i] = i < count ? (half_t*) xhs[i] : nullptr;
+        rot.tg.xsum[i] = (i < count && xsums) ? xsums[i] : nullptr;
+        EXL3_CHECK_ARG(i >= count || (suhs[i] && xhs[i]), "glue_resid_rotate: null consumer pointer");
+    }
+    SlabRef y = { y_slabs, y_S };
+    const int tasks = m * (hidden / 128);
+    const int th = glue_threads(tasks), tpw = th / 32;
+    glue_resid_kernel<true><<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(y.base, y.S, 1, y_dense, (const half_t*) svh, (const half_t*) bias,
+                                                                              (half_t*) resid, ss_new, m, hidden, rot);
+    return exl3_check_launch("glue_resid_rotate");
 }
 
 extern "C" int exl3_glue_rotate(const void* resid, const float* ss_part, const void* w, float eps, const void* const* suhs, void* const* xhs,

@@ -637,6 +637,23 @@ def glue_act(slabs, S: int, svh_g, svh_u, suh_d, xh_d, xsum_d, m: int, a_out=Non
                                     xh_d.shape[-1], _stream(xh_d)))
 
 
+def glue_act_rs(slabs, S: int, svh_g, svh_u, suh_d, xh_d, xsum_d, m: int, ss_prev, ss_new, hidden: int, eps: float, a_out=None):
+    """glue_act for gate / up slabs of a row that glue_resid_rotate normalised with the previous residual's 1/rms: g, u are multiplied by
+    rsqrt(ms_new + eps) / rsqrt(ms_prev + eps) of their row first."""
+    _dev(xh_d)
+    _check(_lib.lib().exl3_glue_act_rs(slabs[0], slabs[1], S, _p(svh_g), _p(svh_u), _p(suh_d), _p(xh_d), _p(xsum_d), _p(a_out), m,
+                                       xh_d.shape[-1], _p(ss_prev), _p(ss_new), int(hidden), float(eps), _stream(xh_d)))
+
+
+def glue_resid_rotate(y_slab, y_S: int, svh, bias, resid, ss_prev, ss_new, w, eps: float, suhs, xhs, m: int, xsums=None, y_dense=None):
+    """glue_resid + glue_rotate in one launch (batches above 4 rows): resid += y, ss_new = block sums of squares of the new residual,
+    xh_i = had128(fp16(resid_new * w * r_prev) * suh_i) with r_prev from ss_prev (another buffer than ss_new); finish the consumers with
+    glue_qkv_rs / glue_act_rs (ss_prev, ss_new)."""
+    _dev(resid)
+    _check(_lib.lib().exl3_glue_resid_rotate(y_slab, y_S, _p(y_dense), _p(svh), _p(bias), _p(resid), _p(ss_prev), _p(ss_new), _p(w), float(eps),
+                                             _parr(suhs), _parr(xhs), _parr(xsums) if xsums else None, len(suhs), m, resid.shape[-1], _stream(resid)))
+
+
 # ---- GEMV launches with an in-kernel tail epilogue (one launch per sublayer boundary of a decode step) ----------------------
 
 def _kK(B):

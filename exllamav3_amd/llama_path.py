@@ -352,6 +352,58 @@ class SyntheticEXL3Llama:
     #: forced split-k factor per call type of the fused pipelines (0 = library heuristic); tools/sweep_split.py tunes these
     split = {"qkv": 0, "o": 0, "gu": 0, "down": 0}
 
+    #: batches above 4 rows, one rank: glue_resid also rotates the new residual for its consumers (ext.glue_resid_rotate: 8 launches per layer
+    #: instead of 10); False = separate glue_resid + glue_rotate launches (the reference's rounding point of the normalised activation)
+    fold_rotate = True
+
+    def _decode_step_fused_folded(self):
+        """decode_step_fused for batches above 4 rows on one rank with the rotation folded into the residual kernel: per layer
+        q|k|v (rotated input) -> glue_qkv_rs -> o -> glue_resid_rotate [-> xh for gate|up] -> gate|up -> glue_act_rs -> down ->
+        glue_resid_rotate [-> xh for the next layer's q|k|v].  A folded launch normalises with the PREVIOUS residual's 1/rms (the new one needs
+        the whole row); the consumers' epilogues multiply by r_new / r_prev.  First and last norm of the step use the separate kernels."""
+        sp, bsz, hd = self.split, self._state_bsz, self.shape.head_dim
+        ROT, DEF = ext.GEMV_IN_ROTATED, ext.GEMV_OUT_DEFERRED
+        x = self.x
+        x.copy_(self.x0)
+        q2 = self.q.view(bsz, -1)
+        hidden = self.shape.hidden
+        ss_c, ss_o = self.ss, self.ss2                                    # sums of squares of the current residual / the other buffer
+        ext.glue_resid(None, 0, None, None, x, ss_c, bsz)
+        L0 = self.layers[0]
+        ext.glue_rotate(x, ss_c, L0["norm1"], self.eps, [L0["q"].suh, L0["k"].suh, L0["v"].suh], self.xh3, bsz)
+        rs = None                                                          # (ss_prev, ss_new) of the pending rescale, None = normalised exactly
+        for li, L in enumerate(self.layers):
+            lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
+            kc, ks = self.kcache[li]
+            vc, vs = self.vcache[li]
+            slabs, S = ext.exl3_gemv_ex(None, self.xh3, None, [lq.trellis, lk.trellis, lv.trellis], None, None, None,
+                                        bsz, lq.mcg, lq.mul1, ROT | DEF, sp["qkv"])
+            ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                            self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd,
+                            rs[0] if rs else None, rs[1] if rs else None, hidden, self.eps)
+            o_in = q2
+            if self.with_attention and hd in (64, 128):
+                ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
+                                       self.attn_pos + 1, workspace=self.attn_ws)
+                o_in = self.attn_out.view(bsz, -1)
+            so, So = ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"])
+            ext.glue_resid_rotate(so[0], So, lo.svh, None, x, ss_c, ss_o, L["norm2"], self.eps, [lg.suh, lu.suh], self.xh3[:2], bsz)
+            rs = (ss_c, ss_o); ss_c, ss_o = ss_o, ss_c
+            sgu, Sgu = ext.exl3_gemv_ex(None, self.xh3[:2], None, [lg.trellis, lu.trellis], None, None, None,
+                                        bsz, lg.mcg, lg.mul1, ROT | DEF, sp["gu"])
+            ext.glue_act_rs(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz, rs[0], rs[1], hidden, self.eps)
+            sd, Sd = ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF, sp["down"])
+            if li + 1 < self.n_layers:
+                N = self.layers[li + 1]
+                ext.glue_resid_rotate(sd[0], Sd, ld.svh, None, x, ss_c, ss_o, N["norm1"], self.eps, [N["q"].suh, N["k"].suh, N["v"].suh], self.xh3, bsz)
+                rs = (ss_c, ss_o); ss_c, ss_o = ss_o, ss_c
+            else:
+                ext.glue_resid(sd[0], Sd, ld.svh, None, x, ss_c, bsz)
+        ext.glue_rotate(x, ss_c, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz)
+        ext.exl3_gemv_ex(None, self.xh3[:1], None, [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
+                         bsz, self.lm_head.mcg, self.lm_head.mul1, ROT)
+        return self.logits
+
     def decode_step_fused(self):
         """Fused decode step, 8 launches per layer: deferred-epilogue GEMVs + glue kernels.  The RMSNorm between two linears is
         split: glue_resid (distributed: split-k reduce + out-Hadamard + residual add + per-block sums of squares) and the consumer
@@ -367,6 +419,8 @@ class SyntheticEXL3Llama:
         ss = self.ss
         # batches above 4 rows: the norm + input Hadamards run once in glue_rotate instead of in every column-block workgroup
         rot = bsz > int(os.environ.get("EXL3_HIP_ROTATE_ABOVE", "4"))
+        if rot and self.fold_rotate and self.tp == 1 and all(_same_kind(L["q"], L["k"], L["v"]) and _same_kind(L["gate"], L["up"]) for L in self.layers):
+            return self._decode_step_fused_folded()
         ext.glue_resid(None, 0, None, None, x, ss, bsz)
         for li, L in enumerate(self.layers):
             lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]

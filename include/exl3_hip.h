@@ -231,6 +231,17 @@ int exl3_glue_qkv_rs(const float* sq, const float* sk, const float* sv, int S, c
 int exl3_gemv_ex_act(const float* g_slabs, const float* u_slabs, int act_S, const void* svh_g, const void* svh_u,
                      const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
                      int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream);
+/* ---- batches above 4 rows: exl3_glue_resid + exl3_glue_rotate in one launch (8 launches per Llama layer instead of 10) --------------------------
+ * resid += y (pending slabs + svh, or a dense fp32 tensor); ss_new [m][hidden/128] = block sums of squares of the new residual;
+ * xh_i = had128(fp16(resid_new * w * r_prev) * suh_i) for up to 3 consumers, r_prev = rsqrt(mean(ss_prev) + eps) of the PREVIOUS residual
+ * (ss_prev != ss_new).  The consumers' outputs are finished with r_new / r_prev by exl3_glue_qkv_rs / exl3_glue_act_rs (same reasoning and
+ * rounding point as exl3_gemv_ex_resid above).  Replaces rms_norm_res_in (norm.cu:193-299) + the input transform of exl3_gemm (quant/exl3_gemm.cu:139-145). */
+int exl3_glue_resid_rotate(const float* y_slabs, int y_S, const float* y_dense, const void* svh, const void* bias, void* resid,
+                           const float* ss_prev, float* ss_new, const void* w, float eps, const void* const* suhs, void* const* xhs,
+                           float* const* xsums, int count, int m, int hidden, void* stream);
+int exl3_glue_act_rs(const float* sg, const float* su, int S, const void* svh_g, const void* svh_u, const void* suh_d,
+                     void* xh_d, float* xsum_d, void* a_out, int m, int inter, const float* ss_prev, const float* ss_new, int hidden,
+                     float eps, void* stream);
 
 /* y[rows][cols] = silu(g) * u (activation.cu) where g and u are fp16 column ranges of wider matrices (row strides ld_g, ld_u). */
 int exl3_silu_mul_2d(const void* g, const void* u, void* y, int64_t rows, int64_t cols, int64_t ld_g, int64_t ld_u, void* stream);

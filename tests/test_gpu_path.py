@@ -281,6 +281,7 @@ def test_in_gemv_rmsnorm_pipeline_is_bit_identical_to_single_workgroup_norm(dev,
     shape = LlamaShape("tiny", 384, 512, 3, 4, 2, 128, 384)
     model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=5, max_ctx=2048)
     model.alloc_state(bsz, pos=99)
+    model.fold_rotate = False                              # bsz 16: the separate glue_resid + glue_rotate launches are the bit-identical form
     l1 = model.decode_step_fused_v1().clone()
     x1, q1 = model.x.clone(), model.q.clone()
     kv1 = [(c.clone(), s.clone()) for c, s in model.kcache + model.vcache]
@@ -690,6 +691,43 @@ def test_resid_in_gemv_pipeline_with_large_residual_scale_change(dev):
     lr = model.decode_step_resid().float().cpu().numpy().copy()
     ref = _oracle_decode(model, _np(model.x0))
     assert np.abs(lr - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+
+
+@pytest.mark.parametrize("cb", [0, 2])
+@pytest.mark.parametrize("bsz", [5, 16])
+def test_folded_resid_rotate_pipeline_matches_oracle_and_separate_launches(dev, cb, bsz):
+    """Batches above 4 rows: glue_resid_rotate (residual add + per-block sums + rotation with the PREVIOUS residual's 1/rms, consumers rescaled by
+    r_new / r_prev in glue_qkv_rs / glue_act_rs) against the oracle and against the separate glue_resid + glue_rotate launches; also with a
+    residual 50x smaller than the sublayer outputs (r_prev far from r_new); graph replay reproduces the eager bits."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_variant(1)
+    shape = LlamaShape("tiny", 512, 1024, 3, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(bsz, pos=700)
+    for scale in (1.0, 0.02):
+        model.x0.mul_(scale)
+        model.fold_rotate = False
+        ls = model.decode_step_fused().float().cpu().numpy().copy()
+        xs = model.x.float().cpu().numpy().copy()
+        model.fold_rotate = True
+        lf = model.decode_step_fused().float().cpu().numpy().copy()
+        assert np.isfinite(lf).all()
+        ref = _oracle_decode(model, _np(model.x0))
+        rms = np.sqrt((ref ** 2).mean())
+        assert np.abs(lf - ref).max() / rms < 3e-2
+        assert np.abs(lf - ls).max() / rms < 1.5e-2
+        xf = model.x.float().cpu().numpy()
+        assert np.abs(xf - xs).max() / np.sqrt((xs ** 2).mean()) < 1e-2
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            model.decode_step_fused()
+    for _ in range(3):
+        model.logits.zero_(); g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(model.logits.float().cpu().numpy(), lf)
 
 
 @pytest.mark.parametrize("bsz", [1, 3])
