@@ -18,6 +18,36 @@
 
 #define KVQ_R32 0.17677669529663688110f     // 1 / sqrt(32)
 
+// Optional cubic compander of the level grid (reference: cache/lmq.cuh LMCubic, used by quant_block_x4 / dequant_block_x4 when compand_a > 0):
+//   decode: t = (2 q + 1) / 2^b - 1;  level = a t + (1 - a) t^3            (fma order as below)
+//   encode: the real root of (1 - a) t^3 + a t = x by Cardano;  q = clamp(floor(fma(t, 2^(b-1), 2^(b-1))), 0, 2^b - 1)
+// sqrtf is correctly rounded here; cbrtf is the device library's (<= 1 ulp), so an x within an ulp of a cell boundary may land in the
+// neighbouring cell compared with another libm -- the parity tests allow that and nothing else.
+struct KvCompander
+{
+    float a, b, inv_b, p3_cub;
+    __device__ __forceinline__ explicit KvCompander(float a_) : a(a_), b(1.0f - a_), inv_b(1.0f / (1.0f - a_))
+    {
+        const float p3 = a * inv_b * (1.0f / 3.0f);
+        p3_cub = p3 * p3 * p3;
+    }
+    __device__ __forceinline__ float decode(uint32_t q, int bits) const
+    {
+        const float t = __builtin_fmaf(2.0f * (float) (int) q + 1.0f, 1.0f / (float) (1 << bits), -1.0f);
+        return t * __builtin_fmaf(t * t, b, a);
+    }
+    __device__ __forceinline__ uint32_t encode(float x, int bits) const
+    {
+        const float q_half = x * inv_b * 0.5f;
+        const float delta = __builtin_fmaf(q_half, q_half, p3_cub);
+        const float s = sqrtf(delta);
+        const float t = cbrtf(q_half + s) + cbrtf(q_half - s);
+        const float half_n = (float) (1 << (bits - 1));
+        const int qi = (int) floorf(__builtin_fmaf(t, half_n, half_n));
+        return (uint32_t) max(min(qi, (1 << bits) - 1), 0);
+    }
+};
+
 template <int VPL>
 struct KvGroup
 {
@@ -66,7 +96,7 @@ struct KvGroup
 
     // quantize the group held in v (already fp16-rounded inputs as fp32); `bits` may be a compile-time or a run-time value (same arithmetic)
     __device__ static __forceinline__ void quantize(const int bits, float (&v)[VPL], uint32_t* __restrict__ out, half_t* __restrict__ out_scale,
-                                                    bool active, int lane)
+                                                    bool active, int lane, const float compand_a = 0.0f)
     {
         const int gl = lane % LPG;
         hadamard(v, lane);
@@ -78,11 +108,20 @@ struct KvGroup
         const float half_range = (float) (1 << (bits - 1));
         const int qmax = (1 << bits) - 1;
         uint32_t q[VPL];
-        #pragma unroll
-        for (int j = 0; j < VPL; ++j)
+        if (compand_a > 0.0f)
         {
-            const int qi = (int) floorf(__builtin_fmaf(v[j] * inv_s, half_range, half_range));
-            q[j] = (uint32_t) max(min(qi, qmax), 0);
+            const KvCompander lm(compand_a);
+            #pragma unroll
+            for (int j = 0; j < VPL; ++j) q[j] = lm.encode(v[j] * inv_s, bits);
+        }
+        else
+        {
+            #pragma unroll
+            for (int j = 0; j < VPL; ++j)
+            {
+                const int qi = (int) floorf(__builtin_fmaf(v[j] * inv_s, half_range, half_range));
+                q[j] = (uint32_t) max(min(qi, qmax), 0);
+            }
         }
         int rem = bits, wb = 0;
         if (bits & 8) { rem -= 8; store_plane<8>(out, wb, gl, q, rem, active); wb += 8; }
@@ -97,7 +136,8 @@ struct KvGroup
     // WITH_R32: include the 1/sqrt(32) of the inverse Hadamard (dequantization to x'); without it the caller folds that factor elsewhere
     // (decode attention keeps K / V in the rotated domain)
     template <bool WITH_R32>
-    __device__ static __forceinline__ void levels(const int bits, const uint32_t* __restrict__ in, const half_t* __restrict__ in_scale, int lane, float (&u)[VPL])
+    __device__ static __forceinline__ void levels(const int bits, const uint32_t* __restrict__ in, const half_t* __restrict__ in_scale, int lane, float (&u)[VPL],
+                                                  const float compand_a = 0.0f)
     {
         const int gl = lane % LPG;
         uint32_t word[4];
@@ -122,6 +162,14 @@ struct KvGroup
             const uint32_t x = word[pi] >> ((gl * VPL * w) & 31);
             #pragma unroll
             for (int j = 0; j < VPL; ++j) q[j] = has ? ((q[j] << w) | ((x >> (j * w)) & ((1u << w) - 1u))) : q[j];
+        }
+        if (compand_a > 0.0f)
+        {
+            const KvCompander lm(compand_a);
+            const float sc = WITH_R32 ? scale * KVQ_R32 : scale;
+            #pragma unroll
+            for (int j = 0; j < VPL; ++j) u[j] = lm.decode(q[j], bits) * sc;
+            return;
         }
         const int m = 1 << (bits - 1);
         const float sm = (WITH_R32 ? scale * KVQ_R32 : scale) * (1.0f / (float) m);

@@ -213,18 +213,20 @@ extern "C" int exl3_rope_strided(void* q, void* k, const float* inv_freq, int bs
 
 // One 32-group per 16-lane DPP row, two consecutive values per lane, four groups (128 values) per wave: exl3_kvq.cuh KvGroup<2>.
 template <int BITS>
-__device__ __forceinline__ void kv_quant_group(const half_t* __restrict__ in, uint32_t* __restrict__ out, half_t* __restrict__ out_scale, bool active, int lane)
+__device__ __forceinline__ void kv_quant_group(const half_t* __restrict__ in, uint32_t* __restrict__ out, half_t* __restrict__ out_scale, bool active, int lane,
+                                               float compand_a)
 {
     float v[2] = { 0.0f, 0.0f };
     if (active) { const half2_t x = ((const half2_t*) in)[lane & 15]; v[0] = (float) x.x; v[1] = (float) x.y; }
-    KvGroup<2>::quantize(BITS, v, out, out_scale, active, lane);
+    KvGroup<2>::quantize(BITS, v, out, out_scale, active, lane, compand_a);
 }
 
 template <int BITS>
-__device__ __forceinline__ void kv_dequant_group(const uint32_t* __restrict__ in, const half_t* __restrict__ in_scale, half_t* __restrict__ out, bool active, int lane)
+__device__ __forceinline__ void kv_dequant_group(const uint32_t* __restrict__ in, const half_t* __restrict__ in_scale, half_t* __restrict__ out, bool active, int lane,
+                                                 float compand_a)
 {
     float u[2];
-    KvGroup<2>::levels<true>(BITS, in, in_scale, lane, u);                 // inactive lanes read group 0 (valid memory), results discarded
+    KvGroup<2>::levels<true>(BITS, in, in_scale, lane, u, compand_a);      // inactive lanes read group 0 (valid memory), results discarded
     KvGroup<2>::hadamard(u, lane);
     if (active) ((half2_t*) out)[lane & 15] = half2_t{ f2h(u[0]), f2h(u[1]) };
 }
@@ -232,22 +234,22 @@ __device__ __forceinline__ void kv_dequant_group(const uint32_t* __restrict__ in
 // contiguous: group g of the flat tensor
 template <int BITS>
 __global__ __launch_bounds__(256)
-void kv_quant_cont_kernel(const half_t* __restrict__ in, uint32_t* __restrict__ out, half_t* __restrict__ scales, int64_t num_groups)
+void kv_quant_cont_kernel(const half_t* __restrict__ in, uint32_t* __restrict__ out, half_t* __restrict__ scales, int64_t num_groups, float compand_a)
 {
     int64_t g = (int64_t) blockIdx.x * 16 + (threadIdx.x >> 4);
     bool active = g < num_groups;
     int64_t gs = active ? g : 0;
-    kv_quant_group<BITS>(in + gs * 32, out + gs * BITS, scales + gs, active, threadIdx.x & 63);
+    kv_quant_group<BITS>(in + gs * 32, out + gs * BITS, scales + gs, active, threadIdx.x & 63, compand_a);
 }
 
 template <int BITS>
 __global__ __launch_bounds__(256)
-void kv_dequant_cont_kernel(const uint32_t* __restrict__ in, const half_t* __restrict__ scales, half_t* __restrict__ out, int64_t num_groups)
+void kv_dequant_cont_kernel(const uint32_t* __restrict__ in, const half_t* __restrict__ scales, half_t* __restrict__ out, int64_t num_groups, float compand_a)
 {
     int64_t g = (int64_t) blockIdx.x * 16 + (threadIdx.x >> 4);
     bool active = g < num_groups;
     int64_t gs = active ? g : 0;
-    kv_dequant_group<BITS>(in + gs * BITS, scales + gs, out + gs * 32, active, threadIdx.x & 63);
+    kv_dequant_group<BITS>(in + gs * BITS, scales + gs, out + gs * 32, active, threadIdx.x & 63, compand_a);
 }
 
 // paged append: grid (ceil(groups_per_token/16), seq_len, bsz); K and V in one launch (blockIdx.x parity split would
@@ -257,43 +259,58 @@ __global__ __launch_bounds__(256)
 void kv_quant_paged_kernel(const half_t* __restrict__ k_in, uint32_t* __restrict__ k_out, half_t* __restrict__ k_scales,
                            const half_t* __restrict__ v_in, uint32_t* __restrict__ v_out, half_t* __restrict__ v_scales,
                            const int32_t* __restrict__ cache_seqlens, const int32_t* __restrict__ block_table,
-                           int blocks_per_seq, int page_size, int groups_per_token, int64_t ld_k, int64_t ld_v)
+                           int blocks_per_seq, int page_size, int groups_per_token, int64_t ld_k, int64_t ld_v, float compand_a, int in_contiguous)
 {
     // ld_k / ld_v: halves between consecutive input tokens (groups_per_token * 32 when contiguous)
     const int batch = blockIdx.z;
     const int token_idx = blockIdx.y + cache_seqlens[batch];
     const int page_idx = token_idx / page_size;
     const int64_t token_pos = (int64_t) block_table[blocks_per_seq * batch + page_idx] * page_size + (token_idx % page_size);
-    const int64_t in_pos = (int64_t) batch * gridDim.y + blockIdx.y;
+    // in_contiguous = 0: k_in / v_in are a flat fp16 staging cache read at the token's own physical row (q_cache_kernels.cuh:316-318)
+    const int64_t in_pos = in_contiguous ? (int64_t) batch * gridDim.y + blockIdx.y : token_pos;
     const int g = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool active = g < groups_per_token;
     const int gs = active ? g : 0;
     const int64_t base = token_pos * groups_per_token + gs;
     const int lane = threadIdx.x & 63;
-    kv_quant_group<KB>(k_in + in_pos * ld_k + gs * 32, k_out + base * KB, k_scales + base, active, lane);
-    kv_quant_group<VB>(v_in + in_pos * ld_v + gs * 32, v_out + base * VB, v_scales + base, active, lane);
+    kv_quant_group<KB>(k_in + in_pos * ld_k + gs * 32, k_out + base * KB, k_scales + base, active, lane, compand_a);
+    kv_quant_group<VB>(v_in + in_pos * ld_v + gs * 32, v_out + base * VB, v_scales + base, active, lane, compand_a);
 }
 
-// paged dequant of every cached token: grid (ceil(groups_per_token/16), max_tokens, bsz)
+// paged dequant of the cached tokens: grid (ceil(groups_per_token/16), max_tokens, bsz).  Which rows are written follows the reference kernel
+// (cache/q_cache_kernels.cuh:342-399): logical positions [0, cache_seqlens[b] + bonus_len); with sliding_window > 0 the reference skips whole
+// thread blocks of 256 "chunks" (a chunk = 4 groups of one token, ceil(groups_per_token / 4) chunks per token) that end at or before
+// max_len - sliding_window -- the same test is applied per group here, so exactly the same rows are left untouched; compact_out writes page p of
+// sequence b densely at row (b * blocks_per_seq + p) * page_size instead of the physical page (dequant_cache_paged_window's scratch layout).
 template <int KB, int VB>
 __global__ __launch_bounds__(256)
 void kv_dequant_paged_kernel(const uint32_t* __restrict__ k_in, const half_t* __restrict__ k_scales, half_t* __restrict__ k_out,
                              const uint32_t* __restrict__ v_in, const half_t* __restrict__ v_scales, half_t* __restrict__ v_out,
                              const int32_t* __restrict__ cache_seqlens, const int32_t* __restrict__ block_table,
-                             int blocks_per_seq, int page_size, int groups_per_token)
+                             int blocks_per_seq, int page_size, int groups_per_token, int sliding_window, float compand_a, int compact_out, int bonus_len)
 {
     const int batch = blockIdx.z;
     const int token_idx = blockIdx.y;
-    if (token_idx >= cache_seqlens[batch]) return;
+    const int max_token_idx = cache_seqlens[batch] + bonus_len;
+    if (token_idx >= max_token_idx) return;
+    const int g = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool in_range = g < groups_per_token;
+    const int gs = in_range ? g : 0;
+    bool active = in_range;
+    if (sliding_window > 0)
+    {
+        const int chunks_per_token = (groups_per_token + 3) >> 2;
+        const int64_t chunk_id = (int64_t) token_idx * chunks_per_token + (gs >> 2);
+        const int64_t next_block_chunk = ((chunk_id >> 8) + 1) << 8;               // 8 warps x 32 iterations of the reference's thread block
+        active = active && !((int) (next_block_chunk / chunks_per_token) <= max_token_idx - sliding_window);
+    }
     const int page_idx = token_idx / page_size;
     const int64_t token_pos = (int64_t) block_table[blocks_per_seq * batch + page_idx] * page_size + (token_idx % page_size);
-    const int g = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const bool active = g < groups_per_token;
-    const int gs = active ? g : 0;
-    const int64_t base = token_pos * groups_per_token + gs;
+    const int64_t out_pos = compact_out ? ((int64_t) batch * blocks_per_seq + page_idx) * page_size + (token_idx % page_size) : token_pos;
+    const int64_t base = token_pos * groups_per_token + gs, base_out = out_pos * groups_per_token + gs;
     const int lane = threadIdx.x & 63;
-    kv_dequant_group<KB>(k_in + base * KB, k_scales + base, k_out + base * 32, active, lane);
-    kv_dequant_group<VB>(v_in + base * VB, v_scales + base, v_out + base * 32, active, lane);
+    kv_dequant_group<KB>(k_in + base * KB, k_scales + base, k_out + base_out * 32, active, lane, compand_a);
+    kv_dequant_group<VB>(v_in + base * VB, v_scales + base, v_out + base_out * 32, active, lane, compand_a);
 }
 
 #define BITS_SWITCH(b, CALL) switch (b) { \
@@ -303,48 +320,63 @@ void kv_dequant_paged_kernel(const uint32_t* __restrict__ k_in, const half_t* __
 
 extern "C" int exl3_quant_cache_cont(const void* in, void* out, void* out_scales, int64_t tokens, int dim, int bits, void* stream)
 {
+    return exl3_quant_cache_cont_ex(in, out, out_scales, tokens, dim, bits, 0.0f, stream);
+}
+
+static bool compand_ok(float a) { return a == 0.0f || (a > 0.0f && a < 1.0f); }      // (1 - a) is a divisor in the encoder
+
+extern "C" int exl3_quant_cache_cont_ex(const void* in, void* out, void* out_scales, int64_t tokens, int dim, int bits, float compand_a, void* stream)
+{
+    EXL3_CHECK_ARG(compand_ok(compand_a), "quant_cache_cont: compand_a must be 0 (off) or in (0, 1)");
     EXL3_CHECK_ARG(in && out && out_scales, "quant_cache_cont: null pointer");
     EXL3_CHECK_ARG(dim % 32 == 0, "quant_cache_cont: dim must be divisible by 32");
     EXL3_CHECK_ARG(bits >= 2 && bits <= 8, "quant_cache_cont: bits must be in [2, 8]");
     int64_t groups = tokens * (dim / 32);
     if (groups == 0) return EXL3_OK;
     dim3 grid((unsigned) ((groups + 15) / 16));
-    BITS_SWITCH(bits, (kv_quant_cont_kernel<BB><<<grid, 256, 0, (hipStream_t) stream>>>((const half_t*) in, (uint32_t*) out, (half_t*) out_scales, groups)));
+    BITS_SWITCH(bits, (kv_quant_cont_kernel<BB><<<grid, 256, 0, (hipStream_t) stream>>>((const half_t*) in, (uint32_t*) out, (half_t*) out_scales, groups, compand_a)));
     return exl3_check_launch("quant_cache_cont");
 }
 
 extern "C" int exl3_dequant_cache_cont(const void* in, const void* in_scales, void* out, int64_t tokens, int dim, int bits, void* stream)
 {
+    return exl3_dequant_cache_cont_ex(in, in_scales, out, tokens, dim, bits, 0.0f, stream);
+}
+
+extern "C" int exl3_dequant_cache_cont_ex(const void* in, const void* in_scales, void* out, int64_t tokens, int dim, int bits, float compand_a, void* stream)
+{
+    EXL3_CHECK_ARG(compand_ok(compand_a), "dequant_cache_cont: compand_a must be 0 (off) or in (0, 1)");
     EXL3_CHECK_ARG(in && out && in_scales, "dequant_cache_cont: null pointer");
     EXL3_CHECK_ARG(dim % 32 == 0, "dequant_cache_cont: dim must be divisible by 32");
     EXL3_CHECK_ARG(bits >= 2 && bits <= 8, "dequant_cache_cont: bits must be in [2, 8]");
     int64_t groups = tokens * (dim / 32);
     if (groups == 0) return EXL3_OK;
     dim3 grid((unsigned) ((groups + 15) / 16));
-    BITS_SWITCH(bits, (kv_dequant_cont_kernel<BB><<<grid, 256, 0, (hipStream_t) stream>>>((const uint32_t*) in, (const half_t*) in_scales, (half_t*) out, groups)));
+    BITS_SWITCH(bits, (kv_dequant_cont_kernel<BB><<<grid, 256, 0, (hipStream_t) stream>>>((const uint32_t*) in, (const half_t*) in_scales, (half_t*) out, groups, compand_a)));
     return exl3_check_launch("dequant_cache_cont");
 }
 
 template <int KB>
 static void launch_quant_paged(int vb, dim3 grid, hipStream_t st, const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
-                               const int32_t* sl, const int32_t* bt, int bps, int ps, int gpt, int64_t ld_k, int64_t ld_v)
+                               const int32_t* sl, const int32_t* bt, int bps, int ps, int gpt, int64_t ld_k, int64_t ld_v, float ca, int in_cont)
 {
     BITS_SWITCH(vb, (kv_quant_paged_kernel<KB, BB><<<grid, 256, 0, st>>>((const half_t*) k_in, (uint32_t*) k_out, (half_t*) k_scales, (const half_t*) v_in,
-                                                                         (uint32_t*) v_out, (half_t*) v_scales, sl, bt, bps, ps, gpt, ld_k, ld_v)));
+                                                                         (uint32_t*) v_out, (half_t*) v_scales, sl, bt, bps, ps, gpt, ld_k, ld_v, ca, in_cont)));
 }
 
 template <int KB>
 static void launch_dequant_paged(int vb, dim3 grid, hipStream_t st, const void* k_in, const void* k_scales, void* k_out, const void* v_in, const void* v_scales, void* v_out,
-                                 const int32_t* sl, const int32_t* bt, int bps, int ps, int gpt)
+                                 const int32_t* sl, const int32_t* bt, int bps, int ps, int gpt, int sw, float ca, int compact, int bonus)
 {
     BITS_SWITCH(vb, (kv_dequant_paged_kernel<KB, BB><<<grid, 256, 0, st>>>((const uint32_t*) k_in, (const half_t*) k_scales, (half_t*) k_out, (const uint32_t*) v_in,
-                                                                           (const half_t*) v_scales, (half_t*) v_out, sl, bt, bps, ps, gpt)));
+                                                                           (const half_t*) v_scales, (half_t*) v_out, sl, bt, bps, ps, gpt, sw, ca, compact, bonus)));
 }
 
 static int quant_cache_paged_impl(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
                                   const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
-                                  int page_size, int seq_len, int dim, int k_bits, int v_bits, int64_t ld_k, int64_t ld_v, void* stream)
+                                  int page_size, int seq_len, int dim, int k_bits, int v_bits, int64_t ld_k, int64_t ld_v, float compand_a, int in_contiguous, void* stream)
 {
+    EXL3_CHECK_ARG(compand_ok(compand_a), "quant_cache_paged: compand_a must be 0 (off) or in (0, 1)");
     EXL3_CHECK_ARG(k_in && k_out && k_scales && v_in && v_out && v_scales && cache_seqlens && block_table, "quant_cache_paged: null pointer");
     EXL3_CHECK_ARG(dim % 32 == 0 && page_size > 0, "quant_cache_paged: dim must be divisible by 32");
     EXL3_CHECK_ARG(k_bits >= 2 && k_bits <= 8 && v_bits >= 2 && v_bits <= 8, "quant_cache_paged: bits must be in [2, 8]");
@@ -353,7 +385,7 @@ static int quant_cache_paged_impl(const void* k_in, void* k_out, void* k_scales,
     const int gpt = dim / 32;
     dim3 grid((gpt + 15) / 16, seq_len, bsz);
     hipStream_t st = (hipStream_t) stream;
-    #define QP(KBv) case KBv: launch_quant_paged<KBv>(v_bits, grid, st, k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, blocks_per_seq, page_size, gpt, ld_k, ld_v); break;
+    #define QP(KBv) case KBv: launch_quant_paged<KBv>(v_bits, grid, st, k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, blocks_per_seq, page_size, gpt, ld_k, ld_v, compand_a, in_contiguous); break;
     switch (k_bits) { QP(2) QP(3) QP(4) QP(5) QP(6) QP(7) QP(8) }
     #undef QP
     return exl3_check_launch("quant_cache_paged");
@@ -364,7 +396,17 @@ extern "C" int exl3_quant_cache_paged(const void* k_in, void* k_out, void* k_sca
                                       int page_size, int seq_len, int dim, int k_bits, int v_bits, void* stream)
 {
     return quant_cache_paged_impl(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, bsz, blocks_per_seq, page_size, seq_len, dim,
-                                  k_bits, v_bits, dim, dim, stream);
+                                  k_bits, v_bits, dim, dim, 0.0f, 1, stream);
+}
+
+// ... with the reference's optional level compander (cache/lmq.cuh; quant.py passes compand_a to every cache op) and explicit token strides
+extern "C" int exl3_quant_cache_paged_ex(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                                         const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                                         int page_size, int seq_len, int dim, int k_bits, int v_bits, int64_t ld_k, int64_t ld_v, float compand_a, int in_contiguous,
+                                         void* stream)
+{
+    return quant_cache_paged_impl(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, bsz, blocks_per_seq, page_size, seq_len, dim,
+                                  k_bits, v_bits, ld_k, ld_v, compand_a, in_contiguous, stream);
 }
 
 // k_in / v_in are column ranges of a wider row-major matrix: ld_k, ld_v = halves per token (the prefill route's fused q|k|v GEMM output)
@@ -373,13 +415,26 @@ extern "C" int exl3_quant_cache_paged_strided(const void* k_in, void* k_out, voi
                                               int page_size, int seq_len, int dim, int k_bits, int v_bits, int64_t ld_k, int64_t ld_v, void* stream)
 {
     return quant_cache_paged_impl(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, bsz, blocks_per_seq, page_size, seq_len, dim,
-                                  k_bits, v_bits, ld_k, ld_v, stream);
+                                  k_bits, v_bits, ld_k, ld_v, 0.0f, 1, stream);
 }
 
 extern "C" int exl3_dequant_cache_paged(const void* k_in, const void* k_scales, void* k_out, const void* v_in, const void* v_scales, void* v_out,
                                         const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
                                         int page_size, int dim, int k_bits, int v_bits, void* stream)
 {
+    return exl3_dequant_cache_paged_ex(k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens, block_table, bsz, blocks_per_seq, page_size, dim,
+                                       k_bits, v_bits, 0, 0.0f, 0, 0, stream);
+}
+
+// sliding_window > 0: rows the reference's dequant_cache_paged leaves untouched before the window stay untouched here (same rule, see the kernel);
+// compact_out + bonus_len: dequant_cache_paged_window (dense per-sequence scratch, rows up to cache_seqlens + bonus_len)
+extern "C" int exl3_dequant_cache_paged_ex(const void* k_in, const void* k_scales, void* k_out, const void* v_in, const void* v_scales, void* v_out,
+                                           const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                                           int page_size, int dim, int k_bits, int v_bits, int sliding_window, float compand_a, int compact_out,
+                                           int bonus_len, void* stream)
+{
+    EXL3_CHECK_ARG(compand_ok(compand_a), "dequant_cache_paged: compand_a must be 0 (off) or in (0, 1)");
+    EXL3_CHECK_ARG(bonus_len >= 0, "dequant_cache_paged: bonus_len must be >= 0");
     EXL3_CHECK_ARG(k_in && k_out && k_scales && v_in && v_out && v_scales && cache_seqlens && block_table, "dequant_cache_paged: null pointer");
     EXL3_CHECK_ARG(dim % 32 == 0 && page_size > 0, "dequant_cache_paged: dim must be divisible by 32");
     EXL3_CHECK_ARG(k_bits >= 2 && k_bits <= 8 && v_bits >= 2 && v_bits <= 8, "dequant_cache_paged: bits must be in [2, 8]");
@@ -387,7 +442,7 @@ extern "C" int exl3_dequant_cache_paged(const void* k_in, const void* k_scales, 
     const int gpt = dim / 32;
     dim3 grid((gpt + 15) / 16, blocks_per_seq * page_size, bsz);
     hipStream_t st = (hipStream_t) stream;
-    #define DP(KBv) case KBv: launch_dequant_paged<KBv>(v_bits, grid, st, k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens, block_table, blocks_per_seq, page_size, gpt); break;
+    #define DP(KBv) case KBv: launch_dequant_paged<KBv>(v_bits, grid, st, k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens, block_table, blocks_per_seq, page_size, gpt, sliding_window, compand_a, compact_out, bonus_len); break;
     switch (k_bits) { DP(2) DP(3) DP(4) DP(5) DP(6) DP(7) DP(8) }
     #undef DP
     return exl3_check_launch("dequant_cache_paged");

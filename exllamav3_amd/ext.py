@@ -469,37 +469,36 @@ def _kv_bits(packed: torch.Tensor, scales: torch.Tensor) -> int:
 
 
 def quant_cache_cont(inp, out, out_scales, compand_a: float = 0.0):
-    """cache/q_cache.cuh: contiguous quantization"""
+    """cache/q_cache.cuh: contiguous quantization (compand_a > 0: the cubic level compander of cache/lmq.cuh)"""
     _dev(inp)
-    _req(compand_a == 0.0, "quant_cache: compander is outside this build")
     _req(inp.dtype == torch.half and inp.is_contiguous() and inp.shape[-1] % 32 == 0, "quant_cache_cont: bad input")
     dim = inp.shape[-1]
     bits = _kv_bits(out, out_scales)
     _req(2 <= bits <= 8, "quant_cache_cont: bits must be in [2, 8]")
-    _check(_lib.lib().exl3_quant_cache_cont(_p(inp), _p(out), _p(out_scales), inp.numel() // dim, dim, bits, _stream(inp)))
+    _check(_lib.lib().exl3_quant_cache_cont_ex(_p(inp), _p(out), _p(out_scales), inp.numel() // dim, dim, bits, float(compand_a), _stream(inp)))
 
 
 def dequant_cache_cont(inp, in_scales, out, compand_a: float = 0.0):
     _dev(inp)
-    _req(compand_a == 0.0, "dequant_cache: compander is outside this build")
     dim = out.shape[-1]
     bits = _kv_bits(inp, in_scales)
     _req(out.dtype == torch.half and out.is_contiguous() and dim % 32 == 0 and 2 <= bits <= 8, "dequant_cache_cont: bad arguments")
-    _check(_lib.lib().exl3_dequant_cache_cont(_p(inp), _p(in_scales), _p(out), out.numel() // dim, dim, bits, _stream(inp)))
+    _check(_lib.lib().exl3_dequant_cache_cont_ex(_p(inp), _p(in_scales), _p(out), out.numel() // dim, dim, bits, float(compand_a), _stream(inp)))
 
 
 def quant_cache_paged(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, page_size: int, seq_len: int,
                       compand_a: float = 0.0, in_contiguous: bool = True):
+    """cache/q_cache.cuh:48-62.  in_contiguous=False: k_in / v_in are the flat fp16 cache (pages, page, dim), read at each new token's own row."""
     _dev(k_in)
-    _req(compand_a == 0.0, "quant_cache: compander is outside this build")
-    _req(in_contiguous, "quant_cache_paged: only in_contiguous inputs are supported by this build")
     _req(page_size == 256, "quant_cache_paged: page size must be 256")
     _req(cache_seqlens.dtype == torch.int32 and block_table.dtype == torch.int32, "cache_seqlens / block_table must be int32")
+    _req(k_in.is_contiguous() and v_in.is_contiguous() and k_in.dtype == torch.half and v_in.dtype == torch.half, "quant_cache_paged: k_in / v_in must be contiguous fp16")
     dim = k_out.shape[-1] // _kv_bits(k_out, k_scales) * 32
     bsz = block_table.shape[0]
-    _check(_lib.lib().exl3_quant_cache_paged(_p(k_in), _p(k_out), _p(k_scales), _p(v_in), _p(v_out), _p(v_scales),
-                                             _p(cache_seqlens), _p(block_table), bsz, block_table.shape[1], page_size, seq_len, dim,
-                                             _kv_bits(k_out, k_scales), _kv_bits(v_out, v_scales), _stream(k_in)))
+    _check(_lib.lib().exl3_quant_cache_paged_ex(_p(k_in), _p(k_out), _p(k_scales), _p(v_in), _p(v_out), _p(v_scales),
+                                                _p(cache_seqlens), _p(block_table), bsz, block_table.shape[1], page_size, seq_len, dim,
+                                                _kv_bits(k_out, k_scales), _kv_bits(v_out, v_scales), dim, dim, float(compand_a),
+                                                int(bool(in_contiguous)), _stream(k_in)))
 
 
 def quant_cache_paged_strided(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, page_size: int, seq_len: int):
@@ -534,14 +533,30 @@ def rope_strided(q, k, inv_freq, position: int, positions, position_ids, attn_fa
 
 def dequant_cache_paged(k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens, block_table, page_size: int,
                         sliding_window: int = 0, compand_a: float = 0.0):
+    """cache/q_cache.cuh:79-92: rows [0, cache_seqlens[b]) of every sequence; sliding_window > 0 leaves the rows the reference skips untouched."""
     _dev(k_in)
-    _req(compand_a == 0.0 and sliding_window == 0, "dequant_cache_paged: compander / sliding window are outside this build")
     _req(page_size == 256, "dequant_cache_paged: page size must be 256")
     dim = k_in.shape[-1] // _kv_bits(k_in, k_scales) * 32
     bsz = block_table.shape[0]
-    _check(_lib.lib().exl3_dequant_cache_paged(_p(k_in), _p(k_scales), _p(k_out), _p(v_in), _p(v_scales), _p(v_out),
-                                               _p(cache_seqlens), _p(block_table), bsz, block_table.shape[1], page_size, dim,
-                                               _kv_bits(k_in, k_scales), _kv_bits(v_in, v_scales), _stream(k_in)))
+    _check(_lib.lib().exl3_dequant_cache_paged_ex(_p(k_in), _p(k_scales), _p(k_out), _p(v_in), _p(v_scales), _p(v_out),
+                                                  _p(cache_seqlens), _p(block_table), bsz, block_table.shape[1], page_size, dim,
+                                                  _kv_bits(k_in, k_scales), _kv_bits(v_in, v_scales), int(sliding_window), float(compand_a), 0, 0,
+                                                  _stream(k_in)))
+
+
+def dequant_cache_paged_window(k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens, block_table, page_size: int,
+                               bonus_len: int, compand_a: float = 0.0):
+    """cache/q_cache.cuh:64-77: page p of sequence b is expanded densely into row (b * pages_per_seq + p) * page_size of the scratch k_out / v_out
+    (at least bsz * pages_per_seq pages), rows up to cache_seqlens[b] + bonus_len."""
+    _dev(k_in)
+    _req(page_size == 256, "dequant_cache_paged_window: page size must be 256")
+    dim = k_in.shape[-1] // _kv_bits(k_in, k_scales) * 32
+    bsz, pps = block_table.shape
+    _req(k_out.shape[0] >= bsz * pps and v_out.shape[0] >= bsz * pps, "scratch too small for block table span")
+    _check(_lib.lib().exl3_dequant_cache_paged_ex(_p(k_in), _p(k_scales), _p(k_out), _p(v_in), _p(v_scales), _p(v_out),
+                                                  _p(cache_seqlens), _p(block_table), bsz, pps, page_size, dim,
+                                                  _kv_bits(k_in, k_scales), _kv_bits(v_in, v_scales), 0, float(compand_a), 1, int(bonus_len),
+                                                  _stream(k_in)))
 
 
 def silu_mul(g, u, y):

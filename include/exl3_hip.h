@@ -313,6 +313,23 @@ int exl3_dequant_cache_paged(const void* k_in, const void* k_scales, void* k_out
                              const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
                              int page_size, int dim, int k_bits, int v_bits, void* stream);
 
+/* The cache ops with the reference's remaining arguments (cache/q_cache.cuh:6-92; cache/quant.py:83-117 passes them on every call):
+ * compand_a > 0 (in (0, 1)): cubic level compander of cache/lmq.cuh instead of the midpoint grid (0 = off);
+ * sliding_window > 0: dequant_cache_paged leaves the rows before the window untouched, by the reference's own rule (whole 256-chunk thread
+ * blocks that end at or before cache_seqlens[b] - sliding_window are skipped; a chunk = 4 groups of one token);
+ * compact_out, bonus_len: dequant_cache_paged_window -- page p of sequence b goes to row (b * blocks_per_seq + p) * page_size of the scratch
+ * and rows up to cache_seqlens[b] + bonus_len are expanded (sliding_window is ignored by the reference there: pass 0). */
+int exl3_quant_cache_cont_ex(const void* in, void* out, void* out_scales, int64_t tokens, int dim, int bits, float compand_a, void* stream);
+int exl3_dequant_cache_cont_ex(const void* in, const void* in_scales, void* out, int64_t tokens, int dim, int bits, float compand_a, void* stream);
+int exl3_quant_cache_paged_ex(const void* k_in, void* k_out, void* k_scales, const void* v_in, void* v_out, void* v_scales,
+                              const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                              int page_size, int seq_len, int dim, int k_bits, int v_bits, int64_t ld_k, int64_t ld_v, float compand_a,
+                              int in_contiguous /* 0: k_in / v_in are a flat fp16 cache read at each token's own physical row */, void* stream);
+int exl3_dequant_cache_paged_ex(const void* k_in, const void* k_scales, void* k_out, const void* v_in, const void* v_scales, void* v_out,
+                                const int32_t* cache_seqlens, const int32_t* block_table, int bsz, int blocks_per_seq,
+                                int page_size, int dim, int k_bits, int v_bits, int sliding_window, float compand_a, int compact_out,
+                                int bonus_len, void* stream);
+
 /* ---- elementwise glue used by the decode step (activation.cu silu_mul, add.cu) -------------------- */
 /* y = silu(g) * u ; g, u fp16 or fp32 (in_fp32) [rows][dim]; y fp16 */
 int exl3_silu_mul(const void* g, const void* u, void* y, int64_t numel, int in_fp32, void* stream);

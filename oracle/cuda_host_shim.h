@@ -201,12 +201,13 @@ template <typename T> static inline T shfl(T v, int src)
     bar();
     return r;
 }
-// run f() once per lane of one 32-thread block (threadIdx.x = 0..31); blockIdx / blockDim / gridDim as set by the caller
-static inline void run_warp(const std::function<void()>& f)
+// run f() once per lane of warp `warp` of the current block (threadIdx.x = 32 * warp + 0..31); blockIdx / blockDim / gridDim as set by the
+// caller.  Kernels without cross-warp communication can be run one warp at a time this way under their real blockDim.
+static inline void run_warp(const std::function<void()>& f, int warp = 0)
 {
     pthread_barrier_init(&g_bar, nullptr, 32);
     std::vector<std::thread> th;
-    for (int l = 0; l < 32; ++l) th.emplace_back([l, &f] { threadIdx.x = (unsigned) l; threadIdx.y = threadIdx.z = 0; f(); });
+    for (int l = 0; l < 32; ++l) th.emplace_back([l, warp, &f] { threadIdx.x = (unsigned) (32 * warp + l); threadIdx.y = threadIdx.z = 0; f(); });
     for (auto& t : th) t.join();
     pthread_barrier_destroy(&g_bar);
 }

@@ -388,7 +388,42 @@ def kv_planes(bits: int):
 KV_RSQRT32 = np.float32(0.17677669529663689)
 
 
-def kv_quant(x: np.ndarray, bits: int):
+def _f32(x):
+    return np.asarray(x, dtype=np.float32)
+
+
+def _fma32(a, b, c):
+    """fp32 fma of fp32 operands through float64 (a * b is exact there; the one extra rounding of the sum can differ from a true fma only when
+    the float64 sum lands within 2^-29 ulp of an fp32 tie)."""
+    return (_f32(a).astype(np.float64) * _f32(b).astype(np.float64) + _f32(c).astype(np.float64)).astype(np.float32)
+
+
+class KvCompander:
+    """Cubic compander of the KV level grid (reference: cache/lmq.cuh:56-85 LMCubic), fp32 in the reference's op order.
+    decode: t = fma(2 q + 1, 2^-b, -1); level = t * fma(t^2, 1 - a, a).
+    encode: q_half = x * inv_b * 0.5; delta = fma(q_half, q_half, p3^3); s = sqrt(delta); t = cbrt(q_half + s) + cbrt(q_half - s);
+            q = clamp(floor(fma(t, 2^(b-1), 2^(b-1))), 0, 2^b - 1).   (np.cbrt / np.sqrt on float32 = libm cbrtf / sqrtf, as in oracle/_ref)"""
+    def __init__(self, a: float):
+        self.a = np.float32(a)
+        self.b = np.float32(1.0) - self.a
+        self.inv_b = np.float32(1.0) / self.b
+        p3 = self.a * self.inv_b * (np.float32(1.0) / np.float32(3.0))
+        self.p3_cub = np.float32(np.float32(p3 * p3) * p3)
+
+    def decode(self, q: np.ndarray, bits: int) -> np.ndarray:
+        t = _fma32(np.float32(2.0) * q.astype(np.float32) + np.float32(1.0), np.float32(1.0 / (1 << bits)), np.float32(-1.0))
+        return (t * _fma32((t * t).astype(np.float32), self.b, self.a)).astype(np.float32)
+
+    def encode(self, x: np.ndarray, bits: int) -> np.ndarray:
+        q_half = ((_f32(x) * self.inv_b).astype(np.float32) * np.float32(0.5)).astype(np.float32)
+        delta = _fma32(q_half, q_half, self.p3_cub)
+        sq = np.sqrt(delta).astype(np.float32)
+        t = (np.cbrt((q_half + sq).astype(np.float32)).astype(np.float32) + np.cbrt((q_half - sq).astype(np.float32)).astype(np.float32)).astype(np.float32)
+        half = np.float32(1 << (bits - 1))
+        return np.clip(np.floor(_fma32(t, half, half)), 0, (1 << bits) - 1).astype(np.uint32)
+
+
+def kv_quant(x: np.ndarray, bits: int, compand_a: float = 0.0):
     """x (..., D) fp16, D % 32 == 0 -> (packed uint32 (..., D/32*bits), scales fp16 (..., D/32)).
     Per 32-group, in fp32 and in the reference's op order (q_cache_kernels.cuh:61-156):
       v = H32(x) * (1/sqrt(32));  s = max|v| + 1e-10;  inv_s = 1/s;
@@ -406,6 +441,8 @@ def kv_quant(x: np.ndarray, bits: int):
     # fma(t, half, half): half is a power of two, so t*half is exact and the fma equals one rounded add
     qf = np.floor((t.astype(np.float64) * np.float64(half) + np.float64(half)).astype(np.float32))
     q = np.clip(qf, 0, (1 << bits) - 1).astype(np.uint32)         # (G, 32)
+    if compand_a > 0.0:
+        q = KvCompander(compand_a).encode(t, bits)                 # compand_a > 0: lmq.cuh encoder instead of the midpoint grid (:111-119)
     words = []
     rem = bits
     e = np.arange(32)
@@ -424,7 +461,7 @@ def kv_quant(x: np.ndarray, bits: int):
     return packed.reshape(shp[:-1] + (D // 32 * bits,)), s.astype(np.float16).reshape(shp[:-1] + (D // 32,))
 
 
-def kv_dequant(packed: np.ndarray, scales: np.ndarray, bits: int) -> np.ndarray:
+def kv_dequant(packed: np.ndarray, scales: np.ndarray, bits: int, compand_a: float = 0.0) -> np.ndarray:
     """Inverse of kv_quant (q_cache_kernels.cuh:160-236): s' = fp32(scale) * (1/sqrt(32)); sm = s' * 2^-(b-1);
     v = (q - (2^(b-1) - 0.5)) * sm; x = H32(v) -> fp16."""
     shp = scales.shape
@@ -442,12 +479,14 @@ def kv_dequant(packed: np.ndarray, scales: np.ndarray, bits: int) -> np.ndarray:
     half = np.float32(1 << (bits - 1))
     sm = (s * (np.float32(1.0) / half)).astype(np.float32)
     v = ((q.astype(np.float32) - (half - np.float32(0.5))) * sm).astype(np.float32)
+    if compand_a > 0.0:
+        v = (KvCompander(compand_a).decode(q, bits) * s).astype(np.float32)      # q_cache_kernels.cuh:205-212: level * (scale / sqrt(32))
     x = _fwht32_f32(v)
     return x.astype(np.float16).reshape(shp[:-1] + (shp[-1] * 32,))
 
 
 def kv_quant_paged(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, block_table, k_bits: int, v_bits: int,
-                   page_size: int = 256, in_contiguous: bool = True, seq_len: int | None = None):
+                   page_size: int = 256, in_contiguous: bool = True, seq_len: int | None = None, compand_a: float = 0.0):
     """quant_cache_paged_kernel's addressing (cache/q_cache_kernels.cuh:289-325): new token j of sequence b lands at logical position
     cache_seqlens[b] + j, i.e. physical row block_table[b][pos // page] * page + pos % page of the flat (pages * page) cache.
     k_in / v_in: (bsz, seq_len, D) fp16 when in_contiguous, else the flat (pages * page, D) staging cache read at the same physical row.
@@ -464,25 +503,39 @@ def kv_quant_paged(k_in, k_out, k_scales, v_in, v_out, v_scales, cache_seqlens, 
             row = int(block_table[b, pos // page_size]) * page_size + pos % page_size
             kx = kf[b, j] if in_contiguous else kf[row]
             vx = vf[b, j] if in_contiguous else vf[row]
-            pk, sc = kv_quant(kx[None, :], k_bits); ko[row] = pk[0]; ks[row] = sc[0]
-            pk, sc = kv_quant(vx[None, :], v_bits); vo[row] = pk[0]; vs[row] = sc[0]
+            pk, sc = kv_quant(kx[None, :], k_bits, compand_a); ko[row] = pk[0]; ks[row] = sc[0]
+            pk, sc = kv_quant(vx[None, :], v_bits, compand_a); vo[row] = pk[0]; vs[row] = sc[0]
 
 
 def kv_dequant_paged(k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens, block_table, k_bits: int, v_bits: int,
-                     page_size: int = 256, bonus_len: int = 0):
-    """dequant_cache_paged_kernel's addressing without a sliding window (cache/q_cache_kernels.cuh:342-399): logical positions
-    [0, cache_seqlens[b] + bonus_len) of every sequence are dequantized into the same physical rows of k_out / v_out (fp16 (pages, page, D));
-    other rows are left untouched.  (With sliding_window > 0 the reference additionally SKIPS whole thread blocks that end before
-    max_len - window: which rows that covers depends on its launch geometry; rows inside the window are always written.)"""
+                     page_size: int = 256, bonus_len: int = 0, sliding_window: int = 0, compand_a: float = 0.0, compact_out: bool = False):
+    """dequant_cache_paged_kernel (cache/q_cache_kernels.cuh:342-399) as launched by cache/q_cache.cu:271-346 (dequant_cache_paged:
+    compact_out False, bonus_len 0) and :358-433 (dequant_cache_paged_window: sliding_window <= 0, compact_out True).
+    Logical positions [0, cache_seqlens[b] + bonus_len) of every sequence are dequantized; the other rows stay untouched.  With
+    sliding_window > 0 the kernel also skips whole thread blocks that end at or before max_len - window.  A block is 8 warps x 32 iterations =
+    256 consecutive "chunks" of the sequence (a chunk = 4 groups of one token, cpt = ceil(groups_per_token / 4) chunks per token), so chunk c
+    of token t is skipped iff floor(256 * (floor((t * cpt + c) / 256) + 1) / cpt) <= max_len - window -- groups of one row can be split
+    when cpt does not divide 256.  compact_out: page p of sequence b is written at rows (b * pages_per_seq + p) * page_size + ... of the
+    output instead of the physical page."""
     D = k_out.shape[-1]
-    ki, ks = k_in.reshape(-1, D // 32 * k_bits), k_scales.reshape(-1, D // 32)
-    vi, vs = v_in.reshape(-1, D // 32 * v_bits), v_scales.reshape(-1, D // 32)
+    gpt = D // 32
+    cpt = (gpt + 3) // 4
+    pps = block_table.shape[1]
+    ki, ks = k_in.reshape(-1, gpt * k_bits), k_scales.reshape(-1, gpt)
+    vi, vs = v_in.reshape(-1, gpt * v_bits), v_scales.reshape(-1, gpt)
     ko, vo = k_out.reshape(-1, D), v_out.reshape(-1, D)
     for b in range(block_table.shape[0]):
-        for pos in range(int(cache_seqlens[b]) + bonus_len):
+        max_len = int(cache_seqlens[b]) + bonus_len
+        for pos in range(max_len):
             row = int(block_table[b, pos // page_size]) * page_size + pos % page_size
-            ko[row] = kv_dequant(ki[row][None, :], ks[row][None, :], k_bits)[0]
-            vo[row] = kv_dequant(vi[row][None, :], vs[row][None, :], v_bits)[0]
+            orow = (b * pps + pos // page_size) * page_size + pos % page_size if compact_out else row
+            kd = kv_dequant(ki[row][None, :], ks[row][None, :], k_bits, compand_a)[0]
+            vd = kv_dequant(vi[row][None, :], vs[row][None, :], v_bits, compand_a)[0]
+            for c in range(cpt):
+                if sliding_window > 0 and (256 * ((pos * cpt + c) // 256 + 1)) // cpt <= max_len - sliding_window:
+                    continue
+                sl = slice(c * 128, min((c + 1) * 128, D))
+                ko[orow, sl] = kd[sl]; vo[orow, sl] = vd[sl]
 
 
 def softcap(x: np.ndarray, scale: float) -> np.ndarray:

@@ -143,16 +143,23 @@ int ref_cuda_dequant_cache_paged(int bits, const uint32_t* k_in, const uint16_t*
                                  uint16_t* v_out, const uint32_t* cache_seqlens, const uint32_t* block_table, int pages_per_seq, int groups_per_token,
                                  int bsz, int max_tokens, int sliding_window, float compand_a, int compact_out, int bonus_len)
 {
+    // launch geometry of cache/q_cache.cu:309-320 (the sliding-window skip works on whole thread blocks, so the geometry is part of the result):
+    // blockDim = min(32 * chunks_per_seq, 32 * MAX_WARPS), grid.x = ceil(ceil(chunks_per_seq / MAX_WARPS) / ITER_PER_TB); the warps of a
+    // block do not communicate, so they are run one after the other.  max_tokens = pages_per_seq * page_size of the real call (or fewer to
+    // save time: blocks past the longest sequence do nothing).
     if (bits < 2 || bits > 8) return -1;
     auto kern = dequant_cache_paged_kernel_instances[bits - 2][bits - 2];
     const int chunks_per_token = (groups_per_token + 3) / 4;
-    blockDim.x = 32; gridDim.y = (unsigned) bsz; gridDim.z = 1;
-    gridDim.x = (unsigned) ((max_tokens * chunks_per_token + ITER_PER_TB - 1) / ITER_PER_TB);
-    for (unsigned y = 0; y < gridDim.y; ++y) for (unsigned x = 0; x < gridDim.x; ++x)
+    const long chunks_per_seq = (long) pages_per_seq * CQ_PAGE_SIZE * chunks_per_token;
+    const int warps = (int) (chunks_per_seq < MAX_WARPS ? chunks_per_seq : MAX_WARPS);
+    blockDim.x = 32 * warps; gridDim.y = (unsigned) bsz; gridDim.z = 1;
+    const long used_chunks = (long) max_tokens * chunks_per_token;
+    gridDim.x = (unsigned) (((used_chunks + warps - 1) / warps + ITER_PER_TB - 1) / ITER_PER_TB);
+    for (unsigned y = 0; y < gridDim.y; ++y) for (unsigned x = 0; x < gridDim.x; ++x) for (int w = 0; w < warps; ++w)
     {
         blockIdx.x = x; blockIdx.y = y; blockIdx.z = 0;
         shim::run_warp([&] { kern(k_in, (const half*) k_scales, (half*) k_out, v_in, (const half*) v_scales, (half*) v_out, cache_seqlens, block_table,
-                                  pages_per_seq, groups_per_token, chunks_per_token, sliding_window, compand_a, compact_out, bonus_len); });
+                                  pages_per_seq, groups_per_token, chunks_per_token, sliding_window, compand_a, compact_out, bonus_len); }, w);
     }
     return 0;
 }

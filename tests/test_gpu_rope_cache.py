@@ -72,6 +72,75 @@ def test_kv_quant_cont_bit_exact(dev, bits):
         assert np.allclose(y8.float().cpu().numpy(), xu.astype(np.float32), atol=0.08, rtol=0.01)
 
 
+@pytest.mark.parametrize("bits", [2, 3, 4, 5, 8])
+@pytest.mark.parametrize("a", [0.65, 0.3])
+def test_kv_compander_against_oracle(dev, bits, a):
+    """compand_a > 0 (cache/lmq.cuh through quant / dequant_cache_cont): the decoder is pure fp32 arithmetic -> dequantized values bit-exact
+    vs the (reference-pinned) oracle; the encoder goes through cbrtf, whose device implementation may differ from libm's in the last ulp ->
+    scales bit-exact, level indices identical except for at most a handful that land in the neighbouring cell."""
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(40 + bits)
+    x = (rng.standard_normal((41, 1024)) * rng.uniform(0.1, 4.0, size=(41, 1))).astype(np.float16)
+    x[3, :64] = 0
+    pk_ref, sc_ref = o.kv_quant(x, bits, a)
+    out = torch.zeros((41, 1024 // 32 * bits), dtype=torch.int32, device=dev)
+    sc = torch.zeros((41, 32), dtype=torch.half, device=dev)
+    ext.quant_cache_cont(_t(x, dev), out, sc, a)
+    assert np.array_equal(sc.cpu().numpy().view(np.uint16), sc_ref.view(np.uint16))
+    # decoder: the oracle's words through the HIP dequantizer
+    y = torch.empty((41, 1024), dtype=torch.half, device=dev)
+    ext.dequant_cache_cont(_t(pk_ref.view(np.int32), dev), _t(sc_ref, dev), y, a)
+    y_ref = o.kv_dequant(pk_ref, sc_ref, bits, a)
+    assert np.array_equal(y.cpu().numpy().view(np.uint16), y_ref.view(np.uint16))
+    # encoder: levels of the HIP words vs the oracle's, compared through the (exact) decoder in the rotated domain
+    lv = lambda words: o.kv_dequant(words, np.ones_like(sc_ref), bits, a).astype(np.float32)     # unit scales: H32 of the levels
+    mine = out.cpu().numpy().view(np.uint32)
+    diff = (lv(mine) != lv(pk_ref)).reshape(-1, 32).any(-1)                # groups with any differing level
+    assert diff.mean() < 2e-3, diff.mean()
+    y2 = torch.empty_like(y)
+    ext.dequant_cache_cont(out, sc, y2, a)                                  # and whatever differs is one cell off at most
+    step = 2.0 / (1 << bits) * 1.5                                          # widest cell of the companded grid is < 1.5 midpoint cells
+    assert np.abs(y2.float().cpu().numpy() - y_ref.astype(np.float32)).max() <= step * np.abs(x.astype(np.float32)).max() * 2
+
+
+def test_kv_paged_sliding_window_window_scratch_and_cache_resident_input(dev):
+    """The remaining arguments of the paged cache ops against the oracle (which is pinned against the reference kernels' own index arithmetic):
+    sliding_window > 0 leaves exactly the rows the reference skips untouched; dequant_cache_paged_window writes the dense per-sequence scratch
+    up to cache_seqlens + bonus_len; quant_cache_paged with in_contiguous=False reads the new tokens from the flat fp16 cache rows."""
+    from exllamav3_amd import ext
+    page, D, bsz, pps, bits = 256, 160, 2, 2, 4
+    G = D // 32
+    rng = np.random.default_rng(5)
+    npages = bsz * pps + 1
+    bt_np = rng.permutation(npages)[: bsz * pps].reshape(bsz, pps).astype(np.int32)
+    seqlens = np.array([300, 131], np.int32)
+    kq = rng.integers(0, 2 ** 32, size=(npages, page, G * bits), dtype=np.uint64).astype(np.uint32); vq = kq[::-1].copy()
+    ks = rng.uniform(0.1, 4.0, size=(npages, page, G)).astype(np.float16); vs = ks[::-1].copy()
+    T = lambda a: _t(a.view(np.int32) if a.dtype == np.uint32 else a, dev)
+    for sw in (70, 33, 299):
+        ko = torch.full((npages, page, D), float("nan"), dtype=torch.half, device=dev); vo = ko.clone()
+        ext.dequant_cache_paged(T(kq), T(ks), ko, T(vq), T(vs), vo, T(seqlens), T(bt_np), page, sliding_window=sw)
+        ko2 = np.full((npages, page, D), np.nan, np.float16); vo2 = ko2.copy()
+        o.kv_dequant_paged(kq, ks, ko2, vq, vs, vo2, seqlens, bt_np, bits, bits, page, sliding_window=sw)
+        assert np.array_equal(ko.cpu().numpy().view(np.uint16), ko2.view(np.uint16)) and np.array_equal(vo.cpu().numpy().view(np.uint16), vo2.view(np.uint16))
+    ko = torch.full((bsz * pps, page, D), float("nan"), dtype=torch.half, device=dev); vo = ko.clone()
+    ext.dequant_cache_paged_window(T(kq), T(ks), ko, T(vq), T(vs), vo, T(seqlens), T(bt_np), page, 7)
+    ko2 = np.full((bsz * pps, page, D), np.nan, np.float16); vo2 = ko2.copy()
+    o.kv_dequant_paged(kq, ks, ko2, vq, vs, vo2, seqlens, bt_np, bits, bits, page, bonus_len=7, compact_out=True)
+    assert np.array_equal(ko.cpu().numpy().view(np.uint16), ko2.view(np.uint16)) and np.array_equal(vo.cpu().numpy().view(np.uint16), vo2.view(np.uint16))
+    # in_contiguous = False: the new tokens already sit in the fp16 cache at their own rows
+    kf = rng.standard_normal((npages, page, D)).astype(np.float16); vf = rng.standard_normal((npages, page, D)).astype(np.float16)
+    n_new = 6
+    mk = lambda: (np.zeros((npages, page, G * bits), np.uint32), np.zeros((npages, page, G), np.float16))
+    (rk, rks), (rv, rvs) = mk(), mk()
+    o.kv_quant_paged(kf, rk, rks, vf, rv, rvs, seqlens, bt_np, bits, bits, page, in_contiguous=False, seq_len=n_new)
+    dk, dks, dv, dvs = (torch.zeros(a.shape, dtype=torch.int32 if a.dtype == np.uint32 else torch.half, device=dev) for a in (rk, rks, rv, rvs))
+    ext.quant_cache_paged(T(kf), dk, dks, T(vf), dv, dvs, T(seqlens), T(bt_np), page, n_new, in_contiguous=False)
+    assert np.array_equal(dk.cpu().numpy().view(np.uint32), rk) and np.array_equal(dv.cpu().numpy().view(np.uint32), rv)
+    assert np.array_equal(dks.cpu().numpy().view(np.uint16), rks.view(np.uint16)) and np.array_equal(dvs.cpu().numpy().view(np.uint16), rvs.view(np.uint16))
+    assert rk.any()
+
+
 @pytest.mark.parametrize("kb,vb", [(8, 8), (4, 4), (6, 5), (2, 3)])
 def test_kv_quant_paged_roundtrip(dev, kb, vb):
     """tests/test_kv_quant.py:21-143: paged quant -> dequant with a permuted page table and a 5-token append."""
