@@ -27,31 +27,52 @@ void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restr
     const int nch = E >> 3;
     if ((E & 7) == 0 && nch <= 64 && (256 % nch) == 0)
     {
-        __shared__ float part_s[256][8];
+        __shared__ float part_s[4][64][8];                                   // [wave][expert chunk][expert in chunk]
         const int ch = tid % nch, rows_per_pass = 256 / nch;
         float acc[8] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-        for (int h = tid / nch; h < H; h += rows_per_pass)
+        // 8 gate rows per thread in flight at a time (one workgroup reads the whole gate matrix: 64 KB at E = 8; with one load per loop trip
+        // the kernel was a chain of 16 memory round trips, 17.8 us)
+        int h = tid / nch;
+        for (; h + 7 * rows_per_pass < H; h += 8 * rows_per_pass)
+        {
+            half8_t g[8]; half_t xs[8];
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) { g[u] = *((const half8_t*) (gate + (size_t) (h + u * rows_per_pass) * E + ch * 8)); xs[u] = x[h + u * rows_per_pass]; }
+            #pragma unroll
+            for (int u = 0; u < 8; ++u)
+            {
+                const float xv = (float) xs[u];
+                #pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(xv, (float) g[u][i], acc[i]);
+            }
+        }
+        for (; h < H; h += rows_per_pass)
         {
             const half8_t g = *((const half8_t*) (gate + (size_t) h * E + ch * 8));
             const float xv = (float) x[h];
             #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(xv, (float) g[i], acc[i]);
         }
+        // fixed-order reduction: butterflies over the lanes of a wave that own the same chunk (lane % nch), then the four waves in sequence
         #pragma unroll
-        for (int i = 0; i < 8; ++i) part_s[tid][i] = acc[i];
+        for (int d = 1; d < 64; d <<= 1)
+        {
+            if (d >= nch)                                                    // uniform
+            {
+                #pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += xor_lane(acc[i], d);
+            }
+        }
+        if (lane < nch)
+        {
+            #pragma unroll
+            for (int i = 0; i < 8; ++i) part_s[wave][lane][i] = acc[i];
+        }
         __syncthreads();
         for (int e = tid; e < E; e += 256)
         {
             const int c = e >> 3, i = e & 7;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;                    // four interleaved chains, fixed order
-            for (int t = c; t < 256; t += 4 * nch)
-            {
-                a0 += part_s[t][i];
-                if (t + nch < 256) a1 += part_s[t + nch][i];
-                if (t + 2 * nch < 256) a2 += part_s[t + 2 * nch][i];
-                if (t + 3 * nch < 256) a3 += part_s[t + 3 * nch][i];
-            }
-            const half_t sc = f2h((a0 + a1) + (a2 + a3));                    // the reference materialises fp16 scores and routes on them
+            const half_t sc = f2h(((part_s[0][c][i] + part_s[1][c][i]) + part_s[2][c][i]) + part_s[3][c][i]);    // the reference materialises fp16 scores and routes on them
             scores[(size_t) row * E + e] = sc;
             logit_s[e] = (float) sc + (bias ? (float) bias[e] : 0.0f);
         }

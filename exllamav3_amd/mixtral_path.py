@@ -32,6 +32,12 @@ class MixtralShape:
     top_k: int
     rope_theta: float = 1000000.0
 
+    def linear_shapes(self):
+        """(k, n) of the quantized linears of one layer (one expert's gate / up / down) + lm_head, keyed like LlamaShape.linear_shapes."""
+        h, i, hd = self.hidden, self.inter, self.head_dim
+        return {"q": (h, self.heads_q * hd), "k": (h, self.heads_kv * hd), "v": (h, self.heads_kv * hd), "o": (self.heads_q * hd, h),
+                "gate": (h, i), "up": (h, i), "down": (i, h), "lm_head": (h, self.vocab)}
+
     def decode_bytes_per_token(self, K: int) -> int:
         """Algorithmic bytes of the quantized linears one token touches at bs = 1: attention linears + top_k experts x (gate, up, down) per layer
         (k * n * K / 8 + 2 (k + n) each) + the fp16 router + lm_head."""
