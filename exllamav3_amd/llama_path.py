@@ -615,8 +615,8 @@ class SyntheticEXL3Llama:
 
     def decode_step_tail(self):
         """Decode step with in-kernel tail epilogues: 4 launches per layer (qkv+rope+KV-append, o+add+norm, gate/up+act, down+add+norm).
-        Tensor-parallel ranks need the all-reduce between o/down and the norm, so TP > 1 uses decode_step_fused."""
-        if self.tp != 1:
+        Tensor-parallel ranks need the all-reduce between o/down and the norm, so TP > 1 (and head_dim 64) uses decode_step_fused."""
+        if self.tp != 1 or self.shape.head_dim != 128:             # the q|k|v tail epilogue handles one head per Hadamard block only
             return self.decode_step_fused()
         bsz, hd = self._state_bsz, self.shape.head_dim
         x = self.x
