@@ -68,30 +68,32 @@ class TPBackendRCCL:
         stays off (returns False, RCCL keeps doing the decode all-reduces) if a peer cannot be mapped or the sums differ."""
         if self.world_size == 1 or self.device is None or self.device.type != "cuda":
             return False
-        try:
-            ipc = IpcAllReduce(self.rank, self.world_size, self.device, max_elems)
+        # every rank issues the SAME sequence of collectives whatever fails locally (a rank that skipped one would pair its next collective
+        # with a different one of its peers): local steps are wrapped, agreement steps are unconditional
+        def agree(ok: bool) -> bool:
+            flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return float(flag.item()) == 1.0
+
+        ipc = IpcAllReduce.create(self.rank, self.world_size, self.device, max_elems, agree)
+        if ipc is None:
+            return False
+        if self_test:
+            g = torch.Generator(device=self.device); g.manual_seed(1234 + self.rank)
+            y = torch.randn((1, 256), device=self.device, generator=g)
+            ref = y.clone(); dist.all_reduce(ref)
             ok = True
-            if self_test:
-                g = torch.Generator(device=self.device); g.manual_seed(1234 + self.rank)
-                y = torch.randn((1, 256), device=self.device, generator=g)
-                ref = y.clone(); dist.all_reduce(ref)
+            try:
                 out = torch.empty_like(y)
                 ipc.reduce(y, y_out=out)
                 ok = ipc.error() == 0 and bool(torch.allclose(out, ref, rtol=1e-5, atol=1e-5))
-            flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)                   # every rank takes the same decision
-            if float(flag.item()) != 1.0:
+            except Exception:
+                ok = False
+            if not agree(ok):
                 ipc.close()
                 return False
-            self.ipc = ipc
-            return True
-        except Exception:
-            flag = torch.tensor([0.0], device=self.device)
-            try:
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            except Exception:
-                pass
-            return False
+        self.ipc = ipc
+        return True
 
     def all_reduce_resid(self, y: torch.Tensor, resid: torch.Tensor, ss_part: torch.Tensor, m: int):
         """resid (fp16) += sum over ranks of y (fp32 [m][hidden]); ss_part = per-block sums of squares of the new residual: the o_proj / down_proj
@@ -159,17 +161,37 @@ class IpcAllReduce:
         from . import _lib
         self._lib = _lib.lib()
         self.rank, self.world, self.device, self.max_elems = rank, world, device, int(max_elems)
-        torch.cuda.set_device(device)
-        ctx = ctypes.c_void_p()
+        self.ctx = None
+
+    @classmethod
+    def create(cls, rank: int, world: int, device: torch.device, max_elems: int, agree):
+        """Collective constructor: allocate, exchange the IPC handles, map the peers.  `agree(ok) -> bool` is an all-ranks AND (a collective);
+        the sequence of collectives is the same on every rank whatever fails locally.  Returns None on every rank if any rank failed."""
+        from . import _lib
+        self = cls(rank, world, device, max_elems)
         handle = ctypes.create_string_buffer(64)
-        _lib.check(self._lib.exl3_ar_create(world, rank, self.max_elems, ctypes.byref(ctx), handle))
-        self.ctx = ctx
+        ok = True
+        try:
+            torch.cuda.set_device(device)
+            ctx = ctypes.c_void_p()
+            _lib.check(self._lib.exl3_ar_create(world, rank, self.max_elems, ctypes.byref(ctx), handle))
+            self.ctx = ctx
+        except Exception:
+            ok = False
         handles = [None] * world
-        dist.all_gather_object(handles, bytes(handle.raw))
-        for r in range(world):
-            if r != rank:
-                _lib.check(self._lib.exl3_ar_open_peer(self.ctx, r, ctypes.create_string_buffer(handles[r], 64)))
-        dist.barrier()
+        dist.all_gather_object(handles, (ok, bytes(handle.raw)))
+        ok = ok and all(h[0] for h in handles)
+        if ok:
+            try:
+                for r in range(world):
+                    if r != rank:
+                        _lib.check(self._lib.exl3_ar_open_peer(self.ctx, r, ctypes.create_string_buffer(handles[r][1], 64)))
+            except Exception:
+                ok = False
+        if not agree(ok):                                                   # also the barrier: nobody pushes before every mapping exists
+            self.close()
+            return None
+        return self
 
     def reduce(self, y: torch.Tensor, y_out: torch.Tensor | None = None, resid: torch.Tensor | None = None, ss_part: torch.Tensor | None = None,
                m: int | None = None):
@@ -186,6 +208,9 @@ class IpcAllReduce:
 
     def close(self):
         if self.ctx is not None:
-            torch.cuda.synchronize(self.device)
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:
+                pass
             self._lib.exl3_ar_destroy(self.ctx)
             self.ctx = None
