@@ -394,6 +394,99 @@ class BC_LinearFP16:
             add(y2, self.bias.view(1, -1).expand(x2.shape[0], -1).contiguous() if x2.shape[0] > 1 else self.bias)
 
 
+class BC_Attention:
+    """libtorch/attention.h:24-228, attention.cpp:246-504: the decode attention block of one layer as one runner -- q / k / v projections,
+    head norms + RoPE, append to the quantized paged cache, flash-decoding attention straight from the quantized cache, o_proj.
+    Same constructor arguments and run() signature as the reference's class.  This build covers the Llama / Mixtral subset of it:
+    quantized cache (`quant_cache`), one new token per sequence (q_len == 1, bsz <= 8), no output gate, no V norm, no K-as-V, no sinks, no
+    padded hidden dim, no llama-4 position scaling; anything else raises at construction (or at run for q_len > 1), it never degrades silently.
+    The reference's slot machinery exists to hold AOT-compiled Triton kernels and their statics: needs_configure() is always False here and
+    configure_slot() accepts and ignores its arguments; capture the whole decode step in one hipGraph instead (all launches of run() are
+    capturable, the per-call tensors are read by pointer)."""
+
+    MAX_BSZ = 8
+    MAX_QLEN = 16
+
+    def __init__(self, num_q_heads, num_kv_heads, head_dim, hidden_size, hidden_size_padded, page_size, q_proj, k_proj, v_proj,
+                 kv_ptrs_trellis=None, kv_ptrs_suh=None, kv_ptrs_svh=None, kv_K=0, kv_mcg=False, kv_mul1=False, o_proj=None,
+                 use_k_as_v=False, gate_mode=0, gate_softplus=False, g_proj=None, g_weight=None, qg_ptrs_trellis=None, qg_ptrs_suh=None,
+                 qg_ptrs_svh=None, qg_K=0, qg_mcg=False, qg_mul1=False, q_norm=None, k_norm=None, norm_eps=1e-6, norm_constant_bias=0.0,
+                 v_norm=False, v_norm_w=None, v_norm_eps=1e-6, v_norm_constant_bias=0.0, v_norm_constant_scale=1.0, inv_freq=None,
+                 rope_style=2, attn_factor=1.0, l4_scaling_beta=0.0, l4_scaling_original=0, post_rope_norm=False, rotate_dims=1,
+                 quant_cache=True, cache_k=None, cache_v=None, cache_k_scales=None, cache_v_scales=None, xh=None, h32=None, sinks=None):
+        _req(quant_cache and cache_k_scales is not None and cache_v_scales is not None, "BC_Attention: this build attends over the quantized paged cache only")
+        _req(gate_mode == 0 and g_proj is None and g_weight is None and qg_ptrs_trellis is None, "BC_Attention: output gates are outside this build")
+        _req(not use_k_as_v and not v_norm and sinks is None, "BC_Attention: K-as-V / V norm / attention sinks are outside this build")
+        _req(hidden_size_padded == hidden_size, "BC_Attention: padded hidden dim is outside this build")
+        _req(l4_scaling_beta == 0.0 and not post_rope_norm and rotate_dims == 1, "BC_Attention: llama-4 scaling / post-rope norm / multi-dim rotation are outside this build")
+        _req(head_dim in (64, 128) and num_q_heads % num_kv_heads == 0, "BC_Attention: head_dim must be 64 or 128")
+        _req(page_size == 256, "BC_Attention: page size must be 256")
+        _req(q_proj is not None and o_proj is not None and ((k_proj is not None and v_proj is not None) or kv_ptrs_trellis is not None),
+             "BC_Attention: no k/v projection path")
+        _req(inv_freq is not None or (q_norm is None and k_norm is None), "BC_Attention: head norms ride on the rope kernel (NoPE modules cannot have them)")
+        self.num_q_heads, self.num_kv_heads, self.head_dim, self.hidden_size, self.page_size = num_q_heads, num_kv_heads, head_dim, hidden_size, page_size
+        self.q_proj, self.k_proj, self.v_proj, self.o_proj = q_proj, k_proj, v_proj, o_proj
+        self.kv_ptrs = (kv_ptrs_trellis, kv_ptrs_suh, kv_ptrs_svh, int(kv_K), bool(kv_mcg), bool(kv_mul1)) if kv_ptrs_trellis is not None else None
+        self.q_norm, self.k_norm, self.norm_eps, self.norm_constant_bias = q_norm, k_norm, norm_eps, norm_constant_bias
+        self.inv_freq, self.rope_style, self.attn_factor = inv_freq, int(rope_style), float(attn_factor)
+        self.cache_k, self.cache_v, self.cache_k_scales, self.cache_v_scales = cache_k, cache_v, cache_k_scales, cache_v_scales
+        self.xh = xh
+        self._st = {}
+
+    def needs_configure(self, bsz: int, q_len: int) -> bool:
+        return False
+
+    def configure_slot(self, *args, **kwargs):
+        return None
+
+    def _statics(self, bsz: int, pages_per_seq: int, dev):
+        key = (bsz, pages_per_seq)
+        st = self._st.get(key)
+        if st is None:
+            hq, hkv, hd = self.num_q_heads, self.num_kv_heads, self.head_dim
+            max_len = pages_per_seq * self.page_size
+            st = {
+                "q": torch.empty((bsz, 1, hq, hd), dtype=torch.half, device=dev),
+                "kv": torch.empty((2, bsz, hkv * hd), dtype=torch.half, device=dev),
+                "o": torch.empty((bsz, hq, hd), dtype=torch.half, device=dev),
+                "lens": torch.empty((bsz,), dtype=torch.int32, device=dev),
+                "ws": torch.empty((bsz * (hq * hd // 128) * ((max_len + 31) // 32) * 132,), dtype=torch.float, device=dev),
+                "xh": torch.empty((2, bsz, self.hidden_size), dtype=torch.half, device=dev),
+                "max_len": max_len,
+            }
+            self._st[key] = st
+        return st
+
+    def run(self, bsz: int, q_len: int, x, y, cache_seqlens, block_table, position: int = 0, positions=None, position_ids=None, inv_freq_override=None):
+        """x, y: (bsz, q_len, hidden) fp16; cache_seqlens int32 (bsz): tokens in the cache BEFORE this call (the new token is appended at that
+        position, attention.cpp:395-400); block_table int32 (bsz, pages); RoPE position of (b, t) = position + t | positions[b] + t |
+        position_ids[b][t] as in ext.rope."""
+        _req(q_len == 1, "BC_Attention: this build decodes one token per sequence (q_len == 1)")
+        _req(1 <= bsz <= self.MAX_BSZ, "BC_Attention: bsz out of range")
+        _req(self.inv_freq is not None or inv_freq_override is None, "BC_Attention: inv_freq override on a NoPE module")
+        hq, hkv, hd = self.num_q_heads, self.num_kv_heads, self.head_dim
+        st = self._statics(bsz, block_table.shape[1], x.device)
+        x2 = x.view(bsz, self.hidden_size)
+        q2, kv = st["q"].view(bsz, hq * hd), st["kv"]
+        self.q_proj.run(x2, q2)
+        if self.kv_ptrs is not None:
+            pt, ps, pv, K, mcg, mul1 = self.kv_ptrs
+            exl3_mgemm(x2.view(1, bsz, -1), pt, kv, ps, st["xh"], pv, None, None, K, -1, mcg, mul1, -1, -1, 0)
+        else:
+            self.k_proj.run(x2, kv[0]); self.v_proj.run(x2, kv[1])
+        k4, v4 = kv[0].view(bsz, 1, hkv, hd), kv[1].view(bsz, 1, hkv, hd)
+        if self.inv_freq is not None:
+            ivf = inv_freq_override if inv_freq_override is not None else self.inv_freq
+            rope(st["q"], st["q"], k4, k4, ivf, int(position), positions, position_ids, self.rope_style, self.attn_factor,
+                 self.q_norm, self.k_norm, self.norm_eps, self.norm_constant_bias)
+        quant_cache_paged(k4.view(bsz, 1, -1), self.cache_k, self.cache_k_scales, v4.view(bsz, 1, -1), self.cache_v, self.cache_v_scales,
+                          cache_seqlens, block_table, self.page_size, 1)
+        torch.add(cache_seqlens, 1, out=st["lens"])                       # the attention kernel's lengths include the appended token
+        attn_decode_qcache(st["q"].view(bsz, hq, hd), st["o"], self.cache_k, self.cache_k_scales, self.cache_v, self.cache_v_scales, block_table,
+                           st["lens"], st["max_len"], workspace=st["ws"])
+        self.o_proj.run(st["o"].view(bsz, hq * hd), y.view(bsz, self.hidden_size))
+
+
 def __getattr__(name: str):
     # PEP 562: anything the wider reference stack looks up that is not part of the EXL3 quantized-linear hot path (SURVEY.md 8)
     raise AttributeError(f"exllamav3_ext (exllamav3_amd build): op '{name}' is outside the EXL3 quantized-linear hot path and is not provided")

@@ -330,6 +330,87 @@ def test_bc_gated_mlp_matches_oracle_and_op_by_op(dev, cb, m):
         ext.BC_GatedMLP(guh, gu, a, dxh, None, None, None, K, False, False, False, True, False, bcs[0], bcs[1], bcs[2], 0.0)
 
 
+@pytest.mark.parametrize("hd,hq,hkv", [(128, 4, 2), (64, 8, 2)])
+@pytest.mark.parametrize("fused_kv,head_norm", [(False, False), (True, True)])
+def test_bc_attention_runner_matches_oracle(dev, hd, hq, hkv, fused_kv, head_norm):
+    """BC_Attention.run (libtorch/attention.cpp:246-504, Llama / Mixtral subset): projections -> (head norm +) RoPE -> append to the 4-bit paged
+    cache -> decode attention over the quantized cache -> o_proj, against the oracle composition; a pre-filled context of different lengths per
+    sequence, positions tensor, the fused k|v pointer-table form, graph replay; unsupported options raise."""
+    from exllamav3_amd import ext
+    hidden, K, cb, bits, page, bsz, pps = 512, 4, 2, 4, 256, 3, 2
+    rng = np.random.default_rng(hd + fused_kv)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mats = {n: o.synth_linear(k, nn, K, seed=70 + i, realistic=True) for i, (n, k, nn) in enumerate(
+        (("q", hidden, hq * hd), ("k", hidden, hkv * hd), ("v", hidden, hkv * hd), ("o", hq * hd, hidden)))}
+    dm = {n: tuple(T(a) for a in t) for n, t in mats.items()}
+    bc = {n: ext.BC_LinearEXL3(t[0], t[1], t[2], K, None, False, True, None) for n, t in dm.items()}
+    G = hkv * hd // 32
+    npages = bsz * pps
+    bt_np = rng.permutation(npages).reshape(bsz, pps).astype(np.int32)
+    lens = np.array([300, 17, 256], np.int32)                                   # tokens already cached (the third ends exactly on a page edge)
+    ck = rng.standard_normal((bsz, pps * page, hkv * hd)).astype(np.float16); cv = rng.standard_normal((bsz, pps * page, hkv * hd)).astype(np.float16)
+    kq = np.zeros((npages, page, G * bits), np.uint32); ks = np.zeros((npages, page, G), np.float16); vq = kq.copy(); vs = ks.copy()
+    for b in range(bsz):
+        pk, sc = o.kv_quant(ck[b], bits); pv, sv = o.kv_quant(cv[b], bits)
+        for pg in range(pps):
+            kq[bt_np[b, pg]] = pk[pg * page:(pg + 1) * page]; ks[bt_np[b, pg]] = sc[pg * page:(pg + 1) * page]
+            vq[bt_np[b, pg]] = pv[pg * page:(pg + 1) * page]; vs[bt_np[b, pg]] = sv[pg * page:(pg + 1) * page]
+    dkq, dks, dvq, dvs = T(kq.view(np.int32)), T(ks), T(vq.view(np.int32)), T(vs)
+    inv_freq = (1.0 / (10000.0 ** (np.arange(0, hd, 2, dtype=np.float32) / hd))).astype(np.float32)
+    qn = (1 + 0.1 * rng.standard_normal(hd)).astype(np.float16) if head_norm else None
+    kn = (1 + 0.1 * rng.standard_normal(hd)).astype(np.float16) if head_norm else None
+    kw = dict(num_q_heads=hq, num_kv_heads=hkv, head_dim=hd, hidden_size=hidden, hidden_size_padded=hidden, page_size=page,
+              q_proj=bc["q"], k_proj=bc["k"], v_proj=bc["v"], o_proj=bc["o"], q_norm=T(qn) if head_norm else None, k_norm=T(kn) if head_norm else None,
+              norm_eps=1e-6, inv_freq=T(inv_freq), rope_style=2, attn_factor=1.0, quant_cache=True, cache_k=dkq, cache_v=dvq, cache_k_scales=dks,
+              cache_v_scales=dvs, xh=None, h32=None)
+    if fused_kv:
+        ptr = lambda i: torch.tensor([dm["k"][i].data_ptr(), dm["v"][i].data_ptr()], dtype=torch.long, device=dev)
+        kw.update(kv_ptrs_trellis=ptr(0), kv_ptrs_suh=ptr(1), kv_ptrs_svh=ptr(2), kv_K=K, kv_mcg=False, kv_mul1=True)
+    attn = ext.BC_Attention(**kw)
+    assert not attn.needs_configure(bsz, 1)
+    x = rng.standard_normal((bsz, 1, hidden)).astype(np.float16)
+    positions = (lens + np.array([0, 5, 0])).astype(np.int32)                    # RoPE position need not equal the cache length
+    y = torch.full((bsz, 1, hidden), float("nan"), dtype=torch.half, device=dev)
+    dl, dbt, dpos = T(lens), T(bt_np), T(positions)
+    attn.run(bsz, 1, T(x), y, dl, dbt, 0, dpos, None, None)
+    # ---- oracle
+    lin = lambda n, a, **k2: o.linear_forward(a, mats[n][0], mats[n][1], mats[n][2], K, cb, **k2)
+    x2 = x.reshape(bsz, hidden)
+    q, k, v = lin("q", x2), lin("k", x2), lin("v", x2)
+    q4, k4 = o.rope(q.reshape(bsz, 1, hq, hd), k.reshape(bsz, 1, hkv, hd), inv_freq, positions=positions, rope_mode=o.ROPE_NEOX,
+                    q_norm=qn, k_norm=kn, norm_eps=1e-6)
+    kd = np.zeros((bsz, pps * page, hkv, hd), np.float16); vd = np.zeros_like(kd)
+    for b in range(bsz):
+        full_k = np.concatenate([ck[b, :lens[b]], k4[b].reshape(1, -1)]); full_v = np.concatenate([cv[b, :lens[b]], v[b].reshape(1, -1)])
+        pk, sc = o.kv_quant(full_k, bits); pv, sv = o.kv_quant(full_v, bits)
+        kd[b, :lens[b] + 1] = o.kv_dequant(pk, sc, bits).reshape(-1, hkv, hd); vd[b, :lens[b] + 1] = o.kv_dequant(pv, sv, bits).reshape(-1, hkv, hd)
+    ao = o.attn_decode_qcache(q4.reshape(bsz, hq, hd), kd, vd, lens + 1)
+    ref = lin("o", ao.reshape(bsz, -1)).astype(np.float32)
+    got = y.float().cpu().numpy().reshape(bsz, hidden)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+    # the new token landed in the cache at position lens[b] of every sequence
+    row = lambda b: (bt_np[b, lens[b] // page], lens[b] % page)
+    for b in range(bsz):
+        pk, sc = o.kv_quant(k4[b].reshape(1, -1), bits)
+        assert np.allclose(dks.cpu().numpy()[row(b)].astype(np.float32), sc[0].astype(np.float32), rtol=1e-2)   # k itself agrees to GEMV tolerance
+    # graph replay of the same call (the appended token is rewritten in place: same bits)
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    dx = T(x)
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            attn.run(bsz, 1, dx, y, dl, dbt, 0, dpos, None, None)
+    y.zero_(); g.replay(); torch.cuda.synchronize()
+    assert np.array_equal(y.float().cpu().numpy().reshape(bsz, hidden), got)
+    with pytest.raises(RuntimeError):
+        attn.run(bsz, 2, T(np.zeros((bsz, 2, hidden), np.float16)), y, dl, dbt, 0, dpos, None, None)
+    with pytest.raises(RuntimeError):
+        ext.BC_Attention(**{**kw, "gate_mode": 2})
+    with pytest.raises(RuntimeError):
+        ext.BC_Attention(**{**kw, "quant_cache": False})
+
+
 def test_prefill_reconstruct_ahead_is_bit_identical_to_inline(dev):
     """ReconstructAhead (W of the next Linears rebuilt on a side stream, ring of 3 buffers, event-ordered) must not change a bit:
     3 layers x 7 linears cycle the ring several times; repeated chunks reuse the scheduler object."""
