@@ -451,6 +451,13 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                 if (rpp > 2 * nwv) rpp = 2 * nwv;
                 args.epi.rows_per_pass = rpp;
             }
+            // 2-D grid (k-slices, column blocks or groups): dispatched x-fastest, i.e. in the order column block * S + slice; the kernel reads
+            // its pair from blockIdx instead of dividing a linear id (exl3_gemv2.kspec.hip prologue)
+            EXL3_CHECK_ARG(grid.x / (unsigned) S <= 65535u, "exl3_gemm: too many column blocks for one launch");
+            grid = dim3((unsigned) S, grid.x / (unsigned) S);
+            for (int i = 1; i < GEMV_MAX_MATS; ++i) args.cbf[i - 1] = args.mat[i].cb_first;
+            args.nwv = nwv;
+            args.magic_m = gemv_magic((uint32_t) mp); args.magic_nwv = gemv_magic((uint32_t) nwv); args.magic_nhw = gemv_magic((uint32_t) (2 * nwv));
             switch (K)
             {
                 case 1: exl3_gemv2_launch_k1(cb, var, ng, nwv, grid, lds, st, args); break;

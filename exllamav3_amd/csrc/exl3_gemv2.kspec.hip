@@ -102,6 +102,25 @@ void exl3_gemv2_kernel(const GemvArgs a)
 #else
     #define G2_T(i)
 #endif
+    // Every scalar argument of the prologue is read HERE, in one batch of scalar loads: left at their use sites they become a chain of 6-10
+    // dependent scalar-cache round trips (~200 ns each) ahead of the first vector load (tools/gemv_timeline.py: 1.1 us (PLAIN) to 2.1 us (NORM)
+    // from workgroup entry to "loads issued").  For the same reason the divisions by launch constants are multiply-highs (gemv_udiv) and the
+    // (k-slice, column block) pair comes from a 2-D grid instead of a division of the linear block id.
+    const int a_S = a.S, a_k = a.k, a_kslice = a.kslice, a_flags = a.flags, a_chb = a.chunk_blocks, a_nm = a.num_mats;
+    const int a_cbf[GEMV_MAX_MATS] = { 0, a.cbf[0], a.cbf[1], a.cbf[2] };
+    const uint32_t mg_m = a.magic_m, mg_nwv = a.magic_nwv, mg_nhw = a.magic_nhw;
+    const int a_nwv = a.nwv;
+    if constexpr (MODE != G2_MODE_TABLE)
+    {
+        // touch the four matrix records (5 cache lines) in the same batch: the record of THIS workgroup's matrix is chosen from the values above
+        // (a dependent load), which then finds its line in the scalar cache instead of paying a second miss
+        const void* t0 = a.mat[0].B; const void* t1 = a.mat[1].B; const void* t2 = a.mat[2].B; const void* t3 = a.mat[3].B; const void* t4 = a.mat[3].xsum;
+        asm volatile("" :: "s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4));
+    }
+    const half_t* const a_A = a.A;
+    const half_t* const a_norm_w = a.norm_w;
+    const float* const a_ss_part = a.ss_part;
+    const float a_eps = a.eps;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -109,15 +128,23 @@ void exl3_gemv2_kernel(const GemvArgs a)
 
     // xcd_local tail epilogues: workgroup i runs on XCD i % 8 (tools/ubench_xcc.hip), so logical workgroup (i % 8) * (grid / 8) + i / 8 puts each
     // run of grid / 8 consecutive logical ids -- hence all S slices of a column block -- on one XCD (host: column blocks % 8 == 0)
-    int bid = blockIdx.x;
-    if constexpr (MODE == G2_MODE_TAIL) { if (a.epi.xcd_local) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3); }
+    // grid = (S k-slices, column blocks): the linear dispatch order (x fastest) is the former 1-D order column block * S + slice
+    int s = blockIdx.x;
+    int cbg = blockIdx.y;                            // classic: global column block of the workgroup; WPC: column-block GROUP of the workgroup
+    if constexpr (MODE == G2_MODE_TAIL)
+    {
+        if (a.epi.xcd_local)
+        {
+            const int lin = blockIdx.y * a_S + blockIdx.x, total = gridDim.x * gridDim.y;
+            const int bid = (lin & 7) * (total >> 3) + (lin >> 3);
+            s = bid % a_S; cbg = bid / a_S;
+        }
+    }
     constexpr bool WPC = G2_IS_WPC(MODE);
-    const int s = bid % a.S;
-    int cbg = bid / a.S;                             // classic: global column block of the workgroup; WPC: column-block GROUP of the workgroup
     int mi = 0;
     const uint32_t* __restrict__ Bm;
     const half_t* __restrict__ suh;
-    const half_t* A_in = a.A;
+    const half_t* A_in = a_A;
     int n, cbl, ws_off;
     bool wave_live = true;                           // WPC: this wave has a column block (the last group of a matrix may be partial)
     if constexpr (MODE == G2_MODE_TABLE)
@@ -128,14 +155,14 @@ void exl3_gemv2_kernel(const GemvArgs a)
         Bm = (const uint32_t*) a.tbl.B[sr.mat_index];
         suh = (const half_t*) a.tbl.suh[sr.mat_index];
         n = a.tbl.n; cbl = cbg - slot * a.tbl.cbs_per_mat;
-        A_in = a.A + (size_t) slot * a.tbl.a_slot_stride;
-        ws_off = slot * a.tbl.cbs_per_mat * a.S * a.m * 128;
+        A_in = a_A + (size_t) slot * a.tbl.a_slot_stride;
+        ws_off = slot * a.tbl.cbs_per_mat * a_S * m * 128;
     }
     else if constexpr (WPC)
     {
         // groups never straddle matrices (q|k|v, gate|up have different suh): mat[i].cb_first holds the first GROUP of matrix i
         #pragma unroll
-        for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.num_mats && cbg >= a.mat[i].cb_first) mi = i;
+        for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a_nm && cbg >= a_cbf[i]) mi = i;
         Bm = a.mat[mi].B; suh = a.mat[mi].suh;
         n = a.mat[mi].n; ws_off = a.mat[mi].ws_offset;
         cbl = (cbg - a.mat[mi].cb_first) * a.cpw + wave;
@@ -145,15 +172,15 @@ void exl3_gemv2_kernel(const GemvArgs a)
     else
     {
         #pragma unroll
-        for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.num_mats && cbg >= a.mat[i].cb_first) mi = i;
+        for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a_nm && cbg >= a_cbf[i]) mi = i;
         Bm = a.mat[mi].B; suh = a.mat[mi].suh;
         n = a.mat[mi].n; cbl = cbg - a.mat[mi].cb_first; ws_off = a.mat[mi].ws_offset;
     }
     const int tiles_n = n >> 4;
-    const int k0s = s * a.kslice;
-    const int k1s = min(k0s + a.kslice, a.k);
+    const int k0s = s * a_kslice;
+    const int k1s = min(k0s + a_kslice, a_k);
     const int nb = (k1s - k0s) >> 7;                 // 128-blocks in the workgroup's slice
-    const int nwv = blockDim.x >> 6;                 // waves per workgroup (1..16)
+    const int nwv = a_nwv;                           // waves per workgroup (1..16) = blockDim.x / 64
     // Work split inside the workgroup: the slice is walked in units of PF (= 2) tile rows, unit u belongs to wave u % nwv.  All waves
     // therefore advance down k together, which lets the workgroup build the activation fragments of a CHUNK of Hadamard blocks ONCE,
     // cooperatively (one (block, row) task per 32-lane half-wave), instead of every wave rotating every block it touches: at batch 16 the
@@ -162,16 +189,16 @@ void exl3_gemv2_kernel(const GemvArgs a)
     // unit i of this wave = ubase + i * ustride.  One chunk (the usual case: the whole slice's fragments fit the LDS budget): contiguous
     // ranges per wave, [units*w/nwv, units*(w+1)/nwv); several chunks: unit u belongs to wave u % nwv so that every wave has rows in
     // every chunk.
-    const bool one_chunk = a.chunk_blocks >= nb;
+    const bool one_chunk = a_chb >= nb;
     // WPC: every live wave walks ALL units of the slice (its own column block); the host guarantees one chunk
-    const int ubase = WPC ? 0 : (one_chunk ? (units * wave) / nwv : wave);
+    const int ubase = WPC ? 0 : (one_chunk ? gemv_udiv(units * wave, mg_nwv) : wave);
     const int ustride = (WPC || one_chunk) ? 1 : nwv;
     const int nunits_w = WPC ? (wave_live ? units : 0)
-                             : (one_chunk ? (units * (wave + 1)) / nwv - ubase : (wave < units ? (units - wave + nwv - 1) / nwv : 0));
+                             : (one_chunk ? gemv_udiv(units * (wave + 1), mg_nwv) - ubase : (wave < units ? gemv_udiv(units - wave + nwv - 1, mg_nwv) : 0));
 
     // LDS carve: fragments of one chunk [blk][tile row 8][row m][AH halves] | partials [nwv][MR][128] fp32 + per-wave row sums |
     //            tile-row sums [blk * 8][m] fp32 (RAW) | 1/rms per row [16] fp32 (NORM)
-    const int chb = a.chunk_blocks;                  // blocks per chunk (host: LDS budget)
+    const int chb = a_chb;                           // blocks per chunk (host: LDS budget)
     const size_t frag_halves = (size_t) chb * 8 * m * AH;
     half_t* xa = (half_t*) smem;
     float* part = (float*) (smem + ((frag_halves * 2 + 15) & ~(size_t) 15));
@@ -182,7 +209,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
     #pragma unroll
     for (int i = 0; i < 2 * NG; ++i) rowsum[i] = 0.0f;
     const int l32 = lane & 31, hw = lane >> 5;
-    const bool in_rotated = (a.flags & GEMV_IN_ROTATED) != 0;
+    const bool in_rotated = (a_flags & GEMV_IN_ROTATED) != 0;
     const half_t* __restrict__ xh_in = MODE == G2_MODE_TABLE ? nullptr : a.mat[mi].xh;
     const half_t* __restrict__ x_src = in_rotated ? xh_in : A_in;          // one scalar select (two pointers picked per load became a stack table)
     const int npass = (m + 1) >> 1;                  // row pairs (2p, 2p + 1) held by the two half-waves of the streaming loop
@@ -213,7 +240,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
     // prep task fetch: task t = it * nhw + hwid of chunk (c0, cnt) -> (block c0 + t / m, row t % m); loads only
     // NORM at m <= 4 and hidden <= 4096: the task owner reduces its row's 32 partial sums of squares itself (loaded with the task's
     // operands: one memory latency, no extra workgroup barrier); otherwise 1/rms per row goes through LDS (rmf_s) once per launch.
-    const bool norm_in_task = in_norm && NG == 1 && (a.k >> 7) <= 32;
+    const bool norm_in_task = in_norm && NG == 1 && (a_k >> 7) <= 32;
     // ACT mode: the first 8 gate and 8 up slab lines of the task's block travel with the task operands (issued before the weight rows)
     constexpr int ACT_PRE = MODE == G2_MODE_ACT ? 8 : (MODE == G2_MODE_WACT ? 2 : 1);   // WPC layouts: 128-VGPR budget
     constexpr int SLAB_PRE = MODE == G2_MODE_ACT ? 8 : (MODE == G2_MODE_WACT ? 2 : (RES ? 4 : 1));                // slab lines of the first set that travel with the task operands
@@ -222,9 +249,10 @@ void exl3_gemv2_kernel(const GemvArgs a)
     {
         PrepIn r; r.xv = half4_t{ 0, 0, 0, 0 }; r.sv = r.xv; r.wv = r.xv; r.ss = 0.0f; r.ssn = 0.0f;
         const int t = min(it * nhw + hwid, cnt * m - 1);
-        const int blk = c0 + t / m, row = t % m;
+        const int tq = gemv_udiv(t, mg_m);
+        const int blk = c0 + tq, row = t - tq * m;
         const size_t kofs = (size_t) k0s + 128 * blk;
-        if constexpr (!G2_IS_ACT(MODE)) r.xv = ((const half4_t*) (x_src + (size_t) row * a.k + kofs))[l32];
+        if constexpr (!G2_IS_ACT(MODE)) r.xv = ((const half4_t*) (x_src + (size_t) row * a_k + kofs))[l32];
         else
         {
             const int blk_abs = (k0s >> 7) + blk;
@@ -256,15 +284,15 @@ void exl3_gemv2_kernel(const GemvArgs a)
         }
         if constexpr (MODE == G2_MODE_TABLE)
         {
-            if (a.tbl.act_u) r.wv = ((const half4_t*) (a.tbl.act_u + (A_in - a.A) + (size_t) row * a.k + kofs))[l32];   // the slot's `up` row
+            if (a.tbl.act_u) r.wv = ((const half4_t*) (a.tbl.act_u + (A_in - a_A) + (size_t) row * a_k + kofs))[l32];   // the slot's `up` row
         }
         if (!in_rotated)
         {
             r.sv = ((const half4_t*) (suh + kofs))[l32];
             if constexpr (in_norm)
             {
-                r.wv = ((const half4_t*) (a.norm_w + kofs))[l32];
-                if (norm_in_task && l32 < (a.k >> 7)) r.ss = a.ss_part[(size_t) row * (a.k >> 7) + l32];
+                r.wv = ((const half4_t*) (a_norm_w + kofs))[l32];
+                if (norm_in_task && l32 < (a_k >> 7)) r.ss = a_ss_part[(size_t) row * (a_k >> 7) + l32];
             }
         }
         return r;
@@ -289,19 +317,19 @@ void exl3_gemv2_kernel(const GemvArgs a)
     if (in_norm && !norm_in_task)
     {
         // 1/rms of row h by half-wave h (m <= 16 <= half-waves of any launch with >= 8 waves; fewer waves loop)
-        const int nblk_k = a.k >> 7;
+        const int nblk_k = a_k >> 7;
         for (int base = 0; base < m; base += nhw)                       // uniform trip count: the butterflies need whole waves
         {
             const int row = min(base + hwid, m - 1);
             float s2 = 0.0f;
             for (int bb = 0; bb < nblk_k; bb += 32)
             {
-                float v = (bb + l32 < nblk_k) ? a.ss_part[(size_t) row * nblk_k + bb + l32] : 0.0f;
+                float v = (bb + l32 < nblk_k) ? a_ss_part[(size_t) row * nblk_k + bb + l32] : 0.0f;
                 #pragma unroll
                 for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
                 s2 += v;
             }
-            if (l32 == 0 && base + hwid < m) rmf_s[row] = __frsqrt_rn(s2 / (float) a.k + a.eps);
+            if (l32 == 0 && base + hwid < m) rmf_s[row] = __frsqrt_rn(s2 / (float) a_k + a_eps);
         }
         __syncthreads();
     }
@@ -319,7 +347,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         // ---- cooperative prep of blocks [c0, c0 + cnt): task t = (block t / m, row t % m), one per half-wave, software pipelined by one
         {
             const int ntask = cnt * m;
-            const int trips = (ntask + nhw - 1) / nhw;
+            const int trips = gemv_udiv(ntask + nhw - 1, mg_nhw);
             if (c0 > 0) nx = fetch(c0, cnt, 0);
             for (int it = 0; it < trips; ++it)
             {
@@ -329,7 +357,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 const int t = it * nhw + hwid;
                 const bool act = t < ntask;
                 const int tc = min(t, ntask - 1);
-                const int blk_l = tc / m, row = tc % m;                 // chunk-local block
+                const int blk_l = gemv_udiv(tc, mg_m), row = tc - blk_l * m;  // chunk-local block
                 half2_t o01, o23;
                 if (in_rotated)
                 {
@@ -424,8 +452,8 @@ void exl3_gemv2_kernel(const GemvArgs a)
                             for (int i = 1; i < 32; i <<= 1) ssq += xor_lane(ssq, i);
                             if (act)
                             {
-                                ((half4_t*) (a.rs_resid_out + (size_t) row * a.k + (size_t) blk_abs * 128))[l32] = xv;
-                                if (l32 == 0) a.rs_ss_out[(size_t) row * (a.k >> 7) + blk_abs] = ssq;
+                                ((half4_t*) (a.rs_resid_out + (size_t) row * a_k + (size_t) blk_abs * 128))[l32] = xv;
+                                if (l32 == 0) a.rs_ss_out[(size_t) row * (a_k >> 7) + blk_abs] = ssq;
                             }
                         }
                     }
@@ -437,7 +465,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
                             float s2 = cur.ss;
                             #pragma unroll
                             for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
-                            r = __frsqrt_rn((0.0f + s2) / (float) a.k + a.eps);
+                            r = __frsqrt_rn((0.0f + s2) / (float) a_k + a_eps);
                         }
                         else r = rmf_s[row];
                         xv = half4_t{ f2h((float) xv.x * (float) cur.wv.x * r), f2h((float) xv.y * (float) cur.wv.y * r),
@@ -451,7 +479,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
                 }
 #ifdef G2_DEBUG_FRAG
                 // diagnostics build: workgroup 0 dumps the rotated activations it built (fp16 [blk][row][128]) at 40 MiB
-                if (blockIdx.x == 0 && act)
+                if (blockIdx.x == 0 && blockIdx.y == 0 && act)
                 {
                     half_t* dbg = (half_t*) ((char*) a.ws_debug + (4ll << 20)) + ((size_t) (k0s / 128 + c0 + blk_l) * m + row) * 128 + 4 * l32;
                     dbg[0] = o01.x; dbg[1] = o01.y; dbg[2] = o23.x; dbg[3] = o23.y;
@@ -656,7 +684,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         if (wave_live)
         {
             const float* pw = part + (size_t) wave * MR * 128;
-            float* slab = a.workspace + ws_off + ((size_t) cbl * a.S + s) * (size_t) m * 128;
+            float* slab = a.workspace + ws_off + ((size_t) cbl * a_S + s) * (size_t) m * 128;
             for (int row = hw; row < m; row += 2)
                 ((float4_t*) (slab + row * 128))[l32] = ((const float4_t*) (pw + row * 128))[l32];
         }
@@ -664,7 +692,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         if (tid == 0)
         {
             tstamp[4] = tstamp[5] = __builtin_amdgcn_s_memrealtime();
-            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) blockIdx.x * 8;
+            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 8;
             for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
             uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             dbg[6] = xcc; dbg[7] = 0;
@@ -677,9 +705,9 @@ void exl3_gemv2_kernel(const GemvArgs a)
 
     const int l = tid & 31, hw8 = tid >> 5;
     const size_t wstride = (size_t) MR * 128;
-    if (a.S > 1 || (a.flags & GEMV_OUT_DEFERRED))
+    if (a_S > 1 || (a_flags & GEMV_OUT_DEFERRED))
     {
-        float* slab = a.workspace + ws_off + ((size_t) cbl * a.S + s) * (size_t) m * 128;
+        float* slab = a.workspace + ws_off + ((size_t) cbl * a_S + s) * (size_t) m * 128;
         for (int row = hw8; row < m; row += nwv * 2)
         {
             const float* p0 = part + row * 128;
@@ -704,7 +732,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         if (tid == 0)
         {
             tstamp[5] = __builtin_amdgcn_s_memrealtime();
-            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) blockIdx.x * 8;
+            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 8;
             for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
             uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             uint32_t hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));

@@ -1,5 +1,6 @@
 // Kernel-argument block shared by the GEMV kernel generations.
 #pragma once
+#include <stddef.h>
 #include "exl3_common.cuh"
 
 #ifndef G2_PF
@@ -108,10 +109,9 @@ __device__ __forceinline__ SlotRef_t resolve_slot(const GemvTable& t, int slot)
 
 struct GemvArgs
 {
-    GemvMat mat[GEMV_MAX_MATS];
-    const half_t* A;       // [m][k] (already offset to the first row of this pass)
-    float* workspace;      // slab region of this launch
-    float* ws_debug;       // diagnostics builds: fixed area at 48 MiB of the per-device workspace
+    // ---- hot block: everything a generation-2 workgroup reads before its first vector load sits in the first two 64-byte lines of the
+    // argument block (and is read in one batch, exl3_gemv2.kspec.hip prologue): the fields used to be spread over 8 cache lines and the
+    // prologue paid a scalar-cache miss per dependent step (tools/gemv_timeline.py)
     int num_mats;
     int m;                 // rows in this pass (1..16)
     int k;
@@ -122,10 +122,19 @@ struct GemvArgs
     int chunk_blocks;      // gen 2: Hadamard blocks of activation fragments a wave keeps in LDS at a time
     int cpw;               // > 0: wave-per-column-block layout (exl3_gemv2.kspec.hip G2_IS_WPC): column blocks per workgroup = waves per workgroup;
                            // mat[i].cb_first then counts GROUPS of cpw column blocks (groups never straddle matrices)
-    int64_t c_row_offset;  // first output row of this pass
+    int cbf[3];            // copies of mat[1..3].cb_first
+    uint32_t magic_m, magic_nwv, magic_nhw;      // exact-division multipliers (gemv_magic / gemv_udiv below; 0 = divisor 1)
+    float eps;
+    const half_t* A;       // [m][k] (already offset to the first row of this pass)
+    float* workspace;      // slab region of this launch
     const half_t* norm_w;  // GEMV_IN_NORM: RMSNorm weight [k]
     const float* ss_part;  // GEMV_IN_NORM: [m][k/128] sums of squares of the residual blocks (exl3_glue_resid)
-    float eps;
+    float* ws_debug;       // diagnostics builds: fixed area at 48 MiB of the per-device workspace
+    int64_t c_row_offset;  // first output row of this pass
+    int nwv;               // gen 2: waves per workgroup (= blockDim.x / 64; reading blockDim costs a scalar load from the implicit arguments
+                           // BEHIND this block, i.e. one more cache line and one more dependent round trip)
+    int pad_hot_[3];       // mat[] starts on the third line
+    GemvMat mat[GEMV_MAX_MATS];
     GemvTable tbl;         // table mode when tbl.B != nullptr
     // ACT mode (GEMV_IN_ACT): the input is silu(g) * u of the PREVIOUS launch's deferred gate / up slabs, finished here per Hadamard block
     const float* act_g; const float* act_u;      // slab bases [inter/128][act_S][m][128] fp32 (the other workspace region)
@@ -137,6 +146,14 @@ struct GemvArgs
     const float* rs_slab; const half_t* rs_svh; half_t* rs_resid_out; float* rs_ss_out; int rs_S;
     GemvEpi epi;
 };
+static_assert(offsetof(GemvArgs, mat) == 128, "GemvArgs: the hot block is two 64-byte lines");
+
+// floor(x / d) for x < 2^32 / d as one multiply-high: M = floor(2^32 / d) + 1 (d >= 2), M = 0 encodes d == 1.  The kernels divide by launch
+// constants (rows, waves per workgroup) in their prologue and prep loops; a runtime integer division is a ~30-instruction v_rcp sequence each.
+static inline uint32_t gemv_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t) ((1ull << 32) / d) + 1u; }
+#ifdef __HIPCC__
+__device__ __forceinline__ int gemv_udiv(int x, uint32_t M) { return M ? (int) __umulhi((uint32_t) x, M) : x; }
+#endif
 
 // generation-2 kernels: one translation unit per K (exl3_gemv2.kspec.hip compiled with -DG2_K=1..8)
 size_t exl3_gemv2_lds_bytes(int ng, int var, int cb, int nwv, int m, int chunk_blocks);
