@@ -138,6 +138,8 @@ def _declare(l):
     sig("exl3_routing_std_slots", vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
     sig("exl3_mgemm_indexed_act", vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_set_glue_threads", i32)
+    sig("exl3_qkv_prep", vp, vp, f32, i32, i32, vp, i32, i32, vp, vp, vp, vp)
+    sig("exl3_glue_qkv_tab", vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, i32, f32, vp, vp, vp, vp)
     sig("exl3_glue_resid_rotate", vp, i32, vp, vp, vp, vp, vp, vp, vp, f32, PP, PP, PP, i32, i32, i32, vp)
     sig("exl3_glue_act_rs", vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, f32, vp)
     sig("exl3_glue_rotate", vp, vp, vp, f32, PP, PP, PP, i32, i32, i32, vp)

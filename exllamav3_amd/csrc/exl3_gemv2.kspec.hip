@@ -110,6 +110,12 @@ void exl3_gemv2_kernel(const GemvArgs a)
     const int a_cbf[GEMV_MAX_MATS] = { 0, a.cbf[0], a.cbf[1], a.cbf[2] };
     const uint32_t mg_m = a.magic_m, mg_nwv = a.magic_nwv, mg_nhw = a.magic_nhw;
     const int a_nwv = a.nwv;
+    // ACT modes: the slab bases of the producer launch live on another line of the argument block: same batch (dead code in the other modes)
+    const float* const a_act_g = a.act_g; const float* const a_act_u = a.act_u;
+    const half_t* const a_act_svh_g = a.act_svh_g; const half_t* const a_act_svh_u = a.act_svh_u;
+    const int a_act_S = a.act_S;
+    const float* const a_act_rs_new = a.act_rs.ss_new;
+    if constexpr (G2_IS_ACT(MODE)) asm volatile("" :: "s"(a_act_g), "s"(a_act_S));     // ... and make it THIS batch (the compiler would sink it to the first use)
     if constexpr (MODE != G2_MODE_TABLE)
     {
         // touch the four matrix records (5 cache lines) in the same batch: the record of THIS workgroup's matrix is chosen from the values above
@@ -256,21 +262,21 @@ void exl3_gemv2_kernel(const GemvArgs a)
         else
         {
             const int blk_abs = (k0s >> 7) + blk;
-            const float* pg = a.act_g + ((size_t) blk_abs * a.act_S * m + row) * 128;
-            const float* pu = a.act_u + ((size_t) blk_abs * a.act_S * m + row) * 128;
+            const float* pg = a_act_g + ((size_t) blk_abs * a_act_S * m + row) * 128;
+            const float* pu = a_act_u + ((size_t) blk_abs * a_act_S * m + row) * 128;
             const size_t st = (size_t) m * 128;
             #pragma unroll
             for (int i = 0; i < ACT_PRE; ++i)
             {
-                r.sg[i] = ((const float4_t*) (pg + (size_t) min(i, a.act_S - 1) * st))[l32];
-                r.su[i] = ((const float4_t*) (pu + (size_t) min(i, a.act_S - 1) * st))[l32];
+                r.sg[i] = ((const float4_t*) (pg + (size_t) min(i, a_act_S - 1) * st))[l32];
+                r.su[i] = ((const float4_t*) (pu + (size_t) min(i, a_act_S - 1) * st))[l32];
             }
-            r.svg = ((const half4_t*) (a.act_svh_g + blk_abs * 128))[l32];
-            r.svu = ((const half4_t*) (a.act_svh_u + blk_abs * 128))[l32];
-            if (a.act_rs.ss_new)
+            r.svg = ((const half4_t*) (a_act_svh_g + blk_abs * 128))[l32];
+            r.svu = ((const half4_t*) (a_act_svh_u + blk_abs * 128))[l32];
+            if (a_act_rs_new)
             {
                 const int nbh = a.act_rs.k >> 7;
-                if (l32 < nbh) { r.ss = a.act_rs.ss_prev[(size_t) row * nbh + l32]; r.ssn = a.act_rs.ss_new[(size_t) row * nbh + l32]; }
+                if (l32 < nbh) { r.ss = a.act_rs.ss_prev[(size_t) row * nbh + l32]; r.ssn = a_act_rs_new[(size_t) row * nbh + l32]; }
             }
         }
         if constexpr (RES)
@@ -384,24 +390,24 @@ void exl3_gemv2_kernel(const GemvArgs a)
                         // slice-order sums (the order of slab_sum2 / glue_act_kernel): the prefetched lines first, any further slices from memory
                         float4_t vg = { 0.f, 0.f, 0.f, 0.f }, vu = vg;
                         #pragma unroll
-                        for (int i = 0; i < ACT_PRE; ++i) if (i < a.act_S)
+                        for (int i = 0; i < ACT_PRE; ++i) if (i < a_act_S)
                         {
                             vg.x += cur.sg[i].x; vg.y += cur.sg[i].y; vg.z += cur.sg[i].z; vg.w += cur.sg[i].w;
                             vu.x += cur.su[i].x; vu.y += cur.su[i].y; vu.z += cur.su[i].z; vu.w += cur.su[i].w;
                         }
-                        for (int sl = ACT_PRE; sl < a.act_S; sl += 4)        // further slices: 4 + 4 independent loads per round, slice-order sums
+                        for (int sl = ACT_PRE; sl < a_act_S; sl += 4)        // further slices: 4 + 4 independent loads per round, slice-order sums
                         {
                             float4_t tg[4], tu[4];
-                            const float* pg = a.act_g + ((size_t) blk_abs * a.act_S * m + row) * 128;
-                            const float* pu = a.act_u + ((size_t) blk_abs * a.act_S * m + row) * 128;
+                            const float* pg = a_act_g + ((size_t) blk_abs * a_act_S * m + row) * 128;
+                            const float* pu = a_act_u + ((size_t) blk_abs * a_act_S * m + row) * 128;
                             #pragma unroll
                             for (int i = 0; i < 4; ++i)
                             {
-                                tg[i] = ((const float4_t*) (pg + (size_t) min(sl + i, a.act_S - 1) * m * 128))[l32];
-                                tu[i] = ((const float4_t*) (pu + (size_t) min(sl + i, a.act_S - 1) * m * 128))[l32];
+                                tg[i] = ((const float4_t*) (pg + (size_t) min(sl + i, a_act_S - 1) * m * 128))[l32];
+                                tu[i] = ((const float4_t*) (pu + (size_t) min(sl + i, a_act_S - 1) * m * 128))[l32];
                             }
                             #pragma unroll
-                            for (int i = 0; i < 4; ++i) if (sl + i < a.act_S)
+                            for (int i = 0; i < 4; ++i) if (sl + i < a_act_S)
                             {
                                 vg.x += tg[i].x; vg.y += tg[i].y; vg.z += tg[i].z; vg.w += tg[i].w;
                                 vu.x += tu[i].x; vu.y += tu[i].y; vu.z += tu[i].z; vu.w += tu[i].w;
@@ -410,7 +416,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
                         float g0, g1, g2, g3, u0, u1, u2, u3;
                         out_had(vg, l32, g0, g1, g2, g3);
                         out_had(vu, l32, u0, u1, u2, u3);
-                        if (a.act_rs.ss_new)
+                        if (a_act_rs_new)
                         {
                             // gate / up were computed from fp16(x * w * r_prev): apply r_new / r_prev (exact sums of squares of the new residual)
                             const float rsc = gemv_rescale(a.act_rs, row, l32, cur.ss, cur.ssn);

@@ -11,6 +11,7 @@
 //
 // Rounding points follow the unfused ops exactly (they are the same device functions), so fused and unfused pipelines agree
 // to fp32 summation order.
+#include <string.h>
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
 #include "exl3_glue_device.cuh"
@@ -132,32 +133,44 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
 // exl3_glue_act_rs; the quantized linear commutes with the row scalar).  ss_part must then be a different buffer than rot.ss_prev.
 struct ResidRotate { const float* ss_prev; const half_t* w; float eps; NormTargets tg; };
 
+// Arguments of glue_resid_kernel.  The kernel is a chain of latencies, not of work (4.7 us for < 100 KB): everything a task needs is in the
+// first cache line of this block and is read in one batch, the task index is split with a multiply-high (gemv_udiv), half-wave tasks per
+// workgroup come from here instead of blockDim (an implicit argument on another line), and every load a task needs -- residual, scales, bias,
+// the slab lines -- is issued before the first value is used.
+struct ResidArgs
+{
+    const float* y_base; const float* y_dense; const half_t* svh; const half_t* bias; half_t* resid; float* ss_part;     // 48 B
+    int y_S, has_y, m, hidden, nblk, tpw; uint32_t magic_nblk; int pad_;                                                // 80 B
+    ResidRotate rot;
+};
+
 template <bool ROT>
 __global__ __launch_bounds__(256)
-void glue_resid_kernel(const float* __restrict__ y_base, int y_S, int has_y, const float* __restrict__ y_dense, const half_t* __restrict__ svh,
-                       const half_t* __restrict__ bias, half_t* __restrict__ resid, float* __restrict__ ss_part, int m, int hidden, ResidRotate rot)
+void glue_resid_kernel(const ResidArgs a)
 {
-    // flat scalar / pointer arguments (16 dwords): eligible for kernarg preloading (-mllvm -amdgpu-kernarg-preload-count=16); measured on
-    // MI355X / ROCm 7.2: no gain (4.73 vs 4.60 us), so the build does not enable it
+    const float* const y_base = a.y_base; const float* const y_dense = a.y_dense; const half_t* const svh = a.svh; const half_t* const bias = a.bias;
+    half_t* const resid = a.resid; float* const ss_part = a.ss_part;
+    const int y_S = a.y_S, has_y = a.has_y, m = a.m, hidden = a.hidden, nblk = a.nblk, tpw = a.tpw;
+    const uint32_t magic_nblk = a.magic_nblk;
     const SlabRef y = { y_base, y_S };
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
-    const int nblk = hidden >> 7;
     const int tasks = m * nblk;
-    const int t = blockIdx.x * (blockDim.x >> 5) + hw;                 // half-wave tasks per workgroup = blockDim / 32
+    const int t = blockIdx.x * tpw + hw;                               // half-wave tasks per workgroup = blockDim / 32
     const bool act = t < tasks;
-    const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+    const int tt = act ? t : 0;
+    const int row = gemv_udiv(tt, magic_nblk), blk = tt - row * nblk;
+    // ---- all loads first
     half4_t r = ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
-    float r0 = (float) r.x, r1 = (float) r.y, r2 = (float) r.z, r3 = (float) r.w;
     half4_t wv = { 0, 0, 0, 0 }, sv[3];
     float ssp0 = 0.0f;
     if constexpr (ROT)
     {
-        // everything the rotation needs that does not depend on the slabs: in flight together with them
-        wv = ((const half4_t*) (rot.w + blk * 128))[l];
+        wv = ((const half4_t*) (a.rot.w + blk * 128))[l];
         #pragma unroll
-        for (int i = 0; i < 3; ++i) sv[i] = i < rot.tg.count ? ((const half4_t*) (rot.tg.suh[i] + blk * 128))[l] : half4_t{ 0, 0, 0, 0 };
-        ssp0 = l < nblk ? rot.ss_prev[(size_t) row * nblk + l] : 0.0f;
+        for (int i = 0; i < 3; ++i) sv[i] = i < a.rot.tg.count ? ((const half4_t*) (a.rot.tg.suh[i] + blk * 128))[l] : half4_t{ 0, 0, 0, 0 };
+        ssp0 = l < nblk ? a.rot.ss_prev[(size_t) row * nblk + l] : 0.0f;
     }
+    float r0, r1, r2, r3;
     if (has_y)
     {
         float h0, h1, h2, h3;
@@ -175,10 +188,10 @@ void glue_resid_kernel(const float* __restrict__ y_base, int y_S, int has_y, con
             h0 *= (float) sc.x; h1 *= (float) sc.y; h2 *= (float) sc.z; h3 *= (float) sc.w;
             if (bias) { h0 += (float) b.x; h1 += (float) b.y; h2 += (float) b.z; h3 += (float) b.w; }
         }
-        r = half4_t{ f2h(r0 + h0), f2h(r1 + h1), f2h(r2 + h2), f2h(r3 + h3) };
-        r0 = (float) r.x; r1 = (float) r.y; r2 = (float) r.z; r3 = (float) r.w;
+        r = half4_t{ f2h((float) r.x + h0), f2h((float) r.y + h1), f2h((float) r.z + h2), f2h((float) r.w + h3) };
         if (act) ((half4_t*) (resid + (size_t) row * hidden + blk * 128))[l] = r;
     }
+    r0 = (float) r.x; r1 = (float) r.y; r2 = (float) r.z; r3 = (float) r.w;
     float ss = r0 * r0;
     ss = __builtin_fmaf(r1, r1, ss); ss = __builtin_fmaf(r2, r2, ss); ss = __builtin_fmaf(r3, r3, ss);
     #pragma unroll
@@ -190,20 +203,20 @@ void glue_resid_kernel(const float* __restrict__ y_base, int y_S, int has_y, con
         float s2 = 0.0f;
         for (int b0 = 0; b0 < nblk; b0 += 32)
         {
-            float v = b0 == 0 ? ssp0 : ((b0 + l < nblk) ? rot.ss_prev[(size_t) row * nblk + b0 + l] : 0.0f);
+            float v = b0 == 0 ? ssp0 : ((b0 + l < nblk) ? a.rot.ss_prev[(size_t) row * nblk + b0 + l] : 0.0f);
             #pragma unroll
             for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
             s2 += v;
         }
-        const float rmf = __frsqrt_rn(s2 / (float) hidden + rot.eps);
+        const float rmf = __frsqrt_rn(s2 / (float) hidden + a.rot.eps);
         const half4_t xn = { f2h(r0 * (float) wv.x * rmf), f2h(r1 * (float) wv.y * rmf), f2h(r2 * (float) wv.z * rmf), f2h(r3 * (float) wv.w * rmf) };
         #pragma unroll
         for (int i = 0; i < 3; ++i)
         {
-            if (i < rot.tg.count)
+            if (i < a.rot.tg.count)
             {
-                float sum = in_had_store_v(xn, sv[i], rot.tg.xh[i] + (size_t) row * hidden + blk * 128, l, act);
-                if (act && l == 0 && rot.tg.xsum[i]) rot.tg.xsum[i][(size_t) row * nblk + blk] = sum;
+                float sum = in_had_store_v(xn, sv[i], a.rot.tg.xh[i] + (size_t) row * hidden + blk * 128, l, act);
+                if (act && l == 0 && a.rot.tg.xsum[i]) a.rot.tg.xsum[i][(size_t) row * nblk + blk] = sum;
             }
         }
     }
@@ -271,84 +284,124 @@ struct QkvArgs
     int hd;
     float attn_factor;
     GemvRescale rs;                                         // ss_new != nullptr: q, k, v came from an exl3_gemv_ex_resid launch (row scale correction)
+    // per-step tables of exl3_qkv_prep (all layers of a decode step share positions and block table): sin / cos [m][64] fp32 (x attn_factor)
+    // and the physical cache row of every token.  With them the kernel has no sincosf, no LDS table, no barrier and no dependent
+    // positions -> block_table load chain; null: it computes all of that itself (the form the reference's per-layer ops have)
+    const float* rope_sin; const float* rope_cos; const int64_t* slots;
+    int tpw; uint32_t magic_heads;                          // half-wave tasks per workgroup; gemv_magic(hq + 2 hkv)
 };
 
-template <int KB, int VB>
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+template <int KB, int VB, bool TAB>
 __global__ __launch_bounds__(256)
-void glue_qkv_kernel(QkvArgs a)
+void glue_qkv_kernel(const QkvArgs a)
 {
-    __shared__ float sn_s[16 * 64], cs_s[16 * 64];
+    __shared__ float sn_s[TAB ? 1 : 16 * 64], cs_s[TAB ? 1 : 16 * 64];
+    // every scalar argument in one batch (see ResidArgs)
+    const int a_m = a.m, a_hq = a.hq, a_hkv = a.hkv, a_hd = a.hd, rope_mode = a.rope_mode, tpw = a.tpw, page_size = a.page_size, bps = a.blocks_per_seq;
+    const uint32_t magic_heads = a.magic_heads;
+    const float attn_factor = a.attn_factor;
+    half_t* const q_out = a.q_out; half_t* const k_out = a.k_out; half_t* const v_out = a.v_out;
+    uint32_t* const k_cache = a.k_cache; half_t* const k_scales = a.k_scales; uint32_t* const v_cache = a.v_cache; half_t* const v_scales = a.v_scales;
+    const int32_t* const positions = a.positions; const int32_t* const block_table = a.block_table; const float* const inv_freq = a.inv_freq;
+    const float* const rope_sin = a.rope_sin; const float* const rope_cos = a.rope_cos; const int64_t* const slots = a.slots;
+    const GemvRescale rs = a.rs;
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
-    const int heads = a.hq + 2 * a.hkv;
-    const int tasks = a.m * heads;
-    const int t = blockIdx.x * (blockDim.x >> 5) + hw;                 // half-wave tasks per workgroup = blockDim / 32
+    const int heads = a_hq + 2 * a_hkv;
+    const int tasks = a_m * heads;
+    const int t = blockIdx.x * tpw + hw;                               // half-wave tasks per workgroup = blockDim / 32
     const bool act = t < tasks;
-    const int row = act ? t / heads : 0, head = act ? t % heads : 0;
-    const int kind = head < a.hq ? 0 : (head < a.hq + a.hkv ? 1 : 2);
-    const int hi = kind == 0 ? head : (kind == 1 ? head - a.hq : head - a.hq - a.hkv);
+    const int tt = act ? t : 0;
+    const int row = gemv_udiv(tt, magic_heads), head = tt - row * heads;
+    const int kind = head < a_hq ? 0 : (head < a_hq + a_hkv ? 1 : 2);
+    const int hi = kind == 0 ? head : (kind == 1 ? head - a_hq : head - a_hq - a_hkv);
     const SlabRef& sr = kind == 0 ? a.sq : (kind == 1 ? a.sk : a.sv);
     const half_t* svh = (kind == 0 ? a.svh_q : (kind == 1 ? a.svh_k : a.svh_v)) + hi * 128;
+    // ---- small loads first, then the slab lines; nothing is used before the slab sum
+    const half4_t sc = ((const half4_t*) svh)[l];
     float rs_p = 0.0f, rs_n = 0.0f;
-    if (a.rs.ss_new && l < (a.rs.k >> 7)) { rs_p = a.rs.ss_prev[(size_t) row * (a.rs.k >> 7) + l]; rs_n = a.rs.ss_new[(size_t) row * (a.rs.k >> 7) + l]; }
-    const float4_t ysum = slab_sum(sr, hi, row, a.m, l);            // slab loads in flight while the sin/cos table is built
-    const int nfreq = a.hd >> 1;                                        // 64 (head_dim 128) or 32 (head_dim 64: two heads per block)
-    for (int i = tid; i < a.m * nfreq; i += blockDim.x)
+    if (rs.ss_new && l < (rs.k >> 7)) { rs_p = rs.ss_prev[(size_t) row * (rs.k >> 7) + l]; rs_n = rs.ss_new[(size_t) row * (rs.k >> 7) + l]; }
+    const int ph = a_hd >> 3;                                           // NEOX partner distance in lanes: 16 (head_dim 128) or 8 (64)
+    float4_t sn4 = { 0.f, 0.f, 0.f, 0.f }, cs4 = { 0.f, 0.f, 0.f, 0.f };
+    int64_t token_pos = 0;
+    if constexpr (TAB)
     {
-        int rw = i / nfreq, f = i % nfreq;
-        float sn, cs;
-        sincosf(a.inv_freq[f] * (float) a.positions[rw], &sn, &cs);
-        sn_s[rw * 64 + f] = sn * a.attn_factor; cs_s[rw * 64 + f] = cs * a.attn_factor;
+        // NEOX: frequencies 4 (l mod ph) .. + 3; GPTJ: 2 (l mod hd/4), + 1 (the upper two lanes of the float4 are not used)
+        const int f = rope_mode == 2 ? 4 * (l & (ph - 1)) : 2 * (l & ((a_hd >> 2) - 1));
+        if (rope_mode == 2) { sn4 = *((const float4_t*) (rope_sin + row * 64 + f)); cs4 = *((const float4_t*) (rope_cos + row * 64 + f)); }
+        else { const f2_t s2 = *((const f2_t*) (rope_sin + row * 64 + f)), c2 = *((const f2_t*) (rope_cos + row * 64 + f)); sn4.x = s2.x; sn4.y = s2.y; cs4.x = c2.x; cs4.y = c2.y; }
+        if (k_cache) token_pos = slots[row];
     }
-    __syncthreads();
+    const float4_t ysum = slab_sum(sr, hi, row, a_m, l);
+    if constexpr (!TAB)
+    {
+        const int nfreq = a_hd >> 1;                                    // 64 (head_dim 128) or 32 (head_dim 64: two heads per block)
+        for (int i = tid; i < a_m * nfreq; i += 32 * tpw)
+        {
+            const int rw = a_hd == 128 ? i >> 6 : i >> 5, f = i & (nfreq - 1);
+            float sn, cs;
+            sincosf(inv_freq[f] * (float) positions[rw], &sn, &cs);
+            sn_s[rw * 64 + f] = sn * attn_factor; cs_s[rw * 64 + f] = cs * attn_factor;
+        }
+        __syncthreads();
+    }
     float h0, h1, h2, h3;
     out_had(ysum, l, h0, h1, h2, h3);
-    if (a.rs.ss_new) { const float rsc = gemv_rescale(a.rs, row, l, rs_p, rs_n); h0 *= rsc; h1 *= rsc; h2 *= rsc; h3 *= rsc; }
-    half4_t sc = ((const half4_t*) svh)[l];
+    if (rs.ss_new) { const float rsc = gemv_rescale(rs, row, l, rs_p, rs_n); h0 *= rsc; h1 *= rsc; h2 *= rsc; h3 *= rsc; }
     half4_t y = half4_t{ f2h(h0), f2h(h1), f2h(h2), f2h(h3) } * sc;       // fp16 output semantics of exl3_gemm
     if (kind != 2)
     {
         // RoPE on the fp16 head vector; lane l holds dims 4l..4l+3
         float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
-        if (a.rope_mode == 2)
+        if (rope_mode == 2)
         {
             // NEOX: pairs (d, d + hd/2) inside a head: partner lane l ^ (hd/8), frequency index d mod hd/2
-            const int ph = a.hd >> 3;                                   // 16 or 8 lanes
             float p0, p1, p2, p3;
             if (ph == 16) { p0 = xor_lane(v0, 16); p1 = xor_lane(v1, 16); p2 = xor_lane(v2, 16); p3 = xor_lane(v3, 16); }
             else          { p0 = xor_lane(v0, 8);  p1 = xor_lane(v1, 8);  p2 = xor_lane(v2, 8);  p3 = xor_lane(v3, 8); }
-            const int f = 4 * (l & (ph - 1));
-            const float* sn = sn_s + row * 64 + f; const float* cs = cs_s + row * 64 + f;
+            if constexpr (!TAB)
+            {
+                const int f = 4 * (l & (ph - 1));
+                sn4 = *((const float4_t*) (sn_s + row * 64 + f)); cs4 = *((const float4_t*) (cs_s + row * 64 + f));
+            }
             const bool upper = (l & ph) != 0;
             // lower half: r1 = v1*cos - v2*sin ; upper half: r2 = v2*cos + v1*sin   (v1 = lower element, v2 = upper element)
-            float r0 = upper ? v0 * cs[0] + p0 * sn[0] : v0 * cs[0] - p0 * sn[0];
-            float r1 = upper ? v1 * cs[1] + p1 * sn[1] : v1 * cs[1] - p1 * sn[1];
-            float r2 = upper ? v2 * cs[2] + p2 * sn[2] : v2 * cs[2] - p2 * sn[2];
-            float r3 = upper ? v3 * cs[3] + p3 * sn[3] : v3 * cs[3] - p3 * sn[3];
+            float r0 = upper ? v0 * cs4.x + p0 * sn4.x : v0 * cs4.x - p0 * sn4.x;
+            float r1 = upper ? v1 * cs4.y + p1 * sn4.y : v1 * cs4.y - p1 * sn4.y;
+            float r2 = upper ? v2 * cs4.z + p2 * sn4.z : v2 * cs4.z - p2 * sn4.z;
+            float r3 = upper ? v3 * cs4.w + p3 * sn4.w : v3 * cs4.w - p3 * sn4.w;
             y = half4_t{ f2h(r0), f2h(r1), f2h(r2), f2h(r3) };
         }
         else
         {
             // GPTJ: pairs (2i, 2i+1) both in this lane: frequencies 2l', 2l'+1 with l' the lane inside the head
-            const int lf = 2 * (l & ((a.hd >> 2) - 1));
-            const float* sn = sn_s + row * 64 + lf; const float* cs = cs_s + row * 64 + lf;
-            y = half4_t{ f2h(v0 * cs[0] - v1 * sn[0]), f2h(v1 * cs[0] + v0 * sn[0]),
-                         f2h(v2 * cs[1] - v3 * sn[1]), f2h(v3 * cs[1] + v2 * sn[1]) };
+            if constexpr (!TAB)
+            {
+                const int lf = 2 * (l & ((a_hd >> 2) - 1));
+                sn4.x = sn_s[row * 64 + lf]; sn4.y = sn_s[row * 64 + lf + 1]; cs4.x = cs_s[row * 64 + lf]; cs4.y = cs_s[row * 64 + lf + 1];
+            }
+            y = half4_t{ f2h(v0 * cs4.x - v1 * sn4.x), f2h(v1 * cs4.x + v0 * sn4.x),
+                         f2h(v2 * cs4.y - v3 * sn4.y), f2h(v3 * cs4.y + v2 * sn4.y) };
         }
     }
-    if (kind == 0 && act) ((half4_t*) (a.q_out + ((size_t) row * a.hq + hi) * 128))[l] = y;
-    half_t* dense = kind == 1 ? a.k_out : (kind == 2 ? a.v_out : nullptr);
-    if (dense && act && kind != 0) ((half4_t*) (dense + ((size_t) row * a.hkv + hi) * 128))[l] = y;
+    if (kind == 0 && act) ((half4_t*) (q_out + ((size_t) row * a_hq + hi) * 128))[l] = y;
+    half_t* dense = kind == 1 ? k_out : (kind == 2 ? v_out : nullptr);
+    if (dense && act && kind != 0) ((half4_t*) (dense + ((size_t) row * a_hkv + hi) * 128))[l] = y;
     // quantized append (all lanes take part in the shuffles; stores are predicated)
-    const bool do_q = act && kind != 0 && a.k_cache != nullptr;
-    const int pos = a.positions[row];
-    const int page_idx = pos / a.page_size;
-    const int64_t token_pos = a.k_cache ? (int64_t) a.block_table[row * a.blocks_per_seq + page_idx] * a.page_size + (pos % a.page_size) : 0;
-    const int groups_per_token = a.hkv * 4;
+    const bool do_q = act && kind != 0 && k_cache != nullptr;
+    if constexpr (!TAB)
+    {
+        const int pos = positions[row];
+        const int page_idx = pos / page_size;
+        token_pos = k_cache ? (int64_t) block_table[row * bps + page_idx] * page_size + (pos % page_size) : 0;
+    }
+    const int groups_per_token = a_hkv * 4;
     const int64_t gbase = token_pos * groups_per_token + hi * 4 + (l >> 3);
     {
         float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
-        kv_quant_regs<KB>(v0, v1, v2, v3, a.k_cache ? a.k_cache + gbase * KB : nullptr, a.k_scales ? a.k_scales + gbase : nullptr, do_q && kind == 1, tid & 63);
-        kv_quant_regs<VB>(v0, v1, v2, v3, a.v_cache ? a.v_cache + gbase * VB : nullptr, a.v_scales ? a.v_scales + gbase : nullptr, do_q && kind == 2, tid & 63);
+        kv_quant_regs<KB>(v0, v1, v2, v3, k_cache ? k_cache + gbase * KB : nullptr, k_scales ? k_scales + gbase : nullptr, do_q && kind == 1, tid & 63);
+        kv_quant_regs<VB>(v0, v1, v2, v3, v_cache ? v_cache + gbase * VB : nullptr, v_scales ? v_scales + gbase : nullptr, do_q && kind == 2, tid & 63);
     }
 }
 
@@ -424,16 +477,21 @@ extern "C" int exl3_glue_norm(const float* y_slabs, int y_S, const float* y_dens
     return exl3_check_launch("glue_norm");
 }
 
-template <int KB>
-static void launch_qkv(int vb, dim3 grid, int threads, hipStream_t st, const QkvArgs& a)
+template <int KB, bool TAB>
+static void launch_qkv_t(int vb, dim3 grid, int threads, hipStream_t st, const QkvArgs& a)
 {
     switch (vb)
     {
-        case 2: glue_qkv_kernel<KB, 2><<<grid, threads, 0, st>>>(a); break; case 3: glue_qkv_kernel<KB, 3><<<grid, threads, 0, st>>>(a); break;
-        case 4: glue_qkv_kernel<KB, 4><<<grid, threads, 0, st>>>(a); break; case 5: glue_qkv_kernel<KB, 5><<<grid, threads, 0, st>>>(a); break;
-        case 6: glue_qkv_kernel<KB, 6><<<grid, threads, 0, st>>>(a); break; case 7: glue_qkv_kernel<KB, 7><<<grid, threads, 0, st>>>(a); break;
-        default: glue_qkv_kernel<KB, 8><<<grid, threads, 0, st>>>(a); break;
+        case 2: glue_qkv_kernel<KB, 2, TAB><<<grid, threads, 0, st>>>(a); break; case 3: glue_qkv_kernel<KB, 3, TAB><<<grid, threads, 0, st>>>(a); break;
+        case 4: glue_qkv_kernel<KB, 4, TAB><<<grid, threads, 0, st>>>(a); break; case 5: glue_qkv_kernel<KB, 5, TAB><<<grid, threads, 0, st>>>(a); break;
+        case 6: glue_qkv_kernel<KB, 6, TAB><<<grid, threads, 0, st>>>(a); break; case 7: glue_qkv_kernel<KB, 7, TAB><<<grid, threads, 0, st>>>(a); break;
+        default: glue_qkv_kernel<KB, 8, TAB><<<grid, threads, 0, st>>>(a); break;
     }
+}
+template <int KB>
+static void launch_qkv(int vb, dim3 grid, int threads, hipStream_t st, const QkvArgs& a)
+{
+    if (a.rope_sin) launch_qkv_t<KB, true>(vb, grid, threads, st, a); else launch_qkv_t<KB, false>(vb, grid, threads, st, a);
 }
 
 // half-wave tasks of the glue kernels are spread over as many CUs as possible: a task's slab lines (S x 512 B) come in at the per-CU load rate, so
@@ -465,6 +523,52 @@ extern "C" int exl3_glue_qkv_rs(const float* sq, const float* sk, const float* s
                                 int page_size, int k_bits, int v_bits, int m, int heads_q, int heads_kv, int head_dim, int rope_mode,
                                 float attn_factor, const float* ss_prev, const float* ss_new, int hidden, float eps, void* stream)
 {
+    return exl3_glue_qkv_tab(sq, sk, sv, S, svh_q, svh_k, svh_v, q_out, k_out, v_out, inv_freq, positions, k_cache, k_scales, v_cache, v_scales,
+                             block_table, blocks_per_seq, page_size, k_bits, v_bits, m, heads_q, heads_kv, head_dim, rope_mode, attn_factor,
+                             ss_prev, ss_new, hidden, eps, nullptr, nullptr, nullptr, stream);
+}
+
+// Per-step tables for exl3_glue_qkv_tab: sin / cos [m][64] fp32 of (position x inverse frequency) x attn_factor -- the same sincosf() values the
+// rope / glue_qkv kernels compute -- and, with a block table, the physical cache row slots[r] = block_table[r][pos / page] * page + pos % page of
+// every token.  One launch per decode step instead of that work in every layer (the reference recomputes it in every rope / cache launch:
+// rope.cu:60-120, q_cache_kernels.cuh:300-318).
+__global__ void qkv_prep_kernel(const float* __restrict__ inv_freq, const int32_t* __restrict__ positions, float attn_factor, int m, int nfreq,
+                                const int32_t* __restrict__ block_table, int blocks_per_seq, int page_size,
+                                float* __restrict__ sin_out, float* __restrict__ cos_out, int64_t* __restrict__ slots)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * 64) return;
+    const int r = i >> 6, f = i & 63;
+    const int pos = positions[r];
+    if (f < nfreq)
+    {
+        float sn, cs;
+        sincosf(inv_freq[f] * (float) pos, &sn, &cs);
+        sin_out[i] = sn * attn_factor; cos_out[i] = cs * attn_factor;
+    }
+    if (f == 0 && slots && block_table) slots[r] = (int64_t) block_table[r * blocks_per_seq + pos / page_size] * page_size + (pos % page_size);
+}
+
+extern "C" int exl3_qkv_prep(const float* inv_freq, const int32_t* positions, float attn_factor, int m, int head_dim, const int32_t* block_table,
+                             int blocks_per_seq, int page_size, float* sin_out, float* cos_out, int64_t* slots, void* stream)
+{
+    EXL3_CHECK_ARG(inv_freq && positions && sin_out && cos_out && m >= 1, "qkv_prep: bad arguments");
+    EXL3_CHECK_ARG(head_dim == 128 || head_dim == 64, "qkv_prep: head_dim must be 128 or 64");
+    EXL3_CHECK_ARG(!slots || (block_table && page_size > 0 && blocks_per_seq > 0), "qkv_prep: slots need the block table");
+    qkv_prep_kernel<<<(m * 64 + 255) / 256, 256, 0, (hipStream_t) stream>>>(inv_freq, positions, attn_factor, m, head_dim / 2, block_table, blocks_per_seq,
+                                                                          page_size, sin_out, cos_out, slots);
+    return exl3_check_launch("qkv_prep");
+}
+
+// exl3_glue_qkv_rs with the per-step tables of exl3_qkv_prep (rope_sin / rope_cos [m][64] fp32, slots int64 [m]; all null: computed in the kernel)
+extern "C" int exl3_glue_qkv_tab(const float* sq, const float* sk, const float* sv, int S, const void* svh_q, const void* svh_k, const void* svh_v,
+                                 void* q_out, void* k_out, void* v_out, const float* inv_freq, const int32_t* positions,
+                                 void* k_cache, void* k_scales, void* v_cache, void* v_scales, const int32_t* block_table, int blocks_per_seq,
+                                 int page_size, int k_bits, int v_bits, int m, int heads_q, int heads_kv, int head_dim, int rope_mode,
+                                 float attn_factor, const float* ss_prev, const float* ss_new, int hidden, float eps,
+                                 const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream)
+{
+    EXL3_CHECK_ARG((!rope_sin && !rope_cos && !slots) || (rope_sin && rope_cos && (slots || !k_cache)), "glue_qkv_tab: sin, cos and (with a cache) slots go together");
     EXL3_CHECK_ARG(!ss_new || (ss_prev && hidden > 0 && hidden % 128 == 0), "glue_qkv_rs: rescale needs ss_prev and hidden");
     EXL3_CHECK_ARG(sq && sk && sv && svh_q && svh_k && svh_v && q_out && inv_freq && positions, "glue_qkv: null pointer");
     EXL3_CHECK_ARG(head_dim == 128 || head_dim == 64, "glue_qkv: head_dim must be 128 or 64 (one or two heads per Hadamard block)");
@@ -482,8 +586,10 @@ extern "C" int exl3_glue_qkv_rs(const float* sq, const float* sk, const float* s
     a.block_table = block_table; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size > 0 ? page_size : 256;
     a.m = m; a.hq = heads_q * head_dim / 128; a.hkv = heads_kv * head_dim / 128; a.hd = head_dim; a.rope_mode = rope_mode; a.attn_factor = attn_factor;
     a.rs = GemvRescale{ ss_prev, ss_new, hidden, eps };
+    a.rope_sin = rope_sin; a.rope_cos = rope_cos; a.slots = slots;
     int tasks = m * (a.hq + 2 * a.hkv);
     const int th = glue_threads(tasks), tpw = th / 32;
+    a.tpw = tpw; a.magic_heads = gemv_magic((uint32_t) (a.hq + 2 * a.hkv));
     dim3 grid((tasks + tpw - 1) / tpw);
     hipStream_t st = (hipStream_t) stream;
     int kb = k_cache ? k_bits : 8, vb = k_cache ? v_bits : 8;
@@ -549,8 +655,12 @@ extern "C" int exl3_glue_resid(const float* y_slabs, int y_S, const float* y_den
     SlabRef y = { y_slabs, y_S };
     const int tasks = m * (hidden / 128);
     const int th = glue_threads(tasks), tpw = th / 32;
-    glue_resid_kernel<false><<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(y.base, y.S, (y_slabs || y_dense) ? 1 : 0, y_dense, (const half_t*) svh,
-                                                                               (const half_t*) bias, (half_t*) resid, ss_part, m, hidden, ResidRotate{});
+    ResidArgs ra;
+    memset((void*) &ra, 0, sizeof(ra));
+    ra.y_base = y.base; ra.y_dense = y_dense; ra.svh = (const half_t*) svh; ra.bias = (const half_t*) bias; ra.resid = (half_t*) resid; ra.ss_part = ss_part;
+    ra.y_S = y.S; ra.has_y = (y_slabs || y_dense) ? 1 : 0; ra.m = m; ra.hidden = hidden; ra.nblk = hidden / 128; ra.tpw = tpw;
+    ra.magic_nblk = gemv_magic((uint32_t) (hidden / 128));
+    glue_resid_kernel<false><<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(ra);
     return exl3_check_launch("glue_resid");
 }
 
@@ -578,8 +688,13 @@ extern "C" int exl3_glue_resid_rotate(const float* y_slabs, int y_S, const float
     SlabRef y = { y_slabs, y_S };
     const int tasks = m * (hidden / 128);
     const int th = glue_threads(tasks), tpw = th / 32;
-    glue_resid_kernel<true><<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(y.base, y.S, 1, y_dense, (const half_t*) svh, (const half_t*) bias,
-                                                                              (half_t*) resid, ss_new, m, hidden, rot);
+    ResidArgs ra;
+    memset((void*) &ra, 0, sizeof(ra));
+    ra.y_base = y.base; ra.y_dense = y_dense; ra.svh = (const half_t*) svh; ra.bias = (const half_t*) bias; ra.resid = (half_t*) resid; ra.ss_part = ss_new;
+    ra.y_S = y.S; ra.has_y = 1; ra.m = m; ra.hidden = hidden; ra.nblk = hidden / 128; ra.tpw = tpw;
+    ra.magic_nblk = gemv_magic((uint32_t) (hidden / 128));
+    ra.rot = rot;
+    glue_resid_kernel<true><<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(ra);
     return exl3_check_launch("glue_resid_rotate");
 }
 

@@ -720,7 +720,10 @@ def glue_norm(y_slab: int | None, y_S: int, svh, bias, resid, w, eps: float, suh
 
 def glue_qkv(slabs, S: int, svh_q, svh_k, svh_v, q_out, k_out, v_out, inv_freq, positions, k_cache, k_scales, v_cache, v_scales,
              block_table, page_size: int, k_bits: int, v_bits: int, m: int, heads_q: int, heads_kv: int, head_dim: int,
-             rope_mode: int = 2, attn_factor: float = 1.0):
+             rope_mode: int = 2, attn_factor: float = 1.0, tab=None):
+    if tab is not None:
+        return glue_qkv_rs(slabs, S, svh_q, svh_k, svh_v, q_out, k_out, v_out, inv_freq, positions, k_cache, k_scales, v_cache, v_scales,
+                           block_table, page_size, k_bits, v_bits, m, heads_q, heads_kv, head_dim, None, None, 0, 0.0, rope_mode, attn_factor, tab)
     _dev(q_out)
     _check(_lib.lib().exl3_glue_qkv(slabs[0], slabs[1], slabs[2], S, _p(svh_q), _p(svh_k), _p(svh_v), _p(q_out), _p(k_out), _p(v_out),
                                     _p(inv_freq), _p(positions), _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table),
@@ -730,13 +733,25 @@ def glue_qkv(slabs, S: int, svh_q, svh_k, svh_v, q_out, k_out, v_out, inv_freq, 
 
 def glue_qkv_rs(slabs, S: int, svh_q, svh_k, svh_v, q_out, k_out, v_out, inv_freq, positions, k_cache, k_scales, v_cache, v_scales,
                 block_table, page_size: int, k_bits: int, v_bits: int, m: int, heads_q: int, heads_kv: int, head_dim: int,
-                ss_prev, ss_new, hidden: int, eps: float, rope_mode: int = 2, attn_factor: float = 1.0):
-    """glue_qkv for slabs written by exl3_gemv_ex_resid: q, k, v are multiplied by rsqrt(ms_new + eps) / rsqrt(ms_prev + eps) of their row."""
+                ss_prev, ss_new, hidden: int, eps: float, rope_mode: int = 2, attn_factor: float = 1.0, tab=None):
+    """glue_qkv for slabs written by exl3_gemv_ex_resid: q, k, v are multiplied by rsqrt(ms_new + eps) / rsqrt(ms_prev + eps) of their row.
+    tab = (sin, cos, slots) of qkv_prep: the kernel reads the per-step tables instead of computing sin / cos and the cache row itself."""
     _dev(q_out)
-    _check(_lib.lib().exl3_glue_qkv_rs(slabs[0], slabs[1], slabs[2], S, _p(svh_q), _p(svh_k), _p(svh_v), _p(q_out), _p(k_out), _p(v_out),
-                                       _p(inv_freq), _p(positions), _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table),
-                                       block_table.shape[1] if block_table is not None else 0, page_size, k_bits, v_bits, m, heads_q, heads_kv,
-                                       head_dim, rope_mode, float(attn_factor), _p(ss_prev), _p(ss_new), int(hidden), float(eps), _stream(q_out)))
+    sn, cs, sl = tab if tab is not None else (None, None, None)
+    _check(_lib.lib().exl3_glue_qkv_tab(slabs[0], slabs[1], slabs[2], S, _p(svh_q), _p(svh_k), _p(svh_v), _p(q_out), _p(k_out), _p(v_out),
+                                        _p(inv_freq), _p(positions), _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table),
+                                        block_table.shape[1] if block_table is not None else 0, page_size, k_bits, v_bits, m, heads_q, heads_kv,
+                                        head_dim, rope_mode, float(attn_factor), _p(ss_prev), _p(ss_new), int(hidden), float(eps),
+                                        _p(sn), _p(cs), _p(sl), _stream(q_out)))
+
+
+def qkv_prep(inv_freq, positions, head_dim: int, block_table, page_size: int, sin_out, cos_out, slots, attn_factor: float = 1.0):
+    """Per-step tables for glue_qkv(tab=...): sin / cos (m, 64) fp32 and the cache row (int64 (m,)) of every token of the step."""
+    _dev(sin_out)
+    _req(sin_out.dtype == torch.float and cos_out.dtype == torch.float and sin_out.shape == cos_out.shape and sin_out.shape[-1] == 64, "qkv_prep: sin / cos must be (m, 64) float32")
+    _req(slots is None or (slots.dtype == torch.long and block_table is not None and block_table.dtype == torch.int32), "qkv_prep: slots must be int64 and need an int32 block table")
+    _check(_lib.lib().exl3_qkv_prep(_p(inv_freq), _p(positions), float(attn_factor), positions.shape[0], int(head_dim), _p(block_table),
+                                    block_table.shape[1] if block_table is not None else 0, int(page_size), _p(sin_out), _p(cos_out), _p(slots), _stream(sin_out)))
 
 
 def glue_act(slabs, S: int, svh_g, svh_u, suh_d, xh_d, xsum_d, m: int, a_out=None):

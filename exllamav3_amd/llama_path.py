@@ -287,6 +287,7 @@ class SyntheticEXL3Llama:
         self.attn_ws = torch.empty((bsz * self.hq * ((pos + 32) // 32) * 132,), dtype=f32, device=dev)
         self.rope_sin = torch.empty((bsz, 64), dtype=f32, device=dev)
         self.rope_cos = torch.empty((bsz, 64), dtype=f32, device=dev)
+        self.kv_slots = torch.empty((bsz,), dtype=torch.long, device=dev)
         self.xs_d = torch.empty((bsz, nb_i), dtype=f32, device=dev)
         self._state_bsz = bsz
 
@@ -352,6 +353,16 @@ class SyntheticEXL3Llama:
     #: forced split-k factor per call type of the fused pipelines (0 = library heuristic); tools/sweep_split.py tunes these
     split = {"qkv": 0, "o": 0, "gu": 0, "down": 0}
 
+    #: per-step sin / cos / cache-row tables for glue_qkv (ext.qkv_prep: one launch per step; False = every layer's glue_qkv computes them itself)
+    use_qkv_tab = True
+
+    def _qkv_tab(self):
+        """Launches ext.qkv_prep for this step's positions / block table and returns glue_qkv's `tab` argument (None when switched off)."""
+        if not self.use_qkv_tab:
+            return None
+        ext.qkv_prep(self.inv_freq, self.positions, self.shape.head_dim, self.block_table, self.page, self.rope_sin, self.rope_cos, self.kv_slots)
+        return (self.rope_sin, self.rope_cos, self.kv_slots)
+
     #: batches above 4 rows, one rank: glue_resid also rotates the new residual for its consumers (ext.glue_resid_rotate: 8 launches per layer
     #: instead of 10); False = separate glue_resid + glue_rotate launches (the reference's rounding point of the normalised activation)
     fold_rotate = True
@@ -368,6 +379,7 @@ class SyntheticEXL3Llama:
         q2 = self.q.view(bsz, -1)
         hidden = self.shape.hidden
         ss_c, ss_o = self.ss, self.ss2                                    # sums of squares of the current residual / the other buffer
+        tab = self._qkv_tab()
         ext.glue_resid(None, 0, None, None, x, ss_c, bsz)
         L0 = self.layers[0]
         ext.glue_rotate(x, ss_c, L0["norm1"], self.eps, [L0["q"].suh, L0["k"].suh, L0["v"].suh], self.xh3, bsz)
@@ -380,7 +392,7 @@ class SyntheticEXL3Llama:
                                         bsz, lq.mcg, lq.mul1, ROT | DEF, sp["qkv"])
             ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
                             self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd,
-                            rs[0] if rs else None, rs[1] if rs else None, hidden, self.eps)
+                            rs[0] if rs else None, rs[1] if rs else None, hidden, self.eps, tab=tab)
             o_in = q2
             if self.with_attention and hd in (64, 128):
                 ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
@@ -421,6 +433,7 @@ class SyntheticEXL3Llama:
         rot = bsz > int(os.environ.get("EXL3_HIP_ROTATE_ABOVE", "4"))
         if rot and self.fold_rotate and self.tp == 1 and all(_same_kind(L["q"], L["k"], L["v"]) and _same_kind(L["gate"], L["up"]) for L in self.layers):
             return self._decode_step_fused_folded()
+        tab = self._qkv_tab()
         ext.glue_resid(None, 0, None, None, x, ss, bsz)
         for li, L in enumerate(self.layers):
             lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
@@ -441,7 +454,7 @@ class SyntheticEXL3Llama:
                     slabs, S = ext.exl3_gemv_ex_norm(x, L["norm1"], ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh],
                                                      None, bsz, lq.mcg, lq.mul1, DEF, sp["qkv"])
                 ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
-                             self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd)
+                             self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, tab=tab)
             # attention core: out of the benchmark's scope by default (attention output := q); with_attention runs the
             # quant-cache-direct decode attention over the cached context (the K/V pages hold whatever the cache holds: zeros here except the
             # appended token, which is enough for timing and for the parity test that fills the cache first)
@@ -512,6 +525,7 @@ class SyntheticEXL3Llama:
         xc, xa, sc, sa = self.x, self.x2, self.ss, self.ss2               # current / alternate residual + sums of squares
         xc.copy_(self.x0)
         q2 = self.q.view(bsz, -1)
+        tab = self._qkv_tab()
         ext.glue_resid(None, 0, None, None, xc, sc, bsz)                  # sums of squares of the embedding row(s)
         pend = None                                                        # (slab, S, svh) of the down_proj whose output is not yet in the residual
         # (column blocks per workgroup, k-slices) of the wave-per-column-block launches; tools/sweep_resid.py tunes these
@@ -525,12 +539,12 @@ class SyntheticEXL3Llama:
                 slabs, S = ext.exl3_gemv_ex_norm(xc, L["norm1"], sc, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh],
                                                  None, bsz, lq.mcg, lq.mul1, DEF, sp["qkv"])
                 ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
-                             self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd)
+                             self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, tab=tab)
             else:
                 slabs, S = ext.exl3_gemv_ex_resid(xc, L["norm1"], sc, self.eps, pend[0], pend[1], pend[2], xa, sa,
                                                   [lq.trellis, lk.trellis, lv.trellis], [lq.suh, lk.suh, lv.suh], bsz, lq.mcg, lq.mul1, wq[1], wq[0])
                 ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
-                                self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, sa, hidden, self.eps)
+                                self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, sa, hidden, self.eps, tab=tab)
                 xc, xa, sc, sa = xa, xc, sa, sc
             o_in = q2
             if self.with_attention and hd in (64, 128):

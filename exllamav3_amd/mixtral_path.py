@@ -111,6 +111,8 @@ class SyntheticEXL3Mixtral:
         self.logits = torch.empty((bsz, self.vocab_local), dtype=f16, device=dev)
         self.attn_pos = pos
         self.attn_out = torch.empty((bsz, self.hq, hd), dtype=f16, device=dev)
+        self.rope_sin = torch.empty((bsz, 64), dtype=f32, device=dev); self.rope_cos = torch.empty((bsz, 64), dtype=f32, device=dev)
+        self.kv_slots = torch.empty((bsz,), dtype=torch.long, device=dev)
         self.attn_lens = torch.full((bsz,), pos + 1, dtype=torch.int32, device=dev)
         self.attn_ws = torch.empty((bsz * self.hq * ((pos + 32) // 32) * 132,), dtype=f32, device=dev)
         for L in self.layers:
@@ -125,6 +127,8 @@ class SyntheticEXL3Mixtral:
         x.copy_(self.x0)
         DEF = ext.GEMV_OUT_DEFERRED
         q2 = self.q.view(bsz, -1)
+        ext.qkv_prep(self.inv_freq, self.positions, hd, self.block_table, self.page, self.rope_sin, self.rope_cos, self.kv_slots)
+        tab = (self.rope_sin, self.rope_cos, self.kv_slots)
         ext.glue_resid(None, 0, None, None, x, ss, bsz)
         for li, L in enumerate(self.layers):
             lq, lk, lv, lo, moe = L["q"], L["k"], L["v"], L["o"], L["moe"]
@@ -133,7 +137,7 @@ class SyntheticEXL3Mixtral:
             slabs, S = ext.exl3_gemv_ex_norm(x, L["norm1"], ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh], None,
                                              bsz, lq.mcg, lq.mul1, DEF)
             ext.glue_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
-                         self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd)
+                         self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, tab=tab)
             o_in = q2                                                  # attention core out of the default scope, as in llama_path
             if self.with_attention:
                 ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,

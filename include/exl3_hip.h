@@ -231,6 +231,18 @@ int exl3_glue_qkv_rs(const float* sq, const float* sk, const float* sv, int S, c
 int exl3_gemv_ex_act(const float* g_slabs, const float* u_slabs, int act_S, const void* svh_g, const void* svh_u,
                      const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
                      int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream);
+/* Per-step tables for exl3_glue_qkv_tab (every layer of a decode step shares positions and block table): sin / cos [m][64] fp32 of
+ * position x inv_freq (x attn_factor; head_dim / 2 entries per row used) and slots[r] = the physical row of token r in the paged cache.
+ * exl3_glue_qkv_tab = exl3_glue_qkv_rs reading them instead of building its own sin / cos table and walking positions -> block_table in every
+ * layer (rope.cu:60-120, q_cache_kernels.cuh:300-318 do that per launch); rope_sin == rope_cos == slots == NULL: identical to exl3_glue_qkv_rs. */
+int exl3_qkv_prep(const float* inv_freq, const int32_t* positions, float attn_factor, int m, int head_dim, const int32_t* block_table,
+                  int blocks_per_seq, int page_size, float* sin_out, float* cos_out, int64_t* slots, void* stream);
+int exl3_glue_qkv_tab(const float* sq, const float* sk, const float* sv, int S, const void* svh_q, const void* svh_k, const void* svh_v,
+                      void* q_out, void* k_out, void* v_out, const float* inv_freq, const int32_t* positions,
+                      void* k_cache, void* k_scales, void* v_cache, void* v_scales, const int32_t* block_table, int blocks_per_seq,
+                      int page_size, int k_bits, int v_bits, int m, int heads_q, int heads_kv, int head_dim, int rope_mode,
+                      float attn_factor, const float* ss_prev, const float* ss_new, int hidden, float eps,
+                      const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream);
 /* ---- batches above 4 rows: exl3_glue_resid + exl3_glue_rotate in one launch (8 launches per Llama layer instead of 10) --------------------------
  * resid += y (pending slabs + svh, or a dense fp32 tensor); ss_new [m][hidden/128] = block sums of squares of the new residual;
  * xh_i = had128(fp16(resid_new * w * r_prev) * suh_i) for up to 3 consumers, r_prev = rsqrt(mean(ss_prev) + eps) of the PREVIOUS residual

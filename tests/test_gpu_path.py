@@ -774,6 +774,30 @@ def test_resid_in_gemv_pipeline_with_large_residual_scale_change(dev):
     assert np.abs(lr - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
 
 
+@pytest.mark.parametrize("hd,hq,hkv", [(128, 4, 2), (64, 8, 4)])
+@pytest.mark.parametrize("bsz", [1, 3, 16])
+def test_per_step_rope_and_slot_tables_are_bit_identical_to_in_kernel_computation(dev, hd, hq, hkv, bsz):
+    """glue_qkv with the per-step tables of qkv_prep (sin / cos / cache row computed once per decode step) against the same kernel computing
+    them per layer: logits, q and every quantized KV page bit for bit, at a position that crosses into the second page."""
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 512, 1024, 2, hq, hkv, hd, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(bsz, pos=300)
+    outs = []
+    for use in (False, True):
+        model.use_qkv_tab = use
+        for c, s in model.kcache + model.vcache:
+            c.zero_(); s.zero_()
+        model.q.zero_()
+        lg = model.decode_step_fused().clone()
+        outs.append((lg, model.q.clone(), [(c.clone(), s.clone()) for c, s in model.kcache + model.vcache]))
+    (l0, q0, kv0), (l1, q1, kv1) = outs
+    assert torch.equal(l0, l1) and torch.equal(q0, q1)
+    assert any(bool(c.any()) for c, _ in kv1)
+    for (c0, s0), (c1, s1) in zip(kv0, kv1):
+        assert torch.equal(c0, c1) and torch.equal(s0, s1)
+
+
 @pytest.mark.parametrize("cb", [0, 2])
 @pytest.mark.parametrize("bsz", [5, 16])
 def test_folded_resid_rotate_pipeline_matches_oracle_and_separate_launches(dev, cb, bsz):
