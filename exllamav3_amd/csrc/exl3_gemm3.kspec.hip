@@ -64,20 +64,29 @@ void exl3_gemm3_kernel(const GemvArgs a)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int m = a.m;
-    const int s = blockIdx.x % a.S;
-    const int cbg = blockIdx.x / a.S;
+    // one batch of scalar loads for the whole prologue, matrix records prefetched, (k-slice, column block) from a 2-D grid, multiply-high
+    // instead of runtime divisions: see the prologue of exl3_gemv2.kspec.hip
+    const int m = a.m, a_S = a.S, a_k = a.k, a_kslice = a.kslice, a_chb = a.chunk_blocks, a_nm = a.num_mats;
+    const int a_cbf[GEMV_MAX_MATS] = { 0, a.cbf[0], a.cbf[1], a.cbf[2] };
+    const uint32_t mg_m = a.magic_m;
+    const half_t* const a_A = a.A;
+    {
+        const void* t0 = a.mat[0].B; const void* t1 = a.mat[1].B; const void* t2 = a.mat[2].B; const void* t3 = a.mat[3].B; const void* t4 = a.mat[3].xsum;
+        asm volatile("" :: "s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4));
+    }
+    const int s = blockIdx.x;
+    const int cbg = blockIdx.y;
     int mi = 0;
     #pragma unroll
-    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a.num_mats && cbg >= a.mat[i].cb_first) mi = i;
+    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a_nm && cbg >= a_cbf[i]) mi = i;
     const uint32_t* __restrict__ Bm = a.mat[mi].B;
     const half_t* __restrict__ suh = a.mat[mi].suh;
     const int n = a.mat[mi].n, cbl = cbg - a.mat[mi].cb_first, ws_off = a.mat[mi].ws_offset;
     const int tiles_n = n >> 4;
-    const int k0s = s * a.kslice;
-    const int k1s = min(k0s + a.kslice, a.k);
+    const int k0s = s * a_kslice;
+    const int k1s = min(k0s + a_kslice, a_k);
     const int nb = (k1s - k0s) >> 7;                 // Hadamard blocks in the slice; every wave streams all of them
-    const int chb = a.chunk_blocks;
+    const int chb = a_chb;
 
     // LDS carve: [wave-private transpose buffers] [activations of one chunk, row-major fp16]; the S == 1 epilogue reuses it for [m][128] fp32
     const int ldx = chb * 128 + G3_XPAD;
@@ -86,7 +95,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
 
     const int l32 = lane & 31;
     constexpr bool in_rotated = ROT;
-    const half_t* __restrict__ x_src = in_rotated ? a.mat[mi].xh : a.A;
+    const half_t* __restrict__ x_src = in_rotated ? a.mat[mi].xh : a_A;
     const int hwid = tid >> 5, nhw = G3_WAVES * 2;
 
     // decode geometry
@@ -105,9 +114,10 @@ void exl3_gemm3_kernel(const GemvArgs a)
     {
         PrepIn r;
         const int t = min(it * nhw + hwid, cnt * m - 1);
-        const int blk = c0 + t / m, row = t % m;
+        const int tq = gemv_udiv(t, mg_m);
+        const int blk = c0 + tq, row = t - tq * m;
         const size_t kofs = (size_t) k0s + 128 * blk;
-        r.xv = ((const half4_t*) (x_src + (size_t) row * a.k + kofs))[l32];
+        r.xv = ((const half4_t*) (x_src + (size_t) row * a_k + kofs))[l32];
         r.sv = ((const half4_t*) (suh + kofs))[l32];
         return r;
     };
@@ -120,7 +130,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
     {
         const half_t* src0 = x_src + (size_t) k0s + 128 * c0 + 8 * min(cp_piece, cnt * 16 - 1);
         #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = *((const uint4_t*) (src0 + (size_t) min(base + cp_rows * j + cp_rsub, m - 1) * a.k));
+        for (int j = 0; j < 4; ++j) v[j] = *((const uint4_t*) (src0 + (size_t) min(base + cp_rows * j + cp_rsub, m - 1) * a_k));
     };
     auto copy_store = [&] (int cnt, int base, const uint4_t (&v)[4])
     {
@@ -235,7 +245,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
                 const int t = it * nhw + hwid;
                 const bool act = t < ntask;
                 const int tc = min(t, ntask - 1);
-                const int blk_l = tc / m, row = tc % m;
+                const int blk_l = gemv_udiv(tc, mg_m), row = tc - blk_l * m;
                 const half4_t xv = cur.xv * cur.sv;
                 float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
                 had128_f32x4(h0, h1, h2, h3, l32);
@@ -288,7 +298,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
         {
             tstamp[4] = tstamp[3];
             tstamp[5] = __builtin_amdgcn_s_memrealtime();
-            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) blockIdx.x * 8;
+            uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 8;
             for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
             uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             dbg[6] = xcc; dbg[7] = __builtin_amdgcn_s_memtime() - cyc0;

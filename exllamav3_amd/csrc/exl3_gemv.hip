@@ -399,6 +399,10 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             if (chunk > bps) chunk = bps;
             args.chunk_blocks = chunk;
             const size_t lds = exl3_gemm3_lds_bytes(mp, chunk);
+            EXL3_CHECK_ARG(grid.x / (unsigned) S <= 65535u, "exl3_gemm: too many column blocks for one launch");
+            grid = dim3((unsigned) S, grid.x / (unsigned) S);                  // (k-slices, column blocks), as for generation 2 below
+            for (int i = 1; i < GEMV_MAX_MATS; ++i) args.cbf[i - 1] = args.mat[i].cb_first;
+            args.magic_m = gemv_magic((uint32_t) mp);
             switch (K)
             {
                 case 1: exl3_gemm3_launch_k1(cb, mt, grid, lds, st, args); break;
