@@ -1,6 +1,34 @@
-# Round-end profile refresh: rocprofv3 kernel stats of the decode bench at bs 1 and bs 16 (every step under its own timeout).
+# Round-end profile refresh (run on the GPU box: gpurun -- 'bash tools/final_profiles.sh r02'): rocprofv3 kernel stats of the bench configs,
+# each under its own timeout, + a separate PMC pass (FETCH_SIZE only, no tracing) for roofline.traffic.  Results: gpurun_out/final/, copy to profiles/.
+TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
-timeout 150 rocprofv3 --kernel-trace --stats -d $O/bs1 -o out --output-format csv -- python $R/bench.py --no-prefill --no-cpu --steps 20 > $O/bs1.log 2>&1
-timeout 150 rocprofv3 --kernel-trace --stats -d $O/bs16 -o out --output-format csv -- python $R/bench.py --batch 16 --no-prefill --no-cpu --steps 20 > $O/bs16.log 2>&1
-rm -f $O/*/out_kernel_trace.csv
-ls $O $O/bs1 $O/bs16; grep "^{" $O/bs1.log | cut -c1-160; grep "^{" $O/bs16.log | cut -c1-160
+run() { # name, bench args...
+  n=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/$n -o out --output-format csv -- python $R/bench.py --no-extra --no-cpu "$@" > $O/${TAG}_bench_${n}_under_rocprof.json 2> $O/$n.err
+  cp $O/$n/out_kernel_stats.csv $O/${TAG}_bench_${n}_kernel_stats.csv 2>/dev/null
+  rm -rf $O/$n
+}
+run bs1 --no-prefill --steps 20
+run bs16 --batch 16 --no-prefill --steps 20
+run mixtral --model mixtral-8x7b --steps 10
+run prefill --steps 5
+# PMC pass: eager launches (one dispatch record per kernel), FETCH_SIZE in KiB, x2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md)
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc -o out --output-format csv -- python $R/bench.py --no-extra --no-cpu --no-prefill --steps 3 --warmup 1 --no-graph > $O/pmc.log 2>&1
+python - <<PY
+import csv, glob, json
+rows = []
+for f in glob.glob("$O/pmc/*counter_collection.csv"):
+    rows += list(csv.DictReader(open(f)))
+g = [r for r in rows if "exl3_gemv2_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == "FETCH_SIZE"]
+if g:
+    per = sum(float(r["Counter_Value"]) for r in g) / len(g) * 1024 * 2
+    json.dump({"kernel": "exl3_gemv2_kernel<4,2,1,1,*> (all launches of the decode step, Llama-3.1-8B 4bpw mul1, bs=1)", "fetch_bytes_per_launch": int(per),
+               "launches_sampled": len(g), "method": "rocprofv3 --pmc FETCH_SIZE (own pass, no tracing) on bench.py --steps 3 --warmup 1 --no-graph; FETCH_SIZE is KiB and reads 1/2 of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section): x1024 x2 applied; average over all gemv2 dispatches (includes the gate/up slab reads of the ACT-mode down_proj and the residual / scale vectors)"},
+              open("$O/traffic.json", "w"), indent=1)
+    print("traffic bytes/launch", int(per), "over", len(g))
+else:
+    print("no PMC rows", len(rows), [r for r in rows[:2]])
+PY
+rm -rf $O/pmc
+timeout 300 python $R/bench.py > $O/${TAG}_bench_default.json 2> $O/default.err
+ls $O; for f in $O/${TAG}_bench_*_under_rocprof.json $O/${TAG}_bench_default.json; do echo $f; grep "^{" $f | cut -c1-200; done
