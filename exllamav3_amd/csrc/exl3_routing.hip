@@ -8,16 +8,52 @@
 #define ROUTING_MAX_EXPERTS 512
 #define ROUTING_MAX_K 16
 
+// NORM: `hidden` is the fp16 RESIDUAL stream and the router input is its RMSNorm, xn = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)), with the
+// row's mean square taken from the per-block sums of squares the residual kernel left behind (ss_part [rows][H/128], the same fixed-order sum the
+// GEMV_IN_NORM launches use).  The workgroup forms xn once (LDS, dynamic: H halves), writes it to xn_out for the expert launches and routes on it:
+// the rms_norm launch in front of a MoE block disappears (modules/block_sparse_mlp.py:1099-1130 runs norm, router and experts as separate ops).
+struct RoutingNorm { const half_t* norm_w; const float* ss_part; half_t* xn_out; float eps; };
+
+template <bool NORM>
 __global__ __launch_bounds__(256)
 void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restrict__ gate, const half_t* __restrict__ bias,
                         half_t* __restrict__ scores, int64_t* __restrict__ topk_indices, half_t* __restrict__ topk_weights,
-                        int H, int E, int K, int64_t* __restrict__ gu_slots, int rows)
+                        int H, int E, int K, int64_t* __restrict__ gu_slots, int rows, RoutingNorm nrm)
 {
+    extern __shared__ __attribute__((aligned(16))) char dyn_s[];
     __shared__ float logit_s[ROUTING_MAX_EXPERTS];
     __shared__ float sel_logit[ROUTING_MAX_K];
     __shared__ int sel_idx[ROUTING_MAX_K];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const half_t* x = hidden + (size_t) row * H;
+    const half_t* xg = hidden + (size_t) row * H;
+    half_t* xn_s = (half_t*) dyn_s;
+    // the router input, element h: global memory (plain) or the normalised row in LDS (NORM, valid after form_xn())
+    auto xin = [&] (int h) -> half_t { if constexpr (NORM) return xn_s[h]; else return xg[h]; };
+    auto form_xn = [&] ()
+    {
+        if constexpr (NORM)
+        {
+            const int nblk = H >> 7, l32 = tid & 31;
+            float s2 = 0.0f;
+            for (int b0 = 0; b0 < nblk; b0 += 32)
+            {
+                float v = (b0 + l32 < nblk) ? nrm.ss_part[(size_t) row * nblk + b0 + l32] : 0.0f;
+                #pragma unroll
+                for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
+                s2 += v;
+            }
+            const float rmf = __frsqrt_rn(s2 / (float) H + nrm.eps);
+            for (int c = tid; c < (H >> 2); c += 256)
+            {
+                const half4_t xv = ((const half4_t*) xg)[c], wv = ((const half4_t*) nrm.norm_w)[c];
+                const half4_t o = { f2h((float) xv.x * (float) wv.x * rmf), f2h((float) xv.y * (float) wv.y * rmf),
+                                    f2h((float) xv.z * (float) wv.z * rmf), f2h((float) xv.w * (float) wv.w * rmf) };
+                ((half4_t*) xn_s)[c] = o;
+                ((half4_t*) (nrm.xn_out + (size_t) row * H))[c] = o;
+            }
+            __syncthreads();
+        }
+    };
 
     // scores: gate is [H][E] row-major, so a thread reads 8 consecutive experts of one hidden row as ONE 16-byte load.  E a multiple of 8 with
     // E / 8 dividing 256 (8, 16, 32, 64 ... 512 experts): thread t owns expert chunk t % (E / 8) and the hidden rows t / (E / 8) + j * (256 / (E / 8));
@@ -33,11 +69,15 @@ void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restr
         // 8 gate rows per thread in flight at a time (one workgroup reads the whole gate matrix: 64 KB at E = 8; with one load per loop trip
         // the kernel was a chain of 16 memory round trips, 17.8 us)
         int h = tid / nch;
+        bool formed = false;
         for (; h + 7 * rows_per_pass < H; h += 8 * rows_per_pass)
         {
             half8_t g[8]; half_t xs[8];
             #pragma unroll
-            for (int u = 0; u < 8; ++u) { g[u] = *((const half8_t*) (gate + (size_t) (h + u * rows_per_pass) * E + ch * 8)); xs[u] = x[h + u * rows_per_pass]; }
+            for (int u = 0; u < 8; ++u) g[u] = *((const half8_t*) (gate + (size_t) (h + u * rows_per_pass) * E + ch * 8));
+            if (!formed) { form_xn(); formed = true; }                        // NORM: the first batch of gate rows is in flight underneath
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) xs[u] = xin(h + u * rows_per_pass);
             #pragma unroll
             for (int u = 0; u < 8; ++u)
             {
@@ -46,10 +86,11 @@ void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restr
                 for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(xv, (float) g[u][i], acc[i]);
             }
         }
+        if (!formed) form_xn();
         for (; h < H; h += rows_per_pass)
         {
             const half8_t g = *((const half8_t*) (gate + (size_t) h * E + ch * 8));
-            const float xv = (float) x[h];
+            const float xv = (float) xin(h);
             #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(xv, (float) g[i], acc[i]);
         }
@@ -79,10 +120,11 @@ void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restr
     }
     else
     {
+        form_xn();
         for (int e = wave; e < E; e += 4)
         {
             float acc = 0.0f;
-            for (int h = lane; h < H; h += 64) acc = __builtin_fmaf((float) x[h], (float) gate[(size_t) h * E + e], acc);
+            for (int h = lane; h < H; h += 64) acc = __builtin_fmaf((float) xin(h), (float) gate[(size_t) h * E + e], acc);
             #pragma unroll
             for (int i = 1; i < 64; i <<= 1) acc += xor_lane(acc, i);
             if (lane == 0)
@@ -153,7 +195,26 @@ extern "C" int exl3_routing_std_slots(const void* hidden, const void* gate, cons
     EXL3_CHECK_ARG(K >= 1 && K <= ROUTING_MAX_K, "Too many experts per token");
     EXL3_CHECK_ARG(K <= num_experts, "K cannot exceed number of experts");
     if (bsz == 0) return EXL3_OK;
-    routing_std_kernel<<<bsz, 256, 0, (hipStream_t) stream>>>((const half_t*) hidden, (const half_t*) gate, (const half_t*) bias, (half_t*) scores,
-                                                             topk_indices, (half_t*) topk_weights, hidden_size, num_experts, K, gu_slots, bsz);
+    routing_std_kernel<false><<<bsz, 256, 0, (hipStream_t) stream>>>((const half_t*) hidden, (const half_t*) gate, (const half_t*) bias, (half_t*) scores,
+                                                                    topk_indices, (half_t*) topk_weights, hidden_size, num_experts, K, gu_slots, bsz, RoutingNorm{});
     return exl3_check_launch("routing_std");
+}
+
+// exl3_routing_std_slots on the RMSNorm of the residual stream, formed inside the launch (see RoutingNorm): resid fp16 [bsz][hidden], norm_w fp16
+// [hidden], ss_part fp32 [bsz][hidden/128] (exl3_glue_resid), xn_out fp16 [bsz][hidden] receives the normalised rows for the expert launches.
+extern "C" int exl3_routing_std_norm(const void* resid, const void* norm_w, const float* ss_part, float eps, void* xn_out, const void* gate, const void* bias,
+                                     void* scores, int64_t* topk_indices, void* topk_weights, int64_t* gu_slots, int bsz, int hidden_size,
+                                     int num_experts, int K, void* stream)
+{
+    EXL3_CHECK_ARG(resid && norm_w && ss_part && xn_out && gate && scores && topk_indices && topk_weights, "routing_std_norm: null pointer");
+    EXL3_CHECK_ARG(hidden_size % 128 == 0 && hidden_size <= 32768, "routing_std_norm: hidden must be a multiple of 128, at most 32768");
+    EXL3_CHECK_ARG(num_experts >= 1 && num_experts <= ROUTING_MAX_EXPERTS, "Too many experts");
+    EXL3_CHECK_ARG(K >= 1 && K <= ROUTING_MAX_K, "Too many experts per token");
+    EXL3_CHECK_ARG(K <= num_experts, "K cannot exceed number of experts");
+    if (bsz == 0) return EXL3_OK;
+    const RoutingNorm nrm = { (const half_t*) norm_w, ss_part, (half_t*) xn_out, eps };
+    routing_std_kernel<true><<<bsz, 256, (size_t) hidden_size * 2, (hipStream_t) stream>>>((const half_t*) resid, (const half_t*) gate, (const half_t*) bias,
+                                                                                          (half_t*) scores, topk_indices, (half_t*) topk_weights, hidden_size,
+                                                                                          num_experts, K, gu_slots, bsz, nrm);
+    return exl3_check_launch("routing_std_norm");
 }

@@ -918,6 +918,18 @@ def routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_sca
                                              hidden.shape[-1], scores.shape[1], topk_indices.shape[1], _stream(hidden)))
 
 
+def routing_std_norm(resid, norm_w, ss_part, eps: float, xn_out, gate, scores, topk_indices, topk_weights, bias=None, gu_slots=None):
+    """routing_std on rms_norm(resid) formed inside the launch (mean square from ss_part of glue_resid); xn_out receives the normalised rows."""
+    _dev(resid)
+    _req(resid.dtype == torch.half and norm_w.dtype == torch.half and xn_out.dtype == torch.half and gate.dtype == torch.half and scores.dtype == torch.half,
+         "routing_std_norm: resid, norm_w, xn_out, gate, scores must be float16")
+    _req(ss_part.dtype == torch.float and topk_indices.dtype == torch.long and topk_weights.dtype == torch.half, "routing_std_norm: bad dtypes")
+    _req(resid.is_contiguous() and xn_out.is_contiguous() and gate.is_contiguous() and scores.is_contiguous() and xn_out.shape == resid.shape, "routing_std_norm: bad layout")
+    bsz = scores.shape[0]
+    _check(_lib.lib().exl3_routing_std_norm(_p(resid), _p(norm_w), _p(ss_part), float(eps), _p(xn_out), _p(gate), _p(bias), _p(scores), _p(topk_indices),
+                                            _p(topk_weights), _p(gu_slots), bsz, resid.shape[-1], scores.shape[1], topk_indices.shape[1], _stream(resid)))
+
+
 def exl3_gemv_ex_act(gu_slabs, gu_S: int, svh_g, svh_u, B, C, suh, svh, m: int, mcg: bool, mul1: bool, flags: int = 0, force_split: int = 0,
                      c_fp32: bool = False):
     """down_proj fed by the gate / up launch's deferred slabs (gu_slabs = [gate ptr, up ptr] as returned by exl3_gemv_ex*): silu(g) * u and the

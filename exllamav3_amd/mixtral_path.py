@@ -89,6 +89,7 @@ class SyntheticEXL3Mixtral:
         self.inv_freq = (1.0 / (shape.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(self.device)
         self.eps, self.page, self.max_ctx = 1e-5, 256, max_ctx
         self.with_attention = False
+        self.norm_in_router = True                                     # False: separate rms_norm launch in front of every MoE block
         self._state_bsz = None
 
     def alloc_state(self, bsz: int, pos: int = 1000):
@@ -121,7 +122,7 @@ class SyntheticEXL3Mixtral:
 
     def decode_step(self):
         """One decode step (bsz tokens, one per sequence), graph-capturable.  Per layer: 4 launches for the attention sublayer (+2 with the
-        attention core), rms_norm + router + 3-5 launches for the MoE block, glue_resid (or the fused IPC all-reduce) after each sublayer."""
+        attention core), router (RMSNorm inside) + 3-5 launches for the MoE block, glue_resid (or the fused IPC all-reduce) after each sublayer."""
         bsz, hd, be = self._state_bsz, self.shape.head_dim, self.backend
         x, ss = self.x, self.ss
         x.copy_(self.x0)
@@ -150,8 +151,11 @@ class SyntheticEXL3Mixtral:
                 lo.bc.run(o_in, self.o)
                 be.all_reduce_resid(self.o, x, ss, bsz)
             # sparse-MoE sublayer: xn = rms_norm(x) ; y = sum_k w_k expert_k(xn) (this rank's experts) ; x += all_reduce(y)
-            ext.rms_norm(x, L["norm2"], self.xn, self.eps)
-            y = moe.forward(self.xn)                                   # (bsz, hidden) fp32 view of the block's output buffer
+            if self.norm_in_router:
+                y = moe.forward(self.xn, resid_norm=(x, L["norm2"], ss, self.eps))    # the router launch forms xn = rms_norm(x) from x and ss
+            else:
+                ext.rms_norm(x, L["norm2"], self.xn, self.eps)
+                y = moe.forward(self.xn)                               # (bsz, hidden) fp32 view of the block's output buffer
             if self.tp == 1:
                 ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=y.contiguous() if not y.is_contiguous() else y)
             else:

@@ -96,13 +96,19 @@ class SyntheticEXL3MoE:
         self.d = torch.empty((t * k, 1, self.hidden), dtype=torch.float, device=dev)
         self._state = t
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        """x: (tokens, hidden) fp16 (already normalised).  Returns (tokens, hidden) fp32 = sum_k w_k * expert_k(x)."""
+    def forward(self, x: torch.Tensor, resid_norm=None) -> torch.Tensor:
+        """x: (tokens, hidden) fp16 (already normalised).  Returns (tokens, hidden) fp32 = sum_k w_k * expert_k(x).
+        resid_norm = (resid, norm_w, ss_part, eps): x is an OUTPUT buffer instead -- the router launch forms rms_norm(resid) itself (mean square
+        from the residual kernel's per-block sums), routes on it and leaves it in x for the expert launches (no rms_norm launch)."""
         t, k = x.shape[0], self.top_k
         if self._state != t:
             self.alloc_state(t)
         # the router also leaves the [gate slots | up slots] index list of the one-launch gate|up mgemm (no torch index kernels in between)
-        ext.routing_std(x, self.router, self.scores, self.sel, self.w, gu_slots=self.sel2)
+        if resid_norm is not None:
+            resid, norm_w, ss_part, eps = resid_norm
+            ext.routing_std_norm(resid, norm_w, ss_part, eps, x, self.router, self.scores, self.sel, self.w, gu_slots=self.sel2)
+        else:
+            ext.routing_std(x, self.router, self.scores, self.sel, self.w, gu_slots=self.sel2)
         mcg, mul1 = self.cb == 1, self.cb == 2
         if (self.first, self.last) != (0, self.E):
             return self._forward_expert_parallel(x)

@@ -356,6 +356,12 @@ int exl3_softcap(const void* x, void* y, int64_t numel, float scale, int is_fp32
  * concatenated gate | up pointer tables.  exl3_mgemm_indexed_act: the down launch whose per-slot input is fp16(silu(G_j) * U_j) (silu_mul folded in). */
 int exl3_routing_std_slots(const void* hidden, const void* gate, const void* bias, void* scores, int64_t* topk_indices, void* topk_weights,
                            int64_t* gu_slots, int bsz, int hidden_size, int num_experts, int K, void* stream);
+/* ... on the RMSNorm of the residual stream formed inside the launch: xn = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)), mean square from
+ * ss_part [bsz][hidden/128] (exl3_glue_resid); xn_out receives xn for the expert launches.  Replaces the rms_norm launch + routing of
+ * modules/block_sparse_mlp.py:1099-1130. */
+int exl3_routing_std_norm(const void* resid, const void* norm_w, const float* ss_part, float eps, void* xn_out, const void* gate, const void* bias,
+                          void* scores, int64_t* topk_indices, void* topk_weights, int64_t* gu_slots, int bsz, int hidden_size,
+                          int num_experts, int K, void* stream);
 int exl3_mgemm_indexed_act(const void* G, const void* U, const void* tbl_B, const void* tbl_suh, const void* tbl_svh,
                            const int64_t* indices, const void* weights, int bszm, void* C, int m, int k, int n, int K, int cb, int c_fp32,
                            int min_index, int max_index, int num_tokens, void* stream);

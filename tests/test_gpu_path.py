@@ -514,6 +514,41 @@ def test_moe_block_matches_oracle(dev, cb, tokens):
     assert np.abs(y - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
 
 
+@pytest.mark.parametrize("experts,hidden", [(8, 4096), (6, 384), (64, 1024)])
+@pytest.mark.parametrize("tokens", [1, 3])
+def test_router_with_rmsnorm_inside_matches_norm_then_router(dev, experts, hidden, tokens):
+    """routing_std_norm (RMSNorm of the residual formed inside the router launch, mean square from glue_resid's per-block sums) against the
+    oracle's rms_norm -> routing_std and against the two separate HIP launches: normalised rows to an fp16 ulp (the mean square is summed in
+    another order), same experts, weights within fp16; Mixtral's 4096 x 8, a non-multiple-of-8 expert count (slow path) and 64 experts."""
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(experts + tokens)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x = (rng.standard_normal((tokens, hidden)) * 3).astype(np.float16)
+    w = (1 + 0.1 * rng.standard_normal(hidden)).astype(np.float16)
+    gate = (rng.standard_normal((hidden, experts)) / np.sqrt(hidden)).astype(np.float16)
+    K = 2
+    dx = T(x)
+    ss = torch.empty((tokens, hidden // 128), dtype=torch.float, device=dev)
+    ext.glue_resid(None, 0, None, None, dx, ss, tokens)                       # per-block sums of squares of x (x itself unchanged)
+    xn = torch.empty_like(dx); sc = torch.empty((tokens, experts), dtype=torch.half, device=dev)
+    sel = torch.empty((tokens, K), dtype=torch.long, device=dev); wt = torch.empty((tokens, K), dtype=torch.half, device=dev)
+    slots = torch.empty((2, tokens * K), dtype=torch.long, device=dev)
+    ext.routing_std_norm(dx, T(w), ss, 1e-5, xn, T(gate), sc, sel, wt, gu_slots=slots)
+    xn_ref = o.rms_norm(x, w, 1e-5)
+    got = xn.float().cpu().numpy()
+    assert np.abs(got - xn_ref.astype(np.float32)).max() <= 2e-3 * np.abs(xn_ref.astype(np.float32)).max()
+    # route the oracle on the kernel's own xn (an ulp in xn may flip a near-tie otherwise)
+    scores, sel_ref, w_ref = o.routing_std(xn.cpu().numpy(), gate, K)
+    assert np.abs(sc.float().cpu().numpy() - scores.astype(np.float32)).max() < 2e-3 * max(1.0, float(np.abs(scores).max()))
+    assert np.array_equal(sel.cpu().numpy(), sel_ref)
+    assert np.abs(wt.float().cpu().numpy() - w_ref.astype(np.float32)).max() < 2e-3
+    assert np.array_equal(slots.cpu().numpy(), np.stack([sel_ref.reshape(-1), sel_ref.reshape(-1) + experts]))
+    # the two separate launches on the same xn give the same bits
+    sc2 = torch.empty_like(sc); sel2 = torch.empty_like(sel); wt2 = torch.empty_like(wt)
+    ext.routing_std(xn, T(gate), sc2, sel2, wt2)
+    assert torch.equal(sc, sc2) and torch.equal(sel, sel2) and torch.equal(wt, wt2)
+
+
 def test_fused_step_with_attention_matches_oracle(dev):
     """decode_step_fused(with_attention): q/k/v -> RoPE -> quantized append -> attention over the (pre-filled) quantized cache -> o_proj ...
     against the oracle composition (attention over the dequantized cache)."""
