@@ -135,6 +135,8 @@ def _declare(l):
     sig("exl3_glue_qkv_rs", vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, i32, f32, vp)
     sig("exl3_gemv_ex_act", vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
     sig("exl3_routing_std", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
+    sig("exl3_mgemm_indexed_act_deferred", vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
+    sig("exl3_glue_resid_moe", vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, vp)
     sig("exl3_routing_std_norm", vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
     sig("exl3_routing_std_slots", vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
     sig("exl3_mgemm_indexed_act", vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp)

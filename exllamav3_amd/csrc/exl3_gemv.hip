@@ -233,7 +233,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     const bool in_norm = (flags & GEMV_IN_NORM) != 0;
     EXL3_CHECK_ARG(!in_norm || (norm_w && ss_part && !rotated && m <= 16), "exl3_gemv_ex: GEMV_IN_NORM needs norm_w, ss_part, raw input and m <= 16");
     EXL3_CHECK_ARG(count >= 1 && (tbl || count <= GEMV_MAX_MATS), "exl3_mgemm: between 1 and %d matrices per launch", GEMV_MAX_MATS);
-    EXL3_CHECK_ARG(!tbl || (m <= 16 && !deferred && !rotated && !epi), "exl3_mgemm (indexed): at most 16 rows per slot");
+    EXL3_CHECK_ARG(!tbl || (m <= 16 && !rotated && !epi), "exl3_mgemm (indexed): at most 16 rows per slot");
     EXL3_CHECK_ARG(K >= 1 && K <= 8, "exl3_gemm: K must be in [1, 8]");
     EXL3_CHECK_ARG(cb >= 0 && cb <= 2, "exl3_gemm: bad codebook");
     EXL3_CHECK_ARG(k % 128 == 0 && k > 0, "exl3_gemm: k must be divisible by 128");
@@ -373,6 +373,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             ws_region += ctx->ws_toggle ? EXL3_WS_REGION_BYTES / 4 : 0;
             ctx->ws_toggle ^= 1;
             if (slabs_out) for (int i = 0; i < (tbl ? 0 : count); ++i) slabs_out[i] = ws_region + args.mat[i].ws_offset;
+            if (slabs_out && tbl) slabs_out[0] = ws_region;                // indexed form: [slot][column block][S][m][128]
         }
         if (S_out) *S_out = S;
         args.flags = pass_flags;
@@ -661,6 +662,27 @@ static int mgemm_indexed_impl(const void* A, const void* act_u, int bszm_in, con
         return exl3_check_launch("exl3_mgemm slot reduce") < 0 ? EXL3_ERR_HIP : rc;
     }
     return rc;
+}
+
+// exl3_mgemm_indexed_act with a deferred epilogue: the launch leaves raw rotated-basis split-k slabs [slot][n/128][S][m][128] fp32 (no svh, no
+// routing weights, no slot sum); exl3_glue_resid_moe finishes them together with the residual add.  No expert range (one rank holds all experts).
+extern "C" int exl3_mgemm_indexed_act_deferred(const void* G, const void* U, const void* tbl_B, const void* tbl_suh, const int64_t* indices, int bszm,
+                                               int m, int k, int n, int K, int cb, float** slab_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(G && U && tbl_B && tbl_suh && indices && slab_out && S_out, "exl3_mgemm_indexed_act_deferred: null pointer");
+    EXL3_CHECK_ARG(bszm >= 1 && m >= 1 && m <= 4, "exl3_mgemm_indexed_act_deferred: 1..4 rows per slot");
+    GemvTable t; memset((void*) &t, 0, sizeof(t));
+    t.B = (const uint64_t*) tbl_B; t.suh = (const uint64_t*) tbl_suh; t.svh = nullptr;
+    t.indices = indices; t.weights = nullptr; t.C = nullptr;
+    t.bszm = bszm; t.min_index = -1; t.max_index = -1; t.n = n; t.cbs_per_mat = n / 128;
+    t.a_slot_stride = (int64_t) m * k;
+    t.c_slot_stride = (int64_t) m * n;
+    t.act_u = (const half_t*) U;
+    const void* Bs[1] = { tbl_B }; int ns[1] = { n };
+    const void* su[1] = { tbl_suh };
+    int rc = run_mgemm(G, Bs, nullptr, su, nullptr, nullptr, ns, bszm, m, k, K, cb, 0, 0, (hipStream_t) stream, GEMV_OUT_DEFERRED, nullptr, nullptr, slab_out,
+                       S_out, nullptr, nullptr, nullptr, 0.0f, &t);
+    return rc < 0 ? rc : EXL3_OK;
 }
 
 // down_proj whose input a = fp16(silu(g) * u) is finished from the gate / up launch's deferred slabs while the activation fragments are

@@ -223,6 +223,57 @@ void glue_resid_kernel(const ResidArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// G1m: glue_resid for a MoE block whose weighted down launch was deferred (exl3_mgemm_indexed_act_deferred): per (token, 128-block) half-wave,
+//      y = sum over the token's top_k slots, in slot order from zero, of  had128(sum_s slab) * (1/sqrt(128) * w_slot) * svh[expert of the slot]
+//      (fp32: the arithmetic and order of exl3_gemv_reduce_kernel + mgemm_slot_reduce_kernel, i.e. of the reference's weighted exl3_mgemm,
+//      quant/exl3_gemm_kernel.cuh:241-290), then resid = fp16(resid + y) and the block's sum of squares as in glue_resid.
+//      Replaces the split-k reduce launch, the slot-sum launch and the residual launch behind a MoE block by one.
+// ------------------------------------------------------------------------------------------------
+struct ResidMoeArgs
+{
+    const float* slabs; const uint64_t* tbl_svh; const int64_t* indices; const half_t* weights; half_t* resid; float* ss_part;     // 48 B
+    int S, top_k, tokens, hidden, nblk, tpw; uint32_t magic_nblk; int pad_;
+};
+
+__global__ __launch_bounds__(256)
+void glue_resid_moe_kernel(const ResidMoeArgs a)
+{
+    const float* const slabs = a.slabs; const uint64_t* const tbl_svh = a.tbl_svh; const int64_t* const indices = a.indices;
+    const half_t* const weights = a.weights; half_t* const resid = a.resid; float* const ss_part = a.ss_part;
+    const int S = a.S, top_k = a.top_k, tokens = a.tokens, hidden = a.hidden, nblk = a.nblk, tpw = a.tpw;
+    const uint32_t magic_nblk = a.magic_nblk;
+    const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
+    const int t = blockIdx.x * tpw + hw;
+    const bool act = t < tokens * nblk;
+    const int tt = act ? t : 0;
+    const int row = gemv_udiv(tt, magic_nblk), blk = tt - row * nblk;
+    half4_t r = ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f, y3 = 0.f;
+    for (int j = 0; j < top_k; ++j)
+    {
+        const int slot = row * top_k + j;
+        const int e = (int) indices[slot];
+        const float w = (float) weights[slot];
+        const half4_t sc = ((const half4_t*) ((const half_t*) tbl_svh[e] + blk * 128))[l];
+        const SlabRef sr = { slabs + (size_t) slot * nblk * S * 128, S };     // m = 1 row per slot: [slot][block][S][128]
+        const float4_t v = slab_sum(sr, blk, 0, 1, l);
+        float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
+        had128_f32x4(h0, h1, h2, h3, l);
+        const float os = HAD_R_SCALE_128 * w;
+        h0 *= os; h1 *= os; h2 *= os; h3 *= os;
+        y0 += h0 * (float) sc.x; y1 += h1 * (float) sc.y; y2 += h2 * (float) sc.z; y3 += h3 * (float) sc.w;
+    }
+    r = half4_t{ f2h((float) r.x + y0), f2h((float) r.y + y1), f2h((float) r.z + y2), f2h((float) r.w + y3) };
+    if (act) ((half4_t*) (resid + (size_t) row * hidden + blk * 128))[l] = r;
+    const float r0 = (float) r.x, r1 = (float) r.y, r2 = (float) r.z, r3 = (float) r.w;
+    float ss = r0 * r0;
+    ss = __builtin_fmaf(r1, r1, ss); ss = __builtin_fmaf(r2, r2, ss); ss = __builtin_fmaf(r3, r3, ss);
+    #pragma unroll
+    for (int i = 1; i < 32; i <<= 1) ss += xor_lane(ss, i);
+    if (act && l == 0) ss_part[(size_t) row * nblk + blk] = ss;
+}
+
+// ------------------------------------------------------------------------------------------------
 // G1b: the other half of the norm boundary for batches above 4 rows: per (row, 128-block) half-wave: 1/rms of the row from the per-block
 //      sums of squares (same fixed-order sum as everywhere else) -> x = fp16(resid * w / rms) -> (x * suh_i) input Hadamard for up to 3
 //      consumers.  At m <= 4 the consumer GEMVs do this themselves (GEMV_IN_NORM); at m = 16 that would repeat 16 Hadamards per block
@@ -662,6 +713,23 @@ extern "C" int exl3_glue_resid(const float* y_slabs, int y_S, const float* y_den
     ra.magic_nblk = gemv_magic((uint32_t) (hidden / 128));
     glue_resid_kernel<false><<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(ra);
     return exl3_check_launch("glue_resid");
+}
+
+// glue_resid_moe_kernel: slabs = exl3_mgemm_indexed_act_deferred's output ([tokens * top_k slots][hidden/128][S][128] fp32, one row per slot),
+// tbl_svh = the down projections' svh pointer table, indices / weights = the router's [tokens][top_k] outputs
+extern "C" int exl3_glue_resid_moe(const float* slabs, int S, const void* tbl_svh, const int64_t* indices, const void* weights, int top_k, void* resid,
+                                   float* ss_part, int tokens, int hidden, void* stream)
+{
+    EXL3_CHECK_ARG(slabs && tbl_svh && indices && weights && resid && ss_part, "glue_resid_moe: null pointer");
+    EXL3_CHECK_ARG(S >= 1 && top_k >= 1 && tokens >= 1 && tokens <= 16 && hidden % 128 == 0, "glue_resid_moe: bad dimensions");
+    const int tasks = tokens * (hidden / 128);
+    const int th = glue_threads(tasks), tpw = th / 32;
+    ResidMoeArgs a;
+    memset((void*) &a, 0, sizeof(a));
+    a.slabs = slabs; a.tbl_svh = (const uint64_t*) tbl_svh; a.indices = indices; a.weights = (const half_t*) weights; a.resid = (half_t*) resid; a.ss_part = ss_part;
+    a.S = S; a.top_k = top_k; a.tokens = tokens; a.hidden = hidden; a.nblk = hidden / 128; a.tpw = tpw; a.magic_nblk = gemv_magic((uint32_t) (hidden / 128));
+    glue_resid_moe_kernel<<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(a);
+    return exl3_check_launch("glue_resid_moe");
 }
 
 // glue_resid + glue_rotate in one launch (see glue_resid_kernel ROT): resid += y; ss_new = block sums of squares of the new residual;

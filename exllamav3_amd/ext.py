@@ -918,6 +918,31 @@ def routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_sca
                                              hidden.shape[-1], scores.shape[1], topk_indices.shape[1], _stream(hidden)))
 
 
+def exl3_mgemm_act_deferred(G, U, B, suh, indices, K: int, mcg: int, mul1: int, n: int):
+    """exl3_mgemm_act whose epilogue is deferred: returns (slab address, S) of the raw split-k slabs [bszm][n/128][S][m][128] fp32 for
+    glue_resid_moe (svh, routing weights and the slot sum are applied there)."""
+    _dev(G)
+    _req(G.dtype == torch.half and U.dtype == torch.half and G.shape == U.shape and G.dim() == 3 and G.is_contiguous() and U.is_contiguous(),
+         "exl3_mgemm_act_deferred: G, U must be contiguous float16 [bszm, m, k]")
+    _req(B.dtype == torch.long and suh.dtype == torch.long and indices.dtype == torch.long and indices.is_contiguous(), "exl3_mgemm_act_deferred: int64 tables")
+    bszm, m, k = G.shape
+    _req(indices.numel() >= bszm, "exl3_mgemm_act_deferred: one index per slot")
+    slab = (_vp * 1)()
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_mgemm_indexed_act_deferred(_p(G), _p(U), _p(B), _p(suh), _p(indices), bszm, m, k, int(n), int(K), _cb(bool(mcg), bool(mul1)),
+                                                      slab, ctypes.byref(S), _stream(G)))
+    return int(slab[0]), S.value
+
+
+def glue_resid_moe(slab: int, S: int, svh_table, indices, weights, resid, ss_part, tokens: int):
+    """Finishes a deferred weighted down launch of a MoE block and adds it to the residual stream (see exl3_glue_resid_moe)."""
+    _dev(resid)
+    _req(svh_table.dtype == torch.long and indices.dtype == torch.long and weights.dtype == torch.half and resid.dtype == torch.half, "glue_resid_moe: bad dtypes")
+    _req(indices.is_contiguous() and weights.is_contiguous() and indices.numel() == weights.numel() and indices.numel() % tokens == 0, "glue_resid_moe: bad routing tensors")
+    _check(_lib.lib().exl3_glue_resid_moe(slab, S, _p(svh_table), _p(indices), _p(weights), indices.numel() // tokens, _p(resid), _p(ss_part), tokens,
+                                          resid.shape[-1], _stream(resid)))
+
+
 def routing_std_norm(resid, norm_w, ss_part, eps: float, xn_out, gate, scores, topk_indices, topk_weights, bias=None, gu_slots=None):
     """routing_std on rms_norm(resid) formed inside the launch (mean square from ss_part of glue_resid); xn_out receives the normalised rows."""
     _dev(resid)

@@ -90,6 +90,7 @@ class SyntheticEXL3Mixtral:
         self.eps, self.page, self.max_ctx = 1e-5, 256, max_ctx
         self.with_attention = False
         self.norm_in_router = True                                     # False: separate rms_norm launch in front of every MoE block
+        self.fused_moe_tail = True                                     # one rank: split-k reduce + slot sum + residual add of a MoE block in one launch
         self._state_bsz = None
 
     def alloc_state(self, bsz: int, pos: int = 1000):
@@ -122,7 +123,7 @@ class SyntheticEXL3Mixtral:
 
     def decode_step(self):
         """One decode step (bsz tokens, one per sequence), graph-capturable.  Per layer: 4 launches for the attention sublayer (+2 with the
-        attention core), router (RMSNorm inside) + 3-5 launches for the MoE block, glue_resid (or the fused IPC all-reduce) after each sublayer."""
+        attention core), router (RMSNorm inside) + gate|up + down + one tail launch for the MoE block on one rank (3-5 launches + the fused IPC all-reduce with EP)."""
         bsz, hd, be = self._state_bsz, self.shape.head_dim, self.backend
         x, ss = self.x, self.ss
         x.copy_(self.x0)
@@ -151,12 +152,15 @@ class SyntheticEXL3Mixtral:
                 lo.bc.run(o_in, self.o)
                 be.all_reduce_resid(self.o, x, ss, bsz)
             # sparse-MoE sublayer: xn = rms_norm(x) ; y = sum_k w_k expert_k(xn) (this rank's experts) ; x += all_reduce(y)
+            add_into = (x, ss) if (self.tp == 1 and self.fused_moe_tail and bsz <= 4) else None
             if self.norm_in_router:
-                y = moe.forward(self.xn, resid_norm=(x, L["norm2"], ss, self.eps))    # the router launch forms xn = rms_norm(x) from x and ss
+                y = moe.forward(self.xn, resid_norm=(x, L["norm2"], ss, self.eps), add_into=add_into)    # the router launch forms xn = rms_norm(x) from x and ss
             else:
                 ext.rms_norm(x, L["norm2"], self.xn, self.eps)
-                y = moe.forward(self.xn)                               # (bsz, hidden) fp32 view of the block's output buffer
-            if self.tp == 1:
+                y = moe.forward(self.xn, add_into=add_into)            # (bsz, hidden) fp32 view of the block's output buffer
+            if add_into is not None:
+                pass                                                   # glue_resid_moe already added the block's output to x and refreshed ss
+            elif self.tp == 1:
                 ext.glue_resid(None, 0, None, None, x, ss, bsz, y_dense=y.contiguous() if not y.is_contiguous() else y)
             else:
                 be.all_reduce_resid(y.contiguous() if not y.is_contiguous() else y, x, ss, bsz)

@@ -96,10 +96,12 @@ class SyntheticEXL3MoE:
         self.d = torch.empty((t * k, 1, self.hidden), dtype=torch.float, device=dev)
         self._state = t
 
-    def forward(self, x: torch.Tensor, resid_norm=None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, resid_norm=None, add_into=None):
         """x: (tokens, hidden) fp16 (already normalised).  Returns (tokens, hidden) fp32 = sum_k w_k * expert_k(x).
         resid_norm = (resid, norm_w, ss_part, eps): x is an OUTPUT buffer instead -- the router launch forms rms_norm(resid) itself (mean square
-        from the residual kernel's per-block sums), routes on it and leaves it in x for the expert launches (no rms_norm launch)."""
+        from the residual kernel's per-block sums), routes on it and leaves it in x for the expert launches (no rms_norm launch).
+        add_into = (resid, ss_part) (one rank, all experts local): the weighted down launch is deferred and ONE glue launch finishes it, sums the
+        slots and adds the result to the residual stream (ext.glue_resid_moe) instead of split-k reduce + slot sum + residual add; returns None."""
         t, k = x.shape[0], self.top_k
         if self._state != t:
             self.alloc_state(t)
@@ -122,6 +124,11 @@ class SyntheticEXL3MoE:
             ext.exl3_mgemm(xs, self.gu_B, self.gu[: t * k], self.gu_suh, None, self.gu_svh, self.sel2[0], None, self.K, -1, mcg, mul1, -1, -1, 0)
             ext.exl3_mgemm(xs, self.gu_B, self.gu[t * k:], self.gu_suh, None, self.gu_svh, self.sel2[1], None, self.K, -1, mcg, mul1, -1, -1, 0)
         # down of the routed experts on a = silu(g) * u, formed while the launch builds its activation fragments (no silu_mul launch)
+        if add_into is not None:
+            resid, ss_part = add_into
+            slab, S = ext.exl3_mgemm_act_deferred(self.gu[: t * k], self.gu[t * k:], self.d_B, self.d_suh, self.sel.view(-1), self.K, mcg, mul1, self.hidden)
+            ext.glue_resid_moe(slab, S, self.d_svh, self.sel.view(-1), self.w.view(-1), resid, ss_part, t)
+            return None
         ext.exl3_mgemm_act(self.gu[: t * k], self.gu[t * k:], self.d_B, self.d, self.d_suh, self.d_svh, self.sel.view(-1), self.w.view(-1), self.K,
                            mcg, mul1, -1, -1, num_tokens=t)
         return self.d[:t, 0]

@@ -243,6 +243,16 @@ int exl3_glue_qkv_tab(const float* sq, const float* sk, const float* sv, int S, 
                       int page_size, int k_bits, int v_bits, int m, int heads_q, int heads_kv, int head_dim, int rope_mode,
                       float attn_factor, const float* ss_prev, const float* ss_new, int hidden, float eps,
                       const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream);
+/* ---- MoE block tail in one launch (one rank holds all experts): exl3_mgemm_indexed_act_deferred = the weighted down launch of
+ * exl3_mgemm_indexed_act leaving raw split-k slabs [slot][n/128][S][m][128] (no svh, no routing weight, no slot sum); exl3_glue_resid_moe finishes
+ * them per (token, 128-block) -- out-Hadamard, x (1/sqrt(128) * w_slot) x svh[expert], slots summed in order from zero (the arithmetic of the
+ * reference's weighted exl3_mgemm, quant/exl3_gemm_kernel.cuh:241-290) -- and adds the result to the fp16 residual stream, leaving the per-block
+ * sums of squares for the next norm.  Replaces three launches (split-k reduce, slot sum, residual add). */
+int exl3_mgemm_indexed_act_deferred(const void* G, const void* U, const void* tbl_B, const void* tbl_suh, const int64_t* indices, int bszm,
+                                    int m, int k, int n, int K, int cb, float** slab_out, int* S_out, void* stream);
+int exl3_glue_resid_moe(const float* slabs, int S, const void* tbl_svh, const int64_t* indices, const void* weights, int top_k, void* resid,
+                        float* ss_part, int tokens, int hidden, void* stream);
+
 /* ---- batches above 4 rows: exl3_glue_resid + exl3_glue_rotate in one launch (8 launches per Llama layer instead of 10) --------------------------
  * resid += y (pending slabs + svh, or a dense fp32 tensor); ss_new [m][hidden/128] = block sums of squares of the new residual;
  * xh_i = had128(fp16(resid_new * w * r_prev) * suh_i) for up to 3 consumers, r_prev = rsqrt(mean(ss_prev) + eps) of the PREVIOUS residual

@@ -871,6 +871,33 @@ def test_folded_resid_rotate_pipeline_matches_oracle_and_separate_launches(dev, 
 
 
 @pytest.mark.parametrize("bsz", [1, 3])
+def test_mixtral_fused_moe_tail_and_router_norm_agree_with_separate_launches(dev, bsz):
+    """The one-rank MoE block in 4 launches (router with the RMSNorm inside, gate|up, deferred weighted down, glue_resid_moe) against the same
+    block with separate rms_norm / split-k reduce / slot sum / residual launches: logits and residual stream agree to fp16 rounding (the
+    deferred launch picks another k-split, so the fp32 sums are ordered differently); graph replay reproduces the eager bits."""
+    from exllamav3_amd.mixtral_path import MixtralShape, SyntheticEXL3Mixtral
+    shape = MixtralShape("tiny-moe", 512, 768, 3, 4, 2, 128, 384, 8, 2)
+    model = SyntheticEXL3Mixtral(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=1024)
+    model.alloc_state(bsz, pos=77)
+    model.norm_in_router, model.fused_moe_tail = False, False
+    l0 = model.decode_step().float().cpu().numpy().copy(); x0 = model.x.float().cpu().numpy().copy()
+    model.norm_in_router, model.fused_moe_tail = True, True
+    l1 = model.decode_step().float().cpu().numpy().copy(); x1 = model.x.float().cpu().numpy().copy()
+    rms = np.sqrt((l0 ** 2).mean())
+    assert np.isfinite(l1).all() and np.abs(l1 - l0).max() / rms < 1e-2
+    assert np.abs(x1 - x0).max() / np.sqrt((x0 ** 2).mean()) < 1e-2
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            model.decode_step()
+    for _ in range(2):
+        model.logits.zero_(); g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(model.logits.float().cpu().numpy(), l1)
+
+
+@pytest.mark.parametrize("bsz", [1, 3])
 @pytest.mark.parametrize("with_attention", [False, True])
 def test_mixtral_layer_path_matches_oracle(dev, bsz, with_attention):
     """mixtral_path.SyntheticEXL3Mixtral (config 5's layer: attention sublayer + sparse-MoE sublayer with top-2 routing, 4-bit KV) against the
