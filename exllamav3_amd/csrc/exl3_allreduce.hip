@@ -46,7 +46,10 @@ struct ArArgs
 {
     char* own; char* peer[EXL3_AR_MAX_RANKS];
     int world, rank; size_t max_elems;
-    const float* y;        // this rank's partial sums [m][hidden] fp32
+    const float* y;        // this rank's partial sums [m][hidden] fp32 (null when slabs are given)
+    const float* slabs; int S; const half_t* svh;     // ... or the deferred split-k slabs [hidden/128][S][m][128] of the row-sharded linear that
+                                                      // produced them + its svh: the task finishes them itself (slab sum, out-Hadamard, x svh in
+                                                      // fp32 = exl3_gemv_reduce_kernel's fp32 path) -- no reduce launch in front of the all-reduce
     float* y_out;          // optional: the reduced fp32 tensor (plain all_reduce semantics)
     half_t* resid;         // optional: fp16 residual stream, resid += sum (glue_resid semantics, norm.cu:193-218 rounding)
     float* ss_part;        // optional (with resid): per-128-block sums of squares of the new residual [m][hidden/128]
@@ -82,7 +85,18 @@ void ar_push_reduce_kernel(ArArgs a)
     const uint32_t epoch = __hip_atomic_load(hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const int set = (int) (epoch & 1u);
     const size_t e0 = (size_t) row * a.hidden + (size_t) blk * 128 + 4 * l;
-    const float4_t mine = act ? *((const float4_t*) (a.y + e0)) : float4_t{ 0.f, 0.f, 0.f, 0.f };
+    float4_t mine = { 0.f, 0.f, 0.f, 0.f };
+    if (a.slabs)
+    {
+        const half4_t sc = ((const half4_t*) (a.svh + blk * 128))[l];
+        const SlabRef sr = { a.slabs, a.S };
+        const float4_t v = slab_sum(sr, blk, row, a.m, l);                 // all 32 lanes take part in the Hadamard butterflies
+        float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
+        had128_f32x4(h0, h1, h2, h3, l);
+        h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
+        mine = float4_t{ h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
+    }
+    else if (act) mine = *((const float4_t*) (a.y + e0));
     // 1. push this rank's 4 values to every rank's slot [set][rank] (own buffer included: one code path, and the local copy is what rank r adds)
     if (act)
     {
@@ -218,13 +232,22 @@ extern "C" int exl3_ar_error(void* ctx, void* stream)
 // residual stream, resid += sum with glue_resid's rounding; ss_part (optional): per-block sums of squares of the new residual.
 extern "C" int exl3_ar_reduce(void* ctx, const float* y, float* y_out, void* resid, float* ss_part, int m, int hidden, void* stream)
 {
+    return exl3_ar_reduce_slabs(ctx, y, nullptr, 0, nullptr, y_out, resid, ss_part, m, hidden, stream);
+}
+
+// ... with this rank's partial given as the deferred split-k slabs of the row-sharded linear (exl3_gemv_ex* with EXL3_GEMV_OUT_DEFERRED:
+// [hidden/128][S][m][128] fp32) + its svh instead of a dense tensor (y == NULL): the all-reduce launch also is that linear's epilogue.
+extern "C" int exl3_ar_reduce_slabs(void* ctx, const float* y, const float* slabs, int S, const void* svh, float* y_out, void* resid, float* ss_part,
+                                    int m, int hidden, void* stream)
+{
     ArCtx* c = (ArCtx*) ctx;
-    EXL3_CHECK_ARG(c && y && (y_out || resid), "ar_reduce: null pointer");
+    EXL3_CHECK_ARG(c && ((y && !slabs) || (!y && slabs && svh && S >= 1)) && (y_out || resid), "ar_reduce: null pointer (give y, or slabs + svh)");
     EXL3_CHECK_ARG(m >= 1 && hidden % 128 == 0 && (size_t) m * hidden <= c->max_elems, "ar_reduce: m * hidden exceeds the buffer / hidden not a multiple of 128");
     for (int r = 0; r < c->world; ++r) EXL3_CHECK_ARG(c->peer[r], "ar_reduce: peer %d not opened", r);
     ArArgs a;
     a.own = c->own; a.world = c->world; a.rank = c->rank; a.max_elems = c->max_elems;
     for (int r = 0; r < EXL3_AR_MAX_RANKS; ++r) a.peer[r] = r < c->world ? c->peer[r] : nullptr;
+    a.slabs = slabs; a.S = S; a.svh = (const half_t*) svh;
     a.y = y; a.y_out = y_out; a.resid = (half_t*) resid; a.ss_part = ss_part; a.m = m; a.hidden = hidden;
     const int tasks = m * (hidden / 128);
     ar_push_reduce_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>(a);

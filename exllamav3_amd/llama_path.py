@@ -353,6 +353,9 @@ class SyntheticEXL3Llama:
     #: forced split-k factor per call type of the fused pipelines (0 = library heuristic); tools/sweep_split.py tunes these
     split = {"qkv": 0, "o": 0, "gu": 0, "down": 0}
 
+    #: TP with the IPC all-reduce enabled: row-sharded linears hand their deferred slabs straight to the all-reduce launch (False: dense fp32 partials)
+    ar_from_slabs = os.environ.get("EXL3_HIP_AR_FROM_SLABS", "1") == "1"
+
     #: per-step sin / cos / cache-row tables for glue_qkv (ext.qkv_prep: one launch per step; False = every layer's glue_qkv computes them itself)
     use_qkv_tab = True
 
@@ -434,6 +437,9 @@ class SyntheticEXL3Llama:
         if rot and self.fold_rotate and self.tp == 1 and all(_same_kind(L["q"], L["k"], L["v"]) and _same_kind(L["gate"], L["up"]) for L in self.layers):
             return self._decode_step_fused_folded()
         tab = self._qkv_tab()
+        # tensor parallel with the IPC all-reduce: o_proj / down_proj keep their deferred epilogue and the all-reduce launch finishes the slabs
+        # (8 launches per layer instead of 10: no split-k reduce launch in front of either all-reduce)
+        ar_slabs = self.tp > 1 and getattr(be, "ipc", None) is not None and self.ar_from_slabs and bsz * self.shape.hidden <= be.ipc.max_elems
         ext.glue_resid(None, 0, None, None, x, ss, bsz)
         for li, L in enumerate(self.layers):
             lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
@@ -466,6 +472,10 @@ class SyntheticEXL3Llama:
             if self.tp == 1:
                 so, So = ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"])
                 ext.glue_resid(so[0], So, lo.svh, None, x, ss, bsz)
+            elif ar_slabs:
+                # row shard with a deferred epilogue: the IPC all-reduce launch finishes the slabs, reduces over the ranks and adds to the residual
+                so, So = ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"])
+                be.all_reduce_resid_slabs(so[0], So, lo.svh, x, ss, bsz)
             else:
                 lo.bc.run(o_in, self.o)
                 be.all_reduce_resid(self.o, x, ss, bsz)                    # one-shot IPC push + residual add, or RCCL all-reduce + glue_resid
@@ -491,13 +501,16 @@ class SyntheticEXL3Llama:
                                                  bsz, lg.mcg, lg.mul1, DEF, sp["gu"])
             if self.tp == 1 and bsz == 1 and self.act_in_gemv:
                 # silu(g) * u + input Hadamard inside the down GEMV (reads the gate / up slabs of the other workspace region): 7 launches / layer
+                # (one rank only: at the TP = 2 shard shapes the ACT-mode launch measured 29 us per layer SLOWER than glue_act + rotated-input
+                # GEMV, tools/ab_tp2.sh)
                 sd, Sd = ext.exl3_gemv_ex_act(sgu, Sgu, lg.svh, lu.svh, ld.trellis, None, ld.suh, None, bsz, ld.mcg, ld.mul1, DEF, sp["down"])
                 ext.glue_resid(sd[0], Sd, ld.svh, None, x, ss, bsz)
                 continue
             ext.glue_act(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz)
-            if self.tp == 1:
+            if self.tp == 1 or ar_slabs:
                 sd, Sd = ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF, sp["down"])
-                ext.glue_resid(sd[0], Sd, ld.svh, None, x, ss, bsz)
+                if self.tp == 1: ext.glue_resid(sd[0], Sd, ld.svh, None, x, ss, bsz)
+                else: be.all_reduce_resid_slabs(sd[0], Sd, ld.svh, x, ss, bsz)
             else:
                 ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.d], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT, c_fp32=True)
                 be.all_reduce_resid(self.d, x, ss, bsz)

@@ -148,6 +148,10 @@ class SyntheticEXL3Mixtral:
             if self.tp == 1:
                 so, So = ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF)
                 ext.glue_resid(so[0], So, lo.svh, None, x, ss, bsz)
+            elif getattr(be, "ipc", None) is not None and bsz * self.shape.hidden <= be.ipc.max_elems:
+                # the IPC all-reduce launch is the row shard's epilogue too (deferred slabs in, residual out), as in llama_path
+                so, So = ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF)
+                be.all_reduce_resid_slabs(so[0], So, lo.svh, x, ss, bsz)
             else:
                 lo.bc.run(o_in, self.o)
                 be.all_reduce_resid(self.o, x, ss, bsz)

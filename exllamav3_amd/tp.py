@@ -105,6 +105,12 @@ class TPBackendRCCL:
         self.all_reduce(y)
         ext.glue_resid(None, 0, None, None, resid, ss_part, m, y_dense=y)
 
+    def all_reduce_resid_slabs(self, slab: int, S: int, svh: torch.Tensor, resid: torch.Tensor, ss_part: torch.Tensor, m: int):
+        """all_reduce_resid for a row-sharded linear launched with a deferred epilogue (ext.exl3_gemv_ex* slabs): the IPC launch finishes the slabs,
+        reduces over the ranks and adds to the residual.  Only with the IPC path enabled (callers check `self.ipc`)."""
+        assert self.ipc is not None, "all_reduce_resid_slabs needs the IPC all-reduce"
+        self.ipc.reduce_slabs(slab, S, svh, resid, ss_part, m)
+
     def fwd_barrier(self):
         if self.world_size > 1:
             dist.barrier()
@@ -201,6 +207,14 @@ class IpcAllReduce:
         rows = m if m is not None else y.numel() // hidden
         p = lambda t: None if t is None else t.data_ptr()
         _lib.check(self._lib.exl3_ar_reduce(self.ctx, p(y), p(y_out), p(resid), p(ss_part), rows, hidden, torch.cuda.current_stream(y.device).cuda_stream))
+
+    def reduce_slabs(self, slab: int, S: int, svh: torch.Tensor, resid: torch.Tensor, ss_part: torch.Tensor, m: int, y_out: torch.Tensor | None = None):
+        from . import _lib
+        hidden = resid.shape[-1] if resid is not None else y_out.shape[-1]
+        p = lambda t: None if t is None else t.data_ptr()
+        dev = resid.device if resid is not None else y_out.device
+        _lib.check(self._lib.exl3_ar_reduce_slabs(self.ctx, None, slab, int(S), p(svh), p(y_out), p(resid), p(ss_part), int(m), hidden,
+                                                  torch.cuda.current_stream(dev).cuda_stream))
 
     def error(self) -> int:
         from . import _lib

@@ -393,6 +393,12 @@ int exl3_ar_open_peer(void* ctx, int peer_rank, const void* handle);
 int exl3_ar_destroy(void* ctx);
 int exl3_ar_error(void* ctx, void* stream);
 int exl3_ar_reduce(void* ctx, const float* y, float* y_out, void* resid, float* ss_part, int m, int hidden, void* stream);
+/* exl3_ar_reduce whose local partial is given as the deferred split-k slabs of the row-sharded o_proj / down_proj launch
+ * ([hidden/128][S][m][128] fp32 from exl3_gemv_ex*, EXL3_GEMV_OUT_DEFERRED) + that linear's svh instead of a dense tensor (y == NULL): the launch
+ * finishes the slabs (sum over S, out-Hadamard, x svh in fp32), pushes, reduces and adds to the residual -- one launch per tensor-parallel sublayer
+ * boundary where the reference runs the GEMM epilogue, the all-reduce and the residual add separately (modules/attn.py:915-960, mlp.py:833-891). */
+int exl3_ar_reduce_slabs(void* ctx, const float* y, const float* slabs, int S, const void* svh, float* y_out, void* resid, float* ss_part,
+                         int m, int hidden, void* stream);
 
 #ifdef __cplusplus
 }

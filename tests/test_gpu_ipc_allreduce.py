@@ -69,6 +69,46 @@ def _worker(rank, world, port, ret):
             graph.replay(); torch.cuda.synchronize()
             gok = gok and all(bool(torch.equal(o_, r_)) for o_, r_ in zip(outs, refs))
         ok["graph_replay"] = gok and ipc.error() == 0
+        # ---- the all-reduce launch as the epilogue of a row-sharded linear: deferred slabs in, residual out == GEMV (fp32 out) + all_reduce_resid
+        import sys as _s
+        _s.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+        import exl3_oracle as o
+        k, n, K, m = 1024, 2048, 4, 2
+        tr, suh, svh = o.synth_linear(k, n, K, seed=500 + rank, realistic=True)            # each rank its own row shard
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        dtr, dsuh, dsvh = T(tr), T(suh), T(svh)
+        xin = torch.randn((m, k), device=dev, generator=g).half()
+        ydense = torch.empty((m, n), dtype=torch.float, device=dev)
+        ext.exl3_gemv_ex(xin, None, None, [dtr], [ydense], [dsuh], [dsvh], m, False, True, 0, c_fp32=True)
+        rA = r0[:, :n].contiguous().clone(); ssA = torch.zeros((m, n // 128), device=dev)
+        be.all_reduce_resid(ydense, rA, ssA, m)
+        slabs, S = ext.exl3_gemv_ex(xin, None, None, [dtr], None, [dsuh], None, m, False, True, ext.GEMV_OUT_DEFERRED)
+        rB = r0[:, :n].contiguous().clone(); ssB = torch.full_like(ssA, float("nan"))
+        be.all_reduce_resid_slabs(slabs[0], S, dsvh, rB, ssB, m)
+        torch.cuda.synchronize()
+        ok["slab_route"] = bool((rA.float() - rB.float()).abs().max() <= 2e-3 * rA.float().abs().max()) and bool(torch.allclose(ssA, ssB, rtol=2e-3)) and ipc.error() == 0
+        # ---- a two-rank tensor-parallel decode step through both routes (dense partials vs slabs into the all-reduce), eager and graph replay
+        from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+        shape = LlamaShape("tiny", 512, 1024, 2, 4, 2, 128, 384)
+        model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, backend=be, kv_bits=4, max_ctx=1024)
+        model.alloc_state(1, pos=50)
+        model.ar_from_slabs = False
+        la = model.decode_step_fused().float().clone()
+        model.ar_from_slabs = True
+        lb = model.decode_step_fused().float().clone()
+        rms = float(la.pow(2).mean().sqrt())
+        step_ok = bool(torch.isfinite(lb).all()) and float((la - lb).abs().max()) / rms < 1e-2
+        st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+        dist.barrier()
+        with torch.cuda.stream(st):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=st):
+                model.decode_step_fused()
+        torch.cuda.synchronize(); dist.barrier()
+        for _ in range(3):
+            model.logits.zero_(); graph.replay()
+        torch.cuda.synchronize()
+        ok["tp_step_slab_route"] = step_ok and bool(torch.equal(model.logits.float(), lb)) and ipc.error() == 0
     except Exception as e:           # report instead of hanging the peer
         ok["exception"] = repr(e)
     ret[rank] = ok
@@ -87,4 +127,4 @@ def test_ipc_allreduce_two_processes_one_gpu(dev):
     for r in range(world):
         res = ret.get(r)
         assert res and "exception" not in res, res
-        assert res == {"enabled": True, "sums_exact": True, "resid_equal": True, "graph_replay": True}, (r, res)
+        assert res == {"enabled": True, "sums_exact": True, "resid_equal": True, "graph_replay": True, "slab_route": True, "tp_step_slab_route": True}, (r, res)
