@@ -36,6 +36,10 @@ def lib() -> ctypes.CDLL:
             raise RuntimeError(
                 f"exllamav3_amd: HIP library not built ({LIB_PATH}); run `python __graft_entry__.py` "
                 f"(there is no CPU fallback for the EXL3 hot path)")
+        # torch first: its wheel bundles its own ROCm runtime (libamdhip64 & co.), and this library must bind to THAT copy.  Loading
+        # libexl3_hip.so before torch pulls in /opt/rocm's runtime with RTLD_GLOBAL and a later `import torch` in the same process segfaults
+        # (two HIP runtimes interposing each other's symbols).  A pure-C consumer has one runtime and no such ordering problem.
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         _lib.exl3_last_error.restype = ctypes.c_char_p
         ver = _lib.exl3_abi_version()
@@ -138,6 +142,7 @@ def _declare(l):
     sig("exl3_routing_std", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
     sig("exl3_mgemm_indexed_act_deferred", vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
     sig("exl3_glue_resid_moe", vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, vp)
+    sig("exl3_routing_std_scaled", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
     sig("exl3_routing_std_norm", vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
     sig("exl3_routing_std_slots", vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
     sig("exl3_mgemm_indexed_act", vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp)

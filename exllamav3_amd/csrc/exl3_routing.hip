@@ -12,7 +12,8 @@
 // row's mean square taken from the per-block sums of squares the residual kernel left behind (ss_part [rows][H/128], the same fixed-order sum the
 // GEMV_IN_NORM launches use).  The workgroup forms xn once (LDS, dynamic: H halves), writes it to xn_out for the expert launches and routes on it:
 // the rms_norm launch in front of a MoE block disappears (modules/block_sparse_mlp.py:1099-1130 runs norm, router and experts as separate ops).
-struct RoutingNorm { const half_t* norm_w; const float* ss_part; half_t* xn_out; float eps; };
+struct RoutingNorm { const half_t* norm_w; const float* ss_part; half_t* xn_out; float eps;
+                     const uint16_t* per_expert_scale; };      // optional bf16 [E]: weight_k *= scale[expert_k] after the softmax (routing.cu:587-588)
 
 template <bool NORM>
 __global__ __launch_bounds__(256)
@@ -168,6 +169,7 @@ void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restr
     ev /= (sum + 1e-20f);
     if (lane < K)
     {
+        if (nrm.per_expert_scale) ev *= __uint_as_float((uint32_t) nrm.per_expert_scale[sel_idx[lane]] << 16);
         topk_indices[(size_t) row * K + lane] = (int64_t) sel_idx[lane];
         topk_weights[(size_t) row * K + lane] = f2h(ev);
         if (gu_slots)
@@ -190,13 +192,22 @@ extern "C" int exl3_routing_std(const void* hidden, const void* gate, const void
 extern "C" int exl3_routing_std_slots(const void* hidden, const void* gate, const void* bias, void* scores, int64_t* topk_indices, void* topk_weights,
                                       int64_t* gu_slots, int bsz, int hidden_size, int num_experts, int K, void* stream)
 {
+    return exl3_routing_std_scaled(hidden, gate, bias, nullptr, scores, topk_indices, topk_weights, gu_slots, bsz, hidden_size, num_experts, K, stream);
+}
+
+// ... with the reference's per_expert_scale argument (bf16 [num_experts], routing.cu:955-1010): the softmax weight of a selected expert is multiplied by it
+extern "C" int exl3_routing_std_scaled(const void* hidden, const void* gate, const void* bias, const void* per_expert_scale, void* scores,
+                                       int64_t* topk_indices, void* topk_weights, int64_t* gu_slots, int bsz, int hidden_size, int num_experts, int K,
+                                       void* stream)
+{
     EXL3_CHECK_ARG(hidden && gate && scores && topk_indices && topk_weights, "routing_std: null pointer");
     EXL3_CHECK_ARG(num_experts >= 1 && num_experts <= ROUTING_MAX_EXPERTS, "Too many experts");
     EXL3_CHECK_ARG(K >= 1 && K <= ROUTING_MAX_K, "Too many experts per token");
     EXL3_CHECK_ARG(K <= num_experts, "K cannot exceed number of experts");
     if (bsz == 0) return EXL3_OK;
     routing_std_kernel<false><<<bsz, 256, 0, (hipStream_t) stream>>>((const half_t*) hidden, (const half_t*) gate, (const half_t*) bias, (half_t*) scores,
-                                                                    topk_indices, (half_t*) topk_weights, hidden_size, num_experts, K, gu_slots, bsz, RoutingNorm{});
+                                                                    topk_indices, (half_t*) topk_weights, hidden_size, num_experts, K, gu_slots, bsz,
+                                                                    RoutingNorm{ nullptr, nullptr, nullptr, 0.0f, (const uint16_t*) per_expert_scale });
     return exl3_check_launch("routing_std");
 }
 
@@ -212,7 +223,7 @@ extern "C" int exl3_routing_std_norm(const void* resid, const void* norm_w, cons
     EXL3_CHECK_ARG(K >= 1 && K <= ROUTING_MAX_K, "Too many experts per token");
     EXL3_CHECK_ARG(K <= num_experts, "K cannot exceed number of experts");
     if (bsz == 0) return EXL3_OK;
-    const RoutingNorm nrm = { (const half_t*) norm_w, ss_part, (half_t*) xn_out, eps };
+    const RoutingNorm nrm = { (const half_t*) norm_w, ss_part, (half_t*) xn_out, eps, nullptr };
     routing_std_kernel<true><<<bsz, 256, (size_t) hidden_size * 2, (hipStream_t) stream>>>((const half_t*) resid, (const half_t*) gate, (const half_t*) bias,
                                                                                           (half_t*) scores, topk_indices, (half_t*) topk_weights, hidden_size,
                                                                                           num_experts, K, gu_slots, bsz, nrm);

@@ -905,7 +905,8 @@ def routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_sca
     gu_slots (this build, optional): int64 [2][bsz * K] receiving [selected | selected + experts], the slot list of one indexed exl3_mgemm over
     concatenated gate | up pointer tables."""
     _dev(hidden)
-    _req(per_expert_scale is None, "routing_std: per_expert_scale is outside this build")
+    _req(per_expert_scale is None or (per_expert_scale.dtype == torch.bfloat16 and per_expert_scale.numel() == scores.shape[1] and per_expert_scale.is_contiguous()),
+         "routing_std: per_expert_scale must be a contiguous bfloat16 tensor with one entry per expert")
     _req(hidden.dtype == torch.half and gate.dtype == torch.half and scores.dtype == torch.half, "routing_std: hidden, gate, scores must be float16")
     _req(topk_indices.dtype == torch.long and topk_weights.dtype == torch.half, "routing_std: topk_indices int64, topk_weights float16")
     _req(gate.dim() == 2 and gate.shape[0] == hidden.shape[-1] and gate.shape[1] == scores.shape[-1], "routing_std: gate must be (hidden, experts)")
@@ -914,8 +915,8 @@ def routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_sca
     bsz = scores.shape[0]
     if gu_slots is not None:
         _req(gu_slots.dtype == torch.long and gu_slots.is_contiguous() and gu_slots.numel() == 2 * topk_indices.numel(), "routing_std: gu_slots must be int64 [2][bsz * K]")
-    _check(_lib.lib().exl3_routing_std_slots(_p(hidden), _p(gate), _p(bias), _p(scores), _p(topk_indices), _p(topk_weights), _p(gu_slots), bsz,
-                                             hidden.shape[-1], scores.shape[1], topk_indices.shape[1], _stream(hidden)))
+    _check(_lib.lib().exl3_routing_std_scaled(_p(hidden), _p(gate), _p(bias), _p(per_expert_scale), _p(scores), _p(topk_indices), _p(topk_weights),
+                                              _p(gu_slots), bsz, hidden.shape[-1], scores.shape[1], topk_indices.shape[1], _stream(hidden)))
 
 
 def exl3_mgemm_act_deferred(G, U, B, suh, indices, K: int, mcg: int, mul1: int, n: int):

@@ -366,6 +366,10 @@ int exl3_softcap(const void* x, void* y, int64_t numel, float scale, int is_fp32
  * concatenated gate | up pointer tables.  exl3_mgemm_indexed_act: the down launch whose per-slot input is fp16(silu(G_j) * U_j) (silu_mul folded in). */
 int exl3_routing_std_slots(const void* hidden, const void* gate, const void* bias, void* scores, int64_t* topk_indices, void* topk_weights,
                            int64_t* gu_slots, int bsz, int hidden_size, int num_experts, int K, void* stream);
+/* ... with per_expert_scale (bf16 [num_experts], routing.cu:955-1010 argument): weight_k *= scale[expert_k] after the softmax */
+int exl3_routing_std_scaled(const void* hidden, const void* gate, const void* bias, const void* per_expert_scale, void* scores,
+                            int64_t* topk_indices, void* topk_weights, int64_t* gu_slots, int bsz, int hidden_size, int num_experts, int K,
+                            void* stream);
 /* ... on the RMSNorm of the residual stream formed inside the launch: xn = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)), mean square from
  * ss_part [bsz][hidden/128] (exl3_glue_resid); xn_out receives xn for the expert launches.  Replaces the rms_norm launch + routing of
  * modules/block_sparse_mlp.py:1099-1130. */

@@ -578,16 +578,19 @@ def synth_linear(k: int, n: int, K: int, seed: int | None = None, realistic: boo
     return trellis, su.astype(np.float16), sv.astype(np.float16)
 
 
-def routing_std(hidden: np.ndarray, gate: np.ndarray, k: int, bias: np.ndarray | None = None):
+def routing_std(hidden: np.ndarray, gate: np.ndarray, k: int, bias: np.ndarray | None = None, per_expert_scale: np.ndarray | None = None):
     """MoE router (exllamav3_ext/routing.cu:457-590 + routing_gemv): scores = fp16(hidden @ gate) ; top-k logits (descending, ties to the lower
-    index) ; weights = fp16(softmax over the k selected logits).  Returns (scores fp16 [b, E], indices int64 [b, k], weights fp16 [b, k])."""
+    index) ; weights = fp16(softmax over the k selected logits [x per_expert_scale[expert], fp32 values of a bf16 tensor, routing.cu:587-588]).
+    Returns (scores fp16 [b, E], indices int64 [b, k], weights fp16 [b, k])."""
     scores = (hidden.astype(np.float32) @ gate.astype(np.float32)).astype(np.float16)
     logits = scores.astype(np.float32) + (bias.astype(np.float32) if bias is not None else 0.0)
     order = np.argsort(-logits, axis=-1, kind="stable")[:, :k]
     sel = np.take_along_axis(logits, order, axis=-1)
     e = np.exp(sel - sel[:, :1])
-    w = (e / (e.sum(-1, keepdims=True) + 1e-20)).astype(np.float16)
-    return scores, order.astype(np.int64), w
+    wf = (e / (e.sum(-1, keepdims=True) + 1e-20)).astype(np.float32)
+    if per_expert_scale is not None:
+        wf = (wf * per_expert_scale.astype(np.float32)[order]).astype(np.float32)
+    return scores, order.astype(np.int64), wf.astype(np.float16)
 
 
 def attn_decode_qcache(q: np.ndarray, k_deq: np.ndarray, v_deq: np.ndarray, lens, scale: float | None = None) -> np.ndarray:

@@ -547,6 +547,11 @@ def test_router_with_rmsnorm_inside_matches_norm_then_router(dev, experts, hidde
     sc2 = torch.empty_like(sc); sel2 = torch.empty_like(sel); wt2 = torch.empty_like(wt)
     ext.routing_std(xn, T(gate), sc2, sel2, wt2)
     assert torch.equal(sc, sc2) and torch.equal(sel, sel2) and torch.equal(wt, wt2)
+    # per_expert_scale (bf16): the selected experts' softmax weights times their scale
+    pes = torch.from_numpy(rng.uniform(0.5, 2.0, experts).astype(np.float32)).to(torch.bfloat16)
+    ext.routing_std(xn, T(gate), sc2, sel2, wt2, per_expert_scale=pes.to(dev))
+    _, _, w_s = o.routing_std(xn.cpu().numpy(), gate, K, per_expert_scale=pes.float().numpy())
+    assert torch.equal(sel2, sel) and np.abs(wt2.float().cpu().numpy() - w_s.astype(np.float32)).max() < 4e-3
 
 
 def test_fused_step_with_attention_matches_oracle(dev):
