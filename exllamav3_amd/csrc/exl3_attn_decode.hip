@@ -153,59 +153,103 @@ void attn_decode_kernel(const AttnArgs a)
     }
 }
 
-// merge of the context splits: one half-wave per (sequence, head).  Lane s fetches split s's (max, sum) so the statistics of up to 32 splits
-// arrive in one memory round trip; the weighted accumulation then streams the split outputs 8 at a time (independent loads).
+// merge of the context splits.  Latency, not work: 32 items x 32 splits x 528 B at a 1000-token context.  The first version gave one half-wave
+// per item three dependent load rounds (maxima, then (max, sum) again, then the split outputs 8 at a time): 6.6 us under rocprofv3.  Now FOUR
+// half-waves share an item, each takes a quarter of the splits, and everything a half-wave needs -- the (max, sum) statistics of ALL splits
+// (lane s holds split s's pair, up to 8 chunks of rw splits in registers) and its own first 8 split outputs -- is requested in ONE round; the
+// statistics reductions are DPP butterflies, the four partial outputs are summed in a fixed order through LDS, and the item -> head index
+// arithmetic uses multiply-highs.
+#define ATT_MERGE_HELPERS 4
+template <int HD>
 __global__ __launch_bounds__(256)
-void attn_merge_kernel(const float* __restrict__ part, half_t* __restrict__ out, int items_total, int nsplit, int hd, int gq, int blocks, int hq)
+void attn_merge_kernel(const float* __restrict__ part, half_t* __restrict__ out, int items_total, int nsplit, int gq, int blocks, int hq,
+                       uint32_t magic_gq, uint32_t magic_bg, uint32_t magic_blocks)
 {
+    constexpr int hd = HD;
+    __shared__ float comb[2][ATT_MERGE_HELPERS][32][4];
     // item = (sequence b, 128-value block h, query index i); at head_dim 64 lanes 0-15 / 16-31 belong to the block's two kv heads
-    const int tid = threadIdx.x, l = tid & 31, lane = tid & 63;
-    const int item = blockIdx.x * 8 + (tid >> 5);
+    const int tid = threadIdx.x, l = tid & 31, lane = tid & 63, hwid = tid >> 5;
+    const int item_local = hwid >> 2, helper = hwid & 3;
+    const int item = blockIdx.x * 2 + item_local;
     const bool act = item < items_total;
-    const int rw = hd >> 2, sub = l / rw, nsub = 128 / hd;
+    constexpr int rw_shift = hd == 128 ? 5 : 4, rw = 1 << rw_shift, nsub = 128 >> (rw_shift + 2);     // compile-time: the butterflies below unroll into DPP ops
+    const int sub = l >> rw_shift;
+    const int lr = l & (rw - 1), lbase = lane - lr;
     const float* p = part + (size_t) (act ? item : 0) * nsplit * 132;
-    // lane lr of a head's rw lanes fetches split (s0 + lr)'s (max, sum) so the statistics of up to rw splits arrive in one memory round trip;
-    // the weighted accumulation then streams the split outputs 8 at a time (independent loads)
-    const int lr = l % rw, lbase = lane - lr;
-    float M = -1.0e30f;
-    for (int s0 = 0; s0 < nsplit; s0 += rw)
+    const int per = (nsplit + ATT_MERGE_HELPERS - 1) / ATT_MERGE_HELPERS;          // splits per helper
+    const int sb = helper * per, cnt_h = max(0, min(per, nsplit - sb));
+    const int nchunk = (nsplit + rw - 1) >> rw_shift;                              // <= 8 (host: nsplit <= 128 at rw = 16, <= 256 at 32)
+    // ---- one round of loads: all statistics + this helper's first 8 outputs
+    float2 st[8];
+    #pragma unroll
+    for (int c = 0; c < 8; ++c)
     {
-        float m = (s0 + lr < nsplit) ? p[(size_t) (s0 + lr) * 132 + 2 * sub] : -1.0e30f;
-        for (int j = 1; j < rw; j <<= 1) m = fmaxf(m, __shfl_xor(m, j, 64));
-        M = fmaxf(M, m);
+        const int sidx = (c << rw_shift) + lr;
+        st[c] = (c < nchunk && sidx < nsplit) ? *((const float2*) (p + (size_t) sidx * 132 + 2 * sub)) : float2{ -1.0e30f, 0.0f };
     }
-    float L = 0.0f, o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
-    for (int s0 = 0; s0 < nsplit; s0 += rw)
+    float4_t ov[8];
+    #pragma unroll
+    for (int u = 0; u < 8; ++u) ov[u] = *((const float4_t*) (p + (size_t) min(sb + min(u, max(cnt_h - 1, 0)), nsplit - 1) * 132 + 4 + 4 * l));
+    // ---- statistics: M = max over all splits, e_s = exp(m_s - M) (kept in the lane that holds split s), L = sum l_s e_s
+    float M = -1.0e30f;
     {
-        const bool has = s0 + lr < nsplit;
-        const float2 ml = has ? *((const float2*) (p + (size_t) (s0 + lr) * 132 + 2 * sub)) : float2{ -1.0e30f, 0.0f };
-        const float e_mine = has ? __expf(ml.x - M) : 0.0f;
-        float lsum = ml.y * e_mine;
-        for (int j = 1; j < rw; j <<= 1) lsum += __shfl_xor(lsum, j, 64);
-        L += lsum;
-        const int cnt = min(rw, nsplit - s0);
-        for (int c0 = 0; c0 < cnt; c0 += 8)
+        float m = st[0].x;                                                           // lane-wise max over the chunks first, one butterfly
+        #pragma unroll
+        for (int c = 1; c < 8; ++c) m = fmaxf(m, st[c].x);
+        #pragma unroll
+        for (int j = 1; j < rw; j <<= 1) m = fmaxf(m, xor_lane(m, j));
+        M = m;
+    }
+    float ec[8], L = 0.0f;
+    #pragma unroll
+    for (int c = 0; c < 8; ++c)
+    {
+        ec[c] = st[c].x > -1.0e29f ? __expf(st[c].x - M) : 0.0f;
+        if (c < nchunk)                                                              // uniform; chunk sums in chunk order (the order of the first version)
         {
-            float4_t ov[8]; float ev[8];
+            float ls = st[c].y * ec[c];
             #pragma unroll
-            for (int u = 0; u < 8; ++u)
-            {
-                const int sidx = min(c0 + u, cnt - 1);
-                ov[u] = *((const float4_t*) (p + (size_t) (s0 + sidx) * 132 + 4 + 4 * l));
-                ev[u] = __shfl(e_mine, lbase + sidx, 64);                            // split sidx's weight lives in lane sidx of this head's lanes
-            }
-            #pragma unroll
-            for (int u = 0; u < 8; ++u) if (c0 + u < cnt) { o0 += ov[u].x * ev[u]; o1 += ov[u].y * ev[u]; o2 += ov[u].z * ev[u]; o3 += ov[u].w * ev[u]; }
+            for (int j = 1; j < rw; j <<= 1) ls += xor_lane(ls, j);
+            L += ls;
         }
+    }
+    // ---- this helper's weighted partial output
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+    for (int c0 = 0; c0 < cnt_h; c0 += 8)
+    {
+        if (c0 > 0)
+        {
+            #pragma unroll
+            for (int u = 0; u < 8; ++u) ov[u] = *((const float4_t*) (p + (size_t) (sb + min(c0 + u, cnt_h - 1)) * 132 + 4 + 4 * l));
+        }
+        #pragma unroll
+        for (int u = 0; u < 8; ++u)
+        {
+            const int sg = sb + min(c0 + u, cnt_h - 1);                              // global split index (uniform per half-wave)
+            const int ch = sg >> rw_shift;
+            float esel = ec[0];
+            #pragma unroll
+            for (int c = 1; c < 8; ++c) esel = ch == c ? ec[c] : esel;
+            const float ev = __shfl(esel, lbase + (sg & (rw - 1)), 64);              // split sg's weight lives in lane sg % rw of this head's lanes
+            if (c0 + u < cnt_h) { o0 += ov[u].x * ev; o1 += ov[u].y * ev; o2 += ov[u].z * ev; o3 += ov[u].w * ev; }
+        }
+    }
+    comb[item_local][helper][l][0] = o0; comb[item_local][helper][l][1] = o1; comb[item_local][helper][l][2] = o2; comb[item_local][helper][l][3] = o3;
+    __syncthreads();
+    if (helper != 0) return;
+    #pragma unroll
+    for (int h2 = 1; h2 < ATT_MERGE_HELPERS; ++h2)
+    {
+        o0 += comb[item_local][h2][l][0]; o1 += comb[item_local][h2][l][1]; o2 += comb[item_local][h2][l][2]; o3 += comb[item_local][h2][l][3];
     }
     const float inv = L > 0.0f ? 1.0f / L : 0.0f;
     float v0 = o0 * inv, v1 = o1 * inv, v2 = o2 * inv, v3 = o3 * inv;
     kvg_had32(v0, v1, v2, v3, lane);
     // item -> query head: b = item / (blocks * gq), h = (item / gq) % blocks, i = item % gq; head = (h * nsub + sub) * gq + i
     const int it = act ? item : 0;
-    const int b = it / (blocks * gq), h = (it / gq) % blocks, i = it % gq;
+    const int b = gemv_udiv(it, magic_bg), ig = gemv_udiv(it, magic_gq), i = it - ig * gq, h = ig - gemv_udiv(ig, magic_blocks) * blocks;
     const int head = (h * nsub + sub) * gq + i;
-    if (act) ((half4_t*) (out + ((size_t) b * hq + head) * hd))[l % rw] = half4_t{ f2h(v0 * ATT_R32), f2h(v1 * ATT_R32), f2h(v2 * ATT_R32), f2h(v3 * ATT_R32) };
+    if (act) ((half4_t*) (out + ((size_t) b * hq + head) * hd))[lr] = half4_t{ f2h(v0 * ATT_R32), f2h(v1 * ATT_R32), f2h(v2 * ATT_R32), f2h(v3 * ATT_R32) };
 }
 
 extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
@@ -225,7 +269,8 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
     const int gq = heads_q / heads_kv;
     int split_tokens = ((max_len + 31) / 32) * bsz * blocks <= 1024 ? 32 : 64;      // 4 or 8 tokens per half-wave
     int nsplit = (max_len + split_tokens - 1) / split_tokens;
-    const int cap = 1024 / (bsz * blocks) > 1 ? 1024 / (bsz * blocks) : 1;
+    int cap = 1024 / (bsz * blocks) > 1 ? 1024 / (bsz * blocks) : 1;
+    if (cap > (head_dim == 128 ? 256 : 128)) cap = head_dim == 128 ? 256 : 128;       // the merge kernel keeps 8 chunks of 32 / 16 split statistics in registers
     if (nsplit > cap) { nsplit = cap; split_tokens = ((max_len + nsplit - 1) / nsplit + 7) / 8 * 8; nsplit = (max_len + split_tokens - 1) / split_tokens; }
     EXL3_CHECK_ARG(nsplit == 1 || (workspace && workspace_floats >= (int64_t) bsz * blocks * gq * nsplit * 132), "attn_decode: workspace too small for the context splits");
     AttnArgs a;
@@ -244,7 +289,10 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
     if (nsplit > 1)
     {
         const int items = bsz * blocks * gq;
-        attn_merge_kernel<<<(items + 7) / 8, 256, 0, st>>>(workspace, (half_t*) out, items, nsplit, head_dim, gq, blocks, heads_q);
+        EXL3_CHECK_ARG(nsplit <= 8 * (head_dim == 128 ? 32 : 16), "attn_decode: too many context splits for the merge kernel");
+        const uint32_t mg = gemv_magic((uint32_t) gq), mbg = gemv_magic((uint32_t) (blocks * gq)), mb = gemv_magic((uint32_t) blocks);
+        if (head_dim == 128) attn_merge_kernel<128><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, nsplit, gq, blocks, heads_q, mg, mbg, mb);
+        else                 attn_merge_kernel<64><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, nsplit, gq, blocks, heads_q, mg, mbg, mb);
         rc = exl3_check_launch("attn_merge");
     }
     return rc;
