@@ -460,17 +460,29 @@ void glue_qkv_kernel(const QkvArgs a)
 // G3: gate/up epilogue per (row, 128-block of the intermediate dim): reduce + out-had + fp16 svh for g and u ->
 //     a = fp16(silu(g) * u) (activation.cu) -> in-had with suh_down -> xh_down + block sum.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256)
-void glue_act_kernel(SlabRef sg, SlabRef su, const half_t* __restrict__ svh_g, const half_t* __restrict__ svh_u,
-                     const half_t* __restrict__ suh_d, half_t* __restrict__ xh_d, float* __restrict__ xsum_d,
-                     half_t* __restrict__ a_out, int m, int inter, GemvRescale rs)
+// arguments in one block, read in one batch; multiply-high task split; tasks per workgroup from here (see ResidArgs)
+struct ActArgs
 {
+    SlabRef sg, su; const half_t* svh_g; const half_t* svh_u; const half_t* suh_d; half_t* xh_d; float* xsum_d; half_t* a_out;      // 80 B
+    int m, inter, nblk, tpw; uint32_t magic_nblk; int pad_;
+    GemvRescale rs;
+};
+
+__global__ __launch_bounds__(256)
+void glue_act_kernel(const ActArgs a)
+{
+    const SlabRef sg = a.sg, su = a.su;
+    const half_t* const svh_g = a.svh_g; const half_t* const svh_u = a.svh_u; const half_t* const suh_d = a.suh_d;
+    half_t* const xh_d = a.xh_d; float* const xsum_d = a.xsum_d; half_t* const a_out = a.a_out;
+    const int m = a.m, inter = a.inter, nblk = a.nblk, tpw = a.tpw;
+    const uint32_t magic_nblk = a.magic_nblk;
+    const GemvRescale rs = a.rs;
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
-    const int nblk = inter >> 7;
     const int tasks = m * nblk;
-    const int t = blockIdx.x * (blockDim.x >> 5) + hw;                 // half-wave tasks per workgroup = blockDim / 32
+    const int t = blockIdx.x * tpw + hw;                               // half-wave tasks per workgroup = blockDim / 32
     const bool act = t < tasks;
-    const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+    const int tt = act ? t : 0;
+    const int row = gemv_udiv(tt, magic_nblk), blk = tt - row * nblk;
     // all independent loads first (scales of this block), then the slabs
     const half4_t svg = ((const half4_t*) (svh_g + blk * 128))[l], svu = ((const half4_t*) (svh_u + blk * 128))[l];
     const half4_t sud = ((const half4_t*) (suh_d + blk * 128))[l];
@@ -671,9 +683,13 @@ extern "C" int exl3_glue_act_rs(const float* sg, const float* su, int S, const v
     int tasks = m * (inter / 128);
     SlabRef g = { sg, S }, u = { su, S };
     const int th = glue_threads(tasks), tpw = th / 32;
-    glue_act_kernel<<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(g, u, (const half_t*) svh_g, (const half_t*) svh_u, (const half_t*) suh_d,
-                                                                       (half_t*) xh_d, xsum_d, (half_t*) a_out, m, inter,
-                                                                       GemvRescale{ ss_prev, ss_new, hidden, eps });
+    ActArgs aa;
+    memset((void*) &aa, 0, sizeof(aa));
+    aa.sg = g; aa.su = u; aa.svh_g = (const half_t*) svh_g; aa.svh_u = (const half_t*) svh_u; aa.suh_d = (const half_t*) suh_d;
+    aa.xh_d = (half_t*) xh_d; aa.xsum_d = xsum_d; aa.a_out = (half_t*) a_out;
+    aa.m = m; aa.inter = inter; aa.nblk = inter / 128; aa.tpw = tpw; aa.magic_nblk = gemv_magic((uint32_t) (inter / 128));
+    aa.rs = GemvRescale{ ss_prev, ss_new, hidden, eps };
+    glue_act_kernel<<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>(aa);
     return exl3_check_launch("glue_act");
 }
 
