@@ -5,7 +5,7 @@ from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
 
 dev = torch.device("cuda:0")
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-model = SyntheticEXL3Llama(SHAPES["llama-3.1-8b"], K=4, cb=2, device=dev, kv_bits=4, layers=layers)
+model = SyntheticEXL3Llama(SHAPES[os.environ.get("MODEL", "llama-3.1-8b")], K=4, cb=2, device=dev, kv_bits=4, layers=layers)
 model.alloc_state(int(os.environ.get('BSZ', '1')))
 from exllamav3_amd import ext
 if os.environ.get('G3MIN'): ext.set_gemm3_min_rows(int(os.environ['G3MIN']))
