@@ -194,6 +194,7 @@ def main():
                                    layers=args.layers or None)
     model.alloc_state(args.batch)
     model.with_attention = bool(args.attention)
+    model.prefill_attention = bool(args.attention)          # the prefill leg then includes dequant_cache_paged + causal attention over the pages
 
     # ---- decode: eager warm-up (also creates library contexts), graph capture, timed replays
     pipeline = "unfused" if args.unfused else args.pipeline

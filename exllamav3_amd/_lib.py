@@ -132,6 +132,8 @@ def _declare(l):
     sig("exl3_gemv_qkv", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_rope_table", vp, vp, f32, i32, vp, vp, vp)
     sig("exl3_debug_copy_workspace", vp, i64, i64, vp)
+    sig("exl3_attn_prefill_paged_strided", vp, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp)
+    sig("exl3_attn_prefill_paged", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp)
     sig("exl3_attn_decode_qcache", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp)
     sig("exl3_silu_mul_2d", vp, vp, vp, i64, i64, i64, i64, vp)
     sig("exl3_gemv_ex_resid", vp, vp, vp, f32, vp, i32, vp, vp, vp, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)

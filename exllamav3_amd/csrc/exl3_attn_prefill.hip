@@ -1,0 +1,223 @@
+// Prefill (multi-token) causal attention over the paged fp16 K/V that dequant_cache_paged expands -- the attention step of the reference's
+// prefill path: CacheLayer_quant.get_kv (cache/quant.py:83-117) dequantizes the pages, then flash_attn_with_kvcache(q, k_pages, v_pages,
+// block_table, cache_seqlens, causal=True) attends (modules/attn.py).  SURVEY.md 8(f)3, "next" row: the decode branch is exl3_attn_decode.hip.
+//
+// gfx950 design: flash-attention forward, one workgroup = 64 consecutive queries of one (sequence, query head), four waves x 16 queries, K/V tiles of
+// 64 keys staged in LDS.  Everything is shaped so that no register transpose is needed between the two matrix products
+// (v_mfma_f32_16x16x32_f16; operand lane (g = lane / 16, c = lane % 16) holds row / column c and contraction slots 8g .. 8g+7, the result lane
+// holds column c, rows 4g .. 4g+3):
+//   * scores are computed TRANSPOSED, S^T = K Q^T (A = K rows from LDS, B = the wave's Q rows, kept in registers for the whole kernel), so a
+//     lane ends up with the probabilities of ONE query (column c) for keys {16 kb + 4g + j}: exactly an A operand of P V if contraction slot
+//     8g + 4h + j of the second product is DEFINED to be key 16 (2 kb2 + h) + 4g + j -- a contraction index can be permuted freely as long
+//     as both operands agree;
+//   * V is staged row-major like K (16-byte LDS writes); the matching B operand (4 consecutive keys of one output column) is gathered by
+//     ds_read_b64_tr_b16, gfx950's LDS transpose read - one instruction per 4 keys, no transposing write pass;
+//   * the GW (1, 2 or 4) query heads that share a kv head sit in ONE workgroup (4 GW waves), so a K/V tile is staged once for all of them;
+//   * softmax statistics live with the query's column lanes; the output accumulator's rows are queries 4g + j, so the running rescale factor
+//     of those four queries is fetched from lanes 4g + j (ds_bpermute, 4 per tile).
+// fp32 softmax and accumulation, fp16 probabilities into the second product (as flash-attention does), fp16 output.
+#include "exl3_common.cuh"
+#include "exl3_api_internal.h"
+#include "exl3_gemv_args.h"
+
+#define PA_BM 64          // queries per workgroup
+#define PA_BN 64          // keys per tile
+
+struct PrefillAttnArgs
+{
+    const half_t* q; half_t* out;                               // [bsz][q_len][hq][HD]
+    const half_t* k_pages; const half_t* v_pages;               // [pages][page_size][hkv][HD] fp16 (dequant_cache_paged's output, or an fp16 cache)
+    const int32_t* block_table; const int32_t* cache_seqlens;   // [bsz][blocks_per_seq]; [bsz] = tokens in the cache INCLUDING the q_len new ones
+    int q_len, hq, hkv, blocks_per_seq, page_size;
+    int64_t ldq;                                                // halves between consecutive tokens of q (hq * HD when contiguous)
+    float scale;
+};
+
+typedef short s16x4_t __attribute__((__vector_size__(4 * sizeof(short))));
+__device__ __forceinline__ half4_t lds_read_tr16(const half_t* p)
+{
+    const s16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*) p);
+    return __builtin_bit_cast(half4_t, r);
+}
+
+// GW query heads of ONE kv head per workgroup (GW in {1, 2, 4}, GW | heads_q / heads_kv): 4 GW waves share every staged K/V tile, so the
+// staging work per matrix instruction drops by GW (with one head per workgroup the four q heads of a Llama kv head each re-staged it)
+template <int HD, int GW>
+__global__ __launch_bounds__(256 * GW)
+void attn_prefill_kernel(const PrefillAttnArgs a)
+{
+    constexpr int NT = 256 * GW;
+    constexpr int KS = HD + 8;                                  // K tile row stride in halves (16-byte aligned rows, rotated banks)
+    __shared__ __attribute__((aligned(16))) half_t Ks[PA_BN * KS];
+    __shared__ __attribute__((aligned(16))) half_t Vs[PA_BN * KS];   // row-major like K; the PV operand is gathered with the LDS transpose read
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all & 3, g = lane >> 4, c = lane & 15;
+    const int qt = blockIdx.x, h = blockIdx.y * GW + (wave_all >> 2), b = blockIdx.z;
+    const int q_len = a.q_len, hq = a.hq, hkv = a.hkv, page_size = a.page_size;
+    const int kvh = (blockIdx.y * GW) / (hq / hkv);           // the same for all GW heads of the workgroup
+    const int kv_len = a.cache_seqlens[b];
+    const int ctx = kv_len - q_len;                             // query i sits at position ctx + i and sees keys 0 .. ctx + i
+    const int q0 = qt * PA_BM + wave * 16;                      // this wave's first query
+    const int qi = min(q0 + c, q_len - 1);                      // this lane's query (column of S^T); clamped rows are never stored
+    const int32_t* bt = a.block_table + (size_t) b * a.blocks_per_seq;
+
+    // Q rows of the wave as B operands of S^T = K Q^T: contraction slots 8g .. 8g+7 of step ks are head dims 32 ks + 8g ..
+    half8_t qf[HD / 32];
+    {
+        const half_t* qp = a.q + ((size_t) b * q_len + qi) * a.ldq + (size_t) h * HD;
+        #pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = *((const half8_t*) (qp + 32 * ks + 8 * g));
+    }
+    float m_run = -1.0e30f, l_run = 0.0f;
+    float4_t oc[HD / 16];
+    #pragma unroll
+    for (int nb = 0; nb < HD / 16; ++nb) oc[nb] = float4_t{ 0.f, 0.f, 0.f, 0.f };
+
+    const int q_last = min(qt * PA_BM + PA_BM, q_len) - 1;      // last query of the workgroup: the tiles needed are those up to its position
+    const int ntiles = (ctx + q_last) / PA_BN + 1;
+    for (int kt = 0; kt < ntiles; ++kt)
+    {
+        const int key0 = kt * PA_BN;
+        __syncthreads();                                        // the previous tile is no longer read
+        // ---- stage K and V (both row-major): 64 keys x HD halves each, 16 bytes per load; a tile never straddles a page (64 | page size)
+        {
+            const int64_t page = bt[min(key0 / page_size, a.blocks_per_seq - 1)];
+            constexpr int CH = HD / 8;                          // 16-byte chunks per key
+            #pragma unroll
+            for (int j = 0; j < (PA_BN * CH + NT - 1) / NT; ++j)
+            {
+                const int idx = tid + NT * j;
+                if ((PA_BN * CH) % NT != 0 && idx >= PA_BN * CH) break;
+                const int key = idx / CH, ch = idx % CH;
+                const bool ok = key0 + key < kv_len;
+                const size_t row = ((size_t) page * page_size + ((key0 + key) % page_size)) * hkv + kvh;
+                half8_t kv = { 0, 0, 0, 0, 0, 0, 0, 0 }, vv = kv;
+                if (ok) { kv = *((const half8_t*) (a.k_pages + row * HD + 8 * ch)); vv = *((const half8_t*) (a.v_pages + row * HD + 8 * ch)); }
+                *((half8_t*) (Ks + key * KS + 8 * ch)) = kv;
+                *((half8_t*) (Vs + key * KS + 8 * ch)) = vv;
+            }
+        }
+        __syncthreads();
+        // ---- S^T block kb: keys key0 + 16 kb + (4g + j) x this lane's query
+        float4_t st[PA_BN / 16];
+        #pragma unroll
+        for (int kb = 0; kb < PA_BN / 16; ++kb)
+        {
+            float4_t acc = { 0.f, 0.f, 0.f, 0.f };
+            #pragma unroll
+            for (int ks = 0; ks < HD / 32; ++ks)
+            {
+                const half8_t ka = *((const half8_t*) (Ks + (16 * kb + c) * KS + 32 * ks + 8 * g));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[ks], acc, 0, 0, 0);
+            }
+            st[kb] = acc;
+        }
+        // ---- online softmax for this lane's query: its 16 values here + the 3 other lane groups of the column
+        const int qpos = ctx + qi;
+        float mx = m_run;
+        #pragma unroll
+        for (int kb = 0; kb < PA_BN / 16; ++kb)
+        {
+            #pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                const int key = key0 + 16 * kb + 4 * g + j;
+                float s = st[kb][j] * a.scale;
+                s = (key <= qpos && key < kv_len) ? s : -1.0e30f;
+                st[kb][j] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = fmaxf(mx, xor_lane(mx, 16)); mx = fmaxf(mx, xor_lane(mx, 32));
+        const float corr = __expf(m_run - mx);
+        float ps = 0.0f;
+        half4_t pa[PA_BN / 16];
+        #pragma unroll
+        for (int kb = 0; kb < PA_BN / 16; ++kb)
+        {
+            float p[4];
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) { p[j] = st[kb][j] > -1.0e29f ? __expf(st[kb][j] - mx) : 0.0f; ps += p[j]; }
+            pa[kb] = half4_t{ (half_t) p[0], (half_t) p[1], (half_t) p[2], (half_t) p[3] };
+        }
+        ps += xor_lane(ps, 16); ps += xor_lane(ps, 32);
+        l_run = l_run * corr + ps;
+        m_run = mx;
+        // ---- rescale the accumulator rows (queries 4g + j of this wave) and add P V
+        float cr[4];
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) cr[j] = __shfl(corr, 4 * g + j, 64);
+        #pragma unroll
+        for (int nb = 0; nb < HD / 16; ++nb)
+        {
+            float4_t o = oc[nb];
+            o.x *= cr[0]; o.y *= cr[1]; o.z *= cr[2]; o.w *= cr[3];
+            #pragma unroll
+            for (int k2 = 0; k2 < PA_BN / 32; ++k2)
+            {
+                // contraction slot 8g + 4h + j = key 16 (2 k2 + h) + 4g + j: A = [P block 2 k2 | P block 2 k2 + 1], B = the same keys of V column (16 nb + c)
+                const half4_t p0 = pa[2 * k2], p1 = pa[2 * k2 + 1];
+                const half8_t pA = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w };
+                // ds_read_b64_tr_b16: the 16 lanes of a group hand in the addresses of a [4 keys][16 dims] block (lane c: key c >> 2, dims 4 (c & 3) ..)
+                // and lane c gets column c of it, i.e. V[key 0 .. 3][16 nb + c] - the transposition the B operand needs, done by the LDS unit
+                const half_t* vr = Vs + (32 * k2 + 4 * g + (c >> 2)) * KS + 16 * nb + 4 * (c & 3);
+                const half4_t v0 = lds_read_tr16(vr), v1 = lds_read_tr16(vr + 16 * KS);
+                const half8_t vB = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(pA, vB, o, 0, 0, 0);
+            }
+            oc[nb] = o;
+        }
+    }
+    // ---- normalise and store: rows = queries q0 + 4g + j, columns 16 nb + c
+    float li[4];
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) { const float lv = __shfl(l_run, 4 * g + j, 64); li[j] = lv > 0.0f ? 1.0f / lv : 0.0f; }
+    #pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+        const int qr = q0 + 4 * g + j;
+        if (qr < q_len)
+        {
+            half_t* op = a.out + (((size_t) b * q_len + qr) * hq + h) * HD + c;
+            #pragma unroll
+            for (int nb = 0; nb < HD / 16; ++nb) op[16 * nb] = (half_t) (oc[nb][j] * li[j]);
+        }
+    }
+}
+
+// q / out: fp16 [bsz][q_len][heads_q][head_dim]; k_pages / v_pages: fp16 [pages][page_size][heads_kv][head_dim] (what exl3_dequant_cache_paged writes);
+// cache_seqlens[b] = tokens of sequence b in the cache INCLUDING the q_len new ones (they were appended before the call, as the reference does);
+// causal: query i of the chunk attends to keys 0 .. cache_seqlens[b] - q_len + i.
+extern "C" int exl3_attn_prefill_paged(const void* q, void* out, const void* k_pages, const void* v_pages, const int32_t* block_table,
+                                       const int32_t* cache_seqlens, int bsz, int q_len, int heads_q, int heads_kv, int head_dim,
+                                       int blocks_per_seq, int page_size, float scale, void* stream)
+{
+    return exl3_attn_prefill_paged_strided(q, (int64_t) heads_q * head_dim, out, k_pages, v_pages, block_table, cache_seqlens, bsz, q_len, heads_q, heads_kv,
+                                           head_dim, blocks_per_seq, page_size, scale, stream);
+}
+
+// q as a column range of a wider row-major matrix (ldq halves per token): the prefill route's fused q|k|v GEMM output, consumed in place
+extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void* out, const void* k_pages, const void* v_pages, const int32_t* block_table,
+                                               const int32_t* cache_seqlens, int bsz, int q_len, int heads_q, int heads_kv, int head_dim,
+                                               int blocks_per_seq, int page_size, float scale, void* stream)
+{
+    EXL3_CHECK_ARG(ldq >= (int64_t) heads_q * head_dim && ldq % 8 == 0, "attn_prefill: bad q token stride");
+    EXL3_CHECK_ARG(q && out && k_pages && v_pages && block_table && cache_seqlens, "attn_prefill: null pointer");
+    EXL3_CHECK_ARG(head_dim == 128 || head_dim == 64, "attn_prefill: head_dim must be 128 or 64");
+    EXL3_CHECK_ARG(heads_kv >= 1 && heads_q % heads_kv == 0, "attn_prefill: heads_q must be a multiple of heads_kv");
+    EXL3_CHECK_ARG(page_size > 0 && page_size % PA_BN == 0 && blocks_per_seq >= 1, "attn_prefill: page size must be a multiple of 64");
+    EXL3_CHECK_ARG(q_len >= 1 && (q_len + PA_BM - 1) / PA_BM <= 65535 && heads_q <= 65535, "attn_prefill: bad q_len / heads");
+    if (bsz == 0) return EXL3_OK;
+    PrefillAttnArgs a;
+    a.q = (const half_t*) q; a.out = (half_t*) out; a.k_pages = (const half_t*) k_pages; a.v_pages = (const half_t*) v_pages;
+    a.block_table = block_table; a.cache_seqlens = cache_seqlens;
+    a.q_len = q_len; a.hq = heads_q; a.hkv = heads_kv; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.scale = scale; a.ldq = ldq;
+    const int gq = heads_q / heads_kv;
+    const int gw = gq % 4 == 0 ? 4 : (gq % 2 == 0 ? 2 : 1);                          // query heads per workgroup (they share a kv head)
+    dim3 grid((q_len + PA_BM - 1) / PA_BM, heads_q / gw, bsz);
+    hipStream_t st = (hipStream_t) stream;
+    #define PA_L(HDv) { if (gw == 4) attn_prefill_kernel<HDv, 4><<<grid, 1024, 0, st>>>(a); else if (gw == 2) attn_prefill_kernel<HDv, 2><<<grid, 512, 0, st>>>(a); \
+                        else attn_prefill_kernel<HDv, 1><<<grid, 256, 0, st>>>(a); }
+    if (head_dim == 128) PA_L(128) else PA_L(64)
+    #undef PA_L
+    return exl3_check_launch("attn_prefill");
+}

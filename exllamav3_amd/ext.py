@@ -1012,6 +1012,25 @@ def exl3_gemv_ex_act_rs(gu_slabs, gu_S: int, svh_g, svh_u, ss_prev, ss_new, hidd
     return [int(slab[0]) if slab[0] else 0], S.value
 
 
+def attn_prefill_paged(q, out, k_pages, v_pages, block_table, cache_seqlens, scale: float | None = None):
+    """Causal attention of a q_len-token chunk over paged fp16 K/V (the pages dequant_cache_paged expands, or an fp16 cache): q / out
+    (bsz, q_len, heads_q, head_dim) fp16, k_pages / v_pages (pages, page, heads_kv, head_dim) fp16, cache_seqlens int32 (bsz) INCLUDING the chunk
+    (append first, as the reference does).  The reference's flash_attn_with_kvcache(..., causal=True) step of the prefill path."""
+    _dev(q)
+    _req(q.dtype == torch.half and out.dtype == torch.half and q.shape == out.shape and q.dim() == 4 and out.is_contiguous(),
+         "attn_prefill: q / out must be float16 (bsz, q_len, heads, head_dim), out contiguous")
+    _req(q.stride(3) == 1 and q.stride(2) == q.shape[3] and q.stride(0) == q.shape[1] * q.stride(1) and q.stride(1) % 8 == 0,
+         "attn_prefill: q may only be strided between tokens (a column range of a wider matrix)")
+    _req(k_pages.dtype == torch.half and v_pages.dtype == torch.half and k_pages.shape == v_pages.shape and k_pages.dim() == 4
+         and k_pages.is_contiguous() and v_pages.is_contiguous(), "attn_prefill: k / v pages must be contiguous float16 (pages, page, heads_kv, head_dim)")
+    _req(block_table.dtype == torch.int32 and cache_seqlens.dtype == torch.int32 and block_table.is_contiguous(), "attn_prefill: block_table / cache_seqlens must be int32")
+    bsz, q_len, hq, hd = q.shape
+    _req(k_pages.shape[3] == hd and block_table.shape[0] == bsz, "attn_prefill: shape mismatch")
+    _check(_lib.lib().exl3_attn_prefill_paged_strided(_p(q), q.stride(1), _p(out), _p(k_pages), _p(v_pages), _p(block_table), _p(cache_seqlens), bsz, q_len, hq,
+                                              k_pages.shape[2], hd, block_table.shape[1], k_pages.shape[1],
+                                              float(scale if scale is not None else hd ** -0.5), _stream(q)))
+
+
 def attn_decode_qcache(q, out, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, max_len: int, scale: float | None = None,
                        workspace: torch.Tensor | None = None):
     """Decode attention straight from the quantized paged cache.  q / out: (bsz, heads_q, 128) fp16; caches (pages, page, G * bits) int32 +

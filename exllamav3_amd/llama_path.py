@@ -339,6 +339,8 @@ class SyntheticEXL3Llama:
     #: MI355X: 68.3k tok/s with it vs 70.6k inline -- the concurrent kernel slows the hipBLASLt GEMM and W is no longer Infinity-Cache-warm
     #: when the GEMM reads it -- so it stays off; kept as a tested option.
     reconstruct_ahead = False
+    #: prefill_chunk also runs the attention core (dequant_cache_paged + causal attention over the pages); off = the benchmark's default scope
+    prefill_attention = False
 
     #: include the decode attention over the quantized cache in decode_step_fused (bench.py --attention)
     with_attention = False
@@ -780,6 +782,11 @@ class SyntheticEXL3Llama:
             self.pf_sl = torch.zeros((1,), dtype=torch.int32, device=dev)
             self.pf_cache = [torch.zeros((pages, self.page, G * self.kv_bits), dtype=torch.int32, device=dev) for _ in range(2)] + \
                             [torch.zeros((pages, self.page, G), dtype=torch.half, device=dev) for _ in range(2)]
+            # prefill attention (optional): dequantized pages, lengths incl. the chunk, attention output
+            self.pf_kd = torch.zeros((pages, self.page, self.hkv * hd), dtype=torch.half, device=dev)
+            self.pf_vd = torch.zeros_like(self.pf_kd)
+            self.pf_len = torch.full((1,), tokens, dtype=torch.int32, device=dev)
+            self.pf_ao = torch.empty((tokens, self.hq * hd), dtype=torch.half, device=dev)
         x = self.px0.clone()
         be = self.backend
         xn = torch.empty_like(x)
@@ -809,8 +816,18 @@ class SyntheticEXL3Llama:
                 ext.quant_cache_paged(k.view(1, tokens, -1), self.pf_cache[0], self.pf_cache[2], v.view(1, tokens, -1), self.pf_cache[1],
                                       self.pf_cache[3], self.pf_sl, self.pf_bt, self.page, tokens)
                 q = q.view(tokens, -1)
+            if self.prefill_attention:
+                # the reference's prefill attention step: dequantize the (just appended) pages, causal attention of the chunk over them
+                # (cache/quant.py:83-117 + flash_attn_with_kvcache; here exl3_attn_prefill.hip).  q may be a column range of the fused q|k|v output.
+                ext.dequant_cache_paged(self.pf_cache[0], self.pf_cache[2], self.pf_kd, self.pf_cache[1], self.pf_cache[3], self.pf_vd, self.pf_len,
+                                        self.pf_bt, self.page)
+                q2 = q if q.dim() == 2 else q.reshape(tokens, -1)
+                q4 = q2.as_strided((1, tokens, self.hq, hd), (tokens * q2.stride(0), q2.stride(0), hd, 1), q2.storage_offset())
+                ext.attn_prefill_paged(q4, self.pf_ao.view(1, tokens, self.hq, hd), self.pf_kd.view(-1, self.page, self.hkv, hd),
+                                       self.pf_vd.view(-1, self.page, self.hkv, hd), self.pf_bt, self.pf_len)
+                q = self.pf_ao
             if self.tp == 1:
-                L["o"].forward_add_residual(q, x)                           # residual add in the GEMM epilogue (q: attention output stand-in)
+                L["o"].forward_add_residual(q, x)                           # residual add in the GEMM epilogue (q: attention output, or its stand-in)
                 ext.rms_norm(x, L["norm2"], xn, self.eps)
             else:
                 o = L["o"].forward(q.contiguous().view(tokens, -1))

@@ -278,6 +278,18 @@ int exl3_attn_decode_qcache(const void* q, void* out, const void* k_cache, const
                             const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
                             int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
                             float* workspace, int64_t workspace_floats, void* stream);
+/* Prefill (multi-token) causal attention over paged fp16 K/V -- the attention step of the reference's prefill path: cache/quant.py:83-117
+ * dequantizes the pages (exl3_dequant_cache_paged), then flash_attn_with_kvcache(q, k_pages, v_pages, block_table, cache_seqlens, causal) attends.
+ * q / out fp16 [bsz][q_len][heads_q][head_dim] (head_dim 128 or 64); k_pages / v_pages fp16 [pages][page_size][heads_kv][head_dim];
+ * cache_seqlens[b] = tokens of sequence b in the cache INCLUDING the q_len new ones (appended before the call);
+ * query i of the chunk attends to keys 0 .. cache_seqlens[b] - q_len + i.  fp32 softmax / accumulation, fp16 probabilities and output. */
+int exl3_attn_prefill_paged(const void* q, void* out, const void* k_pages, const void* v_pages, const int32_t* block_table,
+                            const int32_t* cache_seqlens, int bsz, int q_len, int heads_q, int heads_kv, int head_dim,
+                            int blocks_per_seq, int page_size, float scale, void* stream);
+/* ... with q as a column range of a wider row-major matrix (ldq halves per token, a multiple of 8): the fused q|k|v prefill GEMM output in place */
+int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void* out, const void* k_pages, const void* v_pages, const int32_t* block_table,
+                                    const int32_t* cache_seqlens, int bsz, int q_len, int heads_q, int heads_kv, int head_dim,
+                                    int blocks_per_seq, int page_size, float scale, void* stream);
 
 /* Diagnostics only: copy [byte_offset, byte_offset + nbytes) of the per-device split-k workspace to dst (tools/gemv_timeline.py). */
 int exl3_debug_copy_workspace(void* dst, int64_t byte_offset, int64_t nbytes, void* stream);

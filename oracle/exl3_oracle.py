@@ -593,6 +593,27 @@ def routing_std(hidden: np.ndarray, gate: np.ndarray, k: int, bias: np.ndarray |
     return scores, order.astype(np.int64), wf.astype(np.float16)
 
 
+def attn_prefill(q: np.ndarray, k: np.ndarray, v: np.ndarray, kv_lens, scale: float | None = None) -> np.ndarray:
+    """Causal attention of a chunk of new tokens over the (dequantized) cache, as the reference's prefill path attends
+    (flash_attn_with_kvcache(..., causal=True) after cache/quant.py:83-117): q (b, T, hq, d) fp16; k / v (b, S, hkv, d) fp16 with kv_lens[b] valid
+    rows INCLUDING the T new tokens; query i sees keys 0 .. kv_lens[b] - T + i.  fp32 math, fp16 result."""
+    b, T, hq, d = q.shape
+    hkv = k.shape[2]
+    gq = hq // hkv
+    sc = np.float32(scale if scale is not None else d ** -0.5)
+    out = np.zeros((b, T, hq, d), dtype=np.float32)
+    for bi in range(b):
+        L = int(kv_lens[bi]); ctx = L - T
+        mask = np.arange(L)[None, :] <= (ctx + np.arange(T))[:, None]
+        for h in range(hq):
+            kk = k[bi, :L, h // gq].astype(np.float32); vv = v[bi, :L, h // gq].astype(np.float32)
+            s = (q[bi, :, h].astype(np.float32) @ kk.T) * sc
+            s = np.where(mask, s, np.float32(-1e30))
+            p = np.exp(s - s.max(-1, keepdims=True)); p = np.where(mask, p, 0.0); p /= p.sum(-1, keepdims=True)
+            out[bi, :, h] = p @ vv
+    return out.astype(np.float16)
+
+
 def attn_decode_qcache(q: np.ndarray, k_deq: np.ndarray, v_deq: np.ndarray, lens, scale: float | None = None) -> np.ndarray:
     """Decode attention of one new token per sequence over the DEQUANTIZED cache (what the reference attends to after dequant_cache_paged,
     libtorch/attention.cpp:246-504): q (b, hq, d) fp16; k_deq / v_deq (b, T, hkv, d) fp16 = kv_dequant of the cache; lens[b] tokens valid.

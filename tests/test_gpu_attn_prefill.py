@@ -1,0 +1,103 @@
+"""Prefill (multi-token) causal attention over paged fp16 K/V (exl3_attn_prefill.hip) against the oracle: the reference's prefill path attends with
+flash_attn_with_kvcache(causal=True) over the pages dequant_cache_paged expands (cache/quant.py:83-117).  Tolerance: fp16 probabilities into the
+second product and an fp16 result -> 2e-2 of the output RMS (the decode-attention tests use 1e-2 with fp32 probabilities)."""
+import os, sys
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import exl3_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("hd,hq,hkv", [(128, 8, 2), (64, 8, 4), (128, 4, 4)])
+@pytest.mark.parametrize("q_len,ctx", [(64, [0, 0]), (100, [300, 17]), (1, [255, 256]), (257, [5, 700])])
+def test_attn_prefill_paged_matches_oracle(dev, hd, hq, hkv, q_len, ctx):
+    """Chunks that start an empty cache, continue a context (different lengths per sequence, page-crossing, a page-aligned one), a single
+    token (== decode semantics) and a chunk that is not a multiple of the 64-query workgroup tile; permuted block table; GQA 4 / 2 / 1."""
+    from exllamav3_amd import ext
+    page, bsz = 256, 2
+    rng = np.random.default_rng(hd + q_len)
+    kv_lens = np.array([c + q_len for c in ctx], np.int32)
+    pps = int((kv_lens.max() + page - 1) // page) + 1
+    npages = bsz * pps + 1
+    bt = rng.permutation(npages)[: bsz * pps].reshape(bsz, pps).astype(np.int32)
+    k = rng.standard_normal((bsz, pps * page, hkv, hd)).astype(np.float16); v = rng.standard_normal((bsz, pps * page, hkv, hd)).astype(np.float16)
+    q = (rng.standard_normal((bsz, q_len, hq, hd)) * 1.5).astype(np.float16)
+    kp = np.full((npages, page, hkv, hd), np.nan, np.float16); vp = kp.copy()      # rows beyond the length / unmapped pages must not matter
+    for b in range(bsz):
+        for pg in range(pps):
+            kp[bt[b, pg]] = k[b, pg * page:(pg + 1) * page]; vp[bt[b, pg]] = v[b, pg * page:(pg + 1) * page]
+        kp[bt[b, kv_lens[b] // page], kv_lens[b] % page:] = np.nan if kv_lens[b] % page else kp[bt[b, kv_lens[b] // page], 0:]
+    out = torch.full((bsz, q_len, hq, hd), float("nan"), dtype=torch.half, device=dev)
+    ext.attn_prefill_paged(_t(q, dev), out, _t(kp, dev), _t(vp, dev), _t(bt, dev), _t(kv_lens, dev))
+    ref = o.attn_prefill(q, k, v, kv_lens).astype(np.float32)
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
+
+
+def test_attn_prefill_single_token_equals_decode_attention(dev):
+    """q_len == 1 over a quantized cache: dequant_cache_paged + attn_prefill_paged (the reference's route) against attn_decode_qcache (this
+    build's quant-cache-direct decode kernel): the two attention implementations agree to the quantization-independent tolerance."""
+    from exllamav3_amd import ext
+    hd, hq, hkv, page, bsz, pps, bits = 128, 8, 2, 256, 2, 2, 4
+    rng = np.random.default_rng(1)
+    lens = np.array([301, 77], np.int32)
+    G = hkv * hd // 32
+    npages = bsz * pps
+    bt = rng.permutation(npages).reshape(bsz, pps).astype(np.int32)
+    ck = rng.standard_normal((npages, page, hkv * hd)).astype(np.float16); cv = rng.standard_normal((npages, page, hkv * hd)).astype(np.float16)
+    kq, ks = o.kv_quant(ck, bits); vq, vs = o.kv_quant(cv, bits)
+    T = lambda a: _t(a.view(np.int32) if a.dtype == np.uint32 else a, dev)
+    dkq, dks, dvq, dvs = T(kq), T(ks), T(vq), T(vs)
+    q = rng.standard_normal((bsz, hq, hd)).astype(np.float16)
+    o_dec = torch.empty((bsz, hq, hd), dtype=torch.half, device=dev)
+    ext.attn_decode_qcache(_t(q, dev), o_dec, dkq, dks, dvq, dvs, _t(bt, dev), _t(lens, dev), pps * page)
+    kd = torch.zeros((npages, page, hkv * hd), dtype=torch.half, device=dev); vd = torch.zeros_like(kd)
+    ext.dequant_cache_paged(dkq, dks, kd, dvq, dvs, vd, _t(lens, dev), _t(bt, dev), page)
+    o_pre = torch.empty((bsz, 1, hq, hd), dtype=torch.half, device=dev)
+    ext.attn_prefill_paged(_t(q, dev).view(bsz, 1, hq, hd), o_pre, kd.view(npages, page, hkv, hd), vd.view(npages, page, hkv, hd), _t(bt, dev), _t(lens, dev))
+    a, b_ = o_dec.float().cpu().numpy(), o_pre.float().cpu().numpy().reshape(bsz, hq, hd)
+    assert np.abs(a - b_).max() / np.sqrt((a ** 2).mean()) < 2e-2
+
+
+def test_prefill_chunk_with_attention_matches_oracle(dev):
+    """prefill_chunk with the attention core switched on (fused q|k|v GEMM -> RoPE -> quantized append -> dequant_cache_paged -> causal attention
+    over the pages -> o_proj -> MLP) through one small layer against the oracle composition on EVERY token row (attention couples the rows):
+    residual stream after the layer and the last token's logits."""
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 256, 512, 1, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4)
+    model.prefill_attention = True
+    T = 300
+    logits = model.prefill_chunk(T).float().cpu().numpy()
+    assert np.isfinite(logits).all()
+    _np = lambda t: t.detach().cpu().numpy()
+    lin = lambda l, a, **kw: o.linear_forward(a, _np(l.trellis), _np(l.suh), _np(l.svh), l.K, 1 if l.mcg else (2 if l.mul1 else 0), **kw)
+    x = _np(model.px0)
+    L = model.layers[0]
+    xn = o.rms_norm(x, _np(L["norm1"]), model.eps)
+    q, k, v = lin(L["q"], xn), lin(L["k"], xn), lin(L["v"], xn)
+    q4, k4 = o.rope(q.reshape(1, T, model.hq, 128), k.reshape(1, T, model.hkv, 128), _np(model.inv_freq), position=0, rope_mode=o.ROPE_NEOX)
+    kq, ks = o.kv_quant(k4.reshape(T, -1), 4); vq, vs = o.kv_quant(v.reshape(T, -1), 4)
+    kd = o.kv_dequant(kq, ks, 4).reshape(1, T, model.hkv, 128); vd = o.kv_dequant(vq, vs, 4).reshape(1, T, model.hkv, 128)
+    ao = o.attn_prefill(q4, kd, vd, np.array([T]))
+    ov = lin(L["o"], ao.reshape(T, -1), out_fp32=True)
+    xn2, x1 = o.rms_norm(ov, _np(L["norm2"]), model.eps, residual_in=x)
+    gf, uf = lin(L["gate"], xn2).astype(np.float32), lin(L["up"], xn2).astype(np.float32)
+    a = (gf / (1 + np.exp(-gf)) * uf).astype(np.float16)
+    d = lin(L["down"], a, out_fp32=True)
+    x2 = (x1.astype(np.float32) + d).astype(np.float16)
+    got_x = _np(model.px_out).astype(np.float32)
+    rel = lambda g, r: np.abs(g - r.astype(np.float32)).max() / np.sqrt((r.astype(np.float32) ** 2).mean())
+    assert rel(got_x, x2) < 3e-2
+    xl = o.rms_norm(x2[-1:], _np(model.final_norm), model.eps)
+    ref = lin(model.lm_head, xl).astype(np.float32)
+    assert rel(logits, ref) < 5e-2
