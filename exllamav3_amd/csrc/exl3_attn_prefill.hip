@@ -40,146 +40,202 @@ __device__ __forceinline__ half4_t lds_read_tr16(const half_t* p)
     return __builtin_bit_cast(half4_t, r);
 }
 
-// GW query heads of ONE kv head per workgroup (GW in {1, 2, 4}, GW | heads_q / heads_kv): 4 GW waves share every staged K/V tile, so the
-// staging work per matrix instruction drops by GW (with one head per workgroup the four q heads of a Llama kv head each re-staged it)
+// GW query heads of ONE kv head per workgroup (GW in {1, 2, 4}, GW | heads_q / heads_kv): 2 GW waves share every staged K/V tile, so the
+// staging work per matrix instruction drops by GW (with one head per workgroup the four q heads of a Llama kv head each re-staged it).
+// A wave owns 32 queries of one head as two 16-query groups: every K and V fragment read from LDS feeds two matrix instructions (with one
+// group per wave the LDS pipe, not the matrix pipe, bounded the loop: 32 KB of fragment reads per 32 instructions).
 template <int HD, int GW>
-__global__ __launch_bounds__(256 * GW)
+__global__ __launch_bounds__(128 * GW)
 void attn_prefill_kernel(const PrefillAttnArgs a)
 {
-    constexpr int NT = 256 * GW;
-    constexpr int KS = HD + 8;                                  // K tile row stride in halves (16-byte aligned rows, rotated banks)
+    constexpr int NT = 128 * GW;
+    constexpr int KS = HD + 8;                                  // tile row stride in halves (16-byte aligned rows, rotated banks)
     __shared__ __attribute__((aligned(16))) half_t Ks[PA_BN * KS];
-    __shared__ __attribute__((aligned(16))) half_t Vs[PA_BN * KS];   // row-major like K; the PV operand is gathered with the LDS transpose read
-    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all & 3, g = lane >> 4, c = lane & 15;
-    const int qt = blockIdx.x, h = blockIdx.y * GW + (wave_all >> 2), b = blockIdx.z;
+    constexpr int VS = HD + 16;                                 // V rows 8 dwords apart (mod 64 banks): the 16 four-lane row segments of a transpose read tile the banks
+    __shared__ __attribute__((aligned(16))) half_t Vs[PA_BN * VS];   // row-major like K; the PV operand is gathered with the LDS transpose read
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all & 1, g = lane >> 4, c = lane & 15;
+    const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y * GW + (wave_all >> 1), b = blockIdx.z;   // long (late) query tiles are dispatched first
     const int q_len = a.q_len, hq = a.hq, hkv = a.hkv, page_size = a.page_size;
-    const int kvh = (blockIdx.y * GW) / (hq / hkv);           // the same for all GW heads of the workgroup
+    const int kvh = (blockIdx.y * GW) / (hq / hkv);             // the same for all GW heads of the workgroup
     const int kv_len = a.cache_seqlens[b];
     const int ctx = kv_len - q_len;                             // query i sits at position ctx + i and sees keys 0 .. ctx + i
-    const int q0 = qt * PA_BM + wave * 16;                      // this wave's first query
-    const int qi = min(q0 + c, q_len - 1);                      // this lane's query (column of S^T); clamped rows are never stored
+    const int q0 = qt * PA_BM + wave * 32;                      // this wave's first query; group u covers q0 + 16 u .. + 15
     const int32_t* bt = a.block_table + (size_t) b * a.blocks_per_seq;
+    const float sl = a.scale * 1.44269504f;                      // scale * log2(e)
 
     // Q rows of the wave as B operands of S^T = K Q^T: contraction slots 8g .. 8g+7 of step ks are head dims 32 ks + 8g ..
-    half8_t qf[HD / 32];
+    half8_t qf[2][HD / 32];
+    int qpos[2];                                                // this lane's query (column of S^T) per group; clamped rows are never stored
+    #pragma unroll
+    for (int u = 0; u < 2; ++u)
     {
+        const int qi = min(q0 + 16 * u + c, q_len - 1);
+        qpos[u] = ctx + qi;
         const half_t* qp = a.q + ((size_t) b * q_len + qi) * a.ldq + (size_t) h * HD;
         #pragma unroll
-        for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = *((const half8_t*) (qp + 32 * ks + 8 * g));
+        for (int ks = 0; ks < HD / 32; ++ks) qf[u][ks] = *((const half8_t*) (qp + 32 * ks + 8 * g));
     }
-    float m_run = -1.0e30f, l_run = 0.0f;
-    float4_t oc[HD / 16];
+    float m_run[2] = { -1.0e30f, -1.0e30f }, l_run[2] = { 0.0f, 0.0f };
+    float4_t oc[2][HD / 16];
     #pragma unroll
-    for (int nb = 0; nb < HD / 16; ++nb) oc[nb] = float4_t{ 0.f, 0.f, 0.f, 0.f };
+    for (int u = 0; u < 2; ++u)
+        #pragma unroll
+        for (int nb = 0; nb < HD / 16; ++nb) oc[u][nb] = float4_t{ 0.f, 0.f, 0.f, 0.f };
 
     const int q_last = min(qt * PA_BM + PA_BM, q_len) - 1;      // last query of the workgroup: the tiles needed are those up to its position
     const int ntiles = (ctx + q_last) / PA_BN + 1;
+    // K/V tiles travel HBM -> registers -> LDS; the loads of tile kt + 1 are issued before the matrix work of tile kt and land in LDS after
+    // the barrier that ends it (one register set: 2 x 16 bytes per staging slot)
+    constexpr int CH = HD / 8;                                  // 16-byte chunks per key
+    constexpr int SLOTS = (PA_BN * CH + NT - 1) / NT;
+    half8_t kreg[SLOTS], vreg[SLOTS];
+    auto fetch_tile = [&](int kt)
+    {
+        const int key0 = kt * PA_BN;                            // a tile never straddles a page (64 | page size)
+        const int64_t page = bt[min(key0 / page_size, a.blocks_per_seq - 1)];
+        #pragma unroll
+        for (int j = 0; j < SLOTS; ++j)
+        {
+            const int idx = tid + NT * j;
+            const int key = idx / CH, ch = idx % CH;
+            const bool ok = key0 + key < kv_len && idx < PA_BN * CH;
+            const size_t row = ((size_t) page * page_size + ((key0 + key) % page_size)) * hkv + kvh;
+            half8_t kv = { 0, 0, 0, 0, 0, 0, 0, 0 }, vv = kv;
+            if (ok) { kv = *((const half8_t*) (a.k_pages + row * HD + 8 * ch)); vv = *((const half8_t*) (a.v_pages + row * HD + 8 * ch)); }
+            kreg[j] = kv; vreg[j] = vv;
+        }
+    };
+    fetch_tile(0);
     for (int kt = 0; kt < ntiles; ++kt)
     {
         const int key0 = kt * PA_BN;
         __syncthreads();                                        // the previous tile is no longer read
-        // ---- stage K and V (both row-major): 64 keys x HD halves each, 16 bytes per load; a tile never straddles a page (64 | page size)
+        #pragma unroll
+        for (int j = 0; j < SLOTS; ++j)
         {
-            const int64_t page = bt[min(key0 / page_size, a.blocks_per_seq - 1)];
-            constexpr int CH = HD / 8;                          // 16-byte chunks per key
-            #pragma unroll
-            for (int j = 0; j < (PA_BN * CH + NT - 1) / NT; ++j)
-            {
-                const int idx = tid + NT * j;
-                if ((PA_BN * CH) % NT != 0 && idx >= PA_BN * CH) break;
-                const int key = idx / CH, ch = idx % CH;
-                const bool ok = key0 + key < kv_len;
-                const size_t row = ((size_t) page * page_size + ((key0 + key) % page_size)) * hkv + kvh;
-                half8_t kv = { 0, 0, 0, 0, 0, 0, 0, 0 }, vv = kv;
-                if (ok) { kv = *((const half8_t*) (a.k_pages + row * HD + 8 * ch)); vv = *((const half8_t*) (a.v_pages + row * HD + 8 * ch)); }
-                *((half8_t*) (Ks + key * KS + 8 * ch)) = kv;
-                *((half8_t*) (Vs + key * KS + 8 * ch)) = vv;
-            }
+            const int idx = tid + NT * j;
+            if ((PA_BN * CH) % NT != 0 && idx >= PA_BN * CH) break;
+            const int key = idx / CH, ch = idx % CH;
+            *((half8_t*) (Ks + key * KS + 8 * ch)) = kreg[j];
+            *((half8_t*) (Vs + key * VS + 8 * ch)) = vreg[j];
         }
         __syncthreads();
-        // ---- S^T block kb: keys key0 + 16 kb + (4g + j) x this lane's query
-        float4_t st[PA_BN / 16];
+        if (kt + 1 < ntiles) fetch_tile(kt + 1);
+        // ---- S^T block kb: keys key0 + 16 kb + (4g + j) x this lane's query of either group
+        float4_t st[2][PA_BN / 16];
         #pragma unroll
         for (int kb = 0; kb < PA_BN / 16; ++kb)
         {
-            float4_t acc = { 0.f, 0.f, 0.f, 0.f };
+            float4_t acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = acc0;
             #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks)
             {
                 const half8_t ka = *((const half8_t*) (Ks + (16 * kb + c) * KS + 32 * ks + 8 * g));
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[ks], acc, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[0][ks], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[1][ks], acc1, 0, 0, 0);
             }
-            st[kb] = acc;
+            st[0][kb] = acc0; st[1][kb] = acc1;
         }
-        // ---- online softmax for this lane's query: its 16 values here + the 3 other lane groups of the column
-        const int qpos = ctx + qi;
-        float mx = m_run;
-        #pragma unroll
-        for (int kb = 0; kb < PA_BN / 16; ++kb)
+        // ---- online softmax for this lane's queries: its 16 values here + the 3 other lane groups of the column.  Scores stay unscaled:
+        // p = 2^((s - max) * scale * log2 e) is one fma + v_exp_f32 per value.  Only tiles on the diagonal or at the end of the sequence are masked
+        // (a wave-uniform branch); a masked score is -1e30 and underflows to p = 0 because every query has key 0 in tile 0 (finite running max).
+        half4_t pa[2][PA_BN / 16];
+        float corr[2];
+        const bool masked = key0 + PA_BN - 1 > ctx + min(q0, q_len - 1) || key0 + PA_BN > kv_len;
+        if (masked)
         {
             #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int u = 0; u < 2; ++u)
+                #pragma unroll
+                for (int kb = 0; kb < PA_BN / 16; ++kb)
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                    {
+                        const int key = key0 + 16 * kb + 4 * g + j;
+                        if (!(key <= qpos[u] && key < kv_len)) st[u][kb][j] = -1.0e30f;
+                    }
+        }
+        #pragma unroll
+        for (int u = 0; u < 2; ++u)
+        {
+            float mx = m_run[u];
+            #pragma unroll
+            for (int kb = 0; kb < PA_BN / 16; ++kb)
+                mx = fmaxf(fmaxf(mx, fmaxf(st[u][kb][0], st[u][kb][1])), fmaxf(st[u][kb][2], st[u][kb][3]));
+            mx = fmaxf(mx, xor_lane(mx, 16)); mx = fmaxf(mx, xor_lane(mx, 32));
+            corr[u] = __builtin_amdgcn_exp2f((m_run[u] - mx) * sl);
+            const float mxs = mx * sl;
+            float ps = 0.0f;
+            #pragma unroll
+            for (int kb = 0; kb < PA_BN / 16; ++kb)
             {
-                const int key = key0 + 16 * kb + 4 * g + j;
-                float s = st[kb][j] * a.scale;
-                s = (key <= qpos && key < kv_len) ? s : -1.0e30f;
-                st[kb][j] = s;
-                mx = fmaxf(mx, s);
+                float p[4];
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) { p[j] = __builtin_amdgcn_exp2f(fmaf(st[u][kb][j], sl, -mxs)); ps += p[j]; }
+                pa[u][kb] = half4_t{ (half_t) p[0], (half_t) p[1], (half_t) p[2], (half_t) p[3] };
             }
+            ps += xor_lane(ps, 16); ps += xor_lane(ps, 32);
+            l_run[u] = l_run[u] * corr[u] + ps;
+            m_run[u] = mx;
         }
-        mx = fmaxf(mx, xor_lane(mx, 16)); mx = fmaxf(mx, xor_lane(mx, 32));
-        const float corr = __expf(m_run - mx);
-        float ps = 0.0f;
-        half4_t pa[PA_BN / 16];
-        #pragma unroll
-        for (int kb = 0; kb < PA_BN / 16; ++kb)
+        // ---- rescale the accumulator rows (queries 4g + j of each group) where the running max moved, and add P V
+        if (!__all(corr[0] == 1.0f && corr[1] == 1.0f))
         {
-            float p[4];
+            float cr[2][4];
             #pragma unroll
-            for (int j = 0; j < 4; ++j) { p[j] = st[kb][j] > -1.0e29f ? __expf(st[kb][j] - mx) : 0.0f; ps += p[j]; }
-            pa[kb] = half4_t{ (half_t) p[0], (half_t) p[1], (half_t) p[2], (half_t) p[3] };
+            for (int u = 0; u < 2; ++u)
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) cr[u][j] = __shfl(corr[u], 4 * g + j, 64);
+            #pragma unroll
+            for (int u = 0; u < 2; ++u)
+                #pragma unroll
+                for (int nb = 0; nb < HD / 16; ++nb)
+                {
+                    oc[u][nb].x *= cr[u][0]; oc[u][nb].y *= cr[u][1]; oc[u][nb].z *= cr[u][2]; oc[u][nb].w *= cr[u][3];
+                }
         }
-        ps += xor_lane(ps, 16); ps += xor_lane(ps, 32);
-        l_run = l_run * corr + ps;
-        m_run = mx;
-        // ---- rescale the accumulator rows (queries 4g + j of this wave) and add P V
-        float cr[4];
-        #pragma unroll
-        for (int j = 0; j < 4; ++j) cr[j] = __shfl(corr, 4 * g + j, 64);
         #pragma unroll
         for (int nb = 0; nb < HD / 16; ++nb)
         {
-            float4_t o = oc[nb];
-            o.x *= cr[0]; o.y *= cr[1]; o.z *= cr[2]; o.w *= cr[3];
+            float4_t o0 = oc[0][nb], o1 = oc[1][nb];
             #pragma unroll
             for (int k2 = 0; k2 < PA_BN / 32; ++k2)
             {
-                // contraction slot 8g + 4h + j = key 16 (2 k2 + h) + 4g + j: A = [P block 2 k2 | P block 2 k2 + 1], B = the same keys of V column (16 nb + c)
-                const half4_t p0 = pa[2 * k2], p1 = pa[2 * k2 + 1];
-                const half8_t pA = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w };
+                // contraction slot 8g + 4h + j = key 16 (2 k2 + h) + 4g + j: A = [P block 2 k2 | P block 2 k2 + 1], B = the same keys of V column (16 nb + c).
                 // ds_read_b64_tr_b16: the 16 lanes of a group hand in the addresses of a [4 keys][16 dims] block (lane c: key c >> 2, dims 4 (c & 3) ..)
                 // and lane c gets column c of it, i.e. V[key 0 .. 3][16 nb + c] - the transposition the B operand needs, done by the LDS unit
-                const half_t* vr = Vs + (32 * k2 + 4 * g + (c >> 2)) * KS + 16 * nb + 4 * (c & 3);
-                const half4_t v0 = lds_read_tr16(vr), v1 = lds_read_tr16(vr + 16 * KS);
+                const half_t* vr = Vs + (32 * k2 + 4 * g + (c >> 2)) * VS + 16 * nb + 4 * (c & 3);
+                const half4_t v0 = lds_read_tr16(vr), v1 = lds_read_tr16(vr + 16 * VS);
                 const half8_t vB = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
-                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(pA, vB, o, 0, 0, 0);
+                #pragma unroll
+                for (int u = 0; u < 2; ++u)
+                {
+                    const half4_t p0 = pa[u][2 * k2], p1 = pa[u][2 * k2 + 1];
+                    const half8_t pA = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w };
+                    if (u == 0) o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pA, vB, o0, 0, 0, 0);
+                    else        o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pA, vB, o1, 0, 0, 0);
+                }
             }
-            oc[nb] = o;
+            oc[0][nb] = o0; oc[1][nb] = o1;
         }
     }
-    // ---- normalise and store: rows = queries q0 + 4g + j, columns 16 nb + c
-    float li[4];
+    // ---- normalise and store: rows = queries q0 + 16 u + 4g + j, columns 16 nb + c
     #pragma unroll
-    for (int j = 0; j < 4; ++j) { const float lv = __shfl(l_run, 4 * g + j, 64); li[j] = lv > 0.0f ? 1.0f / lv : 0.0f; }
-    #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int u = 0; u < 2; ++u)
     {
-        const int qr = q0 + 4 * g + j;
-        if (qr < q_len)
+        float li[4];
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) { const float lv = __shfl(l_run[u], 4 * g + j, 64); li[j] = lv > 0.0f ? 1.0f / lv : 0.0f; }
+        #pragma unroll
+        for (int j = 0; j < 4; ++j)
         {
-            half_t* op = a.out + (((size_t) b * q_len + qr) * hq + h) * HD + c;
-            #pragma unroll
-            for (int nb = 0; nb < HD / 16; ++nb) op[16 * nb] = (half_t) (oc[nb][j] * li[j]);
+            const int qr = q0 + 16 * u + 4 * g + j;
+            if (qr < q_len)
+            {
+                half_t* op = a.out + (((size_t) b * q_len + qr) * hq + h) * HD + c;
+                #pragma unroll
+                for (int nb = 0; nb < HD / 16; ++nb) op[16 * nb] = (half_t) (oc[u][nb][j] * li[j]);
+            }
         }
     }
 }
@@ -215,8 +271,8 @@ extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void*
     const int gw = gq % 4 == 0 ? 4 : (gq % 2 == 0 ? 2 : 1);                          // query heads per workgroup (they share a kv head)
     dim3 grid((q_len + PA_BM - 1) / PA_BM, heads_q / gw, bsz);
     hipStream_t st = (hipStream_t) stream;
-    #define PA_L(HDv) { if (gw == 4) attn_prefill_kernel<HDv, 4><<<grid, 1024, 0, st>>>(a); else if (gw == 2) attn_prefill_kernel<HDv, 2><<<grid, 512, 0, st>>>(a); \
-                        else attn_prefill_kernel<HDv, 1><<<grid, 256, 0, st>>>(a); }
+    #define PA_L(HDv) { if (gw == 4) attn_prefill_kernel<HDv, 4><<<grid, 512, 0, st>>>(a); else if (gw == 2) attn_prefill_kernel<HDv, 2><<<grid, 256, 0, st>>>(a); \
+                        else attn_prefill_kernel<HDv, 1><<<grid, 128, 0, st>>>(a); }
     if (head_dim == 128) PA_L(128) else PA_L(64)
     #undef PA_L
     return exl3_check_launch("attn_prefill");

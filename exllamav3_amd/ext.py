@@ -398,8 +398,8 @@ class BC_Attention:
     """libtorch/attention.h:24-228, attention.cpp:246-504: the decode attention block of one layer as one runner -- q / k / v projections,
     head norms + RoPE, append to the quantized paged cache, flash-decoding attention straight from the quantized cache, o_proj.
     Same constructor arguments and run() signature as the reference's class.  This build covers the Llama / Mixtral subset of it:
-    quantized cache (`quant_cache`), one new token per sequence (q_len == 1, bsz <= 8), no output gate, no V norm, no K-as-V, no sinks, no
-    padded hidden dim, no llama-4 position scaling; anything else raises at construction (or at run for q_len > 1), it never degrades silently.
+    quantized cache (`quant_cache`), q_len 1 .. 16 new tokens per sequence, bsz <= 8, no output gate, no V norm, no K-as-V, no sinks, no
+    padded hidden dim, no llama-4 position scaling; anything else raises at construction, it never degrades silently.
     The reference's slot machinery exists to hold AOT-compiled Triton kernels and their statics: needs_configure() is always False here and
     configure_slot() accepts and ignores its arguments; capture the whole decode step in one hipGraph instead (all launches of run() are
     capturable, the per-call tensors are read by pointer)."""
@@ -439,52 +439,69 @@ class BC_Attention:
     def configure_slot(self, *args, **kwargs):
         return None
 
-    def _statics(self, bsz: int, pages_per_seq: int, dev):
-        key = (bsz, pages_per_seq)
+    def _statics(self, bsz: int, q_len: int, pages_per_seq: int, dev):
+        key = (bsz, q_len, pages_per_seq)
         st = self._st.get(key)
         if st is None:
             hq, hkv, hd = self.num_q_heads, self.num_kv_heads, self.head_dim
             max_len = pages_per_seq * self.page_size
+            rows = bsz * q_len
             st = {
-                "q": torch.empty((bsz, 1, hq, hd), dtype=torch.half, device=dev),
-                "kv": torch.empty((2, bsz, hkv * hd), dtype=torch.half, device=dev),
-                "o": torch.empty((bsz, hq, hd), dtype=torch.half, device=dev),
+                "q": torch.empty((bsz, q_len, hq, hd), dtype=torch.half, device=dev),
+                "kv": torch.empty((2, rows, hkv * hd), dtype=torch.half, device=dev),
+                "o": torch.empty((bsz, q_len, hq, hd), dtype=torch.half, device=dev),
                 "lens": torch.empty((bsz,), dtype=torch.int32, device=dev),
-                "ws": torch.empty((bsz * (hq * hd // 128) * ((max_len + 31) // 32) * 132,), dtype=torch.float, device=dev),
-                "xh": torch.empty((2, bsz, self.hidden_size), dtype=torch.half, device=dev),
+                "xh": torch.empty((2, rows, self.hidden_size), dtype=torch.half, device=dev),
                 "max_len": max_len,
             }
+            if q_len == 1:
+                st["ws"] = torch.empty((bsz * (hq * hd // 128) * ((max_len + 31) // 32) * 132,), dtype=torch.float, device=dev)
+            else:
+                # q_len > 1: the pages of the block table are expanded into a dense fp16 window (cache/q_cache.cuh:64-77, what the reference's
+                # quantized cache layer hands to flash-attn) and the chunk attends over it through an identity block table
+                st["kd"] = torch.empty((bsz * pages_per_seq, self.page_size, hkv, hd), dtype=torch.half, device=dev)
+                st["vd"] = torch.empty_like(st["kd"])
+                st["bt"] = torch.arange(bsz * pages_per_seq, dtype=torch.int32, device=dev).view(bsz, pages_per_seq)
             self._st[key] = st
         return st
 
     def run(self, bsz: int, q_len: int, x, y, cache_seqlens, block_table, position: int = 0, positions=None, position_ids=None, inv_freq_override=None):
-        """x, y: (bsz, q_len, hidden) fp16; cache_seqlens int32 (bsz): tokens in the cache BEFORE this call (the new token is appended at that
-        position, attention.cpp:395-400); block_table int32 (bsz, pages); RoPE position of (b, t) = position + t | positions[b] + t |
-        position_ids[b][t] as in ext.rope."""
-        _req(q_len == 1, "BC_Attention: this build decodes one token per sequence (q_len == 1)")
+        """x, y: (bsz, q_len, hidden) fp16; cache_seqlens int32 (bsz): tokens in the cache BEFORE this call (the new tokens are appended from
+        that position, attention.cpp:395-400); block_table int32 (bsz, pages); RoPE position of (b, t) = position + t | positions[b] + t |
+        position_ids[b][t] as in ext.rope.  q_len == 1 attends straight from the quantized cache (flash-decoding); 2 <= q_len <= MAX_QLEN
+        appends, expands the sequence's pages to fp16 and runs the causal chunk attention (exl3_attn_prefill_paged)."""
+        _req(1 <= q_len <= self.MAX_QLEN, "BC_Attention: q_len out of range")
         _req(1 <= bsz <= self.MAX_BSZ, "BC_Attention: bsz out of range")
         _req(self.inv_freq is not None or inv_freq_override is None, "BC_Attention: inv_freq override on a NoPE module")
         hq, hkv, hd = self.num_q_heads, self.num_kv_heads, self.head_dim
-        st = self._statics(bsz, block_table.shape[1], x.device)
-        x2 = x.view(bsz, self.hidden_size)
-        q2, kv = st["q"].view(bsz, hq * hd), st["kv"]
+        rows = bsz * q_len
+        st = self._statics(bsz, q_len, block_table.shape[1], x.device)
+        x2 = x.view(rows, self.hidden_size)
+        q2, kv = st["q"].view(rows, hq * hd), st["kv"]
         self.q_proj.run(x2, q2)
-        if self.kv_ptrs is not None:
+        if self.kv_ptrs is not None and rows <= 16:                       # the pointer-table launch takes at most 16 rows per slot
             pt, ps, pv, K, mcg, mul1 = self.kv_ptrs
-            exl3_mgemm(x2.view(1, bsz, -1), pt, kv, ps, st["xh"], pv, None, None, K, -1, mcg, mul1, -1, -1, 0)
+            exl3_mgemm(x2.view(1, rows, -1), pt, kv, ps, st["xh"], pv, None, None, K, -1, mcg, mul1, -1, -1, 0)
         else:
+            _req(self.k_proj is not None and self.v_proj is not None, "BC_Attention: more than 16 rows need the separate k / v projections")
             self.k_proj.run(x2, kv[0]); self.v_proj.run(x2, kv[1])
-        k4, v4 = kv[0].view(bsz, 1, hkv, hd), kv[1].view(bsz, 1, hkv, hd)
+        k4, v4 = kv[0].view(bsz, q_len, hkv, hd), kv[1].view(bsz, q_len, hkv, hd)
         if self.inv_freq is not None:
             ivf = inv_freq_override if inv_freq_override is not None else self.inv_freq
             rope(st["q"], st["q"], k4, k4, ivf, int(position), positions, position_ids, self.rope_style, self.attn_factor,
                  self.q_norm, self.k_norm, self.norm_eps, self.norm_constant_bias)
-        quant_cache_paged(k4.view(bsz, 1, -1), self.cache_k, self.cache_k_scales, v4.view(bsz, 1, -1), self.cache_v, self.cache_v_scales,
-                          cache_seqlens, block_table, self.page_size, 1)
-        torch.add(cache_seqlens, 1, out=st["lens"])                       # the attention kernel's lengths include the appended token
-        attn_decode_qcache(st["q"].view(bsz, hq, hd), st["o"], self.cache_k, self.cache_k_scales, self.cache_v, self.cache_v_scales, block_table,
-                           st["lens"], st["max_len"], workspace=st["ws"])
-        self.o_proj.run(st["o"].view(bsz, hq * hd), y.view(bsz, self.hidden_size))
+        quant_cache_paged(k4.view(bsz, q_len, -1), self.cache_k, self.cache_k_scales, v4.view(bsz, q_len, -1), self.cache_v, self.cache_v_scales,
+                          cache_seqlens, block_table, self.page_size, q_len)
+        torch.add(cache_seqlens, q_len, out=st["lens"])                   # the attention kernels' lengths include the appended tokens
+        if q_len == 1:
+            attn_decode_qcache(st["q"].view(bsz, hq, hd), st["o"].view(bsz, hq, hd), self.cache_k, self.cache_k_scales, self.cache_v, self.cache_v_scales,
+                               block_table, st["lens"], st["max_len"], workspace=st["ws"])
+        else:
+            dim = hkv * hd
+            dequant_cache_paged_window(self.cache_k, self.cache_k_scales, st["kd"].view(-1, self.page_size, dim), self.cache_v, self.cache_v_scales,
+                                       st["vd"].view(-1, self.page_size, dim), cache_seqlens, block_table, self.page_size, q_len)
+            attn_prefill_paged(st["q"], st["o"], st["kd"], st["vd"], st["bt"], st["lens"])
+        self.o_proj.run(st["o"].view(rows, hq * hd), y.view(rows, self.hidden_size))
 
 
 def __getattr__(name: str):

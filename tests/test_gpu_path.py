@@ -404,11 +404,75 @@ def test_bc_attention_runner_matches_oracle(dev, hd, hq, hkv, fused_kv, head_nor
     y.zero_(); g.replay(); torch.cuda.synchronize()
     assert np.array_equal(y.float().cpu().numpy().reshape(bsz, hidden), got)
     with pytest.raises(RuntimeError):
-        attn.run(bsz, 2, T(np.zeros((bsz, 2, hidden), np.float16)), y, dl, dbt, 0, dpos, None, None)
+        attn.run(bsz, 17, T(np.zeros((bsz, 17, hidden), np.float16)), y, dl, dbt, 0, dpos, None, None)
     with pytest.raises(RuntimeError):
         ext.BC_Attention(**{**kw, "gate_mode": 2})
     with pytest.raises(RuntimeError):
         ext.BC_Attention(**{**kw, "quant_cache": False})
+
+
+@pytest.mark.parametrize("hd,hq,hkv,q_len,fused_kv", [(128, 4, 2, 5, False), (64, 8, 2, 16, True), (128, 8, 2, 16, False)])
+def test_bc_attention_runner_multi_token(dev, hd, hq, hkv, q_len, fused_kv):
+    """BC_Attention.run with 2 <= q_len <= 16 (attention.cpp:246-504; the runner's MAX_QLEN): the chunk is appended to the 4-bit paged cache, the
+    block table's pages are expanded to fp16 and the chunk attends causally over context + itself; against the oracle composition
+    (projections, rope at positions[b] + t, quantize -> dequantize round trip of the whole sequence, causal attention, o_proj)."""
+    from exllamav3_amd import ext
+    hidden, K, cb, bits, page, bsz, pps = 512, 4, 2, 4, 256, 3, 3
+    rng = np.random.default_rng(hd + q_len)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mats = {n: o.synth_linear(k, nn, K, seed=170 + i, realistic=True) for i, (n, k, nn) in enumerate(
+        (("q", hidden, hq * hd), ("k", hidden, hkv * hd), ("v", hidden, hkv * hd), ("o", hq * hd, hidden)))}
+    dm = {n: tuple(T(a) for a in t) for n, t in mats.items()}
+    bc = {n: ext.BC_LinearEXL3(t[0], t[1], t[2], K, None, False, True, None) for n, t in dm.items()}
+    G = hkv * hd // 32
+    npages = bsz * pps
+    bt_np = rng.permutation(npages).reshape(bsz, pps).astype(np.int32)
+    lens = np.array([300, 0, 256 - 3], np.int32)                                # empty context; a chunk that crosses a page edge
+    ck = rng.standard_normal((bsz, pps * page, hkv * hd)).astype(np.float16); cv = rng.standard_normal((bsz, pps * page, hkv * hd)).astype(np.float16)
+    kq = np.zeros((npages, page, G * bits), np.uint32); ks = np.zeros((npages, page, G), np.float16); vq = kq.copy(); vs = ks.copy()
+    for b in range(bsz):
+        pk, sc = o.kv_quant(ck[b], bits); pv, sv = o.kv_quant(cv[b], bits)
+        for pg in range(pps):
+            kq[bt_np[b, pg]] = pk[pg * page:(pg + 1) * page]; ks[bt_np[b, pg]] = sc[pg * page:(pg + 1) * page]
+            vq[bt_np[b, pg]] = pv[pg * page:(pg + 1) * page]; vs[bt_np[b, pg]] = sv[pg * page:(pg + 1) * page]
+    dkq, dks, dvq, dvs = T(kq.view(np.int32)), T(ks), T(vq.view(np.int32)), T(vs)
+    inv_freq = (1.0 / (10000.0 ** (np.arange(0, hd, 2, dtype=np.float32) / hd))).astype(np.float32)
+    kw = dict(num_q_heads=hq, num_kv_heads=hkv, head_dim=hd, hidden_size=hidden, hidden_size_padded=hidden, page_size=page,
+              q_proj=bc["q"], k_proj=bc["k"], v_proj=bc["v"], o_proj=bc["o"], norm_eps=1e-6, inv_freq=T(inv_freq), rope_style=2, attn_factor=1.0,
+              quant_cache=True, cache_k=dkq, cache_v=dvq, cache_k_scales=dks, cache_v_scales=dvs, xh=None, h32=None)
+    if fused_kv:
+        ptr = lambda i: torch.tensor([dm["k"][i].data_ptr(), dm["v"][i].data_ptr()], dtype=torch.long, device=dev)
+        kw.update(kv_ptrs_trellis=ptr(0), kv_ptrs_suh=ptr(1), kv_ptrs_svh=ptr(2), kv_K=K, kv_mcg=False, kv_mul1=True)
+    attn = ext.BC_Attention(**kw)
+    x = rng.standard_normal((bsz, q_len, hidden)).astype(np.float16)
+    y = torch.full((bsz, q_len, hidden), float("nan"), dtype=torch.half, device=dev)
+    dl, dbt, dpos = T(lens), T(bt_np), T(lens)
+    attn.run(bsz, q_len, T(x), y, dl, dbt, 0, dpos, None, None)
+    lin = lambda n, a, **k2: o.linear_forward(a, mats[n][0], mats[n][1], mats[n][2], K, cb, **k2)
+    x2 = x.reshape(bsz * q_len, hidden)
+    q, k, v = lin("q", x2), lin("k", x2), lin("v", x2)
+    pos_ids = (lens[:, None] + np.arange(q_len)[None, :]).astype(np.int32)
+    q4, k4 = o.rope(q.reshape(bsz, q_len, hq, hd), k.reshape(bsz, q_len, hkv, hd), inv_freq, position_ids=pos_ids, rope_mode=o.ROPE_NEOX)
+    v4 = v.reshape(bsz, q_len, hkv * hd)
+    ao = np.zeros((bsz, q_len, hq, hd), np.float32)
+    for b in range(bsz):
+        full_k = np.concatenate([ck[b, :lens[b]], k4[b].reshape(q_len, -1)]); full_v = np.concatenate([cv[b, :lens[b]], v4[b]])
+        pk, sc = o.kv_quant(full_k, bits); pv, sv = o.kv_quant(full_v, bits)
+        kd = o.kv_dequant(pk, sc, bits).reshape(1, -1, hkv, hd); vd = o.kv_dequant(pv, sv, bits).reshape(1, -1, hkv, hd)
+        ao[b] = o.attn_prefill(q4[b:b + 1], kd, vd, np.array([lens[b] + q_len]))[0]
+    ref = lin("o", ao.astype(np.float16).reshape(bsz * q_len, -1)).astype(np.float32)
+    got = y.float().cpu().numpy().reshape(bsz * q_len, hidden)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+    # graph replay (the chunk is rewritten in place with the same bits)
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    dx = T(x)
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            attn.run(bsz, q_len, dx, y, dl, dbt, 0, dpos, None, None)
+    y.zero_(); g.replay(); torch.cuda.synchronize()
+    assert np.array_equal(y.float().cpu().numpy().reshape(bsz * q_len, hidden), got)
 
 
 def test_prefill_reconstruct_ahead_is_bit_identical_to_inline(dev):
