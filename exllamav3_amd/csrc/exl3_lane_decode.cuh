@@ -21,7 +21,9 @@ __device__ __forceinline__ uint32_t lane_state(const uint32_t (&Wx)[K + 1])
         else if constexpr (sh == 16) return Wx[lo] >> 16;
         else return __builtin_amdgcn_ubfe(Wx[lo], sh, 16);
     }
-    else return __builtin_amdgcn_alignbit(Wx[hi], Wx[lo], sh) & 0xffffu;
+    // a window that straddles two words (sh > 16): all such windows of one word boundary lie inside the middle 32 bits of the pair, so they share
+    // ONE v_alignbit (common subexpression) and cost one v_bfe each, instead of an alignbit + mask per window
+    else return __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(Wx[hi], Wx[lo], 16), sh - 16, 16);
 }
 
 template <int K> struct LaneWords { uint32_t w[K]; };
