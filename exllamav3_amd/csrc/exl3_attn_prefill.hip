@@ -44,30 +44,35 @@ __device__ __forceinline__ half4_t lds_read_tr16(const half_t* p)
 // staging work per matrix instruction drops by GW (with one head per workgroup the four q heads of a Llama kv head each re-staged it).
 // A wave owns 32 queries of one head as two 16-query groups: every K and V fragment read from LDS feeds two matrix instructions (with one
 // group per wave the LDS pipe, not the matrix pipe, bounded the loop: 32 KB of fragment reads per 32 instructions).
-template <int HD, int GW>
-__global__ __launch_bounds__(128 * GW)
+template <int HD, int GW, int QG>
+__global__ __launch_bounds__(256 * GW / QG)
 void attn_prefill_kernel(const PrefillAttnArgs a)
 {
-    constexpr int NT = 128 * GW;
+    constexpr int WPH = 4 / QG;                                 // waves per head: each owns QG 16-query groups of the 64-query tile
+    constexpr int NT = 64 * GW * WPH;
     constexpr int KS = HD + 8;                                  // tile row stride in halves (16-byte aligned rows, rotated banks)
     __shared__ __attribute__((aligned(16))) half_t Ks[PA_BN * KS];
     constexpr int VS = HD + 16;                                 // V rows 8 dwords apart (mod 64 banks): the 16 four-lane row segments of a transpose read tile the banks
     __shared__ __attribute__((aligned(16))) half_t Vs[PA_BN * VS];   // row-major like K; the PV operand is gathered with the LDS transpose read
-    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all & 1, g = lane >> 4, c = lane & 15;
-    const int qt = gridDim.x - 1 - blockIdx.x, h = blockIdx.y * GW + (wave_all >> 1), b = blockIdx.z;   // long (late) query tiles are dispatched first
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all % WPH, g = lane >> 4, c = lane & 15;
+    // Dispatch order = blockIdx.x fastest: the head group is the fast index and the query tile the slow one, LONGEST tiles first, so the workgroups
+    // reach the CUs in order of decreasing length (a causal tile qt walks qt + 1 key tiles; with the tile index fast, the second wave of workgroups
+    // handed 64-tile jobs to CUs that had already worked 17, 33, 49 tiles: 1.7x imbalance).  Consecutive workgroups also go to consecutive XCDs, so
+    // with 8 kv heads each head's K/V stays in one XCD's L2.
+    const int qt = gridDim.y - 1 - blockIdx.y, hg = blockIdx.x, h = hg * GW + wave_all / WPH, b = blockIdx.z;
     const int q_len = a.q_len, hq = a.hq, hkv = a.hkv, page_size = a.page_size;
-    const int kvh = (blockIdx.y * GW) / (hq / hkv);             // the same for all GW heads of the workgroup
+    const int kvh = (hg * GW) / (hq / hkv);             // the same for all GW heads of the workgroup
     const int kv_len = a.cache_seqlens[b];
     const int ctx = kv_len - q_len;                             // query i sits at position ctx + i and sees keys 0 .. ctx + i
-    const int q0 = qt * PA_BM + wave * 32;                      // this wave's first query; group u covers q0 + 16 u .. + 15
+    const int q0 = qt * PA_BM + wave * 16 * QG;                 // this wave's first query; group u covers q0 + 16 u .. + 15
     const int32_t* bt = a.block_table + (size_t) b * a.blocks_per_seq;
     const float sl = a.scale * 1.44269504f;                      // scale * log2(e)
 
     // Q rows of the wave as B operands of S^T = K Q^T: contraction slots 8g .. 8g+7 of step ks are head dims 32 ks + 8g ..
-    half8_t qf[2][HD / 32];
-    int qpos[2];                                                // this lane's query (column of S^T) per group; clamped rows are never stored
+    half8_t qf[QG][HD / 32];
+    int qpos[QG];                                                // this lane's query (column of S^T) per group; clamped rows are never stored
     #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < QG; ++u)
     {
         const int qi = min(q0 + 16 * u + c, q_len - 1);
         qpos[u] = ctx + qi;
@@ -75,10 +80,12 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
         #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) qf[u][ks] = *((const half8_t*) (qp + 32 * ks + 8 * g));
     }
-    float m_run[2] = { -1.0e30f, -1.0e30f }, l_run[2] = { 0.0f, 0.0f };
-    float4_t oc[2][HD / 16];
+    float m_run[QG], l_run[QG];
     #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < QG; ++u) { m_run[u] = -1.0e30f; l_run[u] = 0.0f; }
+    float4_t oc[QG][HD / 16];
+    #pragma unroll
+    for (int u = 0; u < QG; ++u)
         #pragma unroll
         for (int nb = 0; nb < HD / 16; ++nb) oc[u][nb] = float4_t{ 0.f, 0.f, 0.f, 0.f };
 
@@ -122,30 +129,33 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
         __syncthreads();
         if (kt + 1 < ntiles) fetch_tile(kt + 1);
         // ---- S^T block kb: keys key0 + 16 kb + (4g + j) x this lane's query of either group
-        float4_t st[2][PA_BN / 16];
+        float4_t st[QG][PA_BN / 16];
         #pragma unroll
         for (int kb = 0; kb < PA_BN / 16; ++kb)
         {
-            float4_t acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = acc0;
+            float4_t acc[QG];
+            #pragma unroll
+            for (int u = 0; u < QG; ++u) acc[u] = float4_t{ 0.f, 0.f, 0.f, 0.f };
             #pragma unroll
             for (int ks = 0; ks < HD / 32; ++ks)
             {
                 const half8_t ka = *((const half8_t*) (Ks + (16 * kb + c) * KS + 32 * ks + 8 * g));
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[0][ks], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[1][ks], acc1, 0, 0, 0);
+                #pragma unroll
+                for (int u = 0; u < QG; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[u][ks], acc[u], 0, 0, 0);
             }
-            st[0][kb] = acc0; st[1][kb] = acc1;
+            #pragma unroll
+            for (int u = 0; u < QG; ++u) st[u][kb] = acc[u];
         }
         // ---- online softmax for this lane's queries: its 16 values here + the 3 other lane groups of the column.  Scores stay unscaled:
         // p = 2^((s - max) * scale * log2 e) is one fma + v_exp_f32 per value.  Only tiles on the diagonal or at the end of the sequence are masked
         // (a wave-uniform branch); a masked score is -1e30 and underflows to p = 0 because every query has key 0 in tile 0 (finite running max).
-        half4_t pa[2][PA_BN / 16];
-        float corr[2];
+        half4_t pa[QG][PA_BN / 16];
+        float corr[QG];
         const bool masked = key0 + PA_BN - 1 > ctx + min(q0, q_len - 1) || key0 + PA_BN > kv_len;
         if (masked)
         {
             #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < QG; ++u)
                 #pragma unroll
                 for (int kb = 0; kb < PA_BN / 16; ++kb)
                     #pragma unroll
@@ -156,7 +166,7 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
                     }
         }
         #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < QG; ++u)
         {
             float mx = m_run[u];
             #pragma unroll
@@ -179,15 +189,18 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
             m_run[u] = mx;
         }
         // ---- rescale the accumulator rows (queries 4g + j of each group) where the running max moved, and add P V
-        if (!__all(corr[0] == 1.0f && corr[1] == 1.0f))
+        bool moved = false;
+        #pragma unroll
+        for (int u = 0; u < QG; ++u) moved = moved || corr[u] != 1.0f;
+        if (__any(moved))
         {
-            float cr[2][4];
+            float cr[QG][4];
             #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < QG; ++u)
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) cr[u][j] = __shfl(corr[u], 4 * g + j, 64);
             #pragma unroll
-            for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < QG; ++u)
                 #pragma unroll
                 for (int nb = 0; nb < HD / 16; ++nb)
                 {
@@ -197,7 +210,6 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
         #pragma unroll
         for (int nb = 0; nb < HD / 16; ++nb)
         {
-            float4_t o0 = oc[0][nb], o1 = oc[1][nb];
             #pragma unroll
             for (int k2 = 0; k2 < PA_BN / 32; ++k2)
             {
@@ -208,20 +220,18 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
                 const half4_t v0 = lds_read_tr16(vr), v1 = lds_read_tr16(vr + 16 * VS);
                 const half8_t vB = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
                 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < QG; ++u)
                 {
                     const half4_t p0 = pa[u][2 * k2], p1 = pa[u][2 * k2 + 1];
                     const half8_t pA = { p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w };
-                    if (u == 0) o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pA, vB, o0, 0, 0, 0);
-                    else        o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(pA, vB, o1, 0, 0, 0);
+                    oc[u][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pA, vB, oc[u][nb], 0, 0, 0);
                 }
             }
-            oc[0][nb] = o0; oc[1][nb] = o1;
         }
     }
     // ---- normalise and store: rows = queries q0 + 16 u + 4g + j, columns 16 nb + c
     #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < QG; ++u)
     {
         float li[4];
         #pragma unroll
@@ -268,12 +278,19 @@ extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void*
     a.block_table = block_table; a.cache_seqlens = cache_seqlens;
     a.q_len = q_len; a.hq = heads_q; a.hkv = heads_kv; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.scale = scale; a.ldq = ldq;
     const int gq = heads_q / heads_kv;
-    const int gw = gq % 4 == 0 ? 4 : (gq % 2 == 0 ? 2 : 1);                          // query heads per workgroup (they share a kv head)
-    dim3 grid((q_len + PA_BM - 1) / PA_BM, heads_q / gw, bsz);
+    int gw = gq % 4 == 0 ? 4 : (gq % 2 == 0 ? 2 : 1);                                // query heads per workgroup (they share a kv head) ...
+    const int64_t qtiles = (int64_t) ((q_len + PA_BM - 1) / PA_BM) * bsz;
+    while (gw > 1 && qtiles * (heads_q / gw) < 512) gw >>= 1;                         // ... fewer when the launch would not fill the 256 CUs twice
+    dim3 grid(heads_q / gw, (q_len + PA_BM - 1) / PA_BM, bsz);
     hipStream_t st = (hipStream_t) stream;
-    #define PA_L(HDv) { if (gw == 4) attn_prefill_kernel<HDv, 4><<<grid, 512, 0, st>>>(a); else if (gw == 2) attn_prefill_kernel<HDv, 2><<<grid, 256, 0, st>>>(a); \
-                        else attn_prefill_kernel<HDv, 1><<<grid, 128, 0, st>>>(a); }
-    if (head_dim == 128) PA_L(128) else PA_L(64)
+    // 16 queries per wave and 4 waves per SIMD (QG = 1) where the registers allow it, else 32 queries per wave at 2 waves per SIMD
+    #define PA_L(HDv, QGv) { if (gw == 4) attn_prefill_kernel<HDv, 4, QGv><<<grid, 1024 / QGv, 0, st>>>(a); else if (gw == 2) attn_prefill_kernel<HDv, 2, QGv><<<grid, 512 / QGv, 0, st>>>(a); \
+                             else attn_prefill_kernel<HDv, 1, QGv><<<grid, 256 / QGv, 0, st>>>(a); }
+    // 32 queries per wave (every K / V fragment feeds two matrix instructions; 216 VGPRs, 2 waves per SIMD) for the 8-wave workgroups, 16 queries per
+    // wave (<= 128 VGPRs, 4 waves per SIMD) for the smaller ones, whose 32-query variant would leave one wave per SIMD
+    static const int qg_env = [] { const char* e = getenv("EXL3_HIP_ATTN_QG"); return e ? atoi(e) : 0; }();
+    const int qg = qg_env ? qg_env : (gw == 4 ? 2 : 1);
+    if (head_dim == 128) { if (qg == 2) PA_L(128, 2) else PA_L(128, 1) } else { if (qg == 2) PA_L(64, 2) else PA_L(64, 1) }
     #undef PA_L
     return exl3_check_launch("attn_prefill");
 }

@@ -1,7 +1,7 @@
 """Times exl3_attn_prefill_paged alone: causal attention of a T-token chunk (Llama-3.1-8B heads by default) over paged fp16 K/V.
    python tools/bench_attn_prefill.py [T] [ctx]   -> µs per launch and TFLOP/s on the causal 4 * hd * hq * (ctx * T + T^2 / 2) flops"""
-import sys, torch
-sys.path.insert(0, ".")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from exllamav3_amd import ext
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
