@@ -454,22 +454,22 @@ class BC_Attention:
                 "xh": torch.empty((2, rows, self.hidden_size), dtype=torch.half, device=dev),
                 "max_len": max_len,
             }
-            if q_len == 1:
-                st["ws"] = torch.empty((bsz * (hq * hd // 128) * ((max_len + 31) // 32) * 132,), dtype=torch.float, device=dev)
-            else:
-                # q_len > 1: the pages of the block table are expanded into a dense fp16 window (cache/q_cache.cuh:64-77, what the reference's
-                # quantized cache layer hands to flash-attn) and the chunk attends over it through an identity block table
-                st["kd"] = torch.empty((bsz * pages_per_seq, self.page_size, hkv, hd), dtype=torch.half, device=dev)
-                st["vd"] = torch.empty_like(st["kd"])
-                st["bt"] = torch.arange(bsz * pages_per_seq, dtype=torch.int32, device=dev).view(bsz, pages_per_seq)
+            # 2 <= q_len <= 16: token t of sequence b attends as its own one-token sequence (b, t) with the same block-table row and length
+            # cache_seqlens[b] + t + 1 -- causal by construction, straight from the quantized pages (no fp16 page window)
+            st["ws"] = torch.empty((rows * (hq * hd // 128) * ((max_len + 31) // 32) * 132,), dtype=torch.float, device=dev)
+            if q_len > 1:
+                st["row_of"] = torch.arange(bsz, device=dev).repeat_interleave(q_len)
+                st["tofs"] = (torch.arange(q_len, dtype=torch.int32, device=dev) + 1).repeat(bsz)
+                st["bt_v"] = torch.empty((rows, pages_per_seq), dtype=torch.int32, device=dev)
+                st["lens_v"] = torch.empty((rows,), dtype=torch.int32, device=dev)
             self._st[key] = st
         return st
 
     def run(self, bsz: int, q_len: int, x, y, cache_seqlens, block_table, position: int = 0, positions=None, position_ids=None, inv_freq_override=None):
         """x, y: (bsz, q_len, hidden) fp16; cache_seqlens int32 (bsz): tokens in the cache BEFORE this call (the new tokens are appended from
         that position, attention.cpp:395-400); block_table int32 (bsz, pages); RoPE position of (b, t) = position + t | positions[b] + t |
-        position_ids[b][t] as in ext.rope.  q_len == 1 attends straight from the quantized cache (flash-decoding); 2 <= q_len <= MAX_QLEN
-        appends, expands the sequence's pages to fp16 and runs the causal chunk attention (exl3_attn_prefill_paged)."""
+        position_ids[b][t] as in ext.rope.  Attention runs straight from the quantized cache (flash-decoding); for 2 <= q_len <= MAX_QLEN every
+        new token is its own query row with length cache_seqlens[b] + t + 1 (causal within the chunk), after the whole chunk was appended."""
         _req(1 <= q_len <= self.MAX_QLEN, "BC_Attention: q_len out of range")
         _req(1 <= bsz <= self.MAX_BSZ, "BC_Attention: bsz out of range")
         _req(self.inv_freq is not None or inv_freq_override is None, "BC_Attention: inv_freq override on a NoPE module")
@@ -492,15 +492,16 @@ class BC_Attention:
                  self.q_norm, self.k_norm, self.norm_eps, self.norm_constant_bias)
         quant_cache_paged(k4.view(bsz, q_len, -1), self.cache_k, self.cache_k_scales, v4.view(bsz, q_len, -1), self.cache_v, self.cache_v_scales,
                           cache_seqlens, block_table, self.page_size, q_len)
-        torch.add(cache_seqlens, q_len, out=st["lens"])                   # the attention kernels' lengths include the appended tokens
         if q_len == 1:
-            attn_decode_qcache(st["q"].view(bsz, hq, hd), st["o"].view(bsz, hq, hd), self.cache_k, self.cache_k_scales, self.cache_v, self.cache_v_scales,
-                               block_table, st["lens"], st["max_len"], workspace=st["ws"])
+            torch.add(cache_seqlens, 1, out=st["lens"])                   # the attention kernel's lengths include the appended token
+            bt_v, lens_v = block_table, st["lens"]
         else:
-            dim = hkv * hd
-            dequant_cache_paged_window(self.cache_k, self.cache_k_scales, st["kd"].view(-1, self.page_size, dim), self.cache_v, self.cache_v_scales,
-                                       st["vd"].view(-1, self.page_size, dim), cache_seqlens, block_table, self.page_size, q_len)
-            attn_prefill_paged(st["q"], st["o"], st["kd"], st["vd"], st["bt"], st["lens"])
+            torch.index_select(block_table, 0, st["row_of"], out=st["bt_v"])
+            torch.index_select(cache_seqlens, 0, st["row_of"], out=st["lens_v"])
+            st["lens_v"].add_(st["tofs"])
+            bt_v, lens_v = st["bt_v"], st["lens_v"]
+        attn_decode_qcache(st["q"].view(rows, hq, hd), st["o"].view(rows, hq, hd), self.cache_k, self.cache_k_scales, self.cache_v, self.cache_v_scales,
+                           bt_v, lens_v, st["max_len"], workspace=st["ws"])
         self.o_proj.run(st["o"].view(rows, hq * hd), y.view(rows, self.hidden_size))
 
 
