@@ -397,6 +397,23 @@ def main():
                                 "frac": round(flops / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                 "note": "linears' 2*k*n flops over the whole chunk time (includes reconstruct_had, norms, rope, kv-quant)"}}
 
+        # the same chunk with the attention core in the timed region (append to the quantized cache, expand the pages, causal attention over them):
+        # reported beside the headline, which follows BASELINE.json's linears-only shapes (science/qgemm_benchmark.py)
+        if not args.attention:
+            model.prefill_attention = True
+            model.prefill_chunk(toks); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                model.prefill_chunk(toks)
+            torch.cuda.synchronize()
+            dta = (time.perf_counter() - t0) / reps
+            model.prefill_attention = False
+            hd_ = shape.head_dim
+            aflops = 4.0 * hd_ * shape.heads_q * (toks * (toks + 1) / 2) * model.n_layers
+            prefill["with_attention"] = {"value": round(toks / dta, 1), "unit": "tok/s", "ms_per_chunk": round(dta * 1e3, 2),
+                                         "tflops": round((flops + aflops) / dta / 1e12, 1),
+                                         "note": "linears + dequant_cache_paged + causal chunk attention (exl3_attn_prefill_paged); flops = linears + causal attention"}
+
         # MI355X option: reconstructed fp16 W kept resident across chunks (LinearEXL3.cache_reconstructed; 0.5 GB per 8B layer).
         # Reported separately: the chunk above reconstructs every matrix per forward exactly like the reference.
         from exllamav3_amd.linear import LinearEXL3
