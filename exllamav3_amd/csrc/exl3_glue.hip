@@ -24,7 +24,7 @@
 // ------------------------------------------------------------------------------------------------
 struct NormTargets { const half_t* suh[3]; half_t* xh[3]; float* xsum[3]; int count; };
 
-#define GN_MAXT 16       // tasks (row, block) per half-wave kept in registers: m * hidden/128 <= 32 * GN_MAXT
+#define GN_MAXT 16       // tasks (row, block) per half-wave: m * hidden/128 <= 32 * GN_MAXT
 
 __global__ __launch_bounds__(1024)
 void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, const half_t* __restrict__ svh, const half_t* __restrict__ bias,
@@ -36,7 +36,7 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
     const int nblk = hidden >> 7;
     const int tasks = m * nblk;
     // phase 1: residual update + sum of squares per (row, block); the updated residual stays in registers
-    half4_t rr[GN_MAXT];
+    half4_t r_first = { 0, 0, 0, 0 };                 // the half-wave's first task keeps its row in registers; further tasks re-read what they stored (or never changed)
     // phase-2 operands of this half-wave's first task are fetched now, with the phase-1 loads (at batch 1 there is only one
     // task per half-wave, and a load issued after the barrier would add a full memory latency to a ~5 us kernel)
     half4_t w_first, suh_first[3];
@@ -77,7 +77,7 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
             r0 = (float) r.x; r1 = (float) r.y; r2 = (float) r.z; r3 = (float) r.w;
             if (act) ((half4_t*) (resid + (size_t) row * hidden + blk * 128))[l] = r;
         }
-        rr[it] = r;
+        if (it == 0) r_first = r;
         float ss = r0 * r0;
         ss = __builtin_fmaf(r1, r1, ss); ss = __builtin_fmaf(r2, r2, ss); ss = __builtin_fmaf(r3, r3, ss);
         #pragma unroll
@@ -103,7 +103,7 @@ void glue_norm_kernel(SlabRef y, int has_y, const float* __restrict__ y_dense, c
             s2 += v;
         }
         const float rmf = __frsqrt_rn(s2 / (float) hidden + eps);
-        half4_t r = rr[it];
+        half4_t r = it == 0 ? r_first : ((const half4_t*) (resid + (size_t) row * hidden + blk * 128))[l];
         half4_t wv = it == 0 ? w_first : ((const half4_t*) (w + blk * 128))[l];
         half4_t xn = { f2h((float) r.x * (float) wv.x * rmf), f2h((float) r.y * (float) wv.y * rmf),
                        f2h((float) r.z * (float) wv.z * rmf), f2h((float) r.w * (float) wv.w * rmf) };

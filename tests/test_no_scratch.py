@@ -10,8 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-# the single-workgroup norm of the first-generation glue pipeline (decode_step_fused_v1, a comparison baseline) keeps 16 tasks in registers
-ALLOWED = ("glue_norm_kernel",)
+ALLOWED = ()
 
 
 @pytest.mark.skipif(not glob.glob(os.path.join(ROOT, "build", "obj", "*.o")) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"),
