@@ -596,7 +596,10 @@ def routing_std(hidden: np.ndarray, gate: np.ndarray, k: int, bias: np.ndarray |
 def attn_prefill(q: np.ndarray, k: np.ndarray, v: np.ndarray, kv_lens, scale: float | None = None) -> np.ndarray:
     """Causal attention of a chunk of new tokens over the (dequantized) cache, as the reference's prefill path attends
     (flash_attn_with_kvcache(..., causal=True) after cache/quant.py:83-117): q (b, T, hq, d) fp16; k / v (b, S, hkv, d) fp16 with kv_lens[b] valid
-    rows INCLUDING the T new tokens; query i sees keys 0 .. kv_lens[b] - T + i.  fp32 math, fp16 result."""
+    rows INCLUDING the T new tokens; query i sees keys 0 .. kv_lens[b] - T + i.  fp32 math, fp16 result.
+    flash-attn 2 is an optional, un-vendored dependency of the reference (no version pin in requirements.txt; call site
+    modules/attention_fn/flash_attn_2.py:12-38); pinned against the reference's own pure-torch equivalent instead
+    (modules/attention_fn/torch.py:81-160, fixtures attn_* of tests/golden/ref_python.npz, tests/test_oracle_pins.py)."""
     b, T, hq, d = q.shape
     hkv = k.shape[2]
     gq = hq // hkv

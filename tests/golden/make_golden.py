@@ -177,6 +177,30 @@ def main():
         out[f"route_{tag}_bias"] = bias.numpy() if with_bias else np.zeros(0, np.float16)
         out[f"route_{tag}_sel"] = sel.numpy(); out[f"route_{tag}_w"] = wts.numpy()
 
+    # --- paged-cache attention semantics (modules/attention_fn/torch.py:81-160 `_torch_bighead_fallback`: the reference's own pure-torch
+    # stand-in for flash_attn_with_kvcache -- new k / v appended at cache_seqlens, causal lower-right mask, GQA): pins the oracle's
+    # attn_prefill / attn_decode_qcache.  fp32 tensors, so the values are the definition, not a kernel's rounding.
+    fake_pkg("exllamav3.modules.attention_fn", REF + "/modules/attention_fn")
+    attn_t = importlib.import_module("exllamav3.modules.attention_fn.torch")
+    attn_t.has_warned_sdpa_fallback = True
+    for tag, (bsz, q_len, hq, hkv, hd, page, pps, lens) in {
+        "a": (2, 7, 4, 2, 64, 16, 4, [20, 0]),          # a chunk over a context / over an empty cache, crossing page edges
+        "b": (3, 1, 8, 2, 32, 16, 3, [5, 31, 16]),      # decode: one new token per sequence
+    }.items():
+        npages = bsz * pps
+        bt = torch.randperm(npages, generator=g).view(bsz, pps).to(torch.int32)
+        kc = torch.randn(npages, page, hkv, hd, generator=g)
+        vc = torch.randn(npages, page, hkv, hd, generator=g)
+        q = torch.randn(bsz, q_len, hq, hd, generator=g)
+        kn = torch.randn(bsz, q_len, hkv, hd, generator=g)
+        vn = torch.randn(bsz, q_len, hkv, hd, generator=g)
+        cl = torch.tensor(lens, dtype=torch.int32)
+        out[f"attn_{tag}_q"] = q.numpy(); out[f"attn_{tag}_k_new"] = kn.numpy(); out[f"attn_{tag}_v_new"] = vn.numpy()
+        out[f"attn_{tag}_k_cache"] = kc.numpy().copy(); out[f"attn_{tag}_v_cache"] = vc.numpy().copy()
+        out[f"attn_{tag}_block_table"] = bt.numpy(); out[f"attn_{tag}_cache_seqlens"] = cl.numpy()
+        o_ = attn_t._torch_bighead_fallback(q, kn, vn, kc, vc, bt.long(), cl, causal=True, softmax_scale=hd ** -0.5)
+        out[f"attn_{tag}_out"] = o_.float().numpy()
+
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: getattr(v, "shape", None) for k, v in out.items()})
 
