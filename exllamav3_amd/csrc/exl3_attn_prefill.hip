@@ -235,7 +235,13 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
     {
         float li[4];
         #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float lv = __shfl(l_run[u], 4 * g + j, 64); li[j] = lv > 0.0f ? 1.0f / lv : 0.0f; }
+        for (int j = 0; j < 4; ++j)
+        {
+            // a query without any visible key (cache_seqlens[b] < q_len: not a valid call, but it must not produce garbage) keeps its running max at the
+            // mask value; its row is written as zeros
+            const float lv = __shfl(l_run[u], 4 * g + j, 64), mv = __shfl(m_run[u], 4 * g + j, 64);
+            li[j] = (lv > 0.0f && mv > -1.0e29f) ? 1.0f / lv : 0.0f;
+        }
         #pragma unroll
         for (int j = 0; j < 4; ++j)
         {
@@ -267,12 +273,13 @@ extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void*
                                                int blocks_per_seq, int page_size, float scale, void* stream)
 {
     EXL3_CHECK_ARG(ldq >= (int64_t) heads_q * head_dim && ldq % 8 == 0, "attn_prefill: bad q token stride");
-    EXL3_CHECK_ARG(q && out && k_pages && v_pages && block_table && cache_seqlens, "attn_prefill: null pointer");
     EXL3_CHECK_ARG(head_dim == 128 || head_dim == 64, "attn_prefill: head_dim must be 128 or 64");
     EXL3_CHECK_ARG(heads_kv >= 1 && heads_q % heads_kv == 0, "attn_prefill: heads_q must be a multiple of heads_kv");
     EXL3_CHECK_ARG(page_size > 0 && page_size % PA_BN == 0 && blocks_per_seq >= 1, "attn_prefill: page size must be a multiple of 64");
     EXL3_CHECK_ARG(q_len >= 1 && (q_len + PA_BM - 1) / PA_BM <= 65535 && heads_q <= 65535, "attn_prefill: bad q_len / heads");
+    EXL3_CHECK_ARG(bsz >= 0 && bsz <= 65535, "attn_prefill: bsz out of range");
     if (bsz == 0) return EXL3_OK;
+    EXL3_CHECK_ARG(q && out && k_pages && v_pages && block_table && cache_seqlens, "attn_prefill: null pointer");
     PrefillAttnArgs a;
     a.q = (const half_t*) q; a.out = (half_t*) out; a.k_pages = (const half_t*) k_pages; a.v_pages = (const half_t*) v_pages;
     a.block_table = block_table; a.cache_seqlens = cache_seqlens;

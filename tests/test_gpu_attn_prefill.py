@@ -101,3 +101,24 @@ def test_prefill_chunk_with_attention_matches_oracle(dev):
     xl = o.rms_norm(x2[-1:], _np(model.final_norm), model.eps)
     ref = lin(model.lm_head, xl).astype(np.float32)
     assert rel(logits, ref) < 5e-2
+
+
+def test_attn_prefill_rows_without_keys_are_zero(dev):
+    """cache_seqlens[b] < q_len is outside the contract (the chunk is appended before the call), but the rows that then see no key must come out as
+    zeros and the others as the causal result, never as garbage; bsz == 0 is a no-op."""
+    from exllamav3_amd import ext
+    hd, hq, hkv, page, q_len = 128, 4, 2, 256, 70
+    rng = np.random.default_rng(3)
+    kv_len = 50                                                              # queries 0 .. 19 sit at positions -20 .. -1
+    k = rng.standard_normal((1, page, hkv, hd)).astype(np.float16); v = rng.standard_normal((1, page, hkv, hd)).astype(np.float16)
+    q = rng.standard_normal((1, q_len, hq, hd)).astype(np.float16)
+    out = torch.full((1, q_len, hq, hd), float("nan"), dtype=torch.half, device=dev)
+    bt = torch.zeros((1, 1), dtype=torch.int32, device=dev)
+    ext.attn_prefill_paged(_t(q, dev), out, _t(k, dev), _t(v, dev), bt, torch.tensor([kv_len], dtype=torch.int32, device=dev))
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all() and not got[0, :q_len - kv_len].any()
+    ref = o.attn_prefill(q[:, q_len - kv_len:], k, v, np.array([kv_len])).astype(np.float32)
+    assert np.abs(got[:, q_len - kv_len:] - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
+    empty = torch.empty((0, q_len, hq, hd), dtype=torch.half, device=dev)
+    ext.attn_prefill_paged(empty, torch.empty_like(empty), _t(k, dev), _t(v, dev), torch.zeros((0, 1), dtype=torch.int32, device=dev),
+                           torch.zeros((0,), dtype=torch.int32, device=dev))
