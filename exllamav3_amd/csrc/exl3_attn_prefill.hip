@@ -2,8 +2,8 @@
 // prefill path: CacheLayer_quant.get_kv (cache/quant.py:83-117) dequantizes the pages, then flash_attn_with_kvcache(q, k_pages, v_pages,
 // block_table, cache_seqlens, causal=True) attends (modules/attn.py).  SURVEY.md 8(f)3, "next" row: the decode branch is exl3_attn_decode.hip.
 //
-// gfx950 design: flash-attention forward, one workgroup = 64 consecutive queries of one (sequence, query head), four waves x 16 queries, K/V tiles of
-// 64 keys staged in LDS.  Everything is shaped so that no register transpose is needed between the two matrix products
+// gfx950 design: flash-attention forward, one workgroup = 64 consecutive queries of the GW query heads that share one kv head of one sequence,
+// K/V tiles of 64 keys staged in LDS.  Everything is shaped so that no register transpose is needed between the two matrix products
 // (v_mfma_f32_16x16x32_f16; operand lane (g = lane / 16, c = lane % 16) holds row / column c and contraction slots 8g .. 8g+7, the result lane
 // holds column c, rows 4g .. 4g+3):
 //   * scores are computed TRANSPOSED, S^T = K Q^T (A = K rows from LDS, B = the wave's Q rows, kept in registers for the whole kernel), so a
@@ -12,7 +12,7 @@
 //     as both operands agree;
 //   * V is staged row-major like K (16-byte LDS writes); the matching B operand (4 consecutive keys of one output column) is gathered by
 //     ds_read_b64_tr_b16, gfx950's LDS transpose read - one instruction per 4 keys, no transposing write pass;
-//   * the GW (1, 2 or 4) query heads that share a kv head sit in ONE workgroup (4 GW waves), so a K/V tile is staged once for all of them;
+//   * the GW (1, 2 or 4) query heads that share a kv head sit in ONE workgroup, so a K/V tile is staged once for all of them;
 //   * softmax statistics live with the query's column lanes; the output accumulator's rows are queries 4g + j, so the running rescale factor
 //     of those four queries is fetched from lanes 4g + j (ds_bpermute, 4 per tile).
 // fp32 softmax and accumulation, fp16 probabilities into the second product (as flash-attention does), fp16 output.
@@ -40,10 +40,10 @@ __device__ __forceinline__ half4_t lds_read_tr16(const half_t* p)
     return __builtin_bit_cast(half4_t, r);
 }
 
-// GW query heads of ONE kv head per workgroup (GW in {1, 2, 4}, GW | heads_q / heads_kv): 2 GW waves share every staged K/V tile, so the
+// GW query heads of ONE kv head per workgroup (GW in {1, 2, 4}, GW | heads_q / heads_kv): all of its waves share every staged K/V tile, so the
 // staging work per matrix instruction drops by GW (with one head per workgroup the four q heads of a Llama kv head each re-staged it).
-// A wave owns 32 queries of one head as two 16-query groups: every K and V fragment read from LDS feeds two matrix instructions (with one
-// group per wave the LDS pipe, not the matrix pipe, bounded the loop: 32 KB of fragment reads per 32 instructions).
+// A wave owns QG 16-query groups of one head (4 / QG waves per head): with QG = 2 every K and V fragment read from LDS feeds two matrix
+// instructions at 2 waves per SIMD, with QG = 1 the kernel fits 128 VGPRs and runs 4 waves per SIMD; the launcher picks by workgroup size.
 template <int HD, int GW, int QG>
 __global__ __launch_bounds__(256 * GW / QG)
 void attn_prefill_kernel(const PrefillAttnArgs a)
