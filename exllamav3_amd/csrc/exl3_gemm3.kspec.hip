@@ -41,12 +41,23 @@ __device__ __forceinline__ void g3_static_for(F&& f)
 #define G3_XPAD 16
 #define G3_WAVES 4
 
-template <int K, int CB, int MT, bool ROT>
+constexpr int g3_waves_per_eu(int K, int MT, bool ROT, bool RAW)
+{
+    (void) RAW;                                      // the raw variant is instantiated for the rotated-input prologue only, whose budgets cover its row-sum accumulators
+    return MT == 4 ? (ROT ? (K >= 5 ? 2 : 3) : ((K == 4 || K <= 2) ? 4 : 3)) : ((K >= 7 || (ROT && K >= 5)) ? 3 : ((ROT || K >= 5) ? 4 : 5));
+}
+
+template <int K, int CB, int MT, bool ROT, bool RAWV>
+// RAWV (mul1 codebook, rotated input = the fused decode pipeline, the library's default GEMV variant): the weights enter the matrix instructions as the packed byte sums 1024 + s the
+// decode produces (exact fp16 integers) instead of fp16(kinv * (1024 + s) + kbias); the affine map is applied once per output,
+// out = kinv * acc + kbias * sum_k x[row][k], with the row sums accumulated by one extra matrix instruction per 32 k against a ones operand (they
+// land in the accumulator layout of the outputs).  Removes a v_pk_fma_f16 per weight pair, 14 % of the streaming loop's VALU instructions; the
+// same arithmetic as generation 2's default variant.
 // ROT: the input is already rotated (fused decode pipeline) -- a separate instantiation so that neither prologue's registers burden the other.
 // five 4-wave workgroups per CU (LDS: 5 x 31 KB) need <= 96 VGPRs; the 64-row passes, the ROT prologue (16 registers of activation copy in
 // flight next to the weight ring) and the wide rings of K >= 5 take the next register budgets instead of spilling (any scratch use slows
 // every launch); the table below is what hipcc 7.2 needs for zero scratch in every (K, codebook, MT, ROT) instantiation
-__global__ __launch_bounds__(64 * G3_WAVES) __attribute__((amdgpu_waves_per_eu(MT == 4 ? (ROT ? (K >= 5 ? 2 : 3) : ((K == 4 || K <= 2) ? 4 : 3)) : ((K >= 7 || (ROT && K >= 5)) ? 3 : ((ROT || K >= 5) ? 4 : 5)))))
+__global__ __launch_bounds__(64 * G3_WAVES) __attribute__((amdgpu_waves_per_eu(g3_waves_per_eu(K, MT, ROT, RAWV && CB == EXL3_CB_MUL1))))
 void exl3_gemm3_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -104,9 +115,13 @@ void exl3_gemm3_kernel(const GemvArgs a)
     const uint32_t* __restrict__ strip = Bm + ((size_t) (k0s >> 4) + g) * row_stride + (size_t) (cbl * 8 + 2 * wave + t2) * NW + (size_t) c * K;
     const int prev_lane_addr = ((lane & ~7) | ((lane - 1) & 7)) << 2;
 
+    constexpr bool RAW = RAWV && CB == EXL3_CB_MUL1;
     float4_t acc[MT][2];
     #pragma unroll
     for (int i = 0; i < MT; ++i) { acc[i][0] = float4_t{ 0.f, 0.f, 0.f, 0.f }; acc[i][1] = acc[i][0]; }
+    float4_t rsum[RAW ? MT : 1];                     // RAW: sum_k x[row][k] for the rows of acc[i][*] (every column lane holds the same value)
+    #pragma unroll
+    for (int i = 0; i < (RAW ? MT : 1); ++i) rsum[i] = float4_t{ 0.f, 0.f, 0.f, 0.f };
 
     // ---- activation fetch helpers
     struct PrepIn { half4_t xv, sv; };
@@ -185,8 +200,8 @@ void exl3_gemm3_kernel(const GemvArgs a)
             {
                 constexpr int q = decltype(qc)::value;
                 half4_t bc[2], bd[2];
-                decode_quad<K, CB, 0, 8 * q>(Wx, bc);
-                decode_quad<K, CB, 0, 8 * q + 4>(Wx, bd);
+                decode_quad<K, CB, RAW ? 1 : 0, 8 * q>(Wx, bc);
+                decode_quad<K, CB, RAW ? 1 : 0, 8 * q + 4>(Wx, bd);
                 union { half4_t h; uint32_t w[2]; } uc, ud; uc.h = bc[0]; ud.h = bd[0];
                 clo[q] = uc.w[0]; chi[q] = uc.w[1]; dlo[q] = ud.w[0]; dhi[q] = ud.w[1];
                 __builtin_amdgcn_sched_barrier(0);      // bound live ranges: 8 weights in flight at a time (occupancy > ILP here)
@@ -204,6 +219,12 @@ void exl3_gemm3_kernel(const GemvArgs a)
                 half8_t af[MT];
                 #pragma unroll
                 for (int i = 0; i < MT; ++i) af[i] = *((const half8_t*) (arow[i] + kloc + 64 * sub + 32 * p));
+                if constexpr (RAW)
+                {
+                    const half8_t ones = { 1, 1, 1, 1, 1, 1, 1, 1 };
+                    #pragma unroll
+                    for (int i = 0; i < MT; ++i) rsum[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], ones, rsum[i], 0, 0, 0);
+                }
                 #pragma unroll
                 for (int t = 0; t < 2; ++t)
                 {
@@ -277,6 +298,18 @@ void exl3_gemm3_kernel(const GemvArgs a)
     // ---- epilogue.  D layout of acc[i][t]: rows 16 i + 4 kg + r, column 32 wave + 16 t + mj
     // (lane index laundered through an empty asm: the output addresses are computed here, not hoisted above the streaming loop where they
     // would cost registers -- the prologue spilled to scratch otherwise, and any scratch use slows every launch)
+    if constexpr (RAW)
+    {
+        const float kinv = (float) u16_as_half(0x1eeeu), kbias = (float) u16_as_half(0xc931u);
+        #pragma unroll
+        for (int i = 0; i < MT; ++i)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const float b = kbias * rsum[i][r];
+                acc[i][0][r] = acc[i][0][r] * kinv + b; acc[i][1][r] = acc[i][1][r] * kinv + b;
+            }
+    }
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int mj_e = lane_e & 15, kg_e = lane_e >> 4;
@@ -359,25 +392,28 @@ void exl3_gemm3_kernel(const GemvArgs a)
 #endif
 
 template <int CB>
-static void g3_launch_cb(int mt, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+static void g3_launch_cb(int mt, bool raw, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
     const bool rot = (args.flags & GEMV_IN_ROTATED) != 0;
-    #define L(M, R) exl3_gemm3_kernel<G2_K, CB, M, R><<<grid, dim3(64 * G3_WAVES), lds, st>>>(args)
-    if (mt == 1)      { if (rot) L(1, true); else L(1, false); }
-    else if (mt == 2) { if (rot) L(2, true); else L(2, false); }
-    else              { if (rot) L(4, true); else L(4, false); }
+    #define L2(M, R, V) exl3_gemm3_kernel<G2_K, CB, M, R, V><<<grid, dim3(64 * G3_WAVES), lds, st>>>(args)
+    // the raw variant serves the fused decode pipeline (rotated input); the standalone op keeps the reference's fp16-rounded weights
+    #define L(M, R) { if constexpr (CB == EXL3_CB_MUL1 && R) { if (raw) L2(M, R, true); else L2(M, R, false); } else L2(M, R, false); }
+    if (mt == 1)      { if (rot) L(1, true) else L(1, false) }
+    else if (mt == 2) { if (rot) L(2, true) else L(2, false) }
+    else              { if (rot) L(4, true) else L(4, false) }
     #undef L
+    #undef L2
 }
 
 #define G3_CAT_(a, b) a##b
 #define G3_CAT(a, b) G3_CAT_(a, b)
 
 // mt = row tiles of 16 per pass: 1, 2 or 4
-void G3_CAT(exl3_gemm3_launch_k, G2_K)(int cb, int mt, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+void G3_CAT(exl3_gemm3_launch_k, G2_K)(int cb, int mt, int var, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
-    if (cb == 0) g3_launch_cb<0>(mt, grid, lds, st, args);
-    else if (cb == 1) g3_launch_cb<1>(mt, grid, lds, st, args);
-    else g3_launch_cb<2>(mt, grid, lds, st, args);
+    if (cb == 0) g3_launch_cb<0>(mt, false, grid, lds, st, args);
+    else if (cb == 1) g3_launch_cb<1>(mt, false, grid, lds, st, args);
+    else g3_launch_cb<2>(mt, var == 1, grid, lds, st, args);
 }
 
 #if G2_K == 4

@@ -406,14 +406,14 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             args.magic_m = gemv_magic((uint32_t) mp);
             switch (K)
             {
-                case 1: exl3_gemm3_launch_k1(cb, mt, grid, lds, st, args); break;
-                case 2: exl3_gemm3_launch_k2(cb, mt, grid, lds, st, args); break;
-                case 3: exl3_gemm3_launch_k3(cb, mt, grid, lds, st, args); break;
-                case 4: exl3_gemm3_launch_k4(cb, mt, grid, lds, st, args); break;
-                case 5: exl3_gemm3_launch_k5(cb, mt, grid, lds, st, args); break;
-                case 6: exl3_gemm3_launch_k6(cb, mt, grid, lds, st, args); break;
-                case 7: exl3_gemm3_launch_k7(cb, mt, grid, lds, st, args); break;
-                case 8: exl3_gemm3_launch_k8(cb, mt, grid, lds, st, args); break;
+                case 1: exl3_gemm3_launch_k1(cb, mt, var, grid, lds, st, args); break;
+                case 2: exl3_gemm3_launch_k2(cb, mt, var, grid, lds, st, args); break;
+                case 3: exl3_gemm3_launch_k3(cb, mt, var, grid, lds, st, args); break;
+                case 4: exl3_gemm3_launch_k4(cb, mt, var, grid, lds, st, args); break;
+                case 5: exl3_gemm3_launch_k5(cb, mt, var, grid, lds, st, args); break;
+                case 6: exl3_gemm3_launch_k6(cb, mt, var, grid, lds, st, args); break;
+                case 7: exl3_gemm3_launch_k7(cb, mt, var, grid, lds, st, args); break;
+                case 8: exl3_gemm3_launch_k8(cb, mt, var, grid, lds, st, args); break;
             }
         }
         else

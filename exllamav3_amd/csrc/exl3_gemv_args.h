@@ -161,7 +161,7 @@ size_t exl3_gemv2_lds_bytes(int ng, int var, int cb, int nwv, int m, int chunk_b
 G2_DECL(1) G2_DECL(2) G2_DECL(3) G2_DECL(4) G2_DECL(5) G2_DECL(6) G2_DECL(7) G2_DECL(8)
 #undef G2_DECL
 // generation 3 (exl3_gemm3.kspec.hip): 5..64 rows per pass through an LDS transpose into 16x16x32 MFMAs
-#define G3_DECL(KK) void exl3_gemm3_launch_k##KK(int cb, int mt, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args);
+#define G3_DECL(KK) void exl3_gemm3_launch_k##KK(int cb, int mt, int var, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args);
 G3_DECL(1) G3_DECL(2) G3_DECL(3) G3_DECL(4) G3_DECL(5) G3_DECL(6) G3_DECL(7) G3_DECL(8)
 #undef G3_DECL
 size_t exl3_gemm3_lds_bytes(int m, int chunk_blocks);
