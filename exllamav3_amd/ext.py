@@ -311,6 +311,75 @@ def exl3_mgemm_bcast(A: torch.Tensor, Bs: list[torch.Tensor], Cs: list[torch.Ten
                                         m, k, K, _cb(mcg, mul1), int(Cs[0].dtype == torch.float), int(force_split), _stream(A)))
 
 
+MOE_ACT_SILU, MOE_ACT_GELU, MOE_ACT_RELU2_NOGATE = 0, 1, 2           # quant/exl3_moe_common.cuh:6-8
+MOE_SLOT_ROWS = 16                                                    # rows of one indexed-launch slot
+
+
+def exl3_moe_max_concurrency(device: int) -> int:
+    """quant/exl3_moe.cu:14-18 (SMs / SMs-per-expert): how many experts the caller should size its temp buffers for.  This build needs no
+    temp buffers (the arguments are accepted and ignored); the value only has to be positive."""
+    return 32
+
+
+def exl3_moe(hidden_state, output_state, expert_count, token_sorted, weight_sorted, temp_state_g, temp_state_u, temp_intermediate_g,
+             temp_intermediate_u, act_function: int, K_gate: int, K_up: int, K_down: int, gate_ptrs_trellis, gate_ptrs_suh, gate_ptrs_svh,
+             up_ptrs_trellis, up_ptrs_suh, up_ptrs_svh, down_ptrs_trellis, down_ptrs_suh, down_ptrs_svh, gate_mcg: bool, gate_mul1: bool,
+             up_mcg: bool, up_mul1: bool, down_mcg: bool, down_mul1: bool, act_limit: float, num_active: int):
+    """quant/exl3_moe.cu:99-301 (same argument list): output_state (bsz, hidden) fp32 += weight * down_e(silu(gate_e(x)) * up_e(x)) for every
+    (token, expert) assignment of an expert e with 0 < expert_count[e] <= max_tokens_per_expert (= temp_state_g.shape[1]); busier experts are left
+    to the caller's other route, as in the reference.  token_sorted / weight_sorted list the assignments grouped by expert.
+    The reference runs this as ONE persistent cooperative kernel (expert tickets, grid-wide hand-offs between gate|up, activation and down); on
+    MI355X an in-kernel grid-wide hand-off costs more than a kernel boundary (DESIGN.md 4.7 e), so the same work is three indexed launches --
+    gate and up of all (expert, <= 16-row chunk) slots, then down with silu * mul formed in its prologue -- and a weighted scatter-add.
+    The slot list is built on the host from expert_count / token_sorted (one device -> host copy: not capturable in a graph; the decode-step
+    route for one rank is moe_path.SyntheticEXL3MoE, 4 launches, capturable).  SiLU only; act_limit must be 0."""
+    _dev(hidden_state)
+    if num_active == 0:
+        return
+    _req(act_function == MOE_ACT_SILU and float(act_limit) == 0.0, "exl3_moe: only the gated SiLU activation without a limit is built")
+    _req(hidden_state.dtype == torch.half and hidden_state.dim() == 2 and hidden_state.is_contiguous(), "exl3_moe: hidden_state must be contiguous float16 (bsz, hidden)")
+    _req(output_state.dtype == torch.float and output_state.shape == hidden_state.shape, "exl3_moe: output_state must be float32 with hidden_state's shape")
+    _req(expert_count.dtype == torch.long and expert_count.dim() == 1 and token_sorted.dtype == torch.long and token_sorted.dim() == 1,
+         "exl3_moe: expert_count / token_sorted must be 1-D int64")
+    _req(weight_sorted.shape == token_sorted.shape and weight_sorted.dtype == torch.half, "exl3_moe: weight_sorted must be float16 with token_sorted's shape")
+    _req(temp_state_g.dim() == 3 and temp_intermediate_g.dim() == 3, "exl3_moe: temp buffers must be 3-D")
+    bsz, hidden = hidden_state.shape
+    inter = temp_intermediate_g.shape[2]
+    max_rows = temp_state_g.shape[1]
+    E = expert_count.shape[0] - 1
+    for t in (gate_ptrs_trellis, gate_ptrs_suh, gate_ptrs_svh, up_ptrs_trellis, up_ptrs_suh, up_ptrs_svh, down_ptrs_trellis, down_ptrs_suh, down_ptrs_svh):
+        _req(t.dtype == torch.long and t.dim() == 1 and t.shape[0] >= E, "exl3_moe: pointer tables must be int64 with one entry per expert")
+    counts = expert_count[:E].tolist()
+    slot_expert, slot_pos = [], []                               # one slot = up to 16 consecutive assignments of one expert
+    off = 0
+    for e, c in enumerate(counts):
+        if 0 < c <= max_rows:
+            for r0 in range(0, c, MOE_SLOT_ROWS):
+                slot_expert.append(e); slot_pos.append((off + r0, min(MOE_SLOT_ROWS, c - r0)))
+        off += c
+    if not slot_expert:
+        return
+    m = max(n for _, n in slot_pos)
+    ns = len(slot_expert)
+    dev = hidden_state.device
+    pos = torch.zeros((ns, m), dtype=torch.long)
+    valid = torch.zeros((ns, m), dtype=torch.bool)
+    for j, (p0, n) in enumerate(slot_pos):
+        pos[j, :n] = torch.arange(p0, p0 + n); valid[j, :n] = True
+    pos, valid = pos.to(dev).view(-1), valid.to(dev).view(-1)
+    tok = token_sorted.index_select(0, pos)                       # padded rows repeat an assignment; they are dropped before the scatter
+    A = hidden_state.index_select(0, tok).view(ns, m, hidden)
+    idx = torch.tensor(slot_expert, dtype=torch.long, device=dev)
+    G = torch.empty((ns, m, inter), dtype=torch.half, device=dev)
+    U = torch.empty_like(G)
+    exl3_mgemm(A, gate_ptrs_trellis, G, gate_ptrs_suh, None, gate_ptrs_svh, idx, None, K_gate, -1, gate_mcg, gate_mul1, -1, -1, 0)
+    exl3_mgemm(A, up_ptrs_trellis, U, up_ptrs_suh, None, up_ptrs_svh, idx, None, K_up, -1, up_mcg, up_mul1, -1, -1, 0)
+    D = torch.empty((ns, m, hidden), dtype=torch.float, device=dev)
+    exl3_mgemm_act(G, U, down_ptrs_trellis, D, down_ptrs_suh, down_ptrs_svh, idx, None, K_down, down_mcg, down_mul1)
+    rows = D.view(ns * m, hidden) * weight_sorted.index_select(0, pos).float().unsqueeze(1)
+    output_state.index_add_(0, tok[valid], rows[valid])
+
+
 def hgemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):
     """hgemm.cu:19-102: c = a @ b, fp16 inputs, fp32 accumulate, c fp16/fp32 (may be a column slice)."""
     _dev(a)

@@ -578,6 +578,52 @@ def test_moe_block_matches_oracle(dev, cb, tokens):
     assert np.abs(y - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
 
 
+def test_exl3_moe_op_matches_oracle(dev):
+    """ext.exl3_moe (quant/exl3_moe.cu:99-301, same argument list): assignments grouped by expert, ragged counts -- an expert with more than 16
+    rows (two slots of the indexed launches), single-row experts, idle experts, and one above max_tokens_per_expert that the op must leave
+    alone -- accumulated into a pre-filled fp32 output; against the oracle's per-assignment composition."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.moe_path import SyntheticEXL3MoE
+    hidden, inter, E, bsz, max_rows = 256, 384, 6, 24, 22
+    moe = SyntheticEXL3MoE(hidden, inter, experts=E, top_k=2, K=4, cb=2, device=dev, seed=9)
+    rng = np.random.default_rng(4)
+    counts = [20, 1, 0, 23, 4, 0]                                            # expert 3 exceeds max_rows: skipped by the op
+    toks, wts = [], []
+    for c in counts:
+        toks += list(rng.permutation(bsz)[:c]); wts += list(rng.uniform(0.1, 0.9, c))
+    x = rng.standard_normal((bsz, hidden)).astype(np.float16)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out0 = rng.standard_normal((bsz, hidden)).astype(np.float32)              # the op accumulates
+    out = T(out0)
+    tmp_s = torch.empty((4, max_rows, hidden), dtype=torch.half, device=dev); tmp_i = torch.empty((4, max_rows, inter), dtype=torch.half, device=dev)
+    wts16 = np.array(wts, np.float16)
+    args = (T(x), out, T(np.array(counts + [0], np.int64)), T(np.array(toks, np.int64)), T(wts16), tmp_s, tmp_s, tmp_i, tmp_i, ext.MOE_ACT_SILU,
+            4, 4, 4, moe.g_B, moe.g_suh, moe.g_svh, moe.u_B, moe.u_suh, moe.u_svh, moe.d_B, moe.d_suh, moe.d_svh, False, True, False, True, False, True)
+    ext.exl3_moe(*args, 0.0, 3)
+    ref = out0.copy()
+    off = 0
+    for e, c in enumerate(counts):
+        if 0 < c <= max_rows:
+            rows = np.array(toks[off:off + c])
+            g = _lin(moe.gate[e], x[rows]).astype(np.float32); u = _lin(moe.up[e], x[rows]).astype(np.float32)
+            a = (g / (1 + np.exp(-g)) * u).astype(np.float16)
+            d = _lin(moe.down[e], a, out_fp32=True)
+            for i, t in enumerate(rows):
+                ref[t] += np.float32(wts16[off + i]) * d[i]
+        off += c
+    got = out.cpu().numpy()
+    delta = ref - out0
+    assert np.abs(got - ref).max() / np.sqrt((delta[np.abs(delta).sum(1) > 0] ** 2).mean()) < 2e-2
+    untouched = np.setdiff1d(np.arange(bsz), np.array([t for e, c in enumerate(counts) if 0 < c <= max_rows
+                                                         for t in toks[sum(counts[:e]): sum(counts[:e]) + c]]))
+    assert np.array_equal(got[untouched], out0[untouched])
+    ext.exl3_moe(*args, 0.0, 0)                                              # num_active == 0: nothing to do
+    assert np.array_equal(out.cpu().numpy(), got)
+    with pytest.raises(RuntimeError):
+        ext.exl3_moe(*args[:9], ext.MOE_ACT_GELU, *args[10:], 0.0, 3)
+    assert ext.exl3_moe_max_concurrency(0) > 0
+
+
 @pytest.mark.parametrize("experts,hidden", [(8, 4096), (6, 384), (64, 1024)])
 @pytest.mark.parametrize("tokens", [1, 3])
 def test_router_with_rmsnorm_inside_matches_norm_then_router(dev, experts, hidden, tokens):
