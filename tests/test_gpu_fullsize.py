@@ -174,3 +174,41 @@ def test_prefill_chunk_8b_layer_vs_oracle_on_sampled_rows(dev):
     # residual stream rows after the layer (prefill_chunk keeps it for this check)
     got_x = _np(model.px_out)[rows].astype(np.float32)
     assert _relerr(got_x, x) < 2e-2
+
+
+def test_prefill_attention_8b_chunk_vs_oracle_on_sampled_queries(dev):
+    """exl3_attn_prefill_paged at BASELINE config 3's prefill size (4096 new tokens, Llama-3.1-8B heads 32 / 8 x 128, 256-token pages in a
+    permuted block table): sampled query rows against the fp32 definition (softmax(q K^T / sqrt(d)) V over keys 0 .. i), plus the causal
+    property at full size: changing the keys and values after position p leaves the outputs of queries <= p bit-identical."""
+    from exllamav3_amd import ext
+    T, hq, hkv, hd, page = 4096, 32, 8, 128, 256
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    pages = T // page
+    bt = torch.randperm(pages, device=dev, generator=g).to(torch.int32).view(1, pages)
+    q = torch.randn((1, T, hq, hd), device=dev, generator=g).half()
+    kp = torch.randn((pages, page, hkv, hd), device=dev, generator=g).half()
+    vp = torch.randn((pages, page, hkv, hd), device=dev, generator=g).half()
+    lens = torch.tensor([T], dtype=torch.int32, device=dev)
+    out = torch.empty_like(q)
+    ext.attn_prefill_paged(q, out, kp, vp, bt, lens)
+    k = kp[bt[0].long()].reshape(T, hkv, hd).float().cpu().numpy(); v = vp[bt[0].long()].reshape(T, hkv, hd).float().cpu().numpy()
+    qn, got = q[0].float().cpu().numpy(), out[0].float().cpu().numpy()
+    rows = [0, 1, 63, 64, 255, 256, 1000, 2047, 2048, 3071, 4000, 4095]
+    worst = 0.0
+    for i in rows:
+        for h in range(0, hq, 5):
+            kk, vv = k[: i + 1, h // (hq // hkv)], v[: i + 1, h // (hq // hkv)]
+            s = (kk @ qn[i, h]) * np.float32(hd ** -0.5)
+            p = np.exp(s - s.max()); p /= p.sum()
+            ref = p @ vv
+            worst = max(worst, float(np.abs(got[i, h] - ref).max() / np.sqrt((ref ** 2).mean())))
+    assert worst < 2e-2
+    # causal property: perturb everything after position p
+    p0 = 1500
+    kp2, vp2 = kp.clone(), vp.clone()
+    flat_k = kp2[bt[0].long()].reshape(T, hkv, hd); flat_v = vp2[bt[0].long()].reshape(T, hkv, hd)
+    flat_k[p0 + 1:] = torch.randn_like(flat_k[p0 + 1:]); flat_v[p0 + 1:] = torch.randn_like(flat_v[p0 + 1:])
+    kp2[bt[0].long()] = flat_k.view(pages, page, hkv, hd); vp2[bt[0].long()] = flat_v.view(pages, page, hkv, hd)
+    out2 = torch.empty_like(q)
+    ext.attn_prefill_paged(q, out2, kp2, vp2, bt, lens)
+    assert torch.equal(out2[0, : p0 + 1], out[0, : p0 + 1]) and not torch.equal(out2[0, p0 + 1:], out[0, p0 + 1:])
