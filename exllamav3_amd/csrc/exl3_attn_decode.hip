@@ -32,10 +32,13 @@ struct AttnArgs
 };
 // hq / hkv in AttnArgs count HEADS; a workgroup handles one 128-value block of the kv vector = 128 / HD kv heads
 
-template <int GQ, int HD>
+// KVB: bits of both caches when known at compile time (4 or 8: one packed field per value, the dequantization folds to a shift and a mask per value
+// instead of four predicated field passes), 0 = read a.k_bits / a.v_bits (any 2-8 bit mix)
+template <int GQ, int HD, int KVB>
 __global__ __launch_bounds__(256)
 void attn_decode_kernel(const AttnArgs a)
 {
+    const int k_bits = KVB ? KVB : a.k_bits, v_bits = KVB ? KVB : a.v_bits;
     constexpr int NSUB = 128 / HD;                              // kv heads per 128-value block (1 or 2)
     constexpr int RW = HD / 4;                                  // lanes per head (32 or 16)
     __shared__ float ml_s[8][GQ][NSUB][2];
@@ -89,8 +92,8 @@ void attn_decode_kernel(const AttnArgs a)
             const int64_t pg = one_page ? page_phys : (int64_t) a.block_table[(size_t) b * a.blocks_per_seq + tc / a.page_size];
             const int64_t token_pos = pg * a.page_size + (tc % a.page_size);
             const int64_t gb = token_pos * G + h * 4 + g;
-            kv_dequant_vals_rt(a.k_bits, a.k_cache + gb * a.k_bits, a.k_scales + gb, lane, kv[u][0], kv[u][1], kv[u][2], kv[u][3]);
-            kv_dequant_vals_rt(a.v_bits, a.v_cache + gb * a.v_bits, a.v_scales + gb, lane, kv[u][4], kv[u][5], kv[u][6], kv[u][7]);
+            kv_dequant_vals_rt(k_bits, a.k_cache + gb * k_bits, a.k_scales + gb, lane, kv[u][0], kv[u][1], kv[u][2], kv[u][3]);
+            kv_dequant_vals_rt(v_bits, a.v_cache + gb * v_bits, a.v_scales + gb, lane, kv[u][4], kv[u][5], kv[u][6], kv[u][7]);
         }
         #pragma unroll
         for (int u = 0; u < ATT_UNROLL; ++u)
@@ -281,8 +284,12 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
     a.nsplit = nsplit; a.split_tokens = split_tokens; a.scale = scale;
     dim3 grid(nsplit, blocks, bsz);
     hipStream_t st = (hipStream_t) stream;
-    #define ATT_L(GQv) case GQv: if (head_dim == 128) attn_decode_kernel<GQv, 128><<<grid, 256, 0, st>>>(a); else attn_decode_kernel<GQv, 64><<<grid, 256, 0, st>>>(a); break;
-    switch (gq) { ATT_L(1) ATT_L(2) ATT_L(3) ATT_L(4) ATT_L(5) ATT_L(6) ATT_L(7) default: if (head_dim == 128) attn_decode_kernel<8, 128><<<grid, 256, 0, st>>>(a); else attn_decode_kernel<8, 64><<<grid, 256, 0, st>>>(a); break; }
+    const int kvb = (k_bits == v_bits && (k_bits == 4 || k_bits == 8)) ? k_bits : 0;
+    #define ATT_K(GQv, HDv) { if (kvb == 4) attn_decode_kernel<GQv, HDv, 4><<<grid, 256, 0, st>>>(a); else if (kvb == 8) attn_decode_kernel<GQv, HDv, 8><<<grid, 256, 0, st>>>(a); \
+                              else attn_decode_kernel<GQv, HDv, 0><<<grid, 256, 0, st>>>(a); }
+    #define ATT_L(GQv) case GQv: if (head_dim == 128) ATT_K(GQv, 128) else ATT_K(GQv, 64) break;
+    switch (gq) { ATT_L(1) ATT_L(2) ATT_L(3) ATT_L(4) ATT_L(5) ATT_L(6) ATT_L(7) default: if (head_dim == 128) ATT_K(8, 128) else ATT_K(8, 64) break; }
+    #undef ATT_K
     #undef ATT_L
     int rc = exl3_check_launch("attn_decode");
     if (rc) return rc;
