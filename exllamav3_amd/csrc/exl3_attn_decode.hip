@@ -156,6 +156,192 @@ void attn_decode_kernel(const AttnArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Long contexts: the same computation on the matrix pipe (head_dim 128, 4-bit K and V).  The kernel above spends ~160 VALU instructions per pair
+// of cached tokens (per-head butterflies, per-lane softmax updates): 43.6 us per layer at 16 000 tokens.  Here a wave takes 16 tokens per step:
+//   * lane (c = lane % 16, kg = lane / 16) loads ONE dword per 32-group = the 8 four-bit levels of dims 8 kg .. 8 kg + 7 of token c and turns them
+//     into fp16 (level - 7.5) * scale / 8 with exact half arithmetic: (x >> (4r - 1)) & 0x001E001E | 0x4C004C00 is the pair (16 + n_r / 32,
+//     16 + n_{r+4} / 32), minus (16 + 15/64) is exact, times 4 * scale rounds once -- the value the reference's dequantization rounds to fp16 too.
+//     The pair order (0, 4, 1, 5, 2, 6, 3, 7) is a permutation of the contraction index, applied to the rotated query fragments as well;
+//   * scores = K q^T with v_mfma_f32_16x16x32_f16 (A = the dequantized K rows, B = rotated queries, one instruction per 32-group): lane (head c, kg)
+//     ends up with the scores of tokens 4 kg .. 4 kg + 3 for query head c -- which is the A operand layout of the second product, so the
+//     probabilities never move between lanes (the S^T trick of exl3_attn_prefill.hip);
+//   * V is dequantized the same way, staged row-major in a wave-private LDS tile and gathered as the B operand (4 tokens of one dim) by
+//     ds_read_b64_tr_b16; output columns are therefore in the pair order and are un-permuted once, when the partial record is written.
+// Partial records and the merge kernel are those of the kernel above.
+struct AttnWideArgs { AttnArgs a; };
+
+#define AW_VS 136          // V tile row stride in halves (272 B: the transpose-read groups tile the banks)
+
+__device__ __forceinline__ half4_t aw_tr16(const half_t* p)
+{
+    typedef short s16x4_t __attribute__((__vector_size__(4 * sizeof(short))));
+    const s16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*) p);
+    return __builtin_bit_cast(half4_t, r);
+}
+
+// 8 four-bit levels of one dword -> 8 halves (level - 7.5) * sc4 / 4 ... in pair order (n0, n4), (n1, n5), (n2, n6), (n3, n7); sc4 = 4 * scale as half2
+__device__ __forceinline__ half8_t aw_dequant8(uint32_t x, half2_t sc4)
+{
+    const half2_t off = { u16_as_half(0xcc0fu), u16_as_half(0xcc0fu) };         // -(16 + 15/64)
+    union { uint32_t u[4]; half8_t h; } r;
+    #pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        const uint32_t sh = i == 0 ? (x << 1) : (x >> (4 * i - 1));
+        const uint32_t m = (sh & 0x001E001Eu) | 0x4C004C00u;
+        const half2_t v = (u32_as_half2(m) + off) * sc4;
+        r.u[i] = half2_as_u32(v);
+    }
+    return r.h;
+}
+
+template <int GQ>
+__global__ __launch_bounds__(256)
+void attn_decode_wide_kernel(const AttnArgs a)
+{
+    constexpr int HD = 128;
+    __shared__ __attribute__((aligned(16))) half_t q_s[8 * 128];               // rotated, pre-scaled queries in pair order (rows >= GQ stay zero)
+    __shared__ __attribute__((aligned(16))) half_t vt[4][16 * AW_VS];          // wave-private dequantized V tiles; after the loop: the waves' partial outputs
+    __shared__ float ml_s[4][8][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, kg = lane >> 4;
+    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;              // h: kv head (one 128-value block of the kv vector)
+    const int len = a.cache_seqlens[b];
+    const int t0 = split * a.split_tokens, t1 = min(len, t0 + a.split_tokens);
+    const int G = a.hkv * HD / 32;
+
+    // ---- rotated queries: half-wave i rotates head i as the kernel above does and stores it in pair order; natural-log scores become log2 scores
+    {
+        const int l = tid & 31, i = tid >> 5;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (i < GQ)
+        {
+            const half4_t qv = ((const half4_t*) (a.q + ((size_t) b * a.hq + h * GQ + i) * HD))[l];
+            v0 = (float) qv.x; v1 = (float) qv.y; v2 = (float) qv.z; v3 = (float) qv.w;
+        }
+        kvg_had32(v0, v1, v2, v3, lane);
+        const float f = ATT_R32 * a.scale * 1.44269504f;
+        const float vv[4] = { v0 * f, v1 * f, v2 * f, v3 * f };
+        #pragma unroll
+        for (int e = 0; e < 4; ++e)
+        {
+            const int d = 4 * l + e, d8 = d & 7;
+            q_s[i * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = i < GQ ? (half_t) vv[e] : (half_t) 0.0f;
+        }
+    }
+    __syncthreads();
+    half8_t qf[4];
+    #pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = c < 8 ? *((const half8_t*) (q_s + c * 128 + 32 * s + 8 * kg)) : half8_t{ 0, 0, 0, 0, 0, 0, 0, 0 };
+
+    float m_run = -1.0e30f, l_run = 0.0f;                       // of query head c (lanes with c >= GQ carry zero queries)
+    float4_t oc[8];
+    #pragma unroll
+    for (int nb = 0; nb < 8; ++nb) oc[nb] = float4_t{ 0.f, 0.f, 0.f, 0.f };
+    half_t* vw = vt[wave];
+
+    const int nsteps = (a.split_tokens + 63) / 64;
+    for (int st = 0; st < nsteps; ++st)
+    {
+        const int tb = t0 + 64 * st + 16 * wave;                // the wave's 16 tokens of this step
+        if (tb >= t1) break;                                    // wave-uniform: nothing left for this wave (its LDS tile is private)
+        const int tk = min(tb + c, t1 - 1);
+        const int64_t pg = a.block_table[(size_t) b * a.blocks_per_seq + tk / a.page_size];
+        const int64_t gbase = (pg * a.page_size + (tk % a.page_size)) * G + h * 4;
+        uint32_t kw[4], vw4[4];
+        #pragma unroll
+        for (int s = 0; s < 4; ++s) { kw[s] = a.k_cache[(gbase + s) * 4 + kg]; vw4[s] = a.v_cache[(gbase + s) * 4 + kg]; }
+        const half4_t ksc = *((const half4_t*) (a.k_scales + gbase)), vsc = *((const half4_t*) (a.v_scales + gbase));
+        // ---- scores of the 16 tokens for all heads: D[token][head]; lane (head c, kg) holds tokens 4 kg .. 4 kg + 3
+        float4_t sc = { 0.f, 0.f, 0.f, 0.f };
+        #pragma unroll
+        for (int s = 0; s < 4; ++s)
+        {
+            const half_t k4 = ksc[s] * (half_t) 4.0f;
+            const half8_t ka = aw_dequant8(kw[s], half2_t{ k4, k4 });
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[s], sc, 0, 0, 0);
+        }
+        // ---- V tile of the wave: token c, dims 32 s + 8 kg .. (pair order) -> LDS row c
+        #pragma unroll
+        for (int s = 0; s < 4; ++s)
+        {
+            const half_t v4 = vsc[s] * (half_t) 4.0f;
+            *((half8_t*) (vw + c * AW_VS + 32 * s + 8 * kg)) = aw_dequant8(vw4[s], half2_t{ v4, v4 });
+        }
+        // ---- online softmax of head c over the step's tokens (log2 domain)
+        float mx = m_run;
+        #pragma unroll
+        for (int r = 0; r < 4; ++r) { if (tb + 4 * kg + r >= t1) sc[r] = -1.0e30f; mx = fmaxf(mx, sc[r]); }
+        mx = fmaxf(mx, xor_lane(mx, 16)); mx = fmaxf(mx, xor_lane(mx, 32));
+        const float corr = __builtin_amdgcn_exp2f(m_run - mx);
+        float p[4], ps = 0.0f;
+        #pragma unroll
+        for (int r = 0; r < 4; ++r) { p[r] = sc[r] > -1.0e29f ? __builtin_amdgcn_exp2f(sc[r] - mx) : 0.0f; ps += p[r]; }
+        ps += xor_lane(ps, 16); ps += xor_lane(ps, 32);
+        l_run = l_run * corr + ps; m_run = mx;
+        const half4_t pa = { (half_t) p[0], (half_t) p[1], (half_t) p[2], (half_t) p[3] };
+        // ---- rescale the accumulators (rows = heads 4 kg + r live in lanes (dim, kg)) where a running max moved, then add P V
+        if (__any(corr != 1.0f))
+        {
+            float cr[4];
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) cr[r] = __shfl(corr, 4 * kg + r, 64);
+            #pragma unroll
+            for (int nb = 0; nb < 8; ++nb) { oc[nb].x *= cr[0]; oc[nb].y *= cr[1]; oc[nb].z *= cr[2]; oc[nb].w *= cr[3]; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        #pragma unroll
+        for (int nb = 0; nb < 8; ++nb)
+        {
+            const half4_t vb = aw_tr16(vw + (4 * kg + (c >> 2)) * AW_VS + 16 * nb + 4 * (c & 3));
+            oc[nb] = __builtin_amdgcn_mfma_f32_16x16x16f16(pa, vb, oc[nb], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- merge the 4 waves: statistics of head c from lanes (c, kg = 0); outputs of heads 4 kg + r, column 16 nb + c (pair order) from every lane
+    __syncthreads();                                            // the V tiles are dead: their space takes the partial outputs [wave][head][128] fp32
+    float* o_s = (float*) &vt[0][0];                            // 4 * 8 * 128 * 4 B = 16 KB <= sizeof(vt) = 17 KB
+    if (kg == 0 && c < 8) { ml_s[wave][c][0] = m_run; ml_s[wave][c][1] = l_run; }
+    #pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+        #pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+            const int head = 4 * kg + r;
+            if (head < 8) o_s[(wave * 8 + head) * 128 + 16 * nb + c] = oc[nb][r];
+        }
+    __syncthreads();
+    // half-wave i finishes head i: lane l owns natural dims 4 l .. 4 l + 3
+    {
+        const int l = tid & 31, i = tid >> 5;
+        if (i < GQ)
+        {
+            float M = -1.0e30f;
+            #pragma unroll
+            for (int w = 0; w < 4; ++w) M = fmaxf(M, ml_s[w][i][0]);
+            float L = 0.0f, O[4] = { 0.f, 0.f, 0.f, 0.f };
+            #pragma unroll
+            for (int w = 0; w < 4; ++w)
+            {
+                const float e = ml_s[w][i][0] > -1.0e29f ? __builtin_amdgcn_exp2f(ml_s[w][i][0] - M) : 0.0f;
+                L += ml_s[w][i][1] * e;
+                #pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4)
+                {
+                    const int d = 4 * l + e4, d8 = d & 7;
+                    O[e4] += o_s[(w * 8 + i) * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] * e;
+                }
+            }
+            float* pr = a.part + ((((size_t) b * gridDim.y + h) * GQ + i) * a.nsplit + split) * 132;
+            if (l == 0) { pr[0] = M * 0.69314718f; pr[1] = L; }              // the merge kernel works in natural-log units
+            *((float4_t*) (pr + 4 + 4 * l)) = float4_t{ O[0], O[1], O[2], O[3] };
+        }
+    }
+}
+
 // merge of the context splits.  Latency, not work: 32 items x 32 splits x 528 B at a 1000-token context.  The first version gave one half-wave
 // per item three dependent load rounds (maxima, then (max, sum) again, then the split outputs 8 at a time): 6.6 us under rocprofv3.  Now FOUR
 // half-waves share an item, each takes a quarter of the splits, and everything a half-wave needs -- the (max, sum) statistics of ALL splits
@@ -282,8 +468,41 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
     a.block_table = block_table; a.cache_seqlens = cache_seqlens; a.part = workspace;
     a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.k_bits = k_bits; a.v_bits = v_bits; a.hq = heads_q; a.hkv = heads_kv;
     a.nsplit = nsplit; a.split_tokens = split_tokens; a.scale = scale;
-    dim3 grid(nsplit, blocks, bsz);
     hipStream_t st = (hipStream_t) stream;
+    // long contexts, head_dim 128, 4-bit K and V: the matrix-pipe kernel (64-token steps; it always writes partial records)
+    static const int wide_min = [] { const char* e = getenv("EXL3_HIP_ATTN_WIDE_MIN"); return e ? atoi(e) : 2048; }();
+    if (head_dim == 128 && k_bits == 4 && v_bits == 4 && max_len >= wide_min && page_size % 16 == 0 && workspace)
+    {
+        int st_tok = 64;
+        int ns = (max_len + st_tok - 1) / st_tok;
+        const int capw = (head_dim == 128 ? 256 : 128);
+        // about two workgroups per CU: more, shorter splits cost more in the merge than they return (16 000 tokens: 380 tok/s at 512, 337 at 2048)
+        static const int wg_cap = [] { const char* e = getenv("EXL3_HIP_ATTN_WIDE_WGS"); return e ? atoi(e) : 512; }();
+        while (ns > capw || (int64_t) ns * bsz * blocks > wg_cap) { st_tok += 64; ns = (max_len + st_tok - 1) / st_tok; }
+        if (ns >= 2 && workspace_floats >= (int64_t) bsz * blocks * gq * ns * 132)
+        {
+            a.nsplit = ns; a.split_tokens = st_tok;
+            dim3 gridw(ns, blocks, bsz);
+            switch (gq)
+            {
+                case 1: attn_decode_wide_kernel<1><<<gridw, 256, 0, st>>>(a); break;
+                case 2: attn_decode_wide_kernel<2><<<gridw, 256, 0, st>>>(a); break;
+                case 3: attn_decode_wide_kernel<3><<<gridw, 256, 0, st>>>(a); break;
+                case 4: attn_decode_wide_kernel<4><<<gridw, 256, 0, st>>>(a); break;
+                case 5: attn_decode_wide_kernel<5><<<gridw, 256, 0, st>>>(a); break;
+                case 6: attn_decode_wide_kernel<6><<<gridw, 256, 0, st>>>(a); break;
+                case 7: attn_decode_wide_kernel<7><<<gridw, 256, 0, st>>>(a); break;
+                default: attn_decode_wide_kernel<8><<<gridw, 256, 0, st>>>(a); break;
+            }
+            int rcw = exl3_check_launch("attn_decode_wide");
+            if (rcw) return rcw;
+            const int items = bsz * blocks * gq;
+            const uint32_t mg = gemv_magic((uint32_t) gq), mbg = gemv_magic((uint32_t) (blocks * gq)), mb = gemv_magic((uint32_t) blocks);
+            attn_merge_kernel<128><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, ns, gq, blocks, heads_q, mg, mbg, mb);
+            return exl3_check_launch("attn_merge");
+        }
+    }
+    dim3 grid(nsplit, blocks, bsz);
     const int kvb = (k_bits == v_bits && (k_bits == 4 || k_bits == 8)) ? k_bits : 0;
     #define ATT_K(GQv, HDv) { if (kvb == 4) attn_decode_kernel<GQv, HDv, 4><<<grid, 256, 0, st>>>(a); else if (kvb == 8) attn_decode_kernel<GQv, HDv, 8><<<grid, 256, 0, st>>>(a); \
                               else attn_decode_kernel<GQv, HDv, 0><<<grid, 256, 0, st>>>(a); }

@@ -209,6 +209,42 @@ def test_attn_decode_qcache(dev, kb, vb, lens, hd, hq, hkv):
     assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
 
 
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 1), (6, 2), (4, 4)])
+@pytest.mark.parametrize("lens,max_len", [([2500, 1, 700], 2560), ([5000, 4096], 8192)])
+def test_attn_decode_qcache_long_context_kernel(dev, hq, hkv, lens, max_len):
+    """The matrix-pipe decode-attention kernel (head_dim 128, 4-bit K / V, length bound >= 2048): 16 tokens per wave step, scores and value
+    products as matrix instructions on fp16 values dequantized in pair order, V gathered with the LDS transpose read; GQA 4 / 8 / 3 / 1, ragged
+    lengths (one token, ends inside / on a 64-token step and a page), a length bound well above the lengths; against the oracle attention
+    over the dequantized cache."""
+    from exllamav3_amd import ext
+    hd, kb, vb, page = 128, 4, 4, 256
+    rng = np.random.default_rng(hq * 10 + hkv + len(lens))
+    bsz = len(lens)
+    pps = max_len // page
+    used = (max(lens) + page - 1) // page
+    npages = bsz * pps + 3
+    perm = rng.permutation(npages)[: bsz * pps].reshape(bsz, pps).astype(np.int32)
+    G = hkv * hd // 32
+    k = (rng.standard_normal((bsz, used * page, hkv * hd)) * 1.5).astype(np.float16)
+    v = rng.standard_normal((bsz, used * page, hkv * hd)).astype(np.float16)
+    kq, ks = o.kv_quant(k, kb); vq, vs = o.kv_quant(v, vb)
+    kc = np.zeros((npages, page, G * kb), dtype=np.uint32); ksc = np.zeros((npages, page, G), dtype=np.float16)
+    vc = np.zeros((npages, page, G * vb), dtype=np.uint32); vsc = np.zeros((npages, page, G), dtype=np.float16)
+    for b in range(bsz):
+        for p in range(used):
+            kc[perm[b, p]] = kq[b, p * page:(p + 1) * page]; ksc[perm[b, p]] = ks[b, p * page:(p + 1) * page]
+            vc[perm[b, p]] = vq[b, p * page:(p + 1) * page]; vsc[perm[b, p]] = vs[b, p * page:(p + 1) * page]
+    q = rng.standard_normal((bsz, hq, hd)).astype(np.float16)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out = torch.full((bsz, hq, hd), float("nan"), dtype=torch.half, device=dev)
+    ext.attn_decode_qcache(T(q), out, T(kc.view(np.int32)), T(ksc), T(vc.view(np.int32)), T(vsc), T(perm), T(np.array(lens, dtype=np.int32)), max_len)
+    kd = o.kv_dequant(kq, ks, kb).reshape(bsz, -1, hkv, hd); vd = o.kv_dequant(vq, vs, vb).reshape(bsz, -1, hkv, hd)
+    ref = o.attn_decode_qcache(q, kd, vd, lens).astype(np.float32)
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
+
+
 @pytest.mark.parametrize("shape", [(1, 300, 32, 8, 128), (2, 17, 5, 3, 128), (1, 64, 40, 40, 128), (1, 16, 1, 0, 128)])
 def test_rope_neox_head_dim_128_prefill_kernel(dev, shape):
     """>= 16 tokens, NEOX, head_dim 128, no head norm: the 16-byte-per-lane kernel (8 lanes per head); scalar position, per-sequence
