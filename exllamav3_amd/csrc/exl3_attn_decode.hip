@@ -469,8 +469,9 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
     a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.k_bits = k_bits; a.v_bits = v_bits; a.hq = heads_q; a.hkv = heads_kv;
     a.nsplit = nsplit; a.split_tokens = split_tokens; a.scale = scale;
     hipStream_t st = (hipStream_t) stream;
-    // long contexts, head_dim 128, 4-bit K and V: the matrix-pipe kernel (64-token steps; it always writes partial records)
-    static const int wide_min = [] { const char* e = getenv("EXL3_HIP_ATTN_WIDE_MIN"); return e ? atoi(e) : 2048; }();
+    // head_dim 128, 4-bit K and V, a length bound of at least two 64-token steps: the matrix-pipe kernel (it always writes partial records); measured
+    // ahead of the half-wave-per-token kernel from a 512-token bound on (463 vs 458 tok/s with attention), far ahead at long contexts
+    static const int wide_min = [] { const char* e = getenv("EXL3_HIP_ATTN_WIDE_MIN"); return e ? atoi(e) : 128; }();
     if (head_dim == 128 && k_bits == 4 && v_bits == 4 && max_len >= wide_min && page_size % 16 == 0 && workspace)
     {
         int st_tok = 64;

@@ -73,6 +73,7 @@ def test_prefill_chunk_with_attention_matches_oracle(dev):
     over the pages -> o_proj -> MLP) through one small layer against the oracle composition on EVERY token row (attention couples the rows):
     residual stream after the layer and the last token's logits."""
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    torch.manual_seed(7)                                      # the chunk's input comes from the global generator: same rows whatever ran before
     shape = LlamaShape("tiny", 256, 512, 1, 4, 2, 128, 384)
     model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4)
     model.prefill_attention = True
