@@ -96,7 +96,8 @@ def cpu_baseline(shape, K, cb):
     out = {"value": round(tok_s, 4), "unit": "tok/s", "cores": threads, "kind": "port", "host_cores": ncpu,
            "thread_probe_s": {str(k): round(v, 3) for k, v in probe.items()},
            "reconstruct_s_per_token": round(t_rec * scale, 3), "matmul_s_per_token": round(t_mm * scale, 4), "linears": parts,
-           "sample": f"torch-CPU oracle (reconstruct = trellis decode + tile permute; matmul = had(x*suh) @ W_hat -> had * svh), {threads} threads "
+           "extrapolated": True,
+           "sample": f"EXTRAPOLATION from a byte-scaled sample (two linears, not a whole-model run): torch-CPU oracle (reconstruct = trellis decode + tile permute; matmul = had(x*suh) @ W_hat -> had * svh), {threads} threads "
                      f"(fastest of the probed pool sizes on {ncpu} host cores), "
                      f"q and gate linears of one layer ({nbytes / 1e6:.1f} MB packed), median of 5 after 1 warm-up ({time.perf_counter() - t_start:.1f} s "
                      f"in all), scaled by packed bytes to the {shape.decode_bytes_per_token(K) / 1e9:.3f} GB/token model"}
@@ -153,7 +154,8 @@ def cpu_baseline_reference(shape, K):
     bytes_call = 2 * (H * I * K // 8) + 2 * 2 * (H + I)
     tok_s = 1.0 / (per_call * shape.decode_bytes_per_token(K) / bytes_call)
     return {"value": round(tok_s, 3), "unit": "tok/s", "cores": threads, "kind": "reference", "us_per_call_median": round(per_call * 1e6, 1),
-            "sample": f"reference cpu/moe_mul1.cpp (oracle/_ref, default ISA tier, {threads} threads), layer built once: up+down linears "
+            "extrapolated": True,
+            "sample": f"EXTRAPOLATION from a byte-scaled sample (one up+down pair, not a whole-model run): reference cpu/moe_mul1.cpp (oracle/_ref, default ISA tier, {threads} threads), layer built once: up+down linears "
                       f"({bytes_call / 1e6:.1f} MB packed) x {len(times)} forward calls, median; scaled by bytes to the "
                       f"{shape.decode_bytes_per_token(K) / 1e9:.3f} GB/token model"}
 
@@ -247,12 +249,11 @@ def main():
     graph = capture()
     if ipc_on:
         # a peer that never arrived leaves the error word set (bounded spins): then every rank drops to RCCL and captures again
-        err = torch.tensor([float(backend.ipc.error())], dtype=torch.float64, device=dev)
-        backend.all_reduce_max(err)
-        if float(err.item()) != 0.0:
+        # (collective: error words + epoch lockstep; on failure every rank barriers, unmaps and frees together -- tp.poll_ipc_allreduce)
+        if not backend.poll_ipc_allreduce():
             if rank == 0:
-                print("bench.py: IPC all-reduce reported a timed-out peer; falling back to RCCL all-reduce", file=sys.stderr)
-            backend.ipc.close(); backend.ipc = None; ipc_on = False
+                print("bench.py: IPC all-reduce reported a timed-out peer / epoch mismatch; falling back to RCCL all-reduce", file=sys.stderr)
+            ipc_on = False
             graph = capture()
     def step():
         if graph is not None:
@@ -276,6 +277,12 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     tok_s = args.batch * args.steps / elapsed
     assert torch.isfinite(model.logits.float()).all(), "non-finite logits"
+    ipc_fell_back_after_timing = False
+    if ipc_on and not backend.poll_ipc_allreduce():
+        # a timed-out push poisons its elements with NaN (caught by the assert above when it reaches the logits); reaching this line means the
+        # error word / epochs disagree without visible damage: report it, the timed region ran on the IPC path
+        ipc_on = False; ipc_fell_back_after_timing = True
+        graph = capture()
     # run-to-run spread: two more blocks of K steps, timed the same way (the contract's `value` is the first block above)
     repeat_ms = [round(ms_per_step, 4)]
     for _ in range(2):
@@ -304,7 +311,16 @@ def main():
         yb = torch.randn((args.batch, shape.hidden), device=dev)
         rb = torch.zeros((args.batch, shape.hidden), dtype=torch.half, device=dev)
         sb = torch.zeros((args.batch, shape.hidden // 128), device=dev)
+        ipc_requested = os.environ.get("EXL3_HIP_TP_ALLREDUCE", "ipc") == "ipc"
+        # per-rank weight bytes streamed per token (the rank's column / row shards + its lm_head shard): gathered so the line shows every rank's share
+        my_bytes = torch.tensor([float(sum((k * n * args.bits // 8 + 2 * (k + n)) * cnt for (k, n, cnt) in model.gemv_launches_per_step()))],
+                                dtype=torch.float64, device=dev)
+        all_bytes = [torch.zeros_like(my_bytes) for _ in range(world)]
+        torch.distributed.all_gather(all_bytes, my_bytes)
         allreduce = {"message_bytes": args.batch * shape.hidden * 4, "per_step": 2 * model.n_layers,
+                     "ipc_requested": ipc_requested, "ipc_enabled": bool(ipc_on), "ipc_fell_back": bool(ipc_requested and not ipc_on),
+                     "ipc_fell_back_after_timing": ipc_fell_back_after_timing,
+                     "bytes_per_token_per_rank": [int(b.item()) for b in all_bytes],
                      "path": "ipc one-shot push + fused residual add (exl3_allreduce.hip)" if ipc_on else "collective library all_reduce + glue_resid"}
         if ipc_on:
             allreduce["ipc_us"] = time_calls(lambda: backend.ipc.reduce(yb, resid=rb, ss_part=sb, m=args.batch))
@@ -364,42 +380,74 @@ def main():
         avg_us = total_us / launches
         bytes_per_launch = bytes_step / launches_step
         achieved = bytes_per_launch / avg_us / 1e3                            # GB/s
-        traffic = None
+        # roofline.traffic is NOT measured in this run (a --pmc pass re-runs the step under the profiler: too heavy for the driver line): it is
+        # the per-launch FETCH_SIZE of the last committed PMC pass (tools/final_profiles.sh -> profiles/traffic.json), and says so
+        traffic = None; traffic_src = None; kernel_only = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("fetch_bytes_per_launch")
+                tj = json.load(open(tf))
+                traffic = tj.get("fetch_bytes_per_launch")
+                traffic_src = ("NOT measured in this run: per-launch FETCH_SIZE of an earlier rocprofv3 --pmc pass over the same command, "
+                               f"profiles/traffic.json (collected {tj.get('collected', 'round 2')}, {tj.get('launches_sampled')} launches)")
+                ko = tj.get("kernel_only")
+                if ko and world == 1:
+                    # rocprofv3 --kernel-trace durations of the same launches (no graph-node gaps): builder-kept, from the profiles/ CSV named
+                    kernel_only = dict(ko)
+                    kernel_only["frac"] = round(bytes_step / launches_step / (ko["avg_launch_us"] * 1e3) / HBM_PEAK_GBPS, 4)
+                    kernel_only["note"] = "NOT measured in this run: average kernel duration of the step's GEMV launches in the committed rocprofv3 stats CSV"
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "exl3_gemv2_kernel (fused trellis decode + Hadamard + MFMA GEMV), all launches of a decode step",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": traffic, "avg_launch_us": round(avg_us, 2), "bytes_per_launch": int(bytes_per_launch),
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel_only": kernel_only,
+                    "avg_launch_us": round(avg_us, 2), "bytes_per_launch": int(bytes_per_launch),
                     "launches_per_step": launches_step,
                     "note": "HIP events around hipGraph replays of the step's GEMV launches (all layers, cold weights); includes inter-node gaps"
                             + ("" if fused else " and the split-k reduce launch") + "; compare profiles/ for rocprofv3 kernel-only durations"}
 
-    # ---- prefill leg (single GPU): one chunk through the same linears
+    # ---- prefill leg: one chunk through the same linears.  N > 1: every rank runs its column / row shards of the chunk and the (tokens, hidden)
+    # partial sums of o_proj / down_proj go through the collective library (RCCL ring: bandwidth matters at 4096 x hidden; reference
+    # model/model_tp_backend.py:119-126, method eval/perf.py:36-56); barrier + synchronize on both sides, MAX over ranks like the decode leg
     prefill = None
-    if world == 1 and not args.no_prefill:
+    if not args.no_prefill and not is_moe:
         toks = args.prefill_tokens
-        model.prefill_chunk(toks)                       # warm-up (hipBLASLt heuristics, allocator)
-        torch.cuda.synchronize()
+        model.prefill_chunk(toks)                       # warm-up (GEMM autotune, allocator)
+        torch.cuda.synchronize(); backend.fwd_barrier()
         t0 = time.perf_counter()
         reps = 2
         for _ in range(reps):
             model.prefill_chunk(toks)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
-        flops = shape.prefill_flops_per_token() * toks * (model.n_layers / shape.layers)
-        prefill = {"metric": "prefill tok/s", "value": round(toks / dt, 1), "unit": "tok/s", "chunk_tokens": toks,
+        torch.cuda.synchronize(); backend.fwd_barrier()
+        dtt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        backend.all_reduce_max(dtt)
+        dt = float(dtt.item())
+        flops = shape.prefill_flops_per_token() * toks * (model.n_layers / shape.layers)      # whole job (all ranks)
+        peak_all = MFMA_PEAK_TFLOPS * world
+        prefill = {"metric": "prefill tok/s", "value": round(toks / dt, 1), "unit": "tok/s", "chunk_tokens": toks, "n_gpus": world,
                    "ms_per_chunk": round(dt * 1e3, 2),
-                   "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(flops / dt / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                                "note": "linears' 2*k*n flops over the whole chunk time (includes reconstruct_had, norms, rope, kv-quant)"}}
+                   "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 1), "peak": peak_all, "unit": "TFLOP/s",
+                                "frac": round(flops / dt / 1e12 / peak_all, 4),
+                                "note": "linears' 2*k*n flops (whole job) over the whole chunk time (includes reconstruct_had, norms, rope, kv-quant"
+                                        + (", the o_proj / down_proj all-reduces" if world > 1 else "") + "); peak = dense fp16 MFMA x n_gpus"}}
+        if world > 1:
+            # the chunk's exchange step alone: 2 all-reduces per layer of the (tokens, hidden) partial sums, in the dtype the TP branch reduces
+            msg = torch.zeros((toks, shape.hidden), dtype=model.prefill_allreduce_dtype(), device=dev)
+            backend.all_reduce(msg); torch.cuda.synchronize(); backend.fwd_barrier()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                backend.all_reduce(msg)
+            e1.record(); torch.cuda.synchronize()
+            tms = torch.tensor([e0.elapsed_time(e1) / 8], dtype=torch.float64, device=dev)
+            backend.all_reduce_max(tms)
+            prefill["allreduce"] = {"message_bytes": msg.numel() * msg.element_size(), "per_chunk": 2 * model.n_layers, "ms_each": round(float(tms.item()), 4),
+                                    "prefill_ms": round(float(tms.item()) * 2 * model.n_layers, 3), "path": "collective library (RCCL) all_reduce",
+                                    "note": "back-to-back, not overlapped with compute in the chunk"}
 
         # the same chunk with the attention core in the timed region (append to the quantized cache, expand the pages, causal attention over them):
         # reported beside the headline, which follows BASELINE.json's linears-only shapes (science/qgemm_benchmark.py)
-        if not args.attention:
+        if not args.attention and world == 1:
             model.prefill_attention = True
             model.prefill_chunk(toks); torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -416,21 +464,22 @@ def main():
 
         # MI355X option: reconstructed fp16 W kept resident across chunks (LinearEXL3.cache_reconstructed; 0.5 GB per 8B layer).
         # Reported separately: the chunk above reconstructs every matrix per forward exactly like the reference.
-        from exllamav3_amd.linear import LinearEXL3
-        LinearEXL3.cache_reconstructed = True
-        model.prefill_chunk(toks); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            model.prefill_chunk(toks)
-        torch.cuda.synchronize()
-        dtc = (time.perf_counter() - t0) / reps
-        LinearEXL3.cache_reconstructed = False
-        for L in model.layers:
-            for lin in L.values():
-                if hasattr(lin, "_w_cache"): del lin._w_cache
-        prefill["resident_w_option"] = {"value": round(toks / dtc, 1), "unit": "tok/s", "ms_per_chunk": round(dtc * 1e3, 2),
-                                        "tflops": round(flops / dtc / 1e12, 1),
-                                        "note": "later chunks with the reconstructed fp16 weights left resident in HBM (not the reference's per-forward reconstruct)"}
+        if world == 1:
+            from exllamav3_amd.linear import LinearEXL3
+            LinearEXL3.cache_reconstructed = True
+            model.prefill_chunk(toks); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                model.prefill_chunk(toks)
+            torch.cuda.synchronize()
+            dtc = (time.perf_counter() - t0) / reps
+            LinearEXL3.cache_reconstructed = False
+            for L in model.layers:
+                for lin in L.values():
+                    if hasattr(lin, "_w_cache"): del lin._w_cache
+            prefill["resident_w_option"] = {"value": round(toks / dtc, 1), "unit": "tok/s", "ms_per_chunk": round(dtc * 1e3, 2),
+                                            "tflops": round(flops / dtc / 1e12, 1),
+                                            "note": "later chunks with the reconstructed fp16 weights left resident in HBM (not the reference's per-forward reconstruct)"}
 
     # ---- the other BASELINE.json configs that fit one GPU, same process, same timing (hipGraph replay, K steps after W warm-ups)
     extra = None
@@ -465,6 +514,12 @@ def main():
         model.with_attention = True
         extra["llama-3.1-8b_bs1_with_attention_ctx1000"] = timed_decode(model, model.decode_step_fused, 1)
         model.with_attention = False
+        # bs 1 with the EXACT GEMV variant (MFMA operands = the reference's fp16-rounded weights bit for bit; the headline runs the default variant,
+        # unrounded lo + hi / raw byte sums, inside the same 1e-2 bound)
+        if args.variant != 0:
+            ext.set_gemv_variant(0)
+            extra["llama-3.1-8b_bs1_gemv_variant0_exact"] = timed_decode(model, model.decode_step_fused, 1)
+            ext.set_gemv_variant(args.variant)
         # config 2: Llama-3.2-1B, bs 1
         m1 = SyntheticEXL3Llama(SHAPES["llama-3.2-1b"], K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits)
         m1.alloc_state(1)

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("EXL3_HIP_LIB") or os.path.join(_HERE, "libexl3_hip.so
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "exl3_hip.h")
 
 _lib = None
+ABI_VERSION = 3            # include/exl3_hip.h EXL3_ABI_VERSION
 
 
 def declared_symbols() -> list[str]:
@@ -43,8 +44,8 @@ def lib() -> ctypes.CDLL:
         _lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         _lib.exl3_last_error.restype = ctypes.c_char_p
         ver = _lib.exl3_abi_version()
-        if ver != 1:
-            raise RuntimeError(f"exllamav3_amd: ABI version mismatch ({ver})")
+        if ver != ABI_VERSION:
+            raise RuntimeError(f"exllamav3_amd: ABI version mismatch (library {ver}, binding {ABI_VERSION}): rebuild with `python __graft_entry__.py`")
         _declare(_lib)
     return _lib
 
@@ -118,6 +119,7 @@ def _declare(l):
     sig("exl3_ar_open_peer", vp, i32, vp)
     sig("exl3_ar_destroy", vp)
     sig("exl3_ar_error", vp, vp)
+    sig("exl3_ar_epoch", vp, ctypes.POINTER(ctypes.c_uint32), vp)
     sig("exl3_ar_reduce", vp, vp, vp, vp, vp, i32, i32, vp)
     sig("exl3_ar_reduce_slabs", vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp)
     PP = ctypes.POINTER(vp)

@@ -12,7 +12,8 @@
 // device memory (the kernel increments them itself, so a captured hipGraph replays correctly); two slot sets alternate by epoch parity: a rank can
 // only be one call ahead of a peer (it needs the peer's push of call n+1, which the peer issues after it finished reading call n).
 //
-// Every spin is bounded: after EXL3_AR_SPIN_LIMIT polls the kernel raises the error word and carries on with what it has (never hangs the GPU).
+// Every spin is bounded: after EXL3_AR_SPIN_LIMIT polls the kernel raises the error word and writes NaN for the elements it could not complete (never
+// hangs the GPU, never lets a stale or partial sum through); the host polls the word collectively (TPBackendRCCL.poll_ipc_allreduce).
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
 #include "exl3_glue_device.cuh"
@@ -21,6 +22,7 @@
 
 #define EXL3_AR_MAX_RANKS 8
 #define EXL3_AR_SPIN_LIMIT (1 << 22)
+#define EXL3_AR_MAX_WGS 512        // launch bound: the grid must be co-resident (every workgroup waits for its peers' twin)
 
 struct ArGranule { float v; uint32_t tag; };
 
@@ -128,7 +130,15 @@ void ar_push_reduce_kernel(ArArgs a)
             sum.x += v[0]; sum.y += v[1]; sum.z += v[2]; sum.w += v[3];
         }
     }
-    if (timeout) __hip_atomic_store(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (timeout)
+    {
+        // a peer did not deliver inside the spin bound: raise the error word AND poison the result, so the failure shows up downstream (NaN
+        // residual / logits) instead of stale or partial sums silently entering the residual stream; TPBackendRCCL.poll_ipc_allreduce reads the
+        // word collectively and moves every rank back to the collective library
+        __hip_atomic_store(hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float qnan = __builtin_nanf("");
+        sum = float4_t{ qnan, qnan, qnan, qnan };
+    }
     // 3. consumers
     if (a.y_out && act) *((float4_t*) (a.y_out + e0)) = sum;
     if (a.resid)
@@ -216,6 +226,16 @@ extern "C" int exl3_ar_destroy(void* ctx)
     return EXL3_OK;
 }
 
+// epoch counter of this rank's buffer (= number of completed reductions): ranks must stay in lockstep, TPBackendRCCL compares them collectively
+extern "C" int exl3_ar_epoch(void* ctx, uint32_t* epoch_out, void* stream)
+{
+    ArCtx* c = (ArCtx*) ctx;
+    EXL3_CHECK_ARG(c && epoch_out, "ar_epoch: null pointer");
+    EXL3_CHECK_HIP(hipMemcpyAsync(epoch_out, c->own, 4, hipMemcpyDeviceToHost, (hipStream_t) stream), "ar_epoch");
+    EXL3_CHECK_HIP(hipStreamSynchronize((hipStream_t) stream), "ar_epoch");
+    return EXL3_OK;
+}
+
 // error word (1 = a spin timed out since the last call of this function); resets it
 extern "C" int exl3_ar_error(void* ctx, void* stream)
 {
@@ -250,6 +270,9 @@ extern "C" int exl3_ar_reduce_slabs(void* ctx, const float* y, const float* slab
     a.slabs = slabs; a.S = S; a.svh = (const half_t*) svh;
     a.y = y; a.y_out = y_out; a.resid = (half_t*) resid; a.ss_part = ss_part; a.m = m; a.hidden = hidden;
     const int tasks = m * (hidden / 128);
+    // every workgroup spin-waits on its peers' matching workgroups, so the whole grid has to be co-resident on every rank whatever the dispatch
+    // order: at most ~2 workgroups per CU (decode messages are 32..512 tasks; prefill-sized messages belong to the collective library)
+    EXL3_CHECK_ARG(tasks <= 8 * EXL3_AR_MAX_WGS, "ar_reduce: m * hidden too large for the one-shot push (use the collective library)");
     ar_push_reduce_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>(a);
     return exl3_check_launch("ar_reduce");
 }

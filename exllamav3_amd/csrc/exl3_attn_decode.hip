@@ -479,7 +479,9 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
         const int capw = (head_dim == 128 ? 256 : 128);
         // about two workgroups per CU: more, shorter splits cost more in the merge than they return (16 000 tokens: 380 tok/s at 512, 337 at 2048)
         static const int wg_cap = [] { const char* e = getenv("EXL3_HIP_ATTN_WIDE_WGS"); return e ? atoi(e) : 512; }();
-        while (ns > capw || (int64_t) ns * bsz * blocks > wg_cap) { st_tok += 64; ns = (max_len + st_tok - 1) / st_tok; }
+        // (ns bottoms out at 1: with bsz * blocks > wg_cap alone the bound cannot be met and the loop must stop there -- the ns >= 2 test
+        // below then hands such batches to the half-wave-per-token kernel)
+        while (ns > 1 && (ns > capw || (int64_t) ns * bsz * blocks > wg_cap)) { st_tok += 64; ns = (max_len + st_tok - 1) / st_tok; }
         if (ns >= 2 && workspace_floats >= (int64_t) bsz * blocks * gq * ns * 132)
         {
             a.nsplit = ns; a.split_tokens = st_tok;

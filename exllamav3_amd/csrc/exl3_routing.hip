@@ -70,24 +70,35 @@ void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restr
         // 8 gate rows per thread in flight at a time (one workgroup reads the whole gate matrix: 64 KB at E = 8; with one load per loop trip
         // the kernel was a chain of 16 memory round trips, 17.8 us)
         int h = tid / nch;
-        bool formed = false;
-        for (; h + 7 * rows_per_pass < H; h += 8 * rows_per_pass)
+        // NORM: the first batch of gate rows is requested by EVERY thread (row indices clamped: threads without a full first batch load valid
+        // rows they will not use), then form_xn() -- which contains the workgroup barriers -- runs at ONE call site that every thread reaches, with
+        // those loads in flight underneath.  (It used to sit inside the loop below, whose trip condition depends on tid: threads that skipped the
+        // loop met the barrier at a different site -- ADVICE round 2.)
+        half8_t g[8];
+        const bool first = h + 7 * rows_per_pass < H;
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) g[u] = *((const half8_t*) (gate + (size_t) min(h + u * rows_per_pass, H - 1) * E + ch * 8));
+        form_xn();
+        if (first)
         {
-            half8_t g[8]; half_t xs[8];
-            #pragma unroll
-            for (int u = 0; u < 8; ++u) g[u] = *((const half8_t*) (gate + (size_t) (h + u * rows_per_pass) * E + ch * 8));
-            if (!formed) { form_xn(); formed = true; }                        // NORM: the first batch of gate rows is in flight underneath
-            #pragma unroll
-            for (int u = 0; u < 8; ++u) xs[u] = xin(h + u * rows_per_pass);
-            #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (;;)
             {
-                const float xv = (float) xs[u];
+                half_t xs[8];
                 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(xv, (float) g[u][i], acc[i]);
+                for (int u = 0; u < 8; ++u) xs[u] = xin(h + u * rows_per_pass);
+                #pragma unroll
+                for (int u = 0; u < 8; ++u)
+                {
+                    const float xv = (float) xs[u];
+                    #pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = __builtin_fmaf(xv, (float) g[u][i], acc[i]);
+                }
+                h += 8 * rows_per_pass;
+                if (!(h + 7 * rows_per_pass < H)) break;
+                #pragma unroll
+                for (int u = 0; u < 8; ++u) g[u] = *((const half8_t*) (gate + (size_t) (h + u * rows_per_pass) * E + ch * 8));
             }
         }
-        if (!formed) form_xn();
         for (; h < H; h += rows_per_pass)
         {
             const half8_t g = *((const half8_t*) (gate + (size_t) h * E + ch * 8));

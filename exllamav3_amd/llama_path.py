@@ -768,6 +768,11 @@ class SyntheticEXL3Llama:
                      (s.hidden, 2 * self.inter_local), (self.inter_local, s.hidden)]
         return [(k, n, self.n_layers) for (k, n) in per_layer] + [(s.hidden, self.vocab_local, 1)]
 
+    def prefill_allreduce_dtype(self):
+        """dtype of the (tokens, hidden) partial sums a TP rank hands to the all-reduce in prefill_chunk (o / down are created with fp32 outputs:
+        architecture/llama.py:95,111)."""
+        return self.layers[0]["o"].default_out_dtype
+
     # ---- one prefill chunk -----------------------------------------------------------------------------
     def prefill_chunk(self, tokens: int):
         """All linears + norms + rope + KV-quant of a `tokens`-token chunk (bsz 1); attention core out of scope.

@@ -90,10 +90,53 @@ class TPBackendRCCL:
             except Exception:
                 ok = False
             if not agree(ok):
+                torch.cuda.synchronize(self.device)
+                dist.barrier()                                              # nobody is still pushing into a buffer that is about to go away
                 ipc.close()
+                dist.barrier()
                 return False
         self.ipc = ipc
         return True
+
+    def _agree(self, ok: bool) -> bool:
+        flag = torch.tensor([1.0 if ok else 0.0], device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return float(flag.item()) == 1.0
+
+    def poll_ipc_allreduce(self) -> bool:
+        """Collective health check of the IPC all-reduce, to be called by EVERY rank at the same point of the decode loop (bench.py: after warm-up
+        and after the timed region; a generation loop: every few dozen steps -- it synchronises the stream).  Reads this rank's error word (a bounded
+        spin gave up: the affected elements are NaN) and epoch counter, agrees over the process group, and if any rank saw a timeout or the epochs
+        are out of lockstep EVERY rank drops the path together: barrier (no peer is still pushing), unmap, free; later all_reduce_resid calls go
+        through the collective library.  Returns True while the IPC path is on.  A caller that captured hipGraphs with the IPC launches inside must
+        re-capture after a False."""
+        if self.ipc is None:
+            return False
+        ok = True
+        epoch = -1
+        try:
+            ok = self.ipc.error() == 0
+            epoch = self.ipc.epoch()
+        except Exception:
+            ok = False
+        ep = torch.tensor([float(epoch), -float(epoch)], dtype=torch.float64, device=self.device)
+        dist.all_reduce(ep, op=dist.ReduceOp.MAX)                            # max(epoch) and -min(epoch)
+        ok = ok and float(ep[0].item()) == -float(ep[1].item())
+        if self._agree(ok):
+            return True
+        self.disable_ipc_allreduce()
+        return False
+
+    def disable_ipc_allreduce(self):
+        """Collective: every rank stops using the IPC path.  The barrier comes first so that no peer is still pushing into a buffer that is about to be
+        unmapped or freed."""
+        if self.ipc is None:
+            return
+        torch.cuda.synchronize(self.device)
+        dist.barrier()
+        self.ipc.close()
+        self.ipc = None
+        dist.barrier()
 
     def all_reduce_resid(self, y: torch.Tensor, resid: torch.Tensor, ss_part: torch.Tensor, m: int):
         """resid (fp16) += sum over ranks of y (fp32 [m][hidden]); ss_part = per-block sums of squares of the new residual: the o_proj / down_proj
@@ -215,6 +258,12 @@ class IpcAllReduce:
         dev = resid.device if resid is not None else y_out.device
         _lib.check(self._lib.exl3_ar_reduce_slabs(self.ctx, None, slab, int(S), p(svh), p(y_out), p(resid), p(ss_part), int(m), hidden,
                                                   torch.cuda.current_stream(dev).cuda_stream))
+
+    def epoch(self) -> int:
+        from . import _lib
+        v = ctypes.c_uint32(0)
+        _lib.check(self._lib.exl3_ar_epoch(self.ctx, ctypes.byref(v), torch.cuda.current_stream(self.device).cuda_stream))
+        return int(v.value)
 
     def error(self) -> int:
         from . import _lib

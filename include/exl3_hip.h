@@ -41,7 +41,7 @@ extern "C" {
 #define EXL3_ERR_HIP  (-2)   /* HIP runtime error (reference: cuda_check, util.cuh:92-100)         */
 #define EXL3_ERR_INIT (-3)   /* per-device context missing while the stream is capturing           */
 
-#define EXL3_ABI_VERSION 1
+#define EXL3_ABI_VERSION 3   /* bumped whenever an exported symbol is removed or changes meaning (round 3: 3) */
 
 const char* exl3_last_error(void);
 int  exl3_abi_version(void);
@@ -403,11 +403,15 @@ int exl3_mgemm_indexed_act(const void* G, const void* U, const void* tbl_B, cons
  *        rank order (same bits on every rank).  y_out (optional) = the sum; resid (optional, fp16 [m][hidden]) += sum with the rounding of
  *        rms_norm_res_in (norm.cu:193-218); ss_part (optional) = per-128-block sums of squares of the new residual (exl3_glue_resid's output).
  *        Graph-capturable (epochs live in device memory).  Every rank must issue the same sequence of calls.
- *   exl3_ar_error(ctx, stream)  1 if a bounded spin gave up since the last query (a peer never arrived), else 0; synchronises the stream. */
+ *        m * hidden / 128 <= 4096 (the grid has to be co-resident on every rank: larger messages go to the collective library).
+ *   exl3_ar_error(ctx, stream)  1 if a bounded spin gave up since the last query (a peer never arrived), else 0; synchronises the stream.
+ *        The elements such a spin could not complete are written as NaN (y_out / resid / ss_part), never as partial sums.
+ *   exl3_ar_epoch(ctx, &epoch, stream)  number of reductions this rank's buffer has completed; ranks must agree (host-side lockstep check). */
 int exl3_ar_create(int world, int rank, int64_t max_elems, void** ctx_out, void* handle_out);
 int exl3_ar_open_peer(void* ctx, int peer_rank, const void* handle);
 int exl3_ar_destroy(void* ctx);
 int exl3_ar_error(void* ctx, void* stream);
+int exl3_ar_epoch(void* ctx, uint32_t* epoch_out, void* stream);
 int exl3_ar_reduce(void* ctx, const float* y, float* y_out, void* resid, float* ss_part, int m, int hidden, void* stream);
 /* exl3_ar_reduce whose local partial is given as the deferred split-k slabs of the row-sharded o_proj / down_proj launch
  * ([hidden/128][S][m][128] fp32 from exl3_gemv_ex*, EXL3_GEMV_OUT_DEFERRED) + that linear's svh instead of a dense tensor (y == NULL): the launch

@@ -36,10 +36,15 @@ def test_bench_two_ranks_control_flow(dev):
     env = dict(os.environ, EXL3_HIP_TP_BACKEND="gloo")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--layers", "2", "--steps", "2", "--warmup", "1",
-                        "--no-graph"], capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
+                        "--no-graph", "--prefill-tokens", "512"], capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     d = _line(r.stdout)
     assert KEYS <= set(d) and d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"] == "tp2" and d["cpu_baseline"] is None
     # the decode all-reduces ran through the IPC push (two processes mapping each other's buffers on the shared GPU) and were timed
     ar = d["allreduce"]
     assert ar["path"].startswith("ipc") and ar["ipc_us"] > 0 and ar["library_us"] > 0 and ar["per_step"] == 4
+    assert ar["ipc_enabled"] and not ar["ipc_fell_back"] and len(ar["bytes_per_token_per_rank"]) == 2
+    # the prefill leg runs under TP too (task 3): whole-job tok/s, the chunk's all-reduces priced separately
+    pf = d["prefill"]
+    assert pf["n_gpus"] == 2 and pf["value"] > 0 and pf["allreduce"]["per_chunk"] == 4 and pf["allreduce"]["prefill_ms"] > 0
+    assert pf["allreduce"]["message_bytes"] == 512 * 4096 * 4

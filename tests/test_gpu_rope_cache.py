@@ -245,6 +245,38 @@ def test_attn_decode_qcache_long_context_kernel(dev, hq, hkv, lens, max_len):
     assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
 
 
+@pytest.mark.timeout(120)
+def test_attn_decode_qcache_more_workgroups_than_the_wide_kernel_cap(dev):
+    """bsz * kv blocks above the matrix-pipe kernel's workgroup cap (512) with head_dim 128, 4-bit K / V and a length bound >= 128: the split
+    search of the wide route has to stop at one split (it used to spin forever on the host: ADVICE round 2) and the half-wave-per-token kernel
+    takes the batch."""
+    from exllamav3_amd import ext
+    hd, hq, hkv, kb, vb, page = 128, 16, 8, 4, 4, 256
+    rng = np.random.default_rng(77)
+    bsz = 70                                                                                  # 70 * 8 = 560 workgroups per split
+    lens = [int(x) for x in rng.integers(1, 200, bsz)]
+    max_len = 200
+    npages = bsz + 2
+    perm = rng.permutation(npages)[:bsz].reshape(bsz, 1).astype(np.int32)
+    G = hkv * hd // 32
+    k = (rng.standard_normal((bsz, page, hkv * hd)) * 1.5).astype(np.float16)
+    v = rng.standard_normal((bsz, page, hkv * hd)).astype(np.float16)
+    kq, ks = o.kv_quant(k, kb); vq, vs = o.kv_quant(v, vb)
+    kc = np.zeros((npages, page, G * kb), dtype=np.uint32); ksc = np.zeros((npages, page, G), dtype=np.float16)
+    vc = np.zeros((npages, page, G * vb), dtype=np.uint32); vsc = np.zeros((npages, page, G), dtype=np.float16)
+    for b in range(bsz):
+        kc[perm[b, 0]] = kq[b]; ksc[perm[b, 0]] = ks[b]; vc[perm[b, 0]] = vq[b]; vsc[perm[b, 0]] = vs[b]
+    q = rng.standard_normal((bsz, hq, hd)).astype(np.float16)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out = torch.full((bsz, hq, hd), float("nan"), dtype=torch.half, device=dev)
+    ext.attn_decode_qcache(T(q), out, T(kc.view(np.int32)), T(ksc), T(vc.view(np.int32)), T(vsc), T(perm), T(np.array(lens, dtype=np.int32)), max_len)
+    kd = o.kv_dequant(kq, ks, kb).reshape(bsz, -1, hkv, hd); vd = o.kv_dequant(vq, vs, vb).reshape(bsz, -1, hkv, hd)
+    ref = o.attn_decode_qcache(q, kd, vd, lens).astype(np.float32)
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
+
+
 @pytest.mark.parametrize("shape", [(1, 300, 32, 8, 128), (2, 17, 5, 3, 128), (1, 64, 40, 40, 128), (1, 16, 1, 0, 128)])
 def test_rope_neox_head_dim_128_prefill_kernel(dev, shape):
     """>= 16 tokens, NEOX, head_dim 128, no head norm: the 16-byte-per-lane kernel (8 lanes per head); scalar position, per-sequence
