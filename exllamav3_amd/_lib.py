@@ -161,5 +161,6 @@ def _declare(l):
     sig("exl3_glue_resid", vp, i32, vp, vp, vp, vp, vp, i32, i32, vp)
     sig("exl3_set_gemv_variant", i32)
     sig("exl3_set_gemv_max_waves", i32)
+    sig("exl3_set_gemv_gen4", i32)
     sig("exl3_set_gemm3_min_rows", i32)
     sig("exl3_set_gemv_defer_wg_per_cu", i32)

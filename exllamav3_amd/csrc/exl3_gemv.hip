@@ -163,6 +163,16 @@ extern "C" int exl3_set_gemv_defer_wg_per_cu(int v) { g_gemv_defer_wg_per_cu = v
 extern "C" int exl3_set_gemv_max_waves(int v) { g_gemv_nwv = v; return EXL3_OK; }
 
 
+// generation 4 (exl3_gemv4.kspec.hip) takes the 1..4-row launches it supports (plain / rotated / RMSNorm / silu-mul input, final or deferred
+// output, slices of at most 32 Hadamard blocks); 0 pins generation 2 (A/B runs, the bit-identity tests between generation-2 pipelines)
+static int g_gemv_gen4 = -1;
+static int gemv_gen4()
+{
+    if (g_gemv_gen4 < 0) { const char* e = getenv("EXL3_HIP_GEMV_GEN4"); g_gemv_gen4 = e ? (atoi(e) != 0) : 1; }
+    return g_gemv_gen4;
+}
+extern "C" int exl3_set_gemv_gen4(int v) { g_gemv_gen4 = v ? 1 : 0; return EXL3_OK; }
+
 static int gemv_variant()
 {
     if (g_gemv_variant < 0)
@@ -419,6 +429,41 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         else
         {
             const int ng = mp <= 4 ? 1 : (mp <= 8 ? 2 : 4);
+            const bool rot_pass = (pass_flags & GEMV_IN_ROTATED) != 0;
+            bool g4 = gemv_gen4() && ng == 1 && !tbl && !epi && cpw == 0 && !rsd && !(act_rs && act_rs->ss_new) && bps <= 32;
+            if (g4 && rot_pass && var == 1 && cb == 2)
+                for (int i = 0; i < count; ++i) if (!args.mat[i].xsum) g4 = false;      // the mul1 FAST variant needs the producer's block sums
+            if (g4)
+            {
+                const int mode = in_act ? 3 : (in_norm ? 2 : (rot_pass ? 0 : 1));
+                const int units4 = bps * 4;
+                int nwv4 = 8;
+                if (nwv4 > (bps > 4 ? bps : 4)) nwv4 = bps > 4 ? bps : 4;
+                if (deferred && nwv4 > 4 && bps <= 16) nwv4 = 4;                       // (generation 2's measured choices, below)
+                if (g_gemv_nwv < 0) nwv4 = -g_gemv_nwv < 8 ? -g_gemv_nwv : 8;
+                if (nwv4 > units4) nwv4 = units4;
+                if (g_gemv_nwv > 0 && nwv4 > g_gemv_nwv) nwv4 = g_gemv_nwv;
+                if (nwv4 < 1) nwv4 = 1;
+                const size_t lds4 = exl3_gemv4_lds_bytes(mode, nwv4, mp, bps);
+                EXL3_CHECK_ARG(grid.x / (unsigned) S <= 65535u, "exl3_gemm: too many column blocks for one launch");
+                grid = dim3((unsigned) S, grid.x / (unsigned) S);
+                for (int i = 1; i < GEMV_MAX_MATS; ++i) args.cbf[i - 1] = args.mat[i].cb_first;
+                args.nwv = nwv4;
+                args.magic_m = gemv_magic((uint32_t) mp); args.magic_nwv = gemv_magic((uint32_t) nwv4); args.magic_nhw = gemv_magic((uint32_t) (2 * nwv4));
+                switch (K)
+                {
+                    case 1: exl3_gemv4_launch_k1(cb, var, mode, nwv4, grid, lds4, st, args); break;
+                    case 2: exl3_gemv4_launch_k2(cb, var, mode, nwv4, grid, lds4, st, args); break;
+                    case 3: exl3_gemv4_launch_k3(cb, var, mode, nwv4, grid, lds4, st, args); break;
+                    case 4: exl3_gemv4_launch_k4(cb, var, mode, nwv4, grid, lds4, st, args); break;
+                    case 5: exl3_gemv4_launch_k5(cb, var, mode, nwv4, grid, lds4, st, args); break;
+                    case 6: exl3_gemv4_launch_k6(cb, var, mode, nwv4, grid, lds4, st, args); break;
+                    case 7: exl3_gemv4_launch_k7(cb, var, mode, nwv4, grid, lds4, st, args); break;
+                    case 8: exl3_gemv4_launch_k8(cb, var, mode, nwv4, grid, lds4, st, args); break;
+                }
+            }
+            else
+            {
             int nwv = 16 / ng;                                   // partial-sum LDS: nwv * 4*ng rows * 512 B <= 32 KB
             const int units = bps * (8 / G2_PF);                 // the waves split the slice's tile rows in units of G2_PF
             // measured on MI355X (tools/prof_tail.py, batch 1): one wave per Hadamard block of the slice, but at least 4 waves --
@@ -473,6 +518,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                 case 6: exl3_gemv2_launch_k6(cb, var, ng, nwv, grid, lds, st, args); break;
                 case 7: exl3_gemv2_launch_k7(cb, var, ng, nwv, grid, lds, st, args); break;
                 case 8: exl3_gemv2_launch_k8(cb, var, ng, nwv, grid, lds, st, args); break;
+            }
             }
         }
         int rc = exl3_check_launch("exl3_gemv");

@@ -1,0 +1,422 @@
+// EXL3 quantized GEMV for gfx950, kernel generation 4: 1..4 rows (decode at batch 1..4), "no per-wave prologue".
+//
+//   C = ((A * suh) H) @ dequant(B) H * svh (+ bias)        reference: quant/exl3_gemv_kernel.cuh:138-402 (semantics only)
+//
+// Why it exists (profiles/r03_gemv_valu_breakdown.json): at batch 1 a generation-2 wave streams only 2..4 work units (a unit =
+// 2 tile rows = 64 weights per lane = 235 VALU instructions), and every wave of every workgroup ran ~450 VALU instructions of prologue and
+// epilogue around them (activation-fragment tasks executed by all waves whether they own a task or not, a run-time division, RAW row sums
+// per wave, chunk bookkeeping, SGPR spills): 5.5 issued VALU per weight against 3.4 in the loop, in a kernel that is bound by VALU issue.
+// Generation 4 keeps generation 2's streaming loop (column pair per lane, compile-time bit windows, v_mfma_f32_4x4x4_16B_f16 A-broadcast)
+// and removes what surrounded it:
+//
+//   * The A operand of the 4x4x4 A-broadcast MFMA comes from lanes 4*abid .. 4*abid+3.  Generation 2 used abid 0..3 for rows 0..15 and fetched
+//     the fragment of the current tile row from LDS in every unit.  Here abid addresses ACTIVATION QUADS instead: lane 4g+i of ONE VGPR pair
+//     holds the 4 halves of (tile row g>>2, quad g&3) for row i, so a single 8-byte-per-lane read (one ds_read_b64, lane-linear: 512
+//     contiguous bytes, conflict-free) covers 4 tile rows x 4 rows of activations, and the 32 MFMAs of those 4 tile rows pick their quad
+//     with the immediate abid = 0..15.  No LDS traffic in the unit, no per-row fragment address.
+//   * Pre-rotated input (GEMV_IN_ROTATED, the producer left fp16 had(x * suh) and per-block sums): the wave loads its quads straight from
+//     global memory into that register layout -- no LDS, no workgroup barrier before streaming, no preparation code at all.
+//   * Raw / RMSNorm input: the (block, row) Hadamard tasks are executed only by the waves that own one (m = 1, 4 blocks: 2 of 4 waves),
+//     the others go straight to the barrier with their weight rows in flight.
+//   * mul1 FAST variant: the affine map k_inv * acc + k_bias * sum(x) is applied once per workgroup by the half-wave that reduces the
+//     waves' partials (block sums from the producer / the task), not per wave from per-tile-row sums.
+//   * No chunks (slice <= 32 Hadamard blocks), no division, no tables, no tail epilogues, no wave-per-column-block layout: those stay
+//     generation 2's (exl3_gemv2.kspec.hip), which remains the kernel for 5..16 rows, MoE tables and the opt-in pipelines.
+//
+// Grid = (k-slices S, column blocks); workgroup = nwv waves that split the slice's units into contiguous ranges; partial sums meet in
+// LDS; output = deferred slabs [colblock][S][m][128] fp32 (S > 1 or GEMV_OUT_DEFERRED) or the final rows (S == 1).
+#include "exl3_common.cuh"
+#include "exl3_api_internal.h"
+#include "exl3_gemv_args.h"
+#include "exl3_lane_decode.cuh"
+#include "exl3_glue_device.cuh"
+
+#include <type_traits>
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void g4_static_for(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); g4_static_for<I + 1, N>(f); }
+}
+
+#define G4_MODE_ROT  0      // GEMV_IN_ROTATED: mat[i].xh (+ xsum for the mul1 FAST variant)
+#define G4_MODE_RAWX 1      // raw x: x * suh -> 128-point Hadamard in the task
+#define G4_MODE_NORM 2      // GEMV_IN_NORM: RMSNorm of the residual stream, then as RAWX
+#define G4_MODE_ACT  3      // GEMV_IN_ACT: silu(g) * u finished from the producer's gate / up slabs, then as RAWX
+
+constexpr int g4_waves_per_eu(int K, int CB, int MODE)
+{
+    if (MODE == G4_MODE_ACT) return 4;
+    if (K >= 5) return 6;
+    return (MODE == G4_MODE_ROT && CB == EXL3_CB_MUL1) ? 8 : 7;
+}
+
+// One work unit = 2 tile rows of the wave's column block.  HALF selects which half of the 4-tile-row activation group the unit is (abid 0..7 or 8..15).
+template <int K, int CB, int VAR, int HALF>
+__device__ __forceinline__ void g4_unit(LaneWords<K> (&ring)[2], const uint32_t* __restrict__ refill, size_t row_stride, int lane,
+                                        half4_t ag0, half4_t ag1, float4_t& acc_c, float4_t& acc_d)
+{
+    constexpr bool SPLIT = (VAR == 1) && (CB != EXL3_CB_MUL1);
+    g4_static_for<0, 2>([&] (auto uc)
+    {
+        constexpr int u = decltype(uc)::value;
+        uint32_t Wx[K + 1];
+        #pragma unroll
+        for (int i = 0; i < K; ++i) Wx[i + 1] = ring[u].w[i];
+        // carry-in = last word of the previous lane of the 8-lane tile group (lane c = 0 wraps to c = 7: the tile stream is circular): two DPP row
+        // rotates + a select, register file only (exl3_gemv2.kspec.hip)
+        {
+            const uint32_t wl = ring[u].w[K - 1];
+            const uint32_t r1 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x121, 0xf, 0xf, true);
+            const uint32_t r9 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x129, 0xf, 0xf, true);
+            Wx[0] = (lane & 7) ? r1 : r9;
+        }
+        load_lane_words<K>(ring[u], refill + (size_t) u * row_stride);           // refill the slot with the next unit's row
+        g4_static_for<0, 4>([&] (auto qc)
+        {
+            constexpr int q = decltype(qc)::value;
+            constexpr int ABID = 8 * HALF + 4 * u + q;
+            half4_t bc[2], bd[2];
+            decode_quad<K, CB, VAR, 8 * q>(Wx, bc);                               // weights 8q..8q+3 -> column c
+            decode_quad<K, CB, VAR, 8 * q + 4>(Wx, bd);                           // 8q+4..8q+7 -> column c + 8
+            acc_c = __builtin_amdgcn_mfma_f32_4x4x4f16(ag0, bc[0], acc_c, 4, ABID, 0);
+            acc_d = __builtin_amdgcn_mfma_f32_4x4x4f16(ag0, bd[0], acc_d, 4, ABID, 0);
+            if constexpr (SPLIT)
+            {
+                acc_c = __builtin_amdgcn_mfma_f32_4x4x4f16(ag1, bc[1], acc_c, 4, ABID, 0);
+                acc_d = __builtin_amdgcn_mfma_f32_4x4x4f16(ag1, bd[1], acc_d, 4, ABID, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);                                    // 8 weights in flight at a time (occupancy over ILP)
+        });
+    });
+}
+
+template <int K, int CB, int VAR, int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(g4_waves_per_eu(K, CB, MODE))))
+void exl3_gemv4_kernel(const GemvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool SPLIT = (VAR == 1) && (CB != EXL3_CB_MUL1);
+    constexpr bool RAW = (VAR == 1) && (CB == EXL3_CB_MUL1);
+    constexpr int NW = 8 * K;
+    constexpr bool IN_LDS = MODE != G4_MODE_ROT;
+
+    // every prologue scalar in one batch of scalar loads out of the first two lines of the argument block (exl3_gemv_args.h)
+    const int a_S = a.S, a_k = a.k, a_kslice = a.kslice, a_flags = a.flags, a_nm = a.num_mats, nwv = a.nwv, m = a.m;
+    const int a_cbf[GEMV_MAX_MATS] = { 0, a.cbf[0], a.cbf[1], a.cbf[2] };
+    const uint32_t mg_m = a.magic_m, mg_nwv = a.magic_nwv;
+    const half_t* const a_A = a.A;
+    const half_t* const a_norm_w = a.norm_w;
+    const float* const a_ss_part = a.ss_part;
+    const float a_eps = a.eps;
+    const float* const a_act_g = a.act_g; const float* const a_act_u = a.act_u;
+    const half_t* const a_act_svh_g = a.act_svh_g; const half_t* const a_act_svh_u = a.act_svh_u;
+    const int a_act_S = a.act_S;
+    if constexpr (MODE == G4_MODE_ACT) asm volatile("" :: "s"(a_act_g), "s"(a_act_S));
+    {
+        const void* t0 = a.mat[0].B; const void* t1 = a.mat[1].B; const void* t2 = a.mat[2].B; const void* t3 = a.mat[3].B; const void* t4 = a.mat[3].xsum;
+        asm volatile("" :: "s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4));     // the workgroup's matrix record (a dependent load) then hits the scalar cache
+    }
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int s = blockIdx.x, cbg = blockIdx.y;
+    int mi = 0;
+    #pragma unroll
+    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a_nm && cbg >= a_cbf[i]) mi = i;
+    const uint32_t* __restrict__ Bm = a.mat[mi].B;
+    const half_t* __restrict__ suh = a.mat[mi].suh;
+    const int n = a.mat[mi].n, cbl = cbg - a.mat[mi].cb_first, ws_off = a.mat[mi].ws_offset;
+    const int tiles_n = n >> 4;
+    const int k0s = s * a_kslice;
+    const int k1s = min(k0s + a_kslice, a_k);
+    const int nb = (k1s - k0s) >> 7;                         // Hadamard blocks of the slice (<= 32, host-checked)
+    const int units = nb * 4;
+    const int ubase = gemv_udiv(units * wave, mg_nwv);
+    const int nun = gemv_udiv(units * (wave + 1), mg_nwv) - ubase;     // this wave's units: [ubase, ubase + nun)
+    const int l32 = lane & 31, hwid = tid >> 5, nhw = nwv * 2;
+
+    // LDS: activation quads [tile row][quad][row < m] x 8 bytes (+ one group of slack for the over-read of a partial last group) | block sums
+    // [nb][m] fp32 | partial sums [nwv][m][128] fp32, which REUSE the quad area after the streaming loop (barrier in between)
+    const int quad_bytes = IN_LDS ? (nb * 8 + 4) * 4 * m * 8 : 0;
+    const int part_bytes = nwv * m * 512;
+    char* quads = smem;
+    float* part = (float*) smem;
+    float* bsum = (float*) (smem + (((quad_bytes > part_bytes ? quad_bytes : part_bytes) + 15) & ~15));
+
+    // ---- streaming state
+    const int T = lane >> 3, c = lane & 7;
+    const size_t row_stride = (size_t) tiles_n * NW;
+    const uint32_t* __restrict__ strip = Bm + ((size_t) (k0s >> 4) * tiles_n + (size_t) cbl * 8) * NW + (size_t) lane * K;
+    const int last_unit = ubase + (nun > 0 ? nun - 1 : 0);
+
+    // ---- preparation tasks (raw / norm / act input): task t = (block t / m, row t % m), one per half-wave; only waves that own a task run them
+    struct PrepIn { half4_t xv, sv, wv; float ss; };
+    const int ntask = nb * m;
+    auto fetch = [&] (int it) -> PrepIn
+    {
+        PrepIn r; r.xv = half4_t{ 0, 0, 0, 0 }; r.sv = r.xv; r.wv = r.xv; r.ss = 0.0f;
+        const int t = min(it * nhw + hwid, ntask - 1);
+        const int blk = gemv_udiv(t, mg_m), row = t - blk * m;
+        const size_t kofs = (size_t) k0s + 128 * blk;
+        if constexpr (MODE == G4_MODE_RAWX || MODE == G4_MODE_NORM) r.xv = ((const half4_t*) (a_A + (size_t) row * a_k + kofs))[l32];
+        r.sv = ((const half4_t*) (suh + kofs))[l32];
+        if constexpr (MODE == G4_MODE_NORM)
+        {
+            r.wv = ((const half4_t*) (a_norm_w + kofs))[l32];
+            if (l32 < (a_k >> 7)) r.ss = a_ss_part[(size_t) row * (a_k >> 7) + l32];
+        }
+        return r;
+    };
+    const bool prep_wave = IN_LDS && 2 * wave < ntask;
+    PrepIn nx;
+    if constexpr (IN_LDS) { if (prep_wave) nx = fetch(0); }
+
+    // first weight rows: requested after the first task's (small, L2-resident) operands so that the task computes underneath the HBM latency
+    LaneWords<K> ring[2];
+    if (nun > 0)
+    {
+        #pragma unroll
+        for (int u = 0; u < 2; ++u) load_lane_words<K>(ring[u], strip + (size_t) (2 * ubase + u) * row_stride);
+    }
+
+    // ---- activation quads of this wave's first group
+    // lane 4g + i: tile row (group base + (g >> 2)), quad g & 3, row min(i, m - 1)
+    const int gq = lane >> 2, gi = min(lane & 3, m - 1);
+    half4_t agc0 = { 0, 0, 0, 0 }, agc1 = agc0;               // current group (agc1: the duplicated second pair of the SPLIT variants)
+    uint2_t agn = { 0u, 0u };                                 // next group, raw
+    const half_t* xh_lane = nullptr;
+    int quad_lane = 0;
+    const int tr_last = nb * 8 - 1;
+    auto load_group = [&] (int tr0) -> uint2_t                 // tr0: slice-local first tile row of the group
+    {
+        uint2_t r;
+        if constexpr (IN_LDS) r = *((const uint2_t*) (quads + (size_t) tr0 * 4 * m * 8 + quad_lane));
+        else
+        {
+            const int tr = min(tr0 + (gq >> 2), tr_last);
+            const uint32_t* p = (const uint32_t*) (xh_lane + 16 * tr);
+            r.x = p[0]; r.y = p[4];                           // halves {2q, 2q+1} and {2q+8, 2q+9} of the tile row
+        }
+        return r;
+    };
+    auto set_group = [&] (uint2_t raw)
+    {
+        if constexpr (SPLIT)
+        {
+            // weight = lo + hi fed as two k-slots against a duplicated activation: (x0, x0, x1, x1), (x2, x2, x3, x3)
+            agc0 = u2_as_half4(__builtin_amdgcn_perm(raw.x, raw.x, 0x01000100u), __builtin_amdgcn_perm(raw.x, raw.x, 0x03020302u));
+            agc1 = u2_as_half4(__builtin_amdgcn_perm(raw.y, raw.y, 0x01000100u), __builtin_amdgcn_perm(raw.y, raw.y, 0x03020302u));
+        }
+        else agc0 = u2_as_half4(raw.x, raw.y);
+    };
+    if constexpr (!IN_LDS)
+    {
+        xh_lane = a.mat[mi].xh + (size_t) gi * a_k + k0s + 2 * (gq & 3);
+        agn = load_group(2 * ubase);
+    }
+    else quad_lane = (gq * m + gi) * 8;
+
+    // mul1 FAST: sum of the slice's rotated activations per row, for the reducing half-waves (rows hwid < m); ROT: from the producer's block sums
+    float xs_pre = 0.0f;
+    if constexpr (RAW && !IN_LDS)
+    {
+        if (hwid < m)
+        {
+            const float* xsr = a.mat[mi].xsum + (size_t) hwid * (a_k >> 7) + (k0s >> 7);
+            for (int b0 = 0; b0 < nb; b0 += 32) if (b0 + l32 < nb) xs_pre += xsr[b0 + l32];
+        }
+    }
+
+    if constexpr (IN_LDS)
+    {
+        if (prep_wave)
+        {
+            for (int it = 0; it * nhw + 2 * wave < ntask; ++it)
+            {
+                const PrepIn cur = nx;
+                if ((it + 1) * nhw + 2 * wave < ntask) nx = fetch(it + 1);
+                const int t = it * nhw + hwid;
+                const bool act = t < ntask;
+                const int tc = min(t, ntask - 1);
+                const int blk = gemv_udiv(tc, mg_m), row = tc - blk * m;
+                half4_t xv = cur.xv;
+                if constexpr (MODE == G4_MODE_ACT)
+                {
+                    // a = fp16(silu(g) * u) of this (row, block): split-k reduce of the producer's gate / up slabs, output Hadamards, svh -- the
+                    // arithmetic of glue_act_kernel (same device functions, slice-order sums)
+                    const int blk_abs = (k0s >> 7) + blk;
+                    const SlabRef sg = { a_act_g, a_act_S }, su = { a_act_u, a_act_S };
+                    float4_t vg, vu;
+                    slab_sum2<4>(sg, su, blk_abs, row, m, l32, vg, vu);
+                    const half4_t svg = ((const half4_t*) (a_act_svh_g + blk_abs * 128))[l32];
+                    const half4_t svu = ((const half4_t*) (a_act_svh_u + blk_abs * 128))[l32];
+                    float g0, g1, g2, g3, u0, u1, u2, u3;
+                    out_had(vg, l32, g0, g1, g2, g3);
+                    out_had(vu, l32, u0, u1, u2, u3);
+                    const half4_t gh = half4_t{ f2h(g0), f2h(g1), f2h(g2), f2h(g3) } * svg;
+                    const half4_t uh = half4_t{ f2h(u0), f2h(u1), f2h(u2), f2h(u3) } * svu;
+                    auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
+                    xv = half4_t{ silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
+                }
+                if constexpr (MODE == G4_MODE_NORM)
+                {
+                    // x = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)): the row's mean square from the per-block sums a glue kernel left behind,
+                    // same arithmetic and summation order as generation 2 / glue_norm_kernel / rms_norm (norm.cu:20-120)
+                    const int nblk_k = a_k >> 7;
+                    float s2 = 0.0f;
+                    for (int b0 = 0; b0 < nblk_k; b0 += 32)
+                    {
+                        float v = cur.ss;
+                        if (b0 > 0) v = (b0 + l32 < nblk_k) ? a_ss_part[(size_t) row * nblk_k + b0 + l32] : 0.0f;
+                        #pragma unroll
+                        for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
+                        s2 += v;
+                    }
+                    const float r = __frsqrt_rn(s2 / (float) a_k + a_eps);
+                    xv = half4_t{ f2h((float) xv.x * (float) cur.wv.x * r), f2h((float) xv.y * (float) cur.wv.y * r),
+                                  f2h((float) xv.z * (float) cur.wv.z * r), f2h((float) xv.w * (float) cur.wv.w * r) };
+                }
+                xv = xv * cur.sv;
+                float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
+                had128_f32x4(h0, h1, h2, h3, l32);
+                const half2_t o01 = { f2h(h0 * HAD_R_SCALE_128), f2h(h1 * HAD_R_SCALE_128) };
+                const half2_t o23 = { f2h(h2 * HAD_R_SCALE_128), f2h(h3 * HAD_R_SCALE_128) };
+                if constexpr (RAW)
+                {
+                    float ts = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
+                    #pragma unroll
+                    for (int i = 1; i < 32; i <<= 1) ts += xor_lane(ts, i);
+                    if (act && l32 == 0) bsum[blk * m + row] = ts;
+                }
+                if (act)
+                {
+                    // elements 4*l32 .. +3 of the block: tile row l32 >> 2; offsets 4*(l32 & 3) .. +3 of the tile row = quads q0, q0 + 1, slot pair sp
+                    const int tr = blk * 8 + (l32 >> 2);
+                    const int q0 = 2 * (l32 & 1), sp = (l32 >> 1) & 1;
+                    char* base = quads + ((size_t) (tr * 4 + q0) * m + row) * 8 + sp * 4;
+                    *((half2_t*) base) = o01;
+                    *((half2_t*) (base + (size_t) m * 8)) = o23;
+                }
+            }
+        }
+        __syncthreads();
+        agn = load_group(2 * ubase);
+    }
+
+    float4_t acc_c = { 0.f, 0.f, 0.f, 0.f }, acc_d = acc_c;
+
+    // ---- streaming: groups of 2 units (4 tile rows share one activation register pair), then an odd last unit
+    const int ngrp = nun >> 1;
+    int unit = ubase;
+    for (int j = 0; j < ngrp; ++j)                              // plain counted loop (an early exit makes the compiler drain vmcnt every trip)
+    {
+        set_group(agn);
+        agn = load_group(2 * min(unit + 2, last_unit));         // next group (clamped: a harmless reload at the end)
+        g4_unit<K, CB, VAR, 0>(ring, strip + (size_t) (2 * min(unit + 1, last_unit)) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
+        g4_unit<K, CB, VAR, 1>(ring, strip + (size_t) (2 * min(unit + 2, last_unit)) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
+        unit += 2;
+    }
+    if (nun & 1)
+    {
+        set_group(agn);
+        g4_unit<K, CB, VAR, 0>(ring, strip + (size_t) (2 * last_unit) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
+    }
+
+    // ---- partial sums -> LDS (the area of the activation quads: every wave is past its last quad read after this barrier)
+    if constexpr (IN_LDS) __syncthreads();
+    {
+        float* pw = part + (size_t) wave * m * 128;
+        const int col = 16 * T + c;
+        #pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < m) { pw[i * 128 + col] = acc_c[i]; pw[i * 128 + col + 8] = acc_d[i]; }
+    }
+    __syncthreads();
+    if (hwid >= m) return;
+
+    // ---- half-wave `row`: sum of the waves' partials, the mul1 FAST affine map, then the slab line or the final output row
+    const int row = hwid, l = l32;
+    float4_t v = ((const float4_t*) (part + row * 128))[l];
+    for (int w = 1; w < nwv; ++w)
+    {
+        const float4_t t = ((const float4_t*) (part + ((size_t) w * m + row) * 128))[l];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if constexpr (RAW)
+    {
+        float xs = xs_pre;
+        if constexpr (IN_LDS) { for (int b0 = 0; b0 < nb; b0 += 32) if (b0 + l < nb) xs += bsum[(b0 + l) * m + row]; }
+        #pragma unroll
+        for (int i = 1; i < 32; i <<= 1) xs += xor_lane(xs, i);
+        const float kinv = (float) u16_as_half(0x1eeeu), kbias = (float) u16_as_half(0xc931u);
+        const float b = kbias * xs;
+        v.x = v.x * kinv + b; v.y = v.y * kinv + b; v.z = v.z * kinv + b; v.w = v.w * kinv + b;
+    }
+    if (a_S > 1 || (a_flags & GEMV_OUT_DEFERRED))
+    {
+        float* slab = a.workspace + ws_off + ((size_t) cbl * a_S + s) * (size_t) m * 128;
+        ((float4_t*) (slab + row * 128))[l] = v;
+        return;
+    }
+    float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
+    had128_f32x4(h0, h1, h2, h3, l);
+    h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
+    const half4_t sc = ((const half4_t*) (a.mat[mi].svh + cbl * 128))[l];
+    const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
+    const size_t off = ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
+    if (a.c_fp32)
+    {
+        float4_t o = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
+        if (bias) { const half4_t bv = ((const half4_t*) bias)[l]; o.x += (float) bv.x; o.y += (float) bv.y; o.z += (float) bv.z; o.w += (float) bv.w; }
+        *((float4_t*) ((float*) a.mat[mi].C + off)) = o;
+    }
+    else
+    {
+        half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
+        o = o * sc;
+        if (bias) o = o + ((const half4_t*) bias)[l];
+        *((half4_t*) ((half_t*) a.mat[mi].C + off)) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch (called from exl3_gemv.hip's dispatcher).  One translation unit per K: built with -DG2_K=1..8.
+// ------------------------------------------------------------------------------------------------
+#ifndef G2_K
+#error "compile with -DG2_K=<bits per weight>"
+#endif
+
+template <int CB>
+static void g4_launch_cb(int var, int mode, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+{
+    #define L(V, M) exl3_gemv4_kernel<G2_K, CB, V, M><<<grid, dim3(64 * nwv), lds, st>>>(args)
+    #define LV(M) { if (var == 0) L(0, M); else L(1, M); }
+    switch (mode)
+    {
+        case G4_MODE_ROT:  LV(G4_MODE_ROT)  break;
+        case G4_MODE_RAWX: LV(G4_MODE_RAWX) break;
+        case G4_MODE_NORM: LV(G4_MODE_NORM) break;
+        default:           LV(G4_MODE_ACT)  break;
+    }
+    #undef LV
+    #undef L
+}
+
+#define G4_CAT_(a, b) a##b
+#define G4_CAT(a, b) G4_CAT_(a, b)
+
+void G4_CAT(exl3_gemv4_launch_k, G2_K)(int cb, int var, int mode, int nwv, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+{
+    if (cb == 0) g4_launch_cb<0>(var, mode, nwv, grid, lds, st, args);
+    else if (cb == 1) g4_launch_cb<1>(var, mode, nwv, grid, lds, st, args);
+    else g4_launch_cb<2>(var, mode, nwv, grid, lds, st, args);
+}
+
+#if G2_K == 4
+size_t exl3_gemv4_lds_bytes(int mode, int nwv, int m, int blocks_per_slice)
+{
+    const size_t quad = mode == G4_MODE_ROT ? 0 : (size_t) (blocks_per_slice * 8 + 4) * 4 * m * 8;
+    const size_t part = (size_t) nwv * m * 512;
+    return (((quad > part ? quad : part) + 15) & ~(size_t) 15) + (size_t) blocks_per_slice * m * 4 + 16;
+}
+#endif

@@ -73,6 +73,11 @@ def set_gemv_max_waves(n: int):
     _lib.lib().exl3_set_gemv_max_waves(int(n))
 
 
+def set_gemv_gen4(on: bool):
+    """1..4-row launches: generation-4 kernel (default) or generation 2 (A/B runs, bit-identity tests between generation-2 pipelines)."""
+    _lib.lib().exl3_set_gemv_gen4(int(bool(on)))
+
+
 def set_tail_xcd_local(on: bool):
     """Opt in to the XCD-local tail hand-off of exl3_gemv_resid (default off: agent-scope hand-off, placement-independent).  Enabling probes the
     workgroup -> XCD mapping the mode relies on and raises RuntimeError (mode stays off) if the device does not dispatch block i to XCD i % 8."""

@@ -37,4 +37,5 @@ def _default_kernel_selection(request):
     if torch.cuda.is_available():
         from exllamav3_amd import ext
         ext.set_gemm3_min_rows(5)
+        ext.set_gemv_gen4(True)
     yield

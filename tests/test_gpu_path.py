@@ -186,8 +186,9 @@ def test_tail_epilogue_pipeline_is_bit_identical_to_glue_pipeline(dev, cb, bsz):
     from exllamav3_amd import ext
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
     ext.set_gemv_variant(1)
-    # the tail epilogues live in the generation-2 kernel: the glue side is pinned to it too (generation 3 sums k in a different order)
+    # the tail epilogues live in the generation-2 kernel: the glue side is pinned to it too (generations 3 / 4 group the partial sums differently)
     ext.set_gemm3_min_rows(0)
+    ext.set_gemv_gen4(False)
     shape = LlamaShape("tiny", 256, 512, 3, 4, 2, 128, 384)
     model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
     model.alloc_state(bsz, pos=1234)
@@ -218,6 +219,7 @@ def test_tail_epilogue_entry_points_raw_input_gptj_and_bits(dev, K):
     """exl3_gemv_qkv / _act / _norm with un-rotated inputs (A + suh), GPTJ rope, 8-bit K / 3-bit V cache, bias, xn_out, a_out:
     against deferred GEMV + glue kernels (bit-exact) for every bitrate."""
     from exllamav3_amd import ext
+    ext.set_gemv_gen4(False)                                # the tail entry points are generation-2 launches: bit-exactness needs the same kernel on the other side
     rng = np.random.default_rng(K)
     k, m, hq, hkv, inter = 512, 3, 3, 1, 384
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -837,6 +839,7 @@ def test_gemv_resid_tail_equals_gemv_plus_glue_resid(dev, k, n, m):
     L2 atomic), otherwise -- and with the switch off -- the agent-scope one; 30 repetitions on the same workspace catch stale reads."""
     from exllamav3_amd import ext
     ext.set_gemm3_min_rows(0)
+    ext.set_gemv_gen4(False)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rng = np.random.default_rng(k + n + m)
     tr, suh, svh = o.synth_linear(k, n, 4, seed=3, realistic=True)
