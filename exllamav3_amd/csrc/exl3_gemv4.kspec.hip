@@ -117,6 +117,15 @@ void exl3_gemv4_kernel(const GemvArgs a)
         const void* t0 = a.mat[0].B; const void* t1 = a.mat[1].B; const void* t2 = a.mat[2].B; const void* t3 = a.mat[3].B; const void* t4 = a.mat[3].xsum;
         asm volatile("" :: "s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4));     // the workgroup's matrix record (a dependent load) then hits the scalar cache
     }
+#ifdef G4_TIMING
+    // diagnostics build: wave 0 of every workgroup leaves 100 MHz timestamps of its phases in the workspace tail (48 MiB offset; tools/gemv_timeline.py)
+    uint64_t tstamp[6];
+    tstamp[0] = __builtin_amdgcn_s_memrealtime();
+    const uint64_t cyc0 = __builtin_amdgcn_s_memtime();
+    #define G4_T(i) tstamp[i] = __builtin_amdgcn_s_memrealtime()
+#else
+    #define G4_T(i)
+#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -179,6 +188,7 @@ void exl3_gemv4_kernel(const GemvArgs a)
         #pragma unroll
         for (int u = 0; u < 2; ++u) load_lane_words<K>(ring[u], strip + (size_t) (2 * ubase + u) * row_stride);
     }
+    G4_T(1);
 
     // ---- activation quads of this wave's first group
     // lane 4g + i: tile row (group base + (g >> 2)), quad g & 3, row min(i, m - 1)
@@ -305,6 +315,7 @@ void exl3_gemv4_kernel(const GemvArgs a)
     }
 
     float4_t acc_c = { 0.f, 0.f, 0.f, 0.f }, acc_d = acc_c;
+    G4_T(2);
 
     // ---- streaming: groups of 2 units (4 tile rows share one activation register pair), then an odd last unit
     const int ngrp = nun >> 1;
@@ -323,6 +334,7 @@ void exl3_gemv4_kernel(const GemvArgs a)
         g4_unit<K, CB, VAR, 0>(ring, strip + (size_t) (2 * last_unit) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
     }
 
+    G4_T(3);
     // ---- partial sums -> LDS (the area of the activation quads: every wave is past its last quad read after this barrier)
     if constexpr (IN_LDS) __syncthreads();
     {
@@ -332,51 +344,72 @@ void exl3_gemv4_kernel(const GemvArgs a)
         for (int i = 0; i < 4; ++i) if (i < m) { pw[i * 128 + col] = acc_c[i]; pw[i * 128 + col + 8] = acc_d[i]; }
     }
     __syncthreads();
-    if (hwid >= m) return;
+    G4_T(4);
 
-    // ---- half-wave `row`: sum of the waves' partials, the mul1 FAST affine map, then the slab line or the final output row
-    const int row = hwid, l = l32;
-    float4_t v = ((const float4_t*) (part + row * 128))[l];
-    for (int w = 1; w < nwv; ++w)
+    // ---- half-wave h takes rows h, h + nhw, ...: sum of the waves' partials, the mul1 FAST affine map, then the slab line or the final output row
+    const int l = l32;
+    for (int row = hwid; row < m; row += nhw)
     {
-        const float4_t t = ((const float4_t*) (part + ((size_t) w * m + row) * 128))[l];
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        float4_t v = ((const float4_t*) (part + row * 128))[l];
+        for (int w = 1; w < nwv; ++w)
+        {
+            const float4_t t = ((const float4_t*) (part + ((size_t) w * m + row) * 128))[l];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if constexpr (RAW)
+        {
+            float xs = 0.0f;
+            if constexpr (IN_LDS) { for (int b0 = 0; b0 < nb; b0 += 32) if (b0 + l < nb) xs += bsum[(b0 + l) * m + row]; }
+            else if (row == hwid) xs = xs_pre;                 // requested at kernel entry
+            else
+            {
+                // (one-wave workgroups with more than two rows only) the further rows' block sums are fetched here
+                const float* xsr = a.mat[mi].xsum + (size_t) row * (a_k >> 7) + (k0s >> 7);
+                for (int b0 = 0; b0 < nb; b0 += 32) if (b0 + l < nb) xs += xsr[b0 + l];
+            }
+            #pragma unroll
+            for (int i = 1; i < 32; i <<= 1) xs += xor_lane(xs, i);
+            const float kinv = (float) u16_as_half(0x1eeeu), kbias = (float) u16_as_half(0xc931u);
+            const float b = kbias * xs;
+            v.x = v.x * kinv + b; v.y = v.y * kinv + b; v.z = v.z * kinv + b; v.w = v.w * kinv + b;
+        }
+        if (a_S > 1 || (a_flags & GEMV_OUT_DEFERRED))
+        {
+            float* slab = a.workspace + ws_off + ((size_t) cbl * a_S + s) * (size_t) m * 128;
+            ((float4_t*) (slab + row * 128))[l] = v;
+            continue;
+        }
+        float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
+        had128_f32x4(h0, h1, h2, h3, l);
+        h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
+        const half4_t sc = ((const half4_t*) (a.mat[mi].svh + cbl * 128))[l];
+        const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
+        const size_t off = ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
+        if (a.c_fp32)
+        {
+            float4_t o = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
+            if (bias) { const half4_t bv = ((const half4_t*) bias)[l]; o.x += (float) bv.x; o.y += (float) bv.y; o.z += (float) bv.z; o.w += (float) bv.w; }
+            *((float4_t*) ((float*) a.mat[mi].C + off)) = o;
+        }
+        else
+        {
+            half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
+            o = o * sc;
+            if (bias) o = o + ((const half4_t*) bias)[l];
+            *((half4_t*) ((half_t*) a.mat[mi].C + off)) = o;
+        }
     }
-    if constexpr (RAW)
+#ifdef G4_TIMING
+    if (tid == 0)
     {
-        float xs = xs_pre;
-        if constexpr (IN_LDS) { for (int b0 = 0; b0 < nb; b0 += 32) if (b0 + l < nb) xs += bsum[(b0 + l) * m + row]; }
-        #pragma unroll
-        for (int i = 1; i < 32; i <<= 1) xs += xor_lane(xs, i);
-        const float kinv = (float) u16_as_half(0x1eeeu), kbias = (float) u16_as_half(0xc931u);
-        const float b = kbias * xs;
-        v.x = v.x * kinv + b; v.y = v.y * kinv + b; v.z = v.z * kinv + b; v.w = v.w * kinv + b;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tstamp[5] = __builtin_amdgcn_s_memrealtime();
+        uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
+        uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        dbg[6] = xcc; dbg[7] = __builtin_amdgcn_s_memtime() - cyc0;
     }
-    if (a_S > 1 || (a_flags & GEMV_OUT_DEFERRED))
-    {
-        float* slab = a.workspace + ws_off + ((size_t) cbl * a_S + s) * (size_t) m * 128;
-        ((float4_t*) (slab + row * 128))[l] = v;
-        return;
-    }
-    float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
-    had128_f32x4(h0, h1, h2, h3, l);
-    h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
-    const half4_t sc = ((const half4_t*) (a.mat[mi].svh + cbl * 128))[l];
-    const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
-    const size_t off = ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
-    if (a.c_fp32)
-    {
-        float4_t o = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
-        if (bias) { const half4_t bv = ((const half4_t*) bias)[l]; o.x += (float) bv.x; o.y += (float) bv.y; o.z += (float) bv.z; o.w += (float) bv.w; }
-        *((float4_t*) ((float*) a.mat[mi].C + off)) = o;
-    }
-    else
-    {
-        half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
-        o = o * sc;
-        if (bias) o = o + ((const half4_t*) bias)[l];
-        *((half4_t*) ((half_t*) a.mat[mi].C + off)) = o;
-    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

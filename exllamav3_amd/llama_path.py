@@ -387,13 +387,13 @@ class SyntheticEXL3Llama:
         tab = self._qkv_tab()
         ext.glue_resid(None, 0, None, None, x, ss_c, bsz)
         L0 = self.layers[0]
-        ext.glue_rotate(x, ss_c, L0["norm1"], self.eps, [L0["q"].suh, L0["k"].suh, L0["v"].suh], self.xh3, bsz)
+        ext.glue_rotate(x, ss_c, L0["norm1"], self.eps, [L0["q"].suh, L0["k"].suh, L0["v"].suh], self.xh3, bsz, xsums=self.xs3)
         rs = None                                                          # (ss_prev, ss_new) of the pending rescale, None = normalised exactly
         for li, L in enumerate(self.layers):
             lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
             kc, ks = self.kcache[li]
             vc, vs = self.vcache[li]
-            slabs, S = ext.exl3_gemv_ex(None, self.xh3, None, [lq.trellis, lk.trellis, lv.trellis], None, None, None,
+            slabs, S = ext.exl3_gemv_ex(None, self.xh3, self.xs3, [lq.trellis, lk.trellis, lv.trellis], None, None, None,
                                         bsz, lq.mcg, lq.mul1, ROT | DEF, sp["qkv"])
             ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
                             self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd,
@@ -404,20 +404,22 @@ class SyntheticEXL3Llama:
                                        self.attn_pos + 1, workspace=self.attn_ws)
                 o_in = self.attn_out.view(bsz, -1)
             so, So = ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"])
-            ext.glue_resid_rotate(so[0], So, lo.svh, None, x, ss_c, ss_o, L["norm2"], self.eps, [lg.suh, lu.suh], self.xh3[:2], bsz)
+            ext.glue_resid_rotate(so[0], So, lo.svh, None, x, ss_c, ss_o, L["norm2"], self.eps, [lg.suh, lu.suh], self.xh3[:2], bsz,
+                                  xsums=self.xs3[:2])
             rs = (ss_c, ss_o); ss_c, ss_o = ss_o, ss_c
-            sgu, Sgu = ext.exl3_gemv_ex(None, self.xh3[:2], None, [lg.trellis, lu.trellis], None, None, None,
+            sgu, Sgu = ext.exl3_gemv_ex(None, self.xh3[:2], self.xs3[:2], [lg.trellis, lu.trellis], None, None, None,
                                         bsz, lg.mcg, lg.mul1, ROT | DEF, sp["gu"])
             ext.glue_act_rs(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz, rs[0], rs[1], hidden, self.eps)
             sd, Sd = ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF, sp["down"])
             if li + 1 < self.n_layers:
                 N = self.layers[li + 1]
-                ext.glue_resid_rotate(sd[0], Sd, ld.svh, None, x, ss_c, ss_o, N["norm1"], self.eps, [N["q"].suh, N["k"].suh, N["v"].suh], self.xh3, bsz)
+                ext.glue_resid_rotate(sd[0], Sd, ld.svh, None, x, ss_c, ss_o, N["norm1"], self.eps, [N["q"].suh, N["k"].suh, N["v"].suh], self.xh3, bsz,
+                                      xsums=self.xs3)
                 rs = (ss_c, ss_o); ss_c, ss_o = ss_o, ss_c
             else:
                 ext.glue_resid(sd[0], Sd, ld.svh, None, x, ss_c, bsz)
-        ext.glue_rotate(x, ss_c, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz)
-        ext.exl3_gemv_ex(None, self.xh3[:1], None, [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
+        ext.glue_rotate(x, ss_c, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz, xsums=self.xs3[:1])
+        ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
                          bsz, self.lm_head.mcg, self.lm_head.mul1, ROT)
         return self.logits
 
@@ -455,8 +457,8 @@ class SyntheticEXL3Llama:
                 ext.quant_cache_paged(self.k.view(bsz, 1, -1), kc, ks, self.v.view(bsz, 1, -1), vc, vs, self.cache_seqlens, self.block_table, self.page, 1)
             else:
                 if rot:
-                    ext.glue_rotate(x, ss, L["norm1"], self.eps, [lq.suh, lk.suh, lv.suh], self.xh3, bsz)
-                    slabs, S = ext.exl3_gemv_ex(None, self.xh3, None, [lq.trellis, lk.trellis, lv.trellis], None, None, None,
+                    ext.glue_rotate(x, ss, L["norm1"], self.eps, [lq.suh, lk.suh, lv.suh], self.xh3, bsz, xsums=self.xs3)
+                    slabs, S = ext.exl3_gemv_ex(None, self.xh3, self.xs3, [lq.trellis, lk.trellis, lv.trellis], None, None, None,
                                                 bsz, lq.mcg, lq.mul1, ROT | DEF, sp["qkv"])
                 else:
                     slabs, S = ext.exl3_gemv_ex_norm(x, L["norm1"], ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh],
@@ -495,8 +497,8 @@ class SyntheticEXL3Llama:
                     be.all_reduce_resid(self.d, x, ss, bsz)
                 continue
             if rot:
-                ext.glue_rotate(x, ss, L["norm2"], self.eps, [lg.suh, lu.suh], self.xh3[:2], bsz)
-                sgu, Sgu = ext.exl3_gemv_ex(None, self.xh3[:2], None, [lg.trellis, lu.trellis], None, None, None,
+                ext.glue_rotate(x, ss, L["norm2"], self.eps, [lg.suh, lu.suh], self.xh3[:2], bsz, xsums=self.xs3[:2])
+                sgu, Sgu = ext.exl3_gemv_ex(None, self.xh3[:2], self.xs3[:2], [lg.trellis, lu.trellis], None, None, None,
                                             bsz, lg.mcg, lg.mul1, ROT | DEF, sp["gu"])
             else:
                 sgu, Sgu = ext.exl3_gemv_ex_norm(x, L["norm2"], ss, self.eps, [lg.trellis, lu.trellis], None, [lg.suh, lu.suh], None,
@@ -517,8 +519,8 @@ class SyntheticEXL3Llama:
                 ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.d], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT, c_fp32=True)
                 be.all_reduce_resid(self.d, x, ss, bsz)
         if rot or self.rotate_for_head:
-            ext.glue_rotate(x, ss, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz)
-            ext.exl3_gemv_ex(None, self.xh3[:1], None, [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
+            ext.glue_rotate(x, ss, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz, xsums=self.xs3[:1])
+            ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
                              bsz, self.lm_head.mcg, self.lm_head.mul1, ROT)
         else:
             ext.exl3_gemv_ex_norm(x, self.final_norm, ss, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
@@ -579,8 +581,8 @@ class SyntheticEXL3Llama:
         ext.glue_resid(pend[0], pend[1], pend[2], None, xc, sc, bsz)
         self.x_final = xc
         if self.rotate_for_head:
-            ext.glue_rotate(xc, sc, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz)
-            ext.exl3_gemv_ex(None, self.xh3[:1], None, [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
+            ext.glue_rotate(xc, sc, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz, xsums=self.xs3[:1])
+            ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
                              bsz, self.lm_head.mcg, self.lm_head.mul1, ext.GEMV_IN_ROTATED)
         else:
             ext.exl3_gemv_ex_norm(xc, self.final_norm, sc, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
@@ -752,7 +754,7 @@ class SyntheticEXL3Llama:
                 calls.append(lambda lg=lg, lu=lu: ext.exl3_mgemm_bcast(self.xn, [lg.trellis, lu.trellis], [self.g, self.u], [lg.suh, lu.suh], [lg.svh, lu.svh], lg.mcg, lg.mul1))
                 calls.append(lambda ld=ld: ld.bc.run(self.a, self.d))
         if pipeline == "glue" and self.tp == 1 and bsz > 4:
-            calls.append(lambda: ext.exl3_gemv_ex(None, self.xh3[:1], None, [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, ROT))
+            calls.append(lambda: ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, ROT))
         elif pipeline == "glue" and self.tp == 1:
             calls.append(lambda: ext.exl3_gemv_ex_norm(self.x, self.final_norm, self.ss, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, 0))
         elif pipeline == "tail" and self.tp == 1:

@@ -67,3 +67,17 @@ def test_reference_classes_reach_the_mirror_with_compatible_signatures():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_reference_seam_script.py"), "cpu"], capture_output=True, text=True,
                        timeout=600, env=env, cwd="/tmp")
     assert r.returncode == 0 and "REFERENCE_CALLS_OK cpu" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+@needs_ref
+def test_loader_and_writer_pinned_against_the_reference_reader_and_naming_code():
+    """SURVEY.md 8f rank 4, parity pinned (task 4a): a checkpoint written by save_checkpoint is read by the reference's own
+    SafetensorsCollection + Linear.load_exl3; a checkpoint named by the reference's LinearEXL3.get_tensors (3INST / mcg / mul1 markers, bias,
+    legacy packed su / sv) is read by exllamav3_amd.loader; stored legacy .su / .sv files through both readers; tensor-parallel shard reads
+    against slices of the reference's whole tensors -- every tensor bit for bit (tests/_reference_loader_script.py)."""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([STUB_DIR, ROOT, REF]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_reference_loader_script.py")], capture_output=True, text=True,
+                       timeout=600, env=env, cwd="/tmp")
+    assert r.returncode == 0 and "REFERENCE_LOADER_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    for tag in ("A_OK 45", "B_OK 4", "C_OK", "D_OK"):
+        assert tag in r.stdout

@@ -1,6 +1,6 @@
 """Whole-step time of the glue pipeline (hipGraph replay) as a function of the split-k factor of each call type.  env: BSZ, G3MIN, CANDS (json)."""
 import json, os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
 
 dev = torch.device("cuda:0")
@@ -9,6 +9,7 @@ model = SyntheticEXL3Llama(SHAPES[os.environ.get("MODEL", "llama-3.1-8b")], K=4,
 model.alloc_state(int(os.environ.get('BSZ', '1')))
 from exllamav3_amd import ext
 if os.environ.get('G3MIN'): ext.set_gemm3_min_rows(int(os.environ['G3MIN']))
+if os.environ.get('MAXW'): ext.set_gemv_max_waves(int(os.environ['MAXW']))
 
 def step_us():
     model.decode_step_fused(); torch.cuda.synchronize()
