@@ -226,7 +226,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                      float** slabs_out = nullptr, int* S_out = nullptr, const GemvEpi* epi = nullptr,
                      const void* norm_w = nullptr, const float* ss_part = nullptr, float eps = 0.0f, const GemvTable* tbl = nullptr,
                      const float* act_g = nullptr, const float* act_u = nullptr, int act_S = 0, const void* act_svh_g = nullptr,
-                     const void* act_svh_u = nullptr, const GemvResidIn* rsd = nullptr, const GemvRescale* act_rs = nullptr, int cpw = 0)
+                     const void* act_svh_u = nullptr, const GemvResidIn* rsd = nullptr, const GemvRescale* act_rs = nullptr, int cpw = 0,
+                     float* fx_ss_out = nullptr)
 {
     if (rsd) flags |= GEMV_IN_RESID;
     // cpw > 0: wave-per-column-block layout (exl3_gemv2.kspec.hip): cpw column blocks of one matrix per workgroup, one wave each
@@ -236,7 +237,13 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                    "exl3_gemv_ex (cpw): wave-per-column-block launches are deferred, m <= 4, raw / resid / act input");
     if (act_g) flags |= GEMV_IN_ACT;
     if (epi) flags |= GEMV_OUT_DEFERRED;
-    const bool deferred = (flags & GEMV_OUT_DEFERRED) != 0, rotated = (flags & GEMV_IN_ROTATED) != 0;
+    // GEMV_OUT_ATOMIC (generation 4): no slabs, every workgroup adds its share of the output into the fixed-point accumulator Cs[i]; like a deferred
+    // launch it keeps every workgroup resident (the split is chosen the same way) and it needs svhs
+    const bool atomic_out = (flags & GEMV_OUT_ATOMIC) != 0, in_fx = (flags & GEMV_IN_FX) != 0;
+    EXL3_CHECK_ARG(!atomic_out || (!(flags & GEMV_OUT_DEFERRED) && Cs && svhs && m <= 4 && !tbl && !epi && cpw == 0 && !rsd),
+                   "exl3_gemv_ex: GEMV_OUT_ATOMIC needs the accumulators (Cs), svhs, m <= 4 and excludes GEMV_OUT_DEFERRED");
+    EXL3_CHECK_ARG(!in_fx || ((flags & GEMV_IN_NORM) && m <= 4 && fx_ss_out), "exl3_gemv_ex_fx: needs GEMV_IN_NORM, m <= 4 and ss_out");
+    const bool deferred = (flags & (GEMV_OUT_DEFERRED | GEMV_OUT_ATOMIC)) != 0, rotated = (flags & GEMV_IN_ROTATED) != 0;
     EXL3_CHECK_ARG(!(deferred || rotated) || m <= 16, "exl3_gemv_ex: at most 16 rows");
     const int epi_sets = !epi ? 0 : (epi->mode == GEMV_EPI_ACT ? 2 : 1);
     EXL3_CHECK_ARG(!rotated || xhs, "exl3_gemv_ex: rotated input requires xh pointers");
@@ -264,6 +271,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     {
         EXL3_CHECK_ARG(ns[i] % 128 == 0 && ns[i] > 0, "exl3_gemm: n must be divisible by 128");
         EXL3_CHECK_ARG(Bs[i] && (deferred || (Cs && Cs[i] && svhs && svhs[i])) && (rotated || (suhs && suhs[i])), "exl3_gemm: null pointer");
+        EXL3_CHECK_ARG(!atomic_out || (Cs[i] && svhs[i]), "exl3_gemv_ex: GEMV_OUT_ATOMIC needs an accumulator and svh per matrix");
         total_cb += ns[i] / 128;
     }
     Exl3DevCtx* ctx = exl3_get_ctx(st);
@@ -305,6 +313,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         args.act_g = act_g; args.act_u = act_u; args.act_S = act_S;
         args.act_svh_g = (const half_t*) act_svh_g; args.act_svh_u = (const half_t*) act_svh_u;
         args.norm_w = (const half_t*) norm_w; args.ss_part = ss_part; args.eps = eps;
+        if (in_fx) args.rs_ss_out = fx_ss_out;
         if (rsd) { args.rs_slab = rsd->slab; args.rs_S = rsd->S; args.rs_svh = (const half_t*) rsd->svh; args.rs_resid_out = (half_t*) rsd->resid_out; args.rs_ss_out = rsd->ss_out; }
         if (act_rs) args.act_rs = *act_rs;
         int fs = force_split;
@@ -376,9 +385,9 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             EXL3_CHECK_ARG(total_cb + 1 <= EXL3_NUM_TICKETS, "exl3_gemv: too many column blocks for the ticket table");
             EXL3_CHECK_ARG(S <= 128, "exl3_gemv: split too deep for the tail epilogue");
         }
-        EXL3_CHECK_ARG((S == 1 && !deferred) || wso * 4 <= EXL3_WS_REGION_BYTES, "exl3_gemm: split-k workspace too small");
+        EXL3_CHECK_ARG((S == 1 && !deferred) || atomic_out || wso * 4 <= EXL3_WS_REGION_BYTES, "exl3_gemm: split-k workspace too small");
         float* ws_region = ctx->workspace;
-        if (S > 1 || deferred)
+        if ((S > 1 || deferred) && !atomic_out)
         {
             ws_region += ctx->ws_toggle ? EXL3_WS_REGION_BYTES / 4 : 0;
             ctx->ws_toggle ^= 1;
@@ -435,7 +444,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                 for (int i = 0; i < count; ++i) if (!args.mat[i].xsum) g4 = false;      // the mul1 FAST variant needs the producer's block sums
             if (g4)
             {
-                const int mode = in_act ? 3 : (in_norm ? 2 : (rot_pass ? 0 : 1));
+                const int mode = in_act ? 3 : (in_norm ? (in_fx ? 4 : 2) : (rot_pass ? 0 : 1));
                 const int units4 = bps * 4;
                 int nwv4 = 8;
                 if (nwv4 > (bps > 4 ? bps : 4)) nwv4 = bps > 4 ? bps : 4;
@@ -464,6 +473,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             }
             else
             {
+            EXL3_CHECK_ARG(!atomic_out && !in_fx, "exl3_gemv_ex: GEMV_OUT_ATOMIC / GEMV_IN_FX are generation-4 launches (m <= 4, slices of <= 32 Hadamard blocks, generation 4 enabled)");
             int nwv = 16 / ng;                                   // partial-sum LDS: nwv * 4*ng rows * 512 B <= 32 KB
             const int units = bps * (8 / G2_PF);                 // the waves split the slice's tile rows in units of G2_PF
             // measured on MI355X (tools/prof_tail.py, batch 1): one wave per Hadamard block of the slice, but at least 4 waves --
@@ -525,6 +535,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         if (rc) return rc;
         if (S > 1 && !deferred)
         {
+            // (GEMV_OUT_ATOMIC launches count as deferred: nothing to reduce)
             int64_t items = (int64_t) total_cb * mp;
             exl3_gemv_reduce_kernel<<<dim3((unsigned) ((items + 7) / 8)), dim3(256), 0, st>>>(args, total_cb);
             rc = exl3_check_launch("exl3_gemv_reduce");
@@ -749,6 +760,22 @@ extern "C" int exl3_gemv_ex_resid(const void* resid_in, const void* norm_w, cons
     return run_mgemm(resid_in, Bs, nullptr, suhs, nullptr, nullptr, ns, count, m, k, K, cb, 0, force_split, (hipStream_t) stream,
                      GEMV_OUT_DEFERRED | GEMV_IN_NORM, nullptr, nullptr, slabs_out, S_out, nullptr, norm_w, ss_prev, eps, nullptr,
                      nullptr, nullptr, 0, nullptr, nullptr, &rsd, nullptr, cpw > 0 ? cpw : 4);
+}
+
+// The "fx" decode pipeline (round 3): the residual stream lives in a 64-bit fixed-point accumulator R [m][hidden] (value * 2^32).  o_proj / down_proj
+// launches ADD their output rows into it (exl3_gemv_ex with EXL3_GEMV_OUT_ATOMIC: integer atomics, order-independent, so no split-k reduce and no
+// residual launch), and this launch is the consumer: exl3_gemv_ex_norm whose input is R.  The RMSNorm scale it applies is the PREVIOUS residual's
+// (ss_prev [m][k/128], complete) because the sums of squares of R itself are only known once every block has been read: the workgroups of column
+// block 0 write them to ss_out, and whoever finishes this launch's slabs multiplies by r_new / r_prev (exl3_glue_qkv_rs, exl3_glue_act_rs) -- the
+// protocol of exl3_gemv_ex_resid without its redundant slab reduction (the memory system has already summed the slices).  Output: deferred slabs.
+extern "C" int exl3_gemv_ex_fx(const void* R, const void* norm_w, const float* ss_prev, float* ss_out, float eps, const void* const* Bs,
+                               const void* const* suhs, const int* ns, int count, int m, int k, int K, int cb, int force_split,
+                               float** slabs_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(Bs && ns && R && suhs && ss_prev && ss_out && ss_prev != ss_out, "exl3_gemv_ex_fx: null table / ss_out must differ from ss_prev");
+    return run_mgemm(R, Bs, nullptr, suhs, nullptr, nullptr, ns, count, m, k, K, cb, 0, force_split, (hipStream_t) stream,
+                     GEMV_OUT_DEFERRED | GEMV_IN_NORM | GEMV_IN_FX, nullptr, nullptr, slabs_out, S_out, nullptr, norm_w, ss_prev, eps, nullptr,
+                     nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, ss_out);
 }
 
 // exl3_gemv_ex (raw input A + suhs, deferred output, m <= 4) in the wave-per-column-block layout: cpw column blocks of one matrix per workgroup,

@@ -43,23 +43,35 @@ __device__ __forceinline__ void g4_static_for(F&& f)
 #define G4_MODE_RAWX 1      // raw x: x * suh -> 128-point Hadamard in the task
 #define G4_MODE_NORM 2      // GEMV_IN_NORM: RMSNorm of the residual stream, then as RAWX
 #define G4_MODE_ACT  3      // GEMV_IN_ACT: silu(g) * u finished from the producer's gate / up slabs, then as RAWX
+#define G4_MODE_NORMFX 4    // GEMV_IN_NORM | GEMV_IN_FX: as NORM, the residual read from the 64-bit fixed-point accumulator (row scale = the previous residual's)
 
 constexpr int g4_waves_per_eu(int K, int CB, int MODE)
 {
     if (MODE == G4_MODE_ACT) return 4;
     if (K >= 5) return 6;
+    if (MODE == G4_MODE_NORMFX) return 6;
     return (MODE == G4_MODE_ROT && CB == EXL3_CB_MUL1) ? 8 : 7;
 }
 
 // One work unit = 2 tile rows of the wave's column block.  HALF selects which half of the 4-tile-row activation group the unit is (abid 0..7 or 8..15).
-template <int K, int CB, int VAR, int HALF>
-__device__ __forceinline__ void g4_unit(LaneWords<K> (&ring)[2], const uint32_t* __restrict__ refill, size_t row_stride, int lane,
+// Units in flight per wave (weight-row register ring = 2 * PFU rows).  One unit of lookahead, like generation 2.  Measured (round 3, same box,
+// three alternations, gpurun_out/r3d): TWO units in flight -- tried because a q|k|v wave streams only 2 units and tools/gemv_timeline.py shows it
+// waiting for its second unit's rows -- is 6 % SLOWER on the whole step (535 vs 568 tok/s): every wave of a launch issues its first requests in the
+// same microsecond, and doubling that burst delays every dependent small load (activations, slabs) behind twice as many weight lines.
+#ifndef G4_PFU
+#define G4_PFU(K) 1
+#endif
+
+template <int K, int CB, int VAR, int HALF, int NR>
+__device__ __forceinline__ void g4_unit(LaneWords<K> (&ringall)[NR], const uint32_t* __restrict__ refill, size_t row_stride, int lane,
                                         half4_t ag0, half4_t ag1, float4_t& acc_c, float4_t& acc_d)
 {
     constexpr bool SPLIT = (VAR == 1) && (CB != EXL3_CB_MUL1);
+    constexpr int R0 = NR == 4 ? 2 * HALF : 0;               // two units in flight: the unit's slot pair alternates with HALF
     g4_static_for<0, 2>([&] (auto uc)
     {
         constexpr int u = decltype(uc)::value;
+        LaneWords<K>* ring = ringall + R0;
         uint32_t Wx[K + 1];
         #pragma unroll
         for (int i = 0; i < K; ++i) Wx[i + 1] = ring[u].w[i];
@@ -160,7 +172,7 @@ void exl3_gemv4_kernel(const GemvArgs a)
     const int last_unit = ubase + (nun > 0 ? nun - 1 : 0);
 
     // ---- preparation tasks (raw / norm / act input): task t = (block t / m, row t % m), one per half-wave; only waves that own a task run them
-    struct PrepIn { half4_t xv, sv, wv; float ss; };
+    struct PrepIn { half4_t xv, sv, wv; float ss; uint4_t f0, f1; };
     const int ntask = nb * m;
     auto fetch = [&] (int it) -> PrepIn
     {
@@ -169,8 +181,13 @@ void exl3_gemv4_kernel(const GemvArgs a)
         const int blk = gemv_udiv(t, mg_m), row = t - blk * m;
         const size_t kofs = (size_t) k0s + 128 * blk;
         if constexpr (MODE == G4_MODE_RAWX || MODE == G4_MODE_NORM) r.xv = ((const half4_t*) (a_A + (size_t) row * a_k + kofs))[l32];
+        if constexpr (MODE == G4_MODE_NORMFX)
+        {
+            const uint4_t* fp = (const uint4_t*) ((const int64_t*) a_A + (size_t) row * a_k + kofs) + 2 * l32;      // 4 x int64 per lane
+            r.f0 = fp[0]; r.f1 = fp[1];
+        }
         r.sv = ((const half4_t*) (suh + kofs))[l32];
-        if constexpr (MODE == G4_MODE_NORM)
+        if constexpr (MODE == G4_MODE_NORM || MODE == G4_MODE_NORMFX)
         {
             r.wv = ((const half4_t*) (a_norm_w + kofs))[l32];
             if (l32 < (a_k >> 7)) r.ss = a_ss_part[(size_t) row * (a_k >> 7) + l32];
@@ -182,11 +199,12 @@ void exl3_gemv4_kernel(const GemvArgs a)
     if constexpr (IN_LDS) { if (prep_wave) nx = fetch(0); }
 
     // first weight rows: requested after the first task's (small, L2-resident) operands so that the task computes underneath the HBM latency
-    LaneWords<K> ring[2];
+    constexpr int PFU = G4_PFU(K), NR = 2 * PFU;
+    LaneWords<K> ring[NR];
     if (nun > 0)
     {
         #pragma unroll
-        for (int u = 0; u < 2; ++u) load_lane_words<K>(ring[u], strip + (size_t) (2 * ubase + u) * row_stride);
+        for (int u = 0; u < NR; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(2 * ubase + u, 2 * last_unit + 1) * row_stride);
     }
     G4_T(1);
 
@@ -269,7 +287,24 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
                     xv = half4_t{ silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
                 }
-                if constexpr (MODE == G4_MODE_NORM)
+                if constexpr (MODE == G4_MODE_NORMFX)
+                {
+                    // the residual stream in 64-bit fixed point (value * 2^32, GEMV_OUT_ATOMIC launches add into it): x = fp16(hi + lo / 2^32)
+                    auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h((float) (int32_t) hi + (float) lo * 2.3283064365386963e-10f); };
+                    xv = half4_t{ fx(cur.f0.x, cur.f0.y), fx(cur.f0.z, cur.f0.w), fx(cur.f1.x, cur.f1.y), fx(cur.f1.z, cur.f1.w) };
+                    if (cbg == 0)
+                    {
+                        // block sums of squares of THIS residual for whoever finishes this launch's outputs (exl3_glue_qkv_rs / _act_rs) and for
+                        // the next consumer's estimate: one workgroup per k-slice (column block 0 of matrix 0) covers every block
+                        const float r0 = (float) xv.x, r1 = (float) xv.y, r2 = (float) xv.z, r3 = (float) xv.w;
+                        float ssq = r0 * r0;
+                        ssq = __builtin_fmaf(r1, r1, ssq); ssq = __builtin_fmaf(r2, r2, ssq); ssq = __builtin_fmaf(r3, r3, ssq);
+                        #pragma unroll
+                        for (int i = 1; i < 32; i <<= 1) ssq += xor_lane(ssq, i);
+                        if (act && l32 == 0) a.rs_ss_out[(size_t) row * (a_k >> 7) + (k0s >> 7) + blk] = ssq;
+                    }
+                }
+                if constexpr (MODE == G4_MODE_NORM || MODE == G4_MODE_NORMFX)
                 {
                     // x = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)): the row's mean square from the per-block sums a glue kernel left behind,
                     // same arithmetic and summation order as generation 2 / glue_norm_kernel / rms_norm (norm.cu:20-120)
@@ -324,14 +359,15 @@ void exl3_gemv4_kernel(const GemvArgs a)
     {
         set_group(agn);
         agn = load_group(2 * min(unit + 2, last_unit));         // next group (clamped: a harmless reload at the end)
-        g4_unit<K, CB, VAR, 0>(ring, strip + (size_t) (2 * min(unit + 1, last_unit)) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
-        g4_unit<K, CB, VAR, 1>(ring, strip + (size_t) (2 * min(unit + 2, last_unit)) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
+        // a unit refills its slots with the rows of the unit PFU ahead (clamped: a harmless reload at the end)
+        g4_unit<K, CB, VAR, 0, NR>(ring, strip + (size_t) (2 * min(unit + PFU, last_unit)) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
+        g4_unit<K, CB, VAR, 1, NR>(ring, strip + (size_t) (2 * min(unit + 1 + PFU, last_unit)) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
         unit += 2;
     }
     if (nun & 1)
     {
         set_group(agn);
-        g4_unit<K, CB, VAR, 0>(ring, strip + (size_t) (2 * last_unit) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
+        g4_unit<K, CB, VAR, 0, NR>(ring, strip + (size_t) (2 * last_unit) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
     }
 
     G4_T(3);
@@ -373,7 +409,7 @@ void exl3_gemv4_kernel(const GemvArgs a)
             const float b = kbias * xs;
             v.x = v.x * kinv + b; v.y = v.y * kinv + b; v.z = v.z * kinv + b; v.w = v.w * kinv + b;
         }
-        if (a_S > 1 || (a_flags & GEMV_OUT_DEFERRED))
+        if ((a_S > 1 && !(a_flags & GEMV_OUT_ATOMIC)) || (a_flags & GEMV_OUT_DEFERRED))
         {
             float* slab = a.workspace + ws_off + ((size_t) cbl * a_S + s) * (size_t) m * 128;
             ((float4_t*) (slab + row * 128))[l] = v;
@@ -384,6 +420,21 @@ void exl3_gemv4_kernel(const GemvArgs a)
         h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
         const half4_t sc = ((const half4_t*) (a.mat[mi].svh + cbl * 128))[l];
         const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
+        if (a_flags & GEMV_OUT_ATOMIC)
+        {
+            // the slice's share of the output rows (out-Hadamard and svh applied to the partial: both linear), added into the fixed-point
+            // accumulator; fp32 arithmetic of glue_resid up to the sum, which here is exact integer addition in any order
+            float o[4] = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
+            if (bias && s == 0) { const half4_t bv = ((const half4_t*) bias)[l]; o[0] += (float) bv.x; o[1] += (float) bv.y; o[2] += (float) bv.z; o[3] += (float) bv.w; }
+            unsigned long long* acc = (unsigned long long*) a.mat[mi].C + ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
+            #pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                const long long f = __double2ll_rn((double) o[i] * GEMV_FX_SCALE);
+                __hip_atomic_fetch_add(acc + i, (unsigned long long) f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;
+        }
         const size_t off = ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
         if (a.c_fp32)
         {
@@ -429,6 +480,7 @@ static void g4_launch_cb(int var, int mode, int nwv, dim3 grid, size_t lds, hipS
         case G4_MODE_ROT:  LV(G4_MODE_ROT)  break;
         case G4_MODE_RAWX: LV(G4_MODE_RAWX) break;
         case G4_MODE_NORM: LV(G4_MODE_NORM) break;
+        case G4_MODE_NORMFX: LV(G4_MODE_NORMFX) break;
         default:           LV(G4_MODE_ACT)  break;
     }
     #undef LV

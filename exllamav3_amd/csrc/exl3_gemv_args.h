@@ -14,6 +14,14 @@
                               // per Hadamard block while the activation fragments are built (replaces the glue_resid launch).  The row scale of the
                               // RMSNorm is taken from the PREVIOUS residual's sums of squares (ss_part); consumers of this launch's outputs
                               // multiply by rsqrt(ms_new + eps) / rsqrt(ms_prev + eps) (GemvRescale) -- the linear map commutes with the scalar
+#define GEMV_OUT_ATOMIC    32  // (generation 4) the finished rows are ADDED into a 64-bit fixed-point accumulator (mat[i].C = int64 [m][n], value * 2^32: the
+                              // residual stream of the "fx" decode pipeline): every workgroup applies the output Hadamard, svh (and slice 0 the bias) to its
+                              // OWN split-k partial -- the Hadamard is linear -- and adds it with agent-scope integer atomics.  Integer addition is
+                              // associative, so the sum does not depend on arrival order (bit-reproducible), and no reduce / residual launch follows.
+#define GEMV_IN_FX         64  // (generation 4, with GEMV_IN_NORM) A is that accumulator: x = fp16(A / 2^32); ss_part holds the block sums of squares of the
+                              // PREVIOUS residual (the row scale is an estimate, corrected downstream exactly as for GEMV_IN_RESID); the workgroups of
+                              // column block 0 of matrix 0 write the block sums of squares of THIS residual to rs_ss_out
+#define GEMV_FX_SCALE 4294967296.0
 #define GEMV_MAX_MATS 4
 
 // r = rsqrt(sum(ss_new[row]) / k + eps) / rsqrt(sum(ss_prev[row]) / k + eps): the exact RMSNorm scale over the estimate a GEMV_IN_RESID launch used.

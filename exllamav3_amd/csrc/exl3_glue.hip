@@ -801,3 +801,71 @@ extern "C" int exl3_glue_rotate(const void* resid, const float* ss_part, const v
     glue_rotate_kernel<<<(tasks + tpw - 1) / tpw, th, 0, (hipStream_t) stream>>>((const half_t*) resid, ss_part, (const half_t*) w, eps, tg, m, hidden);
     return exl3_check_launch("glue_rotate");
 }
+
+// ------------------------------------------------------------------------------------------------
+// "fx" decode pipeline (round 3): the residual stream as a 64-bit fixed-point accumulator R [m][hidden] (value * 2^32) that the o_proj / down_proj
+// launches add into with integer atomics (GEMV_OUT_ATOMIC) and the q|k|v / gate|up launches read (exl3_gemv_ex_fx).  These two kernels are its ends:
+//   fx_init:   R = x (fp16, exact in fixed point) and ss[row][block] = the block sums of squares of x  (the arithmetic of glue_resid without a linear)
+//   fx_finish: x = fp16(R / 2^32) and ss of those fp16 values: the residual handed to the final norm / lm_head (or to any fp16 consumer)
+// One 32-lane half-wave per (row, 128-block), 4 values per lane.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void fx_init_kernel(const half_t* __restrict__ x, long long* __restrict__ R, float* __restrict__ ss, int m, int hidden)
+{
+    const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
+    const int nblk = hidden >> 7;
+    const int t = blockIdx.x * 8 + hw;
+    const bool act = t < m * nblk;
+    const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+    const half4_t r = ((const half4_t*) (x + (size_t) row * hidden + blk * 128))[l];
+    const float r0 = (float) r.x, r1 = (float) r.y, r2 = (float) r.z, r3 = (float) r.w;
+    if (act)
+    {
+        long long* o = R + (size_t) row * hidden + blk * 128 + 4 * l;
+        o[0] = __double2ll_rn((double) r0 * GEMV_FX_SCALE); o[1] = __double2ll_rn((double) r1 * GEMV_FX_SCALE);
+        o[2] = __double2ll_rn((double) r2 * GEMV_FX_SCALE); o[3] = __double2ll_rn((double) r3 * GEMV_FX_SCALE);
+    }
+    float s2 = r0 * r0;
+    s2 = __builtin_fmaf(r1, r1, s2); s2 = __builtin_fmaf(r2, r2, s2); s2 = __builtin_fmaf(r3, r3, s2);
+    #pragma unroll
+    for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
+    if (act && l == 0) ss[(size_t) row * nblk + blk] = s2;
+}
+
+__global__ __launch_bounds__(256)
+void fx_finish_kernel(const long long* __restrict__ R, half_t* __restrict__ x, float* __restrict__ ss, int m, int hidden)
+{
+    const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
+    const int nblk = hidden >> 7;
+    const int t = blockIdx.x * 8 + hw;
+    const bool act = t < m * nblk;
+    const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+    const uint4_t* fp = (const uint4_t*) (R + (size_t) row * hidden + blk * 128) + 2 * l;
+    const uint4_t f0 = fp[0], f1 = fp[1];
+    // the conversion of the generation-4 GEMV's fixed-point input mode (exl3_gemv4.kspec.hip): same fp16 values
+    auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h((float) (int32_t) hi + (float) lo * 2.3283064365386963e-10f); };
+    const half4_t r = { fx(f0.x, f0.y), fx(f0.z, f0.w), fx(f1.x, f1.y), fx(f1.z, f1.w) };
+    if (act && x) ((half4_t*) (x + (size_t) row * hidden + blk * 128))[l] = r;
+    const float r0 = (float) r.x, r1 = (float) r.y, r2 = (float) r.z, r3 = (float) r.w;
+    float s2 = r0 * r0;
+    s2 = __builtin_fmaf(r1, r1, s2); s2 = __builtin_fmaf(r2, r2, s2); s2 = __builtin_fmaf(r3, r3, s2);
+    #pragma unroll
+    for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
+    if (act && l == 0 && ss) ss[(size_t) row * nblk + blk] = s2;
+}
+
+extern "C" int exl3_fx_init(const void* x, void* R, float* ss, int m, int hidden, void* stream)
+{
+    EXL3_CHECK_ARG(x && R && ss && m >= 1 && hidden % 128 == 0, "exl3_fx_init: null pointer / hidden not a multiple of 128");
+    const int tasks = m * (hidden / 128);
+    fx_init_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>((const half_t*) x, (long long*) R, ss, m, hidden);
+    return exl3_check_launch("fx_init");
+}
+
+extern "C" int exl3_fx_finish(const void* R, void* x, float* ss, int m, int hidden, void* stream)
+{
+    EXL3_CHECK_ARG(R && (x || ss) && m >= 1 && hidden % 128 == 0, "exl3_fx_finish: null pointer / hidden not a multiple of 128");
+    const int tasks = m * (hidden / 128);
+    fx_finish_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>((const long long*) R, (half_t*) x, ss, m, hidden);
+    return exl3_check_launch("fx_finish");
+}

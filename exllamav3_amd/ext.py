@@ -780,6 +780,7 @@ def softcap(x, y, scale: float):
 # --------------------------------------------------------------------------------------------------
 
 GEMV_IN_ROTATED, GEMV_OUT_DEFERRED, GEMV_IN_NORM = 1, 2, 4
+GEMV_OUT_ATOMIC = 32      # (m <= 4) Cs[i] = int64 fixed-point accumulator (value * 2^32) the finished rows are added into: the "fx" decode pipeline
 
 
 def _parr(ptrs):
@@ -1059,6 +1060,36 @@ def exl3_gemv_ex_act(gu_slabs, gu_S: int, svh_g, svh_u, B, C, suh, svh, m: int, 
     _check(_lib.lib().exl3_gemv_ex_act(gu_slabs[0], gu_slabs[1], gu_S, _p(svh_g), _p(svh_u), _p(B), _p(C), _p(suh), _p(svh), None, m, k,
                                        B.shape[1] * 16, K, _cb(mcg, mul1), int(c_fp32), flags, force_split, slab, ctypes.byref(S), _stream(B)))
     return [int(slab[0]) if slab[0] else 0], S.value
+
+
+def fx_init(x: torch.Tensor, R: torch.Tensor, ss: torch.Tensor, m: int):
+    """R (int64 [m][hidden], value * 2^32) = x (fp16); ss [m][hidden/128] = block sums of squares of x: the start of the fx decode pipeline."""
+    _dev(x)
+    _req(x.dtype == torch.half and R.dtype == torch.int64 and ss.dtype == torch.float and x.is_contiguous() and R.is_contiguous(), "fx_init: dtypes")
+    _check(_lib.lib().exl3_fx_init(_p(x), _p(R), _p(ss), m, x.shape[-1], _stream(x)))
+
+
+def fx_finish(R: torch.Tensor, x: torch.Tensor | None, ss: torch.Tensor | None, m: int):
+    """x = fp16(R / 2^32), ss = its block sums of squares (either may be None)."""
+    _dev(R)
+    _req(R.dtype == torch.int64 and R.is_contiguous(), "fx_finish: R must be a contiguous int64 tensor")
+    _check(_lib.lib().exl3_fx_finish(_p(R), _p(x), _p(ss), m, R.shape[-1], _stream(R)))
+
+
+def exl3_gemv_ex_fx(R, norm_w, ss_prev, ss_out, eps: float, Bs, suhs, m: int, mcg: bool, mul1: bool, force_split: int = 0):
+    """exl3_gemv_ex_norm whose residual input is the fixed-point accumulator R (int64, value * 2^32; GEMV_OUT_ATOMIC launches add into it).  The row
+    scale is the PREVIOUS residual's (ss_prev); ss_out (another buffer) receives this residual's block sums of squares; finish the returned slabs
+    with glue_qkv_rs / glue_act_rs / exl3_gemv_ex_act_rs (ss_prev, ss_out).  Returns (slabs, S)."""
+    _dev(R)
+    _req(R.dtype == torch.int64, "exl3_gemv_ex_fx: R must be int64")
+    cnt = len(Bs)
+    k, K = _kK(Bs[0])
+    ns = (ctypes.c_int * cnt)(*[B.shape[1] * 16 for B in Bs])
+    slabs = (_vp * cnt)()
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_gemv_ex_fx(_p(R), _p(norm_w), _p(ss_prev), _p(ss_out), float(eps), _parr(Bs), _parr(suhs), ns, cnt, m, k, K,
+                                      _cb(mcg, mul1), force_split, slabs, ctypes.byref(S), _stream(R)))
+    return [int(s) if s else 0 for s in slabs], S.value
 
 
 def exl3_gemv_ex_wpc(A, Bs, suhs, m: int, mcg: bool, mul1: bool, cpw: int, force_split: int = 0):

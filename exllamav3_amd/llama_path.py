@@ -289,6 +289,8 @@ class SyntheticEXL3Llama:
         self.rope_cos = torch.empty((bsz, 64), dtype=f32, device=dev)
         self.kv_slots = torch.empty((bsz,), dtype=torch.long, device=dev)
         self.xs_d = torch.empty((bsz, nb_i), dtype=f32, device=dev)
+        # decode_step_fx: the residual stream as a 64-bit fixed-point accumulator (value * 2^32)
+        self.R = torch.zeros((bsz, s.hidden), dtype=torch.int64, device=dev)
         self._state_bsz = bsz
 
     # ---- one decode step (bsz tokens, one per sequence) -----------------------------------------------
@@ -589,6 +591,56 @@ class SyntheticEXL3Llama:
                                   bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
         return self.logits
 
+    def decode_step_fx(self):
+        """Decode step with the residual stream in a fixed-point accumulator (round 3): 6 launches per layer at batch <= 4, TP = 1 --
+        q|k|v [reads R, RMSNorm inside], glue_qkv_rs, o_proj [adds into R], gate|up [reads R], glue_act_rs, down_proj [adds into R].
+        o_proj / down_proj finish their own outputs (the output Hadamard is linear, so every split-k workgroup applies it and svh to its partial
+        rows) and ADD them into R with integer atomics (order-independent: bit-reproducible); the two split-k-reduce + residual launches of the glue
+        pipeline (glue_resid, 4.7 us each for < 100 KB) disappear.  A consumer normalises with the PREVIOUS residual's 1/rms (the sums of squares of
+        the residual it reads are only complete once it has read every block: its column-block-0 workgroups publish them) and glue_qkv_rs /
+        glue_act_rs multiply by r_new / r_prev -- decode_step_resid's protocol without its redundant slab reduction.  The fp16 residual of the
+        reference (rounded after every add, norm.cu:193-218) is kept at higher precision here.  Other configurations take decode_step_fused."""
+        bsz = self._state_bsz
+        same = all(_same_kind(L["q"], L["k"], L["v"]) and _same_kind(L["gate"], L["up"]) for L in self.layers)
+        if self.tp != 1 or bsz > 4 or not same:
+            return self.decode_step_fused()
+        sp, hd, hidden = self.split, self.shape.head_dim, self.shape.hidden
+        ROT, DEF, ATOM = ext.GEMV_IN_ROTATED, ext.GEMV_OUT_DEFERRED, ext.GEMV_OUT_ATOMIC
+        R = self.R
+        sc, so_ = self.ss, self.ss2                                       # sums of squares: current (complete) / the buffer the next reader fills
+        q2 = self.q.view(bsz, -1)
+        tab = self._qkv_tab()
+        ext.fx_init(self.x0, R, sc, bsz)
+        for li, L in enumerate(self.layers):
+            lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
+            kc, ks = self.kcache[li]
+            vc, vs = self.vcache[li]
+            slabs, S = ext.exl3_gemv_ex_fx(R, L["norm1"], sc, so_, self.eps, [lq.trellis, lk.trellis, lv.trellis], [lq.suh, lk.suh, lv.suh],
+                                           bsz, lq.mcg, lq.mul1, sp["qkv"])
+            ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                            self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, so_, hidden, self.eps, tab=tab)
+            sc, so_ = so_, sc
+            o_in = q2
+            if self.with_attention and hd in (64, 128):
+                ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
+                                       self.attn_pos + 1, workspace=self.attn_ws)
+                o_in = self.attn_out.view(bsz, -1)
+            ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], [R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM, sp["o"])
+            sgu, Sgu = ext.exl3_gemv_ex_fx(R, L["norm2"], sc, so_, self.eps, [lg.trellis, lu.trellis], [lg.suh, lu.suh], bsz, lg.mcg, lg.mul1, sp["gu"])
+            ext.glue_act_rs(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz, sc, so_, hidden, self.eps)
+            sc, so_ = so_, sc
+            ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [R], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT | ATOM, sp["down"])
+        ext.fx_finish(R, self.x, sc, bsz)                                 # fp16 residual + its sums of squares for the final norm
+        self.x_final = self.x
+        if self.rotate_for_head:
+            ext.glue_rotate(self.x, sc, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz, xsums=self.xs3[:1])
+            ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
+                             bsz, self.lm_head.mcg, self.lm_head.mul1, ROT)
+        else:
+            ext.exl3_gemv_ex_norm(self.x, self.final_norm, sc, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
+                                  bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
+        return self.logits
+
     def decode_step_fused_v1(self):
         """First-generation glue pipeline: RMSNorm + input Hadamards in a single-workgroup glue_norm launch (kept as the
         comparison baseline for decode_step_fused; same bits)."""
@@ -685,7 +737,7 @@ class SyntheticEXL3Llama:
         if pipeline is True: pipeline = "glue"
         if pipeline is False: pipeline = "unfused"
         if self.tp != 1 and pipeline == "tail": pipeline = "glue"
-        if pipeline == "resid" and (self.tp != 1 or self._state_bsz > 4): pipeline = "glue"
+        if pipeline in ("resid", "fx") and (self.tp != 1 or self._state_bsz > 4): pipeline = "glue"
         bsz, hd = self._state_bsz, self.shape.head_dim
         q2, k2, v2 = self.q.view(bsz, -1), self.k.view(bsz, -1), self.v.view(bsz, -1)
         ROT, DEF = ext.GEMV_IN_ROTATED, ext.GEMV_OUT_DEFERRED
@@ -708,6 +760,13 @@ class SyntheticEXL3Llama:
                 calls.append(lambda ld=ld, lq=lq, lk=lk, lv=lv, L=L: ext.exl3_gemv_norm(
                     None, self.xh_d, self.xs_d, ld.trellis, None, ld.svh, None, bsz, ld.mcg, ld.mul1, self.x, L["norm1"], self.eps,
                     [lq.suh, lk.suh, lv.suh], self.xh3, self.xs3))
+            elif pipeline == "fx" and self.tp == 1 and bsz <= 4:
+                # decode_step_fx's four GEMV launches per layer (the atomic ones keep adding into R: timing only)
+                ATOM = ext.GEMV_OUT_ATOMIC
+                calls.append(lambda lq=lq, lk=lk, lv=lv, L=L: ext.exl3_gemv_ex_fx(self.R, L["norm1"], self.ss, self.ss2, self.eps, [lq.trellis, lk.trellis, lv.trellis], [lq.suh, lk.suh, lv.suh], bsz, lq.mcg, lq.mul1))
+                calls.append(lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], [self.R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM))
+                calls.append(lambda lg=lg, lu=lu, L=L: ext.exl3_gemv_ex_fx(self.R, L["norm2"], self.ss, self.ss2, self.eps, [lg.trellis, lu.trellis], [lg.suh, lu.suh], bsz, lg.mcg, lg.mul1))
+                calls.append(lambda ld=ld: ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.R], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT | ATOM))
             elif pipeline == "resid" and self.tp == 1 and bsz <= 4:
                 # decode_step_resid's four GEMV launches per layer; producer slabs of one sample launch each stand in for the chain (timing only)
                 sp, hidden = self.split, self.shape.hidden
@@ -755,7 +814,7 @@ class SyntheticEXL3Llama:
                 calls.append(lambda ld=ld: ld.bc.run(self.a, self.d))
         if pipeline == "glue" and self.tp == 1 and bsz > 4:
             calls.append(lambda: ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, ROT))
-        elif pipeline == "glue" and self.tp == 1:
+        elif pipeline in ("glue", "fx") and self.tp == 1:
             calls.append(lambda: ext.exl3_gemv_ex_norm(self.x, self.final_norm, self.ss, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, 0))
         elif pipeline == "tail" and self.tp == 1:
             calls.append(lambda: ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh], bsz, self.lm_head.mcg, self.lm_head.mul1, ROT))

@@ -119,6 +119,10 @@ int exl3_set_gemv_defer_wg_per_cu(int workgroups_per_cu);      /* deferred-epilo
  * *S_out the split count.  Arrays are host arrays of `count` (<= 4) entries. */
 #define EXL3_GEMV_IN_ROTATED   1
 #define EXL3_GEMV_OUT_DEFERRED 2
+#define EXL3_GEMV_OUT_ATOMIC   32  /* m <= 4: Cs[i] is a 64-bit fixed-point accumulator int64 [m][n] (value * 2^32, the residual stream of the "fx" decode
+                                      pipeline below); every workgroup ADDS its split-k share of the finished rows (out-Hadamard * svh, + bias once) with
+                                      integer atomics: no split-k reduce, no residual launch, bit-reproducible (integer addition is associative).  Replaces
+                                      the gemm epilogue + `x += y` of the reference's decode graph (libtorch/attention.cpp, libtorch/mlp.cpp:14-91) */
 int exl3_gemv_ex(const void* A, const void* const* xhs, const float* const* xsums, const void* const* Bs, void* const* Cs,
                  const void* const* suhs, const void* const* svhs, const void* const* biases, const int* ns, int count,
                  int m, int k, int K, int cb, int c_fp32, int flags, int force_split, float** slabs_out, int* S_out, void* stream);
@@ -217,6 +221,18 @@ int exl3_glue_rotate(const void* resid, const float* ss_part, const void* w, flo
 int exl3_gemv_ex_resid(const void* resid_in, const void* norm_w, const float* ss_prev, float eps, const float* prod_slabs, int prod_S,
                        const void* prod_svh, void* resid_out, float* ss_out, const void* const* Bs, const void* const* suhs, const int* ns,
                        int count, int m, int k, int K, int cb, int cpw, int force_split, float** slabs_out, int* S_out, void* stream);
+/* ---- "fx" decode pipeline (m <= 4, one rank): the residual stream is a fixed-point accumulator R int64 [m][hidden] (value * 2^32) -------------------
+ * exl3_fx_init: R = x (fp16) and ss [m][hidden/128] = block sums of squares of x.   exl3_fx_finish: x = fp16(R / 2^32) (x may be NULL), ss of it.
+ * exl3_gemv_ex(..., EXL3_GEMV_OUT_ATOMIC, Cs = {R}): o_proj / down_proj add their rows into R (see the flag).
+ * exl3_gemv_ex_fx: exl3_gemv_ex_norm reading R.  The RMSNorm scale it applies is the PREVIOUS residual's (ss_prev, complete); the sums of squares of R
+ * itself go to ss_out (!= ss_prev), and the consumer of this launch's deferred slabs multiplies by r_new / r_prev (exl3_glue_qkv_rs, exl3_glue_act_rs,
+ * exl3_gemv_ex_act_rs) -- the protocol of exl3_gemv_ex_resid, same rounding point.  5-6 launches per Llama layer instead of 7-8: neither the split-k
+ * reduce nor rms_norm_res_in's residual add (norm.cu:193-218) is a launch any more. */
+int exl3_fx_init(const void* x, void* R, float* ss, int m, int hidden, void* stream);
+int exl3_fx_finish(const void* R, void* x, float* ss, int m, int hidden, void* stream);
+int exl3_gemv_ex_fx(const void* R, const void* norm_w, const float* ss_prev, float* ss_out, float eps, const void* const* Bs,
+                    const void* const* suhs, const int* ns, int count, int m, int k, int K, int cb, int force_split,
+                    float** slabs_out, int* S_out, void* stream);
 /* exl3_gemv_ex (raw input, deferred output, m <= 4) in the wave-per-column-block layout used by the three launches above and below: `cpw` (1..16)
  * column blocks of ONE matrix per workgroup, each wave streams the whole k-slice of its column block and writes its own slab.  The fused
  * prologues then re-read the producer's slabs once per cpw column blocks instead of once per column block. */

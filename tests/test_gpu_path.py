@@ -927,6 +927,87 @@ def test_resid_in_gemv_pipeline_with_large_residual_scale_change(dev):
     assert np.abs(lr - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
 
 
+@pytest.mark.parametrize("cb,K", [(2, 4), (0, 3), (1, 5)])
+@pytest.mark.parametrize("bsz", [1, 3, 4])
+def test_fixed_point_residual_pipeline_matches_oracle_and_glue_pipeline(dev, cb, bsz, K):
+    """decode_step_fx (round 3; 6 launches per layer: o_proj / down_proj add their rows into a 64-bit fixed-point residual accumulator with integer
+    atomics, q|k|v / gate|up read it and normalise with the previous residual's 1/rms, glue_qkv_rs / glue_act_rs correct) against the oracle and the
+    glue pipeline; the residual it leaves equals the glue pipeline's to fp16 rounding; the KV append lands in the same slots; it is bit-reproducible
+    across repetitions (integer atomics commute) and under hipGraph replay."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_variant(1)
+    shape = LlamaShape("tiny", 512, 1024, 3, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=K, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(bsz, pos=700)
+    lf = model.decode_step_fused().float().cpu().numpy().copy()
+    xf = model.x.float().cpu().numpy().copy()
+    kf = [(kc.clone(), ks.clone()) for kc, ks in model.kcache]
+    for kc, ks in model.kcache + model.vcache:
+        kc.zero_(); ks.zero_()
+    lr = model.decode_step_fx().float().cpu().numpy().copy()
+    assert np.isfinite(lr).all()
+    ref = _oracle_decode(model, _np(model.x0))
+    rms = np.sqrt((ref ** 2).mean())
+    assert np.abs(lr - ref).max() / rms < 3e-2
+    assert np.abs(lr - lf).max() / rms < 1.5e-2
+    xr = model.x_final.float().cpu().numpy()
+    assert np.abs(xr - xf).max() / np.sqrt((xf ** 2).mean()) < 1e-2
+    for (kc, ks), (kc0, ks0) in zip(model.kcache, kf):
+        assert bool(((ks != 0) == (ks0 != 0)).all())
+        assert float((ks.float() - ks0.float()).abs().max()) <= 0.02 * float(ks0.float().abs().max()) + 1e-3
+    for _ in range(5):                                       # atomics in any arrival order: the same bits every time
+        assert np.array_equal(model.decode_step_fx().float().cpu().numpy(), lr)
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            model.decode_step_fx()
+    for _ in range(3):
+        model.logits.zero_(); g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(model.logits.float().cpu().numpy(), lr)
+
+
+def test_fixed_point_residual_pipeline_scale_change_large_values_and_bias(dev):
+    """(a) a residual 50x smaller than the sublayer outputs (the 1/rms estimate is far off); (b) residual values in the hundreds (fixed point: no
+    overflow, no loss); (c) GEMV_OUT_ATOMIC with a bias on a 3-slice split: the bias is added exactly once."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 512, 1024, 2, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(1, pos=100)
+    for scale in (0.02, 400.0):
+        model.x0.copy_(torch.randn_like(model.x0.float()).mul_(scale).half())
+        lr = model.decode_step_fx().float().cpu().numpy().copy()
+        ref = _oracle_decode(model, _np(model.x0))
+        assert np.abs(lr - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2, scale
+    # (c) one linear with bias into an accumulator that already holds a residual
+    k, n, m, K = 768, 256, 2, 4
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rng = np.random.default_rng(3)
+    tr, su, sv = o.synth_linear(k, n, K, seed=8, realistic=True)
+    bias = (rng.standard_normal(n) * 0.3).astype(np.float16)
+    x = rng.standard_normal((m, k)).astype(np.float16)
+    r0 = (rng.standard_normal((m, n)) * 2).astype(np.float16)
+    R = torch.zeros((m, n), dtype=torch.int64, device=dev); ss = torch.empty((m, n // 128), dtype=torch.float32, device=dev)
+    ext.fx_init(T(r0), R, ss, m)
+    import ctypes
+    gemv_ex = ext._lib.lib().exl3_gemv_ex                   # the C entry point: the Python wrapper has no bias argument
+    trd, sud, svd, bd, xd = T(tr), T(su), T(sv), T(bias), T(x)
+    Bs = (ctypes.c_void_p * 1)(trd.data_ptr()); Cs = (ctypes.c_void_p * 1)(R.data_ptr()); su_ = (ctypes.c_void_p * 1)(sud.data_ptr())
+    sv_ = (ctypes.c_void_p * 1)(svd.data_ptr()); bi_ = (ctypes.c_void_p * 1)(bd.data_ptr()); ns = (ctypes.c_int * 1)(n)
+    Sout = ctypes.c_int(0); slabs = (ctypes.c_void_p * 1)()
+    rc = gemv_ex(xd.data_ptr(), None, None, Bs, Cs, su_, sv_, bi_, ns, 1, m, k, K, 2, 0, ext.GEMV_OUT_ATOMIC, 3, slabs, ctypes.byref(Sout), None)
+    assert rc >= 0 and Sout.value == 3
+    out = torch.empty((m, n), dtype=torch.half, device=dev)
+    ext.fx_finish(R, out, ss, m)
+    y = o.linear_forward(x, tr, su, sv, K, 2, bias=bias, out_fp32=True).astype(np.float32)
+    ref = (r0.astype(np.float32) + y)
+    assert np.abs(out.float().cpu().numpy() - ref).max() / np.sqrt((y ** 2).mean()) < 1e-2
+    assert np.allclose(ss.cpu().numpy(), (out.float().cpu().numpy().reshape(m, -1, 128) ** 2).sum(-1), rtol=1e-4)
+
+
 @pytest.mark.parametrize("hd,hq,hkv", [(128, 4, 2), (64, 8, 4)])
 @pytest.mark.parametrize("bsz", [1, 3, 16])
 def test_per_step_rope_and_slot_tables_are_bit_identical_to_in_kernel_computation(dev, hd, hq, hkv, bsz):
