@@ -57,8 +57,10 @@ def parse():
     ap.add_argument("--attention", action="store_true", help="include decode attention over the quantized KV cache (context = 1000 tokens) in the timed step")
     ap.add_argument("--unfused", action="store_true", help="one launch per reference op instead of the fused pipeline")
     ap.add_argument("--pipeline", choices=["tail", "glue", "resid", "fx", "unfused"], default="glue",
-                    help="glue: deferred-epilogue GEMVs + glue kernels (8 launches/layer, fastest measured); tail: sublayer boundaries run "
-                         "inside the GEMV launches (4 launches/layer; the in-kernel cross-workgroup hand-off through memory costs more than a launch)")
+                    help="fx (default; batch <= 4 on one rank, otherwise = glue): residual stream in a 64-bit fixed-point accumulator, o_proj / "
+                         "down_proj add into it with integer atomics, 6 launches/layer (fastest measured); glue: deferred-epilogue GEMVs + glue kernels "
+                         "(8 launches/layer); tail: sublayer boundaries run inside the GEMV launches (4 launches/layer; the in-kernel cross-workgroup "
+                         "hand-off through memory costs more than a launch)")
     return ap.parse_args()
 
 
@@ -509,22 +511,22 @@ def main():
         extra = {}
         # config 3, bs 16 (generation-3 GEMM + glue_rotate route)
         model.alloc_state(16)
-        extra["llama-3.1-8b_bs16"] = timed_decode(model, model.decode_step_fused, 16)
+        extra["llama-3.1-8b_bs16"] = timed_decode(model, model.decode_step_fx if pipeline == "fx" else model.decode_step_fused, 16)
         # bs 1 with the quant-cache-direct decode attention over a 1000-token context in the step
         model.alloc_state(1)
         model.with_attention = True
-        extra["llama-3.1-8b_bs1_with_attention_ctx1000"] = timed_decode(model, model.decode_step_fused, 1)
+        extra["llama-3.1-8b_bs1_with_attention_ctx1000"] = timed_decode(model, model.decode_step_fx if pipeline == "fx" else model.decode_step_fused, 1)
         model.with_attention = False
         # bs 1 with the EXACT GEMV variant (MFMA operands = the reference's fp16-rounded weights bit for bit; the headline runs the default variant,
         # unrounded lo + hi / raw byte sums, inside the same 1e-2 bound)
         if args.variant != 0:
             ext.set_gemv_variant(0)
-            extra["llama-3.1-8b_bs1_gemv_variant0_exact"] = timed_decode(model, model.decode_step_fused, 1)
+            extra["llama-3.1-8b_bs1_gemv_variant0_exact"] = timed_decode(model, model.decode_step_fx if pipeline == "fx" else model.decode_step_fused, 1)
             ext.set_gemv_variant(args.variant)
         # config 2: Llama-3.2-1B, bs 1
         m1 = SyntheticEXL3Llama(SHAPES["llama-3.2-1b"], K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits)
         m1.alloc_state(1)
-        extra["llama-3.2-1b_bs1"] = timed_decode(m1, m1.decode_step_fused, 1)
+        extra["llama-3.2-1b_bs1"] = timed_decode(m1, m1.decode_step_fx if pipeline == "fx" else m1.decode_step_fused, 1)
         del m1
         torch.cuda.empty_cache()
         # config 5 on one GPU: Mixtral 8x7B (23 GB of packed weights), bs 1, 4-bit KV; `--gpus 2 --model mixtral-8x7b` runs it TP = 2 / EP = 2

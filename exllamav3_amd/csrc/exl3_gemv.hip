@@ -439,7 +439,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         {
             const int ng = mp <= 4 ? 1 : (mp <= 8 ? 2 : 4);
             const bool rot_pass = (pass_flags & GEMV_IN_ROTATED) != 0;
-            bool g4 = gemv_gen4() && ng == 1 && !tbl && !epi && cpw == 0 && !rsd && !(act_rs && act_rs->ss_new) && bps <= 32;
+            bool g4 = gemv_gen4() && ng == 1 && !tbl && !epi && cpw == 0 && !rsd && bps <= 32;
             if (g4 && rot_pass && var == 1 && cb == 2)
                 for (int i = 0; i < count; ++i) if (!args.mat[i].xsum) g4 = false;      // the mul1 FAST variant needs the producer's block sums
             if (g4)
@@ -801,7 +801,7 @@ extern "C" int exl3_gemv_ex_act_rs(const float* g_slabs, const float* u_slabs, i
     int ns[1] = { n };
     GemvRescale rs = { ss_prev, ss_new, hidden, eps };
     return run_mgemm(nullptr, Bs, C ? Cs : nullptr, su, svh ? sv : nullptr, bi, ns, 1, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream,
-                     (flags & GEMV_OUT_DEFERRED), nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
+                     (flags & (GEMV_OUT_DEFERRED | GEMV_OUT_ATOMIC)), nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
                      g_slabs, u_slabs, act_S, svh_g, svh_u, nullptr, &rs, cpw);
 }
 
@@ -813,6 +813,6 @@ extern "C" int exl3_gemv_ex_act(const float* g_slabs, const float* u_slabs, int 
     const void* Bs[1] = { B }; void* Cs[1] = { C }; const void* su[1] = { suh }; const void* sv[1] = { svh }; const void* bi[1] = { bias };
     int ns[1] = { n };
     return run_mgemm(nullptr, Bs, C ? Cs : nullptr, su, svh ? sv : nullptr, bi, ns, 1, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream,
-                     (flags & GEMV_OUT_DEFERRED), nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
+                     (flags & (GEMV_OUT_DEFERRED | GEMV_OUT_ATOMIC)), nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
                      g_slabs, u_slabs, act_S, svh_g, svh_u);
 }

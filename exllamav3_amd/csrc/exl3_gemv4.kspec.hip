@@ -172,11 +172,11 @@ void exl3_gemv4_kernel(const GemvArgs a)
     const int last_unit = ubase + (nun > 0 ? nun - 1 : 0);
 
     // ---- preparation tasks (raw / norm / act input): task t = (block t / m, row t % m), one per half-wave; only waves that own a task run them
-    struct PrepIn { half4_t xv, sv, wv; float ss; uint4_t f0, f1; };
+    struct PrepIn { half4_t xv, sv, wv; float ss, ssn; uint4_t f0, f1; };
     const int ntask = nb * m;
     auto fetch = [&] (int it) -> PrepIn
     {
-        PrepIn r; r.xv = half4_t{ 0, 0, 0, 0 }; r.sv = r.xv; r.wv = r.xv; r.ss = 0.0f;
+        PrepIn r; r.xv = half4_t{ 0, 0, 0, 0 }; r.sv = r.xv; r.wv = r.xv; r.ss = 0.0f; r.ssn = 0.0f;
         const int t = min(it * nhw + hwid, ntask - 1);
         const int blk = gemv_udiv(t, mg_m), row = t - blk * m;
         const size_t kofs = (size_t) k0s + 128 * blk;
@@ -187,6 +187,16 @@ void exl3_gemv4_kernel(const GemvArgs a)
             r.f0 = fp[0]; r.f1 = fp[1];
         }
         r.sv = ((const half4_t*) (suh + kofs))[l32];
+        if constexpr (MODE == G4_MODE_ACT)
+        {
+            // gate / up came from a launch that normalised with the previous residual's 1/rms (GEMV_IN_RESID / GEMV_IN_FX): the first 32 block sums
+            // of squares of both residuals travel with the task (gemv_rescale)
+            if (a.act_rs.ss_new)
+            {
+                const int nbh = a.act_rs.k >> 7;
+                if (l32 < nbh) { r.ss = a.act_rs.ss_prev[(size_t) row * nbh + l32]; r.ssn = a.act_rs.ss_new[(size_t) row * nbh + l32]; }
+            }
+        }
         if constexpr (MODE == G4_MODE_NORM || MODE == G4_MODE_NORMFX)
         {
             r.wv = ((const half4_t*) (a_norm_w + kofs))[l32];
@@ -201,11 +211,20 @@ void exl3_gemv4_kernel(const GemvArgs a)
     // first weight rows: requested after the first task's (small, L2-resident) operands so that the task computes underneath the HBM latency
     constexpr int PFU = G4_PFU(K), NR = 2 * PFU;
     LaneWords<K> ring[NR];
+#ifdef G4_ABL_PREP_FIRST
+    // experiment: a wave that owns a preparation task requests its weight rows only after the task's operands have arrived
+    if constexpr (IN_LDS) { if (prep_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+#ifdef G4_ABL_ONE_ROW
+    // experiment: only the first row before the preparation barrier (half the initial burst of weight requests); the second after it
+    if (nun > 0) load_lane_words<K>(ring[0], strip + (size_t) (2 * ubase) * row_stride);
+#else
     if (nun > 0)
     {
         #pragma unroll
         for (int u = 0; u < NR; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(2 * ubase + u, 2 * last_unit + 1) * row_stride);
     }
+#endif
     G4_T(1);
 
     // ---- activation quads of this wave's first group
@@ -241,6 +260,9 @@ void exl3_gemv4_kernel(const GemvArgs a)
     if constexpr (!IN_LDS)
     {
         xh_lane = a.mat[mi].xh + (size_t) gi * a_k + k0s + 2 * (gq & 3);
+#ifdef G4_ABL_ONE_ROW
+        if (nun > 0) load_lane_words<K>(ring[1], strip + (size_t) (2 * ubase + 1) * row_stride);
+#endif
         agn = load_group(2 * ubase);
     }
     else quad_lane = (gq * m + gi) * 8;
@@ -282,6 +304,11 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     float g0, g1, g2, g3, u0, u1, u2, u3;
                     out_had(vg, l32, g0, g1, g2, g3);
                     out_had(vu, l32, u0, u1, u2, u3);
+                    if (a.act_rs.ss_new)
+                    {
+                        const float rsc = gemv_rescale(a.act_rs, row, l32, cur.ss, cur.ssn);        // r_new / r_prev of the row
+                        g0 *= rsc; g1 *= rsc; g2 *= rsc; g3 *= rsc; u0 *= rsc; u1 *= rsc; u2 *= rsc; u3 *= rsc;
+                    }
                     const half4_t gh = half4_t{ f2h(g0), f2h(g1), f2h(g2), f2h(g3) } * svg;
                     const half4_t uh = half4_t{ f2h(u0), f2h(u1), f2h(u2), f2h(u3) } * svu;
                     auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
@@ -346,6 +373,9 @@ void exl3_gemv4_kernel(const GemvArgs a)
             }
         }
         __syncthreads();
+#ifdef G4_ABL_ONE_ROW
+        if (nun > 0) load_lane_words<K>(ring[1], strip + (size_t) (2 * ubase + 1) * row_stride);
+#endif
         agn = load_group(2 * ubase);
     }
 

@@ -353,6 +353,8 @@ class SyntheticEXL3Llama:
 
     #: m <= 4: finish silu(g) * u inside the down GEMV instead of a glue_act launch
     act_in_gemv = os.environ.get("EXL3_HIP_ACT_IN_GEMV", "1") != "0"
+    #: decode_step_fx: silu(g) * u inside the down launch (5 launches per layer) instead of glue_act_rs + rotated-input down (6)
+    fx_act_in_gemv = os.environ.get("EXL3_HIP_FX_ACT_IN_GEMV", "0") != "0"
 
     #: forced split-k factor per call type of the fused pipelines (0 = library heuristic); tools/sweep_split.py tunes these
     split = {"qkv": 0, "o": 0, "gu": 0, "down": 0}
@@ -627,6 +629,12 @@ class SyntheticEXL3Llama:
                 o_in = self.attn_out.view(bsz, -1)
             ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], [R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM, sp["o"])
             sgu, Sgu = ext.exl3_gemv_ex_fx(R, L["norm2"], sc, so_, self.eps, [lg.trellis, lu.trellis], [lg.suh, lu.suh], bsz, lg.mcg, lg.mul1, sp["gu"])
+            if self.fx_act_in_gemv:
+                # silu(g) * u (with the row-scale correction) + input Hadamard inside the down launch: 5 launches per layer
+                ext.exl3_gemv_ex_act_rs(sgu, Sgu, lg.svh, lu.svh, sc, so_, hidden, self.eps, ld.trellis, R, ld.suh, ld.svh, bsz, ld.mcg, ld.mul1,
+                                        ATOM, sp["down"])
+                sc, so_ = so_, sc
+                continue
             ext.glue_act_rs(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz, sc, so_, hidden, self.eps)
             sc, so_ = so_, sc
             ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [R], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT | ATOM, sp["down"])

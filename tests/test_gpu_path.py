@@ -958,6 +958,12 @@ def test_fixed_point_residual_pipeline_matches_oracle_and_glue_pipeline(dev, cb,
         assert float((ks.float() - ks0.float()).abs().max()) <= 0.02 * float(ks0.float().abs().max()) + 1e-3
     for _ in range(5):                                       # atomics in any arrival order: the same bits every time
         assert np.array_equal(model.decode_step_fx().float().cpu().numpy(), lr)
+    # 5 launches per layer: silu(g) * u (row-scale corrected) inside the down launch instead of glue_act_rs
+    model.fx_act_in_gemv = True
+    la = model.decode_step_fx().float().cpu().numpy().copy()
+    assert np.isfinite(la).all() and np.abs(la - ref).max() / rms < 3e-2 and np.abs(la - lr).max() / rms < 1e-2
+    assert np.array_equal(model.decode_step_fx().float().cpu().numpy(), la)
+    model.fx_act_in_gemv = False
     st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
         g = torch.cuda.CUDAGraph()
