@@ -240,3 +240,113 @@ extern "C" int exl3_routing_std_norm(const void* resid, const void* norm_w, cons
                                                                                           num_experts, K, gu_slots, bsz, nrm);
     return exl3_check_launch("routing_std_norm");
 }
+
+// ------------------------------------------------------------------------------------------------
+// exl3_moe (quant/exl3_moe.cu:99-301) without a host round trip: the slot list of the indexed launches is built ON THE DEVICE from expert_count /
+// token_sorted, with shapes that depend only on the tensor sizes, so the whole op can be captured in a hipGraph (round 2 built the list on the host
+// from expert_count.tolist(): one device -> host sync per call).
+//   slot j (j < ns_max = min(E, T) + T / m): up to m consecutive assignments of ONE expert e with 0 < count[e] <= max_rows, or unused:
+//     slot_expert[j] = e | -1 (the indexed exl3_mgemm launches skip negative entries), slot_tok[j][r] = token of row r (rows past the chunk repeat its
+//     last assignment: computed and dropped), rowmap[p] = j * m + r for assignment p of an accepted expert, -1 otherwise.
+// One workgroup; expert e's slots start at the exclusive prefix sum of the chunk counts (reference: the expert tickets of exl3_moe_kernel.cuh:17-283).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void moe_build_slots_kernel(const int64_t* __restrict__ expert_count, const int64_t* __restrict__ token_sorted, int E, int T, int max_rows, int m,
+                            int ns_max, int64_t* __restrict__ slot_expert, int64_t* __restrict__ slot_tok, int32_t* __restrict__ rowmap)
+{
+    __shared__ int cnt_s[ROUTING_MAX_EXPERTS], off_s[ROUTING_MAX_EXPERTS], base_s[ROUTING_MAX_EXPERTS];
+    __shared__ int total_s;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < E; e += 256) cnt_s[e] = (int) expert_count[e];
+    for (int p = tid; p < T; p += 256) rowmap[p] = -1;
+    __syncthreads();
+    if (tid == 0)
+    {
+        int off = 0, base = 0;
+        for (int e = 0; e < E; ++e)
+        {
+            const int c = cnt_s[e];
+            off_s[e] = off; base_s[e] = base;
+            off += c;
+            if (c > 0 && c <= max_rows) base += (c + m - 1) / m;
+        }
+        total_s = base;
+    }
+    __syncthreads();
+    const int total = total_s;
+    for (int j = total + tid; j < ns_max; j += 256)
+    {
+        slot_expert[j] = -1;
+        for (int r = 0; r < m; ++r) slot_tok[(size_t) j * m + r] = 0;
+    }
+    for (int e = tid; e < E; e += 256)
+    {
+        const int c = cnt_s[e];
+        if (c <= 0 || c > max_rows) continue;
+        const int off = off_s[e];
+        for (int ch = 0, j = base_s[e]; ch * m < c && j < ns_max; ++ch, ++j)
+        {
+            const int n = min(m, c - ch * m);
+            slot_expert[j] = e;
+            for (int r = 0; r < m; ++r)
+            {
+                const int p = off + ch * m + min(r, n - 1);
+                slot_tok[(size_t) j * m + r] = p < T ? token_sorted[p] : 0;
+                if (r < n && p < T) rowmap[p] = j * m + r;
+            }
+        }
+    }
+}
+
+// out[t] += sum over the token's assignments p (ascending p: a fixed order, so the result is bit-reproducible; index_add_ / atomics are not)
+// of weight[p] * D[rowmap[p]].  One workgroup per token; 4 columns per thread per pass.
+__global__ __launch_bounds__(256)
+void moe_scatter_kernel(const float* __restrict__ D, const int32_t* __restrict__ rowmap, const int64_t* __restrict__ token_sorted,
+                        const half_t* __restrict__ weight_sorted, float* __restrict__ out, int T, int hidden)
+{
+    __shared__ int list_s[64];
+    __shared__ int n_s;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) n_s = 0;
+    __syncthreads();
+    for (int p = tid; p < T; p += 256)
+        if (token_sorted[p] == t && rowmap[p] >= 0) { const int i = atomicAdd(&n_s, 1); if (i < 64) list_s[i] = p; }
+    __syncthreads();
+    const int n = min(n_s, 64);
+    if (n == 0) return;
+    if (tid == 0)
+        for (int i = 1; i < n; ++i) { const int v = list_s[i]; int k = i - 1; while (k >= 0 && list_s[k] > v) { list_s[k + 1] = list_s[k]; --k; } list_s[k + 1] = v; }
+    __syncthreads();
+    for (int c = tid * 4; c < hidden; c += 1024)
+    {
+        float4_t acc = *((const float4_t*) (out + (size_t) t * hidden + c));
+        for (int i = 0; i < n; ++i)
+        {
+            const int p = list_s[i];
+            const float w = (float) weight_sorted[p];
+            const float4_t d = *((const float4_t*) (D + (size_t) rowmap[p] * hidden + c));
+            acc.x += d.x * w; acc.y += d.y * w; acc.z += d.z * w; acc.w += d.w * w;
+        }
+        *((float4_t*) (out + (size_t) t * hidden + c)) = acc;
+    }
+}
+
+extern "C" int exl3_moe_build_slots(const int64_t* expert_count, const int64_t* token_sorted, int num_experts, int num_assignments, int max_rows,
+                                    int rows_per_slot, int max_slots, int64_t* slot_expert, int64_t* slot_tok, int32_t* rowmap, void* stream)
+{
+    EXL3_CHECK_ARG(expert_count && token_sorted && slot_expert && slot_tok && rowmap, "moe_build_slots: null pointer");
+    EXL3_CHECK_ARG(num_experts >= 1 && num_experts <= ROUTING_MAX_EXPERTS, "Too many experts");
+    EXL3_CHECK_ARG(num_assignments >= 1 && max_rows >= 1 && rows_per_slot >= 1 && rows_per_slot <= 16 && max_slots >= 1, "moe_build_slots: bad sizes");
+    moe_build_slots_kernel<<<1, 256, 0, (hipStream_t) stream>>>(expert_count, token_sorted, num_experts, num_assignments, max_rows, rows_per_slot,
+                                                               max_slots, slot_expert, slot_tok, rowmap);
+    return exl3_check_launch("moe_build_slots");
+}
+
+extern "C" int exl3_moe_scatter(const float* D, const int32_t* rowmap, const int64_t* token_sorted, const void* weight_sorted, float* out,
+                                int bsz, int num_assignments, int hidden, void* stream)
+{
+    EXL3_CHECK_ARG(D && rowmap && token_sorted && weight_sorted && out, "moe_scatter: null pointer");
+    EXL3_CHECK_ARG(hidden % 4 == 0 && bsz >= 1 && num_assignments >= 1, "moe_scatter: bad sizes");
+    moe_scatter_kernel<<<bsz, 256, 0, (hipStream_t) stream>>>(D, rowmap, token_sorted, (const half_t*) weight_sorted, out, num_assignments, hidden);
+    return exl3_check_launch("moe_scatter");
+}

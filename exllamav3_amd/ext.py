@@ -336,8 +336,9 @@ def exl3_moe(hidden_state, output_state, expert_count, token_sorted, weight_sort
     The reference runs this as ONE persistent cooperative kernel (expert tickets, grid-wide hand-offs between gate|up, activation and down); on
     MI355X an in-kernel grid-wide hand-off costs more than a kernel boundary (DESIGN.md 4.7 e), so the same work is three indexed launches --
     gate and up of all (expert, <= 16-row chunk) slots, then down with silu * mul formed in its prologue -- and a weighted scatter-add.
-    The slot list is built on the host from expert_count / token_sorted (one device -> host copy: not capturable in a graph; the decode-step
-    route for one rank is moe_path.SyntheticEXL3MoE, 4 launches, capturable).  SiLU only; act_limit must be 0."""
+    The slot list is built on the DEVICE (exl3_moe_build_slots: prefix sum over expert_count, <= 16-row chunks, over-limit experts masked), every
+    shape depends on tensor sizes only and the weighted scatter runs in a fixed order: the op has no host round trip, can be captured in a hipGraph
+    and replays bit for bit.  SiLU only; act_limit must be 0."""
     _dev(hidden_state)
     if num_active == 0:
         return
@@ -354,35 +355,29 @@ def exl3_moe(hidden_state, output_state, expert_count, token_sorted, weight_sort
     E = expert_count.shape[0] - 1
     for t in (gate_ptrs_trellis, gate_ptrs_suh, gate_ptrs_svh, up_ptrs_trellis, up_ptrs_suh, up_ptrs_svh, down_ptrs_trellis, down_ptrs_suh, down_ptrs_svh):
         _req(t.dtype == torch.long and t.dim() == 1 and t.shape[0] >= E, "exl3_moe: pointer tables must be int64 with one entry per expert")
-    counts = expert_count[:E].tolist()
-    slot_expert, slot_pos = [], []                               # one slot = up to 16 consecutive assignments of one expert
-    off = 0
-    for e, c in enumerate(counts):
-        if 0 < c <= max_rows:
-            for r0 in range(0, c, MOE_SLOT_ROWS):
-                slot_expert.append(e); slot_pos.append((off + r0, min(MOE_SLOT_ROWS, c - r0)))
-        off += c
-    if not slot_expert:
+    T = token_sorted.shape[0]
+    if T == 0:
         return
-    m = max(n for _, n in slot_pos)
-    ns = len(slot_expert)
+    # Every shape below depends on tensor SIZES only (no expert_count.tolist(), no boolean-mask indexing): the op is capturable in a hipGraph.
+    # The slot list -- one slot = up to m consecutive assignments of one accepted expert -- is built on the device (exl3_moe_build_slots); unused
+    # slots carry expert -1 and are skipped by the indexed launches; padded rows repeat an assignment and are never scattered (rowmap).
+    m = min(MOE_SLOT_ROWS, max_rows, T)
+    ns = min(E, T) + T // m
     dev = hidden_state.device
-    pos = torch.zeros((ns, m), dtype=torch.long)
-    valid = torch.zeros((ns, m), dtype=torch.bool)
-    for j, (p0, n) in enumerate(slot_pos):
-        pos[j, :n] = torch.arange(p0, p0 + n); valid[j, :n] = True
-    pos, valid = pos.to(dev).view(-1), valid.to(dev).view(-1)
-    tok = token_sorted.index_select(0, pos)                       # padded rows repeat an assignment; they are dropped before the scatter
-    A = hidden_state.index_select(0, tok).view(ns, m, hidden)
-    idx = torch.tensor(slot_expert, dtype=torch.long, device=dev)
+    slot_expert = torch.empty((ns,), dtype=torch.long, device=dev)
+    slot_tok = torch.empty((ns * m,), dtype=torch.long, device=dev)
+    rowmap = torch.empty((T,), dtype=torch.int32, device=dev)
+    st = _stream(hidden_state)
+    _check(_lib.lib().exl3_moe_build_slots(_p(expert_count), _p(token_sorted), E, T, max_rows, m, ns, _p(slot_expert), _p(slot_tok), _p(rowmap), st))
+    A = hidden_state.index_select(0, slot_tok).view(ns, m, hidden)
     G = torch.empty((ns, m, inter), dtype=torch.half, device=dev)
     U = torch.empty_like(G)
-    exl3_mgemm(A, gate_ptrs_trellis, G, gate_ptrs_suh, None, gate_ptrs_svh, idx, None, K_gate, -1, gate_mcg, gate_mul1, -1, -1, 0)
-    exl3_mgemm(A, up_ptrs_trellis, U, up_ptrs_suh, None, up_ptrs_svh, idx, None, K_up, -1, up_mcg, up_mul1, -1, -1, 0)
+    exl3_mgemm(A, gate_ptrs_trellis, G, gate_ptrs_suh, None, gate_ptrs_svh, slot_expert, None, K_gate, -1, gate_mcg, gate_mul1, -1, -1, 0)
+    exl3_mgemm(A, up_ptrs_trellis, U, up_ptrs_suh, None, up_ptrs_svh, slot_expert, None, K_up, -1, up_mcg, up_mul1, -1, -1, 0)
     D = torch.empty((ns, m, hidden), dtype=torch.float, device=dev)
-    exl3_mgemm_act(G, U, down_ptrs_trellis, D, down_ptrs_suh, down_ptrs_svh, idx, None, K_down, down_mcg, down_mul1)
-    rows = D.view(ns * m, hidden) * weight_sorted.index_select(0, pos).float().unsqueeze(1)
-    output_state.index_add_(0, tok[valid], rows[valid])
+    exl3_mgemm_act(G, U, down_ptrs_trellis, D, down_ptrs_suh, down_ptrs_svh, slot_expert, None, K_down, down_mcg, down_mul1)
+    # weighted scatter in a fixed order per token (bit-reproducible; the round-2 index_add_ was an atomic scatter)
+    _check(_lib.lib().exl3_moe_scatter(_p(D), _p(rowmap), _p(token_sorted), _p(weight_sorted), _p(output_state), bsz, T, hidden, st))
 
 
 def hgemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):

@@ -411,6 +411,16 @@ int exl3_mgemm_indexed_act(const void* G, const void* U, const void* tbl_B, cons
                            const int64_t* indices, const void* weights, int bszm, void* C, int m, int k, int n, int K, int cb, int c_fp32,
                            int min_index, int max_index, int num_tokens, void* stream);
 
+/* exl3_moe (quant/exl3_moe.cu:99-301) pieces that keep the op free of host round trips (capturable): the slot list of its indexed launches is built
+ * on the device.  slot j < max_slots (>= min(E, T) + T / rows_per_slot): slot_expert[j] = expert with 0 < count <= max_rows, or -1 (skipped by the
+ * indexed exl3_mgemm launches); slot_tok [max_slots][rows_per_slot] = token of each row (rows past a chunk repeat its last assignment);
+ * rowmap[p] = j * rows_per_slot + r of assignment p, -1 if its expert is not accepted.  exl3_moe_scatter: out[t] += sum over the token's accepted
+ * assignments, in ascending p, of weight_sorted[p] * D[rowmap[p]] (fp32; fixed order: bit-reproducible, unlike an atomic scatter). */
+int exl3_moe_build_slots(const int64_t* expert_count, const int64_t* token_sorted, int num_experts, int num_assignments, int max_rows,
+                         int rows_per_slot, int max_slots, int64_t* slot_expert, int64_t* slot_tok, int32_t* rowmap, void* stream);
+int exl3_moe_scatter(const float* D, const int32_t* rowmap, const int64_t* token_sorted, const void* weight_sorted, float* out,
+                     int bsz, int num_assignments, int hidden, void* stream);
+
 /* ---- tensor-parallel decode all-reduce: one-shot push over IPC-mapped peer buffers (xGMI), fused with the residual add -------------------------
  * Replaces TPBackendNCCL.all_reduce (model/model_tp_backend.py:119-126) / the native small-message all-reduce (exllamav3_ext/parallel/all_reduce.cu:18-232)
  * for the (tokens x hidden) fp32 partial sums after o_proj / down_proj at decode.  One process per GPU:
