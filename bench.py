@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--attention", action="store_true", help="include decode attention over the quantized KV cache (context = 1000 tokens) in the timed step")
     ap.add_argument("--unfused", action="store_true", help="one launch per reference op instead of the fused pipeline")
-    ap.add_argument("--pipeline", choices=["tail", "glue", "resid", "fx", "unfused"], default="glue",
+    ap.add_argument("--pipeline", choices=["tail", "glue", "resid", "fx", "unfused"], default="fx",
                     help="fx (default; batch <= 4 on one rank, otherwise = glue): residual stream in a 64-bit fixed-point accumulator, o_proj / "
                          "down_proj add into it with integer atomics, 6 launches/layer (fastest measured); glue: deferred-epilogue GEMVs + glue kernels "
                          "(8 launches/layer); tail: sublayer boundaries run inside the GEMV launches (4 launches/layer; the in-kernel cross-workgroup "
