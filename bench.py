@@ -401,7 +401,7 @@ def main():
                     kernel_only["note"] = "NOT measured in this run: average kernel duration of the step's GEMV launches in the committed rocprofv3 stats CSV"
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "exl3_gemv2_kernel (fused trellis decode + Hadamard + MFMA GEMV), all launches of a decode step",
+        roofline = {"bound": "hbm", "kernel": ("exl3_gemv4_kernel" if bsz <= 4 else "exl3_gemm3_kernel") + " (fused trellis decode + Hadamard + MFMA GEMV), all GEMV launches of a decode step",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "kernel_only": kernel_only,
                     "avg_launch_us": round(avg_us, 2), "bytes_per_launch": int(bytes_per_launch),

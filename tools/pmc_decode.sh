@@ -14,10 +14,10 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r.get("Kernel_Name", "")
-        if "exl3_gemv2_kernel" in n or "glue_" in n:
+        if "exl3_gemv2_kernel" in n or "exl3_gemv4_kernel" in n or "glue_" in n:
             acc[n.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {c: round(sum(v) / len(v), 1) for c, v in d.items()} | {"dispatches": max(len(v) for v in d.values())} for k, d in acc.items()}
 json.dump(out, open("$R/gpurun_out/pmc_decode.json", "w"), indent=1)
-for k, d in out.items(): print(k[:60], d.get("SQ_ACTIVE_INST_VALU"), d.get("SQ_BUSY_CYCLES"), d.get("FETCH_SIZE"))
+for k, d in out.items(): print(k[:60], d.get("SQ_INSTS_VALU"), d.get("SQ_INSTS_MFMA"), d.get("SQ_ACTIVE_INST_VALU"), d.get("SQ_BUSY_CYCLES"), d.get("FETCH_SIZE"))
 PY
 rm -rf $O
