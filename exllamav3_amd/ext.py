@@ -392,6 +392,11 @@ def hgemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):
                                  int(c.dtype == torch.float), _stream(a)))
 
 
+#: EXL3_HIP_GEMM_NT=1 routes the prefill GEMMs (hgemm_nt) through the hand-written NT MFMA kernel; default 0: hipBLASLt, which measured 1.2-1.3x
+#: faster on every Llama-3.1-8B prefill shape (profiles/r03_gemm_nt_vs_hipblaslt.json)
+_GEMM_NT_OWN = __import__("os").environ.get("EXL3_HIP_GEMM_NT", "0") == "1"
+
+
 def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: bool = False):
     """c = a @ bt.T (+ c if accumulate): bt is B^T, (n, k) with unit column stride (row stride >= k) -- both operands K-major."""
     _dev(a)
@@ -400,6 +405,11 @@ def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: boo
     _req(a.shape[1] == bt.shape[1] and a.shape[0] == c.shape[0] and bt.shape[0] == c.shape[1], "hgemm_nt: shape mismatch")
     _req(a.stride(1) == 1 and bt.stride(1) == 1 and c.stride(1) == 1, "hgemm_nt: a, bt, c need unit column stride")
     _req(not accumulate or c.dtype == torch.half, "hgemm_nt: accumulate needs a float16 c")
+    if _GEMM_NT_OWN and c.dtype == torch.half and bt.shape[0] % 256 == 0 and a.shape[1] % 64 == 0 and a.stride(0) % 8 == 0 and bt.stride(0) % 8 == 0 \
+            and c.stride(0) % 8 == 0 and a.shape[0] >= 256:
+        # EXL3_HIP_GEMM_NT=1: the hand-written MFMA GEMM (exl3_gemm_nt.hip) instead of hipBLASLt wherever its tile shape applies
+        gemm_nt_mfma(a, bt, c, 1 if accumulate else 0)
+        return
     if a.is_contiguous():
         _check(_lib.lib().exl3_hgemm_nt(_p(a), _p(bt), _p(c), a.shape[0], a.shape[1], bt.shape[0], bt.stride(0), c.stride(0),
                                         int(c.dtype == torch.float), int(accumulate), _stream(a)))
@@ -407,6 +417,16 @@ def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: boo
         # a is a column range of a wider row-major matrix
         _check(_lib.lib().exl3_hgemm_nt_lda(_p(a), a.stride(0), _p(bt), _p(c), a.shape[0], a.shape[1], bt.shape[0], bt.stride(0), c.stride(0),
                                             int(c.dtype == torch.float), int(accumulate), _stream(a)))
+
+
+def gemm_nt_mfma(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, epi: int = 0):
+    """The hand-written NT MFMA GEMM (exl3_gemm_nt.hip): c = a @ bt.T; epi 0 store, 1 c += (fp16 residual add), 2 silu(gate) * up on 128 | 128
+    row pairs of bt (c has bt.shape[0] / 2 columns).  Raises for shapes outside the kernel (k % 64, n % 256)."""
+    _dev(a)
+    _req(a.dtype == torch.half and bt.dtype == torch.half and c.dtype == torch.half and a.dim() == 2 and bt.dim() == 2 and c.dim() == 2, "gemm_nt_mfma: 2-D float16 tensors")
+    _req(a.stride(1) == 1 and bt.stride(1) == 1 and c.stride(1) == 1 and a.shape[1] == bt.shape[1], "gemm_nt_mfma: unit column strides, shared k")
+    _req(c.shape[0] == a.shape[0] and c.shape[1] == (bt.shape[0] // 2 if epi == 2 else bt.shape[0]), "gemm_nt_mfma: output shape")
+    _check(_lib.lib().exl3_gemm_nt_mfma(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(c), c.stride(0), a.shape[0], a.shape[1], bt.shape[0], int(epi), _stream(a)))
 
 
 def reconstruct_had_slice_t(unpacked_t: torch.Tensor, packed: torch.Tensor, suh: torch.Tensor, svh: torch.Tensor,

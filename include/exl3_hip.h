@@ -284,6 +284,13 @@ int exl3_glue_act_rs(const float* sg, const float* su, int S, const void* svh_g,
                      void* xh_d, float* xsum_d, void* a_out, int m, int inter, const float* ss_prev, const float* ss_new, int hidden,
                      float eps, void* stream);
 
+/* Hand-written NT MFMA GEMM of the prefill route (exl3_gemm_nt.hip; reference: hgemm.cu:19-78 behind modules/quant/exl3.py:161-218):
+ * c[m][n] = a[m][k] @ bt[n][k]^T, fp16 in, fp32 accumulate, fp16 out; a / bt / c row-major with leading dimensions lda / ldb / ldc (elements).
+ * epi 0: store; 1: c = fp16(c + y) (the residual add of o_proj / down_proj); 2: bt stacks, per 256 rows, 128 gate rows then the 128 up rows of the
+ * same outputs and c[m][n/2] = fp16(silu(fp16 g) * fp16 u) (activation.cu silu_mul fused into the gate|up GEMM).  k % 64 == 0, n % 256 == 0,
+ * 16-byte aligned operands; other shapes return EXL3_ERR_ARG (use exl3_hgemm_nt*, the hipBLASLt route). */
+int exl3_gemm_nt_mfma(const void* a, int64_t lda, const void* bt, int64_t ldb, void* c, int64_t ldc, int m, int k, int n, int epi, void* stream);
+
 /* y[rows][cols] = silu(g) * u (activation.cu) where g and u are fp16 column ranges of wider matrices (row strides ld_g, ld_u). */
 int exl3_silu_mul_2d(const void* g, const void* u, void* y, int64_t rows, int64_t cols, int64_t ld_g, int64_t ld_u, void* stream);
 
