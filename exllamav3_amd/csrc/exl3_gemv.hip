@@ -173,6 +173,15 @@ static int gemv_gen4()
 }
 extern "C" int exl3_set_gemv_gen4(int v) { g_gemv_gen4 = v ? 1 : 0; return EXL3_OK; }
 
+// fx pipeline: exl3_fx_zero_next(ptr, bytes) asks the NEXT generation-4 launch to clear a buffer as a side job (the gate / up accumulators)
+static void* g_fx_zero_ptr = nullptr; static int64_t g_fx_zero_bytes = 0;
+extern "C" int exl3_fx_zero_next(void* ptr, int64_t bytes)
+{
+    EXL3_CHECK_ARG(!ptr || (bytes > 0 && bytes % 16 == 0 && (uintptr_t) ptr % 16 == 0 && bytes / 16 < (1ll << 31)), "exl3_fx_zero_next: 16-byte aligned pointer and size");
+    g_fx_zero_ptr = ptr; g_fx_zero_bytes = ptr ? bytes : 0;
+    return EXL3_OK;
+}
+
 static int gemv_variant()
 {
     if (g_gemv_variant < 0)
@@ -444,7 +453,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                 for (int i = 0; i < count; ++i) if (!args.mat[i].xsum) g4 = false;      // the mul1 FAST variant needs the producer's block sums
             if (g4)
             {
-                const int mode = in_act ? 3 : (in_norm ? (in_fx ? 4 : 2) : (rot_pass ? 0 : 1));
+                const int mode = in_act ? ((flags & GEMV_IN_ACTFX) ? 5 : 3) : (in_norm ? (in_fx ? 4 : 2) : (rot_pass ? 0 : 1));
+                if (g_fx_zero_ptr) { args.fx_zero = g_fx_zero_ptr; args.fx_zero_n16 = (int) (g_fx_zero_bytes / 16); g_fx_zero_ptr = nullptr; g_fx_zero_bytes = 0; }
                 const int units4 = bps * 4;
                 int nwv4 = 8;
                 if (nwv4 > (bps > 4 ? bps : 4)) nwv4 = bps > 4 ? bps : 4;
@@ -473,7 +483,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             }
             else
             {
-            EXL3_CHECK_ARG(!atomic_out && !in_fx, "exl3_gemv_ex: GEMV_OUT_ATOMIC / GEMV_IN_FX are generation-4 launches (m <= 4, slices of <= 32 Hadamard blocks, generation 4 enabled)");
+            EXL3_CHECK_ARG(!atomic_out && !in_fx && !(flags & GEMV_IN_ACTFX), "exl3_gemv_ex: GEMV_OUT_ATOMIC / GEMV_IN_FX / GEMV_IN_ACTFX are generation-4 launches (m <= 4, slices of <= 32 Hadamard blocks, generation 4 enabled)");
             int nwv = 16 / ng;                                   // partial-sum LDS: nwv * 4*ng rows * 512 B <= 32 KB
             const int units = bps * (8 / G2_PF);                 // the waves split the slice's tile rows in units of G2_PF
             // measured on MI355X (tools/prof_tail.py, batch 1): one wave per Hadamard block of the slice, but at least 4 waves --
@@ -776,6 +786,34 @@ extern "C" int exl3_gemv_ex_fx(const void* R, const void* norm_w, const float* s
     return run_mgemm(R, Bs, nullptr, suhs, nullptr, nullptr, ns, count, m, k, K, cb, 0, force_split, (hipStream_t) stream,
                      GEMV_OUT_DEFERRED | GEMV_IN_NORM | GEMV_IN_FX, nullptr, nullptr, slabs_out, S_out, nullptr, norm_w, ss_prev, eps, nullptr,
                      nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, ss_out);
+}
+
+// exl3_gemv_ex_fx whose outputs are ADDED into fixed-point accumulators accs[i] (int64 [m][n_i], zero on entry: exl3_fx_zero_next) instead of being
+// left as slabs: gate|up of the fx pipeline.  The rows still carry the previous residual's 1/rms: the consumer (exl3_gemv_ex_actfx) corrects.
+extern "C" int exl3_gemv_ex_fx_atomic(const void* R, const void* norm_w, const float* ss_prev, float* ss_out, float eps, const void* const* Bs,
+                                      void* const* accs, const void* const* suhs, const void* const* svhs, const int* ns, int count, int m, int k, int K,
+                                      int cb, int force_split, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(Bs && ns && R && suhs && svhs && accs && ss_prev && ss_out && ss_prev != ss_out, "exl3_gemv_ex_fx_atomic: null table");
+    return run_mgemm(R, Bs, accs, suhs, svhs, nullptr, ns, count, m, k, K, cb, 0, force_split, (hipStream_t) stream,
+                     GEMV_OUT_ATOMIC | GEMV_IN_NORM | GEMV_IN_FX, nullptr, nullptr, nullptr, S_out, nullptr, norm_w, ss_prev, eps, nullptr,
+                     nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, ss_out);
+}
+
+// down_proj of the fx pipeline: input = fp16(silu(g) * u) formed from the fixed-point gate / up accumulators (int64 [m][k]) with the row-scale
+// correction r_new / r_prev (ss_prev / ss_new [m][hidden/128]); output added into the residual accumulator R (EXL3_GEMV_OUT_ATOMIC) or left as slabs.
+extern "C" int exl3_gemv_ex_actfx(const void* g_acc, const void* u_acc, const float* ss_prev, const float* ss_new, int hidden, float eps,
+                                  const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
+                                  int flags, int force_split, float** slab_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(g_acc && u_acc && B && suh && m <= 4, "exl3_gemv_ex_actfx: null pointer / m <= 4");
+    const void* Bs[1] = { B }; void* Cs[1] = { C }; const void* su[1] = { suh }; const void* sv[1] = { svh }; const void* bi[1] = { bias };
+    int ns[1] = { n };
+    GemvRescale rs = { ss_prev, ss_new, hidden, eps };
+    // the accumulators travel in the act_g / act_u fields; act_S = 1 and dummy svh pointers satisfy the slab-mode argument checks
+    return run_mgemm(nullptr, Bs, C ? Cs : nullptr, su, svh ? sv : nullptr, bi, ns, 1, m, k, K, cb, 0, force_split, (hipStream_t) stream,
+                     (flags & (GEMV_OUT_DEFERRED | GEMV_OUT_ATOMIC)) | GEMV_IN_ACTFX, nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
+                     (const float*) g_acc, (const float*) u_acc, 1, suh, suh, nullptr, (ss_prev && ss_new) ? &rs : nullptr, 0);
 }
 
 // exl3_gemv_ex (raw input A + suhs, deferred output, m <= 4) in the wave-per-column-block layout: cpw column blocks of one matrix per workgroup,

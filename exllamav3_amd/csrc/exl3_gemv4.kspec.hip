@@ -44,12 +44,13 @@ __device__ __forceinline__ void g4_static_for(F&& f)
 #define G4_MODE_NORM 2      // GEMV_IN_NORM: RMSNorm of the residual stream, then as RAWX
 #define G4_MODE_ACT  3      // GEMV_IN_ACT: silu(g) * u finished from the producer's gate / up slabs, then as RAWX
 #define G4_MODE_NORMFX 4    // GEMV_IN_NORM | GEMV_IN_FX: as NORM, the residual read from the 64-bit fixed-point accumulator (row scale = the previous residual's)
+#define G4_MODE_ACTFX 5     // GEMV_IN_ACTFX: silu(g) * u from the fixed-point gate / up accumulators a GEMV_OUT_ATOMIC gate|up launch added into
 
 constexpr int g4_waves_per_eu(int K, int CB, int MODE)
 {
     if (MODE == G4_MODE_ACT) return 4;
     if (K >= 5) return 6;
-    if (MODE == G4_MODE_NORMFX) return 6;
+    if (MODE == G4_MODE_NORMFX || MODE == G4_MODE_ACTFX) return 6;
     return (MODE == G4_MODE_ROT && CB == EXL3_CB_MUL1) ? 8 : 7;
 }
 
@@ -172,7 +173,7 @@ void exl3_gemv4_kernel(const GemvArgs a)
     const int last_unit = ubase + (nun > 0 ? nun - 1 : 0);
 
     // ---- preparation tasks (raw / norm / act input): task t = (block t / m, row t % m), one per half-wave; only waves that own a task run them
-    struct PrepIn { half4_t xv, sv, wv; float ss, ssn; uint4_t f0, f1; };
+    struct PrepIn { half4_t xv, sv, wv; float ss, ssn; uint4_t f0, f1, f2, f3; };
     const int ntask = nb * m;
     auto fetch = [&] (int it) -> PrepIn
     {
@@ -186,8 +187,14 @@ void exl3_gemv4_kernel(const GemvArgs a)
             const uint4_t* fp = (const uint4_t*) ((const int64_t*) a_A + (size_t) row * a_k + kofs) + 2 * l32;      // 4 x int64 per lane
             r.f0 = fp[0]; r.f1 = fp[1];
         }
+        if constexpr (MODE == G4_MODE_ACTFX)
+        {
+            const uint4_t* gp = (const uint4_t*) ((const int64_t*) a_act_g + (size_t) row * a_k + kofs) + 2 * l32;
+            const uint4_t* up = (const uint4_t*) ((const int64_t*) a_act_u + (size_t) row * a_k + kofs) + 2 * l32;
+            r.f0 = gp[0]; r.f1 = gp[1]; r.f2 = up[0]; r.f3 = up[1];
+        }
         r.sv = ((const half4_t*) (suh + kofs))[l32];
-        if constexpr (MODE == G4_MODE_ACT)
+        if constexpr (MODE == G4_MODE_ACT || MODE == G4_MODE_ACTFX)
         {
             // gate / up came from a launch that normalised with the previous residual's 1/rms (GEMV_IN_RESID / GEMV_IN_FX): the first 32 block sums
             // of squares of both residuals travel with the task (gemv_rescale)
@@ -226,6 +233,14 @@ void exl3_gemv4_kernel(const GemvArgs a)
     }
 #endif
     G4_T(1);
+    if (a.fx_zero)
+    {
+        // side job (fx pipeline): clear this workgroup's share of a buffer a LATER launch accumulates into
+        const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+        const int per = (a.fx_zero_n16 + nwg - 1) / nwg;
+        const int c0 = wg * per, c1 = min(c0 + per, a.fx_zero_n16);
+        for (int cidx = c0 + tid; cidx < c1; cidx += 64 * nwv) ((uint4_t*) a.fx_zero)[cidx] = uint4_t{ 0u, 0u, 0u, 0u };
+    }
 
     // ---- activation quads of this wave's first group
     // lane 4g + i: tile row (group base + (g >> 2)), quad g & 3, row min(i, m - 1)
@@ -313,6 +328,21 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     const half4_t uh = half4_t{ f2h(u0), f2h(u1), f2h(u2), f2h(u3) } * svu;
                     auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
                     xv = half4_t{ silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
+                }
+                if constexpr (MODE == G4_MODE_ACTFX)
+                {
+                    // g, u of this (row, block) are complete in the accumulators (out-Hadamard and svh were applied per split-k partial, the sum is
+                    // exact integer addition): row-scale correction, one rounding to fp16, silu * mul
+                    auto fxf = [] (uint32_t lo, uint32_t hi) -> float { return (float) (int32_t) hi + (float) lo * 2.3283064365386963e-10f; };
+                    float g0 = fxf(cur.f0.x, cur.f0.y), g1 = fxf(cur.f0.z, cur.f0.w), g2 = fxf(cur.f1.x, cur.f1.y), g3 = fxf(cur.f1.z, cur.f1.w);
+                    float u0 = fxf(cur.f2.x, cur.f2.y), u1 = fxf(cur.f2.z, cur.f2.w), u2 = fxf(cur.f3.x, cur.f3.y), u3 = fxf(cur.f3.z, cur.f3.w);
+                    if (a.act_rs.ss_new)
+                    {
+                        const float rsc = gemv_rescale(a.act_rs, row, l32, cur.ss, cur.ssn);
+                        g0 *= rsc; g1 *= rsc; g2 *= rsc; g3 *= rsc; u0 *= rsc; u1 *= rsc; u2 *= rsc; u3 *= rsc;
+                    }
+                    auto silu_mul = [] (float g, float u) -> half_t { const float gf = (float) f2h(g); return f2h(gf / (1.0f + __expf(-gf)) * (float) f2h(u)); };
+                    xv = half4_t{ silu_mul(g0, u0), silu_mul(g1, u1), silu_mul(g2, u2), silu_mul(g3, u3) };
                 }
                 if constexpr (MODE == G4_MODE_NORMFX)
                 {
@@ -511,6 +541,7 @@ static void g4_launch_cb(int var, int mode, int nwv, dim3 grid, size_t lds, hipS
         case G4_MODE_RAWX: LV(G4_MODE_RAWX) break;
         case G4_MODE_NORM: LV(G4_MODE_NORM) break;
         case G4_MODE_NORMFX: LV(G4_MODE_NORMFX) break;
+        case G4_MODE_ACTFX: LV(G4_MODE_ACTFX) break;
         default:           LV(G4_MODE_ACT)  break;
     }
     #undef LV

@@ -22,6 +22,8 @@
                               // PREVIOUS residual (the row scale is an estimate, corrected downstream exactly as for GEMV_IN_RESID); the workgroups of
                               // column block 0 of matrix 0 write the block sums of squares of THIS residual to rs_ss_out
 #define GEMV_FX_SCALE 4294967296.0
+#define GEMV_IN_ACTFX     128  // (generation 4) down_proj whose input silu(g) * u is formed from the gate / up rows that a GEMV_OUT_ATOMIC gate|up launch ADDED into two
+                              // fixed-point accumulators (act_g / act_u reinterpreted as int64 [m][k]): no slab reduction in the prologue, 2 KB per task
 #define GEMV_MAX_MATS 4
 
 // r = rsqrt(sum(ss_new[row]) / k + eps) / rsqrt(sum(ss_prev[row]) / k + eps): the exact RMSNorm scale over the estimate a GEMV_IN_RESID launch used.
@@ -153,6 +155,9 @@ struct GemvArgs
     // workgroups of column block 0 of matrix 0 write resid_out (fp16 [m][k], a DIFFERENT buffer) and ss_out [m][k/128]
     const float* rs_slab; const half_t* rs_svh; half_t* rs_resid_out; float* rs_ss_out; int rs_S;
     GemvEpi epi;
+    // fx pipeline: a buffer this launch clears as a side job (n16 16-byte chunks spread over the workgroups): the gate / up accumulators of the NEXT
+    // gate|up launch are zeroed by the o_proj launch in front of it -- no memset node in the graph
+    void* fx_zero; int fx_zero_n16;
 };
 static_assert(offsetof(GemvArgs, mat) == 128, "GemvArgs: the hot block is two 64-byte lines");
 

@@ -1107,6 +1107,42 @@ def exl3_gemv_ex_fx(R, norm_w, ss_prev, ss_out, eps: float, Bs, suhs, m: int, mc
     return [int(s) if s else 0 for s in slabs], S.value
 
 
+def fx_zero_next(buf: torch.Tensor | None):
+    """The NEXT generation-4 GEMV launch clears `buf` as a side job (the gate / up accumulators of the fx pipeline); None cancels."""
+    if buf is None:
+        _check(_lib.lib().exl3_fx_zero_next(None, 0)); return
+    _dev(buf)
+    _req(buf.is_contiguous() and (buf.numel() * buf.element_size()) % 16 == 0, "fx_zero_next: contiguous buffer, a multiple of 16 bytes")
+    _check(_lib.lib().exl3_fx_zero_next(_p(buf), buf.numel() * buf.element_size()))
+
+
+def exl3_gemv_ex_fx_atomic(R, norm_w, ss_prev, ss_out, eps: float, Bs, accs, suhs, svhs, m: int, mcg: bool, mul1: bool, force_split: int = 0) -> int:
+    """exl3_gemv_ex_fx whose output rows are ADDED into the int64 fixed-point accumulators accs[i] ([m][n_i], zero on entry).  Returns S."""
+    _dev(R)
+    _req(R.dtype == torch.int64 and all(a.dtype == torch.int64 and a.is_contiguous() for a in accs), "exl3_gemv_ex_fx_atomic: int64 R / accumulators")
+    cnt = len(Bs)
+    k, K = _kK(Bs[0])
+    ns = (ctypes.c_int * cnt)(*[B.shape[1] * 16 for B in Bs])
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_gemv_ex_fx_atomic(_p(R), _p(norm_w), _p(ss_prev), _p(ss_out), float(eps), _parr(Bs), _parr(accs), _parr(suhs), _parr(svhs),
+                                             ns, cnt, m, k, K, _cb(mcg, mul1), force_split, ctypes.byref(S), _stream(R)))
+    return S.value
+
+
+def exl3_gemv_ex_actfx(g_acc, u_acc, ss_prev, ss_new, hidden: int, eps: float, B, C, suh, svh, m: int, mcg: bool, mul1: bool, flags: int = 0,
+                       force_split: int = 0):
+    """down_proj whose input silu(g) * u is formed from the int64 fixed-point gate / up accumulators (row-scale correction from ss_prev / ss_new);
+    flags: GEMV_OUT_ATOMIC (C = the residual accumulator) or GEMV_OUT_DEFERRED.  Returns (slab pointer list, S)."""
+    _dev(B)
+    _req(g_acc.dtype == torch.int64 and u_acc.dtype == torch.int64, "exl3_gemv_ex_actfx: int64 accumulators")
+    k, K = _kK(B)
+    slab = (_vp * 1)()
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_gemv_ex_actfx(_p(g_acc), _p(u_acc), _p(ss_prev), _p(ss_new), int(hidden), float(eps), _p(B), _p(C), _p(suh), _p(svh), None,
+                                         m, k, B.shape[1] * 16, K, _cb(mcg, mul1), flags, force_split, slab, ctypes.byref(S), _stream(B)))
+    return [int(slab[0]) if slab[0] else 0], S.value
+
+
 def exl3_gemv_ex_wpc(A, Bs, suhs, m: int, mcg: bool, mul1: bool, cpw: int, force_split: int = 0):
     """exl3_gemv_ex(raw A, deferred) in the wave-per-column-block layout (cpw column blocks of one matrix per workgroup).  Returns (slabs, S)."""
     _dev(A)

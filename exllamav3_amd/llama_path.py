@@ -291,6 +291,7 @@ class SyntheticEXL3Llama:
         self.xs_d = torch.empty((bsz, nb_i), dtype=f32, device=dev)
         # decode_step_fx: the residual stream as a 64-bit fixed-point accumulator (value * 2^32)
         self.R = torch.zeros((bsz, s.hidden), dtype=torch.int64, device=dev)
+        self.GU = torch.zeros((2, bsz, self.inter_local), dtype=torch.int64, device=dev)     # gate / up accumulators (fx_gu_atomic)
         self._state_bsz = bsz
 
     # ---- one decode step (bsz tokens, one per sequence) -----------------------------------------------
@@ -355,6 +356,8 @@ class SyntheticEXL3Llama:
     act_in_gemv = os.environ.get("EXL3_HIP_ACT_IN_GEMV", "1") != "0"
     #: decode_step_fx: silu(g) * u inside the down launch (5 launches per layer) instead of glue_act_rs + rotated-input down (6)
     fx_act_in_gemv = os.environ.get("EXL3_HIP_FX_ACT_IN_GEMV", "0") != "0"
+    #: decode_step_fx: gate|up add into fixed-point accumulators, down forms silu(g) * u from them (5 launches per layer, no slab reduction)
+    fx_gu_atomic = os.environ.get("EXL3_HIP_FX_GU_ATOMIC", "0") != "0"
 
     #: forced split-k factor per call type of the fused pipelines (0 = library heuristic); tools/sweep_split.py tunes these
     split = {"qkv": 0, "o": 0, "gu": 0, "down": 0}
@@ -606,7 +609,9 @@ class SyntheticEXL3Llama:
         same = all(_same_kind(L["q"], L["k"], L["v"]) and _same_kind(L["gate"], L["up"]) for L in self.layers)
         if self.tp != 1 or bsz > 4 or not same:
             return self.decode_step_fused()
-        sp, hd, hidden = self.split, self.shape.head_dim, self.shape.hidden
+        sp, hd, hidden = dict(self.split), self.shape.head_dim, self.shape.hidden
+        if sp["o"] == 0 and self.hq * hd == 4096 and hidden == 4096:
+            sp["o"] = 8          # atomic epilogue: half the atomics of the dispatcher's 16-way split measured -0.8 us per layer (tools/sweep_split.py, STEP=decode_step_fx)
         ROT, DEF, ATOM = ext.GEMV_IN_ROTATED, ext.GEMV_OUT_DEFERRED, ext.GEMV_OUT_ATOMIC
         R = self.R
         sc, so_ = self.ss, self.ss2                                       # sums of squares: current (complete) / the buffer the next reader fills
@@ -627,6 +632,17 @@ class SyntheticEXL3Llama:
                 ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
                                        self.attn_pos + 1, workspace=self.attn_ws)
                 o_in = self.attn_out.view(bsz, -1)
+            if self.fx_gu_atomic:
+                # 5 launches per layer: gate|up ADD their rows into two fixed-point accumulators (cleared by the o_proj launch as a side job) and
+                # down_proj forms silu(g) * u from them in its prologue -- no glue_act launch, no slab reduction anywhere in the MLP
+                ext.fx_zero_next(self.GU)
+                ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], [R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM, sp["o"])
+                ext.exl3_gemv_ex_fx_atomic(R, L["norm2"], sc, so_, self.eps, [lg.trellis, lu.trellis], [self.GU[0], self.GU[1]], [lg.suh, lu.suh],
+                                           [lg.svh, lu.svh], bsz, lg.mcg, lg.mul1, sp["gu"])
+                ext.exl3_gemv_ex_actfx(self.GU[0], self.GU[1], sc, so_, hidden, self.eps, ld.trellis, R, ld.suh, ld.svh, bsz, ld.mcg, ld.mul1,
+                                       ATOM, sp["down"])
+                sc, so_ = so_, sc
+                continue
             ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], [R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM, sp["o"])
             sgu, Sgu = ext.exl3_gemv_ex_fx(R, L["norm2"], sc, so_, self.eps, [lg.trellis, lu.trellis], [lg.suh, lu.suh], bsz, lg.mcg, lg.mul1, sp["gu"])
             if self.fx_act_in_gemv:

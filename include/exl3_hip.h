@@ -233,6 +233,17 @@ int exl3_fx_finish(const void* R, void* x, float* ss, int m, int hidden, void* s
 int exl3_gemv_ex_fx(const void* R, const void* norm_w, const float* ss_prev, float* ss_out, float eps, const void* const* Bs,
                     const void* const* suhs, const int* ns, int count, int m, int k, int K, int cb, int force_split,
                     float** slabs_out, int* S_out, void* stream);
+/* ... with the gate / up rows ADDED into fixed-point accumulators accs[i] (int64 [m][n_i], zero on entry) instead of slabs, and the down_proj that
+ * forms silu(g) * u from them (row-scale correction from ss_prev / ss_new) while it builds its activation quads: the silu_mul node of
+ * libtorch/mlp.cpp:14-91 without a launch and without a slab reduction.  exl3_fx_zero_next(ptr, bytes): the NEXT generation-4 GEMV launch clears
+ * that buffer as a side job (the o_proj launch zeroes the accumulators of the gate|up launch behind it: no memset node). */
+int exl3_gemv_ex_fx_atomic(const void* R, const void* norm_w, const float* ss_prev, float* ss_out, float eps, const void* const* Bs,
+                           void* const* accs, const void* const* suhs, const void* const* svhs, const int* ns, int count, int m, int k, int K,
+                           int cb, int force_split, int* S_out, void* stream);
+int exl3_gemv_ex_actfx(const void* g_acc, const void* u_acc, const float* ss_prev, const float* ss_new, int hidden, float eps,
+                       const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
+                       int flags, int force_split, float** slab_out, int* S_out, void* stream);
+int exl3_fx_zero_next(void* ptr, int64_t bytes);
 /* exl3_gemv_ex (raw input, deferred output, m <= 4) in the wave-per-column-block layout used by the three launches above and below: `cpw` (1..16)
  * column blocks of ONE matrix per workgroup, each wave streams the whole k-slice of its column block and writes its own slab.  The fused
  * prologues then re-read the producer's slabs once per cpw column blocks instead of once per column block. */

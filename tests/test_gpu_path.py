@@ -1019,6 +1019,13 @@ def test_fixed_point_residual_pipeline_matches_oracle_and_glue_pipeline(dev, cb,
     assert np.isfinite(la).all() and np.abs(la - ref).max() / rms < 3e-2 and np.abs(la - lr).max() / rms < 1e-2
     assert np.array_equal(model.decode_step_fx().float().cpu().numpy(), la)
     model.fx_act_in_gemv = False
+    # 5 launches per layer, the other way: gate|up add into fixed-point accumulators (cleared by the o_proj launch), down forms silu(g) * u from them
+    model.fx_gu_atomic = True
+    lg_ = model.decode_step_fx().float().cpu().numpy().copy()
+    assert np.isfinite(lg_).all() and np.abs(lg_ - ref).max() / rms < 3e-2 and np.abs(lg_ - lr).max() / rms < 1e-2
+    for _ in range(3):
+        assert np.array_equal(model.decode_step_fx().float().cpu().numpy(), lg_)
+    model.fx_gu_atomic = False
     st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
         g = torch.cuda.CUDAGraph()

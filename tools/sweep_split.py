@@ -11,13 +11,15 @@ from exllamav3_amd import ext
 if os.environ.get('G3MIN'): ext.set_gemm3_min_rows(int(os.environ['G3MIN']))
 if os.environ.get('MAXW'): ext.set_gemv_max_waves(int(os.environ['MAXW']))
 
+STEP = getattr(model, os.environ.get('STEP', 'decode_step_fused'))
+
 def step_us():
-    model.decode_step_fused(); torch.cuda.synchronize()
+    STEP(); torch.cuda.synchronize()
     st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=st):
-            model.decode_step_fused()
+            STEP()
         g.replay(); st.synchronize()
         best = 1e9
         for _ in range(3):
