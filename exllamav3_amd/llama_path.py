@@ -354,6 +354,9 @@ class SyntheticEXL3Llama:
 
     #: m <= 4: finish silu(g) * u inside the down GEMV instead of a glue_act launch
     act_in_gemv = os.environ.get("EXL3_HIP_ACT_IN_GEMV", "1") != "0"
+    #: decode_step_fx runs up to this batch (the kernels take 4): measured 8B 4 bpw, same box: bs 1 +7..10 %, bs 2 +3 %, bs 4 -6.5 % against the glue pipeline
+    #: (the atomics and the in-launch RMSNorm tasks scale with the rows)
+    fx_max_bsz = 2
     #: decode_step_fx: silu(g) * u inside the down launch (5 launches per layer) instead of glue_act_rs + rotated-input down (6)
     fx_act_in_gemv = os.environ.get("EXL3_HIP_FX_ACT_IN_GEMV", "0") != "0"
     #: decode_step_fx: gate|up add into fixed-point accumulators, down forms silu(g) * u from them (5 launches per layer, no slab reduction)
@@ -607,7 +610,7 @@ class SyntheticEXL3Llama:
         reference (rounded after every add, norm.cu:193-218) is kept at higher precision here.  Other configurations take decode_step_fused."""
         bsz = self._state_bsz
         same = all(_same_kind(L["q"], L["k"], L["v"]) and _same_kind(L["gate"], L["up"]) for L in self.layers)
-        if self.tp != 1 or bsz > 4 or not same:
+        if self.tp != 1 or bsz > self.fx_max_bsz or not same:
             return self.decode_step_fused()
         sp, hd, hidden = dict(self.split), self.shape.head_dim, self.shape.hidden
         if sp["o"] == 0 and self.hq * hd == 4096 and hidden == 4096:
@@ -761,7 +764,8 @@ class SyntheticEXL3Llama:
         if pipeline is True: pipeline = "glue"
         if pipeline is False: pipeline = "unfused"
         if self.tp != 1 and pipeline == "tail": pipeline = "glue"
-        if pipeline in ("resid", "fx") and (self.tp != 1 or self._state_bsz > 4): pipeline = "glue"
+        if pipeline == "resid" and (self.tp != 1 or self._state_bsz > 4): pipeline = "glue"
+        if pipeline == "fx" and (self.tp != 1 or self._state_bsz > self.fx_max_bsz): pipeline = "glue"
         bsz, hd = self._state_bsz, self.shape.head_dim
         q2, k2, v2 = self.q.view(bsz, -1), self.k.view(bsz, -1), self.v.view(bsz, -1)
         ROT, DEF = ext.GEMV_IN_ROTATED, ext.GEMV_OUT_DEFERRED
