@@ -205,7 +205,7 @@ def main():
     if pipeline in ("tail", "fx") and world > 1:
         pipeline = "glue"                                  # TP ranks all-reduce between o/down and the norm
     fused = pipeline != "unfused"
-    run_step = model.decode_step if is_moe else \
+    run_step = (model.decode_step_fx if pipeline == "fx" else model.decode_step) if is_moe else \
         {"tail": model.decode_step_tail, "glue": model.decode_step_fused, "resid": model.decode_step_resid, "fx": model.decode_step_fx,
          "unfused": model.decode_step}[pipeline]
     # tensor-parallel decode: the o_proj / down_proj all-reduces go through the one-shot IPC push (exl3_allreduce.hip, fused with the residual
@@ -533,7 +533,7 @@ def main():
         from exllamav3_amd.mixtral_path import MIXTRAL_8X7B
         mm = SyntheticEXL3Mixtral(MIXTRAL_8X7B, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits)
         mm.alloc_state(1)
-        extra["mixtral-8x7b_bs1"] = timed_decode(mm, mm.decode_step, 1)
+        extra["mixtral-8x7b_bs1"] = timed_decode(mm, mm.decode_step_fx if pipeline == "fx" else mm.decode_step, 1)
         del mm
         torch.cuda.empty_cache()
 

@@ -148,6 +148,9 @@ def _declare(l):
     sig("exl3_glue_resid_moe", vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, vp)
     sig("exl3_routing_std_scaled", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
     sig("exl3_routing_std_norm", vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
+    sig("exl3_routing_std_fx", vp, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
+    sig("exl3_mgemm_indexed_deferred", vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
+    sig("exl3_mgemm_indexed_act_fx", vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_routing_std_slots", vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp)
     sig("exl3_mgemm_indexed_act", vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_set_glue_threads", i32)

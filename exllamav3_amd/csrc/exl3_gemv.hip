@@ -249,7 +249,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     // GEMV_OUT_ATOMIC (generation 4): no slabs, every workgroup adds its share of the output into the fixed-point accumulator Cs[i]; like a deferred
     // launch it keeps every workgroup resident (the split is chosen the same way) and it needs svhs
     const bool atomic_out = (flags & GEMV_OUT_ATOMIC) != 0, in_fx = (flags & GEMV_IN_FX) != 0;
-    EXL3_CHECK_ARG(!atomic_out || (!(flags & GEMV_OUT_DEFERRED) && Cs && svhs && m <= 4 && !tbl && !epi && cpw == 0 && !rsd),
+    EXL3_CHECK_ARG(!atomic_out || (!(flags & GEMV_OUT_DEFERRED) && ((Cs && svhs) || (tbl && tbl->C && tbl->svh && tbl->slots_per_token >= 1)) && m <= 4 && !epi && cpw == 0 && !rsd),
                    "exl3_gemv_ex: GEMV_OUT_ATOMIC needs the accumulators (Cs), svhs, m <= 4 and excludes GEMV_OUT_DEFERRED");
     EXL3_CHECK_ARG(!in_fx || ((flags & GEMV_IN_NORM) && m <= 4 && fx_ss_out), "exl3_gemv_ex_fx: needs GEMV_IN_NORM, m <= 4 and ss_out");
     const bool deferred = (flags & (GEMV_OUT_DEFERRED | GEMV_OUT_ATOMIC)) != 0, rotated = (flags & GEMV_IN_ROTATED) != 0;
@@ -265,7 +265,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     EXL3_CHECK_ARG(k % 128 == 0 && k > 0, "exl3_gemm: k must be divisible by 128");
     EXL3_CHECK_ARG(m >= 1, "exl3_gemm: m must be >= 1");
     const bool in_act = (flags & GEMV_IN_ACT) != 0;
-    EXL3_CHECK_ARG(!in_act || (act_g && act_u && act_svh_g && act_svh_u && act_S >= 1 && !rotated && count == 1 && m <= 4),
+    EXL3_CHECK_ARG(!in_act || (act_g && act_u && ((act_svh_g && act_svh_u && count == 1) || (tbl && tbl->act_svh)) && act_S >= 1 && !rotated && m <= 4),
                    "exl3_gemv_ex_act: needs gate / up slabs + svh, one matrix, m <= 4");
     EXL3_CHECK_ARG(A || rotated || in_act, "exl3_gemm: null A");
     EXL3_CHECK_ARG(!rsd || (in_norm && deferred && m <= 4 && rsd->slab && rsd->S >= 1 && rsd->svh && rsd->resid_out && rsd->ss_out && rsd->resid_out != A),
@@ -448,12 +448,13 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         {
             const int ng = mp <= 4 ? 1 : (mp <= 8 ? 2 : 4);
             const bool rot_pass = (pass_flags & GEMV_IN_ROTATED) != 0;
-            bool g4 = gemv_gen4() && ng == 1 && !tbl && !epi && cpw == 0 && !rsd && bps <= 32;
+            // table launches (MoE): raw-x / slab-act inputs; the fp16 gate / up act input (tbl->act_u) stays generation 2's
+            bool g4 = gemv_gen4() && ng == 1 && (!tbl || !tbl->act_u) && !epi && cpw == 0 && !rsd && bps <= 32;
             if (g4 && rot_pass && var == 1 && cb == 2)
                 for (int i = 0; i < count; ++i) if (!args.mat[i].xsum) g4 = false;      // the mul1 FAST variant needs the producer's block sums
             if (g4)
             {
-                const int mode = in_act ? ((flags & GEMV_IN_ACTFX) ? 5 : 3) : (in_norm ? (in_fx ? 4 : 2) : (rot_pass ? 0 : 1));
+                const int mode = tbl ? (in_act ? 7 : 6) : in_act ? ((flags & GEMV_IN_ACTFX) ? 5 : 3) : (in_norm ? (in_fx ? 4 : 2) : (rot_pass ? 0 : 1));
                 if (g_fx_zero_ptr) { args.fx_zero = g_fx_zero_ptr; args.fx_zero_n16 = (int) (g_fx_zero_bytes / 16); g_fx_zero_ptr = nullptr; g_fx_zero_bytes = 0; }
                 const int units4 = bps * 4;
                 int nwv4 = 8;
@@ -466,6 +467,11 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                 const size_t lds4 = exl3_gemv4_lds_bytes(mode, nwv4, mp, bps);
                 EXL3_CHECK_ARG(grid.x / (unsigned) S <= 65535u, "exl3_gemm: too many column blocks for one launch");
                 grid = dim3((unsigned) S, grid.x / (unsigned) S);
+                if (tbl)
+                {
+                    EXL3_CHECK_ARG(count <= 65535, "exl3_mgemm: too many slots for one launch");
+                    grid = dim3((unsigned) S, (unsigned) (ns[0] / 128), (unsigned) count);       // (k-slices, column blocks of one matrix, slots)
+                }
                 for (int i = 1; i < GEMV_MAX_MATS; ++i) args.cbf[i - 1] = args.mat[i].cb_first;
                 args.nwv = nwv4;
                 args.magic_m = gemv_magic((uint32_t) mp); args.magic_nwv = gemv_magic((uint32_t) nwv4); args.magic_nhw = gemv_magic((uint32_t) (2 * nwv4));
@@ -483,7 +489,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             }
             else
             {
-            EXL3_CHECK_ARG(!atomic_out && !in_fx && !(flags & GEMV_IN_ACTFX), "exl3_gemv_ex: GEMV_OUT_ATOMIC / GEMV_IN_FX / GEMV_IN_ACTFX are generation-4 launches (m <= 4, slices of <= 32 Hadamard blocks, generation 4 enabled)");
+            EXL3_CHECK_ARG(!atomic_out && !in_fx && !(flags & GEMV_IN_ACTFX) && !(tbl && in_act), "exl3_gemv_ex: GEMV_OUT_ATOMIC / GEMV_IN_FX / GEMV_IN_ACTFX / slab-act table launches are generation-4 launches (m <= 4, slices of <= 32 Hadamard blocks, generation 4 enabled)");
             int nwv = 16 / ng;                                   // partial-sum LDS: nwv * 4*ng rows * 512 B <= 32 KB
             const int units = bps * (8 / G2_PF);                 // the waves split the slice's tile rows in units of G2_PF
             // measured on MI355X (tools/prof_tail.py, batch 1): one wave per Hadamard block of the slice, but at least 4 waves --
@@ -749,6 +755,49 @@ extern "C" int exl3_mgemm_indexed_act_deferred(const void* G, const void* U, con
     const void* su[1] = { tbl_suh };
     int rc = run_mgemm(G, Bs, nullptr, su, nullptr, nullptr, ns, bszm, m, k, K, cb, 0, 0, (hipStream_t) stream, GEMV_OUT_DEFERRED, nullptr, nullptr, slab_out,
                        S_out, nullptr, nullptr, nullptr, 0.0f, &t);
+    return rc < 0 ? rc : EXL3_OK;
+}
+
+// Indexed gate|up launch of a MoE block with a deferred epilogue (generation 4): raw x (bszm_in == 1: one shared row set), pointer tables over
+// [gate_0..gate_E-1, up_0..up_E-1], indices = the router's [gate slots | up slots] list; leaves slabs [slot][n/128][S][m][128] for
+// exl3_mgemm_indexed_act_fx.
+extern "C" int exl3_mgemm_indexed_deferred(const void* A, int bszm_in, const void* tbl_B, const void* tbl_suh, const int64_t* indices, int bszm,
+                                           int m, int k, int n, int K, int cb, int force_split, float** slab_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(A && tbl_B && tbl_suh && slab_out && S_out, "exl3_mgemm_indexed_deferred: null pointer");
+    EXL3_CHECK_ARG(bszm >= 1 && (bszm_in == 1 || bszm_in == bszm) && m >= 1 && m <= 4, "exl3_mgemm_indexed_deferred: 1..4 rows per slot; A has 1 or bszm slots");
+    GemvTable t; memset((void*) &t, 0, sizeof(t));
+    t.B = (const uint64_t*) tbl_B; t.suh = (const uint64_t*) tbl_suh;
+    t.indices = indices; t.bszm = bszm; t.min_index = -1; t.max_index = -1; t.n = n; t.cbs_per_mat = n / 128;
+    t.a_slot_stride = bszm_in == 1 ? 0 : (int64_t) m * k;
+    t.c_slot_stride = (int64_t) m * n;
+    const void* Bs[1] = { tbl_B }; int ns[1] = { n }; const void* su[1] = { tbl_suh };
+    int rc = run_mgemm(A, Bs, nullptr, su, nullptr, nullptr, ns, bszm, m, k, K, cb, 0, force_split, (hipStream_t) stream, GEMV_OUT_DEFERRED, nullptr, nullptr, slab_out,
+                       S_out, nullptr, nullptr, nullptr, 0.0f, &t);
+    return rc < 0 ? rc : EXL3_OK;
+}
+
+// Indexed down launch of a MoE block in the fx pipeline (generation 4): slot j's input is fp16(silu(g_j) * u_j) finished from the slabs of
+// exl3_mgemm_indexed_deferred (gate slots first, then the up slots: gu_slabs, act_S; gu_svh_tbl = that launch's svh table, up svh = entry + up_off),
+// its output rows -- out-Hadamard, svh and the routing weight applied per split-k partial -- are ADDED into the fixed-point residual accumulator
+// R [num_tokens][m][n] int64 (slot j -> token j / (bszm / num_tokens)): no slot sum, no split-k reduce, no residual launch.
+extern "C" int exl3_mgemm_indexed_act_fx(const float* gu_slabs, int act_S, const void* gu_svh_tbl, int up_off, const void* tbl_B, const void* tbl_suh,
+                                         const void* tbl_svh, const int64_t* indices, const void* weights, int bszm, void* R, int m, int k, int n,
+                                         int K, int cb, int num_tokens, int force_split, void* stream)
+{
+    EXL3_CHECK_ARG(gu_slabs && gu_svh_tbl && tbl_B && tbl_suh && tbl_svh && R, "exl3_mgemm_indexed_act_fx: null pointer");
+    EXL3_CHECK_ARG(bszm >= 1 && m >= 1 && m <= 4 && act_S >= 1, "exl3_mgemm_indexed_act_fx: 1..4 rows per slot");
+    EXL3_CHECK_ARG(num_tokens >= 1 && bszm % num_tokens == 0, "exl3_mgemm_indexed_act_fx: bszm must be divisible by num_tokens");
+    GemvTable t; memset((void*) &t, 0, sizeof(t));
+    t.B = (const uint64_t*) tbl_B; t.suh = (const uint64_t*) tbl_suh; t.svh = (const uint64_t*) tbl_svh;
+    t.indices = indices; t.weights = (const half_t*) weights; t.C = R;
+    t.bszm = bszm; t.min_index = -1; t.max_index = -1; t.n = n; t.cbs_per_mat = n / 128;
+    t.c_slot_stride = (int64_t) m * n;
+    t.act_svh = (const uint64_t*) gu_svh_tbl; t.act_up_off = up_off; t.slots_per_token = bszm / num_tokens;
+    const size_t sstride = (size_t) (k / 128) * act_S * m * 128;
+    const void* Bs[1] = { tbl_B }; int ns[1] = { n }; const void* su[1] = { tbl_suh }; const void* sv[1] = { tbl_svh };
+    int rc = run_mgemm(nullptr, Bs, nullptr, su, sv, nullptr, ns, bszm, m, k, K, cb, 0, force_split, (hipStream_t) stream, GEMV_OUT_ATOMIC, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, 0.0f, &t, gu_slabs, gu_slabs + (size_t) bszm * sstride, act_S);
     return rc < 0 ? rc : EXL3_OK;
 }
 

@@ -45,10 +45,17 @@ __device__ __forceinline__ void g4_static_for(F&& f)
 #define G4_MODE_ACT  3      // GEMV_IN_ACT: silu(g) * u finished from the producer's gate / up slabs, then as RAWX
 #define G4_MODE_NORMFX 4    // GEMV_IN_NORM | GEMV_IN_FX: as NORM, the residual read from the 64-bit fixed-point accumulator (row scale = the previous residual's)
 #define G4_MODE_ACTFX 5     // GEMV_IN_ACTFX: silu(g) * u from the fixed-point gate / up accumulators a GEMV_OUT_ATOMIC gate|up launch added into
+// Table modes (MoE / indexed exl3_mgemm, a.tbl): grid = (k-slices, column blocks of ONE matrix, slots); slot -> (matrix, routing weight) resolved on the
+// device from the router's index list; the input side is RAWX's / ACT's
+#define G4_MODE_TRAWX 6     // slot input = raw x (one shared row set, or a_slot_stride apart)
+#define G4_MODE_TACT 7      // slot input = silu(g) * u from the slabs a TRAWX gate|up launch over [gate_0..gate_E-1, up_0..up_E-1] left (slot j: gate, slot bszm + j: up)
+constexpr int g4_input_mode(int MODE) { return MODE == G4_MODE_TRAWX ? G4_MODE_RAWX : (MODE == G4_MODE_TACT ? G4_MODE_ACT : MODE); }
 
-constexpr int g4_waves_per_eu(int K, int CB, int MODE)
+constexpr int g4_waves_per_eu(int K, int CB, int MODE_)
 {
+    const int MODE = g4_input_mode(MODE_);
     if (MODE == G4_MODE_ACT) return 4;
+    if (MODE == G4_MODE_ACTFX && K >= 6) return 5;          // four 16-byte accumulator loads in flight per task next to a 12..16-word ring
     if (K >= 5) return 6;
     if (MODE == G4_MODE_NORMFX || MODE == G4_MODE_ACTFX) return 6;
     return (MODE == G4_MODE_ROT && CB == EXL3_CB_MUL1) ? 8 : 7;
@@ -104,11 +111,13 @@ __device__ __forceinline__ void g4_unit(LaneWords<K> (&ringall)[NR], const uint3
     });
 }
 
-template <int K, int CB, int VAR, int MODE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(g4_waves_per_eu(K, CB, MODE))))
+template <int K, int CB, int VAR, int XMODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(g4_waves_per_eu(K, CB, XMODE))))
 void exl3_gemv4_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MODE = g4_input_mode(XMODE);                 // the input side of a table launch is RAWX's / ACT's
+    constexpr bool TBL = XMODE == G4_MODE_TRAWX || XMODE == G4_MODE_TACT;
     constexpr bool SPLIT = (VAR == 1) && (CB != EXL3_CB_MUL1);
     constexpr bool RAW = (VAR == 1) && (CB == EXL3_CB_MUL1);
     constexpr int NW = 8 * K;
@@ -118,12 +127,12 @@ void exl3_gemv4_kernel(const GemvArgs a)
     const int a_S = a.S, a_k = a.k, a_kslice = a.kslice, a_flags = a.flags, a_nm = a.num_mats, nwv = a.nwv, m = a.m;
     const int a_cbf[GEMV_MAX_MATS] = { 0, a.cbf[0], a.cbf[1], a.cbf[2] };
     const uint32_t mg_m = a.magic_m, mg_nwv = a.magic_nwv;
-    const half_t* const a_A = a.A;
+    const half_t* a_A = a.A;
     const half_t* const a_norm_w = a.norm_w;
     const float* const a_ss_part = a.ss_part;
     const float a_eps = a.eps;
-    const float* const a_act_g = a.act_g; const float* const a_act_u = a.act_u;
-    const half_t* const a_act_svh_g = a.act_svh_g; const half_t* const a_act_svh_u = a.act_svh_u;
+    const float* a_act_g = a.act_g; const float* a_act_u = a.act_u;
+    const half_t* a_act_svh_g = a.act_svh_g; const half_t* a_act_svh_u = a.act_svh_u;
     const int a_act_S = a.act_S;
     if constexpr (MODE == G4_MODE_ACT) asm volatile("" :: "s"(a_act_g), "s"(a_act_S));
     {
@@ -145,10 +154,30 @@ void exl3_gemv4_kernel(const GemvArgs a)
     const int s = blockIdx.x, cbg = blockIdx.y;
     int mi = 0;
     #pragma unroll
-    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a_nm && cbg >= a_cbf[i]) mi = i;
+    for (int i = 1; i < GEMV_MAX_MATS; ++i) if (!TBL && i < a_nm && cbg >= a_cbf[i]) mi = i;
     const uint32_t* __restrict__ Bm = a.mat[mi].B;
     const half_t* __restrict__ suh = a.mat[mi].suh;
-    const int n = a.mat[mi].n, cbl = cbg - a.mat[mi].cb_first, ws_off = a.mat[mi].ws_offset;
+    int n = a.mat[mi].n, cbl = cbg - a.mat[mi].cb_first, ws_off = a.mat[mi].ws_offset;
+    int slot = 0, tmat = 0; float tweight = 1.0f;
+    if constexpr (TBL)
+    {
+        slot = blockIdx.z;
+        const SlotRef_t sr = resolve_slot(a.tbl, slot);
+        if (sr.mat_index < 0) return;                           // slot filtered out by the expert range (whole workgroup, before any barrier)
+        tmat = sr.mat_index; tweight = sr.weight;
+        Bm = (const uint32_t*) a.tbl.B[tmat];
+        suh = (const half_t*) a.tbl.suh[tmat];
+        n = a.tbl.n; cbl = cbg; ws_off = slot * a.tbl.cbs_per_mat * a_S * m * 128;
+        if constexpr (MODE == G4_MODE_RAWX) a_A += (size_t) slot * a.tbl.a_slot_stride;
+        if constexpr (MODE == G4_MODE_ACT)
+        {
+            // gate / up slabs of this slot [slot][k/128][act_S][m][128] (act_u = the same launch's slot bszm + j); their svh from the gate|up table
+            const size_t sstride = (size_t) (a_k >> 7) * a_act_S * m * 128;
+            a_act_g += (size_t) slot * sstride; a_act_u += (size_t) slot * sstride;
+            a_act_svh_g = (const half_t*) a.tbl.act_svh[tmat];
+            a_act_svh_u = (const half_t*) a.tbl.act_svh[tmat + a.tbl.act_up_off];
+        }
+    }
     const int tiles_n = n >> 4;
     const int k0s = s * a_kslice;
     const int k1s = min(k0s + a_kslice, a_k);
@@ -478,15 +507,23 @@ void exl3_gemv4_kernel(const GemvArgs a)
         float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
         had128_f32x4(h0, h1, h2, h3, l);
         h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
-        const half4_t sc = ((const half4_t*) (a.mat[mi].svh + cbl * 128))[l];
-        const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
+        const half_t* svh_m = a.mat[mi].svh; void* C_m = a.mat[mi].C; size_t c_row = (size_t) a.c_row_offset + row;
+        const half_t* bias = (!TBL && a.mat[mi].bias) ? a.mat[mi].bias + cbl * 128 : nullptr;
+        if constexpr (TBL)
+        {
+            svh_m = (const half_t*) a.tbl.svh[tmat];
+            h0 *= tweight; h1 *= tweight; h2 *= tweight; h3 *= tweight;       // reference: scale *= weight, then one multiply (exl3_gemm_kernel.cuh:216-217)
+            if (a_flags & GEMV_OUT_ATOMIC) { C_m = a.tbl.C; c_row = (size_t) (slot / a.tbl.slots_per_token) * m + row; }     // every slot of a token adds into that token's rows
+            else C_m = a.c_fp32 ? (void*) ((float*) a.tbl.C + (size_t) slot * a.tbl.c_slot_stride) : (void*) ((half_t*) a.tbl.C + (size_t) slot * a.tbl.c_slot_stride);
+        }
+        const half4_t sc = ((const half4_t*) (svh_m + cbl * 128))[l];
         if (a_flags & GEMV_OUT_ATOMIC)
         {
             // the slice's share of the output rows (out-Hadamard and svh applied to the partial: both linear), added into the fixed-point
             // accumulator; fp32 arithmetic of glue_resid up to the sum, which here is exact integer addition in any order
             float o[4] = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
             if (bias && s == 0) { const half4_t bv = ((const half4_t*) bias)[l]; o[0] += (float) bv.x; o[1] += (float) bv.y; o[2] += (float) bv.z; o[3] += (float) bv.w; }
-            unsigned long long* acc = (unsigned long long*) a.mat[mi].C + ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
+            unsigned long long* acc = (unsigned long long*) C_m + c_row * n + cbl * 128 + 4 * l;
             #pragma unroll
             for (int i = 0; i < 4; ++i)
             {
@@ -495,19 +532,19 @@ void exl3_gemv4_kernel(const GemvArgs a)
             }
             continue;
         }
-        const size_t off = ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
+        const size_t off = c_row * n + cbl * 128 + 4 * l;
         if (a.c_fp32)
         {
             float4_t o = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
             if (bias) { const half4_t bv = ((const half4_t*) bias)[l]; o.x += (float) bv.x; o.y += (float) bv.y; o.z += (float) bv.z; o.w += (float) bv.w; }
-            *((float4_t*) ((float*) a.mat[mi].C + off)) = o;
+            *((float4_t*) ((float*) C_m + off)) = o;
         }
         else
         {
             half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
             o = o * sc;
             if (bias) o = o + ((const half4_t*) bias)[l];
-            *((half4_t*) ((half_t*) a.mat[mi].C + off)) = o;
+            *((half4_t*) ((half_t*) C_m + off)) = o;
         }
     }
 #ifdef G4_TIMING
@@ -542,6 +579,8 @@ static void g4_launch_cb(int var, int mode, int nwv, dim3 grid, size_t lds, hipS
         case G4_MODE_NORM: LV(G4_MODE_NORM) break;
         case G4_MODE_NORMFX: LV(G4_MODE_NORMFX) break;
         case G4_MODE_ACTFX: LV(G4_MODE_ACTFX) break;
+        case G4_MODE_TRAWX: LV(G4_MODE_TRAWX) break;
+        case G4_MODE_TACT: LV(G4_MODE_TACT) break;
         default:           LV(G4_MODE_ACT)  break;
     }
     #undef LV

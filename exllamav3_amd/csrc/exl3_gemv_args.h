@@ -87,6 +87,10 @@ struct GemvTable
     int64_t c_slot_stride;                                          // elements between the outputs of two slots
     const half_t* act_u;                                            // non-null: the input of slot j is fp16(silu(A_j) * act_u_j) (A = gate, act_u = up outputs,
                                                                     // same slot stride): activation.cu silu_mul folded into the down launch of a MoE block
+    // generation 4 (exl3_gemv4.kspec.hip, G4_MODE_TACT / GEMV_OUT_ATOMIC table launches)
+    const uint64_t* act_svh; int act_up_off;                        // svh table of the gate|up launch whose slabs are this launch's input: gate svh = act_svh[matrix],
+                                                                    // up svh = act_svh[matrix + act_up_off]
+    int slots_per_token;                                            // GEMV_OUT_ATOMIC: slot j adds into the rows of token j / slots_per_token
 };
 
 struct SlotRef_t { int mat_index; float weight; };

@@ -12,10 +12,15 @@
 // row's mean square taken from the per-block sums of squares the residual kernel left behind (ss_part [rows][H/128], the same fixed-order sum the
 // GEMV_IN_NORM launches use).  The workgroup forms xn once (LDS, dynamic: H halves), writes it to xn_out for the expert launches and routes on it:
 // the rms_norm launch in front of a MoE block disappears (modules/block_sparse_mlp.py:1099-1130 runs norm, router and experts as separate ops).
+// NORM == 2 (fx pipeline): `hidden` is the residual stream in 64-bit fixed point (int64 [rows][H], value * 2^32: the accumulator the GEMV_OUT_ATOMIC
+// launches add into).  The workgroup reads the whole row anyway, so it takes the EXACT sums of squares of this residual (no estimate from the previous
+// one, unlike the GEMV_IN_FX launches whose workgroups see one k-slice each) and publishes them per Hadamard block in ss_out for the next
+// GEMV_IN_FX launch's estimate and exl3_glue_qkv_rs's correction.
 struct RoutingNorm { const half_t* norm_w; const float* ss_part; half_t* xn_out; float eps;
-                     const uint16_t* per_expert_scale; };      // optional bf16 [E]: weight_k *= scale[expert_k] after the softmax (routing.cu:587-588)
+                     const uint16_t* per_expert_scale;         // optional bf16 [E]: weight_k *= scale[expert_k] after the softmax (routing.cu:587-588)
+                     float* ss_out; };
 
-template <bool NORM>
+template <int NORM>
 __global__ __launch_bounds__(256)
 void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restrict__ gate, const half_t* __restrict__ bias,
                         half_t* __restrict__ scores, int64_t* __restrict__ topk_indices, half_t* __restrict__ topk_weights,
@@ -25,14 +30,101 @@ void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restr
     __shared__ float logit_s[ROUTING_MAX_EXPERTS];
     __shared__ float sel_logit[ROUTING_MAX_K];
     __shared__ int sel_idx[ROUTING_MAX_K];
+    __shared__ float ss_s[256];                                              // NORM == 2: block sums of squares of the row (H <= 32768)
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const half_t* xg = hidden + (size_t) row * H;
     half_t* xn_s = (half_t*) dyn_s;
     // the router input, element h: global memory (plain) or the normalised row in LDS (NORM, valid after form_xn())
-    auto xin = [&] (int h) -> half_t { if constexpr (NORM) return xn_s[h]; else return xg[h]; };
+    auto xin = [&] (int h) -> half_t { if constexpr (NORM != 0) return xn_s[h]; else return xg[h]; };
     auto form_xn = [&] ()
     {
-        if constexpr (NORM)
+        if constexpr (NORM == 2)
+        {
+            const int nblk = H >> 7, l32 = tid & 31, nch4 = H >> 2;
+            const int64_t* rg = (const int64_t*) hidden + (size_t) row * H;
+            auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h((float) (int32_t) hi + (float) lo * 2.3283064365386963e-10f); };
+            auto block_ss = [&] (half4_t xv) -> float                        // sum of squares of one Hadamard block (32 consecutive threads), fixed order
+            {
+                const float r0 = (float) xv.x, r1 = (float) xv.y, r2 = (float) xv.z, r3 = (float) xv.w;
+                float ssq = r0 * r0;
+                ssq = __builtin_fmaf(r1, r1, ssq); ssq = __builtin_fmaf(r2, r2, ssq); ssq = __builtin_fmaf(r3, r3, ssq);
+                #pragma unroll
+                for (int i = 1; i < 32; i <<= 1) ssq += xor_lane(ssq, i);
+                return ssq;
+            };
+            auto row_scale = [&] () -> float                                 // the consumers' fixed-order sum of the block sums
+            {
+                float s2 = 0.0f;
+                for (int b0 = 0; b0 < nblk; b0 += 32)
+                {
+                    float v = (b0 + l32 < nblk) ? ss_s[b0 + l32] : 0.0f;
+                    #pragma unroll
+                    for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
+                    s2 += v;
+                }
+                return __frsqrt_rn(s2 / (float) H + nrm.eps);
+            };
+            auto norm4 = [] (half4_t xv, half4_t wv, float rmf) -> half4_t
+            {
+                return half4_t{ f2h((float) xv.x * (float) wv.x * rmf), f2h((float) xv.y * (float) wv.y * rmf),
+                                f2h((float) xv.z * (float) wv.z * rmf), f2h((float) xv.w * (float) wv.w * rmf) };
+            };
+            if (nch4 <= 1024)
+            {
+                // H <= 4096: the row (4 x 32 bytes per thread) and the norm weight are requested in ONE batch and stay in registers: one memory round trip
+                // (next to the gate rows already in flight), not residual -> barrier -> norm weight
+                uint4_t f0[4], f1[4]; half4_t wv[4], xv[4];
+                #pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    const int c = min(tid + 256 * j, nch4 - 1);              // 32 consecutive threads = one Hadamard block (H / 4 is a multiple of 32)
+                    f0[j] = ((const uint4_t*) rg)[2 * c]; f1[j] = ((const uint4_t*) rg)[2 * c + 1];
+                    wv[j] = ((const half4_t*) nrm.norm_w)[c];
+                }
+                #pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    const int c = tid + 256 * j;
+                    xv[j] = half4_t{ fx(f0[j].x, f0[j].y), fx(f0[j].z, f0[j].w), fx(f1[j].x, f1[j].y), fx(f1[j].z, f1[j].w) };    // x = fp16(R / 2^32), as the GEMV_IN_FX launches read it
+                    const float ssq = block_ss(xv[j]);
+                    if (c < nch4 && l32 == 0) { ss_s[c >> 5] = ssq; nrm.ss_out[(size_t) row * nblk + (c >> 5)] = ssq; }
+                }
+                __syncthreads();
+                const float rmf = row_scale();
+                #pragma unroll
+                for (int j = 0; j < 4; ++j)
+                {
+                    const int c = tid + 256 * j;
+                    if (c < nch4)
+                    {
+                        const half4_t o = norm4(xv[j], wv[j], rmf);
+                        ((half4_t*) xn_s)[c] = o;
+                        ((half4_t*) (nrm.xn_out + (size_t) row * H))[c] = o;
+                    }
+                }
+            }
+            else
+            {
+                for (int c = tid; c < nch4; c += 256)
+                {
+                    const uint4_t f0 = ((const uint4_t*) rg)[2 * c], f1 = ((const uint4_t*) rg)[2 * c + 1];
+                    const half4_t xv = { fx(f0.x, f0.y), fx(f0.z, f0.w), fx(f1.x, f1.y), fx(f1.z, f1.w) };
+                    ((half4_t*) xn_s)[c] = xv;
+                    const float ssq = block_ss(xv);
+                    if (l32 == 0) { ss_s[c >> 5] = ssq; nrm.ss_out[(size_t) row * nblk + (c >> 5)] = ssq; }
+                }
+                __syncthreads();
+                const float rmf = row_scale();
+                for (int c = tid; c < nch4; c += 256)                        // each thread renormalises the chunks it wrote
+                {
+                    const half4_t o = norm4(((const half4_t*) xn_s)[c], ((const half4_t*) nrm.norm_w)[c], rmf);
+                    ((half4_t*) xn_s)[c] = o;
+                    ((half4_t*) (nrm.xn_out + (size_t) row * H))[c] = o;
+                }
+            }
+            __syncthreads();
+        }
+        if constexpr (NORM == 1)
         {
             const int nblk = H >> 7, l32 = tid & 31;
             float s2 = 0.0f;
@@ -216,9 +308,9 @@ extern "C" int exl3_routing_std_scaled(const void* hidden, const void* gate, con
     EXL3_CHECK_ARG(K >= 1 && K <= ROUTING_MAX_K, "Too many experts per token");
     EXL3_CHECK_ARG(K <= num_experts, "K cannot exceed number of experts");
     if (bsz == 0) return EXL3_OK;
-    routing_std_kernel<false><<<bsz, 256, 0, (hipStream_t) stream>>>((const half_t*) hidden, (const half_t*) gate, (const half_t*) bias, (half_t*) scores,
+    routing_std_kernel<0><<<bsz, 256, 0, (hipStream_t) stream>>>((const half_t*) hidden, (const half_t*) gate, (const half_t*) bias, (half_t*) scores,
                                                                     topk_indices, (half_t*) topk_weights, hidden_size, num_experts, K, gu_slots, bsz,
-                                                                    RoutingNorm{ nullptr, nullptr, nullptr, 0.0f, (const uint16_t*) per_expert_scale });
+                                                                    RoutingNorm{ nullptr, nullptr, nullptr, 0.0f, (const uint16_t*) per_expert_scale, nullptr });
     return exl3_check_launch("routing_std");
 }
 
@@ -234,11 +326,30 @@ extern "C" int exl3_routing_std_norm(const void* resid, const void* norm_w, cons
     EXL3_CHECK_ARG(K >= 1 && K <= ROUTING_MAX_K, "Too many experts per token");
     EXL3_CHECK_ARG(K <= num_experts, "K cannot exceed number of experts");
     if (bsz == 0) return EXL3_OK;
-    const RoutingNorm nrm = { (const half_t*) norm_w, ss_part, (half_t*) xn_out, eps, nullptr };
-    routing_std_kernel<true><<<bsz, 256, (size_t) hidden_size * 2, (hipStream_t) stream>>>((const half_t*) resid, (const half_t*) gate, (const half_t*) bias,
+    const RoutingNorm nrm = { (const half_t*) norm_w, ss_part, (half_t*) xn_out, eps, nullptr, nullptr };
+    routing_std_kernel<1><<<bsz, 256, (size_t) hidden_size * 2, (hipStream_t) stream>>>((const half_t*) resid, (const half_t*) gate, (const half_t*) bias,
                                                                                           (half_t*) scores, topk_indices, (half_t*) topk_weights, hidden_size,
                                                                                           num_experts, K, gu_slots, bsz, nrm);
     return exl3_check_launch("routing_std_norm");
+}
+
+// exl3_routing_std_norm of the fx pipeline: resid_fx = the residual stream in 64-bit fixed point (int64 [bsz][hidden], value * 2^32); the launch takes
+// the row's exact mean square itself and leaves the per-block sums of squares in ss_out fp32 [bsz][hidden/128].
+extern "C" int exl3_routing_std_fx(const void* resid_fx, const void* norm_w, float* ss_out, float eps, void* xn_out, const void* gate, const void* bias,
+                                   void* scores, int64_t* topk_indices, void* topk_weights, int64_t* gu_slots, int bsz, int hidden_size,
+                                   int num_experts, int K, void* stream)
+{
+    EXL3_CHECK_ARG(resid_fx && norm_w && ss_out && xn_out && gate && scores && topk_indices && topk_weights, "routing_std_fx: null pointer");
+    EXL3_CHECK_ARG(hidden_size % 128 == 0 && hidden_size <= 32768, "routing_std_fx: hidden must be a multiple of 128, at most 32768");
+    EXL3_CHECK_ARG(num_experts >= 1 && num_experts <= ROUTING_MAX_EXPERTS, "Too many experts");
+    EXL3_CHECK_ARG(K >= 1 && K <= ROUTING_MAX_K, "Too many experts per token");
+    EXL3_CHECK_ARG(K <= num_experts, "K cannot exceed number of experts");
+    if (bsz == 0) return EXL3_OK;
+    const RoutingNorm nrm = { (const half_t*) norm_w, nullptr, (half_t*) xn_out, eps, nullptr, ss_out };
+    routing_std_kernel<2><<<bsz, 256, (size_t) hidden_size * 2, (hipStream_t) stream>>>((const half_t*) resid_fx, (const half_t*) gate, (const half_t*) bias,
+                                                                                       (half_t*) scores, topk_indices, (half_t*) topk_weights, hidden_size,
+                                                                                       num_experts, K, gu_slots, bsz, nrm);
+    return exl3_check_launch("routing_std_fx");
 }
 
 // ------------------------------------------------------------------------------------------------

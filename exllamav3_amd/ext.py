@@ -1064,6 +1064,47 @@ def routing_std_norm(resid, norm_w, ss_part, eps: float, xn_out, gate, scores, t
                                             _p(topk_weights), _p(gu_slots), bsz, resid.shape[-1], scores.shape[1], topk_indices.shape[1], _stream(resid)))
 
 
+def routing_std_fx(resid_fx, norm_w, ss_out, eps: float, xn_out, gate, scores, topk_indices, topk_weights, bias=None, gu_slots=None):
+    """routing_std_norm of the fx pipeline: resid_fx = the int64 fixed-point residual accumulator [bsz, hidden]; the launch takes the row's exact mean
+    square itself, leaves rms_norm(residual) in xn_out and the block sums of squares in ss_out [bsz, hidden / 128]."""
+    _dev(resid_fx)
+    _req(resid_fx.dtype == torch.long and norm_w.dtype == torch.half and xn_out.dtype == torch.half and gate.dtype == torch.half and scores.dtype == torch.half,
+         "routing_std_fx: resid_fx int64; norm_w, xn_out, gate, scores float16")
+    _req(ss_out.dtype == torch.float and topk_indices.dtype == torch.long and topk_weights.dtype == torch.half, "routing_std_fx: bad dtypes")
+    _req(resid_fx.is_contiguous() and xn_out.is_contiguous() and gate.is_contiguous() and scores.is_contiguous() and xn_out.shape == resid_fx.shape
+         and ss_out.is_contiguous() and ss_out.numel() >= resid_fx.numel() // 128, "routing_std_fx: bad layout")
+    bsz = scores.shape[0]
+    _check(_lib.lib().exl3_routing_std_fx(_p(resid_fx), _p(norm_w), _p(ss_out), float(eps), _p(xn_out), _p(gate), _p(bias), _p(scores), _p(topk_indices),
+                                          _p(topk_weights), _p(gu_slots), bsz, resid_fx.shape[-1], scores.shape[1], topk_indices.shape[1], _stream(resid_fx)))
+
+
+def exl3_mgemm_deferred(A, B, suh, indices, K: int, mcg: int, mul1: int, n: int, force_split: int = 0):
+    """Indexed gate|up launch with a deferred epilogue (generation-4 GEMV): A [1 | bszm, m, k] fp16 raw x, B / suh int64 pointer tables, indices int64
+    [bszm]; returns (slab address, S) of the slabs [bszm][n/128][S][m][128] fp32 for exl3_mgemm_act_fx."""
+    _dev(A)
+    _req(A.dtype == torch.half and A.dim() == 3 and A.is_contiguous(), "exl3_mgemm_deferred: A must be contiguous float16 [1 | bszm, m, k]")
+    _req(B.dtype == torch.long and suh.dtype == torch.long and indices.dtype == torch.long and indices.is_contiguous(), "exl3_mgemm_deferred: int64 tables")
+    bszm = indices.numel()
+    _req(A.shape[0] in (1, bszm), "exl3_mgemm_deferred: A has 1 or bszm slots")
+    slab = (_vp * 1)()
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_mgemm_indexed_deferred(_p(A), A.shape[0], _p(B), _p(suh), _p(indices), bszm, A.shape[1], A.shape[2], int(n), int(K),
+                                                  _cb(bool(mcg), bool(mul1)), int(force_split), slab, ctypes.byref(S), _stream(A)))
+    return int(slab[0]), S.value
+
+
+def exl3_mgemm_act_fx(gu_slab: int, gu_S: int, gu_svh, up_off: int, B, suh, svh, indices, weights, R, K: int, mcg: int, mul1: int, k: int, m: int = 1,
+                      num_tokens: int = 1, force_split: int = 0):
+    """Indexed, weighted down launch of a MoE block in the fx pipeline: input silu(g) * u from exl3_mgemm_deferred's slabs, output ADDED into the int64
+    fixed-point residual accumulator R [num_tokens * m, n] (see exl3_mgemm_indexed_act_fx)."""
+    _dev(R)
+    _req(R.dtype == torch.long and R.is_contiguous(), "exl3_mgemm_act_fx: R must be a contiguous int64 accumulator")
+    _req(all(t.dtype == torch.long for t in (gu_svh, B, suh, svh, indices)) and indices.is_contiguous(), "exl3_mgemm_act_fx: int64 tables")
+    _req(weights.dtype == torch.half and weights.is_contiguous() and weights.numel() == indices.numel(), "exl3_mgemm_act_fx: one fp16 weight per slot")
+    _check(_lib.lib().exl3_mgemm_indexed_act_fx(gu_slab, int(gu_S), _p(gu_svh), int(up_off), _p(B), _p(suh), _p(svh), _p(indices), _p(weights), indices.numel(),
+                                                _p(R), int(m), int(k), R.shape[-1], int(K), _cb(bool(mcg), bool(mul1)), int(num_tokens), int(force_split), _stream(R)))
+
+
 def exl3_gemv_ex_act(gu_slabs, gu_S: int, svh_g, svh_u, B, C, suh, svh, m: int, mcg: bool, mul1: bool, flags: int = 0, force_split: int = 0,
                      c_fp32: bool = False):
     """down_proj fed by the gate / up launch's deferred slabs (gu_slabs = [gate ptr, up ptr] as returned by exl3_gemv_ex*): silu(g) * u and the

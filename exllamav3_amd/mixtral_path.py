@@ -110,6 +110,8 @@ class SyntheticEXL3Mixtral:
         self.q = torch.empty((bsz, 1, self.hq, hd), dtype=f16, device=dev)
         self.o = torch.empty((bsz, s.hidden), dtype=f32, device=dev)
         self.ss = torch.empty((bsz, s.hidden // 128), dtype=f32, device=dev)
+        self.ss2 = torch.empty_like(self.ss)
+        self.R = torch.zeros((bsz, s.hidden), dtype=torch.long, device=dev)      # fx pipeline: the residual stream in 64-bit fixed point (value * 2^32)
         self.logits = torch.empty((bsz, self.vocab_local), dtype=f16, device=dev)
         self.attn_pos = pos
         self.attn_out = torch.empty((bsz, self.hq, hd), dtype=f16, device=dev)
@@ -120,6 +122,42 @@ class SyntheticEXL3Mixtral:
         for L in self.layers:
             L["moe"].alloc_state(bsz)
         self._state_bsz = bsz
+
+    def decode_step_fx(self):
+        """Decode step with the residual stream in a fixed-point accumulator (llama_path.decode_step_fx), batch 1, one rank: 6 launches per layer
+        instead of 8 -- q|k|v [reads R, RMSNorm inside], glue_qkv_rs, o_proj [adds into R], router [reads R, exact RMSNorm], indexed gate|up, indexed
+        down [silu(g) * u from the slabs, weighted rows added into R]: 3 launches per MoE block, no split-k reduce / slot sum / residual launch."""
+        bsz, hd, hidden = self._state_bsz, self.shape.head_dim, self.shape.hidden
+        kinds = all(len({(l.K, l.mcg, l.mul1) for l in (L["q"], L["k"], L["v"])}) == 1 for L in self.layers)
+        if self.tp != 1 or bsz != 1 or not kinds:
+            return self.decode_step()
+        R, sc, so_ = self.R, self.ss, self.ss2
+        ATOM = ext.GEMV_OUT_ATOMIC
+        q2 = self.q.view(bsz, -1)
+        ext.qkv_prep(self.inv_freq, self.positions, hd, self.block_table, self.page, self.rope_sin, self.rope_cos, self.kv_slots)
+        tab = (self.rope_sin, self.rope_cos, self.kv_slots)
+        ext.fx_init(self.x0, R, sc, bsz)
+        for li, L in enumerate(self.layers):
+            lq, lk, lv, lo, moe = L["q"], L["k"], L["v"], L["o"], L["moe"]
+            kc, ks = self.kcache[li]
+            vc, vs = self.vcache[li]
+            slabs, S = ext.exl3_gemv_ex_fx(R, L["norm1"], sc, so_, self.eps, [lq.trellis, lk.trellis, lv.trellis], [lq.suh, lk.suh, lv.suh],
+                                           bsz, lq.mcg, lq.mul1)
+            ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                            self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, so_, hidden, self.eps, tab=tab)
+            sc, so_ = so_, sc
+            o_in = q2
+            if self.with_attention:
+                ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
+                                       self.attn_pos + 1, workspace=self.attn_ws)
+                o_in = self.attn_out.view(bsz, -1)
+            ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], [R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM, 8 if self.hq * hd == 4096 else 0)
+            moe.forward_fx(R, L["norm2"], self.eps, so_, self.xn)      # the router leaves the exact sums of squares of the residual it read
+            sc, so_ = so_, sc
+        ext.fx_finish(R, self.x, sc, bsz)
+        ext.exl3_gemv_ex_norm(self.x, self.final_norm, sc, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
+                              bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
+        return self.logits
 
     def decode_step(self):
         """One decode step (bsz tokens, one per sequence), graph-capturable.  Per layer: 4 launches for the attention sublayer (+2 with the

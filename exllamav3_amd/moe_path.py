@@ -30,6 +30,8 @@ class SyntheticEXL3MoE:
         self.first, self.last = 0, experts
         self._build_tables()
 
+    fx_split = tuple(int(v) for v in __import__("os").environ.get("EXL3_HIP_MOE_FX_SPLIT", "0,0").split(","))      # k-slices of the fx block's gate|up / down launches (0: dispatcher)
+
     def _build_tables(self):
         """Device pointer tables of the LOCAL experts [first, last) (all of them without expert parallelism)."""
         ptr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.long, device=self.device)
@@ -132,6 +134,29 @@ class SyntheticEXL3MoE:
         ext.exl3_mgemm_act(self.gu[: t * k], self.gu[t * k:], self.d_B, self.d, self.d_suh, self.d_svh, self.sel.view(-1), self.w.view(-1), self.K,
                            mcg, mul1, -1, -1, num_tokens=t)
         return self.d[:t, 0]
+
+    def forward_fx(self, R: torch.Tensor, norm_w: torch.Tensor, eps: float, ss_out: torch.Tensor, xn: torch.Tensor) -> None:
+        """The block in the fx decode pipeline, 3 launches, one token, all experts local: R (int64 [1, hidden], the fixed-point residual accumulator)
+        += sum_k w_k expert_k(rms_norm(R)).  Router on the RMSNorm it forms from R itself (exact sums of squares -> ss_out for the next layer's
+        q|k|v launch), indexed gate|up launch leaving slabs, indexed down launch that finishes silu(g) * u from them and adds its weighted rows into R
+        with integer atomics (order-independent: bit-reproducible)."""
+        assert R.shape[0] == 1 and (self.first, self.last) == (0, self.E)
+        if self._state != 1:
+            self.alloc_state(1)
+        ext.routing_std_fx(R, norm_w, ss_out, eps, xn, self.router, self.scores, self.sel, self.w, gu_slots=self.sel2)
+        mcg, mul1 = self.cb == 1, self.cb == 2
+        slab, S = ext.exl3_mgemm_deferred(xn.view(1, 1, -1), self.gu_B, self.gu_suh, self.sel2.view(-1), self.K, mcg, mul1, self.inter, self.fx_split[0])
+        sd = self.fx_split[1]
+        if sd == 0:
+            # down launch: slices of 7 Hadamard blocks, so that the 8 half-waves of a 4-wave workgroup finish the slice's silu(g) * u tasks in ONE round
+            # (measured on Mixtral-8x7B, 64 column blocks x 2 slots: S = 8 / 14 / 16 / 19 / 23 -> 368 / 373 / 384 / 375 / 363 tok/s); small blocks keep
+            # the dispatcher's chip-balancing choice
+            nb = self.inter // 128
+            s7 = (nb + 6) // 7
+            if s7 * (self.hidden // 128) * self.top_k >= 512:
+                sd = s7
+        ext.exl3_mgemm_act_fx(slab, S, self.gu_svh, self.E, self.d_B, self.d_suh, self.d_svh, self.sel.view(-1), self.w.view(-1), R, self.K, mcg, mul1,
+                              self.inter, m=1, num_tokens=1, force_split=sd)
 
     def _forward_expert_parallel(self, x: torch.Tensor) -> torch.Tensor:
         """Local experts [first, last) only: the launches filter the routed indices to the range (in-range slots are compacted to the front,

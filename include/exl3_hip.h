@@ -429,6 +429,26 @@ int exl3_mgemm_indexed_act(const void* G, const void* U, const void* tbl_B, cons
                            const int64_t* indices, const void* weights, int bszm, void* C, int m, int k, int n, int K, int cb, int c_fp32,
                            int min_index, int max_index, int num_tokens, void* stream);
 
+/* ---- MoE block of the fx decode pipeline: 3 launches (modules/block_sparse_mlp.py:1099-1130 runs norm, router, the gate / up / down exl3_mgemm launches,
+ * silu_mul and the residual add as separate ops; quant/exl3_gemm_kernel.cuh:88-292 is the indexed kernel).
+ * exl3_routing_std_fx: exl3_routing_std_norm whose input is the residual stream in 64-bit fixed point (int64 [bsz][hidden], value * 2^32, the accumulator
+ *   of the EXL3_GEMV_OUT_ATOMIC launches); the launch takes the row's exact mean square itself and leaves the block sums of squares in ss_out
+ *   [bsz][hidden/128] for the next exl3_gemv_ex_fx / exl3_glue_qkv_rs.
+ * exl3_mgemm_indexed_deferred: the indexed gate|up launch (generation-4 GEMV, raw x, bszm_in == 1: one shared row set) leaving raw split-k slabs
+ *   [slot][n/128][S][m][128]; indices = the router's [gate slots | up slots] list over the tables [gate_0..gate_E-1, up_0..up_E-1].
+ * exl3_mgemm_indexed_act_fx: the indexed down launch: slot j's input fp16(silu(g_j) * u_j) is finished from those slabs (gate slots first, then the up
+ *   slots; gu_svh_tbl = that launch's svh table, up svh = entry + up_off) while the activation fragments are built, and its output rows -- output
+ *   Hadamard, svh and the routing weight applied per split-k partial -- are ADDED into R (int64 [num_tokens][m][n]) with integer atomics:
+ *   no silu_mul, split-k reduce, slot sum or residual launch.  force_split: k-slices (0: the dispatcher balances the chip). */
+int exl3_routing_std_fx(const void* resid_fx, const void* norm_w, float* ss_out, float eps, void* xn_out, const void* gate, const void* bias,
+                        void* scores, int64_t* topk_indices, void* topk_weights, int64_t* gu_slots, int bsz, int hidden_size,
+                        int num_experts, int K, void* stream);
+int exl3_mgemm_indexed_deferred(const void* A, int bszm_in, const void* tbl_B, const void* tbl_suh, const int64_t* indices, int bszm,
+                                int m, int k, int n, int K, int cb, int force_split, float** slab_out, int* S_out, void* stream);
+int exl3_mgemm_indexed_act_fx(const float* gu_slabs, int act_S, const void* gu_svh_tbl, int up_off, const void* tbl_B, const void* tbl_suh,
+                              const void* tbl_svh, const int64_t* indices, const void* weights, int bszm, void* R, int m, int k, int n,
+                              int K, int cb, int num_tokens, int force_split, void* stream);
+
 /* exl3_moe (quant/exl3_moe.cu:99-301) pieces that keep the op free of host round trips (capturable): the slot list of its indexed launches is built
  * on the device.  slot j < max_slots (>= min(E, T) + T / rows_per_slot): slot_expert[j] = expert with 0 < count <= max_rows, or -1 (skipped by the
  * indexed exl3_mgemm launches); slot_tok [max_slots][rows_per_slot] = token of each row (rows past a chunk repeat its last assignment);

@@ -154,3 +154,76 @@ def test_gen4_rmsnorm_hidden_8192_and_graph_replay(dev, m):
             run()
     y.zero_(); g.replay(); g.replay(); torch.cuda.synchronize()
     assert torch.equal(y, y0)
+
+
+@pytest.mark.parametrize("cb", [0, 1, 2])
+@pytest.mark.parametrize("tokens,m", [(1, 1), (2, 1), (1, 3)])
+def test_gen4_table_launches_moe_block_into_fixed_point_accumulator(dev, cb, tokens, m):
+    """The MoE block's two indexed launches of the fx pipeline against the oracle: exl3_mgemm_deferred (table mode, raw x, slabs per slot over the
+    [gate | up] tables) -> exl3_mgemm_act_fx (silu(g) * u from the slabs of slot j / slot bszm + j, routing weight and svh applied per split-k partial,
+    rows ADDED into the int64 accumulator of token j / top_k).  R starts from a known residual; R_after - R_before = sum_k w_k expert_k(x)."""
+    from exllamav3_amd import ext
+    ext.set_gemv_variant(1)
+    K, hidden, inter, E, top = 4, 256, 896, 5, 2
+    rng = np.random.default_rng(10 * cb + tokens + m)
+    T = lambda a: _t(a, dev)
+    gate = [o.synth_linear(hidden, inter, K, seed=10 + e, realistic=True) for e in range(E)]
+    up = [o.synth_linear(hidden, inter, K, seed=30 + e, realistic=True) for e in range(E)]
+    down = [o.synth_linear(inter, hidden, K, seed=50 + e, realistic=True) for e in range(E)]
+    keep = []
+    def table(mats, i):
+        ts = [T(t[i]) for t in mats]; keep.extend(ts)
+        return torch.tensor([t.data_ptr() for t in ts], dtype=torch.long, device=dev)
+    gu_B, gu_suh, gu_svh = (table(gate + up, i) for i in range(3))
+    d_B, d_suh, d_svh = (table(down, i) for i in range(3))
+    sel = np.array([[3, 0], [1, 3]][:tokens], dtype=np.int64)                 # (tokens, top)
+    w = np.array([[0.7, 0.3], [0.45, 0.55]][:tokens], dtype=np.float16)
+    x = rng.standard_normal((tokens, m, hidden)).astype(np.float16)
+    sel2 = np.concatenate([sel.reshape(-1), sel.reshape(-1) + E])            # [gate slots | up slots]
+    A = x if tokens == 1 else np.concatenate([np.repeat(x, top, axis=0)] * 2) # one shared row set, or one per slot
+    r0 = (rng.standard_normal((tokens * m, hidden)) * 3).astype(np.float32)
+    R = torch.from_numpy(np.rint(r0.astype(np.float64) * 2.0 ** 32).astype(np.int64)).to(dev)
+    R0 = R.clone()
+    slab, S = ext.exl3_mgemm_deferred(T(A), gu_B, gu_suh, T(sel2), K, cb == 1, cb == 2, inter)
+    ext.exl3_mgemm_act_fx(slab, S, gu_svh, E, d_B, d_suh, d_svh, T(sel.reshape(-1)), T(w.reshape(-1)), R, K, cb == 1, cb == 2, inter, m=m, num_tokens=tokens)
+    torch.cuda.synchronize()
+    got = ((R - R0).double() / 2.0 ** 32).cpu().numpy().reshape(tokens, m, hidden)
+    lin = lambda xx, t, fp32=False: o.linear_forward(xx, t[0], t[1], t[2], K, cb, out_fp32=fp32).astype(np.float32)
+    for t in range(tokens):
+        ref = np.zeros((m, hidden), dtype=np.float32)
+        for j in range(top):
+            e = int(sel[t, j])
+            g, u = lin(x[t], gate[e]), lin(x[t], up[e])
+            a = (g / (1 + np.exp(-g)) * u).astype(np.float16)
+            ref += float(w[t, j]) * lin(a, down[e], fp32=True)
+        assert _rel(got[t], ref) < 2e-2, (t, _rel(got[t], ref))
+    # order independence: a second run from the same start gives the same integers
+    R2 = R0.clone()
+    slab, S = ext.exl3_mgemm_deferred(T(A), gu_B, gu_suh, T(sel2), K, cb == 1, cb == 2, inter)
+    ext.exl3_mgemm_act_fx(slab, S, gu_svh, E, d_B, d_suh, d_svh, T(sel.reshape(-1)), T(w.reshape(-1)), R2, K, cb == 1, cb == 2, inter, m=m, num_tokens=tokens)
+    assert torch.equal(R, R2)
+
+
+def test_routing_on_the_fixed_point_residual_matches_routing_std_norm(dev):
+    """routing_std_fx (router input = RMSNorm of the int64 fixed-point residual, exact sums of squares taken inside the launch) against
+    routing_std_norm on the fp16 copy of the same residual with glue_resid's block sums: same experts, weights, normalised row and block sums."""
+    from exllamav3_amd import ext
+    E, top = 8, 2
+    rng = np.random.default_rng(3)
+    T = lambda a: _t(a, dev)
+    for bsz, hidden in ((1, 1024), (3, 1024), (2, 5120)):                    # hidden > 4096: the row does not stay in registers
+        xh = (rng.standard_normal((bsz, hidden)) * 2).astype(np.float16)
+        R = torch.from_numpy(np.rint(xh.astype(np.float64) * 2.0 ** 32).astype(np.int64)).to(dev)
+        w = T((1 + 0.1 * rng.standard_normal(hidden)).astype(np.float16)); gate = T((rng.standard_normal((hidden, E)) * 0.05).astype(np.float16))
+        mk = lambda: (torch.empty((bsz, E), dtype=torch.half, device=dev), torch.empty((bsz, top), dtype=torch.long, device=dev),
+                      torch.empty((bsz, top), dtype=torch.half, device=dev), torch.empty((2, bsz * top), dtype=torch.long, device=dev),
+                      torch.empty((bsz, hidden), dtype=torch.half, device=dev))
+        sc0, sel0, w0, gu0, xn0 = mk(); sc1, sel1, w1, gu1, xn1 = mk()
+        ss = torch.empty((bsz, hidden // 128), dtype=torch.float32, device=dev); ss1 = torch.full_like(ss, float("nan"))
+        x_d = T(xh)
+        ext.glue_resid(None, 0, None, None, x_d, ss, bsz)
+        ext.routing_std_norm(x_d, w, ss, 1e-5, xn0, gate, sc0, sel0, w0, gu_slots=gu0)
+        ext.routing_std_fx(R, w, ss1, 1e-5, xn1, gate, sc1, sel1, w1, gu_slots=gu1)
+        torch.cuda.synchronize()
+        assert torch.equal(sel0, sel1) and torch.equal(gu0, gu1) and torch.equal(xn0, xn1) and torch.equal(w0, w1) and torch.equal(sc0, sc1)
+        assert np.allclose(ss1.cpu().numpy(), ss.cpu().numpy(), rtol=1e-6)

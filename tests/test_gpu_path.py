@@ -1165,6 +1165,40 @@ def test_mixtral_fused_moe_tail_and_router_norm_agree_with_separate_launches(dev
     assert np.array_equal(model.logits.float().cpu().numpy(), l1)
 
 
+@pytest.mark.parametrize("cb", [0, 2])
+@pytest.mark.parametrize("with_attention", [False, True])
+def test_mixtral_fixed_point_pipeline_matches_the_launch_per_op_moe_block(dev, cb, with_attention):
+    """mixtral_path.decode_step_fx (batch 1: 6 launches per layer, the MoE block in 3 -- router on the fixed-point residual, indexed gate|up launch leaving
+    slabs, indexed down launch adding its weighted rows into the accumulator with integer atomics) against decode_step with every stage as its own
+    launch: logits and final residual agree to fp16 rounding; the same experts are routed in every layer; graph replay and a second eager run
+    reproduce the bits (integer atomics: no dependence on arrival order)."""
+    from exllamav3_amd.mixtral_path import MixtralShape, SyntheticEXL3Mixtral
+    shape = MixtralShape("tiny-moe", 512, 896, 3, 4, 2, 128, 384, 8, 2)      # inter / 128 = 7 blocks: odd unit counts in the down launch
+    model = SyntheticEXL3Mixtral(shape, K=4, cb=cb, device=dev, kv_bits=4, max_ctx=1024)
+    model.alloc_state(1, pos=77)
+    model.with_attention = with_attention
+    model.norm_in_router, model.fused_moe_tail = False, False
+    l0 = model.decode_step().float().cpu().numpy().copy(); x0 = model.x.float().cpu().numpy().copy()
+    sel0 = [L["moe"].sel.cpu().numpy().copy() for L in model.layers]
+    l1 = model.decode_step_fx().float().cpu().numpy().copy(); x1 = model.x.float().cpu().numpy().copy()
+    sel1 = [L["moe"].sel.cpu().numpy().copy() for L in model.layers]
+    assert all(np.array_equal(a, b) for a, b in zip(sel0, sel1))
+    rms = np.sqrt((l0 ** 2).mean())
+    assert np.isfinite(l1).all() and np.abs(l1 - l0).max() / rms < 1e-2, np.abs(l1 - l0).max() / rms
+    assert np.abs(x1 - x0).max() / np.sqrt((x0 ** 2).mean()) < 1e-2
+    l2 = model.decode_step_fx().float().cpu().numpy().copy()
+    assert np.array_equal(l2, l1)
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            model.decode_step_fx()
+    for _ in range(2):
+        model.logits.zero_(); g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(model.logits.float().cpu().numpy(), l1)
+
+
 @pytest.mark.parametrize("bsz", [1, 3])
 @pytest.mark.parametrize("with_attention", [False, True])
 def test_mixtral_layer_path_matches_oracle(dev, bsz, with_attention):
