@@ -165,15 +165,33 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
                         if (!(key <= qpos[u] && key < kv_len)) st[u][kb][j] = -1.0e30f;
                     }
         }
+        // Deferred running max: the reference point m_run of the exponent moves only when some query of the wave saw a score more than 8 (log2 units)
+        // above it -- p <= 2^8 otherwise, well inside the fp16 / fp32 range -- so the accumulator rescale (64 multiplies + 8 ds_bpermute behind the
+        // other waves' fragment reads) runs in a few early tiles instead of most of them (with 32 queries per wave SOME query's max moves in most tiles)
+        float mxu[QG];
+        bool need = false;
         #pragma unroll
         for (int u = 0; u < QG; ++u)
         {
-            float mx = m_run[u];
+            float mx = st[u][0][0];
             #pragma unroll
             for (int kb = 0; kb < PA_BN / 16; ++kb)
                 mx = fmaxf(fmaxf(mx, fmaxf(st[u][kb][0], st[u][kb][1])), fmaxf(st[u][kb][2], st[u][kb][3]));
             mx = fmaxf(mx, xor_lane(mx, 16)); mx = fmaxf(mx, xor_lane(mx, 32));
-            corr[u] = __builtin_amdgcn_exp2f((m_run[u] - mx) * sl);
+            mxu[u] = mx;
+            need = need || (mx - m_run[u]) * sl > 8.0f;
+        }
+        const bool upd = __any(need);
+        #pragma unroll
+        for (int u = 0; u < QG; ++u)
+        {
+            float mx = m_run[u];
+            corr[u] = 1.0f;
+            if (upd)
+            {
+                mx = fmaxf(mx, mxu[u]);
+                corr[u] = __builtin_amdgcn_exp2f((m_run[u] - mx) * sl);
+            }
             const float mxs = mx * sl;
             float ps = 0.0f;
             #pragma unroll
@@ -189,10 +207,7 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
             m_run[u] = mx;
         }
         // ---- rescale the accumulator rows (queries 4g + j of each group) where the running max moved, and add P V
-        bool moved = false;
-        #pragma unroll
-        for (int u = 0; u < QG; ++u) moved = moved || corr[u] != 1.0f;
-        if (__any(moved))
+        if (upd)
         {
             float cr[QG][4];
             #pragma unroll
