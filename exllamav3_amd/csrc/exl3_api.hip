@@ -48,7 +48,9 @@ static int init_device(int device)
     EXL3_CHECK_HIP(hipMalloc((void**) &c.workspace, EXL3_WORKSPACE_BYTES), "hipMalloc(workspace)");
     EXL3_CHECK_HIP(hipMalloc((void**) &c.tickets, EXL3_NUM_TICKETS * sizeof(uint32_t)), "hipMalloc(tickets)");
     EXL3_CHECK_HIP(hipMemset(c.tickets, 0, EXL3_NUM_TICKETS * sizeof(uint32_t)), "hipMemset(tickets)");
+    EXL3_CHECK_HIP(hipEventCreateWithFlags(&c.switch_event, hipEventDisableTiming), "hipEventCreate");
     EXL3_CHECK_HIP(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    c.last_stream_valid = false;
     c.ready = true;
     (void) hipSetDevice(prev);
     return EXL3_OK;
@@ -71,7 +73,28 @@ Exl3DevCtx* exl3_get_ctx(hipStream_t stream)
         }
         if (init_device(device) != EXL3_OK) return nullptr;
     }
-    return &g_ctx[device];
+    Exl3DevCtx& c = g_ctx[device];
+    if (c.last_stream_valid && c.last_stream != stream)
+    {
+        // another stream than the previous workspace user's: order it behind that one (once per change; nothing on the common one-stream path)
+        hipStreamCaptureStatus so = hipStreamCaptureStatusNone, sn = hipStreamCaptureStatusNone;
+        (void) hipStreamIsCapturing(c.last_stream, &so);
+        (void) hipStreamIsCapturing(stream, &sn);
+        if (so != hipStreamCaptureStatusNone)
+        {
+            exl3_set_error("exl3: the per-device workspace was last used by a stream that is still capturing; all launches of one graph must be issued on one stream");
+            return nullptr;
+        }
+        if (sn == hipStreamCaptureStatusNone)
+        {
+            // (a previous stream that has been destroyed in the meantime fails the record: nothing left to order against)
+            if (hipEventRecord(c.switch_event, c.last_stream) == hipSuccess) (void) hipStreamWaitEvent(stream, c.switch_event, 0);
+            (void) hipGetLastError();
+        }
+        // (a capturing new stream after an eager one: the capture's replays are ordered by whoever launches the graph)
+    }
+    c.last_stream = stream; c.last_stream_valid = true;
+    return &c;
 }
 
 extern "C" int exl3_device_info(int device, int* num_cus, int* gfx_arch, int64_t* hbm_bytes)

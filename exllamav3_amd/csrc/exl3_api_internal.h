@@ -22,6 +22,10 @@ struct Exl3DevCtx
     uint32_t* tickets;         // zero-initialised, every kernel leaves it zeroed
     int    ws_toggle;          // slab-writing launches alternate between two workspace regions: a launch may read its predecessor's slabs
                                // (GEMV ACT mode) while its own workgroups already write theirs
+    // The workspace is one per device: when the issuing stream changes, the new stream is ordered behind the previous one (event edge), so
+    // launches that use the workspace never overlap across streams.  A change in the middle of a graph capture cannot be ordered this way and
+    // is refused (exl3_get_ctx).
+    hipStream_t last_stream; bool last_stream_valid; hipEvent_t switch_event;
 };
 #define EXL3_WORKSPACE_BYTES (64ll << 20)
 #define EXL3_NUM_TICKETS 65536

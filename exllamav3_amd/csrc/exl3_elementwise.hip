@@ -203,6 +203,48 @@ extern "C" int exl3_silu_mul(const void* g, const void* u, void* y, int64_t nume
     return exl3_check_launch("silu_mul");
 }
 
+// y = act(g) * u for the activations of the reference's gated MLP (activation.cu: silu_mul, gelu_mul, relu2_mul, silu_oai_mul; kernels
+// activation_kernels.cuh:142-254).  act: 0 SiLU, 1 GELU (tanh form), 2 relu(x)^2, 3 relu, 4 gpt-oss clamped swiglu ((u + 1) * g * sigmoid(1.702 g), gate clamped
+// from above, up symmetrically, before the activation).  act_limit != 0 (acts 0..3): u clamped to [-limit, limit], act(g) to <= limit.  fp32 arithmetic, one
+// rounding to fp16 (clamped to the finite range) at the end.
+__device__ __forceinline__ float act_mul_one(float g, float u, int act, float limit)
+{
+    if (act == 4)
+    {
+        if (limit != 0.0f) { g = fminf(g, limit); u = fminf(fmaxf(u, -limit), limit); }
+        return (u + 1.0f) * (g / (1.0f + __expf(-1.702f * g)));
+    }
+    float a;
+    if (act == 0) a = g / (1.0f + __expf(-g));
+    else if (act == 1) a = 0.5f * g * (1.0f + tanhf(0.797884560803f * (g + 0.044715f * g * g * g)));
+    else if (act == 2) { a = fmaxf(0.0f, g); a = a * a; }
+    else a = fmaxf(0.0f, g);
+    if (limit != 0.0f) { u = fminf(fmaxf(u, -limit), limit); a = fminf(a, limit); }
+    return fminf(fmaxf(a * u, -65504.0f), 65504.0f);
+}
+
+__global__ __launch_bounds__(256)
+void act_mul_kernel(const void* __restrict__ g, const void* __restrict__ u, half_t* __restrict__ y, int64_t n4, int in_fp32, int act, float limit)
+{
+    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4_t gv = load4(g, i, in_fp32), uv = load4(u, i, in_fp32);
+    float4_t o = { act_mul_one(gv.x, uv.x, act, limit), act_mul_one(gv.y, uv.y, act, limit), act_mul_one(gv.z, uv.z, act, limit), act_mul_one(gv.w, uv.w, act, limit) };
+    store4(y, i, o, false);
+}
+
+extern "C" int exl3_act_mul(const void* g, const void* u, void* y, int64_t numel, int in_fp32, int act, float act_limit, void* stream)
+{
+    EXL3_CHECK_ARG(g && u && y, "act_mul: null pointer");
+    EXL3_CHECK_ARG(numel % 4 == 0, "act_mul: numel must be divisible by 4");
+    EXL3_CHECK_ARG(act >= 0 && act <= 4, "act_mul: activation must be 0 (silu), 1 (gelu), 2 (relu2), 3 (relu) or 4 (silu_oai)");
+    EXL3_CHECK_ARG(act_limit >= 0.0f, "act_mul: act_limit must be >= 0");
+    if (numel == 0) return EXL3_OK;
+    int64_t n4 = numel / 4;
+    act_mul_kernel<<<dim3((unsigned) ((n4 + 255) / 256)), dim3(256), 0, (hipStream_t) stream>>>(g, u, (half_t*) y, n4, in_fp32, act, act_limit);
+    return exl3_check_launch("act_mul");
+}
+
 // row-strided variant (fp16): g and u are column ranges of wider matrices (the fused gate|up prefill GEMM writes one [rows][2*cols] output);
 // 8 halves per thread (16-byte accesses)
 __global__ __launch_bounds__(256)

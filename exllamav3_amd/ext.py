@@ -767,6 +767,33 @@ def silu_mul(g, u, y):
     _check(_lib.lib().exl3_silu_mul(_p(g), _p(u), _p(y), g.numel(), int(g.dtype == torch.float), _stream(g)))
 
 
+ACT_SILU, ACT_GELU, ACT_RELU2, ACT_RELU, ACT_SILU_OAI = 0, 1, 2, 3, 4
+
+
+def act_mul(g, u, y, act: int, act_limit: float = 0.0):
+    """activation.cu silu_mul / gelu_mul / relu2_mul / silu_oai_mul (x, y, z, act_limit): y = fp16(act(g) * u) with the reference's clamps."""
+    _dev(g)
+    _req(g.shape == u.shape and g.dtype == u.dtype and g.dtype in (torch.half, torch.float), "act_mul: bad inputs")
+    _req(y.dtype == torch.half and y.numel() == g.numel(), "act_mul: y must be float16")
+    _req(g.is_contiguous() and u.is_contiguous() and y.is_contiguous(), "act_mul: tensors must be contiguous")
+    _check(_lib.lib().exl3_act_mul(_p(g), _p(u), _p(y), g.numel(), int(g.dtype == torch.float), int(act), float(act_limit), _stream(g)))
+
+
+def gelu_mul(x, y, z, act_limit: float = 0.0):
+    """activation.cu:246-254"""
+    act_mul(x, y, z, ACT_GELU, act_limit)
+
+
+def relu2_mul(x, y, z, act_limit: float = 0.0):
+    """activation.cu:324-332"""
+    act_mul(x, y, z, ACT_RELU2, act_limit)
+
+
+def silu_oai_mul(x, y, z, act_limit: float = 0.0):
+    """activation.cu:168-176 (gpt-oss clamped swiglu)"""
+    act_mul(x, y, z, ACT_SILU_OAI, act_limit)
+
+
 def silu_mul_2d(g, u, y):
     """y = silu(g) * u for fp16 2-D views with unit column stride (g, u may be column ranges of one wider matrix)."""
     _dev(g)
@@ -966,15 +993,16 @@ class BC_GatedMLP:
     runs exl3_mgemm -> silu_mul -> exl3_gemm (+ bias adds) as separate graph nodes; here the SiLU path without biases is three
     launches with no intermediate round trip of g/u: gate/up GEMV with deferred epilogue -> glue_act (split-k reduce, output
     Hadamards, silu(g)*u, input Hadamard of down) -> down GEMV on the pre-rotated input.  `a` still receives silu(g)*u (the
-    reference's observable intermediate).  GELU / relu2 / act_limit are outside this build."""
+    reference's observable intermediate).  GELU / relu2 / an act_limit take the reference's launch-per-op route (gate, up, act_mul, down)."""
 
     def __init__(self, guh, gu, a, down_xh, gu_ptrs_trellis, gu_ptrs_suh, gu_ptrs_svh, gu_K, gu_mcg, gu_mul1,
                  act_silu, act_gelu, act_relu2, gate, up, down, act_limit):
         _req(gu_ptrs_trellis is not None or (gate is not None and up is not None),
              "BC_GatedMLP: need fused mgemm tensors or gate/up handles")
         _req(gate is not None and up is not None and down is not None, "BC_GatedMLP: this build needs the gate/up/down handles")
-        _req(bool(act_silu) and not act_gelu and not act_relu2, "BC_GatedMLP: only the SiLU activation is provided by this build")
-        _req(float(act_limit) == 0.0, "BC_GatedMLP: act_limit is outside this build")
+        _req(int(bool(act_silu)) + int(bool(act_gelu)) + int(bool(act_relu2)) == 1, "BC_GatedMLP: exactly one of act_silu / act_gelu / act_relu2")
+        self.act = ACT_SILU if act_silu else (ACT_GELU if act_gelu else ACT_RELU2)
+        self.act_limit = float(act_limit)
         self.guh, self.gu, self.a, self.down_xh = guh, gu, a, down_xh
         self.gate, self.up, self.down = gate, up, down
         self._xs = None
@@ -990,11 +1018,11 @@ class BC_GatedMLP:
         a_n = self.a.view(-1, inter)[:m]
         xh_n = self.down_xh.view(-1, inter)[:m]
         _req(a_n.shape[0] == m and xh_n.shape[0] == m, "run_bszN: scratch buffers too small for this bsz")
-        if g.bias is not None or u.bias is not None or g.K != u.K or g.mcg != u.mcg or g.mul1 != u.mul1:
-            # op-by-op route (reference's non-mgemm branch, mlp.cpp:62-77)
+        if g.bias is not None or u.bias is not None or g.K != u.K or g.mcg != u.mcg or g.mul1 != u.mul1 or self.act != ACT_SILU or self.act_limit != 0.0:
+            # op-by-op route (reference's non-mgemm branch, mlp.cpp:62-77; also every activation other than the plain SiLU)
             gu_n = self.gu.view(2, -1, inter)[:, :m].contiguous() if self.gu.numel() >= 2 * m * inter else torch.empty((2, m, inter), dtype=torch.half, device=x.device)
             g.run(x2, gu_n[0]); u.run(x2, gu_n[1])
-            silu_mul(gu_n[0], gu_n[1], a_n)
+            act_mul(gu_n[0], gu_n[1], a_n, self.act, self.act_limit)
             dn.run(a_n, d.view(m, -1))
             return
         if self._xs is None or self._xs.shape[0] < m:

@@ -22,9 +22,10 @@
  *   - ONE STREAM PER DEVICE AT A TIME.  The split-k partial slabs, the arrival tickets, the generation-3 rotated-activation scratch and the
  *     hgemm workspace are one per device (like the reference's DevCtx lock buffer + workspace, quant/exl3_devctx.cuh:8-19), and slab-writing
  *     GEMV launches alternate between two workspace regions in issue order (a launch may read its predecessor's slabs: exl3_gemv_ex_act,
- *     exl3_glue_*).  Calls on one device must therefore be issued from one host thread at a time onto one stream (or onto streams that are
- *     ordered with respect to each other); two streams / threads issuing GEMVs concurrently on the same device overwrite each other's
- *     partial sums.  The reference has the same contract (its A_had scratch and lock buffer are shared by every Linear of a device,
+ *     exl3_glue_*).  Calls on one device must therefore be issued from one host thread at a time.  When the issuing stream changes between two
+ *     calls that use the workspace, the library orders the new stream behind the previous one with an event edge (so two streams never overlap
+ *     inside the workspace); a change while the previous stream is still capturing a graph is refused with an error -- all launches of one graph
+ *     go onto one stream.  The reference has the same contract (its A_had scratch and lock buffer are shared by every Linear of a device,
  *     SURVEY.md 8b Ownership).  Different devices are independent.
  */
 #ifndef EXL3_HIP_H
@@ -404,6 +405,15 @@ int exl3_dequant_cache_paged_ex(const void* k_in, const void* k_scales, void* k_
 /* ---- elementwise glue used by the decode step (activation.cu silu_mul, add.cu) -------------------- */
 /* y = silu(g) * u ; g, u fp16 or fp32 (in_fp32) [rows][dim]; y fp16 */
 int exl3_silu_mul(const void* g, const void* u, void* y, int64_t numel, int in_fp32, void* stream);
+/* y = fp16(act(g) * u): the other activations of the reference's gated MLP (activation.cu gelu_mul :181-254, relu2_mul :259-330, silu_oai_mul :103-176; kernels
+ * activation_kernels.cuh:142-254).  act: 0 SiLU, 1 GELU (tanh form), 2 relu^2, 3 relu, 4 gpt-oss clamped swiglu.  act_limit != 0: up clamped to [-limit, limit], the
+ * activated gate to <= limit (act 4: gate and up clamped BEFORE the activation).  g, u fp16 or fp32 (in_fp32), numel % 4 == 0. */
+#define EXL3_ACT_SILU 0
+#define EXL3_ACT_GELU 1
+#define EXL3_ACT_RELU2 2
+#define EXL3_ACT_RELU 3
+#define EXL3_ACT_SILU_OAI 4
+int exl3_act_mul(const void* g, const void* u, void* y, int64_t numel, int in_fp32, int act, float act_limit, void* stream);
 /* x (fp16 or fp32) += y (fp16 or fp32) */
 int exl3_add(void* x, const void* y, int64_t numel, int x_fp32, int y_fp32, void* stream);
 /* softcap(x, y, scale)   softcap.cu:59-100: y = scale * tanh(x / scale) (fp32 math; fp16 or fp32 tensors; y == x allowed); Linear.forward's

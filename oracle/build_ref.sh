@@ -4,6 +4,8 @@
 #   oracle/_ref/libexl3_ref_cuda.so  the reference's DEVICE headers for the codebooks, the trellis window readers and the KV-cache
 #                                    quantizer (quant/codebook.cuh, quant/exl3_dq.cuh, cache/lmq.cuh, cache/q_cache_kernels.cuh) compiled for
 #                                    the host on top of oracle/cuda_host_shim.h, behind the extern "C" harness oracle/ref_cuda_harness.cpp;
+#   oracle/_ref/libexl3_ref_act.so   the reference's activation kernels (activation_kernels.cuh act_mul_kernel_h / _f: silu / gelu / relu2 / relu / silu_oai
+#                                    times up, with the act_limit clamps) the same way, behind oracle/ref_act_harness.cpp;
 #   oracle/_ref/libexl3_ref_mul1.so  the reference's own host-only C++ (exllamav3_ext/cpu/moe_mul1.cpp) + oracle/ref_harness.cpp.
 # Skips quietly when /root/reference is absent (GPU box: the prebuilt .so travels with the snapshot).
 set -e
@@ -20,6 +22,13 @@ if [ "$OUT/libexl3_ref_cuda.so" -nt "$HERE/ref_cuda_harness.cpp" ] && [ "$OUT/li
 else
     g++ -O1 -std=c++17 -fPIC -shared -Wno-attributes -I"$REF" -I"$HERE" "$HERE/ref_cuda_harness.cpp" -lpthread -o "$OUT/libexl3_ref_cuda.so"
     echo "build_ref: built $OUT/libexl3_ref_cuda.so"
+fi
+if [ "$OUT/libexl3_ref_act.so" -nt "$HERE/ref_act_harness.cpp" ] && [ "$OUT/libexl3_ref_act.so" -nt "$HERE/cuda_host_shim.h" ] \
+   && [ "$OUT/libexl3_ref_act.so" -nt "$REF/activation_kernels.cuh" ]; then
+    echo "build_ref: libexl3_ref_act.so up to date"
+else
+    g++ -O1 -std=c++17 -fPIC -shared -Wno-attributes -DUSE_ROCM -I"$REF" -I"$HERE" "$HERE/ref_act_harness.cpp" -lpthread -o "$OUT/libexl3_ref_act.so"
+    echo "build_ref: built $OUT/libexl3_ref_act.so"
 fi
 if [ "$OUT/libexl3_ref_mul1.so" -nt "$HERE/ref_harness.cpp" ] && [ "$OUT/libexl3_ref_mul1.so" -nt "$REF/cpu/moe_mul1.cpp" ]; then
     echo "build_ref: up to date"; exit 0

@@ -538,6 +538,53 @@ def kv_dequant_paged(k_in, k_scales, k_out, v_in, v_scales, v_out, cache_seqlens
                 ko[orow, sl] = kd[sl]; vo[orow, sl] = vd[sl]
 
 
+def act_mul(g: np.ndarray, u: np.ndarray, act: str, act_limit: float = 0.0) -> np.ndarray:
+    """z = act(g) * u of the reference's gated MLP (activation_kernels.cuh:142-254 act_mul_kernel_h / _f; activations :9-128).  act: "silu", "gelu",
+    "relu2", "relu", "silu_oai".  fp16 inputs follow act_mul_kernel_h: the activation result is rounded to fp16 (gelu / relu2 are computed in fp32 and
+    rounded, :40-49, :67-73), the clamps and the product are fp16 operations; fp32 inputs follow act_mul_kernel_f (fp32 throughout, one rounding, clamp
+    to the finite fp16 range).  silu_oai (:118-128) is fp32 in both."""
+    half_in = g.dtype == np.float16
+    gf, uf = g.astype(np.float32), u.astype(np.float32)
+    L = np.float32(act_limit)
+    if act == "silu_oai":
+        if act_limit != 0.0:
+            gf = np.minimum(gf, L); uf = np.minimum(np.maximum(uf, -L), L)
+        r = (uf + np.float32(1)) * (gf / (np.float32(1) + np.exp(np.float32(-1.702) * gf)))
+        r = r.astype(np.float32)
+        return (r if half_in else np.clip(r, -65504.0, 65504.0)).astype(np.float16)
+    if act == "silu":
+        if half_in:
+            # _silu(half2): every step rounded to fp16 (:21-31)
+            e = np.exp(-g.astype(np.float32)).astype(np.float16)
+            sm = (np.float16(1) + e).astype(np.float16)
+            rc = (np.float32(1) / sm.astype(np.float32)).astype(np.float16)
+            a = (g * rc).astype(np.float16)
+        else:
+            a = gf / (np.float32(1) + np.exp(-gf))
+    elif act == "gelu":
+        # tanh_opt of compat.cuh:12-18, the exp-based branch the reference builds on AMD: copysign((1 - e) / (e + 1), x), e = exp(-2 |x|)
+        targ = (np.float32(0.797884560803) * (gf + np.float32(0.044715) * gf * gf * gf)).astype(np.float32)
+        e = np.exp(np.float32(-1) * np.abs(np.float32(2) * targ)).astype(np.float32)
+        th = np.copysign(((np.float32(1) - e) / (e + np.float32(1))).astype(np.float32), targ)
+        a = (np.float32(0.5) * gf * (np.float32(1) + th)).astype(np.float32)
+    elif act == "relu2":
+        a = np.maximum(gf, np.float32(0)) ** 2
+    elif act == "relu":
+        a = np.maximum(gf, np.float32(0))
+    else:
+        raise ValueError(act)
+    if half_in:
+        a = a.astype(np.float16); uu = u
+        if act_limit != 0.0:
+            Lh = np.float16(act_limit)
+            uu = np.minimum(np.maximum(uu, -Lh), Lh); a = np.minimum(a, Lh)
+        return (a.astype(np.float32) * uu.astype(np.float32)).astype(np.float16)
+    a = a.astype(np.float32)
+    if act_limit != 0.0:
+        uf = np.minimum(np.maximum(uf, -L), L); a = np.minimum(a, L)
+    return np.clip(a * uf, -65504.0, 65504.0).astype(np.float16)
+
+
 def softcap(x: np.ndarray, scale: float) -> np.ndarray:
     """y = scale * tanh(x / scale) in fp32, rounded to x's dtype (exllamav3_ext/softcap.cu:11-52)."""
     v = x.astype(np.float32) / np.float32(scale)

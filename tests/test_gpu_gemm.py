@@ -135,6 +135,43 @@ def test_graph_capture_replay(dev):
     assert torch.equal(y, expect)
 
 
+def test_two_streams_share_the_device_workspace_safely(dev):
+    """The split-k slabs live in one per-device workspace: when the issuing stream changes the library orders the new stream behind the old one, so
+    GEMVs issued alternately on two streams (no host synchronisation in between) still give the oracle's rows; switching streams in the middle of a
+    graph capture is refused."""
+    from exllamav3_amd import ext
+    k, n, K, cb = 4096, 512, 4, 2
+    rng = np.random.default_rng(5)
+    tr, suh, svh = o.synth_linear(k, n, K, seed=3, realistic=True)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    tr_d, su_d, sv_d = T(tr), T(suh), T(svh)
+    xs = [rng.standard_normal((1, k)).astype(np.float16) for _ in range(8)]
+    xd = [T(x) for x in xs]
+    ys = [torch.full((1, n), float("nan"), dtype=torch.half, device=dev) for _ in range(8)]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for i in range(8):
+        with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+            ext.exl3_gemm(xd[i], tr_d, ys[i], su_d, None, sv_d, -1, False, True, 0, force_split=8)
+    torch.cuda.synchronize()
+    for i in range(8):
+        ref = o.linear_forward(xs[i], tr, suh, svh, K, cb).astype(np.float32)
+        assert np.abs(ys[i].float().cpu().numpy() - ref).max() < 1e-2 * np.sqrt((ref ** 2).mean()), i
+    # a stream change while the previous stream is capturing cannot be ordered: refused
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(g, stream=st):
+            ext.exl3_gemm(xd[0], tr_d, ys[0], su_d, None, sv_d, -1, False, True, 0, force_split=8)
+            with torch.cuda.stream(s2):
+                with pytest.raises(RuntimeError):
+                    ext.exl3_gemm(xd[1], tr_d, ys[1], su_d, None, sv_d, -1, False, True, 0, force_split=8)
+    torch.cuda.synchronize()
+    g.replay(); torch.cuda.synchronize()
+    ref = o.linear_forward(xs[0], tr, suh, svh, K, cb).astype(np.float32)
+    assert np.abs(ys[0].float().cpu().numpy() - ref).max() < 1e-2 * np.sqrt((ref ** 2).mean())
+
+
 @pytest.mark.parametrize("max_waves", [1, 3, 4, 7, 16])
 def test_gen2_waves_per_workgroup(dev, max_waves):
     """gen 2 lets up to 16 waves split a workgroup's k-slice (uneven block counts, waves without work)."""

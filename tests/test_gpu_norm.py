@@ -77,6 +77,26 @@ def test_silu_mul_add(dev):
     assert np.allclose(a.cpu().numpy(), g + u.astype(np.float16).astype(np.float32), rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("act", ["silu", "gelu", "relu2", "relu", "silu_oai"])
+@pytest.mark.parametrize("limit", [0.0, 1.5])
+def test_act_mul_activations_and_limits(dev, act, limit):
+    """exl3_act_mul (activation.cu gelu_mul / relu2_mul / silu_oai_mul and their act_limit clamps) against the oracle's restatement of the reference
+    kernels, fp16 and fp32 inputs.  The device computes in fp32 and rounds once; the reference's fp16 kernel rounds after every step: 3e-3 covers both."""
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(len(act) + int(limit * 10))
+    g = (rng.standard_normal((5, 512)) * 3).astype(np.float32); u = (rng.standard_normal((5, 512)) * 2).astype(np.float32)
+    code = {"silu": ext.ACT_SILU, "gelu": ext.ACT_GELU, "relu2": ext.ACT_RELU2, "relu": ext.ACT_RELU, "silu_oai": ext.ACT_SILU_OAI}[act]
+    for dt in (np.float16, np.float32):
+        y = torch.full((5, 512), float("nan"), dtype=torch.half, device=dev)
+        ext.act_mul(_t(g.astype(dt), dev), _t(u.astype(dt), dev), y, code, limit)
+        ref = o.act_mul(g.astype(dt), u.astype(dt), act, limit).astype(np.float32)
+        got = y.float().cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.allclose(got, ref, rtol=3e-3, atol=3e-3), np.abs(got - ref).max()
+    with pytest.raises(RuntimeError):
+        ext.act_mul(_t(g, dev), _t(u, dev), torch.empty((5, 512), dtype=torch.half, device=dev), 7, 0.0)
+
+
 @pytest.mark.parametrize("dim", [2048, 4096, 8192])
 @pytest.mark.parametrize("rows", [64, 257, 4096])
 def test_rms_norm_many_rows_fast_path(dev, dim, rows):

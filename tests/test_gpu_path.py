@@ -328,8 +328,19 @@ def test_bc_gated_mlp_matches_oracle_and_op_by_op(dev, cb, m):
         bcs[0].run(T(x2), g2); bcs[1].run(T(x2), u2); ext.silu_mul(g2, u2, a2)
         d2 = torch.empty((m, hidden), dtype=out_dtype, device=dev); bcs[2].run(a2, d2)
         assert float((d2.float() - d.float().view(m, hidden)).abs().max()) < 1e-2 * float(d2.float().abs().max()) + 1e-3
+    # the other activations of libtorch/mlp.h:64-67 (+ act_limit): launch-per-op route, oracle = the reference's activation kernels restated
+    x2 = x.reshape(m, hidden)
+    g = o.linear_forward(x2, mats[0][0], mats[0][1], mats[0][2], K, cb); u = o.linear_forward(x2, mats[1][0], mats[1][1], mats[1][2], K, cb)
+    for flags, name, limit in (((False, True, False), "gelu", 0.0), ((False, False, True), "relu2", 0.75), ((True, False, False), "silu", 0.5)):
+        mlp2 = ext.BC_GatedMLP(guh, gu, a, dxh, None, None, None, K, cb == 1, cb == 2, *flags, bcs[0], bcs[1], bcs[2], limit)
+        d = torch.full((1, m, hidden), float("nan"), dtype=torch.half, device=dev)
+        mlp2.run_bszN(T(x), d)
+        av = o.act_mul(g, u, name, limit)
+        ref = o.linear_forward(av, mats[2][0], mats[2][1], mats[2][2], K, cb).astype(np.float32)
+        got = d.float().cpu().numpy().reshape(m, hidden)
+        assert np.isfinite(got).all() and np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2, name
     with pytest.raises(RuntimeError):
-        ext.BC_GatedMLP(guh, gu, a, dxh, None, None, None, K, False, False, False, True, False, bcs[0], bcs[1], bcs[2], 0.0)
+        ext.BC_GatedMLP(guh, gu, a, dxh, None, None, None, K, False, False, True, True, False, bcs[0], bcs[1], bcs[2], 0.0)      # two activations at once
 
 
 @pytest.mark.parametrize("hd,hq,hkv", [(128, 4, 2), (64, 8, 2)])
