@@ -13,6 +13,7 @@ tables + indices for gate / up and indices + weights for down, libtorch/blockspa
 """
 from __future__ import annotations
 import math
+import os
 import torch
 from . import ext
 from .llama_path import _rand_linear
@@ -30,7 +31,8 @@ class SyntheticEXL3MoE:
         self.first, self.last = 0, experts
         self._build_tables()
 
-    fx_split = tuple(int(v) for v in __import__("os").environ.get("EXL3_HIP_MOE_FX_SPLIT", "0,0").split(","))      # k-slices of the fx block's gate|up / down launches (0: dispatcher)
+    # k-slices of the fx block's gate|up / down launches (0: the dispatcher / the rule in forward_fx); EXL3_HIP_MOE_FX_SPLIT="g,d" overrides (tuning)
+    fx_split = tuple(int(v) for v in os.environ.get("EXL3_HIP_MOE_FX_SPLIT", "0,0").split(","))
 
     def _build_tables(self):
         """Device pointer tables of the LOCAL experts [first, last) (all of them without expert parallelism)."""

@@ -555,8 +555,9 @@ def act_mul(g: np.ndarray, u: np.ndarray, act: str, act_limit: float = 0.0) -> n
     if act == "silu":
         if half_in:
             # _silu(half2): every step rounded to fp16 (:21-31)
-            e = np.exp(-g.astype(np.float32)).astype(np.float16)
-            sm = (np.float16(1) + e).astype(np.float16)
+            with np.errstate(over="ignore"):                 # exp(-g) beyond the fp16 range is inf there too: 1 / inf = 0
+                e = np.exp(-g.astype(np.float32)).astype(np.float16)
+                sm = (np.float16(1) + e).astype(np.float16)
             rc = (np.float32(1) / sm.astype(np.float32)).astype(np.float16)
             a = (g * rc).astype(np.float16)
         else:
