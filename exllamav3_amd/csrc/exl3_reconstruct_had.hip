@@ -53,6 +53,14 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kb = blockIdx.y, nb = blockIdx.x;
+    // the scale vectors this lane needs (its k' rows in GEMM 1, its n' column of every column tile in GEMM 2) are requested FIRST, next to the packed
+    // words: loaded where they are used, each was a dependent L2 round trip in the middle of the kernel (the 8 svh values one per column-tile trip),
+    // and the kernel without decode, matrix instructions and stores still took 33 of 59 us (round 3 ablation, gate_proj shape)
+    const int jq = lane & 15;
+    const half_t su0 = suh[kb * 128 + 16 * (2 * wave) + jq], su1 = suh[kb * 128 + 16 * (2 * wave + 1) + jq];
+    half_t svr[8];
+    #pragma unroll
+    for (int ct = 0; ct < 8; ++ct) svr[ct] = svh[nb * 128 + 16 * ct + jq];
 
     // ---- decode: wave w handles tile rows 2w, 2w+1; lane (8T + c) owns columns c, c+8 of tile T (exl3_lane_decode.cuh):
     //      one contiguous 256*K-byte load per wave and tile row, constant-shift windows, bit-exact fp16 values.
@@ -105,8 +113,8 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
         for (int rt = 0; rt < 2; ++rt)
             #pragma unroll
             for (int ks = 0; ks < 4; ++ks) hb[rt][ks] = had_frag_signed(hbase, 2 * wave + rt, ks, g);
-        const float sc0 = (float) suh[kb * 128 + 16 * (2 * wave) + j] * r128;
-        const float sc1 = (float) suh[kb * 128 + 16 * (2 * wave + 1) + j] * r128;
+        const float sc0 = (float) su0 * r128;
+        const float sc1 = (float) su1 * r128;
         #pragma unroll
         for (int u = 0; u < 4; ++u)
         {
@@ -141,7 +149,7 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
             uint32_t s0 = __builtin_popcount(j & (4 * g + 2 * r)) & 1, s1 = __builtin_popcount(j & (4 * g + 2 * r + 1)) & 1;
             h16[r] = 0x3C003C00u ^ (s0 << 15) ^ (s1 << 31);
         }
-        #pragma unroll 2
+        #pragma unroll
         for (int ct = 0; ct < 8; ++ct)
         {
             float4_t acc0 = { 0.f, 0.f, 0.f, 0.f }, acc1 = { 0.f, 0.f, 0.f, 0.f };
@@ -156,7 +164,7 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0][u], f.h, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[1][u], f.h, acc1, 0, 0, 0);
             }
-            const float sv = (float) svh[nb * 128 + 16 * ct + j] * r128;
+            const float sv = (float) svr[ct] * r128;
             #pragma unroll
             for (int r = 0; r < 4; ++r)
             {
