@@ -17,12 +17,13 @@
 // words [cK, cK + K) of tile (2 wave + t2) of tile row 4 step + g = columns c, c + 8 of that tile, 16 k each: one 16-byte load per lane
 // (K = 4), 256 contiguous bytes per 16-lane group.
 //
-// LDS transpose.  The decoded step is 4 chunk rows r = 2 h + half (h: column c or c + 8, half: k 0..7 or 8..15 of the tile row), each
-// 64 lanes x 16 B, row pitch 1152 B; written with ds_write_b128 at r * 1152 + lane * 16 (contiguous).  MFMA (p, t) -- tile rows 2p, 2p + 1
-// of the step x tile t -- reads for lane (j, kg) the chunk of writer lane 16 (2p + (kg >> 1)) + 8 t + (j & 7) in row 2 (j >> 3) + (kg & 1):
-// the 128-byte pitch offset puts the four 64-byte runs of every 16-lane ds_read_b128 group on disjoint banks.
-// k inside an MFMA is natural (k = 8 kg + i over the two tile rows), so the A operand comes straight from a row-major fp16 copy of the
-// rotated activations (row pitch padded by 32 B: conflict-free ds_read_b128 across the 16 rows).
+// No transpose (round 3).  The decoding lane's registers ARE a B operand of v_mfma_f32_16x16x32_f16: operand lane l supplies column l % 16 and
+// contraction slots 8 (l / 16) .. + 7, and lane 16 g + 8 t2 + c holds, for column c (and c + 8) of tile t2, the 16 k of tile row g as two natural-order
+// runs of 8 (low words: k 0..7, high words: k 8..15).  Reading "column" as the virtual column 8 t2 + c and "contraction group" as tile row g, the four
+// instructions of a step are (k 0..7 | k 8..15 of the four tile rows) x (columns c | c + 8 of the two tiles), their A operand is the 16 bytes
+// x[row][16 (4 step + g) + 8 h ..] of the row-major activations, and their accumulators hold the outputs of the lane's own columns.  (Rounds 1-2 wrote
+// the decoded step to a wave-private LDS buffer and read it back in the natural layout: 4 ds_write_b128 + 4 ds_read_b128 + two wave-level fences
+// per step and 18 KB of LDS per workgroup for nothing -- the contraction index of a matrix product can be enumerated in any order both operands agree on.)
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
 #include "exl3_gemv_args.h"
@@ -36,8 +37,6 @@ __device__ __forceinline__ void g3_static_for(F&& f)
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); g3_static_for<I + 1, N>(f); }
 }
 
-#define G3_STG_ROW 1152
-#define G3_STG_BYTES (4 * G3_STG_ROW)
 #define G3_XPAD 16
 #define G3_WAVES 4
 
@@ -50,9 +49,9 @@ constexpr int g3_waves_per_eu(int K, int MT, bool ROT, bool RAW)
 template <int K, int CB, int MT, bool ROT, bool RAWV>
 // RAWV (mul1 codebook, rotated input = the fused decode pipeline, the library's default GEMV variant): the weights enter the matrix instructions as the packed byte sums 1024 + s the
 // decode produces (exact fp16 integers) instead of fp16(kinv * (1024 + s) + kbias); the affine map is applied once per output,
-// out = kinv * acc + kbias * sum_k x[row][k], with the row sums accumulated by one extra matrix instruction per 32 k against a ones operand (they
-// land in the accumulator layout of the outputs).  Removes a v_pk_fma_f16 per weight pair, 14 % of the streaming loop's VALU instructions; the
-// same arithmetic as generation 2's default variant.
+// out = kinv * acc + kbias * sum_k x[row][k], with the row sums taken from the producer's per-block sums (mat[].xsum; launches without them take the
+// fp16-weight variant).  Removes a v_pk_fma_f16 per weight pair, 14 % of the streaming loop's VALU instructions; the same arithmetic as generation
+// 2's / 4's default variant.
 // ROT: the input is already rotated (fused decode pipeline) -- a separate instantiation so that neither prologue's registers burden the other.
 // five 4-wave workgroups per CU (LDS: 5 x 31 KB) need <= 96 VGPRs; the 64-row passes, the ROT prologue (16 registers of activation copy in
 // flight next to the weight ring) and the wide rings of K >= 5 take the next register budgets instead of spilling (any scratch use slows
@@ -99,10 +98,9 @@ void exl3_gemm3_kernel(const GemvArgs a)
     const int nb = (k1s - k0s) >> 7;                 // Hadamard blocks in the slice; every wave streams all of them
     const int chb = a_chb;
 
-    // LDS carve: [wave-private transpose buffers] [activations of one chunk, row-major fp16]; the S == 1 epilogue reuses it for [m][128] fp32
+    // LDS: the activations of one chunk, row-major fp16; the S == 1 epilogue reuses it for [m][128] fp32
     const int ldx = chb * 128 + G3_XPAD;
-    char* stg = smem + (size_t) wave * G3_STG_BYTES;
-    half_t* xa = (half_t*) (smem + (size_t) G3_WAVES * G3_STG_BYTES);
+    half_t* xa = (half_t*) smem;
 
     const int l32 = lane & 31;
     constexpr bool in_rotated = ROT;
@@ -113,15 +111,27 @@ void exl3_gemm3_kernel(const GemvArgs a)
     const int g = lane >> 4, t2 = (lane >> 3) & 1, c = lane & 7;
     const size_t row_stride = (size_t) tiles_n * NW;
     const uint32_t* __restrict__ strip = Bm + ((size_t) (k0s >> 4) + g) * row_stride + (size_t) (cbl * 8 + 2 * wave + t2) * NW + (size_t) c * K;
-    const int prev_lane_addr = ((lane & ~7) | ((lane - 1) & 7)) << 2;
 
     constexpr bool RAW = RAWV && CB == EXL3_CB_MUL1;
     float4_t acc[MT][2];
     #pragma unroll
     for (int i = 0; i < MT; ++i) { acc[i][0] = float4_t{ 0.f, 0.f, 0.f, 0.f }; acc[i][1] = acc[i][0]; }
-    float4_t rsum[RAW ? MT : 1];                     // RAW: sum_k x[row][k] for the rows of acc[i][*] (every column lane holds the same value)
+    // RAW: sum_k x[row][k] over the slice for the rows of acc[i][*], from the producer's per-block sums (mat[mi].xsum [m][k/128], the launcher
+    // takes this variant only when they exist) -- requested here, needed in the epilogue.  (Rounds 1-2 accumulated them with one extra matrix
+    // instruction per 32 k against a ones operand: 2 of every 6 matrix instructions of the loop.)
+    float4_t rsum[RAW ? MT : 1];
     #pragma unroll
     for (int i = 0; i < (RAW ? MT : 1); ++i) rsum[i] = float4_t{ 0.f, 0.f, 0.f, 0.f };
+    if constexpr (RAW)
+    {
+        const float* xsr = a.mat[mi].xsum + (k0s >> 7);
+        const int nbk = a_k >> 7, kg0 = lane >> 4;
+        for (int blk = 0; blk < nb; ++blk)
+            #pragma unroll
+            for (int i = 0; i < MT; ++i)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) rsum[i][r] += xsr[(size_t) min(16 * i + 4 * kg0 + r, m - 1) * nbk + blk];
+    }
 
     // ---- activation fetch helpers
     struct PrepIn { half4_t xv, sv; };
@@ -175,11 +185,9 @@ void exl3_gemm3_kernel(const GemvArgs a)
 
     // MFMA operand geometry
     const int mj = lane & 15, kg = lane >> 4;
-    const char* bsrc = stg + (2 * (mj >> 3) + (kg & 1)) * G3_STG_ROW + ((kg >> 1) * 16 + (mj & 7)) * 16;   // + (32 p + 8 t) * 16
-    char* bdst = stg + lane * 16;                                                                        // + r * G3_STG_ROW
-    const half_t* arow[MT];
+    const half_t* arow[MT];                              // A operand of (row 16 i + mj, tile row kg of the step): + 16-byte half h
     #pragma unroll
-    for (int i = 0; i < MT; ++i) arow[i] = xa + (size_t) min(16 * i + mj, m - 1) * ldx + 8 * kg;
+    for (int i = 0; i < MT; ++i) arow[i] = xa + (size_t) min(16 * i + mj, m - 1) * ldx + 16 * kg;
 
     // one Hadamard block (2 decode steps) from a ring slot; kloc = chunk-local k of the block
     auto do_block = [&] (LaneWords<K> (&slot)[2], int kloc, int refill_blk)
@@ -190,7 +198,14 @@ void exl3_gemm3_kernel(const GemvArgs a)
             uint32_t Wx[K + 1];
             #pragma unroll
             for (int i = 0; i < K; ++i) Wx[i + 1] = slot[sub].w[i];
-            Wx[0] = (uint32_t) __builtin_amdgcn_ds_bpermute(prev_lane_addr, (int) slot[sub].w[K - 1]);
+            // carry-in = last word of the previous lane of the 8-lane tile group (c = 0 wraps to c = 7): two DPP row rotates + a select, register
+            // file only (generation 4's form; this was a ds_bpermute, i.e. an LDS-crossbar round trip in front of every decode step)
+            {
+                const uint32_t wl = slot[sub].w[K - 1];
+                const uint32_t r1 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x121, 0xf, 0xf, true);
+                const uint32_t r9 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x129, 0xf, 0xf, true);
+                Wx[0] = (lane & 7) ? r1 : r9;
+            }
             // refill the slot half that was just consumed
             load_lane_words<K>(slot[sub], strip + (size_t) (8 * refill_blk + 4 * sub) * row_stride);
 
@@ -206,35 +221,22 @@ void exl3_gemm3_kernel(const GemvArgs a)
                 clo[q] = uc.w[0]; chi[q] = uc.w[1]; dlo[q] = ud.w[0]; dhi[q] = ud.w[1];
                 __builtin_amdgcn_sched_barrier(0);      // bound live ranges: 8 weights in flight at a time (occupancy > ILP here)
             });
-            *((uint4_t*) (bdst + 0 * G3_STG_ROW)) = uint4_t{ clo[0], clo[1], clo[2], clo[3] };
-            *((uint4_t*) (bdst + 1 * G3_STG_ROW)) = uint4_t{ chi[0], chi[1], chi[2], chi[3] };
-            *((uint4_t*) (bdst + 2 * G3_STG_ROW)) = uint4_t{ dlo[0], dlo[1], dlo[2], dlo[3] };
-            *((uint4_t*) (bdst + 3 * G3_STG_ROW)) = uint4_t{ dhi[0], dhi[1], dhi[2], dhi[3] };
-            // the wave's own LDS operations complete in order: no wait between its stores and the loads below, only compiler ordering
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            union { uint32_t w[4]; half8_t h; } bc[2], bd[2];       // [k 0..7 | k 8..15 of the lane's tile row] of column c / c + 8
             #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int q = 0; q < 4; ++q) { bc[0].w[q] = clo[q]; bc[1].w[q] = chi[q]; bd[0].w[q] = dlo[q]; bd[1].w[q] = dhi[q]; }
+            #pragma unroll
+            for (int h = 0; h < 2; ++h)
             {
                 half8_t af[MT];
                 #pragma unroll
-                for (int i = 0; i < MT; ++i) af[i] = *((const half8_t*) (arow[i] + kloc + 64 * sub + 32 * p));
-                if constexpr (RAW)
-                {
-                    const half8_t ones = { 1, 1, 1, 1, 1, 1, 1, 1 };
-                    #pragma unroll
-                    for (int i = 0; i < MT; ++i) rsum[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], ones, rsum[i], 0, 0, 0);
-                }
+                for (int i = 0; i < MT; ++i) af[i] = *((const half8_t*) (arow[i] + kloc + 64 * sub + 8 * h));
                 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int i = 0; i < MT; ++i)
                 {
-                    const half8_t bf = *((const half8_t*) (bsrc + (32 * p + 8 * t) * 16));
-                    #pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf, acc[i][t], 0, 0, 0);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bc[h].h, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bd[h].h, acc[i][1], 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
     };
 
@@ -295,7 +297,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
     }
     G3_T(3);
 
-    // ---- epilogue.  D layout of acc[i][t]: rows 16 i + 4 kg + r, column 32 wave + 16 t + mj
+    // ---- epilogue.  D layout: rows 16 i + 4 kg + r; acc[i][0]: column c of tile t2 = 32 wave + 16 (mj >> 3) + (mj & 7), acc[i][1]: that + 8
     // (lane index laundered through an empty asm: the output addresses are computed here, not hoisted above the streaming loop where they
     // would cost registers -- the prologue spilled to scratch otherwise, and any scratch use slows every launch)
     if constexpr (RAW)
@@ -315,7 +317,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
     const int mj_e = lane_e & 15, kg_e = lane_e >> 4;
     if (a.S > 1 || (a.flags & GEMV_OUT_DEFERRED))
     {
-        float* slab = a.workspace + ws_off + ((size_t) cbl * a.S + s) * (size_t) m * 128 + 32 * wave + mj_e;
+        float* slab = a.workspace + ws_off + ((size_t) cbl * a.S + s) * (size_t) m * 128 + 32 * wave + 16 * (mj_e >> 3) + (mj_e & 7);
         #pragma unroll
         for (int i = 0; i < MT; ++i)
         {
@@ -323,7 +325,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
             for (int r = 0; r < 4; ++r)
             {
                 const int row = 16 * i + 4 * kg_e + r;
-                if (row < m) { slab[row * 128] = acc[i][0][r]; slab[row * 128 + 16] = acc[i][1][r]; }
+                if (row < m) { slab[row * 128] = acc[i][0][r]; slab[row * 128 + 8] = acc[i][1][r]; }
             }
         }
 #ifdef G2_TIMING
@@ -340,7 +342,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
         return;
     }
 
-    // S == 1: the output Hadamard needs whole 128-column rows -> through LDS (over the transpose buffers / activations)
+    // S == 1: the output Hadamard needs whole 128-column rows -> through LDS (over the activations)
     __syncthreads();
     float* part = (float*) smem;
     #pragma unroll
@@ -350,7 +352,8 @@ void exl3_gemm3_kernel(const GemvArgs a)
         for (int r = 0; r < 4; ++r)
         {
             const int row = 16 * i + 4 * kg_e + r;
-            if (row < m) { part[row * 128 + 32 * wave + mj_e] = acc[i][0][r]; part[row * 128 + 32 * wave + 16 + mj_e] = acc[i][1][r]; }
+            const int col = 32 * wave + 16 * (mj_e >> 3) + (mj_e & 7);
+            if (row < m) { part[row * 128 + col] = acc[i][0][r]; part[row * 128 + col + 8] = acc[i][1][r]; }
         }
     }
     __syncthreads();
@@ -395,6 +398,7 @@ template <int CB>
 static void g3_launch_cb(int mt, bool raw, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
     const bool rot = (args.flags & GEMV_IN_ROTATED) != 0;
+    for (int i = 0; i < args.num_mats; ++i) if (!args.mat[i].xsum) raw = false;       // the raw variant takes the activation sums from the producer's block sums
     #define L2(M, R, V) exl3_gemm3_kernel<G2_K, CB, M, R, V><<<grid, dim3(64 * G3_WAVES), lds, st>>>(args)
     // the raw variant serves the fused decode pipeline (rotated input); the standalone op keeps the reference's fp16-rounded weights
     #define L(M, R) { if constexpr (CB == EXL3_CB_MUL1 && R) { if (raw) L2(M, R, true); else L2(M, R, false); } else L2(M, R, false); }
@@ -417,10 +421,10 @@ void G3_CAT(exl3_gemm3_launch_k, G2_K)(int cb, int mt, int var, dim3 grid, size_
 }
 
 #if G2_K == 4
-// LDS bytes of a launch: transpose buffers + activations of one chunk; the S == 1 epilogue's [m][128] fp32 overlays them
+// LDS bytes of a launch: activations of one chunk; the S == 1 epilogue's [m][128] fp32 overlays them
 size_t exl3_gemm3_lds_bytes(int m, int chunk_blocks)
 {
-    const size_t stream = (size_t) G3_WAVES * G3_STG_BYTES + (size_t) m * (chunk_blocks * 128 + G3_XPAD) * 2;
+    const size_t stream = (size_t) m * (chunk_blocks * 128 + G3_XPAD) * 2;
     const size_t part = (size_t) m * 128 * 4;
     return stream > part ? stream : part;
 }

@@ -421,8 +421,10 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         if (gen == 3)
         {
             const int mt = mp > 32 ? 4 : (mp > 16 ? 2 : 1);
-            // four workgroups per CU (the register budget of the rotated-input variants): 18 KB of transpose buffers + <= 22 KB of activations
-            int chunk = (22528 / (mp * 2) - 16) / 128;
+            // four workgroups per CU (the register budget of the rotated-input variants) x <= 36 KB of activations (the workgroup's only LDS since the
+            // transpose buffers went): 16 rows keep a whole 8-block slice resident (one chunk: no second prologue / barrier inside the stream)
+            static const int chunk_bytes = [] { const char* e = getenv("EXL3_HIP_GEMM3_CHUNK_BYTES"); return e ? atoi(e) : 36864; }();
+            int chunk = (chunk_bytes / (mp * 2) - 16) / 128;
             if (chunk > 8) chunk = 8;                            // the rotated-input copy maps a chunk row onto <= 128 16-byte pieces
             if (chunk < 1) chunk = 1;
             if (chunk > bps) chunk = bps;
