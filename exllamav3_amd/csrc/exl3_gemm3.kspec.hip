@@ -92,6 +92,12 @@ void exl3_gemm3_kernel(const GemvArgs a)
     const uint32_t* __restrict__ Bm = a.mat[mi].B;
     const half_t* __restrict__ suh = a.mat[mi].suh;
     const int n = a.mat[mi].n, cbl = cbg - a.mat[mi].cb_first, ws_off = a.mat[mi].ws_offset;
+    {
+        // everything the first vector loads need, in the SECOND batch of scalar loads (the matrix record depends on mi): left alone, the compiler sank
+        // mat[mi].B and chunk_blocks behind the first branch -- a third scalar round trip between entry and the first weight request (ISA, round 3)
+        const void* p0 = Bm; const void* p1 = a.mat[mi].xh; const void* p2 = a.mat[mi].xsum; const void* p3 = suh;
+        asm volatile("" :: "s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(a_chb), "s"(n), "s"(ws_off));
+    }
     const int tiles_n = n >> 4;
     const int k0s = s * a_kslice;
     const int k1s = min(k0s + a_kslice, a_k);
@@ -122,15 +128,20 @@ void exl3_gemm3_kernel(const GemvArgs a)
     float4_t rsum[RAW ? MT : 1];
     #pragma unroll
     for (int i = 0; i < (RAW ? MT : 1); ++i) rsum[i] = float4_t{ 0.f, 0.f, 0.f, 0.f };
-    if constexpr (RAW)
+    constexpr bool RSUM_EARLY = MT == 1;             // the 32- / 64-row passes fetch them in the epilogue instead (their register budgets are full)
+    if constexpr (RAW && RSUM_EARLY)
     {
+        // the 16 lanes that share these rows (one DPP row) take different blocks each: one round of 4 loads per lane covers 16 blocks, nothing waits
+        // on them before the epilogue, where a row sum over the 16 lanes finishes the job.  (Accumulating block after block here stalled every
+        // workgroup for a memory round trip per block BEFORE its weight loads were issued: tools/gemv_timeline.py, 1.7 us from entry to "loads issued".)
+        // (plain loads at a clamped block index, no arithmetic on them here -- an add would make the compiler wait for the value on the spot; lanes
+        // past the slice's last block are zeroed in the epilogue, slices beyond 16 blocks fetch the rest there)
         const float* xsr = a.mat[mi].xsum + (k0s >> 7);
-        const int nbk = a_k >> 7, kg0 = lane >> 4;
-        for (int blk = 0; blk < nb; ++blk)
+        const int nbk = a_k >> 7, kg0 = lane >> 4, blk0 = min(lane & 15, nb - 1);
+        #pragma unroll
+        for (int i = 0; i < MT; ++i)
             #pragma unroll
-            for (int i = 0; i < MT; ++i)
-                #pragma unroll
-                for (int r = 0; r < 4; ++r) rsum[i][r] += xsr[(size_t) min(16 * i + 4 * kg0 + r, m - 1) * nbk + blk];
+            for (int r = 0; r < 4; ++r) rsum[i][r] = xsr[(size_t) min(16 * i + 4 * kg0 + r, m - 1) * nbk + blk0];
     }
 
     // ---- activation fetch helpers
@@ -308,7 +319,12 @@ void exl3_gemm3_kernel(const GemvArgs a)
             #pragma unroll
             for (int r = 0; r < 4; ++r)
             {
-                const float b = kbias * rsum[i][r];
+                float rs = (RSUM_EARLY && (lane & 15) < nb) ? rsum[i][r] : 0.0f;
+                for (int blk = (lane & 15) + (RSUM_EARLY ? 16 : 0); blk < nb; blk += 16)
+                    rs += a.mat[mi].xsum[(size_t) min(16 * i + 4 * (lane >> 4) + r, m - 1) * (a.k >> 7) + (k0s >> 7) + blk];
+                #pragma unroll
+                for (int o = 1; o < 16; o <<= 1) rs += xor_lane(rs, o);                      // the 16 lanes' blocks
+                const float b = kbias * rs;
                 acc[i][0][r] = acc[i][0][r] * kinv + b; acc[i][1][r] = acc[i][1][r] * kinv + b;
             }
     }

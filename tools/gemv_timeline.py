@@ -49,6 +49,10 @@ for i, nm in enumerate(names):
     for j, ph in enumerate(["entry", "loads_issued", "first_prep", "stream_done", "partials", "slab_written"]):
         v = rel[:, j]
         row[ph] = [round(float(np.percentile(v, q)), 2) for q in (0, 50, 100)]
+    # per-workgroup phase durations (stamp j - stamp j-1): what one workgroup spends where, independent of when it started
+    d = np.diff(t[:, :6].astype(float), axis=1) * 0.01
+    row["per_wg_phase_us_p50_p90"] = {ph: [round(float(np.percentile(d[:, j], 50)), 2), round(float(np.percentile(d[:, j], 90)), 2)]
+                                      for j, ph in enumerate(["to_loads_issued", "to_first_prep", "to_stream_done", "to_partials", "to_slab_written"])}
     life = (t[:, 5] - t[:, 0]).astype(float) * 0.01
     if os.environ.get("BSZ", "1") not in ("1", "2", "3", "4"):   # generation 3 stores shader cycles of the workgroup in column 7
         row["shader_clock_GHz_median"] = round(float(np.median(t[:, 7][life > 0] / life[life > 0])) * 1e-3, 3)
