@@ -236,7 +236,10 @@ void exl3_gemv4_kernel(const GemvArgs a)
         if constexpr (MODE == G4_MODE_NORM || MODE == G4_MODE_NORMFX)
         {
             r.wv = ((const half4_t*) (a_norm_w + kofs))[l32];
-            if (l32 < (a_k >> 7)) r.ss = a_ss_part[(size_t) row * (a_k >> 7) + l32];
+            // unconditional (clamped index, masked where it is used): behind a lane condition the compiler cannot count the outstanding loads and waits
+            // with vmcnt(0) in front of the first task -- i.e. for the wave's first WEIGHT rows, which were requested after these operands precisely
+            // so that the task would run underneath their latency (ISA + tools/gemv_timeline.py, round 3: 1.7 / 5.4 us from "loads issued" to "prep done")
+            r.ss = a_ss_part[(size_t) row * (a_k >> 7) + min(l32, (a_k >> 7) - 1)];
         }
         return r;
     };
@@ -255,22 +258,14 @@ void exl3_gemv4_kernel(const GemvArgs a)
     // experiment: only the first row before the preparation barrier (half the initial burst of weight requests); the second after it
     if (nun > 0) load_lane_words<K>(ring[0], strip + (size_t) (2 * ubase) * row_stride);
 #else
-    if (nun > 0)
     {
+        // unconditional (the host gives every wave at least one unit; the row index is clamped into the slice regardless): under `if (nun > 0)` the number
+        // of outstanding loads after the merge is path-dependent and the waits of the preparation task below degrade to vmcnt(0)
         #pragma unroll
-        for (int u = 0; u < NR; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(2 * ubase + u, 2 * last_unit + 1) * row_stride);
+        for (int u = 0; u < NR; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(min(2 * ubase + u, 2 * last_unit + 1), 2 * units - 1) * row_stride);
     }
 #endif
     G4_T(1);
-    if (a.fx_zero)
-    {
-        // side job (fx pipeline): clear this workgroup's share of a buffer a LATER launch accumulates into
-        const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
-        const int per = (a.fx_zero_n16 + nwg - 1) / nwg;
-        const int c0 = wg * per, c1 = min(c0 + per, a.fx_zero_n16);
-        for (int cidx = c0 + tid; cidx < c1; cidx += 64 * nwv) ((uint4_t*) a.fx_zero)[cidx] = uint4_t{ 0u, 0u, 0u, 0u };
-    }
-
     // ---- activation quads of this wave's first group
     // lane 4g + i: tile row (group base + (g >> 2)), quad g & 3, row min(i, m - 1)
     const int gq = lane >> 2, gi = min(lane & 3, m - 1);
@@ -324,17 +319,16 @@ void exl3_gemv4_kernel(const GemvArgs a)
 
     if constexpr (IN_LDS)
     {
-        if (prep_wave)
+        // one preparation task: operands `cur` of round `it`
+        auto do_task = [&] (const PrepIn& cur, int it)
         {
-            for (int it = 0; it * nhw + 2 * wave < ntask; ++it)
             {
-                const PrepIn cur = nx;
-                if ((it + 1) * nhw + 2 * wave < ntask) nx = fetch(it + 1);
                 const int t = it * nhw + hwid;
                 const bool act = t < ntask;
                 const int tc = min(t, ntask - 1);
                 const int blk = gemv_udiv(tc, mg_m), row = tc - blk * m;
                 half4_t xv = cur.xv;
+                float ssq_pub = 0.0f;
                 if constexpr (MODE == G4_MODE_ACT)
                 {
                     // a = fp16(silu(g) * u) of this (row, block): split-k reduce of the producer's gate / up slabs, output Hadamards, svh -- the
@@ -387,7 +381,8 @@ void exl3_gemv4_kernel(const GemvArgs a)
                         ssq = __builtin_fmaf(r1, r1, ssq); ssq = __builtin_fmaf(r2, r2, ssq); ssq = __builtin_fmaf(r3, r3, ssq);
                         #pragma unroll
                         for (int i = 1; i < 32; i <<= 1) ssq += xor_lane(ssq, i);
-                        if (act && l32 == 0) a.rs_ss_out[(size_t) row * (a_k >> 7) + (k0s >> 7) + blk] = ssq;
+                        ssq_pub = ssq;                       // stored at the end of the task: a conditional store HERE makes the load count unknown to the
+                                                             // compiler (vmcnt counts stores) and the wait for the row's sums below becomes vmcnt(0)
                     }
                 }
                 if constexpr (MODE == G4_MODE_NORM || MODE == G4_MODE_NORMFX)
@@ -395,11 +390,12 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     // x = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)): the row's mean square from the per-block sums a glue kernel left behind,
                     // same arithmetic and summation order as generation 2 / glue_norm_kernel / rms_norm (norm.cu:20-120)
                     const int nblk_k = a_k >> 7;
-                    float s2 = 0.0f;
-                    for (int b0 = 0; b0 < nblk_k; b0 += 32)
+                    float s2 = l32 < nblk_k ? cur.ss : 0.0f;      // the first 32 blocks travel with the task (straight-line code: countable waits)
+                    #pragma unroll
+                    for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
+                    for (int b0 = 32; b0 < nblk_k; b0 += 32)       // hidden > 4096 only
                     {
-                        float v = cur.ss;
-                        if (b0 > 0) v = (b0 + l32 < nblk_k) ? a_ss_part[(size_t) row * nblk_k + b0 + l32] : 0.0f;
+                        float v = (b0 + l32 < nblk_k) ? a_ss_part[(size_t) row * nblk_k + b0 + l32] : 0.0f;
                         #pragma unroll
                         for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
                         s2 += v;
@@ -428,6 +424,22 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     char* base = quads + ((size_t) (tr * 4 + q0) * m + row) * 8 + sp * 4;
                     *((half2_t*) base) = o01;
                     *((half2_t*) (base + (size_t) m * 8)) = o23;
+                }
+                if constexpr (MODE == G4_MODE_NORMFX) { if (cbg == 0 && act && l32 == 0) a.rs_ss_out[(size_t) row * (a_k >> 7) + (k0s >> 7) + blk] = ssq_pub; }
+            }
+        };
+        if (prep_wave)
+        {
+            if (ntask <= nhw) do_task(nx, 0);       // the usual case, one round: a straight line in which the compiler counts the outstanding loads and the
+                                                    // task waits for ITS operands only (vmcnt(NR)), not for the weight rows requested behind them -- in
+                                                    // the pipelined loop below the count differs per path and every wait is vmcnt(0)
+            else
+            {
+                for (int it = 0; it * nhw + 2 * wave < ntask; ++it)
+                {
+                    const PrepIn cur = nx;
+                    if ((it + 1) * nhw + 2 * wave < ntask) nx = fetch(it + 1);
+                    do_task(cur, it);
                 }
             }
         }
@@ -547,6 +559,16 @@ void exl3_gemv4_kernel(const GemvArgs a)
             *((half4_t*) ((half_t*) C_m + off)) = o;
         }
     }
+    if (a.fx_zero)
+    {
+        // side job (fx pipeline): clear this workgroup's share of a buffer a LATER launch accumulates into.  Last thing the workgroup does: between the
+        // first loads and the preparation tasks its conditional stores made the outstanding-load count unknown to the compiler (vmcnt(0) in front of the tasks)
+        const int nwg = gridDim.x * gridDim.y, wg = blockIdx.y * gridDim.x + blockIdx.x;
+        const int per = (a.fx_zero_n16 + nwg - 1) / nwg;
+        const int c0 = wg * per, c1 = min(c0 + per, a.fx_zero_n16);
+        for (int cidx = c0 + tid; cidx < c1; cidx += 64 * nwv) ((uint4_t*) a.fx_zero)[cidx] = uint4_t{ 0u, 0u, 0u, 0u };
+    }
+
 #ifdef G4_TIMING
     if (tid == 0)
     {

@@ -12,8 +12,8 @@ from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
 dev = torch.device("cuda:0")
 model = SyntheticEXL3Llama(SHAPES["llama-3.1-8b"], K=4, cb=2, device=dev, kv_bits=4, layers=2)
 model.alloc_state(int(os.environ.get("BSZ", "1")))
-pipeline = os.environ.get("PIPELINE", "glue")       # glue | resid
-(model.decode_step_resid if pipeline == "resid" else model.decode_step_fused)(); torch.cuda.synchronize()
+pipeline = os.environ.get("PIPELINE", "glue")       # glue | resid | fx
+{"resid": model.decode_step_resid, "fx": model.decode_step_fx}.get(pipeline, model.decode_step_fused)(); torch.cuda.synchronize()
 calls = model.gemv_calls(pipeline)
 names = ["qkv", "o", "gate_up", "down"]
 grids = {"qkv": 48, "o": 32, "gate_up": 224, "down": 32, "lm_head": 1002}
