@@ -254,17 +254,19 @@ void exl3_gemv4_kernel(const GemvArgs a)
     // experiment: a wave that owns a preparation task requests its weight rows only after the task's operands have arrived
     if constexpr (IN_LDS) { if (prep_wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
-#ifdef G4_ABL_ONE_ROW
-    // experiment: only the first row before the preparation barrier (half the initial burst of weight requests); the second after it
-    if (nun > 0) load_lane_words<K>(ring[0], strip + (size_t) (2 * ubase) * row_stride);
-#else
+    auto issue_ring = [&] ()
     {
+#ifdef G4_ABL_ONE_ROW
+        // experiment: only the first row before the preparation barrier (half the initial burst of weight requests); the second after it
+        if (nun > 0) load_lane_words<K>(ring[0], strip + (size_t) (2 * ubase) * row_stride);
+#else
         // unconditional (the host gives every wave at least one unit; the row index is clamped into the slice regardless): under `if (nun > 0)` the number
         // of outstanding loads after the merge is path-dependent and the waits of the preparation task below degrade to vmcnt(0)
         #pragma unroll
         for (int u = 0; u < NR; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(min(2 * ubase + u, 2 * last_unit + 1), 2 * units - 1) * row_stride);
-    }
 #endif
+    };
+    if constexpr (IN_LDS) issue_ring();              // (rotated input: behind the first activation group, below)
     G4_T(1);
     // ---- activation quads of this wave's first group
     // lane 4g + i: tile row (group base + (g >> 2)), quad g & 3, row min(i, m - 1)
@@ -296,26 +298,23 @@ void exl3_gemv4_kernel(const GemvArgs a)
         }
         else agc0 = u2_as_half4(raw.x, raw.y);
     };
+    // mul1 FAST: sum of the slice's rotated activations per row, for the reducing half-waves (rows hwid < m); ROT: from the producer's block sums.  A plain
+    // load for every lane (clamped indices, masked in the epilogue): an accumulating loop here waits for each value on the spot
+    float xs_pre = 0.0f;
+    if constexpr (RAW && !IN_LDS) xs_pre = a.mat[mi].xsum[(size_t) min(hwid, m - 1) * (a_k >> 7) + (k0s >> 7) + min(l32, nb - 1)];
     if constexpr (!IN_LDS)
     {
+        // Order of the first requests = the order of a streaming trip (activation group, then weight rows).  The compiler's wait counts at the loop
+        // head are the minimum over the entry path and the back edge: with the group requested AFTER the first weight rows it was the youngest load on
+        // entry, the head waited with vmcnt(1) / vmcnt(0) in EVERY trip, i.e. for the weight rows refilled a few hundred cycles earlier (ISA, round 3).
         xh_lane = a.mat[mi].xh + (size_t) gi * a_k + k0s + 2 * (gq & 3);
+        agn = load_group(2 * ubase);
+        issue_ring();
 #ifdef G4_ABL_ONE_ROW
         if (nun > 0) load_lane_words<K>(ring[1], strip + (size_t) (2 * ubase + 1) * row_stride);
 #endif
-        agn = load_group(2 * ubase);
     }
     else quad_lane = (gq * m + gi) * 8;
-
-    // mul1 FAST: sum of the slice's rotated activations per row, for the reducing half-waves (rows hwid < m); ROT: from the producer's block sums
-    float xs_pre = 0.0f;
-    if constexpr (RAW && !IN_LDS)
-    {
-        if (hwid < m)
-        {
-            const float* xsr = a.mat[mi].xsum + (size_t) hwid * (a_k >> 7) + (k0s >> 7);
-            for (int b0 = 0; b0 < nb; b0 += 32) if (b0 + l32 < nb) xs_pre += xsr[b0 + l32];
-        }
-    }
 
     if constexpr (IN_LDS)
     {
@@ -497,7 +496,12 @@ void exl3_gemv4_kernel(const GemvArgs a)
         {
             float xs = 0.0f;
             if constexpr (IN_LDS) { for (int b0 = 0; b0 < nb; b0 += 32) if (b0 + l < nb) xs += bsum[(b0 + l) * m + row]; }
-            else if (row == hwid) xs = xs_pre;                 // requested at kernel entry
+            else if (row == hwid)
+            {
+                xs = l < nb ? xs_pre : 0.0f;                   // requested at kernel entry (blocks 0..31 of the slice)
+                const float* xsr = a.mat[mi].xsum + (size_t) row * (a_k >> 7) + (k0s >> 7);
+                for (int b0 = 32; b0 < nb; b0 += 32) if (b0 + l < nb) xs += xsr[b0 + l];
+            }
             else
             {
                 // (one-wave workgroups with more than two rows only) the further rows' block sums are fetched here
