@@ -358,6 +358,9 @@ void glue_qkv_kernel(const QkvArgs a)
     const int32_t* const positions = a.positions; const int32_t* const block_table = a.block_table; const float* const inv_freq = a.inv_freq;
     const float* const rope_sin = a.rope_sin; const float* const rope_cos = a.rope_cos; const int64_t* const slots = a.slots;
     const GemvRescale rs = a.rs;
+    // (pinned: the compiler otherwise fetches these in four more scalar round trips, each behind a branch, before the first slab line is requested)
+    asm volatile("" :: "s"(a.sq.base), "s"(a.sk.base), "s"(a.sv.base), "s"(a.sq.S), "s"(a.sk.S), "s"(a.sv.S), "s"(a.svh_q), "s"(a.svh_k), "s"(a.svh_v));
+    asm volatile("" :: "s"(q_out), "s"(k_cache), "s"(k_scales), "s"(v_cache), "s"(v_scales), "s"(rope_sin), "s"(rope_cos), "s"(slots), "s"(rs.ss_prev), "s"(rs.ss_new), "s"(rs.k), "s"(rs.eps));
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
     const int heads = a_hq + 2 * a_hkv;
     const int tasks = a_m * heads;
@@ -477,6 +480,9 @@ void glue_act_kernel(const ActArgs a)
     const int m = a.m, inter = a.inter, nblk = a.nblk, tpw = a.tpw;
     const uint32_t magic_nblk = a.magic_nblk;
     const GemvRescale rs = a.rs;
+    // ONE batch of scalar loads: left alone the compiler fetched the slab pointers behind the first branch (a second scalar round trip in front of the
+    // slab loads of a kernel that is nothing but a latency chain) and the output pointers at the tail
+    asm volatile("" :: "s"(sg.base), "s"(su.base), "s"(sg.S), "s"(su.S), "s"(xh_d), "s"(xsum_d), "s"(a_out), "s"(rs.ss_prev), "s"(rs.ss_new), "s"(rs.k), "s"(inter));
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
     const int tasks = m * nblk;
     const int t = blockIdx.x * tpw + hw;                               // half-wave tasks per workgroup = blockDim / 32
