@@ -471,6 +471,12 @@ void exl3_gemv4_kernel(const GemvArgs a)
     }
 
     G4_T(3);
+    {
+        // the scalars of the output side (matrix record, row offset) are fetched HERE, under the partial-sum exchange: loaded where they are used they
+        // were two dependent scalar round trips between the last barrier and the svh load / the atomics of every workgroup
+        const void* e0 = a.mat[mi].svh; const void* e1 = a.mat[mi].bias; const void* e2 = a.mat[mi].C; const int64_t e3 = a.c_row_offset;
+        asm volatile("" :: "s"(e0), "s"(e1), "s"(e2), "s"(e3));
+    }
     // ---- partial sums -> LDS (the area of the activation quads: every wave is past its last quad read after this barrier)
     if constexpr (IN_LDS) __syncthreads();
     {
