@@ -165,6 +165,8 @@ def _declare(l):
     sig("exl3_glue_resid", vp, i32, vp, vp, vp, vp, vp, i32, i32, vp)
     sig("exl3_fx_init", vp, vp, vp, i32, i32, vp)
     sig("exl3_fx_finish", vp, vp, vp, i32, i32, vp)
+    sig("exl3_fx_init_prep", vp, vp, vp, i32, i32, vp, vp, f32, i32, vp, i32, i32, vp, vp, vp, vp)
+    sig("exl3_fx_finish_rotate", vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, vp)
     sig("exl3_gemv_ex_fx", vp, vp, vp, vp, f32, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
     sig("exl3_moe_build_slots", vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp)
     sig("exl3_moe_scatter", vp, vp, vp, vp, vp, i32, i32, i32, vp)

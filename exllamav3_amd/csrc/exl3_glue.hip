@@ -860,6 +860,129 @@ void fx_finish_kernel(const long long* __restrict__ R, half_t* __restrict__ x, f
     if (act && l == 0 && ss) ss[(size_t) row * nblk + blk] = s2;
 }
 
+// fx_init + qkv_prep in one launch (the two step-level set-up kernels are independent of each other): workgroups [0, fx_blocks) are fx_init's,
+// the rest exl3_qkv_prep's.  One kernel boundary less per decode step.
+__global__ __launch_bounds__(256)
+void fx_init_prep_kernel(const half_t* __restrict__ x, long long* __restrict__ R, float* __restrict__ ss, int m, int hidden, int fx_blocks,
+                         const float* __restrict__ inv_freq, const int32_t* __restrict__ positions, float attn_factor, int nfreq,
+                         const int32_t* __restrict__ block_table, int blocks_per_seq, int page_size,
+                         float* __restrict__ sin_out, float* __restrict__ cos_out, int64_t* __restrict__ slots)
+{
+    if ((int) blockIdx.x >= fx_blocks)
+    {
+        const int i = ((int) blockIdx.x - fx_blocks) * 256 + threadIdx.x;
+        if (i >= m * 64) return;
+        const int r = i >> 6, f = i & 63;
+        const int pos = positions[r];
+        if (f < nfreq)
+        {
+            float sn, cs;
+            sincosf(inv_freq[f] * (float) pos, &sn, &cs);
+            sin_out[i] = sn * attn_factor; cos_out[i] = cs * attn_factor;
+        }
+        if (f == 0 && slots && block_table) slots[r] = (int64_t) block_table[r * blocks_per_seq + pos / page_size] * page_size + (pos % page_size);
+        return;
+    }
+    const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
+    const int nblk = hidden >> 7;
+    const int t = blockIdx.x * 8 + hw;
+    const bool act = t < m * nblk;
+    const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+    const half4_t r = ((const half4_t*) (x + (size_t) row * hidden + blk * 128))[l];
+    const float r0 = (float) r.x, r1 = (float) r.y, r2 = (float) r.z, r3 = (float) r.w;
+    if (act)
+    {
+        long long* o = R + (size_t) row * hidden + blk * 128 + 4 * l;
+        o[0] = __double2ll_rn((double) r0 * GEMV_FX_SCALE); o[1] = __double2ll_rn((double) r1 * GEMV_FX_SCALE);
+        o[2] = __double2ll_rn((double) r2 * GEMV_FX_SCALE); o[3] = __double2ll_rn((double) r3 * GEMV_FX_SCALE);
+    }
+    float s2 = r0 * r0;
+    s2 = __builtin_fmaf(r1, r1, s2); s2 = __builtin_fmaf(r2, r2, s2); s2 = __builtin_fmaf(r3, r3, s2);
+    #pragma unroll
+    for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
+    if (act && l == 0) ss[(size_t) row * nblk + blk] = s2;
+}
+
+extern "C" int exl3_fx_init_prep(const void* x, void* R, float* ss, int m, int hidden, const float* inv_freq, const int32_t* positions, float attn_factor,
+                                 int head_dim, const int32_t* block_table, int blocks_per_seq, int page_size, float* sin_out, float* cos_out,
+                                 int64_t* slots, void* stream)
+{
+    EXL3_CHECK_ARG(x && R && ss && m >= 1 && hidden % 128 == 0, "exl3_fx_init_prep: null pointer / hidden not a multiple of 128");
+    EXL3_CHECK_ARG(inv_freq && positions && sin_out && cos_out, "exl3_fx_init_prep: bad rope arguments");
+    EXL3_CHECK_ARG(head_dim == 128 || head_dim == 64, "exl3_fx_init_prep: head_dim must be 128 or 64");
+    EXL3_CHECK_ARG(!slots || (block_table && page_size > 0 && blocks_per_seq > 0), "exl3_fx_init_prep: slots need the block table");
+    const int fx_blocks = (m * (hidden / 128) + 7) / 8, prep_blocks = (m * 64 + 255) / 256;
+    fx_init_prep_kernel<<<fx_blocks + prep_blocks, 256, 0, (hipStream_t) stream>>>((const half_t*) x, (long long*) R, ss, m, hidden, fx_blocks, inv_freq, positions,
+                                                                                  attn_factor, head_dim / 2, block_table, blocks_per_seq, page_size, sin_out, cos_out, slots);
+    return exl3_check_launch("fx_init_prep");
+}
+
+// fx_finish + glue_rotate in one launch: one workgroup per row (32 half-waves walk the row's Hadamard blocks), x = fp16(R / 2^32) and the block sums of
+// squares as exl3_fx_finish leaves them, a workgroup barrier instead of a kernel boundary, then exl3_glue_rotate's arithmetic for ONE consumer
+// (the lm_head): xh = had128(fp16(x * w * rsqrt(mean(x^2) + eps)) * suh) / sqrt(128), block sums of xh.  Same values as the two launches.
+__global__ __launch_bounds__(1024)
+void fx_finish_rotate_kernel(const long long* __restrict__ R, half_t* __restrict__ x_out, float* __restrict__ ss_out, const half_t* __restrict__ w, float eps,
+                             const half_t* __restrict__ suh, half_t* __restrict__ xh, float* __restrict__ xsum, int hidden)
+{
+    __shared__ float ss_s[256];
+    const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5, nhw = blockDim.x >> 5, row = blockIdx.x;
+    const int nblk = hidden >> 7;
+    auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h((float) (int32_t) hi + (float) lo * 2.3283064365386963e-10f); };
+    // first pass: every block of the row (a half-wave takes blocks hw, hw + nhw, ...; hidden <= 4096: exactly one, kept in registers)
+    half4_t r0v = { 0, 0, 0, 0 };
+    for (int blk = hw; blk < nblk; blk += nhw)
+    {
+        const uint4_t* fp = (const uint4_t*) (R + (size_t) row * hidden + blk * 128) + 2 * l;
+        const uint4_t f0 = fp[0], f1 = fp[1];
+        const half4_t r = { fx(f0.x, f0.y), fx(f0.z, f0.w), fx(f1.x, f1.y), fx(f1.z, f1.w) };
+        if (blk == hw) r0v = r;
+        if (x_out) ((half4_t*) (x_out + (size_t) row * hidden + blk * 128))[l] = r;
+        const float a0 = (float) r.x, a1 = (float) r.y, a2 = (float) r.z, a3 = (float) r.w;
+        float s2 = a0 * a0;
+        s2 = __builtin_fmaf(a1, a1, s2); s2 = __builtin_fmaf(a2, a2, s2); s2 = __builtin_fmaf(a3, a3, s2);
+        #pragma unroll
+        for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
+        if (l == 0) { ss_s[blk] = s2; if (ss_out) ss_out[(size_t) row * nblk + blk] = s2; }
+    }
+    __syncthreads();
+    float s2 = 0.0f;
+    for (int b0 = 0; b0 < nblk; b0 += 32)
+    {
+        float v = (b0 + l < nblk) ? ss_s[b0 + l] : 0.0f;
+        #pragma unroll
+        for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
+        s2 += v;
+    }
+    const float rmf = __frsqrt_rn(s2 / (float) hidden + eps);
+    for (int blk = hw; blk < nblk; blk += nhw)
+    {
+        half4_t r = r0v;
+        if (blk != hw)
+        {
+            const uint4_t* fp = (const uint4_t*) (R + (size_t) row * hidden + blk * 128) + 2 * l;
+            const uint4_t f0 = fp[0], f1 = fp[1];
+            r = half4_t{ fx(f0.x, f0.y), fx(f0.z, f0.w), fx(f1.x, f1.y), fx(f1.z, f1.w) };
+        }
+        const half4_t wv = ((const half4_t*) (w + blk * 128))[l];
+        const half4_t xn = { f2h((float) r.x * (float) wv.x * rmf), f2h((float) r.y * (float) wv.y * rmf),
+                             f2h((float) r.z * (float) wv.z * rmf), f2h((float) r.w * (float) wv.w * rmf) };
+        const float sum = in_had_store(xn, suh + blk * 128, xh + (size_t) row * hidden + blk * 128, l, true);
+        if (l == 0 && xsum) xsum[(size_t) row * nblk + blk] = sum;
+    }
+}
+
+extern "C" int exl3_fx_finish_rotate(const void* R, void* x_out, float* ss_out, const void* norm_w, float eps, const void* suh, void* xh, float* xsum,
+                                     int m, int hidden, void* stream)
+{
+    EXL3_CHECK_ARG(R && norm_w && suh && xh && m >= 1, "exl3_fx_finish_rotate: null pointer");
+    EXL3_CHECK_ARG(hidden % 128 == 0 && hidden <= 32768, "exl3_fx_finish_rotate: hidden must be a multiple of 128, at most 32768");
+    const int nblk = hidden / 128;
+    const int threads = 32 * (nblk < 32 ? nblk : 32);
+    fx_finish_rotate_kernel<<<m, threads, 0, (hipStream_t) stream>>>((const long long*) R, (half_t*) x_out, ss_out, (const half_t*) norm_w, eps,
+                                                                     (const half_t*) suh, (half_t*) xh, xsum, hidden);
+    return exl3_check_launch("fx_finish_rotate");
+}
+
 extern "C" int exl3_fx_init(const void* x, void* R, float* ss, int m, int hidden, void* stream)
 {
     EXL3_CHECK_ARG(x && R && ss && m >= 1 && hidden % 128 == 0, "exl3_fx_init: null pointer / hidden not a multiple of 128");

@@ -1153,6 +1153,27 @@ def fx_init(x: torch.Tensor, R: torch.Tensor, ss: torch.Tensor, m: int):
     _check(_lib.lib().exl3_fx_init(_p(x), _p(R), _p(ss), m, x.shape[-1], _stream(x)))
 
 
+def fx_init_prep(x: torch.Tensor, R: torch.Tensor, ss: torch.Tensor, m: int, inv_freq, positions, head_dim: int, block_table, page_size: int,
+                 sin_out, cos_out, slots, attn_factor: float = 1.0):
+    """fx_init and qkv_prep (the two independent set-up launches of a decode step) as ONE launch; same outputs."""
+    _dev(x)
+    _req(x.dtype == torch.half and R.dtype == torch.int64 and ss.dtype == torch.float and x.is_contiguous() and R.is_contiguous(), "fx_init_prep: dtypes")
+    _req(sin_out.dtype == torch.float and cos_out.dtype == torch.float and sin_out.shape == cos_out.shape and sin_out.shape[-1] == 64, "fx_init_prep: sin / cos must be (m, 64) float32")
+    _req(slots is None or (slots.dtype == torch.long and block_table is not None and block_table.dtype == torch.int32), "fx_init_prep: slots must be int64 and need an int32 block table")
+    _req(positions.shape[0] == m, "fx_init_prep: one position per row")
+    _check(_lib.lib().exl3_fx_init_prep(_p(x), _p(R), _p(ss), m, x.shape[-1], _p(inv_freq), _p(positions), float(attn_factor), int(head_dim), _p(block_table),
+                                        block_table.shape[1] if block_table is not None else 0, int(page_size), _p(sin_out), _p(cos_out), _p(slots), _stream(x)))
+
+
+def fx_finish_rotate(R: torch.Tensor, x, ss, norm_w, eps: float, suh, xh, xsum, m: int):
+    """fx_finish + glue_rotate for one consumer (the lm_head) as ONE launch: x (optional) = fp16(R / 2^32), ss (optional) its block sums of squares,
+    xh = had128(rms_norm(x) * suh) / sqrt(128) [m, hidden] fp16, xsum (optional) = block sums of xh."""
+    _dev(R)
+    _req(R.dtype == torch.int64 and R.is_contiguous() and xh.dtype == torch.half and xh.is_contiguous() and norm_w.dtype == torch.half and suh.dtype == torch.half,
+         "fx_finish_rotate: R int64, xh / norm_w / suh float16")
+    _check(_lib.lib().exl3_fx_finish_rotate(_p(R), _p(x), _p(ss), _p(norm_w), float(eps), _p(suh), _p(xh), _p(xsum), m, R.shape[-1], _stream(R)))
+
+
 def fx_finish(R: torch.Tensor, x: torch.Tensor | None, ss: torch.Tensor | None, m: int):
     """x = fp16(R / 2^32), ss = its block sums of squares (either may be None)."""
     _dev(R)

@@ -370,6 +370,8 @@ class SyntheticEXL3Llama:
 
     #: per-step sin / cos / cache-row tables for glue_qkv (ext.qkv_prep: one launch per step; False = every layer's glue_qkv computes them itself)
     use_qkv_tab = True
+    #: fx pipeline: the step's set-up pair (fx_init, qkv_prep) and its closing pair (fx_finish, glue_rotate for the lm_head) as one launch each
+    fx_merged_boundaries = os.environ.get("EXL3_HIP_FX_MERGED_BOUNDARIES", "1") != "0"
 
     def _qkv_tab(self):
         """Launches ext.qkv_prep for this step's positions / block table and returns glue_qkv's `tab` argument (None when switched off)."""
@@ -619,8 +621,13 @@ class SyntheticEXL3Llama:
         R = self.R
         sc, so_ = self.ss, self.ss2                                       # sums of squares: current (complete) / the buffer the next reader fills
         q2 = self.q.view(bsz, -1)
-        tab = self._qkv_tab()
-        ext.fx_init(self.x0, R, sc, bsz)
+        if self.use_qkv_tab and self.fx_merged_boundaries:
+            # the step's two set-up launches (fixed-point copy of the input rows, rope tables + cache rows) as one
+            ext.fx_init_prep(self.x0, R, sc, bsz, self.inv_freq, self.positions, hd, self.block_table, self.page, self.rope_sin, self.rope_cos, self.kv_slots)
+            tab = (self.rope_sin, self.rope_cos, self.kv_slots)
+        else:
+            tab = self._qkv_tab()
+            ext.fx_init(self.x0, R, sc, bsz)
         for li, L in enumerate(self.layers):
             lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
             kc, ks = self.kcache[li]
@@ -657,13 +664,19 @@ class SyntheticEXL3Llama:
             ext.glue_act_rs(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz, sc, so_, hidden, self.eps)
             sc, so_ = so_, sc
             ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [R], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT | ATOM, sp["down"])
-        ext.fx_finish(R, self.x, sc, bsz)                                 # fp16 residual + its sums of squares for the final norm
         self.x_final = self.x
-        if self.rotate_for_head:
+        if self.rotate_for_head and self.fx_merged_boundaries:
+            # fp16 residual (kept for callers that read it), final norm and the lm_head's input rotation in one launch
+            ext.fx_finish_rotate(R, self.x, sc, self.final_norm, self.eps, self.lm_head.suh, self.xh3[0], self.xs3[0], bsz)
+            ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
+                             bsz, self.lm_head.mcg, self.lm_head.mul1, ROT)
+        elif self.rotate_for_head:
+            ext.fx_finish(R, self.x, sc, bsz)
             ext.glue_rotate(self.x, sc, self.final_norm, self.eps, [self.lm_head.suh], self.xh3[:1], bsz, xsums=self.xs3[:1])
             ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
                              bsz, self.lm_head.mcg, self.lm_head.mul1, ROT)
         else:
+            ext.fx_finish(R, self.x, sc, bsz)                             # fp16 residual + its sums of squares for the final norm
             ext.exl3_gemv_ex_norm(self.x, self.final_norm, sc, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
                                   bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
         return self.logits

@@ -231,6 +231,14 @@ int exl3_gemv_ex_resid(const void* resid_in, const void* norm_w, const float* ss
  * reduce nor rms_norm_res_in's residual add (norm.cu:193-218) is a launch any more. */
 int exl3_fx_init(const void* x, void* R, float* ss, int m, int hidden, void* stream);
 int exl3_fx_finish(const void* R, void* x, float* ss, int m, int hidden, void* stream);
+/* The same two step-level boundaries with one kernel launch less each: exl3_fx_init_prep = exl3_fx_init + exl3_qkv_prep (independent set-up work of a decode
+ * step, one launch); exl3_fx_finish_rotate = exl3_fx_finish + exl3_glue_rotate for ONE consumer (the lm_head): x_out / ss_out optional, xh = rotated
+ * normalised row [m][hidden] fp16, xsum its block sums [m][hidden/128] (optional).  Values identical to the two-launch forms. */
+int exl3_fx_init_prep(const void* x, void* R, float* ss, int m, int hidden, const float* inv_freq, const int32_t* positions, float attn_factor,
+                      int head_dim, const int32_t* block_table, int blocks_per_seq, int page_size, float* sin_out, float* cos_out,
+                      int64_t* slots, void* stream);
+int exl3_fx_finish_rotate(const void* R, void* x_out, float* ss_out, const void* norm_w, float eps, const void* suh, void* xh, float* xsum,
+                          int m, int hidden, void* stream);
 int exl3_gemv_ex_fx(const void* R, const void* norm_w, const float* ss_prev, float* ss_out, float eps, const void* const* Bs,
                     const void* const* suhs, const int* ns, int count, int m, int k, int K, int cb, int force_split,
                     float** slabs_out, int* S_out, void* stream);

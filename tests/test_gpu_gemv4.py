@@ -227,3 +227,32 @@ def test_routing_on_the_fixed_point_residual_matches_routing_std_norm(dev):
         torch.cuda.synchronize()
         assert torch.equal(sel0, sel1) and torch.equal(gu0, gu1) and torch.equal(xn0, xn1) and torch.equal(w0, w1) and torch.equal(sc0, sc1)
         assert np.allclose(ss1.cpu().numpy(), ss.cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("m,hidden", [(1, 4096), (3, 1024), (2, 8192)])
+def test_merged_step_boundaries_equal_the_two_launch_forms(dev, m, hidden):
+    """fx_init_prep == fx_init + qkv_prep and fx_finish_rotate == fx_finish + glue_rotate, bit for bit (one kernel boundary less each per decode step;
+    hidden 8192: a half-wave walks two Hadamard blocks of its row)."""
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(m + hidden)
+    T = lambda a: _t(a, dev)
+    x = T((rng.standard_normal((m, hidden)) * 2).astype(np.float16))
+    hd, page, pps = 128, 256, 4
+    inv_freq = T((1.0 / (500000.0 ** (np.arange(0, hd, 2, dtype=np.float32) / hd))).astype(np.float32))
+    pos = T(np.array([5, 300, 777][:m], dtype=np.int32)); bt = torch.arange(m * pps, dtype=torch.int32, device=dev).view(m, pps)
+    mk = lambda: (torch.zeros((m, hidden), dtype=torch.long, device=dev), torch.zeros((m, hidden // 128), dtype=torch.float32, device=dev),
+                  torch.zeros((m, 64), dtype=torch.float32, device=dev), torch.zeros((m, 64), dtype=torch.float32, device=dev),
+                  torch.zeros((m,), dtype=torch.long, device=dev))
+    R0, ss0, sn0, cs0, sl0 = mk(); R1, ss1, sn1, cs1, sl1 = mk()
+    ext.fx_init(x, R0, ss0, m); ext.qkv_prep(inv_freq, pos, hd, bt, page, sn0, cs0, sl0)
+    ext.fx_init_prep(x, R1, ss1, m, inv_freq, pos, hd, bt, page, sn1, cs1, sl1)
+    assert torch.equal(R0, R1) and torch.equal(ss0, ss1) and torch.equal(sn0, sn1) and torch.equal(cs0, cs1) and torch.equal(sl0, sl1)
+    # a residual that is not exactly representable in fp16
+    R0 += torch.randint(-2 ** 30, 2 ** 30, R0.shape, device=dev)
+    w = T((1 + 0.1 * rng.standard_normal(hidden)).astype(np.float16)); suh = T(np.where(rng.random(hidden) < 0.5, -1.0, 1.0).astype(np.float16))
+    xa = torch.empty((m, hidden), dtype=torch.half, device=dev); ssa = torch.empty((m, hidden // 128), dtype=torch.float32, device=dev)
+    xha = torch.empty_like(xa); xsa = torch.empty_like(ssa)
+    ext.fx_finish(R0, xa, ssa, m); ext.glue_rotate(xa, ssa, w, 1e-5, [suh], [xha], m, xsums=[xsa])
+    xb = torch.empty_like(xa); ssb = torch.empty_like(ssa); xhb = torch.full_like(xa, float("nan")); xsb = torch.empty_like(ssa)
+    ext.fx_finish_rotate(R0, xb, ssb, w, 1e-5, suh, xhb, xsb, m)
+    assert torch.equal(xa, xb) and torch.equal(ssa, ssb) and torch.equal(xha, xhb) and torch.equal(xsa, xsb)
