@@ -134,9 +134,9 @@ class SyntheticEXL3Mixtral:
         R, sc, so_ = self.R, self.ss, self.ss2
         ATOM = ext.GEMV_OUT_ATOMIC
         q2 = self.q.view(bsz, -1)
-        ext.qkv_prep(self.inv_freq, self.positions, hd, self.block_table, self.page, self.rope_sin, self.rope_cos, self.kv_slots)
+        # the step's two set-up launches (fixed-point copy of the input row, rope tables + cache rows) as one
+        ext.fx_init_prep(self.x0, R, sc, bsz, self.inv_freq, self.positions, hd, self.block_table, self.page, self.rope_sin, self.rope_cos, self.kv_slots)
         tab = (self.rope_sin, self.rope_cos, self.kv_slots)
-        ext.fx_init(self.x0, R, sc, bsz)
         for li, L in enumerate(self.layers):
             lq, lk, lv, lo, moe = L["q"], L["k"], L["v"], L["o"], L["moe"]
             kc, ks = self.kcache[li]

@@ -1,8 +1,8 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r3p; mkdir -p $O; cd $R
-timeout 900 python -m pytest tests/test_gpu_gemv4.py tests/test_gpu_path.py -q -x > $O/t1.log 2>&1; tail -2 $O/t1.log
-for rep in 1 2 3; do for v in 0 1; do
-  EXL3_HIP_FX_MERGED_BOUNDARIES=$v timeout 300 python bench.py --no-prefill --no-extra --no-cpu 2>/dev/null | tail -1 | python -c "
+for rep in 1 2 3; do for v in base slabwt slabnt; do
+  L=$R/exllamav3_amd/libexl3_hip.so; [ $v != base ] && L=$R/build/libexl3_hip_$v.so
+  EXL3_HIP_LIB=$L timeout 300 python bench.py --no-prefill --no-extra --no-cpu 2>/dev/null | tail -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print('merged=$v bs1', d['value'], d['ms_per_step'])"
-done; done | tee $O/ab.txt
+d = json.loads(sys.stdin.read()); print('$v bs1', d['value'], d['ms_per_step'])"
+done; done | tee $O/ab_slab.txt
