@@ -1,4 +1,4 @@
-// EXL3 quantized small-m GEMM for gfx950, kernel generation 3 ("decode -> LDS transpose -> 16x16x32 MFMA"), 5..64 rows per pass.
+// EXL3 quantized small-m GEMM for gfx950, kernel generation 3 ("decode -> 16x16x32 MFMA straight from the decoding lane's registers"), 5..64 rows per pass.
 //
 //   C = ((A * suh) H) @ dequant(B) H * svh (+ bias)        reference: quant/exl3_gemm_kernel.cuh:8-80, quant/exl3_gemm_inner.cuh
 //                                                          (semantics only; the reference streams 16 rows per pass)
@@ -6,8 +6,8 @@
 // Why a third kernel: generation 2 (exl3_gemv2.kspec.hip) multiplies straight out of the decoding lane's registers with
 // v_mfma_f32_4x4x4_16B_f16, which does a quarter of the matrix pipe's work per cycle.  That is free at m <= 4 (the decode VALU work
 // dominates) but at 16 rows the kernel is MFMA-bound: 1024 MFMA cycles against ~660 decode cycles per tile row.  Here the fp16 weights
-// go through a wave-private 4.5 KB LDS buffer into the B-operand layout of v_mfma_f32_16x16x32_f16: 64 MFMA cycles per 16 rows per
-// decode step, so the weight pass is decode-bound again and a 32-row pass costs about what a 4-row pass does.
+// feed v_mfma_f32_16x16x32_f16 (B operand; see "No transpose" below): 64 MFMA cycles per 16 rows per decode step, so the weight pass is
+// decode-bound again and a 32-row pass costs about what a 4-row pass does.
 //
 // Work split: a workgroup = 4 waves = one 128-column block x one k-slice, as in generation 2, but the waves split the COLUMNS (32 each),
 // not k: every wave walks the whole slice.  Nothing is reduced across waves -- no partial sums through LDS, no barrier after the

@@ -6,7 +6,7 @@
 // that is a whole number of 128-wide input Hadamard blocks, so BOTH rotations are workgroup-local: the input Hadamard is recomputed per
 // workgroup in the prologue from x (L2-resident) and the output Hadamard runs in the epilogue (S == 1), in the split-k reduce kernel below
 // (S > 1) or in the consumer of a deferred launch (exl3_glue.hip).  The kernels themselves: exl3_gemv2.kspec.hip (1..16 rows per weight
-// pass, column-pair-per-lane decode into v_mfma_f32_4x4x4_16B_f16) and exl3_gemm3.kspec.hip (5..64 rows, LDS transpose into 16x16x32 MFMAs).
+// pass, column-pair-per-lane decode into v_mfma_f32_4x4x4_16B_f16) and exl3_gemm3.kspec.hip (5..64 rows, 16x16x32 MFMAs fed from the decoding lanes' registers).
 // (The first-generation kernel of round 1 -- 4-wave workgroups, 16x16x32 MFMA on B-fragment-ordered lanes -- was an A/B baseline only and
 // has been removed; git history has it.)
 //
