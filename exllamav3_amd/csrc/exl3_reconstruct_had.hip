@@ -13,6 +13,7 @@
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
 #include "exl3_lane_decode.cuh"
+#include <string.h>
 
 #define RH_LD 136          // padded leading dimension (halves) of the 128x128 LDS images: 272 B rows -> conflict-free b128 reads
 
@@ -42,17 +43,34 @@ __device__ __forceinline__ half8_t had_frag_signed(const uint32_t (&base)[4], in
 // row r (0..15) of the lane's column c (HI = 0) or c + 8 (HI = 1) is weight t = 8q + j
 template <int R, int HI> struct RowToWeight { static constexpr int q = (R & 7) >> 1, j = (R & 1) + 2 * (R >> 3) + 4 * HI, t = 8 * q + j; };
 
+// Up to 4 matrices of one launch (same k, bits and codebook), stacked along n in `out` in this order: q | k | v of the prefill route are 1536 workgroups
+// of one launch instead of 1024 + 256 + 256 of three (k and v alone are one workgroup per CU: 10.4 us each for 2 MB).
+#define RH_MAX_MATS 4
+struct ReconMats
+{
+    const uint32_t* packed[RH_MAX_MATS]; const half_t* suh[RH_MAX_MATS]; const half_t* svh[RH_MAX_MATS];
+    int tiles_n_total[RH_MAX_MATS], tile_n_offset[RH_MAX_MATS], nb_first[RH_MAX_MATS];      // nb_first: first 128-column block of matrix i in the grid
+    int count;
+};
+
 template <int K, int CB, bool TR>
 __global__ __launch_bounds__(256)
-void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict__ packed, const half_t* __restrict__ suh,
-                            const half_t* __restrict__ svh, int tiles_n_total, int tile_n_offset, int64_t out_stride)
+void reconstruct_had_kernel(half_t* __restrict__ out, const ReconMats mt, int64_t out_stride)
 {
+    int mi = 0;
+    #pragma unroll
+    for (int i = 1; i < RH_MAX_MATS; ++i) if (i < mt.count && (int) blockIdx.x >= mt.nb_first[i]) mi = i;
+    const uint32_t* __restrict__ packed = mt.packed[mi];
+    const half_t* __restrict__ suh = mt.suh[mi];
+    const half_t* __restrict__ svh = mt.svh[mi];
+    const int tiles_n_total = mt.tiles_n_total[mi], tile_n_offset = mt.tile_n_offset[mi];
+    const int nb_out = blockIdx.x;                              // position in the stacked output
     constexpr int NW = 8 * K;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* Wt = (half_t*) smem;                          // [n][RH_LD]  W_hat transposed; later the output staging [k'][RH_LD]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kb = blockIdx.y, nb = blockIdx.x;
+    const int kb = blockIdx.y, nb = (int) blockIdx.x - mt.nb_first[mi];         // block within its matrix
     // the scale vectors this lane needs (its k' rows in GEMM 1, its n' column of every column tile in GEMM 2) are requested FIRST, next to the packed
     // words: loaded where they are used, each was a dependent L2 round trip in the middle of the kernel (the 8 svh values one per column-tile trip),
     // and the kernel without decode, matrix instructions and stores still took 33 of 59 us (round 3 ablation, gate_proj shape)
@@ -191,10 +209,27 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const uint32_t* __restrict
     {
         int row = (tid >> 4) + 16 * it, seg = tid & 15;
         half8_t v = *((const half8_t*) (Wt + (size_t) row * RH_LD + 8 * seg));
-        if constexpr (TR) *((half8_t*) (out + ((int64_t) nb * 128 + row) * out_stride + (int64_t) kb * 128 + 8 * seg)) = v;     // row = n'
-        else              *((half8_t*) (out + ((int64_t) kb * 128 + row) * out_stride + (int64_t) nb * 128 + 8 * seg)) = v;     // row = k'
+        if constexpr (TR) *((half8_t*) (out + ((int64_t) nb_out * 128 + row) * out_stride + (int64_t) kb * 128 + 8 * seg)) = v;     // row = n'
+        else              *((half8_t*) (out + ((int64_t) kb * 128 + row) * out_stride + (int64_t) nb_out * 128 + 8 * seg)) = v;     // row = k'
 
     }
+}
+
+static int reconstruct_had_launch(void* out, int64_t ld_out, int transposed, const ReconMats& mt, int total_nb, int tiles_k, int K, int cb, void* stream)
+{
+    dim3 grid((unsigned) total_nb, (unsigned) (tiles_k / 8));
+    size_t lds = (size_t) 128 * RH_LD * 2;                 // 34.8 KB: four workgroups per CU
+    hipStream_t st = (hipStream_t) stream;
+    #define RC(KK, CC) case KK * 3 + CC: \
+        if (transposed) reconstruct_had_kernel<KK, CC, true><<<grid, 256, lds, st>>>((half_t*) out, mt, ld_out); \
+        else reconstruct_had_kernel<KK, CC, false><<<grid, 256, lds, st>>>((half_t*) out, mt, ld_out); break;
+    switch (K * 3 + cb)
+    {
+        RC(1,0) RC(1,1) RC(1,2) RC(2,0) RC(2,1) RC(2,2) RC(3,0) RC(3,1) RC(3,2) RC(4,0) RC(4,1) RC(4,2)
+        RC(5,0) RC(5,1) RC(5,2) RC(6,0) RC(6,1) RC(6,2) RC(7,0) RC(7,1) RC(7,2) RC(8,0) RC(8,1) RC(8,2)
+    }
+    #undef RC
+    return exl3_check_launch("reconstruct_had_slice");
 }
 
 static int reconstruct_had_impl(void* out, int64_t ld_out, int transposed, const void* trellis, const void* suh, const void* svh,
@@ -209,21 +244,33 @@ static int reconstruct_had_impl(void* out, int64_t ld_out, int transposed, const
     EXL3_CHECK_ARG(n_offset + n_size <= (int64_t) tiles_n * 16, "reconstruct slice exceeds packed tensor bounds");
     EXL3_CHECK_ARG(ld_out >= (transposed ? (int64_t) tiles_k * 16 : n_size) && ld_out % 8 == 0, "reconstruct_had_slice: bad output row stride");
     if (n_size == 0 || tiles_k == 0) return EXL3_OK;
-    dim3 grid((unsigned) (n_size / 128), (unsigned) (tiles_k / 8));
-    size_t lds = (size_t) 128 * RH_LD * 2;                 // 34.8 KB: four workgroups per CU
-    hipStream_t st = (hipStream_t) stream;
-    #define RC(KK, CC) case KK * 3 + CC: \
-        if (transposed) reconstruct_had_kernel<KK, CC, true><<<grid, 256, lds, st>>>((half_t*) out, (const uint32_t*) trellis, \
-            (const half_t*) suh, (const half_t*) svh, tiles_n, (int) (n_offset / 16), ld_out); \
-        else reconstruct_had_kernel<KK, CC, false><<<grid, 256, lds, st>>>((half_t*) out, (const uint32_t*) trellis, \
-            (const half_t*) suh, (const half_t*) svh, tiles_n, (int) (n_offset / 16), ld_out); break;
-    switch (K * 3 + cb)
+    ReconMats mt; memset((void*) &mt, 0, sizeof(mt));
+    mt.packed[0] = (const uint32_t*) trellis; mt.suh[0] = (const half_t*) suh; mt.svh[0] = (const half_t*) svh;      // (the slice's own svh, as in the reference's narrowed tensor)
+    mt.tiles_n_total[0] = tiles_n; mt.tile_n_offset[0] = (int) (n_offset / 16); mt.nb_first[0] = 0; mt.count = 1;
+    return reconstruct_had_launch(out, ld_out, transposed, mt, (int) (n_size / 128), tiles_k, K, cb, stream);
+}
+
+// W^T of up to 4 matrices with the same k, bits per weight and codebook, stacked along n in `out` ([sum n_i][ld_out], matrix i's rows behind matrix
+// i - 1's): one launch for the fused q|k|v (or gate|up) GEMM of the prefill route.  tiles_n[i] = n_i / 16 (whole matrices; n_i % 128 == 0).
+extern "C" int exl3_reconstruct_had_multi_t(void* out, int64_t ld_out, const void* const* trellis, const void* const* suh, const void* const* svh,
+                                            const int* tiles_n, int count, int tiles_k, int K, int cb, void* stream)
+{
+    EXL3_CHECK_ARG(out && trellis && suh && svh && tiles_n, "reconstruct_had_multi_t: null pointer");
+    EXL3_CHECK_ARG(count >= 1 && count <= RH_MAX_MATS, "reconstruct_had_multi_t: between 1 and 4 matrices");
+    EXL3_CHECK_ARG(K >= 1 && K <= 8 && cb >= 0 && cb <= 2, "reconstruct_had_multi_t: K must be in [1, 8], codebook in [0, 2]");
+    EXL3_CHECK_ARG(tiles_k % 8 == 0 && tiles_k > 0, "reconstruct_had_multi_t: K dimension must be divisible by 128");
+    EXL3_CHECK_ARG(ld_out >= (int64_t) tiles_k * 16 && ld_out % 8 == 0, "reconstruct_had_multi_t: bad output row stride");
+    ReconMats mt; memset((void*) &mt, 0, sizeof(mt));
+    int nb = 0;
+    for (int i = 0; i < count; ++i)
     {
-        RC(1,0) RC(1,1) RC(1,2) RC(2,0) RC(2,1) RC(2,2) RC(3,0) RC(3,1) RC(3,2) RC(4,0) RC(4,1) RC(4,2)
-        RC(5,0) RC(5,1) RC(5,2) RC(6,0) RC(6,1) RC(6,2) RC(7,0) RC(7,1) RC(7,2) RC(8,0) RC(8,1) RC(8,2)
+        EXL3_CHECK_ARG(trellis[i] && suh[i] && svh[i] && tiles_n[i] > 0 && tiles_n[i] % 8 == 0, "reconstruct_had_multi_t: null matrix / n not divisible by 128");
+        mt.packed[i] = (const uint32_t*) trellis[i]; mt.suh[i] = (const half_t*) suh[i]; mt.svh[i] = (const half_t*) svh[i];
+        mt.tiles_n_total[i] = tiles_n[i]; mt.tile_n_offset[i] = 0; mt.nb_first[i] = nb;
+        nb += tiles_n[i] / 8;
     }
-    #undef RC
-    return exl3_check_launch("reconstruct_had_slice");
+    mt.count = count;
+    return reconstruct_had_launch(out, ld_out, 1, mt, nb, tiles_k, K, cb, stream);
 }
 
 extern "C" int exl3_reconstruct_had(void* out, const void* trellis, const void* suh, const void* svh,

@@ -442,6 +442,21 @@ def reconstruct_had_slice_t(unpacked_t: torch.Tensor, packed: torch.Tensor, suh:
                                              K, _cb(mcg, mul1), n_offset, unpacked_t.shape[0], _stream(unpacked_t)))
 
 
+def reconstruct_had_multi_t(unpacked_t: torch.Tensor, packed: list, suhs: list, svhs: list, K: int, mcg: bool, mul1: bool):
+    """W^T of up to 4 whole matrices (same k, K, codebook) stacked along n into unpacked_t (sum n_i, k) in ONE launch."""
+    _dev(unpacked_t)
+    cnt = len(packed)
+    _req(1 <= cnt <= 4 and len(suhs) == cnt and len(svhs) == cnt, "reconstruct_had_multi_t: between 1 and 4 matrices")
+    k = packed[0].shape[0] * 16
+    _req(all(p.dim() == 3 and p.dtype == torch.int16 and p.shape[2] == 16 * K and p.shape[0] * 16 == k and p.is_contiguous() for p in packed), "packed: 3-D int16, dim 2 = 16*K, shared k")
+    _req(unpacked_t.dtype == torch.half and unpacked_t.dim() == 2 and unpacked_t.shape[1] == k and unpacked_t.stride(1) == 1, "unpacked_t must be (sum n, k) float16")
+    _req(unpacked_t.shape[0] == sum(p.shape[1] * 16 for p in packed), "unpacked_t rows = sum of the matrices' n")
+    _req(all(t.dtype == torch.half for t in suhs + svhs), "suh/svh must be float16")
+    tn = (ctypes.c_int * cnt)(*[p.shape[1] for p in packed])
+    _check(_lib.lib().exl3_reconstruct_had_multi_t(_p(unpacked_t), unpacked_t.stride(0), _parr(packed), _parr(suhs), _parr(svhs), tn, cnt, packed[0].shape[0],
+                                                   int(K), _cb(mcg, mul1), _stream(unpacked_t)))
+
+
 def hgemm_acc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):
     """c (fp16, in place) = fp16(a @ b + c): hgemm + residual add in the GEMM epilogue (one rounding, as fp32 output + `x += y`)."""
     _dev(a)

@@ -12,6 +12,7 @@ of the C-ABI ops in exllamav3_amd.ext.
         out_features > MAX_RECONSTRUCT_SLICE_N: column slices
 """
 from __future__ import annotations
+import os
 import torch
 from . import ext
 
@@ -20,6 +21,15 @@ MAX_RECONSTRUCT_SLICE_N = 32768           # exl3.py:11
 # exl3.py:184 switches to the fused route at 1024 rows.  Measured on MI355X (tools/bench_mid_rows.py, Llama-3.1-8B shapes, 144..512 rows) the fused
 # route is 20-35 % faster than had_r_128 + reconstruct + hgemm + had_r_128 at every row count, so it starts right above the small-m threshold.
 FUSED_RECONSTRUCT_MIN_ROWS = AUTO_RECONSTRUCT_THRESHOLD + 1
+
+
+#: the fused prefill GEMMs reconstruct their matrices with ONE launch (ext.reconstruct_had_multi_t); EXL3_HIP_RECON_MULTI=0: one launch per matrix
+RECON_MULTI = os.environ.get("EXL3_HIP_RECON_MULTI", "1") != "0"
+
+
+def _same_kind(*lins) -> bool:
+    """Same bits per weight and codebook (what one multi-matrix launch needs), and the multi-matrix launch switched on."""
+    return RECON_MULTI and len({(l.K, bool(l.mcg), bool(l.mul1)) for l in lins}) == 1
 
 
 class LinearEXL3:
@@ -123,8 +133,11 @@ class LinearEXL3:
             ext.silu_mul(gate.forward(x), up.forward(x), a)
             return a
         wt = torch.empty((2 * n, k), dtype=torch.half, device=dev)
-        ext.reconstruct_had_slice_t(wt[:n], gate.trellis, gate.suh, gate.svh, gate.K, gate.mcg, gate.mul1, 0)
-        ext.reconstruct_had_slice_t(wt[n:], up.trellis, up.suh, up.svh, up.K, up.mcg, up.mul1, 0)
+        if _same_kind(gate, up):
+            ext.reconstruct_had_multi_t(wt, [gate.trellis, up.trellis], [gate.suh, up.suh], [gate.svh, up.svh], gate.K, gate.mcg, gate.mul1)
+        else:
+            ext.reconstruct_had_slice_t(wt[:n], gate.trellis, gate.suh, gate.svh, gate.K, gate.mcg, gate.mul1, 0)
+            ext.reconstruct_had_slice_t(wt[n:], up.trellis, up.suh, up.svh, up.K, up.mcg, up.mul1, 0)
         y = torch.empty((rows, 2 * n), dtype=torch.half, device=dev)
         ext.hgemm_nt(x.view(rows, k), wt, y)
         ext.silu_mul_2d(y[:, :n], y[:, n:], a.view(rows, n))
@@ -146,10 +159,14 @@ class LinearEXL3:
         dev = x.device
         ntot = sum(l.out_features for l in lins)
         wt = torch.empty((ntot, k), dtype=torch.half, device=dev)
-        n0 = 0
-        for l in lins:
-            ext.reconstruct_had_slice_t(wt[n0: n0 + l.out_features], l.trellis, l.suh, l.svh, l.K, l.mcg, l.mul1, 0)
-            n0 += l.out_features
+        if len(lins) <= 4 and _same_kind(*lins):
+            # one launch for all of them (k and v alone are one workgroup per CU: 10.4 us each for 2 MB of W^T)
+            ext.reconstruct_had_multi_t(wt, [l.trellis for l in lins], [l.suh for l in lins], [l.svh for l in lins], lins[0].K, lins[0].mcg, lins[0].mul1)
+        else:
+            n0 = 0
+            for l in lins:
+                ext.reconstruct_had_slice_t(wt[n0: n0 + l.out_features], l.trellis, l.suh, l.svh, l.K, l.mcg, l.mul1, 0)
+                n0 += l.out_features
         y = torch.empty((rows, ntot), dtype=torch.half, device=dev)
         ext.hgemm_nt(x.view(rows, k), wt, y)
         outs, n0 = [], 0

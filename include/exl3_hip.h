@@ -75,6 +75,11 @@ int exl3_reconstruct_had(void* out, const void* trellis, const void* suh, const 
 /* reconstruct_had_slice written transposed: out[n_size][ld_out] = W^T (row = output feature, k contiguous, ld_out >= k). */
 int exl3_reconstruct_had_t(void* out, int64_t ld_out, const void* trellis, const void* suh, const void* svh,
                            int tiles_k, int tiles_n, int K, int cb, int64_t n_offset, int64_t n_size, void* stream);
+/* W^T of up to 4 whole matrices with the same k, bits per weight and codebook in ONE launch, stacked along n: out [sum n_i][ld_out] fp16 (matrix i's
+ * rows behind matrix i - 1's), tiles_n[i] = n_i / 16, n_i % 128 == 0.  The fused q|k|v / gate|up GEMMs of the prefill route (modules/quant/exl3.py:161-218
+ * reconstructs each Linear on its own) read this buffer as one B operand. */
+int exl3_reconstruct_had_multi_t(void* out, int64_t ld_out, const void* const* trellis, const void* const* suh, const void* const* svh,
+                                 const int* tiles_n, int count, int tiles_k, int K, int cb, void* stream);
 
 /* had_r_128(input, output, pre_scale, post_scale, scale)   quant/hadamard.cu:88-173.
  * rows x cols, cols % 128 == 0; fp32 = 0: fp16 in/out, 1: fp32 in/out; scales fp16 [cols] or NULL; in-place allowed */

@@ -136,6 +136,29 @@ def test_hgemm_acc_and_forward_add_residual(dev, m, k, n):
     assert np.abs(ra.float().cpu().numpy() - ref2).max() / np.sqrt((ref2 ** 2).mean()) < 2e-2
 
 
+@pytest.mark.parametrize("K,cb", [(4, 2), (3, 0), (5, 1)])
+def test_reconstruct_had_multi_matches_separate_launches(dev, K, cb):
+    """reconstruct_had_multi_t (q | k | v of the fused prefill GEMM in ONE launch) is bit-identical to one reconstruct_had_slice_t per matrix into the
+    same stacked buffer; matrices of different width, 1 to 4 of them; a row stride wider than k."""
+    from exllamav3_amd import ext
+    k = 512
+    mats = [o.synth_linear(k, n, K, seed=40 + i, realistic=True) for i, n in enumerate((384, 128, 128, 256))]
+    dm = [tuple(_t(a, dev) for a in t) for t in mats]
+    for cnt in (1, 3, 4):
+        ntot = sum(t[0].shape[1] * 16 for t in mats[:cnt])
+        sep = torch.zeros((ntot, k + 64), dtype=torch.half, device=dev); one = torch.zeros_like(sep)
+        n0 = 0
+        for tr, su, sv in dm[:cnt]:
+            n = tr.shape[1] * 16
+            ext.reconstruct_had_slice_t(sep[n0: n0 + n, :k], tr, su, sv, K, cb == 1, cb == 2, 0)
+            n0 += n
+        ext.reconstruct_had_multi_t(one[:, :k], [t[0] for t in dm[:cnt]], [t[1] for t in dm[:cnt]], [t[2] for t in dm[:cnt]], K, cb == 1, cb == 2)
+        assert torch.equal(sep, one), cnt
+    ref = o.weight_tensor(*mats[1], K, cb)
+    got = one[384:512, :k].t().float().cpu().numpy()
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-3
+
+
 @pytest.mark.parametrize("k,n,K,cb", [(256, 384, 4, 2), (512, 256, 3, 0), (1024, 128, 6, 1)])
 def test_reconstruct_had_slice_transposed(dev, k, n, K, cb):
     """reconstruct_had_slice_t writes W^T (row stride >= k): bit-identical to the transpose of reconstruct_had_slice, whole matrix, a column
