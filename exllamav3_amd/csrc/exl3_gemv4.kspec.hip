@@ -54,7 +54,7 @@ constexpr int g4_input_mode(int MODE) { return MODE == G4_MODE_TRAWX ? G4_MODE_R
 constexpr int g4_waves_per_eu(int K, int CB, int MODE_)
 {
     const int MODE = g4_input_mode(MODE_);
-    if (MODE == G4_MODE_ACT) return 4;
+    if (MODE == G4_MODE_ACT) return MODE_ == G4_MODE_TACT ? 4 : 3;     // 8 slab lines travel with a task; the non-table form also carries the row-scale correction
     if (MODE == G4_MODE_ACTFX && K >= 6) return 5;          // four 16-byte accumulator loads in flight per task next to a 12..16-word ring
     if (K >= 5) return 6;
     if (MODE == G4_MODE_NORMFX || MODE == G4_MODE_ACTFX) return 6;
@@ -202,7 +202,10 @@ void exl3_gemv4_kernel(const GemvArgs a)
     const int last_unit = ubase + (nun > 0 ? nun - 1 : 0);
 
     // ---- preparation tasks (raw / norm / act input): task t = (block t / m, row t % m), one per half-wave; only waves that own a task run them
-    struct PrepIn { half4_t xv, sv, wv; float ss, ssn; uint4_t f0, f1, f2, f3; };
+    // (ACT: the first 4 slab lines of gate and up and their svh travel with the task, i.e. they are requested BEFORE the wave's first weight rows -- loaded
+    // inside the task they queued behind those rows)
+    constexpr int NSL = MODE == G4_MODE_ACT ? 4 : 1;
+    struct PrepIn { half4_t xv, sv, wv; float ss, ssn; uint4_t f0, f1, f2, f3; float4_t ga[NSL], ua[NSL]; half4_t svg, svu; };
     const int ntask = nb * m;
     auto fetch = [&] (int it) -> PrepIn
     {
@@ -223,10 +226,24 @@ void exl3_gemv4_kernel(const GemvArgs a)
             r.f0 = gp[0]; r.f1 = gp[1]; r.f2 = up[0]; r.f3 = up[1];
         }
         r.sv = ((const half4_t*) (suh + kofs))[l32];
-        if constexpr (MODE == G4_MODE_ACT || MODE == G4_MODE_ACTFX)
+        if constexpr (MODE == G4_MODE_ACT)
+        {
+            const int blk_abs = (k0s >> 7) + blk;
+            const float* pa = a_act_g + ((size_t) blk_abs * a_act_S * m + row) * 128;
+            const float* pb = a_act_u + ((size_t) blk_abs * a_act_S * m + row) * 128;
+            #pragma unroll
+            for (int i = 0; i < NSL; ++i)
+            {
+                const size_t so = (size_t) min(i, a_act_S - 1) * m * 128;
+                r.ga[i] = ((const float4_t*) (pa + so))[l32]; r.ua[i] = ((const float4_t*) (pb + so))[l32];
+            }
+            r.svg = ((const half4_t*) (a_act_svh_g + blk_abs * 128))[l32];
+            r.svu = ((const half4_t*) (a_act_svh_u + blk_abs * 128))[l32];
+        }
+        if constexpr (!TBL && (MODE == G4_MODE_ACT || MODE == G4_MODE_ACTFX))
         {
             // gate / up came from a launch that normalised with the previous residual's 1/rms (GEMV_IN_RESID / GEMV_IN_FX): the first 32 block sums
-            // of squares of both residuals travel with the task (gemv_rescale)
+            // of squares of both residuals travel with the task (gemv_rescale).  (Table launches never carry a rescale.)
             if (a.act_rs.ss_new)
             {
                 const int nbh = a.act_rs.k >> 7;
@@ -333,15 +350,40 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     // a = fp16(silu(g) * u) of this (row, block): split-k reduce of the producer's gate / up slabs, output Hadamards, svh -- the
                     // arithmetic of glue_act_kernel (same device functions, slice-order sums)
                     const int blk_abs = (k0s >> 7) + blk;
-                    const SlabRef sg = { a_act_g, a_act_S }, su = { a_act_u, a_act_S };
-                    float4_t vg, vu;
-                    slab_sum2<4>(sg, su, blk_abs, row, m, l32, vg, vu);
-                    const half4_t svg = ((const half4_t*) (a_act_svh_g + blk_abs * 128))[l32];
-                    const half4_t svu = ((const half4_t*) (a_act_svh_u + blk_abs * 128))[l32];
+                    // slice-order sums: lines 0..3 came with the task, the rest (splits deeper than 4) are fetched here
+                    float4_t vg = { 0.f, 0.f, 0.f, 0.f }, vu = vg;
+                    #pragma unroll
+                    for (int i = 0; i < NSL; ++i) if (i < a_act_S)
+                    {
+                        vg.x += cur.ga[i].x; vg.y += cur.ga[i].y; vg.z += cur.ga[i].z; vg.w += cur.ga[i].w;
+                        vu.x += cur.ua[i].x; vu.y += cur.ua[i].y; vu.z += cur.ua[i].z; vu.w += cur.ua[i].w;
+                    }
+                    if (a_act_S > NSL)
+                    {
+                        const float* pa = a_act_g + ((size_t) blk_abs * a_act_S * m + row) * 128;
+                        const float* pb = a_act_u + ((size_t) blk_abs * a_act_S * m + row) * 128;
+                        for (int sl = NSL; sl < a_act_S; sl += 4)
+                        {
+                            float4_t ta[4], tb[4];
+                            #pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                            {
+                                const size_t so = (size_t) min(sl + i, a_act_S - 1) * m * 128;
+                                ta[i] = ((const float4_t*) (pa + so))[l32]; tb[i] = ((const float4_t*) (pb + so))[l32];
+                            }
+                            #pragma unroll
+                            for (int i = 0; i < 4; ++i) if (sl + i < a_act_S)
+                            {
+                                vg.x += ta[i].x; vg.y += ta[i].y; vg.z += ta[i].z; vg.w += ta[i].w;
+                                vu.x += tb[i].x; vu.y += tb[i].y; vu.z += tb[i].z; vu.w += tb[i].w;
+                            }
+                        }
+                    }
+                    const half4_t svg = cur.svg, svu = cur.svu;
                     float g0, g1, g2, g3, u0, u1, u2, u3;
                     out_had(vg, l32, g0, g1, g2, g3);
                     out_had(vu, l32, u0, u1, u2, u3);
-                    if (a.act_rs.ss_new)
+                    if (!TBL && a.act_rs.ss_new)
                     {
                         const float rsc = gemv_rescale(a.act_rs, row, l32, cur.ss, cur.ssn);        // r_new / r_prev of the row
                         g0 *= rsc; g1 *= rsc; g2 *= rsc; g3 *= rsc; u0 *= rsc; u1 *= rsc; u2 *= rsc; u3 *= rsc;
