@@ -162,6 +162,7 @@ def _declare(l):
     sig("exl3_glue_act_rs", vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, f32, vp)
     sig("exl3_glue_rotate", vp, vp, vp, f32, PP, PP, PP, i32, i32, i32, vp)
     sig("exl3_mgemm_indexed", vp, i32, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp)
+    sig("exl3_mgemm_indexed_nlist", vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_gemv_ex_norm", vp, vp, vp, f32, PP, PP, PP, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
     sig("exl3_glue_resid", vp, i32, vp, vp, vp, vp, vp, i32, i32, vp)
     sig("exl3_fx_init", vp, vp, vp, i32, i32, vp)

@@ -47,6 +47,7 @@ void exl3_gemv_reduce_kernel(const GemvArgs a, int total_colblocks)
         ws_off = slot * a.tbl.cbs_per_mat * a.S * a.m * 128;
         svh_m = skip ? nullptr : (const half_t*) a.tbl.svh[sr.mat_index];
         C_m = a.c_fp32 ? (void*) ((float*) a.tbl.C + (size_t) slot * a.tbl.c_slot_stride) : (void*) ((half_t*) a.tbl.C + (size_t) slot * a.tbl.c_slot_stride);
+        if (a.tbl.n_list && !skip) { n = a.tbl.n_list[sr.mat_index]; C_m = (void*) a.tbl.c_list[sr.mat_index]; skip = cbl >= (n >> 7); }
         out_scale = HAD_R_SCALE_128 * sr.weight;
     }
     else
@@ -451,7 +452,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             const int ng = mp <= 4 ? 1 : (mp <= 8 ? 2 : 4);
             const bool rot_pass = (pass_flags & GEMV_IN_ROTATED) != 0;
             // table launches (MoE): raw-x / slab-act inputs; the fp16 gate / up act input (tbl->act_u) stays generation 2's
-            bool g4 = gemv_gen4() && ng == 1 && (!tbl || !tbl->act_u) && !epi && cpw == 0 && !rsd && bps <= 32;
+            bool g4 = gemv_gen4() && ng == 1 && (!tbl || (!tbl->act_u && !tbl->n_list)) && !epi && cpw == 0 && !rsd && bps <= 32;
             if (g4 && rot_pass && var == 1 && cb == 2)
                 for (int i = 0; i < count; ++i) if (!args.mat[i].xsum) g4 = false;      // the mul1 FAST variant needs the producer's block sums
             if (g4)
@@ -696,6 +697,29 @@ extern "C" int exl3_mgemm_indexed(const void* A, int bszm_in, const void* tbl_B,
 {
     return mgemm_indexed_impl(A, nullptr, bszm_in, tbl_B, tbl_suh, tbl_svh, indices, weights, bszm, C, m, k, n, K, cb, c_fp32, min_index, max_index,
                               num_tokens, stream);
+}
+
+// exl3_mgemm with per-matrix output widths (quant/exl3_gemm.cuh:54-55, exl3_gemm.cu:433-447, kernel exl3_gemm_kernel.cuh:176-182): matrix i is
+// size_n_list[i] columns wide (device int32, multiples of 128, <= n_max) and its [m][size_n_list[i]] output goes to c_ptrs[i] (device int64 table);
+// slot j runs matrix indices ? indices[j] : j.  As in the reference: no routing weights, no expert range, one token.
+extern "C" int exl3_mgemm_indexed_nlist(const void* A, int bszm_in, const void* tbl_B, const void* tbl_suh, const void* tbl_svh, const int64_t* indices,
+                                        int bszm, const int32_t* size_n_list, const void* c_ptrs, int m, int k, int n_max, int K, int cb, int c_fp32,
+                                        void* stream)
+{
+    EXL3_CHECK_ARG(A && tbl_B && tbl_suh && tbl_svh && size_n_list && c_ptrs, "exl3_mgemm (per-matrix widths): null pointer");
+    EXL3_CHECK_ARG(bszm >= 1 && (bszm_in == 1 || bszm_in == bszm), "exl3_mgemm: A must have 1 or bszm slots");
+    EXL3_CHECK_ARG(m >= 1 && m <= 16, "exl3_mgemm (per-matrix widths): 1..16 rows per slot");
+    GemvTable t; memset((void*) &t, 0, sizeof(t));
+    t.B = (const uint64_t*) tbl_B; t.suh = (const uint64_t*) tbl_suh; t.svh = (const uint64_t*) tbl_svh;
+    t.indices = indices; t.C = (void*) c_ptrs;                        // (never written: every slot's output pointer comes from c_list)
+    t.bszm = bszm; t.min_index = -1; t.max_index = -1; t.n = n_max; t.cbs_per_mat = n_max / 128;
+    t.a_slot_stride = bszm_in == 1 ? 0 : (int64_t) m * k;
+    t.c_slot_stride = 0;
+    t.n_list = size_n_list; t.c_list = (const uint64_t*) c_ptrs;
+    const void* Bs[1] = { tbl_B }; int ns[1] = { n_max };
+    const void* su[1] = { tbl_suh }; const void* sv[1] = { tbl_svh }; void* Cs[1] = { (void*) c_ptrs };
+    return run_mgemm(A, Bs, Cs, su, sv, nullptr, ns, bszm, m, k, K, cb, c_fp32, 0, (hipStream_t) stream, 0, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, 0.0f, &t);
 }
 
 // exl3_mgemm_indexed whose input is fp16(silu(G_j) * U_j) per slot (G, U: [bszm][m][k] fp16, the gate / up outputs of the routed experts): the

@@ -161,6 +161,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         Bm = (const uint32_t*) a.tbl.B[sr.mat_index];
         suh = (const half_t*) a.tbl.suh[sr.mat_index];
         n = a.tbl.n; cbl = cbg - slot * a.tbl.cbs_per_mat;
+        if (a.tbl.n_list) { n = a.tbl.n_list[sr.mat_index]; if (cbl >= (n >> 7)) return; }      // per-matrix widths: the grid is sized for the widest
         A_in = a_A + (size_t) slot * a.tbl.a_slot_stride;
         ws_off = slot * a.tbl.cbs_per_mat * a_S * m * 128;
     }
@@ -758,6 +759,7 @@ void exl3_gemv2_kernel(const GemvArgs a)
         const SlotRef_t sr = resolve_slot(a.tbl, slot);
         svh = (const half_t*) a.tbl.svh[sr.mat_index] + cbl * 128;
         C_m = a.c_fp32 ? (void*) ((float*) a.tbl.C + (size_t) slot * a.tbl.c_slot_stride) : (void*) ((half_t*) a.tbl.C + (size_t) slot * a.tbl.c_slot_stride);
+        if (a.tbl.c_list) C_m = (void*) a.tbl.c_list[sr.mat_index];
         out_scale = HAD_R_SCALE_128 * sr.weight;                       // reference: scale *= weight, then one multiply (kernel.cuh:216-217)
     }
     else

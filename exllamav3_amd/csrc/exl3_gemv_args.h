@@ -91,6 +91,9 @@ struct GemvTable
     const uint64_t* act_svh; int act_up_off;                        // svh table of the gate|up launch whose slabs are this launch's input: gate svh = act_svh[matrix],
                                                                     // up svh = act_svh[matrix + act_up_off]
     int slots_per_token;                                            // GEMV_OUT_ATOMIC: slot j adds into the rows of token j / slots_per_token
+    // per-matrix output widths (quant/exl3_gemm.cu:433-447): matrix i is n_list[i] <= n columns wide and writes [m][n_list[i]] at c_list[i];
+    // n then only sizes the grid and the slabs (generation 2 table launches only)
+    const int32_t* n_list; const uint64_t* c_list;
 };
 
 struct SlotRef_t { int mat_index; float weight; };

@@ -249,9 +249,28 @@ def exl3_mgemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, suh: torch.Ten
                num_tokens: int = 1, size_n_list=None, c_ptrs=None) -> int:
     """quant/exl3_gemm.cuh:58-78 (verbatim argument order).  A [bA, m, k] fp16; B / suh / svh: int64 device tensors of device pointers
     (modules/multilinear.py:30-32, block_sparse_mlp.py); C [bC, m, n] fp16/fp32; indices int64 [*, top] or None; weights fp16 or None.
-    A_had (scratch) is not needed here.  Per-matrix widths (size_n_list / c_ptrs) are outside this build."""
+    A_had (scratch) is not needed here.  size_n_list (int32 [num matrices]) + c_ptrs (int64 [num matrices]): per-matrix output widths and output
+    addresses (exl3_gemm.cu:433-447) -- C then only carries the dtype and the widest matrix's width."""
     _dev(A)
-    _req(size_n_list is None and c_ptrs is None, "exl3_mgemm: per-matrix widths (size_n_list / c_ptrs) are outside this build")
+    if size_n_list is not None or c_ptrs is not None:
+        _req(size_n_list is not None and c_ptrs is not None, "exl3_mgemm: size_n_list requires c_ptrs")
+        _req(size_n_list.dtype == torch.int32 and c_ptrs.dtype == torch.long and size_n_list.is_contiguous() and c_ptrs.is_contiguous(),
+             "exl3_mgemm: size_n_list must be int32, c_ptrs int64")
+        _req(num_tokens == 1 and min_index < 0 and weights is None, "exl3_mgemm: per-matrix widths incompatible with multi-token/filtering/weights")
+        _req(A.dtype == torch.half and A.dim() == 3 and C.dim() == 3 and A.shape[1] == C.shape[1] and A.is_contiguous(), "exl3_mgemm: bad A / C")
+        _req(B.dtype == torch.long and suh.dtype == torch.long and svh.dtype == torch.long and B.dim() == 1, "exl3_mgemm: B, suh, svh must be int64 pointer tensors")
+        _req(C.dtype in (torch.half, torch.float), "exl3_mgemm: C must be float16 or float32")
+        bA, m, k = A.shape
+        bszm = max(bA, int(c_ptrs.shape[0]))                       # exl3_gemm.cu:446-448
+        if indices is not None:
+            _req(indices.dtype == torch.long and indices.is_contiguous() and indices.dim() == 2, "exl3_mgemm: indices must be int64 [*, slots]")
+            bszm = min(bszm, int(indices.shape[1]))                # exl3_gemm.cu:462-464
+        _req(bA in (1, bszm) or bA >= bszm, "exl3_mgemm: A must hold 1 or bszm slots")
+        _req(size_n_list.numel() >= (bszm if indices is None else 1) and c_ptrs.numel() >= (bszm if indices is None else 1), "exl3_mgemm: width / pointer lists too short")
+        _req(k % 128 == 0 and C.shape[2] % 128 == 0, "exl3_mgemm: k and n must be divisible by 128")
+        _check(_lib.lib().exl3_mgemm_indexed_nlist(_p(A), 1 if bA == 1 else bszm, _p(B), _p(suh), _p(svh), _p(indices), bszm, _p(size_n_list), _p(c_ptrs),
+                                                   m, k, int(C.shape[2]), int(K), _cb(bool(mcg), bool(mul1)), int(C.dtype == torch.float), _stream(A)))
+        return 90
     _req(A.dtype == torch.half, "exl3_mgemm: A must be float16")
     _req(B.dtype == torch.long and suh.dtype == torch.long and svh.dtype == torch.long, "exl3_mgemm: B, suh, svh must be int64 pointer tensors")
     _req(C.dtype in (torch.half, torch.float), "exl3_mgemm: C must be float16 or float32")
@@ -338,11 +357,14 @@ def exl3_moe(hidden_state, output_state, expert_count, token_sorted, weight_sort
     gate and up of all (expert, <= 16-row chunk) slots, then down with silu * mul formed in its prologue -- and a weighted scatter-add.
     The slot list is built on the DEVICE (exl3_moe_build_slots: prefix sum over expert_count, <= 16-row chunks, over-limit experts masked), every
     shape depends on tensor sizes only and the weighted scatter runs in a fixed order: the op has no host round trip, can be captured in a hipGraph
-    and replays bit for bit.  SiLU only; act_limit must be 0."""
+    and replays bit for bit.  Gated SiLU without a limit takes the route above; GELU, the non-gated relu^2 (MOE_ACT_RELU2_NOGATE: no gate GEMM, the
+    gate lane is relu(up): hadamard_inner.cuh:343-378) and any act_limit (up clamped to +-limit, the activated gate to <= limit: :389-397) form
+    act(g) * u with one act_mul launch between the up and the down launches."""
     _dev(hidden_state)
     if num_active == 0:
         return
-    _req(act_function == MOE_ACT_SILU and float(act_limit) == 0.0, "exl3_moe: only the gated SiLU activation without a limit is built")
+    _req(act_function in (MOE_ACT_SILU, MOE_ACT_GELU, MOE_ACT_RELU2_NOGATE), "exl3_moe: activation must be SiLU, GELU or the non-gated relu^2")
+    _req(float(act_limit) >= 0.0, "exl3_moe: act_limit must be >= 0")
     _req(hidden_state.dtype == torch.half and hidden_state.dim() == 2 and hidden_state.is_contiguous(), "exl3_moe: hidden_state must be contiguous float16 (bsz, hidden)")
     _req(output_state.dtype == torch.float and output_state.shape == hidden_state.shape, "exl3_moe: output_state must be float32 with hidden_state's shape")
     _req(expert_count.dtype == torch.long and expert_count.dim() == 1 and token_sorted.dtype == torch.long and token_sorted.dim() == 1,
@@ -370,12 +392,20 @@ def exl3_moe(hidden_state, output_state, expert_count, token_sorted, weight_sort
     st = _stream(hidden_state)
     _check(_lib.lib().exl3_moe_build_slots(_p(expert_count), _p(token_sorted), E, T, max_rows, m, ns, _p(slot_expert), _p(slot_tok), _p(rowmap), st))
     A = hidden_state.index_select(0, slot_tok).view(ns, m, hidden)
-    G = torch.empty((ns, m, inter), dtype=torch.half, device=dev)
-    U = torch.empty_like(G)
-    exl3_mgemm(A, gate_ptrs_trellis, G, gate_ptrs_suh, None, gate_ptrs_svh, slot_expert, None, K_gate, -1, gate_mcg, gate_mul1, -1, -1, 0)
+    gated = act_function != MOE_ACT_RELU2_NOGATE
+    U = torch.empty((ns, m, inter), dtype=torch.half, device=dev)
+    G = torch.empty_like(U) if gated else None
+    if gated:
+        exl3_mgemm(A, gate_ptrs_trellis, G, gate_ptrs_suh, None, gate_ptrs_svh, slot_expert, None, K_gate, -1, gate_mcg, gate_mul1, -1, -1, 0)
     exl3_mgemm(A, up_ptrs_trellis, U, up_ptrs_suh, None, up_ptrs_svh, slot_expert, None, K_up, -1, up_mcg, up_mul1, -1, -1, 0)
     D = torch.empty((ns, m, hidden), dtype=torch.float, device=dev)
-    exl3_mgemm_act(G, U, down_ptrs_trellis, D, down_ptrs_suh, down_ptrs_svh, slot_expert, None, K_down, down_mcg, down_mul1)
+    if act_function == MOE_ACT_SILU and float(act_limit) == 0.0:
+        exl3_mgemm_act(G, U, down_ptrs_trellis, D, down_ptrs_suh, down_ptrs_svh, slot_expert, None, K_down, down_mcg, down_mul1)
+    else:
+        # (skipped slots hold uninitialised rows: act_mul runs over them, the down launch and the scatter never read them)
+        Y = torch.empty_like(U)
+        act_mul(G if gated else U, U, Y, {MOE_ACT_SILU: ACT_SILU, MOE_ACT_GELU: ACT_GELU, MOE_ACT_RELU2_NOGATE: ACT_RELU}[act_function], float(act_limit))
+        exl3_mgemm(Y, down_ptrs_trellis, D, down_ptrs_suh, None, down_ptrs_svh, slot_expert, None, K_down, -1, down_mcg, down_mul1, -1, -1, 0)
     # weighted scatter in a fixed order per token (bit-reproducible; the round-2 index_add_ was an atomic scatter)
     _check(_lib.lib().exl3_moe_scatter(_p(D), _p(rowmap), _p(token_sorted), _p(weight_sorted), _p(output_state), bsz, T, hidden, st))
 

@@ -442,6 +442,14 @@ int exl3_routing_std_slots(const void* hidden, const void* gate, const void* bia
 int exl3_routing_std_scaled(const void* hidden, const void* gate, const void* bias, const void* per_expert_scale, void* scores,
                             int64_t* topk_indices, void* topk_weights, int64_t* gu_slots, int bsz, int hidden_size, int num_experts, int K,
                             void* stream);
+/* exl3_mgemm with per-matrix output widths -- replaces the size_n_list / c_ptrs form of quant/exl3_gemm.cuh:54-55,76-77 (launcher
+ * exl3_gemm.cu:433-447, kernel exl3_gemm_kernel.cuh:176-182; caller libtorch/dsv4_attn.cpp:88-98).  Matrix i is size_n_list[i] columns wide (device
+ * int32 [num matrices], multiples of 128, <= n_max) and writes its [m][size_n_list[i]] output (fp16 / fp32 by c_fp32) at c_ptrs[i] (device table of
+ * device addresses); slot j of bszm runs matrix indices ? indices[j] : j on A[j] (or the one shared A).  No routing weights / expert range / token
+ * groups (the reference rejects those combinations too).  1..16 rows. */
+int exl3_mgemm_indexed_nlist(const void* A, int bszm_in, const void* tbl_B, const void* tbl_suh, const void* tbl_svh, const int64_t* indices,
+                             int bszm, const int32_t* size_n_list, const void* c_ptrs, int m, int k, int n_max, int K, int cb, int c_fp32, void* stream);
+
 /* ... on the RMSNorm of the residual stream formed inside the launch: xn = fp16(resid * norm_w * rsqrt(mean(resid^2) + eps)), mean square from
  * ss_part [bsz][hidden/128] (exl3_glue_resid); xn_out receives xn for the expert launches.  Replaces the rms_norm launch + routing of
  * modules/block_sparse_mlp.py:1099-1130. */

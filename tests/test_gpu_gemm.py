@@ -240,6 +240,45 @@ def test_mgemm_indexed_moe_forms(dev, cb, k, n, K):
         ext.exl3_mgemm(T(xs2), pB, C, psu, None, psv, T(sel2), T(w2), K, -1, cb == 1, cb == 2, 0, 4, 0, num_tokens=2)
 
 
+@pytest.mark.parametrize("cb,K", [(0, 4), (2, 3)])
+@pytest.mark.parametrize("m", [1, 3, 7])
+def test_mgemm_per_matrix_widths(dev, cb, K, m):
+    """exl3_mgemm with size_n_list / c_ptrs (quant/exl3_gemm.cu:433-447, the x-side fan of libtorch/dsv4_attn.cpp:88-98): matrices of different widths in
+    one launch, every output at its own address with its own row stride; without indices (slot j = matrix j) and with them (a selection, in another
+    order); fp16 and fp32.  Against the oracle linear per matrix; nothing is written past a matrix's width or into C."""
+    from exllamav3_amd import ext
+    k = 1024
+    widths = [384, 128, 640, 256]
+    rng = np.random.default_rng(7 * m + K + cb)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mats = [o.synth_linear(k, n, K, seed=300 + i, realistic=True) for i, n in enumerate(widths)]
+    tB = [T(t[0]) for t in mats]; tsu = [T(t[1]) for t in mats]; tsv = [T(t[2]) for t in mats]
+    ptr = lambda ts: torch.tensor([t.data_ptr() for t in ts], dtype=torch.long, device=dev)
+    pB, psu, psv = ptr(tB), ptr(tsu), ptr(tsv)
+    nl = torch.tensor(widths, dtype=torch.int32, device=dev)
+    x = rng.standard_normal((1, m, k)).astype(np.float16)
+    tol = lambda ref: 1e-2 * np.sqrt((ref ** 2).mean()) + 1e-3
+    for dt in (torch.half, torch.float):
+        for sel in (None, [2, 0, 3]):
+            outs = [torch.full((m, n + 128), 7.0, dtype=dt, device=dev) for n in widths]        # 128 guard columns behind every output
+            flat = [t.view(-1) for t in outs]
+            Cd = torch.full((1, m, max(widths)), 9.0, dtype=dt, device=dev)                     # dtype + max-width carrier: never written
+            idx = None if sel is None else T(np.array([sel], dtype=np.int64))
+            ext.exl3_mgemm(T(x), pB, Cd, psu, None, psv, idx, None, K, -1, cb == 1, cb == 2, -1, -1, 0, 1, nl, ptr(flat))
+            ran = range(len(widths)) if sel is None else sel
+            for i, n in enumerate(widths):
+                got = flat[i][: m * n].view(m, n).float().cpu().numpy()
+                if i in ran:
+                    ref = o.linear_forward(x[0], mats[i][0], mats[i][1], mats[i][2], K, cb, out_fp32=dt == torch.float).astype(np.float32)
+                    assert np.abs(got - ref).max() < tol(ref), (dt, sel, i)
+                else:
+                    assert bool((flat[i] == 7.0).all())
+                assert bool((flat[i][m * n:] == 7.0).all())
+            assert bool((Cd == 9.0).all())
+    with pytest.raises(RuntimeError):
+        ext.exl3_mgemm(T(x), pB, Cd, psu, None, psv, None, None, K, -1, cb == 1, cb == 2, -1, -1, 0, 1, nl, None)
+
+
 # ---- generation 3 (exl3_gemm3.kspec.hip): 9..64 rows per pass through the LDS transpose into 16x16x32 MFMAs ----------------------------
 
 @pytest.mark.parametrize("cb", [0, 1, 2])

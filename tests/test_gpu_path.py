@@ -632,8 +632,30 @@ def test_exl3_moe_op_matches_oracle(dev):
     assert np.array_equal(got[untouched], out0[untouched])
     ext.exl3_moe(*args, 0.0, 0)                                              # num_active == 0: nothing to do
     assert np.array_equal(out.cpu().numpy(), got)
+    # the other activations of the reference's fused op (exl3_moe_common.cuh:6-8, hadamard_inner.cuh:343-397): GELU, the non-gated relu^2 (no gate
+    # GEMM: relu(u) * u), an activation limit (u clamped to +-limit, the activated gate to <= limit)
+    for act, name, limit in ((ext.MOE_ACT_GELU, "gelu", 0.0), (ext.MOE_ACT_RELU2_NOGATE, "relu", 0.0), (ext.MOE_ACT_SILU, "silu", 0.75),
+                             (ext.MOE_ACT_RELU2_NOGATE, "relu", 0.5)):
+        out = T(out0)
+        ext.exl3_moe(*args[:1], out, *args[2:9], act, *args[10:], limit, 3)
+        ref = out0.copy()
+        off = 0
+        for e, c in enumerate(counts):
+            if 0 < c <= max_rows:
+                rows = np.array(toks[off:off + c])
+                u = _lin(moe.up[e], x[rows]).astype(np.float16)
+                g = _lin(moe.gate[e], x[rows]).astype(np.float16) if act != ext.MOE_ACT_RELU2_NOGATE else u
+                a = o.act_mul(g, u, name, limit)
+                d = _lin(moe.down[e], a, out_fp32=True)
+                for i, t in enumerate(rows):
+                    ref[t] += np.float32(wts16[off + i]) * d[i]
+            off += c
+        got2 = out.cpu().numpy()
+        delta = ref - out0
+        assert np.abs(got2 - ref).max() / np.sqrt((delta[np.abs(delta).sum(1) > 0] ** 2).mean()) < 2e-2, (name, limit)
+        assert np.array_equal(got2[untouched], out0[untouched])
     with pytest.raises(RuntimeError):
-        ext.exl3_moe(*args[:9], ext.MOE_ACT_GELU, *args[10:], 0.0, 3)
+        ext.exl3_moe(*args[:9], 7, *args[10:], 0.0, 3)
     assert ext.exl3_moe_max_concurrency(0) > 0
 
 
