@@ -342,6 +342,15 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                 if ((nbk + b - 1) / b != s) continue;              // not a normalised split
                 const long wg = (long) total_cb * s;
                 double cost = (double) ((wg + cus - 1) / cus) * b + (wg < 2l * cus ? 0.25 : 0.0) + 1e-3 * s;
+                if (g3)
+                {
+                    // generation 3 (5..16 rows here): four workgroups per CU are resident (register budget), a workgroup's prologue (activation
+                    // copy, first weight rows) costs about 8 streamed blocks, a lone workgroup does not fill its CU (one wave per SIMD: count
+                    // it as two), and every slab is read again by the consumer.  Fitted to tools/sweep_split.py at 16 rows (Llama-3.1-8B:
+                    // gate|up 8 -> 2 slices, q|k|v 16 -> 8, o 16 -> 8, down stays at 16): 81.5 -> 76.5 us per layer.
+                    long per_cu = (wg + cus - 1) / cus; if (per_cu < 2) per_cu = 2;
+                    cost = (double) per_cu * b + 8.0 * (double) ((wg + 4l * cus - 1) / (4l * cus)) + 0.5 * s;
+                }
                 if (cost < best_cost) { best_cost = cost; fs = s; }
             }
             if (g_gemv_defer_wg_per_cu > 0) fs = (g_gemv_defer_wg_per_cu * ctx->num_cus + total_cb - 1) / total_cb;
