@@ -58,7 +58,7 @@ def parse():
     ap.add_argument("--unfused", action="store_true", help="one launch per reference op instead of the fused pipeline")
     ap.add_argument("--pipeline", choices=["tail", "glue", "resid", "fx", "unfused"], default="fx",
                     help="fx (default; batch <= 4 on one rank, otherwise = glue): residual stream in a 64-bit fixed-point accumulator, o_proj / "
-                         "down_proj add into it with integer atomics, 6 launches/layer (fastest measured); glue: deferred-epilogue GEMVs + glue kernels "
+                         "down_proj add into it with integer atomics, 5 launches/layer (fastest measured); glue: deferred-epilogue GEMVs + glue kernels "
                          "(8 launches/layer); tail: sublayer boundaries run inside the GEMV launches (4 launches/layer; the in-kernel cross-workgroup "
                          "hand-off through memory costs more than a launch)")
     return ap.parse_args()
@@ -550,7 +550,7 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{shape.name} EXL3 {args.bits}.0bpw {args.codebook} codebook, decode bs={args.batch}, "
                                    f"{model.n_layers} layers, {'attention TP=%d + expert-parallel MoE over %d rank(s)' % (world, world) if is_moe else 'TP=%d' % world}, {args.kv_bits}-bit KV append, "
-                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, { 'glue pipeline + indexed exl3_mgemm MoE block' if is_moe else {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (%d launches/layer)' % (7 if (args.batch == 1 and model.act_in_gemv and world == 1) else ((8 if (world == 1 and model.fold_rotate) else 10) if args.batch > 4 else 8)), 'resid': 'resid-in-GEMV pipeline (5 launches/layer: residual add + RMSNorm finished inside the consumer GEMV)' if (args.batch <= 4 and world == 1) else 'fused glue pipeline', 'fx': 'fixed-point-residual pipeline (6 launches/layer: o_proj / down_proj add into a 64-bit fixed-point residual with integer atomics, no split-k-reduce / residual launches)' if (args.batch <= model.fx_max_bsz and world == 1) else 'fused glue pipeline', 'unfused': 'one launch per reference op'}[pipeline] }; "
+                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, { 'glue pipeline + indexed exl3_mgemm MoE block' if is_moe else {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (%d launches/layer)' % (7 if (args.batch == 1 and model.act_in_gemv and world == 1) else ((8 if (world == 1 and model.fold_rotate) else 10) if args.batch > 4 else 8)), 'resid': 'resid-in-GEMV pipeline (5 launches/layer: residual add + RMSNorm finished inside the consumer GEMV)' if (args.batch <= 4 and world == 1) else 'fused glue pipeline', 'fx': 'fixed-point-residual pipeline (%d launches/layer: o_proj / down_proj add into a 64-bit fixed-point residual with integer atomics, no split-k-reduce / residual launches%s)' % ((5, '; silu(g) * u formed inside the down launch') if (model.fx_act_in_gemv or model.fx_gu_atomic) else (6, '')) if (args.batch <= model.fx_max_bsz and world == 1) else 'fused glue pipeline', 'unfused': 'one launch per reference op'}[pipeline] }; "
                                    f"{'attention core INCLUDED: quant-cache-direct decode attention over a 1000-token context' if args.attention else 'attention core excluded (SURVEY.md 2.1)'}",
                        "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
                        "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),

@@ -108,6 +108,8 @@ class SyntheticEXL3Llama:
                  backend: TPBackendRCCL | None = None, kv_bits: int = 4, seed: int = 0, head_K: int | None = None,
                  max_ctx: int = 4096, layers: int | None = None):
         self.shape, self.K, self.cb, self.kv_bits = shape, K, cb, kv_bits
+        if self.fx_act_in_gemv is None:
+            self.fx_act_in_gemv = shape.hidden <= 2048
         self.device = torch.device(device)
         self.backend = backend or TPBackendRCCL(0, 1, self.device)
         self.tp, self.rank = self.backend.world_size, self.backend.rank
@@ -198,6 +200,8 @@ class SyntheticEXL3Llama:
         stc = loader.SafetensorsCollection(directory)
         self = cls.__new__(cls)
         self.shape, self.kv_bits = shape, kv_bits
+        if self.fx_act_in_gemv is None:
+            self.fx_act_in_gemv = shape.hidden <= 2048
         self.device = torch.device(device)
         self.backend = backend or TPBackendRCCL(0, 1, self.device)
         self.tp, self.rank = self.backend.world_size, self.backend.rank
@@ -358,7 +362,10 @@ class SyntheticEXL3Llama:
     #: (the atomics and the in-launch RMSNorm tasks scale with the rows)
     fx_max_bsz = 2
     #: decode_step_fx: silu(g) * u inside the down launch (5 launches per layer) instead of glue_act_rs + rotated-input down (6)
-    fx_act_in_gemv = os.environ.get("EXL3_HIP_FX_ACT_IN_GEMV", "0") != "0"
+    #: None = by size (resolved in __init__): on for hidden <= 2048, where a launch is worth more than the redundant slab reads (Llama-3.2-1B:
+    #: 1800 -> 1917 tok/s); off for Llama-3.1-8B (+0.2 .. +1.5 % tok/s over six same-box alternations, but the down launch then carries glue_act's
+    #: work: 0.33 -> 0.30 of the per-launch HBM roofline).  EXL3_HIP_FX_ACT_IN_GEMV=0/1 overrides.
+    fx_act_in_gemv = {"0": False, "1": True}.get(os.environ.get("EXL3_HIP_FX_ACT_IN_GEMV", ""), None)
     #: decode_step_fx: gate|up add into fixed-point accumulators, down forms silu(g) * u from them (5 launches per layer, no slab reduction)
     fx_gu_atomic = os.environ.get("EXL3_HIP_FX_GU_ATOMIC", "0") != "0"
 
@@ -602,7 +609,7 @@ class SyntheticEXL3Llama:
         return self.logits
 
     def decode_step_fx(self):
-        """Decode step with the residual stream in a fixed-point accumulator (round 3): 6 launches per layer at batch <= 4, TP = 1 --
+        """Decode step with the residual stream in a fixed-point accumulator (round 3): 6 launches per layer (5 with fx_act_in_gemv, the default of small models) at batch <= 4, TP = 1 --
         q|k|v [reads R, RMSNorm inside], glue_qkv_rs, o_proj [adds into R], gate|up [reads R], glue_act_rs, down_proj [adds into R].
         o_proj / down_proj finish their own outputs (the output Hadamard is linear, so every split-k workgroup applies it and svh to its partial
         rows) and ADD them into R with integer atomics (order-independent: bit-reproducible); the two split-k-reduce + residual launches of the glue
@@ -807,7 +814,14 @@ class SyntheticEXL3Llama:
                 calls.append(lambda lq=lq, lk=lk, lv=lv, L=L: ext.exl3_gemv_ex_fx(self.R, L["norm1"], self.ss, self.ss2, self.eps, [lq.trellis, lk.trellis, lv.trellis], [lq.suh, lk.suh, lv.suh], bsz, lq.mcg, lq.mul1))
                 calls.append(lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], [self.R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM))
                 calls.append(lambda lg=lg, lu=lu, L=L: ext.exl3_gemv_ex_fx(self.R, L["norm2"], self.ss, self.ss2, self.eps, [lg.trellis, lu.trellis], [lg.suh, lu.suh], bsz, lg.mcg, lg.mul1))
-                calls.append(lambda ld=ld: ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.R], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT | ATOM))
+                if self.fx_act_in_gemv and not self.fx_gu_atomic:
+                    # the down launch forms silu(g) * u from gate|up's slabs (those of one sample launch stand in for the chain: timing only)
+                    if li == 0:
+                        gu0 = ext.exl3_gemv_ex_fx(self.R, L["norm2"], self.ss, self.ss2, self.eps, [lg.trellis, lu.trellis], [lg.suh, lu.suh], bsz, lg.mcg, lg.mul1)
+                    calls.append(lambda ld=ld, lg=lg, lu=lu: ext.exl3_gemv_ex_act_rs(gu0[0], gu0[1], lg.svh, lu.svh, self.ss, self.ss2, self.shape.hidden, self.eps,
+                                                                                      ld.trellis, self.R, ld.suh, ld.svh, bsz, ld.mcg, ld.mul1, ATOM))
+                else:
+                    calls.append(lambda ld=ld: ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.R], None, [ld.svh], bsz, ld.mcg, ld.mul1, ROT | ATOM))
             elif pipeline == "resid" and self.tp == 1 and bsz <= 4:
                 # decode_step_resid's four GEMV launches per layer; producer slabs of one sample launch each stand in for the chain (timing only)
                 sp, hidden = self.split, self.shape.hidden

@@ -1029,6 +1029,8 @@ def test_fixed_point_residual_pipeline_matches_oracle_and_glue_pipeline(dev, cb,
     model = SyntheticEXL3Llama(shape, K=K, cb=cb, device=dev, kv_bits=4, max_ctx=2048)
     model.alloc_state(bsz, pos=700)
     model.fx_max_bsz = 4                                     # the kernels take up to 4 rows (the default pipeline choice stops at 2: measured)
+    assert model.fx_act_in_gemv                              # the default: 5 launches per layer; the 6-launch form first
+    model.fx_act_in_gemv = False
     lf = model.decode_step_fused().float().cpu().numpy().copy()
     xf = model.x.float().cpu().numpy().copy()
     kf = [(kc.clone(), ks.clone()) for kc, ks in model.kcache]

@@ -245,6 +245,45 @@ def test_attn_decode_qcache_long_context_kernel(dev, hq, hkv, lens, max_len):
     assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
 
 
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (7, 1), (6, 2), (4, 4), (16, 2)])
+@pytest.mark.parametrize("lens,max_len", [([1024, 1, 700, 257], 1024), ([130, 16], 130), ([1000], 1001), ([512, 513, 255, 256], 640)])
+def test_attn_decode_qcache_short_contexts_ragged(dev, hq, hkv, lens, max_len):
+    """Contexts up to 1024 tokens on the matrix-pipe decode-attention kernel (head_dim 128, 4-bit K / V; written for a one-launch variant -- one
+    16-wave workgroup per (sequence, kv head), no merge launch -- that measured 2.44 vs 1.89 ms per step and was dropped: DESIGN.md 4.10): GQA 4 / 7 /
+    3 / 1 / 8, ragged lengths: a full 1024, one token, ends on / next to a 256-token boundary and a 16-token wave tile, a bound above the lengths;
+    scattered pages; against the oracle; the same bits on a second call."""
+    from exllamav3_amd import ext
+    hd, kb, vb, page = 128, 4, 4, 256
+    rng = np.random.default_rng(hq * 10 + hkv + len(lens) + max_len)
+    bsz = len(lens)
+    pps = (max_len + page - 1) // page
+    npages = bsz * pps + 3
+    perm = rng.permutation(npages)[: bsz * pps].reshape(bsz, pps).astype(np.int32)
+    G = hkv * hd // 32
+    k = (rng.standard_normal((bsz, pps * page, hkv * hd)) * 1.5).astype(np.float16)
+    v = rng.standard_normal((bsz, pps * page, hkv * hd)).astype(np.float16)
+    kq, ks = o.kv_quant(k, kb); vq, vs = o.kv_quant(v, vb)
+    kc = np.zeros((npages, page, G * kb), dtype=np.uint32); ksc = np.zeros((npages, page, G), dtype=np.float16)
+    vc = np.zeros((npages, page, G * vb), dtype=np.uint32); vsc = np.zeros((npages, page, G), dtype=np.float16)
+    for b in range(bsz):
+        for p in range(pps):
+            kc[perm[b, p]] = kq[b, p * page:(p + 1) * page]; ksc[perm[b, p]] = ks[b, p * page:(p + 1) * page]
+            vc[perm[b, p]] = vq[b, p * page:(p + 1) * page]; vsc[perm[b, p]] = vs[b, p * page:(p + 1) * page]
+    q = rng.standard_normal((bsz, hq, hd)).astype(np.float16)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    out = torch.full((bsz, hq, hd), float("nan"), dtype=torch.half, device=dev)
+    args = (T(q), out, T(kc.view(np.int32)), T(ksc), T(vc.view(np.int32)), T(vsc), T(perm), T(np.array(lens, dtype=np.int32)), max_len)
+    ext.attn_decode_qcache(*args)
+    kd = o.kv_dequant(kq, ks, kb).reshape(bsz, -1, hkv, hd); vd = o.kv_dequant(vq, vs, vb).reshape(bsz, -1, hkv, hd)
+    ref = o.attn_decode_qcache(q, kd, vd, lens).astype(np.float32)
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
+    out2 = torch.full_like(out, float("nan"))
+    ext.attn_decode_qcache(args[0], out2, *args[2:])
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.timeout(120)
 def test_attn_decode_qcache_more_workgroups_than_the_wide_kernel_cap(dev):
     """bsz * kv blocks above the matrix-pipe kernel's workgroup cap (512) with head_dim 128, 4-bit K / V and a length bound >= 128: the split
