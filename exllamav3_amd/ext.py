@@ -268,8 +268,15 @@ def exl3_mgemm(A: torch.Tensor, B: torch.Tensor, C: torch.Tensor, suh: torch.Ten
         _req(bA in (1, bszm) or bA >= bszm, "exl3_mgemm: A must hold 1 or bszm slots")
         _req(size_n_list.numel() >= (bszm if indices is None else 1) and c_ptrs.numel() >= (bszm if indices is None else 1), "exl3_mgemm: width / pointer lists too short")
         _req(k % 128 == 0 and C.shape[2] % 128 == 0, "exl3_mgemm: k and n must be divisible by 128")
-        _check(_lib.lib().exl3_mgemm_indexed_nlist(_p(A), 1 if bA == 1 else bszm, _p(B), _p(suh), _p(svh), _p(indices), bszm, _p(size_n_list), _p(c_ptrs),
-                                                   m, k, int(C.shape[2]), int(K), _cb(bool(mcg), bool(mul1)), int(C.dtype == torch.float), _stream(A)))
+        # 16 rows per launch (the reference's kernel walks the rows 16 at a time too: exl3_gemm_kernel.cuh:186-204); later passes write behind the
+        # earlier rows of every matrix: output address + 16 * pass * n_i elements, computed on the device (capturable)
+        esz = 4 if C.dtype == torch.float else 2
+        for m0 in range(0, m, 16):
+            mp = min(16, m - m0)
+            Ap = A if m <= 16 else A[:, m0:m0 + mp].contiguous()
+            cp = c_ptrs if m0 == 0 else c_ptrs + size_n_list.to(torch.long) * (m0 * esz)
+            _check(_lib.lib().exl3_mgemm_indexed_nlist(_p(Ap), 1 if bA == 1 else bszm, _p(B), _p(suh), _p(svh), _p(indices), bszm, _p(size_n_list), _p(cp),
+                                                       mp, k, int(C.shape[2]), int(K), _cb(bool(mcg), bool(mul1)), int(C.dtype == torch.float), _stream(A)))
         return 90
     _req(A.dtype == torch.half, "exl3_mgemm: A must be float16")
     _req(B.dtype == torch.long and suh.dtype == torch.long and svh.dtype == torch.long, "exl3_mgemm: B, suh, svh must be int64 pointer tensors")

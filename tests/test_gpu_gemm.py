@@ -241,7 +241,7 @@ def test_mgemm_indexed_moe_forms(dev, cb, k, n, K):
 
 
 @pytest.mark.parametrize("cb,K", [(0, 4), (2, 3)])
-@pytest.mark.parametrize("m", [1, 3, 7])
+@pytest.mark.parametrize("m", [1, 3, 7, 21])
 def test_mgemm_per_matrix_widths(dev, cb, K, m):
     """exl3_mgemm with size_n_list / c_ptrs (quant/exl3_gemm.cu:433-447, the x-side fan of libtorch/dsv4_attn.cpp:88-98): matrices of different widths in
     one launch, every output at its own address with its own row stride; without indices (slot j = matrix j) and with them (a selection, in another
