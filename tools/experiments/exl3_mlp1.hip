@@ -1,6 +1,7 @@
 // EXPERIMENT (round 3), not part of the product library: built together with mlp1_harness.hip against libexl3_hip.so (see that file).  Measured on
-// MI355X: parity with the three-launch form to 4e-4 of the output RMS, and SLOWER -- 35.6-36.3 vs 31.5-32.0 us per MLP (profiles/r03_mlp1_fused_launch.json,
-// DESIGN.md section 6): the team exchange, the full-row prologue and the reductions are exposed because every CU runs one workgroup in lockstep.
+// MI355X: parity with the three-launch form to 4e-4 of the output RMS; 35.6-36.3 vs 31.5-32.5 us per MLP with the counter-based exchange
+// (profiles/r03_mlp1_fused_launch.json), 31.9-32.6 vs 32.0-32.7 us with -DM1_TAGGED (profiles/r03_mlp1_fused_launch_tagged.json): equal time, one launch instead of
+// three -- no gain at Llama-3.1-8B shapes: the full-row prologue and the reductions are exposed because every CU runs one workgroup in lockstep.
 //
 // The MLP block of a batch-1 decode step in ONE launch (K = 4, mul1 codebook, FAST variant, one row):
 //
@@ -55,7 +56,7 @@ struct Mlp1Args
     int hidden, inter, nteam, nwg;
     const uint32_t* Bg; const uint32_t* Bu; const uint32_t* Bd;
     const half_t* suh_g; const half_t* suh_u; const half_t* svh_g; const half_t* svh_u; const half_t* suh_d; const half_t* svh_d;
-    unsigned long long* exch;         // [nteam][16 members][32 lanes] x 8 bytes: a member's 128 finished fp16 outputs
+    unsigned long long* exch;         // [nteam][16 members][32 lanes] x 8 bytes: a member's 128 finished fp16 outputs (M1_TAGGED: [..][64] granules of { 2 x fp16, tag })
     uint32_t* cnt;                    // zero on entry, zero on exit: team t: arrive at [32 t], depart at [32 t + 16]; grid: read gate at [32 nteam], finish at [32 nteam + 16]
     uint32_t* err;                    // sticky: 1 = a team never completed, 2 = the read gate never completed (bounded polls)
     unsigned long long* dbg;          // diagnostics (EXL3_HIP_MLP1_TIMING=1): 8 x 100 MHz timestamps per workgroup, else null
@@ -135,6 +136,11 @@ void exl3_mlp1_kernel(const Mlp1Args a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, l32 = lane & 31, hwid = tid >> 5;
     const int j = blockIdx.x, t = blockIdx.y;
+#ifdef M1_TAGGED
+    // tagged exchange: every 8-byte granule = { two fp16 values, tag }; tag = launch epoch + 1 (the epoch word lives in memory and is bumped by the last
+    // workgroup of a launch, so a replayed graph sees a new tag; a stale granule carries an older one): data and flag travel in ONE store, no counter
+    const uint32_t tag = a.cnt[32 * a.nteam + 8] + 1u;
+#endif
     #define M1_T(i) do { if (a.dbg && tid == 0) a.dbg[(size_t) (t * M1_TEAM + j) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     M1_T(0);
     const int hidden = a.hidden, inter = a.inter, nb1 = hidden >> 7;
@@ -248,12 +254,22 @@ void exl3_mlp1_kernel(const Mlp1Args a)
         const float rsc = rn / rp;
         g0 *= rsc; g1 *= rsc; g2 *= rsc; g3 *= rsc;
         const half4_t gh = half4_t{ f2h(g0), f2h(g1), f2h(g2), f2h(g3) } * sv1o;
+#ifdef M1_TAGGED
+        union { half4_t h; uint32_t w[2]; } pk; pk.h = gh;
+        unsigned long long* dst = a.exch + ((size_t) (t * M1_TEAM + j) * 64 + 2 * l32);
+        __hip_atomic_store(dst, (unsigned long long) pk.w[0] | ((unsigned long long) tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, (unsigned long long) pk.w[1] | ((unsigned long long) tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         union { half4_t h; unsigned long long u; } pk; pk.h = gh;
         __hip_atomic_store(a.exch + ((size_t) (t * M1_TEAM + j) * 32 + l32), pk.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // written through and acknowledged before the arrival is announced
         if (l32 == 0) __hip_atomic_fetch_add(a.cnt + 32 * t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     }
     M1_T(3);
+#ifdef M1_TAGGED
+    if (wave == 0) m1_issue_ring<K>(ring, strip2, rs2, ub2);
+#else
     if (wave == 0)
     {
         m1_issue_ring<K>(ring, strip2, rs2, ub2);
@@ -277,14 +293,33 @@ void exl3_mlp1_kernel(const Mlp1Args a)
         }
     }
     __syncthreads();
+#endif
     M1_T(4);
 
     // ---------------- phase 3: a = fp16(silu(g) * u) of the team's 8 blocks (glue_act's arithmetic) -> * suh_d -> Hadamard -> quads of down's k-slice
     if (hwid < M1_TBLK)
     {
+#ifdef M1_TAGGED
+        union { half4_t h; uint32_t w[2]; } pg, pu;
+        {
+            // each lane polls its own four granules (two of the gate block, two of the up block) until all carry this launch's tag; bounded
+            const unsigned long long* sg = a.exch + ((size_t) (t * M1_TEAM + hwid) * 64 + 2 * l32);
+            const unsigned long long* su = a.exch + ((size_t) (t * M1_TEAM + M1_TBLK + hwid) * 64 + 2 * l32);
+            int spins = 0; bool ok;
+            do
+            {
+                const unsigned long long g0 = __hip_atomic_load(sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), g1 = __hip_atomic_load(sg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long u0 = __hip_atomic_load(su, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), u1 = __hip_atomic_load(su + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (uint32_t) (g0 >> 32) == tag && (uint32_t) (g1 >> 32) == tag && (uint32_t) (u0 >> 32) == tag && (uint32_t) (u1 >> 32) == tag;
+                pg.w[0] = (uint32_t) g0; pg.w[1] = (uint32_t) g1; pu.w[0] = (uint32_t) u0; pu.w[1] = (uint32_t) u1;
+            } while (__builtin_amdgcn_ballot_w64(!ok) != 0ull && ++spins < M1_SPIN_LIMIT);
+            if (!ok) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#else
         union { half4_t h; unsigned long long u; } pg, pu;
         pg.u = __hip_atomic_load(a.exch + ((size_t) (t * M1_TEAM + hwid) * 32 + l32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pu.u = __hip_atomic_load(a.exch + ((size_t) (t * M1_TEAM + M1_TBLK + hwid) * 32 + l32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
         half4_t xv = { silu_mul(pg.h.x, pu.h.x), silu_mul(pg.h.y, pu.h.y), silu_mul(pg.h.z, pu.h.z), silu_mul(pg.h.w, pu.h.w) };
         xv = xv * sv2;
@@ -307,6 +342,11 @@ void exl3_mlp1_kernel(const Mlp1Args a)
 
     // ---------------- phase 4: down: wave = (column block, Hadamard block of the slice): 4 units
     vc = float4_t{ 0.f, 0.f, 0.f, 0.f }; vd = vc;
+#ifdef M1_TAGGED
+    // the read gate's value requested HERE (almost always complete by now): the check in front of the adds then costs no round trip
+    uint32_t gate_seen = 0;
+    if (hwid < 2) gate_seen = __hip_atomic_load(a.cnt + 32 * a.nteam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     m1_stream<K>(ring, strip2, rs2, quads2, ub2, 4, lane, vc, vd);
     M1_T(6);
     {
@@ -333,11 +373,16 @@ void exl3_mlp1_kernel(const Mlp1Args a)
         out_had(v, l32, h0, h1, h2, h3);
         const float o[4] = { h0 * (float) svo.x, h1 * (float) svo.y, h2 * (float) svo.z, h3 * (float) svo.w };
         // every workgroup of the grid has read its copy of R?  (long true by now: one load; bounded)
+#ifdef M1_TAGGED
+        uint32_t seen = gate_seen; int spins = 0;
+        while (seen < (uint32_t) a.nwg && ++spins < M1_SPIN_LIMIT) seen = __hip_atomic_load(a.cnt + 32 * a.nteam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         uint32_t seen = 0; int spins = 0;
         do
         {
             seen = __hip_atomic_load(a.cnt + 32 * a.nteam, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } while (seen < (uint32_t) a.nwg && ++spins < M1_SPIN_LIMIT);
+#endif
         if (seen < (uint32_t) a.nwg && l32 == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned long long* acc = a.R_acc + (size_t) (2 * j + hwid) * 128 + 4 * l32;
         #pragma unroll
@@ -359,6 +404,9 @@ void exl3_mlp1_kernel(const Mlp1Args a)
         {
             __hip_atomic_store(a.cnt + 32 * a.nteam, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.cnt + 32 * a.nteam + 16, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef M1_TAGGED
+            __hip_atomic_fetch_add(a.cnt + 32 * a.nteam + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // next launch's tag
+#endif
         }
     }
 }
