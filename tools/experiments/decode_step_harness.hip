@@ -1,0 +1,197 @@
+// A whole Llama-3.1-8B batch-1 decode step (the fixed-point-residual pipeline of exllamav3_amd/llama_path.py: decode_step_fx) driven through the C ABI from
+// C++ -- no Python, no torch on the box: synthetic EXL3 4.0 bpw mul1 tensors filled on the device, one hipGraph per step, tok/s from graph replays.  A run
+// costs a few seconds of GPU time, so same-box A/B alternations of a kernel variant are cheap.  Variant B here: the MLP block as ONE launch
+// (exl3_mlp1.hip, -DM1_TAGGED) instead of exl3_gemv_ex_fx(gate|up) -> exl3_glue_act_rs -> exl3_gemv_ex(down); the logits of the two variants are
+// compared.  Attention core excluded, as in bench.py's headline line: o_proj reads q after rope.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-gpu-rdc -DM1_TAGGED -I include -I exllamav3_amd/csrc -o tools/bin/decode_step_harness \
+//         tools/experiments/decode_step_harness.hip tools/experiments/exl3_mlp1.hip -L exllamav3_amd -lexl3_hip -Wl,-rpath,'$ORIGIN/../../exllamav3_amd'
+//   tools/bin/decode_step_harness [layers = 32] [alternations = 3]
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+#include "exl3_hip.h"
+
+extern "C" int exl3_mlp1_fx(void* R, const void* norm_w, const float* ss_prev, float* ss_out, float eps,
+                            const void* B_gate, const void* B_up, const void* suh_g, const void* suh_u, const void* svh_g, const void* svh_u,
+                            const void* B_down, const void* suh_d, const void* svh_d, int m, int hidden, int inter, int K, int cb, void* stream);
+extern "C" int exl3_mlp1_error(int* out, void* stream);
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+#define CE(x) do { int r_ = (x); if (r_ < 0) { fprintf(stderr, "%s:%d exl3 error %d: %s\n", __FILE__, __LINE__, r_, exl3_last_error()); exit(1); } } while (0)
+
+__global__ void fill_hash(uint32_t* p, size_t n, uint32_t seed)
+{
+    for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+    {
+        uint32_t x = (uint32_t) i * 0x9E3779B1u + seed; x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = x;
+    }
+}
+
+static uint64_t rng_s = 0x9876543212345678ull;
+static double urand() { rng_s ^= rng_s << 13; rng_s ^= rng_s >> 7; rng_s ^= rng_s << 17; return (double) (rng_s >> 11) / 9007199254740992.0; }
+static double nrand() { double u = urand() + 1e-12, v = urand(); return sqrt(-2.0 * log(u)) * cos(6.283185307179586 * v); }
+static __half* dev_half(const std::vector<float>& v)
+{
+    std::vector<__half> h(v.size());
+    for (size_t i = 0; i < v.size(); ++i) h[i] = __float2half(v[i]);
+    __half* d; CK(hipMalloc(&d, v.size() * 2)); CK(hipMemcpy(d, h.data(), v.size() * 2, hipMemcpyHostToDevice));
+    return d;
+}
+static std::vector<float> scale_vec(int n, double mag)
+{
+    std::vector<float> v(n);
+    for (int i = 0; i < n; ++i) v[i] = (float) ((urand() < 0.5 ? -1.0 : 1.0) * mag * exp(0.2 * nrand()));
+    return v;
+}
+
+// one EXL3 linear with llama_path._rand_linear's magnitudes (outputs of O(out_scale) for unit-RMS inputs)
+struct Lin { uint32_t* B; __half* suh; __half* svh; int k, n; };
+static uint32_t g_seed = 1;
+static Lin make_lin(int k, int n, int K, double out_scale, hipStream_t st)
+{
+    Lin l; l.k = k; l.n = n;
+    const size_t words = (size_t) k * n * K / 32;
+    CK(hipMalloc(&l.B, words * 4));
+    fill_hash<<<2048, 256, 0, st>>>(l.B, words, g_seed++ * 7919u);
+    l.suh = dev_half(scale_vec(k, 1.0)); l.svh = dev_half(scale_vec(n, out_scale / sqrt((double) k)));
+    return l;
+}
+struct Layer { Lin q, k, v, o, g, u, d; __half *norm1, *norm2; uint32_t *kc, *vc; __half *ks, *vs; };
+
+int main(int argc, char** argv)
+{
+    const int hidden = 4096, inter = 14336, hq = 32, hkv = 8, hd = 128, vocab = 128256, K = 4, cb = 2, page = 256, max_ctx = 4096, kv_bits = 4, pos = 1000;
+    const int n_layers = argc > 1 ? atoi(argv[1]) : 32, alternations = argc > 2 ? atoi(argv[2]) : 3;
+    const float eps = 1e-5f;
+    CK(hipSetDevice(0));
+    CE(exl3_init(0));
+    hipStream_t st; CK(hipStreamCreate(&st));
+
+    std::vector<Layer> L(n_layers);
+    const int G = hkv * hd / 32, n_pages = max_ctx / page;
+    for (int i = 0; i < n_layers; ++i)
+    {
+        L[i].q = make_lin(hidden, hq * hd, K, 0.5, st); L[i].k = make_lin(hidden, hkv * hd, K, 0.5, st); L[i].v = make_lin(hidden, hkv * hd, K, 0.5, st);
+        L[i].o = make_lin(hq * hd, hidden, K, 0.5, st);
+        L[i].g = make_lin(hidden, inter, K, 0.5, st); L[i].u = make_lin(hidden, inter, K, 0.5, st); L[i].d = make_lin(inter, hidden, K, 0.5, st);
+        std::vector<float> nw(hidden); for (auto& x : nw) x = (float) (1.0 + 0.05 * nrand());
+        L[i].norm1 = dev_half(nw); for (auto& x : nw) x = (float) (1.0 + 0.05 * nrand()); L[i].norm2 = dev_half(nw);
+        const size_t cw = (size_t) n_pages * page * G * kv_bits, cs = (size_t) n_pages * page * G;
+        CK(hipMalloc(&L[i].kc, cw * 4)); CK(hipMalloc(&L[i].vc, cw * 4)); CK(hipMalloc(&L[i].ks, cs * 2)); CK(hipMalloc(&L[i].vs, cs * 2));
+        CK(hipMemsetAsync(L[i].kc, 0, cw * 4, st)); CK(hipMemsetAsync(L[i].vc, 0, cw * 4, st)); CK(hipMemsetAsync(L[i].ks, 0, cs * 2, st)); CK(hipMemsetAsync(L[i].vs, 0, cs * 2, st));
+    }
+    Lin head = make_lin(hidden, vocab, K, 0.5, st);
+    std::vector<float> fnw(hidden); for (auto& x : fnw) x = (float) (1.0 + 0.05 * nrand());
+    __half* final_norm = dev_half(fnw);
+
+    // step state (llama_path.alloc_state, bsz = 1)
+    std::vector<float> x0(hidden); for (auto& v : x0) v = (float) nrand();
+    __half* dx0 = dev_half(x0);
+    __half *q, *xout, *xh_d, *xh_head, *logits; int64_t *R, *slots; float *ssA, *ssB, *xs_d, *xs_head, *rsin, *rcos, *inv_freq; int32_t *positions, *block_table;
+    CK(hipMalloc(&q, hq * hd * 2)); CK(hipMalloc(&xout, hidden * 2)); CK(hipMalloc(&xh_d, inter * 2)); CK(hipMalloc(&xh_head, hidden * 2)); CK(hipMalloc(&logits, (size_t) vocab * 2));
+    CK(hipMalloc(&R, hidden * 8)); CK(hipMalloc(&slots, 8)); CK(hipMalloc(&ssA, 32 * 4)); CK(hipMalloc(&ssB, 32 * 4)); CK(hipMalloc(&xs_d, inter / 128 * 4));
+    CK(hipMalloc(&xs_head, 32 * 4)); CK(hipMalloc(&rsin, 64 * 4)); CK(hipMalloc(&rcos, 64 * 4)); CK(hipMalloc(&inv_freq, 64 * 4)); CK(hipMalloc(&positions, 4)); CK(hipMalloc(&block_table, n_pages * 4));
+    {
+        float f[64]; for (int i = 0; i < 64; ++i) f[i] = (float) (1.0 / pow(500000.0, (2.0 * i) / hd));
+        CK(hipMemcpy(inv_freq, f, sizeof(f), hipMemcpyHostToDevice));
+        int32_t p = pos; CK(hipMemcpy(positions, &p, 4, hipMemcpyHostToDevice));
+        std::vector<int32_t> bt(n_pages); for (int i = 0; i < n_pages; ++i) bt[i] = i;
+        CK(hipMemcpy(block_table, bt.data(), n_pages * 4, hipMemcpyHostToDevice));
+    }
+    CK(hipStreamSynchronize(st));
+
+    auto step = [&] (bool one_launch_mlp)
+    {
+        float* sc = ssA; float* so = ssB;
+        CE(exl3_fx_init_prep(dx0, R, sc, 1, hidden, inv_freq, positions, 1.0f, hd, block_table, n_pages, page, rsin, rcos, slots, st));
+        for (int i = 0; i < n_layers; ++i)
+        {
+            Layer& l = L[i];
+            {
+                const void* Bs[3] = { l.q.B, l.k.B, l.v.B }; const void* su[3] = { l.q.suh, l.k.suh, l.v.suh }; int ns[3] = { l.q.n, l.k.n, l.v.n };
+                float* slabs[3] = { nullptr, nullptr, nullptr }; int S = 0;
+                CE(exl3_gemv_ex_fx(R, l.norm1, sc, so, eps, Bs, su, ns, 3, 1, hidden, K, cb, 0, slabs, &S, st));
+                CE(exl3_glue_qkv_tab(slabs[0], slabs[1], slabs[2], S, l.q.svh, l.k.svh, l.v.svh, q, nullptr, nullptr, inv_freq, positions, l.kc, l.ks, l.vc, l.vs,
+                                     block_table, n_pages, page, kv_bits, kv_bits, 1, hq, hkv, hd, 2, 1.0f, sc, so, hidden, eps, rsin, rcos, slots, st));
+                std::swap(sc, so);
+            }
+            {
+                const void* Bs[1] = { l.o.B }; void* Cs[1] = { R }; const void* su[1] = { l.o.suh }; const void* sv[1] = { l.o.svh }; int ns[1] = { hidden };
+                CE(exl3_gemv_ex(q, nullptr, nullptr, Bs, Cs, su, sv, nullptr, ns, 1, 1, hq * hd, K, cb, 0, EXL3_GEMV_OUT_ATOMIC, 8, nullptr, nullptr, st));
+            }
+            if (one_launch_mlp)
+                CE(exl3_mlp1_fx(R, l.norm2, sc, so, eps, l.g.B, l.u.B, l.g.suh, l.u.suh, l.g.svh, l.u.svh, l.d.B, l.d.suh, l.d.svh, 1, hidden, inter, K, cb, st));
+            else
+            {
+                const void* Bs[2] = { l.g.B, l.u.B }; const void* su[2] = { l.g.suh, l.u.suh }; int ns[2] = { inter, inter };
+                float* slabs[2] = { nullptr, nullptr }; int S = 0;
+                CE(exl3_gemv_ex_fx(R, l.norm2, sc, so, eps, Bs, su, ns, 2, 1, hidden, K, cb, 0, slabs, &S, st));
+                CE(exl3_glue_act_rs(slabs[0], slabs[1], S, l.g.svh, l.u.svh, l.d.suh, xh_d, xs_d, nullptr, 1, inter, sc, so, hidden, eps, st));
+                const void* xh[1] = { xh_d }; const float* xs[1] = { xs_d }; const void* Bd[1] = { l.d.B }; void* Cs[1] = { R }; const void* sv[1] = { l.d.svh }; int nd[1] = { hidden };
+                CE(exl3_gemv_ex(nullptr, xh, xs, Bd, Cs, nullptr, sv, nullptr, nd, 1, 1, inter, K, cb, 0, EXL3_GEMV_IN_ROTATED | EXL3_GEMV_OUT_ATOMIC, 0, nullptr, nullptr, st));
+            }
+            std::swap(sc, so);
+        }
+        CE(exl3_fx_finish_rotate(R, xout, sc, final_norm, eps, head.suh, xh_head, xs_head, 1, hidden, st));
+        const void* xh[1] = { xh_head }; const float* xs[1] = { xs_head }; const void* Bh[1] = { head.B }; void* Cs[1] = { logits }; const void* sv[1] = { head.svh }; int nh[1] = { vocab };
+        CE(exl3_gemv_ex(nullptr, xh, xs, Bh, Cs, nullptr, sv, nullptr, nh, 1, 1, hidden, K, cb, 0, EXL3_GEMV_IN_ROTATED, 0, nullptr, nullptr, st));
+    };
+
+    // logits of both variants (eager), compared
+    std::vector<__half> lg[2] = { std::vector<__half>(vocab), std::vector<__half>(vocab) };
+    for (int v = 0; v < 2; ++v)
+    {
+        step(v == 1);
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(lg[v].data(), logits, (size_t) vocab * 2, hipMemcpyDeviceToHost));
+    }
+    int err = -1; CE(exl3_mlp1_error(&err, st));
+    double rms = 0, maxd = 0, sd2 = 0; int nonfinite = 0;
+    for (int i = 0; i < vocab; ++i)
+    {
+        const double a = __half2float(lg[0][i]), b = __half2float(lg[1][i]);
+        if (!std::isfinite(a) || !std::isfinite(b)) { ++nonfinite; continue; }
+        rms += a * a; sd2 += (a - b) * (a - b); maxd = std::max(maxd, fabs(a - b));
+    }
+    rms = sqrt(rms / vocab);
+    printf("{\"model\": \"llama-3.1-8b shapes, %d layers, EXL3 4.0 bpw mul1, bs 1, fx pipeline via the C ABI\", \"logits_rms\": %.5g, \"max_abs_diff_one_launch_mlp\": %.5g, \"rms_diff\": %.5g, "
+           "\"rel_to_rms\": %.3g, \"nonfinite\": %d, \"mlp1_err_word\": %d,\n", n_layers, rms, maxd, sqrt(sd2 / vocab), maxd / (rms + 1e-30), nonfinite, err);
+    fflush(stdout);
+
+    // graphs + alternating timing
+    hipGraphExec_t ge[2];
+    for (int v = 0; v < 2; ++v)
+    {
+        hipGraph_t g;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        step(v == 1);
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge[v], g, nullptr, nullptr, 0));
+        CK(hipGraphDestroy(g));
+    }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    printf(" \"ms_per_step\": [");
+    double best[2] = { 1e30, 1e30 };
+    for (int a = 0; a < alternations; ++a)
+        for (int v = 0; v < 2; ++v)
+        {
+            for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(ge[v], st));
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < 50; ++i) CK(hipGraphLaunch(ge[v], st));
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            best[v] = std::min(best[v], (double) ms / 50.0);
+            printf("%s{\"variant\": \"%s\", \"ms\": %.4f}", (a || v) ? ", " : "", v ? "one_launch_mlp" : "three_launch_mlp", ms / 50.0);
+            fflush(stdout);
+        }
+    err = -1; CE(exl3_mlp1_error(&err, st));
+    printf("],\n \"tok_s\": {\"three_launch_mlp\": %.1f, \"one_launch_mlp\": %.1f}, \"us_per_layer\": {\"three_launch_mlp\": %.2f, \"one_launch_mlp\": %.2f}, \"mlp1_err_word_after_timing\": %d}\n",
+           1e3 / best[0], 1e3 / best[1], best[0] * 1e3 / n_layers, best[1] * 1e3 / n_layers, err);
+    return 0;
+}
