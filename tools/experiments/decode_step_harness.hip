@@ -68,6 +68,9 @@ int main(int argc, char** argv)
 {
     const int hidden = 4096, inter = 14336, hq = 32, hkv = 8, hd = 128, vocab = 128256, K = 4, cb = 2, page = 256, max_ctx = 4096, kv_bits = 4, pos = 1000;
     const int n_layers = argc > 1 ? atoi(argv[1]) : 32, alternations = argc > 2 ? atoi(argv[2]) : 3;
+    // forced split-k factors of the four GEMV launches of a layer (0 = the library's choice; llama_path.decode_step_fx: o = 8, the others 0)
+    const int sp_qkv = argc > 3 ? atoi(argv[3]) : 0, sp_o = argc > 4 ? atoi(argv[4]) : 8, sp_gu = argc > 5 ? atoi(argv[5]) : 0, sp_down = argc > 6 ? atoi(argv[6]) : 0;
+    const bool baseline_only = argc > 7 && atoi(argv[7]) != 0;          // time only the three-launch form (split sweeps)
     const float eps = 1e-5f;
     CK(hipSetDevice(0));
     CE(exl3_init(0));
@@ -116,14 +119,14 @@ int main(int argc, char** argv)
             {
                 const void* Bs[3] = { l.q.B, l.k.B, l.v.B }; const void* su[3] = { l.q.suh, l.k.suh, l.v.suh }; int ns[3] = { l.q.n, l.k.n, l.v.n };
                 float* slabs[3] = { nullptr, nullptr, nullptr }; int S = 0;
-                CE(exl3_gemv_ex_fx(R, l.norm1, sc, so, eps, Bs, su, ns, 3, 1, hidden, K, cb, 0, slabs, &S, st));
+                CE(exl3_gemv_ex_fx(R, l.norm1, sc, so, eps, Bs, su, ns, 3, 1, hidden, K, cb, sp_qkv, slabs, &S, st));
                 CE(exl3_glue_qkv_tab(slabs[0], slabs[1], slabs[2], S, l.q.svh, l.k.svh, l.v.svh, q, nullptr, nullptr, inv_freq, positions, l.kc, l.ks, l.vc, l.vs,
                                      block_table, n_pages, page, kv_bits, kv_bits, 1, hq, hkv, hd, 2, 1.0f, sc, so, hidden, eps, rsin, rcos, slots, st));
                 std::swap(sc, so);
             }
             {
                 const void* Bs[1] = { l.o.B }; void* Cs[1] = { R }; const void* su[1] = { l.o.suh }; const void* sv[1] = { l.o.svh }; int ns[1] = { hidden };
-                CE(exl3_gemv_ex(q, nullptr, nullptr, Bs, Cs, su, sv, nullptr, ns, 1, 1, hq * hd, K, cb, 0, EXL3_GEMV_OUT_ATOMIC, 8, nullptr, nullptr, st));
+                CE(exl3_gemv_ex(q, nullptr, nullptr, Bs, Cs, su, sv, nullptr, ns, 1, 1, hq * hd, K, cb, 0, EXL3_GEMV_OUT_ATOMIC, sp_o, nullptr, nullptr, st));
             }
             if (one_launch_mlp)
                 CE(exl3_mlp1_fx(R, l.norm2, sc, so, eps, l.g.B, l.u.B, l.g.suh, l.u.suh, l.g.svh, l.u.svh, l.d.B, l.d.suh, l.d.svh, 1, hidden, inter, K, cb, st));
@@ -131,10 +134,10 @@ int main(int argc, char** argv)
             {
                 const void* Bs[2] = { l.g.B, l.u.B }; const void* su[2] = { l.g.suh, l.u.suh }; int ns[2] = { inter, inter };
                 float* slabs[2] = { nullptr, nullptr }; int S = 0;
-                CE(exl3_gemv_ex_fx(R, l.norm2, sc, so, eps, Bs, su, ns, 2, 1, hidden, K, cb, 0, slabs, &S, st));
+                CE(exl3_gemv_ex_fx(R, l.norm2, sc, so, eps, Bs, su, ns, 2, 1, hidden, K, cb, sp_gu, slabs, &S, st));
                 CE(exl3_glue_act_rs(slabs[0], slabs[1], S, l.g.svh, l.u.svh, l.d.suh, xh_d, xs_d, nullptr, 1, inter, sc, so, hidden, eps, st));
                 const void* xh[1] = { xh_d }; const float* xs[1] = { xs_d }; const void* Bd[1] = { l.d.B }; void* Cs[1] = { R }; const void* sv[1] = { l.d.svh }; int nd[1] = { hidden };
-                CE(exl3_gemv_ex(nullptr, xh, xs, Bd, Cs, nullptr, sv, nullptr, nd, 1, 1, inter, K, cb, 0, EXL3_GEMV_IN_ROTATED | EXL3_GEMV_OUT_ATOMIC, 0, nullptr, nullptr, st));
+                CE(exl3_gemv_ex(nullptr, xh, xs, Bd, Cs, nullptr, sv, nullptr, nd, 1, 1, inter, K, cb, 0, EXL3_GEMV_IN_ROTATED | EXL3_GEMV_OUT_ATOMIC, sp_down, nullptr, nullptr, st));
             }
             std::swap(sc, so);
         }
@@ -179,7 +182,7 @@ int main(int argc, char** argv)
     printf(" \"ms_per_step\": [");
     double best[2] = { 1e30, 1e30 };
     for (int a = 0; a < alternations; ++a)
-        for (int v = 0; v < 2; ++v)
+        for (int v = 0; v < (baseline_only ? 1 : 2); ++v)
         {
             for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(ge[v], st));
             CK(hipEventRecord(e0, st));
@@ -191,7 +194,7 @@ int main(int argc, char** argv)
             fflush(stdout);
         }
     err = -1; CE(exl3_mlp1_error(&err, st));
-    printf("],\n \"tok_s\": {\"three_launch_mlp\": %.1f, \"one_launch_mlp\": %.1f}, \"us_per_layer\": {\"three_launch_mlp\": %.2f, \"one_launch_mlp\": %.2f}, \"mlp1_err_word_after_timing\": %d}\n",
-           1e3 / best[0], 1e3 / best[1], best[0] * 1e3 / n_layers, best[1] * 1e3 / n_layers, err);
+    printf("],\n \"splits\": {\"qkv\": %d, \"o\": %d, \"gate_up\": %d, \"down\": %d}, \"tok_s\": {\"three_launch_mlp\": %.1f, \"one_launch_mlp\": %.1f}, \"us_per_layer\": {\"three_launch_mlp\": %.2f, \"one_launch_mlp\": %.2f}, \"mlp1_err_word_after_timing\": %d}\n",
+           sp_qkv, sp_o, sp_gu, sp_down, 1e3 / best[0], 1e3 / best[1], best[0] * 1e3 / n_layers, best[1] * 1e3 / n_layers, err);
     return 0;
 }
