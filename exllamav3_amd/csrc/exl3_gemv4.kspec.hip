@@ -279,10 +279,25 @@ void exl3_gemv4_kernel(const GemvArgs a)
 #else
         // unconditional (the host gives every wave at least one unit; the row index is clamped into the slice regardless): under `if (nun > 0)` the number
         // of outstanding loads after the merge is path-dependent and the waits of the preparation task below degrade to vmcnt(0)
+#ifdef G4_RAMP
+        // experiment (G4_PFU = 2): a two-unit ring whose second unit is requested only in front of the streaming loop (issue_ring_second): the deeper
+        // lookahead of the steady state without doubling the launch's initial burst of weight requests.  Measured in the whole step (round 3, same box, two
+        // alternations, tools/experiments/decode_step_harness.hip): 603.3 / 603.6 vs 622.2 / 630.9 tok/s -- slower like the plain two-unit ring; not the default
+        #pragma unroll
+        for (int u = 0; u < 2; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(min(2 * ubase + u, 2 * last_unit + 1), 2 * units - 1) * row_stride);
+#else
         #pragma unroll
         for (int u = 0; u < NR; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(min(2 * ubase + u, 2 * last_unit + 1), 2 * units - 1) * row_stride);
 #endif
+#endif
     };
+#ifdef G4_RAMP
+    auto issue_ring_second = [&] ()
+    {
+        #pragma unroll
+        for (int u = 2; u < NR; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(min(2 * ubase + u, 2 * last_unit + 1), 2 * units - 1) * row_stride);
+    };
+#endif
     if constexpr (IN_LDS) issue_ring();              // (rotated input: behind the first activation group, below)
     G4_T(1);
     // ---- activation quads of this wave's first group
@@ -492,6 +507,9 @@ void exl3_gemv4_kernel(const GemvArgs a)
     }
 
     float4_t acc_c = { 0.f, 0.f, 0.f, 0.f }, acc_d = acc_c;
+#ifdef G4_RAMP
+    issue_ring_second();
+#endif
     G4_T(2);
 
     // ---- streaming: groups of 2 units (4 tile rows share one activation register pair), then an odd last unit
