@@ -60,6 +60,10 @@ constexpr int g4_waves_per_eu(int K, int CB, int MODE_)
     if (MODE == G4_MODE_NORMFX || MODE == G4_MODE_ACTFX) return 6;
     return (MODE == G4_MODE_ROT && CB == EXL3_CB_MUL1) ? 8 : 7;
 }
+// A/B builds: G4_WPE_DELTA = n asks for n fewer waves per SIMD (a larger register budget) in every instantiation
+#ifndef G4_WPE_DELTA
+#define G4_WPE_DELTA 0
+#endif
 
 // One work unit = 2 tile rows of the wave's column block.  HALF selects which half of the 4-tile-row activation group the unit is (abid 0..7 or 8..15).
 // Units in flight per wave (weight-row register ring = 2 * PFU rows).  One unit of lookahead, like generation 2.  Measured (round 3, same box,
@@ -106,13 +110,19 @@ __device__ __forceinline__ void g4_unit(LaneWords<K> (&ringall)[NR], const uint3
                 acc_c = __builtin_amdgcn_mfma_f32_4x4x4f16(ag1, bc[1], acc_c, 4, ABID, 0);
                 acc_d = __builtin_amdgcn_mfma_f32_4x4x4f16(ag1, bd[1], acc_d, 4, ABID, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);                                    // 8 weights in flight at a time (occupancy over ILP)
+            // 8 weights in flight at a time (occupancy over ILP).  A/B builds: G4_NO_SCHED = free scheduling, G4_SCHED2 = 16 weights in flight
+#if defined(G4_NO_SCHED)
+#elif defined(G4_SCHED2)
+            if constexpr (q & 1) __builtin_amdgcn_sched_barrier(0);
+#else
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         });
     });
 }
 
 template <int K, int CB, int VAR, int XMODE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(g4_waves_per_eu(K, CB, XMODE))))
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(g4_waves_per_eu(K, CB, XMODE) - G4_WPE_DELTA)))
 void exl3_gemv4_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -484,6 +494,9 @@ void exl3_gemv4_kernel(const GemvArgs a)
                 if constexpr (MODE == G4_MODE_NORMFX) { if (cbg == 0 && act && l32 == 0) a.rs_ss_out[(size_t) row * (a_k >> 7) + (k0s >> 7) + blk] = ssq_pub; }
             }
         };
+#ifdef G4_PRIO
+        if (prep_wave) __builtin_amdgcn_s_setprio(3);          // A/B build: the workgroup's critical path ahead of its streaming neighbours on the SIMD
+#endif
         if (prep_wave)
         {
             if (ntask <= nhw) do_task(nx, 0);       // the usual case, one round: a straight line in which the compiler counts the outstanding loads and the
@@ -499,6 +512,9 @@ void exl3_gemv4_kernel(const GemvArgs a)
                 }
             }
         }
+#ifdef G4_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
 #ifdef G4_ABL_ONE_ROW
         if (nun > 0) load_lane_words<K>(ring[1], strip + (size_t) (2 * ubase + 1) * row_stride);
@@ -549,6 +565,9 @@ void exl3_gemv4_kernel(const GemvArgs a)
     G4_T(4);
 
     // ---- half-wave h takes rows h, h + nhw, ...: sum of the waves' partials, the mul1 FAST affine map, then the slab line or the final output row
+#ifdef G4_PRIO
+    if (hwid < m) __builtin_amdgcn_s_setprio(3);
+#endif
     const int l = l32;
     for (int row = hwid; row < m; row += nhw)
     {

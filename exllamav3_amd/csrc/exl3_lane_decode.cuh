@@ -28,21 +28,28 @@ __device__ __forceinline__ uint32_t lane_state(const uint32_t (&Wx)[K + 1])
 
 template <int K> struct LaneWords { uint32_t w[K]; };
 
+// EXL3_LOAD_PLAIN (A/B builds, tools/experiments/build_lite.py): the weight rows with the default cache policy instead of non-temporal loads
+#ifdef EXL3_LOAD_PLAIN
+#define EXL3_WLOAD(ptr) (*(ptr))
+#else
+#define EXL3_WLOAD(ptr) __builtin_nontemporal_load(ptr)
+#endif
+
 template <int K>
 __device__ __forceinline__ void load_lane_words(LaneWords<K>& d, const uint32_t* __restrict__ p)
 {
     // p = this lane's first word of the tile row; K consecutive words (contiguous across the wave)
-    if constexpr (K == 4) { uint4_t v = __builtin_nontemporal_load((const uint4_t*) p); d.w[0] = v.x; d.w[1] = v.y; d.w[2] = v.z; d.w[3] = v.w; }
+    if constexpr (K == 4) { uint4_t v = EXL3_WLOAD((const uint4_t*) p); d.w[0] = v.x; d.w[1] = v.y; d.w[2] = v.z; d.w[3] = v.w; }
     else if constexpr (K == 8)
     {
-        uint4_t v = __builtin_nontemporal_load((const uint4_t*) p), u = __builtin_nontemporal_load((const uint4_t*) p + 1);
+        uint4_t v = EXL3_WLOAD((const uint4_t*) p), u = EXL3_WLOAD((const uint4_t*) p + 1);
         d.w[0] = v.x; d.w[1] = v.y; d.w[2] = v.z; d.w[3] = v.w; d.w[4] = u.x; d.w[5] = u.y; d.w[6] = u.z; d.w[7] = u.w;
     }
-    else if constexpr (K == 2) { uint2_t v = __builtin_nontemporal_load((const uint2_t*) p); d.w[0] = v.x; d.w[1] = v.y; }
+    else if constexpr (K == 2) { uint2_t v = EXL3_WLOAD((const uint2_t*) p); d.w[0] = v.x; d.w[1] = v.y; }
     else
     {
         #pragma unroll
-        for (int i = 0; i < K; ++i) d.w[i] = __builtin_nontemporal_load(p + i);
+        for (int i = 0; i < K; ++i) d.w[i] = EXL3_WLOAD(p + i);
     }
 }
 
