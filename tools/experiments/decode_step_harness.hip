@@ -5,7 +5,9 @@
 // compared.  Attention core excluded, as in bench.py's headline line: o_proj reads q after rope.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-gpu-rdc -DM1_TAGGED -I include -I exllamav3_amd/csrc -o tools/bin/decode_step_harness \
 //         tools/experiments/decode_step_harness.hip tools/experiments/exl3_mlp1.hip -L exllamav3_amd -lexl3_hip -Wl,-rpath,'$ORIGIN/../../exllamav3_amd'
-//   tools/bin/decode_step_harness [layers = 32] [alternations = 3]
+//   tools/bin/decode_step_harness [layers = 32] [alternations = 3] [split qkv = 0] [o = 8] [gate|up = 0] [down = 0] [baseline only = 0] [batch = 1]
+// batch > 4 (e.g. 16): the folded glue pipeline of llama_path._decode_step_fused_folded (8 launches per layer, generation-3 kernels) -- the three-launch
+// variant only; this mode was written after the round's GPU seconds were gone: compiled against the header, not yet run.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdio.h>
@@ -70,14 +72,15 @@ int main(int argc, char** argv)
     const int n_layers = argc > 1 ? atoi(argv[1]) : 32, alternations = argc > 2 ? atoi(argv[2]) : 3;
     // forced split-k factors of the four GEMV launches of a layer (0 = the library's choice; llama_path.decode_step_fx: o = 8, the others 0)
     const int sp_qkv = argc > 3 ? atoi(argv[3]) : 0, sp_o = argc > 4 ? atoi(argv[4]) : 8, sp_gu = argc > 5 ? atoi(argv[5]) : 0, sp_down = argc > 6 ? atoi(argv[6]) : 0;
-    const bool baseline_only = argc > 7 && atoi(argv[7]) != 0;          // time only the three-launch form (split sweeps)
+    const int bsz = argc > 8 ? atoi(argv[8]) : 1;
+    const bool baseline_only = (argc > 7 && atoi(argv[7]) != 0) || bsz > 1;          // time only the three-launch form (split sweeps, batches)
     const float eps = 1e-5f;
     CK(hipSetDevice(0));
     CE(exl3_init(0));
     hipStream_t st; CK(hipStreamCreate(&st));
 
     std::vector<Layer> L(n_layers);
-    const int G = hkv * hd / 32, n_pages = max_ctx / page;
+    const int G = hkv * hd / 32, n_pages = max_ctx / page;      // pages per sequence (block_table [bsz][n_pages])
     for (int i = 0; i < n_layers; ++i)
     {
         L[i].q = make_lin(hidden, hq * hd, K, 0.5, st); L[i].k = make_lin(hidden, hkv * hd, K, 0.5, st); L[i].v = make_lin(hidden, hkv * hd, K, 0.5, st);
@@ -85,7 +88,7 @@ int main(int argc, char** argv)
         L[i].g = make_lin(hidden, inter, K, 0.5, st); L[i].u = make_lin(hidden, inter, K, 0.5, st); L[i].d = make_lin(inter, hidden, K, 0.5, st);
         std::vector<float> nw(hidden); for (auto& x : nw) x = (float) (1.0 + 0.05 * nrand());
         L[i].norm1 = dev_half(nw); for (auto& x : nw) x = (float) (1.0 + 0.05 * nrand()); L[i].norm2 = dev_half(nw);
-        const size_t cw = (size_t) n_pages * page * G * kv_bits, cs = (size_t) n_pages * page * G;
+        const size_t cw = (size_t) (argc > 8 ? atoi(argv[8]) : 1) * n_pages * page * G * kv_bits, cs = (size_t) (argc > 8 ? atoi(argv[8]) : 1) * n_pages * page * G;
         CK(hipMalloc(&L[i].kc, cw * 4)); CK(hipMalloc(&L[i].vc, cw * 4)); CK(hipMalloc(&L[i].ks, cs * 2)); CK(hipMalloc(&L[i].vs, cs * 2));
         CK(hipMemsetAsync(L[i].kc, 0, cw * 4, st)); CK(hipMemsetAsync(L[i].vc, 0, cw * 4, st)); CK(hipMemsetAsync(L[i].ks, 0, cs * 2, st)); CK(hipMemsetAsync(L[i].vs, 0, cs * 2, st));
     }
@@ -94,18 +97,22 @@ int main(int argc, char** argv)
     __half* final_norm = dev_half(fnw);
 
     // step state (llama_path.alloc_state, bsz = 1)
-    std::vector<float> x0(hidden); for (auto& v : x0) v = (float) nrand();
+    std::vector<float> x0((size_t) bsz * hidden); for (auto& v : x0) v = (float) nrand();
     __half* dx0 = dev_half(x0);
     __half *q, *xout, *xh_d, *xh_head, *logits; int64_t *R, *slots; float *ssA, *ssB, *xs_d, *xs_head, *rsin, *rcos, *inv_freq; int32_t *positions, *block_table;
-    CK(hipMalloc(&q, hq * hd * 2)); CK(hipMalloc(&xout, hidden * 2)); CK(hipMalloc(&xh_d, inter * 2)); CK(hipMalloc(&xh_head, hidden * 2)); CK(hipMalloc(&logits, (size_t) vocab * 2));
-    CK(hipMalloc(&R, hidden * 8)); CK(hipMalloc(&slots, 8)); CK(hipMalloc(&ssA, 32 * 4)); CK(hipMalloc(&ssB, 32 * 4)); CK(hipMalloc(&xs_d, inter / 128 * 4));
-    CK(hipMalloc(&xs_head, 32 * 4)); CK(hipMalloc(&rsin, 64 * 4)); CK(hipMalloc(&rcos, 64 * 4)); CK(hipMalloc(&inv_freq, 64 * 4)); CK(hipMalloc(&positions, 4)); CK(hipMalloc(&block_table, n_pages * 4));
+    CK(hipMalloc(&q, (size_t) bsz * hq * hd * 2)); CK(hipMalloc(&xout, (size_t) bsz * hidden * 2)); CK(hipMalloc(&xh_d, (size_t) bsz * inter * 2)); CK(hipMalloc(&xh_head, (size_t) bsz * hidden * 2)); CK(hipMalloc(&logits, (size_t) bsz * vocab * 2));
+    CK(hipMalloc(&R, (size_t) bsz * hidden * 8)); CK(hipMalloc(&slots, (size_t) bsz * 8)); CK(hipMalloc(&ssA, (size_t) bsz * 32 * 4)); CK(hipMalloc(&ssB, (size_t) bsz * 32 * 4)); CK(hipMalloc(&xs_d, (size_t) bsz * inter / 128 * 4));
+    CK(hipMalloc(&xs_head, (size_t) bsz * 32 * 4)); CK(hipMalloc(&rsin, (size_t) bsz * 64 * 4)); CK(hipMalloc(&rcos, (size_t) bsz * 64 * 4)); CK(hipMalloc(&inv_freq, 64 * 4)); CK(hipMalloc(&positions, (size_t) bsz * 4)); CK(hipMalloc(&block_table, (size_t) bsz * n_pages * 4));
+    // batches: fp16 residual + three rotated-input buffers (q|k|v or gate|up) of the folded glue pipeline
+    __half* xres; __half* xh3[3]; float* xs3[3];
+    CK(hipMalloc(&xres, (size_t) bsz * hidden * 2));
+    for (int i = 0; i < 3; ++i) { CK(hipMalloc(&xh3[i], (size_t) bsz * hidden * 2)); CK(hipMalloc(&xs3[i], (size_t) bsz * 32 * 4)); }
     {
         float f[64]; for (int i = 0; i < 64; ++i) f[i] = (float) (1.0 / pow(500000.0, (2.0 * i) / hd));
         CK(hipMemcpy(inv_freq, f, sizeof(f), hipMemcpyHostToDevice));
-        int32_t p = pos; CK(hipMemcpy(positions, &p, 4, hipMemcpyHostToDevice));
-        std::vector<int32_t> bt(n_pages); for (int i = 0; i < n_pages; ++i) bt[i] = i;
-        CK(hipMemcpy(block_table, bt.data(), n_pages * 4, hipMemcpyHostToDevice));
+        std::vector<int32_t> p(bsz, pos); CK(hipMemcpy(positions, p.data(), (size_t) bsz * 4, hipMemcpyHostToDevice));
+        std::vector<int32_t> bt((size_t) bsz * n_pages); for (size_t i = 0; i < bt.size(); ++i) bt[i] = (int32_t) i;
+        CK(hipMemcpy(block_table, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
     }
     CK(hipStreamSynchronize(st));
 
@@ -145,6 +152,86 @@ int main(int argc, char** argv)
         const void* xh[1] = { xh_head }; const float* xs[1] = { xs_head }; const void* Bh[1] = { head.B }; void* Cs[1] = { logits }; const void* sv[1] = { head.svh }; int nh[1] = { vocab };
         CE(exl3_gemv_ex(nullptr, xh, xs, Bh, Cs, nullptr, sv, nullptr, nh, 1, 1, hidden, K, cb, 0, EXL3_GEMV_IN_ROTATED, 0, nullptr, nullptr, st));
     };
+
+    // batches above 4 rows: llama_path._decode_step_fused_folded
+    auto step_folded = [&] ()
+    {
+        const int DEF = EXL3_GEMV_OUT_DEFERRED, ROT = EXL3_GEMV_IN_ROTATED;
+        float* ss_c = ssA; float* ss_o = ssB;
+        CK(hipMemcpyAsync(xres, dx0, (size_t) bsz * hidden * 2, hipMemcpyDeviceToDevice, st));
+        CE(exl3_qkv_prep(inv_freq, positions, 1.0f, bsz, hd, block_table, n_pages, page, rsin, rcos, slots, st));
+        CE(exl3_glue_resid(nullptr, 0, nullptr, nullptr, nullptr, xres, ss_c, bsz, hidden, st));
+        {
+            const void* su[3] = { L[0].q.suh, L[0].k.suh, L[0].v.suh }; void* xh[3] = { xh3[0], xh3[1], xh3[2] }; float* xs[3] = { xs3[0], xs3[1], xs3[2] };
+            CE(exl3_glue_rotate(xres, ss_c, L[0].norm1, eps, su, xh, xs, 3, bsz, hidden, st));
+        }
+        const float* rs_prev = nullptr; const float* rs_new = nullptr;
+        for (int i = 0; i < n_layers; ++i)
+        {
+            Layer& l = L[i];
+            {
+                const void* xh[3] = { xh3[0], xh3[1], xh3[2] }; const float* xs[3] = { xs3[0], xs3[1], xs3[2] };
+                const void* Bs[3] = { l.q.B, l.k.B, l.v.B }; int ns[3] = { l.q.n, l.k.n, l.v.n };
+                float* slabs[3] = { nullptr, nullptr, nullptr }; int S = 0;
+                CE(exl3_gemv_ex(nullptr, xh, xs, Bs, nullptr, nullptr, nullptr, nullptr, ns, 3, bsz, hidden, K, cb, 0, ROT | DEF, sp_qkv, slabs, &S, st));
+                CE(exl3_glue_qkv_tab(slabs[0], slabs[1], slabs[2], S, l.q.svh, l.k.svh, l.v.svh, q, nullptr, nullptr, inv_freq, positions, l.kc, l.ks, l.vc, l.vs,
+                                     block_table, n_pages, page, kv_bits, kv_bits, bsz, hq, hkv, hd, 2, 1.0f, rs_prev, rs_new, hidden, eps, rsin, rcos, slots, st));
+            }
+            {
+                const void* Bs[1] = { l.o.B }; const void* su[1] = { l.o.suh }; int ns[1] = { hidden };
+                float* so[1] = { nullptr }; int So = 0;
+                CE(exl3_gemv_ex(q, nullptr, nullptr, Bs, nullptr, su, nullptr, nullptr, ns, 1, bsz, hq * hd, K, cb, 0, DEF, bsz > 4 ? 0 : sp_o, so, &So, st));
+                const void* su2[2] = { l.g.suh, l.u.suh }; void* xh[2] = { xh3[0], xh3[1] }; float* xs[2] = { xs3[0], xs3[1] };
+                CE(exl3_glue_resid_rotate(so[0], So, nullptr, l.o.svh, nullptr, xres, ss_c, ss_o, l.norm2, eps, su2, xh, xs, 2, bsz, hidden, st));
+                rs_prev = ss_c; rs_new = ss_o; std::swap(ss_c, ss_o);
+            }
+            {
+                const void* xh[2] = { xh3[0], xh3[1] }; const float* xs[2] = { xs3[0], xs3[1] };
+                const void* Bs[2] = { l.g.B, l.u.B }; int ns[2] = { inter, inter };
+                float* slabs[2] = { nullptr, nullptr }; int S = 0;
+                CE(exl3_gemv_ex(nullptr, xh, xs, Bs, nullptr, nullptr, nullptr, nullptr, ns, 2, bsz, hidden, K, cb, 0, ROT | DEF, sp_gu, slabs, &S, st));
+                CE(exl3_glue_act_rs(slabs[0], slabs[1], S, l.g.svh, l.u.svh, l.d.suh, xh_d, xs_d, nullptr, bsz, inter, rs_prev, rs_new, hidden, eps, st));
+                const void* xd[1] = { xh_d }; const float* xsd[1] = { xs_d }; const void* Bd[1] = { l.d.B }; int nd[1] = { hidden };
+                float* sd[1] = { nullptr }; int Sd = 0;
+                CE(exl3_gemv_ex(nullptr, xd, xsd, Bd, nullptr, nullptr, nullptr, nullptr, nd, 1, bsz, inter, K, cb, 0, ROT | DEF, sp_down, sd, &Sd, st));
+                if (i + 1 < n_layers)
+                {
+                    Layer& nl = L[i + 1];
+                    const void* su3[3] = { nl.q.suh, nl.k.suh, nl.v.suh }; void* xh3o[3] = { xh3[0], xh3[1], xh3[2] }; float* xs3o[3] = { xs3[0], xs3[1], xs3[2] };
+                    CE(exl3_glue_resid_rotate(sd[0], Sd, nullptr, l.d.svh, nullptr, xres, ss_c, ss_o, nl.norm1, eps, su3, xh3o, xs3o, 3, bsz, hidden, st));
+                    rs_prev = ss_c; rs_new = ss_o; std::swap(ss_c, ss_o);
+                }
+                else CE(exl3_glue_resid(sd[0], Sd, nullptr, l.d.svh, nullptr, xres, ss_c, bsz, hidden, st));
+            }
+        }
+        const void* suh[1] = { head.suh }; void* xhh[1] = { xh3[0] }; float* xsh[1] = { xs3[0] };
+        CE(exl3_glue_rotate(xres, ss_c, final_norm, eps, suh, xhh, xsh, 1, bsz, hidden, st));
+        const void* xh[1] = { xh3[0] }; const float* xs[1] = { xs3[0] }; const void* Bh[1] = { head.B }; void* Cs[1] = { logits }; const void* sv[1] = { head.svh }; int nh[1] = { vocab };
+        CE(exl3_gemv_ex(nullptr, xh, xs, Bh, Cs, nullptr, sv, nullptr, nh, 1, bsz, hidden, K, cb, 0, ROT, 0, nullptr, nullptr, st));
+    };
+    if (bsz > 4)
+    {
+        step_folded(); CK(hipStreamSynchronize(st));
+        hipGraph_t g; hipGraphExec_t gx;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal)); step_folded(); CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&gx, g, nullptr, nullptr, 0)); CK(hipGraphDestroy(g));
+        hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+        double bestb = 1e30;
+        for (int a = 0; a < alternations; ++a)
+        {
+            for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(gx, st));
+            CK(hipEventRecord(a0, st));
+            for (int i = 0; i < 30; ++i) CK(hipGraphLaunch(gx, st));
+            CK(hipEventRecord(a1, st)); CK(hipEventSynchronize(a1));
+            float ms; CK(hipEventElapsedTime(&ms, a0, a1)); bestb = std::min(bestb, (double) ms / 30.0);
+        }
+        std::vector<__half> lgb((size_t) bsz * vocab); CK(hipMemcpy(lgb.data(), logits, lgb.size() * 2, hipMemcpyDeviceToHost));
+        int bad = 0; double r2 = 0; for (auto h : lgb) { const double v = __half2float(h); if (!std::isfinite(v)) ++bad; else r2 += v * v; }
+        printf("{\"model\": \"llama-3.1-8b shapes, %d layers, EXL3 4.0 bpw mul1, bs %d, folded glue pipeline via the C ABI\", \"ms_per_step\": %.4f, \"tok_s\": %.1f, "
+               "\"us_per_layer\": %.2f, \"logits_rms\": %.5g, \"nonfinite\": %d, \"splits\": {\"qkv\": %d, \"gate_up\": %d, \"down\": %d}}\n",
+               n_layers, bsz, bestb, bsz * 1e3 / bestb, bestb * 1e3 / n_layers, sqrt(r2 / (double) lgb.size()), bad, sp_qkv, sp_gu, sp_down);
+        return 0;
+    }
 
     // logits of both variants (eager), compared
     std::vector<__half> lg[2] = { std::vector<__half>(vocab), std::vector<__half>(vocab) };
