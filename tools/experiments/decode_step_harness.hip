@@ -78,6 +78,12 @@ int main(int argc, char** argv)
     CK(hipSetDevice(0));
     CE(exl3_init(0));
     hipStream_t st; CK(hipStreamCreate(&st));
+    // the library's run-time tuning knobs, from the environment (one process per setting: tools/experiments/sweep_splits.sh style sweeps)
+    if (const char* e = getenv("H_GEMV_VARIANT")) CE(exl3_set_gemv_variant(atoi(e)));          // 1 FAST (default) / 0 EXACT
+    if (const char* e = getenv("H_MAX_WAVES")) CE(exl3_set_gemv_max_waves(atoi(e)));
+    if (const char* e = getenv("H_DEFER_WG_PER_CU")) CE(exl3_set_gemv_defer_wg_per_cu(atoi(e)));
+    if (const char* e = getenv("H_GLUE_THREADS")) CE(exl3_set_glue_threads(atoi(e)));
+    if (const char* e = getenv("H_GEMM3_MIN_ROWS")) CE(exl3_set_gemm3_min_rows(atoi(e)));
 
     std::vector<Layer> L(n_layers);
     const int G = hkv * hd / 32, n_pages = max_ctx / page;      // pages per sequence (block_table [bsz][n_pages])
