@@ -6,6 +6,9 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-gpu-rdc -DM1_TAGGED -I include -I exllamav3_amd/csrc -o tools/bin/decode_step_harness \
 //         tools/experiments/decode_step_harness.hip tools/experiments/exl3_mlp1.hip -L exllamav3_amd -lexl3_hip -Wl,-rpath,'$ORIGIN/../../exllamav3_amd'
 //   tools/bin/decode_step_harness [layers = 32] [alternations = 3] [split qkv = 0] [o = 8] [gate|up = 0] [down = 0] [baseline only = 0] [batch = 1]
+//   H_VARIANTS="0,1,2,3": which MLP forms to compare (0 shipped three launches, 1 one launch, 2 silu*mul inside the down launch, 3 gate|up atomics + down);
+//   H_MAX_WAVES / H_DEFER_WG_PER_CU / H_GLUE_THREADS / H_GEMV_VARIANT / H_GEMM3_MIN_ROWS: the library's run-time knobs.  (Variants 2 and 3 and the knobs
+//   were added after the round's GPU seconds were gone: compiled, not yet run.)
 // batch > 4 (e.g. 16): the folded glue pipeline of llama_path._decode_step_fused_folded (8 launches per layer, generation-3 kernels) -- the three-launch
 // variant only; this mode was written after the round's GPU seconds were gone: compiled against the header, not yet run.
 #include <hip/hip_runtime.h>
@@ -109,6 +112,7 @@ int main(int argc, char** argv)
     CK(hipMalloc(&q, (size_t) bsz * hq * hd * 2)); CK(hipMalloc(&xout, (size_t) bsz * hidden * 2)); CK(hipMalloc(&xh_d, (size_t) bsz * inter * 2)); CK(hipMalloc(&xh_head, (size_t) bsz * hidden * 2)); CK(hipMalloc(&logits, (size_t) bsz * vocab * 2));
     CK(hipMalloc(&R, (size_t) bsz * hidden * 8)); CK(hipMalloc(&slots, (size_t) bsz * 8)); CK(hipMalloc(&ssA, (size_t) bsz * 32 * 4)); CK(hipMalloc(&ssB, (size_t) bsz * 32 * 4)); CK(hipMalloc(&xs_d, (size_t) bsz * inter / 128 * 4));
     CK(hipMalloc(&xs_head, (size_t) bsz * 32 * 4)); CK(hipMalloc(&rsin, (size_t) bsz * 64 * 4)); CK(hipMalloc(&rcos, (size_t) bsz * 64 * 4)); CK(hipMalloc(&inv_freq, 64 * 4)); CK(hipMalloc(&positions, (size_t) bsz * 4)); CK(hipMalloc(&block_table, (size_t) bsz * n_pages * 4));
+    int64_t* GU; CK(hipMalloc(&GU, (size_t) 2 * inter * 8)); CK(hipMemsetAsync(GU, 0, (size_t) 2 * inter * 8, st));      // gate / up accumulators (variant 3)
     // batches: fp16 residual + three rotated-input buffers (q|k|v or gate|up) of the folded glue pipeline
     __half* xres; __half* xh3[3]; float* xs3[3];
     CK(hipMalloc(&xres, (size_t) bsz * hidden * 2));
@@ -122,7 +126,9 @@ int main(int argc, char** argv)
     }
     CK(hipStreamSynchronize(st));
 
-    auto step = [&] (bool one_launch_mlp)
+    // MLP variants: 0 = gate|up (slabs) -> glue_act_rs -> down [shipped default at 8B]; 1 = one launch (exl3_mlp1.hip); 2 = silu*mul + rotation inside the down launch
+    // (llama_path fx_act_in_gemv: 5 launches per layer); 3 = gate|up ADD into fixed-point accumulators, down forms silu*mul from them (fx_gu_atomic: 5 launches)
+    auto step = [&] (int variant)
     {
         float* sc = ssA; float* so = ssB;
         CE(exl3_fx_init_prep(dx0, R, sc, 1, hidden, inv_freq, positions, 1.0f, hd, block_table, n_pages, page, rsin, rcos, slots, st));
@@ -139,10 +145,27 @@ int main(int argc, char** argv)
             }
             {
                 const void* Bs[1] = { l.o.B }; void* Cs[1] = { R }; const void* su[1] = { l.o.suh }; const void* sv[1] = { l.o.svh }; int ns[1] = { hidden };
+                if (variant == 3) CE(exl3_fx_zero_next(GU, (int64_t) 2 * inter * 8));      // the o_proj launch clears the gate / up accumulators as a side job
                 CE(exl3_gemv_ex(q, nullptr, nullptr, Bs, Cs, su, sv, nullptr, ns, 1, 1, hq * hd, K, cb, 0, EXL3_GEMV_OUT_ATOMIC, sp_o, nullptr, nullptr, st));
             }
-            if (one_launch_mlp)
+            if (variant == 1)
                 CE(exl3_mlp1_fx(R, l.norm2, sc, so, eps, l.g.B, l.u.B, l.g.suh, l.u.suh, l.g.svh, l.u.svh, l.d.B, l.d.suh, l.d.svh, 1, hidden, inter, K, cb, st));
+            else if (variant == 2)
+            {
+                const void* Bs[2] = { l.g.B, l.u.B }; const void* su[2] = { l.g.suh, l.u.suh }; int ns[2] = { inter, inter };
+                float* slabs[2] = { nullptr, nullptr }; int S = 0;
+                CE(exl3_gemv_ex_fx(R, l.norm2, sc, so, eps, Bs, su, ns, 2, 1, hidden, K, cb, sp_gu, slabs, &S, st));
+                CE(exl3_gemv_ex_act_rs(slabs[0], slabs[1], S, l.g.svh, l.u.svh, sc, so, hidden, eps, l.d.B, R, l.d.suh, l.d.svh, nullptr, 1, inter, hidden, K, cb,
+                                       0, EXL3_GEMV_OUT_ATOMIC, 0, sp_down, nullptr, nullptr, st));
+            }
+            else if (variant == 3)
+            {
+                const void* Bs[2] = { l.g.B, l.u.B }; const void* su[2] = { l.g.suh, l.u.suh }; const void* sv[2] = { l.g.svh, l.u.svh }; int ns[2] = { inter, inter };
+                void* accs[2] = { GU, GU + inter }; int S = 0;
+                CE(exl3_gemv_ex_fx_atomic(R, l.norm2, sc, so, eps, Bs, accs, su, sv, ns, 2, 1, hidden, K, cb, sp_gu, &S, st));
+                CE(exl3_gemv_ex_actfx(GU, GU + inter, sc, so, hidden, eps, l.d.B, R, l.d.suh, l.d.svh, nullptr, 1, inter, hidden, K, cb, EXL3_GEMV_OUT_ATOMIC, sp_down,
+                                      nullptr, nullptr, st));
+            }
             else
             {
                 const void* Bs[2] = { l.g.B, l.u.B }; const void* su[2] = { l.g.suh, l.u.suh }; int ns[2] = { inter, inter };
@@ -239,55 +262,68 @@ int main(int argc, char** argv)
         return 0;
     }
 
-    // logits of both variants (eager), compared
-    std::vector<__half> lg[2] = { std::vector<__half>(vocab), std::vector<__half>(vocab) };
-    for (int v = 0; v < 2; ++v)
+    // selected variants (H_VARIANTS="0,1,2,3"; default "0,1"; baseline only: "0"): logits against variant 0, then alternating graph replays
+    const char* vnames[4] = { "three_launch_mlp", "one_launch_mlp", "act_in_down", "gate_up_atomic" };
+    std::vector<int> vs;
     {
-        step(v == 1);
+        const char* e = baseline_only ? "0" : (getenv("H_VARIANTS") ? getenv("H_VARIANTS") : "0,1");
+        for (const char* c = e; *c; ++c) if (*c >= '0' && *c <= '3') vs.push_back(*c - '0');
+        if (vs.empty() || vs[0] != 0) vs.insert(vs.begin(), 0);
+    }
+    std::vector<std::vector<__half>> lg(vs.size(), std::vector<__half>(vocab));
+    for (size_t i = 0; i < vs.size(); ++i)
+    {
+        step(vs[i]);
         CK(hipStreamSynchronize(st));
-        CK(hipMemcpy(lg[v].data(), logits, (size_t) vocab * 2, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(lg[i].data(), logits, (size_t) vocab * 2, hipMemcpyDeviceToHost));
     }
     int err = -1; CE(exl3_mlp1_error(&err, st));
-    double rms = 0, maxd = 0, sd2 = 0; int nonfinite = 0;
-    for (int i = 0; i < vocab; ++i)
+    printf("{\"model\": \"llama-3.1-8b shapes, %d layers, EXL3 4.0 bpw mul1, bs 1, fx pipeline via the C ABI\", \"mlp1_err_word\": %d, \"logits_vs_variant_0\": [", n_layers, err);
+    for (size_t i = 0; i < vs.size(); ++i)
     {
-        const double a = __half2float(lg[0][i]), b = __half2float(lg[1][i]);
-        if (!std::isfinite(a) || !std::isfinite(b)) { ++nonfinite; continue; }
-        rms += a * a; sd2 += (a - b) * (a - b); maxd = std::max(maxd, fabs(a - b));
+        double rms = 0, maxd = 0, sd2 = 0; int nonfinite = 0;
+        for (int c = 0; c < vocab; ++c)
+        {
+            const double a = __half2float(lg[0][c]), b2 = __half2float(lg[i][c]);
+            if (!std::isfinite(a) || !std::isfinite(b2)) { ++nonfinite; continue; }
+            rms += a * a; sd2 += (a - b2) * (a - b2); maxd = std::max(maxd, fabs(a - b2));
+        }
+        rms = sqrt(rms / vocab);
+        printf("%s{\"variant\": \"%s\", \"logits_rms\": %.5g, \"max_abs_diff\": %.5g, \"rms_diff\": %.5g, \"nonfinite\": %d}", i ? ", " : "", vnames[vs[i]], rms, maxd, sqrt(sd2 / vocab), nonfinite);
     }
-    rms = sqrt(rms / vocab);
-    printf("{\"model\": \"llama-3.1-8b shapes, %d layers, EXL3 4.0 bpw mul1, bs 1, fx pipeline via the C ABI\", \"logits_rms\": %.5g, \"max_abs_diff_one_launch_mlp\": %.5g, \"rms_diff\": %.5g, "
-           "\"rel_to_rms\": %.3g, \"nonfinite\": %d, \"mlp1_err_word\": %d,\n", n_layers, rms, maxd, sqrt(sd2 / vocab), maxd / (rms + 1e-30), nonfinite, err);
+    printf("],\n");
     fflush(stdout);
 
-    // graphs + alternating timing
-    hipGraphExec_t ge[2];
-    for (int v = 0; v < 2; ++v)
+    std::vector<hipGraphExec_t> ge(vs.size());
+    for (size_t i = 0; i < vs.size(); ++i)
     {
         hipGraph_t g;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        step(v == 1);
+        step(vs[i]);
         CK(hipStreamEndCapture(st, &g));
-        CK(hipGraphInstantiate(&ge[v], g, nullptr, nullptr, 0));
+        CK(hipGraphInstantiate(&ge[i], g, nullptr, nullptr, 0));
         CK(hipGraphDestroy(g));
     }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     printf(" \"ms_per_step\": [");
-    double best[2] = { 1e30, 1e30 };
+    std::vector<double> best(vs.size(), 1e30);
     for (int a = 0; a < alternations; ++a)
-        for (int v = 0; v < (baseline_only ? 1 : 2); ++v)
+        for (size_t i = 0; i < vs.size(); ++i)
         {
-            for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(ge[v], st));
+            for (int r = 0; r < 5; ++r) CK(hipGraphLaunch(ge[i], st));
             CK(hipEventRecord(e0, st));
-            for (int i = 0; i < 50; ++i) CK(hipGraphLaunch(ge[v], st));
+            for (int r = 0; r < 50; ++r) CK(hipGraphLaunch(ge[i], st));
             CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-            best[v] = std::min(best[v], (double) ms / 50.0);
-            printf("%s{\"variant\": \"%s\", \"ms\": %.4f}", (a || v) ? ", " : "", v ? "one_launch_mlp" : "three_launch_mlp", ms / 50.0);
+            best[i] = std::min(best[i], (double) ms / 50.0);
+            printf("%s{\"variant\": \"%s\", \"ms\": %.4f}", (a || i) ? ", " : "", vnames[vs[i]], ms / 50.0);
             fflush(stdout);
         }
     err = -1; CE(exl3_mlp1_error(&err, st));
-    printf("],\n \"splits\": {\"qkv\": %d, \"o\": %d, \"gate_up\": %d, \"down\": %d}, \"tok_s\": {\"three_launch_mlp\": %.1f, \"one_launch_mlp\": %.1f}, \"us_per_layer\": {\"three_launch_mlp\": %.2f, \"one_launch_mlp\": %.2f}, \"mlp1_err_word_after_timing\": %d}\n",
-           sp_qkv, sp_o, sp_gu, sp_down, 1e3 / best[0], 1e3 / best[1], best[0] * 1e3 / n_layers, best[1] * 1e3 / n_layers, err);
+    printf("],\n \"splits\": {\"qkv\": %d, \"o\": %d, \"gate_up\": %d, \"down\": %d}, \"tok_s\": {", sp_qkv, sp_o, sp_gu, sp_down);
+    for (size_t i = 0; i < vs.size(); ++i) printf("%s\"%s\": %.1f", i ? ", " : "", vnames[vs[i]], 1e3 / best[i]);
+    printf("}, \"us_per_layer\": {");
+    for (size_t i = 0; i < vs.size(); ++i) printf("%s\"%s\": %.2f", i ? ", " : "", vnames[vs[i]], best[i] * 1e3 / n_layers);
+    printf("}, \"mlp1_err_word_after_timing\": %d}\n", err);
     return 0;
 }

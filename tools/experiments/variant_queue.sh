@@ -23,7 +23,7 @@ case "$1" in
     for v in "${VARIANTS[@]}"; do python tools/experiments/build_lite.py "${v%%:*}" ${v#*:} || exit 1; done
     ;;
   run)
-    one() { LD_LIBRARY_PATH=build/lite_$1 $H 32 2 0 8 0 0 1 2>&1 | tail -1 | sed -e 's/.*"three_launch_mlp": \([0-9.]*\),.*/\1/'; }
+    one() { LD_LIBRARY_PATH=build/lite_$1 $H 32 2 0 8 0 0 1 2>&1 | tail -1 | sed -e 's/.*"tok_s": {"three_launch_mlp": \([0-9.]*\).*/\1/'; }
     echo "# variant  base_before  variant  base_after   (tok/s, Llama-3.1-8B bs 1 fx step, three-launch MLP)"
     for v in "${VARIANTS[@]}"; do t=${v%%:*}; echo "$t $(one base) $(one $t) $(one base)"; done
     ;;
