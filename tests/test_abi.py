@@ -32,3 +32,19 @@ def test_header_cites_reference():
     src = open(os.path.join(ROOT, "include", "exl3_hip.h")).read()
     for needle in ("quant/exl3_gemm.cuh", "quant/reconstruct.cu", "norm.cu", "rope.cu", "q_cache"):
         assert needle in src
+
+
+def test_cpp_consumers_of_the_header_still_compile():
+    """The Python-free hosts under tools/experiments (whole decode step, prefill chunk, MLP block: C++ programs that call the library through
+    include/exl3_hip.h only) are type-checked against the header, so a changed signature cannot silently break the drop-in boundary for a C / C++ consumer
+    (INTEGRATION.md section 5).  Syntax check only: no GPU, no link."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    exp = os.path.join(ROOT, "tools", "experiments")
+    srcs = [os.path.join(exp, f) for f in ("decode_step_harness.hip", "prefill_chunk_harness.hip", "mlp1_harness.hip", "exl3_mlp1.hip")]
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-DM1_TAGGED", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "exllamav3_amd", "csrc")] + srcs, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
