@@ -182,6 +182,9 @@ extern "C" int exl3_ar_create(int world, int rank, int64_t max_elems, void** ctx
     std::lock_guard<std::mutex> lock(g_ar_mutex);
     ArCtx* c = new ArCtx();
     memset((void*) c, 0, sizeof(ArCtx));
+    // the one-shot push keeps its whole grid co-resident (exl3_ar_reduce_slabs: at most 8 * EXL3_AR_MAX_WGS tasks of 128 values): a larger request is
+    // clamped HERE, so that callers routing by max_elems (tp.py: numel() <= max_elems, else the collective library) never reach the launch bound
+    if (max_elems > (int64_t) 8 * EXL3_AR_MAX_WGS * 128) max_elems = (int64_t) 8 * EXL3_AR_MAX_WGS * 128;
     c->world = world; c->rank = rank; c->max_elems = (size_t) max_elems;
     c->bytes = AR_HDR + (size_t) 2 * world * max_elems * sizeof(ArGranule);
     hipError_t e = hipGetDevice(&c->device);

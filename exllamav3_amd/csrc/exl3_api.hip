@@ -74,12 +74,20 @@ Exl3DevCtx* exl3_get_ctx(hipStream_t stream)
         if (init_device(device) != EXL3_OK) return nullptr;
     }
     Exl3DevCtx& c = g_ctx[device];
+    // the stream-switch bookkeeping is shared by every host thread that launches on this device: one lock around it (the common one-stream path takes
+    // it uncontended).  Ordering covers EAGER launches only: a graph replay that uses the workspace is ordered against eager work on other streams by
+    // whoever launches the graph (exl3_hip.h, "Streams").
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
     if (c.last_stream_valid && c.last_stream != stream)
     {
         // another stream than the previous workspace user's: order it behind that one (once per change; nothing on the common one-stream path)
         hipStreamCaptureStatus so = hipStreamCaptureStatusNone, sn = hipStreamCaptureStatusNone;
-        (void) hipStreamIsCapturing(c.last_stream, &so);
-        (void) hipStreamIsCapturing(stream, &sn);
+        // (the previous stream may have been destroyed in the meantime: the query then fails and leaves an error behind -- cleared on every path below,
+        // a later exl3_check_launch must not report it as a failed launch)
+        if (hipStreamIsCapturing(c.last_stream, &so) != hipSuccess) so = hipStreamCaptureStatusNone;
+        (void) hipGetLastError();
+        if (hipStreamIsCapturing(stream, &sn) != hipSuccess) sn = hipStreamCaptureStatusNone;
+        (void) hipGetLastError();
         if (so != hipStreamCaptureStatusNone)
         {
             exl3_set_error("exl3: the per-device workspace was last used by a stream that is still capturing; all launches of one graph must be issued on one stream");

@@ -174,14 +174,23 @@ static int gemv_gen4()
 }
 extern "C" int exl3_set_gemv_gen4(int v) { g_gemv_gen4 = v ? 1 : 0; return EXL3_OK; }
 
-// fx pipeline: exl3_fx_zero_next(ptr, bytes) asks the NEXT generation-4 launch to clear a buffer as a side job (the gate / up accumulators)
-static void* g_fx_zero_ptr = nullptr; static int64_t g_fx_zero_bytes = 0;
+// fx pipeline: exl3_fx_zero_next(ptr, bytes) asks the NEXT run_mgemm call OF THIS THREAD ON THIS DEVICE to clear a buffer as a side job (the gate / up
+// accumulators, cleared by the o_proj launch in front of the gate|up launch that adds into them).  The request is one-shot and never outlives that
+// call: run_mgemm takes it on entry (take_fx_zero), so an argument error, a launch that is not a plain generation-4 launch, or a launch on another
+// device fails loudly ("cannot clear") instead of leaving the pointer armed for an unrelated later launch.
+struct FxZeroReq { void* ptr; int64_t bytes; int device; };
+static thread_local FxZeroReq g_fx_zero = { nullptr, 0, -1 };
 extern "C" int exl3_fx_zero_next(void* ptr, int64_t bytes)
 {
+    g_fx_zero = FxZeroReq{ nullptr, 0, -1 };
     EXL3_CHECK_ARG(!ptr || (bytes > 0 && bytes % 16 == 0 && (uintptr_t) ptr % 16 == 0 && bytes / 16 < (1ll << 31)), "exl3_fx_zero_next: 16-byte aligned pointer and size");
-    g_fx_zero_ptr = ptr; g_fx_zero_bytes = ptr ? bytes : 0;
+    if (!ptr) return EXL3_OK;
+    int dev = -1;
+    EXL3_CHECK_HIP(hipGetDevice(&dev), "exl3_fx_zero_next");
+    g_fx_zero = FxZeroReq{ ptr, bytes, dev };
     return EXL3_OK;
 }
+static FxZeroReq take_fx_zero() { const FxZeroReq r = g_fx_zero; g_fx_zero = FxZeroReq{ nullptr, 0, -1 }; return r; }
 
 static int gemv_variant()
 {
@@ -239,6 +248,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                      const void* act_svh_u = nullptr, const GemvResidIn* rsd = nullptr, const GemvRescale* act_rs = nullptr, int cpw = 0,
                      float* fx_ss_out = nullptr)
 {
+    FxZeroReq fxz = take_fx_zero();          // one-shot: whatever happens below, the request does not survive this call
     if (rsd) flags |= GEMV_IN_RESID;
     // cpw > 0: wave-per-column-block layout (exl3_gemv2.kspec.hip): cpw column blocks of one matrix per workgroup, one wave each
     EXL3_CHECK_ARG(cpw >= 0 && cpw <= 16, "exl3_gemv_ex: column blocks per workgroup must be in [0, 16]");
@@ -428,6 +438,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
 
         args.cpw = cpw;
         dim3 grid((unsigned) ((cpw > 0 ? total_groups : total_cb) * S));
+        EXL3_CHECK_ARG(!(fxz.ptr && gen == 3), "exl3_fx_zero_next: the launch that followed cannot clear the buffer (not a generation-4 launch: rows > 4, a slice of more than 32 Hadamard blocks, a tail / wave-per-column-block mode, or generation 4 switched off)");
         if (gen == 3)
         {
             const int mt = mp > 32 ? 4 : (mp > 16 ? 2 : 1);
@@ -464,10 +475,17 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             bool g4 = gemv_gen4() && ng == 1 && (!tbl || (!tbl->act_u && !tbl->n_list)) && !epi && cpw == 0 && !rsd && bps <= 32;
             if (g4 && rot_pass && var == 1 && cb == 2)
                 for (int i = 0; i < count; ++i) if (!args.mat[i].xsum) g4 = false;      // the mul1 FAST variant needs the producer's block sums
+            EXL3_CHECK_ARG(g4 || !fxz.ptr, "exl3_fx_zero_next: the launch that followed cannot clear the buffer (not a generation-4 launch: rows > 4, a slice of more than 32 Hadamard blocks, a tail / wave-per-column-block mode, or generation 4 switched off)");
             if (g4)
             {
                 const int mode = tbl ? (in_act ? 7 : 6) : in_act ? ((flags & GEMV_IN_ACTFX) ? 5 : 3) : (in_norm ? (in_fx ? 4 : 2) : (rot_pass ? 0 : 1));
-                if (g_fx_zero_ptr) { args.fx_zero = g_fx_zero_ptr; args.fx_zero_n16 = (int) (g_fx_zero_bytes / 16); g_fx_zero_ptr = nullptr; g_fx_zero_bytes = 0; }
+                if (fxz.ptr)
+                {
+                    int dev_now = -1;
+                    EXL3_CHECK_HIP(hipGetDevice(&dev_now), "exl3_gemv_ex");
+                    EXL3_CHECK_ARG(!tbl && dev_now == fxz.device, "exl3_fx_zero_next: the launch that follows must be a plain (non-table) generation-4 launch on the device the request was made on");
+                    args.fx_zero = fxz.ptr; args.fx_zero_n16 = (int) (fxz.bytes / 16); fxz.ptr = nullptr;
+                }
                 const int units4 = bps * 4;
                 int nwv4 = 8;
                 if (nwv4 > (bps > 4 ? bps : 4)) nwv4 = bps > 4 ? bps : 4;

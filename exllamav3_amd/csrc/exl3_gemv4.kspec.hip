@@ -422,7 +422,7 @@ void exl3_gemv4_kernel(const GemvArgs a)
                 {
                     // g, u of this (row, block) are complete in the accumulators (out-Hadamard and svh were applied per split-k partial, the sum is
                     // exact integer addition): row-scale correction, one rounding to fp16, silu * mul
-                    auto fxf = [] (uint32_t lo, uint32_t hi) -> float { return (float) (int32_t) hi + (float) lo * 2.3283064365386963e-10f; };
+                    auto fxf = [] (uint32_t lo, uint32_t hi) -> float { return fx_to_float(lo, hi); };      // NaN for a poisoned accumulator
                     float g0 = fxf(cur.f0.x, cur.f0.y), g1 = fxf(cur.f0.z, cur.f0.w), g2 = fxf(cur.f1.x, cur.f1.y), g3 = fxf(cur.f1.z, cur.f1.w);
                     float u0 = fxf(cur.f2.x, cur.f2.y), u1 = fxf(cur.f2.z, cur.f2.w), u2 = fxf(cur.f3.x, cur.f3.y), u3 = fxf(cur.f3.z, cur.f3.w);
                     if (a.act_rs.ss_new)
@@ -436,7 +436,7 @@ void exl3_gemv4_kernel(const GemvArgs a)
                 if constexpr (MODE == G4_MODE_NORMFX)
                 {
                     // the residual stream in 64-bit fixed point (value * 2^32, GEMV_OUT_ATOMIC launches add into it): x = fp16(hi + lo / 2^32)
-                    auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h((float) (int32_t) hi + (float) lo * 2.3283064365386963e-10f); };
+                    auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h(fx_to_float(lo, hi)); };             // NaN for a poisoned accumulator
                     xv = half4_t{ fx(cur.f0.x, cur.f0.y), fx(cur.f0.z, cur.f0.w), fx(cur.f1.x, cur.f1.y), fx(cur.f1.z, cur.f1.w) };
                     if (cbg == 0)
                     {
@@ -625,12 +625,9 @@ void exl3_gemv4_kernel(const GemvArgs a)
             float o[4] = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
             if (bias && s == 0) { const half4_t bv = ((const half4_t*) bias)[l]; o[0] += (float) bv.x; o[1] += (float) bv.y; o[2] += (float) bv.z; o[3] += (float) bv.w; }
             unsigned long long* acc = (unsigned long long*) C_m + c_row * n + cbl * 128 + 4 * l;
+            // (a NaN / Inf / out-of-range share poisons the accumulator instead of adding finite garbage: fx_atomic_add, exl3_gemv_args.h)
             #pragma unroll
-            for (int i = 0; i < 4; ++i)
-            {
-                const long long f = __double2ll_rn((double) o[i] * GEMV_FX_SCALE);
-                __hip_atomic_fetch_add(acc + i, (unsigned long long) f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (int i = 0; i < 4; ++i) fx_atomic_add(acc + i, o[i]);
             continue;
         }
         const size_t off = c_row * n + cbl * 128 + 4 * l;

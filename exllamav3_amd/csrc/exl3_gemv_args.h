@@ -22,6 +22,30 @@
                               // PREVIOUS residual (the row scale is an estimate, corrected downstream exactly as for GEMV_IN_RESID); the workgroups of
                               // column block 0 of matrix 0 write the block sums of squares of THIS residual to rs_ss_out
 #define GEMV_FX_SCALE 4294967296.0
+// Non-finite or out-of-range contributions must not turn into finite garbage (the reference's fp16 residual carries Inf / NaN through to the logits):
+// a value that is NaN, Inf or >= GEMV_FX_LIMIT in magnitude (16x beyond the fp16 range the reference's residual saturates at) REPLACES the accumulator
+// with GEMV_FX_POISON by an atomic exchange -- not an add: k poisons cannot cancel mod 2^64 -- and every reader (fx_to_float) turns an accumulator
+// beyond +-2^60 into NaN.  Legal adds are < 2^52 each, so no number of them brings a poisoned accumulator back into range.
+#define GEMV_FX_LIMIT 1048576.0f
+#define GEMV_FX_POISON 0x4000000000000000ull
+#ifdef __HIPCC__
+__device__ __forceinline__ float fx_to_float(uint32_t lo, uint32_t hi)
+{
+    const float v = (float) (int32_t) hi + (float) lo * 2.3283064365386963e-10f;
+    return ((uint32_t) (hi + 0x10000000u) < 0x20000000u) ? v : __builtin_nanf("");
+}
+__device__ __forceinline__ long long fx_from_float(float v)
+{
+    return (__builtin_fabsf(v) < GEMV_FX_LIMIT) ? __double2ll_rn((double) v * GEMV_FX_SCALE) : (long long) GEMV_FX_POISON;
+}
+__device__ __forceinline__ void fx_atomic_add(unsigned long long* acc, float v)
+{
+    if (__builtin_fabsf(v) < GEMV_FX_LIMIT)
+        __hip_atomic_fetch_add(acc, (unsigned long long) __double2ll_rn((double) v * GEMV_FX_SCALE), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        __hip_atomic_exchange(acc, (unsigned long long) GEMV_FX_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
 #define GEMV_IN_ACTFX     128  // (generation 4) down_proj whose input silu(g) * u is formed from the gate / up rows that a GEMV_OUT_ATOMIC gate|up launch ADDED into two
                               // fixed-point accumulators (act_g / act_u reinterpreted as int64 [m][k]): no slab reduction in the prologue, 2 KB per task
 #define GEMV_MAX_MATS 4

@@ -828,8 +828,8 @@ void fx_init_kernel(const half_t* __restrict__ x, long long* __restrict__ R, flo
     if (act)
     {
         long long* o = R + (size_t) row * hidden + blk * 128 + 4 * l;
-        o[0] = __double2ll_rn((double) r0 * GEMV_FX_SCALE); o[1] = __double2ll_rn((double) r1 * GEMV_FX_SCALE);
-        o[2] = __double2ll_rn((double) r2 * GEMV_FX_SCALE); o[3] = __double2ll_rn((double) r3 * GEMV_FX_SCALE);
+        o[0] = fx_from_float(r0); o[1] = fx_from_float(r1);                       // a NaN / Inf input row poisons its accumulator (exl3_gemv_args.h)
+        o[2] = fx_from_float(r2); o[3] = fx_from_float(r3);
     }
     float s2 = r0 * r0;
     s2 = __builtin_fmaf(r1, r1, s2); s2 = __builtin_fmaf(r2, r2, s2); s2 = __builtin_fmaf(r3, r3, s2);
@@ -849,7 +849,7 @@ void fx_finish_kernel(const long long* __restrict__ R, half_t* __restrict__ x, f
     const uint4_t* fp = (const uint4_t*) (R + (size_t) row * hidden + blk * 128) + 2 * l;
     const uint4_t f0 = fp[0], f1 = fp[1];
     // the conversion of the generation-4 GEMV's fixed-point input mode (exl3_gemv4.kspec.hip): same fp16 values
-    auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h((float) (int32_t) hi + (float) lo * 2.3283064365386963e-10f); };
+    auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h(fx_to_float(lo, hi)); };
     const half4_t r = { fx(f0.x, f0.y), fx(f0.z, f0.w), fx(f1.x, f1.y), fx(f1.z, f1.w) };
     if (act && x) ((half4_t*) (x + (size_t) row * hidden + blk * 128))[l] = r;
     const float r0 = (float) r.x, r1 = (float) r.y, r2 = (float) r.z, r3 = (float) r.w;
@@ -893,8 +893,8 @@ void fx_init_prep_kernel(const half_t* __restrict__ x, long long* __restrict__ R
     if (act)
     {
         long long* o = R + (size_t) row * hidden + blk * 128 + 4 * l;
-        o[0] = __double2ll_rn((double) r0 * GEMV_FX_SCALE); o[1] = __double2ll_rn((double) r1 * GEMV_FX_SCALE);
-        o[2] = __double2ll_rn((double) r2 * GEMV_FX_SCALE); o[3] = __double2ll_rn((double) r3 * GEMV_FX_SCALE);
+        o[0] = fx_from_float(r0); o[1] = fx_from_float(r1);                       // a NaN / Inf input row poisons its accumulator (exl3_gemv_args.h)
+        o[2] = fx_from_float(r2); o[3] = fx_from_float(r3);
     }
     float s2 = r0 * r0;
     s2 = __builtin_fmaf(r1, r1, s2); s2 = __builtin_fmaf(r2, r2, s2); s2 = __builtin_fmaf(r3, r3, s2);
@@ -927,7 +927,7 @@ void fx_finish_rotate_kernel(const long long* __restrict__ R, half_t* __restrict
     __shared__ float ss_s[256];
     const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5, nhw = blockDim.x >> 5, row = blockIdx.x;
     const int nblk = hidden >> 7;
-    auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h((float) (int32_t) hi + (float) lo * 2.3283064365386963e-10f); };
+    auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h(fx_to_float(lo, hi)); };
     // first pass: every block of the row (a half-wave takes blocks hw, hw + nhw, ...; hidden <= 4096: exactly one, kept in registers)
     half4_t r0v = { 0, 0, 0, 0 };
     for (int blk = hw; blk < nblk; blk += nhw)

@@ -4,6 +4,7 @@
 // One workgroup per row; E <= 512, K <= 16.  This is the caller of the indexed exl3_mgemm.
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
+#include "exl3_gemv_args.h"           // fx_to_float: the fixed-point residual's reader (NaN for a poisoned accumulator)
 
 #define ROUTING_MAX_EXPERTS 512
 #define ROUTING_MAX_K 16
@@ -42,7 +43,7 @@ void routing_std_kernel(const half_t* __restrict__ hidden, const half_t* __restr
         {
             const int nblk = H >> 7, l32 = tid & 31, nch4 = H >> 2;
             const int64_t* rg = (const int64_t*) hidden + (size_t) row * H;
-            auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h((float) (int32_t) hi + (float) lo * 2.3283064365386963e-10f); };
+            auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h(fx_to_float(lo, hi)); };
             auto block_ss = [&] (half4_t xv) -> float                        // sum of squares of one Hadamard block (32 consecutive threads), fixed order
             {
                 const float r0 = (float) xv.x, r1 = (float) xv.y, r2 = (float) xv.z, r3 = (float) xv.w;
@@ -423,7 +424,25 @@ void moe_scatter_kernel(const float* __restrict__ D, const int32_t* __restrict__
     for (int p = tid; p < T; p += 256)
         if (token_sorted[p] == t && rowmap[p] >= 0) { const int i = atomicAdd(&n_s, 1); if (i < 64) list_s[i] = p; }
     __syncthreads();
-    const int n = min(n_s, 64);
+    if (n_s > 64)
+    {
+        // more assignments than the list holds (never with top-k routing, where a token has <= 16): walk all of them in ascending p -- the same fixed
+        // order, no truncation, every thread reads the same p (broadcast loads)
+        for (int c = tid * 4; c < hidden; c += 1024)
+        {
+            float4_t acc = *((const float4_t*) (out + (size_t) t * hidden + c));
+            for (int p = 0; p < T; ++p)
+            {
+                if (token_sorted[p] != t || rowmap[p] < 0) continue;
+                const float w = (float) weight_sorted[p];
+                const float4_t d = *((const float4_t*) (D + (size_t) rowmap[p] * hidden + c));
+                acc.x += d.x * w; acc.y += d.y * w; acc.z += d.z * w; acc.w += d.w * w;
+            }
+            *((float4_t*) (out + (size_t) t * hidden + c)) = acc;
+        }
+        return;
+    }
+    const int n = n_s;
     if (n == 0) return;
     if (tid == 0)
         for (int i = 1; i < n; ++i) { const int v = list_s[i]; int k = i - 1; while (k >= 0 && list_s[k] > v) { list_s[k + 1] = list_s[k]; --k; } list_s[k + 1] = v; }

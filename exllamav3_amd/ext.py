@@ -390,7 +390,11 @@ def exl3_moe(hidden_state, output_state, expert_count, token_sorted, weight_sort
     # Every shape below depends on tensor SIZES only (no expert_count.tolist(), no boolean-mask indexing): the op is capturable in a hipGraph.
     # The slot list -- one slot = up to m consecutive assignments of one accepted expert -- is built on the device (exl3_moe_build_slots); unused
     # slots carry expert -1 and are skipped by the indexed launches; padded rows repeat an assignment and are never scattered (rowmap).
-    m = min(MOE_SLOT_ROWS, max_rows, T)
+    # Slot height: a token routes to DISTINCT experts, so an expert receives at most bsz rows -- at decode sizes (bsz 1..4) the slots are 1..4 rows and
+    # take the generation-4 launches; padding every slot to min(16, T) rows gathered up to top_k x the rows that exist.  (m is only a chunk size: an
+    # expert with more rows than m gets several slots, ns bounds their number.)
+    _req(max_rows >= 1, "exl3_moe: temp_state_g must hold at least one row per expert (max_tokens_per_expert >= 1)")
+    m = max(1, min(MOE_SLOT_ROWS, max_rows, T, bsz))
     ns = min(E, T) + T // m
     dev = hidden_state.device
     slot_expert = torch.empty((ns,), dtype=torch.long, device=dev)

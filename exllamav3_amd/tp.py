@@ -202,14 +202,38 @@ class TPBackendRCCL:
 
 
 
+class OneRankOfMany:
+    """Stand-in backend for measuring ONE rank's compute leg of a tensor-parallel job on a single GPU (bench.py's `llama-3.1-70b_tp8_rank` line,
+    tests/test_gpu_path.py::test_tp_rank_code_path_on_one_gpu): rank 0 of a world of `world_size` whose collectives are no-ops -- the model builds
+    that rank's column / row shards and runs the TP branch of the decode pipeline on its own partial sums.  NOT a collective backend: the numbers
+    it produces are per-rank partial results; the all-reduce is priced separately (bench.py adds a stated estimate)."""
+
+    def __init__(self, world_size: int, device: torch.device | None = None):
+        self.rank, self.world_size, self.device, self.ipc, self.calls = 0, world_size, device, None, 0
+
+    def all_reduce(self, tensor, contribution=True): self.calls += 1
+    def all_reduce_max(self, tensor): pass
+    def fwd_barrier(self): pass
+    def close(self): pass
+
+    def all_reduce_resid(self, y, resid, ss_part, m):
+        # TPBackendRCCL.all_reduce_resid's library route (all_reduce + glue_resid) with the exchange left out
+        from . import ext
+        self.calls += 1
+        ext.glue_resid(None, 0, None, None, resid, ss_part, m, y_dense=y)
+
+
 class IpcAllReduce:
     """Host side of exl3_allreduce.hip: this rank's receive buffer + the peers' buffers mapped through hipIpc handles exchanged over the process
     group.  Every rank must issue the same sequence of reduce() calls (a captured hipGraph replays them identically)."""
 
+    MAX_ELEMS = 8 * 512 * 128          # exl3_allreduce.hip: 8 * EXL3_AR_MAX_WGS tasks x 128 values (the grid has to be co-resident)
+
     def __init__(self, rank: int, world: int, device: torch.device, max_elems: int):
         from . import _lib
         self._lib = _lib.lib()
-        self.rank, self.world, self.device, self.max_elems = rank, world, device, int(max_elems)
+        # exl3_ar_create clamps to the one-shot push's launch bound (8 * 512 tasks of 128 values): larger messages take the collective library
+        self.rank, self.world, self.device, self.max_elems = rank, world, device, min(int(max_elems), self.MAX_ELEMS)
         self.ctx = None
 
     @classmethod

@@ -249,8 +249,13 @@ int exl3_gemv_ex_fx(const void* R, const void* norm_w, const float* ss_prev, flo
                     float** slabs_out, int* S_out, void* stream);
 /* ... with the gate / up rows ADDED into fixed-point accumulators accs[i] (int64 [m][n_i], zero on entry) instead of slabs, and the down_proj that
  * forms silu(g) * u from them (row-scale correction from ss_prev / ss_new) while it builds its activation quads: the silu_mul node of
- * libtorch/mlp.cpp:14-91 without a launch and without a slab reduction.  exl3_fx_zero_next(ptr, bytes): the NEXT generation-4 GEMV launch clears
- * that buffer as a side job (the o_proj launch zeroes the accumulators of the gate|up launch behind it: no memset node). */
+ * libtorch/mlp.cpp:14-91 without a launch and without a slab reduction.  exl3_fx_zero_next(ptr, bytes): the NEXT GEMV entry-point call made by THIS
+ * host thread on THIS device clears that buffer as a side job (the o_proj launch zeroes the accumulators of the gate|up launch behind it: no memset
+ * node).  One-shot: the request never outlives that call -- if it fails an argument check, or is not a plain (non-table) generation-4 launch, it
+ * returns EXL3_ERR_ARG ("cannot clear the buffer") and the request is dropped; (nullptr, 0) cancels.
+ * Non-finite values: a NaN / Inf / |v| >= 2^20 contribution REPLACES its accumulator with a poison value and every reader of an accumulator
+ * (the GEMV_IN_FX / GEMV_IN_ACTFX launches, exl3_fx_finish*, the fx router) turns a poisoned accumulator into NaN, so the failure reaches the logits as
+ * it does through the reference's fp16 residual (norm.cu:193-218). */
 int exl3_gemv_ex_fx_atomic(const void* R, const void* norm_w, const float* ss_prev, float* ss_out, float eps, const void* const* Bs,
                            void* const* accs, const void* const* suhs, const void* const* svhs, const int* ns, int count, int m, int k, int K,
                            int cb, int force_split, int* S_out, void* stream);

@@ -48,3 +48,31 @@ def test_bench_two_ranks_control_flow(dev):
     pf = d["prefill"]
     assert pf["n_gpus"] == 2 and pf["value"] > 0 and pf["allreduce"]["per_chunk"] == 4 and pf["allreduce"]["prefill_ms"] > 0
     assert pf["allreduce"]["message_bytes"] == 512 * 4096 * 4
+
+
+@pytest.mark.parametrize("name,K,cb,bsz,pipeline", [("llama-3.1-8b", 4, 2, 1, "fx"), ("llama-3.1-8b", 4, 0, 1, "fx"), ("llama-3.1-8b", 4, 2, 16, "fx"),
+                                                     ("llama-3.2-1b", 4, 2, 1, "fx"), ("llama-3.1-8b", 4, 2, 1, "glue"), ("llama-3.1-70b", 3, 2, 1, "fx")])
+def test_bench_pinned_logits_gate(dev, name, K, cb, bsz, pipeline):
+    """bench.py's correctness gate: the pipeline it times, over the pin model of the benchmark's shape, reproduces the oracle's committed logits
+    (tests/golden/bench_pins.json, re-derived from the oracle by tests/test_bench_pins.py) within 3e-2 * RMS, and its hipGraph replay equals the eager
+    step bit for bit.  The function asserts; here also that the pin exists (a missing pin would silently skip the gate)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.pinned_logits_check(name, K, cb, bsz, dev, pipeline)
+    assert r["pinned"] and r["ok"] and r["graph_replay_bit_equal"] and r["rel_err_vs_oracle"] < 3e-2
+
+
+def test_bench_pinned_logits_gate_catches_a_wrong_pipeline(dev, monkeypatch):
+    """The gate fails when the step is wrong: with the norm weights of the pin model perturbed after construction the assertion fires."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from exllamav3_amd.llama_path import SyntheticEXL3Llama
+    orig = SyntheticEXL3Llama.pin_model.__func__
+
+    def broken(cls, *a, **kw):
+        m = orig(cls, *a, **kw)
+        m.layers[0]["norm2"].mul_(1.5)
+        return m
+    monkeypatch.setattr(SyntheticEXL3Llama, "pin_model", classmethod(broken))
+    with pytest.raises(AssertionError):
+        bench.pinned_logits_check("llama-3.2-1b", 4, 2, 1, dev, "fx")

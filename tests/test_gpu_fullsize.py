@@ -212,3 +212,171 @@ def test_prefill_attention_8b_chunk_vs_oracle_on_sampled_queries(dev):
     out2 = torch.empty_like(q)
     ext.attn_prefill_paged(q, out2, kp2, vp2, bt, lens)
     assert torch.equal(out2[0, : p0 + 1], out[0, : p0 + 1]) and not torch.equal(out2[0, p0 + 1:], out[0, p0 + 1:])
+
+
+# ---- the SHIPPED DEFAULT decode pipelines at their own shapes: bench.py's headline runs decode_step_fx (generation-4 NORMFX input,
+# GEMV_OUT_ATOMIC epilogues at o_proj S = 8 / down k = 14336, fused q|k|v n = 6144 and gate|up n = 28672); these run exactly that, one layer of the real
+# shape + the real lm_head, against the ORACLE (chunked / threaded oracle linear above), incl. hipGraph replay ----------------------------------------------
+
+def _fill_ctx(model, li, bsz, rng, dev):
+    """Random quantized context in layer li's cache (contiguous pages per sequence in these models); returns the oracle-side packed arrays."""
+    hd, ctx = model.shape.head_dim, model.max_ctx
+    ck = rng.standard_normal((bsz, ctx, model.hkv * hd)).astype(np.float16); cv = rng.standard_normal((bsz, ctx, model.hkv * hd)).astype(np.float16)
+    kq, ks = o.kv_quant(ck, model.kv_bits); vq, vs = o.kv_quant(cv, model.kv_bits)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    kc, ksc = model.kcache[li]; vc, vsc = model.vcache[li]
+    kc.copy_(T(kq.view(np.int32)).view(kc.shape)); ksc.copy_(T(ks).view(ksc.shape)); vc.copy_(T(vq.view(np.int32)).view(vc.shape)); vsc.copy_(T(vs).view(vsc.shape))
+    return kq, ks, vq, vs
+
+
+def _oracle_attention_sublayer(model, L, x, pend, pos, ctx=None):
+    """norm1 (+ pending residual) -> q|k|v -> rope -> [quantized append + attention over the dequantized cache] -> o_proj.  Returns (x, o_out fp32, k4, v)."""
+    s, b = model.shape, x.shape[0]
+    hd = s.head_dim
+    if pend is None: xn = o.rms_norm(x, _np(L["norm1"]), model.eps)
+    else: xn, x = o.rms_norm(pend, _np(L["norm1"]), model.eps, residual_in=x)
+    q, k, v = _lin(L["q"], xn), _lin(L["k"], xn), _lin(L["v"], xn)
+    q4, k4 = o.rope(q.reshape(b, 1, model.hq, hd), k.reshape(b, 1, model.hkv, hd), _np(model.inv_freq), positions=_np(model.positions), rope_mode=o.ROPE_NEOX)
+    att = q4.reshape(b, -1)
+    if ctx is not None:
+        kq, ks, vq, vs = ctx
+        knq, kns = o.kv_quant(k4.reshape(b, 1, -1), model.kv_bits); vnq, vns = o.kv_quant(v.reshape(b, 1, -1), model.kv_bits)
+        kq[:, pos:pos + 1] = knq; ks[:, pos:pos + 1] = kns; vq[:, pos:pos + 1] = vnq; vs[:, pos:pos + 1] = vns
+        kd = o.kv_dequant(kq, ks, model.kv_bits).reshape(b, -1, model.hkv, hd); vd = o.kv_dequant(vq, vs, model.kv_bits).reshape(b, -1, model.hkv, hd)
+        att = o.attn_decode_qcache(q4.reshape(b, model.hq, hd), kd, vd, [pos + 1] * b).reshape(b, -1)
+    return x, _lin(L["o"], att, out_fp32=True), k4, v
+
+
+def _head_cols(vocab, seed=3):
+    rng = np.random.default_rng(seed)
+    starts = sorted({0, vocab - 128, *(int(b) * 128 for b in rng.integers(1, vocab // 128 - 1, size=6))})
+    return [(s0, min(s0 + 256, vocab)) if i % 2 else (s0, s0 + 128) for i, s0 in enumerate(starts)]
+
+
+def _check_logits_on_cols(logits, model, xn_final, cols, tol=3e-2):
+    ref = _lin(model.lm_head, xn_final, cols=cols).astype(np.float32)
+    got = np.concatenate([logits[:, a:b] for a, b in cols], axis=-1)
+    assert np.isfinite(logits).all()
+    err = _relerr(got, ref)
+    assert err < tol, err
+    return ref
+
+
+def _replay_equals(step, model, logits, reps=3):
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            step()
+    for _ in range(reps):
+        model.logits.zero_(); g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(_np(model.logits.float()), logits)
+
+
+def _appended_kv_close(model, li, bsz, pos, k4, v, tol=0.2):
+    """The K / V rows the step appended to the quantized cache against the oracle's quantize -> dequantize of ITS rope(k) / v.  Both sides are dequantized
+    with the oracle; the inputs differ by the linears' rounding (1e-3), so a few levels may flip (one flip moves the 32 values of its group by
+    step / sqrt(32) ~ 0.05 sigma at 4 bits): bound 0.2 of the row's RMS, which a wrong slot / head / rope pairing misses by an order of magnitude."""
+    kc, ks = model.kcache[li]; vc, vs = model.vcache[li]
+    bits = model.kv_bits
+    for b in range(bsz):
+        page, slot = int(model.block_table[b, pos // model.page]), pos % model.page
+        for (c, s_), ref in (((kc, ks), k4[b].reshape(1, 1, -1)), ((vc, vs), v[b].reshape(1, 1, -1))):
+            got = o.kv_dequant(_np(c[page, slot]).view(np.uint32)[None, None], _np(s_[page, slot])[None, None], bits).reshape(-1).astype(np.float32)
+            rq, rs = o.kv_quant(np.ascontiguousarray(ref).astype(np.float16), bits)
+            want = o.kv_dequant(rq, rs, bits).reshape(-1).astype(np.float32)
+            assert np.abs(got - want).max() / np.sqrt((want ** 2).mean()) < tol * (16.0 / 2 ** bits)
+
+
+@pytest.mark.parametrize("bsz,cb,with_attention", [(1, 2, False), (2, 2, False), (1, 0, False), (1, 2, True)])
+def test_fx_decode_step_llama_8b_layer_and_head_vs_oracle(dev, bsz, cb, with_attention):
+    """decode_step_fx -- bench.py's headline pipeline -- on ONE Llama-3.1-8B layer (hidden 4096, 32 / 8 heads x 128, inter 14336) + the 128256-column
+    lm_head at 4 bpw, batch 1 and 2, mul1 and 3INST, both forms of the MLP (glue_act_rs launch / silu * mul inside the down launch), and with the
+    decode attention over a 1000-token 4-bit cache in the step (the driver line's with_attention config): logits on sampled column ranges, the final
+    residual (all hidden columns) and the appended K / V rows against the oracle; hipGraph replay reproduces the eager bits."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_variant(1)
+    shape = LlamaShape("8b-1layer", 4096, 14336, 1, 32, 8, 128, 128256)
+    model = SyntheticEXL3Llama(shape, K=4, cb=cb, device=dev, kv_bits=4, max_ctx=1024)
+    pos = 1000 if with_attention else 700
+    model.alloc_state(bsz, pos=pos)
+    model.with_attention = with_attention
+    assert bsz <= model.fx_max_bsz                         # i.e. bench.py really takes this pipeline at this batch
+    ctx = _fill_ctx(model, 0, bsz, np.random.default_rng(5), dev) if with_attention else None
+    # ---- oracle, once
+    L = model.layers[0]
+    x, ov, k4, v = _oracle_attention_sublayer(model, L, _np(model.x0), None, pos, ctx)
+    xn, x = o.rms_norm(ov, _np(L["norm2"]), model.eps, residual_in=x)
+    gf, uf = _lin(L["gate"], xn).astype(np.float32), _lin(L["up"], xn).astype(np.float32)
+    a = (gf / (1 + np.exp(-gf)) * uf).astype(np.float16)
+    d = _lin(L["down"], a, out_fp32=True)
+    xn_f, x_f = o.rms_norm(d, _np(model.final_norm), model.eps, residual_in=x)
+    cols = _head_cols(shape.vocab)
+    for act_in in (False, True):
+        model.fx_act_in_gemv = act_in
+        for c, s_ in model.kcache + model.vcache:
+            if not with_attention: c.zero_(); s_.zero_()
+        logits = _np(model.decode_step_fx().float()).copy()
+        _check_logits_on_cols(logits, model, xn_f, cols)
+        assert _relerr(_np(model.x_final.float()), x_f) < 1e-2
+        _appended_kv_close(model, 0, bsz, pos, k4, v)
+        assert np.array_equal(_np(model.decode_step_fx().float()), logits)          # integer atomics: the same bits every time
+        _replay_equals(model.decode_step_fx, model, logits)
+
+
+def test_fx_decode_step_llama_1b_layer_and_head_vs_oracle(dev):
+    """Llama-3.2-1B's default step (config 2: hidden 2048, head_dim 64, inter 8192; decode_step_fx in its 5-launch form, silu * mul inside the down
+    launch) on one layer + the lm_head against the oracle, then graph replay."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_variant(1)
+    shape = LlamaShape("1b-1layer", 2048, 8192, 1, 32, 8, 64, 128256)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=1024)
+    assert model.fx_act_in_gemv                             # the default of this size
+    model.alloc_state(1, pos=700)
+    L = model.layers[0]
+    x, ov, k4, v = _oracle_attention_sublayer(model, L, _np(model.x0), None, 700)
+    xn, x = o.rms_norm(ov, _np(L["norm2"]), model.eps, residual_in=x)
+    gf, uf = _lin(L["gate"], xn).astype(np.float32), _lin(L["up"], xn).astype(np.float32)
+    a = (gf / (1 + np.exp(-gf)) * uf).astype(np.float16)
+    d = _lin(L["down"], a, out_fp32=True)
+    xn_f, x_f = o.rms_norm(d, _np(model.final_norm), model.eps, residual_in=x)
+    logits = _np(model.decode_step_fx().float()).copy()
+    _check_logits_on_cols(logits, model, xn_f, _head_cols(shape.vocab))
+    assert _relerr(_np(model.x_final.float()), x_f) < 1e-2
+    _appended_kv_close(model, 0, 1, 700, k4, v)
+    _replay_equals(model.decode_step_fx, model, logits)
+
+
+@pytest.mark.parametrize("with_attention", [False, True])
+def test_fx_decode_step_mixtral_8x7b_layer_vs_oracle(dev, with_attention):
+    """mixtral_path.decode_step_fx (config 5's default on one rank: MoE block in 3 launches, weighted expert rows added into the fixed-point residual)
+    on ONE Mixtral-8x7B layer (hidden 4096, inter 14336, 8 experts top-2, vocab 32000) against the ORACLE composition -- not the launch-per-op step."""
+    from exllamav3_amd.mixtral_path import MixtralShape, SyntheticEXL3Mixtral
+    shape = MixtralShape("mixtral-1layer", 4096, 14336, 1, 32, 8, 128, 32000, 8, 2)
+    model = SyntheticEXL3Mixtral(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=1024)
+    pos = 1000 if with_attention else 300
+    model.alloc_state(1, pos=pos)
+    model.with_attention = with_attention
+    ctx = _fill_ctx(model, 0, 1, np.random.default_rng(9), dev) if with_attention else None
+    logits = _np(model.decode_step_fx().float()).copy()
+    L = model.layers[0]; moe = L["moe"]
+    x, ov, k4, v = _oracle_attention_sublayer(model, L, _np(model.x0), None, pos, ctx)
+    xn, x = o.rms_norm(ov, _np(L["norm2"]), model.eps, residual_in=x)
+    _, sel, w = o.routing_std(xn, _np(moe.router), 2)
+    assert np.array_equal(_np(moe.sel), sel)
+    y = np.zeros((1, shape.hidden), dtype=np.float32)
+    for j in range(2):
+        e = int(sel[0, j])
+        g = _lin(moe.gate[e], xn).astype(np.float32); u = _lin(moe.up[e], xn).astype(np.float32)
+        a = (g / (1 + np.exp(-g)) * u).astype(np.float16)
+        y += float(w[0, j]) * _lin(moe.down[e], a, out_fp32=True)
+    xn_f, x_f = o.rms_norm(y, _np(model.final_norm), model.eps, residual_in=x)
+    ref = _lin(model.lm_head, xn_f).astype(np.float32)
+    assert np.isfinite(logits).all()
+    assert _relerr(logits, ref) < 3e-2
+    assert _relerr(_np(model.x.float()), x_f) < 1e-2
+    _appended_kv_close(model, 0, 1, pos, k4, v)
+    _replay_equals(model.decode_step_fx, model, logits)

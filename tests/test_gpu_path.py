@@ -890,15 +890,9 @@ def test_tp_rank_code_path_on_one_gpu(dev, model_name, tp, bsz):
     from exllamav3_amd import ext
     from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
 
-    class OneRankOfMany:
-        def __init__(self, world): self.rank, self.world_size, self.calls = 0, world, 0
-        def all_reduce(self, tensor, contribution=True): self.calls += 1
-        def fwd_barrier(self): pass
-        def all_reduce_resid(self, y, resid, ss_part, m):            # TPBackendRCCL.all_reduce_resid's fallback route: all_reduce + glue_resid
-            self.all_reduce(y)
-            ext.glue_resid(None, 0, None, None, resid, ss_part, m, y_dense=y)
+    from exllamav3_amd.tp import OneRankOfMany                          # no-op collectives: one rank's compute leg (bench.py uses the same stand-in)
 
-    be = OneRankOfMany(tp)
+    be = OneRankOfMany(tp, dev)
     model = SyntheticEXL3Llama(SHAPES[model_name], K=4, cb=2, device=dev, backend=be, kv_bits=4, max_ctx=1024, layers=1)
     s = SHAPES[model_name]
     assert (model.hq, model.hkv) == (s.heads_q // tp, s.heads_kv // tp) and model.layers[0]["down"].in_features == model.inter_local
@@ -1110,6 +1104,65 @@ def test_fixed_point_residual_pipeline_scale_change_large_values_and_bias(dev):
     ref = (r0.astype(np.float32) + y)
     assert np.abs(out.float().cpu().numpy() - ref).max() / np.sqrt((y ** 2).mean()) < 1e-2
     assert np.allclose(ss.cpu().numpy(), (out.float().cpu().numpy().reshape(m, -1, 128) ** 2).sum(-1), rtol=1e-4)
+
+
+@pytest.mark.parametrize("act_in", [False, True])
+def test_fixed_point_residual_pipeline_carries_nan_inf_and_overflow_to_the_logits(dev, act_in):
+    """the reference's fp16 residual carries NaN / Inf through to the logits (norm.cu:193-218); the fixed-point accumulator must
+    not turn them into finite garbage.  (a) Inf / NaN in one input row: that row's logits are non-finite, the other row's are bit-identical to a clean
+    run; (b) an o_proj whose outputs overflow the accumulator's range (svh x 3e6: |o| >= 2^20 poisons the accumulator instead of wrapping
+    __double2ll_rn): non-finite logits; (c) the same model with a merely LARGE jump (x 300, representable) still matches the oracle."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 512, 1024, 2, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(2, pos=100)
+    model.fx_act_in_gemv = act_in
+    clean = model.decode_step_fx().float().cpu().numpy().copy()
+    assert np.isfinite(clean).all()
+    x_keep = model.x0.clone()
+    for bad in (float("inf"), float("nan"), -float("inf")):
+        model.x0.copy_(x_keep); model.x0[0, 5] = bad
+        lg = model.decode_step_fx().float().cpu().numpy()
+        assert not np.isfinite(lg[0]).any(), bad                           # the Hadamard spreads the bad value over the block, the linears over every output
+        assert np.array_equal(lg[1], clean[1]), bad
+    model.x0.copy_(x_keep)
+    sv_keep = model.layers[0]["o"].svh.clone()
+    model.layers[0]["o"].svh.mul_(300.0)                                    # (c) first: large but representable
+    lg = model.decode_step_fx().float().cpu().numpy().copy()
+    ref = _oracle_decode(model, _np(model.x0))
+    assert np.isfinite(lg).all() and np.abs(lg - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+    model.layers[0]["o"].svh.copy_(sv_keep.float().mul(3e6).clamp(-6e4, 6e4).half())     # (b): |o| far beyond 2^20
+    lg = model.decode_step_fx().float().cpu().numpy()
+    assert not np.isfinite(lg).any()
+    model.layers[0]["o"].svh.copy_(sv_keep)
+    assert np.array_equal(model.decode_step_fx().float().cpu().numpy(), clean)          # nothing sticks: the accumulator is re-initialised every step
+
+
+def test_fx_zero_request_never_outlives_the_next_launch(dev):
+    """exl3_fx_zero_next is one-shot and tied to the launch that follows on this thread -- a following launch that cannot clear the
+    buffer (generation 3: 16 rows) fails loudly and DROPS the request, so a later unrelated generation-4 launch leaves the buffer alone."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import _rand_linear
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    L = _rand_linear(512, 256, 4, 2, dev, gen)
+    buf = torch.full((1024,), 7, dtype=torch.int64, device=dev)
+    x16 = torch.randn((16, 512), device=dev, generator=gen).half(); y16 = torch.empty((16, 256), dtype=torch.half, device=dev)
+    x1 = x16[:1].contiguous(); y1 = torch.empty((1, 256), dtype=torch.half, device=dev)
+    ext.fx_zero_next(buf)
+    with pytest.raises(RuntimeError, match="cannot clear"):
+        ext.exl3_gemm(x16, L.trellis, y16, L.suh, torch.empty_like(x16), L.svh, -1, False, True, 0)
+    ext.exl3_gemm(x1, L.trellis, y1, L.suh, torch.empty_like(x1), L.svh, -1, False, True, 0)       # the dropped request must not fire here
+    torch.cuda.synchronize()
+    assert bool((buf == 7).all())
+    ext.fx_zero_next(buf)                                                    # ... and the intended use clears it exactly once
+    ext.exl3_gemm(x1, L.trellis, y1, L.suh, torch.empty_like(x1), L.svh, -1, False, True, 0)
+    torch.cuda.synchronize()
+    assert bool((buf == 0).all())
+    buf.fill_(7)
+    ext.exl3_gemm(x1, L.trellis, y1, L.suh, torch.empty_like(x1), L.svh, -1, False, True, 0)
+    torch.cuda.synchronize()
+    assert bool((buf == 7).all())
 
 
 @pytest.mark.parametrize("hd,hq,hkv", [(128, 4, 2), (64, 8, 4)])
