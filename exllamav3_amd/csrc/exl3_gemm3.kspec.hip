@@ -13,6 +13,13 @@
 // not k: every wave walks the whole slice.  Nothing is reduced across waves -- no partial sums through LDS, no barrier after the
 // streaming loop, 8 accumulator VGPRs per 16 rows -- and all waves have exactly the same amount of work.
 //
+// Round 4: a workgroup may hold 4, 8 or 16 waves (NWT) = 1, 2 or 4 ADJACENT column blocks of one matrix over the same k-slice.  The waves are as
+// independent as before; what they share is the activation tile in LDS.  With one column block per workgroup every one of the 224 gate|up column
+// blocks copied the same 16 x k activations: 30 MB of L2 -> LDS traffic per launch beside 59 MB of weights, all of it requested in the launch's first
+// microsecond in front of the workgroups' weight rows -- tools/gemv_timeline.py (BSZ=16) showed 2..12 us from entry to "activations staged" once four
+// workgroups shared a CU, so higher occupancy bought nothing (gate|up S = 2 / 4 / 8: the same 24 us).  Four column blocks per workgroup quarter
+// that traffic and the LDS footprint (a whole k = 4096 slice of 16 rows fits: no chunk loop for the lm_head), one workgroup fills a CU.
+//
 // Lane geometry of a decode step (4 tile rows x the wave's 2 tiles): lane = 16 g + 8 t2 + c owns, as in exl3_lane_decode.cuh, the K
 // words [cK, cK + K) of tile (2 wave + t2) of tile row 4 step + g = columns c, c + 8 of that tile, 16 k each: one 16-byte load per lane
 // (K = 4), 256 contiguous bytes per 16-lane group.
@@ -38,15 +45,21 @@ __device__ __forceinline__ void g3_static_for(F&& f)
 }
 
 #define G3_XPAD 16
-#define G3_WAVES 4
+#ifndef G3_NR
+#define G3_NR 4            // weight-ring depth in decode steps (A/B builds: 8)
+#endif
 
 constexpr int g3_waves_per_eu(int K, int MT, bool ROT, bool RAW)
 {
     (void) RAW;                                      // the raw variant is instantiated for the rotated-input prologue only, whose budgets cover its row-sum accumulators
+    if (MT == 4 && K == 7 && !ROT) return 2;         // (round 4, likewise: 7-word ring slots)
+    if (MT == 2 && K == 3 && !ROT) return 4;         // (round 4: the step-granular ring needs 2 more registers here than the 96 of five waves per SIMD)
     return MT == 4 ? (ROT ? (K >= 5 ? 2 : 3) : ((K == 4 || K <= 2) ? 4 : 3)) : ((K >= 7 || (ROT && K >= 5)) ? 3 : ((ROT || K >= 5) ? 4 : 5));
 }
+// waves per workgroup an instantiation can run with: 16 waves on 4 SIMDs need the 4-waves-per-SIMD register budget (128 VGPRs), 8 waves the 2-waves one
+constexpr bool g3_nwt_ok(int K, int MT, bool ROT, bool RAW, int NWT) { return NWT == 4 || (MT == 1 && g3_waves_per_eu(K, MT, ROT, RAW) >= NWT / 4); }
 
-template <int K, int CB, int MT, bool ROT, bool RAWV>
+template <int K, int CB, int MT, bool ROT, bool RAWV, int NWT>
 // RAWV (mul1 codebook, rotated input = the fused decode pipeline, the library's default GEMV variant): the weights enter the matrix instructions as the packed byte sums 1024 + s the
 // decode produces (exact fp16 integers) instead of fp16(kinv * (1024 + s) + kbias); the affine map is applied once per output,
 // out = kinv * acc + kbias * sum_k x[row][k], with the row sums taken from the producer's per-block sums (mat[].xsum; launches without them take the
@@ -56,7 +69,7 @@ template <int K, int CB, int MT, bool ROT, bool RAWV>
 // five 4-wave workgroups per CU (LDS: 5 x 31 KB) need <= 96 VGPRs; the 64-row passes, the ROT prologue (16 registers of activation copy in
 // flight next to the weight ring) and the wide rings of K >= 5 take the next register budgets instead of spilling (any scratch use slows
 // every launch); the table below is what hipcc 7.2 needs for zero scratch in every (K, codebook, MT, ROT) instantiation
-__global__ __launch_bounds__(64 * G3_WAVES) __attribute__((amdgpu_waves_per_eu(g3_waves_per_eu(K, MT, ROT, RAWV && CB == EXL3_CB_MUL1))))
+__global__ __launch_bounds__(64 * NWT) __attribute__((amdgpu_waves_per_eu(g3_waves_per_eu(K, MT, ROT, RAWV && CB == EXL3_CB_MUL1))))
 void exl3_gemm3_kernel(const GemvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -91,7 +104,13 @@ void exl3_gemm3_kernel(const GemvArgs a)
     for (int i = 1; i < GEMV_MAX_MATS; ++i) if (i < a_nm && cbg >= a_cbf[i]) mi = i;
     const uint32_t* __restrict__ Bm = a.mat[mi].B;
     const half_t* __restrict__ suh = a.mat[mi].suh;
-    const int n = a.mat[mi].n, cbl = cbg - a.mat[mi].cb_first, ws_off = a.mat[mi].ws_offset;
+    const int n = a.mat[mi].n, ws_off = a.mat[mi].ws_offset;
+    // the wave's column block: group (cbg - first group of the matrix) x CPW + wave / 4; wv = the wave's 32-column quarter of it.  A matrix whose column
+    // blocks do not fill its last group leaves waves without one: they stage and synchronise with the others, stream a clamped (valid) block and store nothing
+    constexpr int CPW = NWT / 4;
+    const int cb_want = (cbg - a.mat[mi].cb_first) * CPW + (wave >> 2), wv = wave & 3;
+    const bool has_cb = cb_want < (n >> 7);
+    const int cbl = has_cb ? cb_want : (n >> 7) - 1;
     {
         // everything the first vector loads need, in the SECOND batch of scalar loads (the matrix record depends on mi): left alone, the compiler sank
         // mat[mi].B and chunk_blocks behind the first branch -- a third scalar round trip between entry and the first weight request (ISA, round 3)
@@ -111,12 +130,12 @@ void exl3_gemm3_kernel(const GemvArgs a)
     const int l32 = lane & 31;
     constexpr bool in_rotated = ROT;
     const half_t* __restrict__ x_src = in_rotated ? a.mat[mi].xh : a_A;
-    const int hwid = tid >> 5, nhw = G3_WAVES * 2;
+    const int hwid = tid >> 5, nhw = NWT * 2;
 
     // decode geometry
     const int g = lane >> 4, t2 = (lane >> 3) & 1, c = lane & 7;
     const size_t row_stride = (size_t) tiles_n * NW;
-    const uint32_t* __restrict__ strip = Bm + ((size_t) (k0s >> 4) + g) * row_stride + (size_t) (cbl * 8 + 2 * wave + t2) * NW + (size_t) c * K;
+    const uint32_t* __restrict__ strip = Bm + ((size_t) (k0s >> 4) + g) * row_stride + (size_t) (cbl * 8 + 2 * wv + t2) * NW + (size_t) c * K;
 
     constexpr bool RAW = RAWV && CB == EXL3_CB_MUL1;
     float4_t acc[MT][2];
@@ -160,8 +179,8 @@ void exl3_gemm3_kernel(const GemvArgs a)
     // already rotated input (glue_rotate / glue_act): a straight copy in 16-byte pieces.  A row of the chunk is <= 2^cp_sl pieces; thread =
     // (row tid >> cp_sl of the instruction's 256 >> cp_sl rows, piece tid & (2^cp_sl - 1)); four instructions in flight per thread, so one batch
     // covers 16 rows at up to 4 blocks per chunk (the decode shapes), 32 rows at 2, 64 rows at 1
-    const int cp_sl = chb <= 1 ? 4 : (chb <= 2 ? 5 : (chb <= 4 ? 6 : 7));
-    const int cp_piece = tid & ((1 << cp_sl) - 1), cp_rsub = tid >> cp_sl, cp_rows = (64 * G3_WAVES) >> cp_sl;
+    const int cp_sl = chb <= 1 ? 4 : (chb <= 2 ? 5 : (chb <= 4 ? 6 : (chb <= 8 ? 7 : (chb <= 16 ? 8 : 9))));       // (host: 16 chb <= 64 NWT)
+    const int cp_piece = tid & ((1 << cp_sl) - 1), cp_rsub = tid >> cp_sl, cp_rows = (64 * NWT) >> cp_sl;
     auto copy_load = [&] (int c0, int cnt, int base, uint4_t (&v)[4])
     {
         const half_t* src0 = x_src + (size_t) k0s + 128 * c0 + 8 * min(cp_piece, cnt * 16 - 1);
@@ -182,16 +201,21 @@ void exl3_gemm3_kernel(const GemvArgs a)
     uint4_t cv[4];
     if constexpr (in_rotated) copy_load(0, min(chb, nb), 0, cv); else nx = fetch(0, min(chb, nb), 0);
 
-    // weight ring: two slots of one Hadamard block (8 tile rows = 2 decode steps) each
-    LaneWords<K> ring[2][2];
-    auto load_block = [&] (LaneWords<K> (&slot)[2], int blk)
-    {
-        const uint32_t* p = strip + (size_t) (8 * min(blk, nb - 1)) * row_stride;
-        load_lane_words<K>(slot[0], p);
-        load_lane_words<K>(slot[1], p + 4 * row_stride);
-    };
-    load_block(ring[0], 0);
-    load_block(ring[1], 1);
+    // weight ring: G3_NR slots of ONE decode step (4 tile rows) each, consumed round-robin by a loop that is unrolled G3_NR steps per trip, so every slot
+    // is a fixed register set and every wait is countable: in front of step j exactly G3_NR - 1 younger ring loads are outstanding (round 4: the previous
+    // two-block ring with its slot swap for odd block counts and the next chunk's activation rows requested across the loop made the compiler wait with
+    // vmcnt(0) at the loop head, i.e. for the refill issued a step earlier -- one full memory round trip exposed per trip: tools/isa_blocks.py, the reason
+    // the 16-row pass ran at 45 % of its decode VALU bound)
+    constexpr int NR = G3_NR;
+    const int nsteps = 2 * nb;
+    LaneWords<K> ring[NR];
+#ifdef G3_ABL_HOT
+    auto step_ptr = [&] (int st) -> const uint32_t* { return strip + (size_t) (4 * (min(st, nsteps - 1) & 3)) * row_stride; };      // ablation: cache-hot rows
+#else
+    auto step_ptr = [&] (int st) -> const uint32_t* { return strip + (size_t) (4 * min(st, nsteps - 1)) * row_stride; };
+#endif
+    #pragma unroll
+    for (int u = 0; u < NR; ++u) load_lane_words<K>(ring[u], step_ptr(u));
     G3_T(1);
 
     // MFMA operand geometry
@@ -200,69 +224,103 @@ void exl3_gemm3_kernel(const GemvArgs a)
     #pragma unroll
     for (int i = 0; i < MT; ++i) arow[i] = xa + (size_t) min(16 * i + mj, m - 1) * ldx + 16 * kg;
 
-    // one Hadamard block (2 decode steps) from a ring slot; kloc = chunk-local k of the block
-    auto do_block = [&] (LaneWords<K> (&slot)[2], int kloc, int refill_blk)
+    // one decode step (4 tile rows x the wave's 2 tiles) from ring slot `slot`; kloc = chunk-local k of the step; the slot is refilled with step `refill`
+    auto do_step = [&] (LaneWords<K>& slot, int kloc, int refill)
     {
+        uint32_t Wx[K + 1];
         #pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
+        for (int i = 0; i < K; ++i) Wx[i + 1] = slot.w[i];
+        // carry-in = last word of the previous lane of the 8-lane tile group (c = 0 wraps to c = 7): two DPP row rotates + a select, register
+        // file only (generation 4's form; this was a ds_bpermute, i.e. an LDS-crossbar round trip in front of every decode step)
         {
-            uint32_t Wx[K + 1];
-            #pragma unroll
-            for (int i = 0; i < K; ++i) Wx[i + 1] = slot[sub].w[i];
-            // carry-in = last word of the previous lane of the 8-lane tile group (c = 0 wraps to c = 7): two DPP row rotates + a select, register
-            // file only (generation 4's form; this was a ds_bpermute, i.e. an LDS-crossbar round trip in front of every decode step)
-            {
-                const uint32_t wl = slot[sub].w[K - 1];
-                const uint32_t r1 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x121, 0xf, 0xf, true);
-                const uint32_t r9 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x129, 0xf, 0xf, true);
-                Wx[0] = (lane & 7) ? r1 : r9;
-            }
-            // refill the slot half that was just consumed
-            load_lane_words<K>(slot[sub], strip + (size_t) (8 * refill_blk + 4 * sub) * row_stride);
+            const uint32_t wl = slot.w[K - 1];
+            const uint32_t r1 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x121, 0xf, 0xf, true);
+            const uint32_t r9 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x129, 0xf, 0xf, true);
+            Wx[0] = (lane & 7) ? r1 : r9;
+        }
+#ifdef G3_REFILL_EARLY
+        load_lane_words<K>(slot, step_ptr(refill));     // A/B: refill right after the words were copied out (the compiler then copies ring registers at the loop head and waits with vmcnt(0))
+#endif
 
-            // exact fp16 weights: quad q of column c / c + 8 = rows {2q, 2q+1 | 2q+8, 2q+9}: low words -> rows 0..7, high words -> rows 8..15
-            uint32_t clo[4], chi[4], dlo[4], dhi[4];
-            g3_static_for<0, 4>([&] (auto qc)
-            {
-                constexpr int q = decltype(qc)::value;
-                half4_t bc[2], bd[2];
-                decode_quad<K, CB, RAW ? 1 : 0, 8 * q>(Wx, bc);
-                decode_quad<K, CB, RAW ? 1 : 0, 8 * q + 4>(Wx, bd);
-                union { half4_t h; uint32_t w[2]; } uc, ud; uc.h = bc[0]; ud.h = bd[0];
-                clo[q] = uc.w[0]; chi[q] = uc.w[1]; dlo[q] = ud.w[0]; dhi[q] = ud.w[1];
-                __builtin_amdgcn_sched_barrier(0);      // bound live ranges: 8 weights in flight at a time (occupancy > ILP here)
-            });
-            union { uint32_t w[4]; half8_t h; } bc[2], bd[2];       // [k 0..7 | k 8..15 of the lane's tile row] of column c / c + 8
+        // A operands of the step: 16-row passes request them before the decode and consume them after it (8 registers); the 32- / 64-row passes read
+        // them in front of each half's matrix instructions (their register budgets are full: any spill costs 1.5..3 us per launch)
+        constexpr bool AF_EARLY = MT == 1;
+        half8_t af[2][MT];
+#ifdef G3_ABL_NOLDS
+        // ablation: no A-operand reads (garbage activations from registers)
+        #pragma unroll
+        for (int h = 0; h < 2; ++h)
             #pragma unroll
-            for (int q = 0; q < 4; ++q) { bc[0].w[q] = clo[q]; bc[1].w[q] = chi[q]; bd[0].w[q] = dlo[q]; bd[1].w[q] = dhi[q]; }
+            for (int i = 0; i < MT; ++i) { union { uint32_t w[4]; half8_t h8; } u_; u_.w[0] = Wx[1]; u_.w[1] = kloc; u_.w[2] = lane; u_.w[3] = h; af[h][i] = u_.h8; }
+#else
+        if constexpr (AF_EARLY)
+        {
             #pragma unroll
             for (int h = 0; h < 2; ++h)
+                #pragma unroll
+                for (int i = 0; i < MT; ++i) af[h][i] = *((const half8_t*) (arow[i] + kloc + 8 * h));
+        }
+#endif
+
+        // exact fp16 weights: quad q of column c / c + 8 = rows {2q, 2q+1 | 2q+8, 2q+9}: low words -> rows 0..7, high words -> rows 8..15
+        uint32_t clo[4], chi[4], dlo[4], dhi[4];
+#ifdef G3_ABL_NODECODE
+        // ablation: no decode arithmetic (the loaded words go to the matrix instructions as they are)
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) { clo[q] = Wx[1 + (q % K)]; chi[q] = Wx[1 + ((q + 1) % K)] ^ Wx[0]; dlo[q] = Wx[1 + ((q + 2) % K)]; dhi[q] = Wx[1 + ((q + 3) % K)]; }
+        if (false)
+#endif
+        g3_static_for<0, 4>([&] (auto qc)
+        {
+            constexpr int q = decltype(qc)::value;
+            half4_t bc[2], bd[2];
+            decode_quad<K, CB, RAW ? 1 : 0, 8 * q>(Wx, bc);
+            decode_quad<K, CB, RAW ? 1 : 0, 8 * q + 4>(Wx, bd);
+            union { half4_t h; uint32_t w[2]; } uc, ud; uc.h = bc[0]; ud.h = bd[0];
+            clo[q] = uc.w[0]; chi[q] = uc.w[1]; dlo[q] = ud.w[0]; dhi[q] = ud.w[1];
+            __builtin_amdgcn_sched_barrier(0);          // bound live ranges: 8 weights in flight at a time (occupancy > ILP here)
+        });
+#ifndef G3_REFILL_EARLY
+        // refill the slot once its words are dead (clamped: a harmless reload at the end of the slice): the load lands in place, the ring needs no register
+        // copies, and the compiler's waits in the one-chunk loop are counted -- vmcnt(3) / (3) / (2) / (2) at NR = 4 (hipcc 7.2 ISA; tests/test_isa_guards.py)
+        load_lane_words<K>(slot, step_ptr(refill));
+#endif
+        union { uint32_t w[4]; half8_t h; } bc[2], bd[2];           // [k 0..7 | k 8..15 of the lane's tile row] of column c / c + 8
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) { bc[0].w[q] = clo[q]; bc[1].w[q] = chi[q]; bd[0].w[q] = dlo[q]; bd[1].w[q] = dhi[q]; }
+        #pragma unroll
+        for (int h = 0; h < 2; ++h)
+        {
+#ifndef G3_ABL_NOLDS
+            if constexpr (!AF_EARLY)
             {
-                half8_t af[MT];
                 #pragma unroll
-                for (int i = 0; i < MT; ++i) af[i] = *((const half8_t*) (arow[i] + kloc + 64 * sub + 8 * h));
-                #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bc[h].h, acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bd[h].h, acc[i][1], 0, 0, 0);
-                }
+                for (int i = 0; i < MT; ++i) af[h][i] = *((const half8_t*) (arow[i] + kloc + 8 * h));
+            }
+#endif
+            #pragma unroll
+            for (int i = 0; i < MT; ++i)
+            {
+#ifdef G3_ABL_NOMFMA
+                // ablation: no matrix instructions (the operands stay live through one cheap VALU op each)
+                acc[i][0][0] += (float) af[h][i][0] + (float) bc[h].h[0] + (float) bc[h].h[2] + (float) bc[h].h[4] + (float) bc[h].h[6];
+                acc[i][1][0] += (float) af[h][i][1] + (float) bd[h].h[0] + (float) bd[h].h[2] + (float) bd[h].h[4] + (float) bd[h].h[6];
+#else
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[h][i], bc[h].h, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[h][i], bd[h].h, acc[i][1], 0, 0, 0);
+#endif
             }
         }
     };
 
-    for (int c0 = 0; c0 < nb; c0 += chb)
+    // activations of blocks [c0, c0 + cnt) of the slice -> LDS, row-major (the chunk's first batch of rows may already be in `cv` / `nx`)
+    auto stage_chunk = [&] (int c0, int cnt, bool first)
     {
-        const int cnt = min(chb, nb - c0);
-        if (c0 > 0) __syncthreads();
-
-        // ---- activations of blocks [c0, c0 + cnt) -> LDS, row-major
         if constexpr (in_rotated)
         {
-            // the first batch of rows is already in registers (requested before the weight ring, or during the previous chunk's streaming)
             for (int base = 0; base < m; base += 4 * cp_rows)
             {
-                if (base > 0) copy_load(c0, cnt, base, cv);
+                if (base > 0 || !first) copy_load(c0, cnt, base, cv);
                 copy_store(cnt, base, cv);
             }
         }
@@ -271,7 +329,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
             // cooperative input Hadamards: task t = (block t / m, row t % m), one per half-wave, software pipelined by one
             const int ntask = cnt * m;
             const int trips = (ntask + nhw - 1) / nhw;
-            if (c0 > 0) nx = fetch(c0, cnt, 0);
+            if (!first) nx = fetch(c0, cnt, 0);
             for (int it = 0; it < trips; ++it)
             {
                 const PrepIn cur = nx;
@@ -287,24 +345,68 @@ void exl3_gemm3_kernel(const GemvArgs a)
                 if (act) *((half4_t*) (xa + (size_t) row * ldx + blk_l * 128 + 4 * l32)) = o;
             }
         }
-        __syncthreads();
-        if (c0 == 0) { G3_T(2); }
-        // next chunk's first rows: in flight underneath this chunk's streaming
-        if constexpr (in_rotated) { if (c0 + chb < nb) copy_load(c0 + chb, min(chb, nb - c0 - chb), 0, cv); }
+    };
+    // the chunk's streaming: `trips` trips of NR steps from slice-local step st (slot 0 first: every chunk but the slice's last is a whole number of trips)
+    auto stream = [&] (int st, int trips)
+    {
+        int kl = 0;
+        for (int t = 0; t < trips; ++t)                  // plain counted loop (an early exit makes the compiler drain vmcnt every trip)
+        {
+            g3_static_for<0, NR>([&] (auto uc) { constexpr int u = decltype(uc)::value; do_step(ring[u], kl + 64 * u, st + u + NR); });
+            kl += 64 * NR; st += NR;
+        }
+        return kl;
+    };
 
-        // ---- streaming: blocks c0 .. c0 + cnt - 1, two per trip (one per ring slot); an odd tail swaps the slots
-        int b = c0;
-        for (; b + 1 < c0 + cnt; b += 2)
+    // chunks of `chb` Hadamard blocks of activations in LDS.  The host makes every chunk but the last a whole number of trips (2 chb % NR == 0), so the
+    // ring position at a chunk boundary is always slot 0 and only the slice's last chunk has a remainder (steps are even: 0 or 2 of them at NR = 4).
+    // The one-chunk slice (every 16-row launch of the decode step but the lm_head) is its own straight-line path: inside the chunk loop the streaming
+    // loop is a NESTED loop, and there the compiler's wait-count analysis gives up (vmcnt(0) at the loop head again)
+    int kl_last = 0, last_cnt = nb;
+    if (nb <= chb)
+    {
+        stage_chunk(0, nb, true);
+        __syncthreads();
+        G3_T(2);
+        kl_last = stream(0, (2 * nb) / NR);
+    }
+    else
+    {
+        // several chunks, ONE flat loop over the slice's trips with the chunk boundary as a conditional block at the top of a trip (a nested loop per
+        // chunk lost the counted waits, see above): at a boundary every wave has finished the previous chunk's LDS reads (barrier), the chunk is staged,
+        // and the trip continues with chunk-local k = 0.  Every chunk but the last is a whole number of trips (host: 2 chb % NR == 0).
+        stage_chunk(0, chb, true);
+        __syncthreads();
+        G3_T(2);
+        const int tpc = (2 * chb) / NR;                  // trips per full chunk
+        const int total = (2 * nb) / NR;
+        int kl = 0, st = 0, next_b = tpc, c0 = 0;
+        for (int t = 0; t < total; ++t)
         {
-            do_block(ring[0], 128 * (b - c0), min(b + 2, nb - 1));
-            do_block(ring[1], 128 * (b + 1 - c0), min(b + 3, nb - 1));
+            if (t == next_b)
+            {
+                c0 += chb; next_b += tpc; kl = 0;
+                __syncthreads();
+                stage_chunk(c0, min(chb, nb - c0), false);
+                __syncthreads();
+            }
+            g3_static_for<0, NR>([&] (auto uc) { constexpr int u = decltype(uc)::value; do_step(ring[u], kl + 64 * u, st + u + NR); });
+            kl += 64 * NR; st += NR;
         }
-        if (b < c0 + cnt)
+        // (a last chunk shorter than a trip is staged here; its steps are the remainder below)
+        if (total == next_b && c0 + chb < nb)
         {
-            do_block(ring[0], 128 * (b - c0), min(b + 2, nb - 1));
-            #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) { LaneWords<K> t = ring[0][sub]; ring[0][sub] = ring[1][sub]; ring[1][sub] = t; }
+            c0 += chb; kl = 0;
+            __syncthreads();
+            stage_chunk(c0, nb - c0, false);
+            __syncthreads();
         }
+        kl_last = kl; last_cnt = nb - c0;
+    }
+    // remainder of the slice's last chunk: the first (2 last_cnt) % NR slots, in order
+    {
+        const int rem = (2 * last_cnt) % NR;
+        g3_static_for<0, NR - 1>([&] (auto uc) { constexpr int u = decltype(uc)::value; if (u < rem) do_step(ring[u], kl_last + 64 * u, nsteps - 1); });
     }
     G3_T(3);
 
@@ -333,7 +435,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
     const int mj_e = lane_e & 15, kg_e = lane_e >> 4;
     if (a.S > 1 || (a.flags & GEMV_OUT_DEFERRED))
     {
-        float* slab = a.workspace + ws_off + ((size_t) cbl * a.S + s) * (size_t) m * 128 + 32 * wave + 16 * (mj_e >> 3) + (mj_e & 7);
+        float* slab = a.workspace + ws_off + ((size_t) cbl * a.S + s) * (size_t) m * 128 + 32 * wv + 16 * (mj_e >> 3) + (mj_e & 7);
         #pragma unroll
         for (int i = 0; i < MT; ++i)
         {
@@ -341,7 +443,7 @@ void exl3_gemm3_kernel(const GemvArgs a)
             for (int r = 0; r < 4; ++r)
             {
                 const int row = 16 * i + 4 * kg_e + r;
-                if (row < m) { slab[row * 128] = acc[i][0][r]; slab[row * 128 + 8] = acc[i][1][r]; }
+                if (row < m && has_cb) { slab[row * 128] = acc[i][0][r]; slab[row * 128 + 8] = acc[i][1][r]; }
             }
         }
 #ifdef G2_TIMING
@@ -351,16 +453,16 @@ void exl3_gemm3_kernel(const GemvArgs a)
             tstamp[5] = __builtin_amdgcn_s_memrealtime();
             uint64_t* dbg = (uint64_t*) a.ws_debug + (size_t) (blockIdx.y * gridDim.x + blockIdx.x) * 8;
             for (int i = 0; i < 6; ++i) dbg[i] = tstamp[i];
-            uint32_t xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            dbg[6] = xcc; dbg[7] = __builtin_amdgcn_s_memtime() - cyc0;
+            uint32_t xcc, hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            dbg[6] = (xcc & 15u) | ((uint64_t) hwid << 8); dbg[7] = __builtin_amdgcn_s_memtime() - cyc0;      // which CU the workgroup ran on (placement statistics)
         }
 #endif
         return;
     }
 
-    // S == 1: the output Hadamard needs whole 128-column rows -> through LDS (over the activations)
+    // S == 1: the output Hadamard needs whole 128-column rows -> through LDS (over the activations): [column block of the workgroup][m][128] fp32
     __syncthreads();
-    float* part = (float*) smem;
+    float* part = (float*) smem + (size_t) (wave >> 2) * m * 128;
     #pragma unroll
     for (int i = 0; i < MT; ++i)
     {
@@ -368,27 +470,27 @@ void exl3_gemm3_kernel(const GemvArgs a)
         for (int r = 0; r < 4; ++r)
         {
             const int row = 16 * i + 4 * kg_e + r;
-            const int col = 32 * wave + 16 * (mj_e >> 3) + (mj_e & 7);
+            const int col = 32 * wv + 16 * (mj_e >> 3) + (mj_e & 7);
             if (row < m) { part[row * 128 + col] = acc[i][0][r]; part[row * 128 + col + 8] = acc[i][1][r]; }
         }
     }
     __syncthreads();
 
-    const int l = lane_e & 31, hw8 = 2 * wave + (lane_e >> 5);
-    const half_t* svh = a.mat[mi].svh + cbl * 128;
-    const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbl * 128 : nullptr;
+    // task t = (column block t / m of the workgroup, row t % m), one per half-wave
+    const int l = lane_e & 31, hw_e = 2 * wave + (lane_e >> 5);
+    const int cb0 = (cbg - a.mat[mi].cb_first) * CPW, ncb_here = min(CPW, (n >> 7) - cb0);
     void* C_m = a.mat[mi].C;
-    for (int base = 0; base < m; base += G3_WAVES * 2)
+    for (int t = hw_e; t < ncb_here * m; t += 2 * NWT)
     {
-        int row = base + hw8;
-        bool act = row < m;
-        float4_t v = ((const float4_t*) (part + (act ? row : 0) * 128))[l];
+        const int cbw = gemv_udiv(t, mg_m), row = t - cbw * m, cbo = cb0 + cbw;
+        const half_t* svh = a.mat[mi].svh + cbo * 128;
+        const half_t* bias = a.mat[mi].bias ? a.mat[mi].bias + cbo * 128 : nullptr;
+        float4_t v = ((const float4_t*) ((const float*) smem + ((size_t) cbw * m + row) * 128))[l];
         float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
         had128_f32x4(h0, h1, h2, h3, l);
         h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
-        if (!act) continue;
         half4_t sc = ((const half4_t*) svh)[l];
-        size_t off = ((size_t) a.c_row_offset + row) * n + cbl * 128 + 4 * l;
+        size_t off = ((size_t) a.c_row_offset + row) * n + cbo * 128 + 4 * l;
         if (a.c_fp32)
         {
             float4_t o = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
@@ -411,37 +513,48 @@ void exl3_gemm3_kernel(const GemvArgs a)
 #endif
 
 template <int CB>
-static void g3_launch_cb(int mt, bool raw, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+static void g3_launch_cb(int mt, bool raw, int nwt, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
     const bool rot = (args.flags & GEMV_IN_ROTATED) != 0;
     for (int i = 0; i < args.num_mats; ++i) if (!args.mat[i].xsum) raw = false;       // the raw variant takes the activation sums from the producer's block sums
-    #define L2(M, R, V) exl3_gemm3_kernel<G2_K, CB, M, R, V><<<grid, dim3(64 * G3_WAVES), lds, st>>>(args)
+    #define L3(M, R, V, N) { if constexpr (g3_nwt_ok(G2_K, M, R, V && CB == EXL3_CB_MUL1, N)) exl3_gemm3_kernel<G2_K, CB, M, R, V, N><<<grid, dim3(64 * N), lds, st>>>(args); }
+    // 8- / 16-wave workgroups (2 / 4 column blocks sharing one activation tile): 16-row passes only
+    #define L2(M, R, V) { if (M == 1 && nwt == 16) L3(M, R, V, (M == 1 ? 16 : 4)) else if (M == 1 && nwt == 8) L3(M, R, V, (M == 1 ? 8 : 4)) else L3(M, R, V, 4) }
     // the raw variant serves the fused decode pipeline (rotated input); the standalone op keeps the reference's fp16-rounded weights
-    #define L(M, R) { if constexpr (CB == EXL3_CB_MUL1 && R) { if (raw) L2(M, R, true); else L2(M, R, false); } else L2(M, R, false); }
+    #define L(M, R) { if constexpr (CB == EXL3_CB_MUL1 && R) { if (raw) L2(M, R, true) else L2(M, R, false) } else L2(M, R, false) }
     if (mt == 1)      { if (rot) L(1, true) else L(1, false) }
     else if (mt == 2) { if (rot) L(2, true) else L(2, false) }
     else              { if (rot) L(4, true) else L(4, false) }
     #undef L
     #undef L2
+    #undef L3
 }
 
 #define G3_CAT_(a, b) a##b
 #define G3_CAT(a, b) G3_CAT_(a, b)
 
-// mt = row tiles of 16 per pass: 1, 2 or 4
-void G3_CAT(exl3_gemm3_launch_k, G2_K)(int cb, int mt, int var, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
+// mt = row tiles of 16 per pass: 1, 2 or 4; nwt = waves per workgroup: 4, 8 or 16 (exl3_gemm3_max_waves: what the instantiation can run with)
+void G3_CAT(exl3_gemm3_launch_k, G2_K)(int cb, int mt, int var, int nwt, dim3 grid, size_t lds, hipStream_t st, const GemvArgs& args)
 {
-    if (cb == 0) g3_launch_cb<0>(mt, false, grid, lds, st, args);
-    else if (cb == 1) g3_launch_cb<1>(mt, false, grid, lds, st, args);
-    else g3_launch_cb<2>(mt, var == 1, grid, lds, st, args);
+    if (cb == 0) g3_launch_cb<0>(mt, false, nwt, grid, lds, st, args);
+    else if (cb == 1) g3_launch_cb<1>(mt, false, nwt, grid, lds, st, args);
+    else g3_launch_cb<2>(mt, var == 1, nwt, grid, lds, st, args);
+}
+
+// largest workgroup (in waves) the (K, row tiles, rotated input) instantiations can run with: the register budgets of g3_waves_per_eu
+int G3_CAT(exl3_gemm3_max_waves_k, G2_K)(int mt, int rot)
+{
+    if (mt != 1) return 4;
+    const bool r = rot != 0;
+    return g3_nwt_ok(G2_K, 1, r, r, 16) ? 16 : (g3_nwt_ok(G2_K, 1, r, r, 8) ? 8 : 4);
 }
 
 #if G2_K == 4
 // LDS bytes of a launch: activations of one chunk; the S == 1 epilogue's [m][128] fp32 overlays them
-size_t exl3_gemm3_lds_bytes(int m, int chunk_blocks)
+size_t exl3_gemm3_lds_bytes(int m, int chunk_blocks, int nwt)
 {
     const size_t stream = (size_t) m * (chunk_blocks * 128 + G3_XPAD) * 2;
-    const size_t part = (size_t) m * 128 * 4;
+    const size_t part = (size_t) m * 128 * 4 * (nwt / 4);
     return stream > part ? stream : part;
 }
 #endif

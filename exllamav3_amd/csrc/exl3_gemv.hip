@@ -159,6 +159,52 @@ extern "C" int exl3_set_tail_xcd_local(int v)
 }
 static int g_gemm3_min_rows = 5;     // passes with at least this many rows take generation 3 (0 = never); raw (unrotated) input: >= 9
 extern "C" int exl3_set_gemm3_min_rows(int v) { g_gemm3_min_rows = v; return EXL3_OK; }
+// generation 3, 16-row passes: column blocks per workgroup (1, 2 or 4 = 4- / 8- / 16-wave workgroups sharing one activation tile); 0 = cost model
+static int g_gemm3_cpw = -1;
+static int gemm3_cpw() { if (g_gemm3_cpw < 0) { const char* e = getenv("EXL3_HIP_GEMM3_CPW"); g_gemm3_cpw = e ? atoi(e) : 0; } return g_gemm3_cpw; }
+extern "C" int exl3_set_gemm3_cpw(int v) { g_gemm3_cpw = (v == 1 || v == 2 || v == 4) ? v : 0; return EXL3_OK; }
+static int gemm3_max_waves(int K, int mt, int rot)
+{
+    switch (K)
+    {
+        case 1: return exl3_gemm3_max_waves_k1(mt, rot); case 2: return exl3_gemm3_max_waves_k2(mt, rot); case 3: return exl3_gemm3_max_waves_k3(mt, rot);
+        case 4: return exl3_gemm3_max_waves_k4(mt, rot); case 5: return exl3_gemm3_max_waves_k5(mt, rot); case 6: return exl3_gemm3_max_waves_k6(mt, rot);
+        case 7: return exl3_gemm3_max_waves_k7(mt, rot); default: return exl3_gemm3_max_waves_k8(mt, rot);
+    }
+}
+// LDS a generation-3 workgroup may use: one 16-wave workgroup per CU, two 8-wave ones, four of 4 waves (160 KB per CU, some left for the runtime)
+static int gemm3_lds_budget(int cpw3) { return cpw3 == 4 ? 139264 : (cpw3 == 2 ? 73728 : 36864); }
+static int gemm3_chunk_blocks(int mp, int cpw3, int bps)
+{
+    static const int chunk_bytes_env = [] { const char* e = getenv("EXL3_HIP_GEMM3_CHUNK_BYTES"); return e ? atoi(e) : 0; }();
+    const int budget = chunk_bytes_env > 0 ? chunk_bytes_env : gemm3_lds_budget(cpw3);
+    int chunk = (budget / (mp * 2) - 16) / 128;
+    if (chunk > 16 * cpw3) chunk = 16 * cpw3;                // the rotated-input copy maps a chunk row onto <= 64 x waves 16-byte pieces (16 per block)
+    if (chunk > 32) chunk = 32;
+    if (chunk < 1) chunk = 1;
+    if (chunk >= bps) return bps;
+    // several chunks: every chunk but the last must be a whole number of the kernel's trips (G3_NR = 4 decode steps = 2 Hadamard blocks)
+    chunk &= ~1; if (chunk < 2) chunk = 2;
+    return chunk;
+}
+// Cost model of a generation-3 launch at <= 16 rows (us; fitted to tools/gemv_timeline.py at batch 16, round 4): `groups` workgroup columns of cpw3
+// column blocks, s k-slices of b Hadamard blocks.  A wave alone on its SIMD needs ~250 ns per decode step (4 tile rows x 32 columns), w waves sharing a
+// SIMD ~{250, 202, 190, 181} ns of SIMD time per step (issue-bound from 2 waves); a CU holds 4 / cpw3 workgroups; a round of workgroups pays ~1.5 us
+// before it streams (launch, first rows, activation tile) and a slab per slice is written and read again.
+static double gemm3_cost(int groups, int cpw3, int s, int b, int cus, bool deferred)
+{
+    // (w = 4 above the issue-bound figure: with four waves per SIMD the launch's first microseconds -- every workgroup staging its activation tile behind
+    // everyone's first weight rows -- stretch to 3..12 us; sweep of the whole step, tools/r4_g3_sweep.sh: q|k|v 8 / gate|up 2 / down 16 slices at two
+    // column blocks per workgroup 70.9 us per layer against 74.9 for the round-3 choices; 16-wave workgroups measured 10 % slower than 8-wave ones)
+    static const double tw[5] = { 0.0, 0.250, 0.202, 0.195, 0.210 };
+    const long wgs = (long) groups * s;
+    const int cap = 4 / cpw3;
+    const long rounds = (wgs + (long) cus * cap - 1) / ((long) cus * cap);
+    long per_cu = (wgs + cus - 1) / cus; if (per_cu > cap) per_cu = cap;
+    const int w = (int) per_cu * cpw3;
+    const double t_round = 1.5 + 2.0 * b * w * tw[w] * (cpw3 == 4 ? 1.25 : 1.0);
+    return rounds * t_round + 0.03 * s + ((s > 1 && !deferred) ? 5.0 : 0.0);
+}
 
 extern "C" int exl3_set_gemv_defer_wg_per_cu(int v) { g_gemv_defer_wg_per_cu = v; return EXL3_OK; }
 extern "C" int exl3_set_gemv_max_waves(int v) { g_gemv_nwv = v; return EXL3_OK; }
@@ -330,6 +376,34 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             }
             pass_flags |= GEMV_IN_ROTATED;
         }
+        // generation 3: column blocks per workgroup and the split are chosen together (16-row passes; 32- / 64-row passes keep 4-wave workgroups)
+        int g3cpw = 1, g3fs = 0;
+        if (g3)
+        {
+            const int mt_ = mp > 32 ? 4 : (mp > 16 ? 2 : 1);
+            const int maxw = gemm3_max_waves(K, mt_, (pass_flags & GEMV_IN_ROTATED) ? 1 : 0);
+            const int nbk = k / 128, cus = ctx->num_cus;
+            int forced_S = 0;
+            if (force_split > 0) { const int fb = (nbk + (force_split > nbk ? nbk : force_split) - 1) / (force_split > nbk ? nbk : force_split); forced_S = (nbk + fb - 1) / fb; }
+            double best = 1e30;
+            // two column blocks per workgroup wherever the instantiation's register budget allows 8 waves (measured best in the whole step; one block
+            // otherwise; four only on request: exl3_set_gemm3_cpw / EXL3_HIP_GEMM3_CPW) -- the split then follows the cost model for that choice
+            const int c3_want = (gemm3_cpw() && 4 * gemm3_cpw() <= maxw) ? gemm3_cpw() : (maxw >= 8 ? 2 : 1);
+            for (int c3 = c3_want; c3 <= c3_want; ++c3)
+            {
+                int groups = 0;
+                for (int i = 0; i < count; ++i) groups += (ns[i] / 128 + c3 - 1) / c3;
+                for (int s_ = 1; s_ <= nbk && s_ <= 64; ++s_)
+                {
+                    const int b = (nbk + s_ - 1) / s_;
+                    if ((nbk + b - 1) / b != s_) continue;          // not a normalised split
+                    if (forced_S > 0 && s_ != forced_S) continue;
+                    if ((long) total_cb * s_ * mp * 512 > (long) EXL3_WS_REGION_BYTES) continue;       // the slabs must fit one workspace region
+                    const double c = gemm3_cost(groups, c3, s_, b, cus, deferred);
+                    if (c < best) { best = c; g3cpw = c3; g3fs = s_; }
+                }
+            }
+        }
         args.act_g = act_g; args.act_u = act_u; args.act_S = act_S;
         args.act_svh_g = (const half_t*) act_svh_g; args.act_svh_u = (const half_t*) act_svh_u;
         args.norm_w = (const half_t*) norm_w; args.ss_part = ss_part; args.eps = eps;
@@ -337,7 +411,8 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         if (rsd) { args.rs_slab = rsd->slab; args.rs_S = rsd->S; args.rs_svh = (const half_t*) rsd->svh; args.rs_resid_out = (half_t*) rsd->resid_out; args.rs_ss_out = rsd->ss_out; }
         if (act_rs) args.act_rs = *act_rs;
         int fs = force_split;
-        if (deferred && fs == 0)
+        if (g3) fs = g3fs;
+        else if (deferred && fs == 0)
         {
             // deferred epilogue: the reduction is free (a glue kernel / tail epilogue does it), so pick the split that balances the
             // chip.  All workgroups of these launches are resident at once and the kernel is VALU-bound per CU, so the launch
@@ -351,16 +426,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                 const int b = (nbk + s - 1) / s;
                 if ((nbk + b - 1) / b != s) continue;              // not a normalised split
                 const long wg = (long) total_cb * s;
-                double cost = (double) ((wg + cus - 1) / cus) * b + (wg < 2l * cus ? 0.25 : 0.0) + 1e-3 * s;
-                if (g3)
-                {
-                    // generation 3 (5..16 rows here): four workgroups per CU are resident (register budget), a workgroup's prologue (activation
-                    // copy, first weight rows) costs about 8 streamed blocks, a lone workgroup does not fill its CU (one wave per SIMD: count
-                    // it as two), and every slab is read again by the consumer.  Fitted to tools/sweep_split.py at 16 rows (Llama-3.1-8B:
-                    // gate|up 8 -> 2 slices, q|k|v 16 -> 8, o 16 -> 8, down stays at 16): 81.5 -> 76.5 us per layer.
-                    long per_cu = (wg + cus - 1) / cus; if (per_cu < 2) per_cu = 2;
-                    cost = (double) per_cu * b + 8.0 * (double) ((wg + 4l * cus - 1) / (4l * cus)) + 0.5 * s;
-                }
+                const double cost = (double) ((wg + cus - 1) / cus) * b + (wg < 2l * cus ? 0.25 : 0.0) + 1e-3 * s;
                 if (cost < best_cost) { best_cost = cost; fs = s; }
             }
             if (g_gemv_defer_wg_per_cu > 0) fs = (g_gemv_defer_wg_per_cu * ctx->num_cus + total_cb - 1) / total_cb;
@@ -382,7 +448,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             }
             else fs = force_split;
         }
-        const int S = choose_split(gen, total_cb, k, mp, ctx->num_cus, fs);
+        const int S = g3 ? g3fs : choose_split(gen, total_cb, k, mp, ctx->num_cus, fs);
         const int nb = k / 128;
         const int bps = (nb + S - 1) / S;
         int cbf = 0; int64_t wso = 0;
@@ -399,7 +465,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             args.mat[i].n = ns[i];
             args.mat[i].cb_first = cbf;
             args.mat[i].ws_offset = (int) wso;
-            cbf += cpw > 0 ? (ns[i] / 128 + cpw - 1) / cpw : ns[i] / 128;
+            cbf += cpw > 0 ? (ns[i] / 128 + cpw - 1) / cpw : (g3 ? (ns[i] / 128 + g3cpw - 1) / g3cpw : ns[i] / 128);
             wso += (int64_t) (ns[i] / 128) * S * mp * 128;
         }
         if (epi)
@@ -427,7 +493,14 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         args.flags = pass_flags;
         args.A = (const half_t*) A + (size_t) m0 * k;
         args.workspace = ws_region;
-        args.ws_debug = ctx->workspace + (48ll << 20) / 4;
+        {
+            // diagnostics builds (-DG2_TIMING / -DG4_TIMING): phase stamps at 48 MiB of the workspace; EXL3_HIP_TIMING_SLOTS=n (<= 8) rotates n 512-KB slots
+            // over successive launches so that a whole captured step keeps the stamps of its last n GEMV launches (slots 4..7 overlap the
+            // pre-rotation region at 50 MiB: diagnostics only)
+            static const int slots = [] { const char* e = getenv("EXL3_HIP_TIMING_SLOTS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+            static unsigned launch_no = 0;
+            args.ws_debug = ctx->workspace + (48ll << 20) / 4 + (size_t) (slots > 1 ? (launch_no++ % (unsigned) slots) : 0) * (512ll << 10) / 4;
+        }
         args.num_mats = tbl ? 1 : count;
         args.m = mp;
         args.k = k;
@@ -442,29 +515,28 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         if (gen == 3)
         {
             const int mt = mp > 32 ? 4 : (mp > 16 ? 2 : 1);
-            // four workgroups per CU (the register budget of the rotated-input variants) x <= 36 KB of activations (the workgroup's only LDS since the
-            // transpose buffers went): 16 rows keep a whole 8-block slice resident (one chunk: no second prologue / barrier inside the stream)
-            static const int chunk_bytes = [] { const char* e = getenv("EXL3_HIP_GEMM3_CHUNK_BYTES"); return e ? atoi(e) : 36864; }();
-            int chunk = (chunk_bytes / (mp * 2) - 16) / 128;
-            if (chunk > 8) chunk = 8;                            // the rotated-input copy maps a chunk row onto <= 128 16-byte pieces
-            if (chunk < 1) chunk = 1;
-            if (chunk > bps) chunk = bps;
+            // workgroup = 4 g3cpw waves = g3cpw adjacent column blocks of one matrix sharing ONE activation tile in LDS (16 rows keep a whole 8-block
+            // slice resident at 4 waves, a whole k = 4096 at 16: one chunk, no second prologue / barrier inside the stream)
+            const int nwt = 4 * g3cpw;
+            const int chunk = gemm3_chunk_blocks(mp, g3cpw, bps);
             args.chunk_blocks = chunk;
-            const size_t lds = exl3_gemm3_lds_bytes(mp, chunk);
-            EXL3_CHECK_ARG(grid.x / (unsigned) S <= 65535u, "exl3_gemm: too many column blocks for one launch");
-            grid = dim3((unsigned) S, grid.x / (unsigned) S);                  // (k-slices, column blocks), as for generation 2 below
+            const size_t lds = exl3_gemm3_lds_bytes(mp, chunk, nwt);
+            int total_groups3 = 0;
+            for (int i = 0; i < count; ++i) total_groups3 += (ns[i] / 128 + g3cpw - 1) / g3cpw;
+            EXL3_CHECK_ARG(total_groups3 <= 65535, "exl3_gemm: too many column blocks for one launch");
+            grid = dim3((unsigned) S, (unsigned) total_groups3);              // (k-slices, groups of g3cpw column blocks), as for generation 2 below
             for (int i = 1; i < GEMV_MAX_MATS; ++i) args.cbf[i - 1] = args.mat[i].cb_first;
             args.magic_m = gemv_magic((uint32_t) mp);
             switch (K)
             {
-                case 1: exl3_gemm3_launch_k1(cb, mt, var, grid, lds, st, args); break;
-                case 2: exl3_gemm3_launch_k2(cb, mt, var, grid, lds, st, args); break;
-                case 3: exl3_gemm3_launch_k3(cb, mt, var, grid, lds, st, args); break;
-                case 4: exl3_gemm3_launch_k4(cb, mt, var, grid, lds, st, args); break;
-                case 5: exl3_gemm3_launch_k5(cb, mt, var, grid, lds, st, args); break;
-                case 6: exl3_gemm3_launch_k6(cb, mt, var, grid, lds, st, args); break;
-                case 7: exl3_gemm3_launch_k7(cb, mt, var, grid, lds, st, args); break;
-                case 8: exl3_gemm3_launch_k8(cb, mt, var, grid, lds, st, args); break;
+                case 1: exl3_gemm3_launch_k1(cb, mt, var, nwt, grid, lds, st, args); break;
+                case 2: exl3_gemm3_launch_k2(cb, mt, var, nwt, grid, lds, st, args); break;
+                case 3: exl3_gemm3_launch_k3(cb, mt, var, nwt, grid, lds, st, args); break;
+                case 4: exl3_gemm3_launch_k4(cb, mt, var, nwt, grid, lds, st, args); break;
+                case 5: exl3_gemm3_launch_k5(cb, mt, var, nwt, grid, lds, st, args); break;
+                case 6: exl3_gemm3_launch_k6(cb, mt, var, nwt, grid, lds, st, args); break;
+                case 7: exl3_gemm3_launch_k7(cb, mt, var, nwt, grid, lds, st, args); break;
+                case 8: exl3_gemm3_launch_k8(cb, mt, var, nwt, grid, lds, st, args); break;
             }
         }
         else

@@ -102,6 +102,11 @@ def set_gemm3_min_rows(n: int):
     _lib.lib().exl3_set_gemm3_min_rows(int(n))
 
 
+def set_gemm3_cpw(n: int):
+    """generation 3 (5..16 rows): column blocks per workgroup (1 / 2 / 4 = 4- / 8- / 16-wave workgroups sharing one activation tile); 0 = cost model."""
+    _lib.lib().exl3_set_gemm3_cpw(int(n))
+
+
 # --------------------------------------------------------------------------------------------------
 # format ops
 # --------------------------------------------------------------------------------------------------

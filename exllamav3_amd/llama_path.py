@@ -895,10 +895,12 @@ class SyntheticEXL3Llama:
                     wd[1], cpw=wd[0]))
             elif pipeline == "glue" and self.tp == 1 and bsz > 4:
                 # batches above 4 rows: the step rotates once (glue_rotate) and the GEMVs read pre-rotated inputs
-                calls.append(lambda lq=lq, lk=lk, lv=lv: ext.exl3_gemv_ex(None, self.xh3, None, [lq.trellis, lk.trellis, lv.trellis], None, None, None, bsz, lq.mcg, lq.mul1, ROT | DEF))
-                calls.append(lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF))
-                calls.append(lambda lg=lg, lu=lu: ext.exl3_gemv_ex(None, self.xh3[:2], None, [lg.trellis, lu.trellis], None, None, None, bsz, lg.mcg, lg.mul1, ROT | DEF))
-                calls.append(lambda ld=ld: ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF))
+                # (the step's own arguments: block sums for the mul1 raw variant, the forced splits of self.split)
+                sp = self.split
+                calls.append(lambda lq=lq, lk=lk, lv=lv: ext.exl3_gemv_ex(None, self.xh3, self.xs3, [lq.trellis, lk.trellis, lv.trellis], None, None, None, bsz, lq.mcg, lq.mul1, ROT | DEF, sp["qkv"]))
+                calls.append(lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"]))
+                calls.append(lambda lg=lg, lu=lu: ext.exl3_gemv_ex(None, self.xh3[:2], self.xs3[:2], [lg.trellis, lu.trellis], None, None, None, bsz, lg.mcg, lg.mul1, ROT | DEF, sp["gu"]))
+                calls.append(lambda ld=ld: ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ROT | DEF, sp["down"]))
             elif pipeline == "glue" and self.tp == 1:
                 calls.append(lambda lq=lq, lk=lk, lv=lv, L=L: ext.exl3_gemv_ex_norm(self.x, L["norm1"], self.ss, self.eps, [lq.trellis, lk.trellis, lv.trellis], None, [lq.suh, lk.suh, lv.suh], None, bsz, lq.mcg, lq.mul1, DEF))
                 calls.append(lambda lo=lo: ext.exl3_gemv_ex(q2, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF))

@@ -111,6 +111,7 @@ int exl3_set_gemv_max_waves(int max_waves_per_workgroup);   /* 0 = heuristic (up
 int exl3_set_gemv_gen4(int on);                              /* 1 (default; env EXL3_HIP_GEMV_GEN4): 1..4-row launches take the generation-4 kernel
                                                                 (exl3_gemv4.kspec.hip: activation quads in the A-broadcast register layout, no per-wave
                                                                 prologue); 0 pins generation 2 for them */
+int exl3_set_gemm3_cpw(int column_blocks_per_workgroup);    /* generation 3, <= 16-row passes: 1 / 2 / 4 column blocks (4- / 8- / 16-wave workgroups) share one activation tile; 0 = the library's cost model (default; env EXL3_HIP_GEMM3_CPW) */
 int exl3_set_gemm3_min_rows(int min_rows);                   /* passes with >= min_rows rows use the LDS-transpose kernel (exl3_gemm3.kspec.hip); default 5 (9 for raw input), 0 = never */
 int exl3_set_gemv_defer_wg_per_cu(int workgroups_per_cu);      /* deferred-epilogue k-split target, 0 = default (2) */
 

@@ -26,7 +26,8 @@ STUB = r'''
 static void lite_abort(int K) { fprintf(stderr, "libexl3_hip (lite variant build): only K = 4 kernels are in this library, K = %d requested\n", K); abort(); }
 #define STUBS(KK) \
     void exl3_gemv2_launch_k##KK(int, int, int, int, dim3, size_t, hipStream_t, const GemvArgs&) { lite_abort(KK); } \
-    void exl3_gemm3_launch_k##KK(int, int, int, dim3, size_t, hipStream_t, const GemvArgs&) { lite_abort(KK); } \
+    void exl3_gemm3_launch_k##KK(int, int, int, int, dim3, size_t, hipStream_t, const GemvArgs&) { lite_abort(KK); } \
+    int exl3_gemm3_max_waves_k##KK(int, int) { return 4; } \
     void exl3_gemv4_launch_k##KK(int, int, int, int, dim3, size_t, hipStream_t, const GemvArgs&) { lite_abort(KK); }
 STUBS(1) STUBS(2) STUBS(3) STUBS(5) STUBS(6) STUBS(7) STUBS(8)
 '''

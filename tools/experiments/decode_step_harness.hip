@@ -256,6 +256,14 @@ int main(int argc, char** argv)
         }
         std::vector<__half> lgb((size_t) bsz * vocab); CK(hipMemcpy(lgb.data(), logits, lgb.size() * 2, hipMemcpyDeviceToHost));
         int bad = 0; double r2 = 0; for (auto h : lgb) { const double v = __half2float(h); if (!std::isfinite(v)) ++bad; else r2 += v * v; }
+        if (const char* df = getenv("H_DUMP_TIMING"))
+        {
+            // timing builds of the library (-DG2_TIMING) with EXL3_HIP_TIMING_SLOTS=8: the phase stamps of the step's last 8 GEMV launches, as left by the last replay
+            std::vector<char> hb((size_t) 4 << 20); void* db; CK(hipMalloc(&db, hb.size()));
+            CE(exl3_debug_copy_workspace(db, (int64_t) 48 << 20, (int64_t) hb.size(), st)); CK(hipStreamSynchronize(st));
+            CK(hipMemcpy(hb.data(), db, hb.size(), hipMemcpyDeviceToHost));
+            FILE* f = fopen(df, "wb"); if (f) { fwrite(hb.data(), 1, hb.size(), f); fclose(f); }
+        }
         printf("{\"model\": \"llama-3.1-8b shapes, %d layers, EXL3 4.0 bpw mul1, bs %d, folded glue pipeline via the C ABI\", \"ms_per_step\": %.4f, \"tok_s\": %.1f, "
                "\"us_per_layer\": %.2f, \"logits_rms\": %.5g, \"nonfinite\": %d, \"splits\": {\"qkv\": %d, \"gate_up\": %d, \"down\": %d}}\n",
                n_layers, bsz, bestb, bsz * 1e3 / bestb, bestb * 1e3 / n_layers, sqrt(r2 / (double) lgb.size()), bad, sp_qkv, sp_gu, sp_down);

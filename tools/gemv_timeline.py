@@ -14,6 +14,9 @@ model = SyntheticEXL3Llama(SHAPES["llama-3.1-8b"], K=4, cb=2, device=dev, kv_bit
 model.alloc_state(int(os.environ.get("BSZ", "1")))
 pipeline = os.environ.get("PIPELINE", "glue")       # glue | resid | fx
 {"resid": model.decode_step_resid, "fx": model.decode_step_fx}.get(pipeline, model.decode_step_fused)(); torch.cuda.synchronize()
+if os.environ.get("SPLITS"):          # "qkv,o,gu,down" forced split-k factors (0 = the library's choice)
+    q_, o_, g_, d_ = (int(v) for v in os.environ["SPLITS"].split(","))
+    model.split = {"qkv": q_, "o": o_, "gu": g_, "down": d_}
 calls = model.gemv_calls(pipeline)
 names = ["qkv", "o", "gate_up", "down"]
 grids = {"qkv": 48, "o": 32, "gate_up": 224, "down": 32, "lm_head": 1002}
@@ -57,5 +60,22 @@ for i, nm in enumerate(names):
     if os.environ.get("BSZ", "1") not in ("1", "2", "3", "4"):   # generation 3 stores shader cycles of the workgroup in column 7
         row["shader_clock_GHz_median"] = round(float(np.median(t[:, 7][life > 0] / life[life > 0])) * 1e-3, 3)
     row["xcc_counts"] = np.bincount(t[:, 6].astype(int) & 15, minlength=8).tolist()
+    if (t[:, 6] >> 8).any():
+        # generation-3 timing builds also record HW_ID: workgroups per CU (cu_id [11:8], sh_id [12], se_id [15:13] of HW_REG_HW_ID) and the stream phase by co-residency
+        hw = (t[:, 6] >> 8).astype(np.int64)
+        cu_key = (t[:, 6].astype(np.int64) & 15) * 4096 + ((hw >> 8) & 0xff)
+        uniq, inv, cnt = np.unique(cu_key, return_inverse=True, return_counts=True)
+        row["cus_used"] = int(len(uniq)); row["workgroups_per_cu_histogram"] = {int(k): int(v) for k, v in zip(*np.unique(cnt, return_counts=True))}
+        per = cnt[inv]
+        # residency census: the largest number of workgroups whose [entry, last stamp] intervals overlap on one CU
+        mx = []
+        for u in range(len(uniq)):
+            ev = sorted([(int(a), 1) for a in t[inv == u, 0]] + [(int(b), -1) for b in t[inv == u, 5]], key=lambda e: (e[0], e[1]))
+            c = m_ = 0
+            for _, dlt in ev:
+                c += dlt; m_ = max(m_, c)
+            mx.append(m_)
+        row["max_resident_workgroups_per_cu_histogram"] = {int(k): int(v) for k, v in zip(*np.unique(mx, return_counts=True))}
+        row["stream_us_p50_by_workgroups_on_cu"] = {int(k): round(float(np.median(d[per == k, 2])), 2) for k in np.unique(per)}
     out[nm] = row
     print(nm, json.dumps(row), flush=True)
