@@ -29,6 +29,7 @@ struct AttnArgs
     float* part;                                                // [bsz][hq][nsplit][132] partial (m, l, o[128]) when nsplit > 1
     int blocks_per_seq, page_size, k_bits, v_bits, hq, hkv, nsplit, split_tokens;
     float scale;
+    int force_part;                                             // write partial records even with one split (the consumer merges: exl3_gemv_ex_attm)
 };
 // hq / hkv in AttnArgs count HEADS; a workgroup handles one 128-value block of the kv vector = 128 / HD kv heads
 
@@ -139,7 +140,7 @@ void attn_decode_kernel(const AttnArgs a)
             O.x += ov.x * e; O.y += ov.y * e; O.z += ov.z * e; O.w += ov.w * e;
         }
         const int head = kvh * GQ + i;                          // query head of this lane
-        if (a.nsplit == 1)
+        if (a.nsplit == 1 && !a.force_part)
         {
             const float inv = L > 0.0f ? 1.0f / L : 0.0f;
             float v0 = O.x * inv, v1 = O.y * inv, v2 = O.z * inv, v3 = O.w * inv;
@@ -441,18 +442,46 @@ void attn_merge_kernel(const float* __restrict__ part, half_t* __restrict__ out,
     if (act) ((half4_t*) (out + ((size_t) b * hq + head) * hd))[lr] = half4_t{ f2h(v0 * ATT_R32), f2h(v1 * ATT_R32), f2h(v2 * ATT_R32), f2h(v3 * ATT_R32) };
 }
 
+static int attn_decode_impl(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
+                            const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
+                            int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
+                            float* workspace, int64_t workspace_floats, void* stream, int* nsplit_out);
+
 extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
                                        const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
                                        int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
                                        float* workspace, int64_t workspace_floats, void* stream)
 {
-    EXL3_CHECK_ARG(q && out && k_cache && k_scales && v_cache && v_scales && block_table && cache_seqlens, "attn_decode: null pointer");
+    return attn_decode_impl(q, out, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, bsz, blocks_per_seq, page_size, k_bits, v_bits, heads_q, heads_kv,
+                            head_dim, max_len, scale, workspace, workspace_floats, stream, nullptr);
+}
+
+// The context-split half of exl3_attn_decode_qcache only: the partial records {m, l, -, -, o[128]} per (sequence, kv block, query index, split) stay in
+// `workspace` ([bsz][blocks][gq][*nsplit_out][132] fp32, always written, also with one split) and whoever consumes the attention output merges them --
+// exl3_gemv_ex_attm does it inside o_proj's launch.  head_dim 128 only (one query head = one Hadamard block of o_proj's input).
+extern "C" int exl3_attn_decode_qcache_split(const void* q, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
+                                             const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
+                                             int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
+                                             float* workspace, int64_t workspace_floats, int* nsplit_out, void* stream)
+{
+    EXL3_CHECK_ARG(nsplit_out && workspace && head_dim == 128, "attn_decode_split: needs the workspace, nsplit_out and head_dim 128");
+    return attn_decode_impl(q, nullptr, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, bsz, blocks_per_seq, page_size, k_bits, v_bits, heads_q, heads_kv,
+                            head_dim, max_len, scale, workspace, workspace_floats, stream, nsplit_out);
+}
+
+static int attn_decode_impl(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
+                            const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
+                            int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
+                            float* workspace, int64_t workspace_floats, void* stream, int* nsplit_out)
+{
+    const bool split_only = nsplit_out != nullptr;
+    EXL3_CHECK_ARG(q && (out || split_only) && k_cache && k_scales && v_cache && v_scales && block_table && cache_seqlens, "attn_decode: null pointer");
     EXL3_CHECK_ARG(head_dim == 128 || head_dim == 64, "attn_decode: head_dim must be 128 or 64");
     EXL3_CHECK_ARG((heads_kv * head_dim) % 128 == 0, "attn_decode: heads_kv * head_dim must be a multiple of 128 (whole Hadamard blocks)");
     EXL3_CHECK_ARG(heads_kv >= 1 && heads_q % heads_kv == 0 && heads_q / heads_kv <= ATT_MAX_GQ, "attn_decode: heads_q must be a multiple (<= 8x) of heads_kv");
     EXL3_CHECK_ARG(k_bits >= 2 && k_bits <= 8 && v_bits >= 2 && v_bits <= 8, "attn_decode: cache bits must be in [2, 8]");
     EXL3_CHECK_ARG(page_size > 0 && max_len >= 1, "attn_decode: bad page size / length bound");
-    if (bsz == 0) return EXL3_OK;
+    if (bsz == 0) { if (split_only) *nsplit_out = 1; return EXL3_OK; }
     // context splits: enough workgroups to cover the chip, at least 64 tokens (8 per half-wave) each
     const int blocks = heads_kv * head_dim / 128;                                    // 128-value blocks of the kv vector = workgroups per (split, sequence)
     const int gq = heads_q / heads_kv;
@@ -461,13 +490,15 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
     int cap = 1024 / (bsz * blocks) > 1 ? 1024 / (bsz * blocks) : 1;
     if (cap > (head_dim == 128 ? 256 : 128)) cap = head_dim == 128 ? 256 : 128;       // the merge kernel keeps 8 chunks of 32 / 16 split statistics in registers
     if (nsplit > cap) { nsplit = cap; split_tokens = ((max_len + nsplit - 1) / nsplit + 7) / 8 * 8; nsplit = (max_len + split_tokens - 1) / split_tokens; }
-    EXL3_CHECK_ARG(nsplit == 1 || (workspace && workspace_floats >= (int64_t) bsz * blocks * gq * nsplit * 132), "attn_decode: workspace too small for the context splits");
+    // (split-only callers hand the records to a consumer that keeps one chunk of 32 split statistics: cap the split count there)
+    if (split_only && nsplit > 32) { nsplit = 32; split_tokens = ((max_len + nsplit - 1) / nsplit + 7) / 8 * 8; nsplit = (max_len + split_tokens - 1) / split_tokens; }
+    EXL3_CHECK_ARG((nsplit == 1 && !split_only) || (workspace && workspace_floats >= (int64_t) bsz * blocks * gq * nsplit * 132), "attn_decode: workspace too small for the context splits");
     AttnArgs a;
     a.q = (const half_t*) q; a.out = (half_t*) out;
     a.k_cache = (const uint32_t*) k_cache; a.k_scales = (const half_t*) k_scales; a.v_cache = (const uint32_t*) v_cache; a.v_scales = (const half_t*) v_scales;
     a.block_table = block_table; a.cache_seqlens = cache_seqlens; a.part = workspace;
     a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.k_bits = k_bits; a.v_bits = v_bits; a.hq = heads_q; a.hkv = heads_kv;
-    a.nsplit = nsplit; a.split_tokens = split_tokens; a.scale = scale;
+    a.nsplit = nsplit; a.split_tokens = split_tokens; a.scale = scale; a.force_part = split_only ? 1 : 0;
     hipStream_t st = (hipStream_t) stream;
     // head_dim 128, 4-bit K and V, a length bound of at least two 64-token steps: the matrix-pipe kernel (it always writes partial records); measured
     // ahead of the half-wave-per-token kernel from a 512-token bound on (463 vs 458 tok/s with attention), far ahead at long contexts
@@ -476,7 +507,7 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
     {
         int st_tok = 64;
         int ns = (max_len + st_tok - 1) / st_tok;
-        const int capw = (head_dim == 128 ? 256 : 128);
+        const int capw = split_only ? 32 : (head_dim == 128 ? 256 : 128);
         // about two workgroups per CU: more, shorter splits cost more in the merge than they return (16 000 tokens: 380 tok/s at 512, 337 at 2048)
         static const int wg_cap = [] { const char* e = getenv("EXL3_HIP_ATTN_WIDE_WGS"); return e ? atoi(e) : 512; }();
         // (ns bottoms out at 1: with bsz * blocks > wg_cap alone the bound cannot be met and the loop must stop there -- the ns >= 2 test
@@ -499,6 +530,7 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
             }
             int rcw = exl3_check_launch("attn_decode_wide");
             if (rcw) return rcw;
+            if (split_only) { *nsplit_out = ns; return EXL3_OK; }
             const int items = bsz * blocks * gq;
             const uint32_t mg = gemv_magic((uint32_t) gq), mbg = gemv_magic((uint32_t) (blocks * gq)), mb = gemv_magic((uint32_t) blocks);
             attn_merge_kernel<128><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, ns, gq, blocks, heads_q, mg, mbg, mb);
@@ -515,6 +547,7 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
     #undef ATT_L
     int rc = exl3_check_launch("attn_decode");
     if (rc) return rc;
+    if (split_only) { *nsplit_out = nsplit; return EXL3_OK; }
     if (nsplit > 1)
     {
         const int items = bsz * blocks * gq;

@@ -292,7 +292,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                      const void* norm_w = nullptr, const float* ss_part = nullptr, float eps = 0.0f, const GemvTable* tbl = nullptr,
                      const float* act_g = nullptr, const float* act_u = nullptr, int act_S = 0, const void* act_svh_g = nullptr,
                      const void* act_svh_u = nullptr, const GemvResidIn* rsd = nullptr, const GemvRescale* act_rs = nullptr, int cpw = 0,
-                     float* fx_ss_out = nullptr)
+                     float* fx_ss_out = nullptr, const GemvAttm* attm = nullptr)
 {
     FxZeroReq fxz = take_fx_zero();          // one-shot: whatever happens below, the request does not survive this call
     if (rsd) flags |= GEMV_IN_RESID;
@@ -302,6 +302,10 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     EXL3_CHECK_ARG(cpw == 0 || ((flags & GEMV_OUT_DEFERRED) && m <= 4 && !tbl && !epi && !(flags & GEMV_IN_ROTATED)),
                    "exl3_gemv_ex (cpw): wave-per-column-block launches are deferred, m <= 4, raw / resid / act input");
     if (act_g) flags |= GEMV_IN_ACT;
+    if (attm) flags |= GEMV_IN_ATTM;
+    EXL3_CHECK_ARG(!attm || (attm->part && attm->nsplit >= 1 && attm->nsplit <= 32 && attm->gq >= 1 && attm->blocks >= 1 && count == 1 && m <= 4 && !tbl && !epi && cpw == 0
+                             && !rsd && !act_g && !(flags & (GEMV_IN_ROTATED | GEMV_IN_NORM)) && k == attm->gq * attm->blocks * 128),
+                   "exl3_gemv_ex_attm: one matrix, m <= 4, at most 32 context splits, k = heads_q x 128");
     if (epi) flags |= GEMV_OUT_DEFERRED;
     // GEMV_OUT_ATOMIC (generation 4): no slabs, every workgroup adds its share of the output into the fixed-point accumulator Cs[i]; like a deferred
     // launch it keeps every workgroup resident (the split is chosen the same way) and it needs svhs
@@ -324,7 +328,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     const bool in_act = (flags & GEMV_IN_ACT) != 0;
     EXL3_CHECK_ARG(!in_act || (act_g && act_u && ((act_svh_g && act_svh_u && count == 1) || (tbl && tbl->act_svh)) && act_S >= 1 && !rotated && m <= 4),
                    "exl3_gemv_ex_act: needs gate / up slabs + svh, one matrix, m <= 4");
-    EXL3_CHECK_ARG(A || rotated || in_act, "exl3_gemm: null A");
+    EXL3_CHECK_ARG(A || rotated || in_act || attm, "exl3_gemm: null A");
     EXL3_CHECK_ARG(!rsd || (in_norm && deferred && m <= 4 && rsd->slab && rsd->S >= 1 && rsd->svh && rsd->resid_out && rsd->ss_out && rsd->resid_out != A),
                    "exl3_gemv_ex_resid: needs GEMV_IN_NORM, deferred output, m <= 4, producer slabs + svh and a resid_out buffer other than resid_in");
     int total_cb = 0;
@@ -410,6 +414,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         if (in_fx) args.rs_ss_out = fx_ss_out;
         if (rsd) { args.rs_slab = rsd->slab; args.rs_S = rsd->S; args.rs_svh = (const half_t*) rsd->svh; args.rs_resid_out = (half_t*) rsd->resid_out; args.rs_ss_out = rsd->ss_out; }
         if (act_rs) args.act_rs = *act_rs;
+        if (attm) { args.attm = *attm; args.attm.magic_gq = gemv_magic((uint32_t) attm->gq); }
         int fs = force_split;
         if (g3) fs = g3fs;
         else if (deferred && fs == 0)
@@ -550,7 +555,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             EXL3_CHECK_ARG(g4 || !fxz.ptr, "exl3_fx_zero_next: the launch that followed cannot clear the buffer (not a generation-4 launch: rows > 4, a slice of more than 32 Hadamard blocks, a tail / wave-per-column-block mode, or generation 4 switched off)");
             if (g4)
             {
-                const int mode = tbl ? (in_act ? 7 : 6) : in_act ? ((flags & GEMV_IN_ACTFX) ? 5 : 3) : (in_norm ? (in_fx ? 4 : 2) : (rot_pass ? 0 : 1));
+                const int mode = attm ? 8 : tbl ? (in_act ? 7 : 6) : in_act ? ((flags & GEMV_IN_ACTFX) ? 5 : 3) : (in_norm ? (in_fx ? 4 : 2) : (rot_pass ? 0 : 1));
                 if (fxz.ptr)
                 {
                     int dev_now = -1;
@@ -591,7 +596,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             }
             else
             {
-            EXL3_CHECK_ARG(!atomic_out && !in_fx && !(flags & GEMV_IN_ACTFX) && !(tbl && in_act), "exl3_gemv_ex: GEMV_OUT_ATOMIC / GEMV_IN_FX / GEMV_IN_ACTFX / slab-act table launches are generation-4 launches (m <= 4, slices of <= 32 Hadamard blocks, generation 4 enabled)");
+            EXL3_CHECK_ARG(!atomic_out && !in_fx && !attm && !(flags & GEMV_IN_ACTFX) && !(tbl && in_act), "exl3_gemv_ex: GEMV_OUT_ATOMIC / GEMV_IN_FX / GEMV_IN_ACTFX / GEMV_IN_ATTM / slab-act table launches are generation-4 launches (m <= 4, slices of <= 32 Hadamard blocks, generation 4 enabled)");
             int nwv = 16 / ng;                                   // partial-sum LDS: nwv * 4*ng rows * 512 B <= 32 KB
             const int units = bps * (8 / G2_PF);                 // the waves split the slice's tile rows in units of G2_PF
             // measured on MI355X (tools/prof_tail.py, batch 1): one wave per Hadamard block of the slice, but at least 4 waves --
@@ -654,6 +659,9 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         if (S > 1 && !deferred)
         {
             // (GEMV_OUT_ATOMIC launches count as deferred: nothing to reduce)
+            // the reduce kernel walks COLUMN BLOCKS: a launch whose grid counted groups of column blocks (generation 3 with 8- / 16-wave workgroups, the
+            // wave-per-column-block layout) hands it the matrices' first column blocks, not their first groups
+            if (!tbl) { int cbc = 0; for (int i = 0; i < count; ++i) { args.mat[i].cb_first = cbc; cbc += ns[i] / 128; } }
             int64_t items = (int64_t) total_cb * mp;
             exl3_gemv_reduce_kernel<<<dim3((unsigned) ((items + 7) / 8)), dim3(256), 0, st>>>(args, total_cb);
             rc = exl3_check_launch("exl3_gemv_reduce");
@@ -1015,6 +1023,22 @@ extern "C" int exl3_gemv_ex_act_rs(const float* g_slabs, const float* u_slabs, i
     return run_mgemm(nullptr, Bs, C ? Cs : nullptr, su, svh ? sv : nullptr, bi, ns, 1, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream,
                      (flags & (GEMV_OUT_DEFERRED | GEMV_OUT_ATOMIC)), nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
                      g_slabs, u_slabs, act_S, svh_g, svh_u, nullptr, &rs, cpw);
+}
+
+// o_proj whose input is the decode attention's output, finished inside the launch: `part` = the context-split partial records exl3_attn_decode_qcache_split
+// left ([m][blocks][gq][nsplit][132] fp32), merged per (row, query head) by the preparation task that needs that head (head_dim 128: one head = one
+// Hadamard block of o_proj's input) with the arithmetic of the merge kernel -- same bits as attn_decode_qcache + exl3_gemv_ex, one launch less.
+// flags: GEMV_OUT_DEFERRED or GEMV_OUT_ATOMIC (C = the fixed-point residual) or 0 (final output).  reference: libtorch/attention.cpp:246-504 (attention, then o_proj).
+extern "C" int exl3_gemv_ex_attm(const float* part, int nsplit, int gq, int blocks, const void* B, void* C, const void* suh, const void* svh, const void* bias,
+                                 int m, int k, int n, int K, int cb, int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(part && B && suh, "exl3_gemv_ex_attm: null pointer");
+    const void* Bs[1] = { B }; void* Cs[1] = { C }; const void* su[1] = { suh }; const void* sv[1] = { svh }; const void* bi[1] = { bias };
+    int ns[1] = { n };
+    GemvAttm at = { part, nsplit, gq, blocks, 0u };
+    return run_mgemm(nullptr, Bs, C ? Cs : nullptr, su, svh ? sv : nullptr, bi, ns, 1, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream,
+                     (flags & (GEMV_OUT_DEFERRED | GEMV_OUT_ATOMIC)), nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
+                     nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &at);
 }
 
 extern "C" int exl3_gemv_ex_act(const float* g_slabs, const float* u_slabs, int act_S, const void* svh_g, const void* svh_u,

@@ -49,11 +49,13 @@ __device__ __forceinline__ void g4_static_for(F&& f)
 // device from the router's index list; the input side is RAWX's / ACT's
 #define G4_MODE_TRAWX 6     // slot input = raw x (one shared row set, or a_slot_stride apart)
 #define G4_MODE_TACT 7      // slot input = silu(g) * u from the slabs a TRAWX gate|up launch over [gate_0..gate_E-1, up_0..up_E-1] left (slot j: gate, slot bszm + j: up)
+#define G4_MODE_ATTM 8      // GEMV_IN_ATTM: the flash-decoding merge of the attention's context-split partials, then as RAWX (a.A is not read)
 constexpr int g4_input_mode(int MODE) { return MODE == G4_MODE_TRAWX ? G4_MODE_RAWX : (MODE == G4_MODE_TACT ? G4_MODE_ACT : MODE); }
 
 constexpr int g4_waves_per_eu(int K, int CB, int MODE_)
 {
     const int MODE = g4_input_mode(MODE_);
+    if (MODE == G4_MODE_ATTM) return 4;                      // eight 16-byte split outputs travel with a task
     if (MODE == G4_MODE_ACT) return MODE_ == G4_MODE_TACT ? 4 : 3;     // 8 slab lines travel with a task; the non-table form also carries the row-scale correction
     if (MODE == G4_MODE_ACTFX && K >= 6) return 5;          // four 16-byte accumulator loads in flight per task next to a 12..16-word ring
     if (K >= 5) return 6;
@@ -215,7 +217,16 @@ void exl3_gemv4_kernel(const GemvArgs a)
     // (ACT: the first 4 slab lines of gate and up and their svh travel with the task, i.e. they are requested BEFORE the wave's first weight rows -- loaded
     // inside the task they queued behind those rows)
     constexpr int NSL = MODE == G4_MODE_ACT ? 4 : 1;
-    struct PrepIn { half4_t xv, sv, wv; float ss, ssn; uint4_t f0, f1, f2, f3; float4_t ga[NSL], ua[NSL]; half4_t svg, svu; };
+    constexpr int NMO = MODE == G4_MODE_ATTM ? 8 : 1;         // ATTM: the first 8 splits' outputs travel with the task
+    struct PrepIn { half4_t xv, sv, wv; float ss, ssn; uint4_t f0, f1, f2, f3; float4_t ga[NSL], ua[NSL]; half4_t svg, svu; float4_t mo[NMO]; float2 mst; };
+    const int at_nsplit = MODE == G4_MODE_ATTM ? a.attm.nsplit : 1, at_gq = MODE == G4_MODE_ATTM ? a.attm.gq : 1;
+    const float* const at_part = MODE == G4_MODE_ATTM ? a.attm.part : nullptr;
+    // partial records of (row, head): head = absolute Hadamard block of the input = query head (head_dim 128); h = head / gq, i = head % gq
+    auto attm_rec = [&] (int row, int head) -> const float*
+    {
+        const int h = gemv_udiv(head, a.attm.magic_gq), i = head - h * at_gq;
+        return at_part + ((((size_t) row * a.attm.blocks + h) * at_gq + i) * at_nsplit) * 132;
+    };
     const int ntask = nb * m;
     auto fetch = [&] (int it) -> PrepIn
     {
@@ -236,6 +247,13 @@ void exl3_gemv4_kernel(const GemvArgs a)
             r.f0 = gp[0]; r.f1 = gp[1]; r.f2 = up[0]; r.f3 = up[1];
         }
         r.sv = ((const half4_t*) (suh + kofs))[l32];
+        if constexpr (MODE == G4_MODE_ATTM)
+        {
+            const float* p = attm_rec(row, (k0s >> 7) + blk);
+            r.mst = *((const float2*) (p + (size_t) min(l32, at_nsplit - 1) * 132));                 // lane s: {m, l} of split s (masked at its use)
+            #pragma unroll
+            for (int u = 0; u < NMO; ++u) r.mo[u] = *((const float4_t*) (p + (size_t) min(u, at_nsplit - 1) * 132 + 4 + 4 * l32));
+        }
         if constexpr (MODE == G4_MODE_ACT)
         {
             const int blk_abs = (k0s >> 7) + blk;
@@ -418,6 +436,53 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
                     xv = half4_t{ silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
                 }
+                if constexpr (MODE == G4_MODE_ATTM)
+                {
+                    // x = the attention output of query head `blk_abs` of this row: merge of the context splits' partial records -- the arithmetic of
+                    // attn_merge_kernel<128> (exl3_attn_decode.hip) operation for operation, so the bits are those of the two-launch route: statistics by
+                    // butterflies, the splits in four consecutive groups of ceil(nsplit / 4) summed sequentially and combined ((P0 + P1) + P2) + P3
+                    // (its four helper half-waves), 1 / L, the inverse 32-point rotation, fp16.  nsplit <= 32 (host-checked): one chunk of statistics.
+                    const float* p = attm_rec(row, (k0s >> 7) + blk);
+                    const bool has = l32 < at_nsplit;
+                    const float m_s = has ? cur.mst.x : -1.0e30f, l_s = has ? cur.mst.y : 0.0f;
+                    float M = m_s;
+                    #pragma unroll
+                    for (int i = 1; i < 32; i <<= 1) M = fmaxf(M, xor_lane(M, i));
+                    const float e_s = m_s > -1.0e29f ? __expf(m_s - M) : 0.0f;
+                    float L = l_s * e_s;
+                    #pragma unroll
+                    for (int i = 1; i < 32; i <<= 1) L += xor_lane(L, i);
+                    const int per = (at_nsplit + 3) >> 2, lbase = lane - l32;
+                    float4_t P[4];
+                    #pragma unroll
+                    for (int hh = 0; hh < 4; ++hh) P[hh] = float4_t{ 0.f, 0.f, 0.f, 0.f };
+                    for (int s0 = 0; s0 < at_nsplit; s0 += NMO)
+                    {
+                        float4_t ov[NMO];
+                        #pragma unroll
+                        for (int u = 0; u < NMO; ++u) ov[u] = s0 == 0 ? cur.mo[u] : *((const float4_t*) (p + (size_t) min(s0 + u, at_nsplit - 1) * 132 + 4 + 4 * l32));
+                        #pragma unroll
+                        for (int u = 0; u < NMO; ++u)
+                        {
+                            const int sg = min(s0 + u, at_nsplit - 1);
+                            const float ev = __shfl(e_s, lbase + sg, 64);
+                            const int hh = sg >= 3 * per ? 3 : (sg >= 2 * per ? 2 : (sg >= per ? 1 : 0));
+                            if (s0 + u < at_nsplit)
+                            {
+                                #pragma unroll
+                                for (int q = 0; q < 4; ++q) if (q == hh) { P[q].x += ov[u].x * ev; P[q].y += ov[u].y * ev; P[q].z += ov[u].z * ev; P[q].w += ov[u].w * ev; }
+                            }
+                        }
+                    }
+                    float o0 = P[0].x, o1 = P[0].y, o2 = P[0].z, o3 = P[0].w;
+                    #pragma unroll
+                    for (int hh = 1; hh < 4; ++hh) { o0 += P[hh].x; o1 += P[hh].y; o2 += P[hh].z; o3 += P[hh].w; }
+                    const float inv = L > 0.0f ? 1.0f / L : 0.0f;
+                    float v0 = o0 * inv, v1 = o1 * inv, v2 = o2 * inv, v3 = o3 * inv;
+                    kvg_had32(v0, v1, v2, v3, lane);
+                    const float r32 = 0.17677669529663688110f;
+                    xv = half4_t{ f2h(v0 * r32), f2h(v1 * r32), f2h(v2 * r32), f2h(v3 * r32) };
+                }
                 if constexpr (MODE == G4_MODE_ACTFX)
                 {
                     // g, u of this (row, block) are complete in the accumulators (out-Hadamard and svh were applied per split-k partial, the sum is
@@ -494,8 +559,10 @@ void exl3_gemv4_kernel(const GemvArgs a)
                 if constexpr (MODE == G4_MODE_NORMFX) { if (cbg == 0 && act && l32 == 0) a.rs_ss_out[(size_t) row * (a_k >> 7) + (k0s >> 7) + blk] = ssq_pub; }
             }
         };
-#ifdef G4_PRIO
-        if (prep_wave) __builtin_amdgcn_s_setprio(3);          // A/B build: the workgroup's critical path ahead of its streaming neighbours on the SIMD
+#ifndef G4_NO_PRIO
+        // the workgroup's critical path (its preparation tasks, and below the half-waves that finish its outputs) ahead of the streaming waves that share
+        // the SIMD: +1.5 % on the whole batch-1 step (round 4, tools/experiments/variant_queue.sh, same box: 646.4 against 637.6 / 635.4 tok/s)
+        if (prep_wave) __builtin_amdgcn_s_setprio(3);
 #endif
         if (prep_wave)
         {
@@ -512,7 +579,7 @@ void exl3_gemv4_kernel(const GemvArgs a)
                 }
             }
         }
-#ifdef G4_PRIO
+#ifndef G4_NO_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
         __syncthreads();
@@ -565,7 +632,7 @@ void exl3_gemv4_kernel(const GemvArgs a)
     G4_T(4);
 
     // ---- half-wave h takes rows h, h + nhw, ...: sum of the waves' partials, the mul1 FAST affine map, then the slab line or the final output row
-#ifdef G4_PRIO
+#ifndef G4_NO_PRIO
     if (hwid < m) __builtin_amdgcn_s_setprio(3);
 #endif
     const int l = l32;
@@ -689,6 +756,7 @@ static void g4_launch_cb(int var, int mode, int nwv, dim3 grid, size_t lds, hipS
         case G4_MODE_ACTFX: LV(G4_MODE_ACTFX) break;
         case G4_MODE_TRAWX: LV(G4_MODE_TRAWX) break;
         case G4_MODE_TACT: LV(G4_MODE_TACT) break;
+        case G4_MODE_ATTM: LV(G4_MODE_ATTM) break;
         default:           LV(G4_MODE_ACT)  break;
     }
     #undef LV

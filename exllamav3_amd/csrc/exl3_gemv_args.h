@@ -48,10 +48,16 @@ __device__ __forceinline__ void fx_atomic_add(unsigned long long* acc, float v)
 #endif
 #define GEMV_IN_ACTFX     128  // (generation 4) down_proj whose input silu(g) * u is formed from the gate / up rows that a GEMV_OUT_ATOMIC gate|up launch ADDED into two
                               // fixed-point accumulators (act_g / act_u reinterpreted as int64 [m][k]): no slab reduction in the prologue, 2 KB per task
+#define GEMV_IN_ATTM      256  // (generation 4) o_proj whose input is the decode attention's OUTPUT, finished here: the flash-decoding merge of the context-split
+                              // partial records (exl3_attn_decode.hip: {m, l, o[128]} per (sequence, kv block, query index, split)) is the preparation task of
+                              // the (row, head) that needs it -- head_dim 128: one query head = one Hadamard block -- so the merge launch disappears
 #define GEMV_MAX_MATS 4
 
 // r = rsqrt(sum(ss_new[row]) / k + eps) / rsqrt(sum(ss_prev[row]) / k + eps): the exact RMSNorm scale over the estimate a GEMV_IN_RESID launch used.
 struct GemvRescale { const float* ss_prev; const float* ss_new; int k; float eps; };
+
+// GEMV_IN_ATTM operands: partial records part[((row * blocks + h) * gq + i) * nsplit + split][132] fp32 = {m, l, -, -, o[128]} of query head h * gq + i
+struct GemvAttm { const float* part; int nsplit, gq, blocks; uint32_t magic_gq; };
 
 struct GemvMat
 {
@@ -189,6 +195,7 @@ struct GemvArgs
     // fx pipeline: a buffer this launch clears as a side job (n16 16-byte chunks spread over the workgroups): the gate / up accumulators of the NEXT
     // gate|up launch are zeroed by the o_proj launch in front of it -- no memset node in the graph
     void* fx_zero; int fx_zero_n16;
+    GemvAttm attm;
 };
 static_assert(offsetof(GemvArgs, mat) == 128, "GemvArgs: the hot block is two 64-byte lines");
 

@@ -1356,6 +1356,38 @@ def attn_prefill_paged(q, out, k_pages, v_pages, block_table, cache_seqlens, sca
                                               float(scale if scale is not None else hd ** -0.5), _stream(q)))
 
 
+def attn_decode_qcache_split(q, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, max_len: int, workspace: torch.Tensor,
+                             scale: float | None = None) -> int:
+    """The context-split half of attn_decode_qcache (head_dim 128): partial records stay in `workspace`; returns the split count for
+    exl3_gemv_ex_attm, which merges them inside o_proj's launch."""
+    _dev(q)
+    _req(q.dtype == torch.half and q.dim() == 3 and q.shape[-1] == 128 and q.is_contiguous(), "attn_decode_split: q must be contiguous (bsz, heads, 128) float16")
+    _req(block_table.dtype == torch.int32 and cache_seqlens.dtype == torch.int32, "attn_decode: block_table / cache_seqlens must be int32")
+    _req(workspace is not None and workspace.dtype == torch.float and workspace.is_contiguous(), "attn_decode_split: float32 workspace required")
+    bsz, hq, hd = q.shape
+    hkv = k_scales.shape[-1] * 32 // hd
+    kb, vb = _kv_bits(k_cache, k_scales), _kv_bits(v_cache, v_scales)
+    ns = ctypes.c_int(0)
+    _check(_lib.lib().exl3_attn_decode_qcache_split(_p(q), _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table), _p(cache_seqlens),
+                                                    bsz, block_table.shape[1], k_cache.shape[1], kb, vb, hq, hkv, hd, int(max_len),
+                                                    float(scale if scale is not None else hd ** -0.5), _p(workspace), workspace.numel(), ctypes.byref(ns), _stream(q)))
+    return ns.value
+
+
+def exl3_gemv_ex_attm(part: torch.Tensor, nsplit: int, heads_q: int, heads_kv: int, B, C, suh, svh, m: int, mcg: bool, mul1: bool, flags: int = 0,
+                      force_split: int = 0, c_fp32: bool = False):
+    """o_proj whose input is the decode attention's output, merged from the context-split partial records inside the launch (ext.attn_decode_qcache_split).
+    Returns ([slab], S) like exl3_gemv_ex."""
+    _dev(B)
+    k, K = _kK(B)
+    _req(k == heads_q * 128 and heads_q % heads_kv == 0, "exl3_gemv_ex_attm: k must be heads_q x 128")
+    slab = (_vp * 1)()
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_gemv_ex_attm(_p(part), int(nsplit), heads_q // heads_kv, heads_kv, _p(B), _p(C), _p(suh), _p(svh), None, m, k, B.shape[1] * 16, K,
+                                        _cb(mcg, mul1), int(c_fp32), flags, force_split, slab, ctypes.byref(S), _stream(B)))
+    return [int(slab[0]) if slab[0] else 0], S.value
+
+
 def attn_decode_qcache(q, out, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, max_len: int, scale: float | None = None,
                        workspace: torch.Tensor | None = None):
     """Decode attention straight from the quantized paged cache.  q / out: (bsz, heads_q, 128) fp16; caches (pages, page, G * bits) int32 +

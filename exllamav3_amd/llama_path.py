@@ -398,6 +398,9 @@ class SyntheticEXL3Llama:
 
     #: include the decode attention over the quantized cache in decode_step_fused (bench.py --attention)
     with_attention = False
+    #: fx pipeline, head_dim 128: the flash-decoding merge of the attention's context splits runs inside o_proj's launch (ext.exl3_gemv_ex_attm) instead of
+    #: as its own launch -- same bits, one launch less per layer
+    attn_merge_in_oproj = os.environ.get("EXL3_HIP_ATTN_MERGE_IN_OPROJ", "1") != "0"
 
     #: lm_head at m <= 4: glue_rotate + pre-rotated GEMV instead of the in-GEMV RMSNorm (the 1002-column-block launch repeats the 32 input
     #: Hadamards in every workgroup in NORM mode)
@@ -692,10 +695,15 @@ class SyntheticEXL3Llama:
                             self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, so_, hidden, self.eps, tab=tab)
             sc, so_ = so_, sc
             o_in = q2
+            attm = None                                                    # (partial records, splits): the merge runs inside o_proj's launch
             if self.with_attention and hd in (64, 128):
-                ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
-                                       self.attn_pos + 1, workspace=self.attn_ws)
-                o_in = self.attn_out.view(bsz, -1)
+                if hd == 128 and self.attn_merge_in_oproj and not self.fx_gu_atomic:
+                    attm = (self.attn_ws, ext.attn_decode_qcache_split(self.q.view(bsz, self.hq, hd), kc, ks, vc, vs, self.block_table, self.attn_lens,
+                                                                       self.attn_pos + 1, self.attn_ws))
+                else:
+                    ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
+                                           self.attn_pos + 1, workspace=self.attn_ws)
+                    o_in = self.attn_out.view(bsz, -1)
             if self.fx_gu_atomic:
                 # 5 launches per layer: gate|up ADD their rows into two fixed-point accumulators (cleared by the o_proj launch as a side job) and
                 # down_proj forms silu(g) * u from them in its prologue -- no glue_act launch, no slab reduction anywhere in the MLP
@@ -707,7 +715,10 @@ class SyntheticEXL3Llama:
                                        ATOM, sp["down"])
                 sc, so_ = so_, sc
                 continue
-            ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], [R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM, sp["o"])
+            if attm is not None:
+                ext.exl3_gemv_ex_attm(attm[0], attm[1], self.hq, self.hkv, lo.trellis, R, lo.suh, lo.svh, bsz, lo.mcg, lo.mul1, ATOM, sp["o"])
+            else:
+                ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], [R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM, sp["o"])
             sgu, Sgu = ext.exl3_gemv_ex_fx(R, L["norm2"], sc, so_, self.eps, [lg.trellis, lu.trellis], [lg.suh, lu.suh], bsz, lg.mcg, lg.mul1, sp["gu"])
             if self.fx_act_in_gemv:
                 # silu(g) * u (with the row-scale correction) + input Hadamard inside the down launch: 5 launches per layer

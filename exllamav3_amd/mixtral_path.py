@@ -89,6 +89,7 @@ class SyntheticEXL3Mixtral:
         self.inv_freq = (1.0 / (shape.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))).to(self.device)
         self.eps, self.page, self.max_ctx = 1e-5, 256, max_ctx
         self.with_attention = False
+        self.attn_merge_in_oproj = True                                # fx step, head_dim 128: attention merge inside o_proj's launch (ext.exl3_gemv_ex_attm)
         self.norm_in_router = True                                     # False: separate rms_norm launch in front of every MoE block
         self.fused_moe_tail = True                                     # one rank: split-k reduce + slot sum + residual add of a MoE block in one launch
         self._state_bsz = None
@@ -147,11 +148,17 @@ class SyntheticEXL3Mixtral:
                             self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, so_, hidden, self.eps, tab=tab)
             sc, so_ = so_, sc
             o_in = q2
-            if self.with_attention:
-                ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
-                                       self.attn_pos + 1, workspace=self.attn_ws)
-                o_in = self.attn_out.view(bsz, -1)
-            ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], [R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM, 8 if self.hq * hd == 4096 else 0)
+            so_split = 8 if self.hq * hd == 4096 else 0
+            if self.with_attention and hd == 128 and self.attn_merge_in_oproj:
+                # the flash-decoding merge of the context splits runs inside o_proj's launch (llama_path.decode_step_fx)
+                ns = ext.attn_decode_qcache_split(self.q.view(bsz, self.hq, hd), kc, ks, vc, vs, self.block_table, self.attn_lens, self.attn_pos + 1, self.attn_ws)
+                ext.exl3_gemv_ex_attm(self.attn_ws, ns, self.hq, self.hkv, lo.trellis, R, lo.suh, lo.svh, bsz, lo.mcg, lo.mul1, ATOM, so_split)
+            else:
+                if self.with_attention:
+                    ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
+                                           self.attn_pos + 1, workspace=self.attn_ws)
+                    o_in = self.attn_out.view(bsz, -1)
+                ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], [R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM, so_split)
             moe.forward_fx(R, L["norm2"], self.eps, so_, self.xn)      # the router leaves the exact sums of squares of the residual it read
             sc, so_ = so_, sc
         ext.fx_finish(R, self.x, sc, bsz)

@@ -335,6 +335,17 @@ int exl3_attn_decode_qcache(const void* q, void* out, const void* k_cache, const
                             const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
                             int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
                             float* workspace, int64_t workspace_floats, void* stream);
+/* The context-split half of exl3_attn_decode_qcache only (head_dim 128): the partial records {m, l, -, -, o[128]} of every (sequence, 128-value kv block,
+ * query index, split) stay in `workspace` ([bsz][blocks][gq][*nsplit_out][132] fp32, written also with a single split; at most 32 splits) and the
+ * consumer of the attention output merges them: exl3_gemv_ex_attm is o_proj with that merge as the preparation task of each (row, head) -- the
+ * arithmetic of the merge kernel operation for operation, so attention + o_proj give the same bits with one launch less
+ * (libtorch/attention.cpp:246-504: attention, then the o_proj linear).  flags: EXL3_GEMV_OUT_DEFERRED / EXL3_GEMV_OUT_ATOMIC / 0. */
+int exl3_attn_decode_qcache_split(const void* q, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
+                                  const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
+                                  int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
+                                  float* workspace, int64_t workspace_floats, int* nsplit_out, void* stream);
+int exl3_gemv_ex_attm(const float* part, int nsplit, int gq, int blocks, const void* B, void* C, const void* suh, const void* svh, const void* bias,
+                      int m, int k, int n, int K, int cb, int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream);
 /* Prefill (multi-token) causal attention over paged fp16 K/V -- the attention step of the reference's prefill path: cache/quant.py:83-117
  * dequantizes the pages (exl3_dequant_cache_paged), then flash_attn_with_kvcache(q, k_pages, v_pages, block_table, cache_seqlens, causal) attends.
  * q / out fp16 [bsz][q_len][heads_q][head_dim] (head_dim 128 or 64); k_pages / v_pages fp16 [pages][page_size][heads_kv][head_dim];

@@ -792,6 +792,71 @@ def test_fused_step_with_attention_matches_oracle(dev):
     assert np.abs(logits - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
 
 
+@pytest.mark.parametrize("pos", [3, 70, 300, 1000, 3000])
+@pytest.mark.parametrize("bsz", [1, 2])
+def test_attention_merge_inside_oproj_is_bit_identical_to_the_merge_launch(dev, pos, bsz):
+    """fx step with the decode attention in it (head_dim 128): the flash-decoding merge of the context splits as o_proj's preparation task
+    (ext.attn_decode_qcache_split + ext.exl3_gemv_ex_attm, round 4) against attn_decode_qcache (split + merge launches) + o_proj: logits, final residual
+    and the K / V rows appended -- bit for bit up to 32 splits of 64 tokens, from a 4-token context (one split: the half-wave kernel writes a record
+    instead of its output); at 3001 tokens the fused form takes longer splits (another summation order: a few fp16 ulps of the logits, 1e-2 bound); graph replay reproduces the eager bits;
+    the oracle bound holds."""
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 512, 1024, 2, 4, 2, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=4096)
+    model.alloc_state(bsz, pos=pos)
+    model.with_attention = True
+    rng = np.random.default_rng(pos)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ctx = []
+    for li in range(shape.layers):
+        ck = rng.standard_normal((bsz, 4096, model.hkv * 128)).astype(np.float16); cv = rng.standard_normal((bsz, 4096, model.hkv * 128)).astype(np.float16)
+        kq, ks = o.kv_quant(ck, 4); vq, vs = o.kv_quant(cv, 4)
+        kc, ksc = model.kcache[li]; vc, vsc = model.vcache[li]
+        kc.copy_(T(kq.view(np.int32)).view(kc.shape)); ksc.copy_(T(ks).view(ksc.shape)); vc.copy_(T(vq.view(np.int32)).view(vc.shape)); vsc.copy_(T(vs).view(vsc.shape))
+        ctx.append((kq, ks, vq, vs))
+    outs = []
+    for fused in (False, True):
+        model.attn_merge_in_oproj = fused
+        lg = model.decode_step_fx().float().cpu().numpy().copy()
+        outs.append((lg, model.x_final.clone(), [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]))
+    (l0, x0_, kv0), (l1, x1_, kv1) = outs
+    assert np.isfinite(l1).all()
+    if pos <= 1000:
+        assert np.array_equal(l0, l1) and torch.equal(x0_, x1_)
+    else:
+        # beyond 32 splits of 64 tokens the fused form takes fewer, longer splits than the merge launch would (its statistics live in one chunk of 32
+        # lanes): the same attention, another summation order
+        assert np.abs(l0 - l1).max() / np.sqrt((l0 ** 2).mean()) < 1e-2
+    assert all(torch.equal(a0, a1) and torch.equal(b0, b1) for (a0, b0), (a1, b1) in zip(kv0[:2 * shape.layers][:1], kv1[:2 * shape.layers][:1]))      # layer 0's K rows: same inputs
+    # oracle (attention over the dequantized cache incl. the appended token)
+    x = _np(model.x0); pend = None
+    for li, L in enumerate(model.layers):
+        if pend is None: xn = o.rms_norm(x, _np(L["norm1"]), model.eps)
+        else: xn, x = o.rms_norm(pend, _np(L["norm1"]), model.eps, residual_in=x)
+        q, k, v = _lin(L["q"], xn), _lin(L["k"], xn), _lin(L["v"], xn)
+        q4, k4 = o.rope(q.reshape(bsz, 1, model.hq, 128), k.reshape(bsz, 1, model.hkv, 128), _np(model.inv_freq), positions=_np(model.positions), rope_mode=o.ROPE_NEOX)
+        kq, ks, vq, vs = ctx[li]
+        knq, kns = o.kv_quant(k4.reshape(bsz, 1, -1), 4); vnq, vns = o.kv_quant(v.reshape(bsz, 1, -1), 4)
+        kq[:, pos:pos + 1] = knq; ks[:, pos:pos + 1] = kns; vq[:, pos:pos + 1] = vnq; vs[:, pos:pos + 1] = vns
+        kd = o.kv_dequant(kq[:, :pos + 1], ks[:, :pos + 1], 4).reshape(bsz, pos + 1, model.hkv, 128); vd = o.kv_dequant(vq[:, :pos + 1], vs[:, :pos + 1], 4).reshape(bsz, pos + 1, model.hkv, 128)
+        att = o.attn_decode_qcache(q4.reshape(bsz, model.hq, 128), kd, vd, [pos + 1] * bsz).reshape(bsz, -1)
+        ov = _lin(L["o"], att, out_fp32=True)
+        xn, x = o.rms_norm(ov, _np(L["norm2"]), model.eps, residual_in=x)
+        gf, uf = _lin(L["gate"], xn).astype(np.float32), _lin(L["up"], xn).astype(np.float32)
+        a = (gf / (1 + np.exp(-gf)) * uf).astype(np.float16)
+        pend = _lin(L["down"], a, out_fp32=True)
+    xn, x = o.rms_norm(pend, _np(model.final_norm), model.eps, residual_in=x)
+    ref = _lin(model.lm_head, xn).astype(np.float32)
+    assert np.abs(l1 - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            model.decode_step_fx()
+    model.logits.zero_(); g.replay(); torch.cuda.synchronize()
+    assert np.array_equal(model.logits.float().cpu().numpy(), l1)
+
+
 @pytest.mark.parametrize("bsz", [1, 16])
 def test_fused_pipeline_on_70b_tp8_rank_shapes(dev, bsz):
     """The per-rank shapes of Llama-3.1-70B under TP = 8 (hidden 8192, q 8 heads, ONE kv head -> 128-column k / v matrices, inter 3584,
