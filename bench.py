@@ -227,7 +227,6 @@ def main():
         # BASELINE config 5: Mixtral layer = attention (tensor-parallel) + sparse-MoE block (expert-parallel over the ranks), 4-bit KV
         shape = MIXTRAL_SHAPES[args.model]
         model = SyntheticEXL3Mixtral(shape, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits, layers=args.layers or None)
-        args.no_prefill = True
     else:
         shape = SHAPES[args.model]
         model = SyntheticEXL3Llama(shape, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits,
@@ -453,7 +452,7 @@ def main():
     # partial sums of o_proj / down_proj go through the collective library (RCCL ring: bandwidth matters at 4096 x hidden; reference
     # model/model_tp_backend.py:119-126, method eval/perf.py:36-56); barrier + synchronize on both sides, MAX over ranks like the decode leg
     prefill = None
-    if not args.no_prefill and not is_moe:
+    if not args.no_prefill:
         toks = args.prefill_tokens
         model.prefill_chunk(toks)                       # warm-up (GEMM autotune, allocator)
         torch.cuda.synchronize(); backend.fwd_barrier()
@@ -468,7 +467,8 @@ def main():
             backend.all_reduce_max(dtt)
             chunk_s.append(float(dtt.item()))
         dt = sorted(chunk_s)[len(chunk_s) // 2]
-        flops = shape.prefill_flops_per_token() * toks * (model.n_layers / shape.layers)      # whole job (all ranks)
+        # whole job (all ranks); Mixtral: attention linears + top-2 of 8 experts per token (the grouped-by-expert prefill tier, moe_path.forward_prefill)
+        flops = (model.prefill_flops_per_token() * toks) if is_moe else shape.prefill_flops_per_token() * toks * (model.n_layers / shape.layers)
         peak_all = MFMA_PEAK_TFLOPS * world
         prefill = {"metric": "prefill tok/s", "value": round(toks / dt, 1), "unit": "tok/s", "chunk_tokens": toks, "n_gpus": world,
                    "ms_per_chunk": round(dt * 1e3, 2), "repeat_ms_per_chunk": [round(v * 1e3, 2) for v in chunk_s],
@@ -493,7 +493,7 @@ def main():
 
         # the same chunk with the attention core in the timed region (append to the quantized cache, expand the pages, causal attention over them):
         # reported beside the headline, which follows BASELINE.json's linears-only shapes (science/qgemm_benchmark.py)
-        if not args.attention and world == 1:
+        if not args.attention and world == 1 and not is_moe:
             model.prefill_attention = True
             model.prefill_chunk(toks); torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -510,7 +510,7 @@ def main():
 
         # MI355X option: reconstructed fp16 W kept resident across chunks (LinearEXL3.cache_reconstructed; 0.5 GB per 8B layer).
         # Reported separately: the chunk above reconstructs every matrix per forward exactly like the reference.
-        if world == 1:
+        if world == 1 and not is_moe:
             from exllamav3_amd.linear import LinearEXL3
             LinearEXL3.cache_reconstructed = True
             model.prefill_chunk(toks); torch.cuda.synchronize()

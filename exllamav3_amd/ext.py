@@ -426,6 +426,18 @@ def exl3_moe(hidden_state, output_state, expert_count, token_sorted, weight_sort
     _check(_lib.lib().exl3_moe_scatter(_p(D), _p(rowmap), _p(token_sorted), _p(weight_sorted), _p(output_state), bsz, T, hidden, st))
 
 
+def moe_scatter(D: torch.Tensor, rowmap: torch.Tensor, token_sorted: torch.Tensor, weight_sorted: torch.Tensor, out: torch.Tensor):
+    """out[t] (fp32, += in place) += sum over token t's assignments p, in ascending p, of weight_sorted[p] * D[rowmap[p]] -- the weighted scatter of a MoE
+    block in a FIXED order (bit-reproducible; the reference's index_add_ is an atomic scatter, modules/block_sparse_mlp.py:1308-1309).  rowmap[p] < 0: skipped."""
+    _dev(D)
+    _req(D.dtype == torch.float and out.dtype == torch.float and D.dim() == 2 and out.dim() == 2 and D.shape[1] == out.shape[1] and D.is_contiguous() and out.is_contiguous(),
+         "moe_scatter: D / out must be contiguous float32 (rows, hidden)")
+    _req(rowmap.dtype == torch.int32 and token_sorted.dtype == torch.long and weight_sorted.dtype == torch.half and rowmap.numel() == token_sorted.numel() == weight_sorted.numel(),
+         "moe_scatter: rowmap int32, token_sorted int64, weight_sorted float16, one entry per assignment")
+    _req(out.shape[1] % 4 == 0, "moe_scatter: hidden must be a multiple of 4")
+    _check(_lib.lib().exl3_moe_scatter(_p(D), _p(rowmap), _p(token_sorted), _p(weight_sorted), _p(out), out.shape[0], token_sorted.numel(), out.shape[1], _stream(D)))
+
+
 def hgemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):
     """hgemm.cu:19-102: c = a @ b, fp16 inputs, fp32 accumulate, c fp16/fp32 (may be a column slice)."""
     _dev(a)

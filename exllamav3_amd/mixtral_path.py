@@ -166,6 +166,75 @@ class SyntheticEXL3Mixtral:
                               bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
         return self.logits
 
+    # ---- one prefill chunk (config 5's prefill leg) ----------------------------------------------------------------
+    prefill_attention = False
+
+    def prefill_flops_per_token(self) -> int:
+        """2 * (attention linears + top_k x (gate + up + down)) per layer (router and lm_head excluded, as for the Llama shapes)."""
+        s, hd = self.shape, self.shape.head_dim
+        attn = s.hidden * (s.heads_q * hd) * 2 + s.hidden * (s.heads_kv * hd) * 2
+        return 2 * (attn + s.top_k * 3 * s.hidden * s.inter) * self.n_layers
+
+    def prefill_allreduce_dtype(self):
+        """dtype of the (tokens, hidden) partial sums a rank hands to the all-reduce in prefill_chunk (o_proj and the MoE block produce fp32)."""
+        return torch.float
+
+    def prefill_chunk(self, tokens: int):
+        """All linears + norms + rope + KV-quant + the sparse-MoE block of a `tokens`-token chunk (bsz 1): llama_path.prefill_chunk with the MLP replaced
+        by SyntheticEXL3MoE.forward_prefill (modules/block_sparse_mlp.py:1169-1330: the grouped-by-expert large-batch tier).  Attention core out of the
+        default scope like there (attention output := rope(q)); prefill_attention adds dequant_cache_paged + the causal chunk attention.  Tensor /
+        expert parallel ranks all-reduce the o_proj and MoE partial sums."""
+        from .linear import LinearEXL3
+        s, hd, dev, be = self.shape, self.shape.head_dim, self.device, self.backend
+        if getattr(self, "_pf_tokens", None) != tokens:
+            self.px0 = torch.randn((tokens, s.hidden), device=dev).half()
+            self._pf_tokens = tokens
+            G = self.hkv * hd // 32
+            pages = (tokens + self.page - 1) // self.page
+            self.pf_bt = torch.arange(pages, dtype=torch.int32, device=dev).view(1, pages)
+            self.pf_sl = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self.pf_cache = [torch.zeros((pages, self.page, G * self.kv_bits), dtype=torch.int32, device=dev) for _ in range(2)] + \
+                            [torch.zeros((pages, self.page, G), dtype=torch.half, device=dev) for _ in range(2)]
+            self.pf_kd = torch.zeros((pages, self.page, self.hkv * hd), dtype=torch.half, device=dev)
+            self.pf_vd = torch.zeros_like(self.pf_kd)
+            self.pf_len = torch.full((1,), tokens, dtype=torch.int32, device=dev)
+            self.pf_ao = torch.empty((tokens, self.hq * hd), dtype=torch.half, device=dev)
+        x = self.px0.clone()
+        xn = torch.empty_like(x)
+        for L in self.layers:
+            ext.rms_norm(x, L["norm1"], xn, self.eps)
+            qkv = LinearEXL3.forward_multi([L["q"], L["k"], L["v"]], xn) if hd == 128 else None
+            if qkv is not None:
+                q, k, v = qkv                                              # column ranges of ONE GEMM's output: rope and the cache append take the row stride
+                ext.rope_strided(q, k, self.inv_freq, 0, None, None, 1.0, 1, tokens)
+                ext.quant_cache_paged_strided(k, self.pf_cache[0], self.pf_cache[2], v, self.pf_cache[1], self.pf_cache[3], self.pf_sl, self.pf_bt, self.page, tokens)
+            else:
+                q4_ = L["q"].forward(xn).view(1, tokens, self.hq, hd); k4_ = L["k"].forward(xn).view(1, tokens, self.hkv, hd); v4_ = L["v"].forward(xn).view(1, tokens, self.hkv, hd)
+                ext.rope(q4_, q4_, k4_, k4_, self.inv_freq, 0, None, None, 2, 1.0)
+                ext.quant_cache_paged(k4_.view(1, tokens, -1), self.pf_cache[0], self.pf_cache[2], v4_.view(1, tokens, -1), self.pf_cache[1], self.pf_cache[3],
+                                      self.pf_sl, self.pf_bt, self.page, tokens)
+                q = q4_.view(tokens, -1)
+            if self.prefill_attention:
+                ext.dequant_cache_paged(self.pf_cache[0], self.pf_cache[2], self.pf_kd, self.pf_cache[1], self.pf_cache[3], self.pf_vd, self.pf_len, self.pf_bt, self.page)
+                q4 = q.as_strided((1, tokens, self.hq, hd), (tokens * q.stride(0), q.stride(0), hd, 1), q.storage_offset())
+                ext.attn_prefill_paged(q4, self.pf_ao.view(1, tokens, self.hq, hd), self.pf_kd.view(-1, self.page, self.hkv, hd),
+                                       self.pf_vd.view(-1, self.page, self.hkv, hd), self.pf_bt, self.pf_len)
+                q = self.pf_ao
+            if self.tp == 1:
+                L["o"].forward_add_residual(q, x)
+                ext.rms_norm(x, L["norm2"], xn, self.eps)
+            else:
+                o = L["o"].forward(q.contiguous().view(tokens, -1))
+                be.all_reduce(o)
+                ext.rms_norm_res_in(o, L["norm2"], xn, x, self.eps)
+            y = L["moe"].forward_prefill(xn)
+            if self.tp > 1:
+                be.all_reduce(y)
+            ext.add(x, y)
+        self.px_out = x
+        ext.rms_norm(x[-1:], self.final_norm, xn[-1:], self.eps)
+        return self.lm_head.forward(xn[-1:].contiguous())
+
     def decode_step(self):
         """One decode step (bsz tokens, one per sequence), graph-capturable.  Per layer: 4 launches for the attention sublayer (+2 with the
         attention core), router (RMSNorm inside) + gate|up + down + one tail launch for the MoE block on one rank (3-5 launches + the fused IPC all-reduce with EP)."""

@@ -1,5 +1,6 @@
 """
-Sparse-MoE MLP block of the hot path (BASELINE config 5: Mixtral 8x7B shapes), decode form: router -> indexed / weighted exl3_mgemm.
+Sparse-MoE MLP block of the hot path (BASELINE config 5: Mixtral 8x7B shapes): decode form (router -> indexed / weighted exl3_mgemm) and, round 4,
+the prefill form (forward_prefill: assignments grouped by expert, per-expert reconstruct + GEMM, fixed-order weighted scatter).
 
 Mirrors what the reference's BlockSparseMLP does at bsz 1 (modules/block_sparse_mlp.py:51-93 routing_std, then exl3_mgemm with pointer
 tables + indices for gate / up and indices + weights for down, libtorch/blocksparse_mlp.cpp), composed from this build's C-ABI ops:
@@ -159,6 +160,49 @@ class SyntheticEXL3MoE:
                 sd = s7
         ext.exl3_mgemm_act_fx(slab, S, self.gu_svh, self.E, self.d_B, self.d_suh, self.d_svh, self.sel.view(-1), self.w.view(-1), R, self.K, mcg, mul1,
                               self.inter, m=1, num_tokens=1, force_split=sd)
+
+    def forward_prefill(self, x: torch.Tensor) -> torch.Tensor:
+        """The block for a prefill chunk (rows > the decode tiers): the large-batch tier of BlockSparseMLP.forward (modules/block_sparse_mlp.py:1169-1330).
+        x (tokens, hidden) fp16, normalised.  Router over all rows -> assignments grouped by expert (stable argsort + bincount; the counts go to
+        the host like the reference's expert_count.tolist(): they size the GEMMs) -> per expert with rows: gather its tokens, gate|up as ONE GEMM on
+        the stacked reconstructed W^T + silu * mul, down with fp32 output (LinearEXL3's routes: reconstruct_had_slice_t + NT GEMM above 144 rows,
+        the small-m kernel below -- the reference's run_single_expert_dq / run_single_expert tiers) -> weighted scatter in ascending assignment order
+        (ext.moe_scatter: fixed order, bit-reproducible; the reference scatters with index_add_).  Expert parallelism: only the local experts
+        [first, last) run and the result is this rank's partial sum.  Returns (tokens, hidden) fp32."""
+        from .linear import LinearEXL3
+        T, k, dev = x.shape[0], self.top_k, x.device
+        scores = torch.empty((T, self.E), dtype=torch.half, device=dev)
+        sel = torch.empty((T, k), dtype=torch.long, device=dev)
+        w = torch.empty((T, k), dtype=torch.half, device=dev)
+        ext.routing_std(x, self.router, scores, sel, w)
+        self.pf_sel, self.pf_w = sel, w                                   # (parity tests read the routing)
+        nloc = self.last - self.first
+        flat_e = sel.reshape(-1) - self.first
+        flat_e = torch.where((flat_e >= 0) & (flat_e < nloc), flat_e, torch.full_like(flat_e, nloc))      # non-local experts: sentinel group, skipped
+        flat_t = torch.arange(T, device=dev, dtype=torch.long).repeat_interleave(k)
+        order = torch.argsort(flat_e, stable=True)
+        token_sorted = flat_t[order].contiguous()
+        weight_sorted = w.reshape(-1)[order].contiguous()
+        counts = torch.bincount(flat_e, minlength=nloc + 1).tolist()
+        n_local = sum(counts[:nloc])
+        out = torch.zeros((T, self.hidden), dtype=torch.float, device=dev)
+        if n_local == 0:
+            return out
+        D = torch.empty((n_local, self.hidden), dtype=torch.float, device=dev)
+        start = 0
+        for e in range(nloc):
+            c = counts[e]
+            if c == 0:
+                continue
+            xs = x.index_select(0, token_sorted[start: start + c])
+            a = LinearEXL3.forward_gate_up_silu(self.gate[e], self.up[e], xs)
+            D[start: start + c] = self.down[e].forward(a, out_dtype=torch.float)
+            start += c
+        rowmap = torch.arange(T * k, dtype=torch.int32, device=dev)
+        if n_local < T * k:
+            rowmap[n_local:] = -1                                          # assignments of the other ranks' experts
+        ext.moe_scatter(D, rowmap, token_sorted, weight_sorted, out)
+        return out
 
     def _forward_expert_parallel(self, x: torch.Tensor) -> torch.Tensor:
         """Local experts [first, last) only: the launches filter the routed indices to the range (in-range slots are compacted to the front,
