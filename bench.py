@@ -237,8 +237,8 @@ def main():
 
     # ---- decode: eager warm-up (also creates library contexts), graph capture, timed replays
     pipeline = "unfused" if args.unfused else args.pipeline
-    if pipeline in ("tail", "fx") and world > 1:
-        pipeline = "glue"                                  # TP ranks all-reduce between o/down and the norm
+    if pipeline == "tail" and world > 1:
+        pipeline = "glue"                                  # TP ranks all-reduce between o/down and the norm ("fx" has its own TP form: llama_path._decode_step_fx_tp)
     fused = pipeline != "unfused"
     run_step = (model.decode_step_fx if pipeline == "fx" else model.decode_step) if is_moe else \
         {"tail": model.decode_step_tail, "glue": model.decode_step_fused, "resid": model.decode_step_resid, "fx": model.decode_step_fx,
@@ -589,13 +589,14 @@ def main():
         from exllamav3_amd.tp import OneRankOfMany
         m70 = SyntheticEXL3Llama(SHAPES["llama-3.1-70b"], K=3, cb=cb, device=dev, backend=OneRankOfMany(8, dev), kv_bits=args.kv_bits)
         m70.alloc_state(1)
-        r70 = timed_decode(m70, m70.decode_step_fused, 1)
+        r70 = timed_decode(m70, m70.decode_step_fx if pipeline == "fx" else m70.decode_step_fused, 1)
+        r70["launches_per_layer"] = 7 if pipeline == "fx" else 10
         rank_bytes = sum((k * n * 3 // 8 + 2 * (k + n)) * cnt for (k, n, cnt) in m70.gemv_launches_per_step())
         r70.update({"bits": 3, "tp": 8, "rank_bytes_per_token": int(rank_bytes),
                     "frac_of_hbm_roofline": round((1e3 / r70["ms_per_step"]) / (HBM_PEAK_GBPS * 1e9 / rank_bytes), 4),
                     "allreduce_estimate_ms": round(160 * 6.7e-3, 3),
                     "tok_s_with_allreduce_estimate": round(1e3 / (r70["ms_per_step"] + 160 * 6.7e-3), 1),
-                    "note": "one rank's compute leg only (no-op collectives); allreduce_estimate_ms = 160 x 6.7 us, the IPC push + residual add measured between two "
+                    "note": "one rank's compute leg only (the TP form of the timed pipeline with the exchange left out of its all-reduce launches: tp.OneRankOfMany); allreduce_estimate_ms = 160 x 6.7 us, the IPC push + residual add measured between two "
                             "processes on ONE GPU -- an ESTIMATE, no xGMI link was crossed; frac_of_hbm_roofline uses the rank's own bytes"})
         extra["llama-3.1-70b_tp8_rank_bs1"] = r70
         del m70

@@ -178,6 +178,8 @@ def _declare(l):
     sig("exl3_gemv_ex_fx_atomic", vp, vp, vp, vp, f32, PP, PP, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), vp)
     sig("exl3_gemv_ex_actfx", vp, vp, vp, vp, i32, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
     sig("exl3_fx_zero_next", vp, i64)
+    sig("exl3_fx_add", vp, vp, vp, i32, vp, i32, i32, vp)
+    sig("exl3_ar_reduce_fx", vp, vp, vp, i32, vp, vp, i32, i32, vp)
     sig("exl3_set_gemv_variant", i32)
     sig("exl3_set_gemv_max_waves", i32)
     sig("exl3_set_gemv_gen4", i32)

@@ -55,6 +55,9 @@ struct ArArgs
     float* y_out;          // optional: the reduced fp32 tensor (plain all_reduce semantics)
     half_t* resid;         // optional: fp16 residual stream, resid += sum (glue_resid semantics, norm.cu:193-218 rounding)
     float* ss_part;        // optional (with resid): per-128-block sums of squares of the new residual [m][hidden/128]
+    long long* resid_fx;   // optional: the fx pipeline's residual stream, a 64-bit fixed-point accumulator [m][hidden] (value * 2^32): resid_fx += sum.
+                           // Every element belongs to exactly one task of this launch and the sum over the ranks is formed in rank order, so the
+                           // accumulators stay bit-identical on every rank; a timed-out (NaN) sum poisons the accumulator (exl3_gemv_args.h)
     int m, hidden;
 };
 
@@ -154,6 +157,18 @@ void ar_push_reduce_kernel(ArArgs a)
             #pragma unroll
             for (int i = 1; i < 32; i <<= 1) ss += xor_lane(ss, i);
             if (act && l == 0) a.ss_part[(size_t) row * nblk + blk] = ss;
+        }
+    }
+    if (a.resid_fx && act)
+    {
+        long long* r = a.resid_fx + e0;
+        const float sv[4] = { sum.x, sum.y, sum.z, sum.w };
+        #pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const long long old = r[i];
+            const bool bad = !(__builtin_fabsf(sv[i]) < GEMV_FX_LIMIT) || (unsigned long long) (old + (1ll << 60)) > (2ull << 60);      // NaN / Inf / out of range, or already poisoned
+            r[i] = bad ? (long long) GEMV_FX_POISON : old + __double2ll_rn((double) sv[i] * GEMV_FX_SCALE);
         }
     }
     // 4. epoch hand-over: the last workgroup of this launch bumps the epoch for the next call (arrival counter at hdr[2])
@@ -258,20 +273,39 @@ extern "C" int exl3_ar_reduce(void* ctx, const float* y, float* y_out, void* res
     return exl3_ar_reduce_slabs(ctx, y, nullptr, 0, nullptr, y_out, resid, ss_part, m, hidden, stream);
 }
 
+static int ar_reduce_impl(void* ctx, const float* y, const float* slabs, int S, const void* svh, float* y_out, void* resid, float* ss_part, void* resid_fx,
+                          int m, int hidden, void* stream);
+
+// The o_proj / down_proj boundary of a tensor-parallel step of the FX pipeline (llama_path.decode_step_fx under TP): this rank's partial -- dense fp32
+// rows y, or the deferred split-k slabs of the row-sharded linear + its svh -- is pushed to every rank, the W partials are summed in rank order and the
+// sum is ADDED into the 64-bit fixed-point residual accumulator R [m][hidden] (value * 2^32) that the GEMV_IN_FX launches read: one launch per
+// boundary (linear epilogue + all-reduce + residual add), accumulators bit-identical on every rank.  reference: model/model_tp_backend.py:119-126.
+extern "C" int exl3_ar_reduce_fx(void* ctx, const float* y, const float* slabs, int S, const void* svh, void* R, int m, int hidden, void* stream)
+{
+    EXL3_CHECK_ARG(R, "ar_reduce_fx: null accumulator");
+    return ar_reduce_impl(ctx, y, slabs, S, svh, nullptr, nullptr, nullptr, R, m, hidden, stream);
+}
+
 // ... with this rank's partial given as the deferred split-k slabs of the row-sharded linear (exl3_gemv_ex* with EXL3_GEMV_OUT_DEFERRED:
 // [hidden/128][S][m][128] fp32) + its svh instead of a dense tensor (y == NULL): the all-reduce launch also is that linear's epilogue.
 extern "C" int exl3_ar_reduce_slabs(void* ctx, const float* y, const float* slabs, int S, const void* svh, float* y_out, void* resid, float* ss_part,
                                     int m, int hidden, void* stream)
 {
+    return ar_reduce_impl(ctx, y, slabs, S, svh, y_out, resid, ss_part, nullptr, m, hidden, stream);
+}
+
+static int ar_reduce_impl(void* ctx, const float* y, const float* slabs, int S, const void* svh, float* y_out, void* resid, float* ss_part, void* resid_fx,
+                          int m, int hidden, void* stream)
+{
     ArCtx* c = (ArCtx*) ctx;
-    EXL3_CHECK_ARG(c && ((y && !slabs) || (!y && slabs && svh && S >= 1)) && (y_out || resid), "ar_reduce: null pointer (give y, or slabs + svh)");
+    EXL3_CHECK_ARG(c && ((y && !slabs) || (!y && slabs && svh && S >= 1)) && (y_out || resid || resid_fx), "ar_reduce: null pointer (give y, or slabs + svh)");
     EXL3_CHECK_ARG(m >= 1 && hidden % 128 == 0 && (size_t) m * hidden <= c->max_elems, "ar_reduce: m * hidden exceeds the buffer / hidden not a multiple of 128");
     for (int r = 0; r < c->world; ++r) EXL3_CHECK_ARG(c->peer[r], "ar_reduce: peer %d not opened", r);
     ArArgs a;
     a.own = c->own; a.world = c->world; a.rank = c->rank; a.max_elems = c->max_elems;
     for (int r = 0; r < EXL3_AR_MAX_RANKS; ++r) a.peer[r] = r < c->world ? c->peer[r] : nullptr;
     a.slabs = slabs; a.S = S; a.svh = (const half_t*) svh;
-    a.y = y; a.y_out = y_out; a.resid = (half_t*) resid; a.ss_part = ss_part; a.m = m; a.hidden = hidden;
+    a.y = y; a.y_out = y_out; a.resid = (half_t*) resid; a.ss_part = ss_part; a.resid_fx = (long long*) resid_fx; a.m = m; a.hidden = hidden;
     const int tasks = m * (hidden / 128);
     // every workgroup spin-waits on its peers' matching workgroups, so the whole grid has to be co-resident on every rank whatever the dispatch
     // order: at most ~2 workgroups per CU (decode messages are 32..512 tasks; prefill-sized messages belong to the collective library)

@@ -983,6 +983,50 @@ extern "C" int exl3_fx_finish_rotate(const void* R, void* x_out, float* ss_out, 
     return exl3_check_launch("fx_finish_rotate");
 }
 
+// R += the finished rows of a linear whose result was NOT added by its own launch: dense fp32 rows y [m][hidden] (e.g. after a collective-library
+// all-reduce of the ranks' partial sums) or deferred split-k slabs + svh (slab sum, output Hadamard, x svh in fp32: the arithmetic of the IPC all-reduce
+// launch's slab route).  One half-wave per (row, 128-block); every element has one owner, so a plain read-modify-write.  The fx pipeline's
+// tensor-parallel boundary without the IPC push (exl3_ar_reduce_fx is this + the exchange in one launch).
+__global__ __launch_bounds__(256)
+void fx_add_kernel(long long* __restrict__ R, const float* __restrict__ y, SlabRef sr, const half_t* __restrict__ svh, int m, int hidden)
+{
+    const int tid = threadIdx.x, l = tid & 31, hw = tid >> 5;
+    const int nblk = hidden >> 7;
+    const int t = blockIdx.x * 8 + hw;
+    const bool act = t < m * nblk;
+    const int row = act ? t / nblk : 0, blk = act ? t % nblk : 0;
+    float4_t v = { 0.f, 0.f, 0.f, 0.f };
+    if (sr.base)
+    {
+        const half4_t sc = ((const half4_t*) (svh + blk * 128))[l];
+        const float4_t sm = slab_sum(sr, blk, row, m, l);
+        float h0 = sm.x, h1 = sm.y, h2 = sm.z, h3 = sm.w;
+        had128_f32x4(h0, h1, h2, h3, l);
+        h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
+        v = float4_t{ h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
+    }
+    else if (act) v = *((const float4_t*) (y + (size_t) row * hidden + blk * 128 + 4 * l));
+    if (!act) return;
+    long long* r = R + (size_t) row * hidden + blk * 128 + 4 * l;
+    const float sv[4] = { v.x, v.y, v.z, v.w };
+    #pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        const long long old = r[i];
+        const bool bad = !(__builtin_fabsf(sv[i]) < GEMV_FX_LIMIT) || (unsigned long long) (old + (1ll << 60)) > (2ull << 60);
+        r[i] = bad ? (long long) GEMV_FX_POISON : old + __double2ll_rn((double) sv[i] * GEMV_FX_SCALE);
+    }
+}
+
+extern "C" int exl3_fx_add(void* R, const float* y, const float* slabs, int S, const void* svh, int m, int hidden, void* stream)
+{
+    EXL3_CHECK_ARG(R && ((y && !slabs) || (!y && slabs && svh && S >= 1)) && m >= 1 && hidden % 128 == 0, "exl3_fx_add: give y, or slabs + svh; hidden a multiple of 128");
+    SlabRef sr = { slabs, S };
+    const int tasks = m * (hidden / 128);
+    fx_add_kernel<<<(tasks + 7) / 8, 256, 0, (hipStream_t) stream>>>((long long*) R, y, sr, (const half_t*) svh, m, hidden);
+    return exl3_check_launch("fx_add");
+}
+
 extern "C" int exl3_fx_init(const void* x, void* R, float* ss, int m, int hidden, void* stream)
 {
     EXL3_CHECK_ARG(x && R && ss && m >= 1 && hidden % 128 == 0, "exl3_fx_init: null pointer / hidden not a multiple of 128");

@@ -1270,6 +1270,15 @@ def exl3_gemv_ex_fx(R, norm_w, ss_prev, ss_out, eps: float, Bs, suhs, m: int, mc
     return [int(s) if s else 0 for s in slabs], S.value
 
 
+def fx_add(R: torch.Tensor, y: torch.Tensor | None = None, slab: int = 0, S: int = 0, svh: torch.Tensor | None = None):
+    """R (int64 fixed-point residual [m, hidden]) += y (fp32 [m, hidden]) or += the finished deferred slabs (slab address, S, svh) of a linear."""
+    _dev(R)
+    _req(R.dtype == torch.long and R.dim() == 2 and R.is_contiguous(), "fx_add: R must be a contiguous int64 [m, hidden] accumulator")
+    _req((y is not None) != bool(slab), "fx_add: give y or slabs")
+    _req(y is None or (y.dtype == torch.float and y.is_contiguous() and y.numel() == R.numel()), "fx_add: y must be contiguous float32 of R's shape")
+    _check(_lib.lib().exl3_fx_add(_p(R), _p(y), ctypes.c_void_p(slab) if slab else None, int(S), _p(svh), R.shape[0], R.shape[1], _stream(R)))
+
+
 def fx_zero_next(buf: torch.Tensor | None):
     """The NEXT generation-4 GEMV launch clears `buf` as a side job (the gate / up accumulators of the fx pipeline); None cancels."""
     if buf is None:

@@ -669,8 +669,10 @@ class SyntheticEXL3Llama:
         reference (rounded after every add, norm.cu:193-218) is kept at higher precision here.  Other configurations take decode_step_fused."""
         bsz = self._state_bsz
         same = all(_same_kind(L["q"], L["k"], L["v"]) and _same_kind(L["gate"], L["up"]) for L in self.layers)
-        if self.tp != 1 or bsz > self.fx_max_bsz or not same:
+        if bsz > self.fx_max_bsz or not same or (self.tp != 1 and not self.fx_under_tp):
             return self.decode_step_fused()
+        if self.tp != 1:
+            return self._decode_step_fx_tp()
         sp, hd, hidden = dict(self.split), self.shape.head_dim, self.shape.hidden
         if sp["o"] == 0 and self.hq * hd == 4096 and hidden == 4096:
             sp["o"] = 8          # atomic epilogue: half the atomics of the dispatcher's 16-way split measured -0.8 us per layer (tools/sweep_split.py, STEP=decode_step_fx)
@@ -744,6 +746,71 @@ class SyntheticEXL3Llama:
             ext.fx_finish(R, self.x, sc, bsz)                             # fp16 residual + its sums of squares for the final norm
             ext.exl3_gemv_ex_norm(self.x, self.final_norm, sc, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
                                   bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
+        return self.logits
+
+    #: tensor-parallel ranks take the fx pipeline too (round 4): 7 launches per layer instead of the glue pipeline's 8-10
+    fx_under_tp = os.environ.get("EXL3_HIP_FX_UNDER_TP", "1") != "0"
+    #: ... with silu(g) * u formed inside the down shard's launch (7 launches per layer) instead of glue_act_rs + rotated-input down (8)
+    fx_tp_act_in_gemv = os.environ.get("EXL3_HIP_FX_TP_ACT_IN_GEMV", "0") != "0"
+
+    def _decode_step_fx_tp(self):
+        """decode_step_fx on a tensor-parallel rank (batch <= fx_max_bsz): the residual stream is the same 64-bit fixed-point accumulator R, replicated
+        on every rank.  q|k|v and gate|up (column shards) read it exactly as on one rank; o_proj and down_proj (row shards) leave deferred slabs and ONE
+        launch per boundary finishes them, exchanges the ranks' partial rows and adds the rank-order sum into R (IPC push: exl3_ar_reduce_fx; otherwise
+        fp32 partial rows -> collective all-reduce -> exl3_fx_add).  The sums are formed in the same order on every rank and integer adds are exact, so
+        R stays bit-identical across ranks.  7 launches per layer: q|k|v, glue_qkv_rs, o, all-reduce, gate|up, down (silu * mul inside), all-reduce."""
+        bsz, hd, hidden, be = self._state_bsz, self.shape.head_dim, self.shape.hidden, self.backend
+        sp = dict(self.split)
+        DEF = ext.GEMV_OUT_DEFERRED
+        R = self.R
+        sc, so_ = self.ss, self.ss2
+        q2 = self.q.view(bsz, -1)
+        ext.fx_init_prep(self.x0, R, sc, bsz, self.inv_freq, self.positions, hd, self.block_table, self.page, self.rope_sin, self.rope_cos, self.kv_slots)
+        tab = (self.rope_sin, self.rope_cos, self.kv_slots)
+        slab_route = (getattr(be, "ipc", None) is not None and bsz * hidden <= be.ipc.max_elems) or getattr(be, "ipc_like", False)
+        for li, L in enumerate(self.layers):
+            lq, lk, lv, lo, lg, lu, ld = L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"]
+            kc, ks = self.kcache[li]
+            vc, vs = self.vcache[li]
+            slabs, S = ext.exl3_gemv_ex_fx(R, L["norm1"], sc, so_, self.eps, [lq.trellis, lk.trellis, lv.trellis], [lq.suh, lk.suh, lv.suh],
+                                           bsz, lq.mcg, lq.mul1, sp["qkv"])
+            ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                            self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, so_, hidden, self.eps, tab=tab)
+            sc, so_ = so_, sc
+            o_in = q2
+            if self.with_attention and hd in (64, 128):
+                ext.attn_decode_qcache(self.q.view(bsz, self.hq, hd), self.attn_out, kc, ks, vc, vs, self.block_table, self.attn_lens,
+                                       self.attn_pos + 1, workspace=self.attn_ws)
+                o_in = self.attn_out.view(bsz, -1)
+            if slab_route:
+                so, So = ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], None, [lo.suh], None, bsz, lo.mcg, lo.mul1, DEF, sp["o"])
+                be.all_reduce_fx_slabs(so[0], So, lo.svh, R, bsz)
+            else:
+                lo.bc.run(o_in, self.o)
+                be.all_reduce_fx(self.o, R, bsz)
+            sgu, Sgu = ext.exl3_gemv_ex_fx(R, L["norm2"], sc, so_, self.eps, [lg.trellis, lu.trellis], [lg.suh, lu.suh], bsz, lg.mcg, lg.mul1, sp["gu"])
+            if not self.fx_tp_act_in_gemv:
+                # silu(g) * u + down's input rotation as their own launch (the shard's k is short: few workgroups would repeat the slab reduction)
+                ext.glue_act_rs(sgu, Sgu, lg.svh, lu.svh, ld.suh, self.xh_d, self.xs_d, bsz, sc, so_, hidden, self.eps)
+                if slab_route:
+                    sd, Sd = ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], None, None, None, bsz, ld.mcg, ld.mul1, ext.GEMV_IN_ROTATED | DEF, sp["down"])
+                    be.all_reduce_fx_slabs(sd[0], Sd, ld.svh, R, bsz)
+                else:
+                    ext.exl3_gemv_ex(None, [self.xh_d], [self.xs_d], [ld.trellis], [self.d], None, [ld.svh], bsz, ld.mcg, ld.mul1, ext.GEMV_IN_ROTATED, c_fp32=True)
+                    be.all_reduce_fx(self.d, R, bsz)
+            elif slab_route:
+                sd, Sd = ext.exl3_gemv_ex_act_rs(sgu, Sgu, lg.svh, lu.svh, sc, so_, hidden, self.eps, ld.trellis, None, ld.suh, None, bsz, ld.mcg, ld.mul1,
+                                                 DEF, sp["down"])
+                be.all_reduce_fx_slabs(sd[0], Sd, ld.svh, R, bsz)
+            else:
+                ext.exl3_gemv_ex_act_rs(sgu, Sgu, lg.svh, lu.svh, sc, so_, hidden, self.eps, ld.trellis, self.d, ld.suh, ld.svh, bsz, ld.mcg, ld.mul1,
+                                        0, sp["down"], c_fp32=True)
+                be.all_reduce_fx(self.d, R, bsz)
+            sc, so_ = so_, sc
+        self.x_final = self.x
+        ext.fx_finish_rotate(R, self.x, sc, self.final_norm, self.eps, self.lm_head.suh, self.xh3[0], self.xs3[0], bsz)
+        ext.exl3_gemv_ex(None, self.xh3[:1], self.xs3[:1], [self.lm_head.trellis], [self.logits], None, [self.lm_head.svh],
+                         bsz, self.lm_head.mcg, self.lm_head.mul1, ext.GEMV_IN_ROTATED)
         return self.logits
 
     def decode_step_fused_v1(self):

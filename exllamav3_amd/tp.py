@@ -154,6 +154,22 @@ class TPBackendRCCL:
         assert self.ipc is not None, "all_reduce_resid_slabs needs the IPC all-reduce"
         self.ipc.reduce_slabs(slab, S, svh, resid, ss_part, m)
 
+    # ---- the same boundary for the fx pipeline: the residual stream is a 64-bit fixed-point accumulator R (llama_path.decode_step_fx) ----------
+    def all_reduce_fx_slabs(self, slab: int, S: int, svh: torch.Tensor, R: torch.Tensor, m: int):
+        """R += sum over ranks of the row-sharded linear whose deferred slabs (slab, S, svh) this rank holds: ONE launch (slab finish + push + rank-order
+        sum + add into the fixed-point residual; bit-identical accumulators on every rank).  Only with the IPC path enabled (callers check `self.ipc`)."""
+        assert self.ipc is not None, "all_reduce_fx_slabs needs the IPC all-reduce"
+        self.ipc.reduce_fx(R, slab=slab, S=S, svh=svh, m=m)
+
+    def all_reduce_fx(self, y: torch.Tensor, R: torch.Tensor, m: int):
+        """R += sum over ranks of y (fp32 [m, hidden], this rank's partial rows; overwritten by the library route)."""
+        from . import ext
+        if self.ipc is not None and y.numel() <= self.ipc.max_elems:
+            self.ipc.reduce_fx(R, y=y, m=m)
+            return
+        self.all_reduce(y)
+        ext.fx_add(R, y=y)
+
     def fwd_barrier(self):
         if self.world_size > 1:
             dist.barrier()
@@ -222,6 +238,19 @@ class OneRankOfMany:
         self.calls += 1
         ext.glue_resid(None, 0, None, None, resid, ss_part, m, y_dense=y)
 
+    ipc_like = True                     # (llama_path: take the slab route, as with the IPC all-reduce enabled)
+
+    def all_reduce_fx_slabs(self, slab, S, svh, R, m):
+        # the IPC route's one launch per boundary (slab finish + exchange + add into the fixed-point residual) with the exchange left out
+        from . import ext
+        self.calls += 1
+        ext.fx_add(R, slab=slab, S=S, svh=svh)
+
+    def all_reduce_fx(self, y, R, m):
+        from . import ext
+        self.calls += 1
+        ext.fx_add(R, y=y)
+
 
 class IpcAllReduce:
     """Host side of exl3_allreduce.hip: this rank's receive buffer + the peers' buffers mapped through hipIpc handles exchanged over the process
@@ -282,6 +311,16 @@ class IpcAllReduce:
         dev = resid.device if resid is not None else y_out.device
         _lib.check(self._lib.exl3_ar_reduce_slabs(self.ctx, None, slab, int(S), p(svh), p(y_out), p(resid), p(ss_part), int(m), hidden,
                                                   torch.cuda.current_stream(dev).cuda_stream))
+
+    def reduce_fx(self, R: torch.Tensor, y: torch.Tensor | None = None, slab: int = 0, S: int = 0, svh: torch.Tensor | None = None, m: int | None = None):
+        """R (int64 fixed-point accumulator [m, hidden]) += sum over ranks of y (fp32 rows) or of the finished deferred slabs (slab, S, svh)."""
+        from . import _lib
+        assert R.dtype == torch.long and R.is_contiguous() and ((y is not None) != bool(slab))
+        hidden = R.shape[-1]
+        rows = m if m is not None else R.numel() // hidden
+        p = lambda t: None if t is None else t.data_ptr()
+        _lib.check(self._lib.exl3_ar_reduce_fx(self.ctx, p(y), ctypes.c_void_p(slab) if slab else None, int(S), p(svh), p(R), rows, hidden,
+                                               torch.cuda.current_stream(R.device).cuda_stream))
 
     def epoch(self) -> int:
         from . import _lib

@@ -263,6 +263,12 @@ int exl3_gemv_ex_fx_atomic(const void* R, const void* norm_w, const float* ss_pr
 int exl3_gemv_ex_actfx(const void* g_acc, const void* u_acc, const float* ss_prev, const float* ss_new, int hidden, float eps,
                        const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb,
                        int flags, int force_split, float** slab_out, int* S_out, void* stream);
+/* Tensor-parallel boundary of the fx pipeline.  exl3_fx_add: R += the finished rows of a row-sharded linear that did not add them itself -- dense fp32
+ * rows (after a collective-library all-reduce of the ranks' partials), or deferred slabs + svh.  exl3_ar_reduce_fx (with the IPC all-reduce context,
+ * below): the same with the exchange inside -- push this rank's partial, sum the W partials in rank order, R += sum -- one launch per boundary,
+ * accumulators bit-identical on every rank (model/model_tp_backend.py:119-126 + the residual add). */
+int exl3_fx_add(void* R, const float* y, const float* slabs, int S, const void* svh, int m, int hidden, void* stream);
+int exl3_ar_reduce_fx(void* ctx, const float* y, const float* slabs, int S, const void* svh, void* R, int m, int hidden, void* stream);
 int exl3_fx_zero_next(void* ptr, int64_t bytes);
 /* exl3_gemv_ex (raw input, deferred output, m <= 4) in the wave-per-column-block layout used by the three launches above and below: `cpw` (1..16)
  * column blocks of ONE matrix per workgroup, each wave streams the whole k-slice of its column block and writes its own slab.  The fused

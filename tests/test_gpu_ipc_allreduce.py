@@ -92,6 +92,7 @@ def _worker(rank, world, port, ret):
         shape = LlamaShape("tiny", 512, 1024, 2, 4, 2, 128, 384)
         model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, backend=be, kv_bits=4, max_ctx=1024)
         model.alloc_state(1, pos=50)
+        dist.broadcast(model.x0, 0)                                      # one input row for both ranks (alloc_state draws it from the rank's own generator)
         model.ar_from_slabs = False
         la = model.decode_step_fused().float().clone()
         model.ar_from_slabs = True
@@ -109,6 +110,29 @@ def _worker(rank, world, port, ret):
             model.logits.zero_(); graph.replay()
         torch.cuda.synchronize()
         ok["tp_step_slab_route"] = step_ok and bool(torch.equal(model.logits.float(), lb)) and ipc.error() == 0
+        # ---- the fx pipeline under TP (round 4): R += rank-order sum inside the all-reduce launch; logits == the glue TP step to fp16 rounding, the
+        # fixed-point residual BIT-identical on both ranks (gathered below), the library route (fp32 partials -> collective -> fx_add) agrees, graph replay
+        lfx = model.decode_step_fx().float().clone()
+        ok["fx_tp_close_to_glue_tp"] = bool(torch.isfinite(lfx).all()) and float((lfx - la).abs().max()) / rms < 1.5e-2
+        Rmine = model.R.clone()
+        Rall = [torch.empty_like(Rmine) for _ in range(world)]
+        dist.all_gather(Rall, Rmine)
+        ok["fx_tp_residual_bit_identical_across_ranks"] = all(bool(torch.equal(Rall[0], r)) for r in Rall)
+        saved = be.ipc; be.ipc = None
+        llib = model.decode_step_fx().float().clone()
+        be.ipc = saved
+        ok["fx_tp_library_route"] = float((llib - lfx).abs().max()) / rms < 1e-2
+        st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+        dist.barrier()
+        with torch.cuda.stream(st):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=st):
+                model.decode_step_fx()
+        torch.cuda.synchronize(); dist.barrier()
+        for _ in range(3):
+            model.logits.zero_(); graph.replay()
+        torch.cuda.synchronize()
+        ok["fx_tp_graph_replay"] = bool(torch.equal(model.logits.float(), lfx)) and ipc.error() == 0
     except Exception as e:           # report instead of hanging the peer
         ok["exception"] = repr(e)
     ret[rank] = ok
@@ -127,4 +151,6 @@ def test_ipc_allreduce_two_processes_one_gpu(dev):
     for r in range(world):
         res = ret.get(r)
         assert res and "exception" not in res, res
-        assert res == {"enabled": True, "sums_exact": True, "resid_equal": True, "graph_replay": True, "slab_route": True, "tp_step_slab_route": True}, (r, res)
+        assert res == {"enabled": True, "sums_exact": True, "resid_equal": True, "graph_replay": True, "slab_route": True, "tp_step_slab_route": True,
+                       "fx_tp_close_to_glue_tp": True, "fx_tp_residual_bit_identical_across_ranks": True, "fx_tp_library_route": True,
+                       "fx_tp_graph_replay": True}, (r, res)

@@ -976,6 +976,17 @@ def test_tp_rank_code_path_on_one_gpu(dev, model_name, tp, bsz):
             model.decode_step_fused()
         g.replay(); st.synchronize()
     assert np.array_equal(model.logits.float().cpu().numpy(), lf)
+    if bsz <= model.fx_max_bsz:
+        # the TP form of the fx pipeline (round 4: 7 launches per layer, R += the rank's finished rows in the all-reduce launch -- here with the exchange left
+        # out) on the same rank shapes, slab route and dense-partials route: the rank's partial-sum logits agree with the glue TP step
+        n0 = be.calls
+        lx = model.decode_step_fx().float().cpu().numpy().copy()
+        assert be.calls == n0 + 2 and np.isfinite(lx).all() and np.abs(lx - lu).max() / np.sqrt((lu ** 2).mean()) < 1.5e-2
+        be.ipc_like = False
+        ly = model.decode_step_fx().float().cpu().numpy().copy()
+        be.ipc_like = True
+        assert np.abs(ly - lx).max() / np.sqrt((lu ** 2).mean()) < 1e-2
+        assert np.array_equal(model.decode_step_fx().float().cpu().numpy(), lx)
 
 
 @pytest.mark.parametrize("k,n", [(512, 4096), (1792, 4096), (512, 384), (512, 2048)])
