@@ -585,7 +585,7 @@ def main():
         # config 4's compute leg: ONE rank of Llama-3.1-70B at 3 bpw under TP = 8 (q 8192->1024, k/v 8192->128, o 1024->8192, gate/up 8192->3584,
         # down 3584->8192, 16128-column head shard; all 80 layers), collectives replaced by no-ops (tp.OneRankOfMany) -- the part of config 4 one GPU can
         # measure (modules/quant/exl3.py:284-330).  The 160 all-reduces per token are NOT in the step time; an estimate from the one-GPU two-process
-        # measurement of the IPC push (DESIGN.md 5: 6.7 us per all-reduce + residual add) is stated beside it, labelled as such.
+        # measurement of the IPC push (DESIGN.md 7: 6.7 us per all-reduce + residual add) is stated beside it, labelled as such.
         from exllamav3_amd.tp import OneRankOfMany
         m70 = SyntheticEXL3Llama(SHAPES["llama-3.1-70b"], K=3, cb=cb, device=dev, backend=OneRankOfMany(8, dev), kv_bits=args.kv_bits)
         m70.alloc_state(1)

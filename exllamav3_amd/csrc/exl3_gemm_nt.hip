@@ -2,10 +2,10 @@
 //
 //   A  = the activations (tokens x k, fp16, k contiguous), Wt = W^T as exl3_reconstruct_had_slice_t writes it (n x k, k contiguous): both operands
 //   K-major.  reference path: modules/quant/exl3.py:161-218 (reconstruct + hgemm), hgemm.cu:19-78 (cublasGemmEx); north_star: "prefill dequants a
-//   tile into LDS then runs MFMA".  This is the contraction; the dequant + both Hadamards stay in exl3_reconstruct_had.hip (DESIGN.md 4.5: the
-//   Hadamards cannot sit inside a tiled GEMM without doubling its work).  hipBLASLt (exl3_hgemm.hip) remains the A/B line and the fallback
-//   for shapes this kernel does not take; exl3_hgemm_nt* pick per shape by one timed trial (EXL3_HIP_GEMM_NT: 0 = library only, 1 = this kernel
-//   wherever it applies, unset = faster of the two).
+//   tile into LDS then runs MFMA".  This is the contraction; the dequant + both Hadamards stay in exl3_reconstruct_had.hip (DESIGN.md 4.7: the
+//   Hadamards cannot sit inside a tiled GEMM without doubling its work).  hipBLASLt (exl3_hgemm.hip) is the default route (it measured 1.2-1.3x
+//   faster on every prefill shape) and the fallback for shapes this kernel does not take; the host side (ext.hgemm_nt*) takes this kernel only
+//   when EXL3_HIP_GEMM_NT=1 is set (unset or 0 = library).
 //
 // Structure (cdna_hip_programming.md section 5, written for gfx950 only):
 //   * 256 x 256 x 64 tile, 8 waves as 2 (m) x 4 (n): a wave owns 128 x 64 of C = 8 x 4 tiles of v_mfma_f32_16x16x32_f16, 128 accumulator VGPRs.

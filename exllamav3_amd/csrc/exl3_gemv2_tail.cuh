@@ -51,7 +51,7 @@ __device__ __forceinline__ float ld_agent1(const float* p) { return __hip_atomic
 // returns true for the workgroup that arrived last at `ticket` (and re-arms the ticket)
 // local: every participant runs on the same XCD (GemvEpi::xcd_local).  Stores are acknowledged by that XCD's L2 and atomics execute there, so a
 // plain store -> s_waitcnt -> L2 atomic -> plain load chain is ordered without any memory-side (sc1) round trip: the hand-off costs an L2
-// latency instead of the ~2 us per hop of the agent-scope version.
+// latency instead of the ~2 us per hop of the agent-scope version (profiles/NOTES.md B 4.2).
 __device__ __forceinline__ bool tail_arrive(uint32_t* ticket, uint32_t expected, int tid, int* s_flag, bool local = false)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are acknowledged (by L2; write-through ones by memory)

@@ -365,7 +365,7 @@ def exl3_moe(hidden_state, output_state, expert_count, token_sorted, weight_sort
     (token, expert) assignment of an expert e with 0 < expert_count[e] <= max_tokens_per_expert (= temp_state_g.shape[1]); busier experts are left
     to the caller's other route, as in the reference.  token_sorted / weight_sorted list the assignments grouped by expert.
     The reference runs this as ONE persistent cooperative kernel (expert tickets, grid-wide hand-offs between gate|up, activation and down); on
-    MI355X an in-kernel grid-wide hand-off costs more than a kernel boundary (DESIGN.md 4.7 e), so the same work is three indexed launches --
+    MI355X an in-kernel grid-wide hand-off costs more than a kernel boundary (profiles/NOTES.md B 4.7 e), so the same work is three indexed launches --
     gate and up of all (expert, <= 16-row chunk) slots, then down with silu * mul formed in its prologue -- and a weighted scatter-add.
     The slot list is built on the DEVICE (exl3_moe_build_slots: prefix sum over expert_count, <= 16-row chunks, over-limit experts masked), every
     shape depends on tensor sizes only and the weighted scatter runs in a fixed order: the op has no host round trip, can be captured in a hipGraph

@@ -249,7 +249,7 @@ def test_attn_decode_qcache_long_context_kernel(dev, hq, hkv, lens, max_len):
 @pytest.mark.parametrize("lens,max_len", [([1024, 1, 700, 257], 1024), ([130, 16], 130), ([1000], 1001), ([512, 513, 255, 256], 640)])
 def test_attn_decode_qcache_short_contexts_ragged(dev, hq, hkv, lens, max_len):
     """Contexts up to 1024 tokens on the matrix-pipe decode-attention kernel (head_dim 128, 4-bit K / V; written for a one-launch variant -- one
-    16-wave workgroup per (sequence, kv head), no merge launch -- that measured 2.44 vs 1.89 ms per step and was dropped: DESIGN.md 4.10): GQA 4 / 7 /
+    16-wave workgroup per (sequence, kv head), no merge launch -- that measured 2.44 vs 1.89 ms per step and was dropped: profiles/NOTES.md B 4.10): GQA 4 / 7 /
     3 / 1 / 8, ragged lengths: a full 1024, one token, ends on / next to a 256-token boundary and a 16-token wave tile, a bound above the lengths;
     scattered pages; against the oracle; the same bits on a second call."""
     from exllamav3_amd import ext

@@ -4,7 +4,7 @@
   more than the work of a batch-1 launch.  Checked for every instantiation of the 4.0 bpw translation units of generations 3 and 4 (the benchmarked
   bitrate; tools/check_spills.sh runs the same check over K = 1..8).
 * The one-chunk streaming loop of the 16-row generation-3 kernel keeps COUNTED waits (vmcnt(3) / (2), never vmcnt(0)): the round-3 loop form drained
-  every outstanding load at the loop head (DESIGN.md 4.1b, round 4)."""
+  every outstanding load at the loop head (DESIGN.md 4.3)."""
 import os
 import re
 import subprocess

@@ -22,7 +22,7 @@ def test_no_kernel_uses_scratch():
     for hot in ("exl3_gemv2_k4.o", "exl3_gemm3_k4.o", "exl3_glue.o", "exl3_rope_cache.o", "exl3_attn_decode.o"):
         assert rep.get(hot), f"{hot}: no kernels found"
     # the opt-in wave-per-column-block modes of the gen-2 GEMV (MODE 5 / 6 / 7, `bench.py --pipeline resid`, measured slower than the default glue
-    # pipeline: DESIGN.md 4.2) sit at the SGPR limit; a few K / codebook combinations get a <= 128-byte SGPR-spill frame.  No default route uses them.
+    # pipeline: DESIGN.md 4.4) sit at the SGPR limit; a few K / codebook combinations get a <= 128-byte SGPR-spill frame.  No default route uses them.
     def wpc(name):
         return "exl3_gemv2_kernel" in name and name.endswith(("ELi5EEv8GemvArgs", "ELi6EEv8GemvArgs", "ELi7EEv8GemvArgs"))
     bad = [(obj, name, b) for obj, ks in rep.items() for name, b in ks if b and not any(a in name for a in ALLOWED) and not (wpc(name) and b <= 128)]

@@ -1,7 +1,7 @@
 // EXPERIMENT (round 3), not part of the product library: built together with mlp1_harness.hip against libexl3_hip.so (see that file).  Measured on
 // MI355X: parity with the three-launch form to 4e-4 of the output RMS; 35.6-36.3 vs 31.5-32.5 us per MLP with the counter-based exchange
 // (profiles/r03_mlp1_fused_launch.json), 31.9-32.6 vs 32.0-32.7 us with -DM1_TAGGED (profiles/r03_mlp1_fused_launch_tagged.json): equal time, one launch instead of
-// three -- no gain at Llama-3.1-8B shapes: the full-row prologue and the reductions are exposed because every CU runs one workgroup in lockstep.
+// three -- no gain at Llama-3.1-8B shapes (profiles/NOTES.md B section 6): the full-row prologue and the reductions are exposed because every CU runs one workgroup in lockstep.
 //
 // The MLP block of a batch-1 decode step in ONE launch (K = 4, mul1 codebook, FAST variant, one row):
 //

@@ -4,7 +4,7 @@
 #                     + the harness binary under tools/bin/
 #   on the GPU box:   gpurun -- 'tools/experiments/variant_queue.sh run > gpurun_out/variant_queue.txt'
 # Each variant runs between two runs of the base library (same box, alternating); the table is tok/s of the three-launch-MLP step.
-# Variants = compile-time macros of the shipped kernels, all OFF in the product build:
+# Variants = compile-time macros of the shipped kernels, all OFF in the product build (profiles/NOTES.md B section 6):
 VARIANTS=(
   "plain:-DEXL3_LOAD_PLAIN"          # weight rows with the default cache policy instead of non-temporal loads
   "nosched:-DG4_NO_SCHED"            # generation 4: no sched_barrier per decoded quad (free instruction scheduling)

@@ -1,7 +1,7 @@
 // How many waves per SIMD does the EXL3 decode loop need to saturate the VALU on MI355X, and does more per-wave ILP / a deeper weight ring
 // buy any of it back?  (Round 3, written without GPU minutes left; decides whether "fat workgroup" designs -- a fused gate|up -> silu*mul -> down
 // launch with 16-wave workgroups, or a persistent step kernel, both of which run at <= 4 waves per SIMD -- can stream at the rate the shipped
-// 7..8-waves-per-SIMD launches do.  DESIGN.md section 6.)
+// 7..8-waves-per-SIMD launches do.  profiles/NOTES.md B section 6.)
 //
 // The loop body is generation 4's work unit (exl3_gemv4.kspec.hip: 2 tile rows = 64 weights per lane, K = 4, mul1 codebook, FAST variant:
 // compile-time bit windows, v_mul_lo_u32, v_sad_u8, 16 x v_mfma_f32_4x4x4_16B_f16) on a private stream of weight rows:
