@@ -212,6 +212,12 @@ void exl3_gemv4_kernel(const GemvArgs a)
     const size_t row_stride = (size_t) tiles_n * NW;
     const uint32_t* __restrict__ strip = Bm + ((size_t) (k0s >> 4) * tiles_n + (size_t) cbl * 8) * NW + (size_t) lane * K;
     const int last_unit = ubase + (nun > 0 ? nun - 1 : 0);
+#if defined(G4_ABL_HOT_FIRST) || defined(G4_ABL_HOT_ALL)
+    // speed-only ablations (results are garbage): the wave's FIRST ring of weight rows (HOT_FIRST) or every weight row (HOT_ALL) is read from the
+    // matrix's first tile rows -- the same 2 KB per lane position for every workgroup of the launch, i.e. L2-resident after the first touch per XCD.
+    // Upper bound for "the predecessor's drain warms the successor's first rows" (VERDICT r3 task 5 i); profiles/r04_bs1_variant_queue.txt
+    const uint32_t* __restrict__ strip_hot = Bm + (size_t) lane * K;
+#endif
 
     // ---- preparation tasks (raw / norm / act input): task t = (block t / m, row t % m), one per half-wave; only waves that own a task run them
     // (ACT: the first 4 slab lines of gate and up and their svh travel with the task, i.e. they are requested BEFORE the wave's first weight rows -- loaded
@@ -314,8 +320,13 @@ void exl3_gemv4_kernel(const GemvArgs a)
         #pragma unroll
         for (int u = 0; u < 2; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(min(2 * ubase + u, 2 * last_unit + 1), 2 * units - 1) * row_stride);
 #else
+#if defined(G4_ABL_HOT_FIRST) || defined(G4_ABL_HOT_ALL)
+        #pragma unroll
+        for (int u = 0; u < NR; ++u) load_lane_words<K>(ring[u], strip_hot + (size_t) (u & 1) * row_stride);
+#else
         #pragma unroll
         for (int u = 0; u < NR; ++u) load_lane_words<K>(ring[u], strip + (size_t) min(min(2 * ubase + u, 2 * last_unit + 1), 2 * units - 1) * row_stride);
+#endif
 #endif
 #endif
     };
@@ -603,8 +614,13 @@ void exl3_gemv4_kernel(const GemvArgs a)
         set_group(agn);
         agn = load_group(2 * min(unit + 2, last_unit));         // next group (clamped: a harmless reload at the end)
         // a unit refills its slots with the rows of the unit PFU ahead (clamped: a harmless reload at the end)
+#ifdef G4_ABL_HOT_ALL
+        g4_unit<K, CB, VAR, 0, NR>(ring, strip_hot, row_stride, lane, agc0, agc1, acc_c, acc_d);
+        g4_unit<K, CB, VAR, 1, NR>(ring, strip_hot, row_stride, lane, agc0, agc1, acc_c, acc_d);
+#else
         g4_unit<K, CB, VAR, 0, NR>(ring, strip + (size_t) (2 * min(unit + PFU, last_unit)) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
         g4_unit<K, CB, VAR, 1, NR>(ring, strip + (size_t) (2 * min(unit + 1 + PFU, last_unit)) * row_stride, row_stride, lane, agc0, agc1, acc_c, acc_d);
+#endif
         unit += 2;
     }
     if (nun & 1)
