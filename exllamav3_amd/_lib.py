@@ -110,6 +110,7 @@ def _declare(l):
     sig("exl3_quant_cache_paged_ex", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, f32, i32, vp)
     sig("exl3_dequant_cache_paged_ex", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp)
     sig("exl3_quant_cache_paged_strided", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, vp)
+    sig("exl3_rope_ex", vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, u32, vp, vp, i32, i32, f32, vp, vp, i32, f32, f32, i32, i32, f32, i32, i32, i32, i32, vp)
     sig("exl3_rope_strided", vp, vp, vp, i32, i32, i32, i32, i64, i64, u32, vp, vp, f32, vp)
     sig("exl3_dequant_cache_paged", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_silu_mul", vp, vp, vp, i64, i32, vp)

@@ -191,6 +191,196 @@ extern "C" int exl3_rope(const void* q, void* out_q, const void* k, void* out_k,
     return exl3_check_launch("rope");
 }
 
+// ------------------------------------------------------------------------------------------------
+// The reference's whole argument list (rope.cu:16-65, host side :307-470): rotated width p = 2 * (inv_freq columns) < head_dim ("partial rotary"),
+// up to four rotated sub-ranges with their own position each (`rotate_dims`, 3-D position ids: multimodal rope), a start offset, an angle TABLE
+// instead of frequencies, NANOCHAT sign convention, bf16 head-norm weights, an unweighted RMSNorm AFTER the rotation, the llama-4 position scale on
+// query heads, and a head stride wider than head_dim (q / k as the trailing columns of wider heads).
+// One workgroup per token; the sin / cos of every (sub-range, pair) are evaluated once into LDS; one wave per head at a time.  A head lives in a
+// wave-private fp16 LDS line between the stages because the stages address it differently (norm / scale / store: lane owns elements 2l, 2l + 1 of
+// every 128; rotation: lane owns pair t of a sub-range, whose partner sits p/2 away) and because the reference rounds to fp16 between them.
+// ------------------------------------------------------------------------------------------------
+struct RopeExArgs
+{
+    const half_t* q; half_t* out_q; const half_t* k; half_t* out_k; const float* inv_freq;
+    int seq_len, heads_q, heads_k, head_dim, q_head_stride, k_head_stride, p2;
+    uint32_t position; const int32_t* positions; const int32_t* position_ids; int position_ids_stride;
+    float attn_factor; const void* q_norm; const void* k_norm; float norm_eps, norm_constant_bias;
+    int inv_freq_table, inv_freq_stride; float l4_beta; int l4_orig; int post_rope_norm, rotate_dims, rotate_offset;
+};
+
+template <int MODE, bool NORM_BF16>     // 1 = GPTJ, 2 = NEOX, 3 = NANOCHAT
+__global__ __launch_bounds__(256)
+void rope_ex_kernel(const RopeExArgs a)
+{
+    __shared__ float sn_s[4 * 256], cs_s[4 * 256];
+    __shared__ __attribute__((aligned(16))) half_t head_s[4][512];
+    __shared__ float l4_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int token = blockIdx.x, batch = blockIdx.y;
+    const int64_t tok = (int64_t) batch * a.seq_len + token;
+    auto pos_of = [&] (int rdim) -> int
+    {
+        if (a.positions) return token + a.positions[batch];
+        if (a.position_ids) return a.position_ids[tok * a.position_ids_stride + (a.position_ids_stride > 1 ? rdim : 0)];
+        return token + (int) a.position;
+    };
+    for (int e = threadIdx.x; e < a.rotate_dims * a.p2; e += blockDim.x)
+    {
+        const int rdim = e / a.p2, t = e - rdim * a.p2;
+        const int pos = pos_of(rdim);
+        const float ang = a.inv_freq_table ? a.inv_freq[(int64_t) batch * a.inv_freq_stride + (int64_t) pos * a.p2 + t] : a.inv_freq[t] * (float) pos;
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        sn_s[rdim * 256 + t] = sn * a.attn_factor; cs_s[rdim * 256 + t] = cs * a.attn_factor;
+    }
+    if (threadIdx.x == 0) l4_s = a.l4_beta > 0.0f ? 1.0f + a.l4_beta * __logf(1.0f + (float) (pos_of(0) / a.l4_orig)) : 1.0f;
+    __syncthreads();
+    const float l4 = l4_s;
+    half_t* hb = head_s[wave];
+    const int heads = a.heads_q + a.heads_k;
+    for (int head = wave; head < heads; head += 4)
+    {
+        const bool is_q = head < a.heads_q;
+        const int hi = is_q ? head : head - a.heads_q;
+        const half_t* src = is_q ? a.q + (tok * a.heads_q + hi) * a.q_head_stride : a.k + (tok * a.heads_k + hi) * a.k_head_stride;
+        half_t* dst = is_q ? a.out_q + (tok * a.heads_q + hi) * a.q_head_stride : a.out_k + (tok * a.heads_k + hi) * a.k_head_stride;
+        const void* nw = is_q ? a.q_norm : a.k_norm;
+        // ---- load (+ head norm)
+        float v[8];
+        float ss = 0.0f;
+        #pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const int e = 2 * lane + 128 * i;
+            v[2 * i] = 0.f; v[2 * i + 1] = 0.f;
+            if (e < a.head_dim) { const half2_t h = *(const half2_t*) (src + e); v[2 * i] = (float) h[0]; v[2 * i + 1] = (float) h[1]; }
+            ss += v[2 * i] * v[2 * i] + v[2 * i + 1] * v[2 * i + 1];
+        }
+        if (a.q_norm)
+        {
+            #pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss += xor_lane(ss, o);
+            const float rmf = __frsqrt_rn(ss / (float) a.head_dim + a.norm_eps);
+            const half_t bias_h = f2h(a.norm_constant_bias);
+            #pragma unroll
+            for (int i = 0; i < 4; ++i)
+            {
+                const int e = 2 * lane + 128 * i;
+                if (e < a.head_dim)
+                {
+                    #pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                    {
+                        if constexpr (NORM_BF16)
+                        {
+                            const uint32_t wb = (uint32_t) ((const uint16_t*) nw)[e + j] << 16;
+                            float w; __builtin_memcpy(&w, &wb, 4);
+                            v[2 * i + j] = (float) f2h((v[2 * i + j] * rmf) * (w + a.norm_constant_bias));
+                        }
+                        else
+                        {
+                            const half_t w = ((const half_t*) nw)[e + j] + bias_h;
+                            v[2 * i + j] = (float) (w * f2h(v[2 * i + j] * rmf));
+                        }
+                    }
+                }
+            }
+        }
+        #pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const int e = 2 * lane + 128 * i;
+            if (e < a.head_dim) { half2_t h; h[0] = f2h(v[2 * i]); h[1] = f2h(v[2 * i + 1]); *(half2_t*) (hb + e) = h; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- rotation, one sub-range after the other (disjoint element ranges; pairs within a sub-range are disjoint)
+        for (int rdim = 0; rdim < a.rotate_dims; ++rdim)
+        {
+            const int off = a.rotate_offset + 2 * a.p2 * rdim;
+            for (int t = lane; t < a.p2; t += 64)
+            {
+                const int i1 = off + (MODE == 1 ? 2 * t : t), i2 = off + (MODE == 1 ? 2 * t + 1 : t + a.p2);
+                const float sn = MODE == 3 ? -sn_s[rdim * 256 + t] : sn_s[rdim * 256 + t], cs = cs_s[rdim * 256 + t];
+                const float v1 = (float) hb[i1], v2 = (float) hb[i2];
+                hb[i1] = f2h(v1 * cs - v2 * sn);
+                hb[i2] = f2h(v2 * cs + v1 * sn);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- unweighted norm after the rotation, llama-4 scale (query heads), store
+        ss = 0.0f;
+        #pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const int e = 2 * lane + 128 * i;
+            v[2 * i] = 0.f; v[2 * i + 1] = 0.f;
+            if (e < a.head_dim) { const half2_t h = *(const half2_t*) (hb + e); v[2 * i] = (float) h[0]; v[2 * i + 1] = (float) h[1]; }
+            ss += v[2 * i] * v[2 * i] + v[2 * i + 1] * v[2 * i + 1];
+        }
+        if (a.post_rope_norm)
+        {
+            #pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ss += xor_lane(ss, o);
+            const float rmf = __frsqrt_rn(ss / (float) a.head_dim + a.norm_eps);
+            #pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float) f2h(v[j] * rmf);
+        }
+        if (is_q && l4 != 1.0f)
+        {
+            #pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float) f2h(v[j] * l4);
+        }
+        #pragma unroll
+        for (int i = 0; i < 4; ++i)
+        {
+            const int e = 2 * lane + 128 * i;
+            if (e < a.head_dim) { half2_t h; h[0] = f2h(v[2 * i]); h[1] = f2h(v[2 * i + 1]); *(half2_t*) (dst + e) = h; }
+        }
+        __builtin_amdgcn_wave_barrier();          // the line is rewritten by this wave's next head
+    }
+}
+
+extern "C" int exl3_rope_ex(const void* q, void* out_q, const void* k, void* out_k, const float* inv_freq,
+                            int bsz, int seq_len, int heads_q, int heads_k, int head_dim, int q_head_stride, int k_head_stride, int partial_head_dim,
+                            uint32_t position, const int32_t* positions, const int32_t* position_ids, int position_ids_stride,
+                            int rope_mode, float attn_factor, const void* q_norm, const void* k_norm, int norm_bf16, float norm_eps, float norm_constant_bias,
+                            int inv_freq_table, int inv_freq_stride, float l4_beta, int l4_orig, int post_rope_norm, int rotate_dims, int rotate_offset,
+                            void* stream)
+{
+    EXL3_CHECK_ARG(q && out_q && inv_freq, "rope: null pointer");
+    EXL3_CHECK_ARG(heads_k == 0 || (k && out_k), "rope: k given without out_k");
+    EXL3_CHECK_ARG(head_dim % 2 == 0 && head_dim > 0 && head_dim <= 512, "rope: head_dim must be even and <= 512");
+    EXL3_CHECK_ARG(rope_mode >= 1 && rope_mode <= 3, "rope: rope_mode must be 1 (GPTJ), 2 (NEOX) or 3 (NANOCHAT)");
+    EXL3_CHECK_ARG(partial_head_dim > 0 && partial_head_dim % 2 == 0, "rope: rotated width must be even");
+    EXL3_CHECK_ARG(rotate_dims > 0 && rotate_dims <= 4, "rotate_dims out of range");                                             // rope.cu:361
+    EXL3_CHECK_ARG(rotate_dims == 1 || head_dim == partial_head_dim * rotate_dims, "rotate_dims is inconsistent with inv_freq and head_dim");   // :362
+    EXL3_CHECK_ARG(rotate_offset >= 0 && rotate_offset + partial_head_dim * rotate_dims <= head_dim, "rotate_offset out of range");            // :363
+    EXL3_CHECK_ARG(!(positions && position_ids), "rope: positions and position_ids are mutually exclusive");                             // :403
+    EXL3_CHECK_ARG(position_ids_stride == 1 || (position_ids && position_ids_stride == rotate_dims), "rope: position_ids stride must be 1 or rotate_dims");
+    EXL3_CHECK_ARG(q_head_stride >= head_dim && q_head_stride % 2 == 0 && (heads_k == 0 || (k_head_stride >= head_dim && k_head_stride % 2 == 0)),
+                   "rope: head strides must be even and >= head_dim");
+    EXL3_CHECK_ARG(!q_norm == !k_norm || heads_k == 0, "rope: q_norm and k_norm must be given together");
+    EXL3_CHECK_ARG(l4_beta <= 0.0f || l4_orig > 0, "rope: llama_4_scaling_original must be positive");
+    if (bsz == 0 || seq_len == 0) return EXL3_OK;
+    RopeExArgs a;
+    a.q = (const half_t*) q; a.out_q = (half_t*) out_q; a.k = (const half_t*) k; a.out_k = (half_t*) out_k; a.inv_freq = inv_freq;
+    a.seq_len = seq_len; a.heads_q = heads_q; a.heads_k = heads_k; a.head_dim = head_dim; a.q_head_stride = q_head_stride; a.k_head_stride = k_head_stride;
+    a.p2 = partial_head_dim / 2; a.position = position; a.positions = positions; a.position_ids = position_ids; a.position_ids_stride = position_ids_stride;
+    a.attn_factor = attn_factor; a.q_norm = q_norm; a.k_norm = k_norm; a.norm_eps = norm_eps; a.norm_constant_bias = norm_constant_bias;
+    a.inv_freq_table = inv_freq_table; a.inv_freq_stride = inv_freq_stride; a.l4_beta = l4_beta; a.l4_orig = l4_orig > 0 ? l4_orig : 1;
+    a.post_rope_norm = post_rope_norm; a.rotate_dims = rotate_dims; a.rotate_offset = rotate_offset;
+    dim3 grid(seq_len, bsz, 1);
+    hipStream_t st = (hipStream_t) stream;
+    const bool bf = norm_bf16 && q_norm;
+    if (rope_mode == 1)      { if (bf) rope_ex_kernel<1, true><<<grid, 256, 0, st>>>(a); else rope_ex_kernel<1, false><<<grid, 256, 0, st>>>(a); }
+    else if (rope_mode == 2) { if (bf) rope_ex_kernel<2, true><<<grid, 256, 0, st>>>(a); else rope_ex_kernel<2, false><<<grid, 256, 0, st>>>(a); }
+    else                     { if (bf) rope_ex_kernel<3, true><<<grid, 256, 0, st>>>(a); else rope_ex_kernel<3, false><<<grid, 256, 0, st>>>(a); }
+    return exl3_check_launch("rope_ex");
+}
+
 // In-place NEOX rope (head_dim 128, no head norm) on q / k that are column ranges of a wider row-major matrix: ld_q, ld_k = halves per token.
 // Used by the prefill route's fused q|k|v GEMM (linear.LinearEXL3.forward_multi); same kernel as exl3_rope's fast path.
 extern "C" int exl3_rope_strided(void* q, void* k, const float* inv_freq, int bsz, int seq_len, int heads_q, int heads_k, int64_t ld_q, int64_t ld_k,

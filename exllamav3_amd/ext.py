@@ -713,28 +713,59 @@ def rms_norm_res_in(x, w, y, r, epsilon: float, constant_bias: float = 0.0, cons
 def rope(q, out_q, k, out_k, inv_freq, position: int, positions, position_ids, rope_mode: int, attn_factor: float,
          q_norm=None, k_norm=None, norm_eps: float = 1e-6, norm_constant_bias: float = 0.0, l4_beta: float = 0.0,
          l4_orig: int = 1, post_rope_norm: bool = False, rotate_dims: int = 1, rotate_offset: int = 0):
-    """rope.cuh:51-72"""
+    """rope.cuh:51-72 with the host checks of rope.cu:345-470.  Llama / Mixtral calls (full rotary width, one position per token, fp16 head-norm
+    weights, contiguous heads) take the register kernels of exl3_rope; everything else of the argument list -- partial rotary, `rotate_dims` with 3-D
+    position ids, a rotate offset, an angle table, NANOCHAT, bf16 norm weights, the norm after the rotation, the llama-4 query scale, strided heads --
+    takes exl3_rope_ex."""
     _dev(q)
-    _req(q.dim() == 4 and q.dtype == torch.half and q.is_contiguous(), "rope: q must be contiguous float16 (b, s, h, d)")
-    _req(out_q.shape == q.shape and out_q.dtype == torch.half, "rope: out_q mismatch")
+    _req(q.dim() == 4 and q.dtype == torch.half and q.stride(3) == 1, "rope: q must be float16 (b, s, h, d) with a dense innermost dim")
+    _req(out_q.shape == q.shape and out_q.dtype == torch.half and out_q.stride() == q.stride(), "rope: out_q must share q's layout")
     bsz, seq, hq, hd = q.shape
-    hk = 0
+    _req(q.stride(1) == hq * q.stride(2) and q.stride(0) == seq * q.stride(1), "rope: token stride must be heads * head stride")
+    hk, ks = 0, 0
     if k is not None:
-        _req(k.dim() == 4 and k.dtype == torch.half and k.is_contiguous() and k.shape[0] == bsz and k.shape[1] == seq and k.shape[3] == hd,
-             "rope: k must match q")
-        _req(out_k is not None and out_k.shape == k.shape, "rope: out_k mismatch")
-        hk = k.shape[2]
-    _req(l4_beta == 0.0 and not post_rope_norm and rotate_dims == 1 and rotate_offset == 0,
-         "rope: llama-4 scaling / post-rope norm / multi-dim rotation are outside the Llama/Mixtral path of this build")
-    _req(inv_freq.dtype == torch.float and inv_freq.dim() == 1 and inv_freq.numel() * 2 <= hd, "rope: inv_freq must be float32 [<= head_dim/2]")
-    _req(inv_freq.numel() * 2 == hd, "rope: partial rotary is outside this build")
+        _req(k.dim() == 4 and k.dtype == torch.half and k.stride(3) == 1 and k.shape[0] == bsz and k.shape[1] == seq and k.shape[3] == hd,
+             "rope: k is incorrect shape")
+        _req(out_k is not None and out_k.shape == k.shape and out_k.stride() == k.stride(), "rope: out_k mismatch")
+        hk, ks = k.shape[2], k.stride(2)
+        _req(k.stride(1) == hk * ks and k.stride(0) == seq * k.stride(1), "rope: token stride must be heads * head stride")
+    _req(inv_freq.dtype == torch.float and 1 <= inv_freq.dim() <= 3 and inv_freq.is_contiguous(), "rope: inv_freq must be contiguous float32")
+    partial = inv_freq.shape[-1] * 2
+    _req(0 < rotate_dims <= 4, "rotate_dims out of range")
+    _req(rotate_dims == 1 or hd == partial * rotate_dims, "rotate_dims is inconsistent with inv_freq and head_dim")
+    _req(rotate_offset >= 0 and rotate_offset + partial * rotate_dims <= hd, "rotate_offset out of range")
+    _req(positions is None or position_ids is None, "rope: invalid arguments (positions and position_ids)")
+    ids_stride = 1
     for t in (positions, position_ids):
         _req(t is None or t.dtype in (torch.int32, torch.int), "rope: positions / position_ids must be int32")
-    for t in (q_norm, k_norm):
-        _req(t is None or (t.dtype == torch.half and t.numel() == hd), "rope: norm weights must be float16 [head_dim]")
-    _check(_lib.lib().exl3_rope(_p(q), _p(out_q), _p(k), _p(out_k), _p(inv_freq), bsz, seq, hq, hk, hd, int(position),
-                                _p(positions), _p(position_ids), int(rope_mode), float(attn_factor), _p(q_norm), _p(k_norm),
-                                float(norm_eps), float(norm_constant_bias), _stream(q)))
+    if positions is not None:
+        _req(positions.dim() == 1 and positions.shape[0] == bsz, "positions is incorrect shape")
+    if position_ids is not None:
+        _req(position_ids.is_contiguous(), "position_ids must be contiguous")
+        rd = position_ids.dim()
+        _req(rd == 2 or (rd == 3 and position_ids.shape[-1] == rotate_dims), "position_ids wrong number of dims")
+        _req(position_ids.shape[0] == bsz and position_ids.shape[1] == seq, "position_ids is incorrect shape")
+        if rd == 3:
+            ids_stride = rotate_dims
+    bf16 = False
+    if q_norm is not None:
+        _req(q_norm.dim() == 1 and q_norm.shape[0] == hd and q_norm.dtype in (torch.half, torch.bfloat16), "q_norm is incorrect size / dtype")
+        _req(k is None or (k_norm is not None and k_norm.dtype == q_norm.dtype and k_norm.shape == q_norm.shape), "q_norm and k_norm must be same dtype")
+        bf16 = q_norm.dtype == torch.bfloat16
+    table = inv_freq.dim() > 1
+    plain = (not table and partial == hd and rotate_dims == 1 and rotate_offset == 0 and ids_stride == 1 and rope_mode in (1, 2) and not bf16
+             and not post_rope_norm and l4_beta <= 0.0 and q.is_contiguous() and (k is None or k.is_contiguous()))
+    if plain:
+        _check(_lib.lib().exl3_rope(_p(q), _p(out_q), _p(k), _p(out_k), _p(inv_freq), bsz, seq, hq, hk, hd, int(position),
+                                    _p(positions), _p(position_ids), int(rope_mode), float(attn_factor), _p(q_norm), _p(k_norm),
+                                    float(norm_eps), float(norm_constant_bias), _stream(q)))
+        return
+    # rope.cu:388-395: a table of angles [pos][pairs] or [batch][pos][pairs]; the batch stride of a 2-D table is 0 here (one table for every sequence)
+    table_stride = inv_freq.shape[-1] * inv_freq.shape[-2] if inv_freq.dim() == 3 else 0
+    _check(_lib.lib().exl3_rope_ex(_p(q), _p(out_q), _p(k), _p(out_k), _p(inv_freq), bsz, seq, hq, hk, hd, q.stride(2), ks, partial, int(position),
+                                   _p(positions), _p(position_ids), ids_stride, int(rope_mode), float(attn_factor), _p(q_norm), _p(k_norm), int(bf16),
+                                   float(norm_eps), float(norm_constant_bias), int(table), int(table_stride), float(l4_beta), int(l4_orig),
+                                   int(bool(post_rope_norm)), int(rotate_dims), int(rotate_offset), _stream(q)))
 
 
 def _kv_bits(packed: torch.Tensor, scales: torch.Tensor) -> int:

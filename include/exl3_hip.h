@@ -397,6 +397,23 @@ int exl3_rope(const void* q, void* out_q, const void* k, void* out_k, const floa
               int rope_mode, float attn_factor, const void* q_norm, const void* k_norm, float norm_eps,
               float norm_constant_bias, void* stream);
 
+/* The rest of rope.cuh:51-72's argument list (kernel rope.cu:16-305, host checks rope.cu:345-470):
+ *   partial_head_dim   rotated width = 2 * (columns of inv_freq) <= head_dim; elements outside the rotated sub-ranges pass through
+ *   rotate_dims 1..4   sub-range r covers [rotate_offset + partial_head_dim * r, + partial_head_dim) and takes position_ids[b][t][r] when
+ *                      position_ids_stride == rotate_dims (3-D position ids), else the token's one position
+ *   inv_freq_table     inv_freq holds ANGLES indexed [batch * inv_freq_stride + pos * partial_head_dim / 2 + pair] (stride 0: one table for all)
+ *   rope_mode 3        NANOCHAT: NEOX pairs with the opposite sign of sin
+ *   norm_bf16          q_norm / k_norm are bfloat16 (v * rmf * (float(w) + bias), one rounding) instead of fp16 (reference's fp16 arithmetic)
+ *   post_rope_norm     unweighted RMSNorm of the whole head after the rotation
+ *   l4_beta > 0        query heads only, whole head: *= 1 + l4_beta * ln(1 + pos / l4_orig) (integer division), after the rotation
+ *   q_head_stride / k_head_stride   halves between consecutive heads (>= head_dim; token stride = heads * head stride as in the reference) */
+int exl3_rope_ex(const void* q, void* out_q, const void* k, void* out_k, const float* inv_freq,
+                 int bsz, int seq_len, int heads_q, int heads_k, int head_dim, int q_head_stride, int k_head_stride, int partial_head_dim,
+                 uint32_t position, const int32_t* positions, const int32_t* position_ids, int position_ids_stride,
+                 int rope_mode, float attn_factor, const void* q_norm, const void* k_norm, int norm_bf16, float norm_eps, float norm_constant_bias,
+                 int inv_freq_table, int inv_freq_stride, float l4_beta, int l4_orig, int post_rope_norm, int rotate_dims, int rotate_offset,
+                 void* stream);
+
 /* ---- KV-cache quantization   cache/q_cache.cuh:48-62, q_cache_kernels.cuh:61-236 ------------------ */
 /* quant_cache_cont(in, out, out_scales): in fp16 [tokens][dim], out u32 [tokens][dim/32*bits], scales fp16 [tokens][dim/32] */
 int exl3_quant_cache_cont(const void* in, void* out, void* out_scales, int64_t tokens, int dim, int bits, void* stream);

@@ -325,45 +325,93 @@ def rms_norm(x: np.ndarray, w: np.ndarray | None, eps: float, constant_bias: flo
 ROPE_GPTJ, ROPE_NEOX = 1, 2      # util/rope.py RopeStyle
 
 
+ROPE_NANOCHAT = 3
+
+
+def _bf16_round(x: np.ndarray) -> np.ndarray:
+    """float32 -> nearest-even bfloat16, returned as float32 (norm weights of dtype bfloat16, rope.cu:221-231)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return u.view(np.float32)
+
+
 def rope(q: np.ndarray, k: np.ndarray | None, inv_freq: np.ndarray, position: int = 0, positions=None, position_ids=None,
          rope_mode: int = ROPE_NEOX, attn_factor: float = 1.0, q_norm=None, k_norm=None, norm_eps: float = 1e-6,
-         norm_constant_bias: float = 0.0):
-    """q (b, s, hq, d), k (b, s, hk, d) fp16 -> rotated fp16.  Position of token (b, t) = position + t, or
-    positions[b] + t, or position_ids[b, t] (rope.cu:44-60).  Optional per-head RMSNorm before the rotation
-    (rope.cu:62-120).  NEOX pairs (i, i + d/2); GPTJ pairs (2i, 2i+1).  Math in fp32."""
-    def one(x, norm_w):
+         norm_constant_bias: float = 0.0, l4_beta: float = 0.0, l4_orig: int = 1, post_rope_norm: bool = False,
+         rotate_dims: int = 1, rotate_offset: int = 0, norm_bf16: bool = False):
+    """q (b, s, hq, d), k (b, s, hk, d) fp16 -> rotated fp16; the whole argument list of rope.cu:307-343.
+
+    Position of token (b, t) = position + t, or positions[b] + t, or position_ids[b, t] (2-D) / position_ids[b, t, rdim] (3-D, one
+    position per rotated sub-range: rope.cu:56-70).  inv_freq 1-D [p/2]: angle = inv_freq * pos; 2-D / 3-D: a table of angles indexed
+    [batch (if 3-D)][pos][p/2] (rope.cu:80-87, host side :388-395).  p = 2 * inv_freq.shape[-1] is the rotated width ("partial_head_dim"):
+    sub-range rdim covers elements [rotate_offset + p * rdim, + p); everything outside passes through (rope.cu:154-160).
+    Stages, each leaving fp16 values like the kernel's shared half buffer (rope.cu:318-323):
+      1. per-head RMSNorm when q_norm is given (k heads use k_norm): fp16 weights -> normalised value rounded to fp16, (w + bias) formed in fp16,
+         product in fp16 (rope.cu:232-240); bf16 weights -> v * rmf * (float(w) + bias) in fp32, one rounding (rope.cu:221-231);
+      2. rotation per sub-range, NEOX pairs (i, i + p/2), GPTJ pairs (2i, 2i+1), NANOCHAT = NEOX pairs with the opposite sign of sin (rope.cu:162-198);
+      3. post_rope_norm: unweighted RMSNorm of the whole head (rope.cu:247-274);
+      4. llama-4 scale on query heads only: 1 + beta * ln(1 + pos(rdim 0) // orig) on the whole head (rope.cu:90-94, :278-289, :297)."""
+    inv_freq = np.asarray(inv_freq, dtype=np.float32)
+    p2 = inv_freq.shape[-1]
+    table = inv_freq.ndim > 1
+
+    def one(x, norm_w, is_q):
         if x is None:
             return None
         b, s, h, d = x.shape
-        xf = x.astype(np.float32)
-        if norm_w is not None:
-            # rope.cu:199-233: normalised value rounded to fp16, weight (w + bias) formed in fp16, product in fp16
+        assert rotate_dims >= 1 and rotate_offset >= 0 and rotate_offset + 2 * p2 * rotate_dims <= d
+        xf = x.astype(np.float16).astype(np.float32)
+        if q_norm is not None:
             ss = (xf.astype(np.float64) ** 2).sum(-1, keepdims=True).astype(np.float32)
             rmf = np.float32(1.0) / np.sqrt(ss / np.float32(d) + np.float32(norm_eps))
-            vn = (xf * rmf).astype(np.float16)
-            wh = (norm_w.astype(np.float16) + np.float16(norm_constant_bias)).astype(np.float16)
-            xf = (vn * wh).astype(np.float16).astype(np.float32)
-        if position_ids is not None:
-            pos = np.asarray(position_ids).reshape(b, s).astype(np.float32)
-        elif positions is not None:
-            pos = (np.asarray(positions).reshape(b, 1) + np.arange(s)[None, :]).astype(np.float32)
-        else:
-            pos = np.broadcast_to((position + np.arange(s))[None, :], (b, s)).astype(np.float32)
-        ang = pos[:, :, None].astype(np.float32) * inv_freq.astype(np.float32)[None, None, :]      # (b, s, d/2)
-        sin = (np.sin(ang.astype(np.float64)) * attn_factor).astype(np.float32)[:, :, None, :]
-        cos = (np.cos(ang.astype(np.float64)) * attn_factor).astype(np.float32)[:, :, None, :]
-        out = np.empty_like(xf)
-        hd = d // 2
-        if rope_mode == ROPE_NEOX:
-            a, c = xf[..., :hd], xf[..., hd:]
-            out[..., :hd] = a * cos - c * sin
-            out[..., hd:] = c * cos + a * sin
-        else:
-            a, c = xf[..., 0::2], xf[..., 1::2]
-            out[..., 0::2] = a * cos - c * sin
-            out[..., 1::2] = c * cos + a * sin
+            if norm_bf16:
+                w = _bf16_round(np.asarray(norm_w, dtype=np.float32)) + np.float32(norm_constant_bias)
+                xf = ((xf * rmf).astype(np.float32) * w).astype(np.float16).astype(np.float32)
+            else:
+                vn = (xf * rmf).astype(np.float16)
+                wh = (np.asarray(norm_w).astype(np.float16) + np.float16(norm_constant_bias)).astype(np.float16)
+                xf = (vn * wh).astype(np.float16).astype(np.float32)
+
+        def pos_of(rdim):
+            if positions is not None:
+                return (np.asarray(positions).reshape(b, 1) + np.arange(s)[None, :]).astype(np.int64)
+            if position_ids is not None:
+                pi = np.asarray(position_ids)
+                return (pi.reshape(b, s, -1)[:, :, rdim if pi.ndim == 3 else 0]).astype(np.int64)
+            return np.broadcast_to((position + np.arange(s))[None, :], (b, s)).astype(np.int64)
+
+        out = xf.copy()
+        for rdim in range(rotate_dims):
+            pos = pos_of(rdim)
+            if table:
+                tb = inv_freq if inv_freq.ndim == 3 else np.broadcast_to(inv_freq[None], (b,) + inv_freq.shape)
+                ang = tb[np.arange(b)[:, None], pos]                                               # (b, s, p/2)
+            else:
+                ang = pos[:, :, None].astype(np.float32) * inv_freq[None, None, :]
+            sin = (np.sin(ang.astype(np.float64)) * attn_factor).astype(np.float32)[:, :, None, :]
+            cos = (np.cos(ang.astype(np.float64)) * attn_factor).astype(np.float32)[:, :, None, :]
+            o0 = rotate_offset + 2 * p2 * rdim
+            seg = out[..., o0:o0 + 2 * p2]
+            res = np.empty_like(seg)
+            if rope_mode == ROPE_GPTJ:
+                a, c = seg[..., 0::2], seg[..., 1::2]
+                res[..., 0::2] = a * cos - c * sin
+                res[..., 1::2] = c * cos + a * sin
+            else:
+                sg = np.float32(-1.0) if rope_mode == ROPE_NANOCHAT else np.float32(1.0)
+                a, c = seg[..., :p2], seg[..., p2:]
+                res[..., :p2] = a * cos - sg * c * sin
+                res[..., p2:] = c * cos + sg * a * sin
+            out[..., o0:o0 + 2 * p2] = res.astype(np.float16).astype(np.float32)
+        if post_rope_norm:
+            ss = (out.astype(np.float64) ** 2).sum(-1, keepdims=True).astype(np.float32)
+            rmf = np.float32(1.0) / np.sqrt(ss / np.float32(d) + np.float32(norm_eps))
+            out = (out * rmf).astype(np.float16).astype(np.float32)
+        if l4_beta > 0.0 and is_q:
+            sc = (np.float32(1.0) + np.float32(l4_beta) * np.log(np.float32(1.0) + (pos_of(0) // int(l4_orig)).astype(np.float32))).astype(np.float32)
+            out = (out * sc[:, :, None, None]).astype(np.float16).astype(np.float32)
         return out.astype(np.float16)
-    return one(q, q_norm), one(k, k_norm)
+    return one(q, q_norm, True), one(k, k_norm, False)
 
 
 # ------------------------------------------------------------------------------------------

@@ -342,3 +342,140 @@ def test_rope_neox_head_dim_128_prefill_kernel(dev, shape):
     rq, rk = o.rope(q, k, inv, position=7, rope_mode=2)
     ext.rope(tq, tq, tk, tk, _t(inv, dev), 7, None, None, 2, 1.0)
     assert np.allclose(tq.float().cpu().numpy(), rq.astype(np.float32), atol=3e-3, rtol=3e-3)
+
+
+def _rope_ex_case(dev, b, s, hq, hk, hd, *, mode=2, partial=None, rotate_dims=1, rotate_offset=0, pos_mode="position", table=0, norm=None, bias=0.0,
+                  post_norm=False, l4=None, attn_factor=1.0, pad=0, in_place=False, seed=0):
+    """One call of ext.rope through exl3_rope_ex against the oracle (which the reference's own tests/test_rope.py judges on the CPU:
+    tests/test_oracle_pins.py::test_rope_full_argument_list_against_the_references_own_tests)."""
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(seed + hd + 7 * s)
+    partial = partial or hd // rotate_dims
+    # heads as the trailing hd columns of (hd + pad)-wide heads: q.stride(2) = hd + pad (rope.cu:351-353)
+    qw = rng.standard_normal((b, s, hq, hd + pad)).astype(np.float16)
+    kw_ = rng.standard_normal((b, s, hk, hd + pad)).astype(np.float16) if hk else None
+    q, k = qw[..., pad:], (kw_[..., pad:] if hk else None)
+    inv = (1.0 / (10000.0 ** (np.arange(0, partial, 2) / partial))).astype(np.float32)
+    kwargs = dict(position=0, positions=None, position_ids=None)
+    if pos_mode == "position":
+        kwargs["position"] = 19
+    elif pos_mode == "positions":
+        kwargs["positions"] = rng.integers(0, 49, size=b).astype(np.int32)
+    elif pos_mode == "ids":
+        kwargs["position_ids"] = rng.integers(0, 117, size=(b, s)).astype(np.int32)
+    else:                                                   # one position per rotated sub-range
+        kwargs["position_ids"] = rng.integers(0, 117, size=(b, s, rotate_dims)).astype(np.int32)
+    inv_arg = inv
+    if table:
+        # angle table [pos][pairs] (2-D) or [batch][pos][pairs] (3-D), e.g. per-sequence frequency scaling
+        base = np.arange(160, dtype=np.float32)[:, None] * inv[None, :]
+        inv_arg = base if table == 2 else np.stack([base * np.float32(1.0 + 0.25 * i) for i in range(b)])
+    qn = kn = None
+    if norm:
+        qn = (1 + 0.1 * rng.standard_normal(hd)).astype(np.float32)
+        kn = (1 + 0.1 * rng.standard_normal(hd)).astype(np.float32)
+        if norm == "fp16":
+            qn, kn = qn.astype(np.float16), kn.astype(np.float16)
+    l4_beta, l4_orig = l4 if l4 else (0.0, 1)
+    rq, rk = o.rope(q, k, inv_arg, rope_mode=mode, attn_factor=attn_factor, q_norm=qn, k_norm=kn, norm_eps=1e-6, norm_constant_bias=bias,
+                    l4_beta=l4_beta, l4_orig=l4_orig, post_rope_norm=post_norm, rotate_dims=rotate_dims, rotate_offset=rotate_offset,
+                    norm_bf16=(norm == "bf16"), **kwargs)
+    tqw, tkw = _t(qw, dev), (_t(kw_, dev) if hk else None)
+    tq, tk = tqw[..., pad:], (tkw[..., pad:] if hk else None)
+    oq = tq if in_place else torch.zeros_like(tqw)[..., pad:]
+    ok_ = (tk if in_place else torch.zeros_like(tkw)[..., pad:]) if hk else None
+    nt = lambda w: None if w is None else (_t(w, dev).to(torch.bfloat16) if norm == "bf16" else _t(w, dev))
+    ext.rope(tq, oq, tk, ok_, _t(inv_arg, dev), kwargs["position"], None if kwargs["positions"] is None else _t(kwargs["positions"], dev),
+             None if kwargs["position_ids"] is None else _t(kwargs["position_ids"], dev), mode, attn_factor, nt(qn), nt(kn), 1e-6, bias,
+             l4_beta, l4_orig, post_norm, rotate_dims, rotate_offset)
+    tol = 6e-3 if (norm or post_norm) else 3e-3
+    assert np.allclose(oq.float().cpu().numpy(), rq.astype(np.float32), atol=tol, rtol=tol)
+    if hk:
+        assert np.allclose(ok_.float().cpu().numpy(), rk.astype(np.float32), atol=tol, rtol=tol)
+    if not in_place:                                        # inputs untouched, the padding columns of the outputs never written
+        assert torch.equal(tqw.cpu(), torch.from_numpy(qw))
+    return oq, ok_
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("hd,partial", [(128, 64), (128, 32), (96, 48), (256, 64), (80, 40), (64, 64)])
+def test_rope_partial_rotary_and_nanochat(dev, mode, hd, partial):
+    """Rotated width smaller than the head (rope.cu:154-160: the tail passes through), the three pair conventions, every position mode."""
+    for pos_mode in ("position", "positions", "ids"):
+        _rope_ex_case(dev, 2, 9, 8, 2, hd, mode=mode, partial=partial, pos_mode=pos_mode, attn_factor=1.07, seed=mode)
+    _rope_ex_case(dev, 1, 1, 28, 7, hd, mode=mode, partial=partial, norm="fp16", in_place=True)
+    _rope_ex_case(dev, 1, 3, 4, 0, hd, mode=mode, partial=partial)                      # q only
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("norm", [None, "fp16", "bf16"])
+@pytest.mark.parametrize("in_place", [False, True])
+def test_rope_multidim_position_ids(dev, mode, norm, in_place):
+    """tests/test_rope.py:108-230 (the reference's two-axis rope: head_dim 72 = 2 x 36, 3-D position ids), plus 3 and 4 sub-ranges and a
+    2-D position tensor shared by the sub-ranges."""
+    _rope_ex_case(dev, 2, 280, 16, 16, 72, mode=mode, rotate_dims=2, pos_mode="ids3", norm=norm, in_place=in_place)
+    _rope_ex_case(dev, 1, 5, 8, 2, 96, mode=mode, rotate_dims=3, pos_mode="ids3", norm=norm, in_place=in_place)
+    _rope_ex_case(dev, 3, 2, 4, 4, 128, mode=mode, rotate_dims=4, pos_mode="ids3", norm=norm, in_place=in_place)
+    _rope_ex_case(dev, 2, 6, 4, 2, 64, mode=mode, rotate_dims=2, pos_mode="ids", norm=norm, in_place=in_place)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("partial", [128, 64])
+def test_rope_llama4_query_scale(dev, mode, partial):
+    """tests/test_rope.py:233-290: keys bitwise unscaled, the whole query head (also its non-rotated part) scaled by 1 + beta ln(1 + pos // orig);
+    the window straddles the first scale step."""
+    from exllamav3_amd import ext
+    beta, orig = 0.1, 16384
+    b, s, hq, hk, hd = 2, 16, 8, 2, 128
+    rng = np.random.default_rng(partial)
+    q = rng.standard_normal((b, s, hq, hd)).astype(np.float16)
+    k = rng.standard_normal((b, s, hk, hd)).astype(np.float16)
+    inv = (1.0 / (1000000.0 ** (np.arange(0, partial, 2) / partial))).astype(np.float32)
+    pos = orig - s // 2
+    outs = {}
+    for bt in (beta, 0.0):
+        oq, ok_ = torch.zeros((b, s, hq, hd), dtype=torch.half, device=dev), torch.zeros((b, s, hk, hd), dtype=torch.half, device=dev)
+        ext.rope(_t(q, dev), oq, _t(k, dev), ok_, _t(inv, dev), pos, None, None, mode, 1.0, None, None, 1e-6, 0.0, bt, orig, False, 1, 0)
+        outs[bt] = (oq.cpu(), ok_.cpu())
+        rq, rk = o.rope(q, k, inv, position=pos, rope_mode=mode, l4_beta=bt, l4_orig=orig)
+        assert np.allclose(oq.float().cpu().numpy(), rq.astype(np.float32), atol=3e-3, rtol=3e-3)
+    assert torch.equal(outs[beta][1], outs[0.0][1])
+    scale = 1.0 + beta * np.log(1.0 + ((pos + np.arange(s)) // orig).astype(np.float32))
+    assert scale.min() == 1.0 and scale.max() > 1.0
+    expect = (outs[0.0][0].float().numpy() * scale.reshape(1, s, 1, 1)).astype(np.float16).astype(np.float32)
+    assert np.allclose(outs[beta][0].float().numpy(), expect, atol=3e-3, rtol=3e-3)
+    _rope_ex_case(dev, 2, 5, 8, 2, 128, mode=mode, partial=partial, pos_mode="positions", l4=(0.2, 8), norm="fp16", post_norm=True)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_rope_post_norm_tables_offsets_strides(dev, mode):
+    """The remaining arguments: unweighted norm after the rotation, angle tables (2-D shared / 3-D per sequence), a rotate offset (rope.cu:363),
+    heads that are the trailing columns of wider heads (rope.cu:351-353), bf16 norm weights with a constant bias, head_dim 512."""
+    _rope_ex_case(dev, 2, 7, 8, 2, 128, mode=mode, post_norm=True)
+    _rope_ex_case(dev, 2, 7, 8, 2, 128, mode=mode, post_norm=True, norm="bf16", bias=1.0)
+    _rope_ex_case(dev, 1, 11, 4, 4, 64, mode=mode, table=2, pos_mode="ids")
+    _rope_ex_case(dev, 3, 4, 4, 2, 128, mode=mode, table=3, pos_mode="positions", partial=64)
+    _rope_ex_case(dev, 2, 3, 8, 8, 128, mode=mode, partial=32, rotate_offset=96)                         # rotate the LAST 32 columns
+    _rope_ex_case(dev, 2, 3, 8, 8, 192, mode=mode, partial=64, rotate_offset=64, norm="fp16")
+    _rope_ex_case(dev, 2, 5, 6, 3, 64, mode=mode, pad=448)                                               # rope on head[..., -64:] of 512-wide heads
+    _rope_ex_case(dev, 1, 4, 2, 1, 64, mode=mode, pad=64, in_place=True, partial=32)
+    _rope_ex_case(dev, 1, 2, 3, 1, 512, mode=mode, norm="fp16")
+    _rope_ex_case(dev, 1, 2, 3, 1, 512, mode=mode, partial=128, rotate_dims=4, pos_mode="ids3")
+
+
+def test_rope_argument_checks(dev):
+    """The host checks of rope.cu:361-420 raise (RuntimeError) instead of launching."""
+    from exllamav3_amd import ext
+    q = torch.zeros((1, 2, 4, 128), dtype=torch.half, device=dev)
+    inv32 = torch.ones(32, dtype=torch.float, device=dev)
+    ids = torch.zeros((1, 2), dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError, match="rotate_dims"):
+        ext.rope(q, q, None, None, inv32, 0, None, None, 2, 1.0, None, None, 1e-6, 0.0, 0.0, 1, False, 3, 0)           # 128 != 64 * 3
+    with pytest.raises(RuntimeError, match="rotate_offset"):
+        ext.rope(q, q, None, None, inv32, 0, None, None, 2, 1.0, None, None, 1e-6, 0.0, 0.0, 1, False, 1, 96)
+    with pytest.raises(RuntimeError, match="invalid arguments"):
+        ext.rope(q, q, None, None, inv32, 0, torch.zeros(1, dtype=torch.int32, device=dev), ids, 2, 1.0)
+    with pytest.raises(RuntimeError, match="position_ids"):
+        ext.rope(q, q, None, None, inv32, 0, None, torch.zeros((1, 2, 3), dtype=torch.int32, device=dev), 2, 1.0)
+    with pytest.raises(RuntimeError, match="rope_mode"):
+        ext.rope(q, q, None, None, inv32, 0, None, None, 4, 1.0)

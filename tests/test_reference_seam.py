@@ -19,7 +19,7 @@ needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "exllamav3"))
 HOT_MODULES = ["modules/quant/exl3.py", "modules/rmsnorm.py", "util/rope.py", "cache/quant.py", "modules/linear.py"]
 # names those modules use that belong to other subsystems (conversion-time quantizer, LoRA-free fp16 inner, capture) -- outside SURVEY.md 8
 OUTSIDE = {"quantize_tiles", "quantize_tiles_multigpu", "had_paley", "had_paley2", "test_distribution", "count_inf_nan", "gated_rms_norm",
-           "quantize_error", "gen_mrope_pos_ids"}       # mrope: multimodal position ids (rejected by this build's rope)
+           "quantize_error", "gen_mrope_pos_ids"}       # gen_mrope_pos_ids: host-side position-id builder of the multimodal front end (no device work)
 
 
 def _ext_names(path):
