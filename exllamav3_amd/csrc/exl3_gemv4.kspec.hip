@@ -55,9 +55,9 @@ constexpr int g4_input_mode(int MODE) { return MODE == G4_MODE_TRAWX ? G4_MODE_R
 constexpr int g4_waves_per_eu(int K, int CB, int MODE_)
 {
     const int MODE = g4_input_mode(MODE_);
-    if (MODE == G4_MODE_ATTM) return 4;                      // eight 16-byte split outputs travel with a task
+    if (MODE == G4_MODE_ATTM) return 2;                      // eight 16-byte split outputs travel with a task, two tasks in flight in the pipelined task loop: 128 VGPRs spill (4 VGPRs + 79 SGPRs at budget 4); o_proj launches are one wave per SIMD anyway
     if (MODE == G4_MODE_ACT) return MODE_ == G4_MODE_TACT ? 4 : 3;     // 8 slab lines travel with a task; the non-table form also carries the row-scale correction
-    if (MODE == G4_MODE_ACTFX && K >= 6) return 5;          // four 16-byte accumulator loads in flight per task next to a 12..16-word ring
+    if (MODE == G4_MODE_ACTFX && K >= 5) return 5;          // four 16-byte accumulator loads in flight per task next to a 10..16-word ring
     if (K >= 5) return 6;
     if (MODE == G4_MODE_NORMFX || MODE == G4_MODE_ACTFX) return 6;
     return (MODE == G4_MODE_ROT && CB == EXL3_CB_MUL1) ? 8 : 7;
