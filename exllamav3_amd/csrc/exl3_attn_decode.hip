@@ -172,6 +172,22 @@ void attn_decode_kernel(const AttnArgs a)
 // Partial records and the merge kernel are those of the kernel above.
 struct AttnWideArgs { AttnArgs a; };
 
+// The q|k|v launch's epilogue done by the attention kernel itself (FUSED form, round 4): what exl3_glue_qkv_tab does in a launch of its own --
+// split-k reduce of the deferred slabs, output Hadamard, row-scale correction, svh, RoPE from the per-step tables, the 4-bit append of the new token's
+// K / V -- happens in the preparation phase of every workgroup for the query heads it needs; the workgroup whose context split holds the new token
+// (index len - 1) also finishes that token's K and V rows of its kv head, writes them to the cache page AND keeps the words in LDS, from where its
+// streaming loop takes them (no read-back of its own stores).  reference: libtorch/attention.cpp:386-440 (rope, cache append, split kernel).
+struct AttnQkvArgs
+{
+    SlabRef sq, sk, sv;                                         // deferred slabs of the q|k|v launch
+    const half_t* svh_q; const half_t* svh_k; const half_t* svh_v;
+    const float* rope_sin; const float* rope_cos; const int64_t* slots;        // exl3_qkv_prep: [m][64], [m][64], physical cache row of the new token [m]
+    GemvRescale rs;
+    half_t* q_out;                                              // optional [m][hq][128]: the finished (roped) queries, written by context split 0
+    uint32_t* k_cache_w; half_t* k_scales_w; uint32_t* v_cache_w; half_t* v_scales_w;
+    int rope_mode, m;
+};
+
 #define AW_VS 136          // V tile row stride in halves (272 B: the transpose-read groups tile the banks)
 
 __device__ __forceinline__ half4_t aw_tr16(const half_t* p)
@@ -197,11 +213,13 @@ __device__ __forceinline__ half8_t aw_dequant8(uint32_t x, half2_t sc4)
     return r.h;
 }
 
-template <int GQ>
+template <int GQ, bool FUSED>
 __global__ __launch_bounds__(256)
-void attn_decode_wide_kernel(const AttnArgs a)
+void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
 {
     constexpr int HD = 128;
+    __shared__ __attribute__((aligned(16))) uint32_t new_kv[2][16];            // FUSED: the new token's K / V words of this kv head (4 groups x 4 words)
+    __shared__ __attribute__((aligned(8))) half_t new_sc[2][4];                //        and their group scales
     __shared__ __attribute__((aligned(16))) half_t q_s[8 * 128];               // rotated, pre-scaled queries in pair order (rows >= GQ stay zero)
     __shared__ __attribute__((aligned(16))) half_t vt[4][16 * AW_VS];          // wave-private dequantized V tiles; after the loop: the waves' partial outputs
     __shared__ float ml_s[4][8][2];
@@ -212,6 +230,83 @@ void attn_decode_wide_kernel(const AttnArgs a)
     const int G = a.hkv * HD / 32;
 
     // ---- rotated queries: half-wave i rotates head i as the kernel above does and stores it in pair order; natural-log scores become log2 scores
+    // FUSED: the new token (index len - 1) lies in exactly one context split; that workgroup finishes and appends its K / V
+    const bool owner = FUSED && len - 1 >= t0 && len - 1 < t0 + a.split_tokens;
+    // the wave's FIRST 16 tokens are requested here, ahead of the query preparation (which does not depend on them): at a 1000-token context a wave
+    // has exactly one step, and the chain length -> block table -> cache words otherwise starts only after the queries are ready
+    uint32_t kw0[4] = { 0u, 0u, 0u, 0u }, vw0[4] = { 0u, 0u, 0u, 0u };
+    half4_t ksc0 = { 0, 0, 0, 0 }, vsc0 = ksc0;
+    if (t0 + 16 * wave < t1)
+    {
+        const int tk = min(t0 + 16 * wave + c, t1 - 1);
+        const int64_t pg = a.block_table[(size_t) b * a.blocks_per_seq + tk / a.page_size];
+        const int64_t gbase = (pg * a.page_size + (tk % a.page_size)) * G + h * 4;
+        #pragma unroll
+        for (int s = 0; s < 4; ++s) { kw0[s] = a.k_cache[(gbase + s) * 4 + kg]; vw0[s] = a.v_cache[(gbase + s) * 4 + kg]; }
+        ksc0 = *((const half4_t*) (a.k_scales + gbase)); vsc0 = *((const half4_t*) (a.v_scales + gbase));
+    }
+    if constexpr (FUSED)
+    {
+        // tasks, one per half-wave: 0 .. GQ - 1 = query head h * GQ + task; GQ = the new token's K row, GQ + 1 = its V row (kv head h; only in the
+        // workgroup whose split holds the new token).  One code path for the three kinds (per-lane operand pointers, like glue_qkv_kernel), a second
+        // round only for GQ = 7, 8.  Every half-wave of a participating wave runs the arithmetic (the butterflies want whole half-waves); stores are
+        // predicated.  The finished values are those of exl3_glue_qkv_tab bit for bit (qkv_block_finish).
+        const int l = tid & 31, hw = tid >> 5;
+        #pragma nounroll
+        for (int r = 0; r < (GQ + 2 + 7) / 8; ++r)
+        {
+            if (r > 0 && !owner) break;                                                       // workgroup-uniform
+            const int task = r * 8 + hw;
+            const int kind = task < GQ ? 0 : task - GQ + 1;                                    // 0: query, 1: K row, 2: V row, >= 3: nothing
+            const int tw = r * 8 + 2 * wave;
+            const bool wave_has = tw < GQ || (owner && tw + 1 >= GQ && tw <= GQ + 1);          // wave-uniform: tasks tw, tw + 1
+            if (wave_has)
+            {
+                const bool kvt = kind == 1 || kind == 2;
+                const int cblk = kvt ? h : h * GQ + min(task, GQ - 1);
+                const float* sbase = kind == 1 ? x.sk.base : (kind == 2 ? x.sv.base : x.sq.base);
+                const half_t* svh = (kind == 1 ? x.svh_k : (kind == 2 ? x.svh_v : x.svh_q)) + cblk * 128;
+                const half4_t sc = ((const half4_t*) svh)[l];
+                float rs_p = 0.0f, rs_n = 0.0f;
+                if (x.rs.ss_new && l < (x.rs.k >> 7)) { rs_p = x.rs.ss_prev[(size_t) b * (x.rs.k >> 7) + l]; rs_n = x.rs.ss_new[(size_t) b * (x.rs.k >> 7) + l]; }
+                float4_t sn4 = { 0.f, 0.f, 0.f, 0.f }, cs4 = sn4;
+                const int f = x.rope_mode == 2 ? 4 * (l & 15) : 2 * l;
+                if (x.rope_mode == 2) { sn4 = *((const float4_t*) (x.rope_sin + b * 64 + f)); cs4 = *((const float4_t*) (x.rope_cos + b * 64 + f)); }
+                else { sn4.x = x.rope_sin[b * 64 + f]; sn4.y = x.rope_sin[b * 64 + f + 1]; cs4.x = x.rope_cos[b * 64 + f]; cs4.y = x.rope_cos[b * 64 + f + 1]; }
+                const int64_t token_pos = x.slots[b];
+                const SlabRef sr = { sbase, x.sq.S };                                          // one launch wrote the three slab sets: one split count
+                const float4_t ysum = slab_sum(sr, cblk, b, x.m, l);
+                const half4_t y = qkv_block_finish(ysum, sc, x.rs, b, l, rs_p, rs_n, kind != 2, x.rope_mode, 16, sn4, cs4);
+                float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
+                // K / V row: 4-bit append to the cache page and the workgroup's own copy of the words
+                const int64_t gb = token_pos * G + h * 4 + (l >> 3);
+                uint32_t* cw = kind == 2 ? x.v_cache_w : x.k_cache_w; half_t* cs = kind == 2 ? x.v_scales_w : x.k_scales_w;
+                const bool actkv = owner && kvt;
+                kv_quant_regs<4>(v0, v1, v2, v3, cw + gb * 4, cs + gb, actkv, lane);
+                kv_quant_regs<4>(v0, v1, v2, v3, &new_kv[kind == 2 ? 1 : 0][(l >> 3) * 4], &new_sc[kind == 2 ? 1 : 0][l >> 3], actkv, lane);
+                // query: rotated into the cache's H32 domain, pre-scaled, in pair order (the unfused form's staging below)
+                if (kind == 0 && x.q_out && split == 0) ((half4_t*) (x.q_out + ((size_t) b * a.hq + cblk) * HD))[l] = y;
+                kvg_had32(v0, v1, v2, v3, lane);
+                const float fq = ATT_R32 * a.scale * 1.44269504f;
+                const float vv[4] = { v0 * fq, v1 * fq, v2 * fq, v3 * fq };
+                if (kind == 0)
+                {
+                    #pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                    {
+                        const int d = 4 * l + e, d8 = d & 7;
+                        q_s[task * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) vv[e];
+                    }
+                }
+            }
+            if (r == 0 && hw >= GQ)
+            {
+                #pragma unroll
+                for (int e = 0; e < 4; ++e) q_s[hw * 128 + 4 * l + e] = (half_t) 0.0f;          // rows >= GQ of the query operand stay zero
+            }
+        }
+    }
+    else
     {
         const int l = tid & 31, i = tid >> 5;
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
@@ -230,6 +325,21 @@ void attn_decode_wide_kernel(const AttnArgs a)
             q_s[i * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = i < GQ ? (half_t) vv[e] : (half_t) 0.0f;
         }
     }
+    // FUSED: the preparation above holds ~35 scalar argument registers (slab bases, scales, tables, rescale sums); with the streaming loop's own
+    // arguments (cache pointers, block table, partial records) live across it the kernel ran out of SGPRs (24 spills and a 20-byte private segment =
+    // +1.5 .. 3 us per launch).  The loop's arguments are therefore read from the kernel-argument segment AFTER the preparation: the segment pointer
+    // goes through an empty asm, so the compiler cannot hoist those loads to the top
+    AttnArgs al;
+#if defined(__HIP_DEVICE_COMPILE__)                                                            // (the host pass of the compiler has no address space 4)
+    if constexpr (FUSED)
+    {
+        const __attribute__((address_space(4))) char* kp = (const __attribute__((address_space(4))) char*) __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        al = *((const __attribute__((address_space(4))) AttnArgs*) kp);                        // `a` is the first kernel parameter: offset 0
+    }
+    else
+#endif
+    al = a;
     __syncthreads();
     half8_t qf[4];
     #pragma unroll
@@ -241,18 +351,38 @@ void attn_decode_wide_kernel(const AttnArgs a)
     for (int nb = 0; nb < 8; ++nb) oc[nb] = float4_t{ 0.f, 0.f, 0.f, 0.f };
     half_t* vw = vt[wave];
 
-    const int nsteps = (a.split_tokens + 63) / 64;
+    const int nsteps = (al.split_tokens + 63) / 64;
     for (int st = 0; st < nsteps; ++st)
     {
         const int tb = t0 + 64 * st + 16 * wave;                // the wave's 16 tokens of this step
         if (tb >= t1) break;                                    // wave-uniform: nothing left for this wave (its LDS tile is private)
         const int tk = min(tb + c, t1 - 1);
-        const int64_t pg = a.block_table[(size_t) b * a.blocks_per_seq + tk / a.page_size];
-        const int64_t gbase = (pg * a.page_size + (tk % a.page_size)) * G + h * 4;
         uint32_t kw[4], vw4[4];
-        #pragma unroll
-        for (int s = 0; s < 4; ++s) { kw[s] = a.k_cache[(gbase + s) * 4 + kg]; vw4[s] = a.v_cache[(gbase + s) * 4 + kg]; }
-        const half4_t ksc = *((const half4_t*) (a.k_scales + gbase)), vsc = *((const half4_t*) (a.v_scales + gbase));
+        half4_t ksc, vsc;
+        if (st == 0)
+        {
+            #pragma unroll
+            for (int s = 0; s < 4; ++s) { kw[s] = kw0[s]; vw4[s] = vw0[s]; }
+            ksc = ksc0; vsc = vsc0;
+        }
+        else
+        {
+            const int64_t pg = al.block_table[(size_t) b * al.blocks_per_seq + tk / al.page_size];
+            const int64_t gbase = (pg * al.page_size + (tk % al.page_size)) * G + h * 4;
+            #pragma unroll
+            for (int s = 0; s < 4; ++s) { kw[s] = al.k_cache[(gbase + s) * 4 + kg]; vw4[s] = al.v_cache[(gbase + s) * 4 + kg]; }
+            ksc = *((const half4_t*) (al.k_scales + gbase)); vsc = *((const half4_t*) (al.v_scales + gbase));
+        }
+        if constexpr (FUSED)
+        {
+            // the new token's words come from this workgroup's LDS copy (its cache row is being written by this very launch)
+            if (owner && tk == len - 1)
+            {
+                #pragma unroll
+                for (int s = 0; s < 4; ++s) { kw[s] = new_kv[0][s * 4 + kg]; vw4[s] = new_kv[1][s * 4 + kg]; }
+                ksc = *((const half4_t*) new_sc[0]); vsc = *((const half4_t*) new_sc[1]);
+            }
+        }
         // ---- scores of the 16 tokens for all heads: D[token][head]; lane (head c, kg) holds tokens 4 kg .. 4 kg + 3
         float4_t sc = { 0.f, 0.f, 0.f, 0.f };
         #pragma unroll
@@ -336,7 +466,7 @@ void attn_decode_wide_kernel(const AttnArgs a)
                     O[e4] += o_s[(w * 8 + i) * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] * e;
                 }
             }
-            float* pr = a.part + ((((size_t) b * gridDim.y + h) * GQ + i) * a.nsplit + split) * 132;
+            float* pr = al.part + ((((size_t) b * gridDim.y + h) * GQ + i) * al.nsplit + split) * 132;
             if (l == 0) { pr[0] = M * 0.69314718f; pr[1] = L; }              // the merge kernel works in natural-log units
             *((float4_t*) (pr + 4 + 4 * l)) = float4_t{ O[0], O[1], O[2], O[3] };
         }
@@ -442,10 +572,19 @@ void attn_merge_kernel(const float* __restrict__ part, half_t* __restrict__ out,
     if (act) ((half4_t*) (out + ((size_t) b * hq + head) * hd))[lr] = half4_t{ f2h(v0 * ATT_R32), f2h(v1 * ATT_R32), f2h(v2 * ATT_R32), f2h(v3 * ATT_R32) };
 }
 
+// what the fused form needs beyond AttnQkvArgs when it has to fall back to the two-launch form (exl3_glue_qkv_tab, then the split kernels)
+struct QkvFuse { AttnQkvArgs x; int S; const float* inv_freq; const int32_t* positions; float attn_factor; int hidden; int* fused_out; };
+extern "C" int exl3_glue_qkv_tab(const float* sq, const float* sk, const float* sv, int S, const void* svh_q, const void* svh_k, const void* svh_v,
+                                 void* q_out, void* k_out, void* v_out, const float* inv_freq, const int32_t* positions,
+                                 void* k_cache, void* k_scales, void* v_cache, void* v_scales, const int32_t* block_table, int blocks_per_seq,
+                                 int page_size, int k_bits, int v_bits, int m, int heads_q, int heads_kv, int head_dim, int rope_mode,
+                                 float attn_factor, const float* ss_prev, const float* ss_new, int hidden, float eps,
+                                 const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream);
+
 static int attn_decode_impl(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
                             const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
                             int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
-                            float* workspace, int64_t workspace_floats, void* stream, int* nsplit_out);
+                            float* workspace, int64_t workspace_floats, void* stream, int* nsplit_out, const QkvFuse* fuse = nullptr);
 
 extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
                                        const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
@@ -469,12 +608,46 @@ extern "C" int exl3_attn_decode_qcache_split(const void* q, const void* k_cache,
                             head_dim, max_len, scale, workspace, workspace_floats, stream, nsplit_out);
 }
 
+// exl3_glue_qkv_tab + exl3_attn_decode_qcache_split as ONE launch where the matrix-pipe split kernel applies (head_dim 128, 4-bit K and V, a length
+// bound of two or more 64-token splits): every workgroup finishes the query heads it needs from the q|k|v launch's deferred slabs, the workgroup whose
+// split holds the new token appends that token's K / V (libtorch/attention.cpp:386-440 as one node).  Same values as the two launches, bit for bit
+// (shared device functions).  q_out [bsz][heads_q][128] is required: scratch of the two-launch fallback, and written by split 0 of the fused form.
+// *fused_out (optional) reports which form ran.  cache_seqlens INCLUDE the new token; slots[b] = its physical cache row (exl3_qkv_prep).
+extern "C" int exl3_attn_decode_qcache_split_qkv(const float* sq, const float* sk, const float* sv, int S, const void* svh_q, const void* svh_k, const void* svh_v,
+                                                 void* q_out, const float* inv_freq, const int32_t* positions, float attn_factor, int rope_mode,
+                                                 const float* ss_prev, const float* ss_new, int hidden, float eps,
+                                                 const float* rope_sin, const float* rope_cos, const int64_t* slots,
+                                                 void* k_cache, void* k_scales, void* v_cache, void* v_scales,
+                                                 const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
+                                                 int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
+                                                 float* workspace, int64_t workspace_floats, int* nsplit_out, int* fused_out, void* stream)
+{
+    EXL3_CHECK_ARG(nsplit_out && workspace && head_dim == 128, "attn_decode_split_qkv: needs the workspace, nsplit_out and head_dim 128");
+    EXL3_CHECK_ARG(sq && sk && sv && svh_q && svh_k && svh_v && q_out && inv_freq && positions, "attn_decode_split_qkv: null pointer");
+    EXL3_CHECK_ARG(rope_sin && rope_cos && slots, "attn_decode_split_qkv: needs the per-step tables of exl3_qkv_prep");
+    EXL3_CHECK_ARG(rope_mode == 1 || rope_mode == 2, "attn_decode_split_qkv: rope_mode must be 1 (GPTJ) or 2 (NEOX)");
+    EXL3_CHECK_ARG(bsz >= 1 && bsz <= 16 && S >= 1, "attn_decode_split_qkv: 1 <= bsz <= 16");
+    EXL3_CHECK_ARG(!ss_new || (ss_prev && hidden > 0 && hidden % 128 == 0), "attn_decode_split_qkv: rescale needs ss_prev and hidden");
+    QkvFuse f;
+    f.x.sq = { sq, S }; f.x.sk = { sk, S }; f.x.sv = { sv, S };
+    f.x.svh_q = (const half_t*) svh_q; f.x.svh_k = (const half_t*) svh_k; f.x.svh_v = (const half_t*) svh_v;
+    f.x.rope_sin = rope_sin; f.x.rope_cos = rope_cos; f.x.slots = slots;
+    f.x.rs = GemvRescale{ ss_prev, ss_new, hidden, eps };
+    f.x.q_out = (half_t*) q_out;
+    f.x.k_cache_w = (uint32_t*) k_cache; f.x.k_scales_w = (half_t*) k_scales; f.x.v_cache_w = (uint32_t*) v_cache; f.x.v_scales_w = (half_t*) v_scales;
+    f.x.rope_mode = rope_mode; f.x.m = bsz;
+    f.S = S; f.inv_freq = inv_freq; f.positions = positions; f.attn_factor = attn_factor; f.hidden = hidden; f.fused_out = fused_out;
+    return attn_decode_impl(q_out, nullptr, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, bsz, blocks_per_seq, page_size, k_bits, v_bits, heads_q, heads_kv,
+                            head_dim, max_len, scale, workspace, workspace_floats, stream, nsplit_out, &f);
+}
+
 static int attn_decode_impl(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
                             const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
                             int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
-                            float* workspace, int64_t workspace_floats, void* stream, int* nsplit_out)
+                            float* workspace, int64_t workspace_floats, void* stream, int* nsplit_out, const QkvFuse* fuse)
 {
     const bool split_only = nsplit_out != nullptr;
+    const AttnQkvArgs* xq = nullptr;
     EXL3_CHECK_ARG(q && (out || split_only) && k_cache && k_scales && v_cache && v_scales && block_table && cache_seqlens, "attn_decode: null pointer");
     EXL3_CHECK_ARG(head_dim == 128 || head_dim == 64, "attn_decode: head_dim must be 128 or 64");
     EXL3_CHECK_ARG((heads_kv * head_dim) % 128 == 0, "attn_decode: heads_kv * head_dim must be a multiple of 128 (whole Hadamard blocks)");
@@ -516,17 +689,18 @@ static int attn_decode_impl(const void* q, void* out, const void* k_cache, const
         if (ns >= 2 && workspace_floats >= (int64_t) bsz * blocks * gq * ns * 132)
         {
             a.nsplit = ns; a.split_tokens = st_tok;
+            if (fuse) { xq = &fuse->x; if (fuse->fused_out) *fuse->fused_out = 1; }
             dim3 gridw(ns, blocks, bsz);
             switch (gq)
             {
-                case 1: attn_decode_wide_kernel<1><<<gridw, 256, 0, st>>>(a); break;
-                case 2: attn_decode_wide_kernel<2><<<gridw, 256, 0, st>>>(a); break;
-                case 3: attn_decode_wide_kernel<3><<<gridw, 256, 0, st>>>(a); break;
-                case 4: attn_decode_wide_kernel<4><<<gridw, 256, 0, st>>>(a); break;
-                case 5: attn_decode_wide_kernel<5><<<gridw, 256, 0, st>>>(a); break;
-                case 6: attn_decode_wide_kernel<6><<<gridw, 256, 0, st>>>(a); break;
-                case 7: attn_decode_wide_kernel<7><<<gridw, 256, 0, st>>>(a); break;
-                default: attn_decode_wide_kernel<8><<<gridw, 256, 0, st>>>(a); break;
+                case 1: if (xq) attn_decode_wide_kernel<1, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<1, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                case 2: if (xq) attn_decode_wide_kernel<2, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<2, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                case 3: if (xq) attn_decode_wide_kernel<3, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<3, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                case 4: if (xq) attn_decode_wide_kernel<4, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<4, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                case 5: if (xq) attn_decode_wide_kernel<5, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<5, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                case 6: if (xq) attn_decode_wide_kernel<6, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<6, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                case 7: if (xq) attn_decode_wide_kernel<7, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<7, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                default: if (xq) attn_decode_wide_kernel<8, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<8, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
             }
             int rcw = exl3_check_launch("attn_decode_wide");
             if (rcw) return rcw;
@@ -536,6 +710,17 @@ static int attn_decode_impl(const void* q, void* out, const void* k_cache, const
             attn_merge_kernel<128><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, ns, gq, blocks, heads_q, mg, mbg, mb);
             return exl3_check_launch("attn_merge");
         }
+    }
+    if (fuse)
+    {
+        // the fused form does not apply (short length bound, other cache widths, too many sequences for the split budget): the q|k|v epilogue as its
+        // own launch, then the kernels below on its q
+        const AttnQkvArgs& x = fuse->x;
+        if (fuse->fused_out) *fuse->fused_out = 0;
+        int rcg = exl3_glue_qkv_tab(x.sq.base, x.sk.base, x.sv.base, fuse->S, x.svh_q, x.svh_k, x.svh_v, x.q_out, nullptr, nullptr, fuse->inv_freq, fuse->positions,
+                                    x.k_cache_w, x.k_scales_w, x.v_cache_w, x.v_scales_w, block_table, blocks_per_seq, page_size, k_bits, v_bits, bsz, heads_q, heads_kv,
+                                    head_dim, x.rope_mode, fuse->attn_factor, x.rs.ss_prev, x.rs.ss_new, fuse->hidden, x.rs.eps, x.rope_sin, x.rope_cos, x.slots, stream);
+        if (rcg) return rcg;
     }
     dim3 grid(nsplit, blocks, bsz);
     const int kvb = (k_bits == v_bits && (k_bits == 4 || k_bits == 8)) ? k_bits : 0;

@@ -400,45 +400,17 @@ void glue_qkv_kernel(const QkvArgs a)
         }
         __syncthreads();
     }
-    float h0, h1, h2, h3;
-    out_had(ysum, l, h0, h1, h2, h3);
-    if (rs.ss_new) { const float rsc = gemv_rescale(rs, row, l, rs_p, rs_n); h0 *= rsc; h1 *= rsc; h2 *= rsc; h3 *= rsc; }
-    half4_t y = half4_t{ f2h(h0), f2h(h1), f2h(h2), f2h(h3) } * sc;       // fp16 output semantics of exl3_gemm
-    if (kind != 2)
+    if constexpr (!TAB)
     {
-        // RoPE on the fp16 head vector; lane l holds dims 4l..4l+3
-        float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
-        if (rope_mode == 2)
-        {
-            // NEOX: pairs (d, d + hd/2) inside a head: partner lane l ^ (hd/8), frequency index d mod hd/2
-            float p0, p1, p2, p3;
-            if (ph == 16) { p0 = xor_lane(v0, 16); p1 = xor_lane(v1, 16); p2 = xor_lane(v2, 16); p3 = xor_lane(v3, 16); }
-            else          { p0 = xor_lane(v0, 8);  p1 = xor_lane(v1, 8);  p2 = xor_lane(v2, 8);  p3 = xor_lane(v3, 8); }
-            if constexpr (!TAB)
-            {
-                const int f = 4 * (l & (ph - 1));
-                sn4 = *((const float4_t*) (sn_s + row * 64 + f)); cs4 = *((const float4_t*) (cs_s + row * 64 + f));
-            }
-            const bool upper = (l & ph) != 0;
-            // lower half: r1 = v1*cos - v2*sin ; upper half: r2 = v2*cos + v1*sin   (v1 = lower element, v2 = upper element)
-            float r0 = upper ? v0 * cs4.x + p0 * sn4.x : v0 * cs4.x - p0 * sn4.x;
-            float r1 = upper ? v1 * cs4.y + p1 * sn4.y : v1 * cs4.y - p1 * sn4.y;
-            float r2 = upper ? v2 * cs4.z + p2 * sn4.z : v2 * cs4.z - p2 * sn4.z;
-            float r3 = upper ? v3 * cs4.w + p3 * sn4.w : v3 * cs4.w - p3 * sn4.w;
-            y = half4_t{ f2h(r0), f2h(r1), f2h(r2), f2h(r3) };
-        }
+        if (rope_mode == 2) { const int f = 4 * (l & (ph - 1)); sn4 = *((const float4_t*) (sn_s + row * 64 + f)); cs4 = *((const float4_t*) (cs_s + row * 64 + f)); }
         else
         {
-            // GPTJ: pairs (2i, 2i+1) both in this lane: frequencies 2l', 2l'+1 with l' the lane inside the head
-            if constexpr (!TAB)
-            {
-                const int lf = 2 * (l & ((a_hd >> 2) - 1));
-                sn4.x = sn_s[row * 64 + lf]; sn4.y = sn_s[row * 64 + lf + 1]; cs4.x = cs_s[row * 64 + lf]; cs4.y = cs_s[row * 64 + lf + 1];
-            }
-            y = half4_t{ f2h(v0 * cs4.x - v1 * sn4.x), f2h(v1 * cs4.x + v0 * sn4.x),
-                         f2h(v2 * cs4.y - v3 * sn4.y), f2h(v3 * cs4.y + v2 * sn4.y) };
+            const int lf = 2 * (l & ((a_hd >> 2) - 1));
+            sn4.x = sn_s[row * 64 + lf]; sn4.y = sn_s[row * 64 + lf + 1]; cs4.x = cs_s[row * 64 + lf]; cs4.y = cs_s[row * 64 + lf + 1];
         }
     }
+    // reduce -> out-Hadamard -> row-scale correction -> fp16 x svh -> RoPE on q and k (lane l holds dims 4l..4l+3): exl3_glue_device.cuh
+    const half4_t y = qkv_block_finish(ysum, sc, rs, row, l, rs_p, rs_n, kind != 2, rope_mode, ph, sn4, cs4);
     if (kind == 0 && act) ((half4_t*) (q_out + ((size_t) row * a_hq + hi) * 128))[l] = y;
     half_t* dense = kind == 1 ? k_out : (kind == 2 ? v_out : nullptr);
     if (dense && act && kind != 0) ((half4_t*) (dense + ((size_t) row * a_hkv + hi) * 128))[l] = y;

@@ -81,6 +81,45 @@ __device__ __forceinline__ void out_had(float4_t v, int l, float& h0, float& h1,
     h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
 }
 
+// One 128-wide block of the q|k|v launch's output, finished: out-Hadamard of the split-k sum -> row-scale correction (r_new / r_prev, launches that
+// normalised with the previous residual's 1/rms) -> fp16 -> x svh in fp16 (the output semantics of exl3_gemm) -> RoPE on the fp16 values (q and k;
+// sn4 / cs4 = the lane's sin / cos: NEOX frequencies 4 (l mod ph) .. + 3, GPTJ 2 (l mod hd/4), + 1 in .x / .y).  ph = head_dim / 8 = the NEOX partner
+// distance in lanes (16 at head_dim 128, 8 at 64).  Shared by glue_qkv_kernel and the attention kernel that does this work itself
+// (exl3_attn_decode.hip, fused form): one arithmetic, bit-identical results.
+__device__ __forceinline__ half4_t qkv_block_finish(float4_t ysum, half4_t sc, const GemvRescale& rs, int row, int l, float rs_p, float rs_n,
+                                                    bool rope, int rope_mode, int ph, float4_t sn4, float4_t cs4)
+{
+    float h0, h1, h2, h3;
+    out_had(ysum, l, h0, h1, h2, h3);
+    if (rs.ss_new) { const float rsc = gemv_rescale(rs, row, l, rs_p, rs_n); h0 *= rsc; h1 *= rsc; h2 *= rsc; h3 *= rsc; }
+    half4_t y = half4_t{ f2h(h0), f2h(h1), f2h(h2), f2h(h3) } * sc;
+    if (rope)
+    {
+        float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
+        if (rope_mode == 2)
+        {
+            // NEOX: pairs (d, d + hd/2) inside a head: partner lane l ^ (hd/8), frequency index d mod hd/2
+            float p0, p1, p2, p3;
+            if (ph == 16) { p0 = xor_lane(v0, 16); p1 = xor_lane(v1, 16); p2 = xor_lane(v2, 16); p3 = xor_lane(v3, 16); }
+            else          { p0 = xor_lane(v0, 8);  p1 = xor_lane(v1, 8);  p2 = xor_lane(v2, 8);  p3 = xor_lane(v3, 8); }
+            const bool upper = (l & ph) != 0;
+            // lower half: r1 = v1*cos - v2*sin ; upper half: r2 = v2*cos + v1*sin   (v1 = lower element, v2 = upper element)
+            float r0 = upper ? v0 * cs4.x + p0 * sn4.x : v0 * cs4.x - p0 * sn4.x;
+            float r1 = upper ? v1 * cs4.y + p1 * sn4.y : v1 * cs4.y - p1 * sn4.y;
+            float r2 = upper ? v2 * cs4.z + p2 * sn4.z : v2 * cs4.z - p2 * sn4.z;
+            float r3 = upper ? v3 * cs4.w + p3 * sn4.w : v3 * cs4.w - p3 * sn4.w;
+            y = half4_t{ f2h(r0), f2h(r1), f2h(r2), f2h(r3) };
+        }
+        else
+        {
+            // GPTJ: pairs (2i, 2i+1) both in this lane: frequencies 2l', 2l'+1 with l' the lane inside the head
+            y = half4_t{ f2h(v0 * cs4.x - v1 * sn4.x), f2h(v1 * cs4.x + v0 * sn4.x),
+                         f2h(v2 * cs4.y - v3 * sn4.y), f2h(v3 * cs4.y + v2 * sn4.y) };
+        }
+    }
+    return y;
+}
+
 // input Hadamard of the next linear: xh = fp16(had(fp16 x * suh) / sqrt(128)); returns the block sum of the fp16 outputs.
 // The suh values are passed in registers so callers can issue that load at kernel entry (every dependent global load on the
 // path of these latency-bound kernels costs ~1 us).

@@ -560,8 +560,9 @@ class BC_Attention:
     """libtorch/attention.h:24-228, attention.cpp:246-504: the decode attention block of one layer as one runner -- q / k / v projections,
     head norms + RoPE, append to the quantized paged cache, flash-decoding attention straight from the quantized cache, o_proj.
     Same constructor arguments and run() signature as the reference's class.  This build covers the Llama / Mixtral subset of it:
-    quantized cache (`quant_cache`), q_len 1 .. 16 new tokens per sequence, bsz <= 8, no output gate, no V norm, no K-as-V, no sinks, no
-    padded hidden dim, no llama-4 position scaling; anything else raises at construction, it never degrades silently.
+    quantized cache (`quant_cache`), q_len 1 .. 16 new tokens per sequence, bsz <= 8; V norm, K-as-V and the rope options (llama-4 query scale,
+    norm after the rotation, `rotate_dims`) are composed from the ops of this module as the reference composes them (attention.cpp:335-395); no
+    output gate, no sinks, no padded hidden dim: those raise at construction, nothing degrades silently.
     The reference's slot machinery exists to hold AOT-compiled Triton kernels and their statics: needs_configure() is always False here and
     configure_slot() accepts and ignores its arguments; capture the whole decode step in one hipGraph instead (all launches of run() are
     capturable, the per-call tensors are read by pointer)."""
@@ -578,19 +579,23 @@ class BC_Attention:
                  quant_cache=True, cache_k=None, cache_v=None, cache_k_scales=None, cache_v_scales=None, xh=None, h32=None, sinks=None):
         _req(quant_cache and cache_k_scales is not None and cache_v_scales is not None, "BC_Attention: this build attends over the quantized paged cache only")
         _req(gate_mode == 0 and g_proj is None and g_weight is None and qg_ptrs_trellis is None, "BC_Attention: output gates are outside this build")
-        _req(not use_k_as_v and not v_norm and sinks is None, "BC_Attention: K-as-V / V norm / attention sinks are outside this build")
+        _req(sinks is None, "BC_Attention: attention sinks are outside this build")
         _req(hidden_size_padded == hidden_size, "BC_Attention: padded hidden dim is outside this build")
-        _req(l4_scaling_beta == 0.0 and not post_rope_norm and rotate_dims == 1, "BC_Attention: llama-4 scaling / post-rope norm / multi-dim rotation are outside this build")
+        _req(not use_k_as_v or k_proj is not None, "BC_Attention: K-as-V needs the separate k projection")
         _req(head_dim in (64, 128) and num_q_heads % num_kv_heads == 0, "BC_Attention: head_dim must be 64 or 128")
         _req(page_size == 256, "BC_Attention: page size must be 256")
-        _req(q_proj is not None and o_proj is not None and ((k_proj is not None and v_proj is not None) or kv_ptrs_trellis is not None),
+        _req(q_proj is not None and o_proj is not None and (use_k_as_v or (k_proj is not None and v_proj is not None) or kv_ptrs_trellis is not None),
              "BC_Attention: no k/v projection path")
+        _req(not v_norm or v_norm_w is None or v_norm_w.numel() == head_dim, "BC_Attention: v_norm weight must have head_dim entries")
         _req(inv_freq is not None or (q_norm is None and k_norm is None), "BC_Attention: head norms ride on the rope kernel (NoPE modules cannot have them)")
         self.num_q_heads, self.num_kv_heads, self.head_dim, self.hidden_size, self.page_size = num_q_heads, num_kv_heads, head_dim, hidden_size, page_size
         self.q_proj, self.k_proj, self.v_proj, self.o_proj = q_proj, k_proj, v_proj, o_proj
         self.kv_ptrs = (kv_ptrs_trellis, kv_ptrs_suh, kv_ptrs_svh, int(kv_K), bool(kv_mcg), bool(kv_mul1)) if kv_ptrs_trellis is not None else None
         self.q_norm, self.k_norm, self.norm_eps, self.norm_constant_bias = q_norm, k_norm, norm_eps, norm_constant_bias
         self.inv_freq, self.rope_style, self.attn_factor = inv_freq, int(rope_style), float(attn_factor)
+        self.l4_beta, self.l4_orig, self.post_rope_norm, self.rotate_dims = float(l4_scaling_beta), int(l4_scaling_original), bool(post_rope_norm), int(rotate_dims)
+        self.use_k_as_v, self.v_norm, self.v_norm_w = bool(use_k_as_v), bool(v_norm), v_norm_w
+        self.v_norm_eps, self.v_norm_bias, self.v_norm_scale = float(v_norm_eps), float(v_norm_constant_bias), float(v_norm_constant_scale)
         self.cache_k, self.cache_v, self.cache_k_scales, self.cache_v_scales = cache_k, cache_v, cache_k_scales, cache_v_scales
         self.xh = xh
         self._st = {}
@@ -641,17 +646,28 @@ class BC_Attention:
         x2 = x.view(rows, self.hidden_size)
         q2, kv = st["q"].view(rows, hq * hd), st["kv"]
         self.q_proj.run(x2, q2)
-        if self.kv_ptrs is not None and rows <= 16:                       # the pointer-table launch takes at most 16 rows per slot
+        if self.use_k_as_v:
+            # attention.cpp:335-360: V shares the K projection's output, taken before the head norm / RoPE touch K (per-head RMSNorm of it, or a copy)
+            self.k_proj.run(x2, kv[0])
+            if self.v_norm:
+                rms_norm(kv[0].view(rows * hkv, hd), self.v_norm_w, kv[1].view(rows * hkv, hd), self.v_norm_eps, self.v_norm_bias, self.v_norm_scale)
+            else:
+                kv[1].copy_(kv[0])
+        elif self.kv_ptrs is not None and rows <= 16:                     # the pointer-table launch takes at most 16 rows per slot
             pt, ps, pv, K, mcg, mul1 = self.kv_ptrs
             exl3_mgemm(x2.view(1, rows, -1), pt, kv, ps, st["xh"], pv, None, None, K, -1, mcg, mul1, -1, -1, 0)
         else:
             _req(self.k_proj is not None and self.v_proj is not None, "BC_Attention: more than 16 rows need the separate k / v projections")
             self.k_proj.run(x2, kv[0]); self.v_proj.run(x2, kv[1])
+        if self.v_norm and not self.use_k_as_v:                           # attention.cpp:379-384: per-head norm of V, in place
+            v2h = kv[1].view(rows * hkv, hd)
+            rms_norm(v2h, self.v_norm_w, v2h, self.v_norm_eps, self.v_norm_bias, self.v_norm_scale)
         k4, v4 = kv[0].view(bsz, q_len, hkv, hd), kv[1].view(bsz, q_len, hkv, hd)
         if self.inv_freq is not None:
             ivf = inv_freq_override if inv_freq_override is not None else self.inv_freq
             rope(st["q"], st["q"], k4, k4, ivf, int(position), positions, position_ids, self.rope_style, self.attn_factor,
-                 self.q_norm, self.k_norm, self.norm_eps, self.norm_constant_bias)
+                 self.q_norm, self.k_norm, self.norm_eps, self.norm_constant_bias, self.l4_beta, max(self.l4_orig, 1), self.post_rope_norm,
+                 self.rotate_dims, 0)
         quant_cache_paged(k4.view(bsz, q_len, -1), self.cache_k, self.cache_k_scales, v4.view(bsz, q_len, -1), self.cache_v, self.cache_v_scales,
                           cache_seqlens, block_table, self.page_size, q_len)
         if q_len == 1:
@@ -1424,6 +1440,30 @@ def attn_decode_qcache_split(q, k_cache, k_scales, v_cache, v_scales, block_tabl
                                                     bsz, block_table.shape[1], k_cache.shape[1], kb, vb, hq, hkv, hd, int(max_len),
                                                     float(scale if scale is not None else hd ** -0.5), _p(workspace), workspace.numel(), ctypes.byref(ns), _stream(q)))
     return ns.value
+
+
+def attn_decode_qcache_split_qkv(slabs, S: int, svh_q, svh_k, svh_v, q_out, inv_freq, positions, k_cache, k_scales, v_cache, v_scales, block_table,
+                                 cache_seqlens, max_len: int, workspace: torch.Tensor, tab, ss_prev, ss_new, hidden: int, eps: float,
+                                 rope_mode: int = 2, attn_factor: float = 1.0, scale: float | None = None):
+    """glue_qkv_rs(tab=...) + attn_decode_qcache_split as one launch (libtorch/attention.cpp:386-440 as one node): the context-split kernel finishes
+    its own query heads from the q|k|v launch's slabs and the split that holds the new token appends its K / V.  cache_seqlens include the new token.
+    Returns (splits, fused): `fused` False = the two-launch form ran (shapes the matrix-pipe split kernel does not take); same results either way."""
+    _dev(q_out)
+    _req(q_out.dtype == torch.half and q_out.dim() == 3 and q_out.shape[-1] == 128 and q_out.is_contiguous(), "attn_decode_split_qkv: q_out must be contiguous (bsz, heads, 128) float16")
+    _req(block_table.dtype == torch.int32 and cache_seqlens.dtype == torch.int32, "attn_decode: block_table / cache_seqlens must be int32")
+    _req(workspace is not None and workspace.dtype == torch.float and workspace.is_contiguous(), "attn_decode_split_qkv: float32 workspace required")
+    _req(tab is not None and len(tab) == 3, "attn_decode_split_qkv: needs the (sin, cos, slots) tables of qkv_prep")
+    bsz, hq, hd = q_out.shape
+    hkv = k_scales.shape[-1] * 32 // hd
+    kb, vb = _kv_bits(k_cache, k_scales), _kv_bits(v_cache, v_scales)
+    ns, fused = ctypes.c_int(0), ctypes.c_int(0)
+    _check(_lib.lib().exl3_attn_decode_qcache_split_qkv(slabs[0], slabs[1], slabs[2], S, _p(svh_q), _p(svh_k), _p(svh_v), _p(q_out), _p(inv_freq), _p(positions),
+                                                        float(attn_factor), int(rope_mode), _p(ss_prev), _p(ss_new), int(hidden), float(eps), _p(tab[0]), _p(tab[1]),
+                                                        _p(tab[2]), _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table), _p(cache_seqlens), bsz,
+                                                        block_table.shape[1], k_cache.shape[1], kb, vb, hq, hkv, hd, int(max_len),
+                                                        float(scale if scale is not None else hd ** -0.5), _p(workspace), workspace.numel(), ctypes.byref(ns),
+                                                        ctypes.byref(fused), _stream(q_out)))
+    return ns.value, bool(fused.value)
 
 
 def exl3_gemv_ex_attm(part: torch.Tensor, nsplit: int, heads_q: int, heads_kv: int, B, C, suh, svh, m: int, mcg: bool, mul1: bool, flags: int = 0,

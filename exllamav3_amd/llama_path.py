@@ -401,6 +401,9 @@ class SyntheticEXL3Llama:
     #: fx pipeline, head_dim 128: the flash-decoding merge of the attention's context splits runs inside o_proj's launch (ext.exl3_gemv_ex_attm) instead of
     #: as its own launch -- same bits, one launch less per layer
     attn_merge_in_oproj = os.environ.get("EXL3_HIP_ATTN_MERGE_IN_OPROJ", "1") != "0"
+    #: ... and the q|k|v epilogue (split-k reduce, output Hadamard, RoPE, 4-bit append of the new token) runs inside the attention's context-split launch
+    #: (ext.attn_decode_qcache_split_qkv) instead of glue_qkv_rs: 6 launches per layer with attention, same bits
+    attn_qkv_in_split = os.environ.get("EXL3_HIP_ATTN_QKV_IN_SPLIT", "1") != "0"
 
     #: lm_head at m <= 4: glue_rotate + pre-rotated GEMV instead of the in-GEMV RMSNorm (the 1002-column-block launch repeats the 32 input
     #: Hadamards in every workgroup in NORM mode)
@@ -693,12 +696,21 @@ class SyntheticEXL3Llama:
             vc, vs = self.vcache[li]
             slabs, S = ext.exl3_gemv_ex_fx(R, L["norm1"], sc, so_, self.eps, [lq.trellis, lk.trellis, lv.trellis], [lq.suh, lk.suh, lv.suh],
                                            bsz, lq.mcg, lq.mul1, sp["qkv"])
-            ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
-                            self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, so_, hidden, self.eps, tab=tab)
+            attm = None                                                    # (partial records, splits): the merge runs inside o_proj's launch
+            fuse_qkv = (self.with_attention and hd == 128 and self.attn_merge_in_oproj and not self.fx_gu_atomic and self.attn_qkv_in_split
+                        and tab is not None and self.kv_bits == 4)
+            if fuse_qkv:
+                # q|k|v epilogue (reduce, Hadamard, rope, cache append) inside the attention's context-split launch: 6 launches per layer with attention
+                ns_, _ = ext.attn_decode_qcache_split_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q.view(bsz, self.hq, hd), self.inv_freq, self.positions,
+                                                          kc, ks, vc, vs, self.block_table, self.attn_lens, self.attn_pos + 1, self.attn_ws, tab,
+                                                          sc, so_, hidden, self.eps)
+                attm = (self.attn_ws, ns_)
+            else:
+                ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                                self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, so_, hidden, self.eps, tab=tab)
             sc, so_ = so_, sc
             o_in = q2
-            attm = None                                                    # (partial records, splits): the merge runs inside o_proj's launch
-            if self.with_attention and hd in (64, 128):
+            if self.with_attention and hd in (64, 128) and not fuse_qkv:
                 if hd == 128 and self.attn_merge_in_oproj and not self.fx_gu_atomic:
                     attm = (self.attn_ws, ext.attn_decode_qcache_split(self.q.view(bsz, self.hq, hd), kc, ks, vc, vs, self.block_table, self.attn_lens,
                                                                        self.attn_pos + 1, self.attn_ws))

@@ -350,6 +350,22 @@ int exl3_attn_decode_qcache_split(const void* q, const void* k_cache, const void
                                   const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
                                   int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
                                   float* workspace, int64_t workspace_floats, int* nsplit_out, void* stream);
+
+/* exl3_glue_qkv_tab + exl3_attn_decode_qcache_split as ONE launch (round 4; libtorch/attention.cpp:386-440 -- rope, cache append, split kernel -- as one node):
+ * every workgroup of the context-split kernel finishes the query heads it needs from the q|k|v launch's deferred slabs (sq / sk / sv, S slices; svh_*;
+ * row-scale correction ss_prev / ss_new / hidden / eps as in exl3_glue_qkv_rs; RoPE from exl3_qkv_prep's tables), and the workgroup whose split holds the new
+ * token (index cache_seqlens[b] - 1, physical row slots[b]) appends that token's K / V to the 4-bit cache.  Applies where the matrix-pipe split kernel applies
+ * (head_dim 128, 4-bit K and V, length bound >= two 64-token splits); otherwise the two launches run (same results: shared device functions).
+ * q_out [bsz][heads_q][128] fp16 is required (scratch of the two-launch form; the fused form's split 0 writes the finished queries there).
+ * *fused_out (optional): 1 = one launch, 0 = two.  *nsplit_out: splits of the partial records in `workspace` (consumer: exl3_gemv_ex_attm). */
+int exl3_attn_decode_qcache_split_qkv(const float* sq, const float* sk, const float* sv, int S, const void* svh_q, const void* svh_k, const void* svh_v,
+                                      void* q_out, const float* inv_freq, const int32_t* positions, float attn_factor, int rope_mode,
+                                      const float* ss_prev, const float* ss_new, int hidden, float eps,
+                                      const float* rope_sin, const float* rope_cos, const int64_t* slots,
+                                      void* k_cache, void* k_scales, void* v_cache, void* v_scales,
+                                      const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
+                                      int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
+                                      float* workspace, int64_t workspace_floats, int* nsplit_out, int* fused_out, void* stream);
 int exl3_gemv_ex_attm(const float* part, int nsplit, int gq, int blocks, const void* B, void* C, const void* suh, const void* svh, const void* bias,
                       int m, int k, int n, int K, int cb, int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream);
 /* Prefill (multi-token) causal attention over paged fp16 K/V -- the attention step of the reference's prefill path: cache/quant.py:83-117

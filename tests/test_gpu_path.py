@@ -424,6 +424,66 @@ def test_bc_attention_runner_matches_oracle(dev, hd, hq, hkv, fused_kv, head_nor
         ext.BC_Attention(**{**kw, "quant_cache": False})
 
 
+@pytest.mark.parametrize("opt", ["v_norm", "k_as_v", "k_as_v_norm", "l4_post_norm"])
+def test_bc_attention_runner_options(dev, opt):
+    """The runner's options that compose from this build's ops (attention.cpp:335-395): per-head V norm, V = the K projection's output before head
+    norm / RoPE (copied or normed), and the rope options (llama-4 query scale + unweighted norm after the rotation) -- each against the oracle
+    composition, over short contexts (a one-token context would hand single 4-bit level flips of the new token's V straight to the output)."""
+    from exllamav3_amd import ext
+    hidden, K, cb, bits, page, bsz, pps, hd, hq, hkv = 512, 4, 2, 4, 256, 2, 1, 128, 4, 2
+    rng = np.random.default_rng(len(opt))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mats = {n: o.synth_linear(k, nn, K, seed=90 + i, realistic=True) for i, (n, k, nn) in enumerate(
+        (("q", hidden, hq * hd), ("k", hidden, hkv * hd), ("v", hidden, hkv * hd), ("o", hq * hd, hidden)))}
+    dm = {n: tuple(T(a) for a in t) for n, t in mats.items()}
+    bc = {n: ext.BC_LinearEXL3(t[0], t[1], t[2], K, None, False, True, None) for n, t in dm.items()}
+    G = hkv * hd // 32
+    lens = np.array([40, 23], np.int32)
+    bt_np = np.array([[1], [0]], np.int32)
+    ck = rng.standard_normal((bsz, page, hkv * hd)).astype(np.float16); cv = rng.standard_normal((bsz, page, hkv * hd)).astype(np.float16)
+    kq = np.zeros((bsz, page, G * bits), np.uint32); ks = np.zeros((bsz, page, G), np.float16); vq = kq.copy(); vs = ks.copy()
+    for b in range(bsz):
+        pk, sc = o.kv_quant(ck[b], bits); pv, sv = o.kv_quant(cv[b], bits)
+        kq[bt_np[b, 0]] = pk; ks[bt_np[b, 0]] = sc; vq[bt_np[b, 0]] = pv; vs[bt_np[b, 0]] = sv
+    inv_freq = (1.0 / (10000.0 ** (np.arange(0, hd, 2, dtype=np.float32) / hd))).astype(np.float32)
+    vw = (1 + 0.1 * rng.standard_normal(hd)).astype(np.float16)
+    kw = dict(num_q_heads=hq, num_kv_heads=hkv, head_dim=hd, hidden_size=hidden, hidden_size_padded=hidden, page_size=page,
+              q_proj=bc["q"], k_proj=bc["k"], v_proj=bc["v"], o_proj=bc["o"], norm_eps=1e-6, inv_freq=T(inv_freq), rope_style=2, attn_factor=1.0,
+              quant_cache=True, cache_k=T(kq.view(np.int32)), cache_v=T(vq.view(np.int32)), cache_k_scales=T(ks), cache_v_scales=T(vs), xh=None, h32=None)
+    rope_kw = {}
+    if opt == "v_norm":
+        kw.update(v_norm=True, v_norm_w=T(vw), v_norm_eps=1e-5, v_norm_constant_bias=0.0, v_norm_constant_scale=1.0)
+    elif opt == "k_as_v":
+        kw.update(use_k_as_v=True, v_proj=None)
+    elif opt == "k_as_v_norm":
+        kw.update(use_k_as_v=True, v_proj=None, v_norm=True, v_norm_w=None, v_norm_eps=1e-5)
+    else:
+        kw.update(l4_scaling_beta=0.3, l4_scaling_original=16, post_rope_norm=True)
+        rope_kw = dict(l4_beta=0.3, l4_orig=16, post_rope_norm=True)
+    attn = ext.BC_Attention(**kw)
+    x = rng.standard_normal((bsz, 1, hidden)).astype(np.float16)
+    positions = np.array([40, 30], np.int32)
+    y = torch.full((bsz, 1, hidden), float("nan"), dtype=torch.half, device=dev)
+    attn.run(bsz, 1, T(x), y, T(lens), T(bt_np), 0, T(positions), None, None)
+    lin = lambda n, a: o.linear_forward(a, mats[n][0], mats[n][1], mats[n][2], K, cb)
+    x2 = x.reshape(bsz, hidden)
+    q, k = lin("q", x2), lin("k", x2)
+    v = k.copy() if opt.startswith("k_as_v") else lin("v", x2)
+    if opt in ("v_norm", "k_as_v_norm"):
+        v = o.rms_norm(v.reshape(bsz * hkv, hd), vw if opt == "v_norm" else None, 1e-5).reshape(bsz, hkv * hd)
+    q4, k4 = o.rope(q.reshape(bsz, 1, hq, hd), k.reshape(bsz, 1, hkv, hd), inv_freq, positions=positions, rope_mode=o.ROPE_NEOX, norm_eps=1e-6, **rope_kw)
+    kd = np.zeros((bsz, page, hkv, hd), np.float16); vd = np.zeros_like(kd)
+    for b in range(bsz):
+        full_k = np.concatenate([ck[b, :lens[b]], k4[b].reshape(1, -1)]); full_v = np.concatenate([cv[b, :lens[b]], v[b].reshape(1, -1)])
+        pk, sc = o.kv_quant(full_k, bits); pv, sv = o.kv_quant(full_v, bits)
+        kd[b, :lens[b] + 1] = o.kv_dequant(pk, sc, bits).reshape(-1, hkv, hd); vd[b, :lens[b] + 1] = o.kv_dequant(pv, sv, bits).reshape(-1, hkv, hd)
+    ao = o.attn_decode_qcache(q4.reshape(bsz, hq, hd), kd, vd, lens + 1)
+    ref = lin("o", ao.reshape(bsz, -1)).astype(np.float32)
+    got = y.float().cpu().numpy().reshape(bsz, hidden)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+
+
 @pytest.mark.parametrize("hd,hq,hkv,q_len,fused_kv", [(128, 4, 2, 5, False), (64, 8, 2, 16, True), (128, 8, 2, 16, False)])
 def test_bc_attention_runner_multi_token(dev, hd, hq, hkv, q_len, fused_kv):
     """BC_Attention.run with 2 <= q_len <= 16 (attention.cpp:246-504; the runner's MAX_QLEN): the chunk is appended to the 4-bit paged cache, the
@@ -814,12 +874,21 @@ def test_attention_merge_inside_oproj_is_bit_identical_to_the_merge_launch(dev, 
         kc, ksc = model.kcache[li]; vc, vsc = model.vcache[li]
         kc.copy_(T(kq.view(np.int32)).view(kc.shape)); ksc.copy_(T(ks).view(ksc.shape)); vc.copy_(T(vq.view(np.int32)).view(vc.shape)); vsc.copy_(T(vs).view(vsc.shape))
         ctx.append((kq, ks, vq, vs))
+    saved_cache = [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]
     outs = []
-    for fused in (False, True):
-        model.attn_merge_in_oproj = fused
+    # (merge inside o_proj, q|k|v epilogue inside the context-split launch): the three forms of the attention sublayer -- 4 / 3 / 2 launches around o_proj
+    for fused, qkv_in_split in ((False, False), (True, False), (True, True)):
+        model.attn_merge_in_oproj, model.attn_qkv_in_split = fused, qkv_in_split
+        for (c, s_), (c0, s0) in zip(model.kcache + model.vcache, saved_cache):
+            c.copy_(c0); s_.copy_(s0)                                     # every form appends to the same pre-filled cache
         lg = model.decode_step_fx().float().cpu().numpy().copy()
         outs.append((lg, model.x_final.clone(), [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]))
-    (l0, x0_, kv0), (l1, x1_, kv1) = outs
+    (l0, x0_, kv0), (l1, x1_, kv1), (l2, x2_, kv2) = outs
+    # the one-launch form (round 4: ext.attn_decode_qcache_split_qkv) against the two launches it replaces: logits, residual and EVERY cache word and scale
+    # of every layer, at every context length (same splits, shared device functions; below the matrix-pipe kernel's 128-token bound it falls back)
+    assert np.array_equal(l1, l2) and torch.equal(x1_, x2_)
+    assert all(torch.equal(a1, a2) and torch.equal(b1, b2) for (a1, b1), (a2, b2) in zip(kv1, kv2))
+    l1, x1_, kv1 = l2, x2_, kv2
     assert np.isfinite(l1).all()
     if pos <= 1000:
         assert np.array_equal(l0, l1) and torch.equal(x0_, x1_)
