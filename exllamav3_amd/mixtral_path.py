@@ -90,6 +90,7 @@ class SyntheticEXL3Mixtral:
         self.eps, self.page, self.max_ctx = 1e-5, 256, max_ctx
         self.with_attention = False
         self.attn_merge_in_oproj = True                                # fx step, head_dim 128: attention merge inside o_proj's launch (ext.exl3_gemv_ex_attm)
+        self.attn_qkv_in_split = True                                  # ... and the q|k|v epilogue inside the context-split launch (ext.attn_decode_qcache_split_qkv)
         self.norm_in_router = True                                     # False: separate rms_norm launch in front of every MoE block
         self.fused_moe_tail = True                                     # one rank: split-k reduce + slot sum + residual add of a MoE block in one launch
         self._state_bsz = None
@@ -144,12 +145,21 @@ class SyntheticEXL3Mixtral:
             vc, vs = self.vcache[li]
             slabs, S = ext.exl3_gemv_ex_fx(R, L["norm1"], sc, so_, self.eps, [lq.trellis, lk.trellis, lv.trellis], [lq.suh, lk.suh, lv.suh],
                                            bsz, lq.mcg, lq.mul1)
-            ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
-                            self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, so_, hidden, self.eps, tab=tab)
+            so_split = 8 if self.hq * hd == 4096 else 0
+            fuse_qkv = self.with_attention and hd == 128 and self.attn_merge_in_oproj and self.attn_qkv_in_split and tab is not None and self.kv_bits == 4
+            if fuse_qkv:
+                # q|k|v epilogue inside the attention's context-split launch, merge inside o_proj's (llama_path.decode_step_fx): 3 launches for the sublayer
+                ns, _ = ext.attn_decode_qcache_split_qkv(slabs, S, lq.svh, lk.svh, lv.svh, self.q.view(bsz, self.hq, hd), self.inv_freq, self.positions,
+                                                         kc, ks, vc, vs, self.block_table, self.attn_lens, self.attn_pos + 1, self.attn_ws, tab,
+                                                         sc, so_, hidden, self.eps)
+            else:
+                ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
+                                self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, so_, hidden, self.eps, tab=tab)
             sc, so_ = so_, sc
             o_in = q2
-            so_split = 8 if self.hq * hd == 4096 else 0
-            if self.with_attention and hd == 128 and self.attn_merge_in_oproj:
+            if fuse_qkv:
+                ext.exl3_gemv_ex_attm(self.attn_ws, ns, self.hq, self.hkv, lo.trellis, R, lo.suh, lo.svh, bsz, lo.mcg, lo.mul1, ATOM, so_split)
+            elif self.with_attention and hd == 128 and self.attn_merge_in_oproj:
                 # the flash-decoding merge of the context splits runs inside o_proj's launch (llama_path.decode_step_fx)
                 ns = ext.attn_decode_qcache_split(self.q.view(bsz, self.hq, hd), kc, ks, vc, vs, self.block_table, self.attn_lens, self.attn_pos + 1, self.attn_ws)
                 ext.exl3_gemv_ex_attm(self.attn_ws, ns, self.hq, self.hkv, lo.trellis, R, lo.suh, lo.svh, bsz, lo.mcg, lo.mul1, ATOM, so_split)
