@@ -606,6 +606,19 @@ def main():
         mm = SyntheticEXL3Mixtral(MIXTRAL_8X7B, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits)
         mm.alloc_state(1)
         extra["mixtral-8x7b_bs1"] = timed_decode(mm, mm.decode_step_fx if pipeline == "fx" else mm.decode_step, 1)
+        if not args.no_prefill:
+            # config 5's prefill leg: one chunk through the attention linears + the grouped-by-expert MoE tier (moe_path.forward_prefill); median of 3
+            toks_m = args.prefill_tokens
+            mm.prefill_chunk(toks_m); torch.cuda.synchronize()
+            cs = []
+            for _ in range(3):
+                t0 = time.perf_counter(); mm.prefill_chunk(toks_m); torch.cuda.synchronize(); cs.append(time.perf_counter() - t0)
+            dtm = sorted(cs)[1]
+            fl = mm.prefill_flops_per_token() * toks_m
+            extra["mixtral-8x7b_prefill"] = {"tok_s": round(toks_m / dtm, 1), "chunk_tokens": toks_m, "ms_per_chunk": round(dtm * 1e3, 2),
+                                             "repeat_ms_per_chunk": [round(v * 1e3, 2) for v in cs], "tflops": round(fl / dtm / 1e12, 1),
+                                             "frac_of_mfma_peak": round(fl / dtm / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                             "note": "routed flops (attention linears + top-2 of 8 experts per token) over the whole chunk time"}
         del mm
         torch.cuda.empty_cache()
 

@@ -10,6 +10,7 @@ run() { # name, bench args...
 }
 run bs1 --no-prefill --steps 20
 run bs16 --batch 16 --no-prefill --steps 20
+run bs1_attention --attention --no-prefill --steps 20
 run mixtral --model mixtral-8x7b --steps 10
 run prefill --steps 5
 run prefill_attn --attention --steps 5
@@ -32,7 +33,7 @@ if g:
     except Exception as e:
         print("kernel-only figure unavailable:", e)
     json.dump({"kernel": "exl3_gemv4_kernel<4,2,1,*> (all GEMV launches of the decode step, Llama-3.1-8B 4bpw mul1, bs=1, fx pipeline)", "fetch_bytes_per_launch": int(per),
-               "launches_sampled": len(g), "collected": "round 3 (${TAG}), tools/final_profiles.sh", "kernel_only": ko, "method": "rocprofv3 --pmc FETCH_SIZE (own pass, no tracing) on bench.py --steps 3 --warmup 1 --no-graph; FETCH_SIZE is KiB and reads 1/2 of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section): x1024 x2 applied; average over all gemv2 dispatches (includes the activation / residual-accumulator reads and scale vectors)"},
+               "launches_sampled": len(g), "collected": "${TAG}, tools/final_profiles.sh", "kernel_only": ko, "method": "rocprofv3 --pmc FETCH_SIZE (own pass, no tracing) on bench.py --steps 3 --warmup 1 --no-graph; FETCH_SIZE is KiB and reads 1/2 of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section): x1024 x2 applied; average over all gemv2 dispatches (includes the activation / residual-accumulator reads and scale vectors)"},
               open("$O/traffic.json", "w"), indent=1)
     print("traffic bytes/launch", int(per), "over", len(g))
 else:
