@@ -223,7 +223,10 @@ void exl3_gemv4_kernel(const GemvArgs a)
     // (ACT: the first 4 slab lines of gate and up and their svh travel with the task, i.e. they are requested BEFORE the wave's first weight rows -- loaded
     // inside the task they queued behind those rows)
     constexpr int NSL = MODE == G4_MODE_ACT ? 4 : 1;
-    constexpr int NMO = MODE == G4_MODE_ATTM ? 8 : 1;         // ATTM: the first 8 splits' outputs travel with the task
+#ifndef G4_ATTM_NMO
+#define G4_ATTM_NMO 8
+#endif
+    constexpr int NMO = MODE == G4_MODE_ATTM ? G4_ATTM_NMO : 1;         // ATTM: the first 8 splits' outputs travel with the task (16: 254 VGPRs and a private segment -- the pipelined task loop holds two tasks)
     struct PrepIn { half4_t xv, sv, wv; float ss, ssn; uint4_t f0, f1, f2, f3; float4_t ga[NSL], ua[NSL]; half4_t svg, svu; float4_t mo[NMO]; float2 mst; };
     const int at_nsplit = MODE == G4_MODE_ATTM ? a.attm.nsplit : 1, at_gq = MODE == G4_MODE_ATTM ? a.attm.gq : 1;
     const float* const at_part = MODE == G4_MODE_ATTM ? a.attm.part : nullptr;
