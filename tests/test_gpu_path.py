@@ -926,6 +926,38 @@ def test_attention_merge_inside_oproj_is_bit_identical_to_the_merge_launch(dev, 
     assert np.array_equal(model.logits.float().cpu().numpy(), l1)
 
 
+@pytest.mark.parametrize("gq", [1, 2, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("pos,bsz", [(130, 1), (1000, 2)])
+def test_attention_qkv_in_split_every_group_size(dev, gq, pos, bsz):
+    """ext.attn_decode_qcache_split_qkv for every GQA group size the kernel is instantiated for (the K / V tasks sit on half-waves (GQ) % 8 and
+    (GQ + 1) % 8: beside the query tasks up to GQ = 6, in a second task round for 7 and 8): fx step with the q|k|v epilogue inside the context-split
+    launch against glue_qkv_rs + split as two launches -- logits, residual, q and every cache word bit for bit, random pre-filled cache."""
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 512, 768, 2, gq, 1, 128, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(bsz, pos=pos)
+    model.with_attention = True
+    g = torch.Generator(device="cpu").manual_seed(gq * 1000 + pos)
+    for c, s_ in model.kcache + model.vcache:
+        c.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, c.shape, generator=g, dtype=torch.int64).to(torch.int32).to(dev))
+        s_.copy_((torch.rand(s_.shape, generator=g) * 0.5 + 0.05).half().to(dev))
+    saved = [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]
+    outs = []
+    for qkv_in_split in (False, True):
+        model.attn_qkv_in_split = qkv_in_split
+        for (c, s_), (c0, s0) in zip(model.kcache + model.vcache, saved):
+            c.copy_(c0); s_.copy_(s0)
+        model.q.zero_()
+        lg = model.decode_step_fx().float().cpu().numpy().copy()
+        outs.append((lg, model.x_final.clone(), model.q.clone(), [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]))
+    (l0, x0_, q0, kv0), (l1, x1_, q1, kv1) = outs
+    assert np.isfinite(l1).all()
+    assert np.array_equal(l0, l1) and torch.equal(x0_, x1_) and torch.equal(q0, q1)      # q: the last layer's finished queries (split 0 writes them)
+    assert all(torch.equal(a0, a1) and torch.equal(b0, b1) for (a0, b0), (a1, b1) in zip(kv0, kv1))
+    # something was appended: the new token's row differs from the pre-filled words in every layer
+    assert all(not torch.equal(a1, a0) for (a1, _), (a0, _) in zip(kv1, saved))
+
+
 @pytest.mark.parametrize("bsz", [1, 16])
 def test_fused_pipeline_on_70b_tp8_rank_shapes(dev, bsz):
     """The per-rank shapes of Llama-3.1-70B under TP = 8 (hidden 8192, q 8 heads, ONE kv head -> 128-column k / v matrices, inter 3584,
