@@ -483,7 +483,7 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
 template <int HD>
 __global__ __launch_bounds__(256)
 void attn_merge_kernel(const float* __restrict__ part, half_t* __restrict__ out, int items_total, int nsplit, int gq, int blocks, int hq,
-                       uint32_t magic_gq, uint32_t magic_bg, uint32_t magic_blocks)
+                       uint32_t magic_gq, uint32_t magic_bg, uint32_t magic_blocks, const float* __restrict__ sinks)
 {
     constexpr int hd = HD;
     __shared__ float comb[2][ATT_MERGE_HELPERS][32][4];
@@ -520,6 +520,16 @@ void attn_merge_kernel(const float* __restrict__ part, half_t* __restrict__ out,
         for (int j = 1; j < rw; j <<= 1) m = fmaxf(m, xor_lane(m, j));
         M = m;
     }
+    // learned per-head sink logit (gpt-oss style, modules/attention_fn/triton_paged.py:1030-1050): it joins the softmax DENOMINATOR at the final
+    // reduction -- the running maximum and the sum of exponentials -- and contributes no value
+    float snk = 0.0f;
+    if (sinks)
+    {
+        const int it_ = act ? item : 0;
+        const int ig_ = gemv_udiv(it_, magic_gq), i_ = it_ - ig_ * gq, h_ = ig_ - gemv_udiv(ig_, magic_blocks) * blocks;
+        snk = sinks[(h_ * nsub + sub) * gq + i_];
+        M = fmaxf(M, snk);
+    }
     float ec[8], L = 0.0f;
     #pragma unroll
     for (int c = 0; c < 8; ++c)
@@ -533,6 +543,7 @@ void attn_merge_kernel(const float* __restrict__ part, half_t* __restrict__ out,
             L += ls;
         }
     }
+    if (sinks) L += __expf(snk - M);
     // ---- this helper's weighted partial output
     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
     for (int c0 = 0; c0 < cnt_h; c0 += 8)
@@ -584,7 +595,7 @@ extern "C" int exl3_glue_qkv_tab(const float* sq, const float* sk, const float* 
 static int attn_decode_impl(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
                             const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
                             int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
-                            float* workspace, int64_t workspace_floats, void* stream, int* nsplit_out, const QkvFuse* fuse = nullptr);
+                            float* workspace, int64_t workspace_floats, void* stream, int* nsplit_out, const QkvFuse* fuse = nullptr, const float* sinks = nullptr);
 
 extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
                                        const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
@@ -593,6 +604,19 @@ extern "C" int exl3_attn_decode_qcache(const void* q, void* out, const void* k_c
 {
     return attn_decode_impl(q, out, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, bsz, blocks_per_seq, page_size, k_bits, v_bits, heads_q, heads_kv,
                             head_dim, max_len, scale, workspace, workspace_floats, stream, nullptr);
+}
+
+// exl3_attn_decode_qcache with learned attention sinks: sinks[heads_q] fp32, one logit per query head in the units of the scaled scores; it joins the
+// softmax denominator (running maximum and sum of exponentials) and carries no value (modules/attention_fn/triton_paged.py:1030-1050, the combine kernel
+// of libtorch/attention.cpp:463-480 with HAS_SINKS).  Partial records are always written and the merge kernel finishes every head (workspace required).
+extern "C" int exl3_attn_decode_qcache_sinks(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
+                                             const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
+                                             int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
+                                             float* workspace, int64_t workspace_floats, const float* sinks, void* stream)
+{
+    EXL3_CHECK_ARG(sinks && workspace, "attn_decode_sinks: needs the sink logits and the workspace");
+    return attn_decode_impl(q, out, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, bsz, blocks_per_seq, page_size, k_bits, v_bits, heads_q, heads_kv,
+                            head_dim, max_len, scale, workspace, workspace_floats, stream, nullptr, nullptr, sinks);
 }
 
 // The context-split half of exl3_attn_decode_qcache only: the partial records {m, l, -, -, o[128]} per (sequence, kv block, query index, split) stay in
@@ -644,7 +668,7 @@ extern "C" int exl3_attn_decode_qcache_split_qkv(const float* sq, const float* s
 static int attn_decode_impl(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
                             const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
                             int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
-                            float* workspace, int64_t workspace_floats, void* stream, int* nsplit_out, const QkvFuse* fuse)
+                            float* workspace, int64_t workspace_floats, void* stream, int* nsplit_out, const QkvFuse* fuse, const float* sinks)
 {
     const bool split_only = nsplit_out != nullptr;
     const AttnQkvArgs* xq = nullptr;
@@ -665,13 +689,14 @@ static int attn_decode_impl(const void* q, void* out, const void* k_cache, const
     if (nsplit > cap) { nsplit = cap; split_tokens = ((max_len + nsplit - 1) / nsplit + 7) / 8 * 8; nsplit = (max_len + split_tokens - 1) / split_tokens; }
     // (split-only callers hand the records to a consumer that keeps one chunk of 32 split statistics: cap the split count there)
     if (split_only && nsplit > 32) { nsplit = 32; split_tokens = ((max_len + nsplit - 1) / nsplit + 7) / 8 * 8; nsplit = (max_len + split_tokens - 1) / split_tokens; }
-    EXL3_CHECK_ARG((nsplit == 1 && !split_only) || (workspace && workspace_floats >= (int64_t) bsz * blocks * gq * nsplit * 132), "attn_decode: workspace too small for the context splits");
+    EXL3_CHECK_ARG((nsplit == 1 && !split_only && !sinks) || (workspace && workspace_floats >= (int64_t) bsz * blocks * gq * nsplit * 132), "attn_decode: workspace too small for the context splits");
+    EXL3_CHECK_ARG(!sinks || !split_only, "attn_decode: attention sinks are merged by the merge kernel (not by the split-only forms)");
     AttnArgs a;
     a.q = (const half_t*) q; a.out = (half_t*) out;
     a.k_cache = (const uint32_t*) k_cache; a.k_scales = (const half_t*) k_scales; a.v_cache = (const uint32_t*) v_cache; a.v_scales = (const half_t*) v_scales;
     a.block_table = block_table; a.cache_seqlens = cache_seqlens; a.part = workspace;
     a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.k_bits = k_bits; a.v_bits = v_bits; a.hq = heads_q; a.hkv = heads_kv;
-    a.nsplit = nsplit; a.split_tokens = split_tokens; a.scale = scale; a.force_part = split_only ? 1 : 0;
+    a.nsplit = nsplit; a.split_tokens = split_tokens; a.scale = scale; a.force_part = (split_only || sinks) ? 1 : 0;      // sinks: the merge kernel finishes every head
     hipStream_t st = (hipStream_t) stream;
     // head_dim 128, 4-bit K and V, a length bound of at least two 64-token steps: the matrix-pipe kernel (it always writes partial records); measured
     // ahead of the half-wave-per-token kernel from a 512-token bound on (463 vs 458 tok/s with attention), far ahead at long contexts
@@ -707,7 +732,7 @@ static int attn_decode_impl(const void* q, void* out, const void* k_cache, const
             if (split_only) { *nsplit_out = ns; return EXL3_OK; }
             const int items = bsz * blocks * gq;
             const uint32_t mg = gemv_magic((uint32_t) gq), mbg = gemv_magic((uint32_t) (blocks * gq)), mb = gemv_magic((uint32_t) blocks);
-            attn_merge_kernel<128><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, ns, gq, blocks, heads_q, mg, mbg, mb);
+            attn_merge_kernel<128><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, ns, gq, blocks, heads_q, mg, mbg, mb, sinks);
             return exl3_check_launch("attn_merge");
         }
     }
@@ -733,13 +758,13 @@ static int attn_decode_impl(const void* q, void* out, const void* k_cache, const
     int rc = exl3_check_launch("attn_decode");
     if (rc) return rc;
     if (split_only) { *nsplit_out = nsplit; return EXL3_OK; }
-    if (nsplit > 1)
+    if (nsplit > 1 || sinks)
     {
         const int items = bsz * blocks * gq;
         EXL3_CHECK_ARG(nsplit <= 8 * (head_dim == 128 ? 32 : 16), "attn_decode: too many context splits for the merge kernel");
         const uint32_t mg = gemv_magic((uint32_t) gq), mbg = gemv_magic((uint32_t) (blocks * gq)), mb = gemv_magic((uint32_t) blocks);
-        if (head_dim == 128) attn_merge_kernel<128><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, nsplit, gq, blocks, heads_q, mg, mbg, mb);
-        else                 attn_merge_kernel<64><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, nsplit, gq, blocks, heads_q, mg, mbg, mb);
+        if (head_dim == 128) attn_merge_kernel<128><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, nsplit, gq, blocks, heads_q, mg, mbg, mb, sinks);
+        else                 attn_merge_kernel<64><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, nsplit, gq, blocks, heads_q, mg, mbg, mb, sinks);
         rc = exl3_check_launch("attn_merge");
     }
     return rc;

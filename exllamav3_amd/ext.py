@@ -562,7 +562,7 @@ class BC_Attention:
     Same constructor arguments and run() signature as the reference's class.  This build covers the Llama / Mixtral subset of it:
     quantized cache (`quant_cache`), q_len 1 .. 16 new tokens per sequence, bsz <= 8; V norm, K-as-V and the rope options (llama-4 query scale,
     norm after the rotation, `rotate_dims`) are composed from the ops of this module as the reference composes them (attention.cpp:335-395); no
-    output gate, no sinks, no padded hidden dim: those raise at construction, nothing degrades silently.
+    output gate, no padded hidden dim: those raise at construction, nothing degrades silently.  Learned attention sinks go to the merge kernel.
     The reference's slot machinery exists to hold AOT-compiled Triton kernels and their statics: needs_configure() is always False here and
     configure_slot() accepts and ignores its arguments; capture the whole decode step in one hipGraph instead (all launches of run() are
     capturable, the per-call tensors are read by pointer)."""
@@ -579,7 +579,6 @@ class BC_Attention:
                  quant_cache=True, cache_k=None, cache_v=None, cache_k_scales=None, cache_v_scales=None, xh=None, h32=None, sinks=None):
         _req(quant_cache and cache_k_scales is not None and cache_v_scales is not None, "BC_Attention: this build attends over the quantized paged cache only")
         _req(gate_mode == 0 and g_proj is None and g_weight is None and qg_ptrs_trellis is None, "BC_Attention: output gates are outside this build")
-        _req(sinks is None, "BC_Attention: attention sinks are outside this build")
         _req(hidden_size_padded == hidden_size, "BC_Attention: padded hidden dim is outside this build")
         _req(not use_k_as_v or k_proj is not None, "BC_Attention: K-as-V needs the separate k projection")
         _req(head_dim in (64, 128) and num_q_heads % num_kv_heads == 0, "BC_Attention: head_dim must be 64 or 128")
@@ -595,6 +594,7 @@ class BC_Attention:
         self.inv_freq, self.rope_style, self.attn_factor = inv_freq, int(rope_style), float(attn_factor)
         self.l4_beta, self.l4_orig, self.post_rope_norm, self.rotate_dims = float(l4_scaling_beta), int(l4_scaling_original), bool(post_rope_norm), int(rotate_dims)
         self.use_k_as_v, self.v_norm, self.v_norm_w = bool(use_k_as_v), bool(v_norm), v_norm_w
+        self.sinks = sinks                                             # float32 [heads_q] or None: the combine step's learned sink logits
         self.v_norm_eps, self.v_norm_bias, self.v_norm_scale = float(v_norm_eps), float(v_norm_constant_bias), float(v_norm_constant_scale)
         self.cache_k, self.cache_v, self.cache_k_scales, self.cache_v_scales = cache_k, cache_v, cache_k_scales, cache_v_scales
         self.xh = xh
@@ -679,7 +679,7 @@ class BC_Attention:
             st["lens_v"].add_(st["tofs"])
             bt_v, lens_v = st["bt_v"], st["lens_v"]
         attn_decode_qcache(st["q"].view(rows, hq, hd), st["o"].view(rows, hq, hd), self.cache_k, self.cache_k_scales, self.cache_v, self.cache_v_scales,
-                           bt_v, lens_v, st["max_len"], workspace=st["ws"])
+                           bt_v, lens_v, st["max_len"], workspace=st["ws"], sinks=self.sinks)
         self.o_proj.run(st["o"].view(rows, hq * hd), y.view(rows, self.hidden_size))
 
 
@@ -1481,7 +1481,7 @@ def exl3_gemv_ex_attm(part: torch.Tensor, nsplit: int, heads_q: int, heads_kv: i
 
 
 def attn_decode_qcache(q, out, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, max_len: int, scale: float | None = None,
-                       workspace: torch.Tensor | None = None):
+                       workspace: torch.Tensor | None = None, sinks: torch.Tensor | None = None):
     """Decode attention straight from the quantized paged cache.  q / out: (bsz, heads_q, 128) fp16; caches (pages, page, G * bits) int32 +
     scales (pages, page, G) fp16 as written by quant_cache_paged / glue_qkv; cache_seqlens int32 (bsz) INCLUDING the new token."""
     _dev(q)
@@ -1495,8 +1495,15 @@ def attn_decode_qcache(q, out, k_cache, k_scales, v_cache, v_scales, block_table
     kb, vb = _kv_bits(k_cache, k_scales), _kv_bits(v_cache, v_scales)
     nsplit_max = (max_len + 31) // 32
     need = bsz * (hq * hd // 128) * nsplit_max * 132              # one record per (sequence, 128-value block, query index) and split
-    if workspace is None and nsplit_max > 1:
+    if workspace is None and (nsplit_max > 1 or sinks is not None):
         workspace = torch.empty((need,), dtype=torch.float, device=q.device)
+    if sinks is not None:
+        # learned per-head sink logits (float32 [heads_q]): in the softmax denominator only (triton_paged.py:1030-1050)
+        _req(sinks.dtype == torch.float and sinks.numel() == hq and sinks.is_contiguous(), "attn_decode: sinks must be float32 [heads_q]")
+        _check(_lib.lib().exl3_attn_decode_qcache_sinks(_p(q), _p(out), _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table), _p(cache_seqlens),
+                                                        bsz, block_table.shape[1], k_cache.shape[1], kb, vb, hq, hkv, hd, int(max_len),
+                                                        float(scale if scale is not None else hd ** -0.5), _p(workspace), workspace.numel(), _p(sinks), _stream(q)))
+        return
     _check(_lib.lib().exl3_attn_decode_qcache(_p(q), _p(out), _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(block_table), _p(cache_seqlens),
                                               bsz, block_table.shape[1], k_cache.shape[1], kb, vb, hq, hkv, hd, int(max_len),
                                               float(scale if scale is not None else hd ** -0.5), _p(workspace),

@@ -341,6 +341,14 @@ int exl3_attn_decode_qcache(const void* q, void* out, const void* k_cache, const
                             const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
                             int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
                             float* workspace, int64_t workspace_floats, void* stream);
+/* exl3_attn_decode_qcache with learned attention sinks (gpt-oss style): sinks[heads_q] fp32, one logit per query head in the units of the scaled scores,
+ * joining the softmax denominator only (modules/attention_fn/triton_paged.py:1030-1050; the combine kernel of libtorch/attention.cpp:463-480).  The workspace
+ * is required (the merge kernel finishes every head, also with one split). */
+int exl3_attn_decode_qcache_sinks(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
+                                  const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
+                                  int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
+                                  float* workspace, int64_t workspace_floats, const float* sinks, void* stream);
+
 /* The context-split half of exl3_attn_decode_qcache only (head_dim 128): the partial records {m, l, -, -, o[128]} of every (sequence, 128-value kv block,
  * query index, split) stay in `workspace` ([bsz][blocks][gq][*nsplit_out][132] fp32, written also with a single split; at most 32 splits) and the
  * consumer of the attention output merges them: exl3_gemv_ex_attm is o_proj with that merge as the preparation task of each (row, head) -- the

@@ -713,10 +713,13 @@ def attn_prefill(q: np.ndarray, k: np.ndarray, v: np.ndarray, kv_lens, scale: fl
     return out.astype(np.float16)
 
 
-def attn_decode_qcache(q: np.ndarray, k_deq: np.ndarray, v_deq: np.ndarray, lens, scale: float | None = None) -> np.ndarray:
+def attn_decode_qcache(q: np.ndarray, k_deq: np.ndarray, v_deq: np.ndarray, lens, scale: float | None = None, sinks=None) -> np.ndarray:
     """Decode attention of one new token per sequence over the DEQUANTIZED cache (what the reference attends to after dequant_cache_paged,
     libtorch/attention.cpp:246-504): q (b, hq, d) fp16; k_deq / v_deq (b, T, hkv, d) fp16 = kv_dequant of the cache; lens[b] tokens valid.
-    GQA: q head h uses kv head h // (hq / hkv).  fp32 softmax / accumulation, fp16 result."""
+    GQA: q head h uses kv head h // (hq / hkv).  fp32 softmax / accumulation, fp16 result.
+    sinks (hq,) fp32: learned per-head sink logits in the units of the scaled scores, in the softmax denominator only -- the combine kernel's
+    HAS_SINKS branch (modules/attention_fn/triton_paged.py:1030-1050); the reference's own torch restatement: concatenate the logit, softmax, drop
+    the column (tests/test_dsa_kernels.py:54-62)."""
     b, hq, d = q.shape
     hkv = k_deq.shape[2]
     gq = hq // hkv
@@ -727,6 +730,12 @@ def attn_decode_qcache(q: np.ndarray, k_deq: np.ndarray, v_deq: np.ndarray, lens
         for h in range(hq):
             kk = k_deq[bi, :L, h // gq].astype(np.float32); vv = v_deq[bi, :L, h // gq].astype(np.float32)
             s = (kk @ q[bi, h].astype(np.float32)) * sc
+            if sinks is not None:
+                # learned sink logit of head h: in the denominator only (modules/attention_fn/triton_paged.py:1030-1050)
+                m = max(np.float32(s.max()) if L else np.float32(-np.inf), np.float32(sinks[h]))
+                p = np.exp(s - m)
+                out[bi, h] = (p @ vv) / (p.sum() + np.exp(np.float32(sinks[h]) - m))
+                continue
             p = np.exp(s - s.max()); p /= p.sum()
             out[bi, h] = p @ vv
     return out.astype(np.float16)

@@ -424,10 +424,10 @@ def test_bc_attention_runner_matches_oracle(dev, hd, hq, hkv, fused_kv, head_nor
         ext.BC_Attention(**{**kw, "quant_cache": False})
 
 
-@pytest.mark.parametrize("opt", ["v_norm", "k_as_v", "k_as_v_norm", "l4_post_norm"])
+@pytest.mark.parametrize("opt", ["v_norm", "k_as_v", "k_as_v_norm", "l4_post_norm", "sinks"])
 def test_bc_attention_runner_options(dev, opt):
     """The runner's options that compose from this build's ops (attention.cpp:335-395): per-head V norm, V = the K projection's output before head
-    norm / RoPE (copied or normed), and the rope options (llama-4 query scale + unweighted norm after the rotation) -- each against the oracle
+    norm / RoPE (copied or normed), the rope options (llama-4 query scale + unweighted norm after the rotation), learned attention sinks -- each against the oracle
     composition, over short contexts (a one-token context would hand single 4-bit level flips of the new token's V straight to the output)."""
     from exllamav3_amd import ext
     hidden, K, cb, bits, page, bsz, pps, hd, hq, hkv = 512, 4, 2, 4, 256, 2, 1, 128, 4, 2
@@ -457,6 +457,9 @@ def test_bc_attention_runner_options(dev, opt):
         kw.update(use_k_as_v=True, v_proj=None)
     elif opt == "k_as_v_norm":
         kw.update(use_k_as_v=True, v_proj=None, v_norm=True, v_norm_w=None, v_norm_eps=1e-5)
+    elif opt == "sinks":
+        sinks = np.linspace(-2.0, 5.0, hq).astype(np.float32)
+        kw.update(sinks=T(sinks))
     else:
         kw.update(l4_scaling_beta=0.3, l4_scaling_original=16, post_rope_norm=True)
         rope_kw = dict(l4_beta=0.3, l4_orig=16, post_rope_norm=True)
@@ -477,7 +480,7 @@ def test_bc_attention_runner_options(dev, opt):
         full_k = np.concatenate([ck[b, :lens[b]], k4[b].reshape(1, -1)]); full_v = np.concatenate([cv[b, :lens[b]], v[b].reshape(1, -1)])
         pk, sc = o.kv_quant(full_k, bits); pv, sv = o.kv_quant(full_v, bits)
         kd[b, :lens[b] + 1] = o.kv_dequant(pk, sc, bits).reshape(-1, hkv, hd); vd[b, :lens[b] + 1] = o.kv_dequant(pv, sv, bits).reshape(-1, hkv, hd)
-    ao = o.attn_decode_qcache(q4.reshape(bsz, hq, hd), kd, vd, lens + 1)
+    ao = o.attn_decode_qcache(q4.reshape(bsz, hq, hd), kd, vd, lens + 1, sinks=sinks if opt == "sinks" else None)
     ref = lin("o", ao.reshape(bsz, -1)).astype(np.float32)
     got = y.float().cpu().numpy().reshape(bsz, hidden)
     assert np.isfinite(got).all()

@@ -209,6 +209,48 @@ def test_attn_decode_qcache(dev, kb, vb, lens, hd, hq, hkv):
     assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 1e-2
 
 
+@pytest.mark.parametrize("kb,vb,hd,hq,hkv", [(4, 4, 128, 8, 2), (8, 3, 128, 4, 4), (4, 4, 64, 8, 2), (2, 6, 64, 32, 8)])
+@pytest.mark.parametrize("lens,max_len", [([1], 1), ([63, 64], 64), ([300, 1000, 77], 1000), ([2500, 1, 700], 2560)])
+def test_attn_decode_qcache_with_sinks(dev, kb, vb, hd, hq, hkv, lens, max_len):
+    """Learned attention sinks (one fp32 logit per query head, gpt-oss style): the logit joins the softmax denominator at the final reduction and
+    carries no value (modules/attention_fn/triton_paged.py:1030-1050; the torch restatement of the reference's own tests concatenates the sink
+    logit, takes the softmax and drops its column: tests/test_dsa_kernels.py:54-62).  One-token contexts (a sink larger than the score halves the
+    output), one split, many splits, the matrix-pipe kernel; head_dim 128 and 64; sinks from far below to far above the scores."""
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(kb * 100 + vb * 10 + len(lens) + hd)
+    bsz, page = len(lens), 256
+    pps = (max_len + page - 1) // page
+    npages = bsz * pps + 3
+    perm = rng.permutation(npages)[: bsz * pps].reshape(bsz, pps).astype(np.int32)
+    G = hkv * hd // 32
+    k = (rng.standard_normal((bsz, pps * page, hkv * hd)) * 1.5).astype(np.float16)
+    v = rng.standard_normal((bsz, pps * page, hkv * hd)).astype(np.float16)
+    kq, ks = o.kv_quant(k, kb); vq, vs = o.kv_quant(v, vb)
+    kc = np.zeros((npages, page, G * kb), dtype=np.uint32); ksc = np.zeros((npages, page, G), dtype=np.float16)
+    vc = np.zeros((npages, page, G * vb), dtype=np.uint32); vsc = np.zeros((npages, page, G), dtype=np.float16)
+    for b in range(bsz):
+        for pg in range(pps):
+            kc[perm[b, pg]] = kq[b, pg * page:(pg + 1) * page]; ksc[perm[b, pg]] = ks[b, pg * page:(pg + 1) * page]
+            vc[perm[b, pg]] = vq[b, pg * page:(pg + 1) * page]; vsc[perm[b, pg]] = vs[b, pg * page:(pg + 1) * page]
+    q = rng.standard_normal((bsz, hq, hd)).astype(np.float16)
+    sinks = np.linspace(-6.0, 9.0, hq).astype(np.float32)                                      # scores here have a standard deviation of ~1.5
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    kd = o.kv_dequant(kq, ks, kb).reshape(bsz, -1, hkv, hd); vd = o.kv_dequant(vq, vs, vb).reshape(bsz, -1, hkv, hd)
+    outs = {}
+    for sk in (None, sinks):
+        out = torch.full((bsz, hq, hd), float("nan"), dtype=torch.half, device=dev)
+        ext.attn_decode_qcache(T(q), out, T(kc.view(np.int32)), T(ksc), T(vc.view(np.int32)), T(vsc), T(perm), T(np.array(lens, dtype=np.int32)), max_len,
+                               sinks=None if sk is None else T(sk))
+        ref = o.attn_decode_qcache(q, kd, vd, lens, sinks=sk).astype(np.float32)
+        got = out.float().cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() / np.sqrt((o.attn_decode_qcache(q, kd, vd, lens).astype(np.float32) ** 2).mean()) < 1e-2
+        outs[sk is None] = got
+    # the sink only ever shrinks a head's output, by the factor sum / (sum + exp(sink - max))
+    n0, n1 = np.abs(outs[True]).sum(-1), np.abs(outs[False]).sum(-1)
+    assert (n1 <= n0 * 1.001 + 1e-3).all() and (n1[:, -1] < 0.9 * n0[:, -1]).all()
+
+
 @pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 1), (6, 2), (4, 4)])
 @pytest.mark.parametrize("lens,max_len", [([2500, 1, 700], 2560), ([5000, 4096], 8192)])
 def test_attn_decode_qcache_long_context_kernel(dev, hq, hkv, lens, max_len):
