@@ -115,6 +115,8 @@ def _declare(l):
     sig("exl3_dequant_cache_paged", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_silu_mul", vp, vp, vp, i64, i32, vp)
     sig("exl3_act_mul", vp, vp, vp, i64, i32, i32, f32, vp)
+    sig("exl3_mul_gate", vp, vp, i64, i32, i32, vp)
+    sig("exl3_deinterleave_qg", vp, vp, vp, i64, i32, vp)
     sig("exl3_add", vp, vp, i64, i32, i32, vp)
     sig("exl3_softcap", vp, vp, i64, f32, i32, vp)
     sig("exl3_ar_create", i32, i32, i64, ctypes.POINTER(vp), vp)

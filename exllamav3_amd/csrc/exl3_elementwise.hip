@@ -245,6 +245,83 @@ extern "C" int exl3_act_mul(const void* g, const void* u, void* y, int64_t numel
     return exl3_check_launch("act_mul");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Attention output gates (activation.cu:526-660, kernels activation_kernels.cuh:132-139, 300-367): x *= sigmoid(y) elementwise or with one gate per
+// `bcast` consecutive values (one per head), or x *= softplus(y) broadcast.  The sigmoid form is fp16 arithmetic end to end like the reference's
+// (exp of -y rounded to fp16, 1 + e in fp16, reciprocal rounded to fp16, product in fp16); the softplus gate is evaluated in fp32 and only the product
+// rounds (max(y, 0) + log1p(exp(-|y|))).  4 halves per thread; bcast % 4 == 0 or bcast == 0 (elementwise).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ half_t sigmoid_h(half_t y)
+{
+    const half_t e = f2h(__expf(-(float) y));
+    const half_t sum = (half_t) 1.0f + e;
+    return f2h(1.0f / (float) sum);
+}
+
+template <bool SOFTPLUS>
+__global__ __launch_bounds__(256)
+void mul_gate_kernel(half_t* __restrict__ x, const half_t* __restrict__ y, int64_t n4, int bcast)
+{
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    half4_t xv = ((half4_t*) x)[i];
+    if (bcast == 0)
+    {
+        const half4_t yv = ((const half4_t*) y)[i];
+        xv = half4_t{ xv.x * sigmoid_h(yv.x), xv.y * sigmoid_h(yv.y), xv.z * sigmoid_h(yv.z), xv.w * sigmoid_h(yv.w) };
+    }
+    else
+    {
+        const half_t g = y[(i * 4) / bcast];
+        if constexpr (SOFTPLUS)
+        {
+            const float gf = (float) g, sp = fmaxf(gf, 0.0f) + log1pf(__expf(-fabsf(gf)));
+            xv = half4_t{ f2h((float) xv.x * sp), f2h((float) xv.y * sp), f2h((float) xv.z * sp), f2h((float) xv.w * sp) };
+        }
+        else
+        {
+            const half_t sg = sigmoid_h(g);
+            xv = half4_t{ xv.x * sg, xv.y * sg, xv.z * sg, xv.w * sg };
+        }
+    }
+    ((half4_t*) x)[i] = xv;
+}
+
+extern "C" int exl3_mul_gate(void* x, const void* y, int64_t numel, int bcast, int softplus, void* stream)
+{
+    EXL3_CHECK_ARG(x && y, "mul_gate: null pointer");
+    EXL3_CHECK_ARG(numel % 4 == 0 && bcast >= 0 && bcast % 4 == 0, "mul_gate: numel and the broadcast width must be divisible by 4");
+    EXL3_CHECK_ARG(!softplus || bcast > 0, "mul_gate: the softplus gate is the broadcast (one gate per head) form");
+    if (numel == 0) return EXL3_OK;
+    const int64_t n4 = numel / 4;
+    const dim3 grid((unsigned) ((n4 + 255) / 256));
+    if (softplus) mul_gate_kernel<true><<<grid, 256, 0, (hipStream_t) stream>>>((half_t*) x, (const half_t*) y, n4, bcast);
+    else          mul_gate_kernel<false><<<grid, 256, 0, (hipStream_t) stream>>>((half_t*) x, (const half_t*) y, n4, bcast);
+    return exl3_check_launch("mul_gate");
+}
+
+// [.., heads, (q: head_dim, g: head_dim)] -> contiguous q and g (activation.cu:716-785): 16 bytes per thread
+__global__ __launch_bounds__(256)
+void deinterleave_qg_kernel(const half8_t* __restrict__ qg, half8_t* __restrict__ q, half8_t* __restrict__ g, int hd8, int64_t n8)
+{
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const int64_t h = i / hd8, d = i - h * hd8;
+    const int64_t src = h * 2 * hd8 + d;
+    q[i] = qg[src];
+    g[i] = qg[src + hd8];
+}
+
+extern "C" int exl3_deinterleave_qg(const void* qg, void* q, void* g, int64_t heads_total, int head_dim, void* stream)
+{
+    EXL3_CHECK_ARG(qg && q && g, "deinterleave_qg: null pointer");
+    EXL3_CHECK_ARG(head_dim > 0 && head_dim % 8 == 0, "deinterleave_qg: head_dim must be divisible by 8");
+    const int64_t n8 = heads_total * (head_dim / 8);
+    if (n8 == 0) return EXL3_OK;
+    deinterleave_qg_kernel<<<dim3((unsigned) ((n8 + 255) / 256)), 256, 0, (hipStream_t) stream>>>((const half8_t*) qg, (half8_t*) q, (half8_t*) g, head_dim / 8, n8);
+    return exl3_check_launch("deinterleave_qg");
+}
+
 // row-strided variant (fp16): g and u are column ranges of wider matrices (the fused gate|up prefill GEMM writes one [rows][2*cols] output);
 // 8 halves per thread (16-byte accesses)
 __global__ __launch_bounds__(256)

@@ -562,7 +562,8 @@ class BC_Attention:
     Same constructor arguments and run() signature as the reference's class.  This build covers the Llama / Mixtral subset of it:
     quantized cache (`quant_cache`), q_len 1 .. 16 new tokens per sequence, bsz <= 8; V norm, K-as-V and the rope options (llama-4 query scale,
     norm after the rotation, `rotate_dims`) are composed from the ops of this module as the reference composes them (attention.cpp:335-395); no
-    output gate, no padded hidden dim: those raise at construction, nothing degrades silently.  Learned attention sinks go to the merge kernel.
+    padded hidden dim: that raises at construction, nothing degrades silently.  Learned attention sinks go to the merge kernel; the output gates
+    (headwise / full / interleaved, sigmoid or softplus: attention.cpp:283-333, 483-494) are the reference's own op sequence over this module's ops.
     The reference's slot machinery exists to hold AOT-compiled Triton kernels and their statics: needs_configure() is always False here and
     configure_slot() accepts and ignores its arguments; capture the whole decode step in one hipGraph instead (all launches of run() are
     capturable, the per-call tensors are read by pointer)."""
@@ -578,7 +579,13 @@ class BC_Attention:
                  rope_style=2, attn_factor=1.0, l4_scaling_beta=0.0, l4_scaling_original=0, post_rope_norm=False, rotate_dims=1,
                  quant_cache=True, cache_k=None, cache_v=None, cache_k_scales=None, cache_v_scales=None, xh=None, h32=None, sinks=None):
         _req(quant_cache and cache_k_scales is not None and cache_v_scales is not None, "BC_Attention: this build attends over the quantized paged cache only")
-        _req(gate_mode == 0 and g_proj is None and g_weight is None and qg_ptrs_trellis is None, "BC_Attention: output gates are outside this build")
+        _req(gate_mode in (0, 1, 2, 3), "BC_Attention: gate_mode must be 0 (none), 1 (headwise), 2 (full) or 3 (interleaved)")
+        _req(gate_mode != 1 or g_weight is not None, "BC_Attention: headwise gate requires the fp16 gate weight")                        # attention.cpp:303
+        _req(gate_mode != 2 or g_weight is not None or g_proj is not None or qg_ptrs_trellis is not None,
+             "BC_Attention: full gate without fused qg needs a g projection")                                                          # attention.cpp:317
+        _req(g_weight is None or (g_weight.dtype == torch.half and g_weight.dim() == 2 and g_weight.shape[0] == hidden_size
+                                  and g_weight.shape[1] == (num_q_heads if gate_mode == 1 else num_q_heads * head_dim)),
+             "BC_Attention: g_weight must be float16 (hidden, heads) for the headwise gate, (hidden, heads * head_dim) for the full gate")
         _req(hidden_size_padded == hidden_size, "BC_Attention: padded hidden dim is outside this build")
         _req(not use_k_as_v or k_proj is not None, "BC_Attention: K-as-V needs the separate k projection")
         _req(head_dim in (64, 128) and num_q_heads % num_kv_heads == 0, "BC_Attention: head_dim must be 64 or 128")
@@ -595,6 +602,8 @@ class BC_Attention:
         self.l4_beta, self.l4_orig, self.post_rope_norm, self.rotate_dims = float(l4_scaling_beta), int(l4_scaling_original), bool(post_rope_norm), int(rotate_dims)
         self.use_k_as_v, self.v_norm, self.v_norm_w = bool(use_k_as_v), bool(v_norm), v_norm_w
         self.sinks = sinks                                             # float32 [heads_q] or None: the combine step's learned sink logits
+        self.gate_mode, self.gate_softplus, self.g_proj, self.g_weight = int(gate_mode), bool(gate_softplus), g_proj, g_weight
+        self.qg_ptrs = (qg_ptrs_trellis, qg_ptrs_suh, qg_ptrs_svh, int(qg_K), bool(qg_mcg), bool(qg_mul1)) if qg_ptrs_trellis is not None else None
         self.v_norm_eps, self.v_norm_bias, self.v_norm_scale = float(v_norm_eps), float(v_norm_constant_bias), float(v_norm_constant_scale)
         self.cache_k, self.cache_v, self.cache_k_scales, self.cache_v_scales = cache_k, cache_v, cache_k_scales, cache_v_scales
         self.xh = xh
@@ -621,6 +630,16 @@ class BC_Attention:
                 "xh": torch.empty((2, rows, self.hidden_size), dtype=torch.half, device=dev),
                 "max_len": max_len,
             }
+            if self.gate_mode == 1:
+                st["g"] = torch.empty((rows, hq), dtype=torch.half, device=dev)
+            elif self.gate_mode == 2:
+                # q and g as the two halves of one (2, rows, hq * hd) buffer: the fused q + g launch writes both (attention.cpp:291-297)
+                st["qg"] = torch.empty((2, rows, hq * hd), dtype=torch.half, device=dev)
+                st["q"] = st["qg"][0].view(bsz, q_len, hq, hd)
+                st["g"] = st["qg"][1]
+            elif self.gate_mode == 3:
+                st["qg_i"] = torch.empty((rows, 2 * hq * hd), dtype=torch.half, device=dev)
+                st["g"] = torch.empty((rows, hq * hd), dtype=torch.half, device=dev)
             # 2 <= q_len <= 16: token t of sequence b attends as its own one-token sequence (b, t) with the same block-table row and length
             # cache_seqlens[b] + t + 1 -- causal by construction, straight from the quantized pages (no fp16 page window)
             st["ws"] = torch.empty((rows * (hq * hd // 128) * ((max_len + 31) // 32) * 132,), dtype=torch.float, device=dev)
@@ -645,7 +664,23 @@ class BC_Attention:
         st = self._statics(bsz, q_len, block_table.shape[1], x.device)
         x2 = x.view(rows, self.hidden_size)
         q2, kv = st["q"].view(rows, hq * hd), st["kv"]
-        self.q_proj.run(x2, q2)
+        if self.gate_mode == 3:
+            # q_proj emits q and g interleaved per head (attention.cpp:283-289)
+            self.q_proj.run(x2, st["qg_i"])
+            deinterleave_qg(st["qg_i"], q2, st["g"], hd)
+        elif self.gate_mode == 2 and self.qg_ptrs is not None and rows <= 16:
+            pt, ps, pv, K, mcg, mul1 = self.qg_ptrs                       # fused q + g launch (attention.cpp:291-297)
+            exl3_mgemm(x2.view(1, rows, -1), pt, st["qg"], ps, st["xh"], pv, None, None, K, -1, mcg, mul1, -1, -1, 0)
+        else:
+            self.q_proj.run(x2, q2)
+            if self.gate_mode == 1:
+                hgemm(x2, self.g_weight, st["g"])                         # one gate per head (attention.cpp:301-305)
+            elif self.gate_mode == 2:
+                if self.g_weight is not None:
+                    hgemm(x2, self.g_weight, st["g"])
+                else:
+                    _req(self.g_proj is not None, "BC_Attention: more than 16 rows need the separate g projection")
+                    self.g_proj.run(x2, st["g"])
         if self.use_k_as_v:
             # attention.cpp:335-360: V shares the K projection's output, taken before the head norm / RoPE touch K (per-head RMSNorm of it, or a copy)
             self.k_proj.run(x2, kv[0])
@@ -680,6 +715,12 @@ class BC_Attention:
             bt_v, lens_v = st["bt_v"], st["lens_v"]
         attn_decode_qcache(st["q"].view(rows, hq, hd), st["o"].view(rows, hq, hd), self.cache_k, self.cache_k_scales, self.cache_v, self.cache_v_scales,
                            bt_v, lens_v, st["max_len"], workspace=st["ws"], sinks=self.sinks)
+        if self.gate_mode == 1:                                           # attention.cpp:483-494
+            g3 = st["g"].view(bsz, q_len, hq)
+            if self.gate_softplus: mul_softplus_broadcast_(st["o"], g3)
+            else: mul_sigmoid_broadcast_(st["o"], g3)
+        elif self.gate_mode in (2, 3):
+            mul_sigmoid_(st["o"].view(rows, hq * hd), st["g"])
         self.o_proj.run(st["o"].view(rows, hq * hd), y.view(rows, self.hidden_size))
 
 
@@ -912,6 +953,44 @@ def relu2_mul(x, y, z, act_limit: float = 0.0):
 def silu_oai_mul(x, y, z, act_limit: float = 0.0):
     """activation.cu:168-176 (gpt-oss clamped swiglu)"""
     act_mul(x, y, z, ACT_SILU_OAI, act_limit)
+
+
+def mul_sigmoid_(x, y):
+    """activation.cu:526-568: x *= sigmoid(y), fp16, in place"""
+    _dev(x)
+    _req(x.dtype == torch.half and y.dtype == torch.half, "mul_sigmoid_: tensors must be float16")
+    _req(x.numel() == y.numel() and x.is_contiguous() and y.is_contiguous() and x.numel() % 4 == 0, "mul_sigmoid_: contiguous tensors of equal size (a multiple of 4)")
+    _check(_lib.lib().exl3_mul_gate(_p(x), _p(y), x.numel(), 0, 0, _stream(x)))
+
+
+def _mul_gate_broadcast(x, y, softplus: int, name: str):
+    _dev(x)
+    _req(x.dtype == torch.half and y.dtype == torch.half, f"{name}: tensors must be float16")
+    _req(x.dim() == 4, "x must be [B, S, H, D]")
+    _req(y.dim() == 3, "y must be [B, S, H]")
+    _req(x.shape[:3] == y.shape, "x and y have incompatible shapes")
+    _req(x.is_contiguous() and y.is_contiguous(), "x and y must be contiguous")
+    _req(x.shape[3] % 4 == 0, f"{name}: head_dim must be divisible by 4")
+    _check(_lib.lib().exl3_mul_gate(_p(x), _p(y), x.numel(), x.shape[3], softplus, _stream(x)))
+
+
+def mul_sigmoid_broadcast_(x, y):
+    """activation.cu:572-614: x [B, S, H, D] *= sigmoid(y [B, S, H]) broadcast over D (headwise attention gate)"""
+    _mul_gate_broadcast(x, y, 0, "mul_sigmoid_broadcast_")
+
+
+def mul_softplus_broadcast_(x, y):
+    """activation.cu:618-660: x [B, S, H, D] *= softplus(y [B, S, H]) broadcast over D; the gate is evaluated in fp32"""
+    _mul_gate_broadcast(x, y, 1, "mul_softplus_broadcast_")
+
+
+def deinterleave_qg(qg, q, g, head_dim: int):
+    """activation.cu:716-785: [.., heads, (q: head_dim, g: head_dim)] -> contiguous q and g"""
+    _dev(qg)
+    _req(qg.dtype == torch.half and q.dtype == torch.half and g.dtype == torch.half, "deinterleave_qg: tensors must be float16")
+    _req(qg.is_contiguous() and q.is_contiguous() and g.is_contiguous(), "deinterleave_qg: tensors must be contiguous")
+    _req(head_dim % 8 == 0 and q.numel() == g.numel() and qg.numel() == 2 * q.numel() and q.numel() % head_dim == 0, "deinterleave_qg: incompatible shapes")
+    _check(_lib.lib().exl3_deinterleave_qg(_p(qg), _p(q), _p(g), q.numel() // head_dim, int(head_dim), _stream(qg)))
 
 
 def silu_mul_2d(g, u, y):

@@ -491,6 +491,13 @@ int exl3_silu_mul(const void* g, const void* u, void* y, int64_t numel, int in_f
 #define EXL3_ACT_RELU 3
 #define EXL3_ACT_SILU_OAI 4
 int exl3_act_mul(const void* g, const void* u, void* y, int64_t numel, int in_fp32, int act, float act_limit, void* stream);
+
+/* attention output gates   activation.cuh:124-160, activation.cu:526-660 (mul_sigmoid_, mul_sigmoid_broadcast_, mul_softplus_broadcast_):
+ * x fp16 [numel] *= sigmoid(y[i]) (bcast = 0, y [numel]) or *= sigmoid / softplus(y[i / bcast]) (one gate per `bcast` consecutive values = per head).
+ * The sigmoid is fp16 arithmetic like the reference's (activation_kernels.cuh:132-139), the softplus gate fp32 with one rounding of the product. */
+int exl3_mul_gate(void* x, const void* y, int64_t numel, int bcast, int softplus, void* stream);
+/* deinterleave_qg (activation.cu:716-785): qg [heads_total][2][head_dim] fp16 -> q, g [heads_total][head_dim] */
+int exl3_deinterleave_qg(const void* qg, void* q, void* g, int64_t heads_total, int head_dim, void* stream);
 /* x (fp16 or fp32) += y (fp16 or fp32) */
 int exl3_add(void* x, const void* y, int64_t numel, int x_fp32, int y_fp32, void* stream);
 /* softcap(x, y, scale)   softcap.cu:59-100: y = scale * tanh(x / scale) (fp32 math; fp16 or fp32 tensors; y == x allowed); Linear.forward's

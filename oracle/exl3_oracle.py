@@ -319,6 +319,42 @@ def rms_norm(x: np.ndarray, w: np.ndarray | None, eps: float, constant_bias: flo
 
 
 # ------------------------------------------------------------------------------------------
+# Attention output gates     exllamav3_ext/activation_kernels.cuh:132-139, 300-367; activation.cu:716-785
+# ------------------------------------------------------------------------------------------
+
+def _sigmoid_h(y: np.ndarray) -> np.ndarray:
+    """activation_kernels.cuh:132-139: fp16 at every step -- e = fp16(exp(-y)), s = 1 +_h e, r = fp16(1 / s)."""
+    y = np.asarray(y, dtype=np.float16)
+    with np.errstate(over="ignore"):
+        e = np.exp(-y.astype(np.float64)).astype(np.float32).astype(np.float16)
+    sm = (np.float16(1.0) + e).astype(np.float16)
+    with np.errstate(divide="ignore"):
+        return (1.0 / sm.astype(np.float64)).astype(np.float32).astype(np.float16)
+
+
+def mul_sigmoid(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """x * sigmoid(y), product in fp16 (activation_kernels.cuh:300-315); y has x's shape, or one gate per row of x's last dim (:318-336)."""
+    x = np.asarray(x, dtype=np.float16)
+    g = _sigmoid_h(y)
+    if g.shape != x.shape:
+        g = g[..., None]
+    return (x * g).astype(np.float16)
+
+
+def mul_softplus_broadcast(x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """x [.., H, D] * softplus(y [.., H]): gate in fp32 = max(y, 0) + log1p(exp(-|y|)), one rounding of the product (activation_kernels.cuh:338-367)."""
+    yf = np.asarray(y, dtype=np.float16).astype(np.float32)
+    sp = (np.maximum(yf, np.float32(0)) + np.log1p(np.exp(-np.abs(yf)).astype(np.float32)).astype(np.float32)).astype(np.float32)
+    return (np.asarray(x, dtype=np.float16).astype(np.float32) * sp[..., None]).astype(np.float16)
+
+
+def deinterleave_qg(qg: np.ndarray, head_dim: int):
+    """[.., heads * 2 * head_dim] with (q head, g head) pairs per head -> (q, g) [.., heads * head_dim] (activation.cu:716-739)."""
+    v = np.asarray(qg).reshape(qg.shape[:-1] + (-1, 2, head_dim))
+    return (np.ascontiguousarray(v[..., 0, :]).reshape(qg.shape[:-1] + (-1,)), np.ascontiguousarray(v[..., 1, :]).reshape(qg.shape[:-1] + (-1,)))
+
+
+# ------------------------------------------------------------------------------------------
 # RoPE      exllamav3_ext/rope.cu:16-296, util/rope.py:102-140,365-432
 # ------------------------------------------------------------------------------------------
 

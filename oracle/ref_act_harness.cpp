@@ -59,6 +59,25 @@ template <int ACT> static void run(int in_fp32, const void* x, const void* y, ha
 
 extern "C" {
 
+// the reference's attention-gate kernels (activation_kernels.cuh:300-367) run thread by thread: kind 0 mul_sigmoid_kernel_h (y [numel]),
+// 1 mul_sigmoid_broadcast_kernel_h, 2 mul_softplus_broadcast_kernel_h (y [numel / dim]); x is updated in place
+int ref_mul_gate(int kind, uint16_t* x, const uint16_t* y, size_t numel, size_t dim)
+{
+    if (numel % 2) return -1;
+    const size_t pairs = numel / 2;
+    gridDim.x = (unsigned) ((pairs + NUM_THREADS - 1) / NUM_THREADS); blockDim.x = NUM_THREADS;
+    for (unsigned b = 0; b < gridDim.x; ++b)
+        for (unsigned t = 0; t < NUM_THREADS; ++t)
+        {
+            blockIdx.x = b; threadIdx.x = t;
+            if (kind == 0) mul_sigmoid_kernel_h((half*) x, (const half*) y, numel);
+            else if (kind == 1) mul_sigmoid_broadcast_kernel_h((half*) x, (const half*) y, numel, dim);
+            else if (kind == 2) mul_softplus_broadcast_kernel_h((half*) x, (const half*) y, numel, dim);
+            else return -2;
+        }
+    return 0;
+}
+
 // act: the reference's ACT_* codes (activation.cu:14-18).  x, y: fp16 or fp32 [numel]; z: fp16 [numel]
 int ref_act_mul(int act, int in_fp32, const void* x, const void* y, uint16_t* z, float act_limit, size_t numel)
 {

@@ -120,3 +120,33 @@ def test_rms_norm_many_rows_fast_path(dev, dim, rows):
     ext.rms_norm_res_in(_t(x, dev), _t(w, dev), y, rt, 1e-5)
     assert np.allclose(rt.float().cpu().numpy(), r_ref.astype(np.float32), rtol=1e-3, atol=1e-3)
     assert np.allclose(y.float().cpu().numpy(), y_ref.astype(np.float32), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 4, 128), (2, 5, 32, 64), (3, 17, 6, 96)])
+def test_attention_gate_ops_vs_oracle(dev, shape):
+    """mul_sigmoid_ / mul_sigmoid_broadcast_ / mul_softplus_broadcast_ / deinterleave_qg (activation.cu:526-785) against the oracle, which runs
+    against the reference's own kernels on the host (tests/test_oracle_pins.py): the fp16 sigmoid to 2 fp16 ulps of the product (the device exp is not the
+    correctly rounded one), the fp32 softplus gate to 1 ulp, the deinterleave bit for bit; gates from -12 to 12."""
+    from exllamav3_amd import ext
+    from oracle import exl3_oracle as o
+    b, s_, h, d = shape
+    rng = np.random.default_rng(h * d)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x = (rng.standard_normal(shape) * 2).astype(np.float16)
+    y_full = rng.uniform(-12, 12, size=shape).astype(np.float16)
+    y_head = rng.uniform(-12, 12, size=shape[:3]).astype(np.float16)
+    ulps = lambda got, ref: float((np.abs(got.astype(np.float32) - ref.astype(np.float32)) / (np.maximum(np.abs(ref.astype(np.float32)), 2.0 ** -14) * 2.0 ** -10)).max())
+    t = T(x); ext.mul_sigmoid_(t, T(y_full))
+    assert ulps(t.cpu().numpy(), o.mul_sigmoid(x, y_full)) <= 2
+    t = T(x); ext.mul_sigmoid_broadcast_(t, T(y_head))
+    assert ulps(t.cpu().numpy(), o.mul_sigmoid(x, y_head)) <= 2
+    t = T(x); ext.mul_softplus_broadcast_(t, T(y_head))
+    assert ulps(t.cpu().numpy(), o.mul_softplus_broadcast(x, y_head)) <= 1
+    if d % 8 == 0:
+        qg = rng.standard_normal((b, s_, h * 2 * d)).astype(np.float16)
+        q = torch.zeros((b, s_, h * d), dtype=torch.half, device=dev); g = torch.zeros_like(q)
+        ext.deinterleave_qg(T(qg), q, g, d)
+        rq, rg = o.deinterleave_qg(qg, d)
+        assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(g.cpu().numpy(), rg)
+    with pytest.raises(RuntimeError):
+        ext.mul_sigmoid_broadcast_(T(x), T(y_full))                        # y must be [B, S, H]

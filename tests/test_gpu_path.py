@@ -419,12 +419,15 @@ def test_bc_attention_runner_matches_oracle(dev, hd, hq, hkv, fused_kv, head_nor
     with pytest.raises(RuntimeError):
         attn.run(bsz, 17, T(np.zeros((bsz, 17, hidden), np.float16)), y, dl, dbt, 0, dpos, None, None)
     with pytest.raises(RuntimeError):
-        ext.BC_Attention(**{**kw, "gate_mode": 2})
+        ext.BC_Attention(**{**kw, "gate_mode": 2})                              # a full gate without any gate projection (attention.cpp:317)
+    with pytest.raises(RuntimeError):
+        ext.BC_Attention(**{**kw, "hidden_size_padded": hidden + 128})
     with pytest.raises(RuntimeError):
         ext.BC_Attention(**{**kw, "quant_cache": False})
 
 
-@pytest.mark.parametrize("opt", ["v_norm", "k_as_v", "k_as_v_norm", "l4_post_norm", "sinks"])
+@pytest.mark.parametrize("opt", ["v_norm", "k_as_v", "k_as_v_norm", "l4_post_norm", "sinks", "gate_headwise", "gate_headwise_softplus", "gate_full_proj",
+                                 "gate_full_weight", "gate_full_fused", "gate_interleaved"])
 def test_bc_attention_runner_options(dev, opt):
     """The runner's options that compose from this build's ops (attention.cpp:335-395): per-head V norm, V = the K projection's output before head
     norm / RoPE (copied or normed), the rope options (llama-4 query scale + unweighted norm after the rotation), learned attention sinks -- each against the oracle
@@ -434,9 +437,12 @@ def test_bc_attention_runner_options(dev, opt):
     rng = np.random.default_rng(len(opt))
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     mats = {n: o.synth_linear(k, nn, K, seed=90 + i, realistic=True) for i, (n, k, nn) in enumerate(
-        (("q", hidden, hq * hd), ("k", hidden, hkv * hd), ("v", hidden, hkv * hd), ("o", hq * hd, hidden)))}
+        (("q", hidden, hq * hd), ("k", hidden, hkv * hd), ("v", hidden, hkv * hd), ("o", hq * hd, hidden), ("g", hidden, hq * hd),
+         ("qi", hidden, 2 * hq * hd)))}
     dm = {n: tuple(T(a) for a in t) for n, t in mats.items()}
     bc = {n: ext.BC_LinearEXL3(t[0], t[1], t[2], K, None, False, True, None) for n, t in dm.items()}
+    gw_head = (rng.standard_normal((hidden, hq)) * 0.08).astype(np.float16)            # fp16 gate weights: one gate per head / per value
+    gw_full = (rng.standard_normal((hidden, hq * hd)) * 0.08).astype(np.float16)
     G = hkv * hd // 32
     lens = np.array([40, 23], np.int32)
     bt_np = np.array([[1], [0]], np.int32)
@@ -460,6 +466,17 @@ def test_bc_attention_runner_options(dev, opt):
     elif opt == "sinks":
         sinks = np.linspace(-2.0, 5.0, hq).astype(np.float32)
         kw.update(sinks=T(sinks))
+    elif opt.startswith("gate_headwise"):
+        kw.update(gate_mode=1, gate_softplus=opt.endswith("softplus"), g_weight=T(gw_head))
+    elif opt == "gate_full_proj":
+        kw.update(gate_mode=2, g_proj=bc["g"])
+    elif opt == "gate_full_weight":
+        kw.update(gate_mode=2, g_weight=T(gw_full))
+    elif opt == "gate_full_fused":
+        ptr = lambda i: torch.tensor([dm["q"][i].data_ptr(), dm["g"][i].data_ptr()], dtype=torch.long, device=dev)
+        kw.update(gate_mode=2, qg_ptrs_trellis=ptr(0), qg_ptrs_suh=ptr(1), qg_ptrs_svh=ptr(2), qg_K=K, qg_mcg=False, qg_mul1=True)
+    elif opt == "gate_interleaved":
+        kw.update(gate_mode=3, q_proj=bc["qi"])
     else:
         kw.update(l4_scaling_beta=0.3, l4_scaling_original=16, post_rope_norm=True)
         rope_kw = dict(l4_beta=0.3, l4_orig=16, post_rope_norm=True)
@@ -471,6 +488,15 @@ def test_bc_attention_runner_options(dev, opt):
     lin = lambda n, a: o.linear_forward(a, mats[n][0], mats[n][1], mats[n][2], K, cb)
     x2 = x.reshape(bsz, hidden)
     q, k = lin("q", x2), lin("k", x2)
+    gate = None
+    if opt == "gate_interleaved":
+        q, gate = o.deinterleave_qg(lin("qi", x2), hd)
+    elif opt in ("gate_full_proj", "gate_full_fused"):
+        gate = lin("g", x2)
+    elif opt == "gate_full_weight":
+        gate = (x2.astype(np.float32) @ gw_full.astype(np.float32)).astype(np.float16)
+    elif opt.startswith("gate_headwise"):
+        gate = (x2.astype(np.float32) @ gw_head.astype(np.float32)).astype(np.float16)
     v = k.copy() if opt.startswith("k_as_v") else lin("v", x2)
     if opt in ("v_norm", "k_as_v_norm"):
         v = o.rms_norm(v.reshape(bsz * hkv, hd), vw if opt == "v_norm" else None, 1e-5).reshape(bsz, hkv * hd)
@@ -481,6 +507,12 @@ def test_bc_attention_runner_options(dev, opt):
         pk, sc = o.kv_quant(full_k, bits); pv, sv = o.kv_quant(full_v, bits)
         kd[b, :lens[b] + 1] = o.kv_dequant(pk, sc, bits).reshape(-1, hkv, hd); vd[b, :lens[b] + 1] = o.kv_dequant(pv, sv, bits).reshape(-1, hkv, hd)
     ao = o.attn_decode_qcache(q4.reshape(bsz, hq, hd), kd, vd, lens + 1, sinks=sinks if opt == "sinks" else None)
+    if opt == "gate_headwise_softplus":
+        ao = o.mul_softplus_broadcast(ao, gate)                            # (bsz, hq, hd) x (bsz, hq)
+    elif opt == "gate_headwise":
+        ao = o.mul_sigmoid(ao, gate)
+    elif gate is not None:
+        ao = o.mul_sigmoid(ao.reshape(bsz, -1), gate)
     ref = lin("o", ao.reshape(bsz, -1)).astype(np.float32)
     got = y.float().cpu().numpy().reshape(bsz, hidden)
     assert np.isfinite(got).all()
