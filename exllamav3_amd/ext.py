@@ -562,7 +562,7 @@ class BC_Attention:
     Same constructor arguments and run() signature as the reference's class.  This build covers the Llama / Mixtral subset of it:
     quantized cache (`quant_cache`), q_len 1 .. 16 new tokens per sequence, bsz <= 8; V norm, K-as-V and the rope options (llama-4 query scale,
     norm after the rotation, `rotate_dims`) are composed from the ops of this module as the reference composes them (attention.cpp:335-395); no
-    padded hidden dim: that raises at construction, nothing degrades silently.  Learned attention sinks go to the merge kernel; the output gates
+    Learned attention sinks go to the merge kernel; a padded hidden dim is staged through zero-padded statics as in the reference; the output gates
     (headwise / full / interleaved, sigmoid or softplus: attention.cpp:283-333, 483-494) are the reference's own op sequence over this module's ops.
     The reference's slot machinery exists to hold AOT-compiled Triton kernels and their statics: needs_configure() is always False here and
     configure_slot() accepts and ignores its arguments; capture the whole decode step in one hipGraph instead (all launches of run() are
@@ -586,7 +586,7 @@ class BC_Attention:
         _req(g_weight is None or (g_weight.dtype == torch.half and g_weight.dim() == 2 and g_weight.shape[0] == hidden_size
                                   and g_weight.shape[1] == (num_q_heads if gate_mode == 1 else num_q_heads * head_dim)),
              "BC_Attention: g_weight must be float16 (hidden, heads) for the headwise gate, (hidden, heads * head_dim) for the full gate")
-        _req(hidden_size_padded == hidden_size, "BC_Attention: padded hidden dim is outside this build")
+        _req(hidden_size_padded >= hidden_size and hidden_size_padded % 128 == 0, "BC_Attention: hidden_size_padded must be a multiple of 128 >= hidden_size")
         _req(not use_k_as_v or k_proj is not None, "BC_Attention: K-as-V needs the separate k projection")
         _req(head_dim in (64, 128) and num_q_heads % num_kv_heads == 0, "BC_Attention: head_dim must be 64 or 128")
         _req(page_size == 256, "BC_Attention: page size must be 256")
@@ -595,6 +595,7 @@ class BC_Attention:
         _req(not v_norm or v_norm_w is None or v_norm_w.numel() == head_dim, "BC_Attention: v_norm weight must have head_dim entries")
         _req(inv_freq is not None or (q_norm is None and k_norm is None), "BC_Attention: head norms ride on the rope kernel (NoPE modules cannot have them)")
         self.num_q_heads, self.num_kv_heads, self.head_dim, self.hidden_size, self.page_size = num_q_heads, num_kv_heads, head_dim, hidden_size, page_size
+        self.hidden_size_padded = int(hidden_size_padded)
         self.q_proj, self.k_proj, self.v_proj, self.o_proj = q_proj, k_proj, v_proj, o_proj
         self.kv_ptrs = (kv_ptrs_trellis, kv_ptrs_suh, kv_ptrs_svh, int(kv_K), bool(kv_mcg), bool(kv_mul1)) if kv_ptrs_trellis is not None else None
         self.q_norm, self.k_norm, self.norm_eps, self.norm_constant_bias = q_norm, k_norm, norm_eps, norm_constant_bias
@@ -627,9 +628,14 @@ class BC_Attention:
                 "kv": torch.empty((2, rows, hkv * hd), dtype=torch.half, device=dev),
                 "o": torch.empty((bsz, q_len, hq, hd), dtype=torch.half, device=dev),
                 "lens": torch.empty((bsz,), dtype=torch.int32, device=dev),
-                "xh": torch.empty((2, rows, self.hidden_size), dtype=torch.half, device=dev),
+                "xh": torch.empty((2, rows, self.hidden_size_padded), dtype=torch.half, device=dev),
                 "max_len": max_len,
             }
+            if self.hidden_size_padded != self.hidden_size:
+                # attention.cpp:268-280, 497-508: the input is staged through a zero-padded static (the projections' K is the padded width), o_proj
+                # writes the padded width and the exact-width columns are copied out
+                st["xp"] = torch.zeros((rows, self.hidden_size_padded), dtype=torch.half, device=dev)
+                st["yp"] = torch.empty((rows, self.hidden_size_padded), dtype=torch.half, device=dev)
             if self.gate_mode == 1:
                 st["g"] = torch.empty((rows, hq), dtype=torch.half, device=dev)
             elif self.gate_mode == 2:
@@ -663,6 +669,9 @@ class BC_Attention:
         rows = bsz * q_len
         st = self._statics(bsz, q_len, block_table.shape[1], x.device)
         x2 = x.view(rows, self.hidden_size)
+        if "xp" in st:
+            st["xp"][:, :self.hidden_size].copy_(x2)
+            x2 = st["xp"]
         q2, kv = st["q"].view(rows, hq * hd), st["kv"]
         if self.gate_mode == 3:
             # q_proj emits q and g interleaved per head (attention.cpp:283-289)
@@ -721,7 +730,11 @@ class BC_Attention:
             else: mul_sigmoid_broadcast_(st["o"], g3)
         elif self.gate_mode in (2, 3):
             mul_sigmoid_(st["o"].view(rows, hq * hd), st["g"])
-        self.o_proj.run(st["o"].view(rows, hq * hd), y.view(rows, self.hidden_size))
+        if "yp" in st:
+            self.o_proj.run(st["o"].view(rows, hq * hd), st["yp"])
+            y.view(rows, self.hidden_size).copy_(st["yp"][:, :self.hidden_size])
+        else:
+            self.o_proj.run(st["o"].view(rows, hq * hd), y.view(rows, self.hidden_size))
 
 
 def __getattr__(name: str):

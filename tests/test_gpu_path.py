@@ -421,13 +421,13 @@ def test_bc_attention_runner_matches_oracle(dev, hd, hq, hkv, fused_kv, head_nor
     with pytest.raises(RuntimeError):
         ext.BC_Attention(**{**kw, "gate_mode": 2})                              # a full gate without any gate projection (attention.cpp:317)
     with pytest.raises(RuntimeError):
-        ext.BC_Attention(**{**kw, "hidden_size_padded": hidden + 128})
+        ext.BC_Attention(**{**kw, "hidden_size_padded": hidden + 64})           # not a multiple of 128
     with pytest.raises(RuntimeError):
         ext.BC_Attention(**{**kw, "quant_cache": False})
 
 
 @pytest.mark.parametrize("opt", ["v_norm", "k_as_v", "k_as_v_norm", "l4_post_norm", "sinks", "gate_headwise", "gate_headwise_softplus", "gate_full_proj",
-                                 "gate_full_weight", "gate_full_fused", "gate_interleaved"])
+                                 "gate_full_weight", "gate_full_fused", "gate_interleaved", "padded_hidden"])
 def test_bc_attention_runner_options(dev, opt):
     """The runner's options that compose from this build's ops (attention.cpp:335-395): per-head V norm, V = the K projection's output before head
     norm / RoPE (copied or normed), the rope options (llama-4 query scale + unweighted norm after the rotation), learned attention sinks -- each against the oracle
@@ -477,14 +477,19 @@ def test_bc_attention_runner_options(dev, opt):
         kw.update(gate_mode=2, qg_ptrs_trellis=ptr(0), qg_ptrs_suh=ptr(1), qg_ptrs_svh=ptr(2), qg_K=K, qg_mcg=False, qg_mul1=True)
     elif opt == "gate_interleaved":
         kw.update(gate_mode=3, q_proj=bc["qi"])
+    elif opt == "padded_hidden":
+        kw.update(hidden_size=hidden - 32)                                  # the model's width is 480, the quantized linears are padded to 512
     else:
         kw.update(l4_scaling_beta=0.3, l4_scaling_original=16, post_rope_norm=True)
         rope_kw = dict(l4_beta=0.3, l4_orig=16, post_rope_norm=True)
     attn = ext.BC_Attention(**kw)
     x = rng.standard_normal((bsz, 1, hidden)).astype(np.float16)
     positions = np.array([40, 30], np.int32)
-    y = torch.full((bsz, 1, hidden), float("nan"), dtype=torch.half, device=dev)
-    attn.run(bsz, 1, T(x), y, T(lens), T(bt_np), 0, T(positions), None, None)
+    hw = hidden - 32 if opt == "padded_hidden" else hidden                 # width of x and y as the caller sees them
+    if opt == "padded_hidden":
+        x[..., hw:] = 0
+    y = torch.full((bsz, 1, hw), float("nan"), dtype=torch.half, device=dev)
+    attn.run(bsz, 1, T(x[..., :hw]), y, T(lens), T(bt_np), 0, T(positions), None, None)
     lin = lambda n, a: o.linear_forward(a, mats[n][0], mats[n][1], mats[n][2], K, cb)
     x2 = x.reshape(bsz, hidden)
     q, k = lin("q", x2), lin("k", x2)
@@ -513,8 +518,8 @@ def test_bc_attention_runner_options(dev, opt):
         ao = o.mul_sigmoid(ao, gate)
     elif gate is not None:
         ao = o.mul_sigmoid(ao.reshape(bsz, -1), gate)
-    ref = lin("o", ao.reshape(bsz, -1)).astype(np.float32)
-    got = y.float().cpu().numpy().reshape(bsz, hidden)
+    ref = lin("o", ao.reshape(bsz, -1)).astype(np.float32)[:, :hw]
+    got = y.float().cpu().numpy().reshape(bsz, hw)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
 
