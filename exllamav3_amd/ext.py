@@ -557,12 +557,13 @@ class BC_LinearFP16:
 
 
 class BC_Attention:
-    """libtorch/attention.h:24-228, attention.cpp:246-504: the decode attention block of one layer as one runner -- q / k / v projections,
-    head norms + RoPE, append to the quantized paged cache, flash-decoding attention straight from the quantized cache, o_proj.
-    Same constructor arguments and run() signature as the reference's class.  This build covers the Llama / Mixtral subset of it:
-    quantized cache (`quant_cache`), q_len 1 .. 16 new tokens per sequence, bsz <= 8; V norm, K-as-V and the rope options (llama-4 query scale,
-    norm after the rotation, `rotate_dims`) are composed from the ops of this module as the reference composes them (attention.cpp:335-395); no
-    Learned attention sinks go to the merge kernel; a padded hidden dim is staged through zero-padded statics as in the reference; the output gates
+    """libtorch/attention.h:24-228, attention.cpp:246-504: the decode attention block of one layer as one runner -- q / k / v (/ gate) projections,
+    head norms + RoPE, append to the paged cache, attention over the cache, output gate, o_proj.  Same constructor arguments and run() signature as
+    the reference's class; q_len 1 .. 16 new tokens per sequence, bsz <= 8, head_dim 64 / 128, page size 256.
+    Quantized cache (`quant_cache`, 2-8 bits): flash-decoding attention straight from the quantized pages, learned attention sinks in its merge
+    kernel.  fp16 cache: rows appended by index, causal attention of the chunk over the fp16 pages (the prefill path's flash-attention kernel; no
+    sinks).  V norm, K-as-V and the rope options (llama-4 query scale, norm after the rotation, `rotate_dims`) are composed from the ops of this
+    module as the reference composes them (attention.cpp:335-395); a padded hidden dim is staged through zero-padded statics; the output gates
     (headwise / full / interleaved, sigmoid or softplus: attention.cpp:283-333, 483-494) are the reference's own op sequence over this module's ops.
     The reference's slot machinery exists to hold AOT-compiled Triton kernels and their statics: needs_configure() is always False here and
     configure_slot() accepts and ignores its arguments; capture the whole decode step in one hipGraph instead (all launches of run() are
@@ -578,7 +579,12 @@ class BC_Attention:
                  v_norm=False, v_norm_w=None, v_norm_eps=1e-6, v_norm_constant_bias=0.0, v_norm_constant_scale=1.0, inv_freq=None,
                  rope_style=2, attn_factor=1.0, l4_scaling_beta=0.0, l4_scaling_original=0, post_rope_norm=False, rotate_dims=1,
                  quant_cache=True, cache_k=None, cache_v=None, cache_k_scales=None, cache_v_scales=None, xh=None, h32=None, sinks=None):
-        _req(quant_cache and cache_k_scales is not None and cache_v_scales is not None, "BC_Attention: this build attends over the quantized paged cache only")
+        _req(not quant_cache or (cache_k_scales is not None and cache_v_scales is not None), "BC_Attention: a quantized cache needs its scale tensors")
+        _req(quant_cache or (cache_k is not None and cache_k.dtype == torch.half and cache_k.dim() == 4 and cache_k.shape[1] == page_size
+                             and cache_k.shape[2] == num_kv_heads and cache_k.shape[3] == head_dim and cache_v is not None and cache_v.shape == cache_k.shape),
+             "BC_Attention: an unquantized cache is float16 (pages, page_size, kv_heads, head_dim)")
+        _req(quant_cache or sinks is None, "BC_Attention: attention sinks need the quantized cache (the merge kernel of the quant-cache-direct attention)")
+        self.quant_cache = bool(quant_cache)
         _req(gate_mode in (0, 1, 2, 3), "BC_Attention: gate_mode must be 0 (none), 1 (headwise), 2 (full) or 3 (interleaved)")
         _req(gate_mode != 1 or g_weight is not None, "BC_Attention: headwise gate requires the fp16 gate weight")                        # attention.cpp:303
         _req(gate_mode != 2 or g_weight is not None or g_proj is not None or qg_ptrs_trellis is not None,
@@ -712,6 +718,18 @@ class BC_Attention:
             rope(st["q"], st["q"], k4, k4, ivf, int(position), positions, position_ids, self.rope_style, self.attn_factor,
                  self.q_norm, self.k_norm, self.norm_eps, self.norm_constant_bias, self.l4_beta, max(self.l4_orig, 1), self.post_rope_norm,
                  self.rotate_dims, 0)
+        if not self.quant_cache:
+            # fp16 paged cache (attention.cpp:400-418 k_update, then the same attention over fp16 pages): rows appended by index (no host read: capturable),
+            # causal attention of the chunk over the pages -- the flash-attention kernel of the prefill path, which a one-token chunk reduces to decode attention
+            pos = cache_seqlens.view(bsz, 1) + torch.arange(q_len, dtype=torch.int32, device=x.device).view(1, q_len)
+            pg = torch.gather(block_table, 1, (pos // self.page_size).long())
+            flat = (pg.long() * self.page_size + (pos % self.page_size).long()).view(-1)
+            self.cache_k.view(-1, hkv, hd).index_copy_(0, flat, k4.reshape(rows, hkv, hd))
+            self.cache_v.view(-1, hkv, hd).index_copy_(0, flat, v4.reshape(rows, hkv, hd))
+            torch.add(cache_seqlens, q_len, out=st["lens"])
+            attn_prefill_paged(st["q"], st["o"], self.cache_k, self.cache_v, block_table, st["lens"])
+            self._finish(st, bsz, q_len, rows, y)
+            return
         quant_cache_paged(k4.view(bsz, q_len, -1), self.cache_k, self.cache_k_scales, v4.view(bsz, q_len, -1), self.cache_v, self.cache_v_scales,
                           cache_seqlens, block_table, self.page_size, q_len)
         if q_len == 1:
@@ -724,6 +742,11 @@ class BC_Attention:
             bt_v, lens_v = st["bt_v"], st["lens_v"]
         attn_decode_qcache(st["q"].view(rows, hq, hd), st["o"].view(rows, hq, hd), self.cache_k, self.cache_k_scales, self.cache_v, self.cache_v_scales,
                            bt_v, lens_v, st["max_len"], workspace=st["ws"], sinks=self.sinks)
+        self._finish(st, bsz, q_len, rows, y)
+
+    def _finish(self, st, bsz: int, q_len: int, rows: int, y):
+        """output gate + o_proj (attention.cpp:483-508)"""
+        hq, hd = self.num_q_heads, self.head_dim
         if self.gate_mode == 1:                                           # attention.cpp:483-494
             g3 = st["g"].view(bsz, q_len, hq)
             if self.gate_softplus: mul_softplus_broadcast_(st["o"], g3)

@@ -423,7 +423,7 @@ def test_bc_attention_runner_matches_oracle(dev, hd, hq, hkv, fused_kv, head_nor
     with pytest.raises(RuntimeError):
         ext.BC_Attention(**{**kw, "hidden_size_padded": hidden + 64})           # not a multiple of 128
     with pytest.raises(RuntimeError):
-        ext.BC_Attention(**{**kw, "quant_cache": False})
+        ext.BC_Attention(**{**kw, "quant_cache": False})                        # the cache tensors here are the quantized words, not fp16 pages
 
 
 @pytest.mark.parametrize("opt", ["v_norm", "k_as_v", "k_as_v_norm", "l4_post_norm", "sinks", "gate_headwise", "gate_headwise_softplus", "gate_full_proj",
@@ -522,6 +522,69 @@ def test_bc_attention_runner_options(dev, opt):
     got = y.float().cpu().numpy().reshape(bsz, hw)
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 3e-2
+
+
+@pytest.mark.parametrize("hd,hq,hkv,q_len", [(128, 4, 2, 1), (64, 8, 2, 1), (128, 8, 2, 7)])
+def test_bc_attention_runner_fp16_cache(dev, hd, hq, hkv, q_len):
+    """BC_Attention over an UNQUANTIZED paged cache (quant_cache = False, attention.cpp:400-418): the new rows land in the fp16 pages at
+    cache_seqlens[b] + t, attention runs causally over the pages; one new token and a 7-token chunk, contexts ending inside / on a page edge and an
+    empty one, scattered pages; against the oracle (fp32 softmax attention over the same fp16 rows); graph replay reproduces the bits."""
+    from exllamav3_amd import ext
+    hidden, K, cb, page, bsz, pps = 512, 4, 2, 256, 3, 2
+    rng = np.random.default_rng(hd + q_len)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mats = {n: o.synth_linear(k, nn, K, seed=110 + i, realistic=True) for i, (n, k, nn) in enumerate(
+        (("q", hidden, hq * hd), ("k", hidden, hkv * hd), ("v", hidden, hkv * hd), ("o", hq * hd, hidden)))}
+    bc = {n: ext.BC_LinearEXL3(T(t[0]), T(t[1]), T(t[2]), K, None, False, True, None) for n, t in mats.items()}
+    npages = bsz * pps
+    bt_np = rng.permutation(npages).reshape(bsz, pps).astype(np.int32)
+    lens = np.array([300, 0, 256 - q_len if q_len > 1 else 256], np.int32)
+    ck = rng.standard_normal((bsz, pps * page, hkv, hd)).astype(np.float16); cv = rng.standard_normal((bsz, pps * page, hkv, hd)).astype(np.float16)
+    kp = np.zeros((npages, page, hkv, hd), np.float16); vp = np.zeros_like(kp)
+    for b in range(bsz):
+        for pg in range(pps):
+            kp[bt_np[b, pg]] = ck[b, pg * page:(pg + 1) * page]; vp[bt_np[b, pg]] = cv[b, pg * page:(pg + 1) * page]
+    inv_freq = (1.0 / (10000.0 ** (np.arange(0, hd, 2, dtype=np.float32) / hd))).astype(np.float32)
+    dkp, dvp = T(kp), T(vp)
+    attn = ext.BC_Attention(num_q_heads=hq, num_kv_heads=hkv, head_dim=hd, hidden_size=hidden, hidden_size_padded=hidden, page_size=page,
+                            q_proj=bc["q"], k_proj=bc["k"], v_proj=bc["v"], o_proj=bc["o"], norm_eps=1e-6, inv_freq=T(inv_freq), rope_style=2, attn_factor=1.0,
+                            quant_cache=False, cache_k=dkp, cache_v=dvp, xh=None, h32=None)
+    x = rng.standard_normal((bsz, q_len, hidden)).astype(np.float16)
+    y = torch.full((bsz, q_len, hidden), float("nan"), dtype=torch.half, device=dev)
+    dl, dbt = T(lens), T(bt_np)
+    attn.run(bsz, q_len, T(x), y, dl, dbt, 0, dl, None, None)                 # rope positions = positions in the cache
+    lin = lambda n, a: o.linear_forward(a, mats[n][0], mats[n][1], mats[n][2], K, cb)
+    x2 = x.reshape(bsz * q_len, hidden)
+    q, k, v = lin("q", x2), lin("k", x2), lin("v", x2)
+    q4, k4 = o.rope(q.reshape(bsz, q_len, hq, hd), k.reshape(bsz, q_len, hkv, hd), inv_freq, positions=lens, rope_mode=o.ROPE_NEOX, norm_eps=1e-6)
+    v4 = v.reshape(bsz, q_len, hkv, hd)
+    ao = np.zeros((bsz, q_len, hq, hd), np.float16)
+    for b in range(bsz):
+        fk = np.concatenate([ck[b, :lens[b]], k4[b]]); fv = np.concatenate([cv[b, :lens[b]], v4[b]])
+        for t in range(q_len):
+            n = lens[b] + t + 1
+            ao[b, t] = o.attn_decode_qcache(q4[b, t][None], fk[None, :n], fv[None, :n], [n])[0]
+    ref = lin("o", ao.reshape(bsz * q_len, -1)).astype(np.float32)
+    got = y.float().cpu().numpy().reshape(bsz * q_len, hidden)
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
+    # the appended rows are where the block table says (K after rope, to GEMV tolerance)
+    for b in range(bsz):
+        for t in (0, q_len - 1):
+            pos = lens[b] + t
+            row = dkp[bt_np[b, pos // page], pos % page].float().cpu().numpy()
+            assert np.abs(row - k4[b, t].astype(np.float32)).max() < 3e-2 * max(1.0, np.abs(k4[b, t].astype(np.float32)).max())
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    dx = T(x)
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            attn.run(bsz, q_len, dx, y, dl, dbt, 0, dl, None, None)
+    y.zero_(); g.replay(); torch.cuda.synchronize()
+    assert np.array_equal(y.float().cpu().numpy().reshape(bsz * q_len, hidden), got)
+    with pytest.raises(RuntimeError):
+        ext.BC_Attention(num_q_heads=hq, num_kv_heads=hkv, head_dim=hd, hidden_size=hidden, hidden_size_padded=hidden, page_size=page, q_proj=bc["q"], k_proj=bc["k"],
+                         v_proj=bc["v"], o_proj=bc["o"], inv_freq=T(inv_freq), quant_cache=False, cache_k=dkp, cache_v=dvp, sinks=torch.zeros(hq, device=dev))
 
 
 @pytest.mark.parametrize("hd,hq,hkv,q_len,fused_kv", [(128, 4, 2, 5, False), (64, 8, 2, 16, True), (128, 8, 2, 16, False)])
