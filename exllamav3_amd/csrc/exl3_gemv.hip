@@ -88,12 +88,20 @@ void exl3_gemv_reduce_kernel(const GemvArgs a, int total_colblocks)
 }
 
 // Final step of the weighted (MoE) mgemm: every group of `stride` consecutive slots is summed into output row-block t, in slot order
-// (fp16: sequential __hadd from zero, fp32: sequential adds -- quant/exl3_gemm_kernel.cuh:241-290).  Filtered-out slots were never written
-// by this launch; like the reference, the caller zero-fills C when it uses an expert range together with weights.
-__global__ void mgemm_slot_reduce_kernel(void* C, int c_fp32, int num_tokens, int stride, int64_t mn)
+// (fp16: sequential __hadd from zero, fp32: sequential adds -- quant/exl3_gemm_kernel.cuh:241-290).  With an expert range the in-range slots were
+// compacted to the front and only THEY are summed (the reference continues with bszm = the in-range count, exl3_gemm_kernel.cuh:101-127: slots this
+// launch never wrote do not enter the sum, no in-range slot at all gives zeros) -- C needs no zero fill.
+__global__ void mgemm_slot_reduce_kernel(void* C, int c_fp32, int num_tokens, int stride, int64_t mn, const int64_t* __restrict__ indices, int bszm,
+                                         int min_index, int max_index)
 {
     const int64_t col = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= mn) return;
+    if (min_index >= 0)
+    {
+        int cnt = 0;
+        for (int i = 0; i < bszm; ++i) { const int64_t ix = indices[i]; cnt += (ix >= min_index && ix < max_index) ? 1 : 0; }
+        stride = cnt;                                                // num_tokens == 1 with an expert range (host-checked)
+    }
     for (int t = 0; t < num_tokens; ++t)
     {
         if (c_fp32)
@@ -864,7 +872,8 @@ static int mgemm_indexed_impl(const void* A, const void* act_u, int bszm_in, con
     if (weights)
     {
         const int64_t mn = (int64_t) m * n;
-        mgemm_slot_reduce_kernel<<<dim3((unsigned) ((mn + 255) / 256)), dim3(256), 0, (hipStream_t) stream>>>(C, c_fp32, num_tokens, bszm / num_tokens, mn);
+        mgemm_slot_reduce_kernel<<<dim3((unsigned) ((mn + 255) / 256)), dim3(256), 0, (hipStream_t) stream>>>(C, c_fp32, num_tokens, bszm / num_tokens, mn, indices, bszm,
+                                                                                                               min_index, max_index);
         return exl3_check_launch("exl3_mgemm slot reduce") < 0 ? EXL3_ERR_HIP : rc;
     }
     return rc;

@@ -1271,6 +1271,131 @@ class BC_GatedMLP:
             add(d2, dn.bias.view(1, -1).expand(m, -1).contiguous() if m > 1 else dn.bias)
 
 
+class BC_BlockSparseMLP:
+    """libtorch/blocksparse_mlp.h:24-205, blocksparse_mlp.cpp:66-696: the sparse-MoE block's runner the reference's modules/block_sparse_mlp.py:917
+    constructs -- same constructor argument list (the statics of the Python side) and the same three entry points, each the reference's own op
+    sequence over this module's ops:
+      run_bszN(y, selected_experts, routing_weights)    1 .. MAX_BSZN tokens: indexed exl3_mgemm for gate and up over the selected experts (expert
+                                                        range [min_expert, max_expert) under expert parallelism), activation, weighted indexed down
+                                                        exl3_mgemm whose rows 0 .. tokens - 1 of out_d hold the reductions (+ shared experts)
+      run_single_expert(y, e)                            one expert's MLP on <= 32 rows through the quantized kernels, result in out_d2[:rows]
+      run_single_expert_dq(y, e, yh, interm, interm_a, out)   the same through reconstruct + hgemm (large row counts)
+    Not covered (they raise at construction): per-expert biases and the sigmoid-gated shared expert (gpt-oss / Qwen-MoE families).  The reference
+    captures one CUDA graph per batch size inside the class; here run_*() is plain launches -- capture the surrounding step in one hipGraph."""
+
+    MAX_BSZN = 16
+    TEMP_ROWS_GRAPH = 32
+
+    def __init__(self, yh2, yh, interm_gu, interm_g, interm_u, interm_a, interm_a2, out_d, out_d2, out_d_sh, z, dq_temp_up, dq_temp_down,
+                 min_expert, max_expert, gate_ptrs_trellis, gate_ptrs_suh, gate_ptrs_svh, gate_K, gate_mcg, gate_mul1,
+                 up_ptrs_trellis, up_ptrs_suh, up_ptrs_svh, up_K, up_mcg, up_mul1,
+                 down_ptrs_trellis, down_ptrs_suh, down_ptrs_svh, down_K, down_mcg, down_mul1,
+                 act_silu, act_gelu, act_silu_oai, shared_experts, shared_gate, act_limit, gates, ups, downs,
+                 gu_trellis_ptr, gu_suh_ptr, gu_svh_ptr, a_gather, gate_bias_ptrs=None, up_bias_ptrs=None, down_bias_ptrs=None,
+                 y_pad=None, out_trim=None, act_relu2=False):
+        self.gated = len(gates) > 0
+        _req(self.gated or act_relu2, "BC_BlockSparseMLP: gateless experts require act_relu2")                                  # blocksparse_mlp.cpp:493
+        _req(not (shared_experts is not None and (down_bias_ptrs is not None or y_pad is not None)),
+             "BC_BlockSparseMLP: shared experts not supported with expert biases or padded dims")                               # :494
+        _req(gate_bias_ptrs is None and up_bias_ptrs is None and down_bias_ptrs is None, "BC_BlockSparseMLP: per-expert biases are outside this build")
+        _req(shared_gate is None, "BC_BlockSparseMLP: the sigmoid-gated shared expert is outside this build")
+        _req(max_expert <= 512, "BC_BlockSparseMLP: Too many experts")
+        self.yh2, self.yh, self.interm_gu, self.interm_g, self.interm_u, self.interm_a, self.interm_a2 = yh2, yh, interm_gu, interm_g, interm_u, interm_a, interm_a2
+        self.out_d, self.out_d2, self.out_d_sh, self.dq_temp_up, self.dq_temp_down = out_d, out_d2, out_d_sh, dq_temp_up, dq_temp_down
+        self.min_expert, self.max_expert = int(min_expert), int(max_expert)
+        self.gate_t = (gate_ptrs_trellis, gate_ptrs_suh, gate_ptrs_svh, int(gate_K), bool(gate_mcg), bool(gate_mul1))
+        self.up_t = (up_ptrs_trellis, up_ptrs_suh, up_ptrs_svh, int(up_K), bool(up_mcg), bool(up_mul1))
+        self.down_t = (down_ptrs_trellis, down_ptrs_suh, down_ptrs_svh, int(down_K), bool(down_mcg), bool(down_mul1))
+        self.act = (ACT_RELU if not self.gated else ACT_SILU if act_silu else ACT_GELU if act_gelu else ACT_SILU_OAI if act_silu_oai else ACT_RELU2)
+        _req(not self.gated or act_silu or act_gelu or act_silu_oai or act_relu2, "BC_BlockSparseMLP: no activation selected")
+        self.act_limit = float(act_limit)
+        self.shared_experts, self.gates, self.ups, self.downs = shared_experts, list(gates), list(ups), list(downs)
+        self.a_gather, self.y_pad, self.out_trim = a_gather, y_pad, out_trim
+        self._flat_token = {}
+
+    def _act(self, g, u, a):
+        # non-gated: relu(u) * u = relu^2(u) (blocksparse_mlp.cpp:186-188); gated: the activation named at construction, with its clamps
+        act_mul(u if not self.gated else g, u, a, self.act, self.act_limit)
+
+    def run_bszN(self, y: torch.Tensor, selected_experts: torch.Tensor, routing_weights: torch.Tensor):
+        _dev(y)
+        num_tokens = int(y.shape[0])
+        _req(1 <= num_tokens <= self.MAX_BSZN, "run_bszN: bsz out of supported range")
+        numex = int(selected_experts.shape[-1])
+        bszm = num_tokens * numex
+        if num_tokens == 1:
+            src = y
+            if self.y_pad is not None:                                    # padded hidden dim: stage through the zero-padded static (blocksparse_mlp.cpp:86-95)
+                self.y_pad[0:1, :y.shape[1]].copy_(y)
+                src = self.y_pad[0:1]
+            x_dense = src.unsqueeze(0)
+            yi = src.view(1, 1, -1)
+        else:
+            ft = self._flat_token.get(num_tokens)
+            if ft is None:
+                ft = torch.arange(num_tokens, dtype=torch.long, device=y.device).unsqueeze(1).expand(num_tokens, numex).reshape(-1).contiguous()
+                self._flat_token[num_tokens] = ft
+            src = y
+            if self.y_pad is not None:
+                self.y_pad[:num_tokens, :y.shape[1]].copy_(y)
+                src = self.y_pad[:num_tokens]
+            x_dense = src.unsqueeze(0)
+            ag = self.a_gather[:bszm]
+            ag[:, :src.shape[1]].copy_(src.index_select(0, ft))         # every (token, slot) pair gets a copy of its token's row
+            yi = ag.view(bszm, 1, ag.shape[1])
+        yh_n, g_n, u_n, a_n, o_n = self.yh[:bszm], self.interm_g[:bszm], self.interm_u[:bszm], self.interm_a[:bszm], self.out_d[:bszm]
+        sel, w = selected_experts.reshape(1, -1), routing_weights.reshape(1, -1)
+        if self.gated:
+            pt, ps, pv, K, mcg, mul1 = self.gate_t
+            exl3_mgemm(yi, pt, g_n, ps, yh_n, pv, sel, None, K, -1, mcg, mul1, self.min_expert, self.max_expert, 0, num_tokens)
+        pt, ps, pv, K, mcg, mul1 = self.up_t
+        exl3_mgemm(yi, pt, u_n, ps, yh_n, pv, sel, None, K, -1, mcg, mul1, self.min_expert, self.max_expert, 0, num_tokens)
+        self._act(g_n, u_n, a_n)
+        pt, ps, pv, K, mcg, mul1 = self.down_t
+        exl3_mgemm(a_n, pt, o_n, ps, g_n, pv, sel, w, K, -1, mcg, mul1, self.min_expert, self.max_expert, 0, num_tokens)
+        if self.out_trim is not None:
+            self.out_trim[:num_tokens].copy_(o_n[:num_tokens].squeeze(1)[:, :self.out_trim.shape[1]])
+        if self.shared_experts is not None:
+            sh = self.out_d_sh[:, :num_tokens]
+            self.shared_experts.run_bszN(x_dense, sh)
+            add(o_n[:num_tokens].view(num_tokens, -1), sh.view(num_tokens, -1))
+
+    def run_single_expert(self, y: torch.Tensor, expert_idx: int):
+        _dev(y)
+        bsz = int(y.shape[0])
+        _req(bsz <= self.TEMP_ROWS_GRAPH, "run_single_expert: too many rows")
+        ai, oi = self.interm_a2[:bsz], self.out_d2[:bsz]
+        gi, ui = self.interm_gu[:bsz], self.interm_gu[bsz:2 * bsz]
+        e = int(expert_idx)
+        if self.gated:
+            self.gates[e].run(y, gi)
+        self.ups[e].run(y, ui)
+        self._act(gi, ui, ai)
+        self.downs[e].run(ai, oi)
+
+    def run_single_expert_dq(self, y: torch.Tensor, expert_idx: int, yh: torch.Tensor, interm: torch.Tensor, interm_a: torch.Tensor, out: torch.Tensor):
+        """blocksparse_mlp.cpp:640-696: rotate -> reconstruct W_hat into the shared scratch -> hgemm -> rotate back, per matrix."""
+        _dev(y)
+        bsz, e = int(y.shape[0]), int(expert_idx)
+        yh1, yh2 = yh[:bsz], yh[bsz:2 * bsz]
+        i1, i2 = interm[:bsz], interm[bsz:2 * bsz]
+        up, dn = self.ups[e], self.downs[e]
+        if self.gated:
+            gt = self.gates[e]
+            had_r_128(y, yh1, gt.suh, None, 1.0); had_r_128(y, yh2, up.suh, None, 1.0)
+            reconstruct(self.dq_temp_up, gt.trellis, self.gate_t[3], self.gate_t[4], self.gate_t[5]); hgemm(yh1, self.dq_temp_up, i1)
+            reconstruct(self.dq_temp_up, up.trellis, self.up_t[3], self.up_t[4], self.up_t[5]); hgemm(yh2, self.dq_temp_up, i2)
+            had_r_128(i1, i1, None, gt.svh, 1.0); had_r_128(i2, i2, None, up.svh, 1.0)
+        else:
+            had_r_128(y, yh2, up.suh, None, 1.0)
+            reconstruct(self.dq_temp_up, up.trellis, self.up_t[3], self.up_t[4], self.up_t[5]); hgemm(yh2, self.dq_temp_up, i2)
+            had_r_128(i2, i2, None, up.svh, 1.0)
+        self._act(i1, i2, interm_a)
+        had_r_128(interm_a, interm_a, dn.suh, None, 1.0)
+        reconstruct(self.dq_temp_down, dn.trellis, self.down_t[3], self.down_t[4], self.down_t[5]); hgemm(interm_a, self.dq_temp_down, out)
+        had_r_128(out, out, None, dn.svh, 1.0)
+
+
 def routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_scale=None, gate_t=None, bias=None, gu_slots=None):
     """routing.cu:955-1010 (same argument order): scores = hidden @ gate, top-K by logit, softmax over the selected logits.
     gu_slots (this build, optional): int64 [2][bsz * K] receiving [selected | selected + experts], the slot list of one indexed exl3_mgemm over

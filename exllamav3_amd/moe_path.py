@@ -206,11 +206,10 @@ class SyntheticEXL3MoE:
 
     def _forward_expert_parallel(self, x: torch.Tensor) -> torch.Tensor:
         """Local experts [first, last) only: the launches filter the routed indices to the range (in-range slots are compacted to the front,
-        the same order in the gate, up and down launches), C is zero-filled because filtered slots are never written, and the weighted down
-        launch sums the slots.  One token per set of launches (the range filter works on one token's slots, as in the reference)."""
+        the same order in the gate, up and down launches) and the weighted down launch sums the in-range slots only (a token with no expert on
+        this rank gets zeros).  One token per set of launches (the range filter works on one token's slots, as in the reference)."""
         t, k = x.shape[0], self.top_k
         mcg, mul1 = self.cb == 1, self.cb == 2
-        self.d.zero_()
         for i in range(t):
             xi = x[i].view(1, 1, -1)
             sel, w = self.sel[i].contiguous(), self.w[i].contiguous()

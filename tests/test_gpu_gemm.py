@@ -238,6 +238,21 @@ def test_mgemm_indexed_moe_forms(dev, cb, k, n, K):
         assert np.abs(C[t].float().cpu().numpy() - ref).max() < 2 * tol(ref)
     with pytest.raises(RuntimeError):
         ext.exl3_mgemm(T(xs2), pB, C, psu, None, psv, T(sel2), T(w2), K, -1, cb == 1, cb == 2, 0, 4, 0, num_tokens=2)
+    # (5) weights AND an expert range (the down launch of an expert-parallel rank): the in-range slots are compacted to the front together with their
+    # inputs' slots and weights, and only THEY are summed into C[0] (exl3_gemm_kernel.cuh:101-127 continues with bszm = the in-range count) -- a C full
+    # of NaN needs no zero fill; a token none of whose experts live on this rank gives zeros
+    for dt in (torch.float, torch.half):
+        C = torch.full((top, m, n), float("nan"), dtype=dt, device=dev)
+        ext.exl3_mgemm(T(xs), pBl, C, psul, None, psvl, T(sel), T(w), K, -1, cb == 1, cb == 2, lo, hi, 0)
+        kept_j = [j for j, e in enumerate(sel) if lo <= e < hi]
+        # the kernel compacts indices and weights; slot j' of the compacted list reads input slot j' (per-slot inputs are the caller's compacted
+        # activations: the gate / up launches of the same rank wrote them in the same compacted order)
+        ref = sum(float(w[j]) * lin(xs[jc], int(sel[j]), fp32=True) for jc, j in enumerate(kept_j))
+        got = C[0].float().cpu().numpy()
+        assert np.isfinite(got).all() and np.abs(got - ref).max() < 2 * tol(ref)
+        C = torch.full((top, m, n), float("nan"), dtype=dt, device=dev)
+        ext.exl3_mgemm(T(xs), pBl, C, psul, None, psvl, T(np.array([0, 1, 2], np.int64)), T(w), K, -1, cb == 1, cb == 2, lo, hi, 0)
+        assert bool((C[0] == 0).all())
 
 
 @pytest.mark.parametrize("cb,K", [(0, 4), (2, 3)])
