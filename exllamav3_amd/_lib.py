@@ -115,6 +115,9 @@ def _declare(l):
     sig("exl3_dequant_cache_paged", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp)
     sig("exl3_silu_mul", vp, vp, vp, i64, i32, vp)
     sig("exl3_act_mul", vp, vp, vp, i64, i32, i32, f32, vp)
+    sig("exl3_add_sigmoid_gate", vp, vp, vp, i64, i32, vp)
+    sig("exl3_add_sigmoid_gate_proj", vp, vp, vp, vp, i32, i32, vp)
+    sig("exl3_paged_kv_cache_update", vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp)
     sig("exl3_mul_gate", vp, vp, i64, i32, i32, vp)
     sig("exl3_deinterleave_qg", vp, vp, vp, i64, i32, vp)
     sig("exl3_add", vp, vp, i64, i32, i32, vp)

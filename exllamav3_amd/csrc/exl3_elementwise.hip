@@ -300,6 +300,74 @@ extern "C" int exl3_mul_gate(void* x, const void* y, int64_t numel, int bcast, i
     return exl3_check_launch("mul_gate");
 }
 
+// z += x * sigmoid(y)  (activation.cu:480-524, activation_kernels.cuh:278-297: fp32, one gate per `dim` values) and
+// z += x * sigmoid(y . w) (activation.cu:662-714, activation_kernels.cuh:369-411: the gate is the row's projection onto w; a gate below 1e-8 leaves z
+// untouched): the shared-expert merge of the sparse-MoE block.  One workgroup per row for the projection form.
+__global__ __launch_bounds__(256)
+void add_sigmoid_gate_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ z, int64_t numel, int dim)
+{
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numel) return;
+    z[i] += x[i] * (1.0f / (1.0f + __expf(-y[i / dim])));
+}
+
+__global__ __launch_bounds__(256)
+void add_sigmoid_gate_proj_kernel(const float* __restrict__ x, const half_t* __restrict__ y, float* __restrict__ z, const half_t* __restrict__ w, int dim)
+{
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    float yw = 0.0f;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) yw += (float) w[i] * (float) y[(int64_t) b * dim + i];
+    yw = block_sum(yw, red);
+    const float g = 1.0f / (1.0f + __expf(-yw));
+    if (g < 1e-8f) return;
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) z[(int64_t) b * dim + i] += x[(int64_t) b * dim + i] * g;
+}
+
+extern "C" int exl3_add_sigmoid_gate(const float* x, const float* y, float* z, int64_t numel, int dim, void* stream)
+{
+    EXL3_CHECK_ARG(x && y && z && dim > 0 && numel % dim == 0, "add_sigmoid_gate: null pointer / bad sizes");
+    if (numel == 0) return EXL3_OK;
+    add_sigmoid_gate_kernel<<<dim3((unsigned) ((numel + 255) / 256)), 256, 0, (hipStream_t) stream>>>(x, y, z, numel, dim);
+    return exl3_check_launch("add_sigmoid_gate");
+}
+
+extern "C" int exl3_add_sigmoid_gate_proj(const float* x, const void* y, float* z, const void* w, int rows, int dim, void* stream)
+{
+    EXL3_CHECK_ARG(x && y && z && w && dim > 0, "add_sigmoid_gate_proj: null pointer / bad sizes");
+    if (rows == 0) return EXL3_OK;
+    add_sigmoid_gate_proj_kernel<<<dim3(rows), 256, 0, (hipStream_t) stream>>>(x, (const half_t*) y, z, (const half_t*) w, dim);
+    return exl3_check_launch("add_sigmoid_gate_proj");
+}
+
+// fp16 paged cache append (generator/cache.cu:140-240 paged_kv_cache_update): k / v [bsz][s][heads][dim] -> row cache_seqlens[b] + t of the sequence's
+// pages (page size 256); 16 bytes per thread
+__global__ __launch_bounds__(256)
+void paged_kv_update_kernel(const half8_t* __restrict__ k, const half8_t* __restrict__ v, half8_t* __restrict__ kc, half8_t* __restrict__ vc,
+                            const int32_t* __restrict__ block_table, const int32_t* __restrict__ cache_seqlens, int S, int row8, int pages_per_seq, int64_t total8)
+{
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int64_t tok = i / row8, c = i - tok * row8;
+    const int64_t b = tok / S, t = tok - b * S;
+    const int64_t pos = (int64_t) cache_seqlens[b] + t;
+    const int64_t page = block_table[b * pages_per_seq + (pos >> 8)];
+    const int64_t dst = (page * 256 + (pos & 255)) * row8 + c;
+    kc[dst] = k[i]; vc[dst] = v[i];
+}
+
+extern "C" int exl3_paged_kv_cache_update(const void* k, const void* v, void* k_cache, void* v_cache, const int32_t* block_table, const int32_t* cache_seqlens,
+                                          int bsz, int seq_len, int heads, int dim, int pages_per_seq, void* stream)
+{
+    EXL3_CHECK_ARG(k && v && k_cache && v_cache && block_table && cache_seqlens, "paged_kv_cache_update: null pointer");
+    EXL3_CHECK_ARG(dim % 8 == 0, "dim must be divisible by 8");
+    const int64_t total8 = (int64_t) bsz * seq_len * heads * (dim / 8);
+    if (total8 == 0) return EXL3_OK;
+    paged_kv_update_kernel<<<dim3((unsigned) ((total8 + 255) / 256)), 256, 0, (hipStream_t) stream>>>((const half8_t*) k, (const half8_t*) v, (half8_t*) k_cache, (half8_t*) v_cache,
+                                                                                                     block_table, cache_seqlens, seq_len, heads * (dim / 8), pages_per_seq, total8);
+    return exl3_check_launch("paged_kv_cache_update");
+}
+
 // [.., heads, (q: head_dim, g: head_dim)] -> contiguous q and g (activation.cu:716-785): 16 bytes per thread
 __global__ __launch_bounds__(256)
 void deinterleave_qg_kernel(const half8_t* __restrict__ qg, half8_t* __restrict__ q, half8_t* __restrict__ g, int hd8, int64_t n8)

@@ -719,13 +719,9 @@ class BC_Attention:
                  self.q_norm, self.k_norm, self.norm_eps, self.norm_constant_bias, self.l4_beta, max(self.l4_orig, 1), self.post_rope_norm,
                  self.rotate_dims, 0)
         if not self.quant_cache:
-            # fp16 paged cache (attention.cpp:400-418 k_update, then the same attention over fp16 pages): rows appended by index (no host read: capturable),
+            # fp16 paged cache (attention.cpp:400-418 k_update, then the same attention over fp16 pages): rows appended by one launch,
             # causal attention of the chunk over the pages -- the flash-attention kernel of the prefill path, which a one-token chunk reduces to decode attention
-            pos = cache_seqlens.view(bsz, 1) + torch.arange(q_len, dtype=torch.int32, device=x.device).view(1, q_len)
-            pg = torch.gather(block_table, 1, (pos // self.page_size).long())
-            flat = (pg.long() * self.page_size + (pos % self.page_size).long()).view(-1)
-            self.cache_k.view(-1, hkv, hd).index_copy_(0, flat, k4.reshape(rows, hkv, hd))
-            self.cache_v.view(-1, hkv, hd).index_copy_(0, flat, v4.reshape(rows, hkv, hd))
+            paged_kv_cache_update(k4, v4, self.cache_k, self.cache_v, block_table, cache_seqlens)
             torch.add(cache_seqlens, q_len, out=st["lens"])
             attn_prefill_paged(st["q"], st["o"], self.cache_k, self.cache_v, block_table, st["lens"])
             self._finish(st, bsz, q_len, rows, y)
@@ -986,6 +982,11 @@ def relu2_mul(x, y, z, act_limit: float = 0.0):
     act_mul(x, y, z, ACT_RELU2, act_limit)
 
 
+def relu_mul(x, y, z, act_limit: float = 0.0):
+    """activation.cu:336-378: z = relu(x) * y (x = y gives the non-gated relu^2 of NemotronH-style experts)"""
+    act_mul(x, y, z, ACT_RELU, act_limit)
+
+
 def silu_oai_mul(x, y, z, act_limit: float = 0.0):
     """activation.cu:168-176 (gpt-oss clamped swiglu)"""
     act_mul(x, y, z, ACT_SILU_OAI, act_limit)
@@ -1018,6 +1019,40 @@ def mul_sigmoid_broadcast_(x, y):
 def mul_softplus_broadcast_(x, y):
     """activation.cu:618-660: x [B, S, H, D] *= softplus(y [B, S, H]) broadcast over D; the gate is evaluated in fp32"""
     _mul_gate_broadcast(x, y, 1, "mul_softplus_broadcast_")
+
+
+def add_sigmoid_gate(x, y, z):
+    """activation.cu:480-524: z += x * sigmoid(y), fp32, one gate per row of x (y.size(-1) == 1)"""
+    _dev(x)
+    _req(x.dtype == torch.float and y.dtype == torch.float and z.dtype == torch.float, "add_sigmoid_gate: tensors must be float32")
+    _req(y.shape[-1] == 1, "gate must have size(-1) == 1")
+    _req(x.numel() == z.numel() and x.numel() == y.numel() * x.shape[-1] and x.is_contiguous() and y.is_contiguous() and z.is_contiguous(), "add_sigmoid_gate: bad shapes")
+    _check(_lib.lib().exl3_add_sigmoid_gate(_p(x), _p(y), _p(z), x.numel(), x.shape[-1], _stream(x)))
+
+
+def add_sigmoid_gate_proj(x, y, z, w):
+    """activation.cu:662-714: z += x * sigmoid(y @ w): x, z fp32 (bsz, dim); y fp16 (bsz, dim); w fp16 (dim, 1)"""
+    _dev(x)
+    _req(x.dtype == torch.float and z.dtype == torch.float and y.dtype == torch.half and w.dtype == torch.half, "add_sigmoid_gate_proj: x, z float32; y, w float16")
+    dim = x.shape[-1]
+    _req(w.numel() == dim and y.numel() == x.numel() == z.numel() and x.is_contiguous() and y.is_contiguous() and z.is_contiguous() and w.is_contiguous(),
+         "add_sigmoid_gate_proj: bad shapes")
+    _check(_lib.lib().exl3_add_sigmoid_gate_proj(_p(x), _p(y), _p(z), _p(w), x.numel() // dim, dim, _stream(x)))
+
+
+def paged_kv_cache_update(k, v, k_cache, v_cache, block_table, cache_seqlens):
+    """generator/cache.cu:186-240: append k / v [B, S_new, H_k, D] fp16 to the fp16 paged cache [num_blocks, 256, H_k, D] at cache_seqlens[b] + t"""
+    _dev(k)
+    _req(k.dtype == torch.half and v.dtype == torch.half and k_cache.dtype == torch.half and v_cache.dtype == torch.half, "paged_kv_cache_update: tensors must be float16")
+    _req(block_table.dtype == torch.int32 and cache_seqlens.dtype == torch.int32, "paged_kv_cache_update: block_table / cache_seqlens must be int32")
+    _req(k.dim() == 4 and v.shape == k.shape, "k, v must have shape [B, S_new, H_k, D]")
+    _req(k_cache.dim() == 4 and v_cache.shape == k_cache.shape and k_cache.shape[2:] == k.shape[2:], "k_cache / v_cache must have shape [num_blocks, 256, H_k, D]")
+    _req(k_cache.shape[1] == 256, "this kernel needs page_size == 256")
+    _req(block_table.dim() == 2 and cache_seqlens.dim() == 1 and block_table.shape[0] == k.shape[0] == cache_seqlens.shape[0], "block_table [B, max_blocks_per_seq], cache_seqlens [B]")
+    _req(k.shape[3] % 8 == 0, "dim must be divisible by 8")
+    _req(k.is_contiguous() and v.is_contiguous() and k_cache.is_contiguous() and v_cache.is_contiguous() and block_table.is_contiguous(), "paged_kv_cache_update: contiguous tensors")
+    B, S, H, D = k.shape
+    _check(_lib.lib().exl3_paged_kv_cache_update(_p(k), _p(v), _p(k_cache), _p(v_cache), _p(block_table), _p(cache_seqlens), B, S, H, D, block_table.shape[1], _stream(k)))
 
 
 def deinterleave_qg(qg, q, g, head_dim: int):
@@ -1280,10 +1315,10 @@ class BC_BlockSparseMLP:
                                                         exl3_mgemm whose rows 0 .. tokens - 1 of out_d hold the reductions (+ shared experts)
       run_single_expert(y, e)                            one expert's MLP on <= 32 rows through the quantized kernels, result in out_d2[:rows]
       run_single_expert_dq(y, e, yh, interm, interm_a, out)   the same through reconstruct + hgemm (large row counts)
-    Not covered (they raise at construction): per-expert biases and the sigmoid-gated shared expert (gpt-oss / Qwen-MoE families).  The reference
+    Not covered (it raises at construction): per-expert biases (gpt-oss).  The reference
     captures one CUDA graph per batch size inside the class; here run_*() is plain launches -- capture the surrounding step in one hipGraph."""
 
-    MAX_BSZN = 16
+    MAX_BSZN = 8                                                      # mlp.h:11 (must match the Python side's buffer sizes)
     TEMP_ROWS_GRAPH = 32
 
     def __init__(self, yh2, yh, interm_gu, interm_g, interm_u, interm_a, interm_a2, out_d, out_d2, out_d_sh, z, dq_temp_up, dq_temp_down,
@@ -1298,7 +1333,6 @@ class BC_BlockSparseMLP:
         _req(not (shared_experts is not None and (down_bias_ptrs is not None or y_pad is not None)),
              "BC_BlockSparseMLP: shared experts not supported with expert biases or padded dims")                               # :494
         _req(gate_bias_ptrs is None and up_bias_ptrs is None and down_bias_ptrs is None, "BC_BlockSparseMLP: per-expert biases are outside this build")
-        _req(shared_gate is None, "BC_BlockSparseMLP: the sigmoid-gated shared expert is outside this build")
         _req(max_expert <= 512, "BC_BlockSparseMLP: Too many experts")
         self.yh2, self.yh, self.interm_gu, self.interm_g, self.interm_u, self.interm_a, self.interm_a2 = yh2, yh, interm_gu, interm_g, interm_u, interm_a, interm_a2
         self.out_d, self.out_d2, self.out_d_sh, self.dq_temp_up, self.dq_temp_down = out_d, out_d2, out_d_sh, dq_temp_up, dq_temp_down
@@ -1309,7 +1343,7 @@ class BC_BlockSparseMLP:
         self.act = (ACT_RELU if not self.gated else ACT_SILU if act_silu else ACT_GELU if act_gelu else ACT_SILU_OAI if act_silu_oai else ACT_RELU2)
         _req(not self.gated or act_silu or act_gelu or act_silu_oai or act_relu2, "BC_BlockSparseMLP: no activation selected")
         self.act_limit = float(act_limit)
-        self.shared_experts, self.gates, self.ups, self.downs = shared_experts, list(gates), list(ups), list(downs)
+        self.shared_experts, self.shared_gate, self.gates, self.ups, self.downs = shared_experts, shared_gate, list(gates), list(ups), list(downs)
         self.a_gather, self.y_pad, self.out_trim = a_gather, y_pad, out_trim
         self._flat_token = {}
 
@@ -1358,7 +1392,10 @@ class BC_BlockSparseMLP:
         if self.shared_experts is not None:
             sh = self.out_d_sh[:, :num_tokens]
             self.shared_experts.run_bszN(x_dense, sh)
-            add(o_n[:num_tokens].view(num_tokens, -1), sh.view(num_tokens, -1))
+            if self.shared_gate is not None:                              # z += shared(x) * sigmoid(x . w_gate)  (blocksparse_mlp.cpp:238-241)
+                add_sigmoid_gate_proj(sh.view(num_tokens, -1), x_dense.view(num_tokens, -1), o_n[:num_tokens].view(num_tokens, -1), self.shared_gate.weight)
+            else:
+                add(o_n[:num_tokens].view(num_tokens, -1), sh.view(num_tokens, -1))
 
     def run_single_expert(self, y: torch.Tensor, expert_idx: int):
         _dev(y)
@@ -1394,6 +1431,32 @@ class BC_BlockSparseMLP:
         had_r_128(interm_a, interm_a, dn.suh, None, 1.0)
         reconstruct(self.dq_temp_down, dn.trellis, self.down_t[3], self.down_t[4], self.down_t[5]); hgemm(interm_a, self.dq_temp_down, out)
         had_r_128(out, out, None, dn.svh, 1.0)
+
+
+class BC_MLP:
+    """libtorch/mlp.h:116-190, mlp.cpp:149-186: the non-gated MLP's bsz-1 runner -- up -> activation (in place, against a ones tensor) -> down, with the
+    zero-padded input / padded output statics of models whose widths are not multiples of 128.  Same keyword arguments as the reference's class."""
+
+    def __init__(self, xp, u, ones, yp, act_silu, act_gelu, act_relu2, up, down, act_limit, hidden_size, out_size):
+        _req(int(bool(act_silu)) + int(bool(act_gelu)) + int(bool(act_relu2)) == 1, "BC_MLP: exactly one of act_silu / act_gelu / act_relu2")
+        self.xp, self.u, self.ones, self.yp, self.up, self.down = xp, u, ones, yp, up, down
+        self.act = ACT_SILU if act_silu else (ACT_GELU if act_gelu else ACT_RELU2)
+        self.act_limit, self.hidden_size, self.out_size = float(act_limit), int(hidden_size), int(out_size)
+
+    def run_bsz1(self, x: torch.Tensor, d: torch.Tensor):
+        _dev(x)
+        x_in = x
+        if self.xp is not None:
+            self.xp[:, :self.hidden_size].copy_(x.view(1, self.hidden_size))
+            x_in = self.xp
+        u2 = self.u.view(1, -1)
+        self.up.run(x_in.view(1, -1), u2)
+        act_mul(u2, self.ones.view(1, -1), u2, self.act, self.act_limit)
+        if self.yp is not None:
+            self.down.run(u2, self.yp.view(1, -1))
+            d.view(1, self.out_size).copy_(self.yp.view(1, -1)[:, :self.out_size])
+        else:
+            self.down.run(u2, d.view(1, -1))
 
 
 def routing_std(hidden, gate, scores, topk_indices, topk_weights, per_expert_scale=None, gate_t=None, bias=None, gu_slots=None):

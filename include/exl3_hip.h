@@ -498,6 +498,14 @@ int exl3_act_mul(const void* g, const void* u, void* y, int64_t numel, int in_fp
 int exl3_mul_gate(void* x, const void* y, int64_t numel, int bcast, int softplus, void* stream);
 /* deinterleave_qg (activation.cu:716-785): qg [heads_total][2][head_dim] fp16 -> q, g [heads_total][head_dim] */
 int exl3_deinterleave_qg(const void* qg, void* q, void* g, int64_t heads_total, int head_dim, void* stream);
+/* shared-expert merge of the sparse-MoE block (activation.cuh add_sigmoid_gate / add_sigmoid_gate_proj; activation.cu:480-524, 662-714), fp32:
+ * z[i] += x[i] * sigmoid(y[i / dim])   and   z[b][:] += x[b][:] * sigmoid(y[b][:] . w)  (y, w fp16; a gate below 1e-8 leaves the row untouched) */
+int exl3_add_sigmoid_gate(const float* x, const float* y, float* z, int64_t numel, int dim, void* stream);
+int exl3_add_sigmoid_gate_proj(const float* x, const void* y, float* z, const void* w, int rows, int dim, void* stream);
+/* fp16 paged cache append (generator/cache.cu:140-240 paged_kv_cache_update): k / v fp16 [bsz][seq_len][heads][dim] -> row cache_seqlens[b] + t of the
+ * sequence's pages (k_cache / v_cache fp16 [pages][256][heads][dim]) */
+int exl3_paged_kv_cache_update(const void* k, const void* v, void* k_cache, void* v_cache, const int32_t* block_table, const int32_t* cache_seqlens,
+                               int bsz, int seq_len, int heads, int dim, int pages_per_seq, void* stream);
 /* x (fp16 or fp32) += y (fp16 or fp32) */
 int exl3_add(void* x, const void* y, int64_t numel, int x_fp32, int y_fp32, void* stream);
 /* softcap(x, y, scale)   softcap.cu:59-100: y = scale * tanh(x / scale) (fp32 math; fp16 or fp32 tensors; y == x allowed); Linear.forward's

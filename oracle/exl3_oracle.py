@@ -348,6 +348,21 @@ def mul_softplus_broadcast(x: np.ndarray, y: np.ndarray) -> np.ndarray:
     return (np.asarray(x, dtype=np.float16).astype(np.float32) * sp[..., None]).astype(np.float16)
 
 
+def add_sigmoid_gate(x: np.ndarray, y: np.ndarray, z: np.ndarray) -> np.ndarray:
+    """z + x * sigmoid(y), fp32, one gate per row (activation_kernels.cuh:278-297; sigmoid = 1 / (1 + exp(-y)))."""
+    g = (np.float32(1) / (np.float32(1) + np.exp(-np.asarray(y, np.float32)))).astype(np.float32)
+    return (np.asarray(z, np.float32) + np.asarray(x, np.float32) * g).astype(np.float32)
+
+
+def add_sigmoid_gate_proj(x: np.ndarray, y: np.ndarray, z: np.ndarray, w: np.ndarray) -> np.ndarray:
+    """z + x * sigmoid(y . w) per row (activation_kernels.cuh:369-411): x, z fp32; y, w fp16; a gate below 1e-8 leaves the row untouched."""
+    yw = (np.asarray(y, np.float16).astype(np.float32) @ np.asarray(w, np.float16).astype(np.float32).reshape(-1)).astype(np.float32)
+    with np.errstate(over="ignore"):
+        g = (np.float32(1) / (np.float32(1) + np.exp(-yw))).astype(np.float32)
+    g = np.where(g < np.float32(1e-8), np.float32(0), g)
+    return (np.asarray(z, np.float32) + np.asarray(x, np.float32) * g[:, None]).astype(np.float32)
+
+
 def deinterleave_qg(qg: np.ndarray, head_dim: int):
     """[.., heads * 2 * head_dim] with (q head, g head) pairs per head -> (q, g) [.., heads * head_dim] (activation.cu:716-739)."""
     v = np.asarray(qg).reshape(qg.shape[:-1] + (-1, 2, head_dim))

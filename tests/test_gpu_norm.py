@@ -150,3 +150,39 @@ def test_attention_gate_ops_vs_oracle(dev, shape):
         assert np.array_equal(q.cpu().numpy(), rq) and np.array_equal(g.cpu().numpy(), rg)
     with pytest.raises(RuntimeError):
         ext.mul_sigmoid_broadcast_(T(x), T(y_full))                        # y must be [B, S, H]
+
+
+def test_shared_expert_gate_ops_and_fp16_cache_append_vs_oracle(dev):
+    """add_sigmoid_gate / add_sigmoid_gate_proj (activation.cu:480-524, 662-714: the shared-expert merge of the sparse-MoE block), relu_mul, and
+    paged_kv_cache_update (generator/cache.cu:186-240: fp16 cache append at cache_seqlens[b] + t through the block table) against the oracle / numpy."""
+    from exllamav3_amd import ext
+    from oracle import exl3_oracle as o
+    rng = np.random.default_rng(3)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    x = rng.standard_normal((5, 384)).astype(np.float32); z = rng.standard_normal((5, 384)).astype(np.float32)
+    y1 = (rng.standard_normal((5, 1)) * 3).astype(np.float32)
+    tz = T(z); ext.add_sigmoid_gate(T(x), T(y1), tz)
+    assert np.allclose(tz.cpu().numpy(), o.add_sigmoid_gate(x, y1, z), rtol=1e-5, atol=1e-5)
+    yh = rng.standard_normal((5, 384)).astype(np.float16); w = (rng.standard_normal((384, 1)) * 0.1).astype(np.float16)
+    yh[4] = (-40 * np.sign(w[:, 0].astype(np.float32))).astype(np.float16)              # a gate far below 1e-8: the row stays untouched
+    tz = T(z); ext.add_sigmoid_gate_proj(T(x), T(yh), tz, T(w))
+    ref = o.add_sigmoid_gate_proj(x, yh, z, w)
+    assert np.allclose(tz.cpu().numpy(), ref, rtol=1e-4, atol=1e-4) and np.array_equal(tz.cpu().numpy()[4], z[4])
+    g16 = rng.standard_normal((3, 256)).astype(np.float16); u16 = rng.standard_normal((3, 256)).astype(np.float16)
+    t = torch.zeros((3, 256), dtype=torch.half, device=dev); ext.relu_mul(T(g16), T(u16), t)
+    assert np.array_equal(t.cpu().numpy(), o.act_mul(g16, u16, "relu", 0.0))
+    # fp16 cache append: 3 sequences, 5 new tokens each, scattered pages, one sequence crossing a page edge
+    B, S, H, D, pps = 3, 5, 2, 64, 2
+    k = rng.standard_normal((B, S, H, D)).astype(np.float16); v = rng.standard_normal((B, S, H, D)).astype(np.float16)
+    bt = rng.permutation(B * pps).reshape(B, pps).astype(np.int32)
+    lens = np.array([0, 254, 300], np.int32)
+    kc = torch.zeros((B * pps, 256, H, D), dtype=torch.half, device=dev); vc = torch.zeros_like(kc)
+    ext.paged_kv_cache_update(T(k), T(v), kc, vc, T(bt), T(lens))
+    kcn, vcn = kc.cpu().numpy(), vc.cpu().numpy()
+    written = 0
+    for b in range(B):
+        for t_ in range(S):
+            pos = lens[b] + t_
+            assert np.array_equal(kcn[bt[b, pos // 256], pos % 256], k[b, t_]) and np.array_equal(vcn[bt[b, pos // 256], pos % 256], v[b, t_])
+            written += 1
+    assert int((np.abs(kcn).sum((2, 3)) > 0).sum()) == written

@@ -904,6 +904,74 @@ def test_bc_blocksparse_mlp_runner_matches_oracle(dev, act):
         bc.run_bszN(T(np.zeros((17, H), np.float16)), T(np.zeros((17, top), np.int64)), T(np.zeros((17, top), np.float16)))
 
 
+@pytest.mark.parametrize("gate", [False, True])
+def test_bc_blocksparse_mlp_shared_expert_and_bc_mlp(dev, gate):
+    """BC_BlockSparseMLP with a shared expert (a BC_GatedMLP run on every token, blocksparse_mlp.cpp:228-246): plain add, or merged through the
+    sigmoid of the token's projection onto an fp16 gate vector (add_sigmoid_gate_proj); and BC_MLP (libtorch/mlp.h:116-190: the non-gated MLP's
+    bsz-1 runner) with a padded input width -- against the oracle composition."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.moe_path import SyntheticEXL3MoE
+    H, I, E, top, K = 256, 384, 4, 2, 4
+    moe = SyntheticEXL3MoE(H, I, experts=E, top_k=top, K=K, cb=2, device=dev, seed=33)
+    rng = np.random.default_rng(int(gate))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    MAXB = ext.BC_BlockSparseMLP.MAX_BSZN
+    bszn = MAXB * top
+    th = torch.empty((64, H), dtype=torch.half, device=dev); ti = torch.empty((64, I), dtype=torch.half, device=dev)
+    ta = torch.empty((32, I), dtype=torch.half, device=dev); to_ = torch.empty((32, H), dtype=torch.float, device=dev)
+    bcl = lambda l: ext.BC_LinearEXL3(l.trellis, l.suh, l.svh, K, None, l.mcg, l.mul1, None)
+    # the shared expert: one more gated MLP of the same shape
+    sh = SyntheticEXL3MoE(H, I, experts=1, top_k=1, K=K, cb=2, device=dev, seed=34)
+    shg, shu, shd = bcl(sh.gate[0]), bcl(sh.up[0]), bcl(sh.down[0])
+    sh_bc = ext.BC_GatedMLP(torch.empty((2, MAXB, H), dtype=torch.half, device=dev), torch.empty((2, MAXB, I), dtype=torch.half, device=dev),
+                            torch.empty((1, MAXB, I), dtype=torch.half, device=dev), torch.empty((1, MAXB, I), dtype=torch.half, device=dev),
+                            None, None, None, K, False, True, True, False, False, shg, shu, shd, 0.0)
+    gw = (rng.standard_normal((H, 1)) * 0.1).astype(np.float16)
+    sh_gate = ext.BC_LinearFP16(T(gw)) if gate else None
+    out_d_sh = torch.empty((1, MAXB, H), dtype=torch.float, device=dev)
+    bc = ext.BC_BlockSparseMLP(
+        th, th[:bszn].view(bszn, 1, H), ti, ti[:bszn].view(bszn, 1, I), ti[bszn:2 * bszn].view(bszn, 1, I), ta[:bszn].view(bszn, 1, I), ta,
+        to_[:bszn].view(bszn, 1, H), to_, out_d_sh, None, torch.empty((H, I), dtype=torch.half, device=dev), torch.empty((I, H), dtype=torch.half, device=dev),
+        -1, -1, moe.g_B, moe.g_suh, moe.g_svh, K, False, True, moe.u_B, moe.u_suh, moe.u_svh, K, False, True, moe.d_B, moe.d_suh, moe.d_svh, K, False, True,
+        True, False, False, sh_bc, sh_gate, 0.0, [bcl(l) for l in moe.gate], [bcl(l) for l in moe.up], [bcl(l) for l in moe.down],
+        None, None, None, torch.empty((bszn, H), dtype=torch.half, device=dev))
+
+    def mlp(gl, ul, dl, xr):
+        g = _lin(gl, xr).astype(np.float32); u = _lin(ul, xr).astype(np.float32)
+        return _lin(dl, (g / (1 + np.exp(-g)) * u).astype(np.float16), out_fp32=True)
+
+    for bsz in (1, 3):
+        x = rng.standard_normal((bsz, H)).astype(np.float16)
+        sel = np.stack([rng.permutation(E)[:top] for _ in range(bsz)]).astype(np.int64)
+        wts = rng.uniform(0.2, 0.8, (bsz, top)).astype(np.float16)
+        bc.run_bszN(T(x), T(sel), T(wts))
+        ref = np.zeros((bsz, H), np.float32)
+        for t in range(bsz):
+            for j in range(top):
+                e = int(sel[t, j])
+                ref[t] += np.float32(wts[t, j]) * mlp(moe.gate[e], moe.up[e], moe.down[e], x[t:t + 1])[0]
+        shared = mlp(sh.gate[0], sh.up[0], sh.down[0], x)
+        ref = o.add_sigmoid_gate_proj(shared, x, ref, gw) if gate else ref + shared
+        got = to_[:bsz].cpu().numpy()
+        assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2, bsz
+    if gate:
+        return
+    # BC_MLP: up -> gelu (against ones) -> down, the model's width 224 padded to the quantized 256
+    hs = 224
+    up_l, dn_l = moe.up[0], moe.down[0]
+    xp = torch.zeros((1, H), dtype=torch.half, device=dev); yp = torch.empty((1, H), dtype=torch.half, device=dev)
+    m = ext.BC_MLP(xp=xp, u=torch.empty((1, 1, I), dtype=torch.half, device=dev), ones=torch.ones((1, 1, I), dtype=torch.half, device=dev), yp=yp,
+                   act_silu=False, act_gelu=True, act_relu2=False, up=bcl(up_l), down=bcl(dn_l), act_limit=0.0, hidden_size=hs, out_size=hs)
+    x = rng.standard_normal((1, 1, hs)).astype(np.float16)
+    d = torch.zeros((1, 1, hs), dtype=torch.half, device=dev)
+    m.run_bsz1(T(x), d)
+    xpad = np.zeros((1, H), np.float16); xpad[:, :hs] = x.reshape(1, hs)
+    u = _lin(up_l, xpad).astype(np.float16)
+    a = o.act_mul(u, np.ones_like(u), "gelu", 0.0)
+    ref = _lin(dn_l, a).astype(np.float32)[:, :hs]
+    assert np.abs(d.float().cpu().numpy().reshape(1, hs) - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
+
+
 def test_exl3_moe_is_capturable_and_replays_bit_for_bit_with_other_assignments(dev):
     """VERDICT round 2, task 6: ext.exl3_moe has no host round trip (the slot list is built on the device, the scatter runs in a fixed order), so a
     hipGraph captured with ONE routing result replays correctly -- bit for bit against the eager op -- after expert_count / token_sorted /
