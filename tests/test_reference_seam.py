@@ -16,10 +16,16 @@ needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "exllamav3"))
                                reason="needs /root/reference and the stub built by __graft_entry__.build()")
 
 # the callers on the hot path
-HOT_MODULES = ["modules/quant/exl3.py", "modules/rmsnorm.py", "util/rope.py", "cache/quant.py", "modules/linear.py"]
+HOT_MODULES = ["modules/quant/exl3.py", "modules/rmsnorm.py", "util/rope.py", "cache/quant.py", "modules/linear.py",
+               # round 4: the modules that own the runners -- attention (BC_Attention, gates, sinks), the dense and sparse MLPs (BC_GatedMLP, BC_MLP,
+               # BC_BlockSparseMLP, exl3_moe), the pointer-table holder, the fp16 cache layer
+               "modules/attn.py", "modules/mlp.py", "modules/block_sparse_mlp.py", "modules/multilinear.py", "cache/fp16.py", "modules/quant/fp16.py",
+               "modules/transformer.py", "modules/embedding.py", "modules/layernorm.py"]
 # names those modules use that belong to other subsystems (conversion-time quantizer, LoRA-free fp16 inner, capture) -- outside SURVEY.md 8
 OUTSIDE = {"quantize_tiles", "quantize_tiles_multigpu", "had_paley", "had_paley2", "test_distribution", "count_inf_nan", "gated_rms_norm",
-           "quantize_error", "gen_mrope_pos_ids"}       # gen_mrope_pos_ids: host-side position-id builder of the multimodal front end (no device work)
+           "quantize_error", "gen_mrope_pos_ids",
+           # other model families' routers / activations (DeepSeek-V3 and selective-norm routing, xIELU): outside SURVEY.md 8
+           "routing_ds3_nogroup", "routing_sel_norm", "xielu"}       # gen_mrope_pos_ids: host-side position-id builder of the multimodal front end (no device work)
 
 
 def _ext_names(path):
