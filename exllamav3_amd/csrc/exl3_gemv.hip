@@ -300,7 +300,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                      const void* norm_w = nullptr, const float* ss_part = nullptr, float eps = 0.0f, const GemvTable* tbl = nullptr,
                      const float* act_g = nullptr, const float* act_u = nullptr, int act_S = 0, const void* act_svh_g = nullptr,
                      const void* act_svh_u = nullptr, const GemvResidIn* rsd = nullptr, const GemvRescale* act_rs = nullptr, int cpw = 0,
-                     float* fx_ss_out = nullptr, const GemvAttm* attm = nullptr)
+                     float* fx_ss_out = nullptr, const GemvAttm* attm = nullptr, const GemvQkvm* qkvm = nullptr)
 {
     FxZeroReq fxz = take_fx_zero();          // one-shot: whatever happens below, the request does not survive this call
     if (rsd) flags |= GEMV_IN_RESID;
@@ -314,6 +314,12 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     EXL3_CHECK_ARG(!attm || (attm->part && attm->nsplit >= 1 && attm->nsplit <= 32 && attm->gq >= 1 && attm->blocks >= 1 && count == 1 && m <= 4 && !tbl && !epi && cpw == 0
                              && !rsd && !act_g && !(flags & (GEMV_IN_ROTATED | GEMV_IN_NORM)) && k == attm->gq * attm->blocks * 128),
                    "exl3_gemv_ex_attm: one matrix, m <= 4, at most 32 context splits, k = heads_q x 128");
+    if (qkvm) flags |= GEMV_IN_QKVM;
+    EXL3_CHECK_ARG(!qkvm || (qkvm->sq && qkvm->sk && qkvm->sv && qkvm->S >= 1 && qkvm->svh_q && qkvm->svh_k && qkvm->svh_v && qkvm->rope_sin && qkvm->rope_cos && qkvm->slots
+                             && qkvm->k_cache && qkvm->k_scales && qkvm->v_cache && qkvm->v_scales && (qkvm->hd == 64 || qkvm->hd == 128) && qkvm->kvb >= 1
+                             && (qkvm->rope_mode == 1 || qkvm->rope_mode == 2) && count == 1 && m <= 4 && !tbl && !epi && cpw == 0 && !rsd && !act_g && !attm
+                             && !(flags & (GEMV_IN_ROTATED | GEMV_IN_NORM))),
+                   "exl3_gemv_ex_qkvm: one matrix, m <= 4, the q|k|v slabs + scales, the rope tables and cache rows of exl3_qkv_prep, a 4-bit cache");
     if (epi) flags |= GEMV_OUT_DEFERRED;
     // GEMV_OUT_ATOMIC (generation 4): no slabs, every workgroup adds its share of the output into the fixed-point accumulator Cs[i]; like a deferred
     // launch it keeps every workgroup resident (the split is chosen the same way) and it needs svhs
@@ -336,7 +342,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
     const bool in_act = (flags & GEMV_IN_ACT) != 0;
     EXL3_CHECK_ARG(!in_act || (act_g && act_u && ((act_svh_g && act_svh_u && count == 1) || (tbl && tbl->act_svh)) && act_S >= 1 && !rotated && m <= 4),
                    "exl3_gemv_ex_act: needs gate / up slabs + svh, one matrix, m <= 4");
-    EXL3_CHECK_ARG(A || rotated || in_act || attm, "exl3_gemm: null A");
+    EXL3_CHECK_ARG(A || rotated || in_act || attm || qkvm, "exl3_gemm: null A");
     EXL3_CHECK_ARG(!rsd || (in_norm && deferred && m <= 4 && rsd->slab && rsd->S >= 1 && rsd->svh && rsd->resid_out && rsd->ss_out && rsd->resid_out != A),
                    "exl3_gemv_ex_resid: needs GEMV_IN_NORM, deferred output, m <= 4, producer slabs + svh and a resid_out buffer other than resid_in");
     int total_cb = 0;
@@ -423,6 +429,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
         if (rsd) { args.rs_slab = rsd->slab; args.rs_S = rsd->S; args.rs_svh = (const half_t*) rsd->svh; args.rs_resid_out = (half_t*) rsd->resid_out; args.rs_ss_out = rsd->ss_out; }
         if (act_rs) args.act_rs = *act_rs;
         if (attm) { args.attm = *attm; args.attm.magic_gq = gemv_magic((uint32_t) attm->gq); }
+        if (qkvm) args.qkvm = *qkvm;
         int fs = force_split;
         if (g3) fs = g3fs;
         else if (deferred && fs == 0)
@@ -563,7 +570,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             EXL3_CHECK_ARG(g4 || !fxz.ptr, "exl3_fx_zero_next: the launch that followed cannot clear the buffer (not a generation-4 launch: rows > 4, a slice of more than 32 Hadamard blocks, a tail / wave-per-column-block mode, or generation 4 switched off)");
             if (g4)
             {
-                const int mode = attm ? 8 : tbl ? (in_act ? 7 : 6) : in_act ? ((flags & GEMV_IN_ACTFX) ? 5 : 3) : (in_norm ? (in_fx ? 4 : 2) : (rot_pass ? 0 : 1));
+                const int mode = qkvm ? 9 : attm ? 8 : tbl ? (in_act ? 7 : 6) : in_act ? ((flags & GEMV_IN_ACTFX) ? 5 : 3) : (in_norm ? (in_fx ? 4 : 2) : (rot_pass ? 0 : 1));
                 if (fxz.ptr)
                 {
                     int dev_now = -1;
@@ -604,7 +611,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             }
             else
             {
-            EXL3_CHECK_ARG(!atomic_out && !in_fx && !attm && !(flags & GEMV_IN_ACTFX) && !(tbl && in_act), "exl3_gemv_ex: GEMV_OUT_ATOMIC / GEMV_IN_FX / GEMV_IN_ACTFX / GEMV_IN_ATTM / slab-act table launches are generation-4 launches (m <= 4, slices of <= 32 Hadamard blocks, generation 4 enabled)");
+            EXL3_CHECK_ARG(!atomic_out && !in_fx && !attm && !qkvm && !(flags & GEMV_IN_ACTFX) && !(tbl && in_act), "exl3_gemv_ex: GEMV_OUT_ATOMIC / GEMV_IN_FX / GEMV_IN_ACTFX / GEMV_IN_ATTM / GEMV_IN_QKVM / slab-act table launches are generation-4 launches (m <= 4, slices of <= 32 Hadamard blocks, generation 4 enabled)");
             int nwv = 16 / ng;                                   // partial-sum LDS: nwv * 4*ng rows * 512 B <= 32 KB
             const int units = bps * (8 / G2_PF);                 // the waves split the slice's tile rows in units of G2_PF
             // measured on MI355X (tools/prof_tail.py, batch 1): one wave per Hadamard block of the slice, but at least 4 waves --
@@ -1048,6 +1055,34 @@ extern "C" int exl3_gemv_ex_attm(const float* part, int nsplit, int gq, int bloc
     return run_mgemm(nullptr, Bs, C ? Cs : nullptr, su, svh ? sv : nullptr, bi, ns, 1, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream,
                      (flags & (GEMV_OUT_DEFERRED | GEMV_OUT_ATOMIC)), nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
                      nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &at);
+}
+
+// o_proj fed straight by the q|k|v launch's deferred slabs (the decode step WITHOUT the attention core: o_proj's input is the finished q): the q|k|v epilogue
+// -- exl3_glue_qkv_tab's work: split-k reduce, output Hadamard, row-scale correction, svh, RoPE from the per-step tables, the 4-bit append of K / V --
+// runs inside this launch: a preparation task finishes the q block it needs, idle half-waves of the column-block-0 workgroups append K / V.  Same bits
+// as exl3_glue_qkv_tab + exl3_gemv_ex (shared device functions); one launch less per layer.  head_dim 64 | 128, 4-bit K and V.
+// reference: libtorch/attention.cpp:283-400 (q / k / v epilogues, rope, cache append) + :497-508 (o_proj).
+extern "C" int exl3_gemv_ex_qkvm(const float* sq, const float* sk, const float* sv, int S_qkv, const void* svh_q, const void* svh_k, const void* svh_v,
+                                 const float* rope_sin, const float* rope_cos, const int64_t* slots, const float* ss_prev, const float* ss_new, int hidden, float eps,
+                                 int rope_mode, int head_dim, int heads_kv, void* q_out, void* k_cache, void* k_scales, void* v_cache, void* v_scales,
+                                 const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb, int c_fp32,
+                                 int flags, int force_split, float** slab_out, int* S_out, void* stream)
+{
+    EXL3_CHECK_ARG(B && suh, "exl3_gemv_ex_qkvm: null pointer");
+    EXL3_CHECK_ARG(!ss_new || (ss_prev && hidden > 0 && hidden % 128 == 0), "exl3_gemv_ex_qkvm: rescale needs ss_prev and hidden");
+    EXL3_CHECK_ARG((head_dim == 64 || head_dim == 128) && heads_kv >= 1 && (heads_kv * head_dim) % 128 == 0, "exl3_gemv_ex_qkvm: head_dim 64 | 128, whole 128-value kv blocks");
+    const void* Bs[1] = { B }; void* Cs[1] = { C }; const void* su[1] = { suh }; const void* svp[1] = { svh }; const void* bi[1] = { bias };
+    int ns[1] = { n };
+    GemvQkvm q; memset((void*) &q, 0, sizeof(q));
+    q.sq = sq; q.sk = sk; q.sv = sv; q.S = S_qkv; q.rope_mode = rope_mode;
+    q.svh_q = (const half_t*) svh_q; q.svh_k = (const half_t*) svh_k; q.svh_v = (const half_t*) svh_v;
+    q.rope_sin = rope_sin; q.rope_cos = rope_cos; q.slots = slots;
+    q.rs = GemvRescale{ ss_prev, ss_new, hidden, eps };
+    q.q_out = (half_t*) q_out; q.k_cache = (uint32_t*) k_cache; q.k_scales = (half_t*) k_scales; q.v_cache = (uint32_t*) v_cache; q.v_scales = (half_t*) v_scales;
+    q.hd = head_dim; q.kvb = heads_kv * head_dim / 128;
+    return run_mgemm(nullptr, Bs, C ? Cs : nullptr, su, svh ? svp : nullptr, bi, ns, 1, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream,
+                     (flags & (GEMV_OUT_DEFERRED | GEMV_OUT_ATOMIC)), nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
+                     nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, &q);
 }
 
 extern "C" int exl3_gemv_ex_act(const float* g_slabs, const float* u_slabs, int act_S, const void* svh_g, const void* svh_u,

@@ -50,11 +50,13 @@ __device__ __forceinline__ void g4_static_for(F&& f)
 #define G4_MODE_TRAWX 6     // slot input = raw x (one shared row set, or a_slot_stride apart)
 #define G4_MODE_TACT 7      // slot input = silu(g) * u from the slabs a TRAWX gate|up launch over [gate_0..gate_E-1, up_0..up_E-1] left (slot j: gate, slot bszm + j: up)
 #define G4_MODE_ATTM 8      // GEMV_IN_ATTM: the flash-decoding merge of the attention's context-split partials, then as RAWX (a.A is not read)
+#define G4_MODE_QKVM 9      // GEMV_IN_QKVM: q block of the q|k|v launch's slabs finished in the task (+ the K / V append as a side job), then as RAWX (a.A is not read)
 constexpr int g4_input_mode(int MODE) { return MODE == G4_MODE_TRAWX ? G4_MODE_RAWX : (MODE == G4_MODE_TACT ? G4_MODE_ACT : MODE); }
 
 constexpr int g4_waves_per_eu(int K, int CB, int MODE_)
 {
     const int MODE = g4_input_mode(MODE_);
+    if (MODE == G4_MODE_QKVM) return 2;                      // eight slab lines + rope values travel with a task (as ATTM: these launches are one wave per SIMD anyway)
     if (MODE == G4_MODE_ATTM) return 2;                      // eight 16-byte split outputs travel with a task, two tasks in flight in the pipelined task loop: 128 VGPRs spill (4 VGPRs + 79 SGPRs at budget 4); o_proj launches are one wave per SIMD anyway
     if (MODE == G4_MODE_ACT) return MODE_ == G4_MODE_TACT ? 4 : 3;     // 8 slab lines travel with a task; the non-table form also carries the row-scale correction
     if (MODE == G4_MODE_ACTFX && K >= 5) return 5;          // four 16-byte accumulator loads in flight per task next to a 10..16-word ring
@@ -227,7 +229,9 @@ void exl3_gemv4_kernel(const GemvArgs a)
 #define G4_ATTM_NMO 8
 #endif
     constexpr int NMO = MODE == G4_MODE_ATTM ? G4_ATTM_NMO : 1;         // ATTM: the first 8 splits' outputs travel with the task (16: 254 VGPRs and a private segment -- the pipelined task loop holds two tasks)
-    struct PrepIn { half4_t xv, sv, wv; float ss, ssn; uint4_t f0, f1, f2, f3; float4_t ga[NSL], ua[NSL]; half4_t svg, svu; float4_t mo[NMO]; float2 mst; };
+    constexpr int NQL = MODE == G4_MODE_QKVM ? 8 : 1;         // QKVM: the first 8 slab lines of the q block travel with the task
+    struct PrepIn { half4_t xv, sv, wv; float ss, ssn; uint4_t f0, f1, f2, f3; float4_t ga[NSL], ua[NSL]; half4_t svg, svu; float4_t mo[NMO]; float2 mst;
+                    float4_t ql[NQL], sn4, cs4; };
     const int at_nsplit = MODE == G4_MODE_ATTM ? a.attm.nsplit : 1, at_gq = MODE == G4_MODE_ATTM ? a.attm.gq : 1;
     const float* const at_part = MODE == G4_MODE_ATTM ? a.attm.part : nullptr;
     // partial records of (row, head): head = absolute Hadamard block of the input = query head (head_dim 128); h = head / gq, i = head % gq
@@ -262,6 +266,34 @@ void exl3_gemv4_kernel(const GemvArgs a)
             r.mst = *((const float2*) (p + (size_t) min(l32, at_nsplit - 1) * 132));                 // lane s: {m, l} of split s (masked at its use)
             #pragma unroll
             for (int u = 0; u < NMO; ++u) r.mo[u] = *((const float4_t*) (p + (size_t) min(u, at_nsplit - 1) * 132 + 4 + 4 * l32));
+        }
+        if constexpr (MODE == G4_MODE_QKVM)
+        {
+            // q block blk_abs of this row: its first slab lines, column scales, the row's rope values and rescale sums -- requested here, i.e. before the
+            // wave's first weight rows (inside the task they would queue behind those)
+            const int blk_abs = (k0s >> 7) + blk, qS = a.qkvm.S;
+            const float* pq = a.qkvm.sq + ((size_t) blk_abs * qS * m + row) * 128;
+            #pragma unroll
+            for (int i = 0; i < NQL; ++i) r.ql[i] = ((const float4_t*) (pq + (size_t) min(i, qS - 1) * m * 128))[l32];
+            r.svg = ((const half4_t*) (a.qkvm.svh_q + blk_abs * 128))[l32];
+            const int ph = a.qkvm.hd >> 3;
+            r.sn4 = float4_t{ 0.f, 0.f, 0.f, 0.f }; r.cs4 = r.sn4;
+            if (a.qkvm.rope_mode == 2)
+            {
+                const int f = 4 * (l32 & (ph - 1));
+                r.sn4 = *((const float4_t*) (a.qkvm.rope_sin + row * 64 + f)); r.cs4 = *((const float4_t*) (a.qkvm.rope_cos + row * 64 + f));
+            }
+            else
+            {
+                const int f = 2 * (l32 & ((a.qkvm.hd >> 2) - 1));
+                r.sn4.x = a.qkvm.rope_sin[row * 64 + f]; r.sn4.y = a.qkvm.rope_sin[row * 64 + f + 1]; r.cs4.x = a.qkvm.rope_cos[row * 64 + f]; r.cs4.y = a.qkvm.rope_cos[row * 64 + f + 1];
+            }
+            if (a.qkvm.rs.ss_new)
+            {
+                const int nbh = a.qkvm.rs.k >> 7;
+                r.ss = a.qkvm.rs.ss_prev[(size_t) row * nbh + min(l32, nbh - 1)]; r.ssn = a.qkvm.rs.ss_new[(size_t) row * nbh + min(l32, nbh - 1)];
+                if (l32 >= nbh) { r.ss = 0.0f; r.ssn = 0.0f; }
+            }
         }
         if constexpr (MODE == G4_MODE_ACT)
         {
@@ -450,6 +482,29 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
                     xv = half4_t{ silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
                 }
+                if constexpr (MODE == G4_MODE_QKVM)
+                {
+                    // x = q block blk_abs of this row, finished as exl3_glue_qkv_tab finishes it: slab lines summed in slice order from zero (slab_sum),
+                    // then qkv_block_finish (output Hadamard, r_new / r_prev, fp16, x svh, RoPE) -- the same device function, the same bits
+                    const int blk_abs = (k0s >> 7) + blk, qS = a.qkvm.S;
+                    float4_t v = { 0.f, 0.f, 0.f, 0.f };
+                    #pragma unroll
+                    for (int i = 0; i < NQL; ++i) if (i < qS) { v.x += cur.ql[i].x; v.y += cur.ql[i].y; v.z += cur.ql[i].z; v.w += cur.ql[i].w; }
+                    if (qS > NQL)
+                    {
+                        const float* pq = a.qkvm.sq + ((size_t) blk_abs * qS * m + row) * 128;
+                        for (int sl = NQL; sl < qS; sl += 4)
+                        {
+                            float4_t t4[4];
+                            #pragma unroll
+                            for (int i = 0; i < 4; ++i) t4[i] = ((const float4_t*) (pq + (size_t) min(sl + i, qS - 1) * m * 128))[l32];
+                            #pragma unroll
+                            for (int i = 0; i < 4; ++i) if (sl + i < qS) { v.x += t4[i].x; v.y += t4[i].y; v.z += t4[i].z; v.w += t4[i].w; }
+                        }
+                    }
+                    xv = qkv_block_finish(v, cur.svg, a.qkvm.rs, row, l32, cur.ss, cur.ssn, true, a.qkvm.rope_mode, a.qkvm.hd >> 3, cur.sn4, cur.cs4);
+                    if (cbg == 0 && act && a.qkvm.q_out) ((half4_t*) (a.qkvm.q_out + (size_t) row * a_k + (size_t) blk_abs * 128))[l32] = xv;
+                }
                 if constexpr (MODE == G4_MODE_ATTM)
                 {
                     // x = the attention output of query head `blk_abs` of this row: merge of the context splits' partial records -- the arithmetic of
@@ -590,6 +645,50 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     const PrepIn cur = nx;
                     if ((it + 1) * nhw + 2 * wave < ntask) nx = fetch(it + 1);
                     do_task(cur, it);
+                }
+            }
+        }
+        if constexpr (MODE == G4_MODE_QKVM)
+        {
+            // side job of the column-block-0 workgroups (one per k-slice): the new token's K / V rows -- (row, K | V, 128-value block) tasks t = slice + S * j,
+            // j over this workgroup's half-waves starting with those that had NO preparation task (they would idle at the barrier below): at batch 1 a
+            // slice has 4 preparation tasks and 2 of these.  Same arithmetic as glue_qkv_kernel (qkv_block_finish + kv_quant_regs), 4-bit cache.
+            if (cbg == 0)
+            {
+                const int kvb = a.qkvm.kvb, nkv = m * 2 * kvb;
+                const int nj = s < nkv ? (nkv - s + a_S - 1) / a_S : 0;                // this slice's tasks t = s + S * j, j < nj (workgroup-uniform)
+                const int busy = min(ntask, nhw);                                      // half-waves that own a preparation task
+                auto rank = [&] (int hw) { return hw >= busy ? hw - busy : hw + (nhw - busy); };      // idle half-waves first
+                const int jw = rank(hwid), jmin = min(rank(2 * wave), rank(2 * wave + 1));
+                for (int jr = 0; jr * nhw < nj; ++jr)
+                {
+                    if (jmin + nhw * jr >= nj) continue;                                // wave-uniform: neither half-wave of this wave has a task this round
+                    const int j = jw + nhw * jr;
+                    const bool actk = j < nj;
+                    const int tc = s + a_S * min(j, nj - 1);
+                    const int row = tc / (2 * kvb), rem = tc - row * 2 * kvb, isv = rem >= kvb ? 1 : 0, hb = rem - isv * kvb;
+                    const SlabRef sr = { isv ? a.qkvm.sv : a.qkvm.sk, a.qkvm.S };
+                    const half4_t sc = ((const half4_t*) ((isv ? a.qkvm.svh_v : a.qkvm.svh_k) + hb * 128))[l32];
+                    float rs_p = 0.0f, rs_n = 0.0f;
+                    if (a.qkvm.rs.ss_new && l32 < (a.qkvm.rs.k >> 7)) { rs_p = a.qkvm.rs.ss_prev[(size_t) row * (a.qkvm.rs.k >> 7) + l32]; rs_n = a.qkvm.rs.ss_new[(size_t) row * (a.qkvm.rs.k >> 7) + l32]; }
+                    const int ph = a.qkvm.hd >> 3;
+                    float4_t sn4 = { 0.f, 0.f, 0.f, 0.f }, cs4 = sn4;
+                    if (a.qkvm.rope_mode == 2)
+                    {
+                        const int f = 4 * (l32 & (ph - 1));
+                        sn4 = *((const float4_t*) (a.qkvm.rope_sin + row * 64 + f)); cs4 = *((const float4_t*) (a.qkvm.rope_cos + row * 64 + f));
+                    }
+                    else
+                    {
+                        const int f = 2 * (l32 & ((a.qkvm.hd >> 2) - 1));
+                        sn4.x = a.qkvm.rope_sin[row * 64 + f]; sn4.y = a.qkvm.rope_sin[row * 64 + f + 1]; cs4.x = a.qkvm.rope_cos[row * 64 + f]; cs4.y = a.qkvm.rope_cos[row * 64 + f + 1];
+                    }
+                    const int64_t token_pos = a.qkvm.slots[row];
+                    const float4_t ysum = slab_sum(sr, hb, row, m, l32);
+                    const half4_t y = qkv_block_finish(ysum, sc, a.qkvm.rs, row, l32, rs_p, rs_n, !isv, a.qkvm.rope_mode, ph, sn4, cs4);
+                    const int64_t gb = token_pos * (kvb * 4) + hb * 4 + (l32 >> 3);
+                    uint32_t* cw = isv ? a.qkvm.v_cache : a.qkvm.k_cache; half_t* csc = isv ? a.qkvm.v_scales : a.qkvm.k_scales;
+                    kv_quant_regs<4>((float) y.x, (float) y.y, (float) y.z, (float) y.w, cw + gb * 4, csc + gb, actk, lane);
                 }
             }
         }
@@ -776,6 +875,7 @@ static void g4_launch_cb(int var, int mode, int nwv, dim3 grid, size_t lds, hipS
         case G4_MODE_TRAWX: LV(G4_MODE_TRAWX) break;
         case G4_MODE_TACT: LV(G4_MODE_TACT) break;
         case G4_MODE_ATTM: LV(G4_MODE_ATTM) break;
+        case G4_MODE_QKVM: LV(G4_MODE_QKVM) break;
         default:           LV(G4_MODE_ACT)  break;
     }
     #undef LV

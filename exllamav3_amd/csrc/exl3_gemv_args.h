@@ -51,6 +51,10 @@ __device__ __forceinline__ void fx_atomic_add(unsigned long long* acc, float v)
 #define GEMV_IN_ATTM      256  // (generation 4) o_proj whose input is the decode attention's OUTPUT, finished here: the flash-decoding merge of the context-split
                               // partial records (exl3_attn_decode.hip: {m, l, o[128]} per (sequence, kv block, query index, split)) is the preparation task of
                               // the (row, head) that needs it -- head_dim 128: one query head = one Hadamard block -- so the merge launch disappears
+#define GEMV_IN_QKVM      512  // (generation 4) o_proj fed by the q|k|v launch's deferred slabs WITHOUT the attention core in between (the linears-only decode step): the
+                              // preparation task of (row, block) finishes q block `block` (split-k reduce, output Hadamard, row-scale correction, svh, RoPE:
+                              // exl3_glue_device.cuh qkv_block_finish, the arithmetic of glue_qkv_kernel) and half-waves without a preparation task in the
+                              // column-block-0 workgroups finish and append the K / V rows -- the glue_qkv launch disappears
 #define GEMV_MAX_MATS 4
 
 // r = rsqrt(sum(ss_new[row]) / k + eps) / rsqrt(sum(ss_prev[row]) / k + eps): the exact RMSNorm scale over the estimate a GEMV_IN_RESID launch used.
@@ -58,6 +62,19 @@ struct GemvRescale { const float* ss_prev; const float* ss_new; int k; float eps
 
 // GEMV_IN_ATTM operands: partial records part[((row * blocks + h) * gq + i) * nsplit + split][132] fp32 = {m, l, -, -, o[128]} of query head h * gq + i
 struct GemvAttm { const float* part; int nsplit, gq, blocks; uint32_t magic_gq; };
+
+// GEMV_IN_QKVM operands: the q|k|v launch's slab sets (slab(c, s, row) = base + ((c * S + s) * m + row) * 128) and their column scales, the per-step
+// rope tables and cache rows of exl3_qkv_prep, the row-scale correction, the 4-bit paged cache of the layer
+struct GemvQkvm
+{
+    const float* sq; const float* sk; const float* sv; int S; int rope_mode;
+    const half_t* svh_q; const half_t* svh_k; const half_t* svh_v;
+    const float* rope_sin; const float* rope_cos; const int64_t* slots;
+    GemvRescale rs;
+    half_t* q_out;                          // optional [m][k]: the finished queries (written by the column-block-0 workgroups)
+    uint32_t* k_cache; half_t* k_scales; uint32_t* v_cache; half_t* v_scales;
+    int hd, kvb;                            // head_dim (64 | 128), 128-value blocks of the kv vector (heads_kv * hd / 128)
+};
 
 struct GemvMat
 {
@@ -196,6 +213,7 @@ struct GemvArgs
     // gate|up launch are zeroed by the o_proj launch in front of it -- no memset node in the graph
     void* fx_zero; int fx_zero_n16;
     GemvAttm attm;
+    GemvQkvm qkvm;
 };
 static_assert(offsetof(GemvArgs, mat) == 128, "GemvArgs: the hot block is two 64-byte lines");
 

@@ -1783,6 +1783,26 @@ def exl3_gemv_ex_attm(part: torch.Tensor, nsplit: int, heads_q: int, heads_kv: i
     return [int(slab[0]) if slab[0] else 0], S.value
 
 
+def exl3_gemv_ex_qkvm(slabs, S_qkv: int, svh_q, svh_k, svh_v, tab, ss_prev, ss_new, hidden: int, eps: float, head_dim: int, heads_kv: int,
+                      k_cache, k_scales, v_cache, v_scales, B, C, suh, svh, m: int, mcg: bool, mul1: bool, flags: int = 0, force_split: int = 0,
+                      rope_mode: int = 2, q_out=None, c_fp32: bool = False):
+    """o_proj fed straight by the q|k|v launch's deferred slabs (the decode step without the attention core): glue_qkv_rs(tab=...)'s work -- reduce,
+    output Hadamard, row-scale correction, svh, RoPE, 4-bit K / V append -- runs inside o_proj's launch (same bits, one launch less per layer).
+    tab = (sin, cos, slots) of qkv_prep.  Returns ([slab], S) like exl3_gemv_ex."""
+    _dev(B)
+    k, K = _kK(B)
+    _req(tab is not None and len(tab) == 3, "exl3_gemv_ex_qkvm: needs the (sin, cos, slots) tables of qkv_prep")
+    _req(_kv_bits(k_cache, k_scales) == 4 and _kv_bits(v_cache, v_scales) == 4, "exl3_gemv_ex_qkvm: 4-bit K and V cache")
+    _req(head_dim in (64, 128) and k % 128 == 0, "exl3_gemv_ex_qkvm: head_dim 64 | 128")
+    slab = (_vp * 1)()
+    S = ctypes.c_int(0)
+    _check(_lib.lib().exl3_gemv_ex_qkvm(slabs[0], slabs[1], slabs[2], int(S_qkv), _p(svh_q), _p(svh_k), _p(svh_v), _p(tab[0]), _p(tab[1]), _p(tab[2]),
+                                        _p(ss_prev), _p(ss_new), int(hidden), float(eps), int(rope_mode), int(head_dim), int(heads_kv), _p(q_out),
+                                        _p(k_cache), _p(k_scales), _p(v_cache), _p(v_scales), _p(B), _p(C), _p(suh), _p(svh), None, m, k, B.shape[1] * 16, K,
+                                        _cb(mcg, mul1), int(c_fp32), flags, force_split, slab, ctypes.byref(S), _stream(B)))
+    return [int(slab[0]) if slab[0] else 0], S.value
+
+
 def attn_decode_qcache(q, out, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, max_len: int, scale: float | None = None,
                        workspace: torch.Tensor | None = None, sinks: torch.Tensor | None = None):
     """Decode attention straight from the quantized paged cache.  q / out: (bsz, heads_q, 128) fp16; caches (pages, page, G * bits) int32 +

@@ -404,6 +404,9 @@ class SyntheticEXL3Llama:
     #: ... and the q|k|v epilogue (split-k reduce, output Hadamard, RoPE, 4-bit append of the new token) runs inside the attention's context-split launch
     #: (ext.attn_decode_qcache_split_qkv) instead of glue_qkv_rs: 6 launches per layer with attention, same bits
     attn_qkv_in_split = os.environ.get("EXL3_HIP_ATTN_QKV_IN_SPLIT", "1") != "0"
+    #: fx pipeline WITHOUT the attention core (the linears-only step: o_proj's input is the finished q): glue_qkv_rs's work -- reduce, output Hadamard, RoPE,
+    #: 4-bit K / V append -- runs inside o_proj's launch (ext.exl3_gemv_ex_qkvm): 5 launches per layer instead of 6 (4 with fx_act_in_gemv), same bits
+    qkv_in_oproj = os.environ.get("EXL3_HIP_QKV_IN_OPROJ", "1") != "0"
 
     #: lm_head at m <= 4: glue_rotate + pre-rotated GEMV instead of the in-GEMV RMSNorm (the 1002-column-block launch repeats the 32 input
     #: Hadamards in every workgroup in NORM mode)
@@ -705,9 +708,11 @@ class SyntheticEXL3Llama:
                                                           kc, ks, vc, vs, self.block_table, self.attn_lens, self.attn_pos + 1, self.attn_ws, tab,
                                                           sc, so_, hidden, self.eps)
                 attm = (self.attn_ws, ns_)
-            else:
+            qkvm = (not self.with_attention and self.qkv_in_oproj and not self.fx_gu_atomic and tab is not None and self.kv_bits == 4 and hd in (64, 128))
+            if not fuse_qkv and not qkvm:
                 ext.glue_qkv_rs(slabs, S, lq.svh, lk.svh, lv.svh, self.q, None, None, self.inv_freq, self.positions, kc, ks, vc, vs,
                                 self.block_table, self.page, self.kv_bits, self.kv_bits, bsz, self.hq, self.hkv, hd, sc, so_, hidden, self.eps, tab=tab)
+            qk_sc, qk_so = sc, so_                                        # the q|k|v launch's (previous, new) sums of squares: the row-scale correction of its outputs
             sc, so_ = so_, sc
             o_in = q2
             if self.with_attention and hd in (64, 128) and not fuse_qkv:
@@ -731,6 +736,10 @@ class SyntheticEXL3Llama:
                 continue
             if attm is not None:
                 ext.exl3_gemv_ex_attm(attm[0], attm[1], self.hq, self.hkv, lo.trellis, R, lo.suh, lo.svh, bsz, lo.mcg, lo.mul1, ATOM, sp["o"])
+            elif qkvm:
+                # no attention core: q|k|v epilogue (rope, K / V append) inside o_proj's launch, q finished by the preparation task that needs it
+                ext.exl3_gemv_ex_qkvm(slabs, S, lq.svh, lk.svh, lv.svh, tab, qk_sc, qk_so, hidden, self.eps, hd, self.hkv, kc, ks, vc, vs,
+                                      lo.trellis, R, lo.suh, lo.svh, bsz, lo.mcg, lo.mul1, ATOM, sp["o"], q_out=self.q)
             else:
                 ext.exl3_gemv_ex(o_in, None, None, [lo.trellis], [R], [lo.suh], [lo.svh], bsz, lo.mcg, lo.mul1, ATOM, sp["o"])
             sgu, Sgu = ext.exl3_gemv_ex_fx(R, L["norm2"], sc, so_, self.eps, [lg.trellis, lu.trellis], [lg.suh, lu.suh], bsz, lg.mcg, lg.mul1, sp["gu"])

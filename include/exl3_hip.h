@@ -376,6 +376,17 @@ int exl3_attn_decode_qcache_split_qkv(const float* sq, const float* sk, const fl
                                       float* workspace, int64_t workspace_floats, int* nsplit_out, int* fused_out, void* stream);
 int exl3_gemv_ex_attm(const float* part, int nsplit, int gq, int blocks, const void* B, void* C, const void* suh, const void* svh, const void* bias,
                       int m, int k, int n, int K, int cb, int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream);
+
+/* o_proj fed straight by the q|k|v launch's deferred slabs -- the decode step WITHOUT the attention core, where o_proj's input is the finished q:
+ * exl3_glue_qkv_tab's work (split-k reduce, output Hadamard, row-scale correction, svh, RoPE from the per-step tables of exl3_qkv_prep, the 4-bit append of
+ * K / V at slots[row]) runs inside this launch; bit-identical to exl3_glue_qkv_tab + exl3_gemv_ex, one launch less per layer.  head_dim 64 | 128, 4-bit K
+ * and V, m <= 4; q_out (optional, [m][k] fp16) receives the finished queries.  Other arguments as exl3_gemv_ex.
+ * reference nodes replaced: libtorch/attention.cpp:283-400 (q / k / v epilogues, rope, cache append) + :497-508 (o_proj). */
+int exl3_gemv_ex_qkvm(const float* sq, const float* sk, const float* sv, int S_qkv, const void* svh_q, const void* svh_k, const void* svh_v,
+                      const float* rope_sin, const float* rope_cos, const int64_t* slots, const float* ss_prev, const float* ss_new, int hidden, float eps,
+                      int rope_mode, int head_dim, int heads_kv, void* q_out, void* k_cache, void* k_scales, void* v_cache, void* v_scales,
+                      const void* B, void* C, const void* suh, const void* svh, const void* bias, int m, int k, int n, int K, int cb, int c_fp32,
+                      int flags, int force_split, float** slab_out, int* S_out, void* stream);
 /* Prefill (multi-token) causal attention over paged fp16 K/V -- the attention step of the reference's prefill path: cache/quant.py:83-117
  * dequantizes the pages (exl3_dequant_cache_paged), then flash_attn_with_kvcache(q, k_pages, v_pages, block_table, cache_seqlens, causal) attends.
  * q / out fp16 [bsz][q_len][heads_q][head_dim] (head_dim 128 or 64); k_pages / v_pages fp16 [pages][page_size][heads_kv][head_dim];

@@ -1179,6 +1179,44 @@ def test_attention_merge_inside_oproj_is_bit_identical_to_the_merge_launch(dev, 
     assert np.array_equal(model.logits.float().cpu().numpy(), l1)
 
 
+@pytest.mark.parametrize("hq,hkv,hd", [(4, 2, 128), (8, 1, 128), (8, 2, 64), (16, 8, 64)])
+@pytest.mark.parametrize("bsz", [1, 2])
+def test_qkv_epilogue_inside_oproj_is_bit_identical_to_the_glue_launch(dev, hq, hkv, hd, bsz):
+    """fx step WITHOUT the attention core (o_proj's input is the finished q): the q|k|v epilogue inside o_proj's launch (ext.exl3_gemv_ex_qkvm: preparation
+    tasks finish the q block they need, idle half-waves of the column-block-0 workgroups append K / V) against glue_qkv_rs + o_proj as two launches --
+    logits, final residual, the last layer's q and every cache word and scale of every layer bit for bit; head_dim 128 and 64 (two heads per
+    Hadamard block), batch 1 and 2 (the second row's K / V tasks land on busy half-waves); graph replay reproduces the eager bits."""
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 512, 768, 2, hq, hkv, hd, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=1024)
+    model.alloc_state(bsz, pos=77)
+    g = torch.Generator(device="cpu").manual_seed(hq * 100 + hd + bsz)
+    for c, s_ in model.kcache + model.vcache:
+        c.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, c.shape, generator=g, dtype=torch.int64).to(torch.int32).to(dev))
+        s_.copy_((torch.rand(s_.shape, generator=g) * 0.5 + 0.05).half().to(dev))
+    saved = [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]
+    outs = []
+    for fused in (False, True):
+        model.qkv_in_oproj = fused
+        for (c, s_), (c0, s0) in zip(model.kcache + model.vcache, saved):
+            c.copy_(c0); s_.copy_(s0)
+        model.q.zero_()
+        lg = model.decode_step_fx().float().cpu().numpy().copy()
+        outs.append((lg, model.x_final.clone(), model.q.clone(), [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]))
+    (l0, x0_, q0, kv0), (l1, x1_, q1, kv1) = outs
+    assert np.isfinite(l1).all()
+    assert np.array_equal(l0, l1) and torch.equal(x0_, x1_) and torch.equal(q0, q1)
+    assert all(torch.equal(a0, a1) and torch.equal(b0, b1) for (a0, b0), (a1, b1) in zip(kv0, kv1))
+    assert all(not torch.equal(a1, a0) for (a1, _), (a0, _) in zip(kv1, saved))                  # something was appended in every layer
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            model.decode_step_fx()
+    model.logits.zero_(); gr.replay(); torch.cuda.synchronize()
+    assert np.array_equal(model.logits.float().cpu().numpy(), l1)
+
+
 @pytest.mark.parametrize("gq", [1, 2, 3, 5, 6, 7, 8])
 @pytest.mark.parametrize("pos,bsz", [(130, 1), (1000, 2)])
 def test_attention_qkv_in_split_every_group_size(dev, gq, pos, bsz):
