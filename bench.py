@@ -626,6 +626,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(shape, args.bits, cb)
 
+    # the fx pipeline's launches per layer: 6; silu(g) * u inside the down launch: -1; without the attention core the q|k|v epilogue inside o_proj's launch: -1
+    fx_act_in = bool(getattr(model, "fx_act_in_gemv", False) or getattr(model, "fx_gu_atomic", False))
+    fx_qkvm = bool(getattr(model, "qkv_in_oproj", False)) and not args.attention and not getattr(model, "fx_gu_atomic", False) and args.kv_bits == 4 and not is_moe
+    fx_desc = ("fixed-point-residual pipeline (%d launches/layer: o_proj / down_proj add into a 64-bit fixed-point residual with integer atomics, no split-k-reduce / "
+               "residual launches%s%s)" % (6 - int(fx_act_in) - int(fx_qkvm), "; silu(g) * u formed inside the down launch" if fx_act_in else "",
+                                           "; the q|k|v epilogue (RoPE, K / V append) runs inside o_proj's launch" if fx_qkvm else ""))
     if rank == 0:
         out = {
             "metric": ("decode tok/s, Mixtral-8x7B EXL3 %d.0bpw hot path (attention linears + top-2 of 8 experts per layer + RMSNorm + RoPE + KV-quant), bs=%d" % (args.bits, args.batch)) if is_moe else "decode tok/s, %s EXL3 %d.0bpw hot path (all quantized linears + RMSNorm + RoPE + KV-quant), bs=%d" % (
@@ -635,7 +641,7 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{shape.name} EXL3 {args.bits}.0bpw {args.codebook} codebook, decode bs={args.batch}, "
                                    f"{model.n_layers} layers, {'attention TP=%d + expert-parallel MoE over %d rank(s)' % (world, world) if is_moe else 'TP=%d' % world}, {args.kv_bits}-bit KV append, "
-                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, { 'glue pipeline + indexed exl3_mgemm MoE block' if is_moe else {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (%d launches/layer)' % (7 if (args.batch == 1 and model.act_in_gemv and world == 1) else ((8 if (world == 1 and model.fold_rotate) else 10) if args.batch > 4 else 8)), 'resid': 'resid-in-GEMV pipeline (5 launches/layer: residual add + RMSNorm finished inside the consumer GEMV)' if (args.batch <= 4 and world == 1) else 'fused glue pipeline', 'fx': 'fixed-point-residual pipeline (%d launches/layer: o_proj / down_proj add into a 64-bit fixed-point residual with integer atomics, no split-k-reduce / residual launches%s)' % ((5, '; silu(g) * u formed inside the down launch') if (model.fx_act_in_gemv or model.fx_gu_atomic) else (6, '')) if (args.batch <= model.fx_max_bsz and world == 1) else 'fused glue pipeline', 'unfused': 'one launch per reference op'}[pipeline] }; "
+                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, { 'glue pipeline + indexed exl3_mgemm MoE block' if is_moe else {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (%d launches/layer)' % (7 if (args.batch == 1 and model.act_in_gemv and world == 1) else ((8 if (world == 1 and model.fold_rotate) else 10) if args.batch > 4 else 8)), 'resid': 'resid-in-GEMV pipeline (5 launches/layer: residual add + RMSNorm finished inside the consumer GEMV)' if (args.batch <= 4 and world == 1) else 'fused glue pipeline', 'fx': fx_desc if (args.batch <= model.fx_max_bsz and world == 1) else 'fused glue pipeline', 'unfused': 'one launch per reference op'}[pipeline] }; "
                                    f"{'attention core INCLUDED: quant-cache-direct decode attention over a 1000-token context' if args.attention else 'attention core excluded (SURVEY.md 2.1)'}",
                        "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
                        "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),
