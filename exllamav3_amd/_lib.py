@@ -152,7 +152,7 @@ def _declare(l):
         i32, i32, i32, i32, i32, i32, f32, vp, i64, ctypes.POINTER(i32), ctypes.POINTER(i32), vp)
     sig("exl3_attn_decode_qcache_sinks", vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, i64, vp, vp)
     sig("exl3_attn_decode_qcache_split", vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, i64, ctypes.POINTER(i32), vp)
-    sig("exl3_gemv_ex_attm", vp, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
+    sig("exl3_gemv_ex_attm", vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
     sig("exl3_gemv_ex_qkvm", vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
         i32, i32, ctypes.POINTER(vp), ctypes.POINTER(i32), vp)
     sig("exl3_gemv_ex_act_rs", vp, vp, i32, vp, vp, vp, vp, i32, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)

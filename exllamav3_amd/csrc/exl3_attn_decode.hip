@@ -627,7 +627,7 @@ extern "C" int exl3_attn_decode_qcache_split(const void* q, const void* k_cache,
                                              int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
                                              float* workspace, int64_t workspace_floats, int* nsplit_out, void* stream)
 {
-    EXL3_CHECK_ARG(nsplit_out && workspace && head_dim == 128, "attn_decode_split: needs the workspace, nsplit_out and head_dim 128");
+    EXL3_CHECK_ARG(nsplit_out && workspace && (head_dim == 128 || head_dim == 64), "attn_decode_split: needs the workspace, nsplit_out and head_dim 128 or 64");
     return attn_decode_impl(q, nullptr, k_cache, k_scales, v_cache, v_scales, block_table, cache_seqlens, bsz, blocks_per_seq, page_size, k_bits, v_bits, heads_q, heads_kv,
                             head_dim, max_len, scale, workspace, workspace_floats, stream, nsplit_out);
 }
@@ -688,7 +688,8 @@ static int attn_decode_impl(const void* q, void* out, const void* k_cache, const
     if (cap > (head_dim == 128 ? 256 : 128)) cap = head_dim == 128 ? 256 : 128;       // the merge kernel keeps 8 chunks of 32 / 16 split statistics in registers
     if (nsplit > cap) { nsplit = cap; split_tokens = ((max_len + nsplit - 1) / nsplit + 7) / 8 * 8; nsplit = (max_len + split_tokens - 1) / split_tokens; }
     // (split-only callers hand the records to a consumer that keeps one chunk of 32 split statistics: cap the split count there)
-    if (split_only && nsplit > 32) { nsplit = 32; split_tokens = ((max_len + nsplit - 1) / nsplit + 7) / 8 * 8; nsplit = (max_len + split_tokens - 1) / split_tokens; }
+    const int cap_so = head_dim == 128 ? 32 : 16;                                   // (head_dim 64: two heads per half-wave, 16 statistics lanes each)
+    if (split_only && nsplit > cap_so) { nsplit = cap_so; split_tokens = ((max_len + nsplit - 1) / nsplit + 7) / 8 * 8; nsplit = (max_len + split_tokens - 1) / split_tokens; }
     EXL3_CHECK_ARG((nsplit == 1 && !split_only && !sinks) || (workspace && workspace_floats >= (int64_t) bsz * blocks * gq * nsplit * 132), "attn_decode: workspace too small for the context splits");
     EXL3_CHECK_ARG(!sinks || !split_only, "attn_decode: attention sinks are merged by the merge kernel (not by the split-only forms)");
     AttnArgs a;

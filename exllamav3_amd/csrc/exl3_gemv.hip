@@ -311,9 +311,10 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                    "exl3_gemv_ex (cpw): wave-per-column-block launches are deferred, m <= 4, raw / resid / act input");
     if (act_g) flags |= GEMV_IN_ACT;
     if (attm) flags |= GEMV_IN_ATTM;
-    EXL3_CHECK_ARG(!attm || (attm->part && attm->nsplit >= 1 && attm->nsplit <= 32 && attm->gq >= 1 && attm->blocks >= 1 && count == 1 && m <= 4 && !tbl && !epi && cpw == 0
-                             && !rsd && !act_g && !(flags & (GEMV_IN_ROTATED | GEMV_IN_NORM)) && k == attm->gq * attm->blocks * 128),
-                   "exl3_gemv_ex_attm: one matrix, m <= 4, at most 32 context splits, k = heads_q x 128");
+    EXL3_CHECK_ARG(!attm || (attm->part && attm->nsplit >= 1 && (attm->hd == 128 || attm->hd == 64) && attm->nsplit <= (attm->hd == 128 ? 32 : 16) && attm->gq >= 1 && attm->blocks >= 1
+                             && count == 1 && m <= 4 && !tbl && !epi && cpw == 0 && !rsd && !act_g && !(flags & (GEMV_IN_ROTATED | GEMV_IN_NORM))
+                             && k == attm->gq * attm->blocks * 128),
+                   "exl3_gemv_ex_attm: one matrix, m <= 4, at most 32 (head_dim 128) / 16 (head_dim 64) context splits, k = heads_q x head_dim");
     if (qkvm) flags |= GEMV_IN_QKVM;
     EXL3_CHECK_ARG(!qkvm || (qkvm->sq && qkvm->sk && qkvm->sv && qkvm->S >= 1 && qkvm->svh_q && qkvm->svh_k && qkvm->svh_v && qkvm->rope_sin && qkvm->rope_cos && qkvm->slots
                              && qkvm->k_cache && qkvm->k_scales && qkvm->v_cache && qkvm->v_scales && (qkvm->hd == 64 || qkvm->hd == 128) && qkvm->kvb >= 1
@@ -1045,13 +1046,13 @@ extern "C" int exl3_gemv_ex_act_rs(const float* g_slabs, const float* u_slabs, i
 // left ([m][blocks][gq][nsplit][132] fp32), merged per (row, query head) by the preparation task that needs that head (head_dim 128: one head = one
 // Hadamard block of o_proj's input) with the arithmetic of the merge kernel -- same bits as attn_decode_qcache + exl3_gemv_ex, one launch less.
 // flags: GEMV_OUT_DEFERRED or GEMV_OUT_ATOMIC (C = the fixed-point residual) or 0 (final output).  reference: libtorch/attention.cpp:246-504 (attention, then o_proj).
-extern "C" int exl3_gemv_ex_attm(const float* part, int nsplit, int gq, int blocks, const void* B, void* C, const void* suh, const void* svh, const void* bias,
+extern "C" int exl3_gemv_ex_attm(const float* part, int nsplit, int gq, int blocks, int head_dim, const void* B, void* C, const void* suh, const void* svh, const void* bias,
                                  int m, int k, int n, int K, int cb, int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream)
 {
     EXL3_CHECK_ARG(part && B && suh, "exl3_gemv_ex_attm: null pointer");
     const void* Bs[1] = { B }; void* Cs[1] = { C }; const void* su[1] = { suh }; const void* sv[1] = { svh }; const void* bi[1] = { bias };
     int ns[1] = { n };
-    GemvAttm at = { part, nsplit, gq, blocks, 0u };
+    GemvAttm at = { part, nsplit, gq, blocks, 0u, head_dim };
     return run_mgemm(nullptr, Bs, C ? Cs : nullptr, su, svh ? sv : nullptr, bi, ns, 1, m, k, K, cb, c_fp32, force_split, (hipStream_t) stream,
                      (flags & (GEMV_OUT_DEFERRED | GEMV_OUT_ATOMIC)), nullptr, nullptr, slab_out, S_out, nullptr, nullptr, nullptr, 0.0f, nullptr,
                      nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, &at);

@@ -234,11 +234,22 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     float4_t ql[NQL], sn4, cs4; };
     const int at_nsplit = MODE == G4_MODE_ATTM ? a.attm.nsplit : 1, at_gq = MODE == G4_MODE_ATTM ? a.attm.gq : 1;
     const float* const at_part = MODE == G4_MODE_ATTM ? a.attm.part : nullptr;
-    // partial records of (row, head): head = absolute Hadamard block of the input = query head (head_dim 128); h = head / gq, i = head % gq
-    auto attm_rec = [&] (int row, int head) -> const float*
+    // partial records of (row, Hadamard block of o_proj's input).  head_dim 128: the block is query head `blk` = record (kv block blk / gq, query index
+    // blk % gq), lane l32 owns accumulators 4 l32 .. + 3 and the statistics pair at offset 0.  head_dim 64: the block holds query heads 2 blk and 2 blk + 1
+    // (lanes 0-15 / 16-31); head qh belongs to kv head qh / gq = half `kv & 1` of the records of kv block kv >> 1 -- per-lane record base, statistics at
+    // offset 2 * half, accumulators at 4 + 64 * half + 4 * (l32 & 15)
+    const bool at_hd64 = MODE == G4_MODE_ATTM && a.attm.hd == 64;
+    const int at_lr = at_hd64 ? (l32 & 15) : l32;                                      // lane inside its head: holds the statistics of split at_lr
+    struct AttmRec { const float* p; int st_off, acc_off; };
+    auto attm_rec = [&] (int row, int blk) -> AttmRec
     {
-        const int h = gemv_udiv(head, a.attm.magic_gq), i = head - h * at_gq;
-        return at_part + ((((size_t) row * a.attm.blocks + h) * at_gq + i) * at_nsplit) * 132;
+        const int qh = at_hd64 ? 2 * blk + (l32 >> 4) : blk;
+        const int kv = gemv_udiv(qh, a.attm.magic_gq), i = qh - kv * at_gq;
+        const int h = at_hd64 ? kv >> 1 : kv, half = at_hd64 ? (kv & 1) : 0;
+        AttmRec r;
+        r.p = at_part + ((((size_t) row * a.attm.blocks + h) * at_gq + i) * at_nsplit) * 132;
+        r.st_off = 2 * half; r.acc_off = 4 + 64 * half + 4 * at_lr;
+        return r;
     };
     const int ntask = nb * m;
     auto fetch = [&] (int it) -> PrepIn
@@ -262,10 +273,10 @@ void exl3_gemv4_kernel(const GemvArgs a)
         r.sv = ((const half4_t*) (suh + kofs))[l32];
         if constexpr (MODE == G4_MODE_ATTM)
         {
-            const float* p = attm_rec(row, (k0s >> 7) + blk);
-            r.mst = *((const float2*) (p + (size_t) min(l32, at_nsplit - 1) * 132));                 // lane s: {m, l} of split s (masked at its use)
+            const AttmRec rc = attm_rec(row, (k0s >> 7) + blk);
+            r.mst = *((const float2*) (rc.p + (size_t) min(at_lr, at_nsplit - 1) * 132 + rc.st_off));      // lane s of a head: {m, l} of split s (masked at its use)
             #pragma unroll
-            for (int u = 0; u < NMO; ++u) r.mo[u] = *((const float4_t*) (p + (size_t) min(u, at_nsplit - 1) * 132 + 4 + 4 * l32));
+            for (int u = 0; u < NMO; ++u) r.mo[u] = *((const float4_t*) (rc.p + (size_t) min(u, at_nsplit - 1) * 132 + rc.acc_off));
         }
         if constexpr (MODE == G4_MODE_QKVM)
         {
@@ -511,17 +522,21 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     // attn_merge_kernel<128> (exl3_attn_decode.hip) operation for operation, so the bits are those of the two-launch route: statistics by
                     // butterflies, the splits in four consecutive groups of ceil(nsplit / 4) summed sequentially and combined ((P0 + P1) + P2) + P3
                     // (its four helper half-waves), 1 / L, the inverse 32-point rotation, fp16.  nsplit <= 32 (host-checked): one chunk of statistics.
-                    const float* p = attm_rec(row, (k0s >> 7) + blk);
-                    const bool has = l32 < at_nsplit;
+                    // head_dim 64 (attn_merge_kernel<64>): two heads per block, 16 lanes each -- the butterflies stop at 8, at most 16 splits
+                    const AttmRec rc = attm_rec(row, (k0s >> 7) + blk);
+                    const float* p = rc.p;
+                    const bool has = at_lr < at_nsplit;
                     const float m_s = has ? cur.mst.x : -1.0e30f, l_s = has ? cur.mst.y : 0.0f;
                     float M = m_s;
                     #pragma unroll
-                    for (int i = 1; i < 32; i <<= 1) M = fmaxf(M, xor_lane(M, i));
+                    for (int i = 1; i < 16; i <<= 1) M = fmaxf(M, xor_lane(M, i));
+                    if (!at_hd64) M = fmaxf(M, xor_lane(M, 16));
                     const float e_s = m_s > -1.0e29f ? __expf(m_s - M) : 0.0f;
                     float L = l_s * e_s;
                     #pragma unroll
-                    for (int i = 1; i < 32; i <<= 1) L += xor_lane(L, i);
-                    const int per = (at_nsplit + 3) >> 2, lbase = lane - l32;
+                    for (int i = 1; i < 16; i <<= 1) L += xor_lane(L, i);
+                    if (!at_hd64) L += xor_lane(L, 16);
+                    const int per = (at_nsplit + 3) >> 2, lbase = lane - at_lr;
                     float4_t P[4];
                     #pragma unroll
                     for (int hh = 0; hh < 4; ++hh) P[hh] = float4_t{ 0.f, 0.f, 0.f, 0.f };
@@ -529,7 +544,7 @@ void exl3_gemv4_kernel(const GemvArgs a)
                     {
                         float4_t ov[NMO];
                         #pragma unroll
-                        for (int u = 0; u < NMO; ++u) ov[u] = s0 == 0 ? cur.mo[u] : *((const float4_t*) (p + (size_t) min(s0 + u, at_nsplit - 1) * 132 + 4 + 4 * l32));
+                        for (int u = 0; u < NMO; ++u) ov[u] = s0 == 0 ? cur.mo[u] : *((const float4_t*) (p + (size_t) min(s0 + u, at_nsplit - 1) * 132 + rc.acc_off));
                         #pragma unroll
                         for (int u = 0; u < NMO; ++u)
                         {

@@ -61,7 +61,7 @@ __device__ __forceinline__ void fx_atomic_add(unsigned long long* acc, float v)
 struct GemvRescale { const float* ss_prev; const float* ss_new; int k; float eps; };
 
 // GEMV_IN_ATTM operands: partial records part[((row * blocks + h) * gq + i) * nsplit + split][132] fp32 = {m, l, -, -, o[128]} of query head h * gq + i
-struct GemvAttm { const float* part; int nsplit, gq, blocks; uint32_t magic_gq; };
+struct GemvAttm { const float* part; int nsplit, gq, blocks; uint32_t magic_gq; int hd; };      // hd: head_dim 128 | 64 (64: two query heads per Hadamard block, records of exl3_attn_decode.hip's NSUB = 2 form)
 
 // GEMV_IN_QKVM operands: the q|k|v launch's slab sets (slab(c, s, row) = base + ((c * S + s) * m + row) * 128) and their column scales, the per-step
 // rope tables and cache rows of exl3_qkv_prep, the row-scale correction, the 4-bit paged cache of the layer

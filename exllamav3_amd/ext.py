@@ -1732,7 +1732,7 @@ def attn_decode_qcache_split(q, k_cache, k_scales, v_cache, v_scales, block_tabl
     """The context-split half of attn_decode_qcache (head_dim 128): partial records stay in `workspace`; returns the split count for
     exl3_gemv_ex_attm, which merges them inside o_proj's launch."""
     _dev(q)
-    _req(q.dtype == torch.half and q.dim() == 3 and q.shape[-1] == 128 and q.is_contiguous(), "attn_decode_split: q must be contiguous (bsz, heads, 128) float16")
+    _req(q.dtype == torch.half and q.dim() == 3 and q.shape[-1] in (64, 128) and q.is_contiguous(), "attn_decode_split: q must be contiguous (bsz, heads, 64 | 128) float16")
     _req(block_table.dtype == torch.int32 and cache_seqlens.dtype == torch.int32, "attn_decode: block_table / cache_seqlens must be int32")
     _req(workspace is not None and workspace.dtype == torch.float and workspace.is_contiguous(), "attn_decode_split: float32 workspace required")
     bsz, hq, hd = q.shape
@@ -1770,15 +1770,15 @@ def attn_decode_qcache_split_qkv(slabs, S: int, svh_q, svh_k, svh_v, q_out, inv_
 
 
 def exl3_gemv_ex_attm(part: torch.Tensor, nsplit: int, heads_q: int, heads_kv: int, B, C, suh, svh, m: int, mcg: bool, mul1: bool, flags: int = 0,
-                      force_split: int = 0, c_fp32: bool = False):
+                      force_split: int = 0, c_fp32: bool = False, head_dim: int = 128):
     """o_proj whose input is the decode attention's output, merged from the context-split partial records inside the launch (ext.attn_decode_qcache_split).
-    Returns ([slab], S) like exl3_gemv_ex."""
+    head_dim 128, or 64 (two query heads per Hadamard block of o_proj's input, at most 16 splits).  Returns ([slab], S) like exl3_gemv_ex."""
     _dev(B)
     k, K = _kK(B)
-    _req(k == heads_q * 128 and heads_q % heads_kv == 0, "exl3_gemv_ex_attm: k must be heads_q x 128")
+    _req(head_dim in (64, 128) and k == heads_q * head_dim and heads_q % heads_kv == 0 and (heads_kv * head_dim) % 128 == 0, "exl3_gemv_ex_attm: k must be heads_q x head_dim")
     slab = (_vp * 1)()
     S = ctypes.c_int(0)
-    _check(_lib.lib().exl3_gemv_ex_attm(_p(part), int(nsplit), heads_q // heads_kv, heads_kv, _p(B), _p(C), _p(suh), _p(svh), None, m, k, B.shape[1] * 16, K,
+    _check(_lib.lib().exl3_gemv_ex_attm(_p(part), int(nsplit), heads_q // heads_kv, heads_kv * head_dim // 128, int(head_dim), _p(B), _p(C), _p(suh), _p(svh), None, m, k, B.shape[1] * 16, K,
                                         _cb(mcg, mul1), int(c_fp32), flags, force_split, slab, ctypes.byref(S), _stream(B)))
     return [int(slab[0]) if slab[0] else 0], S.value
 

@@ -403,6 +403,9 @@ class SyntheticEXL3Llama:
     attn_merge_in_oproj = os.environ.get("EXL3_HIP_ATTN_MERGE_IN_OPROJ", "1") != "0"
     #: ... and the q|k|v epilogue (split-k reduce, output Hadamard, RoPE, 4-bit append of the new token) runs inside the attention's context-split launch
     #: (ext.attn_decode_qcache_split_qkv) instead of glue_qkv_rs: 6 launches per layer with attention, same bits
+    #: the same merge at head_dim 64 (two query heads per Hadamard block; exl3_gemv_ex_attm takes them): bit-identical, but the 16-split cap of its 16-lane
+    #: statistics makes the context splits twice as long -- Llama-3.2-1B with attention 1468 -> 1377 tok/s (round 4, same box) -- so it stays opt-in
+    attn_merge_in_oproj_hd64 = os.environ.get("EXL3_HIP_ATTN_MERGE_IN_OPROJ_HD64", "0") == "1"
     attn_qkv_in_split = os.environ.get("EXL3_HIP_ATTN_QKV_IN_SPLIT", "1") != "0"
     #: fx pipeline WITHOUT the attention core (the linears-only step: o_proj's input is the finished q): glue_qkv_rs's work -- reduce, output Hadamard, RoPE,
     #: 4-bit K / V append -- runs inside o_proj's launch (ext.exl3_gemv_ex_qkvm): 5 launches per layer instead of 6 (4 with fx_act_in_gemv), same bits
@@ -716,7 +719,7 @@ class SyntheticEXL3Llama:
             sc, so_ = so_, sc
             o_in = q2
             if self.with_attention and hd in (64, 128) and not fuse_qkv:
-                if hd == 128 and self.attn_merge_in_oproj and not self.fx_gu_atomic:
+                if self.attn_merge_in_oproj and not self.fx_gu_atomic and (hd == 128 or self.attn_merge_in_oproj_hd64):
                     attm = (self.attn_ws, ext.attn_decode_qcache_split(self.q.view(bsz, self.hq, hd), kc, ks, vc, vs, self.block_table, self.attn_lens,
                                                                        self.attn_pos + 1, self.attn_ws))
                 else:
@@ -735,7 +738,7 @@ class SyntheticEXL3Llama:
                 sc, so_ = so_, sc
                 continue
             if attm is not None:
-                ext.exl3_gemv_ex_attm(attm[0], attm[1], self.hq, self.hkv, lo.trellis, R, lo.suh, lo.svh, bsz, lo.mcg, lo.mul1, ATOM, sp["o"])
+                ext.exl3_gemv_ex_attm(attm[0], attm[1], self.hq, self.hkv, lo.trellis, R, lo.suh, lo.svh, bsz, lo.mcg, lo.mul1, ATOM, sp["o"], head_dim=hd)
             elif qkvm:
                 # no attention core: q|k|v epilogue (rope, K / V append) inside o_proj's launch, q finished by the preparation task that needs it
                 ext.exl3_gemv_ex_qkvm(slabs, S, lq.svh, lk.svh, lv.svh, tab, qk_sc, qk_so, hidden, self.eps, hd, self.hkv, kc, ks, vc, vs,

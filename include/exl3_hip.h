@@ -374,7 +374,7 @@ int exl3_attn_decode_qcache_split_qkv(const float* sq, const float* sk, const fl
                                       const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
                                       int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
                                       float* workspace, int64_t workspace_floats, int* nsplit_out, int* fused_out, void* stream);
-int exl3_gemv_ex_attm(const float* part, int nsplit, int gq, int blocks, const void* B, void* C, const void* suh, const void* svh, const void* bias,
+int exl3_gemv_ex_attm(const float* part, int nsplit, int gq, int blocks, int head_dim, const void* B, void* C, const void* suh, const void* svh, const void* bias,
                       int m, int k, int n, int K, int cb, int c_fp32, int flags, int force_split, float** slab_out, int* S_out, void* stream);
 
 /* o_proj fed straight by the q|k|v launch's deferred slabs -- the decode step WITHOUT the attention core, where o_proj's input is the finished q:

@@ -1179,6 +1179,39 @@ def test_attention_merge_inside_oproj_is_bit_identical_to_the_merge_launch(dev, 
     assert np.array_equal(model.logits.float().cpu().numpy(), l1)
 
 
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (16, 8), (4, 4)])
+@pytest.mark.parametrize("pos,bsz", [(3, 1), (70, 2), (300, 1), (500, 2), (1000, 1)])
+def test_attention_merge_inside_oproj_head_dim_64(dev, hq, hkv, pos, bsz):
+    """The flash-decoding merge as o_proj's preparation task at head_dim 64 (Llama-3.2-1B's heads): a Hadamard block of o_proj's input holds TWO query
+    heads whose partial records live in different (kv block, query index) records -- per-lane record addressing, 16-lane statistics, at most 16
+    splits.  Against attn_decode_qcache (split + merge launches) + o_proj: bit for bit while both forms take the same splits (<= 512 tokens), 1e-2
+    beyond (the merge launch takes 32 shorter splits there)."""
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 512, 768, 2, hq, hkv, 64, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(bsz, pos=pos)
+    model.with_attention = True
+    g = torch.Generator(device="cpu").manual_seed(hq * 1000 + pos)
+    for c, s_ in model.kcache + model.vcache:
+        c.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, c.shape, generator=g, dtype=torch.int64).to(torch.int32).to(dev))
+        s_.copy_((torch.rand(s_.shape, generator=g) * 0.5 + 0.05).half().to(dev))
+    saved = [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]
+    outs = []
+    model.attn_merge_in_oproj_hd64 = True                                 # opt-in at head_dim 64 (slower there: llama_path.py)
+    for fused in (False, True):
+        model.attn_merge_in_oproj = fused
+        for (c, s_), (c0, s0) in zip(model.kcache + model.vcache, saved):
+            c.copy_(c0); s_.copy_(s0)
+        lg = model.decode_step_fx().float().cpu().numpy().copy()
+        outs.append((lg, model.x_final.clone()))
+    (l0, x0_), (l1, x1_) = outs
+    assert np.isfinite(l1).all()
+    if pos <= 511:
+        assert np.array_equal(l0, l1) and torch.equal(x0_, x1_)
+    else:
+        assert np.abs(l0 - l1).max() / np.sqrt((l0 ** 2).mean()) < 1e-2
+
+
 @pytest.mark.parametrize("hq,hkv,hd", [(4, 2, 128), (8, 1, 128), (8, 2, 64), (16, 8, 64)])
 @pytest.mark.parametrize("bsz", [1, 2])
 def test_qkv_epilogue_inside_oproj_is_bit_identical_to_the_glue_launch(dev, hq, hkv, hd, bsz):
