@@ -580,6 +580,11 @@ def main():
         m1.alloc_state(1)
         extra["llama-3.2-1b_bs1"] = timed_decode(m1, m1.decode_step_fx if pipeline == "fx" else m1.decode_step_fused, 1)
         extra["llama-3.2-1b_bs1"]["logits_check"] = pinned_logits_check("llama-3.2-1b", args.bits, cb, 1, dev, pipeline if pipeline != "unfused" else "glue")
+        if pipeline == "fx":
+            # ... and with the decode attention over a 1000-token 4-bit cache (head_dim 64: two kv heads per 128-value block of the matrix-pipe split kernel)
+            m1.with_attention = True
+            extra["llama-3.2-1b_bs1_with_attention_ctx1000"] = timed_decode(m1, m1.decode_step_fx, 1)
+            m1.with_attention = False
         del m1
         torch.cuda.empty_cache()
         # config 4's compute leg: ONE rank of Llama-3.1-70B at 3 bpw under TP = 8 (q 8192->1024, k/v 8192->128, o 1024->8192, gate/up 8192->3584,

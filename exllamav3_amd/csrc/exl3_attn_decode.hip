@@ -213,7 +213,11 @@ __device__ __forceinline__ half8_t aw_dequant8(uint32_t x, half2_t sc4)
     return r.h;
 }
 
-template <int GQ, bool FUSED>
+// HD64 (head_dim 64, Llama-3.2-1B): the 128-value block of the kv vector holds TWO kv heads.  The kernel runs unchanged on "rows" = the query heads of both
+// (GQ = 2 x heads per kv head <= 8): row (sub, qi) carries its 64 query dims at dims 64 sub .. 64 sub + 63 of a 128-wide row and ZEROS in the other half, so
+// the four score instructions over the block's four 32-groups give every row the dot product with ITS kv head only; the value product computes 128 dims per
+// row of which the row's own half is kept.  Records come out in the NSUB = 2 form of the half-wave kernel ({m0, l0, m1, l1, o[128]} per query index).
+template <int GQ, bool FUSED, bool HD64 = false>
 __global__ __launch_bounds__(256)
 void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
 {
@@ -227,7 +231,7 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;              // h: kv head (one 128-value block of the kv vector)
     const int len = a.cache_seqlens[b];
     const int t0 = split * a.split_tokens, t1 = min(len, t0 + a.split_tokens);
-    const int G = a.hkv * HD / 32;
+    const int G = a.hkv * (HD64 ? 64 : 128) / 32;
 
     // ---- rotated queries: half-wave i rotates head i as the kernel above does and stores it in pair order; natural-log scores become log2 scores
     // FUSED: the new token (index len - 1) lies in exactly one context split; that workgroup finishes and appends its K / V
@@ -251,32 +255,36 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
         // workgroup whose split holds the new token).  One code path for the three kinds (per-lane operand pointers, like glue_qkv_kernel), a second
         // round only for GQ = 7, 8.  Every half-wave of a participating wave runs the arithmetic (the butterflies want whole half-waves); stores are
         // predicated.  The finished values are those of exl3_glue_qkv_tab bit for bit (qkv_block_finish).
+        // HD64: the tasks are 128-value BLOCKS as well -- NT = GQ / 2 query blocks (two adjacent heads each: rows 2 task, 2 task + 1 of the operand),
+        // then the K and the V block of the two kv heads; the rope partner distance and the frequency index follow the 64-wide head
         const int l = tid & 31, hw = tid >> 5;
+        constexpr int NT = HD64 ? GQ / 2 : GQ;
+        constexpr int PH = HD64 ? 8 : 16;
         #pragma nounroll
-        for (int r = 0; r < (GQ + 2 + 7) / 8; ++r)
+        for (int r = 0; r < (NT + 2 + 7) / 8; ++r)
         {
             if (r > 0 && !owner) break;                                                       // workgroup-uniform
             const int task = r * 8 + hw;
-            const int kind = task < GQ ? 0 : task - GQ + 1;                                    // 0: query, 1: K row, 2: V row, >= 3: nothing
+            const int kind = task < NT ? 0 : task - NT + 1;                                    // 0: query, 1: K row, 2: V row, >= 3: nothing
             const int tw = r * 8 + 2 * wave;
-            const bool wave_has = tw < GQ || (owner && tw + 1 >= GQ && tw <= GQ + 1);          // wave-uniform: tasks tw, tw + 1
+            const bool wave_has = tw < NT || (owner && tw + 1 >= NT && tw <= NT + 1);          // wave-uniform: tasks tw, tw + 1
             if (wave_has)
             {
                 const bool kvt = kind == 1 || kind == 2;
-                const int cblk = kvt ? h : h * GQ + min(task, GQ - 1);
+                const int cblk = kvt ? h : h * NT + min(task, NT - 1);
                 const float* sbase = kind == 1 ? x.sk.base : (kind == 2 ? x.sv.base : x.sq.base);
                 const half_t* svh = (kind == 1 ? x.svh_k : (kind == 2 ? x.svh_v : x.svh_q)) + cblk * 128;
                 const half4_t sc = ((const half4_t*) svh)[l];
                 float rs_p = 0.0f, rs_n = 0.0f;
                 if (x.rs.ss_new && l < (x.rs.k >> 7)) { rs_p = x.rs.ss_prev[(size_t) b * (x.rs.k >> 7) + l]; rs_n = x.rs.ss_new[(size_t) b * (x.rs.k >> 7) + l]; }
                 float4_t sn4 = { 0.f, 0.f, 0.f, 0.f }, cs4 = sn4;
-                const int f = x.rope_mode == 2 ? 4 * (l & 15) : 2 * l;
+                const int f = x.rope_mode == 2 ? 4 * (l & (PH - 1)) : 2 * (l & (2 * PH - 1));
                 if (x.rope_mode == 2) { sn4 = *((const float4_t*) (x.rope_sin + b * 64 + f)); cs4 = *((const float4_t*) (x.rope_cos + b * 64 + f)); }
                 else { sn4.x = x.rope_sin[b * 64 + f]; sn4.y = x.rope_sin[b * 64 + f + 1]; cs4.x = x.rope_cos[b * 64 + f]; cs4.y = x.rope_cos[b * 64 + f + 1]; }
                 const int64_t token_pos = x.slots[b];
                 const SlabRef sr = { sbase, x.sq.S };                                          // one launch wrote the three slab sets: one split count
                 const float4_t ysum = slab_sum(sr, cblk, b, x.m, l);
-                const half4_t y = qkv_block_finish(ysum, sc, x.rs, b, l, rs_p, rs_n, kind != 2, x.rope_mode, 16, sn4, cs4);
+                const half4_t y = qkv_block_finish(ysum, sc, x.rs, b, l, rs_p, rs_n, kind != 2, x.rope_mode, PH, sn4, cs4);
                 float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
                 // K / V row: 4-bit append to the cache page and the workgroup's own copy of the words
                 const int64_t gb = token_pos * G + h * 4 + (l >> 3);
@@ -285,17 +293,32 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
                 kv_quant_regs<4>(v0, v1, v2, v3, cw + gb * 4, cs + gb, actkv, lane);
                 kv_quant_regs<4>(v0, v1, v2, v3, &new_kv[kind == 2 ? 1 : 0][(l >> 3) * 4], &new_sc[kind == 2 ? 1 : 0][l >> 3], actkv, lane);
                 // query: rotated into the cache's H32 domain, pre-scaled, in pair order (the unfused form's staging below)
-                if (kind == 0 && x.q_out && split == 0) ((half4_t*) (x.q_out + ((size_t) b * a.hq + cblk) * HD))[l] = y;
+                if (kind == 0 && x.q_out && split == 0) ((half4_t*) (x.q_out + (size_t) b * a.hq * (HD64 ? 64 : 128) + (size_t) cblk * 128))[l] = y;
                 kvg_had32(v0, v1, v2, v3, lane);
                 const float fq = ATT_R32 * a.scale * 1.44269504f;
                 const float vv[4] = { v0 * fq, v1 * fq, v2 * fq, v3 * fq };
                 if (kind == 0)
                 {
-                    #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    if constexpr (HD64)
                     {
-                        const int d = 4 * l + e, d8 = d & 7;
-                        q_s[task * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) vv[e];
+                        // lanes 0-15: head 2 task, lanes 16-31: head 2 task + 1; row i = (sub, qi) keeps its 64 dims in half `sub`, zeros in the other
+                        const int i = 2 * task + (l >> 4), sub = i / NT;
+                        #pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                        {
+                            const int d = 64 * sub + 4 * (l & 15) + e, d8 = d & 7, dz = d ^ 64;
+                            q_s[i * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) vv[e];
+                            q_s[i * 128 + (dz & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) 0.0f;
+                        }
+                    }
+                    else
+                    {
+                        #pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                        {
+                            const int d = 4 * l + e, d8 = d & 7;
+                            q_s[task * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) vv[e];
+                        }
                     }
                 }
             }
@@ -304,6 +327,30 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
                 #pragma unroll
                 for (int e = 0; e < 4; ++e) q_s[hw * 128 + 4 * l + e] = (half_t) 0.0f;          // rows >= GQ of the query operand stay zero
             }
+        }
+    }
+    else if constexpr (HD64)
+    {
+        // row i = sub * (GQ / 2) + qi = query head (2 h + sub) * (GQ / 2) + qi: lanes 0-15 of the half-wave hold its 64 dims, which go to dims 64 sub ..
+        // of the row; lanes 16-31 write the zeros of the other half
+        constexpr int G2 = GQ / 2;
+        const int l = tid & 31, i = tid >> 5;
+        const int sub = i < GQ ? i / G2 : 0, qi = i - sub * G2;          // (rows >= GQ are all zeros: sub 0 keeps their stores inside the row)
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (i < GQ && l < 16)
+        {
+            const half4_t qv = ((const half4_t*) (a.q + ((size_t) b * a.hq + (2 * h + sub) * G2 + qi) * 64))[l];
+            v0 = (float) qv.x; v1 = (float) qv.y; v2 = (float) qv.z; v3 = (float) qv.w;
+        }
+        kvg_had32(v0, v1, v2, v3, lane);
+        const float f = ATT_R32 * a.scale * 1.44269504f;
+        const float vv[4] = { v0 * f, v1 * f, v2 * f, v3 * f };
+        const int dbase = l < 16 ? 64 * sub + 4 * l : 64 * (1 - sub) + 4 * (l - 16);
+        #pragma unroll
+        for (int e = 0; e < 4; ++e)
+        {
+            const int d = dbase + e, d8 = d & 7;
+            q_s[i * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (i < GQ && l < 16) ? (half_t) vv[e] : (half_t) 0.0f;
         }
     }
     else
@@ -466,9 +513,21 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
                     O[e4] += o_s[(w * 8 + i) * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] * e;
                 }
             }
-            float* pr = al.part + ((((size_t) b * gridDim.y + h) * GQ + i) * al.nsplit + split) * 132;
-            if (l == 0) { pr[0] = M * 0.69314718f; pr[1] = L; }              // the merge kernel works in natural-log units
-            *((float4_t*) (pr + 4 + 4 * l)) = float4_t{ O[0], O[1], O[2], O[3] };
+            if constexpr (HD64)
+            {
+                // row i = (sub, qi) -> record qi of the block, statistics pair `sub`, its own 64 of the 128 accumulators (lanes of that half)
+                constexpr int G2 = GQ / 2;
+                const int sub = i / G2, qi = i - sub * G2;
+                float* pr = al.part + ((((size_t) b * gridDim.y + h) * G2 + qi) * al.nsplit + split) * 132;
+                if (l == 16 * sub) { pr[2 * sub] = M * 0.69314718f; pr[2 * sub + 1] = L; }
+                if ((l >> 4) == sub) *((float4_t*) (pr + 4 + 4 * l)) = float4_t{ O[0], O[1], O[2], O[3] };
+            }
+            else
+            {
+                float* pr = al.part + ((((size_t) b * gridDim.y + h) * GQ + i) * al.nsplit + split) * 132;
+                if (l == 0) { pr[0] = M * 0.69314718f; pr[1] = L; }              // the merge kernel works in natural-log units
+                *((float4_t*) (pr + 4 + 4 * l)) = float4_t{ O[0], O[1], O[2], O[3] };
+            }
         }
     }
 }
@@ -646,7 +705,7 @@ extern "C" int exl3_attn_decode_qcache_split_qkv(const float* sq, const float* s
                                                  int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
                                                  float* workspace, int64_t workspace_floats, int* nsplit_out, int* fused_out, void* stream)
 {
-    EXL3_CHECK_ARG(nsplit_out && workspace && head_dim == 128, "attn_decode_split_qkv: needs the workspace, nsplit_out and head_dim 128");
+    EXL3_CHECK_ARG(nsplit_out && workspace && (head_dim == 128 || head_dim == 64), "attn_decode_split_qkv: needs the workspace, nsplit_out and head_dim 128 or 64");
     EXL3_CHECK_ARG(sq && sk && sv && svh_q && svh_k && svh_v && q_out && inv_freq && positions, "attn_decode_split_qkv: null pointer");
     EXL3_CHECK_ARG(rope_sin && rope_cos && slots, "attn_decode_split_qkv: needs the per-step tables of exl3_qkv_prep");
     EXL3_CHECK_ARG(rope_mode == 1 || rope_mode == 2, "attn_decode_split_qkv: rope_mode must be 1 (GPTJ) or 2 (NEOX)");
@@ -702,11 +761,14 @@ static int attn_decode_impl(const void* q, void* out, const void* k_cache, const
     // head_dim 128, 4-bit K and V, a length bound of at least two 64-token steps: the matrix-pipe kernel (it always writes partial records); measured
     // ahead of the half-wave-per-token kernel from a 512-token bound on (463 vs 458 tok/s with attention), far ahead at long contexts
     static const int wide_min = [] { const char* e = getenv("EXL3_HIP_ATTN_WIDE_MIN"); return e ? atoi(e) : 128; }();
-    if (head_dim == 128 && k_bits == 4 && v_bits == 4 && max_len >= wide_min && page_size % 16 == 0 && workspace)
+    // head_dim 64: the same kernel on the two kv heads of a 128-value block (rows = 2 gq <= 8 query heads)
+    static const int wide64 = [] { const char* e = getenv("EXL3_HIP_ATTN_WIDE_HD64"); return e ? atoi(e) : 1; }();
+    const bool wide_hd64 = head_dim == 64 && gq <= 4 && wide64;
+    if ((head_dim == 128 || wide_hd64) && k_bits == 4 && v_bits == 4 && max_len >= wide_min && page_size % 16 == 0 && workspace)
     {
         int st_tok = 64;
         int ns = (max_len + st_tok - 1) / st_tok;
-        const int capw = split_only ? 32 : (head_dim == 128 ? 256 : 128);
+        const int capw = split_only ? (head_dim == 128 ? 32 : 16) : (head_dim == 128 ? 256 : 128);
         // about two workgroups per CU: more, shorter splits cost more in the merge than they return (16 000 tokens: 380 tok/s at 512, 337 at 2048)
         static const int wg_cap = [] { const char* e = getenv("EXL3_HIP_ATTN_WIDE_WGS"); return e ? atoi(e) : 512; }();
         // (ns bottoms out at 1: with bsz * blocks > wg_cap alone the bound cannot be met and the loop must stop there -- the ns >= 2 test
@@ -717,6 +779,17 @@ static int attn_decode_impl(const void* q, void* out, const void* k_cache, const
             a.nsplit = ns; a.split_tokens = st_tok;
             if (fuse) { xq = &fuse->x; if (fuse->fused_out) *fuse->fused_out = 1; }
             dim3 gridw(ns, blocks, bsz);
+            if (wide_hd64)
+            {
+                switch (gq)
+                {
+                    case 1: if (xq) attn_decode_wide_kernel<2, true, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<2, false, true><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                    case 2: if (xq) attn_decode_wide_kernel<4, true, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<4, false, true><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                    case 3: if (xq) attn_decode_wide_kernel<6, true, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<6, false, true><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                    default: if (xq) attn_decode_wide_kernel<8, true, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<8, false, true><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                }
+            }
+            else
             switch (gq)
             {
                 case 1: if (xq) attn_decode_wide_kernel<1, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<1, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
@@ -733,7 +806,8 @@ static int attn_decode_impl(const void* q, void* out, const void* k_cache, const
             if (split_only) { *nsplit_out = ns; return EXL3_OK; }
             const int items = bsz * blocks * gq;
             const uint32_t mg = gemv_magic((uint32_t) gq), mbg = gemv_magic((uint32_t) (blocks * gq)), mb = gemv_magic((uint32_t) blocks);
-            attn_merge_kernel<128><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, ns, gq, blocks, heads_q, mg, mbg, mb, sinks);
+            if (head_dim == 128) attn_merge_kernel<128><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, ns, gq, blocks, heads_q, mg, mbg, mb, sinks);
+            else                 attn_merge_kernel<64><<<(items + 1) / 2, 256, 0, st>>>(workspace, (half_t*) out, items, ns, gq, blocks, heads_q, mg, mbg, mb, sinks);
             return exl3_check_launch("attn_merge");
         }
     }

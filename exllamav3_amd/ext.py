@@ -1752,7 +1752,7 @@ def attn_decode_qcache_split_qkv(slabs, S: int, svh_q, svh_k, svh_v, q_out, inv_
     its own query heads from the q|k|v launch's slabs and the split that holds the new token appends its K / V.  cache_seqlens include the new token.
     Returns (splits, fused): `fused` False = the two-launch form ran (shapes the matrix-pipe split kernel does not take); same results either way."""
     _dev(q_out)
-    _req(q_out.dtype == torch.half and q_out.dim() == 3 and q_out.shape[-1] == 128 and q_out.is_contiguous(), "attn_decode_split_qkv: q_out must be contiguous (bsz, heads, 128) float16")
+    _req(q_out.dtype == torch.half and q_out.dim() == 3 and q_out.shape[-1] in (64, 128) and q_out.is_contiguous(), "attn_decode_split_qkv: q_out must be contiguous (bsz, heads, 128 or 64) float16")
     _req(block_table.dtype == torch.int32 and cache_seqlens.dtype == torch.int32, "attn_decode: block_table / cache_seqlens must be int32")
     _req(workspace is not None and workspace.dtype == torch.float and workspace.is_contiguous(), "attn_decode_split_qkv: float32 workspace required")
     _req(tab is not None and len(tab) == 3, "attn_decode_split_qkv: needs the (sin, cos, slots) tables of qkv_prep")

@@ -403,9 +403,12 @@ class SyntheticEXL3Llama:
     attn_merge_in_oproj = os.environ.get("EXL3_HIP_ATTN_MERGE_IN_OPROJ", "1") != "0"
     #: ... and the q|k|v epilogue (split-k reduce, output Hadamard, RoPE, 4-bit append of the new token) runs inside the attention's context-split launch
     #: (ext.attn_decode_qcache_split_qkv) instead of glue_qkv_rs: 6 launches per layer with attention, same bits
-    #: the same merge at head_dim 64 (two query heads per Hadamard block; exl3_gemv_ex_attm takes them): bit-identical, but the 16-split cap of its 16-lane
-    #: statistics makes the context splits twice as long -- Llama-3.2-1B with attention 1468 -> 1377 tok/s (round 4, same box) -- so it stays opt-in
-    attn_merge_in_oproj_hd64 = os.environ.get("EXL3_HIP_ATTN_MERGE_IN_OPROJ_HD64", "0") == "1"
+    #: the same two fusions at head_dim 64 (two query heads per Hadamard block; exl3_gemv_ex_attm and the matrix-pipe split kernel take them): bit-identical.
+    #: The 16-split cap of the 16-lane statistics makes the context splits longer, which the half-wave-per-token kernel pays for (Llama-3.2-1B with
+    #: attention 1468 -> 1377 tok/s) and the matrix-pipe kernel does not (round 4, same box: 1466 half-wave kernel + merge launch, 1503 matrix-pipe kernel +
+    #: merge launch, 1530 + merge inside o_proj, 1565 + q|k|v epilogue inside the split launch).  None = where the matrix-pipe kernel applies (at most 4
+    #: query heads per kv head, 4-bit cache); EXL3_HIP_ATTN_MERGE_IN_OPROJ_HD64 = 0 / 1 forces it
+    attn_merge_in_oproj_hd64 = {"0": False, "1": True}.get(os.environ.get("EXL3_HIP_ATTN_MERGE_IN_OPROJ_HD64", ""), None)
     attn_qkv_in_split = os.environ.get("EXL3_HIP_ATTN_QKV_IN_SPLIT", "1") != "0"
     #: fx pipeline WITHOUT the attention core (the linears-only step: o_proj's input is the finished q): glue_qkv_rs's work -- reduce, output Hadamard, RoPE,
     #: 4-bit K / V append -- runs inside o_proj's launch (ext.exl3_gemv_ex_qkvm): 5 launches per layer instead of 6 (4 with fx_act_in_gemv), same bits
@@ -703,7 +706,8 @@ class SyntheticEXL3Llama:
             slabs, S = ext.exl3_gemv_ex_fx(R, L["norm1"], sc, so_, self.eps, [lq.trellis, lk.trellis, lv.trellis], [lq.suh, lk.suh, lv.suh],
                                            bsz, lq.mcg, lq.mul1, sp["qkv"])
             attm = None                                                    # (partial records, splits): the merge runs inside o_proj's launch
-            fuse_qkv = (self.with_attention and hd == 128 and self.attn_merge_in_oproj and not self.fx_gu_atomic and self.attn_qkv_in_split
+            merge64 = self.attn_merge_in_oproj_hd64 if self.attn_merge_in_oproj_hd64 is not None else (self.hq // self.hkv <= 4 and self.kv_bits == 4)
+            fuse_qkv = (self.with_attention and (hd == 128 or (hd == 64 and merge64)) and self.attn_merge_in_oproj and not self.fx_gu_atomic and self.attn_qkv_in_split
                         and tab is not None and self.kv_bits == 4)
             if fuse_qkv:
                 # q|k|v epilogue (reduce, Hadamard, rope, cache append) inside the attention's context-split launch: 6 launches per layer with attention
@@ -719,7 +723,7 @@ class SyntheticEXL3Llama:
             sc, so_ = so_, sc
             o_in = q2
             if self.with_attention and hd in (64, 128) and not fuse_qkv:
-                if self.attn_merge_in_oproj and not self.fx_gu_atomic and (hd == 128 or self.attn_merge_in_oproj_hd64):
+                if self.attn_merge_in_oproj and not self.fx_gu_atomic and (hd == 128 or merge64):
                     attm = (self.attn_ws, ext.attn_decode_qcache_split(self.q.view(bsz, self.hq, hd), kc, ks, vc, vs, self.block_table, self.attn_lens,
                                                                        self.attn_pos + 1, self.attn_ws))
                 else:

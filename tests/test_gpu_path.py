@@ -1197,7 +1197,7 @@ def test_attention_merge_inside_oproj_head_dim_64(dev, hq, hkv, pos, bsz):
         s_.copy_((torch.rand(s_.shape, generator=g) * 0.5 + 0.05).half().to(dev))
     saved = [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]
     outs = []
-    model.attn_merge_in_oproj_hd64 = True                                 # opt-in at head_dim 64 (slower there: llama_path.py)
+    model.attn_merge_in_oproj_hd64 = True                                 # (None = only where the matrix-pipe split kernel applies: llama_path.py)
     for fused in (False, True):
         model.attn_merge_in_oproj = fused
         for (c, s_), (c0, s0) in zip(model.kcache + model.vcache, saved):
@@ -1279,6 +1279,39 @@ def test_attention_qkv_in_split_every_group_size(dev, gq, pos, bsz):
     assert np.array_equal(l0, l1) and torch.equal(x0_, x1_) and torch.equal(q0, q1)      # q: the last layer's finished queries (split 0 writes them)
     assert all(torch.equal(a0, a1) and torch.equal(b0, b1) for (a0, b0), (a1, b1) in zip(kv0, kv1))
     # something was appended: the new token's row differs from the pre-filled words in every layer
+    assert all(not torch.equal(a1, a0) for (a1, _), (a0, _) in zip(kv1, saved))
+
+
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (16, 8), (4, 4), (6, 2), (16, 2)])
+@pytest.mark.parametrize("pos,bsz", [(70, 1), (130, 1), (500, 2), (1000, 2)])
+def test_attention_qkv_in_split_head_dim_64(dev, hq, hkv, pos, bsz):
+    """ext.attn_decode_qcache_split_qkv at head_dim 64 (round 4): the matrix-pipe split kernel on the two kv heads of a 128-value block with the q|k|v
+    epilogue in its preparation phase -- tasks are 128-value blocks (two query heads each; the K and the V block of both kv heads), the rope partner
+    distance is 8 lanes.  Against glue_qkv_rs + the split launch (merge inside o_proj in both): logits, residual, q and every cache word and scale bit
+    for bit; group sizes 1 .. 4 take the one-launch form, 8 (two launches inside the entry point) and the 70-token context (below the kernel's bound) fall back."""
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 512, 768, 2, hq, hkv, 64, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(bsz, pos=pos)
+    model.with_attention = True
+    model.attn_merge_in_oproj_hd64 = True
+    g = torch.Generator(device="cpu").manual_seed(hq * 1000 + pos)
+    for c, s_ in model.kcache + model.vcache:
+        c.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, c.shape, generator=g, dtype=torch.int64).to(torch.int32).to(dev))
+        s_.copy_((torch.rand(s_.shape, generator=g) * 0.5 + 0.05).half().to(dev))
+    saved = [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]
+    outs = []
+    for qkv_in_split in (False, True):
+        model.attn_qkv_in_split = qkv_in_split
+        for (c, s_), (c0, s0) in zip(model.kcache + model.vcache, saved):
+            c.copy_(c0); s_.copy_(s0)
+        model.q.zero_()
+        lg = model.decode_step_fx().float().cpu().numpy().copy()
+        outs.append((lg, model.x_final.clone(), model.q.clone(), [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]))
+    (l0, x0_, q0, kv0), (l1, x1_, q1, kv1) = outs
+    assert np.isfinite(l1).all()
+    assert np.array_equal(l0, l1) and torch.equal(x0_, x1_) and torch.equal(q0, q1)
+    assert all(torch.equal(a0, a1) and torch.equal(b0, b1) for (a0, b0), (a1, b1) in zip(kv0, kv1))
     assert all(not torch.equal(a1, a0) for (a1, _), (a0, _) in zip(kv1, saved))
 
 
