@@ -16,6 +16,7 @@
 //   * softmax statistics live with the query's column lanes; the output accumulator's rows are queries 4g + j, so the running rescale factor
 //     of those four queries is fetched from lanes 4g + j (ds_bpermute, 4 per tile).
 // fp32 softmax and accumulation, fp16 probabilities into the second product (as flash-attention does), fp16 output.
+#include <type_traits>
 #include "exl3_common.cuh"
 #include "exl3_api_internal.h"
 #include "exl3_gemv_args.h"
@@ -271,6 +272,331 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// Round 4: one wave per SIMD, 64 queries per wave (head_dim 128, four query heads per kv head).  A workgroup = 4 waves = the four query heads that
+// share a kv head x the same 64 consecutive queries; a wave owns one head's 64 queries and most of the 512-register file: O 64 x 128 fp32 = 128
+// registers, the Q operands 64, the score block 64.  v_mfma_f32_32x32x16_f16 throughout:
+//   * S^T = K Q^T in 32 x 32 blocks (kb: keys, qb: queries): A = K rows from LDS (ds_read_b128, lane (key l % 32, dims 16 ks + 8 (l / 32) ..)), B = the
+//     wave's Q (registers); a lane ends with column (query) l % 32 and rows (keys) 32 kb + 8 (i / 4) + 4 (l / 32) + i % 4, i = 0 .. 15;
+//   * those 16 values are, eight at a time, an A operand of O = P V if contraction slot 8 h + 4 e + j of k-step (kb, bp) is DEFINED as key
+//     32 kb + 16 bp + 8 e + 4 h + j; the matching B operand (two runs of four consecutive keys of one output column) comes from two
+//     ds_read_b64_tr_b16 (V staged row-major, rows 80 dwords apart: the 32 lanes of a transpose-read group tile the 64 banks);
+//   * every K / V fragment read from LDS feeds two 32 x 32 x 16 instructions (the older kernel: one or two 16 x 16 x 32).
+// Software pipeline inside the wave (there is no second wave on the SIMD to hide behind): iteration t runs
+//   phase 1: S_{t+1} = K_{t+1} Q^T (32 MFMA)  beside  the softmax of tile t, query block 1 (max, exp2, row sums, fp16 pack: ~140 VALU)
+//   phase 2: O += P_t V_t (32 MFMA)           beside  the softmax of tile t + 1, query block 0
+// so each half of a tile's softmax sits between the matrix instructions of a phase that does not depend on it.  K runs one tile ahead of V in the
+// LDS ring (two slots each): what iteration t writes at its top (K_{t+2}, V_{t+1}, fetched into registers one iteration earlier) is first read
+// after the next barrier -- ONE barrier per tile.  Running max deferred (moves only when a score exceeds it by 2^8), per query, no branch; the rare
+// accumulator rescale is a wave-uniform branch between the phases.  Row sums stay per lane (a query's two lanes hold disjoint keys) until the end.
+// The output goes through LDS (the ring is free by then) and leaves as whole 256-byte rows.
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// (plain fmaxf on matrix-instruction results makes hipcc canonicalise every operand first -- one extra v_max each; the scores here are never NaN)
+__device__ __forceinline__ float pw_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// maximum of the 32 scores a lane holds for its query in one tile (two 32-key blocks) and of the query's other lane
+__device__ __forceinline__ float pw_rowmax(const f32x16_t& s0, const f32x16_t& s1)
+{
+    float mx = pw_max3(s0[0], s1[0], s0[1]);
+    #pragma unroll
+    for (int e = 1; e < 15; ++e) mx = pw_max3(mx, s1[e], s0[e + 1]);
+    mx = pw_max3(mx, s1[15], s1[15]);
+    return pw_max3(mx, xor_lane(mx, 32), mx);
+}
+__device__ __forceinline__ uint32_t pw_exp_pair(float a, float b)
+{
+    const half2_t h = { (half_t) __builtin_amdgcn_exp2f(a), (half_t) __builtin_amdgcn_exp2f(b) };
+    uint32_t r = half2_as_u32(h);
+    // (an empty volatile asm "uses" the result HERE: without it the optimiser sinks the exponentials of a phase into the next basic block, next to
+    // their consumers, and the matrix instructions of this phase run bare)
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
+// LDS: K ring (2 x 64 keys x 256 B) | V ring (same) | Q (8 waves x 32 queries x 272 B); at the end the Q area takes the output rows.
+// K / V rows are not padded; the conflict-free read comes from permuting the 16-byte chunks of a row: position p of row r holds chunk p ^ f(r),
+//   K: f(r) = r & 15                    (a ds_read_b128 lane group touches 16 rows whose r & 15 are distinct -> 16 distinct positions = all 64 banks)
+//   V: f(r) = ((r & 3) << 2) | ((r >> 2) & 3)   (a transpose-read group touches 4 consecutive rows x 4 consecutive chunks: the rows' chunk quads differ)
+// (PMC: SQ_LDS_BANK_CONFLICT 0.9 % of SQ_LDS_IDX_ACTIVE.)
+//
+// Workgroup = 8 waves = the four query heads of a kv head x the two 32-query blocks of a 64-query tile: two waves per SIMD (one wave alone issues an
+// instruction every ~5 cycles, i.e. at most ~5 beside each 32-cycle matrix instruction; the 64-queries-per-wave form of this kernel, one wave per
+// SIMD, was issue-bound at 9.7 VALU per matrix instruction and, once the softmax was cut down, out of registers -- hipcc spilled accumulators).
+// The softmax is written for instruction count:
+//   * the queries are pre-multiplied by scale * log2(e) (fp16) and the score accumulators START at minus the running reference maximum of their query
+//     (operand C of the first matrix instruction of a chain: a lane's 16 results all belong to one query), so a probability is ONE instruction,
+//     v_exp_f32 of the accumulator -- no multiply-subtract per score;
+//   * the row sums come from the matrix pipe: one more 32-column block of "V" that is all ones (4 instructions per tile instead of 32 adds), and land
+//     in the accumulator layout, where the final division needs no cross-lane traffic;
+//   * the reference maximum moves only when a score exceeds it by 2^8 (probabilities stay below 2^8 in fp16); the tile's scores, the start values and
+//     -- after the tile's P V is complete -- the accumulators are adjusted in rarely taken wave-uniform branches.
+#define PW_TILE_HALVES (64 * 128)
+#define PW_QS 136
+__global__ __launch_bounds__(512)
+void attn_prefill_w64_kernel(const PrefillAttnArgs a)
+{
+    constexpr int HD = 128;
+    __shared__ __attribute__((aligned(1024))) half_t ring[4 * PW_TILE_HALVES + 8 * 32 * PW_QS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
+    half_t* const qs = ring + 4 * PW_TILE_HALVES + wave * 32 * PW_QS;                                        // this wave's queries (later: its output rows)
+    const int qt = gridDim.y - 1 - blockIdx.y, hg = blockIdx.x, head = hg * 4 + (wave & 3), b = blockIdx.z; // longest tiles first (see the kernel above)
+    const int q_len = a.q_len, hq = a.hq, hkv = a.hkv, page_size = a.page_size;
+    const int kvh = (hg * 4) / (hq / hkv);
+    const int kv_len = a.cache_seqlens[b];
+    const int ctx = kv_len - q_len;
+    const int q0 = qt * 64, q0w = q0 + 32 * (wave >> 2);                                                    // the workgroup's / this wave's first query
+    const int32_t* bt = a.block_table + (size_t) b * a.blocks_per_seq;
+    const float sl = a.scale * 1.44269504f;
+    const int q_last = min(q0 + 64, q_len) - 1;
+    const int ntiles = (ctx + q_last) / 64 + 1;
+
+    // ---- staging: 64 keys x 256 B = 1024 16-byte chunks per tile and operand, 2 per thread; HBM -> registers one iteration before the LDS write
+    const int row_halves = hkv * HD;                                                                        // (64 rows x hkv x 128 halves: far inside 32 bits)
+    int goff[2], kdst[2], vdst[2];                                                                          // global offset (halves), LDS offsets (halves)
+    #pragma unroll
+    for (int j = 0; j < 2; ++j)
+    {
+        const int idx = tid + 512 * j, key = idx >> 4, ch = idx & 15;
+        goff[j] = key * row_halves + ch * 8;
+        kdst[j] = key * 128 + ((ch ^ (key & 15)) * 8);
+        vdst[j] = key * 128 + ((ch ^ (((key & 3) << 2) | ((key >> 2) & 3))) * 8);
+    }
+    half8_t kreg[2], vreg[2];
+    auto fetch = [&](int t, half8_t (&reg)[2], const half_t* pages) __attribute__((always_inline))
+    {
+        // a tile index beyond the last one and keys beyond the sequence are clamped (duplicate rows: finite values in slots nobody reads again / masked scores)
+        const int key0 = __builtin_amdgcn_readfirstlane(min(t, ntiles - 1) * 64);                           // (a tile never straddles a page: 64 | page size)
+        const int64_t page = bt[min(key0 / page_size, a.blocks_per_seq - 1)];
+        const half_t* base = pages + ((size_t) page * page_size + (key0 % page_size)) * (size_t) row_halves + (size_t) kvh * HD;   // wave-uniform
+        const int kmax = kv_len - 1 - key0;
+        #pragma unroll
+        for (int j = 0; j < 2; ++j)
+        {
+            const int idx = tid + 512 * j;
+            const uint32_t off = kmax >= 63 ? (uint32_t) goff[j] : (uint32_t) (min(idx >> 4, kmax) * row_halves + (idx & 15) * 8);
+            reg[j] = *((const half8_t*) (base + off));
+        }
+    };
+    auto put = [&](const half8_t (&reg)[2], half_t* slot, const int (&dst)[2]) __attribute__((always_inline))
+    {
+        #pragma unroll
+        for (int j = 0; j < 2; ++j) *((half8_t*) (slot + dst[j])) = reg[j];
+    };
+    auto Kslot = [&](int i) __attribute__((always_inline)) { return ring + (i & 1) * PW_TILE_HALVES; };
+    auto Vslot = [&](int i) __attribute__((always_inline)) { return ring + (2 + (i & 1)) * PW_TILE_HALVES; };
+
+    // ---- queries: global -> x scale log2(e) -> this wave's LDS rows (B operands of S^T are read per k-step: query n, dims 16 ks + 8 h ..)
+    const int qpos = ctx + min(q0w + n, q_len - 1);
+    #pragma unroll
+    for (int j = 0; j < 8; ++j)
+    {
+        const int idx = lane + 64 * j, r = idx >> 4, ch = idx & 15;
+        const int qi = min(q0w + r, q_len - 1);
+        half8_t v = *((const half8_t*) (a.q + ((size_t) b * q_len + qi) * a.ldq + (size_t) head * HD + 8 * ch));
+        #pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (half_t) ((float) v[e] * sl);
+        *((half8_t*) (qs + r * PW_QS + 8 * ch)) = v;
+    }
+    // ---- per-lane fragment addresses (halves from the slot / the wave's query rows): everything that depends on the slice is an immediate offset
+    int kl[8], vl0[4], vl1[4];
+    #pragma unroll
+    for (int ks = 0; ks < 8; ++ks) kl[ks] = n * 128 + (((2 * ks + h) ^ (n & 15)) * 8);                     // key block kb: + 32 * 128
+    {
+        const int G = lane >> 4, c = lane & 15;
+        const int rl = 4 * (G >> 1) + (c >> 2), fh = (c >> 2) & 3, fl = G >> 1, L = 2 * (G & 1) + ((c & 3) >> 1);
+        #pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+        {
+            vl0[nb] = rl * 128 + ((((nb ^ fh) << 2) | (L ^ fl)) * 8) + 4 * (c & 1);                         // k-step kst: + 16 * kst * 128
+            vl1[nb] = (rl + 8) * 128 + ((((nb ^ fh) << 2) | (L ^ (fl | 2))) * 8) + 4 * (c & 1);
+        }
+    }
+    const half_t* const ql = qs + n * PW_QS + 8 * h;                                                        // k-step ks: + 16
+
+    f32x16_t oc[4], lacc, negm;                                 // O, the row sums (ones column), minus the reference maximum (start value of the score chains)
+    #pragma unroll
+    for (int i = 0; i < 16; ++i) { lacc[i] = 0.0f; negm[i] = 0.0f; }
+    #pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+        #pragma unroll
+        for (int i = 0; i < 16; ++i) oc[nb][i] = 0.0f;
+    const half8_t ones = { (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f };
+
+    // scores of one tile (causal / length mask): wave-uniform test, per-element select
+    auto mask_tile = [&](int t, f32x16_t (&S)[2]) __attribute__((always_inline))
+    {
+        const int key0 = t * 64;
+        if (!(key0 + 63 > ctx + min(q0w, q_len - 1) || key0 + 64 > kv_len)) return;
+        int h4 = 4 * h;
+        asm volatile("" : "+v"(h4));                            // (keeps the 32 key indices inside this rarely taken branch: hoisted, they cost registers in every iteration)
+        #pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+            #pragma unroll
+            for (int i = 0; i < 16; ++i)
+            {
+                const int key = key0 + 32 * kb + 8 * (i >> 2) + h4 + (i & 3);
+                if (!(key <= qpos && key < kv_len)) S[kb][i] = -1.0e30f;
+            }
+    };
+    auto k_frag = [&](int s, const half_t* kbuf) __attribute__((always_inline)) { return *((const half8_t*) (kbuf + kl[s >> 1] + (s & 1) * 32 * 128)); };
+    auto q_frag = [&](int ks) __attribute__((always_inline)) { return *((const half8_t*) (ql + 16 * ks)); };
+    auto v_frag = [&](int s, const half_t* vbuf) __attribute__((always_inline))
+    {
+        const int kst = s >> 2, nb = s & 3;                     // k-step (kb, bp) = (kst >> 1, kst & 1): keys 32 kb + 16 bp + 8 e + 4 h + j
+        const half4_t v0 = lds_read_tr16(vbuf + vl0[nb] + kst * 16 * 128), v1 = lds_read_tr16(vbuf + vl1[nb] + kst * 16 * 128);
+        return half8_t{ v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+    };
+    // slice s of a score phase: k-step ks = s >> 1 of key block kb = s & 1; a chain's first instruction starts from -max of the lane's query
+    auto qk_mfma = [&](int s, half8_t ka, half8_t qf, f32x16_t (&S)[2]) __attribute__((always_inline))
+    {
+        S[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf, s < 2 ? negm : S[s & 1], 0, 0, 0);
+    };
+    // slice s of a P V phase: k-step kst = s >> 2, output block nb = s & 3; the ones column rides with nb == 0
+    auto pv_mfma = [&](int s, half8_t vB, const uint32_t (&pa)[16]) __attribute__((always_inline))
+    {
+        const int kst = s >> 2, nb = s & 3;
+        union { uint32_t u[4]; half8_t h8; } p;
+        #pragma unroll
+        for (int i = 0; i < 4; ++i) p.u[i] = pa[4 * kst + i];
+        oc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p.h8, vB, oc[nb], 0, 0, 0);
+        if (nb == 0) lacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(p.h8, ones, lacc, 0, 0, 0);
+    };
+    // probabilities: value pair p = 0 .. 15 of the lane's 32 scores (key block 0: pairs 0-7, key block 1: pairs 8-15)
+    auto exp_pair = [&](int p, const f32x16_t (&S)[2]) __attribute__((always_inline))
+    {
+        return p < 8 ? pw_exp_pair(S[0][2 * p], S[0][2 * p + 1]) : pw_exp_pair(S[1][2 * p - 16], S[1][2 * p - 15]);
+    };
+    // the reference maximum of a query moves when a score of the tile exceeds it by more than 2^8: this tile's scores and the chains' start values move
+    // down by d now; the accumulators (which still take the PREVIOUS tile's P V) are scaled by 2^-d at the end of the phase
+    float corr = 1.0f;
+    bool pend = false;                                          // wave-uniform
+    auto adjust = [&](f32x16_t (&S)[2], float mx) __attribute__((always_inline))
+    {
+        if (!__any(mx > 8.0f)) return;
+        const float d = mx > 8.0f ? mx : 0.0f;
+        #pragma unroll
+        for (int i = 0; i < 16; ++i) { S[0][i] -= d; S[1][i] -= d; negm[i] -= d; }
+        corr = __builtin_amdgcn_exp2f(-d);
+        pend = true;
+    };
+    auto rescale = [&]() __attribute__((always_inline))
+    {
+        if (!pend) return;
+        pend = false;
+        #pragma unroll
+        for (int i = 0; i < 16; ++i)
+        {
+            const float cr = __shfl(corr, 8 * (i >> 2) + 4 * h + (i & 3), 64);                 // row (query) of accumulator element i
+            #pragma unroll
+            for (int nb = 0; nb < 4; ++nb) oc[nb][i] *= cr;
+            lacc[i] *= cr;
+        }
+    };
+
+    // ---- prologue: K_0, K_1, V_0 in LDS, K_2 and V_1 on their way; S_0 with its own maxima as the first reference
+    fetch(0, kreg, a.k_pages); fetch(0, vreg, a.v_pages);
+    put(kreg, Kslot(0), kdst); put(vreg, Vslot(0), vdst);
+    fetch(1, kreg, a.k_pages);
+    put(kreg, Kslot(1), kdst);
+    fetch(1, vreg, a.v_pages); fetch(2, kreg, a.k_pages);
+    __syncthreads();
+    f32x16_t S[2];                                              // [key block]
+    #pragma unroll
+    for (int s = 0; s < 16; ++s) qk_mfma(s, k_frag(s, Kslot(0)), q_frag(s >> 1), S);                       // (negm = 0: true scores)
+    mask_tile(0, S);
+    {
+        float mx = pw_rowmax(S[0], S[1]);
+        if (mx < -1.0e29f) mx = 0.0f;                           // a query without any visible key (not a valid call): all its probabilities become 0
+        #pragma unroll
+        for (int i = 0; i < 16; ++i) { S[0][i] -= mx; S[1][i] -= mx; negm[i] = -mx; }
+    }
+    uint32_t pa[16];                                            // fp16 probability pairs of the current tile
+    #pragma unroll
+    for (int p = 0; p < 16; ++p) pa[p] = exp_pair(p, S);
+
+    // one iteration: phase 1 = tile t + 1's scores (matrix instructions, fragment reads, the staging traffic), phase 2 = tile t's P V beside tile
+    // t + 1's maximum and probabilities.  MORE = tile t + 1 exists.  Ring: at the top of iteration t the slots of K_t and V_{t-1} are dead and take
+    // K_{t+2} and V_{t+1} (in registers since the previous iteration); they are first read after the NEXT barrier
+    auto iteration = [&](int t, auto more_c) __attribute__((always_inline))
+    {
+        constexpr bool MORE = decltype(more_c)::value;
+        __syncthreads();
+        const half_t* kbuf = Kslot(t + 1);
+        const half_t* vbuf = Vslot(t);
+        // fragments are read from LDS TWO slices before their use
+        half8_t kf[16], qfr[8], vf[16];
+        if constexpr (MORE) { kf[0] = k_frag(0, kbuf); kf[1] = k_frag(1, kbuf); qfr[0] = q_frag(0); }
+        else { vf[0] = v_frag(0, vbuf); vf[1] = v_frag(1, vbuf); }
+        put(kreg, Kslot(t), kdst); put(vreg, Vslot(t + 1), vdst);
+        fetch(t + 3, kreg, a.k_pages); fetch(t + 2, vreg, a.v_pages);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 1: S_{t+1}
+        if constexpr (MORE)
+        {
+            #pragma unroll
+            for (int s = 0; s < 16; ++s)
+            {
+                if (s + 2 < 16) kf[s + 2] = k_frag(s + 2, kbuf);
+                if (!(s & 1) && s + 2 < 16) qfr[(s >> 1) + 1] = q_frag((s >> 1) + 1);
+                if (s >= 14) vf[s - 14] = v_frag(s - 14, vbuf);
+                qk_mfma(s, kf[s], qfr[s >> 1], S);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mask_tile(t + 1, S);
+        }
+        // ---- phase 2: O += P_t V_t (and the row sums) beside the maximum and the probabilities of tile t + 1 (slice 0: maximum, slice s: pair s - 1,
+        // slice 15: pairs 14 and 15)
+        uint32_t pn[16];
+        #pragma unroll
+        for (int s = 0; s < 16; ++s)
+        {
+            if (s + 2 < 16) vf[s + 2] = v_frag(s + 2, vbuf);
+            pv_mfma(s, vf[s], pa);
+            if constexpr (MORE)
+            {
+                if (s == 0) adjust(S, pw_rowmax(S[0], S[1]));
+                else
+                {
+                    pn[s - 1] = exp_pair(s - 1, S);
+                    if (s == 15) pn[15] = exp_pair(15, S);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (MORE)
+        {
+            rescale();
+            #pragma unroll
+            for (int i = 0; i < 16; ++i) pa[i] = pn[i];
+        }
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) iteration(t, std::true_type{});
+    iteration(ntiles - 1, std::false_type{});
+
+    // ---- normalise (row sums and outputs share the accumulator layout), stage through this wave's LDS rows (its queries are no longer needed),
+    // store whole rows
+    half_t* os = qs;
+    #pragma unroll
+    for (int i = 0; i < 16; ++i)
+    {
+        const int r = 8 * (i >> 2) + 4 * h + (i & 3);
+        const float li = lacc[i] > 0.0f ? 1.0f / lacc[i] : 0.0f;                             // (a query without any visible key: zeros, as the kernel above)
+        #pragma unroll
+        for (int nb = 0; nb < 4; ++nb) os[r * PW_QS + 32 * nb + n] = (half_t) (oc[nb][i] * li);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));                            // (the row indices of the query loads above are NOT kept alive across the main loop for this)
+    #pragma unroll
+    for (int j = 0; j < 8; ++j)
+    {
+        const int idx = lane_e + 64 * j, r = idx >> 4, ch = idx & 15;
+        if (q0w + r < q_len)
+            *((half8_t*) (a.out + (((size_t) b * q_len + q0w + r) * hq + head) * HD + 8 * ch)) = *((const half8_t*) (os + r * PW_QS + 8 * ch));
+    }
+}
+
 // q / out: fp16 [bsz][q_len][heads_q][head_dim]; k_pages / v_pages: fp16 [pages][page_size][heads_kv][head_dim] (what exl3_dequant_cache_paged writes);
 // cache_seqlens[b] = tokens of sequence b in the cache INCLUDING the q_len new ones (they were appended before the call, as the reference does);
 // causal: query i of the chunk attends to keys 0 .. cache_seqlens[b] - q_len + i.
@@ -300,11 +626,19 @@ extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void*
     a.block_table = block_table; a.cache_seqlens = cache_seqlens;
     a.q_len = q_len; a.hq = heads_q; a.hkv = heads_kv; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.scale = scale; a.ldq = ldq;
     const int gq = heads_q / heads_kv;
+    hipStream_t st = (hipStream_t) stream;
+    // head_dim 128 with four query heads per kv head: one wave per SIMD, 64 queries per wave (round 4)
+    static const int w64 = [] { const char* e = getenv("EXL3_HIP_ATTN_PREFILL_W64"); return e ? atoi(e) : 1; }();
+    if (w64 && head_dim == 128 && gq % 4 == 0 && q_len >= 64)
+    {
+        dim3 gridw(heads_q / 4, (q_len + 63) / 64, bsz);
+        attn_prefill_w64_kernel<<<gridw, 512, 0, st>>>(a);
+        return exl3_check_launch("attn_prefill_w64");
+    }
     int gw = gq % 4 == 0 ? 4 : (gq % 2 == 0 ? 2 : 1);                                // query heads per workgroup (they share a kv head) ...
     const int64_t qtiles = (int64_t) ((q_len + PA_BM - 1) / PA_BM) * bsz;
     while (gw > 1 && qtiles * (heads_q / gw) < 512) gw >>= 1;                         // ... fewer when the launch would not fill the 256 CUs twice
     dim3 grid(heads_q / gw, (q_len + PA_BM - 1) / PA_BM, bsz);
-    hipStream_t st = (hipStream_t) stream;
     // 16 queries per wave and 4 waves per SIMD (QG = 1) where the registers allow it, else 32 queries per wave at 2 waves per SIMD
     #define PA_L(HDv, QGv) { if (gw == 4) attn_prefill_kernel<HDv, 4, QGv><<<grid, 1024 / QGv, 0, st>>>(a); else if (gw == 2) attn_prefill_kernel<HDv, 2, QGv><<<grid, 512 / QGv, 0, st>>>(a); \
                              else attn_prefill_kernel<HDv, 1, QGv><<<grid, 256 / QGv, 0, st>>>(a); }
