@@ -352,36 +352,38 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
 
     // ---- staging: 64 keys x 256 B = 1024 16-byte chunks per tile and operand, 2 per thread; HBM -> registers one iteration before the LDS write
     const int row_halves = hkv * HD;                                                                        // (64 rows x hkv x 128 halves: far inside 32 bits)
-    int goff[2], kdst[2], vdst[2];                                                                          // global offset (halves), LDS offsets (halves)
+    int kdst[2], vdst[2];                                                                                   // LDS offsets (halves)
     #pragma unroll
     for (int j = 0; j < 2; ++j)
     {
         const int idx = tid + 512 * j, key = idx >> 4, ch = idx & 15;
-        goff[j] = key * row_halves + ch * 8;
         kdst[j] = key * 128 + ((ch ^ (key & 15)) * 8);
         vdst[j] = key * 128 + ((ch ^ (((key & 3) << 2) | ((key >> 2) & 3))) * 8);
     }
     half8_t kreg[2], vreg[2];
-    auto fetch = [&](int t, half8_t (&reg)[2], const half_t* pages) __attribute__((always_inline))
+    // Where a tile lives: (tile, page index, first key's offset inside the page), advanced by 64 keys per step without divisions (page_size is a run-time
+    // value: every / and % was a ~30-instruction scalar sequence, three per iteration) and clamped at the last tile.  The page id itself (a scalar load
+    // from the block table) is read one iteration before the fetch that uses it.
+    struct TilePos { int tile, pidx, off; };
+    auto advance = [&](TilePos& p) __attribute__((always_inline))
     {
-        // a tile index beyond the last one and keys beyond the sequence are clamped (duplicate rows: finite values in slots nobody reads again / masked scores)
-        const int key0 = __builtin_amdgcn_readfirstlane(min(t, ntiles - 1) * 64);                           // (a tile never straddles a page: 64 | page size)
-        const int64_t page = bt[min(key0 / page_size, a.blocks_per_seq - 1)];
-        const half_t* base = pages + ((size_t) page * page_size + (key0 % page_size)) * (size_t) row_halves + (size_t) kvh * HD;   // wave-uniform
-        const int kmax = kv_len - 1 - key0;
+        if (p.tile < ntiles - 1) { ++p.tile; p.off += 64; if (p.off >= page_size) { p.off = 0; ++p.pidx; } }
+    };
+    auto page_id_of = [&](const TilePos& p) __attribute__((always_inline)) { return bt[min(p.pidx, a.blocks_per_seq - 1)]; };
+    auto fetch = [&](const TilePos& p, int32_t page_id, half8_t (&reg)[2], const half_t* pages) __attribute__((always_inline))
+    {
+        // keys beyond the sequence are clamped (duplicate rows: finite values; their scores are masked)
+        const half_t* base = pages + ((size_t) page_id * page_size + p.off) * (size_t) row_halves + (size_t) kvh * HD;      // wave-uniform
+        const int kmax = kv_len - 1 - p.tile * 64;
         #pragma unroll
         for (int j = 0; j < 2; ++j)
         {
             const int idx = tid + 512 * j;
-            const uint32_t off = kmax >= 63 ? (uint32_t) goff[j] : (uint32_t) (min(idx >> 4, kmax) * row_halves + (idx & 15) * 8);
-            reg[j] = *((const half8_t*) (base + off));
+            reg[j] = *((const half8_t*) (base + __umul24(min(idx >> 4, kmax), row_halves) + (idx & 15) * 8));      // (no branch: this sits between matrix instructions)
         }
     };
-    auto put = [&](const half8_t (&reg)[2], half_t* slot, const int (&dst)[2]) __attribute__((always_inline))
-    {
-        #pragma unroll
-        for (int j = 0; j < 2; ++j) *((half8_t*) (slot + dst[j])) = reg[j];
-    };
+    auto put1 = [&](int j, const half8_t (&reg)[2], half_t* slot, const int (&dst)[2]) __attribute__((always_inline)) { *((half8_t*) (slot + dst[j])) = reg[j]; };
+    auto put = [&](const half8_t (&reg)[2], half_t* slot, const int (&dst)[2]) __attribute__((always_inline)) { put1(0, reg, slot, dst); put1(1, reg, slot, dst); };
     auto Kslot = [&](int i) __attribute__((always_inline)) { return ring + (i & 1) * PW_TILE_HALVES; };
     auto Vslot = [&](int i) __attribute__((always_inline)) { return ring + (2 + (i & 1)) * PW_TILE_HALVES; };
 
@@ -494,11 +496,20 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
     };
 
     // ---- prologue: K_0, K_1, V_0 in LDS, K_2 and V_1 on their way; S_0 with its own maxima as the first reference
-    fetch(0, kreg, a.k_pages); fetch(0, vreg, a.v_pages);
-    put(kreg, Kslot(0), kdst); put(vreg, Vslot(0), vdst);
-    fetch(1, kreg, a.k_pages);
-    put(kreg, Kslot(1), kdst);
-    fetch(1, vreg, a.v_pages); fetch(2, kreg, a.k_pages);
+    TilePos pk = { 0, 0, 0 }, pv;                               // (the fetch positions of K and V: K runs one tile ahead)
+    int32_t pg_v, pg_k;
+    {
+        // all block-table entries first, then K_0, V_0, K_1 in flight together (one HBM latency, not three)
+        TilePos p1 = pk; advance(p1);
+        TilePos p2 = p1; advance(p2);
+        TilePos p3 = p2; advance(p3);
+        const int32_t g0 = page_id_of(pk), g1 = page_id_of(p1), g2 = page_id_of(p2), g3 = page_id_of(p3);
+        half8_t k1reg[2];
+        fetch(pk, g0, kreg, a.k_pages); fetch(pk, g0, vreg, a.v_pages); fetch(p1, g1, k1reg, a.k_pages);     // K_0, V_0, K_1
+        put(kreg, Kslot(0), kdst); put(vreg, Vslot(0), vdst); put(k1reg, Kslot(1), kdst);
+        fetch(p1, g1, vreg, a.v_pages); fetch(p2, g2, kreg, a.k_pages);                                     // V_1 and K_2 stay in registers
+        pv = p2; pk = p3; pg_v = g2; pg_k = g3;                                                             // iteration 0 fetches V_2 and K_3
+    }
     __syncthreads();
     f32x16_t S[2];                                              // [key block]
     #pragma unroll
@@ -527,8 +538,6 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
         half8_t kf[16], qfr[8], vf[16];
         if constexpr (MORE) { kf[0] = k_frag(0, kbuf); kf[1] = k_frag(1, kbuf); qfr[0] = q_frag(0); }
         else { vf[0] = v_frag(0, vbuf); vf[1] = v_frag(1, vbuf); }
-        put(kreg, Kslot(t), kdst); put(vreg, Vslot(t + 1), vdst);
-        fetch(t + 3, kreg, a.k_pages); fetch(t + 2, vreg, a.v_pages);
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 1: S_{t+1}
         if constexpr (MORE)
@@ -540,6 +549,12 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
                 if (!(s & 1) && s + 2 < 16) qfr[(s >> 1) + 1] = q_frag((s >> 1) + 1);
                 if (s >= 14) vf[s - 14] = v_frag(s - 14, vbuf);
                 qk_mfma(s, kf[s], qfr[s >> 1], S);
+                // the staging traffic rides between the matrix instructions (all eight waves doing it together after the barrier left the pipe idle):
+                // the LDS writes of K_{t+2} / V_{t+1} (in registers since the previous iteration's phase 2) here, the next loads in phase 2
+                if (s == 8) put1(0, kreg, Kslot(t), kdst);
+                if (s == 9) put1(1, kreg, Kslot(t), kdst);
+                if (s == 10) put1(0, vreg, Vslot(t + 1), vdst);
+                if (s == 11) put1(1, vreg, Vslot(t + 1), vdst);
                 __builtin_amdgcn_sched_barrier(0);
             }
             mask_tile(t + 1, S);
@@ -554,6 +569,8 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
             pv_mfma(s, vf[s], pa);
             if constexpr (MORE)
             {
+                if (s == 1) fetch(pk, pg_k, kreg, a.k_pages);                                               // K_{t+3}
+                if (s == 2) { fetch(pv, pg_v, vreg, a.v_pages); pv = pk; pg_v = pg_k; advance(pk); }       // V_{t+2}
                 if (s == 0) adjust(S, pw_rowmax(S[0], S[1]));
                 else
                 {
@@ -568,6 +585,9 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
             rescale();
             #pragma unroll
             for (int i = 0; i < 16; ++i) pa[i] = pn[i];
+            // the block-table entry of the next K fetch: asked for HERE, right before the barrier -- a scalar load in flight turns every LDS wait of
+            // the phases into lgkmcnt(0) (the counter is shared and scalar loads return out of order)
+            pg_k = page_id_of(pk);
         }
     };
     for (int t = 0; t + 1 < ntiles; ++t) iteration(t, std::true_type{});
