@@ -31,6 +31,7 @@ struct PrefillAttnArgs
     const int32_t* block_table; const int32_t* cache_seqlens;   // [bsz][blocks_per_seq]; [bsz] = tokens in the cache INCLUDING the q_len new ones
     int q_len, hq, hkv, blocks_per_seq, page_size;
     int64_t ldq;                                                // halves between consecutive tokens of q (hq * HD when contiguous)
+    int prio_from;                                              // (w64 kernel) waves >= this index raise their issue priority once
     float scale;
 };
 
@@ -331,11 +332,32 @@ __device__ __forceinline__ uint32_t pw_exp_pair(float a, float b)
 //   * the reference maximum moves only when a score exceeds it by 2^8 (probabilities stay below 2^8 in fp16); the tile's scores, the start values and
 //     -- after the tile's P V is complete -- the accumulators are adjusted in rarely taken wave-uniform branches.
 #define PW_TILE_HALVES (64 * 128)
+#ifndef PW_PUT_AT
+#define PW_PUT_AT 0
+#define PW_FETCH_PHASE 1
+#define PW_FETCH_AT 5
+#endif
+#ifndef PW_KD
+#define PW_KD 3            // K fragments: slices (matrix instructions) ahead
+#define PW_QD 2            // Q fragments: k-steps (two slices each) ahead
+#define PW_VD 2            // V fragments: slices ahead
+#endif
+#ifndef PW_PRIO_FROM
+#define PW_PRIO_FROM 4
+#endif
 #define PW_QS 136
+template <int ABL>
 __global__ __launch_bounds__(512)
 void attn_prefill_w64_kernel(const PrefillAttnArgs a)
 {
     constexpr int HD = 128;
+    // variants 11 .. : schedule knobs (K / Q / V fragment read-ahead, slices of the LDS writes and of the next loads)
+    constexpr int KD = ABL == 11 ? 2 : ((ABL == 12 || ABL == 15 || ABL == 16) ? 4 : (ABL == 18 ? 5 : PW_KD));
+    constexpr int QD = ABL == 11 ? 1 : (ABL == 18 ? 3 : PW_QD);
+    constexpr int VD = ABL == 11 ? 1 : ((ABL == 12 || ABL == 15 || ABL == 17 || ABL == 18) ? 3 : PW_VD);
+    constexpr int PUT_AT = (ABL == 13 || ABL == 15 || ABL == 16) ? 6 : (ABL == 14 ? 10 : (ABL == 19 ? 3 : PW_PUT_AT));
+    constexpr int FETCH_PHASE = ABL == 14 ? 2 : PW_FETCH_PHASE;
+    constexpr int FETCH_AT = (ABL == 13 || ABL == 15 || ABL == 16) ? 11 : (ABL == 14 ? 1 : (ABL == 19 ? 8 : PW_FETCH_AT));
     __shared__ __attribute__((aligned(1024))) half_t ring[4 * PW_TILE_HALVES + 8 * 32 * PW_QS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     half_t* const qs = ring + 4 * PW_TILE_HALVES + wave * 32 * PW_QS;                                        // this wave's queries (later: its output rows)
@@ -352,15 +374,18 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
 
     // ---- staging: 64 keys x 256 B = 1024 16-byte chunks per tile and operand, 2 per thread; HBM -> registers one iteration before the LDS write
     const int row_halves = hkv * HD;                                                                        // (64 rows x hkv x 128 halves: far inside 32 bits)
-    int kdst[2], vdst[2];                                                                                   // LDS offsets (halves)
-    #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    // LDS offsets (halves) of chunk j of this thread: recomputed where they are used (two VALU each) rather than held in registers
+    // (tid_o: the thread index behind an empty asm, refreshed per iteration -- otherwise the loop-invariant offsets are hoisted back into registers)
+    int tid_o = tid;
+    auto kdst = [&](int j) __attribute__((always_inline)) { const int idx = tid_o + 512 * j, key = idx >> 4, ch = idx & 15; return key * 128 + ((ch ^ (key & 15)) * 8); };
+    auto vdst = [&](int j) __attribute__((always_inline))
     {
-        const int idx = tid + 512 * j, key = idx >> 4, ch = idx & 15;
-        kdst[j] = key * 128 + ((ch ^ (key & 15)) * 8);
-        vdst[j] = key * 128 + ((ch ^ (((key & 3) << 2) | ((key >> 2) & 3))) * 8);
-    }
-    half8_t kreg[2], vreg[2];
+        const int idx = tid_o + 512 * j, key = idx >> 4, ch = idx & 15;
+        return key * 128 + ((ch ^ (((key & 3) << 2) | ((key >> 2) & 3))) * 8);
+    };
+    // ONE register set: what iteration t fetches (early in its score phase) is written to LDS early in iteration t + 1.  (A second set -- written two
+    // iterations later -- measured the same: the loads cost their instructions, not their latency.)
+    half8_t kreg[1][2], vreg[1][2];
     // Where a tile lives: (tile, page index, first key's offset inside the page), advanced by 64 keys per step without divisions (page_size is a run-time
     // value: every / and % was a ~30-instruction scalar sequence, three per iteration) and clamped at the last tile.  The page id itself (a scalar load
     // from the block table) is read one iteration before the fetch that uses it.
@@ -382,8 +407,8 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
             reg[j] = *((const half8_t*) (base + __umul24(min(idx >> 4, kmax), row_halves) + (idx & 15) * 8));      // (no branch: this sits between matrix instructions)
         }
     };
-    auto put1 = [&](int j, const half8_t (&reg)[2], half_t* slot, const int (&dst)[2]) __attribute__((always_inline)) { *((half8_t*) (slot + dst[j])) = reg[j]; };
-    auto put = [&](const half8_t (&reg)[2], half_t* slot, const int (&dst)[2]) __attribute__((always_inline)) { put1(0, reg, slot, dst); put1(1, reg, slot, dst); };
+    auto putk = [&](int j, const half8_t (&reg)[2], half_t* slot) __attribute__((always_inline)) { *((half8_t*) (slot + kdst(j))) = reg[j]; };
+    auto putv = [&](int j, const half8_t (&reg)[2], half_t* slot) __attribute__((always_inline)) { *((half8_t*) (slot + vdst(j))) = reg[j]; };
     auto Kslot = [&](int i) __attribute__((always_inline)) { return ring + (i & 1) * PW_TILE_HALVES; };
     auto Vslot = [&](int i) __attribute__((always_inline)) { return ring + (2 + (i & 1)) * PW_TILE_HALVES; };
 
@@ -400,24 +425,36 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
         *((half8_t*) (qs + r * PW_QS + 8 * ch)) = v;
     }
     // ---- per-lane fragment addresses (halves from the slot / the wave's query rows): everything that depends on the slice is an immediate offset
-    int kl[8], vl0[4], vl1[4];
+    // (kept as LDS POINTERS into slot 0 of each ring: the slot of an iteration is a compile-time constant of its unrolled copy, so slot, key block
+    // and k-step all go into the read's immediate offset and a fragment read costs no address arithmetic)
+    const half_t* kl[8]; const half_t* vl0[4]; const half_t* vl1[4];
     #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) kl[ks] = n * 128 + (((2 * ks + h) ^ (n & 15)) * 8);                     // key block kb: + 32 * 128
+    for (int ks = 0; ks < 8; ++ks) kl[ks] = ring + n * 128 + (((2 * ks + h) ^ (n & 15)) * 8);              // key block kb: + 32 * 128
     {
         const int G = lane >> 4, c = lane & 15;
         const int rl = 4 * (G >> 1) + (c >> 2), fh = (c >> 2) & 3, fl = G >> 1, L = 2 * (G & 1) + ((c & 3) >> 1);
         #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
         {
-            vl0[nb] = rl * 128 + ((((nb ^ fh) << 2) | (L ^ fl)) * 8) + 4 * (c & 1);                         // k-step kst: + 16 * kst * 128
-            vl1[nb] = (rl + 8) * 128 + ((((nb ^ fh) << 2) | (L ^ (fl | 2))) * 8) + 4 * (c & 1);
+            vl0[nb] = ring + 2 * PW_TILE_HALVES + rl * 128 + ((((nb ^ fh) << 2) | (L ^ fl)) * 8) + 4 * (c & 1);      // k-step kst: + 16 * kst * 128
+            vl1[nb] = ring + 2 * PW_TILE_HALVES + (rl + 8) * 128 + ((((nb ^ fh) << 2) | (L ^ (fl | 2))) * 8) + 4 * (c & 1);
         }
     }
     const half_t* const ql = qs + n * PW_QS + 8 * h;                                                        // k-step ks: + 16
 
-    f32x16_t oc[4], lacc, negm;                                 // O, the row sums (ones column), minus the reference maximum (start value of the score chains)
+    f32x16_t oc[4], lacc;                                       // O, the row sums (ones column)
+    // minus the reference maximum of the lane's query enters every score chain through ONE extra k-step: A = all ones, B = { hi, lo, 0 ... } in the
+    // lanes of the first k half (hi + lo = -max as two fp16; products with 1.0 and the fp32 accumulation are exact) -- 4 registers instead of a
+    // 16-register start value for operand C
+    float mref = 0.0f;
+    half8_t negm = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    auto set_negm = [&]() __attribute__((always_inline))
+    {
+        const half_t hi = (half_t) (-mref), lo = (half_t) (-mref - (float) hi);
+        negm[0] = h == 0 ? hi : (half_t) 0.0f; negm[1] = h == 0 ? lo : (half_t) 0.0f;
+    };
     #pragma unroll
-    for (int i = 0; i < 16; ++i) { lacc[i] = 0.0f; negm[i] = 0.0f; }
+    for (int i = 0; i < 16; ++i) lacc[i] = 0.0f;
     #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
         #pragma unroll
@@ -440,18 +477,20 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
                 if (!(key <= qpos && key < kv_len)) S[kb][i] = -1.0e30f;
             }
     };
-    auto k_frag = [&](int s, const half_t* kbuf) __attribute__((always_inline)) { return *((const half8_t*) (kbuf + kl[s >> 1] + (s & 1) * 32 * 128)); };
+    auto k_frag = [&](int s, int slot) __attribute__((always_inline)) { return *((const half8_t*) (kl[s >> 1] + slot * PW_TILE_HALVES + (s & 1) * 32 * 128)); };
     auto q_frag = [&](int ks) __attribute__((always_inline)) { return *((const half8_t*) (ql + 16 * ks)); };
-    auto v_frag = [&](int s, const half_t* vbuf) __attribute__((always_inline))
+    auto v_frag = [&](int s, int slot) __attribute__((always_inline))
     {
         const int kst = s >> 2, nb = s & 3;                     // k-step (kb, bp) = (kst >> 1, kst & 1): keys 32 kb + 16 bp + 8 e + 4 h + j
-        const half4_t v0 = lds_read_tr16(vbuf + vl0[nb] + kst * 16 * 128), v1 = lds_read_tr16(vbuf + vl1[nb] + kst * 16 * 128);
+        const half4_t v0 = lds_read_tr16(vl0[nb] + slot * PW_TILE_HALVES + kst * 16 * 128), v1 = lds_read_tr16(vl1[nb] + slot * PW_TILE_HALVES + kst * 16 * 128);
         return half8_t{ v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
     };
     // slice s of a score phase: k-step ks = s >> 1 of key block kb = s & 1; a chain's first instruction starts from -max of the lane's query
     auto qk_mfma = [&](int s, half8_t ka, half8_t qf, f32x16_t (&S)[2]) __attribute__((always_inline))
     {
-        S[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf, s < 2 ? negm : S[s & 1], 0, 0, 0);
+        const f32x16_t zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        S[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf, s < 2 ? zero : S[s & 1], 0, 0, 0);
+        if (s >= 14) S[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, negm, S[s & 1], 0, 0, 0);     // ... - max, once per chain
     };
     // slice s of a P V phase: k-step kst = s >> 2, output block nb = s & 3; the ones column rides with nb == 0
     auto pv_mfma = [&](int s, half8_t vB, const uint32_t (&pa)[16]) __attribute__((always_inline))
@@ -477,7 +516,8 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
         if (!__any(mx > 8.0f)) return;
         const float d = mx > 8.0f ? mx : 0.0f;
         #pragma unroll
-        for (int i = 0; i < 16; ++i) { S[0][i] -= d; S[1][i] -= d; negm[i] -= d; }
+        for (int i = 0; i < 16; ++i) { S[0][i] -= d; S[1][i] -= d; }
+        mref += d; set_negm();
         corr = __builtin_amdgcn_exp2f(-d);
         pend = true;
     };
@@ -497,47 +537,64 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
 
     // ---- prologue: K_0, K_1, V_0 in LDS, K_2 and V_1 on their way; S_0 with its own maxima as the first reference
     TilePos pk = { 0, 0, 0 }, pv;                               // (the fetch positions of K and V: K runs one tile ahead)
-    int32_t pg_v, pg_k;
+    int32_t pg_v, pg_k, pg_next = 0;
     {
         // all block-table entries first, then K_0, V_0, K_1 in flight together (one HBM latency, not three)
         TilePos p1 = pk; advance(p1);
         TilePos p2 = p1; advance(p2);
         TilePos p3 = p2; advance(p3);
-        const int32_t g0 = page_id_of(pk), g1 = page_id_of(p1), g2 = page_id_of(p2), g3 = page_id_of(p3);
+        TilePos p4 = p3; advance(p4);
+        const int32_t g0 = page_id_of(pk), g1 = page_id_of(p1), g2 = page_id_of(p2), g3 = page_id_of(p3), g4 = page_id_of(p4);
         half8_t k1reg[2];
-        fetch(pk, g0, kreg, a.k_pages); fetch(pk, g0, vreg, a.v_pages); fetch(p1, g1, k1reg, a.k_pages);     // K_0, V_0, K_1
-        put(kreg, Kslot(0), kdst); put(vreg, Vslot(0), vdst); put(k1reg, Kslot(1), kdst);
-        fetch(p1, g1, vreg, a.v_pages); fetch(p2, g2, kreg, a.k_pages);                                     // V_1 and K_2 stay in registers
-        pv = p2; pk = p3; pg_v = g2; pg_k = g3;                                                             // iteration 0 fetches V_2 and K_3
+        fetch(pk, g0, kreg[0], a.k_pages); fetch(pk, g0, vreg[0], a.v_pages); fetch(p1, g1, k1reg, a.k_pages);       // K_0, V_0, K_1
+        putk(0, kreg[0], Kslot(0)); putk(1, kreg[0], Kslot(0)); putv(0, vreg[0], Vslot(0)); putv(1, vreg[0], Vslot(0));
+        putk(0, k1reg, Kslot(1)); putk(1, k1reg, Kslot(1));
+        fetch(p2, g2, kreg[0], a.k_pages); fetch(p1, g1, vreg[0], a.v_pages);                               // written in iteration 0: K_2, V_1
+        pv = p2; pk = p3; pg_v = g2; pg_k = g3; (void) g4;                                                  // iteration 0 fetches V_2 and K_3
     }
     __syncthreads();
     f32x16_t S[2];                                              // [key block]
     #pragma unroll
-    for (int s = 0; s < 16; ++s) qk_mfma(s, k_frag(s, Kslot(0)), q_frag(s >> 1), S);                       // (negm = 0: true scores)
+    for (int s = 0; s < 16; ++s) qk_mfma(s, k_frag(s, 0), q_frag(s >> 1), S);                              // (negm = 0: true scores)
     mask_tile(0, S);
     {
         float mx = pw_rowmax(S[0], S[1]);
         if (mx < -1.0e29f) mx = 0.0f;                           // a query without any visible key (not a valid call): all its probabilities become 0
         #pragma unroll
-        for (int i = 0; i < 16; ++i) { S[0][i] -= mx; S[1][i] -= mx; negm[i] = -mx; }
+        for (int i = 0; i < 16; ++i) { S[0][i] -= mx; S[1][i] -= mx; }
+        mref = mx; set_negm();
     }
-    uint32_t pa[16];                                            // fp16 probability pairs of the current tile
+    uint32_t pab[2][16];                                        // fp16 probability pairs of the current / the next tile (roles alternate with SET)
     #pragma unroll
-    for (int p = 0; p < 16; ++p) pa[p] = exp_pair(p, S);
+    for (int p = 0; p < 16; ++p) pab[0][p] = exp_pair(p, S);
 
     // one iteration: phase 1 = tile t + 1's scores (matrix instructions, fragment reads, the staging traffic), phase 2 = tile t's P V beside tile
     // t + 1's maximum and probabilities.  MORE = tile t + 1 exists.  Ring: at the top of iteration t the slots of K_t and V_{t-1} are dead and take
     // K_{t+2} and V_{t+1} (in registers since the previous iteration); they are first read after the NEXT barrier
-    auto iteration = [&](int t, auto more_c) __attribute__((always_inline))
+    auto iteration = [&](int t, auto more_c, auto set_c) __attribute__((always_inline))
     {
         constexpr bool MORE = decltype(more_c)::value;
-        __syncthreads();
-        const half_t* kbuf = Kslot(t + 1);
-        const half_t* vbuf = Vslot(t);
+        constexpr int SET = decltype(set_c)::value;             // = t & 1: the ring slots and the probability arrays of this unrolled copy
+        constexpr int RS = 0;                                   // staging register set
+        tid_o = tid; asm volatile("" : "+v"(tid_o));
+        if constexpr (ABL != 3) __syncthreads();
+        constexpr int kbuf = 1 - SET, vbuf = SET;               // ring slots of K_{t+1} and V_t
         // fragments are read from LDS TWO slices before their use
         half8_t kf[16], qfr[8], vf[16];
-        if constexpr (MORE) { kf[0] = k_frag(0, kbuf); kf[1] = k_frag(1, kbuf); qfr[0] = q_frag(0); }
-        else { vf[0] = v_frag(0, vbuf); vf[1] = v_frag(1, vbuf); }
+        // fragment reads run KD / QD / VD slices ahead of their use: a score slice is ONE matrix instruction (32 cycles) and an LDS read under
+        // eight waves' traffic takes well over 100 -- one slice ahead, the wait for the fragment was the longest thing in the loop
+        if constexpr (MORE)
+        {
+            #pragma unroll
+            for (int i = 0; i < KD; ++i) kf[i] = k_frag(i, kbuf);
+            #pragma unroll
+            for (int i = 0; i < QD; ++i) qfr[i] = q_frag(i);
+        }
+        else
+        {
+            #pragma unroll
+            for (int i = 0; i < VD; ++i) vf[i] = v_frag(i, vbuf);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase 1: S_{t+1}
         if constexpr (MORE)
@@ -545,75 +602,115 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
             #pragma unroll
             for (int s = 0; s < 16; ++s)
             {
-                if (s + 2 < 16) kf[s + 2] = k_frag(s + 2, kbuf);
-                if (!(s & 1) && s + 2 < 16) qfr[(s >> 1) + 1] = q_frag((s >> 1) + 1);
-                if (s >= 14) vf[s - 14] = v_frag(s - 14, vbuf);
-                qk_mfma(s, kf[s], qfr[s >> 1], S);
+                if constexpr (ABL != 4 && ABL != 10)
+                {
+                    if (s + KD < 16) kf[s + KD] = k_frag(s + KD, kbuf);
+                    if (!(s & 1) && (s >> 1) + QD < 8) qfr[(s >> 1) + QD] = q_frag((s >> 1) + QD);
+                    if (s >= 16 - VD) vf[s - (16 - VD)] = v_frag(s - (16 - VD), vbuf);
+                }
+                else { if (s + KD < 16) kf[s + KD] = kf[0]; if (!(s & 1) && (s >> 1) + QD < 8) qfr[(s >> 1) + QD] = qfr[0]; if (s >= 16 - VD) vf[s - (16 - VD)] = kf[0]; }
+                if constexpr (ABL != 5 && (ABL != 9 && ABL != 10)) qk_mfma(s, kf[s], qfr[s >> 1], S);
+                else { S[s & 1][s] += (float) kf[s][0] + (float) qfr[s >> 1][1]; }
                 // the staging traffic rides between the matrix instructions (all eight waves doing it together after the barrier left the pipe idle):
                 // the LDS writes of K_{t+2} / V_{t+1} (in registers since the previous iteration's phase 2) here, the next loads in phase 2
-                if (s == 8) put1(0, kreg, Kslot(t), kdst);
-                if (s == 9) put1(1, kreg, Kslot(t), kdst);
-                if (s == 10) put1(0, vreg, Vslot(t + 1), vdst);
-                if (s == 11) put1(1, vreg, Vslot(t + 1), vdst);
+                if constexpr (ABL != 2)
+                {
+                    if constexpr (ABL == 8)
+                    {
+                        // loads are waited for and consumed (one VALU each), nothing is written to LDS
+                        if (s == PUT_AT) { uint32_t x = __builtin_bit_cast(uint32_t, half2_t{ kreg[RS][0][0], vreg[RS][1][1] }) | __builtin_bit_cast(uint32_t, half2_t{ kreg[RS][1][0], vreg[RS][0][1] }); asm volatile("" :: "v"(x)); }
+                    }
+                    else if constexpr (ABL != 6)
+                    {
+                    if (s == PUT_AT) putk(0, kreg[RS], Kslot(t));
+                    if (s == PUT_AT + 1) putk(1, kreg[RS], Kslot(t));
+                    if (s == PUT_AT + 2) putv(0, vreg[RS], Vslot(t + 1));
+                    if (s == PUT_AT + 3) putv(1, vreg[RS], Vslot(t + 1));
+                    }
+                    if constexpr (ABL != 7 && (ABL != 9 && ABL != 10))
+                    {
+                    if (FETCH_PHASE == 1 && s == FETCH_AT) fetch(pk, pg_k, kreg[RS], a.k_pages);                             // K_{t+4}
+                    if (FETCH_PHASE == 1 && s == FETCH_AT + 1)
+                    {
+                        fetch(pv, pg_v, vreg[RS], a.v_pages); pv = pk; pg_v = pg_k; advance(pk);                                                  // V_{t+3}
+                        // the block-table entry of the NEXT iteration's K fetch.  (After the first barrier hipcc no longer proves the table unwritten and
+                        // reads it with a vector load; asked for here and consumed at the end of the iteration, nobody waits for it.)
+                        pg_next = page_id_of(pk);
+                    }
+                    }
+                    else if (ABL == 7 && s == FETCH_AT) { kreg[RS][0] = kf[s]; kreg[RS][1] = kf[s]; vreg[RS][0] = kf[s]; vreg[RS][1] = kf[s]; }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             mask_tile(t + 1, S);
         }
         // ---- phase 2: O += P_t V_t (and the row sums) beside the maximum and the probabilities of tile t + 1 (slice 0: maximum, slice s: pair s - 1,
         // slice 15: pairs 14 and 15)
-        uint32_t pn[16];
+        uint32_t (&pa)[16] = pab[SET];
+        uint32_t (&pn)[16] = pab[1 - SET];
         #pragma unroll
         for (int s = 0; s < 16; ++s)
         {
-            if (s + 2 < 16) vf[s + 2] = v_frag(s + 2, vbuf);
-            pv_mfma(s, vf[s], pa);
+            if constexpr (ABL != 4 && ABL != 10) { if (s + VD < 16) vf[s + VD] = v_frag(s + VD, vbuf); } else { if (s + VD < 16) vf[s + VD] = vf[0]; }
+            if constexpr (ABL != 5 && (ABL != 9 && ABL != 10)) pv_mfma(s, vf[s], pa); else { oc[s & 3][s] += (float) vf[s][0] + (float) pa[s]; }
             if constexpr (MORE)
             {
-                if (s == 1) fetch(pk, pg_k, kreg, a.k_pages);                                               // K_{t+3}
-                if (s == 2) { fetch(pv, pg_v, vreg, a.v_pages); pv = pk; pg_v = pg_k; advance(pk); }       // V_{t+2}
+                if constexpr (ABL != 2)
+                {
+                    if (FETCH_PHASE == 2 && s == FETCH_AT) fetch(pk, pg_k, kreg[RS], a.k_pages);
+                    if (FETCH_PHASE == 2 && s == FETCH_AT + 1) { fetch(pv, pg_v, vreg[RS], a.v_pages); pv = pk; pg_v = pg_k; advance(pk); }
+                }
                 if (s == 0) adjust(S, pw_rowmax(S[0], S[1]));
-                else
+                else if constexpr (ABL != 1 && (ABL != 9 && ABL != 10))
                 {
                     pn[s - 1] = exp_pair(s - 1, S);
                     if (s == 15) pn[15] = exp_pair(15, S);
                 }
+                else { pn[s - 1] = __float_as_uint(S[0][s]); if (s == 15) pn[15] = __float_as_uint(S[1][s]); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (MORE)
         {
             rescale();
-            #pragma unroll
-            for (int i = 0; i < 16; ++i) pa[i] = pn[i];
-            // the block-table entry of the next K fetch: asked for HERE, right before the barrier -- a scalar load in flight turns every LDS wait of
-            // the phases into lgkmcnt(0) (the counter is shared and scalar loads return out of order)
-            pg_k = page_id_of(pk);
+            pg_k = __builtin_amdgcn_readfirstlane(pg_next);
         }
     };
-    for (int t = 0; t + 1 < ntiles; ++t) iteration(t, std::true_type{});
-    iteration(ntiles - 1, std::false_type{});
+    // the second-dispatched half of the workgroup loses the issue arbitration on every segment (priority, then age): one static priority raise for it
+    static const int dummy_prio = 0; (void) dummy_prio;
+    if (__builtin_amdgcn_readfirstlane(wave) >= a.prio_from) __builtin_amdgcn_s_setprio(1);
+    {
+        using T = std::true_type; using F = std::false_type; using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+        int t = 0;
+        for (; t + 2 < ntiles; t += 2) { iteration(t, T{}, S0{}); iteration(t + 1, T{}, S1{}); }
+        if (t + 1 < ntiles) { iteration(t, T{}, S0{}); iteration(t + 1, F{}, S1{}); }
+        else iteration(t, F{}, S0{});
+    }
 
     // ---- normalise (row sums and outputs share the accumulator layout), stage through this wave's LDS rows (its queries are no longer needed),
     // store whole rows
-    half_t* os = qs;
+    // (everything lane-dependent is re-derived from the thread index behind an empty asm: values shared with the prologue are NOT kept alive, or
+    // spilled, across the main loop for this)
+    int tid_e = tid;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6, n_e = lane_e & 31, h_e = lane_e >> 5, head_e = hg * 4 + (wave_e & 3);
+    half_t* os = ring + 4 * PW_TILE_HALVES + wave_e * 32 * PW_QS;
     #pragma unroll
     for (int i = 0; i < 16; ++i)
     {
-        const int r = 8 * (i >> 2) + 4 * h + (i & 3);
+        const int r = 8 * (i >> 2) + 4 * h_e + (i & 3);
         const float li = lacc[i] > 0.0f ? 1.0f / lacc[i] : 0.0f;                             // (a query without any visible key: zeros, as the kernel above)
         #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) os[r * PW_QS + 32 * nb + n] = (half_t) (oc[nb][i] * li);
+        for (int nb = 0; nb < 4; ++nb) os[r * PW_QS + 32 * nb + n_e] = (half_t) (oc[nb][i] * li);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));                            // (the row indices of the query loads above are NOT kept alive across the main loop for this)
     #pragma unroll
     for (int j = 0; j < 8; ++j)
     {
         const int idx = lane_e + 64 * j, r = idx >> 4, ch = idx & 15;
         if (q0w + r < q_len)
-            *((half8_t*) (a.out + (((size_t) b * q_len + q0w + r) * hq + head) * HD + 8 * ch)) = *((const half8_t*) (os + r * PW_QS + 8 * ch));
+            *((half8_t*) (a.out + (((size_t) b * q_len + q0w + r) * hq + head_e) * HD + 8 * ch)) = *((const half8_t*) (os + r * PW_QS + 8 * ch));
     }
 }
 
@@ -644,7 +741,7 @@ extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void*
     PrefillAttnArgs a;
     a.q = (const half_t*) q; a.out = (half_t*) out; a.k_pages = (const half_t*) k_pages; a.v_pages = (const half_t*) v_pages;
     a.block_table = block_table; a.cache_seqlens = cache_seqlens;
-    a.q_len = q_len; a.hq = heads_q; a.hkv = heads_kv; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.scale = scale; a.ldq = ldq;
+    a.q_len = q_len; a.hq = heads_q; a.hkv = heads_kv; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.scale = scale; a.ldq = ldq; a.prio_from = 8;
     const int gq = heads_q / heads_kv;
     hipStream_t st = (hipStream_t) stream;
     // head_dim 128 with four query heads per kv head: one wave per SIMD, 64 queries per wave (round 4)
@@ -652,7 +749,32 @@ extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void*
     if (w64 && head_dim == 128 && gq % 4 == 0 && q_len >= 64)
     {
         dim3 gridw(heads_q / 4, (q_len + 63) / 64, bsz);
-        attn_prefill_w64_kernel<<<gridw, 512, 0, st>>>(a);
+        static const int prio = [] { const char* e = getenv("EXL3_HIP_ATTN_PREFILL_PRIO"); return e ? atoi(e) : PW_PRIO_FROM; }();
+        a.prio_from = prio;
+        static const int abl = [] { const char* e = getenv("EXL3_HIP_ATTN_PREFILL_ABL"); return e ? atoi(e) : 0; }();
+        switch (abl)
+        {
+            case 1: attn_prefill_w64_kernel<1><<<gridw, 512, 0, st>>>(a); break;
+            case 2: attn_prefill_w64_kernel<2><<<gridw, 512, 0, st>>>(a); break;
+            case 3: attn_prefill_w64_kernel<3><<<gridw, 512, 0, st>>>(a); break;
+            case 4: attn_prefill_w64_kernel<4><<<gridw, 512, 0, st>>>(a); break;
+            case 5: attn_prefill_w64_kernel<5><<<gridw, 512, 0, st>>>(a); break;
+            case 6: attn_prefill_w64_kernel<6><<<gridw, 512, 0, st>>>(a); break;
+            case 8: attn_prefill_w64_kernel<8><<<gridw, 512, 0, st>>>(a); break;
+            case 9: attn_prefill_w64_kernel<9><<<gridw, 512, 0, st>>>(a); break;
+            case 10: attn_prefill_w64_kernel<10><<<gridw, 512, 0, st>>>(a); break;
+            case 11: attn_prefill_w64_kernel<11><<<gridw, 512, 0, st>>>(a); break;
+            case 12: attn_prefill_w64_kernel<12><<<gridw, 512, 0, st>>>(a); break;
+            case 13: attn_prefill_w64_kernel<13><<<gridw, 512, 0, st>>>(a); break;
+            case 14: attn_prefill_w64_kernel<14><<<gridw, 512, 0, st>>>(a); break;
+            case 15: attn_prefill_w64_kernel<15><<<gridw, 512, 0, st>>>(a); break;
+            case 16: attn_prefill_w64_kernel<16><<<gridw, 512, 0, st>>>(a); break;
+            case 17: attn_prefill_w64_kernel<17><<<gridw, 512, 0, st>>>(a); break;
+            case 18: attn_prefill_w64_kernel<18><<<gridw, 512, 0, st>>>(a); break;
+            case 19: attn_prefill_w64_kernel<19><<<gridw, 512, 0, st>>>(a); break;
+            case 7: attn_prefill_w64_kernel<7><<<gridw, 512, 0, st>>>(a); break;
+            default: attn_prefill_w64_kernel<0><<<gridw, 512, 0, st>>>(a); break;
+        }
         return exl3_check_launch("attn_prefill_w64");
     }
     int gw = gq % 4 == 0 ? 4 : (gq % 2 == 0 ? 2 : 1);                                // query heads per workgroup (they share a kv head) ...
