@@ -31,7 +31,6 @@ struct PrefillAttnArgs
     const int32_t* block_table; const int32_t* cache_seqlens;   // [bsz][blocks_per_seq]; [bsz] = tokens in the cache INCLUDING the q_len new ones
     int q_len, hq, hkv, blocks_per_seq, page_size;
     int64_t ldq;                                                // halves between consecutive tokens of q (hq * HD when contiguous)
-    int prio_from;                                              // (w64 kernel) waves >= this index raise their issue priority once
     float scale;
 };
 
@@ -274,23 +273,21 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------
-// Round 4: one wave per SIMD, 64 queries per wave (head_dim 128, four query heads per kv head).  A workgroup = 4 waves = the four query heads that
-// share a kv head x the same 64 consecutive queries; a wave owns one head's 64 queries and most of the 512-register file: O 64 x 128 fp32 = 128
-// registers, the Q operands 64, the score block 64.  v_mfma_f32_32x32x16_f16 throughout:
-//   * S^T = K Q^T in 32 x 32 blocks (kb: keys, qb: queries): A = K rows from LDS (ds_read_b128, lane (key l % 32, dims 16 ks + 8 (l / 32) ..)), B = the
-//     wave's Q (registers); a lane ends with column (query) l % 32 and rows (keys) 32 kb + 8 (i / 4) + 4 (l / 32) + i % 4, i = 0 .. 15;
+// Round 4 (head_dim 128, four query heads per kv head): v_mfma_f32_32x32x16_f16, an exponent-only softmax, one barrier per 64-key tile.
+// A workgroup = 8 waves = the four query heads of a kv head x the two 32-query blocks of 64 consecutive queries; a wave owns one head's 32 queries:
+//   * S^T = K Q^T in 32 x 32 blocks (kb: keys): A = K rows from LDS (ds_read_b128, lane (key l % 32, dims 16 ks + 8 (l / 32) ..)), B = the wave's Q rows
+//     (LDS, pre-scaled); a lane ends with column (query) l % 32 and rows (keys) 32 kb + 8 (i / 4) + 4 (l / 32) + i % 4, i = 0 .. 15;
 //   * those 16 values are, eight at a time, an A operand of O = P V if contraction slot 8 h + 4 e + j of k-step (kb, bp) is DEFINED as key
 //     32 kb + 16 bp + 8 e + 4 h + j; the matching B operand (two runs of four consecutive keys of one output column) comes from two
-//     ds_read_b64_tr_b16 (V staged row-major, rows 80 dwords apart: the 32 lanes of a transpose-read group tile the 64 banks);
-//   * every K / V fragment read from LDS feeds two 32 x 32 x 16 instructions (the older kernel: one or two 16 x 16 x 32).
-// Software pipeline inside the wave (there is no second wave on the SIMD to hide behind): iteration t runs
-//   phase 1: S_{t+1} = K_{t+1} Q^T (32 MFMA)  beside  the softmax of tile t, query block 1 (max, exp2, row sums, fp16 pack: ~140 VALU)
-//   phase 2: O += P_t V_t (32 MFMA)           beside  the softmax of tile t + 1, query block 0
-// so each half of a tile's softmax sits between the matrix instructions of a phase that does not depend on it.  K runs one tile ahead of V in the
-// LDS ring (two slots each): what iteration t writes at its top (K_{t+2}, V_{t+1}, fetched into registers one iteration earlier) is first read
-// after the next barrier -- ONE barrier per tile.  Running max deferred (moves only when a score exceeds it by 2^8), per query, no branch; the rare
-// accumulator rescale is a wave-uniform branch between the phases.  Row sums stay per lane (a query's two lanes hold disjoint keys) until the end.
-// The output goes through LDS (the ring is free by then) and leaves as whole 256-byte rows.
+//     ds_read_b64_tr_b16 of the row-major V tile.
+// Software pipeline inside a wave: iteration t runs
+//   phase 1: S_{t+1} = K_{t+1} Q^T (16 + 2 MFMA), the LDS writes of the staged K_{t+2} / V_{t+1} and the loads of K_{t+3} / V_{t+2} between them
+//   phase 2: O += P_t V_t and the row sums (16 + 4 MFMA)  beside  the maximum and the probabilities of tile t + 1
+// K runs one tile ahead of V in the LDS ring (two slots each): what iteration t writes is first read after the NEXT barrier -- one barrier per
+// tile.  The loop is unrolled by two so that ring slots are immediate offsets of the fragment reads and the probability registers alternate
+// without copies.  The output goes through LDS (the wave's query rows are free by then) and leaves as whole 256-byte rows.
+// Measured (profiles/r04_attn_prefill_ablations.txt): 4096 tokens 660 -> 755 - 790 TFLOP/s, 8192: 750 -> 825 - 850; what bounds it is the SIMD's
+// instruction issue (~320 instructions per wave and tile for 38 matrix instructions at ~5 cycles each for the two waves together), not a pipe.
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 // (plain fmaxf on matrix-instruction results makes hipcc canonicalise every operand first -- one extra v_max each; the scores here are never NaN)
@@ -332,32 +329,15 @@ __device__ __forceinline__ uint32_t pw_exp_pair(float a, float b)
 //   * the reference maximum moves only when a score exceeds it by 2^8 (probabilities stay below 2^8 in fp16); the tile's scores, the start values and
 //     -- after the tile's P V is complete -- the accumulators are adjusted in rarely taken wave-uniform branches.
 #define PW_TILE_HALVES (64 * 128)
-#ifndef PW_PUT_AT
-#define PW_PUT_AT 0
-#define PW_FETCH_PHASE 1
-#define PW_FETCH_AT 5
-#endif
-#ifndef PW_KD
-#define PW_KD 3            // K fragments: slices (matrix instructions) ahead
-#define PW_QD 2            // Q fragments: k-steps (two slices each) ahead
-#define PW_VD 2            // V fragments: slices ahead
-#endif
-#ifndef PW_PRIO_FROM
-#define PW_PRIO_FROM 4
-#endif
 #define PW_QS 136
-template <int ABL>
 __global__ __launch_bounds__(512)
 void attn_prefill_w64_kernel(const PrefillAttnArgs a)
 {
     constexpr int HD = 128;
-    // variants 11 .. : schedule knobs (K / Q / V fragment read-ahead, slices of the LDS writes and of the next loads)
-    constexpr int KD = ABL == 11 ? 2 : ((ABL == 12 || ABL == 15 || ABL == 16) ? 4 : (ABL == 18 ? 5 : PW_KD));
-    constexpr int QD = ABL == 11 ? 1 : (ABL == 18 ? 3 : PW_QD);
-    constexpr int VD = ABL == 11 ? 1 : ((ABL == 12 || ABL == 15 || ABL == 17 || ABL == 18) ? 3 : PW_VD);
-    constexpr int PUT_AT = (ABL == 13 || ABL == 15 || ABL == 16) ? 6 : (ABL == 14 ? 10 : (ABL == 19 ? 3 : PW_PUT_AT));
-    constexpr int FETCH_PHASE = ABL == 14 ? 2 : PW_FETCH_PHASE;
-    constexpr int FETCH_AT = (ABL == 13 || ABL == 15 || ABL == 16) ? 11 : (ABL == 14 ? 1 : (ABL == 19 ? 8 : PW_FETCH_AT));
+    // schedule knobs: fragment read-ahead (K / V in slices, Q in k-steps), the score-phase slices of the LDS writes and of the next loads.  Swept
+    // (read-ahead 1 .. 5, writes at 0 .. 10, loads in either phase, static priority for waves 4-7): all inside the run-to-run spread
+    // (profiles/r04_attn_prefill_ablations.txt)
+    constexpr int KD = 3, QD = 2, VD = 2, PUT_AT = 0, FETCH_AT = 5;
     __shared__ __attribute__((aligned(1024))) half_t ring[4 * PW_TILE_HALVES + 8 * 32 * PW_QS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     half_t* const qs = ring + 4 * PW_TILE_HALVES + wave * 32 * PW_QS;                                        // this wave's queries (later: its output rows)
@@ -577,7 +557,7 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
         constexpr int SET = decltype(set_c)::value;             // = t & 1: the ring slots and the probability arrays of this unrolled copy
         constexpr int RS = 0;                                   // staging register set
         tid_o = tid; asm volatile("" : "+v"(tid_o));
-        if constexpr (ABL != 3) __syncthreads();
+        __syncthreads();
         constexpr int kbuf = 1 - SET, vbuf = SET;               // ring slots of K_{t+1} and V_t
         // fragments are read from LDS TWO slices before their use
         half8_t kf[16], qfr[8], vf[16];
@@ -602,43 +582,23 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
             #pragma unroll
             for (int s = 0; s < 16; ++s)
             {
-                if constexpr (ABL != 4 && ABL != 10)
-                {
-                    if (s + KD < 16) kf[s + KD] = k_frag(s + KD, kbuf);
-                    if (!(s & 1) && (s >> 1) + QD < 8) qfr[(s >> 1) + QD] = q_frag((s >> 1) + QD);
-                    if (s >= 16 - VD) vf[s - (16 - VD)] = v_frag(s - (16 - VD), vbuf);
-                }
-                else { if (s + KD < 16) kf[s + KD] = kf[0]; if (!(s & 1) && (s >> 1) + QD < 8) qfr[(s >> 1) + QD] = qfr[0]; if (s >= 16 - VD) vf[s - (16 - VD)] = kf[0]; }
-                if constexpr (ABL != 5 && (ABL != 9 && ABL != 10)) qk_mfma(s, kf[s], qfr[s >> 1], S);
-                else { S[s & 1][s] += (float) kf[s][0] + (float) qfr[s >> 1][1]; }
+                if (s + KD < 16) kf[s + KD] = k_frag(s + KD, kbuf);
+                if (!(s & 1) && (s >> 1) + QD < 8) qfr[(s >> 1) + QD] = q_frag((s >> 1) + QD);
+                if (s >= 16 - VD) vf[s - (16 - VD)] = v_frag(s - (16 - VD), vbuf);
+                qk_mfma(s, kf[s], qfr[s >> 1], S);
                 // the staging traffic rides between the matrix instructions (all eight waves doing it together after the barrier left the pipe idle):
-                // the LDS writes of K_{t+2} / V_{t+1} (in registers since the previous iteration's phase 2) here, the next loads in phase 2
-                if constexpr (ABL != 2)
+                // the LDS writes of K_{t+2} / V_{t+1} (in registers since the previous iteration) first, then the loads of K_{t+3} / V_{t+2}
+                if (s == PUT_AT) putk(0, kreg[RS], Kslot(t));
+                if (s == PUT_AT + 1) putk(1, kreg[RS], Kslot(t));
+                if (s == PUT_AT + 2) putv(0, vreg[RS], Vslot(t + 1));
+                if (s == PUT_AT + 3) putv(1, vreg[RS], Vslot(t + 1));
+                if (s == FETCH_AT) fetch(pk, pg_k, kreg[RS], a.k_pages);
+                if (s == FETCH_AT + 1)
                 {
-                    if constexpr (ABL == 8)
-                    {
-                        // loads are waited for and consumed (one VALU each), nothing is written to LDS
-                        if (s == PUT_AT) { uint32_t x = __builtin_bit_cast(uint32_t, half2_t{ kreg[RS][0][0], vreg[RS][1][1] }) | __builtin_bit_cast(uint32_t, half2_t{ kreg[RS][1][0], vreg[RS][0][1] }); asm volatile("" :: "v"(x)); }
-                    }
-                    else if constexpr (ABL != 6)
-                    {
-                    if (s == PUT_AT) putk(0, kreg[RS], Kslot(t));
-                    if (s == PUT_AT + 1) putk(1, kreg[RS], Kslot(t));
-                    if (s == PUT_AT + 2) putv(0, vreg[RS], Vslot(t + 1));
-                    if (s == PUT_AT + 3) putv(1, vreg[RS], Vslot(t + 1));
-                    }
-                    if constexpr (ABL != 7 && (ABL != 9 && ABL != 10))
-                    {
-                    if (FETCH_PHASE == 1 && s == FETCH_AT) fetch(pk, pg_k, kreg[RS], a.k_pages);                             // K_{t+4}
-                    if (FETCH_PHASE == 1 && s == FETCH_AT + 1)
-                    {
-                        fetch(pv, pg_v, vreg[RS], a.v_pages); pv = pk; pg_v = pg_k; advance(pk);                                                  // V_{t+3}
-                        // the block-table entry of the NEXT iteration's K fetch.  (After the first barrier hipcc no longer proves the table unwritten and
-                        // reads it with a vector load; asked for here and consumed at the end of the iteration, nobody waits for it.)
-                        pg_next = page_id_of(pk);
-                    }
-                    }
-                    else if (ABL == 7 && s == FETCH_AT) { kreg[RS][0] = kf[s]; kreg[RS][1] = kf[s]; vreg[RS][0] = kf[s]; vreg[RS][1] = kf[s]; }
+                    fetch(pv, pg_v, vreg[RS], a.v_pages); pv = pk; pg_v = pg_k; advance(pk);
+                    // the block-table entry of the NEXT iteration's K fetch.  (After the first barrier hipcc no longer proves the table unwritten and
+                    // reads it with a vector load; asked for here and consumed at the end of the iteration, nobody waits for it.)
+                    pg_next = page_id_of(pk);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -651,22 +611,16 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
         #pragma unroll
         for (int s = 0; s < 16; ++s)
         {
-            if constexpr (ABL != 4 && ABL != 10) { if (s + VD < 16) vf[s + VD] = v_frag(s + VD, vbuf); } else { if (s + VD < 16) vf[s + VD] = vf[0]; }
-            if constexpr (ABL != 5 && (ABL != 9 && ABL != 10)) pv_mfma(s, vf[s], pa); else { oc[s & 3][s] += (float) vf[s][0] + (float) pa[s]; }
+            if (s + VD < 16) vf[s + VD] = v_frag(s + VD, vbuf);
+            pv_mfma(s, vf[s], pa);
             if constexpr (MORE)
             {
-                if constexpr (ABL != 2)
-                {
-                    if (FETCH_PHASE == 2 && s == FETCH_AT) fetch(pk, pg_k, kreg[RS], a.k_pages);
-                    if (FETCH_PHASE == 2 && s == FETCH_AT + 1) { fetch(pv, pg_v, vreg[RS], a.v_pages); pv = pk; pg_v = pg_k; advance(pk); }
-                }
                 if (s == 0) adjust(S, pw_rowmax(S[0], S[1]));
-                else if constexpr (ABL != 1 && (ABL != 9 && ABL != 10))
+                else
                 {
                     pn[s - 1] = exp_pair(s - 1, S);
                     if (s == 15) pn[15] = exp_pair(15, S);
                 }
-                else { pn[s - 1] = __float_as_uint(S[0][s]); if (s == 15) pn[15] = __float_as_uint(S[1][s]); }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -676,9 +630,6 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
             pg_k = __builtin_amdgcn_readfirstlane(pg_next);
         }
     };
-    // the second-dispatched half of the workgroup loses the issue arbitration on every segment (priority, then age): one static priority raise for it
-    static const int dummy_prio = 0; (void) dummy_prio;
-    if (__builtin_amdgcn_readfirstlane(wave) >= a.prio_from) __builtin_amdgcn_s_setprio(1);
     {
         using T = std::true_type; using F = std::false_type; using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
         int t = 0;
@@ -741,7 +692,7 @@ extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void*
     PrefillAttnArgs a;
     a.q = (const half_t*) q; a.out = (half_t*) out; a.k_pages = (const half_t*) k_pages; a.v_pages = (const half_t*) v_pages;
     a.block_table = block_table; a.cache_seqlens = cache_seqlens;
-    a.q_len = q_len; a.hq = heads_q; a.hkv = heads_kv; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.scale = scale; a.ldq = ldq; a.prio_from = 8;
+    a.q_len = q_len; a.hq = heads_q; a.hkv = heads_kv; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.scale = scale; a.ldq = ldq;
     const int gq = heads_q / heads_kv;
     hipStream_t st = (hipStream_t) stream;
     // head_dim 128 with four query heads per kv head: one wave per SIMD, 64 queries per wave (round 4)
@@ -749,32 +700,7 @@ extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void*
     if (w64 && head_dim == 128 && gq % 4 == 0 && q_len >= 64)
     {
         dim3 gridw(heads_q / 4, (q_len + 63) / 64, bsz);
-        static const int prio = [] { const char* e = getenv("EXL3_HIP_ATTN_PREFILL_PRIO"); return e ? atoi(e) : PW_PRIO_FROM; }();
-        a.prio_from = prio;
-        static const int abl = [] { const char* e = getenv("EXL3_HIP_ATTN_PREFILL_ABL"); return e ? atoi(e) : 0; }();
-        switch (abl)
-        {
-            case 1: attn_prefill_w64_kernel<1><<<gridw, 512, 0, st>>>(a); break;
-            case 2: attn_prefill_w64_kernel<2><<<gridw, 512, 0, st>>>(a); break;
-            case 3: attn_prefill_w64_kernel<3><<<gridw, 512, 0, st>>>(a); break;
-            case 4: attn_prefill_w64_kernel<4><<<gridw, 512, 0, st>>>(a); break;
-            case 5: attn_prefill_w64_kernel<5><<<gridw, 512, 0, st>>>(a); break;
-            case 6: attn_prefill_w64_kernel<6><<<gridw, 512, 0, st>>>(a); break;
-            case 8: attn_prefill_w64_kernel<8><<<gridw, 512, 0, st>>>(a); break;
-            case 9: attn_prefill_w64_kernel<9><<<gridw, 512, 0, st>>>(a); break;
-            case 10: attn_prefill_w64_kernel<10><<<gridw, 512, 0, st>>>(a); break;
-            case 11: attn_prefill_w64_kernel<11><<<gridw, 512, 0, st>>>(a); break;
-            case 12: attn_prefill_w64_kernel<12><<<gridw, 512, 0, st>>>(a); break;
-            case 13: attn_prefill_w64_kernel<13><<<gridw, 512, 0, st>>>(a); break;
-            case 14: attn_prefill_w64_kernel<14><<<gridw, 512, 0, st>>>(a); break;
-            case 15: attn_prefill_w64_kernel<15><<<gridw, 512, 0, st>>>(a); break;
-            case 16: attn_prefill_w64_kernel<16><<<gridw, 512, 0, st>>>(a); break;
-            case 17: attn_prefill_w64_kernel<17><<<gridw, 512, 0, st>>>(a); break;
-            case 18: attn_prefill_w64_kernel<18><<<gridw, 512, 0, st>>>(a); break;
-            case 19: attn_prefill_w64_kernel<19><<<gridw, 512, 0, st>>>(a); break;
-            case 7: attn_prefill_w64_kernel<7><<<gridw, 512, 0, st>>>(a); break;
-            default: attn_prefill_w64_kernel<0><<<gridw, 512, 0, st>>>(a); break;
-        }
+        attn_prefill_w64_kernel<<<gridw, 512, 0, st>>>(a);
         return exl3_check_launch("attn_prefill_w64");
     }
     int gw = gq % 4 == 0 ? 4 : (gq % 2 == 0 ? 2 : 1);                                // query heads per workgroup (they share a kv head) ...
