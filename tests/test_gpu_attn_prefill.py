@@ -123,3 +123,77 @@ def test_attn_prefill_rows_without_keys_are_zero(dev):
     empty = torch.empty((0, q_len, hq, hd), dtype=torch.half, device=dev)
     ext.attn_prefill_paged(empty, torch.empty_like(empty), _t(k, dev), _t(v, dev), torch.zeros((0, 1), dtype=torch.int32, device=dev),
                            torch.zeros((0,), dtype=torch.int32, device=dev))
+
+
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 1), (16, 4)])
+@pytest.mark.parametrize("q_len,ctx", [(64, [0, 63]), (65, [1, 256]), (200, [700, 0]), (512, [37, 1000])])
+def test_attn_prefill_matrix_kernel_shapes(dev, hq, hkv, q_len, ctx):
+    """The round-4 kernel (head_dim 128, query heads per kv head a multiple of 4, chunks of >= 64 tokens: 8 waves x 32 queries, 32x32x16 matrix
+    instructions, scores started at minus the running maximum, row sums on the matrix pipe): group sizes 4 and 8, two sequences with different
+    contexts (page-aligned, page-crossing, empty), chunk lengths on / off the 64-query tile, permuted block table, NaN in every unmapped row."""
+    from exllamav3_amd import ext
+    hd, page, bsz = 128, 256, 2
+    rng = np.random.default_rng(hq * 1000 + q_len)
+    kv_lens = np.array([c + q_len for c in ctx], np.int32)
+    pps = int((kv_lens.max() + page - 1) // page) + 1
+    npages = bsz * pps + 1
+    bt = rng.permutation(npages)[: bsz * pps].reshape(bsz, pps).astype(np.int32)
+    k = rng.standard_normal((bsz, pps * page, hkv, hd)).astype(np.float16); v = rng.standard_normal((bsz, pps * page, hkv, hd)).astype(np.float16)
+    q = (rng.standard_normal((bsz, q_len, hq, hd)) * 1.5).astype(np.float16)
+    kp = np.full((npages, page, hkv, hd), np.nan, np.float16); vp = kp.copy()
+    for b in range(bsz):
+        for pg in range(pps):
+            kp[bt[b, pg]] = k[b, pg * page:(pg + 1) * page]; vp[bt[b, pg]] = v[b, pg * page:(pg + 1) * page]
+        if kv_lens[b] % page:
+            kp[bt[b, kv_lens[b] // page], kv_lens[b] % page:] = np.nan; vp[bt[b, kv_lens[b] // page], kv_lens[b] % page:] = np.nan
+    out = torch.full((bsz, q_len, hq, hd), float("nan"), dtype=torch.half, device=dev)
+    ext.attn_prefill_paged(_t(q, dev), out, _t(kp, dev), _t(vp, dev), _t(bt, dev), _t(kv_lens, dev))
+    ref = o.attn_prefill(q, k, v, kv_lens).astype(np.float32)
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
+
+
+def test_attn_prefill_matrix_kernel_reference_maximum_moves_late(dev):
+    """The running maximum of the round-4 kernel is a REFERENCE that moves only when a score exceeds it by 2^8 (rarely taken branches adjust the tile's
+    scores, the chains' start value and, after the tile's P V, the accumulators).  Random keys of one scale never take those branches after the first
+    tile; here the key norms grow by 10x along the sequence and single keys are aligned with the queries, so the maximum of every query jumps by far
+    more than 8 log2 units several times, in different tiles for different queries."""
+    from exllamav3_amd import ext
+    hd, hq, hkv, page, q_len, ctx = 128, 8, 2, 256, 320, 448
+    rng = np.random.default_rng(11)
+    L = ctx + q_len
+    pps = (L + page - 1) // page
+    k = rng.standard_normal((1, pps * page, hkv, hd)).astype(np.float32)
+    v = rng.standard_normal((1, pps * page, hkv, hd)).astype(np.float16)
+    q = (rng.standard_normal((1, q_len, hq, hd)) * 1.5).astype(np.float16)
+    k *= np.geomspace(0.3, 3.0, pps * page)[None, :, None, None]                      # norms grow along the sequence
+    for pos in (130, 470, 600, 700):                                                    # spikes: keys aligned with the mean query of their kv head
+        for h in range(hkv):
+            k[0, pos, h] = 4.0 * q[0, :, h * (hq // hkv)].astype(np.float32).mean(0) + k[0, pos, h]
+    k = k.astype(np.float16)
+    kv_lens = np.array([L], np.int32)
+    bt = np.arange(pps, dtype=np.int32)[None, :]
+    out = torch.full((1, q_len, hq, hd), float("nan"), dtype=torch.half, device=dev)
+    ext.attn_prefill_paged(_t(q, dev), out, _t(k.reshape(pps, page, hkv, hd), dev), _t(v.reshape(pps, page, hkv, hd), dev), _t(bt, dev), _t(kv_lens, dev))
+    ref = o.attn_prefill(q, k, v, kv_lens).astype(np.float32)
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
+
+
+def test_attn_prefill_matrix_kernel_rows_without_keys_are_zero(dev):
+    """cache_seqlens[b] < q_len on the round-4 kernel (four query heads per kv head): rows that see no key are zeros, the others the causal result."""
+    from exllamav3_amd import ext
+    hd, hq, hkv, page, q_len = 128, 8, 2, 256, 150
+    rng = np.random.default_rng(5)
+    kv_len = 100                                                             # queries 0 .. 49 sit at negative positions
+    k = rng.standard_normal((1, page, hkv, hd)).astype(np.float16); v = rng.standard_normal((1, page, hkv, hd)).astype(np.float16)
+    q = rng.standard_normal((1, q_len, hq, hd)).astype(np.float16)
+    out = torch.full((1, q_len, hq, hd), float("nan"), dtype=torch.half, device=dev)
+    bt = torch.zeros((1, 1), dtype=torch.int32, device=dev)
+    ext.attn_prefill_paged(_t(q, dev), out, _t(k, dev), _t(v, dev), bt, torch.tensor([kv_len], dtype=torch.int32, device=dev))
+    got = out.float().cpu().numpy()
+    assert np.isfinite(got).all() and not got[0, :q_len - kv_len].any()
+    ref = o.attn_prefill(q[:, q_len - kv_len:], k, v, np.array([kv_len])).astype(np.float32)
+    assert np.abs(got[:, q_len - kv_len:] - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
