@@ -697,7 +697,11 @@ extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void*
     hipStream_t st = (hipStream_t) stream;
     // head_dim 128 with four query heads per kv head: one wave per SIMD, 64 queries per wave (round 4)
     static const int w64 = [] { const char* e = getenv("EXL3_HIP_ATTN_PREFILL_W64"); return e ? atoi(e) : 1; }();
-    if (w64 && head_dim == 128 && gq % 4 == 0 && q_len >= 64)
+    // (four heads per workgroup is fixed there: below ~3/4 of a workgroup per CU the older kernel, which then takes fewer heads per workgroup, is ahead --
+    // 4096-token context + 512 new tokens: 107 vs 111 us, 1024 tokens: 32.9 vs 34.0, 2048: 79.9 vs 66.2 -- so short chunks stay with it)
+    const char* e_min = getenv("EXL3_HIP_ATTN_PREFILL_W64_MIN_WGS");                 // (read per call: the tests force either kernel on small shapes)
+    const int w64_min_wgs = e_min ? atoi(e_min) : 192;
+    if (w64 && head_dim == 128 && gq % 4 == 0 && q_len >= 64 && (int64_t) (heads_q / 4) * ((q_len + 63) / 64) * bsz >= w64_min_wgs)
     {
         dim3 gridw(heads_q / 4, (q_len + 63) / 64, bsz);
         attn_prefill_w64_kernel<<<gridw, 512, 0, st>>>(a);

@@ -18,10 +18,12 @@ def _t(a, dev):
 
 @pytest.mark.parametrize("hd,hq,hkv", [(128, 8, 2), (64, 8, 4), (128, 4, 4)])
 @pytest.mark.parametrize("q_len,ctx", [(64, [0, 0]), (100, [300, 17]), (1, [255, 256]), (257, [5, 700])])
-def test_attn_prefill_paged_matches_oracle(dev, hd, hq, hkv, q_len, ctx):
+@pytest.mark.parametrize("min_wgs", ["0", "1000000"])
+def test_attn_prefill_paged_matches_oracle(dev, monkeypatch, hd, hq, hkv, q_len, ctx, min_wgs):
     """Chunks that start an empty cache, continue a context (different lengths per sequence, page-crossing, a page-aligned one), a single
     token (== decode semantics) and a chunk that is not a multiple of the 64-query workgroup tile; permuted block table; GQA 4 / 2 / 1."""
     from exllamav3_amd import ext
+    monkeypatch.setenv("EXL3_HIP_ATTN_PREFILL_W64_MIN_WGS", min_wgs)         # the round-4 kernel wherever it applies / the round-3 kernel everywhere
     page, bsz = 256, 2
     rng = np.random.default_rng(hd + q_len)
     kv_lens = np.array([c + q_len for c in ctx], np.int32)
@@ -125,9 +127,15 @@ def test_attn_prefill_rows_without_keys_are_zero(dev):
                            torch.zeros((0,), dtype=torch.int32, device=dev))
 
 
+@pytest.fixture
+def matrix_kernel(monkeypatch):
+    """The round-4 kernel is dispatched from ~192 workgroups on (the older one fills the chip better below); these tests run it on small shapes."""
+    monkeypatch.setenv("EXL3_HIP_ATTN_PREFILL_W64_MIN_WGS", "0")
+
+
 @pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 1), (16, 4)])
 @pytest.mark.parametrize("q_len,ctx", [(64, [0, 63]), (65, [1, 256]), (200, [700, 0]), (512, [37, 1000])])
-def test_attn_prefill_matrix_kernel_shapes(dev, hq, hkv, q_len, ctx):
+def test_attn_prefill_matrix_kernel_shapes(dev, matrix_kernel, hq, hkv, q_len, ctx):
     """The round-4 kernel (head_dim 128, query heads per kv head a multiple of 4, chunks of >= 64 tokens: 8 waves x 32 queries, 32x32x16 matrix
     instructions, scores started at minus the running maximum, row sums on the matrix pipe): group sizes 4 and 8, two sequences with different
     contexts (page-aligned, page-crossing, empty), chunk lengths on / off the 64-query tile, permuted block table, NaN in every unmapped row."""
@@ -154,7 +162,7 @@ def test_attn_prefill_matrix_kernel_shapes(dev, hq, hkv, q_len, ctx):
     assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
 
 
-def test_attn_prefill_matrix_kernel_reference_maximum_moves_late(dev):
+def test_attn_prefill_matrix_kernel_reference_maximum_moves_late(dev, matrix_kernel):
     """The running maximum of the round-4 kernel is a REFERENCE that moves only when a score exceeds it by 2^8 (rarely taken branches adjust the tile's
     scores, the chains' start value and, after the tile's P V, the accumulators).  Random keys of one scale never take those branches after the first
     tile; here the key norms grow by 10x along the sequence and single keys are aligned with the queries, so the maximum of every query jumps by far
@@ -182,7 +190,7 @@ def test_attn_prefill_matrix_kernel_reference_maximum_moves_late(dev):
     assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
 
 
-def test_attn_prefill_matrix_kernel_rows_without_keys_are_zero(dev):
+def test_attn_prefill_matrix_kernel_rows_without_keys_are_zero(dev, matrix_kernel):
     """cache_seqlens[b] < q_len on the round-4 kernel (four query heads per kv head): rows that see no key are zeros, the others the causal result."""
     from exllamav3_amd import ext
     hd, hq, hkv, page, q_len = 128, 8, 2, 256, 150
