@@ -341,9 +341,13 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
     __shared__ __attribute__((aligned(1024))) half_t ring[4 * PW_TILE_HALVES + 8 * 32 * PW_QS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
     half_t* const qs = ring + 4 * PW_TILE_HALVES + wave * 32 * PW_QS;                                        // this wave's queries (later: its output rows)
-    const int qt = gridDim.y - 1 - blockIdx.y, hg = blockIdx.x, head = hg * 4 + (wave & 3), b = blockIdx.z; // longest tiles first (see the kernel above)
+    const int qt = gridDim.y - 1 - blockIdx.y, b = blockIdx.z;                                              // longest tiles first (see the kernel above)
     const int q_len = a.q_len, hq = a.hq, hkv = a.hkv, page_size = a.page_size;
-    const int kvh = (hg * 4) / (hq / hkv);
+    // blockIdx.x = (kv head, part): a kv head's query heads in groups of four; the last group of a kv head whose group size is not a multiple of 4
+    // has waves without a head -- they compute a duplicate of the last one (same barriers, same staging) and store nothing
+    const int gq = hq / hkv, parts = (gq + 3) >> 2;
+    const int kvh = (int) blockIdx.x / parts, hpart = (int) blockIdx.x - kvh * parts;
+    const int head = kvh * gq + min(4 * hpart + (wave & 3), gq - 1);
     const int kv_len = a.cache_seqlens[b];
     const int ctx = kv_len - q_len;
     const int q0 = qt * 64, q0w = q0 + 32 * (wave >> 2);                                                    // the workgroup's / this wave's first query
@@ -644,7 +648,8 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
     // spilled, across the main loop for this)
     int tid_e = tid;
     asm volatile("" : "+v"(tid_e));
-    const int lane_e = tid_e & 63, wave_e = tid_e >> 6, n_e = lane_e & 31, h_e = lane_e >> 5, head_e = hg * 4 + (wave_e & 3);
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6, n_e = lane_e & 31, h_e = lane_e >> 5, head_e = kvh * gq + 4 * hpart + (wave_e & 3);
+    const bool has_head = 4 * hpart + (wave_e & 3) < gq;
     half_t* os = ring + 4 * PW_TILE_HALVES + wave_e * 32 * PW_QS;
     #pragma unroll
     for (int i = 0; i < 16; ++i)
@@ -660,7 +665,7 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
     for (int j = 0; j < 8; ++j)
     {
         const int idx = lane_e + 64 * j, r = idx >> 4, ch = idx & 15;
-        if (q0w + r < q_len)
+        if (q0w + r < q_len && has_head)
             *((half8_t*) (a.out + (((size_t) b * q_len + q0w + r) * hq + head_e) * HD + 8 * ch)) = *((const half8_t*) (os + r * PW_QS + 8 * ch));
     }
 }
@@ -701,9 +706,14 @@ extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void*
     // 4096-token context + 512 new tokens: 107 vs 111 us, 1024 tokens: 32.9 vs 34.0, 2048: 79.9 vs 66.2 -- so short chunks stay with it)
     const char* e_min = getenv("EXL3_HIP_ATTN_PREFILL_W64_MIN_WGS");                 // (read per call: the tests force either kernel on small shapes)
     const int w64_min_wgs = e_min ? atoi(e_min) : 192;
-    if (w64 && head_dim == 128 && gq % 4 == 0 && q_len >= 64 && (int64_t) (heads_q / 4) * ((q_len + 63) / 64) * bsz >= w64_min_wgs)
+    // group sizes that fill at least 60 % of the head slots of their workgroups: 3 .. (4096 tokens, same box: 7 heads per kv head 661 vs 422 TFLOP/s on the
+    // older kernel, 3: 580 vs 418, 5: 475 vs 430; 2: 381 vs 444 and 1: 199 vs 296 stay with it)
+    const int parts = (gq + 3) / 4;
+    const char* e_fill = getenv("EXL3_HIP_ATTN_PREFILL_W64_MIN_FILL");                // (percent of head slots used; tuning / tests)
+    const int min_fill = e_fill ? atoi(e_fill) : 60;
+    if (w64 && head_dim == 128 && 100 * gq >= min_fill * 4 * parts && q_len >= 64 && (int64_t) (heads_kv * parts) * ((q_len + 63) / 64) * bsz >= w64_min_wgs)
     {
-        dim3 gridw(heads_q / 4, (q_len + 63) / 64, bsz);
+        dim3 gridw(heads_kv * parts, (q_len + 63) / 64, bsz);
         attn_prefill_w64_kernel<<<gridw, 512, 0, st>>>(a);
         return exl3_check_launch("attn_prefill_w64");
     }

@@ -133,12 +133,13 @@ def matrix_kernel(monkeypatch):
     monkeypatch.setenv("EXL3_HIP_ATTN_PREFILL_W64_MIN_WGS", "0")
 
 
-@pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 1), (16, 4)])
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 1), (16, 4), (6, 2), (12, 2), (7, 1), (14, 2), (10, 2)])
 @pytest.mark.parametrize("q_len,ctx", [(64, [0, 63]), (65, [1, 256]), (200, [700, 0]), (512, [37, 1000])])
 def test_attn_prefill_matrix_kernel_shapes(dev, matrix_kernel, hq, hkv, q_len, ctx):
-    """The round-4 kernel (head_dim 128, query heads per kv head a multiple of 4, chunks of >= 64 tokens: 8 waves x 32 queries, 32x32x16 matrix
-    instructions, scores started at minus the running maximum, row sums on the matrix pipe): group sizes 4 and 8, two sequences with different
-    contexts (page-aligned, page-crossing, empty), chunk lengths on / off the 64-query tile, permuted block table, NaN in every unmapped row."""
+    """The round-4 kernel (head_dim 128, chunks of >= 64 tokens: 8 waves x 32 queries, 32x32x16 matrix instructions, scores started at minus the
+    running maximum, row sums on the matrix pipe): group sizes 4 and 8, and 3 / 5 / 6 / 7 (the last group of four head slots of a kv head partly
+    empty: those waves duplicate a head and store nothing), two sequences with different contexts (page-aligned, page-crossing, empty), chunk
+    lengths on / off the 64-query tile, permuted block table, NaN in every unmapped row."""
     from exllamav3_amd import ext
     hd, page, bsz = 128, 256, 2
     rng = np.random.default_rng(hq * 1000 + q_len)
