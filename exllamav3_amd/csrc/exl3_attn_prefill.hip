@@ -321,9 +321,9 @@ __device__ __forceinline__ uint32_t pw_exp_pair(float a, float b)
 // instruction every ~5 cycles, i.e. at most ~5 beside each 32-cycle matrix instruction; the 64-queries-per-wave form of this kernel, one wave per
 // SIMD, was issue-bound at 9.7 VALU per matrix instruction and, once the softmax was cut down, out of registers -- hipcc spilled accumulators).
 // The softmax is written for instruction count:
-//   * the queries are pre-multiplied by scale * log2(e) (fp16) and the score accumulators START at minus the running reference maximum of their query
-//     (operand C of the first matrix instruction of a chain: a lane's 16 results all belong to one query), so a probability is ONE instruction,
-//     v_exp_f32 of the accumulator -- no multiply-subtract per score;
+//   * the queries are pre-multiplied by scale * log2(e) (fp16) and minus the running reference maximum of a lane's query enters its score chains on
+//     the matrix pipe (one extra k-step per chain: A = ones, B = { hi, lo } with hi + lo = -max; a lane's 16 results all belong to one query), so a
+//     probability is ONE instruction, v_exp_f32 of the accumulator -- no multiply-subtract per score;
 //   * the row sums come from the matrix pipe: one more 32-column block of "V" that is all ones (4 instructions per tile instead of 32 adds), and land
 //     in the accumulator layout, where the final division needs no cross-lane traffic;
 //   * the reference maximum moves only when a score exceeds it by 2^8 (probabilities stay below 2^8 in fp16); the tile's scores, the start values and

@@ -6,7 +6,7 @@ from exllamav3_amd import ext
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ctx = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-hq, hkv, hd, page = int(os.environ.get("HQ", 32)), int(os.environ.get("HKV", 8)), 128, 256      # HQ / HKV: other head counts (e.g. 28 / 4)
+hq, hkv, hd, page = int(os.environ.get("HQ", 32)), int(os.environ.get("HKV", 8)), int(os.environ.get("HD", 128)), 256      # HQ / HKV / HD: other head counts / head_dim (e.g. 28 / 4, 64)
 dev = torch.device("cuda:0")
 L = ctx + T
 pps = (L + page - 1) // page
@@ -27,4 +27,4 @@ for _ in range(n):
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / n
 flops = 4.0 * hd * hq * (ctx * T + T * (T + 1) / 2)
-print(f"attn_prefill hq={hq} hkv={hkv} T={T} ctx={ctx}: {us:.1f} us, {flops / us * 1e-6:.1f} TFLOP/s (causal flops)")
+print(f"attn_prefill hq={hq} hkv={hkv} hd={hd} T={T} ctx={ctx}: {us:.1f} us, {flops / us * 1e-6:.1f} TFLOP/s (causal flops)")
