@@ -328,19 +328,28 @@ __device__ __forceinline__ uint32_t pw_exp_pair(float a, float b)
 //     in the accumulator layout, where the final division needs no cross-lane traffic;
 //   * the reference maximum moves only when a score exceeds it by 2^8 (probabilities stay below 2^8 in fp16); the tile's scores, the start values and
 //     -- after the tile's P V is complete -- the accumulators are adjusted in rarely taken wave-uniform branches.
-#define PW_TILE_HALVES (64 * 128)
-#define PW_QS 136
+// head_dim 64 (template HD): rows of 128 B = 8 chunks; K: f(r) = (r >> 1) & 7 (two rows share a 64-bank line: row parity picks the half, the
+// position the 4-bank group), V: f(r) = ((r >> 1) & 1) << 2 (the two rows of a transpose-read group that share a bank half take different chunk
+// quads); 4 k-steps per score chain and 2 output blocks, i.e. 8 slices per phase instead of 16, two probability pairs per slice.
+template <int HD>
 __global__ __launch_bounds__(512)
 void attn_prefill_w64_kernel(const PrefillAttnArgs a)
 {
-    constexpr int HD = 128;
+    static_assert(HD == 128 || HD == 64, "head_dim 128 or 64");
+    constexpr int TILE = 64 * HD;                               // halves of one K / V tile
+    constexpr int QS = HD + 8;                                  // query / output row stride in halves (272 / 144 B: b128 reads of 16 rows tile the banks)
+    constexpr int CH = HD / 8;                                  // 16-byte chunks per row
+    constexpr int KSN = HD / 16;                                // k-steps of a score chain
+    constexpr int NB = HD / 32;                                 // 32-column output blocks
+    constexpr int NS1 = 2 * KSN, NS2 = 4 * NB;                  // slices (matrix-instruction groups) of the score / the P V phase
+    constexpr int NCH = (64 * CH) / 512;                        // staging chunks per thread and operand (2 / 1)
     // schedule knobs: fragment read-ahead (K / V in slices, Q in k-steps), the score-phase slices of the LDS writes and of the next loads.  Swept
     // (read-ahead 1 .. 5, writes at 0 .. 10, loads in either phase, static priority for waves 4-7): all inside the run-to-run spread
     // (profiles/r04_attn_prefill_ablations.txt)
-    constexpr int KD = 3, QD = 2, VD = 2, PUT_AT = 0, FETCH_AT = 5;
-    __shared__ __attribute__((aligned(1024))) half_t ring[4 * PW_TILE_HALVES + 8 * 32 * PW_QS];
+    constexpr int KD = 3, QD = 2, VD = 2, PUT_AT = 0, FETCH_AT = HD == 128 ? 5 : 3;
+    __shared__ __attribute__((aligned(1024))) half_t ring[4 * TILE + 8 * 32 * QS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, h = lane >> 5;
-    half_t* const qs = ring + 4 * PW_TILE_HALVES + wave * 32 * PW_QS;                                        // this wave's queries (later: its output rows)
+    half_t* const qs = ring + 4 * TILE + wave * 32 * QS;                                                    // this wave's queries (later: its output rows)
     const int qt = gridDim.y - 1 - blockIdx.y, b = blockIdx.z;                                              // longest tiles first (see the kernel above)
     const int q_len = a.q_len, hq = a.hq, hkv = a.hkv, page_size = a.page_size;
     // blockIdx.x = (kv head, part): a kv head's query heads in groups of four; the last group of a kv head whose group size is not a multiple of 4
@@ -356,20 +365,20 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
     const int q_last = min(q0 + 64, q_len) - 1;
     const int ntiles = (ctx + q_last) / 64 + 1;
 
-    // ---- staging: 64 keys x 256 B = 1024 16-byte chunks per tile and operand, 2 per thread; HBM -> registers one iteration before the LDS write
-    const int row_halves = hkv * HD;                                                                        // (64 rows x hkv x 128 halves: far inside 32 bits)
+    // chunk swizzles of the K / V tiles (see above)
+    auto kswz = [&](int r) __attribute__((always_inline)) { return HD == 128 ? (r & 15) : ((r >> 1) & 7); };
+    auto vswz = [&](int r) __attribute__((always_inline)) { return HD == 128 ? (((r & 3) << 2) | ((r >> 2) & 3)) : (((r >> 1) & 1) << 2); };
+
+    // ---- staging: 64 keys x CH 16-byte chunks per tile and operand, NCH per thread; HBM -> registers one iteration before the LDS write
+    const int row_halves = hkv * HD;                                                                        // (64 rows x hkv x HD halves: far inside 32 bits)
     // LDS offsets (halves) of chunk j of this thread: recomputed where they are used (two VALU each) rather than held in registers
     // (tid_o: the thread index behind an empty asm, refreshed per iteration -- otherwise the loop-invariant offsets are hoisted back into registers)
     int tid_o = tid;
-    auto kdst = [&](int j) __attribute__((always_inline)) { const int idx = tid_o + 512 * j, key = idx >> 4, ch = idx & 15; return key * 128 + ((ch ^ (key & 15)) * 8); };
-    auto vdst = [&](int j) __attribute__((always_inline))
-    {
-        const int idx = tid_o + 512 * j, key = idx >> 4, ch = idx & 15;
-        return key * 128 + ((ch ^ (((key & 3) << 2) | ((key >> 2) & 3))) * 8);
-    };
+    auto kdst = [&](int j) __attribute__((always_inline)) { const int idx = tid_o + 512 * j, key = idx / CH, ch = idx % CH; return key * HD + ((ch ^ kswz(key)) * 8); };
+    auto vdst = [&](int j) __attribute__((always_inline)) { const int idx = tid_o + 512 * j, key = idx / CH, ch = idx % CH; return key * HD + ((ch ^ vswz(key)) * 8); };
     // ONE register set: what iteration t fetches (early in its score phase) is written to LDS early in iteration t + 1.  (A second set -- written two
     // iterations later -- measured the same: the loads cost their instructions, not their latency.)
-    half8_t kreg[1][2], vreg[1][2];
+    half8_t kreg[NCH], vreg[NCH];
     // Where a tile lives: (tile, page index, first key's offset inside the page), advanced by 64 keys per step without divisions (page_size is a run-time
     // value: every / and % was a ~30-instruction scalar sequence, three per iteration) and clamped at the last tile.  The page id itself (a scalar load
     // from the block table) is read one iteration before the fetch that uses it.
@@ -379,54 +388,54 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
         if (p.tile < ntiles - 1) { ++p.tile; p.off += 64; if (p.off >= page_size) { p.off = 0; ++p.pidx; } }
     };
     auto page_id_of = [&](const TilePos& p) __attribute__((always_inline)) { return bt[min(p.pidx, a.blocks_per_seq - 1)]; };
-    auto fetch = [&](const TilePos& p, int32_t page_id, half8_t (&reg)[2], const half_t* pages) __attribute__((always_inline))
+    auto fetch = [&](const TilePos& p, int32_t page_id, half8_t (&reg)[NCH], const half_t* pages) __attribute__((always_inline))
     {
         // keys beyond the sequence are clamped (duplicate rows: finite values; their scores are masked)
         const half_t* base = pages + ((size_t) page_id * page_size + p.off) * (size_t) row_halves + (size_t) kvh * HD;      // wave-uniform
         const int kmax = kv_len - 1 - p.tile * 64;
         #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NCH; ++j)
         {
             const int idx = tid + 512 * j;
-            reg[j] = *((const half8_t*) (base + __umul24(min(idx >> 4, kmax), row_halves) + (idx & 15) * 8));      // (no branch: this sits between matrix instructions)
+            reg[j] = *((const half8_t*) (base + __umul24(min(idx / CH, kmax), row_halves) + (idx % CH) * 8));      // (no branch: this sits between matrix instructions)
         }
     };
-    auto putk = [&](int j, const half8_t (&reg)[2], half_t* slot) __attribute__((always_inline)) { *((half8_t*) (slot + kdst(j))) = reg[j]; };
-    auto putv = [&](int j, const half8_t (&reg)[2], half_t* slot) __attribute__((always_inline)) { *((half8_t*) (slot + vdst(j))) = reg[j]; };
-    auto Kslot = [&](int i) __attribute__((always_inline)) { return ring + (i & 1) * PW_TILE_HALVES; };
-    auto Vslot = [&](int i) __attribute__((always_inline)) { return ring + (2 + (i & 1)) * PW_TILE_HALVES; };
+    auto putk = [&](int j, const half8_t (&reg)[NCH], half_t* slot) __attribute__((always_inline)) { *((half8_t*) (slot + kdst(j))) = reg[j]; };
+    auto putv = [&](int j, const half8_t (&reg)[NCH], half_t* slot) __attribute__((always_inline)) { *((half8_t*) (slot + vdst(j))) = reg[j]; };
+    auto Kslot = [&](int i) __attribute__((always_inline)) { return ring + (i & 1) * TILE; };
+    auto Vslot = [&](int i) __attribute__((always_inline)) { return ring + (2 + (i & 1)) * TILE; };
 
     // ---- queries: global -> x scale log2(e) -> this wave's LDS rows (B operands of S^T are read per k-step: query n, dims 16 ks + 8 h ..)
     const int qpos = ctx + min(q0w + n, q_len - 1);
     #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < (32 * CH) / 64; ++j)
     {
-        const int idx = lane + 64 * j, r = idx >> 4, ch = idx & 15;
+        const int idx = lane + 64 * j, r = idx / CH, ch = idx % CH;
         const int qi = min(q0w + r, q_len - 1);
         half8_t v = *((const half8_t*) (a.q + ((size_t) b * q_len + qi) * a.ldq + (size_t) head * HD + 8 * ch));
         #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (half_t) ((float) v[e] * sl);
-        *((half8_t*) (qs + r * PW_QS + 8 * ch)) = v;
+        *((half8_t*) (qs + r * QS + 8 * ch)) = v;
     }
-    // ---- per-lane fragment addresses (halves from the slot / the wave's query rows): everything that depends on the slice is an immediate offset
+    // ---- per-lane fragment addresses: everything that depends on the slice is an immediate offset
     // (kept as LDS POINTERS into slot 0 of each ring: the slot of an iteration is a compile-time constant of its unrolled copy, so slot, key block
     // and k-step all go into the read's immediate offset and a fragment read costs no address arithmetic)
-    const half_t* kl[8]; const half_t* vl0[4]; const half_t* vl1[4];
+    const half_t* kl[KSN]; const half_t* vl0[NB]; const half_t* vl1[NB];
     #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) kl[ks] = ring + n * 128 + (((2 * ks + h) ^ (n & 15)) * 8);              // key block kb: + 32 * 128
+    for (int ks = 0; ks < KSN; ++ks) kl[ks] = ring + n * HD + (((2 * ks + h) ^ kswz(n)) * 8);               // key block kb: + 32 * HD (32 rows: the swizzle repeats)
     {
         const int G = lane >> 4, c = lane & 15;
-        const int rl = 4 * (G >> 1) + (c >> 2), fh = (c >> 2) & 3, fl = G >> 1, L = 2 * (G & 1) + ((c & 3) >> 1);
+        const int rl = 4 * (G >> 1) + (c >> 2), L = 2 * (G & 1) + ((c & 3) >> 1);                           // (rows rl and rl + 8 of a k-step; 16 rows further: the same swizzle)
         #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
         {
-            vl0[nb] = ring + 2 * PW_TILE_HALVES + rl * 128 + ((((nb ^ fh) << 2) | (L ^ fl)) * 8) + 4 * (c & 1);      // k-step kst: + 16 * kst * 128
-            vl1[nb] = ring + 2 * PW_TILE_HALVES + (rl + 8) * 128 + ((((nb ^ fh) << 2) | (L ^ (fl | 2))) * 8) + 4 * (c & 1);
+            vl0[nb] = ring + 2 * TILE + rl * HD + (((4 * nb + L) ^ vswz(rl)) * 8) + 4 * (c & 1);            // k-step kst: + 16 * kst * HD
+            vl1[nb] = ring + 2 * TILE + (rl + 8) * HD + (((4 * nb + L) ^ vswz(rl + 8)) * 8) + 4 * (c & 1);
         }
     }
-    const half_t* const ql = qs + n * PW_QS + 8 * h;                                                        // k-step ks: + 16
+    const half_t* const ql = qs + n * QS + 8 * h;                                                           // k-step ks: + 16
 
-    f32x16_t oc[4], lacc;                                       // O, the row sums (ones column)
+    f32x16_t oc[NB], lacc;                                      // O, the row sums (ones column)
     // minus the reference maximum of the lane's query enters every score chain through ONE extra k-step: A = all ones, B = { hi, lo, 0 ... } in the
     // lanes of the first k half (hi + lo = -max as two fp16; products with 1.0 and the fp32 accumulation are exact) -- 4 registers instead of a
     // 16-register start value for operand C
@@ -440,7 +449,7 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
     #pragma unroll
     for (int i = 0; i < 16; ++i) lacc[i] = 0.0f;
     #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
         #pragma unroll
         for (int i = 0; i < 16; ++i) oc[nb][i] = 0.0f;
     const half8_t ones = { (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f, (half_t) 1.0f };
@@ -461,25 +470,25 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
                 if (!(key <= qpos && key < kv_len)) S[kb][i] = -1.0e30f;
             }
     };
-    auto k_frag = [&](int s, int slot) __attribute__((always_inline)) { return *((const half8_t*) (kl[s >> 1] + slot * PW_TILE_HALVES + (s & 1) * 32 * 128)); };
+    // slice s of the score phase: k-step ks = s >> 1 of key block kb = s & 1; slice s of the P V phase: k-step kst = s / NB, output block nb = s % NB
+    auto k_frag = [&](int s, int slot) __attribute__((always_inline)) { return *((const half8_t*) (kl[s >> 1] + slot * TILE + (s & 1) * 32 * HD)); };
     auto q_frag = [&](int ks) __attribute__((always_inline)) { return *((const half8_t*) (ql + 16 * ks)); };
     auto v_frag = [&](int s, int slot) __attribute__((always_inline))
     {
-        const int kst = s >> 2, nb = s & 3;                     // k-step (kb, bp) = (kst >> 1, kst & 1): keys 32 kb + 16 bp + 8 e + 4 h + j
-        const half4_t v0 = lds_read_tr16(vl0[nb] + slot * PW_TILE_HALVES + kst * 16 * 128), v1 = lds_read_tr16(vl1[nb] + slot * PW_TILE_HALVES + kst * 16 * 128);
+        const int kst = s / NB, nb = s % NB;                    // k-step (kb, bp) = (kst >> 1, kst & 1): keys 32 kb + 16 bp + 8 e + 4 h + j
+        const half4_t v0 = lds_read_tr16(vl0[nb] + slot * TILE + kst * 16 * HD), v1 = lds_read_tr16(vl1[nb] + slot * TILE + kst * 16 * HD);
         return half8_t{ v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
     };
-    // slice s of a score phase: k-step ks = s >> 1 of key block kb = s & 1; a chain's first instruction starts from -max of the lane's query
     auto qk_mfma = [&](int s, half8_t ka, half8_t qf, f32x16_t (&S)[2]) __attribute__((always_inline))
     {
         const f32x16_t zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
         S[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf, s < 2 ? zero : S[s & 1], 0, 0, 0);
-        if (s >= 14) S[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, negm, S[s & 1], 0, 0, 0);     // ... - max, once per chain
+        if (s >= NS1 - 2) S[s & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, negm, S[s & 1], 0, 0, 0);  // ... - max, once per chain
     };
-    // slice s of a P V phase: k-step kst = s >> 2, output block nb = s & 3; the ones column rides with nb == 0
+    // the ones column rides with nb == 0
     auto pv_mfma = [&](int s, half8_t vB, const uint32_t (&pa)[16]) __attribute__((always_inline))
     {
-        const int kst = s >> 2, nb = s & 3;
+        const int kst = s / NB, nb = s % NB;
         union { uint32_t u[4]; half8_t h8; } p;
         #pragma unroll
         for (int i = 0; i < 4; ++i) p.u[i] = pa[4 * kst + i];
@@ -514,7 +523,7 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
         {
             const float cr = __shfl(corr, 8 * (i >> 2) + 4 * h + (i & 3), 64);                 // row (query) of accumulator element i
             #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) oc[nb][i] *= cr;
+            for (int nb = 0; nb < NB; ++nb) oc[nb][i] *= cr;
             lacc[i] *= cr;
         }
     };
@@ -527,19 +536,18 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
         TilePos p1 = pk; advance(p1);
         TilePos p2 = p1; advance(p2);
         TilePos p3 = p2; advance(p3);
-        TilePos p4 = p3; advance(p4);
-        const int32_t g0 = page_id_of(pk), g1 = page_id_of(p1), g2 = page_id_of(p2), g3 = page_id_of(p3), g4 = page_id_of(p4);
-        half8_t k1reg[2];
-        fetch(pk, g0, kreg[0], a.k_pages); fetch(pk, g0, vreg[0], a.v_pages); fetch(p1, g1, k1reg, a.k_pages);       // K_0, V_0, K_1
-        putk(0, kreg[0], Kslot(0)); putk(1, kreg[0], Kslot(0)); putv(0, vreg[0], Vslot(0)); putv(1, vreg[0], Vslot(0));
-        putk(0, k1reg, Kslot(1)); putk(1, k1reg, Kslot(1));
-        fetch(p2, g2, kreg[0], a.k_pages); fetch(p1, g1, vreg[0], a.v_pages);                               // written in iteration 0: K_2, V_1
-        pv = p2; pk = p3; pg_v = g2; pg_k = g3; (void) g4;                                                  // iteration 0 fetches V_2 and K_3
+        const int32_t g0 = page_id_of(pk), g1 = page_id_of(p1), g2 = page_id_of(p2), g3 = page_id_of(p3);
+        half8_t k1reg[NCH];
+        fetch(pk, g0, kreg, a.k_pages); fetch(pk, g0, vreg, a.v_pages); fetch(p1, g1, k1reg, a.k_pages);     // K_0, V_0, K_1
+        #pragma unroll
+        for (int j = 0; j < NCH; ++j) { putk(j, kreg, Kslot(0)); putv(j, vreg, Vslot(0)); putk(j, k1reg, Kslot(1)); }
+        fetch(p2, g2, kreg, a.k_pages); fetch(p1, g1, vreg, a.v_pages);                                     // written in iteration 0: K_2, V_1
+        pv = p2; pk = p3; pg_v = g2; pg_k = g3;                                                             // iteration 0 fetches V_2 and K_3
     }
     __syncthreads();
     f32x16_t S[2];                                              // [key block]
     #pragma unroll
-    for (int s = 0; s < 16; ++s) qk_mfma(s, k_frag(s, 0), q_frag(s >> 1), S);                              // (negm = 0: true scores)
+    for (int s = 0; s < NS1; ++s) qk_mfma(s, k_frag(s, 0), q_frag(s >> 1), S);                             // (negm = 0: true scores)
     mask_tile(0, S);
     {
         float mx = pw_rowmax(S[0], S[1]);
@@ -559,14 +567,12 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
     {
         constexpr bool MORE = decltype(more_c)::value;
         constexpr int SET = decltype(set_c)::value;             // = t & 1: the ring slots and the probability arrays of this unrolled copy
-        constexpr int RS = 0;                                   // staging register set
         tid_o = tid; asm volatile("" : "+v"(tid_o));
         __syncthreads();
         constexpr int kbuf = 1 - SET, vbuf = SET;               // ring slots of K_{t+1} and V_t
-        // fragments are read from LDS TWO slices before their use
-        half8_t kf[16], qfr[8], vf[16];
         // fragment reads run KD / QD / VD slices ahead of their use: a score slice is ONE matrix instruction (32 cycles) and an LDS read under
-        // eight waves' traffic takes well over 100 -- one slice ahead, the wait for the fragment was the longest thing in the loop
+        // eight waves' traffic takes well over 100
+        half8_t kf[NS1], qfr[KSN], vf[NS2];
         if constexpr (MORE)
         {
             #pragma unroll
@@ -584,22 +590,20 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
         if constexpr (MORE)
         {
             #pragma unroll
-            for (int s = 0; s < 16; ++s)
+            for (int s = 0; s < NS1; ++s)
             {
-                if (s + KD < 16) kf[s + KD] = k_frag(s + KD, kbuf);
-                if (!(s & 1) && (s >> 1) + QD < 8) qfr[(s >> 1) + QD] = q_frag((s >> 1) + QD);
-                if (s >= 16 - VD) vf[s - (16 - VD)] = v_frag(s - (16 - VD), vbuf);
+                if (s + KD < NS1) kf[s + KD] = k_frag(s + KD, kbuf);
+                if (!(s & 1) && (s >> 1) + QD < KSN) qfr[(s >> 1) + QD] = q_frag((s >> 1) + QD);
+                if (s >= NS1 - VD) vf[s - (NS1 - VD)] = v_frag(s - (NS1 - VD), vbuf);
                 qk_mfma(s, kf[s], qfr[s >> 1], S);
                 // the staging traffic rides between the matrix instructions (all eight waves doing it together after the barrier left the pipe idle):
                 // the LDS writes of K_{t+2} / V_{t+1} (in registers since the previous iteration) first, then the loads of K_{t+3} / V_{t+2}
-                if (s == PUT_AT) putk(0, kreg[RS], Kslot(t));
-                if (s == PUT_AT + 1) putk(1, kreg[RS], Kslot(t));
-                if (s == PUT_AT + 2) putv(0, vreg[RS], Vslot(t + 1));
-                if (s == PUT_AT + 3) putv(1, vreg[RS], Vslot(t + 1));
-                if (s == FETCH_AT) fetch(pk, pg_k, kreg[RS], a.k_pages);
+                if (s >= PUT_AT && s < PUT_AT + NCH) putk(s - PUT_AT, kreg, Kslot(t));
+                if (s >= PUT_AT + NCH && s < PUT_AT + 2 * NCH) putv(s - PUT_AT - NCH, vreg, Vslot(t + 1));
+                if (s == FETCH_AT) fetch(pk, pg_k, kreg, a.k_pages);
                 if (s == FETCH_AT + 1)
                 {
-                    fetch(pv, pg_v, vreg[RS], a.v_pages); pv = pk; pg_v = pg_k; advance(pk);
+                    fetch(pv, pg_v, vreg, a.v_pages); pv = pk; pg_v = pg_k; advance(pk);
                     // the block-table entry of the NEXT iteration's K fetch.  (After the first barrier hipcc no longer proves the table unwritten and
                     // reads it with a vector load; asked for here and consumed at the end of the iteration, nobody waits for it.)
                     pg_next = page_id_of(pk);
@@ -608,22 +612,23 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
             }
             mask_tile(t + 1, S);
         }
-        // ---- phase 2: O += P_t V_t (and the row sums) beside the maximum and the probabilities of tile t + 1 (slice 0: maximum, slice s: pair s - 1,
-        // slice 15: pairs 14 and 15)
+        // ---- phase 2: O += P_t V_t (and the row sums) beside the maximum and the probabilities of tile t + 1: slice 0 the maximum, slices
+        // 1 .. NS2 - 1 the pairs, 16 / NS2 each, the last slice also the rest
         uint32_t (&pa)[16] = pab[SET];
         uint32_t (&pn)[16] = pab[1 - SET];
+        constexpr int PPS = 16 / NS2;
         #pragma unroll
-        for (int s = 0; s < 16; ++s)
+        for (int s = 0; s < NS2; ++s)
         {
-            if (s + VD < 16) vf[s + VD] = v_frag(s + VD, vbuf);
+            if (s + VD < NS2) vf[s + VD] = v_frag(s + VD, vbuf);
             pv_mfma(s, vf[s], pa);
             if constexpr (MORE)
             {
                 if (s == 0) adjust(S, pw_rowmax(S[0], S[1]));
                 else
                 {
-                    pn[s - 1] = exp_pair(s - 1, S);
-                    if (s == 15) pn[15] = exp_pair(15, S);
+                    #pragma unroll
+                    for (int p = (s - 1) * PPS; p < (s == NS2 - 1 ? 16 : s * PPS); ++p) pn[p] = exp_pair(p, S);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -650,23 +655,23 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
     asm volatile("" : "+v"(tid_e));
     const int lane_e = tid_e & 63, wave_e = tid_e >> 6, n_e = lane_e & 31, h_e = lane_e >> 5, head_e = kvh * gq + 4 * hpart + (wave_e & 3);
     const bool has_head = 4 * hpart + (wave_e & 3) < gq;
-    half_t* os = ring + 4 * PW_TILE_HALVES + wave_e * 32 * PW_QS;
+    half_t* os = ring + 4 * TILE + wave_e * 32 * QS;
     #pragma unroll
     for (int i = 0; i < 16; ++i)
     {
         const int r = 8 * (i >> 2) + 4 * h_e + (i & 3);
         const float li = lacc[i] > 0.0f ? 1.0f / lacc[i] : 0.0f;                             // (a query without any visible key: zeros, as the kernel above)
         #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) os[r * PW_QS + 32 * nb + n_e] = (half_t) (oc[nb][i] * li);
+        for (int nb = 0; nb < NB; ++nb) os[r * QS + 32 * nb + n_e] = (half_t) (oc[nb][i] * li);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < (32 * CH) / 64; ++j)
     {
-        const int idx = lane_e + 64 * j, r = idx >> 4, ch = idx & 15;
+        const int idx = lane_e + 64 * j, r = idx / CH, ch = idx % CH;
         if (q0w + r < q_len && has_head)
-            *((half8_t*) (a.out + (((size_t) b * q_len + q0w + r) * hq + head_e) * HD + 8 * ch)) = *((const half8_t*) (os + r * PW_QS + 8 * ch));
+            *((half8_t*) (a.out + (((size_t) b * q_len + q0w + r) * hq + head_e) * HD + 8 * ch)) = *((const half8_t*) (os + r * QS + 8 * ch));
     }
 }
 
@@ -711,10 +716,10 @@ extern "C" int exl3_attn_prefill_paged_strided(const void* q, int64_t ldq, void*
     const int parts = (gq + 3) / 4;
     const char* e_fill = getenv("EXL3_HIP_ATTN_PREFILL_W64_MIN_FILL");                // (percent of head slots used; tuning / tests)
     const int min_fill = e_fill ? atoi(e_fill) : 60;
-    if (w64 && head_dim == 128 && 100 * gq >= min_fill * 4 * parts && q_len >= 64 && (int64_t) (heads_kv * parts) * ((q_len + 63) / 64) * bsz >= w64_min_wgs)
+    if (w64 && 100 * gq >= min_fill * 4 * parts && q_len >= 64 && (int64_t) (heads_kv * parts) * ((q_len + 63) / 64) * bsz >= w64_min_wgs)
     {
         dim3 gridw(heads_kv * parts, (q_len + 63) / 64, bsz);
-        attn_prefill_w64_kernel<<<gridw, 512, 0, st>>>(a);
+        if (head_dim == 128) attn_prefill_w64_kernel<128><<<gridw, 512, 0, st>>>(a); else attn_prefill_w64_kernel<64><<<gridw, 512, 0, st>>>(a);
         return exl3_check_launch("attn_prefill_w64");
     }
     int gw = gq % 4 == 0 ? 4 : (gq % 2 == 0 ? 2 : 1);                                // query heads per workgroup (they share a kv head) ...

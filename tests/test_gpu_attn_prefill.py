@@ -133,16 +133,17 @@ def matrix_kernel(monkeypatch):
     monkeypatch.setenv("EXL3_HIP_ATTN_PREFILL_W64_MIN_WGS", "0")
 
 
-@pytest.mark.parametrize("hq,hkv", [(8, 2), (8, 1), (16, 4), (6, 2), (12, 2), (7, 1), (14, 2), (10, 2)])
+@pytest.mark.parametrize("hd,hq,hkv", [(128, 8, 2), (128, 8, 1), (128, 16, 4), (128, 6, 2), (128, 12, 2), (128, 7, 1), (128, 14, 2), (128, 10, 2),
+                                       (64, 8, 2), (64, 32, 8), (64, 6, 2), (64, 7, 1)])
 @pytest.mark.parametrize("q_len,ctx", [(64, [0, 63]), (65, [1, 256]), (200, [700, 0]), (512, [37, 1000])])
-def test_attn_prefill_matrix_kernel_shapes(dev, matrix_kernel, hq, hkv, q_len, ctx):
-    """The round-4 kernel (head_dim 128, chunks of >= 64 tokens: 8 waves x 32 queries, 32x32x16 matrix instructions, scores started at minus the
+def test_attn_prefill_matrix_kernel_shapes(dev, matrix_kernel, hd, hq, hkv, q_len, ctx):
+    """The round-4 kernel (head_dim 128 and 64, chunks of >= 64 tokens: 8 waves x 32 queries, 32x32x16 matrix instructions, scores started at minus the
     running maximum, row sums on the matrix pipe): group sizes 4 and 8, and 3 / 5 / 6 / 7 (the last group of four head slots of a kv head partly
     empty: those waves duplicate a head and store nothing), two sequences with different contexts (page-aligned, page-crossing, empty), chunk
     lengths on / off the 64-query tile, permuted block table, NaN in every unmapped row."""
     from exllamav3_amd import ext
-    hd, page, bsz = 128, 256, 2
-    rng = np.random.default_rng(hq * 1000 + q_len)
+    page, bsz = 256, 2
+    rng = np.random.default_rng(hq * 1000 + q_len + hd)
     kv_lens = np.array([c + q_len for c in ctx], np.int32)
     pps = int((kv_lens.max() + page - 1) // page) + 1
     npages = bsz * pps + 1
@@ -163,14 +164,15 @@ def test_attn_prefill_matrix_kernel_shapes(dev, matrix_kernel, hq, hkv, q_len, c
     assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
 
 
-def test_attn_prefill_matrix_kernel_reference_maximum_moves_late(dev, matrix_kernel):
+@pytest.mark.parametrize("hd", [128, 64])
+def test_attn_prefill_matrix_kernel_reference_maximum_moves_late(dev, matrix_kernel, hd):
     """The running maximum of the round-4 kernel is a REFERENCE that moves only when a score exceeds it by 2^8 (rarely taken branches adjust the tile's
     scores, the chains' start value and, after the tile's P V, the accumulators).  Random keys of one scale never take those branches after the first
     tile; here the key norms grow by 10x along the sequence and single keys are aligned with the queries, so the maximum of every query jumps by far
     more than 8 log2 units several times, in different tiles for different queries."""
     from exllamav3_amd import ext
-    hd, hq, hkv, page, q_len, ctx = 128, 8, 2, 256, 320, 448
-    rng = np.random.default_rng(11)
+    hq, hkv, page, q_len, ctx = 8, 2, 256, 320, 448
+    rng = np.random.default_rng(11 + hd)
     L = ctx + q_len
     pps = (L + page - 1) // page
     k = rng.standard_normal((1, pps * page, hkv, hd)).astype(np.float32)
