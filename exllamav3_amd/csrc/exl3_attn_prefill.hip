@@ -273,8 +273,10 @@ void attn_prefill_kernel(const PrefillAttnArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------------------
-// Round 4 (head_dim 128, four query heads per kv head): v_mfma_f32_32x32x16_f16, an exponent-only softmax, one barrier per 64-key tile.
-// A workgroup = 8 waves = the four query heads of a kv head x the two 32-query blocks of 64 consecutive queries; a wave owns one head's 32 queries:
+// Round 4 (head_dim 128 and 64; three or more query heads per kv head; chunks that give ~192 workgroups or more): v_mfma_f32_32x32x16_f16, an
+// exponent-only softmax, one barrier per 64-key tile.
+// A workgroup = 8 waves = four query heads of a kv head x the two 32-query blocks of 64 consecutive queries; a wave owns one head's 32 queries
+// (described for head_dim 128; 64 halves the k-steps and the output blocks):
 //   * S^T = K Q^T in 32 x 32 blocks (kb: keys): A = K rows from LDS (ds_read_b128, lane (key l % 32, dims 16 ks + 8 (l / 32) ..)), B = the wave's Q rows
 //     (LDS, pre-scaled); a lane ends with column (query) l % 32 and rows (keys) 32 kb + 8 (i / 4) + 4 (l / 32) + i % 4, i = 0 .. 15;
 //   * those 16 values are, eight at a time, an A operand of O = P V if contraction slot 8 h + 4 e + j of k-step (kb, bp) is DEFINED as key
