@@ -384,16 +384,26 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
     // Where a tile lives: (tile, page index, first key's offset inside the page), advanced by 64 keys per step without divisions (page_size is a run-time
     // value: every / and % was a ~30-instruction scalar sequence, three per iteration) and clamped at the last tile.  The page id itself (a scalar load
     // from the block table) is read one iteration before the fetch that uses it.
-    struct TilePos { int tile, pidx, off; };
+    // `base` = element offset of the tile's first row of this kv head in the page array: + 64 rows per step inside a page (two scalar adds; the
+    // 64-bit multiplies of a from-scratch address were ~12 scalar instructions per fetch), rebuilt from the page id when a new page begins
+    struct TilePos { int tile, pidx, off; int64_t base; bool newpage; };
+    auto set_base = [&](TilePos& p, int32_t page_id) __attribute__((always_inline))
+    {
+        p.base = ((int64_t) page_id * page_size + p.off) * (int64_t) row_halves + (int64_t) kvh * HD; p.newpage = false;
+    };
     auto advance = [&](TilePos& p) __attribute__((always_inline))
     {
-        if (p.tile < ntiles - 1) { ++p.tile; p.off += 64; if (p.off >= page_size) { p.off = 0; ++p.pidx; } }
+        if (p.tile < ntiles - 1)
+        {
+            ++p.tile; p.off += 64; p.base += (int64_t) 64 * row_halves;
+            if (p.off >= page_size) { p.off = 0; ++p.pidx; p.newpage = true; }
+        }
     };
     auto page_id_of = [&](const TilePos& p) __attribute__((always_inline)) { return bt[min(p.pidx, a.blocks_per_seq - 1)]; };
-    auto fetch = [&](const TilePos& p, int32_t page_id, half8_t (&reg)[NCH], const half_t* pages) __attribute__((always_inline))
+    auto fetch = [&](const TilePos& p, half8_t (&reg)[NCH], const half_t* pages) __attribute__((always_inline))
     {
         // keys beyond the sequence are clamped (duplicate rows: finite values; their scores are masked)
-        const half_t* base = pages + ((size_t) page_id * page_size + p.off) * (size_t) row_halves + (size_t) kvh * HD;      // wave-uniform
+        const half_t* base = pages + p.base;                                                                // wave-uniform
         const int kmax = kv_len - 1 - p.tile * 64;
         #pragma unroll
         for (int j = 0; j < NCH; ++j)
@@ -531,20 +541,21 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
     };
 
     // ---- prologue: K_0, K_1, V_0 in LDS, K_2 and V_1 on their way; S_0 with its own maxima as the first reference
-    TilePos pk = { 0, 0, 0 }, pv;                               // (the fetch positions of K and V: K runs one tile ahead)
-    int32_t pg_v, pg_k, pg_next = 0;
+    TilePos pk = { 0, 0, 0, 0, false }, pv;                     // (the fetch positions of K and V: K runs one tile ahead)
+    int32_t pg_next = 0;
     {
         // all block-table entries first, then K_0, V_0, K_1 in flight together (one HBM latency, not three)
         TilePos p1 = pk; advance(p1);
         TilePos p2 = p1; advance(p2);
         TilePos p3 = p2; advance(p3);
         const int32_t g0 = page_id_of(pk), g1 = page_id_of(p1), g2 = page_id_of(p2), g3 = page_id_of(p3);
+        set_base(pk, g0); set_base(p1, g1); set_base(p2, g2); set_base(p3, g3);
         half8_t k1reg[NCH];
-        fetch(pk, g0, kreg, a.k_pages); fetch(pk, g0, vreg, a.v_pages); fetch(p1, g1, k1reg, a.k_pages);     // K_0, V_0, K_1
+        fetch(pk, kreg, a.k_pages); fetch(pk, vreg, a.v_pages); fetch(p1, k1reg, a.k_pages);               // K_0, V_0, K_1
         #pragma unroll
         for (int j = 0; j < NCH; ++j) { putk(j, kreg, Kslot(0)); putv(j, vreg, Vslot(0)); putk(j, k1reg, Kslot(1)); }
-        fetch(p2, g2, kreg, a.k_pages); fetch(p1, g1, vreg, a.v_pages);                                     // written in iteration 0: K_2, V_1
-        pv = p2; pk = p3; pg_v = g2; pg_k = g3;                                                             // iteration 0 fetches V_2 and K_3
+        fetch(p2, kreg, a.k_pages); fetch(p1, vreg, a.v_pages);                                             // written in iteration 0: K_2, V_1
+        pv = p2; pk = p3;                                                                                   // iteration 0 fetches V_2 and K_3
     }
     __syncthreads();
     f32x16_t S[2];                                              // [key block]
@@ -602,10 +613,10 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
                 // the LDS writes of K_{t+2} / V_{t+1} (in registers since the previous iteration) first, then the loads of K_{t+3} / V_{t+2}
                 if (s >= PUT_AT && s < PUT_AT + NCH) putk(s - PUT_AT, kreg, Kslot(t));
                 if (s >= PUT_AT + NCH && s < PUT_AT + 2 * NCH) putv(s - PUT_AT - NCH, vreg, Vslot(t + 1));
-                if (s == FETCH_AT) fetch(pk, pg_k, kreg, a.k_pages);
+                if (s == FETCH_AT) fetch(pk, kreg, a.k_pages);
                 if (s == FETCH_AT + 1)
                 {
-                    fetch(pv, pg_v, vreg, a.v_pages); pv = pk; pg_v = pg_k; advance(pk);
+                    fetch(pv, vreg, a.v_pages); pv = pk; advance(pk);
                     // the block-table entry of the NEXT iteration's K fetch.  (After the first barrier hipcc no longer proves the table unwritten and
                     // reads it with a vector load; asked for here and consumed at the end of the iteration, nobody waits for it.)
                     pg_next = page_id_of(pk);
@@ -638,7 +649,7 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
         if constexpr (MORE)
         {
             rescale();
-            pg_k = __builtin_amdgcn_readfirstlane(pg_next);
+            if (pk.newpage) set_base(pk, __builtin_amdgcn_readfirstlane(pg_next));           // (wave-uniform, once per page)
         }
     };
     {
