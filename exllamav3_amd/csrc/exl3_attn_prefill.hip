@@ -400,16 +400,28 @@ void attn_prefill_w64_kernel(const PrefillAttnArgs a)
         }
     };
     auto page_id_of = [&](const TilePos& p) __attribute__((always_inline)) { return bt[min(p.pidx, a.blocks_per_seq - 1)]; };
+    // this thread's chunks of a tile as BYTE offsets from the tile's first row: scalar base + 32-bit lane offset is one load instruction without address
+    // arithmetic; only the sequence's last tile (keys beyond the length clamped to the last one: finite duplicates, their scores are masked) recomputes them
+    uint32_t goffb[NCH];
+    #pragma unroll
+    for (int j = 0; j < NCH; ++j) { const int idx = tid + 512 * j; goffb[j] = (uint32_t) ((idx / CH) * row_halves + (idx % CH) * 8) * 2u; }
     auto fetch = [&](const TilePos& p, half8_t (&reg)[NCH], const half_t* pages) __attribute__((always_inline))
     {
-        // keys beyond the sequence are clamped (duplicate rows: finite values; their scores are masked)
-        const half_t* base = pages + p.base;                                                                // wave-uniform
+        const char* base = (const char*) (pages + p.base);                                                  // wave-uniform
         const int kmax = kv_len - 1 - p.tile * 64;
-        #pragma unroll
-        for (int j = 0; j < NCH; ++j)
+        if (kmax >= 63)
         {
-            const int idx = tid + 512 * j;
-            reg[j] = *((const half8_t*) (base + __umul24(min(idx / CH, kmax), row_halves) + (idx % CH) * 8));      // (no branch: this sits between matrix instructions)
+            #pragma unroll
+            for (int j = 0; j < NCH; ++j) reg[j] = *((const half8_t*) (base + goffb[j]));
+        }
+        else
+        {
+            #pragma unroll
+            for (int j = 0; j < NCH; ++j)
+            {
+                const int idx = tid + 512 * j;
+                reg[j] = *((const half8_t*) (base + (uint32_t) (min(idx / CH, kmax) * row_halves + (idx % CH) * 8) * 2u));
+            }
         }
     };
     auto putk = [&](int j, const half8_t (&reg)[NCH], half_t* slot) __attribute__((always_inline)) { *((half8_t*) (slot + kdst(j))) = reg[j]; };
