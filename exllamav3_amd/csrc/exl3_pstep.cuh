@@ -1,0 +1,65 @@
+// Persistent decode step ("generation 5"): plan structures shared by the kernel (exl3_pstep.kspec.hip) and the planner / C ABI (exl3_pstep.hip).
+//
+// One launch runs EVERY quantized linear of a batch-1 decode step (all layers + lm_head) with the glue between them (RMSNorm, q|k|v epilogue with
+// RoPE and the 4-bit K / V append, silu * mul, residual adds); reference graphs it replaces: libtorch/attention.cpp:246-330 + libtorch/mlp.cpp:14-91 per
+// layer (the reference itself keeps input Hadamard -> stream -> output Hadamard of ONE linear inside one cooperative launch with two grid syncs:
+// quant/exl3_gemv_kernel.cuh:138-402).  Grid = one 16-wave workgroup per CU, all co-resident; an "op" = one fused GEMV (q|k|v, o, gate|up, down,
+// lm_head); between two ops every CU meets at an XCD-sharded arrival counter (the EDGE).  What a wave does while it waits at an edge is the point of the
+// design: the weights of the next op do not depend on the activations, so the wave already has them in flight and DECODES its first work units
+// into registers / LDS (decode-ahead); when the activations arrive those units cost one MFMA pass instead of 235 VALU instructions each.
+#pragma once
+#include <stdint.h>
+#include "exl3_common.cuh"
+
+#define PS_WAVES 16
+#define PS_NT (64 * PS_WAVES)
+#define PS_MAX_MATS 3
+#define PS_IN_NORM 0       // input = RMSNorm(R) (R: the 64-bit fixed-point residual), exact row scale (every CU reads the whole row)
+#define PS_IN_QKV 1        // input = q finished from the q|k|v op's slabs (output Hadamard, svh, RoPE, fp16); side job: the new token's K / V append
+#define PS_IN_ACT 2        // input = silu(g) * u finished from the gate|up op's slabs
+#define PS_OUT_SLAB 0      // raw rotated-basis partial rows -> slab[colblock][slice][128] fp32 (finished by the consumer op's preparation)
+#define PS_OUT_ATOMIC 1    // output Hadamard + svh applied to the partial, added into R with integer atomics (exl3_gemv_args.h: fx_atomic_add)
+#define PS_OUT_FINAL 2     // one slice: finished fp16 rows (lm_head)
+
+// LDS map of the kernel (bytes)
+#define PS_QUADS_BYTES 14848                      // activation quads of a slice: (nb * 8 + 4) tile rows x 32 B  ->  nb <= 57 Hadamard blocks
+#define PS_MISC_BYTES 1280                        // block sums of squares [64] | block sums [64] | segment records [2][16][4] | control words
+#define PS_PART_BYTES (PS_WAVES * 2 * 512)        // partial rows [wave][segment][128] fp32
+#define PS_PDEC_BYTES (PS_WAVES * 16 * 64 * 8)    // decode-ahead unit #2 of every wave: [wave][16 operand slots][64 lanes] x 8 B
+#define PS_MAX_SLICE_BLOCKS 57
+
+struct PsMat
+{
+    const uint32_t* B; const half_t* suh; const half_t* svh;
+    float* slab;                       // PS_OUT_SLAB: [n / 128][S][128] fp32
+    int n, tiles_n;
+};
+
+struct PsOp
+{
+    int in_type, out_type, k, nmat;
+    int S, S_in, hd, kvb;              // S: k-slices of this op (= slab lines per column block); S_in: slab lines of the producer op
+    int rope_mode, pad0;
+    float eps; int pad1;
+    PsMat mat[PS_MAX_MATS];
+    const half_t* norm_w;              // PS_IN_NORM
+    const float* in_slab[3];           // PS_IN_QKV: q, k, v slab sets of the producer; PS_IN_ACT: gate, up
+    const half_t* in_svh[3];
+    uint32_t* k_cache; half_t* k_scales; uint32_t* v_cache; half_t* v_scales;      // PS_IN_QKV: the layer's 4-bit paged cache
+};
+
+// what ONE workgroup (CU) does in one op: a rectangle of (ncb column blocks of matrix mat) x (nb Hadamard blocks of k); mat < 0: nothing (it still meets the edge)
+struct PsTile { int mat, cb0, ncb, b0, nb, slice, side, flags; };
+#define PS_TILE_Q_OUT 1               // this workgroup also stores the finished q blocks of its slice (one column group per slice)
+
+struct PsArgs
+{
+    const PsOp* ops; const PsTile* tiles; int nops, ncu;
+    unsigned long long* R; half_t* logits; half_t* q_out;
+    const float* rope_sin; const float* rope_cos; const int64_t* slots;
+    uint32_t* cnt;                    // [nops][8 shards][16 words]: arrivals of edge `op`, zero at launch
+    uint32_t* err;                    // sticky: bit 0 = an edge timed out (results invalid)
+    unsigned long long* dbg;          // optional phase stamps [nops][ncu][8] (100 MHz)
+    int spin_limit, pmax;
+};
+

@@ -1,0 +1,321 @@
+// Persistent decode step (generation 5): planner + C ABI.  Kernel: exl3_pstep_kernel.cuh; design and structures: exl3_pstep.cuh.
+//
+// The planner cuts every fused GEMV ("op") of the step into one rectangle per CU: (column groups of each matrix) x (k-slices), chosen so that
+// the largest rectangle is as small as possible, a rectangle is at most 16 column blocks wide (a wave's run of work units then crosses at most one
+// column-block boundary) and the product of groups x slices fits the CUs.  The tables live in device memory; the kernel reads its rectangle of
+// op i + 1 while it streams op i.
+#include "exl3_pstep_kernel.cuh"
+#include <string>
+#include <vector>
+#include <stdio.h>
+#include <string.h>
+
+template __global__ void exl3_pstep_kernel<4>(const PsArgs);
+#ifndef PS_ONLY_K4
+template __global__ void exl3_pstep_kernel<2>(const PsArgs);
+template __global__ void exl3_pstep_kernel<3>(const PsArgs);
+template __global__ void exl3_pstep_kernel<5>(const PsArgs);
+template __global__ void exl3_pstep_kernel<6>(const PsArgs);
+template __global__ void exl3_pstep_kernel<8>(const PsArgs);
+#endif
+
+#define PS_LDS_BYTES (PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES)
+static_assert(PS_LDS_BYTES <= 160 * 1024, "persistent step: LDS map exceeds a CU's 160 KiB");
+
+namespace
+{
+struct PsHandle
+{
+    int K, nops, ncu, pmax, spin_limit, n_layers;
+    PsOp* d_ops; PsTile* d_tiles; uint32_t* d_cnt; uint32_t* d_err; unsigned long long* d_dbg;
+    float* d_slab_a; float* d_slab_b;
+    size_t cnt_bytes, dbg_words;
+    std::string desc;
+};
+
+struct OpPlan { int S; int g[PS_MAX_MATS]; int G; int wmax, hmax; };
+
+// groups x slices for one op: minimise the largest rectangle (in work units = 2 tile rows x 128 columns); ties -> fewer slices (fewer adds per address / slab lines)
+bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_type, OpPlan& best)
+{
+    double best_cost = 1e30; bool found = false;
+    int total_cb = 0; for (int i = 0; i < nmat; ++i) total_cb += ncb[i];
+    for (int S = 1; S <= nblk && S <= 32; ++S)
+    {
+        if (out_type == PS_OUT_FINAL && S != 1) continue;
+        const int nbmax = (nblk + S - 1) / S;
+        if (nbmax > PS_MAX_SLICE_BLOCKS) continue;
+        if (in_type != PS_IN_NORM && nbmax > 32) continue;                 // one preparation task per half-wave
+        const int G = ncu / S;
+        if (G < nmat) continue;
+        OpPlan p; p.S = S;
+        int sum = 0;
+        for (int i = 0; i < nmat; ++i) { int g = (int) ((long long) G * ncb[i] / total_cb); if (g < 1) g = 1; if (g > ncb[i]) g = ncb[i]; p.g[i] = g; sum += g; }
+        while (sum > G) { int bi = -1; for (int i = 0; i < nmat; ++i) if (p.g[i] > 1 && (bi < 0 || p.g[i] > p.g[bi])) bi = i; if (bi < 0) break; --p.g[bi]; --sum; }
+        if (sum > G) continue;
+        for (;;)
+        {
+            // hand a spare group to the matrix with the widest rectangles
+            if (sum >= G) break;
+            int bi = -1, bw = 0;
+            for (int i = 0; i < nmat; ++i) { const int w = (ncb[i] + p.g[i] - 1) / p.g[i]; if (p.g[i] < ncb[i] && w > bw) { bw = w; bi = i; } }
+            if (bi < 0) break;
+            ++p.g[bi]; ++sum;
+        }
+        p.G = sum; p.wmax = 0;
+        for (int i = 0; i < nmat; ++i) { const int w = (ncb[i] + p.g[i] - 1) / p.g[i]; if (w > p.wmax) p.wmax = w; }
+        if (p.wmax > 16) continue;
+        p.hmax = 4 * nbmax;
+        const double cost = (double) p.wmax * p.hmax + 0.2 * S;
+        if (cost < best_cost) { best_cost = cost; best = p; found = true; }
+    }
+    return found;
+}
+
+void lin_to_mat(const exl3_pstep_linear_t& l, PsMat& m)
+{
+    m.B = (const uint32_t*) l.trellis; m.suh = (const half_t*) l.suh; m.svh = (const half_t*) l.svh; m.slab = nullptr; m.n = l.n; m.tiles_n = l.n / 16;
+}
+}
+
+static void ps_launch(int K, int ncu, hipStream_t st, const PsArgs& args)
+{
+    #define PS_L(KK) case KK: exl3_pstep_kernel<KK><<<dim3(ncu), dim3(PS_NT), PS_LDS_BYTES, st>>>(args); break;
+    switch (K)
+    {
+        PS_L(4)
+#ifndef PS_ONLY_K4
+        PS_L(2) PS_L(3) PS_L(5) PS_L(6) PS_L(8)
+#endif
+        default: break;
+    }
+    #undef PS_L
+}
+
+static int ps_set_lds_attr(int K)
+{
+    #define PS_A(KK) case KK: EXL3_CHECK_HIP(hipFuncSetAttribute((const void*) exl3_pstep_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES), "hipFuncSetAttribute(pstep)"); break;
+    switch (K)
+    {
+        PS_A(4)
+#ifndef PS_ONLY_K4
+        PS_A(2) PS_A(3) PS_A(5) PS_A(6) PS_A(8)
+#endif
+        default: exl3_set_error("exl3_pstep: K = %d has no instantiation", K); return EXL3_ERR_ARG;
+    }
+    #undef PS_A
+    return EXL3_OK;
+}
+
+extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* layers, int n_layers, const exl3_pstep_linear_t* head, const void* final_norm,
+                                 int hidden, int heads_q, int heads_kv, int head_dim, int K, int cb, float eps, int rope_mode, int flags)
+{
+    EXL3_CHECK_ARG(handle_out && layers && n_layers >= 1 && head && final_norm, "exl3_pstep_create: null argument");
+    EXL3_CHECK_ARG(cb == EXL3_CB_MUL1, "exl3_pstep_create: the persistent step is built for the mul1 codebook (cb = 2)");
+    EXL3_CHECK_ARG(hidden % 128 == 0 && hidden >= 128 && hidden / 128 <= PS_MAX_SLICE_BLOCKS, "exl3_pstep_create: hidden must be a multiple of 128 and <= %d", PS_MAX_SLICE_BLOCKS * 128);
+    EXL3_CHECK_ARG((head_dim == 64 || head_dim == 128) && heads_kv >= 1 && heads_q >= heads_kv && (heads_kv * head_dim) % 128 == 0 && (heads_q * head_dim) % 128 == 0,
+                   "exl3_pstep_create: head_dim 64 | 128, whole 128-value blocks of q and kv");
+    EXL3_CHECK_ARG(rope_mode == 1 || rope_mode == 2, "exl3_pstep_create: rope_mode 1 (GPT-J) | 2 (NeoX)");
+    int dev = 0; EXL3_CHECK_HIP(hipGetDevice(&dev), "hipGetDevice");
+    hipDeviceProp_t prop; EXL3_CHECK_HIP(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
+    const int ncu = prop.multiProcessorCount;
+    EXL3_CHECK_ARG(ncu >= 16, "exl3_pstep_create: device has %d CUs", ncu);
+    { const int r = ps_set_lds_attr(K); if (r) return r; }
+
+    const int qdim = heads_q * head_dim, kvdim = heads_kv * head_dim, kvb = kvdim / 128;
+    const int nops = 4 * n_layers + 1;
+    std::vector<PsOp> ops((size_t) nops + 1);                       // + 1: the kernel forms the address of ops[nops] (never read)
+    std::vector<PsTile> tiles((size_t) nops * ncu);
+    memset(ops.data(), 0, ops.size() * sizeof(PsOp));
+    size_t slab_a_floats = 0, slab_b_floats = 0;
+    std::string desc;
+    struct Pending { int op; int which; size_t off[PS_MAX_MATS]; };
+    std::vector<Pending> slab_fix;
+
+    auto add_tiles = [&] (int op, const OpPlan& p, const int* ncb, int nmat, int nblk, int side_tasks)
+    {
+        PsTile* T = tiles.data() + (size_t) op * ncu;
+        for (int c = 0; c < ncu; ++c) { T[c].mat = -1; T[c].cb0 = 0; T[c].ncb = 0; T[c].b0 = 0; T[c].nb = 0; T[c].slice = 0; T[c].side = -1; T[c].flags = 0; }
+        int gi = 0;
+        for (int i = 0; i < nmat; ++i)
+            for (int j = 0; j < p.g[i]; ++j, ++gi)
+            {
+                const int c0 = (int) ((long long) j * ncb[i] / p.g[i]), c1 = (int) ((long long) (j + 1) * ncb[i] / p.g[i]);
+                for (int s = 0; s < p.S; ++s)
+                {
+                    PsTile& t = T[gi * p.S + s];
+                    t.mat = i; t.cb0 = c0; t.ncb = c1 - c0;
+                    t.b0 = (int) ((long long) s * nblk / p.S); t.nb = (int) ((long long) (s + 1) * nblk / p.S) - t.b0;
+                    t.slice = s;
+                    if (i == 0 && j == 0) t.flags |= PS_TILE_Q_OUT;
+                }
+            }
+        for (int t = 0; t < side_tasks; ++t) T[(int) ((long long) t * ncu / side_tasks)].side = t;
+    };
+
+    int op = 0;
+    char line[256];
+    for (int li = 0; li < n_layers; ++li)
+    {
+        const exl3_pstep_layer_t& L = layers[li];
+        EXL3_CHECK_ARG(L.q.k == hidden && L.k.k == hidden && L.v.k == hidden && L.q.n == qdim && L.k.n == kvdim && L.v.n == kvdim && L.o.k == qdim && L.o.n == hidden
+                       && L.gate.k == hidden && L.up.k == hidden && L.gate.n == L.up.n && L.down.k == L.gate.n && L.down.n == hidden && L.gate.n % 128 == 0,
+                       "exl3_pstep_create: layer %d: shapes do not form a Llama block", li);
+        EXL3_CHECK_ARG(L.norm1 && L.norm2 && L.k_cache && L.k_scales && L.v_cache && L.v_scales, "exl3_pstep_create: layer %d: null norm / cache pointer", li);
+        const int inter = L.gate.n;
+        // q|k|v
+        {
+            PsOp& O = ops[op]; O.in_type = PS_IN_NORM; O.out_type = PS_OUT_SLAB; O.k = hidden; O.nmat = 3; O.eps = eps; O.norm_w = (const half_t*) L.norm1;
+            lin_to_mat(L.q, O.mat[0]); lin_to_mat(L.k, O.mat[1]); lin_to_mat(L.v, O.mat[2]);
+            const int ncb[3] = { qdim / 128, kvdim / 128, kvdim / 128 };
+            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 3, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for q|k|v");
+            O.S = p.S; add_tiles(op, p, ncb, 3, hidden / 128, 0);
+            Pending f; f.op = op; f.which = 0; size_t off = 0;
+            for (int i = 0; i < 3; ++i) { f.off[i] = off; off += (size_t) ncb[i] * p.S * 128; }
+            slab_fix.push_back(f); if (off > slab_a_floats) slab_a_floats = off;
+            if (li == 0) { snprintf(line, sizeof(line), "qkv: S=%d groups=%d+%d+%d tile<=%dx%d units; ", p.S, p.g[0], p.g[1], p.g[2], p.wmax, p.hmax); desc += line; }
+            ++op;
+        }
+        // o_proj (input: q finished from the q|k|v slabs; side jobs: K / V append)
+        {
+            PsOp& O = ops[op]; const PsOp& Pq = ops[op - 1];
+            O.in_type = PS_IN_QKV; O.out_type = PS_OUT_ATOMIC; O.k = qdim; O.nmat = 1; O.eps = eps; O.S_in = Pq.S; O.hd = head_dim; O.kvb = kvb; O.rope_mode = rope_mode;
+            lin_to_mat(L.o, O.mat[0]);
+            O.in_svh[0] = (const half_t*) L.q.svh; O.in_svh[1] = (const half_t*) L.k.svh; O.in_svh[2] = (const half_t*) L.v.svh;
+            O.k_cache = (uint32_t*) L.k_cache; O.k_scales = (half_t*) L.k_scales; O.v_cache = (uint32_t*) L.v_cache; O.v_scales = (half_t*) L.v_scales;
+            const int ncb[1] = { hidden / 128 };
+            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, qdim / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for o_proj");
+            O.S = p.S; add_tiles(op, p, ncb, 1, qdim / 128, 2 * kvb);
+            if (li == 0) { snprintf(line, sizeof(line), "o: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
+            ++op;
+        }
+        // gate|up
+        {
+            PsOp& O = ops[op]; O.in_type = PS_IN_NORM; O.out_type = PS_OUT_SLAB; O.k = hidden; O.nmat = 2; O.eps = eps; O.norm_w = (const half_t*) L.norm2;
+            lin_to_mat(L.gate, O.mat[0]); lin_to_mat(L.up, O.mat[1]);
+            const int ncb[2] = { inter / 128, inter / 128 };
+            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 2, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for gate|up");
+            O.S = p.S; add_tiles(op, p, ncb, 2, hidden / 128, 0);
+            Pending f; f.op = op; f.which = 1; size_t off = 0;
+            for (int i = 0; i < 2; ++i) { f.off[i] = off; off += (size_t) ncb[i] * p.S * 128; }
+            slab_fix.push_back(f); if (off > slab_b_floats) slab_b_floats = off;
+            if (li == 0) { snprintf(line, sizeof(line), "gate|up: S=%d groups=%d+%d tile<=%dx%d; ", p.S, p.g[0], p.g[1], p.wmax, p.hmax); desc += line; }
+            ++op;
+        }
+        // down (input: silu(g) * u finished from the gate|up slabs)
+        {
+            PsOp& O = ops[op]; const PsOp& Pg = ops[op - 1];
+            O.in_type = PS_IN_ACT; O.out_type = PS_OUT_ATOMIC; O.k = inter; O.nmat = 1; O.eps = eps; O.S_in = Pg.S;
+            lin_to_mat(L.down, O.mat[0]);
+            O.in_svh[0] = (const half_t*) L.gate.svh; O.in_svh[1] = (const half_t*) L.up.svh;
+            const int ncb[1] = { hidden / 128 };
+            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, inter / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for down_proj");
+            O.S = p.S; add_tiles(op, p, ncb, 1, inter / 128, 0);
+            if (li == 0) { snprintf(line, sizeof(line), "down: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
+            ++op;
+        }
+    }
+    {
+        EXL3_CHECK_ARG(head->k == hidden && head->n % 128 == 0, "exl3_pstep_create: lm_head shape");
+        PsOp& O = ops[op]; O.in_type = PS_IN_NORM; O.out_type = PS_OUT_FINAL; O.k = hidden; O.nmat = 1; O.eps = eps; O.norm_w = (const half_t*) final_norm;
+        lin_to_mat(*head, O.mat[0]);
+        const int ncb[1] = { head->n / 128 };
+        OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for the lm_head (vocab / 128 <= 16 x CUs)");
+        O.S = p.S; add_tiles(op, p, ncb, 1, hidden / 128, 0);
+        snprintf(line, sizeof(line), "head: S=%d groups=%d tile<=%dx%d", p.S, p.g[0], p.wmax, p.hmax); desc += line;
+        ++op;
+    }
+
+    PsHandle* h = new PsHandle();
+    h->K = K; h->nops = nops; h->ncu = ncu; h->pmax = 2; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
+    h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr;
+    h->cnt_bytes = (size_t) nops * 8 * 16 * 4; h->dbg_words = (flags & 1) ? (size_t) nops * ncu * 8 : 0;
+    #define PS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { exl3_set_error("exl3_pstep_create: %s", hipGetErrorString(e_)); exl3_pstep_destroy(h); return EXL3_ERR_HIP; } } while (0)
+    PS_TRY(hipMalloc(&h->d_slab_a, slab_a_floats * 4)); PS_TRY(hipMalloc(&h->d_slab_b, slab_b_floats * 4));
+    PS_TRY(hipMemset(h->d_slab_a, 0, slab_a_floats * 4)); PS_TRY(hipMemset(h->d_slab_b, 0, slab_b_floats * 4));
+    for (const Pending& f : slab_fix)
+    {
+        PsOp& O = ops[f.op];
+        float* base = f.which == 0 ? h->d_slab_a : h->d_slab_b;
+        for (int i = 0; i < O.nmat; ++i) O.mat[i].slab = base + f.off[i];
+        PsOp& C = ops[f.op + 1];                                      // the consumer op reads these slab sets
+        for (int i = 0; i < O.nmat; ++i) C.in_slab[i] = base + f.off[i];
+    }
+    PS_TRY(hipMalloc(&h->d_ops, ops.size() * sizeof(PsOp))); PS_TRY(hipMemcpy(h->d_ops, ops.data(), ops.size() * sizeof(PsOp), hipMemcpyHostToDevice));
+    PS_TRY(hipMalloc(&h->d_tiles, tiles.size() * sizeof(PsTile))); PS_TRY(hipMemcpy(h->d_tiles, tiles.data(), tiles.size() * sizeof(PsTile), hipMemcpyHostToDevice));
+    PS_TRY(hipMalloc(&h->d_cnt, h->cnt_bytes)); PS_TRY(hipMemset(h->d_cnt, 0, h->cnt_bytes));
+    PS_TRY(hipMalloc(&h->d_err, 64)); PS_TRY(hipMemset(h->d_err, 0, 64));
+    if (h->dbg_words) { PS_TRY(hipMalloc(&h->d_dbg, h->dbg_words * 8)); PS_TRY(hipMemset(h->d_dbg, 0, h->dbg_words * 8)); }
+    #undef PS_TRY
+    *handle_out = h;
+    return EXL3_OK;
+}
+
+extern "C" int exl3_pstep_run(void* handle, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream)
+{
+    PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h && R && logits && rope_sin && rope_cos && slots, "exl3_pstep_run: null argument");
+    hipStream_t st = (hipStream_t) stream;
+    EXL3_CHECK_HIP(hipMemsetAsync(h->d_cnt, 0, h->cnt_bytes, st), "exl3_pstep_run: hipMemsetAsync");
+    PsArgs a;
+    a.ops = h->d_ops; a.tiles = h->d_tiles; a.nops = h->nops; a.ncu = h->ncu;
+    a.R = (unsigned long long*) R; a.logits = (half_t*) logits; a.q_out = (half_t*) q_out;
+    a.rope_sin = rope_sin; a.rope_cos = rope_cos; a.slots = slots;
+    a.cnt = h->d_cnt; a.err = h->d_err; a.dbg = h->d_dbg; a.spin_limit = h->spin_limit; a.pmax = h->pmax;
+    ps_launch(h->K, h->ncu, st, a);
+    return exl3_check_launch("exl3_pstep_run");
+}
+
+extern "C" int exl3_pstep_error(void* handle, void* stream)
+{
+    PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h, "exl3_pstep_error: null handle");
+    EXL3_CHECK_HIP(hipStreamSynchronize((hipStream_t) stream), "exl3_pstep_error: hipStreamSynchronize");
+    uint32_t e = 0;
+    EXL3_CHECK_HIP(hipMemcpy(&e, h->d_err, 4, hipMemcpyDeviceToHost), "exl3_pstep_error: hipMemcpy");
+    if (e) EXL3_CHECK_HIP(hipMemset(h->d_err, 0, 4), "exl3_pstep_error: hipMemset");
+    return e ? 1 : 0;
+}
+
+extern "C" int exl3_pstep_set(void* handle, int decode_ahead_units, int spin_limit)
+{
+    PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h && decode_ahead_units >= -1 && decode_ahead_units <= 2, "exl3_pstep_set: decode_ahead_units in 0..2 (-1: keep)");
+    if (decode_ahead_units >= 0) h->pmax = decode_ahead_units;
+    if (spin_limit > 0) h->spin_limit = spin_limit;
+    return EXL3_OK;
+}
+
+extern "C" int exl3_pstep_describe(void* handle, char* buf, int buf_bytes)
+{
+    PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h && buf && buf_bytes > 0, "exl3_pstep_describe: null argument");
+    snprintf(buf, (size_t) buf_bytes, "ops=%d cus=%d K=%d decode_ahead=%d lds=%d | %s", h->nops, h->ncu, h->K, h->pmax, (int) PS_LDS_BYTES, h->desc.c_str());
+    return EXL3_OK;
+}
+
+extern "C" int64_t exl3_pstep_stamps(void* handle, uint64_t* host_out, int64_t max_words, void* stream)
+{
+    PsHandle* h = (PsHandle*) handle;
+    if (!h || !host_out) { exl3_set_error("exl3_pstep_stamps: null argument"); return EXL3_ERR_ARG; }
+    if (!h->d_dbg) return 0;
+    if (hipStreamSynchronize((hipStream_t) stream) != hipSuccess) { exl3_set_error("exl3_pstep_stamps: hipStreamSynchronize"); return EXL3_ERR_HIP; }
+    const int64_t n = (int64_t) h->dbg_words < max_words ? (int64_t) h->dbg_words : max_words;
+    if (hipMemcpy(host_out, h->d_dbg, (size_t) n * 8, hipMemcpyDeviceToHost) != hipSuccess) { exl3_set_error("exl3_pstep_stamps: hipMemcpy"); return EXL3_ERR_HIP; }
+    return n;
+}
+
+extern "C" int exl3_pstep_destroy(void* handle)
+{
+    PsHandle* h = (PsHandle*) handle;
+    if (!h) return EXL3_OK;
+    if (h->d_ops) (void) hipFree(h->d_ops);
+    if (h->d_tiles) (void) hipFree(h->d_tiles);
+    if (h->d_cnt) (void) hipFree(h->d_cnt);
+    if (h->d_err) (void) hipFree(h->d_err);
+    if (h->d_dbg) (void) hipFree(h->d_dbg);
+    if (h->d_slab_a) (void) hipFree(h->d_slab_a);
+    if (h->d_slab_b) (void) hipFree(h->d_slab_b);
+    delete h;
+    return EXL3_OK;
+}

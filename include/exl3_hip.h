@@ -608,6 +608,35 @@ int exl3_ar_reduce(void* ctx, const float* y, float* y_out, void* resid, float* 
 int exl3_ar_reduce_slabs(void* ctx, const float* y, const float* slabs, int S, const void* svh, float* y_out, void* resid, float* ss_part,
                          int m, int hidden, void* stream);
 
+/* ---- the persistent decode step (generation 5, exl3_pstep.hip) ---------------------------------------------------------------------------
+ * ONE launch for every quantized linear of a batch-1 decode step of a Llama-type model (all layers + lm_head) and the glue between them
+ * (RMSNorm, q|k|v epilogue with RoPE + 4-bit K / V append, silu * mul, residual adds).  Replaces, per layer, the graphs of
+ * exllamav3_ext/libtorch/attention.cpp:246-330 (attention core excluded: o_proj consumes q) and libtorch/mlp.cpp:14-91, whose linears each keep
+ * input Hadamard -> stream -> output Hadamard inside one cooperative launch (quant/exl3_gemv_kernel.cuh:138-402); here the whole chain is one
+ * launch of one 16-wave workgroup per CU with an arrival counter between dependent linears, and the waves decode their first weight units of the
+ * NEXT linear while they wait for its input.
+ *   exl3_pstep_create   builds the plan (device-resident op / tile tables, slab and counter buffers) for the given tensors.  K in {2,3,4,5,6,8},
+ *                       cb = 2 (mul1), hidden a multiple of 128 and <= 7168, head_dim 64 | 128, 4-bit cache.  flags: bit 0 = record phase stamps.
+ *   exl3_pstep_run      one decode step: R = the int64 fixed-point residual holding the embedded token (exl3_fx_init / exl3_fx_init_prep, which
+ *                       also produce rope_sin / rope_cos / slots); logits fp16 [vocab]; q_out optional fp16 [heads_q * head_dim].  Graph-capturable.
+ *   exl3_pstep_error    synchronises the stream; 1 if an edge ever timed out (results invalid), else 0.
+ *   exl3_pstep_stamps   copies the phase stamps of the last run ([nops][ncu][8] x u64, 100 MHz) to host memory; returns nops * ncu * 8. */
+typedef struct { const void* trellis; const void* suh; const void* svh; int k, n; } exl3_pstep_linear_t;
+typedef struct
+{
+    exl3_pstep_linear_t q, k, v, o, gate, up, down;
+    const void* norm1; const void* norm2;
+    void* k_cache; void* k_scales; void* v_cache; void* v_scales;
+} exl3_pstep_layer_t;
+int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* layers, int n_layers, const exl3_pstep_linear_t* head, const void* final_norm,
+                      int hidden, int heads_q, int heads_kv, int head_dim, int K, int cb, float eps, int rope_mode, int flags);
+int exl3_pstep_run(void* handle, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream);
+int exl3_pstep_error(void* handle, void* stream);
+int exl3_pstep_set(void* handle, int decode_ahead_units, int spin_limit);
+int exl3_pstep_describe(void* handle, char* buf, int buf_bytes);
+int64_t exl3_pstep_stamps(void* handle, uint64_t* host_out, int64_t max_words, void* stream);
+int exl3_pstep_destroy(void* handle);
+
 #ifdef __cplusplus
 }
 #endif
