@@ -17,21 +17,21 @@
 #define PS_IN_NORM 0       // input = RMSNorm(R) (R: the 64-bit fixed-point residual), exact row scale (every CU reads the whole row)
 #define PS_IN_QKV 1        // input = q finished from the q|k|v op's slabs (output Hadamard, svh, RoPE, fp16); side job: the new token's K / V append
 #define PS_IN_ACT 2        // input = silu(g) * u finished from the gate|up op's slabs
-#define PS_OUT_SLAB 0      // raw rotated-basis partial rows -> slab[colblock][slice][128] fp32 (finished by the consumer op's preparation)
+#define PS_OUT_SLAB 0      // raw rotated-basis partial rows -> slab[colblock][slice][128] tagged granules (finished by the consumer op's preparation; no edge)
 #define PS_OUT_ATOMIC 1    // output Hadamard + svh applied to the partial, added into R with integer atomics (exl3_gemv_args.h: fx_atomic_add)
 #define PS_OUT_FINAL 2     // one slice: finished fp16 rows (lm_head)
 
 // LDS map of the kernel (bytes)
-#define PS_QUADS_BYTES 14848                      // activation quads of a slice: (nb * 8 + 4) tile rows x 32 B  ->  nb <= 57 Hadamard blocks
-#define PS_MISC_BYTES 1280                        // block sums of squares [64] | block sums [64] | segment records [2][16][4] | control words
-#define PS_PART_BYTES (PS_WAVES * 2 * 512)        // partial rows [wave][segment][128] fp32
-#define PS_PDEC_BYTES (PS_WAVES * 16 * 64 * 8)    // decode-ahead unit #2 of every wave: [wave][16 operand slots][64 lanes] x 8 B
-#define PS_MAX_SLICE_BLOCKS 57
+#define PS_QUADS_BYTES 8448                       // activation quads of a slice: (nb * 8 + 4) tile rows x 32 B  ->  nb <= 32 Hadamard blocks
+#define PS_MISC_BYTES 1536                        // block sums of squares [64] | block sums [2][64] | segment records [2][16][4] | control words
+#define PS_PART_BYTES (12 * 2 * 512)              // partial rows [streaming wave][segment][128] fp32
+#define PS_PDEC_BYTES (12 * 16 * 64 * 8)          // decode-ahead unit #2 of every streaming wave: [wave][16 operand slots][64 lanes] x 8 B
+#define PS_MAX_SLICE_BLOCKS 32                    // = the largest k / 128 of an RMSNorm op (hidden <= 4096): 8 service half-waves x 4 blocks
 
 struct PsMat
 {
     const uint32_t* B; const half_t* suh; const half_t* svh;
-    float* slab;                       // PS_OUT_SLAB: [n / 128][S][128] fp32
+    unsigned long long* slab;          // PS_OUT_SLAB: [n / 128][S] lines of 1 KiB: 64 tagged pairs { v0, tag, v1, tag } (exl3_pstep_kernel.cuh)
     int n, tiles_n;
 };
 
@@ -43,7 +43,7 @@ struct PsOp
     float eps; int pad1;
     PsMat mat[PS_MAX_MATS];
     const half_t* norm_w;              // PS_IN_NORM
-    const float* in_slab[3];           // PS_IN_QKV: q, k, v slab sets of the producer; PS_IN_ACT: gate, up
+    const unsigned long long* in_slab[3];   // PS_IN_QKV: q, k, v slab sets of the producer; PS_IN_ACT: gate, up
     const half_t* in_svh[3];
     uint32_t* k_cache; half_t* k_scales; uint32_t* v_cache; half_t* v_scales;      // PS_IN_QKV: the layer's 4-bit paged cache
 };
@@ -58,8 +58,9 @@ struct PsArgs
     unsigned long long* R; half_t* logits; half_t* q_out;
     const float* rope_sin; const float* rope_cos; const int64_t* slots;
     uint32_t* cnt;                    // [nops][8 shards][16 words]: arrivals of edge `op`, zero at launch
-    uint32_t* err;                    // sticky: bit 0 = an edge timed out (results invalid)
-    unsigned long long* dbg;          // optional phase stamps [nops][ncu][8] (100 MHz)
+    uint32_t* epoch;                  // run counter in device memory (tags of the slab granules): read at entry, + 1 at exit
+    uint32_t* err;                    // sticky: bit 0 = an edge timed out, bit 1 = a tagged slab line never arrived (results invalid)
+    unsigned long long* dbg;          // optional phase stamps [nops][ncu][16] (100 MHz)
     int spin_limit, pmax;
 };
 

@@ -28,7 +28,7 @@ struct PsHandle
 {
     int K, nops, ncu, pmax, spin_limit, n_layers;
     PsOp* d_ops; PsTile* d_tiles; uint32_t* d_cnt; uint32_t* d_err; unsigned long long* d_dbg;
-    float* d_slab_a; float* d_slab_b;
+    unsigned long long* d_slab_a; unsigned long long* d_slab_b; uint32_t* d_epoch;
     size_t cnt_bytes, dbg_words;
     std::string desc;
 };
@@ -45,7 +45,7 @@ bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_t
         if (out_type == PS_OUT_FINAL && S != 1) continue;
         const int nbmax = (nblk + S - 1) / S;
         if (nbmax > PS_MAX_SLICE_BLOCKS) continue;
-        if (in_type != PS_IN_NORM && nbmax > 32) continue;                 // one preparation task per half-wave
+        if (in_type != PS_IN_NORM && nbmax > 8) continue;                  // one preparation task per service half-wave
         const int G = ncu / S;
         if (G < nmat) continue;
         OpPlan p; p.S = S;
@@ -64,7 +64,7 @@ bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_t
         }
         p.G = sum; p.wmax = 0;
         for (int i = 0; i < nmat; ++i) { const int w = (ncb[i] + p.g[i] - 1) / p.g[i]; if (w > p.wmax) p.wmax = w; }
-        if (p.wmax > 16) continue;
+        if (p.wmax > 12) continue;                                          // a streaming wave's run crosses at most one column-block boundary
         p.hmax = 4 * nbmax;
         const double cost = (double) p.wmax * p.hmax + 0.2 * S;
         if (cost < best_cost) { best_cost = cost; best = p; found = true; }
@@ -228,15 +228,15 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
 
     PsHandle* h = new PsHandle();
     h->K = K; h->nops = nops; h->ncu = ncu; h->pmax = 2; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
-    h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr;
-    h->cnt_bytes = (size_t) nops * 8 * 16 * 4; h->dbg_words = (flags & 1) ? (size_t) nops * ncu * 8 : 0;
+    h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr; h->d_epoch = nullptr;
+    h->cnt_bytes = (size_t) nops * 8 * 16 * 4; h->dbg_words = (flags & 1) ? (size_t) nops * ncu * 16 : 0;
     #define PS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { exl3_set_error("exl3_pstep_create: %s", hipGetErrorString(e_)); exl3_pstep_destroy(h); return EXL3_ERR_HIP; } } while (0)
-    PS_TRY(hipMalloc(&h->d_slab_a, slab_a_floats * 4)); PS_TRY(hipMalloc(&h->d_slab_b, slab_b_floats * 4));
-    PS_TRY(hipMemset(h->d_slab_a, 0, slab_a_floats * 4)); PS_TRY(hipMemset(h->d_slab_b, 0, slab_b_floats * 4));
+    PS_TRY(hipMalloc(&h->d_slab_a, slab_a_floats * 8)); PS_TRY(hipMalloc(&h->d_slab_b, slab_b_floats * 8));
+    PS_TRY(hipMemset(h->d_slab_a, 0, slab_a_floats * 8)); PS_TRY(hipMemset(h->d_slab_b, 0, slab_b_floats * 8));
     for (const Pending& f : slab_fix)
     {
         PsOp& O = ops[f.op];
-        float* base = f.which == 0 ? h->d_slab_a : h->d_slab_b;
+        unsigned long long* base = f.which == 0 ? h->d_slab_a : h->d_slab_b;
         for (int i = 0; i < O.nmat; ++i) O.mat[i].slab = base + f.off[i];
         PsOp& C = ops[f.op + 1];                                      // the consumer op reads these slab sets
         for (int i = 0; i < O.nmat; ++i) C.in_slab[i] = base + f.off[i];
@@ -245,6 +245,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     PS_TRY(hipMalloc(&h->d_tiles, tiles.size() * sizeof(PsTile))); PS_TRY(hipMemcpy(h->d_tiles, tiles.data(), tiles.size() * sizeof(PsTile), hipMemcpyHostToDevice));
     PS_TRY(hipMalloc(&h->d_cnt, h->cnt_bytes)); PS_TRY(hipMemset(h->d_cnt, 0, h->cnt_bytes));
     PS_TRY(hipMalloc(&h->d_err, 64)); PS_TRY(hipMemset(h->d_err, 0, 64));
+    PS_TRY(hipMalloc(&h->d_epoch, 64)); { const uint32_t one = 1u; PS_TRY(hipMemset(h->d_epoch, 0, 64)); PS_TRY(hipMemcpy(h->d_epoch, &one, 4, hipMemcpyHostToDevice)); }
     if (h->dbg_words) { PS_TRY(hipMalloc(&h->d_dbg, h->dbg_words * 8)); PS_TRY(hipMemset(h->d_dbg, 0, h->dbg_words * 8)); }
     #undef PS_TRY
     *handle_out = h;
@@ -261,7 +262,7 @@ extern "C" int exl3_pstep_run(void* handle, void* R, void* logits, void* q_out, 
     a.ops = h->d_ops; a.tiles = h->d_tiles; a.nops = h->nops; a.ncu = h->ncu;
     a.R = (unsigned long long*) R; a.logits = (half_t*) logits; a.q_out = (half_t*) q_out;
     a.rope_sin = rope_sin; a.rope_cos = rope_cos; a.slots = slots;
-    a.cnt = h->d_cnt; a.err = h->d_err; a.dbg = h->d_dbg; a.spin_limit = h->spin_limit; a.pmax = h->pmax;
+    a.cnt = h->d_cnt; a.epoch = h->d_epoch; a.err = h->d_err; a.dbg = h->d_dbg; a.spin_limit = h->spin_limit; a.pmax = h->pmax;
     ps_launch(h->K, h->ncu, st, a);
     return exl3_check_launch("exl3_pstep_run");
 }
@@ -313,6 +314,7 @@ extern "C" int exl3_pstep_destroy(void* handle)
     if (h->d_tiles) (void) hipFree(h->d_tiles);
     if (h->d_cnt) (void) hipFree(h->d_cnt);
     if (h->d_err) (void) hipFree(h->d_err);
+    if (h->d_epoch) (void) hipFree(h->d_epoch);
     if (h->d_dbg) (void) hipFree(h->d_dbg);
     if (h->d_slab_a) (void) hipFree(h->d_slab_a);
     if (h->d_slab_b) (void) hipFree(h->d_slab_b);

@@ -1,13 +1,16 @@
 // Persistent decode-step kernel body (generation 5), included by exl3_pstep.hip.  Design: exl3_pstep.cuh.  K = bits per weight, mul1 codebook, one row.
 //
-// Per op, per workgroup (one per CU, 16 waves):
-//   [static operands of the preparation requested]  ->  wave 0 polls the previous op's edge  ->  B1
-//   preparation tasks (half-wave per 128-value block of the workgroup's k-slice: RMSNorm | q finish + RoPE | silu * mul, then the input Hadamard) -> LDS quads -> B3
-//   every wave: its decode-ahead units (MFMA only), then the rest of its run of work units (generation 4's unit: exl3_gemv4.kspec.hip g4_unit); the LAST
-//   unit's ring refill already requests the wave's first rows of the NEXT op  ->  partial rows to LDS  ->  B4
-//   half-wave j finishes column block j of the rectangle (sum of the waves' partials, mul1 affine map, slab line | output Hadamard + atomics | final row);
-//   the last finishing wave announces the workgroup's arrival at this op's edge
-//   every wave: decode-ahead of its first unit(s) of the next op (registers; the second unit in LDS) -- this is what fills the edge's wait
+// One 16-wave workgroup per CU, two roles, NO workgroup barrier inside the op loop (the waves meet through monotonic LDS counters):
+//   * waves 0..11 STREAM: for every op they own a run of work units (2 tile rows x 128 columns) of the workgroup's rectangle.  While the op's activations
+//     are not ready they DECODE AHEAD: the first unit into registers, the second into LDS (the weights do not depend on the activations); when the
+//     service waves publish the activation quads they spend one MFMA pass per decoded unit and stream the rest (generation 4's unit, exl3_gemv4.kspec.hip
+//     g4_unit); the last unit's ring refill already requests the wave's first rows of the NEXT op; partial rows -> LDS, counter, on to the next op.
+//   * waves 12..15 SERVE (one per SIMD; their memory queues hold no weight rows, so their small dependent loads are not parked behind HBM streams --
+//     vmcnt returns in order): poll the edge, read R / the producer's tagged slab lines, RMSNorm | q finish + RoPE | silu * mul, input Hadamard -> LDS quads;
+//     when the streamers are done: sum the partial rows, mul1 affine map, then slab line (tagged granules, no edge) | output Hadamard + atomics into R
+//     (drain, arrive at the edge) | final fp16 row; the K / V append of the new token as a side job.
+// Cross-workgroup protocol: R is read only after the edge of the op that added into it; an op that adds into R first passes the READ GATE of the
+// op that last read it (every workgroup arrives at the gate once its R values are in registers); slab lines carry their own tags.
 #pragma once
 #include "exl3_pstep.cuh"
 #include "exl3_api_internal.h"
@@ -22,33 +25,73 @@ __device__ __forceinline__ void ps_static_for(F&& f)
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); ps_static_for<I + 1, N>(f); }
 }
 
-// agent-scope (sc1) accesses: everything one workgroup writes for another inside the launch goes through these (exl3_gemv2_tail.cuh has the same pair)
-__device__ __forceinline__ unsigned long long ps_ld64(const void* p) { return __hip_atomic_load((unsigned long long*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ps_st64(void* p, unsigned long long v) { __hip_atomic_store((unsigned long long*) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float4_t ps_ld_f4(const float* p)
+// The plan tables are immutable during the launch: reading them through the CONSTANT address space makes every field a scalar load (s_load) with a
+// wave-uniform result -- through a plain pointer the compiler must assume the kernel's own stores alias them and emits vector loads + vmcnt(0) waits +
+// readfirstlane (and waterfall loops around every buffer instruction whose resource comes from such a value).  Pointers taken from the tables are
+// generic to the compiler: weight / scale loads cast them to the GLOBAL address space (flat_load would also count against lgkmcnt and couple the
+// weight stream to every LDS wait).
+#define PS_CONST __attribute__((address_space(4)))
+#define PS_GLOBAL __attribute__((address_space(1)))
+typedef const PsOp PS_CONST* ps_op_p;
+typedef const PsMat PS_CONST* ps_mat_p;
+template <class T> __device__ __forceinline__ const T PS_GLOBAL* ps_g(const T* p) { return (const T PS_GLOBAL*) p; }
+__device__ __forceinline__ PsTile ps_load_tile(const PsTile* tiles, size_t idx)
 {
-    union { unsigned long long u[2]; float4_t f; } c;
-    c.u[0] = ps_ld64(p); c.u[1] = ps_ld64(p + 2);
-    return c.f;
+    const int PS_CONST* t = (const int PS_CONST*) (tiles + idx);
+    PsTile r; r.mat = t[0]; r.cb0 = t[1]; r.ncb = t[2]; r.b0 = t[3]; r.nb = t[4]; r.slice = t[5]; r.side = t[6]; r.flags = t[7];
+    return r;
 }
-__device__ __forceinline__ void ps_st_f4(float* p, float4_t v)
+template <int K>
+__device__ __forceinline__ void ps_load_row(LaneWords<K>& d, const uint32_t* __restrict__ p)
 {
-    union { unsigned long long u[2]; float4_t f; } c; c.f = v;
-    ps_st64(p, c.u[0]); ps_st64(p + 2, c.u[1]);
+    // p = this lane's first word of the tile row; K consecutive words (contiguous across the wave), non-temporal, global address space
+    if constexpr (K == 4) { const uint4_t v = __builtin_nontemporal_load((const uint4_t PS_GLOBAL*) p); d.w[0] = v.x; d.w[1] = v.y; d.w[2] = v.z; d.w[3] = v.w; }
+    else if constexpr (K == 8)
+    {
+        const uint4_t v = __builtin_nontemporal_load((const uint4_t PS_GLOBAL*) p), u = __builtin_nontemporal_load((const uint4_t PS_GLOBAL*) p + 1);
+        d.w[0] = v.x; d.w[1] = v.y; d.w[2] = v.z; d.w[3] = v.w; d.w[4] = u.x; d.w[5] = u.y; d.w[6] = u.z; d.w[7] = u.w;
+    }
+    else if constexpr (K == 2) { const uint2_t v = __builtin_nontemporal_load((const uint2_t PS_GLOBAL*) p); d.w[0] = v.x; d.w[1] = v.y; }
+    else
+    {
+        #pragma unroll
+        for (int i = 0; i < K; ++i) d.w[i] = __builtin_nontemporal_load((const uint32_t PS_GLOBAL*) p + i);
+    }
 }
 
-// slab lines of one column block summed in slice order from zero (slab_sum of exl3_glue_device.cuh with agent-scope loads); every load is issued before the first add
+// agent-scope (sc1) accesses: everything one workgroup writes for another inside the launch goes through these (exl3_gemv2_tail.cuh has the same pair)
+__device__ __forceinline__ unsigned long long ps_ld64(const void* p) { return __hip_atomic_load((unsigned long long*) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// 16-byte agent-scope loads / stores: raw buffer instructions with the sc1 bit (aux = 16 on gfx950); the compiler tracks their wait counts
+typedef __amdgpu_buffer_rsrc_t ps_rsrc_t;
+__device__ __forceinline__ ps_rsrc_t ps_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc((void*) base, 0, 0x7ffffff0, 0x00020000); }
+__device__ __forceinline__ uint4_t ps_ld128(ps_rsrc_t r, uint32_t byte_off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int) byte_off, 0, 16); }
+__device__ __forceinline__ void ps_st128(ps_rsrc_t r, uint32_t byte_off, uint4_t v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int) byte_off, 0, 16); }
+
+// Slab lines are TAGGED: a line = 128 values = 64 granule pairs of 16 bytes { v0, tag, v1, tag }, each written by ONE 16-byte agent-scope store; lane l of the
+// writing half-wave owns values 4l..4l+3 = pair l ({4l, 4l+1}) and pair 32 + l ({4l+2, 4l+3}), so a store / load instruction covers 512 contiguous bytes.
+// tag = (run epoch, producer op).  The consumer needs no edge: it loads the lines of its block and re-loads until every tag is the producer's (data and
+// flag in one store: the guide's handoff-1to1 granules).  Lines summed in slice order from zero (slab_sum of exl3_glue_device.cuh).
+#define PS_LINE_BYTES 1024
 template <int NB>
-__device__ __forceinline__ float4_t ps_slab_sum(const float* base, int S, int l)
+__device__ __forceinline__ float4_t ps_slab_sum(ps_rsrc_t r, uint32_t blk_off, int S, int l, uint32_t tag, bool& ok)
 {
     float4_t v = { 0.f, 0.f, 0.f, 0.f };
     for (int s = 0; s < S; s += NB)
     {
-        float4_t t[NB];
+        uint4_t t[NB][2];
         #pragma unroll
-        for (int i = 0; i < NB; ++i) t[i] = ps_ld_f4(base + (size_t) min(s + i, S - 1) * 128 + 4 * l);
+        for (int i = 0; i < NB; ++i)
+        {
+            const uint32_t o = blk_off + (uint32_t) min(s + i, S - 1) * PS_LINE_BYTES + (uint32_t) l * 16;
+            t[i][0] = ps_ld128(r, o); t[i][1] = ps_ld128(r, o + 512);
+        }
         #pragma unroll
-        for (int i = 0; i < NB; ++i) if (s + i < S) { v.x += t[i].x; v.y += t[i].y; v.z += t[i].z; v.w += t[i].w; }
+        for (int i = 0; i < NB; ++i) if (s + i < S)
+        {
+            ok = ok && t[i][0].y == tag && t[i][0].w == tag && t[i][1].y == tag && t[i][1].w == tag;
+            v.x += __uint_as_float(t[i][0].x); v.y += __uint_as_float(t[i][0].z);
+            v.z += __uint_as_float(t[i][1].x); v.w += __uint_as_float(t[i][1].z);
+        }
     }
     return v;
 }
@@ -70,7 +113,7 @@ __device__ __forceinline__ void ps_unit(LaneWords<K> (&ring)[2], const uint32_t*
             const uint32_t r9 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x129, 0xf, 0xf, true);
             Wx[0] = (lane & 7) ? r1 : r9;
         }
-        load_lane_words<K>(ring[u], refill + (size_t) u * refill_rs + lofs);
+        if (refill) ps_load_row<K>(ring[u], refill + (size_t) u * refill_rs + lofs);      // (null: a wave that must drain its stores right after this unit)
         ps_static_for<0, 4>([&] (auto qc)
         {
             constexpr int q = decltype(qc)::value;
@@ -101,7 +144,7 @@ __device__ __forceinline__ void ps_predecode(LaneWords<K> (&ring)[2], const uint
             const uint32_t r9 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x129, 0xf, 0xf, true);
             Wx[0] = (lane & 7) ? r1 : r9;
         }
-        load_lane_words<K>(ring[u], refill + (size_t) u * refill_rs + lofs);
+        ps_load_row<K>(ring[u], refill + (size_t) u * refill_rs + lofs);
         ps_static_for<0, 4>([&] (auto qc)
         {
             constexpr int q = decltype(qc)::value;
@@ -125,7 +168,17 @@ __device__ __forceinline__ void ps_consume(const half4_t (&dec)[16], half4_t ag,
     });
 }
 
-// a wave's run of work units inside its workgroup's rectangle: column-major over (column block j, unit i); at most two column blocks (planner: ncb <= 16)
+#define PS_SW 12                       // streaming waves (3 per SIMD); waves PS_SW .. 15 serve
+#define PS_NSV (PS_WAVES - PS_SW)      // service waves
+// monotonic LDS counters (targets are derived by every wave from the uniform op / tile tables)
+#define PS_C_EDGE 0                    // = op + 1 once the edge in front of op's R read is satisfied (service wave 0 polls)
+#define PS_C_A 1                       // + PS_NSV per RMSNorm op: the service waves' block sums of squares are in LDS
+#define PS_C_T 2                       // + PS_NSV per op: the service waves' activation quads of the op are in LDS
+#define PS_C_S 3                       // + PS_SW per op: the streaming waves' partial rows of the op are in LDS
+#define PS_C_R 4                       // + PS_NSV per op that adds into R: the service waves' atomics are acknowledged
+#define PS_C_G 5                       // = op + 1 once the read gate in front of op's adds into R is satisfied
+
+// a streaming wave's run of work units inside its workgroup's rectangle: column-major over (column block j, unit i); at most two column blocks (planner: ncb <= PS_SW)
 template <int K>
 struct PsSeg
 {
@@ -138,7 +191,7 @@ struct PsSeg
 };
 
 template <int K>
-__device__ __forceinline__ PsSeg<K> ps_make_seg(const PsOp* __restrict__ O, const PsTile& t, int wave)
+__device__ __forceinline__ PsSeg<K> ps_make_seg(ps_op_p O, const PsTile& t, int wave)
 {
     constexpr int NW = 8 * K;
     PsSeg<K> s;
@@ -146,11 +199,11 @@ __device__ __forceinline__ PsSeg<K> ps_make_seg(const PsOp* __restrict__ O, cons
     if (t.mat >= 0)
     {
         const int H = 4 * t.nb, T = H * t.ncb;
-        const int u0 = (T * wave) >> 4, u1 = (T * (wave + 1)) >> 4;
+        const int u0 = (T * wave) / PS_SW, u1 = (T * (wave + 1)) / PS_SW;
         s.n = u1 - u0;
         s.j0 = u0 / H; s.i0 = u0 - s.j0 * H;
         s.len0 = min(s.n, H - s.i0); s.len1 = s.n - s.len0;
-        const PsMat* M = &O->mat[t.mat];
+        const ps_mat_p M = &O->mat[t.mat];
         const uint32_t* B = M->B; const int tn = M->tiles_n;
         s.rs = (size_t) tn * NW;
         s.stripA = B + ((size_t) (t.b0 * 8 + 2 * s.i0) * tn + (size_t) (t.cb0 + s.j0) * 8) * NW;
@@ -165,97 +218,215 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const quads = smem;
     float* const ssblk = (float*) (smem + PS_QUADS_BYTES);
-    float* const bsum = ssblk + 64;
-    int* const seginfo2 = (int*) (bsum + 64);                     // [2 (op parity)][16][4]: j0, len0, len1 of every wave's run
-    uint32_t* const lctl = (uint32_t*) (seginfo2 + 128);            // [0]: finished reducer waves of the current op
+    float* const bsum2 = ssblk + 64;                                // [2 (op parity)][64]: block sums of the rotated activations
+    int* const seginfo2 = (int*) (bsum2 + 128);                     // [2 (op parity)][16][4]: j0, len0, len1 of every streaming wave's run
+    uint32_t* const lctl = (uint32_t*) (seginfo2 + 128);            // the PS_C_* counters
     float* const part = (float*) (smem + PS_QUADS_BYTES + PS_MISC_BYTES);
     char* const pdec = smem + PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hwid = tid >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cu = blockIdx.x, ncu = a.ncu, nops = a.nops;
-    const int quad_lane = (lane >> 2) * 8, lofs = lane * K;
-    const int pmax = a.pmax;
     unsigned long long* const dbg = a.dbg;
-    #define PS_T(i) do { if (dbg && tid == 0) dbg[((size_t) op * ncu + cu) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    // phase stamps (100 MHz, 16 slots per op and workgroup): lane 0 of streaming wave 0 writes slots 0..2, lane 0 of service wave 0 the others
+    // (tools/pstep_stamps.py names them)
+    #define PS_T(i) do { if (dbg && lane == 0) dbg[((size_t) op * ncu + cu) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
-    if (tid == 0) lctl[0] = 0u;
-
-    LaneWords<K> ring[2];
-    half4_t dec0[16];
-    #pragma unroll
-    for (int i = 0; i < 16; ++i) dec0[i] = half4_t{ 0, 0, 0, 0 };
-    #pragma unroll
-    for (int i = 0; i < K; ++i) { ring[0].w[i] = 0u; ring[1].w[i] = 0u; }
-    char* const pdec_w = pdec + (size_t) wave * (16 * 64 * 8) + (size_t) lane * 8;
-
-    // decode-ahead of the wave's first unit(s) of an op: returns the number of units decoded (unit 0 -> dec0, unit 1 -> LDS)
-    auto decode_ahead = [&] (const PsSeg<K>& s, bool ring_loaded) -> int
-    {
-        if (s.n <= 0) return 0;
-        if (!ring_loaded)
-        {
-            load_lane_words<K>(ring[0], s.stripA + lofs);
-            load_lane_words<K>(ring[1], s.stripA + s.rs + lofs);
-        }
-        const int P = min(pmax, s.len0);
-        if (P >= 1) ps_predecode<K>(ring, s.unit_ptr(min(1, s.n - 1)), s.rs, lane, lofs, dec0);
-        if (P >= 2)
-        {
-            half4_t tmp[16];
-            ps_predecode<K>(ring, s.unit_ptr(min(2, s.n - 1)), s.rs, lane, lofs, tmp);
-            #pragma unroll
-            for (int i = 0; i < 16; ++i) *((half4_t*) (pdec_w + i * 512)) = tmp[i];
-        }
-        return P;
-    };
-
-    PsTile tl = a.tiles[cu];
-    PsSeg<K> cur = ps_make_seg<K>(a.ops, tl, wave);
-    int P = decode_ahead(cur, false);
-    bool aborted = false;
+    if (tid < 8) lctl[tid] = 0u;
+    const uint32_t epoch = (uint32_t) __builtin_amdgcn_readfirstlane((int) *a.epoch);      // bumped by workgroup 0 when it leaves: every replay tags afresh
     __syncthreads();
 
-    for (int op = 0; op < nops; ++op)
+    auto c_load = [&] (int i) -> uint32_t { return __hip_atomic_load(lctl + i, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto c_wait = [&] (int i, uint32_t target) { while ((int32_t) (c_load(i) - target) < 0) __builtin_amdgcn_s_sleep(1); };
+    auto c_spin = [&] (int i, uint32_t target) { while ((int32_t) (c_load(i) - target) < 0) { } };          // service waves: no sleep granularity on the latency chain
+    auto c_inc = [&] (int i) -> uint32_t
     {
-        const PsOp* __restrict__ O = a.ops + op;
-        const bool active = tl.mat >= 0;
-        const int b0 = tl.b0, nb = active ? tl.nb : 0, W = active ? tl.ncb : 0;
-        const int in_type = O->in_type, out_type = O->out_type, kk = O->k;
-        PS_T(0);
+        uint32_t old = 0u;
+        if (lane == 0) old = __hip_atomic_fetch_add(lctl + i, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (uint32_t) __builtin_amdgcn_readfirstlane((int) old);
+    };
+    auto c_set = [&] (int i, uint32_t v) { if (lane == 0) __hip_atomic_store(lctl + i, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
-        // ---- the next op's rectangle and this wave's run in it (pointers only): the last streamed unit of this op requests its first rows
-        PsTile tn; tn.mat = -1; tn.cb0 = 0; tn.ncb = 0; tn.b0 = 0; tn.nb = 0; tn.slice = 0; tn.side = -1; tn.flags = 0;
-        if (op + 1 < nops) tn = a.tiles[(size_t) (op + 1) * ncu + cu];
-        const PsSeg<K> nxt = ps_make_seg<K>(O + 1, tn, wave);
-        const uint32_t* const after_all = nxt.n > 0 ? nxt.stripA : (cur.n > 0 ? cur.unit_ptr(cur.n - 1) : nullptr);
-        const size_t after_rs = nxt.n > 0 ? nxt.rs : cur.rs;
+    if (wave < PS_SW)
+    {
+        // =========================================================================================== streaming waves
+        const int quad_lane = (lane >> 2) * 8, lofs = lane * K;
+        const int pmax = a.pmax;
+        LaneWords<K> ring[2];
+        half4_t dec0[16];
+        #pragma unroll
+        for (int i = 0; i < 16; ++i) dec0[i] = half4_t{ 0, 0, 0, 0 };
+        #pragma unroll
+        for (int i = 0; i < K; ++i) { ring[0].w[i] = 0u; ring[1].w[i] = 0u; }
+        char* const pdec_w = pdec + (size_t) wave * (16 * 64 * 8) + (size_t) lane * 8;
 
-        // ---- static operands of the preparation tasks (weights: requested before the wait)
-        half4_t wv[2], sv[2], sva = { 0, 0, 0, 0 }, svb = sva;
-        float4_t sn4 = { 0.f, 0.f, 0.f, 0.f }, cs4 = sn4;
-        wv[0] = sva; wv[1] = sva; sv[0] = sva; sv[1] = sva;
-        const half_t* const suh_m = active ? O->mat[tl.mat].suh : nullptr;
-        const int nblk = kk >> 7;
-        const int tb = min(hwid, max(nb - 1, 0));                 // QKV / ACT: this half-wave's slice-local block (clamped)
-        if (active)
+        const ps_op_p ops_c = (ps_op_p) a.ops;
+        PsTile tl = ps_load_tile(a.tiles, (size_t) cu);
+        PsSeg<K> cur = ps_make_seg<K>(ops_c, tl, wave);
+        bool ring_ready = false;
+        for (int op = 0; op < nops; ++op)
         {
+            const ps_op_p O = ops_c + op;
+            if (wave == 0) PS_T(0);
+            // the next op's rectangle and this wave's run in it (pointers only): the last streamed unit of this op requests its first rows
+            PsTile tn; tn.mat = -1; tn.cb0 = 0; tn.ncb = 0; tn.b0 = 0; tn.nb = 0; tn.slice = 0; tn.side = -1; tn.flags = 0;
+            if (op + 1 < nops) tn = ps_load_tile(a.tiles, (size_t) (op + 1) * ncu + cu);
+            const PsSeg<K> nxt = ps_make_seg<K>(O + 1, tn, wave);
+            const uint32_t* const after_all = nxt.n > 0 ? nxt.stripA : nullptr;           // (null: the last unit does not refill)
+            const size_t after_rs = nxt.rs;
+            if (lane == 0) { int* si = seginfo2 + (op & 1) * 64 + wave * 4; si[0] = cur.j0; si[1] = cur.len0; si[2] = cur.len1; si[3] = 0; }
+
+            // ---- decode-ahead while the service waves have not published the op's activation quads
+            const uint32_t tgt_t = (uint32_t) PS_NSV * (uint32_t) (op + 1);
+            int P = 0;
+            if (cur.n > 0)
+            {
+                if (!ring_ready)
+                {
+                    ps_load_row<K>(ring[0], cur.stripA + lofs);
+                    ps_load_row<K>(ring[1], cur.stripA + cur.rs + lofs);
+                }
+                const int Pm = min(pmax, cur.len0);
+                if (Pm >= 1 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
+                {
+                    ps_predecode<K>(ring, cur.unit_ptr(min(1, cur.n - 1)), cur.rs, lane, lofs, dec0);
+                    P = 1;
+                    if (Pm >= 2 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
+                    {
+                        half4_t tmp[16];
+                        ps_predecode<K>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, tmp);
+                        #pragma unroll
+                        for (int i = 0; i < 16; ++i) *((half4_t*) (pdec_w + i * 512)) = tmp[i];
+                        P = 2;
+                    }
+                }
+            }
+            c_wait(PS_C_T, tgt_t);
+            if (wave == 0) PS_T(1);
+
+            // ---- this wave's run of work units: decode-ahead units first (MFMA only), the rest streamed
+            auto run_seg = [&] (const uint32_t* strip, int len, int pre, const uint32_t* after, size_t aft_rs, int qoff, float* pslot)
+            {
+                float4_t acc_c = { 0.f, 0.f, 0.f, 0.f }, acc_d = acc_c;
+                const char* qb = quads + qoff + quad_lane;
+                const size_t rs = cur.rs;
+                auto up = [&] (int q) -> const uint32_t* { return q < len ? strip + (size_t) (2 * q) * rs : after; };
+                auto ur = [&] (int q) -> size_t { return q < len ? rs : aft_rs; };          // the refill target may lie in the NEXT op's matrix (another row pitch)
+                int p = 0;
+                if (pre > 0)
+                {
+                    const uint2_t raw = *((const uint2_t*) qb);
+                    const half4_t ag = u2_as_half4(raw.x, raw.y);
+                    ps_consume<0>(dec0, ag, acc_c, acc_d);
+                    if (len > 1)
+                    {
+                        if (pre > 1)
+                        {
+                            half4_t tmp[16];
+                            #pragma unroll
+                            for (int i = 0; i < 16; ++i) tmp[i] = *((const half4_t*) (pdec_w + i * 512));
+                            ps_consume<1>(tmp, ag, acc_c, acc_d);
+                        }
+                        else ps_unit<K, 1>(ring, up(2), ur(2), lane, lofs, ag, acc_c, acc_d);
+                    }
+                    p = 2;
+                }
+                for (; p + 1 < len; p += 2)
+                {
+                    const uint2_t raw = *((const uint2_t*) (qb + p * 64));
+                    const half4_t ag = u2_as_half4(raw.x, raw.y);
+                    ps_unit<K, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
+                    ps_unit<K, 1>(ring, up(p + 2), ur(p + 2), lane, lofs, ag, acc_c, acc_d);
+                }
+                if (p < len)
+                {
+                    const uint2_t raw = *((const uint2_t*) (qb + p * 64));
+                    const half4_t ag = u2_as_half4(raw.x, raw.y);
+                    ps_unit<K, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
+                }
+                const int col = 16 * (lane >> 3) + (lane & 7);
+                pslot[col] = acc_c[0]; pslot[col + 8] = acc_d[0];
+            };
+            if (cur.n > 0)
+            {
+                float* pw = part + (size_t) wave * 256;
+                run_seg(cur.stripA, cur.len0, P, cur.len1 > 0 ? cur.stripB : after_all, cur.len1 > 0 ? cur.rs : after_rs, cur.i0 * 64, pw);
+                if (cur.len1 > 0) run_seg(cur.stripB, cur.len1, 0, after_all, after_rs, 0, pw + 128);
+            }
+            ring_ready = cur.n > P && nxt.n > 0;
+            c_inc(PS_C_S);
+            if (wave == 0) PS_T(2);
+            cur = nxt; tl = tn;
+        }
+    }
+    else
+    {
+        // =========================================================================================== service waves
+        const int sw = wave - PS_SW, shw = 2 * sw + (lane >> 5);          // service wave 0..3, service half-wave 0..7
+        __builtin_amdgcn_s_setprio(3);                                    // the workgroup's latency chain runs here
+        bool aborted = false;
+        uint32_t tgt_a = 0u, tgt_r = 0u;
+        auto poll_cnt = [&] (int cop, uint32_t errbit)                    // every workgroup has arrived at counter `cop` (8 XCD shards)
+        {
+            if (aborted) return;
+            const uint32_t* c = a.cnt + ((size_t) cop * 8 + (lane & 7)) * 16;
+            const uint32_t expect = (uint32_t) ((ncu - (lane & 7) + 7) >> 3);
+            // two polls in flight, half a round trip apart: the arrival of the last workgroup is seen after ~ half a memory round trip on average
+            uint32_t v0 = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_s_sleep(12);
+            for (int spins = 0;; ++spins)
+            {
+                uint32_t v1 = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_ballot_w64(v0 < expect) == 0ull) break;
+                v0 = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_ballot_w64(v1 < expect) == 0ull) break;
+                if (spins > a.spin_limit)
+                {
+                    aborted = true;
+                    if (lane == 0) __hip_atomic_fetch_or(a.err, errbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        };
+        auto arrive = [&] (int cop) { if (lane == 0) __hip_atomic_fetch_add(a.cnt + ((size_t) cop * 8 + (cu & 7)) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+
+        const ps_op_p ops_c = (ps_op_p) a.ops;
+        PsTile tl_next = ps_load_tile(a.tiles, (size_t) cu);
+        for (int op = 0; op < nops; ++op)
+        {
+            const ps_op_p O = ops_c + op;
+            const PsTile tl = tl_next;
+            const bool active = tl.mat >= 0;
+            const int b0 = tl.b0, nb = active ? tl.nb : 0, W = active ? tl.ncb : 0;
+            const int in_type = O->in_type, out_type = O->out_type, kk = O->k, nblk = kk >> 7;
+            const uint32_t tag_out = (epoch << 12) | (uint32_t) (op + 1), tag_in = (epoch << 12) | (uint32_t) op;       // tag of op i = (epoch, i + 1), never 0
+            float* const bsum = bsum2 + (op & 1) * 64;
+            const int* const seginfo = seginfo2 + (op & 1) * 64;
+            if (sw == 0) PS_T(3);
+
+            // ---- static operands of the preparation tasks (weights: requested before any wait)
+            half4_t wv[4], sv[4], sva = { 0, 0, 0, 0 }, svb = sva;
+            float4_t sn4 = { 0.f, 0.f, 0.f, 0.f }, cs4 = sn4;
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) { wv[i] = sva; sv[i] = sva; }
+            const half_t* const suh_m = active ? O->mat[tl.mat].suh : nullptr;
+            // NORM: service half-wave shw holds blocks shw + 8 it of the row (and rotates those that lie in the slice); QKV / ACT: task block b0 + shw (planner: nb <= 8)
             if (in_type == PS_IN_NORM)
             {
                 #pragma unroll
-                for (int it = 0; it < 2; ++it)
+                for (int it = 0; it < 4; ++it)
                 {
-                    const int blk = min(hwid + 32 * it, nblk - 1);
-                    wv[it] = ((const half4_t*) (O->norm_w + (size_t) blk * 128))[l32];
-                    sv[it] = ((const half4_t*) (suh_m + (size_t) blk * 128))[l32];
+                    const int blk = min(shw + 8 * it, nblk - 1);
+                    wv[it] = ps_g((const half4_t*) (O->norm_w + (size_t) blk * 128))[l32];
+                    if (active) sv[it] = ps_g((const half4_t*) (suh_m + (size_t) blk * 128))[l32];
                 }
             }
-            else
+            else if (active)
             {
-                const int blk = b0 + tb;
-                sv[0] = ((const half4_t*) (suh_m + (size_t) blk * 128))[l32];
-                sva = ((const half4_t*) (O->in_svh[0] + (size_t) blk * 128))[l32];
-                if (in_type == PS_IN_ACT) svb = ((const half4_t*) (O->in_svh[1] + (size_t) blk * 128))[l32];
+                const int blk = b0 + min(shw, nb - 1);
+                sv[0] = ps_g((const half4_t*) (suh_m + (size_t) blk * 128))[l32];
+                sva = ps_g((const half4_t*) (O->in_svh[0] + (size_t) blk * 128))[l32];
+                if (in_type == PS_IN_ACT) svb = ps_g((const half4_t*) (O->in_svh[1] + (size_t) blk * 128))[l32];
                 else
                 {
                     const int ph = O->hd >> 3;
@@ -271,68 +442,70 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     }
                 }
             }
-        }
-        int* const seginfo = seginfo2 + (op & 1) * 64;
-        if (lane == 0) { int* si = seginfo + wave * 4; si[0] = cur.j0; si[1] = cur.len0; si[2] = cur.len1; }
 
-        // ---- the edge: every workgroup has finished (and drained) the previous op
-        if (wave == 0 && op > 0 && !aborted)
-        {
-            const uint32_t* c = a.cnt + ((size_t) (op - 1) * 8 + (lane & 7)) * 16;
-            const uint32_t expect = (uint32_t) ((ncu - (lane & 7) + 7) >> 3);
-            int spins = 0;
-            for (;;)
+            // the output side's operands too (pointers, the column scales of the two column blocks this half-wave may finish): requested here, used after the streaming
+            const ps_mat_p Mo = &O->mat[active ? tl.mat : 0];
+            unsigned long long* const slab_p = Mo->slab; const half_t* const svh_p = Mo->svh; const int S_op = O->S;
+            half4_t scp[2];
+            #pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2)
             {
-                const uint32_t v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__builtin_amdgcn_ballot_w64(v < expect) == 0ull) break;
-                if (++spins > a.spin_limit)
+                scp[r2] = half4_t{ 0, 0, 0, 0 };
+                if (active && out_type != PS_OUT_SLAB) scp[r2] = ps_g((const half4_t*) (svh_p + (size_t) (tl.cb0 + min(shw + 8 * r2, W - 1)) * 128))[l32];
+            }
+            asm volatile("" :: "s"(slab_p), "s"(S_op));
+
+            // one block: x * suh -> 128-point Hadamard -> fp16 quads in LDS (+ the block's sum for the mul1 affine term)
+            auto rotate_store = [&] (half4_t xv, half4_t svv, int blk_local, bool act)
+            {
+                xv = xv * svv;
+                float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
+                had128_f32x4(h0, h1, h2, h3, l32);
+                const half2_t o01 = { f2h(h0 * HAD_R_SCALE_128), f2h(h1 * HAD_R_SCALE_128) };
+                const half2_t o23 = { f2h(h2 * HAD_R_SCALE_128), f2h(h3 * HAD_R_SCALE_128) };
+                float ts = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
+                #pragma unroll
+                for (int i = 1; i < 32; i <<= 1) ts += xor_lane(ts, i);
+                if (act)
                 {
-                    aborted = true;
-                    if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+                    if (l32 == 0) bsum[blk_local] = ts;
+                    const int tr = blk_local * 8 + (l32 >> 2);
+                    const int q0 = 2 * (l32 & 1), sp = (l32 >> 1) & 1;
+                    char* base = quads + (size_t) (tr * 4 + q0) * 8 + sp * 4;
+                    *((half2_t*) base) = o01;
+                    *((half2_t*) (base + 8)) = o23;
                 }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        __syncthreads();                                                                 // B1
-        PS_T(1);
+            };
 
-        // ---- preparation tasks -> activation quads (+ block sums of the rotated activations for the mul1 affine term)
-        auto rotate_store = [&] (half4_t xv, half4_t svv, int blk_local, bool act)
-        {
-            xv = xv * svv;
-            float h0 = (float) xv.x, h1 = (float) xv.y, h2 = (float) xv.z, h3 = (float) xv.w;
-            had128_f32x4(h0, h1, h2, h3, l32);
-            const half2_t o01 = { f2h(h0 * HAD_R_SCALE_128), f2h(h1 * HAD_R_SCALE_128) };
-            const half2_t o23 = { f2h(h2 * HAD_R_SCALE_128), f2h(h3 * HAD_R_SCALE_128) };
-            float ts = ((float) o01.x + (float) o01.y) + ((float) o23.x + (float) o23.y);
-            #pragma unroll
-            for (int i = 1; i < 32; i <<= 1) ts += xor_lane(ts, i);
-            if (act)
+            if (in_type == PS_IN_NORM)
             {
-                if (l32 == 0) bsum[blk_local] = ts;
-                const int tr = blk_local * 8 + (l32 >> 2);
-                const int q0 = 2 * (l32 & 1), sp = (l32 >> 1) & 1;
-                char* base = quads + (size_t) (tr * 4 + q0) * 8 + sp * 4;
-                *((half2_t*) base) = o01;
-                *((half2_t*) (base + 8)) = o23;
-            }
-        };
-        if (in_type == PS_IN_NORM)
-        {
-            // exact RMSNorm: every workgroup reads the whole row (block sums of squares in rms_norm's order: norm.cu:20-120), then rotates its slice
-            half4_t xr[2];
-            #pragma unroll
-            for (int it = 0; it < 2; ++it)
-            {
-                const int blk = hwid + 32 * it;
-                xr[it] = half4_t{ 0, 0, 0, 0 };
-                if (32 * it < nblk)
+                // ---- the edge: every workgroup's adds of the previous op are in R (service wave 0 polls, the others follow its LDS word)
+                if (op > 0)
                 {
-                    const unsigned long long* rp = a.R + (size_t) min(blk, nblk - 1) * 128 + 4 * l32;
-                    const unsigned long long r0 = ps_ld64(rp), r1 = ps_ld64(rp + 1), r2 = ps_ld64(rp + 2), r3 = ps_ld64(rp + 3);
-                    auto fx = [] (unsigned long long v) -> half_t { return f2h(fx_to_float((uint32_t) v, (uint32_t) (v >> 32))); };
-                    xr[it] = half4_t{ fx(r0), fx(r1), fx(r2), fx(r3) };
+                    if (sw == 0) { poll_cnt(op - 1, 1u); c_set(PS_C_EDGE, (uint32_t) (op + 1)); }
+                    else c_spin(PS_C_EDGE, (uint32_t) (op + 1));
+                }
+                if (sw == 0) PS_T(4);
+                // exact RMSNorm: every workgroup reads the whole row -- service half-wave shw takes blocks shw + 8 i (block sums of squares in rms_norm's
+                // order: norm.cu:20-120) -- then rotates the blocks of its slice
+                half4_t xr[4];
+                const ps_rsrc_t rR = ps_rsrc(a.R);
+                #pragma unroll
+                for (int it = 0; it < 4; ++it)
+                {
+                    xr[it] = half4_t{ 0, 0, 0, 0 };
+                    if (8 * it < nblk)
+                    {
+                        const uint32_t o = (uint32_t) min(shw + 8 * it, nblk - 1) * 1024u + (uint32_t) l32 * 32u;
+                        const uint4_t ra = ps_ld128(rR, o), rb = ps_ld128(rR, o + 16u);
+                        auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h(fx_to_float(lo, hi)); };
+                        xr[it] = half4_t{ fx(ra.x, ra.y), fx(ra.z, ra.w), fx(rb.x, rb.y), fx(rb.z, rb.w) };
+                    }
+                }
+                #pragma unroll
+                for (int it = 0; it < 4; ++it) if (8 * it < nblk)
+                {
+                    const int blk = shw + 8 * it;
                     const float f0 = (float) xr[it].x, f1 = (float) xr[it].y, f2 = (float) xr[it].z, f3 = (float) xr[it].w;
                     float ssq = f0 * f0;
                     ssq = __builtin_fmaf(f1, f1, ssq); ssq = __builtin_fmaf(f2, f2, ssq); ssq = __builtin_fmaf(f3, f3, ssq);
@@ -340,52 +513,210 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     for (int i = 1; i < 32; i <<= 1) ssq += xor_lane(ssq, i);
                     if (blk < nblk && l32 == 0) ssblk[blk] = ssq;
                 }
-            }
-            __syncthreads();                                                             // B2
-            float s2 = l32 < nblk ? ssblk[l32] : 0.0f;
-            #pragma unroll
-            for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
-            if (nblk > 32)
-            {
-                float v = (32 + l32 < nblk) ? ssblk[32 + l32] : 0.0f;
+                if (sw == 0) PS_T(8);
+                // R is in registers: this workgroup passes the read gate in front of the next op that adds into R (no drain: loads only)
+                tgt_a += PS_NSV;
+                { const uint32_t old = c_inc(PS_C_A); if (old + 1u == tgt_a) arrive(op); }
+                c_spin(PS_C_A, tgt_a);
+                if (sw == 0) PS_T(9);
+                float s2 = l32 < nblk ? ssblk[l32] : 0.0f;
                 #pragma unroll
-                for (int i = 1; i < 32; i <<= 1) v += xor_lane(v, i);
-                s2 += v;
-            }
-            const float r = __frsqrt_rn(s2 / (float) kk + O->eps);
-            #pragma unroll
-            for (int it = 0; it < 2; ++it)
-            {
-                const int blk = hwid + 32 * it;
-                if (32 * it < nblk)
+                for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
+                const float r = __frsqrt_rn(s2 / (float) kk + O->eps);
+                #pragma unroll
+                for (int it = 0; it < 4; ++it) if (8 * it < nblk)
                 {
+                    const int blk = shw + 8 * it;                           // the block held in xr[it]
                     const bool act = active && blk >= b0 && blk < b0 + nb;
-                    const half4_t xv = { f2h((float) xr[it].x * (float) wv[it].x * r), f2h((float) xr[it].y * (float) wv[it].y * r),
-                                         f2h((float) xr[it].z * (float) wv[it].z * r), f2h((float) xr[it].w * (float) wv[it].w * r) };
-                    rotate_store(xv, sv[it], min(max(blk - b0, 0), max(nb - 1, 0)), act);
+                    if (__builtin_amdgcn_ballot_w64(act) != 0ull)           // (wave-uniform: neither half-wave holds a block of the slice -> nothing to rotate)
+                    {
+                        const half4_t xv = { f2h((float) xr[it].x * (float) wv[it].x * r), f2h((float) xr[it].y * (float) wv[it].y * r),
+                                             f2h((float) xr[it].z * (float) wv[it].z * r), f2h((float) xr[it].w * (float) wv[it].w * r) };
+                        rotate_store(xv, sv[it], min(max(blk - b0, 0), max(nb - 1, 0)), act);
+                    }
                 }
             }
-        }
-        else if (in_type == PS_IN_QKV)
-        {
-            // q block (b0 + tb) finished from the q|k|v op's slabs exactly as exl3_glue_qkv_tab finishes it (qkv_block_finish), then o_proj's input rotation
-            if (active && 2 * wave < nb)                                    // wave-uniform: this wave owns at least one task
+            else if (in_type == PS_IN_QKV)
             {
-                const bool act = hwid < nb;
-                const int blk = b0 + tb;
-                const float4_t ys = ps_slab_sum<8>(O->in_slab[0] + (size_t) blk * O->S_in * 128, O->S_in, l32);
-                const GemvRescale rs0 = { nullptr, nullptr, 0, 0.0f };
-                const half4_t xq = qkv_block_finish(ys, sva, rs0, 0, l32, 0.0f, 0.0f, true, O->rope_mode, O->hd >> 3, sn4, cs4);
-                if (act && (tl.flags & PS_TILE_Q_OUT) && a.q_out) ((half4_t*) (a.q_out + (size_t) blk * 128))[l32] = xq;
-                rotate_store(xq, sv[0], tb, act);
+                // q block (b0 + shw) finished from the q|k|v op's tagged slab lines exactly as exl3_glue_qkv_tab finishes it (qkv_block_finish), then o_proj's input rotation
+                if (sw == 0) PS_T(4);
+                if (active && 2 * sw < nb)                                 // wave-uniform: this wave owns at least one task
+                {
+                    const bool act = shw < nb;
+                    const int tb = min(shw, nb - 1), blk = b0 + tb;
+                    const ps_rsrc_t rq = ps_rsrc(O->in_slab[0]);
+                    float4_t ys;
+                    for (int spins = 0;; ++spins)
+                    {
+                        bool ok = true;
+                        ys = ps_slab_sum<4>(rq, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok);
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (sw == 0) PS_T(8);
+                    const GemvRescale rs0 = { nullptr, nullptr, 0, 0.0f };
+                    const half4_t xq = qkv_block_finish(ys, sva, rs0, 0, l32, 0.0f, 0.0f, true, O->rope_mode, O->hd >> 3, sn4, cs4);
+                    if (act && (tl.flags & PS_TILE_Q_OUT) && a.q_out) ((half4_t*) (a.q_out + (size_t) blk * 128))[l32] = xq;
+                    rotate_store(xq, sv[0], tb, act);
+                }
             }
-            if (tl.side >= 0 && wave == PS_WAVES - 1)
+            else
+            {
+                // silu(g) * u of block (b0 + shw): slab lines in slice order, output Hadamards, svh -- the arithmetic of glue_act_kernel / generation 4's ACT tasks
+                if (sw == 0) PS_T(4);
+                if (active && 2 * sw < nb)
+                {
+                    const bool act = shw < nb;
+                    const int tb = min(shw, nb - 1), blk = b0 + tb;
+                    const ps_rsrc_t rg = ps_rsrc(O->in_slab[0]), ru = ps_rsrc(O->in_slab[1]);
+                    float4_t vg, vu;
+                    for (int spins = 0;; ++spins)
+                    {
+                        bool ok = true;
+                        vg = ps_slab_sum<4>(rg, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok);
+                        vu = ps_slab_sum<4>(ru, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok);
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    if (sw == 0) PS_T(8);
+                    float g0, g1, g2, g3, u0, u1, u2, u3;
+                    out_had(vg, l32, g0, g1, g2, g3);
+                    out_had(vu, l32, u0, u1, u2, u3);
+                    const half4_t gh = half4_t{ f2h(g0), f2h(g1), f2h(g2), f2h(g3) } * sva;
+                    const half4_t uh = half4_t{ f2h(u0), f2h(u1), f2h(u2), f2h(u3) } * svb;
+                    auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
+                    const half4_t xa = { silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
+                    rotate_store(xa, sv[0], tb, act);
+                }
+            }
+            c_inc(PS_C_T);                                                   // (release: this wave's quads are in LDS)
+            if (op + 1 < nops)
+            {
+                // the next op's rectangle and the cache lines of its descriptor, requested under the streaming (scalar-cache misses otherwise open the next op)
+                tl_next = ps_load_tile(a.tiles, (size_t) (op + 1) * ncu + cu);
+                const int PS_CONST* on = (const int PS_CONST*) (O + 1);
+                const int t0 = on[0], t1 = on[16], t2 = on[32], t3 = on[48];
+                asm volatile("" :: "s"(t0), "s"(t1), "s"(t2), "s"(t3));
+            }
+            if (sw == 0) PS_T(5);
+
+            // ---- an op that adds into R: the read gate of the op that last read R (every workgroup has its values in registers); polled under the streaming
+            if (out_type == PS_OUT_ATOMIC)
+            {
+                if (sw == 0) { if (op > 0) poll_cnt(op - 1, 4u); c_set(PS_C_G, (uint32_t) (op + 1)); }
+            }
+
+            // ---- the streaming waves' partial rows are in LDS: service half-wave shw finishes column blocks shw, shw + 8 of the rectangle
+            c_spin(PS_C_S, (uint32_t) PS_SW * (uint32_t) (op + 1));
+            if (sw == 0) PS_T(6);
+            if (out_type == PS_OUT_ATOMIC && sw != 0) c_spin(PS_C_G, (uint32_t) (op + 1));
+            for (int j = shw; j < W; j += 2 * PS_NSV)
+            {
+                const int l = l32;
+                float4_t v = { 0.f, 0.f, 0.f, 0.f };
+#ifdef PS_SUM_BRANCHY
+                #pragma unroll
+                for (int w = 0; w < PS_SW; ++w)
+                {
+                    const int sj = seginfo[w * 4], s0 = seginfo[w * 4 + 1], s1 = seginfo[w * 4 + 2];
+                    const float4_t t0 = ((const float4_t*) (part + (size_t) w * 256))[l], t1 = ((const float4_t*) (part + (size_t) w * 256 + 128))[l];
+                    if (s0 > 0 && sj == j) { v.x += t0.x; v.y += t0.y; v.z += t0.z; v.w += t0.w; }
+                    if (s1 > 0 && sj + 1 == j) { v.x += t1.x; v.y += t1.y; v.z += t1.z; v.w += t1.w; }
+                }
+#else
+                // every record and every partial row is requested up front and masked in (branch-free: a conditional load here is a chain of 24 dependent LDS
+                // round trips, 1.6-2.2 us by the phase stamps); unused slots may hold anything: the mask is applied to the bits
+                // (four waves' records per round: twelve at once are 144 registers -- the kernel then spills into scratch, and a scratch demand of that
+                //  size makes the dispatcher hold workgroups back: the grid is no longer co-resident and the edges time out; seen once, round 5)
+                #pragma unroll 1
+                for (int w0 = 0; w0 < PS_SW; w0 += 4)
+                {
+                    uint4_t si[4]; float4_t t0[4], t1[4];
+                    #pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                    {
+                        si[i] = ((const uint4_t*) seginfo)[w0 + i];
+                        t0[i] = ((const float4_t*) (part + (size_t) (w0 + i) * 256))[l]; t1[i] = ((const float4_t*) (part + (size_t) (w0 + i) * 256 + 128))[l];
+                    }
+                    #pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                    {
+                        const uint32_t m0 = ((int) si[i].y > 0 && (int) si[i].x == j) ? 0xffffffffu : 0u, m1 = ((int) si[i].z > 0 && (int) si[i].x + 1 == j) ? 0xffffffffu : 0u;
+                        v.x += __uint_as_float(__float_as_uint(t0[i].x) & m0); v.y += __uint_as_float(__float_as_uint(t0[i].y) & m0);
+                        v.z += __uint_as_float(__float_as_uint(t0[i].z) & m0); v.w += __uint_as_float(__float_as_uint(t0[i].w) & m0);
+                        v.x += __uint_as_float(__float_as_uint(t1[i].x) & m1); v.y += __uint_as_float(__float_as_uint(t1[i].y) & m1);
+                        v.z += __uint_as_float(__float_as_uint(t1[i].z) & m1); v.w += __uint_as_float(__float_as_uint(t1[i].w) & m1);
+                    }
+                }
+#endif
+                float xs = 0.0f;
+                for (int q0 = 0; q0 < nb; q0 += 32) if (q0 + l < nb) xs += bsum[q0 + l];
+                #pragma unroll
+                for (int i = 1; i < 32; i <<= 1) xs += xor_lane(xs, i);
+                if (sw == 0 && j == shw) PS_T(10);
+                const float kinv = (float) u16_as_half(0x1eeeu), kbias = (float) u16_as_half(0xc931u);
+                const float bb = kbias * xs;
+                v.x = v.x * kinv + bb; v.y = v.y * kinv + bb; v.z = v.z * kinv + bb; v.w = v.w * kinv + bb;
+                const int cbl = tl.cb0 + j;
+                if (out_type == PS_OUT_SLAB)
+                {
+                    const ps_rsrc_t rsl = ps_rsrc(slab_p);
+                    const uint32_t o = ((uint32_t) cbl * (uint32_t) S_op + (uint32_t) tl.slice) * PS_LINE_BYTES + (uint32_t) l * 16;
+                    ps_st128(rsl, o, uint4_t{ __float_as_uint(v.x), tag_out, __float_as_uint(v.y), tag_out });
+                    ps_st128(rsl, o + 512, uint4_t{ __float_as_uint(v.z), tag_out, __float_as_uint(v.w), tag_out });
+                }
+                else
+                {
+                    float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
+                    had128_f32x4(h0, h1, h2, h3, l);
+                    h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
+                    const half4_t sc = j == shw ? scp[0] : scp[1];
+                    if (out_type == PS_OUT_ATOMIC)
+                    {
+                        const float o[4] = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
+                        unsigned long long* acc = a.R + (size_t) cbl * 128 + 4 * l;
+                        #pragma unroll
+                        for (int i = 0; i < 4; ++i) fx_atomic_add(acc + i, o[i]);
+                    }
+                    else
+                    {
+                        half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
+                        o = o * sc;
+                        ((half4_t*) (a.logits + (size_t) cbl * 128))[l] = o;
+                    }
+                }
+            }
+            if (sw == 0) PS_T(11);
+            if (out_type == PS_OUT_ATOMIC)
+            {
+                // this wave's atomics are acknowledged, then the last service wave announces the workgroup at the edge
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (sw == 0) PS_T(12);
+                tgt_r += PS_NSV;
+                { const uint32_t old = c_inc(PS_C_R); if (old + 1u == tgt_r) arrive(op); }
+            }
+            if (sw == 0) PS_T(7);
+
+            if (in_type == PS_IN_QKV && tl.side >= 0 && sw == PS_NSV - 1)
             {
                 // side job: one (K | V, 128-value block) of the new token: finished like q (RoPE on K only) and appended to the 4-bit paged cache
-                // (the arithmetic of glue_qkv_kernel: qkv_block_finish + kv_quant_regs); both half-waves compute it, the upper one stores
+                // (the arithmetic of glue_qkv_kernel: qkv_block_finish + kv_quant_regs); both half-waves compute it, the upper one stores.  After the
+                // workgroup's arrival: nothing in the launch reads the cache, and the k / v slab lines stay valid until the next layer's q|k|v op,
+                // which is two edges away
                 const int kvb = O->kvb, tsk = tl.side, isv = tsk >= kvb ? 1 : 0, hb = tsk - isv * kvb;
-                const half4_t sc = ((const half4_t*) (O->in_svh[1 + isv] + (size_t) hb * 128))[l32];
-                const float4_t ys = ps_slab_sum<8>(O->in_slab[1 + isv] + (size_t) hb * O->S_in * 128, O->S_in, l32);
+                const half4_t sc = ps_g((const half4_t*) (O->in_svh[1 + isv] + (size_t) hb * 128))[l32];
+                const ps_rsrc_t rk = ps_rsrc(O->in_slab[1 + isv]);
+                float4_t ys;
+                for (int spins = 0;; ++spins)
+                {
+                    bool ok = true;
+                    ys = ps_slab_sum<4>(rk, (uint32_t) hb * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok);
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                    if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
                 const GemvRescale rs0 = { nullptr, nullptr, 0, 0.0f };
                 const int ph = O->hd >> 3;
                 float4_t ksn = { 0.f, 0.f, 0.f, 0.f }, kcs = ksn;
@@ -403,148 +734,10 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 const int64_t token_pos = a.slots[0];
                 const int64_t gb = token_pos * (kvb * 4) + hb * 4 + (l32 >> 3);
                 uint32_t* cw = isv ? O->v_cache : O->k_cache; half_t* csc = isv ? O->v_scales : O->k_scales;
-                kv_quant_regs<4>((float) y.x, (float) y.y, (float) y.z, (float) y.w, cw + gb * 4, csc + gb, hwid == 2 * PS_WAVES - 1, lane);
+                kv_quant_regs<4>((float) y.x, (float) y.y, (float) y.z, (float) y.w, cw + gb * 4, csc + gb, (lane >> 5) == 1, lane);
             }
         }
-        else
-        {
-            // silu(g) * u of block (b0 + tb): slab lines in slice order, output Hadamards, svh -- the arithmetic of glue_act_kernel / generation 4's ACT tasks
-            if (active && 2 * wave < nb)
-            {
-                const bool act = hwid < nb;
-                const int blk = b0 + tb;
-                const float4_t vg = ps_slab_sum<4>(O->in_slab[0] + (size_t) blk * O->S_in * 128, O->S_in, l32);
-                const float4_t vu = ps_slab_sum<4>(O->in_slab[1] + (size_t) blk * O->S_in * 128, O->S_in, l32);
-                float g0, g1, g2, g3, u0, u1, u2, u3;
-                out_had(vg, l32, g0, g1, g2, g3);
-                out_had(vu, l32, u0, u1, u2, u3);
-                const half4_t gh = half4_t{ f2h(g0), f2h(g1), f2h(g2), f2h(g3) } * sva;
-                const half4_t uh = half4_t{ f2h(u0), f2h(u1), f2h(u2), f2h(u3) } * svb;
-                auto silu_mul = [] (half_t g, half_t u) -> half_t { float gf = (float) g; return f2h(gf / (1.0f + __expf(-gf)) * (float) u); };
-                const half4_t xa = { silu_mul(gh.x, uh.x), silu_mul(gh.y, uh.y), silu_mul(gh.z, uh.z), silu_mul(gh.w, uh.w) };
-                rotate_store(xa, sv[0], tb, act);
-            }
-        }
-        __syncthreads();                                                                 // B3
-        PS_T(2);
-
-        // ---- this wave's run of work units: decode-ahead units first (MFMA only), the rest streamed
-        auto run_seg = [&] (const uint32_t* strip, int len, int pre, const uint32_t* after, size_t after_rs, int qoff, float* pslot)
-        {
-            float4_t acc_c = { 0.f, 0.f, 0.f, 0.f }, acc_d = acc_c;
-            const char* qb = quads + qoff + quad_lane;
-            const size_t rs = cur.rs;
-            auto up = [&] (int q) -> const uint32_t* { return q < len ? strip + (size_t) (2 * q) * rs : after; };
-            auto ur = [&] (int q) -> size_t { return q < len ? rs : after_rs; };          // the refill target may lie in the NEXT op's matrix (another row pitch)
-            int p = 0;
-            if (pre > 0)
-            {
-                const uint2_t raw = *((const uint2_t*) qb);
-                const half4_t ag = u2_as_half4(raw.x, raw.y);
-                ps_consume<0>(dec0, ag, acc_c, acc_d);
-                if (len > 1)
-                {
-                    if (pre > 1)
-                    {
-                        half4_t tmp[16];
-                        #pragma unroll
-                        for (int i = 0; i < 16; ++i) tmp[i] = *((const half4_t*) (pdec_w + i * 512));
-                        ps_consume<1>(tmp, ag, acc_c, acc_d);
-                    }
-                    else ps_unit<K, 1>(ring, up(2), ur(2), lane, lofs, ag, acc_c, acc_d);
-                }
-                p = 2;
-            }
-            for (; p + 1 < len; p += 2)
-            {
-                const uint2_t raw = *((const uint2_t*) (qb + p * 64));
-                const half4_t ag = u2_as_half4(raw.x, raw.y);
-                ps_unit<K, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
-                ps_unit<K, 1>(ring, up(p + 2), ur(p + 2), lane, lofs, ag, acc_c, acc_d);
-            }
-            if (p < len)
-            {
-                const uint2_t raw = *((const uint2_t*) (qb + p * 64));
-                const half4_t ag = u2_as_half4(raw.x, raw.y);
-                ps_unit<K, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
-            }
-            const int col = 16 * (lane >> 3) + (lane & 7);
-            pslot[col] = acc_c[0]; pslot[col + 8] = acc_d[0];
-        };
-        if (cur.n > 0)
-        {
-            float* pw = part + (size_t) wave * 256;
-            run_seg(cur.stripA, cur.len0, P, cur.len1 > 0 ? cur.stripB : after_all, cur.len1 > 0 ? cur.rs : after_rs, cur.i0 * 64, pw);
-            if (cur.len1 > 0) run_seg(cur.stripB, cur.len1, 0, after_all, after_rs, 0, pw + 128);
-        }
-        const bool ring_has_next = cur.n > P && nxt.n > 0;
-        PS_T(3);
-        __syncthreads();                                                                 // B4
-        PS_T(4);
-
-        // ---- half-wave j finishes column block j of the rectangle
-        const int nred = active ? (W + 1) >> 1 : 1;
-        if (active && hwid < W)
-        {
-            const int j = hwid, l = l32;
-            float4_t v = { 0.f, 0.f, 0.f, 0.f };
-            for (int w = 0; w < PS_WAVES; ++w)
-            {
-                const int sj = seginfo[w * 4], s0 = seginfo[w * 4 + 1], s1 = seginfo[w * 4 + 2];
-                if (s0 > 0 && sj == j) { const float4_t t = ((const float4_t*) (part + (size_t) w * 256))[l]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-                if (s1 > 0 && sj + 1 == j) { const float4_t t = ((const float4_t*) (part + (size_t) w * 256 + 128))[l]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-            }
-            float xs = 0.0f;
-            for (int q0 = 0; q0 < nb; q0 += 32) if (q0 + l < nb) xs += bsum[q0 + l];
-            #pragma unroll
-            for (int i = 1; i < 32; i <<= 1) xs += xor_lane(xs, i);
-            const float kinv = (float) u16_as_half(0x1eeeu), kbias = (float) u16_as_half(0xc931u);
-            const float bb = kbias * xs;
-            v.x = v.x * kinv + bb; v.y = v.y * kinv + bb; v.z = v.z * kinv + bb; v.w = v.w * kinv + bb;
-            const PsMat* M = &O->mat[tl.mat];
-            const int cbl = tl.cb0 + j;
-            if (out_type == PS_OUT_SLAB) ps_st_f4(M->slab + ((size_t) cbl * O->S + tl.slice) * 128 + 4 * l, v);
-            else
-            {
-                float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
-                had128_f32x4(h0, h1, h2, h3, l);
-                h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
-                const half4_t sc = ((const half4_t*) (M->svh + (size_t) cbl * 128))[l];
-                if (out_type == PS_OUT_ATOMIC)
-                {
-                    const float o[4] = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
-                    unsigned long long* acc = a.R + (size_t) cbl * 128 + 4 * l;
-                    #pragma unroll
-                    for (int i = 0; i < 4; ++i) fx_atomic_add(acc + i, o[i]);
-                }
-                else
-                {
-                    half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
-                    o = o * sc;
-                    ((half4_t*) (a.logits + (size_t) cbl * 128))[l] = o;
-                }
-            }
-        }
-        if (wave < nred)
-        {
-            // this wave's output stores / atomics are acknowledged, then the last such wave announces the workgroup at the edge
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-            {
-                const uint32_t old = __hip_atomic_fetch_add(lctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if ((int) old == nred - 1)
-                {
-                    __hip_atomic_store(lctl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(a.cnt + ((size_t) op * 8 + (cu & 7)) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        PS_T(5);
-
-        // ---- decode-ahead of the next op: fills the wait at the edge
-        P = decode_ahead(nxt, ring_has_next);
-        PS_T(6);
-        cur = nxt; tl = tn;
+        if (cu == 0 && sw == 0 && lane == 0) *a.epoch = epoch + 1u;
     }
     #undef PS_T
 }
