@@ -18,7 +18,8 @@
 #define PS_IN_QKV 1        // input = q finished from the q|k|v op's slabs (output Hadamard, svh, RoPE, fp16); side job: the new token's K / V append
 #define PS_IN_ACT 2        // input = silu(g) * u finished from the gate|up op's slabs
 #define PS_OUT_SLAB 0      // raw rotated-basis partial rows -> slab[colblock][slice][128] tagged granules (finished by the consumer op's preparation; no edge)
-#define PS_OUT_ATOMIC 1    // output Hadamard + svh applied to the partial, added into R with integer atomics (exl3_gemv_args.h: fx_atomic_add)
+#define PS_OUT_ATOMIC 1    // the op adds into the residual row: partial rows as tagged lines, the OWNER of each 128-value block (the slice-0 workgroup) sums them, applies the
+                           // output Hadamard + svh, adds the block of the previous row version and publishes the new version's block as one tagged fp32 line
 #define PS_OUT_FINAL 2     // one slice: finished fp16 rows (lm_head)
 
 // LDS map of the kernel (bytes)
@@ -26,6 +27,7 @@
 #define PS_MISC_BYTES 1536                        // block sums of squares [64] | block sums [2][64] | segment records [2][16][4] | control words
 #define PS_PART_BYTES (12 * 2 * 512)              // partial rows [streaming wave][segment][128] fp32
 #define PS_PDEC_BYTES (12 * 16 * 64 * 8)          // decode-ahead unit #2 of every streaming wave: [wave][16 operand slots][64 lanes] x 8 B
+#define PS_GATH_BYTES (4 * 8 * 512)                // owners of residual-row blocks: [4 blocks][8 service half-waves][128] fp32 gathered sums
 #define PS_MAX_SLICE_BLOCKS 32                    // = the largest k / 128 of an RMSNorm op (hidden <= 4096): 8 service half-waves x 4 blocks
 
 struct PsMat
@@ -39,8 +41,8 @@ struct PsOp
 {
     int in_type, out_type, k, nmat;
     int S, S_in, hd, kvb;              // S: k-slices of this op (= slab lines per column block); S_in: slab lines of the producer op
-    int rope_mode, pad0;
-    float eps; int pad1;
+    int rope_mode, rver;               // rver: version of the residual row a PS_IN_NORM op reads / a PS_OUT_ATOMIC op produces (0 = the caller's fixed-point R)
+    float eps; int gate_op;            // PS_OUT_ATOMIC: the op whose read gate protects the row lines this op's owners overwrite (-1: none)
     PsMat mat[PS_MAX_MATS];
     const half_t* norm_w;              // PS_IN_NORM
     const unsigned long long* in_slab[3];   // PS_IN_QKV: q, k, v slab sets of the producer; PS_IN_ACT: gate, up
@@ -56,6 +58,7 @@ struct PsArgs
 {
     const PsOp* ops; const PsTile* tiles; int nops, ncu;
     unsigned long long* R; half_t* logits; half_t* q_out;
+    unsigned long long* rbuf;         // [2][PS_MAX_SLICE_BLOCKS] lines of 1 KiB: the residual row's versions >= 1 (version v in half v & 1), tagged fp32 pairs
     const float* rope_sin; const float* rope_cos; const int64_t* slots;
     uint32_t* cnt;                    // [nops][8 shards][16 words]: arrivals of edge `op`, zero at launch
     uint32_t* epoch;                  // run counter in device memory (tags of the slab granules): read at entry, + 1 at exit

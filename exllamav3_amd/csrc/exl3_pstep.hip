@@ -19,7 +19,7 @@ template __global__ void exl3_pstep_kernel<6>(const PsArgs);
 template __global__ void exl3_pstep_kernel<8>(const PsArgs);
 #endif
 
-#define PS_LDS_BYTES (PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES)
+#define PS_LDS_BYTES (PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES + PS_GATH_BYTES)
 static_assert(PS_LDS_BYTES <= 160 * 1024, "persistent step: LDS map exceeds a CU's 160 KiB");
 
 namespace
@@ -28,7 +28,7 @@ struct PsHandle
 {
     int K, nops, ncu, pmax, spin_limit, n_layers;
     PsOp* d_ops; PsTile* d_tiles; uint32_t* d_cnt; uint32_t* d_err; unsigned long long* d_dbg;
-    unsigned long long* d_slab_a; unsigned long long* d_slab_b; uint32_t* d_epoch;
+    unsigned long long* d_slab_a; unsigned long long* d_slab_b; unsigned long long* d_slab_c; unsigned long long* d_slab_d; unsigned long long* d_rbuf; uint32_t* d_epoch;
     size_t cnt_bytes, dbg_words;
     std::string desc;
 };
@@ -65,6 +65,7 @@ bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_t
         p.G = sum; p.wmax = 0;
         for (int i = 0; i < nmat; ++i) { const int w = (ncb[i] + p.g[i] - 1) / p.g[i]; if (w > p.wmax) p.wmax = w; }
         if (p.wmax > 12) continue;                                          // a streaming wave's run crosses at most one column-block boundary
+        if (out_type == PS_OUT_ATOMIC && p.wmax > 4) continue;             // an owner workgroup gathers at most four blocks of the residual row
         p.hmax = 4 * nbmax;
         const double cost = (double) p.wmax * p.hmax + 0.2 * S;
         if (cost < best_cost) { best_cost = cost; best = p; found = true; }
@@ -127,7 +128,9 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     std::vector<PsOp> ops((size_t) nops + 1);                       // + 1: the kernel forms the address of ops[nops] (never read)
     std::vector<PsTile> tiles((size_t) nops * ncu);
     memset(ops.data(), 0, ops.size() * sizeof(PsOp));
-    size_t slab_a_floats = 0, slab_b_floats = 0;
+    size_t slab_a_floats = 0, slab_b_floats = 0, slab_c_floats = 0, slab_d_floats = 0;
+    int rver = 0; std::vector<int> reader_of_version;               // op index of the RMSNorm op that reads version v of the residual row
+    reader_of_version.push_back(0);
     std::string desc;
     struct Pending { int op; int which; size_t off[PS_MAX_MATS]; };
     std::vector<Pending> slab_fix;
@@ -166,6 +169,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
         // q|k|v
         {
             PsOp& O = ops[op]; O.in_type = PS_IN_NORM; O.out_type = PS_OUT_SLAB; O.k = hidden; O.nmat = 3; O.eps = eps; O.norm_w = (const half_t*) L.norm1;
+            O.rver = rver; O.gate_op = -1; if ((int) reader_of_version.size() <= rver) reader_of_version.resize(rver + 1); reader_of_version[rver] = op;
             lin_to_mat(L.q, O.mat[0]); lin_to_mat(L.k, O.mat[1]); lin_to_mat(L.v, O.mat[2]);
             const int ncb[3] = { qdim / 128, kvdim / 128, kvdim / 128 };
             OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 3, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for q|k|v");
@@ -186,12 +190,15 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
             const int ncb[1] = { hidden / 128 };
             OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, qdim / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for o_proj");
             O.S = p.S; add_tiles(op, p, ncb, 1, qdim / 128, 2 * kvb);
+            O.rver = ++rver; O.gate_op = rver >= 3 ? reader_of_version[rver - 2] : -1;
+            { Pending f; f.op = op; f.which = 2; f.off[0] = 0; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * 128; if (n > slab_c_floats) slab_c_floats = n; }
             if (li == 0) { snprintf(line, sizeof(line), "o: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
             ++op;
         }
         // gate|up
         {
             PsOp& O = ops[op]; O.in_type = PS_IN_NORM; O.out_type = PS_OUT_SLAB; O.k = hidden; O.nmat = 2; O.eps = eps; O.norm_w = (const half_t*) L.norm2;
+            O.rver = rver; O.gate_op = -1; if ((int) reader_of_version.size() <= rver) reader_of_version.resize(rver + 1); reader_of_version[rver] = op;
             lin_to_mat(L.gate, O.mat[0]); lin_to_mat(L.up, O.mat[1]);
             const int ncb[2] = { inter / 128, inter / 128 };
             OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 2, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for gate|up");
@@ -211,6 +218,8 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
             const int ncb[1] = { hidden / 128 };
             OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, inter / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for down_proj");
             O.S = p.S; add_tiles(op, p, ncb, 1, inter / 128, 0);
+            O.rver = ++rver; O.gate_op = rver >= 3 ? reader_of_version[rver - 2] : -1;
+            { Pending f; f.op = op; f.which = 3; f.off[0] = 0; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * 128; if (n > slab_d_floats) slab_d_floats = n; }
             if (li == 0) { snprintf(line, sizeof(line), "down: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
             ++op;
         }
@@ -218,6 +227,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     {
         EXL3_CHECK_ARG(head->k == hidden && head->n % 128 == 0, "exl3_pstep_create: lm_head shape");
         PsOp& O = ops[op]; O.in_type = PS_IN_NORM; O.out_type = PS_OUT_FINAL; O.k = hidden; O.nmat = 1; O.eps = eps; O.norm_w = (const half_t*) final_norm;
+        O.rver = rver; O.gate_op = -1;
         lin_to_mat(*head, O.mat[0]);
         const int ncb[1] = { head->n / 128 };
         OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for the lm_head (vocab / 128 <= 16 x CUs)");
@@ -228,16 +238,20 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
 
     PsHandle* h = new PsHandle();
     h->K = K; h->nops = nops; h->ncu = ncu; h->pmax = 2; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
-    h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr; h->d_epoch = nullptr;
+    h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr; h->d_slab_c = nullptr; h->d_slab_d = nullptr; h->d_rbuf = nullptr; h->d_epoch = nullptr;
     h->cnt_bytes = (size_t) nops * 8 * 16 * 4; h->dbg_words = (flags & 1) ? (size_t) nops * ncu * 16 : 0;
     #define PS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { exl3_set_error("exl3_pstep_create: %s", hipGetErrorString(e_)); exl3_pstep_destroy(h); return EXL3_ERR_HIP; } } while (0)
     PS_TRY(hipMalloc(&h->d_slab_a, slab_a_floats * 8)); PS_TRY(hipMalloc(&h->d_slab_b, slab_b_floats * 8));
     PS_TRY(hipMemset(h->d_slab_a, 0, slab_a_floats * 8)); PS_TRY(hipMemset(h->d_slab_b, 0, slab_b_floats * 8));
+    PS_TRY(hipMalloc(&h->d_slab_c, slab_c_floats * 8)); PS_TRY(hipMalloc(&h->d_slab_d, slab_d_floats * 8));
+    PS_TRY(hipMemset(h->d_slab_c, 0, slab_c_floats * 8)); PS_TRY(hipMemset(h->d_slab_d, 0, slab_d_floats * 8));
+    PS_TRY(hipMalloc(&h->d_rbuf, (size_t) 2 * PS_MAX_SLICE_BLOCKS * 1024)); PS_TRY(hipMemset(h->d_rbuf, 0, (size_t) 2 * PS_MAX_SLICE_BLOCKS * 1024));
     for (const Pending& f : slab_fix)
     {
         PsOp& O = ops[f.op];
-        unsigned long long* base = f.which == 0 ? h->d_slab_a : h->d_slab_b;
+        unsigned long long* base = f.which == 0 ? h->d_slab_a : f.which == 1 ? h->d_slab_b : f.which == 2 ? h->d_slab_c : h->d_slab_d;
         for (int i = 0; i < O.nmat; ++i) O.mat[i].slab = base + f.off[i];
+        if (f.which >= 2) continue;                                   // (partial lines of an op that adds into the row: read by its own owners)
         PsOp& C = ops[f.op + 1];                                      // the consumer op reads these slab sets
         for (int i = 0; i < O.nmat; ++i) C.in_slab[i] = base + f.off[i];
     }
@@ -262,7 +276,7 @@ extern "C" int exl3_pstep_run(void* handle, void* R, void* logits, void* q_out, 
     a.ops = h->d_ops; a.tiles = h->d_tiles; a.nops = h->nops; a.ncu = h->ncu;
     a.R = (unsigned long long*) R; a.logits = (half_t*) logits; a.q_out = (half_t*) q_out;
     a.rope_sin = rope_sin; a.rope_cos = rope_cos; a.slots = slots;
-    a.cnt = h->d_cnt; a.epoch = h->d_epoch; a.err = h->d_err; a.dbg = h->d_dbg; a.spin_limit = h->spin_limit; a.pmax = h->pmax;
+    a.rbuf = h->d_rbuf; a.cnt = h->d_cnt; a.epoch = h->d_epoch; a.err = h->d_err; a.dbg = h->d_dbg; a.spin_limit = h->spin_limit; a.pmax = h->pmax;
     ps_launch(h->K, h->ncu, st, a);
     return exl3_check_launch("exl3_pstep_run");
 }
@@ -318,6 +332,9 @@ extern "C" int exl3_pstep_destroy(void* handle)
     if (h->d_dbg) (void) hipFree(h->d_dbg);
     if (h->d_slab_a) (void) hipFree(h->d_slab_a);
     if (h->d_slab_b) (void) hipFree(h->d_slab_b);
+    if (h->d_slab_c) (void) hipFree(h->d_slab_c);
+    if (h->d_slab_d) (void) hipFree(h->d_slab_d);
+    if (h->d_rbuf) (void) hipFree(h->d_rbuf);
     delete h;
     return EXL3_OK;
 }

@@ -96,6 +96,31 @@ __device__ __forceinline__ float4_t ps_slab_sum(ps_rsrc_t r, uint32_t blk_off, i
     return v;
 }
 
+// two slab sets of one block at once (gate & up): both sets' lines of a round are in flight before the first add
+template <int NB>
+__device__ __forceinline__ void ps_slab_sum2(ps_rsrc_t ra, ps_rsrc_t rb, uint32_t blk_off, int S, int l, uint32_t tag, bool& ok, float4_t& va, float4_t& vb)
+{
+    va = float4_t{ 0.f, 0.f, 0.f, 0.f }; vb = va;
+    for (int s = 0; s < S; s += NB)
+    {
+        uint4_t ta[NB][2], tb[NB][2];
+        #pragma unroll
+        for (int i = 0; i < NB; ++i)
+        {
+            const uint32_t o = blk_off + (uint32_t) min(s + i, S - 1) * PS_LINE_BYTES + (uint32_t) l * 16;
+            ta[i][0] = ps_ld128(ra, o); ta[i][1] = ps_ld128(ra, o + 512); tb[i][0] = ps_ld128(rb, o); tb[i][1] = ps_ld128(rb, o + 512);
+        }
+        #pragma unroll
+        for (int i = 0; i < NB; ++i) if (s + i < S)
+        {
+            ok = ok && ta[i][0].y == tag && ta[i][0].w == tag && ta[i][1].y == tag && ta[i][1].w == tag
+                    && tb[i][0].y == tag && tb[i][0].w == tag && tb[i][1].y == tag && tb[i][1].w == tag;
+            va.x += __uint_as_float(ta[i][0].x); va.y += __uint_as_float(ta[i][0].z); va.z += __uint_as_float(ta[i][1].x); va.w += __uint_as_float(ta[i][1].z);
+            vb.x += __uint_as_float(tb[i][0].x); vb.y += __uint_as_float(tb[i][0].z); vb.z += __uint_as_float(tb[i][1].x); vb.w += __uint_as_float(tb[i][1].z);
+        }
+    }
+}
+
 // one work unit = 2 tile rows of the wave's 128-column block against the activation group `ag` (exl3_gemv4.kspec.hip g4_unit, mul1 FAST variant)
 template <int K, int HALF>
 __device__ __forceinline__ void ps_unit(LaneWords<K> (&ring)[2], const uint32_t* __restrict__ refill, size_t refill_rs, int lane, int lofs, half4_t ag,
@@ -176,7 +201,8 @@ __device__ __forceinline__ void ps_consume(const half4_t (&dec)[16], half4_t ag,
 #define PS_C_T 2                       // + PS_NSV per op: the service waves' activation quads of the op are in LDS
 #define PS_C_S 3                       // + PS_SW per op: the streaming waves' partial rows of the op are in LDS
 #define PS_C_R 4                       // + PS_NSV per op that adds into R: the service waves' atomics are acknowledged
-#define PS_C_G 5                       // = op + 1 once the read gate in front of op's adds into R is satisfied
+#define PS_C_G 5                       // = op + 1 once the read gate in front of the row lines op's owners overwrite is satisfied
+#define PS_C_O 6                       // + PS_NSV per op whose blocks this workgroup owns: the service half-waves' gathered sums are in LDS
 
 // a streaming wave's run of work units inside its workgroup's rectangle: column-major over (column block j, unit i); at most two column blocks (planner: ncb <= PS_SW)
 template <int K>
@@ -223,6 +249,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
     uint32_t* const lctl = (uint32_t*) (seginfo2 + 128);            // the PS_C_* counters
     float* const part = (float*) (smem + PS_QUADS_BYTES + PS_MISC_BYTES);
     char* const pdec = smem + PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES;
+    float* const gath = (float*) (smem + PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES);      // [4 owned blocks][8 half-waves][128]
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -365,7 +392,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         const int sw = wave - PS_SW, shw = 2 * sw + (lane >> 5);          // service wave 0..3, service half-wave 0..7
         __builtin_amdgcn_s_setprio(3);                                    // the workgroup's latency chain runs here
         bool aborted = false;
-        uint32_t tgt_a = 0u, tgt_r = 0u;
+        uint32_t tgt_a = 0u, tgt_o = 0u;
         auto poll_cnt = [&] (int cop, uint32_t errbit)                    // every workgroup has arrived at counter `cop` (8 XCD shards)
         {
             if (aborted) return;
@@ -479,27 +506,49 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
 
             if (in_type == PS_IN_NORM)
             {
-                // ---- the edge: every workgroup's adds of the previous op are in R (service wave 0 polls, the others follow its LDS word)
-                if (op > 0)
-                {
-                    if (sw == 0) { poll_cnt(op - 1, 1u); c_set(PS_C_EDGE, (uint32_t) (op + 1)); }
-                    else c_spin(PS_C_EDGE, (uint32_t) (op + 1));
-                }
                 if (sw == 0) PS_T(4);
                 // exact RMSNorm: every workgroup reads the whole row -- service half-wave shw takes blocks shw + 8 i (block sums of squares in rms_norm's
-                // order: norm.cu:20-120) -- then rotates the blocks of its slice
+                // order: norm.cu:20-120) -- then rotates the blocks of its slice.  Version 0 of the row is the caller's fixed-point R; later versions are
+                // tagged fp32 lines written by the owners of the previous op's column blocks (no edge: the lines carry the producer's tag)
                 half4_t xr[4];
-                const ps_rsrc_t rR = ps_rsrc(a.R);
-                #pragma unroll
-                for (int it = 0; it < 4; ++it)
+                const int rver = O->rver;
+                if (rver == 0)
                 {
-                    xr[it] = half4_t{ 0, 0, 0, 0 };
-                    if (8 * it < nblk)
+                    const ps_rsrc_t rR = ps_rsrc(a.R);
+                    #pragma unroll
+                    for (int it = 0; it < 4; ++it)
                     {
-                        const uint32_t o = (uint32_t) min(shw + 8 * it, nblk - 1) * 1024u + (uint32_t) l32 * 32u;
-                        const uint4_t ra = ps_ld128(rR, o), rb = ps_ld128(rR, o + 16u);
-                        auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h(fx_to_float(lo, hi)); };
-                        xr[it] = half4_t{ fx(ra.x, ra.y), fx(ra.z, ra.w), fx(rb.x, rb.y), fx(rb.z, rb.w) };
+                        xr[it] = half4_t{ 0, 0, 0, 0 };
+                        if (8 * it < nblk)
+                        {
+                            const uint32_t o = (uint32_t) min(shw + 8 * it, nblk - 1) * 1024u + (uint32_t) l32 * 32u;
+                            const uint4_t ra = ps_ld128(rR, o), rb = ps_ld128(rR, o + 16u);
+                            auto fx = [] (uint32_t lo, uint32_t hi) -> half_t { return f2h(fx_to_float(lo, hi)); };
+                            xr[it] = half4_t{ fx(ra.x, ra.y), fx(ra.z, ra.w), fx(rb.x, rb.y), fx(rb.z, rb.w) };
+                        }
+                    }
+                }
+                else
+                {
+                    const ps_rsrc_t rR = ps_rsrc(a.rbuf + (size_t) (rver & 1) * PS_MAX_SLICE_BLOCKS * 128);
+                    for (int spins = 0;; ++spins)
+                    {
+                        bool ok = true;
+                        #pragma unroll
+                        for (int it = 0; it < 4; ++it)
+                        {
+                            xr[it] = half4_t{ 0, 0, 0, 0 };
+                            if (8 * it < nblk)
+                            {
+                                const uint32_t o = (uint32_t) min(shw + 8 * it, nblk - 1) * PS_LINE_BYTES + (uint32_t) l32 * 16u;
+                                const uint4_t ra = ps_ld128(rR, o), rb = ps_ld128(rR, o + 512u);
+                                ok = ok && ra.y == tag_in && ra.w == tag_in && rb.y == tag_in && rb.w == tag_in;
+                                xr[it] = half4_t{ f2h(__uint_as_float(ra.x)), f2h(__uint_as_float(ra.z)), f2h(__uint_as_float(rb.x)), f2h(__uint_as_float(rb.z)) };
+                            }
+                        }
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        __builtin_amdgcn_s_sleep(2);
                     }
                 }
                 #pragma unroll
@@ -514,7 +563,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     if (blk < nblk && l32 == 0) ssblk[blk] = ssq;
                 }
                 if (sw == 0) PS_T(8);
-                // R is in registers: this workgroup passes the read gate in front of the next op that adds into R (no drain: loads only)
+                // the row is in registers: this workgroup passes the read gate in front of the op that will overwrite this version's lines (loads only: no drain)
                 tgt_a += PS_NSV;
                 { const uint32_t old = c_inc(PS_C_A); if (old + 1u == tgt_a) arrive(op); }
                 c_spin(PS_C_A, tgt_a);
@@ -574,8 +623,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     for (int spins = 0;; ++spins)
                     {
                         bool ok = true;
-                        vg = ps_slab_sum<4>(rg, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok);
-                        vu = ps_slab_sum<4>(ru, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok);
+                        ps_slab_sum2<4>(rg, ru, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok, vg, vu);
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                         if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                         __builtin_amdgcn_s_sleep(2);
@@ -602,16 +650,16 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             }
             if (sw == 0) PS_T(5);
 
-            // ---- an op that adds into R: the read gate of the op that last read R (every workgroup has its values in registers); polled under the streaming
+            // ---- an op that produces a new version of the row: its owners overwrite the lines of the version before the previous one -- the read gate of
+            // the op that read THAT version (every workgroup had it in registers long ago); polled under the streaming
             if (out_type == PS_OUT_ATOMIC)
             {
-                if (sw == 0) { if (op > 0) poll_cnt(op - 1, 4u); c_set(PS_C_G, (uint32_t) (op + 1)); }
+                if (sw == 0) { const int gop = O->gate_op; if (gop >= 0) poll_cnt(gop, 4u); c_set(PS_C_G, (uint32_t) (op + 1)); }
             }
 
             // ---- the streaming waves' partial rows are in LDS: service half-wave shw finishes column blocks shw, shw + 8 of the rectangle
             c_spin(PS_C_S, (uint32_t) PS_SW * (uint32_t) (op + 1));
             if (sw == 0) PS_T(6);
-            if (out_type == PS_OUT_ATOMIC && sw != 0) c_spin(PS_C_G, (uint32_t) (op + 1));
             for (int j = shw; j < W; j += 2 * PS_NSV)
             {
                 const int l = l32;
@@ -660,8 +708,9 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 const float bb = kbias * xs;
                 v.x = v.x * kinv + bb; v.y = v.y * kinv + bb; v.z = v.z * kinv + bb; v.w = v.w * kinv + bb;
                 const int cbl = tl.cb0 + j;
-                if (out_type == PS_OUT_SLAB)
+                if (out_type != PS_OUT_FINAL)
                 {
+                    // the slice's partial row of column block cbl as one tagged line (both op kinds: no atomics, no drain, no edge)
                     const ps_rsrc_t rsl = ps_rsrc(slab_p);
                     const uint32_t o = ((uint32_t) cbl * (uint32_t) S_op + (uint32_t) tl.slice) * PS_LINE_BYTES + (uint32_t) l * 16;
                     ps_st128(rsl, o, uint4_t{ __float_as_uint(v.x), tag_out, __float_as_uint(v.y), tag_out });
@@ -669,34 +718,95 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 }
                 else
                 {
-                    float h0 = v.x, h1 = v.y, h2 = v.z, h3 = v.w;
-                    had128_f32x4(h0, h1, h2, h3, l);
-                    h0 *= HAD_R_SCALE_128; h1 *= HAD_R_SCALE_128; h2 *= HAD_R_SCALE_128; h3 *= HAD_R_SCALE_128;
+                    float h0, h1, h2, h3;
+                    out_had(v, l, h0, h1, h2, h3);
                     const half4_t sc = j == shw ? scp[0] : scp[1];
-                    if (out_type == PS_OUT_ATOMIC)
-                    {
-                        const float o[4] = { h0 * (float) sc.x, h1 * (float) sc.y, h2 * (float) sc.z, h3 * (float) sc.w };
-                        unsigned long long* acc = a.R + (size_t) cbl * 128 + 4 * l;
-                        #pragma unroll
-                        for (int i = 0; i < 4; ++i) fx_atomic_add(acc + i, o[i]);
-                    }
-                    else
-                    {
-                        half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
-                        o = o * sc;
-                        ((half4_t*) (a.logits + (size_t) cbl * 128))[l] = o;
-                    }
+                    half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
+                    o = o * sc;
+                    ((half4_t*) (a.logits + (size_t) cbl * 128))[l] = o;
                 }
             }
             if (sw == 0) PS_T(11);
-            if (out_type == PS_OUT_ATOMIC)
+            if (out_type == PS_OUT_ATOMIC && active && tl.slice == 0)
             {
-                // this wave's atomics are acknowledged, then the last service wave announces the workgroup at the edge
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (sw == 0) PS_T(12);
-                tgt_r += PS_NSV;
-                { const uint32_t old = c_inc(PS_C_R); if (old + 1u == tgt_r) arrive(op); }
+                // OWNERS of the residual row's blocks cb0 .. cb0 + W - 1 (the slice-0 workgroup of the column group).  All eight service half-waves gather: half-wave h
+                // takes the partial lines s = h, h + 8, ... of every owned block (tagged: re-loaded until complete; one round of loads), leaves its sum in LDS, and
+                // the half-wave that owns the block adds the eight sums in order h = 0..7, applies the output Hadamard and svh, adds the block of the previous
+                // row version and publishes the new version's block as ONE tagged line -- every workgroup's next RMSNorm reads it.  Replaces integer atomics
+                // into R + drain + arrival counter + poll (6.5-7 us from "streaming done" to "next op has the row" by the phase stamps; now ~4).
+                const ps_rsrc_t rsl = ps_rsrc(slab_p);
+                const int rv = O->rver;                                       // the version this op produces (>= 1)
+                for (int jj = 0; jj < W; ++jj)
+                {
+                    const int cbl = tl.cb0 + jj;
+                    float4_t ys = { 0.f, 0.f, 0.f, 0.f };
+                    if (shw < S_op)
+                    {
+                        const int nl = (S_op - shw + 7) >> 3;                  // lines shw, shw + 8, ...: at most 4 (S <= 32)
+                        for (int spins = 0;; ++spins)
+                        {
+                            bool ok = true;
+                            uint4_t t[4][2];
+                            #pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                            {
+                                const uint32_t o = ((uint32_t) cbl * (uint32_t) S_op + (uint32_t) (shw + 8 * min(i, nl - 1))) * PS_LINE_BYTES + (uint32_t) l32 * 16;
+                                t[i][0] = ps_ld128(rsl, o); t[i][1] = ps_ld128(rsl, o + 512);
+                            }
+                            ys = float4_t{ 0.f, 0.f, 0.f, 0.f };
+                            #pragma unroll
+                            for (int i = 0; i < 4; ++i) if (i < nl)
+                            {
+                                ok = ok && t[i][0].y == tag_out && t[i][0].w == tag_out && t[i][1].y == tag_out && t[i][1].w == tag_out;
+                                ys.x += __uint_as_float(t[i][0].x); ys.y += __uint_as_float(t[i][0].z); ys.z += __uint_as_float(t[i][1].x); ys.w += __uint_as_float(t[i][1].z);
+                            }
+                            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                            if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                    ((float4_t*) (gath + ((size_t) (jj & 3) * 8 + shw) * 128))[l32] = ys;
+                }
+                tgt_o += PS_NSV;
+                c_inc(PS_C_O);
+                for (int jj = shw; jj < W; jj += 2 * PS_NSV)
+                {
+                    const int cbl = tl.cb0 + jj, l = l32;
+                    float4_t rold;
+                    if (rv == 1)
+                    {
+                        const ps_rsrc_t r0 = ps_rsrc(a.R);
+                        const uint32_t ro = (uint32_t) cbl * 1024u + (uint32_t) l * 32u;
+                        const uint4_t ra = ps_ld128(r0, ro), rb = ps_ld128(r0, ro + 16u);
+                        rold = float4_t{ fx_to_float(ra.x, ra.y), fx_to_float(ra.z, ra.w), fx_to_float(rb.x, rb.y), fx_to_float(rb.z, rb.w) };
+                    }
+                    else
+                    {
+                        const ps_rsrc_t r0 = ps_rsrc(a.rbuf + (size_t) ((rv - 1) & 1) * PS_MAX_SLICE_BLOCKS * 128);
+                        const uint32_t ro = (uint32_t) cbl * PS_LINE_BYTES + (uint32_t) l * 16u;
+                        const uint4_t ra = ps_ld128(r0, ro), rb = ps_ld128(r0, ro + 512u);
+                        rold = float4_t{ __uint_as_float(ra.x), __uint_as_float(ra.z), __uint_as_float(rb.x), __uint_as_float(rb.z) };
+                    }
+                    c_spin(PS_C_O, tgt_o);
+                    float4_t ys = { 0.f, 0.f, 0.f, 0.f };
+                    #pragma unroll
+                    for (int h = 0; h < 8; ++h)
+                    {
+                        const float4_t t = ((const float4_t*) (gath + ((size_t) (jj & 3) * 8 + h) * 128))[l];
+                        ys.x += t.x; ys.y += t.y; ys.z += t.z; ys.w += t.w;
+                    }
+                    float h0, h1, h2, h3;
+                    out_had(ys, l, h0, h1, h2, h3);
+                    const half4_t sc = jj == shw ? scp[0] : scp[1];
+                    const float n0 = rold.x + h0 * (float) sc.x, n1 = rold.y + h1 * (float) sc.y, n2 = rold.z + h2 * (float) sc.z, n3 = rold.w + h3 * (float) sc.w;
+                    if (sw != 0) c_spin(PS_C_G, (uint32_t) (op + 1));
+                    const ps_rsrc_t rn = ps_rsrc(a.rbuf + (size_t) (rv & 1) * PS_MAX_SLICE_BLOCKS * 128);
+                    const uint32_t no = (uint32_t) cbl * PS_LINE_BYTES + (uint32_t) l * 16u;
+                    ps_st128(rn, no, uint4_t{ __float_as_uint(n0), tag_out, __float_as_uint(n1), tag_out });
+                    ps_st128(rn, no + 512, uint4_t{ __float_as_uint(n2), tag_out, __float_as_uint(n3), tag_out });
+                }
             }
+            if (sw == 0) PS_T(12);
             if (sw == 0) PS_T(7);
 
             if (in_type == PS_IN_QKV && tl.side >= 0 && sw == PS_NSV - 1)
