@@ -78,6 +78,17 @@ vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_floa
 u32 = ctypes.c_uint32
 
 
+class PstepLinear(ctypes.Structure):
+    """exl3_pstep_linear_t"""
+    _fields_ = [("trellis", vp), ("suh", vp), ("svh", vp), ("k", i32), ("n", i32)]
+
+
+class PstepLayer(ctypes.Structure):
+    """exl3_pstep_layer_t"""
+    _fields_ = [("q", PstepLinear), ("k", PstepLinear), ("v", PstepLinear), ("o", PstepLinear), ("gate", PstepLinear), ("up", PstepLinear),
+                ("down", PstepLinear), ("norm1", vp), ("norm2", vp), ("k_cache", vp), ("k_scales", vp), ("v_cache", vp), ("v_scales", vp)]
+
+
 def _declare(l):
     def sig(name, *argtypes):
         fn = getattr(l, name)
@@ -129,6 +140,15 @@ def _declare(l):
     sig("exl3_ar_epoch", vp, ctypes.POINTER(ctypes.c_uint32), vp)
     sig("exl3_ar_reduce", vp, vp, vp, vp, vp, i32, i32, vp)
     sig("exl3_ar_reduce_slabs", vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp)
+    # persistent decode step (exl3_pstep.hip): plan structures mirror include/exl3_hip.h
+    sig("exl3_pstep_create", ctypes.POINTER(vp), ctypes.POINTER(PstepLayer), i32, ctypes.POINTER(PstepLinear), vp, i32, i32, i32, i32, i32, i32, f32, i32, i32)
+    sig("exl3_pstep_run", vp, vp, vp, vp, vp, vp, vp, vp)
+    sig("exl3_pstep_error", vp, vp)
+    sig("exl3_pstep_set", vp, i32, i32)
+    sig("exl3_pstep_describe", vp, ctypes.c_char_p, i32)
+    sig("exl3_pstep_destroy", vp)
+    l.exl3_pstep_stamps.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), i64, vp]
+    l.exl3_pstep_stamps.restype = i64
     PP = ctypes.POINTER(vp)
     sig("exl3_reconstruct_had_multi_t", vp, i64, PP, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, vp)
     sig("exl3_gemv_ex", vp, PP, PP, PP, PP, PP, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)

@@ -674,6 +674,23 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     if (s1 > 0 && sj + 1 == j) { v.x += t1.x; v.y += t1.y; v.z += t1.z; v.w += t1.w; }
                 }
 #else
+                if (W == 1)
+                {
+                    // one column block (the usual rectangle of q|k|v, o, down): every wave's segment-0 row counts if the wave has a unit at all -- which follows
+                    // from the rectangle's size alone (scalar arithmetic): no records, twelve independent LDS reads, one round trip
+                    const int T1 = 4 * nb;
+                    float4_t t[PS_SW];
+                    #pragma unroll
+                    for (int w = 0; w < PS_SW; ++w) t[w] = ((const float4_t*) (part + (size_t) w * 256))[l];
+                    #pragma unroll
+                    for (int w = 0; w < PS_SW; ++w)
+                    {
+                        const uint32_t mk = ((T1 * (w + 1)) / PS_SW - (T1 * w) / PS_SW) > 0 ? 0xffffffffu : 0u;
+                        v.x += __uint_as_float(__float_as_uint(t[w].x) & mk); v.y += __uint_as_float(__float_as_uint(t[w].y) & mk);
+                        v.z += __uint_as_float(__float_as_uint(t[w].z) & mk); v.w += __uint_as_float(__float_as_uint(t[w].w) & mk);
+                    }
+                }
+                else
                 // every record and every partial row is requested up front and masked in (branch-free: a conditional load here is a chain of 24 dependent LDS
                 // round trips, 1.6-2.2 us by the phase stamps); unused slots may hold anything: the mask is applied to the bits
                 // (four waves' records per round: twelve at once are 144 registers -- the kernel then spills into scratch, and a scratch demand of that

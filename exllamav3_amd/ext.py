@@ -1831,3 +1831,70 @@ def attn_decode_qcache(q, out, k_cache, k_scales, v_cache, v_scales, block_table
                                               bsz, block_table.shape[1], k_cache.shape[1], kb, vb, hq, hkv, hd, int(max_len),
                                               float(scale if scale is not None else hd ** -0.5), _p(workspace),
                                               workspace.numel() if workspace is not None else 0, _stream(q)))
+
+
+# ---- persistent decode step (generation 5, exl3_pstep.hip) ------------------------------------------------------------------------------
+class PersistentStep:
+    """One launch for every quantized linear of a batch-1 decode step (all layers + lm_head) and the glue between them.  Replaces the per-layer graphs of
+    exllamav3_ext/libtorch/attention.cpp:246-330 (attention core excluded) + libtorch/mlp.cpp:14-91; the plan (rectangles per CU, slab / row buffers)
+    is built once from the layer tensors.  `layers`: dicts with LinearEXL3-like entries q, k, v, o, gate, up, down (attributes trellis, suh, svh, K) and
+    tensors norm1, norm2, kcache = (words, scales), vcache = (words, scales).  mul1 codebook, 4-bit cache, hidden <= 4096 (exl3_pstep_create checks)."""
+
+    def __init__(self, layers, head, final_norm, hidden: int, heads_q: int, heads_kv: int, head_dim: int, eps: float, rope_mode: int = 2, stamps: bool = False):
+        def lin(l):
+            t = l.trellis
+            _req(t.dim() == 3 and l.suh is not None and l.svh is not None, "PersistentStep: EXL3 linears with suh / svh")
+            return _lib.PstepLinear(_p(t), _p(l.suh), _p(l.svh), t.shape[0] * 16, t.shape[1] * 16)
+        K = layers[0]["q"].trellis.shape[-1] // 16
+        arr = (_lib.PstepLayer * len(layers))()
+        for i, L in enumerate(layers):
+            for name in ("q", "k", "v", "o", "gate", "up", "down"):
+                _req(L[name].trellis.shape[-1] // 16 == K and bool(L[name].mul1) and not bool(L[name].mcg), "PersistentStep: one K, mul1 codebook")
+                setattr(arr[i], name, lin(L[name]))
+            arr[i].norm1, arr[i].norm2 = _p(L["norm1"]), _p(L["norm2"])
+            (kw, ks), (vw, vs) = L["kcache"], L["vcache"]
+            arr[i].k_cache, arr[i].k_scales, arr[i].v_cache, arr[i].v_scales = _p(kw), _p(ks), _p(vw), _p(vs)
+        _req(head.trellis.shape[-1] // 16 == K and bool(head.mul1) and not bool(head.mcg), "PersistentStep: lm_head with the layers' K and codebook")
+        hl = lin(head)
+        _dev(final_norm)
+        self._h = ctypes.c_void_p(None)
+        self._keep = (layers, head, final_norm)          # the plan holds raw pointers
+        _check(_lib.lib().exl3_pstep_create(ctypes.byref(self._h), arr, len(layers), ctypes.byref(hl), _p(final_norm), int(hidden), int(heads_q), int(heads_kv),
+                                            int(head_dim), int(K), 2, float(eps), int(rope_mode), 1 if stamps else 0))
+        self.n_layers = len(layers)
+
+    def run(self, R: torch.Tensor, logits: torch.Tensor, q_out: torch.Tensor | None, rope_sin: torch.Tensor, rope_cos: torch.Tensor, slots: torch.Tensor):
+        """R: int64 fixed-point residual of the embedded token (fx_init / fx_init_prep, which also fill rope_sin / rope_cos / slots); graph-capturable."""
+        _dev(R)
+        _req(R.dtype == torch.int64 and logits.dtype == torch.half and slots.dtype == torch.int64, "PersistentStep.run: dtypes")
+        _check(_lib.lib().exl3_pstep_run(self._h, _p(R), _p(logits), _p(q_out), _p(rope_sin), _p(rope_cos), _p(slots), _stream(R)))
+
+    def error(self) -> bool:
+        """Synchronises; True if an edge / tagged line ever timed out since the last query (results invalid)."""
+        return bool(_check(_lib.lib().exl3_pstep_error(self._h, torch.cuda.current_stream().cuda_stream)))
+
+    def set(self, decode_ahead_units: int = -1, spin_limit: int = 0):
+        _check(_lib.lib().exl3_pstep_set(self._h, int(decode_ahead_units), int(spin_limit)))
+
+    def describe(self) -> str:
+        buf = ctypes.create_string_buffer(2048)
+        _check(_lib.lib().exl3_pstep_describe(self._h, buf, 2048))
+        return buf.value.decode()
+
+    def stamps(self):
+        """Phase stamps of the last run as a numpy array [ops][CUs][16] (100 MHz ticks); empty unless created with stamps=True (tools/pstep_stamps.py)."""
+        import numpy as np
+        n = (4 * self.n_layers + 1) * 1024 * 16
+        buf = (ctypes.c_uint64 * n)()
+        got = _lib.lib().exl3_pstep_stamps(self._h, buf, n, torch.cuda.current_stream().cuda_stream)
+        if got < 0:
+            raise RuntimeError(_lib.last_error())
+        return np.frombuffer(buf, dtype=np.uint64, count=int(got)).reshape(4 * self.n_layers + 1, -1, 16).copy()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib.lib().exl3_pstep_destroy(self._h)
+                self._h = ctypes.c_void_p(None)
+        except Exception:
+            pass

@@ -344,6 +344,7 @@ class SyntheticEXL3Llama:
         self.R = torch.zeros((bsz, s.hidden), dtype=torch.int64, device=dev)
         self.GU = torch.zeros((2, bsz, self.inter_local), dtype=torch.int64, device=dev)     # gate / up accumulators (fx_gu_atomic)
         self._state_bsz = bsz
+        self._pstep = None                                 # (the persistent step's plan holds the cache / state pointers)
 
     # ---- one decode step (bsz tokens, one per sequence) -----------------------------------------------
     def decode_step(self):
@@ -775,6 +776,39 @@ class SyntheticEXL3Llama:
             ext.exl3_gemv_ex_norm(self.x, self.final_norm, sc, self.eps, [self.lm_head.trellis], [self.logits], [self.lm_head.suh], [self.lm_head.svh],
                                   bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
         return self.logits
+
+    #: the persistent decode step (round 5, ext.PersistentStep): None = where it is the faster one by measurement (hidden <= 2048: Llama-3.2-1B 2218 vs 1965
+    #: tok/s in tools/experiments/pstep_harness; Llama-3.1-8B 623 vs 634: launches stay); EXL3_HIP_PSTEP=0/1 forces it.  Batch 1, one rank, mul1 codebook,
+    #: 4-bit cache, no attention core (the linears-only step), one K for all layers and the head
+    persistent = {"0": False, "1": True}.get(os.environ.get("EXL3_HIP_PSTEP", ""), None)
+
+    def persistent_applies(self) -> bool:
+        s = self.shape
+        same = all(_same_kind(L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"], self.lm_head) for L in self.layers)
+        return (self._state_bsz == 1 and self.tp == 1 and not self.with_attention and self.cb == 2 and self.kv_bits == 4 and same
+                and s.hidden % 128 == 0 and s.hidden <= 4096 and s.head_dim in (64, 128) and self.use_qkv_tab)
+
+    def decode_step_persistent(self):
+        """The whole decode step as ONE launch (ext.PersistentStep / exl3_pstep.hip) behind the step's set-up launch (fx_init_prep: fixed-point copy of the
+        input row, rope tables, cache rows): every quantized linear of every layer + the lm_head, RMSNorm, q|k|v epilogue with RoPE and the 4-bit K / V
+        append, silu * mul and the residual adds.  Same arithmetic per linear as decode_step_fx (generation 4's work unit, the same glue device functions);
+        the residual is kept in fp32 between the linears and the RMSNorm scale is exact (decode_step_fx: 64-bit fixed point, previous 1/rms + correction).
+        Falls back to decode_step_fx where it does not apply."""
+        if not self.persistent_applies():
+            return self.decode_step_fx()
+        hd = self.shape.head_dim
+        if getattr(self, "_pstep", None) is None:
+            layers = [dict(L, kcache=self.kcache[i], vcache=self.vcache[i]) for i, L in enumerate(self.layers)]
+            self._pstep = ext.PersistentStep(layers, self.lm_head, self.final_norm, self.shape.hidden, self.hq, self.hkv, hd, self.eps, rope_mode=2,
+                                             stamps=bool(os.environ.get("EXL3_HIP_PSTEP_STAMPS")))
+        ext.fx_init_prep(self.x0, self.R, self.ss, 1, self.inv_freq, self.positions, hd, self.block_table, self.page, self.rope_sin, self.rope_cos, self.kv_slots)
+        self._pstep.run(self.R, self.logits, self.q, self.rope_sin, self.rope_cos, self.kv_slots)
+        return self.logits
+
+    def decode_step_auto(self):
+        """decode_step_persistent where it applies and is the faster step (see `persistent`), else decode_step_fx."""
+        use = self.persistent if self.persistent is not None else self.shape.hidden <= 2048
+        return self.decode_step_persistent() if (use and self.persistent_applies()) else self.decode_step_fx()
 
     #: tensor-parallel ranks take the fx pipeline too (round 4): 7 launches per layer instead of the glue pipeline's 8-10
     fx_under_tp = os.environ.get("EXL3_HIP_FX_UNDER_TP", "1") != "0"

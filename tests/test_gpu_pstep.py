@@ -1,0 +1,127 @@
+"""The persistent decode step (ext.PersistentStep / exl3_pstep.hip: the whole step in ONE launch) against the ORACLE composition of the same step
+(reference graphs it replaces: libtorch/attention.cpp:246-330 + libtorch/mlp.cpp:14-91 per layer) and against the launch-per-op fx pipeline.
+Bars: logits 3e-2 * RMS end to end (the bar of every pipeline-vs-oracle test), appended K / V rows as in test_gpu_fullsize, hipGraph replay == eager bits,
+no edge / tagged-line time-out ever."""
+import numpy as np
+import pytest
+import torch
+from oracle import exl3_oracle as o
+from test_gpu_path import _oracle_decode
+from test_gpu_fullsize import (_np, _lin, _relerr, _oracle_attention_sublayer, _head_cols, _check_logits_on_cols, _replay_equals, _appended_kv_close)
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(shape, dev, K=4, pos=700, max_ctx=1024):
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import SyntheticEXL3Llama
+    ext.set_gemv_variant(1)
+    m = SyntheticEXL3Llama(shape, K=K, cb=2, device=dev, kv_bits=4, max_ctx=max_ctx)
+    m.alloc_state(1, pos=pos)
+    assert m.persistent_applies()
+    return m
+
+
+@pytest.mark.parametrize("hidden,inter,hq,hkv,hd,vocab,layers", [
+    (256, 512, 4, 2, 128, 384, 2),          # rectangles smaller than the chip: most workgroups idle in every op
+    (512, 1536, 8, 2, 64, 1024, 3),         # head_dim 64: two query heads per Hadamard block
+    (1024, 2816, 8, 8, 128, 3072, 2),       # MHA-shaped kv, an inter that is not a power of two
+])
+@pytest.mark.parametrize("K", [4, 3])
+def test_persistent_step_matches_oracle_and_fx_pipeline(dev, hidden, inter, hq, hkv, hd, vocab, layers, K):
+    from exllamav3_amd.llama_path import LlamaShape
+    shape = LlamaShape("tiny-ps", hidden, inter, layers, hq, hkv, hd, vocab)
+    m = _model(shape, dev, K=K)
+    ref = _oracle_decode(m, _np(m.x0))
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    lp = _np(m.decode_step_persistent().float()).copy()
+    assert not m._pstep.error()
+    assert np.isfinite(lp).all()
+    assert _relerr(lp, ref) < 3e-2, _relerr(lp, ref)
+    kv_p = [(_np(c).copy(), _np(s_).copy()) for c, s_ in m.kcache + m.vcache]
+    q_p = _np(m.q.float()).copy()
+    # the launch-per-op pipeline on the same tensors: same K / V words (the same device functions finish and quantize them), logits within the bar
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    lf = _np(m.decode_step_fx().float()).copy()
+    assert _relerr(lp, lf) < 2e-2
+    assert np.abs(q_p - _np(m.q.float())).max() < 2e-2 * max(1.0, float(np.abs(q_p).max()))
+    # (a quantization level may flip where the two pipelines' k / v differ by rounding -- split-k order, the residual's representation: compare the
+    #  dequantized rows, bound as in test_gpu_fullsize._appended_kv_close; a wrong slot / head / rope pairing misses it by an order of magnitude)
+    page, slot = int(m.block_table[0, 700 // m.page]), 700 % m.page
+    for (wa, sa), (c, s_) in zip(kv_p, m.kcache + m.vcache):
+        got = o.kv_dequant(wa[page, slot].view(np.uint32)[None, None], sa[page, slot][None, None], 4).reshape(-1).astype(np.float32)
+        want = o.kv_dequant(_np(c[page, slot]).view(np.uint32)[None, None], _np(s_[page, slot])[None, None], 4).reshape(-1).astype(np.float32)
+        assert np.abs(got - want).max() / np.sqrt((want ** 2).mean()) < 0.2
+        assert np.abs(wa).sum() == np.abs(wa[page, slot]).sum()          # nothing but the new token's row was written
+    # eager twice and graph replay: the same bits (slab lines summed in slice order, owners add in a fixed order: nothing depends on arrival order)
+    assert np.array_equal(_np(m.decode_step_persistent().float()), lp)
+    _replay_equals(m.decode_step_persistent, m, lp, reps=5)
+    assert not m._pstep.error()
+
+
+@pytest.mark.parametrize("ahead", [0, 1, 2])
+def test_persistent_step_decode_ahead_depths_give_the_same_bits(dev, ahead):
+    """Decode-ahead only changes WHEN a unit's weights are decoded, not the arithmetic: 0, 1 (registers) and 2 (registers + LDS) units give equal logits."""
+    from exllamav3_amd.llama_path import LlamaShape
+    m = _model(LlamaShape("tiny-ps", 512, 1536, 2, 8, 2, 64, 1024), dev)
+    base = _np(m.decode_step_persistent().float()).copy()
+    m._pstep.set(decode_ahead_units=ahead)
+    assert np.array_equal(_np(m.decode_step_persistent().float()), base)
+    assert not m._pstep.error()
+
+
+@pytest.mark.parametrize("name,hidden,inter,hq,hkv,hd", [("8b", 4096, 14336, 32, 8, 128), ("1b", 2048, 8192, 32, 8, 64)])
+def test_persistent_step_full_size_layer_and_head_vs_oracle(dev, name, hidden, inter, hq, hkv, hd):
+    """ONE layer of Llama-3.1-8B / Llama-3.2-1B shapes + the 128256-column lm_head at 4 bpw through the persistent step: logits on sampled column ranges
+    and the appended K / V rows against the oracle; replay == eager."""
+    from exllamav3_amd.llama_path import LlamaShape
+    shape = LlamaShape(name + "-1layer", hidden, inter, 1, hq, hkv, hd, 128256)
+    m = _model(shape, dev)
+    L = m.layers[0]
+    x, ov, k4, v = _oracle_attention_sublayer(m, L, _np(m.x0), None, 700)
+    xn, x = o.rms_norm(ov, _np(L["norm2"]), m.eps, residual_in=x)
+    gf, uf = _lin(L["gate"], xn).astype(np.float32), _lin(L["up"], xn).astype(np.float32)
+    a = (gf / (1 + np.exp(-gf)) * uf).astype(np.float16)
+    d = _lin(L["down"], a, out_fp32=True)
+    xn_f, _ = o.rms_norm(d, _np(m.final_norm), m.eps, residual_in=x)
+    logits = _np(m.decode_step_persistent().float()).copy()
+    assert not m._pstep.error()
+    _check_logits_on_cols(logits, m, xn_f, _head_cols(shape.vocab))
+    _appended_kv_close(m, 0, 1, 700, k4, v)
+    _replay_equals(m.decode_step_persistent, m, logits)
+
+
+@pytest.mark.parametrize("step", ["fx", "persistent"])
+def test_many_layer_drift_at_hidden_4096_vs_oracle(dev, step):
+    """EIGHT layers at Llama-3.1-8B width (hidden 4096, inter 14336, 32 / 8 heads x 128) + sampled head columns against the oracle: the residual's
+    representation (64-bit fixed point with the previous 1/rms + r_new / r_prev correction in decode_step_fx; fp32 rows with the exact scale in the
+    persistent step) followed through many layers at real width -- the one-layer full-size tests do not see an error that compounds."""
+    from exllamav3_amd.llama_path import LlamaShape
+    shape = LlamaShape("8b-8layers", 4096, 14336, 8, 32, 8, 128, 128256)
+    m = _model(shape, dev)
+    x, pend = _np(m.x0), None
+    for L in m.layers:
+        x, ov, _, _ = _oracle_attention_sublayer(m, L, x, pend, 700)
+        xn, x = o.rms_norm(ov, _np(L["norm2"]), m.eps, residual_in=x)
+        gf, uf = _lin(L["gate"], xn).astype(np.float32), _lin(L["up"], xn).astype(np.float32)
+        a = (gf / (1 + np.exp(-gf)) * uf).astype(np.float16)
+        pend = _lin(L["down"], a, out_fp32=True)
+    xn_f, _ = o.rms_norm(pend, _np(m.final_norm), m.eps, residual_in=x)
+    run = m.decode_step_fx if step == "fx" else m.decode_step_persistent
+    logits = _np(run().float()).copy()
+    if step == "persistent": assert not m._pstep.error()
+    _check_logits_on_cols(logits, m, xn_f, _head_cols(shape.vocab, seed=11))
+    _replay_equals(run, m, logits)
+
+
+def test_persistent_step_refuses_what_it_does_not_cover(dev):
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    m = SyntheticEXL3Llama(LlamaShape("tiny", 256, 512, 1, 4, 2, 128, 384), K=4, cb=0, device=dev, kv_bits=4, max_ctx=1024)     # 3INST codebook
+    m.alloc_state(1, pos=100)
+    assert not m.persistent_applies()
+    layers = [dict(L, kcache=m.kcache[i], vcache=m.vcache[i]) for i, L in enumerate(m.layers)]
+    with pytest.raises(RuntimeError):
+        ext.PersistentStep(layers, m.lm_head, m.final_norm, 256, m.hq, m.hkv, 128, m.eps)
+    lf = m.decode_step_persistent()                       # falls back to the fx pipeline
+    assert torch.isfinite(lf.float()).all()
