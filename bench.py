@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--attention", action="store_true", help="include decode attention over the quantized KV cache (context = 1000 tokens) in the timed step")
     ap.add_argument("--unfused", action="store_true", help="one launch per reference op instead of the fused pipeline")
-    ap.add_argument("--pipeline", choices=["tail", "glue", "resid", "fx", "unfused"], default="fx",
+    ap.add_argument("--pipeline", choices=["tail", "glue", "resid", "fx", "unfused", "persistent"], default="fx",
                     help="fx (default; batch <= 4 on one rank, otherwise = glue): residual stream in a 64-bit fixed-point accumulator, o_proj / "
                          "down_proj add into it with integer atomics, 5 launches/layer (fastest measured); glue: deferred-epilogue GEMVs + glue kernels "
                          "(8 launches/layer); tail: sublayer boundaries run inside the GEMV launches (4 launches/layer; the in-kernel cross-workgroup "
@@ -177,7 +177,10 @@ def pinned_logits_check(model_name, K, cb, bsz, dev, pipeline, tol=3e-2):
     if key not in pins:
         return {"pinned": False, "key": key}
     m = SyntheticEXL3Llama.pin_model(model_name, K, cb, dev, bsz)
-    step = {"tail": m.decode_step_tail, "glue": m.decode_step_fused, "resid": m.decode_step_resid, "fx": m.decode_step_fx, "unfused": m.decode_step}[pipeline]
+    step = {"tail": m.decode_step_tail, "glue": m.decode_step_fused, "resid": m.decode_step_resid, "fx": m.decode_step_fx, "unfused": m.decode_step,
+            "persistent": m.decode_step_persistent}[pipeline]
+    if pipeline == "persistent":
+        assert m.persistent_applies(), "bench.py: the persistent step does not cover this configuration"
     ref = np.asarray(pins[key]["logits"], dtype=np.float32).reshape(pins[key]["shape"])
     eager = step().float().cpu().numpy().copy()
     st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
@@ -192,6 +195,9 @@ def pinned_logits_check(model_name, K, cb, bsz, dev, pipeline, tol=3e-2):
     out = {"pinned": True, "key": key, "rel_err_vs_oracle": round(err, 5), "tol": tol, "ok": bool(err < tol),
            "graph_replay_bit_equal": bool(np.array_equal(replay, eager)), "step": step.__name__,
            "note": "max |logits - oracle logits| / RMS over one layer of the benchmark shape + a 2048-column head (host-seeded tensors; oracle values: tests/golden/bench_pins.json)"}
+    if pipeline == "persistent":
+        out["edge_timeout"] = bool(m._pstep.error())
+        assert not out["edge_timeout"], f"bench.py: the persistent step reported a timed-out edge: {out}"
     del m, g
     torch.cuda.empty_cache()
     assert out["ok"] and out["graph_replay_bit_equal"], f"bench.py: the timed pipeline does not reproduce the oracle's pinned logits: {out}"
@@ -242,7 +248,9 @@ def main():
     fused = pipeline != "unfused"
     run_step = (model.decode_step_fx if pipeline == "fx" else model.decode_step) if is_moe else \
         {"tail": model.decode_step_tail, "glue": model.decode_step_fused, "resid": model.decode_step_resid, "fx": model.decode_step_fx,
-         "unfused": model.decode_step}[pipeline]
+         "unfused": model.decode_step, "persistent": model.decode_step_persistent}[pipeline]
+    if pipeline == "persistent":
+        assert not is_moe and world == 1 and model.persistent_applies(), "--pipeline persistent: batch 1, one rank, mul1 codebook, 4-bit cache, no attention core, hidden <= 4096"
     # tensor-parallel decode: the o_proj / down_proj all-reduces go through the one-shot IPC push (exl3_allreduce.hip, fused with the residual
     # add) unless EXL3_HIP_TP_ALLREDUCE=rccl; the set-up self-tests against the collective library and every rank falls back together
     ipc_on = False
@@ -385,10 +393,11 @@ def main():
         # distinct cold weights) and the replay is bracketed by HIP events on the replay stream, so host/ctypes time
         # is excluded; the figure still contains the ~1-2 us inter-kernel gap of back-to-back graph nodes.
         bsz = args.batch
-        calls = model.gemv_calls(pipeline)
+        calls = model.gemv_calls("fx" if pipeline == "persistent" else pipeline)        # (persistent step: the launch-per-op GEMVs of the same shapes, for the per-launch table)
         per_layer = 4
         groups = [calls[i:len(calls) - 1:per_layer] for i in range(per_layer)] + [[calls[-1]] * 4]
         total_us, launches = 0.0, 0
+        group_us = []                                       # average microseconds per launch of each call type (q|k|v, o, gate|up, down, lm_head)
         st = torch.cuda.Stream()
         st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
@@ -414,6 +423,7 @@ def main():
                 else:
                     n = len(grp)
                 total_us += us; launches += n
+                group_us.append(us / n)
         torch.cuda.synchronize()
         ov = 0.0
         K = args.bits
@@ -440,11 +450,28 @@ def main():
                     kernel_only["note"] = "NOT measured in this run: average kernel duration of the step's GEMV launches in the committed rocprofv3 stats CSV"
             except Exception:
                 traffic = None
+        # per call type (VERDICT r4 task 7: the roofline must be re-derivable from this record alone): HIP-event microseconds per launch, algorithmic
+        # bytes, GB/s -- and the least-squares fit  t = const_us + bytes / stream_rate  over the five call types
+        per_launch, fit = None, None
+        if len(group_us) == 5:
+            names = ["q|k|v", "o", "gate|up", "down", "lm_head"]
+            shp = model.gemv_launches_per_step()
+            per_launch = []
+            for nm, us_, (k_, n_, cnt_) in zip(names, group_us, shp):
+                b_ = k_ * n_ * K // 8 + 2 * (k_ + n_) + 2 * bsz * (k_ + n_)
+                per_launch.append({"launch": nm, "k": int(k_), "n": int(n_), "per_step": int(cnt_), "us": round(us_, 2), "bytes": int(b_), "GBps": round(b_ / us_ / 1e3, 1)})
+            import numpy as _np
+            A_ = _np.array([[1.0, pl["bytes"]] for pl in per_launch]); y_ = _np.array([pl["us"] for pl in per_launch])
+            w_ = _np.array([pl["per_step"] for pl in per_launch], dtype=_np.float64) ** 0.5          # weight by how often the launch occurs in a step
+            c_, *_ = _np.linalg.lstsq(A_ * w_[:, None], y_ * w_, rcond=None)
+            fit = {"const_us": round(float(c_[0]), 2), "stream_TBps": round(1e-6 / float(c_[1]), 3) if c_[1] > 0 else None,
+                   "constants_share_of_step": round(float(c_[0]) * launches_step / (ms_per_step * 1e3), 3),
+                   "note": "t = const_us + bytes / stream_rate, weighted least squares over the call types above (weights = launches per step); the step also has its glue launches"}
         roofline = {"bound": "hbm", "kernel": ("exl3_gemv4_kernel" if bsz <= 4 else "exl3_gemm3_kernel") + " (fused trellis decode + Hadamard + MFMA GEMV), all GEMV launches of a decode step",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "kernel_only": kernel_only,
                     "avg_launch_us": round(avg_us, 2), "bytes_per_launch": int(bytes_per_launch),
-                    "launches_per_step": launches_step,
+                    "launches_per_step": launches_step, "per_launch": per_launch, "fit": fit,
                     "note": "HIP events around hipGraph replays of the step's GEMV launches (all layers, cold weights); includes inter-node gaps"
                             + ("" if fused else " and the split-k reduce launch") + "; compare profiles/ for rocprofv3 kernel-only durations"}
 
@@ -551,36 +578,55 @@ def main():
             bpt = mdl.shape.decode_bytes_per_token(mdl.K)
             return {"tok_s": round(bsz * 1e3 / msx, 1), "ms_per_step": round(msx, 4), "batch": bsz,
                     "frac_of_hbm_roofline": round((1e3 / msx) / (HBM_PEAK_GBPS * 1e9 / bpt), 4)}
+        pipe_x = "fx" if pipeline == "persistent" else pipeline          # (the other configs run the launch-per-op form of the timed pipeline)
         extra = {}
         # config 3, bs 16 (generation-3 GEMM + glue_rotate route)
         model.alloc_state(16)
-        extra["llama-3.1-8b_bs16"] = timed_decode(model, model.decode_step_fx if pipeline == "fx" else model.decode_step_fused, 16)
+        extra["llama-3.1-8b_bs16"] = timed_decode(model, model.decode_step_fx if pipe_x == "fx" else model.decode_step_fused, 16)
         # bs 1 with the quant-cache-direct decode attention over a 1000-token context in the step
         model.alloc_state(1)
         model.with_attention = True
-        extra["llama-3.1-8b_bs1_with_attention_ctx1000"] = timed_decode(model, model.decode_step_fx if pipeline == "fx" else model.decode_step_fused, 1)
+        extra["llama-3.1-8b_bs1_with_attention_ctx1000"] = timed_decode(model, model.decode_step_fx if pipe_x == "fx" else model.decode_step_fused, 1)
         model.with_attention = False
         # bs 1 with the EXACT GEMV variant (MFMA operands = the reference's fp16-rounded weights bit for bit; the headline runs the default variant,
         # unrounded lo + hi / raw byte sums, inside the same 1e-2 bound)
         if args.variant != 0:
             ext.set_gemv_variant(0)
-            extra["llama-3.1-8b_bs1_gemv_variant0_exact"] = timed_decode(model, model.decode_step_fx if pipeline == "fx" else model.decode_step_fused, 1)
+            extra["llama-3.1-8b_bs1_gemv_variant0_exact"] = timed_decode(model, model.decode_step_fx if pipe_x == "fx" else model.decode_step_fused, 1)
             ext.set_gemv_variant(args.variant)
-        extra["llama-3.1-8b_bs16"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, cb, 16, dev, pipeline if pipeline != "unfused" else "glue")
+        extra["llama-3.1-8b_bs16"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, cb, 16, dev, pipe_x if pipe_x != "unfused" else "glue")
+        # the persistent decode step at the headline's own shape (measured, NOT the default at this size: the launch-per-op pipeline is the faster step
+        # for Llama-3.1-8B; profiles/r05_persistent_*): same tensors, same gate
+        if pipe_x == "fx" and cb == 2 and model.persistent_applies():
+            extra["llama-3.1-8b_bs1_persistent_step"] = timed_decode(model, model.decode_step_persistent, 1)
+            extra["llama-3.1-8b_bs1_persistent_step"]["edge_timeout"] = bool(model._pstep.error())
+            extra["llama-3.1-8b_bs1_persistent_step"]["plan"] = model._pstep.describe()
+            extra["llama-3.1-8b_bs1_persistent_step"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, cb, 1, dev, "persistent")
+            model._pstep = None
         # the 3INST codebook (the older public quants, quant/codebook.cuh:56-90; SURVEY.md 8d "run 3INST and mul1"): same shapes, same pipeline
         if cb != 0:
             m3 = SyntheticEXL3Llama(shape, K=args.bits, cb=0, device=dev, backend=backend, kv_bits=args.kv_bits)
             m3.alloc_state(1)
-            extra["llama-3.1-8b_bs1_3inst"] = timed_decode(m3, m3.decode_step_fx if pipeline == "fx" else m3.decode_step_fused, 1)
-            extra["llama-3.1-8b_bs1_3inst"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, 0, 1, dev, pipeline if pipeline != "unfused" else "glue")
+            extra["llama-3.1-8b_bs1_3inst"] = timed_decode(m3, m3.decode_step_fx if pipe_x == "fx" else m3.decode_step_fused, 1)
+            extra["llama-3.1-8b_bs1_3inst"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, 0, 1, dev, pipe_x if pipe_x != "unfused" else "glue")
             del m3
             torch.cuda.empty_cache()
         # config 2: Llama-3.2-1B, bs 1
         m1 = SyntheticEXL3Llama(SHAPES["llama-3.2-1b"], K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits)
         m1.alloc_state(1)
-        extra["llama-3.2-1b_bs1"] = timed_decode(m1, m1.decode_step_fx if pipeline == "fx" else m1.decode_step_fused, 1)
-        extra["llama-3.2-1b_bs1"]["logits_check"] = pinned_logits_check("llama-3.2-1b", args.bits, cb, 1, dev, pipeline if pipeline != "unfused" else "glue")
-        if pipeline == "fx":
+        if pipe_x == "fx" and m1.persistent_applies() and (m1.persistent is None or m1.persistent):
+            # the persistent decode step (one launch per step: exl3_pstep.hip) is this model's default -- the launch-per-op fx pipeline beside it
+            extra["llama-3.2-1b_bs1"] = timed_decode(m1, m1.decode_step_auto, 1)
+            extra["llama-3.2-1b_bs1"]["step"] = "decode_step_persistent (one launch per step; 12 streaming + 4 service waves per CU, decode-ahead, tagged slab / row lines)"
+            extra["llama-3.2-1b_bs1"]["plan"] = m1._pstep.describe()
+            extra["llama-3.2-1b_bs1"]["edge_timeout"] = bool(m1._pstep.error())
+            extra["llama-3.2-1b_bs1"]["logits_check"] = pinned_logits_check("llama-3.2-1b", args.bits, cb, 1, dev, "persistent")
+            extra["llama-3.2-1b_bs1_launch_per_op"] = timed_decode(m1, m1.decode_step_fx, 1)
+            extra["llama-3.2-1b_bs1_launch_per_op"]["logits_check"] = pinned_logits_check("llama-3.2-1b", args.bits, cb, 1, dev, "fx")
+        else:
+            extra["llama-3.2-1b_bs1"] = timed_decode(m1, m1.decode_step_fx if pipe_x == "fx" else m1.decode_step_fused, 1)
+            extra["llama-3.2-1b_bs1"]["logits_check"] = pinned_logits_check("llama-3.2-1b", args.bits, cb, 1, dev, pipe_x if pipe_x != "unfused" else "glue")
+        if pipe_x == "fx":
             # ... and with the decode attention over a 1000-token 4-bit cache (head_dim 64: two kv heads per 128-value block of the matrix-pipe split kernel)
             m1.with_attention = True
             extra["llama-3.2-1b_bs1_with_attention_ctx1000"] = timed_decode(m1, m1.decode_step_fx, 1)
@@ -594,8 +640,8 @@ def main():
         from exllamav3_amd.tp import OneRankOfMany
         m70 = SyntheticEXL3Llama(SHAPES["llama-3.1-70b"], K=3, cb=cb, device=dev, backend=OneRankOfMany(8, dev), kv_bits=args.kv_bits)
         m70.alloc_state(1)
-        r70 = timed_decode(m70, m70.decode_step_fx if pipeline == "fx" else m70.decode_step_fused, 1)
-        r70["launches_per_layer"] = 7 if pipeline == "fx" else 10
+        r70 = timed_decode(m70, m70.decode_step_fx if pipe_x == "fx" else m70.decode_step_fused, 1)
+        r70["launches_per_layer"] = 7 if pipe_x == "fx" else 10
         rank_bytes = sum((k * n * 3 // 8 + 2 * (k + n)) * cnt for (k, n, cnt) in m70.gemv_launches_per_step())
         r70.update({"bits": 3, "tp": 8, "rank_bytes_per_token": int(rank_bytes),
                     "frac_of_hbm_roofline": round((1e3 / r70["ms_per_step"]) / (HBM_PEAK_GBPS * 1e9 / rank_bytes), 4),
@@ -610,7 +656,7 @@ def main():
         from exllamav3_amd.mixtral_path import MIXTRAL_8X7B
         mm = SyntheticEXL3Mixtral(MIXTRAL_8X7B, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits)
         mm.alloc_state(1)
-        extra["mixtral-8x7b_bs1"] = timed_decode(mm, mm.decode_step_fx if pipeline == "fx" else mm.decode_step, 1)
+        extra["mixtral-8x7b_bs1"] = timed_decode(mm, mm.decode_step_fx if pipe_x == "fx" else mm.decode_step, 1)
         if not args.no_prefill:
             # config 5's prefill leg: one chunk through the attention linears + the grouped-by-expert MoE tier (moe_path.forward_prefill); median of 3
             toks_m = args.prefill_tokens
@@ -646,7 +692,7 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{shape.name} EXL3 {args.bits}.0bpw {args.codebook} codebook, decode bs={args.batch}, "
                                    f"{model.n_layers} layers, {'attention TP=%d + expert-parallel MoE over %d rank(s)' % (world, world) if is_moe else 'TP=%d' % world}, {args.kv_bits}-bit KV append, "
-                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, { 'glue pipeline + indexed exl3_mgemm MoE block' if is_moe else {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (%d launches/layer)' % (7 if (args.batch == 1 and model.act_in_gemv and world == 1) else ((8 if (world == 1 and model.fold_rotate) else 10) if args.batch > 4 else 8)), 'resid': 'resid-in-GEMV pipeline (5 launches/layer: residual add + RMSNorm finished inside the consumer GEMV)' if (args.batch <= 4 and world == 1) else 'fused glue pipeline', 'fx': fx_desc if (args.batch <= model.fx_max_bsz and world == 1) else 'fused glue pipeline', 'unfused': 'one launch per reference op'}[pipeline] }; "
+                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, { 'glue pipeline + indexed exl3_mgemm MoE block' if is_moe else {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (%d launches/layer)' % (7 if (args.batch == 1 and model.act_in_gemv and world == 1) else ((8 if (world == 1 and model.fold_rotate) else 10) if args.batch > 4 else 8)), 'resid': 'resid-in-GEMV pipeline (5 launches/layer: residual add + RMSNorm finished inside the consumer GEMV)' if (args.batch <= 4 and world == 1) else 'fused glue pipeline', 'fx': fx_desc if (args.batch <= model.fx_max_bsz and world == 1) else 'fused glue pipeline', 'unfused': 'one launch per reference op', 'persistent': 'persistent decode step: ONE launch per step (exl3_pstep.hip: 12 streaming + 4 service waves per CU, decode-ahead, tagged slab / residual-row lines; residual kept in fp32)'}[pipeline] }; "
                                    f"{'attention core INCLUDED: quant-cache-direct decode attention over a 1000-token context' if args.attention else 'attention core excluded (SURVEY.md 2.1)'}",
                        "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
                        "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),
