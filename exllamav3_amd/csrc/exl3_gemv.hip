@@ -95,13 +95,21 @@ __global__ void mgemm_slot_reduce_kernel(void* C, int c_fp32, int num_tokens, in
                                          int min_index, int max_index)
 {
     const int64_t col = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= mn) return;
     if (min_index >= 0)
     {
-        int cnt = 0;
-        for (int i = 0; i < bszm; ++i) { const int64_t ix = indices[i]; cnt += (ix >= min_index && ix < max_index) ? 1 : 0; }
-        stride = cnt;                                                // num_tokens == 1 with an expert range (host-checked)
+        // the in-range slot count is uniform across the launch: one thread of the workgroup counts, the others read it from LDS (every
+        // thread used to re-read all bszm indices)
+        __shared__ int cnt_s;
+        if (threadIdx.x == 0)
+        {
+            int cnt = 0;
+            for (int i = 0; i < bszm; ++i) { const int64_t ix = indices[i]; cnt += (ix >= min_index && ix < max_index) ? 1 : 0; }
+            cnt_s = cnt;
+        }
+        __syncthreads();
+        stride = cnt_s;                                              // num_tokens == 1 with an expert range (host-checked)
     }
+    if (col >= mn) return;
     for (int t = 0; t < num_tokens; ++t)
     {
         if (c_fp32)
@@ -169,7 +177,7 @@ static int g_gemm3_min_rows = 5;     // passes with at least this many rows take
 extern "C" int exl3_set_gemm3_min_rows(int v) { g_gemm3_min_rows = v; return EXL3_OK; }
 // generation 3, 16-row passes: column blocks per workgroup (1, 2 or 4 = 4- / 8- / 16-wave workgroups sharing one activation tile); 0 = cost model
 static int g_gemm3_cpw = -1;
-static int gemm3_cpw() { if (g_gemm3_cpw < 0) { const char* e = getenv("EXL3_HIP_GEMM3_CPW"); g_gemm3_cpw = e ? atoi(e) : 0; } return g_gemm3_cpw; }
+static int gemm3_cpw() { if (g_gemm3_cpw < 0) { const char* e = getenv("EXL3_HIP_GEMM3_CPW"); const int v = e ? atoi(e) : 0; g_gemm3_cpw = (v == 1 || v == 2 || v == 4) ? v : 0; } return g_gemm3_cpw; }
 extern "C" int exl3_set_gemm3_cpw(int v) { g_gemm3_cpw = (v == 1 || v == 2 || v == 4) ? v : 0; return EXL3_OK; }
 static int gemm3_max_waves(int K, int mt, int rot)
 {
@@ -403,7 +411,11 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             const int maxw = gemm3_max_waves(K, mt_, (pass_flags & GEMV_IN_ROTATED) ? 1 : 0);
             const int nbk = k / 128, cus = ctx->num_cus;
             int forced_S = 0;
-            if (force_split > 0) { const int fb = (nbk + (force_split > nbk ? nbk : force_split) - 1) / (force_split > nbk ? nbk : force_split); forced_S = (nbk + fb - 1) / fb; }
+            if (force_split > 0)
+            {
+                const int fsq = force_split > nbk ? nbk : (force_split > 64 ? 64 : force_split);        // (the search below stops at 64 slices)
+                const int fb = (nbk + fsq - 1) / fsq; forced_S = (nbk + fb - 1) / fb;
+            }
             double best = 1e30;
             // two column blocks per workgroup wherever the instantiation's register budget allows 8 waves (measured best in the whole step; one block
             // otherwise; four only on request: exl3_set_gemm3_cpw / EXL3_HIP_GEMM3_CPW) -- the split then follows the cost model for that choice
@@ -417,11 +429,14 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
                     const int b = (nbk + s_ - 1) / s_;
                     if ((nbk + b - 1) / b != s_) continue;          // not a normalised split
                     if (forced_S > 0 && s_ != forced_S) continue;
-                    if ((long) total_cb * s_ * mp * 512 > (long) EXL3_WS_REGION_BYTES) continue;       // the slabs must fit one workspace region
+                    // the slabs must fit one workspace region -- a launch that writes none (one slice, finished output) always fits (with
+                    // every candidate rejected the split stayed 0 and the slice length below divided by it: lm_head-sized n at 33..64 rows)
+                    if ((s_ > 1 || deferred) && (long) total_cb * s_ * mp * 512 > (long) EXL3_WS_REGION_BYTES) continue;
                     const double c = gemm3_cost(groups, c3, s_, b, cus, deferred);
                     if (c < best) { best = c; g3cpw = c3; g3fs = s_; }
                 }
             }
+            if (g3fs < 1) { g3fs = 1; g3cpw = c3_want; }            // (forced split that is not normalised / nothing fits: one slice)
         }
         args.act_g = act_g; args.act_u = act_u; args.act_S = act_S;
         args.act_svh_g = (const half_t*) act_svh_g; args.act_svh_u = (const half_t*) act_svh_u;
@@ -470,6 +485,7 @@ static int run_mgemm(const void* A, const void* const* Bs, void* const* Cs, cons
             else fs = force_split;
         }
         const int S = g3 ? g3fs : choose_split(gen, total_cb, k, mp, ctx->num_cus, fs);
+        EXL3_CHECK_ARG(S >= 1, "exl3_gemm: internal: split factor %d", S);
         const int nb = k / 128;
         const int bps = (nb + S - 1) / S;
         int cbf = 0; int64_t wso = 0;

@@ -25,7 +25,10 @@
 // Non-finite or out-of-range contributions must not turn into finite garbage (the reference's fp16 residual carries Inf / NaN through to the logits):
 // a value that is NaN, Inf or >= GEMV_FX_LIMIT in magnitude (16x beyond the fp16 range the reference's residual saturates at) REPLACES the accumulator
 // with GEMV_FX_POISON by an atomic exchange -- not an add: k poisons cannot cancel mod 2^64 -- and every reader (fx_to_float) turns an accumulator
-// beyond +-2^60 into NaN.  Legal adds are < 2^52 each, so no number of them brings a poisoned accumulator back into range.
+// beyond +-2^60 into NaN.  Legal adds are < 2^52 each in magnitude: it takes > 768 maximal NEGATIVE adds after the poisoning to bring the
+// word (2^62) back under the readers' 2^60 threshold -- a step performs at most (layers x 2 boundaries x splits) ~ 2.6 k adds per address, of
+// alternating sign and typical magnitude 2^32..2^36, so this is out of reach in practice but not by construction; fx_add_kernel and the
+// all-reduce kernel keep a poisoned word sticky, the atomic path (fx_atomic_add) does not re-check it.
 #define GEMV_FX_LIMIT 1048576.0f
 #define GEMV_FX_POISON 0x4000000000000000ull
 #ifdef __HIPCC__

@@ -352,3 +352,27 @@ def test_gemm3_rotated_input_long_slices(dev, m, split):
     got = y_rot.float().cpu().numpy()
     assert np.isfinite(got).all()
     assert np.abs(got - ref).max() / np.sqrt((ref ** 2).mean()) < TOL
+
+
+def test_gemm3_lm_head_width_at_64_rows_and_oversized_forced_split(dev):
+    """at 33..64 rows an lm_head-wide n (1002 column blocks) made the generation-3 split search reject every candidate -- the slab
+    workspace test was applied to the one-slice launch that writes no slabs -- and the slice length was then divided by a zero split (SIGFPE on the host);
+    a forced split above the search's 64-slice cap ended the same way.  Both now run and match the oracle (sampled columns for the wide one)."""
+    from exllamav3_amd import ext
+    from test_gpu_fullsize import oracle_linear
+    ext.set_gemv_variant(1)
+    k, n, K, cb, m = 256, 128256, 4, 2, 64
+    tr, suh, svh = o.synth_linear(k, n, K, seed=5)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((m, k)).astype(np.float16)
+    y = torch.full((m, n), float("nan"), dtype=torch.half, device=dev)
+    rc = ext.exl3_gemm(_t(x, dev), _t(tr, dev), y, _t(suh, dev), None, _t(svh, dev), -1, False, True, 0)
+    assert rc >= 1
+    got = y.float().cpu().numpy()
+    assert np.isfinite(got).all()
+    cols = [(0, 256), (64000, 64256), (n - 128, n)]
+    ref = oracle_linear(x, tr, suh, svh, K, cb, cols=cols).astype(np.float32)
+    g = np.concatenate([got[:, a:b] for a, b in cols], axis=-1)
+    assert np.abs(g - ref).max() / np.sqrt((ref ** 2).mean()) < TOL
+    # forced split beyond 64 slices (96 Hadamard blocks): normalised, not a crash
+    assert _run(dev, 96 * 128, 256, 4, 2, 8, 1, force_split=80) < TOL
