@@ -590,6 +590,25 @@ def main():
         model.alloc_state(1)
         model.with_attention = True
         extra["llama-3.1-8b_bs1_with_attention_ctx1000"] = timed_decode(model, model.decode_step_fx if pipe_x == "fx" else model.decode_step_fused, 1)
+        # ... and over a 16 000-token context (VERDICT r4 task 4: the long-context cost of the quantized-cache attention on the driver line)
+        try:
+            import copy as _copy
+            m16 = SyntheticEXL3Llama(shape, K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits, max_ctx=16384)
+            m16.layers, m16.lm_head, m16.final_norm = model.layers, model.lm_head, model.final_norm      # the same weights: only the cache is longer
+            m16.alloc_state(1, pos=16000)
+            m16.with_attention = True
+            extra["llama-3.1-8b_bs1_with_attention_ctx16000"] = timed_decode(m16, m16.decode_step_fx if pipe_x == "fx" else m16.decode_step_fused, 1)
+            kvb = 2 * 16000 * model.hkv * shape.head_dim * args.kv_bits // 8 + 2 * 16000 * model.hkv * shape.head_dim // 32 * 2
+            d_ms = extra["llama-3.1-8b_bs1_with_attention_ctx16000"]["ms_per_step"] - ms_per_step
+            extra["llama-3.1-8b_bs1_with_attention_ctx16000"].update({
+                "cache_bytes_per_layer": int(kvb), "attention_sublayer_us_per_layer": round(d_ms * 1e3 / model.n_layers, 2),
+                "cache_words_frac_of_hbm": round(kvb / (d_ms * 1e-3 / model.n_layers) / 1e9 / HBM_PEAK_GBPS, 4) if d_ms > 0 else None,
+                "note": "attention_sublayer_us_per_layer = (this step - the headline step without attention) / layers: the q|k|v epilogue + context-split kernel + merge inside "
+                        "o_proj; cache_words_frac_of_hbm = the layer's quantized K / V words and scales over that time, against 8 TB/s"})
+            del m16
+            torch.cuda.empty_cache()
+        except Exception as e:          # (an out-of-memory on a shared box must not take the headline down)
+            extra["llama-3.1-8b_bs1_with_attention_ctx16000"] = {"error": repr(e)[:200]}
         model.with_attention = False
         # bs 1 with the EXACT GEMV variant (MFMA operands = the reference's fp16-rounded weights bit for bit; the headline runs the default variant,
         # unrounded lo + hi / raw byte sums, inside the same 1e-2 bound)

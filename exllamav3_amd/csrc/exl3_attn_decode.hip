@@ -238,17 +238,30 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
     const bool owner = FUSED && len - 1 >= t0 && len - 1 < t0 + a.split_tokens;
     // the wave's FIRST 16 tokens are requested here, ahead of the query preparation (which does not depend on them): at a 1000-token context a wave
     // has exactly one step, and the chain length -> block table -> cache words otherwise starts only after the queries are ready
-    uint32_t kw0[4] = { 0u, 0u, 0u, 0u }, vw0[4] = { 0u, 0u, 0u, 0u };
-    half4_t ksc0 = { 0, 0, 0, 0 }, vsc0 = ksc0;
-    if (t0 + 16 * wave < t1)
+    // (round 5) cache words as ONE 16-byte load per lane and operand: lane (token c, kg) takes the four words of 32-GROUP kg -- the 8 levels of word s are
+    // dims 32 kg + 8 s .. + 7, a permutation of the contraction index that the query fragments and the V tile follow -- instead of word kg of each of the
+    // four groups (four 4-byte loads); and the loop below keeps the words of TWO steps ahead in registers (it was one memory round trip per 16-token step:
+    // 17 us per layer at a 16 000-token context, 0.14 of the cache words' HBM time).  The page ids of the split (<= 4 pages) are read once, here.
+    const int pg_first = t0 / a.page_size;
+    int64_t pgs[4];
+    #pragma unroll
+    for (int i = 0; i < 4; ++i) pgs[i] = a.block_table[(size_t) b * a.blocks_per_seq + min(pg_first + i, a.blocks_per_seq - 1)];
+    auto page_of = [&] (const AttnArgs& aa, int tk) -> int64_t
     {
-        const int tk = min(t0 + 16 * wave + c, t1 - 1);
-        const int64_t pg = a.block_table[(size_t) b * a.blocks_per_seq + tk / a.page_size];
-        const int64_t gbase = (pg * a.page_size + (tk % a.page_size)) * G + h * 4;
-        #pragma unroll
-        for (int s = 0; s < 4; ++s) { kw0[s] = a.k_cache[(gbase + s) * 4 + kg]; vw0[s] = a.v_cache[(gbase + s) * 4 + kg]; }
-        ksc0 = *((const half4_t*) (a.k_scales + gbase)); vsc0 = *((const half4_t*) (a.v_scales + gbase));
-    }
+        const int pi = tk / aa.page_size - pg_first;
+        return pi == 0 ? pgs[0] : (pi == 1 ? pgs[1] : (pi == 2 ? pgs[2] : (pi == 3 ? pgs[3] : (int64_t) aa.block_table[(size_t) b * aa.blocks_per_seq + tk / aa.page_size])));
+    };
+    struct StepWords { uint4_t k, v; half_t ks, vs; };
+    auto load_step = [&] (const AttnArgs& aa, int st_) -> StepWords
+    {
+        StepWords r;
+        const int tk = max(min(t0 + 64 * st_ + 16 * wave + c, t1 - 1), 0);
+        const int64_t gbase = (page_of(aa, tk) * aa.page_size + (tk % aa.page_size)) * G + h * 4 + kg;
+        r.k = *((const uint4_t*) (aa.k_cache + gbase * 4)); r.v = *((const uint4_t*) (aa.v_cache + gbase * 4));
+        r.ks = aa.k_scales[gbase]; r.vs = aa.v_scales[gbase];
+        return r;
+    };
+    StepWords w0 = load_step(a, 0), w1 = load_step(a, 1);      // (four steps in flight measured the same: 22.2 vs 21.1 us per layer at 16 000 tokens -- the step is a dependent chain per wave, not a memory wait)
     if constexpr (FUSED)
     {
         // tasks, one per half-wave: 0 .. GQ - 1 = query head h * GQ + task; GQ = the new token's K row, GQ + 1 = its V row (kv head h; only in the
@@ -390,7 +403,7 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
     __syncthreads();
     half8_t qf[4];
     #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = c < 8 ? *((const half8_t*) (q_s + c * 128 + 32 * s + 8 * kg)) : half8_t{ 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int s = 0; s < 4; ++s) qf[s] = c < 8 ? *((const half8_t*) (q_s + c * 128 + 32 * kg + 8 * s)) : half8_t{ 0, 0, 0, 0, 0, 0, 0, 0 };
 
     float m_run = -1.0e30f, l_run = 0.0f;                       // of query head c (lanes with c >= GQ carry zero queries)
     float4_t oc[8];
@@ -404,30 +417,18 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
         const int tb = t0 + 64 * st + 16 * wave;                // the wave's 16 tokens of this step
         if (tb >= t1) break;                                    // wave-uniform: nothing left for this wave (its LDS tile is private)
         const int tk = min(tb + c, t1 - 1);
-        uint32_t kw[4], vw4[4];
-        half4_t ksc, vsc;
-        if (st == 0)
-        {
-            #pragma unroll
-            for (int s = 0; s < 4; ++s) { kw[s] = kw0[s]; vw4[s] = vw0[s]; }
-            ksc = ksc0; vsc = vsc0;
-        }
-        else
-        {
-            const int64_t pg = al.block_table[(size_t) b * al.blocks_per_seq + tk / al.page_size];
-            const int64_t gbase = (pg * al.page_size + (tk % al.page_size)) * G + h * 4;
-            #pragma unroll
-            for (int s = 0; s < 4; ++s) { kw[s] = al.k_cache[(gbase + s) * 4 + kg]; vw4[s] = al.v_cache[(gbase + s) * 4 + kg]; }
-            ksc = *((const half4_t*) (al.k_scales + gbase)); vsc = *((const half4_t*) (al.v_scales + gbase));
-        }
+        uint32_t kw[4] = { w0.k.x, w0.k.y, w0.k.z, w0.k.w }, vw4[4] = { w0.v.x, w0.v.y, w0.v.z, w0.v.w };
+        half_t ksc = w0.ks, vsc = w0.vs;
+        w0 = w1;
+        if (st + 2 < nsteps) w1 = load_step(al, st + 2);            // (two steps ahead; clamped addresses past the split's end are never used)
         if constexpr (FUSED)
         {
             // the new token's words come from this workgroup's LDS copy (its cache row is being written by this very launch)
             if (owner && tk == len - 1)
             {
                 #pragma unroll
-                for (int s = 0; s < 4; ++s) { kw[s] = new_kv[0][s * 4 + kg]; vw4[s] = new_kv[1][s * 4 + kg]; }
-                ksc = *((const half4_t*) new_sc[0]); vsc = *((const half4_t*) new_sc[1]);
+                for (int s = 0; s < 4; ++s) { kw[s] = new_kv[0][kg * 4 + s]; vw4[s] = new_kv[1][kg * 4 + s]; }
+                ksc = new_sc[0][kg]; vsc = new_sc[1][kg];
             }
         }
         // ---- scores of the 16 tokens for all heads: D[token][head]; lane (head c, kg) holds tokens 4 kg .. 4 kg + 3
@@ -435,7 +436,7 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
         #pragma unroll
         for (int s = 0; s < 4; ++s)
         {
-            const half_t k4 = ksc[s] * (half_t) 4.0f;
+            const half_t k4 = ksc * (half_t) 4.0f;
             const half8_t ka = aw_dequant8(kw[s], half2_t{ k4, k4 });
             sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[s], sc, 0, 0, 0);
         }
@@ -443,8 +444,8 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
         #pragma unroll
         for (int s = 0; s < 4; ++s)
         {
-            const half_t v4 = vsc[s] * (half_t) 4.0f;
-            *((half8_t*) (vw + c * AW_VS + 32 * s + 8 * kg)) = aw_dequant8(vw4[s], half2_t{ v4, v4 });
+            const half_t v4 = vsc * (half_t) 4.0f;
+            *((half8_t*) (vw + c * AW_VS + 32 * kg + 8 * s)) = aw_dequant8(vw4[s], half2_t{ v4, v4 });
         }
         // ---- online softmax of head c over the step's tokens (log2 domain)
         float mx = m_run;

@@ -44,7 +44,9 @@ __device__ __forceinline__ void g3_static_for(F&& f)
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); g3_static_for<I + 1, N>(f); }
 }
 
+#ifndef G3_XPAD
 #define G3_XPAD 16
+#endif
 #ifndef G3_NR
 #define G3_NR 4            // weight-ring depth in decode steps (A/B builds: 8)
 #endif

@@ -181,6 +181,35 @@ __device__ __forceinline__ void ps_predecode(LaneWords<K> (&ring)[2], const uint
     });
 }
 
+// ... the same unit decoded straight into the wave's LDS slots (the second decode-ahead unit): no 32-register staging array
+template <int K>
+__device__ __forceinline__ void ps_predecode_lds(LaneWords<K> (&ring)[2], const uint32_t* __restrict__ refill, size_t refill_rs, int lane, int lofs, char* pdec_w)
+{
+    ps_static_for<0, 2>([&] (auto uc)
+    {
+        constexpr int u = decltype(uc)::value;
+        uint32_t Wx[K + 1];
+        #pragma unroll
+        for (int i = 0; i < K; ++i) Wx[i + 1] = ring[u].w[i];
+        {
+            const uint32_t wl = ring[u].w[K - 1];
+            const uint32_t r1 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x121, 0xf, 0xf, true);
+            const uint32_t r9 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x129, 0xf, 0xf, true);
+            Wx[0] = (lane & 7) ? r1 : r9;
+        }
+        if (refill) ps_load_row<K>(ring[u], refill + (size_t) u * refill_rs + lofs);
+        ps_static_for<0, 4>([&] (auto qc)
+        {
+            constexpr int q = decltype(qc)::value;
+            half4_t bc[2], bd[2];
+            decode_quad<K, EXL3_CB_MUL1, 1, 8 * q>(Wx, bc);
+            decode_quad<K, EXL3_CB_MUL1, 1, 8 * q + 4>(Wx, bd);
+            *((half4_t*) (pdec_w + ((4 * u + q) * 2) * 512)) = bc[0];
+            *((half4_t*) (pdec_w + ((4 * u + q) * 2 + 1) * 512)) = bd[0];
+        });
+    });
+}
+
 template <int HALF>
 __device__ __forceinline__ void ps_consume(const half4_t (&dec)[16], half4_t ag, float4_t& acc_c, float4_t& acc_d)
 {
@@ -320,10 +349,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     P = 1;
                     if (Pm >= 2 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
                     {
-                        half4_t tmp[16];
-                        ps_predecode<K>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, tmp);
-                        #pragma unroll
-                        for (int i = 0; i < 16; ++i) *((half4_t*) (pdec_w + i * 512)) = tmp[i];
+                        ps_predecode_lds<K>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, pdec_w);
                         P = 2;
                     }
                 }
@@ -396,16 +422,17 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         auto poll_cnt = [&] (int cop, uint32_t errbit)                    // every workgroup has arrived at counter `cop` (8 XCD shards)
         {
             if (aborted) return;
-            const uint32_t* c = a.cnt + ((size_t) cop * 8 + (lane & 7)) * 16;
+            const uint32_t* cbase = a.cnt; asm volatile("" : "+s"(cbase));            // (address formed here, not hoisted: see the op loop)
+            const uint32_t PS_GLOBAL* c = ps_g(cbase + ((size_t) cop * 8 + (lane & 7)) * 16);
             const uint32_t expect = (uint32_t) ((ncu - (lane & 7) + 7) >> 3);
             // two polls in flight, half a round trip apart: the arrival of the last workgroup is seen after ~ half a memory round trip on average
-            uint32_t v0 = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t v0 = __hip_atomic_load((uint32_t PS_GLOBAL*) c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_sleep(12);
             for (int spins = 0;; ++spins)
             {
-                uint32_t v1 = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t v1 = __hip_atomic_load((uint32_t PS_GLOBAL*) c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__builtin_amdgcn_ballot_w64(v0 < expect) == 0ull) break;
-                v0 = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v0 = __hip_atomic_load((uint32_t PS_GLOBAL*) c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__builtin_amdgcn_ballot_w64(v1 < expect) == 0ull) break;
                 if (spins > a.spin_limit)
                 {
@@ -415,7 +442,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 }
             }
         };
-        auto arrive = [&] (int cop) { if (lane == 0) __hip_atomic_fetch_add(a.cnt + ((size_t) cop * 8 + (cu & 7)) * 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        auto arrive = [&] (int cop) { if (lane == 0) __hip_atomic_fetch_add((uint32_t PS_GLOBAL*) (a.cnt + ((size_t) cop * 8 + (cu & 7)) * 16), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
 
         const ps_op_p ops_c = (ps_op_p) a.ops;
         PsTile tl_next = ps_load_tile(a.tiles, (size_t) cu);
@@ -423,6 +450,10 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         {
             const ps_op_p O = ops_c + op;
             const PsTile tl = tl_next;
+            // (per-lane addresses off these bases are formed where they are used: hoisted out of the op loop they stay live for the whole launch and are
+            //  the values the allocator spills -- 36 B of scratch; the empty asm makes the base a fresh value per op)
+            const float* rope_sin_p = a.rope_sin; const float* rope_cos_p = a.rope_cos; half_t* q_out_p = a.q_out; half_t* logits_p = a.logits; uint32_t* cnt_p = a.cnt;
+            asm volatile("" : "+s"(rope_sin_p), "+s"(rope_cos_p), "+s"(q_out_p), "+s"(logits_p), "+s"(cnt_p));
             const bool active = tl.mat >= 0;
             const int b0 = tl.b0, nb = active ? tl.nb : 0, W = active ? tl.ncb : 0;
             const int in_type = O->in_type, out_type = O->out_type, kk = O->k, nblk = kk >> 7;
@@ -460,12 +491,12 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     if (O->rope_mode == 2)
                     {
                         const int f = 4 * (l32 & (ph - 1));
-                        sn4 = *((const float4_t*) (a.rope_sin + f)); cs4 = *((const float4_t*) (a.rope_cos + f));
+                        sn4 = *ps_g((const float4_t*) (rope_sin_p + f)); cs4 = *ps_g((const float4_t*) (rope_cos_p + f));
                     }
                     else
                     {
                         const int f = 2 * (l32 & ((O->hd >> 2) - 1));
-                        sn4.x = a.rope_sin[f]; sn4.y = a.rope_sin[f + 1]; cs4.x = a.rope_cos[f]; cs4.y = a.rope_cos[f + 1];
+                        sn4.x = ps_g(rope_sin_p)[f]; sn4.y = ps_g(rope_sin_p)[f + 1]; cs4.x = ps_g(rope_cos_p)[f]; cs4.y = ps_g(rope_cos_p)[f + 1];
                     }
                 }
             }
@@ -606,7 +637,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     if (sw == 0) PS_T(8);
                     const GemvRescale rs0 = { nullptr, nullptr, 0, 0.0f };
                     const half4_t xq = qkv_block_finish(ys, sva, rs0, 0, l32, 0.0f, 0.0f, true, O->rope_mode, O->hd >> 3, sn4, cs4);
-                    if (act && (tl.flags & PS_TILE_Q_OUT) && a.q_out) ((half4_t*) (a.q_out + (size_t) blk * 128))[l32] = xq;
+                    if (act && (tl.flags & PS_TILE_Q_OUT) && q_out_p) ((half4_t PS_GLOBAL*) (q_out_p + (size_t) blk * 128))[l32] = xq;
                     rotate_store(xq, sv[0], tb, act);
                 }
             }
@@ -623,7 +654,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     for (int spins = 0;; ++spins)
                     {
                         bool ok = true;
-                        ps_slab_sum2<4>(rg, ru, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok, vg, vu);
+                        ps_slab_sum2<3>(rg, ru, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok, vg, vu);
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                         if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                         __builtin_amdgcn_s_sleep(2);
@@ -679,15 +710,21 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     // one column block (the usual rectangle of q|k|v, o, down): every wave's segment-0 row counts if the wave has a unit at all -- which follows
                     // from the rectangle's size alone (scalar arithmetic): no records, twelve independent LDS reads, one round trip
                     const int T1 = 4 * nb;
-                    float4_t t[PS_SW];
                     #pragma unroll
-                    for (int w = 0; w < PS_SW; ++w) t[w] = ((const float4_t*) (part + (size_t) w * 256))[l];
-                    #pragma unroll
-                    for (int w = 0; w < PS_SW; ++w)
+                    for (int w0 = 0; w0 < PS_SW; w0 += 6)                  // (two rounds of six: twelve at once cost the kernel its last free registers)
                     {
-                        const uint32_t mk = ((T1 * (w + 1)) / PS_SW - (T1 * w) / PS_SW) > 0 ? 0xffffffffu : 0u;
-                        v.x += __uint_as_float(__float_as_uint(t[w].x) & mk); v.y += __uint_as_float(__float_as_uint(t[w].y) & mk);
-                        v.z += __uint_as_float(__float_as_uint(t[w].z) & mk); v.w += __uint_as_float(__float_as_uint(t[w].w) & mk);
+                        float4_t t[6];
+                        #pragma unroll
+                        for (int i = 0; i < 6; ++i) t[i] = ((const float4_t*) (part + (size_t) (w0 + i) * 256))[l];
+                        #pragma unroll
+                        for (int i = 0; i < 6; ++i)
+                        {
+                            const int w = w0 + i;
+                            const uint32_t mk = ((T1 * (w + 1)) / PS_SW - (T1 * w) / PS_SW) > 0 ? 0xffffffffu : 0u;
+                            v.x += __uint_as_float(__float_as_uint(t[i].x) & mk); v.y += __uint_as_float(__float_as_uint(t[i].y) & mk);
+                            v.z += __uint_as_float(__float_as_uint(t[i].z) & mk); v.w += __uint_as_float(__float_as_uint(t[i].w) & mk);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 else
@@ -740,7 +777,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     const half4_t sc = j == shw ? scp[0] : scp[1];
                     half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
                     o = o * sc;
-                    ((half4_t*) (a.logits + (size_t) cbl * 128))[l] = o;
+                    ((half4_t PS_GLOBAL*) (logits_p + (size_t) cbl * 128))[l] = o;
                 }
             }
             if (sw == 0) PS_T(11);
@@ -850,12 +887,12 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 if (O->rope_mode == 2)
                 {
                     const int f = 4 * (l32 & (ph - 1));
-                    ksn = *((const float4_t*) (a.rope_sin + f)); kcs = *((const float4_t*) (a.rope_cos + f));
+                    ksn = *ps_g((const float4_t*) (rope_sin_p + f)); kcs = *ps_g((const float4_t*) (rope_cos_p + f));
                 }
                 else
                 {
                     const int f = 2 * (l32 & ((O->hd >> 2) - 1));
-                    ksn.x = a.rope_sin[f]; ksn.y = a.rope_sin[f + 1]; kcs.x = a.rope_cos[f]; kcs.y = a.rope_cos[f + 1];
+                    ksn.x = ps_g(rope_sin_p)[f]; ksn.y = ps_g(rope_sin_p)[f + 1]; kcs.x = ps_g(rope_cos_p)[f]; kcs.y = ps_g(rope_cos_p)[f + 1];
                 }
                 const half4_t y = qkv_block_finish(ys, sc, rs0, 0, l32, 0.0f, 0.0f, !isv, O->rope_mode, ph, ksn, kcs);
                 const int64_t token_pos = a.slots[0];
