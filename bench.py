@@ -162,6 +162,14 @@ def cpu_baseline_reference(shape, K):
                       f"{shape.decode_bytes_per_token(K) / 1e9:.3f} GB/token model"}
 
 
+def dist_backend_name(backend):
+    try:
+        import torch.distributed as dist
+        return str(dist.get_backend()) if dist.is_initialized() else None
+    except Exception:
+        return None
+
+
 def pinned_logits_check(model_name, K, cb, bsz, dev, pipeline, tol=3e-2):
     """Correctness gate of the timed pipeline (VERDICT r3 weak #1 d; replaces `isfinite(logits)`): ONE layer of the benchmark's shape + a 2048-column
     lm_head built from a fixed host seed (SyntheticEXL3Llama.pin_model: the same tensors on every machine) goes through the SAME decode-step function
@@ -370,7 +378,12 @@ def main():
                                 dtype=torch.float64, device=dev)
         all_bytes = [torch.zeros_like(my_bytes) for _ in range(world)]
         torch.distributed.all_gather(all_bytes, my_bytes)
-        allreduce = {"message_bytes": args.batch * shape.hidden * 4, "per_step": 2 * model.n_layers,
+        try:
+            rccl_ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl_ver = None
+        allreduce = {"world_size": world, "collective_backend": dist_backend_name(backend), "rccl_version": rccl_ver,
+                     "message_bytes": args.batch * shape.hidden * 4, "per_step": 2 * model.n_layers,
                      "ipc_requested": ipc_requested, "ipc_enabled": bool(ipc_on), "ipc_fell_back": bool(ipc_requested and not ipc_on),
                      "ipc_fell_back_after_timing": ipc_fell_back_after_timing,
                      "bytes_per_token_per_rank": [int(b.item()) for b in all_bytes],

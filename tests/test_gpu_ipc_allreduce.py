@@ -154,3 +154,82 @@ def test_ipc_allreduce_two_processes_one_gpu(dev):
         assert res == {"enabled": True, "sums_exact": True, "resid_equal": True, "graph_replay": True, "slab_route": True, "tp_step_slab_route": True,
                        "fx_tp_close_to_glue_tp": True, "fx_tp_residual_bit_identical_across_ranks": True, "fx_tp_library_route": True,
                        "fx_tp_graph_replay": True}, (r, res)
+
+
+def _worker8(rank, world, port, ret):
+    """EIGHT ranks on the one GPU of the test box (the collectives over gloo, the all-reduce over the IPC push): what the driver's 8-GPU run does first
+    on real links -- rank-order sums bit-identical on every rank, the fx tensor-parallel step with a bit-identical residual on all eight, and the
+    time-out -> NaN -> every-rank-falls-back path for a rank that stops taking part."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from exllamav3_amd import ext
+    from exllamav3_amd.tp import TPBackendRCCL
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    ext.init(0)
+    be = TPBackendRCCL(rank, world, dev, backend="gloo")
+    ok = {}
+    try:
+        ok["enabled"] = be.enable_ipc_allreduce(2 * 4096)
+        ipc = be.ipc
+        g = torch.Generator(device=dev); g.manual_seed(300 + rank)
+        exact = True
+        for it in range(12):
+            m, hidden = [(1, 4096), (2, 1024), (1, 128)][it % 3]
+            y = torch.randn((m, hidden), device=dev, generator=g)
+            parts = [torch.empty_like(y) for _ in range(world)]
+            dist.all_gather(parts, y)
+            ref = parts[0].clone()
+            for r in range(1, world): ref += parts[r]                    # the rank-order fp32 sum the kernel computes: the same bits on every rank
+            out = torch.empty_like(y)
+            ipc.reduce(y, y_out=out)
+            exact = exact and bool(torch.equal(out, ref))
+        ok["rank_order_sums_bit_exact"] = exact and ipc.error() == 0
+        # ---- the fx pipeline under TP = 8: the fixed-point residual bit-identical on all ranks
+        from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+        shape = LlamaShape("tiny8", 1024, 1024, 2, 8, 8, 128, 1024)
+        model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, backend=be, kv_bits=4, max_ctx=1024)
+        model.alloc_state(1, pos=50)
+        dist.broadcast(model.x0, 0)
+        lfx = model.decode_step_fx().float().clone()
+        Rall = [torch.empty_like(model.R) for _ in range(world)]
+        dist.all_gather(Rall, model.R.clone())
+        ok["fx_tp8_residual_bit_identical"] = bool(torch.isfinite(lfx).all()) and all(bool(torch.equal(Rall[0], r)) for r in Rall) and ipc.error() == 0
+        ok["still_on"] = be.poll_ipc_allreduce()
+        # ---- a rank that stops taking part: the others' bounded spins give up, poison their outputs with NaN and raise the error word; the collective
+        # health check then takes EVERY rank off the IPC path together and later reductions go through the collective library
+        y = torch.ones((1, 1024), device=dev) * (rank + 1)
+        out = torch.zeros_like(y)
+        if rank != world - 1:
+            ipc.reduce(y, y_out=out)
+            torch.cuda.synchronize()
+            ok["timeout_poisons_with_nan"] = bool(torch.isnan(out).any())
+        else:
+            ok["timeout_poisons_with_nan"] = True                        # (this rank sat the call out)
+        ok["every_rank_falls_back"] = (be.poll_ipc_allreduce() is False) and be.ipc is None
+        r0 = torch.zeros((1, 1024), dtype=torch.half, device=dev); ss = torch.zeros((1, 8), device=dev)
+        be.all_reduce_resid(y.clone(), r0, ss, 1)                        # collective-library route
+        torch.cuda.synchronize()
+        ok["library_route_after_fallback"] = bool(torch.equal(r0.float(), torch.full_like(r0.float(), float(sum(range(1, world + 1))))))
+    except Exception as e:
+        ok["exception"] = repr(e)
+    ret[rank] = ok
+    try:
+        be.close()
+    except Exception:
+        pass
+
+
+def test_ipc_allreduce_eight_processes_one_gpu(dev):
+    world = 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29960 + (os.getpid() % 30)
+    mp.spawn(_worker8, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        res = ret.get(r)
+        assert res and "exception" not in res, (r, res)
+        assert res == {"enabled": True, "rank_order_sums_bit_exact": True, "fx_tp8_residual_bit_identical": True, "still_on": True,
+                       "timeout_poisons_with_nan": True, "every_rank_falls_back": True, "library_route_after_fallback": True}, (r, res)
