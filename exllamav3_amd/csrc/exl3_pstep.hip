@@ -73,6 +73,28 @@ bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_t
     return found;
 }
 
+// the rectangles of one op: workgroup (column group gi, slice s) = gi * S + s; every (column block, Hadamard block) of the op lies in exactly one
+// rectangle (tests/test_pstep_plan.py checks the partition on the CPU through exl3_pstep_plan_tiles)
+void fill_tiles(PsTile* T, int ncu, const OpPlan& p, const int* ncb, int nmat, int nblk, int side_tasks)
+{
+    for (int c = 0; c < ncu; ++c) { T[c].mat = -1; T[c].cb0 = 0; T[c].ncb = 0; T[c].b0 = 0; T[c].nb = 0; T[c].slice = 0; T[c].side = -1; T[c].flags = 0; }
+    int gi = 0;
+    for (int i = 0; i < nmat; ++i)
+        for (int j = 0; j < p.g[i]; ++j, ++gi)
+        {
+            const int c0 = (int) ((long long) j * ncb[i] / p.g[i]), c1 = (int) ((long long) (j + 1) * ncb[i] / p.g[i]);
+            for (int s = 0; s < p.S; ++s)
+            {
+                PsTile& t = T[gi * p.S + s];
+                t.mat = i; t.cb0 = c0; t.ncb = c1 - c0;
+                t.b0 = (int) ((long long) s * nblk / p.S); t.nb = (int) ((long long) (s + 1) * nblk / p.S) - t.b0;
+                t.slice = s;
+                if (i == 0 && j == 0) t.flags |= PS_TILE_Q_OUT;
+            }
+        }
+    for (int t = 0; t < side_tasks; ++t) T[(int) ((long long) t * ncu / side_tasks)].side = t;
+}
+
 void lin_to_mat(const exl3_pstep_linear_t& l, PsMat& m)
 {
     m.B = (const uint32_t*) l.trellis; m.suh = (const half_t*) l.suh; m.svh = (const half_t*) l.svh; m.slab = nullptr; m.n = l.n; m.tiles_n = l.n / 16;
@@ -137,23 +159,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
 
     auto add_tiles = [&] (int op, const OpPlan& p, const int* ncb, int nmat, int nblk, int side_tasks)
     {
-        PsTile* T = tiles.data() + (size_t) op * ncu;
-        for (int c = 0; c < ncu; ++c) { T[c].mat = -1; T[c].cb0 = 0; T[c].ncb = 0; T[c].b0 = 0; T[c].nb = 0; T[c].slice = 0; T[c].side = -1; T[c].flags = 0; }
-        int gi = 0;
-        for (int i = 0; i < nmat; ++i)
-            for (int j = 0; j < p.g[i]; ++j, ++gi)
-            {
-                const int c0 = (int) ((long long) j * ncb[i] / p.g[i]), c1 = (int) ((long long) (j + 1) * ncb[i] / p.g[i]);
-                for (int s = 0; s < p.S; ++s)
-                {
-                    PsTile& t = T[gi * p.S + s];
-                    t.mat = i; t.cb0 = c0; t.ncb = c1 - c0;
-                    t.b0 = (int) ((long long) s * nblk / p.S); t.nb = (int) ((long long) (s + 1) * nblk / p.S) - t.b0;
-                    t.slice = s;
-                    if (i == 0 && j == 0) t.flags |= PS_TILE_Q_OUT;
-                }
-            }
-        for (int t = 0; t < side_tasks; ++t) T[(int) ((long long) t * ncu / side_tasks)].side = t;
+        fill_tiles(tiles.data() + (size_t) op * ncu, ncu, p, ncb, nmat, nblk, side_tasks);
     };
 
     int op = 0;
@@ -263,6 +269,33 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     if (h->dbg_words) { PS_TRY(hipMalloc(&h->d_dbg, h->dbg_words * 8)); PS_TRY(hipMemset(h->d_dbg, 0, h->dbg_words * 8)); }
     #undef PS_TRY
     *handle_out = h;
+    return EXL3_OK;
+}
+
+// The planner alone (no device): the rectangles of one op kind of a Llama block for a chip of `ncu` CUs.  op_kind: 0 q|k|v, 1 o_proj, 2 gate|up, 3 down,
+// 4 lm_head.  tiles_out: [ncu][8] = {mat, cb0, ncb, b0, nb, slice, side, flags} (PsTile); S_out: its k-slices.  Host logic only: callable on a box without a GPU.
+extern "C" int exl3_pstep_plan_tiles(int hidden, int inter, int heads_q, int heads_kv, int head_dim, int vocab, int ncu, int op_kind, int32_t* tiles_out, int* S_out)
+{
+    EXL3_CHECK_ARG(tiles_out && S_out && ncu >= 16 && ncu <= 1024 && hidden % 128 == 0 && inter % 128 == 0 && vocab % 128 == 0 && (head_dim == 64 || head_dim == 128),
+                   "exl3_pstep_plan_tiles: bad shape");
+    const int qdim = heads_q * head_dim, kvdim = heads_kv * head_dim;
+    EXL3_CHECK_ARG(qdim % 128 == 0 && kvdim % 128 == 0, "exl3_pstep_plan_tiles: whole 128-value blocks of q and kv");
+    int ncb[3] = { 0, 0, 0 }, nmat = 1, nblk = hidden / 128, in_type = PS_IN_NORM, out_type = PS_OUT_SLAB, side = 0;
+    switch (op_kind)
+    {
+        case 0: ncb[0] = qdim / 128; ncb[1] = ncb[2] = kvdim / 128; nmat = 3; break;
+        case 1: ncb[0] = hidden / 128; nblk = qdim / 128; in_type = PS_IN_QKV; out_type = PS_OUT_ATOMIC; side = 2 * (kvdim / 128); break;
+        case 2: ncb[0] = ncb[1] = inter / 128; nmat = 2; break;
+        case 3: ncb[0] = hidden / 128; nblk = inter / 128; in_type = PS_IN_ACT; out_type = PS_OUT_ATOMIC; break;
+        case 4: ncb[0] = vocab / 128; out_type = PS_OUT_FINAL; break;
+        default: exl3_set_error("exl3_pstep_plan_tiles: op_kind 0..4"); return EXL3_ERR_ARG;
+    }
+    OpPlan p;
+    EXL3_CHECK_ARG(plan_op(ncu, nblk, ncb, nmat, in_type, out_type, p), "exl3_pstep_plan_tiles: no plan for this op on %d CUs", ncu);
+    std::vector<PsTile> T((size_t) ncu);
+    fill_tiles(T.data(), ncu, p, ncb, nmat, nblk, side);
+    memcpy(tiles_out, T.data(), (size_t) ncu * sizeof(PsTile));
+    *S_out = p.S;
     return EXL3_OK;
 }
 

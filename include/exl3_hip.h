@@ -630,6 +630,9 @@ typedef struct
 } exl3_pstep_layer_t;
 int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* layers, int n_layers, const exl3_pstep_linear_t* head, const void* final_norm,
                       int hidden, int heads_q, int heads_kv, int head_dim, int K, int cb, float eps, int rope_mode, int flags);
+/* the planner alone, host logic (no device needed): rectangles [ncu][8] = {matrix, first column block, column blocks, first Hadamard block, blocks, slice,
+ * side task, flags} of one op kind (0 q|k|v, 1 o_proj, 2 gate|up, 3 down, 4 lm_head) for a chip of ncu CUs; *S_out = its k-slices */
+int exl3_pstep_plan_tiles(int hidden, int inter, int heads_q, int heads_kv, int head_dim, int vocab, int ncu, int op_kind, int32_t* tiles_out, int* S_out);
 int exl3_pstep_run(void* handle, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream);
 int exl3_pstep_error(void* handle, void* stream);
 int exl3_pstep_set(void* handle, int decode_ahead_units, int spin_limit);
