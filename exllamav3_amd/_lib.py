@@ -217,4 +217,5 @@ def _declare(l):
     sig("exl3_set_gemv_gen4", i32)
     sig("exl3_set_gemm3_min_rows", i32)
     sig("exl3_set_gemm3_cpw", i32)
+    sig("exl3_set_attn_wide_waves", i32)
     sig("exl3_set_gemv_defer_wg_per_cu", i32)

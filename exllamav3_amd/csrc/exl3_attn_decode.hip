@@ -217,16 +217,19 @@ __device__ __forceinline__ half8_t aw_dequant8(uint32_t x, half2_t sc4)
 // (GQ = 2 x heads per kv head <= 8): row (sub, qi) carries its 64 query dims at dims 64 sub .. 64 sub + 63 of a 128-wide row and ZEROS in the other half, so
 // the four score instructions over the block's four 32-groups give every row the dot product with ITS kv head only; the value product computes 128 dims per
 // row of which the row's own half is kept.  Records come out in the NSUB = 2 form of the half-wave kernel ({m0, l0, m1, l1, o[128]} per query index).
-template <int GQ, bool FUSED, bool HD64 = false>
-__global__ __launch_bounds__(256)
+// NW = waves per workgroup: 4 (one dependent chain per SIMD: the short contexts, where a wave has one step anyway) or 8 (two chains per SIMD: a step is
+// cache words -> dequantize -> 4 score MFMAs -> softmax -> V tile -> 8 transposed reads + MFMAs, ~0.8 us of one wave's latency; at 16 000 tokens the
+// one-wave-per-SIMD form ran 8 such steps back to back per wave)
+template <int GQ, bool FUSED, bool HD64 = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW)
 void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
 {
     constexpr int HD = 128;
     __shared__ __attribute__((aligned(16))) uint32_t new_kv[2][16];            // FUSED: the new token's K / V words of this kv head (4 groups x 4 words)
     __shared__ __attribute__((aligned(8))) half_t new_sc[2][4];                //        and their group scales
     __shared__ __attribute__((aligned(16))) half_t q_s[8 * 128];               // rotated, pre-scaled queries in pair order (rows >= GQ stay zero)
-    __shared__ __attribute__((aligned(16))) half_t vt[4][16 * AW_VS];          // wave-private dequantized V tiles; after the loop: the waves' partial outputs
-    __shared__ float ml_s[4][8][2];
+    __shared__ __attribute__((aligned(16))) half_t vt[NW][16 * AW_VS];          // wave-private dequantized V tiles; after the loop: the waves' partial outputs
+    __shared__ float ml_s[NW][8][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 15, kg = lane >> 4;
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;              // h: kv head (one 128-value block of the kv vector)
     const int len = a.cache_seqlens[b];
@@ -255,7 +258,7 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
     auto load_step = [&] (const AttnArgs& aa, int st_) -> StepWords
     {
         StepWords r;
-        const int tk = max(min(t0 + 64 * st_ + 16 * wave + c, t1 - 1), 0);
+        const int tk = max(min(t0 + 16 * NW * st_ + 16 * wave + c, t1 - 1), 0);
         const int64_t gbase = (page_of(aa, tk) * aa.page_size + (tk % aa.page_size)) * G + h * 4 + kg;
         r.k = *((const uint4_t*) (aa.k_cache + gbase * 4)); r.v = *((const uint4_t*) (aa.v_cache + gbase * 4));
         r.ks = aa.k_scales[gbase]; r.vs = aa.v_scales[gbase];
@@ -273,13 +276,14 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
         const int l = tid & 31, hw = tid >> 5;
         constexpr int NT = HD64 ? GQ / 2 : GQ;
         constexpr int PH = HD64 ? 8 : 16;
+        constexpr int NHW = 2 * NW;                                                           // half-waves = tasks per round
         #pragma nounroll
-        for (int r = 0; r < (NT + 2 + 7) / 8; ++r)
+        for (int r = 0; r < (NT + 2 + NHW - 1) / NHW; ++r)
         {
             if (r > 0 && !owner) break;                                                       // workgroup-uniform
-            const int task = r * 8 + hw;
+            const int task = r * NHW + hw;
             const int kind = task < NT ? 0 : task - NT + 1;                                    // 0: query, 1: K row, 2: V row, >= 3: nothing
-            const int tw = r * 8 + 2 * wave;
+            const int tw = r * NHW + 2 * wave;
             const bool wave_has = tw < NT || (owner && tw + 1 >= NT && tw <= NT + 1);          // wave-uniform: tasks tw, tw + 1
             if (wave_has)
             {
@@ -335,7 +339,7 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
                     }
                 }
             }
-            if (r == 0 && hw >= GQ)
+            if (r == 0 && hw >= GQ && hw < 8)
             {
                 #pragma unroll
                 for (int e = 0; e < 4; ++e) q_s[hw * 128 + 4 * l + e] = (half_t) 0.0f;          // rows >= GQ of the query operand stay zero
@@ -363,7 +367,7 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
         for (int e = 0; e < 4; ++e)
         {
             const int d = dbase + e, d8 = d & 7;
-            q_s[i * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (i < GQ && l < 16) ? (half_t) vv[e] : (half_t) 0.0f;
+            if (i < 8) q_s[i * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (i < GQ && l < 16) ? (half_t) vv[e] : (half_t) 0.0f;        // (NW = 8: half-waves 8 .. 15 have no row)
         }
     }
     else
@@ -382,7 +386,7 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
         for (int e = 0; e < 4; ++e)
         {
             const int d = 4 * l + e, d8 = d & 7;
-            q_s[i * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = i < GQ ? (half_t) vv[e] : (half_t) 0.0f;
+            if (i < 8) q_s[i * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = i < GQ ? (half_t) vv[e] : (half_t) 0.0f;
         }
     }
     // FUSED: the preparation above holds ~35 scalar argument registers (slab bases, scales, tables, rescale sums); with the streaming loop's own
@@ -411,10 +415,10 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
     for (int nb = 0; nb < 8; ++nb) oc[nb] = float4_t{ 0.f, 0.f, 0.f, 0.f };
     half_t* vw = vt[wave];
 
-    const int nsteps = (al.split_tokens + 63) / 64;
+    const int nsteps = (al.split_tokens + 16 * NW - 1) / (16 * NW);
     for (int st = 0; st < nsteps; ++st)
     {
-        const int tb = t0 + 64 * st + 16 * wave;                // the wave's 16 tokens of this step
+        const int tb = t0 + 16 * NW * st + 16 * wave;           // the wave's 16 tokens of this step
         if (tb >= t1) break;                                    // wave-uniform: nothing left for this wave (its LDS tile is private)
         const int tk = min(tb + c, t1 - 1);
         uint32_t kw[4] = { w0.k.x, w0.k.y, w0.k.z, w0.k.w }, vw4[4] = { w0.v.x, w0.v.y, w0.v.z, w0.v.w };
@@ -480,9 +484,10 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
         __builtin_amdgcn_wave_barrier();
     }
 
-    // ---- merge the 4 waves: statistics of head c from lanes (c, kg = 0); outputs of heads 4 kg + r, column 16 nb + c (pair order) from every lane
+    // ---- merge the NW waves: statistics of head c from lanes (c, kg = 0); outputs of heads 4 kg + r, column 16 nb + c (pair order) from every lane
     __syncthreads();                                            // the V tiles are dead: their space takes the partial outputs [wave][head][128] fp32
-    float* o_s = (float*) &vt[0][0];                            // 4 * 8 * 128 * 4 B = 16 KB <= sizeof(vt) = 17 KB
+    float* o_s = (float*) &vt[0][0];                            // NW * 8 * 128 * 4 B = 16 KB (NW = 4) <= sizeof(vt) = 17 KB
+    static_assert(NW * 8 * 128 * 4 <= (int) sizeof(vt), "partial outputs must fit the V tiles");
     if (kg == 0 && c < 8) { ml_s[wave][c][0] = m_run; ml_s[wave][c][1] = l_run; }
     #pragma unroll
     for (int nb = 0; nb < 8; ++nb)
@@ -500,10 +505,10 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
         {
             float M = -1.0e30f;
             #pragma unroll
-            for (int w = 0; w < 4; ++w) M = fmaxf(M, ml_s[w][i][0]);
+            for (int w = 0; w < NW; ++w) M = fmaxf(M, ml_s[w][i][0]);
             float L = 0.0f, O[4] = { 0.f, 0.f, 0.f, 0.f };
             #pragma unroll
-            for (int w = 0; w < 4; ++w)
+            for (int w = 0; w < NW; ++w)
             {
                 const float e = ml_s[w][i][0] > -1.0e29f ? __builtin_amdgcn_exp2f(ml_s[w][i][0] - M) : 0.0f;
                 L += ml_s[w][i][1] * e;
@@ -652,6 +657,10 @@ extern "C" int exl3_glue_qkv_tab(const float* sq, const float* sk, const float* 
                                  float attn_factor, const float* ss_prev, const float* ss_new, int hidden, float eps,
                                  const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream);
 
+// waves per workgroup of the matrix-pipe kernel: 0 = by the split length (8 from two 64-token steps on), 4 / 8 / 16 forced (A/B runs, tests)
+static int g_attn_wide_waves = 0;
+extern "C" int exl3_set_attn_wide_waves(int v) { g_attn_wide_waves = (v == 4 || v == 8 || v == 16) ? v : 0; return EXL3_OK; }
+
 static int attn_decode_impl(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
                             const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
                             int k_bits, int v_bits, int heads_q, int heads_kv, int head_dim, int max_len, float scale,
@@ -780,28 +789,38 @@ static int attn_decode_impl(const void* q, void* out, const void* k_cache, const
             a.nsplit = ns; a.split_tokens = st_tok;
             if (fuse) { xq = &fuse->x; if (fuse->fused_out) *fuse->fused_out = 1; }
             dim3 gridw(ns, blocks, bsz);
+            // eight waves per workgroup (two dependent chains per SIMD) once a 4-wave workgroup would run two or more steps per wave
+            static const int nw_env = [] { const char* e = getenv("EXL3_HIP_ATTN_WIDE_NW"); return e ? atoi(e) : 0; }();
+            const int nw_req = g_attn_wide_waves ? g_attn_wide_waves : nw_env;
+            const bool nw8 = nw_req ? nw_req == 8 : st_tok >= 128;
+            const bool nw16 = nw_req == 16;
+            #define AW_LAUNCH(GQv, HD64v) \
+                { if (nw16) { if (xq) attn_decode_wide_kernel<GQv, true, HD64v, 16><<<gridw, 1024, 0, st>>>(a, *xq); else attn_decode_wide_kernel<GQv, false, HD64v, 16><<<gridw, 1024, 0, st>>>(a, AttnQkvArgs{}); } \
+                  else if (nw8) { if (xq) attn_decode_wide_kernel<GQv, true, HD64v, 8><<<gridw, 512, 0, st>>>(a, *xq); else attn_decode_wide_kernel<GQv, false, HD64v, 8><<<gridw, 512, 0, st>>>(a, AttnQkvArgs{}); } \
+                  else     { if (xq) attn_decode_wide_kernel<GQv, true, HD64v, 4><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<GQv, false, HD64v, 4><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); } }
             if (wide_hd64)
             {
                 switch (gq)
                 {
-                    case 1: if (xq) attn_decode_wide_kernel<2, true, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<2, false, true><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
-                    case 2: if (xq) attn_decode_wide_kernel<4, true, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<4, false, true><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
-                    case 3: if (xq) attn_decode_wide_kernel<6, true, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<6, false, true><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
-                    default: if (xq) attn_decode_wide_kernel<8, true, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<8, false, true><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                    case 1: AW_LAUNCH(2, true) break;
+                    case 2: AW_LAUNCH(4, true) break;
+                    case 3: AW_LAUNCH(6, true) break;
+                    default: AW_LAUNCH(8, true) break;
                 }
             }
             else
             switch (gq)
             {
-                case 1: if (xq) attn_decode_wide_kernel<1, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<1, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
-                case 2: if (xq) attn_decode_wide_kernel<2, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<2, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
-                case 3: if (xq) attn_decode_wide_kernel<3, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<3, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
-                case 4: if (xq) attn_decode_wide_kernel<4, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<4, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
-                case 5: if (xq) attn_decode_wide_kernel<5, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<5, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
-                case 6: if (xq) attn_decode_wide_kernel<6, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<6, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
-                case 7: if (xq) attn_decode_wide_kernel<7, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<7, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
-                default: if (xq) attn_decode_wide_kernel<8, true><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<8, false><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); break;
+                case 1: AW_LAUNCH(1, false) break;
+                case 2: AW_LAUNCH(2, false) break;
+                case 3: AW_LAUNCH(3, false) break;
+                case 4: AW_LAUNCH(4, false) break;
+                case 5: AW_LAUNCH(5, false) break;
+                case 6: AW_LAUNCH(6, false) break;
+                case 7: AW_LAUNCH(7, false) break;
+                default: AW_LAUNCH(8, false) break;
             }
+            #undef AW_LAUNCH
             int rcw = exl3_check_launch("attn_decode_wide");
             if (rcw) return rcw;
             if (split_only) { *nsplit_out = ns; return EXL3_OK; }

@@ -107,6 +107,11 @@ def set_gemm3_cpw(n: int):
     _lib.lib().exl3_set_gemm3_cpw(int(n))
 
 
+def set_attn_wide_waves(n: int):
+    """decode attention, matrix-pipe kernel: waves per workgroup (4 / 8 / 16 = one / two / four token-step chains per SIMD); 0 = by the split length."""
+    _lib.lib().exl3_set_attn_wide_waves(int(n))
+
+
 # --------------------------------------------------------------------------------------------------
 # format ops
 # --------------------------------------------------------------------------------------------------

@@ -1282,6 +1282,48 @@ def test_attention_qkv_in_split_every_group_size(dev, gq, pos, bsz):
     assert all(not torch.equal(a1, a0) for (a1, _), (a0, _) in zip(kv1, saved))
 
 
+@pytest.mark.parametrize("waves", [8, 16])
+@pytest.mark.parametrize("hd,hq,hkv", [(128, 4, 1), (128, 7, 1), (128, 8, 1), (64, 8, 2), (64, 16, 8)])
+@pytest.mark.parametrize("pos,bsz", [(1000, 2), (1900, 1)])
+def test_attention_qkv_in_split_eight_and_sixteen_waves(dev, hd, hq, hkv, pos, bsz, waves):
+    """The matrix-pipe split kernel with 8 / 16 waves per workgroup (round 5: two / four token-step chains per SIMD; the default from two 64-token steps
+    per split on) in its FUSED form -- 16 / 32 half-waves share the q|k|v epilogue's tasks in ONE round -- against glue_qkv_rs + the split launch with the
+    same wave count: logits, residual, q, every cache word and scale bit for bit; and against the 4-wave form within the merge's rounding (another
+    summation order of the same partial sums)."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    shape = LlamaShape("tiny", 512, 768, 2, hq, hkv, hd, 384)
+    model = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
+    model.alloc_state(bsz, pos=pos)
+    model.with_attention = True
+    model.attn_merge_in_oproj_hd64 = True
+    g = torch.Generator(device="cpu").manual_seed(hq * 1000 + pos)
+    for c, s_ in model.kcache + model.vcache:
+        c.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, c.shape, generator=g, dtype=torch.int64).to(torch.int32).to(dev))
+        s_.copy_((torch.rand(s_.shape, generator=g) * 0.5 + 0.05).half().to(dev))
+    saved = [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]
+    outs = []
+    try:
+        for w, qkv_in_split in ((waves, False), (waves, True), (4, True)):
+            ext.set_attn_wide_waves(w)
+            model.attn_qkv_in_split = qkv_in_split
+            for (c, s_), (c0, s0) in zip(model.kcache + model.vcache, saved):
+                c.copy_(c0); s_.copy_(s0)
+            model.q.zero_()
+            lg = model.decode_step_fx().float().cpu().numpy().copy()
+            outs.append((lg, model.x_final.clone(), model.q.clone(), [(c.clone(), s_.clone()) for c, s_ in model.kcache + model.vcache]))
+    finally:
+        ext.set_attn_wide_waves(0)
+    (l0, x0_, q0, kv0), (l1, x1_, q1, kv1), (l4, _, q4, kv4) = outs
+    assert np.isfinite(l1).all()
+    assert np.array_equal(l0, l1) and torch.equal(x0_, x1_) and torch.equal(q0, q1)
+    assert all(torch.equal(a0, a1) and torch.equal(b0, b1) for (a0, b0), (a1, b1) in zip(kv0, kv1))
+    assert all(not torch.equal(a1, a0) for (a1, _), (a0, _) in zip(kv1, saved))
+    # layer 0's new K / V rows do not depend on the attention output: the same words whatever the wave count
+    assert torch.equal(kv1[0][0], kv4[0][0]) and torch.equal(kv1[2][0], kv4[2][0])             # (kcache + vcache of two layers: K0, K1, V0, V1)
+    assert np.abs(l1 - l4).max() / np.sqrt((l4 ** 2).mean()) < 1e-2
+
+
 @pytest.mark.parametrize("hq,hkv", [(8, 2), (16, 8), (4, 4), (6, 2), (16, 2)])
 @pytest.mark.parametrize("pos,bsz", [(70, 1), (130, 1), (500, 2), (1000, 2)])
 def test_attention_qkv_in_split_head_dim_64(dev, hq, hkv, pos, bsz):
