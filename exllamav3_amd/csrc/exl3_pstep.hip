@@ -243,7 +243,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     }
 
     PsHandle* h = new PsHandle();
-    h->K = K; h->nops = nops; h->ncu = ncu; h->pmax = 2; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
+    h->K = K; h->nops = nops; h->ncu = ncu; h->pmax = 3; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
     h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr; h->d_slab_c = nullptr; h->d_slab_d = nullptr; h->d_rbuf = nullptr; h->d_epoch = nullptr;
     h->cnt_bytes = (size_t) nops * 8 * 16 * 4; h->dbg_words = (flags & 1) ? (size_t) nops * ncu * 16 : 0;
     #define PS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { exl3_set_error("exl3_pstep_create: %s", hipGetErrorString(e_)); exl3_pstep_destroy(h); return EXL3_ERR_HIP; } } while (0)
@@ -328,7 +328,7 @@ extern "C" int exl3_pstep_error(void* handle, void* stream)
 extern "C" int exl3_pstep_set(void* handle, int decode_ahead_units, int spin_limit)
 {
     PsHandle* h = (PsHandle*) handle;
-    EXL3_CHECK_ARG(h && decode_ahead_units >= -1 && decode_ahead_units <= 2, "exl3_pstep_set: decode_ahead_units in 0..2 (-1: keep)");
+    EXL3_CHECK_ARG(h && decode_ahead_units >= -1 && decode_ahead_units <= 3, "exl3_pstep_set: decode_ahead_units in 0..3 (-1: keep)");
     if (decode_ahead_units >= 0) h->pmax = decode_ahead_units;
     if (spin_limit > 0) h->spin_limit = spin_limit;
     return EXL3_OK;

@@ -88,7 +88,7 @@ __device__ __forceinline__ float4_t ps_slab_sum(ps_rsrc_t r, uint32_t blk_off, i
         #pragma unroll
         for (int i = 0; i < NB; ++i) if (s + i < S)
         {
-            ok = ok && t[i][0].y == tag && t[i][0].w == tag && t[i][1].y == tag && t[i][1].w == tag;
+            ok &= (t[i][0].y == tag) & (t[i][0].w == tag) & (t[i][1].y == tag) & (t[i][1].w == tag);            // (bitwise: && makes an exec-mask branch per line)
             v.x += __uint_as_float(t[i][0].x); v.y += __uint_as_float(t[i][0].z);
             v.z += __uint_as_float(t[i][1].x); v.w += __uint_as_float(t[i][1].z);
         }
@@ -113,8 +113,8 @@ __device__ __forceinline__ void ps_slab_sum2(ps_rsrc_t ra, ps_rsrc_t rb, uint32_
         #pragma unroll
         for (int i = 0; i < NB; ++i) if (s + i < S)
         {
-            ok = ok && ta[i][0].y == tag && ta[i][0].w == tag && ta[i][1].y == tag && ta[i][1].w == tag
-                    && tb[i][0].y == tag && tb[i][0].w == tag && tb[i][1].y == tag && tb[i][1].w == tag;
+            ok &= (ta[i][0].y == tag) & (ta[i][0].w == tag) & (ta[i][1].y == tag) & (ta[i][1].w == tag)
+                & (tb[i][0].y == tag) & (tb[i][0].w == tag) & (tb[i][1].y == tag) & (tb[i][1].w == tag);
             va.x += __uint_as_float(ta[i][0].x); va.y += __uint_as_float(ta[i][0].z); va.z += __uint_as_float(ta[i][1].x); va.w += __uint_as_float(ta[i][1].z);
             vb.x += __uint_as_float(tb[i][0].x); vb.y += __uint_as_float(tb[i][0].z); vb.z += __uint_as_float(tb[i][1].x); vb.w += __uint_as_float(tb[i][1].z);
         }
@@ -309,9 +309,9 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         const int quad_lane = (lane >> 2) * 8, lofs = lane * K;
         const int pmax = a.pmax;
         LaneWords<K> ring[2];
-        half4_t dec0[16];
+        half4_t dec0[16], dec1[16];
         #pragma unroll
-        for (int i = 0; i < 16; ++i) dec0[i] = half4_t{ 0, 0, 0, 0 };
+        for (int i = 0; i < 16; ++i) { dec0[i] = half4_t{ 0, 0, 0, 0 }; dec1[i] = dec0[i]; }
         #pragma unroll
         for (int i = 0; i < K; ++i) { ring[0].w[i] = 0u; ring[1].w[i] = 0u; }
         char* const pdec_w = pdec + (size_t) wave * (16 * 64 * 8) + (size_t) lane * 8;
@@ -351,6 +351,13 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     {
                         ps_predecode_lds<K>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, pdec_w);
                         P = 2;
+                        // a THIRD unit, in registers again (Llama-3.2-1B's gate|up rectangle is 32 units = 2.67 per wave: with two units ahead eight waves streamed one
+                        // more after the quads were there -- 1.5 us of decode on the critical path of every layer)
+                        if (Pm >= 3 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
+                        {
+                            ps_predecode<K>(ring, cur.unit_ptr(min(3, cur.n - 1)), cur.rs, lane, lofs, dec1);
+                            P = 3;
+                        }
                     }
                 }
             }
@@ -383,6 +390,14 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         else ps_unit<K, 1>(ring, up(2), ur(2), lane, lofs, ag, acc_c, acc_d);
                     }
                     p = 2;
+                    if (pre > 2)                                         // (pre > 2 implies len > 2: decode-ahead stays inside segment 0)
+                    {
+                        const uint2_t raw2 = *((const uint2_t*) (qb + 2 * 64));
+                        const half4_t ag2 = u2_as_half4(raw2.x, raw2.y);
+                        ps_consume<0>(dec1, ag2, acc_c, acc_d);
+                        if (len > 3) ps_unit<K, 1>(ring, up(4), ur(4), lane, lofs, ag2, acc_c, acc_d);
+                        p = 4;
+                    }
                 }
                 for (; p + 1 < len; p += 2)
                 {
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             {
                                 const uint32_t o = (uint32_t) min(shw + 8 * it, nblk - 1) * PS_LINE_BYTES + (uint32_t) l32 * 16u;
                                 const uint4_t ra = ps_ld128(rR, o), rb = ps_ld128(rR, o + 512u);
-                                ok = ok && ra.y == tag_in && ra.w == tag_in && rb.y == tag_in && rb.w == tag_in;
+                                ok &= (ra.y == tag_in) & (ra.w == tag_in) & (rb.y == tag_in) & (rb.w == tag_in);
                                 xr[it] = half4_t{ f2h(__uint_as_float(ra.x)), f2h(__uint_as_float(ra.z)), f2h(__uint_as_float(rb.x)), f2h(__uint_as_float(rb.z)) };
                             }
                         }
@@ -811,7 +826,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             #pragma unroll
                             for (int i = 0; i < 4; ++i) if (i < nl)
                             {
-                                ok = ok && t[i][0].y == tag_out && t[i][0].w == tag_out && t[i][1].y == tag_out && t[i][1].w == tag_out;
+                                ok &= (t[i][0].y == tag_out) & (t[i][0].w == tag_out) & (t[i][1].y == tag_out) & (t[i][1].w == tag_out);
                                 ys.x += __uint_as_float(t[i][0].x); ys.y += __uint_as_float(t[i][0].z); ys.z += __uint_as_float(t[i][1].x); ys.w += __uint_as_float(t[i][1].z);
                             }
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;

@@ -59,11 +59,13 @@ def test_persistent_step_matches_oracle_and_fx_pipeline(dev, hidden, inter, hq, 
     assert not m._pstep.error()
 
 
-@pytest.mark.parametrize("ahead", [0, 1, 2])
+@pytest.mark.parametrize("ahead", [0, 1, 2, 3])
 def test_persistent_step_decode_ahead_depths_give_the_same_bits(dev, ahead):
-    """Decode-ahead only changes WHEN a unit's weights are decoded, not the arithmetic: 0, 1 (registers) and 2 (registers + LDS) units give equal logits."""
+    """Decode-ahead only changes WHEN a unit's weights are decoded, not the arithmetic: 0, 1 (registers), 2 (registers + LDS) and 3 (registers + LDS + registers: the default) units give equal logits."""
     from exllamav3_amd.llama_path import LlamaShape
     m = _model(LlamaShape("tiny-ps", 512, 1536, 2, 8, 2, 64, 1024), dev)
+    m.decode_step_persistent()
+    m._pstep.set(decode_ahead_units=2)
     base = _np(m.decode_step_persistent().float()).copy()
     m._pstep.set(decode_ahead_units=ahead)
     assert np.array_equal(_np(m.decode_step_persistent().float()), base)

@@ -165,7 +165,7 @@ int main(int argc, char** argv)
 
     // variants: index 0 = baseline, then one persistent variant per decode-ahead depth in the list
     std::vector<int> pm;
-    for (const char* c = plist; *c; ++c) if (*c >= '0' && *c <= '2') pm.push_back(*c - '0');
+    for (const char* c = plist; *c; ++c) if (*c >= '0' && *c <= '3') pm.push_back(*c - '0');
     const size_t nv = 1 + pm.size();
     auto run_variant = [&] (size_t v) { if (v == 0) step_base(); else { CE(exl3_pstep_set(ps, pm[v - 1], 0)); step_ps(); } };
 
