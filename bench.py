@@ -56,8 +56,9 @@ def parse():
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--attention", action="store_true", help="include decode attention over the quantized KV cache (context = 1000 tokens) in the timed step")
     ap.add_argument("--unfused", action="store_true", help="one launch per reference op instead of the fused pipeline")
-    ap.add_argument("--pipeline", choices=["tail", "glue", "resid", "fx", "unfused", "persistent"], default="fx",
-                    help="fx (default; batch <= 4 on one rank, otherwise = glue): residual stream in a 64-bit fixed-point accumulator, o_proj / "
+    ap.add_argument("--pipeline", choices=["auto", "tail", "glue", "resid", "fx", "unfused", "persistent"], default="auto",
+                    help="auto (default): persistent where it applies (batch 1, one rank, mul1 codebook, 4-bit cache, no attention core), else fx; "
+                         "persistent: the whole decode step in ONE launch (exl3_pstep.hip); fx (batch <= 4 on one rank, otherwise = glue): residual stream in a 64-bit fixed-point accumulator, o_proj / "
                          "down_proj add into it with integer atomics, 5 launches/layer (fastest measured); glue: deferred-epilogue GEMVs + glue kernels "
                          "(8 launches/layer); tail: sublayer boundaries run inside the GEMV launches (4 launches/layer; the in-kernel cross-workgroup "
                          "hand-off through memory costs more than a launch)")
@@ -254,6 +255,10 @@ def main():
 
     # ---- decode: eager warm-up (also creates library contexts), graph capture, timed replays
     pipeline = "unfused" if args.unfused else args.pipeline
+    if pipeline == "auto":
+        # the persistent decode step (ONE launch per step) wherever it applies -- batch 1, one rank, mul1, 4-bit cache, no attention core -- and is not switched
+        # off (EXL3_HIP_PSTEP=0); else the fixed-point-residual launch-per-op pipeline
+        pipeline = "persistent" if (not is_moe and world == 1 and model.persistent_applies() and model.persistent is not False) else "fx"
     if pipeline == "tail" and world > 1:
         pipeline = "glue"                                  # TP ranks all-reduce between o/down and the norm ("fx" has its own TP form: llama_path._decode_step_fx_tp)
     fused = pipeline != "unfused"
@@ -483,7 +488,47 @@ def main():
             fit = {"const_us": round(float(c_[0]), 2), "stream_TBps": round(1e-6 / float(c_[1]), 3) if c_[1] > 0 else None,
                    "constants_share_of_step": round(float(c_[0]) * launches_step / (ms_per_step * 1e3), 3),
                    "note": "t = const_us + bytes / stream_rate, weighted least squares over the call types above (weights = launches per step); the step also has its glue launches"}
-        roofline = {"bound": "hbm", "kernel": ("exl3_gemv4_kernel" if bsz <= 4 else "exl3_gemm3_kernel") + " (fused trellis decode + Hadamard + MFMA GEMV), all GEMV launches of a decode step",
+        gemv_roofline = None
+        if pipeline == "persistent":
+            # the dominant kernel IS the step: exl3_pstep_kernel<K>, one launch per step.  achieved = the step's algorithmic bytes (the same sum as the
+            # launch-per-op table: every quantized matrix once + activations) / the launch's duration, HIP events around hipGraph replays of the step on the
+            # replay stream (the step's set-up launch fx_init_prep, ~4 us, is inside: it is a node of the same graph)
+            stp = torch.cuda.Stream(); stp.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stp):
+                model.decode_step_persistent(); stp.synchronize()
+                gp = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gp, stream=stp):
+                    model.decode_step_persistent()
+                gp.replay(); stp.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(stp)
+                for _ in range(20): gp.replay()
+                e1.record(stp); stp.synchronize()
+            step_us = e0.elapsed_time(e1) * 1e3 / 20
+            assert not model._pstep.error(), "bench.py: the persistent step reported a timed-out edge"
+            gemv_roofline = {"kernel": "exl3_gemv4_kernel, the launch-per-op pipeline's GEMV launches of the same shapes (reference table; NOT the timed step)",
+                             "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 4), "avg_launch_us": round(avg_us, 2),
+                             "bytes_per_launch": int(bytes_per_launch), "launches_per_step": launches_step, "per_launch": per_launch, "fit": fit,
+                             "traffic": traffic, "traffic_source": traffic_src, "kernel_only": kernel_only}
+            ptraffic = None; ptraffic_src = None
+            try:
+                tj = json.load(open(tf))
+                pj = tj.get("persistent_step", {}).get(args.model)
+                if pj:
+                    ptraffic = pj.get("fetch_bytes_per_launch")
+                    ptraffic_src = f"NOT measured in this run: FETCH_SIZE of exl3_pstep_kernel in an earlier rocprofv3 --pmc pass over the same command, profiles/traffic.json (collected {pj.get('collected')})"
+            except Exception:
+                pass
+            ach_p = bytes_step / step_us / 1e3
+            roofline = {"bound": "hbm", "kernel": f"exl3_pstep_kernel<{K}> (the whole decode step in ONE launch: trellis decode + Hadamards + MFMA GEMV of every linear, RMSNorm, q|k|v epilogue, silu*mul, residual adds)",
+                        "achieved": round(ach_p, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach_p / HBM_PEAK_GBPS, 4),
+                        "traffic": ptraffic, "traffic_source": ptraffic_src,
+                        "avg_launch_us": round(step_us, 2), "bytes_per_launch": int(bytes_step), "launches_per_step": 1,
+                        "plan": model._pstep.describe(),
+                        "launch_per_op_gemv": gemv_roofline,
+                        "note": "HIP events around hipGraph replays of the step (one exl3_pstep_kernel launch + the set-up launch); algorithmic bytes = every packed weight once + scales + activations"}
+        else:
+          roofline = {"bound": "hbm", "kernel": ("exl3_gemv4_kernel" if bsz <= 4 else "exl3_gemm3_kernel") + " (fused trellis decode + Hadamard + MFMA GEMV), all GEMV launches of a decode step",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "kernel_only": kernel_only,
                     "avg_launch_us": round(avg_us, 2), "bytes_per_launch": int(bytes_per_launch),
@@ -595,6 +640,7 @@ def main():
             return {"tok_s": round(bsz * 1e3 / msx, 1), "ms_per_step": round(msx, 4), "batch": bsz,
                     "frac_of_hbm_roofline": round((1e3 / msx) / (HBM_PEAK_GBPS * 1e9 / bpt), 4)}
         pipe_x = "fx" if pipeline == "persistent" else pipeline          # (the other configs run the launch-per-op form of the timed pipeline)
+        fx_step_desc = "decode_step_fx: launch-per-op pipeline, 5 launches per layer (fixed-point residual, atomic epilogues)"
         extra = {}
         # config 3, bs 16 (generation-3 GEMM + glue_rotate route)
         model.alloc_state(16)
@@ -630,9 +676,14 @@ def main():
             extra["llama-3.1-8b_bs1_gemv_variant0_exact"] = timed_decode(model, model.decode_step_fx if pipe_x == "fx" else model.decode_step_fused, 1)
             ext.set_gemv_variant(args.variant)
         extra["llama-3.1-8b_bs16"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, cb, 16, dev, pipe_x if pipe_x != "unfused" else "glue")
-        # the persistent decode step at the headline's own shape (measured, NOT the default at this size: the launch-per-op pipeline is the faster step
-        # for Llama-3.1-8B; profiles/r05_persistent_*): same tensors, same gate
-        if pipe_x == "fx" and cb == 2 and model.persistent_applies():
+        # the headline is the persistent step: the launch-per-op fx pipeline on the same tensors beside it (same gate) ...
+        if pipeline == "persistent":
+            model._pstep = None
+            extra["llama-3.1-8b_bs1_launch_per_op"] = timed_decode(model, model.decode_step_fx, 1)
+            extra["llama-3.1-8b_bs1_launch_per_op"]["step"] = fx_step_desc
+            extra["llama-3.1-8b_bs1_launch_per_op"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, cb, 1, dev, "fx")
+        # ... or the other way round (--pipeline fx / EXL3_HIP_PSTEP=0)
+        elif pipe_x == "fx" and cb == 2 and model.persistent_applies():
             extra["llama-3.1-8b_bs1_persistent_step"] = timed_decode(model, model.decode_step_persistent, 1)
             extra["llama-3.1-8b_bs1_persistent_step"]["edge_timeout"] = bool(model._pstep.error())
             extra["llama-3.1-8b_bs1_persistent_step"]["plan"] = model._pstep.describe()
@@ -731,7 +782,7 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{shape.name} EXL3 {args.bits}.0bpw {args.codebook} codebook, decode bs={args.batch}, "
                                    f"{model.n_layers} layers, {'attention TP=%d + expert-parallel MoE over %d rank(s)' % (world, world) if is_moe else 'TP=%d' % world}, {args.kv_bits}-bit KV append, "
-                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, { 'glue pipeline + indexed exl3_mgemm MoE block' if is_moe else {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (%d launches/layer)' % (7 if (args.batch == 1 and model.act_in_gemv and world == 1) else ((8 if (world == 1 and model.fold_rotate) else 10) if args.batch > 4 else 8)), 'resid': 'resid-in-GEMV pipeline (5 launches/layer: residual add + RMSNorm finished inside the consumer GEMV)' if (args.batch <= 4 and world == 1) else 'fused glue pipeline', 'fx': fx_desc if (args.batch <= model.fx_max_bsz and world == 1) else 'fused glue pipeline', 'unfused': 'one launch per reference op', 'persistent': 'persistent decode step: ONE launch per step (exl3_pstep.hip: 12 streaming + 4 service waves per CU, decode-ahead, tagged slab / residual-row lines; residual kept in fp32)'}[pipeline] }; "
+                                   f"{'hipGraph replay' if graph is not None else 'eager launches'}, { 'glue pipeline + indexed exl3_mgemm MoE block' if is_moe else {'tail': 'tail-epilogue pipeline (4 launches/layer)', 'glue': 'fused glue pipeline (%d launches/layer)' % (7 if (args.batch == 1 and model.act_in_gemv and world == 1) else ((8 if (world == 1 and model.fold_rotate) else 10) if args.batch > 4 else 8)), 'resid': 'resid-in-GEMV pipeline (5 launches/layer: residual add + RMSNorm finished inside the consumer GEMV)' if (args.batch <= 4 and world == 1) else 'fused glue pipeline', 'fx': fx_desc if (args.batch <= model.fx_max_bsz and world == 1) else 'fused glue pipeline', 'unfused': 'one launch per reference op', 'persistent': 'persistent decode step: ONE launch per step (exl3_pstep.hip: 12 streaming + 4 service waves per CU, three decode-ahead units, tagged slab lines, direct residual edges; residual kept in fp32)'}[pipeline] }; "
                                    f"{'attention core INCLUDED: quant-cache-direct decode attention over a 1000-token context' if args.attention else 'attention core excluded (SURVEY.md 2.1)'}",
                        "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
                        "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),

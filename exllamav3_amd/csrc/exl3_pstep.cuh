@@ -21,6 +21,11 @@
 #define PS_OUT_ATOMIC 1    // the op adds into the residual row: partial rows as tagged lines, the OWNER of each 128-value block (the slice-0 workgroup) sums them, applies the
                            // output Hadamard + svh, adds the block of the previous row version and publishes the new version's block as one tagged fp32 line
 #define PS_OUT_FINAL 2     // one slice: finished fp16 rows (lm_head)
+// DIRECT residual edges (bit 8 of in_type / out_type; the low byte is the type): the consumer RMSNorm op finishes the row's new version ITSELF -- every workgroup
+// gathers the producer's partial lines of the blocks of ITS k-slice (one hop instead of partial lines -> owner -> owner's line -> every workgroup: two), adds the
+// previous version's blocks, normalises with the scale it last knew and corrects its partial sums by (true scale / that scale) when the block sums of squares
+// -- published with the new blocks by one workgroup per slice -- have arrived (long before the streaming ends).  The producer op then has no owner stage.
+#define PS_DIRECT 0x100
 
 // LDS map of the kernel (bytes)
 #define PS_QUADS_BYTES 8448                       // activation quads of a slice: (nb * 8 + 4) tile rows x 32 B  ->  nb <= 32 Hadamard blocks
@@ -28,6 +33,7 @@
 #define PS_PART_BYTES (12 * 2 * 512)              // partial rows [streaming wave][segment][128] fp32
 #define PS_PDEC_BYTES (12 * 16 * 64 * 8)          // decode-ahead unit #2 of every streaming wave: [wave][16 operand slots][64 lanes] x 8 B
 #define PS_GATH_BYTES (4 * 8 * 512)                // owners of residual-row blocks: [4 blocks][8 service half-waves][128] fp32 gathered sums
+#define PS_RBUF_BYTES (2 * 32 * 1024 + 2 * 32 * 16)
 #define PS_MAX_SLICE_BLOCKS 32                    // = the largest k / 128 of an RMSNorm op (hidden <= 4096): 8 service half-waves x 4 blocks
 
 struct PsMat
@@ -45,20 +51,22 @@ struct PsOp
     float eps; int gate_op;            // PS_OUT_ATOMIC: the op whose read gate protects the row lines this op's owners overwrite (-1: none)
     PsMat mat[PS_MAX_MATS];
     const half_t* norm_w;              // PS_IN_NORM
-    const unsigned long long* in_slab[3];   // PS_IN_QKV: q, k, v slab sets of the producer; PS_IN_ACT: gate, up
-    const half_t* in_svh[3];
+    const unsigned long long* in_slab[3];   // PS_IN_QKV: q, k, v slab sets of the producer; PS_IN_ACT: gate, up; PS_IN_NORM | PS_DIRECT: [0] = the producer's partial lines (S_in per block)
+    const half_t* in_svh[3];                // ... and the producer's column scales
     uint32_t* k_cache; half_t* k_scales; uint32_t* v_cache; half_t* v_scales;      // PS_IN_QKV: the layer's 4-bit paged cache
 };
 
 // what ONE workgroup (CU) does in one op: a rectangle of (ncb column blocks of matrix mat) x (nb Hadamard blocks of k); mat < 0: nothing (it still meets the edge)
 struct PsTile { int mat, cb0, ncb, b0, nb, slice, side, flags; };
-#define PS_TILE_Q_OUT 1               // this workgroup also stores the finished q blocks of its slice (one column group per slice)
+#define PS_TILE_Q_OUT 1               // this workgroup also stores the finished q blocks of its slice (one column group per slice); in a DIRECT RMSNorm op: it publishes
+                                      // the new row version's blocks of its slice and their sums of squares
 
 struct PsArgs
 {
     const PsOp* ops; const PsTile* tiles; int nops, ncu;
     unsigned long long* R; half_t* logits; half_t* q_out;
-    unsigned long long* rbuf;         // [2][PS_MAX_SLICE_BLOCKS] lines of 1 KiB: the residual row's versions >= 1 (version v in half v & 1), tagged fp32 pairs
+    unsigned long long* rbuf;         // [2][PS_MAX_SLICE_BLOCKS] lines of 1 KiB: the residual row's versions >= 1 (version v in half v & 1), tagged fp32 pairs;
+                                      // then [2][PS_MAX_SLICE_BLOCKS] granules of 16 B { sum of squares of the block, tag, 0, tag }
     const float* rope_sin; const float* rope_cos; const int64_t* slots;
     uint32_t* cnt;                    // [nops][8 shards][16 words]: arrivals of edge `op`, zero at launch
     uint32_t* epoch;                  // run counter in device memory (tags of the slab granules): read at entry, + 1 at exit

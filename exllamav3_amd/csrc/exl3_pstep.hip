@@ -36,7 +36,7 @@ struct PsHandle
 struct OpPlan { int S; int g[PS_MAX_MATS]; int G; int wmax, hmax; };
 
 // groups x slices for one op: minimise the largest rectangle (in work units = 2 tile rows x 128 columns); ties -> fewer slices (fewer adds per address / slab lines)
-bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_type, OpPlan& best)
+bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_type, OpPlan& best, bool direct = false)
 {
     double best_cost = 1e30; bool found = false;
     int total_cb = 0; for (int i = 0; i < nmat; ++i) total_cb += ncb[i];
@@ -46,6 +46,7 @@ bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_t
         const int nbmax = (nblk + S - 1) / S;
         if (nbmax > PS_MAX_SLICE_BLOCKS) continue;
         if (in_type != PS_IN_NORM && nbmax > 8) continue;                  // one preparation task per service half-wave
+        if (direct && nbmax > 4) continue;                                 // a DIRECT RMSNorm op gathers the partial lines of at most four blocks (LDS: gath)
         const int G = ncu / S;
         if (G < nmat) continue;
         OpPlan p; p.S = S;
@@ -147,6 +148,15 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
 
     const int qdim = heads_q * head_dim, kvdim = heads_kv * head_dim, kvb = kvdim / 128;
     const int nops = 4 * n_layers + 1;
+    // DIRECT residual edges (exl3_pstep.cuh) unless flags bit 1 / EXL3_HIP_PSTEP_OWNERS=1 asks for the owner form everywhere (A/B runs); a plan that cannot keep
+    // an RMSNorm op's slice at <= 4 blocks falls back to owners for the whole step
+    bool direct = !(flags & 2);
+    if (const char* e = getenv("EXL3_HIP_PSTEP_OWNERS")) if (atoi(e)) direct = false;
+    {
+        const int ncb3[3] = { qdim / 128, kvdim / 128, kvdim / 128 }; const int ncb2[2] = { layers[0].gate.n / 128, layers[0].gate.n / 128 };
+        OpPlan t;
+        if (direct && !(plan_op(ncu, hidden / 128, ncb3, 3, PS_IN_NORM, PS_OUT_SLAB, t, true) && plan_op(ncu, hidden / 128, ncb2, 2, PS_IN_NORM, PS_OUT_SLAB, t, true))) direct = false;
+    }
     std::vector<PsOp> ops((size_t) nops + 1);                       // + 1: the kernel forms the address of ops[nops] (never read)
     std::vector<PsTile> tiles((size_t) nops * ncu);
     memset(ops.data(), 0, ops.size() * sizeof(PsOp));
@@ -178,7 +188,12 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
             O.rver = rver; O.gate_op = -1; if ((int) reader_of_version.size() <= rver) reader_of_version.resize(rver + 1); reader_of_version[rver] = op;
             lin_to_mat(L.q, O.mat[0]); lin_to_mat(L.k, O.mat[1]); lin_to_mat(L.v, O.mat[2]);
             const int ncb[3] = { qdim / 128, kvdim / 128, kvdim / 128 };
-            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 3, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for q|k|v");
+            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 3, O.in_type, O.out_type, p, direct), "exl3_pstep_create: no plan for q|k|v");
+            if (direct && rver >= 1)
+            {
+                PsOp& Pd = ops[op - 1];                                 // the previous layer's down_proj: its partial lines are gathered here, it has no owner stage
+                O.in_type |= PS_DIRECT; Pd.out_type |= PS_DIRECT; O.S_in = Pd.S; O.in_svh[0] = Pd.mat[0].svh;
+            }
             O.S = p.S; add_tiles(op, p, ncb, 3, hidden / 128, 0);
             Pending f; f.op = op; f.which = 0; size_t off = 0;
             for (int i = 0; i < 3; ++i) { f.off[i] = off; off += (size_t) ncb[i] * p.S * 128; }
@@ -196,7 +211,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
             const int ncb[1] = { hidden / 128 };
             OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, qdim / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for o_proj");
             O.S = p.S; add_tiles(op, p, ncb, 1, qdim / 128, 2 * kvb);
-            O.rver = ++rver; O.gate_op = rver >= 3 ? reader_of_version[rver - 2] : -1;
+            O.rver = ++rver; O.gate_op = direct ? op - 1 : (rver >= 3 ? reader_of_version[rver - 2] : -1);       // (direct: the last readers of the lines an owner overwrites are the op before it)
             { Pending f; f.op = op; f.which = 2; f.off[0] = 0; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * 128; if (n > slab_c_floats) slab_c_floats = n; }
             if (li == 0) { snprintf(line, sizeof(line), "o: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
             ++op;
@@ -207,7 +222,12 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
             O.rver = rver; O.gate_op = -1; if ((int) reader_of_version.size() <= rver) reader_of_version.resize(rver + 1); reader_of_version[rver] = op;
             lin_to_mat(L.gate, O.mat[0]); lin_to_mat(L.up, O.mat[1]);
             const int ncb[2] = { inter / 128, inter / 128 };
-            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 2, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for gate|up");
+            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 2, O.in_type, O.out_type, p, direct), "exl3_pstep_create: no plan for gate|up");
+            if (direct)
+            {
+                PsOp& Po = ops[op - 1];                                 // this layer's o_proj
+                O.in_type |= PS_DIRECT; Po.out_type |= PS_DIRECT; O.S_in = Po.S; O.in_svh[0] = Po.mat[0].svh;
+            }
             O.S = p.S; add_tiles(op, p, ncb, 2, hidden / 128, 0);
             Pending f; f.op = op; f.which = 1; size_t off = 0;
             for (int i = 0; i < 2; ++i) { f.off[i] = off; off += (size_t) ncb[i] * p.S * 128; }
@@ -224,7 +244,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
             const int ncb[1] = { hidden / 128 };
             OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, inter / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for down_proj");
             O.S = p.S; add_tiles(op, p, ncb, 1, inter / 128, 0);
-            O.rver = ++rver; O.gate_op = rver >= 3 ? reader_of_version[rver - 2] : -1;
+            O.rver = ++rver; O.gate_op = direct ? op - 1 : (rver >= 3 ? reader_of_version[rver - 2] : -1);
             { Pending f; f.op = op; f.which = 3; f.off[0] = 0; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * 128; if (n > slab_d_floats) slab_d_floats = n; }
             if (li == 0) { snprintf(line, sizeof(line), "down: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
             ++op;
@@ -238,7 +258,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
         const int ncb[1] = { head->n / 128 };
         OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for the lm_head (vocab / 128 <= 16 x CUs)");
         O.S = p.S; add_tiles(op, p, ncb, 1, hidden / 128, 0);
-        snprintf(line, sizeof(line), "head: S=%d groups=%d tile<=%dx%d", p.S, p.g[0], p.wmax, p.hmax); desc += line;
+        snprintf(line, sizeof(line), "head: S=%d groups=%d tile<=%dx%d; residual edges: %s", p.S, p.g[0], p.wmax, p.hmax, direct ? "direct (consumer gathers)" : "owners"); desc += line;
         ++op;
     }
 
@@ -251,13 +271,18 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     PS_TRY(hipMemset(h->d_slab_a, 0, slab_a_floats * 8)); PS_TRY(hipMemset(h->d_slab_b, 0, slab_b_floats * 8));
     PS_TRY(hipMalloc(&h->d_slab_c, slab_c_floats * 8)); PS_TRY(hipMalloc(&h->d_slab_d, slab_d_floats * 8));
     PS_TRY(hipMemset(h->d_slab_c, 0, slab_c_floats * 8)); PS_TRY(hipMemset(h->d_slab_d, 0, slab_d_floats * 8));
-    PS_TRY(hipMalloc(&h->d_rbuf, (size_t) 2 * PS_MAX_SLICE_BLOCKS * 1024)); PS_TRY(hipMemset(h->d_rbuf, 0, (size_t) 2 * PS_MAX_SLICE_BLOCKS * 1024));
+    PS_TRY(hipMalloc(&h->d_rbuf, (size_t) PS_RBUF_BYTES)); PS_TRY(hipMemset(h->d_rbuf, 0, (size_t) PS_RBUF_BYTES));
     for (const Pending& f : slab_fix)
     {
         PsOp& O = ops[f.op];
         unsigned long long* base = f.which == 0 ? h->d_slab_a : f.which == 1 ? h->d_slab_b : f.which == 2 ? h->d_slab_c : h->d_slab_d;
         for (int i = 0; i < O.nmat; ++i) O.mat[i].slab = base + f.off[i];
-        if (f.which >= 2) continue;                                   // (partial lines of an op that adds into the row: read by its own owners)
+        if (f.which >= 2)
+        {
+            // partial lines of an op that adds into the row: read by its own owners, or (DIRECT) by the RMSNorm op that follows
+            if (O.out_type & PS_DIRECT) ops[f.op + 1].in_slab[0] = base + f.off[0];
+            continue;
+        }
         PsOp& C = ops[f.op + 1];                                      // the consumer op reads these slab sets
         for (int i = 0; i < O.nmat; ++i) C.in_slab[i] = base + f.off[i];
     }
@@ -291,7 +316,16 @@ extern "C" int exl3_pstep_plan_tiles(int hidden, int inter, int heads_q, int hea
         default: exl3_set_error("exl3_pstep_plan_tiles: op_kind 0..4"); return EXL3_ERR_ARG;
     }
     OpPlan p;
-    EXL3_CHECK_ARG(plan_op(ncu, nblk, ncb, nmat, in_type, out_type, p), "exl3_pstep_plan_tiles: no plan for this op on %d CUs", ncu);
+    // the RMSNorm ops of the layers take the DIRECT-edge plan (slices of <= 4 blocks) when both have one, as exl3_pstep_create decides
+    bool direct = false;
+    if (op_kind == 0 || op_kind == 2)
+    {
+        const int ncb3[3] = { qdim / 128, kvdim / 128, kvdim / 128 }; const int ncb2[2] = { inter / 128, inter / 128 };
+        OpPlan t;
+        direct = plan_op(ncu, hidden / 128, ncb3, 3, PS_IN_NORM, PS_OUT_SLAB, t, true) && plan_op(ncu, hidden / 128, ncb2, 2, PS_IN_NORM, PS_OUT_SLAB, t, true);
+        if (const char* e = getenv("EXL3_HIP_PSTEP_OWNERS")) if (atoi(e)) direct = false;
+    }
+    EXL3_CHECK_ARG(plan_op(ncu, nblk, ncb, nmat, in_type, out_type, p, direct), "exl3_pstep_plan_tiles: no plan for this op on %d CUs", ncu);
     std::vector<PsTile> T((size_t) ncu);
     fill_tiles(T.data(), ncu, p, ncb, nmat, nblk, side);
     memcpy(tiles_out, T.data(), (size_t) ncu * sizeof(PsTile));

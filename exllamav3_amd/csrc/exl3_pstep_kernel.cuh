@@ -434,6 +434,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         __builtin_amdgcn_s_setprio(3);                                    // the workgroup's latency chain runs here
         bool aborted = false;
         uint32_t tgt_a = 0u, tgt_o = 0u;
+        float r_last = 1.0f;                                              // the row scale (1 / rms) this workgroup last knew: DIRECT RMSNorm ops form their quads with it
         auto poll_cnt = [&] (int cop, uint32_t errbit)                    // every workgroup has arrived at counter `cop` (8 XCD shards)
         {
             if (aborted) return;
@@ -471,7 +472,8 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             asm volatile("" : "+s"(rope_sin_p), "+s"(rope_cos_p), "+s"(q_out_p), "+s"(logits_p), "+s"(cnt_p));
             const bool active = tl.mat >= 0;
             const int b0 = tl.b0, nb = active ? tl.nb : 0, W = active ? tl.ncb : 0;
-            const int in_type = O->in_type, out_type = O->out_type, kk = O->k, nblk = kk >> 7;
+            const int in_raw = O->in_type, out_raw = O->out_type, in_type = in_raw & 0xff, out_type = out_raw & 0xff, kk = O->k, nblk = kk >> 7;
+            const bool in_direct = (in_raw & PS_DIRECT) != 0, out_direct = (out_raw & PS_DIRECT) != 0;       // DIRECT residual edge (exl3_pstep.cuh)
             const uint32_t tag_out = (epoch << 12) | (uint32_t) (op + 1), tag_in = (epoch << 12) | (uint32_t) op;       // tag of op i = (epoch, i + 1), never 0
             float* const bsum = bsum2 + (op & 1) * 64;
             const int* const seginfo = seginfo2 + (op & 1) * 64;
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             for (int i = 0; i < 4; ++i) { wv[i] = sva; sv[i] = sva; }
             const half_t* const suh_m = active ? O->mat[tl.mat].suh : nullptr;
             // NORM: service half-wave shw holds blocks shw + 8 it of the row (and rotates those that lie in the slice); QKV / ACT: task block b0 + shw (planner: nb <= 8)
-            if (in_type == PS_IN_NORM)
+            if (in_type == PS_IN_NORM && !in_direct)
             {
                 #pragma unroll
                 for (int it = 0; it < 4; ++it)
@@ -499,7 +501,8 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 const int blk = b0 + min(shw, nb - 1);
                 sv[0] = ps_g((const half4_t*) (suh_m + (size_t) blk * 128))[l32];
                 sva = ps_g((const half4_t*) (O->in_svh[0] + (size_t) blk * 128))[l32];
-                if (in_type == PS_IN_ACT) svb = ps_g((const half4_t*) (O->in_svh[1] + (size_t) blk * 128))[l32];
+                if (in_type == PS_IN_NORM) wv[0] = ps_g((const half4_t*) (O->norm_w + (size_t) blk * 128))[l32];      // DIRECT: block b0 + shw is this half-wave's task
+                else if (in_type == PS_IN_ACT) svb = ps_g((const half4_t*) (O->in_svh[1] + (size_t) blk * 128))[l32];
                 else
                 {
                     const int ph = O->hd >> 3;
@@ -550,7 +553,121 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 }
             };
 
-            if (in_type == PS_IN_NORM)
+            float fac_norm = 1.0f, r_next = r_last;                        // DIRECT: (true row scale) / (the scale the quads were formed with) multiplies the partial sums
+            if (in_type == PS_IN_NORM && in_direct)
+            {
+                // DIRECT residual edge: this workgroup finishes the blocks of ITS slice of the row's new version from the producer op's partial lines -- ONE hop
+                // (partial lines -> here) instead of two (partial lines -> owner -> owner's line -> every workgroup).  All eight service half-waves gather (half-wave h:
+                // lines h, h + 8, ... of a block, two blocks per round while S_in <= 16), the block's half-wave adds the eight sums in the owners' order, output
+                // Hadamard, the producer's svh, + the block of the previous version; one workgroup per slice (PS_TILE_Q_OUT) publishes the new blocks and their
+                // sums of squares.  The quads are formed with r_last; the true scale needs every block's sum of squares: see the finish below
+                if (sw == 0) PS_T(4);
+                const int rver = O->rver;
+                if (active)
+                {
+                    const ps_rsrc_t rp = ps_rsrc(O->in_slab[0]);
+                    const int S_p = O->S_in;
+                    const bool two = S_p <= 16;
+                    const int rounds = two ? (nb + 1) >> 1 : nb;
+                    for (int r = 0; r < rounds; ++r)
+                    {
+                        float4_t ya = { 0.f, 0.f, 0.f, 0.f }, yb = ya;
+                        for (int spins = 0;; ++spins)
+                        {
+                            uint4_t t[4][2];
+                            bool ok = true;
+                            #pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                            {
+                                const int jj = two ? 2 * r + (i >> 1) : r, s_ = shw + 8 * (two ? (i & 1) : i);
+                                const uint32_t o = ((uint32_t) (b0 + min(jj, nb - 1)) * (uint32_t) S_p + (uint32_t) min(s_, S_p - 1)) * PS_LINE_BYTES + (uint32_t) l32 * 16;
+                                t[i][0] = ps_ld128(rp, o); t[i][1] = ps_ld128(rp, o + 512);
+                            }
+                            ya = float4_t{ 0.f, 0.f, 0.f, 0.f }; yb = ya;
+                            #pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                            {
+                                const int jj = two ? 2 * r + (i >> 1) : r, s_ = shw + 8 * (two ? (i & 1) : i);
+                                const bool use = jj < nb && s_ < S_p, to_b = two && (i >> 1);
+                                ok &= !use | ((t[i][0].y == tag_in) & (t[i][0].w == tag_in) & (t[i][1].y == tag_in) & (t[i][1].w == tag_in));
+                                const uint32_t ma = (use && !to_b) ? 0xffffffffu : 0u, mb = (use && to_b) ? 0xffffffffu : 0u;
+                                ya.x += __uint_as_float(t[i][0].x & ma); ya.y += __uint_as_float(t[i][0].z & ma); ya.z += __uint_as_float(t[i][1].x & ma); ya.w += __uint_as_float(t[i][1].z & ma);
+                                yb.x += __uint_as_float(t[i][0].x & mb); yb.y += __uint_as_float(t[i][0].z & mb); yb.z += __uint_as_float(t[i][1].x & mb); yb.w += __uint_as_float(t[i][1].z & mb);
+                            }
+                            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                            if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        const int ja = two ? 2 * r : r;
+                        ((float4_t*) (gath + ((size_t) (ja & 3) * 8 + shw) * 128))[l32] = ya;
+                        if (two) ((float4_t*) (gath + ((size_t) ((ja + 1) & 3) * 8 + shw) * 128))[l32] = yb;
+                    }
+                    tgt_o += PS_NSV;
+                    c_inc(PS_C_O);
+                }
+                // the previous version's block of this half-wave's task (tagged by the workgroup that published it two ops ago; version 0 = the caller's R)
+                const bool has_task = active && 2 * sw < nb;               // wave-uniform
+                const int tb = min(shw, max(nb - 1, 0)), blk = b0 + tb;
+                const bool act = active && shw < nb;
+                const ps_rsrc_t rb = ps_rsrc(a.rbuf);
+                float4_t rold = { 0.f, 0.f, 0.f, 0.f };
+                if (has_task)
+                {
+                    if (rver == 1)
+                    {
+                        const ps_rsrc_t r0 = ps_rsrc(a.R);
+                        const uint32_t ro = (uint32_t) blk * 1024u + (uint32_t) l32 * 32u;
+                        const uint4_t ra = ps_ld128(r0, ro), rc = ps_ld128(r0, ro + 16u);
+                        rold = float4_t{ fx_to_float(ra.x, ra.y), fx_to_float(ra.z, ra.w), fx_to_float(rc.x, rc.y), fx_to_float(rc.z, rc.w) };
+                    }
+                    else
+                    {
+                        const uint32_t tag_old = (epoch << 12) | (uint32_t) (op - 2), ro = (uint32_t) ((rver - 1) & 1) * 32768u + (uint32_t) blk * PS_LINE_BYTES + (uint32_t) l32 * 16u;
+                        for (int spins = 0;; ++spins)
+                        {
+                            const uint4_t ra = ps_ld128(rb, ro), rc = ps_ld128(rb, ro + 512u);
+                            rold = float4_t{ __uint_as_float(ra.x), __uint_as_float(ra.z), __uint_as_float(rc.x), __uint_as_float(rc.z) };
+                            const bool ok = (ra.y == tag_old) & (ra.w == tag_old) & (rc.y == tag_old) & (rc.w == tag_old);
+                            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                            if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                }
+                // every row-related load of this wave is in registers: the read gate (all workgroups arrive, also those without a rectangle)
+                tgt_a += PS_NSV;
+                { const uint32_t old = c_inc(PS_C_A); if (old + 1u == tgt_a) arrive(op); }
+                if (active) c_spin(PS_C_O, tgt_o);
+                if (sw == 0) PS_T(8);
+                if (has_task)
+                {
+                    float4_t ys = { 0.f, 0.f, 0.f, 0.f };
+                    #pragma unroll
+                    for (int h = 0; h < 8; ++h)
+                    {
+                        const float4_t t = ((const float4_t*) (gath + ((size_t) (tb & 3) * 8 + h) * 128))[l32];
+                        ys.x += t.x; ys.y += t.y; ys.z += t.z; ys.w += t.w;
+                    }
+                    float h0, h1, h2, h3;
+                    out_had(ys, l32, h0, h1, h2, h3);
+                    const float n0 = rold.x + h0 * (float) sva.x, n1 = rold.y + h1 * (float) sva.y, n2 = rold.z + h2 * (float) sva.z, n3 = rold.w + h3 * (float) sva.w;
+                    float ssq = n0 * n0;
+                    ssq = __builtin_fmaf(n1, n1, ssq); ssq = __builtin_fmaf(n2, n2, ssq); ssq = __builtin_fmaf(n3, n3, ssq);
+                    #pragma unroll
+                    for (int i = 1; i < 32; i <<= 1) ssq += xor_lane(ssq, i);
+                    if (act && (tl.flags & PS_TILE_Q_OUT))
+                    {
+                        const uint32_t no = (uint32_t) (rver & 1) * 32768u + (uint32_t) blk * PS_LINE_BYTES + (uint32_t) l32 * 16u;
+                        ps_st128(rb, no, uint4_t{ __float_as_uint(n0), tag_in, __float_as_uint(n1), tag_in });
+                        ps_st128(rb, no + 512, uint4_t{ __float_as_uint(n2), tag_in, __float_as_uint(n3), tag_in });
+                        if (l32 == 0) ps_st128(rb, 65536u + (uint32_t) ((rver & 1) * 32 + blk) * 16u, uint4_t{ __float_as_uint(ssq), tag_in, 0u, tag_in });
+                    }
+                    const half4_t xv = { f2h(n0 * (float) wv[0].x * r_last), f2h(n1 * (float) wv[0].y * r_last), f2h(n2 * (float) wv[0].z * r_last), f2h(n3 * (float) wv[0].w * r_last) };
+                    rotate_store(xv, sv[0], tb, act);
+                }
+                if (sw == 0) PS_T(9);
+            }
+            else if (in_type == PS_IN_NORM)
             {
                 if (sw == 0) PS_T(4);
                 // exact RMSNorm: every workgroup reads the whole row -- service half-wave shw takes blocks shw + 8 i (block sums of squares in rms_norm's
@@ -618,6 +735,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 #pragma unroll
                 for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
                 const float r = __frsqrt_rn(s2 / (float) kk + O->eps);
+                r_next = r;
                 #pragma unroll
                 for (int it = 0; it < 4; ++it) if (8 * it < nblk)
                 {
@@ -698,9 +816,30 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
 
             // ---- an op that produces a new version of the row: its owners overwrite the lines of the version before the previous one -- the read gate of
             // the op that read THAT version (every workgroup had it in registers long ago); polled under the streaming
-            if (out_type == PS_OUT_ATOMIC)
+            if (out_type == PS_OUT_ATOMIC && !out_direct)
             {
                 if (sw == 0) { const int gop = O->gate_op; if (gop >= 0) poll_cnt(gop, 4u); c_set(PS_C_G, (uint32_t) (op + 1)); }
+            }
+            // DIRECT RMSNorm op: the true row scale from the blocks' sums of squares (published by one workgroup per slice during ITS preparation, one hop
+            // away: here long before the streaming ends); the partial sums are linear in the scale the quads were formed with
+            if (in_type == PS_IN_NORM && in_direct && active)
+            {
+                const ps_rsrc_t rb = ps_rsrc(a.rbuf);
+                const uint32_t go = 65536u + (uint32_t) ((O->rver & 1) * 32 + min(l32, nblk - 1)) * 16u;
+                float s2 = 0.0f;
+                for (int spins = 0;; ++spins)
+                {
+                    const uint4_t g = ps_ld128(rb, go);
+                    s2 = l32 < nblk ? __uint_as_float(g.x) : 0.0f;
+                    const bool ok = (g.y == tag_in) & (g.w == tag_in);
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                    if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                #pragma unroll
+                for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
+                r_next = __frsqrt_rn(s2 / (float) kk + O->eps);
+                fac_norm = r_next / r_last;
             }
 
             // ---- the streaming waves' partial rows are in LDS: service half-wave shw finishes column blocks shw, shw + 8 of the rectangle
@@ -775,7 +914,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 if (sw == 0 && j == shw) PS_T(10);
                 const float kinv = (float) u16_as_half(0x1eeeu), kbias = (float) u16_as_half(0xc931u);
                 const float bb = kbias * xs;
-                v.x = v.x * kinv + bb; v.y = v.y * kinv + bb; v.z = v.z * kinv + bb; v.w = v.w * kinv + bb;
+                v.x = (v.x * kinv + bb) * fac_norm; v.y = (v.y * kinv + bb) * fac_norm; v.z = (v.z * kinv + bb) * fac_norm; v.w = (v.w * kinv + bb) * fac_norm;
                 const int cbl = tl.cb0 + j;
                 if (out_type != PS_OUT_FINAL)
                 {
@@ -796,7 +935,8 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 }
             }
             if (sw == 0) PS_T(11);
-            if (out_type == PS_OUT_ATOMIC && active && tl.slice == 0)
+            r_last = r_next;
+            if (out_type == PS_OUT_ATOMIC && !out_direct && active && tl.slice == 0)
             {
                 // OWNERS of the residual row's blocks cb0 .. cb0 + W - 1 (the slice-0 workgroup of the column group).  All eight service half-waves gather: half-wave h
                 // takes the partial lines s = h, h + 8, ... of every owned block (tagged: re-loaded until complete; one round of loads), leaves its sum in LDS, and
@@ -851,10 +991,18 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     }
                     else
                     {
+                        // (tagged by whoever published version rv - 1: the owners of op - 2, or -- DIRECT -- the publishing workgroups of op - 1; the same tag)
                         const ps_rsrc_t r0 = ps_rsrc(a.rbuf + (size_t) ((rv - 1) & 1) * PS_MAX_SLICE_BLOCKS * 128);
-                        const uint32_t ro = (uint32_t) cbl * PS_LINE_BYTES + (uint32_t) l * 16u;
-                        const uint4_t ra = ps_ld128(r0, ro), rb = ps_ld128(r0, ro + 512u);
-                        rold = float4_t{ __uint_as_float(ra.x), __uint_as_float(ra.z), __uint_as_float(rb.x), __uint_as_float(rb.z) };
+                        const uint32_t ro = (uint32_t) cbl * PS_LINE_BYTES + (uint32_t) l * 16u, tag_old = (epoch << 12) | (uint32_t) (op - 1);
+                        for (int spins = 0;; ++spins)
+                        {
+                            const uint4_t ra = ps_ld128(r0, ro), rb = ps_ld128(r0, ro + 512u);
+                            rold = float4_t{ __uint_as_float(ra.x), __uint_as_float(ra.z), __uint_as_float(rb.x), __uint_as_float(rb.z) };
+                            const bool ok = (ra.y == tag_old) & (ra.w == tag_old) & (rb.y == tag_old) & (rb.w == tag_old);
+                            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                            if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
                     }
                     c_spin(PS_C_O, tgt_o);
                     float4_t ys = { 0.f, 0.f, 0.f, 0.f };

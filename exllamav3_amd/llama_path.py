@@ -777,9 +777,9 @@ class SyntheticEXL3Llama:
                                   bsz, self.lm_head.mcg, self.lm_head.mul1, 0)
         return self.logits
 
-    #: the persistent decode step (round 5, ext.PersistentStep): None = where it is the faster one by measurement (hidden <= 2048: Llama-3.2-1B 2218 vs 1965
-    #: tok/s in tools/experiments/pstep_harness; Llama-3.1-8B 623 vs 634: launches stay); EXL3_HIP_PSTEP=0/1 forces it.  Batch 1, one rank, mul1 codebook,
-    #: 4-bit cache, no attention core (the linears-only step), one K for all layers and the head
+    #: the persistent decode step (round 5, ext.PersistentStep): None = wherever it applies -- with the direct residual edges and three decode-ahead units it is
+    #: the faster step at both measured widths (tools/experiments/pstep_harness, same box: Llama-3.2-1B 2360 vs 1965 tok/s, Llama-3.1-8B 680 vs 641);
+    #: EXL3_HIP_PSTEP=0/1 forces it.  Batch 1, one rank, mul1 codebook, 4-bit cache, no attention core (the linears-only step), one K for all layers and the head
     persistent = {"0": False, "1": True}.get(os.environ.get("EXL3_HIP_PSTEP", ""), None)
 
     def persistent_applies(self) -> bool:
@@ -792,7 +792,8 @@ class SyntheticEXL3Llama:
         """The whole decode step as ONE launch (ext.PersistentStep / exl3_pstep.hip) behind the step's set-up launch (fx_init_prep: fixed-point copy of the
         input row, rope tables, cache rows): every quantized linear of every layer + the lm_head, RMSNorm, q|k|v epilogue with RoPE and the 4-bit K / V
         append, silu * mul and the residual adds.  Same arithmetic per linear as decode_step_fx (generation 4's work unit, the same glue device functions);
-        the residual is kept in fp32 between the linears and the RMSNorm scale is exact (decode_step_fx: 64-bit fixed point, previous 1/rms + correction).
+        the residual is kept in fp32 between the linears; an RMSNorm's input is formed with the scale of the row's previous version and the linear's partial sums
+        are corrected by (true scale / that scale) (decode_step_fx: 64-bit fixed point; the same correction for batches above 4).
         Falls back to decode_step_fx where it does not apply."""
         if not self.persistent_applies():
             return self.decode_step_fx()
@@ -807,7 +808,7 @@ class SyntheticEXL3Llama:
 
     def decode_step_auto(self):
         """decode_step_persistent where it applies and is the faster step (see `persistent`), else decode_step_fx."""
-        use = self.persistent if self.persistent is not None else self.shape.hidden <= 2048
+        use = self.persistent if self.persistent is not None else True
         return self.decode_step_persistent() if (use and self.persistent_applies()) else self.decode_step_fx()
 
     #: tensor-parallel ranks take the fx pipeline too (round 4): 7 launches per layer instead of the glue pipeline's 8-10

@@ -26,6 +26,14 @@ def test_bench_single_process_line(dev):
     assert KEYS <= set(d) and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "workload" in d["config"]
+    # the default step of this configuration is the persistent one: ONE launch per step is the dominant kernel, the launch-per-op GEMV table rides along
+    assert rf["launches_per_step"] == 1 and "exl3_pstep_kernel" in rf["kernel"] and len(rf["launch_per_op_gemv"]["per_launch"]) == 5
+    assert d["logits_check"]["step"] == "decode_step_persistent" and not d["logits_check"]["edge_timeout"]
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--layers", "2", "--steps", "3", "--warmup", "1", "--no-prefill", "--no-cpu", "--pipeline", "fx"],
+                        capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    d2 = _line(r2.stdout)
+    assert d2["roofline"]["launches_per_step"] > 1 and len(d2["roofline"]["per_launch"]) == 5 and d2["roofline"]["fit"]["const_us"] > 0
 
 
 def test_bench_two_ranks_control_flow(dev):
@@ -51,7 +59,8 @@ def test_bench_two_ranks_control_flow(dev):
 
 
 @pytest.mark.parametrize("name,K,cb,bsz,pipeline", [("llama-3.1-8b", 4, 2, 1, "fx"), ("llama-3.1-8b", 4, 0, 1, "fx"), ("llama-3.1-8b", 4, 2, 16, "fx"),
-                                                     ("llama-3.2-1b", 4, 2, 1, "fx"), ("llama-3.1-8b", 4, 2, 1, "glue"), ("llama-3.1-70b", 3, 2, 1, "fx")])
+                                                     ("llama-3.2-1b", 4, 2, 1, "fx"), ("llama-3.1-8b", 4, 2, 1, "glue"), ("llama-3.1-70b", 3, 2, 1, "fx"),
+                                                     ("llama-3.1-8b", 4, 2, 1, "persistent"), ("llama-3.2-1b", 4, 2, 1, "persistent")])
 def test_bench_pinned_logits_gate(dev, name, K, cb, bsz, pipeline):
     """bench.py's correctness gate: the pipeline it times, over the pin model of the benchmark's shape, reproduces the oracle's committed logits
     (tests/golden/bench_pins.json, re-derived from the oracle by tests/test_bench_pins.py) within 3e-2 * RMS, and its hipGraph replay equals the eager
