@@ -33,6 +33,7 @@
 #define PS_PART_BYTES (12 * 2 * 512)              // partial rows [streaming wave][segment][128] fp32
 #define PS_PDEC_BYTES (12 * 16 * 64 * 8)          // decode-ahead unit #2 of every streaming wave: [wave][16 operand slots][64 lanes] x 8 B
 #define PS_GATH_BYTES (4 * 8 * 512)                // owners of residual-row blocks: [4 blocks][8 service half-waves][128] fp32 gathered sums
+#define PS_DBG_SLOTS 32                           // phase stamps per op and workgroup (exl3_pstep_stamps): 0..12 streaming wave 0 / service wave 0, 16 + w: streaming wave w done, 28 + s: service wave s published its quads
 #define PS_RBUF_BYTES (2 * 32 * 1024 + 2 * 32 * 16)
 #define PS_MAX_SLICE_BLOCKS 32                    // = the largest k / 128 of an RMSNorm op (hidden <= 4096): 8 service half-waves x 4 blocks
 
@@ -71,7 +72,7 @@ struct PsArgs
     uint32_t* cnt;                    // [nops][8 shards][16 words]: arrivals of edge `op`, zero at launch
     uint32_t* epoch;                  // run counter in device memory (tags of the slab granules): read at entry, + 1 at exit
     uint32_t* err;                    // sticky: bit 0 = an edge timed out, bit 1 = a tagged slab line never arrived (results invalid)
-    unsigned long long* dbg;          // optional phase stamps [nops][ncu][16] (100 MHz)
+    unsigned long long* dbg;          // optional phase stamps [nops][ncu][PS_DBG_SLOTS] (100 MHz)
     int spin_limit, pmax;
 };
 

@@ -138,14 +138,19 @@ __device__ __forceinline__ void ps_unit(LaneWords<K> (&ring)[2], const uint32_t*
             const uint32_t r9 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x129, 0xf, 0xf, true);
             Wx[0] = (lane & 7) ? r1 : r9;
         }
-        if (refill) ps_load_row<K>(ring[u], refill + (size_t) u * refill_rs + lofs);      // (null: a wave that must drain its stores right after this unit)
+        if (refill) ps_load_row<K>(ring[u], refill + (size_t) u * refill_rs + lofs);      // (null: nothing to request)
         ps_static_for<0, 4>([&] (auto qc)
         {
             constexpr int q = decltype(qc)::value;
             constexpr int ABID = 8 * HALF + 4 * u + q;
             half4_t bc[2], bd[2];
+#ifdef PS_ABL_NODECODE
+            // speed-only ablation (results are garbage): what does the streaming phase cost without the decode arithmetic?
+            bc[0] = u2_as_half4(Wx[q % (K + 1)], Wx[(q + 1) % (K + 1)]); bd[0] = u2_as_half4(Wx[(q + 1) % (K + 1)], Wx[q % (K + 1)]);
+#else
             decode_quad<K, EXL3_CB_MUL1, 1, 8 * q>(Wx, bc);
             decode_quad<K, EXL3_CB_MUL1, 1, 8 * q + 4>(Wx, bd);
+#endif
             acc_c = __builtin_amdgcn_mfma_f32_4x4x4f16(ag, bc[0], acc_c, 4, ABID, 0);
             acc_d = __builtin_amdgcn_mfma_f32_4x4x4f16(ag, bd[0], acc_d, 4, ABID, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -169,7 +174,7 @@ __device__ __forceinline__ void ps_predecode(LaneWords<K> (&ring)[2], const uint
             const uint32_t r9 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) wl, 0x129, 0xf, 0xf, true);
             Wx[0] = (lane & 7) ? r1 : r9;
         }
-        ps_load_row<K>(ring[u], refill + (size_t) u * refill_rs + lofs);
+        if (refill) ps_load_row<K>(ring[u], refill + (size_t) u * refill_rs + lofs);
         ps_static_for<0, 4>([&] (auto qc)
         {
             constexpr int q = decltype(qc)::value;
@@ -254,7 +259,12 @@ __device__ __forceinline__ PsSeg<K> ps_make_seg(ps_op_p O, const PsTile& t, int 
     if (t.mat >= 0)
     {
         const int H = 4 * t.nb, T = H * t.ncb;
+#ifdef PS_TEST_SW8
+        // experiment: only 8 of the 12 streaming waves take units (does the streaming phase scale with the number of streaming waves?)
+        const int u0 = wave < 8 ? (T * wave) / 8 : T, u1 = wave < 8 ? (T * (wave + 1)) / 8 : T;
+#else
         const int u0 = (T * wave) / PS_SW, u1 = (T * (wave + 1)) / PS_SW;
+#endif
         s.n = u1 - u0;
         s.j0 = u0 / H; s.i0 = u0 - s.j0 * H;
         s.len0 = min(s.n, H - s.i0); s.len1 = s.n - s.len0;
@@ -284,9 +294,10 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cu = blockIdx.x, ncu = a.ncu, nops = a.nops;
     unsigned long long* const dbg = a.dbg;
-    // phase stamps (100 MHz, 16 slots per op and workgroup): lane 0 of streaming wave 0 writes slots 0..2, lane 0 of service wave 0 the others
+    // phase stamps (100 MHz, PS_DBG_SLOTS per op and workgroup): lane 0 of streaming wave 0 writes slots 0..2, lane 0 of service wave 0 slots 3..12; slot 16 + w: streaming
+    // wave w has finished its run, slot 28 + s: service wave s has published its quads
     // (tools/pstep_stamps.py names them)
-    #define PS_T(i) do { if (dbg && lane == 0) dbg[((size_t) op * ncu + cu) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    #define PS_T(i) do { if (dbg && lane == 0) dbg[((size_t) op * ncu + cu) * PS_DBG_SLOTS + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
     if (tid < 8) lctl[tid] = 0u;
     const uint32_t epoch = (uint32_t) __builtin_amdgcn_readfirstlane((int) *a.epoch);      // bumped by workgroup 0 when it leaves: every replay tags afresh
@@ -424,6 +435,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             ring_ready = cur.n > P && nxt.n > 0;
             c_inc(PS_C_S);
             if (wave == 0) PS_T(2);
+            PS_T(16 + wave);
             cur = nxt; tl = tn;
         }
     }
@@ -804,6 +816,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 }
             }
             c_inc(PS_C_T);                                                   // (release: this wave's quads are in LDS)
+            PS_T(28 + sw);
             if (op + 1 < nops)
             {
                 // the next op's rectangle and the cache lines of its descriptor, requested under the streaming (scalar-cache misses otherwise open the next op)

@@ -1887,14 +1887,14 @@ class PersistentStep:
         return buf.value.decode()
 
     def stamps(self):
-        """Phase stamps of the last run as a numpy array [ops][CUs][16] (100 MHz ticks); empty unless created with stamps=True (tools/pstep_stamps.py)."""
+        """Phase stamps of the last run as a numpy array [ops][CUs][32] (100 MHz ticks); empty unless created with stamps=True (tools/pstep_stamps.py)."""
         import numpy as np
-        n = (4 * self.n_layers + 1) * 1024 * 16
+        n = (4 * self.n_layers + 1) * 1024 * 32
         buf = (ctypes.c_uint64 * n)()
         got = _lib.lib().exl3_pstep_stamps(self._h, buf, n, torch.cuda.current_stream().cuda_stream)
         if got < 0:
             raise RuntimeError(_lib.last_error())
-        return np.frombuffer(buf, dtype=np.uint64, count=int(got)).reshape(4 * self.n_layers + 1, -1, 16).copy()
+        return np.frombuffer(buf, dtype=np.uint64, count=int(got)).reshape(4 * self.n_layers + 1, -1, 32).copy()
 
     def __del__(self):
         try:

@@ -621,7 +621,7 @@ int exl3_ar_reduce_slabs(void* ctx, const float* y, const float* slabs, int S, c
  *   exl3_pstep_run      one decode step: R = the int64 fixed-point residual holding the embedded token (exl3_fx_init / exl3_fx_init_prep, which
  *                       also produce rope_sin / rope_cos / slots); logits fp16 [vocab]; q_out optional fp16 [heads_q * head_dim].  Graph-capturable.
  *   exl3_pstep_error    synchronises the stream; 1 if an edge ever timed out (results invalid), else 0.
- *   exl3_pstep_stamps   copies the phase stamps of the last run ([nops][ncu][16] x u64, 100 MHz) to host memory; returns nops * ncu * 16. */
+ *   exl3_pstep_stamps   copies the phase stamps of the last run ([nops][ncu][32] x u64, 100 MHz) to host memory; returns nops * ncu * 32. */
 typedef struct { const void* trellis; const void* suh; const void* svh; int k, n; } exl3_pstep_linear_t;
 typedef struct
 {

@@ -243,11 +243,11 @@ int main(int argc, char** argv)
 
     if (stamps_file)
     {
-        // one eager run with the deepest decode-ahead, then the phase stamps [op][cu][8] (100 MHz ticks)
+        // one eager run with the deepest decode-ahead, then the phase stamps [op][cu][32] (100 MHz ticks)
         CE(exl3_pstep_set(ps, pm.empty() ? 2 : pm[0], 0));
         step_ps(); CK(hipStreamSynchronize(st));
         const int nops = 4 * n_layers + 1;
-        std::vector<uint64_t> sb((size_t) nops * 256 * 16 + 16);
+        std::vector<uint64_t> sb((size_t) nops * 512 * 32 + 16);
         const int64_t got = exl3_pstep_stamps(ps, sb.data(), (int64_t) sb.size(), st);
         FILE* f = fopen(stamps_file, "wb");
         if (f && got > 0) { fwrite(sb.data(), 8, (size_t) got, f); fclose(f); fprintf(stderr, "stamps: %lld words -> %s\n", (long long) got, stamps_file); }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of the persistent decode step (exl3_pstep_stamps: [op][cu][16] x u64, 100 MHz) -> per-op-type medians in microseconds.
+"""Phase stamps of the persistent decode step (exl3_pstep_stamps: [op][cu][32] x u64, 100 MHz) -> per-op-type medians in microseconds.
 Slots -- streaming wave 0: 0 op start, 1 activation quads seen, 2 its units done; service wave 0: 3 op start, 4 edge passed, 8 inputs in registers
 (R / slab lines, tags valid), 9 row sum of squares complete (RMSNorm ops), 5 quads published, 6 all streaming waves done, 10 partial rows summed,
 11 outputs issued, 12 atomics acknowledged (ops that add into R), 7 arrived / done.
@@ -11,8 +11,8 @@ def main():
     path, nl = sys.argv[1], int(sys.argv[2])
     a = np.fromfile(path, dtype=np.uint64)
     nops = 4 * nl + 1
-    ncu = a.size // (nops * 16)
-    a = a.reshape(nops, ncu, 16).astype(np.int64)
+    ncu = a.size // (nops * 32)
+    a = a.reshape(nops, ncu, 32).astype(np.int64)
     a = (a - a[0, :, 3].min()) / 100.0
     names = ["qkv", "o", "gate_up", "down"]
     out = {"total_us": float(a[-1, :, 7].max()), "workgroups": int(ncu), "ops": {}}
@@ -39,6 +39,15 @@ def main():
         rec["streaming_wave0"] = {"decode_ahead_and_wait_us": float(np.median(a[ops][:, :, 1] - a[ops][:, :, 0])), "stream_us": float(np.median(a[ops][:, :, 2] - a[ops][:, :, 1]))}
         rec["last_arrival_to_next_op_edge_passed_us"] = float(np.median([np.median(a[o + 1, :, 4]) - a[o, :, 7].max() for o in ops]))
         rec["finish_spread_max_minus_median_us"] = float(np.median([a[o, :, 7].max() - np.median(a[o, :, 7]) for o in ops]))
+        # per streaming wave: done (slot 16 + w) relative to the moment the LAST service wave published its quads (max of slots 28..31); per service wave: publish time
+        # relative to the first
+        qp = a[ops][:, :, 28:32]; fin = a[ops][:, :, 16:28]
+        have = (fin > 0).all(axis=2) & (qp > 0).all(axis=2)
+        if have.any():
+            rel = (fin - qp.max(axis=2, keepdims=True))[have]
+            rec["streaming_waves_done_after_quads_us"] = [round(float(np.median(rel[:, w])), 2) for w in range(12)]
+            rec["service_waves_publish_spread_us"] = [round(float(np.median((qp - qp.min(axis=2, keepdims=True))[have][:, s_])), 2) for s_ in range(4)]
+            print(f"           streaming waves done after the quads: {rec['streaming_waves_done_after_quads_us']}; service publish spread {rec['service_waves_publish_spread_us']}")
         out["ops"][names[k]] = rec
         print(f"  {names[k]:8s} period {per:5.2f} | " + " | ".join(line))
         print(f"           streamer w0: ahead+wait {rec['streaming_wave0']['decode_ahead_and_wait_us']:.2f}, stream {rec['streaming_wave0']['stream_us']:.2f}; last arrival -> next edge passed {rec['last_arrival_to_next_op_edge_passed_us']:.2f}; finish spread {rec['finish_spread_max_minus_median_us']:.2f}")
