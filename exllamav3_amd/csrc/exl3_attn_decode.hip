@@ -198,7 +198,8 @@ __device__ __forceinline__ half4_t aw_tr16(const half_t* p)
 }
 
 // 8 four-bit levels of one dword -> 8 halves (level - 7.5) * sc4 / 4 ... in pair order (n0, n4), (n1, n5), (n2, n6), (n3, n7); sc4 = 4 * scale as half2
-__device__ __forceinline__ half8_t aw_dequant8(uint32_t x, half2_t sc4)
+// (mk = 0x001E001E held in a VGPR by the caller: with both constants as literals the compiler needs v_and + v_or -- one literal per instruction -- instead of v_and_or_b32)
+__device__ __forceinline__ half8_t aw_dequant8(uint32_t x, half2_t sc4, uint32_t mk)
 {
     const half2_t off = { u16_as_half(0xcc0fu), u16_as_half(0xcc0fu) };         // -(16 + 15/64)
     union { uint32_t u[4]; half8_t h; } r;
@@ -206,7 +207,7 @@ __device__ __forceinline__ half8_t aw_dequant8(uint32_t x, half2_t sc4)
     for (int i = 0; i < 4; ++i)
     {
         const uint32_t sh = i == 0 ? (x << 1) : (x >> (4 * i - 1));
-        const uint32_t m = (sh & 0x001E001Eu) | 0x4C004C00u;
+        const uint32_t m = (sh & mk) | 0x4C004C00u;
         const half2_t v = (u32_as_half2(m) + off) * sc4;
         r.u[i] = half2_as_u32(v);
     }
@@ -416,6 +417,8 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
     half_t* vw = vt[wave];
 
     const int nsteps = (al.split_tokens + 16 * NW - 1) / (16 * NW);
+    uint32_t mk_v = 0x001E001Eu;
+    asm volatile("" : "+v"(mk_v));
     for (int st = 0; st < nsteps; ++st)
     {
         const int tb = t0 + 16 * NW * st + 16 * wave;           // the wave's 16 tokens of this step
@@ -441,7 +444,7 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
         for (int s = 0; s < 4; ++s)
         {
             const half_t k4 = ksc * (half_t) 4.0f;
-            const half8_t ka = aw_dequant8(kw[s], half2_t{ k4, k4 });
+            const half8_t ka = aw_dequant8(kw[s], half2_t{ k4, k4 }, mk_v);
             sc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qf[s], sc, 0, 0, 0);
         }
         // ---- V tile of the wave: token c, dims 32 s + 8 kg .. (pair order) -> LDS row c
@@ -449,13 +452,17 @@ void attn_decode_wide_kernel(const AttnArgs a, const AttnQkvArgs x)
         for (int s = 0; s < 4; ++s)
         {
             const half_t v4 = vsc * (half_t) 4.0f;
-            *((half8_t*) (vw + c * AW_VS + 32 * kg + 8 * s)) = aw_dequant8(vw4[s], half2_t{ v4, v4 });
+            *((half8_t*) (vw + c * AW_VS + 32 * kg + 8 * s)) = aw_dequant8(vw4[s], half2_t{ v4, v4 }, mk_v);
         }
         // ---- online softmax of head c over the step's tokens (log2 domain)
         float mx = m_run;
         #pragma unroll
         for (int r = 0; r < 4; ++r) { if (tb + 4 * kg + r >= t1) sc[r] = -1.0e30f; mx = fmaxf(mx, sc[r]); }
         mx = fmaxf(mx, xor_lane(mx, 16)); mx = fmaxf(mx, xor_lane(mx, 32));
+        // lazy reference: the running reference only moves when the maximum grew by more than 2^8 -- probabilities then stay <= 256 (exact enough in fp16: the
+        // relative precision does not depend on the magnitude; sums and accumulators are fp32) and the accumulator rescale below (36 accumulator reads + 16 packed
+        // multiplies + 4 cross-lane reads per step) runs in the first step and almost never again; the merge only needs (reference, sum) to be consistent
+        if (!(mx > m_run + 8.0f)) mx = m_run;
         const float corr = __builtin_amdgcn_exp2f(m_run - mx);
         float p[4], ps = 0.0f;
         #pragma unroll
