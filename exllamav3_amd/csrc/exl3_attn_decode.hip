@@ -664,9 +664,9 @@ extern "C" int exl3_glue_qkv_tab(const float* sq, const float* sk, const float* 
                                  float attn_factor, const float* ss_prev, const float* ss_new, int hidden, float eps,
                                  const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream);
 
-// waves per workgroup of the matrix-pipe kernel: 0 = by the split length (8 from two 64-token steps on), 4 / 8 / 16 forced (A/B runs, tests)
+// waves per workgroup of the matrix-pipe kernel: 0 = by the split length (8 from two 64-token steps on), 4 / 8 forced (A/B runs, tests)
 static int g_attn_wide_waves = 0;
-extern "C" int exl3_set_attn_wide_waves(int v) { g_attn_wide_waves = (v == 4 || v == 8 || v == 16) ? v : 0; return EXL3_OK; }
+extern "C" int exl3_set_attn_wide_waves(int v) { g_attn_wide_waves = (v == 4 || v == 8) ? v : 0; return EXL3_OK; }
 
 static int attn_decode_impl(const void* q, void* out, const void* k_cache, const void* k_scales, const void* v_cache, const void* v_scales,
                             const int32_t* block_table, const int32_t* cache_seqlens, int bsz, int blocks_per_seq, int page_size,
@@ -800,10 +800,9 @@ static int attn_decode_impl(const void* q, void* out, const void* k_cache, const
             static const int nw_env = [] { const char* e = getenv("EXL3_HIP_ATTN_WIDE_NW"); return e ? atoi(e) : 0; }();
             const int nw_req = g_attn_wide_waves ? g_attn_wide_waves : nw_env;
             const bool nw8 = nw_req ? nw_req == 8 : st_tok >= 128;
-            const bool nw16 = nw_req == 16;
+            // (sixteen waves -- four chains per SIMD, a 64 KB merge through LDS -- measured like four: 443 vs 443 vs 457 tok/s with eight at 16 000 tokens; not instantiated)
             #define AW_LAUNCH(GQv, HD64v) \
-                { if (nw16) { if (xq) attn_decode_wide_kernel<GQv, true, HD64v, 16><<<gridw, 1024, 0, st>>>(a, *xq); else attn_decode_wide_kernel<GQv, false, HD64v, 16><<<gridw, 1024, 0, st>>>(a, AttnQkvArgs{}); } \
-                  else if (nw8) { if (xq) attn_decode_wide_kernel<GQv, true, HD64v, 8><<<gridw, 512, 0, st>>>(a, *xq); else attn_decode_wide_kernel<GQv, false, HD64v, 8><<<gridw, 512, 0, st>>>(a, AttnQkvArgs{}); } \
+                { if (nw8) { if (xq) attn_decode_wide_kernel<GQv, true, HD64v, 8><<<gridw, 512, 0, st>>>(a, *xq); else attn_decode_wide_kernel<GQv, false, HD64v, 8><<<gridw, 512, 0, st>>>(a, AttnQkvArgs{}); } \
                   else     { if (xq) attn_decode_wide_kernel<GQv, true, HD64v, 4><<<gridw, 256, 0, st>>>(a, *xq); else attn_decode_wide_kernel<GQv, false, HD64v, 4><<<gridw, 256, 0, st>>>(a, AttnQkvArgs{}); } }
             if (wide_hd64)
             {

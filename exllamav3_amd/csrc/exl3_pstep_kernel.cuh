@@ -227,6 +227,9 @@ __device__ __forceinline__ void ps_consume(const half4_t (&dec)[16], half4_t ag,
     });
 }
 
+#ifndef PS_POLL_SLEEP
+#define PS_POLL_SLEEP 2                // s_sleep between two polls of tagged lines (x 64 clocks)
+#endif
 #define PS_SW 12                       // streaming waves (3 per SIMD); waves PS_SW .. 15 serve
 #define PS_NSV (PS_WAVES - PS_SW)      // service waves
 // monotonic LDS counters (targets are derived by every wave from the uniform op / tile tables)
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             }
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                             if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                            __builtin_amdgcn_s_sleep(2);
+                            __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                         }
                         const int ja = two ? 2 * r : r;
                         ((float4_t*) (gath + ((size_t) (ja & 3) * 8 + shw) * 128))[l32] = ya;
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             const bool ok = (ra.y == tag_old) & (ra.w == tag_old) & (rc.y == tag_old) & (rc.w == tag_old);
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                             if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                            __builtin_amdgcn_s_sleep(2);
+                            __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                         }
                     }
                 }
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         }
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                         if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                     }
                 }
                 #pragma unroll
@@ -777,7 +780,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         ys = ps_slab_sum<4>(rq, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok);
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                         if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                     }
                     if (sw == 0) PS_T(8);
                     const GemvRescale rs0 = { nullptr, nullptr, 0, 0.0f };
@@ -802,7 +805,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         ps_slab_sum2<3>(rg, ru, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok, vg, vu);
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                         if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                     }
                     if (sw == 0) PS_T(8);
                     float g0, g1, g2, g3, u0, u1, u2, u3;
@@ -847,7 +850,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     const bool ok = (g.y == tag_in) & (g.w == tag_in);
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                     if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                 }
                 #pragma unroll
                 for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             }
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                             if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                            __builtin_amdgcn_s_sleep(2);
+                            __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                         }
                     }
                     ((float4_t*) (gath + ((size_t) (jj & 3) * 8 + shw) * 128))[l32] = ys;
@@ -1014,7 +1017,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             const bool ok = (ra.y == tag_old) & (ra.w == tag_old) & (rb.y == tag_old) & (rb.w == tag_old);
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                             if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                            __builtin_amdgcn_s_sleep(2);
+                            __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                         }
                     }
                     c_spin(PS_C_O, tgt_o);
@@ -1055,7 +1058,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     ys = ps_slab_sum<4>(rk, (uint32_t) hb * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok);
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                     if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                 }
                 const GemvRescale rs0 = { nullptr, nullptr, 0, 0.0f };
                 const int ph = O->hd >> 3;

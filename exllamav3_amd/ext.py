@@ -108,7 +108,7 @@ def set_gemm3_cpw(n: int):
 
 
 def set_attn_wide_waves(n: int):
-    """decode attention, matrix-pipe kernel: waves per workgroup (4 / 8 / 16 = one / two / four token-step chains per SIMD); 0 = by the split length."""
+    """decode attention, matrix-pipe kernel: waves per workgroup (4 / 8 = one / two token-step chains per SIMD); 0 = by the split length."""
     _lib.lib().exl3_set_attn_wide_waves(int(n))
 
 

@@ -112,7 +112,7 @@ int exl3_set_gemv_gen4(int on);                              /* 1 (default; env 
                                                                 (exl3_gemv4.kspec.hip: activation quads in the A-broadcast register layout, no per-wave
                                                                 prologue); 0 pins generation 2 for them */
 int exl3_set_gemm3_cpw(int column_blocks_per_workgroup);    /* generation 3, <= 16-row passes: 1 / 2 / 4 column blocks (4- / 8- / 16-wave workgroups) share one activation tile; 0 = the library's cost model (default; env EXL3_HIP_GEMM3_CPW) */
-int exl3_set_attn_wide_waves(int waves_per_workgroup);       /* decode attention, matrix-pipe kernel: 4 / 8 / 16 waves per workgroup (one / two / four dependent token-step chains per SIMD); 0 = by the split length (default; env EXL3_HIP_ATTN_WIDE_NW).  No reference counterpart: A/B runs and tests */
+int exl3_set_attn_wide_waves(int waves_per_workgroup);       /* decode attention, matrix-pipe kernel: 4 / 8 waves per workgroup (one / two dependent token-step chains per SIMD); 0 = by the split length (default; env EXL3_HIP_ATTN_WIDE_NW).  No reference counterpart: A/B runs and tests */
 int exl3_set_gemm3_min_rows(int min_rows);                   /* passes with >= min_rows rows use the LDS-transpose kernel (exl3_gemm3.kspec.hip); default 5 (9 for raw input), 0 = never */
 int exl3_set_gemv_defer_wg_per_cu(int workgroups_per_cu);      /* deferred-epilogue k-split target, 0 = default (2) */
 

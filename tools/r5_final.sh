@@ -15,35 +15,53 @@ run() { # name, bench args...
   rm -rf $O/$n
 }
 run bs1 --no-prefill --steps 20
-run 1b_persistent --model llama-3.2-1b --pipeline persistent --no-prefill --steps 20
-run 1b_launch_per_op --model llama-3.2-1b --no-prefill --steps 20
-run bs1_persistent --pipeline persistent --no-prefill --steps 20
+run bs1_launch_per_op --pipeline fx --no-prefill --steps 20
+run 1b_persistent --model llama-3.2-1b --no-prefill --steps 20
+run 1b_launch_per_op --model llama-3.2-1b --pipeline fx --no-prefill --steps 20
 run bs1_attention --attention --no-prefill --steps 20
 run prefill --steps 5
-# PMC pass: eager launches (one dispatch record per kernel), FETCH_SIZE in KiB, x2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md)
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc -o out --output-format csv -- python $R/bench.py --no-extra --no-cpu --no-prefill --steps 3 --warmup 1 --no-graph > $O/pmc.log 2>&1
+# PMC passes: eager launches (one dispatch record per kernel), FETCH_SIZE in KiB, x2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md).  One pass per pipeline:
+# the launch-per-op GEMV launches, the persistent step's ONE kernel (8B and 1B)
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc -o out --output-format csv -- python $R/bench.py --no-extra --no-cpu --no-prefill --steps 3 --warmup 1 --no-graph --pipeline fx > $O/pmc.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_p8 -o out --output-format csv -- python $R/bench.py --no-extra --no-cpu --no-prefill --steps 3 --warmup 1 --no-graph > $O/pmc_p8.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_p1 -o out --output-format csv -- python $R/bench.py --no-extra --no-cpu --no-prefill --steps 3 --warmup 1 --no-graph --model llama-3.2-1b > $O/pmc_p1.log 2>&1
 python - <<PY
 import csv, glob, json
-rows = []
-for f in glob.glob("$O/pmc/*counter_collection.csv"):
-    rows += list(csv.DictReader(open(f)))
+def rows_of(d):
+    rows = []
+    for f in glob.glob(d + "/*counter_collection.csv"):
+        rows += list(csv.DictReader(open(f)))
+    return rows
+rows = rows_of("$O/pmc")
 g = [r for r in rows if ("exl3_gemv4_kernel" in r.get("Kernel_Name", "") or "exl3_gemv2_kernel" in r.get("Kernel_Name", "")) and r.get("Counter_Name") == "FETCH_SIZE"]
+out = {}
 if g:
     per = sum(float(r["Counter_Value"]) for r in g) / len(g) * 1024 * 2
     ko = None
     try:
-        kr = [r for r in csv.DictReader(open("$O/${TAG}_bench_bs1_kernel_stats.csv")) if "exl3_gemv4_kernel" in r["Name"] or "exl3_gemv2_kernel" in r["Name"]]
+        kr = [r for r in csv.DictReader(open("$O/${TAG}_bench_bs1_launch_per_op_kernel_stats.csv")) if "exl3_gemv4_kernel" in r["Name"] or "exl3_gemv2_kernel" in r["Name"]]
         calls = sum(int(r["Calls"]) for r in kr); tot = sum(float(r["TotalDurationNs"]) for r in kr)
-        ko = {"avg_launch_us": round(tot / calls / 1e3, 3), "calls": calls, "source": "profiles/${TAG}_bench_bs1_kernel_stats.csv"}
+        ko = {"avg_launch_us": round(tot / calls / 1e3, 3), "calls": calls, "source": "profiles/${TAG}_bench_bs1_launch_per_op_kernel_stats.csv"}
     except Exception as e:
         print("kernel-only figure unavailable:", e)
-    json.dump({"kernel": "exl3_gemv4_kernel<4,2,1,*> (all GEMV launches of the decode step, Llama-3.1-8B 4bpw mul1, bs=1, fx pipeline)", "fetch_bytes_per_launch": int(per),
-               "launches_sampled": len(g), "collected": "${TAG}, tools/r5_final.sh", "kernel_only": ko, "method": "rocprofv3 --pmc FETCH_SIZE (own pass, no tracing) on bench.py --steps 3 --warmup 1 --no-graph; FETCH_SIZE is KiB and reads 1/2 of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section): x1024 x2 applied; average over all GEMV dispatches (includes the activation / residual-accumulator reads and scale vectors)"},
-              open("$O/traffic.json", "w"), indent=1)
+    out = {"kernel": "exl3_gemv4_kernel<4,2,1,*> (all GEMV launches of the decode step, Llama-3.1-8B 4bpw mul1, bs=1, fx pipeline)", "fetch_bytes_per_launch": int(per),
+           "launches_sampled": len(g), "collected": "${TAG}, tools/r5_final.sh", "kernel_only": ko, "method": "rocprofv3 --pmc FETCH_SIZE (own pass, no tracing) on bench.py --steps 3 --warmup 1 --no-graph; FETCH_SIZE is KiB and reads 1/2 of a wide coalesced stream on gfx950 (MI355X_MICROARCH.md, HBM section): x1024 x2 applied; average over all GEMV dispatches (includes the activation / residual-accumulator reads and scale vectors)"}
     print("traffic bytes/launch", int(per), "over", len(g))
 else:
-    print("no PMC rows", len(rows))
+    print("no PMC rows (fx)", len(rows))
+ps = {}
+for model, d in (("llama-3.1-8b", "$O/pmc_p8"), ("llama-3.2-1b", "$O/pmc_p1")):
+    r_ = [r for r in rows_of(d) if "exl3_pstep_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == "FETCH_SIZE"]
+    if r_:
+        per = sum(float(r["Counter_Value"]) for r in r_) / len(r_) * 1024 * 2
+        ps[model] = {"fetch_bytes_per_launch": int(per), "launches_sampled": len(r_), "collected": "${TAG}, tools/r5_final.sh",
+                     "method": "rocprofv3 --pmc FETCH_SIZE (own pass) on bench.py --no-graph --steps 3 --warmup 1; x1024 x2 as above; one dispatch = one decode step"}
+        print("persistent step", model, "fetch bytes / launch", int(per), "over", len(r_))
+    else:
+        print("no PMC rows for the persistent step", model)
+out["persistent_step"] = ps
+json.dump(out, open("$O/traffic.json", "w"), indent=1)
 PY
-rm -rf $O/pmc
+rm -rf $O/pmc $O/pmc_p8 $O/pmc_p1
 cd $R; timeout 400 python bench.py > $O/${TAG}_bench_final.json 2> $O/final.err; tail -c 300 $O/final.err
 ls $O; for f in $O/${TAG}_bench_*_under_rocprof.json $O/${TAG}_bench_final.json; do echo $f; grep "^{" $f | cut -c1-260; done
