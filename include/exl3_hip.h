@@ -614,13 +614,16 @@ int exl3_ar_reduce_slabs(void* ctx, const float* y, const float* slabs, int S, c
  * (RMSNorm, q|k|v epilogue with RoPE + 4-bit K / V append, silu * mul, residual adds).  Replaces, per layer, the graphs of
  * exllamav3_ext/libtorch/attention.cpp:246-330 (attention core excluded: o_proj consumes q) and libtorch/mlp.cpp:14-91, whose linears each keep
  * input Hadamard -> stream -> output Hadamard inside one cooperative launch (quant/exl3_gemv_kernel.cuh:138-402); here the whole chain is one
- * launch of one 16-wave workgroup per CU with an arrival counter between dependent linears, and the waves decode their first weight units of the
- * NEXT linear while they wait for its input.
+ * launch of one 16-wave workgroup per CU; what one CU writes for another travels as tagged 16-byte granules (data and flag in one store: no arrival
+ * counter on the critical path), a linear that follows a residual add gathers the partial rows of its own k-slice itself (one hop), and the waves
+ * decode their first three weight units of the NEXT linear while they wait for its input.
  *   exl3_pstep_create   builds the plan (device-resident op / tile tables, slab and counter buffers) for the given tensors.  K in {2,3,4,5,6,8},
- *                       cb = 2 (mul1), hidden a multiple of 128 and <= 7168, head_dim 64 | 128, 4-bit cache.  flags: bit 0 = record phase stamps.
+ *                       cb = 2 (mul1), hidden a multiple of 128 and <= 4096, head_dim 64 | 128, 4-bit cache.  flags: bit 0 = record phase stamps,
+ *                       bit 1 = the owner form of the residual edges (two hops; A/B runs; env EXL3_HIP_PSTEP_OWNERS=1).
  *   exl3_pstep_run      one decode step: R = the int64 fixed-point residual holding the embedded token (exl3_fx_init / exl3_fx_init_prep, which
  *                       also produce rope_sin / rope_cos / slots); logits fp16 [vocab]; q_out optional fp16 [heads_q * head_dim].  Graph-capturable.
- *   exl3_pstep_error    synchronises the stream; 1 if an edge ever timed out (results invalid), else 0.
+ *   exl3_pstep_set      decode-ahead units 0..3 (-1: keep; default 3), spin limit of the bounded waits (0: keep).
+ *   exl3_pstep_error    synchronises the stream; 1 if a wait ever timed out (results invalid), else 0.
  *   exl3_pstep_stamps   copies the phase stamps of the last run ([nops][ncu][32] x u64, 100 MHz) to host memory; returns nops * ncu * 32. */
 typedef struct { const void* trellis; const void* suh; const void* svh; int k, n; } exl3_pstep_linear_t;
 typedef struct
