@@ -266,7 +266,7 @@ def main():
         {"tail": model.decode_step_tail, "glue": model.decode_step_fused, "resid": model.decode_step_resid, "fx": model.decode_step_fx,
          "unfused": model.decode_step, "persistent": model.decode_step_persistent}[pipeline]
     if pipeline == "persistent":
-        assert not is_moe and world == 1 and model.persistent_applies(), "--pipeline persistent: batch 1, one rank, mul1 codebook, 4-bit cache, no attention core, hidden <= 4096"
+        assert not is_moe and world == 1 and model.persistent_applies(), "--pipeline persistent: batch 1, one rank, mul1 codebook, 4-bit cache, hidden <= 4096 (attention core: head_dim 128)"
     # tensor-parallel decode: the o_proj / down_proj all-reduces go through the one-shot IPC push (exl3_allreduce.hip, fused with the residual
     # add) unless EXL3_HIP_TP_ALLREDUCE=rccl; the set-up self-tests against the collective library and every rank falls back together
     ipc_on = False
@@ -648,7 +648,17 @@ def main():
         # bs 1 with the quant-cache-direct decode attention over a 1000-token context in the step
         model.alloc_state(1)
         model.with_attention = True
-        extra["llama-3.1-8b_bs1_with_attention_ctx1000"] = timed_decode(model, model.decode_step_fx if pipe_x == "fx" else model.decode_step_fused, 1)
+        att_persistent = pipeline == "persistent" and model.persistent_applies()         # (the attention INSIDE the persistent step: head_dim 128)
+        att_step = lambda mdl: (mdl.decode_step_auto if att_persistent else (mdl.decode_step_fx if pipe_x == "fx" else mdl.decode_step_fused))
+        att_desc = ("decode_step_persistent with the decode attention inside o_proj's preparation (one (kv head, context split) item per CU on the service waves, records as tagged lines)"
+                    if att_persistent else fx_step_desc + " + the attention core (q|k|v epilogue inside the context-split launch, merge inside o_proj)")
+        extra["llama-3.1-8b_bs1_with_attention_ctx1000"] = timed_decode(model, att_step(model), 1)
+        extra["llama-3.1-8b_bs1_with_attention_ctx1000"]["step"] = att_desc
+        if att_persistent:
+            extra["llama-3.1-8b_bs1_with_attention_ctx1000"]["edge_timeout"] = bool(model._pstep.error())
+            assert not extra["llama-3.1-8b_bs1_with_attention_ctx1000"]["edge_timeout"], "bench.py: the persistent step (attention inside) reported a time-out"
+            model._pstep = None
+            extra["llama-3.1-8b_bs1_with_attention_ctx1000_launch_per_op"] = timed_decode(model, model.decode_step_fx, 1)
         # ... and over a 16 000-token context (VERDICT r4 task 4: the long-context cost of the quantized-cache attention on the driver line)
         try:
             import copy as _copy
@@ -656,7 +666,13 @@ def main():
             m16.layers, m16.lm_head, m16.final_norm = model.layers, model.lm_head, model.final_norm      # the same weights: only the cache is longer
             m16.alloc_state(1, pos=16000)
             m16.with_attention = True
-            extra["llama-3.1-8b_bs1_with_attention_ctx16000"] = timed_decode(m16, m16.decode_step_fx if pipe_x == "fx" else m16.decode_step_fused, 1)
+            extra["llama-3.1-8b_bs1_with_attention_ctx16000"] = timed_decode(m16, att_step(m16), 1)
+            extra["llama-3.1-8b_bs1_with_attention_ctx16000"]["step"] = att_desc
+            if att_persistent:
+                extra["llama-3.1-8b_bs1_with_attention_ctx16000"]["edge_timeout"] = bool(m16._pstep.error())
+                assert not extra["llama-3.1-8b_bs1_with_attention_ctx16000"]["edge_timeout"], "bench.py: the persistent step (attention inside) reported a time-out"
+                m16._pstep = None
+                extra["llama-3.1-8b_bs1_with_attention_ctx16000_launch_per_op"] = timed_decode(m16, m16.decode_step_fx, 1)
             kvb = 2 * 16000 * model.hkv * shape.head_dim * args.kv_bits // 8 + 2 * 16000 * model.hkv * shape.head_dim // 32 * 2
             d_ms = extra["llama-3.1-8b_bs1_with_attention_ctx16000"]["ms_per_step"] - ms_per_step
             extra["llama-3.1-8b_bs1_with_attention_ctx16000"].update({
@@ -669,6 +685,7 @@ def main():
         except Exception as e:          # (an out-of-memory on a shared box must not take the headline down)
             extra["llama-3.1-8b_bs1_with_attention_ctx16000"] = {"error": repr(e)[:200]}
         model.with_attention = False
+        model._pstep = None
         # bs 1 with the EXACT GEMV variant (MFMA operands = the reference's fp16-rounded weights bit for bit; the headline runs the default variant,
         # unrounded lo + hi / raw byte sums, inside the same 1e-2 bound)
         if args.variant != 0:

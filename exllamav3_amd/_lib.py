@@ -143,6 +143,7 @@ def _declare(l):
     # persistent decode step (exl3_pstep.hip): plan structures mirror include/exl3_hip.h
     sig("exl3_pstep_create", ctypes.POINTER(vp), ctypes.POINTER(PstepLayer), i32, ctypes.POINTER(PstepLinear), vp, i32, i32, i32, i32, i32, i32, f32, i32, i32)
     sig("exl3_pstep_run", vp, vp, vp, vp, vp, vp, vp, vp)
+    sig("exl3_pstep_run_attn", vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp)
     sig("exl3_pstep_plan_tiles", i32, i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(i32))
     sig("exl3_pstep_error", vp, vp)
     sig("exl3_pstep_set", vp, i32, i32)

@@ -26,6 +26,11 @@
 // previous version's blocks, normalises with the scale it last knew and corrects its partial sums by (true scale / that scale) when the block sums of squares
 // -- published with the new blocks by one workgroup per slice -- have arrived (long before the streaming ends).  The producer op then has no owner stage.
 #define PS_DIRECT 0x100
+// ATTENTION inside the step (bit 9 of o_proj's in_type): o_proj's preparation then (a) runs ONE item of the decode attention over the quantized cache -- kv block h, context
+// split s of `nsplit` (tile.side = h * nsplit + s): q / k / v finished from the q|k|v op's slab lines as exl3_attn_decode_qcache_split_qkv does (RoPE, 4-bit append of the
+// new token by the split that holds it), the matrix-pipe split kernel's token loop on the four service waves, the partial record published as a tagged line + a statistics
+// granule -- and (b) merges the records of the query heads of ITS k-slice (all splits: one hop) into o_proj's input.  Reference: libtorch/attention.cpp:246-504.
+#define PS_ATTN 0x200
 
 // LDS map of the kernel (bytes)
 #define PS_QUADS_BYTES 8448                       // activation quads of a slice: (nb * 8 + 4) tile rows x 32 B  ->  nb <= 32 Hadamard blocks
@@ -33,6 +38,8 @@
 #define PS_PART_BYTES (12 * 2 * 512)              // partial rows [streaming wave][segment][128] fp32
 #define PS_PDEC_BYTES (12 * 16 * 64 * 8)          // decode-ahead unit #2 of every streaming wave: [wave][16 operand slots][64 lanes] x 8 B
 #define PS_GATH_BYTES (4 * 8 * 512)                // owners of residual-row blocks: [4 blocks][8 service half-waves][128] fp32 gathered sums
+#define PS_ATT_BYTES 20480                         // attention item: new-token words 128 | scales 16 (@128) | wave statistics 256 (@256) | queries 2048 (@512) | V tiles / partial outputs 4 x 4352 (@2560)
+#define PS_ATT_MAX_SPLITS 32                       // statistics of all splits of a head in one half-wave (one lane per split)
 #define PS_DBG_SLOTS 32                           // phase stamps per op and workgroup (exl3_pstep_stamps): 0..12 streaming wave 0 / service wave 0, 16 + w: streaming wave w done, 28 + s: service wave s published its quads
 #define PS_RBUF_BYTES (2 * 32 * 1024 + 2 * 32 * 16)
 #define PS_MAX_SLICE_BLOCKS 32                    // = the largest k / 128 of an RMSNorm op (hidden <= 4096): 8 service half-waves x 4 blocks
@@ -57,6 +64,16 @@ struct PsOp
     uint32_t* k_cache; half_t* k_scales; uint32_t* v_cache; half_t* v_scales;      // PS_IN_QKV: the layer's 4-bit paged cache
 };
 
+// o_proj with PS_ATTN: overlays mat[1] .. mat[2] of its PsOp (o_proj has one matrix)
+struct PsAtt
+{
+    unsigned long long* rec;           // [hq][nsplit] records of 512 B: the split's 128 output accumulators of the head (rotated domain, un-normalised) as fp16 pairs,
+                                       // lane l's granule { O[4l] O[4l+1], tag, O[4l+2] O[4l+3], tag }
+    unsigned long long* stats;         // [hq][PS_ATT_MAX_SPLITS] granules { running maximum (natural log units), tag, sum, tag }
+    int gq, nsplit, hq, hkv;
+};
+static_assert(sizeof(PsAtt) <= 2 * sizeof(PsMat), "PsAtt overlays two PsMat slots");
+
 // what ONE workgroup (CU) does in one op: a rectangle of (ncb column blocks of matrix mat) x (nb Hadamard blocks of k); mat < 0: nothing (it still meets the edge)
 struct PsTile { int mat, cb0, ncb, b0, nb, slice, side, flags; };
 #define PS_TILE_Q_OUT 1               // this workgroup also stores the finished q blocks of its slice (one column group per slice); in a DIRECT RMSNorm op: it publishes
@@ -69,6 +86,8 @@ struct PsArgs
     unsigned long long* rbuf;         // [2][PS_MAX_SLICE_BLOCKS] lines of 1 KiB: the residual row's versions >= 1 (version v in half v & 1), tagged fp32 pairs;
                                       // then [2][PS_MAX_SLICE_BLOCKS] granules of 16 B { sum of squares of the block, tag, 0, tag }
     const float* rope_sin; const float* rope_cos; const int64_t* slots;
+    const int32_t* block_table; const int32_t* seqlens;      // PS_ATTN: the sequence's page ids [blocks_per_seq], its length INCLUDING the new token [1]
+    int blocks_per_seq, page_size; float att_scale;
     uint32_t* cnt;                    // [nops][8 shards][16 words]: arrivals of edge `op`, zero at launch
     uint32_t* epoch;                  // run counter in device memory (tags of the slab granules): read at entry, + 1 at exit
     uint32_t* err;                    // sticky: bit 0 = an edge timed out, bit 1 = a tagged slab line never arrived (results invalid)

@@ -10,16 +10,22 @@
 #include <stdio.h>
 #include <string.h>
 
-template __global__ void exl3_pstep_kernel<4>(const PsArgs);
+template __global__ void exl3_pstep_kernel<4, false>(const PsArgs);
+template __global__ void exl3_pstep_kernel<4, true>(const PsArgs);
 #ifndef PS_ONLY_K4
-template __global__ void exl3_pstep_kernel<2>(const PsArgs);
-template __global__ void exl3_pstep_kernel<3>(const PsArgs);
-template __global__ void exl3_pstep_kernel<5>(const PsArgs);
-template __global__ void exl3_pstep_kernel<6>(const PsArgs);
-template __global__ void exl3_pstep_kernel<8>(const PsArgs);
+template __global__ void exl3_pstep_kernel<2, false>(const PsArgs);
+template __global__ void exl3_pstep_kernel<3, false>(const PsArgs);
+template __global__ void exl3_pstep_kernel<5, false>(const PsArgs);
+template __global__ void exl3_pstep_kernel<6, false>(const PsArgs);
+template __global__ void exl3_pstep_kernel<8, false>(const PsArgs);
+template __global__ void exl3_pstep_kernel<2, true>(const PsArgs);
+template __global__ void exl3_pstep_kernel<3, true>(const PsArgs);
+template __global__ void exl3_pstep_kernel<5, true>(const PsArgs);
+template __global__ void exl3_pstep_kernel<6, true>(const PsArgs);
+template __global__ void exl3_pstep_kernel<8, true>(const PsArgs);
 #endif
 
-#define PS_LDS_BYTES (PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES + PS_GATH_BYTES)
+#define PS_LDS_BYTES (PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES + PS_GATH_BYTES + PS_ATT_BYTES)
 static_assert(PS_LDS_BYTES <= 160 * 1024, "persistent step: LDS map exceeds a CU's 160 KiB");
 
 namespace
@@ -29,6 +35,7 @@ struct PsHandle
     int K, nops, ncu, pmax, spin_limit, n_layers;
     PsOp* d_ops; PsTile* d_tiles; uint32_t* d_cnt; uint32_t* d_err; unsigned long long* d_dbg;
     unsigned long long* d_slab_a; unsigned long long* d_slab_b; unsigned long long* d_slab_c; unsigned long long* d_slab_d; unsigned long long* d_rbuf; uint32_t* d_epoch;
+    unsigned long long* d_att_rec; unsigned long long* d_att_stats; int attn;
     size_t cnt_bytes, dbg_words;
     std::string desc;
 };
@@ -102,9 +109,9 @@ void lin_to_mat(const exl3_pstep_linear_t& l, PsMat& m)
 }
 }
 
-static void ps_launch(int K, int ncu, hipStream_t st, const PsArgs& args)
+static void ps_launch(int K, bool att, int ncu, hipStream_t st, const PsArgs& args)
 {
-    #define PS_L(KK) case KK: exl3_pstep_kernel<KK><<<dim3(ncu), dim3(PS_NT), PS_LDS_BYTES, st>>>(args); break;
+    #define PS_L(KK) case KK: if (att) exl3_pstep_kernel<KK, true><<<dim3(ncu), dim3(PS_NT), PS_LDS_BYTES, st>>>(args); else exl3_pstep_kernel<KK, false><<<dim3(ncu), dim3(PS_NT), PS_LDS_BYTES, st>>>(args); break;
     switch (K)
     {
         PS_L(4)
@@ -118,7 +125,8 @@ static void ps_launch(int K, int ncu, hipStream_t st, const PsArgs& args)
 
 static int ps_set_lds_attr(int K)
 {
-    #define PS_A(KK) case KK: EXL3_CHECK_HIP(hipFuncSetAttribute((const void*) exl3_pstep_kernel<KK>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES), "hipFuncSetAttribute(pstep)"); break;
+    #define PS_A(KK) case KK: EXL3_CHECK_HIP(hipFuncSetAttribute((const void*) exl3_pstep_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES), "hipFuncSetAttribute(pstep)"); \
+                              EXL3_CHECK_HIP(hipFuncSetAttribute((const void*) exl3_pstep_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES), "hipFuncSetAttribute(pstep)"); break;
     switch (K)
     {
         PS_A(4)
@@ -150,6 +158,16 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     const int nops = 4 * n_layers + 1;
     // DIRECT residual edges (exl3_pstep.cuh) unless flags bit 1 / EXL3_HIP_PSTEP_OWNERS=1 asks for the owner form everywhere (A/B runs); a plan that cannot keep
     // an RMSNorm op's slice at <= 4 blocks falls back to owners for the whole step
+    // attention inside the step (flags bit 2): head_dim 128, <= 8 query heads per kv head, the chip holds one item per (kv head, split) with 2..32 splits
+    const bool attn = (flags & 4) != 0;
+    const int att_blocks = kvdim / 128, att_gq = heads_q / heads_kv;
+    int att_nsplit = 0;
+    if (attn)
+    {
+        EXL3_CHECK_ARG(head_dim == 128 && heads_q % heads_kv == 0 && att_gq <= 8, "exl3_pstep_create: attention inside the step needs head_dim 128 and <= 8 query heads per kv head");
+        att_nsplit = ncu / att_blocks; if (att_nsplit > PS_ATT_MAX_SPLITS) att_nsplit = PS_ATT_MAX_SPLITS;
+        EXL3_CHECK_ARG(att_nsplit >= 1, "exl3_pstep_create: more kv heads than CUs");
+    }
     bool direct = !(flags & 2);
     if (const char* e = getenv("EXL3_HIP_PSTEP_OWNERS")) if (atoi(e)) direct = false;
     {
@@ -210,7 +228,13 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
             O.k_cache = (uint32_t*) L.k_cache; O.k_scales = (half_t*) L.k_scales; O.v_cache = (uint32_t*) L.v_cache; O.v_scales = (half_t*) L.v_scales;
             const int ncb[1] = { hidden / 128 };
             OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, qdim / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for o_proj");
-            O.S = p.S; add_tiles(op, p, ncb, 1, qdim / 128, 2 * kvb);
+            O.S = p.S; add_tiles(op, p, ncb, 1, qdim / 128, attn ? att_blocks * att_nsplit : 2 * kvb);      // side: K / V append tasks, or (PS_ATTN) attention items h * nsplit + s
+            if (attn)
+            {
+                O.in_type |= PS_ATTN;
+                PsAtt* A = (PsAtt*) &O.mat[1];
+                A->rec = nullptr; A->stats = nullptr; A->gq = att_gq; A->nsplit = att_nsplit; A->hq = heads_q; A->hkv = heads_kv;      // (buffers: below)
+            }
             O.rver = ++rver; O.gate_op = direct ? op - 1 : (rver >= 3 ? reader_of_version[rver - 2] : -1);       // (direct: the last readers of the lines an owner overwrites are the op before it)
             { Pending f; f.op = op; f.which = 2; f.off[0] = 0; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * 128; if (n > slab_c_floats) slab_c_floats = n; }
             if (li == 0) { snprintf(line, sizeof(line), "o: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
@@ -258,12 +282,14 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
         const int ncb[1] = { head->n / 128 };
         OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for the lm_head (vocab / 128 <= 16 x CUs)");
         O.S = p.S; add_tiles(op, p, ncb, 1, hidden / 128, 0);
-        snprintf(line, sizeof(line), "head: S=%d groups=%d tile<=%dx%d; residual edges: %s", p.S, p.g[0], p.wmax, p.hmax, direct ? "direct (consumer gathers)" : "owners"); desc += line;
+        snprintf(line, sizeof(line), "head: S=%d groups=%d tile<=%dx%d; residual edges: %s%s", p.S, p.g[0], p.wmax, p.hmax, direct ? "direct (consumer gathers)" : "owners", attn ? "; attention inside o_proj's preparation" : ""); desc += line;
+        if (attn) { snprintf(line, sizeof(line), " (%d kv blocks x %d splits)", att_blocks, att_nsplit); desc += line; }
         ++op;
     }
 
     PsHandle* h = new PsHandle();
     h->K = K; h->nops = nops; h->ncu = ncu; h->pmax = 3; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
+    h->d_att_rec = nullptr; h->d_att_stats = nullptr; h->attn = attn ? 1 : 0;
     h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr; h->d_slab_c = nullptr; h->d_slab_d = nullptr; h->d_rbuf = nullptr; h->d_epoch = nullptr;
     h->cnt_bytes = (size_t) nops * 8 * 16 * 4; h->dbg_words = (flags & 1) ? (size_t) nops * ncu * PS_DBG_SLOTS : 0;
     #define PS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { exl3_set_error("exl3_pstep_create: %s", hipGetErrorString(e_)); exl3_pstep_destroy(h); return EXL3_ERR_HIP; } } while (0)
@@ -272,6 +298,13 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     PS_TRY(hipMalloc(&h->d_slab_c, slab_c_floats * 8)); PS_TRY(hipMalloc(&h->d_slab_d, slab_d_floats * 8));
     PS_TRY(hipMemset(h->d_slab_c, 0, slab_c_floats * 8)); PS_TRY(hipMemset(h->d_slab_d, 0, slab_d_floats * 8));
     PS_TRY(hipMalloc(&h->d_rbuf, (size_t) PS_RBUF_BYTES)); PS_TRY(hipMemset(h->d_rbuf, 0, (size_t) PS_RBUF_BYTES));
+    if (attn)
+    {
+        const size_t rec_bytes = (size_t) heads_q * att_nsplit * 1024, st_bytes = (size_t) heads_q * PS_ATT_MAX_SPLITS * 16;
+        PS_TRY(hipMalloc(&h->d_att_rec, rec_bytes)); PS_TRY(hipMemset(h->d_att_rec, 0, rec_bytes));
+        PS_TRY(hipMalloc(&h->d_att_stats, st_bytes)); PS_TRY(hipMemset(h->d_att_stats, 0, st_bytes));
+        for (int i = 0; i < nops; ++i) if ((ops[i].in_type & 0xff) == PS_IN_QKV) { PsAtt* A = (PsAtt*) &ops[i].mat[1]; A->rec = h->d_att_rec; A->stats = h->d_att_stats; }
+    }
     for (const Pending& f : slab_fix)
     {
         PsOp& O = ops[f.op];
@@ -333,9 +366,28 @@ extern "C" int exl3_pstep_plan_tiles(int hidden, int inter, int heads_q, int hea
     return EXL3_OK;
 }
 
+static int ps_run(PsHandle* h, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots,
+                  const int32_t* block_table, const int32_t* seqlens, int blocks_per_seq, int page_size, float scale, void* stream);
+
 extern "C" int exl3_pstep_run(void* handle, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream)
 {
     PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h && !h->attn, "exl3_pstep_run: this plan has the attention inside (exl3_pstep_run_attn)");
+    return ps_run(h, R, logits, q_out, rope_sin, rope_cos, slots, nullptr, nullptr, 0, 0, 0.0f, stream);
+}
+
+extern "C" int exl3_pstep_run_attn(void* handle, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots,
+                                   const int32_t* block_table, const int32_t* cache_seqlens, int blocks_per_seq, int page_size, float scale, void* stream)
+{
+    PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h && h->attn, "exl3_pstep_run_attn: the plan was created without the attention (flags bit 2)");
+    EXL3_CHECK_ARG(block_table && cache_seqlens && blocks_per_seq >= 1 && page_size >= 16 && page_size % 16 == 0, "exl3_pstep_run_attn: block table / lengths / page size");
+    return ps_run(h, R, logits, q_out, rope_sin, rope_cos, slots, block_table, cache_seqlens, blocks_per_seq, page_size, scale, stream);
+}
+
+static int ps_run(PsHandle* h, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots,
+                  const int32_t* block_table, const int32_t* seqlens, int blocks_per_seq, int page_size, float scale, void* stream)
+{
     EXL3_CHECK_ARG(h && R && logits && rope_sin && rope_cos && slots, "exl3_pstep_run: null argument");
     hipStream_t st = (hipStream_t) stream;
     EXL3_CHECK_HIP(hipMemsetAsync(h->d_cnt, 0, h->cnt_bytes, st), "exl3_pstep_run: hipMemsetAsync");
@@ -343,8 +395,9 @@ extern "C" int exl3_pstep_run(void* handle, void* R, void* logits, void* q_out, 
     a.ops = h->d_ops; a.tiles = h->d_tiles; a.nops = h->nops; a.ncu = h->ncu;
     a.R = (unsigned long long*) R; a.logits = (half_t*) logits; a.q_out = (half_t*) q_out;
     a.rope_sin = rope_sin; a.rope_cos = rope_cos; a.slots = slots;
+    a.block_table = block_table; a.seqlens = seqlens; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.att_scale = scale;
     a.rbuf = h->d_rbuf; a.cnt = h->d_cnt; a.epoch = h->d_epoch; a.err = h->d_err; a.dbg = h->d_dbg; a.spin_limit = h->spin_limit; a.pmax = h->pmax;
-    ps_launch(h->K, h->ncu, st, a);
+    ps_launch(h->K, h->attn != 0, h->ncu, st, a);
     return exl3_check_launch("exl3_pstep_run");
 }
 
@@ -397,6 +450,8 @@ extern "C" int exl3_pstep_destroy(void* handle)
     if (h->d_err) (void) hipFree(h->d_err);
     if (h->d_epoch) (void) hipFree(h->d_epoch);
     if (h->d_dbg) (void) hipFree(h->d_dbg);
+    if (h->d_att_rec) (void) hipFree(h->d_att_rec);
+    if (h->d_att_stats) (void) hipFree(h->d_att_stats);
     if (h->d_slab_a) (void) hipFree(h->d_slab_a);
     if (h->d_slab_b) (void) hipFree(h->d_slab_b);
     if (h->d_slab_c) (void) hipFree(h->d_slab_c);

@@ -17,6 +17,7 @@
 #include "exl3_gemv_args.h"
 #include "exl3_lane_decode.cuh"
 #include "exl3_glue_device.cuh"
+#include "exl3_attn_device.cuh"
 #include <type_traits>
 
 template <int I, int N, typename F>
@@ -280,7 +281,9 @@ __device__ __forceinline__ PsSeg<K> ps_make_seg(ps_op_p O, const PsTile& t, int 
     return s;
 }
 
-template <int K>
+// ATT: the plan has the decode attention inside o_proj's preparation (PS_ATTN).  A separate instantiation: with the attention code compiled in, the step WITHOUT attention
+// ran 2.6 % (8B) / 6 % (1B) slower (250 instead of 78 scalar spills on the service path, a third more code)
+template <int K, bool ATT>
 __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -481,6 +484,12 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         {
             const ps_op_p O = ops_c + op;
             const PsTile tl = tl_next;
+            // the lane coordinates are re-derived per op from an opaque copy of the thread id (and once more behind the attention item): everything computed from them then
+            // lives inside the op -- hoisted out of the op loop, a dozen per-lane offsets stayed live across the attention's token loop, whose registers the allocator then
+            // found in scratch (and a kernel with scratch does not keep the grid co-resident)
+            int tid_v = tid;
+            asm volatile("" : "+v"(tid_v));
+            int lane = tid_v & 63, l32 = lane & 31, shw = 2 * sw + (lane >> 5);
             // (per-lane addresses off these bases are formed where they are used: hoisted out of the op loop they stay live for the whole launch and are
             //  the values the allocator spills -- 36 B of scratch; the empty asm makes the base a fresh value per op)
             const float* rope_sin_p = a.rope_sin; const float* rope_cos_p = a.rope_cos; half_t* q_out_p = a.q_out; half_t* logits_p = a.logits; uint32_t* cnt_p = a.cnt;
@@ -489,11 +498,235 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             const int b0 = tl.b0, nb = active ? tl.nb : 0, W = active ? tl.ncb : 0;
             const int in_raw = O->in_type, out_raw = O->out_type, in_type = in_raw & 0xff, out_type = out_raw & 0xff, kk = O->k, nblk = kk >> 7;
             const bool in_direct = (in_raw & PS_DIRECT) != 0, out_direct = (out_raw & PS_DIRECT) != 0;       // DIRECT residual edge (exl3_pstep.cuh)
+            const bool in_attn = ATT && (in_raw & PS_ATTN) != 0;                                               // the attention inside o_proj's preparation
             const uint32_t tag_out = (epoch << 12) | (uint32_t) (op + 1), tag_in = (epoch << 12) | (uint32_t) op;       // tag of op i = (epoch, i + 1), never 0
             float* const bsum = bsum2 + (op & 1) * 64;
             const int* const seginfo = seginfo2 + (op & 1) * 64;
             if (sw == 0) PS_T(3);
 
+            if (in_type == PS_IN_QKV && in_attn)
+            {
+                // (a) of the attention inside o_proj's preparation (see the preparation branch below): this workgroup's item, BEFORE the op's other operands are requested
+                // (the token loop needs the registers)
+                if (sw == 0) PS_T(4);
+                const PsAtt PS_CONST* const AT = (const PsAtt PS_CONST*) &O->mat[1];
+                const int gq = AT->gq, ns = AT->nsplit;
+                const ps_rsrc_t rrec = ps_rsrc(AT->rec), rst = ps_rsrc(AT->stats);
+                auto svc_bar = [&] () { tgt_o += PS_NSV; c_inc(PS_C_O); c_spin(PS_C_O, tgt_o); };
+                // splits in use: enough for 64 tokens (one step of the four waves) each, at most the plan's nsplit; items of the other splits have nothing to do
+                const int len = __builtin_amdgcn_readfirstlane(ps_g(a.seqlens)[0]);
+                const int ns_eff = min(max((len + 63) >> 6, 1), ns);
+                const int item = (tl.side >= 0 && tl.side % ns < ns_eff) ? tl.side : -1;
+                if (item >= 0)
+                {
+                    char* const attl = smem + (PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES + PS_GATH_BYTES);
+                    uint32_t* const new_kv = (uint32_t*) attl;                              // [2][16]: the new token's K / V words of this kv head
+                    half_t* const new_sc = (half_t*) (attl + 128);                          // [2][4]: their group scales
+                    float* const ml_s = (float*) (attl + 256);                              // [4 waves][8 heads][2]
+                    half_t* const q_s = (half_t*) (attl + 512);                             // [8][128] rotated, pre-scaled queries in pair order
+                    half_t* const vt = (half_t*) (attl + 2560);                             // [4 waves][16 * AW_VS]; after the loop: partial outputs [4][8][128] fp32
+                    const int h = item / ns, split = item - h * ns;
+                    const int c = lane & 15, kg = lane >> 4;
+                    const int st_tok = (((len + ns_eff - 1) / ns_eff) + 15) & ~15;          // tokens per split: a multiple of the 16 tokens a wave takes per step
+                    const int t0 = split * st_tok, t1 = min(len, t0 + st_tok);
+                    const int hkv = AT->hkv, G = hkv * 4;
+                    const bool owner = len - 1 >= t0 && len - 1 < t0 + st_tok;              // the split that holds the new token finishes and appends its K / V
+                    const uint32_t* const kc_p = O->k_cache; const half_t* const ks_p = O->k_scales; const uint32_t* const vc_p = O->v_cache; const half_t* const vs_p = O->v_scales;
+                    const int page = a.page_size, bps = a.blocks_per_seq;
+                    auto page_of = [&] (int tk) -> int64_t { return (int64_t) ps_g(a.block_table)[min(tk / page, bps - 1)]; };
+                    struct StepWords { uint4_t k, v; half_t ks, vs; };
+                    auto load_step = [&] (int st_) -> StepWords
+                    {
+                        StepWords r;
+                        const int tk = max(min(t0 + 64 * st_ + 16 * sw + c, t1 - 1), 0);
+                        const int64_t gbase = (page_of(tk) * page + (tk % page)) * G + h * 4 + kg;
+                        r.k = *ps_g((const uint4_t*) (kc_p + gbase * 4)); r.v = *ps_g((const uint4_t*) (vc_p + gbase * 4));
+                        r.ks = ps_g(ks_p)[gbase]; r.vs = ps_g(vs_p)[gbase];
+                        return r;
+                    };
+                    StepWords w0 = load_step(0);
+                    // ---- tasks, one per half-wave: 0 .. gq - 1 = query head h * gq + task, gq = the new token's K row, gq + 1 = its V row (owner only); a second round for gq = 7, 8
+                    {
+                        const uint32_t set_k = (uint32_t) ((const char*) O->in_slab[1] - (const char*) O->in_slab[0]), set_v = (uint32_t) ((const char*) O->in_slab[2] - (const char*) O->in_slab[0]);
+                        const ps_rsrc_t rq = ps_rsrc(O->in_slab[0]);                        // (q, k and v slab sets lie in one allocation: one resource, per-lane offsets)
+                        const int S_q = O->S_in;
+                        float4_t sn4 = { 0.f, 0.f, 0.f, 0.f }, cs4 = sn4;
+                        if (O->rope_mode == 2) { const int f = 4 * (l32 & 15); sn4 = *ps_g((const float4_t*) (rope_sin_p + f)); cs4 = *ps_g((const float4_t*) (rope_cos_p + f)); }
+                        else { const int f = 2 * (l32 & 31); sn4.x = ps_g(rope_sin_p)[f]; sn4.y = ps_g(rope_sin_p)[f + 1]; cs4.x = ps_g(rope_cos_p)[f]; cs4.y = ps_g(rope_cos_p)[f + 1]; }
+                        #pragma nounroll
+                        for (int r = 0; r < (gq + 2 + 7) / 8; ++r)
+                        {
+                            if (r > 0 && !owner) break;
+                            const int task = r * 8 + shw;
+                            const int kind = task < gq ? 0 : task - gq + 1;                 // 0: query, 1: K row, 2: V row, >= 3: nothing
+                            const int tw = r * 8 + 2 * sw;
+                            const bool wave_has = tw < gq || (owner && tw + 1 >= gq && tw <= gq + 1);      // wave-uniform: tasks tw, tw + 1
+                            if (wave_has)
+                            {
+                                const bool kvt = kind == 1 || kind == 2;
+                                const int cblk = kvt ? h : h * gq + min(task, gq - 1);
+                                const half_t* svp = (kind == 1 ? O->in_svh[1] : (kind == 2 ? O->in_svh[2] : O->in_svh[0])) + (size_t) cblk * 128;
+                                const half4_t sc = ps_g((const half4_t*) svp)[l32];
+                                const uint32_t boff = (kind == 1 ? set_k : (kind == 2 ? set_v : 0u)) + (uint32_t) cblk * (uint32_t) S_q * PS_LINE_BYTES;
+                                float4_t ysum;
+                                for (int spins = 0;; ++spins)
+                                {
+                                    bool ok = true;
+                                    ysum = ps_slab_sum<4>(rq, boff, S_q, l32, tag_in, ok);
+                                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                                    if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                                    __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
+                                }
+                                const GemvRescale rs0 = { nullptr, nullptr, 0, 0.0f };
+                                const half4_t y = qkv_block_finish(ysum, sc, rs0, 0, l32, 0.0f, 0.0f, kind != 2, O->rope_mode, 16, sn4, cs4);
+                                float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
+                                const int64_t token_pos = a.slots[0];
+                                const int64_t gb = token_pos * G + h * 4 + (l32 >> 3);
+                                uint32_t* cw = kind == 2 ? O->v_cache : O->k_cache; half_t* cs = kind == 2 ? O->v_scales : O->k_scales;
+                                const bool actkv = owner && kvt;
+                                kv_quant_regs<4>(v0, v1, v2, v3, cw + gb * 4, cs + gb, actkv, lane);
+                                kv_quant_regs<4>(v0, v1, v2, v3, &new_kv[(kind == 2 ? 16 : 0) + (l32 >> 3) * 4], &new_sc[(kind == 2 ? 4 : 0) + (l32 >> 3)], actkv, lane);
+                                if (kind == 0 && q_out_p && split == 0) ((half4_t PS_GLOBAL*) (q_out_p + (size_t) cblk * 128))[l32] = y;
+                                kvg_had32(v0, v1, v2, v3, lane);
+                                const float fq = ATT_R32 * a.att_scale * 1.44269504f;
+                                const float vv[4] = { v0 * fq, v1 * fq, v2 * fq, v3 * fq };
+                                if (kind == 0)
+                                {
+                                    #pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                    {
+                                        const int d = 4 * l32 + e, d8 = d & 7;
+                                        q_s[task * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) vv[e];
+                                    }
+                                }
+                            }
+                            if (r == 0 && shw >= gq)
+                            {
+                                #pragma unroll
+                                for (int e = 0; e < 4; ++e) q_s[shw * 128 + 4 * l32 + e] = (half_t) 0.0f;      // rows >= gq of the query operand stay zero
+                            }
+                        }
+                    }
+                    svc_bar();
+                    if (sw == 0) PS_T(8);
+                    // (the query fragments are re-read from LDS in every step: 16 registers the token loop does not have -- the persistent kernel's budget is 128)
+                    const half_t* const qrow = q_s + min(c, 7) * 128 + 32 * kg;           // rows >= gq are zero rows; lanes c >= 8 read row 7 and are masked below
+                    float m_run = -1.0e30f, l_run = 0.0f;                  // of query head c (lanes with c >= gq carry zero queries)
+                    float4_t oc[8];
+                    #pragma unroll
+                    for (int nbk = 0; nbk < 8; ++nbk) oc[nbk] = float4_t{ 0.f, 0.f, 0.f, 0.f };
+                    half_t* const vw = vt + (size_t) sw * (16 * AW_VS);
+                    uint32_t mk_v = 0x001E001Eu;
+                    asm volatile("" : "+v"(mk_v));
+                    const int nsteps = (st_tok + 63) / 64;
+                    for (int st = 0; st < nsteps; ++st)
+                    {
+                        const int tb_ = t0 + 64 * st + 16 * sw;            // the wave's 16 tokens of this step
+                        if (tb_ >= t1) break;                              // wave-uniform
+                        const int tk = min(tb_ + c, t1 - 1);
+                        if (owner && tk == len - 1)
+                        {
+                            // the new token's words come from this workgroup's LDS copy (its cache row is being written by this very launch)
+                            w0.k = uint4_t{ new_kv[kg * 4], new_kv[kg * 4 + 1], new_kv[kg * 4 + 2], new_kv[kg * 4 + 3] };
+                            w0.v = uint4_t{ new_kv[16 + kg * 4], new_kv[16 + kg * 4 + 1], new_kv[16 + kg * 4 + 2], new_kv[16 + kg * 4 + 3] };
+                            w0.ks = new_sc[kg]; w0.vs = new_sc[4 + kg];
+                        }
+                        float4_t scv = { 0.f, 0.f, 0.f, 0.f };
+                        {
+                            const half_t k4 = w0.ks * (half_t) 4.0f;
+                            #pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                            {
+                                const half8_t ka = aw_dequant8(s == 0 ? w0.k.x : (s == 1 ? w0.k.y : (s == 2 ? w0.k.z : w0.k.w)), half2_t{ k4, k4 }, mk_v);
+                                half8_t qv = *((const half8_t*) (qrow + 8 * s));
+                                if (c >= 8) qv = half8_t{ 0, 0, 0, 0, 0, 0, 0, 0 };
+                                scv = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qv, scv, 0, 0, 0);
+                            }
+                            const half_t v4 = w0.vs * (half_t) 4.0f;
+                            #pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                *((half8_t*) (vw + c * AW_VS + 32 * kg + 8 * s)) = aw_dequant8(s == 0 ? w0.v.x : (s == 1 ? w0.v.y : (s == 2 ? w0.v.z : w0.v.w)), half2_t{ v4, v4 }, mk_v);
+                        }
+                        // the next step's words are requested HERE -- after this step's words are consumed (one set of them in registers: the budget is 128), ahead of the
+                        // softmax and the value product
+                        if (st + 1 < nsteps) w0 = load_step(st + 1);
+                        float mx = m_run;
+                        #pragma unroll
+                        for (int r = 0; r < 4; ++r) { if (tb_ + 4 * kg + r >= t1) scv[r] = -1.0e30f; mx = fmaxf(mx, scv[r]); }
+                        mx = fmaxf(mx, xor_lane(mx, 16)); mx = fmaxf(mx, xor_lane(mx, 32));
+                        if (!(mx > m_run + 8.0f)) mx = m_run;              // lazy reference (exl3_attn_decode.hip)
+                        const float corr = __builtin_amdgcn_exp2f(m_run - mx);
+                        float p[4], psum = 0.0f;
+                        #pragma unroll
+                        for (int r = 0; r < 4; ++r) { p[r] = scv[r] > -1.0e29f ? __builtin_amdgcn_exp2f(scv[r] - mx) : 0.0f; psum += p[r]; }
+                        psum += xor_lane(psum, 16); psum += xor_lane(psum, 32);
+                        l_run = l_run * corr + psum; m_run = mx;
+                        const half4_t pa = { (half_t) p[0], (half_t) p[1], (half_t) p[2], (half_t) p[3] };
+                        if (__any(corr != 1.0f))
+                        {
+                            float cr[4];
+                            #pragma unroll
+                            for (int r = 0; r < 4; ++r) cr[r] = __shfl(corr, 4 * kg + r, 64);
+                            #pragma unroll
+                            for (int nbk = 0; nbk < 8; ++nbk) { oc[nbk].x *= cr[0]; oc[nbk].y *= cr[1]; oc[nbk].z *= cr[2]; oc[nbk].w *= cr[3]; }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        #pragma unroll
+                        for (int nbk = 0; nbk < 8; ++nbk)
+                        {
+                            const half4_t vb = aw_tr16(vw + (4 * kg + (c >> 2)) * AW_VS + 16 * nbk + 4 * (c & 3));
+                            oc[nbk] = __builtin_amdgcn_mfma_f32_16x16x16f16(pa, vb, oc[nbk], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    // ---- merge the 4 waves (statistics of head c from lanes (c, kg = 0); outputs of heads 4 kg + r, column 16 nbk + c in pair order from every lane)
+                    svc_bar();                                             // the V tiles are dead: their space takes the partial outputs [wave][head][128] fp32
+                    float* const o_s = (float*) vt;
+                    if (kg == 0 && c < 8) { ml_s[(sw * 8 + c) * 2] = m_run; ml_s[(sw * 8 + c) * 2 + 1] = l_run; }
+                    #pragma unroll
+                    for (int nbk = 0; nbk < 8; ++nbk)
+                        #pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                        {
+                            const int head = 4 * kg + r;
+                            if (head < 8) o_s[(sw * 8 + head) * 128 + 16 * nbk + c] = oc[nbk][r];
+                        }
+                    svc_bar();
+                    if (shw < gq)
+                    {
+                        // half-wave i finishes head i of the kv block: lane l owns natural dims 4 l .. 4 l + 3; the record = one tagged line + one statistics granule
+                        const int i = shw;
+                        float M = -1.0e30f;
+                        #pragma unroll
+                        for (int w = 0; w < 4; ++w) M = fmaxf(M, ml_s[(w * 8 + i) * 2]);
+                        float L = 0.0f, Oa[4] = { 0.f, 0.f, 0.f, 0.f };
+                        #pragma unroll
+                        for (int w = 0; w < 4; ++w)
+                        {
+                            const float mw = ml_s[(w * 8 + i) * 2];
+                            const float e = mw > -1.0e29f ? __builtin_amdgcn_exp2f(mw - M) : 0.0f;
+                            L += ml_s[(w * 8 + i) * 2 + 1] * e;
+                            #pragma unroll
+                            for (int e4 = 0; e4 < 4; ++e4)
+                            {
+                                const int d = 4 * l32 + e4, d8 = d & 7;
+                                Oa[e4] += o_s[(w * 8 + i) * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] * e;
+                            }
+                        }
+                        const int hd_ = h * gq + i;
+                        // (the record's 128 accumulators as fp16 pairs: ONE 16-byte granule { O0 O1, tag, O2 O3, tag } per lane, 512 bytes per record -- the merge reads
+                        //  nb x splits of them per workgroup; the merged output is rounded to fp16 anyway)
+                        const uint32_t ro = ((uint32_t) hd_ * (uint32_t) ns + (uint32_t) split) * 512u + (uint32_t) l32 * 16u;
+                        ps_st128(rrec, ro, uint4_t{ half2_as_u32(half2_t{ f2h(Oa[0]), f2h(Oa[1]) }), tag_out, half2_as_u32(half2_t{ f2h(Oa[2]), f2h(Oa[3]) }), tag_out });
+                        if (l32 == 0) ps_st128(rst, ((uint32_t) hd_ * PS_ATT_MAX_SPLITS + (uint32_t) split) * 16u, uint4_t{ __float_as_uint(M * 0.69314718f), tag_out, __float_as_uint(L), tag_out });
+                    }
+                }
+                if (sw == 0) PS_T(8);
+                asm volatile("" : "+v"(tid_v));
+                lane = tid_v & 63; l32 = lane & 31; shw = 2 * sw + (lane >> 5);
+            }
             // ---- static operands of the preparation tasks (weights: requested before any wait)
             half4_t wv[4], sv[4], sva = { 0, 0, 0, 0 }, svb = sva;
             float4_t sn4 = { 0.f, 0.f, 0.f, 0.f }, cs4 = sn4;
@@ -762,6 +995,73 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                                              f2h((float) xr[it].z * (float) wv[it].z * r), f2h((float) xr[it].w * (float) wv[it].w * r) };
                         rotate_store(xv, sv[it], min(max(blk - b0, 0), max(nb - 1, 0)), act);
                     }
+                }
+            }
+            else if (in_type == PS_IN_QKV && in_attn)
+            {
+                // ATTENTION inside o_proj's preparation (exl3_pstep.cuh: PS_ATTN).  (a) this workgroup's item = (kv head h, context split) of the decode attention over the
+                // 4-bit paged cache: the matrix-pipe split kernel of exl3_attn_decode.hip (attn_decode_wide_kernel<GQ, FUSED>, head_dim 128) on the four service waves -- its
+                // workgroup barriers are the service waves' LDS counter, its slab sums read tagged lines, its partial record leaves as a tagged line + a statistics granule;
+                // (b) the merge of the records of the query heads of this workgroup's k-slice (exl3_gemv4's ATTM tasks; sequential over the splits) -> o_proj's quads.
+                const PsAtt PS_CONST* const AT = (const PsAtt PS_CONST*) &O->mat[1];
+                const int ns = AT->nsplit;
+                const ps_rsrc_t rrec = ps_rsrc(AT->rec), rst = ps_rsrc(AT->stats);
+                if (sw == 0) PS_T(9);
+                // ---- (b) the attention output of the query heads b0 .. b0 + nb - 1 (= the Hadamard blocks of o_proj's slice): merge of all splits' records
+                if (active && 2 * sw < nb)
+                {
+                    const bool act = shw < nb;
+                    const int tb = min(shw, nb - 1), blk = b0 + tb;
+                    const int len = __builtin_amdgcn_readfirstlane(ps_g(a.seqlens)[0]);
+                    const int nse = min(max((len + 63) >> 6, 1), ns);          // the splits in use (as the items compute it)
+                    float m_s = -1.0e30f, l_s = 0.0f;
+                    for (int spins = 0;; ++spins)
+                    {
+                        const uint4_t g = ps_ld128(rst, ((uint32_t) blk * PS_ATT_MAX_SPLITS + (uint32_t) min(l32, nse - 1)) * 16u);
+                        const bool has = l32 < nse;
+                        m_s = has ? __uint_as_float(g.x) : -1.0e30f; l_s = has ? __uint_as_float(g.z) : 0.0f;
+                        const bool ok = !has | ((g.y == tag_out) & (g.w == tag_out));
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
+                    }
+                    float M = m_s;
+                    #pragma unroll
+                    for (int i = 1; i < 32; i <<= 1) M = fmaxf(M, xor_lane(M, i));
+                    const float e_s = m_s > -1.0e29f ? __expf(m_s - M) : 0.0f;
+                    float L = l_s * e_s;
+                    #pragma unroll
+                    for (int i = 1; i < 32; i <<= 1) L += xor_lane(L, i);
+                    const int lbase = lane - l32;
+                    float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+                    for (int s0 = 0; s0 < nse; s0 += 8)                       // eight records per round trip
+                    {
+                        uint4_t t[8];
+                        for (int spins = 0;; ++spins)
+                        {
+                            bool ok = true;
+                            #pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                t[u] = ps_ld128(rrec, ((uint32_t) blk * (uint32_t) ns + (uint32_t) min(s0 + u, nse - 1)) * 512u + (uint32_t) l32 * 16u);
+                            #pragma unroll
+                            for (int u = 0; u < 8; ++u) ok &= (t[u].y == tag_out) & (t[u].w == tag_out);
+                            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                            if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
+                        }
+                        #pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                        {
+                            const float ev = (s0 + u < nse) ? __shfl(e_s, lbase + min(s0 + u, nse - 1), 64) : 0.0f;
+                            const half2_t a01 = u32_as_half2(t[u].x), a23 = u32_as_half2(t[u].z);
+                            o0 += (float) a01.x * ev; o1 += (float) a01.y * ev; o2 += (float) a23.x * ev; o3 += (float) a23.y * ev;
+                        }
+                    }
+                    const float inv = L > 0.0f ? 1.0f / L : 0.0f;
+                    float v0 = o0 * inv, v1 = o1 * inv, v2 = o2 * inv, v3 = o3 * inv;
+                    kvg_had32(v0, v1, v2, v3, lane);
+                    const half4_t xa = { f2h(v0 * ATT_R32), f2h(v1 * ATT_R32), f2h(v2 * ATT_R32), f2h(v3 * ATT_R32) };
+                    rotate_store(xa, sv[0], tb, act);
                 }
             }
             else if (in_type == PS_IN_QKV)
@@ -1042,7 +1342,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             if (sw == 0) PS_T(12);
             if (sw == 0) PS_T(7);
 
-            if (in_type == PS_IN_QKV && tl.side >= 0 && sw == PS_NSV - 1)
+            if (in_type == PS_IN_QKV && !in_attn && tl.side >= 0 && sw == PS_NSV - 1)
             {
                 // side job: one (K | V, 128-value block) of the new token: finished like q (RoPE on K only) and appended to the 4-bit paged cache
                 // (the arithmetic of glue_qkv_kernel: qkv_block_finish + kv_quant_regs); both half-waves compute it, the upper one stores.  After the

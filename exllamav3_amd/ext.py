@@ -1845,7 +1845,10 @@ class PersistentStep:
     is built once from the layer tensors.  `layers`: dicts with LinearEXL3-like entries q, k, v, o, gate, up, down (attributes trellis, suh, svh, K) and
     tensors norm1, norm2, kcache = (words, scales), vcache = (words, scales).  mul1 codebook, 4-bit cache, hidden <= 4096 (exl3_pstep_create checks)."""
 
-    def __init__(self, layers, head, final_norm, hidden: int, heads_q: int, heads_kv: int, head_dim: int, eps: float, rope_mode: int = 2, stamps: bool = False):
+    def __init__(self, layers, head, final_norm, hidden: int, heads_q: int, heads_kv: int, head_dim: int, eps: float, rope_mode: int = 2, stamps: bool = False,
+                 attention: bool = False):
+        """attention: the decode attention over the 4-bit paged cache runs INSIDE the step (o_proj's preparation: one (kv head, context split) item per CU, the partial
+        records merged by the consumers; libtorch/attention.cpp:246-504 at q_len 1) -- run() then needs block_table / cache_seqlens.  head_dim 128."""
         def lin(l):
             t = l.trellis
             _req(t.dim() == 3 and l.suh is not None and l.svh is not None, "PersistentStep: EXL3 linears with suh / svh")
@@ -1865,13 +1868,23 @@ class PersistentStep:
         self._h = ctypes.c_void_p(None)
         self._keep = (layers, head, final_norm)          # the plan holds raw pointers
         _check(_lib.lib().exl3_pstep_create(ctypes.byref(self._h), arr, len(layers), ctypes.byref(hl), _p(final_norm), int(hidden), int(heads_q), int(heads_kv),
-                                            int(head_dim), int(K), 2, float(eps), int(rope_mode), 1 if stamps else 0))
+                                            int(head_dim), int(K), 2, float(eps), int(rope_mode), (1 if stamps else 0) | (4 if attention else 0)))
         self.n_layers = len(layers)
+        self.attention = bool(attention)
+        self.head_dim = int(head_dim)
 
-    def run(self, R: torch.Tensor, logits: torch.Tensor, q_out: torch.Tensor | None, rope_sin: torch.Tensor, rope_cos: torch.Tensor, slots: torch.Tensor):
-        """R: int64 fixed-point residual of the embedded token (fx_init / fx_init_prep, which also fill rope_sin / rope_cos / slots); graph-capturable."""
+    def run(self, R: torch.Tensor, logits: torch.Tensor, q_out: torch.Tensor | None, rope_sin: torch.Tensor, rope_cos: torch.Tensor, slots: torch.Tensor,
+            block_table: torch.Tensor | None = None, cache_seqlens: torch.Tensor | None = None, page_size: int = 0, scale: float | None = None):
+        """R: int64 fixed-point residual of the embedded token (fx_init / fx_init_prep, which also fill rope_sin / rope_cos / slots); graph-capturable.
+        With the attention inside: block_table int32 (1, pages) and cache_seqlens int32 (1,) = the length INCLUDING the new token (read on the device)."""
         _dev(R)
         _req(R.dtype == torch.int64 and logits.dtype == torch.half and slots.dtype == torch.int64, "PersistentStep.run: dtypes")
+        if self.attention:
+            _req(block_table is not None and cache_seqlens is not None and block_table.dtype == torch.int32 and cache_seqlens.dtype == torch.int32 and page_size > 0,
+                 "PersistentStep.run: the plan has the attention inside: block_table / cache_seqlens (int32) and the page size")
+            _check(_lib.lib().exl3_pstep_run_attn(self._h, _p(R), _p(logits), _p(q_out), _p(rope_sin), _p(rope_cos), _p(slots), _p(block_table), _p(cache_seqlens),
+                                                  int(block_table.shape[-1]), int(page_size), float(scale if scale is not None else self.head_dim ** -0.5), _stream(R)))
+            return
         _check(_lib.lib().exl3_pstep_run(self._h, _p(R), _p(logits), _p(q_out), _p(rope_sin), _p(rope_cos), _p(slots), _stream(R)))
 
     def error(self) -> bool:

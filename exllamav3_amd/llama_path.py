@@ -785,25 +785,33 @@ class SyntheticEXL3Llama:
     def persistent_applies(self) -> bool:
         s = self.shape
         same = all(_same_kind(L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"], self.lm_head) for L in self.layers)
-        return (self._state_bsz == 1 and self.tp == 1 and not self.with_attention and self.cb == 2 and self.kv_bits == 4 and same
+        # with the attention core: inside the step for head_dim 128 and <= 8 query heads per kv head (exl3_pstep.cuh: PS_ATTN); head_dim 64 stays launch-per-op
+        att_ok = (not self.with_attention) or (s.head_dim == 128 and self.hq // self.hkv <= 8 and os.environ.get("EXL3_HIP_PSTEP_ATTN", "1") != "0")
+        return (self._state_bsz == 1 and self.tp == 1 and att_ok and self.cb == 2 and self.kv_bits == 4 and same
                 and s.hidden % 128 == 0 and s.hidden <= 4096 and s.head_dim in (64, 128) and self.use_qkv_tab)
 
     def decode_step_persistent(self):
         """The whole decode step as ONE launch (ext.PersistentStep / exl3_pstep.hip) behind the step's set-up launch (fx_init_prep: fixed-point copy of the
         input row, rope tables, cache rows): every quantized linear of every layer + the lm_head, RMSNorm, q|k|v epilogue with RoPE and the 4-bit K / V
-        append, silu * mul and the residual adds.  Same arithmetic per linear as decode_step_fx (generation 4's work unit, the same glue device functions);
+        append, silu * mul and the residual adds -- and, with `with_attention`, the decode attention over the quantized cache inside o_proj's preparation.
+        Same arithmetic per linear as decode_step_fx (generation 4's work unit, the same glue device functions);
         the residual is kept in fp32 between the linears; an RMSNorm's input is formed with the scale of the row's previous version and the linear's partial sums
         are corrected by (true scale / that scale) (decode_step_fx: 64-bit fixed point; the same correction for batches above 4).
         Falls back to decode_step_fx where it does not apply."""
         if not self.persistent_applies():
             return self.decode_step_fx()
         hd = self.shape.head_dim
-        if getattr(self, "_pstep", None) is None:
+        att = bool(self.with_attention)
+        if getattr(self, "_pstep", None) is None or getattr(self, "_pstep_att", None) != att:
             layers = [dict(L, kcache=self.kcache[i], vcache=self.vcache[i]) for i, L in enumerate(self.layers)]
             self._pstep = ext.PersistentStep(layers, self.lm_head, self.final_norm, self.shape.hidden, self.hq, self.hkv, hd, self.eps, rope_mode=2,
-                                             stamps=bool(os.environ.get("EXL3_HIP_PSTEP_STAMPS")))
+                                             stamps=bool(os.environ.get("EXL3_HIP_PSTEP_STAMPS")), attention=att)
+            self._pstep_att = att
         ext.fx_init_prep(self.x0, self.R, self.ss, 1, self.inv_freq, self.positions, hd, self.block_table, self.page, self.rope_sin, self.rope_cos, self.kv_slots)
-        self._pstep.run(self.R, self.logits, self.q, self.rope_sin, self.rope_cos, self.kv_slots)
+        if att:
+            self._pstep.run(self.R, self.logits, self.q, self.rope_sin, self.rope_cos, self.kv_slots, self.block_table, self.attn_lens, self.page)
+        else:
+            self._pstep.run(self.R, self.logits, self.q, self.rope_sin, self.rope_cos, self.kv_slots)
         return self.logits
 
     def decode_step_auto(self):

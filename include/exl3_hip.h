@@ -619,9 +619,12 @@ int exl3_ar_reduce_slabs(void* ctx, const float* y, const float* slabs, int S, c
  * decode their first three weight units of the NEXT linear while they wait for its input.
  *   exl3_pstep_create   builds the plan (device-resident op / tile tables, slab and counter buffers) for the given tensors.  K in {2,3,4,5,6,8},
  *                       cb = 2 (mul1), hidden a multiple of 128 and <= 4096, head_dim 64 | 128, 4-bit cache.  flags: bit 0 = record phase stamps,
- *                       bit 1 = the owner form of the residual edges (two hops; A/B runs; env EXL3_HIP_PSTEP_OWNERS=1).
+ *                       bit 1 = the owner form of the residual edges (two hops; A/B runs; env EXL3_HIP_PSTEP_OWNERS=1), bit 2 = the decode attention over the
+ *                       4-bit paged cache INSIDE the step (libtorch/attention.cpp:246-504 at q_len 1: o_proj consumes the attention output instead of q; head_dim 128).
  *   exl3_pstep_run      one decode step: R = the int64 fixed-point residual holding the embedded token (exl3_fx_init / exl3_fx_init_prep, which
  *                       also produce rope_sin / rope_cos / slots); logits fp16 [vocab]; q_out optional fp16 [heads_q * head_dim].  Graph-capturable.
+ *   exl3_pstep_run_attn the step of a plan created with flags bit 2: block_table int32 [blocks_per_seq] and cache_seqlens int32 [1] (length INCLUDING the new token)
+ *                       of the one sequence, page size (a multiple of 16), softmax scale.  Graph-capturable (the length is read on the device).
  *   exl3_pstep_set      decode-ahead units 0..3 (-1: keep; default 3), spin limit of the bounded waits (0: keep).
  *   exl3_pstep_error    synchronises the stream; 1 if a wait ever timed out (results invalid), else 0.
  *   exl3_pstep_stamps   copies the phase stamps of the last run ([nops][ncu][32] x u64, 100 MHz) to host memory; returns nops * ncu * 32. */
@@ -638,6 +641,8 @@ int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* layers, int n
  * side task, flags} of one op kind (0 q|k|v, 1 o_proj, 2 gate|up, 3 down, 4 lm_head) for a chip of ncu CUs; *S_out = its k-slices */
 int exl3_pstep_plan_tiles(int hidden, int inter, int heads_q, int heads_kv, int head_dim, int vocab, int ncu, int op_kind, int32_t* tiles_out, int* S_out);
 int exl3_pstep_run(void* handle, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream);
+int exl3_pstep_run_attn(void* handle, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots,
+                        const int32_t* block_table, const int32_t* cache_seqlens, int blocks_per_seq, int page_size, float scale, void* stream);
 int exl3_pstep_error(void* handle, void* stream);
 int exl3_pstep_set(void* handle, int decode_ahead_units, int spin_limit);
 int exl3_pstep_describe(void* handle, char* buf, int buf_bytes);

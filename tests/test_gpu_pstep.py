@@ -127,3 +127,56 @@ def test_persistent_step_refuses_what_it_does_not_cover(dev):
         ext.PersistentStep(layers, m.lm_head, m.final_norm, 256, m.hq, m.hkv, 128, m.eps)
     lf = m.decode_step_persistent()                       # falls back to the fx pipeline
     assert torch.isfinite(lf.float()).all()
+
+
+@pytest.mark.parametrize("hidden,inter,hq,hkv,vocab,layers", [
+    (512, 1536, 4, 1, 1024, 2),             # GQA 4, one kv head: 1 x nsplit items, most workgroups without one
+    (1024, 2816, 8, 2, 3072, 2),            # two kv heads x 4 query heads
+    (1024, 2048, 8, 1, 2048, 2),            # eight query heads per kv head: the K / V tasks take a second task round
+    (512, 1536, 6, 2, 1024, 3),             # 3 query heads per kv head
+])
+@pytest.mark.parametrize("pos", [5, 130, 700, 1900])
+def test_persistent_step_with_attention_inside_matches_the_launch_per_op_step(dev, hidden, inter, hq, hkv, vocab, layers, pos):
+    """The decode attention over the 4-bit paged cache INSIDE the persistent step (o_proj's preparation: one (kv head, context split) item per workgroup on the
+    service waves, partial records as tagged lines, merged by the consumers; head_dim 128) against decode_step_fx with the attention core (itself tested against
+    the oracle in test_gpu_path / test_gpu_fullsize): logits, the finished queries, the appended K / V rows of every layer (dequantized), nothing else written
+    to the cache; random pre-filled cache; eager twice and graph replay give the same bits; no time-out."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_variant(1)
+    shape = LlamaShape("tiny-att", hidden, inter, layers, hq, hkv, 128, vocab)
+    m = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
+    m.alloc_state(1, pos=pos)
+    m.with_attention = True
+    assert m.persistent_applies()
+    g = torch.Generator(device="cpu").manual_seed(hq * 1000 + pos)
+    for c, s_ in m.kcache + m.vcache:
+        c.copy_(torch.randint(-2 ** 31, 2 ** 31 - 1, c.shape, generator=g, dtype=torch.int64).to(torch.int32).to(dev))
+        s_.copy_((torch.rand(s_.shape, generator=g) * 0.5 + 0.05).half().to(dev))
+    saved = [(c.clone(), s_.clone()) for c, s_ in m.kcache + m.vcache]
+
+    def restore():
+        for (c, s_), (c0, s0) in zip(m.kcache + m.vcache, saved):
+            c.copy_(c0); s_.copy_(s0)
+        m.q.zero_()
+    lf = _np(m.decode_step_fx().float()).copy()
+    kv_f = [(_np(c).copy(), _np(s_).copy()) for c, s_ in m.kcache + m.vcache]
+    q_f = _np(m.q.float()).copy()
+    restore()
+    lp = _np(m.decode_step_persistent().float()).copy()
+    assert not m._pstep.error()
+    assert np.isfinite(lp).all()
+    assert _relerr(lp, lf) < 2e-2, _relerr(lp, lf)
+    assert np.abs(q_f - _np(m.q.float())).max() < 2e-2 * max(1.0, float(np.abs(q_f).max()))
+    page, slot = int(m.block_table[0, pos // m.page]), pos % m.page
+    for (wa, sa), (c, s_), (c0, _) in zip(kv_f, m.kcache + m.vcache, saved):
+        got = o.kv_dequant(_np(c[page, slot]).view(np.uint32)[None, None], _np(s_[page, slot])[None, None], 4).reshape(-1).astype(np.float32)
+        want = o.kv_dequant(wa[page, slot].view(np.uint32)[None, None], sa[page, slot][None, None], 4).reshape(-1).astype(np.float32)
+        assert np.abs(got - want).max() / np.sqrt((want ** 2).mean()) < 0.2
+        keep = np.ones(c.shape[:2], dtype=bool); keep[page, slot] = False
+        assert np.array_equal(_np(c)[keep], _np(c0)[keep])                 # nothing but the new token's row was written
+    restore()
+    assert np.array_equal(_np(m.decode_step_persistent().float()), lp)
+    restore()
+    _replay_equals(m.decode_step_persistent, m, lp, reps=3)
+    assert not m._pstep.error()
