@@ -38,7 +38,7 @@
 #define PS_PART_BYTES (12 * 2 * 512)              // partial rows [streaming wave][segment][128] fp32
 #define PS_PDEC_BYTES (12 * 16 * 64 * 8)          // decode-ahead unit #2 of every streaming wave: [wave][16 operand slots][64 lanes] x 8 B
 #define PS_GATH_BYTES (4 * 8 * 512)                // owners of residual-row blocks: [4 blocks][8 service half-waves][128] fp32 gathered sums
-#define PS_ATT_BYTES 20480                         // attention item: new-token words 128 | scales 16 (@128) | wave statistics 256 (@256) | queries 2048 (@512) | V tiles / partial outputs 4 x 4352 (@2560)
+#define PS_ATT_BYTES 21504                         // attention item (with the gather area in front of it: 37 888 B): V tiles / partial outputs 8 x 4352 | new-token words 128 | scales 128 | wave statistics 512 | queries 2048
 #define PS_ATT_MAX_SPLITS 32                       // statistics of all splits of a head in one half-wave (one lane per split)
 #define PS_DBG_SLOTS 32                           // phase stamps per op and workgroup (exl3_pstep_stamps): 0..12 streaming wave 0 / service wave 0, 16 + w: streaming wave w done, 28 + s: service wave s published its quads
 #define PS_RBUF_BYTES (2 * 32 * 1024 + 2 * 32 * 16)

@@ -240,6 +240,8 @@ __device__ __forceinline__ void ps_consume(const half4_t (&dec)[16], half4_t ag,
 #define PS_C_S 3                       // + PS_SW per op: the streaming waves' partial rows of the op are in LDS
 #define PS_C_R 4                       // + PS_NSV per op that adds into R: the service waves' atomics are acknowledged
 #define PS_C_G 5                       // = op + 1 once the read gate in front of the row lines op's owners overwrite is satisfied
+#define PS_C_X 7                       // + 8 per barrier of the attention item's eight waves
+#define PS_C_Q 8                       // = op + 1 once the attention item's rotated queries (and the new token's words) are in LDS
 #define PS_C_O 6                       // + PS_NSV per op whose blocks this workgroup owns: the service half-waves' gathered sums are in LDS
 
 // a streaming wave's run of work units inside its workgroup's rectangle: column-major over (column block j, unit i); at most two column blocks (planner: ncb <= PS_SW)
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
     // (tools/pstep_stamps.py names them)
     #define PS_T(i) do { if (dbg && lane == 0) dbg[((size_t) op * ncu + cu) * PS_DBG_SLOTS + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
-    if (tid < 8) lctl[tid] = 0u;
+    if (tid < 16) lctl[tid] = 0u;
     const uint32_t epoch = (uint32_t) __builtin_amdgcn_readfirstlane((int) *a.epoch);      // bumped by workgroup 0 when it leaves: every replay tags afresh
     __syncthreads();
 
@@ -320,15 +322,139 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
     };
     auto c_set = [&] (int i, uint32_t v) { if (lane == 0) __hip_atomic_store(lctl + i, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
 
+
+    // ---- the attention item's token loop, shared by the four service waves (slots 0..3) and -- when the workgroup has an item -- streaming waves 0..3 (slots 4..7): eight
+    // waves, two per SIMD, take 16 tokens each per 128-token step (attn_decode_wide_kernel<..., NW = 8> of exl3_attn_decode.hip).  LDS: the V tiles of the eight waves start at
+    // the gather area (free in an o_proj op) and run into the attention area; behind them the new token's words, the waves' statistics and the rotated queries.
+    struct AttItem { int h, split, t0, t1, st_tok, len, nsteps, G; bool owner; const uint32_t* kc; const half_t* ks; const uint32_t* vc; const half_t* vs; };
+    struct AttWords { uint4_t k, v; half_t ks, vs; };
+    char* const att_base = smem + (PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES);      // = the gather area
+    half_t* const att_vt = (half_t*) att_base;                                  // [8 waves][16 * AW_VS]; after the loop: partial outputs [8][8][128] fp32 (32 KB <= 34 KB)
+    uint32_t* const att_newkv = (uint32_t*) (att_base + 8 * 16 * AW_VS * 2);     // [2][16]: the new token's K / V words of this kv head
+    half_t* const att_newsc = (half_t*) (att_base + 8 * 16 * AW_VS * 2 + 128);   // [2][4]: their group scales
+    float* const att_ml = (float*) (att_base + 8 * 16 * AW_VS * 2 + 256);        // [8 waves][8 heads][2]
+    half_t* const att_q = (half_t*) (att_base + 8 * 16 * AW_VS * 2 + 768);       // [8][128] rotated, pre-scaled queries in pair order
+    static_assert(8 * 16 * AW_VS * 2 + 768 + 2048 <= PS_GATH_BYTES + PS_ATT_BYTES, "attention item: LDS map");
+    auto att_nse = [] (int len, int ns) -> int { return min(max((len + 127) >> 7, 1), ns); };       // splits in use: enough for one 128-token step each, at most the plan's
+    auto att_make = [&] (ps_op_p O, int item, int len, int ns, int nse, int hkv) -> AttItem
+    {
+        AttItem it;
+        it.h = item / ns; it.split = item - it.h * ns; it.len = len;
+        it.st_tok = (((len + nse - 1) / nse) + 15) & ~15;                       // tokens per split: a multiple of the 16 tokens a wave takes per step
+        it.t0 = it.split * it.st_tok; it.t1 = min(len, it.t0 + it.st_tok);
+        it.nsteps = (it.st_tok + 127) >> 7; it.G = hkv * 4;
+        it.owner = len - 1 >= it.t0 && len - 1 < it.t0 + it.st_tok;             // the split that holds the new token finishes and appends its K / V
+        it.kc = O->k_cache; it.ks = O->k_scales; it.vc = O->v_cache; it.vs = O->v_scales;
+        return it;
+    };
+    auto att_load = [&] (const AttItem& it, int slot, int lane_v, int st_) -> AttWords
+    {
+        AttWords r;
+        const int c = lane_v & 15, kg = lane_v >> 4;
+        const int tk = max(min(it.t0 + 128 * st_ + 16 * slot + c, it.t1 - 1), 0);
+        const int page = a.page_size;
+        const int64_t pg = (int64_t) ps_g(a.block_table)[min(tk / page, a.blocks_per_seq - 1)];
+        const int64_t gbase = (pg * page + (tk % page)) * it.G + it.h * 4 + kg;
+        r.k = *ps_g((const uint4_t*) (it.kc + gbase * 4)); r.v = *ps_g((const uint4_t*) (it.vc + gbase * 4));
+        r.ks = ps_g(it.ks)[gbase]; r.vs = ps_g(it.vs)[gbase];
+        return r;
+    };
+    auto att_tokens = [&] (const AttItem& it, int slot, int lane_v, AttWords w0, uint32_t& tgt_x)
+    {
+        const int c = lane_v & 15, kg = lane_v >> 4;
+        auto att_bar = [&] () { tgt_x += 8u; c_inc(PS_C_X); c_spin(PS_C_X, tgt_x); };
+        // (the query fragments are re-read from LDS in every step: 16 registers the token loop does not have -- the persistent kernel's budget is 128)
+        const half_t* const qrow = att_q + min(c, 7) * 128 + 32 * kg;          // rows >= gq are zero rows; lanes c >= 8 read row 7 and are masked below
+        float m_run = -1.0e30f, l_run = 0.0f;                                   // of query head c (lanes with c >= gq carry zero queries)
+        float4_t oc[8];
+        #pragma unroll
+        for (int nbk = 0; nbk < 8; ++nbk) oc[nbk] = float4_t{ 0.f, 0.f, 0.f, 0.f };
+        half_t* const vw = att_vt + (size_t) slot * (16 * AW_VS);
+        uint32_t mk_v = 0x001E001Eu;
+        asm volatile("" : "+v"(mk_v));
+        for (int st = 0; st < it.nsteps; ++st)
+        {
+            const int tb_ = it.t0 + 128 * st + 16 * slot;                       // the wave's 16 tokens of this step
+            if (tb_ >= it.t1) break;                                            // wave-uniform
+            const int tk = min(tb_ + c, it.t1 - 1);
+            if (it.owner && tk == it.len - 1)
+            {
+                // the new token's words come from this workgroup's LDS copy (its cache row is being written by this very launch)
+                w0.k = uint4_t{ att_newkv[kg * 4], att_newkv[kg * 4 + 1], att_newkv[kg * 4 + 2], att_newkv[kg * 4 + 3] };
+                w0.v = uint4_t{ att_newkv[16 + kg * 4], att_newkv[16 + kg * 4 + 1], att_newkv[16 + kg * 4 + 2], att_newkv[16 + kg * 4 + 3] };
+                w0.ks = att_newsc[kg]; w0.vs = att_newsc[4 + kg];
+            }
+            float4_t scv = { 0.f, 0.f, 0.f, 0.f };
+            {
+                const half_t k4 = w0.ks * (half_t) 4.0f;
+                #pragma unroll
+                for (int s = 0; s < 4; ++s)
+                {
+                    const half8_t ka = aw_dequant8(s == 0 ? w0.k.x : (s == 1 ? w0.k.y : (s == 2 ? w0.k.z : w0.k.w)), half2_t{ k4, k4 }, mk_v);
+                    half8_t qv = *((const half8_t*) (qrow + 8 * s));
+                    if (c >= 8) qv = half8_t{ 0, 0, 0, 0, 0, 0, 0, 0 };
+                    scv = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qv, scv, 0, 0, 0);
+                }
+                const half_t v4 = w0.vs * (half_t) 4.0f;
+                #pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    *((half8_t*) (vw + c * AW_VS + 32 * kg + 8 * s)) = aw_dequant8(s == 0 ? w0.v.x : (s == 1 ? w0.v.y : (s == 2 ? w0.v.z : w0.v.w)), half2_t{ v4, v4 }, mk_v);
+            }
+            // the next step's words are requested HERE -- after this step's words are consumed (one set of them in registers: the budget is 128), ahead of the
+            // softmax and the value product (two steps ahead measured slower here: 468 vs 476 tok/s at 16 000 tokens)
+            if (st + 1 < it.nsteps) w0 = att_load(it, slot, lane_v, st + 1);
+            float mx = m_run;
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) { if (tb_ + 4 * kg + r >= it.t1) scv[r] = -1.0e30f; mx = fmaxf(mx, scv[r]); }
+            mx = fmaxf(mx, xor_lane(mx, 16)); mx = fmaxf(mx, xor_lane(mx, 32));
+            if (!(mx > m_run + 8.0f)) mx = m_run;                               // lazy reference (exl3_attn_decode.hip)
+            const float corr = __builtin_amdgcn_exp2f(m_run - mx);
+            float p[4], psum = 0.0f;
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) { p[r] = scv[r] > -1.0e29f ? __builtin_amdgcn_exp2f(scv[r] - mx) : 0.0f; psum += p[r]; }
+            psum += xor_lane(psum, 16); psum += xor_lane(psum, 32);
+            l_run = l_run * corr + psum; m_run = mx;
+            const half4_t pa = { (half_t) p[0], (half_t) p[1], (half_t) p[2], (half_t) p[3] };
+            if (__any(corr != 1.0f))
+            {
+                float cr[4];
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) cr[r] = __shfl(corr, 4 * kg + r, 64);
+                #pragma unroll
+                for (int nbk = 0; nbk < 8; ++nbk) { oc[nbk].x *= cr[0]; oc[nbk].y *= cr[1]; oc[nbk].z *= cr[2]; oc[nbk].w *= cr[3]; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            #pragma unroll
+            for (int nbk = 0; nbk < 8; ++nbk)
+            {
+                const half4_t vb = aw_tr16(vw + (4 * kg + (c >> 2)) * AW_VS + 16 * nbk + 4 * (c & 3));
+                oc[nbk] = __builtin_amdgcn_mfma_f32_16x16x16f16(pa, vb, oc[nbk], 0, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- the eight waves' partial results (statistics of head c from lanes (c, kg = 0); outputs of heads 4 kg + r, column 16 nbk + c in pair order from every lane)
+        att_bar();                                                             // the V tiles are dead: their space takes the partial outputs [slot][head][128] fp32
+        float* const o_s = (float*) att_vt;
+        if (kg == 0 && c < 8) { att_ml[(slot * 8 + c) * 2] = m_run; att_ml[(slot * 8 + c) * 2 + 1] = l_run; }
+        #pragma unroll
+        for (int nbk = 0; nbk < 8; ++nbk)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const int head = 4 * kg + r;
+                if (head < 8) o_s[(slot * 8 + head) * 128 + 16 * nbk + c] = oc[nbk][r];
+            }
+        att_bar();
+    };
+
     if (wave < PS_SW)
     {
         // =========================================================================================== streaming waves
         const int quad_lane = (lane >> 2) * 8, lofs = lane * K;
         const int pmax = a.pmax;
         LaneWords<K> ring[2];
-        half4_t dec0[16], dec1[16];
-        #pragma unroll
-        for (int i = 0; i < 16; ++i) { dec0[i] = half4_t{ 0, 0, 0, 0 }; dec1[i] = dec0[i]; }
         #pragma unroll
         for (int i = 0; i < K; ++i) { ring[0].w[i] = 0u; ring[1].w[i] = 0u; }
         char* const pdec_w = pdec + (size_t) wave * (16 * 64 * 8) + (size_t) lane * 8;
@@ -337,6 +463,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         PsTile tl = ps_load_tile(a.tiles, (size_t) cu);
         PsSeg<K> cur = ps_make_seg<K>(ops_c, tl, wave);
         bool ring_ready = false;
+        uint32_t tgt_x = 0u;
         for (int op = 0; op < nops; ++op)
         {
             const ps_op_p O = ops_c + op;
@@ -349,6 +476,25 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             const size_t after_rs = nxt.rs;
             if (lane == 0) { int* si = seginfo2 + (op & 1) * 64 + wave * 4; si[0] = cur.j0; si[1] = cur.len0; si[2] = cur.len1; si[3] = 0; }
 
+            if (ATT && wave < 4 && ((O->in_type & (0xff | PS_ATTN)) == (PS_IN_QKV | PS_ATTN)))
+            {
+                // this workgroup's attention item (the service waves' preparation of this op, below): streaming waves 0..3 are its slots 4..7
+                const PsAtt PS_CONST* const AT = (const PsAtt PS_CONST*) &O->mat[1];
+                const int ns = AT->nsplit;
+                const int len = __builtin_amdgcn_readfirstlane(ps_g(a.seqlens)[0]);
+                const int nse = att_nse(len, ns);
+                if (tl.side >= 0 && tl.side % ns < nse)
+                {
+                    const AttItem it = att_make(O, tl.side, len, ns, nse, AT->hkv);
+                    AttWords w0 = att_load(it, 4 + wave, lane, 0);
+                    c_wait(PS_C_Q, (uint32_t) (op + 1));
+                    att_tokens(it, 4 + wave, lane, w0, tgt_x);
+                }
+            }
+            // (the decode-ahead units live inside the op: declared here they are dead during the attention item above)
+            half4_t dec0[16], dec1[16];
+            #pragma unroll
+            for (int i = 0; i < 16; ++i) { dec0[i] = half4_t{ 0, 0, 0, 0 }; dec1[i] = dec0[i]; }
             // ---- decode-ahead while the service waves have not published the op's activation quads
             const uint32_t tgt_t = (uint32_t) PS_NSV * (uint32_t) (op + 1);
             int P = 0;
@@ -451,7 +597,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         const int sw = wave - PS_SW, shw = 2 * sw + (lane >> 5);          // service wave 0..3, service half-wave 0..7
         __builtin_amdgcn_s_setprio(3);                                    // the workgroup's latency chain runs here
         bool aborted = false;
-        uint32_t tgt_a = 0u, tgt_o = 0u;
+        uint32_t tgt_a = 0u, tgt_o = 0u, tgt_x = 0u;
         float r_last = 1.0f;                                              // the row scale (1 / rms) this workgroup last knew: DIRECT RMSNorm ops form their quads with it
         auto poll_cnt = [&] (int cop, uint32_t errbit)                    // every workgroup has arrived at counter `cop` (8 XCD shards)
         {
@@ -513,38 +659,14 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 const int gq = AT->gq, ns = AT->nsplit;
                 const ps_rsrc_t rrec = ps_rsrc(AT->rec), rst = ps_rsrc(AT->stats);
                 auto svc_bar = [&] () { tgt_o += PS_NSV; c_inc(PS_C_O); c_spin(PS_C_O, tgt_o); };
-                // splits in use: enough for 64 tokens (one step of the four waves) each, at most the plan's nsplit; items of the other splits have nothing to do
+                // splits in use: enough for one 128-token step of the item's eight waves each, at most the plan's nsplit; items of the other splits have nothing to do
                 const int len = __builtin_amdgcn_readfirstlane(ps_g(a.seqlens)[0]);
-                const int ns_eff = min(max((len + 63) >> 6, 1), ns);
+                const int ns_eff = att_nse(len, ns);
                 const int item = (tl.side >= 0 && tl.side % ns < ns_eff) ? tl.side : -1;
                 if (item >= 0)
                 {
-                    char* const attl = smem + (PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES + PS_GATH_BYTES);
-                    uint32_t* const new_kv = (uint32_t*) attl;                              // [2][16]: the new token's K / V words of this kv head
-                    half_t* const new_sc = (half_t*) (attl + 128);                          // [2][4]: their group scales
-                    float* const ml_s = (float*) (attl + 256);                              // [4 waves][8 heads][2]
-                    half_t* const q_s = (half_t*) (attl + 512);                             // [8][128] rotated, pre-scaled queries in pair order
-                    half_t* const vt = (half_t*) (attl + 2560);                             // [4 waves][16 * AW_VS]; after the loop: partial outputs [4][8][128] fp32
-                    const int h = item / ns, split = item - h * ns;
-                    const int c = lane & 15, kg = lane >> 4;
-                    const int st_tok = (((len + ns_eff - 1) / ns_eff) + 15) & ~15;          // tokens per split: a multiple of the 16 tokens a wave takes per step
-                    const int t0 = split * st_tok, t1 = min(len, t0 + st_tok);
-                    const int hkv = AT->hkv, G = hkv * 4;
-                    const bool owner = len - 1 >= t0 && len - 1 < t0 + st_tok;              // the split that holds the new token finishes and appends its K / V
-                    const uint32_t* const kc_p = O->k_cache; const half_t* const ks_p = O->k_scales; const uint32_t* const vc_p = O->v_cache; const half_t* const vs_p = O->v_scales;
-                    const int page = a.page_size, bps = a.blocks_per_seq;
-                    auto page_of = [&] (int tk) -> int64_t { return (int64_t) ps_g(a.block_table)[min(tk / page, bps - 1)]; };
-                    struct StepWords { uint4_t k, v; half_t ks, vs; };
-                    auto load_step = [&] (int st_) -> StepWords
-                    {
-                        StepWords r;
-                        const int tk = max(min(t0 + 64 * st_ + 16 * sw + c, t1 - 1), 0);
-                        const int64_t gbase = (page_of(tk) * page + (tk % page)) * G + h * 4 + kg;
-                        r.k = *ps_g((const uint4_t*) (kc_p + gbase * 4)); r.v = *ps_g((const uint4_t*) (vc_p + gbase * 4));
-                        r.ks = ps_g(ks_p)[gbase]; r.vs = ps_g(vs_p)[gbase];
-                        return r;
-                    };
-                    StepWords w0 = load_step(0);
+                    const AttItem it = att_make(O, item, len, ns, ns_eff, AT->hkv);
+                    AttWords w0 = att_load(it, sw, lane, 0);
                     // ---- tasks, one per half-wave: 0 .. gq - 1 = query head h * gq + task, gq = the new token's K row, gq + 1 = its V row (owner only); a second round for gq = 7, 8
                     {
                         const uint32_t set_k = (uint32_t) ((const char*) O->in_slab[1] - (const char*) O->in_slab[0]), set_v = (uint32_t) ((const char*) O->in_slab[2] - (const char*) O->in_slab[0]);
@@ -556,15 +678,15 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         #pragma nounroll
                         for (int r = 0; r < (gq + 2 + 7) / 8; ++r)
                         {
-                            if (r > 0 && !owner) break;
+                            if (r > 0 && !it.owner) break;
                             const int task = r * 8 + shw;
                             const int kind = task < gq ? 0 : task - gq + 1;                 // 0: query, 1: K row, 2: V row, >= 3: nothing
                             const int tw = r * 8 + 2 * sw;
-                            const bool wave_has = tw < gq || (owner && tw + 1 >= gq && tw <= gq + 1);      // wave-uniform: tasks tw, tw + 1
+                            const bool wave_has = tw < gq || (it.owner && tw + 1 >= gq && tw <= gq + 1);      // wave-uniform: tasks tw, tw + 1
                             if (wave_has)
                             {
                                 const bool kvt = kind == 1 || kind == 2;
-                                const int cblk = kvt ? h : h * gq + min(task, gq - 1);
+                                const int cblk = kvt ? it.h : it.h * gq + min(task, gq - 1);
                                 const half_t* svp = (kind == 1 ? O->in_svh[1] : (kind == 2 ? O->in_svh[2] : O->in_svh[0])) + (size_t) cblk * 128;
                                 const half4_t sc = ps_g((const half4_t*) svp)[l32];
                                 const uint32_t boff = (kind == 1 ? set_k : (kind == 2 ? set_v : 0u)) + (uint32_t) cblk * (uint32_t) S_q * PS_LINE_BYTES;
@@ -581,12 +703,12 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                                 const half4_t y = qkv_block_finish(ysum, sc, rs0, 0, l32, 0.0f, 0.0f, kind != 2, O->rope_mode, 16, sn4, cs4);
                                 float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
                                 const int64_t token_pos = a.slots[0];
-                                const int64_t gb = token_pos * G + h * 4 + (l32 >> 3);
+                                const int64_t gb = token_pos * it.G + it.h * 4 + (l32 >> 3);
                                 uint32_t* cw = kind == 2 ? O->v_cache : O->k_cache; half_t* cs = kind == 2 ? O->v_scales : O->k_scales;
-                                const bool actkv = owner && kvt;
+                                const bool actkv = it.owner && kvt;
                                 kv_quant_regs<4>(v0, v1, v2, v3, cw + gb * 4, cs + gb, actkv, lane);
-                                kv_quant_regs<4>(v0, v1, v2, v3, &new_kv[(kind == 2 ? 16 : 0) + (l32 >> 3) * 4], &new_sc[(kind == 2 ? 4 : 0) + (l32 >> 3)], actkv, lane);
-                                if (kind == 0 && q_out_p && split == 0) ((half4_t PS_GLOBAL*) (q_out_p + (size_t) cblk * 128))[l32] = y;
+                                kv_quant_regs<4>(v0, v1, v2, v3, &att_newkv[(kind == 2 ? 16 : 0) + (l32 >> 3) * 4], &att_newsc[(kind == 2 ? 4 : 0) + (l32 >> 3)], actkv, lane);
+                                if (kind == 0 && q_out_p && it.split == 0) ((half4_t PS_GLOBAL*) (q_out_p + (size_t) cblk * 128))[l32] = y;
                                 kvg_had32(v0, v1, v2, v3, lane);
                                 const float fq = ATT_R32 * a.att_scale * 1.44269504f;
                                 const float vv[4] = { v0 * fq, v1 * fq, v2 * fq, v3 * fq };
@@ -596,131 +718,48 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                                     for (int e = 0; e < 4; ++e)
                                     {
                                         const int d = 4 * l32 + e, d8 = d & 7;
-                                        q_s[task * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) vv[e];
+                                        att_q[task * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) vv[e];
                                     }
                                 }
                             }
                             if (r == 0 && shw >= gq)
                             {
                                 #pragma unroll
-                                for (int e = 0; e < 4; ++e) q_s[shw * 128 + 4 * l32 + e] = (half_t) 0.0f;      // rows >= gq of the query operand stay zero
+                                for (int e = 0; e < 4; ++e) att_q[shw * 128 + 4 * l32 + e] = (half_t) 0.0f;      // rows >= gq of the query operand stay zero
                             }
                         }
                     }
                     svc_bar();
+                    c_set(PS_C_Q, (uint32_t) (op + 1));                    // streaming waves 0..3 join the token loop
                     if (sw == 0) PS_T(8);
-                    // (the query fragments are re-read from LDS in every step: 16 registers the token loop does not have -- the persistent kernel's budget is 128)
-                    const half_t* const qrow = q_s + min(c, 7) * 128 + 32 * kg;           // rows >= gq are zero rows; lanes c >= 8 read row 7 and are masked below
-                    float m_run = -1.0e30f, l_run = 0.0f;                  // of query head c (lanes with c >= gq carry zero queries)
-                    float4_t oc[8];
-                    #pragma unroll
-                    for (int nbk = 0; nbk < 8; ++nbk) oc[nbk] = float4_t{ 0.f, 0.f, 0.f, 0.f };
-                    half_t* const vw = vt + (size_t) sw * (16 * AW_VS);
-                    uint32_t mk_v = 0x001E001Eu;
-                    asm volatile("" : "+v"(mk_v));
-                    const int nsteps = (st_tok + 63) / 64;
-                    for (int st = 0; st < nsteps; ++st)
-                    {
-                        const int tb_ = t0 + 64 * st + 16 * sw;            // the wave's 16 tokens of this step
-                        if (tb_ >= t1) break;                              // wave-uniform
-                        const int tk = min(tb_ + c, t1 - 1);
-                        if (owner && tk == len - 1)
-                        {
-                            // the new token's words come from this workgroup's LDS copy (its cache row is being written by this very launch)
-                            w0.k = uint4_t{ new_kv[kg * 4], new_kv[kg * 4 + 1], new_kv[kg * 4 + 2], new_kv[kg * 4 + 3] };
-                            w0.v = uint4_t{ new_kv[16 + kg * 4], new_kv[16 + kg * 4 + 1], new_kv[16 + kg * 4 + 2], new_kv[16 + kg * 4 + 3] };
-                            w0.ks = new_sc[kg]; w0.vs = new_sc[4 + kg];
-                        }
-                        float4_t scv = { 0.f, 0.f, 0.f, 0.f };
-                        {
-                            const half_t k4 = w0.ks * (half_t) 4.0f;
-                            #pragma unroll
-                            for (int s = 0; s < 4; ++s)
-                            {
-                                const half8_t ka = aw_dequant8(s == 0 ? w0.k.x : (s == 1 ? w0.k.y : (s == 2 ? w0.k.z : w0.k.w)), half2_t{ k4, k4 }, mk_v);
-                                half8_t qv = *((const half8_t*) (qrow + 8 * s));
-                                if (c >= 8) qv = half8_t{ 0, 0, 0, 0, 0, 0, 0, 0 };
-                                scv = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka, qv, scv, 0, 0, 0);
-                            }
-                            const half_t v4 = w0.vs * (half_t) 4.0f;
-                            #pragma unroll
-                            for (int s = 0; s < 4; ++s)
-                                *((half8_t*) (vw + c * AW_VS + 32 * kg + 8 * s)) = aw_dequant8(s == 0 ? w0.v.x : (s == 1 ? w0.v.y : (s == 2 ? w0.v.z : w0.v.w)), half2_t{ v4, v4 }, mk_v);
-                        }
-                        // the next step's words are requested HERE -- after this step's words are consumed (one set of them in registers: the budget is 128), ahead of the
-                        // softmax and the value product
-                        if (st + 1 < nsteps) w0 = load_step(st + 1);
-                        float mx = m_run;
-                        #pragma unroll
-                        for (int r = 0; r < 4; ++r) { if (tb_ + 4 * kg + r >= t1) scv[r] = -1.0e30f; mx = fmaxf(mx, scv[r]); }
-                        mx = fmaxf(mx, xor_lane(mx, 16)); mx = fmaxf(mx, xor_lane(mx, 32));
-                        if (!(mx > m_run + 8.0f)) mx = m_run;              // lazy reference (exl3_attn_decode.hip)
-                        const float corr = __builtin_amdgcn_exp2f(m_run - mx);
-                        float p[4], psum = 0.0f;
-                        #pragma unroll
-                        for (int r = 0; r < 4; ++r) { p[r] = scv[r] > -1.0e29f ? __builtin_amdgcn_exp2f(scv[r] - mx) : 0.0f; psum += p[r]; }
-                        psum += xor_lane(psum, 16); psum += xor_lane(psum, 32);
-                        l_run = l_run * corr + psum; m_run = mx;
-                        const half4_t pa = { (half_t) p[0], (half_t) p[1], (half_t) p[2], (half_t) p[3] };
-                        if (__any(corr != 1.0f))
-                        {
-                            float cr[4];
-                            #pragma unroll
-                            for (int r = 0; r < 4; ++r) cr[r] = __shfl(corr, 4 * kg + r, 64);
-                            #pragma unroll
-                            for (int nbk = 0; nbk < 8; ++nbk) { oc[nbk].x *= cr[0]; oc[nbk].y *= cr[1]; oc[nbk].z *= cr[2]; oc[nbk].w *= cr[3]; }
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        #pragma unroll
-                        for (int nbk = 0; nbk < 8; ++nbk)
-                        {
-                            const half4_t vb = aw_tr16(vw + (4 * kg + (c >> 2)) * AW_VS + 16 * nbk + 4 * (c & 3));
-                            oc[nbk] = __builtin_amdgcn_mfma_f32_16x16x16f16(pa, vb, oc[nbk], 0, 0, 0);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    // ---- merge the 4 waves (statistics of head c from lanes (c, kg = 0); outputs of heads 4 kg + r, column 16 nbk + c in pair order from every lane)
-                    svc_bar();                                             // the V tiles are dead: their space takes the partial outputs [wave][head][128] fp32
-                    float* const o_s = (float*) vt;
-                    if (kg == 0 && c < 8) { ml_s[(sw * 8 + c) * 2] = m_run; ml_s[(sw * 8 + c) * 2 + 1] = l_run; }
-                    #pragma unroll
-                    for (int nbk = 0; nbk < 8; ++nbk)
-                        #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                        {
-                            const int head = 4 * kg + r;
-                            if (head < 8) o_s[(sw * 8 + head) * 128 + 16 * nbk + c] = oc[nbk][r];
-                        }
-                    svc_bar();
+                    att_tokens(it, sw, lane, w0, tgt_x);
                     if (shw < gq)
                     {
                         // half-wave i finishes head i of the kv block: lane l owns natural dims 4 l .. 4 l + 3; the record = one tagged line + one statistics granule
                         const int i = shw;
                         float M = -1.0e30f;
                         #pragma unroll
-                        for (int w = 0; w < 4; ++w) M = fmaxf(M, ml_s[(w * 8 + i) * 2]);
+                        for (int w = 0; w < 8; ++w) M = fmaxf(M, att_ml[(w * 8 + i) * 2]);
                         float L = 0.0f, Oa[4] = { 0.f, 0.f, 0.f, 0.f };
                         #pragma unroll
-                        for (int w = 0; w < 4; ++w)
+                        for (int w = 0; w < 8; ++w)
                         {
-                            const float mw = ml_s[(w * 8 + i) * 2];
+                            const float mw = att_ml[(w * 8 + i) * 2];
                             const float e = mw > -1.0e29f ? __builtin_amdgcn_exp2f(mw - M) : 0.0f;
-                            L += ml_s[(w * 8 + i) * 2 + 1] * e;
+                            L += att_ml[(w * 8 + i) * 2 + 1] * e;
                             #pragma unroll
                             for (int e4 = 0; e4 < 4; ++e4)
                             {
                                 const int d = 4 * l32 + e4, d8 = d & 7;
-                                Oa[e4] += o_s[(w * 8 + i) * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] * e;
+                                Oa[e4] += ((const float*) att_vt)[(w * 8 + i) * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] * e;
                             }
                         }
-                        const int hd_ = h * gq + i;
+                        const int hd_ = it.h * gq + i;
                         // (the record's 128 accumulators as fp16 pairs: ONE 16-byte granule { O0 O1, tag, O2 O3, tag } per lane, 512 bytes per record -- the merge reads
                         //  nb x splits of them per workgroup; the merged output is rounded to fp16 anyway)
-                        const uint32_t ro = ((uint32_t) hd_ * (uint32_t) ns + (uint32_t) split) * 512u + (uint32_t) l32 * 16u;
+                        const uint32_t ro = ((uint32_t) hd_ * (uint32_t) ns + (uint32_t) it.split) * 512u + (uint32_t) l32 * 16u;
                         ps_st128(rrec, ro, uint4_t{ half2_as_u32(half2_t{ f2h(Oa[0]), f2h(Oa[1]) }), tag_out, half2_as_u32(half2_t{ f2h(Oa[2]), f2h(Oa[3]) }), tag_out });
-                        if (l32 == 0) ps_st128(rst, ((uint32_t) hd_ * PS_ATT_MAX_SPLITS + (uint32_t) split) * 16u, uint4_t{ __float_as_uint(M * 0.69314718f), tag_out, __float_as_uint(L), tag_out });
+                        if (l32 == 0) ps_st128(rst, ((uint32_t) hd_ * PS_ATT_MAX_SPLITS + (uint32_t) it.split) * 16u, uint4_t{ __float_as_uint(M * 0.69314718f), tag_out, __float_as_uint(L), tag_out });
                     }
                 }
                 if (sw == 0) PS_T(8);
@@ -1013,7 +1052,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     const bool act = shw < nb;
                     const int tb = min(shw, nb - 1), blk = b0 + tb;
                     const int len = __builtin_amdgcn_readfirstlane(ps_g(a.seqlens)[0]);
-                    const int nse = min(max((len + 63) >> 6, 1), ns);          // the splits in use (as the items compute it)
+                    const int nse = att_nse(len, ns);                          // the splits in use (as the items compute it)
                     float m_s = -1.0e30f, l_s = 0.0f;
                     for (int spins = 0;; ++spins)
                     {
