@@ -732,7 +732,15 @@ def main():
         if pipe_x == "fx":
             # ... and with the decode attention over a 1000-token 4-bit cache (head_dim 64: two kv heads per 128-value block of the matrix-pipe split kernel)
             m1.with_attention = True
-            extra["llama-3.2-1b_bs1_with_attention_ctx1000"] = timed_decode(m1, m1.decode_step_fx, 1)
+            m1._pstep = None
+            att1 = pipeline == "persistent" and m1.persistent_applies()
+            extra["llama-3.2-1b_bs1_with_attention_ctx1000"] = timed_decode(m1, m1.decode_step_auto if att1 else m1.decode_step_fx, 1)
+            if att1:
+                extra["llama-3.2-1b_bs1_with_attention_ctx1000"]["step"] = att_desc
+                extra["llama-3.2-1b_bs1_with_attention_ctx1000"]["edge_timeout"] = bool(m1._pstep.error())
+                assert not extra["llama-3.2-1b_bs1_with_attention_ctx1000"]["edge_timeout"], "bench.py: the persistent step (attention inside) reported a time-out"
+                m1._pstep = None
+                extra["llama-3.2-1b_bs1_with_attention_ctx1000_launch_per_op"] = timed_decode(m1, m1.decode_step_fx, 1)
             m1.with_attention = False
         del m1
         torch.cuda.empty_cache()

@@ -164,8 +164,9 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     int att_nsplit = 0;
     if (attn)
     {
-        EXL3_CHECK_ARG(head_dim == 128 && heads_q % heads_kv == 0 && att_gq <= 8, "exl3_pstep_create: attention inside the step needs head_dim 128 and <= 8 query heads per kv head");
-        att_nsplit = ncu / att_blocks; if (att_nsplit > PS_ATT_MAX_SPLITS) att_nsplit = PS_ATT_MAX_SPLITS;
+        EXL3_CHECK_ARG(heads_q % heads_kv == 0 && att_gq * (128 / head_dim) <= 8, "exl3_pstep_create: attention inside the step: at most 8 query heads per 128-value kv block (head_dim 128: 8, head_dim 64: 4 per kv head)");
+        const int cap = head_dim == 128 ? PS_ATT_MAX_SPLITS : 16;                  // (head_dim 64: a head's statistics live in 16 lanes)
+        att_nsplit = ncu / att_blocks; if (att_nsplit > cap) att_nsplit = cap;
         EXL3_CHECK_ARG(att_nsplit >= 1, "exl3_pstep_create: more kv heads than CUs");
     }
     bool direct = !(flags & 2);
@@ -300,7 +301,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     PS_TRY(hipMalloc(&h->d_rbuf, (size_t) PS_RBUF_BYTES)); PS_TRY(hipMemset(h->d_rbuf, 0, (size_t) PS_RBUF_BYTES));
     if (attn)
     {
-        const size_t rec_bytes = (size_t) heads_q * att_nsplit * 1024, st_bytes = (size_t) heads_q * PS_ATT_MAX_SPLITS * 16;
+        const size_t rec_bytes = (size_t) heads_q * att_nsplit * 512, st_bytes = (size_t) heads_q * PS_ATT_MAX_SPLITS * 16;
         PS_TRY(hipMalloc(&h->d_att_rec, rec_bytes)); PS_TRY(hipMemset(h->d_att_rec, 0, rec_bytes));
         PS_TRY(hipMalloc(&h->d_att_stats, st_bytes)); PS_TRY(hipMemset(h->d_att_stats, 0, st_bytes));
         for (int i = 0; i < nops; ++i) if ((ops[i].in_type & 0xff) == PS_IN_QKV) { PsAtt* A = (PsAtt*) &ops[i].mat[1]; A->rec = h->d_att_rec; A->stats = h->d_att_stats; }

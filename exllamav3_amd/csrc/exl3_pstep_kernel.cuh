@@ -335,14 +335,14 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
     float* const att_ml = (float*) (att_base + 8 * 16 * AW_VS * 2 + 256);        // [8 waves][8 heads][2]
     half_t* const att_q = (half_t*) (att_base + 8 * 16 * AW_VS * 2 + 768);       // [8][128] rotated, pre-scaled queries in pair order
     static_assert(8 * 16 * AW_VS * 2 + 768 + 2048 <= PS_GATH_BYTES + PS_ATT_BYTES, "attention item: LDS map");
-    auto att_nse = [] (int len, int ns) -> int { return min(max((len + 127) >> 7, 1), ns); };       // splits in use: enough for one 128-token step each, at most the plan's
+    auto att_nse = [] (int len, int ns) -> int { return min(max((len + 127) >> 7, 1), ns); };       // (head_dim 64: the plan's nsplit is <= 16: one lane per split in a 16-lane head)       // splits in use: enough for one 128-token step each, at most the plan's
     auto att_make = [&] (ps_op_p O, int item, int len, int ns, int nse, int hkv) -> AttItem
     {
         AttItem it;
         it.h = item / ns; it.split = item - it.h * ns; it.len = len;
         it.st_tok = (((len + nse - 1) / nse) + 15) & ~15;                       // tokens per split: a multiple of the 16 tokens a wave takes per step
         it.t0 = it.split * it.st_tok; it.t1 = min(len, it.t0 + it.st_tok);
-        it.nsteps = (it.st_tok + 127) >> 7; it.G = hkv * 4;
+        it.nsteps = (it.st_tok + 127) >> 7; it.G = (hkv * O->hd) >> 5;           // 32-groups per token
         it.owner = len - 1 >= it.t0 && len - 1 < it.t0 + it.st_tok;             // the split that holds the new token finishes and appends its K / V
         it.kc = O->k_cache; it.ks = O->k_scales; it.vc = O->v_cache; it.vs = O->v_scales;
         return it;
@@ -656,7 +656,9 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 // (the token loop needs the registers)
                 if (sw == 0) PS_T(4);
                 const PsAtt PS_CONST* const AT = (const PsAtt PS_CONST*) &O->mat[1];
-                const int gq = AT->gq, ns = AT->nsplit;
+                const int gq = AT->gq, ns = AT->nsplit;                // gq: query heads per kv head = query BLOCKS per kv block
+                const bool hd64 = O->hd == 64;
+                const int rows = hd64 ? 2 * gq : gq;                   // rows of the query operand (<= 8)
                 const ps_rsrc_t rrec = ps_rsrc(AT->rec), rst = ps_rsrc(AT->stats);
                 auto svc_bar = [&] () { tgt_o += PS_NSV; c_inc(PS_C_O); c_spin(PS_C_O, tgt_o); };
                 // splits in use: enough for one 128-token step of the item's eight waves each, at most the plan's nsplit; items of the other splits have nothing to do
@@ -672,9 +674,13 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         const uint32_t set_k = (uint32_t) ((const char*) O->in_slab[1] - (const char*) O->in_slab[0]), set_v = (uint32_t) ((const char*) O->in_slab[2] - (const char*) O->in_slab[0]);
                         const ps_rsrc_t rq = ps_rsrc(O->in_slab[0]);                        // (q, k and v slab sets lie in one allocation: one resource, per-lane offsets)
                         const int S_q = O->S_in;
+                        // head_dim 64 (Llama-3.2-1B): a 128-value block holds TWO heads -- the tasks are still 128-value blocks (gq query blocks of two adjacent heads each, the K and
+                        // the V block of the block's two kv heads), the rope partner distance and the frequency index follow the 64-wide head, the operand has 2 gq rows: row
+                        // i = (sub, qi) keeps its 64 dims in half `sub` of the 128-wide row and zeros in the other (attn_decode_wide_kernel's HD64 form)
+                        const int ph = O->hd >> 3;
                         float4_t sn4 = { 0.f, 0.f, 0.f, 0.f }, cs4 = sn4;
-                        if (O->rope_mode == 2) { const int f = 4 * (l32 & 15); sn4 = *ps_g((const float4_t*) (rope_sin_p + f)); cs4 = *ps_g((const float4_t*) (rope_cos_p + f)); }
-                        else { const int f = 2 * (l32 & 31); sn4.x = ps_g(rope_sin_p)[f]; sn4.y = ps_g(rope_sin_p)[f + 1]; cs4.x = ps_g(rope_cos_p)[f]; cs4.y = ps_g(rope_cos_p)[f + 1]; }
+                        if (O->rope_mode == 2) { const int f = 4 * (l32 & (ph - 1)); sn4 = *ps_g((const float4_t*) (rope_sin_p + f)); cs4 = *ps_g((const float4_t*) (rope_cos_p + f)); }
+                        else { const int f = 2 * (l32 & (2 * ph - 1)); sn4.x = ps_g(rope_sin_p)[f]; sn4.y = ps_g(rope_sin_p)[f + 1]; cs4.x = ps_g(rope_cos_p)[f]; cs4.y = ps_g(rope_cos_p)[f + 1]; }
                         #pragma nounroll
                         for (int r = 0; r < (gq + 2 + 7) / 8; ++r)
                         {
@@ -700,7 +706,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                                     __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                                 }
                                 const GemvRescale rs0 = { nullptr, nullptr, 0, 0.0f };
-                                const half4_t y = qkv_block_finish(ysum, sc, rs0, 0, l32, 0.0f, 0.0f, kind != 2, O->rope_mode, 16, sn4, cs4);
+                                const half4_t y = qkv_block_finish(ysum, sc, rs0, 0, l32, 0.0f, 0.0f, kind != 2, O->rope_mode, ph, sn4, cs4);
                                 float v0 = (float) y.x, v1 = (float) y.y, v2 = (float) y.z, v3 = (float) y.w;
                                 const int64_t token_pos = a.slots[0];
                                 const int64_t gb = token_pos * it.G + it.h * 4 + (l32 >> 3);
@@ -714,18 +720,33 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                                 const float vv[4] = { v0 * fq, v1 * fq, v2 * fq, v3 * fq };
                                 if (kind == 0)
                                 {
-                                    #pragma unroll
-                                    for (int e = 0; e < 4; ++e)
+                                    if (hd64)
                                     {
-                                        const int d = 4 * l32 + e, d8 = d & 7;
-                                        att_q[task * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) vv[e];
+                                        // lanes 0-15: head 2 task, lanes 16-31: head 2 task + 1
+                                        const int i = 2 * task + (l32 >> 4), sub = i >= gq ? 1 : 0;
+                                        #pragma unroll
+                                        for (int e = 0; e < 4; ++e)
+                                        {
+                                            const int d = 64 * sub + 4 * (l32 & 15) + e, d8 = d & 7, dz = d ^ 64;
+                                            att_q[i * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) vv[e];
+                                            att_q[i * 128 + (dz & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) 0.0f;
+                                        }
+                                    }
+                                    else
+                                    {
+                                        #pragma unroll
+                                        for (int e = 0; e < 4; ++e)
+                                        {
+                                            const int d = 4 * l32 + e, d8 = d & 7;
+                                            att_q[task * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] = (half_t) vv[e];
+                                        }
                                     }
                                 }
                             }
-                            if (r == 0 && shw >= gq)
+                            if (r == 0 && shw >= rows)
                             {
                                 #pragma unroll
-                                for (int e = 0; e < 4; ++e) att_q[shw * 128 + 4 * l32 + e] = (half_t) 0.0f;      // rows >= gq of the query operand stay zero
+                                for (int e = 0; e < 4; ++e) att_q[shw * 128 + 4 * l32 + e] = (half_t) 0.0f;      // rows >= rows of the query operand stay zero
                             }
                         }
                     }
@@ -733,9 +754,10 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     c_set(PS_C_Q, (uint32_t) (op + 1));                    // streaming waves 0..3 join the token loop
                     if (sw == 0) PS_T(8);
                     att_tokens(it, sw, lane, w0, tgt_x);
-                    if (shw < gq)
+                    if (shw < rows)
                     {
-                        // half-wave i finishes head i of the kv block: lane l owns natural dims 4 l .. 4 l + 3; the record = one tagged line + one statistics granule
+                        // half-wave i finishes row i of the kv block: lane l owns natural dims 4 l .. 4 l + 3; the record = 32 tagged granules + one statistics granule.
+                        // head_dim 64: row i = (sub, qi) -> record qi of the block, statistics `sub`, its own 64 of the 128 accumulators (the lanes of that half)
                         const int i = shw;
                         float M = -1.0e30f;
                         #pragma unroll
@@ -754,12 +776,15 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                                 Oa[e4] += ((const float*) att_vt)[(w * 8 + i) * 128 + (d & ~7) + 2 * (d8 & 3) + (d8 >> 2)] * e;
                             }
                         }
-                        const int hd_ = it.h * gq + i;
+                        const int sub = hd64 ? (i >= gq ? 1 : 0) : 0, qi = i - sub * gq;
+                        const int rec_ = it.h * gq + qi;
                         // (the record's 128 accumulators as fp16 pairs: ONE 16-byte granule { O0 O1, tag, O2 O3, tag } per lane, 512 bytes per record -- the merge reads
                         //  nb x splits of them per workgroup; the merged output is rounded to fp16 anyway)
-                        const uint32_t ro = ((uint32_t) hd_ * (uint32_t) ns + (uint32_t) it.split) * 512u + (uint32_t) l32 * 16u;
-                        ps_st128(rrec, ro, uint4_t{ half2_as_u32(half2_t{ f2h(Oa[0]), f2h(Oa[1]) }), tag_out, half2_as_u32(half2_t{ f2h(Oa[2]), f2h(Oa[3]) }), tag_out });
-                        if (l32 == 0) ps_st128(rst, ((uint32_t) hd_ * PS_ATT_MAX_SPLITS + (uint32_t) it.split) * 16u, uint4_t{ __float_as_uint(M * 0.69314718f), tag_out, __float_as_uint(L), tag_out });
+                        const uint32_t ro = ((uint32_t) rec_ * (uint32_t) ns + (uint32_t) it.split) * 512u + (uint32_t) l32 * 16u;
+                        if (!hd64 || (l32 >> 4) == sub)
+                            ps_st128(rrec, ro, uint4_t{ half2_as_u32(half2_t{ f2h(Oa[0]), f2h(Oa[1]) }), tag_out, half2_as_u32(half2_t{ f2h(Oa[2]), f2h(Oa[3]) }), tag_out });
+                        const int srow = hd64 ? 2 * rec_ + sub : rec_;
+                        if (l32 == 0) ps_st128(rst, ((uint32_t) srow * PS_ATT_MAX_SPLITS + (uint32_t) it.split) * 16u, uint4_t{ __float_as_uint(M * 0.69314718f), tag_out, __float_as_uint(L), tag_out });
                     }
                 }
                 if (sw == 0) PS_T(8);
@@ -1053,11 +1078,22 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     const int tb = min(shw, nb - 1), blk = b0 + tb;
                     const int len = __builtin_amdgcn_readfirstlane(ps_g(a.seqlens)[0]);
                     const int nse = att_nse(len, ns);                          // the splits in use (as the items compute it)
+                    // head_dim 128: block blk = query head blk = record blk, lane l32 holds the statistics of split l32.  head_dim 64: the block holds query heads 2 blk and
+                    // 2 blk + 1 (lanes 0-15 / 16-31); head qh belongs to kv head qh / gq = half (kv & 1) of the records of kv block kv >> 1: per-lane record, statistics
+                    // row and granule lane; lane (l32 & 15) of a head holds split (l32 & 15) (exl3_gemv4's ATTM tasks)
+                    const bool hd64 = O->hd == 64;
+                    const int gq_ = AT->gq;
+                    const int at_lr = hd64 ? (l32 & 15) : l32;
+                    const int qh = hd64 ? 2 * blk + (l32 >> 4) : blk;
+                    const int kv = qh / gq_, qi = qh - kv * gq_;
+                    const int rec_ = hd64 ? (kv >> 1) * gq_ + qi : blk, half_ = hd64 ? (kv & 1) : 0;
+                    const int srow = hd64 ? 2 * rec_ + half_ : rec_;
+                    const uint32_t glane = hd64 ? (uint32_t) (16 * half_ + at_lr) : (uint32_t) l32;      // the granule of the record that holds this lane's four dims
                     float m_s = -1.0e30f, l_s = 0.0f;
                     for (int spins = 0;; ++spins)
                     {
-                        const uint4_t g = ps_ld128(rst, ((uint32_t) blk * PS_ATT_MAX_SPLITS + (uint32_t) min(l32, nse - 1)) * 16u);
-                        const bool has = l32 < nse;
+                        const uint4_t g = ps_ld128(rst, ((uint32_t) srow * PS_ATT_MAX_SPLITS + (uint32_t) min(at_lr, nse - 1)) * 16u);
+                        const bool has = at_lr < nse;
                         m_s = has ? __uint_as_float(g.x) : -1.0e30f; l_s = has ? __uint_as_float(g.z) : 0.0f;
                         const bool ok = !has | ((g.y == tag_out) & (g.w == tag_out));
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
@@ -1066,12 +1102,14 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     }
                     float M = m_s;
                     #pragma unroll
-                    for (int i = 1; i < 32; i <<= 1) M = fmaxf(M, xor_lane(M, i));
+                    for (int i = 1; i < 16; i <<= 1) M = fmaxf(M, xor_lane(M, i));
+                    if (!hd64) M = fmaxf(M, xor_lane(M, 16));
                     const float e_s = m_s > -1.0e29f ? __expf(m_s - M) : 0.0f;
                     float L = l_s * e_s;
                     #pragma unroll
-                    for (int i = 1; i < 32; i <<= 1) L += xor_lane(L, i);
-                    const int lbase = lane - l32;
+                    for (int i = 1; i < 16; i <<= 1) L += xor_lane(L, i);
+                    if (!hd64) L += xor_lane(L, 16);
+                    const int lbase = lane - at_lr;
                     float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
                     for (int s0 = 0; s0 < nse; s0 += 8)                       // eight records per round trip
                     {
@@ -1081,7 +1119,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             bool ok = true;
                             #pragma unroll
                             for (int u = 0; u < 8; ++u)
-                                t[u] = ps_ld128(rrec, ((uint32_t) blk * (uint32_t) ns + (uint32_t) min(s0 + u, nse - 1)) * 512u + (uint32_t) l32 * 16u);
+                                t[u] = ps_ld128(rrec, ((uint32_t) rec_ * (uint32_t) ns + (uint32_t) min(s0 + u, nse - 1)) * 512u + glane * 16u);
                             #pragma unroll
                             for (int u = 0; u < 8; ++u) ok &= (t[u].y == tag_out) & (t[u].w == tag_out);
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;

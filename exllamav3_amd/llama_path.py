@@ -785,8 +785,8 @@ class SyntheticEXL3Llama:
     def persistent_applies(self) -> bool:
         s = self.shape
         same = all(_same_kind(L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"], self.lm_head) for L in self.layers)
-        # with the attention core: inside the step for head_dim 128 and <= 8 query heads per kv head (exl3_pstep.cuh: PS_ATTN); head_dim 64 stays launch-per-op
-        att_ok = (not self.with_attention) or (s.head_dim == 128 and self.hq // self.hkv <= 8 and os.environ.get("EXL3_HIP_PSTEP_ATTN", "1") != "0")
+        # with the attention core: inside the step (exl3_pstep.cuh: PS_ATTN) for at most 8 query heads per 128-value kv block
+        att_ok = (not self.with_attention) or ((self.hq // self.hkv) * (128 // s.head_dim) <= 8 and os.environ.get("EXL3_HIP_PSTEP_ATTN", "1") != "0")
         return (self._state_bsz == 1 and self.tp == 1 and att_ok and self.cb == 2 and self.kv_bits == 4 and same
                 and s.hidden % 128 == 0 and s.hidden <= 4096 and s.head_dim in (64, 128) and self.use_qkv_tab)
 

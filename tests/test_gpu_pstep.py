@@ -129,25 +129,30 @@ def test_persistent_step_refuses_what_it_does_not_cover(dev):
     assert torch.isfinite(lf.float()).all()
 
 
-@pytest.mark.parametrize("hidden,inter,hq,hkv,vocab,layers", [
-    (512, 1536, 4, 1, 1024, 2),             # GQA 4, one kv head: 1 x nsplit items, most workgroups without one
-    (1024, 2816, 8, 2, 3072, 2),            # two kv heads x 4 query heads
-    (1024, 2048, 8, 1, 2048, 2),            # eight query heads per kv head: the K / V tasks take a second task round
-    (512, 1536, 6, 2, 1024, 3),             # 3 query heads per kv head
+@pytest.mark.parametrize("hidden,inter,hq,hkv,hd,vocab,layers", [
+    (512, 1536, 4, 1, 128, 1024, 2),        # GQA 4, one kv head: 1 x nsplit items, most workgroups without one
+    (1024, 2816, 8, 2, 128, 3072, 2),       # two kv heads x 4 query heads
+    (1024, 2048, 8, 1, 128, 2048, 2),       # eight query heads per kv head: the K / V tasks take a second task round
+    (512, 1536, 6, 2, 128, 1024, 3),        # 3 query heads per kv head
+    (512, 1536, 8, 2, 64, 1024, 2),         # head_dim 64 (Llama-3.2-1B's form): one 128-value kv block = two kv heads, 2 x 4 rows
+    (1024, 2816, 16, 8, 64, 3072, 2),       # head_dim 64, 2 query heads per kv head, four kv blocks
+    (256, 512, 4, 4, 64, 384, 2),           # head_dim 64, MHA: two rows
+    (512, 1536, 6, 2, 64, 1024, 2),         # head_dim 64, 3 query heads per kv head: six rows, q blocks of two heads that straddle nothing (hq * 64 = 384 = 3 blocks)
 ])
 @pytest.mark.parametrize("pos", [5, 130, 700, 1900])
-def test_persistent_step_with_attention_inside_matches_the_launch_per_op_step(dev, hidden, inter, hq, hkv, vocab, layers, pos):
+def test_persistent_step_with_attention_inside_matches_the_launch_per_op_step(dev, hidden, inter, hq, hkv, hd, vocab, layers, pos):
     """The decode attention over the 4-bit paged cache INSIDE the persistent step (o_proj's preparation: one (kv head, context split) item per workgroup on the
-    service waves, partial records as tagged lines, merged by the consumers; head_dim 128) against decode_step_fx with the attention core (itself tested against
+    service + four streaming waves, partial records as tagged granules, merged by the consumers; head_dim 128 and 64) against decode_step_fx with the attention core (itself tested against
     the oracle in test_gpu_path / test_gpu_fullsize): logits, the finished queries, the appended K / V rows of every layer (dequantized), nothing else written
     to the cache; random pre-filled cache; eager twice and graph replay give the same bits; no time-out."""
     from exllamav3_amd import ext
     from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
     ext.set_gemv_variant(1)
-    shape = LlamaShape("tiny-att", hidden, inter, layers, hq, hkv, 128, vocab)
+    shape = LlamaShape("tiny-att", hidden, inter, layers, hq, hkv, hd, vocab)
     m = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
     m.alloc_state(1, pos=pos)
     m.with_attention = True
+    m.attn_merge_in_oproj_hd64 = True
     assert m.persistent_applies()
     g = torch.Generator(device="cpu").manual_seed(hq * 1000 + pos)
     for c, s_ in m.kcache + m.vcache:

@@ -6,7 +6,7 @@ from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
 dev = torch.device("cuda:0")
 ctxs = [int(a) for a in sys.argv[1:]] or [1000, 4000, 16000]
 STEP = os.environ.get("STEP", "fx")
-model = SyntheticEXL3Llama(SHAPES["llama-3.1-8b"], K=4, cb=2, device=dev, kv_bits=4, max_ctx=max(ctxs) // 256 * 256 + 256)
+model = SyntheticEXL3Llama(SHAPES[os.environ.get("MODEL", "llama-3.1-8b")], K=4, cb=2, device=dev, kv_bits=4, max_ctx=max(ctxs) // 256 * 256 + 256)
 for wa in (False, True):
     model.with_attention = wa
     for ctx in (ctxs if wa else ctxs[:1]):
