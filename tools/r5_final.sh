@@ -19,6 +19,7 @@ run bs1_launch_per_op --pipeline fx --no-prefill --steps 20
 run 1b_persistent --model llama-3.2-1b --no-prefill --steps 20
 run 1b_launch_per_op --model llama-3.2-1b --pipeline fx --no-prefill --steps 20
 run bs1_attention --attention --no-prefill --steps 20
+run bs1_attention_launch_per_op --attention --pipeline fx --no-prefill --steps 20
 run prefill --steps 5
 # PMC passes: eager launches (one dispatch record per kernel), FETCH_SIZE in KiB, x2 on gfx950 for wide coalesced reads (MI355X_MICROARCH.md).  One pass per pipeline:
 # the launch-per-op GEMV launches, the persistent step's ONE kernel (8B and 1B)
