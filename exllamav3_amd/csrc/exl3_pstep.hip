@@ -10,20 +10,14 @@
 #include <stdio.h>
 #include <string.h>
 
-template __global__ void exl3_pstep_kernel<4, false>(const PsArgs);
-template __global__ void exl3_pstep_kernel<4, true>(const PsArgs);
+// (K, KH): the layers' bits per weight and the lm_head's -- KH = K, or 6 (the head of a real checkpoint stays at 6 bits whatever the layers have)
+#define PS_INST(KK, KHH) template __global__ void exl3_pstep_kernel<KK, KHH, false>(const PsArgs); template __global__ void exl3_pstep_kernel<KK, KHH, true>(const PsArgs);
+PS_INST(4, 4)
 #ifndef PS_ONLY_K4
-template __global__ void exl3_pstep_kernel<2, false>(const PsArgs);
-template __global__ void exl3_pstep_kernel<3, false>(const PsArgs);
-template __global__ void exl3_pstep_kernel<5, false>(const PsArgs);
-template __global__ void exl3_pstep_kernel<6, false>(const PsArgs);
-template __global__ void exl3_pstep_kernel<8, false>(const PsArgs);
-template __global__ void exl3_pstep_kernel<2, true>(const PsArgs);
-template __global__ void exl3_pstep_kernel<3, true>(const PsArgs);
-template __global__ void exl3_pstep_kernel<5, true>(const PsArgs);
-template __global__ void exl3_pstep_kernel<6, true>(const PsArgs);
-template __global__ void exl3_pstep_kernel<8, true>(const PsArgs);
+PS_INST(2, 2) PS_INST(3, 3) PS_INST(5, 5) PS_INST(6, 6) PS_INST(8, 8)
+PS_INST(2, 6) PS_INST(3, 6) PS_INST(4, 6) PS_INST(5, 6) PS_INST(8, 6)
 #endif
+#undef PS_INST
 
 #define PS_LDS_BYTES (PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES + PS_GATH_BYTES + PS_ATT_BYTES)
 static_assert(PS_LDS_BYTES <= 160 * 1024, "persistent step: LDS map exceeds a CU's 160 KiB");
@@ -32,7 +26,7 @@ namespace
 {
 struct PsHandle
 {
-    int K, nops, ncu, pmax, spin_limit, n_layers;
+    int K, KH, nops, ncu, pmax, spin_limit, n_layers;
     PsOp* d_ops; PsTile* d_tiles; uint32_t* d_cnt; uint32_t* d_err; unsigned long long* d_dbg;
     unsigned long long* d_slab_a; unsigned long long* d_slab_b; unsigned long long* d_slab_c; unsigned long long* d_slab_d; unsigned long long* d_rbuf; uint32_t* d_epoch;
     unsigned long long* d_att_rec; unsigned long long* d_att_stats; int attn;
@@ -109,34 +103,46 @@ void lin_to_mat(const exl3_pstep_linear_t& l, PsMat& m)
 }
 }
 
-static void ps_launch(int K, bool att, int ncu, hipStream_t st, const PsArgs& args)
+template <int KK, int KHH>
+static void ps_launch_kk(bool att, int ncu, hipStream_t st, const PsArgs& args)
 {
-    #define PS_L(KK) case KK: if (att) exl3_pstep_kernel<KK, true><<<dim3(ncu), dim3(PS_NT), PS_LDS_BYTES, st>>>(args); else exl3_pstep_kernel<KK, false><<<dim3(ncu), dim3(PS_NT), PS_LDS_BYTES, st>>>(args); break;
-    switch (K)
-    {
-        PS_L(4)
-#ifndef PS_ONLY_K4
-        PS_L(2) PS_L(3) PS_L(5) PS_L(6) PS_L(8)
-#endif
-        default: break;
-    }
-    #undef PS_L
+    if (att) exl3_pstep_kernel<KK, KHH, true><<<dim3(ncu), dim3(PS_NT), PS_LDS_BYTES, st>>>(args);
+    else     exl3_pstep_kernel<KK, KHH, false><<<dim3(ncu), dim3(PS_NT), PS_LDS_BYTES, st>>>(args);
+}
+template <int KK, int KHH>
+static int ps_attr_kk()
+{
+    EXL3_CHECK_HIP(hipFuncSetAttribute((const void*) exl3_pstep_kernel<KK, KHH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES), "hipFuncSetAttribute(pstep)");
+    EXL3_CHECK_HIP(hipFuncSetAttribute((const void*) exl3_pstep_kernel<KK, KHH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES), "hipFuncSetAttribute(pstep)");
+    return EXL3_OK;
 }
 
-static int ps_set_lds_attr(int K)
-{
-    #define PS_A(KK) case KK: EXL3_CHECK_HIP(hipFuncSetAttribute((const void*) exl3_pstep_kernel<KK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES), "hipFuncSetAttribute(pstep)"); \
-                              EXL3_CHECK_HIP(hipFuncSetAttribute((const void*) exl3_pstep_kernel<KK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES), "hipFuncSetAttribute(pstep)"); break;
-    switch (K)
-    {
-        PS_A(4)
+// dispatch over the instantiated (K, KH) pairs: KH == K, or KH == 6
 #ifndef PS_ONLY_K4
-        PS_A(2) PS_A(3) PS_A(5) PS_A(6) PS_A(8)
+#define PS_PAIRS(X) X(4, 4) X(2, 2) X(3, 3) X(5, 5) X(6, 6) X(8, 8) X(2, 6) X(3, 6) X(4, 6) X(5, 6) X(8, 6)
+#else
+#define PS_PAIRS(X) X(4, 4)
 #endif
-        default: exl3_set_error("exl3_pstep: K = %d has no instantiation", K); return EXL3_ERR_ARG;
-    }
-    #undef PS_A
-    return EXL3_OK;
+static bool ps_pair_ok(int K, int KH)
+{
+    #define PS_X(KK, KHH) if (K == KK && KH == KHH) return true;
+    PS_PAIRS(PS_X)
+    #undef PS_X
+    return false;
+}
+static void ps_launch(int K, int KH, bool att, int ncu, hipStream_t st, const PsArgs& args)
+{
+    #define PS_X(KK, KHH) if (K == KK && KH == KHH) { ps_launch_kk<KK, KHH>(att, ncu, st, args); return; }
+    PS_PAIRS(PS_X)
+    #undef PS_X
+}
+static int ps_set_lds_attr(int K, int KH)
+{
+    #define PS_X(KK, KHH) if (K == KK && KH == KHH) return ps_attr_kk<KK, KHH>();
+    PS_PAIRS(PS_X)
+    #undef PS_X
+    exl3_set_error("exl3_pstep: no instantiation for %d bits per weight in the layers and %d in the lm_head (the head's: the layers' or 6)", K, KH);
+    return EXL3_ERR_ARG;
 }
 
 extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* layers, int n_layers, const exl3_pstep_linear_t* head, const void* final_norm,
@@ -152,7 +158,8 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     hipDeviceProp_t prop; EXL3_CHECK_HIP(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
     const int ncu = prop.multiProcessorCount;
     EXL3_CHECK_ARG(ncu >= 16, "exl3_pstep_create: device has %d CUs", ncu);
-    { const int r = ps_set_lds_attr(K); if (r) return r; }
+    const int KH = ((flags >> 8) & 0xf) ? ((flags >> 8) & 0xf) : K;        // flags bits 8..11: the lm_head's bits per weight when they differ from the layers'
+    { const int r = ps_set_lds_attr(K, KH); if (r) return r; }
 
     const int qdim = heads_q * head_dim, kvdim = heads_kv * head_dim, kvb = kvdim / 128;
     const int nops = 4 * n_layers + 1;
@@ -289,7 +296,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     }
 
     PsHandle* h = new PsHandle();
-    h->K = K; h->nops = nops; h->ncu = ncu; h->pmax = 3; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
+    h->K = K; h->KH = KH; h->nops = nops; h->ncu = ncu; h->pmax = 3; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
     h->d_att_rec = nullptr; h->d_att_stats = nullptr; h->attn = attn ? 1 : 0;
     h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr; h->d_slab_c = nullptr; h->d_slab_d = nullptr; h->d_rbuf = nullptr; h->d_epoch = nullptr;
     h->cnt_bytes = (size_t) nops * 8 * 16 * 4; h->dbg_words = (flags & 1) ? (size_t) nops * ncu * PS_DBG_SLOTS : 0;
@@ -398,7 +405,7 @@ static int ps_run(PsHandle* h, void* R, void* logits, void* q_out, const float* 
     a.rope_sin = rope_sin; a.rope_cos = rope_cos; a.slots = slots;
     a.block_table = block_table; a.seqlens = seqlens; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.att_scale = scale;
     a.rbuf = h->d_rbuf; a.cnt = h->d_cnt; a.epoch = h->d_epoch; a.err = h->d_err; a.dbg = h->d_dbg; a.spin_limit = h->spin_limit; a.pmax = h->pmax;
-    ps_launch(h->K, h->attn != 0, h->ncu, st, a);
+    ps_launch(h->K, h->KH, h->attn != 0, h->ncu, st, a);
     return exl3_check_launch("exl3_pstep_run");
 }
 
@@ -426,7 +433,7 @@ extern "C" int exl3_pstep_describe(void* handle, char* buf, int buf_bytes)
 {
     PsHandle* h = (PsHandle*) handle;
     EXL3_CHECK_ARG(h && buf && buf_bytes > 0, "exl3_pstep_describe: null argument");
-    snprintf(buf, (size_t) buf_bytes, "ops=%d cus=%d K=%d decode_ahead=%d lds=%d | %s", h->nops, h->ncu, h->K, h->pmax, (int) PS_LDS_BYTES, h->desc.c_str());
+    snprintf(buf, (size_t) buf_bytes, "ops=%d cus=%d K=%d head_K=%d decode_ahead=%d lds=%d | %s", h->nops, h->ncu, h->K, h->KH, h->pmax, (int) PS_LDS_BYTES, h->desc.c_str());
     return EXL3_OK;
 }
 

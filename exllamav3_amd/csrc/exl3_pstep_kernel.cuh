@@ -285,7 +285,8 @@ __device__ __forceinline__ PsSeg<K> ps_make_seg(ps_op_p O, const PsTile& t, int 
 
 // ATT: the plan has the decode attention inside o_proj's preparation (PS_ATTN).  A separate instantiation: with the attention code compiled in, the step WITHOUT attention
 // ran 2.6 % (8B) / 6 % (1B) slower (250 instead of 78 scalar spills on the service path, a third more code)
-template <int K, bool ATT>
+// KH: bits per weight of the lm_head (= K, or 6: the head of a real checkpoint)
+template <int K, int KH, bool ATT>
 __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -452,26 +453,31 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
     if (wave < PS_SW)
     {
         // =========================================================================================== streaming waves
-        const int quad_lane = (lane >> 2) * 8, lofs = lane * K;
+        // the op loop of a streaming wave over ops [op0, op1), for matrices of KK bits per weight: the layers' linears share K, the lm_head may have its own (KH: real
+        // checkpoints keep the head at 6 bits) -- then the loop runs twice, the second time over the head alone (no rows requested across the two)
+        uint32_t tgt_x = 0u;
+        auto stream_ops = [&] (auto kc, const int op0, const int op1)
+        {
+        constexpr int KK = decltype(kc)::value;
+        const int quad_lane = (lane >> 2) * 8, lofs = lane * KK;
         const int pmax = a.pmax;
-        LaneWords<K> ring[2];
+        LaneWords<KK> ring[2];
         #pragma unroll
-        for (int i = 0; i < K; ++i) { ring[0].w[i] = 0u; ring[1].w[i] = 0u; }
+        for (int i = 0; i < KK; ++i) { ring[0].w[i] = 0u; ring[1].w[i] = 0u; }
         char* const pdec_w = pdec + (size_t) wave * (16 * 64 * 8) + (size_t) lane * 8;
 
         const ps_op_p ops_c = (ps_op_p) a.ops;
-        PsTile tl = ps_load_tile(a.tiles, (size_t) cu);
-        PsSeg<K> cur = ps_make_seg<K>(ops_c, tl, wave);
+        PsTile tl = ps_load_tile(a.tiles, (size_t) op0 * ncu + cu);
+        PsSeg<KK> cur = ps_make_seg<KK>(ops_c + op0, tl, wave);
         bool ring_ready = false;
-        uint32_t tgt_x = 0u;
-        for (int op = 0; op < nops; ++op)
+        for (int op = op0; op < op1; ++op)
         {
             const ps_op_p O = ops_c + op;
             if (wave == 0) PS_T(0);
             // the next op's rectangle and this wave's run in it (pointers only): the last streamed unit of this op requests its first rows
             PsTile tn; tn.mat = -1; tn.cb0 = 0; tn.ncb = 0; tn.b0 = 0; tn.nb = 0; tn.slice = 0; tn.side = -1; tn.flags = 0;
-            if (op + 1 < nops) tn = ps_load_tile(a.tiles, (size_t) (op + 1) * ncu + cu);
-            const PsSeg<K> nxt = ps_make_seg<K>(O + 1, tn, wave);
+            if (op + 1 < op1) tn = ps_load_tile(a.tiles, (size_t) (op + 1) * ncu + cu);
+            const PsSeg<KK> nxt = ps_make_seg<KK>(O + 1, tn, wave);
             const uint32_t* const after_all = nxt.n > 0 ? nxt.stripA : nullptr;           // (null: the last unit does not refill)
             const size_t after_rs = nxt.rs;
             if (lane == 0) { int* si = seginfo2 + (op & 1) * 64 + wave * 4; si[0] = cur.j0; si[1] = cur.len0; si[2] = cur.len1; si[3] = 0; }
@@ -502,23 +508,23 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             {
                 if (!ring_ready)
                 {
-                    ps_load_row<K>(ring[0], cur.stripA + lofs);
-                    ps_load_row<K>(ring[1], cur.stripA + cur.rs + lofs);
+                    ps_load_row<KK>(ring[0], cur.stripA + lofs);
+                    ps_load_row<KK>(ring[1], cur.stripA + cur.rs + lofs);
                 }
                 const int Pm = min(pmax, cur.len0);
                 if (Pm >= 1 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
                 {
-                    ps_predecode<K>(ring, cur.unit_ptr(min(1, cur.n - 1)), cur.rs, lane, lofs, dec0);
+                    ps_predecode<KK>(ring, cur.unit_ptr(min(1, cur.n - 1)), cur.rs, lane, lofs, dec0);
                     P = 1;
                     if (Pm >= 2 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
                     {
-                        ps_predecode_lds<K>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, pdec_w);
+                        ps_predecode_lds<KK>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, pdec_w);
                         P = 2;
                         // a THIRD unit, in registers again (Llama-3.2-1B's gate|up rectangle is 32 units = 2.67 per wave: with two units ahead eight waves streamed one
                         // more after the quads were there -- 1.5 us of decode on the critical path of every layer)
                         if (Pm >= 3 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
                         {
-                            ps_predecode<K>(ring, cur.unit_ptr(min(3, cur.n - 1)), cur.rs, lane, lofs, dec1);
+                            ps_predecode<KK>(ring, cur.unit_ptr(min(3, cur.n - 1)), cur.rs, lane, lofs, dec1);
                             P = 3;
                         }
                     }
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             for (int i = 0; i < 16; ++i) tmp[i] = *((const half4_t*) (pdec_w + i * 512));
                             ps_consume<1>(tmp, ag, acc_c, acc_d);
                         }
-                        else ps_unit<K, 1>(ring, up(2), ur(2), lane, lofs, ag, acc_c, acc_d);
+                        else ps_unit<KK, 1>(ring, up(2), ur(2), lane, lofs, ag, acc_c, acc_d);
                     }
                     p = 2;
                     if (pre > 2)                                         // (pre > 2 implies len > 2: decode-ahead stays inside segment 0)
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         const uint2_t raw2 = *((const uint2_t*) (qb + 2 * 64));
                         const half4_t ag2 = u2_as_half4(raw2.x, raw2.y);
                         ps_consume<0>(dec1, ag2, acc_c, acc_d);
-                        if (len > 3) ps_unit<K, 1>(ring, up(4), ur(4), lane, lofs, ag2, acc_c, acc_d);
+                        if (len > 3) ps_unit<KK, 1>(ring, up(4), ur(4), lane, lofs, ag2, acc_c, acc_d);
                         p = 4;
                     }
                 }
@@ -566,14 +572,14 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 {
                     const uint2_t raw = *((const uint2_t*) (qb + p * 64));
                     const half4_t ag = u2_as_half4(raw.x, raw.y);
-                    ps_unit<K, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
-                    ps_unit<K, 1>(ring, up(p + 2), ur(p + 2), lane, lofs, ag, acc_c, acc_d);
+                    ps_unit<KK, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
+                    ps_unit<KK, 1>(ring, up(p + 2), ur(p + 2), lane, lofs, ag, acc_c, acc_d);
                 }
                 if (p < len)
                 {
                     const uint2_t raw = *((const uint2_t*) (qb + p * 64));
                     const half4_t ag = u2_as_half4(raw.x, raw.y);
-                    ps_unit<K, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
+                    ps_unit<KK, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
                 }
                 const int col = 16 * (lane >> 3) + (lane & 7);
                 pslot[col] = acc_c[0]; pslot[col + 8] = acc_d[0];
@@ -590,6 +596,9 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             PS_T(16 + wave);
             cur = nxt; tl = tn;
         }
+        };
+        if constexpr (KH == K) stream_ops(std::integral_constant<int, K>{}, 0, nops);
+        else { stream_ops(std::integral_constant<int, K>{}, 0, nops - 1); stream_ops(std::integral_constant<int, KH>{}, nops - 1, nops); }
     }
     else
     {

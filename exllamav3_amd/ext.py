@@ -1862,13 +1862,14 @@ class PersistentStep:
             arr[i].norm1, arr[i].norm2 = _p(L["norm1"]), _p(L["norm2"])
             (kw, ks), (vw, vs) = L["kcache"], L["vcache"]
             arr[i].k_cache, arr[i].k_scales, arr[i].v_cache, arr[i].v_scales = _p(kw), _p(ks), _p(vw), _p(vs)
-        _req(head.trellis.shape[-1] // 16 == K and bool(head.mul1) and not bool(head.mcg), "PersistentStep: lm_head with the layers' K and codebook")
+        KH = head.trellis.shape[-1] // 16
+        _req(KH in (K, 6) and bool(head.mul1) and not bool(head.mcg), "PersistentStep: lm_head with the layers' codebook and the layers' K or 6 bits")
         hl = lin(head)
         _dev(final_norm)
         self._h = ctypes.c_void_p(None)
         self._keep = (layers, head, final_norm)          # the plan holds raw pointers
         _check(_lib.lib().exl3_pstep_create(ctypes.byref(self._h), arr, len(layers), ctypes.byref(hl), _p(final_norm), int(hidden), int(heads_q), int(heads_kv),
-                                            int(head_dim), int(K), 2, float(eps), int(rope_mode), (1 if stamps else 0) | (4 if attention else 0)))
+                                            int(head_dim), int(K), 2, float(eps), int(rope_mode), (1 if stamps else 0) | (4 if attention else 0) | ((KH << 8) if KH != K else 0)))
         self.n_layers = len(layers)
         self.attention = bool(attention)
         self.head_dim = int(head_dim)

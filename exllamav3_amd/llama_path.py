@@ -784,7 +784,9 @@ class SyntheticEXL3Llama:
 
     def persistent_applies(self) -> bool:
         s = self.shape
-        same = all(_same_kind(L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"], self.lm_head) for L in self.layers)
+        # one K and codebook for the layers' linears; the lm_head: the same, or 6 bits (the head of a real checkpoint)
+        same = all(_same_kind(L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"], self.layers[0]["q"]) for L in self.layers)
+        same = same and (_same_kind(self.lm_head, self.layers[0]["q"]) or (self.lm_head.K == 6 and self.lm_head.mul1 == self.layers[0]["q"].mul1 and self.lm_head.mcg == self.layers[0]["q"].mcg))
         # with the attention core: inside the step (exl3_pstep.cuh: PS_ATTN) for at most 8 query heads per 128-value kv block
         att_ok = (not self.with_attention) or ((self.hq // self.hkv) * (128 // s.head_dim) <= 8 and os.environ.get("EXL3_HIP_PSTEP_ATTN", "1") != "0")
         return (self._state_bsz == 1 and self.tp == 1 and att_ok and self.cb == 2 and self.kv_bits == 4 and same

@@ -619,7 +619,7 @@ int exl3_ar_reduce_slabs(void* ctx, const float* y, const float* slabs, int S, c
  * decode their first three weight units of the NEXT linear while they wait for its input.
  *   exl3_pstep_create   builds the plan (device-resident op / tile tables, slab and counter buffers) for the given tensors.  K in {2,3,4,5,6,8},
  *                       cb = 2 (mul1), hidden a multiple of 128 and <= 4096, head_dim 64 | 128, 4-bit cache.  flags: bit 0 = record phase stamps,
- *                       bit 1 = the owner form of the residual edges (two hops; A/B runs; env EXL3_HIP_PSTEP_OWNERS=1), bit 2 = the decode attention over the
+ *                       bit 1 = the owner form of the residual edges (two hops; A/B runs; env EXL3_HIP_PSTEP_OWNERS=1), bits 8..11 = the lm_head's bits per weight when they differ from the layers' K (instantiated: 6), bit 2 = the decode attention over the
  *                       4-bit paged cache INSIDE the step (libtorch/attention.cpp:246-504 at q_len 1: o_proj consumes the attention output instead of q; head_dim 128).
  *   exl3_pstep_run      one decode step: R = the int64 fixed-point residual holding the embedded token (exl3_fx_init / exl3_fx_init_prep, which
  *                       also produce rope_sin / rope_cos / slots); logits fp16 [vocab]; q_out optional fp16 [heads_q * head_dim].  Graph-capturable.

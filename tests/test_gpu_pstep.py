@@ -185,3 +185,31 @@ def test_persistent_step_with_attention_inside_matches_the_launch_per_op_step(de
     restore()
     _replay_equals(m.decode_step_persistent, m, lp, reps=3)
     assert not m._pstep.error()
+
+
+@pytest.mark.parametrize("K", [4, 3])
+@pytest.mark.parametrize("with_attention", [False, True])
+def test_persistent_step_with_a_six_bit_lm_head(dev, K, with_attention):
+    """The lm_head of a real checkpoint stays at 6 bits whatever the layers have: the step's streaming loop then runs the layers with K and the head with its own K
+    (exl3_pstep_kernel<K, 6, ATT>).  Against decode_step_fx on the same tensors (2e-2) and, without attention, the oracle composition (3e-2); replay == eager."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_variant(1)
+    shape = LlamaShape("tiny-h6", 512, 1536, 2, 4, 1, 128, 1024)
+    m = SyntheticEXL3Llama(shape, K=K, cb=2, device=dev, kv_bits=4, max_ctx=1024, head_K=6)
+    m.alloc_state(1, pos=300)
+    m.with_attention = with_attention
+    assert m.lm_head.K == 6 and m.persistent_applies()
+    if not with_attention:
+        ref = _oracle_decode(m, _np(m.x0))
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    lf = _np(m.decode_step_fx().float()).copy()
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    lp = _np(m.decode_step_persistent().float()).copy()
+    assert not m._pstep.error() and "head_K=6" in m._pstep.describe()
+    assert np.isfinite(lp).all() and _relerr(lp, lf) < 2e-2
+    if not with_attention:
+        assert _relerr(lp, ref) < 3e-2
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    _replay_equals(m.decode_step_persistent, m, lp, reps=3)
+    assert not m._pstep.error()
