@@ -352,9 +352,12 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
     {
         AttWords r;
         const int c = lane_v & 15, kg = lane_v >> 4;
-        const int tk = max(min(it.t0 + 128 * st_ + 16 * slot + c, it.t1 - 1), 0);
+        const int tb = it.t0 + 128 * st_ + 16 * slot;                          // the wave's 16 tokens: 16-aligned, inside ONE page (the page size is a multiple of 16)
+        const int tk = max(min(tb + c, it.t1 - 1), 0);
         const int page = a.page_size;
-        const int64_t pg = (int64_t) ps_g(a.block_table)[min(tk / page, a.blocks_per_seq - 1)];
+        // the page id is wave-uniform: a scalar load (the table is not written during the launch) instead of a vector load in front of the cache loads' addresses
+        const int tpg = max(tb < it.t1 ? tb : it.t1 - 1, 0) / page;
+        const int64_t pg = (int64_t) ((const int PS_CONST*) a.block_table)[min(tpg, a.blocks_per_seq - 1)];
         const int64_t gbase = (pg * page + (tk % page)) * it.G + it.h * 4 + kg;
         r.k = *ps_g((const uint4_t*) (it.kc + gbase * 4)); r.v = *ps_g((const uint4_t*) (it.vc + gbase * 4));
         r.ks = ps_g(it.ks)[gbase]; r.vs = ps_g(it.vs)[gbase];
