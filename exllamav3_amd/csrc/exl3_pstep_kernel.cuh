@@ -73,25 +73,56 @@ __device__ __forceinline__ void ps_st128(ps_rsrc_t r, uint32_t byte_off, uint4_t
 // tag = (run epoch, producer op).  The consumer needs no edge: it loads the lines of its block and re-loads until every tag is the producer's (data and
 // flag in one store: the guide's handoff-1to1 granules).  Lines summed in slice order from zero (slab_sum of exl3_glue_device.cuh).
 #define PS_LINE_BYTES 1024
+// PARTIAL lines -- a slice's partial row of a column block on its way to the consumer that sums the slices (slab lines of q|k|v and gate|up, the partial rows of o / down) --
+// travel as fp16 pairs: ONE granule { v0 v1, tag, v2 v3, tag } per lane, 512 bytes per line.  Half the bytes of every hand-off edge and half the registers of a gather round
+// (a q|k|v / gate|up op now gathers the partial lines of all its <= 4 blocks in ONE round trip, o_proj sums its 8 slab lines in one).  The sums stay fp32; what is rounded is
+// each slice's contribution (2^-11 relative, like the activations the consumer forms from it).  The residual row's blocks (rbuf) stay fp32 lines.
+// A/B builds: PS_FP32_PARTIALS keeps the 1 KiB fp32 lines.
+#ifndef PS_FP32_PARTIALS
+#define PS_PLINE_BYTES 512
+struct PsPl { uint4_t a; };
+__device__ __forceinline__ PsPl ps_pl_load(ps_rsrc_t r, uint32_t line_off, int l) { PsPl p; p.a = ps_ld128(r, line_off + (uint32_t) l * 16); return p; }
+__device__ __forceinline__ bool ps_pl_ok(const PsPl& p, uint32_t tag) { return (p.a.y == tag) & (p.a.w == tag); }
+__device__ __forceinline__ float4_t ps_pl_val(const PsPl& p, uint32_t mask = 0xffffffffu)
+{
+    const half2_t a01 = u32_as_half2(p.a.x & mask), a23 = u32_as_half2(p.a.z & mask);
+    return float4_t{ (float) a01.x, (float) a01.y, (float) a23.x, (float) a23.y };
+}
+__device__ __forceinline__ void ps_pl_store(ps_rsrc_t r, uint32_t line_off, int l, float4_t v, uint32_t tag)
+{
+    ps_st128(r, line_off + (uint32_t) l * 16, uint4_t{ half2_as_u32(half2_t{ f2h(v.x), f2h(v.y) }), tag, half2_as_u32(half2_t{ f2h(v.z), f2h(v.w) }), tag });
+}
+#else
+#define PS_PLINE_BYTES 1024
+struct PsPl { uint4_t a, b; };
+__device__ __forceinline__ PsPl ps_pl_load(ps_rsrc_t r, uint32_t line_off, int l) { PsPl p; p.a = ps_ld128(r, line_off + (uint32_t) l * 16); p.b = ps_ld128(r, line_off + 512 + (uint32_t) l * 16); return p; }
+__device__ __forceinline__ bool ps_pl_ok(const PsPl& p, uint32_t tag) { return (p.a.y == tag) & (p.a.w == tag) & (p.b.y == tag) & (p.b.w == tag); }
+__device__ __forceinline__ float4_t ps_pl_val(const PsPl& p, uint32_t mask = 0xffffffffu)
+{
+    return float4_t{ __uint_as_float(p.a.x & mask), __uint_as_float(p.a.z & mask), __uint_as_float(p.b.x & mask), __uint_as_float(p.b.z & mask) };
+}
+__device__ __forceinline__ void ps_pl_store(ps_rsrc_t r, uint32_t line_off, int l, float4_t v, uint32_t tag)
+{
+    ps_st128(r, line_off + (uint32_t) l * 16, uint4_t{ __float_as_uint(v.x), tag, __float_as_uint(v.y), tag });
+    ps_st128(r, line_off + 512 + (uint32_t) l * 16, uint4_t{ __float_as_uint(v.z), tag, __float_as_uint(v.w), tag });
+}
+#endif
+
 template <int NB>
 __device__ __forceinline__ float4_t ps_slab_sum(ps_rsrc_t r, uint32_t blk_off, int S, int l, uint32_t tag, bool& ok)
 {
     float4_t v = { 0.f, 0.f, 0.f, 0.f };
     for (int s = 0; s < S; s += NB)
     {
-        uint4_t t[NB][2];
+        PsPl t[NB];
         #pragma unroll
-        for (int i = 0; i < NB; ++i)
-        {
-            const uint32_t o = blk_off + (uint32_t) min(s + i, S - 1) * PS_LINE_BYTES + (uint32_t) l * 16;
-            t[i][0] = ps_ld128(r, o); t[i][1] = ps_ld128(r, o + 512);
-        }
+        for (int i = 0; i < NB; ++i) t[i] = ps_pl_load(r, blk_off + (uint32_t) min(s + i, S - 1) * PS_PLINE_BYTES, l);
         #pragma unroll
         for (int i = 0; i < NB; ++i) if (s + i < S)
         {
-            ok &= (t[i][0].y == tag) & (t[i][0].w == tag) & (t[i][1].y == tag) & (t[i][1].w == tag);            // (bitwise: && makes an exec-mask branch per line)
-            v.x += __uint_as_float(t[i][0].x); v.y += __uint_as_float(t[i][0].z);
-            v.z += __uint_as_float(t[i][1].x); v.w += __uint_as_float(t[i][1].z);
+            ok &= ps_pl_ok(t[i], tag);                                  // (bitwise: && makes an exec-mask branch per line)
+            const float4_t x = ps_pl_val(t[i]);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
         }
     }
     return v;
@@ -104,20 +135,20 @@ __device__ __forceinline__ void ps_slab_sum2(ps_rsrc_t ra, ps_rsrc_t rb, uint32_
     va = float4_t{ 0.f, 0.f, 0.f, 0.f }; vb = va;
     for (int s = 0; s < S; s += NB)
     {
-        uint4_t ta[NB][2], tb[NB][2];
+        PsPl ta[NB], tb[NB];
         #pragma unroll
         for (int i = 0; i < NB; ++i)
         {
-            const uint32_t o = blk_off + (uint32_t) min(s + i, S - 1) * PS_LINE_BYTES + (uint32_t) l * 16;
-            ta[i][0] = ps_ld128(ra, o); ta[i][1] = ps_ld128(ra, o + 512); tb[i][0] = ps_ld128(rb, o); tb[i][1] = ps_ld128(rb, o + 512);
+            const uint32_t o = blk_off + (uint32_t) min(s + i, S - 1) * PS_PLINE_BYTES;
+            ta[i] = ps_pl_load(ra, o, l); tb[i] = ps_pl_load(rb, o, l);
         }
         #pragma unroll
         for (int i = 0; i < NB; ++i) if (s + i < S)
         {
-            ok &= (ta[i][0].y == tag) & (ta[i][0].w == tag) & (ta[i][1].y == tag) & (ta[i][1].w == tag)
-                & (tb[i][0].y == tag) & (tb[i][0].w == tag) & (tb[i][1].y == tag) & (tb[i][1].w == tag);
-            va.x += __uint_as_float(ta[i][0].x); va.y += __uint_as_float(ta[i][0].z); va.z += __uint_as_float(ta[i][1].x); va.w += __uint_as_float(ta[i][1].z);
-            vb.x += __uint_as_float(tb[i][0].x); vb.y += __uint_as_float(tb[i][0].z); vb.z += __uint_as_float(tb[i][1].x); vb.w += __uint_as_float(tb[i][1].z);
+            ok &= ps_pl_ok(ta[i], tag) & ps_pl_ok(tb[i], tag);
+            const float4_t x = ps_pl_val(ta[i]), y = ps_pl_val(tb[i]);
+            va.x += x.x; va.y += x.y; va.z += x.z; va.w += x.w;
+            vb.x += y.x; vb.y += y.y; vb.z += y.z; vb.w += y.w;
         }
     }
 }
@@ -228,6 +259,14 @@ __device__ __forceinline__ void ps_consume(const half4_t (&dec)[16], half4_t ag,
     });
 }
 
+// lines per round trip of a slab sum: the registers of 4 fp32 lines hold 8 fp16 lines
+#ifndef PS_FP32_PARTIALS
+#define PS_SLAB_NB 8
+#define PS_SLAB2_NB 4
+#else
+#define PS_SLAB_NB 4
+#define PS_SLAB2_NB 3
+#endif
 #ifndef PS_POLL_SLEEP
 #define PS_POLL_SLEEP 2                // s_sleep between two polls of tagged lines (x 64 clocks)
 #endif
@@ -707,12 +746,12 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                                 const int cblk = kvt ? it.h : it.h * gq + min(task, gq - 1);
                                 const half_t* svp = (kind == 1 ? O->in_svh[1] : (kind == 2 ? O->in_svh[2] : O->in_svh[0])) + (size_t) cblk * 128;
                                 const half4_t sc = ps_g((const half4_t*) svp)[l32];
-                                const uint32_t boff = (kind == 1 ? set_k : (kind == 2 ? set_v : 0u)) + (uint32_t) cblk * (uint32_t) S_q * PS_LINE_BYTES;
+                                const uint32_t boff = (kind == 1 ? set_k : (kind == 2 ? set_v : 0u)) + (uint32_t) cblk * (uint32_t) S_q * PS_PLINE_BYTES;
                                 float4_t ysum;
                                 for (int spins = 0;; ++spins)
                                 {
                                     bool ok = true;
-                                    ysum = ps_slab_sum<4>(rq, boff, S_q, l32, tag_in, ok);
+                                    ysum = ps_slab_sum<PS_SLAB_NB>(rq, boff, S_q, l32, tag_in, ok);
                                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                                     if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                                     __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
@@ -891,40 +930,55 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 {
                     const ps_rsrc_t rp = ps_rsrc(O->in_slab[0]);
                     const int S_p = O->S_in;
+                    // NSLOT lines per half-wave and round trip: with <= 16 slices a half-wave has two lines per block -> NSLOT / 2 blocks per round (all four with the fp16
+                    // lines); with up to 32 slices four lines per block
+#ifndef PS_FP32_PARTIALS
+                    constexpr int NSLOT = 8;
+#else
+                    constexpr int NSLOT = 4;
+#endif
                     const bool two = S_p <= 16;
-                    const int rounds = two ? (nb + 1) >> 1 : nb;
+                    const int lpb = two ? 2 : 4, bpr = NSLOT / lpb;           // lines per block and half-wave, blocks per round
+                    const int rounds = (nb + bpr - 1) / bpr;
                     for (int r = 0; r < rounds; ++r)
                     {
-                        float4_t ya = { 0.f, 0.f, 0.f, 0.f }, yb = ya;
+                        float4_t acc[NSLOT / 2];
                         for (int spins = 0;; ++spins)
                         {
-                            uint4_t t[4][2];
+                            PsPl t[NSLOT];
                             bool ok = true;
                             #pragma unroll
-                            for (int i = 0; i < 4; ++i)
+                            for (int i = 0; i < NSLOT; ++i)
                             {
-                                const int jj = two ? 2 * r + (i >> 1) : r, s_ = shw + 8 * (two ? (i & 1) : i);
-                                const uint32_t o = ((uint32_t) (b0 + min(jj, nb - 1)) * (uint32_t) S_p + (uint32_t) min(s_, S_p - 1)) * PS_LINE_BYTES + (uint32_t) l32 * 16;
-                                t[i][0] = ps_ld128(rp, o); t[i][1] = ps_ld128(rp, o + 512);
+                                const int jj = r * bpr + (two ? (i >> 1) : (i >> 2)), s_ = shw + 8 * (two ? (i & 1) : (i & 3));
+                                t[i] = ps_pl_load(rp, ((uint32_t) (b0 + min(jj, nb - 1)) * (uint32_t) S_p + (uint32_t) min(s_, S_p - 1)) * PS_PLINE_BYTES, l32);
                             }
-                            ya = float4_t{ 0.f, 0.f, 0.f, 0.f }; yb = ya;
                             #pragma unroll
-                            for (int i = 0; i < 4; ++i)
+                            for (int q = 0; q < NSLOT / 2; ++q) acc[q] = float4_t{ 0.f, 0.f, 0.f, 0.f };
+                            auto take = [&] (auto twoc)
                             {
-                                const int jj = two ? 2 * r + (i >> 1) : r, s_ = shw + 8 * (two ? (i & 1) : i);
-                                const bool use = jj < nb && s_ < S_p, to_b = two && (i >> 1);
-                                ok &= !use | ((t[i][0].y == tag_in) & (t[i][0].w == tag_in) & (t[i][1].y == tag_in) & (t[i][1].w == tag_in));
-                                const uint32_t ma = (use && !to_b) ? 0xffffffffu : 0u, mb = (use && to_b) ? 0xffffffffu : 0u;
-                                ya.x += __uint_as_float(t[i][0].x & ma); ya.y += __uint_as_float(t[i][0].z & ma); ya.z += __uint_as_float(t[i][1].x & ma); ya.w += __uint_as_float(t[i][1].z & ma);
-                                yb.x += __uint_as_float(t[i][0].x & mb); yb.y += __uint_as_float(t[i][0].z & mb); yb.z += __uint_as_float(t[i][1].x & mb); yb.w += __uint_as_float(t[i][1].z & mb);
-                            }
+                                constexpr bool TWO = decltype(twoc)::value;
+                                ps_static_for<0, NSLOT>([&] (auto ic)
+                                {
+                                    constexpr int i = decltype(ic)::value, bi = TWO ? (i >> 1) : (i >> 2);
+                                    const int jj = r * bpr + bi, s_ = shw + 8 * (TWO ? (i & 1) : (i & 3));
+                                    const bool use = jj < nb && s_ < S_p;
+                                    ok &= !use | ps_pl_ok(t[i], tag_in);
+                                    const float4_t x = ps_pl_val(t[i], use ? 0xffffffffu : 0u);
+                                    acc[bi].x += x.x; acc[bi].y += x.y; acc[bi].z += x.z; acc[bi].w += x.w;
+                                });
+                            };
+                            if (two) take(std::true_type{}); else take(std::false_type{});
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                             if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                             __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                         }
-                        const int ja = two ? 2 * r : r;
-                        ((float4_t*) (gath + ((size_t) (ja & 3) * 8 + shw) * 128))[l32] = ya;
-                        if (two) ((float4_t*) (gath + ((size_t) ((ja + 1) & 3) * 8 + shw) * 128))[l32] = yb;
+                        #pragma unroll
+                        for (int q = 0; q < NSLOT / 2; ++q)
+                        {
+                            const int jj = r * bpr + q;
+                            if (q < bpr && jj < nb) ((float4_t*) (gath + ((size_t) (jj & 3) * 8 + shw) * 128))[l32] = acc[q];
+                        }
                     }
                     tgt_o += PS_NSV;
                     c_inc(PS_C_O);
@@ -1166,7 +1220,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     for (int spins = 0;; ++spins)
                     {
                         bool ok = true;
-                        ys = ps_slab_sum<4>(rq, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok);
+                        ys = ps_slab_sum<PS_SLAB_NB>(rq, (uint32_t) blk * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok);
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                         if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                         __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
@@ -1191,7 +1245,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     for (int spins = 0;; ++spins)
                     {
                         bool ok = true;
-                        ps_slab_sum2<3>(rg, ru, (uint32_t) blk * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok, vg, vu);
+                        ps_slab_sum2<PS_SLAB2_NB>(rg, ru, (uint32_t) blk * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok, vg, vu);
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                         if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                         __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
@@ -1325,9 +1379,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 {
                     // the slice's partial row of column block cbl as one tagged line (both op kinds: no atomics, no drain, no edge)
                     const ps_rsrc_t rsl = ps_rsrc(slab_p);
-                    const uint32_t o = ((uint32_t) cbl * (uint32_t) S_op + (uint32_t) tl.slice) * PS_LINE_BYTES + (uint32_t) l * 16;
-                    ps_st128(rsl, o, uint4_t{ __float_as_uint(v.x), tag_out, __float_as_uint(v.y), tag_out });
-                    ps_st128(rsl, o + 512, uint4_t{ __float_as_uint(v.z), tag_out, __float_as_uint(v.w), tag_out });
+                    ps_pl_store(rsl, ((uint32_t) cbl * (uint32_t) S_op + (uint32_t) tl.slice) * PS_PLINE_BYTES, l, v, tag_out);
                 }
                 else
                 {
@@ -1360,19 +1412,16 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         for (int spins = 0;; ++spins)
                         {
                             bool ok = true;
-                            uint4_t t[4][2];
+                            PsPl t[4];
                             #pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                            {
-                                const uint32_t o = ((uint32_t) cbl * (uint32_t) S_op + (uint32_t) (shw + 8 * min(i, nl - 1))) * PS_LINE_BYTES + (uint32_t) l32 * 16;
-                                t[i][0] = ps_ld128(rsl, o); t[i][1] = ps_ld128(rsl, o + 512);
-                            }
+                            for (int i = 0; i < 4; ++i) t[i] = ps_pl_load(rsl, ((uint32_t) cbl * (uint32_t) S_op + (uint32_t) (shw + 8 * min(i, nl - 1))) * PS_PLINE_BYTES, l32);
                             ys = float4_t{ 0.f, 0.f, 0.f, 0.f };
                             #pragma unroll
                             for (int i = 0; i < 4; ++i) if (i < nl)
                             {
-                                ok &= (t[i][0].y == tag_out) & (t[i][0].w == tag_out) & (t[i][1].y == tag_out) & (t[i][1].w == tag_out);
-                                ys.x += __uint_as_float(t[i][0].x); ys.y += __uint_as_float(t[i][0].z); ys.z += __uint_as_float(t[i][1].x); ys.w += __uint_as_float(t[i][1].z);
+                                ok &= ps_pl_ok(t[i], tag_out);
+                                const float4_t x = ps_pl_val(t[i]);
+                                ys.x += x.x; ys.y += x.y; ys.z += x.z; ys.w += x.w;
                             }
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                             if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
@@ -1444,7 +1493,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 for (int spins = 0;; ++spins)
                 {
                     bool ok = true;
-                    ys = ps_slab_sum<4>(rk, (uint32_t) hb * (uint32_t) O->S_in * PS_LINE_BYTES, O->S_in, l32, tag_in, ok);
+                    ys = ps_slab_sum<PS_SLAB_NB>(rk, (uint32_t) hb * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok);
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                     if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                     __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
