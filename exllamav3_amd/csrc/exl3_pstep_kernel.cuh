@@ -1341,28 +1341,29 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     }
                 }
                 else
-                // every record and every partial row is requested up front and masked in (branch-free: a conditional load here is a chain of 24 dependent LDS
-                // round trips, 1.6-2.2 us by the phase stamps); unused slots may hold anything: the mask is applied to the bits
-                // (four waves' records per round: twelve at once are 144 registers -- the kernel then spills into scratch, and a scratch demand of that
-                //  size makes the dispatcher hold workgroups back: the grid is no longer co-resident and the edges time out; seen once, round 5)
-                #pragma unroll 1
-                for (int w0 = 0; w0 < PS_SW; w0 += 4)
                 {
-                    uint4_t si[4]; float4_t t0[4], t1[4];
+                    // the waves whose run touches column block j follow from the partition (ps_make_seg: wave w takes units [T w / 12, T (w + 1) / 12) of the rectangle's
+                    // T = 4 nb W units, column-major): at most eight consecutive waves from one before floor(12 j / W) on (checked for every nb <= 32, W <= 12); a wave whose
+                    // run STARTS in the column has its row in segment 0, one that started in the column before in segment 1 (a run spans at most two columns).  ONE round of
+                    // eight masked LDS reads -- it was three dependent rounds of records + both rows of all twelve waves (1.4 us by the stamps; 0.8 for one column block)
+                    const int H = 4 * nb, T = H * W;
+                    const int lo_u = j * H, hi_u = lo_u + H;
+                    const int w_first = max((PS_SW * lo_u) / T - 1, 0);
+                    float4_t t[8]; uint32_t mk[8];
                     #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 8; ++i)
                     {
-                        si[i] = ((const uint4_t*) seginfo)[w0 + i];
-                        t0[i] = ((const float4_t*) (part + (size_t) (w0 + i) * 256))[l]; t1[i] = ((const float4_t*) (part + (size_t) (w0 + i) * 256 + 128))[l];
+                        const int w = min(w_first + i, PS_SW - 1);
+                        const int u0 = (T * w) / PS_SW, u1 = (T * (w + 1)) / PS_SW;
+                        const bool in_col = (w_first + i < PS_SW) && u1 > u0 && u0 < hi_u && u1 > lo_u;
+                        t[i] = ((const float4_t*) (part + (size_t) w * 256 + (u0 >= lo_u ? 0 : 128)))[l];
+                        mk[i] = in_col ? 0xffffffffu : 0u;
                     }
                     #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 8; ++i)
                     {
-                        const uint32_t m0 = ((int) si[i].y > 0 && (int) si[i].x == j) ? 0xffffffffu : 0u, m1 = ((int) si[i].z > 0 && (int) si[i].x + 1 == j) ? 0xffffffffu : 0u;
-                        v.x += __uint_as_float(__float_as_uint(t0[i].x) & m0); v.y += __uint_as_float(__float_as_uint(t0[i].y) & m0);
-                        v.z += __uint_as_float(__float_as_uint(t0[i].z) & m0); v.w += __uint_as_float(__float_as_uint(t0[i].w) & m0);
-                        v.x += __uint_as_float(__float_as_uint(t1[i].x) & m1); v.y += __uint_as_float(__float_as_uint(t1[i].y) & m1);
-                        v.z += __uint_as_float(__float_as_uint(t1[i].z) & m1); v.w += __uint_as_float(__float_as_uint(t1[i].w) & m1);
+                        v.x += __uint_as_float(__float_as_uint(t[i].x) & mk[i]); v.y += __uint_as_float(__float_as_uint(t[i].y) & mk[i]);
+                        v.z += __uint_as_float(__float_as_uint(t[i].z) & mk[i]); v.w += __uint_as_float(__float_as_uint(t[i].w) & mk[i]);
                     }
                 }
 #endif
