@@ -926,7 +926,24 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 // sums of squares.  The quads are formed with r_last; the true scale needs every block's sum of squares: see the finish below
                 if (sw == 0) PS_T(4);
                 const int rver = O->rver;
-                if (active)
+                // (a producer with <= 8 slices: the block's own half-wave sums its partial lines in one round trip -- no gather through LDS, no counter among the service
+                //  waves; more slices: all eight half-waves gather)
+                const bool coop = O->S_in > 8;
+                float4_t ys_own = { 0.f, 0.f, 0.f, 0.f };
+                if (active && !coop && 2 * sw < nb)
+                {
+                    const ps_rsrc_t rp = ps_rsrc(O->in_slab[0]);
+                    const int blk_o = b0 + min(shw, nb - 1);
+                    for (int spins = 0;; ++spins)
+                    {
+                        bool ok = true;
+                        ys_own = ps_slab_sum<8>(rp, (uint32_t) blk_o * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok);
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
+                    }
+                }
+                if (active && coop)
                 {
                     const ps_rsrc_t rp = ps_rsrc(O->in_slab[0]);
                     const int S_p = O->S_in;
@@ -1015,16 +1032,19 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 // every row-related load of this wave is in registers: the read gate (all workgroups arrive, also those without a rectangle)
                 tgt_a += PS_NSV;
                 { const uint32_t old = c_inc(PS_C_A); if (old + 1u == tgt_a) arrive(op); }
-                if (active) c_spin(PS_C_O, tgt_o);
+                if (active && coop) c_spin(PS_C_O, tgt_o);
                 if (sw == 0) PS_T(8);
                 if (has_task)
                 {
-                    float4_t ys = { 0.f, 0.f, 0.f, 0.f };
-                    #pragma unroll
-                    for (int h = 0; h < 8; ++h)
+                    float4_t ys = ys_own;
+                    if (coop)
                     {
-                        const float4_t t = ((const float4_t*) (gath + ((size_t) (tb & 3) * 8 + h) * 128))[l32];
-                        ys.x += t.x; ys.y += t.y; ys.z += t.z; ys.w += t.w;
+                        #pragma unroll
+                        for (int h = 0; h < 8; ++h)
+                        {
+                            const float4_t t = ((const float4_t*) (gath + ((size_t) (tb & 3) * 8 + h) * 128))[l32];
+                            ys.x += t.x; ys.y += t.y; ys.z += t.z; ys.w += t.w;
+                        }
                     }
                     float h0, h1, h2, h3;
                     out_had(ys, l32, h0, h1, h2, h3);
