@@ -267,6 +267,9 @@ __device__ __forceinline__ void ps_consume(const half4_t (&dec)[16], half4_t ag,
 #define PS_SLAB_NB 4
 #define PS_SLAB2_NB 3
 #endif
+#ifndef PS_COOP_MIN
+#define PS_COOP_MIN 8                  // a direct row edge gathers cooperatively (all eight service half-waves, through LDS) above this many producer slices
+#endif
 #ifndef PS_POLL_SLEEP
 #define PS_POLL_SLEEP 2                // s_sleep between two polls of tagged lines (x 64 clocks)
 #endif
@@ -928,7 +931,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 const int rver = O->rver;
                 // (a producer with <= 8 slices: the block's own half-wave sums its partial lines in one round trip -- no gather through LDS, no counter among the service
                 //  waves; more slices: all eight half-waves gather)
-                const bool coop = O->S_in > 8;
+                const bool coop = O->S_in > PS_COOP_MIN;
                 float4_t ys_own = { 0.f, 0.f, 0.f, 0.f };
                 if (active && !coop && 2 * sw < nb)
                 {
