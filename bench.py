@@ -273,6 +273,21 @@ def main():
     if world > 1 and os.environ.get("EXL3_HIP_TP_ALLREDUCE", "ipc") == "ipc":
         ipc_on = backend.enable_ipc_allreduce(max(args.batch, 1) * shape.hidden)
 
+    # safety net of the driver's line: the persistent step needs the whole grid co-resident (one workgroup per CU); should a box ever not give that, its bounded
+    # waits time out (flagged, results invalid) -- then the launch-per-op pipeline (the same HIP library, round 4's default) is timed instead, and the line says so
+    persistent_fallback = None
+    if pipeline == "persistent":
+        run_step(); run_step()
+        torch.cuda.synchronize()
+        if model._pstep is None or model._pstep.error():
+            print("bench.py: WARNING: the persistent decode step reported a time-out on this device (grid not co-resident?); timing the launch-per-op fx pipeline instead",
+                  file=sys.stderr, flush=True)
+            persistent_fallback = "the persistent step timed out in the warm-up on this device: launch-per-op fx pipeline timed"
+            pipeline = "fx"
+            model.persistent = False
+            model._pstep = None
+            run_step = model.decode_step_fx
+
     def capture():
         run_step()
         torch.cuda.synchronize()
@@ -812,7 +827,7 @@ def main():
                        "bytes_per_token": shape.decode_bytes_per_token(args.bits), "hbm_roofline_tok_s": round(HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits), 1),
                        "frac_of_hbm_roofline": round(tok_s / args.batch / (HBM_PEAK_GBPS * 1e9 / shape.decode_bytes_per_token(args.bits)), 4),
                        "parallelism": f"tp{world}", "gemv_variant": args.variant},
-            "repeat_ms_per_step": repeat_ms, "allreduce": allreduce,
+            "repeat_ms_per_step": repeat_ms, "allreduce": allreduce, "persistent_fallback": persistent_fallback,
             "logits_check": logits_check,
             "roofline": roofline, "cpu_baseline": cpu, "prefill": prefill, "other_configs": extra,
         }
