@@ -809,11 +809,23 @@ class SyntheticEXL3Llama:
             self._pstep = ext.PersistentStep(layers, self.lm_head, self.final_norm, self.shape.hidden, self.hq, self.hkv, hd, self.eps, rope_mode=2,
                                              stamps=bool(os.environ.get("EXL3_HIP_PSTEP_STAMPS")), attention=att)
             self._pstep_att = att
+            self._pstep_checked = False
         ext.fx_init_prep(self.x0, self.R, self.ss, 1, self.inv_freq, self.positions, hd, self.block_table, self.page, self.rope_sin, self.rope_cos, self.kv_slots)
         if att:
             self._pstep.run(self.R, self.logits, self.q, self.rope_sin, self.rope_cos, self.kv_slots, self.block_table, self.attn_lens, self.page)
         else:
             self._pstep.run(self.R, self.logits, self.q, self.rope_sin, self.rope_cos, self.kv_slots)
+        if not self._pstep_checked and not torch.cuda.is_current_stream_capturing():
+            # first run of a new plan: the step needs the whole grid co-resident (one workgroup per CU); if this device does not give that, its bounded waits time
+            # out (flagged) -- then the launch-per-op pipeline takes over for good, loudly
+            self._pstep_checked = True
+            if self._pstep.error():
+                import warnings
+                warnings.warn("exllamav3_amd: the persistent decode step timed out on this device (grid not co-resident?); using the launch-per-op pipeline", RuntimeWarning)
+                type(self).persistent = False
+                self.persistent = False
+                self._pstep = None
+                return self.decode_step_fx()
         return self.logits
 
     def decode_step_auto(self):
