@@ -4,9 +4,10 @@
 // RoPE and the 4-bit K / V append, silu * mul, residual adds); reference graphs it replaces: libtorch/attention.cpp:246-330 + libtorch/mlp.cpp:14-91 per
 // layer (the reference itself keeps input Hadamard -> stream -> output Hadamard of ONE linear inside one cooperative launch with two grid syncs:
 // quant/exl3_gemv_kernel.cuh:138-402).  Grid = one 16-wave workgroup per CU, all co-resident; an "op" = one fused GEMV (q|k|v, o, gate|up, down,
-// lm_head); between two ops every CU meets at an XCD-sharded arrival counter (the EDGE).  What a wave does while it waits at an edge is the point of the
-// design: the weights of the next op do not depend on the activations, so the wave already has them in flight and DECODES its first work units
-// into registers / LDS (decode-ahead); when the activations arrive those units cost one MFMA pass instead of 235 VALU instructions each.
+// lm_head); what one CU hands to another between two ops (the EDGE) travels as TAGGED LINES -- data and flag in one 16-byte store, tag = (run epoch, producer
+// op) -- that the consumer re-loads until every tag is the producer's: no arrival counter is polled on the data path.  What a wave does while it waits at an
+// edge is the point of the design: the weights of the next op do not depend on the activations, so the wave already has them in flight and DECODES its first
+// work units into registers / LDS (decode-ahead: three units); when the activations arrive those units cost one MFMA pass instead of 235 VALU instructions each.
 #pragma once
 #include <stdint.h>
 #include "exl3_common.cuh"
@@ -28,8 +29,9 @@
 #define PS_DIRECT 0x100
 // ATTENTION inside the step (bit 9 of o_proj's in_type): o_proj's preparation then (a) runs ONE item of the decode attention over the quantized cache -- kv block h, context
 // split s of `nsplit` (tile.side = h * nsplit + s): q / k / v finished from the q|k|v op's slab lines as exl3_attn_decode_qcache_split_qkv does (RoPE, 4-bit append of the
-// new token by the split that holds it), the matrix-pipe split kernel's token loop on the four service waves, the partial record published as a tagged line + a statistics
-// granule -- and (b) merges the records of the query heads of ITS k-slice (all splits: one hop) into o_proj's input.  Reference: libtorch/attention.cpp:246-504.
+// new token by the split that holds it), the matrix-pipe split kernel's token loop on eight waves (the four service waves + streaming waves 0-3: two per SIMD), the
+// partial record published as 32 tagged fp16 granules + a statistics granule -- and (b) merges the records of the query heads of ITS k-slice (all splits in use: one hop,
+// eight records per round trip) into o_proj's input.  The splits in use follow the length on the device.  Reference: libtorch/attention.cpp:246-504.
 #define PS_ATTN 0x200
 
 // LDS map of the kernel (bytes)
@@ -37,7 +39,7 @@
 #define PS_MISC_BYTES 1536                        // block sums of squares [64] | block sums [2][64] | segment records [2][16][4] | control words
 #define PS_PART_BYTES (12 * 2 * 512)              // partial rows [streaming wave][segment][128] fp32
 #define PS_PDEC_BYTES (12 * 16 * 64 * 8)          // decode-ahead unit #2 of every streaming wave: [wave][16 operand slots][64 lanes] x 8 B
-#define PS_GATH_BYTES (4 * 8 * 512)                // owners of residual-row blocks: [4 blocks][8 service half-waves][128] fp32 gathered sums
+#define PS_GATH_BYTES (4 * 8 * 512)                // finishers of residual-row blocks (owners; direct RMSNorm ops whose producer has > 8 slices): [4 blocks][8 service half-waves][128] fp32 gathered sums
 #define PS_ATT_BYTES 21504                         // attention item (with the gather area in front of it: 37 888 B): V tiles / partial outputs 8 x 4352 | new-token words 128 | scales 128 | wave statistics 512 | queries 2048
 #define PS_ATT_MAX_SPLITS 32                       // statistics of all splits of a head in one half-wave (one lane per split)
 #define PS_DBG_SLOTS 32                           // phase stamps per op and workgroup (exl3_pstep_stamps): 0..12 streaming wave 0 / service wave 0, 16 + w: streaming wave w done, 28 + s: service wave s published its quads
@@ -47,7 +49,7 @@
 struct PsMat
 {
     const uint32_t* B; const half_t* suh; const half_t* svh;
-    unsigned long long* slab;          // PS_OUT_SLAB: [n / 128][S] lines of 1 KiB: 64 tagged pairs { v0, tag, v1, tag } (exl3_pstep_kernel.cuh)
+    unsigned long long* slab;          // PS_OUT_SLAB: [n / 128][S] partial lines (PS_PLINE_BYTES = 512: 32 tagged fp16 granules { v0 v1, tag, v2 v3, tag }; exl3_pstep_kernel.cuh)
     int n, tiles_n;
 };
 
