@@ -145,10 +145,15 @@ def test_persistent_step_with_attention_inside_matches_the_launch_per_op_step(de
     service + four streaming waves, partial records as tagged granules, merged by the consumers; head_dim 128 and 64) against decode_step_fx with the attention core (itself tested against
     the oracle in test_gpu_path / test_gpu_fullsize): logits, the finished queries, the appended K / V rows of every layer (dequantized), nothing else written
     to the cache; random pre-filled cache; eager twice and graph replay give the same bits; no time-out."""
+    from exllamav3_amd.llama_path import LlamaShape
+    _attention_inside_case(dev, LlamaShape("tiny-att", hidden, inter, layers, hq, hkv, hd, vocab), pos)
+
+
+def _attention_inside_case(dev, shape, pos):
     from exllamav3_amd import ext
-    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    from exllamav3_amd.llama_path import SyntheticEXL3Llama
     ext.set_gemv_variant(1)
-    shape = LlamaShape("tiny-att", hidden, inter, layers, hq, hkv, hd, vocab)
+    hq = shape.heads_q
     m = SyntheticEXL3Llama(shape, K=4, cb=2, device=dev, kv_bits=4, max_ctx=2048)
     m.alloc_state(1, pos=pos)
     m.with_attention = True
@@ -213,3 +218,43 @@ def test_persistent_step_with_a_six_bit_lm_head(dev, K, with_attention):
     for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
     _replay_equals(m.decode_step_persistent, m, lp, reps=3)
     assert not m._pstep.error()
+
+
+# shapes of other public Llama-shaped checkpoints: their plans use slice counts no BASELINE shape has (6, 7, 10, 12, 15, 16, 18, 25 slices per op on 256 CUs; slab sums of
+# 12 / 16 lines, cooperative row gathers over 10 - 25 partial lines, uneven slices) -- two layers (the second q|k|v op takes the direct row edge) + a 16384-column head
+MID_SHAPES = [("llama-3.2-3b", 3072, 8192, 24, 8, 128), ("qwen2.5-7b", 3584, 18944, 28, 4, 128), ("qwen2.5-1.5b", 1536, 8960, 12, 2, 128),
+              ("llama-2-7b", 4096, 11008, 32, 32, 128), ("tinyllama", 2048, 5632, 32, 4, 64), ("hidden-2560", 2560, 6912, 20, 4, 128)]
+
+
+@pytest.mark.parametrize("name,hidden,inter,hq,hkv,hd", MID_SHAPES)
+def test_persistent_step_other_checkpoint_shapes_vs_launch_per_op(dev, name, hidden, inter, hq, hkv, hd):
+    """Without the attention core: logits / finished queries / appended K / V rows of the persistent step against decode_step_fx on the same tensors (the launch-per-op
+    GEMVs are shape-general and oracle-tested per shape in test_gpu_gemv / test_gpu_fullsize), eager twice == graph replay, no time-out."""
+    from exllamav3_amd.llama_path import LlamaShape
+    m = _model(LlamaShape(name + "-2layer", hidden, inter, 2, hq, hkv, hd, 16384), dev)
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    lf = _np(m.decode_step_fx().float()).copy()
+    kv_f = [(_np(c).copy(), _np(s_).copy()) for c, s_ in m.kcache + m.vcache]
+    q_f = _np(m.q.float()).copy()
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    m.q.zero_()
+    lp = _np(m.decode_step_persistent().float()).copy()
+    assert m._pstep is not None and not m._pstep.error()
+    assert np.isfinite(lp).all()
+    assert _relerr(lp, lf) < 2e-2, _relerr(lp, lf)
+    assert np.abs(q_f - _np(m.q.float())).max() < 2e-2 * max(1.0, float(np.abs(q_f).max()))
+    page, slot = int(m.block_table[0, 700 // m.page]), 700 % m.page
+    for (wa, sa), (c, s_) in zip(kv_f, m.kcache + m.vcache):
+        got = o.kv_dequant(_np(c[page, slot]).view(np.uint32)[None, None], _np(s_[page, slot])[None, None], 4).reshape(-1).astype(np.float32)
+        want = o.kv_dequant(wa[page, slot].view(np.uint32)[None, None], sa[page, slot][None, None], 4).reshape(-1).astype(np.float32)
+        assert np.abs(got - want).max() / np.sqrt((want ** 2).mean()) < 0.2
+        assert np.abs(_np(c)).sum() == np.abs(_np(c[page, slot])).sum()          # nothing but the new token's row was written
+    assert np.array_equal(_np(m.decode_step_persistent().float()), lp)
+    _replay_equals(m.decode_step_persistent, m, lp, reps=3)
+    assert not m._pstep.error()
+
+
+@pytest.mark.parametrize("name,hidden,inter,hq,hkv,hd", [s_ for s_ in MID_SHAPES if (s_[3] // s_[4]) * (128 // s_[5]) <= 8])
+def test_persistent_step_other_checkpoint_shapes_with_attention_inside(dev, name, hidden, inter, hq, hkv, hd):
+    from exllamav3_amd.llama_path import LlamaShape
+    _attention_inside_case(dev, LlamaShape(name + "-2layer", hidden, inter, 2, hq, hkv, hd, 16384), 700)

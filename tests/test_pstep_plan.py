@@ -8,7 +8,10 @@ import numpy as np
 import pytest
 
 SHAPES = {"llama-3.1-8b": (4096, 14336, 32, 8, 128, 128256), "llama-3.2-1b": (2048, 8192, 32, 8, 64, 128256),
-          "tiny": (256, 512, 4, 2, 128, 384), "odd": (1024, 2816, 8, 8, 128, 3072), "hd64": (512, 1536, 8, 2, 64, 1024)}
+          "tiny": (256, 512, 4, 2, 128, 384), "odd": (1024, 2816, 8, 8, 128, 3072), "hd64": (512, 1536, 8, 2, 64, 1024),
+          # other public Llama-shaped checkpoints (slice counts 6 .. 25 on 256 CUs; the GPU side: test_gpu_pstep.MID_SHAPES)
+          "llama-3.2-3b": (3072, 8192, 24, 8, 128, 128256), "qwen2.5-7b": (3584, 18944, 28, 4, 128, 152064), "qwen2.5-1.5b": (1536, 8960, 12, 2, 128, 151936),
+          "llama-2-7b": (4096, 11008, 32, 32, 128, 32000), "tinyllama": (2048, 5632, 32, 4, 64, 32000), "hidden-2560": (2560, 6912, 20, 4, 128, 50304)}
 
 
 @pytest.mark.parametrize("ncu", [256, 304, 64])
