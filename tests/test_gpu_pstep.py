@@ -220,6 +220,34 @@ def test_persistent_step_with_a_six_bit_lm_head(dev, K, with_attention):
     assert not m._pstep.error()
 
 
+@pytest.mark.parametrize("K,head_K", [(2, None), (5, None), (6, None), (8, None), (2, 6), (5, 6), (8, 6)])
+@pytest.mark.parametrize("with_attention", [False, True])
+def test_persistent_step_every_instantiated_bit_width(dev, K, head_K, with_attention):
+    """Every (K, head K) pair the library instantiates besides the 4- and 3-bit ones above (exl3_pstep.hip: PS_PAIRS) runs the step: against decode_step_fx on the same
+    tensors (2e-2), without attention also against the oracle composition (3e-2); replay == eager; no time-out."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_variant(1)
+    shape = LlamaShape("small-k%d" % K, 1024, 2816, 2, 8, 2, 128, 3072)
+    m = SyntheticEXL3Llama(shape, K=K, cb=2, device=dev, kv_bits=4, max_ctx=1024, head_K=head_K)
+    m.alloc_state(1, pos=300)
+    m.with_attention = with_attention
+    assert m.lm_head.K == (head_K or K) and m.persistent_applies()
+    if not with_attention:
+        ref = _oracle_decode(m, _np(m.x0))
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    lf = _np(m.decode_step_fx().float()).copy()
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    lp = _np(m.decode_step_persistent().float()).copy()
+    assert m._pstep is not None and not m._pstep.error() and ("head_K=%d" % (head_K or K)) in m._pstep.describe()
+    assert np.isfinite(lp).all() and _relerr(lp, lf) < 2e-2, _relerr(lp, lf)
+    if not with_attention:
+        assert _relerr(lp, ref) < 3e-2
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    _replay_equals(m.decode_step_persistent, m, lp, reps=3)
+    assert not m._pstep.error()
+
+
 # shapes of other public Llama-shaped checkpoints: their plans use slice counts no BASELINE shape has (6, 7, 10, 12, 15, 16, 18, 25 slices per op on 256 CUs; slab sums of
 # 12 / 16 lines, cooperative row gathers over 10 - 25 partial lines, uneven slices) -- two layers (the second q|k|v op takes the direct row edge) + a 16384-column head
 MID_SHAPES = [("llama-3.2-3b", 3072, 8192, 24, 8, 128), ("qwen2.5-7b", 3584, 18944, 28, 4, 128), ("qwen2.5-1.5b", 1536, 8960, 12, 2, 128),
