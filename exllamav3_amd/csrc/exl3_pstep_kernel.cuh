@@ -267,6 +267,7 @@ __device__ __forceinline__ void ps_consume(const half4_t (&dec)[16], half4_t ag,
 #define PS_SLAB_NB 4
 #define PS_SLAB2_NB 3
 #endif
+// PS_SUM_HALFWAVES (A/B builds): the partial rows of a rectangle summed one column per service HALF-wave (the form before the end of round 5) instead of one per service wave
 #ifndef PS_COOP_MIN
 #define PS_COOP_MIN 8                  // a direct row edge gathers cooperatively (all eight service half-waves, through LDS) above this many producer slices
 #endif
@@ -635,6 +636,15 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 run_seg(cur.stripA, cur.len0, P, cur.len1 > 0 ? cur.stripB : after_all, cur.len1 > 0 ? cur.rs : after_rs, cur.i0 * 64, pw);
                 if (cur.len1 > 0) run_seg(cur.stripB, cur.len1, 0, after_all, after_rs, 0, pw + 128);
             }
+#ifndef PS_SUM_HALFWAVES
+            else
+            {
+                // (a wave without a unit in this op leaves a zero row: the service wave that sums a one-column rectangle then adds all twelve rows unmasked)
+                float* pw = part + (size_t) wave * 256;
+                const int col = 16 * (lane >> 3) + (lane & 7);
+                pw[col] = 0.0f; pw[col + 8] = 0.0f;
+            }
+#endif
             ring_ready = cur.n > P && nxt.n > 0;
             c_inc(PS_C_S);
             if (wave == 0) PS_T(2);
@@ -1296,6 +1306,52 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             }
             if (sw == 0) PS_T(5);
 
+#ifndef PS_SUM_HALFWAVES
+            // ---- the sum of the streaming waves' partial rows, prepared UNDER the streaming.  One column block per service WAVE (column index wave-uniform: the partition
+            // arithmetic is scalar and done here, off the chain), its candidate rows split between the wave's two half-waves and the halves added through v_permlane32_swap: a
+            // one-column rectangle = rows 0-5 | 6-11 (unit-less waves leave zero rows: no masks), a wider one = candidates 0-3 | 4-7 of the partition formula.  It was one
+            // column per HALF-wave: a per-lane column index -> ~200 VALU instructions of integer arithmetic and masks between "last streaming wave done" and "partial line
+            // published" (0.9-1.2 us by the stamps), and with W <= 2 one service wave did it all.
+            const float kinv_s = (float) u16_as_half(0x1eeeu);
+            float bb_s = 0.0f;
+            uint32_t ctab[3] = { 0u, 0u, 0u };
+            if (out_type != PS_OUT_FINAL && sw < W)
+            {
+                c_spin(PS_C_T, (uint32_t) PS_NSV * (uint32_t) (op + 1));      // (every service wave's block sums are in LDS: true long before the streaming ends)
+                float xs = 0.0f;
+                for (int q0 = 0; q0 < nb; q0 += 32) if (q0 + l32 < nb) xs += bsum[q0 + l32];
+                #pragma unroll
+                for (int i = 1; i < 32; i <<= 1) xs += xor_lane(xs, i);
+                bb_s = (float) u16_as_half(0xc931u) * xs;
+                if (W > 1)
+                {
+                    // (ps_make_seg: wave w takes units [T w / 12, T (w + 1) / 12) of the rectangle's T = 4 nb W units, column-major; the waves whose run touches column j: at
+                    //  most eight consecutive ones from one before floor(12 j / W) on -- checked for every nb <= 32, W <= 12; a run that STARTS in the column has its row in
+                    //  segment 0, one that started in the column before in segment 1)
+                    const int H = 4 * nb, T = H * W;
+                    #pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                    {
+                        const int j = sw + PS_NSV * r;
+                        if (j < W)
+                        {
+                            const int lo_u = j * H, hi_u = lo_u + H;
+                            const int w_first = max((PS_SW * lo_u) / T - 1, 0);
+                            uint32_t inb = 0u, sgb = 0u;                  // candidate i counts | its row is segment 1
+                            #pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                            {
+                                const int w = min(w_first + i, PS_SW - 1);
+                                const int u0 = (T * w) / PS_SW, u1 = (T * (w + 1)) / PS_SW;
+                                const bool in_col = (w_first + i < PS_SW) && u1 > u0 && u0 < hi_u && u1 > lo_u;
+                                inb |= (in_col ? 1u : 0u) << i; sgb |= (u0 >= lo_u ? 0u : 1u) << i;
+                            }
+                            ctab[r] = (uint32_t) w_first | (inb << 8) | (sgb << 16);
+                        }
+                    }
+                }
+            }
+#endif
             // ---- an op that produces a new version of the row: its owners overwrite the lines of the version before the previous one -- the read gate of
             // the op that read THAT version (every workgroup had it in registers long ago); polled under the streaming
             if (out_type == PS_OUT_ATOMIC && !out_direct)
@@ -1327,6 +1383,66 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             // ---- the streaming waves' partial rows are in LDS: service half-wave shw finishes column blocks shw, shw + 8 of the rectangle
             c_spin(PS_C_S, (uint32_t) PS_SW * (uint32_t) (op + 1));
             if (sw == 0) PS_T(6);
+#ifndef PS_SUM_HALFWAVES
+            if (out_type != PS_OUT_FINAL)
+            {
+                if (sw < W)
+                {
+                    const int l = l32, hi = lane >> 5;
+                    const ps_rsrc_t rsl = ps_rsrc(slab_p);
+                    auto halves = [] (float x) -> float
+                    {
+                        // r[0] = { x.lo, x.lo }, r[1] = { x.hi, x.hi } (lanes 0-31 | 32-63): the same sum lo + hi in every lane
+                        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+                        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                    };
+                    auto publish = [&] (float4_t v, int j)
+                    {
+                        v.x = halves(v.x); v.y = halves(v.y); v.z = halves(v.z); v.w = halves(v.w);
+                        v.x = (v.x * kinv_s + bb_s) * fac_norm; v.y = (v.y * kinv_s + bb_s) * fac_norm; v.z = (v.z * kinv_s + bb_s) * fac_norm; v.w = (v.w * kinv_s + bb_s) * fac_norm;
+                        if (!hi) ps_pl_store(rsl, ((uint32_t) (tl.cb0 + j) * (uint32_t) S_op + (uint32_t) tl.slice) * PS_PLINE_BYTES, l, v, tag_out);
+                    };
+                    if (W == 1)
+                    {
+                        float4_t t[6];
+                        #pragma unroll
+                        for (int i = 0; i < 6; ++i) t[i] = ((const float4_t*) (part + (size_t) (6 * hi + i) * 256))[l];
+                        float4_t v = t[0];
+                        #pragma unroll
+                        for (int i = 1; i < 6; ++i) v += t[i];             // (vector adds: v_pk_add_f32)
+                        if (sw == 0) PS_T(10);
+                        publish(v, 0);
+                    }
+                    else
+                    {
+                        #pragma unroll
+                        for (int r = 0; r < 3; ++r)
+                        {
+                            const int j = sw + PS_NSV * r;
+                            if (j >= W) break;
+                            const uint32_t ct = ctab[r];                  // (scalar: formed under the streaming, above)
+                            const uint32_t inh = ((ct >> 8) & 0xffu) >> (4 * hi), sgh = (ct >> 16) >> (4 * hi);
+                            const int wb = (int) (ct & 0xffu) + 4 * hi;
+                            float4_t t[4];
+                            #pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                t[c] = ((const float4_t*) (part + (size_t) min(wb + c, PS_SW - 1) * 256 + (size_t) ((sgh >> c) & 1u) * 128))[l];
+                            float4_t v = { 0.f, 0.f, 0.f, 0.f };
+                            #pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                            {
+                                const uint32_t mk = (uint32_t) (-(int32_t) ((inh >> c) & 1u));
+                                v.x += __uint_as_float(__float_as_uint(t[c].x) & mk); v.y += __uint_as_float(__float_as_uint(t[c].y) & mk);
+                                v.z += __uint_as_float(__float_as_uint(t[c].z) & mk); v.w += __uint_as_float(__float_as_uint(t[c].w) & mk);
+                            }
+                            if (sw == 0 && r == 0) PS_T(10);
+                            publish(v, j);
+                        }
+                    }
+                }
+            }
+            else
+#endif
             for (int j = shw; j < W; j += 2 * PS_NSV)
             {
                 const int l = l32;

@@ -16,7 +16,7 @@ print("gate $L rms_diff", d)
 sys.exit(1 if bad or max(d+[1.0] if not d else d) > 0.005 else 0)
 PY
 done
-for r in 1 2 3; do for L in "$@"; do for m in 8b 1b; do
+for r in $(seq 1 ${ROUNDS:-3}); do for L in "$@"; do for m in 8b 1b; do
   LD_LIBRARY_PATH=$PWD/$L:$LD_LIBRARY_PATH H_SPIN_LIMIT=20000 timeout 90 $H $m 0 2 "3" > $O/ab_${m}.json 2> $O/ab_${m}.err
   python3 - <<PY
 import re
