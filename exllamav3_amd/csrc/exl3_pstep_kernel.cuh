@@ -502,11 +502,13 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         // the op loop of a streaming wave over ops [op0, op1), for matrices of KK bits per weight: the layers' linears share K, the lm_head may have its own (KH: real
         // checkpoints keep the head at 6 bits) -- then the loop runs twice, the second time over the head alone (no rows requested across the two)
         uint32_t tgt_x = 0u;
-        auto stream_ops = [&] (auto kc, const int op0, const int op1)
+        auto stream_ops = [&] (auto kc, auto pmc, const int op0, const int op1)
         {
         constexpr int KK = decltype(kc)::value;
+        constexpr int PMC = decltype(pmc)::value;          // decode-ahead units this pass may hold (a head of its own K: two -- the third unit's registers on top of a 6-bit
+                                                           // ring are what pushed the mixed instantiations into scratch, and one unit of ~ 26 per wave is nothing there)
         const int quad_lane = (lane >> 2) * 8, lofs = lane * KK;
-        const int pmax = a.pmax;
+        const int pmax = min(a.pmax, PMC);
         LaneWords<KK> ring[2];
         #pragma unroll
         for (int i = 0; i < KK; ++i) { ring[0].w[i] = 0u; ring[1].w[i] = 0u; }
@@ -568,10 +570,13 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         P = 2;
                         // a THIRD unit, in registers again (Llama-3.2-1B's gate|up rectangle is 32 units = 2.67 per wave: with two units ahead eight waves streamed one
                         // more after the quads were there -- 1.5 us of decode on the critical path of every layer)
-                        if (Pm >= 3 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
+                        if constexpr (PMC >= 3)
                         {
-                            ps_predecode<KK>(ring, cur.unit_ptr(min(3, cur.n - 1)), cur.rs, lane, lofs, dec1);
-                            P = 3;
+                            if (Pm >= 3 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
+                            {
+                                ps_predecode<KK>(ring, cur.unit_ptr(min(3, cur.n - 1)), cur.rs, lane, lofs, dec1);
+                                P = 3;
+                            }
                         }
                     }
                 }
@@ -605,13 +610,16 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         else ps_unit<KK, 1>(ring, up(2), ur(2), lane, lofs, ag, acc_c, acc_d);
                     }
                     p = 2;
-                    if (pre > 2)                                         // (pre > 2 implies len > 2: decode-ahead stays inside segment 0)
+                    if constexpr (PMC >= 3)
                     {
-                        const uint2_t raw2 = *((const uint2_t*) (qb + 2 * 64));
-                        const half4_t ag2 = u2_as_half4(raw2.x, raw2.y);
-                        ps_consume<0>(dec1, ag2, acc_c, acc_d);
-                        if (len > 3) ps_unit<KK, 1>(ring, up(4), ur(4), lane, lofs, ag2, acc_c, acc_d);
-                        p = 4;
+                        if (pre > 2)                                     // (pre > 2 implies len > 2: decode-ahead stays inside segment 0)
+                        {
+                            const uint2_t raw2 = *((const uint2_t*) (qb + 2 * 64));
+                            const half4_t ag2 = u2_as_half4(raw2.x, raw2.y);
+                            ps_consume<0>(dec1, ag2, acc_c, acc_d);
+                            if (len > 3) ps_unit<KK, 1>(ring, up(4), ur(4), lane, lofs, ag2, acc_c, acc_d);
+                            p = 4;
+                        }
                     }
                 }
                 for (; p + 1 < len; p += 2)
@@ -652,8 +660,10 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             cur = nxt; tl = tn;
         }
         };
-        if constexpr (KH == K) stream_ops(std::integral_constant<int, K>{}, 0, nops);
-        else { stream_ops(std::integral_constant<int, K>{}, 0, nops - 1); stream_ops(std::integral_constant<int, KH>{}, nops - 1, nops); }
+        // (8-bit layers: two units ahead as well -- a 16-word ring + three decoded units sat at the 128-register limit of a 16-wave workgroup, one change away from scratch)
+        constexpr int PM_MAIN = K >= 8 ? 2 : 3;
+        if constexpr (KH == K) stream_ops(std::integral_constant<int, K>{}, std::integral_constant<int, PM_MAIN>{}, 0, nops);
+        else { stream_ops(std::integral_constant<int, K>{}, std::integral_constant<int, PM_MAIN>{}, 0, nops - 1); stream_ops(std::integral_constant<int, KH>{}, std::integral_constant<int, 2>{}, nops - 1, nops); }
     }
     else
     {
@@ -1314,7 +1324,26 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             // published" (0.9-1.2 us by the stamps), and with W <= 2 one service wave did it all.
             const float kinv_s = (float) u16_as_half(0x1eeeu);
             float bb_s = 0.0f;
-            uint32_t ctab[3] = { 0u, 0u, 0u };
+            uint32_t ctab0 = 0u, ctab1 = 0u;
+            // (ps_make_seg: wave w takes units [T w / 12, T (w + 1) / 12) of the rectangle's T = 4 nb W units, column-major; the waves whose run touches column j: at most eight
+            //  consecutive ones from one before floor(12 j / W) on -- checked for every nb <= 32, W <= 12; a run that STARTS in the column has its row in segment 0, one that
+            //  started in the column before in segment 1.  Packed: first candidate wave | candidate i counts << 8 | its row is segment 1 << 16)
+            auto col_table = [&] (int j) -> uint32_t
+            {
+                const int H = 4 * nb, T = H * W;
+                const int lo_u = j * H, hi_u = lo_u + H;
+                const int w_first = max((PS_SW * lo_u) / T - 1, 0);
+                uint32_t inb = 0u, sgb = 0u;
+                #pragma unroll
+                for (int i = 0; i < 8; ++i)
+                {
+                    const int w = min(w_first + i, PS_SW - 1);
+                    const int u0 = (T * w) / PS_SW, u1 = (T * (w + 1)) / PS_SW;
+                    const bool in_col = (w_first + i < PS_SW) && u1 > u0 && u0 < hi_u && u1 > lo_u;
+                    inb |= (in_col ? 1u : 0u) << i; sgb |= (u0 >= lo_u ? 0u : 1u) << i;
+                }
+                return (uint32_t) w_first | (inb << 8) | (sgb << 16);
+            };
             if (out_type != PS_OUT_FINAL && sw < W)
             {
                 c_spin(PS_C_T, (uint32_t) PS_NSV * (uint32_t) (op + 1));      // (every service wave's block sums are in LDS: true long before the streaming ends)
@@ -1323,33 +1352,8 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 #pragma unroll
                 for (int i = 1; i < 32; i <<= 1) xs += xor_lane(xs, i);
                 bb_s = (float) u16_as_half(0xc931u) * xs;
-                if (W > 1)
-                {
-                    // (ps_make_seg: wave w takes units [T w / 12, T (w + 1) / 12) of the rectangle's T = 4 nb W units, column-major; the waves whose run touches column j: at
-                    //  most eight consecutive ones from one before floor(12 j / W) on -- checked for every nb <= 32, W <= 12; a run that STARTS in the column has its row in
-                    //  segment 0, one that started in the column before in segment 1)
-                    const int H = 4 * nb, T = H * W;
-                    #pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                    {
-                        const int j = sw + PS_NSV * r;
-                        if (j < W)
-                        {
-                            const int lo_u = j * H, hi_u = lo_u + H;
-                            const int w_first = max((PS_SW * lo_u) / T - 1, 0);
-                            uint32_t inb = 0u, sgb = 0u;                  // candidate i counts | its row is segment 1
-                            #pragma unroll
-                            for (int i = 0; i < 8; ++i)
-                            {
-                                const int w = min(w_first + i, PS_SW - 1);
-                                const int u0 = (T * w) / PS_SW, u1 = (T * (w + 1)) / PS_SW;
-                                const bool in_col = (w_first + i < PS_SW) && u1 > u0 && u0 < hi_u && u1 > lo_u;
-                                inb |= (in_col ? 1u : 0u) << i; sgb |= (u0 >= lo_u ? 0u : 1u) << i;
-                            }
-                            ctab[r] = (uint32_t) w_first | (inb << 8) | (sgb << 16);
-                        }
-                    }
-                }
+                if (W > 1) ctab0 = col_table(sw);                             // (this wave's first two columns; a rectangle wider than eight: the third after them, on the chain)
+                if (W > sw + PS_NSV) ctab1 = col_table(sw + PS_NSV);
             }
 #endif
             // ---- an op that produces a new version of the row: its owners overwrite the lines of the version before the previous one -- the read gate of
@@ -1415,12 +1419,9 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     }
                     else
                     {
-                        #pragma unroll
-                        for (int r = 0; r < 3; ++r)
+                        for (int j = sw; j < W; j += PS_NSV)
                         {
-                            const int j = sw + PS_NSV * r;
-                            if (j >= W) break;
-                            const uint32_t ct = ctab[r];                  // (scalar: formed under the streaming, above)
+                            const uint32_t ct = j == sw ? ctab0 : (j == sw + PS_NSV ? ctab1 : col_table(j));      // (scalar; the first two formed under the streaming, above)
                             const uint32_t inh = ((ct >> 8) & 0xffu) >> (4 * hi), sgh = (ct >> 16) >> (4 * hi);
                             const int wb = (int) (ct & 0xffu) + 4 * hi;
                             float4_t t[4];
@@ -1435,7 +1436,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                                 v.x += __uint_as_float(__float_as_uint(t[c].x) & mk); v.y += __uint_as_float(__float_as_uint(t[c].y) & mk);
                                 v.z += __uint_as_float(__float_as_uint(t[c].z) & mk); v.w += __uint_as_float(__float_as_uint(t[c].w) & mk);
                             }
-                            if (sw == 0 && r == 0) PS_T(10);
+                            if (sw == 0 && j == 0) PS_T(10);
                             publish(v, j);
                         }
                     }
