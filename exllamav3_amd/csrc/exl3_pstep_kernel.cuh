@@ -952,6 +952,23 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 // (a producer with <= 8 slices: the block's own half-wave sums its partial lines in one round trip -- no gather through LDS, no counter among the service
                 //  waves; more slices: all eight half-waves gather)
                 const bool coop = O->S_in > PS_COOP_MIN;
+                // the previous version's block of this half-wave's task (tagged by the workgroup that published it two ops ago; version 0 = the caller's R) is REQUESTED here, in
+                // front of the gather of the producer's partial lines, and checked behind it: it was a second dependent memory round trip after the gather (~ 0.8 us of every
+                // direct RMSNorm op by the stamps -- the block has been in memory for two ops)
+                const bool has_task = active && 2 * sw < nb;               // wave-uniform
+                const int tb = min(shw, max(nb - 1, 0)), blk = b0 + tb;
+                const bool act = active && shw < nb;
+                const ps_rsrc_t rb = ps_rsrc(a.rbuf);
+                const uint32_t ro_old = rver == 1 ? (uint32_t) blk * 1024u + (uint32_t) l32 * 32u
+                                                  : (uint32_t) ((rver - 1) & 1) * 32768u + (uint32_t) blk * PS_LINE_BYTES + (uint32_t) l32 * 16u;
+                uint4_t pra = { 0u, 0u, 0u, 0u }, prc = pra;
+#ifndef PS_ROLD_LATE
+                if (has_task)
+                {
+                    if (rver == 1) { const ps_rsrc_t r0 = ps_rsrc(a.R); pra = ps_ld128(r0, ro_old); prc = ps_ld128(r0, ro_old + 16u); }
+                    else { pra = ps_ld128(rb, ro_old); prc = ps_ld128(rb, ro_old + 512u); }
+                }
+#endif
                 float4_t ys_own = { 0.f, 0.f, 0.f, 0.f };
                 if (active && !coop && 2 * sw < nb)
                 {
@@ -1023,32 +1040,30 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     tgt_o += PS_NSV;
                     c_inc(PS_C_O);
                 }
-                // the previous version's block of this half-wave's task (tagged by the workgroup that published it two ops ago; version 0 = the caller's R)
-                const bool has_task = active && 2 * sw < nb;               // wave-uniform
-                const int tb = min(shw, max(nb - 1, 0)), blk = b0 + tb;
-                const bool act = active && shw < nb;
-                const ps_rsrc_t rb = ps_rsrc(a.rbuf);
                 float4_t rold = { 0.f, 0.f, 0.f, 0.f };
                 if (has_task)
                 {
                     if (rver == 1)
                     {
-                        const ps_rsrc_t r0 = ps_rsrc(a.R);
-                        const uint32_t ro = (uint32_t) blk * 1024u + (uint32_t) l32 * 32u;
-                        const uint4_t ra = ps_ld128(r0, ro), rc = ps_ld128(r0, ro + 16u);
-                        rold = float4_t{ fx_to_float(ra.x, ra.y), fx_to_float(ra.z, ra.w), fx_to_float(rc.x, rc.y), fx_to_float(rc.z, rc.w) };
+#ifdef PS_ROLD_LATE
+                        { const ps_rsrc_t r0 = ps_rsrc(a.R); pra = ps_ld128(r0, ro_old); prc = ps_ld128(r0, ro_old + 16u); }
+#endif
+                        rold = float4_t{ fx_to_float(pra.x, pra.y), fx_to_float(pra.z, pra.w), fx_to_float(prc.x, prc.y), fx_to_float(prc.z, prc.w) };
                     }
                     else
                     {
-                        const uint32_t tag_old = (epoch << 12) | (uint32_t) (op - 2), ro = (uint32_t) ((rver - 1) & 1) * 32768u + (uint32_t) blk * PS_LINE_BYTES + (uint32_t) l32 * 16u;
+                        const uint32_t tag_old = (epoch << 12) | (uint32_t) (op - 2);
+#ifdef PS_ROLD_LATE
+                        pra = ps_ld128(rb, ro_old); prc = ps_ld128(rb, ro_old + 512u);
+#endif
                         for (int spins = 0;; ++spins)
                         {
-                            const uint4_t ra = ps_ld128(rb, ro), rc = ps_ld128(rb, ro + 512u);
-                            rold = float4_t{ __uint_as_float(ra.x), __uint_as_float(ra.z), __uint_as_float(rc.x), __uint_as_float(rc.z) };
-                            const bool ok = (ra.y == tag_old) & (ra.w == tag_old) & (rc.y == tag_old) & (rc.w == tag_old);
+                            rold = float4_t{ __uint_as_float(pra.x), __uint_as_float(pra.z), __uint_as_float(prc.x), __uint_as_float(prc.z) };
+                            const bool ok = (pra.y == tag_old) & (pra.w == tag_old) & (prc.y == tag_old) & (prc.w == tag_old);
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                             if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
                             __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
+                            pra = ps_ld128(rb, ro_old); prc = ps_ld128(rb, ro_old + 512u);
                         }
                     }
                 }
