@@ -56,3 +56,37 @@ def test_planner_refuses_what_the_kernel_cannot_take():
     assert l.exl3_pstep_plan_tiles(4096, 14336, 32, 8, 128, 128256, 256, 7, P, ctypes.byref(S)) < 0          # no such op kind
     assert l.exl3_pstep_plan_tiles(4100, 14336, 32, 8, 128, 128256, 256, 0, P, ctypes.byref(S)) < 0          # hidden not a multiple of 128
     assert l.exl3_pstep_plan_tiles(4096, 14336, 32, 8, 96, 128256, 256, 0, P, ctypes.byref(S)) < 0           # head_dim
+
+
+def test_partial_row_partition_formula_matches_the_streaming_waves_runs():
+    """The service waves of the persistent step find the partial rows of column j of a rectangle WITHOUT records (exl3_pstep_kernel.cuh: col_table): streaming wave w takes
+    units [T w / 12, T (w + 1) / 12) of the rectangle's T = 4 nb W units, column-major (ps_make_seg), so the waves whose run touches column j are at most EIGHT consecutive
+    ones from max(floor(12 j / W) - 1, 0) on, a run that starts in the column has its row in segment 0 and one that started in the column before in segment 1, and a run
+    spans at most two columns (W <= 12).  Brute force over every rectangle the planner can make (nb <= 32, W <= 12): the formula's (wave, segment) set per column equals the
+    set read off the runs themselves; for a one-column rectangle the rows are segment 0 of every wave that has a unit."""
+    SW = 12
+    for nb in range(1, 33):
+        H = 4 * nb
+        for W in range(1, 13):
+            T = H * W
+            runs = [((T * w) // SW, (T * (w + 1)) // SW) for w in range(SW)]
+            truth = {j: set() for j in range(W)}
+            for w, (u0, u1) in enumerate(runs):
+                if u1 <= u0: continue
+                cols = sorted({u // H for u in range(u0, u1)})
+                assert len(cols) <= 2                                     # (a wave keeps two partial rows: segments 0 and 1)
+                for seg, c in enumerate(cols): truth[c].add((w, seg))
+            if W == 1:
+                assert truth[0] == {(w, 0) for w, (u0, u1) in enumerate(runs) if u1 > u0}
+                continue
+            for j in range(W):
+                lo_u, hi_u = j * H, j * H + H
+                w_first = max((SW * lo_u) // T - 1, 0)
+                assert (SW * lo_u) // T == (SW * j) // W
+                got = set()
+                for i in range(8):
+                    w = min(w_first + i, SW - 1)
+                    u0, u1 = runs[w]
+                    if w_first + i < SW and u1 > u0 and u0 < hi_u and u1 > lo_u:
+                        got.add((w, 0 if u0 >= lo_u else 1))
+                assert got == truth[j], (nb, W, j, got, truth[j])
