@@ -171,16 +171,18 @@ def dist_backend_name(backend):
         return None
 
 
-def pinned_logits_check(model_name, K, cb, bsz, dev, pipeline, tol=3e-2):
+def pinned_logits_check(model_name, K, cb, bsz, dev, pipeline, tol=3e-2, ctx=None):
     """Correctness gate of the timed pipeline (VERDICT r3 weak #1 d; replaces `isfinite(logits)`): ONE layer of the benchmark's shape + a 2048-column
     lm_head built from a fixed host seed (SyntheticEXL3Llama.pin_model: the same tensors on every machine) goes through the SAME decode-step function
     bench.py times, eagerly and as a replayed hipGraph, and the logits are compared with the ORACLE's logits for that model, committed as
     tests/golden/bench_pins.json (made by tests/golden/make_bench_pins.py on the CPU; tests/test_bench_pins.py re-derives them from the oracle).
-    Bar: max |d| <= 3e-2 * RMS, the end-to-end bar of every pipeline-vs-oracle test.  The oracle itself is never imported here."""
+    Bar: max |d| <= 3e-2 * RMS, the end-to-end bar of every pipeline-vs-oracle test.  The oracle itself is never imported here.
+    ctx: the pin WITH the decode attention in the step (round 6): the new token behind a host-seeded pre-filled 4-bit cache of `ctx` tokens -- the gate of the
+    ..._with_attention_ctx* lines (at 16 000 tokens a context split of the persistent step's attention takes several 128-token steps)."""
     import numpy as np
     import torch
     from exllamav3_amd.llama_path import SyntheticEXL3Llama
-    key = SyntheticEXL3Llama.pin_key(model_name, K, cb, bsz)
+    key = SyntheticEXL3Llama.pin_key(model_name, K, cb, bsz, ctx)
     pf = os.path.join(ROOT, "tests", "golden", "bench_pins.json")
     pins = json.load(open(pf))["pins"] if os.path.exists(pf) else {}
     if key not in pins:
@@ -188,7 +190,10 @@ def pinned_logits_check(model_name, K, cb, bsz, dev, pipeline, tol=3e-2):
         # isfinite assertion of the caller -- said loudly in the record
         return {"pinned": False, "key": key, "WARNING": "NO ORACLE PIN for this configuration: the value on this line is gated by isfinite(logits) only; add the "
                                                         "configuration to tests/golden/make_bench_pins.py to pin it"}
-    m = SyntheticEXL3Llama.pin_model(model_name, K, cb, dev, bsz)
+    m = SyntheticEXL3Llama.pin_model(model_name, K, cb, dev, bsz, ctx)
+    if ctx is not None:
+        m.attn_merge_in_oproj_hd64 = True
+        cache0 = [(c.clone(), s_.clone()) for c, s_ in m.kcache + m.vcache]           # (every run appends the new token's row: the same bits each time, restored anyway)
     step = {"tail": m.decode_step_tail, "glue": m.decode_step_fused, "resid": m.decode_step_resid, "fx": m.decode_step_fx, "unfused": m.decode_step,
             "persistent": m.decode_step_persistent}[pipeline]
     if pipeline == "persistent":
@@ -200,13 +205,18 @@ def pinned_logits_check(model_name, K, cb, bsz, dev, pipeline, tol=3e-2):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=st):
             step()
+    if ctx is not None:
+        for (c, s_), (c0, s0) in zip(m.kcache + m.vcache, cache0): c.copy_(c0); s_.copy_(s0)
     m.logits.zero_(); g.replay(); torch.cuda.synchronize()
     replay = m.logits.float().cpu().numpy()
     rms = float(np.sqrt((ref.astype(np.float64) ** 2).mean()))
     err = float(np.abs(eager - ref).max() / rms) if np.isfinite(eager).all() else float("inf")
     out = {"pinned": True, "key": key, "rel_err_vs_oracle": round(err, 5), "tol": tol, "ok": bool(err < tol),
            "graph_replay_bit_equal": bool(np.array_equal(replay, eager)), "step": step.__name__,
-           "note": "max |logits - oracle logits| / RMS over one layer of the benchmark shape + a 2048-column head (host-seeded tensors; oracle values: tests/golden/bench_pins.json)"}
+           "note": "max |logits - oracle logits| / RMS over one layer of the benchmark shape + a 2048-column head (host-seeded tensors; oracle values: tests/golden/bench_pins.json)"
+                   + ("; the decode attention over a host-seeded %d-token 4-bit cache in the step" % ctx if ctx is not None else "")}
+    if ctx is not None and pipeline == "persistent":
+        out["attention_splits_tokens_steps"] = list(m._pstep.attn_geometry(ctx + 1))
     if pipeline == "persistent":
         out["edge_timeout"] = bool(m._pstep.error())
         assert not out["edge_timeout"], f"bench.py: the persistent step reported a timed-out edge: {out}"
@@ -356,8 +366,9 @@ def main():
     assert torch.isfinite(model.logits.float()).all(), "non-finite logits"
     # the pipeline that was just timed, on a pinned one-layer model of the same shape, against the oracle's committed logits (Llama shapes, one rank)
     logits_check = None
-    if world == 1 and not is_moe and not args.attention:
-        logits_check = pinned_logits_check(args.model, args.bits, cb, args.batch, dev, pipeline)
+    if world == 1 and not is_moe:
+        # (--attention: the pin with the decode attention over a host-seeded 1000-token cache in the step)
+        logits_check = pinned_logits_check(args.model, args.bits, cb, args.batch, dev, pipeline, ctx=1000 if args.attention else None)
     ipc_fell_back_after_timing = False
     if ipc_on and not backend.poll_ipc_allreduce():
         # a timed-out push poisons its elements with NaN (caught by the assert above when it reaches the logits); reaching this line means the
@@ -669,11 +680,14 @@ def main():
                     if att_persistent else fx_step_desc + " + the attention core (q|k|v epilogue inside the context-split launch, merge inside o_proj)")
         extra["llama-3.1-8b_bs1_with_attention_ctx1000"] = timed_decode(model, att_step(model), 1)
         extra["llama-3.1-8b_bs1_with_attention_ctx1000"]["step"] = att_desc
+        att_pipe = "persistent" if att_persistent else (pipe_x if pipe_x != "unfused" else "glue")
+        extra["llama-3.1-8b_bs1_with_attention_ctx1000"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, cb, 1, dev, att_pipe, ctx=1000)
         if att_persistent:
             extra["llama-3.1-8b_bs1_with_attention_ctx1000"]["edge_timeout"] = bool(model._pstep.error())
             assert not extra["llama-3.1-8b_bs1_with_attention_ctx1000"]["edge_timeout"], "bench.py: the persistent step (attention inside) reported a time-out"
             model._pstep = None
             extra["llama-3.1-8b_bs1_with_attention_ctx1000_launch_per_op"] = timed_decode(model, model.decode_step_fx, 1)
+            extra["llama-3.1-8b_bs1_with_attention_ctx1000_launch_per_op"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, cb, 1, dev, "fx", ctx=1000)
         # ... and over a 16 000-token context (VERDICT r4 task 4: the long-context cost of the quantized-cache attention on the driver line)
         try:
             import copy as _copy
@@ -683,11 +697,13 @@ def main():
             m16.with_attention = True
             extra["llama-3.1-8b_bs1_with_attention_ctx16000"] = timed_decode(m16, att_step(m16), 1)
             extra["llama-3.1-8b_bs1_with_attention_ctx16000"]["step"] = att_desc
+            extra["llama-3.1-8b_bs1_with_attention_ctx16000"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, cb, 1, dev, att_pipe, ctx=16000)
             if att_persistent:
                 extra["llama-3.1-8b_bs1_with_attention_ctx16000"]["edge_timeout"] = bool(m16._pstep.error())
                 assert not extra["llama-3.1-8b_bs1_with_attention_ctx16000"]["edge_timeout"], "bench.py: the persistent step (attention inside) reported a time-out"
                 m16._pstep = None
                 extra["llama-3.1-8b_bs1_with_attention_ctx16000_launch_per_op"] = timed_decode(m16, m16.decode_step_fx, 1)
+                extra["llama-3.1-8b_bs1_with_attention_ctx16000_launch_per_op"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, cb, 1, dev, "fx", ctx=16000)
             kvb = 2 * 16000 * model.hkv * shape.head_dim * args.kv_bits // 8 + 2 * 16000 * model.hkv * shape.head_dim // 32 * 2
             d_ms = extra["llama-3.1-8b_bs1_with_attention_ctx16000"]["ms_per_step"] - ms_per_step
             extra["llama-3.1-8b_bs1_with_attention_ctx16000"].update({
@@ -750,12 +766,14 @@ def main():
             m1._pstep = None
             att1 = pipeline == "persistent" and m1.persistent_applies()
             extra["llama-3.2-1b_bs1_with_attention_ctx1000"] = timed_decode(m1, m1.decode_step_auto if att1 else m1.decode_step_fx, 1)
+            extra["llama-3.2-1b_bs1_with_attention_ctx1000"]["logits_check"] = pinned_logits_check("llama-3.2-1b", args.bits, cb, 1, dev, "persistent" if att1 else "fx", ctx=1000)
             if att1:
                 extra["llama-3.2-1b_bs1_with_attention_ctx1000"]["step"] = att_desc
                 extra["llama-3.2-1b_bs1_with_attention_ctx1000"]["edge_timeout"] = bool(m1._pstep.error())
                 assert not extra["llama-3.2-1b_bs1_with_attention_ctx1000"]["edge_timeout"], "bench.py: the persistent step (attention inside) reported a time-out"
                 m1._pstep = None
                 extra["llama-3.2-1b_bs1_with_attention_ctx1000_launch_per_op"] = timed_decode(m1, m1.decode_step_fx, 1)
+                extra["llama-3.2-1b_bs1_with_attention_ctx1000_launch_per_op"]["logits_check"] = pinned_logits_check("llama-3.2-1b", args.bits, cb, 1, dev, "fx", ctx=1000)
             m1.with_attention = False
         del m1
         torch.cuda.empty_cache()

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("EXL3_HIP_LIB") or os.path.join(_HERE, "libexl3_hip.so
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "exl3_hip.h")
 
 _lib = None
-ABI_VERSION = 3            # include/exl3_hip.h EXL3_ABI_VERSION
+ABI_VERSION = 4            # include/exl3_hip.h EXL3_ABI_VERSION
 
 
 def declared_symbols() -> list[str]:
@@ -80,7 +80,7 @@ u32 = ctypes.c_uint32
 
 class PstepLinear(ctypes.Structure):
     """exl3_pstep_linear_t"""
-    _fields_ = [("trellis", vp), ("suh", vp), ("svh", vp), ("k", i32), ("n", i32)]
+    _fields_ = [("trellis", vp), ("suh", vp), ("svh", vp), ("k", i32), ("n", i32), ("K", i32), ("cb", i32)]
 
 
 class PstepLayer(ctypes.Structure):
@@ -146,6 +146,9 @@ def _declare(l):
     sig("exl3_pstep_run_attn", vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp)
     sig("exl3_pstep_plan_tiles", i32, i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(i32))
     sig("exl3_pstep_error", vp, vp)
+    sig("exl3_pstep_error_peek", vp)
+    sig("exl3_pstep_attn_geometry", vp, i32, ctypes.POINTER(i32))
+    sig("exl3_pstep_unpack_op", vp, i32, i32, vp, vp)
     sig("exl3_pstep_set", vp, i32, i32)
     sig("exl3_pstep_describe", vp, ctypes.c_char_p, i32)
     sig("exl3_pstep_destroy", vp)

@@ -64,7 +64,15 @@ struct PsOp
     const unsigned long long* in_slab[3];   // PS_IN_QKV: q, k, v slab sets of the producer; PS_IN_ACT: gate, up; PS_IN_NORM | PS_DIRECT: [0] = the producer's partial lines (S_in per block)
     const half_t* in_svh[3];                // ... and the producer's column scales
     uint32_t* k_cache; half_t* k_scales; uint32_t* v_cache; half_t* v_scales;      // PS_IN_QKV: the layer's 4-bit paged cache
+    // ---- round 6 (the descriptor is 320 B = five 64-byte lines now)
+    const uint32_t* Bp;                // REPACKED weights of the op (null: the checkpoint's tile-row-major tensors through mat[].B): the op's work units in the order the
+                                       // plan's workgroups and streaming waves take them -- [CU rectangle][unit], unit = 2 tile rows x 128 columns = 128 K contiguous
+                                       // words -- so that every streaming wave reads ONE contiguous run (re-ordering tiles at load time is a legal
+                                       // one-time transform; exl3_pstep_create permutes on the device, exl3_pstep_unpack_op inverts it for the bit-exactness test)
+    int K, cb;                         // bits per weight and codebook of THIS op's matrices (a qgroup shares both: conversion/allocation.py:131-141 bumps whole qgroups)
+    int pad_[12];
 };
+static_assert(sizeof(PsOp) == 320, "PsOp: five 64-byte lines (the service waves prefetch the next op's descriptor line by line)");
 
 // o_proj with PS_ATTN: overlays mat[1] .. mat[2] of its PsOp (o_proj has one matrix)
 struct PsAtt
@@ -77,7 +85,8 @@ struct PsAtt
 static_assert(sizeof(PsAtt) <= 2 * sizeof(PsMat), "PsAtt overlays two PsMat slots");
 
 // what ONE workgroup (CU) does in one op: a rectangle of (ncb column blocks of matrix mat) x (nb Hadamard blocks of k); mat < 0: nothing (it still meets the edge)
-struct PsTile { int mat, cb0, ncb, b0, nb, slice, side, flags; };
+struct PsTile { int mat, cb0, ncb, b0, nb, slice, side, flags, ubase, r0_, r1_, r2_; };      // ubase: first work unit of the rectangle in the op's repacked weights (PsOp::Bp)
+#define PS_TILE_INTS 12
 #define PS_TILE_Q_OUT 1               // this workgroup also stores the finished q blocks of its slice (one column group per slice); in a DIRECT RMSNorm op: it publishes
                                       // the new row version's blocks of its slice and their sums of squares
 
@@ -92,7 +101,8 @@ struct PsArgs
     int blocks_per_seq, page_size; float att_scale;
     uint32_t* cnt;                    // [nops][8 shards][16 words]: arrivals of edge `op`, zero at launch
     uint32_t* epoch;                  // run counter in device memory (tags of the slab granules): read at entry, + 1 at exit
-    uint32_t* err;                    // sticky: bit 0 = an edge timed out, bit 1 = a tagged slab line never arrived (results invalid)
+    uint32_t* err;                    // sticky: bit 0 = an edge timed out, bit 1 = a tagged slab line never arrived (results invalid); words 2..3: the address of the pinned
+                                      // host mirror (set to 1 by the wave that times out: a caller reads it without synchronising) or null
     unsigned long long* dbg;          // optional phase stamps [nops][ncu][PS_DBG_SLOTS] (100 MHz)
     int spin_limit, pmax;
 };

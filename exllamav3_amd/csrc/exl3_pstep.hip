@@ -30,6 +30,10 @@ struct PsHandle
     PsOp* d_ops; PsTile* d_tiles; uint32_t* d_cnt; uint32_t* d_err; unsigned long long* d_dbg;
     unsigned long long* d_slab_a; unsigned long long* d_slab_b; unsigned long long* d_slab_c; unsigned long long* d_slab_d; unsigned long long* d_rbuf; uint32_t* d_epoch;
     unsigned long long* d_att_rec; unsigned long long* d_att_stats; int attn;
+    uint32_t* d_repack; size_t repack_words;               // the ops' weights in plan order (PsOp::Bp); null: the checkpoint layout is streamed as it is
+    uint32_t* h_err;                                       // pinned host mirror of the error word: copied behind every run (capturable), read without a synchronisation
+    int att_nsplit, att_cap, head_dim;
+    std::vector<PsOp> ops; std::vector<PsTile> tiles;      // host copies of the plan (exl3_pstep_unpack_op, exl3_pstep_attn_geometry)
     size_t cnt_bytes, dbg_words;
     std::string desc;
 };
@@ -79,7 +83,7 @@ bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_t
 // rectangle (tests/test_pstep_plan.py checks the partition on the CPU through exl3_pstep_plan_tiles)
 void fill_tiles(PsTile* T, int ncu, const OpPlan& p, const int* ncb, int nmat, int nblk, int side_tasks)
 {
-    for (int c = 0; c < ncu; ++c) { T[c].mat = -1; T[c].cb0 = 0; T[c].ncb = 0; T[c].b0 = 0; T[c].nb = 0; T[c].slice = 0; T[c].side = -1; T[c].flags = 0; }
+    for (int c = 0; c < ncu; ++c) { T[c].mat = -1; T[c].cb0 = 0; T[c].ncb = 0; T[c].b0 = 0; T[c].nb = 0; T[c].slice = 0; T[c].side = -1; T[c].flags = 0; T[c].ubase = 0; T[c].r0_ = T[c].r1_ = T[c].r2_ = 0; }
     int gi = 0;
     for (int i = 0; i < nmat; ++i)
         for (int j = 0; j < p.g[i]; ++j, ++gi)
@@ -95,6 +99,9 @@ void fill_tiles(PsTile* T, int ncu, const OpPlan& p, const int* ncb, int nmat, i
             }
         }
     for (int t = 0; t < side_tasks; ++t) T[(int) ((long long) t * ncu / side_tasks)].side = t;
+    // first work unit (2 tile rows x 128 columns) of every rectangle in the op's repacked weights: rectangles in workgroup order, 4 nb x ncb units each
+    int ub = 0;
+    for (int c = 0; c < ncu; ++c) { T[c].ubase = ub; if (T[c].mat >= 0) ub += 4 * T[c].nb * T[c].ncb; }
 }
 
 void lin_to_mat(const exl3_pstep_linear_t& l, PsMat& m)
@@ -145,6 +152,46 @@ static int ps_set_lds_attr(int K, int KH)
     return EXL3_ERR_ARG;
 }
 
+// Load-time repack ("re-ordering tiles at load time is a legal one-time transform"): the op's packed words copied into the order the plan streams them --
+// [workgroup rectangle][work unit q = column-major (column block j, unit i)][2 tile rows][8 tiles x 8 K words] -- so that streaming wave w of the rectangle reads the
+// contiguous range of units [T w / 12, T (w + 1) / 12) instead of 1 KiB row pieces at a stride of n / 16 x 16 K bytes.  Same words, other addresses: decode is untouched.
+// inverse != 0: the same walk copies repacked -> checkpoint layout into `plain` for matrix `only_mat` (exl3_pstep_unpack_op: the bit-exactness test of the permutation).
+__global__ __launch_bounds__(128) void ps_repack_kernel(const PsOp* __restrict__ op, const PsTile* __restrict__ tiles, uint32_t* __restrict__ packed, int K,
+                                                        int inverse, int only_mat, uint32_t* __restrict__ plain)
+{
+    const PsTile t = tiles[blockIdx.y];
+    if (t.mat < 0 || (inverse && t.mat != only_mat)) return;
+    const int H = 4 * t.nb, T = H * t.ncb, NW = 8 * K, row_words = 8 * NW;
+    const uint32_t* B = op->mat[t.mat].B; const int tn = op->mat[t.mat].tiles_n;
+    for (int q = blockIdx.x; q < T; q += gridDim.x)
+    {
+        const int j = q / H, i = q - j * H;
+        for (int r = 0; r < 2; ++r)
+        {
+            const size_t src = ((size_t) (t.b0 * 8 + 2 * i + r) * tn + (size_t) (t.cb0 + j) * 8) * NW;
+            uint32_t* const pk = packed + (size_t) (t.ubase + q) * (2 * row_words) + (size_t) r * row_words;
+            if (!inverse) for (int w = threadIdx.x; w < row_words; w += blockDim.x) pk[w] = B[src + w];
+            else          for (int w = threadIdx.x; w < row_words; w += blockDim.x) plain[src + w] = pk[w];
+        }
+    }
+}
+
+template <int KK, int KHH>
+static int ps_occupancy_kk(bool att)
+{
+    int nb = 0;
+    hipError_t e = att ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*) exl3_pstep_kernel<KK, KHH, true>, PS_NT, PS_LDS_BYTES)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*) exl3_pstep_kernel<KK, KHH, false>, PS_NT, PS_LDS_BYTES);
+    return e == hipSuccess ? nb : -1;
+}
+static int ps_occupancy(int K, int KH, bool att)
+{
+    #define PS_X(KK, KHH) if (K == KK && KH == KHH) return ps_occupancy_kk<KK, KHH>(att);
+    PS_PAIRS(PS_X)
+    #undef PS_X
+    return -1;
+}
+
 extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* layers, int n_layers, const exl3_pstep_linear_t* head, const void* final_norm,
                                  int hidden, int heads_q, int heads_kv, int head_dim, int K, int cb, float eps, int rope_mode, int flags)
 {
@@ -160,9 +207,16 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     EXL3_CHECK_ARG(ncu >= 16, "exl3_pstep_create: device has %d CUs", ncu);
     const int KH = ((flags >> 8) & 0xf) ? ((flags >> 8) & 0xf) : K;        // flags bits 8..11: the lm_head's bits per weight when they differ from the layers'
     { const int r = ps_set_lds_attr(K, KH); if (r) return r; }
+    {
+        // the step's edges need the WHOLE grid co-resident (one workgroup per CU): the kernel must fit a CU (155 KiB of LDS, 1024 threads, no scratch) -- checked here, at
+        // create, instead of discovered as a time-out at the first step; a grid of exactly multiProcessorCount workgroups is then placed one per CU
+        const int occ = ps_occupancy(K, KH, (flags & 4) != 0);
+        EXL3_CHECK_ARG(occ != 0, "exl3_pstep_create: the step kernel does not fit a CU of this device (occupancy 0): the grid could not be co-resident");
+    }
 
     const int qdim = heads_q * head_dim, kvdim = heads_kv * head_dim, kvb = kvdim / 128;
     const int nops = 4 * n_layers + 1;
+    EXL3_CHECK_ARG(nops < 4095, "exl3_pstep_create: %d ops: the tags of the step's lines carry the producer op in 12 bits (at most 1023 layers)", nops);
     // DIRECT residual edges (exl3_pstep.cuh) unless flags bit 1 / EXL3_HIP_PSTEP_OWNERS=1 asks for the owner form everywhere (A/B runs); a plan that cannot keep
     // an RMSNorm op's slice at <= 4 blocks falls back to owners for the whole step
     // attention inside the step (flags bit 2): head_dim 128, <= 8 query heads per kv head, the chip holds one item per (kv head, split) with 2..32 splits
@@ -190,7 +244,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     int rver = 0; std::vector<int> reader_of_version;               // op index of the RMSNorm op that reads version v of the residual row
     reader_of_version.push_back(0);
     std::string desc;
-    struct Pending { int op; int which; size_t off[PS_MAX_MATS]; };
+    struct Pending { int op; int which; size_t off[PS_MAX_MATS]; int parity; };
     std::vector<Pending> slab_fix;
 
     auto add_tiles = [&] (int op, const OpPlan& p, const int* ncb, int nmat, int nblk, int side_tasks)
@@ -221,7 +275,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
                 O.in_type |= PS_DIRECT; Pd.out_type |= PS_DIRECT; O.S_in = Pd.S; O.in_svh[0] = Pd.mat[0].svh;
             }
             O.S = p.S; add_tiles(op, p, ncb, 3, hidden / 128, 0);
-            Pending f; f.op = op; f.which = 0; size_t off = 0;
+            Pending f; f.op = op; f.which = 0; f.parity = li & 1; size_t off = 0;
             for (int i = 0; i < 3; ++i) { f.off[i] = off; off += (size_t) ncb[i] * p.S * 128; }
             slab_fix.push_back(f); if (off > slab_a_floats) slab_a_floats = off;
             if (li == 0) { snprintf(line, sizeof(line), "qkv: S=%d groups=%d+%d+%d tile<=%dx%d units; ", p.S, p.g[0], p.g[1], p.g[2], p.wmax, p.hmax); desc += line; }
@@ -244,7 +298,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
                 A->rec = nullptr; A->stats = nullptr; A->gq = att_gq; A->nsplit = att_nsplit; A->hq = heads_q; A->hkv = heads_kv;      // (buffers: below)
             }
             O.rver = ++rver; O.gate_op = direct ? op - 1 : (rver >= 3 ? reader_of_version[rver - 2] : -1);       // (direct: the last readers of the lines an owner overwrites are the op before it)
-            { Pending f; f.op = op; f.which = 2; f.off[0] = 0; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * 128; if (n > slab_c_floats) slab_c_floats = n; }
+            { Pending f; f.op = op; f.which = 2; f.off[0] = 0; f.parity = 0; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * 128; if (n > slab_c_floats) slab_c_floats = n; }
             if (li == 0) { snprintf(line, sizeof(line), "o: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
             ++op;
         }
@@ -261,7 +315,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
                 O.in_type |= PS_DIRECT; Po.out_type |= PS_DIRECT; O.S_in = Po.S; O.in_svh[0] = Po.mat[0].svh;
             }
             O.S = p.S; add_tiles(op, p, ncb, 2, hidden / 128, 0);
-            Pending f; f.op = op; f.which = 1; size_t off = 0;
+            Pending f; f.op = op; f.which = 1; f.parity = 0; size_t off = 0;
             for (int i = 0; i < 2; ++i) { f.off[i] = off; off += (size_t) ncb[i] * p.S * 128; }
             slab_fix.push_back(f); if (off > slab_b_floats) slab_b_floats = off;
             if (li == 0) { snprintf(line, sizeof(line), "gate|up: S=%d groups=%d+%d tile<=%dx%d; ", p.S, p.g[0], p.g[1], p.wmax, p.hmax); desc += line; }
@@ -277,7 +331,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
             OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, inter / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for down_proj");
             O.S = p.S; add_tiles(op, p, ncb, 1, inter / 128, 0);
             O.rver = ++rver; O.gate_op = direct ? op - 1 : (rver >= 3 ? reader_of_version[rver - 2] : -1);
-            { Pending f; f.op = op; f.which = 3; f.off[0] = 0; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * 128; if (n > slab_d_floats) slab_d_floats = n; }
+            { Pending f; f.op = op; f.which = 3; f.off[0] = 0; f.parity = 0; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * 128; if (n > slab_d_floats) slab_d_floats = n; }
             if (li == 0) { snprintf(line, sizeof(line), "down: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
             ++op;
         }
@@ -297,12 +351,14 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
 
     PsHandle* h = new PsHandle();
     h->K = K; h->KH = KH; h->nops = nops; h->ncu = ncu; h->pmax = 3; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
-    h->d_att_rec = nullptr; h->d_att_stats = nullptr; h->attn = attn ? 1 : 0;
+    h->d_att_rec = nullptr; h->d_att_stats = nullptr; h->attn = attn ? 1 : 0; h->d_repack = nullptr; h->repack_words = 0; h->h_err = nullptr;
     h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr; h->d_slab_c = nullptr; h->d_slab_d = nullptr; h->d_rbuf = nullptr; h->d_epoch = nullptr;
     h->cnt_bytes = (size_t) nops * 8 * 16 * 4; h->dbg_words = (flags & 1) ? (size_t) nops * ncu * PS_DBG_SLOTS : 0;
     #define PS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { exl3_set_error("exl3_pstep_create: %s", hipGetErrorString(e_)); exl3_pstep_destroy(h); return EXL3_ERR_HIP; } } while (0)
-    PS_TRY(hipMalloc(&h->d_slab_a, slab_a_floats * 8)); PS_TRY(hipMalloc(&h->d_slab_b, slab_b_floats * 8));
-    PS_TRY(hipMemset(h->d_slab_a, 0, slab_a_floats * 8)); PS_TRY(hipMemset(h->d_slab_b, 0, slab_b_floats * 8));
+    // (the q|k|v slab lines: TWO sets, alternating by layer -- without the attention inside, the K / V append side job of layer i reads the k / v lines after its workgroup
+    //  has published o_proj's partial rows, and with direct row edges nothing orders that read against layer i + 1's q|k|v writers: they now write the other set)
+    PS_TRY(hipMalloc(&h->d_slab_a, 2 * slab_a_floats * 8)); PS_TRY(hipMalloc(&h->d_slab_b, slab_b_floats * 8));
+    PS_TRY(hipMemset(h->d_slab_a, 0, 2 * slab_a_floats * 8)); PS_TRY(hipMemset(h->d_slab_b, 0, slab_b_floats * 8));
     PS_TRY(hipMalloc(&h->d_slab_c, slab_c_floats * 8)); PS_TRY(hipMalloc(&h->d_slab_d, slab_d_floats * 8));
     PS_TRY(hipMemset(h->d_slab_c, 0, slab_c_floats * 8)); PS_TRY(hipMemset(h->d_slab_d, 0, slab_d_floats * 8));
     PS_TRY(hipMalloc(&h->d_rbuf, (size_t) PS_RBUF_BYTES)); PS_TRY(hipMemset(h->d_rbuf, 0, (size_t) PS_RBUF_BYTES));
@@ -316,7 +372,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     for (const Pending& f : slab_fix)
     {
         PsOp& O = ops[f.op];
-        unsigned long long* base = f.which == 0 ? h->d_slab_a : f.which == 1 ? h->d_slab_b : f.which == 2 ? h->d_slab_c : h->d_slab_d;
+        unsigned long long* base = f.which == 0 ? h->d_slab_a + (size_t) f.parity * slab_a_floats : f.which == 1 ? h->d_slab_b : f.which == 2 ? h->d_slab_c : h->d_slab_d;
         for (int i = 0; i < O.nmat; ++i) O.mat[i].slab = base + f.off[i];
         if (f.which >= 2)
         {
@@ -327,10 +383,64 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
         PsOp& C = ops[f.op + 1];                                      // the consumer op reads these slab sets
         for (int i = 0; i < O.nmat; ++i) C.in_slab[i] = base + f.off[i];
     }
+    // bits per weight / codebook per op: the tensors of one fused linear share both (a reference qgroup); the kernel instantiations cover one K for the layers (+ the
+    // head's) and the mul1 codebook
+    {
+        auto kind = [&] (const exl3_pstep_linear_t& l, int& Ko, int& cbo) { Ko = l.K ? l.K : K; cbo = l.K ? l.cb : cb; };
+        for (int li = 0; li < n_layers; ++li)
+        {
+            const exl3_pstep_linear_t* grp[4][3] = { { &layers[li].q, &layers[li].k, &layers[li].v }, { &layers[li].o, nullptr, nullptr },
+                                                     { &layers[li].gate, &layers[li].up, nullptr }, { &layers[li].down, nullptr, nullptr } };
+            for (int g = 0; g < 4; ++g)
+            {
+                PsOp& O = ops[(size_t) 4 * li + g];
+                kind(*grp[g][0], O.K, O.cb); O.Bp = nullptr;
+                for (int j = 1; j < 3 && grp[g][j]; ++j)
+                {
+                    int Kj, cbj; kind(*grp[g][j], Kj, cbj);
+                    if (Kj != O.K || cbj != O.cb) { exl3_set_error("exl3_pstep_create: layer %d: the tensors of one fused linear differ in bits per weight / codebook", li); exl3_pstep_destroy(h); return EXL3_ERR_ARG; }
+                }
+                if (O.K != K || O.cb != EXL3_CB_MUL1) { exl3_set_error("exl3_pstep_create: layer %d: %d bits / codebook %d: the step is built for one K in the layers and the mul1 codebook", li, O.K, O.cb); exl3_pstep_destroy(h); return EXL3_ERR_ARG; }
+            }
+        }
+        PsOp& H = ops[(size_t) nops - 1];
+        kind(*head, H.K, H.cb); H.Bp = nullptr;
+        if (!head->K) H.K = KH;
+        if (H.K != KH || H.cb != EXL3_CB_MUL1) { exl3_set_error("exl3_pstep_create: lm_head: %d bits / codebook %d do not match the plan's (flags bits 8..11)", H.K, H.cb); exl3_pstep_destroy(h); return EXL3_ERR_ARG; }
+    }
+    // the ops' weights in plan order (flags bit 4 / EXL3_HIP_PSTEP_REPACK=0: stream the checkpoint layout as it is -- A/B runs, and callers that cannot afford the second copy:
+    // the plan then holds pointers into the caller's tensors only)
+    bool repack = !(flags & 16);
+    if (const char* e = getenv("EXL3_HIP_PSTEP_REPACK")) repack = atoi(e) != 0;
+    std::vector<size_t> rp_off((size_t) nops, 0);
+    if (repack)
+    {
+        size_t words = 0;
+        for (int i = 0; i < nops; ++i)
+        {
+            rp_off[i] = words;
+            const PsTile* T = tiles.data() + (size_t) i * ncu;
+            size_t units = 0; for (int c = 0; c < ncu; ++c) if (T[c].mat >= 0) units += (size_t) 4 * T[c].nb * T[c].ncb;
+            words += units * (size_t) (128 * ops[i].K);
+        }
+        h->repack_words = words;
+        PS_TRY(hipMalloc(&h->d_repack, words * 4));
+        for (int i = 0; i < nops; ++i) ops[i].Bp = h->d_repack + rp_off[i];
+    }
     PS_TRY(hipMalloc(&h->d_ops, ops.size() * sizeof(PsOp))); PS_TRY(hipMemcpy(h->d_ops, ops.data(), ops.size() * sizeof(PsOp), hipMemcpyHostToDevice));
     PS_TRY(hipMalloc(&h->d_tiles, tiles.size() * sizeof(PsTile))); PS_TRY(hipMemcpy(h->d_tiles, tiles.data(), tiles.size() * sizeof(PsTile), hipMemcpyHostToDevice));
+    if (repack)
+    {
+        for (int i = 0; i < nops; ++i)
+            ps_repack_kernel<<<dim3(64, ncu), dim3(128), 0, 0>>>(h->d_ops + i, h->d_tiles + (size_t) i * ncu, h->d_repack + rp_off[i], ops[i].K, 0, 0, nullptr);
+        PS_TRY(hipGetLastError());
+        PS_TRY(hipDeviceSynchronize());
+    }
+    h->ops = ops; h->tiles = tiles; h->att_nsplit = att_nsplit; h->att_cap = head_dim == 128 ? PS_ATT_MAX_SPLITS : 16; h->head_dim = head_dim;
     PS_TRY(hipMalloc(&h->d_cnt, h->cnt_bytes)); PS_TRY(hipMemset(h->d_cnt, 0, h->cnt_bytes));
     PS_TRY(hipMalloc(&h->d_err, 64)); PS_TRY(hipMemset(h->d_err, 0, 64));
+    PS_TRY(hipHostMalloc((void**) &h->h_err, 64, hipHostMallocMapped)); h->h_err[0] = 0u;
+    { void* dp = nullptr; PS_TRY(hipHostGetDevicePointer(&dp, h->h_err, 0)); PS_TRY(hipMemcpy((char*) h->d_err + 8, &dp, 8, hipMemcpyHostToDevice)); }      // (behind the error word: PsArgs::err)
     PS_TRY(hipMalloc(&h->d_epoch, 64)); { const uint32_t one = 1u; PS_TRY(hipMemset(h->d_epoch, 0, 64)); PS_TRY(hipMemcpy(h->d_epoch, &one, 4, hipMemcpyHostToDevice)); }
     if (h->dbg_words) { PS_TRY(hipMalloc(&h->d_dbg, h->dbg_words * 8)); PS_TRY(hipMemset(h->d_dbg, 0, h->dbg_words * 8)); }
     #undef PS_TRY
@@ -369,7 +479,7 @@ extern "C" int exl3_pstep_plan_tiles(int hidden, int inter, int heads_q, int hea
     EXL3_CHECK_ARG(plan_op(ncu, nblk, ncb, nmat, in_type, out_type, p, direct), "exl3_pstep_plan_tiles: no plan for this op on %d CUs", ncu);
     std::vector<PsTile> T((size_t) ncu);
     fill_tiles(T.data(), ncu, p, ncb, nmat, nblk, side);
-    memcpy(tiles_out, T.data(), (size_t) ncu * sizeof(PsTile));
+    for (int c = 0; c < ncu; ++c) memcpy(tiles_out + (size_t) c * 8, &T[(size_t) c], 8 * sizeof(int32_t));      // (the first eight fields; ubase follows from them)
     *S_out = p.S;
     return EXL3_OK;
 }
@@ -417,7 +527,41 @@ extern "C" int exl3_pstep_error(void* handle, void* stream)
     uint32_t e = 0;
     EXL3_CHECK_HIP(hipMemcpy(&e, h->d_err, 4, hipMemcpyDeviceToHost), "exl3_pstep_error: hipMemcpy");
     if (e) EXL3_CHECK_HIP(hipMemset(h->d_err, 0, 4), "exl3_pstep_error: hipMemset");
+    if (h->h_err) h->h_err[0] = 0u;
     return e ? 1 : 0;
+}
+
+// no synchronisation: the pinned host mirror of the error word, written by the kernel itself when a wait times out (system-scope store).  A caller that replays a captured
+// step polls this between replays: != 0 means some EARLIER step timed out (its logits were NaN) -- exl3_pstep_error then confirms and clears.
+extern "C" int exl3_pstep_error_peek(void* handle)
+{
+    PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h, "exl3_pstep_error_peek: null handle");
+    return h->h_err && ((volatile uint32_t*) h->h_err)[0] ? 1 : 0;
+}
+
+// the attention item's geometry at a sequence length (host restatement of att_nse / att_make of the kernel): out3 = { splits in use, tokens per split, 128-token steps per split }
+extern "C" int exl3_pstep_attn_geometry(void* handle, int len, int* out3)
+{
+    PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h && out3 && len >= 1, "exl3_pstep_attn_geometry: null argument");
+    EXL3_CHECK_ARG(h->attn, "exl3_pstep_attn_geometry: the plan was created without the attention");
+    int nse = (len + 127) >> 7; if (nse < 1) nse = 1; if (nse > h->att_nsplit) nse = h->att_nsplit;
+    const int st_tok = (((len + nse - 1) / nse) + 15) & ~15;
+    out3[0] = nse; out3[1] = st_tok; out3[2] = (st_tok + 127) >> 7;
+    return EXL3_OK;
+}
+
+// the inverse of the load-time repack for matrix `mat` of op `op`: the repacked words copied back into a checkpoint-layout tensor [k / 16][n / 16][16 K] (device memory,
+// the caller's): equality with the original tensor proves the permutation (tests/test_gpu_pstep.py).  EXL3_ERR_ARG if the plan streams the checkpoint layout.
+extern "C" int exl3_pstep_unpack_op(void* handle, int op, int mat, void* trellis_out, void* stream)
+{
+    PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h && trellis_out && op >= 0 && op < h->nops && mat >= 0 && mat < h->ops[(size_t) op].nmat, "exl3_pstep_unpack_op: op / matrix out of range");
+    EXL3_CHECK_ARG(h->d_repack && h->ops[(size_t) op].Bp, "exl3_pstep_unpack_op: this plan streams the checkpoint layout (created without the repack)");
+    ps_repack_kernel<<<dim3(64, h->ncu), dim3(128), 0, (hipStream_t) stream>>>(h->d_ops + op, h->d_tiles + (size_t) op * h->ncu, (uint32_t*) h->ops[(size_t) op].Bp, h->ops[(size_t) op].K,
+                                                                                1, mat, (uint32_t*) trellis_out);
+    return exl3_check_launch("exl3_pstep_unpack_op");
 }
 
 extern "C" int exl3_pstep_set(void* handle, int decode_ahead_units, int spin_limit)
@@ -433,7 +577,8 @@ extern "C" int exl3_pstep_describe(void* handle, char* buf, int buf_bytes)
 {
     PsHandle* h = (PsHandle*) handle;
     EXL3_CHECK_ARG(h && buf && buf_bytes > 0, "exl3_pstep_describe: null argument");
-    snprintf(buf, (size_t) buf_bytes, "ops=%d cus=%d K=%d head_K=%d decode_ahead=%d lds=%d | %s", h->nops, h->ncu, h->K, h->KH, h->pmax, (int) PS_LDS_BYTES, h->desc.c_str());
+    snprintf(buf, (size_t) buf_bytes, "ops=%d cus=%d K=%d head_K=%d decode_ahead=%d lds=%d weights=%s | %s", h->nops, h->ncu, h->K, h->KH, h->pmax, (int) PS_LDS_BYTES,
+             h->d_repack ? "repacked (one contiguous run per streaming wave)" : "checkpoint layout", h->desc.c_str());
     return EXL3_OK;
 }
 
@@ -465,6 +610,8 @@ extern "C" int exl3_pstep_destroy(void* handle)
     if (h->d_slab_c) (void) hipFree(h->d_slab_c);
     if (h->d_slab_d) (void) hipFree(h->d_slab_d);
     if (h->d_rbuf) (void) hipFree(h->d_rbuf);
+    if (h->d_repack) (void) hipFree(h->d_repack);
+    if (h->h_err) (void) hipHostFree(h->h_err);
     delete h;
     return EXL3_OK;
 }

@@ -39,7 +39,8 @@ template <class T> __device__ __forceinline__ const T PS_GLOBAL* ps_g(const T* p
 __device__ __forceinline__ PsTile ps_load_tile(const PsTile* tiles, size_t idx)
 {
     const int PS_CONST* t = (const int PS_CONST*) (tiles + idx);
-    PsTile r; r.mat = t[0]; r.cb0 = t[1]; r.ncb = t[2]; r.b0 = t[3]; r.nb = t[4]; r.slice = t[5]; r.side = t[6]; r.flags = t[7];
+    PsTile r; r.mat = t[0]; r.cb0 = t[1]; r.ncb = t[2]; r.b0 = t[3]; r.nb = t[4]; r.slice = t[5]; r.side = t[6]; r.flags = t[7]; r.ubase = t[8];
+    r.r0_ = 0; r.r1_ = 0; r.r2_ = 0;
     return r;
 }
 template <int K>
@@ -286,6 +287,7 @@ __device__ __forceinline__ void ps_consume(const half4_t (&dec)[16], half4_t ag,
 #define PS_C_X 7                       // + 8 per barrier of the attention item's eight waves
 #define PS_C_Q 8                       // = op + 1 once the attention item's rotated queries (and the new token's words) are in LDS
 #define PS_C_O 6                       // + PS_NSV per op whose blocks this workgroup owns: the service half-waves' gathered sums are in LDS
+#define PS_C_ABORT 9                   // != 0 once a bounded wait of this workgroup timed out (the service waves then give up every later wait after one poll)
 
 // a streaming wave's run of work units inside its workgroup's rectangle: column-major over (column block j, unit i); at most two column blocks (planner: ncb <= PS_SW)
 template <int K>
@@ -317,11 +319,23 @@ __device__ __forceinline__ PsSeg<K> ps_make_seg(ps_op_p O, const PsTile& t, int 
         s.n = u1 - u0;
         s.j0 = u0 / H; s.i0 = u0 - s.j0 * H;
         s.len0 = min(s.n, H - s.i0); s.len1 = s.n - s.len0;
-        const ps_mat_p M = &O->mat[t.mat];
-        const uint32_t* B = M->B; const int tn = M->tiles_n;
-        s.rs = (size_t) tn * NW;
-        s.stripA = B + ((size_t) (t.b0 * 8 + 2 * s.i0) * tn + (size_t) (t.cb0 + s.j0) * 8) * NW;
-        s.stripB = B + ((size_t) (t.b0 * 8) * tn + (size_t) (t.cb0 + s.j0 + 1) * 8) * NW;
+        const uint32_t* const Bp = O->Bp;
+        if (Bp)
+        {
+            // REPACKED weights (exl3_pstep.cuh: PsOp::Bp): the rectangle's units lie in the order the waves take them, a unit = 2 tile rows of 128 columns = 16 NW
+            // contiguous words -> this wave's whole run (both segments) is ONE contiguous range
+            s.rs = (size_t) 8 * NW;
+            s.stripA = Bp + (size_t) (t.ubase + u0) * (16 * NW);
+            s.stripB = s.stripA + (size_t) s.len0 * (16 * NW);
+        }
+        else
+        {
+            const ps_mat_p M = &O->mat[t.mat];
+            const uint32_t* B = M->B; const int tn = M->tiles_n;
+            s.rs = (size_t) tn * NW;
+            s.stripA = B + ((size_t) (t.b0 * 8 + 2 * s.i0) * tn + (size_t) (t.cb0 + s.j0) * 8) * NW;
+            s.stripB = B + ((size_t) (t.b0 * 8) * tn + (size_t) (t.cb0 + s.j0 + 1) * 8) * NW;
+        }
     }
     return s;
 }
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             const ps_op_p O = ops_c + op;
             if (wave == 0) PS_T(0);
             // the next op's rectangle and this wave's run in it (pointers only): the last streamed unit of this op requests its first rows
-            PsTile tn; tn.mat = -1; tn.cb0 = 0; tn.ncb = 0; tn.b0 = 0; tn.nb = 0; tn.slice = 0; tn.side = -1; tn.flags = 0;
+            PsTile tn; tn.mat = -1; tn.cb0 = 0; tn.ncb = 0; tn.b0 = 0; tn.nb = 0; tn.slice = 0; tn.side = -1; tn.flags = 0; tn.ubase = 0; tn.r0_ = 0; tn.r1_ = 0; tn.r2_ = 0;
             if (op + 1 < op1) tn = ps_load_tile(a.tiles, (size_t) (op + 1) * ncu + cu);
             const PsSeg<KK> nxt = ps_make_seg<KK>(O + 1, tn, wave);
             const uint32_t* const after_all = nxt.n > 0 ? nxt.stripA : nullptr;           // (null: the last unit does not refill)
@@ -670,12 +684,28 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         // =========================================================================================== service waves
         const int sw = wave - PS_SW, shw = 2 * sw + (lane >> 5);          // service wave 0..3, service half-wave 0..7
         __builtin_amdgcn_s_setprio(3);                                    // the workgroup's latency chain runs here
-        bool aborted = false;
+        // bounded waits: every wait of this wave gives up after `slim` polls.  The FIRST time-out anywhere in the workgroup (an edge counter, a tagged line that never came: the
+        // grid is not co-resident, a producer died) sets the sticky error word, drops this wave's limit to zero and raises an LDS flag the other service waves pick up once per
+        // op -- every later wait then fails after one poll instead of spinning its full limit again (129 ops x several waits x 2^17 polls: minutes), and the lm_head writes NaN
+        // logits (the fx pipeline's poison convention): a timed-out step cannot be consumed silently
+        int slim = a.spin_limit;
+        auto ps_timeout = [&] (uint32_t errbit)
+        {
+            slim = 0;
+            if (lane == 0)
+            {
+                __hip_atomic_fetch_or(a.err, errbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (the pinned host mirror's address lives behind the error word, not in the kernel arguments: two scalar registers less in every path that never times out)
+                uint32_t* const eh = *((uint32_t* const*) (a.err + 2));
+                if (eh) __hip_atomic_store(eh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(lctl + PS_C_ABORT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
         uint32_t tgt_a = 0u, tgt_o = 0u, tgt_x = 0u;
         float r_last = 1.0f;                                              // the row scale (1 / rms) this workgroup last knew: DIRECT RMSNorm ops form their quads with it
         auto poll_cnt = [&] (int cop, uint32_t errbit)                    // every workgroup has arrived at counter `cop` (8 XCD shards)
         {
-            if (aborted) return;
+            if (slim == 0) return;
             const uint32_t* cbase = a.cnt; asm volatile("" : "+s"(cbase));            // (address formed here, not hoisted: see the op loop)
             const uint32_t PS_GLOBAL* c = ps_g(cbase + ((size_t) cop * 8 + (lane & 7)) * 16);
             const uint32_t expect = (uint32_t) ((ncu - (lane & 7) + 7) >> 3);
@@ -688,12 +718,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 if (__builtin_amdgcn_ballot_w64(v0 < expect) == 0ull) break;
                 v0 = __hip_atomic_load((uint32_t PS_GLOBAL*) c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__builtin_amdgcn_ballot_w64(v1 < expect) == 0ull) break;
-                if (spins > a.spin_limit)
-                {
-                    aborted = true;
-                    if (lane == 0) __hip_atomic_fetch_or(a.err, errbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
+                if (spins > slim) { ps_timeout(errbit); break; }
             }
         };
         auto arrive = [&] (int cop) { if (lane == 0) __hip_atomic_fetch_add((uint32_t PS_GLOBAL*) (a.cnt + ((size_t) cop * 8 + (cu & 7)) * 16), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -776,7 +801,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                                     bool ok = true;
                                     ysum = ps_slab_sum<PS_SLAB_NB>(rq, boff, S_q, l32, tag_in, ok);
                                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                                    if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                                    if (spins > slim) { ps_timeout(2u); break; }
                                     __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                                 }
                                 const GemvRescale rs0 = { nullptr, nullptr, 0, 0.0f };
@@ -979,7 +1004,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         bool ok = true;
                         ys_own = ps_slab_sum<8>(rp, (uint32_t) blk_o * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok);
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                        if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (spins > slim) { ps_timeout(8u); break; }
                         __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                     }
                 }
@@ -1027,7 +1052,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             };
                             if (two) take(std::true_type{}); else take(std::false_type{});
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                            if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            if (spins > slim) { ps_timeout(8u); break; }
                             __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                         }
                         #pragma unroll
@@ -1061,7 +1086,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             rold = float4_t{ __uint_as_float(pra.x), __uint_as_float(pra.z), __uint_as_float(prc.x), __uint_as_float(prc.z) };
                             const bool ok = (pra.y == tag_old) & (pra.w == tag_old) & (prc.y == tag_old) & (prc.w == tag_old);
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                            if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            if (spins > slim) { ps_timeout(1u); break; }
                             __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                             pra = ps_ld128(rb, ro_old); prc = ps_ld128(rb, ro_old + 512u);
                         }
@@ -1146,7 +1171,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             }
                         }
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                        if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (spins > slim) { ps_timeout(1u); break; }
                         __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                     }
                 }
@@ -1221,7 +1246,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         m_s = has ? __uint_as_float(g.x) : -1.0e30f; l_s = has ? __uint_as_float(g.z) : 0.0f;
                         const bool ok = !has | ((g.y == tag_out) & (g.w == tag_out));
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                        if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (spins > slim) { ps_timeout(2u); break; }
                         __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                     }
                     float M = m_s;
@@ -1247,7 +1272,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             #pragma unroll
                             for (int u = 0; u < 8; ++u) ok &= (t[u].y == tag_out) & (t[u].w == tag_out);
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                            if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            if (spins > slim) { ps_timeout(2u); break; }
                             __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                         }
                         #pragma unroll
@@ -1280,7 +1305,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         bool ok = true;
                         ys = ps_slab_sum<PS_SLAB_NB>(rq, (uint32_t) blk * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok);
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                        if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (spins > slim) { ps_timeout(2u); break; }
                         __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                     }
                     if (sw == 0) PS_T(8);
@@ -1305,7 +1330,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         bool ok = true;
                         ps_slab_sum2<PS_SLAB2_NB>(rg, ru, (uint32_t) blk * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok, vg, vu);
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                        if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                        if (spins > slim) { ps_timeout(2u); break; }
                         __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                     }
                     if (sw == 0) PS_T(8);
@@ -1321,13 +1346,14 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             }
             c_inc(PS_C_T);                                                   // (release: this wave's quads are in LDS)
             PS_T(28 + sw);
+            if (slim != 0 && __hip_atomic_load(lctl + PS_C_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) slim = 0;      // (another wave of the workgroup timed out)
             if (op + 1 < nops)
             {
                 // the next op's rectangle and the cache lines of its descriptor, requested under the streaming (scalar-cache misses otherwise open the next op)
                 tl_next = ps_load_tile(a.tiles, (size_t) (op + 1) * ncu + cu);
                 const int PS_CONST* on = (const int PS_CONST*) (O + 1);
-                const int t0 = on[0], t1 = on[16], t2 = on[32], t3 = on[48];
-                asm volatile("" :: "s"(t0), "s"(t1), "s"(t2), "s"(t3));
+                const int t0 = on[0], t1 = on[16], t2 = on[32], t3 = on[48], t4 = on[64];
+                asm volatile("" :: "s"(t0), "s"(t1), "s"(t2), "s"(t3), "s"(t4));
             }
             if (sw == 0) PS_T(5);
 
@@ -1390,7 +1416,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     s2 = l32 < nblk ? __uint_as_float(g.x) : 0.0f;
                     const bool ok = (g.y == tag_in) & (g.w == tag_in);
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                    if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (spins > slim) { ps_timeout(1u); break; }
                     __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                 }
                 #pragma unroll
@@ -1402,6 +1428,14 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             // ---- the streaming waves' partial rows are in LDS: service half-wave shw finishes column blocks shw, shw + 8 of the rectangle
             c_spin(PS_C_S, (uint32_t) PS_SW * (uint32_t) (op + 1));
             if (sw == 0) PS_T(6);
+            // the lm_head poisons its logits if any wait of the launch has timed out by now: this workgroup's own flag, or the device's sticky error word (one load per step,
+            // requested here, consumed behind the output Hadamard)
+            uint32_t poison = 0u;                                            // OR-ed into the fp16 pairs of the logits: 0x7e00 | x is a NaN whatever x
+            if (out_type == PS_OUT_FINAL)
+            {
+                const uint32_t e = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                poison = (slim == 0 || __builtin_amdgcn_readfirstlane((int) e) != 0) ? 0x7e007e00u : 0u;
+            }
 #ifndef PS_SUM_HALFWAVES
             if (out_type != PS_OUT_FINAL)
             {
@@ -1544,6 +1578,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     const half4_t sc = j == shw ? scp[0] : scp[1];
                     half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
                     o = o * sc;
+                    { union { half4_t h; uint32_t u[2]; } ob; ob.h = o; ob.u[0] |= poison; ob.u[1] |= poison; o = ob.h; }      // (a wait timed out: NaN, never a plausible row)
                     ((half4_t PS_GLOBAL*) (logits_p + (size_t) cbl * 128))[l] = o;
                 }
             }
@@ -1580,7 +1615,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                                 ys.x += x.x; ys.y += x.y; ys.z += x.z; ys.w += x.w;
                             }
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                            if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            if (spins > slim) { ps_timeout(8u); break; }
                             __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                         }
                     }
@@ -1610,7 +1645,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             rold = float4_t{ __uint_as_float(ra.x), __uint_as_float(ra.z), __uint_as_float(rb.x), __uint_as_float(rb.z) };
                             const bool ok = (ra.y == tag_old) & (ra.w == tag_old) & (rb.y == tag_old) & (rb.w == tag_old);
                             if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                            if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            if (spins > slim) { ps_timeout(1u); break; }
                             __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                         }
                     }
@@ -1651,7 +1686,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     bool ok = true;
                     ys = ps_slab_sum<PS_SLAB_NB>(rk, (uint32_t) hb * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok);
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                    if (spins > a.spin_limit) { if (lane == 0) __hip_atomic_fetch_or(a.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                    if (spins > slim) { ps_timeout(2u); break; }
                     __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
                 }
                 const GemvRescale rs0 = { nullptr, nullptr, 0, 0.0f };
@@ -1674,7 +1709,25 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 kv_quant_regs<4>((float) y.x, (float) y.y, (float) y.z, (float) y.w, cw + gb * 4, csc + gb, (lane >> 5) == 1, lane);
             }
         }
-        if (cu == 0 && sw == 0 && lane == 0) *a.epoch = epoch + 1u;
+        if (cu == 0 && sw == 0)
+        {
+            if (lane == 0) *a.epoch = epoch + 1u;
+            if constexpr (ATT)
+            {
+                // the tags keep 20 bits of the run epoch.  Every line of the step is re-written in every run EXCEPT the attention records / statistics of splits that are
+                // not in use at the current length: left alone, one written 2^20 runs ago would carry the current tag again.  The run that wraps the 20 bits
+                // clears them (tag 0 = no producer): once per 2^20 runs, after this workgroup's last op -- nothing in the launch touches them behind o_proj of the last layer.
+                if (((epoch + 1u) & 0xfffffu) == 0u && nops >= 2)
+                {
+                    const PsAtt PS_CONST* const AT = (const PsAtt PS_CONST*) &ops_c[1].mat[1];
+                    const ps_rsrc_t rrec = ps_rsrc(AT->rec), rst = ps_rsrc(AT->stats);
+                    const uint4_t z = { 0u, 0u, 0u, 0u };
+                    const int n_st = AT->hq * PS_ATT_MAX_SPLITS, n_rec = AT->hq * AT->nsplit * 32;
+                    for (int i = lane; i < n_st; i += 64) ps_st128(rst, (uint32_t) i * 16u, z);
+                    for (int i = lane; i < n_rec; i += 64) ps_st128(rrec, (uint32_t) i * 16u, z);
+                }
+            }
+        }
     }
     #undef PS_T
 }

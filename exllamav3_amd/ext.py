@@ -1846,13 +1846,15 @@ class PersistentStep:
     tensors norm1, norm2, kcache = (words, scales), vcache = (words, scales).  mul1 codebook, 4-bit cache, hidden <= 4096 (exl3_pstep_create checks)."""
 
     def __init__(self, layers, head, final_norm, hidden: int, heads_q: int, heads_kv: int, head_dim: int, eps: float, rope_mode: int = 2, stamps: bool = False,
-                 attention: bool = False):
+                 attention: bool = False, repack: bool | None = None):
         """attention: the decode attention over the 4-bit paged cache runs INSIDE the step (o_proj's preparation: one (kv head, context split) item per CU, the partial
-        records merged by the consumers; libtorch/attention.cpp:246-504 at q_len 1) -- run() then needs block_table / cache_seqlens.  head_dim 128."""
+        records merged by the consumers; libtorch/attention.cpp:246-504 at q_len 1) -- run() then needs block_table / cache_seqlens.  head_dim 128.
+        repack: None (default) / True = the plan copies every op's packed words once into the order its streaming waves read them (a second copy of the weights owned by
+        the plan: one contiguous run per wave; SURVEY 8(f)4's legal load-time transform); False = stream the caller's checkpoint-layout tensors as they are."""
         def lin(l):
             t = l.trellis
             _req(t.dim() == 3 and l.suh is not None and l.svh is not None, "PersistentStep: EXL3 linears with suh / svh")
-            return _lib.PstepLinear(_p(t), _p(l.suh), _p(l.svh), t.shape[0] * 16, t.shape[1] * 16)
+            return _lib.PstepLinear(_p(t), _p(l.suh), _p(l.svh), t.shape[0] * 16, t.shape[1] * 16, t.shape[-1] // 16, 1 if l.mcg else (2 if l.mul1 else 0))
         K = layers[0]["q"].trellis.shape[-1] // 16
         arr = (_lib.PstepLayer * len(layers))()
         for i, L in enumerate(layers):
@@ -1869,7 +1871,8 @@ class PersistentStep:
         self._h = ctypes.c_void_p(None)
         self._keep = (layers, head, final_norm)          # the plan holds raw pointers
         _check(_lib.lib().exl3_pstep_create(ctypes.byref(self._h), arr, len(layers), ctypes.byref(hl), _p(final_norm), int(hidden), int(heads_q), int(heads_kv),
-                                            int(head_dim), int(K), 2, float(eps), int(rope_mode), (1 if stamps else 0) | (4 if attention else 0) | ((KH << 8) if KH != K else 0)))
+                                            int(head_dim), int(K), 2, float(eps), int(rope_mode),
+                                            (1 if stamps else 0) | (4 if attention else 0) | ((KH << 8) if KH != K else 0) | (16 if repack is False else 0)))
         self.n_layers = len(layers)
         self.attention = bool(attention)
         self.head_dim = int(head_dim)
@@ -1891,6 +1894,23 @@ class PersistentStep:
     def error(self) -> bool:
         """Synchronises; True if an edge / tagged line ever timed out since the last query (results invalid)."""
         return bool(_check(_lib.lib().exl3_pstep_error(self._h, torch.cuda.current_stream().cuda_stream)))
+
+    def error_peek(self) -> bool:
+        """No synchronisation: True once the kernel has reported a timed-out wait to the pinned host word (some EARLIER step wrote NaN logits); error() confirms and clears."""
+        return bool(_check(_lib.lib().exl3_pstep_error_peek(self._h)))
+
+    def attn_geometry(self, length: int):
+        """(context splits in use, tokens per split, 128-token steps per split) of the attention inside the step at a sequence length (incl. the new token)."""
+        out = (ctypes.c_int * 3)()
+        _check(_lib.lib().exl3_pstep_attn_geometry(self._h, int(length), out))
+        return int(out[0]), int(out[1]), int(out[2])
+
+    def unpack_op(self, op: int, mat: int, like: torch.Tensor) -> torch.Tensor:
+        """The plan's repacked words of matrix `mat` of op `op` (4 * layer + {0 q|k|v, 1 o, 2 gate|up, 3 down}; last op = lm_head) copied back into a checkpoint-layout
+        tensor shaped like `like` (the original trellis): equal to it bit for bit if the load-time permutation is one."""
+        out = torch.zeros_like(like)
+        _check(_lib.lib().exl3_pstep_unpack_op(self._h, int(op), int(mat), _p(out), _stream(like)))
+        return out
 
     def set(self, decode_ahead_units: int = -1, spin_limit: int = 0):
         _check(_lib.lib().exl3_pstep_set(self._h, int(decode_ahead_units), int(spin_limit)))

@@ -178,20 +178,32 @@ class SyntheticEXL3Llama:
     PIN_VOCAB, PIN_POS, PIN_SEED = 2048, 700, 20260925
 
     @classmethod
-    def pin_model(cls, shape_name: str, K: int, cb: int, device, bsz: int = 1) -> "SyntheticEXL3Llama":
+    def pin_model(cls, shape_name: str, K: int, cb: int, device, bsz: int = 1, ctx: int | None = None) -> "SyntheticEXL3Llama":
         """ONE layer of the named shape + a 2048-column lm_head, every tensor and the input rows drawn on the host from a fixed PCG64 seed (the same
         bits on every machine), state allocated at position 700.  tests/golden/make_bench_pins.py runs the ORACLE over exactly this model on the CPU and
         commits its logits (tests/golden/bench_pins.json; tests/test_bench_pins.py re-derives them from the oracle); bench.py runs its timed pipeline over
         it on the GPU and compares -- the check behind the headline number that `isfinite(logits)` used to stand in for (VERDICT r3 weak #1 d)."""
         base = SHAPES[shape_name]
         shape = LlamaShape(base.name + "-pin", base.hidden, base.inter, 1, base.heads_q, base.heads_kv, base.head_dim, cls.PIN_VOCAB, base.rope_theta)
-        model = cls(shape, K=K, cb=cb, device=device, kv_bits=4, max_ctx=1024, host_seed=cls.PIN_SEED + 131 * K + cb)
-        model.alloc_state(bsz, pos=cls.PIN_POS)
+        if ctx is None:
+            model = cls(shape, K=K, cb=cb, device=device, kv_bits=4, max_ctx=1024, host_seed=cls.PIN_SEED + 131 * K + cb)
+            model.alloc_state(bsz, pos=cls.PIN_POS)
+            return model
+        # ... WITH the decode attention (round 6: the gate of bench.py's ..._with_attention_ctx* lines): the new token at position ctx behind a pre-filled 4-bit cache whose
+        # words and group scales are drawn from the same host stream (uniform levels, scales in [0.05, 0.55)): the cache IS the data, no quantizer involved
+        import numpy as np
+        model = cls(shape, K=K, cb=cb, device=device, kv_bits=4, max_ctx=(ctx + 1 + 255) // 256 * 256, host_seed=cls.PIN_SEED + 131 * K + cb + 7919 * ctx)
+        model.alloc_state(bsz, pos=ctx)
+        model.with_attention = True
+        rng = model._host_rng
+        for c, s_ in model.kcache + model.vcache:
+            c.copy_(torch.from_numpy(rng.integers(0, 2 ** 32, size=tuple(c.shape), dtype=np.uint32).view(np.int32)).to(c.device))
+            s_.copy_(torch.from_numpy((rng.random(tuple(s_.shape)) * 0.5 + 0.05).astype(np.float16)).to(s_.device))
         return model
 
     @staticmethod
-    def pin_key(shape_name: str, K: int, cb: int, bsz: int) -> str:
-        return f"{shape_name}:K{K}:cb{cb}:bs{bsz}"
+    def pin_key(shape_name: str, K: int, cb: int, bsz: int, ctx: int | None = None) -> str:
+        return f"{shape_name}:K{K}:cb{cb}:bs{bsz}" + (f":ctx{ctx}" if ctx is not None else "")
 
     # ---- checkpoints ----------------------------------------------------------------
     _HF = {"q": "self_attn.q_proj", "k": "self_attn.k_proj", "v": "self_attn.v_proj", "o": "self_attn.o_proj",
@@ -806,10 +818,28 @@ class SyntheticEXL3Llama:
         att = bool(self.with_attention)
         if getattr(self, "_pstep", None) is None or getattr(self, "_pstep_att", None) != att:
             layers = [dict(L, kcache=self.kcache[i], vcache=self.vcache[i]) for i, L in enumerate(self.layers)]
-            self._pstep = ext.PersistentStep(layers, self.lm_head, self.final_norm, self.shape.hidden, self.hq, self.hkv, hd, self.eps, rope_mode=2,
-                                             stamps=bool(os.environ.get("EXL3_HIP_PSTEP_STAMPS")), attention=att)
+            try:
+                self._pstep = ext.PersistentStep(layers, self.lm_head, self.final_norm, self.shape.hidden, self.hq, self.hkv, hd, self.eps, rope_mode=2,
+                                                 stamps=bool(os.environ.get("EXL3_HIP_PSTEP_STAMPS")), attention=att)
+            except RuntimeError as e:
+                # the planner / the device refused (no plan for this shape on this chip, the kernel does not fit a CU, out of memory for the repacked copy): the
+                # launch-per-op pipeline computes the same step (persistent_applies() does not mirror every constraint of exl3_pstep_create)
+                import warnings
+                warnings.warn(f"exllamav3_amd: no persistent decode step for this model ({e}); using the launch-per-op pipeline", RuntimeWarning)
+                self.persistent = False
+                self._pstep = None
+                return self.decode_step_fx()
             self._pstep_att = att
             self._pstep_checked = False
+        elif self._pstep.error_peek() and not torch.cuda.is_current_stream_capturing():
+            # some earlier (possibly graph-replayed) step reported a timed-out wait to the pinned host word -- its logits were NaN; no synchronisation was needed to see it
+            import warnings
+            if self._pstep.error():
+                warnings.warn("exllamav3_amd: the persistent decode step timed out (its logits were NaN-poisoned); using the launch-per-op pipeline from here on", RuntimeWarning)
+                type(self).persistent = False
+                self.persistent = False
+                self._pstep = None
+                return self.decode_step_fx()
         ext.fx_init_prep(self.x0, self.R, self.ss, 1, self.inv_freq, self.positions, hd, self.block_table, self.page, self.rope_sin, self.rope_cos, self.kv_slots)
         if att:
             self._pstep.run(self.R, self.logits, self.q, self.rope_sin, self.rope_cos, self.kv_slots, self.block_table, self.attn_lens, self.page)

@@ -42,7 +42,7 @@ extern "C" {
 #define EXL3_ERR_HIP  (-2)   /* HIP runtime error (reference: cuda_check, util.cuh:92-100)         */
 #define EXL3_ERR_INIT (-3)   /* per-device context missing while the stream is capturing           */
 
-#define EXL3_ABI_VERSION 3   /* bumped whenever an exported symbol is removed or changes meaning (round 3: 3) */
+#define EXL3_ABI_VERSION 4   /* bumped whenever an exported symbol is removed or changes meaning (round 3: 3; round 6: 4 -- exl3_pstep_linear_t carries K and codebook) */
 
 const char* exl3_last_error(void);
 int  exl3_abi_version(void);
@@ -625,10 +625,24 @@ int exl3_ar_reduce_slabs(void* ctx, const float* y, const float* slabs, int S, c
  *                       also produce rope_sin / rope_cos / slots); logits fp16 [vocab]; q_out optional fp16 [heads_q * head_dim].  Graph-capturable.
  *   exl3_pstep_run_attn the step of a plan created with flags bit 2: block_table int32 [blocks_per_seq] and cache_seqlens int32 [1] (length INCLUDING the new token)
  *                       of the one sequence, page size (a multiple of 16), softmax scale.  Graph-capturable (the length is read on the device).
+ *                       bit 4 = stream the checkpoint's tile-row-major tensors as they are (default: exl3_pstep_create copies every op's packed words ONCE into the
+ *                       order the plan's workgroups and streaming waves read them -- one contiguous run per wave instead of 1 KiB row pieces at a stride of
+ *                       n / 16 x 16 K bytes; SURVEY 8(f)4: a legal load-time transform; the plan then owns a second copy of the weights, the caller's tensors
+ *                       are not read by the step any more.  env EXL3_HIP_PSTEP_REPACK=0 | 1 overrides).
+ *                       At create the kernel's occupancy is checked (the step needs one co-resident workgroup per CU): EXL3_ERR_ARG if it does not fit.
  *   exl3_pstep_set      decode-ahead units 0..3 (-1: keep; default 3), spin limit of the bounded waits (0: keep).
- *   exl3_pstep_error    synchronises the stream; 1 if a wait ever timed out (results invalid), else 0.
+ *   exl3_pstep_error    synchronises the stream; 1 if a wait ever timed out (results invalid: the step wrote NaN logits), else 0; clears the flag.
+ *   exl3_pstep_error_peek  the same flag WITHOUT a synchronisation (a pinned host word the kernel sets when a wait times out): what a caller that replays a captured
+ *                       step checks between replays; does not clear.
+ *   exl3_pstep_attn_geometry  (plans with the attention inside) out3 = { context splits in use, tokens per split, 128-token steps per split } at sequence length len
+ *                       (the kernel derives the same on the device from cache_seqlens).
+ *   exl3_pstep_unpack_op  the inverse of the load-time repack: matrix `mat` of op `op` (op = 4 layer + {0 q|k|v, 1 o, 2 gate|up, 3 down}, last = lm_head) copied from
+ *                       the plan's order back into a checkpoint-layout tensor [k / 16][n / 16][16 K] -- equality with the original proves the permutation.
  *   exl3_pstep_stamps   copies the phase stamps of the last run ([nops][ncu][32] x u64, 100 MHz) to host memory; returns nops * ncu * 32. */
-typedef struct { const void* trellis; const void* suh; const void* svh; int k, n; } exl3_pstep_linear_t;
+/* K: bits per weight of this tensor, cb: its codebook (0 3INST, 1 mcg, 2 mul1: exllamav3_ext/quant/codebook.cuh:56-90).  K = 0: the create call's K and cb.
+ * The tensors of one fused linear (q / k / v; gate / up) share K and cb -- a reference qgroup (modules/attn.py:244-308, modules/mlp.py:537-574) is quantized as one;
+ * different fused linears may differ by one bit (fractional-bpw checkpoints: conversion/allocation.py:131-141 bumps whole qgroups). */
+typedef struct { const void* trellis; const void* suh; const void* svh; int k, n; int K, cb; } exl3_pstep_linear_t;
 typedef struct
 {
     exl3_pstep_linear_t q, k, v, o, gate, up, down;
@@ -644,6 +658,9 @@ int exl3_pstep_run(void* handle, void* R, void* logits, void* q_out, const float
 int exl3_pstep_run_attn(void* handle, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots,
                         const int32_t* block_table, const int32_t* cache_seqlens, int blocks_per_seq, int page_size, float scale, void* stream);
 int exl3_pstep_error(void* handle, void* stream);
+int exl3_pstep_error_peek(void* handle);
+int exl3_pstep_attn_geometry(void* handle, int len, int* out3);
+int exl3_pstep_unpack_op(void* handle, int op, int mat, void* trellis_out, void* stream);
 int exl3_pstep_set(void* handle, int decode_ahead_units, int spin_limit);
 int exl3_pstep_describe(void* handle, char* buf, int buf_bytes);
 int64_t exl3_pstep_stamps(void* handle, uint64_t* host_out, int64_t max_words, void* stream);

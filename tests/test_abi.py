@@ -13,7 +13,7 @@ def test_library_exports_every_declared_symbol():
         __graft_entry__.build(verbose=False)
     syms = _lib.check_symbols()
     assert len(syms) >= 20
-    assert _lib.lib().exl3_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib().exl3_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_argument_errors_are_reported_without_gpu():

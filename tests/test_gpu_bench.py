@@ -71,6 +71,19 @@ def test_bench_pinned_logits_gate(dev, name, K, cb, bsz, pipeline):
     assert r["pinned"] and r["ok"] and r["graph_replay_bit_equal"] and r["rel_err_vs_oracle"] < 3e-2
 
 
+@pytest.mark.parametrize("name,ctx,pipeline", [("llama-3.1-8b", 1000, "persistent"), ("llama-3.1-8b", 16000, "persistent"), ("llama-3.2-1b", 1000, "persistent"),
+                                               ("llama-3.1-8b", 1000, "fx"), ("llama-3.1-8b", 16000, "fx"), ("llama-3.2-1b", 1000, "fx")])
+def test_bench_pinned_logits_gate_with_attention(dev, name, ctx, pipeline):
+    """The gate of bench.py's ..._with_attention_ctx* lines (round 6: they carried `edge_timeout: false` only): the timed step with the decode attention over a host-seeded
+    pre-filled 4-bit cache reproduces the oracle's committed logits; at 16 000 tokens the persistent step's context splits take several 128-token steps."""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.pinned_logits_check(name, 4, 2, 1, dev, pipeline, ctx=ctx)
+    assert r["pinned"] and r["ok"] and r["graph_replay_bit_equal"] and r["rel_err_vs_oracle"] < 3e-2
+    if pipeline == "persistent" and ctx == 16000:
+        assert r["attention_splits_tokens_steps"][2] > 1
+
+
 def test_bench_pinned_logits_gate_catches_a_wrong_pipeline(dev, monkeypatch):
     """The gate fails when the step is wrong: with the norm weights of the pin model perturbed after construction the assertion fires."""
     sys.path.insert(0, ROOT)
