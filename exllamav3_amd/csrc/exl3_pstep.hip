@@ -79,9 +79,47 @@ bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_t
     return found;
 }
 
+// How the twelve streaming waves share a rectangle of T = 4 nb x ncb work units (H = 4 nb per column).  A SIMD hosts waves w, w + 4, w + 8 and arbitrates oldest-first: the
+// age groups A (0-3) / B (4-7) / C (8-11) stream at ~ 1.05 / 0.89 / 0.44 units per us while all three run (per-unit stamps of an 8B gate|up op: profiles/r06_*), so equal runs
+// leave the youngest wave streaming alone, latency-bound, for the last third of the phase.  Every wave decodes `pre` units ahead while the op's input is on its way (those cost
+// no time behind the input); the REST of the SIMD's share is cut in the ratio of the groups' rates (permille fA : fB : 1000 - fA - fB).  out[g] = n_g << 2 | e_g: the four waves
+// of group g take n_g units, the first e_g of them one more.  All zero = the uniform partition [T w / 12, T (w + 1) / 12): rectangles whose units are all decoded ahead, runs
+// that would be longer than a column (a wave keeps two partial rows: its run may cross ONE column boundary), and the lm_head (its finish still uses the closed formulas).
+void wave_partition(int T, int H, int pre, int fA, int fB, int* out)
+{
+    out[0] = out[1] = out[2] = 0;
+    if (fA <= 0 || fB <= 0 || fA + fB >= 1000 || T <= 12 * pre) return;
+    const double rest = (double) T / 4.0 - 3.0 * pre;                        // units per SIMD streamed behind the input
+    int G[3];
+    G[0] = (int) (4.0 * (pre + rest * fA / 1000.0) + 0.5);
+    G[1] = (int) (4.0 * (pre + rest * fB / 1000.0) + 0.5);
+    G[2] = T - G[0] - G[1];
+    if (G[2] < 4 * pre || G[0] < G[1] || G[1] < G[2]) return;
+    for (int g = 0; g < 3; ++g) if ((G[g] + 3) / 4 > H) return;             // (a run longer than a column would cross two boundaries)
+    // the finish reads the partial rows of a column from at most EIGHT consecutive waves (exl3_pstep_kernel.cuh: col_table): check every column of this cut
+    {
+        int u0[12], u1[12], b = 0;
+        for (int g = 0; g < 3; ++g) { const int n = G[g] / 4, e = G[g] % 4; for (int i = 0; i < 4; ++i) { u0[4 * g + i] = b + i * n + (i < e ? i : e); u1[4 * g + i] = u0[4 * g + i] + n + (i < e ? 1 : 0); } b += G[g]; }
+        for (int j = 0; j * H < T; ++j)
+        {
+            int first = -1, last = -1;
+            for (int w = 0; w < 12; ++w) if (u1[w] > u0[w] && u0[w] < (j + 1) * H && u1[w] > j * H) { if (first < 0) first = w; last = w; }
+            if (first >= 0 && last - first >= 8) return;
+        }
+    }
+    for (int g = 0; g < 3; ++g) out[g] = ((G[g] / 4) << 2) | (G[g] % 4);
+}
+
+// the shares of the age groups (permille of the units streamed behind the input): EXL3_HIP_PSTEP_SHARES="fA,fB" overrides ("0,0": uniform partition everywhere)
+void wave_shares(int& fA, int& fB)
+{
+    fA = 460; fB = 370;                    // (same-box sweep on MI355X, Llama-3.1-8B: profiles/r06_pstep_wave_shares_ab.txt)
+    if (const char* e = getenv("EXL3_HIP_PSTEP_SHARES")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2) { fA = a; fB = b; } }
+}
+
 // the rectangles of one op: workgroup (column group gi, slice s) = gi * S + s; every (column block, Hadamard block) of the op lies in exactly one
 // rectangle (tests/test_pstep_plan.py checks the partition on the CPU through exl3_pstep_plan_tiles)
-void fill_tiles(PsTile* T, int ncu, const OpPlan& p, const int* ncb, int nmat, int nblk, int side_tasks)
+void fill_tiles(PsTile* T, int ncu, const OpPlan& p, const int* ncb, int nmat, int nblk, int side_tasks, bool weighted = true)
 {
     for (int c = 0; c < ncu; ++c) { T[c].mat = -1; T[c].cb0 = 0; T[c].ncb = 0; T[c].b0 = 0; T[c].nb = 0; T[c].slice = 0; T[c].side = -1; T[c].flags = 0; T[c].ubase = 0; T[c].r0_ = T[c].r1_ = T[c].r2_ = 0; }
     int gi = 0;
@@ -102,6 +140,13 @@ void fill_tiles(PsTile* T, int ncu, const OpPlan& p, const int* ncb, int nmat, i
     // first work unit (2 tile rows x 128 columns) of every rectangle in the op's repacked weights: rectangles in workgroup order, 4 nb x ncb units each
     int ub = 0;
     for (int c = 0; c < ncu; ++c) { T[c].ubase = ub; if (T[c].mat >= 0) ub += 4 * T[c].nb * T[c].ncb; }
+    // the streaming waves' shares of every rectangle (wave_partition)
+    int fA, fB; wave_shares(fA, fB);
+    for (int c = 0; c < ncu; ++c) if (weighted && T[c].mat >= 0)
+    {
+        int o3[3]; wave_partition(4 * T[c].nb * T[c].ncb, 4 * T[c].nb, 3, fA, fB, o3);
+        T[c].r0_ = o3[0]; T[c].r1_ = o3[1]; T[c].r2_ = o3[2];
+    }
 }
 
 void lin_to_mat(const exl3_pstep_linear_t& l, PsMat& m)
@@ -343,7 +388,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
         lin_to_mat(*head, O.mat[0]);
         const int ncb[1] = { head->n / 128 };
         OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for the lm_head (vocab / 128 <= 16 x CUs)");
-        O.S = p.S; add_tiles(op, p, ncb, 1, hidden / 128, 0);
+        O.S = p.S; fill_tiles(tiles.data() + (size_t) op * ncu, ncu, p, ncb, 1, hidden / 128, 0, false);      // (the head's finish uses the uniform partition's closed formulas)
         snprintf(line, sizeof(line), "head: S=%d groups=%d tile<=%dx%d; residual edges: %s%s", p.S, p.g[0], p.wmax, p.hmax, direct ? "direct (consumer gathers)" : "owners", attn ? "; attention inside o_proj's preparation" : ""); desc += line;
         if (attn) { snprintf(line, sizeof(line), " (%d kv blocks x %d splits)", att_blocks, att_nsplit); desc += line; }
         ++op;
@@ -354,6 +399,9 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     h->d_att_rec = nullptr; h->d_att_stats = nullptr; h->attn = attn ? 1 : 0; h->d_repack = nullptr; h->repack_words = 0; h->h_err = nullptr;
     h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr; h->d_slab_c = nullptr; h->d_slab_d = nullptr; h->d_rbuf = nullptr; h->d_epoch = nullptr;
     h->cnt_bytes = (size_t) nops * 8 * 16 * 4; h->dbg_words = (flags & 1) ? (size_t) nops * ncu * PS_DBG_SLOTS : 0;
+#ifdef PS_DBG_UNITS
+    if (flags & 1) h->dbg_words = (size_t) (nops + 3) * ncu * PS_DBG_SLOTS;        // (diagnostic build: three more areas for the per-unit stamps of one SIMD's streaming waves)
+#endif
     #define PS_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { exl3_set_error("exl3_pstep_create: %s", hipGetErrorString(e_)); exl3_pstep_destroy(h); return EXL3_ERR_HIP; } } while (0)
     // (the q|k|v slab lines: TWO sets, alternating by layer -- without the attention inside, the K / V append side job of layer i reads the k / v lines after its workgroup
     //  has published o_proj's partial rows, and with direct row edges nothing orders that read against layer i + 1's q|k|v writers: they now write the other set)
@@ -449,7 +497,8 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
 }
 
 // The planner alone (no device): the rectangles of one op kind of a Llama block for a chip of `ncu` CUs.  op_kind: 0 q|k|v, 1 o_proj, 2 gate|up, 3 down,
-// 4 lm_head.  tiles_out: [ncu][8] = {mat, cb0, ncb, b0, nb, slice, side, flags} (PsTile); S_out: its k-slices.  Host logic only: callable on a box without a GPU.
+// 4 lm_head.  tiles_out: [ncu][12] = {mat, cb0, ncb, b0, nb, slice, side, flags, ubase, pA, pB, pC} (PsTile; pX = n << 2 | e: the streaming waves' shares by age
+// group, all zero = uniform: wave_partition); S_out: its k-slices.  Host logic only: callable on a box without a GPU.
 extern "C" int exl3_pstep_plan_tiles(int hidden, int inter, int heads_q, int heads_kv, int head_dim, int vocab, int ncu, int op_kind, int32_t* tiles_out, int* S_out)
 {
     EXL3_CHECK_ARG(tiles_out && S_out && ncu >= 16 && ncu <= 1024 && hidden % 128 == 0 && inter % 128 == 0 && vocab % 128 == 0 && (head_dim == 64 || head_dim == 128),
@@ -478,8 +527,8 @@ extern "C" int exl3_pstep_plan_tiles(int hidden, int inter, int heads_q, int hea
     }
     EXL3_CHECK_ARG(plan_op(ncu, nblk, ncb, nmat, in_type, out_type, p, direct), "exl3_pstep_plan_tiles: no plan for this op on %d CUs", ncu);
     std::vector<PsTile> T((size_t) ncu);
-    fill_tiles(T.data(), ncu, p, ncb, nmat, nblk, side);
-    for (int c = 0; c < ncu; ++c) memcpy(tiles_out + (size_t) c * 8, &T[(size_t) c], 8 * sizeof(int32_t));      // (the first eight fields; ubase follows from them)
+    fill_tiles(T.data(), ncu, p, ncb, nmat, nblk, side, op_kind != 4);
+    memcpy(tiles_out, T.data(), (size_t) ncu * sizeof(PsTile));
     *S_out = p.S;
     return EXL3_OK;
 }

@@ -40,7 +40,7 @@ __device__ __forceinline__ PsTile ps_load_tile(const PsTile* tiles, size_t idx)
 {
     const int PS_CONST* t = (const int PS_CONST*) (tiles + idx);
     PsTile r; r.mat = t[0]; r.cb0 = t[1]; r.ncb = t[2]; r.b0 = t[3]; r.nb = t[4]; r.slice = t[5]; r.side = t[6]; r.flags = t[7]; r.ubase = t[8];
-    r.r0_ = 0; r.r1_ = 0; r.r2_ = 0;
+    r.r0_ = t[9]; r.r1_ = t[10]; r.r2_ = t[11];
     return r;
 }
 template <int K>
@@ -289,6 +289,37 @@ __device__ __forceinline__ void ps_consume(const half4_t (&dec)[16], half4_t ag,
 #define PS_C_O 6                       // + PS_NSV per op whose blocks this workgroup owns: the service half-waves' gathered sums are in LDS
 #define PS_C_ABORT 9                   // != 0 once a bounded wait of this workgroup timed out (the service waves then give up every later wait after one poll)
 
+// Issue priority of the streaming waves.  A SIMD arbitrates its ready waves oldest-first: of the three streaming waves it hosts (w, w + 4, w + 8) the oldest streams at its
+// own latency-bound pace and the youngest gets what is left -- by the phase stamps of an 8B gate|up op the waves 0-3 were done 6.3 us after the quads, the waves 8-11 after
+// 12.8 us, with the SIMD half idle behind a single wave for the last third.  PS_PRIO_ROT: every wave walks its priority 0 -> 1 -> 2 -> 0 per work unit (offset by its
+// group): over a run every wave spends the same number of units at every level.  PS_PRIO_INV (diagnostic): static 0 / 1 / 2 for the groups, youngest highest.
+__device__ __forceinline__ void ps_prio_rot(int n)
+{
+#ifdef PS_PRIO_ROT
+    const int r = n % 3;
+    if (r == 0) __builtin_amdgcn_s_setprio(0); else if (r == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+#endif
+}
+
+// The run of work units [u0, u1) streaming wave w takes of a rectangle of T units.  UNIFORM (the tile's r0_ = r1_ = r2_ = 0): [T w / 12, T (w + 1) / 12).  WEIGHTED (round 6):
+// a SIMD arbitrates its ready waves oldest-first, so of the three streaming waves it hosts (w, w + 4, w + 8) the oldest streams at its own memory-latency-bound pace
+// (~ 0.95 us per unit by the per-unit stamps of an 8B gate|up op), the second nearly so (1.1) and the youngest gets the issue slots that are left (2.4-2.9) -- with equal
+// runs the two older waves were done 7.4 / 8.5 us after the activations arrived and the youngest then streamed its last third ALONE, latency-bound, until 13.6 us.  The
+// planner therefore cuts the rectangle by AGE GROUP: waves 0-3 / 4-7 / 8-11 take n_A >= n_B >= n_C units each (r0_ / r1_ / r2_ = n_g << 2 | e_g: the first e_g waves of
+// the group take one more), chosen so that the three finish together (exl3_pstep.hip: wave_partition).  Everything here is wave-uniform (scalar arithmetic).
+struct PsRange { int u0, u1; };
+__device__ __forceinline__ PsRange ps_wave_range(const PsTile& t, int T, int w)
+{
+    PsRange r;
+    if ((t.r0_ | t.r1_ | t.r2_) == 0) { r.u0 = (T * w) / PS_SW; r.u1 = (T * (w + 1)) / PS_SW; return r; }
+    const int g = w >> 2, i = w & 3;
+    const int GA = 4 * (t.r0_ >> 2) + (t.r0_ & 3), GB = 4 * (t.r1_ >> 2) + (t.r1_ & 3);
+    const int pg = g == 0 ? t.r0_ : (g == 1 ? t.r1_ : t.r2_), base = g == 0 ? 0 : (g == 1 ? GA : GA + GB);
+    const int n = pg >> 2, e = pg & 3;
+    r.u0 = base + i * n + min(i, e); r.u1 = r.u0 + n + (i < e ? 1 : 0);
+    return r;
+}
+
 // a streaming wave's run of work units inside its workgroup's rectangle: column-major over (column block j, unit i); at most two column blocks (planner: ncb <= PS_SW)
 template <int K>
 struct PsSeg
@@ -297,6 +328,9 @@ struct PsSeg
     int j0, i0, len0, len1, n;
     __device__ __forceinline__ const uint32_t* unit_ptr(int q) const       // 0 <= q < n
     {
+#ifdef PS_ABL_HOT
+        return stripA;
+#endif
         return q < len0 ? stripA + (size_t) (2 * q) * rs : stripB + (size_t) (2 * (q - len0)) * rs;
     }
 };
@@ -314,7 +348,8 @@ __device__ __forceinline__ PsSeg<K> ps_make_seg(ps_op_p O, const PsTile& t, int 
         // experiment: only 8 of the 12 streaming waves take units (does the streaming phase scale with the number of streaming waves?)
         const int u0 = wave < 8 ? (T * wave) / 8 : T, u1 = wave < 8 ? (T * (wave + 1)) / 8 : T;
 #else
-        const int u0 = (T * wave) / PS_SW, u1 = (T * (wave + 1)) / PS_SW;
+        const PsRange rg = ps_wave_range(t, T, wave);
+        const int u0 = rg.u0, u1 = rg.u1;
 #endif
         s.n = u1 - u0;
         s.j0 = u0 / H; s.i0 = u0 - s.j0 * H;
@@ -327,6 +362,10 @@ __device__ __forceinline__ PsSeg<K> ps_make_seg(ps_op_p O, const PsTile& t, int 
             s.rs = (size_t) 8 * NW;
             s.stripA = Bp + (size_t) (t.ubase + u0) * (16 * NW);
             s.stripB = s.stripA + (size_t) s.len0 * (16 * NW);
+#ifdef PS_ABL_HOT
+            // speed-only ablation (results are garbage): every unit of the rectangle reads the SAME 2 tile rows per wave -- the weight stream without HBM behind it
+            s.stripA = Bp + (size_t) (t.ubase + wave) * (16 * NW); s.stripB = s.stripA;
+#endif
         }
         else
         {
@@ -364,6 +403,8 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
     // wave w has finished its run, slot 28 + s: service wave s has published its quads
     // (tools/pstep_stamps.py names them)
     #define PS_T(i) do { if (dbg && lane == 0) dbg[((size_t) op * ncu + cu) * PS_DBG_SLOTS + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    // (slots 13 / 14: the SHADER clock counter (s_memtime) at stamps 1 / 2 of streaming wave 0 -- (14 - 13) / (2 - 1) = the core clock during the op's streaming phase)
+    #define PS_TC(i) do { if (dbg && lane == 0) dbg[((size_t) op * ncu + cu) * PS_DBG_SLOTS + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 
     if (tid < 16) lctl[tid] = 0u;
     const uint32_t epoch = (uint32_t) __builtin_amdgcn_readfirstlane((int) *a.epoch);      // bumped by workgroup 0 when it leaves: every replay tags afresh
@@ -523,6 +564,9 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                                                            // ring are what pushed the mixed instantiations into scratch, and one unit of ~ 26 per wave is nothing there)
         const int quad_lane = (lane >> 2) * 8, lofs = lane * KK;
         const int pmax = min(a.pmax, PMC);
+#ifdef PS_PRIO_INV
+        if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1); else if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(2);
+#endif
         LaneWords<KK> ring[2];
         #pragma unroll
         for (int i = 0; i < KK; ++i) { ring[0].w[i] = 0u; ring[1].w[i] = 0u; }
@@ -563,6 +607,13 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             half4_t dec0[16], dec1[16];
             #pragma unroll
             for (int i = 0; i < 16; ++i) { dec0[i] = half4_t{ 0, 0, 0, 0 }; dec1[i] = dec0[i]; }
+#ifdef PS_DBG_UNITS
+            int dbg_u = 0;
+            #define PS_TP() do { if (dbg && op == PS_DBG_UNITS && (wave & 3) == 0 && lane == 0 && dbg_u < PS_DBG_SLOTS) dbg[((size_t) (nops + (wave >> 2)) * ncu + cu) * PS_DBG_SLOTS + dbg_u++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+            #define PS_TP() do { } while (0)
+#endif
+            PS_TP();                                       // [0] op start
             // ---- decode-ahead while the service waves have not published the op's activation quads
             const uint32_t tgt_t = (uint32_t) PS_NSV * (uint32_t) (op + 1);
             int P = 0;
@@ -576,12 +627,15 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 const int Pm = min(pmax, cur.len0);
                 if (Pm >= 1 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
                 {
+                    PS_TP();                               // [1] first rows there? (the predecode waits for them)
                     ps_predecode<KK>(ring, cur.unit_ptr(min(1, cur.n - 1)), cur.rs, lane, lofs, dec0);
                     P = 1;
+                    PS_TP();
                     if (Pm >= 2 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
                     {
                         ps_predecode_lds<KK>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, pdec_w);
                         P = 2;
+                        PS_TP();
                         // a THIRD unit, in registers again (Llama-3.2-1B's gate|up rectangle is 32 units = 2.67 per wave: with two units ahead eight waves streamed one
                         // more after the quads were there -- 1.5 us of decode on the critical path of every layer)
                         if constexpr (PMC >= 3)
@@ -590,13 +644,15 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             {
                                 ps_predecode<KK>(ring, cur.unit_ptr(min(3, cur.n - 1)), cur.rs, lane, lofs, dec1);
                                 P = 3;
+                                PS_TP();
                             }
                         }
                     }
                 }
             }
             c_wait(PS_C_T, tgt_t);
-            if (wave == 0) PS_T(1);
+            PS_TP();                                       // quads seen
+            if (wave == 0) { PS_T(1); PS_TC(13); }
 
             // ---- this wave's run of work units: decode-ahead units first (MFMA only), the rest streamed
             auto run_seg = [&] (const uint32_t* strip, int len, int pre, const uint32_t* after, size_t aft_rs, int qoff, float* pslot)
@@ -604,13 +660,25 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 float4_t acc_c = { 0.f, 0.f, 0.f, 0.f }, acc_d = acc_c;
                 const char* qb = quads + qoff + quad_lane;
                 const size_t rs = cur.rs;
+#ifdef PS_ABL_HOT
+                auto up = [&] (int q) -> const uint32_t* { return q < len ? strip : after; };
+#else
                 auto up = [&] (int q) -> const uint32_t* { return q < len ? strip + (size_t) (2 * q) * rs : after; };
+#endif
                 auto ur = [&] (int q) -> size_t { return q < len ? rs : aft_rs; };          // the refill target may lie in the NEXT op's matrix (another row pitch)
                 int p = 0;
+#ifdef PS_DBG_UNITS
+                // diagnostic build: streaming waves 0 / 4 / 8 (one SIMD's three) stamp the start of every work unit of op PS_DBG_UNITS into three extra stamp areas behind
+                // the ops' (exl3_pstep.hip allocates them in this build): tools/pstep_unit_timeline.py
+                #define PS_TU() do { if (dbg && op == PS_DBG_UNITS && (wave & 3) == 0 && lane == 0 && dbg_u < PS_DBG_SLOTS) dbg[((size_t) (nops + (wave >> 2)) * ncu + cu) * PS_DBG_SLOTS + dbg_u++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+                #define PS_TU() do { } while (0)
+#endif
                 if (pre > 0)
                 {
                     const uint2_t raw = *((const uint2_t*) qb);
                     const half4_t ag = u2_as_half4(raw.x, raw.y);
+                    PS_TU();
                     ps_consume<0>(dec0, ag, acc_c, acc_d);
                     if (len > 1)
                     {
@@ -619,9 +687,10 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             half4_t tmp[16];
                             #pragma unroll
                             for (int i = 0; i < 16; ++i) tmp[i] = *((const half4_t*) (pdec_w + i * 512));
+                            PS_TU();
                             ps_consume<1>(tmp, ag, acc_c, acc_d);
                         }
-                        else ps_unit<KK, 1>(ring, up(2), ur(2), lane, lofs, ag, acc_c, acc_d);
+                        else { PS_TU(); ps_unit<KK, 1>(ring, up(2), ur(2), lane, lofs, ag, acc_c, acc_d); }
                     }
                     p = 2;
                     if constexpr (PMC >= 3)
@@ -630,8 +699,9 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         {
                             const uint2_t raw2 = *((const uint2_t*) (qb + 2 * 64));
                             const half4_t ag2 = u2_as_half4(raw2.x, raw2.y);
+                            PS_TU();
                             ps_consume<0>(dec1, ag2, acc_c, acc_d);
-                            if (len > 3) ps_unit<KK, 1>(ring, up(4), ur(4), lane, lofs, ag2, acc_c, acc_d);
+                            if (len > 3) { PS_TU(); ps_unit<KK, 1>(ring, up(4), ur(4), lane, lofs, ag2, acc_c, acc_d); }
                             p = 4;
                         }
                     }
@@ -640,17 +710,24 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 {
                     const uint2_t raw = *((const uint2_t*) (qb + p * 64));
                     const half4_t ag = u2_as_half4(raw.x, raw.y);
+                    ps_prio_rot(p + (wave >> 2));
+                    PS_TU();
                     ps_unit<KK, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
+                    ps_prio_rot(p + 1 + (wave >> 2));
+                    PS_TU();
                     ps_unit<KK, 1>(ring, up(p + 2), ur(p + 2), lane, lofs, ag, acc_c, acc_d);
                 }
                 if (p < len)
                 {
                     const uint2_t raw = *((const uint2_t*) (qb + p * 64));
                     const half4_t ag = u2_as_half4(raw.x, raw.y);
+                    PS_TU();
                     ps_unit<KK, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
                 }
+                PS_TU();
                 const int col = 16 * (lane >> 3) + (lane & 7);
                 pslot[col] = acc_c[0]; pslot[col + 8] = acc_d[0];
+                #undef PS_TU
             };
             if (cur.n > 0)
             {
@@ -669,7 +746,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
 #endif
             ring_ready = cur.n > P && nxt.n > 0;
             c_inc(PS_C_S);
-            if (wave == 0) PS_T(2);
+            if (wave == 0) { PS_T(2); PS_TC(14); }
             PS_T(16 + wave);
             cur = nxt; tl = tn;
         }
@@ -1366,24 +1443,24 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             const float kinv_s = (float) u16_as_half(0x1eeeu);
             float bb_s = 0.0f;
             uint32_t ctab0 = 0u, ctab1 = 0u;
-            // (ps_make_seg: wave w takes units [T w / 12, T (w + 1) / 12) of the rectangle's T = 4 nb W units, column-major; the waves whose run touches column j: at most eight
-            //  consecutive ones from one before floor(12 j / W) on -- checked for every nb <= 32, W <= 12; a run that STARTS in the column has its row in segment 0, one that
-            //  started in the column before in segment 1.  Packed: first candidate wave | candidate i counts << 8 | its row is segment 1 << 16)
+            // (the waves whose run touches column j and which of their two partial rows belongs to it, straight from the partition (ps_wave_range): a run that STARTS in the
+            //  column has its row in segment 0, one that started in the column before in segment 1.  At most EIGHT consecutive waves touch a column -- the uniform partition
+            //  by arithmetic (tests/test_pstep_plan.py), a weighted one because the planner checks it (wave_partition).  Packed: first candidate wave | candidate i counts << 8
+            //  | its row is segment 1 << 16)
             auto col_table = [&] (int j) -> uint32_t
             {
                 const int H = 4 * nb, T = H * W;
                 const int lo_u = j * H, hi_u = lo_u + H;
-                const int w_first = max((PS_SW * lo_u) / T - 1, 0);
                 uint32_t inb = 0u, sgb = 0u;
                 #pragma unroll
-                for (int i = 0; i < 8; ++i)
+                for (int w = 0; w < PS_SW; ++w)
                 {
-                    const int w = min(w_first + i, PS_SW - 1);
-                    const int u0 = (T * w) / PS_SW, u1 = (T * (w + 1)) / PS_SW;
-                    const bool in_col = (w_first + i < PS_SW) && u1 > u0 && u0 < hi_u && u1 > lo_u;
-                    inb |= (in_col ? 1u : 0u) << i; sgb |= (u0 >= lo_u ? 0u : 1u) << i;
+                    const PsRange rg = ps_wave_range(tl, T, w);
+                    const bool in_col = rg.u1 > rg.u0 && rg.u0 < hi_u && rg.u1 > lo_u;
+                    inb |= (in_col ? 1u : 0u) << w; sgb |= (rg.u0 >= lo_u ? 0u : 1u) << w;
                 }
-                return (uint32_t) w_first | (inb << 8) | (sgb << 16);
+                const int w_first = inb ? __builtin_ctz(inb) : 0;
+                return (uint32_t) w_first | (((inb >> w_first) & 0xffu) << 8) | (((sgb >> w_first) & 0xffu) << 16);
             };
             if (out_type != PS_OUT_FINAL && sw < W)
             {
@@ -1426,7 +1503,13 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             }
 
             // ---- the streaming waves' partial rows are in LDS: service half-wave shw finishes column blocks shw, shw + 8 of the rectangle
+            // (the one LONG wait of a service wave sleeps between its polls: spinning at priority 3 it took ~ 10 % of its SIMD's VALU issue away from the three streaming
+            //  waves it was waiting for -- same box 1.2797 -> 1.2734 ms; PS_WAIT_S_SPIN: the busy loop)
+#ifdef PS_WAIT_S_SPIN
             c_spin(PS_C_S, (uint32_t) PS_SW * (uint32_t) (op + 1));
+#else
+            c_wait(PS_C_S, (uint32_t) PS_SW * (uint32_t) (op + 1));
+#endif
             if (sw == 0) PS_T(6);
             // the lm_head poisons its logits if any wait of the launch has timed out by now: this workgroup's own flag, or the device's sticky error word (one load per step,
             // requested here, consumed behind the output Hadamard)
@@ -1730,4 +1813,6 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         }
     }
     #undef PS_T
+    #undef PS_TC
+    #undef PS_TP
 }

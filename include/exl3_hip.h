@@ -651,8 +651,11 @@ typedef struct
 } exl3_pstep_layer_t;
 int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* layers, int n_layers, const exl3_pstep_linear_t* head, const void* final_norm,
                       int hidden, int heads_q, int heads_kv, int head_dim, int K, int cb, float eps, int rope_mode, int flags);
-/* the planner alone, host logic (no device needed): rectangles [ncu][8] = {matrix, first column block, column blocks, first Hadamard block, blocks, slice,
- * side task, flags} of one op kind (0 q|k|v, 1 o_proj, 2 gate|up, 3 down, 4 lm_head) for a chip of ncu CUs; *S_out = its k-slices */
+/* the planner alone, host logic (no device needed): rectangles [ncu][12] = {matrix, first column block, column blocks, first Hadamard block, blocks, slice,
+ * side task, flags, first work unit in the op's repacked weights, pA, pB, pC} of one op kind (0 q|k|v, 1 o_proj, 2 gate|up, 3 down, 4 lm_head) for a chip of ncu CUs;
+ * pA / pB / pC = n << 2 | e: the work units each streaming wave of age group A (waves 0-3) / B (4-7) / C (8-11) takes of the rectangle (the first e waves of the group
+ * one more; all zero: the uniform partition) -- a SIMD runs its waves oldest-first, so equal shares leave the youngest streaming alone at the end;
+ * env EXL3_HIP_PSTEP_SHARES="fA,fB" (permille) sets the ratio, "0,0" = uniform everywhere.  *S_out = the op's k-slices */
 int exl3_pstep_plan_tiles(int hidden, int inter, int heads_q, int heads_kv, int head_dim, int vocab, int ncu, int op_kind, int32_t* tiles_out, int* S_out);
 int exl3_pstep_run(void* handle, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots, void* stream);
 int exl3_pstep_run_attn(void* handle, void* R, void* logits, void* q_out, const float* rope_sin, const float* rope_cos, const int64_t* slots,

@@ -24,7 +24,7 @@ def test_rectangles_partition_every_op(name, ncu):
     ops = {0: ([qdim // 128, kvdim // 128, kvdim // 128], hidden // 128), 1: ([hidden // 128], qdim // 128), 2: ([inter // 128, inter // 128], hidden // 128),
            3: ([hidden // 128], inter // 128), 4: ([vocab // 128], hidden // 128)}
     for kind, (ncbs, nblk) in ops.items():
-        tiles = np.zeros((ncu, 8), dtype=np.int32); S = ctypes.c_int(0)
+        tiles = np.zeros((ncu, 12), dtype=np.int32); S = ctypes.c_int(0)
         rc = l.exl3_pstep_plan_tiles(hidden, inter, hq, hkv, hd, vocab, ncu, kind, tiles.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.byref(S))
         if rc != 0:
             # legitimate refusals, small chips only: an lm_head wider than 12 column blocks per CU (a streaming wave's run would cross two boundaries), or an
@@ -33,8 +33,13 @@ def test_rectangles_partition_every_op(name, ncu):
             continue
         cover = [np.zeros((c, nblk), dtype=np.int32) for c in ncbs]
         slices = {}
-        for mat, cb0, ncb, b0, nb, sl, side, flags in tiles:
+        ub = 0
+        for mat, cb0, ncb, b0, nb, sl, side, flags, ubase, pA, pB, pC in tiles:
             if mat < 0: continue
+            # the rectangle's place in the op's repacked weights, and the streaming waves' shares of it (uniform: all zero; weighted: n << 2 | e per age group)
+            assert ubase == ub
+            ub += 4 * nb * ncb
+            _check_wave_shares(4 * nb * ncb, 4 * nb, (pA, pB, pC), head=(kind == 4))
             assert 0 <= mat < len(ncbs) and ncb >= 1 and nb >= 1 and 0 <= sl < S.value
             assert ncb <= 12
             if kind in (1, 3): assert nb <= 8 and ncb <= 4
@@ -48,10 +53,67 @@ def test_rectangles_partition_every_op(name, ncu):
         assert sum(1 for t in tiles if t[0] >= 0 and (t[7] & 1)) == (S.value if True else 0)           # one column group per slice carries the q-out flag
 
 
+def _wave_runs(T, shares):
+    """exl3_pstep_kernel.cuh: ps_wave_range, restated."""
+    pA, pB, pC = shares
+    if pA == 0 and pB == 0 and pC == 0:
+        return [((T * w) // 12, (T * (w + 1)) // 12) for w in range(12)]
+    out, base = [], 0
+    for p in (pA, pB, pC):
+        n, e = p >> 2, p & 3
+        for i in range(4):
+            u0 = base + i * n + min(i, e)
+            out.append((u0, u0 + n + (1 if i < e else 0)))
+        base += 4 * n + e
+    return out
+
+
+def _check_wave_shares(T, H, shares, head=False):
+    """The twelve runs tile [0, T) in wave order, no run is longer than a column (it may cross ONE column boundary: a wave keeps two partial rows), older age groups take
+    at least as much as younger ones, and every wave keeps the three units it decodes ahead."""
+    runs = _wave_runs(T, shares)
+    assert runs[0][0] == 0 and runs[-1][1] == T and all(runs[i][1] == runs[i + 1][0] for i in range(11))
+    assert all(0 <= u1 - u0 <= H or H * 12 < T for u0, u1 in runs) or any(shares)
+    if any(shares):
+        assert not head and T > 36
+        n = [u1 - u0 for u0, u1 in runs]
+        assert max(n) <= H and min(n) >= 3 and min(n[0:4]) >= max(n[4:8]) - 1 and min(n[4:8]) >= max(n[8:12]) - 1 and n[0] > n[11]
+    for u0, u1 in runs:
+        if u1 > u0: assert (u1 - 1) // H - u0 // H <= 1
+    # the finish reads the partial rows of a column from at most eight consecutive waves (exl3_pstep_kernel.cuh: col_table)
+    for j in range(T // H if T > H else 0):          # (a one-column rectangle: rows 0-5 | 6-11 of all twelve waves, no table)
+        touch = [w for w, (u0, u1) in enumerate(runs) if u1 > u0 and u0 < (j + 1) * H and u1 > j * H]
+        assert touch and touch[-1] - touch[0] < 8
+
+
+def test_weighted_partition_is_what_the_bench_shapes_get():
+    """Llama-3.1-8B on 256 CUs: gate|up (112 units per rectangle) and down (56) are cut by age group, q|k|v / o (all units decoded ahead) and the lm_head stay uniform;
+    EXL3_HIP_PSTEP_SHARES=0,0 turns the weighting off."""
+    import os
+    from exllamav3_amd import _lib
+    l = _lib.lib()
+
+    def plan(kind):
+        tiles = np.zeros((256, 12), dtype=np.int32); S = ctypes.c_int(0)
+        assert l.exl3_pstep_plan_tiles(4096, 14336, 32, 8, 128, 128256, 256, kind, tiles.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), ctypes.byref(S)) == 0
+        return tiles
+    for kind, weighted in ((0, False), (1, False), (2, True), (3, True), (4, False)):
+        t = plan(kind)
+        act = t[t[:, 0] >= 0]
+        assert bool((act[:, 9:12] != 0).any()) == weighted, kind
+        if weighted:
+            assert (act[:, 9] >> 2 >= act[:, 10] >> 2).all() and (act[:, 10] >> 2 >= act[:, 11] >> 2).all()
+    os.environ["EXL3_HIP_PSTEP_SHARES"] = "0,0"
+    try:
+        assert not (plan(2)[:, 9:12] != 0).any()
+    finally:
+        del os.environ["EXL3_HIP_PSTEP_SHARES"]
+
+
 def test_planner_refuses_what_the_kernel_cannot_take():
     from exllamav3_amd import _lib
     l = _lib.lib()
-    tiles = np.zeros((256, 8), dtype=np.int32); S = ctypes.c_int(0)
+    tiles = np.zeros((256, 12), dtype=np.int32); S = ctypes.c_int(0)
     P = tiles.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
     assert l.exl3_pstep_plan_tiles(4096, 14336, 32, 8, 128, 128256, 256, 7, P, ctypes.byref(S)) < 0          # no such op kind
     assert l.exl3_pstep_plan_tiles(4100, 14336, 32, 8, 128, 128256, 256, 0, P, ctypes.byref(S)) < 0          # hidden not a multiple of 128
@@ -59,7 +121,9 @@ def test_planner_refuses_what_the_kernel_cannot_take():
 
 
 def test_partial_row_partition_formula_matches_the_streaming_waves_runs():
-    """The service waves of the persistent step find the partial rows of column j of a rectangle WITHOUT records (exl3_pstep_kernel.cuh: col_table): streaming wave w takes
+    """(The UNIFORM partition: what the lm_head's finish and the PS_SUM_HALFWAVES builds use; the weighted partitions are read off ps_wave_range by a scan over the twelve
+    waves, checked in _check_wave_shares above.)
+    The service waves of the persistent step find the partial rows of column j of a rectangle WITHOUT records (exl3_pstep_kernel.cuh: col_table): streaming wave w takes
     units [T w / 12, T (w + 1) / 12) of the rectangle's T = 4 nb W units, column-major (ps_make_seg), so the waves whose run touches column j are at most EIGHT consecutive
     ones from max(floor(12 j / W) - 1, 0) on, a run that starts in the column has its row in segment 0 and one that started in the column before in segment 1, and a run
     spans at most two columns (W <= 12).  Brute force over every rectangle the planner can make (nb <= 32, W <= 12): the formula's (wave, segment) set per column equals the

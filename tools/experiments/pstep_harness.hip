@@ -57,7 +57,7 @@ static Lin make_lin(int k, int n, int K, double out_scale, hipStream_t st)
     return l;
 }
 struct Layer { Lin q, k, v, o, g, u, d; __half *norm1, *norm2; uint32_t *kc, *vc; __half *ks, *vs; };
-static exl3_pstep_linear_t pl(const Lin& l) { exl3_pstep_linear_t r; r.trellis = l.B; r.suh = l.suh; r.svh = l.svh; r.k = l.k; r.n = l.n; return r; }
+static exl3_pstep_linear_t pl(const Lin& l) { exl3_pstep_linear_t r; r.trellis = l.B; r.suh = l.suh; r.svh = l.svh; r.k = l.k; r.n = l.n; r.K = 0; r.cb = 0; return r; }      // (K = 0: the create call's K / codebook)
 
 int main(int argc, char** argv)
 {

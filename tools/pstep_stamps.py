@@ -13,6 +13,7 @@ def main():
     nops = 4 * nl + 1
     ncu = a.size // (nops * 32)
     a = a.reshape(nops, ncu, 32).astype(np.int64)
+    a0 = a.copy()                                    # raw ticks (slots 13 / 14 are shader-clock counts, not 100 MHz stamps)
     a = (a - a[0, :, 3].min()) / 100.0
     names = ["qkv", "o", "gate_up", "down"]
     out = {"total_us": float(a[-1, :, 7].max()), "workgroups": int(ncu), "ops": {}}
@@ -37,6 +38,11 @@ def main():
         per = float(np.median([np.median(a[o + 1, :, 3] - a[o, :, 3]) for o in ops]))
         rec["period_us"] = per
         rec["streaming_wave0"] = {"decode_ahead_and_wait_us": float(np.median(a[ops][:, :, 1] - a[ops][:, :, 0])), "stream_us": float(np.median(a[ops][:, :, 2] - a[ops][:, :, 1]))}
+        dt = (a0[ops][:, :, 2] - a0[ops][:, :, 1]).astype(np.float64); dc = (a0[ops][:, :, 14] - a0[ops][:, :, 13]).astype(np.float64)
+        okc = (dt > 50) & (a0[ops][:, :, 13] > 0)
+        if okc.any():
+            rec["shader_clock_mhz_during_streaming"] = float(np.median(dc[okc] / dt[okc] * 100.0))
+            print(f"           shader clock during the streaming phase (s_memtime / s_memrealtime, wave 0): {rec['shader_clock_mhz_during_streaming']:.0f} MHz")
         rec["last_arrival_to_next_op_edge_passed_us"] = float(np.median([np.median(a[o + 1, :, 4]) - a[o, :, 7].max() for o in ops]))
         rec["finish_spread_max_minus_median_us"] = float(np.median([a[o, :, 7].max() - np.median(a[o, :, 7]) for o in ops]))
         # per streaming wave: done (slot 16 + w) relative to the moment the LAST service wave published its quads (max of slots 28..31); per service wave: publish time
@@ -54,6 +60,8 @@ def main():
     o = nops - 1
     out["ops"]["head"] = {"edge_wait_us": float(np.median(a[o, :, 4] - a[o, :, 3])), "prep_us": float(np.median(a[o, :, 5] - a[o, :, 4])),
                           "wait_streamers_us": float(np.median(a[o, :, 6] - a[o, :, 5])), "finish_us": float(np.median(a[o, :, 7] - a[o, :, 6]))}
+    dt = float(np.median(a0[o, :, 2] - a0[o, :, 1])); dc = float(np.median(a0[o, :, 14] - a0[o, :, 13]))
+    if dt > 50 and dc > 0: out["ops"]["head"]["shader_clock_mhz_during_streaming"] = dc / dt * 100.0
     print("  head    ", out["ops"]["head"])
     if len(sys.argv) > 3:
         json.dump(out, open(sys.argv[3], "w"), indent=1)
