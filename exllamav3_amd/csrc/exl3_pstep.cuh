@@ -105,5 +105,6 @@ struct PsArgs
                                       // host mirror (set to 1 by the wave that times out: a caller reads it without synchronising) or null
     unsigned long long* dbg;          // optional phase stamps [nops][ncu][PS_DBG_SLOTS] (100 MHz)
     int spin_limit, pmax;
+    const int* runs;                  // the ops in runs of equal bits per weight: { end op, K } pairs (the streaming waves' loop is instantiated per width)
 };
 

@@ -4,29 +4,19 @@
 // the largest rectangle is as small as possible, a rectangle is at most 16 column blocks wide (a wave's run of work units then crosses at most one
 // column-block boundary) and the product of groups x slices fits the CUs.  The tables live in device memory; the kernel reads its rectangle of
 // op i + 1 while it streams op i.
-#include "exl3_pstep_kernel.cuh"
+#include "exl3_pstep_launch.h"
+#include "exl3_api_internal.h"
 #include <string>
 #include <vector>
 #include <stdio.h>
 #include <string.h>
 
-// (K, KH): the layers' bits per weight and the lm_head's -- KH = K, or 6 (the head of a real checkpoint stays at 6 bits whatever the layers have)
-#define PS_INST(KK, KHH) template __global__ void exl3_pstep_kernel<KK, KHH, false>(const PsArgs); template __global__ void exl3_pstep_kernel<KK, KHH, true>(const PsArgs);
-PS_INST(4, 4)
-#ifndef PS_ONLY_K4
-PS_INST(2, 2) PS_INST(3, 3) PS_INST(5, 5) PS_INST(6, 6) PS_INST(8, 8)
-PS_INST(2, 6) PS_INST(3, 6) PS_INST(4, 6) PS_INST(5, 6) PS_INST(8, 6)
-#endif
-#undef PS_INST
-
-#define PS_LDS_BYTES (PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES + PS_GATH_BYTES + PS_ATT_BYTES)
-static_assert(PS_LDS_BYTES <= 160 * 1024, "persistent step: LDS map exceeds a CU's 160 KiB");
-
 namespace
 {
 struct PsHandle
 {
-    int K, KH, nops, ncu, pmax, spin_limit, n_layers;
+    int K, K2, KH, cb, nops, ncu, pmax, spin_limit, n_layers;
+    const PsKernelSet* kset; int* d_runs;
     PsOp* d_ops; PsTile* d_tiles; uint32_t* d_cnt; uint32_t* d_err; unsigned long long* d_dbg;
     unsigned long long* d_slab_a; unsigned long long* d_slab_b; unsigned long long* d_slab_c; unsigned long long* d_slab_d; unsigned long long* d_rbuf; uint32_t* d_epoch;
     unsigned long long* d_att_rec; unsigned long long* d_att_stats; int attn;
@@ -155,46 +145,15 @@ void lin_to_mat(const exl3_pstep_linear_t& l, PsMat& m)
 }
 }
 
-template <int KK, int KHH>
-static void ps_launch_kk(bool att, int ncu, hipStream_t st, const PsArgs& args)
+// the kernel unit of the layers' bits per weight (exl3_pstep.kspec.hip, one translation unit per K)
+static const PsKernelSet* ps_kset(int K)
 {
-    if (att) exl3_pstep_kernel<KK, KHH, true><<<dim3(ncu), dim3(PS_NT), PS_LDS_BYTES, st>>>(args);
-    else     exl3_pstep_kernel<KK, KHH, false><<<dim3(ncu), dim3(PS_NT), PS_LDS_BYTES, st>>>(args);
-}
-template <int KK, int KHH>
-static int ps_attr_kk()
-{
-    EXL3_CHECK_HIP(hipFuncSetAttribute((const void*) exl3_pstep_kernel<KK, KHH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES), "hipFuncSetAttribute(pstep)");
-    EXL3_CHECK_HIP(hipFuncSetAttribute((const void*) exl3_pstep_kernel<KK, KHH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES), "hipFuncSetAttribute(pstep)");
-    return EXL3_OK;
-}
-
-// dispatch over the instantiated (K, KH) pairs: KH == K, or KH == 6
-#ifndef PS_ONLY_K4
-#define PS_PAIRS(X) X(4, 4) X(2, 2) X(3, 3) X(5, 5) X(6, 6) X(8, 8) X(2, 6) X(3, 6) X(4, 6) X(5, 6) X(8, 6)
-#else
-#define PS_PAIRS(X) X(4, 4)
-#endif
-static bool ps_pair_ok(int K, int KH)
-{
-    #define PS_X(KK, KHH) if (K == KK && KH == KHH) return true;
-    PS_PAIRS(PS_X)
-    #undef PS_X
-    return false;
-}
-static void ps_launch(int K, int KH, bool att, int ncu, hipStream_t st, const PsArgs& args)
-{
-    #define PS_X(KK, KHH) if (K == KK && KH == KHH) { ps_launch_kk<KK, KHH>(att, ncu, st, args); return; }
-    PS_PAIRS(PS_X)
-    #undef PS_X
-}
-static int ps_set_lds_attr(int K, int KH)
-{
-    #define PS_X(KK, KHH) if (K == KK && KH == KHH) return ps_attr_kk<KK, KHH>();
-    PS_PAIRS(PS_X)
-    #undef PS_X
-    exl3_set_error("exl3_pstep: no instantiation for %d bits per weight in the layers and %d in the lm_head (the head's: the layers' or 6)", K, KH);
-    return EXL3_ERR_ARG;
+    switch (K)
+    {
+        case 1: return ps_kernel_set_k1(); case 2: return ps_kernel_set_k2(); case 3: return ps_kernel_set_k3(); case 4: return ps_kernel_set_k4();
+        case 5: return ps_kernel_set_k5(); case 6: return ps_kernel_set_k6(); case 7: return ps_kernel_set_k7(); case 8: return ps_kernel_set_k8();
+    }
+    return nullptr;
 }
 
 // Load-time repack ("re-ordering tiles at load time is a legal one-time transform"): the op's packed words copied into the order the plan streams them --
@@ -221,27 +180,11 @@ __global__ __launch_bounds__(128) void ps_repack_kernel(const PsOp* __restrict__
     }
 }
 
-template <int KK, int KHH>
-static int ps_occupancy_kk(bool att)
-{
-    int nb = 0;
-    hipError_t e = att ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*) exl3_pstep_kernel<KK, KHH, true>, PS_NT, PS_LDS_BYTES)
-                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*) exl3_pstep_kernel<KK, KHH, false>, PS_NT, PS_LDS_BYTES);
-    return e == hipSuccess ? nb : -1;
-}
-static int ps_occupancy(int K, int KH, bool att)
-{
-    #define PS_X(KK, KHH) if (K == KK && KH == KHH) return ps_occupancy_kk<KK, KHH>(att);
-    PS_PAIRS(PS_X)
-    #undef PS_X
-    return -1;
-}
-
 extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* layers, int n_layers, const exl3_pstep_linear_t* head, const void* final_norm,
                                  int hidden, int heads_q, int heads_kv, int head_dim, int K, int cb, float eps, int rope_mode, int flags)
 {
     EXL3_CHECK_ARG(handle_out && layers && n_layers >= 1 && head && final_norm, "exl3_pstep_create: null argument");
-    EXL3_CHECK_ARG(cb == EXL3_CB_MUL1, "exl3_pstep_create: the persistent step is built for the mul1 codebook (cb = 2)");
+    EXL3_CHECK_ARG(cb >= 0 && cb <= 2, "exl3_pstep_create: codebook 0 (3INST) | 1 (mcg) | 2 (mul1)");
     EXL3_CHECK_ARG(hidden % 128 == 0 && hidden >= 128 && hidden / 128 <= PS_MAX_SLICE_BLOCKS, "exl3_pstep_create: hidden must be a multiple of 128 and <= %d", PS_MAX_SLICE_BLOCKS * 128);
     EXL3_CHECK_ARG((head_dim == 64 || head_dim == 128) && heads_kv >= 1 && heads_q >= heads_kv && (heads_kv * head_dim) % 128 == 0 && (heads_q * head_dim) % 128 == 0,
                    "exl3_pstep_create: head_dim 64 | 128, whole 128-value blocks of q and kv");
@@ -250,18 +193,52 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     hipDeviceProp_t prop; EXL3_CHECK_HIP(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
     const int ncu = prop.multiProcessorCount;
     EXL3_CHECK_ARG(ncu >= 16, "exl3_pstep_create: device has %d CUs", ncu);
-    const int KH = ((flags >> 8) & 0xf) ? ((flags >> 8) & 0xf) : K;        // flags bits 8..11: the lm_head's bits per weight when they differ from the layers'
-    { const int r = ps_set_lds_attr(K, KH); if (r) return r; }
-    {
-        // the step's edges need the WHOLE grid co-resident (one workgroup per CU): the kernel must fit a CU (155 KiB of LDS, 1024 threads, no scratch) -- checked here, at
-        // create, instead of discovered as a time-out at the first step (ADVICE r5); a grid of exactly multiProcessorCount workgroups is then placed one per CU
-        const int occ = ps_occupancy(K, KH, (flags & 4) != 0);
-        EXL3_CHECK_ARG(occ != 0, "exl3_pstep_create: the step kernel does not fit a CU of this device (occupancy 0): the grid could not be co-resident");
-    }
-
     const int qdim = heads_q * head_dim, kvdim = heads_kv * head_dim, kvb = kvdim / 128;
     const int nops = 4 * n_layers + 1;
     EXL3_CHECK_ARG(nops < 4095, "exl3_pstep_create: %d ops: the tags of the step's lines carry the producer op in 12 bits (at most 1023 layers)", nops);
+    // ---- bits per weight / codebook per op.  The tensors of one fused linear share both (a reference qgroup is quantized as one: modules/attn.py:244-308,
+    // modules/mlp.py:537-574); the fused linears of the layers may have TWO adjacent widths (a fractional-bpw checkpoint: conversion/allocation.py:131-141 bumps whole
+    // qgroups by one bit), the lm_head its own (flags bits 8..11 when its tensor does not say), one codebook for everything
+    std::vector<int> opK((size_t) nops, 0);
+    int cbm = -1, Klo = 99, Khi = 0;
+    {
+        auto kind = [&] (const exl3_pstep_linear_t& l, int& Ko, int& cbo) { Ko = l.K ? l.K : K; cbo = l.K ? l.cb : cb; };
+        for (int li = 0; li < n_layers; ++li)
+        {
+            const exl3_pstep_linear_t* grp[4][3] = { { &layers[li].q, &layers[li].k, &layers[li].v }, { &layers[li].o, nullptr, nullptr },
+                                                     { &layers[li].gate, &layers[li].up, nullptr }, { &layers[li].down, nullptr, nullptr } };
+            for (int g = 0; g < 4; ++g)
+                for (int j = 0; j < 3 && grp[g][j]; ++j)
+                {
+                    int Kj, cbj; kind(*grp[g][j], Kj, cbj);
+                    if (cbm < 0) cbm = cbj;
+                    EXL3_CHECK_ARG(cbj == cbm, "exl3_pstep_create: layer %d: tensors of different codebooks (%d / %d) in one model", li, cbj, cbm);
+                    if (j == 0) opK[(size_t) 4 * li + g] = Kj;
+                    EXL3_CHECK_ARG(Kj == opK[(size_t) 4 * li + g], "exl3_pstep_create: layer %d: the tensors of one fused linear (q / k / v; gate / up) differ in bits per weight", li);
+                    if (Kj < Klo) Klo = Kj;
+                    if (Kj > Khi) Khi = Kj;
+                }
+        }
+        int Kh, cbh; kind(*head, Kh, cbh);
+        if (!head->K && ((flags >> 8) & 0xf)) Kh = (flags >> 8) & 0xf;           // flags bits 8..11: the lm_head's bits per weight when its tensor does not carry them
+        EXL3_CHECK_ARG(cbh == cbm, "exl3_pstep_create: the lm_head's codebook (%d) differs from the layers' (%d)", cbh, cbm);
+        opK[(size_t) nops - 1] = Kh;
+    }
+    const int KH = opK[(size_t) nops - 1];
+    EXL3_CHECK_ARG(Khi - Klo <= 1, "exl3_pstep_create: the layers' linears have %d .. %d bits per weight: the step takes one width or two adjacent ones", Klo, Khi);
+    const int cb_all = cbm;
+    K = Klo; const int K2 = Khi;
+    const PsKernelSet* const kset = ps_kset(K);
+    {
+        // the step's edges need the WHOLE grid co-resident (one workgroup per CU): the kernel must fit a CU (155 KiB of LDS, 1024 threads, no scratch) -- checked here, at
+        // create, instead of discovered as a time-out at the first step (ADVICE r5); a grid of exactly multiProcessorCount workgroups is then placed one per CU
+        int occ = -1;
+        const int r = kset ? kset->prepare(K2, KH, cb_all, (flags & 4) != 0, &occ) : 1;
+        if (r < 0) return r;
+        EXL3_CHECK_ARG(r == 0, "exl3_pstep_create: no kernel for layers of %d%s bits per weight, a %d-bit lm_head and codebook %d (exl3_pstep.kspec.hip lists the instantiations)",
+                       K, K2 != K ? " / + 1" : "", KH, cb_all);
+        EXL3_CHECK_ARG(occ != 0, "exl3_pstep_create: the step kernel does not fit a CU of this device (occupancy 0): the grid could not be co-resident");
+    }
     // DIRECT residual edges (exl3_pstep.cuh) unless flags bit 1 / EXL3_HIP_PSTEP_OWNERS=1 asks for the owner form everywhere (A/B runs); a plan that cannot keep
     // an RMSNorm op's slice at <= 4 blocks falls back to owners for the whole step
     // attention inside the step (flags bit 2): head_dim 128, <= 8 query heads per kv head, the chip holds one item per (kv head, split) with 2..32 splits
@@ -395,7 +372,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     }
 
     PsHandle* h = new PsHandle();
-    h->K = K; h->KH = KH; h->nops = nops; h->ncu = ncu; h->pmax = 3; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
+    h->K = K; h->K2 = K2; h->KH = KH; h->cb = cb_all; h->kset = kset; h->d_runs = nullptr; h->nops = nops; h->ncu = ncu; h->pmax = 3; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
     h->d_att_rec = nullptr; h->d_att_stats = nullptr; h->attn = attn ? 1 : 0; h->d_repack = nullptr; h->repack_words = 0; h->h_err = nullptr;
     h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr; h->d_slab_c = nullptr; h->d_slab_d = nullptr; h->d_rbuf = nullptr; h->d_epoch = nullptr;
     h->cnt_bytes = (size_t) nops * 8 * 16 * 4; h->dbg_words = (flags & 1) ? (size_t) nops * ncu * PS_DBG_SLOTS : 0;
@@ -431,31 +408,11 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
         PsOp& C = ops[f.op + 1];                                      // the consumer op reads these slab sets
         for (int i = 0; i < O.nmat; ++i) C.in_slab[i] = base + f.off[i];
     }
-    // bits per weight / codebook per op: the tensors of one fused linear share both (a reference qgroup); the kernel instantiations cover one K for the layers (+ the
-    // head's) and the mul1 codebook
-    {
-        auto kind = [&] (const exl3_pstep_linear_t& l, int& Ko, int& cbo) { Ko = l.K ? l.K : K; cbo = l.K ? l.cb : cb; };
-        for (int li = 0; li < n_layers; ++li)
-        {
-            const exl3_pstep_linear_t* grp[4][3] = { { &layers[li].q, &layers[li].k, &layers[li].v }, { &layers[li].o, nullptr, nullptr },
-                                                     { &layers[li].gate, &layers[li].up, nullptr }, { &layers[li].down, nullptr, nullptr } };
-            for (int g = 0; g < 4; ++g)
-            {
-                PsOp& O = ops[(size_t) 4 * li + g];
-                kind(*grp[g][0], O.K, O.cb); O.Bp = nullptr;
-                for (int j = 1; j < 3 && grp[g][j]; ++j)
-                {
-                    int Kj, cbj; kind(*grp[g][j], Kj, cbj);
-                    if (Kj != O.K || cbj != O.cb) { exl3_set_error("exl3_pstep_create: layer %d: the tensors of one fused linear differ in bits per weight / codebook", li); exl3_pstep_destroy(h); return EXL3_ERR_ARG; }
-                }
-                if (O.K != K || O.cb != EXL3_CB_MUL1) { exl3_set_error("exl3_pstep_create: layer %d: %d bits / codebook %d: the step is built for one K in the layers and the mul1 codebook", li, O.K, O.cb); exl3_pstep_destroy(h); return EXL3_ERR_ARG; }
-            }
-        }
-        PsOp& H = ops[(size_t) nops - 1];
-        kind(*head, H.K, H.cb); H.Bp = nullptr;
-        if (!head->K) H.K = KH;
-        if (H.K != KH || H.cb != EXL3_CB_MUL1) { exl3_set_error("exl3_pstep_create: lm_head: %d bits / codebook %d do not match the plan's (flags bits 8..11)", H.K, H.cb); exl3_pstep_destroy(h); return EXL3_ERR_ARG; }
-    }
+    for (int i = 0; i < nops; ++i) { ops[i].K = opK[(size_t) i]; ops[i].cb = cb_all; ops[i].Bp = nullptr; }
+    // runs of equal width for the streaming waves: { end op, K } pairs (+ a terminator)
+    std::vector<int> runs;
+    for (int i = 0; i < nops; ++i) if (i + 1 == nops || opK[(size_t) i + 1] != opK[(size_t) i]) { runs.push_back(i + 1); runs.push_back(opK[(size_t) i]); }
+    runs.push_back(nops); runs.push_back(0);
     // the ops' weights in plan order (flags bit 4 / EXL3_HIP_PSTEP_REPACK=0: stream the checkpoint layout as it is -- A/B runs, and callers that cannot afford the second copy:
     // the plan then holds pointers into the caller's tensors only)
     bool repack = !(flags & 16);
@@ -485,6 +442,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
         PS_TRY(hipDeviceSynchronize());
     }
     h->ops = ops; h->tiles = tiles; h->att_nsplit = att_nsplit; h->att_cap = head_dim == 128 ? PS_ATT_MAX_SPLITS : 16; h->head_dim = head_dim;
+    PS_TRY(hipMalloc(&h->d_runs, runs.size() * sizeof(int))); PS_TRY(hipMemcpy(h->d_runs, runs.data(), runs.size() * sizeof(int), hipMemcpyHostToDevice));
     PS_TRY(hipMalloc(&h->d_cnt, h->cnt_bytes)); PS_TRY(hipMemset(h->d_cnt, 0, h->cnt_bytes));
     PS_TRY(hipMalloc(&h->d_err, 64)); PS_TRY(hipMemset(h->d_err, 0, 64));
     PS_TRY(hipHostMalloc((void**) &h->h_err, 64, hipHostMallocMapped)); h->h_err[0] = 0u;
@@ -564,7 +522,8 @@ static int ps_run(PsHandle* h, void* R, void* logits, void* q_out, const float* 
     a.rope_sin = rope_sin; a.rope_cos = rope_cos; a.slots = slots;
     a.block_table = block_table; a.seqlens = seqlens; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.att_scale = scale;
     a.rbuf = h->d_rbuf; a.cnt = h->d_cnt; a.epoch = h->d_epoch; a.err = h->d_err; a.dbg = h->d_dbg; a.spin_limit = h->spin_limit; a.pmax = h->pmax;
-    ps_launch(h->K, h->KH, h->attn != 0, h->ncu, st, a);
+    a.runs = h->d_runs;
+    h->kset->launch(h->K2, h->KH, h->cb, h->attn != 0, h->ncu, st, a);
     return exl3_check_launch("exl3_pstep_run");
 }
 
@@ -626,7 +585,8 @@ extern "C" int exl3_pstep_describe(void* handle, char* buf, int buf_bytes)
 {
     PsHandle* h = (PsHandle*) handle;
     EXL3_CHECK_ARG(h && buf && buf_bytes > 0, "exl3_pstep_describe: null argument");
-    snprintf(buf, (size_t) buf_bytes, "ops=%d cus=%d K=%d head_K=%d decode_ahead=%d lds=%d weights=%s | %s", h->nops, h->ncu, h->K, h->KH, h->pmax, (int) PS_LDS_BYTES,
+    snprintf(buf, (size_t) buf_bytes, "ops=%d cus=%d K=%d%s head_K=%d codebook=%s decode_ahead=%d lds=%d weights=%s | %s", h->nops, h->ncu, h->K, h->K2 != h->K ? "+1" : "", h->KH,
+             h->cb == 2 ? "mul1" : (h->cb == 1 ? "mcg" : "3inst"), h->pmax, (int) PS_LDS_BYTES,
              h->d_repack ? "repacked (one contiguous run per streaming wave)" : "checkpoint layout", h->desc.c_str());
     return EXL3_OK;
 }
@@ -660,6 +620,7 @@ extern "C" int exl3_pstep_destroy(void* handle)
     if (h->d_slab_d) (void) hipFree(h->d_slab_d);
     if (h->d_rbuf) (void) hipFree(h->d_rbuf);
     if (h->d_repack) (void) hipFree(h->d_repack);
+    if (h->d_runs) (void) hipFree(h->d_runs);
     if (h->h_err) (void) hipHostFree(h->h_err);
     delete h;
     return EXL3_OK;

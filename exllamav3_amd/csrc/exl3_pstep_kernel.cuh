@@ -155,7 +155,11 @@ __device__ __forceinline__ void ps_slab_sum2(ps_rsrc_t ra, ps_rsrc_t rb, uint32_
 }
 
 // one work unit = 2 tile rows of the wave's 128-column block against the activation group `ag` (exl3_gemv4.kspec.hip g4_unit, mul1 FAST variant)
-template <int K, int HALF>
+// CB: the codebook of the op's tensors.  mul1: the FAST operand (fp16 of 1024 + byte sum; the affine map is applied once per output by the service waves).  3INST / mcg:
+// the EXACT fp16 weight (lo + hi halves in one fp16 add: the reference's bits, quant/codebook.cuh:56-77) -- ONE operand per quad like mul1, so a decoded unit takes the
+// same 32 registers / 8 KiB and the same MFMA pass (generation 4's FAST form for these codebooks feeds the two halves as two k-slots: twice the decode-ahead storage)
+#define PS_VAR(CB) ((CB) == EXL3_CB_MUL1 ? 1 : 0)
+template <int K, int CB, int HALF>
 __device__ __forceinline__ void ps_unit(LaneWords<K> (&ring)[2], const uint32_t* __restrict__ refill, size_t refill_rs, int lane, int lofs, half4_t ag,
                                         float4_t& acc_c, float4_t& acc_d)
 {
@@ -181,8 +185,8 @@ __device__ __forceinline__ void ps_unit(LaneWords<K> (&ring)[2], const uint32_t*
             // speed-only ablation (results are garbage): what does the streaming phase cost without the decode arithmetic?
             bc[0] = u2_as_half4(Wx[q % (K + 1)], Wx[(q + 1) % (K + 1)]); bd[0] = u2_as_half4(Wx[(q + 1) % (K + 1)], Wx[q % (K + 1)]);
 #else
-            decode_quad<K, EXL3_CB_MUL1, 1, 8 * q>(Wx, bc);
-            decode_quad<K, EXL3_CB_MUL1, 1, 8 * q + 4>(Wx, bd);
+            decode_quad<K, CB, PS_VAR(CB), 8 * q>(Wx, bc);
+            decode_quad<K, CB, PS_VAR(CB), 8 * q + 4>(Wx, bd);
 #endif
             acc_c = __builtin_amdgcn_mfma_f32_4x4x4f16(ag, bc[0], acc_c, 4, ABID, 0);
             acc_d = __builtin_amdgcn_mfma_f32_4x4x4f16(ag, bd[0], acc_d, 4, ABID, 0);
@@ -192,7 +196,7 @@ __device__ __forceinline__ void ps_unit(LaneWords<K> (&ring)[2], const uint32_t*
 }
 
 // decode-ahead: the same unit decoded into 16 B operands (no activations needed), the ring refilled as a streamed unit refills it
-template <int K>
+template <int K, int CB>
 __device__ __forceinline__ void ps_predecode(LaneWords<K> (&ring)[2], const uint32_t* __restrict__ refill, size_t refill_rs, int lane, int lofs, half4_t (&dec)[16])
 {
     ps_static_for<0, 2>([&] (auto uc)
@@ -212,15 +216,15 @@ __device__ __forceinline__ void ps_predecode(LaneWords<K> (&ring)[2], const uint
         {
             constexpr int q = decltype(qc)::value;
             half4_t bc[2], bd[2];
-            decode_quad<K, EXL3_CB_MUL1, 1, 8 * q>(Wx, bc);
-            decode_quad<K, EXL3_CB_MUL1, 1, 8 * q + 4>(Wx, bd);
+            decode_quad<K, CB, PS_VAR(CB), 8 * q>(Wx, bc);
+            decode_quad<K, CB, PS_VAR(CB), 8 * q + 4>(Wx, bd);
             dec[(4 * u + q) * 2] = bc[0]; dec[(4 * u + q) * 2 + 1] = bd[0];
         });
     });
 }
 
 // ... the same unit decoded straight into the wave's LDS slots (the second decode-ahead unit): no 32-register staging array
-template <int K>
+template <int K, int CB>
 __device__ __forceinline__ void ps_predecode_lds(LaneWords<K> (&ring)[2], const uint32_t* __restrict__ refill, size_t refill_rs, int lane, int lofs, char* pdec_w)
 {
     ps_static_for<0, 2>([&] (auto uc)
@@ -240,8 +244,8 @@ __device__ __forceinline__ void ps_predecode_lds(LaneWords<K> (&ring)[2], const 
         {
             constexpr int q = decltype(qc)::value;
             half4_t bc[2], bd[2];
-            decode_quad<K, EXL3_CB_MUL1, 1, 8 * q>(Wx, bc);
-            decode_quad<K, EXL3_CB_MUL1, 1, 8 * q + 4>(Wx, bd);
+            decode_quad<K, CB, PS_VAR(CB), 8 * q>(Wx, bc);
+            decode_quad<K, CB, PS_VAR(CB), 8 * q + 4>(Wx, bd);
             *((half4_t*) (pdec_w + ((4 * u + q) * 2) * 512)) = bc[0];
             *((half4_t*) (pdec_w + ((4 * u + q) * 2 + 1) * 512)) = bd[0];
         });
@@ -379,10 +383,12 @@ __device__ __forceinline__ PsSeg<K> ps_make_seg(ps_op_p O, const PsTile& t, int 
     return s;
 }
 
+// K / K2: bits per weight of the layers' fused linears -- K2 = K, or K + 1 for a fractional-bpw checkpoint (the reference's allocator bumps whole qgroups by one bit:
+// conversion/allocation.py:131-141); CB: the codebook of every tensor (mul1 | 3INST | mcg).
 // ATT: the plan has the decode attention inside o_proj's preparation (PS_ATTN).  A separate instantiation: with the attention code compiled in, the step WITHOUT attention
 // ran 2.6 % (8B) / 6 % (1B) slower (250 instead of 78 scalar spills on the service path, a third more code)
 // KH: bits per weight of the lm_head (= K, or 6: the head of a real checkpoint)
-template <int K, int KH, bool ATT>
+template <int K, int K2, int KH, int CB, bool ATT>
 __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -628,12 +634,12 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 if (Pm >= 1 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
                 {
                     PS_TP();                               // [1] first rows there? (the predecode waits for them)
-                    ps_predecode<KK>(ring, cur.unit_ptr(min(1, cur.n - 1)), cur.rs, lane, lofs, dec0);
+                    ps_predecode<KK, CB>(ring, cur.unit_ptr(min(1, cur.n - 1)), cur.rs, lane, lofs, dec0);
                     P = 1;
                     PS_TP();
                     if (Pm >= 2 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
                     {
-                        ps_predecode_lds<KK>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, pdec_w);
+                        ps_predecode_lds<KK, CB>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, pdec_w);
                         P = 2;
                         PS_TP();
                         // a THIRD unit, in registers again (Llama-3.2-1B's gate|up rectangle is 32 units = 2.67 per wave: with two units ahead eight waves streamed one
@@ -642,7 +648,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         {
                             if (Pm >= 3 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
                             {
-                                ps_predecode<KK>(ring, cur.unit_ptr(min(3, cur.n - 1)), cur.rs, lane, lofs, dec1);
+                                ps_predecode<KK, CB>(ring, cur.unit_ptr(min(3, cur.n - 1)), cur.rs, lane, lofs, dec1);
                                 P = 3;
                                 PS_TP();
                             }
@@ -690,7 +696,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             PS_TU();
                             ps_consume<1>(tmp, ag, acc_c, acc_d);
                         }
-                        else { PS_TU(); ps_unit<KK, 1>(ring, up(2), ur(2), lane, lofs, ag, acc_c, acc_d); }
+                        else { PS_TU(); ps_unit<KK, CB, 1>(ring, up(2), ur(2), lane, lofs, ag, acc_c, acc_d); }
                     }
                     p = 2;
                     if constexpr (PMC >= 3)
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             const half4_t ag2 = u2_as_half4(raw2.x, raw2.y);
                             PS_TU();
                             ps_consume<0>(dec1, ag2, acc_c, acc_d);
-                            if (len > 3) { PS_TU(); ps_unit<KK, 1>(ring, up(4), ur(4), lane, lofs, ag2, acc_c, acc_d); }
+                            if (len > 3) { PS_TU(); ps_unit<KK, CB, 1>(ring, up(4), ur(4), lane, lofs, ag2, acc_c, acc_d); }
                             p = 4;
                         }
                     }
@@ -712,17 +718,17 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     const half4_t ag = u2_as_half4(raw.x, raw.y);
                     ps_prio_rot(p + (wave >> 2));
                     PS_TU();
-                    ps_unit<KK, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
+                    ps_unit<KK, CB, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
                     ps_prio_rot(p + 1 + (wave >> 2));
                     PS_TU();
-                    ps_unit<KK, 1>(ring, up(p + 2), ur(p + 2), lane, lofs, ag, acc_c, acc_d);
+                    ps_unit<KK, CB, 1>(ring, up(p + 2), ur(p + 2), lane, lofs, ag, acc_c, acc_d);
                 }
                 if (p < len)
                 {
                     const uint2_t raw = *((const uint2_t*) (qb + p * 64));
                     const half4_t ag = u2_as_half4(raw.x, raw.y);
                     PS_TU();
-                    ps_unit<KK, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
+                    ps_unit<KK, CB, 0>(ring, up(p + 1), ur(p + 1), lane, lofs, ag, acc_c, acc_d);
                 }
                 PS_TU();
                 const int col = 16 * (lane >> 3) + (lane & 7);
@@ -752,9 +758,23 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         }
         };
         // (8-bit layers: two units ahead as well -- a 16-word ring + three decoded units sat at the 128-register limit of a 16-wave workgroup, one change away from scratch)
+        // the ops in RUNS of equal bits per weight (PsArgs::runs = { end op, K } pairs; a uniform model with the head at the layers' K: one run; no rows are requested across
+        // a run boundary).  The lm_head's pass and 6-bit layer passes of a mixed plan hold two decode-ahead units (register budget: see above)
         constexpr int PM_MAIN = K >= 8 ? 2 : 3;
-        if constexpr (KH == K) stream_ops(std::integral_constant<int, K>{}, std::integral_constant<int, PM_MAIN>{}, 0, nops);
-        else { stream_ops(std::integral_constant<int, K>{}, std::integral_constant<int, PM_MAIN>{}, 0, nops - 1); stream_ops(std::integral_constant<int, KH>{}, std::integral_constant<int, 2>{}, nops - 1, nops); }
+        constexpr int PM_2 = (K2 >= 6 || CB != EXL3_CB_MUL1) ? 2 : 3;
+        const int PS_CONST* const runs = (const int PS_CONST*) a.runs;
+        int op0 = 0;
+        for (int r = 0; op0 < nops; ++r)
+        {
+            const int op1 = runs[2 * r], Kr = runs[2 * r + 1];
+            if (Kr == K) stream_ops(std::integral_constant<int, K>{}, std::integral_constant<int, PM_MAIN>{}, op0, op1);
+            else
+            {
+                if constexpr (K2 != K) { if (Kr == K2) stream_ops(std::integral_constant<int, K2>{}, std::integral_constant<int, PM_2>{}, op0, op1); }
+                if constexpr (KH != K && KH != K2) { if (Kr == KH) stream_ops(std::integral_constant<int, KH>{}, std::integral_constant<int, 2>{}, op0, op1); }
+            }
+            op0 = op1;
+        }
     }
     else
     {
@@ -1440,7 +1460,9 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             // one-column rectangle = rows 0-5 | 6-11 (unit-less waves leave zero rows: no masks), a wider one = candidates 0-3 | 4-7 of the partition formula.  It was one
             // column per HALF-wave: a per-lane column index -> ~200 VALU instructions of integer arithmetic and masks between "last streaming wave done" and "partial line
             // published" (0.9-1.2 us by the stamps), and with W <= 2 one service wave did it all.
-            const float kinv_s = (float) u16_as_half(0x1eeeu);
+            // (mul1: value = kinv * (1024 + byte sum) + kbias, applied here once per output; 3INST / mcg operands are the weights themselves)
+            const bool op_mul1 = CB == EXL3_CB_MUL1;
+            const float kinv_s = op_mul1 ? (float) u16_as_half(0x1eeeu) : 1.0f;
             float bb_s = 0.0f;
             uint32_t ctab0 = 0u, ctab1 = 0u;
             // (the waves whose run touches column j and which of their two partial rows belongs to it, straight from the partition (ps_wave_range): a run that STARTS in the
@@ -1469,7 +1491,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 for (int q0 = 0; q0 < nb; q0 += 32) if (q0 + l32 < nb) xs += bsum[q0 + l32];
                 #pragma unroll
                 for (int i = 1; i < 32; i <<= 1) xs += xor_lane(xs, i);
-                bb_s = (float) u16_as_half(0xc931u) * xs;
+                bb_s = op_mul1 ? (float) u16_as_half(0xc931u) * xs : 0.0f;
                 if (W > 1) ctab0 = col_table(sw);                             // (this wave's first two columns; a rectangle wider than eight: the third after them, on the chain)
                 if (W > sw + PS_NSV) ctab1 = col_table(sw + PS_NSV);
             }
@@ -1644,7 +1666,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 #pragma unroll
                 for (int i = 1; i < 32; i <<= 1) xs += xor_lane(xs, i);
                 if (sw == 0 && j == shw) PS_T(10);
-                const float kinv = (float) u16_as_half(0x1eeeu), kbias = (float) u16_as_half(0xc931u);
+                const float kinv = CB == EXL3_CB_MUL1 ? (float) u16_as_half(0x1eeeu) : 1.0f, kbias = CB == EXL3_CB_MUL1 ? (float) u16_as_half(0xc931u) : 0.0f;
                 const float bb = kbias * xs;
                 v.x = (v.x * kinv + bb) * fac_norm; v.y = (v.y * kinv + bb) * fac_norm; v.z = (v.z * kinv + bb) * fac_norm; v.w = (v.w * kinv + bb) * fac_norm;
                 const int cbl = tl.cb0 + j;

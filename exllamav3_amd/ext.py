@@ -1843,7 +1843,9 @@ class PersistentStep:
     """One launch for every quantized linear of a batch-1 decode step (all layers + lm_head) and the glue between them.  Replaces the per-layer graphs of
     exllamav3_ext/libtorch/attention.cpp:246-330 (attention core excluded) + libtorch/mlp.cpp:14-91; the plan (rectangles per CU, slab / row buffers)
     is built once from the layer tensors.  `layers`: dicts with LinearEXL3-like entries q, k, v, o, gate, up, down (attributes trellis, suh, svh, K) and
-    tensors norm1, norm2, kcache = (words, scales), vcache = (words, scales).  mul1 codebook, 4-bit cache, hidden <= 4096 (exl3_pstep_create checks)."""
+    tensors norm1, norm2, kcache = (words, scales), vcache = (words, scales).  4-bit cache, hidden <= 4096; one codebook for the model (mul1 | 3INST | mcg), the tensors
+    of one fused linear (q / k / v; gate / up) share their bits per weight, the layers' linears have one width or two adjacent ones (a fractional-bpw checkpoint), the
+    lm_head the layers' or 6 bits -- exl3_pstep_create checks and names the kernel instantiations (exl3_pstep.kspec.hip)."""
 
     def __init__(self, layers, head, final_norm, hidden: int, heads_q: int, heads_kv: int, head_dim: int, eps: float, rope_mode: int = 2, stamps: bool = False,
                  attention: bool = False, repack: bool | None = None):
@@ -1855,23 +1857,22 @@ class PersistentStep:
             t = l.trellis
             _req(t.dim() == 3 and l.suh is not None and l.svh is not None, "PersistentStep: EXL3 linears with suh / svh")
             return _lib.PstepLinear(_p(t), _p(l.suh), _p(l.svh), t.shape[0] * 16, t.shape[1] * 16, t.shape[-1] // 16, 1 if l.mcg else (2 if l.mul1 else 0))
-        K = layers[0]["q"].trellis.shape[-1] // 16
+        K = min(L[name].trellis.shape[-1] // 16 for L in layers for name in ("q", "k", "v", "o", "gate", "up", "down"))
+        cb = 1 if layers[0]["q"].mcg else (2 if layers[0]["q"].mul1 else 0)
         arr = (_lib.PstepLayer * len(layers))()
         for i, L in enumerate(layers):
             for name in ("q", "k", "v", "o", "gate", "up", "down"):
-                _req(L[name].trellis.shape[-1] // 16 == K and bool(L[name].mul1) and not bool(L[name].mcg), "PersistentStep: one K, mul1 codebook")
                 setattr(arr[i], name, lin(L[name]))
             arr[i].norm1, arr[i].norm2 = _p(L["norm1"]), _p(L["norm2"])
             (kw, ks), (vw, vs) = L["kcache"], L["vcache"]
             arr[i].k_cache, arr[i].k_scales, arr[i].v_cache, arr[i].v_scales = _p(kw), _p(ks), _p(vw), _p(vs)
         KH = head.trellis.shape[-1] // 16
-        _req(KH in (K, 6) and bool(head.mul1) and not bool(head.mcg), "PersistentStep: lm_head with the layers' codebook and the layers' K or 6 bits")
         hl = lin(head)
         _dev(final_norm)
         self._h = ctypes.c_void_p(None)
         self._keep = (layers, head, final_norm)          # the plan holds raw pointers
         _check(_lib.lib().exl3_pstep_create(ctypes.byref(self._h), arr, len(layers), ctypes.byref(hl), _p(final_norm), int(hidden), int(heads_q), int(heads_kv),
-                                            int(head_dim), int(K), 2, float(eps), int(rope_mode),
+                                            int(head_dim), int(K), int(cb), float(eps), int(rope_mode),
                                             (1 if stamps else 0) | (4 if attention else 0) | ((KH << 8) if KH != K else 0) | (16 if repack is False else 0)))
         self.n_layers = len(layers)
         self.attention = bool(attention)

@@ -110,17 +110,19 @@ def _rand_linear_host(k: int, n: int, K: int, cb: int, device, rng, out_dtype=No
 def _same_kind(*lins: LinearEXL3) -> bool:
     """One fused launch takes matrices of one bits-per-weight and codebook (the kernels are compiled per K); the reference fuses q|k|v and
     gate|up under the same test (modules/attn.py:439, modules/mlp.py:635) and otherwise runs one GEMV per matrix.  Its bit allocation moves
-    q, k, v together (qgroup key.qkv, modules/attn.py:244-280) but gate and up separately, so a fractional-bpw checkpoint can have one
-    layer whose gate and up differ by a bit (conversion/allocation.py:131-141)."""
+    q, k, v together (qgroup key.qkv, modules/attn.py:244-280) and gate, up together (key.gu, modules/mlp.py:537-556); o and down are groups of
+    their own, so a fractional-bpw checkpoint has fused linears of two adjacent widths (conversion/allocation.py:131-141)."""
     return len({(l.K, l.mcg, l.mul1) for l in lins}) == 1
 
 
 class SyntheticEXL3Llama:
     def __init__(self, shape: LlamaShape, K: int = 4, cb: int = 2, device: torch.device | str = "cuda:0",
                  backend: TPBackendRCCL | None = None, kv_bits: int = 4, seed: int = 0, head_K: int | None = None,
-                 max_ctx: int = 4096, layers: int | None = None, host_seed: int | None = None):
+                 max_ctx: int = 4096, layers: int | None = None, host_seed: int | None = None, layer_K=None):
         """host_seed: draw every tensor (and alloc_state's input rows) on the host from numpy's PCG64 stream of that seed instead of the device
-        generator -- machine-independent tensors, used by the pinned-logits check (bench.py, tests/golden/make_bench_pins.py); TP = 1 only."""
+        generator -- machine-independent tensors, used by the pinned-logits check (bench.py, tests/golden/make_bench_pins.py); TP = 1 only.
+        layer_K: optional callable (layer index, "qkv" | "o" | "gu" | "d") -> bits per weight of that fused linear (a qgroup of the reference: the allocator of a
+        fractional-bpw conversion bumps whole qgroups by one bit, conversion/allocation.py:131-141); default: K everywhere."""
         self.shape, self.K, self.cb, self.kv_bits = shape, K, cb, kv_bits
         if self.fx_act_in_gemv is None:
             self.fx_act_in_gemv = shape.hidden <= 2048
@@ -151,16 +153,17 @@ class SyntheticEXL3Llama:
         self.vocab_ldims = [vpts[r + 1] - vpts[r] for r in range(tp)]
         h = shape.hidden
         self.layers = []
-        for _ in range(self.n_layers):
+        for li in range(self.n_layers):
+            kq, ko, kg, kd = (layer_K(li, g) for g in ("qkv", "o", "gu", "d")) if layer_K else (K, K, K, K)
             L = {
-                "q": mk_lin(h, self.hq * hd, K),
-                "k": mk_lin(h, self.hkv * hd, K),
-                "v": mk_lin(h, self.hkv * hd, K),
+                "q": mk_lin(h, self.hq * hd, kq),
+                "k": mk_lin(h, self.hkv * hd, kq),
+                "v": mk_lin(h, self.hkv * hd, kq),
                 # o / down: row shards, fp32 partial sums (architecture/llama.py:95,111 out_dtype = float)
-                "o": mk_lin(self.hq * hd, h, K, out_dtype=torch.float),
-                "gate": mk_lin(h, self.inter_local, K),
-                "up": mk_lin(h, self.inter_local, K),
-                "down": mk_lin(self.inter_local, h, K, out_dtype=torch.float),
+                "o": mk_lin(self.hq * hd, h, ko, out_dtype=torch.float),
+                "gate": mk_lin(h, self.inter_local, kg),
+                "up": mk_lin(h, self.inter_local, kg),
+                "down": mk_lin(self.inter_local, h, kd, out_dtype=torch.float),
                 "norm1": mk_norm(h),
                 "norm2": mk_norm(h),
             }
@@ -796,12 +799,16 @@ class SyntheticEXL3Llama:
 
     def persistent_applies(self) -> bool:
         s = self.shape
-        # one K and codebook for the layers' linears; the lm_head: the same, or 6 bits (the head of a real checkpoint)
-        same = all(_same_kind(L["q"], L["k"], L["v"], L["o"], L["gate"], L["up"], L["down"], self.layers[0]["q"]) for L in self.layers)
-        same = same and (_same_kind(self.lm_head, self.layers[0]["q"]) or (self.lm_head.K == 6 and self.lm_head.mul1 == self.layers[0]["q"].mul1 and self.lm_head.mcg == self.layers[0]["q"].mcg))
+        # one codebook; the tensors of a fused linear share their width; the layers' linears: one width or two adjacent ones (round 6); the lm_head: the layers' or 6 bits
+        q0 = self.layers[0]["q"]
+        lins = [L[n] for L in self.layers for n in ("q", "k", "v", "o", "gate", "up", "down")] + [self.lm_head]
+        same = all(l.mul1 == q0.mul1 and l.mcg == q0.mcg for l in lins)
+        same = same and all(_same_kind(L["q"], L["k"], L["v"]) and _same_kind(L["gate"], L["up"]) for L in self.layers)
+        ks = sorted({l.K for l in lins[:-1]})
+        same = same and len(ks) <= 2 and ks[-1] - ks[0] <= 1 and (self.lm_head.K == 6 or (len(ks) == 1 and self.lm_head.K == ks[0]))
         # with the attention core: inside the step (exl3_pstep.cuh: PS_ATTN) for at most 8 query heads per 128-value kv block
         att_ok = (not self.with_attention) or ((self.hq // self.hkv) * (128 // s.head_dim) <= 8 and os.environ.get("EXL3_HIP_PSTEP_ATTN", "1") != "0")
-        return (self._state_bsz == 1 and self.tp == 1 and att_ok and self.cb == 2 and self.kv_bits == 4 and same
+        return (self._state_bsz == 1 and self.tp == 1 and att_ok and self.kv_bits == 4 and same
                 and s.hidden % 128 == 0 and s.hidden <= 4096 and s.head_dim in (64, 128) and self.use_qkv_tab)
 
     def decode_step_persistent(self):
