@@ -276,7 +276,7 @@ def main():
         {"tail": model.decode_step_tail, "glue": model.decode_step_fused, "resid": model.decode_step_resid, "fx": model.decode_step_fx,
          "unfused": model.decode_step, "persistent": model.decode_step_persistent}[pipeline]
     if pipeline == "persistent":
-        assert not is_moe and world == 1 and model.persistent_applies(), "--pipeline persistent: batch 1, one rank, mul1 codebook, 4-bit cache, hidden <= 4096 (attention core: head_dim 128)"
+        assert not is_moe and world == 1 and model.persistent_applies(), "--pipeline persistent: batch 1, one rank, 4-bit cache, hidden <= 4096"
     # tensor-parallel decode: the o_proj / down_proj all-reduces go through the one-shot IPC push (exl3_allreduce.hip, fused with the residual
     # add) unless EXL3_HIP_TP_ALLREDUCE=rccl; the set-up self-tests against the collective library and every rank falls back together
     ipc_on = False
@@ -741,10 +741,44 @@ def main():
         if cb != 0:
             m3 = SyntheticEXL3Llama(shape, K=args.bits, cb=0, device=dev, backend=backend, kv_bits=args.kv_bits)
             m3.alloc_state(1)
-            extra["llama-3.1-8b_bs1_3inst"] = timed_decode(m3, m3.decode_step_fx if pipe_x == "fx" else m3.decode_step_fused, 1)
-            extra["llama-3.1-8b_bs1_3inst"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, 0, 1, dev, pipe_x if pipe_x != "unfused" else "glue")
+            p3 = pipeline == "persistent" and m3.persistent_applies()          # (round 6: the persistent step takes the 3INST / mcg codebooks: exl3_pstep.kspec.hip)
+            extra["llama-3.1-8b_bs1_3inst"] = timed_decode(m3, m3.decode_step_auto if p3 else (m3.decode_step_fx if pipe_x == "fx" else m3.decode_step_fused), 1)
+            if p3 and m3._pstep is not None:
+                extra["llama-3.1-8b_bs1_3inst"]["step"] = "decode_step_persistent (exact fp16 3INST weights per quad operand)"
+                extra["llama-3.1-8b_bs1_3inst"]["plan"] = m3._pstep.describe()
+                extra["llama-3.1-8b_bs1_3inst"]["edge_timeout"] = bool(m3._pstep.error())
+                assert not extra["llama-3.1-8b_bs1_3inst"]["edge_timeout"], "bench.py: the persistent step (3INST) reported a time-out"
+                extra["llama-3.1-8b_bs1_3inst"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, 0, 1, dev, "persistent")
+                m3._pstep = None
+                extra["llama-3.1-8b_bs1_3inst_launch_per_op"] = timed_decode(m3, m3.decode_step_fx, 1)
+                extra["llama-3.1-8b_bs1_3inst_launch_per_op"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, 0, 1, dev, "fx")
+            else:
+                extra["llama-3.1-8b_bs1_3inst"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, 0, 1, dev, pipe_x if pipe_x != "unfused" else "glue")
             del m3
             torch.cuda.empty_cache()
+        # a fractional-bpw checkpoint (4.5 bpw-style: the reference's allocator bumps whole qgroups by one bit, conversion/allocation.py:131-141): half the layers' MLPs
+        # one bit up, the lm_head at 6 bits -- the persistent step runs the ops in runs of equal width (exl3_pstep_kernel<K, K + 1, 6, ...>)
+        if pipeline == "persistent" and cb == 2 and args.bits <= 5:
+            try:
+                kb = args.bits
+                mm = SyntheticEXL3Llama(shape, K=kb, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits, head_K=6,
+                                        layer_K=lambda li, g: kb + 1 if (li % 2 == 1 and g in ("gu", "d")) else kb)
+                mm.alloc_state(1)
+                if mm.persistent_applies():
+                    key = "llama-3.1-8b_bs1_mixed_%d_%dbit_head6" % (kb, kb + 1)
+                    extra[key] = timed_decode(mm, mm.decode_step_auto, 1)
+                    bpm = sum((k_ * n_ * l_.K // 8 + 2 * (k_ + n_)) for L in mm.layers for nm, l_ in L.items() if hasattr(l_, "trellis")
+                              for (k_, n_) in [(l_.trellis.shape[0] * 16, l_.trellis.shape[1] * 16)]) + shape.hidden * shape.vocab * 6 // 8
+                    extra[key].update({"bytes_per_token": int(bpm), "frac_of_hbm_roofline": round((1e3 / extra[key]["ms_per_step"]) / (HBM_PEAK_GBPS * 1e9 / bpm), 4),
+                                       "plan": mm._pstep.describe() if mm._pstep is not None else None, "edge_timeout": bool(mm._pstep.error()) if mm._pstep is not None else None,
+                                       "note": "odd layers' gate|up and down at %d bits, everything else at %d, lm_head at 6; gated by the GPU suite's oracle test "
+                                               "(tests/test_gpu_pstep.py::test_persistent_step_two_adjacent_widths_in_the_layers), no bench pin" % (kb + 1, kb)})
+                    mm._pstep = None
+                    extra[key + "_launch_per_op"] = timed_decode(mm, mm.decode_step_fx, 1)
+                del mm
+                torch.cuda.empty_cache()
+            except Exception as e:
+                extra["llama-3.1-8b_bs1_mixed_width"] = {"error": repr(e)[:200]}
         # config 2: Llama-3.2-1B, bs 1
         m1 = SyntheticEXL3Llama(SHAPES["llama-3.2-1b"], K=args.bits, cb=cb, device=dev, backend=backend, kv_bits=args.kv_bits)
         m1.alloc_state(1)

@@ -109,7 +109,7 @@ void wave_shares(int& fA, int& fB)
 
 // the rectangles of one op: workgroup (column group gi, slice s) = gi * S + s; every (column block, Hadamard block) of the op lies in exactly one
 // rectangle (tests/test_pstep_plan.py checks the partition on the CPU through exl3_pstep_plan_tiles)
-void fill_tiles(PsTile* T, int ncu, const OpPlan& p, const int* ncb, int nmat, int nblk, int side_tasks, bool weighted = true)
+void fill_tiles(PsTile* T, int ncu, const OpPlan& p, const int* ncb, int nmat, int nblk, int side_tasks, bool weighted = true, int pre = 3)
 {
     for (int c = 0; c < ncu; ++c) { T[c].mat = -1; T[c].cb0 = 0; T[c].ncb = 0; T[c].b0 = 0; T[c].nb = 0; T[c].slice = 0; T[c].side = -1; T[c].flags = 0; T[c].ubase = 0; T[c].r0_ = T[c].r1_ = T[c].r2_ = 0; }
     int gi = 0;
@@ -134,7 +134,7 @@ void fill_tiles(PsTile* T, int ncu, const OpPlan& p, const int* ncb, int nmat, i
     int fA, fB; wave_shares(fA, fB);
     for (int c = 0; c < ncu; ++c) if (weighted && T[c].mat >= 0)
     {
-        int o3[3]; wave_partition(4 * T[c].nb * T[c].ncb, 4 * T[c].nb, 3, fA, fB, o3);
+        int o3[3]; wave_partition(4 * T[c].nb * T[c].ncb, 4 * T[c].nb, pre, fA, fB, o3);
         T[c].r0_ = o3[0]; T[c].r1_ = o3[1]; T[c].r2_ = o3[2];
     }
 }
@@ -271,7 +271,8 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
 
     auto add_tiles = [&] (int op, const OpPlan& p, const int* ncb, int nmat, int nblk, int side_tasks)
     {
-        fill_tiles(tiles.data() + (size_t) op * ncu, ncu, p, ncb, nmat, nblk, side_tasks);
+        // (units every wave decodes ahead: the kernel's PM_MAIN / PM_2 -- three, two at 8 bits, for the wider of two widths when it is 6, and for 3INST / mcg)
+        fill_tiles(tiles.data() + (size_t) op * ncu, ncu, p, ncb, nmat, nblk, side_tasks, true, (cb_all != EXL3_CB_MUL1 || opK[(size_t) op] >= 8 || (K2 != K && opK[(size_t) op] == K2 && K2 >= 6)) ? 2 : 3);
     };
 
     int op = 0;

@@ -156,13 +156,26 @@ __device__ __forceinline__ void ps_slab_sum2(ps_rsrc_t ra, ps_rsrc_t rb, uint32_
 
 // one work unit = 2 tile rows of the wave's 128-column block against the activation group `ag` (exl3_gemv4.kspec.hip g4_unit, mul1 FAST variant)
 // CB: the codebook of the op's tensors.  mul1: the FAST operand (fp16 of 1024 + byte sum; the affine map is applied once per output by the service waves).  3INST / mcg:
-// the EXACT fp16 weight (lo + hi halves in one fp16 add: the reference's bits, quant/codebook.cuh:56-77) -- ONE operand per quad like mul1, so a decoded unit takes the
-// same 32 registers / 8 KiB and the same MFMA pass (generation 4's FAST form for these codebooks feeds the two halves as two k-slots: twice the decode-ahead storage)
+//   * units decoded AHEAD hold the EXACT fp16 weight (lo + hi halves in one fp16 add: the reference's bits, quant/codebook.cuh:56-77) -- ONE operand per quad like mul1, so a
+//     decoded unit takes the same 32 registers / 8 KiB and the same MFMA pass; the three extra slow VALU instructions per weight pair are spent while the wave waits for
+//     its input anyway;
+//   * STREAMED units take generation 4's FAST form: the masked product's two fp16 halves go to the matrix pipe as two k-slots against duplicated activations
+//     ((a0 a0 a1 a1), (a2 a2 a3 a3)) -- two more MFMAs per quad, no VALU instruction for the sum (exact streaming measured no faster than the launch-per-op step:
+//     586.7 vs 582.8 tok/s at Llama-3.1-8B).  The number of units decoded ahead is then FIXED by the plan (not by when the input arrives), so a step's bits do not depend
+//     on timing.
 #define PS_VAR(CB) ((CB) == EXL3_CB_MUL1 ? 1 : 0)
 template <int K, int CB, int HALF>
 __device__ __forceinline__ void ps_unit(LaneWords<K> (&ring)[2], const uint32_t* __restrict__ refill, size_t refill_rs, int lane, int lofs, half4_t ag,
                                         float4_t& acc_c, float4_t& acc_d)
 {
+    // (3INST / mcg: the activation quad with every value twice: the k-slots of a weight's lo and hi halves)
+    half4_t ag_lo = ag, ag_hi = ag;
+    if constexpr (CB != EXL3_CB_MUL1)
+    {
+        union { half4_t h; uint32_t u[2]; } c; c.h = ag;
+        ag_lo = u2_as_half4(__builtin_amdgcn_perm(c.u[0], c.u[0], 0x01000100u), __builtin_amdgcn_perm(c.u[0], c.u[0], 0x03020302u));
+        ag_hi = u2_as_half4(__builtin_amdgcn_perm(c.u[1], c.u[1], 0x01000100u), __builtin_amdgcn_perm(c.u[1], c.u[1], 0x03020302u));
+    }
     ps_static_for<0, 2>([&] (auto uc)
     {
         constexpr int u = decltype(uc)::value;
@@ -185,11 +198,22 @@ __device__ __forceinline__ void ps_unit(LaneWords<K> (&ring)[2], const uint32_t*
             // speed-only ablation (results are garbage): what does the streaming phase cost without the decode arithmetic?
             bc[0] = u2_as_half4(Wx[q % (K + 1)], Wx[(q + 1) % (K + 1)]); bd[0] = u2_as_half4(Wx[(q + 1) % (K + 1)], Wx[q % (K + 1)]);
 #else
-            decode_quad<K, CB, PS_VAR(CB), 8 * q>(Wx, bc);
-            decode_quad<K, CB, PS_VAR(CB), 8 * q + 4>(Wx, bd);
+            decode_quad<K, CB, 1, 8 * q>(Wx, bc);
+            decode_quad<K, CB, 1, 8 * q + 4>(Wx, bd);
 #endif
-            acc_c = __builtin_amdgcn_mfma_f32_4x4x4f16(ag, bc[0], acc_c, 4, ABID, 0);
-            acc_d = __builtin_amdgcn_mfma_f32_4x4x4f16(ag, bd[0], acc_d, 4, ABID, 0);
+            if constexpr (CB == EXL3_CB_MUL1)
+            {
+                acc_c = __builtin_amdgcn_mfma_f32_4x4x4f16(ag, bc[0], acc_c, 4, ABID, 0);
+                acc_d = __builtin_amdgcn_mfma_f32_4x4x4f16(ag, bd[0], acc_d, 4, ABID, 0);
+            }
+            else
+            {
+                // bc[0] = { lo0 hi0 lo1 hi1 }, bc[1] = { lo2 hi2 lo3 hi3 } of the quad's four weights: two k-slots per weight
+                acc_c = __builtin_amdgcn_mfma_f32_4x4x4f16(ag_lo, bc[0], acc_c, 4, ABID, 0);
+                acc_d = __builtin_amdgcn_mfma_f32_4x4x4f16(ag_lo, bd[0], acc_d, 4, ABID, 0);
+                acc_c = __builtin_amdgcn_mfma_f32_4x4x4f16(ag_hi, bc[1], acc_c, 4, ABID, 0);
+                acc_d = __builtin_amdgcn_mfma_f32_4x4x4f16(ag_hi, bd[1], acc_d, 4, ABID, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
     });
@@ -631,13 +655,15 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     ps_load_row<KK>(ring[1], cur.stripA + cur.rs + lofs);
                 }
                 const int Pm = min(pmax, cur.len0);
-                if (Pm >= 1 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
+                // (3INST / mcg: units decoded ahead and streamed units differ in rounding, so HOW MANY are decoded ahead must not depend on when the input arrives)
+                constexpr bool FIXED_P = CB != EXL3_CB_MUL1;
+                if (Pm >= 1 && (FIXED_P || (int32_t) (c_load(PS_C_T) - tgt_t) < 0))
                 {
                     PS_TP();                               // [1] first rows there? (the predecode waits for them)
                     ps_predecode<KK, CB>(ring, cur.unit_ptr(min(1, cur.n - 1)), cur.rs, lane, lofs, dec0);
                     P = 1;
                     PS_TP();
-                    if (Pm >= 2 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
+                    if (Pm >= 2 && (FIXED_P || (int32_t) (c_load(PS_C_T) - tgt_t) < 0))
                     {
                         ps_predecode_lds<KK, CB>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, pdec_w);
                         P = 2;
@@ -646,7 +672,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         // more after the quads were there -- 1.5 us of decode on the critical path of every layer)
                         if constexpr (PMC >= 3)
                         {
-                            if (Pm >= 3 && (int32_t) (c_load(PS_C_T) - tgt_t) < 0)
+                            if (Pm >= 3 && (FIXED_P || (int32_t) (c_load(PS_C_T) - tgt_t) < 0))
                             {
                                 ps_predecode<KK, CB>(ring, cur.unit_ptr(min(3, cur.n - 1)), cur.rs, lane, lofs, dec1);
                                 P = 3;
@@ -760,7 +786,8 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
         // (8-bit layers: two units ahead as well -- a 16-word ring + three decoded units sat at the 128-register limit of a 16-wave workgroup, one change away from scratch)
         // the ops in RUNS of equal bits per weight (PsArgs::runs = { end op, K } pairs; a uniform model with the head at the layers' K: one run; no rows are requested across
         // a run boundary).  The lm_head's pass and 6-bit layer passes of a mixed plan hold two decode-ahead units (register budget: see above)
-        constexpr int PM_MAIN = K >= 8 ? 2 : 3;
+        // (3INST / mcg: two units ahead -- their exact decode costs 1.8x a mul1 unit and runs whether or not the input is already there: same box 638 vs 631 tok/s)
+        constexpr int PM_MAIN = (K >= 8 || CB != EXL3_CB_MUL1) ? 2 : 3;
         constexpr int PM_2 = (K2 >= 6 || CB != EXL3_CB_MUL1) ? 2 : 3;
         const int PS_CONST* const runs = (const int PS_CONST*) a.runs;
         int op0 = 0;

@@ -62,7 +62,7 @@ static exl3_pstep_linear_t pl(const Lin& l) { exl3_pstep_linear_t r; r.trellis =
 int main(int argc, char** argv)
 {
     const bool small = argc > 1 && !strcmp(argv[1], "1b");
-    const int hidden = small ? 2048 : 4096, inter = small ? 8192 : 14336, hq = 32, hkv = 8, hd = small ? 64 : 128, vocab = 128256, K = 4, cb = 2;
+    const int hidden = small ? 2048 : 4096, inter = small ? 8192 : 14336, hq = 32, hkv = 8, hd = small ? 64 : 128, vocab = 128256, K = 4, cb = getenv("H_CB") ? atoi(getenv("H_CB")) : 2;      // H_CB: 0 3INST | 1 mcg | 2 mul1 (default)
     const int page = 256, max_ctx = 4096, kv_bits = 4, pos = 1000;
     const int n_layers = argc > 2 && atoi(argv[2]) > 0 ? atoi(argv[2]) : (small ? 16 : 32), alternations = argc > 3 ? atoi(argv[3]) : 3;
     const char* plist = argc > 4 ? argv[4] : "2,1,0";
