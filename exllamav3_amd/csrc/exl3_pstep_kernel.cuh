@@ -665,6 +665,12 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     PS_TP();
                     if (Pm >= 2 && (FIXED_P || (int32_t) (c_load(PS_C_T) - tgt_t) < 0))
                     {
+                        // (the SECOND unit in registers too where the pass may hold three: the op's input then meets two register units -- all of a q|k|v wave's work at
+                        //  Llama-3.1-8B -- and only the third comes back through 8 KiB of LDS.  PS_UNIT2_LDS: the order before round 6, second unit in LDS)
+#ifndef PS_UNIT2_LDS
+                        if constexpr (PMC >= 3) ps_predecode<KK, CB>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, dec1);
+                        else
+#endif
                         ps_predecode_lds<KK, CB>(ring, cur.unit_ptr(min(2, cur.n - 1)), cur.rs, lane, lofs, pdec_w);
                         P = 2;
                         PS_TP();
@@ -674,7 +680,11 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                         {
                             if (Pm >= 3 && (FIXED_P || (int32_t) (c_load(PS_C_T) - tgt_t) < 0))
                             {
+#ifndef PS_UNIT2_LDS
+                                ps_predecode_lds<KK, CB>(ring, cur.unit_ptr(min(3, cur.n - 1)), cur.rs, lane, lofs, pdec_w);
+#else
                                 ps_predecode<KK, CB>(ring, cur.unit_ptr(min(3, cur.n - 1)), cur.rs, lane, lofs, dec1);
+#endif
                                 P = 3;
                                 PS_TP();
                             }
@@ -716,11 +726,17 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     {
                         if (pre > 1)
                         {
-                            half4_t tmp[16];
-                            #pragma unroll
-                            for (int i = 0; i < 16; ++i) tmp[i] = *((const half4_t*) (pdec_w + i * 512));
-                            PS_TU();
-                            ps_consume<1>(tmp, ag, acc_c, acc_d);
+#ifndef PS_UNIT2_LDS
+                            if constexpr (PMC >= 3) { PS_TU(); ps_consume<1>(dec1, ag, acc_c, acc_d); }
+                            else
+#endif
+                            {
+                                half4_t tmp[16];
+                                #pragma unroll
+                                for (int i = 0; i < 16; ++i) tmp[i] = *((const half4_t*) (pdec_w + i * 512));
+                                PS_TU();
+                                ps_consume<1>(tmp, ag, acc_c, acc_d);
+                            }
                         }
                         else { PS_TU(); ps_unit<KK, CB, 1>(ring, up(2), ur(2), lane, lofs, ag, acc_c, acc_d); }
                     }
@@ -732,7 +748,16 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             const uint2_t raw2 = *((const uint2_t*) (qb + 2 * 64));
                             const half4_t ag2 = u2_as_half4(raw2.x, raw2.y);
                             PS_TU();
+#ifndef PS_UNIT2_LDS
+                            {
+                                half4_t tmp[16];
+                                #pragma unroll
+                                for (int i = 0; i < 16; ++i) tmp[i] = *((const half4_t*) (pdec_w + i * 512));
+                                ps_consume<0>(tmp, ag2, acc_c, acc_d);
+                            }
+#else
                             ps_consume<0>(dec1, ag2, acc_c, acc_d);
+#endif
                             if (len > 3) { PS_TU(); ps_unit<KK, CB, 1>(ring, up(4), ur(4), lane, lofs, ag2, acc_c, acc_d); }
                             p = 4;
                         }
