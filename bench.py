@@ -818,8 +818,18 @@ def main():
         from exllamav3_amd.tp import OneRankOfMany
         m70 = SyntheticEXL3Llama(SHAPES["llama-3.1-70b"], K=3, cb=cb, device=dev, backend=OneRankOfMany(8, dev), kv_bits=args.kv_bits)
         m70.alloc_state(1)
-        r70 = timed_decode(m70, m70.decode_step_fx if pipe_x == "fx" else m70.decode_step_fused, 1)
-        r70["launches_per_layer"] = 7 if pipe_x == "fx" else 10
+        p70 = pipeline == "persistent" and m70.persistent_applies()            # (round 6: the persistent step takes rows up to 8192 wide)
+        r70 = timed_decode(m70, m70.decode_step_auto if p70 else (m70.decode_step_fx if pipe_x == "fx" else m70.decode_step_fused), 1)
+        if p70 and m70._pstep is not None:
+            r70["step"] = "decode_step_persistent over the rank's shards (one launch per step; the o_proj / down_proj partial rows are NOT exchanged: compute leg only)"
+            r70["plan"] = m70._pstep.describe()
+            r70["edge_timeout"] = bool(m70._pstep.error())
+            assert not r70["edge_timeout"], "bench.py: the persistent step (70B rank shapes) reported a time-out"
+            m70._pstep = None
+            extra["llama-3.1-70b_tp8_rank_bs1_launch_per_op"] = timed_decode(m70, m70.decode_step_fx, 1)
+            extra["llama-3.1-70b_tp8_rank_bs1_launch_per_op"]["launches_per_layer"] = 7
+        else:
+            r70["launches_per_layer"] = 7 if pipe_x == "fx" else 10
         rank_bytes = sum((k * n * 3 // 8 + 2 * (k + n)) * cnt for (k, n, cnt) in m70.gemv_launches_per_step())
         r70.update({"bits": 3, "tp": 8, "rank_bytes_per_token": int(rank_bytes),
                     "frac_of_hbm_roofline": round((1e3 / r70["ms_per_step"]) / (HBM_PEAK_GBPS * 1e9 / rank_bytes), 4),

@@ -35,7 +35,8 @@
 #define PS_ATTN 0x200
 
 // LDS map of the kernel (bytes)
-#define PS_QUADS_BYTES 8448                       // activation quads of a slice: (nb * 8 + 4) tile rows x 32 B  ->  nb <= 32 Hadamard blocks
+#define PS_QUADS_BYTES 8448                       // activation quads of a slice: (nb * 8 + 4) tile rows x 32 B  ->  nb <= 32 Hadamard blocks (a 64-block slice -- the lm_head of a
+                                                  // model wider than 4096 -- runs 8 KiB into the gather area behind them: exl3_pstep_kernel.cuh)
 #define PS_MISC_BYTES 1536                        // block sums of squares [64] | block sums [2][64] | segment records [2][16][4] | control words
 #define PS_PART_BYTES (12 * 2 * 512)              // partial rows [streaming wave][segment][128] fp32
 #define PS_PDEC_BYTES (12 * 16 * 64 * 8)          // decode-ahead unit #2 of every streaming wave: [wave][16 operand slots][64 lanes] x 8 B
@@ -43,8 +44,11 @@
 #define PS_ATT_BYTES 21504                         // attention item (with the gather area in front of it: 37 888 B): V tiles / partial outputs 8 x 4352 | new-token words 128 | scales 128 | wave statistics 512 | queries 2048
 #define PS_ATT_MAX_SPLITS 32                       // statistics of all splits of a head in one half-wave (one lane per split)
 #define PS_DBG_SLOTS 32                           // phase stamps per op and workgroup (exl3_pstep_stamps): 0..12 streaming wave 0 / service wave 0, 16 + w: streaming wave w done, 28 + s: service wave s published its quads
-#define PS_RBUF_BYTES (2 * 32 * 1024 + 2 * 32 * 16)
-#define PS_MAX_SLICE_BLOCKS 32                    // = the largest k / 128 of an RMSNorm op (hidden <= 4096): 8 service half-waves x 4 blocks
+#define PS_MAX_ROW_BLOCKS 64                      // the residual row: hidden <= 8192 (round 6; Llama-3.1-70B's width): 8 service half-waves x 8 blocks
+#define PS_ROW_IT (PS_MAX_ROW_BLOCKS / 8)
+#define PS_RROW_BYTES (PS_MAX_ROW_BLOCKS * 1024u)  // one version of the row: a 1 KiB tagged line per block
+#define PS_RBUF_BYTES (2 * PS_MAX_ROW_BLOCKS * 1024 + 2 * PS_MAX_ROW_BLOCKS * 16)
+#define PS_MAX_SLICE_BLOCKS 32                    // the largest k-slice of an op (quads in LDS); the lm_head's one slice may be the whole row
 
 struct PsMat
 {
@@ -94,8 +98,8 @@ struct PsArgs
 {
     const PsOp* ops; const PsTile* tiles; int nops, ncu;
     unsigned long long* R; half_t* logits; half_t* q_out;
-    unsigned long long* rbuf;         // [2][PS_MAX_SLICE_BLOCKS] lines of 1 KiB: the residual row's versions >= 1 (version v in half v & 1), tagged fp32 pairs;
-                                      // then [2][PS_MAX_SLICE_BLOCKS] granules of 16 B { sum of squares of the block, tag, 0, tag }
+    unsigned long long* rbuf;         // [2][PS_MAX_ROW_BLOCKS] lines of 1 KiB: the residual row's versions >= 1 (version v in half v & 1), tagged fp32 pairs;
+                                      // then [2][PS_MAX_ROW_BLOCKS] granules of 16 B { sum of squares of the block, tag, 0, tag }
     const float* rope_sin; const float* rope_cos; const int64_t* slots;
     const int32_t* block_table; const int32_t* seqlens;      // PS_ATTN: the sequence's page ids [blocks_per_seq], its length INCLUDING the new token [1]
     int blocks_per_seq, page_size; float att_scale;

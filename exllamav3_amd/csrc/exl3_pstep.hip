@@ -39,7 +39,7 @@ bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_t
     {
         if (out_type == PS_OUT_FINAL && S != 1) continue;
         const int nbmax = (nblk + S - 1) / S;
-        if (nbmax > PS_MAX_SLICE_BLOCKS) continue;
+        if (nbmax > (out_type == PS_OUT_FINAL ? PS_MAX_ROW_BLOCKS : PS_MAX_SLICE_BLOCKS)) continue;      // (quads in LDS; the lm_head's one slice may be the whole row)
         if (in_type != PS_IN_NORM && nbmax > 8) continue;                  // one preparation task per service half-wave
         if (direct && nbmax > 4) continue;                                 // a DIRECT RMSNorm op gathers the partial lines of at most four blocks (LDS: gath)
         const int G = ncu / S;
@@ -185,7 +185,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
 {
     EXL3_CHECK_ARG(handle_out && layers && n_layers >= 1 && head && final_norm, "exl3_pstep_create: null argument");
     EXL3_CHECK_ARG(cb >= 0 && cb <= 2, "exl3_pstep_create: codebook 0 (3INST) | 1 (mcg) | 2 (mul1)");
-    EXL3_CHECK_ARG(hidden % 128 == 0 && hidden >= 128 && hidden / 128 <= PS_MAX_SLICE_BLOCKS, "exl3_pstep_create: hidden must be a multiple of 128 and <= %d", PS_MAX_SLICE_BLOCKS * 128);
+    EXL3_CHECK_ARG(hidden % 128 == 0 && hidden >= 128 && hidden / 128 <= PS_MAX_ROW_BLOCKS, "exl3_pstep_create: hidden must be a multiple of 128 and <= %d", PS_MAX_ROW_BLOCKS * 128);
     EXL3_CHECK_ARG((head_dim == 64 || head_dim == 128) && heads_kv >= 1 && heads_q >= heads_kv && (heads_kv * head_dim) % 128 == 0 && (heads_q * head_dim) % 128 == 0,
                    "exl3_pstep_create: head_dim 64 | 128, whole 128-value blocks of q and kv");
     EXL3_CHECK_ARG(rope_mode == 1 || rope_mode == 2, "exl3_pstep_create: rope_mode 1 (GPT-J) | 2 (NeoX)");

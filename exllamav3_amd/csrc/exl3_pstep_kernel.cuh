@@ -416,14 +416,16 @@ template <int K, int K2, int KH, int CB, bool ATT>
 __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const quads = smem;
-    float* const ssblk = (float*) (smem + PS_QUADS_BYTES);
+    // (the activation quads lie IN FRONT of the gather area: a slice of more than 32 Hadamard blocks -- only the lm_head of a model wider than 4096, one slice of the whole
+    //  row -- runs up to 8 KiB into it; that op gathers nothing)
+    char* const quads = smem + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES;
+    float* const ssblk = (float*) smem;
     float* const bsum2 = ssblk + 64;                                // [2 (op parity)][64]: block sums of the rotated activations
     int* const seginfo2 = (int*) (bsum2 + 128);                     // [2 (op parity)][16][4]: j0, len0, len1 of every streaming wave's run
     uint32_t* const lctl = (uint32_t*) (seginfo2 + 128);            // the PS_C_* counters
-    float* const part = (float*) (smem + PS_QUADS_BYTES + PS_MISC_BYTES);
-    char* const pdec = smem + PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES;
-    float* const gath = (float*) (smem + PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES);      // [4 owned blocks][8 half-waves][128]
+    float* const part = (float*) (smem + PS_MISC_BYTES);
+    char* const pdec = smem + PS_MISC_BYTES + PS_PART_BYTES;
+    float* const gath = (float*) (smem + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES + PS_QUADS_BYTES);      // [4 owned blocks][8 half-waves][128]
 
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
     // the gather area (free in an o_proj op) and run into the attention area; behind them the new token's words, the waves' statistics and the rotated queries.
     struct AttItem { int h, split, t0, t1, st_tok, len, nsteps, G; bool owner; const uint32_t* kc; const half_t* ks; const uint32_t* vc; const half_t* vs; };
     struct AttWords { uint4_t k, v; half_t ks, vs; };
-    char* const att_base = smem + (PS_QUADS_BYTES + PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES);      // = the gather area
+    char* const att_base = smem + (PS_MISC_BYTES + PS_PART_BYTES + PS_PDEC_BYTES + PS_QUADS_BYTES);      // = the gather area
     half_t* const att_vt = (half_t*) att_base;                                  // [8 waves][16 * AW_VS]; after the loop: partial outputs [8][8][128] fp32 (32 KB <= 34 KB)
     uint32_t* const att_newkv = (uint32_t*) (att_base + 8 * 16 * AW_VS * 2);     // [2][16]: the new token's K / V words of this kv head
     half_t* const att_newsc = (half_t*) (att_base + 8 * 16 * AW_VS * 2 + 128);   // [2][4]: their group scales
@@ -1134,7 +1136,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 const bool act = active && shw < nb;
                 const ps_rsrc_t rb = ps_rsrc(a.rbuf);
                 const uint32_t ro_old = rver == 1 ? (uint32_t) blk * 1024u + (uint32_t) l32 * 32u
-                                                  : (uint32_t) ((rver - 1) & 1) * 32768u + (uint32_t) blk * PS_LINE_BYTES + (uint32_t) l32 * 16u;
+                                                  : (uint32_t) ((rver - 1) & 1) * PS_RROW_BYTES + (uint32_t) blk * PS_LINE_BYTES + (uint32_t) l32 * 16u;
                 uint4_t pra = { 0u, 0u, 0u, 0u }, prc = pra;
 #ifndef PS_ROLD_LATE
                 if (has_task)
@@ -1267,10 +1269,10 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     for (int i = 1; i < 32; i <<= 1) ssq += xor_lane(ssq, i);
                     if (act && (tl.flags & PS_TILE_Q_OUT))
                     {
-                        const uint32_t no = (uint32_t) (rver & 1) * 32768u + (uint32_t) blk * PS_LINE_BYTES + (uint32_t) l32 * 16u;
+                        const uint32_t no = (uint32_t) (rver & 1) * PS_RROW_BYTES + (uint32_t) blk * PS_LINE_BYTES + (uint32_t) l32 * 16u;
                         ps_st128(rb, no, uint4_t{ __float_as_uint(n0), tag_in, __float_as_uint(n1), tag_in });
                         ps_st128(rb, no + 512, uint4_t{ __float_as_uint(n2), tag_in, __float_as_uint(n3), tag_in });
-                        if (l32 == 0) ps_st128(rb, 65536u + (uint32_t) ((rver & 1) * 32 + blk) * 16u, uint4_t{ __float_as_uint(ssq), tag_in, 0u, tag_in });
+                        if (l32 == 0) ps_st128(rb, 2u * PS_RROW_BYTES + (uint32_t) ((rver & 1) * PS_MAX_ROW_BLOCKS + blk) * 16u, uint4_t{ __float_as_uint(ssq), tag_in, 0u, tag_in });
                     }
                     const half4_t xv = { f2h(n0 * (float) wv[0].x * r_last), f2h(n1 * (float) wv[0].y * r_last), f2h(n2 * (float) wv[0].z * r_last), f2h(n3 * (float) wv[0].w * r_last) };
                     rotate_store(xv, sv[0], tb, act);
@@ -1283,13 +1285,13 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 // exact RMSNorm: every workgroup reads the whole row -- service half-wave shw takes blocks shw + 8 i (block sums of squares in rms_norm's
                 // order: norm.cu:20-120) -- then rotates the blocks of its slice.  Version 0 of the row is the caller's fixed-point R; later versions are
                 // tagged fp32 lines written by the owners of the previous op's column blocks (no edge: the lines carry the producer's tag)
-                half4_t xr[4];
+                half4_t xr[PS_ROW_IT];
                 const int rver = O->rver;
                 if (rver == 0)
                 {
                     const ps_rsrc_t rR = ps_rsrc(a.R);
                     #pragma unroll
-                    for (int it = 0; it < 4; ++it)
+                    for (int it = 0; it < PS_ROW_IT; ++it)
                     {
                         xr[it] = half4_t{ 0, 0, 0, 0 };
                         if (8 * it < nblk)
@@ -1303,12 +1305,12 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 }
                 else
                 {
-                    const ps_rsrc_t rR = ps_rsrc(a.rbuf + (size_t) (rver & 1) * PS_MAX_SLICE_BLOCKS * 128);
+                    const ps_rsrc_t rR = ps_rsrc(a.rbuf + (size_t) (rver & 1) * PS_MAX_ROW_BLOCKS * 128);
                     for (int spins = 0;; ++spins)
                     {
                         bool ok = true;
                         #pragma unroll
-                        for (int it = 0; it < 4; ++it)
+                        for (int it = 0; it < PS_ROW_IT; ++it)
                         {
                             xr[it] = half4_t{ 0, 0, 0, 0 };
                             if (8 * it < nblk)
@@ -1325,7 +1327,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     }
                 }
                 #pragma unroll
-                for (int it = 0; it < 4; ++it) if (8 * it < nblk)
+                for (int it = 0; it < PS_ROW_IT; ++it) if (8 * it < nblk)
                 {
                     const int blk = shw + 8 * it;
                     const float f0 = (float) xr[it].x, f1 = (float) xr[it].y, f2 = (float) xr[it].z, f3 = (float) xr[it].w;
@@ -1341,21 +1343,29 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 { const uint32_t old = c_inc(PS_C_A); if (old + 1u == tgt_a) arrive(op); }
                 c_spin(PS_C_A, tgt_a);
                 if (sw == 0) PS_T(9);
-                float s2 = l32 < nblk ? ssblk[l32] : 0.0f;
+                float s2 = (l32 < nblk ? ssblk[l32] : 0.0f) + (l32 + 32 < nblk ? ssblk[l32 + 32] : 0.0f);
                 #pragma unroll
                 for (int i = 1; i < 32; i <<= 1) s2 += xor_lane(s2, i);
                 const float r = __frsqrt_rn(s2 / (float) kk + O->eps);
                 r_next = r;
                 #pragma unroll
-                for (int it = 0; it < 4; ++it) if (8 * it < nblk)
+                for (int it = 0; it < PS_ROW_IT; ++it) if (8 * it < nblk)
                 {
                     const int blk = shw + 8 * it;                           // the block held in xr[it]
                     const bool act = active && blk >= b0 && blk < b0 + nb;
                     if (__builtin_amdgcn_ballot_w64(act) != 0ull)           // (wave-uniform: neither half-wave holds a block of the slice -> nothing to rotate)
                     {
-                        const half4_t xv = { f2h((float) xr[it].x * (float) wv[it].x * r), f2h((float) xr[it].y * (float) wv[it].y * r),
-                                             f2h((float) xr[it].z * (float) wv[it].z * r), f2h((float) xr[it].w * (float) wv[it].w * r) };
-                        rotate_store(xv, sv[it], min(max(blk - b0, 0), max(nb - 1, 0)), act);
+                        half4_t w_ = wv[it & 3], s_ = sv[it & 3];
+                        if (it >= 4)
+                        {
+                            // (blocks 32 .. 63 of a row wider than 4096: norm weight and input scale fetched here, not ahead -- eight register pairs more per path otherwise)
+                            const int bc_ = min(blk, nblk - 1);
+                            w_ = ps_g((const half4_t*) (O->norm_w + (size_t) bc_ * 128))[l32];
+                            s_ = ps_g((const half4_t*) (suh_m + (size_t) bc_ * 128))[l32];
+                        }
+                        const half4_t xv = { f2h((float) xr[it].x * (float) w_.x * r), f2h((float) xr[it].y * (float) w_.y * r),
+                                             f2h((float) xr[it].z * (float) w_.z * r), f2h((float) xr[it].w * (float) w_.w * r) };
+                        rotate_store(xv, s_, min(max(blk - b0, 0), max(nb - 1, 0)), act);
                     }
                 }
             }
@@ -1559,13 +1569,20 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             if (in_type == PS_IN_NORM && in_direct && active)
             {
                 const ps_rsrc_t rb = ps_rsrc(a.rbuf);
-                const uint32_t go = 65536u + (uint32_t) ((O->rver & 1) * 32 + min(l32, nblk - 1)) * 16u;
+                const uint32_t go = 2u * PS_RROW_BYTES + (uint32_t) ((O->rver & 1) * PS_MAX_ROW_BLOCKS + min(l32, nblk - 1)) * 16u;
+                const uint32_t go2 = 2u * PS_RROW_BYTES + (uint32_t) ((O->rver & 1) * PS_MAX_ROW_BLOCKS + min(l32 + 32, nblk - 1)) * 16u;      // (blocks 32 .. 63 of a row wider than 4096)
                 float s2 = 0.0f;
                 for (int spins = 0;; ++spins)
                 {
                     const uint4_t g = ps_ld128(rb, go);
                     s2 = l32 < nblk ? __uint_as_float(g.x) : 0.0f;
-                    const bool ok = (g.y == tag_in) & (g.w == tag_in);
+                    bool ok = (g.y == tag_in) & (g.w == tag_in);
+                    if (nblk > 32)
+                    {
+                        const uint4_t g2 = ps_ld128(rb, go2);
+                        s2 += l32 + 32 < nblk ? __uint_as_float(g2.x) : 0.0f;
+                        ok &= (g2.y == tag_in) & (g2.w == tag_in);
+                    }
                     if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                     if (spins > slim) { ps_timeout(1u); break; }
                     __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
@@ -1794,7 +1811,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     else
                     {
                         // (tagged by whoever published version rv - 1: the owners of op - 2, or -- DIRECT -- the publishing workgroups of op - 1; the same tag)
-                        const ps_rsrc_t r0 = ps_rsrc(a.rbuf + (size_t) ((rv - 1) & 1) * PS_MAX_SLICE_BLOCKS * 128);
+                        const ps_rsrc_t r0 = ps_rsrc(a.rbuf + (size_t) ((rv - 1) & 1) * PS_MAX_ROW_BLOCKS * 128);
                         const uint32_t ro = (uint32_t) cbl * PS_LINE_BYTES + (uint32_t) l * 16u, tag_old = (epoch << 12) | (uint32_t) (op - 1);
                         for (int spins = 0;; ++spins)
                         {
@@ -1819,7 +1836,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     const half4_t sc = jj == shw ? scp[0] : scp[1];
                     const float n0 = rold.x + h0 * (float) sc.x, n1 = rold.y + h1 * (float) sc.y, n2 = rold.z + h2 * (float) sc.z, n3 = rold.w + h3 * (float) sc.w;
                     if (sw != 0) c_spin(PS_C_G, (uint32_t) (op + 1));
-                    const ps_rsrc_t rn = ps_rsrc(a.rbuf + (size_t) (rv & 1) * PS_MAX_SLICE_BLOCKS * 128);
+                    const ps_rsrc_t rn = ps_rsrc(a.rbuf + (size_t) (rv & 1) * PS_MAX_ROW_BLOCKS * 128);
                     const uint32_t no = (uint32_t) cbl * PS_LINE_BYTES + (uint32_t) l * 16u;
                     ps_st128(rn, no, uint4_t{ __float_as_uint(n0), tag_out, __float_as_uint(n1), tag_out });
                     ps_st128(rn, no + 512, uint4_t{ __float_as_uint(n2), tag_out, __float_as_uint(n3), tag_out });

@@ -808,8 +808,12 @@ class SyntheticEXL3Llama:
         same = same and len(ks) <= 2 and ks[-1] - ks[0] <= 1 and (self.lm_head.K == 6 or (len(ks) == 1 and self.lm_head.K == ks[0]))
         # with the attention core: inside the step (exl3_pstep.cuh: PS_ATTN) for at most 8 query heads per 128-value kv block
         att_ok = (not self.with_attention) or ((self.hq // self.hkv) * (128 // s.head_dim) <= 8 and os.environ.get("EXL3_HIP_PSTEP_ATTN", "1") != "0")
-        return (self._state_bsz == 1 and self.tp == 1 and att_ok and self.kv_bits == 4 and same
-                and s.hidden % 128 == 0 and s.hidden <= 4096 and s.head_dim in (64, 128) and self.use_qkv_tab)
+        # one rank -- or ONE rank's compute leg of a tensor-parallel job with the exchange left out (tp.OneRankOfMany: bench.py's llama-3.1-70b_tp8_rank line; a real TP
+        # rank needs its peers' partial lines pushed into the step's slab buffers: not built)
+        from .tp import OneRankOfMany
+        one_rank = self.tp == 1 or isinstance(self.backend, OneRankOfMany)
+        return (self._state_bsz == 1 and one_rank and att_ok and self.kv_bits == 4 and same
+                and s.hidden % 128 == 0 and s.hidden <= 8192 and s.head_dim in (64, 128) and self.use_qkv_tab)
 
     def decode_step_persistent(self):
         """The whole decode step as ONE launch (ext.PersistentStep / exl3_pstep.hip) behind the step's set-up launch (fx_init_prep: fixed-point copy of the

@@ -514,3 +514,61 @@ def test_persistent_step_time_out_poisons_the_logits_and_drains_quickly(dev):
     assert not m._pstep.error_peek()
     assert np.array_equal(_np(m.decode_step_persistent().float()), good)
     assert not m._pstep.error()
+
+
+@pytest.mark.parametrize("K,head_K,with_attention", [(3, 6, False), (4, None, False), (3, 6, True)])
+def test_persistent_step_rows_wider_than_4096_vs_oracle(dev, K, head_K, with_attention):
+    """hidden 8192 (Llama-3.1-70B's width; round 6: the residual row may have 64 Hadamard blocks -- eight per service half-wave in the exact RMSNorm of the first op and the
+    lm_head, two sum-of-squares granules per lane on the direct row edges, the lm_head's one 64-block slice of activation quads running into the gather area of the LDS map):
+    two layers + a 4096-column head against the oracle composition (3e-2) and decode_step_fx (2e-2); replay == eager; no time-out."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+    ext.set_gemv_variant(1)
+    shape = LlamaShape("wide-8192", 8192, 3584, 2, 16, 2, 128, 4096)
+    m = SyntheticEXL3Llama(shape, K=K, cb=2, device=dev, kv_bits=4, max_ctx=1024, head_K=head_K)
+    m.alloc_state(1, pos=300)
+    m.with_attention = with_attention
+    assert m.persistent_applies()
+    if not with_attention:
+        ref = _oracle_decode(m, _np(m.x0))
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    lf = _np(m.decode_step_fx().float()).copy()
+    kv_f = [(_np(c).copy(), _np(s_).copy()) for c, s_ in m.kcache + m.vcache]
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    lp = _np(m.decode_step_persistent().float()).copy()
+    assert m._pstep is not None and not m._pstep.error()
+    assert np.isfinite(lp).all() and _relerr(lp, lf) < 2e-2, _relerr(lp, lf)
+    if not with_attention:
+        assert _relerr(lp, ref) < 3e-2, _relerr(lp, ref)
+    page, slot = int(m.block_table[0, 300 // m.page]), 300 % m.page
+    for (wa, sa), (c, s_) in zip(kv_f, m.kcache + m.vcache):
+        _kv_rows_match_in_levels(wa[page, slot], sa[page, slot], _np(c[page, slot]), _np(s_[page, slot]), 0.02)
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    _replay_equals(m.decode_step_persistent, m, lp, reps=3)
+    assert not m._pstep.error()
+
+
+def test_persistent_step_on_one_rank_of_a_70b_tp8_job_without_the_exchange(dev):
+    """ONE rank's shards of Llama-3.1-70B at 3 bpw under TP = 8 (q 8192 -> 1024, k / v 8192 -> 128, o 1024 -> 8192, gate / up 8192 -> 3584, down 3584 -> 8192, a 16128-column
+    head shard) with the collectives left out (tp.OneRankOfMany: bench.py's llama-3.1-70b_tp8_rank line measures this compute leg): the persistent step over the rank's
+    tensors against the launch-per-op TP branch (decode_step_fx under TP, exchange left out the same way) -- logits 2e-2, appended rows level by level; replay == eager."""
+    from exllamav3_amd import ext
+    from exllamav3_amd.llama_path import SHAPES, SyntheticEXL3Llama
+    from exllamav3_amd.tp import OneRankOfMany
+    ext.set_gemv_variant(1)
+    m = SyntheticEXL3Llama(SHAPES["llama-3.1-70b"], K=3, cb=2, device=dev, backend=OneRankOfMany(8, dev), kv_bits=4, max_ctx=1024, layers=3)
+    m.alloc_state(1, pos=300)
+    assert m.tp == 8 and m.hq == 8 and m.hkv == 1 and m.persistent_applies()
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    lf = _np(m.decode_step_fx().float()).copy()
+    kv_f = [(_np(c).copy(), _np(s_).copy()) for c, s_ in m.kcache + m.vcache]
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    lp = _np(m.decode_step_persistent().float()).copy()
+    assert m._pstep is not None and not m._pstep.error()
+    assert np.isfinite(lp).all() and _relerr(lp, lf) < 2e-2, _relerr(lp, lf)
+    page, slot = int(m.block_table[0, 300 // m.page]), 300 % m.page
+    for (wa, sa), (c, s_) in zip(kv_f, m.kcache + m.vcache):
+        _kv_rows_match_in_levels(wa[page, slot], sa[page, slot], _np(c[page, slot]), _np(s_[page, slot]), 0.02)
+    for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+    _replay_equals(m.decode_step_persistent, m, lp, reps=3)
+    assert not m._pstep.error()
