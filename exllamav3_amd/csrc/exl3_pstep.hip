@@ -63,7 +63,13 @@ bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_t
         if (p.wmax > 12) continue;                                          // a streaming wave's run crosses at most one column-block boundary
         if (out_type == PS_OUT_ATOMIC && p.wmax > 4) continue;             // an owner workgroup gathers at most four blocks of the residual row
         p.hmax = 4 * nbmax;
-        const double cost = (double) p.wmax * p.hmax + 0.2 * S;
+        // cost in work units (~ 0.1 us of a CU's streaming each): the rectangle's units beyond what the waves decode ahead while the input is on its way (those are free), plus
+        // what the CONSUMER pays to gather this op's S partial lines per block -- one more round trip per eight lines (EXL3_HIP_PSTEP_COST=0: the round-5 cost, the
+        // largest rectangle alone)
+        static const int cost_model = getenv("EXL3_HIP_PSTEP_COST") ? atoi(getenv("EXL3_HIP_PSTEP_COST")) : 1;
+        const int units = p.wmax * p.hmax;
+        const double cost = cost_model == 0 ? (double) units + 0.2 * S
+                                            : (double) (units > 30 ? units - 30 : 0) + 6.0 * ((S + 7) / 8) + 0.05 * S + 0.05 * units;
         if (cost < best_cost) { best_cost = cost; best = p; found = true; }
     }
     return found;
