@@ -149,6 +149,9 @@ def _declare(l):
     sig("exl3_pstep_error_peek", vp)
     sig("exl3_pstep_attn_geometry", vp, i32, ctypes.POINTER(i32))
     sig("exl3_pstep_unpack_op", vp, i32, i32, vp, vp)
+    sig("exl3_pstep_tp_handle", vp, vp)
+    sig("exl3_pstep_tp_open_peer", vp, i32, vp)
+    sig("exl3_pstep_tp_commit", vp)
     sig("exl3_pstep_set", vp, i32, i32)
     sig("exl3_pstep_describe", vp, ctypes.c_char_p, i32)
     sig("exl3_pstep_destroy", vp)

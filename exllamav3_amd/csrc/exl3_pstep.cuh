@@ -74,7 +74,13 @@ struct PsOp
                                        // words -- so that every streaming wave reads ONE contiguous run (re-ordering tiles at load time is a legal
                                        // one-time transform; exl3_pstep_create permutes on the device, exl3_pstep_unpack_op inverts it for the bit-exactness test)
     int K, cb;                         // bits per weight and codebook of THIS op's matrices (a qgroup shares both: conversion/allocation.py:131-141 bumps whole qgroups)
-    int pad_[12];
+    // tensor parallelism inside the step (round 6; model/model_tp_backend.py:119-126, modules/attn.py:547, modules/mlp.py:770: the all-reduce behind o_proj / down_proj).
+    // A row-sharded op's partial row is pushed into every rank's EXCHANGE BUFFER (fine-grained memory, IPC-mapped by the peers: PsArgs::err + 4 holds the table of the
+    // ranks' base addresses) at byte offset xoff: line (column block, line0 + slice) of S_all = tp_world x S lines per block.  Consumers sum the S_all lines in index order:
+    // the same bits on every rank.
+    int S_all, line0, tp_world, pad0_;
+    long long xoff;
+    int pad_[6];
 };
 static_assert(sizeof(PsOp) == 320, "PsOp: five 64-byte lines (the service waves prefetch the next op's descriptor line by line)");
 
@@ -106,7 +112,8 @@ struct PsArgs
     uint32_t* cnt;                    // [nops][8 shards][16 words]: arrivals of edge `op`, zero at launch
     uint32_t* epoch;                  // run counter in device memory (tags of the slab granules): read at entry, + 1 at exit
     uint32_t* err;                    // sticky: bit 0 = an edge timed out, bit 1 = a tagged slab line never arrived (results invalid); words 2..3: the address of the pinned
-                                      // host mirror (set to 1 by the wave that times out: a caller reads it without synchronising) or null
+                                      // host mirror (set to 1 by the wave that times out: a caller reads it without synchronising) or null; words 4..5: the address of the table of the tensor-parallel
+                                      // ranks' exchange buffers (device memory, tp_world x 8 B) or null
     unsigned long long* dbg;          // optional phase stamps [nops][ncu][PS_DBG_SLOTS] (100 MHz)
     int spin_limit, pmax;
     const int* runs;                  // the ops in runs of equal bits per weight: { end op, K } pairs (the streaming waves' loop is instantiated per width)

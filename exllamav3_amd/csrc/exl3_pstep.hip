@@ -17,6 +17,7 @@ struct PsHandle
 {
     int K, K2, KH, cb, nops, ncu, pmax, spin_limit, n_layers;
     const PsKernelSet* kset; int* d_runs;
+    int tp_world, tp_rank; char* d_xbuf; size_t xbuf_bytes; unsigned long long* d_peers; void* peer_ptr[8];      // tensor parallelism inside the step: this rank's exchange buffer, the ranks' mapped buffers
     PsOp* d_ops; PsTile* d_tiles; uint32_t* d_cnt; uint32_t* d_err; unsigned long long* d_dbg;
     unsigned long long* d_slab_a; unsigned long long* d_slab_b; unsigned long long* d_slab_c; unsigned long long* d_slab_d; unsigned long long* d_rbuf; uint32_t* d_epoch;
     unsigned long long* d_att_rec; unsigned long long* d_att_stats; int attn;
@@ -31,11 +32,11 @@ struct PsHandle
 struct OpPlan { int S; int g[PS_MAX_MATS]; int G; int wmax, hmax; };
 
 // groups x slices for one op: minimise the largest rectangle (in work units = 2 tile rows x 128 columns); ties -> fewer slices (fewer adds per address / slab lines)
-bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_type, OpPlan& best, bool direct = false)
+bool plan_op(int ncu, int nblk, const int* ncb, int nmat, int in_type, int out_type, OpPlan& best, bool direct = false, int max_S = 32)
 {
     double best_cost = 1e30; bool found = false;
     int total_cb = 0; for (int i = 0; i < nmat; ++i) total_cb += ncb[i];
-    for (int S = 1; S <= nblk && S <= 32; ++S)
+    for (int S = 1; S <= nblk && S <= max_S; ++S)
     {
         if (out_type == PS_OUT_FINAL && S != 1) continue;
         const int nbmax = (nblk + S - 1) / S;
@@ -197,11 +198,19 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     EXL3_CHECK_ARG(rope_mode == 1 || rope_mode == 2, "exl3_pstep_create: rope_mode 1 (GPT-J) | 2 (NeoX)");
     int dev = 0; EXL3_CHECK_HIP(hipGetDevice(&dev), "hipGetDevice");
     hipDeviceProp_t prop; EXL3_CHECK_HIP(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
-    const int ncu = prop.multiProcessorCount;
+    int ncu = prop.multiProcessorCount;
+    // (test hook: EXL3_HIP_PSTEP_NCU plans for fewer CUs than the device has -- two tensor-parallel ranks sharing ONE GPU, each launching on a stream whose CU mask
+    //  holds that many CUs, so that both grids are co-resident: tests/test_gpu_pstep_tp.py)
+    if (const char* e = getenv("EXL3_HIP_PSTEP_NCU")) { const int v = atoi(e); if (v >= 16 && v <= ncu) ncu = v; }
     EXL3_CHECK_ARG(ncu >= 16, "exl3_pstep_create: device has %d CUs", ncu);
     const int qdim = heads_q * head_dim, kvdim = heads_kv * head_dim, kvb = kvdim / 128;
     const int nops = 4 * n_layers + 1;
     EXL3_CHECK_ARG(nops < 4095, "exl3_pstep_create: %d ops: the tags of the step's lines carry the producer op in 12 bits (at most 1023 layers)", nops);
+    // ---- tensor parallelism inside the step (flags bits 12..15 = ranks, 16..19 = this rank; the tensors passed are THIS rank's shards: q / k / v / gate / up column shards,
+    // o / down row shards, an lm_head column shard; heads_q / heads_kv are the rank's; hidden is the model's).  The all-reduce behind o_proj / down_proj
+    // (model/model_tp_backend.py:119-126) happens on the step's row edges: every rank pushes its partial lines into every rank's exchange buffer.
+    const int tpw = ((flags >> 12) & 0xf) > 1 ? ((flags >> 12) & 0xf) : 1, tpr = (flags >> 16) & 0xf;
+    EXL3_CHECK_ARG(tpw <= 8 && tpr < tpw, "exl3_pstep_create: tensor-parallel rank %d of %d", tpr, tpw);
     // ---- bits per weight / codebook per op.  The tensors of one fused linear share both (a reference qgroup is quantized as one: modules/attn.py:244-308,
     // modules/mlp.py:537-574); the fused linears of the layers may have TWO adjacent widths (a fractional-bpw checkpoint: conversion/allocation.py:131-141 bumps whole
     // qgroups by one bit), the lm_head its own (flags bits 8..11 when its tensor does not say), one codebook for everything
@@ -318,7 +327,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
             O.in_svh[0] = (const half_t*) L.q.svh; O.in_svh[1] = (const half_t*) L.k.svh; O.in_svh[2] = (const half_t*) L.v.svh;
             O.k_cache = (uint32_t*) L.k_cache; O.k_scales = (half_t*) L.k_scales; O.v_cache = (uint32_t*) L.v_cache; O.v_scales = (half_t*) L.v_scales;
             const int ncb[1] = { hidden / 128 };
-            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, qdim / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for o_proj");
+            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, qdim / 128, ncb, 1, O.in_type, O.out_type, p, false, 32 / tpw), "exl3_pstep_create: no plan for o_proj");
             O.S = p.S; add_tiles(op, p, ncb, 1, qdim / 128, attn ? att_blocks * att_nsplit : 2 * kvb);      // side: K / V append tasks, or (PS_ATTN) attention items h * nsplit + s
             if (attn)
             {
@@ -327,7 +336,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
                 A->rec = nullptr; A->stats = nullptr; A->gq = att_gq; A->nsplit = att_nsplit; A->hq = heads_q; A->hkv = heads_kv;      // (buffers: below)
             }
             O.rver = ++rver; O.gate_op = direct ? op - 1 : (rver >= 3 ? reader_of_version[rver - 2] : -1);       // (direct: the last readers of the lines an owner overwrites are the op before it)
-            { Pending f; f.op = op; f.which = 2; f.off[0] = 0; f.parity = 0; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * 128; if (n > slab_c_floats) slab_c_floats = n; }
+            { Pending f; f.op = op; f.which = 2; f.off[0] = 0; f.parity = li & 1; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * tpw * 128; if (n > slab_c_floats) slab_c_floats = n; }
             if (li == 0) { snprintf(line, sizeof(line), "o: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
             ++op;
         }
@@ -357,10 +366,10 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
             lin_to_mat(L.down, O.mat[0]);
             O.in_svh[0] = (const half_t*) L.gate.svh; O.in_svh[1] = (const half_t*) L.up.svh;
             const int ncb[1] = { hidden / 128 };
-            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, inter / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for down_proj");
+            OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, inter / 128, ncb, 1, O.in_type, O.out_type, p, false, 32 / tpw), "exl3_pstep_create: no plan for down_proj");
             O.S = p.S; add_tiles(op, p, ncb, 1, inter / 128, 0);
             O.rver = ++rver; O.gate_op = direct ? op - 1 : (rver >= 3 ? reader_of_version[rver - 2] : -1);
-            { Pending f; f.op = op; f.which = 3; f.off[0] = 0; f.parity = 0; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * 128; if (n > slab_d_floats) slab_d_floats = n; }
+            { Pending f; f.op = op; f.which = 3; f.off[0] = 0; f.parity = li & 1; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * tpw * 128; if (n > slab_d_floats) slab_d_floats = n; }
             if (li == 0) { snprintf(line, sizeof(line), "down: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
             ++op;
         }
@@ -379,7 +388,8 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     }
 
     PsHandle* h = new PsHandle();
-    h->K = K; h->K2 = K2; h->KH = KH; h->cb = cb_all; h->kset = kset; h->d_runs = nullptr; h->nops = nops; h->ncu = ncu; h->pmax = 3; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
+    h->K = K; h->K2 = K2; h->KH = KH; h->cb = cb_all; h->kset = kset; h->d_runs = nullptr; h->nops = nops;
+    h->tp_world = tpw; h->tp_rank = tpr; h->d_xbuf = nullptr; h->xbuf_bytes = 0; h->d_peers = nullptr; for (int i = 0; i < 8; ++i) h->peer_ptr[i] = nullptr; h->ncu = ncu; h->pmax = 3; h->spin_limit = 1 << 17; h->n_layers = n_layers; h->desc = desc;
     h->d_att_rec = nullptr; h->d_att_stats = nullptr; h->attn = attn ? 1 : 0; h->d_repack = nullptr; h->repack_words = 0; h->h_err = nullptr;
     h->d_ops = nullptr; h->d_tiles = nullptr; h->d_cnt = nullptr; h->d_err = nullptr; h->d_dbg = nullptr; h->d_slab_a = nullptr; h->d_slab_b = nullptr; h->d_slab_c = nullptr; h->d_slab_d = nullptr; h->d_rbuf = nullptr; h->d_epoch = nullptr;
     h->cnt_bytes = (size_t) nops * 8 * 16 * 4; h->dbg_words = (flags & 1) ? (size_t) nops * ncu * PS_DBG_SLOTS : 0;
@@ -391,8 +401,22 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     //  has published o_proj's partial rows, and with direct row edges nothing orders that read against layer i + 1's q|k|v writers: they now write the other set)
     PS_TRY(hipMalloc(&h->d_slab_a, 2 * slab_a_floats * 8)); PS_TRY(hipMalloc(&h->d_slab_b, slab_b_floats * 8));
     PS_TRY(hipMemset(h->d_slab_a, 0, 2 * slab_a_floats * 8)); PS_TRY(hipMemset(h->d_slab_b, 0, slab_b_floats * 8));
-    PS_TRY(hipMalloc(&h->d_slab_c, slab_c_floats * 8)); PS_TRY(hipMalloc(&h->d_slab_d, slab_d_floats * 8));
-    PS_TRY(hipMemset(h->d_slab_c, 0, slab_c_floats * 8)); PS_TRY(hipMemset(h->d_slab_d, 0, slab_d_floats * 8));
+    if (tpw > 1)
+    {
+        // the EXCHANGE BUFFER of a tensor-parallel rank: the partial lines of o_proj and down_proj of ALL ranks ([column block][rank x S + slice] per op kind), one
+        // fine-grained allocation (peer GPUs write it while this rank's kernel reads it) that the peers map through its IPC handle (exl3_pstep_tp_handle / _open_peer)
+        h->xbuf_bytes = 2 * (slab_c_floats + slab_d_floats) * 8;
+        PS_TRY(hipExtMallocWithFlags((void**) &h->d_xbuf, h->xbuf_bytes, hipDeviceMallocFinegrained));
+        PS_TRY(hipMemset(h->d_xbuf, 0, h->xbuf_bytes));
+        PS_TRY(hipMalloc(&h->d_peers, 8 * sizeof(unsigned long long))); PS_TRY(hipMemset(h->d_peers, 0, 8 * sizeof(unsigned long long)));
+        h->peer_ptr[tpr] = h->d_xbuf;
+    }
+    else
+    {
+        // (two sets each, alternating by layer, like the q|k|v lines: a rank may be a layer ahead of the slowest reader of a peer)
+        PS_TRY(hipMalloc(&h->d_slab_c, 2 * slab_c_floats * 8)); PS_TRY(hipMalloc(&h->d_slab_d, 2 * slab_d_floats * 8));
+        PS_TRY(hipMemset(h->d_slab_c, 0, 2 * slab_c_floats * 8)); PS_TRY(hipMemset(h->d_slab_d, 0, 2 * slab_d_floats * 8));
+    }
     PS_TRY(hipMalloc(&h->d_rbuf, (size_t) PS_RBUF_BYTES)); PS_TRY(hipMemset(h->d_rbuf, 0, (size_t) PS_RBUF_BYTES));
     if (attn)
     {
@@ -404,7 +428,11 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
     for (const Pending& f : slab_fix)
     {
         PsOp& O = ops[f.op];
-        unsigned long long* base = f.which == 0 ? h->d_slab_a + (size_t) f.parity * slab_a_floats : f.which == 1 ? h->d_slab_b : f.which == 2 ? h->d_slab_c : h->d_slab_d;
+        unsigned long long* const xc = tpw > 1 ? (unsigned long long*) h->d_xbuf : h->d_slab_c;
+        unsigned long long* const xd = tpw > 1 ? (unsigned long long*) h->d_xbuf + 2 * slab_c_floats : h->d_slab_d;
+        unsigned long long* base = f.which == 0 ? h->d_slab_a + (size_t) f.parity * slab_a_floats : f.which == 1 ? h->d_slab_b
+                                 : f.which == 2 ? xc + (size_t) f.parity * slab_c_floats : xd + (size_t) f.parity * slab_d_floats;
+        if (f.which >= 2) O.xoff = (long long) ((const char*) base - (const char*) (tpw > 1 ? (unsigned long long*) h->d_xbuf : base));
         for (int i = 0; i < O.nmat; ++i) O.mat[i].slab = base + f.off[i];
         if (f.which >= 2)
         {
@@ -416,6 +444,14 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
         for (int i = 0; i < O.nmat; ++i) C.in_slab[i] = base + f.off[i];
     }
     for (int i = 0; i < nops; ++i) { ops[i].K = opK[(size_t) i]; ops[i].cb = cb_all; ops[i].Bp = nullptr; }
+    // lines per column block of every op's output, and what its consumer gathers: tp_world x S for the row shards (o_proj, down_proj) of a tensor-parallel rank
+    for (int i = 0; i < nops; ++i)
+    {
+        PsOp& O = ops[i];
+        const bool row_shard = tpw > 1 && (O.out_type & 0xff) == PS_OUT_ATOMIC;
+        O.tp_world = tpw; O.S_all = row_shard ? O.S * tpw : O.S; O.line0 = row_shard ? tpr * O.S : 0;
+        if (row_shard && (O.out_type & PS_DIRECT)) ops[i + 1].S_in = O.S_all;
+    }
     // runs of equal width for the streaming waves: { end op, K } pairs (+ a terminator)
     std::vector<int> runs;
     for (int i = 0; i < nops; ++i) if (i + 1 == nops || opK[(size_t) i + 1] != opK[(size_t) i]) { runs.push_back(i + 1); runs.push_back(opK[(size_t) i]); }
@@ -555,6 +591,42 @@ extern "C" int exl3_pstep_error_peek(void* handle)
     return h->h_err && ((volatile uint32_t*) h->h_err)[0] ? 1 : 0;
 }
 
+// ---- tensor parallelism inside the step: the ranks exchange the IPC handles of their exchange buffers (64 bytes each, over the process group), map the peers' and commit.
+// Every rank must then run the same sequence of steps (a step's lines carry the run epoch: the ranks' epochs advance together).
+extern "C" int exl3_pstep_tp_handle(void* handle, void* handle64_out)
+{
+    PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h && handle64_out && h->tp_world > 1 && h->d_xbuf, "exl3_pstep_tp_handle: the plan was not created as a tensor-parallel rank (flags bits 12..19)");
+    hipIpcMemHandle_t ih;
+    EXL3_CHECK_HIP(hipIpcGetMemHandle(&ih, h->d_xbuf), "exl3_pstep_tp_handle: hipIpcGetMemHandle");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    memcpy(handle64_out, &ih, 64);
+    return EXL3_OK;
+}
+
+extern "C" int exl3_pstep_tp_open_peer(void* handle, int peer_rank, const void* handle64)
+{
+    PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h && handle64 && h->tp_world > 1 && peer_rank >= 0 && peer_rank < h->tp_world && peer_rank != h->tp_rank && !h->peer_ptr[peer_rank], "exl3_pstep_tp_open_peer: bad arguments");
+    hipIpcMemHandle_t ih; memcpy(&ih, handle64, 64);
+    void* p = nullptr;
+    EXL3_CHECK_HIP(hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess), "exl3_pstep_tp_open_peer: hipIpcOpenMemHandle");
+    h->peer_ptr[peer_rank] = p;
+    return EXL3_OK;
+}
+
+// all peers mapped: the table of the ranks' buffers goes to the device (behind the error word: PsArgs::err + 4).  The caller barriers the ranks AFTER this and before the first step.
+extern "C" int exl3_pstep_tp_commit(void* handle)
+{
+    PsHandle* h = (PsHandle*) handle;
+    EXL3_CHECK_ARG(h && h->tp_world > 1, "exl3_pstep_tp_commit: not a tensor-parallel plan");
+    unsigned long long tab[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int r = 0; r < h->tp_world; ++r) { EXL3_CHECK_ARG(h->peer_ptr[r], "exl3_pstep_tp_commit: rank %d's exchange buffer is not mapped", r); tab[r] = (unsigned long long) h->peer_ptr[r]; }
+    EXL3_CHECK_HIP(hipMemcpy(h->d_peers, tab, sizeof(tab), hipMemcpyHostToDevice), "exl3_pstep_tp_commit: hipMemcpy");
+    EXL3_CHECK_HIP(hipMemcpy((char*) h->d_err + 16, &h->d_peers, 8, hipMemcpyHostToDevice), "exl3_pstep_tp_commit: hipMemcpy");
+    return EXL3_OK;
+}
+
 // the attention item's geometry at a sequence length (host restatement of att_nse / att_make of the kernel): out3 = { splits in use, tokens per split, 128-token steps per split }
 extern "C" int exl3_pstep_attn_geometry(void* handle, int len, int* out3)
 {
@@ -627,6 +699,9 @@ extern "C" int exl3_pstep_destroy(void* handle)
     if (h->d_slab_d) (void) hipFree(h->d_slab_d);
     if (h->d_rbuf) (void) hipFree(h->d_rbuf);
     if (h->d_repack) (void) hipFree(h->d_repack);
+    for (int i = 0; i < 8; ++i) if (h->peer_ptr[i] && i != h->tp_rank) (void) hipIpcCloseMemHandle(h->peer_ptr[i]);
+    if (h->d_xbuf) (void) hipFree(h->d_xbuf);
+    if (h->d_peers) (void) hipFree(h->d_peers);
     if (h->d_runs) (void) hipFree(h->d_runs);
     if (h->h_err) (void) hipHostFree(h->h_err);
     delete h;

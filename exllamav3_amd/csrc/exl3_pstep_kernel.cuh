@@ -66,8 +66,16 @@ __device__ __forceinline__ unsigned long long ps_ld64(const void* p) { return __
 // 16-byte agent-scope loads / stores: raw buffer instructions with the sc1 bit (aux = 16 on gfx950); the compiler tracks their wait counts
 typedef __amdgpu_buffer_rsrc_t ps_rsrc_t;
 __device__ __forceinline__ ps_rsrc_t ps_rsrc(const void* base) { return __builtin_amdgcn_make_buffer_rsrc((void*) base, 0, 0x7ffffff0, 0x00020000); }
-__device__ __forceinline__ uint4_t ps_ld128(ps_rsrc_t r, uint32_t byte_off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int) byte_off, 0, 16); }
-__device__ __forceinline__ void ps_st128(ps_rsrc_t r, uint32_t byte_off, uint4_t v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int) byte_off, 0, 16); }
+// (PS_SCOPE_AUX: 16 = sc1, agent scope; 17 = sc0 | sc1, system scope -- what lines pushed into a PEER GPU's buffer and read from a buffer peers push into need)
+#ifndef PS_SCOPE_AUX
+#define PS_SCOPE_AUX 16
+#endif
+__device__ __forceinline__ uint4_t ps_ld128(ps_rsrc_t r, uint32_t byte_off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int) byte_off, 0, PS_SCOPE_AUX); }
+__device__ __forceinline__ void ps_st128(ps_rsrc_t r, uint32_t byte_off, uint4_t v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int) byte_off, 0, PS_SCOPE_AUX); }
+// ... and the system-scope pair (sc0 | sc1) for the lines of a tensor-parallel plan: a partial row is pushed into EVERY rank's exchange buffer (its own included) over the
+// IPC-mapped addresses, and the consumer reads a buffer that peer GPUs write while its kernel runs (fine-grained memory: exl3_pstep.hip)
+__device__ __forceinline__ uint4_t ps_ld128_sys(ps_rsrc_t r, uint32_t byte_off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int) byte_off, 0, 17); }
+__device__ __forceinline__ void ps_st128_sys(ps_rsrc_t r, uint32_t byte_off, uint4_t v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, (int) byte_off, 0, 17); }
 
 // Slab lines are TAGGED: a line = 128 values = 64 granule pairs of 16 bytes { v0, tag, v1, tag }, each written by ONE 16-byte agent-scope store; lane l of the
 // writing half-wave owns values 4l..4l+3 = pair l ({4l, 4l+1}) and pair 32 + l ({4l+2, 4l+3}), so a store / load instruction covers 512 contiguous bytes.
@@ -83,6 +91,7 @@ __device__ __forceinline__ void ps_st128(ps_rsrc_t r, uint32_t byte_off, uint4_t
 #define PS_PLINE_BYTES 512
 struct PsPl { uint4_t a; };
 __device__ __forceinline__ PsPl ps_pl_load(ps_rsrc_t r, uint32_t line_off, int l) { PsPl p; p.a = ps_ld128(r, line_off + (uint32_t) l * 16); return p; }
+__device__ __forceinline__ PsPl ps_pl_load_x(ps_rsrc_t r, uint32_t line_off, int l, bool sys) { PsPl p; p.a = sys ? ps_ld128_sys(r, line_off + (uint32_t) l * 16) : ps_ld128(r, line_off + (uint32_t) l * 16); return p; }
 __device__ __forceinline__ bool ps_pl_ok(const PsPl& p, uint32_t tag) { return (p.a.y == tag) & (p.a.w == tag); }
 __device__ __forceinline__ float4_t ps_pl_val(const PsPl& p, uint32_t mask = 0xffffffffu)
 {
@@ -92,6 +101,10 @@ __device__ __forceinline__ float4_t ps_pl_val(const PsPl& p, uint32_t mask = 0xf
 __device__ __forceinline__ void ps_pl_store(ps_rsrc_t r, uint32_t line_off, int l, float4_t v, uint32_t tag)
 {
     ps_st128(r, line_off + (uint32_t) l * 16, uint4_t{ half2_as_u32(half2_t{ f2h(v.x), f2h(v.y) }), tag, half2_as_u32(half2_t{ f2h(v.z), f2h(v.w) }), tag });
+}
+__device__ __forceinline__ void ps_pl_store_sys(ps_rsrc_t r, uint32_t line_off, int l, float4_t v, uint32_t tag)
+{
+    ps_st128_sys(r, line_off + (uint32_t) l * 16, uint4_t{ half2_as_u32(half2_t{ f2h(v.x), f2h(v.y) }), tag, half2_as_u32(half2_t{ f2h(v.z), f2h(v.w) }), tag });
 }
 #else
 #define PS_PLINE_BYTES 1024
@@ -110,14 +123,14 @@ __device__ __forceinline__ void ps_pl_store(ps_rsrc_t r, uint32_t line_off, int 
 #endif
 
 template <int NB>
-__device__ __forceinline__ float4_t ps_slab_sum(ps_rsrc_t r, uint32_t blk_off, int S, int l, uint32_t tag, bool& ok)
+__device__ __forceinline__ float4_t ps_slab_sum(ps_rsrc_t r, uint32_t blk_off, int S, int l, uint32_t tag, bool& ok, bool sys = false)
 {
     float4_t v = { 0.f, 0.f, 0.f, 0.f };
     for (int s = 0; s < S; s += NB)
     {
         PsPl t[NB];
         #pragma unroll
-        for (int i = 0; i < NB; ++i) t[i] = ps_pl_load(r, blk_off + (uint32_t) min(s + i, S - 1) * PS_PLINE_BYTES, l);
+        for (int i = 0; i < NB; ++i) t[i] = ps_pl_load_x(r, blk_off + (uint32_t) min(s + i, S - 1) * PS_PLINE_BYTES, l, sys);
         #pragma unroll
         for (int i = 0; i < NB; ++i) if (s + i < S)
         {
@@ -1083,7 +1096,10 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
 
             // the output side's operands too (pointers, the column scales of the two column blocks this half-wave may finish): requested here, used after the streaming
             const ps_mat_p Mo = &O->mat[active ? tl.mat : 0];
-            unsigned long long* const slab_p = Mo->slab; const half_t* const svh_p = Mo->svh; const int S_op = O->S;
+            // (S_op: partial lines per column block of this op's output; a tensor-parallel rank's own lines are line0 .. line0 + S - 1 of the tp_world x S, and every
+            //  rank's exchange buffer receives them: exl3_pstep.cuh)
+            unsigned long long* const slab_p = Mo->slab; const half_t* const svh_p = Mo->svh; const int S_op = O->S_all;
+            const int tpw = O->tp_world; const bool tp_sys = tpw > 1;
             half4_t scp[2];
             #pragma unroll
             for (int r2 = 0; r2 < 2; ++r2)
@@ -1153,7 +1169,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     for (int spins = 0;; ++spins)
                     {
                         bool ok = true;
-                        ys_own = ps_slab_sum<8>(rp, (uint32_t) blk_o * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok);
+                        ys_own = ps_slab_sum<8>(rp, (uint32_t) blk_o * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok, tp_sys);
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                         if (spins > slim) { ps_timeout(8u); break; }
                         __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
@@ -1184,7 +1200,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             for (int i = 0; i < NSLOT; ++i)
                             {
                                 const int jj = r * bpr + (two ? (i >> 1) : (i >> 2)), s_ = shw + 8 * (two ? (i & 1) : (i & 3));
-                                t[i] = ps_pl_load(rp, ((uint32_t) (b0 + min(jj, nb - 1)) * (uint32_t) S_p + (uint32_t) min(s_, S_p - 1)) * PS_PLINE_BYTES, l32);
+                                t[i] = ps_pl_load_x(rp, ((uint32_t) (b0 + min(jj, nb - 1)) * (uint32_t) S_p + (uint32_t) min(s_, S_p - 1)) * PS_PLINE_BYTES, l32, tp_sys);
                             }
                             #pragma unroll
                             for (int q = 0; q < NSLOT / 2; ++q) acc[q] = float4_t{ 0.f, 0.f, 0.f, 0.f };
@@ -1627,7 +1643,19 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     {
                         v.x = halves(v.x); v.y = halves(v.y); v.z = halves(v.z); v.w = halves(v.w);
                         v.x = (v.x * kinv_s + bb_s) * fac_norm; v.y = (v.y * kinv_s + bb_s) * fac_norm; v.z = (v.z * kinv_s + bb_s) * fac_norm; v.w = (v.w * kinv_s + bb_s) * fac_norm;
-                        if (!hi) ps_pl_store(rsl, ((uint32_t) (tl.cb0 + j) * (uint32_t) S_op + (uint32_t) tl.slice) * PS_PLINE_BYTES, l, v, tag_out);
+                        const uint32_t loff = ((uint32_t) (tl.cb0 + j) * (uint32_t) S_op + (uint32_t) (O->line0 + tl.slice)) * PS_PLINE_BYTES;
+                        if (!(tp_sys && out_type == PS_OUT_ATOMIC)) { if (!hi) ps_pl_store(rsl, loff, l, v, tag_out); }
+                        else
+                        {
+                            // a row shard's partial row goes to EVERY rank (this one included): the consumers of all ranks then sum the same tp_world x S lines in the same
+                            // order -- the all-reduce of model/model_tp_backend.py:119-126 without a launch, a flag or a fence (the tag is the flag)
+                            const unsigned long long PS_CONST* const peers = *((const unsigned long long PS_CONST* const PS_CONST*) (a.err + 4));
+                            for (int pr = 0; pr < tpw; ++pr)
+                            {
+                                const ps_rsrc_t rp = ps_rsrc((const char*) peers[pr] + O->xoff);
+                                if (!hi) ps_pl_store_sys(rp, loff, l, v, tag_out);
+                            }
+                        }
                     };
                     if (W == 1)
                     {
@@ -1779,7 +1807,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             bool ok = true;
                             PsPl t[4];
                             #pragma unroll
-                            for (int i = 0; i < 4; ++i) t[i] = ps_pl_load(rsl, ((uint32_t) cbl * (uint32_t) S_op + (uint32_t) (shw + 8 * min(i, nl - 1))) * PS_PLINE_BYTES, l32);
+                            for (int i = 0; i < 4; ++i) t[i] = ps_pl_load_x(rsl, ((uint32_t) cbl * (uint32_t) S_op + (uint32_t) (shw + 8 * min(i, nl - 1))) * PS_PLINE_BYTES, l32, tp_sys);
                             ys = float4_t{ 0.f, 0.f, 0.f, 0.f };
                             #pragma unroll
                             for (int i = 0; i < 4; ++i) if (i < nl)

@@ -1848,11 +1848,14 @@ class PersistentStep:
     lm_head the layers' or 6 bits -- exl3_pstep_create checks and names the kernel instantiations (exl3_pstep.kspec.hip)."""
 
     def __init__(self, layers, head, final_norm, hidden: int, heads_q: int, heads_kv: int, head_dim: int, eps: float, rope_mode: int = 2, stamps: bool = False,
-                 attention: bool = False, repack: bool | None = None):
+                 attention: bool = False, repack: bool | None = None, tp: tuple | None = None):
         """attention: the decode attention over the 4-bit paged cache runs INSIDE the step (o_proj's preparation: one (kv head, context split) item per CU, the partial
         records merged by the consumers; libtorch/attention.cpp:246-504 at q_len 1) -- run() then needs block_table / cache_seqlens.  head_dim 128.
         repack: None (default) / True = the plan copies every op's packed words once into the order its streaming waves read them (a second copy of the weights owned by
-        the plan: one contiguous run per wave; SURVEY 8(f)4's legal load-time transform); False = stream the caller's checkpoint-layout tensors as they are."""
+        the plan: one contiguous run per wave; SURVEY 8(f)4's legal load-time transform); False = stream the caller's checkpoint-layout tensors as they are.
+        tp = (ranks, this rank): the layers are this rank's tensor-parallel shards (q / k / v / gate / up column shards, o / down row shards, an lm_head column shard;
+        heads_q / heads_kv the rank's, hidden the model's) and the all-reduce behind o_proj / down_proj (model/model_tp_backend.py:119-126) happens INSIDE the step: every
+        rank pushes its partial rows into every rank's exchange buffer -- exchange tp_handle() over the process group, tp_open_peer() each, tp_commit(), barrier."""
         def lin(l):
             t = l.trellis
             _req(t.dim() == 3 and l.suh is not None and l.svh is not None, "PersistentStep: EXL3 linears with suh / svh")
@@ -1873,7 +1876,9 @@ class PersistentStep:
         self._keep = (layers, head, final_norm)          # the plan holds raw pointers
         _check(_lib.lib().exl3_pstep_create(ctypes.byref(self._h), arr, len(layers), ctypes.byref(hl), _p(final_norm), int(hidden), int(heads_q), int(heads_kv),
                                             int(head_dim), int(K), int(cb), float(eps), int(rope_mode),
-                                            (1 if stamps else 0) | (4 if attention else 0) | ((KH << 8) if KH != K else 0) | (16 if repack is False else 0)))
+                                            (1 if stamps else 0) | (4 if attention else 0) | ((KH << 8) if KH != K else 0) | (16 if repack is False else 0)
+                                            | (((int(tp[0]) << 12) | (int(tp[1]) << 16)) if tp is not None and int(tp[0]) > 1 else 0)))
+        self.tp = tuple(int(v) for v in tp) if tp is not None and int(tp[0]) > 1 else None
         self.n_layers = len(layers)
         self.attention = bool(attention)
         self.head_dim = int(head_dim)
@@ -1912,6 +1917,18 @@ class PersistentStep:
         out = torch.zeros_like(like)
         _check(_lib.lib().exl3_pstep_unpack_op(self._h, int(op), int(mat), _p(out), _stream(like)))
         return out
+
+    def tp_handle(self) -> bytes:
+        """The 64-byte IPC handle of this rank's exchange buffer (a tensor-parallel plan)."""
+        buf = ctypes.create_string_buffer(64)
+        _check(_lib.lib().exl3_pstep_tp_handle(self._h, buf))
+        return bytes(buf.raw)
+
+    def tp_open_peer(self, rank: int, handle: bytes):
+        _check(_lib.lib().exl3_pstep_tp_open_peer(self._h, int(rank), ctypes.create_string_buffer(handle, 64)))
+
+    def tp_commit(self):
+        _check(_lib.lib().exl3_pstep_tp_commit(self._h))
 
     def set(self, decode_ahead_units: int = -1, spin_limit: int = 0):
         _check(_lib.lib().exl3_pstep_set(self._h, int(decode_ahead_units), int(spin_limit)))

@@ -811,7 +811,11 @@ class SyntheticEXL3Llama:
         # one rank -- or ONE rank's compute leg of a tensor-parallel job with the exchange left out (tp.OneRankOfMany: bench.py's llama-3.1-70b_tp8_rank line; a real TP
         # rank needs its peers' partial lines pushed into the step's slab buffers: not built)
         from .tp import OneRankOfMany
-        one_rank = self.tp == 1 or isinstance(self.backend, OneRankOfMany)
+        import torch.distributed as dist
+        # ... or a real tensor-parallel rank (round 6): the all-reduce behind o_proj / down_proj happens on the step's row edges (every rank pushes its partial lines into every
+        # rank's exchange buffer over IPC-mapped addresses: ext.PersistentStep(tp=...)); EXL3_HIP_PSTEP_TP=0 keeps the launch-per-op TP branch
+        one_rank = (self.tp == 1 or isinstance(self.backend, OneRankOfMany)
+                    or (self.tp <= 8 and dist.is_available() and dist.is_initialized() and os.environ.get("EXL3_HIP_PSTEP_TP", "1") != "0"))
         return (self._state_bsz == 1 and one_rank and att_ok and self.kv_bits == 4 and same
                 and s.hidden % 128 == 0 and s.hidden <= 8192 and s.head_dim in (64, 128) and self.use_qkv_tab)
 
@@ -823,26 +827,53 @@ class SyntheticEXL3Llama:
         the residual is kept in fp32 between the linears; an RMSNorm's input is formed with the scale of the row's previous version and the linear's partial sums
         are corrected by (true scale / that scale) (decode_step_fx: 64-bit fixed point; the same correction for batches above 4).
         Falls back to decode_step_fx where it does not apply."""
-        if not self.persistent_applies():
+        if not self.persistent_applies() or getattr(self, "_pstep_failed", False):
             return self.decode_step_fx()
         hd = self.shape.head_dim
         att = bool(self.with_attention)
         if getattr(self, "_pstep", None) is None or getattr(self, "_pstep_att", None) != att:
             layers = [dict(L, kcache=self.kcache[i], vcache=self.vcache[i]) for i, L in enumerate(self.layers)]
+            from .tp import OneRankOfMany
+            tp_real = self.tp > 1 and not isinstance(self.backend, OneRankOfMany)
+            err_txt = None
             try:
                 self._pstep = ext.PersistentStep(layers, self.lm_head, self.final_norm, self.shape.hidden, self.hq, self.hkv, hd, self.eps, rope_mode=2,
-                                                 stamps=bool(os.environ.get("EXL3_HIP_PSTEP_STAMPS")), attention=att)
+                                                 stamps=bool(os.environ.get("EXL3_HIP_PSTEP_STAMPS")), attention=att, tp=(self.tp, self.rank) if tp_real else None)
             except RuntimeError as e:
+                err_txt = str(e)
+                self._pstep = None
+            if tp_real:
+                # collective set-up: every rank takes part whatever failed locally -- the exchange buffers' IPC handles over the process group, the peers mapped, the table
+                # committed, a barrier before anyone pushes; one rank without a plan -> every rank takes the launch-per-op TP branch
+                import torch.distributed as dist
+                handles = [None] * self.tp
+                dist.all_gather_object(handles, self._pstep.tp_handle() if self._pstep is not None else None)
+                ok = all(h is not None for h in handles)
+                if ok:
+                    try:
+                        for r in range(self.tp):
+                            if r != self.rank: self._pstep.tp_open_peer(r, handles[r])
+                        self._pstep.tp_commit()
+                    except RuntimeError as e:
+                        ok, err_txt = False, str(e)
+                flags = [None] * self.tp
+                dist.all_gather_object(flags, ok)                       # (also the barrier: nobody pushes before every mapping exists)
+                if not all(flags):
+                    err_txt = err_txt or "a peer rank has no persistent plan"
+                    self._pstep = None
+            if self._pstep is None:
+                e = err_txt
                 # the planner / the device refused (no plan for this shape on this chip, the kernel does not fit a CU, out of memory for the repacked copy): the
                 # launch-per-op pipeline computes the same step (ADVICE r5: persistent_applies() does not mirror every constraint of exl3_pstep_create)
                 import warnings
                 warnings.warn(f"exllamav3_amd: no persistent decode step for this model ({e}); using the launch-per-op pipeline", RuntimeWarning)
                 self.persistent = False
                 self._pstep = None
+                self._pstep_failed = True                              # (no second attempt: under TP every attempt is a collective)
                 return self.decode_step_fx()
             self._pstep_att = att
             self._pstep_checked = False
-        elif self._pstep.error_peek() and not torch.cuda.is_current_stream_capturing():
+        elif self._pstep.tp is None and self._pstep.error_peek() and not torch.cuda.is_current_stream_capturing():
             # some earlier (possibly graph-replayed) step reported a timed-out wait to the pinned host word -- its logits were NaN; no synchronisation was needed to see it
             import warnings
             if self._pstep.error():
@@ -860,8 +891,16 @@ class SyntheticEXL3Llama:
             # first run of a new plan: the step needs the whole grid co-resident (one workgroup per CU); if this device does not give that, its bounded waits time
             # out (flagged) -- then the launch-per-op pipeline takes over for good, loudly
             self._pstep_checked = True
-            if self._pstep.error():
+            bad = bool(self._pstep.error())
+            if self._pstep.tp is not None:
+                # a tensor-parallel plan: the ranks decide TOGETHER (a rank that saw no time-out itself must not keep pushing into peers that stopped listening)
+                import torch.distributed as dist
+                votes = [None] * self.tp
+                dist.all_gather_object(votes, bad)
+                bad = any(votes)
+            if bad:
                 import warnings
+                self._pstep_failed = True
                 warnings.warn("exllamav3_amd: the persistent decode step timed out on this device (grid not co-resident?); using the launch-per-op pipeline", RuntimeWarning)
                 type(self).persistent = False
                 self.persistent = False

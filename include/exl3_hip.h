@@ -664,6 +664,16 @@ int exl3_pstep_error(void* handle, void* stream);
 int exl3_pstep_error_peek(void* handle);
 int exl3_pstep_attn_geometry(void* handle, int len, int* out3);
 int exl3_pstep_unpack_op(void* handle, int op, int mat, void* trellis_out, void* stream);
+/* Tensor parallelism INSIDE the step (exl3_pstep_create flags bits 12..15 = ranks (2..8), bits 16..19 = this rank; the tensors passed are this rank's shards, heads_q / heads_kv
+ * the rank's, hidden the model's).  Replaces the all-reduce launches behind o_proj / down_proj (model/model_tp_backend.py:119-126; modules/attn.py:547, modules/mlp.py:770):
+ * every rank pushes the partial rows of its row shards as tagged lines into EVERY rank's exchange buffer over IPC-mapped addresses; the consumers of all ranks sum the same
+ * ranks x slices lines in the same order (bit-identical residual rows on every rank), no launch, flag or fence in between.
+ *   exl3_pstep_tp_handle     the 64-byte IPC handle of this rank's exchange buffer (send it to the peers over the process group);
+ *   exl3_pstep_tp_open_peer  maps rank r's buffer from its handle;
+ *   exl3_pstep_tp_commit     after every peer is mapped; the caller barriers the ranks behind it and before the first step.  All ranks then run the same sequence of steps. */
+int exl3_pstep_tp_handle(void* handle, void* handle64_out);
+int exl3_pstep_tp_open_peer(void* handle, int peer_rank, const void* handle64);
+int exl3_pstep_tp_commit(void* handle);
 int exl3_pstep_set(void* handle, int decode_ahead_units, int spin_limit);
 int exl3_pstep_describe(void* handle, char* buf, int buf_bytes);
 int64_t exl3_pstep_stamps(void* handle, uint64_t* host_out, int64_t max_words, void* stream);
