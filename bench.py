@@ -268,7 +268,11 @@ def main():
     if pipeline == "auto":
         # the persistent decode step (ONE launch per step) wherever it applies -- batch 1, one rank, mul1, 4-bit cache, no attention core -- and is not switched
         # off (EXL3_HIP_PSTEP=0); else the fixed-point-residual launch-per-op pipeline
-        pipeline = "persistent" if (not is_moe and world == 1 and model.persistent_applies() and model.persistent is not False) else "fx"
+        # N > 1 (round 6): the tensor-parallel step too -- the all-reduce behind o_proj / down_proj happens on the step's row edges (every rank pushes its partial lines into
+        # every rank's exchange buffer: ext.PersistentStep(tp=...)).  Only over a real collective backend: ranks that SHARE a GPU (the gloo test hook) cannot both keep a
+        # whole-chip grid resident (EXL3_HIP_PSTEP_TP=1 forces it, =0 keeps the launch-per-op TP branch)
+        tp_ps = world == 1 or (os.environ.get("EXL3_HIP_PSTEP_TP", "") == "1" or (dist_backend_name(backend) == "nccl" and os.environ.get("EXL3_HIP_PSTEP_TP", "") != "0"))
+        pipeline = "persistent" if (not is_moe and tp_ps and model.persistent_applies() and model.persistent is not False) else "fx"
     if pipeline == "tail" and world > 1:
         pipeline = "glue"                                  # TP ranks all-reduce between o/down and the norm ("fx" has its own TP form: llama_path._decode_step_fx_tp)
     fused = pipeline != "unfused"
@@ -276,7 +280,7 @@ def main():
         {"tail": model.decode_step_tail, "glue": model.decode_step_fused, "resid": model.decode_step_resid, "fx": model.decode_step_fx,
          "unfused": model.decode_step, "persistent": model.decode_step_persistent}[pipeline]
     if pipeline == "persistent":
-        assert not is_moe and world == 1 and model.persistent_applies(), "--pipeline persistent: batch 1, one rank, 4-bit cache, hidden <= 4096"
+        assert not is_moe and model.persistent_applies(), "--pipeline persistent: batch 1, 4-bit cache, hidden <= 8192"
     # tensor-parallel decode: the o_proj / down_proj all-reduces go through the one-shot IPC push (exl3_allreduce.hip, fused with the residual
     # add) unless EXL3_HIP_TP_ALLREDUCE=rccl; the set-up self-tests against the collective library and every rank falls back together
     ipc_on = False
@@ -289,7 +293,13 @@ def main():
     if pipeline == "persistent":
         run_step(); run_step()
         torch.cuda.synchronize()
-        if model._pstep is None or model._pstep.error():
+        ps_bad = model._pstep is None or bool(model._pstep.error())
+        if world > 1:
+            # the ranks decide together (a rank that keeps the step while a peer left it would wait for lines that never come)
+            tb = torch.tensor([1.0 if ps_bad else 0.0], dtype=torch.float64, device=dev)
+            backend.all_reduce_max(tb)
+            ps_bad = float(tb.item()) != 0.0
+        if ps_bad:
             print("bench.py: WARNING: the persistent decode step reported a time-out on this device (grid not co-resident?); timing the launch-per-op fx pipeline instead",
                   file=sys.stderr, flush=True)
             persistent_fallback = "the persistent step timed out in the warm-up on this device: launch-per-op fx pipeline timed"
@@ -418,7 +428,10 @@ def main():
                      "ipc_requested": ipc_requested, "ipc_enabled": bool(ipc_on), "ipc_fell_back": bool(ipc_requested and not ipc_on),
                      "ipc_fell_back_after_timing": ipc_fell_back_after_timing,
                      "bytes_per_token_per_rank": [int(b.item()) for b in all_bytes],
-                     "path": "ipc one-shot push + fused residual add (exl3_allreduce.hip)" if ipc_on else "collective library all_reduce + glue_resid"}
+                     "path": ("inside the persistent step: every rank pushes the partial lines of its row shards into every rank's exchange buffer (no all-reduce launch)"
+                              if pipeline == "persistent" else
+                              ("ipc one-shot push + fused residual add (exl3_allreduce.hip)" if ipc_on else "collective library all_reduce + glue_resid")),
+                     "inside_persistent_step": pipeline == "persistent"}
         if ipc_on:
             allreduce["ipc_us"] = time_calls(lambda: backend.ipc.reduce(yb, resid=rb, ss_part=sb, m=args.batch))
         saved_ipc, backend.ipc = backend.ipc, None

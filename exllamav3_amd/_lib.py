@@ -152,6 +152,8 @@ def _declare(l):
     sig("exl3_pstep_tp_handle", vp, vp)
     sig("exl3_pstep_tp_open_peer", vp, i32, vp)
     sig("exl3_pstep_tp_commit", vp)
+    l.exl3_pstep_tp_peek.argtypes = [vp, vp, i64]
+    l.exl3_pstep_tp_peek.restype = i64
     sig("exl3_pstep_set", vp, i32, i32)
     sig("exl3_pstep_describe", vp, ctypes.c_char_p, i32)
     sig("exl3_pstep_destroy", vp)

@@ -627,6 +627,16 @@ extern "C" int exl3_pstep_tp_commit(void* handle)
     return EXL3_OK;
 }
 
+// diagnostics: this rank's exchange buffer copied to host memory (synchronises the device); returns the bytes copied
+extern "C" int64_t exl3_pstep_tp_peek(void* handle, void* host_out, int64_t max_bytes)
+{
+    PsHandle* h = (PsHandle*) handle;
+    if (!h || !host_out || !h->d_xbuf) { exl3_set_error("exl3_pstep_tp_peek: not a tensor-parallel plan"); return EXL3_ERR_ARG; }
+    const int64_t n = (int64_t) h->xbuf_bytes < max_bytes ? (int64_t) h->xbuf_bytes : max_bytes;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, h->d_xbuf, (size_t) n, hipMemcpyDeviceToHost) != hipSuccess) { exl3_set_error("exl3_pstep_tp_peek: hipMemcpy"); return EXL3_ERR_HIP; }
+    return n;
+}
+
 // the attention item's geometry at a sequence length (host restatement of att_nse / att_make of the kernel): out3 = { splits in use, tokens per split, 128-token steps per split }
 extern "C" int exl3_pstep_attn_geometry(void* handle, int len, int* out3)
 {

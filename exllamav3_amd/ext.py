@@ -1930,6 +1930,15 @@ class PersistentStep:
     def tp_commit(self):
         _check(_lib.lib().exl3_pstep_tp_commit(self._h))
 
+    def tp_peek(self):
+        """Diagnostics: this rank's exchange buffer (the partial lines of every rank's row shards) as a numpy uint32 array; synchronises the device."""
+        import numpy as np
+        buf = (ctypes.c_uint32 * (1 << 23))()
+        n = _lib.lib().exl3_pstep_tp_peek(self._h, buf, 4 << 23)
+        if n < 0:
+            raise RuntimeError(_lib.last_error())
+        return np.frombuffer(buf, dtype=np.uint32, count=int(n) // 4).copy()
+
     def set(self, decode_ahead_units: int = -1, spin_limit: int = 0):
         _check(_lib.lib().exl3_pstep_set(self._h, int(decode_ahead_units), int(spin_limit)))
 

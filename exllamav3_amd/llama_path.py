@@ -167,6 +167,16 @@ class SyntheticEXL3Llama:
                 "norm1": mk_norm(h),
                 "norm2": mk_norm(h),
             }
+            if tp > 1:
+                # row shards of ONE quantized linear share its output-side scale vector (modules/quant/exl3.py:300-313: an in-split slices suh and the trellis, svh stays
+                # whole): o / down of every rank get the SAME svh (a rank-independent stream) -- what makes "sum the ranks' rotated-basis partial rows, then apply the
+                # output Hadamard and svh once" (the persistent step's row edges under TP) equal to "finish every rank's row, then sum" (the all-reduce launches)
+                gsh = torch.Generator(device=self.device)
+                gsh.manual_seed(seed * 1000 + 7777 + li)
+                for nm in ("o", "down"):
+                    kk = L[nm].trellis.shape[0] * 16 * tp
+                    sg = torch.where(torch.rand(h, device=self.device, generator=gsh) < 0.5, -1.0, 1.0)
+                    L[nm].svh.copy_((sg * (0.5 / math.sqrt(kk)) * torch.exp(0.2 * torch.randn(h, device=self.device, generator=gsh))).half())
             self.layers.append(L)
         self.final_norm = mk_norm(h)
         self.lm_head = mk_lin(h, self.vocab_local, head_K or K)

@@ -674,6 +674,7 @@ int exl3_pstep_unpack_op(void* handle, int op, int mat, void* trellis_out, void*
 int exl3_pstep_tp_handle(void* handle, void* handle64_out);
 int exl3_pstep_tp_open_peer(void* handle, int peer_rank, const void* handle64);
 int exl3_pstep_tp_commit(void* handle);
+int64_t exl3_pstep_tp_peek(void* handle, void* host_out, int64_t max_bytes);    /* diagnostics: this rank's exchange buffer -> host memory (synchronises); bytes copied */
 int exl3_pstep_set(void* handle, int decode_ahead_units, int spin_limit);
 int exl3_pstep_describe(void* handle, char* buf, int buf_bytes);
 int64_t exl3_pstep_stamps(void* handle, uint64_t* host_out, int64_t max_words, void* stream);

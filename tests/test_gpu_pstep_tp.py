@@ -96,6 +96,12 @@ def _worker(rank, world, port, ret, case):
                 same = same and bool(np.array_equal(_np(m.decode_step_persistent()), lp))
                 stream.synchronize()
             ok["repeatable"] = same and m._pstep is not None and not m._pstep.error()
+            # every rank holds the same lines: the exchange buffers of the ranks are equal word for word (what each rank's consumers sum, in the same order -> the same
+            # residual rows on every rank: the bit-identity the all-reduce launches get from their rank-order sums)
+            xb = torch.from_numpy(m._pstep.tp_peek().astype(np.int64))
+            allx = [torch.empty_like(xb) for _ in range(world)]
+            dist.all_gather(allx, xb)
+            ok["exchange_buffers_identical"] = all(bool(torch.equal(allx[0], t)) for t in allx) and int((xb != 0).sum()) > 1000
         ok["plan"] = m._pstep.describe() if m._pstep is not None else None
     except Exception as e:           # report instead of hanging the peer
         import traceback
@@ -120,4 +126,61 @@ def test_persistent_step_two_tensor_parallel_ranks_on_one_gpu(dev, case):
         res = ret.get(r)
         assert res and "exception" not in res, res
         assert res["applies"] and res["took_the_persistent_step"] and res["no_timeout"], res
-        assert res["logits_rel_err"] < 2e-2 and res["kv_rows"] is True and res["repeatable"], res
+        assert res["logits_rel_err"] < 2e-2 and res["kv_rows"] is True and res["repeatable"] and res["exchange_buffers_identical"], res
+
+
+def _worker_fallback(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    import warnings
+    import torch.distributed as dist
+    ok = {}
+    be = None
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        from exllamav3_amd import ext
+        from exllamav3_amd.tp import TPBackendRCCL
+        from exllamav3_amd.llama_path import LlamaShape, SyntheticEXL3Llama
+        ext.init(0)
+        be = TPBackendRCCL(rank, world, dev, backend="gloo")
+        m = SyntheticEXL3Llama(LlamaShape("tp-fb", 1024, 2816, 2, 8, 2, 128, 3072), K=4, cb=2, device=dev, backend=be, kv_bits=4, max_ctx=1024)
+        m.alloc_state(1, pos=300)
+        dist.broadcast(m.x0, 0)
+        ok["ipc_allreduce"] = be.enable_ipc_allreduce(1024)
+        ref = m.decode_step_fx().float().cpu().numpy().copy()
+        for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+        if rank == 1:
+            def refuse(*a, **k): raise RuntimeError("no plan on this rank (test)")
+            ext.PersistentStep = refuse
+        torch.cuda.synchronize(); dist.barrier()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = m.decode_step_persistent().float().cpu().numpy().copy()
+        ok["fell_back"] = m._pstep is None and any("no persistent decode step" in str(x.message) for x in w)
+        ok["same_as_launch_per_op"] = bool(np.array_equal(got, ref))
+        for c, s_ in m.kcache + m.vcache: c.zero_(); s_.zero_()
+        ok["stays_fallen_back"] = bool(np.array_equal(m.decode_step_persistent().float().cpu().numpy(), ref)) and m._pstep is None
+    except Exception as e:
+        import traceback
+        ok["exception"] = repr(e) + traceback.format_exc()[-1500:]
+    ret[rank] = ok
+    try:
+        if be is not None: be.close()
+    except Exception:
+        pass
+
+
+def test_one_rank_without_a_plan_takes_every_rank_to_the_launch_per_op_branch(dev):
+    """The set-up of a tensor-parallel persistent step is a collective: a rank that cannot make its plan says so, and EVERY rank (the one with a good plan included) runs the
+    launch-per-op TP branch -- the same bits as decode_step_fx -- now and on later calls."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29900 + (os.getpid() % 40)
+    mp.spawn(_worker_fallback, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        res = ret.get(r)
+        assert res and "exception" not in res, res
+        assert res["fell_back"] and res["same_as_launch_per_op"] and res["stays_fallen_back"], res
