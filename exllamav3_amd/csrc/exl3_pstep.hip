@@ -380,7 +380,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
         O.rver = rver; O.gate_op = -1;
         lin_to_mat(*head, O.mat[0]);
         const int ncb[1] = { head->n / 128 };
-        OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for the lm_head (vocab / 128 <= 16 x CUs)");
+        OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for the lm_head (a rectangle is at most 12 column blocks wide: vocab / 128 <= 12 x CUs)");
         O.S = p.S; fill_tiles(tiles.data() + (size_t) op * ncu, ncu, p, ncb, 1, hidden / 128, 0, false);      // (the head's finish uses the uniform partition's closed formulas)
         snprintf(line, sizeof(line), "head: S=%d groups=%d tile<=%dx%d; residual edges: %s%s", p.S, p.g[0], p.wmax, p.hmax, direct ? "direct (consumer gathers)" : "owners", attn ? "; attention inside o_proj's preparation" : ""); desc += line;
         if (attn) { snprintf(line, sizeof(line), " (%d kv blocks x %d splits)", att_blocks, att_nsplit); desc += line; }

@@ -117,7 +117,15 @@ def _worker(rank, world, port, ret, case):
                                   (2048, 4096, 3, 16, 4, 128, 2048, 3, False),         # 3 bpw, three layers (the row-edge lines alternate between two sets by layer)
                                   (1024, 2816, 2, 8, 2, 128, 3072, 4, True)])          # the decode attention inside the step, every rank over its own kv heads
 def test_persistent_step_two_tensor_parallel_ranks_on_one_gpu(dev, case):
-    world = 2
+    _run_ranks(2, case)
+
+
+def test_persistent_step_four_tensor_parallel_ranks_on_one_gpu(dev):
+    """FOUR ranks on a quarter of the chip each (64 CUs): every row edge gathers 4 x S lines pushed by four processes -- the fan-in of the driver's first multi-GPU run."""
+    _run_ranks(4, (1024, 4096, 2, 16, 4, 128, 4096, 4, False))
+
+
+def _run_ranks(world, case):
     mgr = mp.Manager()
     ret = mgr.dict()
     port = 29950 + (os.getpid() % 40)
