@@ -171,6 +171,26 @@ def dist_backend_name(backend):
         return None
 
 
+def persistent_phases(model_name):
+    """Per-op phase medians of the persistent step's final kernel (in-kernel stamps of a separate builder-side run of the C++ harness with stamps on: the stamps cost
+    ~ 8 % of the step, so they are NOT collected inside the timed region) -- profiles/r06_persistent_layer_phases.json, labelled as such."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r06_persistent_layer_phases.json"))).get(model_name)
+        if not d:
+            return None
+        out = {"source": "NOT measured in this run: in-kernel phase stamps (100 MHz) of the same kernel in a builder-side run with stamps on, profiles/r06_persistent_layer_phases.json",
+               "step_us_with_stamps_on": d.get("total_us"), "per_op_median_us": {}}
+        for op, rec in d.get("ops", {}).items():
+            if op == "head":
+                out["per_op_median_us"][op] = {k: round(v, 2) for k, v in rec.items() if isinstance(v, (int, float))}
+            else:
+                out["per_op_median_us"][op] = {"period": round(rec.get("period_us", 0.0), 2),
+                                               **{k: round(v["median_us"], 2) for k, v in rec.items() if isinstance(v, dict) and "median_us" in v}}
+        return out
+    except Exception:
+        return None
+
+
 def pinned_logits_check(model_name, K, cb, bsz, dev, pipeline, tol=3e-2, ctx=None):
     """Correctness gate of the timed pipeline (VERDICT r3 weak #1 d; replaces `isfinite(logits)`): ONE layer of the benchmark's shape + a 2048-column
     lm_head built from a fixed host seed (SyntheticEXL3Llama.pin_model: the same tensors on every machine) goes through the SAME decode-step function
@@ -564,6 +584,7 @@ def main():
                         "traffic": ptraffic, "traffic_source": ptraffic_src,
                         "avg_launch_us": round(step_us, 2), "bytes_per_launch": int(bytes_step), "launches_per_step": 1,
                         "plan": model._pstep.describe(),
+                        "phases": persistent_phases(args.model),
                         "launch_per_op_gemv": gemv_roofline,
                         "note": "HIP events around hipGraph replays of the step (one exl3_pstep_kernel launch + the set-up launch); algorithmic bytes = every packed weight once + scales + activations"}
         else:

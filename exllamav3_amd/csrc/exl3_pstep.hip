@@ -11,6 +11,12 @@
 #include <stdio.h>
 #include <string.h>
 
+#ifdef PS_TEST_NO_ROW_PARITY
+#define PS_ROW_PARITY(li) 0
+#else
+#define PS_ROW_PARITY(li) ((li) & 1)
+#endif
+
 namespace
 {
 struct PsHandle
@@ -248,10 +254,10 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
         // the step's edges need the WHOLE grid co-resident (one workgroup per CU): the kernel must fit a CU (155 KiB of LDS, 1024 threads, no scratch) -- checked here, at
         // create, instead of discovered as a time-out at the first step; a grid of exactly multiProcessorCount workgroups is then placed one per CU
         int occ = -1;
-        const int r = kset ? kset->prepare(K2, KH, cb_all, (flags & 4) != 0, &occ) : 1;
+        const int r = kset ? kset->prepare(K2, KH, cb_all, (flags & 4) != 0, tpw > 1, &occ) : 1;
         if (r < 0) return r;
-        EXL3_CHECK_ARG(r == 0, "exl3_pstep_create: no kernel for layers of %d%s bits per weight, a %d-bit lm_head and codebook %d (exl3_pstep.kspec.hip lists the instantiations)",
-                       K, K2 != K ? " / + 1" : "", KH, cb_all);
+        EXL3_CHECK_ARG(r == 0, "exl3_pstep_create: no kernel for layers of %d%s bits per weight, a %d-bit lm_head and codebook %d%s (exl3_pstep.kspec.hip lists the instantiations)",
+                       K, K2 != K ? " / + 1" : "", KH, cb_all, tpw > 1 ? " as a tensor-parallel rank" : "");
         EXL3_CHECK_ARG(occ != 0, "exl3_pstep_create: the step kernel does not fit a CU of this device (occupancy 0): the grid could not be co-resident");
     }
     // DIRECT residual edges (exl3_pstep.cuh) unless flags bit 1 / EXL3_HIP_PSTEP_OWNERS=1 asks for the owner form everywhere (A/B runs); a plan that cannot keep
@@ -336,7 +342,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
                 A->rec = nullptr; A->stats = nullptr; A->gq = att_gq; A->nsplit = att_nsplit; A->hq = heads_q; A->hkv = heads_kv;      // (buffers: below)
             }
             O.rver = ++rver; O.gate_op = direct ? op - 1 : (rver >= 3 ? reader_of_version[rver - 2] : -1);       // (direct: the last readers of the lines an owner overwrites are the op before it)
-            { Pending f; f.op = op; f.which = 2; f.off[0] = 0; f.parity = li & 1; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * tpw * 128; if (n > slab_c_floats) slab_c_floats = n; }
+            { Pending f; f.op = op; f.which = 2; f.off[0] = 0; f.parity = PS_ROW_PARITY(li); slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * tpw * 128; if (n > slab_c_floats) slab_c_floats = n; }
             if (li == 0) { snprintf(line, sizeof(line), "o: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
             ++op;
         }
@@ -369,7 +375,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
             OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, inter / 128, ncb, 1, O.in_type, O.out_type, p, false, 32 / tpw), "exl3_pstep_create: no plan for down_proj");
             O.S = p.S; add_tiles(op, p, ncb, 1, inter / 128, 0);
             O.rver = ++rver; O.gate_op = direct ? op - 1 : (rver >= 3 ? reader_of_version[rver - 2] : -1);
-            { Pending f; f.op = op; f.which = 3; f.off[0] = 0; f.parity = li & 1; slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * tpw * 128; if (n > slab_d_floats) slab_d_floats = n; }
+            { Pending f; f.op = op; f.which = 3; f.off[0] = 0; f.parity = PS_ROW_PARITY(li); slab_fix.push_back(f); const size_t n = (size_t) ncb[0] * p.S * tpw * 128; if (n > slab_d_floats) slab_d_floats = n; }
             if (li == 0) { snprintf(line, sizeof(line), "down: S=%d groups=%d tile<=%dx%d; ", p.S, p.g[0], p.wmax, p.hmax); desc += line; }
             ++op;
         }
@@ -566,7 +572,7 @@ static int ps_run(PsHandle* h, void* R, void* logits, void* q_out, const float* 
     a.block_table = block_table; a.seqlens = seqlens; a.blocks_per_seq = blocks_per_seq; a.page_size = page_size; a.att_scale = scale;
     a.rbuf = h->d_rbuf; a.cnt = h->d_cnt; a.epoch = h->d_epoch; a.err = h->d_err; a.dbg = h->d_dbg; a.spin_limit = h->spin_limit; a.pmax = h->pmax;
     a.runs = h->d_runs;
-    h->kset->launch(h->K2, h->KH, h->cb, h->attn != 0, h->ncu, st, a);
+    h->kset->launch(h->K2, h->KH, h->cb, h->attn != 0, h->tp_world > 1, h->ncu, st, a);
     return exl3_check_launch("exl3_pstep_run");
 }
 

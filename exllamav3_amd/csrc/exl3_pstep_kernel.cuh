@@ -91,7 +91,15 @@ __device__ __forceinline__ void ps_st128_sys(ps_rsrc_t r, uint32_t byte_off, uin
 #define PS_PLINE_BYTES 512
 struct PsPl { uint4_t a; };
 __device__ __forceinline__ PsPl ps_pl_load(ps_rsrc_t r, uint32_t line_off, int l) { PsPl p; p.a = ps_ld128(r, line_off + (uint32_t) l * 16); return p; }
-__device__ __forceinline__ PsPl ps_pl_load_x(ps_rsrc_t r, uint32_t line_off, int l, bool sys) { PsPl p; p.a = sys ? ps_ld128_sys(r, line_off + (uint32_t) l * 16) : ps_ld128(r, line_off + (uint32_t) l * 16); return p; }
+// (the scope is a COMPILE-TIME choice at every gather site: a per-load select between the two instructions cost the single-rank step 3.6-4.2 % -- the gathers of a
+//  tensor-parallel plan are instantiated a second time instead and picked by one wave-uniform branch)
+template <bool SYS>
+__device__ __forceinline__ PsPl ps_pl_load_t(ps_rsrc_t r, uint32_t line_off, int l)
+{
+    PsPl p;
+    if constexpr (SYS) p.a = ps_ld128_sys(r, line_off + (uint32_t) l * 16); else p.a = ps_ld128(r, line_off + (uint32_t) l * 16);
+    return p;
+}
 __device__ __forceinline__ bool ps_pl_ok(const PsPl& p, uint32_t tag) { return (p.a.y == tag) & (p.a.w == tag); }
 __device__ __forceinline__ float4_t ps_pl_val(const PsPl& p, uint32_t mask = 0xffffffffu)
 {
@@ -122,15 +130,15 @@ __device__ __forceinline__ void ps_pl_store(ps_rsrc_t r, uint32_t line_off, int 
 }
 #endif
 
-template <int NB>
-__device__ __forceinline__ float4_t ps_slab_sum(ps_rsrc_t r, uint32_t blk_off, int S, int l, uint32_t tag, bool& ok, bool sys = false)
+template <int NB, bool SYS = false>
+__device__ __forceinline__ float4_t ps_slab_sum(ps_rsrc_t r, uint32_t blk_off, int S, int l, uint32_t tag, bool& ok)
 {
     float4_t v = { 0.f, 0.f, 0.f, 0.f };
     for (int s = 0; s < S; s += NB)
     {
         PsPl t[NB];
         #pragma unroll
-        for (int i = 0; i < NB; ++i) t[i] = ps_pl_load_x(r, blk_off + (uint32_t) min(s + i, S - 1) * PS_PLINE_BYTES, l, sys);
+        for (int i = 0; i < NB; ++i) t[i] = ps_pl_load_t<SYS>(r, blk_off + (uint32_t) min(s + i, S - 1) * PS_PLINE_BYTES, l);
         #pragma unroll
         for (int i = 0; i < NB; ++i) if (s + i < S)
         {
@@ -425,7 +433,10 @@ __device__ __forceinline__ PsSeg<K> ps_make_seg(ps_op_p O, const PsTile& t, int 
 // ATT: the plan has the decode attention inside o_proj's preparation (PS_ATTN).  A separate instantiation: with the attention code compiled in, the step WITHOUT attention
 // ran 2.6 % (8B) / 6 % (1B) slower (250 instead of 78 scalar spills on the service path, a third more code)
 // KH: bits per weight of the lm_head (= K, or 6: the head of a real checkpoint)
-template <int K, int K2, int KH, int CB, bool ATT>
+// TP: the plan is one rank of a tensor-parallel job (the row shards' partial lines go to every rank's exchange buffer, the row edges read with system-scope loads).  Its own
+// instantiations: compiled into the one kernel -- as run-time branches on the plan's rank count -- the tensor-parallel paths cost the SINGLE-rank step 3.5-4 % (1B 0.398 ->
+// 0.414 ms, same box: a fifth more scalar spills on the service path), the same lesson as ATT.
+template <int K, int K2, int KH, int CB, bool ATT, bool TP = false>
 __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1098,8 +1109,10 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             const ps_mat_p Mo = &O->mat[active ? tl.mat : 0];
             // (S_op: partial lines per column block of this op's output; a tensor-parallel rank's own lines are line0 .. line0 + S - 1 of the tp_world x S, and every
             //  rank's exchange buffer receives them: exl3_pstep.cuh)
-            unsigned long long* const slab_p = Mo->slab; const half_t* const svh_p = Mo->svh; const int S_op = O->S_all;
-            const int tpw = O->tp_world; const bool tp_sys = tpw > 1;
+            unsigned long long* const slab_p = Mo->slab; const half_t* const svh_p = Mo->svh; const int S_op = TP ? O->S_all : O->S;
+            const int tpw = TP ? O->tp_world : 1, line0 = TP ? O->line0 : 0;
+            constexpr bool tp_sys = TP;       // (requested HERE with the op's other descriptor fields: a scalar load inside the
+                                                                                            //  publish sat on the chain of every op: 8B +2.5 %, 1B +4 %)
             half4_t scp[2];
             #pragma unroll
             for (int r2 = 0; r2 < 2; ++r2)
@@ -1107,7 +1120,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 scp[r2] = half4_t{ 0, 0, 0, 0 };
                 if (active && out_type != PS_OUT_SLAB) scp[r2] = ps_g((const half4_t*) (svh_p + (size_t) (tl.cb0 + min(shw + 8 * r2, W - 1)) * 128))[l32];
             }
-            asm volatile("" :: "s"(slab_p), "s"(S_op));
+            asm volatile("" :: "s"(slab_p), "s"(S_op), "s"(tpw), "s"(line0));
 
             // one block: x * suh -> 128-point Hadamard -> fp16 quads in LDS (+ the block's sum for the mul1 affine term)
             auto rotate_store = [&] (half4_t xv, half4_t svv, int blk_local, bool act)
@@ -1162,6 +1175,9 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 }
 #endif
                 float4_t ys_own = { 0.f, 0.f, 0.f, 0.f };
+                auto gather_direct = [&] (auto sysc)
+                {
+                constexpr bool SYS = decltype(sysc)::value;                 // a tensor-parallel plan reads its exchange buffer with system-scope loads (peer GPUs write it)
                 if (active && !coop && 2 * sw < nb)
                 {
                     const ps_rsrc_t rp = ps_rsrc(O->in_slab[0]);
@@ -1169,7 +1185,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     for (int spins = 0;; ++spins)
                     {
                         bool ok = true;
-                        ys_own = ps_slab_sum<8>(rp, (uint32_t) blk_o * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok, tp_sys);
+                        ys_own = ps_slab_sum<8, SYS>(rp, (uint32_t) blk_o * (uint32_t) O->S_in * PS_PLINE_BYTES, O->S_in, l32, tag_in, ok);
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
                         if (spins > slim) { ps_timeout(8u); break; }
                         __builtin_amdgcn_s_sleep(PS_POLL_SLEEP);
@@ -1200,7 +1216,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             for (int i = 0; i < NSLOT; ++i)
                             {
                                 const int jj = r * bpr + (two ? (i >> 1) : (i >> 2)), s_ = shw + 8 * (two ? (i & 1) : (i & 3));
-                                t[i] = ps_pl_load_x(rp, ((uint32_t) (b0 + min(jj, nb - 1)) * (uint32_t) S_p + (uint32_t) min(s_, S_p - 1)) * PS_PLINE_BYTES, l32, tp_sys);
+                                t[i] = ps_pl_load_t<SYS>(rp, ((uint32_t) (b0 + min(jj, nb - 1)) * (uint32_t) S_p + (uint32_t) min(s_, S_p - 1)) * PS_PLINE_BYTES, l32);
                             }
                             #pragma unroll
                             for (int q = 0; q < NSLOT / 2; ++q) acc[q] = float4_t{ 0.f, 0.f, 0.f, 0.f };
@@ -1232,6 +1248,8 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     tgt_o += PS_NSV;
                     c_inc(PS_C_O);
                 }
+                };
+                gather_direct(std::integral_constant<bool, TP>{});
                 float4_t rold = { 0.f, 0.f, 0.f, 0.f };
                 if (has_task)
                 {
@@ -1643,7 +1661,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     {
                         v.x = halves(v.x); v.y = halves(v.y); v.z = halves(v.z); v.w = halves(v.w);
                         v.x = (v.x * kinv_s + bb_s) * fac_norm; v.y = (v.y * kinv_s + bb_s) * fac_norm; v.z = (v.z * kinv_s + bb_s) * fac_norm; v.w = (v.w * kinv_s + bb_s) * fac_norm;
-                        const uint32_t loff = ((uint32_t) (tl.cb0 + j) * (uint32_t) S_op + (uint32_t) (O->line0 + tl.slice)) * PS_PLINE_BYTES;
+                        const uint32_t loff = ((uint32_t) (tl.cb0 + j) * (uint32_t) S_op + (uint32_t) (line0 + tl.slice)) * PS_PLINE_BYTES;
                         if (!(tp_sys && out_type == PS_OUT_ATOMIC)) { if (!hi) ps_pl_store(rsl, loff, l, v, tag_out); }
                         else
                         {
@@ -1807,7 +1825,11 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                             bool ok = true;
                             PsPl t[4];
                             #pragma unroll
-                            for (int i = 0; i < 4; ++i) t[i] = ps_pl_load_x(rsl, ((uint32_t) cbl * (uint32_t) S_op + (uint32_t) (shw + 8 * min(i, nl - 1))) * PS_PLINE_BYTES, l32, tp_sys);
+                            for (int i = 0; i < 4; ++i)
+                            {
+                                const uint32_t lo_ = ((uint32_t) cbl * (uint32_t) S_op + (uint32_t) (shw + 8 * min(i, nl - 1))) * PS_PLINE_BYTES;
+                                t[i] = ps_pl_load_t<TP>(rsl, lo_, l32);
+                            }
                             ys = float4_t{ 0.f, 0.f, 0.f, 0.f };
                             #pragma unroll
                             for (int i = 0; i < 4; ++i) if (i < nl)

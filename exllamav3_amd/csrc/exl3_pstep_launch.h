@@ -8,8 +8,9 @@ static_assert(PS_LDS_BYTES <= 160 * 1024, "persistent step: LDS map exceeds a CU
 struct PsKernelSet
 {
     // both return 0, or 1 if the unit has no kernel for (second layer width K2, head width KH, codebook cb)
-    int (*prepare)(int K2, int KH, int cb, bool att, int* occupancy);      // dynamic-LDS attribute + workgroups of this kernel that fit one CU (-1: query failed); < 0: HIP error
-    int (*launch)(int K2, int KH, int cb, bool att, int ncu, hipStream_t st, const PsArgs& args);
+    // (tp: the instantiation of a tensor-parallel rank)
+    int (*prepare)(int K2, int KH, int cb, bool att, bool tp, int* occupancy);      // dynamic-LDS attribute + workgroups of this kernel that fit one CU (-1: query failed); < 0: HIP error
+    int (*launch)(int K2, int KH, int cb, bool att, bool tp, int ncu, hipStream_t st, const PsArgs& args);
 };
 // nullptr: no instantiation for layers of that width (K = 1, 7)
 const PsKernelSet* ps_kernel_set_k1(); const PsKernelSet* ps_kernel_set_k2(); const PsKernelSet* ps_kernel_set_k3(); const PsKernelSet* ps_kernel_set_k4();
