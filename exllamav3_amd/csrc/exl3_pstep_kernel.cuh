@@ -1313,6 +1313,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 }
                 if (sw == 0) PS_T(9);
             }
+#ifndef PS_ABL_NO_COLD
             else if (in_type == PS_IN_NORM)
             {
                 if (sw == 0) PS_T(4);
@@ -1403,6 +1404,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     }
                 }
             }
+#endif
             else if (in_type == PS_IN_QKV && in_attn)
             {
                 // ATTENTION inside o_proj's preparation (exl3_pstep.cuh: PS_ATTN).  (a) this workgroup's item = (kv head h, context split) of the decode attention over the
@@ -1804,6 +1806,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             }
             if (sw == 0) PS_T(11);
             r_last = r_next;
+#ifndef PS_ABL_NO_COLD
             if (out_type == PS_OUT_ATOMIC && !out_direct && active && tl.slice == 0)
             {
                 // OWNERS of the residual row's blocks cb0 .. cb0 + W - 1 (the slice-0 workgroup of the column group).  All eight service half-waves gather: half-wave h
@@ -1892,6 +1895,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     ps_st128(rn, no + 512, uint4_t{ __float_as_uint(n2), tag_out, __float_as_uint(n3), tag_out });
                 }
             }
+#endif
             if (sw == 0) PS_T(12);
             if (sw == 0) PS_T(7);
 
