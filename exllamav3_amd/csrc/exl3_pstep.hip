@@ -387,7 +387,7 @@ extern "C" int exl3_pstep_create(void** handle_out, const exl3_pstep_layer_t* la
         lin_to_mat(*head, O.mat[0]);
         const int ncb[1] = { head->n / 128 };
         OpPlan p; EXL3_CHECK_ARG(plan_op(ncu, hidden / 128, ncb, 1, O.in_type, O.out_type, p), "exl3_pstep_create: no plan for the lm_head (a rectangle is at most 12 column blocks wide: vocab / 128 <= 12 x CUs)");
-        O.S = p.S; fill_tiles(tiles.data() + (size_t) op * ncu, ncu, p, ncb, 1, hidden / 128, 0, false);      // (the head's finish uses the uniform partition's closed formulas)
+        O.S = p.S; fill_tiles(tiles.data() + (size_t) op * ncu, ncu, p, ncb, 1, hidden / 128, 0, true, (cb_all != EXL3_CB_MUL1 || KH != K || KH >= 8) ? 2 : 3);      // (units ahead: the kernel's head pass)
         snprintf(line, sizeof(line), "head: S=%d groups=%d tile<=%dx%d; residual edges: %s%s", p.S, p.g[0], p.wmax, p.hmax, direct ? "direct (consumer gathers)" : "owners", attn ? "; attention inside o_proj's preparation" : ""); desc += line;
         if (attn) { snprintf(line, sizeof(line), " (%d kv blocks x %d splits)", att_blocks, att_nsplit); desc += line; }
         ++op;
@@ -534,7 +534,7 @@ extern "C" int exl3_pstep_plan_tiles(int hidden, int inter, int heads_q, int hea
     }
     EXL3_CHECK_ARG(plan_op(ncu, nblk, ncb, nmat, in_type, out_type, p, direct), "exl3_pstep_plan_tiles: no plan for this op on %d CUs", ncu);
     std::vector<PsTile> T((size_t) ncu);
-    fill_tiles(T.data(), ncu, p, ncb, nmat, nblk, side, op_kind != 4);
+    fill_tiles(T.data(), ncu, p, ncb, nmat, nblk, side, true);
     memcpy(tiles_out, T.data(), (size_t) ncu * sizeof(PsTile));
     *S_out = p.S;
     return EXL3_OK;

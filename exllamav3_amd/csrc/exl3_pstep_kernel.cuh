@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
             for (int r2 = 0; r2 < 2; ++r2)
             {
                 scp[r2] = half4_t{ 0, 0, 0, 0 };
-                if (active && out_type != PS_OUT_SLAB) scp[r2] = ps_g((const half4_t*) (svh_p + (size_t) (tl.cb0 + min(shw + 8 * r2, W - 1)) * 128))[l32];
+                if (active && out_type == PS_OUT_ATOMIC) scp[r2] = ps_g((const half4_t*) (svh_p + (size_t) (tl.cb0 + min(shw + 8 * r2, W - 1)) * 128))[l32];
             }
             asm volatile("" :: "s"(slab_p), "s"(S_op), "s"(tpw), "s"(line0));
 
@@ -1582,8 +1582,14 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 const int w_first = inb ? __builtin_ctz(inb) : 0;
                 return (uint32_t) w_first | (((inb >> w_first) & 0xffu) << 8) | (((sgb >> w_first) & 0xffu) << 16);
             };
-            if (out_type != PS_OUT_FINAL && sw < W)
+            half4_t scw0 = { 0, 0, 0, 0 }, scw1 = scw0;                     // (the lm_head: the column scales of this wave's first two column blocks)
+            if (sw < W)
             {
+                if (out_type == PS_OUT_FINAL)
+                {
+                    scw0 = ps_g((const half4_t*) (svh_p + (size_t) (tl.cb0 + sw) * 128))[l32];
+                    scw1 = ps_g((const half4_t*) (svh_p + (size_t) (tl.cb0 + min(sw + PS_NSV, W - 1)) * 128))[l32];
+                }
                 c_spin(PS_C_T, (uint32_t) PS_NSV * (uint32_t) (op + 1));      // (every service wave's block sums are in LDS: true long before the streaming ends)
                 float xs = 0.0f;
                 for (int q0 = 0; q0 < nb; q0 += 32) if (q0 + l32 < nb) xs += bsum[q0 + l32];
@@ -1647,7 +1653,6 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                 poison = (slim == 0 || __builtin_amdgcn_readfirstlane((int) e) != 0) ? 0x7e007e00u : 0u;
             }
 #ifndef PS_SUM_HALFWAVES
-            if (out_type != PS_OUT_FINAL)
             {
                 if (sw < W)
                 {
@@ -1663,6 +1668,20 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     {
                         v.x = halves(v.x); v.y = halves(v.y); v.z = halves(v.z); v.w = halves(v.w);
                         v.x = (v.x * kinv_s + bb_s) * fac_norm; v.y = (v.y * kinv_s + bb_s) * fac_norm; v.z = (v.z * kinv_s + bb_s) * fac_norm; v.w = (v.w * kinv_s + bb_s) * fac_norm;
+                        if (out_type == PS_OUT_FINAL)
+                        {
+                            // the lm_head (round 6: on the service-wave path too, so its rectangles can be shared by age group like the layers'): output Hadamard, column
+                            // scale, fp16 logits; NaN if any wait of the launch timed out
+                            const int cbl = tl.cb0 + j;
+                            const half4_t sc = j == sw ? scw0 : (j == sw + PS_NSV ? scw1 : ps_g((const half4_t*) (svh_p + (size_t) cbl * 128))[l]);
+                            float h0, h1, h2, h3;
+                            out_had(v, l, h0, h1, h2, h3);
+                            half4_t o = { f2h(h0), f2h(h1), f2h(h2), f2h(h3) };
+                            o = o * sc;
+                            { union { half4_t h; uint32_t u[2]; } ob; ob.h = o; ob.u[0] |= poison; ob.u[1] |= poison; o = ob.h; }
+                            if (!hi) ((half4_t PS_GLOBAL*) (logits_p + (size_t) cbl * 128))[l] = o;
+                            return;
+                        }
                         const uint32_t loff = ((uint32_t) (tl.cb0 + j) * (uint32_t) S_op + (uint32_t) (line0 + tl.slice)) * PS_PLINE_BYTES;
                         if (!(tp_sys && out_type == PS_OUT_ATOMIC)) { if (!hi) ps_pl_store(rsl, loff, l, v, tag_out); }
                         else
@@ -1713,8 +1732,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     }
                 }
             }
-            else
-#endif
+#else
             for (int j = shw; j < W; j += 2 * PS_NSV)
             {
                 const int l = l32;
@@ -1804,6 +1822,7 @@ __global__ __launch_bounds__(PS_NT) void exl3_pstep_kernel(const PsArgs a)
                     ((half4_t PS_GLOBAL*) (logits_p + (size_t) cbl * 128))[l] = o;
                 }
             }
+#endif
             if (sw == 0) PS_T(11);
             r_last = r_next;
 #ifndef PS_ABL_NO_COLD

@@ -329,6 +329,11 @@ int exl3_glue_act_rs(const float* sg, const float* su, int S, const void* svh_g,
  * 16-byte aligned operands; other shapes return EXL3_ERR_ARG (use exl3_hgemm_nt*, the hipBLASLt route). */
 int exl3_gemm_nt_mfma(const void* a, int64_t lda, const void* bt, int64_t ldb, void* c, int64_t ldc, int m, int k, int n, int epi, void* stream);
 
+/* Generation 2 of the same contraction (exl3_gemm_nt2.hip; same reference, same contract and epilogues): one wave per SIMD with a 128 x 128 wave tile, the K-loop one
+ * hand-allocated assembly statement (v_mfma_f32_32x32x16_f16 on 256 accumulator registers, four LDS buffers filled three K-tiles ahead, one barrier per K-tile).
+ * k % 128 == 0, n % 256 == 0, 16-byte aligned operands; other shapes return EXL3_ERR_ARG (generation 1 or exl3_hgemm_nt* take them). */
+int exl3_gemm_nt2_mfma(const void* a, int64_t lda, const void* bt, int64_t ldb, void* c, int64_t ldc, int m, int k, int n, int epi, void* stream);
+
 /* y[rows][cols] = silu(g) * u (activation.cu) where g and u are fp16 column ranges of wider matrices (row strides ld_g, ld_u). */
 int exl3_silu_mul_2d(const void* g, const void* u, void* y, int64_t rows, int64_t cols, int64_t ld_g, int64_t ld_u, void* stream);
 

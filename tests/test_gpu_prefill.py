@@ -332,9 +332,12 @@ def test_bc_linear_fp16(dev):
         assert float((y.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("m,k,n", [(256, 128, 256), (300, 512, 512), (1024, 4096, 768), (4096, 1024, 256)])
-def test_hand_written_nt_mfma_gemm_against_fp32_matmul_and_the_library(dev, m, k, n):
-    """exl3_gemm_nt.hip (256 x 256 x 64 tiles, global_load_lds staging with the XOR-permuted source, staggered wave groups): plain store, the fp16
+@pytest.mark.parametrize("gen", [1, 2])
+@pytest.mark.parametrize("m,k,n", [(256, 128, 256), (300, 512, 512), (1024, 4096, 768), (4096, 1024, 256), (520, 1152, 1024)])
+def test_hand_written_nt_mfma_gemm_against_fp32_matmul_and_the_library(dev, m, k, n, gen):
+    """Both generations of the hand-written contraction -- exl3_gemm_nt2.hip (gen 2: one wave per SIMD, 128 x 128 wave tiles of v_mfma_f32_32x32x16_f16, the K-loop one
+    hand-allocated assembly statement, four LDS buffers filled three K-tiles ahead) and
+    exl3_gemm_nt.hip (256 x 256 x 64 tiles, global_load_lds staging with the XOR-permuted source, staggered wave groups): plain store, the fp16
     residual-add epilogue and the fused silu(gate) * up epilogue against an fp32 matmul of the same fp16 operands; ragged row counts (300: the last
     m-tile is partial), one and several K-tiles, strided A (a column range of a wider matrix).  The plain result is also compared with the
     hipBLASLt route (same fp32 accumulation up to summation order)."""
@@ -346,7 +349,7 @@ def test_hand_written_nt_mfma_gemm_against_fp32_matmul_and_the_library(dev, m, k
     ref = a.float() @ bt.float().T
     scale = float(ref.abs().max())
     c = torch.full((m, n), float("nan"), dtype=torch.half, device=dev)
-    ext.gemm_nt_mfma(a, bt, c, 0)
+    ext.gemm_nt_mfma(a, bt, c, 0, gen)
     assert bool(torch.isfinite(c).all())
     assert float((c.float() - ref).abs().max()) < 2e-3 * scale
     lib = torch.empty_like(c)
@@ -355,16 +358,16 @@ def test_hand_written_nt_mfma_gemm_against_fp32_matmul_and_the_library(dev, m, k
     # residual add: c = fp16(c + y)
     r0 = torch.randn((m, n), device=dev, generator=g).half()
     r = r0.clone()
-    ext.gemm_nt_mfma(a, bt, r, 1)
+    ext.gemm_nt_mfma(a, bt, r, 1, gen)
     assert float((r.float() - (r0.float() + ref)).abs().max()) < 3e-3 * max(scale, 1.0)
     # silu(gate) * up: rows of bt per 256-row tile = 128 gate rows | the 128 up rows of the same outputs
     half_n = n // 2
     gate, up = bt[:half_n], bt[half_n:]
     bt_s = torch.stack([gate.view(half_n // 128, 128, k), up.view(half_n // 128, 128, k)], dim=1).reshape(n, k).contiguous()
     y = torch.full((m, half_n), float("nan"), dtype=torch.half, device=dev)
-    ext.gemm_nt_mfma(a, bt_s, y, 2)
+    ext.gemm_nt_mfma(a, bt_s, y, 2, gen)
     gf = (a.float() @ gate.float().T).half().float(); uf = (a.float() @ up.float().T).half().float()
     yref = gf / (1 + torch.exp(-gf)) * uf
     assert float((y.float() - yref).abs().max()) < 4e-3 * max(float(yref.abs().max()), 1.0)
     with pytest.raises(RuntimeError):
-        ext.gemm_nt_mfma(a[:, :96], bt[:, :96].contiguous(), c, 0)                 # k % 64
+        ext.gemm_nt_mfma(a[:, :96], bt[:, :96].contiguous(), c, 0, gen)            # k % 64 / k % 128

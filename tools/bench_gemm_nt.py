@@ -1,4 +1,4 @@
-"""Hand-written NT MFMA GEMM (exl3_gemm_nt.hip) against the hipBLASLt route on the prefill shapes of Llama-3.1-8B (4096 tokens), random data:
+"""Hand-written NT MFMA GEMM (GEN=2: exl3_gemm_nt2.hip, the default here; GEN=1: exl3_gemm_nt.hip) against the hipBLASLt route on the prefill shapes of Llama-3.1-8B (4096 tokens), random data:
 correctness on sampled entries first, then TFLOP/s of both (HIP events, 20 launches after warm-up).  gpurun -- 'python tools/bench_gemm_nt.py'"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,6 +17,9 @@ def timeit(fn, n=20):
 
 out = []
 M = int(os.environ.get("M", "4096"))
+GEN = int(os.environ.get("GEN", "2"))
+_mfma = ext.gemm_nt_mfma
+ext.gemm_nt_mfma = lambda a, bt, c, epi: _mfma(a, bt, c, epi, GEN)
 for name, k, n in [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("down", 14336, 4096)]:
     a = torch.randn((M, k), device=dev).half()
     bt = (torch.randn((n, k), device=dev) * 0.02).half()
@@ -29,7 +32,7 @@ for name, k, n in [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 286
     t1 = timeit(lambda: ext.gemm_nt_mfma(a, bt, c1, 0)); t2 = timeit(lambda: ext.hgemm_nt(a, bt, c2))
     fl = 2.0 * M * k * n
     row = {"shape": name, "m": M, "k": k, "n": n, "err_mine": round(e1, 5), "err_lib": round(e2, 5), "max_diff_vs_lib": round(full, 5),
-           "mine_us": round(t1, 1), "lib_us": round(t2, 1), "mine_tflops": round(fl / t1 / 1e6, 1), "lib_tflops": round(fl / t2 / 1e6, 1)}
+           "gen": GEN, "mine_us": round(t1, 1), "lib_us": round(t2, 1), "mine_tflops": round(fl / t1 / 1e6, 1), "lib_tflops": round(fl / t2 / 1e6, 1)}
     if name == "gate_up":
         # fused silu * mul epilogue against GEMM + silu_mul_2d: bt rows re-stacked per 256-row tile as 128 gate | 128 up
         inter = n // 2
@@ -54,5 +57,5 @@ for name, k, n in [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 286
     print(json.dumps(row), flush=True)
     out.append(row)
     del a, bt, c1, c2
-os.makedirs("gpurun_out/r3h", exist_ok=True)
-json.dump(out, open("gpurun_out/r3h/bench_gemm_nt.json", "w"), indent=1)
+os.makedirs("gpurun_out/r6", exist_ok=True)
+json.dump(out, open(f"gpurun_out/r6/bench_gemm_nt_gen{GEN}.json", "w"), indent=1)
