@@ -492,8 +492,8 @@ def gemm_nt_mfma(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, epi: int = 
     _req(c.shape[0] == a.shape[0] and c.shape[1] == (bt.shape[0] // 2 if epi == 2 else bt.shape[0]), "gemm_nt_mfma: output shape")
     if gen == 0:
         gen = 2 if a.shape[1] % 128 == 0 else 1
-    fn = _lib.lib().exl3_gemm_nt2_mfma if gen == 2 else _lib.lib().exl3_gemm_nt_mfma
-    _check(fn(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(c), c.stride(0), a.shape[0], a.shape[1], bt.shape[0], int(epi), _stream(a)))
+    fn = _lib.lib().exl3_gemm_nt2_mfma if gen >= 2 else _lib.lib().exl3_gemm_nt_mfma
+    _check(fn(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(c), c.stride(0), a.shape[0], a.shape[1], bt.shape[0], int(epi) | (0x100 if gen == 3 else 0), _stream(a)))
 
 
 def reconstruct_had_slice_t(unpacked_t: torch.Tensor, packed: torch.Tensor, suh: torch.Tensor, svh: torch.Tensor,

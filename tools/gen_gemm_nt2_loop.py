@@ -21,6 +21,9 @@ Register map (the statement's clobbers): a[0:255]; v[192:223] / v[224:255] fragm
 epilogue temporaries; s[68:81].  Operands (names below) are placed by the compiler in the registers it keeps.
 """
 
+import os
+import sys
+FLAGS = set(a for a in sys.argv[1:] if a != "clobbers")          # diagnostics (tools/r6_gn2_variants.sh): noglds noreads nobar spread -- timing only, wrong results
 MF = "v_mfma_f32_32x32x16_f16"
 SET_A = (192, 224)
 SET_B = (208, 240)
@@ -28,7 +31,14 @@ out = []
 
 
 def emit(s):
+    if in_loop and (("noglds" in FLAGS and s.startswith("global_load_lds")) or ("noreads" in FLAGS and s.startswith("ds_read")) or ("nobar" in FLAGS and s == "s_barrier")):
+        return
+    if in_loop and "noglds" in FLAGS and s.startswith("s_waitcnt vmcnt(16)"):
+        s = "s_waitcnt lgkmcnt(0)"
     out.append(s)
+
+
+in_loop = False
 
 
 def acc(im, jn):
@@ -60,6 +70,14 @@ def reads(s, buf, ks):
 
 def glds_setup(tile_expr_add, tmp="s74"):
     """scalar part of a K-tile's requests: s[76:77] / s[78:79] = operand bases + min(j + add, nk - 1) * 64"""
+    if "src128" in FLAGS:                             # timing only: K-tiles 128 bytes apart, wrapped at k / 2 (8 rows x 128 B per request: full cache lines)
+        return [f"s_add_u32 {tmp}, s73, {tile_expr_add}",
+                f"s_and_b32 {tmp}, {tmp}, s81",
+                f"s_lshl_b32 {tmp}, {tmp}, 7",
+                f"s_add_u32 s76, s68, {tmp}",
+                "s_addc_u32 s77, s69, 0",
+                f"s_add_u32 s78, s70, {tmp}",
+                "s_addc_u32 s79, s71, 0"]
     return [f"s_add_u32 {tmp}, s73, {tile_expr_add}",
             f"s_min_u32 {tmp}, {tmp}, s72",
             f"s_lshl_b32 {tmp}, {tmp}, 6",
@@ -81,6 +99,8 @@ def glds_list():
 # ------------------------------------------------------------------------------------------------------------------ prologue
 emit("s_mov_b32 s68, %[alo]"); emit("s_mov_b32 s69, %[ahi]"); emit("s_mov_b32 s70, %[blo]"); emit("s_mov_b32 s71, %[bhi]")
 emit("s_sub_u32 s72, %[nk], 1"); emit("s_mov_b32 s73, 0"); emit("s_mov_b32 s80, %[ldsw]")
+if "src128" in FLAGS:
+    emit("s_lshr_b32 s81, %[nk], 1"); emit("s_sub_u32 s81, s81, 1")
 emit("v_add_u32 v160, 0x10000, %[rdA0]"); emit("v_add_u32 v161, 0x10000, %[rdA1]"); emit("v_add_u32 v162, 0x10000, %[rdB0]"); emit("v_add_u32 v163, 0x10000, %[rdB1]")
 for t in range(4):
     # tiles 0..3 into buffers 0..3 (nk >= 4)
@@ -100,38 +120,37 @@ for r in reads(0, 0, 0):
 emit("s_waitcnt lgkmcnt(0)")
 
 # ------------------------------------------------------------------------------------------------------------------ main loop, four K-tiles per trip
+in_loop = True
 emit("L_gnt2_loop%=:")
+# slots 0..15 = the matrix instructions of half 0 (set 0), 16..31 = half 1 (set 1) of tile j = s73 + b; `extras[slot]` follow that slot's matrix instruction.
+#   * half 0 carries the fragment reads of half 1 of the same tile (into set 1), half 1 those of half 0 of tile j + 1 (into set 0)
+#   * after slot 12: tile j + 1 has landed (this wave's part; vmcnt leaves the younger requests in flight) and this wave's reads of buffer b are complete -> barrier;
+#     from then on buffer b may be overwritten: the 8 requests of tile j + 4
+GL_SLOTS = [24, 25, 26, 27, 28, 29, 30, 31] if "spread" not in FLAGS else [13, 15, 18, 20, 22, 25, 27, 29]
 for b in range(4):
-    # ---- half 0 of tile j = s73 + b (set 0); reads half 1 of the same tile into set 1
-    rd = reads(1, b, 1)
+    extras = {i: [] for i in range(32)}
+    for i, r in enumerate(reads(1, b, 1)):
+        extras[i].append(r)
+    for i, r in enumerate(reads(0, (b + 1) & 3, 0)):
+        extras[16 + i].append(r)
     sal = glds_setup(b + 4)
-    for i in range(16):
-        mfma(0, i)
-        if i < 8:
-            emit(rd[i])
-        elif i - 8 < len(sal) and i < 12:
-            emit(sal[2 * (i - 8)])
-            if 2 * (i - 8) + 1 < len(sal):
-                emit(sal[2 * (i - 8) + 1])
-        if i == 12:
-            # tile j + 1 has landed (this wave's part; two younger tiles stay in flight), this wave's reads of buffer b are complete
-            emit("s_waitcnt vmcnt(16) lgkmcnt(0)")
-            emit("s_barrier")
     assert len(sal) == 7
-    # ---- half 1 of tile j (set 1); reads half 0 of tile j + 1 into set 0; requests tile j + 4 into buffer b
-    rd = reads(0, (b + 1) & 3, 0)
+    for i, x in enumerate(sal):
+        extras[8 + i // 2].append(x)                  # (s_add / s_addc pairs stay in order: nothing else here writes SCC)
+    # requests issued before the wait at slot 12 of the NEXT tile's half 0 do not exist (all sit at slots >= 13): vmcnt(16) = two younger tiles
+    extras[12] += ["s_waitcnt vmcnt(16) lgkmcnt(0)", "s_barrier"]
     gl = glds_list()
-    for i in range(16):
-        mfma(1, i)
-        if i < 8:
-            emit(rd[i])
-        if i == 7:
-            emit(f"s_add_u32 m0, s80, {b * 32768}")
-        if i >= 8:
-            emit(gl[i - 8])
-            if i < 15:
-                emit("s_add_u32 m0, m0, 0x1000")
-    emit("s_waitcnt lgkmcnt(0)")
+    extras[GL_SLOTS[0] - 1].append(f"s_add_u32 m0, s80, {b * 32768}")
+    for k in range(8):
+        extras[GL_SLOTS[k]].append(gl[k])
+        if k < 7:
+            extras[GL_SLOTS[k]].append("s_add_u32 m0, m0, 0x1000")
+    extras[31].append("s_waitcnt lgkmcnt(0)")
+    for i in range(32):
+        mfma(i >> 4, i & 15)
+        for x in extras[i]:
+            emit(x)
+in_loop = False
 emit("s_add_u32 s73, s73, 4")
 emit("s_cmp_lt_u32 s73, %[nk]")
 emit("s_cbranch_scc1 L_gnt2_loop%=")
@@ -155,7 +174,6 @@ for im in range(4):
 emit("s_waitcnt lgkmcnt(0)")
 emit("s_barrier")
 
-import sys
 print("// generated by tools/gen_gemm_nt2_loop.py -- do not edit")
 if len(sys.argv) > 1 and sys.argv[1] == "clobbers":
     for i in range(0, 256, 16):

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled K-loop of the prefill NT GEMM, 64-deep K-tiles and v_mfma_f32_16x16x32_f16 (exllamav3_amd/csrc/exl3_gemm_nt2.hip, -DGN2_K64 body):
+
+    python tools/gen_gemm_nt3_loop.py > exllamav3_amd/csrc/exl3_gemm_nt3_loop.inc
+
+Same skeleton as tools/gen_gemm_nt2_loop.py (one wave per SIMD, 128 x 128 wave tile, 256 accumulator registers, every register named by hand), with the two things the
+first version's measurements asked for (profiles/NOTES.md R6.3): operand rows of 128 bytes -- one request = 8 full cache lines instead of 16 halves (half the L2 requests,
+half the issue time of a request) -- and the 16x16x32 matrix instruction, which the chip sustains at a higher clock on random operands than 32x32x16.
+
+  * 256 x 256 x 64 tiles in TWO LDS stages of 64 KiB (A 32 KiB | W^T 32 KiB; 128-byte rows, 16-byte chunk c of row r at position c ^ ((r >> 1) & 7): generation 1's map,
+    measured conflict-free).  16 requests per wave and K-tile.
+  * accumulators: tile (im, jn) of 16 x 16 = a[4 (8 im + jn) : + 3]; W^T fragment first, activation fragment second: lane l holds row m = l & 15 and four consecutive columns.
+  * two fragment sets of 64 registers (8 A + 8 W^T fragments of one 32-deep half).  Per K-tile t (stage t & 1), slots = the 128 matrix instructions:
+        0..15    reads of half 1 of tile t -> set 1                      (set 0 multiplies: slots 0..63)
+        20       vmcnt(0) [tile t + 1 landed] lgkmcnt(0) [stage t & 1 read]  ->  barrier
+        21..     the 16 requests of tile t + 2 into stage t & 1, every second slot
+        64..79   reads of half 0 of tile t + 1 -> set 0                    (set 1 multiplies: slots 64..127)
+  * every K-tile issues its 16 requests, the last two clamped to the last tile (uniform counts, no tail code).
+
+Register map (clobbers): a[0:255]; v[128:191] / v[192:255] fragment sets 0 / 1 (A 32 | W^T 32); v[120:123] read addresses + 64 KiB; v[104:119] epilogue temporaries; s[68:81].
+Flags (diagnostics, timing only): noglds noreads nobar
+"""
+import sys
+
+FLAGS = set(a for a in sys.argv[1:] if a != "clobbers")
+MF = "v_mfma_f32_16x16x32_f16"
+SET_A = (128, 192)
+SET_B = (160, 224)
+out = []
+in_loop = False
+
+
+def emit(s):
+    if in_loop and (("noglds" in FLAGS and s.startswith("global_load_lds")) or ("noreads" in FLAGS and s.startswith("ds_read")) or ("nobar" in FLAGS and s == "s_barrier")):
+        return
+    if in_loop and "noglds" in FLAGS and s.startswith("s_waitcnt vmcnt(0) lgkmcnt(0)"):
+        s = "s_waitcnt lgkmcnt(0)"
+    out.append(s)
+
+
+def acc(im, jn):
+    t = (im * 8 + jn) * 4
+    return f"a[{t}:{t + 3}]"
+
+
+def frag(base, i):
+    return f"v[{base + 4 * i}:{base + 4 * i + 3}]"
+
+
+def mfma(s, i):
+    im, jn = i >> 3, i & 7
+    emit(f"{MF} {acc(im, jn)}, {frag(SET_B[s], jn)}, {frag(SET_A[s], im)}, {acc(im, jn)}")
+
+
+def reads(s, stage, ks):
+    """the sixteen fragment reads of (stage, 32-deep half ks) into set s: A0 B0 B1 A1 B2 B3 ... the order the matrix instructions first touch them (im = 0 runs over all jn)"""
+    ra = (f"v{120 + ks}" if stage else f"%[rdA{ks}]")
+    rb = (f"v{122 + ks}" if stage else f"%[rdB{ks}]")
+    a = [f"ds_read_b128 {frag(SET_A[s], i)}, {ra} offset:{i * 2048}" for i in range(8)]
+    b = [f"ds_read_b128 {frag(SET_B[s], i)}, {rb} offset:{i * 2048}" for i in range(8)]
+    return [a[0]] + b + a[1:]
+
+
+def glds_setup(add, tmp="s74"):
+    return [f"s_add_u32 {tmp}, s73, {add}",
+            f"s_min_u32 {tmp}, {tmp}, s72",
+            f"s_lshl_b32 {tmp}, {tmp}, 7",
+            f"s_add_u32 s76, s68, {tmp}",
+            "s_addc_u32 s77, s69, 0",
+            f"s_add_u32 s78, s70, {tmp}",
+            "s_addc_u32 s79, s71, 0"]
+
+
+def glds_list():
+    return [f"global_load_lds_dwordx4 %[goA{i}], s[76:77]" for i in range(8)] + [f"global_load_lds_dwordx4 %[goB{i}], s[78:79]" for i in range(8)]
+
+
+# ------------------------------------------------------------------------------------------------------------------ prologue
+emit("s_mov_b32 s68, %[alo]"); emit("s_mov_b32 s69, %[ahi]"); emit("s_mov_b32 s70, %[blo]"); emit("s_mov_b32 s71, %[bhi]")
+emit("s_sub_u32 s72, %[nk], 1"); emit("s_mov_b32 s73, 0"); emit("s_mov_b32 s80, %[ldsw]")
+emit("v_add_u32 v120, 0x10000, %[rdA0]"); emit("v_add_u32 v121, 0x10000, %[rdA1]"); emit("v_add_u32 v122, 0x10000, %[rdB0]"); emit("v_add_u32 v123, 0x10000, %[rdB1]")
+for t in range(2):
+    emit(f"s_add_u32 s76, s68, {t * 128}"); emit("s_addc_u32 s77, s69, 0"); emit(f"s_add_u32 s78, s70, {t * 128}"); emit("s_addc_u32 s79, s71, 0")
+    emit(f"s_add_u32 m0, s80, {t * 65536}")
+    emit("s_nop 0")
+    for k, g in enumerate(glds_list()):
+        emit(g)
+        if k < 15:
+            emit("s_add_u32 m0, m0, 0x1000"); emit("s_nop 0")
+for i in range(256):
+    emit(f"v_accvgpr_write_b32 a{i}, 0")
+emit("s_waitcnt vmcnt(16)")
+emit("s_barrier")
+for r in reads(0, 0, 0):
+    emit(r)
+emit("s_waitcnt lgkmcnt(0)")
+
+# ------------------------------------------------------------------------------------------------------------------ main loop, two K-tiles per trip
+in_loop = True
+# The four waves of the workgroup run FOUR copies of the loop that differ only in the slots of their requests: wave w issues request k after matrix instruction
+# GL0 + GL_STEP k + w, so the CU's one address unit sees one request per slot instead of four at once (measured: a request issued by all four waves in the same slot
+# stalls each of them ~26 cycles beyond the matrix instruction it hides behind -- profiles/NOTES.md R6.3).  "nostagger": one copy, all waves in the same slots.
+STAGGER = "nostagger" not in FLAGS
+GL0, GL_STEP = (21, 4) if STAGGER else (21, 2)
+NW = 4 if STAGGER else 1
+if STAGGER:
+    for w in range(1, 4):
+        emit(f"s_cmp_eq_u32 %[wid], {w}")
+        emit(f"s_cbranch_scc1 L_gnt3_w{w}%=")
+for w in range(NW):
+    emit(f"L_gnt3_w{w}%=:")
+    for st in range(2):
+        extras = {i: [] for i in range(128)}
+        for i, r in enumerate(reads(1, st, 1)):
+            extras[i].append(r)
+        for i, r in enumerate(reads(0, st ^ 1, 0)):
+            extras[64 + i].append(r)
+        sal = glds_setup(st + 2)
+        for i, x in enumerate(sal):
+            extras[16 + i // 2].append(x)
+        extras[20] += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier", f"s_add_u32 m0, s80, {st * 65536}"]
+        gl = glds_list()
+        for k in range(16):
+            extras[GL0 + GL_STEP * k + w].append(gl[k])
+            if k < 15:
+                extras[GL0 + GL_STEP * k + w].append("s_add_u32 m0, m0, 0x1000")
+        extras[127].append("s_waitcnt lgkmcnt(0)")
+        for i in range(128):
+            mfma(i >> 6, i & 63)
+            for x in extras[i]:
+                emit(x)
+    emit("s_add_u32 s73, s73, 2")
+    emit("s_cmp_lt_u32 s73, %[nk]")
+    emit(f"s_cbranch_scc1 L_gnt3_w{w}%=")
+    if STAGGER and w < 3:
+        emit("s_branch L_gnt3_done%=")
+emit("L_gnt3_done%=:")
+in_loop = False
+
+# ------------------------------------------------------------------------------------------------------------------ accumulators -> fp16 C tile in LDS
+emit("s_waitcnt vmcnt(0)")
+emit("s_barrier")
+emit("s_nop 15")
+n = 0
+for im in range(8):
+    for jn in range(8):
+        a0 = (im * 8 + jn) * 4
+        t = 104 + 8 * (n & 1)
+        for e in range(4):
+            emit(f"v_accvgpr_read_b32 v{t + e}, a{a0 + e}")
+        emit(f"v_cvt_pk_f16_f32 v{t + 4}, v{t}, v{t + 1}")
+        emit(f"v_cvt_pk_f16_f32 v{t + 5}, v{t + 2}, v{t + 3}")
+        emit(f"ds_write_b64 %[ct], v[{t + 4}:{t + 5}] offset:{im * 16 * 528 + jn * 32}")
+        n += 1
+emit("s_waitcnt lgkmcnt(0)")
+emit("s_barrier")
+
+print("// generated by tools/gen_gemm_nt3_loop.py -- do not edit")
+for s in out:
+    print(f'"{s}\\n\\t"')

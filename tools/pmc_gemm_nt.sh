@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over the hand-written NT GEMM and the library route on the o_proj shape (4096^3): gpurun -- 'bash tools/pmc_gemm_nt.sh' -> gpurun_out/pmc_gemm_nt.json
+# PMC passes over the hand-written NT GEMM and the library route on the o_proj shape (4096^3): gpurun -- 'bash tools/pmc_gemm_nt.sh' -> gpurun_out/r6/pmc_gemm_nt2.json
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmcg; mkdir -p $O
 cat > /tmp/g.py <<PY
 import sys, os, torch
@@ -9,7 +9,7 @@ dev = torch.device("cuda:0"); ext.init(0)
 M, k, n = 4096, 4096, 4096
 a = torch.randn((M, k), device=dev).half(); bt = (torch.randn((n, k), device=dev) * 0.02).half()
 c = torch.empty((M, n), dtype=torch.half, device=dev)
-for _ in range(3): ext.gemm_nt_mfma(a, bt, c, 0)
+for _ in range(3): ext.gemm_nt_mfma(a, bt, c, 0, int(os.environ.get("GEN", "2")))
 for _ in range(3): ext.hgemm_nt(a, bt, c)
 torch.cuda.synchronize()
 PY
@@ -26,10 +26,10 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/p*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r.get("Kernel_Name", "")
-        if "exl3_gemm_nt_kernel" in n or "Cijk" in n:
+        if "exl3_gemm_nt" in n or "Cijk" in n:
             acc[n.split("(")[0][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {c: round(sum(v) / len(v), 1) for c, v in d.items()} for k, d in acc.items()}
-json.dump(out, open("$R/gpurun_out/pmc_gemm_nt.json", "w"), indent=1)
+json.dump(out, open("$R/gpurun_out/r6/pmc_gemm_nt2.json", "w"), indent=1)
 for k, d in out.items():
     print(k); print("  ", d)
 PY
