@@ -484,16 +484,17 @@ def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: boo
 
 def gemm_nt_mfma(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, epi: int = 0, gen: int = 0):
     """The hand-written NT MFMA GEMM: c = a @ bt.T; epi 0 store, 1 c += (fp16 residual add), 2 silu(gate) * up on 128 | 128
-    row pairs of bt (c has bt.shape[0] / 2 columns).  gen 2: exl3_gemm_nt2.hip (one wave per SIMD, assembly K-loop; k % 128, n % 256), gen 1:
-    exl3_gemm_nt.hip (k % 64, n % 256), gen 0: generation 2 where its shape applies.  Raises for shapes outside the chosen kernel."""
+    row pairs of bt (c has bt.shape[0] / 2 columns).  gen 0: exl3_gemm_nt2.hip (one wave per SIMD, assembly K-loop; k % 64, n % 128) with the tile it picks for the
+    shape; gen 3 / 4 force its 256 x 256 / 256 x 128 tile, gen 2 its first version (32-deep K-tiles, k % 128); gen 1: exl3_gemm_nt.hip (k % 64, n % 256).
+    Raises for shapes outside the chosen kernel."""
     _dev(a)
     _req(a.dtype == torch.half and bt.dtype == torch.half and c.dtype == torch.half and a.dim() == 2 and bt.dim() == 2 and c.dim() == 2, "gemm_nt_mfma: 2-D float16 tensors")
     _req(a.stride(1) == 1 and bt.stride(1) == 1 and c.stride(1) == 1 and a.shape[1] == bt.shape[1], "gemm_nt_mfma: unit column strides, shared k")
     _req(c.shape[0] == a.shape[0] and c.shape[1] == (bt.shape[0] // 2 if epi == 2 else bt.shape[0]), "gemm_nt_mfma: output shape")
-    if gen == 0:
-        gen = 2 if a.shape[1] % 128 == 0 else 1
-    fn = _lib.lib().exl3_gemm_nt2_mfma if gen >= 2 else _lib.lib().exl3_gemm_nt_mfma
-    _check(fn(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(c), c.stride(0), a.shape[0], a.shape[1], bt.shape[0], int(epi) | (0x100 if gen == 3 else 0), _stream(a)))
+    if gen == 0 and a.shape[1] % 64 != 0:
+        gen = 1
+    fn = _lib.lib().exl3_gemm_nt2_mfma if gen != 1 else _lib.lib().exl3_gemm_nt_mfma
+    _check(fn(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(c), c.stride(0), a.shape[0], a.shape[1], bt.shape[0], int(epi) | {2: 0x100, 3: 0x400, 4: 0x200}.get(gen, 0), _stream(a)))
 
 
 def reconstruct_had_slice_t(unpacked_t: torch.Tensor, packed: torch.Tensor, suh: torch.Tensor, svh: torch.Tensor,

@@ -332,7 +332,7 @@ def test_bc_linear_fp16(dev):
         assert float((y.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("gen", [1, 2, 3])
+@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("m,k,n", [(256, 128, 256), (300, 512, 512), (1024, 4096, 768), (4096, 1024, 256), (520, 1152, 1024)])
 def test_hand_written_nt_mfma_gemm_against_fp32_matmul_and_the_library(dev, m, k, n, gen):
     """Both generations of the hand-written contraction -- exl3_gemm_nt2.hip (gen 2: one wave per SIMD, 128 x 128 wave tiles of v_mfma_f32_32x32x16_f16, the K-loop one
@@ -371,3 +371,24 @@ def test_hand_written_nt_mfma_gemm_against_fp32_matmul_and_the_library(dev, m, k
     assert float((y.float() - yref).abs().max()) < 4e-3 * max(float(yref.abs().max()), 1.0)
     with pytest.raises(RuntimeError):
         ext.gemm_nt_mfma(a[:, :96], bt[:, :96].contiguous(), c, 0, gen)            # k % 64 / k % 128
+
+
+@pytest.mark.parametrize("gen", [0, 4])
+@pytest.mark.parametrize("m,k,n", [(300, 192, 384), (256, 64, 128), (1000, 4096, 6144 + 128), (4096, 320, 1280)])
+def test_assembly_gemm_narrow_tile_and_odd_shapes(dev, m, k, n, gen):
+    """exl3_gemm_nt2.hip outside the 256-multiples: k % 64 (one, three, five K-tiles: the three-stage loop leaves at every tile boundary), n % 128 (the 256 x 128 tile is
+    the only form that takes it), ragged m; plain store and the residual add against an fp32 matmul of the same fp16 operands."""
+    from exllamav3_amd import ext
+    g = torch.Generator(device=dev); g.manual_seed(m * 7 + k + n)
+    a = torch.randn((m, k), device=dev, generator=g).half()
+    bt = (torch.randn((n, k), device=dev, generator=g) * 0.05).half()
+    ref = a.float() @ bt.float().T
+    scale = float(ref.abs().max())
+    c = torch.full((m, n), float("nan"), dtype=torch.half, device=dev)
+    ext.gemm_nt_mfma(a, bt, c, 0, gen)
+    assert bool(torch.isfinite(c).all())
+    assert float((c.float() - ref).abs().max()) < 2e-3 * scale
+    r0 = torch.randn((m, n), device=dev, generator=g).half()
+    r = r0.clone()
+    ext.gemm_nt_mfma(a, bt, r, 1, gen)
+    assert float((r.float() - (r0.float() + ref)).abs().max()) < 3e-3 * max(scale, 1.0)

@@ -17,7 +17,7 @@ def timeit(fn, n=20):
 
 out = []
 M = int(os.environ.get("M", "4096"))
-GEN = int(os.environ.get("GEN", "2"))
+GEN = int(os.environ.get("GEN", "0"))
 _mfma = ext.gemm_nt_mfma
 ext.gemm_nt_mfma = lambda a, bt, c, epi: _mfma(a, bt, c, epi, GEN)
 for name, k, n in [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("down", 14336, 4096)]:

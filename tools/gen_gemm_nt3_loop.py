@@ -23,6 +23,14 @@ Flags (diagnostics, timing only): noglds noreads nobar
 import sys
 
 FLAGS = set(a for a in sys.argv[1:] if a != "clobbers")
+# "n128": the 256 x 128 tile (wave tile 128 x 64, four W^T fragments per half, a[0:127]) in THREE stages of 48 KiB, requests three K-tiles ahead with a counted vmcnt --
+# for shapes whose 256 x 256 tile count leaves CUs idle in the last round (q|k|v of Llama-3.1-8B: 384 tiles on 256 CUs; 768 narrow tiles = three full rounds)
+NB = 4 if "n128" in FLAGS else 8                      # W^T fragments of a wave per 32-deep half
+S = 3 if NB == 4 else 2                               # LDS stages
+STAGE = [0, 65536] if S == 2 else [0, 49152, 98304]
+NG = 8 + NB                                           # requests / fragment reads per wave and K-tile / half
+NS = 16 * NB                                          # matrix instructions per wave and K-tile
+RP = 1                                                # fragment reads per slot (two per slot with all four waves in step saturate the LDS port: +12 % cycles, measured)
 MF = "v_mfma_f32_16x16x32_f16"
 SET_A = (128, 192)
 SET_B = (160, 224)
@@ -33,13 +41,13 @@ in_loop = False
 def emit(s):
     if in_loop and (("noglds" in FLAGS and s.startswith("global_load_lds")) or ("noreads" in FLAGS and s.startswith("ds_read")) or ("nobar" in FLAGS and s == "s_barrier")):
         return
-    if in_loop and "noglds" in FLAGS and s.startswith("s_waitcnt vmcnt(0) lgkmcnt(0)"):
+    if in_loop and "noglds" in FLAGS and s.startswith("s_waitcnt vmcnt(") and s.endswith("lgkmcnt(0)"):
         s = "s_waitcnt lgkmcnt(0)"
     out.append(s)
 
 
 def acc(im, jn):
-    t = (im * 8 + jn) * 4
+    t = (im * NB + jn) * 4
     return f"a[{t}:{t + 3}]"
 
 
@@ -48,16 +56,20 @@ def frag(base, i):
 
 
 def mfma(s, i):
-    im, jn = i >> 3, i & 7
+    im, jn = i // NB, i % NB
+    if (im & 1) and "noserp" not in FLAGS:
+        jn = NB - 1 - jn                                  # serpentine: at a change of the A fragment the W^T fragment stays (one operand toggles, not two)
     emit(f"{MF} {acc(im, jn)}, {frag(SET_B[s], jn)}, {frag(SET_A[s], im)}, {acc(im, jn)}")
 
 
 def reads(s, stage, ks):
     """the sixteen fragment reads of (stage, 32-deep half ks) into set s: A0 B0 B1 A1 B2 B3 ... the order the matrix instructions first touch them (im = 0 runs over all jn)"""
-    ra = (f"v{120 + ks}" if stage else f"%[rdA{ks}]")
-    rb = (f"v{122 + ks}" if stage else f"%[rdB{ks}]")
-    a = [f"ds_read_b128 {frag(SET_A[s], i)}, {ra} offset:{i * 2048}" for i in range(8)]
-    b = [f"ds_read_b128 {frag(SET_B[s], i)}, {rb} offset:{i * 2048}" for i in range(8)]
+    hi = STAGE[stage] >= 65536
+    imm0 = STAGE[stage] - (65536 if hi else 0)
+    ra = (f"v{120 + ks}" if hi else f"%[rdA{ks}]")
+    rb = (f"v{122 + ks}" if hi else f"%[rdB{ks}]")
+    a = [f"ds_read_b128 {frag(SET_A[s], i)}, {ra} offset:{imm0 + i * 2048}" for i in range(8)]
+    b = [f"ds_read_b128 {frag(SET_B[s], i)}, {rb} offset:{imm0 + i * 2048}" for i in range(NB)]
     return [a[0]] + b + a[1:]
 
 
@@ -72,65 +84,76 @@ def glds_setup(add, tmp="s74"):
 
 
 def glds_list():
-    return [f"global_load_lds_dwordx4 %[goA{i}], s[76:77]" for i in range(8)] + [f"global_load_lds_dwordx4 %[goB{i}], s[78:79]" for i in range(8)]
+    return [f"global_load_lds_dwordx4 %[goA{i}], s[76:77]" for i in range(8)] + [f"global_load_lds_dwordx4 %[goB{i}], s[78:79]" for i in range(NB)]
 
 
 # ------------------------------------------------------------------------------------------------------------------ prologue
 emit("s_mov_b32 s68, %[alo]"); emit("s_mov_b32 s69, %[ahi]"); emit("s_mov_b32 s70, %[blo]"); emit("s_mov_b32 s71, %[bhi]")
 emit("s_sub_u32 s72, %[nk], 1"); emit("s_mov_b32 s73, 0"); emit("s_mov_b32 s80, %[ldsw]")
 emit("v_add_u32 v120, 0x10000, %[rdA0]"); emit("v_add_u32 v121, 0x10000, %[rdA1]"); emit("v_add_u32 v122, 0x10000, %[rdB0]"); emit("v_add_u32 v123, 0x10000, %[rdB1]")
-for t in range(2):
-    emit(f"s_add_u32 s76, s68, {t * 128}"); emit("s_addc_u32 s77, s69, 0"); emit(f"s_add_u32 s78, s70, {t * 128}"); emit("s_addc_u32 s79, s71, 0")
-    emit(f"s_add_u32 m0, s80, {t * 65536}")
+for t in range(S):
+    # tiles 0 .. S - 1 into stages 0 .. S - 1 (clamped: nk may be smaller than S)
+    emit(f"s_min_u32 s74, {t}, s72"); emit("s_lshl_b32 s74, s74, 7")
+    emit("s_add_u32 s76, s68, s74"); emit("s_addc_u32 s77, s69, 0"); emit("s_add_u32 s78, s70, s74"); emit("s_addc_u32 s79, s71, 0")
+    emit(f"s_add_u32 m0, s80, {STAGE[t]}")
     emit("s_nop 0")
     for k, g in enumerate(glds_list()):
         emit(g)
-        if k < 15:
+        if k < NG - 1:
             emit("s_add_u32 m0, m0, 0x1000"); emit("s_nop 0")
-for i in range(256):
+for i in range(8 * NB * 4):
     emit(f"v_accvgpr_write_b32 a{i}, 0")
-emit("s_waitcnt vmcnt(16)")
+emit(f"s_waitcnt vmcnt({(S - 1) * NG})")
 emit("s_barrier")
 for r in reads(0, 0, 0):
     emit(r)
 emit("s_waitcnt lgkmcnt(0)")
 
-# ------------------------------------------------------------------------------------------------------------------ main loop, two K-tiles per trip
+# ------------------------------------------------------------------------------------------------------------------ main loop, S K-tiles per trip
 in_loop = True
 # The four waves of the workgroup run FOUR copies of the loop that differ only in the slots of their requests: wave w issues request k after matrix instruction
-# GL0 + GL_STEP k + w, so the CU's one address unit sees one request per slot instead of four at once (measured: a request issued by all four waves in the same slot
+# GL0 + 4 k + w, so the CU's one address unit sees one request per slot instead of four at once (measured: a request issued by all four waves in the same slot
 # stalls each of them ~26 cycles beyond the matrix instruction it hides behind -- profiles/NOTES.md R6.3).  "nostagger": one copy, all waves in the same slots.
+# Per K-tile t (stage t % S), slots = its NS matrix instructions:
+#     0 ..           the NG reads of half 1 of tile t -> set 1 (RP per slot)                 (set 0 multiplies: slots 0 .. NS / 2 - 1)
+#     BS             vmcnt((S - 2) NG) [tile t + 1 landed] lgkmcnt(0) [stage t % S read] -> barrier
+#     BS + 1 ..      the NG requests of tile t + S into stage t % S
+#     NS / 2 ..      the NG reads of half 0 of tile t + 1 -> set 0                            (set 1 multiplies: slots NS / 2 .. NS - 1)
 STAGGER = "nostagger" not in FLAGS
-GL0, GL_STEP = (21, 4) if STAGGER else (21, 2)
 NW = 4 if STAGGER else 1
+RSL = NG // RP                                        # slots that carry fragment reads
+SAL0 = RSL if NB == 8 else RSL - 4                    # the scalar part of the requests: after the reads, or (narrow tile: 64 slots) beside the last four
+BS = SAL0 + 4
+GL0, GL_STEP = (BS + 1, 4) if STAGGER else (BS + 1, 2)
+assert GL0 + GL_STEP * (NG - 1) + (NW - 1) < NS
 if STAGGER:
     for w in range(1, 4):
         emit(f"s_cmp_eq_u32 %[wid], {w}")
         emit(f"s_cbranch_scc1 L_gnt3_w{w}%=")
 for w in range(NW):
     emit(f"L_gnt3_w{w}%=:")
-    for st in range(2):
-        extras = {i: [] for i in range(128)}
+    for st in range(S):
+        extras = {i: [] for i in range(NS)}
         for i, r in enumerate(reads(1, st, 1)):
-            extras[i].append(r)
-        for i, r in enumerate(reads(0, st ^ 1, 0)):
-            extras[64 + i].append(r)
-        sal = glds_setup(st + 2)
+            extras[i // RP].append(r)
+        for i, r in enumerate(reads(0, (st + 1) % S, 0)):
+            extras[NS // 2 + i // RP].append(r)
+        sal = glds_setup(S)
         for i, x in enumerate(sal):
-            extras[16 + i // 2].append(x)
-        extras[20] += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier", f"s_add_u32 m0, s80, {st * 65536}"]
+            extras[SAL0 + i // 2].append(x)
+        extras[BS] += [f"s_waitcnt vmcnt({(S - 2) * NG}) lgkmcnt(0)", "s_barrier", f"s_add_u32 m0, s80, {STAGE[st]}"]
         gl = glds_list()
-        for k in range(16):
+        for k in range(NG):
             extras[GL0 + GL_STEP * k + w].append(gl[k])
-            if k < 15:
+            if k < NG - 1:
                 extras[GL0 + GL_STEP * k + w].append("s_add_u32 m0, m0, 0x1000")
-        extras[127].append("s_waitcnt lgkmcnt(0)")
-        for i in range(128):
-            mfma(i >> 6, i & 63)
+        extras[NS - 1] += ["s_waitcnt lgkmcnt(0)", "s_add_u32 s73, s73, 1", "s_cmp_lt_u32 s73, %[nk]"]
+        for i in range(NS):
+            mfma(i // (NS // 2), i % (NS // 2))
             for x in extras[i]:
                 emit(x)
-    emit("s_add_u32 s73, s73, 2")
-    emit("s_cmp_lt_u32 s73, %[nk]")
+        if st < S - 1:
+            emit("s_cbranch_scc0 L_gnt3_done%=")
     emit(f"s_cbranch_scc1 L_gnt3_w{w}%=")
     if STAGGER and w < 3:
         emit("s_branch L_gnt3_done%=")
@@ -143,8 +166,8 @@ emit("s_barrier")
 emit("s_nop 15")
 n = 0
 for im in range(8):
-    for jn in range(8):
-        a0 = (im * 8 + jn) * 4
+    for jn in range(NB):
+        a0 = (im * NB + jn) * 4
         t = 104 + 8 * (n & 1)
         for e in range(4):
             emit(f"v_accvgpr_read_b32 v{t + e}, a{a0 + e}")
