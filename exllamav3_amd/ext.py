@@ -455,9 +455,10 @@ def hgemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):
                                  int(c.dtype == torch.float), _stream(a)))
 
 
-#: EXL3_HIP_GEMM_NT=1 routes the prefill GEMMs (hgemm_nt) through the hand-written NT MFMA kernel; default 0: hipBLASLt, which measured 1.2-1.3x
-#: faster on every Llama-3.1-8B prefill shape (profiles/r03_gemm_nt_vs_hipblaslt.json)
-_GEMM_NT_OWN = __import__("os").environ.get("EXL3_HIP_GEMM_NT", "0") == "1"
+#: The prefill GEMMs (hgemm_nt) run the hand-written NT MFMA kernel (exl3_gemm_nt2.hip: assembly K-loop, one wave per SIMD) wherever its tiles apply; the
+#: library GEMM (hipBLASLt) takes the other shapes, and all of them with EXL3_HIP_GEMM_NT=0.  On the four Llama-3.1-8B prefill shapes the own kernel measures
+#: 1.03 / 0.97 / 0.95 / 0.98 x the library (q|k|v, o, gate|up, down; profiles/r06_gemm_nt_vs_hipblaslt.json), 0.96 x over the whole chunk.
+_GEMM_NT_OWN = __import__("os").environ.get("EXL3_HIP_GEMM_NT", "1") == "1"
 
 
 def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: bool = False):
@@ -468,9 +469,9 @@ def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: boo
     _req(a.shape[1] == bt.shape[1] and a.shape[0] == c.shape[0] and bt.shape[0] == c.shape[1], "hgemm_nt: shape mismatch")
     _req(a.stride(1) == 1 and bt.stride(1) == 1 and c.stride(1) == 1, "hgemm_nt: a, bt, c need unit column stride")
     _req(not accumulate or c.dtype == torch.half, "hgemm_nt: accumulate needs a float16 c")
-    if _GEMM_NT_OWN and c.dtype == torch.half and bt.shape[0] % 256 == 0 and a.shape[1] % 64 == 0 and a.stride(0) % 8 == 0 and bt.stride(0) % 8 == 0 \
-            and c.stride(0) % 8 == 0 and a.shape[0] >= 256:
-        # EXL3_HIP_GEMM_NT=1: the hand-written MFMA GEMM (exl3_gemm_nt.hip) instead of hipBLASLt wherever its tile shape applies
+    if _GEMM_NT_OWN and c.dtype == torch.half and bt.shape[0] % 128 == 0 and a.shape[1] % 64 == 0 and a.stride(0) % 8 == 0 and bt.stride(0) % 8 == 0 \
+            and c.stride(0) % 8 == 0 and a.shape[0] >= 256 and (a.data_ptr() | bt.data_ptr() | c.data_ptr()) % 16 == 0:
+        # the hand-written MFMA GEMM (exl3_gemm_nt2.hip) wherever its tile shapes apply (k % 64, n % 128, rows >= one tile)
         gemm_nt_mfma(a, bt, c, 1 if accumulate else 0)
         return
     if a.is_contiguous():
@@ -494,7 +495,7 @@ def gemm_nt_mfma(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, epi: int = 
     if gen == 0 and a.shape[1] % 64 != 0:
         gen = 1
     fn = _lib.lib().exl3_gemm_nt2_mfma if gen != 1 else _lib.lib().exl3_gemm_nt_mfma
-    _check(fn(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(c), c.stride(0), a.shape[0], a.shape[1], bt.shape[0], int(epi) | {2: 0x100, 3: 0x400, 4: 0x200}.get(gen, 0), _stream(a)))
+    _check(fn(_p(a), a.stride(0), _p(bt), bt.stride(0), _p(c), c.stride(0), a.shape[0], a.shape[1], bt.shape[0], int(epi) | {2: 0x100, 3: 0x400, 4: 0x200, 5: 0x800, 6: 0xC00, 7: 0x1400}.get(gen, 0), _stream(a)))
 
 
 def reconstruct_had_slice_t(unpacked_t: torch.Tensor, packed: torch.Tensor, suh: torch.Tensor, svh: torch.Tensor,

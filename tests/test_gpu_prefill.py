@@ -332,7 +332,7 @@ def test_bc_linear_fp16(dev):
         assert float((y.float() - ref).abs().max()) < 2e-2 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("gen", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("m,k,n", [(256, 128, 256), (300, 512, 512), (1024, 4096, 768), (4096, 1024, 256), (520, 1152, 1024)])
 def test_hand_written_nt_mfma_gemm_against_fp32_matmul_and_the_library(dev, m, k, n, gen):
     """Both generations of the hand-written contraction -- exl3_gemm_nt2.hip (gen 2: one wave per SIMD, 128 x 128 wave tiles of v_mfma_f32_32x32x16_f16, the K-loop one

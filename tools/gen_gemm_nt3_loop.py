@@ -30,7 +30,7 @@ S = 3 if NB == 4 else 2                               # LDS stages
 STAGE = [0, 65536] if S == 2 else [0, 49152, 98304]
 NG = 8 + NB                                           # requests / fragment reads per wave and K-tile / half
 NS = 16 * NB                                          # matrix instructions per wave and K-tile
-RP = 1                                                # fragment reads per slot (two per slot with all four waves in step saturate the LDS port: +12 % cycles, measured)
+RP = 2 if "rp2" in FLAGS else 1                       # fragment reads per slot (two per slot with all four waves in step saturate the LDS port: +12 % cycles, measured)
 MF = "v_mfma_f32_16x16x32_f16"
 SET_A = (128, 192)
 SET_B = (160, 224)
@@ -91,74 +91,158 @@ def glds_list():
 emit("s_mov_b32 s68, %[alo]"); emit("s_mov_b32 s69, %[ahi]"); emit("s_mov_b32 s70, %[blo]"); emit("s_mov_b32 s71, %[bhi]")
 emit("s_sub_u32 s72, %[nk], 1"); emit("s_mov_b32 s73, 0"); emit("s_mov_b32 s80, %[ldsw]")
 emit("v_add_u32 v120, 0x10000, %[rdA0]"); emit("v_add_u32 v121, 0x10000, %[rdA1]"); emit("v_add_u32 v122, 0x10000, %[rdB0]"); emit("v_add_u32 v123, 0x10000, %[rdB1]")
-for t in range(S):
-    # tiles 0 .. S - 1 into stages 0 .. S - 1 (clamped: nk may be smaller than S)
-    emit(f"s_min_u32 s74, {t}, s72"); emit("s_lshl_b32 s74, s74, 7")
-    emit("s_add_u32 s76, s68, s74"); emit("s_addc_u32 s77, s69, 0"); emit("s_add_u32 s78, s70, s74"); emit("s_addc_u32 s79, s71, 0")
-    emit(f"s_add_u32 m0, s80, {STAGE[t]}")
-    emit("s_nop 0")
-    for k, g in enumerate(glds_list()):
-        emit(g)
-        if k < NG - 1:
-            emit("s_add_u32 m0, m0, 0x1000"); emit("s_nop 0")
-for i in range(8 * NB * 4):
-    emit(f"v_accvgpr_write_b32 a{i}, 0")
-emit(f"s_waitcnt vmcnt({(S - 1) * NG})")
-emit("s_barrier")
-for r in reads(0, 0, 0):
-    emit(r)
-emit("s_waitcnt lgkmcnt(0)")
+A3 = "a3" in FLAGS
+if A3:
+    # ---- "a3": THREE stages for the activations (0 / 32 / 64 KiB), two for W^T (96 / 128 KiB) = all 160 KiB of the CU.  After barrier(t) a wave requests W^T(t + 2), then
+    # A(t + 3): the requests that are needed first are issued first, the others get a whole K-tile more of flight time (operands that come from HBM rather than the
+    # 256 MB cache -- the down projection inside a prefill chunk -- arrived late with two stages each: +10 % there, profiles/NOTES.md R6.3).  Six K-tiles per trip.
+    assert NB == 8
+    STA = [0, 32768, 65536]; STB = [0, 32768]          # (W^T stages relative to 96 KiB: %[rdB*] and the request base carry the 96 KiB)
 
-# ------------------------------------------------------------------------------------------------------------------ main loop, S K-tiles per trip
-in_loop = True
-# The four waves of the workgroup run FOUR copies of the loop that differ only in the slots of their requests: wave w issues request k after matrix instruction
-# GL0 + 4 k + w, so the CU's one address unit sees one request per slot instead of four at once (measured: a request issued by all four waves in the same slot
-# stalls each of them ~26 cycles beyond the matrix instruction it hides behind -- profiles/NOTES.md R6.3).  "nostagger": one copy, all waves in the same slots.
-# Per K-tile t (stage t % S), slots = its NS matrix instructions:
-#     0 ..           the NG reads of half 1 of tile t -> set 1 (RP per slot)                 (set 0 multiplies: slots 0 .. NS / 2 - 1)
-#     BS             vmcnt((S - 2) NG) [tile t + 1 landed] lgkmcnt(0) [stage t % S read] -> barrier
-#     BS + 1 ..      the NG requests of tile t + S into stage t % S
-#     NS / 2 ..      the NG reads of half 0 of tile t + 1 -> set 0                            (set 1 multiplies: slots NS / 2 .. NS - 1)
-STAGGER = "nostagger" not in FLAGS
-NW = 4 if STAGGER else 1
-RSL = NG // RP                                        # slots that carry fragment reads
-SAL0 = RSL if NB == 8 else RSL - 4                    # the scalar part of the requests: after the reads, or (narrow tile: 64 slots) beside the last four
-BS = SAL0 + 4
-GL0, GL_STEP = (BS + 1, 4) if STAGGER else (BS + 1, 2)
-assert GL0 + GL_STEP * (NG - 1) + (NW - 1) < NS
-if STAGGER:
+    def reads3(s_, ta, tb, ks):
+        sa, sb = ta % 3, tb % 2
+        ra = f"v{120 + ks}" if sa == 2 else f"%[rdA{ks}]"
+        ia = 0 if sa == 2 else STA[sa]
+        a = [f"ds_read_b128 {frag(SET_A[s_], i)}, {ra} offset:{ia + i * 2048}" for i in range(8)]
+        b = [f"ds_read_b128 {frag(SET_B[s_], i)}, %[rdB{ks}] offset:{STB[sb] + i * 2048}" for i in range(8)]
+        return [a[0]] + b + a[1:]
+
+    def setup3(addB, addA):
+        return [f"s_add_u32 s74, s73, {addB}", "s_min_u32 s74, s74, s72", "s_lshl_b32 s74, s74, 7", "s_add_u32 s78, s70, s74", "s_addc_u32 s79, s71, 0",
+                f"s_add_u32 s75, s73, {addA}", "s_min_u32 s75, s75, s72", "s_lshl_b32 s75, s75, 7", "s_add_u32 s76, s68, s75", "s_addc_u32 s77, s69, 0"]
+
+    gA = [f"global_load_lds_dwordx4 %[goA{i}], s[76:77]" for i in range(8)]
+    gB = [f"global_load_lds_dwordx4 %[goB{i}], s[78:79]" for i in range(8)]
+
+    def pro(kind, t):
+        emit(f"s_min_u32 s74, {t}, s72"); emit("s_lshl_b32 s74, s74, 7")
+        if kind == "A":
+            emit("s_add_u32 s76, s68, s74"); emit("s_addc_u32 s77, s69, 0"); emit(f"s_add_u32 m0, s80, {STA[t % 3]}")
+        else:
+            emit("s_add_u32 s78, s70, s74"); emit("s_addc_u32 s79, s71, 0"); emit(f"s_add_u32 m0, s80, {98304 + STB[t % 2]}")
+        emit("s_nop 0")
+        for k, g in enumerate(gA if kind == "A" else gB):
+            emit(g)
+            if k < 7:
+                emit("s_add_u32 m0, m0, 0x1000"); emit("s_nop 0")
+
+    pro("A", 0); pro("B", 0); pro("A", 1); pro("B", 1); pro("A", 2)
+    for i in range(256):
+        emit(f"v_accvgpr_write_b32 a{i}, 0")
+    emit("s_waitcnt vmcnt(24)")
+    emit("s_barrier")
+    for r in reads3(0, 0, 0, 0):
+        emit(r)
+    emit("s_waitcnt lgkmcnt(0)")
+    in_loop = True
     for w in range(1, 4):
         emit(f"s_cmp_eq_u32 %[wid], {w}")
         emit(f"s_cbranch_scc1 L_gnt3_w{w}%=")
-for w in range(NW):
-    emit(f"L_gnt3_w{w}%=:")
-    for st in range(S):
-        extras = {i: [] for i in range(NS)}
-        for i, r in enumerate(reads(1, st, 1)):
-            extras[i // RP].append(r)
-        for i, r in enumerate(reads(0, (st + 1) % S, 0)):
-            extras[NS // 2 + i // RP].append(r)
-        sal = glds_setup(S)
-        for i, x in enumerate(sal):
-            extras[SAL0 + i // 2].append(x)
-        extras[BS] += [f"s_waitcnt vmcnt({(S - 2) * NG}) lgkmcnt(0)", "s_barrier", f"s_add_u32 m0, s80, {STAGE[st]}"]
-        gl = glds_list()
-        for k in range(NG):
-            extras[GL0 + GL_STEP * k + w].append(gl[k])
+    for w in range(4):
+        emit(f"L_gnt3_w{w}%=:")
+        for tau in range(6):
+            extras = {i: [] for i in range(128)}
+            for i, r in enumerate(reads3(1, tau, tau, 1)):
+                extras[i].append(r)
+            for i, r in enumerate(reads3(0, tau + 1, tau + 1, 0)):
+                extras[64 + i].append(r)
+            sal = setup3(2, 3)
+            for i, x in enumerate(sal):
+                extras[16 + [0, 0, 0, 1, 1, 2, 2, 2, 3, 3][i]].append(x)
+            extras[20] += ["s_waitcnt vmcnt(8) lgkmcnt(0)", "s_barrier", f"s_add_u32 m0, s80, {98304 + STB[tau % 2]}"]
+            gl = gB + gA
+            for k in range(16):
+                slot = 21 + 4 * k + w
+                extras[slot].append(gl[k])
+                if k == 7:
+                    extras[slot].append(f"s_add_u32 m0, s80, {STA[tau % 3]}")
+                elif k < 15:
+                    extras[slot].append("s_add_u32 m0, m0, 0x1000")
+            extras[127] += ["s_waitcnt lgkmcnt(0)", "s_add_u32 s73, s73, 1", "s_cmp_lt_u32 s73, %[nk]"]
+            for i in range(128):
+                mfma(i >> 6, i & 63)
+                for x in extras[i]:
+                    emit(x)
+            if tau < 5:
+                emit("s_cbranch_scc0 L_gnt3_done%=")
+        emit(f"s_cbranch_scc1 L_gnt3_w{w}%=")
+        if w < 3:
+            emit("s_branch L_gnt3_done%=")
+    emit("L_gnt3_done%=:")
+    in_loop = False
+else:
+    for t in range(S):
+        # tiles 0 .. S - 1 into stages 0 .. S - 1 (clamped: nk may be smaller than S)
+        emit(f"s_min_u32 s74, {t}, s72"); emit("s_lshl_b32 s74, s74, 7")
+        emit("s_add_u32 s76, s68, s74"); emit("s_addc_u32 s77, s69, 0"); emit("s_add_u32 s78, s70, s74"); emit("s_addc_u32 s79, s71, 0")
+        emit(f"s_add_u32 m0, s80, {STAGE[t]}")
+        emit("s_nop 0")
+        for k, g in enumerate(glds_list()):
+            emit(g)
             if k < NG - 1:
-                extras[GL0 + GL_STEP * k + w].append("s_add_u32 m0, m0, 0x1000")
-        extras[NS - 1] += ["s_waitcnt lgkmcnt(0)", "s_add_u32 s73, s73, 1", "s_cmp_lt_u32 s73, %[nk]"]
-        for i in range(NS):
-            mfma(i // (NS // 2), i % (NS // 2))
-            for x in extras[i]:
-                emit(x)
-        if st < S - 1:
-            emit("s_cbranch_scc0 L_gnt3_done%=")
-    emit(f"s_cbranch_scc1 L_gnt3_w{w}%=")
-    if STAGGER and w < 3:
-        emit("s_branch L_gnt3_done%=")
-emit("L_gnt3_done%=:")
-in_loop = False
+                emit("s_add_u32 m0, m0, 0x1000"); emit("s_nop 0")
+    for i in range(8 * NB * 4):
+        emit(f"v_accvgpr_write_b32 a{i}, 0")
+    emit(f"s_waitcnt vmcnt({(S - 1) * NG})")
+    emit("s_barrier")
+    for r in reads(0, 0, 0):
+        emit(r)
+    emit("s_waitcnt lgkmcnt(0)")
+
+    # ------------------------------------------------------------------------------------------------------------------ main loop, S K-tiles per trip
+    in_loop = True
+    # The four waves of the workgroup run FOUR copies of the loop that differ only in the slots of their requests: wave w issues request k after matrix instruction
+    # GL0 + 4 k + w, so the CU's one address unit sees one request per slot instead of four at once (measured: a request issued by all four waves in the same slot
+    # stalls each of them ~26 cycles beyond the matrix instruction it hides behind -- profiles/NOTES.md R6.3).  "nostagger": one copy, all waves in the same slots.
+    # Per K-tile t (stage t % S), slots = its NS matrix instructions:
+    #     0 ..           the NG reads of half 1 of tile t -> set 1 (RP per slot)                 (set 0 multiplies: slots 0 .. NS / 2 - 1)
+    #     BS             vmcnt((S - 2) NG) [tile t + 1 landed] lgkmcnt(0) [stage t % S read] -> barrier
+    #     BS + 1 ..      the NG requests of tile t + S into stage t % S
+    #     NS / 2 ..      the NG reads of half 0 of tile t + 1 -> set 0                            (set 1 multiplies: slots NS / 2 .. NS - 1)
+    STAGGER = "nostagger" not in FLAGS
+    NW = 4 if STAGGER else 1
+    RSL = NG // RP                                        # slots that carry fragment reads
+    SAL0 = RSL if NB == 8 else RSL - 4                    # the scalar part of the requests: after the reads, or (narrow tile: 64 slots) beside the last four
+    BS = SAL0 + 4
+    GL0, GL_STEP = (BS + 1, 4) if STAGGER else (BS + 1, 2)
+    for f in FLAGS:
+        if f.startswith("glstep="):
+            GL_STEP = int(f[7:])
+    assert GL0 + GL_STEP * (NG - 1) + (NW - 1 if GL_STEP >= 4 else GL_STEP - 1) < NS
+    if STAGGER:
+        for w in range(1, 4):
+            emit(f"s_cmp_eq_u32 %[wid], {w}")
+            emit(f"s_cbranch_scc1 L_gnt3_w{w}%=")
+    for w in range(NW):
+        emit(f"L_gnt3_w{w}%=:")
+        for st in range(S):
+            extras = {i: [] for i in range(NS)}
+            for i, r in enumerate(reads(1, st, 1)):
+                extras[i // RP].append(r)
+            for i, r in enumerate(reads(0, (st + 1) % S, 0)):
+                extras[NS // 2 + i // RP].append(r)
+            sal = glds_setup(S)
+            for i, x in enumerate(sal):
+                extras[SAL0 + i // 2].append(x)
+            extras[BS] += [f"s_waitcnt vmcnt({(S - 2) * NG}) lgkmcnt(0)", "s_barrier", f"s_add_u32 m0, s80, {STAGE[st]}"]
+            gl = glds_list()
+            for k in range(NG):
+                slot = GL0 + GL_STEP * k + (w if GL_STEP >= 4 else w % GL_STEP if GL_STEP > 1 else 0)
+                extras[slot].append(gl[k])
+                if k < NG - 1:
+                    extras[slot].append("s_add_u32 m0, m0, 0x1000")
+            extras[NS - 1] += ["s_waitcnt lgkmcnt(0)", "s_add_u32 s73, s73, 1", "s_cmp_lt_u32 s73, %[nk]"]
+            for i in range(NS):
+                mfma(i // (NS // 2), i % (NS // 2))
+                for x in extras[i]:
+                    emit(x)
+            if st < S - 1:
+                emit("s_cbranch_scc0 L_gnt3_done%=")
+        emit(f"s_cbranch_scc1 L_gnt3_w{w}%=")
+        if STAGGER and w < 3:
+            emit("s_branch L_gnt3_done%=")
+    emit("L_gnt3_done%=:")
+    in_loop = False
 
 # ------------------------------------------------------------------------------------------------------------------ accumulators -> fp16 C tile in LDS
 emit("s_waitcnt vmcnt(0)")

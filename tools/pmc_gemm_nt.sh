@@ -9,7 +9,7 @@ dev = torch.device("cuda:0"); ext.init(0)
 M, k, n = 4096, 4096, 4096
 a = torch.randn((M, k), device=dev).half(); bt = (torch.randn((n, k), device=dev) * 0.02).half()
 c = torch.empty((M, n), dtype=torch.half, device=dev)
-for _ in range(3): ext.gemm_nt_mfma(a, bt, c, 0, int(os.environ.get("GEN", "2")))
+for _ in range(3): ext.gemm_nt_mfma(a, bt, c, 0, int(os.environ.get("GEN", "0")))
 for _ in range(3): ext.hgemm_nt(a, bt, c)
 torch.cuda.synchronize()
 PY
