@@ -461,15 +461,16 @@ def hgemm(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):
 _GEMM_NT_OWN = __import__("os").environ.get("EXL3_HIP_GEMM_NT", "1") == "1"
 
 
-def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: bool = False):
-    """c = a @ bt.T (+ c if accumulate): bt is B^T, (n, k) with unit column stride (row stride >= k) -- both operands K-major."""
+def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: bool = False, route: str | None = None):
+    """c = a @ bt.T (+ c if accumulate): bt is B^T, (n, k) with unit column stride (row stride >= k) -- both operands K-major.
+    route: None = the module default (own kernel where its tiles apply, EXL3_HIP_GEMM_NT=0: library), "library" / "own" force one (tests, A/B tools)."""
     _dev(a)
     _req(a.dtype == torch.half and bt.dtype == torch.half and c.dtype in (torch.half, torch.float), "hgemm_nt: bad dtypes")
     _req(a.dim() == 2 and bt.dim() == 2 and c.dim() == 2, "hgemm_nt: tensors must be 2-D")
     _req(a.shape[1] == bt.shape[1] and a.shape[0] == c.shape[0] and bt.shape[0] == c.shape[1], "hgemm_nt: shape mismatch")
     _req(a.stride(1) == 1 and bt.stride(1) == 1 and c.stride(1) == 1, "hgemm_nt: a, bt, c need unit column stride")
     _req(not accumulate or c.dtype == torch.half, "hgemm_nt: accumulate needs a float16 c")
-    if _GEMM_NT_OWN and c.dtype == torch.half and bt.shape[0] % 128 == 0 and a.shape[1] % 64 == 0 and a.stride(0) % 8 == 0 and bt.stride(0) % 8 == 0 \
+    if (_GEMM_NT_OWN if route is None else route == "own") and c.dtype == torch.half and bt.shape[0] % 128 == 0 and a.shape[1] % 64 == 0 and a.stride(0) % 8 == 0 and bt.stride(0) % 8 == 0 \
             and c.stride(0) % 8 == 0 and a.shape[0] >= 256 and (a.data_ptr() | bt.data_ptr() | c.data_ptr()) % 16 == 0:
         # the hand-written MFMA GEMM (exl3_gemm_nt2.hip) wherever its tile shapes apply (k % 64, n % 128, rows >= one tile)
         gemm_nt_mfma(a, bt, c, 1 if accumulate else 0)

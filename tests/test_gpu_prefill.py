@@ -192,14 +192,15 @@ def test_hgemm_nt(dev, m, k, n):
     b = _t((rng.standard_normal((k, n)) / np.sqrt(k)).astype(np.float16), dev)
     bt = b.t().contiguous()
     ref = a.float() @ b.float()
-    for dt in (torch.half, torch.float):
-        c = torch.empty((m, n), dtype=dt, device=dev)
-        ext.hgemm_nt(a, bt, c)
-        assert float((c.float() - ref).abs().max()) < 2e-2
-    r0 = _t(rng.standard_normal((m, n)).astype(np.float16), dev)
-    r1 = r0.clone()
-    ext.hgemm_nt(a, bt, r1, accumulate=True)
-    assert float((r1.float() - (r0.float() + ref)).abs().max()) < 3e-2
+    for route in (None, "library", "own"):                # default = the own kernel where its tiles apply (fp16 output, rows >= 256), the library otherwise
+        for dt in (torch.half, torch.float):
+            c = torch.empty((m, n), dtype=dt, device=dev)
+            ext.hgemm_nt(a, bt, c, route=route)
+            assert float((c.float() - ref).abs().max()) < 2e-2
+        r0 = _t(rng.standard_normal((m, n)).astype(np.float16), dev)
+        r1 = r0.clone()
+        ext.hgemm_nt(a, bt, r1, accumulate=True, route=route)
+        assert float((r1.float() - (r0.float() + ref)).abs().max()) < 3e-2
 
 
 def test_forward_gate_up_silu_fused_gemm(dev):
@@ -353,7 +354,7 @@ def test_hand_written_nt_mfma_gemm_against_fp32_matmul_and_the_library(dev, m, k
     assert bool(torch.isfinite(c).all())
     assert float((c.float() - ref).abs().max()) < 2e-3 * scale
     lib = torch.empty_like(c)
-    ext.hgemm_nt(a, bt, lib)
+    ext.hgemm_nt(a, bt, lib, route="library")
     assert float((c.float() - lib.float()).abs().max()) < 1e-3 * scale
     # residual add: c = fp16(c + y)
     r0 = torch.randn((m, n), device=dev, generator=g).half()

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from exllamav3_amd import ext
 dev = torch.device("cuda:0"); ext.init(0)
+ext._GEMM_NT_OWN = False                              # ext.hgemm_nt = the library route here; the own kernel is called as ext.gemm_nt_mfma
 torch.manual_seed(0)
 
 def timeit(fn, n=20):

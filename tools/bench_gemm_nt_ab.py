@@ -4,7 +4,9 @@ import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from exllamav3_amd import ext
-dev = torch.device("cuda:0"); ext.init(0); torch.manual_seed(0)
+dev = torch.device("cuda:0"); ext.init(0)
+ext._GEMM_NT_OWN = False                              # ext.hgemm_nt = the library route here; the own kernel is called as ext.gemm_nt_mfma
+torch.manual_seed(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 def block(fn, n):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)

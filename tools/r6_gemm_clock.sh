@@ -5,7 +5,7 @@ cat > /tmp/gc.py <<PY
 import sys, os, torch
 sys.path.insert(0, "$R")
 from exllamav3_amd import ext
-dev = torch.device("cuda:0"); ext.init(0)
+dev = torch.device("cuda:0"); ext.init(0); ext._GEMM_NT_OWN = False
 M, k, n = 4096, 4096, 4096
 a = torch.randn((M, k), device=dev).half(); bt = (torch.randn((n, k), device=dev) * 0.02).half()
 c = torch.empty((M, n), dtype=torch.half, device=dev)
