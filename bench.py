@@ -215,7 +215,7 @@ def pinned_logits_check(model_name, K, cb, bsz, dev, pipeline, tol=3e-2, ctx=Non
         m.attn_merge_in_oproj_hd64 = True
         cache0 = [(c.clone(), s_.clone()) for c, s_ in m.kcache + m.vcache]           # (every run appends the new token's row: the same bits each time, restored anyway)
     step = {"tail": m.decode_step_tail, "glue": m.decode_step_fused, "resid": m.decode_step_resid, "fx": m.decode_step_fx, "unfused": m.decode_step,
-            "persistent": m.decode_step_persistent}[pipeline]
+            "persistent": m.decode_step_persistent, "bc_runners": m.decode_step_bc_runners}[pipeline]
     if pipeline == "persistent":
         assert m.persistent_applies(), "bench.py: the persistent step does not cover this configuration"
     ref = np.asarray(pins[key]["logits"], dtype=np.float32).reshape(pins[key]["shape"])
@@ -714,6 +714,15 @@ def main():
                     if att_persistent else fx_step_desc + " + the attention core (q|k|v epilogue inside the context-split launch, merge inside o_proj)")
         extra["llama-3.1-8b_bs1_with_attention_ctx1000"] = timed_decode(model, att_step(model), 1)
         extra["llama-3.1-8b_bs1_with_attention_ctx1000"]["step"] = att_desc
+        # ... and the same step (attention over the same 1000-token cache) through the reference's RUNNER objects: what the reference stack over the installed stub delivers
+        try:
+            extra["llama-3.1-8b_bs1_with_attention_ctx1000_through_bc_runners"] = timed_decode(model, model.decode_step_bc_runners, 1)
+            extra["llama-3.1-8b_bs1_with_attention_ctx1000_through_bc_runners"].update({
+                "step": "per layer: rms_norm, ext.BC_Attention.run, add, rms_norm, ext.BC_GatedMLP.run_bszN, add; BC_LinearEXL3.run for the head -- the launch-per-op kernels "
+                        "behind the reference's per-module surface (libtorch/attention.cpp:506, libtorch/mlp.cpp:93), one hipGraph per step",
+                "logits_check": pinned_logits_check("llama-3.1-8b", args.bits, cb, 1, dev, "bc_runners", ctx=1000)})
+        except Exception as e:
+            extra["llama-3.1-8b_bs1_with_attention_ctx1000_through_bc_runners"] = {"error": repr(e)[:300]}
         att_pipe = "persistent" if att_persistent else (pipe_x if pipe_x != "unfused" else "glue")
         extra["llama-3.1-8b_bs1_with_attention_ctx1000"]["logits_check"] = pinned_logits_check("llama-3.1-8b", args.bits, cb, 1, dev, att_pipe, ctx=1000)
         if att_persistent:

@@ -414,6 +414,43 @@ class SyntheticEXL3Llama:
         self.lm_head.bc.run(self.xn, self.logits)
         return self.logits
 
+    # ---- the step through the reference's RUNNER objects -------------------------------------------------------------------------
+    def decode_step_bc_runners(self):
+        """The decode step as the reference's own module stack runs it over this build's seam: per layer RMSNorm -> `BC_Attention.run` -> residual add -> RMSNorm ->
+        `BC_GatedMLP.run_bszN` -> residual add (modules/transformer.py's block order over libtorch/attention.cpp:506, libtorch/mlp.cpp:93), final norm,
+        `BC_LinearEXL3.run` for the head -- what a maintainer gets who installs the `exllamav3_ext` stub and changes nothing else.  The attention over the
+        quantized cache is part of `BC_Attention.run` (needs `alloc_state`); graph-capturable."""
+        bsz, h, dev = self._state_bsz, self.shape.hidden, self.device
+        if getattr(self, "_bc_runners", None) is None or self._bc_runners[0] != bsz:
+            hd = self.shape.head_dim
+            y = torch.empty((bsz, 1, h), dtype=torch.half, device=dev); d = torch.empty((1, bsz, h), dtype=torch.half, device=dev)
+            m8 = max(8, bsz)
+            guh = torch.empty((2, m8, h), dtype=torch.half, device=dev); gu = torch.empty((2, m8, self.inter_local), dtype=torch.half, device=dev)
+            a = torch.empty((1, m8, self.inter_local), dtype=torch.half, device=dev); dxh = torch.empty_like(a)
+            runners = []
+            for li, L in enumerate(self.layers):
+                (kc, ks), (vc, vs) = self.kcache[li], self.vcache[li]
+                attn = ext.BC_Attention(num_q_heads=self.hq, num_kv_heads=self.hkv, head_dim=hd, hidden_size=h, hidden_size_padded=h, page_size=self.page,
+                                        q_proj=L["q"].bc, k_proj=L["k"].bc, v_proj=L["v"].bc, o_proj=L["o"].bc, norm_eps=self.eps, inv_freq=self.inv_freq, rope_style=2,
+                                        attn_factor=1.0, quant_cache=True, cache_k=kc, cache_v=vc, cache_k_scales=ks, cache_v_scales=vs, xh=None, h32=None)
+                mlp = ext.BC_GatedMLP(guh, gu, a, dxh, None, None, None, L["gate"].K, L["gate"].mcg, L["gate"].mul1, True, False, False,
+                                      L["gate"].bc, L["up"].bc, L["down"].bc, 0.0)
+                runners.append((attn, mlp))
+            self._bc_runners = (bsz, runners, y, d)
+        _, runners, y, d = self._bc_runners
+        x = self.x
+        x.copy_(self.x0)
+        for (attn, mlp), L in zip(runners, self.layers):
+            ext.rms_norm(x, L["norm1"], self.xn, self.eps)
+            attn.run(bsz, 1, self.xn.view(bsz, 1, h), y, self.cache_seqlens, self.block_table, 0, self.positions, None, None)
+            ext.add(x, y.view(bsz, h))
+            ext.rms_norm(x, L["norm2"], self.xn, self.eps)
+            mlp.run_bszN(self.xn.view(1, bsz, h), d)
+            ext.add(x, d.view(bsz, h))
+        ext.rms_norm(x, self.final_norm, self.xn, self.eps)
+        self.lm_head.bc.run(self.xn, self.logits)
+        return self.logits
+
     # ---- the same step with the fused pipeline: deferred-epilogue GEMVs + glue kernels (8 launches per layer) ----------
     #: prefill: rebuild the next Linears' fp16 W on a side stream while the current GEMM runs (linear.ReconstructAhead).  Measured on
     #: MI355X: 68.3k tok/s with it vs 70.6k inline -- the concurrent kernel slows the hipBLASLt GEMM and W is no longer Infinity-Cache-warm

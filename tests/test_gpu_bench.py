@@ -72,7 +72,9 @@ def test_bench_pinned_logits_gate(dev, name, K, cb, bsz, pipeline):
 
 
 @pytest.mark.parametrize("name,ctx,pipeline", [("llama-3.1-8b", 1000, "persistent"), ("llama-3.1-8b", 16000, "persistent"), ("llama-3.2-1b", 1000, "persistent"),
-                                               ("llama-3.1-8b", 1000, "fx"), ("llama-3.1-8b", 16000, "fx"), ("llama-3.2-1b", 1000, "fx")])
+                                               ("llama-3.1-8b", 1000, "fx"), ("llama-3.1-8b", 16000, "fx"), ("llama-3.2-1b", 1000, "fx"),
+                                               # the step through the reference's runner objects (ext.BC_Attention / BC_GatedMLP / BC_LinearEXL3: llama_path.decode_step_bc_runners)
+                                               ("llama-3.1-8b", 1000, "bc_runners"), ("llama-3.2-1b", 1000, "bc_runners")])
 def test_bench_pinned_logits_gate_with_attention(dev, name, ctx, pipeline):
     """The gate of bench.py's ..._with_attention_ctx* lines (round 6: they carried `edge_timeout: false` only): the timed step with the decode attention over a host-seeded
     pre-filled 4-bit cache reproduces the oracle's committed logits; at 16 000 tokens the persistent step's context splits take several 128-token steps."""
