@@ -393,3 +393,36 @@ def test_assembly_gemm_narrow_tile_and_odd_shapes(dev, m, k, n, gen):
     r = r0.clone()
     ext.gemm_nt_mfma(a, bt, r, 1, gen)
     assert float((r.float() - (r0.float() + ref)).abs().max()) < 3e-3 * max(scale, 1.0)
+
+
+def test_hgemm_nt_default_route_strided_operands_and_fallbacks(dev):
+    """ext.hgemm_nt's default route: W^T and the output as column / row ranges of wider matrices (leading dimensions > k / n) through the own kernel; operands the kernel
+    does not take -- a pointer that is not 16-byte aligned, fewer than 256 rows, fp32 output -- silently take the library and give the same values."""
+    from exllamav3_amd import ext
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    m, k, n = 512, 320, 384
+    aw = torch.randn((m, k + 64), device=dev, generator=g).half(); a = aw[:, 32: 32 + k]
+    bw = (torch.randn((n, k + 128), device=dev, generator=g) * 0.05).half(); bt = bw[:, 64: 64 + k]
+    cw = torch.full((m, n + 256), float("nan"), dtype=torch.half, device=dev); c = cw[:, 128: 128 + n]
+    ref = a.float() @ bt.float().T
+    scale = float(ref.abs().max())
+    ext.hgemm_nt(a, bt, c)
+    assert float((c.float() - ref).abs().max()) < 2e-3 * scale
+    assert bool(torch.isnan(cw[:, :128]).all()) and bool(torch.isnan(cw[:, 128 + n:]).all())          # nothing written outside the column range
+    lib = torch.empty((m, n), dtype=torch.half, device=dev)
+    ext.hgemm_nt(a, bt.contiguous(), lib, route="library")
+    assert float((c.float() - lib.float()).abs().max()) < 1e-3 * scale
+    # 8-byte aligned start: not a shape of the own kernel (16-byte requests) -> library, same values
+    flat = torch.zeros((m * k + 4,), dtype=torch.half, device=dev)
+    a8 = flat[4:].view(m, k); a8.copy_(a)
+    assert a8.data_ptr() % 16 == 8
+    c8 = torch.empty((m, n), dtype=torch.half, device=dev)
+    ext.hgemm_nt(a8, bt.contiguous(), c8)
+    assert float((c8.float() - ref).abs().max()) < 2e-3 * scale
+    # fewer rows than a tile, and fp32 output
+    c_small = torch.empty((100, n), dtype=torch.half, device=dev)
+    ext.hgemm_nt(a[:100], bt, c_small)
+    assert float((c_small.float() - ref[:100]).abs().max()) < 2e-3 * scale
+    c32 = torch.empty((m, n), dtype=torch.float, device=dev)
+    ext.hgemm_nt(a, bt.contiguous(), c32)
+    assert float((c32 - ref).abs().max()) < 2e-3 * scale
