@@ -161,6 +161,7 @@ def _declare(l):
     l.exl3_pstep_stamps.restype = i64
     PP = ctypes.POINTER(vp)
     sig("exl3_reconstruct_had_multi_t", vp, i64, PP, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, vp)
+    sig("exl3_reconstruct_had_multi_t_interleaved", vp, i64, PP, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, vp)
     sig("exl3_gemv_ex", vp, PP, PP, PP, PP, PP, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
     sig("exl3_glue_norm", vp, i32, vp, vp, vp, vp, vp, f32, PP, PP, PP, i32, i32, i32, vp, vp)
     sig("exl3_glue_qkv", vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp)

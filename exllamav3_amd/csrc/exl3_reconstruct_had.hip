@@ -51,6 +51,7 @@ struct ReconMats
     const uint32_t* packed[RH_MAX_MATS]; const half_t* suh[RH_MAX_MATS]; const half_t* svh[RH_MAX_MATS];
     int tiles_n_total[RH_MAX_MATS], tile_n_offset[RH_MAX_MATS], nb_first[RH_MAX_MATS];      // nb_first: first 128-column block of matrix i in the grid
     int count;
+    int interleave;                                       // 1: block row nb of matrix i is written at position nb * count + i (equal n_i): the tile pairing of a fused epilogue
 };
 
 template <int K, int CB, bool TR>
@@ -64,7 +65,7 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const ReconMats mt, int64_
     const half_t* __restrict__ suh = mt.suh[mi];
     const half_t* __restrict__ svh = mt.svh[mi];
     const int tiles_n_total = mt.tiles_n_total[mi], tile_n_offset = mt.tile_n_offset[mi];
-    const int nb_out = blockIdx.x;                              // position in the stacked output
+    const int nb_out = mt.interleave ? ((int) blockIdx.x - mt.nb_first[mi]) * mt.count + mi : (int) blockIdx.x;          // position in the stacked output
     constexpr int NW = 8 * K;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     half_t* Wt = (half_t*) smem;                          // [n][RH_LD]  W_hat transposed; later the output staging [k'][RH_LD]
@@ -270,6 +271,30 @@ extern "C" int exl3_reconstruct_had_multi_t(void* out, int64_t ld_out, const voi
         nb += tiles_n[i] / 8;
     }
     mt.count = count;
+    return reconstruct_had_launch(out, ld_out, 1, mt, nb, tiles_k, K, cb, stream);
+}
+
+// The same launch with the matrices' 128-row blocks INTERLEAVED: block row j of matrix i lands at rows (j * count + i) * 128 (all n_i equal).  count = 2 is the operand the
+// prefill GEMM's fused silu(gate) * up epilogue wants: every 256-row tile of W^T = 128 gate rows | the 128 up rows of the same outputs (exl3_gemm_nt2_mfma, epi 2).
+extern "C" int exl3_reconstruct_had_multi_t_interleaved(void* out, int64_t ld_out, const void* const* trellis, const void* const* suh, const void* const* svh,
+                                                        const int* tiles_n, int count, int tiles_k, int K, int cb, void* stream)
+{
+    EXL3_CHECK_ARG(out && trellis && suh && svh && tiles_n, "reconstruct_had_multi_t_interleaved: null pointer");
+    EXL3_CHECK_ARG(count >= 1 && count <= RH_MAX_MATS, "reconstruct_had_multi_t_interleaved: between 1 and 4 matrices");
+    EXL3_CHECK_ARG(K >= 1 && K <= 8 && cb >= 0 && cb <= 2, "reconstruct_had_multi_t_interleaved: K must be in [1, 8], codebook in [0, 2]");
+    EXL3_CHECK_ARG(tiles_k % 8 == 0 && tiles_k > 0, "reconstruct_had_multi_t_interleaved: K dimension must be divisible by 128");
+    EXL3_CHECK_ARG(ld_out >= (int64_t) tiles_k * 16 && ld_out % 8 == 0, "reconstruct_had_multi_t_interleaved: bad output row stride");
+    ReconMats mt; memset((void*) &mt, 0, sizeof(mt));
+    int nb = 0;
+    for (int i = 0; i < count; ++i)
+    {
+        EXL3_CHECK_ARG(trellis[i] && suh[i] && svh[i] && tiles_n[i] > 0 && tiles_n[i] % 8 == 0 && tiles_n[i] == tiles_n[0],
+                       "reconstruct_had_multi_t_interleaved: null matrix / n not divisible by 128 / matrices of different n");
+        mt.packed[i] = (const uint32_t*) trellis[i]; mt.suh[i] = (const half_t*) suh[i]; mt.svh[i] = (const half_t*) svh[i];
+        mt.tiles_n_total[i] = tiles_n[i]; mt.tile_n_offset[i] = 0; mt.nb_first[i] = nb;
+        nb += tiles_n[i] / 8;
+    }
+    mt.count = count; mt.interleave = 1;
     return reconstruct_had_launch(out, ld_out, 1, mt, nb, tiles_k, K, cb, stream);
 }
 

@@ -484,6 +484,11 @@ def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: boo
                                             int(c.dtype == torch.float), int(accumulate), _stream(a)))
 
 
+def gemm_nt_own_default() -> bool:
+    """Whether ext.hgemm_nt's default route is the hand-written kernel (EXL3_HIP_GEMM_NT != 0)."""
+    return _GEMM_NT_OWN
+
+
 def gemm_nt_mfma(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, epi: int = 0, gen: int = 0):
     """The hand-written NT MFMA GEMM: c = a @ bt.T; epi 0 store, 1 c += (fp16 residual add), 2 silu(gate) * up on 128 | 128
     row pairs of bt (c has bt.shape[0] / 2 columns).  gen 0: exl3_gemm_nt2.hip (one wave per SIMD, assembly K-loop; k % 64, n % 128) with the tile it picks for the
@@ -512,8 +517,9 @@ def reconstruct_had_slice_t(unpacked_t: torch.Tensor, packed: torch.Tensor, suh:
                                              K, _cb(mcg, mul1), n_offset, unpacked_t.shape[0], _stream(unpacked_t)))
 
 
-def reconstruct_had_multi_t(unpacked_t: torch.Tensor, packed: list, suhs: list, svhs: list, K: int, mcg: bool, mul1: bool):
-    """W^T of up to 4 whole matrices (same k, K, codebook) stacked along n into unpacked_t (sum n_i, k) in ONE launch."""
+def reconstruct_had_multi_t(unpacked_t: torch.Tensor, packed: list, suhs: list, svhs: list, K: int, mcg: bool, mul1: bool, interleave: bool = False):
+    """W^T of up to 4 whole matrices (same k, K, codebook) stacked along n into unpacked_t (sum n_i, k) in ONE launch.  interleave: the matrices' 128-row blocks
+    alternate (block j of matrix i at rows (j * count + i) * 128; equal n): the operand of gemm_nt_mfma's fused silu(gate) * up epilogue."""
     _dev(unpacked_t)
     cnt = len(packed)
     _req(1 <= cnt <= 4 and len(suhs) == cnt and len(svhs) == cnt, "reconstruct_had_multi_t: between 1 and 4 matrices")
@@ -523,8 +529,9 @@ def reconstruct_had_multi_t(unpacked_t: torch.Tensor, packed: list, suhs: list, 
     _req(unpacked_t.shape[0] == sum(p.shape[1] * 16 for p in packed), "unpacked_t rows = sum of the matrices' n")
     _req(all(t.dtype == torch.half for t in suhs + svhs), "suh/svh must be float16")
     tn = (ctypes.c_int * cnt)(*[p.shape[1] for p in packed])
-    _check(_lib.lib().exl3_reconstruct_had_multi_t(_p(unpacked_t), unpacked_t.stride(0), _parr(packed), _parr(suhs), _parr(svhs), tn, cnt, packed[0].shape[0],
-                                                   int(K), _cb(mcg, mul1), _stream(unpacked_t)))
+    _req(not interleave or all(p.shape[1] == packed[0].shape[1] for p in packed), "reconstruct_had_multi_t (interleave): matrices of one n")
+    fn = _lib.lib().exl3_reconstruct_had_multi_t_interleaved if interleave else _lib.lib().exl3_reconstruct_had_multi_t
+    _check(fn(_p(unpacked_t), unpacked_t.stride(0), _parr(packed), _parr(suhs), _parr(svhs), tn, cnt, packed[0].shape[0], int(K), _cb(mcg, mul1), _stream(unpacked_t)))
 
 
 def hgemm_acc(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor):

@@ -80,6 +80,11 @@ int exl3_reconstruct_had_t(void* out, int64_t ld_out, const void* trellis, const
  * reconstructs each Linear on its own) read this buffer as one B operand. */
 int exl3_reconstruct_had_multi_t(void* out, int64_t ld_out, const void* const* trellis, const void* const* suh, const void* const* svh,
                                  const int* tiles_n, int count, int tiles_k, int K, int cb, void* stream);
+/* The same launch with the matrices' 128-row blocks interleaved (block row j of matrix i at rows (j * count + i) * 128; equal n_i): for count = 2 every 256-row tile of
+ * the output is 128 gate rows | the 128 up rows of the same outputs -- the B operand of exl3_gemm_nt2_mfma's fused silu(gate) * up epilogue (activation.cu silu_mul
+ * behind modules/mlp.py's gate / up forwards; the reference runs the two GEMMs and the activation as separate launches). */
+int exl3_reconstruct_had_multi_t_interleaved(void* out, int64_t ld_out, const void* const* trellis, const void* const* suh, const void* const* svh,
+                                             const int* tiles_n, int count, int tiles_k, int K, int cb, void* stream);
 
 /* had_r_128(input, output, pre_scale, post_scale, scale)   quant/hadamard.cu:88-173.
  * rows x cols, cols % 128 == 0; fp32 = 0: fp16 in/out, 1: fp32 in/out; scales fp16 [cols] or NULL; in-place allowed */

@@ -203,11 +203,28 @@ def test_hgemm_nt(dev, m, k, n):
         assert float((r1.float() - (r0.float() + ref)).abs().max()) < 3e-2
 
 
-def test_forward_gate_up_silu_fused_gemm(dev):
-    """One NT GEMM for gate|up + silu_mul_2d against two forwards + silu_mul and the oracle."""
+def test_reconstruct_had_multi_t_interleaved_is_a_block_permutation(dev):
+    """exl3_reconstruct_had_multi_t_interleaved: the same values as the stacked form, the matrices' 128-row blocks alternating (bit-exact)."""
+    from exllamav3_amd import ext
+    k, n, K = 256, 384, 4
+    mats = [o.synth_linear(k, n, K, seed=s_, realistic=True) for s_ in (3, 4)]
+    tr = [_t(m[0], dev) for m in mats]; su = [_t(m[1], dev) for m in mats]; sv = [_t(m[2], dev) for m in mats]
+    st = torch.empty((2 * n, k), dtype=torch.half, device=dev); il = torch.full((2 * n, k), float("nan"), dtype=torch.half, device=dev)
+    ext.reconstruct_had_multi_t(st, tr, su, sv, K, False, True)
+    ext.reconstruct_had_multi_t(il, tr, su, sv, K, False, True, True)
+    want = st.view(2, n // 128, 128, k).permute(1, 0, 2, 3).reshape(2 * n, k)
+    assert torch.equal(il, want)
+    with pytest.raises(RuntimeError):
+        ext.reconstruct_had_multi_t(il[: n + 128], [tr[0], _t(o.synth_linear(k, 128, K, seed=5)[0], dev)], su, sv, K, False, True, True)      # different n
+
+
+@pytest.mark.parametrize("rows", [1024, 200])
+def test_forward_gate_up_silu_fused_gemm(dev, rows):
+    """gate|up + silu·mul of the prefill route against two forwards + silu_mul and the oracle: from 256 rows ONE own GEMM whose epilogue applies silu(g) * u to the tile
+    (W^T with gate / up blocks interleaved); below, one library GEMM + silu_mul_2d."""
     from exllamav3_amd import ext
     from exllamav3_amd.linear import LinearEXL3
-    k, n, K, rows = 256, 384, 4, 1024
+    k, n, K = 256, 384, 4
     g = o.synth_linear(k, n, K, seed=1, realistic=True); u = o.synth_linear(k, n, K, seed=2, realistic=True)
     lg = LinearEXL3(k, n, _t(g[0], dev), _t(g[1], dev), _t(g[2], dev), mul1=True)
     lu = LinearEXL3(k, n, _t(u[0], dev), _t(u[1], dev), _t(u[2], dev), mul1=True)

@@ -17,16 +17,20 @@ def block(fn, n):
 for name, k, n in [("o", 4096, 4096), ("gate_up", 4096, 28672), ("down", 14336, 4096), ("qkv", 4096, 6144)][:int(os.environ.get("NSHAPES", "4"))]:
     a = torch.randn((4096, k), device=dev).half(); bt = (torch.randn((n, k), device=dev) * 0.02).half(); c = torch.empty((4096, n), dtype=torch.half, device=dev)
     EPI = int(os.environ.get("EPI", "0"))                                       # 1: the residual-add form of both (c += a @ bt^T; values grow, timing only)
-    if EPI: c.zero_()
+    if EPI == 1: c.zero_()
     ROT = int(os.environ.get("ROTATE", "1"))                                    # > 1: that many copies of a / bt walked round-robin (operands from HBM, not the 256 MB cache)
     As = [a] + [a.clone() for _ in range(ROT - 1)]; Bs = [bt] + [bt.clone() for _ in range(ROT - 1)]
     ctr = [0]
+    y1 = torch.empty((4096, n // 2), dtype=torch.half, device=dev) if EPI == 2 else None; y2 = torch.empty_like(y1) if EPI == 2 else None
     def own():
         i = ctr[0] % ROT; ctr[0] += 1
-        ext.gemm_nt_mfma(As[i], Bs[i], c, EPI, int(os.environ.get("OWN_GEN", "0")))
+        ext.gemm_nt_mfma(As[i], Bs[i], y1 if EPI == 2 else c, EPI, int(os.environ.get("OWN_GEN", "0")))
     def lib():
         i = ctr[0] % ROT; ctr[0] += 1
-        ext.hgemm_nt(As[i], Bs[i], c, accumulate=bool(EPI))                                      # (run with EXL3_HIP_GEMM_NT=0: hgemm_nt = the library route)
+        if EPI == 2:                                                             # (the fused silu(gate) * up epilogue against GEMM + the separate pass; timing only: rows not re-stacked)
+            ext.hgemm_nt(As[i], Bs[i], c); ext.silu_mul_2d(c[:, :n // 2], c[:, n // 2:], y2)
+        else:
+            ext.hgemm_nt(As[i], Bs[i], c, accumulate=bool(EPI))                                      # (run with EXL3_HIP_GEMM_NT=0: hgemm_nt = the library route)
     own(); lib(); lib(); torch.cuda.synchronize()
     seq = []
     for order in ("OLOLOL", "LOLOLO"):
