@@ -624,6 +624,21 @@ def main():
                                 "frac": round(flops / dt / 1e12 / peak_all, 4),
                                 "note": "linears' 2*k*n flops (whole job) over the whole chunk time (includes reconstruct_had, norms, rope, kv-quant"
                                         + (", the o_proj / down_proj all-reduces" if world > 1 else "") + "); peak = dense fp16 MFMA x n_gpus"}}
+        prefill["contraction"] = ("exl3_gemm_nt2_mfma: hand-written NT MFMA GEMM, assembly K-loop, one wave per SIMD (fused residual-add / silu*mul epilogues)"
+                                  if ext.gemm_nt_own_default() else "hipBLASLt (EXL3_HIP_GEMM_NT=0)")
+        if world == 1 and ext.gemm_nt_own_default():
+            # the same chunk through the library GEMM (hipBLASLt + the separate silu * mul pass), same process, right behind the timed one: the number the own kernel replaces
+            try:
+                ext._GEMM_NT_OWN = False
+                model.prefill_chunk(toks); torch.cuda.synchronize()
+                ls = []
+                for _ in range(3):
+                    t0 = time.perf_counter(); model.prefill_chunk(toks); torch.cuda.synchronize(); ls.append(time.perf_counter() - t0)
+                ldt = sorted(ls)[1]
+                prefill["library_route"] = {"value": round(toks / ldt, 1), "unit": "tok/s", "ms_per_chunk": round(ldt * 1e3, 2), "frac": round(flops / ldt / 1e12 / peak_all, 4),
+                                            "note": "ext.hgemm_nt forced to hipBLASLt for every GEMM of the chunk (+ silu_mul_2d as its own pass)"}
+            finally:
+                ext._GEMM_NT_OWN = True
         if world > 1:
             # the chunk's exchange step alone: 2 all-reduces per layer of the (tokens, hidden) partial sums, in the dtype the TP branch reduces
             msg = torch.zeros((toks, shape.hidden), dtype=model.prefill_allreduce_dtype(), device=dev)
