@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel time of one prefill chunk (4 layers, tools/prof_prefill.py) with the own GEMM route and with the library route: where the chunk's difference sits
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pftrace; mkdir -p $O $R/gpurun_out/r6
-for E in 1 0; do
+for E in ${ROUTES:-1 0}; do
   EXL3_HIP_GEMM_NT=$E timeout 300 rocprofv3 --kernel-trace --stats -d $O/e$E -o out --output-format csv -- python $R/tools/prof_prefill.py > $O/e$E.log 2>&1
   python - <<PY
 import csv
