@@ -218,6 +218,7 @@ def _declare(l):
     sig("exl3_moe_scatter", vp, vp, vp, vp, vp, i32, i32, i32, vp)
     sig("exl3_gemm_nt_mfma", vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp)
     sig("exl3_gemm_nt2_mfma", vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp)
+    sig("exl3_gemm_nt2_grouped", vp, i64, vp, i64, i64, vp, i64, vp, i32, i32, i32, i32, i32, vp)
     sig("exl3_gemv_ex_fx_atomic", vp, vp, vp, vp, f32, PP, PP, PP, PP, ctypes.POINTER(i32), i32, i32, i32, i32, i32, i32, ctypes.POINTER(i32), vp)
     sig("exl3_gemv_ex_actfx", vp, vp, vp, vp, i32, f32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, PP, ctypes.POINTER(i32), vp)
     sig("exl3_fx_zero_next", vp, i64)

@@ -484,6 +484,19 @@ def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: boo
                                             int(c.dtype == torch.float), int(accumulate), _stream(a)))
 
 
+def gemm_nt_grouped(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, rows: torch.Tensor, epi: int = 0):
+    """Grouped form of the hand-written NT GEMM (exl3_gemm_nt2_grouped): bt (count, n, k) fp16 holds one W^T per problem, a (R, k) / c (R, n) -- (R, n / 2) for epi 2,
+    float32 for epi 3 -- the problems' rows back to back, rows (count + 1,) int32 ON THE DEVICE their boundaries (rows[count] <= R; never read on the host)."""
+    _dev(a)
+    _req(a.dtype == torch.half and bt.dtype == torch.half and a.dim() == 2 and bt.dim() == 3 and c.dim() == 2, "gemm_nt_grouped: a (R, k), bt (count, n, k) float16")
+    _req(c.dtype == (torch.float if epi == 3 else torch.half), "gemm_nt_grouped: c float16 (float32 for epi 3)")
+    _req(rows.dtype == torch.int32 and rows.is_cuda and rows.is_contiguous() and rows.numel() == bt.shape[0] + 1, "gemm_nt_grouped: rows = device int32 (count + 1)")
+    _req(a.stride(1) == 1 and bt.stride(2) == 1 and c.stride(1) == 1 and a.shape[1] == bt.shape[2] and c.shape[0] == a.shape[0], "gemm_nt_grouped: unit column strides, shared k, shared rows")
+    _req(c.shape[1] == (bt.shape[1] // 2 if epi == 2 else bt.shape[1]), "gemm_nt_grouped: output columns")
+    _check(_lib.lib().exl3_gemm_nt2_grouped(_p(a), a.stride(0), _p(bt), bt.stride(1), bt.stride(0), _p(c), c.stride(0), _p(rows), bt.shape[0], a.shape[0],
+                                            a.shape[1], bt.shape[1], int(epi), _stream(a)))
+
+
 def gemm_nt_own_default() -> bool:
     """Whether ext.hgemm_nt's default route is the hand-written kernel (EXL3_HIP_GEMM_NT != 0)."""
     return _GEMM_NT_OWN

@@ -32,6 +32,10 @@ class SyntheticEXL3MoE:
         self.first, self.last = 0, experts
         self._build_tables()
 
+    #: forward_prefill: the block as two grouped GEMMs over all experts (ext.gemm_nt_grouped) where every expert is local and the shapes fit the own kernel; False:
+    #: the per-expert loop (the reference's structure: one GEMM pair per expert, sized on the host)
+    grouped_prefill = True
+
     # k-slices of the fx block's gate|up / down launches (0: the dispatcher / the rule in forward_fx); EXL3_HIP_MOE_FX_SPLIT="g,d" overrides (tuning)
     fx_split = tuple(int(v) for v in os.environ.get("EXL3_HIP_MOE_FX_SPLIT", "0,0").split(","))
 
@@ -169,7 +173,7 @@ class SyntheticEXL3MoE:
         the small-m kernel below -- the reference's run_single_expert_dq / run_single_expert tiers) -> weighted scatter in ascending assignment order
         (ext.moe_scatter: fixed order, bit-reproducible; the reference scatters with index_add_).  Expert parallelism: only the local experts
         [first, last) run and the result is this rank's partial sum.  Returns (tokens, hidden) fp32."""
-        from .linear import LinearEXL3
+        from .linear import LinearEXL3, _same_kind
         T, k, dev = x.shape[0], self.top_k, x.device
         scores = torch.empty((T, self.E), dtype=torch.half, device=dev)
         sel = torch.empty((T, k), dtype=torch.long, device=dev)
@@ -177,6 +181,38 @@ class SyntheticEXL3MoE:
         ext.routing_std(x, self.router, scores, sel, w)
         self.pf_sel, self.pf_w = sel, w                                   # (parity tests read the routing)
         nloc = self.last - self.first
+        if (self.grouped_prefill and nloc == self.E and ext.gemm_nt_own_default() and T * k >= 256 and self.hidden % 256 == 0 and self.inter % 128 == 0
+                and _same_kind(*self.gate, *self.up) and _same_kind(*self.down) and x.stride(0) % 8 == 0):
+            # ---- every expert local: the block as TWO grouped GEMMs (ext.gemm_nt_grouped: one launch walks all experts' tiles; the row boundaries are the cumulative
+            # sum of the router's bincount, read by the kernel from device memory -- no expert_count.tolist(), no host synchronisation in the block, capturable).
+            # gate|up with silu(g) * u in the epilogue on W^T whose gate / up blocks alternate; down with fp32 output (the reference's fp32 expert outputs in front of
+            # its index_add_); same values as the per-expert loop below to the order of the k summation.
+            R = T * k
+            flat_e = sel.reshape(-1)
+            order = torch.argsort(flat_e, stable=True)
+            token_sorted = torch.arange(T, device=dev, dtype=torch.long).repeat_interleave(k)[order].contiguous()
+            weight_sorted = w.reshape(-1)[order].contiguous()
+            rows = torch.zeros((self.E + 1,), dtype=torch.int32, device=dev)
+            rows[1:] = torch.cumsum(torch.bincount(flat_e, minlength=self.E), 0).to(torch.int32)
+            xs = x.index_select(0, token_sorted)
+            g0 = self.gate[0]
+            wt = torch.empty((self.E, 2 * self.inter, self.hidden), dtype=torch.half, device=dev)
+            for e in range(self.E):
+                ext.reconstruct_had_multi_t(wt[e], [self.gate[e].trellis, self.up[e].trellis], [self.gate[e].suh, self.up[e].suh], [self.gate[e].svh, self.up[e].svh],
+                                            g0.K, g0.mcg, g0.mul1, True)
+            a = torch.empty((R, self.inter), dtype=torch.half, device=dev)
+            ext.gemm_nt_grouped(xs, wt, a, rows, 2)
+            del wt
+            d0 = self.down[0]
+            wd = torch.empty((self.E, self.hidden, self.inter), dtype=torch.half, device=dev)
+            for e in range(self.E):
+                ext.reconstruct_had_slice_t(wd[e], self.down[e].trellis, self.down[e].suh, self.down[e].svh, d0.K, d0.mcg, d0.mul1, 0)
+            D = torch.empty((R, self.hidden), dtype=torch.float, device=dev)
+            ext.gemm_nt_grouped(a, wd, D, rows, 3)
+            del wd
+            out = torch.zeros((T, self.hidden), dtype=torch.float, device=dev)
+            ext.moe_scatter(D, torch.arange(R, dtype=torch.int32, device=dev), token_sorted, weight_sorted, out)
+            return out
         flat_e = sel.reshape(-1) - self.first
         flat_e = torch.where((flat_e >= 0) & (flat_e < nloc), flat_e, torch.full_like(flat_e, nloc))      # non-local experts: sentinel group, skipped
         flat_t = torch.arange(T, device=dev, dtype=torch.long).repeat_interleave(k)

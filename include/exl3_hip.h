@@ -339,6 +339,15 @@ int exl3_gemm_nt_mfma(const void* a, int64_t lda, const void* bt, int64_t ldb, v
  * k % 128 == 0, n % 256 == 0, 16-byte aligned operands; other shapes return EXL3_ERR_ARG (generation 1 or exl3_hgemm_nt* take them). */
 int exl3_gemm_nt2_mfma(const void* a, int64_t lda, const void* bt, int64_t ldb, void* c, int64_t ldc, int m, int k, int n, int epi, void* stream);
 
+/* The same kernel as a GROUPED launch: `count` problems c_e[m_e][n] = a_e[m_e][k] @ bt_e[n][k]^T of one k and n in ONE grid -- the experts of a MoE block over the
+ * assignments sorted by expert (the reference runs one GEMM per expert, sized on the host from expert_count.tolist(): quant/exl3_moe.cu:99-301,
+ * modules/block_sparse_mlp.py:1169-1330).  a / c hold the problems' rows back to back: problem e = rows [rows[e], rows[e + 1]); `rows` is DEVICE memory (int32
+ * [count + 1], e.g. the cumulative sum of the router's bincount: the sizes never visit the host); bt_e = bt + e * bt_stride elements; max_rows >= rows[count] sizes the
+ * grid.  epi 0 store, 1 c += (fp16), 2 silu(gate) * up (bt_e as exl3_reconstruct_had_multi_t_interleaved writes it; c has n / 2 columns), 3 fp32 output (c float, ldc
+ * in floats: the reference's fp32 expert outputs in front of its index_add_).  k % 64 == 0, n % 256 == 0, 16-byte aligned operands. */
+int exl3_gemm_nt2_grouped(const void* a, int64_t lda, const void* bt, int64_t ldb, int64_t bt_stride, void* c, int64_t ldc, const int* rows, int count, int max_rows,
+                          int k, int n, int epi, void* stream);
+
 /* y[rows][cols] = silu(g) * u (activation.cu) where g and u are fp16 column ranges of wider matrices (row strides ld_g, ld_u). */
 int exl3_silu_mul_2d(const void* g, const void* u, void* y, int64_t rows, int64_t cols, int64_t ld_g, int64_t ld_u, void* stream);
 

@@ -13,10 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "exllamav3_amd", "csrc")
 FORMS = {"exl3_gemm_nt2_loop.inc": ("gen_gemm_nt2_loop.py", []), "exl3_gemm_nt3_loop.inc": ("gen_gemm_nt3_loop.py", []),
          "exl3_gemm_nt3n_loop.inc": ("gen_gemm_nt3_loop.py", ["n128"]), "exl3_gemm_nt3a_loop.inc": ("gen_gemm_nt3_loop.py", ["a3"]),
-         "exl3_gemm_nt2_clobbers.inc": ("gen_gemm_nt2_loop.py", ["clobbers"])}
+         "exl3_gemm_nt2_clobbers.inc": ("gen_gemm_nt2_loop.py", ["clobbers"]),
+         # the grouped kernel: the K-loop without an ending + the endings as statements of their own (fp16 C tile, two fp32 half tiles)
+         "exl3_gemm_nt3g_loop.inc": ("gen_gemm_nt3_loop.py", ["a3", "noend"]), "exl3_gemm_nt3_end_f16.inc": ("gen_gemm_nt3_loop.py", ["end_f16"]),
+         "exl3_gemm_nt3_end_f32_p0.inc": ("gen_gemm_nt3_loop.py", ["end_f32_p0"]), "exl3_gemm_nt3_end_f32_p1.inc": ("gen_gemm_nt3_loop.py", ["end_f32_p1"])}
 # requests per K-tile and wave, matrix instructions per K-tile and wave, K-tiles per loop trip, loop copies, the counted wait inside the loop
 SHAPE = {"exl3_gemm_nt2_loop.inc": (8, 32, 4, 1, 16), "exl3_gemm_nt3_loop.inc": (16, 128, 2, 4, 0), "exl3_gemm_nt3n_loop.inc": (12, 64, 3, 4, 12),
-         "exl3_gemm_nt3a_loop.inc": (16, 128, 6, 4, 8)}
+         "exl3_gemm_nt3a_loop.inc": (16, 128, 6, 4, 8), "exl3_gemm_nt3g_loop.inc": (16, 128, 6, 4, 8)}
 
 
 def _gen(script, args):
@@ -121,3 +124,28 @@ def test_request_source_permutation_matches_the_read_side(rows_per_req, chunks):
             row, pos = base + L // chunks, L % chunks
             fetched = pos ^ f(row)
             assert fetched ^ f(row) == pos and 0 <= fetched < chunks
+
+
+def test_no_compiler_access_to_accumulation_registers_outside_the_statements():
+    """The grouped kernel keeps a[0:255] live ACROSS asm statements (K-loop, then the ending chosen at run time with C++ in between): the compiler must not touch an
+    accumulation register or spill there.  Compiles the unit to assembly (hipcc cross-compiles without a GPU) and looks outside ;;#ASMSTART / ;;#ASMEND."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "g.s")
+        r = subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                            "-S", "--cuda-device-only", os.path.join(CSRC, "exl3_gemm_nt2.hip"), "-o", out], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        text = open(out).read()
+    kernels = re.findall(r"^(_Z\d+exl3_gemm_nt\w+):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) >= 5
+    for name, body in kernels:
+        outside, inasm = [], False
+        for l in body.splitlines():
+            if ";;#ASMSTART" in l: inasm = True; continue
+            if ";;#ASMEND" in l: inasm = False; continue
+            if not inasm: outside.append(l)
+        bad = [l for l in outside if re.search(r"accvgpr|scratch_|[\s,\[]a\d+[\],:\s]|\ba\[\d+:\d+\]", l)]
+        assert not bad, (name, bad[:5])

@@ -1925,14 +1925,17 @@ def test_mixtral_layer_path_matches_oracle(dev, bsz, with_attention):
     assert np.array_equal(model.logits.float().cpu().numpy(), logits)
 
 
+@pytest.mark.parametrize("grouped", [True, False])
 @pytest.mark.parametrize("tokens,experts,top_k", [(600, 6, 2), (1200, 8, 2), (160, 4, 3)])
-def test_moe_prefill_block_matches_oracle(dev, tokens, experts, top_k):
+def test_moe_prefill_block_matches_oracle(dev, tokens, experts, top_k, grouped):
     """SyntheticEXL3MoE.forward_prefill (round 4; the grouped-by-expert large-batch tier of modules/block_sparse_mlp.py:1169-1330: router over all rows,
     per expert gather -> gate|up GEMM + silu * mul -> down GEMM, fixed-order weighted scatter) against the oracle per token: routing identical, outputs
     to 2e-2 of their RMS; experts land on both sides of the 144-row switch between the small-m kernels and the reconstruct + GEMM route; a second
-    run reproduces the bits (no atomic scatter)."""
+    run reproduces the bits (no atomic scatter).  grouped: the block as two grouped GEMMs over all experts (ext.gemm_nt_grouped, row boundaries on the device, silu * mul
+    in the first one's epilogue, fp32 output from the second) -- no host synchronisation inside; not grouped: the per-expert loop."""
     from exllamav3_amd.moe_path import SyntheticEXL3MoE
     moe = SyntheticEXL3MoE(256, 384, experts=experts, top_k=top_k, K=4, cb=2, device=dev, seed=21)
+    moe.grouped_prefill = grouped
     x = torch.randn((tokens, 256), device=dev, generator=torch.Generator(device=dev).manual_seed(tokens)).half()
     y = moe.forward_prefill(x)
     y1 = y.clone()
@@ -1959,7 +1962,10 @@ def test_moe_prefill_expert_parallel_partials_sum_to_the_whole(dev):
     from exllamav3_amd.moe_path import SyntheticEXL3MoE
     full = SyntheticEXL3MoE(256, 384, experts=8, top_k=2, K=4, cb=2, device=dev, seed=5)
     x = torch.randn((400, 256), device=dev, generator=torch.Generator(device=dev).manual_seed(1)).half()
+    yg = full.forward_prefill(x).clone()                   # (every expert local: the two grouped GEMMs)
+    full.grouped_prefill = False                           # the per-expert loop, the structure the ranks below run: same kernels per expert -> the sums agree to fp32 rounding
     y = full.forward_prefill(x).clone()
+    assert np.abs(_np(yg) - _np(y)).max() / np.sqrt((_np(y) ** 2).mean()) < 2e-2          # grouped against the loop (the small-m kernels below 144 rows per expert there): the bar both meet against the oracle
     parts = []
     for first, last in ((0, 4), (4, 8)):
         half = SyntheticEXL3MoE(256, 384, experts=8, top_k=2, K=4, cb=2, device=dev, seed=5)

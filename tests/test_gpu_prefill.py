@@ -443,3 +443,43 @@ def test_hgemm_nt_default_route_strided_operands_and_fallbacks(dev):
     c32 = torch.empty((m, n), dtype=torch.float, device=dev)
     ext.hgemm_nt(a, bt.contiguous(), c32)
     assert float((c32 - ref).abs().max()) < 2e-3 * scale
+
+
+@pytest.mark.parametrize("k,n,bounds", [(192, 512, [0, 300, 300, 1000]), (4096, 256, [0, 17, 1041, 2048, 2049]), (64, 768, [0, 256])])
+def test_grouped_assembly_gemm_against_fp32_matmul(dev, k, n, bounds):
+    """exl3_gemm_nt2_grouped: several problems of one k / n in one launch, row boundaries read from DEVICE memory (an empty problem, partial last tiles, a problem of one
+    tile row); the four epilogues -- store, fp16 residual add, silu(gate) * up on interleaved W^T blocks, fp32 output -- against an fp32 matmul per problem; rows past
+    rows[count] are left alone."""
+    from exllamav3_amd import ext
+    g = torch.Generator(device=dev); g.manual_seed(k + n + len(bounds))
+    cnt, R = len(bounds) - 1, bounds[-1] + 37                                 # (37 rows of slack behind the last problem: max_rows is an upper bound)
+    a = torch.randn((R, k), device=dev, generator=g).half()
+    bt = (torch.randn((cnt, n, k), device=dev, generator=g) * 0.05).half()
+    rows = torch.tensor(bounds, dtype=torch.int32, device=dev)
+    ref = torch.zeros((R, n), dtype=torch.float, device=dev)
+    for e in range(cnt):
+        ref[bounds[e]: bounds[e + 1]] = a[bounds[e]: bounds[e + 1]].float() @ bt[e].float().T
+    scale = float(ref.abs().max())
+    used = bounds[-1]
+    c = torch.full((R, n), float("nan"), dtype=torch.half, device=dev)
+    ext.gemm_nt_grouped(a, bt, c, rows, 0)
+    assert bool(torch.isfinite(c[:used]).all()) and bool(torch.isnan(c[used:]).all())
+    assert float((c[:used].float() - ref[:used]).abs().max()) < 2e-3 * scale
+    c32 = torch.full((R, n), float("nan"), dtype=torch.float, device=dev)
+    ext.gemm_nt_grouped(a, bt, c32, rows, 3)
+    assert bool(torch.isnan(c32[used:]).all())
+    assert float((c32[:used] - ref[:used]).abs().max()) < 1e-3 * scale                       # fp32 out: only the operands are rounded
+    assert torch.equal(c32[:used].half(), c[:used])                                           # the fp16 store is the same accumulator, rounded once
+    r0 = torch.randn((R, n), device=dev, generator=g).half(); r = r0.clone()
+    ext.gemm_nt_grouped(a, bt, r, rows, 1)
+    assert torch.equal(r[used:], r0[used:])
+    assert float((r[:used].float() - (r0[:used].float() + ref[:used])).abs().max()) < 3e-3 * max(scale, 1.0)
+    # silu(gate) * up: per problem, W^T = 128-row blocks of gate and up alternating
+    half_n = n // 2
+    bt_s = torch.stack([bt[:, :half_n].reshape(cnt, half_n // 128, 128, k), bt[:, half_n:].reshape(cnt, half_n // 128, 128, k)], dim=2).reshape(cnt, n, k).contiguous()
+    y = torch.full((R, half_n), float("nan"), dtype=torch.half, device=dev)
+    ext.gemm_nt_grouped(a, bt_s, y, rows, 2)
+    gf = ref[:, :half_n].half().float(); uf = ref[:, half_n:].half().float()
+    yref = gf / (1 + torch.exp(-gf)) * uf
+    assert float((y[:used].float() - yref[:used]).abs().max()) < 4e-3 * max(float(yref[:used].abs().max()), 1.0)
+    assert bool(torch.isnan(y[used:]).all())

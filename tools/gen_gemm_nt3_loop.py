@@ -244,23 +244,48 @@ else:
     emit("L_gnt3_done%=:")
     in_loop = False
 
-# ------------------------------------------------------------------------------------------------------------------ accumulators -> fp16 C tile in LDS
-emit("s_waitcnt vmcnt(0)")
-emit("s_barrier")
-emit("s_nop 15")
-n = 0
-for im in range(8):
-    for jn in range(NB):
-        a0 = (im * NB + jn) * 4
-        t = 104 + 8 * (n & 1)
-        for e in range(4):
-            emit(f"v_accvgpr_read_b32 v{t + e}, a{a0 + e}")
-        emit(f"v_cvt_pk_f16_f32 v{t + 4}, v{t}, v{t + 1}")
-        emit(f"v_cvt_pk_f16_f32 v{t + 5}, v{t + 2}, v{t + 3}")
-        emit(f"ds_write_b64 %[ct], v[{t + 4}:{t + 5}] offset:{im * 16 * 528 + jn * 32}")
-        n += 1
-emit("s_waitcnt lgkmcnt(0)")
-emit("s_barrier")
+# ------------------------------------------------------------------------------------------------------------------ accumulators -> C tile in LDS
+# "noend": the K-loop statement stops behind its last matrix instruction (the grouped kernel picks its ending at run time: exl3_gemm_nt2_body.inc, GN2_SPLIT_END);
+# "end_f16" / "end_f32_p0" / "end_f32_p1": only that ending, as its own statement -- the fp16 C tile, or one 128-row half of the tile as fp32 ([128][260] floats:
+# the rows of accumulator tiles im = 4 p .. 4 p + 3 of both wave rows).
+END_ONLY = [f for f in FLAGS if f.startswith("end_")]
+if END_ONLY:
+    out = []
+if "noend" in FLAGS or END_ONLY:
+    if not END_ONLY:
+        emit("s_waitcnt vmcnt(0)")
+        emit("s_barrier")
+        emit("s_nop 15")
+else:
+    emit("s_waitcnt vmcnt(0)")
+    emit("s_barrier")
+    emit("s_nop 15")
+if "noend" not in FLAGS and (not END_ONLY or END_ONLY[0] == "end_f16"):
+    n = 0
+    for im in range(8):
+        for jn in range(NB):
+            a0 = (im * NB + jn) * 4
+            t = 104 + 8 * (n & 1)
+            for e in range(4):
+                emit(f"v_accvgpr_read_b32 v{t + e}, a{a0 + e}")
+            emit(f"v_cvt_pk_f16_f32 v{t + 4}, v{t}, v{t + 1}")
+            emit(f"v_cvt_pk_f16_f32 v{t + 5}, v{t + 2}, v{t + 3}")
+            emit(f"ds_write_b64 %[ct], v[{t + 4}:{t + 5}] offset:{im * 16 * 528 + jn * 32}")
+            n += 1
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+elif END_ONLY:
+    p_ = int(END_ONLY[0][-1])
+    n = 0
+    for im in range(4 * p_, 4 * p_ + 4):
+        for jn in range(NB):
+            a0 = (im * NB + jn) * 4
+            t = 104 + 4 * (n & 3)
+            for e in range(4):
+                emit(f"v_accvgpr_read_b32 v{t + e}, a{a0 + e}")
+            emit(f"ds_write_b128 %[ct], v[{t}:{t + 3}] offset:{(im - 4 * p_) * 16 * 1040 + jn * 64}")
+            n += 1
+    emit("s_waitcnt lgkmcnt(0)")
 
 print("// generated by tools/gen_gemm_nt3_loop.py -- do not edit")
 for s in out:
