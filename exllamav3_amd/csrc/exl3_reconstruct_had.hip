@@ -15,6 +15,14 @@
 #include "exl3_lane_decode.cuh"
 #include <string.h>
 
+// diagnostics builds (tools/alt_lib.py rh_x exl3_reconstruct_had.o -DRH_ABL_NOMFMA / -DRH_ABL_NOSTORE): timing-only ablations.  Round 6, gate shape (4096 x 14336): 42.7 us whole,
+// 28.6 without the matrix instructions, 34.2 without the global stores, 13.9 without both -- the three parts ADD (no overlap to speak of between the four workgroups of a CU);
+// packing the 2-byte LDS stores of the W^T epilogue into 8-byte ones changed nothing (44.1 us), nor did starting the four workgroups of a CU a quarter of a block apart (42.3 / 43.3)
+#ifdef RH_ABL_NOMFMA
+#define RH_MFMA(a, b, c) (c)
+#else
+#define RH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
 #define RH_LD 136          // padded leading dimension (halves) of the 128x128 LDS images: 272 B rows -> conflict-free b128 reads
 
 // Sylvester structure: H128[a][b] = H8[a >> 4][b >> 4] * H16[a & 15][b & 15].  For an MFMA fragment whose k-slots are
@@ -146,8 +154,8 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const ReconMats mt, int64_
                 for (int ks = 0; ks < 4; ++ks)
                 {
                     half8_t af = *((const half8_t*) (Wt + (size_t) (16 * (2 * u + e) + j) * RH_LD + 32 * ks + 8 * g));
-                    acc[e][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, hb[0][ks], acc[e][0], 0, 0, 0);
-                    acc[e][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, hb[1][ks], acc[e][1], 0, 0, 0);
+                    acc[e][0] = RH_MFMA(af, hb[0][ks], acc[e][0]);
+                    acc[e][1] = RH_MFMA(af, hb[1][ks], acc[e][1]);
                 }
             }
             ta[0][u] = half8_t{ (half_t) (acc[0][0][0] * sc0), (half_t) (acc[0][0][1] * sc0), (half_t) (acc[0][0][2] * sc0), (half_t) (acc[0][0][3] * sc0),
@@ -180,8 +188,8 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const ReconMats mt, int64_
                 const uint32_t nb2 = (__builtin_popcount((2 * u + 1) & ct) & 1) ? 0x80008000u : 0u;
                 union { uint32_t w[4]; half8_t h; } f;
                 f.w[0] = h16[0] ^ na; f.w[1] = h16[1] ^ na; f.w[2] = h16[0] ^ nb2; f.w[3] = h16[1] ^ nb2;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[0][u], f.h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ta[1][u], f.h, acc1, 0, 0, 0);
+                acc0 = RH_MFMA(ta[0][u], f.h, acc0);
+                acc1 = RH_MFMA(ta[1][u], f.h, acc1);
             }
             const float sv = (float) svr[ct] * r128;
             #pragma unroll
@@ -210,6 +218,9 @@ void reconstruct_had_kernel(half_t* __restrict__ out, const ReconMats mt, int64_
     {
         int row = (tid >> 4) + 16 * it, seg = tid & 15;
         half8_t v = *((const half8_t*) (Wt + (size_t) row * RH_LD + 8 * seg));
+#ifdef RH_ABL_NOSTORE
+        if (v[0] == (half_t) 12345.0f)
+#endif
         if constexpr (TR) *((half8_t*) (out + ((int64_t) nb_out * 128 + row) * out_stride + (int64_t) kb * 128 + 8 * seg)) = v;     // row = n'
         else              *((half8_t*) (out + ((int64_t) kb * 128 + row) * out_stride + (int64_t) nb_out * 128 + 8 * seg)) = v;     // row = k'
 
