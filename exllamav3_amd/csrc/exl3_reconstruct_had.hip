@@ -62,8 +62,11 @@ struct ReconMats
     int interleave;                                       // 1: block row nb of matrix i is written at position nb * count + i (equal n_i): the tile pairing of a fused epilogue
 };
 
+#ifndef RH_WAVES
+#define RH_WAVES 4          // (3: the compiler's own choice, 143 registers; 4: 97 registers, no scratch, four workgroups per CU: gate shape 43.3 -> 38.0 us)
+#endif
 template <int K, int CB, bool TR>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RH_WAVES, RH_WAVES)))
 void reconstruct_had_kernel(half_t* __restrict__ out, const ReconMats mt, int64_t out_stride)
 {
     int mi = 0;
