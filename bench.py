@@ -690,6 +690,42 @@ def main():
                                             "tflops": round(flops / dtc / 1e12, 1),
                                             "note": "later chunks with the reconstructed fp16 weights left resident in HBM (not the reference's per-forward reconstruct)"}
 
+    if prefill is not None and world == 1 and not is_moe:
+        # where the chunk's time goes: HIP events around every op of ONE more chunk (the events cost a few percent: shares, not the timed number)
+        try:
+            import collections
+            names = ["hgemm_nt", "gemm_nt_mfma", "reconstruct_had_multi_t", "reconstruct_had_slice_t", "silu_mul_2d", "silu_mul", "rms_norm", "rope_strided", "rope",
+                     "quant_cache_paged_strided", "quant_cache_paged", "add"]
+            from exllamav3_amd import linear as _lin
+            orig, recs, depth = {n: getattr(ext, n) for n in names if hasattr(ext, n)}, [], [0]
+            def _wrap(n, f):
+                def g(*a, **k):
+                    if depth[0]: return f(*a, **k)              # (ext.hgemm_nt calls ext.gemm_nt_mfma: count the outer call only)
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                    depth[0] += 1
+                    try:
+                        e0.record(); r = f(*a, **k); e1.record()
+                    finally:
+                        depth[0] -= 1
+                    recs.append((n, e0, e1)); return r
+                return g
+            for n, f in orig.items(): setattr(ext, n, _wrap(n, f))
+            try:
+                model.prefill_chunk(toks); torch.cuda.synchronize()
+            finally:
+                for n, f in orig.items(): setattr(ext, n, f)
+            acc = collections.defaultdict(float)
+            for n, e0, e1 in recs: acc[n] += e0.elapsed_time(e1) * 1e3
+            grp = {"contraction (NT GEMM incl. its fused epilogues)": acc["hgemm_nt"] + acc["gemm_nt_mfma"],
+                   "reconstruct_had (W^T of every Linear, per chunk as the reference does)": acc["reconstruct_had_multi_t"] + acc["reconstruct_had_slice_t"],
+                   "rms_norm": acc["rms_norm"], "rope + kv-quant": acc["rope_strided"] + acc["rope"] + acc["quant_cache_paged_strided"] + acc["quant_cache_paged"],
+                   "silu * mul as its own pass": acc["silu_mul_2d"] + acc["silu_mul"], "residual add as its own pass": acc["add"]}
+            tot = sum(grp.values())
+            prefill["per_layer_us"] = {k: round(v / model.n_layers, 1) for k, v in grp.items() if v > 0}
+            prefill["per_layer_share"] = {k: round(v / tot, 3) for k, v in grp.items() if v > 0}
+        except Exception as e:          # (diagnostics only)
+            prefill["per_layer_us"] = {"error": repr(e)[:200]}
+
     # ---- the other BASELINE.json configs that fit one GPU, same process, same timing (hipGraph replay, K steps after W warm-ups)
     extra = None
     if world == 1 and not args.no_extra and args.model == "llama-3.1-8b" and args.batch == 1 and not args.attention and not args.layers:
