@@ -471,7 +471,8 @@ def hgemm_nt(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, accumulate: boo
     _req(a.stride(1) == 1 and bt.stride(1) == 1 and c.stride(1) == 1, "hgemm_nt: a, bt, c need unit column stride")
     _req(not accumulate or c.dtype == torch.half, "hgemm_nt: accumulate needs a float16 c")
     if (_GEMM_NT_OWN if route is None else route == "own") and c.dtype == torch.half and bt.shape[0] % 128 == 0 and a.shape[1] % 64 == 0 and a.stride(0) % 8 == 0 and bt.stride(0) % 8 == 0 \
-            and c.stride(0) % 8 == 0 and a.shape[0] >= 256 and (a.data_ptr() | bt.data_ptr() | c.data_ptr()) % 16 == 0:
+            and c.stride(0) % 8 == 0 and a.shape[0] >= 256 and (a.data_ptr() | bt.data_ptr() | c.data_ptr()) % 16 == 0 \
+            and (route == "own" or gemm_nt_own_fills_chip(a.shape[0], bt.shape[0], a.device)):
         # the hand-written MFMA GEMM (exl3_gemm_nt2.hip) wherever its tile shapes apply (k % 64, n % 128, rows >= one tile)
         gemm_nt_mfma(a, bt, c, 1 if accumulate else 0)
         return
@@ -495,6 +496,25 @@ def gemm_nt_grouped(a: torch.Tensor, bt: torch.Tensor, c: torch.Tensor, rows: to
     _req(c.shape[1] == (bt.shape[1] // 2 if epi == 2 else bt.shape[1]), "gemm_nt_grouped: output columns")
     _check(_lib.lib().exl3_gemm_nt2_grouped(_p(a), a.stride(0), _p(bt), bt.stride(1), bt.stride(0), _p(c), c.stride(0), _p(rows), bt.shape[0], a.shape[0],
                                             a.shape[1], bt.shape[1], int(epi), _stream(a)))
+
+
+_CUS = {}
+
+
+def gemm_nt_own_fills_chip(m: int, n: int, device=None, wide_only: bool = False) -> bool:
+    """Whether the own NT GEMM is the right kernel for an (m, n) problem: one workgroup per CU and tile, so a problem of few tiles leaves CUs idle where the library's
+    stream-K kernel splits k.  Measured (MI355X, 8B shapes, rows 256 .. 4096): within 0.9 - 1.1 x the library where the tile form it picks (256 x 256, or 256 x 128 when that
+    wastes fewer rounds) fills >= 70 % of its rounds, 0.66 - 0.85 x below (rows 512 - 1024 on the 4096-column projections).  Same tile choice as exl3_gemm_nt2_mfma."""
+    dev = torch.cuda.current_device() if device is None else (device.index if device.index is not None else torch.cuda.current_device())
+    cus = _CUS.get(dev)
+    if cus is None:
+        cus = _CUS[dev] = max(1, torch.cuda.get_device_properties(dev).multi_processor_count)
+    tm = (m + 255) // 256
+    tw, tn = tm * (n // 256), tm * (n // 128)
+    rw, rn = -(-tw // cus), -(-tn // cus)
+    narrow = (not wide_only) and (n % 256 != 0 or 0.54 * rn < rw)
+    tiles, rounds = (tn, rn) if narrow else (tw, rw)
+    return tiles >= 0.7 * rounds * cus
 
 
 def gemm_nt_own_default() -> bool:

@@ -134,7 +134,8 @@ class LinearEXL3:
             return a
         wt = torch.empty((2 * n, k), dtype=torch.half, device=dev)
         x2 = x.view(rows, k)
-        if (_same_kind(gate, up) and rows >= 256 and k % 64 == 0 and ext.gemm_nt_own_default() and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0):
+        if (_same_kind(gate, up) and rows >= 256 and k % 64 == 0 and ext.gemm_nt_own_default() and x2.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0
+                and ext.gemm_nt_own_fills_chip(rows, 2 * n, x2.device, wide_only=True)):
             # the own GEMM's fused epilogue: W^T with the 128-row blocks of gate and up alternating (every 256-row tile = the gate | up rows of the same 128
             # outputs), silu(g) * u applied to the tile before it leaves the CU -- no (rows, 2n) round trip, no activation launch
             ext.reconstruct_had_multi_t(wt, [gate.trellis, up.trellis], [gate.suh, up.suh], [gate.svh, up.svh], gate.K, gate.mcg, gate.mul1, True)

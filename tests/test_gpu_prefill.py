@@ -423,9 +423,14 @@ def test_hgemm_nt_default_route_strided_operands_and_fallbacks(dev):
     cw = torch.full((m, n + 256), float("nan"), dtype=torch.half, device=dev); c = cw[:, 128: 128 + n]
     ref = a.float() @ bt.float().T
     scale = float(ref.abs().max())
-    ext.hgemm_nt(a, bt, c)
+    assert not ext.gemm_nt_own_fills_chip(m, n, a.device) and ext.gemm_nt_own_fills_chip(4096, 4096, a.device) and ext.gemm_nt_own_fills_chip(2048, 4096, a.device) \
+        and not ext.gemm_nt_own_fills_chip(1024, 4096, a.device)        # (6 tiles here: the default route hands such a problem to the library; the kernel itself is forced below)
+    ext.hgemm_nt(a, bt, c, route="own")
     assert float((c.float() - ref).abs().max()) < 2e-3 * scale
     assert bool(torch.isnan(cw[:, :128]).all()) and bool(torch.isnan(cw[:, 128 + n:]).all())          # nothing written outside the column range
+    cd = torch.empty((m, n), dtype=torch.half, device=dev)
+    ext.hgemm_nt(a, bt, cd)                                                                              # default route (the library for this size): same values
+    assert float((cd.float() - c.float()).abs().max()) < 1e-3 * scale
     lib = torch.empty((m, n), dtype=torch.half, device=dev)
     ext.hgemm_nt(a, bt.contiguous(), lib, route="library")
     assert float((c.float() - lib.float()).abs().max()) < 1e-3 * scale

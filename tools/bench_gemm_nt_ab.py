@@ -8,6 +8,7 @@ dev = torch.device("cuda:0"); ext.init(0)
 ext._GEMM_NT_OWN = False                              # ext.hgemm_nt = the library route here; the own kernel is called as ext.gemm_nt_mfma
 torch.manual_seed(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+M = int(os.environ.get("M", "4096"))                   # rows of the activation operand (the chunk length)
 def block(fn, n):
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -15,13 +16,13 @@ def block(fn, n):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
 for name, k, n in [("o", 4096, 4096), ("gate_up", 4096, 28672), ("down", 14336, 4096), ("qkv", 4096, 6144)][:int(os.environ.get("NSHAPES", "4"))]:
-    a = torch.randn((4096, k), device=dev).half(); bt = (torch.randn((n, k), device=dev) * 0.02).half(); c = torch.empty((4096, n), dtype=torch.half, device=dev)
+    a = torch.randn((M, k), device=dev).half(); bt = (torch.randn((n, k), device=dev) * 0.02).half(); c = torch.empty((M, n), dtype=torch.half, device=dev)
     EPI = int(os.environ.get("EPI", "0"))                                       # 1: the residual-add form of both (c += a @ bt^T; values grow, timing only)
     if EPI == 1: c.zero_()
     ROT = int(os.environ.get("ROTATE", "1"))                                    # > 1: that many copies of a / bt walked round-robin (operands from HBM, not the 256 MB cache)
     As = [a] + [a.clone() for _ in range(ROT - 1)]; Bs = [bt] + [bt.clone() for _ in range(ROT - 1)]
     ctr = [0]
-    y1 = torch.empty((4096, n // 2), dtype=torch.half, device=dev) if EPI == 2 else None; y2 = torch.empty_like(y1) if EPI == 2 else None
+    y1 = torch.empty((M, n // 2), dtype=torch.half, device=dev) if EPI == 2 else None; y2 = torch.empty_like(y1) if EPI == 2 else None
     def own():
         i = ctr[0] % ROT; ctr[0] += 1
         ext.gemm_nt_mfma(As[i], Bs[i], y1 if EPI == 2 else c, EPI, int(os.environ.get("OWN_GEN", "0")))
