@@ -488,3 +488,24 @@ def test_grouped_assembly_gemm_against_fp32_matmul(dev, k, n, bounds):
     yref = gf / (1 + torch.exp(-gf)) * uf
     assert float((y[:used].float() - yref[:used]).abs().max()) < 4e-3 * max(float(yref[:used].abs().max()), 1.0)
     assert bool(torch.isnan(y[used:]).all())
+
+
+def test_assembly_gemm_random_shapes(dev):
+    """exl3_gemm_nt2.hip over 24 seeded random shapes (rows 256 .. 3000, k = 64 * 1 .. 40, n = 128 * 1 .. 24, every loop form incl. forced tiles, plain store / residual add):
+    against an fp32 matmul; every exit position of the six- / three- / two-tile loop trips and ragged last row tiles come up."""
+    from exllamav3_amd import ext
+    rng = np.random.default_rng(2026)
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    for case in range(24):
+        m = int(rng.integers(256, 3001)); k = 64 * int(rng.integers(1, 41)); n = 128 * int(rng.integers(1, 25))
+        gen = int(rng.choice([0, 3, 4, 7])) if n % 256 == 0 else int(rng.choice([0, 4]))
+        epi = int(rng.integers(0, 2))
+        a = torch.randn((m, k), device=dev, generator=g).half()
+        bt = (torch.randn((n, k), device=dev, generator=g) / np.sqrt(k)).half()
+        ref = a.float() @ bt.float().T
+        c0 = torch.randn((m, n), device=dev, generator=g).half() if epi else torch.full((m, n), float("nan"), dtype=torch.half, device=dev)
+        c = c0.clone()
+        ext.gemm_nt_mfma(a, bt, c, epi, gen)
+        want = ref + (c0.float() if epi else 0.0)
+        err = float((c.float() - want).abs().max()) / max(float(want.abs().max()), 1.0)
+        assert bool(torch.isfinite(c).all()) and err < 3e-3, (case, m, k, n, gen, epi, err)
