@@ -193,7 +193,9 @@ class SyntheticEXL3MoE:
             token_sorted = torch.arange(T, device=dev, dtype=torch.long).repeat_interleave(k)[order].contiguous()
             weight_sorted = w.reshape(-1)[order].contiguous()
             rows = torch.zeros((self.E + 1,), dtype=torch.int32, device=dev)
-            rows[1:] = torch.cumsum(torch.bincount(flat_e, minlength=self.E), 0).to(torch.int32)
+            counts = torch.zeros((self.E,), dtype=torch.int32, device=dev)
+            counts.index_add_(0, flat_e, torch.ones_like(flat_e, dtype=torch.int32))            # (torch.bincount sizes its result on the host)
+            rows[1:] = torch.cumsum(counts, 0).to(torch.int32)
             xs = x.index_select(0, token_sorted)
             g0 = self.gate[0]
             wt = torch.empty((self.E, 2 * self.inter, self.hidden), dtype=torch.half, device=dev)

@@ -1957,6 +1957,26 @@ def test_moe_prefill_block_matches_oracle(dev, tokens, experts, top_k, grouped):
     assert np.abs(_np(y1) - ref).max() / np.sqrt((ref ** 2).mean()) < 2e-2
 
 
+def test_moe_prefill_grouped_block_is_capturable(dev):
+    """The grouped branch of forward_prefill has no host synchronisation (row boundaries stay on the device): it records into a hipGraph, and a replay over OTHER activations
+    (other routing, other per-expert row counts) gives what the eager call gives."""
+    from exllamav3_amd.moe_path import SyntheticEXL3MoE
+    moe = SyntheticEXL3MoE(256, 384, experts=8, top_k=2, K=4, cb=2, device=dev, seed=9)
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    x = torch.randn((700, 256), device=dev, generator=gen).half()
+    moe.forward_prefill(x); torch.cuda.synchronize()                      # (first-call set-up of the launchers happens outside the capture)
+    st = torch.cuda.Stream(); st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            y = moe.forward_prefill(x)
+    x2 = torch.randn((700, 256), device=dev, generator=gen).half()
+    x.copy_(x2); g.replay(); torch.cuda.synchronize()
+    got = y.clone()
+    want = moe.forward_prefill(x2)
+    assert torch.equal(got, want)
+
+
 def test_moe_prefill_expert_parallel_partials_sum_to_the_whole(dev):
     """forward_prefill under expert parallelism: the partial sums of the two halves of the experts add up to the one-rank result (same routing on every rank)."""
     from exllamav3_amd.moe_path import SyntheticEXL3MoE
